@@ -1,0 +1,225 @@
+/*
+ * varden_amd.h -- C-ABI of the MI355X-native VARDEN hot path.
+ *
+ * This is the drop-in boundary for the reference's per-timestep path
+ *     advance_module::advance_timestep      (reference src/advance_timestep.f90:26-44)
+ *     estdt_module::estdt                   (reference src/estdt.f90:15)
+ *     hgproject_module::hgproject           (reference src/hgproject.f90:17-18, called by the
+ *                                            driver for the initial projection, varden.f90:134)
+ * and for the BoxLib (FBoxLib, external to the reference tree) containers those
+ * routines take: box / ml_layout / multifab / bc_tower.  A Fortran ISO_C_BINDING
+ * module that re-exports these entry points under the BoxLib names lives in
+ * varden_amd/fortran/varden_amd_mod.f90; INTEGRATION.md shows the binding.
+ *
+ * Conventions
+ *   - every function returns 0 on success, non-zero on error; the message is
+ *     available from vdn_last_error() (reference: bl_error aborts; the Fortran
+ *     shim turns non-zero into `error stop`).
+ *   - plain pointers and sizes only.  "device" pointers are hipMalloc'ed HBM.
+ *   - all floating point data is IEEE f64; arrays use the BoxLib fab layout:
+ *         p(lo1-ng:hi1+ng[+nodal1], lo2-ng:..., lo3-ng:..., 1:nc)   column-major,
+ *     x fastest, component slowest (reference evidence: src/mkflux.f90:74-92).
+ *   - indices (lo/hi) are 0-based cell indices of the level's index space, as in
+ *     BoxLib; direction index d = 0,1,2 ; side 0 = lo, 1 = hi.
+ */
+#ifndef VARDEN_AMD_H
+#define VARDEN_AMD_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- bc_module constants (FBoxLib values; reference use: src/define_bc_tower.f90:199-335,
+ *      exec/test/inputs_*: -1 periodic, 11 inlet, 12 outlet, 14 slip, 15 no-slip) -------- */
+enum {
+  VDN_PERIODIC = -1, VDN_INTERIOR = 0, VDN_INLET = 11, VDN_OUTLET = 12, VDN_SYMMETRY = 13,
+  VDN_SLIP_WALL = 14, VDN_NO_SLIP_WALL = 15,
+  VDN_REFLECT_ODD = 20, VDN_REFLECT_EVEN = 21, VDN_FOEXTRAP = 22, VDN_EXT_DIR = 23, VDN_HOEXTRAP = 24,
+  VDN_BC_PER = -1, VDN_BC_INT = 0, VDN_BC_DIR = 1, VDN_BC_NEU = 2
+};
+
+/* ---- proj_parameters (reference src/proj_parameters.f90:5-8) ------------------------------ */
+enum { VDN_INITIAL_PROJECTION = 1, VDN_DIVU_ITERS = 2, VDN_PRESSURE_ITERS = 3, VDN_REGULAR_TIMESTEP = 4 };
+
+/* ---- runtime parameters read implicitly by the reference kernels through probin_module
+ *      (reference src/_parameters, src/probin.template).  One POD passed once. ------------- */
+typedef struct vdn_params {
+  int    dm;              /* dim_in: only 3 is implemented on the device path                 */
+  int    nscal;           /* nscal (2)                                                        */
+  int    slope_order;     /* 0, 2 or 4 (default 4)                                            */
+  int    use_minion;      /* logical use_minion (default 0)                                   */
+  int    boussinesq;      /* default 0                                                        */
+  int    stencil_order;   /* 2                                                                */
+  int    diffusion_type;  /* 1 = Crank-Nicolson, 2 = backward Euler                           */
+  int    verbose;
+  int    mg_verbose;
+  int    prob_type;       /* only used for the hgproject abs-eps special case (prob_type 4)   */
+  double visc_coef;       /* must be 0 in this round (viscous solve is a "next" row)          */
+  double diff_coef;       /* must be 0 in this round                                          */
+  double cflfac;          /* 0.8                                                              */
+  double max_dt_growth;   /* 1.1                                                              */
+  /* inflow data used by multifab_physbc EXT_DIR fills: [dir][side]                           */
+  double u_bc[3][2], v_bc[3][2], w_bc[3][2], rho_bc[3][2], trac_bc[3][2];
+  /* multigrid controls (the solvers are external to the reference tree; these are ours)      */
+  int    mg_nu1, mg_nu2;          /* pre/post smoothing sweeps (2,2)                          */
+  int    mg_nub;                  /* bottom sweeps on the coarsest level                      */
+  int    mg_max_iter;             /* max V-cycles for the MAC solve (100)                     */
+  int    hg_max_iter;             /* max V-cycles for the nodal solve (reference: 100)        */
+  int    hg_nu1, hg_nu2, hg_nub;
+  double hg_omega;                /* nodal Jacobi damping                                     */
+  double mac_rel_eps;             /* 1e-10: reference src/macproject.f90:91-93                */
+  double hg_rel_eps;              /* <=0: use 1e-12/1e-11/1e-10 by nlevs, hgproject.f90:113-119 */
+} vdn_params;
+
+/* fills *p with the reference defaults (src/_parameters) */
+void vdn_params_default(vdn_params *p);
+
+typedef struct vdn_box { int lo[3]; int hi[3]; } vdn_box;
+
+typedef struct vdn_layout   vdn_layout;    /* ml_layout (+ per-level layout, box->rank map)    */
+typedef struct vdn_multifab vdn_multifab;  /* multifab of one level                            */
+typedef struct vdn_bc_tower vdn_bc_tower;  /* define_bc_module::bc_tower                       */
+
+/* ------------------------------------------------------------------------------------------- */
+/* runtime                                                                                     */
+/* ------------------------------------------------------------------------------------------- */
+int  vdn_init(const vdn_params *prm, int rank, int nranks, int device);
+int  vdn_finalize(void);
+const char *vdn_last_error(void);
+int  vdn_set_stream(void *hip_stream);      /* all kernels are launched on this stream (default 0) */
+int  vdn_device_synchronize(void);
+int  vdn_get_params(vdn_params *out);
+
+/* ------------------------------------------------------------------------------------------- */
+/* ml_layout: nlev levels; rr[nlev-1][3] refinement ratios; pd[nlev] problem domains;          */
+/* boxes of all levels concatenated (nboxes[l] each); owner[] = rank of each box;              */
+/* pmask[3] periodicity.  (BoxLib: ml_layout_build / layout_build_ba)                          */
+/* ------------------------------------------------------------------------------------------- */
+int  vdn_layout_create(int nlev, const int *rr, const vdn_box *pd, const int *nboxes,
+                       const vdn_box *boxes, const int *owner, const int *pmask, vdn_layout **out);
+int  vdn_layout_destroy(vdn_layout *la);
+int  vdn_layout_nlevel(const vdn_layout *la);
+int  vdn_layout_nboxes(const vdn_layout *la, int lev);          /* global number of boxes     */
+int  vdn_layout_nlocal(const vdn_layout *la, int lev);          /* boxes owned by this rank    */
+int  vdn_layout_global_index(const vdn_layout *la, int lev, int local_i);
+int  vdn_layout_get_box(const vdn_layout *la, int lev, int global_i, vdn_box *out);
+
+/* ------------------------------------------------------------------------------------------- */
+/* bc_tower: built from the domain phys_bc[dir][side] exactly as define_bc_tower.f90 does       */
+/* (phys 129-156, adv 158-252, ell 254-340).  Arrays are addressed [grid][dir][side][comp]      */
+/* with grid 0 = whole domain, grids 1..nlocal = local boxes, comp 0-based.                     */
+/* ------------------------------------------------------------------------------------------- */
+int  vdn_bc_tower_create(const vdn_layout *la, const int *phys_bc /*[3][2]*/, vdn_bc_tower **out);
+int  vdn_bc_tower_destroy(vdn_bc_tower *bct);
+int  vdn_bc_tower_phys(const vdn_bc_tower *b, int lev, int grid, int dir, int side);
+int  vdn_bc_tower_adv (const vdn_bc_tower *b, int lev, int grid, int dir, int side, int comp);
+int  vdn_bc_tower_ell (const vdn_bc_tower *b, int lev, int grid, int dir, int side, int comp);
+
+/* ------------------------------------------------------------------------------------------- */
+/* multifab (BoxLib multifab_module names in comments)                                          */
+/* ------------------------------------------------------------------------------------------- */
+int  vdn_multifab_create(const vdn_layout *la, int lev, int nc, int ng, const int *nodal /*[3] or NULL*/,
+                         vdn_multifab **out);                                   /* multifab_build[_edge] */
+int  vdn_multifab_destroy(vdn_multifab *mf);                                    /* multifab_destroy      */
+int  vdn_multifab_nfabs(const vdn_multifab *mf);                                /* nfabs                 */
+int  vdn_multifab_ncomp(const vdn_multifab *mf);
+int  vdn_multifab_nghost(const vdn_multifab *mf);
+int  vdn_multifab_get_box(const vdn_multifab *mf, int local_i, vdn_box *out);   /* get_box (valid cells) */
+long vdn_multifab_fab_size(const vdn_multifab *mf, int local_i);                /* doubles in the fab    */
+int  vdn_multifab_dataptr(const vdn_multifab *mf, int local_i, double **dev);   /* dataptr (DEVICE ptr)  */
+int  vdn_multifab_copy_to_host(const vdn_multifab *mf, int local_i, double *host);
+int  vdn_multifab_copy_from_host(vdn_multifab *mf, int local_i, const double *host);
+int  vdn_multifab_setval(vdn_multifab *mf, double val, int comp, int nc, int all);     /* setval       */
+int  vdn_multifab_copy_c(vdn_multifab *dst, int dcomp, const vdn_multifab *src, int scomp,
+                         int nc, int ng);                                               /* copy_c       */
+int  vdn_multifab_norm_inf(const vdn_multifab *mf, int comp, int nc, double *out);      /* norm_inf     */
+int  vdn_multifab_min_max(const vdn_multifab *mf, int comp, double *mn, double *mx);    /* min_c/max_c  */
+int  vdn_multifab_fill_boundary(vdn_multifab *mf);                       /* multifab_fill_boundary    */
+int  vdn_multifab_physbc(vdn_multifab *mf, int scomp, int bccomp, int nc,
+                         const vdn_bc_tower *bct);                        /* multifab_physbc.f90:17    */
+
+/* ------------------------------------------------------------------------------------------- */
+/* the hot path.  Arrays of per-level multifab handles (length nlevel).                         */
+/* dx is [nlevel][3].  press_comp is the 1-based bc component (dm+nscal+1) as in the reference. */
+/* ------------------------------------------------------------------------------------------- */
+int  vdn_advance_timestep(int istep, vdn_layout *mla,
+                          vdn_multifab **sold, vdn_multifab **uold,
+                          vdn_multifab **snew, vdn_multifab **unew,
+                          vdn_multifab **gp,   vdn_multifab **p,
+                          vdn_multifab **ext_vel_force, vdn_multifab **ext_scal_force,
+                          const vdn_bc_tower *the_bc_tower,
+                          double dt, double time, const double *dx,
+                          int press_comp, int proj_type);
+/* estdt(lev,u,s,gp,ext_vel_force,dx,dtold,dt)  (reference src/estdt.f90:15-87) */
+int  vdn_estdt(int lev, const vdn_multifab *u, const vdn_multifab *s, const vdn_multifab *gp,
+               const vdn_multifab *ext_vel_force, const double *dx /*[3]*/, double dtold, double *dt);
+/* hgproject(proj_type,mla,unew,uold,rhohalf,p,gp,dx,dt,the_bc_tower,press_comp)
+ * (reference src/hgproject.f90:17) */
+int  vdn_hgproject(int proj_type, vdn_layout *mla, vdn_multifab **unew, vdn_multifab **uold,
+                   vdn_multifab **rhohalf, vdn_multifab **p, vdn_multifab **gp,
+                   const double *dx, double dt, const vdn_bc_tower *bct, int press_comp);
+/* macproject(mla,umac,rho,mac_rhs,dx,the_bc_tower,bc_comp)  (reference src/macproject.f90:20);
+ * umac is [nlevel][3] */
+int  vdn_macproject(vdn_layout *mla, vdn_multifab **umac, vdn_multifab **rho, vdn_multifab **mac_rhs,
+                    const double *dx, const vdn_bc_tower *bct, int bc_comp);
+
+/* per-phase wall seconds of the last vdn_advance_timestep (reference prints them,
+ * advance_timestep.f90:159-166): [0]=scalar [1]=velocity [2]=MAC [3]=HG [4]=total              */
+int  vdn_last_step_timing(double *sec5);
+/* diagnostics of the last MAC / HG solves: cycles, initial and final residual norms             */
+int  vdn_last_solver_stats(int which /*0=MAC,1=HG*/, int *cycles, double *res0, double *res);
+
+/* ------------------------------------------------------------------------------------------- */
+/* unit-test hooks: one per reference kernel, single-level, all local boxes.                    */
+/* ------------------------------------------------------------------------------------------- */
+/* slope_module (src/slope.f90): slopes of comps [0,nc) in direction dir on [lo-1,hi+1]^3;
+ * slope multifab must have ng=1, nc comps; bccomp = 0-based first adv_bc component             */
+int  vdn_k_slope(const vdn_multifab *s, vdn_multifab *slope, int dir, int bccomp, const vdn_bc_tower *bct);
+/* velpred (src/velpred.f90:16): u(3,ng3), force(3,ng1) -> umac[3] (face, ng1), incl. fill_boundary */
+int  vdn_k_velpred(const vdn_multifab *u, vdn_multifab **umac, const vdn_multifab *force,
+                   const double *dx, double dt, const vdn_bc_tower *bct);
+/* mkflux (src/mkflux.f90:16) */
+int  vdn_k_mkflux(const vdn_multifab *s, vdn_multifab **sedge, vdn_multifab **flux,
+                  vdn_multifab **umac, const vdn_multifab *force, const vdn_multifab *mac_rhs,
+                  const double *dx, double dt, const vdn_bc_tower *bct, int is_vel, const int *is_cons);
+/* update (src/update.f90:16), incl. the ghost fill of snew */
+int  vdn_k_update(const vdn_multifab *sold, vdn_multifab **umac, vdn_multifab **sedge, vdn_multifab **flux,
+                  const vdn_multifab *force, vdn_multifab *snew, const double *dx, double dt,
+                  int is_vel, const int *is_cons, const vdn_bc_tower *bct);
+/* mkvelforce / mkscalforce (src/mkforce.f90:18,238), incl. ghost fill */
+int  vdn_k_mkvelforce(vdn_multifab *vel_force, const vdn_multifab *ext_vel_force, const vdn_multifab *s,
+                      const vdn_multifab *gp, const vdn_multifab *lapu /*may be NULL*/, double visc_fac,
+                      const vdn_bc_tower *bct);
+int  vdn_k_mkscalforce(vdn_multifab *scal_force, const vdn_multifab *ext_scal_force,
+                       const vdn_multifab *laps /*may be NULL*/, double diff_fac, const vdn_bc_tower *bct);
+/* make_at_halftime (src/make_at_halftime.f90:18) */
+int  vdn_k_make_at_halftime(vdn_multifab *rhohalf, const vdn_multifab *sold, const vdn_multifab *snew,
+                            int in_comp, int out_comp, const vdn_bc_tower *bct);
+
+/* cell-centred multigrid: solves (-div beta grad) phi = rh with the boundary types
+ * bc[dir][side] in {VDN_BC_NEU, VDN_BC_DIR, VDN_BC_PER}; replaces ml_cc_solve as called from
+ * reference src/mac_multigrid.f90:53-62 (alpha = 0).  phi has ng=1, rh ng=0, beta[3] faces.      */
+int  vdn_cc_solve(vdn_multifab *rh, vdn_multifab *phi, vdn_multifab **beta, const double *dx,
+                  const int *bc /*[3][2]*/, double rel_eps, double abs_eps, int max_iter,
+                  int *cycles, double *res0, double *res);
+/* one red-black Gauss-Seidel sweep pair (nsweeps times) of that operator on the finest level --
+ * the kernel the smoother roofline is quoted on                                                   */
+int  vdn_cc_smooth(vdn_multifab *rh, vdn_multifab *phi, vdn_multifab **beta, const double *dx,
+                   const int *bc /*[3][2]*/, int nsweeps);
+/* nodal multigrid: solves div(sigma grad phi) = div(u) (+rh in) with sigma = coeffs (cell, ng=1,
+ * zero outside the domain), dense (Q1) stencil; replaces ml_nd_solve as called from reference
+ * src/hg_multigrid.f90:95-105 (add_divu=.true., u=unew).  phi, rh nodal ng=1.                     */
+int  vdn_nd_solve(vdn_multifab *rh, vdn_multifab *phi, const vdn_multifab *coeffs, const vdn_multifab *u,
+                  const double *dx, const int *bc /*[3][2]*/, double rel_eps, double abs_eps, int max_iter,
+                  int *cycles, double *res0, double *res);
+
+/* ---- kernel timing (HIP events on the launch stream) for bench.py's roofline object ---------- */
+/* times `nlaunch` back-to-back launches of ONE colour pass of the cc smoother on the finest level
+ * and returns the average milliseconds per launch and the number of cells one launch covers      */
+int  vdn_bench_cc_smoother(vdn_multifab *rh, vdn_multifab *phi, vdn_multifab **beta, const double *dx,
+                           const int *bc, int nlaunch, double *avg_ms, long *cells);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VARDEN_AMD_H */

@@ -1,0 +1,154 @@
+/*
+ * oracle/vo.h -- CPU restatement ("oracle") of VARDEN's advance_timestep hot path.
+ *
+ * TEST INFRASTRUCTURE ONLY.  Nothing under varden_amd/ may include, link or call this.
+ * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg use it, and only as
+ * the checker / the reported CPU baseline.
+ *
+ * PARITY STATUS: **parity unpinned**.  The reference (BoxLib-Codes/VARDEN, pure Fortran 90) ships
+ * no golden vectors, fixtures or known-answer tests for this path, and it
+ * cannot be built here: it needs FBoxLib (external, absent, unpinned) and a generated
+ * probin.f90.  Building it against hand-written stand-ins for those modules is not allowed
+ * by this round's rules, so this restatement is checked only against (i) a line-by-line
+ * reading of the reference sources it cites and (ii) the known-answer invariants listed in
+ * SURVEY.md section 8(c) (tests/test_oracle_invariants.py).  Both multigrid solvers live in FBoxLib and
+ * have NO reference text at all: oracle/vo_mg_cc.c and vo_mg_nd.c define the discrete systems
+ *  and an algorithm of our own.
+ *
+ * Arithmetic: IEEE f64, compiled with -ffp-contract=off so that expression order is the
+ * only thing that determines the bits (the reference CPU build has no FMA contraction on
+ * baseline x86-64).  Every function cites the reference file:line it follows.
+ */
+#ifndef VO_H
+#define VO_H
+#include <stddef.h>
+#include "../include/varden_amd.h"   /* vdn_params and the bc enums: the product's PUBLIC header */
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* one fab in BoxLib layout: p(lo-ng:hi+ng+nd, ..., 0:nc-1), x fastest */
+typedef struct vo_fab {
+  double *p;
+  int lo[3], hi[3];   /* valid CELL box */
+  int ng;
+  int nd[3];          /* nodal flags */
+  int nc;
+  long n[3];          /* allocated extents */
+  long sc;            /* component stride */
+} vo_fab;
+
+static inline void vo_fab_init(vo_fab *f, double *p, const int *lo, const int *hi, int ng,
+                               const int *nd, int nc) {
+  f->p = p; f->ng = ng; f->nc = nc;
+  for (int d = 0; d < 3; d++) {
+    f->lo[d] = lo[d]; f->hi[d] = hi[d]; f->nd[d] = nd ? nd[d] : 0;
+    f->n[d] = hi[d] - lo[d] + 1 + f->nd[d] + 2 * ng;
+  }
+  f->sc = f->n[0] * f->n[1] * f->n[2];
+}
+static inline long vo_size(const vo_fab *f) { return f->sc * f->nc; }
+static inline long vo_idx(const vo_fab *f, int i, int j, int k, int c) {
+  return (long)(i - f->lo[0] + f->ng) + f->n[0] * ((long)(j - f->lo[1] + f->ng) +
+         f->n[1] * (long)(k - f->lo[2] + f->ng)) + f->sc * c;
+}
+#define VF(f, i, j, k, c) ((f)->p[vo_idx((f), (i), (j), (k), (c))])
+
+/* bc tables for ONE box: phys[dir][side]; adv[dir][side][comp] with comp 0-based in the
+ * reference order vel(0..dm-1), rho, tracers, press, extrap (define_bc_tower.f90:171-193);
+ * ell[dir][side][comp] */
+#define VO_MAXCOMP 16
+typedef struct vo_bc {
+  int phys[3][2];
+  int adv[3][2][VO_MAXCOMP];
+  int ell[3][2][VO_MAXCOMP];
+  int ncomp_adv, ncomp_ell;
+  int press_comp, extrap_comp;   /* 0-based */
+} vo_bc;
+
+void vo_bc_build(vo_bc *bc, const int phys[3][2], int dm, int nscal);
+
+/* ---- ghost cells ---------------------------------------------------------------------- */
+/* single-box multifab_fill_boundary: periodic wrap only (pmask), cell/face/nodal aware */
+void vo_fill_boundary(vo_fab *f, const int pmask[3]);
+/* multifab_physbc.f90:238-561, component scomp (0-based) with adv bc component bccomp (0-based) */
+void vo_physbc(vo_fab *f, int scomp, int bccomp, int nc, const vo_bc *bc, const vdn_params *prm);
+
+/* ---- Godunov pieces --------------------------------------------------------------------- */
+/* slope.f90:148-588; out: slope fab with ng=1 (cells [lo-1,hi+1]), comps [0,nc) of s using
+ * adv bc comps bccomp+c; dir = 0,1,2 */
+void vo_slope(const vo_fab *s, vo_fab *slope, int dir, int nc, int bccomp, const vo_bc *bc,
+              int slope_order);
+/* velpred.f90:1776-2765 (kernel only, no ghost fill) */
+void vo_velpred(const vo_fab *u, vo_fab *umac[3], const vo_fab *force, const double dx[3],
+                double dt, const vo_bc *bc, const vdn_params *prm);
+/* mkflux.f90:1186-2567 (kernel only) */
+void vo_mkflux(const vo_fab *s, vo_fab *sedge[3], vo_fab *flux[3], vo_fab *umac[3],
+               const vo_fab *force, const vo_fab *mac_rhs, const double dx[3], double dt,
+               int is_vel, const int *is_cons, int bccomp, const vo_bc *bc, const vdn_params *prm);
+/* update.f90:186-278 (kernel only) */
+void vo_update(const vo_fab *sold, vo_fab *umac[3], vo_fab *sedge[3], vo_fab *flux[3],
+               const vo_fab *force, vo_fab *snew, const double dx[3], double dt, int is_vel,
+               const int *is_cons);
+/* mkforce.f90:144-236 / 333-402 (kernels only) */
+void vo_mkvelforce(vo_fab *vel_force, const vo_fab *ext, const vo_fab *gp, const vo_fab *s,
+                   const vo_fab *lapu, double visc_fac, const vdn_params *prm);
+void vo_mkscalforce(vo_fab *scal_force, const vo_fab *ext, const vo_fab *laps, double diff_fac,
+                    const vdn_params *prm);
+/* make_at_halftime.f90:95-115 */
+void vo_make_at_halftime(vo_fab *rhohalf, int out_comp, const vo_fab *sold, const vo_fab *snew, int in_comp);
+/* estdt.f90:131-181 + 69-78 */
+double vo_estdt(const vo_fab *u, const vo_fab *s, const vo_fab *gp, const vo_fab *ext, const double dx[3],
+                double dtold, const vdn_params *prm);
+
+/* ---- MAC projection ------------------------------------------------------------------------ */
+/* macproject.f90:250-278 */
+void vo_divumac(vo_fab *umac[3], vo_fab *rh, const double dx[3]);
+/* macproject.f90:361-401 */
+void vo_mk_mac_coeffs(const vo_fab *rho, vo_fab *beta[3]);
+/* macproject.f90:578-645 restated with ghost-phi gradients at box faces (see vo_macproject.c) */
+void vo_mkumac(vo_fab *umac[3], const vo_fab *phi, vo_fab *beta[3], const double dx[3], const int ellbc[3][2]);
+/* our cell-centred multigrid (replaces FBoxLib ml_cc_solve, mac_multigrid.f90:53) */
+typedef struct vo_mgstat { int cycles; double res0, res; } vo_mgstat;
+int  vo_cc_solve(const vo_fab *rh, vo_fab *phi, vo_fab *beta[3], const double dx[3], const int ellbc[3][2],
+                 double rel_eps, double abs_eps, int max_iter, int nu1, int nu2, int nub, vo_mgstat *st);
+void vo_cc_smooth(const vo_fab *rh, vo_fab *phi, vo_fab *beta[3], const double dx[3], const int ellbc[3][2],
+                  int nsweeps);
+/* macproject.f90:20-133, single level */
+void vo_macproject(vo_fab *umac[3], vo_fab *rho, const vo_fab *mac_rhs, const double dx[3], const vo_bc *bc,
+                   const int pmask[3], const vdn_params *prm, vo_mgstat *st);
+
+/* ---- HG projection -------------------------------------------------------------------------- */
+/* hgproject.f90:434-513 */
+void vo_create_uvec(vo_fab *unew, const vo_fab *uold, const vo_fab *rhohalf, vo_fab *gp, double dt,
+                    const vo_bc *bc, int proj_type);
+/* hgproject.f90:543-577 */
+void vo_mkgphi(vo_fab *gphi, const vo_fab *phi, const double dx[3]);
+/* hgproject.f90:638-698 */
+void vo_hg_update(int proj_type, vo_fab *unew, const vo_fab *uold, vo_fab *gp, const vo_fab *gphi,
+                  const vo_fab *rhohalf, vo_fab *p, const vo_fab *phi, double dt);
+/* our nodal multigrid (replaces FBoxLib ml_nd_solve, hg_multigrid.f90:95) */
+void vo_nd_divu(const vo_fab *u, vo_fab *rh, const double dx[3], const int ellbc[3][2]);
+int  vo_nd_solve(vo_fab *rh, vo_fab *phi, const vo_fab *coeffs, const vo_fab *u, const double dx[3],
+                 const int ellbc[3][2], const int pmask[3], double rel_eps, double abs_eps, int max_iter,
+                 int nu1, int nu2, int nub, double omega, vo_mgstat *st);
+/* hgproject.f90:17-178 + hg_multigrid.f90:18-119, single level */
+void vo_hgproject(int proj_type, vo_fab *unew, const vo_fab *uold, vo_fab *rhohalf, vo_fab *p, vo_fab *gp,
+                  const double dx[3], double dt, const vo_bc *bc, const int pmask[3], const vdn_params *prm,
+                  vo_mgstat *st);
+
+/* ---- advance_timestep.f90:26-170, single level, single box ---------------------------------- */
+typedef struct vo_state {
+  vo_fab uold, sold, unew, snew, gp, p, ext_vel_force, ext_scal_force;
+} vo_state;
+void vo_advance_timestep(vo_state *S, const double dx[3], double dt, const vo_bc *bc, const int pmask[3],
+                         const vdn_params *prm, int proj_type, vo_mgstat st[2], double phase_sec[4]);
+
+/* ---- initdata.f90:201-311 (prob_type 1 and 2) ----------------------------------------------- */
+void vo_initdata(vo_fab *u, vo_fab *s, const double dx[3], int prob_type);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,369 @@
+/* oracle/vo_godunov.c -- unsplit Godunov predictors.
+ * TEST INFRASTRUCTURE ONLY (see vo.h).  parity unpinned.
+ *
+ *   vo_velpred : reference src/velpred.f90:1776-2765 (velpred_3d; default path)
+ *   vo_mkflux  : reference src/mkflux.f90:1186-2567  (mkflux_3d;  default path)
+ *
+ * The reference kernels march in k keeping two planes of ~30 intermediates; the
+ * non-rolling *_debug_3d variants (velpred.f90:880-1774, mkflux.f90:2569-3882) hold every
+ * intermediate as a full array and are the same arithmetic.  This restatement uses the
+ * full-array form, written once for a generic face direction d and transverse directions,
+ * and keeps the rolling kernels' behaviour where the two differ:
+ *   - hi-x OUTLET in velpred uses min(ulx,0)                 (velpred.f90:2075; debug uses max)
+ *   - z-lo INLET in mkflux takes the ghost cell s(:,:,ks-1)  (mkflux.f90:1808; debug reads ks)
+ * Expression order follows the reference statement by statement (IEEE add/mul are
+ * commutative, so only association matters).
+ */
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+#include "vo.h"
+
+typedef struct { double *p; int lo[3]; long n[3]; } wk;   /* work array over [lo-1, hi+2]^3 */
+static void wk_alloc(wk *w, const int *lo, const int *hi) {
+  for (int d = 0; d < 3; d++) { w->lo[d] = lo[d] - 1; w->n[d] = hi[d] - lo[d] + 4; }
+  w->p = (double *)malloc(sizeof(double) * w->n[0] * w->n[1] * w->n[2]);
+  for (long i = 0; i < w->n[0] * w->n[1] * w->n[2]; i++) w->p[i] = NAN;   /* poison: unset reads show up */
+}
+static inline long wk_idx(const wk *w, const int *q) {
+  return (q[0] - w->lo[0]) + w->n[0] * ((long)(q[1] - w->lo[1]) + w->n[1] * (long)(q[2] - w->lo[2]));
+}
+#define W(w, q) ((w).p[wk_idx(&(w), (q))])
+static inline double fabv(const vo_fab *f, const int *q, int c) { return VF(f, q[0], q[1], q[2], c); }
+
+/* boundary treatment of a (left,right) state pair on a domain face; same rule at every stage:
+ * velpred.f90:2044-2079 (normal predictor), 2200-2224 (transverse), mkflux.f90:1463-1515 etc.
+ *   phys     physical bc of that face,  side 0 = lo, 1 = hi
+ *   is_vel   the advected quantity is velocity;  normal: its component is the face normal
+ *   ghost    value of the quantity in the ghost cell just outside the face (INLET datum)
+ *   quirk    velpred_3d hi-x OUTLET uses min instead of max (velpred.f90:2075)           */
+static inline void bc_pair(double *L, double *R, int phys, int side, int is_vel, int normal,
+                           double ghost, int quirk)
+{
+  if (phys == VDN_INLET) { *L = ghost; *R = ghost; }
+  else if (phys == VDN_SLIP_WALL) {
+    if (is_vel && normal) { *L = 0.0; *R = 0.0; }
+    else if (side == 0) *L = *R; else *R = *L;
+  } else if (phys == VDN_NO_SLIP_WALL) {
+    if (is_vel) { *L = 0.0; *R = 0.0; }
+    else if (side == 0) *L = *R; else *R = *L;
+  } else if (phys == VDN_OUTLET) {
+    if (is_vel && normal) {
+      double v;
+      if (side == 0) v = fmin(*R, 0.0);
+      else v = quirk ? fmin(*L, 0.0) : fmax(*L, 0.0);
+      *L = v; *R = v;
+    } else if (side == 0) *L = *R; else *R = *L;
+  }
+}
+
+/* which domain face (if any) does face index f of direction d sit on? returns side or -1 */
+static inline int face_side(int f, int d, const int *lo, const int *hi) {
+  if (f == lo[d]) return 0;
+  if (f == hi[d] + 1) return 1;
+  return -1;
+}
+
+/* ==========================================================================================
+ * velpred_3d
+ * ======================================================================================== */
+void vo_velpred(const vo_fab *u, vo_fab *umac[3], const vo_fab *force, const double dx[3],
+                double dt, const vo_bc *bc, const vdn_params *prm)
+{
+  const int *lo = u->lo, *hi = u->hi;
+  const double dt2 = 0.5 * dt, dt4 = dt / 4.0, dt6 = dt / 6.0;
+  const int use_minion = prm->use_minion;
+  int nd0[3] = { 0, 0, 0 };
+
+  /* slopes of all three components in all three directions (velpred.f90:1848-1852) */
+  vo_fab slope[3];
+  for (int d = 0; d < 3; d++) {
+    vo_fab_init(&slope[d], NULL, lo, hi, 1, nd0, 3);
+    slope[d].p = (double *)malloc(sizeof(double) * vo_size(&slope[d]));
+    vo_slope(u, &slope[d], d, 3, 0, bc, prm->slope_order);
+  }
+
+  /* eps relative to the max velocity of the box (velpred.f90:1965-1980) */
+  double umax = fabs(VF(u, lo[0], lo[1], lo[2], 0));
+  for (int k = lo[2]; k <= hi[2]; k++) for (int j = lo[1]; j <= hi[1]; j++) for (int i = lo[0]; i <= hi[0]; i++)
+    for (int c = 0; c < 3; c++) umax = fmax(umax, fabs(VF(u, i, j, k, c)));
+  double eps = (umax == 0.0) ? 1.0e-8 : 1.0e-8 * umax;
+
+  /* stage B: uL^d, uR^d (3 comps, after bc) and uimh_d (3 comps) on d-faces */
+  wk UL[3][3], UR[3][3], UI[3][3];      /* [d][comp] */
+  for (int d = 0; d < 3; d++) for (int c = 0; c < 3; c++) { wk_alloc(&UL[d][c], lo, hi); wk_alloc(&UR[d][c], lo, hi); wk_alloc(&UI[d][c], lo, hi); }
+
+  for (int d = 0; d < 3; d++) {
+    int rlo[3], rhi[3];
+    for (int t = 0; t < 3; t++) { rlo[t] = lo[t] - 1; rhi[t] = hi[t] + 1; }
+    rlo[d] = lo[d]; rhi[d] = hi[d] + 1;
+    #pragma omp parallel for collapse(2)
+    for (int k = rlo[2]; k <= rhi[2]; k++) for (int j = rlo[1]; j <= rhi[1]; j++) for (int i = rlo[0]; i <= rhi[0]; i++) {
+      int f[3] = { i, j, k }, cl[3] = { i, j, k };
+      cl[d] -= 1;
+      double L[3], R[3];
+      double ul = fabv(u, cl, d), ur = fabv(u, f, d);
+      double cfl_l, cfl_r;
+      /* velpred.f90:2022 (x), 2108 (y-left: the division sits INSIDE max), 2286 (z) */
+      if (d == 1) cfl_l = dt2 * fmax(0.0, ul / dx[1]); else cfl_l = dt2 * fmax(0.0, ul) / dx[d];
+      cfl_r = dt2 * fmin(0.0, ur) / dx[d];
+      for (int c = 0; c < 3; c++) {
+        L[c] = fabv(u, cl, c) + (0.5 - cfl_l) * fabv(&slope[d], cl, c);
+        R[c] = fabv(u, f, c) - (0.5 + cfl_r) * fabv(&slope[d], f, c);
+        if (use_minion) { L[c] = L[c] + dt2 * fabv(force, cl, c); R[c] = R[c] + dt2 * fabv(force, f, c); }
+      }
+      int side = face_side(f[d], d, lo, hi);
+      if (side >= 0) {
+        int g[3] = { i, j, k }; if (side == 0) g[d] -= 1;      /* ghost cell outside the face */
+        for (int c = 0; c < 3; c++)
+          bc_pair(&L[c], &R[c], bc->phys[d][side], side, 1, c == d, fabv(u, g, c), d == 0 && side == 1);
+      }
+      /* normal Riemann problem, then upwind the transverse components (velpred.f90:2081-2098) */
+      double uavg = 0.5 * (L[d] + R[d]);
+      int test = ((L[d] <= 0.0 && R[d] >= 0.0) || (fabs(L[d] + R[d]) < eps));
+      double un = (uavg > 0.0) ? L[d] : R[d];
+      un = test ? 0.0 : un;
+      for (int c = 0; c < 3; c++) {
+        W(UL[d][c], f) = L[c]; W(UR[d][c], f) = R[c];
+        if (c == d) W(UI[d][c], f) = un;
+        else {
+          double v = (un > 0.0) ? L[c] : R[c];
+          double av = 0.5 * (L[c] + R[c]);
+          W(UI[d][c], f) = (fabs(un) < eps) ? av : v;
+        }
+      }
+    }
+  }
+
+  /* stage C: component c on d-faces (d != c), corrected by the third direction o
+   * e.g. uimhyz = (c=0,d=1,o=2) velpred.f90:2466-2503; wimhxy = (c=2,d=0,o=1) 2189-2229 */
+  wk XC[3][3];     /* [c][d] */
+  for (int c = 0; c < 3; c++) for (int d = 0; d < 3; d++) if (c != d) {
+    int o = 3 - c - d;
+    wk_alloc(&XC[c][d], lo, hi);
+    int rlo[3], rhi[3];
+    rlo[d] = lo[d]; rhi[d] = hi[d] + 1;       /* normal: faces   */
+    rlo[o] = lo[o]; rhi[o] = hi[o];           /* corrected dir   */
+    rlo[c] = lo[c] - 1; rhi[c] = hi[c] + 1;   /* remaining dir   */
+    #pragma omp parallel for collapse(2)
+    for (int k = rlo[2]; k <= rhi[2]; k++) for (int j = rlo[1]; j <= rhi[1]; j++) for (int i = rlo[0]; i <= rhi[0]; i++) {
+      int f[3] = { i, j, k }, cl[3] = { i, j, k }, clp[3], fp[3] = { i, j, k };
+      cl[d] -= 1;
+      clp[0] = cl[0]; clp[1] = cl[1]; clp[2] = cl[2]; clp[o] += 1; fp[o] += 1;
+      double L = W(UL[d][c], f) - (dt6 / dx[o]) * (W(UI[o][o], clp) + W(UI[o][o], cl)) * (W(UI[o][c], clp) - W(UI[o][c], cl));
+      double R = W(UR[d][c], f) - (dt6 / dx[o]) * (W(UI[o][o], fp) + W(UI[o][o], f)) * (W(UI[o][c], fp) - W(UI[o][c], f));
+      int side = face_side(f[d], d, lo, hi);
+      if (side >= 0) {
+        int g[3] = { i, j, k }; if (side == 0) g[d] -= 1;
+        bc_pair(&L, &R, bc->phys[d][side], side, 1, 0, fabv(u, g, c), 0);
+      }
+      double un = W(UI[d][d], f);
+      double v = (un > 0.0) ? L : R;
+      double av = 0.5 * (L + R);
+      W(XC[c][d], f) = (fabs(un) < eps) ? av : v;
+    }
+  }
+
+  /* stage D: umac_d on valid d-faces (velpred.f90:2616-2660 umac, 2666-2710 vmac, 2372-2416 wmac) */
+  for (int d = 0; d < 3; d++) {
+    int t1 = (d == 0) ? 1 : 0, t2 = (d == 2) ? 1 : 2;     /* the other two directions, ascending */
+    vo_fab *um = umac[d];
+    int rlo[3], rhi[3];
+    for (int t = 0; t < 3; t++) { rlo[t] = lo[t]; rhi[t] = hi[t]; }
+    rhi[d] = hi[d] + 1;
+    #pragma omp parallel for collapse(2)
+    for (int k = rlo[2]; k <= rhi[2]; k++) for (int j = rlo[1]; j <= rhi[1]; j++) for (int i = rlo[0]; i <= rhi[0]; i++) {
+      int f[3] = { i, j, k }, cl[3] = { i, j, k };
+      cl[d] -= 1;
+      int cl1[3] = { cl[0], cl[1], cl[2] }, cl2[3] = { cl[0], cl[1], cl[2] };
+      int f1[3] = { i, j, k }, f2[3] = { i, j, k };
+      cl1[t1] += 1; cl2[t2] += 1; f1[t1] += 1; f2[t2] += 1;
+      double L = W(UL[d][d], f)
+        - (dt4 / dx[t1]) * (W(UI[t1][t1], cl1) + W(UI[t1][t1], cl)) * (W(XC[d][t1], cl1) - W(XC[d][t1], cl))
+        - (dt4 / dx[t2]) * (W(UI[t2][t2], cl2) + W(UI[t2][t2], cl)) * (W(XC[d][t2], cl2) - W(XC[d][t2], cl));
+      double R = W(UR[d][d], f)
+        - (dt4 / dx[t1]) * (W(UI[t1][t1], f1) + W(UI[t1][t1], f)) * (W(XC[d][t1], f1) - W(XC[d][t1], f))
+        - (dt4 / dx[t2]) * (W(UI[t2][t2], f2) + W(UI[t2][t2], f)) * (W(XC[d][t2], f2) - W(XC[d][t2], f));
+      if (!use_minion) { L = L + dt2 * fabv(force, cl, d); R = R + dt2 * fabv(force, f, d); }
+      double uavg = 0.5 * (L + R);
+      int test = ((L <= 0.0 && R >= 0.0) || (fabs(L + R) < eps));
+      double v = (uavg > 0.0) ? L : R;
+      v = test ? 0.0 : v;
+      int side = face_side(f[d], d, lo, hi);
+      if (side >= 0) {                                   /* velpred.f90:2642-2659 */
+        int ph = bc->phys[d][side];
+        int g[3] = { i, j, k }; if (side == 0) g[d] -= 1;
+        if (ph == VDN_SLIP_WALL || ph == VDN_NO_SLIP_WALL) v = 0.0;
+        else if (ph == VDN_INLET) v = fabv(u, g, d);
+        else if (ph == VDN_OUTLET) v = (side == 0) ? fmin(R, 0.0) : fmax(L, 0.0);
+      }
+      VF(um, i, j, k, 0) = v;
+    }
+  }
+
+  for (int d = 0; d < 3; d++) {
+    free(slope[d].p);
+    for (int c = 0; c < 3; c++) { free(UL[d][c].p); free(UR[d][c].p); free(UI[d][c].p); if (c != d) free(XC[c][d].p); }
+  }
+}
+
+/* ==========================================================================================
+ * mkflux_3d
+ * ======================================================================================== */
+static inline double upwind_mac(double L, double R, double umac, double eps)
+{   /* mkflux.f90:1520-1522 */
+  double v = (umac > 0.0) ? L : R;
+  double savg = 0.5 * (L + R);
+  return (fabs(umac) > eps) ? v : savg;
+}
+
+void vo_mkflux(const vo_fab *s, vo_fab *sedge[3], vo_fab *flux[3], vo_fab *umac[3],
+               const vo_fab *force, const vo_fab *mac_rhs, const double dx[3], double dt,
+               int is_vel, const int *is_cons, int bccomp, const vo_bc *bc, const vdn_params *prm)
+{
+  const int *lo = s->lo, *hi = s->hi;
+  const int ncomp = s->nc;
+  const double dt2 = 0.5 * dt, dt3 = dt / 3.0, dt4 = dt / 4.0, dt6 = dt / 6.0;
+  const int use_minion = prm->use_minion;
+  int nd0[3] = { 0, 0, 0 };
+
+  vo_fab slope[3];
+  for (int d = 0; d < 3; d++) {
+    vo_fab_init(&slope[d], NULL, lo, hi, 1, nd0, ncomp);
+    slope[d].p = (double *)malloc(sizeof(double) * vo_size(&slope[d]));
+    vo_slope(s, &slope[d], d, ncomp, bccomp, bc, prm->slope_order);
+  }
+
+  /* eps relative to the max MAC velocity on the valid faces (mkflux.f90:1374-1401) */
+  double umax = fabs(VF(umac[0], lo[0], lo[1], lo[2], 0));
+  for (int d = 0; d < 3; d++) {
+    int rhi[3] = { hi[0], hi[1], hi[2] }; rhi[d] += 1;
+    for (int k = lo[2]; k <= rhi[2]; k++) for (int j = lo[1]; j <= rhi[1]; j++) for (int i = lo[0]; i <= rhi[0]; i++)
+      umax = fmax(umax, fabs(VF(umac[d], i, j, k, 0)));
+  }
+  double eps = (umax == 0.0) ? 1.0e-8 : 1.0e-8 * umax;
+
+  wk SL[3], SR[3], SI[3], SC[3][3];
+  for (int d = 0; d < 3; d++) { wk_alloc(&SL[d], lo, hi); wk_alloc(&SR[d], lo, hi); wk_alloc(&SI[d], lo, hi);
+    for (int t = 0; t < 3; t++) if (t != d) wk_alloc(&SC[d][t], lo, hi); }
+
+  for (int comp = 0; comp < ncomp; comp++) {
+    const int cons = is_cons[comp];
+
+    /* stage B: s_L^d, s_R^d (after bc) and simh_d (mkflux.f90:1440-1524 x, 1527-1611 y, 1779-1865 z) */
+    for (int d = 0; d < 3; d++) {
+      int rlo[3], rhi[3];
+      for (int t = 0; t < 3; t++) { rlo[t] = lo[t] - 1; rhi[t] = hi[t] + 1; }
+      rlo[d] = lo[d]; rhi[d] = hi[d] + 1;
+      #pragma omp parallel for collapse(2)
+      for (int k = rlo[2]; k <= rhi[2]; k++) for (int j = rlo[1]; j <= rhi[1]; j++) for (int i = rlo[0]; i <= rhi[0]; i++) {
+        int f[3] = { i, j, k }, cl[3] = { i, j, k };
+        cl[d] -= 1;
+        double um = fabv(umac[d], f, 0);
+        double L = fabv(s, cl, comp) + (0.5 - dt2 * um / dx[d]) * fabv(&slope[d], cl, comp);
+        double R = fabv(s, f, comp) - (0.5 + dt2 * um / dx[d]) * fabv(&slope[d], f, comp);
+        if (use_minion) {
+          L = L + dt2 * fabv(force, cl, comp); R = R + dt2 * fabv(force, f, comp);
+          if (cons) { L = L - dt2 * fabv(s, cl, comp) * fabv(mac_rhs, cl, 0); R = R - dt2 * fabv(s, f, comp) * fabv(mac_rhs, f, 0); }
+        }
+        int side = face_side(f[d], d, lo, hi);
+        if (side >= 0) {
+          int g[3] = { i, j, k }; if (side == 0) g[d] -= 1;
+          bc_pair(&L, &R, bc->phys[d][side], side, is_vel, comp == d, fabv(s, g, comp), 0);
+        }
+        W(SL[d], f) = L; W(SR[d], f) = R;
+        W(SI[d], f) = upwind_mac(L, R, um, eps);
+      }
+    }
+
+    /* stage C: simh_{d t}: d-face state corrected by transverse direction t
+     * (mkflux.f90:1614-1691 xy, 1694-1773 yx, 1975-2144 zx/zy, 2147-2304 xz/yz) */
+    for (int d = 0; d < 3; d++) for (int t = 0; t < 3; t++) if (t != d) {
+      int o = 3 - d - t;
+      int rlo[3], rhi[3];
+      rlo[d] = lo[d]; rhi[d] = hi[d] + 1;
+      rlo[t] = lo[t]; rhi[t] = hi[t];
+      rlo[o] = lo[o] - 1; rhi[o] = hi[o] + 1;
+      #pragma omp parallel for collapse(2)
+      for (int k = rlo[2]; k <= rhi[2]; k++) for (int j = rlo[1]; j <= rhi[1]; j++) for (int i = rlo[0]; i <= rhi[0]; i++) {
+        int f[3] = { i, j, k }, cl[3] = { i, j, k }, clp[3], fp[3] = { i, j, k };
+        cl[d] -= 1;
+        clp[0] = cl[0]; clp[1] = cl[1]; clp[2] = cl[2]; clp[t] += 1; fp[t] += 1;
+        double L, R;
+        if (cons) {
+          L = W(SL[d], f) - (dt3 / dx[t]) * (W(SI[t], clp) * fabv(umac[t], clp, 0) - W(SI[t], cl) * fabv(umac[t], cl, 0));
+          R = W(SR[d], f) - (dt3 / dx[t]) * (W(SI[t], fp) * fabv(umac[t], fp, 0) - W(SI[t], f) * fabv(umac[t], f, 0));
+        } else {
+          L = W(SL[d], f) - (dt6 / dx[t]) * (fabv(umac[t], clp, 0) + fabv(umac[t], cl, 0)) * (W(SI[t], clp) - W(SI[t], cl));
+          R = W(SR[d], f) - (dt6 / dx[t]) * (fabv(umac[t], fp, 0) + fabv(umac[t], f, 0)) * (W(SI[t], fp) - W(SI[t], f));
+        }
+        int side = face_side(f[d], d, lo, hi);
+        if (side >= 0) {
+          int g[3] = { i, j, k }; if (side == 0) g[d] -= 1;
+          bc_pair(&L, &R, bc->phys[d][side], side, is_vel, comp == d, fabv(s, g, comp), 0);
+        }
+        W(SC[d][t], f) = upwind_mac(L, R, fabv(umac[d], f, 0), eps);
+      }
+    }
+
+    /* stage D: edge states and fluxes on valid faces
+     * (mkflux.f90:2307-2408 sedgex, 2411-2511 sedgey, 1867-1972 sedgez) */
+    for (int d = 0; d < 3; d++) {
+      int t1 = (d == 0) ? 1 : 0, t2 = (d == 2) ? 1 : 2;
+      int rlo[3], rhi[3];
+      for (int t = 0; t < 3; t++) { rlo[t] = lo[t]; rhi[t] = hi[t]; }
+      rhi[d] = hi[d] + 1;
+      #pragma omp parallel for collapse(2)
+      for (int k = rlo[2]; k <= rhi[2]; k++) for (int j = rlo[1]; j <= rhi[1]; j++) for (int i = rlo[0]; i <= rhi[0]; i++) {
+        int f[3] = { i, j, k }, cl[3] = { i, j, k };
+        cl[d] -= 1;
+        double LR[2];
+        for (int sd = 0; sd < 2; sd++) {
+          const int *c0 = sd == 0 ? cl : f;              /* the cell this state is extrapolated from */
+          int c1[3] = { c0[0], c0[1], c0[2] }, c2[3] = { c0[0], c0[1], c0[2] };
+          c1[t1] += 1; c2[t2] += 1;
+          double v = (sd == 0) ? W(SL[d], f) : W(SR[d], f);
+          /* x-face: y term uses simhyz = SC[t1][t2], z term uses simhzy = SC[t2][t1] */
+          if (cons) {
+            v = v
+              - (dt2 / dx[t1]) * (W(SC[t1][t2], c1) * fabv(umac[t1], c1, 0) - W(SC[t1][t2], c0) * fabv(umac[t1], c0, 0))
+              - (dt2 / dx[t2]) * (W(SC[t2][t1], c2) * fabv(umac[t2], c2, 0) - W(SC[t2][t1], c0) * fabv(umac[t2], c0, 0))
+              + (dt2 / dx[t1]) * fabv(s, c0, comp) * (fabv(umac[t1], c1, 0) - fabv(umac[t1], c0, 0))
+              + (dt2 / dx[t2]) * fabv(s, c0, comp) * (fabv(umac[t2], c2, 0) - fabv(umac[t2], c0, 0));
+          } else {
+            v = v
+              - (dt4 / dx[t1]) * (fabv(umac[t1], c1, 0) + fabv(umac[t1], c0, 0)) * (W(SC[t1][t2], c1) - W(SC[t1][t2], c0))
+              - (dt4 / dx[t2]) * (fabv(umac[t2], c2, 0) + fabv(umac[t2], c0, 0)) * (W(SC[t2][t1], c2) - W(SC[t2][t1], c0));
+          }
+          if (!use_minion) {
+            v = v + dt2 * fabv(force, c0, comp);
+            if (cons) v = v - dt2 * fabv(s, c0, comp) * fabv(mac_rhs, c0, 0);
+          }
+          LR[sd] = v;
+        }
+        double um = fabv(umac[d], f, 0);
+        double e = upwind_mac(LR[0], LR[1], um, eps);
+        int side = face_side(f[d], d, lo, hi);
+        if (side >= 0) {                                  /* mkflux.f90:2369-2402 */
+          int ph = bc->phys[d][side];
+          int g[3] = { i, j, k }; if (side == 0) g[d] -= 1;
+          double in = (side == 0) ? LR[1] : LR[0];        /* interior-side state */
+          if (ph == VDN_INLET) e = fabv(s, g, comp);
+          else if (ph == VDN_SLIP_WALL) e = (is_vel && comp == d) ? 0.0 : in;
+          else if (ph == VDN_NO_SLIP_WALL) e = is_vel ? 0.0 : in;
+          else if (ph == VDN_OUTLET) {
+            if (is_vel && comp == d) e = (side == 0) ? fmin(in, 0.0) : fmax(in, 0.0);
+            else e = in;
+          }
+        }
+        VF(sedge[d], i, j, k, comp) = e;
+        if (cons) VF(flux[d], i, j, k, comp) = e * um;    /* mkflux.f90:1969, 2405, 2508 */
+      }
+    }
+  }
+
+  for (int d = 0; d < 3; d++) {
+    free(slope[d].p); free(SL[d].p); free(SR[d].p); free(SI[d].p);
+    for (int t = 0; t < 3; t++) if (t != d) free(SC[d][t].p);
+  }
+}

@@ -1,0 +1,406 @@
+/* oracle/vo_hgproject.c -- nodal (HG) projection: reference src/hgproject.f90, src/hg_multigrid.f90,
+ * and the nodal multigrid that stands in for FBoxLib's ml_nd_solve (hg_multigrid.f90:95-105).
+ * TEST INFRASTRUCTURE ONLY (see vo.h).  parity unpinned.
+ *
+ * Discrete system.  Fixed by the reference: phi, rh nodal (hgproject.f90:74-75);
+ * sigma = 1/rhohalf on cells, ZERO in ghost cells outside the domain (hg_multigrid.f90:73-79); the RHS
+ * is the nodal divergence of the cell-centred unew whose wall ghost planes were zeroed
+ * (hgproject.f90:506-511); dense stencil (hgproject.f90:52; 27-point, 21 when dx=dy=dz,
+ * hg_hypre.f90:100-113).  Our definition: trilinear (Q1) finite elements, sigma constant per cell,
+ * equations scaled by 1/(hx hy hz):
+ *      (K phi)_n = sum_{cells c touching n} sigma_c sum_{corners m of c} w(n,m) phi_m ,
+ *      w = 4F (m=n), -4f_a+2f_b+2f_c (m differs from n along a only), -2f_a-2f_b+f_c (along a,b),
+ *          -F (all three),   f_d = 1/(36 h_d^2),  F = fx+fy+fz ,
+ * and we solve  -K phi = rh  ( = "div(sigma grad phi) = div u" ),  rh = D u :
+ *      (D u)_n = sum_d ( [sum of u_d over the 4 cells on the + side] - [... - side] ) * 0.25/h_d .
+ * Outflow (BC_DIR) boundary nodes carry phi = 0; wall nodes are natural (sigma = 0, u = 0 outside).
+ *
+ * ALGORITHM (ours): V(nu1,nu2) cycles with damped-Jacobi smoothing (one pass per sweep: the GPU-
+ * friendly choice), full-weighting restriction (= P^T/8), trilinear prolongation,
+ * coarse sigma = mean of the 8 children, coarsening while every extent is even and > 2, `nub`
+ * Jacobi sweeps on the coarsest level.  Convergence: ||rh + K phi||_inf <= rel*||rh||_inf or <= abs,
+ * tested on the residual computed after pre-smoothing, at most max_iter cycles.
+ */
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+#include <stdio.h>
+#include "vo.h"
+
+/* hgproject.f90:434-513 */
+void vo_create_uvec(vo_fab *unew, const vo_fab *uold, const vo_fab *rhohalf, vo_fab *gp, double dt,
+                    const vo_bc *bc, int proj_type)
+{
+  const int *lo = unew->lo, *hi = unew->hi;
+  double dtinv = 1.0 / dt;
+  /* gp ghost layer zeroed at INLET faces (453-458) */
+  for (int d = 0; d < 3; d++) for (int s = 0; s < 2; s++) if (bc->phys[d][s] == VDN_INLET) {
+    int rlo[3] = { lo[0] - 1, lo[1] - 1, lo[2] - 1 }, rhi[3] = { hi[0] + 1, hi[1] + 1, hi[2] + 1 };
+    rlo[d] = rhi[d] = s ? hi[d] + 1 : lo[d] - 1;
+    for (int m = 0; m < 3; m++) for (int k = rlo[2]; k <= rhi[2]; k++) for (int j = rlo[1]; j <= rhi[1]; j++) for (int i = rlo[0]; i <= rhi[0]; i++)
+      VF(gp, i, j, k, m) = 0.0;
+  }
+  if (proj_type == VDN_PRESSURE_ITERS) {
+    for (int m = 0; m < 3; m++) for (int k = lo[2] - 1; k <= hi[2] + 1; k++) for (int j = lo[1] - 1; j <= hi[1] + 1; j++) for (int i = lo[0] - 1; i <= hi[0] + 1; i++)
+      VF(unew, i, j, k, m) = (VF(unew, i, j, k, m) - VF(uold, i, j, k, m)) * dtinv;
+  } else if (proj_type == VDN_REGULAR_TIMESTEP) {
+    for (int m = 0; m < 3; m++) for (int k = lo[2] - 1; k <= hi[2] + 1; k++) for (int j = lo[1] - 1; j <= hi[1] + 1; j++) for (int i = lo[0] - 1; i <= hi[0] + 1; i++)
+      VF(unew, i, j, k, m) = VF(unew, i, j, k, m) + dt * VF(gp, i, j, k, m) / VF(rhohalf, i, j, k, 0);
+  }
+  /* zero the ENTIRE first ghost plane of unew at walls (506-511: unew(lo(1)-1,:,:,:) = ZERO) */
+  int ng = unew->ng;
+  for (int d = 0; d < 3; d++) for (int s = 0; s < 2; s++)
+    if (bc->phys[d][s] == VDN_SLIP_WALL || bc->phys[d][s] == VDN_NO_SLIP_WALL) {
+      int rlo[3] = { lo[0] - ng, lo[1] - ng, lo[2] - ng }, rhi[3] = { hi[0] + ng, hi[1] + ng, hi[2] + ng };
+      rlo[d] = rhi[d] = s ? hi[d] + 1 : lo[d] - 1;
+      for (int m = 0; m < 3; m++) for (int k = rlo[2]; k <= rhi[2]; k++) for (int j = rlo[1]; j <= rhi[1]; j++) for (int i = rlo[0]; i <= rhi[0]; i++)
+        VF(unew, i, j, k, m) = 0.0;
+    }
+}
+
+/* hgproject.f90:543-577 */
+void vo_mkgphi(vo_fab *gp, const vo_fab *phi, const double dx[3])
+{
+  const int *lo = gp->lo, *hi = gp->hi;
+  double dxinv[3] = { 1.0 / dx[0], 1.0 / dx[1], 1.0 / dx[2] };
+  #pragma omp parallel for
+  for (int k = lo[2]; k <= hi[2]; k++) for (int j = lo[1]; j <= hi[1]; j++) for (int i = lo[0]; i <= hi[0]; i++) {
+    #define P(a, b, c) VF(phi, i + (a), j + (b), k + (c), 0)
+    VF(gp, i, j, k, 0) = 0.25 * (P(1, 0, 0) + P(1, 1, 0) + P(1, 0, 1) + P(1, 1, 1) - P(0, 0, 0) - P(0, 1, 0) - P(0, 0, 1) - P(0, 1, 1)) * dxinv[0];
+    VF(gp, i, j, k, 1) = 0.25 * (P(0, 1, 0) + P(1, 1, 0) + P(0, 1, 1) + P(1, 1, 1) - P(0, 0, 0) - P(1, 0, 0) - P(0, 0, 1) - P(1, 0, 1)) * dxinv[1];
+    VF(gp, i, j, k, 2) = 0.25 * (P(0, 0, 1) + P(1, 0, 1) + P(0, 1, 1) + P(1, 1, 1) - P(0, 0, 0) - P(1, 0, 0) - P(0, 1, 0) - P(1, 1, 0)) * dxinv[2];
+    #undef P
+  }
+}
+
+/* hgproject.f90:638-698 */
+void vo_hg_update(int proj_type, vo_fab *unew, const vo_fab *uold, vo_fab *gp, const vo_fab *gphi,
+                  const vo_fab *rhohalf, vo_fab *p, const vo_fab *phi, double dt)
+{
+  const int *lo = unew->lo, *hi = unew->hi;
+  double dtinv = 1.0 / dt;
+  for (int m = 0; m < 3; m++) for (int k = lo[2]; k <= hi[2]; k++) for (int j = lo[1]; j <= hi[1]; j++) for (int i = lo[0]; i <= hi[0]; i++) {
+    double v = VF(unew, i, j, k, m) - VF(gphi, i, j, k, m) / VF(rhohalf, i, j, k, 0);
+    if (proj_type == VDN_PRESSURE_ITERS) v = VF(uold, i, j, k, m) + dt * v;
+    VF(unew, i, j, k, m) = v;
+  }
+  if (proj_type == VDN_INITIAL_PROJECTION || proj_type == VDN_DIVU_ITERS) {
+    memset(gp->p, 0, sizeof(double) * vo_size(gp));
+    memset(p->p, 0, sizeof(double) * vo_size(p));
+  } else if (proj_type == VDN_PRESSURE_ITERS) {
+    for (int m = 0; m < 3; m++) for (int k = lo[2]; k <= hi[2]; k++) for (int j = lo[1]; j <= hi[1]; j++) for (int i = lo[0]; i <= hi[0]; i++)
+      VF(gp, i, j, k, m) = VF(gp, i, j, k, m) + VF(gphi, i, j, k, m);
+    for (int k = lo[2]; k <= hi[2] + 1; k++) for (int j = lo[1]; j <= hi[1] + 1; j++) for (int i = lo[0]; i <= hi[0] + 1; i++)
+      VF(p, i, j, k, 0) = VF(p, i, j, k, 0) + VF(phi, i, j, k, 0);
+  } else if (proj_type == VDN_REGULAR_TIMESTEP) {
+    for (int m = 0; m < 3; m++) for (int k = lo[2]; k <= hi[2]; k++) for (int j = lo[1]; j <= hi[1]; j++) for (int i = lo[0]; i <= hi[0]; i++)
+      VF(gp, i, j, k, m) = dtinv * VF(gphi, i, j, k, m);
+    for (int k = lo[2]; k <= hi[2] + 1; k++) for (int j = lo[1]; j <= hi[1] + 1; j++) for (int i = lo[0]; i <= hi[0] + 1; i++)
+      VF(p, i, j, k, 0) = dtinv * VF(phi, i, j, k, 0);
+  }
+}
+
+/* ---------------------------------------------------------------------------------------------
+ * nodal multigrid
+ * ------------------------------------------------------------------------------------------- */
+typedef struct ndlev {
+  int n[3];              /* cells; nodes are 0..n[d] */
+  double h[3], f[3];     /* f_d = 1/(36 h_d^2) */
+  double *phi, *tmp;     /* nodes with one ghost layer: (n+3)^3 */
+  double *b;             /* right-hand side of  K phi = b  (b = -rh)                      */
+  double *res;           /* residual b - K phi, with ghost layer                           */
+  double *sig;           /* cells with one ghost layer: (n+2)^3                            */
+  unsigned char *dir;    /* Dirichlet mask on nodes (no ghost)                             */
+} ndlev;
+
+#define NN(L, i, j, k) (((i) + 1) + (long)((L)->n[0] + 3) * (((j) + 1) + (long)((L)->n[1] + 3) * ((k) + 1)))
+#define NS(L, i, j, k) (((i) + 1) + (long)((L)->n[0] + 2) * (((j) + 1) + (long)((L)->n[1] + 2) * ((k) + 1)))
+#define NM(L, i, j, k) ((i) + (long)((L)->n[0] + 1) * ((j) + (long)((L)->n[1] + 1) * (k)))
+
+static void nd_alloc(ndlev *L, const int n[3], const double h[3])
+{
+  for (int d = 0; d < 3; d++) { L->n[d] = n[d]; L->h[d] = h[d]; L->f[d] = 1.0 / (36.0 * (h[d] * h[d])); }
+  long nn = (long)(n[0] + 3) * (n[1] + 3) * (n[2] + 3), ns = (long)(n[0] + 2) * (n[1] + 2) * (n[2] + 2);
+  L->phi = (double *)calloc(nn, sizeof(double)); L->tmp = (double *)calloc(nn, sizeof(double));
+  L->b = (double *)calloc(nn, sizeof(double));   L->res = (double *)calloc(nn, sizeof(double));
+  L->sig = (double *)calloc(ns, sizeof(double));
+  L->dir = (unsigned char *)calloc((long)(n[0] + 1) * (n[1] + 1) * (n[2] + 1), 1);
+}
+static void nd_free(ndlev *L) { free(L->phi); free(L->tmp); free(L->b); free(L->res); free(L->sig); free(L->dir); }
+
+/* ghost nodes: periodic image, else zero.  Also makes node n[d] the alias of node 0. */
+static void nd_fill_nodes(const ndlev *L, double *a, const int per[3])
+{
+  const int *n = L->n;
+  for (int k = -1; k <= n[2] + 1; k++) for (int j = -1; j <= n[1] + 1; j++) for (int i = -1; i <= n[0] + 1; i++) {
+    int q[3] = { i, j, k }, s[3] = { i, j, k }, g = 0, zero = 0;
+    for (int d = 0; d < 3; d++) {
+      if (per[d]) { if (q[d] < 0) { s[d] = q[d] + n[d]; g = 1; } else if (q[d] >= n[d]) { s[d] = q[d] - n[d]; g = 1; } }
+      else if (q[d] < 0 || q[d] > n[d]) { g = 1; zero = 1; }
+    }
+    if (g) a[NN(L, i, j, k)] = zero ? 0.0 : a[NN(L, s[0], s[1], s[2])];
+  }
+}
+static void nd_fill_cells(const ndlev *L, double *a, const int per[3])
+{
+  const int *n = L->n;
+  for (int k = -1; k <= n[2]; k++) for (int j = -1; j <= n[1]; j++) for (int i = -1; i <= n[0]; i++) {
+    int q[3] = { i, j, k }, s[3] = { i, j, k }, g = 0, zero = 0;
+    for (int d = 0; d < 3; d++) {
+      if (q[d] < 0) { g = 1; if (per[d]) s[d] = q[d] + n[d]; else zero = 1; }
+      else if (q[d] >= n[d]) { g = 1; if (per[d]) s[d] = q[d] - n[d]; else zero = 1; }
+    }
+    if (g) a[NS(L, i, j, k)] = zero ? 0.0 : a[NS(L, s[0], s[1], s[2])];
+  }
+}
+
+/* K phi at node (i,j,k) and the diagonal; fixed expression order shared with the HIP kernel:
+ * cells in the order (ck,cj,ci) ascending; inside a cell corners (mz,my,mx) ascending. */
+static inline void nd_apply(const ndlev *L, const double *phi, int i, int j, int k, double *Kp, double *diag)
+{
+  const double fx = L->f[0], fy = L->f[1], fz = L->f[2];
+  const double F = fx + fy + fz;
+  /* weight by which coordinates differ: index bit0=x differs, bit1=y, bit2=z */
+  double w[8];
+  w[0] = 4.0 * F;
+  w[1] = -4.0 * fx + 2.0 * fy + 2.0 * fz;
+  w[2] = 2.0 * fx - 4.0 * fy + 2.0 * fz;
+  w[3] = -2.0 * fx - 2.0 * fy + fz;
+  w[4] = 2.0 * fx + 2.0 * fy - 4.0 * fz;
+  w[5] = -2.0 * fx + fy - 2.0 * fz;
+  w[6] = fx - 2.0 * fy - 2.0 * fz;
+  w[7] = -F;
+  double acc = 0.0, ssum = 0.0;
+  for (int ck = k - 1; ck <= k; ck++) for (int cj = j - 1; cj <= j; cj++) for (int ci = i - 1; ci <= i; ci++) {
+    double sg = L->sig[NS(L, ci, cj, ck)];
+    double t = 0.0;
+    for (int mz = 0; mz < 2; mz++) for (int my = 0; my < 2; my++) for (int mx = 0; mx < 2; mx++) {
+      int ni = ci + mx, nj = cj + my, nk = ck + mz;
+      int idx = (ni != i) | ((nj != j) << 1) | ((nk != k) << 2);
+      t = t + w[idx] * phi[NN(L, ni, nj, nk)];
+    }
+    acc = acc + sg * t;
+    ssum = ssum + sg;
+  }
+  *Kp = acc;
+  *diag = w[0] * ssum;
+}
+
+static void nd_jacobi(ndlev *L, const int per[3], int nsweeps, double omega)
+{
+  const int *n = L->n;
+  for (int s = 0; s < nsweeps; s++) {
+    nd_fill_nodes(L, L->phi, per);
+    #pragma omp parallel for
+    for (int k = 0; k <= n[2]; k++) for (int j = 0; j <= n[1]; j++) for (int i = 0; i <= n[0]; i++) {
+      double p0 = L->phi[NN(L, i, j, k)], v = p0;
+      if (!L->dir[NM(L, i, j, k)]) {
+        double Kp, diag; nd_apply(L, L->phi, i, j, k, &Kp, &diag);
+        if (diag != 0.0) v = p0 + omega * ((L->b[NN(L, i, j, k)] - Kp) / diag);
+      }
+      L->tmp[NN(L, i, j, k)] = v;
+    }
+    double *t = L->phi; L->phi = L->tmp; L->tmp = t;
+  }
+}
+
+static double nd_residual(ndlev *L, const int per[3])
+{
+  const int *n = L->n; double nrm = 0.0;
+  nd_fill_nodes(L, L->phi, per);
+  #pragma omp parallel for reduction(max : nrm)
+  for (int k = 0; k <= n[2]; k++) for (int j = 0; j <= n[1]; j++) for (int i = 0; i <= n[0]; i++) {
+    double r = 0.0;
+    if (!L->dir[NM(L, i, j, k)]) {
+      double Kp, diag; nd_apply(L, L->phi, i, j, k, &Kp, &diag);
+      r = L->b[NN(L, i, j, k)] - Kp;
+    }
+    L->res[NN(L, i, j, k)] = r;
+    nrm = fmax(nrm, fabs(r));
+  }
+  nd_fill_nodes(L, L->res, per);
+  return nrm;
+}
+
+static void nd_restrict(const ndlev *Fv, ndlev *C)
+{
+  const int *n = C->n;
+  const double wt[3] = { 0.5, 1.0, 0.5 };
+  #pragma omp parallel for
+  for (int k = 0; k <= n[2]; k++) for (int j = 0; j <= n[1]; j++) for (int i = 0; i <= n[0]; i++) {
+    double s = 0.0;
+    if (!C->dir[NM(C, i, j, k)])
+      for (int c = -1; c <= 1; c++) for (int b = -1; b <= 1; b++) for (int a = -1; a <= 1; a++)
+        s = s + (wt[a + 1] * wt[b + 1] * wt[c + 1]) * Fv->res[NN(Fv, 2 * i + a, 2 * j + b, 2 * k + c)];
+    C->b[NN(C, i, j, k)] = s * 0.125;
+  }
+}
+
+static void nd_prolong_add(ndlev *Fv, const ndlev *C)
+{
+  const int *n = Fv->n;
+  #pragma omp parallel for
+  for (int k = 0; k <= n[2]; k++) for (int j = 0; j <= n[1]; j++) for (int i = 0; i <= n[0]; i++) {
+    if (Fv->dir[NM(Fv, i, j, k)]) continue;
+    int I = i >> 1, J = j >> 1, K = k >> 1, oi = i & 1, oj = j & 1, ok = k & 1;
+    double s = 0.0;
+    for (int c = 0; c <= ok; c++) for (int b = 0; b <= oj; b++) for (int a = 0; a <= oi; a++)
+      s = s + C->phi[NN(C, I + a, J + b, K + c)];
+    double scale = 1.0 / (double)((1 + oi) * (1 + oj) * (1 + ok));
+    Fv->phi[NN(Fv, i, j, k)] = Fv->phi[NN(Fv, i, j, k)] + s * scale;
+  }
+}
+
+static void nd_coarsen_sigma(const ndlev *Fv, ndlev *C, const int per[3])
+{
+  const int *n = C->n;
+  for (int k = 0; k < n[2]; k++) for (int j = 0; j < n[1]; j++) for (int i = 0; i < n[0]; i++) {
+    double s = 0.0;
+    for (int c = 0; c < 2; c++) for (int b = 0; b < 2; b++) for (int a = 0; a < 2; a++)
+      s = s + Fv->sig[NS(Fv, 2 * i + a, 2 * j + b, 2 * k + c)];
+    C->sig[NS(C, i, j, k)] = s * 0.125;
+  }
+  nd_fill_cells(C, C->sig, per);
+}
+
+static void nd_set_mask(ndlev *L, const int ellbc[3][2])
+{
+  const int *n = L->n;
+  for (int k = 0; k <= n[2]; k++) for (int j = 0; j <= n[1]; j++) for (int i = 0; i <= n[0]; i++) {
+    int q[3] = { i, j, k }, dflag = 0;
+    for (int d = 0; d < 3; d++) {
+      if (q[d] == 0 && ellbc[d][0] == VDN_BC_DIR) dflag = 1;
+      if (q[d] == n[d] && ellbc[d][1] == VDN_BC_DIR) dflag = 1;
+    }
+    L->dir[NM(L, i, j, k)] = (unsigned char)dflag;
+  }
+}
+
+typedef struct ndmg { int nlev; ndlev lev[32]; int per[3]; } ndmg;
+
+static void nd_vcycle(ndmg *M, int l, int nu1, int nu2, int nub, double omega)
+{
+  ndlev *L = &M->lev[l];
+  long nn = (long)(L->n[0] + 3) * (L->n[1] + 3) * (L->n[2] + 3);
+  memset(L->phi, 0, sizeof(double) * nn);
+  if (l == M->nlev - 1) { nd_jacobi(L, M->per, nub, omega); return; }
+  nd_jacobi(L, M->per, nu1, omega);
+  (void)nd_residual(L, M->per);
+  nd_restrict(L, &M->lev[l + 1]);
+  nd_vcycle(M, l + 1, nu1, nu2, nub, omega);
+  nd_fill_nodes(&M->lev[l + 1], M->lev[l + 1].phi, M->per);
+  nd_prolong_add(L, &M->lev[l + 1]);
+  nd_jacobi(L, M->per, nu2, omega);
+}
+
+/* nodal divergence, our definition (see header comment); u must have >= 1 ghost cell */
+void vo_nd_divu(const vo_fab *u, vo_fab *rh, const double dx[3], const int ellbc[3][2])
+{
+  const int *lo = u->lo, *hi = u->hi;
+  double fx = 0.25 / dx[0], fy = 0.25 / dx[1], fz = 0.25 / dx[2];
+  (void)ellbc;
+  #pragma omp parallel for
+  for (int k = lo[2]; k <= hi[2] + 1; k++) for (int j = lo[1]; j <= hi[1] + 1; j++) for (int i = lo[0]; i <= hi[0] + 1; i++) {
+    #define U(a, b, c, m) VF(u, i + (a), j + (b), k + (c), m)
+    double dux = (((U(0, 0, 0, 0) + U(0, -1, 0, 0)) + U(0, 0, -1, 0)) + U(0, -1, -1, 0))
+               - (((U(-1, 0, 0, 0) + U(-1, -1, 0, 0)) + U(-1, 0, -1, 0)) + U(-1, -1, -1, 0));
+    double duy = (((U(0, 0, 0, 1) + U(-1, 0, 0, 1)) + U(0, 0, -1, 1)) + U(-1, 0, -1, 1))
+               - (((U(0, -1, 0, 1) + U(-1, -1, 0, 1)) + U(0, -1, -1, 1)) + U(-1, -1, -1, 1));
+    double duz = (((U(0, 0, 0, 2) + U(-1, 0, 0, 2)) + U(0, -1, 0, 2)) + U(-1, -1, 0, 2))
+               - (((U(0, 0, -1, 2) + U(-1, 0, -1, 2)) + U(0, -1, -1, 2)) + U(-1, -1, -1, 2));
+    #undef U
+    VF(rh, i, j, k, 0) = VF(rh, i, j, k, 0) + (dux * fx + duy * fy + duz * fz);
+  }
+}
+
+int vo_nd_solve(vo_fab *rh, vo_fab *phi, const vo_fab *coeffs, const vo_fab *u, const double dx[3],
+                const int ellbc[3][2], const int pmask[3], double rel_eps, double abs_eps, int max_iter,
+                int nu1, int nu2, int nub, double omega, vo_mgstat *st)
+{
+  ndmg M; M.nlev = 0;
+  int n[3]; double h[3];
+  for (int d = 0; d < 3; d++) { n[d] = coeffs->hi[d] - coeffs->lo[d] + 1; h[d] = dx[d]; M.per[d] = pmask[d]; }
+  for (;;) {
+    ndlev *L = &M.lev[M.nlev];
+    nd_alloc(L, n, h);
+    nd_set_mask(L, ellbc);
+    if (M.nlev == 0) {
+      for (int k = -1; k <= n[2]; k++) for (int j = -1; j <= n[1]; j++) for (int i = -1; i <= n[0]; i++)
+        L->sig[NS(L, i, j, k)] = VF(coeffs, coeffs->lo[0] + i, coeffs->lo[1] + j, coeffs->lo[2] + k, 0);
+    } else nd_coarsen_sigma(&M.lev[M.nlev - 1], L, M.per);
+    M.nlev++;
+    int can = 1;
+    for (int d = 0; d < 3; d++) if ((n[d] & 1) || n[d] <= 2) can = 0;
+    if (!can || M.nlev >= 31) break;
+    for (int d = 0; d < 3; d++) { n[d] /= 2; h[d] *= 2.0; }
+  }
+  ndlev *L0 = &M.lev[0];
+  const int *n0 = L0->n;
+  if (u) vo_nd_divu(u, rh, dx, ellbc);                 /* add_divu = .true. (hg_multigrid.f90:96) */
+  double bnorm = 0.0;
+  for (int k = 0; k <= n0[2]; k++) for (int j = 0; j <= n0[1]; j++) for (int i = 0; i <= n0[0]; i++) {
+    double r = VF(rh, rh->lo[0] + i, rh->lo[1] + j, rh->lo[2] + k, 0);
+    if (L0->dir[NM(L0, i, j, k)]) r = 0.0;
+    L0->b[NN(L0, i, j, k)] = -r;
+    L0->phi[NN(L0, i, j, k)] = L0->dir[NM(L0, i, j, k)] ? 0.0 : VF(phi, phi->lo[0] + i, phi->lo[1] + j, phi->lo[2] + k, 0);
+    bnorm = fmax(bnorm, fabs(r));
+  }
+  int cyc = 0, conv = 0; double rn = 0.0;
+  if (bnorm == 0.0) conv = 1;
+  while (!conv) {
+    nd_jacobi(L0, M.per, M.nlev == 1 ? nub : nu1, omega);
+    rn = nd_residual(L0, M.per);
+    if (rn <= rel_eps * bnorm || rn <= abs_eps) { conv = 1; break; }
+    if (cyc >= max_iter) break;
+    if (M.nlev > 1) {
+      nd_restrict(L0, &M.lev[1]);
+      nd_vcycle(&M, 1, nu1, nu2, nub, omega);
+      nd_fill_nodes(&M.lev[1], M.lev[1].phi, M.per);
+      nd_prolong_add(L0, &M.lev[1]);
+      nd_jacobi(L0, M.per, nu2, omega);
+    }
+    cyc++;
+  }
+  nd_fill_nodes(L0, L0->phi, M.per);
+  for (int k = -1; k <= n0[2] + 1; k++) for (int j = -1; j <= n0[1] + 1; j++) for (int i = -1; i <= n0[0] + 1; i++)
+    VF(phi, phi->lo[0] + i, phi->lo[1] + j, phi->lo[2] + k, 0) = L0->phi[NN(L0, i, j, k)];
+  if (st) { st->cycles = cyc; st->res0 = bnorm; st->res = rn; }
+  for (int l = 0; l < M.nlev; l++) nd_free(&M.lev[l]);
+  return conv ? 0 : 1;
+}
+
+/* hgproject.f90:17-178 with hg_multigrid.f90:18-119, one level / one box */
+void vo_hgproject(int proj_type, vo_fab *unew, const vo_fab *uold, vo_fab *rhohalf, vo_fab *p, vo_fab *gp,
+                  const double dx[3], double dt, const vo_bc *bc, const int pmask[3], const vdn_params *prm,
+                  vo_mgstat *st)
+{
+  const int *lo = unew->lo, *hi = unew->hi;
+  int nd0[3] = { 0, 0, 0 }, nd1[3] = { 1, 1, 1 };
+  vo_fab rh, phi, gphi, coeffs;
+  vo_fab_init(&rh, NULL, lo, hi, 1, nd1, 1);   rh.p = (double *)calloc(vo_size(&rh), sizeof(double));
+  vo_fab_init(&phi, NULL, lo, hi, 1, nd1, 1);  phi.p = (double *)calloc(vo_size(&phi), sizeof(double));
+  vo_fab_init(&gphi, NULL, lo, hi, 0, nd0, 3); gphi.p = (double *)calloc(vo_size(&gphi), sizeof(double));
+  vo_fab_init(&coeffs, NULL, lo, hi, 1, nd0, 1); coeffs.p = (double *)calloc(vo_size(&coeffs), sizeof(double));
+  int ellbc[3][2];
+  for (int d = 0; d < 3; d++) for (int s = 0; s < 2; s++) ellbc[d][s] = bc->ell[d][s][bc->press_comp];
+
+  vo_create_uvec(unew, uold, rhohalf, gp, dt, bc, proj_type);
+  vo_fill_boundary(unew, pmask);                                        /* hgproject.f90:232 */
+
+  double rel = prm->hg_rel_eps > 0.0 ? prm->hg_rel_eps : 1.e-12;       /* nlevs == 1: hgproject.f90:113-114 */
+  double abs_eps = -1.0;
+  if (proj_type == VDN_INITIAL_PROJECTION && prm->prob_type == 4) abs_eps = 1.e-12;   /* 125-127 */
+
+  /* coeffs = 1/rhohalf on valid cells, ghosts 0, then fill_boundary (hg_multigrid.f90:68-79) */
+  for (int k = lo[2]; k <= hi[2]; k++) for (int j = lo[1]; j <= hi[1]; j++) for (int i = lo[0]; i <= hi[0]; i++)
+    VF(&coeffs, i, j, k, 0) = 1.0 / VF(rhohalf, i, j, k, 0);
+  vo_fill_boundary(&coeffs, pmask);
+
+  vo_nd_solve(&rh, &phi, &coeffs, unew, dx, ellbc, pmask, rel, abs_eps, prm->hg_max_iter,
+              prm->hg_nu1, prm->hg_nu2, prm->hg_nub, prm->hg_omega, st);
+
+  vo_mkgphi(&gphi, &phi, dx);
+  vo_hg_update(proj_type, unew, uold, gp, &gphi, rhohalf, p, &phi, dt);
+  vo_fill_boundary(gp, pmask); vo_fill_boundary(p, pmask);              /* hgproject.f90:359-362 */
+  free(rh.p); free(phi.p); free(gphi.p); free(coeffs.p);
+}

@@ -1,0 +1,339 @@
+/* oracle/vo_macproject.c -- MAC projection (reference src/macproject.f90) and the cell-centred
+ * multigrid that stands in for FBoxLib's ml_cc_solve (called at src/mac_multigrid.f90:53-62).
+ * TEST INFRASTRUCTURE ONLY (see vo.h).  parity unpinned.
+ *
+ * The discrete system (fixed by macproject.f90:185-196, 376-394, 611-612):
+ *      -sum_d [ b_d(i+e_d) (phi(i+e_d)-phi(i)) - b_d(i) (phi(i)-phi(i-e_d)) ] / h_d^2 = rh(i)
+ * with b_d = beta on d-faces.  Domain faces:  Neumann -> face term dropped (b := 0);
+ * Dirichlet (phi = 0 on the face, linear closure phi_ghost = -phi_i) -> b := 2 b with a zero
+ * ghost;  periodic -> wrap.  So after the b-modification the ghost cells of phi are 0 (or the
+ * periodic image) and the operator has no boundary branches.
+ *
+ * The ALGORITHM is ours (F_MG is not in the reference tree): V(nu1,nu2) cycles, red-black
+ * Gauss-Seidel smoothing, 8-cell average restriction, piecewise-constant prolongation, coarse
+ * b = average of the 4 fine faces, coarsening while every extent is even and > 2, `nub` sweeps on
+ * the coarsest level; convergence is tested on the residual the cycle computes after its
+ * pre-smoothing:  ||r||_inf <= rel_eps*||rh||_inf  or  <= abs_eps.
+ * The HIP solver (varden_amd/csrc/mg_cc.hip) implements the same algorithm with the same
+ * expression order, so the two agree to round-off of the max-norm test (bit-exact in practice).
+ */
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+#include <stdio.h>
+#include "vo.h"
+
+/* macproject.f90:250-278 */
+void vo_divumac(vo_fab *umac[3], vo_fab *rh, const double dx[3])
+{
+  const int *lo = rh->lo, *hi = rh->hi;
+  double dxinv[3] = { 1.0 / dx[0], 1.0 / dx[1], 1.0 / dx[2] };
+  #pragma omp parallel for
+  for (int k = lo[2]; k <= hi[2]; k++) for (int j = lo[1]; j <= hi[1]; j++) for (int i = lo[0]; i <= hi[0]; i++)
+    VF(rh, i, j, k, 0) = (VF(umac[0], i + 1, j, k, 0) - VF(umac[0], i, j, k, 0)) * dxinv[0]
+                       + (VF(umac[1], i, j + 1, k, 0) - VF(umac[1], i, j, k, 0)) * dxinv[1]
+                       + (VF(umac[2], i, j, k + 1, 0) - VF(umac[2], i, j, k, 0)) * dxinv[2];
+}
+
+/* macproject.f90:361-401 */
+void vo_mk_mac_coeffs(const vo_fab *rho, vo_fab *beta[3])
+{
+  const int *lo = rho->lo, *hi = rho->hi;
+  for (int d = 0; d < 3; d++) {
+    int rhi[3] = { hi[0], hi[1], hi[2] }; rhi[d] += 1;
+    for (int k = lo[2]; k <= rhi[2]; k++) for (int j = lo[1]; j <= rhi[1]; j++) for (int i = lo[0]; i <= rhi[0]; i++) {
+      int m[3] = { i, j, k }; m[d] -= 1;
+      VF(beta[d], i, j, k, 0) = 2.0 / (VF(rho, i, j, k, 0) + VF(rho, m[0], m[1], m[2], 0));
+    }
+  }
+}
+
+/* macproject.f90:578-645.  Interior faces: u -= beta (phi_i - phi_{i-1})/dx (611-612).  Box faces: the
+ * reference subtracts the solver's flux register (608-609, FBoxLib bndry_reg, not in the tree); that
+ * flux is beta * dphi/dn of the solver's own boundary closure, i.e. 0 at Neumann faces,
+ * beta*(phi_i - (-phi_i))/dx at Dirichlet faces, and the ordinary difference with the periodic /
+ * neighbour ghost value otherwise.  phi's ghosts are filled accordingly before this is called. */
+void vo_mkumac(vo_fab *umac[3], const vo_fab *phi, vo_fab *beta[3], const double dx[3], const int ellbc[3][2])
+{
+  const int *lo = phi->lo, *hi = phi->hi;
+  for (int d = 0; d < 3; d++) {
+    int rhi[3] = { hi[0], hi[1], hi[2] }; rhi[d] += 1;
+    #pragma omp parallel for
+    for (int k = lo[2]; k <= rhi[2]; k++) for (int j = lo[1]; j <= rhi[1]; j++) for (int i = lo[0]; i <= rhi[0]; i++) {
+      int q[3] = { i, j, k }, m[3] = { i, j, k }; m[d] -= 1;
+      int side = (q[d] == lo[d]) ? 0 : ((q[d] == hi[d] + 1) ? 1 : -1);
+      if (side >= 0 && ellbc[d][side] == VDN_BC_NEU) continue;
+      double gphi = (VF(phi, i, j, k, 0) - VF(phi, m[0], m[1], m[2], 0)) / dx[d];
+      VF(umac[d], i, j, k, 0) = VF(umac[d], i, j, k, 0) - VF(beta[d], i, j, k, 0) * gphi;
+    }
+  }
+}
+
+/* ---------------------------------------------------------------------------------------------
+ * cell-centred multigrid
+ * ------------------------------------------------------------------------------------------- */
+typedef struct cclev {
+  int n[3];              /* cells */
+  double h[3], hi2[3];   /* spacing, 1/h^2 */
+  double *phi;           /* (n+2)^3 with one ghost layer */
+  double *rh;            /* n^3 */
+  double *res;           /* n^3 */
+  double *b[3];          /* face coefficients, (n+e_d) extents, bc-modified */
+} cclev;
+
+#define PHI(L, i, j, k) (L)->phi[((i) + 1) + ((L)->n[0] + 2) * (((j) + 1) + (long)((L)->n[1] + 2) * ((k) + 1))]
+#define CC(L, a, i, j, k) (a)[(i) + (long)(L)->n[0] * ((j) + (long)(L)->n[1] * (k))]
+#define BX(L, i, j, k) (L)->b[0][(i) + (long)((L)->n[0] + 1) * ((j) + (long)(L)->n[1] * (k))]
+#define BY(L, i, j, k) (L)->b[1][(i) + (long)(L)->n[0] * ((j) + (long)((L)->n[1] + 1) * (k))]
+#define BZ(L, i, j, k) (L)->b[2][(i) + (long)(L)->n[0] * ((j) + (long)(L)->n[1] * (k))]
+
+static void cc_alloc(cclev *L, const int n[3], const double h[3])
+{
+  for (int d = 0; d < 3; d++) { L->n[d] = n[d]; L->h[d] = h[d]; L->hi2[d] = 1.0 / (h[d] * h[d]); }
+  long nc = (long)n[0] * n[1] * n[2], ng = (long)(n[0] + 2) * (n[1] + 2) * (n[2] + 2);
+  L->phi = (double *)calloc(ng, sizeof(double));
+  L->rh = (double *)calloc(nc, sizeof(double));
+  L->res = (double *)calloc(nc, sizeof(double));
+  for (int d = 0; d < 3; d++) {
+    long nf = 1; for (int t = 0; t < 3; t++) nf *= (n[t] + (t == d));
+    L->b[d] = (double *)calloc(nf, sizeof(double));
+  }
+}
+static void cc_free(cclev *L) { free(L->phi); free(L->rh); free(L->res); for (int d = 0; d < 3; d++) free(L->b[d]); }
+
+static void cc_fill_periodic(cclev *L, const int per[3])
+{
+  int any = per[0] || per[1] || per[2]; if (!any) return;
+  const int *n = L->n;
+  for (int k = -1; k <= n[2]; k++) for (int j = -1; j <= n[1]; j++) for (int i = -1; i <= n[0]; i++) {
+    int q[3] = { i, j, k }, s[3] = { i, j, k }, g = 0, ok = 1;
+    for (int d = 0; d < 3; d++) {
+      if (q[d] < 0) { g = 1; if (per[d]) s[d] = q[d] + n[d]; else ok = 0; }
+      else if (q[d] >= n[d]) { g = 1; if (per[d]) s[d] = q[d] - n[d]; else ok = 0; }
+    }
+    if (g && ok) PHI(L, i, j, k) = PHI(L, s[0], s[1], s[2]);
+  }
+}
+
+/* A phi at one cell and the diagonal, in the fixed expression order shared with the HIP kernel */
+static inline void cc_apply(const cclev *L, int i, int j, int k, double *Ap, double *diag)
+{
+  double p0 = PHI(L, i, j, k);
+  double bxm = BX(L, i, j, k), bxp = BX(L, i + 1, j, k);
+  double bym = BY(L, i, j, k), byp = BY(L, i, j + 1, k);
+  double bzm = BZ(L, i, j, k), bzp = BZ(L, i, j, k + 1);
+  double ax = (bxp * (p0 - PHI(L, i + 1, j, k)) + bxm * (p0 - PHI(L, i - 1, j, k))) * L->hi2[0];
+  double ay = (byp * (p0 - PHI(L, i, j + 1, k)) + bym * (p0 - PHI(L, i, j - 1, k))) * L->hi2[1];
+  double az = (bzp * (p0 - PHI(L, i, j, k + 1)) + bzm * (p0 - PHI(L, i, j, k - 1))) * L->hi2[2];
+  *Ap = ax + ay + az;
+  *diag = (bxp + bxm) * L->hi2[0] + (byp + bym) * L->hi2[1] + (bzp + bzm) * L->hi2[2];
+}
+
+static void cc_gsrb(cclev *L, const int per[3], int nsweeps)
+{
+  const int *n = L->n;
+  for (int s = 0; s < nsweeps; s++) for (int color = 0; color < 2; color++) {
+    cc_fill_periodic(L, per);
+    #pragma omp parallel for
+    for (int k = 0; k < n[2]; k++) for (int j = 0; j < n[1]; j++)
+      for (int i = (j + k + color) & 1; i < n[0]; i += 2) {
+        double Ap, diag; cc_apply(L, i, j, k, &Ap, &diag);
+        if (diag != 0.0) PHI(L, i, j, k) = PHI(L, i, j, k) + (CC(L, L->rh, i, j, k) - Ap) / diag;
+      }
+  }
+}
+
+static double cc_residual(cclev *L, const int per[3])
+{
+  const int *n = L->n; double nrm = 0.0;
+  cc_fill_periodic(L, per);
+  #pragma omp parallel for reduction(max : nrm)
+  for (int k = 0; k < n[2]; k++) for (int j = 0; j < n[1]; j++) for (int i = 0; i < n[0]; i++) {
+    double Ap, diag; cc_apply(L, i, j, k, &Ap, &diag);
+    double r = CC(L, L->rh, i, j, k) - Ap;
+    CC(L, L->res, i, j, k) = r;
+    nrm = fmax(nrm, fabs(r));
+  }
+  return nrm;
+}
+
+static void cc_restrict(const cclev *F, cclev *C)
+{
+  const int *n = C->n;
+  #pragma omp parallel for
+  for (int k = 0; k < n[2]; k++) for (int j = 0; j < n[1]; j++) for (int i = 0; i < n[0]; i++) {
+    int I = 2 * i, J = 2 * j, K = 2 * k;
+    double s = CC(F, F->res, I, J, K) + CC(F, F->res, I + 1, J, K) + CC(F, F->res, I, J + 1, K) + CC(F, F->res, I + 1, J + 1, K)
+             + CC(F, F->res, I, J, K + 1) + CC(F, F->res, I + 1, J, K + 1) + CC(F, F->res, I, J + 1, K + 1) + CC(F, F->res, I + 1, J + 1, K + 1);
+    CC(C, C->rh, i, j, k) = s * 0.125;
+  }
+}
+
+static void cc_prolong_add(cclev *F, const cclev *C)
+{
+  const int *n = F->n;
+  #pragma omp parallel for
+  for (int k = 0; k < n[2]; k++) for (int j = 0; j < n[1]; j++) for (int i = 0; i < n[0]; i++)
+    PHI(F, i, j, k) = PHI(F, i, j, k) + PHI(C, i / 2, j / 2, k / 2);
+}
+
+static void cc_coarsen_coeffs(const cclev *F, cclev *C)
+{
+  const int *n = C->n;
+  for (int k = 0; k < n[2]; k++) for (int j = 0; j < n[1]; j++) for (int i = 0; i <= n[0]; i++)
+    BX(C, i, j, k) = (BX(F, 2 * i, 2 * j, 2 * k) + BX(F, 2 * i, 2 * j + 1, 2 * k) + BX(F, 2 * i, 2 * j, 2 * k + 1) + BX(F, 2 * i, 2 * j + 1, 2 * k + 1)) * 0.25;
+  for (int k = 0; k < n[2]; k++) for (int j = 0; j <= n[1]; j++) for (int i = 0; i < n[0]; i++)
+    BY(C, i, j, k) = (BY(F, 2 * i, 2 * j, 2 * k) + BY(F, 2 * i + 1, 2 * j, 2 * k) + BY(F, 2 * i, 2 * j, 2 * k + 1) + BY(F, 2 * i + 1, 2 * j, 2 * k + 1)) * 0.25;
+  for (int k = 0; k <= n[2]; k++) for (int j = 0; j < n[1]; j++) for (int i = 0; i < n[0]; i++)
+    BZ(C, i, j, k) = (BZ(F, 2 * i, 2 * j, 2 * k) + BZ(F, 2 * i + 1, 2 * j, 2 * k) + BZ(F, 2 * i, 2 * j + 1, 2 * k) + BZ(F, 2 * i + 1, 2 * j + 1, 2 * k)) * 0.25;
+}
+
+typedef struct ccmg { int nlev; cclev lev[32]; int per[3]; } ccmg;
+
+static void ccmg_build(ccmg *M, vo_fab *beta[3], const double dx[3], const int ellbc[3][2])
+{
+  const vo_fab *b0 = beta[0];
+  int n[3]; double h[3];
+  for (int d = 0; d < 3; d++) { n[d] = b0->hi[d] - b0->lo[d] + 1; h[d] = dx[d]; M->per[d] = (ellbc[d][0] == VDN_BC_PER); }
+  M->nlev = 0;
+  for (;;) {
+    cclev *L = &M->lev[M->nlev];
+    cc_alloc(L, n, h);
+    if (M->nlev == 0) {
+      /* copy beta with the boundary modification */
+      for (int d = 0; d < 3; d++) {
+        const vo_fab *bf = beta[d];
+        int e[3] = { n[0], n[1], n[2] }; e[d] += 1;
+        for (int k = 0; k < e[2]; k++) for (int j = 0; j < e[1]; j++) for (int i = 0; i < e[0]; i++) {
+          int q[3] = { i, j, k };
+          double v = VF(bf, bf->lo[0] + i, bf->lo[1] + j, bf->lo[2] + k, 0);
+          int side = (q[d] == 0) ? 0 : ((q[d] == n[d]) ? 1 : -1);
+          if (side >= 0) {
+            if (ellbc[d][side] == VDN_BC_NEU) v = 0.0;
+            else if (ellbc[d][side] == VDN_BC_DIR) v = 2.0 * v;
+          }
+          L->b[d][i + (long)e[0] * (j + (long)e[1] * k)] = v;
+        }
+      }
+    } else cc_coarsen_coeffs(&M->lev[M->nlev - 1], L);
+    M->nlev++;
+    int can = 1;
+    for (int d = 0; d < 3; d++) if ((n[d] & 1) || n[d] <= 2) can = 0;
+    if (!can || M->nlev >= 31) break;
+    for (int d = 0; d < 3; d++) { n[d] /= 2; h[d] *= 2.0; }
+  }
+}
+static void ccmg_free(ccmg *M) { for (int l = 0; l < M->nlev; l++) cc_free(&M->lev[l]); }
+
+/* coarse-grid correction below level l (error equation, zero initial guess) */
+static void cc_vcycle(ccmg *M, int l, int nu1, int nu2, int nub)
+{
+  cclev *L = &M->lev[l];
+  long ng = (long)(L->n[0] + 2) * (L->n[1] + 2) * (L->n[2] + 2);
+  memset(L->phi, 0, sizeof(double) * ng);
+  if (l == M->nlev - 1) { cc_gsrb(L, M->per, nub); return; }
+  cc_gsrb(L, M->per, nu1);
+  (void)cc_residual(L, M->per);
+  cc_restrict(L, &M->lev[l + 1]);
+  cc_vcycle(M, l + 1, nu1, nu2, nub);
+  cc_prolong_add(L, &M->lev[l + 1]);
+  cc_gsrb(L, M->per, nu2);
+}
+
+static void cc_load(cclev *L, const vo_fab *rh, const vo_fab *phi)
+{
+  const int *n = L->n;
+  for (int k = 0; k < n[2]; k++) for (int j = 0; j < n[1]; j++) for (int i = 0; i < n[0]; i++) {
+    CC(L, L->rh, i, j, k) = VF(rh, rh->lo[0] + i, rh->lo[1] + j, rh->lo[2] + k, 0);
+    PHI(L, i, j, k) = VF(phi, phi->lo[0] + i, phi->lo[1] + j, phi->lo[2] + k, 0);
+  }
+}
+/* store phi incl. the ghost layer the solver's closure implies: Neumann ghost = phi_i, Dirichlet
+ * ghost = -phi_i, periodic = image (edges/corners are not needed by mkumac and left alone) */
+static void cc_store(cclev *L, vo_fab *phi, const int ellbc[3][2], const int per[3])
+{
+  const int *n = L->n;
+  cc_fill_periodic(L, per);
+  for (int k = 0; k < n[2]; k++) for (int j = 0; j < n[1]; j++) for (int i = 0; i < n[0]; i++)
+    VF(phi, phi->lo[0] + i, phi->lo[1] + j, phi->lo[2] + k, 0) = PHI(L, i, j, k);
+  for (int d = 0; d < 3; d++) for (int s = 0; s < 2; s++) {
+    int t1 = (d + 1) % 3, t2 = (d + 2) % 3;
+    for (int b2 = 0; b2 < n[t2]; b2++) for (int b1 = 0; b1 < n[t1]; b1++) {
+      int q[3], g[3]; q[t1] = g[t1] = b1; q[t2] = g[t2] = b2;
+      q[d] = s ? n[d] - 1 : 0; g[d] = s ? n[d] : -1;
+      double v;
+      if (ellbc[d][s] == VDN_BC_NEU) v = PHI(L, q[0], q[1], q[2]);
+      else if (ellbc[d][s] == VDN_BC_DIR) v = -PHI(L, q[0], q[1], q[2]);
+      else v = PHI(L, g[0], g[1], g[2]);
+      VF(phi, phi->lo[0] + g[0], phi->lo[1] + g[1], phi->lo[2] + g[2], 0) = v;
+    }
+  }
+}
+
+int vo_cc_solve(const vo_fab *rh, vo_fab *phi, vo_fab *beta[3], const double dx[3], const int ellbc[3][2],
+                double rel_eps, double abs_eps, int max_iter, int nu1, int nu2, int nub, vo_mgstat *st)
+{
+  ccmg M; ccmg_build(&M, beta, dx, ellbc);
+  cclev *L0 = &M.lev[0];
+  cc_load(L0, rh, phi);
+  double bnorm = 0.0;
+  for (long i = 0; i < (long)L0->n[0] * L0->n[1] * L0->n[2]; i++) bnorm = fmax(bnorm, fabs(L0->rh[i]));
+  int cyc = 0, conv = 0; double rn = 0.0, r0 = -1.0;
+  if (bnorm == 0.0) { conv = 1; r0 = 0.0; }
+  while (!conv && cyc <= max_iter) {
+    if (M.nlev == 1) cc_gsrb(L0, M.per, nub); else cc_gsrb(L0, M.per, nu1);
+    rn = cc_residual(L0, M.per);
+    if (r0 < 0.0) r0 = rn;
+    if (rn <= rel_eps * bnorm || rn <= abs_eps) { conv = 1; break; }
+    if (cyc == max_iter) break;
+    if (M.nlev > 1) {
+      cc_restrict(L0, &M.lev[1]);
+      cc_vcycle(&M, 1, nu1, nu2, nub);
+      cc_prolong_add(L0, &M.lev[1]);
+      cc_gsrb(L0, M.per, nu2);
+    }
+    cyc++;
+  }
+  cc_store(L0, phi, ellbc, M.per);
+  if (st) { st->cycles = cyc; st->res0 = bnorm; st->res = rn; }
+  ccmg_free(&M);
+  return conv ? 0 : 1;
+}
+
+void vo_cc_smooth(const vo_fab *rh, vo_fab *phi, vo_fab *beta[3], const double dx[3], const int ellbc[3][2], int nsweeps)
+{
+  ccmg M; ccmg_build(&M, beta, dx, ellbc);
+  cc_load(&M.lev[0], rh, phi);
+  cc_gsrb(&M.lev[0], M.per, nsweeps);
+  cc_store(&M.lev[0], phi, ellbc, M.per);
+  ccmg_free(&M);
+}
+
+/* macproject.f90:20-133 for one level / one box */
+void vo_macproject(vo_fab *umac[3], vo_fab *rho, const vo_fab *mac_rhs, const double dx[3], const vo_bc *bc,
+                   const int pmask[3], const vdn_params *prm, vo_mgstat *st)
+{
+  const int *lo = rho->lo, *hi = rho->hi;
+  int nd0[3] = { 0, 0, 0 };
+  vo_fab rh, phi, beta[3], *bp[3];
+  vo_fab_init(&rh, NULL, lo, hi, 0, nd0, 1);  rh.p = (double *)calloc(vo_size(&rh), sizeof(double));
+  vo_fab_init(&phi, NULL, lo, hi, 1, nd0, 1); phi.p = (double *)calloc(vo_size(&phi), sizeof(double));
+  for (int d = 0; d < 3; d++) {
+    int nd[3] = { 0, 0, 0 }; nd[d] = 1;
+    vo_fab_init(&beta[d], NULL, lo, hi, 0, nd, 1); beta[d].p = (double *)calloc(vo_size(&beta[d]), sizeof(double));
+    bp[d] = &beta[d];
+  }
+  int ellbc[3][2];
+  for (int d = 0; d < 3; d++) for (int s = 0; s < 2; s++) ellbc[d][s] = bc->ell[d][s][bc->press_comp];
+
+  /* divumac(before): rh = mac_rhs - div(umac)   (macproject.f90:190-196) */
+  vo_divumac(umac, &rh, dx);
+  for (int k = lo[2]; k <= hi[2]; k++) for (int j = lo[1]; j <= hi[1]; j++) for (int i = lo[0]; i <= hi[0]; i++)
+    VF(&rh, i, j, k, 0) = VF(&rh, i, j, k, 0) * -1.0 + VF(mac_rhs, i, j, k, 0);
+  vo_mk_mac_coeffs(rho, bp);
+  /* rel = 1e-10, abs = -1 (macproject.f90:91-93) */
+  vo_cc_solve(&rh, &phi, bp, dx, ellbc, prm->mac_rel_eps, -1.0, prm->mg_max_iter, prm->mg_nu1, prm->mg_nu2, prm->mg_nub, st);
+  vo_mkumac(umac, &phi, bp, dx, ellbc);
+  for (int d = 0; d < 3; d++) vo_fill_boundary(umac[d], pmask);     /* macproject.f90:115-119 */
+  free(rh.p); free(phi.p); for (int d = 0; d < 3; d++) free(beta[d].p);
+}

@@ -1,0 +1,210 @@
+"""ctypes loader + numpy helpers for the CPU oracle (oracle/libvoracle.so).
+
+TEST INFRASTRUCTURE ONLY: imported by tests/, __graft_entry__.smoke() and bench.py's cpu_baseline
+leg.  Nothing under varden_amd/ imports this module.  parity unpinned (see oracle/vo.h).
+"""
+import ctypes as C
+import os
+import subprocess
+import sys
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.dirname(_HERE))
+from varden_amd.capi import Params, default_params  # noqa: E402  (public POD only)
+
+LIB = os.path.join(_HERE, "libvoracle.so")
+VO_MAXCOMP = 16
+
+PERIODIC, INTERIOR, INLET, OUTLET, SYMMETRY, SLIP_WALL, NO_SLIP_WALL = -1, 0, 11, 12, 13, 14, 15
+REFLECT_ODD, REFLECT_EVEN, FOEXTRAP, EXT_DIR, HOEXTRAP = 20, 21, 22, 23, 24
+BC_PER, BC_INT, BC_DIR, BC_NEU = -1, 0, 1, 2
+INITIAL_PROJECTION, DIVU_ITERS, PRESSURE_ITERS, REGULAR_TIMESTEP = 1, 2, 3, 4
+
+
+class CFab(C.Structure):
+    _fields_ = [("p", C.c_void_p), ("lo", C.c_int * 3), ("hi", C.c_int * 3), ("ng", C.c_int),
+                ("nd", C.c_int * 3), ("nc", C.c_int), ("n", C.c_long * 3), ("sc", C.c_long)]
+
+
+class CBc(C.Structure):
+    _fields_ = [("phys", (C.c_int * 2) * 3), ("adv", ((C.c_int * VO_MAXCOMP) * 2) * 3),
+                ("ell", ((C.c_int * VO_MAXCOMP) * 2) * 3), ("ncomp_adv", C.c_int), ("ncomp_ell", C.c_int),
+                ("press_comp", C.c_int), ("extrap_comp", C.c_int)]
+
+
+class CMgStat(C.Structure):
+    _fields_ = [("cycles", C.c_int), ("res0", C.c_double), ("res", C.c_double)]
+
+
+class CState(C.Structure):
+    _fields_ = [(k, CFab) for k in ("uold", "sold", "unew", "snew", "gp", "p", "ext_vel_force", "ext_scal_force")]
+
+
+def build():
+    subprocess.check_call(["make", "-s", "-C", _HERE])
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB):
+            build()
+        _lib = C.CDLL(LIB)
+        _lib.vo_estdt.restype = C.c_double
+        _lib.vo_cc_solve.restype = C.c_int
+        _lib.vo_nd_solve.restype = C.c_int
+    return _lib
+
+
+class Fab:
+    """one BoxLib-layout fab backed by a numpy array ``a[i, j, k, c]`` (Fortran order).
+    index 0 of each axis is lo-ng."""
+
+    def __init__(self, lo, hi, ng=0, nc=1, nodal=(0, 0, 0), val=0.0):
+        self.lo = tuple(int(x) for x in lo)
+        self.hi = tuple(int(x) for x in hi)
+        self.ng, self.nc, self.nodal = int(ng), int(nc), tuple(int(x) for x in nodal)
+        shp = tuple(self.hi[d] - self.lo[d] + 1 + self.nodal[d] + 2 * self.ng for d in range(3)) + (self.nc,)
+        self.a = np.full(shp, val, dtype=np.float64, order="F")
+        self.c = CFab()
+        self.c.p = self.a.ctypes.data
+        for d in range(3):
+            self.c.lo[d], self.c.hi[d], self.c.nd[d], self.c.n[d] = self.lo[d], self.hi[d], self.nodal[d], shp[d]
+        self.c.ng, self.c.nc = self.ng, self.nc
+        self.c.sc = shp[0] * shp[1] * shp[2]
+
+    @property
+    def ref(self):
+        return C.byref(self.c)
+
+    def valid(self, grow=0):
+        """view of the valid region (incl. nodal extra point), optionally grown"""
+        g = self.ng - grow
+        sl = tuple(slice(g, self.a.shape[d] - g) for d in range(3))
+        return self.a[sl]
+
+    def like(self, val=0.0):
+        return Fab(self.lo, self.hi, self.ng, self.nc, self.nodal, val)
+
+    def copy(self):
+        f = self.like()
+        f.a[...] = self.a
+        return f
+
+
+def fab_ptr_array(fabs):
+    arr = (C.POINTER(CFab) * len(fabs))()
+    for i, f in enumerate(fabs):
+        arr[i] = C.pointer(f.c)
+    return arr
+
+
+def make_bc(phys, dm=3, nscal=2):
+    """phys[d][side] -> CBc following define_bc_tower.f90"""
+    bc = CBc()
+    ph = ((C.c_int * 2) * 3)()
+    for d in range(3):
+        for s in range(2):
+            ph[d][s] = int(phys[d][s])
+    lib().vo_bc_build(C.byref(bc), ph, dm, nscal)
+    return bc
+
+
+def ellbc_of(bc):
+    e = ((C.c_int * 2) * 3)()
+    for d in range(3):
+        for s in range(2):
+            e[d][s] = bc.ell[d][s][bc.press_comp]
+    return e
+
+
+def dvec(x):
+    return (C.c_double * 3)(*[float(v) for v in x])
+
+
+def ivec(x):
+    return (C.c_int * len(x))(*[int(v) for v in x])
+
+
+class Sim:
+    """the reference driver's single-level flow (src/varden.f90:108-345) on ONE box, on the CPU oracle.
+    Used for the end-to-end parity tests and bench.py's cpu_baseline."""
+
+    def __init__(self, n, phys, prm=None, prob_type=1, grav=-9.8, prob_hi=(1.0, 1.0, 1.0), init_shrink=1.0,
+                 init_iter=4, do_initial_projection=1):
+        L = lib()
+        self.n = tuple(int(x) for x in (n if hasattr(n, "__len__") else (n, n, n)))
+        self.prm = prm or default_params()
+        self.prm.prob_type = prob_type
+        self.phys = [[int(phys[d][s]) for s in range(2)] for d in range(3)]
+        self.pmask = ivec([1 if self.phys[d][0] == PERIODIC else 0 for d in range(3)])
+        self.bc = make_bc(self.phys, 3, self.prm.nscal)
+        lo, hi = (0, 0, 0), tuple(x - 1 for x in self.n)
+        self.dx = dvec([prob_hi[d] / self.n[d] for d in range(3)])
+        ns = self.prm.nscal
+        self.uold, self.sold = Fab(lo, hi, 3, 3), Fab(lo, hi, 3, ns)
+        self.unew, self.snew = Fab(lo, hi, 3, 3), Fab(lo, hi, 3, ns)
+        self.gp, self.p = Fab(lo, hi, 1, 3), Fab(lo, hi, 1, 1, (1, 1, 1))
+        self.ext_vel_force, self.ext_scal_force = Fab(lo, hi, 1, 3), Fab(lo, hi, 1, ns)
+        self.ext_vel_force.a[..., 2] = grav                       # varden.f90:428-429
+        self.init_shrink, self.init_iter = init_shrink, init_iter
+        self.time, self.dt, self.istep = 0.0, 0.0, 0
+        self.mgstat = (CMgStat * 2)()
+        self.phase = (C.c_double * 4)()
+        L.vo_initdata(self.uold.ref, self.sold.ref, self.dx, prob_type)
+        if do_initial_projection:                                 # varden.f90:126-138
+            rhohalf = Fab(lo, hi, 1, 1, val=1.0)
+            st = CMgStat()
+            # fill ghosts first so that create_uvec/divu see the boundary data (initialize.f90 does this)
+            self.fill_state_ghosts()
+            L.vo_hgproject(INITIAL_PROJECTION, self.uold.ref, self.uold.ref, rhohalf.ref, self.p.ref, self.gp.ref,
+                           self.dx, C.c_double(1.0), C.byref(self.bc), self.pmask, C.byref(self.prm), C.byref(st))
+            self.initial_projection_stat = (st.cycles, st.res0, st.res)
+        self.p.a[...] = 0.0
+        self.gp.a[...] = 0.0
+        self.fill_state_ghosts()                                  # varden.f90:165-178
+        self.unew.a[...] = self.uold.a
+        self.snew.a[...] = self.sold.a
+        self.dt = self.estdt(1.0e20) * init_shrink                # varden.f90:186-194
+        for _ in range(init_iter):                                # varden.f90:460-490
+            self.advance(PRESSURE_ITERS)
+
+    def fill_state_ghosts(self):
+        L = lib()
+        L.vo_fill_boundary(self.uold.ref, self.pmask)
+        L.vo_fill_boundary(self.sold.ref, self.pmask)
+        L.vo_fill_boundary(self.gp.ref, self.pmask)
+        L.vo_physbc(self.uold.ref, 0, 0, 3, C.byref(self.bc), C.byref(self.prm))
+        L.vo_physbc(self.sold.ref, 0, 3, self.prm.nscal, C.byref(self.bc), C.byref(self.prm))
+
+    def estdt(self, dtold):
+        return lib().vo_estdt(self.uold.ref, self.sold.ref, self.gp.ref, self.ext_vel_force.ref, self.dx,
+                              C.c_double(dtold), C.byref(self.prm))
+
+    def state(self):
+        S = CState()
+        for k in ("uold", "sold", "unew", "snew", "gp", "p", "ext_vel_force", "ext_scal_force"):
+            setattr(S, k, getattr(self, k).c)
+        return S
+
+    def advance(self, proj_type=REGULAR_TIMESTEP):
+        S = self.state()
+        lib().vo_advance_timestep(C.byref(S), self.dx, C.c_double(self.dt), C.byref(self.bc), self.pmask,
+                                  C.byref(self.prm), proj_type, self.mgstat, self.phase)
+
+    def step(self):
+        """one pass of the time loop body, varden.f90:291-328"""
+        self.istep += 1
+        self.fill_state_ghosts()
+        if self.istep > 1:
+            self.dt = self.estdt(self.dt)
+        self.advance(REGULAR_TIMESTEP)
+        g = 3
+        self.uold.a[g:-g, g:-g, g:-g, :] = self.unew.a[g:-g, g:-g, g:-g, :]     # copy_c valid only
+        self.sold.a[g:-g, g:-g, g:-g, :] = self.snew.a[g:-g, g:-g, g:-g, :]
+        self.time += self.dt

@@ -1,0 +1,123 @@
+"""The reference's hot-path entry points, same names and argument order, over the C-ABI.
+
+    advance_timestep   reference src/advance_timestep.f90:26-44
+    estdt              reference src/estdt.f90:15
+    hgproject          reference src/hgproject.f90:17-18
+    macproject         reference src/macproject.f90:20
+    velpred / mkflux / update / mkvelforce / mkscalforce / make_at_halftime : the per-kernel modules
+
+Multifab arguments are lists with one :class:`MultiFab` per level, as in the Fortran (``sold(:)``).
+"""
+import ctypes as C
+
+from . import capi
+from .boxlib import handle_array
+from .capi import check
+
+
+def _dx(dx):
+    flat = [float(v) for lev in dx for v in lev] if hasattr(dx[0], "__len__") else [float(v) for v in dx]
+    return (C.c_double * len(flat))(*flat)
+
+
+def advance_timestep(istep, mla, sold, uold, snew, unew, gp, p, ext_vel_force, ext_scal_force,
+                     the_bc_tower, dt, time, dx, press_comp, proj_type):
+    lib = capi.load()
+    check(lib.vdn_advance_timestep(istep, mla.h, handle_array(sold), handle_array(uold), handle_array(snew),
+                                   handle_array(unew), handle_array(gp), handle_array(p),
+                                   handle_array(ext_vel_force), handle_array(ext_scal_force), the_bc_tower.h,
+                                   float(dt), float(time), _dx(dx), press_comp, proj_type))
+
+
+def estdt(lev, u, s, gp, ext_vel_force, dx, dtold):
+    """returns dt (the reference's intent(out) argument)"""
+    out = C.c_double()
+    check(capi.load().vdn_estdt(lev, u.h, s.h, gp.h, ext_vel_force.h, _dx(dx), float(dtold), C.byref(out)))
+    return out.value
+
+
+def hgproject(proj_type, mla, unew, uold, rhohalf, p, gp, dx, dt, the_bc_tower, press_comp):
+    check(capi.load().vdn_hgproject(proj_type, mla.h, handle_array(unew), handle_array(uold), handle_array(rhohalf),
+                                    handle_array(p), handle_array(gp), _dx(dx), float(dt), the_bc_tower.h, press_comp))
+
+
+def macproject(mla, umac, rho, mac_rhs, dx, the_bc_tower, bc_comp):
+    """umac: list per level of [umac, vmac, wmac]"""
+    flat = [m for lev in umac for m in lev]
+    check(capi.load().vdn_macproject(mla.h, handle_array(flat), handle_array(rho), handle_array(mac_rhs), _dx(dx),
+                                     the_bc_tower.h, bc_comp))
+
+
+def last_step_timing():
+    t = (C.c_double * 5)()
+    capi.load().vdn_last_step_timing(t)
+    return dict(scalar=t[0], velocity=t[1], mac=t[2], hg=t[3], total=t[4])
+
+
+def last_solver_stats(which):
+    cyc, r0, r = C.c_int(), C.c_double(), C.c_double()
+    capi.load().vdn_last_solver_stats(0 if which == "mac" else 1, C.byref(cyc), C.byref(r0), C.byref(r))
+    return cyc.value, r0.value, r.value
+
+
+# ---- per-kernel modules (single level) ------------------------------------------------------------
+def _iv(x):
+    return (C.c_int * len(x))(*[int(v) for v in x])
+
+
+def slope(s, slope_mf, dir, bccomp, bct):
+    check(capi.load().vdn_k_slope(s.h, slope_mf.h, dir, bccomp, bct.h))
+
+
+def velpred(u, umac, force, dx, dt, bct):
+    check(capi.load().vdn_k_velpred(u.h, handle_array(umac), force.h, _dx(dx), float(dt), bct.h))
+
+
+def mkflux(s, sedge, flux, umac, force, mac_rhs, dx, dt, bct, is_vel, is_conservative):
+    check(capi.load().vdn_k_mkflux(s.h, handle_array(sedge), handle_array(flux), handle_array(umac), force.h, mac_rhs.h,
+                                   _dx(dx), float(dt), bct.h, 1 if is_vel else 0, _iv(is_conservative)))
+
+
+def update(sold, umac, sedge, flux, force, snew, dx, dt, is_vel, is_cons, bct):
+    check(capi.load().vdn_k_update(sold.h, handle_array(umac), handle_array(sedge), handle_array(flux), force.h, snew.h,
+                                   _dx(dx), float(dt), 1 if is_vel else 0, _iv(is_cons), bct.h))
+
+
+def mkvelforce(vel_force, ext_vel_force, s, gp, lapu, visc_fac, bct):
+    check(capi.load().vdn_k_mkvelforce(vel_force.h, ext_vel_force.h, s.h, gp.h, lapu.h if lapu else None, float(visc_fac), bct.h))
+
+
+def mkscalforce(scal_force, ext_scal_force, laps, diff_fac, bct):
+    check(capi.load().vdn_k_mkscalforce(scal_force.h, ext_scal_force.h, laps.h if laps else None, float(diff_fac), bct.h))
+
+
+def make_at_halftime(rhohalf, sold, snew, in_comp, out_comp, bct):
+    check(capi.load().vdn_k_make_at_halftime(rhohalf.h, sold.h, snew.h, in_comp, out_comp, bct.h))
+
+
+def cc_solve(rh, phi, beta, dx, bc, rel_eps, abs_eps=-1.0, max_iter=100):
+    cyc, r0, r = C.c_int(), C.c_double(), C.c_double()
+    flat = _iv([bc[d][s] for d in range(3) for s in range(2)])
+    check(capi.load().vdn_cc_solve(rh.h, phi.h, handle_array(beta), _dx(dx), flat, rel_eps, abs_eps, max_iter,
+                                   C.byref(cyc), C.byref(r0), C.byref(r)))
+    return cyc.value, r0.value, r.value
+
+
+def cc_smooth(rh, phi, beta, dx, bc, nsweeps):
+    flat = _iv([bc[d][s] for d in range(3) for s in range(2)])
+    check(capi.load().vdn_cc_smooth(rh.h, phi.h, handle_array(beta), _dx(dx), flat, nsweeps))
+
+
+def nd_solve(rh, phi, coeffs, u, dx, bc, rel_eps, abs_eps=-1.0, max_iter=100):
+    cyc, r0, r = C.c_int(), C.c_double(), C.c_double()
+    flat = _iv([bc[d][s] for d in range(3) for s in range(2)])
+    check(capi.load().vdn_nd_solve(rh.h, phi.h, coeffs.h, u.h if u else None, _dx(dx), flat, rel_eps, abs_eps, max_iter,
+                                   C.byref(cyc), C.byref(r0), C.byref(r)))
+    return cyc.value, r0.value, r.value
+
+
+def bench_cc_smoother(rh, phi, beta, dx, bc, nlaunch):
+    ms, cells = C.c_double(), C.c_long()
+    flat = _iv([bc[d][s] for d in range(3) for s in range(2)])
+    check(capi.load().vdn_bench_cc_smoother(rh.h, phi.h, handle_array(beta), _dx(dx), flat, nlaunch, C.byref(ms), C.byref(cells)))
+    return ms.value, cells.value

@@ -1,0 +1,393 @@
+// mg_cc.hip -- MAC projection (reference src/macproject.f90:20-133) and the cell-centred multigrid
+// that replaces FBoxLib's ml_cc_solve (called from reference src/mac_multigrid.f90:53-62).
+//
+// System:  -sum_d [b_d(i+e_d)(phi(i+e_d)-phi(i)) - b_d(i)(phi(i)-phi(i-e_d))]/h_d^2 = rh
+// with Neumann domain faces folded into b (b := 0), Dirichlet faces into b := 2b with a zero ghost,
+// periodic faces through a ghost image.  Algorithm: V(nu1,nu2), red-black Gauss-Seidel, 8-cell
+// average restriction, piecewise-constant prolongation, coarse b = mean of the 4 fine faces; the
+// same algorithm and expression order as oracle/vo_macproject.c.
+//
+// HBM layout of one level (all six fields phi, rh, res, bx, by, bz share it): index (i,j,k) in
+// [-1..n] maps to  (i + 16) + PX*((j+1) + PY*(k+1)),  PX a multiple of 16 doubles, so cell i = 0 of
+// every row starts a 128-byte line and a wave's row segment is made of whole lines.
+// The smoother is the kernel the north-star roofline is quoted on: ALGORITHMIC traffic per colour
+// pass = 48 B/cell (phi r+w 16, rh 8, bx/by/bz 24), see DESIGN.md.
+#include "vdn_dev.h"
+#include <chrono>
+
+struct CLev {
+  int n[3]; int PX, PY; long sz;
+  double hi2[3];
+  double *phi, *rh, *res, *b[3];
+};
+DEVI long cidx(const CLev &L, int i, int j, int k) { return (long)(i + 16) + (long)L.PX * ((long)(j + 1) + (long)L.PY * (long)(k + 1)); }
+
+// A phi and diag in the fixed expression order shared with the oracle (cc_apply in vo_macproject.c)
+DEVI void cc_apply(const CLev &L, long c, double &Ap, double &diag) {
+  const long sy = L.PX, sz = (long)L.PX * L.PY;
+  const double p0 = L.phi[c];
+  const double bxm = L.b[0][c], bxp = L.b[0][c + 1];
+  const double bym = L.b[1][c], byp = L.b[1][c + sy];
+  const double bzm = L.b[2][c], bzp = L.b[2][c + sz];
+  const double ax = (bxp * (p0 - L.phi[c + 1]) + bxm * (p0 - L.phi[c - 1])) * L.hi2[0];
+  const double ay = (byp * (p0 - L.phi[c + sy]) + bym * (p0 - L.phi[c - sy])) * L.hi2[1];
+  const double az = (bzp * (p0 - L.phi[c + sz]) + bzm * (p0 - L.phi[c - sz])) * L.hi2[2];
+  Ap = ax + ay + az;
+  diag = (bxp + bxm) * L.hi2[0] + (byp + bym) * L.hi2[1] + (bzp + bzm) * L.hi2[2];
+}
+
+// one colour pass of red-black Gauss-Seidel: thread t of a row updates cell i = 2t + ((j+k+color)&1)
+__global__ void __launch_bounds__(256) kk_cc_gsrb(CLev L, int color) {
+  const int j = blockIdx.y * blockDim.y + threadIdx.y;
+  const int k = blockIdx.z;
+  const int i = 2 * (int)(blockIdx.x * blockDim.x + threadIdx.x) + ((j + k + color) & 1);
+  if (i >= L.n[0] || j >= L.n[1]) return;
+  const long c = cidx(L, i, j, k);
+  double Ap, diag; cc_apply(L, c, Ap, diag);
+  if (diag != 0.0) L.phi[c] = L.phi[c] + (L.rh[c] - Ap) / diag;
+}
+
+__global__ void __launch_bounds__(256) kk_cc_residual(CLev L, double *nrm) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  const int j = blockIdx.y * blockDim.y + threadIdx.y;
+  const int k = blockIdx.z;
+  double r = 0.0;
+  if (i < L.n[0] && j < L.n[1]) {
+    const long c = cidx(L, i, j, k);
+    double Ap, diag; cc_apply(L, c, Ap, diag);
+    r = L.rh[c] - Ap;
+    L.res[c] = r;
+  }
+  if (nrm) block_atomic_max(nrm, fabs(r));
+}
+
+__global__ void kk_cc_restrict(CLev F, CLev C) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  const int j = blockIdx.y * blockDim.y + threadIdx.y;
+  const int k = blockIdx.z;
+  if (i >= C.n[0] || j >= C.n[1]) return;
+  const long sy = F.PX, sz = (long)F.PX * F.PY;
+  const long f = cidx(F, 2 * i, 2 * j, 2 * k);
+  const double *r = F.res;
+  double s = r[f] + r[f + 1] + r[f + sy] + r[f + sy + 1] + r[f + sz] + r[f + sz + 1] + r[f + sz + sy] + r[f + sz + sy + 1];
+  C.rh[cidx(C, i, j, k)] = s * 0.125;
+}
+
+__global__ void kk_cc_prolong(CLev F, CLev C) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  const int j = blockIdx.y * blockDim.y + threadIdx.y;
+  const int k = blockIdx.z;
+  if (i >= F.n[0] || j >= F.n[1]) return;
+  const long f = cidx(F, i, j, k);
+  F.phi[f] = F.phi[f] + C.phi[cidx(C, i >> 1, j >> 1, k >> 1)];
+}
+
+__global__ void kk_cc_coarsen_b(CLev F, CLev C) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  const int j = blockIdx.y * blockDim.y + threadIdx.y;
+  const int k = blockIdx.z;
+  if (i > C.n[0] || j > C.n[1] || k > C.n[2]) return;
+  const long sy = F.PX, sz = (long)F.PX * F.PY;
+  const long f = cidx(F, 2 * i, 2 * j, 2 * k), c = cidx(C, i, j, k);
+  if (j < C.n[1] && k < C.n[2]) C.b[0][c] = (F.b[0][f] + F.b[0][f + sy] + F.b[0][f + sz] + F.b[0][f + sz + sy]) * 0.25;
+  if (i < C.n[0] && k < C.n[2]) C.b[1][c] = (F.b[1][f] + F.b[1][f + 1] + F.b[1][f + sz] + F.b[1][f + sz + 1]) * 0.25;
+  if (i < C.n[0] && j < C.n[1]) C.b[2][c] = (F.b[2][f] + F.b[2][f + 1] + F.b[2][f + sy] + F.b[2][f + sy + 1]) * 0.25;
+}
+
+// periodic images of the face ghosts of phi (edges/corners are not read by the 7-point operator)
+__global__ void kk_cc_periodic(CLev L, int per0, int per1, int per2) {
+  const int a = blockIdx.x * blockDim.x + threadIdx.x;
+  const int b = blockIdx.y * blockDim.y + threadIdx.y;
+  const int face = blockIdx.z;                       // 0..5
+  const int d = face >> 1, s = face & 1;
+  const int per = d == 0 ? per0 : (d == 1 ? per1 : per2);
+  if (!per) return;
+  const int t1 = (d == 0) ? 1 : 0, t2 = (d == 2) ? 1 : 2;
+  if (a >= L.n[t1] || b >= L.n[t2]) return;
+  int g[3], q[3];
+  g[t1] = q[t1] = a; g[t2] = q[t2] = b;
+  g[d] = s ? L.n[d] : -1; q[d] = s ? 0 : L.n[d] - 1;
+  L.phi[cidx(L, g[0], g[1], g[2])] = L.phi[cidx(L, q[0], q[1], q[2])];
+}
+
+// ---- transfers between BoxLib-layout multifabs and level 0 ---------------------------------------------
+__global__ void kk_cc_load(CLev L, FV rh, FV phi, FV bx, FV by, FV bz, int lo0, int lo1, int lo2, int ebc00, int ebc01, int ebc10, int ebc11, int ebc20, int ebc21) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  const int j = blockIdx.y * blockDim.y + threadIdx.y;
+  const int k = blockIdx.z;
+  if (i > L.n[0] || j > L.n[1] || k > L.n[2]) return;
+  const long c = cidx(L, i, j, k);
+  const bool ci = i < L.n[0], cj = j < L.n[1], ck = k < L.n[2];
+  if (ci && cj && ck) { L.rh[c] = fv_get(rh, lo0 + i, lo1 + j, lo2 + k); L.phi[c] = fv_get(phi, lo0 + i, lo1 + j, lo2 + k); }
+  if (cj && ck) {
+    double v = fv_get(bx, lo0 + i, lo1 + j, lo2 + k);
+    int e = (i == 0) ? ebc00 : (i == L.n[0] ? ebc01 : VDN_BC_INT);
+    if (e == VDN_BC_NEU) v = 0.0; else if (e == VDN_BC_DIR) v = 2.0 * v;
+    L.b[0][c] = v;
+  }
+  if (ci && ck) {
+    double v = fv_get(by, lo0 + i, lo1 + j, lo2 + k);
+    int e = (j == 0) ? ebc10 : (j == L.n[1] ? ebc11 : VDN_BC_INT);
+    if (e == VDN_BC_NEU) v = 0.0; else if (e == VDN_BC_DIR) v = 2.0 * v;
+    L.b[1][c] = v;
+  }
+  if (ci && cj) {
+    double v = fv_get(bz, lo0 + i, lo1 + j, lo2 + k);
+    int e = (k == 0) ? ebc20 : (k == L.n[2] ? ebc21 : VDN_BC_INT);
+    if (e == VDN_BC_NEU) v = 0.0; else if (e == VDN_BC_DIR) v = 2.0 * v;
+    L.b[2][c] = v;
+  }
+}
+// phi back, incl. the face ghost layer the closure implies (Neumann: phi_i, Dirichlet: -phi_i, periodic: image)
+__global__ void kk_cc_store(CLev L, FV phi, int lo0, int lo1, int lo2, int ebc00, int ebc01, int ebc10, int ebc11, int ebc20, int ebc21) {
+  const int i = (int)(blockIdx.x * blockDim.x + threadIdx.x) - 1;
+  const int j = (int)(blockIdx.y * blockDim.y + threadIdx.y) - 1;
+  const int k = (int)blockIdx.z - 1;
+  if (i > L.n[0] || j > L.n[1] || k > L.n[2]) return;
+  const int out = (i < 0) + (i == L.n[0]) + (j < 0) + (j == L.n[1]) + (k < 0) + (k == L.n[2]);
+  if (out > 1) return;
+  double v;
+  if (out == 0) v = L.phi[cidx(L, i, j, k)];
+  else {
+    int e; int qi = i, qj = j, qk = k;
+    if (i < 0) { e = ebc00; qi = 0; } else if (i == L.n[0]) { e = ebc01; qi = L.n[0] - 1; }
+    else if (j < 0) { e = ebc10; qj = 0; } else if (j == L.n[1]) { e = ebc11; qj = L.n[1] - 1; }
+    else if (k < 0) { e = ebc20; qk = 0; } else { e = ebc21; qk = L.n[2] - 1; }
+    if (e == VDN_BC_NEU) v = L.phi[cidx(L, qi, qj, qk)];
+    else if (e == VDN_BC_DIR) v = -L.phi[cidx(L, qi, qj, qk)];
+    else v = L.phi[cidx(L, i, j, k)];          // periodic image already in the ghost slot
+  }
+  fv_at(phi, lo0 + i, lo1 + j, lo2 + k) = v;
+}
+
+// ---- host side ------------------------------------------------------------------------------------------
+struct CCMG {
+  std::vector<CLev> lev;
+  int per[3];
+  double *d_nrm;     // device scalar
+};
+
+static dim3 g3(int nx, int ny, int nz, dim3 b) { return dim3((nx + b.x - 1) / b.x, (ny + b.y - 1) / b.y, nz); }
+static const dim3 BLK(64, 4, 1);
+
+static void cc_build(CCMG &M, const int n0[3], const double *dx, const int bc[3][2]) {
+  int n[3] = { n0[0], n0[1], n0[2] }; double h[3] = { dx[0], dx[1], dx[2] };
+  for (int d = 0; d < 3; d++) M.per[d] = (bc[d][0] == VDN_BC_PER);
+  for (;;) {
+    CLev L;
+    for (int d = 0; d < 3; d++) { L.n[d] = n[d]; L.hi2[d] = 1.0 / (h[d] * h[d]); }
+    L.PX = ((n[0] + 17 + 15) / 16) * 16; L.PY = n[1] + 2;
+    L.sz = (long)L.PX * L.PY * (n[2] + 2);
+    double *base = (double *)arena_alloc(sizeof(double) * L.sz * 6);
+    HIPCHK(hipMemsetAsync(base, 0, sizeof(double) * L.sz * 6, ctx().stream));
+    L.phi = base; L.rh = base + L.sz; L.res = base + 2 * L.sz;
+    for (int d = 0; d < 3; d++) L.b[d] = base + (3 + d) * L.sz;
+    M.lev.push_back(L);
+    bool can = true;
+    for (int d = 0; d < 3; d++) if ((n[d] & 1) || n[d] <= 2) can = false;
+    if (!can || M.lev.size() >= 31) break;
+    for (int d = 0; d < 3; d++) { n[d] /= 2; h[d] *= 2.0; }
+  }
+  M.d_nrm = (double *)arena_alloc(256);
+}
+
+static void cc_periodic(const CCMG &M, const CLev &L) {
+  if (!(M.per[0] || M.per[1] || M.per[2])) return;
+  int m = std::max(L.n[0], std::max(L.n[1], L.n[2]));
+  hipLaunchKernelGGL(kk_cc_periodic, g3(m, m, 6, BLK), BLK, 0, ctx().stream, L, M.per[0], M.per[1], M.per[2]);
+}
+static void cc_gsrb(const CCMG &M, const CLev &L, int nsweeps) {
+  for (int s = 0; s < nsweeps; s++) for (int color = 0; color < 2; color++) {
+    cc_periodic(M, L);
+    hipLaunchKernelGGL(kk_cc_gsrb, g3((L.n[0] + 1) / 2, L.n[1], L.n[2], BLK), BLK, 0, ctx().stream, L, color);
+  }
+}
+static void cc_residual(const CCMG &M, const CLev &L, bool norm) {
+  cc_periodic(M, L);
+  if (norm) HIPCHK(hipMemsetAsync(M.d_nrm, 0, sizeof(double), ctx().stream));
+  hipLaunchKernelGGL(kk_cc_residual, g3(L.n[0], L.n[1], L.n[2], BLK), BLK, 0, ctx().stream, L, norm ? M.d_nrm : nullptr);
+}
+static double read_scalar(double *d) {
+  VdnCtx &c = ctx();
+  HIPCHK(hipMemcpyAsync(c.h_scal, d, sizeof(double), hipMemcpyDeviceToHost, c.stream));
+  HIPCHK(hipStreamSynchronize(c.stream));
+  return c.h_scal[0];
+}
+static void cc_vcycle(const CCMG &M, int l) {
+  const vdn_params &P = ctx().prm;
+  const CLev &L = M.lev[l];
+  HIPCHK(hipMemsetAsync(L.phi, 0, sizeof(double) * L.sz, ctx().stream));
+  if (l == (int)M.lev.size() - 1) { cc_gsrb(M, L, P.mg_nub); return; }
+  const CLev &C = M.lev[l + 1];
+  cc_gsrb(M, L, P.mg_nu1);
+  cc_residual(M, L, false);
+  hipLaunchKernelGGL(kk_cc_restrict, g3(C.n[0], C.n[1], C.n[2], BLK), BLK, 0, ctx().stream, L, C);
+  cc_vcycle(M, l + 1);
+  hipLaunchKernelGGL(kk_cc_prolong, g3(L.n[0], L.n[1], L.n[2], BLK), BLK, 0, ctx().stream, L, C);
+  cc_gsrb(M, L, P.mg_nu2);
+}
+
+static void cc_setup(CCMG &M, vdn_multifab *rh, vdn_multifab *phi, vdn_multifab **beta, const double *dx, const int bc[3][2]) {
+  REQUIRE(rh->nfabs() == 1, "cc multigrid: exactly one local box per rank is supported in this round (got %d)", rh->nfabs());
+  REQUIRE(phi->ng >= 1, "cc multigrid: phi needs one ghost cell");
+  const vdn_box &bx = rh->vbox[0];
+  int n0[3]; for (int d = 0; d < 3; d++) n0[d] = bx.hi[d] - bx.lo[d] + 1;
+  cc_build(M, n0, dx, bc);
+  const CLev &L0 = M.lev[0];
+  hipLaunchKernelGGL(kk_cc_load, g3(n0[0] + 1, n0[1] + 1, n0[2] + 1, BLK), BLK, 0, ctx().stream, L0, rh->fabs[0], phi->fabs[0],
+                     beta[0]->fabs[0], beta[1]->fabs[0], beta[2]->fabs[0], bx.lo[0], bx.lo[1], bx.lo[2],
+                     bc[0][0], bc[0][1], bc[1][0], bc[1][1], bc[2][0], bc[2][1]);
+  for (size_t l = 1; l < M.lev.size(); l++) {
+    const CLev &C = M.lev[l];
+    hipLaunchKernelGGL(kk_cc_coarsen_b, g3(C.n[0] + 1, C.n[1] + 1, C.n[2] + 1, BLK), BLK, 0, ctx().stream, M.lev[l - 1], C);
+  }
+}
+static void cc_store(const CCMG &M, vdn_multifab *phi, const int bc[3][2]) {
+  const CLev &L0 = M.lev[0];
+  cc_periodic(M, L0);
+  const vdn_box &bx = phi->vbox[0];
+  hipLaunchKernelGGL(kk_cc_store, g3(L0.n[0] + 2, L0.n[1] + 2, L0.n[2] + 2, BLK), BLK, 0, ctx().stream, L0, phi->fabs[0],
+                     bx.lo[0], bx.lo[1], bx.lo[2], bc[0][0], bc[0][1], bc[1][0], bc[1][1], bc[2][0], bc[2][1]);
+}
+
+int cc_solve(vdn_multifab *rh, vdn_multifab *phi, vdn_multifab **beta, const double *dx, const int bc[3][2],
+             double rel_eps, double abs_eps, int max_iter, int *cycles, double *res0, double *res) {
+  const vdn_params &P = ctx().prm;
+  size_t mark = arena_mark();
+  CCMG M; cc_setup(M, rh, phi, beta, dx, bc);
+  const CLev &L0 = M.lev[0];
+  const double bnorm = mf_norm_inf(rh, 0, 1);
+  int cyc = 0; bool conv = (bnorm == 0.0); double rn = 0.0;
+  while (!conv) {
+    cc_gsrb(M, L0, M.lev.size() == 1 ? P.mg_nub : P.mg_nu1);
+    cc_residual(M, L0, true);
+    rn = read_scalar(M.d_nrm);
+    if (rn <= rel_eps * bnorm || rn <= abs_eps) { conv = true; break; }
+    if (cyc >= max_iter) break;
+    if (M.lev.size() > 1) {
+      const CLev &C = M.lev[1];
+      hipLaunchKernelGGL(kk_cc_restrict, g3(C.n[0], C.n[1], C.n[2], BLK), BLK, 0, ctx().stream, L0, C);
+      cc_vcycle(M, 1);
+      hipLaunchKernelGGL(kk_cc_prolong, g3(L0.n[0], L0.n[1], L0.n[2], BLK), BLK, 0, ctx().stream, L0, C);
+      cc_gsrb(M, L0, P.mg_nu2);
+    }
+    cyc++;
+  }
+  cc_store(M, phi, bc);
+  if (cycles) *cycles = cyc; if (res0) *res0 = bnorm; if (res) *res = rn;
+  arena_release(mark);
+  return conv ? 0 : 1;
+}
+
+void cc_smooth(vdn_multifab *rh, vdn_multifab *phi, vdn_multifab **beta, const double *dx, const int bc[3][2], int nsweeps) {
+  size_t mark = arena_mark();
+  CCMG M; cc_setup(M, rh, phi, beta, dx, bc);
+  cc_gsrb(M, M.lev[0], nsweeps);
+  cc_store(M, phi, bc);
+  arena_release(mark);
+}
+
+void cc_bench_smoother(vdn_multifab *rh, vdn_multifab *phi, vdn_multifab **beta, const double *dx, const int bc[3][2],
+                       int nlaunch, double *avg_ms, long *cells) {
+  size_t mark = arena_mark();
+  CCMG M; cc_setup(M, rh, phi, beta, dx, bc);
+  const CLev &L = M.lev[0];
+  hipStream_t st = ctx().stream;
+  hipEvent_t e0, e1; HIPCHK(hipEventCreate(&e0)); HIPCHK(hipEventCreate(&e1));
+  for (int w = 0; w < 4; w++) hipLaunchKernelGGL(kk_cc_gsrb, g3((L.n[0] + 1) / 2, L.n[1], L.n[2], BLK), BLK, 0, st, L, w & 1);
+  HIPCHK(hipEventRecord(e0, st));
+  for (int w = 0; w < nlaunch; w++) hipLaunchKernelGGL(kk_cc_gsrb, g3((L.n[0] + 1) / 2, L.n[1], L.n[2], BLK), BLK, 0, st, L, w & 1);
+  HIPCHK(hipEventRecord(e1, st));
+  HIPCHK(hipEventSynchronize(e1));
+  float ms = 0; HIPCHK(hipEventElapsedTime(&ms, e0, e1));
+  *avg_ms = (double)ms / nlaunch; *cells = (long)L.n[0] * L.n[1] * L.n[2];
+  HIPCHK(hipEventDestroy(e0)); HIPCHK(hipEventDestroy(e1));
+  arena_release(mark);
+}
+
+// ====================================================================================================
+// MAC projection pieces (macproject.f90)
+// ====================================================================================================
+__global__ void kk_divumac(FV um, FV vm, FV wm, FV macrhs, FV rh, double dxi0, double dxi1, double dxi2, Range3 r) {
+  THREAD_IJK(r)
+  if (!in_range) return;
+  // macproject.f90:270-272 then 190-196:  rh = -div + mac_rhs
+  double div = (fv_get(um, i + 1, j, k) - fv_get(um, i, j, k)) * dxi0
+             + (fv_get(vm, i, j + 1, k) - fv_get(vm, i, j, k)) * dxi1
+             + (fv_get(wm, i, j, k + 1) - fv_get(wm, i, j, k)) * dxi2;
+  fv_at(rh, i, j, k) = div * -1.0 + fv_get(macrhs, i, j, k);
+}
+__global__ void kk_mk_mac_coeffs(FV rho, FV bx, FV by, FV bz, Range3 r, int h0, int h1, int h2) {
+  THREAD_IJK(r)
+  if (!in_range) return;
+  const double r0 = fv_get(rho, i, j, k);
+  if (j <= h1 && k <= h2) fv_at(bx, i, j, k) = 2.0 / (r0 + fv_get(rho, i - 1, j, k));     // macproject.f90:376
+  if (i <= h0 && k <= h2) fv_at(by, i, j, k) = 2.0 / (r0 + fv_get(rho, i, j - 1, k));     // 385
+  if (i <= h0 && j <= h1) fv_at(bz, i, j, k) = 2.0 / (r0 + fv_get(rho, i, j, k - 1));     // 394
+}
+struct UmacArgs { int lo[3], hi[3]; int ebc[3][2]; double dx[3]; };
+__global__ void kk_mkumac(FV um, FV vm, FV wm, FV phi, FV bx, FV by, FV bz, UmacArgs A, Range3 r) {
+  THREAD_IJK(r)
+  if (!in_range) return;
+  const double p0 = fv_get(phi, i, j, k);
+  // macproject.f90:608-612; box faces use the ghost value the solver's closure implies, Neumann faces keep umac
+  if (j <= A.hi[1] && k <= A.hi[2]) {
+    int side = (i == A.lo[0]) ? 0 : (i == A.hi[0] + 1 ? 1 : -1);
+    if (!(side >= 0 && A.ebc[0][side] == VDN_BC_NEU)) {
+      double g = (p0 - fv_get(phi, i - 1, j, k)) / A.dx[0];
+      fv_at(um, i, j, k) = fv_get(um, i, j, k) - fv_get(bx, i, j, k) * g;
+    }
+  }
+  if (i <= A.hi[0] && k <= A.hi[2]) {
+    int side = (j == A.lo[1]) ? 0 : (j == A.hi[1] + 1 ? 1 : -1);
+    if (!(side >= 0 && A.ebc[1][side] == VDN_BC_NEU)) {
+      double g = (p0 - fv_get(phi, i, j - 1, k)) / A.dx[1];
+      fv_at(vm, i, j, k) = fv_get(vm, i, j, k) - fv_get(by, i, j, k) * g;
+    }
+  }
+  if (i <= A.hi[0] && j <= A.hi[1]) {
+    int side = (k == A.lo[2]) ? 0 : (k == A.hi[2] + 1 ? 1 : -1);
+    if (!(side >= 0 && A.ebc[2][side] == VDN_BC_NEU)) {
+      double g = (p0 - fv_get(phi, i, j, k - 1)) / A.dx[2];
+      fv_at(wm, i, j, k) = fv_get(wm, i, j, k) - fv_get(bz, i, j, k) * g;
+    }
+  }
+}
+
+void do_macproject(vdn_layout *mla, vdn_multifab **umac, vdn_multifab **rho, vdn_multifab **mac_rhs, const double *dx,
+                   const vdn_bc_tower *bct, int bc_comp0) {
+  REQUIRE(mla->nlev == 1, "macproject: multilevel hierarchies are not implemented in this round");
+  const int n = 0;
+  hipStream_t st = ctx().stream;
+  size_t mark = arena_mark();
+  vdn_multifab *rh = mf_temp(mla, n, 1, 0, -1, false, 0.0);
+  vdn_multifab *phi = mf_temp(mla, n, 1, 1, -1, true, 0.0);
+  vdn_multifab *beta[3];
+  for (int d = 0; d < 3; d++) beta[d] = mf_temp(mla, n, 1, 0, d, false, 0.0);
+  vdn_multifab *um[3] = { umac[0], umac[1], umac[2] };
+  REQUIRE(rho[n]->ng >= 1, "macproject: rho needs a filled ghost cell");
+  for (int i = 0; i < rh->nfabs(); i++) {
+    Range3 r, rf; for (int d = 0; d < 3; d++) { r.lo[d] = rf.lo[d] = rh->vbox[i].lo[d]; r.hi[d] = rh->vbox[i].hi[d]; rf.hi[d] = r.hi[d] + 1; }
+    hipLaunchKernelGGL(kk_divumac, grid_for(r), BLK, 0, st, um[0]->fabs[i], um[1]->fabs[i], um[2]->fabs[i], mac_rhs[n]->fabs[i], rh->fabs[i],
+                       1.0 / dx[0], 1.0 / dx[1], 1.0 / dx[2], r);
+    hipLaunchKernelGGL(kk_mk_mac_coeffs, grid_for(rf), BLK, 0, st, rho[n]->fabs[i], beta[0]->fabs[i], beta[1]->fabs[i], beta[2]->fabs[i], rf,
+                       r.hi[0], r.hi[1], r.hi[2]);
+  }
+  int ebc[3][2];
+  for (int d = 0; d < 3; d++) for (int s = 0; s < 2; s++) ebc[d][s] = bct->ell_bc(n, 0, d, s, bc_comp0);   // grid 0 = whole domain
+  int cyc; double r0, rr;
+  int rc = cc_solve(rh, phi, beta, dx, ebc, ctx().prm.mac_rel_eps, -1.0, ctx().prm.mg_max_iter, &cyc, &r0, &rr);   // macproject.f90:91-93
+  ctx().solver_cycles[0] = cyc; ctx().solver_res0[0] = r0; ctx().solver_res[0] = rr;
+  if (rc != 0 && ctx().prm.verbose) fprintf(stderr, "varden_amd: MAC multigrid did not converge in %d cycles (res %g / %g)\n", cyc, rr, r0);
+  for (int i = 0; i < rh->nfabs(); i++) {
+    UmacArgs A; Range3 rf;
+    for (int d = 0; d < 3; d++) { A.lo[d] = rf.lo[d] = rh->vbox[i].lo[d]; A.hi[d] = rh->vbox[i].hi[d]; rf.hi[d] = A.hi[d] + 1; A.dx[d] = dx[d];
+      for (int s = 0; s < 2; s++) A.ebc[d][s] = bct->ell_bc(n, i + 1, d, s, bc_comp0); }
+    hipLaunchKernelGGL(kk_mkumac, grid_for(rf), BLK, 0, st, um[0]->fabs[i], um[1]->fabs[i], um[2]->fabs[i], phi->fabs[i],
+                       beta[0]->fabs[i], beta[1]->fabs[i], beta[2]->fabs[i], A, rf);
+  }
+  for (int d = 0; d < 3; d++) mf_fill_boundary(um[d]);          // macproject.f90:115-119
+  for (int d = 0; d < 3; d++) mf_temp_free(beta[d]);
+  mf_temp_free(phi); mf_temp_free(rh);
+  arena_release(mark);
+}

@@ -1,0 +1,443 @@
+// mg_nd.hip -- nodal (HG) projection (reference src/hgproject.f90:17-178, src/hg_multigrid.f90:18-119)
+// and the nodal multigrid that replaces FBoxLib's ml_nd_solve (hg_multigrid.f90:95-105).
+//
+// Discrete system and algorithm: see oracle/vo_hgproject.c (same definitions, same expression order):
+// Q1 finite-element stiffness with cell-constant sigma scaled by 1/(hx hy hz) ("dense" 27-point
+// stencil, 21-point when dx=dy=dz), RHS = nodal divergence, outflow nodes phi = 0, walls natural.
+// V(nu1,nu2) cycles, damped Jacobi (one streaming pass per sweep -- a lexicographic Gauss-Seidel, as
+// a CPU code would use, has no parallel order; an 8-colour one costs 8 passes over the level),
+// full-weighting restriction, trilinear prolongation, coarse sigma = mean of the 8 children.
+//
+// HBM layout of a level: node (i,j,k) in [-1..n+1] and cell (i,j,k) in [-1..n] both map to
+// (i + 16) + PX*((j+1) + PY*(k+1)), PX a multiple of 16 doubles (rows start on a 128-byte line).
+// Algorithmic traffic of one Jacobi sweep: phi read 8 + phi write 8 + rhs 8 + sigma 8 = 32 B/node.
+#include "vdn_dev.h"
+
+struct NLev {
+  int n[3]; int PX, PY; long sz;
+  double f[3];                    // 1/(36 h^2)
+  double *phi, *tmp, *b, *res, *sig;
+  int dirlo[3], dirhi[3];         // Dirichlet (outflow) faces
+  int per[3];
+};
+DEVI long nidx(const NLev &L, int i, int j, int k) { return (long)(i + 16) + (long)L.PX * ((long)(j + 1) + (long)L.PY * (long)(k + 1)); }
+DEVI bool nd_is_dir(const NLev &L, int i, int j, int k) {
+  return (i == 0 && L.dirlo[0]) || (i == L.n[0] && L.dirhi[0]) || (j == 0 && L.dirlo[1]) || (j == L.n[1] && L.dirhi[1]) ||
+         (k == 0 && L.dirlo[2]) || (k == L.n[2] && L.dirhi[2]);
+}
+
+// K phi and the diagonal at node (i,j,k): cells (ck,cj,ci) ascending, corners (mz,my,mx) ascending --
+// the order of nd_apply in oracle/vo_hgproject.c
+DEVI void nd_apply(const NLev &L, const double *__restrict__ phi, int i, int j, int k, double &Kp, double &diag) {
+  const double fx = L.f[0], fy = L.f[1], fz = L.f[2];
+  const double F = fx + fy + fz;
+  double w[8];
+  w[0] = 4.0 * F;
+  w[1] = -4.0 * fx + 2.0 * fy + 2.0 * fz;
+  w[2] = 2.0 * fx - 4.0 * fy + 2.0 * fz;
+  w[3] = -2.0 * fx - 2.0 * fy + fz;
+  w[4] = 2.0 * fx + 2.0 * fy - 4.0 * fz;
+  w[5] = -2.0 * fx + fy - 2.0 * fz;
+  w[6] = fx - 2.0 * fy - 2.0 * fz;
+  w[7] = -F;
+  const long sy = L.PX, sz = (long)L.PX * L.PY;
+  const long c0 = nidx(L, i, j, k);
+  double p[3][3][3];
+  #pragma unroll
+  for (int c = 0; c < 3; c++)
+    #pragma unroll
+    for (int b = 0; b < 3; b++)
+      #pragma unroll
+      for (int a = 0; a < 3; a++) p[c][b][a] = phi[c0 + (a - 1) + (b - 1) * sy + (c - 1) * sz];
+  double acc = 0.0, ssum = 0.0;
+  #pragma unroll
+  for (int dk = 0; dk < 2; dk++)
+    #pragma unroll
+    for (int dj = 0; dj < 2; dj++)
+      #pragma unroll
+      for (int di = 0; di < 2; di++) {
+        // cell (i-1+di, j-1+dj, k-1+dk); its corner (mx,my,mz) is node offset (di+mx-1, ...) from (i,j,k)
+        const double sg = L.sig[c0 + (di - 1) + (dj - 1) * sy + (dk - 1) * sz];
+        double t = 0.0;
+        #pragma unroll
+        for (int mz = 0; mz < 2; mz++)
+          #pragma unroll
+          for (int my = 0; my < 2; my++)
+            #pragma unroll
+            for (int mx = 0; mx < 2; mx++) {
+              const int oa = di + mx - 1, ob = dj + my - 1, oc = dk + mz - 1;
+              const int idx = (oa != 0) | ((ob != 0) << 1) | ((oc != 0) << 2);
+              t = t + w[idx] * p[oc + 1][ob + 1][oa + 1];
+            }
+        acc = acc + sg * t;
+        ssum = ssum + sg;
+      }
+  Kp = acc;
+  diag = w[0] * ssum;
+}
+
+#define NODE_IJK(L)                                                    \
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;                 \
+  const int j = blockIdx.y * blockDim.y + threadIdx.y;                 \
+  const int k = blockIdx.z;                                            \
+  const bool in_range = (i <= (L).n[0]) && (j <= (L).n[1]) && (k <= (L).n[2]);
+
+__global__ void __launch_bounds__(256) kk_nd_jacobi(NLev L, const double *__restrict__ phi, double *__restrict__ out, double omega) {
+  NODE_IJK(L)
+  if (!in_range) return;
+  const long c = nidx(L, i, j, k);
+  const double p0 = phi[c];
+  double v = p0;
+  if (!nd_is_dir(L, i, j, k)) {
+    double Kp, diag; nd_apply(L, phi, i, j, k, Kp, diag);
+    if (diag != 0.0) v = p0 + omega * ((L.b[c] - Kp) / diag);
+  }
+  out[c] = v;
+}
+__global__ void __launch_bounds__(256) kk_nd_residual(NLev L, double *nrm) {
+  NODE_IJK(L)
+  double r = 0.0;
+  if (in_range) {
+    const long c = nidx(L, i, j, k);
+    if (!nd_is_dir(L, i, j, k)) { double Kp, diag; nd_apply(L, L.phi, i, j, k, Kp, diag); r = L.b[c] - Kp; }
+    L.res[c] = r;
+  }
+  if (nrm) block_atomic_max(nrm, fabs(r));
+}
+// ghost nodes (and the periodic alias node n): periodic image, else zero
+__global__ void kk_nd_fill_nodes(NLev L, double *a) {
+  const int i = (int)(blockIdx.x * blockDim.x + threadIdx.x) - 1;
+  const int j = (int)(blockIdx.y * blockDim.y + threadIdx.y) - 1;
+  const int k = (int)blockIdx.z - 1;
+  if (i > L.n[0] + 1 || j > L.n[1] + 1 || k > L.n[2] + 1) return;
+  int q[3] = { i, j, k }, s[3] = { i, j, k }; bool g = false, zero = false;
+  #pragma unroll
+  for (int d = 0; d < 3; d++) {
+    if (L.per[d]) { if (q[d] < 0) { s[d] = q[d] + L.n[d]; g = true; } else if (q[d] >= L.n[d]) { s[d] = q[d] - L.n[d]; g = true; } }
+    else if (q[d] < 0 || q[d] > L.n[d]) { g = true; zero = true; }
+  }
+  if (g) a[nidx(L, i, j, k)] = zero ? 0.0 : a[nidx(L, s[0], s[1], s[2])];
+}
+__global__ void kk_nd_fill_cells(NLev L, double *a) {
+  const int i = (int)(blockIdx.x * blockDim.x + threadIdx.x) - 1;
+  const int j = (int)(blockIdx.y * blockDim.y + threadIdx.y) - 1;
+  const int k = (int)blockIdx.z - 1;
+  if (i > L.n[0] || j > L.n[1] || k > L.n[2]) return;
+  int q[3] = { i, j, k }, s[3] = { i, j, k }; bool g = false, zero = false;
+  #pragma unroll
+  for (int d = 0; d < 3; d++) {
+    if (q[d] < 0) { g = true; if (L.per[d]) s[d] = q[d] + L.n[d]; else zero = true; }
+    else if (q[d] >= L.n[d]) { g = true; if (L.per[d]) s[d] = q[d] - L.n[d]; else zero = true; }
+  }
+  if (g) a[nidx(L, i, j, k)] = zero ? 0.0 : a[nidx(L, s[0], s[1], s[2])];
+}
+__global__ void kk_nd_restrict(NLev F, NLev C) {
+  NODE_IJK(C)
+  if (!in_range) return;
+  double s = 0.0;
+  if (!nd_is_dir(C, i, j, k)) {
+    const long sy = F.PX, sz = (long)F.PX * F.PY;
+    const long f0 = nidx(F, 2 * i, 2 * j, 2 * k);
+    #pragma unroll
+    for (int c = -1; c <= 1; c++)
+      #pragma unroll
+      for (int b = -1; b <= 1; b++)
+        #pragma unroll
+        for (int a = -1; a <= 1; a++) {
+          const double wa = a ? 0.5 : 1.0, wb = b ? 0.5 : 1.0, wc = c ? 0.5 : 1.0;
+          s = s + (wa * wb * wc) * F.res[f0 + a + b * sy + c * sz];
+        }
+  }
+  C.b[nidx(C, i, j, k)] = s * 0.125;
+}
+__global__ void kk_nd_prolong(NLev F, NLev C) {
+  NODE_IJK(F)
+  if (!in_range) return;
+  if (nd_is_dir(F, i, j, k)) return;
+  const int I = i >> 1, J = j >> 1, K = k >> 1, oi = i & 1, oj = j & 1, ok = k & 1;
+  double s = 0.0;
+  for (int c = 0; c <= ok; c++) for (int b = 0; b <= oj; b++) for (int a = 0; a <= oi; a++) s = s + C.phi[nidx(C, I + a, J + b, K + c)];
+  const double scale = 1.0 / (double)((1 + oi) * (1 + oj) * (1 + ok));
+  const long f = nidx(F, i, j, k);
+  F.phi[f] = F.phi[f] + s * scale;
+}
+__global__ void kk_nd_coarsen_sigma(NLev F, NLev C) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  const int j = blockIdx.y * blockDim.y + threadIdx.y;
+  const int k = blockIdx.z;
+  if (i >= C.n[0] || j >= C.n[1] || k >= C.n[2]) return;
+  const long sy = F.PX, sz = (long)F.PX * F.PY;
+  const long f = nidx(F, 2 * i, 2 * j, 2 * k);
+  double s = 0.0;
+  #pragma unroll
+  for (int c = 0; c < 2; c++)
+    #pragma unroll
+    for (int b = 0; b < 2; b++)
+      #pragma unroll
+      for (int a = 0; a < 2; a++) s = s + F.sig[f + a + b * sy + c * sz];
+  C.sig[nidx(C, i, j, k)] = s * 0.125;
+}
+
+// ---- load / store / divergence -------------------------------------------------------------------------
+__global__ void kk_nd_load_sigma(NLev L, FV coeffs, int lo0, int lo1, int lo2) {
+  const int i = (int)(blockIdx.x * blockDim.x + threadIdx.x) - 1;
+  const int j = (int)(blockIdx.y * blockDim.y + threadIdx.y) - 1;
+  const int k = (int)blockIdx.z - 1;
+  if (i > L.n[0] || j > L.n[1] || k > L.n[2]) return;
+  L.sig[nidx(L, i, j, k)] = fv_get(coeffs, lo0 + i, lo1 + j, lo2 + k);
+}
+// rh(node) += D u  (definition in oracle/vo_hgproject.c::vo_nd_divu)
+__global__ void kk_nd_divu(FV u, FV rh, double fx, double fy, double fz, Range3 r) {
+  THREAD_IJK(r)
+  if (!in_range) return;
+  #define U(a, b, c, m) fv_get(u, i + (a), j + (b), k + (c), m)
+  const double dux = (((U(0, 0, 0, 0) + U(0, -1, 0, 0)) + U(0, 0, -1, 0)) + U(0, -1, -1, 0))
+                   - (((U(-1, 0, 0, 0) + U(-1, -1, 0, 0)) + U(-1, 0, -1, 0)) + U(-1, -1, -1, 0));
+  const double duy = (((U(0, 0, 0, 1) + U(-1, 0, 0, 1)) + U(0, 0, -1, 1)) + U(-1, 0, -1, 1))
+                   - (((U(0, -1, 0, 1) + U(-1, -1, 0, 1)) + U(0, -1, -1, 1)) + U(-1, -1, -1, 1));
+  const double duz = (((U(0, 0, 0, 2) + U(-1, 0, 0, 2)) + U(0, -1, 0, 2)) + U(-1, -1, 0, 2))
+                   - (((U(0, 0, -1, 2) + U(-1, 0, -1, 2)) + U(0, -1, -1, 2)) + U(-1, -1, -1, 2));
+  #undef U
+  fv_at(rh, i, j, k) = fv_get(rh, i, j, k) + (dux * fx + duy * fy + duz * fz);
+}
+__global__ void kk_nd_load(NLev L, FV rh, FV phi, int lo0, int lo1, int lo2, double *nrm) {
+  NODE_IJK(L)
+  double r = 0.0;
+  if (in_range) {
+    const bool dir = nd_is_dir(L, i, j, k);
+    r = dir ? 0.0 : fv_get(rh, lo0 + i, lo1 + j, lo2 + k);
+    const long c = nidx(L, i, j, k);
+    L.b[c] = -r;
+    L.phi[c] = dir ? 0.0 : fv_get(phi, lo0 + i, lo1 + j, lo2 + k);
+  }
+  block_atomic_max(nrm, fabs(r));
+}
+__global__ void kk_nd_store(NLev L, FV phi, int lo0, int lo1, int lo2) {
+  const int i = (int)(blockIdx.x * blockDim.x + threadIdx.x) - 1;
+  const int j = (int)(blockIdx.y * blockDim.y + threadIdx.y) - 1;
+  const int k = (int)blockIdx.z - 1;
+  if (i > L.n[0] + 1 || j > L.n[1] + 1 || k > L.n[2] + 1) return;
+  fv_at(phi, lo0 + i, lo1 + j, lo2 + k) = L.phi[nidx(L, i, j, k)];
+}
+
+// ---- host ---------------------------------------------------------------------------------------------------
+static const dim3 NBLK(64, 4, 1);
+static dim3 ng3(int nx, int ny, int nz) { return dim3((nx + 63) / 64, (ny + 3) / 4, nz); }
+
+struct NDMG { std::vector<NLev> lev; double *d_nrm; };
+
+static void nd_fill_nodes(const NLev &L, double *a) {
+  hipLaunchKernelGGL(kk_nd_fill_nodes, ng3(L.n[0] + 3, L.n[1] + 3, L.n[2] + 3), NBLK, 0, ctx().stream, L, a);
+}
+static void nd_jacobi(NLev &L, int nsweeps) {
+  for (int s = 0; s < nsweeps; s++) {
+    nd_fill_nodes(L, L.phi);
+    hipLaunchKernelGGL(kk_nd_jacobi, ng3(L.n[0] + 1, L.n[1] + 1, L.n[2] + 1), NBLK, 0, ctx().stream, L, L.phi, L.tmp, ctx().prm.hg_omega);
+    std::swap(L.phi, L.tmp);
+  }
+}
+static void nd_residual(NDMG &M, NLev &L, bool norm) {
+  nd_fill_nodes(L, L.phi);
+  if (norm) HIPCHK(hipMemsetAsync(M.d_nrm, 0, sizeof(double), ctx().stream));
+  hipLaunchKernelGGL(kk_nd_residual, ng3(L.n[0] + 1, L.n[1] + 1, L.n[2] + 1), NBLK, 0, ctx().stream, L, norm ? M.d_nrm : nullptr);
+  nd_fill_nodes(L, L.res);
+}
+static void nd_vcycle(NDMG &M, int l) {
+  const vdn_params &P = ctx().prm;
+  NLev &L = M.lev[l];
+  HIPCHK(hipMemsetAsync(L.phi, 0, sizeof(double) * L.sz, ctx().stream));
+  if (l == (int)M.lev.size() - 1) { nd_jacobi(L, P.hg_nub); return; }
+  NLev &C = M.lev[l + 1];
+  nd_jacobi(L, P.hg_nu1);
+  nd_residual(M, L, false);
+  hipLaunchKernelGGL(kk_nd_restrict, ng3(C.n[0] + 1, C.n[1] + 1, C.n[2] + 1), NBLK, 0, ctx().stream, L, C);
+  nd_vcycle(M, l + 1);
+  nd_fill_nodes(C, C.phi);
+  hipLaunchKernelGGL(kk_nd_prolong, ng3(L.n[0] + 1, L.n[1] + 1, L.n[2] + 1), NBLK, 0, ctx().stream, L, C);
+  nd_jacobi(L, P.hg_nu2);
+}
+static double nd_read(double *d) {
+  VdnCtx &c = ctx();
+  HIPCHK(hipMemcpyAsync(c.h_scal, d, sizeof(double), hipMemcpyDeviceToHost, c.stream));
+  HIPCHK(hipStreamSynchronize(c.stream));
+  return c.h_scal[0];
+}
+
+int nd_solve(vdn_multifab *rh, vdn_multifab *phi, const vdn_multifab *coeffs, const vdn_multifab *u, const double *dx,
+             const int bc[3][2], double rel_eps, double abs_eps, int max_iter, int *cycles, double *res0, double *res) {
+  const vdn_params &P = ctx().prm;
+  REQUIRE(rh->nfabs() == 1, "nodal multigrid: exactly one local box per rank is supported in this round (got %d)", rh->nfabs());
+  REQUIRE(rh->ng >= 1 && phi->ng >= 1 && coeffs->ng >= 1, "nodal multigrid: rh, phi, coeffs need one ghost layer");
+  hipStream_t st = ctx().stream;
+  size_t mark = arena_mark();
+  NDMG M;
+  const vdn_box &bx = coeffs->vbox[0];
+  int n[3]; double h[3];
+  for (int d = 0; d < 3; d++) { n[d] = bx.hi[d] - bx.lo[d] + 1; h[d] = dx[d]; }
+  for (;;) {
+    NLev L;
+    for (int d = 0; d < 3; d++) {
+      L.n[d] = n[d]; L.f[d] = 1.0 / (36.0 * (h[d] * h[d]));
+      L.dirlo[d] = (bc[d][0] == VDN_BC_DIR); L.dirhi[d] = (bc[d][1] == VDN_BC_DIR); L.per[d] = (bc[d][0] == VDN_BC_PER);
+    }
+    L.PX = ((n[0] + 18 + 15) / 16) * 16; L.PY = n[1] + 3; L.sz = (long)L.PX * L.PY * (n[2] + 3);
+    double *base = (double *)arena_alloc(sizeof(double) * L.sz * 5);
+    HIPCHK(hipMemsetAsync(base, 0, sizeof(double) * L.sz * 5, st));
+    L.phi = base; L.tmp = base + L.sz; L.b = base + 2 * L.sz; L.res = base + 3 * L.sz; L.sig = base + 4 * L.sz;
+    M.lev.push_back(L);
+    bool can = true;
+    for (int d = 0; d < 3; d++) if ((n[d] & 1) || n[d] <= 2) can = false;
+    if (!can || M.lev.size() >= 31) break;
+    for (int d = 0; d < 3; d++) { n[d] /= 2; h[d] *= 2.0; }
+  }
+  M.d_nrm = (double *)arena_alloc(256);
+  NLev &L0 = M.lev[0];
+  hipLaunchKernelGGL(kk_nd_load_sigma, ng3(L0.n[0] + 2, L0.n[1] + 2, L0.n[2] + 2), NBLK, 0, st, L0, coeffs->fabs[0], bx.lo[0], bx.lo[1], bx.lo[2]);
+  for (size_t l = 1; l < M.lev.size(); l++) {
+    NLev &C = M.lev[l];
+    hipLaunchKernelGGL(kk_nd_coarsen_sigma, ng3(C.n[0], C.n[1], C.n[2]), NBLK, 0, st, M.lev[l - 1], C);
+    hipLaunchKernelGGL(kk_nd_fill_cells, ng3(C.n[0] + 2, C.n[1] + 2, C.n[2] + 2), NBLK, 0, st, C, C.sig);
+  }
+  if (u) {                                                  // add_divu = .true., hg_multigrid.f90:96
+    REQUIRE(u->ng >= 1 && u->nc >= 3, "nodal multigrid: u needs a ghost cell");
+    Range3 r; for (int d = 0; d < 3; d++) { r.lo[d] = bx.lo[d]; r.hi[d] = bx.hi[d] + 1; }
+    hipLaunchKernelGGL(kk_nd_divu, grid_for(r), NBLK, 0, st, u->fabs[0], rh->fabs[0], 0.25 / dx[0], 0.25 / dx[1], 0.25 / dx[2], r);
+  }
+  HIPCHK(hipMemsetAsync(M.d_nrm, 0, sizeof(double), st));
+  hipLaunchKernelGGL(kk_nd_load, ng3(L0.n[0] + 1, L0.n[1] + 1, L0.n[2] + 1), NBLK, 0, st, L0, rh->fabs[0], phi->fabs[0], bx.lo[0], bx.lo[1], bx.lo[2], M.d_nrm);
+  const double bnorm = nd_read(M.d_nrm);
+  int cyc = 0; bool conv = (bnorm == 0.0); double rn = 0.0;
+  while (!conv) {
+    nd_jacobi(L0, M.lev.size() == 1 ? P.hg_nub : P.hg_nu1);
+    nd_residual(M, L0, true);
+    rn = nd_read(M.d_nrm);
+    if (rn <= rel_eps * bnorm || rn <= abs_eps) { conv = true; break; }
+    if (cyc >= max_iter) break;
+    if (M.lev.size() > 1) {
+      NLev &C = M.lev[1];
+      hipLaunchKernelGGL(kk_nd_restrict, ng3(C.n[0] + 1, C.n[1] + 1, C.n[2] + 1), NBLK, 0, st, L0, C);
+      nd_vcycle(M, 1);
+      nd_fill_nodes(C, C.phi);
+      hipLaunchKernelGGL(kk_nd_prolong, ng3(L0.n[0] + 1, L0.n[1] + 1, L0.n[2] + 1), NBLK, 0, st, L0, C);
+      nd_jacobi(L0, P.hg_nu2);
+    }
+    cyc++;
+  }
+  nd_fill_nodes(L0, L0.phi);
+  hipLaunchKernelGGL(kk_nd_store, ng3(L0.n[0] + 3, L0.n[1] + 3, L0.n[2] + 3), NBLK, 0, st, L0, phi->fabs[0], bx.lo[0], bx.lo[1], bx.lo[2]);
+  if (cycles) *cycles = cyc; if (res0) *res0 = bnorm; if (res) *res = rn;
+  arena_release(mark);
+  return conv ? 0 : 1;
+}
+
+// ====================================================================================================
+// hgproject pieces (hgproject.f90)
+// ====================================================================================================
+struct UvecArgs { int lo[3], hi[3], ng; int phys[3][2]; double dt, dtinv; int proj_type; };
+// gp ghost zeroing at INLET, the projected quantity on the grown box, wall ghost planes zeroed
+// (hgproject.f90:453-511), fused in one pass over the ghosted fab
+__global__ void kk_create_uvec(FV unew, FV uold, FV rhohalf, FV gp, UvecArgs A, Range3 r) {
+  THREAD_IJK(r)
+  if (!in_range) return;
+  const int q[3] = { i, j, k };
+  bool g1 = true;                         // inside the box grown by 1
+  #pragma unroll
+  for (int d = 0; d < 3; d++) if (q[d] < A.lo[d] - 1 || q[d] > A.hi[d] + 1) g1 = false;
+  bool wall_plane = false, inlet_plane = false;
+  #pragma unroll
+  for (int d = 0; d < 3; d++) {
+    if (q[d] == A.lo[d] - 1) { int p = A.phys[d][0]; if (p == VDN_SLIP_WALL || p == VDN_NO_SLIP_WALL) wall_plane = true; if (p == VDN_INLET) inlet_plane = true; }
+    if (q[d] == A.hi[d] + 1) { int p = A.phys[d][1]; if (p == VDN_SLIP_WALL || p == VDN_NO_SLIP_WALL) wall_plane = true; if (p == VDN_INLET) inlet_plane = true; }
+  }
+  #pragma unroll
+  for (int m = 0; m < 3; m++) {
+    double gpv = 0.0;
+    if (g1) { gpv = fv_get(gp, i, j, k, m); if (inlet_plane) { gpv = 0.0; fv_at(gp, i, j, k, m) = 0.0; } }
+    if (wall_plane) { fv_at(unew, i, j, k, m) = 0.0; continue; }
+    if (!g1) continue;
+    double v = fv_get(unew, i, j, k, m);
+    if (A.proj_type == VDN_PRESSURE_ITERS) v = (v - fv_get(uold, i, j, k, m)) * A.dtinv;
+    else if (A.proj_type == VDN_REGULAR_TIMESTEP) v = v + A.dt * gpv / fv_get(rhohalf, i, j, k, 0);
+    fv_at(unew, i, j, k, m) = v;
+  }
+}
+__global__ void kk_coeffs(FV coeffs, FV rhohalf, Range3 r) {
+  THREAD_IJK(r)
+  if (!in_range) return;
+  fv_at(coeffs, i, j, k) = 1.0 / fv_get(rhohalf, i, j, k, 0);      // hg_multigrid.f90:76-77
+}
+__global__ void kk_mkgphi(FV gp, FV phi, double dxi0, double dxi1, double dxi2, Range3 r) {
+  THREAD_IJK(r)
+  if (!in_range) return;
+  #define P(a, b, c) fv_get(phi, i + (a), j + (b), k + (c))
+  fv_at(gp, i, j, k, 0) = 0.25 * (P(1, 0, 0) + P(1, 1, 0) + P(1, 0, 1) + P(1, 1, 1) - P(0, 0, 0) - P(0, 1, 0) - P(0, 0, 1) - P(0, 1, 1)) * dxi0;
+  fv_at(gp, i, j, k, 1) = 0.25 * (P(0, 1, 0) + P(1, 1, 0) + P(0, 1, 1) + P(1, 1, 1) - P(0, 0, 0) - P(1, 0, 0) - P(0, 0, 1) - P(1, 0, 1)) * dxi1;
+  fv_at(gp, i, j, k, 2) = 0.25 * (P(0, 0, 1) + P(1, 0, 1) + P(0, 1, 1) + P(1, 1, 1) - P(0, 0, 0) - P(1, 0, 0) - P(0, 1, 0) - P(1, 1, 0)) * dxi2;
+  #undef P
+}
+struct HgUpdArgs { int hi[3]; double dt, dtinv; int proj_type; };
+__global__ void kk_hg_update(FV unew, FV uold, FV gp, FV gphi, FV rhohalf, FV p, FV phi, HgUpdArgs A, Range3 r) {
+  THREAD_IJK(r)           // r covers nodes lo..hi+1
+  if (!in_range) return;
+  const bool cell = i <= A.hi[0] && j <= A.hi[1] && k <= A.hi[2];
+  if (cell) {
+    const double rho = fv_get(rhohalf, i, j, k, 0);
+    #pragma unroll
+    for (int m = 0; m < 3; m++) {
+      const double gph = fv_get(gphi, i, j, k, m);
+      double v = fv_get(unew, i, j, k, m) - gph / rho;                    // hgproject.f90:659-667
+      if (A.proj_type == VDN_PRESSURE_ITERS) v = fv_get(uold, i, j, k, m) + A.dt * v;
+      fv_at(unew, i, j, k, m) = v;
+      if (A.proj_type == VDN_PRESSURE_ITERS) fv_at(gp, i, j, k, m) = fv_get(gp, i, j, k, m) + gph;
+      else if (A.proj_type == VDN_REGULAR_TIMESTEP) fv_at(gp, i, j, k, m) = A.dtinv * gph;
+    }
+  }
+  if (A.proj_type == VDN_PRESSURE_ITERS) fv_at(p, i, j, k) = fv_get(p, i, j, k) + fv_get(phi, i, j, k);
+  else if (A.proj_type == VDN_REGULAR_TIMESTEP) fv_at(p, i, j, k) = A.dtinv * fv_get(phi, i, j, k);
+}
+
+void do_hgproject(int proj_type, vdn_layout *mla, vdn_multifab **unew, vdn_multifab **uold, vdn_multifab **rhohalf,
+                  vdn_multifab **p, vdn_multifab **gp, const double *dx, double dt, const vdn_bc_tower *bct, int press_comp0) {
+  REQUIRE(mla->nlev == 1, "hgproject: multilevel hierarchies are not implemented in this round");
+  REQUIRE(proj_type >= VDN_INITIAL_PROJECTION && proj_type <= VDN_REGULAR_TIMESTEP, "No proj_type by this number");
+  const int n = 0;
+  hipStream_t st = ctx().stream;
+  size_t mark = arena_mark();
+  vdn_multifab *rh = mf_temp(mla, n, 1, 1, 3, true, 0.0);
+  vdn_multifab *phi = mf_temp(mla, n, 1, 1, 3, true, 0.0);
+  vdn_multifab *gphi = mf_temp(mla, n, 3, 0, -1, false, 0.0);
+  vdn_multifab *coeffs = mf_temp(mla, n, 1, 1, -1, true, 0.0);        // ghosts 0: hg_multigrid.f90:73
+  vdn_multifab *un = unew[n], *uo = uold[n], *rhh = rhohalf[n], *gpp = gp[n], *pp = p[n];
+  REQUIRE(un->ng >= 1 && gpp->ng >= 1 && rhh->ng >= 1 && pp->ng >= 1, "hgproject: ghost widths");
+  for (int i = 0; i < un->nfabs(); i++) {
+    UvecArgs A; Range3 r; BoxP bp = make_boxp(un, i, bct);
+    for (int d = 0; d < 3; d++) { A.lo[d] = bp.lo[d]; A.hi[d] = bp.hi[d]; r.lo[d] = bp.lo[d] - un->ng; r.hi[d] = bp.hi[d] + un->ng;
+      for (int s = 0; s < 2; s++) A.phys[d][s] = bp.phys[d][s]; }
+    A.ng = un->ng; A.dt = dt; A.dtinv = 1.0 / dt; A.proj_type = proj_type;
+    hipLaunchKernelGGL(kk_create_uvec, grid_for(r), NBLK, 0, st, un->fabs[i], uo->fabs[i], rhh->fabs[i], gpp->fabs[i], A, r);
+    Range3 rv; for (int d = 0; d < 3; d++) { rv.lo[d] = bp.lo[d]; rv.hi[d] = bp.hi[d]; }
+    hipLaunchKernelGGL(kk_coeffs, grid_for(rv), NBLK, 0, st, coeffs->fabs[i], rhh->fabs[i], rv);
+  }
+  mf_fill_boundary(un);                                               // hgproject.f90:232
+  mf_fill_boundary(coeffs);                                           // hg_multigrid.f90:79
+  double rel = ctx().prm.hg_rel_eps > 0.0 ? ctx().prm.hg_rel_eps : 1.e-12;   // hgproject.f90:113-119 (nlevs = 1)
+  double abs_eps = -1.0;
+  if (proj_type == VDN_INITIAL_PROJECTION && ctx().prm.prob_type == 4) abs_eps = 1.e-12;   // 125-127
+  int ebc[3][2];
+  for (int d = 0; d < 3; d++) for (int s = 0; s < 2; s++) ebc[d][s] = bct->ell_bc(n, 0, d, s, press_comp0);
+  int cyc; double r0, rr;
+  int rc = nd_solve(rh, phi, coeffs, un, dx, ebc, rel, abs_eps, ctx().prm.hg_max_iter, &cyc, &r0, &rr);
+  ctx().solver_cycles[1] = cyc; ctx().solver_res0[1] = r0; ctx().solver_res[1] = rr;
+  if (rc != 0 && ctx().prm.verbose) fprintf(stderr, "varden_amd: nodal multigrid did not converge in %d cycles (res %g / %g)\n", cyc, rr, r0);
+  if (proj_type == VDN_INITIAL_PROJECTION || proj_type == VDN_DIVU_ITERS) { mf_setval(gpp, 0.0, 0, gpp->nc, true); mf_setval(pp, 0.0, 0, 1, true); }   // 673-676
+  for (int i = 0; i < un->nfabs(); i++) {
+    Range3 rv, rn; HgUpdArgs H;
+    for (int d = 0; d < 3; d++) { rv.lo[d] = rn.lo[d] = un->vbox[i].lo[d]; rv.hi[d] = un->vbox[i].hi[d]; rn.hi[d] = rv.hi[d] + 1; H.hi[d] = rv.hi[d]; }
+    H.dt = dt; H.dtinv = 1.0 / dt; H.proj_type = proj_type;
+    hipLaunchKernelGGL(kk_mkgphi, grid_for(rv), NBLK, 0, st, gphi->fabs[i], phi->fabs[i], 1.0 / dx[0], 1.0 / dx[1], 1.0 / dx[2], rv);
+    hipLaunchKernelGGL(kk_hg_update, grid_for(rn), NBLK, 0, st, un->fabs[i], uo->fabs[i], gpp->fabs[i], gphi->fabs[i], rhh->fabs[i], pp->fabs[i], phi->fabs[i], H, rn);
+  }
+  mf_fill_boundary(gpp); mf_fill_boundary(pp);                        // hgproject.f90:359-362
+  mf_temp_free(coeffs); mf_temp_free(gphi); mf_temp_free(phi); mf_temp_free(rh);
+  arena_release(mark);
+}

@@ -1,0 +1,146 @@
+// pointwise.hip -- streaming kernels of the hot path: forcing terms, conservative/convective update,
+// rho at half time, CFL maxima.  All HBM-bound, one thread per cell, x fastest (coalesced 512 B per
+// wave-row), expression order identical to the reference Fortran (fp-contract off).
+//
+//   k_mkvelforce       reference src/mkforce.f90:144-236
+//   k_mkscalforce      reference src/mkforce.f90:333-402
+//   k_update           reference src/update.f90:186-278
+//   k_make_at_halftime reference src/make_at_halftime.f90:95-115
+//   k_estdt_max        reference src/estdt.f90:131-181 (the maxima; the scalar tail runs on the host)
+#include "vdn_dev.h"
+
+struct ForceArgs { int lo[3], hi[3]; double visc_coef, fac; int boussinesq, nscal; };
+
+__global__ void kk_mkvelforce(FV vf, FV ext, FV gp, FV s, FV lapu, int has_lapu, ForceArgs A, Range3 r) {
+  THREAD_IJK(r)
+  if (!in_range) return;
+  const int out = (i < A.lo[0]) + (i > A.hi[0]) + (j < A.lo[1]) + (j > A.hi[1]) + (k < A.lo[2]) + (k > A.hi[2]);
+  if (out > 1) return;                              // the six face halos only, no edges/corners (mkforce.f90:186-234)
+  const int ic = min(max(i, A.lo[0]), A.hi[0]), jc = min(max(j, A.lo[1]), A.hi[1]), kc = min(max(k, A.lo[2]), A.hi[2]);
+  const double rho = fv_get(s, i, j, k, 0);
+  #pragma unroll
+  for (int m = 0; m < 3; m++) {
+    double l = has_lapu ? fv_get(lapu, ic, jc, kc, m) : 0.0;   // 0th-order extrapolation of lapu
+    double lapu_local = A.visc_coef * A.fac * l;
+    double e = fv_get(ext, i, j, k, m);
+    if (out == 0 && A.boussinesq == 1) e = fv_get(s, i, j, k, 1) * e;
+    fv_at(vf, i, j, k, m) = e + (lapu_local - fv_get(gp, i, j, k, m)) / rho;
+  }
+}
+
+void k_mkvelforce(vdn_multifab *vf, const vdn_multifab *ext, const vdn_multifab *s, const vdn_multifab *gp,
+                  const vdn_multifab *lapu, double visc_fac) {
+  REQUIRE(vf->ng >= 1 && ext->ng >= 1 && gp->ng >= 1 && s->ng >= 1, "mkvelforce: operands need a ghost cell");
+  mf_setval(vf, 0.0, 0, vf->nc, true);              // mkforce.f90:52
+  for (int i = 0; i < vf->nfabs(); i++) {
+    ForceArgs A; Range3 r;
+    for (int d = 0; d < 3; d++) { A.lo[d] = vf->vbox[i].lo[d]; A.hi[d] = vf->vbox[i].hi[d]; r.lo[d] = A.lo[d] - 1; r.hi[d] = A.hi[d] + 1; }
+    A.visc_coef = ctx().prm.visc_coef; A.fac = visc_fac; A.boussinesq = ctx().prm.boussinesq; A.nscal = ctx().prm.nscal;
+    hipLaunchKernelGGL(kk_mkvelforce, grid_for(r), dim3(64, 4, 1), 0, ctx().stream, vf->fabs[i], ext->fabs[i], gp->fabs[i],
+                       s->fabs[i], lapu ? lapu->fabs[i] : vf->fabs[i], lapu ? 1 : 0, A, r);
+  }
+}
+
+__global__ void kk_mkscalforce(FV sf, FV ext, FV laps, int has_laps, ForceArgs A, Range3 r) {
+  THREAD_IJK(r)
+  if (!in_range) return;
+  const int out = (i < A.lo[0]) + (i > A.hi[0]) + (j < A.lo[1]) + (j > A.hi[1]) + (k < A.lo[2]) + (k > A.hi[2]);
+  if (out > 1) return;
+  const int ic = min(max(i, A.lo[0]), A.hi[0]), jc = min(max(j, A.lo[1]), A.hi[1]), kc = min(max(k, A.lo[2]), A.hi[2]);
+  for (int m = 1; m < A.nscal; m++) {               // density (comp 1) does not diffuse: force stays 0
+    double l = has_laps ? fv_get(laps, ic, jc, kc, m) : 0.0;
+    double laps_local = A.visc_coef * A.fac * l;    // here visc_coef carries diff_coef
+    fv_at(sf, i, j, k, m) = fv_get(ext, i, j, k, m) + laps_local;
+  }
+}
+
+void k_mkscalforce(vdn_multifab *sf, const vdn_multifab *ext, const vdn_multifab *laps, double diff_fac) {
+  mf_setval(sf, 0.0, 0, sf->nc, true);              // mkforce.f90:267 / 346
+  for (int i = 0; i < sf->nfabs(); i++) {
+    ForceArgs A; Range3 r;
+    for (int d = 0; d < 3; d++) { A.lo[d] = sf->vbox[i].lo[d]; A.hi[d] = sf->vbox[i].hi[d]; r.lo[d] = A.lo[d] - 1; r.hi[d] = A.hi[d] + 1; }
+    A.visc_coef = ctx().prm.diff_coef; A.fac = diff_fac; A.boussinesq = 0; A.nscal = ctx().prm.nscal;
+    hipLaunchKernelGGL(kk_mkscalforce, grid_for(r), dim3(64, 4, 1), 0, ctx().stream, sf->fabs[i], ext->fabs[i],
+                       laps ? laps->fabs[i] : sf->fabs[i], laps ? 1 : 0, A, r);
+  }
+}
+
+// ---- update -------------------------------------------------------------------------------------
+struct UpdArgs { double dx[3], dt; int ncomp; int cons[VDN_MAXCOMP]; };
+
+__global__ void kk_update(FV sold, FV snew, FV um, FV vm, FV wm, FV sx, FV sy, FV sz, FV fx, FV fy, FV fz, FV force,
+                          UpdArgs A, Range3 r) {
+  THREAD_IJK(r)
+  if (!in_range) return;
+  const double ubar = 0.5 * (fv_get(um, i, j, k) + fv_get(um, i + 1, j, k));
+  const double vbar = 0.5 * (fv_get(vm, i, j, k) + fv_get(vm, i, j + 1, k));
+  const double wbar = 0.5 * (fv_get(wm, i, j, k) + fv_get(wm, i, j, k + 1));
+  for (int c = 0; c < A.ncomp; c++) {
+    double so = fv_get(sold, i, j, k, c), f = fv_get(force, i, j, k, c), v;
+    if (A.cons[c]) {                                 // update.f90:250-253
+      double divsu = (fv_get(fx, i + 1, j, k, c) - fv_get(fx, i, j, k, c)) / A.dx[0]
+                   + (fv_get(fy, i, j + 1, k, c) - fv_get(fy, i, j, k, c)) / A.dx[1]
+                   + (fv_get(fz, i, j, k + 1, c) - fv_get(fz, i, j, k, c)) / A.dx[2];
+      v = so - A.dt * divsu + A.dt * f;
+    } else {                                         // update.f90:220-238, 263-269
+      double ugrads = ubar * (fv_get(sx, i + 1, j, k, c) - fv_get(sx, i, j, k, c)) / A.dx[0]
+                    + vbar * (fv_get(sy, i, j + 1, k, c) - fv_get(sy, i, j, k, c)) / A.dx[1]
+                    + wbar * (fv_get(sz, i, j, k + 1, c) - fv_get(sz, i, j, k, c)) / A.dx[2];
+      v = so - A.dt * ugrads + A.dt * f;
+    }
+    fv_at(snew, i, j, k, c) = v;
+  }
+}
+
+void k_update(const vdn_multifab *sold, vdn_multifab **umac, vdn_multifab **sedge, vdn_multifab **flux,
+              const vdn_multifab *force, vdn_multifab *snew, const double *dx, double dt, bool is_vel, const int *is_cons) {
+  for (int i = 0; i < sold->nfabs(); i++) {
+    UpdArgs A; Range3 r;
+    for (int d = 0; d < 3; d++) { A.dx[d] = dx[d]; r.lo[d] = sold->vbox[i].lo[d]; r.hi[d] = sold->vbox[i].hi[d]; }
+    A.dt = dt; A.ncomp = sold->nc;
+    for (int c = 0; c < sold->nc; c++) A.cons[c] = (!is_vel && is_cons[c]) ? 1 : 0;
+    hipLaunchKernelGGL(kk_update, grid_for(r), dim3(64, 4, 1), 0, ctx().stream, sold->fabs[i], snew->fabs[i],
+                       umac[0]->fabs[i], umac[1]->fabs[i], umac[2]->fabs[i], sedge[0]->fabs[i], sedge[1]->fabs[i],
+                       sedge[2]->fabs[i], flux[0]->fabs[i], flux[1]->fabs[i], flux[2]->fabs[i], force->fabs[i], A, r);
+  }
+}
+
+// ---- rho at half time -----------------------------------------------------------------------------
+__global__ void kk_halftime(FV rh, int oc, FV so, FV sn, int ic, Range3 r) {
+  THREAD_IJK(r)
+  if (!in_range) return;
+  fv_at(rh, i, j, k, oc) = 0.5 * (fv_get(so, i, j, k, ic) + fv_get(sn, i, j, k, ic));
+}
+void k_make_at_halftime(vdn_multifab *rhohalf, const vdn_multifab *sold, const vdn_multifab *snew, int in_comp, int out_comp) {
+  for (int i = 0; i < rhohalf->nfabs(); i++) {
+    Range3 r; for (int d = 0; d < 3; d++) { r.lo[d] = rhohalf->vbox[i].lo[d]; r.hi[d] = rhohalf->vbox[i].hi[d]; }
+    hipLaunchKernelGGL(kk_halftime, grid_for(r), dim3(64, 4, 1), 0, ctx().stream, rhohalf->fabs[i], out_comp, sold->fabs[i], snew->fabs[i], in_comp, r);
+  }
+}
+
+// ---- estdt maxima: wave-level reduction (64 lanes, shuffles) + one atomic per wave ----------------
+__global__ void kk_estdt(FV u, FV s, FV gp, FV ext, Range3 r, double *out6) {
+  THREAD_IJK(r)
+  double m[6] = { 0, 0, 0, 0, 0, 0 };
+  if (in_range) {
+    const double rho = fv_get(s, i, j, k, 0);
+    #pragma unroll
+    for (int c = 0; c < 3; c++) {
+      m[c] = fabs(fv_get(u, i, j, k, c));
+      m[3 + c] = fabs(fv_get(gp, i, j, k, c) / rho - fv_get(ext, i, j, k, c));
+    }
+  }
+  #pragma unroll
+  for (int c = 0; c < 6; c++) block_atomic_max(out6 + c, m[c]);
+}
+void k_estdt_max(const vdn_multifab *u, const vdn_multifab *s, const vdn_multifab *gp, const vdn_multifab *ext, double out6[6]) {
+  VdnCtx &c = ctx();
+  HIPCHK(hipMemsetAsync(c.d_scal, 0, 6 * sizeof(double), c.stream));
+  for (int i = 0; i < u->nfabs(); i++) {
+    Range3 r; for (int d = 0; d < 3; d++) { r.lo[d] = u->vbox[i].lo[d]; r.hi[d] = u->vbox[i].hi[d]; }
+    hipLaunchKernelGGL(kk_estdt, grid_for(r), dim3(64, 4, 1), 0, c.stream, u->fabs[i], s->fabs[i], gp->fabs[i], ext->fabs[i], r, c.d_scal);
+  }
+  HIPCHK(hipMemcpyAsync(c.h_scal, c.d_scal, 6 * sizeof(double), hipMemcpyDeviceToHost, c.stream));
+  HIPCHK(hipStreamSynchronize(c.stream));
+  for (int k = 0; k < 6; k++) out6[k] = c.h_scal[k];
+}

@@ -1,0 +1,564 @@
+// runtime.hip -- context, arena, ml_layout / multifab / bc_tower containers and the ghost-cell
+// operators (multifab_fill_boundary, multifab_physbc) of the MI355X-native VARDEN hot path.
+//
+// Reference behaviour restated here:
+//   define_bc_tower.f90:129-340   (phys / adv / ell tables)
+//   multifab_physbc.f90:238-561   (physbc_3d)
+//   FBoxLib multifab_fill_boundary / setval / copy_c / norm_inf (external to the reference tree;
+//   semantics from their call sites)
+#include "vdn_dev.h"
+#include <algorithm>
+#include <chrono>
+#include <tuple>
+
+// ================================================================================================
+// context / errors / arena
+// ================================================================================================
+static VdnCtx g_ctx;
+VdnCtx &ctx() { return g_ctx; }
+static thread_local char g_err[1024] = "";
+
+void vdn_set_error(const char *fmt, ...) { va_list ap; va_start(ap, fmt); vsnprintf(g_err, sizeof g_err, fmt, ap); va_end(ap); }
+void vdn_fail(const char *fmt, ...) {
+  char buf[1024]; va_list ap; va_start(ap, fmt); vsnprintf(buf, sizeof buf, fmt, ap); va_end(ap);
+  throw VdnErr(buf);
+}
+
+void arena_reset() { g_ctx.arena_off = 0; }
+// make sure the arena holds at least `bytes`; only legal while nothing is live in it
+void arena_reserve(size_t bytes) {
+  VdnCtx &c = g_ctx;
+  if (bytes <= c.arena_bytes) return;
+  REQUIRE(c.arena_off == 0, "arena_reserve while temporaries are live");
+  if (c.arena) { HIPCHK(hipStreamSynchronize(c.stream)); HIPCHK(hipFree(c.arena)); c.arena = nullptr; c.arena_bytes = 0; }
+  HIPCHK(hipMalloc((void **)&c.arena, bytes));
+  c.arena_bytes = bytes;
+}
+// temporaries needed by one advance_timestep / projection on this layout: a generous count of
+// ng=3 cell fields per local box (Appendix B of SURVEY.md lists ~45 live fields; the Godunov
+// intermediates add ~40 more)
+void arena_reserve_for(const vdn_layout *la) {
+  size_t per_field = 0;
+  for (int l = 0; l < la->nlev; l++) for (int g : la->local[l]) {
+    const vdn_box &b = la->boxes[l][g];
+    per_field += (size_t)(b.hi[0] - b.lo[0] + 8) * (b.hi[1] - b.lo[1] + 8) * (b.hi[2] - b.lo[2] + 8) * sizeof(double);
+  }
+  arena_reserve(per_field * 150 + (64u << 20));
+}
+size_t arena_mark() { return g_ctx.arena_off; }
+void arena_release(size_t mark) { g_ctx.arena_off = mark; }
+void *arena_alloc(size_t bytes) {
+  VdnCtx &c = g_ctx;
+  size_t off = (c.arena_off + 255) & ~(size_t)255;
+  if (off + bytes > c.arena_bytes) {
+    // grow: only legal when nothing is live (arena_off == 0) -- otherwise fail loudly
+    if (c.arena_off != 0) vdn_fail("arena exhausted: need %zu more bytes (have %zu); call vdn_reserve first", bytes, c.arena_bytes);
+    size_t want = std::max(bytes * 2, c.arena_bytes * 2);
+    if (c.arena) HIPCHK(hipFree(c.arena));
+    HIPCHK(hipMalloc((void **)&c.arena, want));
+    c.arena_bytes = want; off = 0;
+  }
+  c.arena_off = off + bytes;
+  return c.arena + off;
+}
+
+extern "C" void vdn_params_default(vdn_params *p) {
+  memset(p, 0, sizeof *p);
+  p->dm = 3; p->nscal = 2; p->slope_order = 4; p->use_minion = 0; p->boussinesq = 0;
+  p->stencil_order = 2; p->diffusion_type = 1; p->verbose = 0; p->mg_verbose = 0; p->prob_type = 1;
+  p->visc_coef = 0.0; p->diff_coef = 0.0; p->cflfac = 0.8; p->max_dt_growth = 1.1;
+  p->mg_nu1 = 2; p->mg_nu2 = 2; p->mg_nub = 8; p->mg_max_iter = 100;
+  p->hg_max_iter = 100; p->hg_nu1 = 3; p->hg_nu2 = 3; p->hg_nub = 32; p->hg_omega = 0.8;
+  p->mac_rel_eps = 1.0e-10; p->hg_rel_eps = -1.0;
+}
+
+extern "C" const char *vdn_last_error(void) { return g_err; }
+
+extern "C" int vdn_init(const vdn_params *prm, int rank, int nranks, int device) {
+  VDN_TRY
+  REQUIRE(prm != nullptr, "vdn_init: null params");
+  REQUIRE(prm->dm == 3, "vdn_init: only dm = 3 is implemented on the device path (got %d)", prm->dm);
+  REQUIRE(prm->nscal >= 1 && prm->nscal + 5 <= VDN_MAXCOMP, "vdn_init: bad nscal %d", prm->nscal);
+  REQUIRE(prm->visc_coef == 0.0 && prm->diff_coef == 0.0,
+          "vdn_init: visc_coef/diff_coef > 0 (implicit viscous solves) are not implemented yet");
+  REQUIRE(prm->slope_order == 0 || prm->slope_order == 2 || prm->slope_order == 4, "bad slope_order");
+  int ndev = 0;
+  HIPCHK(hipGetDeviceCount(&ndev));
+  REQUIRE(ndev > 0, "vdn_init: no HIP device visible -- the product path has no CPU fallback");
+  REQUIRE(device >= 0 && device < ndev, "vdn_init: device %d out of range (%d devices)", device, ndev);
+  HIPCHK(hipSetDevice(device));
+  VdnCtx &c = g_ctx;
+  c.prm = *prm; c.rank = rank; c.nranks = nranks; c.device = device;
+  if (!c.d_scal) { HIPCHK(hipMalloc((void **)&c.d_scal, 64 * sizeof(double))); HIPCHK(hipHostMalloc((void **)&c.h_scal, 64 * sizeof(double))); }
+  c.inited = true;
+  VDN_CATCH
+}
+extern "C" int vdn_finalize(void) {
+  VDN_TRY
+  VdnCtx &c = g_ctx;
+  if (c.arena) { HIPCHK(hipFree(c.arena)); c.arena = nullptr; c.arena_bytes = 0; c.arena_off = 0; }
+  if (c.d_scal) { HIPCHK(hipFree(c.d_scal)); c.d_scal = nullptr; HIPCHK(hipHostFree(c.h_scal)); c.h_scal = nullptr; }
+  c.inited = false;
+  VDN_CATCH
+}
+extern "C" int vdn_set_stream(void *s) { g_ctx.stream = (hipStream_t)s; return 0; }
+extern "C" int vdn_device_synchronize(void) { VDN_TRY HIPCHK(hipStreamSynchronize(g_ctx.stream)); VDN_CATCH }
+extern "C" int vdn_get_params(vdn_params *out) { *out = g_ctx.prm; return 0; }
+extern "C" int vdn_last_step_timing(double *s) { for (int i = 0; i < 5; i++) s[i] = g_ctx.step_sec[i]; return 0; }
+extern "C" int vdn_last_solver_stats(int w, int *cyc, double *r0, double *r) {
+  if (w < 0 || w > 1) return 1;
+  *cyc = g_ctx.solver_cycles[w]; *r0 = g_ctx.solver_res0[w]; *r = g_ctx.solver_res[w]; return 0;
+}
+
+// ================================================================================================
+// ml_layout
+// ================================================================================================
+extern "C" int vdn_layout_create(int nlev, const int *rr, const vdn_box *pd, const int *nboxes, const vdn_box *boxes,
+                                 const int *owner, const int *pmask, vdn_layout **out) {
+  VDN_TRY
+  REQUIRE(g_ctx.inited, "vdn_layout_create: call vdn_init first");
+  REQUIRE(nlev >= 1, "nlev must be >= 1");
+  vdn_layout *la = new vdn_layout;
+  la->nlev = nlev;
+  if (nlev > 1) la->rr.assign(rr, rr + 3 * (nlev - 1));
+  la->pd.assign(pd, pd + nlev);
+  for (int d = 0; d < 3; d++) la->pmask[d] = pmask ? pmask[d] : 0;
+  int off = 0;
+  la->boxes.resize(nlev); la->owner.resize(nlev); la->local.resize(nlev);
+  for (int l = 0; l < nlev; l++) {
+    for (int b = 0; b < nboxes[l]; b++) {
+      const vdn_box &bx = boxes[off + b];
+      for (int d = 0; d < 3; d++) REQUIRE(bx.hi[d] - bx.lo[d] + 1 >= 4, "box %d of level %d is narrower than 4 cells", b, l);
+      la->boxes[l].push_back(bx);
+      int ow = owner ? owner[off + b] : 0;
+      REQUIRE(ow >= 0 && ow < g_ctx.nranks, "owner %d out of range", ow);
+      la->owner[l].push_back(ow);
+      if (ow == g_ctx.rank) la->local[l].push_back(b);
+    }
+    off += nboxes[l];
+  }
+  *out = la;
+  VDN_CATCH
+}
+extern "C" int vdn_layout_destroy(vdn_layout *la) { delete la; return 0; }
+extern "C" int vdn_layout_nlevel(const vdn_layout *la) { return la->nlev; }
+extern "C" int vdn_layout_nboxes(const vdn_layout *la, int lev) { return (int)la->boxes[lev].size(); }
+extern "C" int vdn_layout_nlocal(const vdn_layout *la, int lev) { return (int)la->local[lev].size(); }
+extern "C" int vdn_layout_global_index(const vdn_layout *la, int lev, int i) { return la->local[lev][i]; }
+extern "C" int vdn_layout_get_box(const vdn_layout *la, int lev, int g, vdn_box *out) { *out = la->boxes[lev][g]; return 0; }
+
+// ================================================================================================
+// bc_tower  (define_bc_tower.f90)
+// ================================================================================================
+static void build_adv_ell(int p, int d, int dm, int nscal, int *a, int *e) {
+  const int press = dm + nscal, extrap = press + 1;
+  if (p == VDN_SLIP_WALL) {                       // define_bc_tower.f90:199-207, 291-297
+    for (int c = 0; c < dm; c++) a[c] = VDN_HOEXTRAP;
+    a[d] = VDN_EXT_DIR;
+    for (int n = 0; n < nscal; n++) a[dm + n] = VDN_HOEXTRAP;
+    a[press] = VDN_FOEXTRAP; a[extrap] = VDN_FOEXTRAP;
+    for (int c = 0; c < dm; c++) e[c] = VDN_BC_NEU;
+    e[d] = VDN_BC_DIR;
+    for (int n = 0; n < nscal; n++) e[dm + n] = VDN_BC_NEU;
+    e[press] = VDN_BC_NEU;
+  } else if (p == VDN_NO_SLIP_WALL) {             // 209-216, 299-304
+    for (int c = 0; c < dm; c++) a[c] = VDN_EXT_DIR;
+    for (int n = 0; n < nscal; n++) a[dm + n] = VDN_HOEXTRAP;
+    a[press] = VDN_FOEXTRAP; a[extrap] = VDN_FOEXTRAP;
+    for (int c = 0; c < dm; c++) e[c] = VDN_BC_DIR;
+    for (int n = 0; n < nscal; n++) e[dm + n] = VDN_BC_NEU;
+    e[press] = VDN_BC_NEU;
+  } else if (p == VDN_INLET) {                    // 218-225, 306-311
+    for (int c = 0; c < dm; c++) a[c] = VDN_EXT_DIR;
+    for (int n = 0; n < nscal; n++) a[dm + n] = VDN_EXT_DIR;
+    a[press] = VDN_FOEXTRAP; a[extrap] = VDN_FOEXTRAP;
+    for (int c = 0; c < dm; c++) e[c] = VDN_BC_DIR;
+    for (int n = 0; n < nscal; n++) e[dm + n] = VDN_BC_DIR;
+    e[press] = VDN_BC_NEU;
+  } else if (p == VDN_OUTLET) {                   // 227-234, 313-318
+    for (int c = 0; c < dm; c++) a[c] = VDN_FOEXTRAP;
+    for (int n = 0; n < nscal; n++) a[dm + n] = VDN_FOEXTRAP;
+    a[press] = VDN_EXT_DIR; a[extrap] = VDN_FOEXTRAP;
+    for (int c = 0; c < dm; c++) e[c] = VDN_BC_NEU;
+    for (int n = 0; n < nscal; n++) e[dm + n] = VDN_BC_NEU;
+    e[press] = VDN_BC_DIR;
+  } else if (p == VDN_SYMMETRY) {                 // 236-244, 320-326
+    for (int c = 0; c < dm; c++) a[c] = VDN_REFLECT_EVEN;
+    a[d] = VDN_REFLECT_ODD;
+    for (int n = 0; n < nscal; n++) a[dm + n] = VDN_REFLECT_EVEN;
+    a[press] = VDN_EXT_DIR; a[extrap] = VDN_REFLECT_EVEN;
+    for (int c = 0; c < dm; c++) e[c] = VDN_BC_NEU;
+    e[d] = VDN_BC_DIR;
+    for (int n = 0; n < nscal; n++) e[dm + n] = VDN_BC_NEU;
+    e[press] = VDN_BC_NEU;
+  } else if (p == VDN_PERIODIC) {                 // 328-334 (ell only)
+    for (int c = 0; c < dm + nscal + 1; c++) e[c] = VDN_BC_PER;
+  }
+}
+
+extern "C" int vdn_bc_tower_create(const vdn_layout *la, const int *phys_bc, vdn_bc_tower **out) {
+  VDN_TRY
+  vdn_bc_tower *b = new vdn_bc_tower;
+  b->la = la; b->dm = g_ctx.prm.dm; b->nscal = g_ctx.prm.nscal;
+  b->ncomp_adv = b->dm + b->nscal + 2; b->ncomp_ell = b->dm + b->nscal + 1;
+  for (int d = 0; d < 3; d++) for (int s = 0; s < 2; s++) b->domain_bc[d][s] = phys_bc[d * 2 + s];
+  b->phys.resize(la->nlev); b->adv.resize(la->nlev); b->ell.resize(la->nlev);
+  for (int l = 0; l < la->nlev; l++) {
+    int ng = (int)la->local[l].size() + 1;
+    b->phys[l].resize(ng); b->adv[l].resize(ng); b->ell[l].resize(ng);
+    for (int g = 0; g < ng; g++) {
+      BoxP &bp = b->phys[l][g];
+      vdn_box bx = (g == 0) ? la->pd[l] : la->boxes[l][la->local[l][g - 1]];
+      for (int d = 0; d < 3; d++) {
+        bp.lo[d] = bx.lo[d]; bp.hi[d] = bx.hi[d];
+        // phys_bc_level_build, define_bc_tower.f90:129-156
+        bp.phys[d][0] = (bx.lo[d] == la->pd[l].lo[d]) ? b->domain_bc[d][0] : VDN_INTERIOR;
+        bp.phys[d][1] = (bx.hi[d] == la->pd[l].hi[d]) ? b->domain_bc[d][1] : VDN_INTERIOR;
+      }
+      b->adv[l][g].assign(6 * b->ncomp_adv, VDN_INTERIOR);
+      b->ell[l][g].assign(6 * b->ncomp_ell, VDN_BC_INT);
+      for (int d = 0; d < 3; d++) for (int s = 0; s < 2; s++)
+        build_adv_ell(bp.phys[d][s], d, b->dm, b->nscal, &b->adv[l][g][(d * 2 + s) * b->ncomp_adv], &b->ell[l][g][(d * 2 + s) * b->ncomp_ell]);
+    }
+  }
+  *out = b;
+  VDN_CATCH
+}
+extern "C" int vdn_bc_tower_destroy(vdn_bc_tower *b) { delete b; return 0; }
+extern "C" int vdn_bc_tower_phys(const vdn_bc_tower *b, int lev, int grid, int dir, int side) { return b->phys[lev][grid].phys[dir][side]; }
+extern "C" int vdn_bc_tower_adv(const vdn_bc_tower *b, int lev, int grid, int dir, int side, int comp) { return b->adv_bc(lev, grid, dir, side, comp); }
+extern "C" int vdn_bc_tower_ell(const vdn_bc_tower *b, int lev, int grid, int dir, int side, int comp) { return b->ell_bc(lev, grid, dir, side, comp); }
+
+BoxP make_boxp(const vdn_multifab *mf, int i, const vdn_bc_tower *bct) {
+  BoxP bp;
+  if (bct) bp = bct->phys[mf->lev][i + 1];
+  else for (int d = 0; d < 3; d++) { bp.phys[d][0] = bp.phys[d][1] = VDN_INTERIOR; }
+  for (int d = 0; d < 3; d++) { bp.lo[d] = mf->vbox[i].lo[d]; bp.hi[d] = mf->vbox[i].hi[d]; }
+  return bp;
+}
+
+// ================================================================================================
+// multifab
+// ================================================================================================
+static void mf_layout_fabs(vdn_multifab *mf, size_t *total_doubles) {
+  const vdn_layout *la = mf->la;
+  size_t off = 0;
+  mf->fabs.clear(); mf->vbox.clear();
+  for (int g : la->local[mf->lev]) {
+    const vdn_box &bx = la->boxes[mf->lev][g];
+    FV f;
+    f.a0 = bx.lo[0] - mf->ng; f.a1 = bx.lo[1] - mf->ng; f.a2 = bx.lo[2] - mf->ng;
+    f.n0 = bx.hi[0] - bx.lo[0] + 1 + mf->nodal[0] + 2 * mf->ng;
+    f.n1 = bx.hi[1] - bx.lo[1] + 1 + mf->nodal[1] + 2 * mf->ng;
+    f.n2 = bx.hi[2] - bx.lo[2] + 1 + mf->nodal[2] + 2 * mf->ng;
+    f.sc = (long)f.n0 * f.n1 * f.n2;
+    f.p = (double *)(uintptr_t)(off * sizeof(double));   // offset for now
+    off += (size_t)f.sc * mf->nc;
+    off = (off + 31) & ~(size_t)31;                      // 256-byte aligned fabs
+    mf->fabs.push_back(f); mf->vbox.push_back(bx);
+  }
+  *total_doubles = off;
+}
+
+extern "C" int vdn_multifab_create(const vdn_layout *la, int lev, int nc, int ng, const int *nodal, vdn_multifab **out) {
+  VDN_TRY
+  REQUIRE(la && lev >= 0 && lev < la->nlev, "vdn_multifab_create: bad level");
+  REQUIRE(nc >= 1 && ng >= 0, "vdn_multifab_create: bad nc/ng");
+  vdn_multifab *mf = new vdn_multifab;
+  mf->la = la; mf->lev = lev; mf->nc = nc; mf->ng = ng;
+  for (int d = 0; d < 3; d++) mf->nodal[d] = nodal ? (nodal[d] != 0) : 0;
+  size_t tot; mf_layout_fabs(mf, &tot);
+  mf->bytes = std::max<size_t>(tot, 1) * sizeof(double);
+  HIPCHK(hipMalloc((void **)&mf->base, mf->bytes));
+  for (auto &f : mf->fabs) f.p = (double *)((char *)mf->base + (uintptr_t)f.p);
+  HIPCHK(hipMemsetAsync(mf->base, 0, mf->bytes, g_ctx.stream));
+  *out = mf;
+  VDN_CATCH
+}
+
+vdn_multifab *mf_temp(const vdn_layout *la, int lev, int nc, int ng, int face_dir, bool fill, double val) {
+  vdn_multifab *mf = new vdn_multifab;
+  mf->la = la; mf->lev = lev; mf->nc = nc; mf->ng = ng; mf->owns = false;
+  for (int d = 0; d < 3; d++) mf->nodal[d] = (face_dir == 3) ? 1 : (face_dir == d ? 1 : 0);
+  size_t tot; mf_layout_fabs(mf, &tot);
+  mf->bytes = std::max<size_t>(tot, 1) * sizeof(double);
+  mf->base = (double *)arena_alloc(mf->bytes);
+  for (auto &f : mf->fabs) f.p = (double *)((char *)mf->base + (uintptr_t)f.p);
+  if (fill) mf_setval(mf, val, 0, nc, true);
+  return mf;
+}
+void mf_temp_free(vdn_multifab *mf) { delete mf; }
+
+extern "C" int vdn_multifab_destroy(vdn_multifab *mf) {
+  VDN_TRY
+  if (mf) { if (mf->owns && mf->base) { HIPCHK(hipStreamSynchronize(g_ctx.stream)); HIPCHK(hipFree(mf->base)); } delete mf; }
+  VDN_CATCH
+}
+extern "C" int vdn_multifab_nfabs(const vdn_multifab *mf) { return mf->nfabs(); }
+extern "C" int vdn_multifab_ncomp(const vdn_multifab *mf) { return mf->nc; }
+extern "C" int vdn_multifab_nghost(const vdn_multifab *mf) { return mf->ng; }
+extern "C" int vdn_multifab_get_box(const vdn_multifab *mf, int i, vdn_box *out) { *out = mf->vbox[i]; return 0; }
+extern "C" long vdn_multifab_fab_size(const vdn_multifab *mf, int i) { return mf->fab_size(i); }
+extern "C" int vdn_multifab_dataptr(const vdn_multifab *mf, int i, double **dev) { *dev = mf->fabs[i].p; return 0; }
+extern "C" int vdn_multifab_copy_to_host(const vdn_multifab *mf, int i, double *host) {
+  VDN_TRY
+  HIPCHK(hipMemcpyAsync(host, mf->fabs[i].p, mf->fab_size(i) * sizeof(double), hipMemcpyDeviceToHost, g_ctx.stream));
+  HIPCHK(hipStreamSynchronize(g_ctx.stream));
+  VDN_CATCH
+}
+extern "C" int vdn_multifab_copy_from_host(vdn_multifab *mf, int i, const double *host) {
+  VDN_TRY
+  HIPCHK(hipMemcpyAsync(mf->fabs[i].p, host, mf->fab_size(i) * sizeof(double), hipMemcpyHostToDevice, g_ctx.stream));
+  HIPCHK(hipStreamSynchronize(g_ctx.stream));
+  VDN_CATCH
+}
+
+// ---- setval / copy / norm ----------------------------------------------------------------------
+__global__ void k_setval(FV f, Range3 r, int comp, int nc, double val) {
+  THREAD_IJK(r)
+  if (!in_range) return;
+  for (int c = comp; c < comp + nc; c++) fv_at(f, i, j, k, c) = val;
+}
+static Range3 fab_range(const vdn_multifab *mf, int i, int grow) {   // valid (incl. nodal) grown by `grow`
+  Range3 r;
+  for (int d = 0; d < 3; d++) { r.lo[d] = mf->vbox[i].lo[d] - grow; r.hi[d] = mf->vbox[i].hi[d] + mf->nodal[d] + grow; }
+  return r;
+}
+void mf_setval(vdn_multifab *mf, double val, int comp, int nc, bool all) {
+  for (int i = 0; i < mf->nfabs(); i++) {
+    Range3 r = fab_range(mf, i, all ? mf->ng : 0);
+    hipLaunchKernelGGL(k_setval, grid_for(r), dim3(64, 4, 1), 0, g_ctx.stream, mf->fabs[i], r, comp, nc, val);
+  }
+}
+extern "C" int vdn_multifab_setval(vdn_multifab *mf, double val, int comp, int nc, int all) {
+  VDN_TRY
+  REQUIRE(comp >= 0 && comp + nc <= mf->nc, "setval: component range");
+  mf_setval(mf, val, comp, nc, all != 0);
+  VDN_CATCH
+}
+
+__global__ void k_copy(FV d, int dc, FV s, int scomp, int nc, Range3 r) {
+  THREAD_IJK(r)
+  if (!in_range) return;
+  for (int c = 0; c < nc; c++) fv_at(d, i, j, k, dc + c) = fv_get(s, i, j, k, scomp + c);
+}
+void mf_copy(vdn_multifab *dst, int dcomp, const vdn_multifab *src, int scomp, int nc, int ng) {
+  REQUIRE(dst->nfabs() == src->nfabs(), "copy_c: layouts differ");
+  REQUIRE(ng <= dst->ng && ng <= src->ng, "copy_c: ng too large");
+  for (int i = 0; i < dst->nfabs(); i++) {
+    Range3 r = fab_range(dst, i, ng);
+    hipLaunchKernelGGL(k_copy, grid_for(r), dim3(64, 4, 1), 0, g_ctx.stream, dst->fabs[i], dcomp, src->fabs[i], scomp, nc, r);
+  }
+}
+extern "C" int vdn_multifab_copy_c(vdn_multifab *dst, int dcomp, const vdn_multifab *src, int scomp, int nc, int ng) {
+  VDN_TRY mf_copy(dst, dcomp, src, scomp, nc, ng); VDN_CATCH
+}
+
+__global__ void k_absmax(FV f, Range3 r, int comp, int nc, double *out) {
+  THREAD_IJK(r)
+  double v = 0.0;
+  if (in_range) for (int c = comp; c < comp + nc; c++) v = fmax(v, fabs(fv_get(f, i, j, k, c)));
+  block_atomic_max(out, v);
+}
+__global__ void k_minmax(FV f, Range3 r, int comp, double *out /* [0]=max(-x) shifted, [1]=max(x) shifted */, double shift) {
+  THREAD_IJK(r)
+  double a = 0.0, b = 0.0;   // max of (shift - x) and (x + shift), both non-negative when |x| <= shift
+  if (in_range) { double x = fv_get(f, i, j, k, comp); a = shift - x; b = x + shift; }
+  block_atomic_max(out, a); block_atomic_max(out + 1, b);
+}
+double mf_norm_inf(const vdn_multifab *mf, int comp, int nc) {
+  VdnCtx &c = g_ctx;
+  HIPCHK(hipMemsetAsync(c.d_scal, 0, sizeof(double), c.stream));
+  for (int i = 0; i < mf->nfabs(); i++) {
+    Range3 r = fab_range(mf, i, 0);
+    hipLaunchKernelGGL(k_absmax, grid_for(r), dim3(64, 4, 1), 0, c.stream, mf->fabs[i], r, comp, nc, c.d_scal);
+  }
+  HIPCHK(hipMemcpyAsync(c.h_scal, c.d_scal, sizeof(double), hipMemcpyDeviceToHost, c.stream));
+  HIPCHK(hipStreamSynchronize(c.stream));
+  return c.h_scal[0];     // single rank; multi-rank callers all-reduce MAX
+}
+extern "C" int vdn_multifab_norm_inf(const vdn_multifab *mf, int comp, int nc, double *out) {
+  VDN_TRY *out = mf_norm_inf(mf, comp, nc); VDN_CATCH
+}
+extern "C" int vdn_multifab_min_max(const vdn_multifab *mf, int comp, double *mn, double *mx) {
+  VDN_TRY
+  VdnCtx &c = g_ctx;
+  double amax = mf_norm_inf(mf, comp, 1);
+  double shift = amax;     // x + shift >= 0 and shift - x >= 0
+  HIPCHK(hipMemsetAsync(c.d_scal, 0, 2 * sizeof(double), c.stream));
+  for (int i = 0; i < mf->nfabs(); i++) {
+    Range3 r = fab_range(mf, i, 0);
+    hipLaunchKernelGGL(k_minmax, grid_for(r), dim3(64, 4, 1), 0, c.stream, mf->fabs[i], r, comp, c.d_scal, shift);
+  }
+  HIPCHK(hipMemcpyAsync(c.h_scal, c.d_scal, 2 * sizeof(double), hipMemcpyDeviceToHost, c.stream));
+  HIPCHK(hipStreamSynchronize(c.stream));
+  *mn = shift - c.h_scal[0]; *mx = c.h_scal[1] - shift;
+  VDN_CATCH
+}
+
+// ================================================================================================
+// multifab_fill_boundary: ghost points (outside the fab's own valid region) that lie inside another
+// box's valid region -- directly or through a periodic shift -- are copied from it.
+// One kernel per (dst, src, shift) descriptor batch.
+// ================================================================================================
+struct CopyDesc { FV dst, src; int lo[3], hi[3]; int sh[3]; int vlo[3], vhi[3]; };
+
+__global__ void k_fill_boundary(const CopyDesc *descs, int nc) {
+  const CopyDesc &D = descs[blockIdx.z];
+  const int nx = D.hi[0] - D.lo[0] + 1, ny = D.hi[1] - D.lo[1] + 1, nz = D.hi[2] - D.lo[2] + 1;
+  const long tot = (long)nx * ny * nz;
+  for (long t = (long)blockIdx.x * blockDim.x + threadIdx.x; t < tot; t += (long)gridDim.x * blockDim.x) {
+    int i = D.lo[0] + (int)(t % nx), j = D.lo[1] + (int)((t / nx) % ny), k = D.lo[2] + (int)(t / ((long)nx * ny));
+    bool inside = i >= D.vlo[0] && i <= D.vhi[0] && j >= D.vlo[1] && j <= D.vhi[1] && k >= D.vlo[2] && k <= D.vhi[2];
+    if (inside) continue;
+    for (int c = 0; c < nc; c++) fv_at(D.dst, i, j, k, c) = fv_get(D.src, i - D.sh[0], j - D.sh[1], k - D.sh[2], c);
+  }
+}
+
+void mf_fill_boundary(vdn_multifab *mf) {
+  if (mf->ng == 0) return;
+  const vdn_layout *la = mf->la;
+  REQUIRE(g_ctx.nranks == 1 || la->boxes[mf->lev].size() == la->local[mf->lev].size(),
+          "fill_boundary across ranks is not wired in this build");
+  std::vector<CopyDesc> descs;
+  const vdn_box &pd = la->pd[mf->lev];
+  int per[3]; for (int d = 0; d < 3; d++) per[d] = pd.hi[d] - pd.lo[d] + 1;
+  int nshift[3]; for (int d = 0; d < 3; d++) nshift[d] = la->pmask[d] ? 1 : 0;
+  for (int i = 0; i < mf->nfabs(); i++) {
+    int glo[3], ghi[3], vlo[3], vhi[3];
+    for (int d = 0; d < 3; d++) { vlo[d] = mf->vbox[i].lo[d]; vhi[d] = mf->vbox[i].hi[d] + mf->nodal[d]; glo[d] = vlo[d] - mf->ng; ghi[d] = vhi[d] + mf->ng; }
+    for (int jx = 0; jx < mf->nfabs(); jx++)
+      for (int sz = -nshift[2]; sz <= nshift[2]; sz++) for (int sy = -nshift[1]; sy <= nshift[1]; sy++) for (int sx = -nshift[0]; sx <= nshift[0]; sx++) {
+        if (jx == i && sx == 0 && sy == 0 && sz == 0) continue;
+        int sh[3] = { sx * per[0], sy * per[1], sz * per[2] };
+        CopyDesc D; memset(&D, 0, sizeof D); bool empty = false;
+        for (int d = 0; d < 3; d++) {
+          int slo = mf->vbox[jx].lo[d] + sh[d], shi = mf->vbox[jx].hi[d] + mf->nodal[d] + sh[d];
+          D.lo[d] = std::max(glo[d], slo); D.hi[d] = std::min(ghi[d], shi);
+          if (D.lo[d] > D.hi[d]) empty = true;
+          D.sh[d] = sh[d]; D.vlo[d] = vlo[d]; D.vhi[d] = vhi[d];
+        }
+        if (empty) continue;
+        // skip regions entirely inside the destination's valid region
+        bool all_inside = true;
+        for (int d = 0; d < 3; d++) if (D.lo[d] < vlo[d] || D.hi[d] > vhi[d]) all_inside = false;
+        if (all_inside) continue;
+        D.dst = mf->fabs[i]; D.src = mf->fabs[jx];
+        descs.push_back(D);
+      }
+  }
+  if (descs.empty()) return;
+  // the descriptor table is cached on the device per (allocation, shape): temporaries from the
+  // arena get the same addresses every step, so steady-state steps upload nothing (the analogue of
+  // FBoxLib's cached copyassoc, reference src/main.f90:23,39-47)
+  struct Key { const void *base; const void *la; int lev, nc, ng, nd; bool operator<(const Key &o) const {
+    return std::tie(base, la, lev, nc, ng, nd) < std::tie(o.base, o.la, o.lev, o.nc, o.ng, o.nd); } };
+  struct Val { CopyDesc *d; size_t n; std::vector<CopyDesc> h; };
+  static std::map<Key, Val> cache;
+  Key key{ mf->base, mf->la, mf->lev, mf->nc, mf->ng, mf->nodal[0] | (mf->nodal[1] << 1) | (mf->nodal[2] << 2) };
+  auto it = cache.find(key);
+  bool same = it != cache.end() && it->second.n == descs.size() &&
+              memcmp(it->second.h.data(), descs.data(), descs.size() * sizeof(CopyDesc)) == 0;
+  if (!same) {
+    if (it != cache.end()) { HIPCHK(hipFree(it->second.d)); cache.erase(it); }
+    Val v; v.n = descs.size(); v.h = descs;
+    HIPCHK(hipMalloc((void **)&v.d, descs.size() * sizeof(CopyDesc)));
+    HIPCHK(hipMemcpyAsync(v.d, v.h.data(), descs.size() * sizeof(CopyDesc), hipMemcpyHostToDevice, g_ctx.stream));
+    HIPCHK(hipStreamSynchronize(g_ctx.stream));
+    it = cache.emplace(key, std::move(v)).first;
+  }
+  hipLaunchKernelGGL(k_fill_boundary, dim3(64, 1, (unsigned)descs.size()), dim3(256), 0, g_ctx.stream, it->second.d, mf->nc);
+}
+extern "C" int vdn_multifab_fill_boundary(vdn_multifab *mf) { VDN_TRY mf_fill_boundary(mf); VDN_CATCH }
+
+// ================================================================================================
+// multifab_physbc  (multifab_physbc.f90:238-561)
+// ================================================================================================
+struct PhysArgs {
+  int lo[3], hi[3], ng;
+  int d, s;            // face
+  int t1, t2;          // transverse directions (t1 < t2)
+  int r1lo, r1hi, r2lo, r2hi;
+  int bc; double ev;   // bc code, EXT_DIR value
+  int comp;
+};
+__global__ void k_physbc(FV f, PhysArgs A) {
+  int b1 = A.r1lo + (int)(blockIdx.x * blockDim.x + threadIdx.x);
+  int b2 = A.r2lo + (int)(blockIdx.y * blockDim.y + threadIdx.y);
+  if (b1 > A.r1hi || b2 > A.r2hi) return;
+  int q[3]; q[A.t1] = b1; q[A.t2] = b2;
+  const int edge = A.s == 0 ? A.lo[A.d] : A.hi[A.d];
+  const int in = A.s == 0 ? 1 : -1;
+  double v = 0.0;
+  if (A.bc == VDN_FOEXTRAP) { q[A.d] = edge; v = fv_get(f, q[0], q[1], q[2], A.comp); }
+  else if (A.bc == VDN_HOEXTRAP) {
+    q[A.d] = edge;          double s0 = fv_get(f, q[0], q[1], q[2], A.comp);
+    q[A.d] = edge + in;     double s1 = fv_get(f, q[0], q[1], q[2], A.comp);
+    q[A.d] = edge + 2 * in; double s2 = fv_get(f, q[0], q[1], q[2], A.comp);
+    v = (15.0 * s0 - 10.0 * s1 + 3.0 * s2) * 0.125;
+  } else if (A.bc == VDN_EXT_DIR) v = A.ev;
+  for (int g = 1; g <= A.ng; g++) {
+    if (A.bc == VDN_REFLECT_EVEN || A.bc == VDN_REFLECT_ODD) {
+      q[A.d] = edge + in * (g - 1);
+      v = fv_get(f, q[0], q[1], q[2], A.comp);
+      if (A.bc == VDN_REFLECT_ODD) v = -v;
+    }
+    q[A.d] = edge - in * g;
+    fv_at(f, q[0], q[1], q[2], A.comp) = v;
+  }
+}
+
+static bool extdir_value(int icomp1, int d, int s, double *v) {
+  const vdn_params &p = g_ctx.prm;
+  switch (icomp1) {               // multifab_physbc.f90:282-287
+    case 1: *v = p.u_bc[d][s]; return true;
+    case 2: *v = p.v_bc[d][s]; return true;
+    case 3: *v = p.w_bc[d][s]; return true;
+    case 4: *v = p.rho_bc[d][s]; return true;
+    case 5: *v = p.trac_bc[d][s]; return true;
+  }
+  return false;
+}
+
+void mf_physbc(vdn_multifab *mf, int scomp, int bccomp, int nc, const vdn_bc_tower *bct, bool same_boundary) {
+  if (mf->ng == 0) return;
+  REQUIRE(!mf->nodal[0] && !mf->nodal[1] && !mf->nodal[2], "physbc on a nodal multifab");
+  for (int i = 0; i < mf->nfabs(); i++) for (int c = 0; c < nc; c++) {
+    const int bcc = same_boundary ? bccomp : bccomp + c;
+    REQUIRE(bcc < bct->ncomp_adv, "physbc: bc component %d out of range", bcc);
+    int bc[3][2];
+    for (int d = 0; d < 3; d++) for (int s = 0; s < 2; s++) bc[d][s] = bct->adv_bc(mf->lev, i + 1, d, s, bcc);
+    const int *lo = mf->vbox[i].lo, *hi = mf->vbox[i].hi;
+    const int ng = mf->ng;
+    for (int d = 0; d < 3; d++) for (int s = 0; s < 2; s++) {
+      int b = bc[d][s];
+      if (b == VDN_INTERIOR) continue;
+      PhysArgs A;
+      for (int t = 0; t < 3; t++) { A.lo[t] = lo[t]; A.hi[t] = hi[t]; }
+      A.ng = ng; A.d = d; A.s = s; A.bc = b; A.ev = 0.0; A.comp = scomp + c;
+      A.t1 = (d == 0) ? 1 : 0; A.t2 = (d == 2) ? 1 : 2;
+      if (b == VDN_EXT_DIR) { if (!extdir_value(bcc + 1, d, s, &A.ev)) continue; }
+      else REQUIRE(b == VDN_FOEXTRAP || b == VDN_HOEXTRAP || b == VDN_REFLECT_EVEN || b == VDN_REFLECT_ODD,
+                   "physbc: bc(%d,%d) = %d NOT YET SUPPORTED", d + 1, s + 1, b);
+      // transverse ranges (254-276): EXT_DIR covers everything; otherwise directions after d skip
+      // their ghost layers on physical sides
+      int rlo[3], rhi[3];
+      for (int t = 0; t < 3; t++) {
+        int nlo = ng, nhi = ng;
+        if (b != VDN_EXT_DIR && t > d) { nlo = (bc[t][0] == VDN_INTERIOR) ? ng : 0; nhi = (bc[t][1] == VDN_INTERIOR) ? ng : 0; }
+        rlo[t] = lo[t] - nlo; rhi[t] = hi[t] + nhi;
+      }
+      A.r1lo = rlo[A.t1]; A.r1hi = rhi[A.t1]; A.r2lo = rlo[A.t2]; A.r2hi = rhi[A.t2];
+      dim3 blk(64, 4, 1), grd((A.r1hi - A.r1lo + 64) / 64, (A.r2hi - A.r2lo + 4) / 4, 1);
+      hipLaunchKernelGGL(k_physbc, grd, blk, 0, g_ctx.stream, mf->fabs[i], A);
+    }
+  }
+}
+extern "C" int vdn_multifab_physbc(vdn_multifab *mf, int scomp, int bccomp, int nc, const vdn_bc_tower *bct) {
+  VDN_TRY mf_physbc(mf, scomp, bccomp, nc, bct, false); VDN_CATCH
+}
+
+void mf_restrict_and_fill(vdn_multifab *mf, int icomp, int bcomp, int nc, bool same_boundary, const vdn_bc_tower *bct) {
+  mf_fill_boundary(mf);
+  mf_physbc(mf, icomp, bcomp, nc, bct, same_boundary);
+}

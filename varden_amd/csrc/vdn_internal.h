@@ -1,0 +1,147 @@
+// vdn_internal.h -- host-side data model of the MI355X-native VARDEN hot path (private to csrc/).
+//
+// box / layout / multifab / bc_tower mirror the FBoxLib containers the reference's hot path takes
+// (reference evidence of the layout: src/mkflux.f90:74-92, src/define_bc_tower.f90:9-33).
+// State lives in HBM for the whole run; per-step temporaries come from a persistent arena so a step
+// performs no hipMalloc/hipFree (the reference allocates ~25 multifabs per step,
+// src/advance_timestep.f90:65-80,141-148).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <string>
+#include <vector>
+#include <map>
+#include <cstdio>
+#include <cstdarg>
+#include <cstring>
+#include <stdexcept>
+#include "../../include/varden_amd.h"
+
+// ---- device-visible views ---------------------------------------------------------------------
+// one fab: p(alo0:, alo1:, alo2:, 0:nc-1), x fastest.  alo = valid lo - ng.
+struct FV {
+  double *p;
+  int a0, a1, a2;     // lowest allocated index per direction
+  int n0, n1, n2;     // allocated extents
+  long sc;            // component stride
+};
+// index-space description of one box and its physical bcs, passed by value to kernels
+struct BoxP {
+  int lo[3], hi[3];   // valid cell box
+  int phys[3][2];     // phys_bc_level_array(i,:,:)  (INTERIOR on faces inside the domain)
+};
+
+#define VDN_MAXCOMP 16
+
+// ---- host structures ---------------------------------------------------------------------------
+struct vdn_layout {
+  int nlev = 0;
+  std::vector<int> rr;                       // [nlev-1][3]
+  std::vector<vdn_box> pd;                   // [nlev]
+  std::vector<std::vector<vdn_box>> boxes;   // [lev][global box]
+  std::vector<std::vector<int>> owner;       // [lev][global box]
+  std::vector<std::vector<int>> local;       // [lev][local i] -> global index
+  int pmask[3] = {0, 0, 0};
+};
+
+struct vdn_multifab {
+  const vdn_layout *la = nullptr;
+  int lev = 0, nc = 1, ng = 0;
+  int nodal[3] = {0, 0, 0};
+  double *base = nullptr;                    // one allocation for all local fabs
+  bool owns = true;                          // false: memory belongs to the arena
+  size_t bytes = 0;
+  std::vector<FV> fabs;                      // per local box
+  std::vector<vdn_box> vbox;                 // valid cell box per local box
+  int nfabs() const { return (int)fabs.size(); }
+  long fab_size(int i) const { return fabs[i].sc * nc; }
+};
+
+struct vdn_bc_tower {
+  const vdn_layout *la = nullptr;
+  int dm = 3, nscal = 2;
+  int ncomp_adv = 0, ncomp_ell = 0;
+  // [lev][grid (0 = domain, 1.. = local boxes)]
+  std::vector<std::vector<BoxP>> phys;                       // only .phys used
+  std::vector<std::vector<std::vector<int>>> adv;            // [lev][grid][ (d*2+s)*ncomp_adv + c ]
+  std::vector<std::vector<std::vector<int>>> ell;
+  int domain_bc[3][2];
+  int press_comp0() const { return dm + nscal; }             // 0-based
+  int extrap_comp0() const { return dm + nscal + 1; }
+  int adv_bc(int lev, int grid, int d, int s, int c) const { return adv[lev][grid][(d * 2 + s) * ncomp_adv + c]; }
+  int ell_bc(int lev, int grid, int d, int s, int c) const { return ell[lev][grid][(d * 2 + s) * ncomp_ell + c]; }
+};
+
+// ---- global context ----------------------------------------------------------------------------
+struct VdnCtx {
+  bool inited = false;
+  vdn_params prm;
+  int rank = 0, nranks = 1, device = 0;
+  hipStream_t stream = 0;
+  // persistent arena for per-step temporaries (bump allocator, reset at the start of each public call)
+  char *arena = nullptr; size_t arena_bytes = 0, arena_off = 0;
+  // small device scratch for reductions + pinned host mirror
+  double *d_scal = nullptr; double *h_scal = nullptr;       // 64 doubles each
+  double step_sec[5] = {0, 0, 0, 0, 0};
+  int solver_cycles[2] = {0, 0}; double solver_res0[2] = {0, 0}, solver_res[2] = {0, 0};
+};
+VdnCtx &ctx();
+
+// error handling: C-ABI functions wrap their body in VDN_TRY/VDN_CATCH
+void vdn_set_error(const char *fmt, ...);
+struct VdnErr : std::runtime_error { using std::runtime_error::runtime_error; };
+[[noreturn]] void vdn_fail(const char *fmt, ...);
+#define HIPCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) vdn_fail("%s failed: %s (%s:%d)", #x, hipGetErrorString(e_), __FILE__, __LINE__); } while (0)
+#define VDN_TRY try {
+#define VDN_CATCH } catch (const std::exception &e) { vdn_set_error("%s", e.what()); return 1; } return 0;
+#define REQUIRE(c, ...) do { if (!(c)) vdn_fail(__VA_ARGS__); } while (0)
+
+// arena
+void  arena_reset();
+void  arena_reserve(size_t bytes);
+void  arena_reserve_for(const vdn_layout *la);
+void *arena_alloc(size_t bytes);
+size_t arena_mark();
+void  arena_release(size_t mark);
+// temporary multifab living in the arena (freed by arena_release/reset); filled with val if fill
+vdn_multifab *mf_temp(const vdn_layout *la, int lev, int nc, int ng, int face_dir /* -1 cell, 0..2 face, 3 nodal */,
+                      bool fill, double val);
+void mf_temp_free(vdn_multifab *mf);
+
+// helpers shared between translation units
+BoxP make_boxp(const vdn_multifab *mf, int i, const vdn_bc_tower *bct);
+void mf_setval(vdn_multifab *mf, double val, int comp, int nc, bool all);
+void mf_fill_boundary(vdn_multifab *mf);
+void mf_physbc(vdn_multifab *mf, int scomp, int bccomp, int nc, const vdn_bc_tower *bct, bool same_boundary = false);
+void mf_copy(vdn_multifab *dst, int dcomp, const vdn_multifab *src, int scomp, int nc, int ng);
+double mf_norm_inf(const vdn_multifab *mf, int comp, int nc);
+// ml_restrict_and_fill on one level = fill_boundary + physbc
+void mf_restrict_and_fill(vdn_multifab *mf, int icomp, int bcomp, int nc, bool same_boundary, const vdn_bc_tower *bct);
+
+// godunov.hip
+void k_velpred(const vdn_multifab *u, vdn_multifab **umac, const vdn_multifab *force, const double *dx, double dt,
+               const vdn_bc_tower *bct);
+void k_mkflux(const vdn_multifab *s, vdn_multifab **sedge, vdn_multifab **flux, vdn_multifab **umac,
+              const vdn_multifab *force, const vdn_multifab *mac_rhs, const double *dx, double dt,
+              const vdn_bc_tower *bct, bool is_vel, const int *is_cons);
+void k_slope(const vdn_multifab *s, vdn_multifab *slope, int dir, int bccomp, const vdn_bc_tower *bct);
+// pointwise.hip
+void k_update(const vdn_multifab *sold, vdn_multifab **umac, vdn_multifab **sedge, vdn_multifab **flux,
+              const vdn_multifab *force, vdn_multifab *snew, const double *dx, double dt, bool is_vel, const int *is_cons);
+void k_mkvelforce(vdn_multifab *vf, const vdn_multifab *ext, const vdn_multifab *s, const vdn_multifab *gp,
+                  const vdn_multifab *lapu, double visc_fac);
+void k_mkscalforce(vdn_multifab *sf, const vdn_multifab *ext, const vdn_multifab *laps, double diff_fac);
+void k_make_at_halftime(vdn_multifab *rhohalf, const vdn_multifab *sold, const vdn_multifab *snew, int in_comp, int out_comp);
+void k_estdt_max(const vdn_multifab *u, const vdn_multifab *s, const vdn_multifab *gp, const vdn_multifab *ext, double out6[6]);
+// macproject.hip / mg_cc.hip
+void do_macproject(vdn_layout *mla, vdn_multifab **umac, vdn_multifab **rho, vdn_multifab **mac_rhs, const double *dx,
+                   const vdn_bc_tower *bct, int bc_comp0);
+int  cc_solve(vdn_multifab *rh, vdn_multifab *phi, vdn_multifab **beta, const double *dx, const int bc[3][2],
+              double rel_eps, double abs_eps, int max_iter, int *cycles, double *res0, double *res);
+void cc_smooth(vdn_multifab *rh, vdn_multifab *phi, vdn_multifab **beta, const double *dx, const int bc[3][2], int nsweeps);
+void cc_bench_smoother(vdn_multifab *rh, vdn_multifab *phi, vdn_multifab **beta, const double *dx, const int bc[3][2],
+                       int nlaunch, double *avg_ms, long *cells);
+// hgproject.hip / mg_nd.hip
+void do_hgproject(int proj_type, vdn_layout *mla, vdn_multifab **unew, vdn_multifab **uold, vdn_multifab **rhohalf,
+                  vdn_multifab **p, vdn_multifab **gp, const double *dx, double dt, const vdn_bc_tower *bct, int press_comp0);
+int  nd_solve(vdn_multifab *rh, vdn_multifab *phi, const vdn_multifab *coeffs, const vdn_multifab *u, const double *dx,
+              const int bc[3][2], double rel_eps, double abs_eps, int max_iter, int *cycles, double *res0, double *res);

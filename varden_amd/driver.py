@@ -1,0 +1,107 @@
+"""Thin single-level driver around the hot path: what reference src/varden.f90 does around
+``advance_timestep`` (initial projection 126-138, ghost fills 165-178 / 291-300, estdt 186-199 /
+302-318, initial pressure iterations 460-490, the step loop 237-345), with every array in HBM.
+
+The driver is NOT the product of this round (SURVEY.md section 8 marks it "next"); it exists so that the
+hot path can be exercised and timed exactly the way the reference calls it.
+"""
+import numpy as np
+
+from . import advance as adv
+from . import boxlib as bl
+from .capi import default_params
+
+
+def initdata_numpy(n, dx, prob_type=1, ng=3, nscal=2):
+    """reference src/initdata.f90:212-259 (prob_type 1 bubble / 2 advected blob), numpy restatement used
+    for synthetic bench input."""
+    u = np.zeros(tuple(x + 2 * ng for x in n) + (3,), order="F")
+    s = np.zeros(tuple(x + 2 * ng for x in n) + (nscal,), order="F")
+    s[..., 0] = 1.0
+    if prob_type == 2:
+        u[..., 0] = 1.0
+    x = dx[0] * (np.arange(n[0]) + 0.5)
+    y = dx[1] * (np.arange(n[1]) + 0.5)
+    z = dx[2] * (np.arange(n[2]) + 0.5)
+    X, Y, Z = np.meshgrid(x, y, z, indexing="ij")
+    dist = np.sqrt((X - 0.5) ** 2 + (Y - 0.5) ** 2 + (Z - 0.5) ** 2)
+    r = 1.0 + 0.5 * (10.0 - 1.0) * (1.0 - np.tanh(30.0 * (dist - 0.1)))
+    g = ng
+    s[g:-g, g:-g, g:-g, 0] = r
+    if nscal > 1:
+        s[g:-g, g:-g, g:-g, 1] = r
+    return u, s
+
+
+class Varden:
+    def __init__(self, n, phys_bc, params=None, prob_type=1, grav=-9.8, prob_hi=(1.0, 1.0, 1.0), init_shrink=1.0,
+                 init_iter=4, do_initial_projection=1, u0=None, s0=None, device=0, max_grid_size=None):
+        self.n = tuple(int(x) for x in (n if hasattr(n, "__len__") else (n, n, n)))
+        self.prm = params or default_params()
+        self.prm.prob_type = prob_type
+        bl.initialize(self.prm, 0, 1, device)
+        self.phys = [[int(phys_bc[d][s]) for s in range(2)] for d in range(3)]
+        pmask = tuple(1 if self.phys[d][0] == bl.PERIODIC else 0 for d in range(3))
+        lo, hi = (0, 0, 0), tuple(x - 1 for x in self.n)
+        self.mla = bl.MLLayout([(lo, hi)], [[(lo, hi)]], pmask=pmask)
+        self.bct = bl.BCTower(self.mla, self.phys)
+        self.dx = [[prob_hi[d] / self.n[d] for d in range(3)]]
+        dm, ns = 3, self.prm.nscal
+        self.dm, self.nscal, self.press_comp = dm, ns, dm + ns + 1
+        mk = lambda nc, ng, nodal=None: [bl.MultiFab(self.mla, 0, nc, ng, nodal)]   # noqa: E731
+        self.uold, self.sold, self.unew, self.snew = mk(dm, 3), mk(ns, 3), mk(dm, 3), mk(ns, 3)
+        self.gp, self.p = mk(dm, 1), mk(1, 1, (1, 1, 1))
+        self.ext_vel_force, self.ext_scal_force = mk(dm, 1), mk(ns, 1)
+        self.ext_vel_force[0].setval(grav, dm - 1, 1, all=True)                    # varden.f90:428-429
+        if u0 is None:
+            u0, s0 = initdata_numpy(self.n, self.dx[0], prob_type, 3, ns)
+        self.uold[0].from_numpy(u0)
+        self.sold[0].from_numpy(s0)
+        self.time, self.dt, self.istep = 0.0, 0.0, 0
+        self.fill_state_ghosts()                                                   # initdata.f90:52-56
+        if do_initial_projection:                                                  # varden.f90:126-138
+            rhohalf = mk(1, 1)
+            rhohalf[0].setval(1.0, all=True)
+            adv.hgproject(bl.INITIAL_PROJECTION, self.mla, self.uold, self.uold, rhohalf, self.p, self.gp, self.dx, 1.0,
+                          self.bct, self.press_comp)
+            self.initial_projection_stat = adv.last_solver_stats("hg")
+            rhohalf[0].destroy()
+        self.p[0].setval(0.0, all=True)
+        self.gp[0].setval(0.0, all=True)
+        self.fill_state_ghosts()                                                   # varden.f90:165-172
+        self.unew[0].copy_c(0, self.uold[0], 0, dm, 3)                             # varden.f90:175-176
+        self.snew[0].copy_c(0, self.sold[0], 0, ns, 3)
+        self.dt = self.estdt(1.0e20) * init_shrink                                 # varden.f90:186-194
+        for it in range(init_iter):                                                # varden.f90:460-490
+            self.advance(bl.PRESSURE_ITERS, it + 1)
+
+    def fill_state_ghosts(self):
+        for mf in (self.uold[0], self.sold[0], self.gp[0]):
+            mf.fill_boundary()
+        self.uold[0].physbc(0, 0, self.dm, self.bct)
+        self.sold[0].physbc(0, self.dm, self.nscal, self.bct)
+
+    def estdt(self, dtold):
+        return adv.estdt(1, self.uold[0], self.sold[0], self.gp[0], self.ext_vel_force[0], self.dx[0], dtold)
+
+    def advance(self, proj_type=bl.REGULAR_TIMESTEP, istep=0):
+        adv.advance_timestep(istep, self.mla, self.sold, self.uold, self.snew, self.unew, self.gp, self.p,
+                             self.ext_vel_force, self.ext_scal_force, self.bct, self.dt, self.time, self.dx,
+                             self.press_comp, proj_type)
+
+    def step(self):
+        """one pass of the time-loop body, varden.f90:291-328"""
+        self.istep += 1
+        self.fill_state_ghosts()
+        if self.istep > 1:
+            self.dt = self.estdt(self.dt)
+        self.advance(bl.REGULAR_TIMESTEP, self.istep)
+        self.uold[0].copy_c(0, self.unew[0], 0, self.dm, 0)
+        self.sold[0].copy_c(0, self.snew[0], 0, self.nscal, 0)
+        self.time += self.dt
+
+    def close(self):
+        for lst in (self.uold, self.sold, self.unew, self.snew, self.gp, self.p, self.ext_vel_force, self.ext_scal_force):
+            lst[0].destroy()
+        self.bct.destroy()
+        self.mla.destroy()
