@@ -1,0 +1,154 @@
+#!/usr/bin/env python
+"""bench.py -- cells*steps/sec of advance_timestep on the MI355X-native hot path.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--n 256] [--no-cpu]
+
+Workload (BASELINE.json configs[1]): 3-D 256^3 single-level variable-density bubble
+(reference src/initdata.f90:212-238, exec/test/inputs_bubble_3d with visc_coef = 0), one 256^3 box,
+no-slip walls, gravity -9.8, cflfac 0.9, init_shrink 0.1, init_iter 1; MAC + HG projection every
+step.  A "step" = one pass of the reference's time-loop body (src/varden.f90:291-328): ghost fills,
+estdt, advance_timestep, uold<-unew.  All state is resident in HBM before the timed region.
+
+One JSON line is printed by rank 0.  `roofline` is the MAC-multigrid red-black Gauss-Seidel colour
+pass on the finest level (48 algorithmic B/cell/pass), timed with HIP events on the launch
+stream inside the library; `cpu_baseline` is the CPU oracle (a port, OpenMP) on a bounded sample.
+For N > 1 this round runs N independent replicas (one box per rank, no ghost exchange): the
+domain-decomposed path is not implemented yet and the line says so in config.parallelism.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0   # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--n", type=int, default=256)
+    ap.add_argument("--cpu-n", type=int, default=128)
+    ap.add_argument("--no-cpu", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    assert torch.cuda.is_available(), "bench.py needs a GPU: the product path has no CPU fallback"
+
+    from varden_amd import advance as adv
+    from varden_amd import boxlib as bl
+    from varden_amd import driver
+    from varden_amd.capi import default_params
+
+    n = args.n
+    walls = [[bl.NO_SLIP_WALL] * 2] * 3
+    prm = default_params(cflfac=0.9)
+    G = driver.Varden(n, walls, prm, prob_type=1, grav=-9.8, init_shrink=0.1, init_iter=1, device=local_rank)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        G.step()
+    barrier()
+    t0 = time.perf_counter()
+    phases = dict(scalar=0.0, velocity=0.0, mac=0.0, hg=0.0, total=0.0)
+    cyc = dict(mac=0, hg=0)
+    for _ in range(args.steps):
+        G.step()
+        for k, v in adv.last_step_timing().items():
+            phases[k] += v
+        cyc["mac"] += adv.last_solver_stats("mac")[0]
+        cyc["hg"] += adv.last_solver_stats("hg")[0]
+    barrier()
+    el = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([el], device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        el = float(t.item())
+
+    cells = n ** 3 * world
+    value = cells * args.steps / el
+
+    # ---- roofline of the dominant kernel: one colour pass of the MAC-MG smoother at n^3 ----------
+    roof = None
+    if rank == 0:
+        mla, bct = G.mla, G.bct
+        rh, phi = bl.MultiFab(mla, 0, 1, 0), bl.MultiFab(mla, 0, 1, 1)
+        beta = [bl.MultiFab(mla, 0, 1, 0, tuple(1 if t == d else 0 for t in range(3))) for d in range(3)]
+        import numpy as np
+        rho = G.sold[0].to_numpy()[..., 0]
+        for d in range(3):      # beta = 2/(rho_i + rho_{i-1})  (macproject.f90:376-394), built on the host for the probe
+            sl_hi = [slice(3, -3)] * 3
+            sl_lo = [slice(3, -3)] * 3
+            sl_hi[d] = slice(3, rho.shape[d] - 2)
+            sl_lo[d] = slice(2, rho.shape[d] - 3)
+            beta[d].from_numpy((2.0 / (rho[tuple(sl_hi)] + rho[tuple(sl_lo)]))[..., None])
+        rng = np.random.default_rng(0)
+        r = rng.standard_normal((n, n, n, 1))
+        rh.from_numpy(r - r.mean())
+        bc = [[bl.BC_NEU] * 2] * 3
+        ms, ncell = adv.bench_cc_smoother(rh, phi, beta, G.dx[0], bc, 200)
+        alg_bytes = 48.0 * ncell
+        achieved = alg_bytes / (ms * 1e-3) / 1e9
+        roof = {"bound": "hbm", "kernel": "kk_cc_gsrb (MAC-MG red-black GS colour pass, %d^3)" % n,
+                "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                "avg_launch_ms": round(ms, 5), "alg_bytes_per_launch": alg_bytes}
+        for m in [rh, phi] + beta:
+            m.destroy()
+
+    # ---- CPU baseline: the oracle (a port of the same algorithm, OpenMP) on a bounded sample ------
+    cpu = None
+    if rank == 0 and not args.no_cpu:
+        nthreads = min(16, os.cpu_count() or 1)
+        os.environ["OMP_NUM_THREADS"] = str(nthreads)
+        from oracle import voracle as vo
+        cn = args.cpu_n
+        O = vo.Sim(cn, walls, default_params(cflfac=0.9), prob_type=1, grav=-9.8, init_shrink=0.1, init_iter=1)
+        tc = time.perf_counter()
+        O.step()
+        tcpu = time.perf_counter() - tc
+        cpu = {"value": round(cn ** 3 / tcpu, 1), "unit": "cells*steps/s", "cores": nthreads, "kind": "port",
+               "sample": "%d^3 bubble (same problem, smaller box), 1 timed step after the initial pressure iteration; "
+                         "gcc -O2 -fopenmp, OMP_NUM_THREADS=%d" % (cn, nthreads)}
+
+    if rank == 0:
+        out = {
+            "metric": "cells*steps/sec on advance_timestep",
+            "value": round(value, 1), "unit": "cells*steps/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(1e3 * el / args.steps, 3),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f64", "data": "synthetic",
+            "config": {"workload": "3D %d^3 single-level variable-density bubble, 1 box/GPU, MAC+HG projection each step "
+                                   "(BASELINE.json configs[1])" % n,
+                       "parallelism": "single GPU" if world == 1 else
+                                      "%d independent replicas (no ghost exchange; domain decomposition not implemented in round 1)" % world,
+                       "phase_ms_per_step": {k: round(1e3 * v / args.steps, 3) for k, v in phases.items()},
+                       "vcycles_per_step": {k: round(v / args.steps, 2) for k, v in cyc.items()}},
+            "roofline": roof, "cpu_baseline": cpu,
+        }
+        print(json.dumps(out))
+    G.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -17,8 +17,8 @@
  *
  * ALGORITHM (ours): V(nu1,nu2) cycles with damped-Jacobi smoothing (one pass per sweep: the GPU-
  * friendly choice), full-weighting restriction (= P^T/8), trilinear prolongation,
- * coarse sigma = mean of the 8 children, coarsening while every extent is even and > 2, `nub`
- * Jacobi sweeps on the coarsest level.  Convergence: ||rh + K phi||_inf <= rel*||rh||_inf or <= abs,
+ * coarse sigma = mean of the 8 children, coarsening while every extent is even and > 2,
+ * max(nub, 2 N^2) Jacobi sweeps on the coarsest level (N = its largest extent).  Convergence: ||rh + K phi||_inf <= rel*||rh||_inf or <= abs,
  * tested on the residual computed after pre-smoothing, at most max_iter cycles.
  */
 #include <math.h>
@@ -278,12 +278,19 @@ static void nd_set_mask(ndlev *L, const int ellbc[3][2])
 
 typedef struct ndmg { int nlev; ndlev lev[32]; int per[3]; } ndmg;
 
+/* Jacobi sweeps on the coarsest level: max(nub, 2 N^2), N = its largest extent (see cc_bottom_sweeps) */
+static int nd_bottom_sweeps(const ndlev *L, int nub)
+{
+  int N = L->n[0] > L->n[1] ? L->n[0] : L->n[1]; if (L->n[2] > N) N = L->n[2];
+  return nub > 2 * N * N ? nub : 2 * N * N;
+}
+
 static void nd_vcycle(ndmg *M, int l, int nu1, int nu2, int nub, double omega)
 {
   ndlev *L = &M->lev[l];
   long nn = (long)(L->n[0] + 3) * (L->n[1] + 3) * (L->n[2] + 3);
   memset(L->phi, 0, sizeof(double) * nn);
-  if (l == M->nlev - 1) { nd_jacobi(L, M->per, nub, omega); return; }
+  if (l == M->nlev - 1) { nd_jacobi(L, M->per, nd_bottom_sweeps(L, nub), omega); return; }
   nd_jacobi(L, M->per, nu1, omega);
   (void)nd_residual(L, M->per);
   nd_restrict(L, &M->lev[l + 1]);
@@ -348,7 +355,7 @@ int vo_nd_solve(vo_fab *rh, vo_fab *phi, const vo_fab *coeffs, const vo_fab *u, 
   int cyc = 0, conv = 0; double rn = 0.0;
   if (bnorm == 0.0) conv = 1;
   while (!conv) {
-    nd_jacobi(L0, M.per, M.nlev == 1 ? nub : nu1, omega);
+    nd_jacobi(L0, M.per, M.nlev == 1 ? nd_bottom_sweeps(L0, nub) : nu1, omega);
     rn = nd_residual(L0, M.per);
     if (rn <= rel_eps * bnorm || rn <= abs_eps) { conv = 1; break; }
     if (cyc >= max_iter) break;

@@ -11,8 +11,8 @@
  *
  * The ALGORITHM is ours (F_MG is not in the reference tree): V(nu1,nu2) cycles, red-black
  * Gauss-Seidel smoothing, 8-cell average restriction, piecewise-constant prolongation, coarse
- * b = average of the 4 fine faces, coarsening while every extent is even and > 2, `nub` sweeps on
- * the coarsest level; convergence is tested on the residual the cycle computes after its
+ * b = average of the 4 fine faces, coarsening while every extent is even and > 2, max(nub, N^2) sweeps
+ * on the coarsest level (N = its largest extent); convergence is tested on the residual the cycle computes after its
  * pre-smoothing:  ||r||_inf <= rel_eps*||rh||_inf  or  <= abs_eps.
  * The HIP solver (varden_amd/csrc/mg_cc.hip) implements the same algorithm with the same
  * expression order, so the two agree to round-off of the max-norm test (bit-exact in practice).
@@ -226,12 +226,22 @@ static void ccmg_build(ccmg *M, vo_fab *beta[3], const double dx[3], const int e
 static void ccmg_free(ccmg *M) { for (int l = 0; l < M->nlev; l++) cc_free(&M->lev[l]); }
 
 /* coarse-grid correction below level l (error equation, zero initial guess) */
+/* sweeps on the coarsest level: `nub`, raised to N^2 (N = its largest extent) so that boxes that stop
+ * coarsening early (non-cubic, or extents with odd factors) still get a bottom solve of ~1e-3 accuracy
+ * (red-black GS on N cells contracts like 1 - pi^2/N^2; the reference asks its bottom solver for 1e-3,
+ * mac_multigrid.f90:56) */
+static int cc_bottom_sweeps(const cclev *L, int nub)
+{
+  int N = L->n[0] > L->n[1] ? L->n[0] : L->n[1]; if (L->n[2] > N) N = L->n[2];
+  return nub > N * N ? nub : N * N;
+}
+
 static void cc_vcycle(ccmg *M, int l, int nu1, int nu2, int nub)
 {
   cclev *L = &M->lev[l];
   long ng = (long)(L->n[0] + 2) * (L->n[1] + 2) * (L->n[2] + 2);
   memset(L->phi, 0, sizeof(double) * ng);
-  if (l == M->nlev - 1) { cc_gsrb(L, M->per, nub); return; }
+  if (l == M->nlev - 1) { cc_gsrb(L, M->per, cc_bottom_sweeps(L, nub)); return; }
   cc_gsrb(L, M->per, nu1);
   (void)cc_residual(L, M->per);
   cc_restrict(L, &M->lev[l + 1]);
@@ -281,7 +291,7 @@ int vo_cc_solve(const vo_fab *rh, vo_fab *phi, vo_fab *beta[3], const double dx[
   int cyc = 0, conv = 0; double rn = 0.0, r0 = -1.0;
   if (bnorm == 0.0) { conv = 1; r0 = 0.0; }
   while (!conv && cyc <= max_iter) {
-    if (M.nlev == 1) cc_gsrb(L0, M.per, nub); else cc_gsrb(L0, M.per, nu1);
+    if (M.nlev == 1) cc_gsrb(L0, M.per, cc_bottom_sweeps(L0, nub)); else cc_gsrb(L0, M.per, nu1);
     rn = cc_residual(L0, M.per);
     if (r0 < 0.0) r0 = rn;
     if (rn <= rel_eps * bnorm || rn <= abs_eps) { conv = 1; break; }

@@ -54,6 +54,10 @@ def lib():
     if _lib is None:
         if not os.path.exists(LIB):
             build()
+        # libgomp sizes its pool from the visible CPUs, which on the GPU boxes is far more than the
+        # cgroup share; oversubscribed spinning threads make the many tiny parallel regions crawl
+        os.environ.setdefault("OMP_NUM_THREADS", str(min(8, os.cpu_count() or 1)))
+        os.environ.setdefault("OMP_WAIT_POLICY", "passive")
         _lib = C.CDLL(LIB)
         _lib.vo_estdt.restype = C.c_double
         _lib.vo_cc_solve.restype = C.c_int

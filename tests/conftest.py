@@ -1,0 +1,28 @@
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run by the driver with -m gpu)")
+
+
+@pytest.fixture(scope="session")
+def oracle():
+    from oracle import voracle
+    voracle.lib()
+    return voracle
+
+
+@pytest.fixture(scope="session")
+def gpu():
+    """initialised HIP runtime; fails loudly (no fallback) when the library or the GPU is missing"""
+    from varden_amd import boxlib, capi
+    capi.load()
+    boxlib.initialize(capi.default_params(), 0, 1, 0)
+    yield boxlib

@@ -1,0 +1,212 @@
+"""GPU parity (through the C-ABI) of every per-box kernel of the hot path against the CPU oracle, on
+seeded inputs and for every boundary-condition family the reference handles.  The bar for the
+Godunov / streaming kernels is BIT-EXACT: the HIP kernels keep the reference's expression order and are
+built with fp-contract off (tolerance 0 ulp)."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from tests.util import BC_SETS, Case, assert_bits
+
+pytestmark = pytest.mark.gpu
+
+
+def face_fabs(case, ng, nc, val=0.0):
+    return [case.ofab(ng, nc, tuple(1 if t == d else 0 for t in range(3)), val) for d in range(3)]
+
+
+@pytest.mark.parametrize("bcname", list(BC_SETS))
+@pytest.mark.parametrize("order", [4, 2, 0])
+def test_slope(gpu, oracle, bcname, order):
+    from varden_amd import advance as adv
+    case = Case((16, 12, 8), BC_SETS[bcname], seed=1, slope_order=order)
+    u, s = case.random_state()
+    for src, bccomp in ((u, 0), (s, 3)):
+        gsrc = case.gmf(src)
+        for d in range(3):
+            osl = case.ofab(1, src.nc)
+            oracle.lib().vo_slope(src.ref, osl.ref, d, src.nc, bccomp, C.byref(case.obc), order)
+            gsl = case.gmf(case.ofab(1, src.nc))
+            adv.slope(gsrc, gsl, d, bccomp, case.bct)
+            assert_bits(gsl.to_numpy(), osl.a, "slope dir %d bc %s order %d" % (d, bcname, order))
+    case.close()
+
+
+def test_slope_minimum_width(gpu, oracle):
+    """boxes exactly 4 cells wide: the lo and hi one-sided corrections interleave (slope.f90:243-283)"""
+    from varden_amd import advance as adv
+    case = Case((4, 4, 4), BC_SETS["walls"], seed=5)
+    u, _ = case.random_state()
+    gu = case.gmf(u)
+    for d in range(3):
+        osl = case.ofab(1, 3)
+        oracle.lib().vo_slope(u.ref, osl.ref, d, 3, 0, C.byref(case.obc), 4)
+        gsl = case.gmf(case.ofab(1, 3))
+        adv.slope(gu, gsl, d, 0, case.bct)
+        assert_bits(gsl.to_numpy(), osl.a, "slope width-4 dir %d" % d)
+    case.close()
+
+
+@pytest.mark.parametrize("bcname", list(BC_SETS))
+@pytest.mark.parametrize("minion", [0, 1])
+def test_velpred(gpu, oracle, bcname, minion):
+    from varden_amd import advance as adv
+    case = Case((16, 12, 8), BC_SETS[bcname], seed=2, use_minion=minion)
+    u, _ = case.random_state()
+    force = case.ofab(1, 3)
+    force.a[...] = case.rng.standard_normal(force.a.shape)
+    oracle.lib().vo_fill_boundary(force.ref, case.opm)      # periodic images, as ml_restrict_and_fill leaves them
+    dt = 0.4 * min(case.dx)
+    oum = face_fabs(case, 1, 1, 1.0e20)
+    oracle.lib().vo_velpred(u.ref, oracle.fab_ptr_array(oum), force.ref, case.odx, C.c_double(dt), C.byref(case.obc), C.byref(case.prm))
+    for f in oum:
+        oracle.lib().vo_fill_boundary(f.ref, case.opm)
+    gum = [case.gmf(f) for f in face_fabs(case, 1, 1, 1.0e20)]
+    adv.velpred(case.gmf(u), gum, case.gmf(force), case.dx, dt, case.bct)
+    for d in range(3):
+        assert_bits(gum[d].to_numpy(), oum[d].a, "umac[%d] bc %s minion %d" % (d, bcname, minion))
+    case.close()
+
+
+@pytest.mark.parametrize("bcname", list(BC_SETS))
+@pytest.mark.parametrize("is_vel", [0, 1])
+@pytest.mark.parametrize("minion", [0, 1])
+def test_mkflux(gpu, oracle, bcname, is_vel, minion):
+    from varden_amd import advance as adv
+    case = Case((12, 16, 8), BC_SETS[bcname], seed=3, use_minion=minion)
+    u, s = case.random_state()
+    src = u if is_vel else s
+    nc = src.nc
+    is_cons = [0, 0, 0] if is_vel else [1, 0]
+    force = case.ofab(1, nc)
+    force.a[...] = case.rng.standard_normal(force.a.shape)
+    mac_rhs = case.ofab(1, 1)
+    mac_rhs.a[...] = 0.1 * case.rng.standard_normal(mac_rhs.a.shape)
+    oracle.lib().vo_fill_boundary(force.ref, case.opm)
+    oracle.lib().vo_fill_boundary(mac_rhs.ref, case.opm)
+    # a MAC velocity field with filled (periodic) ghost faces and 1e20 elsewhere, like the reference's
+    oum = face_fabs(case, 1, 1, 1.0e20)
+    for d, f in enumerate(oum):
+        v = f.valid()
+        v[...] = case.rng.uniform(-1, 1, size=v.shape)
+        if case.pmask[d]:
+            sl = [slice(None)] * 4
+            sl_lo, sl_hi = list(sl), list(sl)
+            sl_lo[d], sl_hi[d] = 0, -1
+            v[tuple(sl_hi)] = v[tuple(sl_lo)]          # periodic: the hi face is the lo face
+        oracle.lib().vo_fill_boundary(f.ref, case.opm)
+    dt = 0.4 * min(case.dx)
+    osedge, oflux = face_fabs(case, 0, nc), face_fabs(case, 0, nc)
+    oracle.lib().vo_mkflux(src.ref, oracle.fab_ptr_array(osedge), oracle.fab_ptr_array(oflux), oracle.fab_ptr_array(oum), force.ref,
+                           mac_rhs.ref, case.odx, C.c_double(dt), is_vel, oracle.ivec(is_cons), 0 if is_vel else 3,
+                           C.byref(case.obc), C.byref(case.prm))
+    gsedge = [case.gmf(f) for f in face_fabs(case, 0, nc)]
+    gflux = [case.gmf(f) for f in face_fabs(case, 0, nc)]
+    adv.mkflux(case.gmf(src), gsedge, gflux, [case.gmf(f) for f in oum], case.gmf(force), case.gmf(mac_rhs), case.dx, dt, case.bct,
+               is_vel, is_cons)
+    for d in range(3):
+        assert not np.isnan(osedge[d].a).any(), "oracle produced NaN (read of an unset intermediate)"
+        assert_bits(gsedge[d].to_numpy(), osedge[d].a, "sedge[%d] bc %s is_vel %d" % (d, bcname, is_vel))
+        assert_bits(gflux[d].to_numpy(), oflux[d].a, "flux[%d] bc %s is_vel %d" % (d, bcname, is_vel))
+    case.close()
+
+
+@pytest.mark.parametrize("bcname", ["walls", "periodic", "inout"])
+def test_forces_update_halftime(gpu, oracle, bcname):
+    from varden_amd import advance as adv
+    case = Case((8, 12, 16), BC_SETS[bcname], seed=4)
+    L = oracle.lib()
+    u, s = case.random_state()
+    ns = case.prm.nscal
+    gp, ext, exts = case.ofab(1, 3), case.ofab(1, 3), case.ofab(1, ns)
+    for f in (gp, ext, exts):
+        f.a[...] = case.rng.standard_normal(f.a.shape)
+    # mkvelforce + ghost fill
+    ovf = case.ofab(1, 3)
+    L.vo_mkvelforce(ovf.ref, ext.ref, gp.ref, s.ref, None, C.c_double(1.0), C.byref(case.prm))
+    L.vo_fill_boundary(ovf.ref, case.opm)
+    for c in range(3):
+        L.vo_physbc(ovf.ref, c, case.obc.extrap_comp, 1, C.byref(case.obc), C.byref(case.prm))
+    gvf = case.gmf(case.ofab(1, 3))
+    gs, gu = case.gmf(s), case.gmf(u)
+    adv.mkvelforce(gvf, case.gmf(ext), gs, case.gmf(gp), None, 1.0, case.bct)
+    assert_bits(gvf.to_numpy(), ovf.a, "vel_force " + bcname)
+    # mkscalforce
+    osf = case.ofab(1, ns)
+    L.vo_mkscalforce(osf.ref, exts.ref, None, C.c_double(1.0), C.byref(case.prm))
+    L.vo_fill_boundary(osf.ref, case.opm)
+    for c in range(ns):
+        L.vo_physbc(osf.ref, c, case.obc.extrap_comp, 1, C.byref(case.obc), C.byref(case.prm))
+    gsf = case.gmf(case.ofab(1, ns))
+    adv.mkscalforce(gsf, case.gmf(exts), None, 1.0, case.bct)
+    assert_bits(gsf.to_numpy(), osf.a, "scal_force " + bcname)
+    # update (scalars: conservative + convective; velocity) incl. the ghost fill of the result
+    oum = face_fabs(case, 1, 1, 0.0)
+    for f in oum:
+        f.a[...] = case.rng.uniform(-1, 1, size=f.a.shape)
+    gum = [case.gmf(f) for f in oum]
+    dt = 0.3 * min(case.dx)
+    for is_vel, src, gsrc, frc, gfrc, bccomp in ((0, s, gs, osf, gsf, 3), (1, u, gu, ovf, gvf, 0)):
+        nc = src.nc
+        ose, ofl = face_fabs(case, 0, nc), face_fabs(case, 0, nc)
+        for f in ose + ofl:
+            f.a[...] = case.rng.standard_normal(f.a.shape)
+        is_cons = [1, 0] if not is_vel else [0, 0, 0]
+        onew = case.ofab(3, nc)
+        L.vo_update(src.ref, oracle.fab_ptr_array(oum), oracle.fab_ptr_array(ose), oracle.fab_ptr_array(ofl), frc.ref, onew.ref,
+                    case.odx, C.c_double(dt), is_vel, oracle.ivec(is_cons))
+        L.vo_fill_boundary(onew.ref, case.opm)
+        L.vo_physbc(onew.ref, 0, bccomp, nc, C.byref(case.obc), C.byref(case.prm))
+        gnew = case.gmf(case.ofab(3, nc))
+        adv.update(gsrc, gum, [case.gmf(f) for f in ose], [case.gmf(f) for f in ofl], gfrc, gnew, case.dx, dt, is_vel, is_cons, case.bct)
+        assert_bits(gnew.to_numpy(), onew.a, "update is_vel=%d %s" % (is_vel, bcname))
+    # make_at_halftime
+    s2 = s.copy()
+    s2.a[...] += 0.1
+    orh = case.ofab(1, 3)
+    L.vo_make_at_halftime(orh.ref, 0, s.ref, s2.ref, 0)
+    L.vo_fill_boundary(orh.ref, case.opm)
+    L.vo_physbc(orh.ref, 0, 3, 1, C.byref(case.obc), C.byref(case.prm))
+    grh = case.gmf(case.ofab(1, 3))
+    adv.make_at_halftime(grh, gs, case.gmf(s2), 0, 0, case.bct)
+    assert_bits(grh.to_numpy()[..., 0], orh.a[..., 0], "rhohalf " + bcname)
+    case.close()
+
+
+@pytest.mark.parametrize("bcname", list(BC_SETS))
+def test_physbc_fill_boundary_estdt(gpu, oracle, bcname):
+    from varden_amd import advance as adv
+    case = Case((8, 8, 12), BC_SETS[bcname], seed=6)
+    L = oracle.lib()
+    u_raw, s_raw = case.random_state(with_ghost_fill=False)
+    gu, gs = case.gmf(u_raw), case.gmf(s_raw)
+    u, s = u_raw.copy(), s_raw.copy()
+    L.vo_fill_boundary(u.ref, case.opm); L.vo_fill_boundary(s.ref, case.opm)
+    L.vo_physbc(u.ref, 0, 0, 3, C.byref(case.obc), C.byref(case.prm))
+    L.vo_physbc(s.ref, 0, 3, case.prm.nscal, C.byref(case.obc), C.byref(case.prm))
+    gu.fill_boundary(); gs.fill_boundary()
+    gu.physbc(0, 0, 3, case.bct); gs.physbc(0, 3, case.prm.nscal, case.bct)
+    assert_bits(gu.to_numpy(), u.a, "physbc(u) " + bcname)
+    assert_bits(gs.to_numpy(), s.a, "physbc(s) " + bcname)
+    # face-centred and nodal fill_boundary
+    for nodal in ((1, 0, 0), (0, 0, 1), (1, 1, 1)):
+        f = case.ofab(1, 1, nodal)
+        f.a[...] = case.rng.standard_normal(f.a.shape)
+        for d in range(3):          # a nodal point on a periodic hi face IS the lo-face point
+            if nodal[d] and case.pmask[d]:
+                hi_sl, lo_sl = [slice(None)] * 4, [slice(None)] * 4
+                hi_sl[d], lo_sl[d] = -2, 1
+                f.a[tuple(hi_sl)] = f.a[tuple(lo_sl)]
+        g = case.gmf(f)
+        L.vo_fill_boundary(f.ref, case.opm)
+        g.fill_boundary()
+        assert_bits(g.to_numpy(), f.a, "fill_boundary nodal=%r %s" % (nodal, bcname))
+    gp, ext = case.ofab(1, 3), case.ofab(1, 3)
+    gp.a[...] = case.rng.standard_normal(gp.a.shape)
+    ext.a[..., 2] = -9.8
+    for dtold in (1.0e20, 1.0e-4):
+        odt = L.vo_estdt(u.ref, s.ref, gp.ref, ext.ref, case.odx, C.c_double(dtold), C.byref(case.prm))
+        gdt = adv.estdt(1, gu, gs, case.gmf(gp), case.gmf(ext), case.dx, dtold)
+        assert gdt == odt, "estdt %r vs %r" % (gdt, odt)
+    case.close()

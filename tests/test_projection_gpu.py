@@ -1,0 +1,175 @@
+"""GPU parity of the two projection solves (MAC cell-centred multigrid, HG nodal multigrid) and of the
+projection drivers against the CPU oracle.  Both sides run the same algorithm in the same expression
+order; the only order-dependent reduction is a max-norm, so the results are expected to be identical.
+Tolerance written here: bit-exact for the smoother; 1e-11 relative (L-inf) for the converged solves
+(tolerance-limited quantities: the reference itself stops at 1e-10 / 1e-12 relative residual)."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from tests.util import BC_SETS, Case, assert_bits
+
+pytestmark = pytest.mark.gpu
+
+
+def face_fabs(case, ng, nc, val=0.0):
+    return [case.ofab(ng, nc, tuple(1 if t == d else 0 for t in range(3)), val) for d in range(3)]
+
+
+def mac_problem(case):
+    """rho bubble-like, beta from mk_mac_coeffs, a compatible rhs"""
+    L = __import__("oracle.voracle", fromlist=["x"]).lib()
+    _, s = case.random_state()
+    s.a[..., 0] = np.abs(s.a[..., 0]) + 0.5
+    beta = face_fabs(case, 0, 1)
+    from oracle import voracle as vo
+    L.vo_mk_mac_coeffs(s.ref, vo.fab_ptr_array(beta))
+    rh = case.ofab(0, 1)
+    rh.a[...] = case.rng.standard_normal(rh.a.shape)
+    ell = vo.ellbc_of(case.obc)
+    if all(ell[d][sd] != 1 for d in range(3) for sd in range(2)):      # no Dirichlet face: make it solvable
+        rh.a[...] -= rh.a.mean()
+    return s, beta, rh, ell
+
+
+@pytest.mark.parametrize("bcname", ["walls", "periodic", "inout", "mixed"])
+def test_cc_smoother_bits(gpu, oracle, bcname):
+    from varden_amd import advance as adv
+    case = Case((16, 8, 12), BC_SETS[bcname], seed=11, iso=True)
+    s, beta, rh, ell = mac_problem(case)
+    ophi = case.ofab(1, 1)
+    oracle.lib().vo_cc_smooth(rh.ref, ophi.ref, oracle.fab_ptr_array(beta), case.odx, ell, 3)
+    gphi = case.gmf(case.ofab(1, 1))
+    bc = [[ell[d][sd] for sd in range(2)] for d in range(3)]
+    adv.cc_smooth(case.gmf(rh), gphi, [case.gmf(b) for b in beta], case.dx, bc, 3)
+    g = gphi.to_numpy()
+    assert_bits(g[1:-1, 1:-1, 1:-1], ophi.a[1:-1, 1:-1, 1:-1], "3 RB-GS sweeps " + bcname)
+    case.close()
+
+
+@pytest.mark.parametrize("bcname", ["walls", "periodic", "inout", "mixed"])
+@pytest.mark.parametrize("n", [(16, 16, 16), (32, 16, 8), (12, 20, 24)])
+def test_cc_solve(gpu, oracle, bcname, n):
+    from varden_amd import advance as adv
+    case = Case(n, BC_SETS[bcname], seed=12, iso=True)
+    s, beta, rh, ell = mac_problem(case)
+    P = case.prm
+    ophi = case.ofab(1, 1)
+    st = oracle.CMgStat()
+    rc = oracle.lib().vo_cc_solve(rh.ref, ophi.ref, oracle.fab_ptr_array(beta), case.odx, ell, C.c_double(1e-10), C.c_double(-1.0), 100,
+                                  P.mg_nu1, P.mg_nu2, P.mg_nub, C.byref(st))
+    assert rc == 0, "oracle MG did not converge"
+    gphi = case.gmf(case.ofab(1, 1))
+    bc = [[ell[d][sd] for sd in range(2)] for d in range(3)]
+    cyc, r0, r = adv.cc_solve(case.gmf(rh), gphi, [case.gmf(b) for b in beta], case.dx, bc, 1e-10)
+    assert cyc == st.cycles and r0 == st.res0
+    g = gphi.to_numpy()[1:-1, 1:-1, 1:-1, 0]
+    o = ophi.a[1:-1, 1:-1, 1:-1, 0]
+    scale = np.abs(o - o.mean()).max()
+    err = float(np.abs(g - o).max())
+    assert err <= 1e-11 * scale, "phi differs: %.3e (scale %.3e)" % (err, scale)
+    assert r <= 1e-10 * r0
+    case.close()
+
+
+@pytest.mark.parametrize("bcname", ["walls", "periodic", "inout", "mixed"])
+def test_macproject(gpu, oracle, bcname):
+    """whole MAC projection: div(umac) = 0 afterwards (known-answer, macproject.f90:209-221) and parity"""
+    from varden_amd import advance as adv
+    from varden_amd import boxlib as bl
+    case = Case((16, 16, 16), BC_SETS[bcname], seed=13, iso=True)
+    L = oracle.lib()
+    _, s = case.random_state()
+    s.a[..., 0] = np.abs(s.a[..., 0]) + 0.5
+    L.vo_fill_boundary(s.ref, case.opm)
+    L.vo_physbc(s.ref, 0, 3, case.prm.nscal, C.byref(case.obc), C.byref(case.prm))
+    # umac from velpred of a random velocity (so that boundary faces carry the bc values)
+    u, _ = case.random_state()
+    force = case.ofab(1, 3)
+    oum = face_fabs(case, 1, 1, 1.0e20)
+    L.vo_velpred(u.ref, oracle.fab_ptr_array(oum), force.ref, case.odx, C.c_double(0.2 * min(case.dx)), C.byref(case.obc), C.byref(case.prm))
+    for f in oum:
+        L.vo_fill_boundary(f.ref, case.opm)
+    mac_rhs = case.ofab(1, 1)
+    gum = [case.gmf(f) for f in oum]
+    st = oracle.CMgStat()
+    L.vo_macproject(oracle.fab_ptr_array(oum), s.ref, mac_rhs.ref, case.odx, C.byref(case.obc), case.opm, C.byref(case.prm), C.byref(st))
+    adv.macproject(case.mla, [gum], [case.gmf(s)], [case.gmf(mac_rhs)], [case.dx], case.bct, case.obc.press_comp + 1)
+    cyc, r0, r = adv.last_solver_stats("mac")
+    assert cyc == st.cycles
+    for d in range(3):
+        g, o = gum[d].to_numpy(), oum[d].a
+        scale = np.abs(o[1:-1, 1:-1, 1:-1]).max()
+        assert np.abs(g - o)[1:-1, 1:-1, 1:-1].max() <= 1e-11 * scale
+    # divergence-free to the solver tolerance
+    div = sum((np.diff(gum[d].to_numpy()[1:-1, 1:-1, 1:-1, 0], axis=d)[tuple(slice(0, case.n[t]) for t in range(3))]) / case.dx[d] for d in range(3))
+    assert np.abs(div).max() <= 1e-9 * r0, "max |div umac| = %.3e (initial %.3e)" % (np.abs(div).max(), r0)
+    case.close()
+
+
+@pytest.mark.parametrize("bcname", ["walls", "periodic", "inout", "mixed"])
+@pytest.mark.parametrize("n", [(16, 16, 16), (8, 16, 32)])
+def test_nd_solve(gpu, oracle, bcname, n):
+    from varden_amd import advance as adv
+    case = Case(n, BC_SETS[bcname], seed=14, iso=True)
+    L = oracle.lib()
+    P = case.prm
+    u, s = case.random_state()
+    # zero wall ghosts like create_uvec does, so the system is compatible
+    rhohalf = case.ofab(1, 1)
+    rhohalf.a[...] = np.abs(s.a[2:-2, 2:-2, 2:-2, :1]) + 0.5
+    gpz = case.ofab(1, 3)
+    L.vo_create_uvec(u.ref, u.ref, rhohalf.ref, gpz.ref, C.c_double(1.0), C.byref(case.obc), 1)
+    L.vo_fill_boundary(u.ref, case.opm)
+    coeffs = case.ofab(1, 1)
+    coeffs.a[1:-1, 1:-1, 1:-1, 0] = 1.0 / rhohalf.a[1:-1, 1:-1, 1:-1, 0]
+    L.vo_fill_boundary(coeffs.ref, case.opm)
+    ell = oracle.ellbc_of(case.obc)
+    nodal = (1, 1, 1)
+    orh, ophi = case.ofab(1, 1, nodal), case.ofab(1, 1, nodal)
+    st = oracle.CMgStat()
+    rc = L.vo_nd_solve(orh.ref, ophi.ref, coeffs.ref, u.ref, case.odx, ell, case.opm, C.c_double(1e-11), C.c_double(-1.0), 100,
+                       P.hg_nu1, P.hg_nu2, P.hg_nub, C.c_double(P.hg_omega), C.byref(st))
+    assert rc == 0, "oracle nodal MG did not converge (%d cycles, %g / %g)" % (st.cycles, st.res, st.res0)
+    grh, gphi = case.gmf(case.ofab(1, 1, nodal)), case.gmf(case.ofab(1, 1, nodal))
+    bc = [[ell[d][sd] for sd in range(2)] for d in range(3)]
+    cyc, r0, r = adv.nd_solve(grh, gphi, case.gmf(coeffs), case.gmf(u), case.dx, bc, 1e-11)
+    assert cyc == st.cycles and r0 == st.res0
+    assert_bits(grh.to_numpy()[1:-1, 1:-1, 1:-1], orh.a[1:-1, 1:-1, 1:-1], "nodal divergence " + bcname)
+    g, o = gphi.to_numpy()[1:-1, 1:-1, 1:-1, 0], ophi.a[1:-1, 1:-1, 1:-1, 0]
+    scale = np.abs(o - o.mean()).max()
+    err = float(np.abs(g - o).max())
+    assert err <= 1e-11 * scale, "phi differs: %.3e (scale %.3e)" % (err, scale)
+    case.close()
+
+
+@pytest.mark.parametrize("bcname", ["walls", "periodic", "inout"])
+@pytest.mark.parametrize("proj_type", [1, 3, 4])
+def test_hgproject(gpu, oracle, bcname, proj_type):
+    from varden_amd import advance as adv
+    case = Case((16, 16, 16), BC_SETS[bcname], seed=15, iso=True)
+    L = oracle.lib()
+    uold, s = case.random_state()
+    unew, _ = case.random_state()
+    rhohalf = case.ofab(1, 1)
+    rhohalf.a[...] = np.abs(s.a[2:-2, 2:-2, 2:-2, :1]) + 0.5
+    gp, p = case.ofab(1, 3), case.ofab(1, 1, (1, 1, 1))
+    gp.a[1:-1, 1:-1, 1:-1] = case.rng.standard_normal(gp.a[1:-1, 1:-1, 1:-1].shape)
+    L.vo_fill_boundary(gp.ref, case.opm)
+    p.a[...] = case.rng.standard_normal(p.a.shape)
+    dt = 0.01
+    g_un, g_uo, g_rh, g_p, g_gp = case.gmf(unew), case.gmf(uold), case.gmf(rhohalf), case.gmf(p), case.gmf(gp)
+    st = oracle.CMgStat()
+    L.vo_hgproject(proj_type, unew.ref, uold.ref, rhohalf.ref, p.ref, gp.ref, case.odx, C.c_double(dt), C.byref(case.obc), case.opm,
+                   C.byref(case.prm), C.byref(st))
+    adv.hgproject(proj_type, case.mla, [g_un], [g_uo], [g_rh], [g_p], [g_gp], [case.dx], dt, case.bct, case.obc.press_comp + 1)
+    cyc, r0, r = adv.last_solver_stats("hg")
+    assert cyc == st.cycles, "cycles %d vs %d" % (cyc, st.cycles)
+    v = (slice(3, -3),) * 3
+    for name, g, o, sl in (("unew", g_un.to_numpy(), unew.a, v), ("gp", g_gp.to_numpy(), gp.a, (slice(1, -1),) * 3),
+                           ("p", g_p.to_numpy(), p.a, (slice(1, -1),) * 3)):
+        scale = max(np.abs(o[sl]).max(), 1e-300)
+        err = np.abs(g[sl] - o[sl]).max()
+        assert err <= 1e-10 * scale, "%s differs after hgproject(%d): %.3e (scale %.3e)" % (name, proj_type, err, scale)
+    case.close()

@@ -110,6 +110,44 @@ __global__ void kk_cc_periodic(CLev L, int per0, int per1, int per2) {
   L.phi[cidx(L, g[0], g[1], g[2])] = L.phi[cidx(L, q[0], q[1], q[2])];
 }
 
+// bottom solve: all sweeps of the coarsest level in ONE launch by one workgroup (the level is tiny and
+// L2-resident; a launch per colour pass would be pure launch latency).  __syncthreads() orders the
+// global-memory writes of one colour pass before the reads of the next within the workgroup.
+__global__ void __launch_bounds__(1024) kk_cc_bottom(CLev L, int nsweeps, int per0, int per1, int per2) {
+  const int nx = L.n[0], ny = L.n[1], nz = L.n[2];
+  const int half = (nx + 1) / 2;
+  const int tot = half * ny * nz;
+  const bool anyper = per0 || per1 || per2;
+  for (int s = 0; s < nsweeps; s++) for (int color = 0; color < 2; color++) {
+    if (anyper) {
+      const int m = max(nx, max(ny, nz));
+      for (int t = threadIdx.x; t < 6 * m * m; t += blockDim.x) {
+        const int face = t / (m * m), a = (t / m) % m, b = t % m;
+        const int d = face >> 1, sd = face & 1;
+        const int per = d == 0 ? per0 : (d == 1 ? per1 : per2);
+        const int t1 = (d == 0) ? 1 : 0, t2 = (d == 2) ? 1 : 2;
+        if (per && a < L.n[t1] && b < L.n[t2]) {
+          int g[3], q[3];
+          g[t1] = q[t1] = a; g[t2] = q[t2] = b;
+          g[d] = sd ? L.n[d] : -1; q[d] = sd ? 0 : L.n[d] - 1;
+          L.phi[cidx(L, g[0], g[1], g[2])] = L.phi[cidx(L, q[0], q[1], q[2])];
+        }
+      }
+      __syncthreads();
+    }
+    for (int t = threadIdx.x; t < tot; t += blockDim.x) {
+      const int k = t / (half * ny), j = (t / half) % ny;
+      const int i = 2 * (t % half) + ((j + k + color) & 1);
+      if (i < nx) {
+        const long c = cidx(L, i, j, k);
+        double Ap, diag; cc_apply(L, c, Ap, diag);
+        if (diag != 0.0) L.phi[c] = L.phi[c] + (L.rh[c] - Ap) / diag;
+      }
+    }
+    __syncthreads();
+  }
+}
+
 // ---- transfers between BoxLib-layout multifabs and level 0 ---------------------------------------------
 __global__ void kk_cc_load(CLev L, FV rh, FV phi, FV bx, FV by, FV bz, int lo0, int lo1, int lo2, int ebc00, int ebc01, int ebc10, int ebc11, int ebc20, int ebc21) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -202,6 +240,12 @@ static void cc_gsrb(const CCMG &M, const CLev &L, int nsweeps) {
     hipLaunchKernelGGL(kk_cc_gsrb, g3((L.n[0] + 1) / 2, L.n[1], L.n[2], BLK), BLK, 0, ctx().stream, L, color);
   }
 }
+// max(nub, N^2) sweeps on the coarsest level, N = its largest extent (same rule as the oracle)
+static void cc_bottom(const CCMG &M, const CLev &L) {
+  const int N = std::max(L.n[0], std::max(L.n[1], L.n[2]));
+  const int ns = std::max(ctx().prm.mg_nub, N * N);
+  hipLaunchKernelGGL(kk_cc_bottom, dim3(1), dim3(1024), 0, ctx().stream, L, ns, M.per[0], M.per[1], M.per[2]);
+}
 static void cc_residual(const CCMG &M, const CLev &L, bool norm) {
   cc_periodic(M, L);
   if (norm) HIPCHK(hipMemsetAsync(M.d_nrm, 0, sizeof(double), ctx().stream));
@@ -217,7 +261,7 @@ static void cc_vcycle(const CCMG &M, int l) {
   const vdn_params &P = ctx().prm;
   const CLev &L = M.lev[l];
   HIPCHK(hipMemsetAsync(L.phi, 0, sizeof(double) * L.sz, ctx().stream));
-  if (l == (int)M.lev.size() - 1) { cc_gsrb(M, L, P.mg_nub); return; }
+  if (l == (int)M.lev.size() - 1) { cc_bottom(M, L); return; }
   const CLev &C = M.lev[l + 1];
   cc_gsrb(M, L, P.mg_nu1);
   cc_residual(M, L, false);
@@ -259,7 +303,7 @@ int cc_solve(vdn_multifab *rh, vdn_multifab *phi, vdn_multifab **beta, const dou
   const double bnorm = mf_norm_inf(rh, 0, 1);
   int cyc = 0; bool conv = (bnorm == 0.0); double rn = 0.0;
   while (!conv) {
-    cc_gsrb(M, L0, M.lev.size() == 1 ? P.mg_nub : P.mg_nu1);
+    if (M.lev.size() == 1) cc_bottom(M, L0); else cc_gsrb(M, L0, P.mg_nu1);
     cc_residual(M, L0, true);
     rn = read_scalar(M.d_nrm);
     if (rn <= rel_eps * bnorm || rn <= abs_eps) { conv = true; break; }

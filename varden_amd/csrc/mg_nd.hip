@@ -178,6 +178,40 @@ __global__ void kk_nd_coarsen_sigma(NLev F, NLev C) {
   C.sig[nidx(C, i, j, k)] = s * 0.125;
 }
 
+// bottom solve: all Jacobi sweeps of the coarsest level in one launch by one workgroup (ping-pong between
+// phi and tmp; ghost nodes refreshed by the same workgroup between sweeps).  Returns with the result in
+// `a` if nsweeps is even, in `b` otherwise (the host swaps accordingly).
+__global__ void __launch_bounds__(1024) kk_nd_bottom(NLev L, double *a, double *b, int nsweeps, double omega) {
+  const int ex = L.n[0] + 3, ey = L.n[1] + 3, ez = L.n[2] + 3;
+  const int nx = L.n[0] + 1, ny = L.n[1] + 1, nz = L.n[2] + 1;
+  double *src = a, *dst = b;
+  for (int s = 0; s < nsweeps; s++) {
+    for (int t = threadIdx.x; t < ex * ey * ez; t += blockDim.x) {       // nd_fill_nodes
+      const int i = t % ex - 1, j = (t / ex) % ey - 1, k = t / (ex * ey) - 1;
+      int q[3] = { i, j, k }, sidx[3] = { i, j, k }; bool g = false, zero = false;
+      for (int d = 0; d < 3; d++) {
+        if (L.per[d]) { if (q[d] < 0) { sidx[d] = q[d] + L.n[d]; g = true; } else if (q[d] >= L.n[d]) { sidx[d] = q[d] - L.n[d]; g = true; } }
+        else if (q[d] < 0 || q[d] > L.n[d]) { g = true; zero = true; }
+      }
+      if (g) src[nidx(L, i, j, k)] = zero ? 0.0 : src[nidx(L, sidx[0], sidx[1], sidx[2])];
+    }
+    __syncthreads();
+    for (int t = threadIdx.x; t < nx * ny * nz; t += blockDim.x) {
+      const int i = t % nx, j = (t / nx) % ny, k = t / (nx * ny);
+      const long c = nidx(L, i, j, k);
+      const double p0 = src[c];
+      double v = p0;
+      if (!nd_is_dir(L, i, j, k)) {
+        double Kp, diag; nd_apply(L, src, i, j, k, Kp, diag);
+        if (diag != 0.0) v = p0 + omega * ((L.b[c] - Kp) / diag);
+      }
+      dst[c] = v;
+    }
+    __syncthreads();
+    double *tsw = src; src = dst; dst = tsw;
+  }
+}
+
 // ---- load / store / divergence -------------------------------------------------------------------------
 __global__ void kk_nd_load_sigma(NLev L, FV coeffs, int lo0, int lo1, int lo2) {
   const int i = (int)(blockIdx.x * blockDim.x + threadIdx.x) - 1;
@@ -236,6 +270,13 @@ static void nd_jacobi(NLev &L, int nsweeps) {
     std::swap(L.phi, L.tmp);
   }
 }
+// max(nub, 2 N^2) sweeps on the coarsest level (same rule as the oracle)
+static void nd_bottom(NLev &L) {
+  const int N = std::max(L.n[0], std::max(L.n[1], L.n[2]));
+  const int ns = std::max(ctx().prm.hg_nub, 2 * N * N);
+  hipLaunchKernelGGL(kk_nd_bottom, dim3(1), dim3(1024), 0, ctx().stream, L, L.phi, L.tmp, ns, ctx().prm.hg_omega);
+  if (ns & 1) std::swap(L.phi, L.tmp);
+}
 static void nd_residual(NDMG &M, NLev &L, bool norm) {
   nd_fill_nodes(L, L.phi);
   if (norm) HIPCHK(hipMemsetAsync(M.d_nrm, 0, sizeof(double), ctx().stream));
@@ -246,7 +287,7 @@ static void nd_vcycle(NDMG &M, int l) {
   const vdn_params &P = ctx().prm;
   NLev &L = M.lev[l];
   HIPCHK(hipMemsetAsync(L.phi, 0, sizeof(double) * L.sz, ctx().stream));
-  if (l == (int)M.lev.size() - 1) { nd_jacobi(L, P.hg_nub); return; }
+  if (l == (int)M.lev.size() - 1) { nd_bottom(L); return; }
   NLev &C = M.lev[l + 1];
   nd_jacobi(L, P.hg_nu1);
   nd_residual(M, L, false);
@@ -308,7 +349,7 @@ int nd_solve(vdn_multifab *rh, vdn_multifab *phi, const vdn_multifab *coeffs, co
   const double bnorm = nd_read(M.d_nrm);
   int cyc = 0; bool conv = (bnorm == 0.0); double rn = 0.0;
   while (!conv) {
-    nd_jacobi(L0, M.lev.size() == 1 ? P.hg_nub : P.hg_nu1);
+    if (M.lev.size() == 1) nd_bottom(L0); else nd_jacobi(L0, P.hg_nu1);
     nd_residual(M, L0, true);
     rn = nd_read(M.d_nrm);
     if (rn <= rel_eps * bnorm || rn <= abs_eps) { conv = true; break; }
