@@ -266,9 +266,9 @@ __global__ void kk_mk_D(FV s, FV sl0, FV sl1, FV sl2, FV um, FV vm, FV wm, FV fo
 
 // max |umac| over the valid faces of the three MAC components (mkflux.f90:1374-1396)
 __global__ void kk_macmax(FV um, FV vm, FV wm, GArgs A, Range3 r, double *out) {
-  THREAD_IJK(r)
+  REDUCE_IJ(r)
   double m = 0.0;
-  if (in_range) {
+  if (in_ij) REDUCE_KLOOP(r) {
     if (j <= A.hi[1] && k <= A.hi[2]) m = fmax(m, fabs(fv_get(um, i, j, k)));
     if (i <= A.hi[0] && k <= A.hi[2]) m = fmax(m, fabs(fv_get(vm, i, j, k)));
     if (i <= A.hi[0] && j <= A.hi[1]) m = fmax(m, fabs(fv_get(wm, i, j, k)));
@@ -276,9 +276,9 @@ __global__ void kk_macmax(FV um, FV vm, FV wm, GArgs A, Range3 r, double *out) {
   block_atomic_max(out, m);
 }
 __global__ void kk_velmax(FV u, Range3 r, double *out) {             // velpred.f90:1965-1975
-  THREAD_IJK(r)
+  REDUCE_IJ(r)
   double m = 0.0;
-  if (in_range) m = fmax(fmax(fabs(fv_get(u, i, j, k, 0)), fabs(fv_get(u, i, j, k, 1))), fabs(fv_get(u, i, j, k, 2)));
+  if (in_ij) REDUCE_KLOOP(r) m = fmax(m, fmax(fmax(fabs(fv_get(u, i, j, k, 0)), fabs(fv_get(u, i, j, k, 1))), fabs(fv_get(u, i, j, k, 2))));
   block_atomic_max(out, m);
 }
 
@@ -336,7 +336,7 @@ void k_mkflux(const vdn_multifab *s, vdn_multifab **sedge, vdn_multifab **flux, 
     Range3 rg, rf;
     for (int d = 0; d < 3; d++) { rg.lo[d] = A.lo[d] - 1; rg.hi[d] = A.hi[d] + 1; rf.lo[d] = A.lo[d]; rf.hi[d] = A.hi[d] + 1; }
     const FV &um = umac[0]->fabs[ib], &vm = umac[1]->fabs[ib], &wm = umac[2]->fabs[ib];
-    hipLaunchKernelGGL(kk_macmax, grid_for(rf), dim3(64, 4, 1), 0, st, um, vm, wm, A, rf, umax);
+    hipLaunchKernelGGL(kk_macmax, reduce_grid(rf), dim3(64, 4, 1), 0, st, um, vm, wm, A, rf, umax);
     hipLaunchKernelGGL(kk_slopes, grid_for(rg), dim3(64, 4, 1), 0, st, s->fabs[ib], sl[0], sl[1], sl[2], A, rg, 7);
     hipLaunchKernelGGL(kk_mk_B, grid_for(rg), dim3(64, 4, 1), 0, st, s->fabs[ib], sl[0], sl[1], sl[2], um, vm, wm, force->fabs[ib], mac_rhs->fabs[ib], SI, A, rg, umax);
     hipLaunchKernelGGL(kk_mk_C, grid_for(rg), dim3(64, 4, 1), 0, st, s->fabs[ib], sl[0], sl[1], sl[2], um, vm, wm, force->fabs[ib], mac_rhs->fabs[ib], SI, SC, A, rg, umax);
@@ -502,7 +502,7 @@ void k_velpred(const vdn_multifab *u, vdn_multifab **umac, const vdn_multifab *f
     HIPCHK(hipMemsetAsync(umax, 0, sizeof(double), st));
     Range3 rv, rg, rf;
     for (int d = 0; d < 3; d++) { rv.lo[d] = A.lo[d]; rv.hi[d] = A.hi[d]; rg.lo[d] = A.lo[d] - 1; rg.hi[d] = A.hi[d] + 1; rf.lo[d] = A.lo[d]; rf.hi[d] = A.hi[d] + 1; }
-    hipLaunchKernelGGL(kk_velmax, grid_for(rv), dim3(64, 4, 1), 0, st, u->fabs[ib], rv, umax);
+    hipLaunchKernelGGL(kk_velmax, reduce_grid(rv), dim3(64, 4, 1), 0, st, u->fabs[ib], rv, umax);
     hipLaunchKernelGGL(kk_slopes, grid_for(rg), dim3(64, 4, 1), 0, st, u->fabs[ib], sl[0], sl[1], sl[2], A, rg, 7);
     hipLaunchKernelGGL(kk_vp_B, grid_for(rg), dim3(64, 4, 1), 0, st, u->fabs[ib], sl[0], sl[1], sl[2], force->fabs[ib], UI, A, rg, umax);
     hipLaunchKernelGGL(kk_vp_C, grid_for(rg), dim3(64, 4, 1), 0, st, u->fabs[ib], sl[0], sl[1], sl[2], force->fabs[ib], UI, XC, A, rg, umax);

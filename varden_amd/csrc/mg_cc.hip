@@ -50,15 +50,16 @@ __global__ void __launch_bounds__(256) kk_cc_gsrb(CLev L, int color) {
 __global__ void __launch_bounds__(256) kk_cc_residual(CLev L, double *nrm) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   const int j = blockIdx.y * blockDim.y + threadIdx.y;
-  const int k = blockIdx.z;
-  double r = 0.0;
-  if (i < L.n[0] && j < L.n[1]) {
-    const long c = cidx(L, i, j, k);
-    double Ap, diag; cc_apply(L, c, Ap, diag);
-    r = L.rh[c] - Ap;
-    L.res[c] = r;
-  }
-  if (nrm) block_atomic_max(nrm, fabs(r));
+  double rmax = 0.0;
+  if (i < L.n[0] && j < L.n[1])
+    for (int k = blockIdx.z; k < L.n[2]; k += gridDim.z) {
+      const long c = cidx(L, i, j, k);
+      double Ap, diag; cc_apply(L, c, Ap, diag);
+      const double r = L.rh[c] - Ap;
+      L.res[c] = r;
+      rmax = fmax(rmax, fabs(r));
+    }
+  if (nrm) block_atomic_max(nrm, rmax);
 }
 
 __global__ void kk_cc_restrict(CLev F, CLev C) {
@@ -249,7 +250,9 @@ static void cc_bottom(const CCMG &M, const CLev &L) {
 static void cc_residual(const CCMG &M, const CLev &L, bool norm) {
   cc_periodic(M, L);
   if (norm) HIPCHK(hipMemsetAsync(M.d_nrm, 0, sizeof(double), ctx().stream));
-  hipLaunchKernelGGL(kk_cc_residual, g3(L.n[0], L.n[1], L.n[2], BLK), BLK, 0, ctx().stream, L, norm ? M.d_nrm : nullptr);
+  // with the norm: at most 16 workgroups along k (each marches its share of planes) so that the
+  // per-workgroup atomics stay in the low thousands; without it one workgroup per plane
+  hipLaunchKernelGGL(kk_cc_residual, g3(L.n[0], L.n[1], norm ? std::min(L.n[2], 16) : L.n[2], BLK), BLK, 0, ctx().stream, L, norm ? M.d_nrm : nullptr);
 }
 static double read_scalar(double *d) {
   VdnCtx &c = ctx();

@@ -95,14 +95,18 @@ __global__ void __launch_bounds__(256) kk_nd_jacobi(NLev L, const double *__rest
   out[c] = v;
 }
 __global__ void __launch_bounds__(256) kk_nd_residual(NLev L, double *nrm) {
-  NODE_IJK(L)
-  double r = 0.0;
-  if (in_range) {
-    const long c = nidx(L, i, j, k);
-    if (!nd_is_dir(L, i, j, k)) { double Kp, diag; nd_apply(L, L.phi, i, j, k, Kp, diag); r = L.b[c] - Kp; }
-    L.res[c] = r;
-  }
-  if (nrm) block_atomic_max(nrm, fabs(r));
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  const int j = blockIdx.y * blockDim.y + threadIdx.y;
+  double rmax = 0.0;
+  if (i <= L.n[0] && j <= L.n[1])
+    for (int k = blockIdx.z; k <= L.n[2]; k += gridDim.z) {
+      const long c = nidx(L, i, j, k);
+      double r = 0.0;
+      if (!nd_is_dir(L, i, j, k)) { double Kp, diag; nd_apply(L, L.phi, i, j, k, Kp, diag); r = L.b[c] - Kp; }
+      L.res[c] = r;
+      rmax = fmax(rmax, fabs(r));
+    }
+  if (nrm) block_atomic_max(nrm, rmax);
 }
 // ghost nodes (and the periodic alias node n): periodic image, else zero
 __global__ void kk_nd_fill_nodes(NLev L, double *a) {
@@ -235,16 +239,19 @@ __global__ void kk_nd_divu(FV u, FV rh, double fx, double fy, double fz, Range3 
   fv_at(rh, i, j, k) = fv_get(rh, i, j, k) + (dux * fx + duy * fy + duz * fz);
 }
 __global__ void kk_nd_load(NLev L, FV rh, FV phi, int lo0, int lo1, int lo2, double *nrm) {
-  NODE_IJK(L)
-  double r = 0.0;
-  if (in_range) {
-    const bool dir = nd_is_dir(L, i, j, k);
-    r = dir ? 0.0 : fv_get(rh, lo0 + i, lo1 + j, lo2 + k);
-    const long c = nidx(L, i, j, k);
-    L.b[c] = -r;
-    L.phi[c] = dir ? 0.0 : fv_get(phi, lo0 + i, lo1 + j, lo2 + k);
-  }
-  block_atomic_max(nrm, fabs(r));
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  const int j = blockIdx.y * blockDim.y + threadIdx.y;
+  double rmax = 0.0;
+  if (i <= L.n[0] && j <= L.n[1])
+    for (int k = blockIdx.z; k <= L.n[2]; k += gridDim.z) {
+      const bool dir = nd_is_dir(L, i, j, k);
+      const double r = dir ? 0.0 : fv_get(rh, lo0 + i, lo1 + j, lo2 + k);
+      const long c = nidx(L, i, j, k);
+      L.b[c] = -r;
+      L.phi[c] = dir ? 0.0 : fv_get(phi, lo0 + i, lo1 + j, lo2 + k);
+      rmax = fmax(rmax, fabs(r));
+    }
+  block_atomic_max(nrm, rmax);
 }
 __global__ void kk_nd_store(NLev L, FV phi, int lo0, int lo1, int lo2) {
   const int i = (int)(blockIdx.x * blockDim.x + threadIdx.x) - 1;
@@ -261,6 +268,7 @@ static dim3 ng3(int nx, int ny, int nz) { return dim3((nx + 63) / 64, (ny + 3) /
 struct NDMG { std::vector<NLev> lev; double *d_nrm; };
 
 static void nd_fill_nodes(const NLev &L, double *a) {
+  if (!(L.per[0] || L.per[1] || L.per[2])) return;     // ghosts stay zero: set once by the setup memset, never written
   hipLaunchKernelGGL(kk_nd_fill_nodes, ng3(L.n[0] + 3, L.n[1] + 3, L.n[2] + 3), NBLK, 0, ctx().stream, L, a);
 }
 static void nd_jacobi(NLev &L, int nsweeps) {
@@ -280,7 +288,7 @@ static void nd_bottom(NLev &L) {
 static void nd_residual(NDMG &M, NLev &L, bool norm) {
   nd_fill_nodes(L, L.phi);
   if (norm) HIPCHK(hipMemsetAsync(M.d_nrm, 0, sizeof(double), ctx().stream));
-  hipLaunchKernelGGL(kk_nd_residual, ng3(L.n[0] + 1, L.n[1] + 1, L.n[2] + 1), NBLK, 0, ctx().stream, L, norm ? M.d_nrm : nullptr);
+  hipLaunchKernelGGL(kk_nd_residual, ng3(L.n[0] + 1, L.n[1] + 1, norm ? std::min(L.n[2] + 1, 16) : L.n[2] + 1), NBLK, 0, ctx().stream, L, norm ? M.d_nrm : nullptr);
   nd_fill_nodes(L, L.res);
 }
 static void nd_vcycle(NDMG &M, int l) {
@@ -345,7 +353,7 @@ int nd_solve(vdn_multifab *rh, vdn_multifab *phi, const vdn_multifab *coeffs, co
     hipLaunchKernelGGL(kk_nd_divu, grid_for(r), NBLK, 0, st, u->fabs[0], rh->fabs[0], 0.25 / dx[0], 0.25 / dx[1], 0.25 / dx[2], r);
   }
   HIPCHK(hipMemsetAsync(M.d_nrm, 0, sizeof(double), st));
-  hipLaunchKernelGGL(kk_nd_load, ng3(L0.n[0] + 1, L0.n[1] + 1, L0.n[2] + 1), NBLK, 0, st, L0, rh->fabs[0], phi->fabs[0], bx.lo[0], bx.lo[1], bx.lo[2], M.d_nrm);
+  hipLaunchKernelGGL(kk_nd_load, ng3(L0.n[0] + 1, L0.n[1] + 1, std::min(L0.n[2] + 1, 16)), NBLK, 0, st, L0, rh->fabs[0], phi->fabs[0], bx.lo[0], bx.lo[1], bx.lo[2], M.d_nrm);
   const double bnorm = nd_read(M.d_nrm);
   int cyc = 0; bool conv = (bnorm == 0.0); double rn = 0.0;
   while (!conv) {

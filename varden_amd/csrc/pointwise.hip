@@ -120,14 +120,14 @@ void k_make_at_halftime(vdn_multifab *rhohalf, const vdn_multifab *sold, const v
 
 // ---- estdt maxima: wave-level reduction (64 lanes, shuffles) + one atomic per wave ----------------
 __global__ void kk_estdt(FV u, FV s, FV gp, FV ext, Range3 r, double *out6) {
-  THREAD_IJK(r)
+  REDUCE_IJ(r)
   double m[6] = { 0, 0, 0, 0, 0, 0 };
-  if (in_range) {
+  if (in_ij) REDUCE_KLOOP(r) {
     const double rho = fv_get(s, i, j, k, 0);
     #pragma unroll
     for (int c = 0; c < 3; c++) {
-      m[c] = fabs(fv_get(u, i, j, k, c));
-      m[3 + c] = fabs(fv_get(gp, i, j, k, c) / rho - fv_get(ext, i, j, k, c));
+      m[c] = fmax(m[c], fabs(fv_get(u, i, j, k, c)));
+      m[3 + c] = fmax(m[3 + c], fabs(fv_get(gp, i, j, k, c) / rho - fv_get(ext, i, j, k, c)));
     }
   }
   #pragma unroll
@@ -138,7 +138,7 @@ void k_estdt_max(const vdn_multifab *u, const vdn_multifab *s, const vdn_multifa
   HIPCHK(hipMemsetAsync(c.d_scal, 0, 6 * sizeof(double), c.stream));
   for (int i = 0; i < u->nfabs(); i++) {
     Range3 r; for (int d = 0; d < 3; d++) { r.lo[d] = u->vbox[i].lo[d]; r.hi[d] = u->vbox[i].hi[d]; }
-    hipLaunchKernelGGL(kk_estdt, grid_for(r), dim3(64, 4, 1), 0, c.stream, u->fabs[i], s->fabs[i], gp->fabs[i], ext->fabs[i], r, c.d_scal);
+    hipLaunchKernelGGL(kk_estdt, reduce_grid(r), dim3(64, 4, 1), 0, c.stream, u->fabs[i], s->fabs[i], gp->fabs[i], ext->fabs[i], r, c.d_scal);
   }
   HIPCHK(hipMemcpyAsync(c.h_scal, c.d_scal, 6 * sizeof(double), hipMemcpyDeviceToHost, c.stream));
   HIPCHK(hipStreamSynchronize(c.stream));

@@ -355,15 +355,15 @@ extern "C" int vdn_multifab_copy_c(vdn_multifab *dst, int dcomp, const vdn_multi
 }
 
 __global__ void k_absmax(FV f, Range3 r, int comp, int nc, double *out) {
-  THREAD_IJK(r)
+  REDUCE_IJ(r)
   double v = 0.0;
-  if (in_range) for (int c = comp; c < comp + nc; c++) v = fmax(v, fabs(fv_get(f, i, j, k, c)));
+  if (in_ij) REDUCE_KLOOP(r) for (int c = comp; c < comp + nc; c++) v = fmax(v, fabs(fv_get(f, i, j, k, c)));
   block_atomic_max(out, v);
 }
 __global__ void k_minmax(FV f, Range3 r, int comp, double *out /* [0]=max(-x) shifted, [1]=max(x) shifted */, double shift) {
-  THREAD_IJK(r)
+  REDUCE_IJ(r)
   double a = 0.0, b = 0.0;   // max of (shift - x) and (x + shift), both non-negative when |x| <= shift
-  if (in_range) { double x = fv_get(f, i, j, k, comp); a = shift - x; b = x + shift; }
+  if (in_ij) REDUCE_KLOOP(r) { double x = fv_get(f, i, j, k, comp); a = fmax(a, shift - x); b = fmax(b, x + shift); }
   block_atomic_max(out, a); block_atomic_max(out + 1, b);
 }
 double mf_norm_inf(const vdn_multifab *mf, int comp, int nc) {
@@ -371,7 +371,7 @@ double mf_norm_inf(const vdn_multifab *mf, int comp, int nc) {
   HIPCHK(hipMemsetAsync(c.d_scal, 0, sizeof(double), c.stream));
   for (int i = 0; i < mf->nfabs(); i++) {
     Range3 r = fab_range(mf, i, 0);
-    hipLaunchKernelGGL(k_absmax, grid_for(r), dim3(64, 4, 1), 0, c.stream, mf->fabs[i], r, comp, nc, c.d_scal);
+    hipLaunchKernelGGL(k_absmax, reduce_grid(r), dim3(64, 4, 1), 0, c.stream, mf->fabs[i], r, comp, nc, c.d_scal);
   }
   HIPCHK(hipMemcpyAsync(c.h_scal, c.d_scal, sizeof(double), hipMemcpyDeviceToHost, c.stream));
   HIPCHK(hipStreamSynchronize(c.stream));
@@ -388,7 +388,7 @@ extern "C" int vdn_multifab_min_max(const vdn_multifab *mf, int comp, double *mn
   HIPCHK(hipMemsetAsync(c.d_scal, 0, 2 * sizeof(double), c.stream));
   for (int i = 0; i < mf->nfabs(); i++) {
     Range3 r = fab_range(mf, i, 0);
-    hipLaunchKernelGGL(k_minmax, grid_for(r), dim3(64, 4, 1), 0, c.stream, mf->fabs[i], r, comp, c.d_scal, shift);
+    hipLaunchKernelGGL(k_minmax, reduce_grid(r), dim3(64, 4, 1), 0, c.stream, mf->fabs[i], r, comp, c.d_scal, shift);
   }
   HIPCHK(hipMemcpyAsync(c.h_scal, c.d_scal, 2 * sizeof(double), hipMemcpyDeviceToHost, c.stream));
   HIPCHK(hipStreamSynchronize(c.stream));

@@ -34,7 +34,32 @@ DEVI void atomic_max_nonneg(double *addr, double v) {
   // for non-negative IEEE doubles the u64 bit pattern is monotone in the value
   atomicMax(reinterpret_cast<unsigned long long *>(addr), (unsigned long long)__double_as_longlong(v));
 }
+// block-level max, then ONE atomic per workgroup.  Every thread of the block must call it.
+// (A single device-scope atomic costs ~12 ns and atomics on one address serialise: one per wave on a
+// 256^3 box is 262k atomics = 3 ms, measured; reduction kernels therefore also loop over k-planes so
+// that a launch has only a few thousand workgroups -- see REDUCE_KLOOP / reduce_grid.)
 DEVI void block_atomic_max(double *addr, double v) {
+  __shared__ double sm_[16];
   v = wave_max(v);
-  if (((threadIdx.x + blockDim.x * (threadIdx.y + blockDim.y * threadIdx.z)) & 63) == 0) atomic_max_nonneg(addr, v);
+  const int tid = threadIdx.x + blockDim.x * (threadIdx.y + blockDim.y * threadIdx.z);
+  const int nw = (blockDim.x * blockDim.y * blockDim.z + 63) >> 6;
+  if ((tid & 63) == 0) sm_[tid >> 6] = v;
+  __syncthreads();
+  if (tid == 0) {
+    for (int w = 1; w < nw; w++) v = fmax(v, sm_[w]);
+    atomic_max_nonneg(addr, v);
+  }
+  __syncthreads();
 }
+// grid for a reduction over range r: x,y tiled by the block, at most 8 workgroups along z, each looping
+// over its share of k-planes with stride gridDim.z
+static inline dim3 reduce_grid(const Range3 &r, dim3 block = dim3(64, 4, 1)) {
+  dim3 g = grid_for(r, block);
+  if (g.z > 8) g.z = 8;
+  return g;
+}
+#define REDUCE_IJ(r)                                                      \
+  const int i = (r).lo[0] + (int)(blockIdx.x * blockDim.x + threadIdx.x); \
+  const int j = (r).lo[1] + (int)(blockIdx.y * blockDim.y + threadIdx.y); \
+  const bool in_ij = (i <= (r).hi[0]) && (j <= (r).hi[1]);
+#define REDUCE_KLOOP(r) for (int k = (r).lo[2] + (int)blockIdx.z; k <= (r).hi[2]; k += (int)gridDim.z)
