@@ -106,9 +106,15 @@ def main():
         ms, ncell = adv.bench_cc_smoother(rh, phi, beta, G.dx[0], bc, 200)
         alg_bytes = 48.0 * ncell
         achieved = alg_bytes / (ms * 1e-3) / 1e9
+        # HBM traffic per launch from the PMC passes (FETCH_SIZE x2 + WRITE_SIZE, MI355X_MICROARCH.md), collected
+        # separately with `rocprofv3 --pmc` on tools/smoother_probe.py and committed under profiles/
+        traffic = None
+        pmc = os.path.join(ROOT, "profiles", "r01_smoother_pmc.json")
+        if n == 256 and os.path.exists(pmc):
+            traffic = json.load(open(pmc))["hbm_bytes_per_launch"]
         roof = {"bound": "hbm", "kernel": "kk_cc_gsrb (MAC-MG red-black GS colour pass, %d^3)" % n,
                 "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                 "avg_launch_ms": round(ms, 5), "alg_bytes_per_launch": alg_bytes}
         for m in [rh, phi] + beta:
             m.destroy()
