@@ -91,6 +91,22 @@ int  vdn_device_synchronize(void);
 int  vdn_get_params(vdn_params *out);
 
 /* ------------------------------------------------------------------------------------------- */
+/* rank-to-rank transport (replaces FBoxLib's `parallel` MPI wrapper on the hot path): one rank  */
+/* per GPU, RCCL point-to-point for ghost exchange, ncclAllReduce(MAX) for norms / estdt.          */
+/* Rank 0 calls vdn_comm_get_unique_id, the host broadcasts the 128 bytes (MPI_Bcast in a Fortran   */
+/* driver, torch.distributed in bench.py), every rank calls vdn_comm_init.  No-ops when nranks = 1. */
+/* ------------------------------------------------------------------------------------------- */
+int  vdn_comm_get_unique_id(char *id128);
+int  vdn_comm_init(const char *id128);
+int  vdn_comm_finalize(void);
+/* host-only introspection of the ghost-exchange plan (used by the CPU multi-process tests): the remote  */
+/* copies rank `as_rank` performs for a multifab (nc, ng, nodal) on the given boxes; rows of 14 longs:  */
+/* [kind 0=send 1=recv, peer, lo[3], hi[3], shift[3], buffer offset (doubles), dst box, src box]          */
+int  vdn_plan_describe(const vdn_box *pd, const int *pmask, int nboxes, const vdn_box *boxes, const int *owner,
+                       int nc, int ng, const int *nodal, int as_rank, long *rows, int maxrows,
+                       int *nrows, int *nlocal_descs);
+
+/* ------------------------------------------------------------------------------------------- */
 /* ml_layout: nlev levels; rr[nlev-1][3] refinement ratios; pd[nlev] problem domains;          */
 /* boxes of all levels concatenated (nboxes[l] each); owner[] = rank of each box;              */
 /* pmask[3] periodicity.  (BoxLib: ml_layout_build / layout_build_ba)                          */

@@ -61,6 +61,11 @@ SIGNATURES = {
     "vdn_set_stream": (C.c_int, [_VP]),
     "vdn_device_synchronize": (C.c_int, []),
     "vdn_get_params": (C.c_int, [C.POINTER(Params)]),
+    "vdn_comm_get_unique_id": (C.c_int, [C.c_char_p]),
+    "vdn_comm_init": (C.c_int, [C.c_char_p]),
+    "vdn_comm_finalize": (C.c_int, []),
+    "vdn_plan_describe": (C.c_int, [C.POINTER(Box), _PI, C.c_int, C.POINTER(Box), _PI, C.c_int, C.c_int, _PI, C.c_int,
+                                    C.POINTER(C.c_long), C.c_int, _PI, _PI]),
     "vdn_layout_create": (C.c_int, [C.c_int, _PI, C.POINTER(Box), _PI, C.POINTER(Box), _PI, _PI, _PVP]),
     "vdn_layout_destroy": (C.c_int, [_VP]),
     "vdn_layout_nlevel": (C.c_int, [_VP]),

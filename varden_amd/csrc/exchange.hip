@@ -1,0 +1,340 @@
+// exchange.hip -- ghost-point exchange (FBoxLib multifab_fill_boundary) and the rank-to-rank
+// transport of the MI355X-native VARDEN hot path.
+//
+// One rank per GPU.  Boxes owned by this rank exchange ghosts with device-side copies; boxes owned by
+// other ranks go through packed HBM buffers and RCCL point-to-point (ncclSend/ncclRecv inside one
+// group per exchange -- xGMI is point-to-point, a 256^3 box has at most 26 neighbours and the seven
+// face/edge/corner peers of a 2x2x2 decomposition map onto the seven links).  Reductions
+// (residual norms, estdt maxima, umac_norm) are ncclAllReduce(MAX) on a device scalar.
+//
+// RCCL is bound with dlopen("librccl.so.1") at vdn_comm_init time instead of at link time: the host
+// process (PyTorch in bench.py, an MPI Fortran driver elsewhere) may already have an RCCL loaded, and the
+// dynamic linker then hands back that same copy instead of a second one.
+//
+// The exchange plan -- which region of which box goes where -- is the analogue of FBoxLib's cached
+// `copyassoc` (reference src/main.f90:23,39-47); it is built once per (allocation, shape) and kept on
+// the device.  Both sides of a remote copy enumerate (dst box, src box, periodic shift) in the same
+// canonical order, so offsets into the per-peer buffers agree without any handshake.
+#include "vdn_dev.h"
+#include <dlfcn.h>
+#include <algorithm>
+#include <tuple>
+
+void mg_halo_cache_purge(unsigned long uid);   // mg_cc.hip / mg_nd.hip keep key -> plan maps; they drop the keys
+
+// ====================================================================================================
+// RCCL through dlopen
+// ====================================================================================================
+typedef struct ncclComm *ncclComm_t;
+typedef struct { char internal[128]; } ncclUniqueId;
+enum { ncclSuccess = 0 };
+enum { ncclFloat64 = 8 };       // ncclDataType_t: ncclDouble
+enum { ncclSum = 0, ncclMax = 2 };
+struct Rccl {
+  void *h = nullptr;
+  int (*GetUniqueId)(ncclUniqueId *) = nullptr;
+  int (*CommInitRank)(ncclComm_t *, int, ncclUniqueId, int) = nullptr;
+  int (*CommDestroy)(ncclComm_t) = nullptr;
+  int (*Send)(const void *, size_t, int, int, ncclComm_t, hipStream_t) = nullptr;
+  int (*Recv)(void *, size_t, int, int, ncclComm_t, hipStream_t) = nullptr;
+  int (*AllReduce)(const void *, void *, size_t, int, int, ncclComm_t, hipStream_t) = nullptr;
+  int (*AllGather)(const void *, void *, size_t, int, ncclComm_t, hipStream_t) = nullptr;
+  int (*GroupStart)() = nullptr;
+  int (*GroupEnd)() = nullptr;
+  const char *(*GetErrorString)(int) = nullptr;
+  ncclComm_t comm = nullptr;
+};
+static Rccl g_rccl;
+#define NCCLCHK(x) do { int r_ = (x); if (r_ != ncclSuccess) vdn_fail("%s failed: %s", #x, g_rccl.GetErrorString ? g_rccl.GetErrorString(r_) : "?"); } while (0)
+
+static void rccl_load() {
+  if (g_rccl.h) return;
+  const char *names[] = { "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1" };
+  for (const char *n : names) { g_rccl.h = dlopen(n, RTLD_NOW | RTLD_GLOBAL); if (g_rccl.h) break; }
+  REQUIRE(g_rccl.h, "cannot dlopen librccl.so.1: %s", dlerror());
+  #define SYM(field, name) do { *(void **)(&g_rccl.field) = dlsym(g_rccl.h, name); REQUIRE(g_rccl.field, "RCCL symbol %s missing", name); } while (0)
+  SYM(GetUniqueId, "ncclGetUniqueId"); SYM(CommInitRank, "ncclCommInitRank"); SYM(CommDestroy, "ncclCommDestroy");
+  SYM(Send, "ncclSend"); SYM(Recv, "ncclRecv"); SYM(AllReduce, "ncclAllReduce"); SYM(AllGather, "ncclAllGather");
+  SYM(GroupStart, "ncclGroupStart"); SYM(GroupEnd, "ncclGroupEnd"); SYM(GetErrorString, "ncclGetErrorString");
+  #undef SYM
+}
+
+extern "C" int vdn_comm_get_unique_id(char *id128) {
+  VDN_TRY
+  rccl_load();
+  ncclUniqueId id; NCCLCHK(g_rccl.GetUniqueId(&id));
+  memcpy(id128, id.internal, 128);
+  VDN_CATCH
+}
+extern "C" int vdn_comm_init(const char *id128) {
+  VDN_TRY
+  REQUIRE(ctx().inited, "vdn_comm_init: call vdn_init first");
+  if (ctx().nranks == 1) return 0;
+  rccl_load();
+  ncclUniqueId id; memcpy(id.internal, id128, 128);
+  NCCLCHK(g_rccl.CommInitRank(&g_rccl.comm, ctx().nranks, id, ctx().rank));
+  VDN_CATCH
+}
+extern "C" int vdn_comm_finalize(void) {
+  VDN_TRY
+  if (g_rccl.comm) { HIPCHK(hipStreamSynchronize(ctx().stream)); NCCLCHK(g_rccl.CommDestroy(g_rccl.comm)); g_rccl.comm = nullptr; }
+  VDN_CATCH
+}
+bool comm_active() { return ctx().nranks > 1; }
+static void need_comm() { REQUIRE(g_rccl.comm != nullptr, "this operation spans ranks: call vdn_comm_init first (nranks = %d)", ctx().nranks); }
+
+// all-reduce MAX of n device doubles, in place, on the launch stream
+void comm_allreduce_max_dev(double *d, int n) {
+  if (!comm_active()) return;
+  need_comm();
+  NCCLCHK(g_rccl.AllReduce(d, d, (size_t)n, ncclFloat64, ncclMax, g_rccl.comm, ctx().stream));
+}
+// all-gather: every rank contributes `count` doubles; recv holds nranks*count
+void comm_allgather_dev(const double *send, double *recv, size_t count) {
+  if (!comm_active()) { if (send != recv) HIPCHK(hipMemcpyAsync(recv, send, count * sizeof(double), hipMemcpyDeviceToDevice, ctx().stream)); return; }
+  need_comm();
+  NCCLCHK(g_rccl.AllGather(send, recv, count, ncclFloat64, g_rccl.comm, ctx().stream));
+}
+
+// ====================================================================================================
+// exchange plans
+// ====================================================================================================
+struct CopyDesc { FV dst, src; int lo[3], hi[3]; int sh[3]; int vlo[3], vhi[3]; };
+struct PackDesc { FV fv; int lo[3], hi[3]; int sh[3]; int vlo[3], vhi[3]; long off; };   // pack: fv = src (read at q - sh); unpack: fv = dst
+
+__global__ void k_xcopy(const CopyDesc *descs, int nc) {
+  const CopyDesc &D = descs[blockIdx.z];
+  const int nx = D.hi[0] - D.lo[0] + 1, ny = D.hi[1] - D.lo[1] + 1, nz = D.hi[2] - D.lo[2] + 1;
+  const long tot = (long)nx * ny * nz;
+  for (long t = (long)blockIdx.x * blockDim.x + threadIdx.x; t < tot; t += (long)gridDim.x * blockDim.x) {
+    const int i = D.lo[0] + (int)(t % nx), j = D.lo[1] + (int)((t / nx) % ny), k = D.lo[2] + (int)(t / ((long)nx * ny));
+    const bool inside = i >= D.vlo[0] && i <= D.vhi[0] && j >= D.vlo[1] && j <= D.vhi[1] && k >= D.vlo[2] && k <= D.vhi[2];
+    if (inside) continue;                 // only ghost points are filled
+    for (int c = 0; c < nc; c++) fv_at(D.dst, i, j, k, c) = fv_get(D.src, i - D.sh[0], j - D.sh[1], k - D.sh[2], c);
+  }
+}
+__global__ void k_xpack(const PackDesc *descs, int nc, double *buf) {
+  const PackDesc &D = descs[blockIdx.z];
+  const int nx = D.hi[0] - D.lo[0] + 1, ny = D.hi[1] - D.lo[1] + 1, nz = D.hi[2] - D.lo[2] + 1;
+  const long tot = (long)nx * ny * nz;
+  for (long t = (long)blockIdx.x * blockDim.x + threadIdx.x; t < tot; t += (long)gridDim.x * blockDim.x) {
+    const int i = D.lo[0] + (int)(t % nx), j = D.lo[1] + (int)((t / nx) % ny), k = D.lo[2] + (int)(t / ((long)nx * ny));
+    for (int c = 0; c < nc; c++) buf[D.off + c * tot + t] = fv_get(D.fv, i - D.sh[0], j - D.sh[1], k - D.sh[2], c);
+  }
+}
+__global__ void k_xunpack(const PackDesc *descs, int nc, const double *buf) {
+  const PackDesc &D = descs[blockIdx.z];
+  const int nx = D.hi[0] - D.lo[0] + 1, ny = D.hi[1] - D.lo[1] + 1, nz = D.hi[2] - D.lo[2] + 1;
+  const long tot = (long)nx * ny * nz;
+  for (long t = (long)blockIdx.x * blockDim.x + threadIdx.x; t < tot; t += (long)gridDim.x * blockDim.x) {
+    const int i = D.lo[0] + (int)(t % nx), j = D.lo[1] + (int)((t / nx) % ny), k = D.lo[2] + (int)(t / ((long)nx * ny));
+    const bool inside = i >= D.vlo[0] && i <= D.vhi[0] && j >= D.vlo[1] && j <= D.vhi[1] && k >= D.vlo[2] && k <= D.vhi[2];
+    if (inside) continue;
+    for (int c = 0; c < nc; c++) fv_at(D.fv, i, j, k, c) = buf[D.off + c * tot + t];
+  }
+}
+
+struct Peer {
+  int rank = -1;
+  std::vector<PackDesc> pack, unpack;
+  size_t nsend = 0, nrecv = 0;           // doubles
+  PackDesc *d_pack = nullptr, *d_unpack = nullptr;
+  double *d_send = nullptr, *d_recv = nullptr;
+};
+struct XPlan {
+  std::vector<CopyDesc> local; CopyDesc *d_local = nullptr;
+  std::vector<Peer> peers;
+  int nc = 1;
+};
+
+// the plan for: every box b (global list) has valid point range [vlo,vhi] (incl. nodal points) and, if
+// local, an FV view; ghosts of width ng are filled from other boxes' valid points, through periodic
+// shifts of the domain `pd` where pmask says so.
+XPlan *xplan_build(const std::vector<XBoxInfo> &boxes, const vdn_box &pd, const int pmask[3], int ng, int nc) {
+  XPlan *P = new XPlan; P->nc = nc;
+  const int me = ctx().rank;
+  int per[3], nshift[3];
+  for (int d = 0; d < 3; d++) { per[d] = pd.hi[d] - pd.lo[d] + 1; nshift[d] = pmask[d] ? 1 : 0; }
+  std::map<int, Peer> peers;
+  const int nb = (int)boxes.size();
+  for (int i = 0; i < nb; i++) {
+    const XBoxInfo &B = boxes[i];
+    int glo[3], ghi[3];
+    for (int d = 0; d < 3; d++) { glo[d] = B.vlo[d] - ng; ghi[d] = B.vhi[d] + ng; }
+    for (int j = 0; j < nb; j++) {
+      const XBoxInfo &S = boxes[j];
+      if (B.owner != me && S.owner != me) continue;
+      for (int sz = -nshift[2]; sz <= nshift[2]; sz++) for (int sy = -nshift[1]; sy <= nshift[1]; sy++) for (int sx = -nshift[0]; sx <= nshift[0]; sx++) {
+        if (j == i && sx == 0 && sy == 0 && sz == 0) continue;
+        const int sh[3] = { sx * per[0], sy * per[1], sz * per[2] };
+        int lo[3], hi[3]; bool empty = false, all_inside = true;
+        for (int d = 0; d < 3; d++) {
+          lo[d] = std::max(glo[d], S.vlo[d] + sh[d]); hi[d] = std::min(ghi[d], S.vhi[d] + sh[d]);
+          if (lo[d] > hi[d]) empty = true;
+          if (lo[d] < B.vlo[d] || hi[d] > B.vhi[d]) all_inside = false;
+        }
+        if (empty || all_inside) continue;
+        const long cnt = (long)(hi[0] - lo[0] + 1) * (hi[1] - lo[1] + 1) * (hi[2] - lo[2] + 1) * nc;
+        if (B.owner == me && S.owner == me) {
+          CopyDesc D; memset(&D, 0, sizeof D);
+          D.dst = B.fv; D.src = S.fv;
+          for (int d = 0; d < 3; d++) { D.lo[d] = lo[d]; D.hi[d] = hi[d]; D.sh[d] = sh[d]; D.vlo[d] = B.vlo[d]; D.vhi[d] = B.vhi[d]; }
+          P->local.push_back(D);
+        } else {
+          PackDesc D; memset(&D, 0, sizeof D);
+          for (int d = 0; d < 3; d++) { D.lo[d] = lo[d]; D.hi[d] = hi[d]; D.sh[d] = sh[d]; D.vlo[d] = B.vlo[d]; D.vhi[d] = B.vhi[d]; }
+          if (S.owner == me) {            // I send to the owner of the destination box
+            Peer &pr = peers[B.owner]; pr.rank = B.owner;
+            D.fv = S.fv; D.off = (long)pr.nsend; pr.nsend += cnt; pr.pack.push_back(D);
+          } else {                        // I receive from the owner of the source box
+            Peer &pr = peers[S.owner]; pr.rank = S.owner;
+            D.fv = B.fv; D.off = (long)pr.nrecv; pr.nrecv += cnt; pr.unpack.push_back(D);
+          }
+        }
+      }
+    }
+  }
+  hipStream_t st = ctx().stream;
+  if (!P->local.empty()) {
+    HIPCHK(hipMalloc((void **)&P->d_local, P->local.size() * sizeof(CopyDesc)));
+    HIPCHK(hipMemcpyAsync(P->d_local, P->local.data(), P->local.size() * sizeof(CopyDesc), hipMemcpyHostToDevice, st));
+  }
+  for (auto &kv : peers) {
+    Peer pr = kv.second;
+    if (!pr.pack.empty()) { HIPCHK(hipMalloc((void **)&pr.d_pack, pr.pack.size() * sizeof(PackDesc)));
+      HIPCHK(hipMemcpyAsync(pr.d_pack, pr.pack.data(), pr.pack.size() * sizeof(PackDesc), hipMemcpyHostToDevice, st));
+      HIPCHK(hipMalloc((void **)&pr.d_send, pr.nsend * sizeof(double))); }
+    if (!pr.unpack.empty()) { HIPCHK(hipMalloc((void **)&pr.d_unpack, pr.unpack.size() * sizeof(PackDesc)));
+      HIPCHK(hipMemcpyAsync(pr.d_unpack, pr.unpack.data(), pr.unpack.size() * sizeof(PackDesc), hipMemcpyHostToDevice, st));
+      HIPCHK(hipMalloc((void **)&pr.d_recv, pr.nrecv * sizeof(double))); }
+    P->peers.push_back(pr);
+  }
+  HIPCHK(hipStreamSynchronize(st));
+  return P;
+}
+
+void xplan_free(XPlan *P) {
+  if (!P) return;
+  HIPCHK(hipStreamSynchronize(ctx().stream));
+  if (P->d_local) HIPCHK(hipFree(P->d_local));
+  for (auto &pr : P->peers) {
+    if (pr.d_pack) HIPCHK(hipFree(pr.d_pack));
+    if (pr.d_unpack) HIPCHK(hipFree(pr.d_unpack));
+    if (pr.d_send) HIPCHK(hipFree(pr.d_send));
+    if (pr.d_recv) HIPCHK(hipFree(pr.d_recv));
+  }
+  delete P;
+}
+
+void xplan_run(XPlan *P) {
+  hipStream_t st = ctx().stream;
+  const int nc = P->nc;
+  // pack + post the remote traffic first so that it overlaps the local copies
+  if (!P->peers.empty()) {
+    need_comm();
+    for (auto &pr : P->peers)
+      if (!pr.pack.empty()) hipLaunchKernelGGL(k_xpack, dim3(32, 1, (unsigned)pr.pack.size()), dim3(256), 0, st, pr.d_pack, nc, pr.d_send);
+    NCCLCHK(g_rccl.GroupStart());
+    for (auto &pr : P->peers) {
+      if (pr.nsend) NCCLCHK(g_rccl.Send(pr.d_send, pr.nsend, ncclFloat64, pr.rank, g_rccl.comm, st));
+      if (pr.nrecv) NCCLCHK(g_rccl.Recv(pr.d_recv, pr.nrecv, ncclFloat64, pr.rank, g_rccl.comm, st));
+    }
+    NCCLCHK(g_rccl.GroupEnd());
+  }
+  if (!P->local.empty())
+    hipLaunchKernelGGL(k_xcopy, dim3(64, 1, (unsigned)P->local.size()), dim3(256), 0, st, P->d_local, nc);
+  for (auto &pr : P->peers)
+    if (!pr.unpack.empty()) hipLaunchKernelGGL(k_xunpack, dim3(32, 1, (unsigned)pr.unpack.size()), dim3(256), 0, st, pr.d_unpack, nc, pr.d_recv);
+}
+
+// ====================================================================================================
+// multifab_fill_boundary
+// ====================================================================================================
+std::vector<XBoxInfo> xboxes_of(const vdn_multifab *mf) {
+  const vdn_layout *la = mf->la;
+  std::vector<XBoxInfo> v;
+  const auto &bx = la->boxes[mf->lev];
+  int li = 0;
+  for (size_t g = 0; g < bx.size(); g++) {
+    XBoxInfo b; memset(&b, 0, sizeof b);
+    for (int d = 0; d < 3; d++) { b.vlo[d] = bx[g].lo[d]; b.vhi[d] = bx[g].hi[d] + mf->nodal[d]; }
+    b.owner = la->owner[mf->lev][g];
+    if (b.owner == ctx().rank) b.fv = mf->fabs[li++];
+    v.push_back(b);
+  }
+  return v;
+}
+
+// plan caches are keyed by the layout's uid (never by its address: a freed layout's address is reused) and by the
+// allocation; they are purged when the layout is destroyed
+struct FbKey { unsigned long uid; const void *base; int lev, nc, ng, nd; bool operator<(const FbKey &o) const {
+  return std::tie(uid, base, lev, nc, ng, nd) < std::tie(o.uid, o.base, o.lev, o.nc, o.ng, o.nd); } };
+static std::map<FbKey, XPlan *> g_fb_cache;
+static std::multimap<unsigned long, XPlan *> g_halo_owned;     // multigrid halo plans, by layout uid
+void halo_cache_register(unsigned long uid, XPlan *P) { g_halo_owned.emplace(uid, P); }
+void xplan_cache_purge(unsigned long uid) {
+  for (auto it = g_fb_cache.begin(); it != g_fb_cache.end();) {
+    if (it->first.uid == uid) { xplan_free(it->second); it = g_fb_cache.erase(it); } else ++it;
+  }
+  auto rng = g_halo_owned.equal_range(uid);
+  for (auto it = rng.first; it != rng.second; ++it) xplan_free(it->second);
+  g_halo_owned.erase(rng.first, rng.second);
+  mg_halo_cache_purge(uid);
+}
+
+void mf_fill_boundary(vdn_multifab *mf) {
+  if (mf->ng == 0) return;
+  FbKey key{ mf->la->uid, mf->base, mf->lev, mf->nc, mf->ng, mf->nodal[0] | (mf->nodal[1] << 1) | (mf->nodal[2] << 2) };
+  auto it = g_fb_cache.find(key);
+  if (it == g_fb_cache.end()) {
+    XPlan *P = xplan_build(xboxes_of(mf), mf->la->pd[mf->lev], mf->la->pmask, mf->ng, mf->nc);
+    it = g_fb_cache.emplace(key, P).first;
+    if (g_fb_cache.size() > 4096) vdn_fail("fill_boundary plan cache grew beyond 4096 entries (leaking multifabs?)");
+  }
+  XPlan *P = it->second;
+  if (P->local.empty() && P->peers.empty()) return;
+  xplan_run(P);
+}
+extern "C" int vdn_multifab_fill_boundary(vdn_multifab *mf) { VDN_TRY mf_fill_boundary(mf); VDN_CATCH }
+
+// plan introspection for the CPU tests of the host logic (pure host code, no GPU, no layout object): the remote
+// descriptors rank `as_rank` would build for a multifab of the given shape on the given boxes, one row of 14
+// longs each: [kind (0 = I send, 1 = I receive), peer, lo[3], hi[3], shift[3], buffer offset, dst box, src box]
+extern "C" int vdn_plan_describe(const vdn_box *pd, const int *pmask, int nboxes, const vdn_box *boxes, const int *owner,
+                                 int nc, int ng, const int *nodal, int as_rank, long *rows, int maxrows,
+                                 int *nrows, int *nlocal_descs) {
+  VDN_TRY
+  int per[3], nshift[3];
+  for (int d = 0; d < 3; d++) { per[d] = pd->hi[d] - pd->lo[d] + 1; nshift[d] = pmask[d] ? 1 : 0; }
+  std::map<int, std::pair<long, long>> offs;     // peer -> (send offset, recv offset)
+  int n = 0, nloc = 0;
+  for (int i = 0; i < nboxes; i++) for (int j = 0; j < nboxes; j++) {
+    if (owner[i] != as_rank && owner[j] != as_rank) continue;
+    int bvlo[3], bvhi[3], svlo[3], svhi[3];
+    for (int d = 0; d < 3; d++) {
+      bvlo[d] = boxes[i].lo[d]; bvhi[d] = boxes[i].hi[d] + (nodal ? nodal[d] : 0);
+      svlo[d] = boxes[j].lo[d]; svhi[d] = boxes[j].hi[d] + (nodal ? nodal[d] : 0);
+    }
+    for (int sz = -nshift[2]; sz <= nshift[2]; sz++) for (int sy = -nshift[1]; sy <= nshift[1]; sy++) for (int sx = -nshift[0]; sx <= nshift[0]; sx++) {
+      if (j == i && sx == 0 && sy == 0 && sz == 0) continue;
+      const int sh[3] = { sx * per[0], sy * per[1], sz * per[2] };
+      int lo[3], hi[3]; bool empty = false, all_inside = true;
+      for (int d = 0; d < 3; d++) {
+        lo[d] = std::max(bvlo[d] - ng, svlo[d] + sh[d]); hi[d] = std::min(bvhi[d] + ng, svhi[d] + sh[d]);
+        if (lo[d] > hi[d]) empty = true;
+        if (lo[d] < bvlo[d] || hi[d] > bvhi[d]) all_inside = false;
+      }
+      if (empty || all_inside) continue;
+      const long cnt = (long)(hi[0] - lo[0] + 1) * (hi[1] - lo[1] + 1) * (hi[2] - lo[2] + 1) * nc;
+      if (owner[i] == as_rank && owner[j] == as_rank) { nloc++; continue; }
+      const int kind = (owner[j] == as_rank) ? 0 : 1;
+      const int peer = kind == 0 ? owner[i] : owner[j];
+      long &off = kind == 0 ? offs[peer].first : offs[peer].second;
+      if (n < maxrows) { long *r = rows + 14 * n; r[0] = kind; r[1] = peer; for (int d = 0; d < 3; d++) { r[2 + d] = lo[d]; r[5 + d] = hi[d]; r[8 + d] = sh[d]; } r[11] = off; r[12] = i; r[13] = j; }
+      off += cnt; n++;
+    }
+  }
+  *nrows = n;
+  if (nlocal_descs) *nlocal_descs = nloc;
+  VDN_CATCH
+}

@@ -14,6 +14,8 @@
 // pass = 48 B/cell (phi r+w 16, rh 8, bx/by/bz 24), see DESIGN.md.
 #include "vdn_dev.h"
 #include <chrono>
+#include <tuple>
+#include <algorithm>
 
 struct CLev {
   int n[3]; int PX, PY; long sz;
@@ -199,60 +201,214 @@ __global__ void kk_cc_store(CLev L, FV phi, int lo0, int lo1, int lo2, int ebc00
   fv_at(phi, lo0 + i, lo1 + j, lo2 + k) = v;
 }
 
+// ---- gather of the first agglomerated level ------------------------------------------------------------------
+// Below a box extent of 4 the per-box levels stop; the next coarser level of the WHOLE domain (and everything
+// under it) is held redundantly by every rank as one box ("agglomerated tail"): latency-bound work is not worth
+// distributing over xGMI.  Each rank restricts its boxes' residuals into a packed buffer, one all-gather makes
+// every rank's buffer visible everywhere, and an unpack kernel assembles the global coarse right-hand side.
+// The face coefficients of the tail's first level travel the same way once per solve.
+struct GBox { int c0[3]; int n[3]; long off; };     // where a box's coarse cells sit in the tail level / in the buffer
+
+__global__ void kk_cc_restrict_pack(CLev F, double *buf, long off, int nx, int ny, int nz) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  const int j = blockIdx.y * blockDim.y + threadIdx.y;
+  const int k = blockIdx.z;
+  if (i >= nx || j >= ny) return;
+  const long sy = F.PX, sz = (long)F.PX * F.PY;
+  const long f = cidx(F, 2 * i, 2 * j, 2 * k);
+  const double *r = F.res;
+  double s = r[f] + r[f + 1] + r[f + sy] + r[f + sy + 1] + r[f + sz] + r[f + sz + 1] + r[f + sz + sy] + r[f + sz + sy + 1];
+  buf[off + i + (long)nx * (j + (long)ny * k)] = s * 0.125;
+}
+// coarse face coefficients of one box into the buffer: [bx (nx+1,ny,nz) | by (nx,ny+1,nz) | bz (nx,ny,nz+1)]
+__global__ void kk_cc_coarsen_b_pack(CLev F, double *buf, long off, int nx, int ny, int nz) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  const int j = blockIdx.y * blockDim.y + threadIdx.y;
+  const int k = blockIdx.z;
+  if (i > nx || j > ny || k > nz) return;
+  const long sy = F.PX, sz = (long)F.PX * F.PY;
+  const long f = cidx(F, 2 * i, 2 * j, 2 * k);
+  const long o1 = off + (long)(nx + 1) * ny * nz, o2 = o1 + (long)nx * (ny + 1) * nz;
+  if (j < ny && k < nz) buf[off + i + (long)(nx + 1) * (j + (long)ny * k)] = (F.b[0][f] + F.b[0][f + sy] + F.b[0][f + sz] + F.b[0][f + sz + sy]) * 0.25;
+  if (i < nx && k < nz) buf[o1 + i + (long)nx * (j + (long)(ny + 1) * k)] = (F.b[1][f] + F.b[1][f + 1] + F.b[1][f + sz] + F.b[1][f + sz + 1]) * 0.25;
+  if (i < nx && j < ny) buf[o2 + i + (long)nx * (j + (long)ny * k)] = (F.b[2][f] + F.b[2][f + 1] + F.b[2][f + sy] + F.b[2][f + sy + 1]) * 0.25;
+}
+__global__ void kk_cc_unpack_rh(CLev T, const double *buf, const GBox *gb) {
+  const GBox g = gb[blockIdx.z];
+  const int tot = g.n[0] * g.n[1] * g.n[2];
+  for (int t = blockIdx.x * blockDim.x + threadIdx.x; t < tot; t += gridDim.x * blockDim.x) {
+    const int i = t % g.n[0], j = (t / g.n[0]) % g.n[1], k = t / (g.n[0] * g.n[1]);
+    T.rh[cidx(T, g.c0[0] + i, g.c0[1] + j, g.c0[2] + k)] = buf[g.off + t];
+  }
+}
+__global__ void kk_cc_unpack_b(CLev T, const double *buf, const GBox *gb) {
+  const GBox g = gb[blockIdx.z];
+  const int nx = g.n[0], ny = g.n[1], nz = g.n[2];
+  const long n0 = (long)(nx + 1) * ny * nz, n1 = (long)nx * (ny + 1) * nz, n2 = (long)nx * ny * (nz + 1);
+  for (long t = blockIdx.x * blockDim.x + threadIdx.x; t < n0 + n1 + n2; t += gridDim.x * blockDim.x) {
+    int d; long u = t;
+    if (u < n0) d = 0; else if (u < n0 + n1) { d = 1; u -= n0; } else { d = 2; u -= n0 + n1; }
+    const int ex = nx + (d == 0), ey = ny + (d == 1);
+    const int i = (int)(u % ex), j = (int)((u / ex) % ey), k = (int)(u / ((long)ex * ey));
+    T.b[d][cidx(T, g.c0[0] + i, g.c0[1] + j, g.c0[2] + k)] = buf[g.off + t];
+  }
+}
+// prolongation from the (global, replicated) tail level into a box of the last distributed level
+__global__ void kk_cc_prolong_tail(CLev F, CLev T, int c00, int c01, int c02) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  const int j = blockIdx.y * blockDim.y + threadIdx.y;
+  const int k = blockIdx.z;
+  if (i >= F.n[0] || j >= F.n[1]) return;
+  const long f = cidx(F, i, j, k);
+  F.phi[f] = F.phi[f] + T.phi[cidx(T, c00 + (i >> 1), c01 + (j >> 1), c02 + (k >> 1))];
+}
+
 // ---- host side ------------------------------------------------------------------------------------------
+struct CBox { CLev L; int lo[3]; int gidx; };                    // one local box on one distributed level; lo = global index of its cell 0
+struct CDLev { std::vector<CBox> boxes; XPlan *halo = nullptr; int ng[3]; /* global extents of the level */ };
 struct CCMG {
-  std::vector<CLev> lev;
+  std::vector<CDLev> dlev;          // distributed levels (finest first)
+  std::vector<CLev> tail;           // agglomerated levels, whole domain, replicated on every rank
   int per[3];
-  double *d_nrm;     // device scalar
+  double *d_nrm;
+  // gather machinery
+  std::vector<GBox> gb_rh, gb_b; GBox *d_gb_rh = nullptr, *d_gb_b = nullptr;
+  double *sendbuf = nullptr, *recvbuf = nullptr; size_t cnt_rh = 0, cnt_b = 0;   // per-rank counts (doubles)
+  std::vector<long> loc_off_rh, loc_off_b;                                       // offsets of my boxes inside my send buffer
 };
 
 static dim3 g3(int nx, int ny, int nz, dim3 b) { return dim3((nx + b.x - 1) / b.x, (ny + b.y - 1) / b.y, nz); }
 static const dim3 BLK(64, 4, 1);
 
-static void cc_build(CCMG &M, const int n0[3], const double *dx, const int bc[3][2]) {
-  int n[3] = { n0[0], n0[1], n0[2] }; double h[3] = { dx[0], dx[1], dx[2] };
+static CLev cc_alloc_lev(const int n[3], const double h[3]) {
+  CLev L;
+  for (int d = 0; d < 3; d++) { L.n[d] = n[d]; L.hi2[d] = 1.0 / (h[d] * h[d]); }
+  L.PX = ((n[0] + 17 + 15) / 16) * 16; L.PY = n[1] + 2;
+  L.sz = (long)L.PX * L.PY * (n[2] + 2);
+  double *base = (double *)arena_alloc(sizeof(double) * L.sz * 6);
+  HIPCHK(hipMemsetAsync(base, 0, sizeof(double) * L.sz * 6, ctx().stream));
+  L.phi = base; L.rh = base + L.sz; L.res = base + 2 * L.sz;
+  for (int d = 0; d < 3; d++) L.b[d] = base + (3 + d) * L.sz;
+  return L;
+}
+static FV cc_phi_view(const CLev &L, const int lo[3]) {
+  FV f; f.p = L.phi; f.a0 = lo[0] - 16; f.a1 = lo[1] - 1; f.a2 = lo[2] - 1; f.n0 = L.PX; f.n1 = L.PY; f.n2 = L.n[2] + 2; f.sc = L.sz;
+  return f;
+}
+
+// plans for the per-level phi halos are cached across solves: arena addresses repeat from step to step
+struct HaloKey { unsigned long uid; const void *p0; int lev, l, per; bool operator<(const HaloKey &o) const { return std::tie(uid, p0, lev, l, per) < std::tie(o.uid, o.p0, o.lev, o.l, o.per); } };
+static std::map<HaloKey, XPlan *> g_halo_cache;
+void cc_halo_cache_purge(unsigned long uid) {        // the plans themselves are freed by exchange.hip (halo_cache_register)
+  for (auto it = g_halo_cache.begin(); it != g_halo_cache.end();) { if (it->first.uid == uid) it = g_halo_cache.erase(it); else ++it; }
+}
+
+static void cc_build(CCMG &M, const vdn_multifab *rh, const double *dx, const int bc[3][2]) {
+  const vdn_layout *la = rh->la; const int lev = rh->lev;
+  const auto &gboxes = la->boxes[lev];
+  const int nb = (int)gboxes.size();
   for (int d = 0; d < 3; d++) M.per[d] = (bc[d][0] == VDN_BC_PER);
+  // all boxes must share one size and be aligned to it (2x2x2-style decompositions); the general case needs
+  // per-box gather sizes and is left for the AMR round
+  int bn[3]; for (int d = 0; d < 3; d++) bn[d] = gboxes[0].hi[d] - gboxes[0].lo[d] + 1;
+  for (const auto &b : gboxes) for (int d = 0; d < 3; d++) {
+    REQUIRE(b.hi[d] - b.lo[d] + 1 == bn[d], "cc multigrid: all boxes of a level must have the same size");
+    REQUIRE((b.lo[d] - la->pd[lev].lo[d]) % bn[d] == 0, "cc multigrid: boxes must be aligned to their size");
+  }
+  std::vector<int> nloc_of(ctx().nranks, 0);
+  for (int g = 0; g < nb; g++) nloc_of[la->owner[lev][g]]++;
+  int maxloc = 0; for (int r = 0; r < ctx().nranks; r++) maxloc = std::max(maxloc, nloc_of[r]);
+  // ---- distributed levels: while every extent of the boxes is even and >= 4 --------------------------------
+  int n[3] = { bn[0], bn[1], bn[2] }; double h[3] = { dx[0], dx[1], dx[2] };
+  int scale = 1;
   for (;;) {
-    CLev L;
-    for (int d = 0; d < 3; d++) { L.n[d] = n[d]; L.hi2[d] = 1.0 / (h[d] * h[d]); }
-    L.PX = ((n[0] + 17 + 15) / 16) * 16; L.PY = n[1] + 2;
-    L.sz = (long)L.PX * L.PY * (n[2] + 2);
-    double *base = (double *)arena_alloc(sizeof(double) * L.sz * 6);
-    HIPCHK(hipMemsetAsync(base, 0, sizeof(double) * L.sz * 6, ctx().stream));
-    L.phi = base; L.rh = base + L.sz; L.res = base + 2 * L.sz;
-    for (int d = 0; d < 3; d++) L.b[d] = base + (3 + d) * L.sz;
-    M.lev.push_back(L);
-    bool can = true;
-    for (int d = 0; d < 3; d++) if ((n[d] & 1) || n[d] <= 2) can = false;
-    if (!can || M.lev.size() >= 31) break;
+    CDLev DL;
+    std::vector<XBoxInfo> xb;
+    for (int g = 0; g < nb; g++) {
+      XBoxInfo x; memset(&x, 0, sizeof x);
+      int lo[3];
+      for (int d = 0; d < 3; d++) { lo[d] = (gboxes[g].lo[d] - la->pd[lev].lo[d]) / scale; x.vlo[d] = lo[d]; x.vhi[d] = lo[d] + n[d] - 1; }
+      x.owner = la->owner[lev][g];
+      if (x.owner == ctx().rank) {
+        CBox B; B.L = cc_alloc_lev(n, h); B.gidx = g; for (int d = 0; d < 3; d++) B.lo[d] = lo[d];
+        x.fv = cc_phi_view(B.L, lo);
+        DL.boxes.push_back(B);
+      }
+      xb.push_back(x);
+    }
+    vdn_box lpd; for (int d = 0; d < 3; d++) { lpd.lo[d] = 0; lpd.hi[d] = (la->pd[lev].hi[d] - la->pd[lev].lo[d] + 1) / scale - 1; DL.ng[d] = lpd.hi[d] + 1; }
+    if (nb > 1 || M.per[0] || M.per[1] || M.per[2]) {
+      HaloKey key{ la->uid, DL.boxes.empty() ? nullptr : (const void *)DL.boxes[0].L.phi, lev, (int)M.dlev.size(), M.per[0] | (M.per[1] << 1) | (M.per[2] << 2) };
+      auto it = g_halo_cache.find(key);
+      if (it == g_halo_cache.end()) { XPlan *P = xplan_build(xb, lpd, M.per, 1, 1); halo_cache_register(la->uid, P); it = g_halo_cache.emplace(key, P).first; }
+      DL.halo = it->second;
+    }
+    M.dlev.push_back(DL);
+    // the hierarchy of GLOBAL levels is the single-box one (oracle rule: coarsen while every global extent is
+    // even and > 2); a level stays distributed while the boxes halve cleanly to extents >= 4
+    bool can = true, next_dist = true;
+    for (int d = 0; d < 3; d++) {
+      const int N = lpd.hi[d] + 1;
+      if ((N & 1) || N <= 2) can = false;
+    }
+    if (can) for (int d = 0; d < 3; d++) REQUIRE(!(n[d] & 1), "cc multigrid: box extent %d is odd while the domain can still be coarsened", n[d]);
+    for (int d = 0; d < 3; d++) if (n[d] / 2 < 4 || ((n[d] / 2) & 1)) next_dist = false;
+    if (!can) break;                                   // the domain cannot be coarsened: this level is the bottom
+    if (!next_dist) {
+      // ---- agglomerated tail starting at the half of this level ---------------------------------------------
+      int tn[3]; double th[3]; int cn[3];
+      for (int d = 0; d < 3; d++) { cn[d] = n[d] / 2; tn[d] = (lpd.hi[d] + 1) / 2; th[d] = h[d] * 2.0; }
+      for (;;) {
+        M.tail.push_back(cc_alloc_lev(tn, th));
+        bool c2 = true;
+        for (int d = 0; d < 3; d++) if ((tn[d] & 1) || tn[d] <= 2) c2 = false;
+        if (!c2 || M.tail.size() >= 31) break;
+        for (int d = 0; d < 3; d++) { tn[d] /= 2; th[d] *= 2.0; }
+      }
+      // gather descriptors: rank r's buffer holds its boxes in local order, padded to maxloc boxes
+      const long per_rh = (long)cn[0] * cn[1] * cn[2];
+      const long per_b = (long)(cn[0] + 1) * cn[1] * cn[2] + (long)cn[0] * (cn[1] + 1) * cn[2] + (long)cn[0] * cn[1] * (cn[2] + 1);
+      M.cnt_rh = (size_t)per_rh * maxloc; M.cnt_b = (size_t)per_b * maxloc;
+      std::vector<int> seen(ctx().nranks, 0);
+      for (int g = 0; g < nb; g++) {
+        const int r = la->owner[lev][g], l = seen[r]++;
+        GBox a, b2;
+        for (int d = 0; d < 3; d++) { a.c0[d] = b2.c0[d] = (gboxes[g].lo[d] - la->pd[lev].lo[d]) / scale / 2; a.n[d] = b2.n[d] = cn[d]; }
+        a.off = (long)r * M.cnt_rh + (long)l * per_rh; b2.off = (long)r * M.cnt_b + (long)l * per_b;
+        M.gb_rh.push_back(a); M.gb_b.push_back(b2);
+        if (r == ctx().rank) { M.loc_off_rh.push_back((long)l * per_rh); M.loc_off_b.push_back((long)l * per_b); }
+      }
+      M.d_gb_rh = (GBox *)arena_alloc(nb * sizeof(GBox)); M.d_gb_b = (GBox *)arena_alloc(nb * sizeof(GBox));
+      HIPCHK(hipMemcpyAsync(M.d_gb_rh, M.gb_rh.data(), nb * sizeof(GBox), hipMemcpyHostToDevice, ctx().stream));
+      HIPCHK(hipMemcpyAsync(M.d_gb_b, M.gb_b.data(), nb * sizeof(GBox), hipMemcpyHostToDevice, ctx().stream));
+      HIPCHK(hipStreamSynchronize(ctx().stream));     // the host vectors above are read by the copies
+      M.sendbuf = (double *)arena_alloc(sizeof(double) * M.cnt_b);
+      M.recvbuf = (double *)arena_alloc(sizeof(double) * M.cnt_b * ctx().nranks);
+      break;
+    }
     for (int d = 0; d < 3; d++) { n[d] /= 2; h[d] *= 2.0; }
+    scale *= 2;
+    if (M.dlev.size() >= 31) break;
   }
   M.d_nrm = (double *)arena_alloc(256);
 }
 
-static void cc_periodic(const CCMG &M, const CLev &L) {
-  if (!(M.per[0] || M.per[1] || M.per[2])) return;
-  int m = std::max(L.n[0], std::max(L.n[1], L.n[2]));
-  hipLaunchKernelGGL(kk_cc_periodic, g3(m, m, 6, BLK), BLK, 0, ctx().stream, L, M.per[0], M.per[1], M.per[2]);
-}
-static void cc_gsrb(const CCMG &M, const CLev &L, int nsweeps) {
+static void cc_halo(const CCMG &M, const CDLev &DL) { if (DL.halo) xplan_run(DL.halo); }
+static void cc_gsrb_d(const CCMG &M, const CDLev &DL, int nsweeps) {
   for (int s = 0; s < nsweeps; s++) for (int color = 0; color < 2; color++) {
-    cc_periodic(M, L);
-    hipLaunchKernelGGL(kk_cc_gsrb, g3((L.n[0] + 1) / 2, L.n[1], L.n[2], BLK), BLK, 0, ctx().stream, L, color);
+    cc_halo(M, DL);
+    for (const CBox &B : DL.boxes) {
+      const int c = (color + B.lo[0] + B.lo[1] + B.lo[2]) & 1;       // colour by GLOBAL cell index
+      hipLaunchKernelGGL(kk_cc_gsrb, g3((B.L.n[0] + 1) / 2, B.L.n[1], B.L.n[2], BLK), BLK, 0, ctx().stream, B.L, c);
+    }
   }
 }
-// max(nub, N^2) sweeps on the coarsest level, N = its largest extent (same rule as the oracle)
-static void cc_bottom(const CCMG &M, const CLev &L) {
-  const int N = std::max(L.n[0], std::max(L.n[1], L.n[2]));
-  const int ns = std::max(ctx().prm.mg_nub, N * N);
-  hipLaunchKernelGGL(kk_cc_bottom, dim3(1), dim3(1024), 0, ctx().stream, L, ns, M.per[0], M.per[1], M.per[2]);
-}
-static void cc_residual(const CCMG &M, const CLev &L, bool norm) {
-  cc_periodic(M, L);
+static void cc_residual_d(const CCMG &M, const CDLev &DL, bool norm) {
+  cc_halo(M, DL);
   if (norm) HIPCHK(hipMemsetAsync(M.d_nrm, 0, sizeof(double), ctx().stream));
-  // with the norm: at most 16 workgroups along k (each marches its share of planes) so that the
-  // per-workgroup atomics stay in the low thousands; without it one workgroup per plane
-  hipLaunchKernelGGL(kk_cc_residual, g3(L.n[0], L.n[1], norm ? std::min(L.n[2], 16) : L.n[2], BLK), BLK, 0, ctx().stream, L, norm ? M.d_nrm : nullptr);
+  for (const CBox &B : DL.boxes)
+    hipLaunchKernelGGL(kk_cc_residual, g3(B.L.n[0], B.L.n[1], norm ? std::min(B.L.n[2], 16) : B.L.n[2], BLK), BLK, 0, ctx().stream, B.L, norm ? M.d_nrm : nullptr);
+  if (norm) comm_allreduce_max_dev(M.d_nrm, 1);
 }
 static double read_scalar(double *d) {
   VdnCtx &c = ctx();
@@ -260,41 +416,141 @@ static double read_scalar(double *d) {
   HIPCHK(hipStreamSynchronize(c.stream));
   return c.h_scal[0];
 }
-static void cc_vcycle(const CCMG &M, int l) {
+
+// ---- the replicated tail: single-box V-cycle --------------------------------------------------------------------
+static void cc_periodic_t(const CCMG &M, const CLev &L) {
+  if (!(M.per[0] || M.per[1] || M.per[2])) return;
+  int m = std::max(L.n[0], std::max(L.n[1], L.n[2]));
+  hipLaunchKernelGGL(kk_cc_periodic, g3(m, m, 6, BLK), BLK, 0, ctx().stream, L, M.per[0], M.per[1], M.per[2]);
+}
+static void cc_gsrb_t(const CCMG &M, const CLev &L, int nsweeps) {
+  for (int s = 0; s < nsweeps; s++) for (int color = 0; color < 2; color++) {
+    cc_periodic_t(M, L);
+    hipLaunchKernelGGL(kk_cc_gsrb, g3((L.n[0] + 1) / 2, L.n[1], L.n[2], BLK), BLK, 0, ctx().stream, L, color);
+  }
+}
+static void cc_bottom_t(const CCMG &M, const CLev &L) {      // max(nub, N^2) sweeps, N = largest extent (same rule as the oracle)
+  const int N = std::max(L.n[0], std::max(L.n[1], L.n[2]));
+  const int ns = std::max(ctx().prm.mg_nub, N * N);
+  hipLaunchKernelGGL(kk_cc_bottom, dim3(1), dim3(1024), 0, ctx().stream, L, ns, M.per[0], M.per[1], M.per[2]);
+}
+static void cc_vcycle_t(const CCMG &M, int l) {
   const vdn_params &P = ctx().prm;
-  const CLev &L = M.lev[l];
+  const CLev &L = M.tail[l];
   HIPCHK(hipMemsetAsync(L.phi, 0, sizeof(double) * L.sz, ctx().stream));
-  if (l == (int)M.lev.size() - 1) { cc_bottom(M, L); return; }
-  const CLev &C = M.lev[l + 1];
-  cc_gsrb(M, L, P.mg_nu1);
-  cc_residual(M, L, false);
+  if (l == (int)M.tail.size() - 1) { cc_bottom_t(M, L); return; }
+  const CLev &C = M.tail[l + 1];
+  cc_gsrb_t(M, L, P.mg_nu1);
+  cc_periodic_t(M, L);
+  hipLaunchKernelGGL(kk_cc_residual, g3(L.n[0], L.n[1], L.n[2], BLK), BLK, 0, ctx().stream, L, (double *)nullptr);
   hipLaunchKernelGGL(kk_cc_restrict, g3(C.n[0], C.n[1], C.n[2], BLK), BLK, 0, ctx().stream, L, C);
-  cc_vcycle(M, l + 1);
+  cc_vcycle_t(M, l + 1);
   hipLaunchKernelGGL(kk_cc_prolong, g3(L.n[0], L.n[1], L.n[2], BLK), BLK, 0, ctx().stream, L, C);
-  cc_gsrb(M, L, P.mg_nu2);
+  cc_gsrb_t(M, L, P.mg_nu2);
+}
+
+// restrict the residual of distributed level l into level l+1 (distributed) or into the tail (gather)
+static void cc_restrict_down(CCMG &M, int l) {
+  CDLev &DL = M.dlev[l];
+  if (l + 1 < (int)M.dlev.size()) {
+    CDLev &DC = M.dlev[l + 1];
+    for (size_t b = 0; b < DL.boxes.size(); b++) {
+      const CLev &C = DC.boxes[b].L;
+      hipLaunchKernelGGL(kk_cc_restrict, g3(C.n[0], C.n[1], C.n[2], BLK), BLK, 0, ctx().stream, DL.boxes[b].L, C);
+    }
+  } else {
+    const CLev &T = M.tail[0];
+    for (size_t b = 0; b < DL.boxes.size(); b++) {
+      const CLev &F = DL.boxes[b].L;
+      const int nx = F.n[0] / 2, ny = F.n[1] / 2, nz = F.n[2] / 2;
+      hipLaunchKernelGGL(kk_cc_restrict_pack, g3(nx, ny, nz, BLK), BLK, 0, ctx().stream, F, M.sendbuf, M.loc_off_rh[b], nx, ny, nz);
+    }
+    comm_allgather_dev(M.sendbuf, M.recvbuf, M.cnt_rh);
+    hipLaunchKernelGGL(kk_cc_unpack_rh, dim3(4, 1, (unsigned)M.gb_rh.size()), dim3(256), 0, ctx().stream, T, M.recvbuf, M.d_gb_rh);
+  }
+}
+static void cc_prolong_up(CCMG &M, int l) {
+  CDLev &DL = M.dlev[l];
+  for (size_t b = 0; b < DL.boxes.size(); b++) {
+    const CBox &B = DL.boxes[b];
+    if (l + 1 < (int)M.dlev.size())
+      hipLaunchKernelGGL(kk_cc_prolong, g3(B.L.n[0], B.L.n[1], B.L.n[2], BLK), BLK, 0, ctx().stream, B.L, M.dlev[l + 1].boxes[b].L);
+    else
+      hipLaunchKernelGGL(kk_cc_prolong_tail, g3(B.L.n[0], B.L.n[1], B.L.n[2], BLK), BLK, 0, ctx().stream, B.L, M.tail[0], B.lo[0] / 2, B.lo[1] / 2, B.lo[2] / 2);
+  }
+}
+// error-equation V-cycle on distributed level l (zero initial guess)
+static void cc_vcycle_d(CCMG &M, int l) {
+  const vdn_params &P = ctx().prm;
+  CDLev &DL = M.dlev[l];
+  for (const CBox &B : DL.boxes) HIPCHK(hipMemsetAsync(B.L.phi, 0, sizeof(double) * B.L.sz, ctx().stream));
+  const bool last = (l == (int)M.dlev.size() - 1);
+  if (last && M.tail.empty()) {         // nothing below: bottom sweeps on the distributed level itself
+    const int N = std::max(DL.ng[0], std::max(DL.ng[1], DL.ng[2]));     // largest GLOBAL extent, as in the oracle
+    cc_gsrb_d(M, DL, std::max(P.mg_nub, N * N));
+    return;
+  }
+  cc_gsrb_d(M, DL, P.mg_nu1);
+  cc_residual_d(M, DL, false);
+  cc_restrict_down(M, l);
+  if (last) cc_vcycle_t(M, 0); else cc_vcycle_d(M, l + 1);
+  cc_prolong_up(M, l);
+  cc_gsrb_d(M, DL, P.mg_nu2);
 }
 
 static void cc_setup(CCMG &M, vdn_multifab *rh, vdn_multifab *phi, vdn_multifab **beta, const double *dx, const int bc[3][2]) {
-  REQUIRE(rh->nfabs() == 1, "cc multigrid: exactly one local box per rank is supported in this round (got %d)", rh->nfabs());
   REQUIRE(phi->ng >= 1, "cc multigrid: phi needs one ghost cell");
-  const vdn_box &bx = rh->vbox[0];
-  int n0[3]; for (int d = 0; d < 3; d++) n0[d] = bx.hi[d] - bx.lo[d] + 1;
-  cc_build(M, n0, dx, bc);
-  const CLev &L0 = M.lev[0];
-  hipLaunchKernelGGL(kk_cc_load, g3(n0[0] + 1, n0[1] + 1, n0[2] + 1, BLK), BLK, 0, ctx().stream, L0, rh->fabs[0], phi->fabs[0],
-                     beta[0]->fabs[0], beta[1]->fabs[0], beta[2]->fabs[0], bx.lo[0], bx.lo[1], bx.lo[2],
-                     bc[0][0], bc[0][1], bc[1][0], bc[1][1], bc[2][0], bc[2][1]);
-  for (size_t l = 1; l < M.lev.size(); l++) {
-    const CLev &C = M.lev[l];
-    hipLaunchKernelGGL(kk_cc_coarsen_b, g3(C.n[0] + 1, C.n[1] + 1, C.n[2] + 1, BLK), BLK, 0, ctx().stream, M.lev[l - 1], C);
+  cc_build(M, rh, dx, bc);
+  const vdn_layout *la = rh->la; const int lev = rh->lev;
+  CDLev &D0 = M.dlev[0];
+  for (size_t b = 0; b < D0.boxes.size(); b++) {
+    const CLev &L0 = D0.boxes[b].L;
+    const vdn_box &bx = rh->vbox[b];
+    // boundary folding only on faces that are DOMAIN faces
+    int e[3][2];
+    for (int d = 0; d < 3; d++) {
+      e[d][0] = (bx.lo[d] == la->pd[lev].lo[d]) ? bc[d][0] : VDN_BC_INT;
+      e[d][1] = (bx.hi[d] == la->pd[lev].hi[d]) ? bc[d][1] : VDN_BC_INT;
+    }
+    hipLaunchKernelGGL(kk_cc_load, g3(L0.n[0] + 1, L0.n[1] + 1, L0.n[2] + 1, BLK), BLK, 0, ctx().stream, L0, rh->fabs[b], phi->fabs[b],
+                       beta[0]->fabs[b], beta[1]->fabs[b], beta[2]->fabs[b], bx.lo[0], bx.lo[1], bx.lo[2],
+                       e[0][0], e[0][1], e[1][0], e[1][1], e[2][0], e[2][1]);
+  }
+  for (size_t l = 1; l < M.dlev.size(); l++)
+    for (size_t b = 0; b < M.dlev[l].boxes.size(); b++) {
+      const CLev &C = M.dlev[l].boxes[b].L;
+      hipLaunchKernelGGL(kk_cc_coarsen_b, g3(C.n[0] + 1, C.n[1] + 1, C.n[2] + 1, BLK), BLK, 0, ctx().stream, M.dlev[l - 1].boxes[b].L, C);
+    }
+  if (!M.tail.empty()) {
+    CDLev &DL = M.dlev.back();
+    for (size_t b = 0; b < DL.boxes.size(); b++) {
+      const CLev &F = DL.boxes[b].L;
+      const int nx = F.n[0] / 2, ny = F.n[1] / 2, nz = F.n[2] / 2;
+      hipLaunchKernelGGL(kk_cc_coarsen_b_pack, g3(nx + 1, ny + 1, nz + 1, BLK), BLK, 0, ctx().stream, F, M.sendbuf, M.loc_off_b[b], nx, ny, nz);
+    }
+    comm_allgather_dev(M.sendbuf, M.recvbuf, M.cnt_b);
+    hipLaunchKernelGGL(kk_cc_unpack_b, dim3(4, 1, (unsigned)M.gb_b.size()), dim3(256), 0, ctx().stream, M.tail[0], M.recvbuf, M.d_gb_b);
+    for (size_t l = 1; l < M.tail.size(); l++) {
+      const CLev &C = M.tail[l];
+      hipLaunchKernelGGL(kk_cc_coarsen_b, g3(C.n[0] + 1, C.n[1] + 1, C.n[2] + 1, BLK), BLK, 0, ctx().stream, M.tail[l - 1], C);
+    }
   }
 }
-static void cc_store(const CCMG &M, vdn_multifab *phi, const int bc[3][2]) {
-  const CLev &L0 = M.lev[0];
-  cc_periodic(M, L0);
-  const vdn_box &bx = phi->vbox[0];
-  hipLaunchKernelGGL(kk_cc_store, g3(L0.n[0] + 2, L0.n[1] + 2, L0.n[2] + 2, BLK), BLK, 0, ctx().stream, L0, phi->fabs[0],
-                     bx.lo[0], bx.lo[1], bx.lo[2], bc[0][0], bc[0][1], bc[1][0], bc[1][1], bc[2][0], bc[2][1]);
+static void cc_store(CCMG &M, vdn_multifab *phi, const int bc[3][2]) {
+  CDLev &D0 = M.dlev[0];
+  cc_halo(M, D0);
+  const vdn_layout *la = phi->la; const int lev = phi->lev;
+  for (size_t b = 0; b < D0.boxes.size(); b++) {
+    const CLev &L0 = D0.boxes[b].L;
+    const vdn_box &bx = phi->vbox[b];
+    int e[3][2];
+    for (int d = 0; d < 3; d++) {
+      e[d][0] = (bx.lo[d] == la->pd[lev].lo[d]) ? bc[d][0] : VDN_BC_INT;
+      e[d][1] = (bx.hi[d] == la->pd[lev].hi[d]) ? bc[d][1] : VDN_BC_INT;
+    }
+    hipLaunchKernelGGL(kk_cc_store, g3(L0.n[0] + 2, L0.n[1] + 2, L0.n[2] + 2, BLK), BLK, 0, ctx().stream, L0, phi->fabs[b],
+                       bx.lo[0], bx.lo[1], bx.lo[2], e[0][0], e[0][1], e[1][0], e[1][1], e[2][0], e[2][1]);
+  }
 }
 
 int cc_solve(vdn_multifab *rh, vdn_multifab *phi, vdn_multifab **beta, const double *dx, const int bc[3][2],
@@ -302,21 +558,22 @@ int cc_solve(vdn_multifab *rh, vdn_multifab *phi, vdn_multifab **beta, const dou
   const vdn_params &P = ctx().prm;
   size_t mark = arena_mark();
   CCMG M; cc_setup(M, rh, phi, beta, dx, bc);
-  const CLev &L0 = M.lev[0];
+  CDLev &D0 = M.dlev[0];
   const double bnorm = mf_norm_inf(rh, 0, 1);
   int cyc = 0; bool conv = (bnorm == 0.0); double rn = 0.0;
+  const bool single = (M.dlev.size() == 1 && M.tail.empty());
   while (!conv) {
-    if (M.lev.size() == 1) cc_bottom(M, L0); else cc_gsrb(M, L0, P.mg_nu1);
-    cc_residual(M, L0, true);
+    if (single) { const int N = std::max(D0.ng[0], std::max(D0.ng[1], D0.ng[2])); cc_gsrb_d(M, D0, std::max(P.mg_nub, N * N)); }
+    else cc_gsrb_d(M, D0, P.mg_nu1);
+    cc_residual_d(M, D0, true);
     rn = read_scalar(M.d_nrm);
     if (rn <= rel_eps * bnorm || rn <= abs_eps) { conv = true; break; }
     if (cyc >= max_iter) break;
-    if (M.lev.size() > 1) {
-      const CLev &C = M.lev[1];
-      hipLaunchKernelGGL(kk_cc_restrict, g3(C.n[0], C.n[1], C.n[2], BLK), BLK, 0, ctx().stream, L0, C);
-      cc_vcycle(M, 1);
-      hipLaunchKernelGGL(kk_cc_prolong, g3(L0.n[0], L0.n[1], L0.n[2], BLK), BLK, 0, ctx().stream, L0, C);
-      cc_gsrb(M, L0, P.mg_nu2);
+    if (!single) {
+      cc_restrict_down(M, 0);
+      if (M.dlev.size() > 1) cc_vcycle_d(M, 1); else cc_vcycle_t(M, 0);
+      cc_prolong_up(M, 0);
+      cc_gsrb_d(M, D0, P.mg_nu2);
     }
     cyc++;
   }
@@ -329,7 +586,7 @@ int cc_solve(vdn_multifab *rh, vdn_multifab *phi, vdn_multifab **beta, const dou
 void cc_smooth(vdn_multifab *rh, vdn_multifab *phi, vdn_multifab **beta, const double *dx, const int bc[3][2], int nsweeps) {
   size_t mark = arena_mark();
   CCMG M; cc_setup(M, rh, phi, beta, dx, bc);
-  cc_gsrb(M, M.lev[0], nsweeps);
+  cc_gsrb_d(M, M.dlev[0], nsweeps);
   cc_store(M, phi, bc);
   arena_release(mark);
 }
@@ -338,7 +595,8 @@ void cc_bench_smoother(vdn_multifab *rh, vdn_multifab *phi, vdn_multifab **beta,
                        int nlaunch, double *avg_ms, long *cells) {
   size_t mark = arena_mark();
   CCMG M; cc_setup(M, rh, phi, beta, dx, bc);
-  const CLev &L = M.lev[0];
+  REQUIRE(M.dlev[0].boxes.size() == 1, "smoother probe: one local box expected");
+  const CLev &L = M.dlev[0].boxes[0].L;
   hipStream_t st = ctx().stream;
   hipEvent_t e0, e1; HIPCHK(hipEventCreate(&e0)); HIPCHK(hipEventCreate(&e1));
   for (int w = 0; w < 4; w++) hipLaunchKernelGGL(kk_cc_gsrb, g3((L.n[0] + 1) / 2, L.n[1], L.n[2], BLK), BLK, 0, st, L, w & 1);

@@ -12,6 +12,13 @@
 // (i + 16) + PX*((j+1) + PY*(k+1)), PX a multiple of 16 doubles (rows start on a 128-byte line).
 // Algorithmic traffic of one Jacobi sweep: phi read 8 + phi write 8 + rhs 8 + sigma 8 = 32 B/node.
 #include "vdn_dev.h"
+#include <tuple>
+#include <algorithm>
+
+void cc_halo_cache_purge(unsigned long uid);
+void nd_halo_cache_purge(unsigned long uid);
+void mg_halo_cache_purge(unsigned long uid) { cc_halo_cache_purge(uid); nd_halo_cache_purge(uid); }
+void nd_halo_cache_purge(unsigned long uid) { (void)uid; }
 
 struct NLev {
   int n[3]; int PX, PY; long sz;

@@ -116,9 +116,10 @@ extern "C" int vdn_last_solver_stats(int w, int *cyc, double *r0, double *r) {
 extern "C" int vdn_layout_create(int nlev, const int *rr, const vdn_box *pd, const int *nboxes, const vdn_box *boxes,
                                  const int *owner, const int *pmask, vdn_layout **out) {
   VDN_TRY
-  REQUIRE(g_ctx.inited, "vdn_layout_create: call vdn_init first");
   REQUIRE(nlev >= 1, "nlev must be >= 1");
+  static unsigned long next_uid = 1;
   vdn_layout *la = new vdn_layout;
+  la->uid = next_uid++;
   la->nlev = nlev;
   if (nlev > 1) la->rr.assign(rr, rr + 3 * (nlev - 1));
   la->pd.assign(pd, pd + nlev);
@@ -140,7 +141,7 @@ extern "C" int vdn_layout_create(int nlev, const int *rr, const vdn_box *pd, con
   *out = la;
   VDN_CATCH
 }
-extern "C" int vdn_layout_destroy(vdn_layout *la) { delete la; return 0; }
+extern "C" int vdn_layout_destroy(vdn_layout *la) { VDN_TRY if (la) { xplan_cache_purge(la->uid); delete la; } VDN_CATCH }
 extern "C" int vdn_layout_nlevel(const vdn_layout *la) { return la->nlev; }
 extern "C" int vdn_layout_nboxes(const vdn_layout *la, int lev) { return (int)la->boxes[lev].size(); }
 extern "C" int vdn_layout_nlocal(const vdn_layout *la, int lev) { return (int)la->local[lev].size(); }
@@ -373,9 +374,10 @@ double mf_norm_inf(const vdn_multifab *mf, int comp, int nc) {
     Range3 r = fab_range(mf, i, 0);
     hipLaunchKernelGGL(k_absmax, reduce_grid(r), dim3(64, 4, 1), 0, c.stream, mf->fabs[i], r, comp, nc, c.d_scal);
   }
+  comm_allreduce_max_dev(c.d_scal, 1);        // FBoxLib norm_inf is a global (all-rank) norm
   HIPCHK(hipMemcpyAsync(c.h_scal, c.d_scal, sizeof(double), hipMemcpyDeviceToHost, c.stream));
   HIPCHK(hipStreamSynchronize(c.stream));
-  return c.h_scal[0];     // single rank; multi-rank callers all-reduce MAX
+  return c.h_scal[0];
 }
 extern "C" int vdn_multifab_norm_inf(const vdn_multifab *mf, int comp, int nc, double *out) {
   VDN_TRY *out = mf_norm_inf(mf, comp, nc); VDN_CATCH
@@ -390,86 +392,12 @@ extern "C" int vdn_multifab_min_max(const vdn_multifab *mf, int comp, double *mn
     Range3 r = fab_range(mf, i, 0);
     hipLaunchKernelGGL(k_minmax, reduce_grid(r), dim3(64, 4, 1), 0, c.stream, mf->fabs[i], r, comp, c.d_scal, shift);
   }
+  comm_allreduce_max_dev(c.d_scal, 2);
   HIPCHK(hipMemcpyAsync(c.h_scal, c.d_scal, 2 * sizeof(double), hipMemcpyDeviceToHost, c.stream));
   HIPCHK(hipStreamSynchronize(c.stream));
   *mn = shift - c.h_scal[0]; *mx = c.h_scal[1] - shift;
   VDN_CATCH
 }
-
-// ================================================================================================
-// multifab_fill_boundary: ghost points (outside the fab's own valid region) that lie inside another
-// box's valid region -- directly or through a periodic shift -- are copied from it.
-// One kernel per (dst, src, shift) descriptor batch.
-// ================================================================================================
-struct CopyDesc { FV dst, src; int lo[3], hi[3]; int sh[3]; int vlo[3], vhi[3]; };
-
-__global__ void k_fill_boundary(const CopyDesc *descs, int nc) {
-  const CopyDesc &D = descs[blockIdx.z];
-  const int nx = D.hi[0] - D.lo[0] + 1, ny = D.hi[1] - D.lo[1] + 1, nz = D.hi[2] - D.lo[2] + 1;
-  const long tot = (long)nx * ny * nz;
-  for (long t = (long)blockIdx.x * blockDim.x + threadIdx.x; t < tot; t += (long)gridDim.x * blockDim.x) {
-    int i = D.lo[0] + (int)(t % nx), j = D.lo[1] + (int)((t / nx) % ny), k = D.lo[2] + (int)(t / ((long)nx * ny));
-    bool inside = i >= D.vlo[0] && i <= D.vhi[0] && j >= D.vlo[1] && j <= D.vhi[1] && k >= D.vlo[2] && k <= D.vhi[2];
-    if (inside) continue;
-    for (int c = 0; c < nc; c++) fv_at(D.dst, i, j, k, c) = fv_get(D.src, i - D.sh[0], j - D.sh[1], k - D.sh[2], c);
-  }
-}
-
-void mf_fill_boundary(vdn_multifab *mf) {
-  if (mf->ng == 0) return;
-  const vdn_layout *la = mf->la;
-  REQUIRE(g_ctx.nranks == 1 || la->boxes[mf->lev].size() == la->local[mf->lev].size(),
-          "fill_boundary across ranks is not wired in this build");
-  std::vector<CopyDesc> descs;
-  const vdn_box &pd = la->pd[mf->lev];
-  int per[3]; for (int d = 0; d < 3; d++) per[d] = pd.hi[d] - pd.lo[d] + 1;
-  int nshift[3]; for (int d = 0; d < 3; d++) nshift[d] = la->pmask[d] ? 1 : 0;
-  for (int i = 0; i < mf->nfabs(); i++) {
-    int glo[3], ghi[3], vlo[3], vhi[3];
-    for (int d = 0; d < 3; d++) { vlo[d] = mf->vbox[i].lo[d]; vhi[d] = mf->vbox[i].hi[d] + mf->nodal[d]; glo[d] = vlo[d] - mf->ng; ghi[d] = vhi[d] + mf->ng; }
-    for (int jx = 0; jx < mf->nfabs(); jx++)
-      for (int sz = -nshift[2]; sz <= nshift[2]; sz++) for (int sy = -nshift[1]; sy <= nshift[1]; sy++) for (int sx = -nshift[0]; sx <= nshift[0]; sx++) {
-        if (jx == i && sx == 0 && sy == 0 && sz == 0) continue;
-        int sh[3] = { sx * per[0], sy * per[1], sz * per[2] };
-        CopyDesc D; memset(&D, 0, sizeof D); bool empty = false;
-        for (int d = 0; d < 3; d++) {
-          int slo = mf->vbox[jx].lo[d] + sh[d], shi = mf->vbox[jx].hi[d] + mf->nodal[d] + sh[d];
-          D.lo[d] = std::max(glo[d], slo); D.hi[d] = std::min(ghi[d], shi);
-          if (D.lo[d] > D.hi[d]) empty = true;
-          D.sh[d] = sh[d]; D.vlo[d] = vlo[d]; D.vhi[d] = vhi[d];
-        }
-        if (empty) continue;
-        // skip regions entirely inside the destination's valid region
-        bool all_inside = true;
-        for (int d = 0; d < 3; d++) if (D.lo[d] < vlo[d] || D.hi[d] > vhi[d]) all_inside = false;
-        if (all_inside) continue;
-        D.dst = mf->fabs[i]; D.src = mf->fabs[jx];
-        descs.push_back(D);
-      }
-  }
-  if (descs.empty()) return;
-  // the descriptor table is cached on the device per (allocation, shape): temporaries from the
-  // arena get the same addresses every step, so steady-state steps upload nothing (the analogue of
-  // FBoxLib's cached copyassoc, reference src/main.f90:23,39-47)
-  struct Key { const void *base; const void *la; int lev, nc, ng, nd; bool operator<(const Key &o) const {
-    return std::tie(base, la, lev, nc, ng, nd) < std::tie(o.base, o.la, o.lev, o.nc, o.ng, o.nd); } };
-  struct Val { CopyDesc *d; size_t n; std::vector<CopyDesc> h; };
-  static std::map<Key, Val> cache;
-  Key key{ mf->base, mf->la, mf->lev, mf->nc, mf->ng, mf->nodal[0] | (mf->nodal[1] << 1) | (mf->nodal[2] << 2) };
-  auto it = cache.find(key);
-  bool same = it != cache.end() && it->second.n == descs.size() &&
-              memcmp(it->second.h.data(), descs.data(), descs.size() * sizeof(CopyDesc)) == 0;
-  if (!same) {
-    if (it != cache.end()) { HIPCHK(hipFree(it->second.d)); cache.erase(it); }
-    Val v; v.n = descs.size(); v.h = descs;
-    HIPCHK(hipMalloc((void **)&v.d, descs.size() * sizeof(CopyDesc)));
-    HIPCHK(hipMemcpyAsync(v.d, v.h.data(), descs.size() * sizeof(CopyDesc), hipMemcpyHostToDevice, g_ctx.stream));
-    HIPCHK(hipStreamSynchronize(g_ctx.stream));
-    it = cache.emplace(key, std::move(v)).first;
-  }
-  hipLaunchKernelGGL(k_fill_boundary, dim3(64, 1, (unsigned)descs.size()), dim3(256), 0, g_ctx.stream, it->second.d, mf->nc);
-}
-extern "C" int vdn_multifab_fill_boundary(vdn_multifab *mf) { VDN_TRY mf_fill_boundary(mf); VDN_CATCH }
 
 // ================================================================================================
 // multifab_physbc  (multifab_physbc.f90:238-561)

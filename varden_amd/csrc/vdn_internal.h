@@ -34,6 +34,7 @@ struct BoxP {
 
 // ---- host structures ---------------------------------------------------------------------------
 struct vdn_layout {
+  unsigned long uid = 0;                     // unique per created layout: cache keys must survive pointer reuse
   int nlev = 0;
   std::vector<int> rr;                       // [nlev-1][3]
   std::vector<vdn_box> pd;                   // [nlev]
@@ -106,6 +107,19 @@ void  arena_release(size_t mark);
 vdn_multifab *mf_temp(const vdn_layout *la, int lev, int nc, int ng, int face_dir /* -1 cell, 0..2 face, 3 nodal */,
                       bool fill, double val);
 void mf_temp_free(vdn_multifab *mf);
+
+// exchange.hip: ghost exchange plans and the RCCL transport
+struct XBoxInfo { FV fv; int vlo[3], vhi[3]; int owner; };      // valid POINT range (incl. nodal points); fv only if local
+struct XPlan;
+XPlan *xplan_build(const std::vector<XBoxInfo> &boxes, const vdn_box &pd, const int pmask[3], int ng, int nc);
+void   xplan_run(XPlan *P);
+void   xplan_free(XPlan *P);
+void   xplan_cache_purge(unsigned long layout_uid);   // drop every cached plan built for that layout
+void   halo_cache_register(unsigned long layout_uid, XPlan *P);
+std::vector<XBoxInfo> xboxes_of(const vdn_multifab *mf);
+bool   comm_active();
+void   comm_allreduce_max_dev(double *d, int n);
+void   comm_allgather_dev(const double *send, double *recv, size_t count);
 
 // helpers shared between translation units
 BoxP make_boxp(const vdn_multifab *mf, int i, const vdn_bc_tower *bct);
