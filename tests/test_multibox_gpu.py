@@ -147,3 +147,54 @@ def test_godunov_multibox(gpu, oracle, bcname):
         b = um1[d].to_numpy()[1:-1, 1:-1, 1:-1]
         assert np.abs(a - b).max() <= 1e-13 * np.abs(b).max(), "umac[%d] multibox" % d
     sp.close(); case.close()
+
+
+@pytest.mark.parametrize("bcname", ["walls", "periodic", "inout"])
+def test_nd_solve_multibox_equals_single_box(gpu, oracle, bcname):
+    from varden_amd import advance as adv
+    case = Case((16, 16, 16), BC_SETS[bcname], seed=24, iso=True)
+    L = oracle.lib()
+    u, s = case.random_state()
+    rhohalf = case.ofab(1, 1)
+    rhohalf.a[...] = np.abs(s.a[2:-2, 2:-2, 2:-2, :1]) + 0.5
+    gpz = case.ofab(1, 3)
+    L.vo_create_uvec(u.ref, u.ref, rhohalf.ref, gpz.ref, C.c_double(1.0), C.byref(case.obc), 1)
+    L.vo_fill_boundary(u.ref, case.opm)
+    coeffs = case.ofab(1, 1)
+    coeffs.a[1:-1, 1:-1, 1:-1, 0] = 1.0 / rhohalf.a[1:-1, 1:-1, 1:-1, 0]
+    L.vo_fill_boundary(coeffs.ref, case.opm)
+    ell = oracle.ellbc_of(case.obc)
+    bc = [[ell[d][sd] for sd in range(2)] for d in range(3)]
+    nodal = (1, 1, 1)
+    p1 = case.gmf(case.ofab(1, 1, nodal))
+    c1 = adv.nd_solve(case.gmf(case.ofab(1, 1, nodal)), p1, case.gmf(coeffs), case.gmf(u), case.dx, bc, 1e-11)
+    sp = Split(case)
+    p8 = sp.scatter(case.ofab(1, 1, nodal))
+    c8 = adv.nd_solve(sp.scatter(case.ofab(1, 1, nodal)), p8, sp.scatter(coeffs), sp.scatter(u), case.dx, bc, 1e-11)
+    assert c8[0] == c1[0] and c8[1] == c1[1], (c1, c8)
+    a = sp.gather(p8, case.ofab(1, 1, nodal))[1:-1, 1:-1, 1:-1, 0]
+    b = p1.to_numpy()[1:-1, 1:-1, 1:-1, 0]
+    scale = np.abs(b - b.mean()).max()
+    assert np.abs(a - b).max() <= 1e-11 * scale, (float(np.abs(a - b).max()), float(scale))
+    sp.close(); case.close()
+
+
+@pytest.mark.parametrize("name,phys,prob", [("bubble-walls", BC_SETS["walls"], 1), ("bubble-periodic", BC_SETS["periodic"], 1),
+                                            ("blob-inout", BC_SETS["inout"], 2)])
+def test_advance_timestep_multibox_equals_single_box(gpu, name, phys, prob):
+    """3 steps of the whole path on 2x2x2 boxes vs one box (tolerance 1e-9: the per-box eps of the Godunov
+    kernels is decomposition dependent by the reference's own definition)"""
+    from tests.util import params_for
+    from varden_amd import driver
+    n = 32
+    res = []
+    for decomp in ((1, 1, 1), (2, 2, 2)):
+        G = driver.Varden(n, phys, params_for(phys, cflfac=0.9), prob_type=prob, init_shrink=0.1, init_iter=1, decomp=decomp)
+        for _ in range(3):
+            G.step()
+        res.append((G.gather_valid(G.unew[0]), G.gather_valid(G.snew[0]), G.dt))
+        G.close()
+    (u1, s1, dt1), (u8, s8, dt8) = res
+    assert abs(dt1 - dt8) <= 1e-12 * dt1
+    assert np.abs(u1 - u8).max() <= 1e-9 * max(np.abs(u1).max(), 1e-300), float(np.abs(u1 - u8).max())
+    assert np.abs(s1 - s8).max() <= 1e-9 * np.abs(s1).max()

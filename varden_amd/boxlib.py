@@ -34,6 +34,17 @@ def initialize(params=None, rank=0, nranks=1, device=0):
     return prm
 
 
+def comm_get_unique_id():
+    """rank 0: the 128-byte RCCL unique id to broadcast to the other ranks"""
+    buf = C.create_string_buffer(128)
+    check(capi.load().vdn_comm_get_unique_id(buf))
+    return buf.raw
+
+
+def comm_init(id128):
+    check(capi.load().vdn_comm_init(C.c_char_p(bytes(id128))))
+
+
 def finalize():
     global _initialised
     if _initialised:

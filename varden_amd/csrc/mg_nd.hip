@@ -18,7 +18,6 @@
 void cc_halo_cache_purge(unsigned long uid);
 void nd_halo_cache_purge(unsigned long uid);
 void mg_halo_cache_purge(unsigned long uid) { cc_halo_cache_purge(uid); nd_halo_cache_purge(uid); }
-void nd_halo_cache_purge(unsigned long uid) { (void)uid; }
 
 struct NLev {
   int n[3]; int PX, PY; long sz;
@@ -268,49 +267,304 @@ __global__ void kk_nd_store(NLev L, FV phi, int lo0, int lo1, int lo2) {
   fv_at(phi, lo0 + i, lo1 + j, lo2 + k) = L.phi[nidx(L, i, j, k)];
 }
 
+// ---- gather of the first agglomerated level (see mg_cc.hip: same scheme, nodes instead of cells) --------------------
+struct NGBox { int c0[3]; int n[3]; long off; };     // n = coarse CELLS of the box; nodes are n+1
+
+__global__ void kk_nd_restrict_pack(NLev F, NLev Cf /* flags + extents of the coarse box */, double *buf, long off) {
+  NODE_IJK(Cf)
+  if (!in_range) return;
+  double s = 0.0;
+  if (!nd_is_dir(Cf, i, j, k)) {
+    const long sy = F.PX, sz = (long)F.PX * F.PY;
+    const long f0 = nidx(F, 2 * i, 2 * j, 2 * k);
+    #pragma unroll
+    for (int c = -1; c <= 1; c++)
+      #pragma unroll
+      for (int b = -1; b <= 1; b++)
+        #pragma unroll
+        for (int a = -1; a <= 1; a++) {
+          const double wa = a ? 0.5 : 1.0, wb = b ? 0.5 : 1.0, wc = c ? 0.5 : 1.0;
+          s = s + (wa * wb * wc) * F.res[f0 + a + b * sy + c * sz];
+        }
+  }
+  buf[off + i + (long)(Cf.n[0] + 1) * (j + (long)(Cf.n[1] + 1) * k)] = s * 0.125;
+}
+__global__ void kk_nd_coarsen_sigma_pack(NLev F, double *buf, long off, int nx, int ny, int nz) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  const int j = blockIdx.y * blockDim.y + threadIdx.y;
+  const int k = blockIdx.z;
+  if (i >= nx || j >= ny || k >= nz) return;
+  const long sy = F.PX, sz = (long)F.PX * F.PY;
+  const long f = nidx(F, 2 * i, 2 * j, 2 * k);
+  double s = 0.0;
+  #pragma unroll
+  for (int c = 0; c < 2; c++)
+    #pragma unroll
+    for (int b = 0; b < 2; b++)
+      #pragma unroll
+      for (int a = 0; a < 2; a++) s = s + F.sig[f + a + b * sy + c * sz];
+  buf[off + i + (long)nx * (j + (long)ny * k)] = s * 0.125;
+}
+__global__ void kk_nd_unpack(NLev T, double *dst, const double *buf, const NGBox *gb, int nodal) {
+  const NGBox g = gb[blockIdx.z];
+  const int ex = g.n[0] + nodal, ey = g.n[1] + nodal, ez = g.n[2] + nodal;
+  const int tot = ex * ey * ez;
+  for (int t = blockIdx.x * blockDim.x + threadIdx.x; t < tot; t += gridDim.x * blockDim.x) {
+    const int i = t % ex, j = (t / ex) % ey, k = t / (ex * ey);
+    dst[nidx(T, g.c0[0] + i, g.c0[1] + j, g.c0[2] + k)] = buf[g.off + t];
+  }
+}
+__global__ void kk_nd_prolong_tail(NLev F, NLev T, int c00, int c01, int c02, int f00, int f01, int f02) {
+  NODE_IJK(F)
+  if (!in_range) return;
+  if (nd_is_dir(F, i, j, k)) return;
+  // global fine node = f0 + (i,j,k); the box origin is even, so parity and halving are local
+  const int I = c00 + (i >> 1), J = c01 + (j >> 1), K = c02 + (k >> 1), oi = i & 1, oj = j & 1, ok = k & 1;
+  (void)f00; (void)f01; (void)f02;
+  double s = 0.0;
+  for (int c = 0; c <= ok; c++) for (int b = 0; b <= oj; b++) for (int a = 0; a <= oi; a++) s = s + T.phi[nidx(T, I + a, J + b, K + c)];
+  const double scale = 1.0 / (double)((1 + oi) * (1 + oj) * (1 + ok));
+  const long f = nidx(F, i, j, k);
+  F.phi[f] = F.phi[f] + s * scale;
+}
+
 // ---- host ---------------------------------------------------------------------------------------------------
 static const dim3 NBLK(64, 4, 1);
 static dim3 ng3(int nx, int ny, int nz) { return dim3((nx + 63) / 64, (ny + 3) / 4, nz); }
 
-struct NDMG { std::vector<NLev> lev; double *d_nrm; };
+struct NBox { NLev L; int lo[3]; XPlan *hA = nullptr, *hB = nullptr; double *A = nullptr, *B = nullptr; };
+struct NDLev { std::vector<NBox> boxes; XPlan *halo_A = nullptr, *halo_B = nullptr, *halo_res = nullptr, *halo_sig = nullptr; int ng[3]; bool flip = false; };
+struct NDMG {
+  std::vector<NDLev> dlev; std::vector<NLev> tail; int per[3]; double *d_nrm;
+  std::vector<NGBox> gb; NGBox *d_gb = nullptr;
+  double *sendbuf = nullptr, *recvbuf = nullptr; size_t cnt_nodes = 0, cnt_cells = 0;
+  std::vector<long> loc_off_nodes, loc_off_cells;
+};
 
+struct NdHaloKey { unsigned long uid; const void *p0; int lev, l, which, per; bool operator<(const NdHaloKey &o) const {
+  return std::tie(uid, p0, lev, l, which, per) < std::tie(o.uid, o.p0, o.lev, o.l, o.which, o.per); } };
+static std::map<NdHaloKey, XPlan *> g_nd_halo_cache;
+void nd_halo_cache_purge(unsigned long uid) {
+  for (auto it = g_nd_halo_cache.begin(); it != g_nd_halo_cache.end();) { if (it->first.uid == uid) it = g_nd_halo_cache.erase(it); else ++it; }
+}
+
+static NLev nd_alloc_lev(const int n[3], const double h[3]) {
+  NLev L;
+  for (int d = 0; d < 3; d++) { L.n[d] = n[d]; L.f[d] = 1.0 / (36.0 * (h[d] * h[d])); L.dirlo[d] = L.dirhi[d] = L.per[d] = 0; }
+  L.PX = ((n[0] + 18 + 15) / 16) * 16; L.PY = n[1] + 3; L.sz = (long)L.PX * L.PY * (n[2] + 3);
+  double *base = (double *)arena_alloc(sizeof(double) * L.sz * 5);
+  HIPCHK(hipMemsetAsync(base, 0, sizeof(double) * L.sz * 5, ctx().stream));
+  L.phi = base; L.tmp = base + L.sz; L.b = base + 2 * L.sz; L.res = base + 3 * L.sz; L.sig = base + 4 * L.sz;
+  return L;
+}
+static FV nd_view(const NLev &L, double *p, const int lo[3], int extra /* 3 for nodes, 2 for cells */) {
+  FV f; f.p = p; f.a0 = lo[0] - 16; f.a1 = lo[1] - 1; f.a2 = lo[2] - 1; f.n0 = L.PX; f.n1 = L.PY; f.n2 = L.n[2] + extra; f.sc = L.sz;
+  return f;
+}
+
+static void nd_build(NDMG &M, const vdn_multifab *coeffs, const double *dx, const int bc[3][2]) {
+  const vdn_layout *la = coeffs->la; const int lev = coeffs->lev;
+  const auto &gboxes = la->boxes[lev];
+  const int nb = (int)gboxes.size();
+  for (int d = 0; d < 3; d++) M.per[d] = (bc[d][0] == VDN_BC_PER);
+  int bn[3]; for (int d = 0; d < 3; d++) bn[d] = gboxes[0].hi[d] - gboxes[0].lo[d] + 1;
+  for (const auto &b : gboxes) for (int d = 0; d < 3; d++) {
+    REQUIRE(b.hi[d] - b.lo[d] + 1 == bn[d], "nodal multigrid: all boxes of a level must have the same size");
+    REQUIRE((b.lo[d] - la->pd[lev].lo[d]) % bn[d] == 0, "nodal multigrid: boxes must be aligned to their size");
+  }
+  std::vector<int> nloc_of(ctx().nranks, 0);
+  for (int g = 0; g < nb; g++) nloc_of[la->owner[lev][g]]++;
+  int maxloc = 0; for (int r = 0; r < ctx().nranks; r++) maxloc = std::max(maxloc, nloc_of[r]);
+  const int perbits = M.per[0] | (M.per[1] << 1) | (M.per[2] << 2);
+  int n[3] = { bn[0], bn[1], bn[2] }; double h[3] = { dx[0], dx[1], dx[2] };
+  int scale = 1;
+  for (;;) {
+    NDLev DL;
+    std::vector<XBoxInfo> xa, xb2, xr, xs;
+    vdn_box lpd; for (int d = 0; d < 3; d++) { lpd.lo[d] = 0; lpd.hi[d] = (la->pd[lev].hi[d] - la->pd[lev].lo[d] + 1) / scale - 1; DL.ng[d] = lpd.hi[d] + 1; }
+    for (int g = 0; g < nb; g++) {
+      XBoxInfo x; memset(&x, 0, sizeof x);
+      int lo[3];
+      for (int d = 0; d < 3; d++) { lo[d] = (gboxes[g].lo[d] - la->pd[lev].lo[d]) / scale; x.vlo[d] = lo[d]; x.vhi[d] = lo[d] + n[d]; }   // nodes lo..lo+n
+      x.owner = la->owner[lev][g];
+      XBoxInfo xc = x; for (int d = 0; d < 3; d++) xc.vhi[d] = lo[d] + n[d] - 1;                                                   // cells
+      XBoxInfo xA = x, xB = x, xR = x;
+      if (x.owner == ctx().rank) {
+        NBox B; B.L = nd_alloc_lev(n, h); for (int d = 0; d < 3; d++) B.lo[d] = lo[d];
+        for (int d = 0; d < 3; d++) {          // Dirichlet (outflow) flags only on DOMAIN faces
+          B.L.dirlo[d] = (lo[d] == 0 && bc[d][0] == VDN_BC_DIR); B.L.dirhi[d] = (lo[d] + n[d] == lpd.hi[d] + 1 && bc[d][1] == VDN_BC_DIR);
+        }
+        B.A = B.L.phi; B.B = B.L.tmp;
+        xA.fv = nd_view(B.L, B.A, lo, 3); xB.fv = nd_view(B.L, B.B, lo, 3); xR.fv = nd_view(B.L, B.L.res, lo, 3); xc.fv = nd_view(B.L, B.L.sig, lo, 3);
+        DL.boxes.push_back(B);
+      }
+      xa.push_back(xA); xb2.push_back(xB); xr.push_back(xR); xs.push_back(xc);
+    }
+    if (nb > 1 || perbits) {
+      const void *p0 = DL.boxes.empty() ? nullptr : (const void *)DL.boxes[0].A;
+      auto get = [&](int which, const std::vector<XBoxInfo> &xv, const vdn_box &pdm) {
+        NdHaloKey key{ la->uid, p0, lev, (int)M.dlev.size(), which, perbits };
+        auto it = g_nd_halo_cache.find(key);
+        if (it == g_nd_halo_cache.end()) { XPlan *P = xplan_build(xv, pdm, M.per, 1, 1); halo_cache_register(la->uid, P); it = g_nd_halo_cache.emplace(key, P).first; }
+        return it->second;
+      };
+      // the node "domain" for periodic shifts has the CELL period (node n is node 0): use the cell domain box
+      DL.halo_A = get(0, xa, lpd); DL.halo_B = get(1, xb2, lpd); DL.halo_res = get(2, xr, lpd); DL.halo_sig = get(3, xs, lpd);
+    }
+    M.dlev.push_back(DL);
+    bool can = true, next_dist = true;
+    for (int d = 0; d < 3; d++) { const int N = lpd.hi[d] + 1; if ((N & 1) || N <= 2) can = false; }
+    if (can) for (int d = 0; d < 3; d++) REQUIRE(!(n[d] & 1), "nodal multigrid: box extent %d is odd while the domain can still be coarsened", n[d]);
+    for (int d = 0; d < 3; d++) if (n[d] / 2 < 4 || ((n[d] / 2) & 1)) next_dist = false;
+    if (!can) break;
+    if (!next_dist) {
+      int tn[3]; double th[3]; int cn[3];
+      for (int d = 0; d < 3; d++) { cn[d] = n[d] / 2; tn[d] = (lpd.hi[d] + 1) / 2; th[d] = h[d] * 2.0; }
+      for (;;) {
+        NLev T = nd_alloc_lev(tn, th);
+        for (int d = 0; d < 3; d++) { T.dirlo[d] = (bc[d][0] == VDN_BC_DIR); T.dirhi[d] = (bc[d][1] == VDN_BC_DIR); T.per[d] = M.per[d]; }
+        M.tail.push_back(T);
+        bool c2 = true;
+        for (int d = 0; d < 3; d++) if ((tn[d] & 1) || tn[d] <= 2) c2 = false;
+        if (!c2 || M.tail.size() >= 31) break;
+        for (int d = 0; d < 3; d++) { tn[d] /= 2; th[d] *= 2.0; }
+      }
+      const long per_nodes = (long)(cn[0] + 1) * (cn[1] + 1) * (cn[2] + 1), per_cells = (long)cn[0] * cn[1] * cn[2];
+      M.cnt_nodes = (size_t)per_nodes * maxloc; M.cnt_cells = (size_t)per_cells * maxloc;
+      std::vector<int> seen(ctx().nranks, 0);
+      std::vector<NGBox> gbn, gbc;
+      for (int g = 0; g < nb; g++) {
+        const int r = la->owner[lev][g], l = seen[r]++;
+        NGBox a, c;
+        for (int d = 0; d < 3; d++) { a.c0[d] = c.c0[d] = (gboxes[g].lo[d] - la->pd[lev].lo[d]) / scale / 2; a.n[d] = c.n[d] = cn[d]; }
+        a.off = (long)r * M.cnt_nodes + (long)l * per_nodes; c.off = (long)r * M.cnt_cells + (long)l * per_cells;
+        gbn.push_back(a); gbc.push_back(c);
+        if (r == ctx().rank) { M.loc_off_nodes.push_back((long)l * per_nodes); M.loc_off_cells.push_back((long)l * per_cells); }
+      }
+      M.gb = gbn; M.gb.insert(M.gb.end(), gbc.begin(), gbc.end());      // [nodes... | cells...]
+      M.d_gb = (NGBox *)arena_alloc(2 * nb * sizeof(NGBox));
+      HIPCHK(hipMemcpyAsync(M.d_gb, M.gb.data(), 2 * nb * sizeof(NGBox), hipMemcpyHostToDevice, ctx().stream));
+      HIPCHK(hipStreamSynchronize(ctx().stream));
+      M.sendbuf = (double *)arena_alloc(sizeof(double) * M.cnt_nodes);
+      M.recvbuf = (double *)arena_alloc(sizeof(double) * M.cnt_nodes * ctx().nranks);
+      break;
+    }
+    for (int d = 0; d < 3; d++) { n[d] /= 2; h[d] *= 2.0; }
+    scale *= 2;
+    if (M.dlev.size() >= 31) break;
+  }
+  M.d_nrm = (double *)arena_alloc(256);
+}
+
+// ---- distributed levels ------------------------------------------------------------------------------------------
+static void nd_halo_phi(NDLev &DL) { XPlan *P = DL.flip ? DL.halo_B : DL.halo_A; if (P) xplan_run(P); }
+static void nd_jacobi_d(NDLev &DL, int nsweeps) {
+  for (int s = 0; s < nsweeps; s++) {
+    nd_halo_phi(DL);
+    for (NBox &B : DL.boxes) {
+      hipLaunchKernelGGL(kk_nd_jacobi, ng3(B.L.n[0] + 1, B.L.n[1] + 1, B.L.n[2] + 1), NBLK, 0, ctx().stream, B.L, B.L.phi, B.L.tmp, ctx().prm.hg_omega);
+      std::swap(B.L.phi, B.L.tmp);
+    }
+    DL.flip = !DL.flip;
+  }
+}
+static void nd_residual_d(NDMG &M, NDLev &DL, bool norm) {
+  nd_halo_phi(DL);
+  if (norm) HIPCHK(hipMemsetAsync(M.d_nrm, 0, sizeof(double), ctx().stream));
+  for (NBox &B : DL.boxes)
+    hipLaunchKernelGGL(kk_nd_residual, ng3(B.L.n[0] + 1, B.L.n[1] + 1, norm ? std::min(B.L.n[2] + 1, 16) : B.L.n[2] + 1), NBLK, 0, ctx().stream, B.L, norm ? M.d_nrm : nullptr);
+  if (DL.halo_res) xplan_run(DL.halo_res);
+  if (norm) comm_allreduce_max_dev(M.d_nrm, 1);
+}
+static void nd_zero_phi(NDLev &DL) {
+  for (NBox &B : DL.boxes) HIPCHK(hipMemsetAsync(B.L.phi, 0, sizeof(double) * B.L.sz, ctx().stream));
+}
+
+// ---- replicated tail ------------------------------------------------------------------------------------------------
 static void nd_fill_nodes(const NLev &L, double *a) {
   if (!(L.per[0] || L.per[1] || L.per[2])) return;     // ghosts stay zero: set once by the setup memset, never written
   hipLaunchKernelGGL(kk_nd_fill_nodes, ng3(L.n[0] + 3, L.n[1] + 3, L.n[2] + 3), NBLK, 0, ctx().stream, L, a);
 }
-static void nd_jacobi(NLev &L, int nsweeps) {
+static void nd_jacobi_t(NLev &L, int nsweeps) {
   for (int s = 0; s < nsweeps; s++) {
     nd_fill_nodes(L, L.phi);
     hipLaunchKernelGGL(kk_nd_jacobi, ng3(L.n[0] + 1, L.n[1] + 1, L.n[2] + 1), NBLK, 0, ctx().stream, L, L.phi, L.tmp, ctx().prm.hg_omega);
     std::swap(L.phi, L.tmp);
   }
 }
-// max(nub, 2 N^2) sweeps on the coarsest level (same rule as the oracle)
-static void nd_bottom(NLev &L) {
+static void nd_bottom_t(NLev &L) {          // max(nub, 2 N^2) sweeps (same rule as the oracle)
   const int N = std::max(L.n[0], std::max(L.n[1], L.n[2]));
   const int ns = std::max(ctx().prm.hg_nub, 2 * N * N);
   hipLaunchKernelGGL(kk_nd_bottom, dim3(1), dim3(1024), 0, ctx().stream, L, L.phi, L.tmp, ns, ctx().prm.hg_omega);
   if (ns & 1) std::swap(L.phi, L.tmp);
 }
-static void nd_residual(NDMG &M, NLev &L, bool norm) {
-  nd_fill_nodes(L, L.phi);
-  if (norm) HIPCHK(hipMemsetAsync(M.d_nrm, 0, sizeof(double), ctx().stream));
-  hipLaunchKernelGGL(kk_nd_residual, ng3(L.n[0] + 1, L.n[1] + 1, norm ? std::min(L.n[2] + 1, 16) : L.n[2] + 1), NBLK, 0, ctx().stream, L, norm ? M.d_nrm : nullptr);
-  nd_fill_nodes(L, L.res);
-}
-static void nd_vcycle(NDMG &M, int l) {
+static void nd_vcycle_t(NDMG &M, int l) {
   const vdn_params &P = ctx().prm;
-  NLev &L = M.lev[l];
+  NLev &L = M.tail[l];
   HIPCHK(hipMemsetAsync(L.phi, 0, sizeof(double) * L.sz, ctx().stream));
-  if (l == (int)M.lev.size() - 1) { nd_bottom(L); return; }
-  NLev &C = M.lev[l + 1];
-  nd_jacobi(L, P.hg_nu1);
-  nd_residual(M, L, false);
+  if (l == (int)M.tail.size() - 1) { nd_bottom_t(L); return; }
+  NLev &C = M.tail[l + 1];
+  nd_jacobi_t(L, P.hg_nu1);
+  nd_fill_nodes(L, L.phi);
+  hipLaunchKernelGGL(kk_nd_residual, ng3(L.n[0] + 1, L.n[1] + 1, L.n[2] + 1), NBLK, 0, ctx().stream, L, (double *)nullptr);
+  nd_fill_nodes(L, L.res);
   hipLaunchKernelGGL(kk_nd_restrict, ng3(C.n[0] + 1, C.n[1] + 1, C.n[2] + 1), NBLK, 0, ctx().stream, L, C);
-  nd_vcycle(M, l + 1);
+  nd_vcycle_t(M, l + 1);
   nd_fill_nodes(C, C.phi);
   hipLaunchKernelGGL(kk_nd_prolong, ng3(L.n[0] + 1, L.n[1] + 1, L.n[2] + 1), NBLK, 0, ctx().stream, L, C);
-  nd_jacobi(L, P.hg_nu2);
+  nd_jacobi_t(L, P.hg_nu2);
+}
+
+static void nd_restrict_down(NDMG &M, int l) {
+  NDLev &DL = M.dlev[l];
+  if (l + 1 < (int)M.dlev.size()) {
+    NDLev &DC = M.dlev[l + 1];
+    for (size_t b = 0; b < DL.boxes.size(); b++) {
+      NLev &C = DC.boxes[b].L;
+      hipLaunchKernelGGL(kk_nd_restrict, ng3(C.n[0] + 1, C.n[1] + 1, C.n[2] + 1), NBLK, 0, ctx().stream, DL.boxes[b].L, C);
+    }
+  } else {
+    NLev &T = M.tail[0];
+    const int nb = (int)M.gb.size() / 2;
+    for (size_t b = 0; b < DL.boxes.size(); b++) {
+      const NLev &F = DL.boxes[b].L;
+      NLev Cf = F;                       // extents + Dirichlet flags of the coarse box
+      for (int d = 0; d < 3; d++) Cf.n[d] = F.n[d] / 2;
+      hipLaunchKernelGGL(kk_nd_restrict_pack, ng3(Cf.n[0] + 1, Cf.n[1] + 1, Cf.n[2] + 1), NBLK, 0, ctx().stream, F, Cf, M.sendbuf, M.loc_off_nodes[b]);
+    }
+    comm_allgather_dev(M.sendbuf, M.recvbuf, M.cnt_nodes);
+    hipLaunchKernelGGL(kk_nd_unpack, dim3(4, 1, (unsigned)nb), dim3(256), 0, ctx().stream, T, T.b, M.recvbuf, M.d_gb, 1);
+  }
+}
+static void nd_prolong_up(NDMG &M, int l) {
+  NDLev &DL = M.dlev[l];
+  if (l + 1 < (int)M.dlev.size()) { NDLev &DC = M.dlev[l + 1]; nd_halo_phi(DC); }
+  else nd_fill_nodes(M.tail[0], M.tail[0].phi);
+  for (size_t b = 0; b < DL.boxes.size(); b++) {
+    NBox &B = DL.boxes[b];
+    if (l + 1 < (int)M.dlev.size())
+      hipLaunchKernelGGL(kk_nd_prolong, ng3(B.L.n[0] + 1, B.L.n[1] + 1, B.L.n[2] + 1), NBLK, 0, ctx().stream, B.L, M.dlev[l + 1].boxes[b].L);
+    else
+      hipLaunchKernelGGL(kk_nd_prolong_tail, ng3(B.L.n[0] + 1, B.L.n[1] + 1, B.L.n[2] + 1), NBLK, 0, ctx().stream, B.L, M.tail[0],
+                         B.lo[0] / 2, B.lo[1] / 2, B.lo[2] / 2, B.lo[0], B.lo[1], B.lo[2]);
+  }
+}
+static int nd_bottom_sweeps_global(const NDLev &DL) {
+  const int N = std::max(DL.ng[0], std::max(DL.ng[1], DL.ng[2]));
+  return std::max(ctx().prm.hg_nub, 2 * N * N);
+}
+static void nd_vcycle_d(NDMG &M, int l) {
+  const vdn_params &P = ctx().prm;
+  NDLev &DL = M.dlev[l];
+  nd_zero_phi(DL);
+  const bool last = (l == (int)M.dlev.size() - 1);
+  if (last && M.tail.empty()) { nd_jacobi_d(DL, nd_bottom_sweeps_global(DL)); return; }
+  nd_jacobi_d(DL, P.hg_nu1);
+  nd_residual_d(M, DL, false);
+  nd_restrict_down(M, l);
+  if (last) nd_vcycle_t(M, 0); else nd_vcycle_d(M, l + 1);
+  nd_prolong_up(M, l);
+  nd_jacobi_d(DL, P.hg_nu2);
 }
 static double nd_read(double *d) {
   VdnCtx &c = ctx();
@@ -322,65 +576,75 @@ static double nd_read(double *d) {
 int nd_solve(vdn_multifab *rh, vdn_multifab *phi, const vdn_multifab *coeffs, const vdn_multifab *u, const double *dx,
              const int bc[3][2], double rel_eps, double abs_eps, int max_iter, int *cycles, double *res0, double *res) {
   const vdn_params &P = ctx().prm;
-  REQUIRE(rh->nfabs() == 1, "nodal multigrid: exactly one local box per rank is supported in this round (got %d)", rh->nfabs());
   REQUIRE(rh->ng >= 1 && phi->ng >= 1 && coeffs->ng >= 1, "nodal multigrid: rh, phi, coeffs need one ghost layer");
   hipStream_t st = ctx().stream;
   size_t mark = arena_mark();
-  NDMG M;
-  const vdn_box &bx = coeffs->vbox[0];
-  int n[3]; double h[3];
-  for (int d = 0; d < 3; d++) { n[d] = bx.hi[d] - bx.lo[d] + 1; h[d] = dx[d]; }
-  for (;;) {
-    NLev L;
-    for (int d = 0; d < 3; d++) {
-      L.n[d] = n[d]; L.f[d] = 1.0 / (36.0 * (h[d] * h[d]));
-      L.dirlo[d] = (bc[d][0] == VDN_BC_DIR); L.dirhi[d] = (bc[d][1] == VDN_BC_DIR); L.per[d] = (bc[d][0] == VDN_BC_PER);
-    }
-    L.PX = ((n[0] + 18 + 15) / 16) * 16; L.PY = n[1] + 3; L.sz = (long)L.PX * L.PY * (n[2] + 3);
-    double *base = (double *)arena_alloc(sizeof(double) * L.sz * 5);
-    HIPCHK(hipMemsetAsync(base, 0, sizeof(double) * L.sz * 5, st));
-    L.phi = base; L.tmp = base + L.sz; L.b = base + 2 * L.sz; L.res = base + 3 * L.sz; L.sig = base + 4 * L.sz;
-    M.lev.push_back(L);
-    bool can = true;
-    for (int d = 0; d < 3; d++) if ((n[d] & 1) || n[d] <= 2) can = false;
-    if (!can || M.lev.size() >= 31) break;
-    for (int d = 0; d < 3; d++) { n[d] /= 2; h[d] *= 2.0; }
+  NDMG M; nd_build(M, coeffs, dx, bc);
+  NDLev &D0 = M.dlev[0];
+  // sigma: level 0 from the (ghost-filled) coeffs multifab; coarser distributed levels by averaging + halo exchange
+  for (size_t b = 0; b < D0.boxes.size(); b++) {
+    NLev &L0 = D0.boxes[b].L; const vdn_box &bx = coeffs->vbox[b];
+    hipLaunchKernelGGL(kk_nd_load_sigma, ng3(L0.n[0] + 2, L0.n[1] + 2, L0.n[2] + 2), NBLK, 0, st, L0, coeffs->fabs[b], bx.lo[0], bx.lo[1], bx.lo[2]);
   }
-  M.d_nrm = (double *)arena_alloc(256);
-  NLev &L0 = M.lev[0];
-  hipLaunchKernelGGL(kk_nd_load_sigma, ng3(L0.n[0] + 2, L0.n[1] + 2, L0.n[2] + 2), NBLK, 0, st, L0, coeffs->fabs[0], bx.lo[0], bx.lo[1], bx.lo[2]);
-  for (size_t l = 1; l < M.lev.size(); l++) {
-    NLev &C = M.lev[l];
-    hipLaunchKernelGGL(kk_nd_coarsen_sigma, ng3(C.n[0], C.n[1], C.n[2]), NBLK, 0, st, M.lev[l - 1], C);
-    hipLaunchKernelGGL(kk_nd_fill_cells, ng3(C.n[0] + 2, C.n[1] + 2, C.n[2] + 2), NBLK, 0, st, C, C.sig);
+  for (size_t l = 1; l < M.dlev.size(); l++) {
+    for (size_t b = 0; b < M.dlev[l].boxes.size(); b++) {
+      NLev &C = M.dlev[l].boxes[b].L;
+      hipLaunchKernelGGL(kk_nd_coarsen_sigma, ng3(C.n[0], C.n[1], C.n[2]), NBLK, 0, st, M.dlev[l - 1].boxes[b].L, C);
+    }
+    if (M.dlev[l].halo_sig) xplan_run(M.dlev[l].halo_sig);        // interior / periodic ghost cells; domain ghosts stay 0
+  }
+  if (!M.tail.empty()) {
+    NDLev &DL = M.dlev.back();
+    const int nb = (int)M.gb.size() / 2;
+    for (size_t b = 0; b < DL.boxes.size(); b++) {
+      const NLev &F = DL.boxes[b].L;
+      hipLaunchKernelGGL(kk_nd_coarsen_sigma_pack, ng3(F.n[0] / 2, F.n[1] / 2, F.n[2] / 2), NBLK, 0, st, F, M.sendbuf, M.loc_off_cells[b], F.n[0] / 2, F.n[1] / 2, F.n[2] / 2);
+    }
+    comm_allgather_dev(M.sendbuf, M.recvbuf, M.cnt_cells);
+    hipLaunchKernelGGL(kk_nd_unpack, dim3(4, 1, (unsigned)nb), dim3(256), 0, st, M.tail[0], M.tail[0].sig, M.recvbuf, M.d_gb + nb, 0);
+    hipLaunchKernelGGL(kk_nd_fill_cells, ng3(M.tail[0].n[0] + 2, M.tail[0].n[1] + 2, M.tail[0].n[2] + 2), NBLK, 0, st, M.tail[0], M.tail[0].sig);
+    for (size_t l = 1; l < M.tail.size(); l++) {
+      NLev &C = M.tail[l];
+      hipLaunchKernelGGL(kk_nd_coarsen_sigma, ng3(C.n[0], C.n[1], C.n[2]), NBLK, 0, st, M.tail[l - 1], C);
+      hipLaunchKernelGGL(kk_nd_fill_cells, ng3(C.n[0] + 2, C.n[1] + 2, C.n[2] + 2), NBLK, 0, st, C, C.sig);
+    }
   }
   if (u) {                                                  // add_divu = .true., hg_multigrid.f90:96
     REQUIRE(u->ng >= 1 && u->nc >= 3, "nodal multigrid: u needs a ghost cell");
-    Range3 r; for (int d = 0; d < 3; d++) { r.lo[d] = bx.lo[d]; r.hi[d] = bx.hi[d] + 1; }
-    hipLaunchKernelGGL(kk_nd_divu, grid_for(r), NBLK, 0, st, u->fabs[0], rh->fabs[0], 0.25 / dx[0], 0.25 / dx[1], 0.25 / dx[2], r);
+    for (size_t b = 0; b < D0.boxes.size(); b++) {
+      const vdn_box &bx = coeffs->vbox[b];
+      Range3 r; for (int d = 0; d < 3; d++) { r.lo[d] = bx.lo[d]; r.hi[d] = bx.hi[d] + 1; }
+      hipLaunchKernelGGL(kk_nd_divu, grid_for(r), NBLK, 0, st, u->fabs[b], rh->fabs[b], 0.25 / dx[0], 0.25 / dx[1], 0.25 / dx[2], r);
+    }
   }
   HIPCHK(hipMemsetAsync(M.d_nrm, 0, sizeof(double), st));
-  hipLaunchKernelGGL(kk_nd_load, ng3(L0.n[0] + 1, L0.n[1] + 1, std::min(L0.n[2] + 1, 16)), NBLK, 0, st, L0, rh->fabs[0], phi->fabs[0], bx.lo[0], bx.lo[1], bx.lo[2], M.d_nrm);
+  for (size_t b = 0; b < D0.boxes.size(); b++) {
+    NLev &L0 = D0.boxes[b].L; const vdn_box &bx = coeffs->vbox[b];
+    hipLaunchKernelGGL(kk_nd_load, ng3(L0.n[0] + 1, L0.n[1] + 1, std::min(L0.n[2] + 1, 16)), NBLK, 0, st, L0, rh->fabs[b], phi->fabs[b], bx.lo[0], bx.lo[1], bx.lo[2], M.d_nrm);
+  }
+  comm_allreduce_max_dev(M.d_nrm, 1);
   const double bnorm = nd_read(M.d_nrm);
   int cyc = 0; bool conv = (bnorm == 0.0); double rn = 0.0;
+  const bool single = (M.dlev.size() == 1 && M.tail.empty());
   while (!conv) {
-    if (M.lev.size() == 1) nd_bottom(L0); else nd_jacobi(L0, P.hg_nu1);
-    nd_residual(M, L0, true);
+    nd_jacobi_d(D0, single ? nd_bottom_sweeps_global(D0) : P.hg_nu1);
+    nd_residual_d(M, D0, true);
     rn = nd_read(M.d_nrm);
     if (rn <= rel_eps * bnorm || rn <= abs_eps) { conv = true; break; }
     if (cyc >= max_iter) break;
-    if (M.lev.size() > 1) {
-      NLev &C = M.lev[1];
-      hipLaunchKernelGGL(kk_nd_restrict, ng3(C.n[0] + 1, C.n[1] + 1, C.n[2] + 1), NBLK, 0, st, L0, C);
-      nd_vcycle(M, 1);
-      nd_fill_nodes(C, C.phi);
-      hipLaunchKernelGGL(kk_nd_prolong, ng3(L0.n[0] + 1, L0.n[1] + 1, L0.n[2] + 1), NBLK, 0, st, L0, C);
-      nd_jacobi(L0, P.hg_nu2);
+    if (!single) {
+      nd_restrict_down(M, 0);
+      if (M.dlev.size() > 1) nd_vcycle_d(M, 1); else nd_vcycle_t(M, 0);
+      nd_prolong_up(M, 0);
+      nd_jacobi_d(D0, P.hg_nu2);
     }
     cyc++;
   }
-  nd_fill_nodes(L0, L0.phi);
-  hipLaunchKernelGGL(kk_nd_store, ng3(L0.n[0] + 3, L0.n[1] + 3, L0.n[2] + 3), NBLK, 0, st, L0, phi->fabs[0], bx.lo[0], bx.lo[1], bx.lo[2]);
+  nd_halo_phi(D0);
+  for (size_t b = 0; b < D0.boxes.size(); b++) {
+    NLev &L0 = D0.boxes[b].L; const vdn_box &bx = coeffs->vbox[b];
+    hipLaunchKernelGGL(kk_nd_store, ng3(L0.n[0] + 3, L0.n[1] + 3, L0.n[2] + 3), NBLK, 0, st, L0, phi->fabs[b], bx.lo[0], bx.lo[1], bx.lo[2]);
+  }
   if (cycles) *cycles = cyc; if (res0) *res0 = bnorm; if (res) *res = rn;
   arena_release(mark);
   return conv ? 0 : 1;

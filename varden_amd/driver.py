@@ -35,15 +35,32 @@ def initdata_numpy(n, dx, prob_type=1, ng=3, nscal=2):
 
 class Varden:
     def __init__(self, n, phys_bc, params=None, prob_type=1, grav=-9.8, prob_hi=(1.0, 1.0, 1.0), init_shrink=1.0,
-                 init_iter=4, do_initial_projection=1, u0=None, s0=None, device=0, max_grid_size=None):
+                 init_iter=4, do_initial_projection=1, u0=None, s0=None, device=0, decomp=(1, 1, 1), rank=0, nranks=1,
+                 comm_id=None):
+        """decomp = (bx, by, bz): the domain is cut into bx*by*bz equal boxes (max_grid_size of the reference,
+        src/_parameters:27), dealt round-robin to the ranks (one rank per GPU).  comm_id: the 128-byte RCCL unique
+        id broadcast by the caller when nranks > 1."""
         self.n = tuple(int(x) for x in (n if hasattr(n, "__len__") else (n, n, n)))
         self.prm = params or default_params()
         self.prm.prob_type = prob_type
-        bl.initialize(self.prm, 0, 1, device)
+        self.rank, self.nranks = rank, nranks
+        bl.initialize(self.prm, rank, nranks, device)
+        if nranks > 1:
+            bl.comm_init(comm_id)
         self.phys = [[int(phys_bc[d][s]) for s in range(2)] for d in range(3)]
         pmask = tuple(1 if self.phys[d][0] == bl.PERIODIC else 0 for d in range(3))
         lo, hi = (0, 0, 0), tuple(x - 1 for x in self.n)
-        self.mla = bl.MLLayout([(lo, hi)], [[(lo, hi)]], pmask=pmask)
+        bs = tuple(self.n[d] // decomp[d] for d in range(3))
+        assert all(bs[d] * decomp[d] == self.n[d] for d in range(3)), "decomp must divide n"
+        self.boxes = []
+        for kz in range(decomp[2]):
+            for ky in range(decomp[1]):
+                for kx in range(decomp[0]):
+                    blo = (kx * bs[0], ky * bs[1], kz * bs[2])
+                    self.boxes.append((blo, tuple(blo[d] + bs[d] - 1 for d in range(3))))
+        self.owner = [i % nranks for i in range(len(self.boxes))]
+        self.local = [i for i in range(len(self.boxes)) if self.owner[i] == rank]
+        self.mla = bl.MLLayout([(lo, hi)], [self.boxes], owner=[self.owner], pmask=pmask)
         self.bct = bl.BCTower(self.mla, self.phys)
         self.dx = [[prob_hi[d] / self.n[d] for d in range(3)]]
         dm, ns = 3, self.prm.nscal
@@ -55,8 +72,11 @@ class Varden:
         self.ext_vel_force[0].setval(grav, dm - 1, 1, all=True)                    # varden.f90:428-429
         if u0 is None:
             u0, s0 = initdata_numpy(self.n, self.dx[0], prob_type, 3, ns)
-        self.uold[0].from_numpy(u0)
-        self.sold[0].from_numpy(s0)
+        for li, gi in enumerate(self.local):              # each rank uploads the boxes it owns (global arrays carry 3 ghosts)
+            blo, bhi = self.boxes[gi]
+            sl = tuple(slice(blo[d], bhi[d] + 1 + 6) for d in range(3))
+            self.uold[0].from_numpy(np.array(u0[sl], order="F"), li)
+            self.sold[0].from_numpy(np.array(s0[sl], order="F"), li)
         self.time, self.dt, self.istep = 0.0, 0.0, 0
         self.fill_state_ghosts()                                                   # initdata.f90:52-56
         if do_initial_projection:                                                  # varden.f90:126-138
@@ -99,6 +119,17 @@ class Varden:
         self.uold[0].copy_c(0, self.unew[0], 0, self.dm, 0)
         self.sold[0].copy_c(0, self.snew[0], 0, self.nscal, 0)
         self.time += self.dt
+
+    def gather_valid(self, mf):
+        """valid cells of the LOCAL boxes assembled into a global array (NaN where other ranks own the data)"""
+        out = np.full(self.n + (mf.nc,), np.nan, order="F")
+        g = mf.ng
+        for li, gi in enumerate(self.local):
+            blo, bhi = self.boxes[gi]
+            a = mf.to_numpy(li)
+            v = a[g:a.shape[0] - g, g:a.shape[1] - g, g:a.shape[2] - g] if g else a
+            out[tuple(slice(blo[d], bhi[d] + 1) for d in range(3))] = v[:bhi[0] - blo[0] + 1, :bhi[1] - blo[1] + 1, :bhi[2] - blo[2] + 1]
+        return out
 
     def close(self):
         for lst in (self.uold, self.sold, self.unew, self.snew, self.gp, self.p, self.ext_vel_force, self.ext_scal_force):
