@@ -1,7 +1,7 @@
 #!/usr/bin/env python
 """bench.py -- cells*steps/sec of advance_timestep on the MI355X-native hot path.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--n 256] [--no-cpu]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--box 256] [--skip-cpu]
 
 Workload (BASELINE.json configs[1]): 3-D 256^3 single-level variable-density bubble
 (reference src/initdata.f90:212-238, exec/test/inputs_bubble_3d with visc_coef = 0), one 256^3 box,
@@ -12,8 +12,9 @@ estdt, advance_timestep, uold<-unew.  All state is resident in HBM before the ti
 One JSON line is printed by rank 0.  `roofline` is the MAC-multigrid red-black Gauss-Seidel colour
 pass on the finest level (48 algorithmic B/cell/pass), timed with HIP events on the launch
 stream inside the library; `cpu_baseline` is the CPU oracle (a port, OpenMP) on a bounded sample.
-For N > 1 this round runs N independent replicas (one box per rank, no ghost exchange): the
-domain-decomposed path is not implemented yet and the line says so in config.parallelism.
+For N > 1 the domain is decomposed: one 256^3 box per rank/GPU (weak scaling; N = 8 is the 512^3 / 2x2x2
+case of BASELINE.json configs[2]), ghost cells and multigrid halos exchanged with RCCL point-to-point
+over xGMI, norms / estdt by ncclAllReduce, coarse multigrid levels agglomerated (all-gather).
 """
 import argparse
 import json
@@ -32,9 +33,9 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--n", type=int, default=256)
-    ap.add_argument("--cpu-n", type=int, default=128)
-    ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--box", dest="n", type=int, default=256)
+    ap.add_argument("--cpu-box", dest="cpu_n", type=int, default=128)
+    ap.add_argument("--skip-cpu", dest="no_cpu", action="store_true")
     args = ap.parse_args()
 
     import torch
@@ -42,10 +43,16 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    one_dev = os.environ.get("VDN_BENCH_ONE_DEVICE") == "1"     # debugging aid: every rank on GPU 0, gloo control plane
+    if one_dev:
+        local_rank = 0
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if one_dev:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     assert torch.cuda.is_available(), "bench.py needs a GPU: the product path has no CPU fallback"
 
     from varden_amd import advance as adv
@@ -56,7 +63,21 @@ def main():
     n = args.n
     walls = [[bl.NO_SLIP_WALL] * 2] * 3
     prm = default_params(cflfac=0.9)
-    G = driver.Varden(n, walls, prm, prob_type=1, grav=-9.8, init_shrink=0.1, init_iter=1, device=local_rank)
+    decomp = {1: (1, 1, 1), 2: (2, 1, 1), 4: (2, 2, 1), 8: (2, 2, 2)}.get(world)
+    assert decomp is not None, "bench.py supports 1, 2, 4 or 8 GPUs"
+    nglob = tuple(n * decomp[d] for d in range(3))
+    h = 1.0 / (n * max(decomp))                            # dx = dy = dz; N = 8 gives the unit cube at 512^3
+    prob_hi = tuple(nglob[d] * h for d in range(3))
+    comm_id = None
+    if world > 1:                                          # RCCL unique id: rank 0 creates it, everybody receives it
+        bl.initialize(prm, rank, world, local_rank)
+        idt = torch.zeros(128, dtype=torch.uint8, device="cpu" if one_dev else "cuda")
+        if rank == 0:
+            idt.copy_(torch.tensor(list(bl.comm_get_unique_id()), dtype=torch.uint8))
+        dist.broadcast(idt, 0)
+        comm_id = bytes(idt.cpu().tolist())
+    G = driver.Varden(nglob, walls, prm, prob_type=1, grav=-9.8, prob_hi=prob_hi, init_shrink=0.1, init_iter=1,
+                      device=local_rank, decomp=decomp, rank=rank, nranks=world, comm_id=comm_id)
 
     def barrier():
         if world > 1:
@@ -78,21 +99,24 @@ def main():
     barrier()
     el = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([el], device="cuda")
+        t = torch.tensor([el], device="cpu" if one_dev else "cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         el = float(t.item())
 
     cells = n ** 3 * world
     value = cells * args.steps / el
+    rho = G.sold[0].to_numpy()[..., 0] if rank == 0 else None      # rank 0's box, for the smoother probe's coefficients
+    G.close()                                                     # also tears the RCCL communicator down
 
     # ---- roofline of the dominant kernel: one colour pass of the MAC-MG smoother at n^3 ----------
     roof = None
     if rank == 0:
-        mla, bct = G.mla, G.bct
+        bl.initialize(prm, 0, 1, local_rank)               # the probe is a single-rank, single-box measurement
+        lo0, hi0 = (0, 0, 0), (n - 1,) * 3
+        mla = bl.MLLayout([(lo0, hi0)], [[(lo0, hi0)]])
         rh, phi = bl.MultiFab(mla, 0, 1, 0), bl.MultiFab(mla, 0, 1, 1)
         beta = [bl.MultiFab(mla, 0, 1, 0, tuple(1 if t == d else 0 for t in range(3))) for d in range(3)]
         import numpy as np
-        rho = G.sold[0].to_numpy()[..., 0]
         for d in range(3):      # beta = 2/(rho_i + rho_{i-1})  (macproject.f90:376-394), built on the host for the probe
             sl_hi = [slice(3, -3)] * 3
             sl_lo = [slice(3, -3)] * 3
@@ -103,7 +127,7 @@ def main():
         r = rng.standard_normal((n, n, n, 1))
         rh.from_numpy(r - r.mean())
         bc = [[bl.BC_NEU] * 2] * 3
-        ms, ncell = adv.bench_cc_smoother(rh, phi, beta, G.dx[0], bc, 200)
+        ms, ncell = adv.bench_cc_smoother(rh, phi, beta, [1.0 / n] * 3, bc, 200)
         alg_bytes = 48.0 * ncell
         achieved = alg_bytes / (ms * 1e-3) / 1e9
         # HBM traffic per launch from the PMC passes (FETCH_SIZE x2 + WRITE_SIZE, MI355X_MICROARCH.md), collected
@@ -145,13 +169,12 @@ def main():
             "config": {"workload": "3D %d^3 single-level variable-density bubble, 1 box/GPU, MAC+HG projection each step "
                                    "(BASELINE.json configs[1])" % n,
                        "parallelism": "single GPU" if world == 1 else
-                                      "%d independent replicas (no ghost exchange; domain decomposition not implemented in round 1)" % world,
+                                      "domain decomposition %dx%dx%d, one 256^3 box per GPU (global %dx%dx%d), RCCL p2p ghost exchange + allreduce" % (decomp + nglob),
                        "phase_ms_per_step": {k: round(1e3 * v / args.steps, 3) for k, v in phases.items()},
                        "vcycles_per_step": {k: round(v / args.steps, 2) for k, v in cyc.items()}},
             "roofline": roof, "cpu_baseline": cpu,
         }
         print(json.dumps(out))
-    G.close()
     if world > 1:
         dist.destroy_process_group()
 

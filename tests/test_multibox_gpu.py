@@ -198,3 +198,14 @@ def test_advance_timestep_multibox_equals_single_box(gpu, name, phys, prob):
     assert abs(dt1 - dt8) <= 1e-12 * dt1
     assert np.abs(u1 - u8).max() <= 1e-9 * max(np.abs(u1).max(), 1e-300), float(np.abs(u1 - u8).max())
     assert np.abs(s1 - s8).max() <= 1e-9 * np.abs(s1).max()
+
+
+def test_packed_exchange_path(gpu, oracle, monkeypatch):
+    """VDN_FORCE_PACKED=1 routes the rank's own box-to-box copies through the pack -> buffer -> unpack kernels
+    that cross-rank copies use (only the ncclSend/ncclRecv hand-over is replaced by a device memcpy)"""
+    monkeypatch.setenv("VDN_FORCE_PACKED", "1")
+    test_fill_boundary_multibox(gpu, oracle, "periodic")
+    test_fill_boundary_multibox(gpu, oracle, "mixed")
+    test_cc_solve_multibox_equals_single_box(gpu, oracle, "periodic")
+    test_nd_solve_multibox_equals_single_box(gpu, oracle, "walls")
+    test_advance_timestep_multibox_equals_single_box(gpu, "bubble-periodic", BC_SETS["periodic"], 1)

@@ -45,6 +45,10 @@ def comm_init(id128):
     check(capi.load().vdn_comm_init(C.c_char_p(bytes(id128))))
 
 
+def comm_finalize():
+    check(capi.load().vdn_comm_finalize())
+
+
 def finalize():
     global _initialised
     if _initialised:

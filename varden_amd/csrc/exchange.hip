@@ -17,6 +17,7 @@
 // canonical order, so offsets into the per-peer buffers agree without any handshake.
 #include "vdn_dev.h"
 #include <dlfcn.h>
+#include <cstdlib>
 #include <algorithm>
 #include <tuple>
 
@@ -153,6 +154,9 @@ struct XPlan {
 XPlan *xplan_build(const std::vector<XBoxInfo> &boxes, const vdn_box &pd, const int pmask[3], int ng, int nc) {
   XPlan *P = new XPlan; P->nc = nc;
   const int me = ctx().rank;
+  // self-test mode: route the rank's OWN box-to-box copies through the pack -> buffer -> unpack path that remote
+  // copies take (peer == me, buffer handed over with a device memcpy instead of ncclSend/ncclRecv)
+  const bool force_packed = getenv("VDN_FORCE_PACKED") && atoi(getenv("VDN_FORCE_PACKED")) == 1;
   int per[3], nshift[3];
   for (int d = 0; d < 3; d++) { per[d] = pd.hi[d] - pd.lo[d] + 1; nshift[d] = pmask[d] ? 1 : 0; }
   std::map<int, Peer> peers;
@@ -175,7 +179,7 @@ XPlan *xplan_build(const std::vector<XBoxInfo> &boxes, const vdn_box &pd, const 
         }
         if (empty || all_inside) continue;
         const long cnt = (long)(hi[0] - lo[0] + 1) * (hi[1] - lo[1] + 1) * (hi[2] - lo[2] + 1) * nc;
-        if (B.owner == me && S.owner == me) {
+        if (B.owner == me && S.owner == me && !force_packed) {
           CopyDesc D; memset(&D, 0, sizeof D);
           D.dst = B.fv; D.src = S.fv;
           for (int d = 0; d < 3; d++) { D.lo[d] = lo[d]; D.hi[d] = hi[d]; D.sh[d] = sh[d]; D.vlo[d] = B.vlo[d]; D.vhi[d] = B.vhi[d]; }
@@ -185,10 +189,11 @@ XPlan *xplan_build(const std::vector<XBoxInfo> &boxes, const vdn_box &pd, const 
           for (int d = 0; d < 3; d++) { D.lo[d] = lo[d]; D.hi[d] = hi[d]; D.sh[d] = sh[d]; D.vlo[d] = B.vlo[d]; D.vhi[d] = B.vhi[d]; }
           if (S.owner == me) {            // I send to the owner of the destination box
             Peer &pr = peers[B.owner]; pr.rank = B.owner;
-            D.fv = S.fv; D.off = (long)pr.nsend; pr.nsend += cnt; pr.pack.push_back(D);
-          } else {                        // I receive from the owner of the source box
+            PackDesc Ds = D; Ds.fv = S.fv; Ds.off = (long)pr.nsend; pr.nsend += cnt; pr.pack.push_back(Ds);
+          }
+          if (B.owner == me) {            // I receive from the owner of the source box
             Peer &pr = peers[S.owner]; pr.rank = S.owner;
-            D.fv = B.fv; D.off = (long)pr.nrecv; pr.nrecv += cnt; pr.unpack.push_back(D);
+            PackDesc Dr = D; Dr.fv = B.fv; Dr.off = (long)pr.nrecv; pr.nrecv += cnt; pr.unpack.push_back(Dr);
           }
         }
       }
@@ -231,15 +236,23 @@ void xplan_run(XPlan *P) {
   const int nc = P->nc;
   // pack + post the remote traffic first so that it overlaps the local copies
   if (!P->peers.empty()) {
-    need_comm();
-    for (auto &pr : P->peers)
-      if (!pr.pack.empty()) hipLaunchKernelGGL(k_xpack, dim3(32, 1, (unsigned)pr.pack.size()), dim3(256), 0, st, pr.d_pack, nc, pr.d_send);
-    NCCLCHK(g_rccl.GroupStart());
+    bool remote = false;
     for (auto &pr : P->peers) {
-      if (pr.nsend) NCCLCHK(g_rccl.Send(pr.d_send, pr.nsend, ncclFloat64, pr.rank, g_rccl.comm, st));
-      if (pr.nrecv) NCCLCHK(g_rccl.Recv(pr.d_recv, pr.nrecv, ncclFloat64, pr.rank, g_rccl.comm, st));
+      if (pr.rank != ctx().rank) remote = true;
+      if (!pr.pack.empty()) hipLaunchKernelGGL(k_xpack, dim3(32, 1, (unsigned)pr.pack.size()), dim3(256), 0, st, pr.d_pack, nc, pr.d_send);
     }
-    NCCLCHK(g_rccl.GroupEnd());
+    if (remote) {
+      need_comm();
+      NCCLCHK(g_rccl.GroupStart());
+      for (auto &pr : P->peers) {
+        if (pr.rank == ctx().rank) continue;
+        if (pr.nsend) NCCLCHK(g_rccl.Send(pr.d_send, pr.nsend, ncclFloat64, pr.rank, g_rccl.comm, st));
+        if (pr.nrecv) NCCLCHK(g_rccl.Recv(pr.d_recv, pr.nrecv, ncclFloat64, pr.rank, g_rccl.comm, st));
+      }
+      NCCLCHK(g_rccl.GroupEnd());
+    }
+    for (auto &pr : P->peers)           // self-test mode (VDN_FORCE_PACKED): my own buffer is my inbox
+      if (pr.rank == ctx().rank && pr.nsend) { REQUIRE(pr.nsend == pr.nrecv, "self exchange: send/recv sizes differ"); HIPCHK(hipMemcpyAsync(pr.d_recv, pr.d_send, pr.nsend * sizeof(double), hipMemcpyDeviceToDevice, st)); }
   }
   if (!P->local.empty())
     hipLaunchKernelGGL(k_xcopy, dim3(64, 1, (unsigned)P->local.size()), dim3(256), 0, st, P->d_local, nc);

@@ -12,19 +12,19 @@ from . import boxlib as bl
 from .capi import default_params
 
 
-def initdata_numpy(n, dx, prob_type=1, ng=3, nscal=2):
+def initdata_numpy(n, dx, prob_type=1, ng=3, nscal=2, lo=(0, 0, 0), centre=(0.5, 0.5, 0.5)):
     """reference src/initdata.f90:212-259 (prob_type 1 bubble / 2 advected blob), numpy restatement used
-    for synthetic bench input."""
+    for synthetic bench input; fills the box [lo, lo+n) (with ng ghost layers left at the background value)."""
     u = np.zeros(tuple(x + 2 * ng for x in n) + (3,), order="F")
     s = np.zeros(tuple(x + 2 * ng for x in n) + (nscal,), order="F")
     s[..., 0] = 1.0
     if prob_type == 2:
         u[..., 0] = 1.0
-    x = dx[0] * (np.arange(n[0]) + 0.5)
-    y = dx[1] * (np.arange(n[1]) + 0.5)
-    z = dx[2] * (np.arange(n[2]) + 0.5)
+    x = dx[0] * (lo[0] + np.arange(n[0]) + 0.5)
+    y = dx[1] * (lo[1] + np.arange(n[1]) + 0.5)
+    z = dx[2] * (lo[2] + np.arange(n[2]) + 0.5)
     X, Y, Z = np.meshgrid(x, y, z, indexing="ij")
-    dist = np.sqrt((X - 0.5) ** 2 + (Y - 0.5) ** 2 + (Z - 0.5) ** 2)
+    dist = np.sqrt((X - centre[0]) ** 2 + (Y - centre[1]) ** 2 + (Z - centre[2]) ** 2)
     r = 1.0 + 0.5 * (10.0 - 1.0) * (1.0 - np.tanh(30.0 * (dist - 0.1)))
     g = ng
     s[g:-g, g:-g, g:-g, 0] = r
@@ -70,13 +70,15 @@ class Varden:
         self.gp, self.p = mk(dm, 1), mk(1, 1, (1, 1, 1))
         self.ext_vel_force, self.ext_scal_force = mk(dm, 1), mk(ns, 1)
         self.ext_vel_force[0].setval(grav, dm - 1, 1, all=True)                    # varden.f90:428-429
-        if u0 is None:
-            u0, s0 = initdata_numpy(self.n, self.dx[0], prob_type, 3, ns)
-        for li, gi in enumerate(self.local):              # each rank uploads the boxes it owns (global arrays carry 3 ghosts)
+        for li, gi in enumerate(self.local):              # each rank initialises / uploads only the boxes it owns
             blo, bhi = self.boxes[gi]
-            sl = tuple(slice(blo[d], bhi[d] + 1 + 6) for d in range(3))
-            self.uold[0].from_numpy(np.array(u0[sl], order="F"), li)
-            self.sold[0].from_numpy(np.array(s0[sl], order="F"), li)
+            if u0 is None:                                # blob centred in the domain (= (0.5,0.5,0.5) on the unit cube)
+                ub, sb = initdata_numpy(bs, self.dx[0], prob_type, 3, ns, lo=blo, centre=tuple(0.5 * prob_hi[d] for d in range(3)))
+            else:                                         # caller-supplied global arrays (carry 3 ghost layers)
+                sl = tuple(slice(blo[d], bhi[d] + 1 + 6) for d in range(3))
+                ub, sb = np.array(u0[sl], order="F"), np.array(s0[sl], order="F")
+            self.uold[0].from_numpy(ub, li)
+            self.sold[0].from_numpy(sb, li)
         self.time, self.dt, self.istep = 0.0, 0.0, 0
         self.fill_state_ghosts()                                                   # initdata.f90:52-56
         if do_initial_projection:                                                  # varden.f90:126-138
@@ -136,3 +138,5 @@ class Varden:
             lst[0].destroy()
         self.bct.destroy()
         self.mla.destroy()
+        if self.nranks > 1:
+            bl.comm_finalize()
