@@ -79,6 +79,7 @@ typedef struct cclev {
   double *rh;            /* n^3 */
   double *res;           /* n^3 */
   double *b[3];          /* face coefficients, (n+e_d) extents, bc-modified */
+  double *alpha;         /* cell coefficient of the (alpha - div b grad) operator, NULL when alpha = 0 */
 } cclev;
 
 #define PHI(L, i, j, k) (L)->phi[((i) + 1) + ((L)->n[0] + 2) * (((j) + 1) + (long)((L)->n[1] + 2) * ((k) + 1))]
@@ -98,8 +99,9 @@ static void cc_alloc(cclev *L, const int n[3], const double h[3])
     long nf = 1; for (int t = 0; t < 3; t++) nf *= (n[t] + (t == d));
     L->b[d] = (double *)calloc(nf, sizeof(double));
   }
+  L->alpha = NULL;
 }
-static void cc_free(cclev *L) { free(L->phi); free(L->rh); free(L->res); for (int d = 0; d < 3; d++) free(L->b[d]); }
+static void cc_free(cclev *L) { free(L->phi); free(L->rh); free(L->res); for (int d = 0; d < 3; d++) free(L->b[d]); free(L->alpha); }
 
 static void cc_fill_periodic(cclev *L, const int per[3])
 {
@@ -127,6 +129,11 @@ static inline void cc_apply(const cclev *L, int i, int j, int k, double *Ap, dou
   double az = (bzp * (p0 - PHI(L, i, j, k + 1)) + bzm * (p0 - PHI(L, i, j, k - 1))) * L->hi2[2];
   *Ap = ax + ay + az;
   *diag = (bxp + bxm) * L->hi2[0] + (byp + bym) * L->hi2[1] + (bzp + bzm) * L->hi2[2];
+  if (L->alpha) {                       /* (alpha - div b grad): viscous / diffusive solves */
+    double a0 = CC(L, L->alpha, i, j, k);
+    *Ap = *Ap + a0 * p0;
+    *diag = *diag + a0;
+  }
 }
 
 static void cc_gsrb(cclev *L, const int per[3], int nsweeps)
@@ -190,7 +197,7 @@ static void cc_coarsen_coeffs(const cclev *F, cclev *C)
 
 typedef struct ccmg { int nlev; cclev lev[32]; int per[3]; } ccmg;
 
-static void ccmg_build(ccmg *M, vo_fab *beta[3], const double dx[3], const int ellbc[3][2])
+static void ccmg_build(ccmg *M, const vo_fab *alpha, vo_fab *beta[3], const double dx[3], const int ellbc[3][2])
 {
   const vo_fab *b0 = beta[0];
   int n[3]; double h[3];
@@ -216,6 +223,20 @@ static void ccmg_build(ccmg *M, vo_fab *beta[3], const double dx[3], const int e
         }
       }
     } else cc_coarsen_coeffs(&M->lev[M->nlev - 1], L);
+    if (alpha) {                          /* level 0: copy; coarser: mean of the 8 children */
+      long nc = (long)n[0] * n[1] * n[2];
+      L->alpha = (double *)calloc(nc, sizeof(double));
+      for (int k = 0; k < n[2]; k++) for (int j = 0; j < n[1]; j++) for (int i = 0; i < n[0]; i++) {
+        if (M->nlev == 0) CC(L, L->alpha, i, j, k) = VF(alpha, alpha->lo[0] + i, alpha->lo[1] + j, alpha->lo[2] + k, 0);
+        else {
+          const cclev *F = &M->lev[M->nlev - 1];
+          int I = 2 * i, J = 2 * j, K = 2 * k;
+          double sum = CC(F, F->alpha, I, J, K) + CC(F, F->alpha, I + 1, J, K) + CC(F, F->alpha, I, J + 1, K) + CC(F, F->alpha, I + 1, J + 1, K)
+                     + CC(F, F->alpha, I, J, K + 1) + CC(F, F->alpha, I + 1, J, K + 1) + CC(F, F->alpha, I, J + 1, K + 1) + CC(F, F->alpha, I + 1, J + 1, K + 1);
+          CC(L, L->alpha, i, j, k) = sum * 0.125;
+        }
+      }
+    }
     M->nlev++;
     int can = 1;
     for (int d = 0; d < 3; d++) if ((n[d] & 1) || n[d] <= 2) can = 0;
@@ -250,12 +271,24 @@ static void cc_vcycle(ccmg *M, int l, int nu1, int nu2, int nub)
   cc_gsrb(L, M->per, nu2);
 }
 
-static void cc_load(cclev *L, const vo_fab *rh, const vo_fab *phi)
+/* Inhomogeneous Dirichlet data: the ghost cells of the incoming phi hold the boundary-FACE values (that is what
+ * multifab_physbc's EXT_DIR fill leaves there, and how visc_solve hands unew to the solver, viscsolve.f90:270).
+ * The face term 2 b (phi_i - phi_b)/h^2 is split: the phi_b part moves to the right-hand side here (order:
+ * x-lo, x-hi, y-lo, y-hi, z-lo, z-hi), the solver then works with a zero ghost. */
+static void cc_load(cclev *L, const vo_fab *rh, const vo_fab *phi, const int ellbc[3][2])
 {
   const int *n = L->n;
   for (int k = 0; k < n[2]; k++) for (int j = 0; j < n[1]; j++) for (int i = 0; i < n[0]; i++) {
-    CC(L, L->rh, i, j, k) = VF(rh, rh->lo[0] + i, rh->lo[1] + j, rh->lo[2] + k, 0);
-    PHI(L, i, j, k) = VF(phi, phi->lo[0] + i, phi->lo[1] + j, phi->lo[2] + k, 0);
+    double r = VF(rh, rh->lo[0] + i, rh->lo[1] + j, rh->lo[2] + k, 0);
+    const int gi = phi->lo[0] + i, gj = phi->lo[1] + j, gk = phi->lo[2] + k;
+    if (i == 0 && ellbc[0][0] == VDN_BC_DIR)        r = r + BX(L, 0, j, k) * VF(phi, gi - 1, gj, gk, 0) * L->hi2[0];
+    if (i == n[0] - 1 && ellbc[0][1] == VDN_BC_DIR) r = r + BX(L, n[0], j, k) * VF(phi, gi + 1, gj, gk, 0) * L->hi2[0];
+    if (j == 0 && ellbc[1][0] == VDN_BC_DIR)        r = r + BY(L, i, 0, k) * VF(phi, gi, gj - 1, gk, 0) * L->hi2[1];
+    if (j == n[1] - 1 && ellbc[1][1] == VDN_BC_DIR) r = r + BY(L, i, n[1], k) * VF(phi, gi, gj + 1, gk, 0) * L->hi2[1];
+    if (k == 0 && ellbc[2][0] == VDN_BC_DIR)        r = r + BZ(L, i, j, 0) * VF(phi, gi, gj, gk - 1, 0) * L->hi2[2];
+    if (k == n[2] - 1 && ellbc[2][1] == VDN_BC_DIR) r = r + BZ(L, i, j, n[2]) * VF(phi, gi, gj, gk + 1, 0) * L->hi2[2];
+    CC(L, L->rh, i, j, k) = r;
+    PHI(L, i, j, k) = VF(phi, gi, gj, gk, 0);
   }
 }
 /* store phi incl. the ghost layer the solver's closure implies: Neumann ghost = phi_i, Dirichlet
@@ -283,11 +316,19 @@ static void cc_store(cclev *L, vo_fab *phi, const int ellbc[3][2], const int per
 int vo_cc_solve(const vo_fab *rh, vo_fab *phi, vo_fab *beta[3], const double dx[3], const int ellbc[3][2],
                 double rel_eps, double abs_eps, int max_iter, int nu1, int nu2, int nub, vo_mgstat *st)
 {
-  ccmg M; ccmg_build(&M, beta, dx, ellbc);
+  return vo_cc_solve_ab(rh, phi, NULL, beta, dx, ellbc, rel_eps, abs_eps, max_iter, nu1, nu2, nub, st);
+}
+
+/* (alpha - div beta grad) phi = rh; alpha may be NULL (= 0).  Dirichlet data in phi's ghost cells. */
+int vo_cc_solve_ab(const vo_fab *rh, vo_fab *phi, const vo_fab *alpha, vo_fab *beta[3], const double dx[3], const int ellbc[3][2],
+                   double rel_eps, double abs_eps, int max_iter, int nu1, int nu2, int nub, vo_mgstat *st)
+{
+  ccmg M; ccmg_build(&M, alpha, beta, dx, ellbc);
   cclev *L0 = &M.lev[0];
-  cc_load(L0, rh, phi);
-  double bnorm = 0.0;
-  for (long i = 0; i < (long)L0->n[0] * L0->n[1] * L0->n[2]; i++) bnorm = fmax(bnorm, fabs(L0->rh[i]));
+  cc_load(L0, rh, phi, ellbc);
+  double bnorm = 0.0;      /* norm of the right-hand side as given (before the Dirichlet data moved into it) */
+  for (int k = rh->lo[2]; k <= rh->hi[2]; k++) for (int j = rh->lo[1]; j <= rh->hi[1]; j++) for (int i = rh->lo[0]; i <= rh->hi[0]; i++)
+    bnorm = fmax(bnorm, fabs(VF(rh, i, j, k, 0)));
   int cyc = 0, conv = 0; double rn = 0.0, r0 = -1.0;
   if (bnorm == 0.0) { conv = 1; r0 = 0.0; }
   while (!conv && cyc <= max_iter) {
@@ -312,8 +353,8 @@ int vo_cc_solve(const vo_fab *rh, vo_fab *phi, vo_fab *beta[3], const double dx[
 
 void vo_cc_smooth(const vo_fab *rh, vo_fab *phi, vo_fab *beta[3], const double dx[3], const int ellbc[3][2], int nsweeps)
 {
-  ccmg M; ccmg_build(&M, beta, dx, ellbc);
-  cc_load(&M.lev[0], rh, phi);
+  ccmg M; ccmg_build(&M, NULL, beta, dx, ellbc);
+  cc_load(&M.lev[0], rh, phi, ellbc);
   cc_gsrb(&M.lev[0], M.per, nsweeps);
   cc_store(&M.lev[0], phi, ellbc, M.per);
   ccmg_free(&M);

@@ -60,3 +60,27 @@ def test_advance_properties_64(gpu):
     assert np.abs(s[..., 0] - s[:, ::-1, :, 0]).max() <= 1e-8 * np.abs(s).max()
     assert u[..., 2].max() > 0 or u[..., 2].min() < 0     # gravity moved something
     G.close()
+
+
+@pytest.mark.parametrize("name,phys,prob,dtype", [("bubble-walls-CN", WALLS, 1, 1), ("blob-inout-CN", INOUT, 2, 1), ("bubble-periodic-BE", PER, 1, 2)])
+def test_advance_parity_viscous(gpu, name, phys, prob, dtype):
+    """the shipped inputs all have visc_coef > 0 (exec/test/inputs_bubble_3d:33): explicit diffusive term + implicit
+    Crank-Nicolson / backward-Euler viscous and scalar-diffusion solves (viscsolve.f90), against the oracle"""
+    from oracle import voracle as vo
+    from varden_amd import driver
+    n = 16
+    kw = dict(cflfac=0.9, visc_coef=0.01, diff_coef=0.005, diffusion_type=dtype)
+    O = vo.Sim(n, phys, params_for(phys, **kw), prob_type=prob, init_shrink=0.1, init_iter=1)
+    ou, os_ = vo.Fab((0, 0, 0), (n - 1,) * 3, 3, 3), vo.Fab((0, 0, 0), (n - 1,) * 3, 3, 2)
+    vo.lib().vo_initdata(ou.ref, os_.ref, O.dx, prob)
+    G = driver.Varden(n, phys, params_for(phys, **kw), prob_type=prob, init_shrink=0.1, init_iter=1, u0=ou.a, s0=os_.a)
+    for _ in range(3):
+        O.step(); G.step()
+        assert G.dt == O.dt
+    g = 3
+    for nm, gm, om in (("u", G.unew[0], O.unew), ("s", G.snew[0], O.snew)):
+        a_, b_ = gm.to_numpy()[g:-g, g:-g, g:-g], om.valid()
+        scale = max(float(np.abs(b_).max()), 1e-300)
+        err = float(np.abs(a_ - b_).max())
+        assert err <= 1e-9 * scale, "%s: %s differs by %.3e (scale %.3e)" % (name, nm, err, scale)
+    G.close()

@@ -64,8 +64,8 @@ def test_rejects_unimplemented_configurations():
     lib = capi.load()
     p = capi.default_params(dm=2)
     assert lib.vdn_init(C.byref(p), 0, 1, 0) != 0 and b"dm = 3" in lib.vdn_last_error()
-    p = capi.default_params(visc_coef=0.001)
-    assert lib.vdn_init(C.byref(p), 0, 1, 0) != 0 and b"visc" in lib.vdn_last_error()
+    p = capi.default_params(diffusion_type=3)
+    assert lib.vdn_init(C.byref(p), 0, 1, 0) != 0 and b"DIFFUSION" in lib.vdn_last_error()
 
 
 def test_product_does_not_reference_the_oracle():

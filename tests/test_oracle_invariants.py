@@ -281,3 +281,34 @@ def test_estdt_matches_the_reference_formula():
     u.a[...] = 0.0
     ext.a[...] = 0.0
     assert vo.lib().vo_estdt(u.ref, s.ref, gp.ref, ext.ref, vo.dvec([dx] * 3), C.c_double(-1.0), C.byref(prm)) == dx * 0.5
+
+
+@pytest.mark.parametrize("dtype", [1, 2])
+def test_viscous_solve_decays_a_fourier_mode_exactly(dtype):
+    """periodic box, rho = 1: one Crank-Nicolson (or backward-Euler) viscous solve multiplies a discrete eigenmode of the
+    7-point laplacian by (1 - mu' lam)/(1 + mu' lam) with mu' = dt nu / 2  (resp. 1/(1 + dt nu lam)) -- viscsolve.f90:264-302"""
+    n = 16
+    prm = default_params(diffusion_type=dtype, visc_coef=0.1)
+    bc = vo.make_bc(PER)
+    pm = vo.ivec([1, 1, 1])
+    lo, hi = (0, 0, 0), (n - 1,) * 3
+    dx = vo.dvec([1.0 / n] * 3)
+    x = (np.arange(-3, n + 3) + 0.5) / n
+    X, Y, Z = np.meshgrid(x, x, x, indexing="ij")
+    mode = np.sin(2 * np.pi * X) * np.cos(4 * np.pi * Y)
+    lam = ((2 - 2 * np.cos(2 * np.pi / n)) + (2 - 2 * np.cos(4 * np.pi / n))) * n * n
+    unew = vo.Fab(lo, hi, 3, 3)
+    for c in range(3):
+        unew.a[..., c] = (c + 1) * mode
+    lapu = vo.Fab(lo, hi, 0, 3)
+    for c in range(3):
+        vo.lib().vo_explicit_diffusive_term(lapu.ref, unew.ref, c, c, dx, C.byref(bc))
+    assert np.abs(lapu.a[..., 0] + lam * mode[3:-3, 3:-3, 3:-3]).max() <= 1e-9 * lam
+    rho, mac_rhs = vo.Fab(lo, hi, 1, 1, val=1.0), vo.Fab(lo, hi, 1, 1)
+    dt, nu = 0.01, 0.1
+    mu = 0.5 * dt * nu if dtype == 1 else dt * nu
+    st = vo.CMgStat()
+    vo.lib().vo_visc_solve(unew.ref, lapu.ref, rho.ref, mac_rhs.ref, dx, C.c_double(mu), C.byref(bc), pm, C.byref(prm), C.byref(st))
+    fac = (1 - mu * lam) / (1 + mu * lam) if dtype == 1 else 1.0 / (1 + mu * lam)
+    for c in range(3):
+        assert np.abs(unew.valid()[..., c] - fac * (c + 1) * mode[3:-3, 3:-3, 3:-3]).max() <= 1e-10

@@ -44,13 +44,19 @@ extern "C" int vdn_advance_timestep(int istep, vdn_layout *mla, vdn_multifab **s
   vdn_multifab *rhohalf = mf_temp(mla, n, dm, 1, -1, true, 0.0);
   vdn_multifab *umac[3];
   for (int d = 0; d < 3; d++) umac[d] = mf_temp(mla, n, 1, 1, d, true, 1.e20);
-  // (lapu == 0 when visc_coef == 0, advance_timestep.f90:85-93: passed as NULL)
+  // lapu (advance_timestep.f90:85-93); NULL stands for the all-zero field when visc_coef == 0
+  const bool viscous = P.visc_coef > 0.0, diffusive = P.diff_coef > 0.0;
+  vdn_multifab *lapu = nullptr;
+  if (viscous) {
+    lapu = mf_temp(mla, n, dm, 0, -1, true, 0.0);
+    for (int c = 0; c < dm; c++) k_explicit_diffusive_term(lapu, uold[n], c, c, dx, bct);
+  }
 
   // advance_premac.f90:44-51
   {
     size_t mark = arena_mark();
     vdn_multifab *vel_force = mf_temp(mla, n, dm, 1, -1, false, 0.0);
-    k_mkvelforce(vel_force, ext_vel_force[n], sold[n], gp[n], nullptr, 1.0);
+    k_mkvelforce(vel_force, ext_vel_force[n], sold[n], gp[n], lapu, 1.0);
     mf_restrict_and_fill(vel_force, 0, bct->extrap_comp0(), dm, true, bct);            // mkforce.f90:75-76
     k_velpred(uold[n], umac, vel_force, dx, dt, bct);
     for (int d = 0; d < 3; d++) mf_fill_boundary(umac[d]);                              // velpred.f90:108-112
@@ -75,13 +81,23 @@ extern "C" int vdn_advance_timestep(int istep, vdn_layout *mla, vdn_multifab **s
     vdn_multifab *divu = mf_temp(mla, n, 1, 1, -1, true, 0.0);
     vdn_multifab *sflux[3], *sedge[3];
     for (int d = 0; d < 3; d++) { sflux[d] = mf_temp(mla, n, nscal, 0, d, true, 0.0); sedge[d] = mf_temp(mla, n, nscal, 0, d, true, 0.0); }
-    k_mkscalforce(scal_force, ext_scal_force[n], nullptr, 1.0);
+    vdn_multifab *laps = nullptr;                                                      // scalar_advance.f90:80-89
+    if (diffusive) {
+      laps = mf_temp(mla, n, nscal, 0, -1, true, 0.0);
+      for (int c = 1; c < nscal; c++) k_explicit_diffusive_term(laps, sold[n], c, dm + c, dx, bct);
+    }
+    k_mkscalforce(scal_force, ext_scal_force[n], laps, 1.0);
     mf_restrict_and_fill(scal_force, 0, bct->extrap_comp0(), nscal, true, bct);        // mkforce.f90:283-284
     k_mkflux(sold[n], sedge, sflux, umac, scal_force, divu, dx, dt, bct, false, is_cons);
-    k_mkscalforce(scal_force, ext_scal_force[n], nullptr, 0.0);
+    k_mkscalforce(scal_force, ext_scal_force[n], laps, 0.0);
     mf_restrict_and_fill(scal_force, 0, bct->extrap_comp0(), nscal, true, bct);
     k_update(sold[n], umac, sedge, sflux, scal_force, snew[n], dx, dt, false, is_cons);
     mf_restrict_and_fill(snew[n], 0, dm, nscal, false, bct);                            // update.f90:106
+    if (diffusive) {                                                                    // scalar_advance.f90:144-162
+      const double visc_mu = (P.diffusion_type == 1) ? 0.5 * dt * P.diff_coef : dt * P.diff_coef;
+      for (int c = 1; c < nscal; c++) do_diff_scalar_solve(mla, snew[n], laps, dx, visc_mu, bct, c, dm + c);
+      mf_temp_free(laps);
+    }
     for (int d = 0; d < 3; d++) { mf_temp_free(sflux[d]); mf_temp_free(sedge[d]); }
     mf_temp_free(divu); mf_temp_free(scal_force);
     arena_release(mark);
@@ -91,6 +107,7 @@ extern "C" int vdn_advance_timestep(int istep, vdn_layout *mla, vdn_multifab **s
   // make_at_halftime (advance_timestep.f90:114, make_at_halftime.f90:64-65)
   k_make_at_halftime(rhohalf, sold[n], snew[n], 0, 0);
   mf_restrict_and_fill(rhohalf, 0, dm + 0, 1, false, bct);
+  if (viscous && P.diffusion_type == 2) mf_setval(lapu, 0.0, 0, dm, true);             // advance_timestep.f90:116-120
 
   // velocity_advance.f90:48-93
   t0 = wall();
@@ -100,13 +117,17 @@ extern "C" int vdn_advance_timestep(int istep, vdn_layout *mla, vdn_multifab **s
     vdn_multifab *vel_force = mf_temp(mla, n, dm, 1, -1, false, 0.0);
     vdn_multifab *uflux[3], *uedge[3];
     for (int d = 0; d < 3; d++) { uflux[d] = mf_temp(mla, n, dm, 0, d, true, 0.0); uedge[d] = mf_temp(mla, n, dm, 0, d, true, 0.0); }
-    k_mkvelforce(vel_force, ext_vel_force[n], sold[n], gp[n], nullptr, 1.0);
+    k_mkvelforce(vel_force, ext_vel_force[n], sold[n], gp[n], lapu, 1.0);
     mf_restrict_and_fill(vel_force, 0, bct->extrap_comp0(), dm, true, bct);
     k_mkflux(uold[n], uedge, uflux, umac, vel_force, mac_rhs, dx, dt, bct, true, is_cons);
-    k_mkvelforce(vel_force, ext_vel_force[n], rhohalf, gp[n], nullptr, 0.0);
+    k_mkvelforce(vel_force, ext_vel_force[n], rhohalf, gp[n], lapu, 0.0);
     mf_restrict_and_fill(vel_force, 0, bct->extrap_comp0(), dm, true, bct);
     k_update(uold[n], umac, uedge, uflux, vel_force, unew[n], dx, dt, true, is_cons);
     mf_restrict_and_fill(unew[n], 0, 0, dm, false, bct);                                // update.f90:104
+    if (viscous) {                                                                      // velocity_advance.f90:103-118
+      const double visc_mu = (P.diffusion_type == 1) ? 0.5 * dt * P.visc_coef : dt * P.visc_coef;
+      do_visc_solve(mla, unew[n], lapu, rhohalf, mac_rhs, dx, visc_mu, bct);
+    }
     for (int d = 0; d < 3; d++) { mf_temp_free(uflux[d]); mf_temp_free(uedge[d]); }
     mf_temp_free(vel_force);
     arena_release(mark);
@@ -122,6 +143,7 @@ extern "C" int vdn_advance_timestep(int istep, vdn_layout *mla, vdn_multifab **s
   sync(); ctx().step_sec[3] = wall() - t0;
 
   for (int d = 0; d < 3; d++) mf_temp_free(umac[d]);
+  if (lapu) mf_temp_free(lapu);
   mf_temp_free(rhohalf); mf_temp_free(mac_rhs);
   arena_reset();
   ctx().step_sec[4] = wall() - t_begin;

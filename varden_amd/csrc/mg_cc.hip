@@ -21,6 +21,7 @@ struct CLev {
   int n[3]; int PX, PY; long sz;
   double hi2[3];
   double *phi, *rh, *res, *b[3];
+  double *alpha;        // cell coefficient of (alpha - div b grad); nullptr when alpha = 0 (MAC projection)
 };
 DEVI long cidx(const CLev &L, int i, int j, int k) { return (long)(i + 16) + (long)L.PX * ((long)(j + 1) + (long)L.PY * (long)(k + 1)); }
 
@@ -36,6 +37,11 @@ DEVI void cc_apply(const CLev &L, long c, double &Ap, double &diag) {
   const double az = (bzp * (p0 - L.phi[c + sz]) + bzm * (p0 - L.phi[c - sz])) * L.hi2[2];
   Ap = ax + ay + az;
   diag = (bxp + bxm) * L.hi2[0] + (byp + bym) * L.hi2[1] + (bzp + bzm) * L.hi2[2];
+  if (L.alpha) {                        // viscous / diffusive solves (+8 B/cell of traffic)
+    const double a0 = L.alpha[c];
+    Ap = Ap + a0 * p0;
+    diag = diag + a0;
+  }
 }
 
 // one colour pass of red-black Gauss-Seidel: thread t of a row updates cell i = 2t + ((j+k+color)&1)
@@ -152,14 +158,14 @@ __global__ void __launch_bounds__(1024) kk_cc_bottom(CLev L, int nsweeps, int pe
 }
 
 // ---- transfers between BoxLib-layout multifabs and level 0 ---------------------------------------------
-__global__ void kk_cc_load(CLev L, FV rh, FV phi, FV bx, FV by, FV bz, int lo0, int lo1, int lo2, int ebc00, int ebc01, int ebc10, int ebc11, int ebc20, int ebc21) {
+__global__ void kk_cc_load(CLev L, FV rh, FV phi, FV alpha, FV bx, FV by, FV bz, int lo0, int lo1, int lo2, int ebc00, int ebc01, int ebc10, int ebc11, int ebc20, int ebc21) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   const int j = blockIdx.y * blockDim.y + threadIdx.y;
   const int k = blockIdx.z;
   if (i > L.n[0] || j > L.n[1] || k > L.n[2]) return;
   const long c = cidx(L, i, j, k);
   const bool ci = i < L.n[0], cj = j < L.n[1], ck = k < L.n[2];
-  if (ci && cj && ck) { L.rh[c] = fv_get(rh, lo0 + i, lo1 + j, lo2 + k); L.phi[c] = fv_get(phi, lo0 + i, lo1 + j, lo2 + k); }
+  if (ci && cj && ck) { L.phi[c] = fv_get(phi, lo0 + i, lo1 + j, lo2 + k); if (L.alpha) L.alpha[c] = fv_get(alpha, lo0 + i, lo1 + j, lo2 + k); }
   if (cj && ck) {
     double v = fv_get(bx, lo0 + i, lo1 + j, lo2 + k);
     int e = (i == 0) ? ebc00 : (i == L.n[0] ? ebc01 : VDN_BC_INT);
@@ -179,6 +185,39 @@ __global__ void kk_cc_load(CLev L, FV rh, FV phi, FV bx, FV by, FV bz, int lo0, 
     L.b[2][c] = v;
   }
 }
+// right-hand side, with the inhomogeneous Dirichlet data moved into it: the ghost cells of the incoming phi hold the
+// boundary-FACE values (multifab_physbc EXT_DIR; visc_solve hands unew over that way, viscsolve.f90:270); the face term
+// 2b(phi_i - phi_b)/h^2 keeps its phi_i part in the operator (b := 2b, zero ghost) and its phi_b part goes here, in the
+// order x-lo, x-hi, y-lo, y-hi, z-lo, z-hi (same as the oracle).  Runs after kk_cc_load (needs the folded b).
+__global__ void kk_cc_load_rh(CLev L, FV rh, FV phi, int lo0, int lo1, int lo2, int ebc00, int ebc01, int ebc10, int ebc11, int ebc20, int ebc21) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  const int j = blockIdx.y * blockDim.y + threadIdx.y;
+  const int k = blockIdx.z;
+  if (i >= L.n[0] || j >= L.n[1]) return;
+  const long c = cidx(L, i, j, k);
+  const long sy = L.PX, sz = (long)L.PX * L.PY;
+  const int gi = lo0 + i, gj = lo1 + j, gk = lo2 + k;
+  double r = fv_get(rh, gi, gj, gk);
+  if (i == 0 && ebc00 == VDN_BC_DIR)            r = r + L.b[0][c] * fv_get(phi, gi - 1, gj, gk) * L.hi2[0];
+  if (i == L.n[0] - 1 && ebc01 == VDN_BC_DIR)   r = r + L.b[0][c + 1] * fv_get(phi, gi + 1, gj, gk) * L.hi2[0];
+  if (j == 0 && ebc10 == VDN_BC_DIR)            r = r + L.b[1][c] * fv_get(phi, gi, gj - 1, gk) * L.hi2[1];
+  if (j == L.n[1] - 1 && ebc11 == VDN_BC_DIR)   r = r + L.b[1][c + sy] * fv_get(phi, gi, gj + 1, gk) * L.hi2[1];
+  if (k == 0 && ebc20 == VDN_BC_DIR)            r = r + L.b[2][c] * fv_get(phi, gi, gj, gk - 1) * L.hi2[2];
+  if (k == L.n[2] - 1 && ebc21 == VDN_BC_DIR)   r = r + L.b[2][c + sz] * fv_get(phi, gi, gj, gk + 1) * L.hi2[2];
+  L.rh[c] = r;
+}
+// mean of the 8 children of a cell field (alpha)
+__global__ void kk_cc_coarsen_cell(CLev F, const double *src, CLev C, double *dst) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  const int j = blockIdx.y * blockDim.y + threadIdx.y;
+  const int k = blockIdx.z;
+  if (i >= C.n[0] || j >= C.n[1]) return;
+  const long sy = F.PX, sz = (long)F.PX * F.PY;
+  const long f = cidx(F, 2 * i, 2 * j, 2 * k);
+  double s = src[f] + src[f + 1] + src[f + sy] + src[f + sy + 1] + src[f + sz] + src[f + sz + 1] + src[f + sz + sy] + src[f + sz + sy + 1];
+  dst[cidx(C, i, j, k)] = s * 0.125;
+}
+
 // phi back, incl. the face ghost layer the closure implies (Neumann: phi_i, Dirichlet: -phi_i, periodic: image)
 __global__ void kk_cc_store(CLev L, FV phi, int lo0, int lo1, int lo2, int ebc00, int ebc01, int ebc10, int ebc11, int ebc20, int ebc21) {
   const int i = (int)(blockIdx.x * blockDim.x + threadIdx.x) - 1;
@@ -209,14 +248,13 @@ __global__ void kk_cc_store(CLev L, FV phi, int lo0, int lo1, int lo2, int ebc00
 // The face coefficients of the tail's first level travel the same way once per solve.
 struct GBox { int c0[3]; int n[3]; long off; };     // where a box's coarse cells sit in the tail level / in the buffer
 
-__global__ void kk_cc_restrict_pack(CLev F, double *buf, long off, int nx, int ny, int nz) {
+__global__ void kk_cc_restrict_pack(CLev F, const double *r, double *buf, long off, int nx, int ny, int nz) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   const int j = blockIdx.y * blockDim.y + threadIdx.y;
   const int k = blockIdx.z;
   if (i >= nx || j >= ny) return;
   const long sy = F.PX, sz = (long)F.PX * F.PY;
   const long f = cidx(F, 2 * i, 2 * j, 2 * k);
-  const double *r = F.res;
   double s = r[f] + r[f + 1] + r[f + sy] + r[f + sy + 1] + r[f + sz] + r[f + sz + 1] + r[f + sz + sy] + r[f + sz + sy + 1];
   buf[off + i + (long)nx * (j + (long)ny * k)] = s * 0.125;
 }
@@ -233,12 +271,12 @@ __global__ void kk_cc_coarsen_b_pack(CLev F, double *buf, long off, int nx, int 
   if (i < nx && k < nz) buf[o1 + i + (long)nx * (j + (long)(ny + 1) * k)] = (F.b[1][f] + F.b[1][f + 1] + F.b[1][f + sz] + F.b[1][f + sz + 1]) * 0.25;
   if (i < nx && j < ny) buf[o2 + i + (long)nx * (j + (long)ny * k)] = (F.b[2][f] + F.b[2][f + 1] + F.b[2][f + sy] + F.b[2][f + sy + 1]) * 0.25;
 }
-__global__ void kk_cc_unpack_rh(CLev T, const double *buf, const GBox *gb) {
+__global__ void kk_cc_unpack_rh(CLev T, double *dst, const double *buf, const GBox *gb) {
   const GBox g = gb[blockIdx.z];
   const int tot = g.n[0] * g.n[1] * g.n[2];
   for (int t = blockIdx.x * blockDim.x + threadIdx.x; t < tot; t += gridDim.x * blockDim.x) {
     const int i = t % g.n[0], j = (t / g.n[0]) % g.n[1], k = t / (g.n[0] * g.n[1]);
-    T.rh[cidx(T, g.c0[0] + i, g.c0[1] + j, g.c0[2] + k)] = buf[g.off + t];
+    dst[cidx(T, g.c0[0] + i, g.c0[1] + j, g.c0[2] + k)] = buf[g.off + t];
   }
 }
 __global__ void kk_cc_unpack_b(CLev T, const double *buf, const GBox *gb) {
@@ -280,15 +318,17 @@ struct CCMG {
 static dim3 g3(int nx, int ny, int nz, dim3 b) { return dim3((nx + b.x - 1) / b.x, (ny + b.y - 1) / b.y, nz); }
 static const dim3 BLK(64, 4, 1);
 
-static CLev cc_alloc_lev(const int n[3], const double h[3]) {
+static CLev cc_alloc_lev(const int n[3], const double h[3], bool has_alpha) {
   CLev L;
   for (int d = 0; d < 3; d++) { L.n[d] = n[d]; L.hi2[d] = 1.0 / (h[d] * h[d]); }
   L.PX = ((n[0] + 17 + 15) / 16) * 16; L.PY = n[1] + 2;
   L.sz = (long)L.PX * L.PY * (n[2] + 2);
-  double *base = (double *)arena_alloc(sizeof(double) * L.sz * 6);
-  HIPCHK(hipMemsetAsync(base, 0, sizeof(double) * L.sz * 6, ctx().stream));
+  const int nf = has_alpha ? 7 : 6;
+  double *base = (double *)arena_alloc(sizeof(double) * L.sz * nf);
+  HIPCHK(hipMemsetAsync(base, 0, sizeof(double) * L.sz * nf, ctx().stream));
   L.phi = base; L.rh = base + L.sz; L.res = base + 2 * L.sz;
   for (int d = 0; d < 3; d++) L.b[d] = base + (3 + d) * L.sz;
+  L.alpha = has_alpha ? base + 6 * L.sz : nullptr;
   return L;
 }
 static FV cc_phi_view(const CLev &L, const int lo[3]) {
@@ -303,7 +343,7 @@ void cc_halo_cache_purge(unsigned long uid) {        // the plans themselves are
   for (auto it = g_halo_cache.begin(); it != g_halo_cache.end();) { if (it->first.uid == uid) it = g_halo_cache.erase(it); else ++it; }
 }
 
-static void cc_build(CCMG &M, const vdn_multifab *rh, const double *dx, const int bc[3][2]) {
+static void cc_build(CCMG &M, const vdn_multifab *rh, const double *dx, const int bc[3][2], bool has_alpha) {
   const vdn_layout *la = rh->la; const int lev = rh->lev;
   const auto &gboxes = la->boxes[lev];
   const int nb = (int)gboxes.size();
@@ -330,7 +370,7 @@ static void cc_build(CCMG &M, const vdn_multifab *rh, const double *dx, const in
       for (int d = 0; d < 3; d++) { lo[d] = (gboxes[g].lo[d] - la->pd[lev].lo[d]) / scale; x.vlo[d] = lo[d]; x.vhi[d] = lo[d] + n[d] - 1; }
       x.owner = la->owner[lev][g];
       if (x.owner == ctx().rank) {
-        CBox B; B.L = cc_alloc_lev(n, h); B.gidx = g; for (int d = 0; d < 3; d++) B.lo[d] = lo[d];
+        CBox B; B.L = cc_alloc_lev(n, h, has_alpha); B.gidx = g; for (int d = 0; d < 3; d++) B.lo[d] = lo[d];
         x.fv = cc_phi_view(B.L, lo);
         DL.boxes.push_back(B);
       }
@@ -359,7 +399,7 @@ static void cc_build(CCMG &M, const vdn_multifab *rh, const double *dx, const in
       int tn[3]; double th[3]; int cn[3];
       for (int d = 0; d < 3; d++) { cn[d] = n[d] / 2; tn[d] = (lpd.hi[d] + 1) / 2; th[d] = h[d] * 2.0; }
       for (;;) {
-        M.tail.push_back(cc_alloc_lev(tn, th));
+        M.tail.push_back(cc_alloc_lev(tn, th, has_alpha));
         bool c2 = true;
         for (int d = 0; d < 3; d++) if ((tn[d] & 1) || tn[d] <= 2) c2 = false;
         if (!c2 || M.tail.size() >= 31) break;
@@ -463,10 +503,10 @@ static void cc_restrict_down(CCMG &M, int l) {
     for (size_t b = 0; b < DL.boxes.size(); b++) {
       const CLev &F = DL.boxes[b].L;
       const int nx = F.n[0] / 2, ny = F.n[1] / 2, nz = F.n[2] / 2;
-      hipLaunchKernelGGL(kk_cc_restrict_pack, g3(nx, ny, nz, BLK), BLK, 0, ctx().stream, F, M.sendbuf, M.loc_off_rh[b], nx, ny, nz);
+      hipLaunchKernelGGL(kk_cc_restrict_pack, g3(nx, ny, nz, BLK), BLK, 0, ctx().stream, F, (const double *)F.res, M.sendbuf, M.loc_off_rh[b], nx, ny, nz);
     }
     comm_allgather_dev(M.sendbuf, M.recvbuf, M.cnt_rh);
-    hipLaunchKernelGGL(kk_cc_unpack_rh, dim3(4, 1, (unsigned)M.gb_rh.size()), dim3(256), 0, ctx().stream, T, M.recvbuf, M.d_gb_rh);
+    hipLaunchKernelGGL(kk_cc_unpack_rh, dim3(4, 1, (unsigned)M.gb_rh.size()), dim3(256), 0, ctx().stream, T, T.rh, M.recvbuf, M.d_gb_rh);
   }
 }
 static void cc_prolong_up(CCMG &M, int l) {
@@ -498,9 +538,9 @@ static void cc_vcycle_d(CCMG &M, int l) {
   cc_gsrb_d(M, DL, P.mg_nu2);
 }
 
-static void cc_setup(CCMG &M, vdn_multifab *rh, vdn_multifab *phi, vdn_multifab **beta, const double *dx, const int bc[3][2]) {
+static void cc_setup(CCMG &M, vdn_multifab *rh, vdn_multifab *phi, const vdn_multifab *alpha, vdn_multifab **beta, const double *dx, const int bc[3][2]) {
   REQUIRE(phi->ng >= 1, "cc multigrid: phi needs one ghost cell");
-  cc_build(M, rh, dx, bc);
+  cc_build(M, rh, dx, bc, alpha != nullptr);
   const vdn_layout *la = rh->la; const int lev = rh->lev;
   CDLev &D0 = M.dlev[0];
   for (size_t b = 0; b < D0.boxes.size(); b++) {
@@ -513,13 +553,16 @@ static void cc_setup(CCMG &M, vdn_multifab *rh, vdn_multifab *phi, vdn_multifab 
       e[d][1] = (bx.hi[d] == la->pd[lev].hi[d]) ? bc[d][1] : VDN_BC_INT;
     }
     hipLaunchKernelGGL(kk_cc_load, g3(L0.n[0] + 1, L0.n[1] + 1, L0.n[2] + 1, BLK), BLK, 0, ctx().stream, L0, rh->fabs[b], phi->fabs[b],
-                       beta[0]->fabs[b], beta[1]->fabs[b], beta[2]->fabs[b], bx.lo[0], bx.lo[1], bx.lo[2],
+                       alpha ? alpha->fabs[b] : rh->fabs[b], beta[0]->fabs[b], beta[1]->fabs[b], beta[2]->fabs[b], bx.lo[0], bx.lo[1], bx.lo[2],
                        e[0][0], e[0][1], e[1][0], e[1][1], e[2][0], e[2][1]);
+    hipLaunchKernelGGL(kk_cc_load_rh, g3(L0.n[0], L0.n[1], L0.n[2], BLK), BLK, 0, ctx().stream, L0, rh->fabs[b], phi->fabs[b],
+                       bx.lo[0], bx.lo[1], bx.lo[2], e[0][0], e[0][1], e[1][0], e[1][1], e[2][0], e[2][1]);
   }
   for (size_t l = 1; l < M.dlev.size(); l++)
     for (size_t b = 0; b < M.dlev[l].boxes.size(); b++) {
       const CLev &C = M.dlev[l].boxes[b].L;
       hipLaunchKernelGGL(kk_cc_coarsen_b, g3(C.n[0] + 1, C.n[1] + 1, C.n[2] + 1, BLK), BLK, 0, ctx().stream, M.dlev[l - 1].boxes[b].L, C);
+      if (alpha) hipLaunchKernelGGL(kk_cc_coarsen_cell, g3(C.n[0], C.n[1], C.n[2], BLK), BLK, 0, ctx().stream, M.dlev[l - 1].boxes[b].L, (const double *)M.dlev[l - 1].boxes[b].L.alpha, C, C.alpha);
     }
   if (!M.tail.empty()) {
     CDLev &DL = M.dlev.back();
@@ -530,9 +573,19 @@ static void cc_setup(CCMG &M, vdn_multifab *rh, vdn_multifab *phi, vdn_multifab 
     }
     comm_allgather_dev(M.sendbuf, M.recvbuf, M.cnt_b);
     hipLaunchKernelGGL(kk_cc_unpack_b, dim3(4, 1, (unsigned)M.gb_b.size()), dim3(256), 0, ctx().stream, M.tail[0], M.recvbuf, M.d_gb_b);
+    if (alpha) {                       // alpha of the first tail level: per-box 8-cell means, gathered like the residual
+      for (size_t b = 0; b < DL.boxes.size(); b++) {
+        const CLev &F = DL.boxes[b].L;
+        const int nx = F.n[0] / 2, ny = F.n[1] / 2, nz = F.n[2] / 2;
+        hipLaunchKernelGGL(kk_cc_restrict_pack, g3(nx, ny, nz, BLK), BLK, 0, ctx().stream, F, (const double *)F.alpha, M.sendbuf, M.loc_off_rh[b], nx, ny, nz);
+      }
+      comm_allgather_dev(M.sendbuf, M.recvbuf, M.cnt_rh);
+      hipLaunchKernelGGL(kk_cc_unpack_rh, dim3(4, 1, (unsigned)M.gb_rh.size()), dim3(256), 0, ctx().stream, M.tail[0], M.tail[0].alpha, M.recvbuf, M.d_gb_rh);
+    }
     for (size_t l = 1; l < M.tail.size(); l++) {
       const CLev &C = M.tail[l];
       hipLaunchKernelGGL(kk_cc_coarsen_b, g3(C.n[0] + 1, C.n[1] + 1, C.n[2] + 1, BLK), BLK, 0, ctx().stream, M.tail[l - 1], C);
+      if (alpha) hipLaunchKernelGGL(kk_cc_coarsen_cell, g3(C.n[0], C.n[1], C.n[2], BLK), BLK, 0, ctx().stream, M.tail[l - 1], (const double *)M.tail[l - 1].alpha, C, C.alpha);
     }
   }
 }
@@ -554,10 +607,10 @@ static void cc_store(CCMG &M, vdn_multifab *phi, const int bc[3][2]) {
 }
 
 int cc_solve(vdn_multifab *rh, vdn_multifab *phi, vdn_multifab **beta, const double *dx, const int bc[3][2],
-             double rel_eps, double abs_eps, int max_iter, int *cycles, double *res0, double *res) {
+             double rel_eps, double abs_eps, int max_iter, int *cycles, double *res0, double *res, const vdn_multifab *alpha) {
   const vdn_params &P = ctx().prm;
   size_t mark = arena_mark();
-  CCMG M; cc_setup(M, rh, phi, beta, dx, bc);
+  CCMG M; cc_setup(M, rh, phi, alpha, beta, dx, bc);
   CDLev &D0 = M.dlev[0];
   const double bnorm = mf_norm_inf(rh, 0, 1);
   int cyc = 0; bool conv = (bnorm == 0.0); double rn = 0.0;
@@ -585,7 +638,7 @@ int cc_solve(vdn_multifab *rh, vdn_multifab *phi, vdn_multifab **beta, const dou
 
 void cc_smooth(vdn_multifab *rh, vdn_multifab *phi, vdn_multifab **beta, const double *dx, const int bc[3][2], int nsweeps) {
   size_t mark = arena_mark();
-  CCMG M; cc_setup(M, rh, phi, beta, dx, bc);
+  CCMG M; cc_setup(M, rh, phi, nullptr, beta, dx, bc);
   cc_gsrb_d(M, M.dlev[0], nsweeps);
   cc_store(M, phi, bc);
   arena_release(mark);
@@ -594,7 +647,7 @@ void cc_smooth(vdn_multifab *rh, vdn_multifab *phi, vdn_multifab **beta, const d
 void cc_bench_smoother(vdn_multifab *rh, vdn_multifab *phi, vdn_multifab **beta, const double *dx, const int bc[3][2],
                        int nlaunch, double *avg_ms, long *cells) {
   size_t mark = arena_mark();
-  CCMG M; cc_setup(M, rh, phi, beta, dx, bc);
+  CCMG M; cc_setup(M, rh, phi, nullptr, beta, dx, bc);
   REQUIRE(M.dlev[0].boxes.size() == 1, "smoother probe: one local box expected");
   const CLev &L = M.dlev[0].boxes[0].L;
   hipStream_t st = ctx().stream;

@@ -79,8 +79,8 @@ extern "C" int vdn_init(const vdn_params *prm, int rank, int nranks, int device)
   REQUIRE(prm != nullptr, "vdn_init: null params");
   REQUIRE(prm->dm == 3, "vdn_init: only dm = 3 is implemented on the device path (got %d)", prm->dm);
   REQUIRE(prm->nscal >= 1 && prm->nscal + 5 <= VDN_MAXCOMP, "vdn_init: bad nscal %d", prm->nscal);
-  REQUIRE(prm->visc_coef == 0.0 && prm->diff_coef == 0.0,
-          "vdn_init: visc_coef/diff_coef > 0 (implicit viscous solves) are not implemented yet");
+  REQUIRE(prm->visc_coef >= 0.0 && prm->diff_coef >= 0.0, "vdn_init: negative visc_coef / diff_coef");
+  REQUIRE(prm->diffusion_type == 1 || prm->diffusion_type == 2, "BAD DIFFUSION TYPE");      // velocity_advance.f90:113
   REQUIRE(prm->slope_order == 0 || prm->slope_order == 2 || prm->slope_order == 4, "bad slope_order");
   int ndev = 0;
   HIPCHK(hipGetDeviceCount(&ndev));

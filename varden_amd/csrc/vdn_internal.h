@@ -150,10 +150,17 @@ void k_estdt_max(const vdn_multifab *u, const vdn_multifab *s, const vdn_multifa
 void do_macproject(vdn_layout *mla, vdn_multifab **umac, vdn_multifab **rho, vdn_multifab **mac_rhs, const double *dx,
                    const vdn_bc_tower *bct, int bc_comp0);
 int  cc_solve(vdn_multifab *rh, vdn_multifab *phi, vdn_multifab **beta, const double *dx, const int bc[3][2],
-              double rel_eps, double abs_eps, int max_iter, int *cycles, double *res0, double *res);
+              double rel_eps, double abs_eps, int max_iter, int *cycles, double *res0, double *res,
+              const vdn_multifab *alpha = nullptr);
 void cc_smooth(vdn_multifab *rh, vdn_multifab *phi, vdn_multifab **beta, const double *dx, const int bc[3][2], int nsweeps);
 void cc_bench_smoother(vdn_multifab *rh, vdn_multifab *phi, vdn_multifab **beta, const double *dx, const int bc[3][2],
                        int nlaunch, double *avg_ms, long *cells);
+// viscous.hip
+void k_explicit_diffusive_term(vdn_multifab *lap, const vdn_multifab *data, int comp, int bccomp0, const double *dx, const vdn_bc_tower *bct);
+void do_visc_solve(vdn_layout *mla, vdn_multifab *unew, const vdn_multifab *lapu, const vdn_multifab *rho, const vdn_multifab *mac_rhs,
+                   const double *dx, double mu, const vdn_bc_tower *bct);
+void do_diff_scalar_solve(vdn_layout *mla, vdn_multifab *snew, const vdn_multifab *laps, const double *dx, double mu,
+                          const vdn_bc_tower *bct, int icomp, int bccomp0);
 // hgproject.hip / mg_nd.hip
 void do_hgproject(int proj_type, vdn_layout *mla, vdn_multifab **unew, vdn_multifab **uold, vdn_multifab **rhohalf,
                   vdn_multifab **p, vdn_multifab **gp, const double *dx, double dt, const vdn_bc_tower *bct, int press_comp0);

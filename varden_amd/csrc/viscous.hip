@@ -1,0 +1,131 @@
+// viscous.hip -- explicit diffusive term and the implicit viscous / diffusive solves.
+//   get_explicit_diffusive_term   reference src/explicit_diffusive_term.f90:16-88 (FBoxLib cc_applyop, alpha = 0, beta = -1)
+//   visc_solve                    reference src/viscsolve.f90:19-306
+//   diff_scalar_solve             reference src/viscsolve.f90:308-515
+// Same definitions and expression order as oracle/vo_viscous.c: second-order cell-centred differences, zero flux on
+// Neumann faces, Dirichlet faces use the ghost cell as the boundary-FACE value with a half-cell gradient, periodic wrap.
+// The solves reuse the cell-centred multigrid of mg_cc.hip with the alpha term switched on (56 B/cell/colour pass).
+#include "vdn_dev.h"
+
+struct LapArgs { int lo[3], hi[3]; int ebc[3][2]; double hi2[3]; int comp; };
+__global__ void kk_lap(FV lap, FV data, LapArgs A, Range3 r) {
+  THREAD_IJK(r)
+  if (!in_range) return;
+  const int q[3] = { i, j, k };
+  const double p0 = fv_get(data, i, j, k, A.comp);
+  double sum = 0.0;
+  #pragma unroll
+  for (int d = 0; d < 3; d++) {
+    const double pm = fv_get(data, i - (d == 0), j - (d == 1), k - (d == 2), A.comp);
+    const double pp = fv_get(data, i + (d == 0), j + (d == 1), k + (d == 2), A.comp);
+    double fm = p0 - pm, fp = pp - p0;
+    if (q[d] == A.lo[d]) { const int e = A.ebc[d][0]; if (e == VDN_BC_NEU) fm = 0.0; else if (e == VDN_BC_DIR) fm = 2.0 * fm; }
+    if (q[d] == A.hi[d]) { const int e = A.ebc[d][1]; if (e == VDN_BC_NEU) fp = 0.0; else if (e == VDN_BC_DIR) fp = 2.0 * fp; }
+    sum = sum + (fp - fm) * A.hi2[d];
+  }
+  fv_at(lap, i, j, k, A.comp) = sum;
+}
+
+// lap(comp) = laplacian(data(comp)); bccomp0 = 0-based ell bc component.  data must have its ghost cells filled.
+void k_explicit_diffusive_term(vdn_multifab *lap, const vdn_multifab *data, int comp, int bccomp0, const double *dx, const vdn_bc_tower *bct) {
+  REQUIRE(data->ng >= 1, "explicit diffusive term: data needs a filled ghost cell");
+  for (int i = 0; i < data->nfabs(); i++) {
+    LapArgs A; Range3 r;
+    for (int d = 0; d < 3; d++) {
+      A.lo[d] = r.lo[d] = data->vbox[i].lo[d]; A.hi[d] = r.hi[d] = data->vbox[i].hi[d]; A.hi2[d] = 1.0 / (dx[d] * dx[d]);
+      for (int s = 0; s < 2; s++) A.ebc[d][s] = bct->ell_bc(data->lev, i + 1, d, s, bccomp0);     // BC_INT on interior box faces
+    }
+    A.comp = comp;
+    hipLaunchKernelGGL(kk_lap, grid_for(r), dim3(64, 4, 1), 0, ctx().stream, lap->fabs[i], data->fabs[i], A, r);
+  }
+}
+
+struct VrhsArgs { int comp, dtype; double mu, third_vmd_over_dx; };
+// mkrhs_3d (viscsolve.f90:264-302): phi = unew(comp) on the grown box, rh = rho*unew + mu*lapu [+ (1/3) visc_mu_dt d(mac_rhs)/dx_comp]
+__global__ void kk_visc_rhs(FV rh, FV phi, FV unew, FV lapu, FV rho, FV macrhs, VrhsArgs A, Range3 rg, int lo0, int lo1, int lo2, int hi0, int hi1, int hi2, double dxc, double third, double visc_mu_dt) {
+  THREAD_IJK(rg)
+  if (!in_range) return;
+  const double u = fv_get(unew, i, j, k, A.comp);
+  fv_at(phi, i, j, k) = u;
+  if (i < lo0 || i > hi0 || j < lo1 || j > hi1 || k < lo2 || k > hi2) return;
+  double r = u * fv_get(rho, i, j, k, 0);
+  if (A.dtype == 1) r = r + A.mu * fv_get(lapu, i, j, k, A.comp);
+  const int c = A.comp;
+  const double mp = fv_get(macrhs, i + (c == 0), j + (c == 1), k + (c == 2)), mm = fv_get(macrhs, i - (c == 0), j - (c == 1), k - (c == 2));
+  r = r + third * visc_mu_dt * (mp - mm) / dxc;
+  fv_at(rh, i, j, k) = r;
+}
+__global__ void kk_diff_rhs(FV rh, FV phi, FV snew, FV laps, int comp, int dtype, double mu, Range3 rg, int lo0, int lo1, int lo2, int hi0, int hi1, int hi2) {
+  THREAD_IJK(rg)
+  if (!in_range) return;
+  const double s = fv_get(snew, i, j, k, comp);
+  fv_at(phi, i, j, k) = s;
+  if (i < lo0 || i > hi0 || j < lo1 || j > hi1 || k < lo2 || k > hi2) return;
+  double r = s;
+  if (dtype == 1) r = r + mu * fv_get(laps, i, j, k, comp);
+  fv_at(rh, i, j, k) = r;
+}
+
+static void ell_of(const vdn_bc_tower *bct, int lev, int comp0, int ebc[3][2]) {
+  for (int d = 0; d < 3; d++) for (int s = 0; s < 2; s++) ebc[d][s] = bct->ell_bc(lev, 0, d, s, comp0);
+}
+
+void do_visc_solve(vdn_layout *mla, vdn_multifab *unew, const vdn_multifab *lapu, const vdn_multifab *rho, const vdn_multifab *mac_rhs,
+                   const double *dx, double mu, const vdn_bc_tower *bct) {
+  const int n = 0;
+  hipStream_t st = ctx().stream;
+  size_t mark = arena_mark();
+  vdn_multifab *rh = mf_temp(mla, n, 1, 0, -1, false, 0.0);
+  vdn_multifab *phi = mf_temp(mla, n, 1, 1, -1, true, 0.0);
+  vdn_multifab *alpha = mf_temp(mla, n, 1, 0, -1, false, 0.0);
+  vdn_multifab *beta[3];
+  for (int d = 0; d < 3; d++) beta[d] = mf_temp(mla, n, 1, 0, d, true, mu);           // setval(beta, mu), viscsolve.f90:58-60
+  mf_copy(alpha, 0, rho, 0, 1, 0);                                                     // alpha = rho, viscsolve.f90:57
+  const double visc_mu_dt = (ctx().prm.diffusion_type == 1) ? 2.0 * mu : mu;
+  for (int d = 0; d < 3; d++) {
+    for (int i = 0; i < unew->nfabs(); i++) {
+      const vdn_box &bx = unew->vbox[i];
+      Range3 rg; for (int a = 0; a < 3; a++) { rg.lo[a] = bx.lo[a] - 1; rg.hi[a] = bx.hi[a] + 1; }
+      VrhsArgs A; A.comp = d; A.dtype = ctx().prm.diffusion_type; A.mu = mu; A.third_vmd_over_dx = 0.0;
+      hipLaunchKernelGGL(kk_visc_rhs, grid_for(rg), dim3(64, 4, 1), 0, st, rh->fabs[i], phi->fabs[i], unew->fabs[i], lapu->fabs[i], rho->fabs[i],
+                         mac_rhs->fabs[i], A, rg, bx.lo[0], bx.lo[1], bx.lo[2], bx.hi[0], bx.hi[1], bx.hi[2], dx[d], 1.0 / 3.0, visc_mu_dt);
+    }
+    int ebc[3][2]; ell_of(bct, n, d, ebc);                                             // bc_comp = d, viscsolve.f90:99
+    int cyc; double r0, rr;
+    int rc = cc_solve(rh, phi, beta, dx, ebc, 1.e-12, -1.0, ctx().prm.mg_max_iter, &cyc, &r0, &rr, alpha);   // viscsolve.f90:88-89
+    if (rc != 0 && ctx().prm.verbose) fprintf(stderr, "varden_amd: viscous solve %d did not converge in %d cycles (res %g / %g)\n", d, cyc, rr, r0);
+    mf_copy(unew, d, phi, 0, 1, 0);                                                    // viscsolve.f90:103
+  }
+  mf_restrict_and_fill(unew, 0, 0, 3, false, bct);                                     // viscsolve.f90:106
+  for (int d = 0; d < 3; d++) mf_temp_free(beta[d]);
+  mf_temp_free(alpha); mf_temp_free(phi); mf_temp_free(rh);
+  arena_release(mark);
+}
+
+void do_diff_scalar_solve(vdn_layout *mla, vdn_multifab *snew, const vdn_multifab *laps, const double *dx, double mu,
+                          const vdn_bc_tower *bct, int icomp, int bccomp0) {
+  const int n = 0;
+  hipStream_t st = ctx().stream;
+  size_t mark = arena_mark();
+  vdn_multifab *rh = mf_temp(mla, n, 1, 0, -1, false, 0.0);
+  vdn_multifab *phi = mf_temp(mla, n, 1, 1, -1, true, 0.0);
+  vdn_multifab *alpha = mf_temp(mla, n, 1, 0, -1, true, 1.0);                          // viscsolve.f90:349
+  vdn_multifab *beta[3];
+  for (int d = 0; d < 3; d++) beta[d] = mf_temp(mla, n, 1, 0, d, true, mu);
+  for (int i = 0; i < snew->nfabs(); i++) {
+    const vdn_box &bx = snew->vbox[i];
+    Range3 rg; for (int a = 0; a < 3; a++) { rg.lo[a] = bx.lo[a] - 1; rg.hi[a] = bx.hi[a] + 1; }
+    hipLaunchKernelGGL(kk_diff_rhs, grid_for(rg), dim3(64, 4, 1), 0, st, rh->fabs[i], phi->fabs[i], snew->fabs[i], laps->fabs[i], icomp,
+                       ctx().prm.diffusion_type, mu, rg, bx.lo[0], bx.lo[1], bx.lo[2], bx.hi[0], bx.hi[1], bx.hi[2]);
+  }
+  int ebc[3][2]; ell_of(bct, n, bccomp0, ebc);
+  int cyc; double r0, rr;
+  int rc = cc_solve(rh, phi, beta, dx, ebc, 1.e-12, -1.0, ctx().prm.mg_max_iter, &cyc, &r0, &rr, alpha);
+  if (rc != 0 && ctx().prm.verbose) fprintf(stderr, "varden_amd: diffusive solve did not converge in %d cycles (res %g / %g)\n", cyc, rr, r0);
+  mf_copy(snew, icomp, phi, 0, 1, 0);                                                  // viscsolve.f90:374
+  mf_fill_boundary(snew);                                                              // 378-381 (all comps: a superset of fill_boundary_c)
+  mf_physbc(snew, icomp, bccomp0, 1, bct, false);
+  for (int d = 0; d < 3; d++) mf_temp_free(beta[d]);
+  mf_temp_free(alpha); mf_temp_free(phi); mf_temp_free(rh);
+  arena_release(mark);
+}
