@@ -34,9 +34,10 @@ def mac_problem(case):
 
 
 @pytest.mark.parametrize("bcname", ["walls", "periodic", "inout", "mixed"])
-def test_cc_smoother_bits(gpu, oracle, bcname):
+@pytest.mark.parametrize("n", [(16, 8, 12), (72, 36, 44)])      # the larger box takes the fused red+black LDS kernel (non-periodic cases)
+def test_cc_smoother_bits(gpu, oracle, bcname, n):
     from varden_amd import advance as adv
-    case = Case((16, 8, 12), BC_SETS[bcname], seed=11, iso=True)
+    case = Case(n, BC_SETS[bcname], seed=11, iso=True)
     s, beta, rh, ell = mac_problem(case)
     ophi = case.ofab(1, 1)
     oracle.lib().vo_cc_smooth(rh.ref, ophi.ref, oracle.fab_ptr_array(beta), case.odx, ell, 3)

@@ -85,7 +85,7 @@ template <int D> DEVI double slope_at(const FV &s, int c, int i, int j, int k, i
   return f0.flag * fmin(fabs(ds), f0.lim);
 }
 
-__global__ void kk_slopes(FV s, FV sl0, FV sl1, FV sl2, GArgs A, Range3 r, int dirmask) {
+__global__ void __launch_bounds__(256) kk_slopes(FV s, FV sl0, FV sl1, FV sl2, GArgs A, Range3 r, int dirmask) {
   THREAD_IJK(r)
   if (!in_range) return;
   for (int c = 0; c < A.ncomp; c++) {
@@ -149,7 +149,7 @@ template <int D> DEVI void mk_pair(const GArgs &A, const FV &s, const FV &slp, c
 }
 
 // stage B: simh_D on the lower faces of cell (i,j,k);  SI has 3*ncomp comps: [D*ncomp + c]
-__global__ void kk_mk_B(FV s, FV sl0, FV sl1, FV sl2, FV um, FV vm, FV wm, FV force, FV macrhs, FV SI, GArgs A, Range3 r, const double *umax) {
+__global__ void __launch_bounds__(256) kk_mk_B(FV s, FV sl0, FV sl1, FV sl2, FV um, FV vm, FV wm, FV force, FV macrhs, FV SI, GArgs A, Range3 r, const double *umax) {
   THREAD_IJK(r)
   if (!in_range) return;
   const double eps = eps_from(umax);
@@ -192,7 +192,7 @@ template <int D, int T> DEVI void mk_C_one(const GArgs &A, const FV &s, const FV
 }
 DEVI int sc_idx(int D, int T, int ncomp, int c) { return (D * 2 + (T > D ? T - 1 : T)) * ncomp + c; }
 
-__global__ void kk_mk_C(FV s, FV sl0, FV sl1, FV sl2, FV um, FV vm, FV wm, FV force, FV macrhs, FV SI, FV SC, GArgs A, Range3 r, const double *umax) {
+__global__ void __launch_bounds__(256) kk_mk_C(FV s, FV sl0, FV sl1, FV sl2, FV um, FV vm, FV wm, FV force, FV macrhs, FV SI, FV SC, GArgs A, Range3 r, const double *umax) {
   THREAD_IJK(r)
   if (!in_range) return;
   const double eps = eps_from(umax);
@@ -252,7 +252,7 @@ template <int D> DEVI void mk_D_one(const GArgs &A, const FV &s, const FV &slp, 
   if (cons) fv_at(flux, i, j, k, c) = e * um;        // mkflux.f90:1969, 2405, 2508
 }
 
-__global__ void kk_mk_D(FV s, FV sl0, FV sl1, FV sl2, FV um, FV vm, FV wm, FV force, FV macrhs, FV SC,
+__global__ void __launch_bounds__(256) kk_mk_D(FV s, FV sl0, FV sl1, FV sl2, FV um, FV vm, FV wm, FV force, FV macrhs, FV SC,
                         FV sex, FV sey, FV sez, FV flx, FV fly, FV flz, GArgs A, Range3 r, const double *umax) {
   THREAD_IJK(r)
   if (!in_range) return;
@@ -395,7 +395,7 @@ template <int D> DEVI void vp_B_one(const GArgs &A, const FV &u, const FV &slp, 
     fv_at(UI, i, j, k, D * 3 + c) = out;
   }
 }
-__global__ void kk_vp_B(FV u, FV sl0, FV sl1, FV sl2, FV force, FV UI, GArgs A, Range3 r, const double *umax) {
+__global__ void __launch_bounds__(256) kk_vp_B(FV u, FV sl0, FV sl1, FV sl2, FV force, FV UI, GArgs A, Range3 r, const double *umax) {
   THREAD_IJK(r)
   if (!in_range) return;
   const double eps = eps_from(umax);
@@ -428,7 +428,7 @@ template <int C, int D> DEVI void vp_C_one(const GArgs &A, const FV &u, const FV
   const double av = 0.5 * (L + R);
   fv_at(XC, i, j, k, xc_idx(C, D)) = (fabs(un) < eps) ? av : v;
 }
-__global__ void kk_vp_C(FV u, FV sl0, FV sl1, FV sl2, FV force, FV UI, FV XC, GArgs A, Range3 r, const double *umax) {
+__global__ void __launch_bounds__(256) kk_vp_C(FV u, FV sl0, FV sl1, FV sl2, FV force, FV UI, FV XC, GArgs A, Range3 r, const double *umax) {
   THREAD_IJK(r)
   if (!in_range) return;
   const double eps = eps_from(umax);
@@ -474,7 +474,7 @@ template <int D> DEVI void vp_D_one(const GArgs &A, const FV &u, const FV &slp, 
   }
   fv_at(umac, i, j, k) = v;
 }
-__global__ void kk_vp_D(FV u, FV sl0, FV sl1, FV sl2, FV force, FV UI, FV XC, FV um, FV vm, FV wm, GArgs A, Range3 r, const double *umax) {
+__global__ void __launch_bounds__(256) kk_vp_D(FV u, FV sl0, FV sl1, FV sl2, FV force, FV UI, FV XC, FV um, FV vm, FV wm, GArgs A, Range3 r, const double *umax) {
   THREAD_IJK(r)
   if (!in_range) return;
   const double eps = eps_from(umax);

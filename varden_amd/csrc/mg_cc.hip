@@ -22,6 +22,7 @@ struct CLev {
   double hi2[3];
   double *phi, *rh, *res, *b[3];
   double *alpha;        // cell coefficient of (alpha - div b grad); nullptr when alpha = 0 (MAC projection)
+  double *phi2;         // ping-pong partner of phi for the fused red+black sweep (nullptr when not used)
 };
 DEVI long cidx(const CLev &L, int i, int j, int k) { return (long)(i + 16) + (long)L.PX * ((long)(j + 1) + (long)L.PY * (long)(k + 1)); }
 
@@ -53,6 +54,98 @@ __global__ void __launch_bounds__(256) kk_cc_gsrb(CLev L, int color) {
   const long c = cidx(L, i, j, k);
   double Ap, diag; cc_apply(L, c, Ap, diag);
   if (diag != 0.0) L.phi[c] = L.phi[c] + (L.rh[c] - Ap) / diag;
+}
+
+// ---- fused red+black sweep ---------------------------------------------------------------------------------------
+// One launch = one full red-black Gauss-Seidel sweep (both colour passes) with ONE read of phi, rhs, b and one write of
+// phi: half the HBM traffic of two colour-pass launches.  A workgroup owns a 64 x 8 tile of (i,j) and marches through
+// a slab of k planes with a rolling window of four phi planes in LDS (tile grown by 2): at step k it (1) loads plane
+// k+2, (2) updates the RED cells of plane k+1 on the tile grown by 1 (their black neighbours are still old), (3) updates
+// the BLACK cells of plane k on the tile (their red neighbours in planes k-1, k, k+1 are new) and writes plane k out.
+// Red cells in the one-cell ring around the tile are recomputed by the neighbouring workgroups too (identical
+// arithmetic, so identical bits); results are bit-identical to two kk_cc_gsrb launches.  The sweep reads `pin` and
+// writes `pout` (ping-pong: a neighbour workgroup must still see the OLD black values in its halo).
+// Valid when the level is one box without periodic faces: then the ghost layer of phi is identically zero.
+#define FT_X 64
+#define FT_Y 8
+DEVI double cc_point_update(const CLev &L, long c, double p0, double pxm, double pxp, double pym, double pyp, double pzm, double pzp) {
+  const long sy = L.PX, sz = (long)L.PX * L.PY;
+  const double bxm = L.b[0][c], bxp = L.b[0][c + 1];
+  const double bym = L.b[1][c], byp = L.b[1][c + sy];
+  const double bzm = L.b[2][c], bzp = L.b[2][c + sz];
+  const double ax = (bxp * (p0 - pxp) + bxm * (p0 - pxm)) * L.hi2[0];
+  const double ay = (byp * (p0 - pyp) + bym * (p0 - pym)) * L.hi2[1];
+  const double az = (bzp * (p0 - pzp) + bzm * (p0 - pzm)) * L.hi2[2];
+  double Ap = ax + ay + az;
+  double diag = (bxp + bxm) * L.hi2[0] + (byp + bym) * L.hi2[1] + (bzp + bzm) * L.hi2[2];
+  if (L.alpha) { const double a0 = L.alpha[c]; Ap = Ap + a0 * p0; diag = diag + a0; }
+  return (diag != 0.0) ? p0 + (L.rh[c] - Ap) / diag : p0;
+}
+__global__ void __launch_bounds__(256) kk_cc_gsrb_fused(CLev L, const double *__restrict__ pin, double *__restrict__ pout, int kchunk) {
+  __shared__ double sp[4][FT_Y + 4][FT_X + 4];
+  const int tid = threadIdx.x;
+  const int i0 = blockIdx.x * FT_X, j0 = blockIdx.y * FT_Y;
+  const int nx = L.n[0], ny = L.n[1], nz = L.n[2];
+  const int k0 = blockIdx.z * kchunk, k1 = min(k0 + kchunk, nz) - 1;
+  if (k0 > k1) return;
+  // old values of plane k into slot k&3; zero outside the allocated [-1..n] range
+  auto load_plane = [&](int k) {
+    for (int t = tid; t < (FT_Y + 4) * (FT_X + 4); t += 256) {
+      const int jl = t / (FT_X + 4), il = t - jl * (FT_X + 4);
+      const int gi = i0 + il - 2, gj = j0 + jl - 2;
+      double v = 0.0;
+      if (k >= -1 && k <= nz && gj >= -1 && gj <= ny && gi >= -1 && gi <= nx) v = pin[cidx(L, gi, gj, k)];
+      sp[k & 3][jl][il] = v;
+    }
+  };
+  auto point = [&](int gi, int gj, int k) -> double {
+    const int il = gi - i0 + 2, jl = gj - j0 + 2;
+    const int s0 = k & 3, sm = (k - 1) & 3, sq = (k + 1) & 3;
+    return cc_point_update(L, cidx(L, gi, gj, k), sp[s0][jl][il], sp[s0][jl][il - 1], sp[s0][jl][il + 1], sp[s0][jl - 1][il], sp[s0][jl + 1][il],
+                           sp[sm][jl][il], sp[sq][jl][il]);
+  };
+  // red cells ((i+j+k) even) of plane k on the tile grown by one
+  auto red = [&](int k) {
+    if (k < 0 || k >= nz) return;
+    constexpr int HW = (FT_X + 2) / 2;                     // 33 red cells per row of 66
+    for (int t = tid; t < (FT_Y + 2) * HW; t += 256) {
+      const int jr = t / HW, ii = t - jr * HW;
+      const int gj = j0 - 1 + jr;
+      const int gi = i0 - 1 + 2 * ii + ((i0 - 1 + gj + k) & 1);
+      if (gi >= 0 && gi < nx && gj >= 0 && gj < ny && gi <= i0 + FT_X) {
+        const double v = point(gi, gj, k);
+        sp[k & 3][gj - j0 + 2][gi - i0 + 2] = v;           // red updates of one plane do not read each other
+      }
+    }
+  };
+  load_plane(k0 - 2); load_plane(k0 - 1); load_plane(k0); load_plane(k0 + 1);
+  __syncthreads();
+  red(k0 - 1);
+  __syncthreads();
+  red(k0);
+  __syncthreads();
+  for (int k = k0; k <= k1; k++) {
+    load_plane(k + 2);                                     // overwrites plane k-2, no longer needed
+    __syncthreads();
+    red(k + 1);
+    __syncthreads();
+    {                                                      // black cells of plane k on the tile: one per thread (64*8/2 = 256)
+      const int jr = tid / (FT_X / 2), ii = tid - jr * (FT_X / 2);
+      const int gj = j0 + jr;
+      const int gi = i0 + 2 * ii + ((i0 + gj + k + 1) & 1);
+      double v = 0.0; bool ok = (gi < nx && gj < ny);
+      if (ok) v = point(gi, gj, k);
+      __syncthreads();                                     // every black update has read its neighbours
+      if (ok) sp[k & 3][gj - j0 + 2][gi - i0 + 2] = v;
+    }
+    __syncthreads();
+    for (int t = tid; t < FT_Y * FT_X; t += 256) {         // write plane k of the tile (both colours final), x-contiguous
+      const int jr = t / FT_X, il = t - jr * FT_X;
+      const int gi = i0 + il, gj = j0 + jr;
+      if (gi < nx && gj < ny) pout[cidx(L, gi, gj, k)] = sp[k & 3][jr + 2][il + 2];
+    }
+    __syncthreads();
+  }
 }
 
 __global__ void __launch_bounds__(256) kk_cc_residual(CLev L, double *nrm) {
@@ -303,7 +396,7 @@ __global__ void kk_cc_prolong_tail(CLev F, CLev T, int c00, int c01, int c02) {
 
 // ---- host side ------------------------------------------------------------------------------------------
 struct CBox { CLev L; int lo[3]; int gidx; };                    // one local box on one distributed level; lo = global index of its cell 0
-struct CDLev { std::vector<CBox> boxes; XPlan *halo = nullptr; int ng[3]; /* global extents of the level */ };
+struct CDLev { std::vector<CBox> boxes; XPlan *halo = nullptr; int ng[3]; /* global extents of the level */ bool single_box = false; };
 struct CCMG {
   std::vector<CDLev> dlev;          // distributed levels (finest first)
   std::vector<CLev> tail;           // agglomerated levels, whole domain, replicated on every rank
@@ -329,6 +422,7 @@ static CLev cc_alloc_lev(const int n[3], const double h[3], bool has_alpha) {
   L.phi = base; L.rh = base + L.sz; L.res = base + 2 * L.sz;
   for (int d = 0; d < 3; d++) L.b[d] = base + (3 + d) * L.sz;
   L.alpha = has_alpha ? base + 6 * L.sz : nullptr;
+  L.phi2 = nullptr;
   return L;
 }
 static FV cc_phi_view(const CLev &L, const int lo[3]) {
@@ -370,7 +464,15 @@ static void cc_build(CCMG &M, const vdn_multifab *rh, const double *dx, const in
       for (int d = 0; d < 3; d++) { lo[d] = (gboxes[g].lo[d] - la->pd[lev].lo[d]) / scale; x.vlo[d] = lo[d]; x.vhi[d] = lo[d] + n[d] - 1; }
       x.owner = la->owner[lev][g];
       if (x.owner == ctx().rank) {
-        CBox B; B.L = cc_alloc_lev(n, h, has_alpha); B.gidx = g; for (int d = 0; d < 3; d++) B.lo[d] = lo[d];
+        CBox B; B.L = cc_alloc_lev(n, h, has_alpha); B.gidx = g;
+        // the fused red+black sweep is an opt-in experiment (VDN_FUSED_GSRB=1): measured on MI355X at 256^3 it takes
+        // 0.30 ms per sweep against 2 x 0.15 ms for two colour-pass launches (barrier-bound plane pipeline), and it is
+        // slower on the 64^3 / 128^3 levels -- see DESIGN.md
+        static const bool use_fused = getenv("VDN_FUSED_GSRB") && atoi(getenv("VDN_FUSED_GSRB")) == 1;
+        if (use_fused && nb == 1 && !(M.per[0] || M.per[1] || M.per[2]) && (long)n[0] * n[1] * n[2] > 32L * 32 * 32) {
+          B.L.phi2 = (double *)arena_alloc(sizeof(double) * B.L.sz);
+          HIPCHK(hipMemsetAsync(B.L.phi2, 0, sizeof(double) * B.L.sz, ctx().stream));
+        } for (int d = 0; d < 3; d++) B.lo[d] = lo[d];
         x.fv = cc_phi_view(B.L, lo);
         DL.boxes.push_back(B);
       }
@@ -383,6 +485,7 @@ static void cc_build(CCMG &M, const vdn_multifab *rh, const double *dx, const in
       if (it == g_halo_cache.end()) { XPlan *P = xplan_build(xb, lpd, M.per, 1, 1); halo_cache_register(la->uid, P); it = g_halo_cache.emplace(key, P).first; }
       DL.halo = it->second;
     }
+    DL.single_box = (nb == 1);
     M.dlev.push_back(DL);
     // the hierarchy of GLOBAL levels is the single-box one (oracle rule: coarsen while every global extent is
     // even and > 2); a level stays distributed while the boxes halve cleanly to extents >= 4
@@ -433,8 +536,26 @@ static void cc_build(CCMG &M, const vdn_multifab *rh, const double *dx, const in
   M.d_nrm = (double *)arena_alloc(256);
 }
 
-static void cc_halo(const CCMG &M, const CDLev &DL) { if (DL.halo) xplan_run(DL.halo); }
-static void cc_gsrb_d(const CCMG &M, const CDLev &DL, int nsweeps) {
+static void cc_halo(CCMG &M, CDLev &DL) { if (DL.halo) xplan_run(DL.halo); }
+// levels of at most 8^3 cells held in ONE box are smoothed by a single workgroup in one launch (all sweeps, both
+// colours, periodic images included): such levels are launch-latency bound, not bandwidth bound
+static const long SMALL_LEVEL_CELLS = 8L * 8 * 8;
+static void cc_launch_fused(CLev &L, int nsweeps) {
+  const int tiles = ((L.n[0] + FT_X - 1) / FT_X) * ((L.n[1] + FT_Y - 1) / FT_Y);
+  int kchunk = L.n[2];
+  while (kchunk > 16 && tiles * ((L.n[2] + kchunk - 1) / kchunk) < 1024) kchunk = (kchunk + 1) / 2;
+  const int nch = (L.n[2] + kchunk - 1) / kchunk;
+  for (int s = 0; s < nsweeps; s++) {
+    hipLaunchKernelGGL(kk_cc_gsrb_fused, dim3((L.n[0] + FT_X - 1) / FT_X, (L.n[1] + FT_Y - 1) / FT_Y, nch), dim3(256), 0, ctx().stream, L, (const double *)L.phi, L.phi2, kchunk);
+    std::swap(L.phi, L.phi2);
+  }
+}
+static void cc_gsrb_d(CCMG &M, CDLev &DL, int nsweeps) {
+  if (DL.single_box && DL.boxes.size() == 1 && (long)DL.ng[0] * DL.ng[1] * DL.ng[2] <= SMALL_LEVEL_CELLS) {
+    hipLaunchKernelGGL(kk_cc_bottom, dim3(1), dim3(1024), 0, ctx().stream, DL.boxes[0].L, nsweeps, M.per[0], M.per[1], M.per[2]);
+    return;
+  }
+  if (DL.single_box && DL.boxes.size() == 1 && DL.boxes[0].L.phi2) { cc_launch_fused(DL.boxes[0].L, nsweeps); return; }
   for (int s = 0; s < nsweeps; s++) for (int color = 0; color < 2; color++) {
     cc_halo(M, DL);
     for (const CBox &B : DL.boxes) {
@@ -443,7 +564,7 @@ static void cc_gsrb_d(const CCMG &M, const CDLev &DL, int nsweeps) {
     }
   }
 }
-static void cc_residual_d(const CCMG &M, const CDLev &DL, bool norm) {
+static void cc_residual_d(CCMG &M, CDLev &DL, bool norm) {
   cc_halo(M, DL);
   if (norm) HIPCHK(hipMemsetAsync(M.d_nrm, 0, sizeof(double), ctx().stream));
   for (const CBox &B : DL.boxes)
@@ -464,6 +585,10 @@ static void cc_periodic_t(const CCMG &M, const CLev &L) {
   hipLaunchKernelGGL(kk_cc_periodic, g3(m, m, 6, BLK), BLK, 0, ctx().stream, L, M.per[0], M.per[1], M.per[2]);
 }
 static void cc_gsrb_t(const CCMG &M, const CLev &L, int nsweeps) {
+  if ((long)L.n[0] * L.n[1] * L.n[2] <= SMALL_LEVEL_CELLS) {
+    hipLaunchKernelGGL(kk_cc_bottom, dim3(1), dim3(1024), 0, ctx().stream, L, nsweeps, M.per[0], M.per[1], M.per[2]);
+    return;
+  }
   for (int s = 0; s < nsweeps; s++) for (int color = 0; color < 2; color++) {
     cc_periodic_t(M, L);
     hipLaunchKernelGGL(kk_cc_gsrb, g3((L.n[0] + 1) / 2, L.n[1], L.n[2], BLK), BLK, 0, ctx().stream, L, color);

@@ -440,7 +440,7 @@ template <int MODE> static void nd_launch_march(const NLev &L, const double *phi
 }
 
 struct NBox { NLev L; int lo[3]; XPlan *hA = nullptr, *hB = nullptr; double *A = nullptr, *B = nullptr; };
-struct NDLev { std::vector<NBox> boxes; XPlan *halo_A = nullptr, *halo_B = nullptr, *halo_res = nullptr, *halo_sig = nullptr; int ng[3]; bool flip = false; };
+struct NDLev { std::vector<NBox> boxes; XPlan *halo_A = nullptr, *halo_B = nullptr, *halo_res = nullptr, *halo_sig = nullptr; int ng[3]; bool flip = false; bool single_box = false; int per[3] = {0, 0, 0}; };
 struct NDMG {
   std::vector<NDLev> dlev; std::vector<NLev> tail; int per[3]; double *d_nrm;
   std::vector<NGBox> gb; NGBox *d_gb = nullptr;
@@ -518,6 +518,7 @@ static void nd_build(NDMG &M, const vdn_multifab *coeffs, const double *dx, cons
       // the node "domain" for periodic shifts has the CELL period (node n is node 0): use the cell domain box
       DL.halo_A = get(0, xa, lpd); DL.halo_B = get(1, xb2, lpd); DL.halo_res = get(2, xr, lpd); DL.halo_sig = get(3, xs, lpd);
     }
+    DL.single_box = (nb == 1); for (int d = 0; d < 3; d++) DL.per[d] = M.per[d];
     M.dlev.push_back(DL);
     bool can = true, next_dist = true;
     for (int d = 0; d < 3; d++) { const int N = lpd.hi[d] + 1; if ((N & 1) || N <= 2) can = false; }
@@ -565,7 +566,17 @@ static void nd_build(NDMG &M, const vdn_multifab *coeffs, const double *dx, cons
 
 // ---- distributed levels ------------------------------------------------------------------------------------------
 static void nd_halo_phi(NDLev &DL) { XPlan *P = DL.flip ? DL.halo_B : DL.halo_A; if (P) xplan_run(P); }
+// levels of at most 9^3 nodes held in ONE box: all sweeps in a single one-workgroup launch (launch-latency bound otherwise)
+static const long SMALL_LEVEL_NODES = 9L * 9 * 9;
 static void nd_jacobi_d(NDLev &DL, int nsweeps) {
+  if (DL.single_box && DL.boxes.size() == 1 && (long)(DL.ng[0] + 1) * (DL.ng[1] + 1) * (DL.ng[2] + 1) <= SMALL_LEVEL_NODES) {
+    NBox &B = DL.boxes[0];
+    NLev Lp = B.L;                      // the kernel refreshes periodic images itself: give it the periodicity flags
+    for (int d = 0; d < 3; d++) Lp.per[d] = DL.per[d];
+    hipLaunchKernelGGL(kk_nd_bottom, dim3(1), dim3(1024), 0, ctx().stream, Lp, B.L.phi, B.L.tmp, nsweeps, ctx().prm.hg_omega);
+    if (nsweeps & 1) { std::swap(B.L.phi, B.L.tmp); DL.flip = !DL.flip; }
+    return;
+  }
   for (int s = 0; s < nsweeps; s++) {
     nd_halo_phi(DL);
     for (NBox &B : DL.boxes) {
@@ -593,6 +604,11 @@ static void nd_fill_nodes(const NLev &L, double *a) {
   hipLaunchKernelGGL(kk_nd_fill_nodes, ng3(L.n[0] + 3, L.n[1] + 3, L.n[2] + 3), NBLK, 0, ctx().stream, L, a);
 }
 static void nd_jacobi_t(NLev &L, int nsweeps) {
+  if ((long)(L.n[0] + 1) * (L.n[1] + 1) * (L.n[2] + 1) <= SMALL_LEVEL_NODES) {
+    hipLaunchKernelGGL(kk_nd_bottom, dim3(1), dim3(1024), 0, ctx().stream, L, L.phi, L.tmp, nsweeps, ctx().prm.hg_omega);
+    if (nsweeps & 1) std::swap(L.phi, L.tmp);
+    return;
+  }
   for (int s = 0; s < nsweeps; s++) {
     nd_fill_nodes(L, L.phi);
     nd_launch_march<0>(L, L.phi, L.tmp, nullptr);
