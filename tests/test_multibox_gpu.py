@@ -209,3 +209,20 @@ def test_packed_exchange_path(gpu, oracle, monkeypatch):
     test_cc_solve_multibox_equals_single_box(gpu, oracle, "periodic")
     test_nd_solve_multibox_equals_single_box(gpu, oracle, "walls")
     test_advance_timestep_multibox_equals_single_box(gpu, "bubble-periodic", BC_SETS["periodic"], 1)
+
+
+def test_rccl_self_exchange_path(gpu, oracle, monkeypatch):
+    """VDN_FORCE_PACKED=2 on ONE GPU: a 1-rank RCCL communicator is built through the same dlopen'ed entry points the
+    multi-rank job uses, the rank's own packed halo buffers travel through ncclSend/ncclRecv (inside one group) and
+    the norms through ncclAllReduce / ncclAllGather -- the hardware check of the RCCL call sequence that a one-GPU
+    box allows (two ranks on one device are refused by RCCL)"""
+    monkeypatch.setenv("VDN_FORCE_PACKED", "2")
+    gpu.comm_init(gpu.comm_get_unique_id())
+    try:
+        test_fill_boundary_multibox(gpu, oracle, "periodic")
+        test_fill_boundary_multibox(gpu, oracle, "mixed")
+        test_cc_solve_multibox_equals_single_box(gpu, oracle, "periodic")
+        test_nd_solve_multibox_equals_single_box(gpu, oracle, "walls")
+        test_advance_timestep_multibox_equals_single_box(gpu, "bubble-periodic", BC_SETS["periodic"], 1)
+    finally:
+        gpu.comm_finalize()

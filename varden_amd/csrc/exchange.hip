@@ -46,6 +46,7 @@ struct Rccl {
   ncclComm_t comm = nullptr;
 };
 static Rccl g_rccl;
+static int packed_mode() { const char *e = getenv("VDN_FORCE_PACKED"); return e ? atoi(e) : 0; }
 #define NCCLCHK(x) do { int r_ = (x); if (r_ != ncclSuccess) vdn_fail("%s failed: %s", #x, g_rccl.GetErrorString ? g_rccl.GetErrorString(r_) : "?"); } while (0)
 
 static void rccl_load() {
@@ -70,7 +71,9 @@ extern "C" int vdn_comm_get_unique_id(char *id128) {
 extern "C" int vdn_comm_init(const char *id128) {
   VDN_TRY
   REQUIRE(ctx().inited, "vdn_comm_init: call vdn_init first");
-  if (ctx().nranks == 1) return 0;
+  // VDN_FORCE_PACKED=2 (hardware self-test of the RCCL call path on ONE GPU): build a 1-rank communicator and send
+  // the rank's own packed buffers to itself with ncclSend/ncclRecv; reductions go through ncclAllReduce too
+  if (ctx().nranks == 1 && packed_mode() != 2) return 0;
   rccl_load();
   ncclUniqueId id; memcpy(id.internal, id128, 128);
   NCCLCHK(g_rccl.CommInitRank(&g_rccl.comm, ctx().nranks, id, ctx().rank));
@@ -81,7 +84,7 @@ extern "C" int vdn_comm_finalize(void) {
   if (g_rccl.comm) { HIPCHK(hipStreamSynchronize(ctx().stream)); NCCLCHK(g_rccl.CommDestroy(g_rccl.comm)); g_rccl.comm = nullptr; }
   VDN_CATCH
 }
-bool comm_active() { return ctx().nranks > 1; }
+bool comm_active() { return ctx().nranks > 1 || g_rccl.comm != nullptr; }
 static void need_comm() { REQUIRE(g_rccl.comm != nullptr, "this operation spans ranks: call vdn_comm_init first (nranks = %d)", ctx().nranks); }
 
 // all-reduce MAX of n device doubles, in place, on the launch stream
@@ -156,7 +159,7 @@ XPlan *xplan_build(const std::vector<XBoxInfo> &boxes, const vdn_box &pd, const 
   const int me = ctx().rank;
   // self-test mode: route the rank's OWN box-to-box copies through the pack -> buffer -> unpack path that remote
   // copies take (peer == me, buffer handed over with a device memcpy instead of ncclSend/ncclRecv)
-  const bool force_packed = getenv("VDN_FORCE_PACKED") && atoi(getenv("VDN_FORCE_PACKED")) == 1;
+  const bool force_packed = packed_mode() >= 1;
   int per[3], nshift[3];
   for (int d = 0; d < 3; d++) { per[d] = pd.hi[d] - pd.lo[d] + 1; nshift[d] = pmask[d] ? 1 : 0; }
   std::map<int, Peer> peers;
@@ -236,7 +239,8 @@ void xplan_run(XPlan *P) {
   const int nc = P->nc;
   // pack + post the remote traffic first so that it overlaps the local copies
   if (!P->peers.empty()) {
-    bool remote = false;
+    const bool self_rccl = packed_mode() == 2 && g_rccl.comm != nullptr;    // self peer through ncclSend/ncclRecv
+    bool remote = self_rccl;
     for (auto &pr : P->peers) {
       if (pr.rank != ctx().rank) remote = true;
       if (!pr.pack.empty()) hipLaunchKernelGGL(k_xpack, dim3(32, 1, (unsigned)pr.pack.size()), dim3(256), 0, st, pr.d_pack, nc, pr.d_send);
@@ -245,14 +249,14 @@ void xplan_run(XPlan *P) {
       need_comm();
       NCCLCHK(g_rccl.GroupStart());
       for (auto &pr : P->peers) {
-        if (pr.rank == ctx().rank) continue;
+        if (pr.rank == ctx().rank && !self_rccl) continue;
         if (pr.nsend) NCCLCHK(g_rccl.Send(pr.d_send, pr.nsend, ncclFloat64, pr.rank, g_rccl.comm, st));
         if (pr.nrecv) NCCLCHK(g_rccl.Recv(pr.d_recv, pr.nrecv, ncclFloat64, pr.rank, g_rccl.comm, st));
       }
       NCCLCHK(g_rccl.GroupEnd());
     }
     for (auto &pr : P->peers)           // self-test mode (VDN_FORCE_PACKED): my own buffer is my inbox
-      if (pr.rank == ctx().rank && pr.nsend) { REQUIRE(pr.nsend == pr.nrecv, "self exchange: send/recv sizes differ"); HIPCHK(hipMemcpyAsync(pr.d_recv, pr.d_send, pr.nsend * sizeof(double), hipMemcpyDeviceToDevice, st)); }
+      if (pr.rank == ctx().rank && pr.nsend && !self_rccl) { REQUIRE(pr.nsend == pr.nrecv, "self exchange: send/recv sizes differ"); HIPCHK(hipMemcpyAsync(pr.d_recv, pr.d_send, pr.nsend * sizeof(double), hipMemcpyDeviceToDevice, st)); }
   }
   if (!P->local.empty())
     hipLaunchKernelGGL(k_xcopy, dim3(64, 1, (unsigned)P->local.size()), dim3(256), 0, st, P->d_local, nc);
