@@ -210,3 +210,49 @@ def test_physbc_fill_boundary_estdt(gpu, oracle, bcname):
         gdt = adv.estdt(1, gu, gs, case.gmf(gp), case.gmf(ext), case.dx, dtold)
         assert gdt == odt, "estdt %r vs %r" % (gdt, odt)
     case.close()
+
+
+@pytest.mark.gpu
+def test_godunov_marching_equals_face_centred(gpu):
+    """the cell-centred k-marching stage kernels (default) and the face-centred one-thread-per-cell kernels
+    (VDN_GODUNOV_PLAIN=1, read at the first launch of the process, so run in a child process) agree bit for bit"""
+    import os, subprocess, sys, textwrap
+    code = textwrap.dedent("""
+        import sys, hashlib
+        sys.path.insert(0, %r)
+        import numpy as np
+        from varden_amd import advance as adv, boxlib as bl, capi
+        n = 24
+        bl.initialize(capi.default_params(), 0, 1, 0)
+        lo, hi = (0, 0, 0), (n - 1, n - 3, n + 1)
+        mla = bl.MLLayout([(lo, hi)], [[(lo, hi)]])
+        bct = bl.BCTower(mla, [[bl.INLET, bl.OUTLET], [bl.SLIP_WALL, bl.NO_SLIP_WALL], [bl.NO_SLIP_WALL, bl.OUTLET]])
+        rng = np.random.default_rng(7)
+        def mf(nc, ng, nodal=None):
+            m = bl.MultiFab(mla, 0, nc, ng, nodal); m.from_numpy(rng.standard_normal(m.shape(0))); return m
+        u, s = mf(3, 3), mf(2, 3)
+        f3, f2, rhs = mf(3, 1), mf(2, 1), mf(1, 1)
+        nd = [tuple(1 if t == d else 0 for t in range(3)) for d in range(3)]
+        umac = [mf(1, 1, nd[d]) for d in range(3)]
+        ue = [mf(3, 0, nd[d]) for d in range(3)]; uf = [mf(3, 0, nd[d]) for d in range(3)]
+        se = [mf(2, 0, nd[d]) for d in range(3)]; sf = [mf(2, 0, nd[d]) for d in range(3)]
+        dx = [1.0 / n] * 3
+        adv.velpred(u, umac, f3, dx, 0.3 / n, bct)
+        for m in umac: m.fill_boundary()
+        adv.mkflux(u, ue, uf, umac, f3, rhs, dx, 0.3 / n, bct, True, [0, 0, 0])
+        adv.mkflux(s, se, sf, umac, f2, rhs, dx, 0.3 / n, bct, False, [1, 0])
+        h = hashlib.sha256()
+        for m in umac + ue + se + [sf[d] for d in range(3)]:
+            h.update(np.ascontiguousarray(m.to_numpy()).tobytes())
+        print("HASH", h.hexdigest())
+    """ % os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    out = []
+    for plain in (False, True):
+        env = dict(os.environ)
+        env.pop("VDN_GODUNOV_PLAIN", None)
+        if plain:
+            env["VDN_GODUNOV_PLAIN"] = "1"
+        r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stderr[-2000:]
+        out.append([l for l in r.stdout.splitlines() if l.startswith("HASH")][0])
+    assert out[0] == out[1]

@@ -264,6 +264,345 @@ __global__ void __launch_bounds__(256) kk_mk_D(FV s, FV sl0, FV sl1, FV sl2, FV 
   }
 }
 
+// ====================================================================================================
+// Cell-centred, k-marching form of the stage B / C / D kernels (the default path)
+// ====================================================================================================
+// Measured on MI355X (rocprofv3 PMC, 256^3): the face-centred kernels above issue ~230 loads per cell in stage D, most of
+// them re-reading, for the LEFT side of a face, what the neighbouring thread reads for the RIGHT side of its own face;
+// the per-CU vector L1 (TCP) is the bound (1.1e9 tag accesses, 1.8e9 pending-stall cycles per launch), not HBM.
+// Every left/right state of a face is a function of ONE cell (the cell on that side), so here a thread owns a CELL,
+// computes that cell's contribution to its lower faces (right states) and to its upper faces (left states) once, and
+// hands the left states to the owner of the upper face:
+//   x: to lane+1 by a wave shuffle      (tiles overlap by one cell: lane 0 is halo-only)
+//   y: to row+1 through LDS             (tiles overlap by one row: row 0 is halo-only, one barrier per plane)
+//   z: to itself at the next k-plane    (the workgroup marches in k; a register carry)
+// The arithmetic of every state is unchanged (same expressions in the same order), so results are bit-identical.
+// Boundary rule: on a physical boundary face the state of the OUTSIDE cell is dead (bc_pair overwrites it from the
+// inside state or the ghost value) and the inside cell can apply its half of bc_pair alone; bc_pair is idempotent, so
+// the face owner then applies the complete rule to the pair it has assembled.
+// Code shape: every plane starts with ONE unconditional batch of loads (indices clamped into the arrays; threads outside
+// the computable region produce values nobody uses), the rare boundary work sits in one branch after it.
+static bool plain_godunov() { static const bool p = getenv("VDN_GODUNOV_PLAIN") != nullptr; return p; }
+constexpr int TNY = 8;              // rows per tile: workgroup = 64 x TNY threads
+static int march_chunks() { static const int n = getenv("VDN_KCHUNKS") ? atoi(getenv("VDN_KCHUNKS")) : 12; return n < 1 ? 1 : n; }
+static dim3 march_grid(const Range3 &r, int &klen) {
+  const int nx = r.hi[0] - r.lo[0] + 1, ny = r.hi[1] - r.lo[1] + 1, nz = r.hi[2] - r.lo[2] + 1;
+  klen = (nz + march_chunks() - 1) / march_chunks(); if (klen < 1) klen = 1;
+  return dim3((nx + 62) / 63, (ny + TNY - 2) / (TNY - 1), (nz + klen - 1) / klen);
+}
+// i, j: the thread's cell;  ic, jc: the same clamped into the grown box (load indices);  own_ij: this thread emits
+#define MARCH_SETUP(r)                                                                   \
+  const int lane = threadIdx.x, row = threadIdx.y;                                       \
+  const int i = (r).lo[0] - 1 + (int)blockIdx.x * 63 + lane;                             \
+  const int j = (r).lo[1] - 1 + (int)blockIdx.y * (TNY - 1) + row;                       \
+  const bool own_ij = lane >= 1 && row >= 1 && i <= (r).hi[0] && j <= (r).hi[1];         \
+  const int ic = min(max(i, A.lo[0] - 1), A.hi[0] + 1), jc = min(max(j, A.lo[1] - 1), A.hi[1] + 1); \
+  const int ip = min(ic + 1, A.hi[0] + 1), jp = min(jc + 1, A.hi[1] + 1);                \
+  const bool edge_ij = ic == A.lo[0] || ic >= A.hi[0] || jc == A.lo[1] || jc >= A.hi[1]; \
+  const bool vx = in_valid(A, 0, i), vy = in_valid(A, 1, j);                             \
+  const int k0 = (r).lo[2] + (int)blockIdx.z * klen, k1 = min(k0 + klen - 1, (r).hi[2]);
+#define MARCH_PLANE                                                                      \
+    const int kc = min(max(k, A.lo[2] - 1), A.hi[2] + 1), kp = min(kc + 1, A.hi[2] + 1); \
+    const bool emit = own_ij && k >= k0;                                                 \
+    const bool vz = in_valid(A, 2, k);                                                   \
+    const bool edge = edge_ij || kc == A.lo[2] || kc >= A.hi[2];                         \
+    const int buf = k & 1;                                                               \
+    (void)kp; (void)vz; (void)edge; (void)ip; (void)jp; (void)vx; (void)vy;
+
+DEVI double shfl_prev(double v) { return __shfl_up(v, 1, 64); }
+DEVI bool in_valid(const GArgs &A, int d, int q) { return q >= A.lo[d] && q <= A.hi[d]; }
+DEVI double tv(bool cons, double fcons, double fconv, double dxT, double sp, double s0, double mp, double m0) {   // = trans_term on values
+  if (cons) return (fcons / dxT) * (sp * mp - s0 * m0);
+  return (fconv / dxT) * (mp + m0) * (sp - s0);
+}
+
+// one-dimensional predictor bases of component c in a cell along D: Lb = left state of the cell's UPPER D-face,
+// Rb = right state of its LOWER D-face (mk_pair without the boundary rule)
+template <int D> DEVI void mk_bases(const GArgs &A, int c, double s0, double slD, double mlo, double mup, double fterm, double mterm, double &Lb, double &Rb) {
+  const double dt2 = 0.5 * A.dt;
+  Lb = s0 + (0.5 - dt2 * mup / A.dx[D]) * slD;
+  Rb = s0 - (0.5 + dt2 * mlo / A.dx[D]) * slD;
+  if (A.use_minion) {
+    Lb = Lb + fterm; Rb = Rb + fterm;
+    if (A.cons[c]) { Lb = Lb - mterm; Rb = Rb - mterm; }
+  }
+}
+// this cell's half of the boundary rule on its bases (cells next to a box face only)
+template <int D> DEVI void mk_premod(const GArgs &A, const FV &s, int c, int i, int j, int k, double &Lb, double &Rb) {
+  const int q = coord<D>(i, j, k);
+  if (q == A.lo[D]) { double o = Rb; bc_pair(o, Rb, A.phys[D][0], 0, A.is_vel != 0, c == D, ld<D>(s, i, j, k, -1, c), false); }
+  if (q == A.hi[D]) { double o = Lb; bc_pair(Lb, o, A.phys[D][1], 1, A.is_vel != 0, c == D, ld<D>(s, i, j, k, 1, c), false); }
+}
+// the complete boundary rule on an assembled pair of the lower D-face of cell (i,j,k)
+template <int D> DEVI void mk_face_bc(const GArgs &A, const FV &s, int c, int i, int j, int k, double s0, double &L, double &R) {
+  const int side = face_side<D>(A, i, j, k);
+  if (side >= 0) bc_pair(L, R, A.phys[D][side], side, A.is_vel != 0, c == D, side == 0 ? ld<D>(s, i, j, k, -1, c) : s0, false);
+}
+
+// the per-plane load batch shared by the three mkflux stages
+#define MK_LOAD_CELL                                                                                                   \
+    const double m_lo[3] = { fv_get(um, ic, jc, kc), fv_get(vm, ic, jc, kc), fv_get(wm, ic, jc, kc) };                   \
+    const double m_up[3] = { fv_get(um, ic + 1, jc, kc), fv_get(vm, ic, jc + 1, kc), fv_get(wm, ic, jc, kc + 1) };       \
+    double s0[NC], sl[NC][3];                                                                                           \
+    _Pragma("unroll") for (int c = 0; c < NC; c++) {                                                                    \
+      s0[c] = fv_get(s, ic, jc, kc, c0 + c);                                                                                  \
+      sl[c][0] = fv_get(sl0, ic, jc, kc, c0 + c); sl[c][1] = fv_get(sl1, ic, jc, kc, c0 + c); sl[c][2] = fv_get(sl2, ic, jc, kc, c0 + c); \
+    }
+
+// ---- stage B ----------------------------------------------------------------------------------------------------
+template <int NC> __global__ void __launch_bounds__(64 * TNY) kk_mk_B_m(FV s, FV sl0, FV sl1, FV sl2, FV um, FV vm, FV wm, FV force, FV macrhs, FV SI,
+                                                                         GArgs A, Range3 r, int klen, const double *umax, int c0, int ns) {
+  __shared__ double ly[2][NC][TNY][64];
+  MARCH_SETUP(r)
+  const double eps = eps_from(umax);
+  const double dt2 = 0.5 * A.dt;
+  double Lz[NC];
+  #pragma unroll
+  for (int c = 0; c < NC; c++) Lz[c] = 0.0;
+  for (int k = k0 - 1; k <= k1; k++) {
+    MARCH_PLANE
+    MK_LOAD_CELL
+    double ft[NC], mt[NC];
+    #pragma unroll
+    for (int c = 0; c < NC; c++) { ft[c] = 0.0; mt[c] = 0.0; }
+    if (A.use_minion) {
+      const double mr = fv_get(macrhs, ic, jc, kc);
+      #pragma unroll
+      for (int c = 0; c < NC; c++) { ft[c] = dt2 * fv_get(force, ic, jc, kc, c0 + c); mt[c] = dt2 * s0[c] * mr; }
+    }
+    double Lb[NC][3], Rb[NC][3];
+    #pragma unroll
+    for (int c = 0; c < NC; c++) {
+      mk_bases<0>(A, c0 + c, s0[c], sl[c][0], m_lo[0], m_up[0], ft[c], mt[c], Lb[c][0], Rb[c][0]);
+      mk_bases<1>(A, c0 + c, s0[c], sl[c][1], m_lo[1], m_up[1], ft[c], mt[c], Lb[c][1], Rb[c][1]);
+      mk_bases<2>(A, c0 + c, s0[c], sl[c][2], m_lo[2], m_up[2], ft[c], mt[c], Lb[c][2], Rb[c][2]);
+    }
+    // (no premod needed in stage B: the owner's complete rule is applied to the untouched pair)
+    #pragma unroll
+    for (int c = 0; c < NC; c++) ly[buf][c][row][lane] = Lb[c][1];
+    __syncthreads();
+    double Lx[NC], Ly[NC], Lzc[NC];
+    #pragma unroll
+    for (int c = 0; c < NC; c++) {
+      Lx[c] = shfl_prev(Lb[c][0]);
+      Ly[c] = ly[buf][c][row >= 1 ? row - 1 : 0][lane];
+      Lzc[c] = Lz[c]; Lz[c] = Lb[c][2];
+    }
+    if (emit) {
+      if (edge) {
+        #pragma unroll
+        for (int c = 0; c < NC; c++) {
+          mk_face_bc<0>(A, s, c0 + c, i, j, k, s0[c], Lx[c], Rb[c][0]); mk_face_bc<1>(A, s, c0 + c, i, j, k, s0[c], Ly[c], Rb[c][1]); mk_face_bc<2>(A, s, c0 + c, i, j, k, s0[c], Lzc[c], Rb[c][2]);
+        }
+      }
+      #pragma unroll
+      for (int c = 0; c < NC; c++) {
+        if (i >= A.lo[0]) fv_at(SI, i, j, k, 0 * ns + c0 + c) = upwind_mac(Lx[c], Rb[c][0], m_lo[0], eps);
+        if (j >= A.lo[1]) fv_at(SI, i, j, k, 1 * ns + c0 + c) = upwind_mac(Ly[c], Rb[c][1], m_lo[1], eps);
+        if (k >= A.lo[2]) fv_at(SI, i, j, k, 2 * ns + c0 + c) = upwind_mac(Lzc[c], Rb[c][2], m_lo[2], eps);
+      }
+    }
+  }
+}
+
+// ---- stage C ----------------------------------------------------------------------------------------------------
+// per cell and component: the three transverse terms t_T (from SI_T, mac_T) and the six chains base_D - t_T
+template <int NC> __global__ void __launch_bounds__(64 * TNY) kk_mk_C_m(FV s, FV sl0, FV sl1, FV sl2, FV um, FV vm, FV wm, FV force, FV macrhs, FV SI, FV SC,
+                                                                         GArgs A, Range3 r, int klen, const double *umax, int c0, int ns) {
+  __shared__ double ly[2][NC][2][TNY][64];
+  MARCH_SETUP(r)
+  const double eps = eps_from(umax);
+  const double dt2 = 0.5 * A.dt, dt3 = A.dt / 3.0, dt6 = A.dt / 6.0;
+  double Lz[NC][2];
+  #pragma unroll
+  for (int c = 0; c < NC; c++) { Lz[c][0] = 0.0; Lz[c][1] = 0.0; }
+  for (int k = k0 - 1; k <= k1; k++) {
+    MARCH_PLANE
+    MK_LOAD_CELL
+    double si0[NC][3], si1[NC][3];          // SI_T at the cell's lower / upper T-face
+    #pragma unroll
+    for (int c = 0; c < NC; c++) {
+      si0[c][0] = fv_get(SI, ic, jc, kc, 0 * ns + c0 + c); si1[c][0] = fv_get(SI, ip, jc, kc, 0 * ns + c0 + c);
+      si0[c][1] = fv_get(SI, ic, jc, kc, 1 * ns + c0 + c); si1[c][1] = fv_get(SI, ic, jp, kc, 1 * ns + c0 + c);
+      si0[c][2] = fv_get(SI, ic, jc, kc, 2 * ns + c0 + c); si1[c][2] = fv_get(SI, ic, jc, kp, 2 * ns + c0 + c);
+    }
+    double ft[NC], mt[NC];
+    #pragma unroll
+    for (int c = 0; c < NC; c++) { ft[c] = 0.0; mt[c] = 0.0; }
+    if (A.use_minion) {
+      const double mr = fv_get(macrhs, ic, jc, kc);
+      #pragma unroll
+      for (int c = 0; c < NC; c++) { ft[c] = dt2 * fv_get(force, ic, jc, kc, c0 + c); mt[c] = dt2 * s0[c] * mr; }
+    }
+    double Lb[NC][3], Rb[NC][3];
+    #pragma unroll
+    for (int c = 0; c < NC; c++) {
+      mk_bases<0>(A, c0 + c, s0[c], sl[c][0], m_lo[0], m_up[0], ft[c], mt[c], Lb[c][0], Rb[c][0]);
+      mk_bases<1>(A, c0 + c, s0[c], sl[c][1], m_lo[1], m_up[1], ft[c], mt[c], Lb[c][1], Rb[c][1]);
+      mk_bases<2>(A, c0 + c, s0[c], sl[c][2], m_lo[2], m_up[2], ft[c], mt[c], Lb[c][2], Rb[c][2]);
+    }
+    if (edge) {
+      #pragma unroll
+      for (int c = 0; c < NC; c++) { mk_premod<0>(A, s, c0 + c, ic, jc, kc, Lb[c][0], Rb[c][0]); mk_premod<1>(A, s, c0 + c, ic, jc, kc, Lb[c][1], Rb[c][1]); mk_premod<2>(A, s, c0 + c, ic, jc, kc, Lb[c][2], Rb[c][2]); }
+    }
+    // VL[c][D][n] / VR[c][D][n]: n = 0,1 -> the two transverse directions of D in increasing order
+    double VL[NC][3][2], VR[NC][3][2];
+    #pragma unroll
+    for (int c = 0; c < NC; c++) {
+      const bool cons = A.cons[c0 + c] != 0;
+      double t[3];
+      t[0] = tv(cons, dt3, dt6, A.dx[0], si1[c][0], si0[c][0], m_up[0], m_lo[0]);
+      t[1] = tv(cons, dt3, dt6, A.dx[1], si1[c][1], si0[c][1], m_up[1], m_lo[1]);
+      t[2] = tv(cons, dt3, dt6, A.dx[2], si1[c][2], si0[c][2], m_up[2], m_lo[2]);
+      // D = 0: T = 1, 2;  D = 1: T = 0, 2;  D = 2: T = 0, 1
+      VL[c][0][0] = Lb[c][0] - t[1]; VR[c][0][0] = Rb[c][0] - t[1]; VL[c][0][1] = Lb[c][0] - t[2]; VR[c][0][1] = Rb[c][0] - t[2];
+      VL[c][1][0] = Lb[c][1] - t[0]; VR[c][1][0] = Rb[c][1] - t[0]; VL[c][1][1] = Lb[c][1] - t[2]; VR[c][1][1] = Rb[c][1] - t[2];
+      VL[c][2][0] = Lb[c][2] - t[0]; VR[c][2][0] = Rb[c][2] - t[0]; VL[c][2][1] = Lb[c][2] - t[1]; VR[c][2][1] = Rb[c][2] - t[1];
+    }
+    #pragma unroll
+    for (int c = 0; c < NC; c++) { ly[buf][c][0][row][lane] = VL[c][1][0]; ly[buf][c][1][row][lane] = VL[c][1][1]; }
+    __syncthreads();
+    double Lx[NC][2], Ly[NC][2], Lzc[NC][2];
+    #pragma unroll
+    for (int c = 0; c < NC; c++) {
+      Lx[c][0] = shfl_prev(VL[c][0][0]); Lx[c][1] = shfl_prev(VL[c][0][1]);
+      Ly[c][0] = ly[buf][c][0][row >= 1 ? row - 1 : 0][lane]; Ly[c][1] = ly[buf][c][1][row >= 1 ? row - 1 : 0][lane];
+      Lzc[c][0] = Lz[c][0]; Lzc[c][1] = Lz[c][1];
+      Lz[c][0] = VL[c][2][0]; Lz[c][1] = VL[c][2][1];
+    }
+    if (emit) {
+      if (edge) {
+        #pragma unroll
+        for (int c = 0; c < NC; c++) {
+          #pragma unroll
+          for (int n = 0; n < 2; n++) {
+            mk_face_bc<0>(A, s, c0 + c, i, j, k, s0[c], Lx[c][n], VR[c][0][n]); mk_face_bc<1>(A, s, c0 + c, i, j, k, s0[c], Ly[c][n], VR[c][1][n]); mk_face_bc<2>(A, s, c0 + c, i, j, k, s0[c], Lzc[c][n], VR[c][2][n]);
+          }
+        }
+      }
+      // SC index (D,T): (D*2 + (T > D ? T-1 : T)) * NC + c;  valid where the D-face index >= lo[D] and the T index is valid
+      #pragma unroll
+      for (int c = 0; c < NC; c++) {
+        if (i >= A.lo[0]) {
+          if (vy) fv_at(SC, i, j, k, 0 * ns + c0 + c) = upwind_mac(Lx[c][0], VR[c][0][0], m_lo[0], eps);
+          if (vz) fv_at(SC, i, j, k, 1 * ns + c0 + c) = upwind_mac(Lx[c][1], VR[c][0][1], m_lo[0], eps);
+        }
+        if (j >= A.lo[1]) {
+          if (vx) fv_at(SC, i, j, k, 2 * ns + c0 + c) = upwind_mac(Ly[c][0], VR[c][1][0], m_lo[1], eps);
+          if (vz) fv_at(SC, i, j, k, 3 * ns + c0 + c) = upwind_mac(Ly[c][1], VR[c][1][1], m_lo[1], eps);
+        }
+        if (k >= A.lo[2]) {
+          if (vx) fv_at(SC, i, j, k, 4 * ns + c0 + c) = upwind_mac(Lzc[c][0], VR[c][2][0], m_lo[2], eps);
+          if (vy) fv_at(SC, i, j, k, 5 * ns + c0 + c) = upwind_mac(Lzc[c][1], VR[c][2][1], m_lo[2], eps);
+        }
+      }
+    }
+  }
+}
+
+// ---- stage D ----------------------------------------------------------------------------------------------------
+template <int D> DEVI double mk_edge_bc(const GArgs &A, const FV &s, int c, int i, int j, int k, double s0, double L, double R, double e) {
+  const int side = face_side<D>(A, i, j, k);
+  if (side >= 0) {                                   // mkflux.f90:2369-2402
+    const int ph = A.phys[D][side];
+    const double in = (side == 0) ? R : L;
+    const bool vel = A.is_vel != 0;
+    if (ph == VDN_INLET) e = (side == 0) ? ld<D>(s, i, j, k, -1, c) : s0;
+    else if (ph == VDN_SLIP_WALL) e = (vel && c == D) ? 0.0 : in;
+    else if (ph == VDN_NO_SLIP_WALL) e = vel ? 0.0 : in;
+    else if (ph == VDN_OUTLET) e = (vel && c == D) ? ((side == 0) ? fmin(in, 0.0) : fmax(in, 0.0)) : in;
+  }
+  return e;
+}
+template <int NC> __global__ void __launch_bounds__(64 * TNY) kk_mk_D_m(FV s, FV sl0, FV sl1, FV sl2, FV um, FV vm, FV wm, FV force, FV macrhs, FV SC,
+                                                                         FV sex, FV sey, FV sez, FV flx, FV fly, FV flz, GArgs A, Range3 r, int klen, const double *umax, int c0, int ns) {
+  __shared__ double ly[2][NC][TNY][64];
+  MARCH_SETUP(r)
+  const double eps = eps_from(umax);
+  const double dt2 = 0.5 * A.dt, dt4 = A.dt / 4.0;
+  double Lz[NC];
+  #pragma unroll
+  for (int c = 0; c < NC; c++) Lz[c] = 0.0;
+  for (int k = k0 - 1; k <= k1; k++) {
+    MARCH_PLANE
+    MK_LOAD_CELL
+    const double mr = fv_get(macrhs, ic, jc, kc);
+    double ft[NC], mt[NC];
+    // q0[c][n] / q1[c][n]: SC component n at the cell's lower / upper face of the direction that component lives on
+    //   n: 0 = (0,1) 1 = (0,2) on x-faces, 2 = (1,0) 3 = (1,2) on y-faces, 4 = (2,0) 5 = (2,1) on z-faces
+    double q0[NC][6], q1[NC][6];
+    #pragma unroll
+    for (int c = 0; c < NC; c++) {
+      ft[c] = dt2 * fv_get(force, ic, jc, kc, c0 + c); mt[c] = dt2 * s0[c] * mr;
+      #pragma unroll
+      for (int n = 0; n < 6; n++) q0[c][n] = fv_get(SC, ic, jc, kc, n * ns + c0 + c);
+      q1[c][0] = fv_get(SC, ip, jc, kc, 0 * ns + c0 + c); q1[c][1] = fv_get(SC, ip, jc, kc, 1 * ns + c0 + c);
+      q1[c][2] = fv_get(SC, ic, jp, kc, 2 * ns + c0 + c); q1[c][3] = fv_get(SC, ic, jp, kc, 3 * ns + c0 + c);
+      q1[c][4] = fv_get(SC, ic, jc, kp, 4 * ns + c0 + c); q1[c][5] = fv_get(SC, ic, jc, kp, 5 * ns + c0 + c);
+    }
+    double Lb[NC][3], Rb[NC][3];
+    #pragma unroll
+    for (int c = 0; c < NC; c++) {
+      mk_bases<0>(A, c0 + c, s0[c], sl[c][0], m_lo[0], m_up[0], ft[c], mt[c], Lb[c][0], Rb[c][0]);
+      mk_bases<1>(A, c0 + c, s0[c], sl[c][1], m_lo[1], m_up[1], ft[c], mt[c], Lb[c][1], Rb[c][1]);
+      mk_bases<2>(A, c0 + c, s0[c], sl[c][2], m_lo[2], m_up[2], ft[c], mt[c], Lb[c][2], Rb[c][2]);
+    }
+    if (edge) {
+      #pragma unroll
+      for (int c = 0; c < NC; c++) { mk_premod<0>(A, s, c0 + c, ic, jc, kc, Lb[c][0], Rb[c][0]); mk_premod<1>(A, s, c0 + c, ic, jc, kc, Lb[c][1], Rb[c][1]); mk_premod<2>(A, s, c0 + c, ic, jc, kc, Lb[c][2], Rb[c][2]); }
+    }
+    double VL[NC][3], VR[NC][3];
+    #pragma unroll
+    for (int c = 0; c < NC; c++) {
+      const bool cons = A.cons[c0 + c] != 0;
+      // a_T = (dt2/dx_T) * s0 * (mac_T(+) - mac_T)
+      const double a[3] = { (dt2 / A.dx[0]) * s0[c] * (m_up[0] - m_lo[0]), (dt2 / A.dx[1]) * s0[c] * (m_up[1] - m_lo[1]), (dt2 / A.dx[2]) * s0[c] * (m_up[2] - m_lo[2]) };
+      #define CHAIN(Dd, T1, T2, n1, n2)                                                                    \
+        { const double t1 = tv(cons, dt2, dt4, A.dx[T1], q1[c][n1], q0[c][n1], m_up[T1], m_lo[T1]);          \
+          const double t2 = tv(cons, dt2, dt4, A.dx[T2], q1[c][n2], q0[c][n2], m_up[T2], m_lo[T2]);          \
+          double vl = Lb[c][Dd], vr = Rb[c][Dd];                                                             \
+          vl = vl - t1; vr = vr - t1; vl = vl - t2; vr = vr - t2;                                            \
+          if (cons) { vl = vl + a[T1]; vr = vr + a[T1]; vl = vl + a[T2]; vr = vr + a[T2]; }                  \
+          if (!A.use_minion) { vl = vl + ft[c]; vr = vr + ft[c]; if (cons) { vl = vl - mt[c]; vr = vr - mt[c]; } } \
+          VL[c][Dd] = vl; VR[c][Dd] = vr; }
+      CHAIN(0, 1, 2, 3, 5)      // D = 0: T1 = 1 with SC(1,2) = simhyz,  T2 = 2 with SC(2,1) = simhzy
+      CHAIN(1, 0, 2, 1, 4)      // D = 1: T1 = 0 with SC(0,2),           T2 = 2 with SC(2,0)
+      CHAIN(2, 0, 1, 0, 2)      // D = 2: T1 = 0 with SC(0,1),           T2 = 1 with SC(1,0)
+      #undef CHAIN
+    }
+    #pragma unroll
+    for (int c = 0; c < NC; c++) ly[buf][c][row][lane] = VL[c][1];
+    __syncthreads();
+    double L[NC][3];
+    #pragma unroll
+    for (int c = 0; c < NC; c++) {
+      L[c][0] = shfl_prev(VL[c][0]);
+      L[c][1] = ly[buf][c][row >= 1 ? row - 1 : 0][lane];
+      L[c][2] = Lz[c]; Lz[c] = VL[c][2];
+    }
+    if (emit) {
+      double e[NC][3];
+      #pragma unroll
+      for (int c = 0; c < NC; c++) { e[c][0] = upwind_mac(L[c][0], VR[c][0], m_lo[0], eps); e[c][1] = upwind_mac(L[c][1], VR[c][1], m_lo[1], eps); e[c][2] = upwind_mac(L[c][2], VR[c][2], m_lo[2], eps); }
+      if (edge) {
+        #pragma unroll
+        for (int c = 0; c < NC; c++) {
+          e[c][0] = mk_edge_bc<0>(A, s, c0 + c, i, j, k, s0[c], L[c][0], VR[c][0], e[c][0]);
+          e[c][1] = mk_edge_bc<1>(A, s, c0 + c, i, j, k, s0[c], L[c][1], VR[c][1], e[c][1]);
+          e[c][2] = mk_edge_bc<2>(A, s, c0 + c, i, j, k, s0[c], L[c][2], VR[c][2], e[c][2]);
+        }
+      }
+      #pragma unroll
+      for (int c = 0; c < NC; c++) {
+        const bool cons = A.cons[c0 + c] != 0;
+        if (vy && vz) { fv_at(sex, i, j, k, c0 + c) = e[c][0]; if (cons) fv_at(flx, i, j, k, c0 + c) = e[c][0] * m_lo[0]; }
+        if (vx && vz) { fv_at(sey, i, j, k, c0 + c) = e[c][1]; if (cons) fv_at(fly, i, j, k, c0 + c) = e[c][1] * m_lo[1]; }
+        if (vx && vy) { fv_at(sez, i, j, k, c0 + c) = e[c][2]; if (cons) fv_at(flz, i, j, k, c0 + c) = e[c][2] * m_lo[2]; }
+      }
+    }
+  }
+}
+
 // max |umac| over the valid faces of the three MAC components (mkflux.f90:1374-1396)
 __global__ void kk_macmax(FV um, FV vm, FV wm, GArgs A, Range3 r, double *out) {
   REDUCE_IJ(r)
@@ -338,10 +677,35 @@ void k_mkflux(const vdn_multifab *s, vdn_multifab **sedge, vdn_multifab **flux, 
     const FV &um = umac[0]->fabs[ib], &vm = umac[1]->fabs[ib], &wm = umac[2]->fabs[ib];
     hipLaunchKernelGGL(kk_macmax, reduce_grid(rf), dim3(64, 4, 1), 0, st, um, vm, wm, A, rf, umax);
     hipLaunchKernelGGL(kk_slopes, grid_for(rg), dim3(64, 4, 1), 0, st, s->fabs[ib], sl[0], sl[1], sl[2], A, rg, 7);
-    hipLaunchKernelGGL(kk_mk_B, grid_for(rg), dim3(64, 4, 1), 0, st, s->fabs[ib], sl[0], sl[1], sl[2], um, vm, wm, force->fabs[ib], mac_rhs->fabs[ib], SI, A, rg, umax);
-    hipLaunchKernelGGL(kk_mk_C, grid_for(rg), dim3(64, 4, 1), 0, st, s->fabs[ib], sl[0], sl[1], sl[2], um, vm, wm, force->fabs[ib], mac_rhs->fabs[ib], SI, SC, A, rg, umax);
-    hipLaunchKernelGGL(kk_mk_D, grid_for(rf), dim3(64, 4, 1), 0, st, s->fabs[ib], sl[0], sl[1], sl[2], um, vm, wm, force->fabs[ib], mac_rhs->fabs[ib], SC,
-                       sedge[0]->fabs[ib], sedge[1]->fabs[ib], sedge[2]->fabs[ib], flux[0]->fabs[ib], flux[1]->fabs[ib], flux[2]->fabs[ib], A, rf, umax);
+    if (plain_godunov()) {
+      hipLaunchKernelGGL(kk_mk_B, grid_for(rg), dim3(64, 4, 1), 0, st, s->fabs[ib], sl[0], sl[1], sl[2], um, vm, wm, force->fabs[ib], mac_rhs->fabs[ib], SI, A, rg, umax);
+      hipLaunchKernelGGL(kk_mk_C, grid_for(rg), dim3(64, 4, 1), 0, st, s->fabs[ib], sl[0], sl[1], sl[2], um, vm, wm, force->fabs[ib], mac_rhs->fabs[ib], SI, SC, A, rg, umax);
+      hipLaunchKernelGGL(kk_mk_D, grid_for(rf), dim3(64, 4, 1), 0, st, s->fabs[ib], sl[0], sl[1], sl[2], um, vm, wm, force->fabs[ib], mac_rhs->fabs[ib], SC,
+                         sedge[0]->fabs[ib], sedge[1]->fabs[ib], sedge[2]->fabs[ib], flux[0]->fabs[ib], flux[1]->fabs[ib], flux[2]->fabs[ib], A, rf, umax);
+    } else {
+      int klg, klf;
+      const dim3 gg = march_grid(rg, klg), gf = march_grid(rf, klf), blk(64, TNY, 1);
+      // components per launch: the 3-component stage D needs more than 256 VGPRs, so it runs one component at a time
+      #define MK_ARGS_B(c0) s->fabs[ib], sl[0], sl[1], sl[2], um, vm, wm, force->fabs[ib], mac_rhs->fabs[ib], SI, A, rg, klg, umax, c0, ncomp
+      #define MK_ARGS_C(c0) s->fabs[ib], sl[0], sl[1], sl[2], um, vm, wm, force->fabs[ib], mac_rhs->fabs[ib], SI, SC, A, rg, klg, umax, c0, ncomp
+      #define MK_ARGS_D(c0) s->fabs[ib], sl[0], sl[1], sl[2], um, vm, wm, force->fabs[ib], mac_rhs->fabs[ib], SC, \
+                            sedge[0]->fabs[ib], sedge[1]->fabs[ib], sedge[2]->fabs[ib], flux[0]->fabs[ib], flux[1]->fabs[ib], flux[2]->fabs[ib], A, rf, klf, umax, c0, ncomp
+      // measured at 256^3: D fused <3> 3.18 ms (61 spilled VGPRs) vs 3 x <1> 2.3 ms; the 2-component scalars are faster fused
+      static const int split_env = getenv("VDN_MK_SPLIT") ? atoi(getenv("VDN_MK_SPLIT")) : -1;   // bit 0: B, 1: C, 2: D per component
+      const int split = split_env >= 0 ? split_env : (ncomp == 3 ? 4 : 0);
+      #define MK_STAGE(K, ARGS, g, bit)                                                                               \
+        if ((split >> bit) & 1) { for (int c0 = 0; c0 < ncomp; c0++) hipLaunchKernelGGL(K<1>, g, blk, 0, st, ARGS(c0)); } \
+        else if (ncomp == 3) hipLaunchKernelGGL(K<3>, g, blk, 0, st, ARGS(0));                                        \
+        else if (ncomp == 2) hipLaunchKernelGGL(K<2>, g, blk, 0, st, ARGS(0));                                        \
+        else hipLaunchKernelGGL(K<1>, g, blk, 0, st, ARGS(0));
+      MK_STAGE(kk_mk_B_m, MK_ARGS_B, gg, 0)
+      MK_STAGE(kk_mk_C_m, MK_ARGS_C, gg, 1)
+      MK_STAGE(kk_mk_D_m, MK_ARGS_D, gf, 2)
+      #undef MK_STAGE
+      #undef MK_ARGS_B
+      #undef MK_ARGS_C
+      #undef MK_ARGS_D
+    }
     arena_release(mark);
   }
 }
@@ -483,6 +847,255 @@ __global__ void __launch_bounds__(256) kk_vp_D(FV u, FV sl0, FV sl1, FV sl2, FV 
   vp_D_one<2>(A, u, sl2, force, UI, XC, wm, i, j, k, eps);
 }
 
+// ---- velpred, cell-centred k-marching form -------------------------------------------------------------------------
+// predictor bases of all three velocity components in a cell along D (vp_pair split by side, no boundary rule)
+template <int D> DEVI void vp_bases(const GArgs &A, const double uc[3], const double sl[3], const double ft[3], double Lb[3], double Rb[3]) {
+  const double dt2 = 0.5 * A.dt;
+  double cfl_l;
+  if (D == 1) cfl_l = dt2 * fmax(0.0, uc[D] / A.dx[1]);       // velpred.f90:2108: division inside max()
+  else cfl_l = dt2 * fmax(0.0, uc[D]) / A.dx[D];
+  const double cfl_r = dt2 * fmin(0.0, uc[D]) / A.dx[D];
+  #pragma unroll
+  for (int c = 0; c < 3; c++) {
+    Lb[c] = uc[c] + (0.5 - cfl_l) * sl[c];
+    Rb[c] = uc[c] - (0.5 + cfl_r) * sl[c];
+    if (A.use_minion) { Lb[c] = Lb[c] + ft[c]; Rb[c] = Rb[c] + ft[c]; }
+  }
+}
+// this cell's half of the boundary rule on component c of its D-bases
+template <int D> DEVI void vp_premod(const GArgs &A, const FV &u, int c, int i, int j, int k, double &Lb, double &Rb) {
+  const int q = coord<D>(i, j, k);
+  if (q == A.lo[D]) { double o = Rb; bc_pair(o, Rb, A.phys[D][0], 0, true, c == D, ld<D>(u, i, j, k, -1, c), false); }
+  if (q == A.hi[D]) { double o = Lb; bc_pair(Lb, o, A.phys[D][1], 1, true, c == D, ld<D>(u, i, j, k, 1, c), D == 0); }   // :2075 quirk
+}
+template <int D> DEVI void vp_face_bc(const GArgs &A, const FV &u, int c, bool normal, bool quirk_ok, int i, int j, int k, double uc, double &L, double &R) {
+  const int side = face_side<D>(A, i, j, k);
+  if (side >= 0) bc_pair(L, R, A.phys[D][side], side, true, normal, side == 0 ? ld<D>(u, i, j, k, -1, c) : uc, quirk_ok && D == 0 && side == 1);
+}
+template <int D> DEVI void vp_B_emit(const FV &UI, int i, int j, int k, const double L[3], const double R[3], double eps) {
+  const double uavg = 0.5 * (L[D] + R[D]);
+  const bool test = ((L[D] <= 0.0 && R[D] >= 0.0) || (fabs(L[D] + R[D]) < eps));
+  double un = (uavg > 0.0) ? L[D] : R[D];
+  un = test ? 0.0 : un;
+  #pragma unroll
+  for (int c = 0; c < 3; c++) {
+    double out;
+    if (c == D) out = un;
+    else {
+      double v = (un > 0.0) ? L[c] : R[c];
+      double av = 0.5 * (L[c] + R[c]);
+      out = (fabs(un) < eps) ? av : v;
+    }
+    fv_at(UI, i, j, k, D * 3 + c) = out;
+  }
+}
+#define VP_LOAD_CELL                                                                                                    \
+    double uc[3], s0[3], s1[3], s2[3], ft[3] = { 0.0, 0.0, 0.0 };                                                         \
+    _Pragma("unroll") for (int c = 0; c < 3; c++) {                                                                      \
+      uc[c] = fv_get(u, ic, jc, kc, c); s0[c] = fv_get(sl0, ic, jc, kc, c); s1[c] = fv_get(sl1, ic, jc, kc, c); s2[c] = fv_get(sl2, ic, jc, kc, c); \
+    }
+
+__global__ void __launch_bounds__(64 * TNY) kk_vp_B_m(FV u, FV sl0, FV sl1, FV sl2, FV force, FV UI, GArgs A, Range3 r, int klen, const double *umax) {
+  __shared__ double ly[2][3][TNY][64];
+  MARCH_SETUP(r)
+  const double eps = eps_from(umax);
+  const double dt2 = 0.5 * A.dt;
+  double Lz[3] = { 0.0, 0.0, 0.0 };
+  for (int k = k0 - 1; k <= k1; k++) {
+    MARCH_PLANE
+    VP_LOAD_CELL
+    if (A.use_minion) {
+      #pragma unroll
+      for (int c = 0; c < 3; c++) ft[c] = dt2 * fv_get(force, ic, jc, kc, c);
+    }
+    double Lb[3][3], Rb[3][3];
+    vp_bases<0>(A, uc, s0, ft, Lb[0], Rb[0]);
+    vp_bases<1>(A, uc, s1, ft, Lb[1], Rb[1]);
+    vp_bases<2>(A, uc, s2, ft, Lb[2], Rb[2]);
+    #pragma unroll
+    for (int c = 0; c < 3; c++) ly[buf][c][row][lane] = Lb[1][c];
+    __syncthreads();
+    double Lx[3], Ly[3], Lzc[3];
+    #pragma unroll
+    for (int c = 0; c < 3; c++) {
+      Lx[c] = shfl_prev(Lb[0][c]);
+      Ly[c] = ly[buf][c][row >= 1 ? row - 1 : 0][lane];
+      Lzc[c] = Lz[c]; Lz[c] = Lb[2][c];
+    }
+    if (emit) {
+      if (edge) {
+        #pragma unroll
+        for (int c = 0; c < 3; c++) {
+          vp_face_bc<0>(A, u, c, c == 0, true, i, j, k, uc[c], Lx[c], Rb[0][c]);
+          vp_face_bc<1>(A, u, c, c == 1, true, i, j, k, uc[c], Ly[c], Rb[1][c]);
+          vp_face_bc<2>(A, u, c, c == 2, true, i, j, k, uc[c], Lzc[c], Rb[2][c]);
+        }
+      }
+      if (i >= A.lo[0]) vp_B_emit<0>(UI, i, j, k, Lx, Rb[0], eps);
+      if (j >= A.lo[1]) vp_B_emit<1>(UI, i, j, k, Ly, Rb[1], eps);
+      if (k >= A.lo[2]) vp_B_emit<2>(UI, i, j, k, Lzc, Rb[2], eps);
+    }
+  }
+}
+
+// stage C: XC(C,D) = component C on D-faces corrected by the third direction O
+DEVI double vp_up(double un, double L, double R, double eps) {
+  const double v = (un > 0.0) ? L : R;
+  const double av = 0.5 * (L + R);
+  return (fabs(un) < eps) ? av : v;
+}
+__global__ void __launch_bounds__(64 * TNY) kk_vp_C_m(FV u, FV sl0, FV sl1, FV sl2, FV force, FV UI, FV XC, GArgs A, Range3 r, int klen, const double *umax) {
+  __shared__ double ly[2][2][TNY][64];
+  MARCH_SETUP(r)
+  const double eps = eps_from(umax);
+  const double dt2 = 0.5 * A.dt, dt6 = A.dt / 6.0;
+  double Lz[2] = { 0.0, 0.0 };
+  for (int k = k0 - 1; k <= k1; k++) {
+    MARCH_PLANE
+    VP_LOAD_CELL
+    // w0[O][c] / w1[O][c]: UI[O*3+c] at the cell's lower / upper O-face
+    double w0[3][3], w1[3][3];
+    #pragma unroll
+    for (int c = 0; c < 3; c++) {
+      w0[0][c] = fv_get(UI, ic, jc, kc, 0 + c); w1[0][c] = fv_get(UI, ip, jc, kc, 0 + c);
+      w0[1][c] = fv_get(UI, ic, jc, kc, 3 + c); w1[1][c] = fv_get(UI, ic, jp, kc, 3 + c);
+      w0[2][c] = fv_get(UI, ic, jc, kc, 6 + c); w1[2][c] = fv_get(UI, ic, jc, kp, 6 + c);
+    }
+    if (A.use_minion) {
+      #pragma unroll
+      for (int c = 0; c < 3; c++) ft[c] = dt2 * fv_get(force, ic, jc, kc, c);
+    }
+    double Lb[3][3], Rb[3][3];
+    vp_bases<0>(A, uc, s0, ft, Lb[0], Rb[0]);
+    vp_bases<1>(A, uc, s1, ft, Lb[1], Rb[1]);
+    vp_bases<2>(A, uc, s2, ft, Lb[2], Rb[2]);
+    if (edge) {
+      #pragma unroll
+      for (int c = 0; c < 3; c++) { vp_premod<0>(A, u, c, ic, jc, kc, Lb[0][c], Rb[0][c]); vp_premod<1>(A, u, c, ic, jc, kc, Lb[1][c], Rb[1][c]); vp_premod<2>(A, u, c, ic, jc, kc, Lb[2][c], Rb[2][c]); }
+    }
+    // t[C][O] = (dt6/dx_O) * (UI[OO](+) + UI[OO]) * (UI[OC](+) - UI[OC])
+    double t[3][3];
+    #pragma unroll
+    for (int O = 0; O < 3; O++) {
+      const double sm = w1[O][O] + w0[O][O];
+      #pragma unroll
+      for (int C = 0; C < 3; C++) t[C][O] = (dt6 / A.dx[O]) * sm * (w1[O][C] - w0[O][C]);
+    }
+    // VL[D][n], VR[D][n]: D = 0: C = 1, 2;  D = 1: C = 0, 2;  D = 2: C = 0, 1
+    double VL[3][2], VR[3][2];
+    VL[0][0] = Lb[0][1] - t[1][2]; VR[0][0] = Rb[0][1] - t[1][2];   // D=0 C=1 O=2
+    VL[0][1] = Lb[0][2] - t[2][1]; VR[0][1] = Rb[0][2] - t[2][1];   // D=0 C=2 O=1
+    VL[1][0] = Lb[1][0] - t[0][2]; VR[1][0] = Rb[1][0] - t[0][2];   // D=1 C=0 O=2
+    VL[1][1] = Lb[1][2] - t[2][0]; VR[1][1] = Rb[1][2] - t[2][0];   // D=1 C=2 O=0
+    VL[2][0] = Lb[2][0] - t[0][1]; VR[2][0] = Rb[2][0] - t[0][1];   // D=2 C=0 O=1
+    VL[2][1] = Lb[2][1] - t[1][0]; VR[2][1] = Rb[2][1] - t[1][0];   // D=2 C=1 O=0
+    ly[buf][0][row][lane] = VL[1][0]; ly[buf][1][row][lane] = VL[1][1];
+    __syncthreads();
+    double L[3][2];
+    L[0][0] = shfl_prev(VL[0][0]); L[0][1] = shfl_prev(VL[0][1]);
+    L[1][0] = ly[buf][0][row >= 1 ? row - 1 : 0][lane]; L[1][1] = ly[buf][1][row >= 1 ? row - 1 : 0][lane];
+    L[2][0] = Lz[0]; L[2][1] = Lz[1];
+    Lz[0] = VL[2][0]; Lz[1] = VL[2][1];
+    if (emit) {
+      if (edge) {
+        vp_face_bc<0>(A, u, 1, false, false, i, j, k, uc[1], L[0][0], VR[0][0]); vp_face_bc<0>(A, u, 2, false, false, i, j, k, uc[2], L[0][1], VR[0][1]);
+        vp_face_bc<1>(A, u, 0, false, false, i, j, k, uc[0], L[1][0], VR[1][0]); vp_face_bc<1>(A, u, 2, false, false, i, j, k, uc[2], L[1][1], VR[1][1]);
+        vp_face_bc<2>(A, u, 0, false, false, i, j, k, uc[0], L[2][0], VR[2][0]); vp_face_bc<2>(A, u, 1, false, false, i, j, k, uc[1], L[2][1], VR[2][1]);
+      }
+      // the advecting normal velocity on the cell's lower faces: UI[DD] = w0[D][D]
+      if (i >= A.lo[0]) { if (vz) fv_at(XC, i, j, k, xc_idx(1, 0)) = vp_up(w0[0][0], L[0][0], VR[0][0], eps); if (vy) fv_at(XC, i, j, k, xc_idx(2, 0)) = vp_up(w0[0][0], L[0][1], VR[0][1], eps); }
+      if (j >= A.lo[1]) { if (vz) fv_at(XC, i, j, k, xc_idx(0, 1)) = vp_up(w0[1][1], L[1][0], VR[1][0], eps); if (vx) fv_at(XC, i, j, k, xc_idx(2, 1)) = vp_up(w0[1][1], L[1][1], VR[1][1], eps); }
+      if (k >= A.lo[2]) { if (vy) fv_at(XC, i, j, k, xc_idx(0, 2)) = vp_up(w0[2][2], L[2][0], VR[2][0], eps); if (vx) fv_at(XC, i, j, k, xc_idx(1, 2)) = vp_up(w0[2][2], L[2][1], VR[2][1], eps); }
+    }
+  }
+}
+
+// stage D: the MAC velocity on valid D-faces
+template <int D> DEVI double vp_D_face(const GArgs &A, const FV &u, int i, int j, int k, double ucD, double L, double R, double eps, bool edge) {
+  const double uavg = 0.5 * (L + R);
+  const bool test = ((L <= 0.0 && R >= 0.0) || (fabs(L + R) < eps));
+  double v = (uavg > 0.0) ? L : R;
+  v = test ? 0.0 : v;
+  if (edge) {
+    const int side = face_side<D>(A, i, j, k);
+    if (side >= 0) {                                   // velpred.f90:2642-2659
+      const int ph = A.phys[D][side];
+      if (ph == VDN_SLIP_WALL || ph == VDN_NO_SLIP_WALL) v = 0.0;
+      else if (ph == VDN_INLET) v = (side == 0) ? ld<D>(u, i, j, k, -1, D) : ucD;
+      else if (ph == VDN_OUTLET) v = (side == 0) ? fmin(R, 0.0) : fmax(L, 0.0);
+    }
+  }
+  return v;
+}
+__global__ void __launch_bounds__(64 * TNY) kk_vp_D_m(FV u, FV sl0, FV sl1, FV sl2, FV force, FV UI, FV XC, FV um, FV vm, FV wm, GArgs A, Range3 r, int klen, const double *umax) {
+  __shared__ double ly[2][TNY][64];
+  MARCH_SETUP(r)
+  const double eps = eps_from(umax);
+  const double dt2 = 0.5 * A.dt, dt4 = A.dt / 4.0;
+  double Lz = 0.0;
+  for (int k = k0 - 1; k <= k1; k++) {
+    MARCH_PLANE
+    double uc[3], sd[3], ft[3];
+    #pragma unroll
+    for (int c = 0; c < 3; c++) { uc[c] = fv_get(u, ic, jc, kc, c); ft[c] = dt2 * fv_get(force, ic, jc, kc, c); }
+    sd[0] = fv_get(sl0, ic, jc, kc, 0); sd[1] = fv_get(sl1, ic, jc, kc, 1); sd[2] = fv_get(sl2, ic, jc, kc, 2);
+    // g[T] = UI[TT](+) + UI[TT];  x0/x1[n]: XC component n at the lower / upper face of its direction
+    //   XC index C*2 + (D > C ? D-1 : D): n 0 = (C0,D1) 1 = (C0,D2) 2 = (C1,D0) 3 = (C1,D2) 4 = (C2,D0) 5 = (C2,D1)
+    double g[3];
+    g[0] = fv_get(UI, ip, jc, kc, 0) + fv_get(UI, ic, jc, kc, 0);
+    g[1] = fv_get(UI, ic, jp, kc, 4) + fv_get(UI, ic, jc, kc, 4);
+    g[2] = fv_get(UI, ic, jc, kp, 8) + fv_get(UI, ic, jc, kc, 8);
+    double x0[6], x1[6];
+    #pragma unroll
+    for (int n = 0; n < 6; n++) x0[n] = fv_get(XC, ic, jc, kc, n);
+    x1[0] = fv_get(XC, ic, jp, kc, 0); x1[1] = fv_get(XC, ic, jc, kp, 1); x1[2] = fv_get(XC, ip, jc, kc, 2);
+    x1[3] = fv_get(XC, ic, jc, kp, 3); x1[4] = fv_get(XC, ip, jc, kc, 4); x1[5] = fv_get(XC, ic, jp, kc, 5);
+    // base of the NORMAL component only (vp_pair component D along D)
+    double Lb[3], Rb[3];
+    #define NBASE(Dd)                                                                                              \
+      { double cl; if (Dd == 1) cl = dt2 * fmax(0.0, uc[Dd] / A.dx[1]); else cl = dt2 * fmax(0.0, uc[Dd]) / A.dx[Dd];  \
+        const double cr = dt2 * fmin(0.0, uc[Dd]) / A.dx[Dd];                                                        \
+        Lb[Dd] = uc[Dd] + (0.5 - cl) * sd[Dd]; Rb[Dd] = uc[Dd] - (0.5 + cr) * sd[Dd];                                \
+        if (A.use_minion) { Lb[Dd] = Lb[Dd] + ft[Dd]; Rb[Dd] = Rb[Dd] + ft[Dd]; } }
+    NBASE(0) NBASE(1) NBASE(2)
+    #undef NBASE
+    if (edge) { vp_premod<0>(A, u, 0, ic, jc, kc, Lb[0], Rb[0]); vp_premod<1>(A, u, 1, ic, jc, kc, Lb[1], Rb[1]); vp_premod<2>(A, u, 2, ic, jc, kc, Lb[2], Rb[2]); }
+    double VL[3], VR[3];
+    {   // D = 0: T1 = 1 with XC(0,1) = n0,  T2 = 2 with XC(0,2) = n1
+      const double a1 = (dt4 / A.dx[1]) * g[1] * (x1[0] - x0[0]);
+      const double a2 = (dt4 / A.dx[2]) * g[2] * (x1[1] - x0[1]);
+      double vl = Lb[0] - a1 - a2, vr = Rb[0] - a1 - a2;
+      if (!A.use_minion) { vl = vl + ft[0]; vr = vr + ft[0]; }
+      VL[0] = vl; VR[0] = vr;
+    }
+    {   // D = 1: T1 = 0 with XC(1,0) = n2,  T2 = 2 with XC(1,2) = n3
+      const double a1 = (dt4 / A.dx[0]) * g[0] * (x1[2] - x0[2]);
+      const double a2 = (dt4 / A.dx[2]) * g[2] * (x1[3] - x0[3]);
+      double vl = Lb[1] - a1 - a2, vr = Rb[1] - a1 - a2;
+      if (!A.use_minion) { vl = vl + ft[1]; vr = vr + ft[1]; }
+      VL[1] = vl; VR[1] = vr;
+    }
+    {   // D = 2: T1 = 0 with XC(2,0) = n4,  T2 = 1 with XC(2,1) = n5
+      const double a1 = (dt4 / A.dx[0]) * g[0] * (x1[4] - x0[4]);
+      const double a2 = (dt4 / A.dx[1]) * g[1] * (x1[5] - x0[5]);
+      double vl = Lb[2] - a1 - a2, vr = Rb[2] - a1 - a2;
+      if (!A.use_minion) { vl = vl + ft[2]; vr = vr + ft[2]; }
+      VL[2] = vl; VR[2] = vr;
+    }
+    ly[buf][row][lane] = VL[1];
+    __syncthreads();
+    const double Lx = shfl_prev(VL[0]);
+    const double Ly = ly[buf][row >= 1 ? row - 1 : 0][lane];
+    const double Lzc = Lz;
+    Lz = VL[2];
+    if (emit) {
+      if (vy && vz) fv_at(um, i, j, k) = vp_D_face<0>(A, u, i, j, k, uc[0], Lx, VR[0], eps, edge);
+      if (vx && vz) fv_at(vm, i, j, k) = vp_D_face<1>(A, u, i, j, k, uc[1], Ly, VR[1], eps, edge);
+      if (vx && vy) fv_at(wm, i, j, k) = vp_D_face<2>(A, u, i, j, k, uc[2], Lzc, VR[2], eps, edge);
+    }
+  }
+}
+
 void k_velpred(const vdn_multifab *u, vdn_multifab **umac, const vdn_multifab *force, const double *dx, double dt,
                const vdn_bc_tower *bct) {
   REQUIRE(u->nc == 3 && u->ng >= 3 && force->ng >= 1 && umac[0]->ng >= 1, "velpred: operand shapes");
@@ -504,10 +1117,19 @@ void k_velpred(const vdn_multifab *u, vdn_multifab **umac, const vdn_multifab *f
     for (int d = 0; d < 3; d++) { rv.lo[d] = A.lo[d]; rv.hi[d] = A.hi[d]; rg.lo[d] = A.lo[d] - 1; rg.hi[d] = A.hi[d] + 1; rf.lo[d] = A.lo[d]; rf.hi[d] = A.hi[d] + 1; }
     hipLaunchKernelGGL(kk_velmax, reduce_grid(rv), dim3(64, 4, 1), 0, st, u->fabs[ib], rv, umax);
     hipLaunchKernelGGL(kk_slopes, grid_for(rg), dim3(64, 4, 1), 0, st, u->fabs[ib], sl[0], sl[1], sl[2], A, rg, 7);
-    hipLaunchKernelGGL(kk_vp_B, grid_for(rg), dim3(64, 4, 1), 0, st, u->fabs[ib], sl[0], sl[1], sl[2], force->fabs[ib], UI, A, rg, umax);
-    hipLaunchKernelGGL(kk_vp_C, grid_for(rg), dim3(64, 4, 1), 0, st, u->fabs[ib], sl[0], sl[1], sl[2], force->fabs[ib], UI, XC, A, rg, umax);
-    hipLaunchKernelGGL(kk_vp_D, grid_for(rf), dim3(64, 4, 1), 0, st, u->fabs[ib], sl[0], sl[1], sl[2], force->fabs[ib], UI, XC,
-                       umac[0]->fabs[ib], umac[1]->fabs[ib], umac[2]->fabs[ib], A, rf, umax);
+    if (plain_godunov()) {
+      hipLaunchKernelGGL(kk_vp_B, grid_for(rg), dim3(64, 4, 1), 0, st, u->fabs[ib], sl[0], sl[1], sl[2], force->fabs[ib], UI, A, rg, umax);
+      hipLaunchKernelGGL(kk_vp_C, grid_for(rg), dim3(64, 4, 1), 0, st, u->fabs[ib], sl[0], sl[1], sl[2], force->fabs[ib], UI, XC, A, rg, umax);
+      hipLaunchKernelGGL(kk_vp_D, grid_for(rf), dim3(64, 4, 1), 0, st, u->fabs[ib], sl[0], sl[1], sl[2], force->fabs[ib], UI, XC,
+                         umac[0]->fabs[ib], umac[1]->fabs[ib], umac[2]->fabs[ib], A, rf, umax);
+    } else {
+      int klg, klf;
+      const dim3 gg = march_grid(rg, klg), gf = march_grid(rf, klf), blk(64, TNY, 1);
+      hipLaunchKernelGGL(kk_vp_B_m, gg, blk, 0, st, u->fabs[ib], sl[0], sl[1], sl[2], force->fabs[ib], UI, A, rg, klg, umax);
+      hipLaunchKernelGGL(kk_vp_C_m, gg, blk, 0, st, u->fabs[ib], sl[0], sl[1], sl[2], force->fabs[ib], UI, XC, A, rg, klg, umax);
+      hipLaunchKernelGGL(kk_vp_D_m, gf, blk, 0, st, u->fabs[ib], sl[0], sl[1], sl[2], force->fabs[ib], UI, XC,
+                         umac[0]->fabs[ib], umac[1]->fabs[ib], umac[2]->fabs[ib], A, rf, klf, umax);
+    }
     arena_release(mark);
   }
 }
