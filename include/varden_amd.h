@@ -54,8 +54,8 @@ typedef struct vdn_params {
   int    verbose;
   int    mg_verbose;
   int    prob_type;       /* only used for the hgproject abs-eps special case (prob_type 4)   */
-  double visc_coef;       /* must be 0 in this round (viscous solve is a "next" row)          */
-  double diff_coef;       /* must be 0 in this round                                          */
+  double visc_coef;       /* >= 0; > 0 enables the viscous solve (viscsolve.f90:19-306)          */
+  double diff_coef;       /* >= 0; > 0 enables diff_scalar_solve (viscsolve.f90:308-515)        */
   double cflfac;          /* 0.8                                                              */
   double max_dt_growth;   /* 1.1                                                              */
   /* inflow data used by multifab_physbc EXT_DIR fills: [dir][side]                           */

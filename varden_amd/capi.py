@@ -29,7 +29,7 @@ class Params(C.Structure):
 
 def default_params(**kw):
     """reference defaults (src/_parameters:10-92) + our multigrid controls; keep in sync with
-    vdn_params_default() in varden_amd/csrc/runtime.cpp (tests/test_capi_cpu.py checks it)."""
+    vdn_params_default() in varden_amd/csrc/runtime.hip (tests/test_capi_cpu.py checks it)."""
     p = Params()
     p.dm = 3; p.nscal = 2; p.slope_order = 4; p.use_minion = 0; p.boussinesq = 0
     p.stencil_order = 2; p.diffusion_type = 1; p.verbose = 0; p.mg_verbose = 0; p.prob_type = 1
