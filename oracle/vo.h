@@ -37,21 +37,30 @@ typedef struct vo_fab {
   int nc;
   long n[3];          /* allocated extents */
   long sc;            /* component stride */
+  int gz;             /* ghost width along z (= ng in 3-D, 0 for the one-plane fabs of a 2-D run) */
+  int dm;             /* 2 or 3 */
 } vo_fab;
 
 static inline void vo_fab_init(vo_fab *f, double *p, const int *lo, const int *hi, int ng,
                                const int *nd, int nc) {
-  f->p = p; f->ng = ng; f->nc = nc;
+  f->p = p; f->ng = ng; f->nc = nc; f->gz = ng; f->dm = 3;
   for (int d = 0; d < 3; d++) {
     f->lo[d] = lo[d]; f->hi[d] = hi[d]; f->nd[d] = nd ? nd[d] : 0;
     f->n[d] = hi[d] - lo[d] + 1 + f->nd[d] + 2 * ng;
   }
   f->sc = f->n[0] * f->n[1] * f->n[2];
 }
+/* a fab of a 2-D run: BoxLib layout p(lo1-ng:hi1+ng, lo2-ng:hi2+ng, nc) held as one z-plane (lo[2] = hi[2] = 0) */
+static inline void vo_fab_init2d(vo_fab *f, double *p, const int *lo, const int *hi, int ng, const int *nd, int nc) {
+  f->p = p; f->ng = ng; f->nc = nc; f->gz = 0; f->dm = 2;
+  for (int d = 0; d < 3; d++) { f->lo[d] = d < 2 ? lo[d] : 0; f->hi[d] = d < 2 ? hi[d] : 0; f->nd[d] = (nd && d < 2) ? nd[d] : 0; }
+  f->n[0] = f->hi[0] - f->lo[0] + 1 + f->nd[0] + 2 * ng; f->n[1] = f->hi[1] - f->lo[1] + 1 + f->nd[1] + 2 * ng; f->n[2] = 1;
+  f->sc = f->n[0] * f->n[1];
+}
 static inline long vo_size(const vo_fab *f) { return f->sc * f->nc; }
 static inline long vo_idx(const vo_fab *f, int i, int j, int k, int c) {
   return (long)(i - f->lo[0] + f->ng) + f->n[0] * ((long)(j - f->lo[1] + f->ng) +
-         f->n[1] * (long)(k - f->lo[2] + f->ng)) + f->sc * c;
+         f->n[1] * (long)(k - f->lo[2] + f->gz)) + f->sc * c;
 }
 #define VF(f, i, j, k, c) ((f)->p[vo_idx((f), (i), (j), (k), (c))])
 
@@ -157,6 +166,31 @@ void vo_advance_timestep(vo_state *S, const double dx[3], double dt, const vo_bc
 
 /* ---- initdata.f90:201-311 (prob_type 1 and 2) ----------------------------------------------- */
 void vo_initdata(vo_fab *u, vo_fab *s, const double dx[3], int prob_type);
+
+/* ---- the 2-D path (oracle/vo_2d.c): velpred_2d, mkflux_2d, update_2d, mkforce 2-D, estdt_2d, macproject / hgproject
+ *      2-D kernels, our 5-point cell-centred and 9-point nodal multigrids, advance_timestep with dm = 2 ------------ */
+#define V2(f, i, j, c) VF(f, i, j, 0, c)
+void vo2_velpred(const vo_fab *u, vo_fab *umac[2], const vo_fab *force, const double dx[2], double dt, const vo_bc *bc, const vdn_params *prm);
+void vo2_mkflux(const vo_fab *s, vo_fab *sedge[2], vo_fab *flux[2], vo_fab *umac[2], const vo_fab *force, const vo_fab *mac_rhs,
+                const double dx[2], double dt, int is_vel, const int *is_cons, int bccomp, const vo_bc *bc, const vdn_params *prm);
+void vo2_update(const vo_fab *sold, vo_fab *umac[2], vo_fab *sedge[2], vo_fab *flux[2], const vo_fab *force, vo_fab *snew,
+                const double dx[2], double dt, int is_vel, const int *is_cons);
+void vo2_mkvelforce(vo_fab *vf, const vo_fab *ext, const vo_fab *gp, const vo_fab *s, const vo_fab *lapu, double visc_fac, const vdn_params *prm);
+void vo2_mkscalforce(vo_fab *sf, const vo_fab *ext, const vo_fab *laps, double diff_fac, const vdn_params *prm);
+double vo2_estdt(const vo_fab *u, const vo_fab *s, const vo_fab *gp, const vo_fab *ext, const double dx[2], double dtold, const vdn_params *prm);
+int  vo2_cc_solve(const vo_fab *rh, vo_fab *phi, const vo_fab *alpha, vo_fab *beta[2], const double dx[2], const int ellbc[3][2],
+                  double rel_eps, double abs_eps, int max_iter, int nu1, int nu2, int nub, vo_mgstat *st);
+void vo2_macproject(vo_fab *umac[2], vo_fab *rho, const vo_fab *mac_rhs, const double dx[2], const vo_bc *bc, const int pmask[3],
+                    const vdn_params *prm, vo_mgstat *st);
+int  vo2_nd_solve(vo_fab *rh, vo_fab *phi, const vo_fab *coeffs, const vo_fab *u, const double dx[2], const int ellbc[3][2], const int pmask[3],
+                  double rel_eps, double abs_eps, int max_iter, int nu1, int nu2, int nub, double omega, vo_mgstat *st);
+void vo2_hgproject(int proj_type, vo_fab *unew, const vo_fab *uold, vo_fab *rhohalf, vo_fab *p, vo_fab *gp, const double dx[2], double dt,
+                   const vo_bc *bc, const int pmask[3], const vdn_params *prm, vo_mgstat *st);
+void vo2_explicit_diffusive_term(vo_fab *lap, const vo_fab *data, int comp, int bccomp, const double dx[2], const vo_bc *bc);
+void vo2_advance_timestep(vo_state *S, const double dx[2], double dt, const vo_bc *bc, const int pmask[3], const vdn_params *prm,
+                          int proj_type, vo_mgstat st[2], double phase_sec[4]);
+void vo2_initdata(vo_fab *u, vo_fab *s, const double dx[2], int prob_type);
+
 
 #ifdef __cplusplus
 }

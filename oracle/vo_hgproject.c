@@ -111,15 +111,17 @@ typedef struct ndlev {
   double *res;           /* residual b - K phi, with ghost layer                           */
   double *sig;           /* cells with one ghost layer: (n+2)^3                            */
   unsigned char *dir;    /* Dirichlet mask on nodes (no ghost)                             */
+  int dm;                /* 2: one plane of nodes (n[2] = 0), 9-point Q1 operator, f_d = 1/(6 h_d^2) */
 } ndlev;
 
 #define NN(L, i, j, k) (((i) + 1) + (long)((L)->n[0] + 3) * (((j) + 1) + (long)((L)->n[1] + 3) * ((k) + 1)))
 #define NS(L, i, j, k) (((i) + 1) + (long)((L)->n[0] + 2) * (((j) + 1) + (long)((L)->n[1] + 2) * ((k) + 1)))
 #define NM(L, i, j, k) ((i) + (long)((L)->n[0] + 1) * ((j) + (long)((L)->n[1] + 1) * (k)))
 
-static void nd_alloc(ndlev *L, const int n[3], const double h[3])
+static void nd_alloc(ndlev *L, const int n[3], const double h[3], int dm)
 {
-  for (int d = 0; d < 3; d++) { L->n[d] = n[d]; L->h[d] = h[d]; L->f[d] = 1.0 / (36.0 * (h[d] * h[d])); }
+  L->dm = dm;
+  for (int d = 0; d < 3; d++) { L->n[d] = n[d]; L->h[d] = h[d]; L->f[d] = (dm == 2) ? 1.0 / (6.0 * (h[d] * h[d])) : 1.0 / (36.0 * (h[d] * h[d])); }
   long nn = (long)(n[0] + 3) * (n[1] + 3) * (n[2] + 3), ns = (long)(n[0] + 2) * (n[1] + 2) * (n[2] + 2);
   L->phi = (double *)calloc(nn, sizeof(double)); L->tmp = (double *)calloc(nn, sizeof(double));
   L->b = (double *)calloc(nn, sizeof(double));   L->res = (double *)calloc(nn, sizeof(double));
@@ -132,9 +134,10 @@ static void nd_free(ndlev *L) { free(L->phi); free(L->tmp); free(L->b); free(L->
 static void nd_fill_nodes(const ndlev *L, double *a, const int per[3])
 {
   const int *n = L->n;
-  for (int k = -1; k <= n[2] + 1; k++) for (int j = -1; j <= n[1] + 1; j++) for (int i = -1; i <= n[0] + 1; i++) {
+  const int k0 = L->dm == 2 ? 0 : -1, k1 = L->dm == 2 ? 0 : n[2] + 1;
+  for (int k = k0; k <= k1; k++) for (int j = -1; j <= n[1] + 1; j++) for (int i = -1; i <= n[0] + 1; i++) {
     int q[3] = { i, j, k }, s[3] = { i, j, k }, g = 0, zero = 0;
-    for (int d = 0; d < 3; d++) {
+    for (int d = 0; d < L->dm; d++) {
       if (per[d]) { if (q[d] < 0) { s[d] = q[d] + n[d]; g = 1; } else if (q[d] >= n[d]) { s[d] = q[d] - n[d]; g = 1; } }
       else if (q[d] < 0 || q[d] > n[d]) { g = 1; zero = 1; }
     }
@@ -144,9 +147,10 @@ static void nd_fill_nodes(const ndlev *L, double *a, const int per[3])
 static void nd_fill_cells(const ndlev *L, double *a, const int per[3])
 {
   const int *n = L->n;
-  for (int k = -1; k <= n[2]; k++) for (int j = -1; j <= n[1]; j++) for (int i = -1; i <= n[0]; i++) {
+  const int k0 = L->dm == 2 ? 0 : -1, k1 = L->dm == 2 ? 0 : n[2];
+  for (int k = k0; k <= k1; k++) for (int j = -1; j <= n[1]; j++) for (int i = -1; i <= n[0]; i++) {
     int q[3] = { i, j, k }, s[3] = { i, j, k }, g = 0, zero = 0;
-    for (int d = 0; d < 3; d++) {
+    for (int d = 0; d < L->dm; d++) {
       if (q[d] < 0) { g = 1; if (per[d]) s[d] = q[d] + n[d]; else zero = 1; }
       else if (q[d] >= n[d]) { g = 1; if (per[d]) s[d] = q[d] - n[d]; else zero = 1; }
     }
@@ -158,6 +162,27 @@ static void nd_fill_cells(const ndlev *L, double *a, const int per[3])
  * cells in the order (ck,cj,ci) ascending; inside a cell corners (mz,my,mx) ascending. */
 static inline void nd_apply(const ndlev *L, const double *phi, int i, int j, int k, double *Kp, double *diag)
 {
+  if (L->dm == 2) {
+    /* bilinear (Q1) elements in 2-D, equations scaled by 1/(hx hy): weights by which coordinates differ,
+     * w = 2(fx+fy) (same node), -2fx+fy (x differs), fx-2fy (y differs), -(fx+fy) (both), f_d = 1/(6 h_d^2) */
+    const double fx = L->f[0], fy = L->f[1];
+    double w[4];
+    w[0] = 2.0 * (fx + fy); w[1] = -2.0 * fx + fy; w[2] = fx - 2.0 * fy; w[3] = -(fx + fy);
+    double acc = 0.0, ssum = 0.0;
+    for (int cj = j - 1; cj <= j; cj++) for (int ci = i - 1; ci <= i; ci++) {
+      double sg = L->sig[NS(L, ci, cj, 0)];
+      double t = 0.0;
+      for (int my = 0; my < 2; my++) for (int mx = 0; mx < 2; mx++) {
+        int ni = ci + mx, nj = cj + my;
+        int idx = (ni != i) | ((nj != j) << 1);
+        t = t + w[idx] * phi[NN(L, ni, nj, 0)];
+      }
+      acc = acc + sg * t;
+      ssum = ssum + sg;
+    }
+    *Kp = acc; *diag = w[0] * ssum;
+    return;
+  }
   const double fx = L->f[0], fy = L->f[1], fz = L->f[2];
   const double F = fx + fy + fz;
   /* weight by which coordinates differ: index bit0=x differs, bit1=y, bit2=z */
@@ -229,6 +254,13 @@ static void nd_restrict(const ndlev *Fv, ndlev *C)
   #pragma omp parallel for
   for (int k = 0; k <= n[2]; k++) for (int j = 0; j <= n[1]; j++) for (int i = 0; i <= n[0]; i++) {
     double s = 0.0;
+    if (C->dm == 2) {                        /* full weighting in the plane: P^T / 4 */
+      if (!C->dir[NM(C, i, j, k)])
+        for (int b = -1; b <= 1; b++) for (int a = -1; a <= 1; a++)
+          s = s + (wt[a + 1] * wt[b + 1]) * Fv->res[NN(Fv, 2 * i + a, 2 * j + b, 0)];
+      C->b[NN(C, i, j, k)] = s * 0.25;
+      continue;
+    }
     if (!C->dir[NM(C, i, j, k)])
       for (int c = -1; c <= 1; c++) for (int b = -1; b <= 1; b++) for (int a = -1; a <= 1; a++)
         s = s + (wt[a + 1] * wt[b + 1] * wt[c + 1]) * Fv->res[NN(Fv, 2 * i + a, 2 * j + b, 2 * k + c)];
@@ -254,8 +286,13 @@ static void nd_prolong_add(ndlev *Fv, const ndlev *C)
 static void nd_coarsen_sigma(const ndlev *Fv, ndlev *C, const int per[3])
 {
   const int *n = C->n;
-  for (int k = 0; k < n[2]; k++) for (int j = 0; j < n[1]; j++) for (int i = 0; i < n[0]; i++) {
+  for (int k = 0; k < (C->dm == 2 ? 1 : n[2]); k++) for (int j = 0; j < n[1]; j++) for (int i = 0; i < n[0]; i++) {
     double s = 0.0;
+    if (C->dm == 2) {
+      for (int b = 0; b < 2; b++) for (int a = 0; a < 2; a++) s = s + Fv->sig[NS(Fv, 2 * i + a, 2 * j + b, 0)];
+      C->sig[NS(C, i, j, k)] = s * 0.25;
+      continue;
+    }
     for (int c = 0; c < 2; c++) for (int b = 0; b < 2; b++) for (int a = 0; a < 2; a++)
       s = s + Fv->sig[NS(Fv, 2 * i + a, 2 * j + b, 2 * k + c)];
     C->sig[NS(C, i, j, k)] = s * 0.125;
@@ -268,7 +305,7 @@ static void nd_set_mask(ndlev *L, const int ellbc[3][2])
   const int *n = L->n;
   for (int k = 0; k <= n[2]; k++) for (int j = 0; j <= n[1]; j++) for (int i = 0; i <= n[0]; i++) {
     int q[3] = { i, j, k }, dflag = 0;
-    for (int d = 0; d < 3; d++) {
+    for (int d = 0; d < L->dm; d++) {
       if (q[d] == 0 && ellbc[d][0] == VDN_BC_DIR) dflag = 1;
       if (q[d] == n[d] && ellbc[d][1] == VDN_BC_DIR) dflag = 1;
     }
@@ -281,7 +318,7 @@ typedef struct ndmg { int nlev; ndlev lev[32]; int per[3]; } ndmg;
 /* Jacobi sweeps on the coarsest level: max(nub, 2 N^2), N = its largest extent (see cc_bottom_sweeps) */
 static int nd_bottom_sweeps(const ndlev *L, int nub)
 {
-  int N = L->n[0] > L->n[1] ? L->n[0] : L->n[1]; if (L->n[2] > N) N = L->n[2];
+  int N = L->n[0] > L->n[1] ? L->n[0] : L->n[1]; if (L->dm == 3 && L->n[2] > N) N = L->n[2];
   return nub > 2 * N * N ? nub : 2 * N * N;
 }
 
@@ -304,6 +341,15 @@ static void nd_vcycle(ndmg *M, int l, int nu1, int nu2, int nub, double omega)
 void vo_nd_divu(const vo_fab *u, vo_fab *rh, const double dx[3], const int ellbc[3][2])
 {
   const int *lo = u->lo, *hi = u->hi;
+  if (u->dm == 2) {      /* (D u)_n = ([u_d over the 2 cells on the + side] - [- side]) * 0.5/h_d */
+    double gx = 0.5 / dx[0], gy = 0.5 / dx[1];
+    for (int j = lo[1]; j <= hi[1] + 1; j++) for (int i = lo[0]; i <= hi[0] + 1; i++) {
+      double dux = (V2(u, i, j, 0) + V2(u, i, j - 1, 0)) - (V2(u, i - 1, j, 0) + V2(u, i - 1, j - 1, 0));
+      double duy = (V2(u, i, j, 1) + V2(u, i - 1, j, 1)) - (V2(u, i, j - 1, 1) + V2(u, i - 1, j - 1, 1));
+      V2(rh, i, j, 0) = V2(rh, i, j, 0) + (dux * gx + duy * gy);
+    }
+    return;
+  }
   double fx = 0.25 / dx[0], fy = 0.25 / dx[1], fz = 0.25 / dx[2];
   (void)ellbc;
   #pragma omp parallel for
@@ -326,20 +372,22 @@ int vo_nd_solve(vo_fab *rh, vo_fab *phi, const vo_fab *coeffs, const vo_fab *u, 
 {
   ndmg M; M.nlev = 0;
   int n[3]; double h[3];
-  for (int d = 0; d < 3; d++) { n[d] = coeffs->hi[d] - coeffs->lo[d] + 1; h[d] = dx[d]; M.per[d] = pmask[d]; }
+  const int dm = coeffs->dm;
+  for (int d = 0; d < 3; d++) { n[d] = coeffs->hi[d] - coeffs->lo[d] + 1; h[d] = dx[d]; M.per[d] = (d < dm) && pmask[d]; }
+  if (dm == 2) { n[2] = 0; h[2] = 1.0; }
   for (;;) {
     ndlev *L = &M.lev[M.nlev];
-    nd_alloc(L, n, h);
+    nd_alloc(L, n, h, dm);
     nd_set_mask(L, ellbc);
     if (M.nlev == 0) {
-      for (int k = -1; k <= n[2]; k++) for (int j = -1; j <= n[1]; j++) for (int i = -1; i <= n[0]; i++)
+      for (int k = (dm == 2 ? 0 : -1); k <= (dm == 2 ? 0 : n[2]); k++) for (int j = -1; j <= n[1]; j++) for (int i = -1; i <= n[0]; i++)
         L->sig[NS(L, i, j, k)] = VF(coeffs, coeffs->lo[0] + i, coeffs->lo[1] + j, coeffs->lo[2] + k, 0);
     } else nd_coarsen_sigma(&M.lev[M.nlev - 1], L, M.per);
     M.nlev++;
     int can = 1;
-    for (int d = 0; d < 3; d++) if ((n[d] & 1) || n[d] <= 2) can = 0;
+    for (int d = 0; d < dm; d++) if ((n[d] & 1) || n[d] <= 2) can = 0;
     if (!can || M.nlev >= 31) break;
-    for (int d = 0; d < 3; d++) { n[d] /= 2; h[d] *= 2.0; }
+    for (int d = 0; d < dm; d++) { n[d] /= 2; h[d] *= 2.0; }
   }
   ndlev *L0 = &M.lev[0];
   const int *n0 = L0->n;
@@ -369,7 +417,7 @@ int vo_nd_solve(vo_fab *rh, vo_fab *phi, const vo_fab *coeffs, const vo_fab *u, 
     cyc++;
   }
   nd_fill_nodes(L0, L0->phi, M.per);
-  for (int k = -1; k <= n0[2] + 1; k++) for (int j = -1; j <= n0[1] + 1; j++) for (int i = -1; i <= n0[0] + 1; i++)
+  for (int k = (dm == 2 ? 0 : -1); k <= (dm == 2 ? 0 : n0[2] + 1); k++) for (int j = -1; j <= n0[1] + 1; j++) for (int i = -1; i <= n0[0] + 1; i++)
     VF(phi, phi->lo[0] + i, phi->lo[1] + j, phi->lo[2] + k, 0) = L0->phi[NN(L0, i, j, k)];
   if (st) { st->cycles = cyc; st->res0 = bnorm; st->res = rn; }
   for (int l = 0; l < M.nlev; l++) nd_free(&M.lev[l]);

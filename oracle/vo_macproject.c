@@ -80,6 +80,7 @@ typedef struct cclev {
   double *res;           /* n^3 */
   double *b[3];          /* face coefficients, (n+e_d) extents, bc-modified */
   double *alpha;         /* cell coefficient of the (alpha - div b grad) operator, NULL when alpha = 0 */
+  int dm;                /* 2: one z-plane (n[2] = 1), b[2] = 0, no coarsening along z -> the 5-point operator */
 } cclev;
 
 #define PHI(L, i, j, k) (L)->phi[((i) + 1) + ((L)->n[0] + 2) * (((j) + 1) + (long)((L)->n[1] + 2) * ((k) + 1))]
@@ -99,7 +100,7 @@ static void cc_alloc(cclev *L, const int n[3], const double h[3])
     long nf = 1; for (int t = 0; t < 3; t++) nf *= (n[t] + (t == d));
     L->b[d] = (double *)calloc(nf, sizeof(double));
   }
-  L->alpha = NULL;
+  L->alpha = NULL; L->dm = 3;
 }
 static void cc_free(cclev *L) { free(L->phi); free(L->rh); free(L->res); for (int d = 0; d < 3; d++) free(L->b[d]); free(L->alpha); }
 
@@ -170,6 +171,11 @@ static void cc_restrict(const cclev *F, cclev *C)
   #pragma omp parallel for
   for (int k = 0; k < n[2]; k++) for (int j = 0; j < n[1]; j++) for (int i = 0; i < n[0]; i++) {
     int I = 2 * i, J = 2 * j, K = 2 * k;
+    if (C->dm == 2) {                        /* 4-cell average */
+      double s = CC(F, F->res, I, J, 0) + CC(F, F->res, I + 1, J, 0) + CC(F, F->res, I, J + 1, 0) + CC(F, F->res, I + 1, J + 1, 0);
+      CC(C, C->rh, i, j, k) = s * 0.25;
+      continue;
+    }
     double s = CC(F, F->res, I, J, K) + CC(F, F->res, I + 1, J, K) + CC(F, F->res, I, J + 1, K) + CC(F, F->res, I + 1, J + 1, K)
              + CC(F, F->res, I, J, K + 1) + CC(F, F->res, I + 1, J, K + 1) + CC(F, F->res, I, J + 1, K + 1) + CC(F, F->res, I + 1, J + 1, K + 1);
     CC(C, C->rh, i, j, k) = s * 0.125;
@@ -187,6 +193,11 @@ static void cc_prolong_add(cclev *F, const cclev *C)
 static void cc_coarsen_coeffs(const cclev *F, cclev *C)
 {
   const int *n = C->n;
+  if (C->dm == 2) {                          /* coarse face coefficient = mean of the 2 fine faces */
+    for (int j = 0; j < n[1]; j++) for (int i = 0; i <= n[0]; i++) BX(C, i, j, 0) = (BX(F, 2 * i, 2 * j, 0) + BX(F, 2 * i, 2 * j + 1, 0)) * 0.5;
+    for (int j = 0; j <= n[1]; j++) for (int i = 0; i < n[0]; i++) BY(C, i, j, 0) = (BY(F, 2 * i, 2 * j, 0) + BY(F, 2 * i + 1, 2 * j, 0)) * 0.5;
+    return;
+  }
   for (int k = 0; k < n[2]; k++) for (int j = 0; j < n[1]; j++) for (int i = 0; i <= n[0]; i++)
     BX(C, i, j, k) = (BX(F, 2 * i, 2 * j, 2 * k) + BX(F, 2 * i, 2 * j + 1, 2 * k) + BX(F, 2 * i, 2 * j, 2 * k + 1) + BX(F, 2 * i, 2 * j + 1, 2 * k + 1)) * 0.25;
   for (int k = 0; k < n[2]; k++) for (int j = 0; j <= n[1]; j++) for (int i = 0; i < n[0]; i++)
@@ -201,14 +212,16 @@ static void ccmg_build(ccmg *M, const vo_fab *alpha, vo_fab *beta[3], const doub
 {
   const vo_fab *b0 = beta[0];
   int n[3]; double h[3];
-  for (int d = 0; d < 3; d++) { n[d] = b0->hi[d] - b0->lo[d] + 1; h[d] = dx[d]; M->per[d] = (ellbc[d][0] == VDN_BC_PER); }
+  const int dm = b0->dm;
+  for (int d = 0; d < 3; d++) { n[d] = b0->hi[d] - b0->lo[d] + 1; h[d] = dx[d]; M->per[d] = (d < dm) && (ellbc[d][0] == VDN_BC_PER); }
+  if (dm == 2) { n[2] = 1; h[2] = 1.0; }
   M->nlev = 0;
   for (;;) {
     cclev *L = &M->lev[M->nlev];
-    cc_alloc(L, n, h);
+    cc_alloc(L, n, h); L->dm = dm;
     if (M->nlev == 0) {
       /* copy beta with the boundary modification */
-      for (int d = 0; d < 3; d++) {
+      for (int d = 0; d < dm; d++) {
         const vo_fab *bf = beta[d];
         int e[3] = { n[0], n[1], n[2] }; e[d] += 1;
         for (int k = 0; k < e[2]; k++) for (int j = 0; j < e[1]; j++) for (int i = 0; i < e[0]; i++) {
@@ -231,6 +244,7 @@ static void ccmg_build(ccmg *M, const vo_fab *alpha, vo_fab *beta[3], const doub
         else {
           const cclev *F = &M->lev[M->nlev - 1];
           int I = 2 * i, J = 2 * j, K = 2 * k;
+          if (dm == 2) { CC(L, L->alpha, i, j, k) = (CC(F, F->alpha, I, J, 0) + CC(F, F->alpha, I + 1, J, 0) + CC(F, F->alpha, I, J + 1, 0) + CC(F, F->alpha, I + 1, J + 1, 0)) * 0.25; continue; }
           double sum = CC(F, F->alpha, I, J, K) + CC(F, F->alpha, I + 1, J, K) + CC(F, F->alpha, I, J + 1, K) + CC(F, F->alpha, I + 1, J + 1, K)
                      + CC(F, F->alpha, I, J, K + 1) + CC(F, F->alpha, I + 1, J, K + 1) + CC(F, F->alpha, I, J + 1, K + 1) + CC(F, F->alpha, I + 1, J + 1, K + 1);
           CC(L, L->alpha, i, j, k) = sum * 0.125;
@@ -239,9 +253,9 @@ static void ccmg_build(ccmg *M, const vo_fab *alpha, vo_fab *beta[3], const doub
     }
     M->nlev++;
     int can = 1;
-    for (int d = 0; d < 3; d++) if ((n[d] & 1) || n[d] <= 2) can = 0;
+    for (int d = 0; d < dm; d++) if ((n[d] & 1) || n[d] <= 2) can = 0;
     if (!can || M->nlev >= 31) break;
-    for (int d = 0; d < 3; d++) { n[d] /= 2; h[d] *= 2.0; }
+    for (int d = 0; d < dm; d++) { n[d] /= 2; h[d] *= 2.0; }
   }
 }
 static void ccmg_free(ccmg *M) { for (int l = 0; l < M->nlev; l++) cc_free(&M->lev[l]); }
@@ -253,7 +267,7 @@ static void ccmg_free(ccmg *M) { for (int l = 0; l < M->nlev; l++) cc_free(&M->l
  * mac_multigrid.f90:56) */
 static int cc_bottom_sweeps(const cclev *L, int nub)
 {
-  int N = L->n[0] > L->n[1] ? L->n[0] : L->n[1]; if (L->n[2] > N) N = L->n[2];
+  int N = L->n[0] > L->n[1] ? L->n[0] : L->n[1]; if (L->dm == 3 && L->n[2] > N) N = L->n[2];
   return nub > N * N ? nub : N * N;
 }
 
@@ -285,8 +299,8 @@ static void cc_load(cclev *L, const vo_fab *rh, const vo_fab *phi, const int ell
     if (i == n[0] - 1 && ellbc[0][1] == VDN_BC_DIR) r = r + BX(L, n[0], j, k) * VF(phi, gi + 1, gj, gk, 0) * L->hi2[0];
     if (j == 0 && ellbc[1][0] == VDN_BC_DIR)        r = r + BY(L, i, 0, k) * VF(phi, gi, gj - 1, gk, 0) * L->hi2[1];
     if (j == n[1] - 1 && ellbc[1][1] == VDN_BC_DIR) r = r + BY(L, i, n[1], k) * VF(phi, gi, gj + 1, gk, 0) * L->hi2[1];
-    if (k == 0 && ellbc[2][0] == VDN_BC_DIR)        r = r + BZ(L, i, j, 0) * VF(phi, gi, gj, gk - 1, 0) * L->hi2[2];
-    if (k == n[2] - 1 && ellbc[2][1] == VDN_BC_DIR) r = r + BZ(L, i, j, n[2]) * VF(phi, gi, gj, gk + 1, 0) * L->hi2[2];
+    if (L->dm == 3 && k == 0 && ellbc[2][0] == VDN_BC_DIR)        r = r + BZ(L, i, j, 0) * VF(phi, gi, gj, gk - 1, 0) * L->hi2[2];
+    if (L->dm == 3 && k == n[2] - 1 && ellbc[2][1] == VDN_BC_DIR) r = r + BZ(L, i, j, n[2]) * VF(phi, gi, gj, gk + 1, 0) * L->hi2[2];
     CC(L, L->rh, i, j, k) = r;
     PHI(L, i, j, k) = VF(phi, gi, gj, gk, 0);
   }
@@ -299,7 +313,7 @@ static void cc_store(cclev *L, vo_fab *phi, const int ellbc[3][2], const int per
   cc_fill_periodic(L, per);
   for (int k = 0; k < n[2]; k++) for (int j = 0; j < n[1]; j++) for (int i = 0; i < n[0]; i++)
     VF(phi, phi->lo[0] + i, phi->lo[1] + j, phi->lo[2] + k, 0) = PHI(L, i, j, k);
-  for (int d = 0; d < 3; d++) for (int s = 0; s < 2; s++) {
+  for (int d = 0; d < L->dm; d++) for (int s = 0; s < 2; s++) {
     int t1 = (d + 1) % 3, t2 = (d + 2) % 3;
     for (int b2 = 0; b2 < n[t2]; b2++) for (int b1 = 0; b1 < n[t1]; b1++) {
       int q[3], g[3]; q[t1] = g[t1] = b1; q[t2] = g[t2] = b2;

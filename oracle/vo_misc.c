@@ -79,7 +79,7 @@ void vo_fill_boundary(vo_fab *f, const int pmask[3])
   for (int d = 0; d < 3; d++) { per[d] = f->hi[d] - f->lo[d] + 1; vlo[d] = f->lo[d]; vhi[d] = f->hi[d] + f->nd[d]; }
   int ng = f->ng;
   for (int c = 0; c < f->nc; c++)
-  for (int k = vlo[2] - ng; k <= vhi[2] + ng; k++)
+  for (int k = vlo[2] - f->gz; k <= vhi[2] + f->gz; k++)
   for (int j = vlo[1] - ng; j <= vhi[1] + ng; j++)
   for (int i = vlo[0] - ng; i <= vhi[0] + ng; i++) {
     int idx[3] = { i, j, k }, src[3] = { i, j, k }, ghost = 0, ok = 1;
@@ -94,9 +94,13 @@ void vo_fill_boundary(vo_fab *f, const int pmask[3])
 /* ------------------------------------------------------------------------------------------
  * multifab_physbc.f90:238-561 (physbc_3d), one component at a time.
  * ---------------------------------------------------------------------------------------- */
-static double extdir_value(const vdn_params *prm, int icomp1, int d, int s, int *has)
+static double extdir_value(const vdn_params *prm, int icomp1, int d, int s, int *has, int dm)
 {
   *has = 1;
+  if (dm == 2) {                 /* multifab_physbc.f90:96-99: u, v, rho, tracer */
+    switch (icomp1) { case 1: return prm->u_bc[d][s]; case 2: return prm->v_bc[d][s]; case 3: return prm->rho_bc[d][s]; case 4: return prm->trac_bc[d][s]; }
+    *has = 0; return 0.0;
+  }
   switch (icomp1) {              /* 1-based bc component, multifab_physbc.f90:282-287 */
     case 1: return prm->u_bc[d][s];
     case 2: return prm->v_bc[d][s];
@@ -114,22 +118,23 @@ static void physbc_one(vo_fab *f, int scomp, const int bc[3][2], int icomp1, con
   /* transverse ranges: x faces skip y/z ghosts where those sides are physical (254-276);
    * y faces use full x, restricted z; z faces use full x,y */
   int glo[3][3], ghi[3][3];   /* [face dir][transverse dir] */
+  const int gd[3] = { ng, ng, f->gz };                 /* ghost width per direction (2-D fabs: none along z) */
   for (int d = 0; d < 3; d++) for (int t = 0; t < 3; t++) {
     int restricted = (t > d);                          /* x: y,z restricted; y: z restricted */
-    int nlo = ng, nhi = ng;
-    if (restricted) { nlo = (bc[t][0] == VDN_INTERIOR) ? ng : 0; nhi = (bc[t][1] == VDN_INTERIOR) ? ng : 0; }
+    int nlo = gd[t], nhi = gd[t];
+    if (restricted) { nlo = (bc[t][0] == VDN_INTERIOR) ? gd[t] : 0; nhi = (bc[t][1] == VDN_INTERIOR) ? gd[t] : 0; }
     glo[d][t] = lo[t] - nlo; ghi[d][t] = hi[t] + nhi;
   }
-  for (int d = 0; d < 3; d++) for (int s = 0; s < 2; s++) {
+  for (int d = 0; d < f->dm; d++) for (int s = 0; s < 2; s++) {
     int b = bc[d][s];
     if (b == VDN_INTERIOR) continue;
     int t1 = (d + 1) % 3, t2 = (d + 2) % 3;
     if (t1 > t2) { int t = t1; t1 = t2; t2 = t; }
     int r1lo, r1hi, r2lo, r2hi;
-    if (b == VDN_EXT_DIR) { r1lo = lo[t1] - ng; r1hi = hi[t1] + ng; r2lo = lo[t2] - ng; r2hi = hi[t2] + ng; }
+    if (b == VDN_EXT_DIR) { r1lo = lo[t1] - gd[t1]; r1hi = hi[t1] + gd[t1]; r2lo = lo[t2] - gd[t2]; r2hi = hi[t2] + gd[t2]; }
     else { r1lo = glo[d][t1]; r1hi = ghi[d][t1]; r2lo = glo[d][t2]; r2hi = ghi[d][t2]; }
     int has = 0; double ev = 0.0;
-    if (b == VDN_EXT_DIR) { ev = extdir_value(prm, icomp1, d, s, &has); if (!has) continue; }
+    if (b == VDN_EXT_DIR) { ev = extdir_value(prm, icomp1, d, s, &has, f->dm); if (!has) continue; }
     else if (b != VDN_FOEXTRAP && b != VDN_HOEXTRAP && b != VDN_REFLECT_EVEN && b != VDN_REFLECT_ODD) {
       fprintf(stderr, "vo_physbc: bc(%d,%d) = %d NOT YET SUPPORTED\n", d + 1, s + 1, b); abort();
     }

@@ -34,8 +34,8 @@ void vo_slope(const vo_fab *s, vo_fab *sl, int dir, int nc, int bccomp, const vo
     int lo_special = (bclo == VDN_EXT_DIR || bclo == VDN_HOEXTRAP);
     int hi_special = (bchi == VDN_EXT_DIR || bchi == VDN_HOEXTRAP);
     #pragma omp for collapse(2)
-    for (int b2 = lo[t2] - 1; b2 <= hi[t2] + 1; b2++)
-    for (int b1 = lo[t1] - 1; b1 <= hi[t1] + 1; b1++) {
+    for (int b2 = lo[t2] - ((t2 == 2 && s->dm == 2) ? 0 : 1); b2 <= hi[t2] + ((t2 == 2 && s->dm == 2) ? 0 : 1); b2++)
+    for (int b1 = lo[t1] - ((t1 == 2 && s->dm == 2) ? 0 : 1); b1 <= hi[t1] + ((t1 == 2 && s->dm == 2) ? 0 : 1); b1++) {
       int q[3]; q[t1] = b1; q[t2] = b2;
       #define S(i)  (q[dir] = (i), VF(s, q[0], q[1], q[2], comp))
       #define SL(i) (q[dir] = (i), &VF(sl, q[0], q[1], q[2], comp))

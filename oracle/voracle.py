@@ -25,7 +25,7 @@ INITIAL_PROJECTION, DIVU_ITERS, PRESSURE_ITERS, REGULAR_TIMESTEP = 1, 2, 3, 4
 
 class CFab(C.Structure):
     _fields_ = [("p", C.c_void_p), ("lo", C.c_int * 3), ("hi", C.c_int * 3), ("ng", C.c_int),
-                ("nd", C.c_int * 3), ("nc", C.c_int), ("n", C.c_long * 3), ("sc", C.c_long)]
+                ("nd", C.c_int * 3), ("nc", C.c_int), ("n", C.c_long * 3), ("sc", C.c_long), ("gz", C.c_int), ("dm", C.c_int)]
 
 
 class CBc(C.Structure):
@@ -60,6 +60,7 @@ def lib():
         os.environ.setdefault("OMP_WAIT_POLICY", "passive")
         _lib = C.CDLL(LIB)
         _lib.vo_estdt.restype = C.c_double
+        _lib.vo2_estdt.restype = C.c_double
         _lib.vo_cc_solve.restype = C.c_int
         _lib.vo_nd_solve.restype = C.c_int
     return _lib
@@ -69,17 +70,22 @@ class Fab:
     """one BoxLib-layout fab backed by a numpy array ``a[i, j, k, c]`` (Fortran order).
     index 0 of each axis is lo-ng."""
 
-    def __init__(self, lo, hi, ng=0, nc=1, nodal=(0, 0, 0), val=0.0):
-        self.lo = tuple(int(x) for x in lo)
-        self.hi = tuple(int(x) for x in hi)
-        self.ng, self.nc, self.nodal = int(ng), int(nc), tuple(int(x) for x in nodal)
-        shp = tuple(self.hi[d] - self.lo[d] + 1 + self.nodal[d] + 2 * self.ng for d in range(3)) + (self.nc,)
+    def __init__(self, lo, hi, ng=0, nc=1, nodal=(0, 0, 0), val=0.0, dm=3):
+        """dm = 2: one z-plane, no ghost cells along z (the BoxLib 2-D layout p(lo1-ng:hi1+ng, lo2-ng:hi2+ng, nc))"""
+        self.dm = int(dm)
+        self.lo = tuple(int(x) for x in lo[:self.dm]) + (0,) * (3 - self.dm)
+        self.hi = tuple(int(x) for x in hi[:self.dm]) + (0,) * (3 - self.dm)
+        self.ng, self.nc = int(ng), int(nc)
+        self.nodal = tuple(int(x) for x in nodal[:self.dm]) + (0,) * (3 - self.dm)
+        self.gd = (self.ng, self.ng, self.ng if self.dm == 3 else 0)
+        shp = tuple(self.hi[d] - self.lo[d] + 1 + self.nodal[d] + 2 * self.gd[d] for d in range(3)) + (self.nc,)
         self.a = np.full(shp, val, dtype=np.float64, order="F")
         self.c = CFab()
         self.c.p = self.a.ctypes.data
         for d in range(3):
             self.c.lo[d], self.c.hi[d], self.c.nd[d], self.c.n[d] = self.lo[d], self.hi[d], self.nodal[d], shp[d]
         self.c.ng, self.c.nc = self.ng, self.nc
+        self.c.gz, self.c.dm = self.gd[2], self.dm
         self.c.sc = shp[0] * shp[1] * shp[2]
 
     @property
@@ -88,12 +94,11 @@ class Fab:
 
     def valid(self, grow=0):
         """view of the valid region (incl. nodal extra point), optionally grown"""
-        g = self.ng - grow
-        sl = tuple(slice(g, self.a.shape[d] - g) for d in range(3))
+        sl = tuple(slice(self.gd[d] - min(grow, self.gd[d]), self.a.shape[d] - (self.gd[d] - min(grow, self.gd[d]))) for d in range(3))
         return self.a[sl]
 
     def like(self, val=0.0):
-        return Fab(self.lo, self.hi, self.ng, self.nc, self.nodal, val)
+        return Fab(self.lo, self.hi, self.ng, self.nc, self.nodal, val, self.dm)
 
     def copy(self):
         f = self.like()
@@ -140,33 +145,38 @@ class Sim:
     Used for the end-to-end parity tests and bench.py's cpu_baseline."""
 
     def __init__(self, n, phys, prm=None, prob_type=1, grav=-9.8, prob_hi=(1.0, 1.0, 1.0), init_shrink=1.0,
-                 init_iter=4, do_initial_projection=1):
+                 init_iter=4, do_initial_projection=1, dm=3):
         L = lib()
-        self.n = tuple(int(x) for x in (n if hasattr(n, "__len__") else (n, n, n)))
+        self.dm = dm
+        self.n = tuple(int(x) for x in (n if hasattr(n, "__len__") else (n,) * dm))
+        if dm == 2:
+            self.n = self.n[:2] + (1,)
         self.prm = prm or default_params()
         self.prm.prob_type = prob_type
-        self.phys = [[int(phys[d][s]) for s in range(2)] for d in range(3)]
+        self.prm.dm = dm
+        self.phys = [[int(phys[d][s]) for s in range(2)] if d < dm else [INTERIOR, INTERIOR] for d in range(3)]
         self.pmask = ivec([1 if self.phys[d][0] == PERIODIC else 0 for d in range(3)])
-        self.bc = make_bc(self.phys, 3, self.prm.nscal)
+        self.bc = make_bc(self.phys, dm, self.prm.nscal)
         lo, hi = (0, 0, 0), tuple(x - 1 for x in self.n)
         self.dx = dvec([prob_hi[d] / self.n[d] for d in range(3)])
         ns = self.prm.nscal
-        self.uold, self.sold = Fab(lo, hi, 3, 3), Fab(lo, hi, 3, ns)
-        self.unew, self.snew = Fab(lo, hi, 3, 3), Fab(lo, hi, 3, ns)
-        self.gp, self.p = Fab(lo, hi, 1, 3), Fab(lo, hi, 1, 1, (1, 1, 1))
-        self.ext_vel_force, self.ext_scal_force = Fab(lo, hi, 1, 3), Fab(lo, hi, 1, ns)
-        self.ext_vel_force.a[..., 2] = grav                       # varden.f90:428-429
+        self.uold, self.sold = Fab(lo, hi, 3, dm, dm=dm), Fab(lo, hi, 3, ns, dm=dm)
+        self.unew, self.snew = Fab(lo, hi, 3, dm, dm=dm), Fab(lo, hi, 3, ns, dm=dm)
+        self.gp, self.p = Fab(lo, hi, 1, dm, dm=dm), Fab(lo, hi, 1, 1, (1, 1, 1), dm=dm)
+        self.ext_vel_force, self.ext_scal_force = Fab(lo, hi, 1, dm, dm=dm), Fab(lo, hi, 1, ns, dm=dm)
+        self.ext_vel_force.a[..., dm - 1] = grav                  # varden.f90:428-429
         self.init_shrink, self.init_iter = init_shrink, init_iter
         self.time, self.dt, self.istep = 0.0, 0.0, 0
         self.mgstat = (CMgStat * 2)()
         self.phase = (C.c_double * 4)()
-        L.vo_initdata(self.uold.ref, self.sold.ref, self.dx, prob_type)
+        (L.vo2_initdata if dm == 2 else L.vo_initdata)(self.uold.ref, self.sold.ref, self.dx, prob_type)
         if do_initial_projection:                                 # varden.f90:126-138
-            rhohalf = Fab(lo, hi, 1, 1, val=1.0)
+            rhohalf = Fab(lo, hi, 1, 1, val=1.0, dm=dm)
             st = CMgStat()
             # fill ghosts first so that create_uvec/divu see the boundary data (initialize.f90 does this)
             self.fill_state_ghosts()
-            L.vo_hgproject(INITIAL_PROJECTION, self.uold.ref, self.uold.ref, rhohalf.ref, self.p.ref, self.gp.ref,
+            (L.vo2_hgproject if dm == 2 else L.vo_hgproject)(
+                           INITIAL_PROJECTION, self.uold.ref, self.uold.ref, rhohalf.ref, self.p.ref, self.gp.ref,
                            self.dx, C.c_double(1.0), C.byref(self.bc), self.pmask, C.byref(self.prm), C.byref(st))
             self.initial_projection_stat = (st.cycles, st.res0, st.res)
         self.p.a[...] = 0.0
@@ -183,11 +193,11 @@ class Sim:
         L.vo_fill_boundary(self.uold.ref, self.pmask)
         L.vo_fill_boundary(self.sold.ref, self.pmask)
         L.vo_fill_boundary(self.gp.ref, self.pmask)
-        L.vo_physbc(self.uold.ref, 0, 0, 3, C.byref(self.bc), C.byref(self.prm))
-        L.vo_physbc(self.sold.ref, 0, 3, self.prm.nscal, C.byref(self.bc), C.byref(self.prm))
+        L.vo_physbc(self.uold.ref, 0, 0, self.dm, C.byref(self.bc), C.byref(self.prm))
+        L.vo_physbc(self.sold.ref, 0, self.dm, self.prm.nscal, C.byref(self.bc), C.byref(self.prm))
 
     def estdt(self, dtold):
-        return lib().vo_estdt(self.uold.ref, self.sold.ref, self.gp.ref, self.ext_vel_force.ref, self.dx,
+        return (lib().vo2_estdt if self.dm == 2 else lib().vo_estdt)(self.uold.ref, self.sold.ref, self.gp.ref, self.ext_vel_force.ref, self.dx,
                               C.c_double(dtold), C.byref(self.prm))
 
     def state(self):
@@ -198,7 +208,7 @@ class Sim:
 
     def advance(self, proj_type=REGULAR_TIMESTEP):
         S = self.state()
-        lib().vo_advance_timestep(C.byref(S), self.dx, C.c_double(self.dt), C.byref(self.bc), self.pmask,
+        (lib().vo2_advance_timestep if self.dm == 2 else lib().vo_advance_timestep)(C.byref(S), self.dx, C.c_double(self.dt), C.byref(self.bc), self.pmask,
                                   C.byref(self.prm), proj_type, self.mgstat, self.phase)
 
     def step(self):
@@ -208,7 +218,6 @@ class Sim:
         if self.istep > 1:
             self.dt = self.estdt(self.dt)
         self.advance(REGULAR_TIMESTEP)
-        g = 3
-        self.uold.a[g:-g, g:-g, g:-g, :] = self.unew.a[g:-g, g:-g, g:-g, :]     # copy_c valid only
-        self.sold.a[g:-g, g:-g, g:-g, :] = self.snew.a[g:-g, g:-g, g:-g, :]
+        self.uold.valid()[...] = self.unew.valid()                                # copy_c valid only
+        self.sold.valid()[...] = self.snew.valid()
         self.time += self.dt
