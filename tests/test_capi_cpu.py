@@ -62,8 +62,8 @@ def test_no_cpu_fallback_and_error_convention():
 def test_rejects_unimplemented_configurations():
     from varden_amd import capi
     lib = capi.load()
-    p = capi.default_params(dm=2)
-    assert lib.vdn_init(C.byref(p), 0, 1, 0) != 0 and b"dm = 3" in lib.vdn_last_error()
+    p = capi.default_params(dm=1)
+    assert lib.vdn_init(C.byref(p), 0, 1, 0) != 0 and b"dm must be 2 or 3" in lib.vdn_last_error()
     p = capi.default_params(diffusion_type=3)
     assert lib.vdn_init(C.byref(p), 0, 1, 0) != 0 and b"DIFFUSION" in lib.vdn_last_error()
 

@@ -312,3 +312,63 @@ def test_viscous_solve_decays_a_fourier_mode_exactly(dtype):
     fac = (1 - mu * lam) / (1 + mu * lam) if dtype == 1 else 1.0 / (1 + mu * lam)
     for c in range(3):
         assert np.abs(unew.valid()[..., c] - fac * (c + 1) * mode[3:-3, 3:-3, 3:-3]).max() <= 1e-10
+
+
+# ---- dm = 2 (BASELINE.json configs[0]) --------------------------------------------------------------------------------
+def _sim2(n, phys, **kw):
+    from oracle import voracle as vo
+    from varden_amd.capi import default_params
+    return vo.Sim(n, [list(phys[0]), list(phys[1]), [0, 0]], default_params(dm=2, **kw), dm=2, init_shrink=0.1, init_iter=1)
+
+
+def test_2d_uniform_flow_is_a_fixed_point(oracle):
+    """constant u, rho with periodic bcs: umac = u, unew = u, snew = s (velpred_2d / mkflux_2d / update_2d), phi = 0"""
+    import ctypes as C
+    vo = oracle
+    S = _sim2(16, [[-1, -1], [-1, -1]])
+    S.uold.a[..., 0] = 0.7; S.uold.a[..., 1] = -0.3; S.sold.a[...] = 1.5
+    S.ext_vel_force.a[...] = 0.0
+    S.gp.a[...] = 0.0; S.dt = 0.01
+    S.fill_state_ghosts()
+    S.advance(vo.REGULAR_TIMESTEP)
+    assert np.abs(S.unew.valid()[..., 0] - 0.7).max() < 1e-13 and np.abs(S.unew.valid()[..., 1] + 0.3).max() < 1e-13
+    assert np.abs(S.snew.valid() - 1.5).max() < 1e-13
+
+
+def test_2d_bubble_mass_symmetry_and_projection(oracle):
+    S = _sim2(32, [[15, 15], [15, 15]])
+    m0 = S.sold.valid()[..., 0].sum()
+    for _ in range(3):
+        S.step()
+        assert S.mgstat[0].cycles < 30 and S.mgstat[1].cycles < 40
+    s = S.snew.valid()[:, :, 0, 0]; u = S.unew.valid()[:, :, 0, :]
+    assert abs(s.sum() - m0) <= 1e-12 * m0                                   # conservative density update, zero wall flux
+    assert np.abs(s - s[::-1, :]).max() <= 1e-10 and np.abs(u[..., 0] + u[::-1, :, 0]).max() <= 1e-10
+    assert u[..., 1].max() > 0.0                                             # the light... heavy bubble moves under gravity
+
+
+def test_2d_mac_projection_is_divergence_free(oracle):
+    import ctypes as C
+    vo = oracle
+    from varden_amd.capi import default_params
+    n = 32
+    lo, hi = (0, 0, 0), (n - 1, n - 1, 0)
+    rng = np.random.default_rng(5)
+    prm = default_params(dm=2)
+    phys = [[15, 14], [-1, -1], [0, 0]]
+    bc = vo.make_bc(phys, 2, 2)
+    pm = vo.ivec([0, 1, 0])
+    rho = vo.Fab(lo, hi, 3, 2, dm=2); rho.a[...] = 1.0 + 0.5 * rng.random(rho.a.shape)
+    um = [vo.Fab(lo, hi, 1, 1, (1, 0, 0), dm=2), vo.Fab(lo, hi, 1, 1, (0, 1, 0), dm=2)]
+    for m in um:
+        m.a[...] = rng.standard_normal(m.a.shape)
+    um[0].a[1, :, 0, 0] = 0.0; um[0].a[-2, :, 0, 0] = 0.0                      # wall-normal MAC velocity
+    um[1].a[:, -2, 0, 0] = um[1].a[:, 1, 0, 0]                                 # periodic alias faces
+    rhs = vo.Fab(lo, hi, 1, 1, dm=2)
+    L = vo.lib()
+    L.vo_fill_boundary(rho.ref, pm); L.vo_physbc(rho.ref, 0, 2, 2, C.byref(bc), C.byref(prm))
+    st = vo.CMgStat()
+    L.vo2_macproject(vo.fab_ptr_array(um), rho.ref, rhs.ref, vo.dvec([1.0 / n, 1.0 / n, 1.0]), C.byref(bc), pm, C.byref(prm), C.byref(st))
+    u, v = um[0].a[1:-1, 1:-1, 0, 0], um[1].a[1:-1, 1:-1, 0, 0]
+    div = (u[1:, :] - u[:-1, :]) * n + (v[:, 1:] - v[:, :-1]) * n
+    assert np.abs(div).max() <= 1e-8 * max(np.abs(u).max(), 1.0) * n

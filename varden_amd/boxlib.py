@@ -22,15 +22,17 @@ BC_PER, BC_INT, BC_DIR, BC_NEU = -1, 0, 1, 2
 INITIAL_PROJECTION, DIVU_ITERS, PRESSURE_ITERS, REGULAR_TIMESTEP = 1, 2, 3, 4
 
 _initialised = False
+_dm = 3                      # dim_in of the current run (set by initialize); 2: fabs are one z-plane on the host
 
 
 def initialize(params=None, rank=0, nranks=1, device=0):
     """boxlib_initialize + probin_init: bind the GPU and hand the runtime parameters over."""
-    global _initialised
+    global _initialised, _dm
     lib = capi.load()
     prm = params if params is not None else capi.default_params()
     check(lib.vdn_init(C.byref(prm), rank, nranks, device))
     _initialised = True
+    _dm = int(prm.dm)
     return prm
 
 
@@ -122,6 +124,8 @@ class MultiFab:
     def __init__(self, mla, lev, nc, ng, nodal=None):
         self.mla, self.lev, self.nc, self.ng = mla, lev, int(nc), int(ng)
         self.nodal = tuple(int(x) for x in (nodal or (0, 0, 0)))
+        if _dm == 2:
+            self.nodal = self.nodal[:2] + (0,)
         nd = (C.c_int * 3)(*self.nodal)
         self.h = C.c_void_p()
         check(capi.load().vdn_multifab_create(mla.h, lev, self.nc, self.ng, nd, C.byref(self.h)))
@@ -166,7 +170,8 @@ class MultiFab:
     # -- host copies --------------------------------------------------------------------------
     def shape(self, i):
         lo, hi = self.get_box(i)
-        return tuple(hi[d] - lo[d] + 1 + self.nodal[d] + 2 * self.ng for d in range(3)) + (self.nc,)
+        gd = (self.ng, self.ng, self.ng if _dm == 3 else 0)      # dm = 2: the BoxLib 2-D layout, one z-plane
+        return tuple(hi[d] - lo[d] + 1 + self.nodal[d] + 2 * gd[d] for d in range(3)) + (self.nc,)
 
     def to_numpy(self, i=0):
         a = np.empty(self.shape(i), dtype=np.float64, order="F")

@@ -42,8 +42,8 @@ extern "C" int vdn_advance_timestep(int istep, vdn_layout *mla, vdn_multifab **s
   // advance_timestep.f90:65-80
   vdn_multifab *mac_rhs = mf_temp(mla, n, 1, 1, -1, true, 0.0);
   vdn_multifab *rhohalf = mf_temp(mla, n, dm, 1, -1, true, 0.0);
-  vdn_multifab *umac[3];
-  for (int d = 0; d < 3; d++) umac[d] = mf_temp(mla, n, 1, 1, d, true, 1.e20);
+  vdn_multifab *umac[3] = { nullptr, nullptr, nullptr };
+  for (int d = 0; d < dm; d++) umac[d] = mf_temp(mla, n, 1, 1, d, true, 1.e20);
   // lapu (advance_timestep.f90:85-93); NULL stands for the all-zero field when visc_coef == 0
   const bool viscous = P.visc_coef > 0.0, diffusive = P.diff_coef > 0.0;
   vdn_multifab *lapu = nullptr;
@@ -59,7 +59,7 @@ extern "C" int vdn_advance_timestep(int istep, vdn_layout *mla, vdn_multifab **s
     k_mkvelforce(vel_force, ext_vel_force[n], sold[n], gp[n], lapu, 1.0);
     mf_restrict_and_fill(vel_force, 0, bct->extrap_comp0(), dm, true, bct);            // mkforce.f90:75-76
     k_velpred(uold[n], umac, vel_force, dx, dt, bct);
-    for (int d = 0; d < 3; d++) mf_fill_boundary(umac[d]);                              // velpred.f90:108-112
+    for (int d = 0; d < dm; d++) mf_fill_boundary(umac[d]);                             // velpred.f90:108-112
     mf_temp_free(vel_force);
     arena_release(mark);
   }
@@ -79,8 +79,8 @@ extern "C" int vdn_advance_timestep(int istep, vdn_layout *mla, vdn_multifab **s
     int is_cons[VDN_MAXCOMP]; is_cons[0] = 1; for (int c = 1; c < nscal; c++) is_cons[c] = 0;
     vdn_multifab *scal_force = mf_temp(mla, n, nscal, 1, -1, false, 0.0);
     vdn_multifab *divu = mf_temp(mla, n, 1, 1, -1, true, 0.0);
-    vdn_multifab *sflux[3], *sedge[3];
-    for (int d = 0; d < 3; d++) { sflux[d] = mf_temp(mla, n, nscal, 0, d, true, 0.0); sedge[d] = mf_temp(mla, n, nscal, 0, d, true, 0.0); }
+    vdn_multifab *sflux[3] = { nullptr, nullptr, nullptr }, *sedge[3] = { nullptr, nullptr, nullptr };
+    for (int d = 0; d < dm; d++) { sflux[d] = mf_temp(mla, n, nscal, 0, d, true, 0.0); sedge[d] = mf_temp(mla, n, nscal, 0, d, true, 0.0); }
     vdn_multifab *laps = nullptr;                                                      // scalar_advance.f90:80-89
     if (diffusive) {
       laps = mf_temp(mla, n, nscal, 0, -1, true, 0.0);
@@ -98,7 +98,7 @@ extern "C" int vdn_advance_timestep(int istep, vdn_layout *mla, vdn_multifab **s
       for (int c = 1; c < nscal; c++) do_diff_scalar_solve(mla, snew[n], laps, dx, visc_mu, bct, c, dm + c);
       mf_temp_free(laps);
     }
-    for (int d = 0; d < 3; d++) { mf_temp_free(sflux[d]); mf_temp_free(sedge[d]); }
+    for (int d = 0; d < dm; d++) { mf_temp_free(sflux[d]); mf_temp_free(sedge[d]); }
     mf_temp_free(divu); mf_temp_free(scal_force);
     arena_release(mark);
   }
@@ -115,8 +115,8 @@ extern "C" int vdn_advance_timestep(int istep, vdn_layout *mla, vdn_multifab **s
     size_t mark = arena_mark();
     int is_cons[3] = { 0, 0, 0 };
     vdn_multifab *vel_force = mf_temp(mla, n, dm, 1, -1, false, 0.0);
-    vdn_multifab *uflux[3], *uedge[3];
-    for (int d = 0; d < 3; d++) { uflux[d] = mf_temp(mla, n, dm, 0, d, true, 0.0); uedge[d] = mf_temp(mla, n, dm, 0, d, true, 0.0); }
+    vdn_multifab *uflux[3] = { nullptr, nullptr, nullptr }, *uedge[3] = { nullptr, nullptr, nullptr };
+    for (int d = 0; d < dm; d++) { uflux[d] = mf_temp(mla, n, dm, 0, d, true, 0.0); uedge[d] = mf_temp(mla, n, dm, 0, d, true, 0.0); }
     k_mkvelforce(vel_force, ext_vel_force[n], sold[n], gp[n], lapu, 1.0);
     mf_restrict_and_fill(vel_force, 0, bct->extrap_comp0(), dm, true, bct);
     k_mkflux(uold[n], uedge, uflux, umac, vel_force, mac_rhs, dx, dt, bct, true, is_cons);
@@ -128,7 +128,7 @@ extern "C" int vdn_advance_timestep(int istep, vdn_layout *mla, vdn_multifab **s
       const double visc_mu = (P.diffusion_type == 1) ? 0.5 * dt * P.visc_coef : dt * P.visc_coef;
       do_visc_solve(mla, unew[n], lapu, rhohalf, mac_rhs, dx, visc_mu, bct);
     }
-    for (int d = 0; d < 3; d++) { mf_temp_free(uflux[d]); mf_temp_free(uedge[d]); }
+    for (int d = 0; d < dm; d++) { mf_temp_free(uflux[d]); mf_temp_free(uedge[d]); }
     mf_temp_free(vel_force);
     arena_release(mark);
   }
@@ -142,7 +142,7 @@ extern "C" int vdn_advance_timestep(int istep, vdn_layout *mla, vdn_multifab **s
   }
   sync(); ctx().step_sec[3] = wall() - t0;
 
-  for (int d = 0; d < 3; d++) mf_temp_free(umac[d]);
+  for (int d = 0; d < dm; d++) mf_temp_free(umac[d]);
   if (lapu) mf_temp_free(lapu);
   mf_temp_free(rhohalf); mf_temp_free(mac_rhs);
   arena_reset();
@@ -165,11 +165,12 @@ extern "C" int vdn_estdt(int lev, const vdn_multifab *u, const vdn_multifab *s, 
   double dt = 1.e20;
   if (m[0] > eps) dt = fmin(dt, dx[0] / m[0]);
   if (m[1] > eps) dt = fmin(dt, dx[1] / m[1]);
-  if (m[2] > eps) dt = fmin(dt, dx[2] / m[2]);
+  const int dm = ctx().prm.dm;
+  if (dm == 3 && m[2] > eps) dt = fmin(dt, dx[2] / m[2]);
   if (m[3] > eps) dt = fmin(dt, sqrt(2.0 * dx[0] / m[3]));
   if (m[4] > eps) dt = fmin(dt, sqrt(2.0 * dx[1] / m[4]));
-  if (m[5] > eps) dt = fmin(dt, sqrt(2.0 * dx[2] / m[5]));
-  if (dt == 1.e20) { dt = fmin(dx[0], dx[1]); dt = fmin(dt, dx[2]); }     // estdt.f90:71-74
+  if (dm == 3 && m[5] > eps) dt = fmin(dt, sqrt(2.0 * dx[2] / m[5]));
+  if (dt == 1.e20) { dt = fmin(dx[0], dx[1]); if (dm == 3) dt = fmin(dt, dx[2]); }     // estdt.f90:71-74
   dt = dt * ctx().prm.cflfac;
   if (dtold > 0.0) dt = fmin(dt, ctx().prm.max_dt_growth * dtold);
   *dt_out = dt;
@@ -207,7 +208,7 @@ extern "C" int vdn_k_velpred(const vdn_multifab *u, vdn_multifab **umac, const v
                              const vdn_bc_tower *bct) {
   HOOK_BEGIN(u)
   k_velpred(u, umac, force, dx, dt, bct);
-  for (int d = 0; d < 3; d++) mf_fill_boundary(umac[d]);
+  for (int d = 0; d < ctx().prm.dm; d++) mf_fill_boundary(umac[d]);
   HOOK_END
 }
 extern "C" int vdn_k_mkflux(const vdn_multifab *s, vdn_multifab **sedge, vdn_multifab **flux, vdn_multifab **umac,

@@ -625,7 +625,7 @@ static void fill_gargs(GArgs &A, const vdn_multifab *s, int ibox, const vdn_bc_t
   memset(&A, 0, sizeof A);
   BoxP bp = make_boxp(s, ibox, bct);
   for (int d = 0; d < 3; d++) {
-    A.lo[d] = bp.lo[d]; A.hi[d] = bp.hi[d]; A.dx[d] = dx ? dx[d] : 1.0;
+    A.lo[d] = bp.lo[d]; A.hi[d] = bp.hi[d]; A.dx[d] = (dx && d < ctx().prm.dm) ? dx[d] : 1.0;      // dx holds dm entries
     for (int sd = 0; sd < 2; sd++) {
       A.phys[d][sd] = bp.phys[d][sd];
       for (int c = 0; c < ncomp && c < 3; c++) A.adv[d][sd][c] = bct->adv_bc(s->lev, ibox + 1, d, sd, bccomp + c);
@@ -633,6 +633,9 @@ static void fill_gargs(GArgs &A, const vdn_multifab *s, int ibox, const vdn_bc_t
   }
   A.dt = dt; A.ncomp = ncomp; A.use_minion = ctx().prm.use_minion; A.slope_order = ctx().prm.slope_order;
 }
+static void k2_velpred(const vdn_multifab *u, vdn_multifab **umac, const vdn_multifab *force, const double *dx, double dt, const vdn_bc_tower *bct);
+static void k2_mkflux(const vdn_multifab *s, vdn_multifab **sedge, vdn_multifab **flux, vdn_multifab **umac, const vdn_multifab *force,
+                      const vdn_multifab *mac_rhs, const double *dx, double dt, const vdn_bc_tower *bct, bool is_vel, const int *is_cons);
 static FV work_fv(double *p, const BoxP &b, int nc_unused) {
   (void)nc_unused;
   FV f; f.p = p; f.a0 = b.lo[0] - 1; f.a1 = b.lo[1] - 1; f.a2 = b.lo[2] - 1;
@@ -653,6 +656,7 @@ void k_slope(const vdn_multifab *s, vdn_multifab *slope, int dir, int bccomp, co
 void k_mkflux(const vdn_multifab *s, vdn_multifab **sedge, vdn_multifab **flux, vdn_multifab **umac,
               const vdn_multifab *force, const vdn_multifab *mac_rhs, const double *dx, double dt,
               const vdn_bc_tower *bct, bool is_vel, const int *is_cons) {
+  if (ctx().prm.dm == 2) { k2_mkflux(s, sedge, flux, umac, force, mac_rhs, dx, dt, bct, is_vel, is_cons); return; }
   const int ncomp = s->nc;
   REQUIRE(ncomp <= 3, "mkflux: at most 3 components per call (got %d)", ncomp);
   REQUIRE(s->ng >= 3 && umac[0]->ng >= 1 && force->ng >= 1 && mac_rhs->ng >= 1, "mkflux: ghost widths");
@@ -1096,8 +1100,227 @@ __global__ void __launch_bounds__(64 * TNY) kk_vp_D_m(FV u, FV sl0, FV sl1, FV s
   }
 }
 
+// ====================================================================================================
+// dm = 2 (BASELINE.json configs[0], the reference's CPU-runnable case): velpred_2d (velpred.f90:125-524) and mkflux_2d
+// (mkflux.f90:152-691).  Two stages only -- the transverse terms use the stage-B states directly.  One thread per cell
+// of the grown box, plane k = 0; fabs of a 2-D run are one z-plane on the device (z-ghost planes exist but are unused).
+// ====================================================================================================
+// velpred_2d pair on the lower D-face (D = 0, 1) of cell (i,j): NB every CFL factor divides INSIDE max()/min()
+// (velpred.f90:255-261, 332-338), unlike velpred_3d
+template <int D> DEVI void vp2_pair(const GArgs &A, const FV &u, const FV &slp, const FV &force, int i, int j, double L[2], double R[2]) {
+  const double dt2 = 0.5 * A.dt;
+  const double ul = ld<D>(u, i, j, 0, -1, D), ur = fv_get(u, i, j, 0, D);
+  const double cl = dt2 * fmax(0.0, ul / A.dx[D]), cr = dt2 * fmin(0.0, ur / A.dx[D]);
+  #pragma unroll
+  for (int c = 0; c < 2; c++) {
+    L[c] = ld<D>(u, i, j, 0, -1, c) + (0.5 - cl) * ld<D>(slp, i, j, 0, -1, c);
+    R[c] = fv_get(u, i, j, 0, c) - (0.5 + cr) * fv_get(slp, i, j, 0, c);
+    if (A.use_minion) { L[c] = L[c] + dt2 * ld<D>(force, i, j, 0, -1, c); R[c] = R[c] + dt2 * fv_get(force, i, j, 0, c); }
+  }
+  const int side = face_side<D>(A, i, j, 0);
+  if (side >= 0) {
+    #pragma unroll
+    for (int c = 0; c < 2; c++) bc_pair(L[c], R[c], A.phys[D][side], side, true, c == D, (side == 0) ? ld<D>(u, i, j, 0, -1, c) : fv_get(u, i, j, 0, c), false);
+  }
+}
+DEVI double riemann0(double L, double R, double eps) {
+  const double uavg = 0.5 * (L + R);
+  const bool test = ((L <= 0.0 && R >= 0.0) || (fabs(L + R) < eps));
+  double un = (uavg > 0.0) ? L : R;
+  return test ? 0.0 : un;
+}
+// UI: [0] uimhx(.,1) (normal), [1] uimhx(.,2), [2] uimhy(.,1), [3] uimhy(.,2) (normal)
+__global__ void __launch_bounds__(256) kk_vp2_B(FV u, FV sl0, FV sl1, FV force, FV UI, GArgs A, Range3 r, const double *umax) {
+  THREAD_IJK(r)
+  if (!in_range) return;
+  const double eps = eps_from(umax);
+  double L[2], R[2];
+  if (i >= A.lo[0]) {
+    vp2_pair<0>(A, u, sl0, force, i, j, L, R);
+    const double un = riemann0(L[0], R[0], eps);
+    fv_at(UI, i, j, 0, 0) = un;
+    const double v = (un > 0.0) ? L[1] : R[1], av = 0.5 * (L[1] + R[1]);
+    fv_at(UI, i, j, 0, 1) = (fabs(un) < eps) ? av : v;
+  }
+  if (j >= A.lo[1]) {
+    vp2_pair<1>(A, u, sl1, force, i, j, L, R);
+    const double un = riemann0(L[1], R[1], eps);
+    fv_at(UI, i, j, 0, 3) = un;
+    const double v = (un > 0.0) ? L[0] : R[0], av = 0.5 * (L[0] + R[0]);
+    fv_at(UI, i, j, 0, 2) = (fabs(un) < eps) ? av : v;
+  }
+}
+// the MAC velocities (velpred.f90:402-443 vmac, 455-496 umac)
+template <int D> DEVI void vp2_D_one(const GArgs &A, const FV &u, const FV &slp, const FV &force, const FV &UI, const FV &umac, int i, int j, double eps) {
+  constexpr int T = 1 - D;
+  if (coord<T>(i, j, 0) > A.hi[T]) return;
+  double Lv[2], Rv[2];
+  vp2_pair<D>(A, u, slp, force, i, j, Lv, Rv);
+  const double dt2 = 0.5 * A.dt, dt4 = A.dt / 4.0;
+  // transverse data live on T-faces: normal comp UI[T*2+T'] ... index: x-faces 0 (normal), 1;  y-faces 2, 3 (normal)
+  constexpr int nrm = (T == 0) ? 0 : 3, trn = (T == 0) ? 1 : 2;      // for D = 0 (T = 1): advect with uimhy(.,2) = 3, difference uimhy(.,1) = 2
+  double LR[2] = { Lv[D], Rv[D] };
+  #pragma unroll
+  for (int sd = 0; sd < 2; sd++) {
+    const int ci = i - ((sd == 0) && D == 0), cj = j - ((sd == 0) && D == 1);
+    double v = LR[sd] - (dt4 / A.dx[T]) * (ld<T>(UI, ci, cj, 0, 1, nrm) + fv_get(UI, ci, cj, 0, nrm)) * (ld<T>(UI, ci, cj, 0, 1, trn) - fv_get(UI, ci, cj, 0, trn));
+    if (!A.use_minion) v = v + dt2 * fv_get(force, ci, cj, 0, D);
+    LR[sd] = v;
+  }
+  double v = riemann0(LR[0], LR[1], eps);
+  const int side = face_side<D>(A, i, j, 0);
+  if (side >= 0) {
+    const int ph = A.phys[D][side];
+    if (ph == VDN_SLIP_WALL || ph == VDN_NO_SLIP_WALL) v = 0.0;
+    else if (ph == VDN_INLET) v = (side == 0) ? ld<D>(u, i, j, 0, -1, D) : fv_get(u, i, j, 0, D);
+    else if (ph == VDN_OUTLET) v = (side == 0) ? fmin(LR[1], 0.0) : fmax(LR[0], 0.0);
+  }
+  fv_at(umac, i, j, 0) = v;
+}
+__global__ void __launch_bounds__(256) kk_vp2_D(FV u, FV sl0, FV sl1, FV force, FV UI, FV um, FV vm, GArgs A, Range3 r, const double *umax) {
+  THREAD_IJK(r)
+  if (!in_range) return;
+  const double eps = eps_from(umax);
+  vp2_D_one<0>(A, u, sl0, force, UI, um, i, j, eps);
+  vp2_D_one<1>(A, u, sl1, force, UI, vm, i, j, eps);
+}
+__global__ void kk_velmax2(FV u, Range3 r, double *out) {             // velpred.f90:216-222
+  REDUCE_IJ(r)
+  double m = 0.0;
+  if (in_ij) m = fmax(fabs(fv_get(u, i, j, 0, 0)), fabs(fv_get(u, i, j, 0, 1)));
+  block_atomic_max(out, m);
+}
+__global__ void kk_macmax2(FV um, FV vm, GArgs A, Range3 r, double *out) {   // mkflux.f90:248-259
+  REDUCE_IJ(r)
+  double m = 0.0;
+  if (in_ij) {
+    if (j <= A.hi[1]) m = fmax(m, fabs(fv_get(um, i, j, 0)));
+    if (i <= A.hi[0]) m = fmax(m, fabs(fv_get(vm, i, j, 0)));
+  }
+  block_atomic_max(out, m);
+}
+// SI: [0*nc + c] simhx, [1*nc + c] simhy
+__global__ void __launch_bounds__(256) kk_mk2_B(FV s, FV sl0, FV sl1, FV um, FV vm, FV force, FV macrhs, FV SI, GArgs A, Range3 r, const double *umax) {
+  THREAD_IJK(r)
+  if (!in_range) return;
+  const double eps = eps_from(umax);
+  for (int c = 0; c < A.ncomp; c++) {
+    double L, R;
+    if (i >= A.lo[0]) { mk_pair<0>(A, s, sl0, um, force, macrhs, c, i, j, 0, L, R); fv_at(SI, i, j, 0, 0 * A.ncomp + c) = upwind_mac(L, R, fv_get(um, i, j, 0), eps); }
+    if (j >= A.lo[1]) { mk_pair<1>(A, s, sl1, vm, force, macrhs, c, i, j, 0, L, R); fv_at(SI, i, j, 0, 1 * A.ncomp + c) = upwind_mac(L, R, fv_get(vm, i, j, 0), eps); }
+  }
+}
+// edge states and fluxes (mkflux.f90:472-558 sedgey, 570-660 sedgex)
+template <int D> DEVI void mk2_D_one(const GArgs &A, const FV &s, const FV &slp, const FV &macD, const FV &macT, const FV &force, const FV &macrhs,
+                                     const FV &SI, const FV &sedge, const FV &flux, int c, int i, int j, double eps) {
+  constexpr int T = 1 - D;
+  if (coord<T>(i, j, 0) > A.hi[T]) return;
+  double L, R;
+  mk_pair<D>(A, s, slp, macD, force, macrhs, c, i, j, 0, L, R);
+  const double dt2 = 0.5 * A.dt, dt4 = A.dt / 4.0;
+  const bool cons = A.cons[c] != 0;
+  double LR[2] = { L, R };
+  #pragma unroll
+  for (int sd = 0; sd < 2; sd++) {
+    const int ci = i - ((sd == 0) && D == 0), cj = j - ((sd == 0) && D == 1);
+    const double s0 = fv_get(s, ci, cj, 0, c);
+    double v = LR[sd] - trans_term<T>(A, SI, T * A.ncomp + c, macT, cons, ci, cj, 0, dt2, dt4);
+    if (cons) v = v + (dt2 / A.dx[T]) * s0 * (ld<T>(macT, ci, cj, 0, 1) - fv_get(macT, ci, cj, 0));
+    if (!A.use_minion) {
+      v = v + dt2 * fv_get(force, ci, cj, 0, c);
+      if (cons) v = v - dt2 * s0 * fv_get(macrhs, ci, cj, 0);
+    }
+    LR[sd] = v;
+  }
+  const double um = fv_get(macD, i, j, 0);
+  double e = upwind_mac(LR[0], LR[1], um, eps);
+  const int side = face_side<D>(A, i, j, 0);
+  if (side >= 0) {
+    const int ph = A.phys[D][side];
+    const double in = (side == 0) ? LR[1] : LR[0];
+    const bool vel = A.is_vel != 0;
+    if (ph == VDN_INLET) e = (side == 0) ? ld<D>(s, i, j, 0, -1, c) : fv_get(s, i, j, 0, c);
+    else if (ph == VDN_SLIP_WALL) e = (vel && c == D) ? 0.0 : in;
+    else if (ph == VDN_NO_SLIP_WALL) e = vel ? 0.0 : in;
+    else if (ph == VDN_OUTLET) e = (vel && c == D) ? ((side == 0) ? fmin(in, 0.0) : fmax(in, 0.0)) : in;
+  }
+  fv_at(sedge, i, j, 0, c) = e;
+  if (cons) fv_at(flux, i, j, 0, c) = e * um;
+}
+__global__ void __launch_bounds__(256) kk_mk2_D(FV s, FV sl0, FV sl1, FV um, FV vm, FV force, FV macrhs, FV SI, FV sex, FV sey, FV flx, FV fly,
+                                                GArgs A, Range3 r, const double *umax) {
+  THREAD_IJK(r)
+  if (!in_range) return;
+  const double eps = eps_from(umax);
+  for (int c = 0; c < A.ncomp; c++) {
+    mk2_D_one<0>(A, s, sl0, um, vm, force, macrhs, SI, sex, flx, c, i, j, eps);
+    mk2_D_one<1>(A, s, sl1, vm, um, force, macrhs, SI, sey, fly, c, i, j, eps);
+  }
+}
+static FV work_fv2(const BoxP &b) {        // one plane over [lo-1, hi+1]^2
+  FV f; f.p = nullptr; f.a0 = b.lo[0] - 1; f.a1 = b.lo[1] - 1; f.a2 = 0;
+  f.n0 = b.hi[0] - b.lo[0] + 3; f.n1 = b.hi[1] - b.lo[1] + 3; f.n2 = 1;
+  f.sc = (long)f.n0 * f.n1;
+  return f;
+}
+static void ranges2(const GArgs &A, Range3 &rv, Range3 &rg, Range3 &rf) {
+  for (int d = 0; d < 2; d++) { rv.lo[d] = A.lo[d]; rv.hi[d] = A.hi[d]; rg.lo[d] = A.lo[d] - 1; rg.hi[d] = A.hi[d] + 1; rf.lo[d] = A.lo[d]; rf.hi[d] = A.hi[d] + 1; }
+  rv.lo[2] = rv.hi[2] = rg.lo[2] = rg.hi[2] = rf.lo[2] = rf.hi[2] = 0;
+}
+static void k2_velpred(const vdn_multifab *u, vdn_multifab **umac, const vdn_multifab *force, const double *dx, double dt, const vdn_bc_tower *bct) {
+  REQUIRE(u->nc == 2 && u->ng >= 3 && force->ng >= 1 && umac[0]->ng >= 1, "velpred (dm = 2): operand shapes");
+  hipStream_t st = ctx().stream;
+  for (int ib = 0; ib < u->nfabs(); ib++) {
+    size_t mark = arena_mark();
+    GArgs A; fill_gargs(A, u, ib, bct, 0, 2, dx, dt);
+    A.is_vel = 1;
+    BoxP bp = make_boxp(u, ib, bct);
+    FV w = work_fv2(bp);
+    const size_t fld = (size_t)w.sc * sizeof(double);
+    FV sl[2] = { w, w }, UI = w;
+    sl[0].p = (double *)arena_alloc(fld * 2); sl[1].p = (double *)arena_alloc(fld * 2); UI.p = (double *)arena_alloc(fld * 4);
+    double *umax = (double *)arena_alloc(256);
+    HIPCHK(hipMemsetAsync(umax, 0, sizeof(double), st));
+    Range3 rv, rg, rf; ranges2(A, rv, rg, rf);
+    hipLaunchKernelGGL(kk_velmax2, reduce_grid(rv), dim3(64, 4, 1), 0, st, u->fabs[ib], rv, umax);
+    hipLaunchKernelGGL(kk_slopes, grid_for(rg), dim3(64, 4, 1), 0, st, u->fabs[ib], sl[0], sl[1], sl[1], A, rg, 3);
+    hipLaunchKernelGGL(kk_vp2_B, grid_for(rg), dim3(64, 4, 1), 0, st, u->fabs[ib], sl[0], sl[1], force->fabs[ib], UI, A, rg, umax);
+    hipLaunchKernelGGL(kk_vp2_D, grid_for(rf), dim3(64, 4, 1), 0, st, u->fabs[ib], sl[0], sl[1], force->fabs[ib], UI, umac[0]->fabs[ib], umac[1]->fabs[ib], A, rf, umax);
+    arena_release(mark);
+  }
+}
+static void k2_mkflux(const vdn_multifab *s, vdn_multifab **sedge, vdn_multifab **flux, vdn_multifab **umac, const vdn_multifab *force,
+                      const vdn_multifab *mac_rhs, const double *dx, double dt, const vdn_bc_tower *bct, bool is_vel, const int *is_cons) {
+  const int ncomp = s->nc;
+  REQUIRE(ncomp <= 3 && s->ng >= 3 && umac[0]->ng >= 1 && force->ng >= 1 && mac_rhs->ng >= 1, "mkflux (dm = 2): operand shapes");
+  const int bccomp = is_vel ? 0 : bct->dm;
+  hipStream_t st = ctx().stream;
+  for (int ib = 0; ib < s->nfabs(); ib++) {
+    size_t mark = arena_mark();
+    GArgs A; fill_gargs(A, s, ib, bct, bccomp, ncomp, dx, dt);
+    A.is_vel = is_vel ? 1 : 0;
+    for (int c = 0; c < ncomp; c++) A.cons[c] = is_cons[c] ? 1 : 0;
+    BoxP bp = make_boxp(s, ib, bct);
+    FV w = work_fv2(bp);
+    const size_t fld = (size_t)w.sc * sizeof(double);
+    FV sl[2] = { w, w }, SI = w;
+    sl[0].p = (double *)arena_alloc(fld * ncomp); sl[1].p = (double *)arena_alloc(fld * ncomp); SI.p = (double *)arena_alloc(fld * 2 * ncomp);
+    double *umax = (double *)arena_alloc(256);
+    HIPCHK(hipMemsetAsync(umax, 0, sizeof(double), st));
+    Range3 rv, rg, rf; ranges2(A, rv, rg, rf);
+    const FV &um = umac[0]->fabs[ib], &vm = umac[1]->fabs[ib];
+    hipLaunchKernelGGL(kk_macmax2, reduce_grid(rf), dim3(64, 4, 1), 0, st, um, vm, A, rf, umax);
+    hipLaunchKernelGGL(kk_slopes, grid_for(rg), dim3(64, 4, 1), 0, st, s->fabs[ib], sl[0], sl[1], sl[1], A, rg, 3);
+    hipLaunchKernelGGL(kk_mk2_B, grid_for(rg), dim3(64, 4, 1), 0, st, s->fabs[ib], sl[0], sl[1], um, vm, force->fabs[ib], mac_rhs->fabs[ib], SI, A, rg, umax);
+    hipLaunchKernelGGL(kk_mk2_D, grid_for(rf), dim3(64, 4, 1), 0, st, s->fabs[ib], sl[0], sl[1], um, vm, force->fabs[ib], mac_rhs->fabs[ib], SI,
+                       sedge[0]->fabs[ib], sedge[1]->fabs[ib], flux[0]->fabs[ib], flux[1]->fabs[ib], A, rf, umax);
+    arena_release(mark);
+  }
+}
+
 void k_velpred(const vdn_multifab *u, vdn_multifab **umac, const vdn_multifab *force, const double *dx, double dt,
                const vdn_bc_tower *bct) {
+  if (ctx().prm.dm == 2) { k2_velpred(u, umac, force, dx, dt, bct); return; }
   REQUIRE(u->nc == 3 && u->ng >= 3 && force->ng >= 1 && umac[0]->ng >= 1, "velpred: operand shapes");
   hipStream_t st = ctx().stream;
   for (int ib = 0; ib < u->nfabs(); ib++) {

@@ -733,6 +733,7 @@ static void cc_store(CCMG &M, vdn_multifab *phi, const int bc[3][2]) {
 
 int cc_solve(vdn_multifab *rh, vdn_multifab *phi, vdn_multifab **beta, const double *dx, const int bc[3][2],
              double rel_eps, double abs_eps, int max_iter, int *cycles, double *res0, double *res, const vdn_multifab *alpha) {
+  if (ctx().prm.dm == 2) return cc2_solve(rh, phi, beta, dx, bc, rel_eps, abs_eps, max_iter, cycles, res0, res, alpha);
   const vdn_params &P = ctx().prm;
   size_t mark = arena_mark();
   CCMG M; cc_setup(M, rh, phi, alpha, beta, dx, bc);
@@ -839,6 +840,7 @@ __global__ void kk_mkumac(FV um, FV vm, FV wm, FV phi, FV bx, FV by, FV bz, Umac
 
 void do_macproject(vdn_layout *mla, vdn_multifab **umac, vdn_multifab **rho, vdn_multifab **mac_rhs, const double *dx,
                    const vdn_bc_tower *bct, int bc_comp0) {
+  if (ctx().prm.dm == 2) { do2_macproject(mla, umac, rho, mac_rhs, dx, bct, bc_comp0); return; }
   REQUIRE(mla->nlev == 1, "macproject: multilevel hierarchies are not implemented in this round");
   const int n = 0;
   hipStream_t st = ctx().stream;

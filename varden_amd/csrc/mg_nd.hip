@@ -707,6 +707,7 @@ static double nd_read(double *d) {
 
 int nd_solve(vdn_multifab *rh, vdn_multifab *phi, const vdn_multifab *coeffs, const vdn_multifab *u, const double *dx,
              const int bc[3][2], double rel_eps, double abs_eps, int max_iter, int *cycles, double *res0, double *res) {
+  if (ctx().prm.dm == 2) return nd2_solve(rh, phi, coeffs, u, dx, bc, rel_eps, abs_eps, max_iter, cycles, res0, res);
   const vdn_params &P = ctx().prm;
   REQUIRE(rh->ng >= 1 && phi->ng >= 1 && coeffs->ng >= 1, "nodal multigrid: rh, phi, coeffs need one ghost layer");
   hipStream_t st = ctx().stream;
@@ -850,6 +851,7 @@ __global__ void kk_hg_update(FV unew, FV uold, FV gp, FV gphi, FV rhohalf, FV p,
 
 void do_hgproject(int proj_type, vdn_layout *mla, vdn_multifab **unew, vdn_multifab **uold, vdn_multifab **rhohalf,
                   vdn_multifab **p, vdn_multifab **gp, const double *dx, double dt, const vdn_bc_tower *bct, int press_comp0) {
+  if (ctx().prm.dm == 2) { do2_hgproject(proj_type, mla, unew, uold, rhohalf, p, gp, dx, dt, bct, press_comp0); return; }
   REQUIRE(mla->nlev == 1, "hgproject: multilevel hierarchies are not implemented in this round");
   REQUIRE(proj_type >= VDN_INITIAL_PROJECTION && proj_type <= VDN_REGULAR_TIMESTEP, "No proj_type by this number");
   const int n = 0;

@@ -30,6 +30,7 @@ __global__ void kk_mkvelforce(FV vf, FV ext, FV gp, FV s, FV lapu, int has_lapu,
 
 void k_mkvelforce(vdn_multifab *vf, const vdn_multifab *ext, const vdn_multifab *s, const vdn_multifab *gp,
                   const vdn_multifab *lapu, double visc_fac) {
+  if (ctx().prm.dm == 2) { k2_mkvelforce(vf, ext, s, gp, lapu, visc_fac); return; }
   REQUIRE(vf->ng >= 1 && ext->ng >= 1 && gp->ng >= 1 && s->ng >= 1, "mkvelforce: operands need a ghost cell");
   mf_setval(vf, 0.0, 0, vf->nc, true);              // mkforce.f90:52
   for (int i = 0; i < vf->nfabs(); i++) {
@@ -55,6 +56,7 @@ __global__ void kk_mkscalforce(FV sf, FV ext, FV laps, int has_laps, ForceArgs A
 }
 
 void k_mkscalforce(vdn_multifab *sf, const vdn_multifab *ext, const vdn_multifab *laps, double diff_fac) {
+  if (ctx().prm.dm == 2) { k2_mkscalforce(sf, ext, laps, diff_fac); return; }
   mf_setval(sf, 0.0, 0, sf->nc, true);              // mkforce.f90:267 / 346
   for (int i = 0; i < sf->nfabs(); i++) {
     ForceArgs A; Range3 r;
@@ -94,6 +96,7 @@ __global__ void kk_update(FV sold, FV snew, FV um, FV vm, FV wm, FV sx, FV sy, F
 
 void k_update(const vdn_multifab *sold, vdn_multifab **umac, vdn_multifab **sedge, vdn_multifab **flux,
               const vdn_multifab *force, vdn_multifab *snew, const double *dx, double dt, bool is_vel, const int *is_cons) {
+  if (ctx().prm.dm == 2) { k2_update(sold, umac, sedge, flux, force, snew, dx, dt, is_vel, is_cons); return; }
   for (int i = 0; i < sold->nfabs(); i++) {
     UpdArgs A; Range3 r;
     for (int d = 0; d < 3; d++) { A.dx[d] = dx[d]; r.lo[d] = sold->vbox[i].lo[d]; r.hi[d] = sold->vbox[i].hi[d]; }
@@ -134,6 +137,7 @@ __global__ void kk_estdt(FV u, FV s, FV gp, FV ext, Range3 r, double *out6) {
   for (int c = 0; c < 6; c++) block_atomic_max(out6 + c, m[c]);
 }
 void k_estdt_max(const vdn_multifab *u, const vdn_multifab *s, const vdn_multifab *gp, const vdn_multifab *ext, double out6[6]) {
+  if (ctx().prm.dm == 2) { k2_estdt_max(u, s, gp, ext, out6); return; }
   VdnCtx &c = ctx();
   HIPCHK(hipMemsetAsync(c.d_scal, 0, 6 * sizeof(double), c.stream));
   for (int i = 0; i < u->nfabs(); i++) {

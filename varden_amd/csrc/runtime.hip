@@ -77,7 +77,7 @@ extern "C" const char *vdn_last_error(void) { return g_err; }
 extern "C" int vdn_init(const vdn_params *prm, int rank, int nranks, int device) {
   VDN_TRY
   REQUIRE(prm != nullptr, "vdn_init: null params");
-  REQUIRE(prm->dm == 3, "vdn_init: only dm = 3 is implemented on the device path (got %d)", prm->dm);
+  REQUIRE(prm->dm == 3 || prm->dm == 2, "vdn_init: dm must be 2 or 3 (got %d)", prm->dm);
   REQUIRE(prm->nscal >= 1 && prm->nscal + 5 <= VDN_MAXCOMP, "vdn_init: bad nscal %d", prm->nscal);
   REQUIRE(prm->visc_coef >= 0.0 && prm->diff_coef >= 0.0, "vdn_init: negative visc_coef / diff_coef");
   REQUIRE(prm->diffusion_type == 1 || prm->diffusion_type == 2, "BAD DIFFUSION TYPE");      // velocity_advance.f90:113
@@ -129,7 +129,8 @@ extern "C" int vdn_layout_create(int nlev, const int *rr, const vdn_box *pd, con
   for (int l = 0; l < nlev; l++) {
     for (int b = 0; b < nboxes[l]; b++) {
       const vdn_box &bx = boxes[off + b];
-      for (int d = 0; d < 3; d++) REQUIRE(bx.hi[d] - bx.lo[d] + 1 >= 4, "box %d of level %d is narrower than 4 cells", b, l);
+      for (int d = 0; d < g_ctx.prm.dm; d++) REQUIRE(bx.hi[d] - bx.lo[d] + 1 >= 4, "box %d of level %d is narrower than 4 cells", b, l);
+      if (g_ctx.prm.dm == 2) REQUIRE(bx.lo[2] == 0 && bx.hi[2] == 0, "dm = 2: boxes must have lo(3) = hi(3) = 0");
       la->boxes[l].push_back(bx);
       int ow = owner ? owner[off + b] : 0;
       REQUIRE(ow >= 0 && ow < g_ctx.nranks, "owner %d out of range", ow);
@@ -202,7 +203,7 @@ extern "C" int vdn_bc_tower_create(const vdn_layout *la, const int *phys_bc, vdn
   vdn_bc_tower *b = new vdn_bc_tower;
   b->la = la; b->dm = g_ctx.prm.dm; b->nscal = g_ctx.prm.nscal;
   b->ncomp_adv = b->dm + b->nscal + 2; b->ncomp_ell = b->dm + b->nscal + 1;
-  for (int d = 0; d < 3; d++) for (int s = 0; s < 2; s++) b->domain_bc[d][s] = phys_bc[d * 2 + s];
+  for (int d = 0; d < 3; d++) for (int s = 0; s < 2; s++) b->domain_bc[d][s] = (d < b->dm) ? phys_bc[d * 2 + s] : VDN_INTERIOR;   // dm = 2: no z faces
   b->phys.resize(la->nlev); b->adv.resize(la->nlev); b->ell.resize(la->nlev);
   for (int l = 0; l < la->nlev; l++) {
     int ng = (int)la->local[l].size() + 1;
@@ -299,16 +300,33 @@ extern "C" int vdn_multifab_nfabs(const vdn_multifab *mf) { return mf->nfabs(); 
 extern "C" int vdn_multifab_ncomp(const vdn_multifab *mf) { return mf->nc; }
 extern "C" int vdn_multifab_nghost(const vdn_multifab *mf) { return mf->ng; }
 extern "C" int vdn_multifab_get_box(const vdn_multifab *mf, int i, vdn_box *out) { *out = mf->vbox[i]; return 0; }
-extern "C" long vdn_multifab_fab_size(const vdn_multifab *mf, int i) { return mf->fab_size(i); }
+// dm = 2: the host sees the BoxLib 2-D layout p(lo1-ng:hi1+ng, lo2-ng:hi2+ng, nc) = plane k = 0 of every component
+static bool host_2d(const vdn_multifab *mf) { return g_ctx.prm.dm == 2; (void)mf; }
+extern "C" long vdn_multifab_fab_size(const vdn_multifab *mf, int i) {
+  if (host_2d(mf)) return (long)mf->fabs[i].n0 * mf->fabs[i].n1 * mf->nc;
+  return mf->fab_size(i);
+}
+static void copy_plane0(const vdn_multifab *mf, int i, double *host, bool to_host) {
+  const FV &f = mf->fabs[i];
+  const long plane = (long)f.n0 * f.n1;
+  for (int c = 0; c < mf->nc; c++) {
+    double *dev = f.p + f.sc * c + plane * (0 - f.a2);
+    if (to_host) HIPCHK(hipMemcpyAsync(host + plane * c, dev, plane * sizeof(double), hipMemcpyDeviceToHost, g_ctx.stream));
+    else HIPCHK(hipMemcpyAsync(dev, host + plane * c, plane * sizeof(double), hipMemcpyHostToDevice, g_ctx.stream));
+  }
+  HIPCHK(hipStreamSynchronize(g_ctx.stream));
+}
 extern "C" int vdn_multifab_dataptr(const vdn_multifab *mf, int i, double **dev) { *dev = mf->fabs[i].p; return 0; }
 extern "C" int vdn_multifab_copy_to_host(const vdn_multifab *mf, int i, double *host) {
   VDN_TRY
+  if (host_2d(mf)) { copy_plane0(mf, i, host, true); return 0; }
   HIPCHK(hipMemcpyAsync(host, mf->fabs[i].p, mf->fab_size(i) * sizeof(double), hipMemcpyDeviceToHost, g_ctx.stream));
   HIPCHK(hipStreamSynchronize(g_ctx.stream));
   VDN_CATCH
 }
 extern "C" int vdn_multifab_copy_from_host(vdn_multifab *mf, int i, const double *host) {
   VDN_TRY
+  if (host_2d(mf)) { copy_plane0(mf, i, const_cast<double *>(host), false); return 0; }
   HIPCHK(hipMemcpyAsync(mf->fabs[i].p, host, mf->fab_size(i) * sizeof(double), hipMemcpyHostToDevice, g_ctx.stream));
   HIPCHK(hipStreamSynchronize(g_ctx.stream));
   VDN_CATCH
@@ -438,6 +456,10 @@ __global__ void k_physbc(FV f, PhysArgs A) {
 
 static bool extdir_value(int icomp1, int d, int s, double *v) {
   const vdn_params &p = g_ctx.prm;
+  if (p.dm == 2) {                // multifab_physbc.f90:96-99
+    switch (icomp1) { case 1: *v = p.u_bc[d][s]; return true; case 2: *v = p.v_bc[d][s]; return true; case 3: *v = p.rho_bc[d][s]; return true; case 4: *v = p.trac_bc[d][s]; return true; }
+    return false;
+  }
   switch (icomp1) {               // multifab_physbc.f90:282-287
     case 1: *v = p.u_bc[d][s]; return true;
     case 2: *v = p.v_bc[d][s]; return true;

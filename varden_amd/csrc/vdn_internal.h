@@ -166,3 +166,21 @@ void do_hgproject(int proj_type, vdn_layout *mla, vdn_multifab **unew, vdn_multi
                   vdn_multifab **p, vdn_multifab **gp, const double *dx, double dt, const vdn_bc_tower *bct, int press_comp0);
 int  nd_solve(vdn_multifab *rh, vdn_multifab *phi, const vdn_multifab *coeffs, const vdn_multifab *u, const double *dx,
               const int bc[3][2], double rel_eps, double abs_eps, int max_iter, int *cycles, double *res0, double *res);
+
+// dim2.hip: the dm = 2 path (one level, one box)
+void k2_mkvelforce(vdn_multifab *vf, const vdn_multifab *ext, const vdn_multifab *s, const vdn_multifab *gp, const vdn_multifab *lapu, double visc_fac);
+void k2_mkscalforce(vdn_multifab *sf, const vdn_multifab *ext, const vdn_multifab *laps, double diff_fac);
+void k2_update(const vdn_multifab *sold, vdn_multifab **umac, vdn_multifab **sedge, vdn_multifab **flux, const vdn_multifab *force, vdn_multifab *snew,
+               const double *dx, double dt, bool is_vel, const int *is_cons);
+void k2_estdt_max(const vdn_multifab *u, const vdn_multifab *s, const vdn_multifab *gp, const vdn_multifab *ext, double out6[6]);
+int  cc2_solve(vdn_multifab *rh, vdn_multifab *phi, vdn_multifab **beta, const double *dx, const int bc[3][2], double rel_eps, double abs_eps, int max_iter,
+               int *cycles, double *res0, double *res, const vdn_multifab *alpha);
+void do2_macproject(vdn_layout *mla, vdn_multifab **umac, vdn_multifab **rho, vdn_multifab **mac_rhs, const double *dx, const vdn_bc_tower *bct, int bc_comp0);
+void k2_explicit_diffusive_term(vdn_multifab *lap, const vdn_multifab *data, int comp, int bccomp0, const double *dx, const vdn_bc_tower *bct);
+void do2_visc_solve(vdn_layout *mla, vdn_multifab *unew, const vdn_multifab *lapu, const vdn_multifab *rho, const vdn_multifab *mac_rhs,
+                    const double *dx, double mu, const vdn_bc_tower *bct);
+void do2_diff_scalar_solve(vdn_layout *mla, vdn_multifab *snew, const vdn_multifab *laps, const double *dx, double mu, const vdn_bc_tower *bct, int icomp, int bccomp0);
+int  nd2_solve(vdn_multifab *rh, vdn_multifab *phi, const vdn_multifab *coeffs, const vdn_multifab *u, const double *dx, const int bc[3][2],
+               double rel_eps, double abs_eps, int max_iter, int *cycles, double *res0, double *res);
+void do2_hgproject(int proj_type, vdn_layout *mla, vdn_multifab **unew, vdn_multifab **uold, vdn_multifab **rhohalf, vdn_multifab **p, vdn_multifab **gp,
+                   const double *dx, double dt, const vdn_bc_tower *bct, int press_comp0);

@@ -28,6 +28,7 @@ __global__ void kk_lap(FV lap, FV data, LapArgs A, Range3 r) {
 
 // lap(comp) = laplacian(data(comp)); bccomp0 = 0-based ell bc component.  data must have its ghost cells filled.
 void k_explicit_diffusive_term(vdn_multifab *lap, const vdn_multifab *data, int comp, int bccomp0, const double *dx, const vdn_bc_tower *bct) {
+  if (ctx().prm.dm == 2) { k2_explicit_diffusive_term(lap, data, comp, bccomp0, dx, bct); return; }
   REQUIRE(data->ng >= 1, "explicit diffusive term: data needs a filled ghost cell");
   for (int i = 0; i < data->nfabs(); i++) {
     LapArgs A; Range3 r;
@@ -72,6 +73,7 @@ static void ell_of(const vdn_bc_tower *bct, int lev, int comp0, int ebc[3][2]) {
 
 void do_visc_solve(vdn_layout *mla, vdn_multifab *unew, const vdn_multifab *lapu, const vdn_multifab *rho, const vdn_multifab *mac_rhs,
                    const double *dx, double mu, const vdn_bc_tower *bct) {
+  if (ctx().prm.dm == 2) { do2_visc_solve(mla, unew, lapu, rho, mac_rhs, dx, mu, bct); return; }
   const int n = 0;
   hipStream_t st = ctx().stream;
   size_t mark = arena_mark();
@@ -104,6 +106,7 @@ void do_visc_solve(vdn_layout *mla, vdn_multifab *unew, const vdn_multifab *lapu
 
 void do_diff_scalar_solve(vdn_layout *mla, vdn_multifab *snew, const vdn_multifab *laps, const double *dx, double mu,
                           const vdn_bc_tower *bct, int icomp, int bccomp0) {
+  if (ctx().prm.dm == 2) { do2_diff_scalar_solve(mla, snew, laps, dx, mu, bct, icomp, bccomp0); return; }
   const int n = 0;
   hipStream_t st = ctx().stream;
   size_t mark = arena_mark();

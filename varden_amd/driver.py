@@ -12,9 +12,25 @@ from . import boxlib as bl
 from .capi import default_params
 
 
-def initdata_numpy(n, dx, prob_type=1, ng=3, nscal=2, lo=(0, 0, 0), centre=(0.5, 0.5, 0.5)):
+def initdata_numpy(n, dx, prob_type=1, ng=3, nscal=2, lo=(0, 0, 0), centre=(0.5, 0.5, 0.5), dm=3):
     """reference src/initdata.f90:212-259 (prob_type 1 bubble / 2 advected blob), numpy restatement used
-    for synthetic bench input; fills the box [lo, lo+n) (with ng ghost layers left at the background value)."""
+    for synthetic bench input; fills the box [lo, lo+n) (with ng ghost layers left at the background value).
+    dm = 2: initdata_2d (initdata.f90:127-171, densfact = 2), arrays of shape (nx+2ng, ny+2ng, 1, nc)."""
+    if dm == 2:
+        u = np.zeros((n[0] + 2 * ng, n[1] + 2 * ng, 1, 2), order="F")
+        s = np.zeros((n[0] + 2 * ng, n[1] + 2 * ng, 1, nscal), order="F")
+        s[..., 0] = 1.0
+        if prob_type == 2:
+            u[..., 0] = 1.0
+        x = dx[0] * (lo[0] + np.arange(n[0]) + 0.5)
+        y = dx[1] * (lo[1] + np.arange(n[1]) + 0.5)
+        X, Y = np.meshgrid(x, y, indexing="ij")
+        dist = np.sqrt((X - centre[0]) ** 2 + (Y - centre[1]) ** 2)
+        r = 1.0 + 0.5 * (2.0 - 1.0) * (1.0 - np.tanh(30.0 * (dist - 0.1)))
+        s[ng:-ng, ng:-ng, 0, 0] = r
+        if nscal > 1:
+            s[ng:-ng, ng:-ng, 0, 1] = r
+        return u, s
     u = np.zeros(tuple(x + 2 * ng for x in n) + (3,), order="F")
     s = np.zeros(tuple(x + 2 * ng for x in n) + (nscal,), order="F")
     s[..., 0] = 1.0
@@ -40,14 +56,18 @@ class Varden:
         """decomp = (bx, by, bz): the domain is cut into bx*by*bz equal boxes (max_grid_size of the reference,
         src/_parameters:27), dealt round-robin to the ranks (one rank per GPU).  comm_id: the 128-byte RCCL unique
         id broadcast by the caller when nranks > 1."""
-        self.n = tuple(int(x) for x in (n if hasattr(n, "__len__") else (n, n, n)))
         self.prm = params or default_params()
+        dm = int(self.prm.dm)
+        self.n = tuple(int(x) for x in (n if hasattr(n, "__len__") else (n,) * dm))
+        if dm == 2:
+            self.n = self.n[:2] + (1,)
+            decomp = (decomp[0], decomp[1], 1)
         self.prm.prob_type = prob_type
         self.rank, self.nranks = rank, nranks
         bl.initialize(self.prm, rank, nranks, device)
         if nranks > 1:
             bl.comm_init(comm_id)
-        self.phys = [[int(phys_bc[d][s]) for s in range(2)] for d in range(3)]
+        self.phys = [[int(phys_bc[d][s]) for s in range(2)] if d < dm else [bl.INTERIOR, bl.INTERIOR] for d in range(3)]
         pmask = tuple(1 if self.phys[d][0] == bl.PERIODIC else 0 for d in range(3))
         lo, hi = (0, 0, 0), tuple(x - 1 for x in self.n)
         bs = tuple(self.n[d] // decomp[d] for d in range(3))
@@ -62,8 +82,8 @@ class Varden:
         self.local = [i for i in range(len(self.boxes)) if self.owner[i] == rank]
         self.mla = bl.MLLayout([(lo, hi)], [self.boxes], owner=[self.owner], pmask=pmask)
         self.bct = bl.BCTower(self.mla, self.phys)
-        self.dx = [[prob_hi[d] / self.n[d] for d in range(3)]]
-        dm, ns = 3, self.prm.nscal
+        self.dx = [[prob_hi[d] / self.n[d] for d in range(dm)]]
+        ns = self.prm.nscal
         self.dm, self.nscal, self.press_comp = dm, ns, dm + ns + 1
         mk = lambda nc, ng, nodal=None: [bl.MultiFab(self.mla, 0, nc, ng, nodal)]   # noqa: E731
         self.uold, self.sold, self.unew, self.snew = mk(dm, 3), mk(ns, 3), mk(dm, 3), mk(ns, 3)
@@ -73,9 +93,9 @@ class Varden:
         for li, gi in enumerate(self.local):              # each rank initialises / uploads only the boxes it owns
             blo, bhi = self.boxes[gi]
             if u0 is None:                                # blob centred in the domain (= (0.5,0.5,0.5) on the unit cube)
-                ub, sb = initdata_numpy(bs, self.dx[0], prob_type, 3, ns, lo=blo, centre=tuple(0.5 * prob_hi[d] for d in range(3)))
+                ub, sb = initdata_numpy(bs, self.dx[0], prob_type, 3, ns, lo=blo, centre=tuple(0.5 * prob_hi[d] for d in range(3)), dm=dm)
             else:                                         # caller-supplied global arrays (carry 3 ghost layers)
-                sl = tuple(slice(blo[d], bhi[d] + 1 + 6) for d in range(3))
+                sl = tuple(slice(blo[d], bhi[d] + 1 + 6) if d < dm else slice(None) for d in range(3))
                 ub, sb = np.array(u0[sl], order="F"), np.array(s0[sl], order="F")
             self.uold[0].from_numpy(ub, li)
             self.sold[0].from_numpy(sb, li)
@@ -126,10 +146,11 @@ class Varden:
         """valid cells of the LOCAL boxes assembled into a global array (NaN where other ranks own the data)"""
         out = np.full(self.n + (mf.nc,), np.nan, order="F")
         g = mf.ng
+        gz = g if self.dm == 3 else 0
         for li, gi in enumerate(self.local):
             blo, bhi = self.boxes[gi]
             a = mf.to_numpy(li)
-            v = a[g:a.shape[0] - g, g:a.shape[1] - g, g:a.shape[2] - g] if g else a
+            v = a[g:a.shape[0] - g, g:a.shape[1] - g, gz:a.shape[2] - gz] if g else a
             out[tuple(slice(blo[d], bhi[d] + 1) for d in range(3))] = v[:bhi[0] - blo[0] + 1, :bhi[1] - blo[1] + 1, :bhi[2] - blo[2] + 1]
         return out
 
