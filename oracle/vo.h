@@ -167,6 +167,18 @@ void vo_advance_timestep(vo_state *S, const double dx[3], double dt, const vo_bc
 /* ---- initdata.f90:201-311 (prob_type 1 and 2) ----------------------------------------------- */
 void vo_initdata(vo_fab *u, vo_fab *s, const double dx[3], int prob_type);
 
+/* ---- two-level AMR (oracle/vo_amr.c): FBoxLib's multi-level operators (our definitions) and the multilevel macproject ---- */
+void vo_ml_cc_restriction(vo_fab *crse, const vo_fab *fine, int icomp, int nc);
+void vo_ml_edge_restriction(vo_fab *crse, const vo_fab *fine, int dir);
+void vo_fill_ghost_cells(vo_fab *fine, const vo_fab *crse, int icomp, int nc);
+void vo_create_umac_grown(vo_fab *fine, const vo_fab *crse, int dir);
+void vo_ml_restrict_and_fill(int nlev, vo_fab **mf, int icomp, int bcomp, int nc, int same_boundary, const vo_bc *bc, const int pmask[3],
+                             const int *pd, const vdn_params *prm);
+int  vo_ml_cc_solve(int nlev, vo_fab **rh, vo_fab **phi, vo_fab **beta, const double *dx, const int ellbc[2][3][2], const int pmask[3], const int *pd,
+                    double rel_eps, int max_iter, const vdn_params *prm, vo_mgstat *st);
+void vo_ml_macproject(int nlev, vo_fab **umac, vo_fab **rho, vo_fab **mac_rhs, const double *dx, const vo_bc *bc, const int pmask[3], const int *pd,
+                      const vdn_params *prm, vo_mgstat *st);
+
 /* ---- the 2-D path (oracle/vo_2d.c): velpred_2d, mkflux_2d, update_2d, mkforce 2-D, estdt_2d, macproject / hgproject
  *      2-D kernels, our 5-point cell-centred and 9-point nodal multigrids, advance_timestep with dm = 2 ------------ */
 #define V2(f, i, j, c) VF(f, i, j, 0, c)

@@ -1,0 +1,325 @@
+/* oracle/vo_amr.c -- two-level AMR pieces of the hot path (BASELINE.json configs[3]): the FBoxLib multi-level
+ * operators the reference calls (ml_cc_restriction, ml_edge_restriction, multifab_fill_ghost_cells, create_umac_grown,
+ * ml_restrict_and_fill, ml_cc_solve) and the multilevel macproject (src/macproject.f90:20-133) built on them.
+ * TEST INFRASTRUCTURE ONLY (see vo.h).  parity unpinned.
+ *
+ * None of these operators is in the reference tree (FBoxLib); the call sites fix WHAT they must do, the definitions
+ * below are ours and are the ones the HIP path (varden_amd/csrc/amr.hip) implements:
+ *   ml_cc_restriction     coarse cell = mean of its 8 fine cells                       (macproject.f90:204-206, hgproject.f90:355-357)
+ *   ml_edge_restriction   coarse face = mean of the 4 fine faces that cover it         (velpred.f90:115-119, macproject.f90:330-333, 497-500)
+ *   fill_ghost_cells      fine ghost cell = coarse parent + limited linear slopes      (macproject.f90:304-310; ml_restrict_and_fill)
+ *                         (MC-limited central differences per direction, the limiter of slope.f90:181-187)
+ *   create_umac_grown     fine ghost face = coarse face value (even index) or the mean of the two coarse faces around it
+ *                         (odd index), piecewise constant across the face           (velpred.f90:102-107, macproject.f90:107-113)
+ *   ml_cc_solve           composite solve: fine cells + uncovered coarse cells; coarse-fine ghost cells by quadratic
+ *                         interpolation normal to the interface (8/15, 2/3, -1/5) of the transversely (central-slope)
+ *                         interpolated coarse value and two fine cells; the coarse flux through an interface face is the
+ *                         mean of the four fine fluxes.  Algorithm: FAC iteration -- composite residual, one V-cycle of
+ *                         the single-level multigrid on the whole coarse level, piecewise-constant prolongation, red-black
+ *                         relaxation of the fine level with a homogeneous interface.
+ * This round: ONE box per level, two levels, refinement ratio 2, the fine box properly nested (>= 1 coarse cell away from
+ * any domain face it does not touch).
+ */
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+#include <stdio.h>
+#include "vo.h"
+
+static inline int fdiv2(int a) { return a >= 0 ? a / 2 : -((-a + 1) / 2); }       /* floor(a/2) */
+static inline double sgn1(double x) { return copysign(1.0, x); }
+static inline double mc_limited(double del, double sm, double s0, double sp)
+{
+  double dmin = 2.0 * (s0 - sm), dpls = 2.0 * (sp - s0);
+  double slim = fmin(fabs(dpls), fabs(dmin));
+  slim = (dpls * dmin > 0.0) ? slim : 0.0;
+  return sgn1(del) * fmin(slim, fabs(del));
+}
+static inline int in_alloc(const vo_fab *f, int i, int j, int k)
+{
+  return i >= f->lo[0] - f->ng && i <= f->hi[0] + f->nd[0] + f->ng && j >= f->lo[1] - f->ng && j <= f->hi[1] + f->nd[1] + f->ng &&
+         k >= f->lo[2] - f->gz && k <= f->hi[2] + f->nd[2] + f->gz;
+}
+
+void vo_ml_cc_restriction(vo_fab *crse, const vo_fab *fine, int icomp, int nc)
+{
+  for (int c = icomp; c < icomp + nc; c++)
+  for (int K = fine->lo[2] / 2; K <= fine->hi[2] / 2; K++) for (int J = fine->lo[1] / 2; J <= fine->hi[1] / 2; J++) for (int I = fine->lo[0] / 2; I <= fine->hi[0] / 2; I++) {
+    double s = 0.0;
+    for (int kk = 0; kk < 2; kk++) for (int jj = 0; jj < 2; jj++) for (int ii = 0; ii < 2; ii++) s = s + VF(fine, 2 * I + ii, 2 * J + jj, 2 * K + kk, c);
+    VF(crse, I, J, K, c) = s * 0.125;
+  }
+}
+void vo_ml_edge_restriction(vo_fab *crse, const vo_fab *fine, int dir)
+{
+  int lo[3], hi[3];
+  for (int d = 0; d < 3; d++) { lo[d] = fine->lo[d] / 2; hi[d] = fine->hi[d] / 2; }
+  hi[dir] += 1;
+  const int t1 = (dir + 1) % 3, t2 = (dir + 2) % 3;
+  for (int K = lo[2]; K <= hi[2]; K++) for (int J = lo[1]; J <= hi[1]; J++) for (int I = lo[0]; I <= hi[0]; I++) {
+    int Q[3] = { I, J, K };
+    double s = 0.0;
+    for (int b = 0; b < 2; b++) for (int a = 0; a < 2; a++) {
+      int q[3]; q[dir] = 2 * Q[dir]; q[t1] = 2 * Q[t1] + a; q[t2] = 2 * Q[t2] + b;
+      s = s + VF(fine, q[0], q[1], q[2], 0);
+    }
+    VF(crse, I, J, K, 0) = s * 0.25;
+  }
+}
+/* every ghost cell of the fine fab whose parent lies inside the coarse fab's allocation */
+void vo_fill_ghost_cells(vo_fab *fine, const vo_fab *crse, int icomp, int nc)
+{
+  const int ng = fine->ng;
+  for (int c = icomp; c < icomp + nc; c++)
+  for (int k = fine->lo[2] - ng; k <= fine->hi[2] + ng; k++) for (int j = fine->lo[1] - ng; j <= fine->hi[1] + ng; j++) for (int i = fine->lo[0] - ng; i <= fine->hi[0] + ng; i++) {
+    if (i >= fine->lo[0] && i <= fine->hi[0] && j >= fine->lo[1] && j <= fine->hi[1] && k >= fine->lo[2] && k <= fine->hi[2]) continue;
+    const int q[3] = { i, j, k }, P[3] = { fdiv2(i), fdiv2(j), fdiv2(k) };
+    if (!in_alloc(crse, P[0], P[1], P[2])) continue;
+    const double c0 = VF(crse, P[0], P[1], P[2], c);
+    double v = c0;
+    for (int d = 0; d < 3; d++) {
+      int m[3] = { P[0], P[1], P[2] }, p[3] = { P[0], P[1], P[2] }; m[d] -= 1; p[d] += 1;
+      double sl = 0.0;
+      if (in_alloc(crse, m[0], m[1], m[2]) && in_alloc(crse, p[0], p[1], p[2])) {
+        const double cm = VF(crse, m[0], m[1], m[2], c), cp = VF(crse, p[0], p[1], p[2], c);
+        sl = mc_limited(0.5 * (cp - cm), cm, c0, cp);
+      }
+      const double sg = (q[d] - 2 * P[d]) ? 0.25 : -0.25;
+      v = v + sg * sl;
+    }
+    VF(fine, i, j, k, c) = v;
+  }
+}
+void vo_create_umac_grown(vo_fab *fine, const vo_fab *crse, int dir)
+{
+  const int ng = fine->ng;
+  for (int k = fine->lo[2] - ng; k <= fine->hi[2] + fine->nd[2] + ng; k++) for (int j = fine->lo[1] - ng; j <= fine->hi[1] + fine->nd[1] + ng; j++)
+  for (int i = fine->lo[0] - ng; i <= fine->hi[0] + fine->nd[0] + ng; i++) {
+    if (i >= fine->lo[0] && i <= fine->hi[0] + fine->nd[0] && j >= fine->lo[1] && j <= fine->hi[1] + fine->nd[1] && k >= fine->lo[2] && k <= fine->hi[2] + fine->nd[2]) continue;
+    const int q[3] = { i, j, k };
+    int P[3] = { fdiv2(i), fdiv2(j), fdiv2(k) }, P2[3];
+    const int odd = q[dir] - 2 * P[dir];
+    P2[0] = P[0]; P2[1] = P[1]; P2[2] = P[2]; P2[dir] += 1;
+    if (!in_alloc(crse, P[0], P[1], P[2]) || (odd && !in_alloc(crse, P2[0], P2[1], P2[2]))) continue;
+    VF(fine, i, j, k, 0) = odd ? 0.5 * (VF(crse, P[0], P[1], P[2], 0) + VF(crse, P2[0], P2[1], P2[2], 0)) : VF(crse, P[0], P[1], P[2], 0);
+  }
+}
+/* fill_boundary of a level that is one box inside the domain pd: periodic wrap only where the box spans the domain */
+static void level_fill_boundary(vo_fab *f, const int pmask[3], const int pdlo[3], const int pdhi[3])
+{
+  int pm[3];
+  for (int d = 0; d < 3; d++) pm[d] = pmask[d] && f->lo[d] == pdlo[d] && f->hi[d] == pdhi[d];
+  vo_fill_boundary(f, pm);
+}
+/* ml_restrict_and_fill for two levels: average down, coarse ghosts, fine ghosts (coarse interpolation, then same-level
+ * periodic images, then the physical boundary) */
+void vo_ml_restrict_and_fill(int nlev, vo_fab **mf, int icomp, int bcomp, int nc, int same_boundary, const vo_bc *bc, const int pmask[3],
+                             const int *pd /* [lev][2][3] */, const vdn_params *prm)
+{
+  for (int n = nlev - 1; n >= 1; n--) vo_ml_cc_restriction(mf[n - 1], mf[n], icomp, nc);
+  for (int n = 0; n < nlev; n++) {
+    if (n > 0) vo_fill_ghost_cells(mf[n], mf[n - 1], icomp, nc);
+    level_fill_boundary(mf[n], pmask, pd + 6 * n, pd + 6 * n + 3);
+    for (int c = 0; c < nc; c++) vo_physbc(mf[n], icomp + c, same_boundary ? bcomp : bcomp + c, 1, &bc[n], prm);
+  }
+}
+
+/* ---------------------------------------------------------------------------------------------------------------------
+ * composite cell-centred solve, two levels
+ * ------------------------------------------------------------------------------------------------------------------- */
+/* ghost layer of phi on one level: domain faces by the solver's closure (Neumann: phi_i, Dirichlet: -phi_i), periodic images */
+static void phi_closure(vo_fab *phi, const int ellbc[3][2], const int pmask[3], const int pdlo[3], const int pdhi[3])
+{
+  const int *lo = phi->lo, *hi = phi->hi;
+  for (int d = 0; d < 3; d++) for (int s = 0; s < 2; s++) {
+    if (ellbc[d][s] != VDN_BC_NEU && ellbc[d][s] != VDN_BC_DIR) continue;
+    const int t1 = (d + 1) % 3, t2 = (d + 2) % 3;
+    for (int b2 = lo[t2]; b2 <= hi[t2]; b2++) for (int b1 = lo[t1]; b1 <= hi[t1]; b1++) {
+      int q[3], g[3]; q[t1] = g[t1] = b1; q[t2] = g[t2] = b2; q[d] = s ? hi[d] : lo[d]; g[d] = s ? hi[d] + 1 : lo[d] - 1;
+      const double v = VF(phi, q[0], q[1], q[2], 0);
+      VF(phi, g[0], g[1], g[2], 0) = (ellbc[d][s] == VDN_BC_NEU) ? v : -v;
+    }
+  }
+  level_fill_boundary(phi, pmask, pdlo, pdhi);
+}
+/* coarse-fine ghost cells of the fine phi on the faces of the fine box that are not domain faces */
+static void cf_interp(vo_fab *pf, const vo_fab *pc, const int ellbc_f[3][2])
+{
+  const int *lo = pf->lo, *hi = pf->hi;
+  for (int d = 0; d < 3; d++) for (int s = 0; s < 2; s++) {
+    if (ellbc_f[d][s] != VDN_BC_INT) continue;
+    const int t1 = (d + 1) % 3, t2 = (d + 2) % 3;
+    const int ta = t1 < t2 ? t1 : t2, tb = t1 < t2 ? t2 : t1;
+    for (int b2 = lo[tb]; b2 <= hi[tb]; b2++) for (int b1 = lo[ta]; b1 <= hi[ta]; b1++) {
+      int g[3], f1[3], f2[3]; g[ta] = f1[ta] = f2[ta] = b1; g[tb] = f1[tb] = f2[tb] = b2;
+      g[d] = s ? hi[d] + 1 : lo[d] - 1; f1[d] = s ? hi[d] : lo[d]; f2[d] = s ? hi[d] - 1 : lo[d] + 1;
+      const int P[3] = { fdiv2(g[0]), fdiv2(g[1]), fdiv2(g[2]) };
+      double pcs = VF(pc, P[0], P[1], P[2], 0);
+      const int tt[2] = { ta, tb };
+      for (int n = 0; n < 2; n++) {
+        const int t = tt[n];
+        int m[3] = { P[0], P[1], P[2] }, p[3] = { P[0], P[1], P[2] }; m[t] -= 1; p[t] += 1;
+        const double sg = (g[t] - 2 * P[t]) ? 0.125 : -0.125;
+        pcs = pcs + sg * (VF(pc, p[0], p[1], p[2], 0) - VF(pc, m[0], m[1], m[2], 0));
+      }
+      VF(pf, g[0], g[1], g[2], 0) = (8.0 / 15.0) * pcs + (2.0 / 3.0) * VF(pf, f1[0], f1[1], f1[2], 0) - 0.2 * VF(pf, f2[0], f2[1], f2[2], 0);
+    }
+  }
+}
+/* res = rh - A phi on the valid cells of one level, phi's ghost layer already filled; returns the max-norm over cells
+ * where mask (may be NULL) is 0 */
+static double plain_residual(const vo_fab *rh, const vo_fab *phi, vo_fab *beta[3], const double dx[3], vo_fab *res)
+{
+  const int *lo = rh->lo, *hi = rh->hi;
+  const double hi2[3] = { 1.0 / (dx[0] * dx[0]), 1.0 / (dx[1] * dx[1]), 1.0 / (dx[2] * dx[2]) };
+  double nrm = 0.0;
+  for (int k = lo[2]; k <= hi[2]; k++) for (int j = lo[1]; j <= hi[1]; j++) for (int i = lo[0]; i <= hi[0]; i++) {
+    const double p0 = VF(phi, i, j, k, 0);
+    const double ax = (VF(beta[0], i + 1, j, k, 0) * (p0 - VF(phi, i + 1, j, k, 0)) + VF(beta[0], i, j, k, 0) * (p0 - VF(phi, i - 1, j, k, 0))) * hi2[0];
+    const double ay = (VF(beta[1], i, j + 1, k, 0) * (p0 - VF(phi, i, j + 1, k, 0)) + VF(beta[1], i, j, k, 0) * (p0 - VF(phi, i, j - 1, k, 0))) * hi2[1];
+    const double az = (VF(beta[2], i, j, k + 1, 0) * (p0 - VF(phi, i, j, k + 1, 0)) + VF(beta[2], i, j, k, 0) * (p0 - VF(phi, i, j, k - 1, 0))) * hi2[2];
+    const double r = VF(rh, i, j, k, 0) - (ax + ay + az);
+    VF(res, i, j, k, 0) = r;
+    nrm = fmax(nrm, fabs(r));
+  }
+  return nrm;
+}
+/* Neumann domain faces carry no flux: the plain residual above would use beta*(phi_i - ghost) with ghost = phi_i = 0 flux, and
+ * Dirichlet faces beta*(phi_i - (-phi_i)) = the 2b closure -- so the closure ghosts make the plain stencil exact. */
+
+/* flux matching: replace, in the residual of the uncovered coarse cells next to the fine box, the coarse flux through each
+ * interface face by the mean of the four fine fluxes */
+static void reflux_residual(vo_fab *res_c, const vo_fab *phi_c, vo_fab *beta_c[3], const double dxc[3],
+                            const vo_fab *phi_f, vo_fab *beta_f[3], const double dxf[3], const int ellbc_f[3][2])
+{
+  const int *flo = phi_f->lo, *fhi = phi_f->hi;
+  for (int d = 0; d < 3; d++) for (int s = 0; s < 2; s++) {
+    if (ellbc_f[d][s] != VDN_BC_INT) continue;
+    const int t1 = (d + 1) % 3, t2 = (d + 2) % 3;
+    const int ff = s ? fhi[d] + 1 : flo[d];              /* fine face index of the interface */
+    const int Fc = ff / 2;                                /* coarse face index */
+    for (int B2 = flo[t2] / 2; B2 <= fhi[t2] / 2; B2++) for (int B1 = flo[t1] / 2; B1 <= fhi[t1] / 2; B1++) {
+      double sum = 0.0;
+      for (int b = 0; b < 2; b++) for (int a = 0; a < 2; a++) {
+        int q[3], m[3]; q[d] = ff; q[t1] = 2 * B1 + a; q[t2] = 2 * B2 + b; m[0] = q[0]; m[1] = q[1]; m[2] = q[2]; m[d] -= 1;
+        sum = sum + VF(beta_f[d], q[0], q[1], q[2], 0) * (VF(phi_f, q[0], q[1], q[2], 0) - VF(phi_f, m[0], m[1], m[2], 0)) / dxf[d];
+      }
+      const double Ff = sum * 0.25;
+      int Q[3], M[3]; Q[d] = Fc; Q[t1] = B1; Q[t2] = B2; M[0] = Q[0]; M[1] = Q[1]; M[2] = Q[2]; M[d] -= 1;
+      const double Fcrs = VF(beta_c[d], Q[0], Q[1], Q[2], 0) * (VF(phi_c, Q[0], Q[1], Q[2], 0) - VF(phi_c, M[0], M[1], M[2], 0)) / dxc[d];
+      /* r = rh + (F_hi - F_lo)/h:  lo side of the fine box: the interface is the HI face of the uncovered cell M */
+      if (s == 0) VF(res_c, M[0], M[1], M[2], 0) = VF(res_c, M[0], M[1], M[2], 0) + (Ff - Fcrs) / dxc[d];
+      else        VF(res_c, Q[0], Q[1], Q[2], 0) = VF(res_c, Q[0], Q[1], Q[2], 0) - (Ff - Fcrs) / dxc[d];
+    }
+  }
+}
+static int covered(const vo_fab *fine, int I, int J, int K)
+{
+  return I >= fine->lo[0] / 2 && I <= fine->hi[0] / 2 && J >= fine->lo[1] / 2 && J <= fine->hi[1] / 2 && K >= fine->lo[2] / 2 && K <= fine->hi[2] / 2;
+}
+static void fab_like(vo_fab *f, const vo_fab *like, int ng, double val)
+{
+  vo_fab_init(f, NULL, like->lo, like->hi, ng, like->nd, 1);
+  long n = vo_size(f);
+  f->p = (double *)malloc(sizeof(double) * n);
+  for (long i = 0; i < n; i++) f->p[i] = val;
+}
+
+/* composite residual of both levels; res[0] on covered cells = restriction of res[1]; returns the composite max-norm */
+static double composite_residual(vo_fab **rh, vo_fab **phi, vo_fab **beta, const double *dx, const int ellbc[2][3][2], const int pmask[3], const int *pd, vo_fab **res)
+{
+  vo_ml_cc_restriction(phi[0], phi[1], 0, 1);                     /* keep the coarse level consistent under the fine one */
+  phi_closure(phi[0], ellbc[0], pmask, pd, pd + 3);
+  phi_closure(phi[1], ellbc[1], pmask, pd + 6, pd + 9);
+  cf_interp(phi[1], phi[0], ellbc[1]);
+  double nf = plain_residual(rh[1], phi[1], beta + 3, dx + 3, res[1]);
+  (void)plain_residual(rh[0], phi[0], beta, dx, res[0]);
+  reflux_residual(res[0], phi[0], beta, dx, phi[1], beta + 3, dx + 3, ellbc[1]);
+  vo_ml_cc_restriction(res[0], res[1], 0, 1);
+  double nc = 0.0;
+  for (int k = res[0]->lo[2]; k <= res[0]->hi[2]; k++) for (int j = res[0]->lo[1]; j <= res[0]->hi[1]; j++) for (int i = res[0]->lo[0]; i <= res[0]->hi[0]; i++)
+    if (!covered(phi[1], i, j, k)) nc = fmax(nc, fabs(VF(res[0], i, j, k, 0)));
+  return fmax(nf, nc);
+}
+
+/* rh, phi: [lev];  beta: [lev*3 + d];  dx: [lev*3 + d];  ellbc[lev] per box;  pd: [lev][2][3];  nu_f fine relaxation sweeps */
+int vo_ml_cc_solve(int nlev, vo_fab **rh, vo_fab **phi, vo_fab **beta, const double *dx, const int ellbc[2][3][2], const int pmask[3], const int *pd,
+                   double rel_eps, int max_iter, const vdn_params *prm, vo_mgstat *st)
+{
+  if (nlev != 2) { fprintf(stderr, "vo_ml_cc_solve: two levels only\n"); abort(); }
+  vo_fab res[2], e[2], *rp[2] = { &res[0], &res[1] };
+  for (int n = 0; n < 2; n++) { fab_like(&res[n], rh[n], 0, 0.0); fab_like(&e[n], rh[n], 1, 0.0); }
+  /* norm of the right-hand side over the composite grid */
+  double bnorm = 0.0;
+  for (int n = 0; n < 2; n++)
+    for (int k = rh[n]->lo[2]; k <= rh[n]->hi[2]; k++) for (int j = rh[n]->lo[1]; j <= rh[n]->hi[1]; j++) for (int i = rh[n]->lo[0]; i <= rh[n]->hi[0]; i++)
+      if (n == 1 || !covered(rh[1], i, j, k)) bnorm = fmax(bnorm, fabs(VF(rh[n], i, j, k, 0)));
+  int it = 0, conv = 0; double rn = 0.0;
+  if (bnorm == 0.0) conv = 1;
+  const int nu_f = prm->mg_nu1 + prm->mg_nu2;
+  while (!conv) {
+    rn = composite_residual(rh, phi, beta, dx, ellbc, pmask, pd, rp);
+    if (rn <= rel_eps * bnorm) { conv = 1; break; }
+    if (it >= max_iter) break;
+    /* coarse correction: ONE V-cycle of the single-level multigrid on the whole coarse level */
+    memset(e[0].p, 0, sizeof(double) * vo_size(&e[0]));
+    vo_mgstat cs;
+    vo_cc_solve_ab(&res[0], &e[0], NULL, beta, dx, ellbc[0], 0.0, -1.0, 1, prm->mg_nu1, prm->mg_nu2, prm->mg_nub, &cs);
+    for (int k = phi[0]->lo[2]; k <= phi[0]->hi[2]; k++) for (int j = phi[0]->lo[1]; j <= phi[0]->hi[1]; j++) for (int i = phi[0]->lo[0]; i <= phi[0]->hi[0]; i++)
+      VF(phi[0], i, j, k, 0) = VF(phi[0], i, j, k, 0) + VF(&e[0], i, j, k, 0);
+    for (int k = phi[1]->lo[2]; k <= phi[1]->hi[2]; k++) for (int j = phi[1]->lo[1]; j <= phi[1]->hi[1]; j++) for (int i = phi[1]->lo[0]; i <= phi[1]->hi[0]; i++)
+      VF(phi[1], i, j, k, 0) = VF(phi[1], i, j, k, 0) + VF(&e[0], i / 2, j / 2, k / 2, 0);
+    /* fine relaxation on the new residual, homogeneous interface */
+    phi_closure(phi[0], ellbc[0], pmask, pd, pd + 3);
+    phi_closure(phi[1], ellbc[1], pmask, pd + 6, pd + 9);
+    cf_interp(phi[1], phi[0], ellbc[1]);
+    (void)plain_residual(rh[1], phi[1], beta + 3, dx + 3, &res[1]);
+    memset(e[1].p, 0, sizeof(double) * vo_size(&e[1]));
+    vo_cc_smooth(&res[1], &e[1], beta + 3, dx + 3, ellbc[1], nu_f);
+    for (int k = phi[1]->lo[2]; k <= phi[1]->hi[2]; k++) for (int j = phi[1]->lo[1]; j <= phi[1]->hi[1]; j++) for (int i = phi[1]->lo[0]; i <= phi[1]->hi[0]; i++)
+      VF(phi[1], i, j, k, 0) = VF(phi[1], i, j, k, 0) + VF(&e[1], i, j, k, 0);
+    it++;
+  }
+  /* leave phi with consistent ghosts for mkumac */
+  vo_ml_cc_restriction(phi[0], phi[1], 0, 1);
+  phi_closure(phi[0], ellbc[0], pmask, pd, pd + 3);
+  phi_closure(phi[1], ellbc[1], pmask, pd + 6, pd + 9);
+  cf_interp(phi[1], phi[0], ellbc[1]);
+  if (st) { st->cycles = it; st->res0 = bnorm; st->res = rn; }
+  for (int n = 0; n < 2; n++) { free(res[n].p); free(e[n].p); }
+  return conv ? 0 : 1;
+}
+
+/* macproject.f90:20-133, two levels.  umac: [lev*3 + d] (ng = 1), rho: [lev] (ghosts filled), mac_rhs: [lev] */
+void vo_ml_macproject(int nlev, vo_fab **umac, vo_fab **rho, vo_fab **mac_rhs, const double *dx, const vo_bc *bc, const int pmask[3], const int *pd,
+                      const vdn_params *prm, vo_mgstat *st)
+{
+  if (nlev != 2) { fprintf(stderr, "vo_ml_macproject: two levels only\n"); abort(); }
+  vo_fab rh[2], phi[2], beta[6], *rhp[2], *php[2], *bp[6];
+  int ellbc[2][3][2];
+  for (int n = 0; n < 2; n++) {
+    fab_like(&rh[n], rho[n], 0, 0.0); fab_like(&phi[n], rho[n], 1, 0.0); rhp[n] = &rh[n]; php[n] = &phi[n];
+    for (int d = 0; d < 3; d++) {
+      int nd[3] = { 0, 0, 0 }; nd[d] = 1;
+      vo_fab_init(&beta[3 * n + d], NULL, rho[n]->lo, rho[n]->hi, 0, nd, 1);
+      beta[3 * n + d].p = (double *)calloc(vo_size(&beta[3 * n + d]), sizeof(double)); bp[3 * n + d] = &beta[3 * n + d];
+      for (int s = 0; s < 2; s++) ellbc[n][d][s] = bc[n].ell[d][s][bc[n].press_comp];
+    }
+  }
+  /* divumac (macproject.f90:161-206): rh = mac_rhs - div(umac) on every level, then ml_cc_restriction */
+  for (int n = 0; n < 2; n++) {
+    vo_divumac(umac + 3 * n, &rh[n], dx + 3 * n);
+    for (int k = rh[n].lo[2]; k <= rh[n].hi[2]; k++) for (int j = rh[n].lo[1]; j <= rh[n].hi[1]; j++) for (int i = rh[n].lo[0]; i <= rh[n].hi[0]; i++)
+      VF(&rh[n], i, j, k, 0) = VF(&rh[n], i, j, k, 0) * -1.0 + VF(mac_rhs[n], i, j, k, 0);
+  }
+  vo_ml_cc_restriction(&rh[0], &rh[1], 0, 1);
+  /* mk_mac_coeffs (macproject.f90:296-334): rho's fine ghosts come from the caller's ml_restrict_and_fill; edge restriction */
+  for (int n = 0; n < 2; n++) vo_mk_mac_coeffs(rho[n], bp + 3 * n);
+  for (int d = 0; d < 3; d++) vo_ml_edge_restriction(bp[d], bp[3 + d], d);
+  vo_ml_cc_solve(2, rhp, php, bp, dx, ellbc, pmask, pd, prm->mac_rel_eps, prm->mg_max_iter, prm, st);
+  /* mkumac on every level with the solver's ghost cells, then edge restriction and the ghost faces (macproject.f90:103-119) */
+  for (int n = 0; n < 2; n++) vo_mkumac(umac + 3 * n, &phi[n], bp + 3 * n, dx + 3 * n, ellbc[n]);
+  for (int d = 0; d < 3; d++) vo_ml_edge_restriction(umac[d], umac[3 + d], d);
+  for (int d = 0; d < 3; d++) { level_fill_boundary(umac[d], pmask, pd, pd + 3); vo_create_umac_grown(umac[3 + d], umac[d], d); level_fill_boundary(umac[3 + d], pmask, pd + 6, pd + 9); }
+  for (int n = 0; n < 2; n++) { free(rh[n].p); free(phi[n].p); for (int d = 0; d < 3; d++) free(beta[3 * n + d].p); }
+}

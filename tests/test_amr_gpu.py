@@ -1,0 +1,168 @@
+"""Two-level AMR (BASELINE.json configs[3]): FBoxLib's multi-level operators as defined in oracle/vo_amr.c (the reference calls
+them but does not contain them) and the multilevel MAC projection (src/macproject.f90:20-133), HIP vs oracle.
+Transfer operators: bit-exact.  Composite solve: same FAC iteration count, MAC velocities to 1e-9, and the size-independent
+property that the projected field is discretely divergence-free on the composite grid (fine cells, uncovered coarse cells,
+and -- through ml_edge_restriction -- covered coarse cells)."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from tests.util import assert_bits
+
+pytestmark = pytest.mark.gpu
+
+WALLS = [[15, 15]] * 3
+
+
+class Amr2:
+    """coarse level: one box [0,nc)^3; fine level: the box flo..fhi (fine indices), optionally split in x for the GPU"""
+
+    def __init__(self, nc, flo, fhi, phys=WALLS, split=1, seed=0):
+        from oracle import voracle as vo
+        from varden_amd import boxlib as bl
+        from varden_amd.capi import default_params
+        self.vo, self.bl = vo, bl
+        self.nc, self.flo, self.fhi = nc, tuple(flo), tuple(fhi)
+        self.prm = default_params()
+        bl.initialize(self.prm, 0, 1, 0)
+        self.rng = np.random.default_rng(seed)
+        self.clo, self.chi = (0, 0, 0), (nc - 1,) * 3
+        pdf = ((0, 0, 0), (2 * nc - 1,) * 3)
+        nx = (fhi[0] - flo[0] + 1) // split
+        self.fboxes = [((flo[0] + s * nx, flo[1], flo[2]), (flo[0] + (s + 1) * nx - 1, fhi[1], fhi[2])) for s in range(split)]
+        self.mla = bl.MLLayout([(self.clo, self.chi), pdf], [[(self.clo, self.chi)], self.fboxes], rr=[(2, 2, 2)])
+        self.bct = bl.BCTower(self.mla, phys)
+        self.dx = [[1.0 / nc] * 3, [0.5 / nc] * 3]
+        # oracle side: one box per level
+        physf = [[phys[d][0] if flo[d] == 0 else 0, phys[d][1] if fhi[d] == 2 * nc - 1 else 0] for d in range(3)]
+        self.obcs = (vo.CBc * 2)(vo.make_bc(phys, 3, 2), vo.make_bc(physf, 3, 2))
+        self.opm = vo.ivec([0, 0, 0])
+        self.opd = vo.ivec([0, 0, 0, nc - 1, nc - 1, nc - 1, 0, 0, 0, 2 * nc - 1, 2 * nc - 1, 2 * nc - 1])
+        self.odx = (C.c_double * 6)(*(self.dx[0] + self.dx[1]))
+        self._mfs = []
+
+    def ofabs(self, ng, nc, nodal=(0, 0, 0)):
+        return [self.vo.Fab(self.clo, self.chi, ng, nc, nodal), self.vo.Fab(self.flo, self.fhi, ng, nc, nodal)]
+
+    def gmfs(self, ofabs):
+        """GPU multifabs (per level) holding the oracle fabs' contents (the fine one cut into the GPU's boxes)"""
+        out = []
+        for lev, of in enumerate(ofabs):
+            mf = self.bl.MultiFab(self.mla, lev, of.nc, of.ng, of.nodal)
+            for i in range(mf.nfabs()):
+                lo, hi = mf.get_box(i)
+                sl = tuple(slice(lo[d] - of.lo[d], hi[d] - of.lo[d] + 1 + of.nodal[d] + 2 * of.ng) for d in range(3))
+                mf.from_numpy(np.asfortranarray(of.a[sl]), i)
+            self._mfs.append(mf); out.append(mf)
+        return out
+
+    def gather(self, mf, of):
+        """the GPU level multifab assembled in the shape of the oracle fab (valid + ghost of each box; later boxes win on overlaps
+        of ghost regions, valid data always last)"""
+        out = np.full(of.a.shape, np.nan, order="F")
+        for phase in (0, 1):
+            for i in range(mf.nfabs()):
+                lo, hi = mf.get_box(i)
+                a = mf.to_numpy(i)
+                g = of.ng
+                if phase == 0:
+                    sl = tuple(slice(lo[d] - of.lo[d], hi[d] - of.lo[d] + 1 + of.nodal[d] + 2 * g) for d in range(3))
+                    out[sl] = a
+                else:
+                    sl = tuple(slice(lo[d] - of.lo[d] + g, hi[d] - of.lo[d] + 1 + of.nodal[d] + g) for d in range(3))
+                    out[sl] = a[tuple(slice(g, a.shape[d] - g) for d in range(3))] if g else a
+        return out
+
+    def smooth(self, of, lev, amp=1.0, base=0.0):
+        h = self.dx[lev][0]
+        idx = [np.arange(of.lo[d] - of.ng, of.hi[d] + of.nodal[d] + of.ng + 1) for d in range(3)]
+        X, Y, Z = np.meshgrid(*[(idx[d] + 0.5) * h for d in range(3)], indexing="ij")
+        for c in range(of.nc):
+            of.a[..., c] = base + amp * (np.sin(2 * np.pi * (X + 0.3 * c)) * np.cos(2 * np.pi * Y) * np.sin(np.pi * Z + 0.2) + 0.3 * np.cos(4 * np.pi * X * Y + c))
+
+    def close(self):
+        for m in self._mfs:
+            m.destroy()
+        self.bct.destroy(); self.mla.destroy()
+
+
+def test_transfer_operators_bits(gpu, oracle):
+    from varden_amd import advance as adv
+    vo = oracle
+    K = Amr2(16, (8, 8, 8), (23, 23, 23))
+    L = vo.lib()
+    # ml_cc_restriction and fill_ghost_cells / ml_restrict_and_fill on a 2-component ng = 3 state
+    s = K.ofabs(3, 2)
+    for lev in range(2):
+        K.smooth(s[lev], lev, 0.3, 2.0)
+    g = K.gmfs(s)
+    L.vo_ml_restrict_and_fill(2, vo.fab_ptr_array(s), 0, 3, 2, 0, K.obcs, K.opm, K.opd, C.byref(K.prm))
+    adv.ml_restrict_and_fill(g, 0, 3, 2, K.bct)
+    for lev in range(2):
+        assert_bits(K.gather(g[lev], s[lev]), s[lev].a, "ml_restrict_and_fill level %d" % lev)
+    # ml_edge_restriction + create_umac_grown on a face field
+    for d in range(3):
+        nd = tuple(1 if t == d else 0 for t in range(3))
+        u = K.ofabs(1, 1, nd)
+        for lev in range(2):
+            K.smooth(u[lev], lev)
+        gu = K.gmfs(u)
+        L.vo_ml_edge_restriction(u[0].ref, u[1].ref, d)
+        adv.ml_edge_restriction(gu[0], gu[1], d)
+        assert_bits(K.gather(gu[0], u[0]), u[0].a, "ml_edge_restriction dir %d" % d)
+        L.vo_create_umac_grown(u[1].ref, u[0].ref, d)
+        adv.create_umac_grown(gu[1], gu[0], d)
+        assert_bits(K.gather(gu[1], u[1]), u[1].a, "create_umac_grown dir %d" % d)
+    K.close()
+
+
+def _mac_case(K, vo):
+    L = vo.lib()
+    rho = K.ofabs(3, 2)
+    for lev in range(2):
+        K.smooth(rho[lev], lev, 0.2, 1.5)
+    L.vo_ml_restrict_and_fill(2, vo.fab_ptr_array(rho), 0, 3, 2, 0, K.obcs, K.opm, K.opd, C.byref(K.prm))
+    um = []
+    for lev in range(2):
+        for d in range(3):
+            f = K.ofabs(1, 1, tuple(1 if t == d else 0 for t in range(3)))[lev]
+            K.smooth(f, lev, 1.0 + 0.1 * d)
+            um.append(f)
+    for d in range(3):                                    # wall-normal MAC velocity zero on the domain boundary; levels consistent
+        sl = [slice(None)] * 4; sl[d] = 1; um[d].a[tuple(sl)] = 0.0; sl[d] = -2; um[d].a[tuple(sl)] = 0.0
+        L.vo_ml_edge_restriction(um[d].ref, um[3 + d].ref, d)
+    rhs = K.ofabs(1, 1)
+    return rho, um, rhs
+
+
+def _div(um3, h):
+    U, V, W = (m[1:-1, 1:-1, 1:-1, 0] for m in um3)
+    return (U[1:, :, :] - U[:-1, :, :]) / h + (V[:, 1:, :] - V[:, :-1, :]) / h + (W[:, :, 1:] - W[:, :, :-1]) / h
+
+
+@pytest.mark.parametrize("split", [1, 2])
+def test_ml_macproject(gpu, oracle, split):
+    from varden_amd import advance as adv
+    vo = oracle
+    K = Amr2(16, (8, 8, 8), (23, 23, 23), split=split)
+    L = vo.lib()
+    rho, um, rhs = _mac_case(K, vo)
+    grho, grhs = K.gmfs(rho), K.gmfs(rhs)
+    gum = [K.gmfs([um[d], um[3 + d]]) for d in range(3)]               # gum[d][lev]
+    st = vo.CMgStat()
+    L.vo_ml_macproject(2, vo.fab_ptr_array(um), vo.fab_ptr_array(rho), vo.fab_ptr_array(rhs), K.odx, K.obcs, K.opm, K.opd, C.byref(K.prm), C.byref(st))
+    adv.macproject(K.mla, [[gum[d][lev] for d in range(3)] for lev in range(2)], grho, grhs, K.dx, K.bct, 3 + 2 + 1)
+    it_gpu = adv.last_solver_stats("mac")[0]
+    assert st.cycles < 40 and abs(it_gpu - st.cycles) <= (0 if split == 1 else 1), (it_gpu, st.cycles)
+    scale = max(np.abs(m.a).max() for m in um)
+    got = [[K.gather(gum[d][lev], um[3 * lev + d]) for d in range(3)] for lev in range(2)]
+    for lev in range(2):
+        for d in range(3):
+            a, b = got[lev][d][1:-1, 1:-1, 1:-1], um[3 * lev + d].a[1:-1, 1:-1, 1:-1]
+            assert np.abs(a - b).max() <= 1e-9 * scale, "umac level %d dir %d differs by %.3e" % (lev, d, np.abs(a - b).max())
+    # composite divergence of the GPU result
+    df, dc = _div(got[1], K.dx[1][0]), _div(got[0], K.dx[0][0])
+    tol = 1e-8 * st.res0
+    assert np.abs(df).max() <= tol and np.abs(dc).max() <= tol, (np.abs(df).max(), np.abs(dc).max(), st.res0)
+    K.close()

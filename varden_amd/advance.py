@@ -121,3 +121,24 @@ def bench_cc_smoother(rh, phi, beta, dx, bc, nlaunch):
     flat = _iv([bc[d][s] for d in range(3) for s in range(2)])
     check(capi.load().vdn_bench_cc_smoother(rh.h, phi.h, handle_array(beta), _dx(dx), flat, nlaunch, C.byref(ms), C.byref(cells)))
     return ms.value, cells.value
+
+
+# ---- multi-level operators (two levels) -----------------------------------------------------------------------------------
+def ml_cc_restriction(crse, fine, icomp=0, nc=None):
+    check(capi.load().vdn_ml_cc_restriction(crse.h, fine.h, icomp, crse.nc if nc is None else nc))
+
+
+def ml_edge_restriction(crse, fine, dir):
+    check(capi.load().vdn_ml_edge_restriction(crse.h, fine.h, dir))
+
+
+def fill_ghost_cells(fine, crse, icomp=0, nc=None):
+    check(capi.load().vdn_multifab_fill_ghost_cells(fine.h, crse.h, icomp, fine.nc if nc is None else nc))
+
+
+def create_umac_grown(fine, crse, dir):
+    check(capi.load().vdn_create_umac_grown(fine.h, crse.h, dir))
+
+
+def ml_restrict_and_fill(mfs, icomp, bcomp, nc, bct, same_boundary=False):
+    check(capi.load().vdn_ml_restrict_and_fill(len(mfs), handle_array(mfs), icomp, bcomp, nc, 1 if same_boundary else 0, bct.h))

@@ -99,6 +99,11 @@ SIGNATURES = {
     "vdn_estdt": (C.c_int, [C.c_int, _VP, _VP, _VP, _VP, _PD, C.c_double, _PD]),
     "vdn_hgproject": (C.c_int, [C.c_int, _VP, _PVP, _PVP, _PVP, _PVP, _PVP, _PD, C.c_double, _VP, C.c_int]),
     "vdn_macproject": (C.c_int, [_VP, _PVP, _PVP, _PVP, _PD, _VP, C.c_int]),
+    "vdn_ml_cc_restriction": (C.c_int, [_VP, _VP, C.c_int, C.c_int]),
+    "vdn_ml_edge_restriction": (C.c_int, [_VP, _VP, C.c_int]),
+    "vdn_multifab_fill_ghost_cells": (C.c_int, [_VP, _VP, C.c_int, C.c_int]),
+    "vdn_create_umac_grown": (C.c_int, [_VP, _VP, C.c_int]),
+    "vdn_ml_restrict_and_fill": (C.c_int, [C.c_int, _PVP, C.c_int, C.c_int, C.c_int, C.c_int, _VP]),
     "vdn_last_step_timing": (C.c_int, [_PD]),
     "vdn_last_solver_stats": (C.c_int, [C.c_int, _PI, _PD, _PD]),
     "vdn_k_slope": (C.c_int, [_VP, _VP, C.c_int, C.c_int, _VP]),

@@ -190,7 +190,7 @@ extern "C" int vdn_hgproject(int proj_type, vdn_layout *mla, vdn_multifab **unew
 extern "C" int vdn_macproject(vdn_layout *mla, vdn_multifab **umac, vdn_multifab **rho, vdn_multifab **mac_rhs,
                               const double *dx, const vdn_bc_tower *bct, int bc_comp) {
   VDN_TRY
-  check_single_level(mla);
+  REQUIRE(mla && mla->nlev <= 2, "macproject: at most two levels are implemented (nlevel = %d)", mla ? mla->nlev : -1);
   arena_reset(); arena_reserve_for(mla);
   do_macproject(mla, umac, rho, mac_rhs, dx, bct, bc_comp - 1);
   arena_reset();

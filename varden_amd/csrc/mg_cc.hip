@@ -838,12 +838,37 @@ __global__ void kk_mkumac(FV um, FV vm, FV wm, FV phi, FV bx, FV by, FV bz, Umac
   }
 }
 
+// per-level pieces of macproject, shared by the single-level driver below and the multilevel one in amr.hip
+void mac_level_rhs(vdn_multifab **um, const vdn_multifab *mac_rhs, vdn_multifab *rh, const double *dx) {      // divumac + (190-196)
+  for (int i = 0; i < rh->nfabs(); i++) {
+    Range3 r; for (int d = 0; d < 3; d++) { r.lo[d] = rh->vbox[i].lo[d]; r.hi[d] = rh->vbox[i].hi[d]; }
+    hipLaunchKernelGGL(kk_divumac, grid_for(r), BLK, 0, ctx().stream, um[0]->fabs[i], um[1]->fabs[i], um[2]->fabs[i], mac_rhs->fabs[i], rh->fabs[i],
+                       1.0 / dx[0], 1.0 / dx[1], 1.0 / dx[2], r);
+  }
+}
+void mac_level_coeffs(const vdn_multifab *rho, vdn_multifab **beta) {                                          // mk_mac_coeffs_3d
+  for (int i = 0; i < rho->nfabs(); i++) {
+    Range3 rf; for (int d = 0; d < 3; d++) { rf.lo[d] = rho->vbox[i].lo[d]; rf.hi[d] = rho->vbox[i].hi[d] + 1; }
+    hipLaunchKernelGGL(kk_mk_mac_coeffs, grid_for(rf), BLK, 0, ctx().stream, rho->fabs[i], beta[0]->fabs[i], beta[1]->fabs[i], beta[2]->fabs[i], rf,
+                       rf.hi[0] - 1, rf.hi[1] - 1, rf.hi[2] - 1);
+  }
+}
+void mac_level_mkumac(vdn_multifab **um, const vdn_multifab *phi, vdn_multifab **beta, const double *dx, const vdn_bc_tower *bct, int bc_comp0) {
+  const int n = phi->lev;
+  for (int i = 0; i < phi->nfabs(); i++) {
+    UmacArgs A; Range3 rf;
+    for (int d = 0; d < 3; d++) { A.lo[d] = rf.lo[d] = phi->vbox[i].lo[d]; A.hi[d] = phi->vbox[i].hi[d]; rf.hi[d] = A.hi[d] + 1; A.dx[d] = dx[d];
+      for (int s = 0; s < 2; s++) A.ebc[d][s] = bct->ell_bc(n, i + 1, d, s, bc_comp0); }
+    hipLaunchKernelGGL(kk_mkumac, grid_for(rf), BLK, 0, ctx().stream, um[0]->fabs[i], um[1]->fabs[i], um[2]->fabs[i], phi->fabs[i],
+                       beta[0]->fabs[i], beta[1]->fabs[i], beta[2]->fabs[i], A, rf);
+  }
+}
+
 void do_macproject(vdn_layout *mla, vdn_multifab **umac, vdn_multifab **rho, vdn_multifab **mac_rhs, const double *dx,
                    const vdn_bc_tower *bct, int bc_comp0) {
   if (ctx().prm.dm == 2) { do2_macproject(mla, umac, rho, mac_rhs, dx, bct, bc_comp0); return; }
-  REQUIRE(mla->nlev == 1, "macproject: multilevel hierarchies are not implemented in this round");
+  if (mla->nlev > 1) { do_ml_macproject(mla, umac, rho, mac_rhs, dx, bct, bc_comp0); return; }
   const int n = 0;
-  hipStream_t st = ctx().stream;
   size_t mark = arena_mark();
   vdn_multifab *rh = mf_temp(mla, n, 1, 0, -1, false, 0.0);
   vdn_multifab *phi = mf_temp(mla, n, 1, 1, -1, true, 0.0);
@@ -851,26 +876,15 @@ void do_macproject(vdn_layout *mla, vdn_multifab **umac, vdn_multifab **rho, vdn
   for (int d = 0; d < 3; d++) beta[d] = mf_temp(mla, n, 1, 0, d, false, 0.0);
   vdn_multifab *um[3] = { umac[0], umac[1], umac[2] };
   REQUIRE(rho[n]->ng >= 1, "macproject: rho needs a filled ghost cell");
-  for (int i = 0; i < rh->nfabs(); i++) {
-    Range3 r, rf; for (int d = 0; d < 3; d++) { r.lo[d] = rf.lo[d] = rh->vbox[i].lo[d]; r.hi[d] = rh->vbox[i].hi[d]; rf.hi[d] = r.hi[d] + 1; }
-    hipLaunchKernelGGL(kk_divumac, grid_for(r), BLK, 0, st, um[0]->fabs[i], um[1]->fabs[i], um[2]->fabs[i], mac_rhs[n]->fabs[i], rh->fabs[i],
-                       1.0 / dx[0], 1.0 / dx[1], 1.0 / dx[2], r);
-    hipLaunchKernelGGL(kk_mk_mac_coeffs, grid_for(rf), BLK, 0, st, rho[n]->fabs[i], beta[0]->fabs[i], beta[1]->fabs[i], beta[2]->fabs[i], rf,
-                       r.hi[0], r.hi[1], r.hi[2]);
-  }
+  mac_level_rhs(um, mac_rhs[n], rh, dx);
+  mac_level_coeffs(rho[n], beta);
   int ebc[3][2];
   for (int d = 0; d < 3; d++) for (int s = 0; s < 2; s++) ebc[d][s] = bct->ell_bc(n, 0, d, s, bc_comp0);   // grid 0 = whole domain
   int cyc; double r0, rr;
   int rc = cc_solve(rh, phi, beta, dx, ebc, ctx().prm.mac_rel_eps, -1.0, ctx().prm.mg_max_iter, &cyc, &r0, &rr);   // macproject.f90:91-93
   ctx().solver_cycles[0] = cyc; ctx().solver_res0[0] = r0; ctx().solver_res[0] = rr;
   if (rc != 0 && ctx().prm.verbose) fprintf(stderr, "varden_amd: MAC multigrid did not converge in %d cycles (res %g / %g)\n", cyc, rr, r0);
-  for (int i = 0; i < rh->nfabs(); i++) {
-    UmacArgs A; Range3 rf;
-    for (int d = 0; d < 3; d++) { A.lo[d] = rf.lo[d] = rh->vbox[i].lo[d]; A.hi[d] = rh->vbox[i].hi[d]; rf.hi[d] = A.hi[d] + 1; A.dx[d] = dx[d];
-      for (int s = 0; s < 2; s++) A.ebc[d][s] = bct->ell_bc(n, i + 1, d, s, bc_comp0); }
-    hipLaunchKernelGGL(kk_mkumac, grid_for(rf), BLK, 0, st, um[0]->fabs[i], um[1]->fabs[i], um[2]->fabs[i], phi->fabs[i],
-                       beta[0]->fabs[i], beta[1]->fabs[i], beta[2]->fabs[i], A, rf);
-  }
+  mac_level_mkumac(um, phi, beta, dx, bct, bc_comp0);
   for (int d = 0; d < 3; d++) mf_fill_boundary(um[d]);          // macproject.f90:115-119
   for (int d = 0; d < 3; d++) mf_temp_free(beta[d]);
   mf_temp_free(phi); mf_temp_free(rh);

@@ -184,3 +184,14 @@ int  nd2_solve(vdn_multifab *rh, vdn_multifab *phi, const vdn_multifab *coeffs, 
                double rel_eps, double abs_eps, int max_iter, int *cycles, double *res0, double *res);
 void do2_hgproject(int proj_type, vdn_layout *mla, vdn_multifab **unew, vdn_multifab **uold, vdn_multifab **rhohalf, vdn_multifab **p, vdn_multifab **gp,
                    const double *dx, double dt, const vdn_bc_tower *bct, int press_comp0);
+
+// per-level pieces of macproject (mg_cc.hip) and the two-level AMR operators (amr.hip)
+void mac_level_rhs(vdn_multifab **um, const vdn_multifab *mac_rhs, vdn_multifab *rh, const double *dx);
+void mac_level_coeffs(const vdn_multifab *rho, vdn_multifab **beta);
+void mac_level_mkumac(vdn_multifab **um, const vdn_multifab *phi, vdn_multifab **beta, const double *dx, const vdn_bc_tower *bct, int bc_comp0);
+void ml_cc_restriction(vdn_multifab *crse, const vdn_multifab *fine, int icomp, int nc);
+void ml_edge_restriction(vdn_multifab *crse, const vdn_multifab *fine, int dir);
+void ml_fill_ghost_cells(vdn_multifab *fine, const vdn_multifab *crse, int icomp, int nc);
+void ml_create_umac_grown(vdn_multifab *fine, const vdn_multifab *crse, int dir);
+void ml_restrict_and_fill(int nlev, vdn_multifab **mf, int icomp, int bcomp, int nc, bool same_boundary, const vdn_bc_tower *bct);
+void do_ml_macproject(vdn_layout *mla, vdn_multifab **umac, vdn_multifab **rho, vdn_multifab **mac_rhs, const double *dx, const vdn_bc_tower *bct, int bc_comp0);
