@@ -323,3 +323,38 @@ void vo_ml_macproject(int nlev, vo_fab **umac, vo_fab **rho, vo_fab **mac_rhs, c
   for (int d = 0; d < 3; d++) { level_fill_boundary(umac[d], pmask, pd, pd + 3); vo_create_umac_grown(umac[3 + d], umac[d], d); level_fill_boundary(umac[3 + d], pmask, pd + 6, pd + 9); }
   for (int n = 0; n < 2; n++) { free(rh[n].p); free(phi[n].p); for (int d = 0; d < 3; d++) free(beta[3 * n + d].p); }
 }
+
+/* hgproject.f90:17-178 with nlevs = 2 (rel tolerance 1e-11, hgproject.f90:115-116) */
+void vo_ml_hgproject(int proj_type, vo_fab **unew, vo_fab **uold, vo_fab **rhohalf, vo_fab **p, vo_fab **gp, const double *dx, double dt,
+                     const vo_bc *bc, const int pmask[3], const int *pd, const vdn_params *prm, vo_mgstat *st)
+{
+  vo_fab rh[2], phi[2], gphi[2], coeffs[2], *rhp[2], *php[2], *cfp[2];
+  int ellbc[2][3][2];
+  int nd1[3] = { 1, 1, 1 };
+  for (int n = 0; n < 2; n++) {
+    const int *lo = unew[n]->lo, *hi = unew[n]->hi;
+    vo_fab_init(&rh[n], NULL, lo, hi, 1, nd1, 1);    rh[n].p = (double *)calloc(vo_size(&rh[n]), sizeof(double));
+    vo_fab_init(&phi[n], NULL, lo, hi, 1, nd1, 1);   phi[n].p = (double *)calloc(vo_size(&phi[n]), sizeof(double));
+    vo_fab_init(&gphi[n], NULL, lo, hi, 0, NULL, 3); gphi[n].p = (double *)calloc(vo_size(&gphi[n]), sizeof(double));
+    vo_fab_init(&coeffs[n], NULL, lo, hi, 1, NULL, 1); coeffs[n].p = (double *)calloc(vo_size(&coeffs[n]), sizeof(double));
+    rhp[n] = &rh[n]; php[n] = &phi[n]; cfp[n] = &coeffs[n];
+    for (int d = 0; d < 3; d++) for (int s = 0; s < 2; s++) ellbc[n][d][s] = bc[n].ell[d][s][bc[n].press_comp];
+    vo_create_uvec(unew[n], uold[n], rhohalf[n], gp[n], dt, &bc[n], proj_type);
+    level_fill_boundary(unew[n], pmask, pd + 6 * n, pd + 6 * n + 3);
+    for (int k = lo[2]; k <= hi[2]; k++) for (int j = lo[1]; j <= hi[1]; j++) for (int i = lo[0]; i <= hi[0]; i++)
+      VF(&coeffs[n], i, j, k, 0) = 1.0 / VF(rhohalf[n], i, j, k, 0);
+    level_fill_boundary(&coeffs[n], pmask, pd + 6 * n, pd + 6 * n + 3);
+  }
+  double rel = prm->hg_rel_eps > 0.0 ? prm->hg_rel_eps : 1.e-11;
+  double abs_eps = -1.0;
+  if (proj_type == VDN_INITIAL_PROJECTION && prm->prob_type == 4) abs_eps = 1.e-12;
+  vo_ml_nd_solve(rhp, php, cfp, unew, dx, ellbc, pmask, rel, abs_eps, prm->hg_max_iter, prm, st);
+  for (int n = 0; n < 2; n++) {
+    vo_mkgphi(&gphi[n], &phi[n], dx + 3 * n);
+    vo_hg_update(proj_type, unew[n], uold[n], gp[n], &gphi[n], rhohalf[n], p[n], &phi[n], dt);
+  }
+  vo_ml_cc_restriction(gp[0], gp[1], 0, 3);                                   /* hgproject.f90:355-357 */
+  for (int n = 0; n < 2; n++) { level_fill_boundary(gp[n], pmask, pd + 6 * n, pd + 6 * n + 3); level_fill_boundary(p[n], pmask, pd + 6 * n, pd + 6 * n + 3); }
+  vo_ml_restrict_and_fill(2, unew, 0, 0, 3, 0, bc, pmask, pd, prm);          /* hgproject.f90:364-366 */
+  for (int n = 0; n < 2; n++) { free(rh[n].p); free(phi[n].p); free(gphi[n].p); free(coeffs[n].p); }
+}

@@ -459,3 +459,207 @@ void vo_hgproject(int proj_type, vo_fab *unew, const vo_fab *uold, vo_fab *rhoha
   vo_fill_boundary(gp, pmask); vo_fill_boundary(p, pmask);              /* hgproject.f90:359-362 */
   free(rh.p); free(phi.p); free(gphi.p); free(coeffs.p);
 }
+
+/* =============================================================================================================================
+ * Two-level composite nodal solve and the multilevel hgproject (hgproject.f90:17-178, hg_multigrid.f90:18-119 with nlevs = 2).
+ * FBoxLib's ml_nd_solve is not in the reference tree; our definition (finite elements on the composite mesh):
+ *   unknowns      coarse nodes outside / on the boundary of the fine box, fine nodes strictly inside it; fine nodes ON the
+ *                 coarse-fine interface are slaves, phi_f = P phi_c (trilinear)
+ *   equations     fine interior nodes: the fine 27-point equation; other coarse nodes: coarse-side part (sigma = 0 and u = 0 in
+ *                 covered cells) + full-weighting restriction (P^T/8) of the fine-side parts (sigma = 0 and u = 0 outside the
+ *                 fine box) -- i.e. the Galerkin equation of the coarse hat function on the composite mesh
+ *   algorithm     FAC: composite residual; one V-cycle of the single-level nodal multigrid on the whole coarse level (sigma under
+ *                 the fine box = the averaged-down fine sigma); trilinear prolongation of the correction; damped-Jacobi
+ *                 relaxation of the fine interior nodes with the interface held fixed.
+ * One box per level.
+ * ============================================================================================================================= */
+static void nd_level_from_fab(ndlev *L, const vo_fab *coeffs, const double dx[3])
+{
+  int n[3];
+  for (int d = 0; d < 3; d++) n[d] = coeffs->hi[d] - coeffs->lo[d] + 1;
+  nd_alloc(L, n, dx, 3);
+  for (int k = -1; k <= n[2]; k++) for (int j = -1; j <= n[1]; j++) for (int i = -1; i <= n[0]; i++)
+    L->sig[NS(L, i, j, k)] = VF(coeffs, coeffs->lo[0] + i, coeffs->lo[1] + j, coeffs->lo[2] + k, 0);
+}
+/* masked copy of u with one ghost layer: zero outside `keep` (cells lo..hi) or, if invert, zero INSIDE it */
+static void masked_u(vo_fab *out, const vo_fab *u, const int klo[3], const int khi[3], int invert)
+{
+  vo_fab_init(out, NULL, u->lo, u->hi, 1, NULL, 3);
+  out->p = (double *)calloc(vo_size(out), sizeof(double));
+  for (int c = 0; c < 3; c++) for (int k = u->lo[2] - 1; k <= u->hi[2] + 1; k++) for (int j = u->lo[1] - 1; j <= u->hi[1] + 1; j++) for (int i = u->lo[0] - 1; i <= u->hi[0] + 1; i++) {
+    int in = i >= klo[0] && i <= khi[0] && j >= klo[1] && j <= khi[1] && k >= klo[2] && k <= khi[2];
+    VF(out, i, j, k, c) = (in != invert) ? VF(u, i, j, k, c) : 0.0;
+  }
+}
+typedef struct mlnd {
+  ndlev Lc, Lf;               /* coarse with MASKED sigma; fine */
+  int per[3];
+  int clo[3], flo[3];          /* global index of local node 0 on each level */
+  int ilo[3], ihi[3];          /* fine-box node range in COARSE node indices (local to Lc) */
+  unsigned char *cf;           /* fine nodes on the coarse-fine interface */
+  unsigned char *pdir_f;       /* fine physical Dirichlet nodes */
+} mlnd;
+#define CFM(M, i, j, k) (M)->cf[NM(&(M)->Lf, i, j, k)]
+
+static void ml_nd_interface(mlnd *M)
+{
+  ndlev *F = &M->Lf, *Cc = &M->Lc;
+  for (int k = 0; k <= F->n[2]; k++) for (int j = 0; j <= F->n[1]; j++) for (int i = 0; i <= F->n[0]; i++) {
+    if (!CFM(M, i, j, k)) continue;
+    int gi = M->flo[0] + i, gj = M->flo[1] + j, gk = M->flo[2] + k;            /* global fine node */
+    int I = (gi >> 1) - M->clo[0], J = (gj >> 1) - M->clo[1], K = (gk >> 1) - M->clo[2], oi = gi & 1, oj = gj & 1, ok = gk & 1;
+    double s = 0.0;
+    for (int c = 0; c <= ok; c++) for (int b = 0; b <= oj; b++) for (int a = 0; a <= oi; a++) s = s + Cc->phi[NN(Cc, I + a, J + b, K + c)];
+    F->phi[NN(F, i, j, k)] = s * (1.0 / (double)((1 + oi) * (1 + oj) * (1 + ok)));
+  }
+}
+/* composite residual: F->res (all fine nodes, partial at the interface), C->res; returns the composite max-norm */
+static double ml_nd_residual(mlnd *M)
+{
+  ndlev *F = &M->Lf, *Cc = &M->Lc;
+  double nrm = 0.0;
+  ml_nd_interface(M);
+  nd_fill_nodes(F, F->phi, M->per);           /* ghost nodes of a box inside the domain: zero (never used: sigma = 0 there) */
+  nd_fill_nodes(Cc, Cc->phi, M->per);
+  memset(F->res, 0, sizeof(double) * (size_t)(F->n[0] + 3) * (F->n[1] + 3) * (F->n[2] + 3));
+  for (int k = 0; k <= F->n[2]; k++) for (int j = 0; j <= F->n[1]; j++) for (int i = 0; i <= F->n[0]; i++) {
+    double r = 0.0;
+    if (!M->pdir_f[NM(F, i, j, k)]) { double Kp, diag; nd_apply(F, F->phi, i, j, k, &Kp, &diag); r = F->b[NN(F, i, j, k)] - Kp; }
+    F->res[NN(F, i, j, k)] = r;
+    if (!CFM(M, i, j, k)) nrm = fmax(nrm, fabs(r));
+  }
+  const double wt[3] = { 0.5, 1.0, 0.5 };
+  for (int k = 0; k <= Cc->n[2]; k++) for (int j = 0; j <= Cc->n[1]; j++) for (int i = 0; i <= Cc->n[0]; i++) {
+    double r = 0.0;
+    if (!Cc->dir[NM(Cc, i, j, k)]) {
+      double Kp, diag; nd_apply(Cc, Cc->phi, i, j, k, &Kp, &diag);
+      r = Cc->b[NN(Cc, i, j, k)] - Kp;
+      if (i >= M->ilo[0] && i <= M->ihi[0] && j >= M->ilo[1] && j <= M->ihi[1] && k >= M->ilo[2] && k <= M->ihi[2]) {
+        int fi = 2 * (i + M->clo[0]) - M->flo[0], fj = 2 * (j + M->clo[1]) - M->flo[1], fk = 2 * (k + M->clo[2]) - M->flo[2];   /* local fine node */
+        double s = 0.0;
+        for (int c = -1; c <= 1; c++) for (int b = -1; b <= 1; b++) for (int a = -1; a <= 1; a++) {
+          int ii = fi + a, jj = fj + b, kk = fk + c;
+          if (ii < 0 || ii > F->n[0] || jj < 0 || jj > F->n[1] || kk < 0 || kk > F->n[2]) continue;
+          s = s + (wt[a + 1] * wt[b + 1] * wt[c + 1]) * F->res[NN(F, ii, jj, kk)];
+        }
+        r = r + s * 0.125;
+      }
+    }
+    Cc->res[NN(Cc, i, j, k)] = r;
+    int inside = i > M->ilo[0] && i < M->ihi[0] && j > M->ilo[1] && j < M->ihi[1] && k > M->ilo[2] && k < M->ihi[2];
+    if (!inside) nrm = fmax(nrm, fabs(r));
+  }
+  return nrm;
+}
+
+/* rh[lev] nodal (ng 1; in: extra source, normally 0), phi[lev] nodal (ng 1, in/out), coeffs[lev] cells (ng 1, ghost 0 outside the
+ * level), u[lev] cells with >= 1 ghost (wall ghosts zeroed by create_uvec); dx: [lev*3+d]; ellbc per level/box */
+int vo_ml_nd_solve(vo_fab **rh, vo_fab **phi, vo_fab **coeffs, vo_fab **u, const double *dx, const int ellbc[2][3][2], const int pmask[3],
+                   double rel_eps, double abs_eps, int max_iter, const vdn_params *prm, vo_mgstat *st)
+{
+  mlnd M; memset(&M, 0, sizeof M);
+  for (int d = 0; d < 3; d++) { M.per[d] = 0; (void)pmask; M.clo[d] = coeffs[0]->lo[d]; M.flo[d] = coeffs[1]->lo[d]; }
+  const int *flo = coeffs[1]->lo, *fhi = coeffs[1]->hi;
+  int klo[3], khi[3];
+  for (int d = 0; d < 3; d++) { klo[d] = flo[d] / 2; khi[d] = fhi[d] / 2; M.ilo[d] = klo[d] - M.clo[d]; M.ihi[d] = khi[d] + 1 - M.clo[d]; }
+  /* coarse level with masked sigma; full-sigma fab stays in coeffs[0] for the correction solve */
+  vo_fab cm; vo_fab_init(&cm, NULL, coeffs[0]->lo, coeffs[0]->hi, 1, NULL, 1); cm.p = (double *)malloc(sizeof(double) * vo_size(&cm));
+  memcpy(cm.p, coeffs[0]->p, sizeof(double) * vo_size(&cm));
+  for (int k = klo[2]; k <= khi[2]; k++) for (int j = klo[1]; j <= khi[1]; j++) for (int i = klo[0]; i <= khi[0]; i++) VF(&cm, i, j, k, 0) = 0.0;
+  nd_level_from_fab(&M.Lc, &cm, dx); nd_set_mask(&M.Lc, ellbc[0]);
+  nd_level_from_fab(&M.Lf, coeffs[1], dx + 3); nd_set_mask(&M.Lf, ellbc[1]);
+  ndlev *F = &M.Lf, *Cc = &M.Lc;
+  long nfn = (long)(F->n[0] + 1) * (F->n[1] + 1) * (F->n[2] + 1);
+  M.cf = (unsigned char *)calloc(nfn, 1); M.pdir_f = (unsigned char *)malloc(nfn);
+  memcpy(M.pdir_f, F->dir, nfn);
+  for (int k = 0; k <= F->n[2]; k++) for (int j = 0; j <= F->n[1]; j++) for (int i = 0; i <= F->n[0]; i++) {
+    int q[3] = { i, j, k }, onface = 0;
+    for (int d = 0; d < 3; d++) { if (q[d] == 0 && ellbc[1][d][0] == VDN_BC_INT) onface = 1; if (q[d] == F->n[d] && ellbc[1][d][1] == VDN_BC_INT) onface = 1; }
+    if (onface && !M.pdir_f[NM(F, i, j, k)]) { M.cf[NM(F, i, j, k)] = 1; F->dir[NM(F, i, j, k)] = 1; }      /* fixed during the fine relaxation */
+  }
+  /* right-hand sides: rh += D u with the masked velocities (vo_nd_divu), b = -rh */
+  vo_fab uf, uc;
+  masked_u(&uf, u[1], flo, fhi, 0);                    /* fine: zero outside the fine box */
+  masked_u(&uc, u[0], klo, khi, 1);                    /* coarse: zero in the covered cells */
+  vo_nd_divu(&uf, rh[1], dx + 3, ellbc[1]);
+  vo_nd_divu(&uc, rh[0], dx, ellbc[0]);
+  free(uf.p); free(uc.p);
+  double bnorm = 0.0;
+  for (int n = 0; n < 2; n++) {
+    ndlev *L = n ? F : Cc;
+    const unsigned char *pd = n ? M.pdir_f : Cc->dir;
+    for (int k = 0; k <= L->n[2]; k++) for (int j = 0; j <= L->n[1]; j++) for (int i = 0; i <= L->n[0]; i++) {
+      double r = VF(rh[n], rh[n]->lo[0] + i, rh[n]->lo[1] + j, rh[n]->lo[2] + k, 0);
+      if (pd[NM(L, i, j, k)]) r = 0.0;
+      L->b[NN(L, i, j, k)] = -r;
+      L->phi[NN(L, i, j, k)] = pd[NM(L, i, j, k)] ? 0.0 : VF(phi[n], phi[n]->lo[0] + i, phi[n]->lo[1] + j, phi[n]->lo[2] + k, 0);
+    }
+  }
+  /* norm of the composite right-hand side = the composite residual of phi = 0 ... use the residual of the initial guess's
+   * right-hand side: evaluate with phi = 0 */
+  {
+    double *sf = F->phi, *sc = Cc->phi;
+    long nnf = (long)(F->n[0] + 3) * (F->n[1] + 3) * (F->n[2] + 3), nnc = (long)(Cc->n[0] + 3) * (Cc->n[1] + 3) * (Cc->n[2] + 3);
+    F->phi = (double *)calloc(nnf, sizeof(double)); Cc->phi = (double *)calloc(nnc, sizeof(double));
+    bnorm = ml_nd_residual(&M);
+    free(F->phi); free(Cc->phi); F->phi = sf; Cc->phi = sc;
+  }
+  /* scratch fabs for the coarse correction solve */
+  vo_fab er, ee; int nd1[3] = { 1, 1, 1 };
+  vo_fab_init(&er, NULL, coeffs[0]->lo, coeffs[0]->hi, 1, nd1, 1); er.p = (double *)calloc(vo_size(&er), sizeof(double));
+  vo_fab_init(&ee, NULL, coeffs[0]->lo, coeffs[0]->hi, 1, nd1, 1); ee.p = (double *)calloc(vo_size(&ee), sizeof(double));
+  int it = 0, conv = (bnorm == 0.0); double rn = 0.0;
+  const int nu_f = prm->hg_nu1 + prm->hg_nu2;
+  while (!conv) {
+    rn = ml_nd_residual(&M);
+    if (rn <= rel_eps * bnorm || rn <= abs_eps) { conv = 1; break; }
+    if (it >= max_iter) break;
+    /* coarse correction: K_c e = r_c, one V-cycle (vo_nd_solve takes rh with b = -rh) */
+    memset(ee.p, 0, sizeof(double) * vo_size(&ee));
+    for (int k = 0; k <= Cc->n[2]; k++) for (int j = 0; j <= Cc->n[1]; j++) for (int i = 0; i <= Cc->n[0]; i++)
+      VF(&er, er.lo[0] + i, er.lo[1] + j, er.lo[2] + k, 0) = -Cc->res[NN(Cc, i, j, k)];
+    vo_mgstat cs;
+    vo_nd_solve(&er, &ee, coeffs[0], NULL, dx, ellbc[0], pmask, 0.0, -1.0, 1, prm->hg_nu1, prm->hg_nu2, prm->hg_nub, prm->hg_omega, &cs);
+    for (int k = 0; k <= Cc->n[2]; k++) for (int j = 0; j <= Cc->n[1]; j++) for (int i = 0; i <= Cc->n[0]; i++)
+      Cc->phi[NN(Cc, i, j, k)] = Cc->phi[NN(Cc, i, j, k)] + VF(&ee, ee.lo[0] + i, ee.lo[1] + j, ee.lo[2] + k, 0);
+    for (int k = 0; k <= F->n[2]; k++) for (int j = 0; j <= F->n[1]; j++) for (int i = 0; i <= F->n[0]; i++) {
+      if (M.pdir_f[NM(F, i, j, k)]) continue;
+      int gi = M.flo[0] + i, gj = M.flo[1] + j, gk = M.flo[2] + k;
+      int I = (gi >> 1), J = (gj >> 1), K = (gk >> 1), oi = gi & 1, oj = gj & 1, ok = gk & 1;
+      double s = 0.0;
+      for (int c = 0; c <= ok; c++) for (int b = 0; b <= oj; b++) for (int a = 0; a <= oi; a++) s = s + VF(&ee, I + a, J + b, K + c, 0);
+      F->phi[NN(F, i, j, k)] = F->phi[NN(F, i, j, k)] + s * (1.0 / (double)((1 + oi) * (1 + oj) * (1 + ok)));
+    }
+    /* fine relaxation of the correction equation K_f e = r_f, interface nodes fixed (e = 0) */
+    (void)ml_nd_residual(&M);
+    {
+      double *sphi = F->phi, *sb = F->b;
+      long nnf = (long)(F->n[0] + 3) * (F->n[1] + 3) * (F->n[2] + 3);
+      double *e = (double *)calloc(nnf, sizeof(double)), *rb = (double *)malloc(sizeof(double) * nnf);
+      memcpy(rb, F->res, sizeof(double) * nnf);
+      F->phi = e; F->b = rb;
+      nd_jacobi(F, M.per, nu_f, prm->hg_omega);           /* swaps F->phi / F->tmp internally */
+      e = F->phi;
+      F->b = sb;
+      for (int k = 0; k <= F->n[2]; k++) for (int j = 0; j <= F->n[1]; j++) for (int i = 0; i <= F->n[0]; i++)
+        sphi[NN(F, i, j, k)] = sphi[NN(F, i, j, k)] + e[NN(F, i, j, k)];
+      /* nd_jacobi ping-pongs between phi and tmp: keep the two scratch buffers as phi/tmp owners consistent */
+      double *other = F->tmp;
+      F->phi = sphi;
+      if (other == sphi) { F->tmp = e; } else { free(e); }
+      free(rb);
+    }
+    it++;
+  }
+  ml_nd_interface(&M);
+  nd_fill_nodes(F, F->phi, M.per); nd_fill_nodes(Cc, Cc->phi, M.per);
+  for (int n = 0; n < 2; n++) {
+    ndlev *L = n ? F : Cc;
+    for (int k = -1; k <= L->n[2] + 1; k++) for (int j = -1; j <= L->n[1] + 1; j++) for (int i = -1; i <= L->n[0] + 1; i++)
+      VF(phi[n], phi[n]->lo[0] + i, phi[n]->lo[1] + j, phi[n]->lo[2] + k, 0) = L->phi[NN(L, i, j, k)];
+  }
+  if (st) { st->cycles = it; st->res0 = bnorm; st->res = rn; }
+  free(er.p); free(ee.p); free(cm.p); free(M.cf); free(M.pdir_f);
+  nd_free(F); nd_free(Cc);
+  return conv ? 0 : 1;
+}

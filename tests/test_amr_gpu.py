@@ -166,3 +166,36 @@ def test_ml_macproject(gpu, oracle, split):
     tol = 1e-8 * st.res0
     assert np.abs(df).max() <= tol and np.abs(dc).max() <= tol, (np.abs(df).max(), np.abs(dc).max(), st.res0)
     K.close()
+
+
+def test_ml_hgproject(gpu, oracle):
+    """hgproject on two levels: composite nodal solve (interface nodes slaved to the coarse level, Galerkin equations at the coarse
+    nodes of the interface), then gradient / velocity / pressure updates and ml_restrict_and_fill(unew)"""
+    from varden_amd import advance as adv
+    vo = oracle
+    K = Amr2(16, (8, 8, 8), (23, 23, 23))
+    L = vo.lib()
+    unew, uold, rhoh, gp, p = K.ofabs(3, 3), K.ofabs(3, 3), K.ofabs(1, 1), K.ofabs(1, 3), K.ofabs(1, 1, (1, 1, 1))
+    for lev in range(2):
+        K.smooth(unew[lev], lev, 1.0); K.smooth(rhoh[lev], lev, 0.2, 1.5); K.smooth(gp[lev], lev, 0.1)
+    L.vo_ml_restrict_and_fill(2, vo.fab_ptr_array(unew), 0, 0, 3, 0, K.obcs, K.opm, K.opd, C.byref(K.prm))
+    L.vo_ml_restrict_and_fill(2, vo.fab_ptr_array(rhoh), 0, 3, 1, 0, K.obcs, K.opm, K.opd, C.byref(K.prm))
+    L.vo_ml_restrict_and_fill(2, vo.fab_ptr_array(gp), 0, 6, 3, 1, K.obcs, K.opm, K.opd, C.byref(K.prm))
+    for lev in range(2):
+        uold[lev].a[...] = 0.5 * unew[lev].a
+    gun, guo, grh, ggp, gpp = K.gmfs(unew), K.gmfs(uold), K.gmfs(rhoh), K.gmfs(gp), K.gmfs(p)
+    dt = 0.01
+    st = vo.CMgStat()
+    L.vo_ml_hgproject(vo.REGULAR_TIMESTEP, vo.fab_ptr_array(unew), vo.fab_ptr_array(uold), vo.fab_ptr_array(rhoh), vo.fab_ptr_array(p), vo.fab_ptr_array(gp),
+                      K.odx, C.c_double(dt), K.obcs, K.opm, K.opd, C.byref(K.prm), C.byref(st))
+    adv.hgproject(vo.REGULAR_TIMESTEP, K.mla, gun, guo, grh, gpp, ggp, K.dx, dt, K.bct, 3 + 2 + 1)
+    it_gpu = adv.last_solver_stats("hg")[0]
+    assert st.cycles < 40 and it_gpu == st.cycles, (it_gpu, st.cycles)
+    for lev in range(2):
+        a, b = K.gather(gun[lev], unew[lev]), unew[lev].a
+        assert np.abs(a - b).max() <= 1e-9 * np.abs(b).max(), "unew level %d: %.3e" % (lev, np.abs(a - b).max())
+        a, b = K.gather(ggp[lev], gp[lev])[1:-1, 1:-1, 1:-1], gp[lev].a[1:-1, 1:-1, 1:-1]
+        assert np.abs(a - b).max() <= 1e-8 * np.abs(b).max(), "gp level %d: %.3e" % (lev, np.abs(a - b).max())
+        a, b = K.gather(gpp[lev], p[lev])[1:-1, 1:-1, 1:-1], p[lev].a[1:-1, 1:-1, 1:-1]
+        assert np.abs(a - b).max() <= 1e-8 * np.abs(b).max(), "p level %d: %.3e" % (lev, np.abs(a - b).max())
+    K.close()

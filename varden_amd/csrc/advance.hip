@@ -181,7 +181,7 @@ extern "C" int vdn_hgproject(int proj_type, vdn_layout *mla, vdn_multifab **unew
                              vdn_multifab **rhohalf, vdn_multifab **p, vdn_multifab **gp,
                              const double *dx, double dt, const vdn_bc_tower *bct, int press_comp) {
   VDN_TRY
-  check_single_level(mla);
+  REQUIRE(mla && mla->nlev <= 2, "hgproject: at most two levels are implemented (nlevel = %d)", mla ? mla->nlev : -1);
   arena_reset(); arena_reserve_for(mla);
   do_hgproject(proj_type, mla, unew, uold, rhohalf, p, gp, dx, dt, bct, press_comp - 1);
   arena_reset();

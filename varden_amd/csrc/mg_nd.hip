@@ -849,20 +849,11 @@ __global__ void kk_hg_update(FV unew, FV uold, FV gp, FV gphi, FV rhohalf, FV p,
   else if (A.proj_type == VDN_REGULAR_TIMESTEP) fv_at(p, i, j, k) = A.dtinv * fv_get(phi, i, j, k);
 }
 
-void do_hgproject(int proj_type, vdn_layout *mla, vdn_multifab **unew, vdn_multifab **uold, vdn_multifab **rhohalf,
-                  vdn_multifab **p, vdn_multifab **gp, const double *dx, double dt, const vdn_bc_tower *bct, int press_comp0) {
-  if (ctx().prm.dm == 2) { do2_hgproject(proj_type, mla, unew, uold, rhohalf, p, gp, dx, dt, bct, press_comp0); return; }
-  REQUIRE(mla->nlev == 1, "hgproject: multilevel hierarchies are not implemented in this round");
-  REQUIRE(proj_type >= VDN_INITIAL_PROJECTION && proj_type <= VDN_REGULAR_TIMESTEP, "No proj_type by this number");
-  const int n = 0;
+// per-level pieces of hgproject, shared by the single-level driver and the two-level one
+static void hg_level_pre(int proj_type, vdn_multifab *un, const vdn_multifab *uo, const vdn_multifab *rhh, vdn_multifab *gpp, vdn_multifab *coeffs,
+                         double dt, const vdn_bc_tower *bct) {
   hipStream_t st = ctx().stream;
-  size_t mark = arena_mark();
-  vdn_multifab *rh = mf_temp(mla, n, 1, 1, 3, true, 0.0);
-  vdn_multifab *phi = mf_temp(mla, n, 1, 1, 3, true, 0.0);
-  vdn_multifab *gphi = mf_temp(mla, n, 3, 0, -1, false, 0.0);
-  vdn_multifab *coeffs = mf_temp(mla, n, 1, 1, -1, true, 0.0);        // ghosts 0: hg_multigrid.f90:73
-  vdn_multifab *un = unew[n], *uo = uold[n], *rhh = rhohalf[n], *gpp = gp[n], *pp = p[n];
-  REQUIRE(un->ng >= 1 && gpp->ng >= 1 && rhh->ng >= 1 && pp->ng >= 1, "hgproject: ghost widths");
+  REQUIRE(un->ng >= 1 && gpp->ng >= 1 && rhh->ng >= 1, "hgproject: ghost widths");
   for (int i = 0; i < un->nfabs(); i++) {
     UvecArgs A; Range3 r; BoxP bp = make_boxp(un, i, bct);
     for (int d = 0; d < 3; d++) { A.lo[d] = bp.lo[d]; A.hi[d] = bp.hi[d]; r.lo[d] = bp.lo[d] - un->ng; r.hi[d] = bp.hi[d] + un->ng;
@@ -874,6 +865,36 @@ void do_hgproject(int proj_type, vdn_layout *mla, vdn_multifab **unew, vdn_multi
   }
   mf_fill_boundary(un);                                               // hgproject.f90:232
   mf_fill_boundary(coeffs);                                           // hg_multigrid.f90:79
+}
+static void hg_level_post(int proj_type, vdn_multifab *un, const vdn_multifab *uo, const vdn_multifab *rhh, vdn_multifab *gpp, vdn_multifab *pp,
+                          vdn_multifab *gphi, const vdn_multifab *phi, const double *dx, double dt) {
+  hipStream_t st = ctx().stream;
+  if (proj_type == VDN_INITIAL_PROJECTION || proj_type == VDN_DIVU_ITERS) { mf_setval(gpp, 0.0, 0, gpp->nc, true); mf_setval(pp, 0.0, 0, 1, true); }   // 673-676
+  for (int i = 0; i < un->nfabs(); i++) {
+    Range3 rv, rn; HgUpdArgs H;
+    for (int d = 0; d < 3; d++) { rv.lo[d] = rn.lo[d] = un->vbox[i].lo[d]; rv.hi[d] = un->vbox[i].hi[d]; rn.hi[d] = rv.hi[d] + 1; H.hi[d] = rv.hi[d]; }
+    H.dt = dt; H.dtinv = 1.0 / dt; H.proj_type = proj_type;
+    hipLaunchKernelGGL(kk_mkgphi, grid_for(rv), NBLK, 0, st, gphi->fabs[i], phi->fabs[i], 1.0 / dx[0], 1.0 / dx[1], 1.0 / dx[2], rv);
+    hipLaunchKernelGGL(kk_hg_update, grid_for(rn), NBLK, 0, st, un->fabs[i], uo->fabs[i], gpp->fabs[i], gphi->fabs[i], rhh->fabs[i], pp->fabs[i], phi->fabs[i], H, rn);
+  }
+}
+static void do_ml_hgproject(int proj_type, vdn_layout *mla, vdn_multifab **unew, vdn_multifab **uold, vdn_multifab **rhohalf,
+                            vdn_multifab **p, vdn_multifab **gp, const double *dx, double dt, const vdn_bc_tower *bct, int press_comp0);
+
+void do_hgproject(int proj_type, vdn_layout *mla, vdn_multifab **unew, vdn_multifab **uold, vdn_multifab **rhohalf,
+                  vdn_multifab **p, vdn_multifab **gp, const double *dx, double dt, const vdn_bc_tower *bct, int press_comp0) {
+  if (ctx().prm.dm == 2) { do2_hgproject(proj_type, mla, unew, uold, rhohalf, p, gp, dx, dt, bct, press_comp0); return; }
+  REQUIRE(proj_type >= VDN_INITIAL_PROJECTION && proj_type <= VDN_REGULAR_TIMESTEP, "No proj_type by this number");
+  if (mla->nlev > 1) { do_ml_hgproject(proj_type, mla, unew, uold, rhohalf, p, gp, dx, dt, bct, press_comp0); return; }
+  const int n = 0;
+  size_t mark = arena_mark();
+  vdn_multifab *rh = mf_temp(mla, n, 1, 1, 3, true, 0.0);
+  vdn_multifab *phi = mf_temp(mla, n, 1, 1, 3, true, 0.0);
+  vdn_multifab *gphi = mf_temp(mla, n, 3, 0, -1, false, 0.0);
+  vdn_multifab *coeffs = mf_temp(mla, n, 1, 1, -1, true, 0.0);        // ghosts 0: hg_multigrid.f90:73
+  vdn_multifab *un = unew[n], *uo = uold[n], *rhh = rhohalf[n], *gpp = gp[n], *pp = p[n];
+  REQUIRE(pp->ng >= 1, "hgproject: ghost widths");
+  hg_level_pre(proj_type, un, uo, rhh, gpp, coeffs, dt, bct);
   double rel = ctx().prm.hg_rel_eps > 0.0 ? ctx().prm.hg_rel_eps : 1.e-12;   // hgproject.f90:113-119 (nlevs = 1)
   double abs_eps = -1.0;
   if (proj_type == VDN_INITIAL_PROJECTION && ctx().prm.prob_type == 4) abs_eps = 1.e-12;   // 125-127
@@ -883,15 +904,249 @@ void do_hgproject(int proj_type, vdn_layout *mla, vdn_multifab **unew, vdn_multi
   int rc = nd_solve(rh, phi, coeffs, un, dx, ebc, rel, abs_eps, ctx().prm.hg_max_iter, &cyc, &r0, &rr);
   ctx().solver_cycles[1] = cyc; ctx().solver_res0[1] = r0; ctx().solver_res[1] = rr;
   if (rc != 0 && ctx().prm.verbose) fprintf(stderr, "varden_amd: nodal multigrid did not converge in %d cycles (res %g / %g)\n", cyc, rr, r0);
-  if (proj_type == VDN_INITIAL_PROJECTION || proj_type == VDN_DIVU_ITERS) { mf_setval(gpp, 0.0, 0, gpp->nc, true); mf_setval(pp, 0.0, 0, 1, true); }   // 673-676
-  for (int i = 0; i < un->nfabs(); i++) {
-    Range3 rv, rn; HgUpdArgs H;
-    for (int d = 0; d < 3; d++) { rv.lo[d] = rn.lo[d] = un->vbox[i].lo[d]; rv.hi[d] = un->vbox[i].hi[d]; rn.hi[d] = rv.hi[d] + 1; H.hi[d] = rv.hi[d]; }
-    H.dt = dt; H.dtinv = 1.0 / dt; H.proj_type = proj_type;
-    hipLaunchKernelGGL(kk_mkgphi, grid_for(rv), NBLK, 0, st, gphi->fabs[i], phi->fabs[i], 1.0 / dx[0], 1.0 / dx[1], 1.0 / dx[2], rv);
-    hipLaunchKernelGGL(kk_hg_update, grid_for(rn), NBLK, 0, st, un->fabs[i], uo->fabs[i], gpp->fabs[i], gphi->fabs[i], rhh->fabs[i], pp->fabs[i], phi->fabs[i], H, rn);
-  }
+  hg_level_post(proj_type, un, uo, rhh, gpp, pp, gphi, phi, dx, dt);
   mf_fill_boundary(gpp); mf_fill_boundary(pp);                        // hgproject.f90:359-362
   mf_temp_free(coeffs); mf_temp_free(gphi); mf_temp_free(phi); mf_temp_free(rh);
+  arena_release(mark);
+}
+
+// =====================================================================================================================
+// two-level composite nodal solve (oracle/vo_hgproject.c: vo_ml_nd_solve) and the multilevel hgproject
+// =====================================================================================================================
+// Works directly on the multifab fabs (nodal, one ghost layer).  This round: one fine box (the coarse level may be any
+// decomposition the single-level multigrid accepts), single rank.
+DEVI void ndf_apply(const FV &phi, const FV &sig, const double f[3], int i, int j, int k, double &Kp, double &diag) {
+  const double fx = f[0], fy = f[1], fz = f[2], F = fx + fy + fz;
+  double w[8];
+  w[0] = 4.0 * F; w[1] = -4.0 * fx + 2.0 * fy + 2.0 * fz; w[2] = 2.0 * fx - 4.0 * fy + 2.0 * fz; w[3] = -2.0 * fx - 2.0 * fy + fz;
+  w[4] = 2.0 * fx + 2.0 * fy - 4.0 * fz; w[5] = -2.0 * fx + fy - 2.0 * fz; w[6] = fx - 2.0 * fy - 2.0 * fz; w[7] = -F;
+  double acc = 0.0, ssum = 0.0;
+  #pragma unroll
+  for (int dk = 0; dk < 2; dk++)
+    #pragma unroll
+    for (int dj = 0; dj < 2; dj++)
+      #pragma unroll
+      for (int di = 0; di < 2; di++) {
+        const int ci = i - 1 + di, cj = j - 1 + dj, ck = k - 1 + dk;
+        const double sg = fv_get(sig, ci, cj, ck);
+        double t = 0.0;
+        #pragma unroll
+        for (int mz = 0; mz < 2; mz++)
+          #pragma unroll
+          for (int my = 0; my < 2; my++)
+            #pragma unroll
+            for (int mx = 0; mx < 2; mx++) {
+              const int ni = ci + mx, nj = cj + my, nk = ck + mz;
+              const int idx = (ni != i) | ((nj != j) << 1) | ((nk != k) << 2);
+              t = t + w[idx] * fv_get(phi, ni, nj, nk);
+            }
+        acc = acc + sg * t;
+        ssum = ssum + sg;
+      }
+  Kp = acc; diag = w[0] * ssum;
+}
+struct NdfArgs { double f[3]; int lo[3], hi[3]; int dirlo[3], dirhi[3]; int cflo[3], cfhi[3]; int ilo[3], ihi[3]; };
+DEVI bool ndf_pdir(const NdfArgs &A, int i, int j, int k) {
+  return (i == A.lo[0] && A.dirlo[0]) || (i == A.hi[0] && A.dirhi[0]) || (j == A.lo[1] && A.dirlo[1]) || (j == A.hi[1] && A.dirhi[1]) ||
+         (k == A.lo[2] && A.dirlo[2]) || (k == A.hi[2] && A.dirhi[2]);
+}
+DEVI bool ndf_cf(const NdfArgs &A, int i, int j, int k) {          // node on a coarse-fine face of the (single) fine box
+  return (i == A.lo[0] && A.cflo[0]) || (i == A.hi[0] && A.cfhi[0]) || (j == A.lo[1] && A.cflo[1]) || (j == A.hi[1] && A.cfhi[1]) ||
+         (k == A.lo[2] && A.cflo[2]) || (k == A.hi[2] && A.cfhi[2]);
+}
+// A.lo/hi: node range of the box.  excl: 0 none, 1 exclude interface nodes from the norm (fine), 2 exclude coarse nodes strictly
+// inside the fine box (A.ilo/ihi, coarse node indices)
+__global__ void kk_ndf_residual(FV b, FV phi, FV sig, FV res, NdfArgs A, int excl, Range3 r, double *nrm) {
+  REDUCE_IJ(r)
+  double rmax = 0.0;
+  if (in_ij) REDUCE_KLOOP(r) {
+    double rr = 0.0;
+    if (!ndf_pdir(A, i, j, k)) { double Kp, diag; ndf_apply(phi, sig, A.f, i, j, k, Kp, diag); rr = fv_get(b, i, j, k) - Kp; }
+    fv_at(res, i, j, k) = rr;
+    bool skip = false;
+    if (excl == 1) skip = ndf_cf(A, i, j, k) && !ndf_pdir(A, i, j, k);
+    if (excl == 2) skip = i > A.ilo[0] && i < A.ihi[0] && j > A.ilo[1] && j < A.ihi[1] && k > A.ilo[2] && k < A.ihi[2];
+    if (!skip) rmax = fmax(rmax, fabs(rr));
+  }
+  if (nrm) block_atomic_max(nrm, rmax);
+}
+__global__ void kk_ndf_absmax(FV a, NdfArgs A, int excl, Range3 r, double *nrm) {
+  REDUCE_IJ(r)
+  double m = 0.0;
+  if (in_ij) REDUCE_KLOOP(r) {
+    bool skip = false;
+    if (excl == 2) skip = i > A.ilo[0] && i < A.ihi[0] && j > A.ilo[1] && j < A.ihi[1] && k > A.ilo[2] && k < A.ihi[2];
+    if (!skip) m = fmax(m, fabs(fv_get(a, i, j, k)));
+  }
+  block_atomic_max(nrm, m);
+}
+// res_c += full weighting of the fine residual (zero outside the fine box's nodes) on the coarse nodes A.ilo..A.ihi
+__global__ void kk_ndf_restrict_add(FV res_c, FV res_f, NdfArgs Af, NdfArgs Ac, Range3 r) {
+  THREAD_IJK(r)
+  if (!in_range || ndf_pdir(Ac, i, j, k)) return;
+  const double wt[3] = { 0.5, 1.0, 0.5 };
+  double s = 0.0;
+  for (int c = -1; c <= 1; c++) for (int b = -1; b <= 1; b++) for (int a = -1; a <= 1; a++) {
+    const int ii = 2 * i + a, jj = 2 * j + b, kk = 2 * k + c;
+    if (ii < Af.lo[0] || ii > Af.hi[0] || jj < Af.lo[1] || jj > Af.hi[1] || kk < Af.lo[2] || kk > Af.hi[2]) continue;
+    s = s + (wt[a + 1] * wt[b + 1] * wt[c + 1]) * fv_get(res_f, ii, jj, kk);
+  }
+  fv_at(res_c, i, j, k) = fv_get(res_c, i, j, k) + s * 0.125;
+}
+// mode 0: phi_f = P phi_c on the interface nodes;  mode 1: phi_f += P e_c on every node that is not a physical Dirichlet node
+__global__ void kk_ndf_prolong(FV pf, FV pc, NdfArgs Af, int mode, Range3 r) {
+  THREAD_IJK(r)
+  if (!in_range) return;
+  if (ndf_pdir(Af, i, j, k)) return;
+  if (mode == 0 && !ndf_cf(Af, i, j, k)) return;
+  const int I = i >> 1, J = j >> 1, K = k >> 1, oi = i & 1, oj = j & 1, ok = k & 1;
+  double s = 0.0;
+  for (int c = 0; c <= ok; c++) for (int b = 0; b <= oj; b++) for (int a = 0; a <= oi; a++) s = s + fv_get(pc, I + a, J + b, K + c);
+  const double v = s * (1.0 / (double)((1 + oi) * (1 + oj) * (1 + ok)));
+  fv_at(pf, i, j, k) = (mode == 0) ? v : fv_get(pf, i, j, k) + v;
+}
+__global__ void kk_ndf_jacobi(FV ein, FV eout, FV rb, FV sig, NdfArgs A, double omega, Range3 r) {
+  THREAD_IJK(r)
+  if (!in_range) return;
+  const double p0 = fv_get(ein, i, j, k);
+  double v = p0;
+  if (!ndf_pdir(A, i, j, k) && !ndf_cf(A, i, j, k)) { double Kp, diag; ndf_apply(ein, sig, A.f, i, j, k, Kp, diag); if (diag != 0.0) v = p0 + omega * ((fv_get(rb, i, j, k) - Kp) / diag); }
+  fv_at(eout, i, j, k) = v;
+}
+// out = u (3 comps, one ghost layer) with zero outside [klo,khi] (invert = 0) or zero inside it (invert = 1)
+__global__ void kk_ndf_mask_u(FV out, FV u, Range3 r, int k0, int k1, int k2, int h0, int h1, int h2, int invert) {
+  THREAD_IJK(r)
+  if (!in_range) return;
+  const bool in = i >= k0 && i <= h0 && j >= k1 && j <= h1 && k >= k2 && k <= h2;
+  #pragma unroll
+  for (int c = 0; c < 3; c++) fv_at(out, i, j, k, c) = (in != (invert != 0)) ? fv_get(u, i, j, k, c) : 0.0;
+}
+__global__ void kk_ndf_setbox(FV a, Range3 r, double v) { THREAD_IJK(r) if (!in_range) return; fv_at(a, i, j, k) = v; }
+__global__ void kk_ndf_neg(FV out, FV in, NdfArgs A, Range3 r) {       // b = -rh, zero on physical Dirichlet nodes
+  THREAD_IJK(r)
+  if (!in_range) return;
+  fv_at(out, i, j, k) = ndf_pdir(A, i, j, k) ? 0.0 : -fv_get(in, i, j, k);
+}
+__global__ void kk_ndf_add(FV a, FV b, Range3 r) { THREAD_IJK(r) if (!in_range) return; fv_at(a, i, j, k) = fv_get(a, i, j, k) + fv_get(b, i, j, k); }
+
+static double ndf_read(double *d) { double h; HIPCHK(hipMemcpyAsync(&h, d, sizeof(double), hipMemcpyDeviceToHost, ctx().stream)); HIPCHK(hipStreamSynchronize(ctx().stream)); return h; }
+struct MLND {
+  vdn_multifab *phi[2], *b[2], *res[2], *sig[2];     // sig[0]: MASKED coarse sigma
+  NdfArgs A[2]; Range3 rn[2]; double *d_nrm;
+};
+static double ml_nd_residual(MLND &S, bool zero_phi_unused) {
+  (void)zero_phi_unused;
+  hipStream_t st = ctx().stream;
+  hipLaunchKernelGGL(kk_ndf_prolong, grid_for(S.rn[1]), NBLK, 0, st, S.phi[1]->fabs[0], S.phi[0]->fabs[0], S.A[1], 0, S.rn[1]);
+  HIPCHK(hipMemsetAsync(S.d_nrm, 0, sizeof(double), st));
+  hipLaunchKernelGGL(kk_ndf_residual, reduce_grid(S.rn[1]), NBLK, 0, st, S.b[1]->fabs[0], S.phi[1]->fabs[0], S.sig[1]->fabs[0], S.res[1]->fabs[0], S.A[1], 1, S.rn[1], S.d_nrm);
+  hipLaunchKernelGGL(kk_ndf_residual, reduce_grid(S.rn[0]), NBLK, 0, st, S.b[0]->fabs[0], S.phi[0]->fabs[0], S.sig[0]->fabs[0], S.res[0]->fabs[0], S.A[0], 0, S.rn[0], (double *)nullptr);
+  Range3 ri; for (int d = 0; d < 3; d++) { ri.lo[d] = S.A[0].ilo[d]; ri.hi[d] = S.A[0].ihi[d]; }
+  hipLaunchKernelGGL(kk_ndf_restrict_add, grid_for(ri), NBLK, 0, st, S.res[0]->fabs[0], S.res[1]->fabs[0], S.A[1], S.A[0], ri);
+  hipLaunchKernelGGL(kk_ndf_absmax, reduce_grid(S.rn[0]), NBLK, 0, st, S.res[0]->fabs[0], S.A[0], 2, S.rn[0], S.d_nrm);
+  return ndf_read(S.d_nrm);
+}
+// rh, phi: nodal ng 1 per level; coeffs: cells ng 1 (ghost 0 outside the level); u: cells (>= 1 ghost); dx: [lev*3+d]
+static int ml_nd_solve(vdn_layout *la, vdn_multifab **rh, vdn_multifab **phi, vdn_multifab **coeffs, vdn_multifab **u, const double *dx,
+                       const vdn_bc_tower *bct, int press_comp0, double rel_eps, double abs_eps, int max_iter, int *iters, double *res0, double *res) {
+  REQUIRE(la->nlev == 2 && ctx().nranks == 1, "composite nodal solve: two levels, single rank");
+  REQUIRE(phi[0]->nfabs() == 1 && phi[1]->nfabs() == 1, "composite nodal solve: one box per level in this round");
+  REQUIRE(!(la->pmask[0] || la->pmask[1] || la->pmask[2]), "composite nodal solve: periodic domains are not implemented");
+  hipStream_t st = ctx().stream;
+  const size_t mark = arena_mark();
+  const vdn_params &P = ctx().prm;
+  MLND S; S.d_nrm = (double *)arena_alloc(256);
+  const vdn_box &cb = phi[0]->vbox[0], &fb = phi[1]->vbox[0];
+  for (int n = 0; n < 2; n++) {
+    const vdn_box &bx = n ? fb : cb;
+    NdfArgs &A = S.A[n];
+    for (int d = 0; d < 3; d++) {
+      A.f[d] = 1.0 / (36.0 * (dx[3 * n + d] * dx[3 * n + d]));
+      A.lo[d] = bx.lo[d]; A.hi[d] = bx.hi[d] + 1;
+      const int e0 = bct->ell_bc(n, 1, d, 0, press_comp0), e1 = bct->ell_bc(n, 1, d, 1, press_comp0);
+      A.dirlo[d] = e0 == VDN_BC_DIR; A.dirhi[d] = e1 == VDN_BC_DIR;
+      A.cflo[d] = (n == 1) && e0 == VDN_BC_INT; A.cfhi[d] = (n == 1) && e1 == VDN_BC_INT;
+      A.ilo[d] = fb.lo[d] / 2; A.ihi[d] = fb.hi[d] / 2 + 1;
+      S.rn[n].lo[d] = A.lo[d]; S.rn[n].hi[d] = A.hi[d];
+    }
+    S.phi[n] = phi[n];
+    S.b[n] = mf_temp(la, n, 1, 1, 3, true, 0.0); S.res[n] = mf_temp(la, n, 1, 1, 3, true, 0.0);
+  }
+  // masked coarse sigma and the masked velocities
+  S.sig[1] = coeffs[1];
+  S.sig[0] = mf_temp(la, 0, 1, 1, -1, true, 0.0);
+  mf_copy(S.sig[0], 0, coeffs[0], 0, 1, 1);
+  Range3 rcov; for (int d = 0; d < 3; d++) { rcov.lo[d] = fb.lo[d] / 2; rcov.hi[d] = fb.hi[d] / 2; }
+  hipLaunchKernelGGL(kk_ndf_setbox, grid_for(rcov), NBLK, 0, st, S.sig[0]->fabs[0], rcov, 0.0);
+  for (int n = 0; n < 2; n++) {
+    const vdn_box &bx = n ? fb : cb;
+    vdn_multifab *um = mf_temp(la, n, 3, 1, -1, false, 0.0);
+    Range3 rg; for (int d = 0; d < 3; d++) { rg.lo[d] = bx.lo[d] - 1; rg.hi[d] = bx.hi[d] + 1; }
+    if (n == 1) hipLaunchKernelGGL(kk_ndf_mask_u, grid_for(rg), NBLK, 0, st, um->fabs[0], u[1]->fabs[0], rg, fb.lo[0], fb.lo[1], fb.lo[2], fb.hi[0], fb.hi[1], fb.hi[2], 0);
+    else        hipLaunchKernelGGL(kk_ndf_mask_u, grid_for(rg), NBLK, 0, st, um->fabs[0], u[0]->fabs[0], rg, rcov.lo[0], rcov.lo[1], rcov.lo[2], rcov.hi[0], rcov.hi[1], rcov.hi[2], 1);
+    hipLaunchKernelGGL(kk_nd_divu, grid_for(S.rn[n]), NBLK, 0, st, um->fabs[0], rh[n]->fabs[0], 0.25 / dx[3 * n], 0.25 / dx[3 * n + 1], 0.25 / dx[3 * n + 2], S.rn[n]);
+    hipLaunchKernelGGL(kk_ndf_neg, grid_for(S.rn[n]), NBLK, 0, st, S.b[n]->fabs[0], rh[n]->fabs[0], S.A[n], S.rn[n]);
+    mf_temp_free(um);
+  }
+  // norm of the composite right-hand side = composite residual of phi = 0
+  vdn_multifab *keep[2] = { S.phi[0], S.phi[1] }, *zero[2] = { mf_temp(la, 0, 1, 1, 3, true, 0.0), mf_temp(la, 1, 1, 1, 3, true, 0.0) };
+  S.phi[0] = zero[0]; S.phi[1] = zero[1];
+  const double bnorm = ml_nd_residual(S, true);
+  S.phi[0] = keep[0]; S.phi[1] = keep[1];
+  vdn_multifab *er = zero[0], *ee = mf_temp(la, 0, 1, 1, 3, true, 0.0);      // scratch of the coarse correction solve
+  vdn_multifab *ef = zero[1], *ef2 = mf_temp(la, 1, 1, 1, 3, true, 0.0);     // fine Jacobi ping-pong
+  int ebc0[3][2];
+  for (int d = 0; d < 3; d++) for (int s = 0; s < 2; s++) ebc0[d][s] = bct->ell_bc(0, 0, d, s, press_comp0);
+  int it = 0; bool conv = (bnorm == 0.0); double rn = 0.0;
+  while (!conv) {
+    rn = ml_nd_residual(S, false);
+    if (rn <= rel_eps * bnorm || rn <= abs_eps) { conv = true; break; }
+    if (it >= max_iter) break;
+    // coarse correction K_c e = r_c: one V-cycle of the single-level solver (which takes rh with b = -rh)
+    mf_setval(ee, 0.0, 0, 1, true); mf_setval(er, 0.0, 0, 1, true);
+    { NdfArgs Z = S.A[0]; for (int d = 0; d < 3; d++) { Z.dirlo[d] = Z.dirhi[d] = 0; }
+      hipLaunchKernelGGL(kk_ndf_neg, grid_for(S.rn[0]), NBLK, 0, st, er->fabs[0], S.res[0]->fabs[0], Z, S.rn[0]); }
+    int cyc; double r0, rr;
+    nd_solve(er, ee, coeffs[0], nullptr, dx, ebc0, 0.0, -1.0, 1, &cyc, &r0, &rr);
+    hipLaunchKernelGGL(kk_ndf_add, grid_for(S.rn[0]), NBLK, 0, st, S.phi[0]->fabs[0], ee->fabs[0], S.rn[0]);
+    hipLaunchKernelGGL(kk_ndf_prolong, grid_for(S.rn[1]), NBLK, 0, st, S.phi[1]->fabs[0], ee->fabs[0], S.A[1], 1, S.rn[1]);
+    // fine relaxation of K_f e = r_f with the interface fixed
+    (void)ml_nd_residual(S, false);
+    mf_setval(ef, 0.0, 0, 1, true);
+    vdn_multifab *a = ef, *b2 = ef2;
+    for (int s = 0; s < P.hg_nu1 + P.hg_nu2; s++) {
+      hipLaunchKernelGGL(kk_ndf_jacobi, grid_for(S.rn[1]), NBLK, 0, st, a->fabs[0], b2->fabs[0], S.res[1]->fabs[0], S.sig[1]->fabs[0], S.A[1], P.hg_omega, S.rn[1]);
+      std::swap(a, b2);
+    }
+    hipLaunchKernelGGL(kk_ndf_add, grid_for(S.rn[1]), NBLK, 0, st, S.phi[1]->fabs[0], a->fabs[0], S.rn[1]);
+    it++;
+  }
+  hipLaunchKernelGGL(kk_ndf_prolong, grid_for(S.rn[1]), NBLK, 0, st, S.phi[1]->fabs[0], S.phi[0]->fabs[0], S.A[1], 0, S.rn[1]);
+  if (iters) *iters = it; if (res0) *res0 = bnorm; if (res) *res = rn;
+  HIPCHK(hipStreamSynchronize(st));
+  arena_release(mark);
+  return conv ? 0 : 1;
+}
+// hgproject.f90:17-178 with nlevs = 2 (rel 1e-11, hgproject.f90:115-116)
+static void do_ml_hgproject(int proj_type, vdn_layout *mla, vdn_multifab **unew, vdn_multifab **uold, vdn_multifab **rhohalf,
+                            vdn_multifab **p, vdn_multifab **gp, const double *dx, double dt, const vdn_bc_tower *bct, int press_comp0) {
+  const size_t mark = arena_mark();
+  vdn_multifab *rh[2], *phi[2], *gphi[2], *coeffs[2];
+  for (int n = 0; n < 2; n++) {
+    rh[n] = mf_temp(mla, n, 1, 1, 3, true, 0.0); phi[n] = mf_temp(mla, n, 1, 1, 3, true, 0.0);
+    gphi[n] = mf_temp(mla, n, 3, 0, -1, false, 0.0); coeffs[n] = mf_temp(mla, n, 1, 1, -1, true, 0.0);
+    hg_level_pre(proj_type, unew[n], uold[n], rhohalf[n], gp[n], coeffs[n], dt, bct);
+  }
+  double rel = ctx().prm.hg_rel_eps > 0.0 ? ctx().prm.hg_rel_eps : 1.e-11;
+  double abs_eps = -1.0;
+  if (proj_type == VDN_INITIAL_PROJECTION && ctx().prm.prob_type == 4) abs_eps = 1.e-12;
+  int it; double r0, rr;
+  int rc = ml_nd_solve(mla, rh, phi, coeffs, unew, dx, bct, press_comp0, rel, abs_eps, ctx().prm.hg_max_iter, &it, &r0, &rr);
+  ctx().solver_cycles[1] = it; ctx().solver_res0[1] = r0; ctx().solver_res[1] = rr;
+  if (rc != 0 && ctx().prm.verbose) fprintf(stderr, "varden_amd: composite nodal solve did not converge in %d iterations (res %g / %g)\n", it, rr, r0);
+  for (int n = 0; n < 2; n++) hg_level_post(proj_type, unew[n], uold[n], rhohalf[n], gp[n], p[n], gphi[n], phi[n], dx + 3 * n, dt);
+  ml_cc_restriction(gp[0], gp[1], 0, 3);                               // hgproject.f90:355-357
+  for (int n = 0; n < 2; n++) { mf_fill_boundary(gp[n]); mf_fill_boundary(p[n]); }
+  ml_restrict_and_fill(2, unew, 0, 0, 3, false, bct);                  // hgproject.f90:364-366
   arena_release(mark);
 }
