@@ -184,6 +184,9 @@ int  vo_ml_nd_solve(vo_fab **rh, vo_fab **phi, vo_fab **coeffs, vo_fab **u, cons
 void vo_ml_hgproject(int proj_type, vo_fab **unew, vo_fab **uold, vo_fab **rhohalf, vo_fab **p, vo_fab **gp, const double *dx, double dt,
                      const vo_bc *bc, const int pmask[3], const int *pd, const vdn_params *prm, vo_mgstat *st);
 
+void vo_ml_advance_timestep(vo_state *S, const double *dx, double dt, const vo_bc *bc, const int pmask[3], const int *pd, const vdn_params *prm,
+                            int proj_type, vo_mgstat st[2]);
+
 /* ---- the 2-D path (oracle/vo_2d.c): velpred_2d, mkflux_2d, update_2d, mkforce 2-D, estdt_2d, macproject / hgproject
  *      2-D kernels, our 5-point cell-centred and 9-point nodal multigrids, advance_timestep with dm = 2 ------------ */
 #define V2(f, i, j, c) VF(f, i, j, 0, c)

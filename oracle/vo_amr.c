@@ -358,3 +358,78 @@ void vo_ml_hgproject(int proj_type, vo_fab **unew, vo_fab **uold, vo_fab **rhoha
   vo_ml_restrict_and_fill(2, unew, 0, 0, 3, 0, bc, pmask, pd, prm);          /* hgproject.f90:364-366 */
   for (int n = 0; n < 2; n++) { free(rh[n].p); free(phi[n].p); free(gphi[n].p); free(coeffs[n].p); }
 }
+
+/* advance_timestep.f90:26-170 on two levels (inviscid): the orchestration of oracle/vo_advance.c with level loops, ml_restrict_and_fill
+ * in place of fill_boundary + physbc, the velpred tail of velpred.f90:102-122 and the multilevel projections.  S: [lev] */
+static void fab_new_l(vo_fab *f, const vo_fab *like, int ng, int face_dir, int nc, double val)
+{
+  int nd[3] = { 0, 0, 0 }; if (face_dir >= 0) nd[face_dir] = 1;
+  vo_fab_init(f, NULL, like->lo, like->hi, ng, nd, nc);
+  long n = vo_size(f);
+  f->p = (double *)malloc(sizeof(double) * n);
+  for (long i = 0; i < n; i++) f->p[i] = val;
+}
+void vo_ml_advance_timestep(vo_state *S, const double *dx, double dt, const vo_bc *bc, const int pmask[3], const int *pd, const vdn_params *prm,
+                            int proj_type, vo_mgstat st[2])
+{
+  const int dm = 3, nscal = prm->nscal, NL = 2;
+  vo_fab mac_rhs[2], rhohalf[2], umac[6], vel_force[2], scal_force[2], divu[2], sedge[6], sflux[6], uedge[6], uflux[6];
+  vo_fab *mrp[2], *rhp[2], *ump[6], *vfp[2], *sfp2[2], *sep[6], *sfp[6], *uep[6], *ufp[6];
+  vo_fab *uoldp[2], *soldp[2], *unewp[2], *snewp[2], *gpp[2], *pp[2];
+  for (int n = 0; n < NL; n++) {
+    uoldp[n] = &S[n].uold; soldp[n] = &S[n].sold; unewp[n] = &S[n].unew; snewp[n] = &S[n].snew; gpp[n] = &S[n].gp; pp[n] = &S[n].p;
+    fab_new_l(&mac_rhs[n], &S[n].uold, 1, -1, 1, 0.0); mrp[n] = &mac_rhs[n];
+    fab_new_l(&rhohalf[n], &S[n].uold, 1, -1, dm, 0.0); rhp[n] = &rhohalf[n];
+    for (int d = 0; d < 3; d++) { fab_new_l(&umac[3 * n + d], &S[n].uold, 1, d, 1, 1.e20); ump[3 * n + d] = &umac[3 * n + d]; }
+    fab_new_l(&vel_force[n], &S[n].uold, 1, -1, dm, 0.0); vfp[n] = &vel_force[n];
+  }
+  /* advance_premac */
+  for (int n = 0; n < NL; n++) vo_mkvelforce(&vel_force[n], &S[n].ext_vel_force, &S[n].gp, &S[n].sold, NULL, 1.0, prm);
+  vo_ml_restrict_and_fill(NL, vfp, 0, bc[0].extrap_comp, dm, 1, bc, pmask, pd, prm);
+  for (int n = 0; n < NL; n++) vo_velpred(&S[n].uold, ump + 3 * n, &vel_force[n], dx + 3 * n, dt, &bc[n], prm);
+  for (int d = 0; d < 3; d++) level_fill_boundary(&umac[d], pmask, pd, pd + 3);
+  for (int d = 0; d < 3; d++) { vo_create_umac_grown(&umac[3 + d], &umac[d], d); level_fill_boundary(&umac[3 + d], pmask, pd + 6, pd + 9); }
+  for (int d = 0; d < 3; d++) vo_ml_edge_restriction(&umac[d], &umac[3 + d], d);
+  /* MAC projection */
+  vo_ml_macproject(NL, ump, soldp, mrp, dx, bc, pmask, pd, prm, &st[0]);
+  /* scalar advance */
+  {
+    int is_cons[VO_MAXCOMP]; is_cons[0] = 1; for (int c = 1; c < nscal; c++) is_cons[c] = 0;
+    for (int n = 0; n < NL; n++) {
+      fab_new_l(&scal_force[n], &S[n].uold, 1, -1, nscal, 0.0); sfp2[n] = &scal_force[n];
+      fab_new_l(&divu[n], &S[n].uold, 1, -1, 1, 0.0);
+      for (int d = 0; d < 3; d++) { fab_new_l(&sflux[3 * n + d], &S[n].uold, 0, d, nscal, 0.0); fab_new_l(&sedge[3 * n + d], &S[n].uold, 0, d, nscal, 0.0); sfp[3 * n + d] = &sflux[3 * n + d]; sep[3 * n + d] = &sedge[3 * n + d]; }
+      vo_mkscalforce(&scal_force[n], &S[n].ext_scal_force, NULL, 1.0, prm);
+    }
+    vo_ml_restrict_and_fill(NL, sfp2, 0, bc[0].extrap_comp, nscal, 1, bc, pmask, pd, prm);
+    for (int n = 0; n < NL; n++) {
+      vo_mkflux(&S[n].sold, sep + 3 * n, sfp + 3 * n, ump + 3 * n, &scal_force[n], &divu[n], dx + 3 * n, dt, 0, is_cons, dm, &bc[n], prm);
+      vo_mkscalforce(&scal_force[n], &S[n].ext_scal_force, NULL, 0.0, prm);
+    }
+    vo_ml_restrict_and_fill(NL, sfp2, 0, bc[0].extrap_comp, nscal, 1, bc, pmask, pd, prm);
+    for (int n = 0; n < NL; n++) vo_update(&S[n].sold, ump + 3 * n, sep + 3 * n, sfp + 3 * n, &scal_force[n], &S[n].snew, dx + 3 * n, dt, 0, is_cons);
+    vo_ml_restrict_and_fill(NL, snewp, 0, dm, nscal, 0, bc, pmask, pd, prm);
+    for (int n = 0; n < NL; n++) { free(scal_force[n].p); free(divu[n].p); for (int d = 0; d < 3; d++) { free(sflux[3 * n + d].p); free(sedge[3 * n + d].p); } }
+  }
+  for (int n = 0; n < NL; n++) vo_make_at_halftime(&rhohalf[n], 0, &S[n].sold, &S[n].snew, 0);
+  vo_ml_restrict_and_fill(NL, rhp, 0, dm + 0, 1, 0, bc, pmask, pd, prm);
+  /* velocity advance */
+  {
+    int is_cons[3] = { 0, 0, 0 };
+    for (int n = 0; n < NL; n++) {
+      for (int d = 0; d < 3; d++) { fab_new_l(&uflux[3 * n + d], &S[n].uold, 0, d, dm, 0.0); fab_new_l(&uedge[3 * n + d], &S[n].uold, 0, d, dm, 0.0); ufp[3 * n + d] = &uflux[3 * n + d]; uep[3 * n + d] = &uedge[3 * n + d]; }
+      vo_mkvelforce(&vel_force[n], &S[n].ext_vel_force, &S[n].gp, &S[n].sold, NULL, 1.0, prm);
+    }
+    vo_ml_restrict_and_fill(NL, vfp, 0, bc[0].extrap_comp, dm, 1, bc, pmask, pd, prm);
+    for (int n = 0; n < NL; n++) {
+      vo_mkflux(&S[n].uold, uep + 3 * n, ufp + 3 * n, ump + 3 * n, &vel_force[n], &mac_rhs[n], dx + 3 * n, dt, 1, is_cons, 0, &bc[n], prm);
+      vo_mkvelforce(&vel_force[n], &S[n].ext_vel_force, &S[n].gp, &rhohalf[n], NULL, 0.0, prm);
+    }
+    vo_ml_restrict_and_fill(NL, vfp, 0, bc[0].extrap_comp, dm, 1, bc, pmask, pd, prm);
+    for (int n = 0; n < NL; n++) vo_update(&S[n].uold, ump + 3 * n, uep + 3 * n, ufp + 3 * n, &vel_force[n], &S[n].unew, dx + 3 * n, dt, 1, is_cons);
+    vo_ml_restrict_and_fill(NL, unewp, 0, 0, dm, 0, bc, pmask, pd, prm);
+    for (int n = 0; n < NL; n++) for (int d = 0; d < 3; d++) { free(uflux[3 * n + d].p); free(uedge[3 * n + d].p); }
+  }
+  vo_ml_hgproject(proj_type, unewp, uoldp, rhp, pp, gpp, dx, dt, bc, pmask, pd, prm, &st[1]);
+  for (int n = 0; n < NL; n++) { free(mac_rhs[n].p); free(rhohalf[n].p); free(vel_force[n].p); for (int d = 0; d < 3; d++) free(umac[3 * n + d].p); }
+}

@@ -372,3 +372,43 @@ def test_2d_mac_projection_is_divergence_free(oracle):
     u, v = um[0].a[1:-1, 1:-1, 0, 0], um[1].a[1:-1, 1:-1, 0, 0]
     div = (u[1:, :] - u[:-1, :]) * n + (v[:, 1:] - v[:, :-1]) * n
     assert np.abs(div).max() <= 1e-8 * max(np.abs(u).max(), 1.0) * n
+
+
+# ---- two-level AMR (BASELINE.json configs[3]) ---------------------------------------------------------------------------------
+def test_amr_transfer_operators(oracle):
+    """restriction of a constant / linear field is exact; limited linear ghost interpolation reproduces a linear field; the
+    composite MAC projection leaves a discretely divergence-free field on fine cells, uncovered and covered coarse cells"""
+    import ctypes as C
+    vo = oracle
+    L = vo.lib()
+    nc = 8
+    clo, chi, flo, fhi = (0, 0, 0), (nc - 1,) * 3, (4, 4, 4), (11, 11, 11)
+    c, f = vo.Fab(clo, chi, 3, 1), vo.Fab(flo, fhi, 3, 1)
+    xi = np.arange(-3, nc + 3) + 0.5
+    X, Y, Z = np.meshgrid(xi, xi, xi, indexing="ij")
+    c.a[..., 0] = 1.0 + 0.5 * X - 0.25 * Y + 2.0 * Z                       # linear in coarse cell-centre coordinates
+    L.vo_fill_ghost_cells(f.ref, c.ref, 0, 1)
+    fi = (np.arange(flo[0] - 3, fhi[0] + 4) + 0.5) / 2.0
+    Xf, Yf, Zf = np.meshgrid(fi, fi, fi, indexing="ij")
+    exact = 1.0 + 0.5 * Xf - 0.25 * Yf + 2.0 * Zf
+    ghost = np.ones(f.a.shape[:3], bool); ghost[3:-3, 3:-3, 3:-3] = False
+    assert np.abs(f.a[..., 0] - exact)[ghost].max() < 1e-12
+    f.a[..., 0] = exact
+    c.a[...] = 0.0
+    L.vo_ml_cc_restriction(c.ref, f.ref, 0, 1)
+    got = c.a[3 + 2:3 + 6, 3 + 2:3 + 6, 3 + 2:3 + 6, 0]
+    want = (1.0 + 0.5 * X - 0.25 * Y + 2.0 * Z)[3 + 2:3 + 6, 3 + 2:3 + 6, 3 + 2:3 + 6]
+    assert np.abs(got - want).max() < 1e-13
+
+
+def test_amr_two_level_bubble(oracle):
+    vo = oracle
+    S = vo.Sim2L(16, (8, 8, 8), (23, 23, 23), [[15, 15]] * 3)
+    for _ in range(2):
+        S.step()
+        assert S.mgstat[0].cycles < 40 and S.mgstat[1].cycles < 40
+    s1 = S.snew[1].valid()[..., 0]
+    assert np.abs(s1 - s1[::-1]).max() < 1e-10 and np.abs(s1 - s1[:, ::-1]).max() < 1e-10
+    s0 = S.snew[0].valid()[4:12, 4:12, 4:12, 0]
+    assert np.abs(s0 - s1.reshape(8, 2, 8, 2, 8, 2).mean(axis=(1, 3, 5))).max() < 1e-13
+    assert S.unew[1].valid()[..., 2].min() < 0.0          # the heavy bubble sinks

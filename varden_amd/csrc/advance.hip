@@ -20,6 +20,12 @@ static void check_single_level(const vdn_layout *mla) {
   REQUIRE(mla && mla->nlev == 1, "this round implements single-level hierarchies only (nlevel = %d)", mla ? mla->nlev : -1);
 }
 
+// ml_restrict_and_fill: one level = fill_boundary + physbc; two levels = average down + coarse-fine ghost interpolation too
+static void restrict_and_fill(int nlev, vdn_multifab **mf, int icomp, int bcomp, int nc, bool same_boundary, const vdn_bc_tower *bct) {
+  if (nlev == 1) mf_restrict_and_fill(mf[0], icomp, bcomp, nc, same_boundary, bct);
+  else ml_restrict_and_fill(nlev, mf, icomp, bcomp, nc, same_boundary, bct);
+}
+
 extern "C" int vdn_advance_timestep(int istep, vdn_layout *mla, vdn_multifab **sold, vdn_multifab **uold,
                                     vdn_multifab **snew, vdn_multifab **unew, vdn_multifab **gp, vdn_multifab **p,
                                     vdn_multifab **ext_vel_force, vdn_multifab **ext_scal_force,
@@ -28,48 +34,56 @@ extern "C" int vdn_advance_timestep(int istep, vdn_layout *mla, vdn_multifab **s
   VDN_TRY
   (void)istep; (void)time;
   REQUIRE(ctx().inited, "vdn_init has not been called");
-  check_single_level(mla);
+  REQUIRE(mla && mla->nlev >= 1 && mla->nlev <= 2, "advance_timestep: one or two levels are implemented (nlevel = %d)", mla ? mla->nlev : -1);
   const vdn_params &P = ctx().prm;
-  const int dm = P.dm, nscal = P.nscal, n = 0;
+  const int dm = P.dm, nscal = P.nscal, nlevs = mla->nlev;
+  const bool viscous = P.visc_coef > 0.0, diffusive = P.diff_coef > 0.0;
+  REQUIRE(nlevs == 1 || (dm == 3 && !viscous && !diffusive), "advance_timestep: two-level hierarchies are implemented for dm = 3, inviscid (this round)");
   REQUIRE(press_comp == dm + nscal + 1, "press_comp must be dm+nscal+1 (got %d)", press_comp);
-  REQUIRE(uold[n]->ng >= 3 && sold[n]->ng >= 3 && unew[n]->ng >= 3 && snew[n]->ng >= 3, "state needs ng_cell = 3");
-  REQUIRE(gp[n]->ng >= 1 && p[n]->ng >= 1 && ext_vel_force[n]->ng >= 1 && ext_scal_force[n]->ng >= 1, "gp/p/ext forces need ng = 1");
-  REQUIRE(sold[n]->nc == nscal && nscal <= 3, "sold must have nscal (<= 3) components");
+  for (int n = 0; n < nlevs; n++) {
+    REQUIRE(uold[n]->ng >= 3 && sold[n]->ng >= 3 && unew[n]->ng >= 3 && snew[n]->ng >= 3, "state needs ng_cell = 3");
+    REQUIRE(gp[n]->ng >= 1 && p[n]->ng >= 1 && ext_vel_force[n]->ng >= 1 && ext_scal_force[n]->ng >= 1, "gp/p/ext forces need ng = 1");
+    REQUIRE(sold[n]->nc == nscal && nscal <= 3, "sold must have nscal (<= 3) components");
+  }
   arena_reset();
   arena_reserve_for(mla);
   const double t_begin = wall();
+  #define DXL(n) (dx + (n) * dm)
 
-  // advance_timestep.f90:65-80
-  vdn_multifab *mac_rhs = mf_temp(mla, n, 1, 1, -1, true, 0.0);
-  vdn_multifab *rhohalf = mf_temp(mla, n, dm, 1, -1, true, 0.0);
-  vdn_multifab *umac[3] = { nullptr, nullptr, nullptr };
-  for (int d = 0; d < dm; d++) umac[d] = mf_temp(mla, n, 1, 1, d, true, 1.e20);
-  // lapu (advance_timestep.f90:85-93); NULL stands for the all-zero field when visc_coef == 0
-  const bool viscous = P.visc_coef > 0.0, diffusive = P.diff_coef > 0.0;
-  vdn_multifab *lapu = nullptr;
-  if (viscous) {
-    lapu = mf_temp(mla, n, dm, 0, -1, true, 0.0);
-    for (int c = 0; c < dm; c++) k_explicit_diffusive_term(lapu, uold[n], c, c, dx, bct);
+  // advance_timestep.f90:65-80; umac is [lev*3 + d]
+  vdn_multifab *mac_rhs[2], *rhohalf[2], *umac[6] = { nullptr, nullptr, nullptr, nullptr, nullptr, nullptr }, *lapu[2] = { nullptr, nullptr };
+  for (int n = 0; n < nlevs; n++) {
+    mac_rhs[n] = mf_temp(mla, n, 1, 1, -1, true, 0.0);
+    rhohalf[n] = mf_temp(mla, n, dm, 1, -1, true, 0.0);
+    for (int d = 0; d < dm; d++) umac[3 * n + d] = mf_temp(mla, n, 1, 1, d, true, 1.e20);
+    // lapu (advance_timestep.f90:85-93); NULL stands for the all-zero field when visc_coef == 0
+    if (viscous) {
+      lapu[n] = mf_temp(mla, n, dm, 0, -1, true, 0.0);
+      for (int c = 0; c < dm; c++) k_explicit_diffusive_term(lapu[n], uold[n], c, c, DXL(n), bct);
+    }
   }
 
   // advance_premac.f90:44-51
   {
     size_t mark = arena_mark();
-    vdn_multifab *vel_force = mf_temp(mla, n, dm, 1, -1, false, 0.0);
-    k_mkvelforce(vel_force, ext_vel_force[n], sold[n], gp[n], lapu, 1.0);
-    mf_restrict_and_fill(vel_force, 0, bct->extrap_comp0(), dm, true, bct);            // mkforce.f90:75-76
-    k_velpred(uold[n], umac, vel_force, dx, dt, bct);
-    for (int d = 0; d < dm; d++) mf_fill_boundary(umac[d]);                             // velpred.f90:108-112
-    mf_temp_free(vel_force);
+    vdn_multifab *vel_force[2];
+    for (int n = 0; n < nlevs; n++) {
+      vel_force[n] = mf_temp(mla, n, dm, 1, -1, false, 0.0);
+      k_mkvelforce(vel_force[n], ext_vel_force[n], sold[n], gp[n], lapu[n], 1.0);
+    }
+    restrict_and_fill(nlevs, vel_force, 0, bct->extrap_comp0(), dm, true, bct);         // mkforce.f90:75-76
+    for (int n = 0; n < nlevs; n++) k_velpred(uold[n], umac + 3 * n, vel_force[n], DXL(n), dt, bct);
+    // velpred.f90:102-122: ghost faces (coarse: same-level images; fine: from the coarse level, then same-level), edge restriction
+    for (int d = 0; d < dm; d++) mf_fill_boundary(umac[d]);
+    for (int n = 1; n < nlevs; n++) for (int d = 0; d < dm; d++) { ml_create_umac_grown(umac[3 * n + d], umac[3 * (n - 1) + d], d); mf_fill_boundary(umac[3 * n + d]); }
+    for (int n = nlevs - 1; n >= 1; n--) for (int d = 0; d < dm; d++) ml_edge_restriction(umac[3 * (n - 1) + d], umac[3 * n + d], d);
+    for (int n = nlevs - 1; n >= 0; n--) mf_temp_free(vel_force[n]);
     arena_release(mark);
   }
 
   // MAC projection (advance_timestep.f90:97-104)
   sync(); double t0 = wall();
-  {
-    vdn_multifab *mr[1] = { mac_rhs };
-    do_macproject(mla, umac, sold, mr, dx, bct, press_comp - 1);
-  }
+  do_macproject(mla, umac, sold, mac_rhs, dx, bct, press_comp - 1);
   sync(); ctx().step_sec[2] = wall() - t0;
 
   // scalar_advance.f90:54-118
@@ -77,74 +91,71 @@ extern "C" int vdn_advance_timestep(int istep, vdn_layout *mla, vdn_multifab **s
   {
     size_t mark = arena_mark();
     int is_cons[VDN_MAXCOMP]; is_cons[0] = 1; for (int c = 1; c < nscal; c++) is_cons[c] = 0;
-    vdn_multifab *scal_force = mf_temp(mla, n, nscal, 1, -1, false, 0.0);
-    vdn_multifab *divu = mf_temp(mla, n, 1, 1, -1, true, 0.0);
-    vdn_multifab *sflux[3] = { nullptr, nullptr, nullptr }, *sedge[3] = { nullptr, nullptr, nullptr };
-    for (int d = 0; d < dm; d++) { sflux[d] = mf_temp(mla, n, nscal, 0, d, true, 0.0); sedge[d] = mf_temp(mla, n, nscal, 0, d, true, 0.0); }
-    vdn_multifab *laps = nullptr;                                                      // scalar_advance.f90:80-89
-    if (diffusive) {
-      laps = mf_temp(mla, n, nscal, 0, -1, true, 0.0);
-      for (int c = 1; c < nscal; c++) k_explicit_diffusive_term(laps, sold[n], c, dm + c, dx, bct);
+    vdn_multifab *scal_force[2], *divu[2], *sflux[6], *sedge[6], *laps[2] = { nullptr, nullptr };
+    for (int n = 0; n < nlevs; n++) {
+      scal_force[n] = mf_temp(mla, n, nscal, 1, -1, false, 0.0);
+      divu[n] = mf_temp(mla, n, 1, 1, -1, true, 0.0);
+      for (int d = 0; d < dm; d++) { sflux[3 * n + d] = mf_temp(mla, n, nscal, 0, d, true, 0.0); sedge[3 * n + d] = mf_temp(mla, n, nscal, 0, d, true, 0.0); }
+      if (diffusive) {                                                                  // scalar_advance.f90:80-89
+        laps[n] = mf_temp(mla, n, nscal, 0, -1, true, 0.0);
+        for (int c = 1; c < nscal; c++) k_explicit_diffusive_term(laps[n], sold[n], c, dm + c, DXL(n), bct);
+      }
+      k_mkscalforce(scal_force[n], ext_scal_force[n], laps[n], 1.0);
     }
-    k_mkscalforce(scal_force, ext_scal_force[n], laps, 1.0);
-    mf_restrict_and_fill(scal_force, 0, bct->extrap_comp0(), nscal, true, bct);        // mkforce.f90:283-284
-    k_mkflux(sold[n], sedge, sflux, umac, scal_force, divu, dx, dt, bct, false, is_cons);
-    k_mkscalforce(scal_force, ext_scal_force[n], laps, 0.0);
-    mf_restrict_and_fill(scal_force, 0, bct->extrap_comp0(), nscal, true, bct);
-    k_update(sold[n], umac, sedge, sflux, scal_force, snew[n], dx, dt, false, is_cons);
-    mf_restrict_and_fill(snew[n], 0, dm, nscal, false, bct);                            // update.f90:106
+    restrict_and_fill(nlevs, scal_force, 0, bct->extrap_comp0(), nscal, true, bct);     // mkforce.f90:283-284
+    for (int n = 0; n < nlevs; n++) {
+      k_mkflux(sold[n], sedge + 3 * n, sflux + 3 * n, umac + 3 * n, scal_force[n], divu[n], DXL(n), dt, bct, false, is_cons);
+      k_mkscalforce(scal_force[n], ext_scal_force[n], laps[n], 0.0);
+    }
+    restrict_and_fill(nlevs, scal_force, 0, bct->extrap_comp0(), nscal, true, bct);
+    for (int n = 0; n < nlevs; n++) k_update(sold[n], umac + 3 * n, sedge + 3 * n, sflux + 3 * n, scal_force[n], snew[n], DXL(n), dt, false, is_cons);
+    restrict_and_fill(nlevs, snew, 0, dm, nscal, false, bct);                           // update.f90:106
     if (diffusive) {                                                                    // scalar_advance.f90:144-162
       const double visc_mu = (P.diffusion_type == 1) ? 0.5 * dt * P.diff_coef : dt * P.diff_coef;
-      for (int c = 1; c < nscal; c++) do_diff_scalar_solve(mla, snew[n], laps, dx, visc_mu, bct, c, dm + c);
-      mf_temp_free(laps);
+      for (int c = 1; c < nscal; c++) do_diff_scalar_solve(mla, snew[0], laps[0], dx, visc_mu, bct, c, dm + c);
     }
-    for (int d = 0; d < dm; d++) { mf_temp_free(sflux[d]); mf_temp_free(sedge[d]); }
-    mf_temp_free(divu); mf_temp_free(scal_force);
     arena_release(mark);
   }
   sync(); ctx().step_sec[0] = wall() - t0;
 
   // make_at_halftime (advance_timestep.f90:114, make_at_halftime.f90:64-65)
-  k_make_at_halftime(rhohalf, sold[n], snew[n], 0, 0);
-  mf_restrict_and_fill(rhohalf, 0, dm + 0, 1, false, bct);
-  if (viscous && P.diffusion_type == 2) mf_setval(lapu, 0.0, 0, dm, true);             // advance_timestep.f90:116-120
+  for (int n = 0; n < nlevs; n++) k_make_at_halftime(rhohalf[n], sold[n], snew[n], 0, 0);
+  restrict_and_fill(nlevs, rhohalf, 0, dm + 0, 1, false, bct);
+  if (viscous && P.diffusion_type == 2) mf_setval(lapu[0], 0.0, 0, dm, true);          // advance_timestep.f90:116-120
 
   // velocity_advance.f90:48-93
   t0 = wall();
   {
     size_t mark = arena_mark();
     int is_cons[3] = { 0, 0, 0 };
-    vdn_multifab *vel_force = mf_temp(mla, n, dm, 1, -1, false, 0.0);
-    vdn_multifab *uflux[3] = { nullptr, nullptr, nullptr }, *uedge[3] = { nullptr, nullptr, nullptr };
-    for (int d = 0; d < dm; d++) { uflux[d] = mf_temp(mla, n, dm, 0, d, true, 0.0); uedge[d] = mf_temp(mla, n, dm, 0, d, true, 0.0); }
-    k_mkvelforce(vel_force, ext_vel_force[n], sold[n], gp[n], lapu, 1.0);
-    mf_restrict_and_fill(vel_force, 0, bct->extrap_comp0(), dm, true, bct);
-    k_mkflux(uold[n], uedge, uflux, umac, vel_force, mac_rhs, dx, dt, bct, true, is_cons);
-    k_mkvelforce(vel_force, ext_vel_force[n], rhohalf, gp[n], lapu, 0.0);
-    mf_restrict_and_fill(vel_force, 0, bct->extrap_comp0(), dm, true, bct);
-    k_update(uold[n], umac, uedge, uflux, vel_force, unew[n], dx, dt, true, is_cons);
-    mf_restrict_and_fill(unew[n], 0, 0, dm, false, bct);                                // update.f90:104
+    vdn_multifab *vel_force[2], *uflux[6], *uedge[6];
+    for (int n = 0; n < nlevs; n++) {
+      vel_force[n] = mf_temp(mla, n, dm, 1, -1, false, 0.0);
+      for (int d = 0; d < dm; d++) { uflux[3 * n + d] = mf_temp(mla, n, dm, 0, d, true, 0.0); uedge[3 * n + d] = mf_temp(mla, n, dm, 0, d, true, 0.0); }
+      k_mkvelforce(vel_force[n], ext_vel_force[n], sold[n], gp[n], lapu[n], 1.0);
+    }
+    restrict_and_fill(nlevs, vel_force, 0, bct->extrap_comp0(), dm, true, bct);
+    for (int n = 0; n < nlevs; n++) {
+      k_mkflux(uold[n], uedge + 3 * n, uflux + 3 * n, umac + 3 * n, vel_force[n], mac_rhs[n], DXL(n), dt, bct, true, is_cons);
+      k_mkvelforce(vel_force[n], ext_vel_force[n], rhohalf[n], gp[n], lapu[n], 0.0);
+    }
+    restrict_and_fill(nlevs, vel_force, 0, bct->extrap_comp0(), dm, true, bct);
+    for (int n = 0; n < nlevs; n++) k_update(uold[n], umac + 3 * n, uedge + 3 * n, uflux + 3 * n, vel_force[n], unew[n], DXL(n), dt, true, is_cons);
+    restrict_and_fill(nlevs, unew, 0, 0, dm, false, bct);                               // update.f90:104
     if (viscous) {                                                                      // velocity_advance.f90:103-118
       const double visc_mu = (P.diffusion_type == 1) ? 0.5 * dt * P.visc_coef : dt * P.visc_coef;
-      do_visc_solve(mla, unew[n], lapu, rhohalf, mac_rhs, dx, visc_mu, bct);
+      do_visc_solve(mla, unew[0], lapu[0], rhohalf[0], mac_rhs[0], dx, visc_mu, bct);
     }
-    for (int d = 0; d < dm; d++) { mf_temp_free(uflux[d]); mf_temp_free(uedge[d]); }
-    mf_temp_free(vel_force);
     arena_release(mark);
   }
   sync(); ctx().step_sec[1] = wall() - t0;
 
   // hgproject (advance_timestep.f90:129-137)
   t0 = wall();
-  {
-    vdn_multifab *rh[1] = { rhohalf };
-    do_hgproject(proj_type, mla, unew, uold, rh, p, gp, dx, dt, bct, press_comp - 1);
-  }
+  do_hgproject(proj_type, mla, unew, uold, rhohalf, p, gp, dx, dt, bct, press_comp - 1);
   sync(); ctx().step_sec[3] = wall() - t0;
+  #undef DXL
 
-  for (int d = 0; d < dm; d++) mf_temp_free(umac[d]);
-  if (lapu) mf_temp_free(lapu);
-  mf_temp_free(rhohalf); mf_temp_free(mac_rhs);
   arena_reset();
   ctx().step_sec[4] = wall() - t_begin;
   if (P.verbose >= 1 && ctx().rank == 0) {                                              // advance_timestep.f90:159-166

@@ -911,7 +911,7 @@ void do_hgproject(int proj_type, vdn_layout *mla, vdn_multifab **unew, vdn_multi
 }
 
 // =====================================================================================================================
-// two-level composite nodal solve (oracle/vo_hgproject.c: vo_ml_nd_solve) and the multilevel hgproject
+// composite nodal solve on two levels (the algorithm stated with vo_ml_nd_solve in the CPU restatement) and the multilevel hgproject
 // =====================================================================================================================
 // Works directly on the multifab fabs (nodal, one ghost layer).  This round: one fine box (the coarse level may be any
 // decomposition the single-level multigrid accepts), single rank.
