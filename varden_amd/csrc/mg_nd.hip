@@ -1034,10 +1034,14 @@ struct MLND {
   vdn_multifab *phi[2], *b[2], *res[2], *sig[2];     // sig[0]: MASKED coarse sigma
   NdfArgs A[2]; Range3 rn[2]; double *d_nrm;
 };
-static double ml_nd_residual(MLND &S, bool zero_phi_unused) {
-  (void)zero_phi_unused;
+// fine_only: just the fine-level residual (what the fine relaxation needs), no norm
+static double ml_nd_residual(MLND &S, bool fine_only) {
   hipStream_t st = ctx().stream;
   hipLaunchKernelGGL(kk_ndf_prolong, grid_for(S.rn[1]), NBLK, 0, st, S.phi[1]->fabs[0], S.phi[0]->fabs[0], S.A[1], 0, S.rn[1]);
+  if (fine_only) {
+    hipLaunchKernelGGL(kk_ndf_residual, reduce_grid(S.rn[1]), NBLK, 0, st, S.b[1]->fabs[0], S.phi[1]->fabs[0], S.sig[1]->fabs[0], S.res[1]->fabs[0], S.A[1], 1, S.rn[1], (double *)nullptr);
+    return 0.0;
+  }
   HIPCHK(hipMemsetAsync(S.d_nrm, 0, sizeof(double), st));
   hipLaunchKernelGGL(kk_ndf_residual, reduce_grid(S.rn[1]), NBLK, 0, st, S.b[1]->fabs[0], S.phi[1]->fabs[0], S.sig[1]->fabs[0], S.res[1]->fabs[0], S.A[1], 1, S.rn[1], S.d_nrm);
   hipLaunchKernelGGL(kk_ndf_residual, reduce_grid(S.rn[0]), NBLK, 0, st, S.b[0]->fabs[0], S.phi[0]->fabs[0], S.sig[0]->fabs[0], S.res[0]->fabs[0], S.A[0], 0, S.rn[0], (double *)nullptr);
@@ -1091,7 +1095,7 @@ static int ml_nd_solve(vdn_layout *la, vdn_multifab **rh, vdn_multifab **phi, vd
   // norm of the composite right-hand side = composite residual of phi = 0
   vdn_multifab *keep[2] = { S.phi[0], S.phi[1] }, *zero[2] = { mf_temp(la, 0, 1, 1, 3, true, 0.0), mf_temp(la, 1, 1, 1, 3, true, 0.0) };
   S.phi[0] = zero[0]; S.phi[1] = zero[1];
-  const double bnorm = ml_nd_residual(S, true);
+  const double bnorm = ml_nd_residual(S, false);
   S.phi[0] = keep[0]; S.phi[1] = keep[1];
   vdn_multifab *er = zero[0], *ee = mf_temp(la, 0, 1, 1, 3, true, 0.0);      // scratch of the coarse correction solve
   vdn_multifab *ef = zero[1], *ef2 = mf_temp(la, 1, 1, 1, 3, true, 0.0);     // fine Jacobi ping-pong
@@ -1111,7 +1115,7 @@ static int ml_nd_solve(vdn_layout *la, vdn_multifab **rh, vdn_multifab **phi, vd
     hipLaunchKernelGGL(kk_ndf_add, grid_for(S.rn[0]), NBLK, 0, st, S.phi[0]->fabs[0], ee->fabs[0], S.rn[0]);
     hipLaunchKernelGGL(kk_ndf_prolong, grid_for(S.rn[1]), NBLK, 0, st, S.phi[1]->fabs[0], ee->fabs[0], S.A[1], 1, S.rn[1]);
     // fine relaxation of K_f e = r_f with the interface fixed
-    (void)ml_nd_residual(S, false);
+    (void)ml_nd_residual(S, true);
     mf_setval(ef, 0.0, 0, 1, true);
     vdn_multifab *a = ef, *b2 = ef2;
     for (int s = 0; s < P.hg_nu1 + P.hg_nu2; s++) {

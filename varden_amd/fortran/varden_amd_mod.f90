@@ -63,7 +63,8 @@ module varden_amd
   public :: multifab_build, multifab_build_edge, multifab_build_nodal, multifab_destroy, nfabs, get_box, dataptr, &
             setval, multifab_copy_c, norm_inf, multifab_fill_boundary, multifab_physbc, &
             multifab_copy_to_host, multifab_copy_from_host, multifab_fab_size
-  public :: advance_timestep, estdt, hgproject
+  public :: advance_timestep, estdt, hgproject, macproject
+  public :: ml_cc_restriction, ml_edge_restriction, multifab_fill_ghost_cells, create_umac_grown, ml_restrict_and_fill
 
   interface
      subroutine vdn_params_default(p) bind(C, name="vdn_params_default")
@@ -197,6 +198,39 @@ module varden_amd
        type(c_ptr), intent(in) :: unew(*), uold(*), rhohalf(*), p(*), gp(*)
        real(c_double), intent(in) :: dx(*)
        real(c_double), value :: dt
+     end function
+     integer(c_int) function vdn_macproject(mla, umac, rho, mac_rhs, dx, bct, bc_comp) bind(C, name="vdn_macproject")
+       import :: c_int, c_ptr, c_double
+       type(c_ptr), value :: mla, bct
+       type(c_ptr), intent(in) :: umac(*), rho(*), mac_rhs(*)
+       real(c_double), intent(in) :: dx(*)
+       integer(c_int), value :: bc_comp
+     end function
+     integer(c_int) function vdn_ml_cc_restriction(crse, fine, icomp, nc) bind(C, name="vdn_ml_cc_restriction")
+       import :: c_int, c_ptr
+       type(c_ptr), value :: crse, fine
+       integer(c_int), value :: icomp, nc
+     end function
+     integer(c_int) function vdn_ml_edge_restriction(crse, fine, dir) bind(C, name="vdn_ml_edge_restriction")
+       import :: c_int, c_ptr
+       type(c_ptr), value :: crse, fine
+       integer(c_int), value :: dir
+     end function
+     integer(c_int) function vdn_multifab_fill_ghost_cells(fine, crse, icomp, nc) bind(C, name="vdn_multifab_fill_ghost_cells")
+       import :: c_int, c_ptr
+       type(c_ptr), value :: fine, crse
+       integer(c_int), value :: icomp, nc
+     end function
+     integer(c_int) function vdn_create_umac_grown(fine, crse, dir) bind(C, name="vdn_create_umac_grown")
+       import :: c_int, c_ptr
+       type(c_ptr), value :: fine, crse
+       integer(c_int), value :: dir
+     end function
+     integer(c_int) function vdn_ml_restrict_and_fill(nlev, mf, icomp, bcomp, nc, same_boundary, bct) bind(C, name="vdn_ml_restrict_and_fill")
+       import :: c_int, c_ptr
+       integer(c_int), value :: nlev, icomp, bcomp, nc, same_boundary
+       type(c_ptr), intent(in) :: mf(*)
+       type(c_ptr), value :: bct
      end function
      integer(c_size_t) function c_strlen(s) bind(C, name="strlen")
        import :: c_ptr, c_size_t
@@ -454,6 +488,60 @@ contains
     call chk(vdn_hgproject(int(proj_type, c_int), mla%h, handles(unew), handles(uold), handles(rhohalf), handles(p), &
                            handles(gp), dxc, dt, the_bc_tower%h, int(press_comp, c_int)), 'hgproject')
   end subroutine hgproject
+
+  ! macproject(mla, umac, rho, dx, the_bc_tower, bc_comp, mac_rhs)  (src/macproject.f90:20); umac(n,d)
+  subroutine macproject(mla, umac, rho, dx, the_bc_tower, bc_comp, mac_rhs)
+    type(ml_layout), intent(in   ) :: mla
+    type(multifab) , intent(inout) :: umac(:,:)
+    type(multifab) , intent(in   ) :: rho(:), mac_rhs(:)
+    real(dp_t)     , intent(in   ) :: dx(:,:)
+    type(bc_tower) , intent(in   ) :: the_bc_tower
+    integer        , intent(in   ) :: bc_comp
+    real(c_double) :: dxc(3 * size(dx, 1))
+    type(c_ptr) :: um(3 * size(umac, 1))
+    integer :: n, d
+    do n = 1, size(dx, 1)
+       do d = 1, 3
+          dxc((n - 1) * 3 + d) = dx(n, d)
+          um((n - 1) * 3 + d) = umac(n, d)%h
+       end do
+    end do
+    call chk(vdn_macproject(mla%h, um, handles(rho), handles(mac_rhs), dxc, the_bc_tower%h, int(bc_comp, c_int)), 'macproject')
+  end subroutine macproject
+
+  ! FBoxLib names; components 1-based as in the reference, rr is accepted for signature compatibility (ratio 2 only)
+  subroutine ml_cc_restriction(crse, fine, rr)
+    type(multifab), intent(inout) :: crse
+    type(multifab), intent(in   ) :: fine
+    integer       , intent(in   ) :: rr(:)
+    call chk(vdn_ml_cc_restriction(crse%h, fine%h, 0_c_int, int(crse%nc, c_int)), 'ml_cc_restriction')
+  end subroutine ml_cc_restriction
+  subroutine ml_edge_restriction(crse, fine, rr, dir)
+    type(multifab), intent(inout) :: crse
+    type(multifab), intent(in   ) :: fine
+    integer       , intent(in   ) :: rr(:), dir
+    call chk(vdn_ml_edge_restriction(crse%h, fine%h, int(dir - 1, c_int)), 'ml_edge_restriction')
+  end subroutine ml_edge_restriction
+  subroutine multifab_fill_ghost_cells(fine, crse, icomp, nc)
+    type(multifab), intent(inout) :: fine
+    type(multifab), intent(in   ) :: crse
+    integer       , intent(in   ) :: icomp, nc
+    call chk(vdn_multifab_fill_ghost_cells(fine%h, crse%h, int(icomp - 1, c_int), int(nc, c_int)), 'multifab_fill_ghost_cells')
+  end subroutine multifab_fill_ghost_cells
+  subroutine create_umac_grown(fine, crse, dir)
+    type(multifab), intent(inout) :: fine
+    type(multifab), intent(in   ) :: crse
+    integer       , intent(in   ) :: dir
+    call chk(vdn_create_umac_grown(fine%h, crse%h, int(dir - 1, c_int)), 'create_umac_grown')
+  end subroutine create_umac_grown
+  subroutine ml_restrict_and_fill(nlevs, mf, the_bc_tower, icomp, bcomp, nc, same_boundary)
+    integer       , intent(in   ) :: nlevs, icomp, bcomp, nc
+    type(multifab), intent(inout) :: mf(:)
+    type(bc_tower), intent(in   ) :: the_bc_tower
+    logical       , intent(in   ) :: same_boundary
+    call chk(vdn_ml_restrict_and_fill(int(nlevs, c_int), handles(mf), int(icomp - 1, c_int), int(bcomp - 1, c_int), int(nc, c_int), &
+                                      merge(1_c_int, 0_c_int, same_boundary), the_bc_tower%h), 'ml_restrict_and_fill')
+  end subroutine ml_restrict_and_fill
 
   function handles(mfs) result(h)
     type(multifab), intent(in) :: mfs(:)
