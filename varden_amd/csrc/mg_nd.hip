@@ -265,16 +265,29 @@ __global__ void kk_nd_restrict(NLev F, NLev C) {
   }
   C.b[nidx(C, i, j, k)] = s * 0.125;
 }
+// trilinear interpolation of the coarse field at fine node offsets (oi,oj,ok) of coarse node (I,J,K): the eight coarse values are
+// loaded in one unconditional batch and added under predicates in the order (c,b,a) ascending of the oracle's loops
+DEVI double nd_interp8(const NLev &C, const double *__restrict__ cp, int I, int J, int K, int oi, int oj, int ok) {
+  const long c0 = nidx(C, I, J, K), sy = C.PX, sz = (long)C.PX * C.PY;
+  const double v000 = cp[c0], v100 = cp[c0 + 1], v010 = cp[c0 + sy], v110 = cp[c0 + sy + 1];
+  const double v001 = cp[c0 + sz], v101 = cp[c0 + sz + 1], v011 = cp[c0 + sz + sy], v111 = cp[c0 + sz + sy + 1];
+  double s = 0.0;
+  s = s + v000;
+  s = oi ? s + v100 : s;
+  s = oj ? s + v010 : s;
+  s = (oi && oj) ? s + v110 : s;
+  s = ok ? s + v001 : s;
+  s = (ok && oi) ? s + v101 : s;
+  s = (ok && oj) ? s + v011 : s;
+  s = (ok && oi && oj) ? s + v111 : s;
+  return s * (1.0 / (double)((1 + oi) * (1 + oj) * (1 + ok)));
+}
 __global__ void kk_nd_prolong(NLev F, NLev C) {
   NODE_IJK(F)
   if (!in_range) return;
   if (nd_is_dir(F, i, j, k)) return;
-  const int I = i >> 1, J = j >> 1, K = k >> 1, oi = i & 1, oj = j & 1, ok = k & 1;
-  double s = 0.0;
-  for (int c = 0; c <= ok; c++) for (int b = 0; b <= oj; b++) for (int a = 0; a <= oi; a++) s = s + C.phi[nidx(C, I + a, J + b, K + c)];
-  const double scale = 1.0 / (double)((1 + oi) * (1 + oj) * (1 + ok));
   const long f = nidx(F, i, j, k);
-  F.phi[f] = F.phi[f] + s * scale;
+  F.phi[f] = F.phi[f] + nd_interp8(C, C.phi, i >> 1, j >> 1, k >> 1, i & 1, j & 1, k & 1);
 }
 __global__ void kk_nd_coarsen_sigma(NLev F, NLev C) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -424,13 +437,9 @@ __global__ void kk_nd_prolong_tail(NLev F, NLev T, int c00, int c01, int c02, in
   if (!in_range) return;
   if (nd_is_dir(F, i, j, k)) return;
   // global fine node = f0 + (i,j,k); the box origin is even, so parity and halving are local
-  const int I = c00 + (i >> 1), J = c01 + (j >> 1), K = c02 + (k >> 1), oi = i & 1, oj = j & 1, ok = k & 1;
   (void)f00; (void)f01; (void)f02;
-  double s = 0.0;
-  for (int c = 0; c <= ok; c++) for (int b = 0; b <= oj; b++) for (int a = 0; a <= oi; a++) s = s + T.phi[nidx(T, I + a, J + b, K + c)];
-  const double scale = 1.0 / (double)((1 + oi) * (1 + oj) * (1 + ok));
   const long f = nidx(F, i, j, k);
-  F.phi[f] = F.phi[f] + s * scale;
+  F.phi[f] = F.phi[f] + nd_interp8(T, T.phi, c00 + (i >> 1), c01 + (j >> 1), c02 + (k >> 1), i & 1, j & 1, k & 1);
 }
 
 // ---- host ---------------------------------------------------------------------------------------------------
