@@ -12,6 +12,15 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run by the driver with -m gpu)")
 
 
+def pytest_sessionstart(session):
+    """the shared libraries are build products (git-ignored): build them when a fresh checkout has none"""
+    lib = os.path.join(ROOT, "varden_amd", "csrc", "libvarden_amd.so")
+    olib = os.path.join(ROOT, "oracle", "libvoracle.so")
+    if not (os.path.exists(lib) and os.path.exists(olib)):
+        import __graft_entry__ as g
+        g.build()
+
+
 @pytest.fixture(scope="session")
 def oracle():
     from oracle import voracle
