@@ -145,7 +145,7 @@ def main():
 
     # ---- CPU baseline: the oracle (a port of the same algorithm, OpenMP) on a bounded sample ------
     cpu = None
-    if rank == 0 and not args.no_cpu:
+    if rank == 0 and world == 1 and not args.no_cpu:      # reported at N = 1 only
         nthreads = min(16, os.cpu_count() or 1)
         os.environ["OMP_NUM_THREADS"] = str(nthreads)
         from oracle import voracle as vo
