@@ -168,12 +168,13 @@ def test_ml_macproject(gpu, oracle, split):
     K.close()
 
 
-def test_ml_hgproject(gpu, oracle):
-    """hgproject on two levels: composite nodal solve (interface nodes slaved to the coarse level, Galerkin equations at the coarse
+@pytest.mark.parametrize("split", [1, 2])
+def test_ml_hgproject(gpu, oracle, split):
+    """hgproject on two levels (split = 2: the fine level cut into two boxes on the GPU, one box in the oracle): composite nodal solve (interface nodes slaved to the coarse level, Galerkin equations at the coarse
     nodes of the interface), then gradient / velocity / pressure updates and ml_restrict_and_fill(unew)"""
     from varden_amd import advance as adv
     vo = oracle
-    K = Amr2(16, (8, 8, 8), (23, 23, 23))
+    K = Amr2(16, (8, 8, 8), (23, 23, 23), split=split)
     L = vo.lib()
     unew, uold, rhoh, gp, p = K.ofabs(3, 3), K.ofabs(3, 3), K.ofabs(1, 1), K.ofabs(1, 3), K.ofabs(1, 1, (1, 1, 1))
     for lev in range(2):
@@ -201,7 +202,8 @@ def test_ml_hgproject(gpu, oracle):
     K.close()
 
 
-def test_two_level_advance(gpu, oracle):
+@pytest.mark.parametrize("split", [1, 2])
+def test_two_level_advance(gpu, oracle, split):
     """BASELINE.json configs[3] in miniature: bubble on a 16^3 base grid with the centre refined (fixed grids), three steps of
     advance_timestep on both levels, HIP vs oracle.  Tolerance 1e-8 relative (two FAC solves per step at 1e-10 / 1e-11)."""
     from varden_amd import advance as adv
@@ -209,19 +211,23 @@ def test_two_level_advance(gpu, oracle):
     vo = oracle
     flo, fhi = (8, 8, 8), (23, 23, 23)
     O = vo.Sim2L(16, flo, fhi, WALLS)
-    G = driver.VardenAMR(16, [(flo, fhi)], WALLS)
+    fboxes = [(flo, fhi)] if split == 1 else [((8, 8, 8), (15, 23, 23)), ((16, 8, 8), (23, 23, 23))]
+    G = driver.VardenAMR(16, fboxes, WALLS)
     assert G.dt == O.dt
     for _ in range(3):
         O.step(); G.step()
         assert abs(G.dt - O.dt) <= 1e-12 * O.dt
         assert adv.last_solver_stats("mac")[0] == O.mgstat[0].cycles and adv.last_solver_stats("hg")[0] == O.mgstat[1].cycles
+    def level_valid(mfl, n):
+        a = np.concatenate([mfl[n].to_numpy(i)[3:-3, 3:-3, 3:-3] for i in range(mfl[n].nfabs())], axis=0)
+        return a
     for n in range(2):
-        for nm, gm, om in (("u", G.unew[n], O.unew[n]), ("s", G.snew[n], O.snew[n])):
-            a, b = gm.to_numpy()[3:-3, 3:-3, 3:-3], om.valid()
+        for nm, gm, om in (("u", G.unew, O.unew[n]), ("s", G.snew, O.snew[n])):
+            a, b = level_valid(gm, n), om.valid()
             scale = max(np.abs(b).max(), 1e-300)
             assert np.abs(a - b).max() <= 1e-8 * scale, "level %d %s differs by %.3e (scale %.3e)" % (n, nm, np.abs(a - b).max(), scale)
     # the refined bubble stays mirror-symmetric and the coarse level under the fine box is its average
-    s1 = G.snew[1].to_numpy()[3:-3, 3:-3, 3:-3, 0]
+    s1 = level_valid(G.snew, 1)[..., 0]
     assert np.abs(s1 - s1[::-1]).max() <= 1e-9
     s0 = G.snew[0].to_numpy()[3:-3, 3:-3, 3:-3, 0][4:12, 4:12, 4:12]
     avg = s1.reshape(8, 2, 8, 2, 8, 2).mean(axis=(1, 3, 5))

@@ -1038,69 +1038,140 @@ __global__ void kk_ndf_neg(FV out, FV in, NdfArgs A, Range3 r) {       // b = -r
 }
 __global__ void kk_ndf_add(FV a, FV b, Range3 r) { THREAD_IJK(r) if (!in_range) return; fv_at(a, i, j, k) = fv_get(a, i, j, k) + fv_get(b, i, j, k); }
 
+__global__ void kk_ndf_absmax_mask(FV a, FV mask, Range3 r, double *nrm) {
+  REDUCE_IJ(r)
+  double m = 0.0;
+  if (in_ij) REDUCE_KLOOP(r) if (fv_get(mask, i, j, k) == 0.0) m = fmax(m, fabs(fv_get(a, i, j, k)));
+  block_atomic_max(nrm, m);
+}
+__global__ void kk_ndf_mul3(FV out, FV u, FV mask, Range3 r) {          // out(1:3) = u(1:3) * mask
+  THREAD_IJK(r)
+  if (!in_range) return;
+  const double m = fv_get(mask, i, j, k);
+  #pragma unroll
+  for (int c = 0; c < 3; c++) fv_at(out, i, j, k, c) = (m != 0.0) ? fv_get(u, i, j, k, c) : 0.0;
+}
+__global__ void kk_ndf_zero3(FV a, Range3 r) { THREAD_IJK(r) if (!in_range) return; fv_at(a, i, j, k, 0) = 0.0; fv_at(a, i, j, k, 1) = 0.0; fv_at(a, i, j, k, 2) = 0.0; }
+// res_c += full weighting of the fine residual of ONE fine box (ghost nodes included: filled from the neighbouring fine boxes,
+// zero outside the fine level).  A coarse node whose centre fine node sits on a face shared by two fine boxes is taken by the
+// box that has it on its LOW face (own_hi[d] = 0 on shared high faces).
+__global__ void kk_ndf_restrict_add2(FV res_c, FV res_f, NdfArgs Af, NdfArgs Ac, int own0, int own1, int own2, Range3 r) {
+  THREAD_IJK(r)
+  if (!in_range || ndf_pdir(Ac, i, j, k)) return;
+  if ((2 * i == Af.hi[0] && !own0) || (2 * j == Af.hi[1] && !own1) || (2 * k == Af.hi[2] && !own2)) return;
+  const double wt[3] = { 0.5, 1.0, 0.5 };
+  double s = 0.0;
+  for (int c = -1; c <= 1; c++) for (int b = -1; b <= 1; b++) for (int a = -1; a <= 1; a++) {
+    const int ii = 2 * i + a, jj = 2 * j + b, kk = 2 * k + c;
+    if (ii < Af.lo[0] - 1 || ii > Af.hi[0] + 1 || jj < Af.lo[1] - 1 || jj > Af.hi[1] + 1 || kk < Af.lo[2] - 1 || kk > Af.hi[2] + 1) continue;
+    s = s + (wt[a + 1] * wt[b + 1] * wt[c + 1]) * fv_get(res_f, ii, jj, kk);
+  }
+  fv_at(res_c, i, j, k) = fv_get(res_c, i, j, k) + s * 0.125;
+}
+
 static double ndf_read(double *d) { double h; HIPCHK(hipMemcpyAsync(&h, d, sizeof(double), hipMemcpyDeviceToHost, ctx().stream)); HIPCHK(hipStreamSynchronize(ctx().stream)); return h; }
 struct MLND {
   vdn_multifab *phi[2], *b[2], *res[2], *sig[2];     // sig[0]: MASKED coarse sigma
-  NdfArgs A[2]; Range3 rn[2]; double *d_nrm;
+  vdn_multifab *cin;                                 // coarse nodes strictly inside a fine box (excluded from the norm)
+  NdfArgs Ac; Range3 rc;                             // the coarse box
+  std::vector<NdfArgs> Af; std::vector<Range3> rf;   // fine boxes
+  std::vector<int> own_hi;                           // [box*3 + d]: the box owns the nodes of its high d-face
+  bool multi; double *d_nrm;
 };
 // fine_only: just the fine-level residual (what the fine relaxation needs), no norm
 static double ml_nd_residual(MLND &S, bool fine_only) {
   hipStream_t st = ctx().stream;
-  hipLaunchKernelGGL(kk_ndf_prolong, grid_for(S.rn[1]), NBLK, 0, st, S.phi[1]->fabs[0], S.phi[0]->fabs[0], S.A[1], 0, S.rn[1]);
-  if (fine_only) {
-    hipLaunchKernelGGL(kk_ndf_residual, reduce_grid(S.rn[1]), NBLK, 0, st, S.b[1]->fabs[0], S.phi[1]->fabs[0], S.sig[1]->fabs[0], S.res[1]->fabs[0], S.A[1], 1, S.rn[1], (double *)nullptr);
-    return 0.0;
+  const int nf = (int)S.Af.size();
+  for (int f = 0; f < nf; f++) hipLaunchKernelGGL(kk_ndf_prolong, grid_for(S.rf[f]), NBLK, 0, st, S.phi[1]->fabs[f], S.phi[0]->fabs[0], S.Af[f], 0, S.rf[f]);
+  if (S.multi) mf_fill_boundary(S.phi[1]);
+  if (!fine_only) HIPCHK(hipMemsetAsync(S.d_nrm, 0, sizeof(double), st));
+  for (int f = 0; f < nf; f++)
+    hipLaunchKernelGGL(kk_ndf_residual, reduce_grid(S.rf[f]), NBLK, 0, st, S.b[1]->fabs[f], S.phi[1]->fabs[f], S.sig[1]->fabs[f], S.res[1]->fabs[f], S.Af[f], 1, S.rf[f],
+                       fine_only ? (double *)nullptr : S.d_nrm);
+  if (fine_only) return 0.0;
+  if (S.multi) mf_fill_boundary(S.res[1]);
+  hipLaunchKernelGGL(kk_ndf_residual, reduce_grid(S.rc), NBLK, 0, st, S.b[0]->fabs[0], S.phi[0]->fabs[0], S.sig[0]->fabs[0], S.res[0]->fabs[0], S.Ac, 0, S.rc, (double *)nullptr);
+  for (int f = 0; f < nf; f++) {
+    Range3 ri; for (int d = 0; d < 3; d++) { ri.lo[d] = S.Af[f].lo[d] / 2; ri.hi[d] = S.Af[f].hi[d] / 2; }
+    hipLaunchKernelGGL(kk_ndf_restrict_add2, grid_for(ri), NBLK, 0, st, S.res[0]->fabs[0], S.res[1]->fabs[f], S.Af[f], S.Ac,
+                       S.own_hi[3 * f], S.own_hi[3 * f + 1], S.own_hi[3 * f + 2], ri);
   }
-  HIPCHK(hipMemsetAsync(S.d_nrm, 0, sizeof(double), st));
-  hipLaunchKernelGGL(kk_ndf_residual, reduce_grid(S.rn[1]), NBLK, 0, st, S.b[1]->fabs[0], S.phi[1]->fabs[0], S.sig[1]->fabs[0], S.res[1]->fabs[0], S.A[1], 1, S.rn[1], S.d_nrm);
-  hipLaunchKernelGGL(kk_ndf_residual, reduce_grid(S.rn[0]), NBLK, 0, st, S.b[0]->fabs[0], S.phi[0]->fabs[0], S.sig[0]->fabs[0], S.res[0]->fabs[0], S.A[0], 0, S.rn[0], (double *)nullptr);
-  Range3 ri; for (int d = 0; d < 3; d++) { ri.lo[d] = S.A[0].ilo[d]; ri.hi[d] = S.A[0].ihi[d]; }
-  hipLaunchKernelGGL(kk_ndf_restrict_add, grid_for(ri), NBLK, 0, st, S.res[0]->fabs[0], S.res[1]->fabs[0], S.A[1], S.A[0], ri);
-  hipLaunchKernelGGL(kk_ndf_absmax, reduce_grid(S.rn[0]), NBLK, 0, st, S.res[0]->fabs[0], S.A[0], 2, S.rn[0], S.d_nrm);
+  hipLaunchKernelGGL(kk_ndf_absmax_mask, reduce_grid(S.rc), NBLK, 0, st, S.res[0]->fabs[0], S.cin->fabs[0], S.rc, S.d_nrm);
   return ndf_read(S.d_nrm);
 }
 // rh, phi: nodal ng 1 per level; coeffs: cells ng 1 (ghost 0 outside the level); u: cells (>= 1 ghost); dx: [lev*3+d]
 static int ml_nd_solve(vdn_layout *la, vdn_multifab **rh, vdn_multifab **phi, vdn_multifab **coeffs, vdn_multifab **u, const double *dx,
                        const vdn_bc_tower *bct, int press_comp0, double rel_eps, double abs_eps, int max_iter, int *iters, double *res0, double *res) {
   REQUIRE(la->nlev == 2 && ctx().nranks == 1, "composite nodal solve: two levels, single rank");
-  REQUIRE(phi[0]->nfabs() == 1 && phi[1]->nfabs() == 1, "composite nodal solve: one box per level in this round");
+  REQUIRE(phi[0]->nfabs() == 1, "composite nodal solve: the coarse level must be one box in this round");
   REQUIRE(!(la->pmask[0] || la->pmask[1] || la->pmask[2]), "composite nodal solve: periodic domains are not implemented");
   hipStream_t st = ctx().stream;
   const size_t mark = arena_mark();
   const vdn_params &P = ctx().prm;
   MLND S; S.d_nrm = (double *)arena_alloc(256);
-  const vdn_box &cb = phi[0]->vbox[0], &fb = phi[1]->vbox[0];
-  for (int n = 0; n < 2; n++) {
-    const vdn_box &bx = n ? fb : cb;
-    NdfArgs &A = S.A[n];
-    for (int d = 0; d < 3; d++) {
-      A.f[d] = 1.0 / (36.0 * (dx[3 * n + d] * dx[3 * n + d]));
-      A.lo[d] = bx.lo[d]; A.hi[d] = bx.hi[d] + 1;
-      const int e0 = bct->ell_bc(n, 1, d, 0, press_comp0), e1 = bct->ell_bc(n, 1, d, 1, press_comp0);
-      A.dirlo[d] = e0 == VDN_BC_DIR; A.dirhi[d] = e1 == VDN_BC_DIR;
-      A.cflo[d] = (n == 1) && e0 == VDN_BC_INT; A.cfhi[d] = (n == 1) && e1 == VDN_BC_INT;
-      A.ilo[d] = fb.lo[d] / 2; A.ihi[d] = fb.hi[d] / 2 + 1;
-      S.rn[n].lo[d] = A.lo[d]; S.rn[n].hi[d] = A.hi[d];
-    }
-    S.phi[n] = phi[n];
-    S.b[n] = mf_temp(la, n, 1, 1, 3, true, 0.0); S.res[n] = mf_temp(la, n, 1, 1, 3, true, 0.0);
+  const int nf = phi[1]->nfabs();
+  S.multi = nf > 1;
+  const vdn_box &cb = phi[0]->vbox[0];
+  for (int d = 0; d < 3; d++) {
+    S.Ac.f[d] = 1.0 / (36.0 * (dx[d] * dx[d]));
+    S.Ac.lo[d] = cb.lo[d]; S.Ac.hi[d] = cb.hi[d] + 1;
+    S.Ac.dirlo[d] = bct->ell_bc(0, 1, d, 0, press_comp0) == VDN_BC_DIR; S.Ac.dirhi[d] = bct->ell_bc(0, 1, d, 1, press_comp0) == VDN_BC_DIR;
+    S.Ac.cflo[d] = S.Ac.cfhi[d] = 0; S.Ac.ilo[d] = S.Ac.ihi[d] = 0;
+    S.rc.lo[d] = S.Ac.lo[d]; S.rc.hi[d] = S.Ac.hi[d];
   }
-  // masked coarse sigma and the masked velocities
+  // fine boxes: a face that is not a domain face is either shared as a whole with ONE neighbouring fine box or coarse-fine
+  S.Af.resize(nf); S.rf.resize(nf); S.own_hi.assign(3 * nf, 1);
+  for (int f = 0; f < nf; f++) {
+    const vdn_box &bx = phi[1]->vbox[f];
+    NdfArgs &A = S.Af[f];
+    for (int d = 0; d < 3; d++) {
+      A.f[d] = 1.0 / (36.0 * (dx[3 + d] * dx[3 + d]));
+      A.lo[d] = bx.lo[d]; A.hi[d] = bx.hi[d] + 1; A.ilo[d] = A.ihi[d] = 0;
+      S.rf[f].lo[d] = A.lo[d]; S.rf[f].hi[d] = A.hi[d];
+      for (int sd = 0; sd < 2; sd++) {
+        const int e = bct->ell_bc(1, f + 1, d, sd, press_comp0);
+        bool shared = false;
+        for (int g = 0; g < nf && e == VDN_BC_INT; g++) {
+          if (g == f) continue;
+          const vdn_box &ob = phi[1]->vbox[g];
+          const bool touch = sd ? (ob.lo[d] == bx.hi[d] + 1) : (ob.hi[d] + 1 == bx.lo[d]);
+          if (!touch) continue;
+          bool same = true, overlap = true;
+          for (int t = 0; t < 3; t++) if (t != d) { if (ob.lo[t] != bx.lo[t] || ob.hi[t] != bx.hi[t]) same = false; if (ob.hi[t] < bx.lo[t] || ob.lo[t] > bx.hi[t]) overlap = false; }
+          if (!overlap) continue;
+          REQUIRE(same, "composite nodal solve: neighbouring fine boxes must share whole faces (box %d / %d)", f, g);
+          shared = true;
+        }
+        (sd ? A.dirhi[d] : A.dirlo[d]) = (e == VDN_BC_DIR);
+        (sd ? A.cfhi[d] : A.cflo[d]) = (e == VDN_BC_INT && !shared);
+        if (sd == 1 && shared) S.own_hi[3 * f + d] = 0;
+      }
+    }
+  }
+  for (int n = 0; n < 2; n++) { S.phi[n] = phi[n]; S.b[n] = mf_temp(la, n, 1, 1, 3, true, 0.0); S.res[n] = mf_temp(la, n, 1, 1, 3, true, 0.0); }
+  // masked coarse sigma, the coarse-node mask of the norm, the masked velocities
   S.sig[1] = coeffs[1];
   S.sig[0] = mf_temp(la, 0, 1, 1, -1, true, 0.0);
   mf_copy(S.sig[0], 0, coeffs[0], 0, 1, 1);
-  Range3 rcov; for (int d = 0; d < 3; d++) { rcov.lo[d] = fb.lo[d] / 2; rcov.hi[d] = fb.hi[d] / 2; }
-  hipLaunchKernelGGL(kk_ndf_setbox, grid_for(rcov), NBLK, 0, st, S.sig[0]->fabs[0], rcov, 0.0);
-  for (int n = 0; n < 2; n++) {
-    const vdn_box &bx = n ? fb : cb;
-    vdn_multifab *um = mf_temp(la, n, 3, 1, -1, false, 0.0);
-    Range3 rg; for (int d = 0; d < 3; d++) { rg.lo[d] = bx.lo[d] - 1; rg.hi[d] = bx.hi[d] + 1; }
-    if (n == 1) hipLaunchKernelGGL(kk_ndf_mask_u, grid_for(rg), NBLK, 0, st, um->fabs[0], u[1]->fabs[0], rg, fb.lo[0], fb.lo[1], fb.lo[2], fb.hi[0], fb.hi[1], fb.hi[2], 0);
-    else        hipLaunchKernelGGL(kk_ndf_mask_u, grid_for(rg), NBLK, 0, st, um->fabs[0], u[0]->fabs[0], rg, rcov.lo[0], rcov.lo[1], rcov.lo[2], rcov.hi[0], rcov.hi[1], rcov.hi[2], 1);
-    hipLaunchKernelGGL(kk_nd_divu, grid_for(S.rn[n]), NBLK, 0, st, um->fabs[0], rh[n]->fabs[0], 0.25 / dx[3 * n], 0.25 / dx[3 * n + 1], 0.25 / dx[3 * n + 2], S.rn[n]);
-    hipLaunchKernelGGL(kk_ndf_neg, grid_for(S.rn[n]), NBLK, 0, st, S.b[n]->fabs[0], rh[n]->fabs[0], S.A[n], S.rn[n]);
-    mf_temp_free(um);
+  S.cin = mf_temp(la, 0, 1, 1, 3, true, 0.0);
+  vdn_multifab *umc = mf_temp(la, 0, 3, 1, -1, false, 0.0), *umf = mf_temp(la, 1, 3, 1, -1, false, 0.0), *fmask = mf_temp(la, 1, 1, 1, -1, true, 0.0);
+  mf_copy(umc, 0, u[0], 0, 3, 1);
+  mf_setval(fmask, 1.0, 0, 1, false);
+  mf_fill_boundary(fmask);
+  for (int f = 0; f < nf; f++) {
+    const vdn_box &fb = phi[1]->vbox[f];
+    Range3 rcov, rin, rg; bool has_in = true;
+    for (int d = 0; d < 3; d++) { rcov.lo[d] = fb.lo[d] / 2; rcov.hi[d] = fb.hi[d] / 2; rin.lo[d] = rcov.lo[d] + 1; rin.hi[d] = rcov.hi[d]; if (rin.lo[d] > rin.hi[d]) has_in = false;
+      rg.lo[d] = fb.lo[d] - 1; rg.hi[d] = fb.hi[d] + 1; }
+    hipLaunchKernelGGL(kk_ndf_setbox, grid_for(rcov), NBLK, 0, st, S.sig[0]->fabs[0], rcov, 0.0);
+    hipLaunchKernelGGL(kk_ndf_zero3, grid_for(rcov), NBLK, 0, st, umc->fabs[0], rcov);
+    if (has_in) hipLaunchKernelGGL(kk_ndf_setbox, grid_for(rin), NBLK, 0, st, S.cin->fabs[0], rin, 1.0);
+    hipLaunchKernelGGL(kk_ndf_mul3, grid_for(rg), NBLK, 0, st, umf->fabs[f], u[1]->fabs[f], fmask->fabs[f], rg);
+    hipLaunchKernelGGL(kk_nd_divu, grid_for(S.rf[f]), NBLK, 0, st, umf->fabs[f], rh[1]->fabs[f], 0.25 / dx[3], 0.25 / dx[4], 0.25 / dx[5], S.rf[f]);
+    hipLaunchKernelGGL(kk_ndf_neg, grid_for(S.rf[f]), NBLK, 0, st, S.b[1]->fabs[f], rh[1]->fabs[f], S.Af[f], S.rf[f]);
   }
+  hipLaunchKernelGGL(kk_nd_divu, grid_for(S.rc), NBLK, 0, st, umc->fabs[0], rh[0]->fabs[0], 0.25 / dx[0], 0.25 / dx[1], 0.25 / dx[2], S.rc);
+  hipLaunchKernelGGL(kk_ndf_neg, grid_for(S.rc), NBLK, 0, st, S.b[0]->fabs[0], rh[0]->fabs[0], S.Ac, S.rc);
   // norm of the composite right-hand side = composite residual of phi = 0
   vdn_multifab *keep[2] = { S.phi[0], S.phi[1] }, *zero[2] = { mf_temp(la, 0, 1, 1, 3, true, 0.0), mf_temp(la, 1, 1, 1, 3, true, 0.0) };
   S.phi[0] = zero[0]; S.phi[1] = zero[1];
@@ -1117,24 +1188,27 @@ static int ml_nd_solve(vdn_layout *la, vdn_multifab **rh, vdn_multifab **phi, vd
     if (it >= max_iter) break;
     // coarse correction K_c e = r_c: one V-cycle of the single-level solver (which takes rh with b = -rh)
     mf_setval(ee, 0.0, 0, 1, true); mf_setval(er, 0.0, 0, 1, true);
-    { NdfArgs Z = S.A[0]; for (int d = 0; d < 3; d++) { Z.dirlo[d] = Z.dirhi[d] = 0; }
-      hipLaunchKernelGGL(kk_ndf_neg, grid_for(S.rn[0]), NBLK, 0, st, er->fabs[0], S.res[0]->fabs[0], Z, S.rn[0]); }
+    { NdfArgs Z = S.Ac; for (int d = 0; d < 3; d++) { Z.dirlo[d] = Z.dirhi[d] = 0; }
+      hipLaunchKernelGGL(kk_ndf_neg, grid_for(S.rc), NBLK, 0, st, er->fabs[0], S.res[0]->fabs[0], Z, S.rc); }
     int cyc; double r0, rr;
     nd_solve(er, ee, coeffs[0], nullptr, dx, ebc0, 0.0, -1.0, 1, &cyc, &r0, &rr);
-    hipLaunchKernelGGL(kk_ndf_add, grid_for(S.rn[0]), NBLK, 0, st, S.phi[0]->fabs[0], ee->fabs[0], S.rn[0]);
-    hipLaunchKernelGGL(kk_ndf_prolong, grid_for(S.rn[1]), NBLK, 0, st, S.phi[1]->fabs[0], ee->fabs[0], S.A[1], 1, S.rn[1]);
+    hipLaunchKernelGGL(kk_ndf_add, grid_for(S.rc), NBLK, 0, st, S.phi[0]->fabs[0], ee->fabs[0], S.rc);
+    for (int f = 0; f < nf; f++) hipLaunchKernelGGL(kk_ndf_prolong, grid_for(S.rf[f]), NBLK, 0, st, S.phi[1]->fabs[f], ee->fabs[0], S.Af[f], 1, S.rf[f]);
     // fine relaxation of K_f e = r_f with the interface fixed
     (void)ml_nd_residual(S, true);
     mf_setval(ef, 0.0, 0, 1, true);
     vdn_multifab *a = ef, *b2 = ef2;
     for (int s = 0; s < P.hg_nu1 + P.hg_nu2; s++) {
-      hipLaunchKernelGGL(kk_ndf_jacobi, grid_for(S.rn[1]), NBLK, 0, st, a->fabs[0], b2->fabs[0], S.res[1]->fabs[0], S.sig[1]->fabs[0], S.A[1], P.hg_omega, S.rn[1]);
+      if (S.multi && s > 0) mf_fill_boundary(a);
+      for (int f = 0; f < nf; f++)
+        hipLaunchKernelGGL(kk_ndf_jacobi, grid_for(S.rf[f]), NBLK, 0, st, a->fabs[f], b2->fabs[f], S.res[1]->fabs[f], S.sig[1]->fabs[f], S.Af[f], P.hg_omega, S.rf[f]);
       std::swap(a, b2);
     }
-    hipLaunchKernelGGL(kk_ndf_add, grid_for(S.rn[1]), NBLK, 0, st, S.phi[1]->fabs[0], a->fabs[0], S.rn[1]);
+    for (int f = 0; f < nf; f++) hipLaunchKernelGGL(kk_ndf_add, grid_for(S.rf[f]), NBLK, 0, st, S.phi[1]->fabs[f], a->fabs[f], S.rf[f]);
     it++;
   }
-  hipLaunchKernelGGL(kk_ndf_prolong, grid_for(S.rn[1]), NBLK, 0, st, S.phi[1]->fabs[0], S.phi[0]->fabs[0], S.A[1], 0, S.rn[1]);
+  for (int f = 0; f < nf; f++) hipLaunchKernelGGL(kk_ndf_prolong, grid_for(S.rf[f]), NBLK, 0, st, S.phi[1]->fabs[f], S.phi[0]->fabs[0], S.Af[f], 0, S.rf[f]);
+  if (S.multi) mf_fill_boundary(S.phi[1]);
   if (iters) *iters = it; if (res0) *res0 = bnorm; if (res) *res = rn;
   HIPCHK(hipStreamSynchronize(st));
   arena_release(mark);
