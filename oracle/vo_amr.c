@@ -15,8 +15,8 @@
  *                         interpolation normal to the interface (8/15, 2/3, -1/5) of the transversely (central-slope)
  *                         interpolated coarse value and two fine cells; the coarse flux through an interface face is the
  *                         mean of the four fine fluxes.  Algorithm: FAC iteration -- composite residual, one V-cycle of
- *                         the single-level multigrid on the whole coarse level, piecewise-constant prolongation, red-black
- *                         relaxation of the fine level with a homogeneous interface.
+ *                         nu1 red-black sweeps on the fine level (homogeneous interface), one V-cycle of the single-level
+ *                         multigrid on the whole coarse level, piecewise-constant prolongation, nu2 fine sweeps.
  * This round: ONE box per level, two levels, refinement ratio 2, the fine box properly nested (>= 1 coarse cell away from
  * any domain face it does not touch).
  */
@@ -256,15 +256,20 @@ int vo_ml_cc_solve(int nlev, vo_fab **rh, vo_fab **phi, vo_fab **beta, const dou
       if (n == 1 || !covered(rh[1], i, j, k)) bnorm = fmax(bnorm, fabs(VF(rh[n], i, j, k, 0)));
   int it = 0, conv = 0; double rn = 0.0;
   if (bnorm == 0.0) conv = 1;
-  const int nu_f = prm->mg_nu1 + prm->mg_nu2;
   while (!conv) {
     rn = composite_residual(rh, phi, beta, dx, ellbc, pmask, pd, rp);
     if (rn <= rel_eps * bnorm) { conv = 1; break; }
     if (it >= max_iter) break;
+    /* pre-relaxation of the fine level (homogeneous interface), then the residual the coarse level will see */
+    memset(e[1].p, 0, sizeof(double) * vo_size(&e[1]));
+    vo_cc_smooth(&res[1], &e[1], beta + 3, dx + 3, ellbc[1], prm->mg_nu1);
+    for (int k = phi[1]->lo[2]; k <= phi[1]->hi[2]; k++) for (int j = phi[1]->lo[1]; j <= phi[1]->hi[1]; j++) for (int i = phi[1]->lo[0]; i <= phi[1]->hi[0]; i++)
+      VF(phi[1], i, j, k, 0) = VF(phi[1], i, j, k, 0) + VF(&e[1], i, j, k, 0);
+    (void)composite_residual(rh, phi, beta, dx, ellbc, pmask, pd, rp);
     /* coarse correction: ONE V-cycle of the single-level multigrid on the whole coarse level */
     memset(e[0].p, 0, sizeof(double) * vo_size(&e[0]));
     vo_mgstat cs;
-    vo_cc_solve_ab(&res[0], &e[0], NULL, beta, dx, ellbc[0], 0.0, -1.0, 1, prm->mg_nu1, prm->mg_nu2, prm->mg_nub, &cs);
+    vo_cc_solve_ab(&res[0], &e[0], NULL, beta, dx, ellbc[0], 0.0, -1.0, -1, prm->mg_nu1, prm->mg_nu2, prm->mg_nub, &cs);
     for (int k = phi[0]->lo[2]; k <= phi[0]->hi[2]; k++) for (int j = phi[0]->lo[1]; j <= phi[0]->hi[1]; j++) for (int i = phi[0]->lo[0]; i <= phi[0]->hi[0]; i++)
       VF(phi[0], i, j, k, 0) = VF(phi[0], i, j, k, 0) + VF(&e[0], i, j, k, 0);
     for (int k = phi[1]->lo[2]; k <= phi[1]->hi[2]; k++) for (int j = phi[1]->lo[1]; j <= phi[1]->hi[1]; j++) for (int i = phi[1]->lo[0]; i <= phi[1]->hi[0]; i++)
@@ -275,7 +280,7 @@ int vo_ml_cc_solve(int nlev, vo_fab **rh, vo_fab **phi, vo_fab **beta, const dou
     cf_interp(phi[1], phi[0], ellbc[1]);
     (void)plain_residual(rh[1], phi[1], beta + 3, dx + 3, &res[1]);
     memset(e[1].p, 0, sizeof(double) * vo_size(&e[1]));
-    vo_cc_smooth(&res[1], &e[1], beta + 3, dx + 3, ellbc[1], nu_f);
+    vo_cc_smooth(&res[1], &e[1], beta + 3, dx + 3, ellbc[1], prm->mg_nu2);
     for (int k = phi[1]->lo[2]; k <= phi[1]->hi[2]; k++) for (int j = phi[1]->lo[1]; j <= phi[1]->hi[1]; j++) for (int i = phi[1]->lo[0]; i <= phi[1]->hi[0]; i++)
       VF(phi[1], i, j, k, 0) = VF(phi[1], i, j, k, 0) + VF(&e[1], i, j, k, 0);
     it++;

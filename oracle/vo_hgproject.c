@@ -402,6 +402,20 @@ int vo_nd_solve(vo_fab *rh, vo_fab *phi, const vo_fab *coeffs, const vo_fab *u, 
   }
   int cyc = 0, conv = 0; double rn = 0.0;
   if (bnorm == 0.0) conv = 1;
+  if (max_iter < 0) {            /* exactly -max_iter V-cycles, no convergence test (coarse correction of the composite solve) */
+    for (int c = 0; c < -max_iter; c++) {
+      if (M.nlev == 1) { nd_jacobi(L0, M.per, nd_bottom_sweeps(L0, nub), omega); continue; }
+      nd_jacobi(L0, M.per, nu1, omega);
+      (void)nd_residual(L0, M.per);
+      nd_restrict(L0, &M.lev[1]);
+      nd_vcycle(&M, 1, nu1, nu2, nub, omega);
+      nd_fill_nodes(&M.lev[1], M.lev[1].phi, M.per);
+      nd_prolong_add(L0, &M.lev[1]);
+      nd_jacobi(L0, M.per, nu2, omega);
+      cyc++;
+    }
+    conv = 1;
+  }
   while (!conv) {
     nd_jacobi(L0, M.per, M.nlev == 1 ? nd_bottom_sweeps(L0, nub) : nu1, omega);
     rn = nd_residual(L0, M.per);
@@ -619,7 +633,7 @@ int vo_ml_nd_solve(vo_fab **rh, vo_fab **phi, vo_fab **coeffs, vo_fab **u, const
     for (int k = 0; k <= Cc->n[2]; k++) for (int j = 0; j <= Cc->n[1]; j++) for (int i = 0; i <= Cc->n[0]; i++)
       VF(&er, er.lo[0] + i, er.lo[1] + j, er.lo[2] + k, 0) = -Cc->res[NN(Cc, i, j, k)];
     vo_mgstat cs;
-    vo_nd_solve(&er, &ee, coeffs[0], NULL, dx, ellbc[0], pmask, 0.0, -1.0, 1, prm->hg_nu1, prm->hg_nu2, prm->hg_nub, prm->hg_omega, &cs);
+    vo_nd_solve(&er, &ee, coeffs[0], NULL, dx, ellbc[0], pmask, 0.0, -1.0, -1, prm->hg_nu1, prm->hg_nu2, prm->hg_nub, prm->hg_omega, &cs);
     for (int k = 0; k <= Cc->n[2]; k++) for (int j = 0; j <= Cc->n[1]; j++) for (int i = 0; i <= Cc->n[0]; i++)
       Cc->phi[NN(Cc, i, j, k)] = Cc->phi[NN(Cc, i, j, k)] + VF(&ee, ee.lo[0] + i, ee.lo[1] + j, ee.lo[2] + k, 0);
     for (int k = 0; k <= F->n[2]; k++) for (int j = 0; j <= F->n[1]; j++) for (int i = 0; i <= F->n[0]; i++) {

@@ -344,6 +344,21 @@ int vo_cc_solve_ab(const vo_fab *rh, vo_fab *phi, const vo_fab *alpha, vo_fab *b
   for (int k = rh->lo[2]; k <= rh->hi[2]; k++) for (int j = rh->lo[1]; j <= rh->hi[1]; j++) for (int i = rh->lo[0]; i <= rh->hi[0]; i++)
     bnorm = fmax(bnorm, fabs(VF(rh, i, j, k, 0)));
   int cyc = 0, conv = 0; double rn = 0.0, r0 = -1.0;
+  if (max_iter < 0) {            /* exactly -max_iter V-cycles, no convergence test (coarse correction of the composite solves) */
+    for (int c = 0; c < -max_iter; c++) {
+      if (M.nlev == 1) { cc_gsrb(L0, M.per, cc_bottom_sweeps(L0, nub)); continue; }
+      cc_gsrb(L0, M.per, nu1);
+      (void)cc_residual(L0, M.per);
+      cc_restrict(L0, &M.lev[1]);
+      cc_vcycle(&M, 1, nu1, nu2, nub);
+      cc_prolong_add(L0, &M.lev[1]);
+      cc_gsrb(L0, M.per, nu2);
+    }
+    cc_store(L0, phi, ellbc, M.per);
+    if (st) { st->cycles = -max_iter; st->res0 = bnorm; st->res = 0.0; }
+    ccmg_free(&M);
+    return 0;
+  }
   if (bnorm == 0.0) { conv = 1; r0 = 0.0; }
   while (!conv && cyc <= max_iter) {
     if (M.nlev == 1) cc_gsrb(L0, M.per, cc_bottom_sweeps(L0, nub)); else cc_gsrb(L0, M.per, nu1);

@@ -7,8 +7,8 @@
 //   fill_ghost_cells      fine ghost cell = coarse parent + MC-limited linear slopes   (macproject.f90:304-310, ml_restrict_and_fill)
 //   create_umac_grown     fine ghost face = coarse face (even index) / mean of the two coarse faces around it (odd)
 //   ml_cc_solve           composite solve by FAC iteration: composite residual (quadratic coarse-fine ghost cells, coarse flux
-//                         through an interface face = mean of the four fine fluxes), one V-cycle of the single-level multigrid
-//                         on the whole coarse level, piecewise-constant prolongation, red-black relaxation of the fine level
+//                         through an interface face = mean of the four fine fluxes), nu1 red-black sweeps on the fine level, one
+//                         V-cycle of the single-level multigrid on the whole coarse level, piecewise-constant prolongation, nu2 fine sweeps
 // This round: two levels, refinement ratio 2, every box on this rank (nranks = 1); any number of boxes per level for the
 // transfer operators, the fine level's boxes must be properly nested.
 #include "vdn_dev.h"
@@ -411,10 +411,15 @@ int ml_cc_solve(vdn_layout *la, vdn_multifab **rh, vdn_multifab **phi, vdn_multi
     rn = composite_residual(S);
     if (rn <= rel_eps * bnorm) { conv = true; break; }
     if (it >= max_iter) break;
+    // pre-relaxation of the fine level (homogeneous interface), then the residual the coarse level will see
+    mf_setval(S.e[1], 0.0, 0, 1, true);
+    fine_relax(S, P.mg_nu1);
+    for (int b = 0; b < phi[1]->nfabs(); b++) { Range3 r = valid_range(phi[1], b); hipLaunchKernelGGL(kk_add, grid_for(r), AB, 0, st, phi[1]->fabs[b], S.e[1]->fabs[b], r); }
+    (void)composite_residual(S);
     // coarse correction: ONE V-cycle of the single-level multigrid on the whole coarse level
     mf_setval(S.e[0], 0.0, 0, 1, true);
     int cyc; double r0, rr;
-    cc_solve(S.res[0], S.e[0], beta, dx, ebc0, 0.0, -1.0, 1, &cyc, &r0, &rr);
+    cc_solve(S.res[0], S.e[0], beta, dx, ebc0, 0.0, -1.0, -1, &cyc, &r0, &rr);
     for (int b = 0; b < phi[0]->nfabs(); b++) { Range3 r = valid_range(phi[0], b); hipLaunchKernelGGL(kk_add, grid_for(r), AB, 0, st, phi[0]->fabs[b], S.e[0]->fabs[b], r); }
     for (int f = 0; f < phi[1]->nfabs(); f++) for (int c = 0; c < phi[0]->nfabs(); c++) {
       Range3 r = valid_range(phi[1], f); const vdn_box &cb = phi[0]->vbox[c];
@@ -426,7 +431,7 @@ int ml_cc_solve(vdn_layout *la, vdn_multifab **rh, vdn_multifab **phi, vdn_multi
     cf_interp(phi[1], phi[0], bct, bc_comp0);
     level_residual(S, 1, false, false);
     mf_setval(S.e[1], 0.0, 0, 1, true);
-    fine_relax(S, P.mg_nu1 + P.mg_nu2);
+    fine_relax(S, P.mg_nu2);
     for (int b = 0; b < phi[1]->nfabs(); b++) { Range3 r = valid_range(phi[1], b); hipLaunchKernelGGL(kk_add, grid_for(r), AB, 0, st, phi[1]->fabs[b], S.e[1]->fabs[b], r); }
     it++;
   }

@@ -738,9 +738,24 @@ int cc_solve(vdn_multifab *rh, vdn_multifab *phi, vdn_multifab **beta, const dou
   size_t mark = arena_mark();
   CCMG M; cc_setup(M, rh, phi, alpha, beta, dx, bc);
   CDLev &D0 = M.dlev[0];
+  const bool single = (M.dlev.size() == 1 && M.tail.empty());
+  if (max_iter < 0) {            // exactly -max_iter V-cycles, no norms, no convergence test (the coarse correction of the composite solves)
+    for (int c = 0; c < -max_iter; c++) {
+      if (single) { const int N = std::max(D0.ng[0], std::max(D0.ng[1], D0.ng[2])); cc_gsrb_d(M, D0, std::max(P.mg_nub, N * N)); continue; }
+      cc_gsrb_d(M, D0, P.mg_nu1);
+      cc_residual_d(M, D0, false);
+      cc_restrict_down(M, 0);
+      if (M.dlev.size() > 1) cc_vcycle_d(M, 1); else cc_vcycle_t(M, 0);
+      cc_prolong_up(M, 0);
+      cc_gsrb_d(M, D0, P.mg_nu2);
+    }
+    cc_store(M, phi, bc);
+    if (cycles) *cycles = -max_iter; if (res0) *res0 = 0.0; if (res) *res = 0.0;
+    arena_release(mark);
+    return 0;
+  }
   const double bnorm = mf_norm_inf(rh, 0, 1);
   int cyc = 0; bool conv = (bnorm == 0.0); double rn = 0.0;
-  const bool single = (M.dlev.size() == 1 && M.tail.empty());
   while (!conv) {
     if (single) { const int N = std::max(D0.ng[0], std::max(D0.ng[1], D0.ng[2])); cc_gsrb_d(M, D0, std::max(P.mg_nub, N * N)); }
     else cc_gsrb_d(M, D0, P.mg_nu1);

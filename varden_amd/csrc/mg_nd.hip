@@ -765,9 +765,21 @@ int nd_solve(vdn_multifab *rh, vdn_multifab *phi, const vdn_multifab *coeffs, co
     hipLaunchKernelGGL(kk_nd_load, ng3(L0.n[0] + 1, L0.n[1] + 1, std::min(L0.n[2] + 1, 16)), NBLK, 0, st, L0, rh->fabs[b], phi->fabs[b], bx.lo[0], bx.lo[1], bx.lo[2], M.d_nrm);
   }
   comm_allreduce_max_dev(M.d_nrm, 1);
-  const double bnorm = nd_read(M.d_nrm);
-  int cyc = 0; bool conv = (bnorm == 0.0); double rn = 0.0;
   const bool single = (M.dlev.size() == 1 && M.tail.empty());
+  const bool fixed_cycles = max_iter < 0;     // exactly -max_iter V-cycles, no norms, no convergence test (composite coarse correction)
+  const double bnorm = fixed_cycles ? 1.0 : nd_read(M.d_nrm);
+  int cyc = 0; bool conv = (bnorm == 0.0); double rn = 0.0;
+  for (int c = 0; fixed_cycles && c < -max_iter; c++) {
+    if (single) { nd_jacobi_d(D0, nd_bottom_sweeps_global(D0)); continue; }
+    nd_jacobi_d(D0, P.hg_nu1);
+    nd_residual_d(M, D0, false);
+    nd_restrict_down(M, 0);
+    if (M.dlev.size() > 1) nd_vcycle_d(M, 1); else nd_vcycle_t(M, 0);
+    nd_prolong_up(M, 0);
+    nd_jacobi_d(D0, P.hg_nu2);
+    cyc++;
+  }
+  if (fixed_cycles) conv = true;
   while (!conv) {
     nd_jacobi_d(D0, single ? nd_bottom_sweeps_global(D0) : P.hg_nu1);
     nd_residual_d(M, D0, true);
@@ -1038,6 +1050,98 @@ __global__ void kk_ndf_neg(FV out, FV in, NdfArgs A, Range3 r) {       // b = -r
 }
 __global__ void kk_ndf_add(FV a, FV b, Range3 r) { THREAD_IJK(r) if (!in_range) return; fv_at(a, i, j, k) = fv_get(a, i, j, k) + fv_get(b, i, j, k); }
 
+// k-marching forms of kk_ndf_jacobi / kk_ndf_residual (same structure as kk_nd_march: own-column loads, i-1 / i+1 columns by wave
+// shuffles, three phi planes and two sigma planes in registers).  r: the node range of the box; tiles of 62 nodes along i.
+// MODE 0: eout = ein + omega (rb - K ein)/diag on free nodes;  MODE 1: res = b - K phi (0 on physical Dirichlet nodes), max-norm
+// over the nodes that are not interface nodes (excl = 1) / all nodes (excl = 0)
+template <int MODE>
+__global__ void __launch_bounds__(256) kk_ndf_march(FV phi, FV out, FV rb, FV sig, NdfArgs A, double omega, int excl, int kchunk, Range3 r, double *nrm) {
+  const int lane = threadIdx.x;
+  const int i = r.lo[0] + (int)blockIdx.x * 62 + lane - 1;
+  const int j = r.lo[1] + (int)(blockIdx.y * blockDim.y + threadIdx.y);
+  const int k0 = r.lo[2] + (int)blockIdx.z * kchunk, k1 = min(k0 + kchunk - 1, r.hi[2]);
+  const bool active = lane >= 1 && lane <= 62 && i <= r.hi[0] && j <= r.hi[1];
+  const int ic = min(i, r.hi[0] + 1), jc = min(j, r.hi[1]);
+  double rmax = 0.0;
+  if (k0 <= k1) {
+    double p[3][3][3], sg[2][2][2];
+    #pragma unroll
+    for (int b = 0; b < 3; b++) { p[0][b][1] = fv_get(phi, ic, jc + b - 1, k0 - 1); p[1][b][1] = fv_get(phi, ic, jc + b - 1, k0); }
+    #pragma unroll
+    for (int dj = 0; dj < 2; dj++) sg[0][dj][1] = fv_get(sig, ic, jc + dj - 1, k0 - 1);
+    #pragma unroll
+    for (int b = 0; b < 3; b++) {
+      p[0][b][0] = __shfl_up(p[0][b][1], 1, 64); p[0][b][2] = __shfl_down(p[0][b][1], 1, 64);
+      p[1][b][0] = __shfl_up(p[1][b][1], 1, 64); p[1][b][2] = __shfl_down(p[1][b][1], 1, 64);
+    }
+    #pragma unroll
+    for (int dj = 0; dj < 2; dj++) sg[0][dj][0] = __shfl_up(sg[0][dj][1], 1, 64);
+    const double fx = A.f[0], fy = A.f[1], fz = A.f[2], F = fx + fy + fz;
+    double w[8];
+    w[0] = 4.0 * F; w[1] = -4.0 * fx + 2.0 * fy + 2.0 * fz; w[2] = 2.0 * fx - 4.0 * fy + 2.0 * fz; w[3] = -2.0 * fx - 2.0 * fy + fz;
+    w[4] = 2.0 * fx + 2.0 * fy - 4.0 * fz; w[5] = -2.0 * fx + fy - 2.0 * fz; w[6] = fx - 2.0 * fy - 2.0 * fz; w[7] = -F;
+    for (int k = k0; k <= k1; k++) {
+      #pragma unroll
+      for (int b = 0; b < 3; b++) p[2][b][1] = fv_get(phi, ic, jc + b - 1, k + 1);
+      #pragma unroll
+      for (int dj = 0; dj < 2; dj++) sg[1][dj][1] = fv_get(sig, ic, jc + dj - 1, k);
+      const double rhs = fv_get(rb, ic, jc, k);
+      #pragma unroll
+      for (int b = 0; b < 3; b++) { p[2][b][0] = __shfl_up(p[2][b][1], 1, 64); p[2][b][2] = __shfl_down(p[2][b][1], 1, 64); }
+      #pragma unroll
+      for (int dj = 0; dj < 2; dj++) sg[1][dj][0] = __shfl_up(sg[1][dj][1], 1, 64);
+      // K phi in the order of ndf_apply: cells (dk,dj,di) ascending, corners (mz,my,mx) ascending
+      double acc = 0.0, ssum = 0.0;
+      #pragma unroll
+      for (int dk = 0; dk < 2; dk++)
+        #pragma unroll
+        for (int dj = 0; dj < 2; dj++)
+          #pragma unroll
+          for (int di = 0; di < 2; di++) {
+            double t = 0.0;
+            #pragma unroll
+            for (int mz = 0; mz < 2; mz++)
+              #pragma unroll
+              for (int my = 0; my < 2; my++)
+                #pragma unroll
+                for (int mx = 0; mx < 2; mx++) {
+                  const int oa = di + mx - 1, ob = dj + my - 1, oc = dk + mz - 1;
+                  const int idx = (oa != 0) | ((ob != 0) << 1) | ((oc != 0) << 2);
+                  t = t + w[idx] * p[oc + 1][ob + 1][oa + 1];
+                }
+            acc = acc + sg[dk][dj][di] * t;
+            ssum = ssum + sg[dk][dj][di];
+          }
+      const double Kp = acc, diag = w[0] * ssum;
+      const double p0 = p[1][1][1];
+      const bool pdir = ndf_pdir(A, i, j, k), cf = ndf_cf(A, i, j, k);
+      if (MODE == 0) {
+        double v = p0;
+        if (!pdir && !cf && diag != 0.0) v = p0 + omega * ((rhs - Kp) / diag);
+        if (active) fv_at(out, i, j, k) = v;
+      } else {
+        const double rr = pdir ? 0.0 : rhs - Kp;
+        if (active) { fv_at(out, i, j, k) = rr; if (!(excl == 1 && cf && !pdir)) rmax = fmax(rmax, fabs(rr)); }
+      }
+      #pragma unroll
+      for (int b = 0; b < 3; b++)
+        #pragma unroll
+        for (int a = 0; a < 3; a++) { p[0][b][a] = p[1][b][a]; p[1][b][a] = p[2][b][a]; }
+      #pragma unroll
+      for (int dj = 0; dj < 2; dj++)
+        #pragma unroll
+        for (int di = 0; di < 2; di++) sg[0][dj][di] = sg[1][dj][di];
+    }
+  }
+  if (MODE == 1 && nrm) block_atomic_max(nrm, rmax);
+}
+template <int MODE> static void ndf_launch_march(const FV &phi, const FV &out, const FV &rb, const FV &sig, const NdfArgs &A, double omega, int excl, const Range3 &r, double *nrm) {
+  const int nx = r.hi[0] - r.lo[0] + 1, ny = r.hi[1] - r.lo[1] + 1, nz = r.hi[2] - r.lo[2] + 1;
+  const int tiles = ((nx + 61) / 62) * ((ny + 3) / 4);
+  int kchunk = nz;
+  while (kchunk > 8 && tiles * ((nz + kchunk - 1) / kchunk) < 2048) kchunk = (kchunk + 1) / 2;
+  hipLaunchKernelGGL(kk_ndf_march<MODE>, dim3((nx + 61) / 62, (ny + 3) / 4, (nz + kchunk - 1) / kchunk), NBLK, 0, ctx().stream, phi, out, rb, sig, A, omega, excl, kchunk, r, nrm);
+}
 __global__ void kk_ndf_absmax_mask(FV a, FV mask, Range3 r, double *nrm) {
   REDUCE_IJ(r)
   double m = 0.0;
@@ -1086,11 +1190,10 @@ static double ml_nd_residual(MLND &S, bool fine_only) {
   if (S.multi) mf_fill_boundary(S.phi[1]);
   if (!fine_only) HIPCHK(hipMemsetAsync(S.d_nrm, 0, sizeof(double), st));
   for (int f = 0; f < nf; f++)
-    hipLaunchKernelGGL(kk_ndf_residual, reduce_grid(S.rf[f]), NBLK, 0, st, S.b[1]->fabs[f], S.phi[1]->fabs[f], S.sig[1]->fabs[f], S.res[1]->fabs[f], S.Af[f], 1, S.rf[f],
-                       fine_only ? (double *)nullptr : S.d_nrm);
+    ndf_launch_march<1>(S.phi[1]->fabs[f], S.res[1]->fabs[f], S.b[1]->fabs[f], S.sig[1]->fabs[f], S.Af[f], 0.0, 1, S.rf[f], fine_only ? (double *)nullptr : S.d_nrm);
   if (fine_only) return 0.0;
   if (S.multi) mf_fill_boundary(S.res[1]);
-  hipLaunchKernelGGL(kk_ndf_residual, reduce_grid(S.rc), NBLK, 0, st, S.b[0]->fabs[0], S.phi[0]->fabs[0], S.sig[0]->fabs[0], S.res[0]->fabs[0], S.Ac, 0, S.rc, (double *)nullptr);
+  ndf_launch_march<1>(S.phi[0]->fabs[0], S.res[0]->fabs[0], S.b[0]->fabs[0], S.sig[0]->fabs[0], S.Ac, 0.0, 0, S.rc, (double *)nullptr);
   for (int f = 0; f < nf; f++) {
     Range3 ri; for (int d = 0; d < 3; d++) { ri.lo[d] = S.Af[f].lo[d] / 2; ri.hi[d] = S.Af[f].hi[d] / 2; }
     hipLaunchKernelGGL(kk_ndf_restrict_add2, grid_for(ri), NBLK, 0, st, S.res[0]->fabs[0], S.res[1]->fabs[f], S.Af[f], S.Ac,
@@ -1191,7 +1294,7 @@ static int ml_nd_solve(vdn_layout *la, vdn_multifab **rh, vdn_multifab **phi, vd
     { NdfArgs Z = S.Ac; for (int d = 0; d < 3; d++) { Z.dirlo[d] = Z.dirhi[d] = 0; }
       hipLaunchKernelGGL(kk_ndf_neg, grid_for(S.rc), NBLK, 0, st, er->fabs[0], S.res[0]->fabs[0], Z, S.rc); }
     int cyc; double r0, rr;
-    nd_solve(er, ee, coeffs[0], nullptr, dx, ebc0, 0.0, -1.0, 1, &cyc, &r0, &rr);
+    nd_solve(er, ee, coeffs[0], nullptr, dx, ebc0, 0.0, -1.0, -1, &cyc, &r0, &rr);
     hipLaunchKernelGGL(kk_ndf_add, grid_for(S.rc), NBLK, 0, st, S.phi[0]->fabs[0], ee->fabs[0], S.rc);
     for (int f = 0; f < nf; f++) hipLaunchKernelGGL(kk_ndf_prolong, grid_for(S.rf[f]), NBLK, 0, st, S.phi[1]->fabs[f], ee->fabs[0], S.Af[f], 1, S.rf[f]);
     // fine relaxation of K_f e = r_f with the interface fixed
@@ -1201,7 +1304,7 @@ static int ml_nd_solve(vdn_layout *la, vdn_multifab **rh, vdn_multifab **phi, vd
     for (int s = 0; s < P.hg_nu1 + P.hg_nu2; s++) {
       if (S.multi && s > 0) mf_fill_boundary(a);
       for (int f = 0; f < nf; f++)
-        hipLaunchKernelGGL(kk_ndf_jacobi, grid_for(S.rf[f]), NBLK, 0, st, a->fabs[f], b2->fabs[f], S.res[1]->fabs[f], S.sig[1]->fabs[f], S.Af[f], P.hg_omega, S.rf[f]);
+        ndf_launch_march<0>(a->fabs[f], b2->fabs[f], S.res[1]->fabs[f], S.sig[1]->fabs[f], S.Af[f], P.hg_omega, 0, S.rf[f], (double *)nullptr);
       std::swap(a, b2);
     }
     for (int f = 0; f < nf; f++) hipLaunchKernelGGL(kk_ndf_add, grid_for(S.rf[f]), NBLK, 0, st, S.phi[1]->fabs[f], a->fabs[f], S.rf[f]);
