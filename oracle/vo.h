@@ -174,17 +174,17 @@ void vo_fill_ghost_cells(vo_fab *fine, const vo_fab *crse, int icomp, int nc);
 void vo_create_umac_grown(vo_fab *fine, const vo_fab *crse, int dir);
 void vo_ml_restrict_and_fill(int nlev, vo_fab **mf, int icomp, int bcomp, int nc, int same_boundary, const vo_bc *bc, const int pmask[3],
                              const int *pd, const vdn_params *prm);
-int  vo_ml_cc_solve(int nlev, vo_fab **rh, vo_fab **phi, vo_fab **beta, const double *dx, const int ellbc[2][3][2], const int pmask[3], const int *pd,
+int  vo_ml_cc_solve(int nlev, vo_fab **rh, vo_fab **phi, vo_fab **beta, const double *dx, const int ellbc[][3][2], const int pmask[3], const int *pd,
                     double rel_eps, int max_iter, const vdn_params *prm, vo_mgstat *st);
 void vo_ml_macproject(int nlev, vo_fab **umac, vo_fab **rho, vo_fab **mac_rhs, const double *dx, const vo_bc *bc, const int pmask[3], const int *pd,
                       const vdn_params *prm, vo_mgstat *st);
 
-int  vo_ml_nd_solve(vo_fab **rh, vo_fab **phi, vo_fab **coeffs, vo_fab **u, const double *dx, const int ellbc[2][3][2], const int pmask[3],
+int  vo_ml_nd_solve(int nlev, vo_fab **rh, vo_fab **phi, vo_fab **coeffs, vo_fab **u, const double *dx, const int ellbc[][3][2], const int pmask[3],
                     double rel_eps, double abs_eps, int max_iter, const vdn_params *prm, vo_mgstat *st);
-void vo_ml_hgproject(int proj_type, vo_fab **unew, vo_fab **uold, vo_fab **rhohalf, vo_fab **p, vo_fab **gp, const double *dx, double dt,
+void vo_ml_hgproject(int nlev, int proj_type, vo_fab **unew, vo_fab **uold, vo_fab **rhohalf, vo_fab **p, vo_fab **gp, const double *dx, double dt,
                      const vo_bc *bc, const int pmask[3], const int *pd, const vdn_params *prm, vo_mgstat *st);
 
-void vo_ml_advance_timestep(vo_state *S, const double *dx, double dt, const vo_bc *bc, const int pmask[3], const int *pd, const vdn_params *prm,
+void vo_ml_advance_timestep(int nlev, vo_state *S, const double *dx, double dt, const vo_bc *bc, const int pmask[3], const int *pd, const vdn_params *prm,
                             int proj_type, vo_mgstat st[2]);
 
 /* ---- the 2-D path (oracle/vo_2d.c): velpred_2d, mkflux_2d, update_2d, mkforce 2-D, estdt_2d, macproject / hgproject

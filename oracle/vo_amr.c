@@ -225,84 +225,98 @@ static void fab_like(vo_fab *f, const vo_fab *like, int ng, double val)
   for (long i = 0; i < n; i++) f->p[i] = val;
 }
 
-/* composite residual of both levels; res[0] on covered cells = restriction of res[1]; returns the composite max-norm */
-static double composite_residual(vo_fab **rh, vo_fab **phi, vo_fab **beta, const double *dx, const int ellbc[2][3][2], const int pmask[3], const int *pd, vo_fab **res)
+#define VO_MAXLEV 4
+typedef const int (*ellbc_t)[3][2];
+static void fill_phi_ghosts(int nlev, vo_fab **phi, ellbc_t ellbc, const int pmask[3], const int *pd)
 {
-  vo_ml_cc_restriction(phi[0], phi[1], 0, 1);                     /* keep the coarse level consistent under the fine one */
-  phi_closure(phi[0], ellbc[0], pmask, pd, pd + 3);
-  phi_closure(phi[1], ellbc[1], pmask, pd + 6, pd + 9);
-  cf_interp(phi[1], phi[0], ellbc[1]);
-  double nf = plain_residual(rh[1], phi[1], beta + 3, dx + 3, res[1]);
-  (void)plain_residual(rh[0], phi[0], beta, dx, res[0]);
-  reflux_residual(res[0], phi[0], beta, dx, phi[1], beta + 3, dx + 3, ellbc[1]);
-  vo_ml_cc_restriction(res[0], res[1], 0, 1);
-  double nc = 0.0;
-  for (int k = res[0]->lo[2]; k <= res[0]->hi[2]; k++) for (int j = res[0]->lo[1]; j <= res[0]->hi[1]; j++) for (int i = res[0]->lo[0]; i <= res[0]->hi[0]; i++)
-    if (!covered(phi[1], i, j, k)) nc = fmax(nc, fabs(VF(res[0], i, j, k, 0)));
-  return fmax(nf, nc);
+  for (int n = nlev - 1; n >= 1; n--) vo_ml_cc_restriction(phi[n - 1], phi[n], 0, 1);     /* keep coarser levels consistent under finer ones */
+  for (int n = 0; n < nlev; n++) phi_closure(phi[n], ellbc[n], pmask, pd + 6 * n, pd + 6 * n + 3);
+  for (int n = 1; n < nlev; n++) cf_interp(phi[n], phi[n - 1], ellbc[n]);
+}
+/* composite residual on every level; res[n] on cells covered by level n+1 = restriction of res[n+1]; returns the composite max-norm
+ * (cells of each level that are not covered by the next finer one) */
+static double composite_residual(int nlev, vo_fab **rh, vo_fab **phi, vo_fab **beta, const double *dx, ellbc_t ellbc, const int pmask[3], const int *pd, vo_fab **res)
+{
+  fill_phi_ghosts(nlev, phi, ellbc, pmask, pd);
+  for (int n = 0; n < nlev; n++) (void)plain_residual(rh[n], phi[n], beta + 3 * n, dx + 3 * n, res[n]);
+  for (int n = 1; n < nlev; n++) reflux_residual(res[n - 1], phi[n - 1], beta + 3 * (n - 1), dx + 3 * (n - 1), phi[n], beta + 3 * n, dx + 3 * n, ellbc[n]);
+  for (int n = nlev - 1; n >= 1; n--) vo_ml_cc_restriction(res[n - 1], res[n], 0, 1);
+  double nrm = 0.0;
+  for (int n = 0; n < nlev; n++)
+    for (int k = res[n]->lo[2]; k <= res[n]->hi[2]; k++) for (int j = res[n]->lo[1]; j <= res[n]->hi[1]; j++) for (int i = res[n]->lo[0]; i <= res[n]->hi[0]; i++)
+      if (n == nlev - 1 || !covered(phi[n + 1], i, j, k)) nrm = fmax(nrm, fabs(VF(res[n], i, j, k, 0)));
+  return nrm;
+}
+/* phi[n] += e (valid cells of level n), and the piecewise-constant prolongation of that correction on every finer level */
+static void apply_correction(int nlev, int n, vo_fab **phi, vo_fab *e, vo_fab *scratch)
+{
+  for (int k = phi[n]->lo[2]; k <= phi[n]->hi[2]; k++) for (int j = phi[n]->lo[1]; j <= phi[n]->hi[1]; j++) for (int i = phi[n]->lo[0]; i <= phi[n]->hi[0]; i++)
+    VF(phi[n], i, j, k, 0) = VF(phi[n], i, j, k, 0) + VF(&e[n], i, j, k, 0);
+  const vo_fab *src = &e[n];
+  for (int m = n + 1; m < nlev; m++) {
+    for (int k = phi[m]->lo[2]; k <= phi[m]->hi[2]; k++) for (int j = phi[m]->lo[1]; j <= phi[m]->hi[1]; j++) for (int i = phi[m]->lo[0]; i <= phi[m]->hi[0]; i++) {
+      const double v = VF(src, i / 2, j / 2, k / 2, 0);
+      VF(&scratch[m], i, j, k, 0) = v;
+      VF(phi[m], i, j, k, 0) = VF(phi[m], i, j, k, 0) + v;
+    }
+    src = &scratch[m];
+  }
 }
 
-/* rh, phi: [lev];  beta: [lev*3 + d];  dx: [lev*3 + d];  ellbc[lev] per box;  pd: [lev][2][3];  nu_f fine relaxation sweeps */
-int vo_ml_cc_solve(int nlev, vo_fab **rh, vo_fab **phi, vo_fab **beta, const double *dx, const int ellbc[2][3][2], const int pmask[3], const int *pd,
+/* rh, phi: [lev];  beta: [lev*3 + d];  dx: [lev*3 + d];  ellbc[lev] per box;  pd: [lev][2][3].
+ * One FAC iteration: composite residual / test; for n = finest..1: nu1 red-black sweeps on level n (homogeneous interface), correction
+ * applied to level n and prolonged to the finer ones, composite residual; ONE V-cycle of the single-level multigrid on level 0, applied
+ * and prolonged, composite residual; for n = 1..finest: nu2 sweeps on level n, applied and prolonged (composite residual before the next). */
+int vo_ml_cc_solve(int nlev, vo_fab **rh, vo_fab **phi, vo_fab **beta, const double *dx, const int ellbc[][3][2], const int pmask[3], const int *pd,
                    double rel_eps, int max_iter, const vdn_params *prm, vo_mgstat *st)
 {
-  if (nlev != 2) { fprintf(stderr, "vo_ml_cc_solve: two levels only\n"); abort(); }
-  vo_fab res[2], e[2], *rp[2] = { &res[0], &res[1] };
-  for (int n = 0; n < 2; n++) { fab_like(&res[n], rh[n], 0, 0.0); fab_like(&e[n], rh[n], 1, 0.0); }
+  if (nlev < 2 || nlev > VO_MAXLEV) { fprintf(stderr, "vo_ml_cc_solve: 2..%d levels\n", VO_MAXLEV); abort(); }
+  vo_fab res[VO_MAXLEV], e[VO_MAXLEV], scr[VO_MAXLEV], *rp[VO_MAXLEV];
+  for (int n = 0; n < nlev; n++) { fab_like(&res[n], rh[n], 0, 0.0); fab_like(&e[n], rh[n], 1, 0.0); fab_like(&scr[n], rh[n], 0, 0.0); rp[n] = &res[n]; }
   /* norm of the right-hand side over the composite grid */
   double bnorm = 0.0;
-  for (int n = 0; n < 2; n++)
+  for (int n = 0; n < nlev; n++)
     for (int k = rh[n]->lo[2]; k <= rh[n]->hi[2]; k++) for (int j = rh[n]->lo[1]; j <= rh[n]->hi[1]; j++) for (int i = rh[n]->lo[0]; i <= rh[n]->hi[0]; i++)
-      if (n == 1 || !covered(rh[1], i, j, k)) bnorm = fmax(bnorm, fabs(VF(rh[n], i, j, k, 0)));
+      if (n == nlev - 1 || !covered(rh[n + 1], i, j, k)) bnorm = fmax(bnorm, fabs(VF(rh[n], i, j, k, 0)));
   int it = 0, conv = 0; double rn = 0.0;
   if (bnorm == 0.0) conv = 1;
   while (!conv) {
-    rn = composite_residual(rh, phi, beta, dx, ellbc, pmask, pd, rp);
+    rn = composite_residual(nlev, rh, phi, beta, dx, ellbc, pmask, pd, rp);
     if (rn <= rel_eps * bnorm) { conv = 1; break; }
     if (it >= max_iter) break;
-    /* pre-relaxation of the fine level (homogeneous interface), then the residual the coarse level will see */
-    memset(e[1].p, 0, sizeof(double) * vo_size(&e[1]));
-    vo_cc_smooth(&res[1], &e[1], beta + 3, dx + 3, ellbc[1], prm->mg_nu1);
-    for (int k = phi[1]->lo[2]; k <= phi[1]->hi[2]; k++) for (int j = phi[1]->lo[1]; j <= phi[1]->hi[1]; j++) for (int i = phi[1]->lo[0]; i <= phi[1]->hi[0]; i++)
-      VF(phi[1], i, j, k, 0) = VF(phi[1], i, j, k, 0) + VF(&e[1], i, j, k, 0);
-    (void)composite_residual(rh, phi, beta, dx, ellbc, pmask, pd, rp);
+    for (int n = nlev - 1; n >= 1; n--) {               /* pre-relaxation, finest first */
+      memset(e[n].p, 0, sizeof(double) * vo_size(&e[n]));
+      vo_cc_smooth(&res[n], &e[n], beta + 3 * n, dx + 3 * n, ellbc[n], prm->mg_nu1);
+      apply_correction(nlev, n, phi, e, scr);
+      (void)composite_residual(nlev, rh, phi, beta, dx, ellbc, pmask, pd, rp);
+    }
     /* coarse correction: ONE V-cycle of the single-level multigrid on the whole coarse level */
     memset(e[0].p, 0, sizeof(double) * vo_size(&e[0]));
     vo_mgstat cs;
     vo_cc_solve_ab(&res[0], &e[0], NULL, beta, dx, ellbc[0], 0.0, -1.0, -1, prm->mg_nu1, prm->mg_nu2, prm->mg_nub, &cs);
-    for (int k = phi[0]->lo[2]; k <= phi[0]->hi[2]; k++) for (int j = phi[0]->lo[1]; j <= phi[0]->hi[1]; j++) for (int i = phi[0]->lo[0]; i <= phi[0]->hi[0]; i++)
-      VF(phi[0], i, j, k, 0) = VF(phi[0], i, j, k, 0) + VF(&e[0], i, j, k, 0);
-    for (int k = phi[1]->lo[2]; k <= phi[1]->hi[2]; k++) for (int j = phi[1]->lo[1]; j <= phi[1]->hi[1]; j++) for (int i = phi[1]->lo[0]; i <= phi[1]->hi[0]; i++)
-      VF(phi[1], i, j, k, 0) = VF(phi[1], i, j, k, 0) + VF(&e[0], i / 2, j / 2, k / 2, 0);
-    /* fine relaxation on the new residual, homogeneous interface */
-    phi_closure(phi[0], ellbc[0], pmask, pd, pd + 3);
-    phi_closure(phi[1], ellbc[1], pmask, pd + 6, pd + 9);
-    cf_interp(phi[1], phi[0], ellbc[1]);
-    (void)plain_residual(rh[1], phi[1], beta + 3, dx + 3, &res[1]);
-    memset(e[1].p, 0, sizeof(double) * vo_size(&e[1]));
-    vo_cc_smooth(&res[1], &e[1], beta + 3, dx + 3, ellbc[1], prm->mg_nu2);
-    for (int k = phi[1]->lo[2]; k <= phi[1]->hi[2]; k++) for (int j = phi[1]->lo[1]; j <= phi[1]->hi[1]; j++) for (int i = phi[1]->lo[0]; i <= phi[1]->hi[0]; i++)
-      VF(phi[1], i, j, k, 0) = VF(phi[1], i, j, k, 0) + VF(&e[1], i, j, k, 0);
+    apply_correction(nlev, 0, phi, e, scr);
+    for (int n = 1; n < nlev; n++) {                    /* post-relaxation, coarsest first */
+      if (n < nlev - 1) (void)composite_residual(nlev, rh, phi, beta, dx, ellbc, pmask, pd, rp);
+      else { fill_phi_ghosts(nlev, phi, ellbc, pmask, pd); (void)plain_residual(rh[n], phi[n], beta + 3 * n, dx + 3 * n, &res[n]); }
+      memset(e[n].p, 0, sizeof(double) * vo_size(&e[n]));
+      vo_cc_smooth(&res[n], &e[n], beta + 3 * n, dx + 3 * n, ellbc[n], prm->mg_nu2);
+      apply_correction(nlev, n, phi, e, scr);
+    }
     it++;
   }
-  /* leave phi with consistent ghosts for mkumac */
-  vo_ml_cc_restriction(phi[0], phi[1], 0, 1);
-  phi_closure(phi[0], ellbc[0], pmask, pd, pd + 3);
-  phi_closure(phi[1], ellbc[1], pmask, pd + 6, pd + 9);
-  cf_interp(phi[1], phi[0], ellbc[1]);
+  fill_phi_ghosts(nlev, phi, ellbc, pmask, pd);       /* leave phi with consistent ghosts for mkumac */
   if (st) { st->cycles = it; st->res0 = bnorm; st->res = rn; }
-  for (int n = 0; n < 2; n++) { free(res[n].p); free(e[n].p); }
+  for (int n = 0; n < nlev; n++) { free(res[n].p); free(e[n].p); free(scr[n].p); }
   return conv ? 0 : 1;
 }
 
-/* macproject.f90:20-133, two levels.  umac: [lev*3 + d] (ng = 1), rho: [lev] (ghosts filled), mac_rhs: [lev] */
+/* macproject.f90:20-133 on nlev levels.  umac: [lev*3 + d] (ng = 1), rho: [lev] (ghosts filled), mac_rhs: [lev] */
 void vo_ml_macproject(int nlev, vo_fab **umac, vo_fab **rho, vo_fab **mac_rhs, const double *dx, const vo_bc *bc, const int pmask[3], const int *pd,
                       const vdn_params *prm, vo_mgstat *st)
 {
-  if (nlev != 2) { fprintf(stderr, "vo_ml_macproject: two levels only\n"); abort(); }
-  vo_fab rh[2], phi[2], beta[6], *rhp[2], *php[2], *bp[6];
-  int ellbc[2][3][2];
-  for (int n = 0; n < 2; n++) {
+  vo_fab rh[VO_MAXLEV], phi[VO_MAXLEV], beta[3 * VO_MAXLEV], *rhp[VO_MAXLEV], *php[VO_MAXLEV], *bp[3 * VO_MAXLEV];
+  int ellbc[VO_MAXLEV][3][2];
+  for (int n = 0; n < nlev; n++) {
     fab_like(&rh[n], rho[n], 0, 0.0); fab_like(&phi[n], rho[n], 1, 0.0); rhp[n] = &rh[n]; php[n] = &phi[n];
     for (int d = 0; d < 3; d++) {
       int nd[3] = { 0, 0, 0 }; nd[d] = 1;
@@ -312,31 +326,32 @@ void vo_ml_macproject(int nlev, vo_fab **umac, vo_fab **rho, vo_fab **mac_rhs, c
     }
   }
   /* divumac (macproject.f90:161-206): rh = mac_rhs - div(umac) on every level, then ml_cc_restriction */
-  for (int n = 0; n < 2; n++) {
+  for (int n = 0; n < nlev; n++) {
     vo_divumac(umac + 3 * n, &rh[n], dx + 3 * n);
     for (int k = rh[n].lo[2]; k <= rh[n].hi[2]; k++) for (int j = rh[n].lo[1]; j <= rh[n].hi[1]; j++) for (int i = rh[n].lo[0]; i <= rh[n].hi[0]; i++)
       VF(&rh[n], i, j, k, 0) = VF(&rh[n], i, j, k, 0) * -1.0 + VF(mac_rhs[n], i, j, k, 0);
   }
-  vo_ml_cc_restriction(&rh[0], &rh[1], 0, 1);
+  for (int n = nlev - 1; n >= 1; n--) vo_ml_cc_restriction(&rh[n - 1], &rh[n], 0, 1);
   /* mk_mac_coeffs (macproject.f90:296-334): rho's fine ghosts come from the caller's ml_restrict_and_fill; edge restriction */
-  for (int n = 0; n < 2; n++) vo_mk_mac_coeffs(rho[n], bp + 3 * n);
-  for (int d = 0; d < 3; d++) vo_ml_edge_restriction(bp[d], bp[3 + d], d);
-  vo_ml_cc_solve(2, rhp, php, bp, dx, ellbc, pmask, pd, prm->mac_rel_eps, prm->mg_max_iter, prm, st);
+  for (int n = 0; n < nlev; n++) vo_mk_mac_coeffs(rho[n], bp + 3 * n);
+  for (int n = nlev - 1; n >= 1; n--) for (int d = 0; d < 3; d++) vo_ml_edge_restriction(bp[3 * (n - 1) + d], bp[3 * n + d], d);
+  vo_ml_cc_solve(nlev, rhp, php, bp, dx, (const int (*)[3][2])ellbc, pmask, pd, prm->mac_rel_eps, prm->mg_max_iter, prm, st);
   /* mkumac on every level with the solver's ghost cells, then edge restriction and the ghost faces (macproject.f90:103-119) */
-  for (int n = 0; n < 2; n++) vo_mkumac(umac + 3 * n, &phi[n], bp + 3 * n, dx + 3 * n, ellbc[n]);
-  for (int d = 0; d < 3; d++) vo_ml_edge_restriction(umac[d], umac[3 + d], d);
-  for (int d = 0; d < 3; d++) { level_fill_boundary(umac[d], pmask, pd, pd + 3); vo_create_umac_grown(umac[3 + d], umac[d], d); level_fill_boundary(umac[3 + d], pmask, pd + 6, pd + 9); }
-  for (int n = 0; n < 2; n++) { free(rh[n].p); free(phi[n].p); for (int d = 0; d < 3; d++) free(beta[3 * n + d].p); }
+  for (int n = 0; n < nlev; n++) vo_mkumac(umac + 3 * n, &phi[n], bp + 3 * n, dx + 3 * n, ellbc[n]);
+  for (int n = nlev - 1; n >= 1; n--) for (int d = 0; d < 3; d++) vo_ml_edge_restriction(umac[3 * (n - 1) + d], umac[3 * n + d], d);
+  for (int d = 0; d < 3; d++) level_fill_boundary(umac[d], pmask, pd, pd + 3);
+  for (int n = 1; n < nlev; n++) for (int d = 0; d < 3; d++) { vo_create_umac_grown(umac[3 * n + d], umac[3 * (n - 1) + d], d); level_fill_boundary(umac[3 * n + d], pmask, pd + 6 * n, pd + 6 * n + 3); }
+  for (int n = 0; n < nlev; n++) { free(rh[n].p); free(phi[n].p); for (int d = 0; d < 3; d++) free(beta[3 * n + d].p); }
 }
 
-/* hgproject.f90:17-178 with nlevs = 2 (rel tolerance 1e-11, hgproject.f90:115-116) */
-void vo_ml_hgproject(int proj_type, vo_fab **unew, vo_fab **uold, vo_fab **rhohalf, vo_fab **p, vo_fab **gp, const double *dx, double dt,
+/* hgproject.f90:17-178 with nlevs > 1 (rel tolerance 1e-11 for two levels, 1e-10 for more: hgproject.f90:115-119) */
+void vo_ml_hgproject(int nlev, int proj_type, vo_fab **unew, vo_fab **uold, vo_fab **rhohalf, vo_fab **p, vo_fab **gp, const double *dx, double dt,
                      const vo_bc *bc, const int pmask[3], const int *pd, const vdn_params *prm, vo_mgstat *st)
 {
-  vo_fab rh[2], phi[2], gphi[2], coeffs[2], *rhp[2], *php[2], *cfp[2];
-  int ellbc[2][3][2];
+  vo_fab rh[VO_MAXLEV], phi[VO_MAXLEV], gphi[VO_MAXLEV], coeffs[VO_MAXLEV], *rhp[VO_MAXLEV], *php[VO_MAXLEV], *cfp[VO_MAXLEV];
+  int ellbc[VO_MAXLEV][3][2];
   int nd1[3] = { 1, 1, 1 };
-  for (int n = 0; n < 2; n++) {
+  for (int n = 0; n < nlev; n++) {
     const int *lo = unew[n]->lo, *hi = unew[n]->hi;
     vo_fab_init(&rh[n], NULL, lo, hi, 1, nd1, 1);    rh[n].p = (double *)calloc(vo_size(&rh[n]), sizeof(double));
     vo_fab_init(&phi[n], NULL, lo, hi, 1, nd1, 1);   phi[n].p = (double *)calloc(vo_size(&phi[n]), sizeof(double));
@@ -350,21 +365,21 @@ void vo_ml_hgproject(int proj_type, vo_fab **unew, vo_fab **uold, vo_fab **rhoha
       VF(&coeffs[n], i, j, k, 0) = 1.0 / VF(rhohalf[n], i, j, k, 0);
     level_fill_boundary(&coeffs[n], pmask, pd + 6 * n, pd + 6 * n + 3);
   }
-  double rel = prm->hg_rel_eps > 0.0 ? prm->hg_rel_eps : 1.e-11;
+  double rel = prm->hg_rel_eps > 0.0 ? prm->hg_rel_eps : (nlev == 2 ? 1.e-11 : 1.e-10);
   double abs_eps = -1.0;
   if (proj_type == VDN_INITIAL_PROJECTION && prm->prob_type == 4) abs_eps = 1.e-12;
-  vo_ml_nd_solve(rhp, php, cfp, unew, dx, ellbc, pmask, rel, abs_eps, prm->hg_max_iter, prm, st);
-  for (int n = 0; n < 2; n++) {
+  vo_ml_nd_solve(nlev, rhp, php, cfp, unew, dx, (const int (*)[3][2])ellbc, pmask, rel, abs_eps, prm->hg_max_iter, prm, st);
+  for (int n = 0; n < nlev; n++) {
     vo_mkgphi(&gphi[n], &phi[n], dx + 3 * n);
     vo_hg_update(proj_type, unew[n], uold[n], gp[n], &gphi[n], rhohalf[n], p[n], &phi[n], dt);
   }
-  vo_ml_cc_restriction(gp[0], gp[1], 0, 3);                                   /* hgproject.f90:355-357 */
-  for (int n = 0; n < 2; n++) { level_fill_boundary(gp[n], pmask, pd + 6 * n, pd + 6 * n + 3); level_fill_boundary(p[n], pmask, pd + 6 * n, pd + 6 * n + 3); }
-  vo_ml_restrict_and_fill(2, unew, 0, 0, 3, 0, bc, pmask, pd, prm);          /* hgproject.f90:364-366 */
-  for (int n = 0; n < 2; n++) { free(rh[n].p); free(phi[n].p); free(gphi[n].p); free(coeffs[n].p); }
+  for (int n = nlev - 1; n >= 1; n--) vo_ml_cc_restriction(gp[n - 1], gp[n], 0, 3);              /* hgproject.f90:355-357 */
+  for (int n = 0; n < nlev; n++) { level_fill_boundary(gp[n], pmask, pd + 6 * n, pd + 6 * n + 3); level_fill_boundary(p[n], pmask, pd + 6 * n, pd + 6 * n + 3); }
+  vo_ml_restrict_and_fill(nlev, unew, 0, 0, 3, 0, bc, pmask, pd, prm);        /* hgproject.f90:364-366 */
+  for (int n = 0; n < nlev; n++) { free(rh[n].p); free(phi[n].p); free(gphi[n].p); free(coeffs[n].p); }
 }
 
-/* advance_timestep.f90:26-170 on two levels (inviscid): the orchestration of oracle/vo_advance.c with level loops, ml_restrict_and_fill
+/* advance_timestep.f90:26-170 on nlev levels (inviscid): the orchestration of oracle/vo_advance.c with level loops, ml_restrict_and_fill
  * in place of fill_boundary + physbc, the velpred tail of velpred.f90:102-122 and the multilevel projections.  S: [lev] */
 static void fab_new_l(vo_fab *f, const vo_fab *like, int ng, int face_dir, int nc, double val)
 {
@@ -374,13 +389,13 @@ static void fab_new_l(vo_fab *f, const vo_fab *like, int ng, int face_dir, int n
   f->p = (double *)malloc(sizeof(double) * n);
   for (long i = 0; i < n; i++) f->p[i] = val;
 }
-void vo_ml_advance_timestep(vo_state *S, const double *dx, double dt, const vo_bc *bc, const int pmask[3], const int *pd, const vdn_params *prm,
+void vo_ml_advance_timestep(int NL, vo_state *S, const double *dx, double dt, const vo_bc *bc, const int pmask[3], const int *pd, const vdn_params *prm,
                             int proj_type, vo_mgstat st[2])
 {
-  const int dm = 3, nscal = prm->nscal, NL = 2;
-  vo_fab mac_rhs[2], rhohalf[2], umac[6], vel_force[2], scal_force[2], divu[2], sedge[6], sflux[6], uedge[6], uflux[6];
-  vo_fab *mrp[2], *rhp[2], *ump[6], *vfp[2], *sfp2[2], *sep[6], *sfp[6], *uep[6], *ufp[6];
-  vo_fab *uoldp[2], *soldp[2], *unewp[2], *snewp[2], *gpp[2], *pp[2];
+  const int dm = 3, nscal = prm->nscal;
+  vo_fab mac_rhs[VO_MAXLEV], rhohalf[VO_MAXLEV], umac[3 * VO_MAXLEV], vel_force[VO_MAXLEV], scal_force[VO_MAXLEV], divu[VO_MAXLEV], sedge[3 * VO_MAXLEV], sflux[3 * VO_MAXLEV], uedge[3 * VO_MAXLEV], uflux[3 * VO_MAXLEV];
+  vo_fab *mrp[VO_MAXLEV], *rhp[VO_MAXLEV], *ump[3 * VO_MAXLEV], *vfp[VO_MAXLEV], *sfp2[VO_MAXLEV], *sep[3 * VO_MAXLEV], *sfp[3 * VO_MAXLEV], *uep[3 * VO_MAXLEV], *ufp[3 * VO_MAXLEV];
+  vo_fab *uoldp[VO_MAXLEV], *soldp[VO_MAXLEV], *unewp[VO_MAXLEV], *snewp[VO_MAXLEV], *gpp[VO_MAXLEV], *pp[VO_MAXLEV];
   for (int n = 0; n < NL; n++) {
     uoldp[n] = &S[n].uold; soldp[n] = &S[n].sold; unewp[n] = &S[n].unew; snewp[n] = &S[n].snew; gpp[n] = &S[n].gp; pp[n] = &S[n].p;
     fab_new_l(&mac_rhs[n], &S[n].uold, 1, -1, 1, 0.0); mrp[n] = &mac_rhs[n];
@@ -393,8 +408,8 @@ void vo_ml_advance_timestep(vo_state *S, const double *dx, double dt, const vo_b
   vo_ml_restrict_and_fill(NL, vfp, 0, bc[0].extrap_comp, dm, 1, bc, pmask, pd, prm);
   for (int n = 0; n < NL; n++) vo_velpred(&S[n].uold, ump + 3 * n, &vel_force[n], dx + 3 * n, dt, &bc[n], prm);
   for (int d = 0; d < 3; d++) level_fill_boundary(&umac[d], pmask, pd, pd + 3);
-  for (int d = 0; d < 3; d++) { vo_create_umac_grown(&umac[3 + d], &umac[d], d); level_fill_boundary(&umac[3 + d], pmask, pd + 6, pd + 9); }
-  for (int d = 0; d < 3; d++) vo_ml_edge_restriction(&umac[d], &umac[3 + d], d);
+  for (int n = 1; n < NL; n++) for (int d = 0; d < 3; d++) { vo_create_umac_grown(&umac[3 * n + d], &umac[3 * (n - 1) + d], d); level_fill_boundary(&umac[3 * n + d], pmask, pd + 6 * n, pd + 6 * n + 3); }
+  for (int n = NL - 1; n >= 1; n--) for (int d = 0; d < 3; d++) vo_ml_edge_restriction(&umac[3 * (n - 1) + d], &umac[3 * n + d], d);
   /* MAC projection */
   vo_ml_macproject(NL, ump, soldp, mrp, dx, bc, pmask, pd, prm, &st[0]);
   /* scalar advance */
@@ -435,6 +450,6 @@ void vo_ml_advance_timestep(vo_state *S, const double *dx, double dt, const vo_b
     vo_ml_restrict_and_fill(NL, unewp, 0, 0, dm, 0, bc, pmask, pd, prm);
     for (int n = 0; n < NL; n++) for (int d = 0; d < 3; d++) { free(uflux[3 * n + d].p); free(uedge[3 * n + d].p); }
   }
-  vo_ml_hgproject(proj_type, unewp, uoldp, rhp, pp, gpp, dx, dt, bc, pmask, pd, prm, &st[1]);
+  vo_ml_hgproject(NL, proj_type, unewp, uoldp, rhp, pp, gpp, dx, dt, bc, pmask, pd, prm, &st[1]);
   for (int n = 0; n < NL; n++) { free(mac_rhs[n].p); free(rhohalf[n].p); free(vel_force[n].p); for (int d = 0; d < 3; d++) free(umac[3 * n + d].p); }
 }

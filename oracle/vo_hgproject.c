@@ -495,128 +495,158 @@ static void nd_level_from_fab(ndlev *L, const vo_fab *coeffs, const double dx[3]
   for (int k = -1; k <= n[2]; k++) for (int j = -1; j <= n[1]; j++) for (int i = -1; i <= n[0]; i++)
     L->sig[NS(L, i, j, k)] = VF(coeffs, coeffs->lo[0] + i, coeffs->lo[1] + j, coeffs->lo[2] + k, 0);
 }
-/* masked copy of u with one ghost layer: zero outside `keep` (cells lo..hi) or, if invert, zero INSIDE it */
-static void masked_u(vo_fab *out, const vo_fab *u, const int klo[3], const int khi[3], int invert)
+/* copy of u with one ghost layer, zero outside the level's own box (cells blo..bhi; NULL: keep everything) and zero in the cells
+ * covered by the next finer level (clo..chi; NULL: none) */
+static void masked_u(vo_fab *out, const vo_fab *u, const int *blo, const int *bhi, const int *clo, const int *chi)
 {
   vo_fab_init(out, NULL, u->lo, u->hi, 1, NULL, 3);
   out->p = (double *)calloc(vo_size(out), sizeof(double));
   for (int c = 0; c < 3; c++) for (int k = u->lo[2] - 1; k <= u->hi[2] + 1; k++) for (int j = u->lo[1] - 1; j <= u->hi[1] + 1; j++) for (int i = u->lo[0] - 1; i <= u->hi[0] + 1; i++) {
-    int in = i >= klo[0] && i <= khi[0] && j >= klo[1] && j <= khi[1] && k >= klo[2] && k <= khi[2];
-    VF(out, i, j, k, c) = (in != invert) ? VF(u, i, j, k, c) : 0.0;
+    int keep = 1;
+    if (blo && !(i >= blo[0] && i <= bhi[0] && j >= blo[1] && j <= bhi[1] && k >= blo[2] && k <= bhi[2])) keep = 0;
+    if (clo && (i >= clo[0] && i <= chi[0] && j >= clo[1] && j <= chi[1] && k >= clo[2] && k <= chi[2])) keep = 0;
+    VF(out, i, j, k, c) = keep ? VF(u, i, j, k, c) : 0.0;
   }
 }
+#define ND_MAXLEV 4
 typedef struct mlnd {
-  ndlev Lc, Lf;               /* coarse with MASKED sigma; fine */
+  int nlev;
+  ndlev L[ND_MAXLEV];                 /* sig = MASKED sigma (zero in the cells covered by the next finer level) */
+  double *sigfull[ND_MAXLEV];         /* full sigma (relaxation of the levels >= 1; level 0's correction solve takes the fab) */
   int per[3];
-  int clo[3], flo[3];          /* global index of local node 0 on each level */
-  int ilo[3], ihi[3];          /* fine-box node range in COARSE node indices (local to Lc) */
-  unsigned char *cf;           /* fine nodes on the coarse-fine interface */
-  unsigned char *pdir_f;       /* fine physical Dirichlet nodes */
+  int org[ND_MAXLEV][3];              /* global index of local node 0 */
+  int ilo[ND_MAXLEV][3], ihi[ND_MAXLEV][3];   /* node range, local to level n, of the box of level n+1 */
+  unsigned char *cf[ND_MAXLEV];       /* nodes slaved to level n-1 (coarse-fine interface) */
+  unsigned char *pdir[ND_MAXLEV];     /* physical Dirichlet nodes */
 } mlnd;
-#define CFM(M, i, j, k) (M)->cf[NM(&(M)->Lf, i, j, k)]
 
-static void ml_nd_interface(mlnd *M)
+/* trilinear interpolation of the coarse array `cp` (level n-1, local indexing of Lc) at local node (i,j,k) of level n */
+static double ml_nd_interp(const mlnd *M, int n, const ndlev *Lc, const double *cp, int i, int j, int k)
 {
-  ndlev *F = &M->Lf, *Cc = &M->Lc;
-  for (int k = 0; k <= F->n[2]; k++) for (int j = 0; j <= F->n[1]; j++) for (int i = 0; i <= F->n[0]; i++) {
-    if (!CFM(M, i, j, k)) continue;
-    int gi = M->flo[0] + i, gj = M->flo[1] + j, gk = M->flo[2] + k;            /* global fine node */
-    int I = (gi >> 1) - M->clo[0], J = (gj >> 1) - M->clo[1], K = (gk >> 1) - M->clo[2], oi = gi & 1, oj = gj & 1, ok = gk & 1;
-    double s = 0.0;
-    for (int c = 0; c <= ok; c++) for (int b = 0; b <= oj; b++) for (int a = 0; a <= oi; a++) s = s + Cc->phi[NN(Cc, I + a, J + b, K + c)];
-    F->phi[NN(F, i, j, k)] = s * (1.0 / (double)((1 + oi) * (1 + oj) * (1 + ok)));
-  }
+  int gi = M->org[n][0] + i, gj = M->org[n][1] + j, gk = M->org[n][2] + k;
+  int I = (gi >> 1) - M->org[n - 1][0], J = (gj >> 1) - M->org[n - 1][1], K = (gk >> 1) - M->org[n - 1][2], oi = gi & 1, oj = gj & 1, ok = gk & 1;
+  double s = 0.0;
+  for (int c = 0; c <= ok; c++) for (int b = 0; b <= oj; b++) for (int a = 0; a <= oi; a++) s = s + cp[NN(Lc, I + a, J + b, K + c)];
+  return s * (1.0 / (double)((1 + oi) * (1 + oj) * (1 + ok)));
 }
-/* composite residual: F->res (all fine nodes, partial at the interface), C->res; returns the composite max-norm */
+static void ml_nd_interface(mlnd *M, int n)
+{
+  ndlev *F = &M->L[n], *Cc = &M->L[n - 1];
+  for (int k = 0; k <= F->n[2]; k++) for (int j = 0; j <= F->n[1]; j++) for (int i = 0; i <= F->n[0]; i++)
+    if (M->cf[n][NM(F, i, j, k)]) F->phi[NN(F, i, j, k)] = ml_nd_interp(M, n, Cc, Cc->phi, i, j, k);
+}
+/* composite residual: L[n].res on every level (partial sums at the interfaces); returns the composite max-norm */
 static double ml_nd_residual(mlnd *M)
 {
-  ndlev *F = &M->Lf, *Cc = &M->Lc;
   double nrm = 0.0;
-  ml_nd_interface(M);
-  nd_fill_nodes(F, F->phi, M->per);           /* ghost nodes of a box inside the domain: zero (never used: sigma = 0 there) */
-  nd_fill_nodes(Cc, Cc->phi, M->per);
-  memset(F->res, 0, sizeof(double) * (size_t)(F->n[0] + 3) * (F->n[1] + 3) * (F->n[2] + 3));
-  for (int k = 0; k <= F->n[2]; k++) for (int j = 0; j <= F->n[1]; j++) for (int i = 0; i <= F->n[0]; i++) {
-    double r = 0.0;
-    if (!M->pdir_f[NM(F, i, j, k)]) { double Kp, diag; nd_apply(F, F->phi, i, j, k, &Kp, &diag); r = F->b[NN(F, i, j, k)] - Kp; }
-    F->res[NN(F, i, j, k)] = r;
-    if (!CFM(M, i, j, k)) nrm = fmax(nrm, fabs(r));
-  }
   const double wt[3] = { 0.5, 1.0, 0.5 };
-  for (int k = 0; k <= Cc->n[2]; k++) for (int j = 0; j <= Cc->n[1]; j++) for (int i = 0; i <= Cc->n[0]; i++) {
-    double r = 0.0;
-    if (!Cc->dir[NM(Cc, i, j, k)]) {
-      double Kp, diag; nd_apply(Cc, Cc->phi, i, j, k, &Kp, &diag);
-      r = Cc->b[NN(Cc, i, j, k)] - Kp;
-      if (i >= M->ilo[0] && i <= M->ihi[0] && j >= M->ilo[1] && j <= M->ihi[1] && k >= M->ilo[2] && k <= M->ihi[2]) {
-        int fi = 2 * (i + M->clo[0]) - M->flo[0], fj = 2 * (j + M->clo[1]) - M->flo[1], fk = 2 * (k + M->clo[2]) - M->flo[2];   /* local fine node */
-        double s = 0.0;
-        for (int c = -1; c <= 1; c++) for (int b = -1; b <= 1; b++) for (int a = -1; a <= 1; a++) {
-          int ii = fi + a, jj = fj + b, kk = fk + c;
-          if (ii < 0 || ii > F->n[0] || jj < 0 || jj > F->n[1] || kk < 0 || kk > F->n[2]) continue;
-          s = s + (wt[a + 1] * wt[b + 1] * wt[c + 1]) * F->res[NN(F, ii, jj, kk)];
+  for (int n = 1; n < M->nlev; n++) ml_nd_interface(M, n);
+  for (int n = 0; n < M->nlev; n++) nd_fill_nodes(&M->L[n], M->L[n].phi, M->per);
+  for (int n = M->nlev - 1; n >= 0; n--) {
+    ndlev *L = &M->L[n];
+    const int has_fine = n < M->nlev - 1;
+    memset(L->res, 0, sizeof(double) * (size_t)(L->n[0] + 3) * (L->n[1] + 3) * (L->n[2] + 3));
+    for (int k = 0; k <= L->n[2]; k++) for (int j = 0; j <= L->n[1]; j++) for (int i = 0; i <= L->n[0]; i++) {
+      double r = 0.0;
+      if (!M->pdir[n][NM(L, i, j, k)]) {
+        double Kp, diag; nd_apply(L, L->phi, i, j, k, &Kp, &diag);
+        r = L->b[NN(L, i, j, k)] - Kp;
+        if (has_fine && i >= M->ilo[n][0] && i <= M->ihi[n][0] && j >= M->ilo[n][1] && j <= M->ihi[n][1] && k >= M->ilo[n][2] && k <= M->ihi[n][2]) {
+          const ndlev *F = &M->L[n + 1];
+          int fi = 2 * (i + M->org[n][0]) - M->org[n + 1][0], fj = 2 * (j + M->org[n][1]) - M->org[n + 1][1], fk = 2 * (k + M->org[n][2]) - M->org[n + 1][2];
+          double s = 0.0;
+          for (int c = -1; c <= 1; c++) for (int b = -1; b <= 1; b++) for (int a = -1; a <= 1; a++) {
+            int ii = fi + a, jj = fj + b, kk = fk + c;
+            if (ii < 0 || ii > F->n[0] || jj < 0 || jj > F->n[1] || kk < 0 || kk > F->n[2]) continue;
+            s = s + (wt[a + 1] * wt[b + 1] * wt[c + 1]) * F->res[NN(F, ii, jj, kk)];
+          }
+          r = r + s * 0.125;
         }
-        r = r + s * 0.125;
       }
+      L->res[NN(L, i, j, k)] = r;
+      int skip = M->cf[n] && M->cf[n][NM(L, i, j, k)];
+      if (has_fine && i > M->ilo[n][0] && i < M->ihi[n][0] && j > M->ilo[n][1] && j < M->ihi[n][1] && k > M->ilo[n][2] && k < M->ihi[n][2]) skip = 1;
+      if (!skip) nrm = fmax(nrm, fabs(r));
     }
-    Cc->res[NN(Cc, i, j, k)] = r;
-    int inside = i > M->ilo[0] && i < M->ihi[0] && j > M->ilo[1] && j < M->ihi[1] && k > M->ilo[2] && k < M->ihi[2];
-    if (!inside) nrm = fmax(nrm, fabs(r));
   }
   return nrm;
+}
+/* phi_n += e (local node array of level n), and its trilinear prolongation on every finer level (not on physical Dirichlet nodes) */
+static void ml_nd_apply_correction(mlnd *M, int n, double *e, double **scratch)
+{
+  ndlev *L = &M->L[n];
+  for (int k = 0; k <= L->n[2]; k++) for (int j = 0; j <= L->n[1]; j++) for (int i = 0; i <= L->n[0]; i++)
+    L->phi[NN(L, i, j, k)] = L->phi[NN(L, i, j, k)] + e[NN(L, i, j, k)];
+  const double *src = e;
+  for (int m = n + 1; m < M->nlev; m++) {
+    ndlev *F = &M->L[m];
+    memset(scratch[m], 0, sizeof(double) * (size_t)(F->n[0] + 3) * (F->n[1] + 3) * (F->n[2] + 3));
+    for (int k = 0; k <= F->n[2]; k++) for (int j = 0; j <= F->n[1]; j++) for (int i = 0; i <= F->n[0]; i++) {
+      if (M->pdir[m][NM(F, i, j, k)]) continue;
+      const double v = ml_nd_interp(M, m, &M->L[m - 1], src, i, j, k);
+      scratch[m][NN(F, i, j, k)] = v;
+      F->phi[NN(F, i, j, k)] = F->phi[NN(F, i, j, k)] + v;
+    }
+    src = scratch[m];
+  }
 }
 
 /* rh[lev] nodal (ng 1; in: extra source, normally 0), phi[lev] nodal (ng 1, in/out), coeffs[lev] cells (ng 1, ghost 0 outside the
  * level), u[lev] cells with >= 1 ghost (wall ghosts zeroed by create_uvec); dx: [lev*3+d]; ellbc per level/box */
-int vo_ml_nd_solve(vo_fab **rh, vo_fab **phi, vo_fab **coeffs, vo_fab **u, const double *dx, const int ellbc[2][3][2], const int pmask[3],
+int vo_ml_nd_solve(int nlev, vo_fab **rh, vo_fab **phi, vo_fab **coeffs, vo_fab **u, const double *dx, const int ellbc[][3][2], const int pmask[3],
                    double rel_eps, double abs_eps, int max_iter, const vdn_params *prm, vo_mgstat *st)
 {
+  if (nlev < 2 || nlev > ND_MAXLEV) { fprintf(stderr, "vo_ml_nd_solve: 2..%d levels\n", ND_MAXLEV); abort(); }
   mlnd M; memset(&M, 0, sizeof M);
-  for (int d = 0; d < 3; d++) { M.per[d] = 0; (void)pmask; M.clo[d] = coeffs[0]->lo[d]; M.flo[d] = coeffs[1]->lo[d]; }
-  const int *flo = coeffs[1]->lo, *fhi = coeffs[1]->hi;
-  int klo[3], khi[3];
-  for (int d = 0; d < 3; d++) { klo[d] = flo[d] / 2; khi[d] = fhi[d] / 2; M.ilo[d] = klo[d] - M.clo[d]; M.ihi[d] = khi[d] + 1 - M.clo[d]; }
-  /* coarse level with masked sigma; full-sigma fab stays in coeffs[0] for the correction solve */
-  vo_fab cm; vo_fab_init(&cm, NULL, coeffs[0]->lo, coeffs[0]->hi, 1, NULL, 1); cm.p = (double *)malloc(sizeof(double) * vo_size(&cm));
-  memcpy(cm.p, coeffs[0]->p, sizeof(double) * vo_size(&cm));
-  for (int k = klo[2]; k <= khi[2]; k++) for (int j = klo[1]; j <= khi[1]; j++) for (int i = klo[0]; i <= khi[0]; i++) VF(&cm, i, j, k, 0) = 0.0;
-  nd_level_from_fab(&M.Lc, &cm, dx); nd_set_mask(&M.Lc, ellbc[0]);
-  nd_level_from_fab(&M.Lf, coeffs[1], dx + 3); nd_set_mask(&M.Lf, ellbc[1]);
-  ndlev *F = &M.Lf, *Cc = &M.Lc;
-  long nfn = (long)(F->n[0] + 1) * (F->n[1] + 1) * (F->n[2] + 1);
-  M.cf = (unsigned char *)calloc(nfn, 1); M.pdir_f = (unsigned char *)malloc(nfn);
-  memcpy(M.pdir_f, F->dir, nfn);
-  for (int k = 0; k <= F->n[2]; k++) for (int j = 0; j <= F->n[1]; j++) for (int i = 0; i <= F->n[0]; i++) {
-    int q[3] = { i, j, k }, onface = 0;
-    for (int d = 0; d < 3; d++) { if (q[d] == 0 && ellbc[1][d][0] == VDN_BC_INT) onface = 1; if (q[d] == F->n[d] && ellbc[1][d][1] == VDN_BC_INT) onface = 1; }
-    if (onface && !M.pdir_f[NM(F, i, j, k)]) { M.cf[NM(F, i, j, k)] = 1; F->dir[NM(F, i, j, k)] = 1; }      /* fixed during the fine relaxation */
-  }
-  /* right-hand sides: rh += D u with the masked velocities (vo_nd_divu), b = -rh */
-  vo_fab uf, uc;
-  masked_u(&uf, u[1], flo, fhi, 0);                    /* fine: zero outside the fine box */
-  masked_u(&uc, u[0], klo, khi, 1);                    /* coarse: zero in the covered cells */
-  vo_nd_divu(&uf, rh[1], dx + 3, ellbc[1]);
-  vo_nd_divu(&uc, rh[0], dx, ellbc[0]);
-  free(uf.p); free(uc.p);
-  double bnorm = 0.0;
-  for (int n = 0; n < 2; n++) {
-    ndlev *L = n ? F : Cc;
-    const unsigned char *pd = n ? M.pdir_f : Cc->dir;
+  M.nlev = nlev; (void)pmask;
+  double *scratch[ND_MAXLEV] = { 0 };
+  for (int n = 0; n < nlev; n++) {
+    for (int d = 0; d < 3; d++) M.org[n][d] = coeffs[n]->lo[d];
+    const int has_fine = n < nlev - 1;
+    int klo[3] = { 0, 0, 0 }, khi[3] = { -1, -1, -1 };
+    if (has_fine) for (int d = 0; d < 3; d++) { klo[d] = coeffs[n + 1]->lo[d] / 2; khi[d] = coeffs[n + 1]->hi[d] / 2; M.ilo[n][d] = klo[d] - M.org[n][d]; M.ihi[n][d] = khi[d] + 1 - M.org[n][d]; }
+    /* masked sigma level; the full sigma kept aside */
+    vo_fab cm; vo_fab_init(&cm, NULL, coeffs[n]->lo, coeffs[n]->hi, 1, NULL, 1); cm.p = (double *)malloc(sizeof(double) * vo_size(&cm));
+    memcpy(cm.p, coeffs[n]->p, sizeof(double) * vo_size(&cm));
+    for (int k = klo[2]; k <= khi[2]; k++) for (int j = klo[1]; j <= khi[1]; j++) for (int i = klo[0]; i <= khi[0]; i++) VF(&cm, i, j, k, 0) = 0.0;
+    ndlev *L = &M.L[n];
+    nd_level_from_fab(L, &cm, dx + 3 * n); nd_set_mask(L, ellbc[n]);
+    free(cm.p);
+    long ns = (long)(L->n[0] + 2) * (L->n[1] + 2) * (L->n[2] + 2), nn = (long)(L->n[0] + 3) * (L->n[1] + 3) * (L->n[2] + 3);
+    M.sigfull[n] = (double *)malloc(sizeof(double) * ns);
+    for (int k = -1; k <= L->n[2]; k++) for (int j = -1; j <= L->n[1]; j++) for (int i = -1; i <= L->n[0]; i++)
+      M.sigfull[n][NS(L, i, j, k)] = VF(coeffs[n], coeffs[n]->lo[0] + i, coeffs[n]->lo[1] + j, coeffs[n]->lo[2] + k, 0);
+    scratch[n] = (double *)calloc(nn, sizeof(double));
+    long nnm = (long)(L->n[0] + 1) * (L->n[1] + 1) * (L->n[2] + 1);
+    M.pdir[n] = (unsigned char *)malloc(nnm); memcpy(M.pdir[n], L->dir, nnm);
+    M.cf[n] = NULL;
+    if (n >= 1) {
+      M.cf[n] = (unsigned char *)calloc(nnm, 1);
+      for (int k = 0; k <= L->n[2]; k++) for (int j = 0; j <= L->n[1]; j++) for (int i = 0; i <= L->n[0]; i++) {
+        int q[3] = { i, j, k }, onface = 0;
+        for (int d = 0; d < 3; d++) { if (q[d] == 0 && ellbc[n][d][0] == VDN_BC_INT) onface = 1; if (q[d] == L->n[d] && ellbc[n][d][1] == VDN_BC_INT) onface = 1; }
+        if (onface && !M.pdir[n][NM(L, i, j, k)]) { M.cf[n][NM(L, i, j, k)] = 1; L->dir[NM(L, i, j, k)] = 1; }      /* fixed during the relaxation */
+      }
+    }
+    /* right-hand side: rh += D u with the masked velocity (vo_nd_divu), b = -rh */
+    vo_fab um;
+    masked_u(&um, u[n], n >= 1 ? coeffs[n]->lo : NULL, n >= 1 ? coeffs[n]->hi : NULL, has_fine ? klo : NULL, has_fine ? khi : NULL);
+    vo_nd_divu(&um, rh[n], dx + 3 * n, ellbc[n]);
+    free(um.p);
     for (int k = 0; k <= L->n[2]; k++) for (int j = 0; j <= L->n[1]; j++) for (int i = 0; i <= L->n[0]; i++) {
       double r = VF(rh[n], rh[n]->lo[0] + i, rh[n]->lo[1] + j, rh[n]->lo[2] + k, 0);
-      if (pd[NM(L, i, j, k)]) r = 0.0;
+      if (M.pdir[n][NM(L, i, j, k)]) r = 0.0;
       L->b[NN(L, i, j, k)] = -r;
-      L->phi[NN(L, i, j, k)] = pd[NM(L, i, j, k)] ? 0.0 : VF(phi[n], phi[n]->lo[0] + i, phi[n]->lo[1] + j, phi[n]->lo[2] + k, 0);
+      L->phi[NN(L, i, j, k)] = M.pdir[n][NM(L, i, j, k)] ? 0.0 : VF(phi[n], phi[n]->lo[0] + i, phi[n]->lo[1] + j, phi[n]->lo[2] + k, 0);
     }
   }
-  /* norm of the composite right-hand side = the composite residual of phi = 0 ... use the residual of the initial guess's
-   * right-hand side: evaluate with phi = 0 */
+  /* norm of the composite right-hand side = composite residual of phi = 0 */
+  double bnorm;
   {
-    double *sf = F->phi, *sc = Cc->phi;
-    long nnf = (long)(F->n[0] + 3) * (F->n[1] + 3) * (F->n[2] + 3), nnc = (long)(Cc->n[0] + 3) * (Cc->n[1] + 3) * (Cc->n[2] + 3);
-    F->phi = (double *)calloc(nnf, sizeof(double)); Cc->phi = (double *)calloc(nnc, sizeof(double));
+    double *save[ND_MAXLEV];
+    for (int n = 0; n < nlev; n++) { ndlev *L = &M.L[n]; save[n] = L->phi; L->phi = (double *)calloc((size_t)(L->n[0] + 3) * (L->n[1] + 3) * (L->n[2] + 3), sizeof(double)); }
     bnorm = ml_nd_residual(&M);
-    free(F->phi); free(Cc->phi); F->phi = sf; Cc->phi = sc;
+    for (int n = 0; n < nlev; n++) { free(M.L[n].phi); M.L[n].phi = save[n]; }
   }
   /* scratch fabs for the coarse correction solve */
   vo_fab er, ee; int nd1[3] = { 1, 1, 1 };
@@ -624,56 +654,50 @@ int vo_ml_nd_solve(vo_fab **rh, vo_fab **phi, vo_fab **coeffs, vo_fab **u, const
   vo_fab_init(&ee, NULL, coeffs[0]->lo, coeffs[0]->hi, 1, nd1, 1); ee.p = (double *)calloc(vo_size(&ee), sizeof(double));
   int it = 0, conv = (bnorm == 0.0); double rn = 0.0;
   const int nu_f = prm->hg_nu1 + prm->hg_nu2;
+  ndlev *Cc = &M.L[0];
   while (!conv) {
     rn = ml_nd_residual(&M);
     if (rn <= rel_eps * bnorm || rn <= abs_eps) { conv = 1; break; }
     if (it >= max_iter) break;
-    /* coarse correction: K_c e = r_c, one V-cycle (vo_nd_solve takes rh with b = -rh) */
+    /* coarse correction: K_0 e = r_0, one V-cycle (vo_nd_solve takes rh with b = -rh) */
     memset(ee.p, 0, sizeof(double) * vo_size(&ee));
     for (int k = 0; k <= Cc->n[2]; k++) for (int j = 0; j <= Cc->n[1]; j++) for (int i = 0; i <= Cc->n[0]; i++)
       VF(&er, er.lo[0] + i, er.lo[1] + j, er.lo[2] + k, 0) = -Cc->res[NN(Cc, i, j, k)];
     vo_mgstat cs;
     vo_nd_solve(&er, &ee, coeffs[0], NULL, dx, ellbc[0], pmask, 0.0, -1.0, -1, prm->hg_nu1, prm->hg_nu2, prm->hg_nub, prm->hg_omega, &cs);
     for (int k = 0; k <= Cc->n[2]; k++) for (int j = 0; j <= Cc->n[1]; j++) for (int i = 0; i <= Cc->n[0]; i++)
-      Cc->phi[NN(Cc, i, j, k)] = Cc->phi[NN(Cc, i, j, k)] + VF(&ee, ee.lo[0] + i, ee.lo[1] + j, ee.lo[2] + k, 0);
-    for (int k = 0; k <= F->n[2]; k++) for (int j = 0; j <= F->n[1]; j++) for (int i = 0; i <= F->n[0]; i++) {
-      if (M.pdir_f[NM(F, i, j, k)]) continue;
-      int gi = M.flo[0] + i, gj = M.flo[1] + j, gk = M.flo[2] + k;
-      int I = (gi >> 1), J = (gj >> 1), K = (gk >> 1), oi = gi & 1, oj = gj & 1, ok = gk & 1;
-      double s = 0.0;
-      for (int c = 0; c <= ok; c++) for (int b = 0; b <= oj; b++) for (int a = 0; a <= oi; a++) s = s + VF(&ee, I + a, J + b, K + c, 0);
-      F->phi[NN(F, i, j, k)] = F->phi[NN(F, i, j, k)] + s * (1.0 / (double)((1 + oi) * (1 + oj) * (1 + ok)));
-    }
-    /* fine relaxation of the correction equation K_f e = r_f, interface nodes fixed (e = 0) */
-    (void)ml_nd_residual(&M);
-    {
-      double *sphi = F->phi, *sb = F->b;
+      scratch[0][NN(Cc, i, j, k)] = VF(&ee, ee.lo[0] + i, ee.lo[1] + j, ee.lo[2] + k, 0);
+    ml_nd_apply_correction(&M, 0, scratch[0], scratch);
+    /* relaxation of the correction equation K_n e = r_n on the finer levels, coarsest first; interface nodes fixed (e = 0) */
+    for (int n = 1; n < nlev; n++) {
+      ndlev *F = &M.L[n];
+      (void)ml_nd_residual(&M);
+      double *sphi = F->phi, *sb = F->b, *ssig = F->sig;
       long nnf = (long)(F->n[0] + 3) * (F->n[1] + 3) * (F->n[2] + 3);
       double *e = (double *)calloc(nnf, sizeof(double)), *rb = (double *)malloc(sizeof(double) * nnf);
       memcpy(rb, F->res, sizeof(double) * nnf);
-      F->phi = e; F->b = rb;
-      nd_jacobi(F, M.per, nu_f, prm->hg_omega);           /* swaps F->phi / F->tmp internally */
+      F->phi = e; F->b = rb; F->sig = M.sigfull[n];
+      nd_jacobi(F, M.per, nu_f, prm->hg_omega);           /* ping-pongs between F->phi and F->tmp */
       e = F->phi;
-      F->b = sb;
-      for (int k = 0; k <= F->n[2]; k++) for (int j = 0; j <= F->n[1]; j++) for (int i = 0; i <= F->n[0]; i++)
-        sphi[NN(F, i, j, k)] = sphi[NN(F, i, j, k)] + e[NN(F, i, j, k)];
-      /* nd_jacobi ping-pongs between phi and tmp: keep the two scratch buffers as phi/tmp owners consistent */
+      F->b = sb; F->sig = ssig;
       double *other = F->tmp;
       F->phi = sphi;
+      /* after the sweeps one of the two scratch buffers holds e and the other is F->tmp: keep them apart from sphi */
+      ml_nd_apply_correction(&M, n, e, scratch);
       if (other == sphi) { F->tmp = e; } else { free(e); }
       free(rb);
     }
     it++;
   }
-  ml_nd_interface(&M);
-  nd_fill_nodes(F, F->phi, M.per); nd_fill_nodes(Cc, Cc->phi, M.per);
-  for (int n = 0; n < 2; n++) {
-    ndlev *L = n ? F : Cc;
+  for (int n = 1; n < nlev; n++) ml_nd_interface(&M, n);
+  for (int n = 0; n < nlev; n++) {
+    ndlev *L = &M.L[n];
+    nd_fill_nodes(L, L->phi, M.per);
     for (int k = -1; k <= L->n[2] + 1; k++) for (int j = -1; j <= L->n[1] + 1; j++) for (int i = -1; i <= L->n[0] + 1; i++)
       VF(phi[n], phi[n]->lo[0] + i, phi[n]->lo[1] + j, phi[n]->lo[2] + k, 0) = L->phi[NN(L, i, j, k)];
   }
   if (st) { st->cycles = it; st->res0 = bnorm; st->res = rn; }
-  free(er.p); free(ee.p); free(cm.p); free(M.cf); free(M.pdir_f);
-  nd_free(F); nd_free(Cc);
+  free(er.p); free(ee.p);
+  for (int n = 0; n < nlev; n++) { free(M.cf[n]); free(M.pdir[n]); free(M.sigfull[n]); free(scratch[n]); nd_free(&M.L[n]); }
   return conv ? 0 : 1;
 }

@@ -223,40 +223,46 @@ class Sim:
         self.time += self.dt
 
 
-class Sim2L:
-    """two-level (fixed grids, one box per level) bubble run on the CPU oracle: what src/varden.f90's time loop does around
-    advance_timestep for nlevs = 2 (ghost fills by ml_restrict_and_fill, dt = min over levels of estdt)."""
+class SimML:
+    """multi-level (fixed properly nested grids, one box per level) bubble run on the CPU oracle: what src/varden.f90's time loop does
+    around advance_timestep for nlevs > 1 (ghost fills by ml_restrict_and_fill, dt = min over levels of estdt).
+    boxes: [(lo, hi)] of levels 1.. in each level's own index space."""
 
-    def __init__(self, nc, flo, fhi, phys, prm=None, prob_type=1, grav=-9.8, init_shrink=0.1):
+    def __init__(self, nc, boxes, phys, prm=None, prob_type=1, grav=-9.8, init_shrink=0.1):
         L = lib()
         self.prm = prm or default_params()
         self.prm.prob_type = prob_type
         self.nc = nc
+        self.nlev = NL = 1 + len(boxes)
         ns = self.prm.nscal
-        los, his = [(0, 0, 0), tuple(flo)], [(nc - 1,) * 3, tuple(fhi)]
-        physf = [[phys[d][0] if flo[d] == 0 else INTERIOR, phys[d][1] if fhi[d] == 2 * nc - 1 else INTERIOR] for d in range(3)]
-        self.bcs = (CBc * 2)(make_bc(phys, 3, ns), make_bc(physf, 3, ns))
+        los, his = [(0, 0, 0)] + [tuple(b[0]) for b in boxes], [(nc - 1,) * 3] + [tuple(b[1]) for b in boxes]
+        bcl, pd, self.dxl = [make_bc(phys, 3, ns)], [0, 0, 0, nc - 1, nc - 1, nc - 1], [[1.0 / nc] * 3]
+        for n in range(1, NL):
+            nd = nc << n
+            bcl.append(make_bc([[phys[d][0] if los[n][d] == 0 else INTERIOR, phys[d][1] if his[n][d] == nd - 1 else INTERIOR] for d in range(3)], 3, ns))
+            pd += [0, 0, 0, nd - 1, nd - 1, nd - 1]
+            self.dxl.append([1.0 / nd] * 3)
+        self.bcs = (CBc * NL)(*bcl)
         self.pmask = ivec([0, 0, 0])
-        self.pd = ivec([0, 0, 0, nc - 1, nc - 1, nc - 1, 0, 0, 0, 2 * nc - 1, 2 * nc - 1, 2 * nc - 1])
-        self.dxl = [[1.0 / nc] * 3, [0.5 / nc] * 3]
-        self.dx = (C.c_double * 6)(*(self.dxl[0] + self.dxl[1]))
-        mk = lambda ng, ncomp, nodal=(0, 0, 0): [Fab(los[n], his[n], ng, ncomp, nodal) for n in range(2)]   # noqa: E731
+        self.pd = ivec(pd)
+        self.dx = (C.c_double * (3 * NL))(*sum(self.dxl, []))
+        mk = lambda ng, ncomp, nodal=(0, 0, 0): [Fab(los[n], his[n], ng, ncomp, nodal) for n in range(NL)]   # noqa: E731
         self.uold, self.sold, self.unew, self.snew = mk(3, 3), mk(3, ns), mk(3, 3), mk(3, ns)
         self.gp, self.p = mk(1, 3), mk(1, 1, (1, 1, 1))
         self.ext_vel_force, self.ext_scal_force = mk(1, 3), mk(1, ns)
-        for n in range(2):
+        for n in range(NL):
             self.ext_vel_force[n].a[..., 2] = grav
             L.vo_initdata(self.uold[n].ref, self.sold[n].ref, dvec(self.dxl[n]), prob_type)
         self.mgstat = (CMgStat * 2)()
         self.time, self.istep = 0.0, 0
         self.fill_state_ghosts()
-        for n in range(2):
+        for n in range(NL):
             self.unew[n].a[...] = self.uold[n].a
             self.snew[n].a[...] = self.sold[n].a
         self.dt = self.estdt(1.0e20) * init_shrink
 
     def _rf(self, mfs, icomp, bcomp, nc, same=0):
-        lib().vo_ml_restrict_and_fill(2, fab_ptr_array(mfs), icomp, bcomp, nc, same, self.bcs, self.pmask, self.pd, C.byref(self.prm))
+        lib().vo_ml_restrict_and_fill(self.nlev, fab_ptr_array(mfs), icomp, bcomp, nc, same, self.bcs, self.pmask, self.pd, C.byref(self.prm))
 
     def fill_state_ghosts(self):
         self._rf(self.uold, 0, 0, 3)
@@ -266,19 +272,26 @@ class Sim2L:
     def estdt(self, dtold):
         L = lib()
         return min(L.vo_estdt(self.uold[n].ref, self.sold[n].ref, self.gp[n].ref, self.ext_vel_force[n].ref, dvec(self.dxl[n]),
-                              C.c_double(dtold), C.byref(self.prm)) for n in range(2))
+                              C.c_double(dtold), C.byref(self.prm)) for n in range(self.nlev))
 
     def step(self):
         self.istep += 1
         self.fill_state_ghosts()
         if self.istep > 1:
             self.dt = self.estdt(self.dt)
-        S = (CState * 2)()
-        for n in range(2):
+        S = (CState * self.nlev)()
+        for n in range(self.nlev):
             for k in ("uold", "sold", "unew", "snew", "gp", "p", "ext_vel_force", "ext_scal_force"):
                 setattr(S[n], k, getattr(self, k)[n].c)
-        lib().vo_ml_advance_timestep(S, self.dx, C.c_double(self.dt), self.bcs, self.pmask, self.pd, C.byref(self.prm), REGULAR_TIMESTEP, self.mgstat)
-        for n in range(2):
+        lib().vo_ml_advance_timestep(self.nlev, S, self.dx, C.c_double(self.dt), self.bcs, self.pmask, self.pd, C.byref(self.prm), REGULAR_TIMESTEP, self.mgstat)
+        for n in range(self.nlev):
             self.uold[n].valid()[...] = self.unew[n].valid()
             self.sold[n].valid()[...] = self.snew[n].valid()
         self.time += self.dt
+
+
+class Sim2L(SimML):
+    """two levels: SimML with one fine box"""
+
+    def __init__(self, nc, flo, fhi, phys, **kw):
+        SimML.__init__(self, nc, [(flo, fhi)], phys, **kw)

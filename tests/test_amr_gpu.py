@@ -18,7 +18,8 @@ WALLS = [[15, 15]] * 3
 class Amr2:
     """coarse level: one box [0,nc)^3; fine level: the box flo..fhi (fine indices), optionally split in x for the GPU"""
 
-    def __init__(self, nc, flo, fhi, phys=WALLS, split=1, seed=0):
+    def __init__(self, nc, flo, fhi, phys=WALLS, split=1, seed=0, finer=()):
+        """finer: (lo, hi) boxes of the levels 2.. (one box each, own index space)"""
         from oracle import voracle as vo
         from varden_amd import boxlib as bl
         from varden_amd.capi import default_params
@@ -28,22 +29,29 @@ class Amr2:
         bl.initialize(self.prm, 0, 1, 0)
         self.rng = np.random.default_rng(seed)
         self.clo, self.chi = (0, 0, 0), (nc - 1,) * 3
-        pdf = ((0, 0, 0), (2 * nc - 1,) * 3)
+        self.los = [self.clo, tuple(flo)] + [tuple(b[0]) for b in finer]
+        self.his = [self.chi, tuple(fhi)] + [tuple(b[1]) for b in finer]
+        self.nlev = NL = len(self.los)
+        pds = [((0, 0, 0), ((nc << n) - 1,) * 3) for n in range(NL)]
         nx = (fhi[0] - flo[0] + 1) // split
         self.fboxes = [((flo[0] + s * nx, flo[1], flo[2]), (flo[0] + (s + 1) * nx - 1, fhi[1], fhi[2])) for s in range(split)]
-        self.mla = bl.MLLayout([(self.clo, self.chi), pdf], [[(self.clo, self.chi)], self.fboxes], rr=[(2, 2, 2)])
+        self.mla = bl.MLLayout(pds, [[(self.clo, self.chi)], self.fboxes] + [[(tuple(b[0]), tuple(b[1]))] for b in finer], rr=[(2, 2, 2)] * (NL - 1))
         self.bct = bl.BCTower(self.mla, phys)
-        self.dx = [[1.0 / nc] * 3, [0.5 / nc] * 3]
+        self.dx = [[1.0 / (nc << n)] * 3 for n in range(NL)]
         # oracle side: one box per level
-        physf = [[phys[d][0] if flo[d] == 0 else 0, phys[d][1] if fhi[d] == 2 * nc - 1 else 0] for d in range(3)]
-        self.obcs = (vo.CBc * 2)(vo.make_bc(phys, 3, 2), vo.make_bc(physf, 3, 2))
+        bcl, opd = [vo.make_bc(phys, 3, 2)], [0, 0, 0, nc - 1, nc - 1, nc - 1]
+        for n in range(1, NL):
+            nd = nc << n
+            bcl.append(vo.make_bc([[phys[d][0] if self.los[n][d] == 0 else 0, phys[d][1] if self.his[n][d] == nd - 1 else 0] for d in range(3)], 3, 2))
+            opd += [0, 0, 0, nd - 1, nd - 1, nd - 1]
+        self.obcs = (vo.CBc * NL)(*bcl)
         self.opm = vo.ivec([0, 0, 0])
-        self.opd = vo.ivec([0, 0, 0, nc - 1, nc - 1, nc - 1, 0, 0, 0, 2 * nc - 1, 2 * nc - 1, 2 * nc - 1])
-        self.odx = (C.c_double * 6)(*(self.dx[0] + self.dx[1]))
+        self.opd = vo.ivec(opd)
+        self.odx = (C.c_double * (3 * NL))(*sum(self.dx, []))
         self._mfs = []
 
     def ofabs(self, ng, nc, nodal=(0, 0, 0)):
-        return [self.vo.Fab(self.clo, self.chi, ng, nc, nodal), self.vo.Fab(self.flo, self.fhi, ng, nc, nodal)]
+        return [self.vo.Fab(self.los[n], self.his[n], ng, nc, nodal) for n in range(self.nlev)]
 
     def gmfs(self, ofabs):
         """GPU multifabs (per level) holding the oracle fabs' contents (the fine one cut into the GPU's boxes)"""
@@ -119,19 +127,21 @@ def test_transfer_operators_bits(gpu, oracle):
 
 def _mac_case(K, vo):
     L = vo.lib()
+    NL = K.nlev
     rho = K.ofabs(3, 2)
-    for lev in range(2):
+    for lev in range(NL):
         K.smooth(rho[lev], lev, 0.2, 1.5)
-    L.vo_ml_restrict_and_fill(2, vo.fab_ptr_array(rho), 0, 3, 2, 0, K.obcs, K.opm, K.opd, C.byref(K.prm))
+    L.vo_ml_restrict_and_fill(NL, vo.fab_ptr_array(rho), 0, 3, 2, 0, K.obcs, K.opm, K.opd, C.byref(K.prm))
     um = []
-    for lev in range(2):
+    for lev in range(NL):
         for d in range(3):
             f = K.ofabs(1, 1, tuple(1 if t == d else 0 for t in range(3)))[lev]
             K.smooth(f, lev, 1.0 + 0.1 * d)
             um.append(f)
     for d in range(3):                                    # wall-normal MAC velocity zero on the domain boundary; levels consistent
         sl = [slice(None)] * 4; sl[d] = 1; um[d].a[tuple(sl)] = 0.0; sl[d] = -2; um[d].a[tuple(sl)] = 0.0
-        L.vo_ml_edge_restriction(um[d].ref, um[3 + d].ref, d)
+        for lev in range(NL - 1, 0, -1):
+            L.vo_ml_edge_restriction(um[3 * (lev - 1) + d].ref, um[3 * lev + d].ref, d)
     rhs = K.ofabs(1, 1)
     return rho, um, rhs
 
@@ -187,7 +197,7 @@ def test_ml_hgproject(gpu, oracle, split):
     gun, guo, grh, ggp, gpp = K.gmfs(unew), K.gmfs(uold), K.gmfs(rhoh), K.gmfs(gp), K.gmfs(p)
     dt = 0.01
     st = vo.CMgStat()
-    L.vo_ml_hgproject(vo.REGULAR_TIMESTEP, vo.fab_ptr_array(unew), vo.fab_ptr_array(uold), vo.fab_ptr_array(rhoh), vo.fab_ptr_array(p), vo.fab_ptr_array(gp),
+    L.vo_ml_hgproject(2, vo.REGULAR_TIMESTEP, vo.fab_ptr_array(unew), vo.fab_ptr_array(uold), vo.fab_ptr_array(rhoh), vo.fab_ptr_array(p), vo.fab_ptr_array(gp),
                       K.odx, C.c_double(dt), K.obcs, K.opm, K.opd, C.byref(K.prm), C.byref(st))
     adv.hgproject(vo.REGULAR_TIMESTEP, K.mla, gun, guo, grh, gpp, ggp, K.dx, dt, K.bct, 3 + 2 + 1)
     it_gpu = adv.last_solver_stats("hg")[0]
@@ -232,4 +242,85 @@ def test_two_level_advance(gpu, oracle, split):
     s0 = G.snew[0].to_numpy()[3:-3, 3:-3, 3:-3, 0][4:12, 4:12, 4:12]
     avg = s1.reshape(8, 2, 8, 2, 8, 2).mean(axis=(1, 3, 5))
     assert np.abs(s0 - avg).max() <= 1e-13
+    G.close()
+
+
+FINER = [((24, 24, 24), (39, 39, 39))]        # level 2 of the three-level cases: 16^3 cells over the centre of level 1
+
+
+def test_three_level_macproject(gpu, oracle):
+    """the composite MAC solve on three nested levels (precursor of BASELINE.json configs[4]): same FAC iteration count as the
+    oracle, MAC velocities to 1e-9, discretely divergence-free on every level"""
+    from varden_amd import advance as adv
+    vo = oracle
+    K = Amr2(16, (8, 8, 8), (23, 23, 23), finer=FINER)
+    L = vo.lib()
+    rho, um, rhs = _mac_case(K, vo)
+    grho, grhs = K.gmfs(rho), K.gmfs(rhs)
+    gum = [K.gmfs([um[3 * lev + d] for lev in range(3)]) for d in range(3)]               # gum[d][lev]
+    st = vo.CMgStat()
+    L.vo_ml_macproject(3, vo.fab_ptr_array(um), vo.fab_ptr_array(rho), vo.fab_ptr_array(rhs), K.odx, K.obcs, K.opm, K.opd, C.byref(K.prm), C.byref(st))
+    adv.macproject(K.mla, [[gum[d][lev] for d in range(3)] for lev in range(3)], grho, grhs, K.dx, K.bct, 3 + 2 + 1)
+    it_gpu = adv.last_solver_stats("mac")[0]
+    assert st.cycles < 40 and it_gpu == st.cycles, (it_gpu, st.cycles)
+    scale = max(np.abs(m.a).max() for m in um)
+    got = [[K.gather(gum[d][lev], um[3 * lev + d]) for d in range(3)] for lev in range(3)]
+    for lev in range(3):
+        for d in range(3):
+            a, b = got[lev][d][1:-1, 1:-1, 1:-1], um[3 * lev + d].a[1:-1, 1:-1, 1:-1]
+            assert np.abs(a - b).max() <= 1e-9 * scale, "umac level %d dir %d differs by %.3e" % (lev, d, np.abs(a - b).max())
+        assert np.abs(_div(got[lev], K.dx[lev][0])).max() <= 1e-8 * st.res0, lev
+    K.close()
+
+
+def test_three_level_hgproject(gpu, oracle):
+    from varden_amd import advance as adv
+    vo = oracle
+    K = Amr2(16, (8, 8, 8), (23, 23, 23), finer=FINER)
+    L = vo.lib()
+    unew, uold, rhoh, gp, p = K.ofabs(3, 3), K.ofabs(3, 3), K.ofabs(1, 1), K.ofabs(1, 3), K.ofabs(1, 1, (1, 1, 1))
+    for lev in range(3):
+        K.smooth(unew[lev], lev, 1.0); K.smooth(rhoh[lev], lev, 0.2, 1.5); K.smooth(gp[lev], lev, 0.1)
+    L.vo_ml_restrict_and_fill(3, vo.fab_ptr_array(unew), 0, 0, 3, 0, K.obcs, K.opm, K.opd, C.byref(K.prm))
+    L.vo_ml_restrict_and_fill(3, vo.fab_ptr_array(rhoh), 0, 3, 1, 0, K.obcs, K.opm, K.opd, C.byref(K.prm))
+    L.vo_ml_restrict_and_fill(3, vo.fab_ptr_array(gp), 0, 6, 3, 1, K.obcs, K.opm, K.opd, C.byref(K.prm))
+    for lev in range(3):
+        uold[lev].a[...] = 0.5 * unew[lev].a
+    gun, guo, grh, ggp, gpp = K.gmfs(unew), K.gmfs(uold), K.gmfs(rhoh), K.gmfs(gp), K.gmfs(p)
+    dt = 0.01
+    st = vo.CMgStat()
+    L.vo_ml_hgproject(3, vo.REGULAR_TIMESTEP, vo.fab_ptr_array(unew), vo.fab_ptr_array(uold), vo.fab_ptr_array(rhoh), vo.fab_ptr_array(p), vo.fab_ptr_array(gp),
+                      K.odx, C.c_double(dt), K.obcs, K.opm, K.opd, C.byref(K.prm), C.byref(st))
+    adv.hgproject(vo.REGULAR_TIMESTEP, K.mla, gun, guo, grh, gpp, ggp, K.dx, dt, K.bct, 3 + 2 + 1)
+    it_gpu = adv.last_solver_stats("hg")[0]
+    assert st.cycles < 40 and it_gpu == st.cycles, (it_gpu, st.cycles)
+    for lev in range(3):
+        a, b = K.gather(gun[lev], unew[lev]), unew[lev].a
+        assert np.abs(a - b).max() <= 1e-8 * np.abs(b).max(), "unew level %d: %.3e" % (lev, np.abs(a - b).max())
+        a, b = K.gather(ggp[lev], gp[lev])[1:-1, 1:-1, 1:-1], gp[lev].a[1:-1, 1:-1, 1:-1]
+        assert np.abs(a - b).max() <= 1e-7 * np.abs(b).max(), "gp level %d: %.3e" % (lev, np.abs(a - b).max())
+    K.close()
+
+
+def test_three_level_advance(gpu, oracle):
+    """base 16^3 + two nested refinements over the bubble (fixed grids), three steps of advance_timestep on all three levels, HIP vs
+    oracle.  Tolerance 1e-7 relative (composite solves at 1e-10)."""
+    from varden_amd import advance as adv
+    from varden_amd import driver
+    vo = oracle
+    flo, fhi = (8, 8, 8), (23, 23, 23)
+    O = vo.SimML(16, [(flo, fhi)] + FINER, WALLS)
+    G = driver.VardenAMR(16, [(flo, fhi)], WALLS, finer_levels=[FINER])
+    assert G.dt == O.dt
+    for _ in range(3):
+        O.step(); G.step()
+        assert abs(G.dt - O.dt) <= 1e-10 * O.dt
+        assert adv.last_solver_stats("mac")[0] == O.mgstat[0].cycles and adv.last_solver_stats("hg")[0] == O.mgstat[1].cycles
+    for n in range(3):
+        for nm, gm, om in (("u", G.unew, O.unew[n]), ("s", G.snew, O.snew[n])):
+            a, b = gm[n].to_numpy(0)[3:-3, 3:-3, 3:-3], om.valid()
+            scale = max(np.abs(b).max(), 1e-300)
+            assert np.abs(a - b).max() <= 1e-7 * scale, "level %d %s differs by %.3e (scale %.3e)" % (n, nm, np.abs(a - b).max(), scale)
+    s2 = G.snew[2].to_numpy(0)[3:-3, 3:-3, 3:-3, 0]
+    assert np.abs(s2 - s2[::-1]).max() <= 1e-9
     G.close()

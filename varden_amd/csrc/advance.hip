@@ -34,11 +34,11 @@ extern "C" int vdn_advance_timestep(int istep, vdn_layout *mla, vdn_multifab **s
   VDN_TRY
   (void)istep; (void)time;
   REQUIRE(ctx().inited, "vdn_init has not been called");
-  REQUIRE(mla && mla->nlev >= 1 && mla->nlev <= 2, "advance_timestep: one or two levels are implemented (nlevel = %d)", mla ? mla->nlev : -1);
+  REQUIRE(mla && mla->nlev >= 1 && mla->nlev <= VDN_MAXLEV, "advance_timestep: 1..%d levels are implemented (nlevel = %d)", VDN_MAXLEV, mla ? mla->nlev : -1);
   const vdn_params &P = ctx().prm;
   const int dm = P.dm, nscal = P.nscal, nlevs = mla->nlev;
   const bool viscous = P.visc_coef > 0.0, diffusive = P.diff_coef > 0.0;
-  REQUIRE(nlevs == 1 || (dm == 3 && !viscous && !diffusive), "advance_timestep: two-level hierarchies are implemented for dm = 3, inviscid (this round)");
+  REQUIRE(nlevs == 1 || (dm == 3 && !viscous && !diffusive), "advance_timestep: multi-level hierarchies are implemented for dm = 3, inviscid (this round)");
   REQUIRE(press_comp == dm + nscal + 1, "press_comp must be dm+nscal+1 (got %d)", press_comp);
   for (int n = 0; n < nlevs; n++) {
     REQUIRE(uold[n]->ng >= 3 && sold[n]->ng >= 3 && unew[n]->ng >= 3 && snew[n]->ng >= 3, "state needs ng_cell = 3");
@@ -51,7 +51,7 @@ extern "C" int vdn_advance_timestep(int istep, vdn_layout *mla, vdn_multifab **s
   #define DXL(n) (dx + (n) * dm)
 
   // advance_timestep.f90:65-80; umac is [lev*3 + d]
-  vdn_multifab *mac_rhs[2], *rhohalf[2], *umac[6] = { nullptr, nullptr, nullptr, nullptr, nullptr, nullptr }, *lapu[2] = { nullptr, nullptr };
+  vdn_multifab *mac_rhs[VDN_MAXLEV], *rhohalf[VDN_MAXLEV], *umac[3 * VDN_MAXLEV] = { nullptr }, *lapu[VDN_MAXLEV] = { nullptr };
   for (int n = 0; n < nlevs; n++) {
     mac_rhs[n] = mf_temp(mla, n, 1, 1, -1, true, 0.0);
     rhohalf[n] = mf_temp(mla, n, dm, 1, -1, true, 0.0);
@@ -66,7 +66,7 @@ extern "C" int vdn_advance_timestep(int istep, vdn_layout *mla, vdn_multifab **s
   // advance_premac.f90:44-51
   {
     size_t mark = arena_mark();
-    vdn_multifab *vel_force[2];
+    vdn_multifab *vel_force[VDN_MAXLEV];
     for (int n = 0; n < nlevs; n++) {
       vel_force[n] = mf_temp(mla, n, dm, 1, -1, false, 0.0);
       k_mkvelforce(vel_force[n], ext_vel_force[n], sold[n], gp[n], lapu[n], 1.0);
@@ -91,7 +91,7 @@ extern "C" int vdn_advance_timestep(int istep, vdn_layout *mla, vdn_multifab **s
   {
     size_t mark = arena_mark();
     int is_cons[VDN_MAXCOMP]; is_cons[0] = 1; for (int c = 1; c < nscal; c++) is_cons[c] = 0;
-    vdn_multifab *scal_force[2], *divu[2], *sflux[6], *sedge[6], *laps[2] = { nullptr, nullptr };
+    vdn_multifab *scal_force[VDN_MAXLEV], *divu[VDN_MAXLEV], *sflux[3 * VDN_MAXLEV], *sedge[3 * VDN_MAXLEV], *laps[VDN_MAXLEV] = { nullptr };
     for (int n = 0; n < nlevs; n++) {
       scal_force[n] = mf_temp(mla, n, nscal, 1, -1, false, 0.0);
       divu[n] = mf_temp(mla, n, 1, 1, -1, true, 0.0);
@@ -128,7 +128,7 @@ extern "C" int vdn_advance_timestep(int istep, vdn_layout *mla, vdn_multifab **s
   {
     size_t mark = arena_mark();
     int is_cons[3] = { 0, 0, 0 };
-    vdn_multifab *vel_force[2], *uflux[6], *uedge[6];
+    vdn_multifab *vel_force[VDN_MAXLEV], *uflux[3 * VDN_MAXLEV], *uedge[3 * VDN_MAXLEV];
     for (int n = 0; n < nlevs; n++) {
       vel_force[n] = mf_temp(mla, n, dm, 1, -1, false, 0.0);
       for (int d = 0; d < dm; d++) { uflux[3 * n + d] = mf_temp(mla, n, dm, 0, d, true, 0.0); uedge[3 * n + d] = mf_temp(mla, n, dm, 0, d, true, 0.0); }
@@ -192,7 +192,7 @@ extern "C" int vdn_hgproject(int proj_type, vdn_layout *mla, vdn_multifab **unew
                              vdn_multifab **rhohalf, vdn_multifab **p, vdn_multifab **gp,
                              const double *dx, double dt, const vdn_bc_tower *bct, int press_comp) {
   VDN_TRY
-  REQUIRE(mla && mla->nlev <= 2, "hgproject: at most two levels are implemented (nlevel = %d)", mla ? mla->nlev : -1);
+  REQUIRE(mla && mla->nlev <= VDN_MAXLEV, "hgproject: at most %d levels are implemented (nlevel = %d)", VDN_MAXLEV, mla ? mla->nlev : -1);
   arena_reset(); arena_reserve_for(mla);
   do_hgproject(proj_type, mla, unew, uold, rhohalf, p, gp, dx, dt, bct, press_comp - 1);
   arena_reset();
@@ -201,7 +201,7 @@ extern "C" int vdn_hgproject(int proj_type, vdn_layout *mla, vdn_multifab **unew
 extern "C" int vdn_macproject(vdn_layout *mla, vdn_multifab **umac, vdn_multifab **rho, vdn_multifab **mac_rhs,
                               const double *dx, const vdn_bc_tower *bct, int bc_comp) {
   VDN_TRY
-  REQUIRE(mla && mla->nlev <= 2, "macproject: at most two levels are implemented (nlevel = %d)", mla ? mla->nlev : -1);
+  REQUIRE(mla && mla->nlev <= VDN_MAXLEV, "macproject: at most %d levels are implemented (nlevel = %d)", VDN_MAXLEV, mla ? mla->nlev : -1);
   arena_reset(); arena_reserve_for(mla);
   do_macproject(mla, umac, rho, mac_rhs, dx, bct, bc_comp - 1);
   arena_reset();

@@ -1,4 +1,4 @@
-// amr.hip -- two-level AMR pieces of the hot path (BASELINE.json configs[3]).
+// amr.hip -- multi-level (fixed grids) AMR pieces of the hot path (BASELINE.json configs[3], [4]).
 //
 // The FBoxLib multi-level operators the reference calls are not in its tree; the call sites fix what they must do, the
 // definitions are ours (stated in oracle/vo_amr.c, which this file mirrors operation for operation):
@@ -7,20 +7,21 @@
 //   fill_ghost_cells      fine ghost cell = coarse parent + MC-limited linear slopes   (macproject.f90:304-310, ml_restrict_and_fill)
 //   create_umac_grown     fine ghost face = coarse face (even index) / mean of the two coarse faces around it (odd)
 //   ml_cc_solve           composite solve by FAC iteration: composite residual (quadratic coarse-fine ghost cells, coarse flux
-//                         through an interface face = mean of the four fine fluxes), nu1 red-black sweeps on the fine level, one
-//                         V-cycle of the single-level multigrid on the whole coarse level, piecewise-constant prolongation, nu2 fine sweeps
-// This round: two levels, refinement ratio 2, every box on this rank (nranks = 1); any number of boxes per level for the
-// transfer operators, the fine level's boxes must be properly nested.
+//                         through an interface face = mean of the four fine fluxes), nu1 red-black sweeps on the levels finest to 1,
+//                         one V-cycle of the single-level multigrid on the whole level 0, piecewise-constant prolongation, nu2 sweeps
+//                         on the levels 1 to finest
+// This round: up to VDN_MAXLEV levels, refinement ratio 2, every box on this rank (nranks = 1); the levels must be properly nested
+// (a level-n box keeps at least two level-(n-1) cells between itself and the edge of level n-1, or touches the domain boundary).
 #include "vdn_dev.h"
 #include <vector>
 #include <algorithm>
 
 static const dim3 AB(64, 4, 1);
 static void require_amr(const vdn_layout *la) {
-  REQUIRE(la->nlev == 2, "AMR path: two levels are implemented (nlevel = %d)", la->nlev);
+  REQUIRE(la->nlev >= 2 && la->nlev <= VDN_MAXLEV, "AMR path: 2..%d levels are implemented (nlevel = %d)", VDN_MAXLEV, la->nlev);
   REQUIRE(ctx().nranks == 1, "AMR path: single rank only in this round");
   REQUIRE(ctx().prm.dm == 3, "AMR path: dm = 3 only");
-  for (int d = 0; d < 3; d++) REQUIRE(la->rr[d] == 2, "AMR path: refinement ratio 2 only");
+  for (size_t d = 0; d < la->rr.size(); d++) REQUIRE(la->rr[d] == 2, "AMR path: refinement ratio 2 only");
 }
 DEVI int fdiv2(int a) { return a >= 0 ? a / 2 : -((-a + 1) / 2); }
 static int hfdiv2(int a) { return a >= 0 ? a / 2 : -((-a + 1) / 2); }
@@ -111,10 +112,11 @@ __global__ void kk_ml_interp_ghost(FV fine, FV crse, InterpArgs A, Range3 r) {
   }
 }
 // parents inside a coarse box's VALID region come from that box; parents outside the domain (physical / periodic ghost
-// cells of the coarse level) come from the first coarse box whose allocation holds them
+// cells of the coarse level) come from the first coarse box whose allocation holds them.  A one-box coarse level that does not
+// cover the domain: parents outside the box (its own ghost cells, filled from the next coarser level) count as "outside"
 void ml_fill_ghost_cells(vdn_multifab *fine, const vdn_multifab *crse, int icomp, int nc) {
   if (fine->ng == 0) return;
-  const vdn_box &pdc = crse->la->pd[crse->lev];
+  const vdn_box &pdc = crse->nfabs() == 1 ? crse->vbox[0] : crse->la->pd[crse->lev];
   for (int f = 0; f < fine->nfabs(); f++) {
     InterpArgs A; Range3 r;
     int glo[3], ghi[3];
@@ -308,78 +310,101 @@ __global__ void kk_amr_gsrb(FV e, FV rh, FV bx, FV by, FV bz, GsArgs A, int colo
   if (diag != 0.0) fv_at(e, i, j, k) = p0 + (fv_get(rh, i, j, k) - Ap) / diag;
 }
 __global__ void kk_add(FV a, FV b, Range3 r) { THREAD_IJK(r) if (!in_range) return; fv_at(a, i, j, k) = fv_get(a, i, j, k) + fv_get(b, i, j, k); }
-__global__ void kk_add_prolong(FV af, FV ec, Range3 r, int plo0, int plo1, int plo2, int phi0, int phi1, int phi2) {
+// af += the parent's increment; keep: also store that increment in sc (the next finer level prolongs it in turn)
+__global__ void kk_add_prolong(FV af, FV sc, int keep, FV ec, Range3 r, int plo0, int plo1, int plo2, int phi0, int phi1, int phi2) {
   THREAD_IJK(r)
   if (!in_range) return;
   const int I = i / 2, J = j / 2, K = k / 2;
   if (I < plo0 || I > phi0 || J < plo1 || J > phi1 || K < plo2 || K > phi2) return;
-  fv_at(af, i, j, k) = fv_get(af, i, j, k) + fv_get(ec, I, J, K);
+  const double v = fv_get(ec, I, J, K);
+  if (keep) fv_at(sc, i, j, k) = v;
+  fv_at(af, i, j, k) = fv_get(af, i, j, k) + v;
 }
 __global__ void kk_setbox(FV a, Range3 r, double v) { THREAD_IJK(r) if (!in_range) return; fv_at(a, i, j, k) = v; }
 
 static Range3 valid_range(const vdn_multifab *mf, int b) { Range3 r; for (int d = 0; d < 3; d++) { r.lo[d] = mf->vbox[b].lo[d]; r.hi[d] = mf->vbox[b].hi[d]; } return r; }
 static double read_dev(double *d) { double h; HIPCHK(hipMemcpyAsync(&h, d, sizeof(double), hipMemcpyDeviceToHost, ctx().stream)); HIPCHK(hipStreamSynchronize(ctx().stream)); return h; }
 
-struct MLCC { vdn_layout *la; vdn_multifab **rh, **phi, **beta; vdn_multifab *res[2], *e[2], *mask; const double *dx; const vdn_bc_tower *bct; int bcc; double *d_nrm; };
-static void level_residual(MLCC &S, int n, bool masked, bool norm) {
+struct MLCC { int nlev; vdn_layout *la; vdn_multifab **rh, **phi, **beta; vdn_multifab *res[VDN_MAXLEV], *e[VDN_MAXLEV], *scr[VDN_MAXLEV], *mask[VDN_MAXLEV];
+              const double *dx; const vdn_bc_tower *bct; int bcc; double *d_nrm; };
+static void level_residual(MLCC &S, int n, bool norm) {
   ResArgs A; for (int d = 0; d < 3; d++) A.hi2[d] = 1.0 / (S.dx[3 * n + d] * S.dx[3 * n + d]);
   for (int b = 0; b < S.rh[n]->nfabs(); b++) {
     Range3 r = valid_range(S.rh[n], b);
     hipLaunchKernelGGL(kk_amr_residual, reduce_grid(r), AB, 0, ctx().stream, S.rh[n]->fabs[b], S.phi[n]->fabs[b], S.beta[3 * n]->fabs[b], S.beta[3 * n + 1]->fabs[b], S.beta[3 * n + 2]->fabs[b],
-                       S.res[n]->fabs[b], masked ? S.mask->fabs[b] : S.rh[n]->fabs[b], masked ? 1 : 0, A, r, norm ? S.d_nrm : (double *)nullptr);
+                       S.res[n]->fabs[b], S.rh[n]->fabs[b], 0, A, r, norm ? S.d_nrm : (double *)nullptr);
   }
 }
 static void fill_phi_ghosts(MLCC &S) {
-  ml_cc_restriction(S.phi[0], S.phi[1], 0, 1);
-  phi_closure(S.phi[0], S.bct, S.bcc);
-  phi_closure(S.phi[1], S.bct, S.bcc);
-  cf_interp(S.phi[1], S.phi[0], S.bct, S.bcc);
+  for (int n = S.nlev - 1; n >= 1; n--) ml_cc_restriction(S.phi[n - 1], S.phi[n], 0, 1);
+  for (int n = 0; n < S.nlev; n++) phi_closure(S.phi[n], S.bct, S.bcc);
+  for (int n = 1; n < S.nlev; n++) cf_interp(S.phi[n], S.phi[n - 1], S.bct, S.bcc);
 }
 static double composite_residual(MLCC &S) {
   hipStream_t st = ctx().stream;
+  const int L = S.nlev;
   fill_phi_ghosts(S);
   HIPCHK(hipMemsetAsync(S.d_nrm, 0, sizeof(double), st));
-  level_residual(S, 1, false, true);
-  level_residual(S, 0, false, false);
-  // flux matching on the coarse cells next to the fine boxes: lo faces then hi faces of every direction (one update per cell
-  // and launch, hence deterministic)
-  for (int d = 0; d < 3; d++) for (int s = 0; s < 2; s++)
-    for (int f = 0; f < S.phi[1]->nfabs(); f++) {
-      if (S.bct->ell_bc(1, f + 1, d, s, S.bcc) != VDN_BC_INT) continue;
-      const vdn_box &fb = S.phi[1]->vbox[f];
-      int clo[3], chi[3];
-      for (int t = 0; t < 3; t++) { clo[t] = fb.lo[t] / 2; chi[t] = fb.hi[t] / 2; }
-      clo[d] = chi[d] = (s ? fb.hi[d] + 1 : fb.lo[d]) / 2;
-      for (int c = 0; c < S.phi[0]->nfabs(); c++) {
-        int blo[3], bhi[3]; Range3 r;
-        for (int t = 0; t < 3; t++) { blo[t] = S.phi[0]->vbox[c].lo[t]; bhi[t] = S.phi[0]->vbox[c].hi[t]; }
-        // the coarse cell that gets the correction must be a valid cell of box c
-        if (s == 0) { blo[d] += 1; bhi[d] += 1; }
-        if (!isect(clo, chi, blo, bhi, r)) continue;
-        RefluxArgs A; A.d = d; A.s = s; A.dxf = S.dx[3 + d]; A.dxc = S.dx[d];
-        hipLaunchKernelGGL(kk_reflux, grid_for(r), AB, 0, st, S.res[0]->fabs[c], S.phi[0]->fabs[c], S.beta[d]->fabs[c], S.mask->fabs[c], S.phi[1]->fabs[f], S.beta[3 + d]->fabs[f], A, r);
+  for (int n = 0; n < L; n++) level_residual(S, n, n == L - 1);
+  // flux matching on the cells of level n-1 next to the boxes of level n: lo faces then hi faces of every direction (one update
+  // per cell and launch, hence deterministic)
+  for (int n = 1; n < L; n++)
+    for (int d = 0; d < 3; d++) for (int s = 0; s < 2; s++)
+      for (int f = 0; f < S.phi[n]->nfabs(); f++) {
+        if (S.bct->ell_bc(n, f + 1, d, s, S.bcc) != VDN_BC_INT) continue;
+        const vdn_box &fb = S.phi[n]->vbox[f];
+        int clo[3], chi[3];
+        for (int t = 0; t < 3; t++) { clo[t] = fb.lo[t] / 2; chi[t] = fb.hi[t] / 2; }
+        clo[d] = chi[d] = (s ? fb.hi[d] + 1 : fb.lo[d]) / 2;
+        for (int c = 0; c < S.phi[n - 1]->nfabs(); c++) {
+          int blo[3], bhi[3]; Range3 r;
+          for (int t = 0; t < 3; t++) { blo[t] = S.phi[n - 1]->vbox[c].lo[t]; bhi[t] = S.phi[n - 1]->vbox[c].hi[t]; }
+          // the coarse cell that gets the correction must be a valid cell of box c
+          if (s == 0) { blo[d] += 1; bhi[d] += 1; }
+          if (!isect(clo, chi, blo, bhi, r)) continue;
+          RefluxArgs A; A.d = d; A.s = s; A.dxf = S.dx[3 * n + d]; A.dxc = S.dx[3 * (n - 1) + d];
+          hipLaunchKernelGGL(kk_reflux, grid_for(r), AB, 0, st, S.res[n - 1]->fabs[c], S.phi[n - 1]->fabs[c], S.beta[3 * (n - 1) + d]->fabs[c], S.mask[n - 1]->fabs[c],
+                             S.phi[n]->fabs[f], S.beta[3 * n + d]->fabs[f], A, r);
+        }
       }
+  for (int n = L - 1; n >= 1; n--) ml_cc_restriction(S.res[n - 1], S.res[n], 0, 1);
+  for (int n = 0; n < L - 1; n++)
+    for (int b = 0; b < S.res[n]->nfabs(); b++) {
+      Range3 r = valid_range(S.res[n], b);
+      hipLaunchKernelGGL(kk_absmax_masked, reduce_grid(r), AB, 0, st, S.res[n]->fabs[b], S.mask[n]->fabs[b], 1, r, S.d_nrm);
     }
-  ml_cc_restriction(S.res[0], S.res[1], 0, 1);
-  for (int b = 0; b < S.res[0]->nfabs(); b++) {
-    Range3 r = valid_range(S.res[0], b);
-    hipLaunchKernelGGL(kk_absmax_masked, reduce_grid(r), AB, 0, st, S.res[0]->fabs[b], S.mask->fabs[b], 1, r, S.d_nrm);
-  }
   return read_dev(S.d_nrm);
 }
-static void fine_relax(MLCC &S, int nsweeps) {
+// nsweeps red-black sweeps of A_n e = res_n from e = 0 (homogeneous coarse-fine interface)
+static void level_relax(MLCC &S, int n, int nsweeps) {
   hipStream_t st = ctx().stream;
-  vdn_multifab *e = S.e[1];
+  vdn_multifab *e = S.e[n];
+  mf_setval(e, 0.0, 0, 1, true);
   const bool exchange = e->nfabs() > 1 || S.la->pmask[0] || S.la->pmask[1] || S.la->pmask[2];
   for (int s = 0; s < nsweeps; s++) for (int col = 0; col < 2; col++) {
     if (exchange) mf_fill_boundary(e);
     for (int b = 0; b < e->nfabs(); b++) {
       GsArgs A; Range3 r = valid_range(e, b);
-      for (int d = 0; d < 3; d++) { A.lo[d] = r.lo[d]; A.hi[d] = r.hi[d]; A.hi2[d] = 1.0 / (S.dx[3 + d] * S.dx[3 + d]); for (int sd = 0; sd < 2; sd++) A.e[d][sd] = S.bct->ell_bc(1, b + 1, d, sd, S.bcc); }
+      for (int d = 0; d < 3; d++) { A.lo[d] = r.lo[d]; A.hi[d] = r.hi[d]; A.hi2[d] = 1.0 / (S.dx[3 * n + d] * S.dx[3 * n + d]); for (int sd = 0; sd < 2; sd++) A.e[d][sd] = S.bct->ell_bc(n, b + 1, d, sd, S.bcc); }
       const int nx = r.hi[0] - r.lo[0] + 1;
       dim3 g(((nx + 1) / 2 + 63) / 64, (r.hi[1] - r.lo[1] + 4) / 4, r.hi[2] - r.lo[2] + 1);
-      hipLaunchKernelGGL(kk_amr_gsrb, g, AB, 0, st, e->fabs[b], S.res[1]->fabs[b], S.beta[3]->fabs[b], S.beta[4]->fabs[b], S.beta[5]->fabs[b], A, col, r);
+      hipLaunchKernelGGL(kk_amr_gsrb, g, AB, 0, st, e->fabs[b], S.res[n]->fabs[b], S.beta[3 * n]->fabs[b], S.beta[3 * n + 1]->fabs[b], S.beta[3 * n + 2]->fabs[b], A, col, r);
     }
+  }
+}
+// phi_n += e_n, and the piecewise-constant prolongation of that correction on every finer level
+static void apply_correction(MLCC &S, int n) {
+  hipStream_t st = ctx().stream;
+  for (int b = 0; b < S.phi[n]->nfabs(); b++) { Range3 r = valid_range(S.phi[n], b); hipLaunchKernelGGL(kk_add, grid_for(r), AB, 0, st, S.phi[n]->fabs[b], S.e[n]->fabs[b], r); }
+  vdn_multifab *src = S.e[n];
+  for (int m = n + 1; m < S.nlev; m++) {
+    const bool keep = m < S.nlev - 1;                        // a finer level still needs this level's increment
+    for (int f = 0; f < S.phi[m]->nfabs(); f++) for (int c = 0; c < src->nfabs(); c++) {
+      Range3 r = valid_range(S.phi[m], f); const vdn_box &cb = src->vbox[c];
+      hipLaunchKernelGGL(kk_add_prolong, grid_for(r), AB, 0, st, S.phi[m]->fabs[f], keep ? S.scr[m]->fabs[f] : S.phi[m]->fabs[f], keep ? 1 : 0, src->fabs[c], r,
+                         cb.lo[0], cb.lo[1], cb.lo[2], cb.hi[0], cb.hi[1], cb.hi[2]);
+    }
+    src = S.scr[m];
   }
 }
 // rh, phi: [lev];  beta: [lev*3 + d];  dx: [lev*3 + d]
@@ -388,19 +413,26 @@ int ml_cc_solve(vdn_layout *la, vdn_multifab **rh, vdn_multifab **phi, vdn_multi
   require_amr(la);
   hipStream_t st = ctx().stream;
   const size_t mark = arena_mark();
-  MLCC S; S.la = la; S.rh = rh; S.phi = phi; S.beta = beta; S.dx = dx; S.bct = bct; S.bcc = bc_comp0;
+  const int L = la->nlev;
+  MLCC S; S.nlev = L; S.la = la; S.rh = rh; S.phi = phi; S.beta = beta; S.dx = dx; S.bct = bct; S.bcc = bc_comp0;
   S.d_nrm = (double *)arena_alloc(256);
-  for (int n = 0; n < 2; n++) { S.res[n] = mf_temp(la, n, 1, 0, -1, true, 0.0); S.e[n] = mf_temp(la, n, 1, 1, -1, true, 0.0); }
-  S.mask = mf_temp(la, 0, 1, 0, -1, true, 0.0);
-  for (int f = 0; f < phi[1]->nfabs(); f++) for (int c = 0; c < S.mask->nfabs(); c++) {
-    int clo[3], chi[3]; Range3 r;
-    for (int d = 0; d < 3; d++) { clo[d] = phi[1]->vbox[f].lo[d] / 2; chi[d] = phi[1]->vbox[f].hi[d] / 2; }
-    if (isect(clo, chi, S.mask->vbox[c].lo, S.mask->vbox[c].hi, r)) hipLaunchKernelGGL(kk_setbox, grid_for(r), AB, 0, st, S.mask->fabs[c], r, 1.0);
+  for (int n = 0; n < L; n++) {
+    S.res[n] = mf_temp(la, n, 1, 0, -1, true, 0.0); S.e[n] = mf_temp(la, n, 1, 1, -1, true, 0.0);
+    S.scr[n] = (n >= 1 && n < L - 1) ? mf_temp(la, n, 1, 0, -1, true, 0.0) : nullptr;
+    S.mask[n] = nullptr;
+    if (n < L - 1) {                                         // cells of level n covered by level n+1
+      S.mask[n] = mf_temp(la, n, 1, 0, -1, true, 0.0);
+      for (int f = 0; f < phi[n + 1]->nfabs(); f++) for (int c = 0; c < S.mask[n]->nfabs(); c++) {
+        int clo[3], chi[3]; Range3 r;
+        for (int d = 0; d < 3; d++) { clo[d] = phi[n + 1]->vbox[f].lo[d] / 2; chi[d] = phi[n + 1]->vbox[f].hi[d] / 2; }
+        if (isect(clo, chi, S.mask[n]->vbox[c].lo, S.mask[n]->vbox[c].hi, r)) hipLaunchKernelGGL(kk_setbox, grid_for(r), AB, 0, st, S.mask[n]->fabs[c], r, 1.0);
+      }
+    }
   }
   HIPCHK(hipMemsetAsync(S.d_nrm, 0, sizeof(double), st));
-  for (int n = 0; n < 2; n++) for (int b = 0; b < rh[n]->nfabs(); b++) {
+  for (int n = 0; n < L; n++) for (int b = 0; b < rh[n]->nfabs(); b++) {
     Range3 r = valid_range(rh[n], b);
-    hipLaunchKernelGGL(kk_absmax_masked, reduce_grid(r), AB, 0, st, rh[n]->fabs[b], n == 0 ? S.mask->fabs[b] : rh[n]->fabs[b], n == 0 ? 1 : 0, r, S.d_nrm);
+    hipLaunchKernelGGL(kk_absmax_masked, reduce_grid(r), AB, 0, st, rh[n]->fabs[b], n < L - 1 ? S.mask[n]->fabs[b] : rh[n]->fabs[b], n < L - 1 ? 1 : 0, r, S.d_nrm);
   }
   const double bnorm = read_dev(S.d_nrm);
   const vdn_params &P = ctx().prm;
@@ -411,60 +443,58 @@ int ml_cc_solve(vdn_layout *la, vdn_multifab **rh, vdn_multifab **phi, vdn_multi
     rn = composite_residual(S);
     if (rn <= rel_eps * bnorm) { conv = true; break; }
     if (it >= max_iter) break;
-    // pre-relaxation of the fine level (homogeneous interface), then the residual the coarse level will see
-    mf_setval(S.e[1], 0.0, 0, 1, true);
-    fine_relax(S, P.mg_nu1);
-    for (int b = 0; b < phi[1]->nfabs(); b++) { Range3 r = valid_range(phi[1], b); hipLaunchKernelGGL(kk_add, grid_for(r), AB, 0, st, phi[1]->fabs[b], S.e[1]->fabs[b], r); }
-    (void)composite_residual(S);
-    // coarse correction: ONE V-cycle of the single-level multigrid on the whole coarse level
+    // pre-relaxation, finest level first (homogeneous interface), then the residual the next coarser level will see
+    for (int n = L - 1; n >= 1; n--) {
+      level_relax(S, n, P.mg_nu1);
+      apply_correction(S, n);
+      (void)composite_residual(S);
+    }
+    // coarse correction: ONE V-cycle of the single-level multigrid on the whole level 0
     mf_setval(S.e[0], 0.0, 0, 1, true);
     int cyc; double r0, rr;
     cc_solve(S.res[0], S.e[0], beta, dx, ebc0, 0.0, -1.0, -1, &cyc, &r0, &rr);
-    for (int b = 0; b < phi[0]->nfabs(); b++) { Range3 r = valid_range(phi[0], b); hipLaunchKernelGGL(kk_add, grid_for(r), AB, 0, st, phi[0]->fabs[b], S.e[0]->fabs[b], r); }
-    for (int f = 0; f < phi[1]->nfabs(); f++) for (int c = 0; c < phi[0]->nfabs(); c++) {
-      Range3 r = valid_range(phi[1], f); const vdn_box &cb = phi[0]->vbox[c];
-      hipLaunchKernelGGL(kk_add_prolong, grid_for(r), AB, 0, st, phi[1]->fabs[f], S.e[0]->fabs[c], r, cb.lo[0], cb.lo[1], cb.lo[2], cb.hi[0], cb.hi[1], cb.hi[2]);
+    apply_correction(S, 0);
+    // post-relaxation on the new residual, coarsest level first
+    for (int n = 1; n < L; n++) {
+      if (n < L - 1) (void)composite_residual(S);
+      else { fill_phi_ghosts(S); level_residual(S, n, false); }
+      level_relax(S, n, P.mg_nu2);
+      apply_correction(S, n);
     }
-    // fine relaxation on the new residual, homogeneous interface
-    phi_closure(phi[0], bct, bc_comp0);
-    phi_closure(phi[1], bct, bc_comp0);
-    cf_interp(phi[1], phi[0], bct, bc_comp0);
-    level_residual(S, 1, false, false);
-    mf_setval(S.e[1], 0.0, 0, 1, true);
-    fine_relax(S, P.mg_nu2);
-    for (int b = 0; b < phi[1]->nfabs(); b++) { Range3 r = valid_range(phi[1], b); hipLaunchKernelGGL(kk_add, grid_for(r), AB, 0, st, phi[1]->fabs[b], S.e[1]->fabs[b], r); }
     it++;
   }
   fill_phi_ghosts(S);
   if (iters) *iters = it; if (res0) *res0 = bnorm; if (res) *res = rn;
-  mf_temp_free(S.mask); for (int n = 1; n >= 0; n--) { mf_temp_free(S.e[n]); mf_temp_free(S.res[n]); }
+  for (int n = L - 1; n >= 0; n--) { if (S.mask[n]) mf_temp_free(S.mask[n]); if (S.scr[n]) mf_temp_free(S.scr[n]); mf_temp_free(S.e[n]); mf_temp_free(S.res[n]); }
   HIPCHK(hipStreamSynchronize(st));
   arena_release(mark);
   return conv ? 0 : 1;
 }
 
-// macproject.f90:20-133 on two levels.  umac: [lev*3 + d]
+// macproject.f90:20-133 on several levels.  umac: [lev*3 + d]
 void do_ml_macproject(vdn_layout *mla, vdn_multifab **umac, vdn_multifab **rho, vdn_multifab **mac_rhs, const double *dx, const vdn_bc_tower *bct, int bc_comp0) {
   require_amr(mla);
   const size_t mark = arena_mark();
-  vdn_multifab *rh[2], *phi[2], *beta[6];
-  for (int n = 0; n < 2; n++) {
+  const int L = mla->nlev;
+  vdn_multifab *rh[VDN_MAXLEV], *phi[VDN_MAXLEV], *beta[3 * VDN_MAXLEV];
+  for (int n = 0; n < L; n++) {
     REQUIRE(rho[n]->ng >= 1, "macproject: rho needs a filled ghost cell");
     rh[n] = mf_temp(mla, n, 1, 0, -1, false, 0.0); phi[n] = mf_temp(mla, n, 1, 1, -1, true, 0.0);
     for (int d = 0; d < 3; d++) beta[3 * n + d] = mf_temp(mla, n, 1, 0, d, false, 0.0);
     mac_level_rhs(umac + 3 * n, mac_rhs[n], rh[n], dx + 3 * n);                  // divumac, macproject.f90:161-196
     mac_level_coeffs(rho[n], beta + 3 * n);                                      // mk_mac_coeffs, 296-328
   }
-  ml_cc_restriction(rh[0], rh[1], 0, 1);                                          // 204-206
-  for (int d = 0; d < 3; d++) ml_edge_restriction(beta[d], beta[3 + d], d);       // 330-333
+  for (int n = L - 1; n >= 1; n--) ml_cc_restriction(rh[n - 1], rh[n], 0, 1);     // 204-206
+  for (int n = L - 1; n >= 1; n--) for (int d = 0; d < 3; d++) ml_edge_restriction(beta[3 * (n - 1) + d], beta[3 * n + d], d);       // 330-333
   int it; double r0, rr;
   int rc = ml_cc_solve(mla, rh, phi, beta, dx, bct, bc_comp0, ctx().prm.mac_rel_eps, ctx().prm.mg_max_iter, &it, &r0, &rr);
   ctx().solver_cycles[0] = it; ctx().solver_res0[0] = r0; ctx().solver_res[0] = rr;
   if (rc != 0 && ctx().prm.verbose) fprintf(stderr, "varden_amd: composite MAC solve did not converge in %d iterations (res %g / %g)\n", it, rr, r0);
-  for (int n = 0; n < 2; n++) mac_level_mkumac(umac + 3 * n, phi[n], beta + 3 * n, dx + 3 * n, bct, bc_comp0);   // 103
-  for (int d = 0; d < 3; d++) ml_edge_restriction(umac[d], umac[3 + d], d);       // 497-500
-  for (int d = 0; d < 3; d++) { mf_fill_boundary(umac[d]); ml_create_umac_grown(umac[3 + d], umac[d], d); mf_fill_boundary(umac[3 + d]); }   // 107-119
-  for (int n = 1; n >= 0; n--) { for (int d = 2; d >= 0; d--) mf_temp_free(beta[3 * n + d]); mf_temp_free(phi[n]); mf_temp_free(rh[n]); }
+  for (int n = 0; n < L; n++) mac_level_mkumac(umac + 3 * n, phi[n], beta + 3 * n, dx + 3 * n, bct, bc_comp0);   // 103
+  for (int n = L - 1; n >= 1; n--) for (int d = 0; d < 3; d++) ml_edge_restriction(umac[3 * (n - 1) + d], umac[3 * n + d], d);       // 497-500
+  for (int d = 0; d < 3; d++) mf_fill_boundary(umac[d]);
+  for (int n = 1; n < L; n++) for (int d = 0; d < 3; d++) { ml_create_umac_grown(umac[3 * n + d], umac[3 * (n - 1) + d], d); mf_fill_boundary(umac[3 * n + d]); }   // 107-119
+  for (int n = L - 1; n >= 0; n--) { for (int d = 2; d >= 0; d--) mf_temp_free(beta[3 * n + d]); mf_temp_free(phi[n]); mf_temp_free(rh[n]); }
   arena_release(mark);
 }
 

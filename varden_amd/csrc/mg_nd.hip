@@ -1174,114 +1174,162 @@ __global__ void kk_ndf_restrict_add2(FV res_c, FV res_f, NdfArgs Af, NdfArgs Ac,
 }
 
 static double ndf_read(double *d) { double h; HIPCHK(hipMemcpyAsync(&h, d, sizeof(double), hipMemcpyDeviceToHost, ctx().stream)); HIPCHK(hipStreamSynchronize(ctx().stream)); return h; }
+// nodes on a coarse-fine face of the box (not physical Dirichlet) -> mask = 1
+__global__ void kk_ndf_mark_cf(FV mask, NdfArgs A, Range3 r) {
+  THREAD_IJK(r)
+  if (!in_range) return;
+  if (ndf_cf(A, i, j, k) && !ndf_pdir(A, i, j, k)) fv_at(mask, i, j, k) = 1.0;
+}
+// levels 0 .. nlev-2 are one box each, the finest level may have several boxes that share whole faces
 struct MLND {
-  vdn_multifab *phi[2], *b[2], *res[2], *sig[2];     // sig[0]: MASKED coarse sigma
-  vdn_multifab *cin;                                 // coarse nodes strictly inside a fine box (excluded from the norm)
-  NdfArgs Ac; Range3 rc;                             // the coarse box
-  std::vector<NdfArgs> Af; std::vector<Range3> rf;   // fine boxes
-  std::vector<int> own_hi;                           // [box*3 + d]: the box owns the nodes of its high d-face
-  bool multi; double *d_nrm;
+  int nlev;
+  vdn_multifab *phi[VDN_MAXLEV], *b[VDN_MAXLEV], *res[VDN_MAXLEV];
+  vdn_multifab *sig[VDN_MAXLEV];                     // MASKED sigma (zero under the next finer level); the finest level's own sigma
+  vdn_multifab *sigfull[VDN_MAXLEV];                 // the caller's coefficients
+  vdn_multifab *skip[VDN_MAXLEV];                    // nodes left out of the norm: strictly inside a finer box, or slaved to the coarser level
+  vdn_multifab *ea[VDN_MAXLEV], *eb[VDN_MAXLEV], *scr[VDN_MAXLEV];   // Jacobi ping-pong of the correction; prolonged increment
+  std::vector<NdfArgs> A[VDN_MAXLEV]; std::vector<Range3> r[VDN_MAXLEV];
+  std::vector<int> own_hi[VDN_MAXLEV];               // [box*3 + d]: the box owns the nodes of its high d-face
+  bool multi[VDN_MAXLEV]; double *d_nrm;
 };
-// fine_only: just the fine-level residual (what the fine relaxation needs), no norm
-static double ml_nd_residual(MLND &S, bool fine_only) {
+// interface nodes of level n <- trilinear interpolation of level n-1
+static void ml_nd_interface(MLND &S, int n) {
+  for (size_t f = 0; f < S.A[n].size(); f++)
+    hipLaunchKernelGGL(kk_ndf_prolong, grid_for(S.r[n][f]), NBLK, 0, ctx().stream, S.phi[n]->fabs[f], S.phi[n - 1]->fabs[0], S.A[n][f], 0, S.r[n][f]);
+  if (S.multi[n]) mf_fill_boundary(S.phi[n]);
+}
+// finest_only: just the finest level's residual (what its relaxation needs), no norm
+static double ml_nd_residual(MLND &S, bool finest_only) {
   hipStream_t st = ctx().stream;
-  const int nf = (int)S.Af.size();
-  for (int f = 0; f < nf; f++) hipLaunchKernelGGL(kk_ndf_prolong, grid_for(S.rf[f]), NBLK, 0, st, S.phi[1]->fabs[f], S.phi[0]->fabs[0], S.Af[f], 0, S.rf[f]);
-  if (S.multi) mf_fill_boundary(S.phi[1]);
-  if (!fine_only) HIPCHK(hipMemsetAsync(S.d_nrm, 0, sizeof(double), st));
-  for (int f = 0; f < nf; f++)
-    ndf_launch_march<1>(S.phi[1]->fabs[f], S.res[1]->fabs[f], S.b[1]->fabs[f], S.sig[1]->fabs[f], S.Af[f], 0.0, 1, S.rf[f], fine_only ? (double *)nullptr : S.d_nrm);
-  if (fine_only) return 0.0;
-  if (S.multi) mf_fill_boundary(S.res[1]);
-  ndf_launch_march<1>(S.phi[0]->fabs[0], S.res[0]->fabs[0], S.b[0]->fabs[0], S.sig[0]->fabs[0], S.Ac, 0.0, 0, S.rc, (double *)nullptr);
-  for (int f = 0; f < nf; f++) {
-    Range3 ri; for (int d = 0; d < 3; d++) { ri.lo[d] = S.Af[f].lo[d] / 2; ri.hi[d] = S.Af[f].hi[d] / 2; }
-    hipLaunchKernelGGL(kk_ndf_restrict_add2, grid_for(ri), NBLK, 0, st, S.res[0]->fabs[0], S.res[1]->fabs[f], S.Af[f], S.Ac,
-                       S.own_hi[3 * f], S.own_hi[3 * f + 1], S.own_hi[3 * f + 2], ri);
+  const int L = S.nlev;
+  if (finest_only) ml_nd_interface(S, L - 1);
+  else { for (int n = 1; n < L; n++) ml_nd_interface(S, n); HIPCHK(hipMemsetAsync(S.d_nrm, 0, sizeof(double), st)); }
+  for (int n = L - 1; n >= (finest_only ? L - 1 : 0); n--) {
+    const bool finest = n == L - 1;
+    for (size_t f = 0; f < S.A[n].size(); f++)
+      ndf_launch_march<1>(S.phi[n]->fabs[f], S.res[n]->fabs[f], S.b[n]->fabs[f], S.sig[n]->fabs[f], S.A[n][f], 0.0, finest ? 1 : 0, S.r[n][f],
+                          (finest && !finest_only) ? S.d_nrm : (double *)nullptr);
+    if (finest_only) return 0.0;
+    if (S.multi[n]) mf_fill_boundary(S.res[n]);
+    if (finest) continue;
+    for (size_t f = 0; f < S.A[n + 1].size(); f++) {
+      const NdfArgs &Af = S.A[n + 1][f];
+      Range3 ri; for (int d = 0; d < 3; d++) { ri.lo[d] = Af.lo[d] / 2; ri.hi[d] = Af.hi[d] / 2; }
+      hipLaunchKernelGGL(kk_ndf_restrict_add2, grid_for(ri), NBLK, 0, st, S.res[n]->fabs[0], S.res[n + 1]->fabs[f], Af, S.A[n][0],
+                         S.own_hi[n + 1][3 * f], S.own_hi[n + 1][3 * f + 1], S.own_hi[n + 1][3 * f + 2], ri);
+    }
+    hipLaunchKernelGGL(kk_ndf_absmax_mask, reduce_grid(S.r[n][0]), NBLK, 0, st, S.res[n]->fabs[0], S.skip[n]->fabs[0], S.r[n][0], S.d_nrm);
   }
-  hipLaunchKernelGGL(kk_ndf_absmax_mask, reduce_grid(S.rc), NBLK, 0, st, S.res[0]->fabs[0], S.cin->fabs[0], S.rc, S.d_nrm);
   return ndf_read(S.d_nrm);
+}
+// phi_n += e (nodes of level n) and its trilinear prolongation on every finer level (not on physical Dirichlet nodes)
+static void ml_nd_apply_correction(MLND &S, int n, vdn_multifab *e) {
+  hipStream_t st = ctx().stream;
+  for (size_t f = 0; f < S.A[n].size(); f++) hipLaunchKernelGGL(kk_ndf_add, grid_for(S.r[n][f]), NBLK, 0, st, S.phi[n]->fabs[f], e->fabs[f], S.r[n][f]);
+  vdn_multifab *src = e;
+  for (int m = n + 1; m < S.nlev; m++) {
+    if (m == S.nlev - 1) {
+      for (size_t f = 0; f < S.A[m].size(); f++) hipLaunchKernelGGL(kk_ndf_prolong, grid_for(S.r[m][f]), NBLK, 0, st, S.phi[m]->fabs[f], src->fabs[0], S.A[m][f], 1, S.r[m][f]);
+    } else {                                             // one box: keep the increment for the next finer level
+      mf_setval(S.scr[m], 0.0, 0, 1, true);
+      hipLaunchKernelGGL(kk_ndf_prolong, grid_for(S.r[m][0]), NBLK, 0, st, S.scr[m]->fabs[0], src->fabs[0], S.A[m][0], 1, S.r[m][0]);
+      hipLaunchKernelGGL(kk_ndf_add, grid_for(S.r[m][0]), NBLK, 0, st, S.phi[m]->fabs[0], S.scr[m]->fabs[0], S.r[m][0]);
+      src = S.scr[m];
+    }
+  }
 }
 // rh, phi: nodal ng 1 per level; coeffs: cells ng 1 (ghost 0 outside the level); u: cells (>= 1 ghost); dx: [lev*3+d]
 static int ml_nd_solve(vdn_layout *la, vdn_multifab **rh, vdn_multifab **phi, vdn_multifab **coeffs, vdn_multifab **u, const double *dx,
                        const vdn_bc_tower *bct, int press_comp0, double rel_eps, double abs_eps, int max_iter, int *iters, double *res0, double *res) {
-  REQUIRE(la->nlev == 2 && ctx().nranks == 1, "composite nodal solve: two levels, single rank");
-  REQUIRE(phi[0]->nfabs() == 1, "composite nodal solve: the coarse level must be one box in this round");
+  const int L = la->nlev;
+  REQUIRE(L >= 2 && L <= VDN_MAXLEV && ctx().nranks == 1, "composite nodal solve: 2..%d levels, single rank", VDN_MAXLEV);
+  for (int n = 0; n < L - 1; n++) REQUIRE(phi[n]->nfabs() == 1, "composite nodal solve: every level but the finest must be one box in this round (level %d)", n);
   REQUIRE(!(la->pmask[0] || la->pmask[1] || la->pmask[2]), "composite nodal solve: periodic domains are not implemented");
   hipStream_t st = ctx().stream;
   const size_t mark = arena_mark();
   const vdn_params &P = ctx().prm;
-  MLND S; S.d_nrm = (double *)arena_alloc(256);
-  const int nf = phi[1]->nfabs();
-  S.multi = nf > 1;
-  const vdn_box &cb = phi[0]->vbox[0];
-  for (int d = 0; d < 3; d++) {
-    S.Ac.f[d] = 1.0 / (36.0 * (dx[d] * dx[d]));
-    S.Ac.lo[d] = cb.lo[d]; S.Ac.hi[d] = cb.hi[d] + 1;
-    S.Ac.dirlo[d] = bct->ell_bc(0, 1, d, 0, press_comp0) == VDN_BC_DIR; S.Ac.dirhi[d] = bct->ell_bc(0, 1, d, 1, press_comp0) == VDN_BC_DIR;
-    S.Ac.cflo[d] = S.Ac.cfhi[d] = 0; S.Ac.ilo[d] = S.Ac.ihi[d] = 0;
-    S.rc.lo[d] = S.Ac.lo[d]; S.rc.hi[d] = S.Ac.hi[d];
-  }
-  // fine boxes: a face that is not a domain face is either shared as a whole with ONE neighbouring fine box or coarse-fine
-  S.Af.resize(nf); S.rf.resize(nf); S.own_hi.assign(3 * nf, 1);
-  for (int f = 0; f < nf; f++) {
-    const vdn_box &bx = phi[1]->vbox[f];
-    NdfArgs &A = S.Af[f];
-    for (int d = 0; d < 3; d++) {
-      A.f[d] = 1.0 / (36.0 * (dx[3 + d] * dx[3 + d]));
-      A.lo[d] = bx.lo[d]; A.hi[d] = bx.hi[d] + 1; A.ilo[d] = A.ihi[d] = 0;
-      S.rf[f].lo[d] = A.lo[d]; S.rf[f].hi[d] = A.hi[d];
-      for (int sd = 0; sd < 2; sd++) {
-        const int e = bct->ell_bc(1, f + 1, d, sd, press_comp0);
-        bool shared = false;
-        for (int g = 0; g < nf && e == VDN_BC_INT; g++) {
-          if (g == f) continue;
-          const vdn_box &ob = phi[1]->vbox[g];
-          const bool touch = sd ? (ob.lo[d] == bx.hi[d] + 1) : (ob.hi[d] + 1 == bx.lo[d]);
-          if (!touch) continue;
-          bool same = true, overlap = true;
-          for (int t = 0; t < 3; t++) if (t != d) { if (ob.lo[t] != bx.lo[t] || ob.hi[t] != bx.hi[t]) same = false; if (ob.hi[t] < bx.lo[t] || ob.lo[t] > bx.hi[t]) overlap = false; }
-          if (!overlap) continue;
-          REQUIRE(same, "composite nodal solve: neighbouring fine boxes must share whole faces (box %d / %d)", f, g);
-          shared = true;
+  MLND S; S.nlev = L; S.d_nrm = (double *)arena_alloc(256);
+  std::vector<vdn_multifab *> temps;
+  auto T = [&](vdn_multifab *m) { temps.push_back(m); return m; };
+  // boxes: a face that is not a domain face is either shared as a whole with ONE neighbouring box of the level or coarse-fine
+  for (int n = 0; n < L; n++) {
+    const int nb = phi[n]->nfabs();
+    S.multi[n] = nb > 1;
+    S.A[n].resize(nb); S.r[n].resize(nb); S.own_hi[n].assign(3 * nb, 1);
+    for (int f = 0; f < nb; f++) {
+      const vdn_box &bx = phi[n]->vbox[f];
+      NdfArgs &A = S.A[n][f];
+      for (int d = 0; d < 3; d++) {
+        A.f[d] = 1.0 / (36.0 * (dx[3 * n + d] * dx[3 * n + d]));
+        A.lo[d] = bx.lo[d]; A.hi[d] = bx.hi[d] + 1; A.ilo[d] = A.ihi[d] = 0;
+        S.r[n][f].lo[d] = A.lo[d]; S.r[n][f].hi[d] = A.hi[d];
+        for (int sd = 0; sd < 2; sd++) {
+          const int e = bct->ell_bc(n, f + 1, d, sd, press_comp0);
+          bool shared = false;
+          for (int g = 0; g < nb && e == VDN_BC_INT; g++) {
+            if (g == f) continue;
+            const vdn_box &ob = phi[n]->vbox[g];
+            const bool touch = sd ? (ob.lo[d] == bx.hi[d] + 1) : (ob.hi[d] + 1 == bx.lo[d]);
+            if (!touch) continue;
+            bool same = true, overlap = true;
+            for (int t = 0; t < 3; t++) if (t != d) { if (ob.lo[t] != bx.lo[t] || ob.hi[t] != bx.hi[t]) same = false; if (ob.hi[t] < bx.lo[t] || ob.lo[t] > bx.hi[t]) overlap = false; }
+            if (!overlap) continue;
+            REQUIRE(same, "composite nodal solve: neighbouring fine boxes must share whole faces (box %d / %d)", f, g);
+            shared = true;
+          }
+          (sd ? A.dirhi[d] : A.dirlo[d]) = (e == VDN_BC_DIR);
+          (sd ? A.cfhi[d] : A.cflo[d]) = (n > 0 && e == VDN_BC_INT && !shared);
+          if (sd == 1 && shared) S.own_hi[n][3 * f + d] = 0;
         }
-        (sd ? A.dirhi[d] : A.dirlo[d]) = (e == VDN_BC_DIR);
-        (sd ? A.cfhi[d] : A.cflo[d]) = (e == VDN_BC_INT && !shared);
-        if (sd == 1 && shared) S.own_hi[3 * f + d] = 0;
       }
     }
   }
-  for (int n = 0; n < 2; n++) { S.phi[n] = phi[n]; S.b[n] = mf_temp(la, n, 1, 1, 3, true, 0.0); S.res[n] = mf_temp(la, n, 1, 1, 3, true, 0.0); }
-  // masked coarse sigma, the coarse-node mask of the norm, the masked velocities
-  S.sig[1] = coeffs[1];
-  S.sig[0] = mf_temp(la, 0, 1, 1, -1, true, 0.0);
-  mf_copy(S.sig[0], 0, coeffs[0], 0, 1, 1);
-  S.cin = mf_temp(la, 0, 1, 1, 3, true, 0.0);
-  vdn_multifab *umc = mf_temp(la, 0, 3, 1, -1, false, 0.0), *umf = mf_temp(la, 1, 3, 1, -1, false, 0.0), *fmask = mf_temp(la, 1, 1, 1, -1, true, 0.0);
-  mf_copy(umc, 0, u[0], 0, 3, 1);
-  mf_setval(fmask, 1.0, 0, 1, false);
-  mf_fill_boundary(fmask);
-  for (int f = 0; f < nf; f++) {
-    const vdn_box &fb = phi[1]->vbox[f];
-    Range3 rcov, rin, rg; bool has_in = true;
-    for (int d = 0; d < 3; d++) { rcov.lo[d] = fb.lo[d] / 2; rcov.hi[d] = fb.hi[d] / 2; rin.lo[d] = rcov.lo[d] + 1; rin.hi[d] = rcov.hi[d]; if (rin.lo[d] > rin.hi[d]) has_in = false;
-      rg.lo[d] = fb.lo[d] - 1; rg.hi[d] = fb.hi[d] + 1; }
-    hipLaunchKernelGGL(kk_ndf_setbox, grid_for(rcov), NBLK, 0, st, S.sig[0]->fabs[0], rcov, 0.0);
-    hipLaunchKernelGGL(kk_ndf_zero3, grid_for(rcov), NBLK, 0, st, umc->fabs[0], rcov);
-    if (has_in) hipLaunchKernelGGL(kk_ndf_setbox, grid_for(rin), NBLK, 0, st, S.cin->fabs[0], rin, 1.0);
-    hipLaunchKernelGGL(kk_ndf_mul3, grid_for(rg), NBLK, 0, st, umf->fabs[f], u[1]->fabs[f], fmask->fabs[f], rg);
-    hipLaunchKernelGGL(kk_nd_divu, grid_for(S.rf[f]), NBLK, 0, st, umf->fabs[f], rh[1]->fabs[f], 0.25 / dx[3], 0.25 / dx[4], 0.25 / dx[5], S.rf[f]);
-    hipLaunchKernelGGL(kk_ndf_neg, grid_for(S.rf[f]), NBLK, 0, st, S.b[1]->fabs[f], rh[1]->fabs[f], S.Af[f], S.rf[f]);
+  vdn_multifab *zero[VDN_MAXLEV];
+  for (int n = 0; n < L; n++) {
+    S.phi[n] = phi[n]; S.b[n] = T(mf_temp(la, n, 1, 1, 3, true, 0.0)); S.res[n] = T(mf_temp(la, n, 1, 1, 3, true, 0.0));
+    zero[n] = T(mf_temp(la, n, 1, 1, 3, true, 0.0));
+    S.sigfull[n] = coeffs[n]; S.sig[n] = coeffs[n]; S.skip[n] = nullptr; S.scr[n] = nullptr;
+    S.ea[n] = n >= 1 ? zero[n] : nullptr; S.eb[n] = n >= 1 ? T(mf_temp(la, n, 1, 1, 3, true, 0.0)) : nullptr;
+    if (n >= 1 && n < L - 1) S.scr[n] = T(mf_temp(la, n, 1, 1, 3, true, 0.0));
   }
-  hipLaunchKernelGGL(kk_nd_divu, grid_for(S.rc), NBLK, 0, st, umc->fabs[0], rh[0]->fabs[0], 0.25 / dx[0], 0.25 / dx[1], 0.25 / dx[2], S.rc);
-  hipLaunchKernelGGL(kk_ndf_neg, grid_for(S.rc), NBLK, 0, st, S.b[0]->fabs[0], rh[0]->fabs[0], S.Ac, S.rc);
+  // masked sigma, the node mask of the norm, the masked velocities and the right-hand side b = -(rh + D u)
+  for (int n = 0; n < L; n++) {
+    vdn_multifab *um = T(mf_temp(la, n, 3, 1, -1, false, 0.0));
+    if (n == 0) mf_copy(um, 0, u[0], 0, 3, 1);
+    else {
+      vdn_multifab *fmask = T(mf_temp(la, n, 1, 1, -1, true, 0.0));
+      mf_setval(fmask, 1.0, 0, 1, false);
+      mf_fill_boundary(fmask);
+      for (int f = 0; f < phi[n]->nfabs(); f++) {
+        const vdn_box &fb = phi[n]->vbox[f];
+        Range3 rg; for (int d = 0; d < 3; d++) { rg.lo[d] = fb.lo[d] - 1; rg.hi[d] = fb.hi[d] + 1; }
+        hipLaunchKernelGGL(kk_ndf_mul3, grid_for(rg), NBLK, 0, st, um->fabs[f], u[n]->fabs[f], fmask->fabs[f], rg);
+      }
+    }
+    if (n < L - 1) {
+      S.sig[n] = T(mf_temp(la, n, 1, 1, -1, true, 0.0));
+      mf_copy(S.sig[n], 0, coeffs[n], 0, 1, 1);
+      S.skip[n] = T(mf_temp(la, n, 1, 1, 3, true, 0.0));
+      if (n >= 1) hipLaunchKernelGGL(kk_ndf_mark_cf, grid_for(S.r[n][0]), NBLK, 0, st, S.skip[n]->fabs[0], S.A[n][0], S.r[n][0]);
+      for (int f = 0; f < phi[n + 1]->nfabs(); f++) {
+        const vdn_box &fb = phi[n + 1]->vbox[f];
+        Range3 rcov, rin; bool has_in = true;
+        for (int d = 0; d < 3; d++) { rcov.lo[d] = fb.lo[d] / 2; rcov.hi[d] = fb.hi[d] / 2; rin.lo[d] = rcov.lo[d] + 1; rin.hi[d] = rcov.hi[d]; if (rin.lo[d] > rin.hi[d]) has_in = false; }
+        hipLaunchKernelGGL(kk_ndf_setbox, grid_for(rcov), NBLK, 0, st, S.sig[n]->fabs[0], rcov, 0.0);
+        hipLaunchKernelGGL(kk_ndf_zero3, grid_for(rcov), NBLK, 0, st, um->fabs[0], rcov);
+        if (has_in) hipLaunchKernelGGL(kk_ndf_setbox, grid_for(rin), NBLK, 0, st, S.skip[n]->fabs[0], rin, 1.0);
+      }
+    }
+    for (int f = 0; f < phi[n]->nfabs(); f++) {
+      hipLaunchKernelGGL(kk_nd_divu, grid_for(S.r[n][f]), NBLK, 0, st, um->fabs[f], rh[n]->fabs[f], 0.25 / dx[3 * n], 0.25 / dx[3 * n + 1], 0.25 / dx[3 * n + 2], S.r[n][f]);
+      hipLaunchKernelGGL(kk_ndf_neg, grid_for(S.r[n][f]), NBLK, 0, st, S.b[n]->fabs[f], rh[n]->fabs[f], S.A[n][f], S.r[n][f]);
+    }
+  }
   // norm of the composite right-hand side = composite residual of phi = 0
-  vdn_multifab *keep[2] = { S.phi[0], S.phi[1] }, *zero[2] = { mf_temp(la, 0, 1, 1, 3, true, 0.0), mf_temp(la, 1, 1, 1, 3, true, 0.0) };
-  S.phi[0] = zero[0]; S.phi[1] = zero[1];
+  for (int n = 0; n < L; n++) S.phi[n] = zero[n];
   const double bnorm = ml_nd_residual(S, false);
-  S.phi[0] = keep[0]; S.phi[1] = keep[1];
-  vdn_multifab *er = zero[0], *ee = mf_temp(la, 0, 1, 1, 3, true, 0.0);      // scratch of the coarse correction solve
-  vdn_multifab *ef = zero[1], *ef2 = mf_temp(la, 1, 1, 1, 3, true, 0.0);     // fine Jacobi ping-pong
+  for (int n = 0; n < L; n++) S.phi[n] = phi[n];
+  vdn_multifab *er = zero[0], *ee = T(mf_temp(la, 0, 1, 1, 3, true, 0.0));      // scratch of the coarse correction solve
   int ebc0[3][2];
   for (int d = 0; d < 3; d++) for (int s = 0; s < 2; s++) ebc0[d][s] = bct->ell_bc(0, 0, d, s, press_comp0);
   int it = 0; bool conv = (bnorm == 0.0); double rn = 0.0;
@@ -1289,54 +1337,58 @@ static int ml_nd_solve(vdn_layout *la, vdn_multifab **rh, vdn_multifab **phi, vd
     rn = ml_nd_residual(S, false);
     if (rn <= rel_eps * bnorm || rn <= abs_eps) { conv = true; break; }
     if (it >= max_iter) break;
-    // coarse correction K_c e = r_c: one V-cycle of the single-level solver (which takes rh with b = -rh)
+    // coarse correction K_0 e = r_0: one V-cycle of the single-level solver (which takes rh with b = -rh)
     mf_setval(ee, 0.0, 0, 1, true); mf_setval(er, 0.0, 0, 1, true);
-    { NdfArgs Z = S.Ac; for (int d = 0; d < 3; d++) { Z.dirlo[d] = Z.dirhi[d] = 0; }
-      hipLaunchKernelGGL(kk_ndf_neg, grid_for(S.rc), NBLK, 0, st, er->fabs[0], S.res[0]->fabs[0], Z, S.rc); }
+    { NdfArgs Z = S.A[0][0]; for (int d = 0; d < 3; d++) { Z.dirlo[d] = Z.dirhi[d] = 0; }
+      hipLaunchKernelGGL(kk_ndf_neg, grid_for(S.r[0][0]), NBLK, 0, st, er->fabs[0], S.res[0]->fabs[0], Z, S.r[0][0]); }
     int cyc; double r0, rr;
     nd_solve(er, ee, coeffs[0], nullptr, dx, ebc0, 0.0, -1.0, -1, &cyc, &r0, &rr);
-    hipLaunchKernelGGL(kk_ndf_add, grid_for(S.rc), NBLK, 0, st, S.phi[0]->fabs[0], ee->fabs[0], S.rc);
-    for (int f = 0; f < nf; f++) hipLaunchKernelGGL(kk_ndf_prolong, grid_for(S.rf[f]), NBLK, 0, st, S.phi[1]->fabs[f], ee->fabs[0], S.Af[f], 1, S.rf[f]);
-    // fine relaxation of K_f e = r_f with the interface fixed
-    (void)ml_nd_residual(S, true);
-    mf_setval(ef, 0.0, 0, 1, true);
-    vdn_multifab *a = ef, *b2 = ef2;
-    for (int s = 0; s < P.hg_nu1 + P.hg_nu2; s++) {
-      if (S.multi && s > 0) mf_fill_boundary(a);
-      for (int f = 0; f < nf; f++)
-        ndf_launch_march<0>(a->fabs[f], b2->fabs[f], S.res[1]->fabs[f], S.sig[1]->fabs[f], S.Af[f], P.hg_omega, 0, S.rf[f], (double *)nullptr);
-      std::swap(a, b2);
+    ml_nd_apply_correction(S, 0, ee);
+    // relaxation of K_n e = r_n on the finer levels, coarsest first, with the interface fixed
+    for (int n = 1; n < L; n++) {
+      (void)ml_nd_residual(S, n == L - 1);
+      mf_setval(S.ea[n], 0.0, 0, 1, true);
+      vdn_multifab *a = S.ea[n], *b2 = S.eb[n];
+      for (int s = 0; s < P.hg_nu1 + P.hg_nu2; s++) {
+        if (S.multi[n] && s > 0) mf_fill_boundary(a);
+        for (size_t f = 0; f < S.A[n].size(); f++)
+          ndf_launch_march<0>(a->fabs[f], b2->fabs[f], S.res[n]->fabs[f], S.sigfull[n]->fabs[f], S.A[n][f], P.hg_omega, 0, S.r[n][f], (double *)nullptr);
+        std::swap(a, b2);
+      }
+      ml_nd_apply_correction(S, n, a);
     }
-    for (int f = 0; f < nf; f++) hipLaunchKernelGGL(kk_ndf_add, grid_for(S.rf[f]), NBLK, 0, st, S.phi[1]->fabs[f], a->fabs[f], S.rf[f]);
     it++;
   }
-  for (int f = 0; f < nf; f++) hipLaunchKernelGGL(kk_ndf_prolong, grid_for(S.rf[f]), NBLK, 0, st, S.phi[1]->fabs[f], S.phi[0]->fabs[0], S.Af[f], 0, S.rf[f]);
-  if (S.multi) mf_fill_boundary(S.phi[1]);
+  for (int n = 1; n < L; n++) ml_nd_interface(S, n);
   if (iters) *iters = it; if (res0) *res0 = bnorm; if (res) *res = rn;
   HIPCHK(hipStreamSynchronize(st));
+  for (size_t i = temps.size(); i-- > 0;) mf_temp_free(temps[i]);
   arena_release(mark);
   return conv ? 0 : 1;
 }
-// hgproject.f90:17-178 with nlevs = 2 (rel 1e-11, hgproject.f90:115-116)
+// hgproject.f90:17-178 with nlevs > 1 (rel 1e-11 for two levels, 1e-10 for more: hgproject.f90:115-119)
 static void do_ml_hgproject(int proj_type, vdn_layout *mla, vdn_multifab **unew, vdn_multifab **uold, vdn_multifab **rhohalf,
                             vdn_multifab **p, vdn_multifab **gp, const double *dx, double dt, const vdn_bc_tower *bct, int press_comp0) {
   const size_t mark = arena_mark();
-  vdn_multifab *rh[2], *phi[2], *gphi[2], *coeffs[2];
-  for (int n = 0; n < 2; n++) {
+  const int L = mla->nlev;
+  REQUIRE(L <= VDN_MAXLEV, "hgproject: at most %d levels", VDN_MAXLEV);
+  vdn_multifab *rh[VDN_MAXLEV], *phi[VDN_MAXLEV], *gphi[VDN_MAXLEV], *coeffs[VDN_MAXLEV];
+  for (int n = 0; n < L; n++) {
     rh[n] = mf_temp(mla, n, 1, 1, 3, true, 0.0); phi[n] = mf_temp(mla, n, 1, 1, 3, true, 0.0);
     gphi[n] = mf_temp(mla, n, 3, 0, -1, false, 0.0); coeffs[n] = mf_temp(mla, n, 1, 1, -1, true, 0.0);
     hg_level_pre(proj_type, unew[n], uold[n], rhohalf[n], gp[n], coeffs[n], dt, bct);
   }
-  double rel = ctx().prm.hg_rel_eps > 0.0 ? ctx().prm.hg_rel_eps : 1.e-11;
+  double rel = ctx().prm.hg_rel_eps > 0.0 ? ctx().prm.hg_rel_eps : (L == 2 ? 1.e-11 : 1.e-10);
   double abs_eps = -1.0;
   if (proj_type == VDN_INITIAL_PROJECTION && ctx().prm.prob_type == 4) abs_eps = 1.e-12;
   int it; double r0, rr;
   int rc = ml_nd_solve(mla, rh, phi, coeffs, unew, dx, bct, press_comp0, rel, abs_eps, ctx().prm.hg_max_iter, &it, &r0, &rr);
   ctx().solver_cycles[1] = it; ctx().solver_res0[1] = r0; ctx().solver_res[1] = rr;
   if (rc != 0 && ctx().prm.verbose) fprintf(stderr, "varden_amd: composite nodal solve did not converge in %d iterations (res %g / %g)\n", it, rr, r0);
-  for (int n = 0; n < 2; n++) hg_level_post(proj_type, unew[n], uold[n], rhohalf[n], gp[n], p[n], gphi[n], phi[n], dx + 3 * n, dt);
-  ml_cc_restriction(gp[0], gp[1], 0, 3);                               // hgproject.f90:355-357
-  for (int n = 0; n < 2; n++) { mf_fill_boundary(gp[n]); mf_fill_boundary(p[n]); }
-  ml_restrict_and_fill(2, unew, 0, 0, 3, false, bct);                  // hgproject.f90:364-366
+  for (int n = 0; n < L; n++) hg_level_post(proj_type, unew[n], uold[n], rhohalf[n], gp[n], p[n], gphi[n], phi[n], dx + 3 * n, dt);
+  for (int n = L - 1; n >= 1; n--) ml_cc_restriction(gp[n - 1], gp[n], 0, 3);      // hgproject.f90:355-357
+  for (int n = 0; n < L; n++) { mf_fill_boundary(gp[n]); mf_fill_boundary(p[n]); }
+  ml_restrict_and_fill(L, unew, 0, 0, 3, false, bct);                  // hgproject.f90:364-366
+  for (int n = L - 1; n >= 0; n--) { mf_temp_free(coeffs[n]); mf_temp_free(gphi[n]); mf_temp_free(phi[n]); mf_temp_free(rh[n]); }
   arena_release(mark);
 }

@@ -6,6 +6,7 @@
 // performs no hipMalloc/hipFree (the reference allocates ~25 multifabs per step,
 // src/advance_timestep.f90:65-80,141-148).
 #pragma once
+#define VDN_MAXLEV 4          // deepest hierarchy the multi-level operators take (arrays sized [lev], [lev*3 + d])
 #include <hip/hip_runtime.h>
 #include <string>
 #include <vector>

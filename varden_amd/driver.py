@@ -164,28 +164,31 @@ class Varden:
 
 
 class VardenAMR:
-    """two-level hierarchy on fixed grids (the reference's fixed_grids mode, src/initialize.f90:93-150): level 0 = one box covering
-    the domain [0,nc)^3, level 1 = the given fine boxes (fine index space, refinement ratio 2).  The loop body of src/varden.f90:
-    ml_restrict_and_fill ghost fills, dt = min over levels of estdt, advance_timestep, new -> old copies."""
+    """multi-level hierarchy on fixed grids (the reference's fixed_grids mode, src/initialize.f90:93-150): level 0 = one box covering
+    the domain [0,nc)^3, level 1 = the given fine boxes (fine index space, refinement ratio 2); `finer_levels`: box lists of the
+    levels 2.. (one properly nested box each but the last).  The loop body of src/varden.f90: ml_restrict_and_fill ghost fills,
+    dt = min over levels of estdt, advance_timestep, new -> old copies."""
 
-    def __init__(self, nc, fine_boxes, phys_bc, params=None, prob_type=1, grav=-9.8, init_shrink=0.1, device=0):
+    def __init__(self, nc, fine_boxes, phys_bc, params=None, prob_type=1, grav=-9.8, init_shrink=0.1, device=0, finer_levels=()):
         self.prm = params or default_params()
         self.prm.prob_type = prob_type
         bl.initialize(self.prm, 0, 1, device)
         self.nc = nc
         self.phys = [[int(phys_bc[d][s]) for s in range(2)] for d in range(3)]
-        pd = [((0, 0, 0), (nc - 1,) * 3), ((0, 0, 0), (2 * nc - 1,) * 3)]
-        self.boxes = [[pd[0]], [(tuple(b[0]), tuple(b[1])) for b in fine_boxes]]
-        self.mla = bl.MLLayout(pd, self.boxes, rr=[(2, 2, 2)])
+        lev_boxes = [fine_boxes] + list(finer_levels)
+        self.nlev = NL = 1 + len(lev_boxes)
+        pd = [((0, 0, 0), ((nc << n) - 1,) * 3) for n in range(NL)]
+        self.boxes = [[pd[0]]] + [[(tuple(b[0]), tuple(b[1])) for b in lb] for lb in lev_boxes]
+        self.mla = bl.MLLayout(pd, self.boxes, rr=[(2, 2, 2)] * (NL - 1))
         self.bct = bl.BCTower(self.mla, self.phys)
-        self.dx = [[1.0 / nc] * 3, [0.5 / nc] * 3]
+        self.dx = [[1.0 / (nc << n)] * 3 for n in range(NL)]
         dm, ns = 3, self.prm.nscal
         self.dm, self.nscal, self.press_comp = dm, ns, dm + ns + 1
-        mk = lambda nc_, ng, nodal=None: [bl.MultiFab(self.mla, n, nc_, ng, nodal) for n in range(2)]   # noqa: E731
+        mk = lambda nc_, ng, nodal=None: [bl.MultiFab(self.mla, n, nc_, ng, nodal) for n in range(NL)]   # noqa: E731
         self.uold, self.sold, self.unew, self.snew = mk(dm, 3), mk(ns, 3), mk(dm, 3), mk(ns, 3)
         self.gp, self.p = mk(dm, 1), mk(1, 1, (1, 1, 1))
         self.ext_vel_force, self.ext_scal_force = mk(dm, 1), mk(ns, 1)
-        for n in range(2):
+        for n in range(self.nlev):
             self.ext_vel_force[n].setval(grav, dm - 1, 1, all=True)
             for i, (blo, bhi) in enumerate(self.boxes[n]):
                 nb = tuple(bhi[d] - blo[d] + 1 for d in range(3))
@@ -194,7 +197,7 @@ class VardenAMR:
                 self.sold[n].from_numpy(sb, i)
         self.time, self.istep = 0.0, 0
         self.fill_state_ghosts()
-        for n in range(2):
+        for n in range(self.nlev):
             self.unew[n].copy_c(0, self.uold[n], 0, dm, 3)
             self.snew[n].copy_c(0, self.sold[n], 0, ns, 3)
         self.dt = self.estdt(1.0e20) * init_shrink
@@ -205,7 +208,7 @@ class VardenAMR:
         adv.ml_restrict_and_fill(self.gp, 0, self.press_comp, self.dm, self.bct, same_boundary=True)   # extrap_comp (0-based press_comp + 1)
 
     def estdt(self, dtold):
-        return min(adv.estdt(n + 1, self.uold[n], self.sold[n], self.gp[n], self.ext_vel_force[n], self.dx[n], dtold) for n in range(2))
+        return min(adv.estdt(n + 1, self.uold[n], self.sold[n], self.gp[n], self.ext_vel_force[n], self.dx[n], dtold) for n in range(self.nlev))
 
     def step(self):
         self.istep += 1
@@ -214,7 +217,7 @@ class VardenAMR:
             self.dt = self.estdt(self.dt)
         adv.advance_timestep(self.istep, self.mla, self.sold, self.uold, self.snew, self.unew, self.gp, self.p,
                              self.ext_vel_force, self.ext_scal_force, self.bct, self.dt, self.time, self.dx, self.press_comp, bl.REGULAR_TIMESTEP)
-        for n in range(2):
+        for n in range(self.nlev):
             self.uold[n].copy_c(0, self.unew[n], 0, self.dm, 0)
             self.sold[n].copy_c(0, self.snew[n], 0, self.nscal, 0)
         self.time += self.dt
