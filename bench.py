@@ -169,7 +169,7 @@ def main():
             "config": {"workload": "3D %d^3 single-level variable-density bubble, 1 box/GPU, MAC+HG projection each step "
                                    "(BASELINE.json configs[1])" % n,
                        "parallelism": "single GPU" if world == 1 else
-                                      "domain decomposition %dx%dx%d, one 256^3 box per GPU (global %dx%dx%d), RCCL p2p ghost exchange + allreduce" % (decomp + nglob),
+                                      "domain decomposition %dx%dx%d, one %d^3 box per GPU (global %dx%dx%d), RCCL p2p ghost exchange + allreduce" % (decomp + (n,) + nglob),
                        "phase_ms_per_step": {k: round(1e3 * v / args.steps, 3) for k, v in phases.items()},
                        "vcycles_per_step": {k: round(v / args.steps, 2) for k, v in cyc.items()}},
             "roofline": roof, "cpu_baseline": cpu,

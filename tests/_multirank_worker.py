@@ -1,0 +1,55 @@
+"""one rank of a multi-rank run on ONE GPU (tests/test_multirank_gpu.py): ranks are processes, the transport is the RCCL test
+double tests/fake_rccl (VDN_RCCL_LIB), the rendezvous a file.  argv: rank nranks idfile outprefix bx by bz nx ny nz nsteps periodic"""
+import os
+import sys
+import time
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+
+def main():
+    rank, nranks = int(sys.argv[1]), int(sys.argv[2])
+    idfile, outprefix = sys.argv[3], sys.argv[4]
+    decomp = tuple(int(x) for x in sys.argv[5:8])
+    n = tuple(int(x) for x in sys.argv[8:11])
+    nsteps, periodic = int(sys.argv[11]), int(sys.argv[12])
+    from varden_amd import boxlib as bl
+    from varden_amd import driver
+    from varden_amd.capi import default_params
+    prm = default_params(cflfac=0.9)
+    comm_id = None
+    if nranks > 1:
+        bl.initialize(prm, rank, nranks, 0)
+        if rank == 0:
+            cid = bl.comm_get_unique_id()
+            with open(idfile + ".tmp", "wb") as f:
+                f.write(cid)
+            os.rename(idfile + ".tmp", idfile)
+        t0 = time.time()
+        while not os.path.exists(idfile):
+            time.sleep(0.01)
+            assert time.time() - t0 < 120, "rendezvous timed out"
+        comm_id = open(idfile, "rb").read()
+    walls = [[bl.NO_SLIP_WALL] * 2] * 3
+    if periodic:
+        walls = [[bl.PERIODIC] * 2] + [[bl.NO_SLIP_WALL] * 2] * 2
+    h = 1.0 / max(n)
+    G = driver.Varden(n, walls, prm, prob_type=1, grav=-9.8, prob_hi=tuple(n[d] * h for d in range(3)), init_shrink=0.1, init_iter=1,
+                      device=0, decomp=decomp, rank=rank, nranks=nranks, comm_id=comm_id)
+    dts = []
+    for _ in range(nsteps):
+        G.step()
+        dts.append(G.dt)
+    out = {"dt": np.array(dts)}
+    for li, gi in enumerate(G.local):
+        out["u%d" % gi] = G.unew[0].to_numpy(li)[3:-3, 3:-3, 3:-3]
+        out["s%d" % gi] = G.snew[0].to_numpy(li)[3:-3, 3:-3, 3:-3]
+        out["p%d" % gi] = G.p[0].to_numpy(li)[1:-1, 1:-1, 1:-1]
+    np.savez(outprefix + ".%d.npz" % rank, **out)
+    G.close()
+
+
+if __name__ == "__main__":
+    main()

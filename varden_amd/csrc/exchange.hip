@@ -51,8 +51,9 @@ static int packed_mode() { const char *e = getenv("VDN_FORCE_PACKED"); return e 
 
 static void rccl_load() {
   if (g_rccl.h) return;
-  const char *names[] = { "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1" };
-  for (const char *n : names) { g_rccl.h = dlopen(n, RTLD_NOW | RTLD_GLOBAL); if (g_rccl.h) break; }
+  // VDN_RCCL_LIB: an explicit library path (tests/fake_rccl: several ranks on ONE GPU for the multi-rank tests)
+  const char *names[] = { getenv("VDN_RCCL_LIB"), "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1" };
+  for (const char *n : names) { if (!n || !*n) continue; g_rccl.h = dlopen(n, RTLD_NOW | RTLD_LOCAL); if (g_rccl.h) break; }
   REQUIRE(g_rccl.h, "cannot dlopen librccl.so.1: %s", dlerror());
   #define SYM(field, name) do { *(void **)(&g_rccl.field) = dlsym(g_rccl.h, name); REQUIRE(g_rccl.field, "RCCL symbol %s missing", name); } while (0)
   SYM(GetUniqueId, "ncclGetUniqueId"); SYM(CommInitRank, "ncclCommInitRank"); SYM(CommDestroy, "ncclCommDestroy");
