@@ -95,7 +95,7 @@ extern "C" int vdn_advance_timestep(int istep, vdn_layout *mla, vdn_multifab **s
     for (int n = 0; n < nlevs; n++) {
       scal_force[n] = mf_temp(mla, n, nscal, 1, -1, false, 0.0);
       divu[n] = mf_temp(mla, n, 1, 1, -1, true, 0.0);
-      for (int d = 0; d < dm; d++) { sflux[3 * n + d] = mf_temp(mla, n, nscal, 0, d, true, 0.0); sedge[3 * n + d] = mf_temp(mla, n, nscal, 0, d, true, 0.0); }
+      for (int d = 0; d < dm; d++) { sflux[3 * n + d] = mf_temp(mla, n, nscal, 0, d, true, 0.0); sedge[3 * n + d] = mf_temp(mla, n, nscal, 0, d, false, 0.0); }   // mkflux writes every edge state
       if (diffusive) {                                                                  // scalar_advance.f90:80-89
         laps[n] = mf_temp(mla, n, nscal, 0, -1, true, 0.0);
         for (int c = 1; c < nscal; c++) k_explicit_diffusive_term(laps[n], sold[n], c, dm + c, DXL(n), bct);
@@ -131,7 +131,7 @@ extern "C" int vdn_advance_timestep(int istep, vdn_layout *mla, vdn_multifab **s
     vdn_multifab *vel_force[VDN_MAXLEV], *uflux[3 * VDN_MAXLEV], *uedge[3 * VDN_MAXLEV];
     for (int n = 0; n < nlevs; n++) {
       vel_force[n] = mf_temp(mla, n, dm, 1, -1, false, 0.0);
-      for (int d = 0; d < dm; d++) { uflux[3 * n + d] = mf_temp(mla, n, dm, 0, d, true, 0.0); uedge[3 * n + d] = mf_temp(mla, n, dm, 0, d, true, 0.0); }
+      for (int d = 0; d < dm; d++) { uflux[3 * n + d] = mf_temp(mla, n, dm, 0, d, false, 0.0); uedge[3 * n + d] = mf_temp(mla, n, dm, 0, d, false, 0.0); }   // uedge: written everywhere; uflux: never read (no conservative velocity component)
       k_mkvelforce(vel_force[n], ext_vel_force[n], sold[n], gp[n], lapu[n], 1.0);
     }
     restrict_and_fill(nlevs, vel_force, 0, bct->extrap_comp0(), dm, true, bct);

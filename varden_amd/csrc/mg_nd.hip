@@ -289,6 +289,46 @@ __global__ void kk_nd_prolong(NLev F, NLev C) {
   const long f = nidx(F, i, j, k);
   F.phi[f] = F.phi[f] + nd_interp8(C, C.phi, i >> 1, j >> 1, k >> 1, i & 1, j & 1, k & 1);
 }
+// k-marching form of kk_nd_prolong / kk_nd_prolong_tail: a thread owns a fine (i,j) column of a slab of planes and keeps the four
+// coarse values of planes K and K+1 in registers -- 4 coarse loads per TWO fine planes instead of 8 per node; same sums, same order
+__global__ void __launch_bounds__(256) kk_nd_prolong_m(NLev F, NLev C, int c00, int c01, int c02, int kchunk) {
+  const int i = blockIdx.x * 64 + threadIdx.x, j = blockIdx.y * 4 + threadIdx.y;
+  const int k0 = (int)blockIdx.z * kchunk, k1 = min(k0 + kchunk - 1, F.n[2]);          // kchunk is even: k0 is even
+  if (i > F.n[0] || j > F.n[1] || k0 > k1) return;
+  const int oi = i & 1, oj = j & 1;
+  const long sy = C.PX, sz = (long)C.PX * C.PY;
+  const double *__restrict__ cp = C.phi;
+  long c0 = nidx(C, c00 + (i >> 1), c01 + (j >> 1), c02 + (k0 >> 1));
+  double a00 = cp[c0], a10 = cp[c0 + 1], a01 = cp[c0 + sy], a11 = cp[c0 + sy + 1];
+  const bool dir_ij = (i == 0 && F.dirlo[0]) || (i == F.n[0] && F.dirhi[0]) || (j == 0 && F.dirlo[1]) || (j == F.n[1] && F.dirhi[1]);
+  const double w0 = 1.0 / (double)((1 + oi) * (1 + oj)), w1 = 1.0 / (double)((1 + oi) * (1 + oj) * 2);
+  for (int k = k0; k <= k1; k += 2) {
+    const double b00 = cp[c0 + sz], b10 = cp[c0 + sz + 1], b01 = cp[c0 + sz + sy], b11 = cp[c0 + sz + sy + 1];
+    const long f = nidx(F, i, j, k);
+    const double pe = F.phi[f];
+    const bool odd_in = k + 1 <= k1;
+    const long f2 = f + (long)F.PX * F.PY;
+    const double po = odd_in ? F.phi[f2] : 0.0;
+    double s = 0.0;
+    s = s + a00;
+    s = oi ? s + a10 : s;
+    s = oj ? s + a01 : s;
+    s = (oi && oj) ? s + a11 : s;
+    double t = s;
+    t = t + b00;
+    t = oi ? t + b10 : t;
+    t = oj ? t + b01 : t;
+    t = (oi && oj) ? t + b11 : t;
+    if (!(dir_ij || (k == 0 && F.dirlo[2]) || (k == F.n[2] && F.dirhi[2]))) F.phi[f] = pe + s * w0;
+    if (odd_in && !(dir_ij || (k + 1 == F.n[2] && F.dirhi[2]))) F.phi[f2] = po + t * w1;
+    a00 = b00; a10 = b10; a01 = b01; a11 = b11; c0 += sz;
+  }
+}
+static void nd_launch_prolong(const NLev &F, const NLev &C, int c00, int c01, int c02) {
+  const int nzp = F.n[2] + 1;
+  const int kchunk = nzp > 64 ? 16 : (nzp > 16 ? 8 : 2);
+  hipLaunchKernelGGL(kk_nd_prolong_m, dim3((F.n[0] + 64) / 64, (F.n[1] + 4) / 4, (nzp + kchunk - 1) / kchunk), dim3(64, 4, 1), 0, ctx().stream, F, C, c00, c01, c02, kchunk);
+}
 __global__ void kk_nd_coarsen_sigma(NLev F, NLev C) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   const int j = blockIdx.y * blockDim.y + threadIdx.y;
@@ -652,7 +692,7 @@ static void nd_vcycle_t(NDMG &M, int l) {
   hipLaunchKernelGGL(kk_nd_restrict, ng3(C.n[0] + 1, C.n[1] + 1, C.n[2] + 1), NBLK, 0, ctx().stream, L, C);
   nd_vcycle_t(M, l + 1);
   nd_fill_nodes(C, C.phi);
-  hipLaunchKernelGGL(kk_nd_prolong, ng3(L.n[0] + 1, L.n[1] + 1, L.n[2] + 1), NBLK, 0, ctx().stream, L, C);
+  nd_launch_prolong(L, C, 0, 0, 0);
   nd_jacobi_t(L, P.hg_nu2);
 }
 
@@ -684,10 +724,9 @@ static void nd_prolong_up(NDMG &M, int l) {
   for (size_t b = 0; b < DL.boxes.size(); b++) {
     NBox &B = DL.boxes[b];
     if (l + 1 < (int)M.dlev.size())
-      hipLaunchKernelGGL(kk_nd_prolong, ng3(B.L.n[0] + 1, B.L.n[1] + 1, B.L.n[2] + 1), NBLK, 0, ctx().stream, B.L, M.dlev[l + 1].boxes[b].L);
+      nd_launch_prolong(B.L, M.dlev[l + 1].boxes[b].L, 0, 0, 0);
     else
-      hipLaunchKernelGGL(kk_nd_prolong_tail, ng3(B.L.n[0] + 1, B.L.n[1] + 1, B.L.n[2] + 1), NBLK, 0, ctx().stream, B.L, M.tail[0],
-                         B.lo[0] / 2, B.lo[1] / 2, B.lo[2] / 2, B.lo[0], B.lo[1], B.lo[2]);
+      nd_launch_prolong(B.L, M.tail[0], B.lo[0] / 2, B.lo[1] / 2, B.lo[2] / 2);
   }
 }
 static int nd_bottom_sweeps_global(const NDLev &DL) {
