@@ -148,6 +148,125 @@ __global__ void __launch_bounds__(256) kk_cc_gsrb_fused(CLev L, const double *__
   }
 }
 
+// ---- fused red+black sweep, register/shuffle form -----------------------------------------------------------------------
+// Same pipeline as kk_cc_gsrb_fused (per k step: load plane k+2, RED cells of plane k+1, BLACK cells of plane k, write plane k)
+// with the planes in registers.  A thread owns a PAIR of adjacent columns (2t, 2t+1) of one row j: in step k exactly one column
+// of the pair (the same one for the whole wave: the "worker") has its cell of plane k+1 red and its cell of plane k black, so
+// every lane does one red and one black update per step -- no idle lanes -- and fetches, unconditionally, the coefficients of
+// the OTHER column's two updates of step k+1 (software prefetch by one step, one register set per column).  Neighbours:
+// i-1 / i+1 = the thread's other column and the adjacent lane's (one wave shuffle), j-1 / j+1 = a three-plane LDS ring,
+// k-1 / k+1 = own registers.  One barrier per plane.  A workgroup is 16 rows x 128 columns; the outer ring of two columns/rows
+// only feeds values (tile of 124 x 12 outputs), the ring of one recomputes the red cells its neighbours own (identical
+// arithmetic, identical bits).  Reads `pin`, writes `pout`.  Valid when the level is one box without periodic faces (the ghost
+// layer of phi is then identically zero).
+#define GW_L 64            // lanes per row
+#define GW_Y 16
+#define GW_OX (2 * GW_L - 4)
+#define GW_OY (GW_Y - 4)
+struct CCoef { double bxm, bxp, bym, byp, bzm, bzp, rh, a0; };
+DEVI void cc_load_coef(const CLev &L, long c, CCoef &q) {
+  const long sy = L.PX, sz = (long)L.PX * L.PY;
+  q.bxm = L.b[0][c]; q.bxp = L.b[0][c + 1];
+  q.bym = L.b[1][c]; q.byp = L.b[1][c + sy];
+  q.bzm = L.b[2][c]; q.bzp = L.b[2][c + sz];
+  q.rh = L.rh[c];
+  q.a0 = L.alpha ? L.alpha[c] : 0.0;
+}
+DEVI double cc_update_coef(const CLev &L, const CCoef &q, double p0, double pxm, double pxp, double pym, double pyp, double pzm, double pzp) {
+  const double ax = (q.bxp * (p0 - pxp) + q.bxm * (p0 - pxm)) * L.hi2[0];
+  const double ay = (q.byp * (p0 - pyp) + q.bym * (p0 - pym)) * L.hi2[1];
+  const double az = (q.bzp * (p0 - pzp) + q.bzm * (p0 - pzm)) * L.hi2[2];
+  double Ap = ax + ay + az;
+  double diag = (q.bxp + q.bxm) * L.hi2[0] + (q.byp + q.bym) * L.hi2[1] + (q.bzp + q.bzm) * L.hi2[2];
+  if (L.alpha) { Ap = Ap + q.a0 * p0; diag = diag + q.a0; }
+  return (diag != 0.0) ? p0 + (q.rh - Ap) / diag : p0;
+}
+__global__ void __launch_bounds__(GW_L * GW_Y) kk_cc_gsrb_wave(CLev L, const double *__restrict__ pin, double *__restrict__ pout, int kchunk) {
+  __shared__ double sp[3][GW_Y][2][GW_L];                     // [plane ring][row][even / odd column of the pair][lane]
+  const int lane = threadIdx.x, row = threadIdx.y;
+  const int nx = L.n[0], ny = L.n[1], nz = L.n[2];
+  const int j = (int)blockIdx.y * GW_OY - 2 + row;
+  const int k0 = (int)blockIdx.z * kchunk, k1 = min(k0 + kchunk, nz) - 1;
+  if (k0 > k1) return;
+  // X = the column that works in the steps with k - k0 even: (iX + j + k0) odd.  The pair starts at an even i.
+  // colours: X is red in the planes k0-1, k0+1, ..., Y in the planes k0, k0+2, ...
+  const bool xleft = ((j + k0) & 1) != 0;                    // wave-uniform: X is the left (even) column of the pair
+  const int cX = xleft ? 0 : 1, cY = 1 - cX;
+  const int ia = (int)blockIdx.x * GW_OX - 2 + 2 * lane;
+  const int iX = ia + cX, iY = ia + cY, pX = 2 * lane + cX, pY = 2 * lane + cY;       // global index / position in the 128-column row
+  const bool row_red = row >= 1 && row <= GW_Y - 2 && j >= 0 && j < ny, row_out = row >= 2 && row <= GW_Y - 3 && j >= 0 && j < ny;
+  const bool redX = row_red && iX >= 0 && iX < nx && pX >= 1 && pX <= 2 * GW_L - 2, outX = row_out && iX >= 0 && iX < nx && pX >= 2 && pX <= 2 * GW_L - 3;
+  const bool redY = row_red && iY >= 0 && iY < nx && pY >= 1 && pY <= 2 * GW_L - 2, outY = row_out && iY >= 0 && iY < nx && pY >= 2 && pY <= 2 * GW_L - 3;
+  const int jc = min(max(j, -1), ny), jcc = min(max(j, 0), ny - 1);
+  const long sz = (long)L.PX * L.PY;
+  const long colX = cidx(L, min(max(iX, -1), nx), jc, 0), colY = cidx(L, min(max(iY, -1), nx), jc, 0);          // phi columns (ghost ring allowed)
+  const long cofX = cidx(L, min(max(iX, 0), nx - 1), jcc, 0), cofY = cidx(L, min(max(iY, 0), nx - 1), jcc, 0);  // coefficient columns (cells)
+  const int rm = max(row - 1, 0), rp = min(row + 1, GW_Y - 1);
+  auto ldp = [&](long col, int k) -> double { return pin[col + (long)min(max(k, -1), nz) * sz]; };
+  auto cof = [&](long c, int k) -> long { return c + (long)min(max(k, 0), nz - 1) * sz; };
+  // x-neighbours (lo = i-1, hi = i+1) of an X cell are Y cells -- the thread's own and the adjacent lane's -- and vice versa
+  auto nbr_of_X = [&](double vY, double &lo, double &hi) { const double sh = xleft ? __shfl_up(vY, 1, 64) : __shfl_down(vY, 1, 64); lo = xleft ? sh : vY; hi = xleft ? vY : sh; };
+  auto nbr_of_Y = [&](double vX, double &lo, double &hi) { const double sh = xleft ? __shfl_down(vX, 1, 64) : __shfl_up(vX, 1, 64); lo = xleft ? vX : sh; hi = xleft ? sh : vX; };
+  double pmX = ldp(colX, k0 - 1), p0X = ldp(colX, k0), p1X = ldp(colX, k0 + 1), p2X = ldp(colX, k0 + 2);
+  double pmY = ldp(colY, k0 - 1), p0Y = ldp(colY, k0), p1Y = ldp(colY, k0 + 1), p2Y = ldp(colY, k0 + 2);
+  const double pmmX = ldp(colX, k0 - 2);
+  double q1X = ldp(colX, k0 + 3), q1Y = ldp(colY, k0 + 3), q2X = ldp(colX, k0 + 4), q2Y = ldp(colY, k0 + 4);     // planes fetched ahead
+  CCoef crX, cbX, crY, cbY;
+  cc_load_coef(L, cof(cofX, k0 + 1), crX); cc_load_coef(L, cof(cofX, k0), cbX);       // step k0: X red in plane k0+1, black in plane k0
+  // warm-up: the red cells of planes k0-1 (column X) and k0 (column Y).  Slot of plane p: (p + 3) % 3
+  sp[(k0 + 2) % 3][row][cX][lane] = pmX; sp[(k0 + 2) % 3][row][cY][lane] = pmY;
+  sp[k0 % 3][row][cX][lane] = p0X;       sp[k0 % 3][row][cY][lane] = p0Y;
+  sp[(k0 + 1) % 3][row][cX][lane] = p1X; sp[(k0 + 1) % 3][row][cY][lane] = p1Y;
+  __syncthreads();
+  {
+    double lo, hi; nbr_of_X(pmY, lo, hi);
+    CCoef q; cc_load_coef(L, cof(cofX, k0 - 1), q);
+    if (redX && k0 - 1 >= 0) pmX = cc_update_coef(L, q, pmX, lo, hi, sp[(k0 + 2) % 3][rm][cX][lane], sp[(k0 + 2) % 3][rp][cX][lane], pmmX, p0X);
+  }
+  {
+    double lo, hi; nbr_of_Y(p0X, lo, hi);
+    CCoef q; cc_load_coef(L, cof(cofY, k0), q);
+    if (redY) { p0Y = cc_update_coef(L, q, p0Y, lo, hi, sp[k0 % 3][rm][cY][lane], sp[k0 % 3][rp][cY][lane], pmY, p1Y); sp[k0 % 3][row][cY][lane] = p0Y; }
+  }
+  // one step: U = the working column, V = the other one
+  #define GW_STEP(k, U, V)                                                                                                         \
+  {                                                                                                                                \
+    cc_load_coef(L, cof(cof##V, (k) + 2), cr##V); cc_load_coef(L, cof(cof##V, (k) + 1), cb##V);   /* for step k+1 */               \
+    __syncthreads();                                            /* plane k+1 (old) and the red cells of plane k are visible */    \
+    sp[((k) + 2) % 3][row][cX][lane] = p2X; sp[((k) + 2) % 3][row][cY][lane] = p2Y;      /* old plane k+2, read in the next step */ \
+    double lo1, hi1, lo0, hi0;                                                                                                     \
+    nbr_of_##U(p1##V, lo1, hi1);                                                                                                   \
+    nbr_of_##U(p0##V, lo0, hi0);                                                                                                   \
+    if (red##U && (k) + 1 < nz) {                                                                                                  \
+      p1##U = cc_update_coef(L, cr##U, p1##U, lo1, hi1, sp[((k) + 1) % 3][rm][c##U][lane], sp[((k) + 1) % 3][rp][c##U][lane], p0##U, p2##U); \
+      sp[((k) + 1) % 3][row][c##U][lane] = p1##U;                                                                                  \
+    }                                                                                                                              \
+    if (out##U) p0##U = cc_update_coef(L, cb##U, p0##U, lo0, hi0, sp[(k) % 3][rm][c##U][lane], sp[(k) % 3][rp][c##U][lane], pm##U, p1##U); \
+    if (outX) pout[colX + (long)(k) * sz] = p0X;                                                                                   \
+    if (outY) pout[colY + (long)(k) * sz] = p0Y;                                                                                   \
+    pmX = p0X; p0X = p1X; p1X = p2X; p2X = q1X; q1X = q2X; q2X = ldp(colX, (k) + 5);                                               \
+    pmY = p0Y; p0Y = p1Y; p1Y = p2Y; p2Y = q1Y; q1Y = q2Y; q2Y = ldp(colY, (k) + 5);                                               \
+  }
+  int k = k0;
+  for (; k + 1 <= k1; k += 2) {
+    GW_STEP(k, X, Y)
+    GW_STEP(k + 1, Y, X)
+  }
+  if (k <= k1) GW_STEP(k, X, Y)
+  #undef GW_STEP
+}
+static void cc_launch_wave(CLev &L, int nsweeps) {
+  const int tx = (L.n[0] + GW_OX - 1) / GW_OX, ty = (L.n[1] + GW_OY - 1) / GW_OY;
+  int kchunk = L.n[2];
+  while (kchunk > 32 && tx * ty * ((L.n[2] + kchunk - 1) / kchunk) < 512) kchunk = (kchunk + 1) / 2;
+  kchunk += kchunk & 1;                                       // even: the column roles of a chunk follow from (j + k0)
+  const int nch = (L.n[2] + kchunk - 1) / kchunk;
+  for (int s = 0; s < nsweeps; s++) {
+    hipLaunchKernelGGL(kk_cc_gsrb_wave, dim3(tx, ty, nch), dim3(GW_L, GW_Y, 1), 0, ctx().stream, L, (const double *)L.phi, L.phi2, kchunk);
+    std::swap(L.phi, L.phi2);
+  }
+}
+
 __global__ void __launch_bounds__(256) kk_cc_residual(CLev L, double *nrm) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   const int j = blockIdx.y * blockDim.y + threadIdx.y;
@@ -465,10 +584,12 @@ static void cc_build(CCMG &M, const vdn_multifab *rh, const double *dx, const in
       x.owner = la->owner[lev][g];
       if (x.owner == ctx().rank) {
         CBox B; B.L = cc_alloc_lev(n, h, has_alpha); B.gidx = g;
-        // the fused red+black sweep is an opt-in experiment (VDN_FUSED_GSRB=1): measured on MI355X at 256^3 it takes
-        // 0.30 ms per sweep against 2 x 0.15 ms for two colour-pass launches (barrier-bound plane pipeline), and it is
-        // slower on the 64^3 / 128^3 levels -- see DESIGN.md
-        static const bool use_fused = getenv("VDN_FUSED_GSRB") && atoi(getenv("VDN_FUSED_GSRB")) == 1;
+        // the fused red+black sweeps are opt-in experiments (VDN_FUSED_GSRB=1: LDS plane ring, =2: register/shuffle column
+        // pairs): measured on MI355X at 256^3 they take 0.30 ms (=1) and 0.33 ms (=2) per sweep against 2 x 0.15 ms for two
+        // colour-pass launches, and are slower still on the 64^3 / 128^3 levels.  Halving the HBM traffic does not pay here: the
+        // plane pipeline costs a barrier per plane, the halo rings recompute 40 % of the red cells, and the f64 divisions of two
+        // updates per thread and step keep the SIMDs busy for ~2 us per plane -- see DESIGN.md
+        static const bool use_fused = getenv("VDN_FUSED_GSRB") && atoi(getenv("VDN_FUSED_GSRB")) >= 1;
         if (use_fused && nb == 1 && !(M.per[0] || M.per[1] || M.per[2]) && (long)n[0] * n[1] * n[2] > 32L * 32 * 32) {
           B.L.phi2 = (double *)arena_alloc(sizeof(double) * B.L.sz);
           HIPCHK(hipMemsetAsync(B.L.phi2, 0, sizeof(double) * B.L.sz, ctx().stream));
@@ -540,7 +661,10 @@ static void cc_halo(CCMG &M, CDLev &DL) { if (DL.halo) xplan_run(DL.halo); }
 // levels of at most 8^3 cells held in ONE box are smoothed by a single workgroup in one launch (all sweeps, both
 // colours, periodic images included): such levels are launch-latency bound, not bandwidth bound
 static const long SMALL_LEVEL_CELLS = 8L * 8 * 8;
+static void cc_launch_wave(CLev &L, int nsweeps);
 static void cc_launch_fused(CLev &L, int nsweeps) {
+  static const int mode = getenv("VDN_FUSED_GSRB") ? atoi(getenv("VDN_FUSED_GSRB")) : 0;
+  if (mode == 2) { cc_launch_wave(L, nsweeps); return; }
   const int tiles = ((L.n[0] + FT_X - 1) / FT_X) * ((L.n[1] + FT_Y - 1) / FT_Y);
   int kchunk = L.n[2];
   while (kchunk > 16 && tiles * ((L.n[2] + kchunk - 1) / kchunk) < 1024) kchunk = (kchunk + 1) / 2;
@@ -793,10 +917,18 @@ void cc_bench_smoother(vdn_multifab *rh, vdn_multifab *phi, vdn_multifab **beta,
   const CLev &L = M.dlev[0].boxes[0].L;
   hipStream_t st = ctx().stream;
   hipEvent_t e0, e1; HIPCHK(hipEventCreate(&e0)); HIPCHK(hipEventCreate(&e1));
+  CLev &Lm = M.dlev[0].boxes[0].L;
+  if (Lm.phi2) {           // the fused sweep is what the solver runs: time full sweeps, reported per colour pass (nlaunch counts passes)
+    cc_launch_fused(Lm, 2);
+    HIPCHK(hipEventRecord(e0, st));
+    cc_launch_fused(Lm, nlaunch / 2);
+    HIPCHK(hipEventRecord(e1, st));
+  } else {
   for (int w = 0; w < 4; w++) hipLaunchKernelGGL(kk_cc_gsrb, g3((L.n[0] + 1) / 2, L.n[1], L.n[2], BLK), BLK, 0, st, L, w & 1);
   HIPCHK(hipEventRecord(e0, st));
   for (int w = 0; w < nlaunch; w++) hipLaunchKernelGGL(kk_cc_gsrb, g3((L.n[0] + 1) / 2, L.n[1], L.n[2], BLK), BLK, 0, st, L, w & 1);
   HIPCHK(hipEventRecord(e1, st));
+  }
   HIPCHK(hipEventSynchronize(e1));
   float ms = 0; HIPCHK(hipEventElapsedTime(&ms, e0, e1));
   *avg_ms = (double)ms / nlaunch; *cells = (long)L.n[0] * L.n[1] * L.n[2];
