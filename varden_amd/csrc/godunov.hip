@@ -309,7 +309,7 @@ static dim3 march_grid(const Range3 &r, int &klen) {
     const int buf = k & 1;                                                               \
     (void)kp; (void)vz; (void)edge; (void)ip; (void)jp; (void)vx; (void)vy;
 
-DEVI double shfl_prev(double v) { return __shfl_up(v, 1, 64); }
+DEVI double shfl_prev(double v) { return lane_prev(v); }
 DEVI bool in_valid(const GArgs &A, int d, int q) { return q >= A.lo[d] && q <= A.hi[d]; }
 DEVI double tv(bool cons, double fcons, double fconv, double dxT, double sp, double s0, double mp, double m0) {   // = trans_term on values
   if (cons) return (fcons / dxT) * (sp * mp - s0 * m0);

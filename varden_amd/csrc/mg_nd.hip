@@ -179,11 +179,11 @@ __global__ void __launch_bounds__(256) kk_nd_march(NLev L, const double *__restr
     for (int dj = 0; dj < 2; dj++) sg[0][dj][1] = L.sig[c - sz + (dj - 1) * sy];
     #pragma unroll
     for (int b = 0; b < 3; b++) {
-      p[0][b][0] = __shfl_up(p[0][b][1], 1, 64); p[0][b][2] = __shfl_down(p[0][b][1], 1, 64);
-      p[1][b][0] = __shfl_up(p[1][b][1], 1, 64); p[1][b][2] = __shfl_down(p[1][b][1], 1, 64);
+      p[0][b][0] = lane_prev(p[0][b][1]); p[0][b][2] = lane_next(p[0][b][1]);
+      p[1][b][0] = lane_prev(p[1][b][1]); p[1][b][2] = lane_next(p[1][b][1]);
     }
     #pragma unroll
-    for (int dj = 0; dj < 2; dj++) sg[0][dj][0] = __shfl_up(sg[0][dj][1], 1, 64);
+    for (int dj = 0; dj < 2; dj++) sg[0][dj][0] = lane_prev(sg[0][dj][1]);
     const bool dir_ij = (i == 0 && L.dirlo[0]) || (i == L.n[0] && L.dirhi[0]) || (j == 0 && L.dirlo[1]) || (j == L.n[1] && L.dirhi[1]);
     for (int k = k0; k <= k1; k++, c += sz) {
       #pragma unroll
@@ -192,9 +192,9 @@ __global__ void __launch_bounds__(256) kk_nd_march(NLev L, const double *__restr
       for (int dj = 0; dj < 2; dj++) sg[1][dj][1] = L.sig[c + (dj - 1) * sy];
       const double rhs = L.b[c];
       #pragma unroll
-      for (int b = 0; b < 3; b++) { p[2][b][0] = __shfl_up(p[2][b][1], 1, 64); p[2][b][2] = __shfl_down(p[2][b][1], 1, 64); }
+      for (int b = 0; b < 3; b++) { p[2][b][0] = lane_prev(p[2][b][1]); p[2][b][2] = lane_next(p[2][b][1]); }
       #pragma unroll
-      for (int dj = 0; dj < 2; dj++) sg[1][dj][0] = __shfl_up(sg[1][dj][1], 1, 64);
+      for (int dj = 0; dj < 2; dj++) sg[1][dj][0] = lane_prev(sg[1][dj][1]);
       const bool dir = dir_ij || (k == 0 && L.dirlo[2]) || (k == L.n[2] && L.dirhi[2]);
       const double p0 = p[1][1][1];
       double Kp, diag; nd_apply_reg(L, p, sg, Kp, diag);
@@ -1110,11 +1110,11 @@ __global__ void __launch_bounds__(256) kk_ndf_march(FV phi, FV out, FV rb, FV si
     for (int dj = 0; dj < 2; dj++) sg[0][dj][1] = fv_get(sig, ic, jc + dj - 1, k0 - 1);
     #pragma unroll
     for (int b = 0; b < 3; b++) {
-      p[0][b][0] = __shfl_up(p[0][b][1], 1, 64); p[0][b][2] = __shfl_down(p[0][b][1], 1, 64);
-      p[1][b][0] = __shfl_up(p[1][b][1], 1, 64); p[1][b][2] = __shfl_down(p[1][b][1], 1, 64);
+      p[0][b][0] = lane_prev(p[0][b][1]); p[0][b][2] = lane_next(p[0][b][1]);
+      p[1][b][0] = lane_prev(p[1][b][1]); p[1][b][2] = lane_next(p[1][b][1]);
     }
     #pragma unroll
-    for (int dj = 0; dj < 2; dj++) sg[0][dj][0] = __shfl_up(sg[0][dj][1], 1, 64);
+    for (int dj = 0; dj < 2; dj++) sg[0][dj][0] = lane_prev(sg[0][dj][1]);
     const double fx = A.f[0], fy = A.f[1], fz = A.f[2], F = fx + fy + fz;
     double w[8];
     w[0] = 4.0 * F; w[1] = -4.0 * fx + 2.0 * fy + 2.0 * fz; w[2] = 2.0 * fx - 4.0 * fy + 2.0 * fz; w[3] = -2.0 * fx - 2.0 * fy + fz;
@@ -1126,9 +1126,9 @@ __global__ void __launch_bounds__(256) kk_ndf_march(FV phi, FV out, FV rb, FV si
       for (int dj = 0; dj < 2; dj++) sg[1][dj][1] = fv_get(sig, ic, jc + dj - 1, k);
       const double rhs = fv_get(rb, ic, jc, k);
       #pragma unroll
-      for (int b = 0; b < 3; b++) { p[2][b][0] = __shfl_up(p[2][b][1], 1, 64); p[2][b][2] = __shfl_down(p[2][b][1], 1, 64); }
+      for (int b = 0; b < 3; b++) { p[2][b][0] = lane_prev(p[2][b][1]); p[2][b][2] = lane_next(p[2][b][1]); }
       #pragma unroll
-      for (int dj = 0; dj < 2; dj++) sg[1][dj][0] = __shfl_up(sg[1][dj][1], 1, 64);
+      for (int dj = 0; dj < 2; dj++) sg[1][dj][0] = lane_prev(sg[1][dj][1]);
       // K phi in the order of ndf_apply: cells (dk,dj,di) ascending, corners (mz,my,mx) ascending
       double acc = 0.0, ssum = 0.0;
       #pragma unroll

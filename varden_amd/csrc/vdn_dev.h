@@ -4,6 +4,21 @@
 #include "vdn_internal.h"
 
 #define DEVI __device__ __forceinline__
+// neighbouring-lane reads by DPP wave shifts (gfx9 wave_shr:1 / wave_shl:1) instead of ds_bpermute: no LDS round trip.
+// lane_prev: lane l gets lane l-1's value (lane 0 keeps its own), lane_next: lane l gets lane l+1's (lane 63 keeps its own) --
+// the semantics of __shfl_up(v, 1, 64) / __shfl_down(v, 1, 64)
+__device__ __forceinline__ double lane_prev(double v) {
+  int lo = __double2loint(v), hi = __double2hiint(v);
+  lo = __builtin_amdgcn_update_dpp(lo, lo, 0x138, 0xf, 0xf, false);
+  hi = __builtin_amdgcn_update_dpp(hi, hi, 0x138, 0xf, 0xf, false);
+  return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double lane_next(double v) {
+  int lo = __double2loint(v), hi = __double2hiint(v);
+  lo = __builtin_amdgcn_update_dpp(lo, lo, 0x130, 0xf, 0xf, false);
+  hi = __builtin_amdgcn_update_dpp(hi, hi, 0x130, 0xf, 0xf, false);
+  return __hiloint2double(hi, lo);
+}
 
 DEVI long fv_idx(const FV &f, int i, int j, int k) {
   return (long)(i - f.a0) + (long)f.n0 * ((long)(j - f.a1) + (long)f.n1 * (long)(k - f.a2));
