@@ -179,13 +179,13 @@ int  vdn_hgproject(int proj_type, vdn_layout *mla, vdn_multifab **unew, vdn_mult
 int  vdn_macproject(vdn_layout *mla, vdn_multifab **umac, vdn_multifab **rho, vdn_multifab **mac_rhs,
                     const double *dx, const vdn_bc_tower *bct, int bc_comp);
 
-/* ---- multi-level operators (FBoxLib; two levels, refinement ratio 2, single rank in this round) ---------------------------------
+/* ---- multi-level operators (FBoxLib; up to 4 levels, refinement ratio 2, single rank in this round) ---------------------------------
  * ml_cc_restriction(crse, fine, rr)            reference call sites src/macproject.f90:204-206, src/hgproject.f90:355-357
  * ml_edge_restriction(crse, fine, rr, dir)     src/velpred.f90:115-119, src/macproject.f90:330-333, 497-500
  * multifab_fill_ghost_cells(fine, crse, ...)   src/macproject.f90:304-310 (and inside ml_restrict_and_fill)
  * create_umac_grown(fine, crse, ...)           src/velpred.f90:102-107, src/macproject.f90:107-113
  * ml_restrict_and_fill(nlevs, mf, rr, bc, icomp, bcomp, nc, same_boundary)   src/update.f90:103-107, src/mkforce.f90:75-76, ...
- * components 0-based.  vdn_macproject accepts nlevel = 2 (composite solve); umac is then [lev*3 + dir]. */
+ * components 0-based.  vdn_macproject / vdn_hgproject / vdn_advance_timestep accept nlevel = 2..4 (composite solves); umac is then [lev*3 + dir]. */
 int vdn_ml_cc_restriction(vdn_multifab *crse, const vdn_multifab *fine, int icomp, int nc);
 int vdn_ml_edge_restriction(vdn_multifab *crse, const vdn_multifab *fine, int dir);
 int vdn_multifab_fill_ghost_cells(vdn_multifab *fine, const vdn_multifab *crse, int icomp, int nc);
