@@ -18,8 +18,9 @@ WALLS = [[15, 15]] * 3
 class Amr2:
     """coarse level: one box [0,nc)^3; fine level: the box flo..fhi (fine indices), optionally split in x for the GPU"""
 
-    def __init__(self, nc, flo, fhi, phys=WALLS, split=1, seed=0, finer=()):
-        """finer: (lo, hi) boxes of the levels 2.. (one box each, own index space)"""
+    def __init__(self, nc, flo, fhi, phys=WALLS, split=1, seed=0, finer=(), fboxes=None, cboxes=None):
+        """finer: (lo, hi) boxes of the levels 2.. (one box each, own index space); fboxes / cboxes: explicit GPU box lists of
+        level 1 / level 0 (any partition of the oracle's one box)"""
         from oracle import voracle as vo
         from varden_amd import boxlib as bl
         from varden_amd.capi import default_params
@@ -35,7 +36,10 @@ class Amr2:
         pds = [((0, 0, 0), ((nc << n) - 1,) * 3) for n in range(NL)]
         nx = (fhi[0] - flo[0] + 1) // split
         self.fboxes = [((flo[0] + s * nx, flo[1], flo[2]), (flo[0] + (s + 1) * nx - 1, fhi[1], fhi[2])) for s in range(split)]
-        self.mla = bl.MLLayout(pds, [[(self.clo, self.chi)], self.fboxes] + [[(tuple(b[0]), tuple(b[1]))] for b in finer], rr=[(2, 2, 2)] * (NL - 1))
+        if fboxes is not None:
+            self.fboxes = [(tuple(b[0]), tuple(b[1])) for b in fboxes]
+        self.cboxes = [(self.clo, self.chi)] if cboxes is None else [(tuple(b[0]), tuple(b[1])) for b in cboxes]
+        self.mla = bl.MLLayout(pds, [self.cboxes, self.fboxes] + [[(tuple(b[0]), tuple(b[1]))] for b in finer], rr=[(2, 2, 2)] * (NL - 1))
         self.bct = bl.BCTower(self.mla, phys)
         self.dx = [[1.0 / (nc << n)] * 3 for n in range(NL)]
         # oracle side: one box per level
@@ -324,3 +328,53 @@ def test_three_level_advance(gpu, oracle):
     s2 = G.snew[2].to_numpy(0)[3:-3, 3:-3, 3:-3, 0]
     assert np.abs(s2 - s2[::-1]).max() <= 1e-9
     G.close()
+
+
+# the fine region 8..23 cut so that box 0 shares only PART of a face with boxes 1 and 2; the coarse level cut into four boxes
+IRREG_F = [((8, 8, 8), (15, 23, 23)), ((16, 8, 8), (23, 15, 23)), ((16, 16, 8), (23, 23, 23))]
+QUAD_C = [((0, 0, 0), (7, 7, 15)), ((8, 0, 0), (15, 7, 15)), ((0, 8, 0), (7, 15, 15)), ((8, 8, 0), (15, 15, 15))]
+
+
+@pytest.mark.parametrize("fb,cb", [(IRREG_F, None), (None, QUAD_C), (IRREG_F, QUAD_C)])
+def test_ml_projections_on_irregular_box_unions(gpu, oracle, fb, cb):
+    """the composite solves do not depend on how a level is cut into boxes: fine boxes that share partial faces and a multi-box
+    coarse level (GPU) against one box per level (oracle): same FAC iteration counts (+-1 for the cell-centred solve whose red-black
+    order is per box), velocities to 1e-9"""
+    from varden_amd import advance as adv
+    vo = oracle
+    K = Amr2(16, (8, 8, 8), (23, 23, 23), fboxes=fb, cboxes=cb)
+    L = vo.lib()
+    # MAC projection
+    rho, um, rhs = _mac_case(K, vo)
+    grho, grhs = K.gmfs(rho), K.gmfs(rhs)
+    gum = [K.gmfs([um[d], um[3 + d]]) for d in range(3)]
+    st = vo.CMgStat()
+    L.vo_ml_macproject(2, vo.fab_ptr_array(um), vo.fab_ptr_array(rho), vo.fab_ptr_array(rhs), K.odx, K.obcs, K.opm, K.opd, C.byref(K.prm), C.byref(st))
+    adv.macproject(K.mla, [[gum[d][lev] for d in range(3)] for lev in range(2)], grho, grhs, K.dx, K.bct, 3 + 2 + 1)
+    assert abs(adv.last_solver_stats("mac")[0] - st.cycles) <= 1, (adv.last_solver_stats("mac")[0], st.cycles)
+    scale = max(np.abs(m.a).max() for m in um)
+    for lev in range(2):
+        for d in range(3):
+            a, b = K.gather(gum[d][lev], um[3 * lev + d])[1:-1, 1:-1, 1:-1], um[3 * lev + d].a[1:-1, 1:-1, 1:-1]
+            assert np.abs(a - b).max() <= 1e-9 * scale, "umac level %d dir %d differs by %.3e" % (lev, d, np.abs(a - b).max())
+    # HG projection
+    unew, uold, rhoh, gp, p = K.ofabs(3, 3), K.ofabs(3, 3), K.ofabs(1, 1), K.ofabs(1, 3), K.ofabs(1, 1, (1, 1, 1))
+    for lev in range(2):
+        K.smooth(unew[lev], lev, 1.0); K.smooth(rhoh[lev], lev, 0.2, 1.5); K.smooth(gp[lev], lev, 0.1)
+    L.vo_ml_restrict_and_fill(2, vo.fab_ptr_array(unew), 0, 0, 3, 0, K.obcs, K.opm, K.opd, C.byref(K.prm))
+    L.vo_ml_restrict_and_fill(2, vo.fab_ptr_array(rhoh), 0, 3, 1, 0, K.obcs, K.opm, K.opd, C.byref(K.prm))
+    L.vo_ml_restrict_and_fill(2, vo.fab_ptr_array(gp), 0, 6, 3, 1, K.obcs, K.opm, K.opd, C.byref(K.prm))
+    for lev in range(2):
+        uold[lev].a[...] = 0.5 * unew[lev].a
+    gun, guo, grh, ggp, gpp = K.gmfs(unew), K.gmfs(uold), K.gmfs(rhoh), K.gmfs(gp), K.gmfs(p)
+    L.vo_ml_hgproject(2, vo.REGULAR_TIMESTEP, vo.fab_ptr_array(unew), vo.fab_ptr_array(uold), vo.fab_ptr_array(rhoh), vo.fab_ptr_array(p), vo.fab_ptr_array(gp),
+                      K.odx, C.c_double(0.01), K.obcs, K.opm, K.opd, C.byref(K.prm), C.byref(st))
+    adv.hgproject(vo.REGULAR_TIMESTEP, K.mla, gun, guo, grh, gpp, ggp, K.dx, 0.01, K.bct, 3 + 2 + 1)
+    assert adv.last_solver_stats("hg")[0] == st.cycles, (adv.last_solver_stats("hg")[0], st.cycles)
+    for lev in range(2):
+        g = 3
+        a, b = K.gather(gun[lev], unew[lev])[g:-g, g:-g, g:-g], unew[lev].a[g:-g, g:-g, g:-g]
+        assert np.abs(a - b).max() <= 1e-9 * np.abs(b).max(), "unew level %d: %.3e" % (lev, np.abs(a - b).max())
+        a, b = K.gather(gpp[lev], p[lev])[1:-1, 1:-1, 1:-1], p[lev].a[1:-1, 1:-1, 1:-1]
+        assert np.abs(a - b).max() <= 1e-8 * np.abs(b).max(), "p level %d: %.3e" % (lev, np.abs(a - b).max())
+    K.close()

@@ -168,14 +168,18 @@ __global__ void kk_ml_umac_grown(FV fine, FV crse, GrownArgs A, Range3 r) {
   if (odd) { P[A.dir] += 1; v = 0.5 * (a + fv_get(crse, P[0], P[1], P[2])); }
   fv_at(fine, i, j, k) = v;
 }
+// parents on VALID faces of a coarse box come from that box; the remaining ones (outside the domain, or -- for a one-box coarse
+// level that does not cover the domain -- in that box's own ghost faces) from the first coarse box whose allocation holds them
 void ml_create_umac_grown(vdn_multifab *fine, const vdn_multifab *crse, int dir) {
   for (int f = 0; f < fine->nfabs(); f++) {
     GrownArgs A; Range3 r; A.dir = dir;
     for (int d = 0; d < 3; d++) { A.flo[d] = fine->vbox[f].lo[d]; A.fhi[d] = fine->vbox[f].hi[d] + (d == dir); r.lo[d] = A.flo[d] - fine->ng; r.hi[d] = A.fhi[d] + fine->ng; }
-    for (int c = 0; c < crse->nfabs(); c++) {      // coarse faces of box c incl. its ghost faces (filled by fill_boundary)
-      for (int d = 0; d < 3; d++) { A.plo[d] = crse->vbox[c].lo[d] - crse->ng; A.phi[d] = crse->vbox[c].hi[d] + (d == dir) + crse->ng; }
+    // the first box with its ghost faces (filled by fill_boundary), then every box's valid faces on top (same values where both hold one)
+    for (int d = 0; d < 3; d++) { A.plo[d] = crse->vbox[0].lo[d] - crse->ng; A.phi[d] = crse->vbox[0].hi[d] + (d == dir) + crse->ng; }
+    hipLaunchKernelGGL(kk_ml_umac_grown, grid_for(r), AB, 0, ctx().stream, fine->fabs[f], crse->fabs[0], A, r);
+    for (int c = 0; c < crse->nfabs() && crse->nfabs() > 1; c++) {
+      for (int d = 0; d < 3; d++) { A.plo[d] = crse->vbox[c].lo[d]; A.phi[d] = crse->vbox[c].hi[d] + (d == dir); }
       hipLaunchKernelGGL(kk_ml_umac_grown, grid_for(r), AB, 0, ctx().stream, fine->fabs[f], crse->fabs[c], A, r);
-      break;     // level 0 of a two-level hierarchy on one rank: the first box that holds the parent; multi-box coarse levels: see DESIGN.md
     }
   }
 }

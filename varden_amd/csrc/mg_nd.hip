@@ -1094,7 +1094,7 @@ __global__ void kk_ndf_add(FV a, FV b, Range3 r) { THREAD_IJK(r) if (!in_range) 
 // MODE 0: eout = ein + omega (rb - K ein)/diag on free nodes;  MODE 1: res = b - K phi (0 on physical Dirichlet nodes), max-norm
 // over the nodes that are not interface nodes (excl = 1) / all nodes (excl = 0)
 template <int MODE>
-__global__ void __launch_bounds__(256) kk_ndf_march(FV phi, FV out, FV rb, FV sig, NdfArgs A, double omega, int excl, int kchunk, Range3 r, double *nrm) {
+__global__ void __launch_bounds__(256) kk_ndf_march(FV phi, FV out, FV rb, FV sig, FV slave, int has_slave, NdfArgs A, double omega, int excl, int kchunk, Range3 r, double *nrm) {
   const int lane = threadIdx.x;
   const int i = r.lo[0] + (int)blockIdx.x * 62 + lane - 1;
   const int j = r.lo[1] + (int)(blockIdx.y * blockDim.y + threadIdx.y);
@@ -1153,7 +1153,8 @@ __global__ void __launch_bounds__(256) kk_ndf_march(FV phi, FV out, FV rb, FV si
           }
       const double Kp = acc, diag = w[0] * ssum;
       const double p0 = p[1][1][1];
-      const bool pdir = ndf_pdir(A, i, j, k), cf = ndf_cf(A, i, j, k);
+      const bool pdir = ndf_pdir(A, i, j, k);
+      const bool cf = (has_slave && (MODE == 0 || excl == 1)) ? (fv_get(slave, ic, jc, k) != 0.0) : false;      // slaved to the coarser level
       if (MODE == 0) {
         double v = p0;
         if (!pdir && !cf && diag != 0.0) v = p0 + omega * ((rhs - Kp) / diag);
@@ -1174,12 +1175,12 @@ __global__ void __launch_bounds__(256) kk_ndf_march(FV phi, FV out, FV rb, FV si
   }
   if (MODE == 1 && nrm) block_atomic_max(nrm, rmax);
 }
-template <int MODE> static void ndf_launch_march(const FV &phi, const FV &out, const FV &rb, const FV &sig, const NdfArgs &A, double omega, int excl, const Range3 &r, double *nrm) {
+template <int MODE> static void ndf_launch_march(const FV &phi, const FV &out, const FV &rb, const FV &sig, const FV *slave, const NdfArgs &A, double omega, int excl, const Range3 &r, double *nrm) {
   const int nx = r.hi[0] - r.lo[0] + 1, ny = r.hi[1] - r.lo[1] + 1, nz = r.hi[2] - r.lo[2] + 1;
   const int tiles = ((nx + 61) / 62) * ((ny + 3) / 4);
   int kchunk = nz;
   while (kchunk > 8 && tiles * ((nz + kchunk - 1) / kchunk) < 2048) kchunk = (kchunk + 1) / 2;
-  hipLaunchKernelGGL(kk_ndf_march<MODE>, dim3((nx + 61) / 62, (ny + 3) / 4, (nz + kchunk - 1) / kchunk), NBLK, 0, ctx().stream, phi, out, rb, sig, A, omega, excl, kchunk, r, nrm);
+  hipLaunchKernelGGL(kk_ndf_march<MODE>, dim3((nx + 61) / 62, (ny + 3) / 4, (nz + kchunk - 1) / kchunk), NBLK, 0, ctx().stream, phi, out, rb, sig, slave ? *slave : phi, slave ? 1 : 0, A, omega, excl, kchunk, r, nrm);
 }
 __global__ void kk_ndf_absmax_mask(FV a, FV mask, Range3 r, double *nrm) {
   REDUCE_IJ(r)
@@ -1213,28 +1214,104 @@ __global__ void kk_ndf_restrict_add2(FV res_c, FV res_f, NdfArgs Af, NdfArgs Ac,
 }
 
 static double ndf_read(double *d) { double h; HIPCHK(hipMemcpyAsync(&h, d, sizeof(double), hipMemcpyDeviceToHost, ctx().stream)); HIPCHK(hipStreamSynchronize(ctx().stream)); return h; }
-// nodes on a coarse-fine face of the box (not physical Dirichlet) -> mask = 1
-__global__ void kk_ndf_mark_cf(FV mask, NdfArgs A, Range3 r) {
+// ---- composite nodal solve on arbitrary unions of boxes: node masks instead of per-face flags ----------------------------------
+// cell mask -> node mask.  mode 0 ("slave"): 1 on the nodes that are not physical Dirichlet nodes and touch a cell INSIDE the
+// domain whose mask is 0 (a cell the level does not cover): the nodes of the coarse-fine interface.  mode 1 ("inside"): 1 on the
+// nodes whose eight cells are all inside the domain and masked (strictly inside the region the next finer level covers)
+struct MarkArgs { int dlo[3], dhi[3]; };
+__global__ void kk_ndm_mark(FV out, FV cmask, NdfArgs A, MarkArgs D, int mode, Range3 r) {
   THREAD_IJK(r)
   if (!in_range) return;
-  if (ndf_cf(A, i, j, k) && !ndf_pdir(A, i, j, k)) fv_at(mask, i, j, k) = 1.0;
+  bool any_open = false, all_in = true;
+  #pragma unroll
+  for (int c = -1; c <= 0; c++)
+    #pragma unroll
+    for (int b = -1; b <= 0; b++)
+      #pragma unroll
+      for (int a = -1; a <= 0; a++) {
+        const int ci = i + a, cj = j + b, ck = k + c;
+        const bool in_dom = ci >= D.dlo[0] && ci <= D.dhi[0] && cj >= D.dlo[1] && cj <= D.dhi[1] && ck >= D.dlo[2] && ck <= D.dhi[2];
+        const bool m = in_dom && fv_get(cmask, ci, cj, ck) != 0.0;
+        if (in_dom && !m) any_open = true;
+        if (!m) all_in = false;
+      }
+  if (mode == 0) { if (any_open && !ndf_pdir(A, i, j, k)) fv_at(out, i, j, k) = 1.0; }
+  else if (all_in) fv_at(out, i, j, k) = 1.0;
 }
-// levels 0 .. nlev-2 are one box each, the finest level may have several boxes that share whole faces
+__global__ void kk_ndm_mul(FV out, FV a, FV keep0, Range3 r) {          // out = a where keep0 == 0, else 0   (cells)
+  THREAD_IJK(r)
+  if (!in_range) return;
+  fv_at(out, i, j, k) = (fv_get(keep0, i, j, k) != 0.0) ? 0.0 : fv_get(a, i, j, k);
+}
+__global__ void kk_ndm_mask_u(FV out, FV u, FV inlev, int has_inlev, FV cov, int has_cov, Range3 r) {   // masked velocity, 3 components
+  THREAD_IJK(r)
+  if (!in_range) return;
+  const bool keep = (!has_inlev || fv_get(inlev, i, j, k) != 0.0) && !(has_cov && fv_get(cov, i, j, k) != 0.0);
+  #pragma unroll
+  for (int c = 0; c < 3; c++) fv_at(out, i, j, k, c) = keep ? fv_get(u, i, j, k, c) : 0.0;
+}
+// mode 0: phi_f = P phi_c on the slave nodes;  mode 1: phi_f += P e_c on every node that is not a physical Dirichlet node;
+// mode 2: phi_f = P e_c there (0 + P e_c).  Only nodes whose coarse parent (i>>1, j>>1, k>>1) is a valid node of this coarse box
+__global__ void kk_ndm_prolong(FV pf, FV pc, FV slave, FV own_c, int has_own, NdfArgs Af, int mode, int clo0, int clo1, int clo2, int chi0, int chi1, int chi2, Range3 r) {
+  THREAD_IJK(r)
+  if (!in_range) return;
+  if (ndf_pdir(Af, i, j, k)) return;
+  if (mode == 0 && fv_get(slave, i, j, k) == 0.0) return;
+  const int I = i >> 1, J = j >> 1, K = k >> 1, oi = i & 1, oj = j & 1, ok = k & 1;
+  if (I < clo0 || I > chi0 || J < clo1 || J > chi1 || K < clo2 || K > chi2) return;
+  if (has_own && fv_get(own_c, I, J, K) == 0.0) return;          // a coarse node shared by several boxes: its owner does the work, once
+  double s = 0.0;
+  for (int c = 0; c <= ok; c++) for (int b = 0; b <= oj; b++) for (int a = 0; a <= oi; a++) s = s + fv_get(pc, I + a, J + b, K + c);
+  const double v = s * (1.0 / (double)((1 + oi) * (1 + oj) * (1 + ok)));
+  fv_at(pf, i, j, k) = (mode == 1) ? fv_get(pf, i, j, k) + v : v;
+}
+// res_c += full weighting of the fine residual around the fine node (2i,2j,2k), taken from the fine box that OWNS that node (its
+// ghost nodes hold the neighbouring boxes' values, zero outside the level)
+__global__ void kk_ndm_restrict_add(FV res_c, FV res_f, FV own_f, NdfArgs Af, NdfArgs Ac, Range3 r) {
+  THREAD_IJK(r)
+  if (!in_range || ndf_pdir(Ac, i, j, k)) return;
+  if (fv_get(own_f, 2 * i, 2 * j, 2 * k) == 0.0) return;
+  const double wt[3] = { 0.5, 1.0, 0.5 };
+  double s = 0.0;
+  for (int c = -1; c <= 1; c++) for (int b = -1; b <= 1; b++) for (int a = -1; a <= 1; a++) {
+    const int ii = 2 * i + a, jj = 2 * j + b, kk = 2 * k + c;
+    if (ii < Af.lo[0] - 1 || ii > Af.hi[0] + 1 || jj < Af.lo[1] - 1 || jj > Af.hi[1] + 1 || kk < Af.lo[2] - 1 || kk > Af.hi[2] + 1) continue;
+    s = s + (wt[a + 1] * wt[b + 1] * wt[c + 1]) * fv_get(res_f, ii, jj, kk);
+  }
+  fv_at(res_c, i, j, k) = fv_get(res_c, i, j, k) + s * 0.125;
+}
+static bool nd_isect(const Range3 &a, const Range3 &b, Range3 &r) {
+  for (int d = 0; d < 3; d++) { r.lo[d] = std::max(a.lo[d], b.lo[d]); r.hi[d] = std::min(a.hi[d], b.hi[d]); if (r.lo[d] > r.hi[d]) return false; }
+  return true;
+}
+// every level may be any union of boxes (properly nested in the next coarser one)
 struct MLND {
   int nlev;
   vdn_multifab *phi[VDN_MAXLEV], *b[VDN_MAXLEV], *res[VDN_MAXLEV];
   vdn_multifab *sig[VDN_MAXLEV];                     // MASKED sigma (zero under the next finer level); the finest level's own sigma
   vdn_multifab *sigfull[VDN_MAXLEV];                 // the caller's coefficients
-  vdn_multifab *skip[VDN_MAXLEV];                    // nodes left out of the norm: strictly inside a finer box, or slaved to the coarser level
+  vdn_multifab *slave[VDN_MAXLEV];                   // nodes slaved to the next coarser level (levels >= 1)
+  vdn_multifab *own[VDN_MAXLEV];                     // 1 in the fab that owns a node shared by several boxes (lowest box index)
+  vdn_multifab *skip[VDN_MAXLEV];                    // nodes left out of the norm: slaves and nodes strictly inside the finer level
   vdn_multifab *ea[VDN_MAXLEV], *eb[VDN_MAXLEV], *scr[VDN_MAXLEV];   // Jacobi ping-pong of the correction; prolonged increment
-  std::vector<NdfArgs> A[VDN_MAXLEV]; std::vector<Range3> r[VDN_MAXLEV];
-  std::vector<int> own_hi[VDN_MAXLEV];               // [box*3 + d]: the box owns the nodes of its high d-face
+  std::vector<NdfArgs> A[VDN_MAXLEV]; std::vector<Range3> r[VDN_MAXLEV];      // per box: operator weights, node range, physical Dirichlet faces
   bool multi[VDN_MAXLEV]; double *d_nrm;
 };
-// interface nodes of level n <- trilinear interpolation of level n-1
-static void ml_nd_interface(MLND &S, int n) {
+// mode 0: slaves of level n <- P phi_{n-1};  mode 1: dst_n += P src_{n-1};  mode 2: dst_n = P src_{n-1} (dst zeroed first by the caller)
+static void ml_nd_prolong(MLND &S, int n, vdn_multifab *dst, vdn_multifab *src, int mode) {
   for (size_t f = 0; f < S.A[n].size(); f++)
-    hipLaunchKernelGGL(kk_ndf_prolong, grid_for(S.r[n][f]), NBLK, 0, ctx().stream, S.phi[n]->fabs[f], S.phi[n - 1]->fabs[0], S.A[n][f], 0, S.r[n][f]);
+    for (size_t c = 0; c < S.A[n - 1].size(); c++) {
+      const Range3 &rc = S.r[n - 1][c];
+      Range3 fr; for (int d = 0; d < 3; d++) { fr.lo[d] = std::max(S.r[n][f].lo[d], 2 * rc.lo[d]); fr.hi[d] = std::min(S.r[n][f].hi[d], 2 * rc.hi[d] + 1); }
+      if (fr.lo[0] > fr.hi[0] || fr.lo[1] > fr.hi[1] || fr.lo[2] > fr.hi[2]) continue;
+      hipLaunchKernelGGL(kk_ndm_prolong, grid_for(fr), NBLK, 0, ctx().stream, dst->fabs[f], src->fabs[c], S.slave[n]->fabs[f],
+                         S.own[n - 1] ? S.own[n - 1]->fabs[c] : src->fabs[c], S.own[n - 1] ? 1 : 0, S.A[n][f], mode,
+                         rc.lo[0], rc.lo[1], rc.lo[2], rc.hi[0], rc.hi[1], rc.hi[2], fr);
+    }
+}
+static void ml_nd_interface(MLND &S, int n) {
+  if (S.multi[n - 1]) mf_fill_boundary(S.phi[n - 1]);        // the parents of a fine node may sit in a coarse box's ghost nodes
+  ml_nd_prolong(S, n, S.phi[n], S.phi[n - 1], 0);
   if (S.multi[n]) mf_fill_boundary(S.phi[n]);
 }
 // finest_only: just the finest level's residual (what its relaxation needs), no norm
@@ -1242,22 +1319,29 @@ static double ml_nd_residual(MLND &S, bool finest_only) {
   hipStream_t st = ctx().stream;
   const int L = S.nlev;
   if (finest_only) ml_nd_interface(S, L - 1);
-  else { for (int n = 1; n < L; n++) ml_nd_interface(S, n); HIPCHK(hipMemsetAsync(S.d_nrm, 0, sizeof(double), st)); }
+  else {
+    if (S.multi[0]) mf_fill_boundary(S.phi[0]);
+    for (int n = 1; n < L; n++) ml_nd_interface(S, n);
+    HIPCHK(hipMemsetAsync(S.d_nrm, 0, sizeof(double), st));
+  }
   for (int n = L - 1; n >= (finest_only ? L - 1 : 0); n--) {
     const bool finest = n == L - 1;
     for (size_t f = 0; f < S.A[n].size(); f++)
-      ndf_launch_march<1>(S.phi[n]->fabs[f], S.res[n]->fabs[f], S.b[n]->fabs[f], S.sig[n]->fabs[f], S.A[n][f], 0.0, finest ? 1 : 0, S.r[n][f],
-                          (finest && !finest_only) ? S.d_nrm : (double *)nullptr);
+      ndf_launch_march<1>(S.phi[n]->fabs[f], S.res[n]->fabs[f], S.b[n]->fabs[f], S.sig[n]->fabs[f], S.slave[n] ? &S.slave[n]->fabs[f] : (const FV *)nullptr, S.A[n][f], 0.0,
+                          (finest && S.slave[n]) ? 1 : 0, S.r[n][f], (finest && !finest_only) ? S.d_nrm : (double *)nullptr);
     if (finest_only) return 0.0;
     if (S.multi[n]) mf_fill_boundary(S.res[n]);
     if (finest) continue;
     for (size_t f = 0; f < S.A[n + 1].size(); f++) {
       const NdfArgs &Af = S.A[n + 1][f];
-      Range3 ri; for (int d = 0; d < 3; d++) { ri.lo[d] = Af.lo[d] / 2; ri.hi[d] = Af.hi[d] / 2; }
-      hipLaunchKernelGGL(kk_ndf_restrict_add2, grid_for(ri), NBLK, 0, st, S.res[n]->fabs[0], S.res[n + 1]->fabs[f], Af, S.A[n][0],
-                         S.own_hi[n + 1][3 * f], S.own_hi[n + 1][3 * f + 1], S.own_hi[n + 1][3 * f + 2], ri);
+      Range3 rf; for (int d = 0; d < 3; d++) { rf.lo[d] = (Af.lo[d] + 1) / 2; rf.hi[d] = Af.hi[d] / 2; }       // coarse nodes whose fine twin is a node of box f
+      for (size_t c = 0; c < S.A[n].size(); c++) {
+        Range3 ri; if (!nd_isect(rf, S.r[n][c], ri)) continue;
+        hipLaunchKernelGGL(kk_ndm_restrict_add, grid_for(ri), NBLK, 0, st, S.res[n]->fabs[c], S.res[n + 1]->fabs[f], S.own[n + 1]->fabs[f], Af, S.A[n][c], ri);
+      }
     }
-    hipLaunchKernelGGL(kk_ndf_absmax_mask, reduce_grid(S.r[n][0]), NBLK, 0, st, S.res[n]->fabs[0], S.skip[n]->fabs[0], S.r[n][0], S.d_nrm);
+    for (size_t c = 0; c < S.A[n].size(); c++)
+      hipLaunchKernelGGL(kk_ndf_absmax_mask, reduce_grid(S.r[n][c]), NBLK, 0, st, S.res[n]->fabs[c], S.skip[n]->fabs[c], S.r[n][c], S.d_nrm);
   }
   return ndf_read(S.d_nrm);
 }
@@ -1267,12 +1351,12 @@ static void ml_nd_apply_correction(MLND &S, int n, vdn_multifab *e) {
   for (size_t f = 0; f < S.A[n].size(); f++) hipLaunchKernelGGL(kk_ndf_add, grid_for(S.r[n][f]), NBLK, 0, st, S.phi[n]->fabs[f], e->fabs[f], S.r[n][f]);
   vdn_multifab *src = e;
   for (int m = n + 1; m < S.nlev; m++) {
-    if (m == S.nlev - 1) {
-      for (size_t f = 0; f < S.A[m].size(); f++) hipLaunchKernelGGL(kk_ndf_prolong, grid_for(S.r[m][f]), NBLK, 0, st, S.phi[m]->fabs[f], src->fabs[0], S.A[m][f], 1, S.r[m][f]);
-    } else {                                             // one box: keep the increment for the next finer level
+    if (S.multi[m - 1]) mf_fill_boundary(src);
+    if (m == S.nlev - 1) ml_nd_prolong(S, m, S.phi[m], src, 1);
+    else {                                               // keep the increment for the next finer level
       mf_setval(S.scr[m], 0.0, 0, 1, true);
-      hipLaunchKernelGGL(kk_ndf_prolong, grid_for(S.r[m][0]), NBLK, 0, st, S.scr[m]->fabs[0], src->fabs[0], S.A[m][0], 1, S.r[m][0]);
-      hipLaunchKernelGGL(kk_ndf_add, grid_for(S.r[m][0]), NBLK, 0, st, S.phi[m]->fabs[0], S.scr[m]->fabs[0], S.r[m][0]);
+      ml_nd_prolong(S, m, S.scr[m], src, 2);
+      for (size_t f = 0; f < S.A[m].size(); f++) hipLaunchKernelGGL(kk_ndf_add, grid_for(S.r[m][f]), NBLK, 0, st, S.phi[m]->fabs[f], S.scr[m]->fabs[f], S.r[m][f]);
       src = S.scr[m];
     }
   }
@@ -1282,7 +1366,6 @@ static int ml_nd_solve(vdn_layout *la, vdn_multifab **rh, vdn_multifab **phi, vd
                        const vdn_bc_tower *bct, int press_comp0, double rel_eps, double abs_eps, int max_iter, int *iters, double *res0, double *res) {
   const int L = la->nlev;
   REQUIRE(L >= 2 && L <= VDN_MAXLEV && ctx().nranks == 1, "composite nodal solve: 2..%d levels, single rank", VDN_MAXLEV);
-  for (int n = 0; n < L - 1; n++) REQUIRE(phi[n]->nfabs() == 1, "composite nodal solve: every level but the finest must be one box in this round (level %d)", n);
   REQUIRE(!(la->pmask[0] || la->pmask[1] || la->pmask[2]), "composite nodal solve: periodic domains are not implemented");
   hipStream_t st = ctx().stream;
   const size_t mark = arena_mark();
@@ -1290,76 +1373,78 @@ static int ml_nd_solve(vdn_layout *la, vdn_multifab **rh, vdn_multifab **phi, vd
   MLND S; S.nlev = L; S.d_nrm = (double *)arena_alloc(256);
   std::vector<vdn_multifab *> temps;
   auto T = [&](vdn_multifab *m) { temps.push_back(m); return m; };
-  // boxes: a face that is not a domain face is either shared as a whole with ONE neighbouring box of the level or coarse-fine
   for (int n = 0; n < L; n++) {
     const int nb = phi[n]->nfabs();
     S.multi[n] = nb > 1;
-    S.A[n].resize(nb); S.r[n].resize(nb); S.own_hi[n].assign(3 * nb, 1);
+    S.A[n].resize(nb); S.r[n].resize(nb);
     for (int f = 0; f < nb; f++) {
       const vdn_box &bx = phi[n]->vbox[f];
       NdfArgs &A = S.A[n][f];
       for (int d = 0; d < 3; d++) {
         A.f[d] = 1.0 / (36.0 * (dx[3 * n + d] * dx[3 * n + d]));
-        A.lo[d] = bx.lo[d]; A.hi[d] = bx.hi[d] + 1; A.ilo[d] = A.ihi[d] = 0;
+        A.lo[d] = bx.lo[d]; A.hi[d] = bx.hi[d] + 1; A.ilo[d] = A.ihi[d] = 0; A.cflo[d] = A.cfhi[d] = 0;
         S.r[n][f].lo[d] = A.lo[d]; S.r[n][f].hi[d] = A.hi[d];
-        for (int sd = 0; sd < 2; sd++) {
-          const int e = bct->ell_bc(n, f + 1, d, sd, press_comp0);
-          bool shared = false;
-          for (int g = 0; g < nb && e == VDN_BC_INT; g++) {
-            if (g == f) continue;
-            const vdn_box &ob = phi[n]->vbox[g];
-            const bool touch = sd ? (ob.lo[d] == bx.hi[d] + 1) : (ob.hi[d] + 1 == bx.lo[d]);
-            if (!touch) continue;
-            bool same = true, overlap = true;
-            for (int t = 0; t < 3; t++) if (t != d) { if (ob.lo[t] != bx.lo[t] || ob.hi[t] != bx.hi[t]) same = false; if (ob.hi[t] < bx.lo[t] || ob.lo[t] > bx.hi[t]) overlap = false; }
-            if (!overlap) continue;
-            REQUIRE(same, "composite nodal solve: neighbouring fine boxes must share whole faces (box %d / %d)", f, g);
-            shared = true;
-          }
-          (sd ? A.dirhi[d] : A.dirlo[d]) = (e == VDN_BC_DIR);
-          (sd ? A.cfhi[d] : A.cflo[d]) = (n > 0 && e == VDN_BC_INT && !shared);
-          if (sd == 1 && shared) S.own_hi[n][3 * f + d] = 0;
-        }
+        A.dirlo[d] = bct->ell_bc(n, f + 1, d, 0, press_comp0) == VDN_BC_DIR;
+        A.dirhi[d] = bct->ell_bc(n, f + 1, d, 1, press_comp0) == VDN_BC_DIR;
       }
     }
   }
-  vdn_multifab *zero[VDN_MAXLEV];
+  vdn_multifab *zero[VDN_MAXLEV], *inlev[VDN_MAXLEV], *cov[VDN_MAXLEV];
   for (int n = 0; n < L; n++) {
     S.phi[n] = phi[n]; S.b[n] = T(mf_temp(la, n, 1, 1, 3, true, 0.0)); S.res[n] = T(mf_temp(la, n, 1, 1, 3, true, 0.0));
     zero[n] = T(mf_temp(la, n, 1, 1, 3, true, 0.0));
-    S.sigfull[n] = coeffs[n]; S.sig[n] = coeffs[n]; S.skip[n] = nullptr; S.scr[n] = nullptr;
+    S.sigfull[n] = coeffs[n]; S.sig[n] = coeffs[n]; S.skip[n] = S.slave[n] = S.own[n] = S.scr[n] = nullptr;
     S.ea[n] = n >= 1 ? zero[n] : nullptr; S.eb[n] = n >= 1 ? T(mf_temp(la, n, 1, 1, 3, true, 0.0)) : nullptr;
     if (n >= 1 && n < L - 1) S.scr[n] = T(mf_temp(la, n, 1, 1, 3, true, 0.0));
+    inlev[n] = cov[n] = nullptr;
   }
-  // masked sigma, the node mask of the norm, the masked velocities and the right-hand side b = -(rh + D u)
+  // cell masks: inlev[n] = the cells of level n (its ghost cells included where another box of the level covers them),
+  // cov[n] = the cells of level n under level n+1
   for (int n = 0; n < L; n++) {
-    vdn_multifab *um = T(mf_temp(la, n, 3, 1, -1, false, 0.0));
-    if (n == 0) mf_copy(um, 0, u[0], 0, 3, 1);
-    else {
-      vdn_multifab *fmask = T(mf_temp(la, n, 1, 1, -1, true, 0.0));
-      mf_setval(fmask, 1.0, 0, 1, false);
-      mf_fill_boundary(fmask);
+    MarkArgs D; for (int d = 0; d < 3; d++) { D.dlo[d] = la->pd[n].lo[d]; D.dhi[d] = la->pd[n].hi[d]; }
+    if (n >= 1 || S.multi[n]) {
+      S.own[n] = T(mf_temp(la, n, 1, 1, 3, true, 0.0));
       for (int f = 0; f < phi[n]->nfabs(); f++) {
-        const vdn_box &fb = phi[n]->vbox[f];
-        Range3 rg; for (int d = 0; d < 3; d++) { rg.lo[d] = fb.lo[d] - 1; rg.hi[d] = fb.hi[d] + 1; }
-        hipLaunchKernelGGL(kk_ndf_mul3, grid_for(rg), NBLK, 0, st, um->fabs[f], u[n]->fabs[f], fmask->fabs[f], rg);
+        hipLaunchKernelGGL(kk_ndf_setbox, grid_for(S.r[n][f]), NBLK, 0, st, S.own[n]->fabs[f], S.r[n][f], 1.0);
+        for (int g = 0; g < f; g++) { Range3 ri; if (nd_isect(S.r[n][f], S.r[n][g], ri)) hipLaunchKernelGGL(kk_ndf_setbox, grid_for(ri), NBLK, 0, st, S.own[n]->fabs[f], ri, 0.0); }
       }
+    }
+    if (n >= 1) {
+      inlev[n] = T(mf_temp(la, n, 1, 1, -1, true, 0.0));
+      mf_setval(inlev[n], 1.0, 0, 1, false);
+      mf_fill_boundary(inlev[n]);
+      S.slave[n] = T(mf_temp(la, n, 1, 1, 3, true, 0.0));
+      for (int f = 0; f < phi[n]->nfabs(); f++)
+        hipLaunchKernelGGL(kk_ndm_mark, grid_for(S.r[n][f]), NBLK, 0, st, S.slave[n]->fabs[f], inlev[n]->fabs[f], S.A[n][f], D, 0, S.r[n][f]);
+      if (S.multi[n]) mf_fill_boundary(S.slave[n]);
     }
     if (n < L - 1) {
-      S.sig[n] = T(mf_temp(la, n, 1, 1, -1, true, 0.0));
-      mf_copy(S.sig[n], 0, coeffs[n], 0, 1, 1);
-      S.skip[n] = T(mf_temp(la, n, 1, 1, 3, true, 0.0));
-      if (n >= 1) hipLaunchKernelGGL(kk_ndf_mark_cf, grid_for(S.r[n][0]), NBLK, 0, st, S.skip[n]->fabs[0], S.A[n][0], S.r[n][0]);
+      cov[n] = T(mf_temp(la, n, 1, 1, -1, true, 0.0));
       for (int f = 0; f < phi[n + 1]->nfabs(); f++) {
         const vdn_box &fb = phi[n + 1]->vbox[f];
-        Range3 rcov, rin; bool has_in = true;
-        for (int d = 0; d < 3; d++) { rcov.lo[d] = fb.lo[d] / 2; rcov.hi[d] = fb.hi[d] / 2; rin.lo[d] = rcov.lo[d] + 1; rin.hi[d] = rcov.hi[d]; if (rin.lo[d] > rin.hi[d]) has_in = false; }
-        hipLaunchKernelGGL(kk_ndf_setbox, grid_for(rcov), NBLK, 0, st, S.sig[n]->fabs[0], rcov, 0.0);
-        hipLaunchKernelGGL(kk_ndf_zero3, grid_for(rcov), NBLK, 0, st, um->fabs[0], rcov);
-        if (has_in) hipLaunchKernelGGL(kk_ndf_setbox, grid_for(rin), NBLK, 0, st, S.skip[n]->fabs[0], rin, 1.0);
+        Range3 rcov; for (int d = 0; d < 3; d++) { rcov.lo[d] = fb.lo[d] / 2; rcov.hi[d] = fb.hi[d] / 2; }
+        for (int c = 0; c < phi[n]->nfabs(); c++) {
+          Range3 rb2, ri; for (int d = 0; d < 3; d++) { rb2.lo[d] = phi[n]->vbox[c].lo[d] - 1; rb2.hi[d] = phi[n]->vbox[c].hi[d] + 1; }
+          if (nd_isect(rcov, rb2, ri)) hipLaunchKernelGGL(kk_ndf_setbox, grid_for(ri), NBLK, 0, st, cov[n]->fabs[c], ri, 1.0);
+        }
       }
-    }
+      S.sig[n] = T(mf_temp(la, n, 1, 1, -1, true, 0.0));
+      S.skip[n] = T(mf_temp(la, n, 1, 1, 3, true, 0.0));
+      if (S.slave[n]) mf_copy(S.skip[n], 0, S.slave[n], 0, 1, 0);
+      for (int c = 0; c < phi[n]->nfabs(); c++) {
+        Range3 rg; for (int d = 0; d < 3; d++) { rg.lo[d] = phi[n]->vbox[c].lo[d] - 1; rg.hi[d] = phi[n]->vbox[c].hi[d] + 1; }
+        hipLaunchKernelGGL(kk_ndm_mul, grid_for(rg), NBLK, 0, st, S.sig[n]->fabs[c], coeffs[n]->fabs[c], cov[n]->fabs[c], rg);
+        hipLaunchKernelGGL(kk_ndm_mark, grid_for(S.r[n][c]), NBLK, 0, st, S.skip[n]->fabs[c], cov[n]->fabs[c], S.A[n][c], D, 1, S.r[n][c]);
+      }
+    } else S.skip[n] = S.slave[n];
+  }
+  // right-hand side b = -(rh + D u) with the masked velocity (zero outside the level and under the next finer one)
+  for (int n = 0; n < L; n++) {
+    vdn_multifab *um = T(mf_temp(la, n, 3, 1, -1, false, 0.0));
     for (int f = 0; f < phi[n]->nfabs(); f++) {
+      Range3 rg; for (int d = 0; d < 3; d++) { rg.lo[d] = phi[n]->vbox[f].lo[d] - 1; rg.hi[d] = phi[n]->vbox[f].hi[d] + 1; }
+      hipLaunchKernelGGL(kk_ndm_mask_u, grid_for(rg), NBLK, 0, st, um->fabs[f], u[n]->fabs[f], inlev[n] ? inlev[n]->fabs[f] : u[n]->fabs[f], inlev[n] ? 1 : 0,
+                         cov[n] ? cov[n]->fabs[f] : u[n]->fabs[f], cov[n] ? 1 : 0, rg);
       hipLaunchKernelGGL(kk_nd_divu, grid_for(S.r[n][f]), NBLK, 0, st, um->fabs[f], rh[n]->fabs[f], 0.25 / dx[3 * n], 0.25 / dx[3 * n + 1], 0.25 / dx[3 * n + 2], S.r[n][f]);
       hipLaunchKernelGGL(kk_ndf_neg, grid_for(S.r[n][f]), NBLK, 0, st, S.b[n]->fabs[f], rh[n]->fabs[f], S.A[n][f], S.r[n][f]);
     }
@@ -1378,8 +1463,10 @@ static int ml_nd_solve(vdn_layout *la, vdn_multifab **rh, vdn_multifab **phi, vd
     if (it >= max_iter) break;
     // coarse correction K_0 e = r_0: one V-cycle of the single-level solver (which takes rh with b = -rh)
     mf_setval(ee, 0.0, 0, 1, true); mf_setval(er, 0.0, 0, 1, true);
-    { NdfArgs Z = S.A[0][0]; for (int d = 0; d < 3; d++) { Z.dirlo[d] = Z.dirhi[d] = 0; }
-      hipLaunchKernelGGL(kk_ndf_neg, grid_for(S.r[0][0]), NBLK, 0, st, er->fabs[0], S.res[0]->fabs[0], Z, S.r[0][0]); }
+    for (size_t c = 0; c < S.A[0].size(); c++) {
+      NdfArgs Z = S.A[0][c]; for (int d = 0; d < 3; d++) { Z.dirlo[d] = Z.dirhi[d] = 0; }
+      hipLaunchKernelGGL(kk_ndf_neg, grid_for(S.r[0][c]), NBLK, 0, st, er->fabs[c], S.res[0]->fabs[c], Z, S.r[0][c]);
+    }
     int cyc; double r0, rr;
     nd_solve(er, ee, coeffs[0], nullptr, dx, ebc0, 0.0, -1.0, -1, &cyc, &r0, &rr);
     ml_nd_apply_correction(S, 0, ee);
@@ -1391,13 +1478,14 @@ static int ml_nd_solve(vdn_layout *la, vdn_multifab **rh, vdn_multifab **phi, vd
       for (int s = 0; s < P.hg_nu1 + P.hg_nu2; s++) {
         if (S.multi[n] && s > 0) mf_fill_boundary(a);
         for (size_t f = 0; f < S.A[n].size(); f++)
-          ndf_launch_march<0>(a->fabs[f], b2->fabs[f], S.res[n]->fabs[f], S.sigfull[n]->fabs[f], S.A[n][f], P.hg_omega, 0, S.r[n][f], (double *)nullptr);
+          ndf_launch_march<0>(a->fabs[f], b2->fabs[f], S.res[n]->fabs[f], S.sigfull[n]->fabs[f], &S.slave[n]->fabs[f], S.A[n][f], P.hg_omega, 0, S.r[n][f], (double *)nullptr);
         std::swap(a, b2);
       }
       ml_nd_apply_correction(S, n, a);
     }
     it++;
   }
+  if (S.multi[0]) mf_fill_boundary(S.phi[0]);
   for (int n = 1; n < L; n++) ml_nd_interface(S, n);
   if (iters) *iters = it; if (res0) *res0 = bnorm; if (res) *res = rn;
   HIPCHK(hipStreamSynchronize(st));
