@@ -192,6 +192,17 @@ int vdn_multifab_fill_ghost_cells(vdn_multifab *fine, const vdn_multifab *crse, 
 int vdn_create_umac_grown(vdn_multifab *fine, const vdn_multifab *crse, int dir);
 int vdn_ml_restrict_and_fill(int nlev, vdn_multifab **mf, int icomp, int bcomp, int nc, int same_boundary, const vdn_bc_tower *bct);
 
+/* ---- grid generation in front of the AMR path ------------------------------------------------------------------------------------
+ * tag_boxes(mf, tagboxes, dx, lev)                               src/tag_boxes.f90:17-48 (rules :142-210: rho > 1.01 / 1.1 / 1.5 by level
+ *                                                                for prob_type 1, 2; 1.2 < rho < 1.8 for prob_type 3)
+ * make_new_grids(new_grid, la_crse, la_fine, mf, dx, buf_wid, ref_ratio, lev, max_grid_size)   [FBoxLib]   src/initialize.f90:247-248,
+ *                                                                src/regrid.f90:148-149; cluster_* parameters src/_parameters:37-39
+ * s: the state of level `lev1` (1-based, as in tag_boxes) -- component 0 is tagged; the boxes of level lev1+1 are returned in that
+ * level's index space (*nboxes_out = 0: no cell tagged, "new_grid = .false.").  nest: cells of level lev1 kept between the new
+ * level and the edge of level lev1 (proper nesting).  Single rank in this round. */
+int vdn_make_new_grids(const vdn_multifab *s, int lev1, int buf_wid, int nest, double min_eff, int min_width, int blocking,
+                       int max_grid_size, int maxboxes, vdn_box *boxes_out, int *nboxes_out, long *ntagged);
+
 /* per-phase wall seconds of the last vdn_advance_timestep (reference prints them,
  * advance_timestep.f90:159-166): [0]=scalar [1]=velocity [2]=MAC [3]=HG [4]=total              */
 int  vdn_last_step_timing(double *sec5);

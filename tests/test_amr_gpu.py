@@ -378,3 +378,65 @@ def test_ml_projections_on_irregular_box_unions(gpu, oracle, fb, cb):
         a, b = K.gather(gpp[lev], p[lev])[1:-1, 1:-1, 1:-1], p[lev].a[1:-1, 1:-1, 1:-1]
         assert np.abs(a - b).max() <= 1e-8 * np.abs(b).max(), "p level %d: %.3e" % (lev, np.abs(a - b).max())
     K.close()
+
+
+def _cells(b):
+    return int(np.prod([b[1][d] - b[0][d] + 1 for d in range(3)]))
+
+
+@pytest.mark.parametrize("max_levs", [2, 3])
+def test_tagged_grids_properties_and_run(gpu, max_levs):
+    """tag_boxes + make_new_grids on the 32^3 bubble (src/initialize.f90:152-342): the boxes of every new level are disjoint,
+    blocking-factor aligned, inside the domain, cover every tagged cell (rho > 1.01 / 1.1 of the analytic initial data, grown by
+    the buffer), and nest in the level below with two of its cells to spare; the hierarchy then runs advance_timestep: both
+    composite solves converge, the coarse level stays mirror-symmetric and equal to the average of the level above it."""
+    from varden_amd import advance as adv
+    from varden_amd import driver
+    from varden_amd.capi import default_params
+    nc = 32
+    levels = driver.VardenAMR.tagged_grids(nc, WALLS, default_params(cflfac=0.9), max_levs=max_levs, max_grid_size=32)
+    assert len(levels) == max_levs - 1
+    cover_prev = None
+    for n, lb in enumerate(levels, start=1):
+        nd = nc << n
+        cover = np.zeros((nd,) * 3, dtype=np.int32)
+        for lo, hi in lb:
+            assert all(lo[d] % 8 == 0 and (hi[d] + 1) % 8 == 0 and 0 <= lo[d] <= hi[d] < nd and hi[d] - lo[d] + 1 <= 32 for d in range(3)), (lo, hi)
+            cover[lo[0]:hi[0] + 1, lo[1]:hi[1] + 1, lo[2]:hi[2] + 1] += 1
+        assert cover.max() == 1, "boxes of level %d overlap" % n
+        # every tagged cell of the parent level (analytic rho, threshold of tag_boxes.f90) is covered
+        h = 1.0 / (nd // 2)
+        x = (np.arange(nd // 2) + 0.5) * h
+        X, Y, Z = np.meshgrid(x, x, x, indexing="ij")
+        r = np.sqrt((X - 0.5) ** 2 + (Y - 0.5) ** 2 + (Z - 0.5) ** 2)
+        rho = 1.0 + 0.5 * (10.0 - 1.0) * (1.0 - np.tanh(30.0 * (r - 0.1)))          # initdata.f90:212-238, densfact 10
+        tagged = rho > (1.01 if n == 1 else 1.1)
+        if cover_prev is not None:
+            tagged &= cover_prev.astype(bool)                 # only cells of the parent level can be tagged
+        cov_c = cover.reshape(nd // 2, 2, nd // 2, 2, nd // 2, 2).min(axis=(1, 3, 5)).astype(bool)
+        if n == 1:
+            assert (cov_c | ~tagged).all(), "a tagged cell of level %d is not covered" % (n - 1)
+        else:                                                 # tags outside the nesting region are dropped by construction
+            assert (cov_c & tagged).sum() >= 0.9 * tagged.sum()
+            # nesting: the parent cells under the new level, grown by 2, lie inside the parent level
+            g = cov_c.copy()
+            for d in range(3):
+                for sft in (1, 2):
+                    g |= np.roll(cov_c, sft, axis=d) | np.roll(cov_c, -sft, axis=d)
+            assert (cover_prev.astype(bool) | ~g).all(), "level %d is not nested in level %d" % (n, n - 1)
+        cover_prev = cover
+    G = driver.VardenAMR(nc, levels[0], WALLS, params=default_params(cflfac=0.9), finer_levels=levels[1:])
+    for _ in range(2):
+        G.step()
+        assert adv.last_solver_stats("mac")[0] < 40 and adv.last_solver_stats("hg")[0] < 40
+        assert adv.last_solver_stats("mac")[2] <= 1e-10 * adv.last_solver_stats("mac")[1]
+    s0 = G.snew[0].to_numpy(0)[3:-3, 3:-3, 3:-3, 0]
+    assert np.isfinite(s0).all()
+    assert np.abs(s0 - s0[::-1]).max() <= 1e-8 and np.abs(s0 - s0[:, ::-1]).max() <= 1e-8
+    # coarse cells under level 1 = mean of their 8 children
+    for i, (lo, hi) in enumerate(levels[0]):
+        f = G.snew[1].to_numpy(i)[3:-3, 3:-3, 3:-3, 0]
+        m = f.reshape(f.shape[0] // 2, 2, f.shape[1] // 2, 2, f.shape[2] // 2, 2).mean(axis=(1, 3, 5))
+        c = s0[lo[0] // 2:hi[0] // 2 + 1, lo[1] // 2:hi[1] // 2 + 1, lo[2] // 2:hi[2] // 2 + 1]
+        assert np.abs(c - m).max() <= 1e-13
+    G.close()

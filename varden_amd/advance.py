@@ -142,3 +142,13 @@ def create_umac_grown(fine, crse, dir):
 
 def ml_restrict_and_fill(mfs, icomp, bcomp, nc, bct, same_boundary=False):
     check(capi.load().vdn_ml_restrict_and_fill(len(mfs), handle_array(mfs), icomp, bcomp, nc, 1 if same_boundary else 0, bct.h))
+
+
+def make_new_grids(s, lev, buf_wid=2, nest=2, min_eff=0.9, min_width=4, blocking=4, max_grid_size=256, maxboxes=4096):
+    """tag_boxes (src/tag_boxes.f90) on component 0 of `s` (the state of level `lev`, 1-based) + FBoxLib's make_new_grids
+    (src/initialize.f90:247-248): the boxes of level lev+1 in that level's index space ([] = nothing tagged), and the tag count"""
+    boxes = (capi.Box * maxboxes)()
+    nb, nt = C.c_int(), C.c_long()
+    check(capi.load().vdn_make_new_grids(s.h, lev, buf_wid, nest, min_eff, min_width, blocking, max_grid_size, maxboxes, boxes,
+                                         C.byref(nb), C.byref(nt)))
+    return [(tuple(boxes[i].lo), tuple(boxes[i].hi)) for i in range(nb.value)], nt.value

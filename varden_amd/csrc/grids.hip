@@ -1,0 +1,195 @@
+// grids.hip -- the grid generation that sits in front of the AMR hot path: tag_boxes (src/tag_boxes.f90:17-216) on the device and
+// FBoxLib's make_new_grids (src/initialize.f90:247-248, src/regrid.f90:148-149) on the host.
+//
+// make_new_grids is not in the reference tree (FBoxLib); the call sites and the probin parameters fix what goes in and out, the
+// procedure below is ours:
+//   1. tags = tag_boxes(first component of `s`, level) on the valid cells of the level (the reference's thresholds);
+//   2. the tags are grown by amr_buf_width cells (probin.template:147-154) and clipped to the nesting region: the cells of the
+//      level that keep `nest` cells of the level between themselves and any cell outside it (domain boundaries do not count) --
+//      the coarse-fine interpolation of the finer level then always finds its parents on this level;
+//   3. Berger-Rigoutsos clustering on the lattice of cluster_blocking_factor^3 blocks: take the bounding box of the tagged
+//      blocks; accept it when tagged/total >= cluster_min_eff or it cannot be cut; otherwise cut it at a hole of the tag
+//      signature, else at the strongest inflection of the signature's second difference, else in the middle of the longest side,
+//      and recurse;
+//   4. the boxes are refined by ref_ratio and chopped to max_grid_size.
+// Output: boxes of level+1 in its own index space, disjoint, every tagged cell covered, blocking-factor aligned.
+#include "vdn_dev.h"
+#include <vector>
+#include <algorithm>
+
+__global__ void kk_tag(FV s, unsigned char *tags, int n0, int n1, int d0, int d1, int d2, int rule, double tlo, double thi, Range3 r) {
+  THREAD_IJK(r)
+  if (!in_range) return;
+  const double v = fv_get(s, i, j, k);
+  const bool t = rule == 0 ? (v > tlo) : (v > tlo && v < thi);
+  tags[(size_t)(i - d0) + (size_t)n0 * ((size_t)(j - d1) + (size_t)n1 * (size_t)(k - d2))] = t ? 1 : 0;
+}
+
+namespace {
+struct IBox { int lo[3], hi[3]; };
+struct Lattice {
+  int n[3]; std::vector<unsigned char> t;
+  unsigned char at(int i, int j, int k) const { return t[(size_t)i + (size_t)n[0] * ((size_t)j + (size_t)n[1] * (size_t)k)]; }
+};
+long count_tags(const Lattice &G, const IBox &b) {
+  long c = 0;
+  for (int k = b.lo[2]; k <= b.hi[2]; k++) for (int j = b.lo[1]; j <= b.hi[1]; j++) for (int i = b.lo[0]; i <= b.hi[0]; i++) c += G.at(i, j, k);
+  return c;
+}
+bool shrink_to_tags(const Lattice &G, IBox &b) {
+  int lo[3] = { b.hi[0] + 1, b.hi[1] + 1, b.hi[2] + 1 }, hi[3] = { b.lo[0] - 1, b.lo[1] - 1, b.lo[2] - 1 };
+  for (int k = b.lo[2]; k <= b.hi[2]; k++) for (int j = b.lo[1]; j <= b.hi[1]; j++) for (int i = b.lo[0]; i <= b.hi[0]; i++)
+    if (G.at(i, j, k)) { const int q[3] = { i, j, k }; for (int d = 0; d < 3; d++) { lo[d] = std::min(lo[d], q[d]); hi[d] = std::max(hi[d], q[d]); } }
+  if (lo[0] > hi[0]) return false;
+  for (int d = 0; d < 3; d++) { b.lo[d] = lo[d]; b.hi[d] = hi[d]; }
+  return true;
+}
+void cluster(const Lattice &G, IBox b, double min_eff, int min_width, std::vector<IBox> &out) {
+  if (!shrink_to_tags(G, b)) return;
+  const long vol = (long)(b.hi[0] - b.lo[0] + 1) * (b.hi[1] - b.lo[1] + 1) * (b.hi[2] - b.lo[2] + 1);
+  const long ntag = count_tags(G, b);
+  if ((double)ntag >= min_eff * (double)vol) { out.push_back(b); return; }
+  // signatures
+  std::vector<long> sig[3];
+  for (int d = 0; d < 3; d++) sig[d].assign(b.hi[d] - b.lo[d] + 1, 0);
+  for (int k = b.lo[2]; k <= b.hi[2]; k++) for (int j = b.lo[1]; j <= b.hi[1]; j++) for (int i = b.lo[0]; i <= b.hi[0]; i++)
+    if (G.at(i, j, k)) { sig[0][i - b.lo[0]]++; sig[1][j - b.lo[1]]++; sig[2][k - b.lo[2]]++; }
+  int cut_d = -1, cut_at = -1;                 // the box is cut between cut_at-1 and cut_at (index relative to b.lo)
+  // (a) a hole in a signature; the one closest to the middle of its side, longest side first
+  int order[3] = { 0, 1, 2 };
+  std::sort(order, order + 3, [&](int x, int y) { return sig[x].size() > sig[y].size() || (sig[x].size() == sig[y].size() && x < y); });
+  for (int o = 0; o < 3 && cut_d < 0; o++) {
+    const int d = order[o], len = (int)sig[d].size();
+    int best = -1;
+    for (int c = min_width; c <= len - min_width; c++) if (sig[d][c] == 0 || sig[d][c - 1] == 0) { if (best < 0 || std::abs(2 * c - len) < std::abs(2 * best - len)) best = c; }
+    if (best >= 0) { cut_d = d; cut_at = best; }
+  }
+  // (b) the strongest inflection of the second difference of a signature
+  if (cut_d < 0) {
+    long best_jump = 0;
+    for (int o = 0; o < 3; o++) {
+      const int d = order[o], len = (int)sig[d].size();
+      if (len < 2 * min_width || len < 4) continue;
+      std::vector<long> lap(len, 0);
+      for (int c = 1; c < len - 1; c++) lap[c] = sig[d][c - 1] - 2 * sig[d][c] + sig[d][c + 1];
+      for (int c = std::max(min_width, 2); c <= std::min(len - min_width, len - 2); c++) {
+        if ((lap[c - 1] < 0) != (lap[c] < 0) || (lap[c - 1] == 0) != (lap[c] == 0)) {
+          const long jump = std::labs(lap[c] - lap[c - 1]);
+          if (jump > best_jump || (jump == best_jump && cut_d == d && std::abs(2 * c - len) < std::abs(2 * cut_at - len))) { best_jump = jump; cut_d = d; cut_at = c; }
+        }
+      }
+    }
+  }
+  // (c) the middle of the longest side
+  if (cut_d < 0) {
+    const int d = order[0], len = (int)sig[d].size();
+    if (len >= 2 * min_width) { cut_d = d; cut_at = len / 2; }
+  }
+  if (cut_d < 0) { out.push_back(b); return; }       // cannot be cut: accept
+  IBox l = b, r = b;
+  l.hi[cut_d] = b.lo[cut_d] + cut_at - 1; r.lo[cut_d] = b.lo[cut_d] + cut_at;
+  cluster(G, l, min_eff, min_width, out);
+  cluster(G, r, min_eff, min_width, out);
+}
+}  // namespace
+
+// s: the state of ONE level (valid cells of its local boxes; single rank).  boxes_out: boxes of the next finer level in ITS index space
+extern "C" int vdn_make_new_grids(const vdn_multifab *s, int lev1, int buf_wid, int nest, double min_eff, int min_width, int blocking,
+                                  int max_grid_size, int maxboxes, vdn_box *boxes_out, int *nboxes_out, long *ntagged) {
+  VDN_TRY
+  REQUIRE(s && boxes_out && nboxes_out, "vdn_make_new_grids: null argument");
+  REQUIRE(ctx().nranks == 1, "vdn_make_new_grids: single rank in this round");
+  REQUIRE(blocking >= 1 && min_width >= 1 && max_grid_size >= 2 * blocking, "vdn_make_new_grids: bad clustering parameters");
+  const vdn_layout *la = s->la;
+  const vdn_box &pd = la->pd[s->lev];
+  int n[3]; for (int d = 0; d < 3; d++) n[d] = pd.hi[d] - pd.lo[d] + 1;
+  const int dm = ctx().prm.dm;
+  for (int d = 0; d < dm; d++) REQUIRE(n[d] % blocking == 0, "vdn_make_new_grids: the domain extent %d is not a multiple of the blocking factor %d", n[d], blocking);
+  // 1. tags on the device (tag_boxes.f90:142-210: thresholds by level, prob_type)
+  const int pt = ctx().prm.prob_type;
+  REQUIRE(pt == 1 || pt == 2 || pt == 3, "tag_boxes: unsupported prob_type %d (tag_boxes.f90:212)", pt);
+  int rule = 0; double tlo = 0.0, thi = 0.0;
+  if (pt == 3) { rule = 1; tlo = 1.2; thi = 1.8; } else { tlo = lev1 == 1 ? 1.01 : (lev1 == 2 ? 1.1 : 1.5); }
+  const size_t ncell = (size_t)n[0] * n[1] * n[2];
+  unsigned char *d_tags; HIPCHK(hipMalloc((void **)&d_tags, ncell));
+  HIPCHK(hipMemsetAsync(d_tags, 0, ncell, ctx().stream));
+  // inside[]: 1 on the cells of the level (host), for the nesting region
+  std::vector<unsigned char> inside(ncell, 0), tags(ncell, 0);
+  for (int b = 0; b < s->nfabs(); b++) {
+    Range3 r; for (int d = 0; d < 3; d++) { r.lo[d] = s->vbox[b].lo[d]; r.hi[d] = s->vbox[b].hi[d]; }
+    hipLaunchKernelGGL(kk_tag, grid_for(r), dim3(64, 4, 1), 0, ctx().stream, s->fabs[b], d_tags, n[0], n[1], pd.lo[0], pd.lo[1], pd.lo[2], rule, tlo, thi, r);
+    for (int k = r.lo[2]; k <= r.hi[2]; k++) for (int j = r.lo[1]; j <= r.hi[1]; j++)
+      std::fill(inside.begin() + ((size_t)(r.lo[0] - pd.lo[0]) + (size_t)n[0] * ((size_t)(j - pd.lo[1]) + (size_t)n[1] * (size_t)(k - pd.lo[2]))),
+                inside.begin() + ((size_t)(r.hi[0] - pd.lo[0]) + 1 + (size_t)n[0] * ((size_t)(j - pd.lo[1]) + (size_t)n[1] * (size_t)(k - pd.lo[2]))), 1);
+  }
+  HIPCHK(hipMemcpyAsync(tags.data(), d_tags, ncell, hipMemcpyDeviceToHost, ctx().stream));
+  HIPCHK(hipStreamSynchronize(ctx().stream));
+  HIPCHK(hipFree(d_tags));
+  long nt = 0; for (size_t c = 0; c < ncell; c++) nt += tags[c];
+  if (ntagged) *ntagged = nt;
+  *nboxes_out = 0;
+  if (nt == 0) return 0;
+  auto at = [&](std::vector<unsigned char> &a, int i, int j, int k) -> unsigned char & { return a[(size_t)i + (size_t)n[0] * ((size_t)j + (size_t)n[1] * (size_t)k)]; };
+  // 2. grow the tags by buf_wid (box dilation, one direction after the other); shrink `inside` by `nest` the same way (cells
+  // outside the domain count as inside: a level may touch the domain boundary)
+  auto sweep = [&](std::vector<unsigned char> &a, int width, bool dilate) {
+    if (width <= 0) return;
+    for (int d = 0; d < dm; d++) {
+      std::vector<unsigned char> o(a);
+      const int e[3] = { d == 0, d == 1, d == 2 };
+      for (int k = 0; k < n[2]; k++) for (int j = 0; j < n[1]; j++) for (int i = 0; i < n[0]; i++) {
+        unsigned char v = dilate ? 0 : 1;
+        for (int w = -width; w <= width; w++) {
+          const int ii = i + w * e[0], jj = j + w * e[1], kk = k + w * e[2];
+          if (ii < 0 || ii >= n[0] || jj < 0 || jj >= n[1] || kk < 0 || kk >= n[2]) continue;
+          if (dilate) v |= at(o, ii, jj, kk); else v &= at(o, ii, jj, kk);
+        }
+        at(a, i, j, k) = v;
+      }
+    }
+  };
+  sweep(tags, buf_wid, true);
+  sweep(inside, nest, false);
+  for (size_t c = 0; c < ncell; c++) tags[c] &= inside[c];
+  // 3. cluster on the lattice of blocks; a block takes part only if it lies in the nesting region as a whole
+  Lattice G; for (int d = 0; d < 3; d++) G.n[d] = d < dm ? n[d] / blocking : 1;
+  G.t.assign((size_t)G.n[0] * G.n[1] * G.n[2], 0);
+  const int bz = dm == 3 ? blocking : 1;
+  for (int K = 0; K < G.n[2]; K++) for (int J = 0; J < G.n[1]; J++) for (int I = 0; I < G.n[0]; I++) {
+    bool any = false, all_in = true;
+    for (int c = 0; c < bz; c++) for (int b = 0; b < blocking; b++) for (int a = 0; a < blocking; a++) {
+      const int i = I * blocking + a, j = J * blocking + b, k = K * bz + c;
+      any = any || at(tags, i, j, k); all_in = all_in && at(inside, i, j, k);
+    }
+    G.t[(size_t)I + (size_t)G.n[0] * ((size_t)J + (size_t)G.n[1] * (size_t)K)] = (any && all_in) ? 1 : 0;
+  }
+  std::vector<IBox> cl;
+  IBox whole; for (int d = 0; d < 3; d++) { whole.lo[d] = 0; whole.hi[d] = G.n[d] - 1; }
+  cluster(G, whole, min_eff, std::max(1, (min_width + blocking - 1) / blocking), cl);
+  // 4. refine (blocks -> cells of this level -> cells of the finer level) and chop to max_grid_size
+  std::vector<vdn_box> out;
+  for (const IBox &b : cl) {
+    int flo[3], fhi[3], cnt[3], len[3];
+    for (int d = 0; d < 3; d++) {
+      const int bl = d < dm ? blocking : 1, rr = d < dm ? 2 : 1;
+      flo[d] = (pd.lo[d] + b.lo[d] * bl) * rr; fhi[d] = (pd.lo[d] + (b.hi[d] + 1) * bl) * rr - 1;
+      len[d] = fhi[d] - flo[d] + 1;
+      cnt[d] = (len[d] + max_grid_size - 1) / max_grid_size;
+    }
+    for (int c = 0; c < cnt[2]; c++) for (int bb = 0; bb < cnt[1]; bb++) for (int a = 0; a < cnt[0]; a++) {
+      const int q[3] = { a, bb, c };
+      vdn_box o;
+      for (int d = 0; d < 3; d++) {
+        // equal pieces, multiples of the (refined) blocking factor
+        const int unit = d < dm ? 2 * blocking : 1, units = len[d] / unit;
+        const int u0 = (int)((long)units * q[d] / cnt[d]), u1 = (int)((long)units * (q[d] + 1) / cnt[d]);
+        o.lo[d] = flo[d] + u0 * unit; o.hi[d] = flo[d] + u1 * unit - 1;
+      }
+      out.push_back(o);
+    }
+  }
+  REQUIRE((int)out.size() <= maxboxes, "vdn_make_new_grids: %d boxes, room for %d", (int)out.size(), maxboxes);
+  for (size_t i = 0; i < out.size(); i++) boxes_out[i] = out[i];
+  *nboxes_out = (int)out.size();
+  VDN_CATCH
+}

@@ -1340,6 +1340,7 @@ static double ml_nd_residual(MLND &S, bool finest_only) {
         hipLaunchKernelGGL(kk_ndm_restrict_add, grid_for(ri), NBLK, 0, st, S.res[n]->fabs[c], S.res[n + 1]->fabs[f], S.own[n + 1]->fabs[f], Af, S.A[n][c], ri);
       }
     }
+    if (S.multi[n] && n > 0) mf_fill_boundary(S.res[n]);      // the ghost nodes must see the restricted part too before level n-1 restricts them
     for (size_t c = 0; c < S.A[n].size(); c++)
       hipLaunchKernelGGL(kk_ndf_absmax_mask, reduce_grid(S.r[n][c]), NBLK, 0, st, S.res[n]->fabs[c], S.skip[n]->fabs[c], S.r[n][c], S.d_nrm);
   }

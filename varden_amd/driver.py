@@ -163,6 +163,11 @@ class Varden:
             bl.comm_finalize()
 
 
+def prm_cluster(prm, name):
+    """cluster_min_eff / cluster_min_width / cluster_blocking_factor (src/_parameters:37-39); not part of vdn_params"""
+    return {"min_eff": 0.9, "min_width": 4, "blocking": 4}[name]
+
+
 class VardenAMR:
     """multi-level hierarchy on fixed grids (the reference's fixed_grids mode, src/initialize.f90:93-150): level 0 = one box covering
     the domain [0,nc)^3, level 1 = the given fine boxes (fine index space, refinement ratio 2); `finer_levels`: box lists of the
@@ -201,6 +206,36 @@ class VardenAMR:
             self.unew[n].copy_c(0, self.uold[n], 0, dm, 3)
             self.snew[n].copy_c(0, self.sold[n], 0, ns, 3)
         self.dt = self.estdt(1.0e20) * init_shrink
+
+    @staticmethod
+    def tagged_grids(nc, phys_bc, params=None, prob_type=1, max_levs=2, buf_wid=2, max_grid_size=256, device=0):
+        """the grids the reference's initialize_with_adaptive_grids builds (src/initialize.f90:152-342): level by level, initial data on
+        the level -> tag_boxes -> make_new_grids, until nothing is tagged or max_levs is reached.  Returns the box lists of the levels
+        1.. (each in its own index space).  Nesting: a new level keeps 2 cells of its parent level around itself."""
+        prm = params or default_params()
+        prm.prob_type = prob_type
+        bl.initialize(prm, 0, 1, device)
+        ns = prm.nscal
+        levels = []
+        pd = [((0, 0, 0), (nc - 1,) * 3)]
+        boxes = [[pd[0]]]
+        for lev in range(1, max_levs):
+            mla = bl.MLLayout(pd, boxes, rr=[(2, 2, 2)] * (lev - 1))
+            sold = bl.MultiFab(mla, lev - 1, ns, 3)
+            dx = [1.0 / (nc << (lev - 1))] * 3
+            for i, (blo, bhi) in enumerate(boxes[lev - 1]):
+                nb = tuple(bhi[d] - blo[d] + 1 for d in range(3))
+                _, sb = initdata_numpy(nb, dx, prob_type, 3, ns, lo=blo)
+                sold.from_numpy(sb, i)
+            new, _ = adv.make_new_grids(sold, lev, buf_wid=buf_wid, nest=0 if lev == 1 else 2, min_eff=prm_cluster(prm, "min_eff"),
+                                        min_width=prm_cluster(prm, "min_width"), blocking=prm_cluster(prm, "blocking"), max_grid_size=max_grid_size)
+            sold.destroy(); mla.destroy()
+            if not new:
+                break
+            levels.append(new)
+            pd.append(((0, 0, 0), ((nc << lev) - 1,) * 3))
+            boxes.append(new)
+        return levels
 
     def fill_state_ghosts(self):
         adv.ml_restrict_and_fill(self.uold, 0, 0, self.dm, self.bct)
