@@ -16,7 +16,7 @@
 #include <vector>
 #include <algorithm>
 
-static const dim3 AB(64, 4, 1);
+
 static void require_amr(const vdn_layout *la) {
   REQUIRE(la->nlev >= 2 && la->nlev <= VDN_MAXLEV, "AMR path: 2..%d levels are implemented (nlevel = %d)", VDN_MAXLEV, la->nlev);
   REQUIRE(ctx().nranks == 1, "AMR path: single rank only in this round");
@@ -31,51 +31,58 @@ static bool isect(const int alo[3], const int ahi[3], const int blo[3], const in
 }
 
 // ---- restriction ----------------------------------------------------------------------------------------------------
-__global__ void kk_ml_restrict(FV crse, FV fine, Range3 r, int icomp, int nc) {
-  THREAD_IJK(r)
-  if (!in_range) return;
-  for (int c = icomp; c < icomp + nc; c++) {
+// (all multi-box loops of this file go through launch_batched / BatchSet: one launch per operation and level, vdn_dev.h)
+struct RestrictB { Range3 r; int g[3]; FV crse, fine; int icomp, nc;
+  static __device__ double body(const RestrictB &a, int i, int j, int k, int) {
+    for (int c = a.icomp; c < a.icomp + a.nc; c++) {
+      double s = 0.0;
+      #pragma unroll
+      for (int kk = 0; kk < 2; kk++)
+        #pragma unroll
+        for (int jj = 0; jj < 2; jj++)
+          #pragma unroll
+          for (int ii = 0; ii < 2; ii++) s = s + fv_get(a.fine, 2 * i + ii, 2 * j + jj, 2 * k + kk, c);
+      fv_at(a.crse, i, j, k, c) = s * 0.125;
+    }
+    return 0.0;
+  } };
+void ml_cc_restriction(vdn_multifab *crse, const vdn_multifab *fine, int icomp, int nc) {
+  std::vector<RestrictB> v;
+  for (int f = 0; f < fine->nfabs(); f++) for (int c = 0; c < crse->nfabs(); c++) {
+    int clo[3], chi[3]; RestrictB a;
+    for (int d = 0; d < 3; d++) { clo[d] = fine->vbox[f].lo[d] / 2; chi[d] = fine->vbox[f].hi[d] / 2; }
+    if (!isect(clo, chi, crse->vbox[c].lo, crse->vbox[c].hi, a.r)) continue;
+    a.crse = crse->fabs[c]; a.fine = fine->fabs[f]; a.icomp = icomp; a.nc = nc;
+    v.push_back(a);
+  }
+  launch_batched(v, 0, (double *)nullptr, 0, ctx().stream);
+}
+struct EdgeRestrictB { Range3 r; int g[3]; FV crse, fine; int dir;
+  static __device__ double body(const EdgeRestrictB &a, int i, int j, int k, int) {
+    const int Q[3] = { i, j, k };
+    const int dir = a.dir, t1 = (dir + 1) % 3, t2 = (dir + 2) % 3;
     double s = 0.0;
     #pragma unroll
-    for (int kk = 0; kk < 2; kk++)
+    for (int b = 0; b < 2; b++)
       #pragma unroll
-      for (int jj = 0; jj < 2; jj++)
-        #pragma unroll
-        for (int ii = 0; ii < 2; ii++) s = s + fv_get(fine, 2 * i + ii, 2 * j + jj, 2 * k + kk, c);
-    fv_at(crse, i, j, k, c) = s * 0.125;
-  }
-}
-void ml_cc_restriction(vdn_multifab *crse, const vdn_multifab *fine, int icomp, int nc) {
-  for (int f = 0; f < fine->nfabs(); f++) for (int c = 0; c < crse->nfabs(); c++) {
-    int clo[3], chi[3]; Range3 r;
-    for (int d = 0; d < 3; d++) { clo[d] = fine->vbox[f].lo[d] / 2; chi[d] = fine->vbox[f].hi[d] / 2; }
-    if (!isect(clo, chi, crse->vbox[c].lo, crse->vbox[c].hi, r)) continue;
-    hipLaunchKernelGGL(kk_ml_restrict, grid_for(r), AB, 0, ctx().stream, crse->fabs[c], fine->fabs[f], r, icomp, nc);
-  }
-}
-__global__ void kk_ml_edge_restrict(FV crse, FV fine, Range3 r, int dir) {
-  THREAD_IJK(r)
-  if (!in_range) return;
-  const int Q[3] = { i, j, k };
-  const int t1 = (dir + 1) % 3, t2 = (dir + 2) % 3;
-  double s = 0.0;
-  #pragma unroll
-  for (int b = 0; b < 2; b++)
-    #pragma unroll
-    for (int a = 0; a < 2; a++) {
-      int q[3]; q[dir] = 2 * Q[dir]; q[t1] = 2 * Q[t1] + a; q[t2] = 2 * Q[t2] + b;
-      s = s + fv_get(fine, q[0], q[1], q[2]);
-    }
-  fv_at(crse, i, j, k) = s * 0.25;
-}
+      for (int aa = 0; aa < 2; aa++) {
+        int q[3]; q[dir] = 2 * Q[dir]; q[t1] = 2 * Q[t1] + aa; q[t2] = 2 * Q[t2] + b;
+        s = s + fv_get(a.fine, q[0], q[1], q[2]);
+      }
+    fv_at(a.crse, i, j, k) = s * 0.25;
+    return 0.0;
+  } };
 void ml_edge_restriction(vdn_multifab *crse, const vdn_multifab *fine, int dir) {
+  std::vector<EdgeRestrictB> v;
   for (int f = 0; f < fine->nfabs(); f++) for (int c = 0; c < crse->nfabs(); c++) {
-    int clo[3], chi[3], blo[3], bhi[3]; Range3 r;
+    int clo[3], chi[3], blo[3], bhi[3]; EdgeRestrictB a;
     for (int d = 0; d < 3; d++) { clo[d] = fine->vbox[f].lo[d] / 2; chi[d] = fine->vbox[f].hi[d] / 2; blo[d] = crse->vbox[c].lo[d]; bhi[d] = crse->vbox[c].hi[d]; }
     chi[dir] += 1; bhi[dir] += 1;
-    if (!isect(clo, chi, blo, bhi, r)) continue;
-    hipLaunchKernelGGL(kk_ml_edge_restrict, grid_for(r), AB, 0, ctx().stream, crse->fabs[c], fine->fabs[f], r, dir);
+    if (!isect(clo, chi, blo, bhi, a.r)) continue;
+    a.crse = crse->fabs[c]; a.fine = fine->fabs[f]; a.dir = dir;
+    v.push_back(a);
   }
+  launch_batched(v, 0, (double *)nullptr, 0, ctx().stream);
 }
 
 // ---- coarse -> fine ghost interpolation ---------------------------------------------------------------------------------
@@ -88,13 +95,13 @@ DEVI double mc_limited(double del, double sm, double s0, double sp) {
 }
 // r: fine cells (the grown fine box); a thread writes its cell if it is a ghost cell whose parent lies in [plo,phi];
 // [alo,ahi]: the allocation of the coarse fab (slopes need both neighbours inside it)
-__global__ void kk_ml_interp_ghost(FV fine, FV crse, InterpArgs A, Range3 r) {
-  THREAD_IJK(r)
-  if (!in_range) return;
-  if (i >= A.flo[0] && i <= A.fhi[0] && j >= A.flo[1] && j <= A.fhi[1] && k >= A.flo[2] && k <= A.fhi[2]) return;
+struct InterpB { Range3 r; int g[3]; FV fine, crse; InterpArgs A;
+  static __device__ double body(const InterpB &a_, int i, int j, int k, int) {
+  const FV &fine = a_.fine, &crse = a_.crse; const InterpArgs &A = a_.A;
+  if (i >= A.flo[0] && i <= A.fhi[0] && j >= A.flo[1] && j <= A.fhi[1] && k >= A.flo[2] && k <= A.fhi[2]) return 0.0;
   const int q[3] = { i, j, k }, P[3] = { fdiv2(i), fdiv2(j), fdiv2(k) };
   #pragma unroll
-  for (int d = 0; d < 3; d++) if (P[d] < A.plo[d] || P[d] > A.phi[d]) return;
+  for (int d = 0; d < 3; d++) if (P[d] < A.plo[d] || P[d] > A.phi[d]) return 0.0;
   for (int c = A.icomp; c < A.icomp + A.nc; c++) {
     const double c0 = fv_get(crse, P[0], P[1], P[2], c);
     double v = c0;
@@ -110,12 +117,14 @@ __global__ void kk_ml_interp_ghost(FV fine, FV crse, InterpArgs A, Range3 r) {
     }
     fv_at(fine, i, j, k, c) = v;
   }
-}
+  return 0.0;
+} };
 // parents inside a coarse box's VALID region come from that box; parents outside the domain (physical / periodic ghost
 // cells of the coarse level) come from the first coarse box whose allocation holds them.  A one-box coarse level that does not
 // cover the domain: parents outside the box (its own ghost cells, filled from the next coarser level) count as "outside"
 void ml_fill_ghost_cells(vdn_multifab *fine, const vdn_multifab *crse, int icomp, int nc) {
   if (fine->ng == 0) return;
+  std::vector<InterpB> v;
   const vdn_box &pdc = crse->nfabs() == 1 ? crse->vbox[0] : crse->la->pd[crse->lev];
   for (int f = 0; f < fine->nfabs(); f++) {
     InterpArgs A; Range3 r;
@@ -144,44 +153,52 @@ void ml_fill_ghost_cells(vdn_multifab *fine, const vdn_multifab *crse, int icomp
             if (s == 0) { if (pr.lo[d] >= pdc.lo[d]) continue; B.phi[d] = std::min(pr.hi[d], pdc.lo[d] - 1); }
             else        { if (pr.hi[d] <= pdc.hi[d]) continue; B.plo[d] = std::max(pr.lo[d], pdc.hi[d] + 1); }
             for (int e = 0; e < d; e++) { B.plo[e] = std::max(B.plo[e], pdc.lo[e]); B.phi[e] = std::min(B.phi[e], pdc.hi[e]); if (B.plo[e] > B.phi[e]) goto next; }
-            hipLaunchKernelGGL(kk_ml_interp_ghost, grid_for(r), AB, 0, ctx().stream, fine->fabs[f], crse->fabs[c], B, r);
+            { InterpB e; e.r = r; e.fine = fine->fabs[f]; e.crse = crse->fabs[c]; e.A = B; v.push_back(e); }
             next:;
           }
           if (crse->nfabs() > 0) break;      // first coarse box whose allocation holds them
         } else
-          hipLaunchKernelGGL(kk_ml_interp_ghost, grid_for(r), AB, 0, ctx().stream, fine->fabs[f], crse->fabs[c], A, r);
+          { InterpB e; e.r = r; e.fine = fine->fabs[f]; e.crse = crse->fabs[c]; e.A = A; v.push_back(e); }
       }
   }
+  launch_batched(v, 0, (double *)nullptr, 0, ctx().stream);       // every ghost cell has exactly one parent range: order-free
 }
 struct GrownArgs { int flo[3], fhi[3]; int plo[3], phi[3]; int dir; };
-__global__ void kk_ml_umac_grown(FV fine, FV crse, GrownArgs A, Range3 r) {
-  THREAD_IJK(r)
-  if (!in_range) return;
-  if (i >= A.flo[0] && i <= A.fhi[0] && j >= A.flo[1] && j <= A.fhi[1] && k >= A.flo[2] && k <= A.fhi[2]) return;     // valid faces
+struct GrownB { Range3 r; int g[3]; FV fine, crse; GrownArgs A;
+  static __device__ double body(const GrownB &a_, int i, int j, int k, int) {
+  const FV &fine = a_.fine, &crse = a_.crse; const GrownArgs &A = a_.A;
+  if (i >= A.flo[0] && i <= A.fhi[0] && j >= A.flo[1] && j <= A.fhi[1] && k >= A.flo[2] && k <= A.fhi[2]) return 0.0;     // valid faces
   const int q[3] = { i, j, k };
   int P[3] = { fdiv2(i), fdiv2(j), fdiv2(k) };
   const int odd = q[A.dir] - 2 * P[A.dir];
   #pragma unroll
-  for (int d = 0; d < 3; d++) if (P[d] < A.plo[d] || P[d] + ((d == A.dir) ? odd : 0) > A.phi[d]) return;
+  for (int d = 0; d < 3; d++) if (P[d] < A.plo[d] || P[d] + ((d == A.dir) ? odd : 0) > A.phi[d]) return 0.0;
   const double a = fv_get(crse, P[0], P[1], P[2]);
   double v = a;
   if (odd) { P[A.dir] += 1; v = 0.5 * (a + fv_get(crse, P[0], P[1], P[2])); }
   fv_at(fine, i, j, k) = v;
-}
+  return 0.0;
+} };
 // parents on VALID faces of a coarse box come from that box; the remaining ones (outside the domain, or -- for a one-box coarse
 // level that does not cover the domain -- in that box's own ghost faces) from the first coarse box whose allocation holds them
 void ml_create_umac_grown(vdn_multifab *fine, const vdn_multifab *crse, int dir) {
+  // the first box with its ghost faces (filled by fill_boundary), then every box's valid faces on top (same values where both hold
+  // one): two launches so that the second pass wins
+  std::vector<GrownB> v0, v1;
   for (int f = 0; f < fine->nfabs(); f++) {
-    GrownArgs A; Range3 r; A.dir = dir;
-    for (int d = 0; d < 3; d++) { A.flo[d] = fine->vbox[f].lo[d]; A.fhi[d] = fine->vbox[f].hi[d] + (d == dir); r.lo[d] = A.flo[d] - fine->ng; r.hi[d] = A.fhi[d] + fine->ng; }
-    // the first box with its ghost faces (filled by fill_boundary), then every box's valid faces on top (same values where both hold one)
-    for (int d = 0; d < 3; d++) { A.plo[d] = crse->vbox[0].lo[d] - crse->ng; A.phi[d] = crse->vbox[0].hi[d] + (d == dir) + crse->ng; }
-    hipLaunchKernelGGL(kk_ml_umac_grown, grid_for(r), AB, 0, ctx().stream, fine->fabs[f], crse->fabs[0], A, r);
+    GrownB e; e.A.dir = dir; e.fine = fine->fabs[f];
+    for (int d = 0; d < 3; d++) { e.A.flo[d] = fine->vbox[f].lo[d]; e.A.fhi[d] = fine->vbox[f].hi[d] + (d == dir); e.r.lo[d] = e.A.flo[d] - fine->ng; e.r.hi[d] = e.A.fhi[d] + fine->ng; }
+    for (int d = 0; d < 3; d++) { e.A.plo[d] = crse->vbox[0].lo[d] - crse->ng; e.A.phi[d] = crse->vbox[0].hi[d] + (d == dir) + crse->ng; }
+    e.crse = crse->fabs[0];
+    v0.push_back(e);
     for (int c = 0; c < crse->nfabs() && crse->nfabs() > 1; c++) {
-      for (int d = 0; d < 3; d++) { A.plo[d] = crse->vbox[c].lo[d]; A.phi[d] = crse->vbox[c].hi[d] + (d == dir); }
-      hipLaunchKernelGGL(kk_ml_umac_grown, grid_for(r), AB, 0, ctx().stream, fine->fabs[f], crse->fabs[c], A, r);
+      for (int d = 0; d < 3; d++) { e.A.plo[d] = crse->vbox[c].lo[d]; e.A.phi[d] = crse->vbox[c].hi[d] + (d == dir); }
+      e.crse = crse->fabs[c];
+      v1.push_back(e);
     }
   }
+  launch_batched(v0, 0, (double *)nullptr, 0, ctx().stream);
+  launch_batched(v1, 0, (double *)nullptr, 0, ctx().stream);
 }
 void ml_restrict_and_fill(int nlev, vdn_multifab **mf, int icomp, int bcomp, int nc, bool same_boundary, const vdn_bc_tower *bct) {
   for (int n = nlev - 1; n >= 1; n--) ml_cc_restriction(mf[n - 1], mf[n], icomp, nc);
@@ -194,222 +211,261 @@ void ml_restrict_and_fill(int nlev, vdn_multifab **mf, int icomp, int bcomp, int
 
 // ---- composite cell-centred solve -------------------------------------------------------------------------------------------
 struct FaceBc { int lo[3], hi[3]; int e[3][2]; };
-__global__ void kk_phi_closure(FV phi, FaceBc B, int d, int s, Range3 r) {
-  THREAD_IJK(r)                              // r: the boundary cells of face (d,s)
-  if (!in_range) return;
-  const double v = fv_get(phi, i, j, k);
-  const int gi = i + (d == 0 ? (s ? 1 : -1) : 0), gj = j + (d == 1 ? (s ? 1 : -1) : 0), gk = k + (d == 2 ? (s ? 1 : -1) : 0);
-  fv_at(phi, gi, gj, gk) = (B.e[d][s] == VDN_BC_NEU) ? v : -v;
-}
-static void phi_closure(vdn_multifab *phi, const vdn_bc_tower *bct, int bc_comp0) {
-  for (int b = 0; b < phi->nfabs(); b++) {
-    FaceBc B;
-    for (int d = 0; d < 3; d++) { B.lo[d] = phi->vbox[b].lo[d]; B.hi[d] = phi->vbox[b].hi[d]; for (int s = 0; s < 2; s++) B.e[d][s] = bct->ell_bc(phi->lev, b + 1, d, s, bc_comp0); }
+struct ClosureB { Range3 r; int g[3]; FV phi; int bc, d, s;          // r: the boundary cells of face (d,s)
+  static __device__ double body(const ClosureB &a, int i, int j, int k, int) {
+    const double v = fv_get(a.phi, i, j, k);
+    const int d = a.d, s = a.s;
+    const int gi = i + (d == 0 ? (s ? 1 : -1) : 0), gj = j + (d == 1 ? (s ? 1 : -1) : 0), gk = k + (d == 2 ? (s ? 1 : -1) : 0);
+    fv_at(a.phi, gi, gj, gk) = (a.bc == VDN_BC_NEU) ? v : -v;
+    return 0.0;
+  } };
+static void closure_descs(vdn_multifab *phi, const vdn_bc_tower *bct, int bc_comp0, std::vector<ClosureB> &v) {
+  for (int b = 0; b < phi->nfabs(); b++)
     for (int d = 0; d < 3; d++) for (int s = 0; s < 2; s++) {
-      if (B.e[d][s] != VDN_BC_NEU && B.e[d][s] != VDN_BC_DIR) continue;
-      Range3 r; for (int t = 0; t < 3; t++) { r.lo[t] = B.lo[t]; r.hi[t] = B.hi[t]; }
-      r.lo[d] = r.hi[d] = s ? B.hi[d] : B.lo[d];
-      hipLaunchKernelGGL(kk_phi_closure, grid_for(r), AB, 0, ctx().stream, phi->fabs[b], B, d, s, r);
+      const int e = bct->ell_bc(phi->lev, b + 1, d, s, bc_comp0);
+      if (e != VDN_BC_NEU && e != VDN_BC_DIR) continue;
+      ClosureB a; a.phi = phi->fabs[b]; a.bc = e; a.d = d; a.s = s;
+      for (int t = 0; t < 3; t++) { a.r.lo[t] = phi->vbox[b].lo[t]; a.r.hi[t] = phi->vbox[b].hi[t]; }
+      a.r.lo[d] = a.r.hi[d] = s ? phi->vbox[b].hi[d] : phi->vbox[b].lo[d];
+      v.push_back(a);
     }
-  }
-  mf_fill_boundary(phi);
 }
 struct CfArgs { int d, s; int plo[3], phi[3]; };
-__global__ void kk_cf_interp(FV pf, FV pc, CfArgs A, Range3 r) {
-  THREAD_IJK(r)                              // r: the ghost cells just outside face (d,s) of the fine box
-  if (!in_range) return;
-  const int g[3] = { i, j, k };
-  const int P[3] = { fdiv2(i), fdiv2(j), fdiv2(k) };
-  #pragma unroll
-  for (int t = 0; t < 3; t++) if (P[t] < A.plo[t] || P[t] > A.phi[t]) return;
-  const int in = A.s ? -1 : 1;
-  int f1[3] = { i, j, k }, f2[3] = { i, j, k }; f1[A.d] += in; f2[A.d] += 2 * in;
-  double pcs = fv_get(pc, P[0], P[1], P[2]);
-  #pragma unroll
-  for (int t = 0; t < 3; t++) {
-    if (t == A.d) continue;
-    const double sg = (g[t] - 2 * P[t]) ? 0.125 : -0.125;
-    pcs = pcs + sg * (fv_get(pc, P[0] + (t == 0), P[1] + (t == 1), P[2] + (t == 2)) - fv_get(pc, P[0] - (t == 0), P[1] - (t == 1), P[2] - (t == 2)));
-  }
-  fv_at(pf, i, j, k) = (8.0 / 15.0) * pcs + (2.0 / 3.0) * fv_get(pf, f1[0], f1[1], f1[2]) - 0.2 * fv_get(pf, f2[0], f2[1], f2[2]);
-}
+struct CfB { Range3 r; int g[3]; FV pf, pc; CfArgs A;                // r: the ghost cells just outside face (d,s) of the fine box
+  static __device__ double body(const CfB &a, int i, int j, int k, int) {
+    const CfArgs &A = a.A; const FV &pf = a.pf, &pc = a.pc;
+    const int gq[3] = { i, j, k };
+    const int P[3] = { fdiv2(i), fdiv2(j), fdiv2(k) };
+    #pragma unroll
+    for (int t = 0; t < 3; t++) if (P[t] < A.plo[t] || P[t] > A.phi[t]) return 0.0;
+    const int in = A.s ? -1 : 1;
+    int f1[3] = { i, j, k }, f2[3] = { i, j, k }; f1[A.d] += in; f2[A.d] += 2 * in;
+    double pcs = fv_get(pc, P[0], P[1], P[2]);
+    #pragma unroll
+    for (int t = 0; t < 3; t++) {
+      if (t == A.d) continue;
+      const double sg = (gq[t] - 2 * P[t]) ? 0.125 : -0.125;
+      pcs = pcs + sg * (fv_get(pc, P[0] + (t == 0), P[1] + (t == 1), P[2] + (t == 2)) - fv_get(pc, P[0] - (t == 0), P[1] - (t == 1), P[2] - (t == 2)));
+    }
+    fv_at(pf, i, j, k) = (8.0 / 15.0) * pcs + (2.0 / 3.0) * fv_get(pf, f1[0], f1[1], f1[2]) - 0.2 * fv_get(pf, f2[0], f2[1], f2[2]);
+    return 0.0;
+  } };
 // ghost cells of the fine phi: coarse-fine interpolation on every face that is not a domain face, then the same-level exchange
-// (which overwrites the cells that another fine box covers), then nothing else: domain faces were closed by phi_closure
-static void cf_interp(vdn_multifab *pf, const vdn_multifab *pc, const vdn_bc_tower *bct, int bc_comp0) {
+// (which overwrites the cells that another fine box covers); domain faces were closed by the closure
+static void cf_descs(vdn_multifab *pf, const vdn_multifab *pc, const vdn_bc_tower *bct, int bc_comp0, std::vector<CfB> &v) {
   for (int f = 0; f < pf->nfabs(); f++) for (int d = 0; d < 3; d++) for (int s = 0; s < 2; s++) {
     if (bct->ell_bc(pf->lev, f + 1, d, s, bc_comp0) != VDN_BC_INT) continue;
     Range3 r; for (int t = 0; t < 3; t++) { r.lo[t] = pf->vbox[f].lo[t]; r.hi[t] = pf->vbox[f].hi[t]; }
     r.lo[d] = r.hi[d] = s ? pf->vbox[f].hi[d] + 1 : pf->vbox[f].lo[d] - 1;
     for (int c = 0; c < pc->nfabs(); c++) {
-      CfArgs A; A.d = d; A.s = s;
-      for (int t = 0; t < 3; t++) { A.plo[t] = pc->vbox[c].lo[t]; A.phi[t] = pc->vbox[c].hi[t]; }
-      hipLaunchKernelGGL(kk_cf_interp, grid_for(r), AB, 0, ctx().stream, pf->fabs[f], pc->fabs[c], A, r);
+      // only coarse boxes that hold a parent of this slab
+      int plo[3], phi[3], q[3]; Range3 dummy;
+      for (int t = 0; t < 3; t++) { plo[t] = hfdiv2(r.lo[t]); phi[t] = hfdiv2(r.hi[t]); q[t] = 0; }
+      (void)q;
+      if (!isect(plo, phi, pc->vbox[c].lo, pc->vbox[c].hi, dummy)) continue;
+      CfB a; a.r = r; a.pf = pf->fabs[f]; a.pc = pc->fabs[c]; a.A.d = d; a.A.s = s;
+      for (int t = 0; t < 3; t++) { a.A.plo[t] = pc->vbox[c].lo[t]; a.A.phi[t] = pc->vbox[c].hi[t]; }
+      v.push_back(a);
     }
   }
-  mf_fill_boundary(pf);
 }
 struct ResArgs { double hi2[3]; };
-__global__ void kk_amr_residual(FV rh, FV phi, FV bx, FV by, FV bz, FV res, FV mask, int has_mask, ResArgs A, Range3 r, double *nrm) {
-  REDUCE_IJ(r)
-  double rmax = 0.0;
-  if (in_ij) REDUCE_KLOOP(r) {
+struct ResidualB { Range3 r; int g[3]; FV rh, phi, bx, by, bz, res; ResArgs A;
+  static __device__ double body(const ResidualB &a, int i, int j, int k, int) {
+    const FV &phi = a.phi;
     const double p0 = fv_get(phi, i, j, k);
-    const double ax = (fv_get(bx, i + 1, j, k) * (p0 - fv_get(phi, i + 1, j, k)) + fv_get(bx, i, j, k) * (p0 - fv_get(phi, i - 1, j, k))) * A.hi2[0];
-    const double ay = (fv_get(by, i, j + 1, k) * (p0 - fv_get(phi, i, j + 1, k)) + fv_get(by, i, j, k) * (p0 - fv_get(phi, i, j - 1, k))) * A.hi2[1];
-    const double az = (fv_get(bz, i, j, k + 1) * (p0 - fv_get(phi, i, j, k + 1)) + fv_get(bz, i, j, k) * (p0 - fv_get(phi, i, j, k - 1))) * A.hi2[2];
-    const double rr = fv_get(rh, i, j, k) - (ax + ay + az);
-    fv_at(res, i, j, k) = rr;
-    if (!(has_mask && fv_get(mask, i, j, k) != 0.0)) rmax = fmax(rmax, fabs(rr));
-  }
-  if (nrm) block_atomic_max(nrm, rmax);
-}
-__global__ void kk_absmax_masked(FV a, FV mask, int has_mask, Range3 r, double *nrm) {
-  REDUCE_IJ(r)
-  double m = 0.0;
-  if (in_ij) REDUCE_KLOOP(r) if (!(has_mask && fv_get(mask, i, j, k) != 0.0)) m = fmax(m, fabs(fv_get(a, i, j, k)));
-  block_atomic_max(nrm, m);
-}
+    const double ax = (fv_get(a.bx, i + 1, j, k) * (p0 - fv_get(phi, i + 1, j, k)) + fv_get(a.bx, i, j, k) * (p0 - fv_get(phi, i - 1, j, k))) * a.A.hi2[0];
+    const double ay = (fv_get(a.by, i, j + 1, k) * (p0 - fv_get(phi, i, j + 1, k)) + fv_get(a.by, i, j, k) * (p0 - fv_get(phi, i, j - 1, k))) * a.A.hi2[1];
+    const double az = (fv_get(a.bz, i, j, k + 1) * (p0 - fv_get(phi, i, j, k + 1)) + fv_get(a.bz, i, j, k) * (p0 - fv_get(phi, i, j, k - 1))) * a.A.hi2[2];
+    const double rr = fv_get(a.rh, i, j, k) - (ax + ay + az);
+    fv_at(a.res, i, j, k) = rr;
+    return fabs(rr);
+  } };
+struct AbsmaxB { Range3 r; int g[3]; FV a, mask; int has_mask;
+  static __device__ double body(const AbsmaxB &q, int i, int j, int k, int) {
+    if (q.has_mask && fv_get(q.mask, i, j, k) != 0.0) return 0.0;
+    return fabs(fv_get(q.a, i, j, k));
+  } };
 struct RefluxArgs { int d, s; double dxf, dxc; };
 // r: coarse faces (index along d fixed = the interface); the uncovered cell is on the outside of the fine box
-__global__ void kk_reflux(FV res_c, FV phi_c, FV beta_c, FV mask, FV phi_f, FV beta_f, RefluxArgs A, Range3 r) {
-  THREAD_IJK(r)
-  if (!in_range) return;
-  const int Q[3] = { i, j, k };
-  int M[3] = { i, j, k }; M[A.d] -= 1;
-  const int *out = A.s == 0 ? M : Q;                    // the cell outside the fine box
-  if (fv_get(mask, out[0], out[1], out[2]) != 0.0) return;   // covered by another fine box: not a coarse-fine interface
-  const int t1 = (A.d + 1) % 3, t2 = (A.d + 2) % 3;
-  double sum = 0.0;
-  #pragma unroll
-  for (int b = 0; b < 2; b++)
+struct RefluxB { Range3 r; int g[3]; FV res_c, phi_c, beta_c, mask, phi_f, beta_f; RefluxArgs A;
+  static __device__ double body(const RefluxB &a, int i, int j, int k, int) {
+    const RefluxArgs &A = a.A;
+    const int Q[3] = { i, j, k };
+    int M[3] = { i, j, k }; M[A.d] -= 1;
+    const int *out = A.s == 0 ? M : Q;                    // the cell outside the fine box
+    if (fv_get(a.mask, out[0], out[1], out[2]) != 0.0) return 0.0;   // covered by another fine box: not a coarse-fine interface
+    const int t1 = (A.d + 1) % 3, t2 = (A.d + 2) % 3;
+    double sum = 0.0;
     #pragma unroll
-    for (int a = 0; a < 2; a++) {
-      int q[3], m[3]; q[A.d] = 2 * Q[A.d]; q[t1] = 2 * Q[t1] + a; q[t2] = 2 * Q[t2] + b; m[0] = q[0]; m[1] = q[1]; m[2] = q[2]; m[A.d] -= 1;
-      sum = sum + fv_get(beta_f, q[0], q[1], q[2]) * (fv_get(phi_f, q[0], q[1], q[2]) - fv_get(phi_f, m[0], m[1], m[2])) / A.dxf;
-    }
-  const double Ff = sum * 0.25;
-  const double Fc = fv_get(beta_c, Q[0], Q[1], Q[2]) * (fv_get(phi_c, Q[0], Q[1], Q[2]) - fv_get(phi_c, M[0], M[1], M[2])) / A.dxc;
-  if (A.s == 0) fv_at(res_c, M[0], M[1], M[2]) = fv_get(res_c, M[0], M[1], M[2]) + (Ff - Fc) / A.dxc;
-  else          fv_at(res_c, Q[0], Q[1], Q[2]) = fv_get(res_c, Q[0], Q[1], Q[2]) - (Ff - Fc) / A.dxc;
-}
+    for (int b = 0; b < 2; b++)
+      #pragma unroll
+      for (int aa = 0; aa < 2; aa++) {
+        int q[3], m[3]; q[A.d] = 2 * Q[A.d]; q[t1] = 2 * Q[t1] + aa; q[t2] = 2 * Q[t2] + b; m[0] = q[0]; m[1] = q[1]; m[2] = q[2]; m[A.d] -= 1;
+        sum = sum + fv_get(a.beta_f, q[0], q[1], q[2]) * (fv_get(a.phi_f, q[0], q[1], q[2]) - fv_get(a.phi_f, m[0], m[1], m[2])) / A.dxf;
+      }
+    const double Ff = sum * 0.25;
+    const double Fc = fv_get(a.beta_c, Q[0], Q[1], Q[2]) * (fv_get(a.phi_c, Q[0], Q[1], Q[2]) - fv_get(a.phi_c, M[0], M[1], M[2])) / A.dxc;
+    if (A.s == 0) fv_at(a.res_c, M[0], M[1], M[2]) = fv_get(a.res_c, M[0], M[1], M[2]) + (Ff - Fc) / A.dxc;
+    else          fv_at(a.res_c, Q[0], Q[1], Q[2]) = fv_get(a.res_c, Q[0], Q[1], Q[2]) - (Ff - Fc) / A.dxc;
+    return 0.0;
+  } };
 struct GsArgs { int lo[3], hi[3]; int e[3][2]; double hi2[3]; };
-// red-black Gauss-Seidel on the fabs of the fine level: ghost cells of e are 0 at the coarse-fine interface and at Dirichlet
-// faces (b := 2b), Neumann faces carry b := 0 -- the folding of mg_cc.hip applied on the fly; colour by global index
-__global__ void kk_amr_gsrb(FV e, FV rh, FV bx, FV by, FV bz, GsArgs A, int color, Range3 r) {
-  const int j = r.lo[1] + (int)(blockIdx.y * blockDim.y + threadIdx.y), k = r.lo[2] + (int)blockIdx.z;
-  const int i = r.lo[0] + 2 * (int)(blockIdx.x * blockDim.x + threadIdx.x) + ((r.lo[0] + j + k + color) & 1);
-  if (i > r.hi[0] || j > r.hi[1] || k > r.hi[2]) return;
-  double bxm = fv_get(bx, i, j, k), bxp = fv_get(bx, i + 1, j, k), bym = fv_get(by, i, j, k), byp = fv_get(by, i, j + 1, k), bzm = fv_get(bz, i, j, k), bzp = fv_get(bz, i, j, k + 1);
-  #define FOLD(b, dd, ss) { const int t = A.e[dd][ss]; if (t == VDN_BC_NEU) b = 0.0; else if (t == VDN_BC_DIR) b = 2.0 * b; }
-  if (i == A.lo[0]) FOLD(bxm, 0, 0) if (i == A.hi[0]) FOLD(bxp, 0, 1)
-  if (j == A.lo[1]) FOLD(bym, 1, 0) if (j == A.hi[1]) FOLD(byp, 1, 1)
-  if (k == A.lo[2]) FOLD(bzm, 2, 0) if (k == A.hi[2]) FOLD(bzp, 2, 1)
-  #undef FOLD
-  const double p0 = fv_get(e, i, j, k);
-  const double ax = (bxp * (p0 - fv_get(e, i + 1, j, k)) + bxm * (p0 - fv_get(e, i - 1, j, k))) * A.hi2[0];
-  const double ay = (byp * (p0 - fv_get(e, i, j + 1, k)) + bym * (p0 - fv_get(e, i, j - 1, k))) * A.hi2[1];
-  const double az = (bzp * (p0 - fv_get(e, i, j, k + 1)) + bzm * (p0 - fv_get(e, i, j, k - 1))) * A.hi2[2];
-  const double Ap = ax + ay + az;
-  const double diag = (bxp + bxm) * A.hi2[0] + (byp + bym) * A.hi2[1] + (bzp + bzm) * A.hi2[2];
-  if (diag != 0.0) fv_at(e, i, j, k) = p0 + (fv_get(rh, i, j, k) - Ap) / diag;
-}
-__global__ void kk_add(FV a, FV b, Range3 r) { THREAD_IJK(r) if (!in_range) return; fv_at(a, i, j, k) = fv_get(a, i, j, k) + fv_get(b, i, j, k); }
+// red-black Gauss-Seidel on the fabs of a level: ghost cells of e are 0 at the coarse-fine interface and at Dirichlet faces
+// (b := 2b), Neumann faces carry b := 0 -- the folding of mg_cc.hip applied on the fly; colour by global index.
+// r: lo[0] .. lo[0] + ceil(nx/2) - 1 along x (half the cells of a row), the colour picks which half
+struct GsrbB { Range3 r; int g[3]; FV e, rh, bx, by, bz; GsArgs A;
+  static __device__ double body(const GsrbB &a, int ih, int j, int k, int color) {
+    const GsArgs &A = a.A; const FV &e = a.e;
+    const int i = A.lo[0] + 2 * (ih - A.lo[0]) + ((A.lo[0] + j + k + color) & 1);
+    if (i > A.hi[0]) return 0.0;
+    double bxm = fv_get(a.bx, i, j, k), bxp = fv_get(a.bx, i + 1, j, k), bym = fv_get(a.by, i, j, k), byp = fv_get(a.by, i, j + 1, k), bzm = fv_get(a.bz, i, j, k), bzp = fv_get(a.bz, i, j, k + 1);
+    #define FOLD(b, dd, ss) { const int t = A.e[dd][ss]; if (t == VDN_BC_NEU) b = 0.0; else if (t == VDN_BC_DIR) b = 2.0 * b; }
+    if (i == A.lo[0]) FOLD(bxm, 0, 0) if (i == A.hi[0]) FOLD(bxp, 0, 1)
+    if (j == A.lo[1]) FOLD(bym, 1, 0) if (j == A.hi[1]) FOLD(byp, 1, 1)
+    if (k == A.lo[2]) FOLD(bzm, 2, 0) if (k == A.hi[2]) FOLD(bzp, 2, 1)
+    #undef FOLD
+    const double p0 = fv_get(e, i, j, k);
+    const double ax = (bxp * (p0 - fv_get(e, i + 1, j, k)) + bxm * (p0 - fv_get(e, i - 1, j, k))) * A.hi2[0];
+    const double ay = (byp * (p0 - fv_get(e, i, j + 1, k)) + bym * (p0 - fv_get(e, i, j - 1, k))) * A.hi2[1];
+    const double az = (bzp * (p0 - fv_get(e, i, j, k + 1)) + bzm * (p0 - fv_get(e, i, j, k - 1))) * A.hi2[2];
+    const double Ap = ax + ay + az;
+    const double diag = (bxp + bxm) * A.hi2[0] + (byp + bym) * A.hi2[1] + (bzp + bzm) * A.hi2[2];
+    if (diag != 0.0) fv_at(e, i, j, k) = p0 + (fv_get(a.rh, i, j, k) - Ap) / diag;
+    return 0.0;
+  } };
+struct AddB { Range3 r; int g[3]; FV a, b;
+  static __device__ double body(const AddB &q, int i, int j, int k, int) { fv_at(q.a, i, j, k) = fv_get(q.a, i, j, k) + fv_get(q.b, i, j, k); return 0.0; } };
 // af += the parent's increment; keep: also store that increment in sc (the next finer level prolongs it in turn)
-__global__ void kk_add_prolong(FV af, FV sc, int keep, FV ec, Range3 r, int plo0, int plo1, int plo2, int phi0, int phi1, int phi2) {
-  THREAD_IJK(r)
-  if (!in_range) return;
-  const int I = i / 2, J = j / 2, K = k / 2;
-  if (I < plo0 || I > phi0 || J < plo1 || J > phi1 || K < plo2 || K > phi2) return;
-  const double v = fv_get(ec, I, J, K);
-  if (keep) fv_at(sc, i, j, k) = v;
-  fv_at(af, i, j, k) = fv_get(af, i, j, k) + v;
-}
-__global__ void kk_setbox(FV a, Range3 r, double v) { THREAD_IJK(r) if (!in_range) return; fv_at(a, i, j, k) = v; }
+struct AddProlongB { Range3 r; int g[3]; FV af, sc, ec; int keep, plo[3], phi[3];
+  static __device__ double body(const AddProlongB &q, int i, int j, int k, int) {
+    const int I = i / 2, J = j / 2, K = k / 2;
+    if (I < q.plo[0] || I > q.phi[0] || J < q.plo[1] || J > q.phi[1] || K < q.plo[2] || K > q.phi[2]) return 0.0;
+    const double v = fv_get(q.ec, I, J, K);
+    if (q.keep) fv_at(q.sc, i, j, k) = v;
+    fv_at(q.af, i, j, k) = fv_get(q.af, i, j, k) + v;
+    return 0.0;
+  } };
+struct SetboxB { Range3 r; int g[3]; FV a; double v;
+  static __device__ double body(const SetboxB &q, int i, int j, int k, int) { fv_at(q.a, i, j, k) = q.v; return 0.0; } };
 
 static Range3 valid_range(const vdn_multifab *mf, int b) { Range3 r; for (int d = 0; d < 3; d++) { r.lo[d] = mf->vbox[b].lo[d]; r.hi[d] = mf->vbox[b].hi[d]; } return r; }
 static double read_dev(double *d) { double h; HIPCHK(hipMemcpyAsync(&h, d, sizeof(double), hipMemcpyDeviceToHost, ctx().stream)); HIPCHK(hipStreamSynchronize(ctx().stream)); return h; }
 
+// descriptor sets are built once per solve: the fields of a solve do not move
 struct MLCC { int nlev; vdn_layout *la; vdn_multifab **rh, **phi, **beta; vdn_multifab *res[VDN_MAXLEV], *e[VDN_MAXLEV], *scr[VDN_MAXLEV], *mask[VDN_MAXLEV];
-              const double *dx; const vdn_bc_tower *bct; int bcc; double *d_nrm; };
-static void level_residual(MLCC &S, int n, bool norm) {
-  ResArgs A; for (int d = 0; d < 3; d++) A.hi2[d] = 1.0 / (S.dx[3 * n + d] * S.dx[3 * n + d]);
-  for (int b = 0; b < S.rh[n]->nfabs(); b++) {
-    Range3 r = valid_range(S.rh[n], b);
-    hipLaunchKernelGGL(kk_amr_residual, reduce_grid(r), AB, 0, ctx().stream, S.rh[n]->fabs[b], S.phi[n]->fabs[b], S.beta[3 * n]->fabs[b], S.beta[3 * n + 1]->fabs[b], S.beta[3 * n + 2]->fabs[b],
-                       S.res[n]->fabs[b], S.rh[n]->fabs[b], 0, A, r, norm ? S.d_nrm : (double *)nullptr);
+              const double *dx; const vdn_bc_tower *bct; int bcc; double *d_nrm;
+              BatchSet<ClosureB> closure[VDN_MAXLEV]; BatchSet<CfB> cf[VDN_MAXLEV]; BatchSet<ResidualB> resid[VDN_MAXLEV];
+              BatchSet<RefluxB> reflux[VDN_MAXLEV][6];          // [fine level][d*2+s]: one launch per side so that a coarse cell is updated once per launch
+              BatchSet<AbsmaxB> absmax[VDN_MAXLEV]; BatchSet<GsrbB> gsrb[VDN_MAXLEV]; BatchSet<AddB> add[VDN_MAXLEV];
+              BatchSet<AddProlongB> prolong[VDN_MAXLEV][VDN_MAXLEV];   // [source level n][target level m]: src = e[n] (m = n+1) or scr[m-1]
+              BatchSet<RestrictB> rphi[VDN_MAXLEV], rres[VDN_MAXLEV];  // [fine level]
+};
+static void restrict_descs(vdn_multifab *crse, const vdn_multifab *fine, std::vector<RestrictB> &v) {
+  for (int f = 0; f < fine->nfabs(); f++) for (int c = 0; c < crse->nfabs(); c++) {
+    int clo[3], chi[3]; RestrictB a;
+    for (int d = 0; d < 3; d++) { clo[d] = fine->vbox[f].lo[d] / 2; chi[d] = fine->vbox[f].hi[d] / 2; }
+    if (!isect(clo, chi, crse->vbox[c].lo, crse->vbox[c].hi, a.r)) continue;
+    a.crse = crse->fabs[c]; a.fine = fine->fabs[f]; a.icomp = 0; a.nc = 1;
+    v.push_back(a);
+  }
+}
+static void mlcc_build_sets(MLCC &S) {
+  hipStream_t st = ctx().stream;
+  const int L = S.nlev;
+  for (int n = 0; n < L; n++) {
+    { std::vector<ClosureB> v; closure_descs(S.phi[n], S.bct, S.bcc, v); S.closure[n].build(v, 0, st); }
+    if (n >= 1) { std::vector<CfB> v; cf_descs(S.phi[n], S.phi[n - 1], S.bct, S.bcc, v); S.cf[n].build(v, 0, st); }
+    if (n >= 1) { std::vector<RestrictB> v; restrict_descs(S.phi[n - 1], S.phi[n], v); S.rphi[n].build(v, 0, st); }
+    if (n >= 1) { std::vector<RestrictB> v; restrict_descs(S.res[n - 1], S.res[n], v); S.rres[n].build(v, 0, st); }
+    std::vector<ResidualB> vr; std::vector<AbsmaxB> va; std::vector<GsrbB> vg; std::vector<AddB> vadd;
+    for (int b = 0; b < S.rh[n]->nfabs(); b++) {
+      const Range3 r = valid_range(S.rh[n], b);
+      ResidualB q; q.r = r; q.rh = S.rh[n]->fabs[b]; q.phi = S.phi[n]->fabs[b]; q.bx = S.beta[3 * n]->fabs[b]; q.by = S.beta[3 * n + 1]->fabs[b]; q.bz = S.beta[3 * n + 2]->fabs[b];
+      q.res = S.res[n]->fabs[b]; for (int d = 0; d < 3; d++) q.A.hi2[d] = 1.0 / (S.dx[3 * n + d] * S.dx[3 * n + d]);
+      vr.push_back(q);
+      if (n < L - 1) { AbsmaxB m; m.r = r; m.a = S.res[n]->fabs[b]; m.mask = S.mask[n]->fabs[b]; m.has_mask = 1; va.push_back(m); }
+      if (n >= 1) {
+        GsrbB gq; gq.e = S.e[n]->fabs[b]; gq.rh = S.res[n]->fabs[b]; gq.bx = q.bx; gq.by = q.by; gq.bz = q.bz;
+        for (int d = 0; d < 3; d++) { gq.A.lo[d] = r.lo[d]; gq.A.hi[d] = r.hi[d]; gq.A.hi2[d] = q.A.hi2[d]; for (int sd = 0; sd < 2; sd++) gq.A.e[d][sd] = S.bct->ell_bc(n, b + 1, d, sd, S.bcc); }
+        gq.r = r; gq.r.hi[0] = r.lo[0] + (r.hi[0] - r.lo[0] + 2) / 2 - 1;
+        vg.push_back(gq);
+      }
+      AddB ad; ad.r = r; ad.a = S.phi[n]->fabs[b]; ad.b = S.e[n]->fabs[b]; vadd.push_back(ad);
+    }
+    S.resid[n].build(vr, 16, st); S.absmax[n].build(va, 16, st); S.gsrb[n].build(vg, 0, st); S.add[n].build(vadd, 0, st);
+    // flux matching on the cells of level n-1 next to the boxes of level n
+    if (n >= 1)
+      for (int d = 0; d < 3; d++) for (int s = 0; s < 2; s++) {
+        std::vector<RefluxB> v;
+        for (int f = 0; f < S.phi[n]->nfabs(); f++) {
+          if (S.bct->ell_bc(n, f + 1, d, s, S.bcc) != VDN_BC_INT) continue;
+          const vdn_box &fb = S.phi[n]->vbox[f];
+          int clo[3], chi[3];
+          for (int t = 0; t < 3; t++) { clo[t] = fb.lo[t] / 2; chi[t] = fb.hi[t] / 2; }
+          clo[d] = chi[d] = (s ? fb.hi[d] + 1 : fb.lo[d]) / 2;
+          for (int c = 0; c < S.phi[n - 1]->nfabs(); c++) {
+            int blo[3], bhi[3]; RefluxB q;
+            for (int t = 0; t < 3; t++) { blo[t] = S.phi[n - 1]->vbox[c].lo[t]; bhi[t] = S.phi[n - 1]->vbox[c].hi[t]; }
+            if (s == 0) { blo[d] += 1; bhi[d] += 1; }          // the coarse cell that gets the correction must be a valid cell of box c
+            if (!isect(clo, chi, blo, bhi, q.r)) continue;
+            q.A.d = d; q.A.s = s; q.A.dxf = S.dx[3 * n + d]; q.A.dxc = S.dx[3 * (n - 1) + d];
+            q.res_c = S.res[n - 1]->fabs[c]; q.phi_c = S.phi[n - 1]->fabs[c]; q.beta_c = S.beta[3 * (n - 1) + d]->fabs[c]; q.mask = S.mask[n - 1]->fabs[c];
+            q.phi_f = S.phi[n]->fabs[f]; q.beta_f = S.beta[3 * n + d]->fabs[f];
+            v.push_back(q);
+          }
+        }
+        S.reflux[n][2 * d + s].build(v, 0, st);
+      }
+    // prolongation of the correction of level n to the levels above it
+    for (int m = n + 1; m < L; m++) {
+      vdn_multifab *src = (m == n + 1) ? S.e[n] : S.scr[m - 1];
+      const bool keep = m < L - 1;
+      std::vector<AddProlongB> v;
+      for (int f = 0; f < S.phi[m]->nfabs(); f++) for (int c = 0; c < src->nfabs(); c++) {
+        AddProlongB q; q.r = valid_range(S.phi[m], f); q.af = S.phi[m]->fabs[f]; q.sc = keep ? S.scr[m]->fabs[f] : S.phi[m]->fabs[f]; q.keep = keep ? 1 : 0; q.ec = src->fabs[c];
+        for (int d = 0; d < 3; d++) { q.plo[d] = src->vbox[c].lo[d]; q.phi[d] = src->vbox[c].hi[d]; }
+        int plo[3], phi[3]; Range3 dummy;
+        for (int d = 0; d < 3; d++) { plo[d] = q.r.lo[d] / 2; phi[d] = q.r.hi[d] / 2; }
+        if (!isect(plo, phi, q.plo, q.phi, dummy)) continue;
+        v.push_back(q);
+      }
+      S.prolong[n][m].build(v, 0, st);
+    }
   }
 }
 static void fill_phi_ghosts(MLCC &S) {
-  for (int n = S.nlev - 1; n >= 1; n--) ml_cc_restriction(S.phi[n - 1], S.phi[n], 0, 1);
-  for (int n = 0; n < S.nlev; n++) phi_closure(S.phi[n], S.bct, S.bcc);
-  for (int n = 1; n < S.nlev; n++) cf_interp(S.phi[n], S.phi[n - 1], S.bct, S.bcc);
+  hipStream_t st = ctx().stream;
+  for (int n = S.nlev - 1; n >= 1; n--) S.rphi[n].run(0, (double *)nullptr, st);
+  for (int n = 0; n < S.nlev; n++) { S.closure[n].run(0, (double *)nullptr, st); mf_fill_boundary(S.phi[n]); }
+  for (int n = 1; n < S.nlev; n++) { S.cf[n].run(0, (double *)nullptr, st); mf_fill_boundary(S.phi[n]); }
 }
 static double composite_residual(MLCC &S) {
   hipStream_t st = ctx().stream;
   const int L = S.nlev;
   fill_phi_ghosts(S);
   HIPCHK(hipMemsetAsync(S.d_nrm, 0, sizeof(double), st));
-  for (int n = 0; n < L; n++) level_residual(S, n, n == L - 1);
-  // flux matching on the cells of level n-1 next to the boxes of level n: lo faces then hi faces of every direction (one update
-  // per cell and launch, hence deterministic)
-  for (int n = 1; n < L; n++)
-    for (int d = 0; d < 3; d++) for (int s = 0; s < 2; s++)
-      for (int f = 0; f < S.phi[n]->nfabs(); f++) {
-        if (S.bct->ell_bc(n, f + 1, d, s, S.bcc) != VDN_BC_INT) continue;
-        const vdn_box &fb = S.phi[n]->vbox[f];
-        int clo[3], chi[3];
-        for (int t = 0; t < 3; t++) { clo[t] = fb.lo[t] / 2; chi[t] = fb.hi[t] / 2; }
-        clo[d] = chi[d] = (s ? fb.hi[d] + 1 : fb.lo[d]) / 2;
-        for (int c = 0; c < S.phi[n - 1]->nfabs(); c++) {
-          int blo[3], bhi[3]; Range3 r;
-          for (int t = 0; t < 3; t++) { blo[t] = S.phi[n - 1]->vbox[c].lo[t]; bhi[t] = S.phi[n - 1]->vbox[c].hi[t]; }
-          // the coarse cell that gets the correction must be a valid cell of box c
-          if (s == 0) { blo[d] += 1; bhi[d] += 1; }
-          if (!isect(clo, chi, blo, bhi, r)) continue;
-          RefluxArgs A; A.d = d; A.s = s; A.dxf = S.dx[3 * n + d]; A.dxc = S.dx[3 * (n - 1) + d];
-          hipLaunchKernelGGL(kk_reflux, grid_for(r), AB, 0, st, S.res[n - 1]->fabs[c], S.phi[n - 1]->fabs[c], S.beta[3 * (n - 1) + d]->fabs[c], S.mask[n - 1]->fabs[c],
-                             S.phi[n]->fabs[f], S.beta[3 * n + d]->fabs[f], A, r);
-        }
-      }
-  for (int n = L - 1; n >= 1; n--) ml_cc_restriction(S.res[n - 1], S.res[n], 0, 1);
-  for (int n = 0; n < L - 1; n++)
-    for (int b = 0; b < S.res[n]->nfabs(); b++) {
-      Range3 r = valid_range(S.res[n], b);
-      hipLaunchKernelGGL(kk_absmax_masked, reduce_grid(r), AB, 0, st, S.res[n]->fabs[b], S.mask[n]->fabs[b], 1, r, S.d_nrm);
-    }
+  for (int n = 0; n < L; n++) S.resid[n].run(0, n == L - 1 ? S.d_nrm : (double *)nullptr, st);
+  // flux matching: lo faces then hi faces of every direction (one update per coarse cell and launch, hence deterministic)
+  for (int n = 1; n < L; n++) for (int ds = 0; ds < 6; ds++) S.reflux[n][ds].run(0, (double *)nullptr, st);
+  for (int n = L - 1; n >= 1; n--) S.rres[n].run(0, (double *)nullptr, st);
+  for (int n = 0; n < L - 1; n++) S.absmax[n].run(0, S.d_nrm, st);
   return read_dev(S.d_nrm);
 }
 // nsweeps red-black sweeps of A_n e = res_n from e = 0 (homogeneous coarse-fine interface)
 static void level_relax(MLCC &S, int n, int nsweeps) {
-  hipStream_t st = ctx().stream;
   vdn_multifab *e = S.e[n];
   mf_setval(e, 0.0, 0, 1, true);
   const bool exchange = e->nfabs() > 1 || S.la->pmask[0] || S.la->pmask[1] || S.la->pmask[2];
   for (int s = 0; s < nsweeps; s++) for (int col = 0; col < 2; col++) {
     if (exchange) mf_fill_boundary(e);
-    for (int b = 0; b < e->nfabs(); b++) {
-      GsArgs A; Range3 r = valid_range(e, b);
-      for (int d = 0; d < 3; d++) { A.lo[d] = r.lo[d]; A.hi[d] = r.hi[d]; A.hi2[d] = 1.0 / (S.dx[3 * n + d] * S.dx[3 * n + d]); for (int sd = 0; sd < 2; sd++) A.e[d][sd] = S.bct->ell_bc(n, b + 1, d, sd, S.bcc); }
-      const int nx = r.hi[0] - r.lo[0] + 1;
-      dim3 g(((nx + 1) / 2 + 63) / 64, (r.hi[1] - r.lo[1] + 4) / 4, r.hi[2] - r.lo[2] + 1);
-      hipLaunchKernelGGL(kk_amr_gsrb, g, AB, 0, st, e->fabs[b], S.res[n]->fabs[b], S.beta[3 * n]->fabs[b], S.beta[3 * n + 1]->fabs[b], S.beta[3 * n + 2]->fabs[b], A, col, r);
-    }
+    S.gsrb[n].run(col, (double *)nullptr, ctx().stream);
   }
 }
 // phi_n += e_n, and the piecewise-constant prolongation of that correction on every finer level
 static void apply_correction(MLCC &S, int n) {
-  hipStream_t st = ctx().stream;
-  for (int b = 0; b < S.phi[n]->nfabs(); b++) { Range3 r = valid_range(S.phi[n], b); hipLaunchKernelGGL(kk_add, grid_for(r), AB, 0, st, S.phi[n]->fabs[b], S.e[n]->fabs[b], r); }
-  vdn_multifab *src = S.e[n];
-  for (int m = n + 1; m < S.nlev; m++) {
-    const bool keep = m < S.nlev - 1;                        // a finer level still needs this level's increment
-    for (int f = 0; f < S.phi[m]->nfabs(); f++) for (int c = 0; c < src->nfabs(); c++) {
-      Range3 r = valid_range(S.phi[m], f); const vdn_box &cb = src->vbox[c];
-      hipLaunchKernelGGL(kk_add_prolong, grid_for(r), AB, 0, st, S.phi[m]->fabs[f], keep ? S.scr[m]->fabs[f] : S.phi[m]->fabs[f], keep ? 1 : 0, src->fabs[c], r,
-                         cb.lo[0], cb.lo[1], cb.lo[2], cb.hi[0], cb.hi[1], cb.hi[2]);
-    }
-    src = S.scr[m];
-  }
+  S.add[n].run(0, (double *)nullptr, ctx().stream);
+  for (int m = n + 1; m < S.nlev; m++) S.prolong[n][m].run(0, (double *)nullptr, ctx().stream);
 }
 // rh, phi: [lev];  beta: [lev*3 + d];  dx: [lev*3 + d]
 int ml_cc_solve(vdn_layout *la, vdn_multifab **rh, vdn_multifab **phi, vdn_multifab **beta, const double *dx, const vdn_bc_tower *bct, int bc_comp0,
@@ -426,17 +482,22 @@ int ml_cc_solve(vdn_layout *la, vdn_multifab **rh, vdn_multifab **phi, vdn_multi
     S.mask[n] = nullptr;
     if (n < L - 1) {                                         // cells of level n covered by level n+1
       S.mask[n] = mf_temp(la, n, 1, 0, -1, true, 0.0);
+      std::vector<SetboxB> v;
       for (int f = 0; f < phi[n + 1]->nfabs(); f++) for (int c = 0; c < S.mask[n]->nfabs(); c++) {
-        int clo[3], chi[3]; Range3 r;
+        int clo[3], chi[3]; SetboxB q;
         for (int d = 0; d < 3; d++) { clo[d] = phi[n + 1]->vbox[f].lo[d] / 2; chi[d] = phi[n + 1]->vbox[f].hi[d] / 2; }
-        if (isect(clo, chi, S.mask[n]->vbox[c].lo, S.mask[n]->vbox[c].hi, r)) hipLaunchKernelGGL(kk_setbox, grid_for(r), AB, 0, st, S.mask[n]->fabs[c], r, 1.0);
+        if (!isect(clo, chi, S.mask[n]->vbox[c].lo, S.mask[n]->vbox[c].hi, q.r)) continue;
+        q.a = S.mask[n]->fabs[c]; q.v = 1.0; v.push_back(q);
       }
+      launch_batched(v, 0, (double *)nullptr, 0, st);
     }
   }
+  mlcc_build_sets(S);
   HIPCHK(hipMemsetAsync(S.d_nrm, 0, sizeof(double), st));
-  for (int n = 0; n < L; n++) for (int b = 0; b < rh[n]->nfabs(); b++) {
-    Range3 r = valid_range(rh[n], b);
-    hipLaunchKernelGGL(kk_absmax_masked, reduce_grid(r), AB, 0, st, rh[n]->fabs[b], n < L - 1 ? S.mask[n]->fabs[b] : rh[n]->fabs[b], n < L - 1 ? 1 : 0, r, S.d_nrm);
+  for (int n = 0; n < L; n++) {
+    std::vector<AbsmaxB> v;
+    for (int b = 0; b < rh[n]->nfabs(); b++) { AbsmaxB q; q.r = valid_range(rh[n], b); q.a = rh[n]->fabs[b]; q.mask = n < L - 1 ? S.mask[n]->fabs[b] : rh[n]->fabs[b]; q.has_mask = n < L - 1 ? 1 : 0; v.push_back(q); }
+    launch_batched(v, 0, S.d_nrm, 16, st);
   }
   const double bnorm = read_dev(S.d_nrm);
   const vdn_params &P = ctx().prm;
@@ -461,7 +522,7 @@ int ml_cc_solve(vdn_layout *la, vdn_multifab **rh, vdn_multifab **phi, vdn_multi
     // post-relaxation on the new residual, coarsest level first
     for (int n = 1; n < L; n++) {
       if (n < L - 1) (void)composite_residual(S);
-      else { fill_phi_ghosts(S); level_residual(S, n, false); }
+      else { fill_phi_ghosts(S); S.resid[n].run(0, (double *)nullptr, st); }
       level_relax(S, n, P.mg_nu2);
       apply_correction(S, n);
     }

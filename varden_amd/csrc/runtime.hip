@@ -291,6 +291,39 @@ vdn_multifab *mf_temp(const vdn_layout *la, int lev, int nc, int ng, int face_di
 }
 void mf_temp_free(vdn_multifab *mf) { delete mf; }
 
+
+// device scratch for the descriptor arrays of one-off batched launches: a ring; reuse is safe because uploads and launches are
+// ordered on the one launch stream
+void *desc_scratch(size_t bytes) {
+  static char *ring = nullptr; static size_t cap = 0, head = 0;
+  const size_t need = (bytes + 255) & ~(size_t)255;
+  if (!ring || need > cap) {
+    if (ring) { HIPCHK(hipStreamSynchronize(ctx().stream)); HIPCHK(hipFree(ring)); }
+    cap = std::max<size_t>((size_t)64 << 20, 2 * need); head = 0;
+    HIPCHK(hipMalloc((void **)&ring, cap));
+  }
+  if (head + need > cap) head = 0;
+  void *p = ring + head; head += need;
+  return p;
+}
+// small host -> device uploads (descriptor arrays of the batched launches) through a pinned ring: the copy is asynchronous on
+// the launch stream, the caller's buffer may be freed at once; the ring is drained (stream sync) when it wraps
+void upload_staged(void *dst, const void *src, size_t bytes) {
+  static char *ring = nullptr; static size_t cap = 0, head = 0;
+  VdnCtx &c = ctx();
+  if (bytes == 0) return;
+  if (!ring || bytes > cap) {
+    if (ring) { HIPCHK(hipStreamSynchronize(c.stream)); HIPCHK(hipHostFree(ring)); }
+    cap = std::max<size_t>((size_t)32 << 20, 2 * bytes); head = 0;
+    HIPCHK(hipHostMalloc((void **)&ring, cap, hipHostMallocDefault));
+  }
+  const size_t need = (bytes + 255) & ~(size_t)255;
+  if (head + need > cap) { HIPCHK(hipStreamSynchronize(c.stream)); head = 0; }
+  memcpy(ring + head, src, bytes);
+  HIPCHK(hipMemcpyAsync(dst, ring + head, bytes, hipMemcpyHostToDevice, c.stream));
+  head += need;
+}
+
 extern "C" int vdn_multifab_destroy(vdn_multifab *mf) {
   VDN_TRY
   if (mf) { if (mf->owns && mf->base) { HIPCHK(hipStreamSynchronize(g_ctx.stream)); HIPCHK(hipFree(mf->base)); } delete mf; }
