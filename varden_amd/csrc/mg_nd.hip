@@ -389,9 +389,7 @@ __global__ void kk_nd_load_sigma(NLev L, FV coeffs, int lo0, int lo1, int lo2) {
   L.sig[nidx(L, i, j, k)] = fv_get(coeffs, lo0 + i, lo1 + j, lo2 + k);
 }
 // rh(node) += D u  (definition in oracle/vo_hgproject.c::vo_nd_divu)
-__global__ void kk_nd_divu(FV u, FV rh, double fx, double fy, double fz, Range3 r) {
-  THREAD_IJK(r)
-  if (!in_range) return;
+DEVI void nd_divu_node(const FV &u, const FV &rh, double fx, double fy, double fz, int i, int j, int k) {
   #define U(a, b, c, m) fv_get(u, i + (a), j + (b), k + (c), m)
   const double dux = (((U(0, 0, 0, 0) + U(0, -1, 0, 0)) + U(0, 0, -1, 0)) + U(0, -1, -1, 0))
                    - (((U(-1, 0, 0, 0) + U(-1, -1, 0, 0)) + U(-1, 0, -1, 0)) + U(-1, -1, -1, 0));
@@ -401,6 +399,11 @@ __global__ void kk_nd_divu(FV u, FV rh, double fx, double fy, double fz, Range3 
                    - (((U(0, 0, -1, 2) + U(-1, 0, -1, 2)) + U(0, -1, -1, 2)) + U(-1, -1, -1, 2));
   #undef U
   fv_at(rh, i, j, k) = fv_get(rh, i, j, k) + (dux * fx + duy * fy + duz * fz);
+}
+__global__ void kk_nd_divu(FV u, FV rh, double fx, double fy, double fz, Range3 r) {
+  THREAD_IJK(r)
+  if (!in_range) return;
+  nd_divu_node(u, rh, fx, fy, fz, i, j, k);
 }
 __global__ void kk_nd_load(NLev L, FV rh, FV phi, int lo0, int lo1, int lo2, double *nrm) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1093,12 +1096,22 @@ __global__ void kk_ndf_add(FV a, FV b, Range3 r) { THREAD_IJK(r) if (!in_range) 
 // shuffles, three phi planes and two sigma planes in registers).  r: the node range of the box; tiles of 62 nodes along i.
 // MODE 0: eout = ein + omega (rb - K ein)/diag on free nodes;  MODE 1: res = b - K phi (0 on physical Dirichlet nodes), max-norm
 // over the nodes that are not interface nodes (excl = 1) / all nodes (excl = 0)
+struct MarchB { FV phi, out, rb, sig, slave; int has_slave; NdfArgs A; Range3 r; int g[3], kchunk; };
 template <int MODE>
-__global__ void __launch_bounds__(256) kk_ndf_march(FV phi, FV out, FV rb, FV sig, FV slave, int has_slave, NdfArgs A, double omega, int excl, int kchunk, Range3 r, double *nrm) {
+__global__ void __launch_bounds__(256) kk_ndf_march(const MarchB *args, const int *start, int nbox, double omega, int excl, double *nrm) {
+  int lo_ = 0, hi_ = nbox - 1;
+  const int bid = (int)blockIdx.x;
+  while (lo_ < hi_) { const int mid = (lo_ + hi_ + 1) >> 1; if (start[mid] <= bid) lo_ = mid; else hi_ = mid - 1; }
+  const MarchB B = args[lo_];                                // by value: a reference into global memory would be re-read after every store
+  const FV phi = B.phi, out = B.out, rb = B.rb, sig = B.sig, slave = B.slave;
+  const int has_slave = B.has_slave, kchunk = B.kchunk;
+  const NdfArgs A = B.A; const Range3 r = B.r;
+  const int lb = bid - start[lo_];
+  const int bx = lb % B.g[0], by = (lb / B.g[0]) % B.g[1], bz = lb / (B.g[0] * B.g[1]);
   const int lane = threadIdx.x;
-  const int i = r.lo[0] + (int)blockIdx.x * 62 + lane - 1;
-  const int j = r.lo[1] + (int)(blockIdx.y * blockDim.y + threadIdx.y);
-  const int k0 = r.lo[2] + (int)blockIdx.z * kchunk, k1 = min(k0 + kchunk - 1, r.hi[2]);
+  const int i = r.lo[0] + bx * 62 + lane - 1;
+  const int j = r.lo[1] + by * (int)blockDim.y + (int)threadIdx.y;
+  const int k0 = r.lo[2] + bz * kchunk, k1 = min(k0 + kchunk - 1, r.hi[2]);
   const bool active = lane >= 1 && lane <= 62 && i <= r.hi[0] && j <= r.hi[1];
   const int ic = min(i, r.hi[0] + 1), jc = min(j, r.hi[1]);
   double rmax = 0.0;
@@ -1154,7 +1167,8 @@ __global__ void __launch_bounds__(256) kk_ndf_march(FV phi, FV out, FV rb, FV si
       const double Kp = acc, diag = w[0] * ssum;
       const double p0 = p[1][1][1];
       const bool pdir = ndf_pdir(A, i, j, k);
-      const bool cf = (has_slave && (MODE == 0 || excl == 1)) ? (fv_get(slave, ic, jc, k) != 0.0) : false;      // slaved to the coarser level
+      // slaved to the coarser level: has_slave = 1 node mask (any union of boxes), 2 = the level is ONE box: its non-physical faces (no mask traffic)
+      const bool cf = (has_slave == 2) ? (ndf_cf(A, i, j, k) && !pdir) : ((has_slave == 1 && (MODE == 0 || excl == 1)) ? (fv_get(slave, ic, jc, k) != 0.0) : false);
       if (MODE == 0) {
         double v = p0;
         if (!pdir && !cf && diag != 0.0) v = p0 + omega * ((rhs - Kp) / diag);
@@ -1175,12 +1189,31 @@ __global__ void __launch_bounds__(256) kk_ndf_march(FV phi, FV out, FV rb, FV si
   }
   if (MODE == 1 && nrm) block_atomic_max(nrm, rmax);
 }
-template <int MODE> static void ndf_launch_march(const FV &phi, const FV &out, const FV &rb, const FV &sig, const FV *slave, const NdfArgs &A, double omega, int excl, const Range3 &r, double *nrm) {
-  const int nx = r.hi[0] - r.lo[0] + 1, ny = r.hi[1] - r.lo[1] + 1, nz = r.hi[2] - r.lo[2] + 1;
-  const int tiles = ((nx + 61) / 62) * ((ny + 3) / 4);
-  int kchunk = nz;
-  while (kchunk > 8 && tiles * ((nz + kchunk - 1) / kchunk) < 2048) kchunk = (kchunk + 1) / 2;
-  hipLaunchKernelGGL(kk_ndf_march<MODE>, dim3((nx + 61) / 62, (ny + 3) / 4, (nz + kchunk - 1) / kchunk), NBLK, 0, ctx().stream, phi, out, rb, sig, slave ? *slave : phi, slave ? 1 : 0, A, omega, excl, kchunk, r, nrm);
+// one launch for all boxes of a level
+struct MarchSet { MarchB *d_args = nullptr; int *d_start = nullptr; int nbox = 0, tot = 0; };
+static MarchSet ndf_build_march(std::vector<MarchB> &v) {
+  MarchSet S; S.nbox = (int)v.size();
+  if (v.empty()) return S;
+  std::vector<int> start(v.size());
+  for (size_t b = 0; b < v.size(); b++) {
+    MarchB &B = v[b];
+    const int nx = B.r.hi[0] - B.r.lo[0] + 1, ny = B.r.hi[1] - B.r.lo[1] + 1, nz = B.r.hi[2] - B.r.lo[2] + 1;
+    const int tiles = ((nx + 61) / 62) * ((ny + 3) / 4);
+    int kchunk = nz;
+    while (kchunk > 8 && tiles * ((nz + kchunk - 1) / kchunk) < 2048) kchunk = (kchunk + 1) / 2;
+    if (v.size() > 16 && nz <= 64) kchunk = nz;              // many small boxes fill the chip by themselves: no redundant warm-up planes
+    B.kchunk = kchunk; B.g[0] = (nx + 61) / 62; B.g[1] = (ny + 3) / 4; B.g[2] = (nz + kchunk - 1) / kchunk;
+    start[b] = S.tot; S.tot += B.g[0] * B.g[1] * B.g[2];
+  }
+  S.d_args = (MarchB *)arena_alloc(sizeof(MarchB) * v.size());
+  S.d_start = (int *)arena_alloc(sizeof(int) * v.size());
+  upload_staged(S.d_args, v.data(), sizeof(MarchB) * v.size());
+  upload_staged(S.d_start, start.data(), sizeof(int) * v.size());
+  return S;
+}
+template <int MODE> static void ndf_run_march(const MarchSet &S, double omega, int excl, double *nrm) {
+  if (S.nbox == 0) return;
+  hipLaunchKernelGGL(kk_ndf_march<MODE>, dim3(S.tot), NBLK, 0, ctx().stream, (const MarchB *)S.d_args, (const int *)S.d_start, S.nbox, omega, excl, nrm);
 }
 __global__ void kk_ndf_absmax_mask(FV a, FV mask, Range3 r, double *nrm) {
   REDUCE_IJ(r)
@@ -1215,76 +1248,87 @@ __global__ void kk_ndf_restrict_add2(FV res_c, FV res_f, NdfArgs Af, NdfArgs Ac,
 
 static double ndf_read(double *d) { double h; HIPCHK(hipMemcpyAsync(&h, d, sizeof(double), hipMemcpyDeviceToHost, ctx().stream)); HIPCHK(hipStreamSynchronize(ctx().stream)); return h; }
 // ---- composite nodal solve on arbitrary unions of boxes: node masks instead of per-face flags ----------------------------------
+// (batched kernels: one launch per operation and level, vdn_dev.h)
 // cell mask -> node mask.  mode 0 ("slave"): 1 on the nodes that are not physical Dirichlet nodes and touch a cell INSIDE the
 // domain whose mask is 0 (a cell the level does not cover): the nodes of the coarse-fine interface.  mode 1 ("inside"): 1 on the
 // nodes whose eight cells are all inside the domain and masked (strictly inside the region the next finer level covers)
 struct MarkArgs { int dlo[3], dhi[3]; };
-__global__ void kk_ndm_mark(FV out, FV cmask, NdfArgs A, MarkArgs D, int mode, Range3 r) {
-  THREAD_IJK(r)
-  if (!in_range) return;
-  bool any_open = false, all_in = true;
-  #pragma unroll
-  for (int c = -1; c <= 0; c++)
+struct NdmMarkB { Range3 r; int g[3]; FV out, cmask; NdfArgs A; MarkArgs D; int mode;
+  static __device__ double body(const NdmMarkB &q, int i, int j, int k, int) {
+    bool any_open = false, all_in = true;
     #pragma unroll
-    for (int b = -1; b <= 0; b++)
+    for (int c = -1; c <= 0; c++)
       #pragma unroll
-      for (int a = -1; a <= 0; a++) {
-        const int ci = i + a, cj = j + b, ck = k + c;
-        const bool in_dom = ci >= D.dlo[0] && ci <= D.dhi[0] && cj >= D.dlo[1] && cj <= D.dhi[1] && ck >= D.dlo[2] && ck <= D.dhi[2];
-        const bool m = in_dom && fv_get(cmask, ci, cj, ck) != 0.0;
-        if (in_dom && !m) any_open = true;
-        if (!m) all_in = false;
-      }
-  if (mode == 0) { if (any_open && !ndf_pdir(A, i, j, k)) fv_at(out, i, j, k) = 1.0; }
-  else if (all_in) fv_at(out, i, j, k) = 1.0;
-}
-__global__ void kk_ndm_mul(FV out, FV a, FV keep0, Range3 r) {          // out = a where keep0 == 0, else 0   (cells)
-  THREAD_IJK(r)
-  if (!in_range) return;
-  fv_at(out, i, j, k) = (fv_get(keep0, i, j, k) != 0.0) ? 0.0 : fv_get(a, i, j, k);
-}
-__global__ void kk_ndm_mask_u(FV out, FV u, FV inlev, int has_inlev, FV cov, int has_cov, Range3 r) {   // masked velocity, 3 components
-  THREAD_IJK(r)
-  if (!in_range) return;
-  const bool keep = (!has_inlev || fv_get(inlev, i, j, k) != 0.0) && !(has_cov && fv_get(cov, i, j, k) != 0.0);
-  #pragma unroll
-  for (int c = 0; c < 3; c++) fv_at(out, i, j, k, c) = keep ? fv_get(u, i, j, k, c) : 0.0;
-}
+      for (int b = -1; b <= 0; b++)
+        #pragma unroll
+        for (int a = -1; a <= 0; a++) {
+          const int ci = i + a, cj = j + b, ck = k + c;
+          const bool in_dom = ci >= q.D.dlo[0] && ci <= q.D.dhi[0] && cj >= q.D.dlo[1] && cj <= q.D.dhi[1] && ck >= q.D.dlo[2] && ck <= q.D.dhi[2];
+          const bool m = in_dom && fv_get(q.cmask, ci, cj, ck) != 0.0;
+          if (in_dom && !m) any_open = true;
+          if (!m) all_in = false;
+        }
+    if (q.mode == 0) { if (any_open && !ndf_pdir(q.A, i, j, k)) fv_at(q.out, i, j, k) = 1.0; }
+    else if (all_in) fv_at(q.out, i, j, k) = 1.0;
+    return 0.0;
+  } };
+struct NdmMulB { Range3 r; int g[3]; FV out, a, keep0;               // out = a where keep0 == 0, else 0   (cells)
+  static __device__ double body(const NdmMulB &q, int i, int j, int k, int) { fv_at(q.out, i, j, k) = (fv_get(q.keep0, i, j, k) != 0.0) ? 0.0 : fv_get(q.a, i, j, k); return 0.0; } };
+struct NdmMaskUB { Range3 r; int g[3]; FV out, u, inlev, cov; int has_inlev, has_cov;      // masked velocity, 3 components
+  static __device__ double body(const NdmMaskUB &q, int i, int j, int k, int) {
+    const bool keep = (!q.has_inlev || fv_get(q.inlev, i, j, k) != 0.0) && !(q.has_cov && fv_get(q.cov, i, j, k) != 0.0);
+    #pragma unroll
+    for (int c = 0; c < 3; c++) fv_at(q.out, i, j, k, c) = keep ? fv_get(q.u, i, j, k, c) : 0.0;
+    return 0.0;
+  } };
+struct NdDivuB { Range3 r; int g[3]; FV u, rh; double f0, f1, f2;    // rh += D u (kk_nd_divu)
+  static __device__ double body(const NdDivuB &q, int i, int j, int k, int) { nd_divu_node(q.u, q.rh, q.f0, q.f1, q.f2, i, j, k); return 0.0; } };
+struct NdfNegB { Range3 r; int g[3]; FV out, in; NdfArgs A;          // b = -rh, zero on physical Dirichlet nodes
+  static __device__ double body(const NdfNegB &q, int i, int j, int k, int) { fv_at(q.out, i, j, k) = ndf_pdir(q.A, i, j, k) ? 0.0 : -fv_get(q.in, i, j, k); return 0.0; } };
+struct NdfAddB { Range3 r; int g[3]; FV a, b;
+  static __device__ double body(const NdfAddB &q, int i, int j, int k, int) { fv_at(q.a, i, j, k) = fv_get(q.a, i, j, k) + fv_get(q.b, i, j, k); return 0.0; } };
+struct NdfSetB { Range3 r; int g[3]; FV a; double v;
+  static __device__ double body(const NdfSetB &q, int i, int j, int k, int) { fv_at(q.a, i, j, k) = q.v; return 0.0; } };
+struct NdfAbsmaxB { Range3 r; int g[3]; FV a, mask;
+  static __device__ double body(const NdfAbsmaxB &q, int i, int j, int k, int) { return fv_get(q.mask, i, j, k) == 0.0 ? fabs(fv_get(q.a, i, j, k)) : 0.0; } };
 // mode 0: phi_f = P phi_c on the slave nodes;  mode 1: phi_f += P e_c on every node that is not a physical Dirichlet node;
 // mode 2: phi_f = P e_c there (0 + P e_c).  Only nodes whose coarse parent (i>>1, j>>1, k>>1) is a valid node of this coarse box
-__global__ void kk_ndm_prolong(FV pf, FV pc, FV slave, FV own_c, int has_own, NdfArgs Af, int mode, int clo0, int clo1, int clo2, int chi0, int chi1, int chi2, Range3 r) {
-  THREAD_IJK(r)
-  if (!in_range) return;
-  if (ndf_pdir(Af, i, j, k)) return;
-  if (mode == 0 && fv_get(slave, i, j, k) == 0.0) return;
-  const int I = i >> 1, J = j >> 1, K = k >> 1, oi = i & 1, oj = j & 1, ok = k & 1;
-  if (I < clo0 || I > chi0 || J < clo1 || J > chi1 || K < clo2 || K > chi2) return;
-  if (has_own && fv_get(own_c, I, J, K) == 0.0) return;          // a coarse node shared by several boxes: its owner does the work, once
-  double s = 0.0;
-  for (int c = 0; c <= ok; c++) for (int b = 0; b <= oj; b++) for (int a = 0; a <= oi; a++) s = s + fv_get(pc, I + a, J + b, K + c);
-  const double v = s * (1.0 / (double)((1 + oi) * (1 + oj) * (1 + ok)));
-  fv_at(pf, i, j, k) = (mode == 1) ? fv_get(pf, i, j, k) + v : v;
-}
+struct NdmProlongB { Range3 r; int g[3]; FV pf, pc, slave, own_c; int has_own; NdfArgs Af; int clo[3], chi[3];
+  static __device__ double body(const NdmProlongB &q, int i, int j, int k, int mode) {
+    if (ndf_pdir(q.Af, i, j, k)) return 0.0;
+    if (mode == 0 && fv_get(q.slave, i, j, k) == 0.0) return 0.0;
+    const int I = i >> 1, J = j >> 1, K = k >> 1, oi = i & 1, oj = j & 1, ok = k & 1;
+    if (I < q.clo[0] || I > q.chi[0] || J < q.clo[1] || J > q.chi[1] || K < q.clo[2] || K > q.chi[2]) return 0.0;
+    if (q.has_own && fv_get(q.own_c, I, J, K) == 0.0) return 0.0;          // a coarse node shared by several boxes: its owner does the work, once
+    double s = 0.0;
+    for (int c = 0; c <= ok; c++) for (int b = 0; b <= oj; b++) for (int a = 0; a <= oi; a++) s = s + fv_get(q.pc, I + a, J + b, K + c);
+    const double v = s * (1.0 / (double)((1 + oi) * (1 + oj) * (1 + ok)));
+    fv_at(q.pf, i, j, k) = (mode == 1) ? fv_get(q.pf, i, j, k) + v : v;
+    return 0.0;
+  } };
 // res_c += full weighting of the fine residual around the fine node (2i,2j,2k), taken from the fine box that OWNS that node (its
 // ghost nodes hold the neighbouring boxes' values, zero outside the level)
-__global__ void kk_ndm_restrict_add(FV res_c, FV res_f, FV own_f, NdfArgs Af, NdfArgs Ac, Range3 r) {
-  THREAD_IJK(r)
-  if (!in_range || ndf_pdir(Ac, i, j, k)) return;
-  if (fv_get(own_f, 2 * i, 2 * j, 2 * k) == 0.0) return;
-  const double wt[3] = { 0.5, 1.0, 0.5 };
-  double s = 0.0;
-  for (int c = -1; c <= 1; c++) for (int b = -1; b <= 1; b++) for (int a = -1; a <= 1; a++) {
-    const int ii = 2 * i + a, jj = 2 * j + b, kk = 2 * k + c;
-    if (ii < Af.lo[0] - 1 || ii > Af.hi[0] + 1 || jj < Af.lo[1] - 1 || jj > Af.hi[1] + 1 || kk < Af.lo[2] - 1 || kk > Af.hi[2] + 1) continue;
-    s = s + (wt[a + 1] * wt[b + 1] * wt[c + 1]) * fv_get(res_f, ii, jj, kk);
-  }
-  fv_at(res_c, i, j, k) = fv_get(res_c, i, j, k) + s * 0.125;
-}
+struct NdmRestrictB { Range3 r; int g[3]; FV res_c, res_f, own_f; NdfArgs Af, Ac;
+  static __device__ double body(const NdmRestrictB &q, int i, int j, int k, int) {
+    if (ndf_pdir(q.Ac, i, j, k)) return 0.0;
+    if (fv_get(q.own_f, 2 * i, 2 * j, 2 * k) == 0.0) return 0.0;
+    const double wt[3] = { 0.5, 1.0, 0.5 };
+    const NdfArgs &Af = q.Af;
+    double s = 0.0;
+    for (int c = -1; c <= 1; c++) for (int b = -1; b <= 1; b++) for (int a = -1; a <= 1; a++) {
+      const int ii = 2 * i + a, jj = 2 * j + b, kk = 2 * k + c;
+      if (ii < Af.lo[0] - 1 || ii > Af.hi[0] + 1 || jj < Af.lo[1] - 1 || jj > Af.hi[1] + 1 || kk < Af.lo[2] - 1 || kk > Af.hi[2] + 1) continue;
+      s = s + (wt[a + 1] * wt[b + 1] * wt[c + 1]) * fv_get(q.res_f, ii, jj, kk);
+    }
+    fv_at(q.res_c, i, j, k) = fv_get(q.res_c, i, j, k) + s * 0.125;
+    return 0.0;
+  } };
 static bool nd_isect(const Range3 &a, const Range3 &b, Range3 &r) {
   for (int d = 0; d < 3; d++) { r.lo[d] = std::max(a.lo[d], b.lo[d]); r.hi[d] = std::min(a.hi[d], b.hi[d]); if (r.lo[d] > r.hi[d]) return false; }
   return true;
 }
-// every level may be any union of boxes (properly nested in the next coarser one)
+// every level may be any union of boxes (properly nested in the next coarser one).  The per-iteration kernels run from descriptor
+// sets built once per solve.
 struct MLND {
   int nlev;
   vdn_multifab *phi[VDN_MAXLEV], *b[VDN_MAXLEV], *res[VDN_MAXLEV];
@@ -1296,60 +1340,60 @@ struct MLND {
   vdn_multifab *ea[VDN_MAXLEV], *eb[VDN_MAXLEV], *scr[VDN_MAXLEV];   // Jacobi ping-pong of the correction; prolonged increment
   std::vector<NdfArgs> A[VDN_MAXLEV]; std::vector<Range3> r[VDN_MAXLEV];      // per box: operator weights, node range, physical Dirichlet faces
   bool multi[VDN_MAXLEV]; double *d_nrm;
+  MarchSet m_res[VDN_MAXLEV], m_res0[VDN_MAXLEV];    // residual of phi / of the zero field (norm of the right-hand side)
+  MarchSet m_jac[VDN_MAXLEV][2];                     // Jacobi ea -> eb, eb -> ea
+  BatchSet<NdmRestrictB> rst[VDN_MAXLEV];            // [fine level]
+  BatchSet<NdfAbsmaxB> amax[VDN_MAXLEV];
 };
 // mode 0: slaves of level n <- P phi_{n-1};  mode 1: dst_n += P src_{n-1};  mode 2: dst_n = P src_{n-1} (dst zeroed first by the caller)
 static void ml_nd_prolong(MLND &S, int n, vdn_multifab *dst, vdn_multifab *src, int mode) {
+  std::vector<NdmProlongB> v;
   for (size_t f = 0; f < S.A[n].size(); f++)
     for (size_t c = 0; c < S.A[n - 1].size(); c++) {
       const Range3 &rc = S.r[n - 1][c];
-      Range3 fr; for (int d = 0; d < 3; d++) { fr.lo[d] = std::max(S.r[n][f].lo[d], 2 * rc.lo[d]); fr.hi[d] = std::min(S.r[n][f].hi[d], 2 * rc.hi[d] + 1); }
-      if (fr.lo[0] > fr.hi[0] || fr.lo[1] > fr.hi[1] || fr.lo[2] > fr.hi[2]) continue;
-      hipLaunchKernelGGL(kk_ndm_prolong, grid_for(fr), NBLK, 0, ctx().stream, dst->fabs[f], src->fabs[c], S.slave[n]->fabs[f],
-                         S.own[n - 1] ? S.own[n - 1]->fabs[c] : src->fabs[c], S.own[n - 1] ? 1 : 0, S.A[n][f], mode,
-                         rc.lo[0], rc.lo[1], rc.lo[2], rc.hi[0], rc.hi[1], rc.hi[2], fr);
+      NdmProlongB q;
+      for (int d = 0; d < 3; d++) { q.r.lo[d] = std::max(S.r[n][f].lo[d], 2 * rc.lo[d]); q.r.hi[d] = std::min(S.r[n][f].hi[d], 2 * rc.hi[d] + 1); q.clo[d] = rc.lo[d]; q.chi[d] = rc.hi[d]; }
+      if (q.r.lo[0] > q.r.hi[0] || q.r.lo[1] > q.r.hi[1] || q.r.lo[2] > q.r.hi[2]) continue;
+      q.pf = dst->fabs[f]; q.pc = src->fabs[c]; q.slave = S.slave[n]->fabs[f];
+      q.own_c = S.own[n - 1] ? S.own[n - 1]->fabs[c] : src->fabs[c]; q.has_own = S.own[n - 1] ? 1 : 0; q.Af = S.A[n][f];
+      v.push_back(q);
     }
+  launch_batched(v, mode, (double *)nullptr, 0, ctx().stream);
+}
+static void ml_nd_add(MLND &S, int n, vdn_multifab *dst, vdn_multifab *src) {
+  std::vector<NdfAddB> v;
+  for (size_t f = 0; f < S.A[n].size(); f++) { NdfAddB q; q.r = S.r[n][f]; q.a = dst->fabs[f]; q.b = src->fabs[f]; v.push_back(q); }
+  launch_batched(v, 0, (double *)nullptr, 0, ctx().stream);
 }
 static void ml_nd_interface(MLND &S, int n) {
   if (S.multi[n - 1]) mf_fill_boundary(S.phi[n - 1]);        // the parents of a fine node may sit in a coarse box's ghost nodes
   ml_nd_prolong(S, n, S.phi[n], S.phi[n - 1], 0);
   if (S.multi[n]) mf_fill_boundary(S.phi[n]);
 }
-// finest_only: just the finest level's residual (what its relaxation needs), no norm
-static double ml_nd_residual(MLND &S, bool finest_only) {
+// finest_only: just the finest level's residual (what its relaxation needs), no norm.  zero_field: the residual of phi = 0
+static double ml_nd_residual(MLND &S, bool finest_only, bool zero_field = false) {
   hipStream_t st = ctx().stream;
   const int L = S.nlev;
-  if (finest_only) ml_nd_interface(S, L - 1);
-  else {
-    if (S.multi[0]) mf_fill_boundary(S.phi[0]);
-    for (int n = 1; n < L; n++) ml_nd_interface(S, n);
-    HIPCHK(hipMemsetAsync(S.d_nrm, 0, sizeof(double), st));
+  if (!zero_field) {
+    if (finest_only) ml_nd_interface(S, L - 1);
+    else { if (S.multi[0]) mf_fill_boundary(S.phi[0]); for (int n = 1; n < L; n++) ml_nd_interface(S, n); }
   }
+  if (!finest_only) HIPCHK(hipMemsetAsync(S.d_nrm, 0, sizeof(double), st));
   for (int n = L - 1; n >= (finest_only ? L - 1 : 0); n--) {
     const bool finest = n == L - 1;
-    for (size_t f = 0; f < S.A[n].size(); f++)
-      ndf_launch_march<1>(S.phi[n]->fabs[f], S.res[n]->fabs[f], S.b[n]->fabs[f], S.sig[n]->fabs[f], S.slave[n] ? &S.slave[n]->fabs[f] : (const FV *)nullptr, S.A[n][f], 0.0,
-                          (finest && S.slave[n]) ? 1 : 0, S.r[n][f], (finest && !finest_only) ? S.d_nrm : (double *)nullptr);
+    ndf_run_march<1>(zero_field ? S.m_res0[n] : S.m_res[n], 0.0, (finest && S.slave[n]) ? 1 : 0, (finest && !finest_only) ? S.d_nrm : (double *)nullptr);
     if (finest_only) return 0.0;
     if (S.multi[n]) mf_fill_boundary(S.res[n]);
     if (finest) continue;
-    for (size_t f = 0; f < S.A[n + 1].size(); f++) {
-      const NdfArgs &Af = S.A[n + 1][f];
-      Range3 rf; for (int d = 0; d < 3; d++) { rf.lo[d] = (Af.lo[d] + 1) / 2; rf.hi[d] = Af.hi[d] / 2; }       // coarse nodes whose fine twin is a node of box f
-      for (size_t c = 0; c < S.A[n].size(); c++) {
-        Range3 ri; if (!nd_isect(rf, S.r[n][c], ri)) continue;
-        hipLaunchKernelGGL(kk_ndm_restrict_add, grid_for(ri), NBLK, 0, st, S.res[n]->fabs[c], S.res[n + 1]->fabs[f], S.own[n + 1]->fabs[f], Af, S.A[n][c], ri);
-      }
-    }
+    S.rst[n + 1].run(0, (double *)nullptr, st);
     if (S.multi[n] && n > 0) mf_fill_boundary(S.res[n]);      // the ghost nodes must see the restricted part too before level n-1 restricts them
-    for (size_t c = 0; c < S.A[n].size(); c++)
-      hipLaunchKernelGGL(kk_ndf_absmax_mask, reduce_grid(S.r[n][c]), NBLK, 0, st, S.res[n]->fabs[c], S.skip[n]->fabs[c], S.r[n][c], S.d_nrm);
+    S.amax[n].run(0, S.d_nrm, st);
   }
   return ndf_read(S.d_nrm);
 }
 // phi_n += e (nodes of level n) and its trilinear prolongation on every finer level (not on physical Dirichlet nodes)
 static void ml_nd_apply_correction(MLND &S, int n, vdn_multifab *e) {
-  hipStream_t st = ctx().stream;
-  for (size_t f = 0; f < S.A[n].size(); f++) hipLaunchKernelGGL(kk_ndf_add, grid_for(S.r[n][f]), NBLK, 0, st, S.phi[n]->fabs[f], e->fabs[f], S.r[n][f]);
+  ml_nd_add(S, n, S.phi[n], e);
   vdn_multifab *src = e;
   for (int m = n + 1; m < S.nlev; m++) {
     if (S.multi[m - 1]) mf_fill_boundary(src);
@@ -1357,7 +1401,7 @@ static void ml_nd_apply_correction(MLND &S, int n, vdn_multifab *e) {
     else {                                               // keep the increment for the next finer level
       mf_setval(S.scr[m], 0.0, 0, 1, true);
       ml_nd_prolong(S, m, S.scr[m], src, 2);
-      for (size_t f = 0; f < S.A[m].size(); f++) hipLaunchKernelGGL(kk_ndf_add, grid_for(S.r[m][f]), NBLK, 0, st, S.phi[m]->fabs[f], S.scr[m]->fabs[f], S.r[m][f]);
+      ml_nd_add(S, m, S.phi[m], S.scr[m]);
       src = S.scr[m];
     }
   }
@@ -1383,10 +1427,13 @@ static int ml_nd_solve(vdn_layout *la, vdn_multifab **rh, vdn_multifab **phi, vd
       NdfArgs &A = S.A[n][f];
       for (int d = 0; d < 3; d++) {
         A.f[d] = 1.0 / (36.0 * (dx[3 * n + d] * dx[3 * n + d]));
-        A.lo[d] = bx.lo[d]; A.hi[d] = bx.hi[d] + 1; A.ilo[d] = A.ihi[d] = 0; A.cflo[d] = A.cfhi[d] = 0;
+        A.lo[d] = bx.lo[d]; A.hi[d] = bx.hi[d] + 1; A.ilo[d] = A.ihi[d] = 0;
         S.r[n][f].lo[d] = A.lo[d]; S.r[n][f].hi[d] = A.hi[d];
         A.dirlo[d] = bct->ell_bc(n, f + 1, d, 0, press_comp0) == VDN_BC_DIR;
         A.dirhi[d] = bct->ell_bc(n, f + 1, d, 1, press_comp0) == VDN_BC_DIR;
+        // a one-box level: its interface nodes are those of its non-physical faces (the marching kernels then skip the node mask)
+        A.cflo[d] = (n > 0 && nb == 1 && bct->ell_bc(n, f + 1, d, 0, press_comp0) == VDN_BC_INT) ? 1 : 0;
+        A.cfhi[d] = (n > 0 && nb == 1 && bct->ell_bc(n, f + 1, d, 1, press_comp0) == VDN_BC_INT) ? 1 : 0;
       }
     }
   }
@@ -1395,65 +1442,108 @@ static int ml_nd_solve(vdn_layout *la, vdn_multifab **rh, vdn_multifab **phi, vd
     S.phi[n] = phi[n]; S.b[n] = T(mf_temp(la, n, 1, 1, 3, true, 0.0)); S.res[n] = T(mf_temp(la, n, 1, 1, 3, true, 0.0));
     zero[n] = T(mf_temp(la, n, 1, 1, 3, true, 0.0));
     S.sigfull[n] = coeffs[n]; S.sig[n] = coeffs[n]; S.skip[n] = S.slave[n] = S.own[n] = S.scr[n] = nullptr;
-    S.ea[n] = n >= 1 ? zero[n] : nullptr; S.eb[n] = n >= 1 ? T(mf_temp(la, n, 1, 1, 3, true, 0.0)) : nullptr;
+    S.ea[n] = n >= 1 ? T(mf_temp(la, n, 1, 1, 3, true, 0.0)) : nullptr; S.eb[n] = n >= 1 ? T(mf_temp(la, n, 1, 1, 3, true, 0.0)) : nullptr;
     if (n >= 1 && n < L - 1) S.scr[n] = T(mf_temp(la, n, 1, 1, 3, true, 0.0));
     inlev[n] = cov[n] = nullptr;
   }
   // cell masks: inlev[n] = the cells of level n (its ghost cells included where another box of the level covers them),
-  // cov[n] = the cells of level n under level n+1
+  // cov[n] = the cells of level n under level n+1; node masks: own, slave, skip
   for (int n = 0; n < L; n++) {
     MarkArgs D; for (int d = 0; d < 3; d++) { D.dlo[d] = la->pd[n].lo[d]; D.dhi[d] = la->pd[n].hi[d]; }
+    const int nb = phi[n]->nfabs();
     if (n >= 1 || S.multi[n]) {
       S.own[n] = T(mf_temp(la, n, 1, 1, 3, true, 0.0));
-      for (int f = 0; f < phi[n]->nfabs(); f++) {
-        hipLaunchKernelGGL(kk_ndf_setbox, grid_for(S.r[n][f]), NBLK, 0, st, S.own[n]->fabs[f], S.r[n][f], 1.0);
-        for (int g = 0; g < f; g++) { Range3 ri; if (nd_isect(S.r[n][f], S.r[n][g], ri)) hipLaunchKernelGGL(kk_ndf_setbox, grid_for(ri), NBLK, 0, st, S.own[n]->fabs[f], ri, 0.0); }
+      std::vector<NdfSetB> v1, v0;
+      for (int f = 0; f < nb; f++) {
+        NdfSetB q; q.r = S.r[n][f]; q.a = S.own[n]->fabs[f]; q.v = 1.0; v1.push_back(q);
+        for (int g = 0; g < f; g++) { NdfSetB z; if (nd_isect(S.r[n][f], S.r[n][g], z.r)) { z.a = S.own[n]->fabs[f]; z.v = 0.0; v0.push_back(z); } }
       }
+      launch_batched(v1, 0, (double *)nullptr, 0, st);
+      launch_batched(v0, 0, (double *)nullptr, 0, st);
     }
     if (n >= 1) {
       inlev[n] = T(mf_temp(la, n, 1, 1, -1, true, 0.0));
       mf_setval(inlev[n], 1.0, 0, 1, false);
       mf_fill_boundary(inlev[n]);
       S.slave[n] = T(mf_temp(la, n, 1, 1, 3, true, 0.0));
-      for (int f = 0; f < phi[n]->nfabs(); f++)
-        hipLaunchKernelGGL(kk_ndm_mark, grid_for(S.r[n][f]), NBLK, 0, st, S.slave[n]->fabs[f], inlev[n]->fabs[f], S.A[n][f], D, 0, S.r[n][f]);
+      std::vector<NdmMarkB> v;
+      for (int f = 0; f < nb; f++) { NdmMarkB q; q.r = S.r[n][f]; q.out = S.slave[n]->fabs[f]; q.cmask = inlev[n]->fabs[f]; q.A = S.A[n][f]; q.D = D; q.mode = 0; v.push_back(q); }
+      launch_batched(v, 0, (double *)nullptr, 0, st);
       if (S.multi[n]) mf_fill_boundary(S.slave[n]);
     }
     if (n < L - 1) {
       cov[n] = T(mf_temp(la, n, 1, 1, -1, true, 0.0));
+      std::vector<NdfSetB> vc;
       for (int f = 0; f < phi[n + 1]->nfabs(); f++) {
         const vdn_box &fb = phi[n + 1]->vbox[f];
         Range3 rcov; for (int d = 0; d < 3; d++) { rcov.lo[d] = fb.lo[d] / 2; rcov.hi[d] = fb.hi[d] / 2; }
-        for (int c = 0; c < phi[n]->nfabs(); c++) {
-          Range3 rb2, ri; for (int d = 0; d < 3; d++) { rb2.lo[d] = phi[n]->vbox[c].lo[d] - 1; rb2.hi[d] = phi[n]->vbox[c].hi[d] + 1; }
-          if (nd_isect(rcov, rb2, ri)) hipLaunchKernelGGL(kk_ndf_setbox, grid_for(ri), NBLK, 0, st, cov[n]->fabs[c], ri, 1.0);
+        for (int c = 0; c < nb; c++) {
+          Range3 rb2; NdfSetB q; for (int d = 0; d < 3; d++) { rb2.lo[d] = phi[n]->vbox[c].lo[d] - 1; rb2.hi[d] = phi[n]->vbox[c].hi[d] + 1; }
+          if (nd_isect(rcov, rb2, q.r)) { q.a = cov[n]->fabs[c]; q.v = 1.0; vc.push_back(q); }
         }
       }
+      launch_batched(vc, 0, (double *)nullptr, 0, st);
       S.sig[n] = T(mf_temp(la, n, 1, 1, -1, true, 0.0));
       S.skip[n] = T(mf_temp(la, n, 1, 1, 3, true, 0.0));
       if (S.slave[n]) mf_copy(S.skip[n], 0, S.slave[n], 0, 1, 0);
-      for (int c = 0; c < phi[n]->nfabs(); c++) {
-        Range3 rg; for (int d = 0; d < 3; d++) { rg.lo[d] = phi[n]->vbox[c].lo[d] - 1; rg.hi[d] = phi[n]->vbox[c].hi[d] + 1; }
-        hipLaunchKernelGGL(kk_ndm_mul, grid_for(rg), NBLK, 0, st, S.sig[n]->fabs[c], coeffs[n]->fabs[c], cov[n]->fabs[c], rg);
-        hipLaunchKernelGGL(kk_ndm_mark, grid_for(S.r[n][c]), NBLK, 0, st, S.skip[n]->fabs[c], cov[n]->fabs[c], S.A[n][c], D, 1, S.r[n][c]);
+      std::vector<NdmMulB> vm; std::vector<NdmMarkB> vk;
+      for (int c = 0; c < nb; c++) {
+        NdmMulB q; for (int d = 0; d < 3; d++) { q.r.lo[d] = phi[n]->vbox[c].lo[d] - 1; q.r.hi[d] = phi[n]->vbox[c].hi[d] + 1; }
+        q.out = S.sig[n]->fabs[c]; q.a = coeffs[n]->fabs[c]; q.keep0 = cov[n]->fabs[c]; vm.push_back(q);
+        NdmMarkB k2; k2.r = S.r[n][c]; k2.out = S.skip[n]->fabs[c]; k2.cmask = cov[n]->fabs[c]; k2.A = S.A[n][c]; k2.D = D; k2.mode = 1; vk.push_back(k2);
       }
+      launch_batched(vm, 0, (double *)nullptr, 0, st);
+      launch_batched(vk, 0, (double *)nullptr, 0, st);
     } else S.skip[n] = S.slave[n];
   }
   // right-hand side b = -(rh + D u) with the masked velocity (zero outside the level and under the next finer one)
   for (int n = 0; n < L; n++) {
     vdn_multifab *um = T(mf_temp(la, n, 3, 1, -1, false, 0.0));
+    std::vector<NdmMaskUB> vu; std::vector<NdDivuB> vd; std::vector<NdfNegB> vn;
     for (int f = 0; f < phi[n]->nfabs(); f++) {
-      Range3 rg; for (int d = 0; d < 3; d++) { rg.lo[d] = phi[n]->vbox[f].lo[d] - 1; rg.hi[d] = phi[n]->vbox[f].hi[d] + 1; }
-      hipLaunchKernelGGL(kk_ndm_mask_u, grid_for(rg), NBLK, 0, st, um->fabs[f], u[n]->fabs[f], inlev[n] ? inlev[n]->fabs[f] : u[n]->fabs[f], inlev[n] ? 1 : 0,
-                         cov[n] ? cov[n]->fabs[f] : u[n]->fabs[f], cov[n] ? 1 : 0, rg);
-      hipLaunchKernelGGL(kk_nd_divu, grid_for(S.r[n][f]), NBLK, 0, st, um->fabs[f], rh[n]->fabs[f], 0.25 / dx[3 * n], 0.25 / dx[3 * n + 1], 0.25 / dx[3 * n + 2], S.r[n][f]);
-      hipLaunchKernelGGL(kk_ndf_neg, grid_for(S.r[n][f]), NBLK, 0, st, S.b[n]->fabs[f], rh[n]->fabs[f], S.A[n][f], S.r[n][f]);
+      NdmMaskUB q; for (int d = 0; d < 3; d++) { q.r.lo[d] = phi[n]->vbox[f].lo[d] - 1; q.r.hi[d] = phi[n]->vbox[f].hi[d] + 1; }
+      q.out = um->fabs[f]; q.u = u[n]->fabs[f]; q.inlev = inlev[n] ? inlev[n]->fabs[f] : u[n]->fabs[f]; q.has_inlev = inlev[n] ? 1 : 0;
+      q.cov = cov[n] ? cov[n]->fabs[f] : u[n]->fabs[f]; q.has_cov = cov[n] ? 1 : 0; vu.push_back(q);
+      NdDivuB dv; dv.r = S.r[n][f]; dv.u = um->fabs[f]; dv.rh = rh[n]->fabs[f]; dv.f0 = 0.25 / dx[3 * n]; dv.f1 = 0.25 / dx[3 * n + 1]; dv.f2 = 0.25 / dx[3 * n + 2]; vd.push_back(dv);
+      NdfNegB ng; ng.r = S.r[n][f]; ng.out = S.b[n]->fabs[f]; ng.in = rh[n]->fabs[f]; ng.A = S.A[n][f]; vn.push_back(ng);
+    }
+    launch_batched(vu, 0, (double *)nullptr, 0, st);
+    launch_batched(vd, 0, (double *)nullptr, 0, st);
+    launch_batched(vn, 0, (double *)nullptr, 0, st);
+  }
+  // descriptor sets of the per-iteration kernels
+  for (int n = 0; n < L; n++) {
+    std::vector<MarchB> vr, vr0, vj0, vj1; std::vector<NdfAbsmaxB> va;
+    for (size_t f = 0; f < S.A[n].size(); f++) {
+      MarchB q; q.phi = phi[n]->fabs[f]; q.out = S.res[n]->fabs[f]; q.rb = S.b[n]->fabs[f]; q.sig = S.sig[n]->fabs[f];
+      q.slave = S.slave[n] ? S.slave[n]->fabs[f] : phi[n]->fabs[f]; q.has_slave = S.slave[n] ? (S.multi[n] ? 1 : 2) : 0; q.A = S.A[n][f]; q.r = S.r[n][f];
+      vr.push_back(q);
+      q.phi = zero[n]->fabs[f]; vr0.push_back(q);
+      if (n >= 1) {
+        MarchB j0 = q; j0.phi = S.ea[n]->fabs[f]; j0.out = S.eb[n]->fabs[f]; j0.rb = S.res[n]->fabs[f]; j0.sig = S.sigfull[n]->fabs[f]; vj0.push_back(j0);
+        MarchB j1 = j0; j1.phi = S.eb[n]->fabs[f]; j1.out = S.ea[n]->fabs[f]; vj1.push_back(j1);
+      }
+      if (n < L - 1) { NdfAbsmaxB m; m.r = S.r[n][f]; m.a = S.res[n]->fabs[f]; m.mask = S.skip[n]->fabs[f]; va.push_back(m); }
+    }
+    S.m_res[n] = ndf_build_march(vr); S.m_res0[n] = ndf_build_march(vr0);
+    S.m_jac[n][0] = ndf_build_march(vj0); S.m_jac[n][1] = ndf_build_march(vj1);
+    S.amax[n].build(va, 16, st);
+    if (n >= 1) {
+      std::vector<NdmRestrictB> v;
+      for (size_t f = 0; f < S.A[n].size(); f++) {
+        const NdfArgs &Af = S.A[n][f];
+        Range3 rf; for (int d = 0; d < 3; d++) { rf.lo[d] = (Af.lo[d] + 1) / 2; rf.hi[d] = Af.hi[d] / 2; }       // coarse nodes whose fine twin is a node of box f
+        for (size_t c = 0; c < S.A[n - 1].size(); c++) {
+          NdmRestrictB q; if (!nd_isect(rf, S.r[n - 1][c], q.r)) continue;
+          q.res_c = S.res[n - 1]->fabs[c]; q.res_f = S.res[n]->fabs[f]; q.own_f = S.own[n]->fabs[f]; q.Af = Af; q.Ac = S.A[n - 1][c];
+          v.push_back(q);
+        }
+      }
+      S.rst[n].build(v, 0, st);
     }
   }
   // norm of the composite right-hand side = composite residual of phi = 0
-  for (int n = 0; n < L; n++) S.phi[n] = zero[n];
-  const double bnorm = ml_nd_residual(S, false);
-  for (int n = 0; n < L; n++) S.phi[n] = phi[n];
+  const double bnorm = ml_nd_residual(S, false, true);
   vdn_multifab *er = zero[0], *ee = T(mf_temp(la, 0, 1, 1, 3, true, 0.0));      // scratch of the coarse correction solve
   int ebc0[3][2];
   for (int d = 0; d < 3; d++) for (int s = 0; s < 2; s++) ebc0[d][s] = bct->ell_bc(0, 0, d, s, press_comp0);
@@ -1464,9 +1554,13 @@ static int ml_nd_solve(vdn_layout *la, vdn_multifab **rh, vdn_multifab **phi, vd
     if (it >= max_iter) break;
     // coarse correction K_0 e = r_0: one V-cycle of the single-level solver (which takes rh with b = -rh)
     mf_setval(ee, 0.0, 0, 1, true); mf_setval(er, 0.0, 0, 1, true);
-    for (size_t c = 0; c < S.A[0].size(); c++) {
-      NdfArgs Z = S.A[0][c]; for (int d = 0; d < 3; d++) { Z.dirlo[d] = Z.dirhi[d] = 0; }
-      hipLaunchKernelGGL(kk_ndf_neg, grid_for(S.r[0][c]), NBLK, 0, st, er->fabs[c], S.res[0]->fabs[c], Z, S.r[0][c]);
+    {
+      std::vector<NdfNegB> v;
+      for (size_t c = 0; c < S.A[0].size(); c++) {
+        NdfNegB q; q.r = S.r[0][c]; q.out = er->fabs[c]; q.in = S.res[0]->fabs[c]; q.A = S.A[0][c]; for (int d = 0; d < 3; d++) { q.A.dirlo[d] = q.A.dirhi[d] = 0; }
+        v.push_back(q);
+      }
+      launch_batched(v, 0, (double *)nullptr, 0, st);
     }
     int cyc; double r0, rr;
     nd_solve(er, ee, coeffs[0], nullptr, dx, ebc0, 0.0, -1.0, -1, &cyc, &r0, &rr);
@@ -1478,8 +1572,7 @@ static int ml_nd_solve(vdn_layout *la, vdn_multifab **rh, vdn_multifab **phi, vd
       vdn_multifab *a = S.ea[n], *b2 = S.eb[n];
       for (int s = 0; s < P.hg_nu1 + P.hg_nu2; s++) {
         if (S.multi[n] && s > 0) mf_fill_boundary(a);
-        for (size_t f = 0; f < S.A[n].size(); f++)
-          ndf_launch_march<0>(a->fabs[f], b2->fabs[f], S.res[n]->fabs[f], S.sigfull[n]->fabs[f], &S.slave[n]->fabs[f], S.A[n][f], P.hg_omega, 0, S.r[n][f], (double *)nullptr);
+        ndf_run_march<0>(S.m_jac[n][s & 1], P.hg_omega, 0, (double *)nullptr);
         std::swap(a, b2);
       }
       ml_nd_apply_correction(S, n, a);

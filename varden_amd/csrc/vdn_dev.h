@@ -55,7 +55,7 @@ __global__ void __launch_bounds__(256) kk_batched(const A *args, const int *star
   int lo = 0, hi = nbox - 1;
   const int bid = (int)blockIdx.x;
   while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (start[mid] <= bid) lo = mid; else hi = mid - 1; }
-  const A &a = args[lo];
+  const A a = args[lo];                                       // by value: a reference into global memory would be re-read after every store
   const int lb = bid - start[lo];
   const int bx = lb % a.g[0], by = (lb / a.g[0]) % a.g[1], bz = lb / (a.g[0] * a.g[1]);
   const int i = a.r.lo[0] + bx * 64 + (int)threadIdx.x, j = a.r.lo[1] + by * 4 + (int)threadIdx.y;
