@@ -376,11 +376,21 @@ static Range3 fab_range(const vdn_multifab *mf, int i, int grow) {   // valid (i
   for (int d = 0; d < 3; d++) { r.lo[d] = mf->vbox[i].lo[d] - grow; r.hi[d] = mf->vbox[i].hi[d] + mf->nodal[d] + grow; }
   return r;
 }
+struct SetvalB { Range3 r; int g[3]; FV f; int comp, nc; double val;
+  static __device__ double body(const SetvalB &q, int i, int j, int k, int) { for (int c = q.comp; c < q.comp + q.nc; c++) fv_at(q.f, i, j, k, c) = q.val; return 0.0; } };
+struct CopyB { Range3 r; int g[3]; FV d, s; int dc, sc, nc;
+  static __device__ double body(const CopyB &q, int i, int j, int k, int) { for (int c = 0; c < q.nc; c++) fv_at(q.d, i, j, k, q.dc + c) = fv_get(q.s, i, j, k, q.sc + c); return 0.0; } };
 void mf_setval(vdn_multifab *mf, double val, int comp, int nc, bool all) {
-  for (int i = 0; i < mf->nfabs(); i++) {
-    Range3 r = fab_range(mf, i, all ? mf->ng : 0);
-    hipLaunchKernelGGL(k_setval, grid_for(r), dim3(64, 4, 1), 0, g_ctx.stream, mf->fabs[i], r, comp, nc, val);
+  // zero over everything the multifab owns: one memset of its allocation (the fabs are contiguous)
+  if (val == 0.0 && all && comp == 0 && nc == mf->nc && mf->nfabs() > 1) { HIPCHK(hipMemsetAsync(mf->base, 0, mf->bytes, g_ctx.stream)); return; }
+  if (mf->nfabs() == 1) {
+    Range3 r = fab_range(mf, 0, all ? mf->ng : 0);
+    hipLaunchKernelGGL(k_setval, grid_for(r), dim3(64, 4, 1), 0, g_ctx.stream, mf->fabs[0], r, comp, nc, val);
+    return;
   }
+  std::vector<SetvalB> v;
+  for (int i = 0; i < mf->nfabs(); i++) { SetvalB q; q.r = fab_range(mf, i, all ? mf->ng : 0); q.f = mf->fabs[i]; q.comp = comp; q.nc = nc; q.val = val; v.push_back(q); }
+  launch_batched(v, 0, (double *)nullptr, 0, g_ctx.stream);
 }
 extern "C" int vdn_multifab_setval(vdn_multifab *mf, double val, int comp, int nc, int all) {
   VDN_TRY
@@ -397,10 +407,14 @@ __global__ void k_copy(FV d, int dc, FV s, int scomp, int nc, Range3 r) {
 void mf_copy(vdn_multifab *dst, int dcomp, const vdn_multifab *src, int scomp, int nc, int ng) {
   REQUIRE(dst->nfabs() == src->nfabs(), "copy_c: layouts differ");
   REQUIRE(ng <= dst->ng && ng <= src->ng, "copy_c: ng too large");
-  for (int i = 0; i < dst->nfabs(); i++) {
-    Range3 r = fab_range(dst, i, ng);
-    hipLaunchKernelGGL(k_copy, grid_for(r), dim3(64, 4, 1), 0, g_ctx.stream, dst->fabs[i], dcomp, src->fabs[i], scomp, nc, r);
+  if (dst->nfabs() == 1) {
+    Range3 r = fab_range(dst, 0, ng);
+    hipLaunchKernelGGL(k_copy, grid_for(r), dim3(64, 4, 1), 0, g_ctx.stream, dst->fabs[0], dcomp, src->fabs[0], scomp, nc, r);
+    return;
   }
+  std::vector<CopyB> v;
+  for (int i = 0; i < dst->nfabs(); i++) { CopyB q; q.r = fab_range(dst, i, ng); q.d = dst->fabs[i]; q.s = src->fabs[i]; q.dc = dcomp; q.sc = scomp; q.nc = nc; v.push_back(q); }
+  launch_batched(v, 0, (double *)nullptr, 0, g_ctx.stream);
 }
 extern "C" int vdn_multifab_copy_c(vdn_multifab *dst, int dcomp, const vdn_multifab *src, int scomp, int nc, int ng) {
   VDN_TRY mf_copy(dst, dcomp, src, scomp, nc, ng); VDN_CATCH
