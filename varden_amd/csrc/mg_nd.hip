@@ -584,7 +584,11 @@ static void nd_build(NDMG &M, const vdn_multifab *coeffs, const double *dx, cons
     bool can = true, next_dist = true;
     for (int d = 0; d < 3; d++) { const int N = lpd.hi[d] + 1; if ((N & 1) || N <= 2) can = false; }
     if (can) for (int d = 0; d < 3; d++) REQUIRE(!(n[d] & 1), "nodal multigrid: box extent %d is odd while the domain can still be coarsened", n[d]);
-    for (int d = 0; d < 3; d++) if (n[d] / 2 < 4 || ((n[d] / 2) & 1)) next_dist = false;
+    // several boxes: stop exchanging halos once the boxes get small (VDN_MG_AGGLOM, default 32) -- every level that stays distributed costs
+    // ~10 halo exchanges per V-cycle, the replicated tail of a 32^3-per-box level costs microseconds
+    static const int agglom = getenv("VDN_MG_AGGLOM") ? std::max(4, atoi(getenv("VDN_MG_AGGLOM"))) : 32;
+    const int min_dist = nb > 1 ? agglom : 4;
+    for (int d = 0; d < 3; d++) if (n[d] / 2 < min_dist || ((n[d] / 2) & 1)) next_dist = false;
     if (!can) break;
     if (!next_dist) {
       int tn[3]; double th[3]; int cn[3];
