@@ -192,6 +192,14 @@ int vdn_multifab_fill_ghost_cells(vdn_multifab *fine, const vdn_multifab *crse, 
 int vdn_create_umac_grown(vdn_multifab *fine, const vdn_multifab *crse, int dir);
 int vdn_ml_restrict_and_fill(int nlev, vdn_multifab **mf, int icomp, int bcomp, int nc, int same_boundary, const vdn_bc_tower *bct);
 
+/* regridding (src/regrid.f90:280-337, build_and_fill_data): fillpatch(fine, crse, ng = 0, ...) fills every valid cell of a new fine
+ * level from the coarser one (coarse ghost cells filled; interpolation of multifab_fill_ghost_cells); ml_nodal_prolongation does the
+ * same for the nodal pressure (trilinear); multifab_copy_c between multifabs of one level whose box lists differ copies the points
+ * valid in both (old data over the interpolated data). */
+int vdn_fillpatch(vdn_multifab *fine, const vdn_multifab *crse, int icomp, int nc);
+int vdn_ml_nodal_prolongation(vdn_multifab *fine, vdn_multifab *crse);
+int vdn_multifab_copy_layouts(vdn_multifab *dst, int dcomp, const vdn_multifab *src, int scomp, int nc);
+
 /* ---- grid generation in front of the AMR path ------------------------------------------------------------------------------------
  * tag_boxes(mf, tagboxes, dx, lev)                               src/tag_boxes.f90:17-48 (rules :142-210: rho > 1.01 / 1.1 / 1.5 by level
  *                                                                for prob_type 1, 2; 1.2 < rho < 1.8 for prob_type 3)

@@ -440,3 +440,91 @@ def test_tagged_grids_properties_and_run(gpu, max_levs):
         c = s0[lo[0] // 2:hi[0] // 2 + 1, lo[1] // 2:hi[1] // 2 + 1, lo[2] // 2:hi[2] // 2 + 1]
         assert np.abs(c - m).max() <= 1e-13
     G.close()
+
+
+def test_fillpatch_and_nodal_prolongation_reproduce_linear_fields(gpu):
+    """regrid.f90:311-327: fillpatch (limited linear interpolation) is exact for a linear cell field, ml_nodal_prolongation (trilinear)
+    for a trilinear nodal field; copy between layouts moves exactly the points valid in both"""
+    from varden_amd import advance as adv
+    from varden_amd import boxlib as bl
+    from varden_amd.capi import default_params
+    bl.initialize(default_params(), 0, 1, 0)
+    nc = 16
+    pd = [((0, 0, 0), (nc - 1,) * 3), ((0, 0, 0), (2 * nc - 1,) * 3)]
+    cboxes = [((0, 0, 0), (7, 15, 15)), ((8, 0, 0), (15, 15, 15))]
+    fboxes = [((8, 8, 8), (15, 23, 23)), ((16, 8, 8), (23, 15, 23)), ((16, 16, 8), (23, 23, 23))]
+    mla = bl.MLLayout(pd, [cboxes, fboxes], rr=[(2, 2, 2)])
+    lin = lambda x, y, z: 1.0 + 2.0 * x - 3.0 * y + 0.5 * z                                    # noqa: E731
+    tri = lambda x, y, z: 1.0 + x - 2.0 * y + 3.0 * z + x * y - 0.5 * y * z + 2.0 * x * y * z     # noqa: E731
+    crse, fine = bl.MultiFab(mla, 0, 1, 1), bl.MultiFab(mla, 1, 1, 0)
+    pc, pf = bl.MultiFab(mla, 0, 1, 1, (1, 1, 1)), bl.MultiFab(mla, 1, 1, 1, (1, 1, 1))
+    for i, (lo, hi) in enumerate(cboxes):
+        ax = [(np.arange(lo[d] - 1, hi[d] + 2) + 0.5) / nc for d in range(3)]
+        crse.from_numpy(lin(*np.meshgrid(*ax, indexing="ij"))[..., None], i)
+        an = [np.arange(lo[d] - 1, hi[d] + 3) / nc for d in range(3)]
+        pc.from_numpy(tri(*np.meshgrid(*an, indexing="ij"))[..., None], i)
+    adv.fillpatch(fine, crse, 0, 1)
+    adv.ml_nodal_prolongation(pf, pc)
+    for i, (lo, hi) in enumerate(fboxes):
+        ax = [(np.arange(lo[d], hi[d] + 1) + 0.5) / (2 * nc) for d in range(3)]
+        assert np.abs(fine.to_numpy(i)[..., 0] - lin(*np.meshgrid(*ax, indexing="ij"))).max() <= 1e-14
+        an = [np.arange(lo[d], hi[d] + 2) / (2 * nc) for d in range(3)]
+        assert np.abs(pf.to_numpy(i)[1:-1, 1:-1, 1:-1, 0] - tri(*np.meshgrid(*an, indexing="ij"))).max() <= 1e-14
+    # copy between two box lists of level 1
+    mlb = bl.MLLayout(pd, [cboxes, [((12, 12, 12), (19, 19, 19))]], rr=[(2, 2, 2)])
+    other = bl.MultiFab(mlb, 1, 1, 0)
+    other.setval(-7.0, all=True)
+    adv.copy_layouts(other, 0, fine, 0, 1)
+    ax = [(np.arange(12, 20) + 0.5) / (2 * nc) for d in range(3)]
+    assert np.abs(other.to_numpy(0)[..., 0] - lin(*np.meshgrid(*ax, indexing="ij"))).max() <= 1e-14
+    for m in (crse, fine, pc, pf, other):
+        m.destroy()
+    mla.destroy(); mlb.destroy()
+
+
+def test_regrid(gpu):
+    """src/regrid.f90: (1) regridding an unchanged state gives the same boxes and, bit for bit, the same data (everything is copied
+    from the old level); (2) a hierarchy that starts with ONE large fine box regrids onto the tagged boxes inside it, keeps the old
+    fine data there bit for bit, and goes on stepping with the regrid interval of the reference's inputs (regrid_int = 2)."""
+    from varden_amd import advance as adv
+    from varden_amd import driver
+    from varden_amd.capi import default_params
+    nc = 32
+    levels = driver.VardenAMR.tagged_grids(nc, WALLS, default_params(cflfac=0.9), max_levs=2, max_grid_size=32)
+    G = driver.VardenAMR(nc, levels[0], WALLS, params=default_params(cflfac=0.9), regrid_int=2, max_levs=2, max_grid_size=32)
+    G.step()
+    before = {k: [[getattr(G, k)[n].to_numpy(i) for i in range(getattr(G, k)[n].nfabs())] for n in range(G.nlev)] for k in ("uold", "sold", "gp", "p")}
+    boxes_before = [list(b) for b in G.boxes]
+    G.fill_state_ghosts()
+    ghosts = {k: [[getattr(G, k)[n].to_numpy(i) for i in range(getattr(G, k)[n].nfabs())] for n in range(G.nlev)] for k in ("uold", "sold", "gp")}
+    G.regrid(buf_wid=2)
+    assert [sorted(b) for b in G.boxes] == [sorted(b) for b in boxes_before]
+    for k in ("uold", "sold", "gp"):
+        for n in range(G.nlev):
+            for i, bx in enumerate(G.boxes[n]):
+                j = boxes_before[n].index(bx)
+                assert np.array_equal(getattr(G, k)[n].to_numpy(i), ghosts[k][n][j]), (k, n, i)
+    for n in range(G.nlev):
+        for i, bx in enumerate(G.boxes[n]):
+            j = boxes_before[n].index(bx)
+            assert np.array_equal(G.p[n].to_numpy(i)[1:-1, 1:-1, 1:-1], before["p"][n][j][1:-1, 1:-1, 1:-1])
+    for _ in range(4):                                       # steps 2..5: regrids before steps 3 and 5
+        G.step()
+    assert G.nregrids >= 3 and adv.last_solver_stats("hg")[0] < 40
+    s0 = G.snew[0].to_numpy(0)[3:-3, 3:-3, 3:-3, 0]
+    assert np.isfinite(s0).all() and np.abs(s0 - s0[::-1]).max() <= 1e-8
+    G.close()
+    # (2) one big fine box -> tagged boxes inside it
+    H = driver.VardenAMR(nc, [((8, 8, 8), (55, 55, 55))], WALLS, params=default_params(cflfac=0.9), regrid_int=2, max_levs=2, max_grid_size=32)
+    H.step()
+    big = H.sold[1].to_numpy(0)
+    H.regrid(buf_wid=2)
+    assert len(H.boxes[1]) > 1
+    for i, (lo, hi) in enumerate(H.boxes[1]):
+        assert all(8 <= lo[d] and hi[d] <= 55 for d in range(3))
+        a = H.sold[1].to_numpy(i)[3:-3, 3:-3, 3:-3]
+        b = big[3 + lo[0] - 8:3 + hi[0] - 8 + 1, 3 + lo[1] - 8:3 + hi[1] - 8 + 1, 3 + lo[2] - 8:3 + hi[2] - 8 + 1]
+        assert np.array_equal(a, b)
+    H.step(); H.step()
+    assert np.isfinite(H.snew[0].to_numpy(0)).all()
+    H.close()

@@ -152,3 +152,17 @@ def make_new_grids(s, lev, buf_wid=2, nest=2, min_eff=0.9, min_width=4, blocking
     check(capi.load().vdn_make_new_grids(s.h, lev, buf_wid, nest, min_eff, min_width, blocking, max_grid_size, maxboxes, boxes,
                                          C.byref(nb), C.byref(nt)))
     return [(tuple(boxes[i].lo), tuple(boxes[i].hi)) for i in range(nb.value)], nt.value
+
+
+def fillpatch(fine, crse, icomp, nc):
+    """fillpatch(fine, crse, 0, ...) of src/regrid.f90:311-325: valid cells of a new fine level from the coarser one"""
+    check(capi.load().vdn_fillpatch(fine.h, crse.h, icomp, nc))
+
+
+def ml_nodal_prolongation(fine, crse):
+    check(capi.load().vdn_ml_nodal_prolongation(fine.h, crse.h))
+
+
+def copy_layouts(dst, dcomp, src, scomp, nc):
+    """multifab_copy_c between two multifabs of one level whose box lists differ (src/regrid.f90:333-337)"""
+    check(capi.load().vdn_multifab_copy_layouts(dst.h, dcomp, src.h, scomp, nc))

@@ -104,6 +104,9 @@ SIGNATURES = {
     "vdn_multifab_fill_ghost_cells": (C.c_int, [_VP, _VP, C.c_int, C.c_int]),
     "vdn_create_umac_grown": (C.c_int, [_VP, _VP, C.c_int]),
     "vdn_ml_restrict_and_fill": (C.c_int, [C.c_int, _PVP, C.c_int, C.c_int, C.c_int, C.c_int, _VP]),
+    "vdn_fillpatch": (C.c_int, [_VP, _VP, C.c_int, C.c_int]),
+    "vdn_ml_nodal_prolongation": (C.c_int, [_VP, _VP]),
+    "vdn_multifab_copy_layouts": (C.c_int, [_VP, C.c_int, _VP, C.c_int, C.c_int]),
     "vdn_make_new_grids": (C.c_int, [_VP, C.c_int, C.c_int, C.c_int, C.c_double, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(Box), _PI, C.POINTER(C.c_long)]),
     "vdn_last_step_timing": (C.c_int, [_PD]),
     "vdn_last_solver_stats": (C.c_int, [C.c_int, _PI, _PD, _PD]),

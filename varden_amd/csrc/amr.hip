@@ -163,6 +163,75 @@ void ml_fill_ghost_cells(vdn_multifab *fine, const vdn_multifab *crse, int icomp
   }
   launch_batched(v, 0, (double *)nullptr, 0, ctx().stream);       // every ghost cell has exactly one parent range: order-free
 }
+// fillpatch(fine, crse, ng = 0, ...) of src/regrid.f90:311-325: every VALID cell of the fine level from the coarse one, by the
+// interpolation of multifab_fill_ghost_cells (the coarse ghost cells must be filled; the fine level is properly nested)
+void ml_fillpatch(vdn_multifab *fine, const vdn_multifab *crse, int icomp, int nc) {
+  std::vector<InterpB> v;
+  for (int f = 0; f < fine->nfabs(); f++)
+    for (int c = 0; c < crse->nfabs(); c++) {
+      InterpB e; int plo[3], phi[3]; Range3 pr;
+      for (int d = 0; d < 3; d++) {
+        e.r.lo[d] = fine->vbox[f].lo[d]; e.r.hi[d] = fine->vbox[f].hi[d];
+        e.A.flo[d] = 1; e.A.fhi[d] = 0;                                   // no cell is skipped as "valid"
+        plo[d] = hfdiv2(e.r.lo[d]); phi[d] = hfdiv2(e.r.hi[d]);
+        e.A.alo[d] = crse->vbox[c].lo[d] - crse->ng; e.A.ahi[d] = crse->vbox[c].hi[d] + crse->ng;
+      }
+      if (!isect(plo, phi, crse->vbox[c].lo, crse->vbox[c].hi, pr)) continue;
+      for (int d = 0; d < 3; d++) { e.A.plo[d] = pr.lo[d]; e.A.phi[d] = pr.hi[d]; }
+      e.A.icomp = icomp; e.A.nc = nc; e.fine = fine->fabs[f]; e.crse = crse->fabs[c];
+      v.push_back(e);
+    }
+  launch_batched(v, 0, (double *)nullptr, 0, ctx().stream);
+}
+// ml_nodal_prolongation(fine, crse, rr) of src/regrid.f90:327: trilinear interpolation of a nodal field on every node of the fine level
+struct NodalProlongB { Range3 r; int g[3]; FV pf, pc; int clo[3], chi[3];
+  static __device__ double body(const NodalProlongB &q, int i, int j, int k, int) {
+    const int I = fdiv2(i), J = fdiv2(j), K = fdiv2(k), oi = i - 2 * I, oj = j - 2 * J, ok = k - 2 * K;
+    if (I < q.clo[0] || I > q.chi[0] || J < q.clo[1] || J > q.chi[1] || K < q.clo[2] || K > q.chi[2]) return 0.0;
+    double s = 0.0;
+    for (int c = 0; c <= ok; c++) for (int b = 0; b <= oj; b++) for (int a = 0; a <= oi; a++) s = s + fv_get(q.pc, I + a, J + b, K + c);
+    fv_at(q.pf, i, j, k) = s * (1.0 / (double)((1 + oi) * (1 + oj) * (1 + ok)));
+    return 0.0;
+  } };
+void ml_nodal_prolongation(vdn_multifab *fine, vdn_multifab *crse) {
+  REQUIRE(fine->nodal[0] && fine->nodal[1] && fine->nodal[2] && crse->nodal[0] && crse->nodal[1] && crse->nodal[2], "ml_nodal_prolongation: nodal multifabs expected");
+  mf_fill_boundary(crse);                                   // a parent node may sit in a coarse box's ghost layer
+  std::vector<NodalProlongB> v;
+  for (int f = 0; f < fine->nfabs(); f++)
+    for (int c = 0; c < crse->nfabs(); c++) {
+      NodalProlongB q; bool empty = false;
+      for (int d = 0; d < 3; d++) {
+        q.clo[d] = crse->vbox[c].lo[d]; q.chi[d] = crse->vbox[c].hi[d] + 1;
+        q.r.lo[d] = std::max(fine->vbox[f].lo[d], 2 * q.clo[d]); q.r.hi[d] = std::min(fine->vbox[f].hi[d] + 1, 2 * q.chi[d]);
+        if (q.r.lo[d] > q.r.hi[d]) empty = true;
+      }
+      if (empty) continue;
+      q.pf = fine->fabs[f]; q.pc = crse->fabs[c];
+      v.push_back(q);
+    }
+  launch_batched(v, 0, (double *)nullptr, 0, ctx().stream);
+}
+// multifab_copy_c between two multifabs of the SAME index space whose box lists differ (src/regrid.f90:333-337): valid points of
+// dst that are valid points of src
+struct CopyLB { Range3 r; int g[3]; FV d, s; int dc, sc, nc;
+  static __device__ double body(const CopyLB &q, int i, int j, int k, int) { for (int c = 0; c < q.nc; c++) fv_at(q.d, i, j, k, q.dc + c) = fv_get(q.s, i, j, k, q.sc + c); return 0.0; } };
+void mf_copy_layouts(vdn_multifab *dst, int dcomp, const vdn_multifab *src, int scomp, int nc) {
+  for (int d = 0; d < 3; d++) REQUIRE(dst->nodal[d] == src->nodal[d], "copy between layouts: nodal flags differ");
+  std::vector<CopyLB> v;
+  for (int a = 0; a < dst->nfabs(); a++)
+    for (int b = 0; b < src->nfabs(); b++) {
+      CopyLB q; bool empty = false;
+      for (int d = 0; d < 3; d++) {
+        q.r.lo[d] = std::max(dst->vbox[a].lo[d], src->vbox[b].lo[d]);
+        q.r.hi[d] = std::min(dst->vbox[a].hi[d], src->vbox[b].hi[d]) + dst->nodal[d];
+        if (q.r.lo[d] > q.r.hi[d]) empty = true;
+      }
+      if (empty) continue;
+      q.d = dst->fabs[a]; q.s = src->fabs[b]; q.dc = dcomp; q.sc = scomp; q.nc = nc;
+      v.push_back(q);
+    }
+  launch_batched(v, 0, (double *)nullptr, 0, ctx().stream);
+}
 struct GrownArgs { int flo[3], fhi[3]; int plo[3], phi[3]; int dir; };
 struct GrownB { Range3 r; int g[3]; FV fine, crse; GrownArgs A;
   static __device__ double body(const GrownB &a_, int i, int j, int k, int) {
@@ -568,6 +637,14 @@ extern "C" int vdn_ml_cc_restriction(vdn_multifab *crse, const vdn_multifab *fin
 extern "C" int vdn_ml_edge_restriction(vdn_multifab *crse, const vdn_multifab *fine, int dir) { VDN_TRY ml_edge_restriction(crse, fine, dir); VDN_CATCH }
 extern "C" int vdn_multifab_fill_ghost_cells(vdn_multifab *fine, const vdn_multifab *crse, int icomp, int nc) { VDN_TRY ml_fill_ghost_cells(fine, crse, icomp, nc); VDN_CATCH }
 extern "C" int vdn_create_umac_grown(vdn_multifab *fine, const vdn_multifab *crse, int dir) { VDN_TRY ml_create_umac_grown(fine, crse, dir); VDN_CATCH }
+extern "C" int vdn_fillpatch(vdn_multifab *fine, const vdn_multifab *crse, int icomp, int nc) { VDN_TRY ml_fillpatch(fine, crse, icomp, nc); VDN_CATCH }
+extern "C" int vdn_ml_nodal_prolongation(vdn_multifab *fine, vdn_multifab *crse) { VDN_TRY ml_nodal_prolongation(fine, crse); VDN_CATCH }
+extern "C" int vdn_multifab_copy_layouts(vdn_multifab *dst, int dcomp, const vdn_multifab *src, int scomp, int nc) {
+  VDN_TRY
+  REQUIRE(dcomp >= 0 && dcomp + nc <= dst->nc && scomp >= 0 && scomp + nc <= src->nc, "copy between layouts: component range");
+  mf_copy_layouts(dst, dcomp, src, scomp, nc);
+  VDN_CATCH
+}
 extern "C" int vdn_ml_restrict_and_fill(int nlev, vdn_multifab **mf, int icomp, int bcomp, int nc, int same_boundary, const vdn_bc_tower *bct) {
   VDN_TRY ml_restrict_and_fill(nlev, mf, icomp, bcomp, nc, same_boundary != 0, bct); VDN_CATCH
 }

@@ -174,14 +174,18 @@ class VardenAMR:
     levels 2.. (one properly nested box each but the last).  The loop body of src/varden.f90: ml_restrict_and_fill ghost fills,
     dt = min over levels of estdt, advance_timestep, new -> old copies."""
 
-    def __init__(self, nc, fine_boxes, phys_bc, params=None, prob_type=1, grav=-9.8, init_shrink=0.1, device=0, finer_levels=()):
+    def __init__(self, nc, fine_boxes, phys_bc, params=None, prob_type=1, grav=-9.8, init_shrink=0.1, device=0, finer_levels=(),
+                 regrid_int=-1, max_levs=None, max_grid_size=256):
         self.prm = params or default_params()
+        self.grav, self.regrid_int, self.max_grid_size = grav, regrid_int, max_grid_size
         self.prm.prob_type = prob_type
         bl.initialize(self.prm, 0, 1, device)
         self.nc = nc
         self.phys = [[int(phys_bc[d][s]) for s in range(2)] for d in range(3)]
         lev_boxes = [fine_boxes] + list(finer_levels)
         self.nlev = NL = 1 + len(lev_boxes)
+        self.max_levs = max_levs or NL
+        self.nregrids = 0
         pd = [((0, 0, 0), ((nc << n) - 1,) * 3) for n in range(NL)]
         self.boxes = [[pd[0]]] + [[(tuple(b[0]), tuple(b[1])) for b in lb] for lb in lev_boxes]
         self.mla = bl.MLLayout(pd, self.boxes, rr=[(2, 2, 2)] * (NL - 1))
@@ -247,6 +251,8 @@ class VardenAMR:
 
     def step(self):
         self.istep += 1
+        if self.max_levs > 1 and self.regrid_int > 0 and self.istep > 1 and (self.istep - 1) % self.regrid_int == 0:   # varden.f90:256-264
+            self.regrid()
         self.fill_state_ghosts()
         if self.istep > 1:
             self.dt = self.estdt(self.dt)
@@ -256,6 +262,86 @@ class VardenAMR:
             self.uold[n].copy_c(0, self.unew[n], 0, self.dm, 0)
             self.sold[n].copy_c(0, self.snew[n], 0, self.nscal, 0)
         self.time += self.dt
+
+    # ---- regridding (src/regrid.f90:17-263) ------------------------------------------------------------------------------------
+    def _alloc_state(self, boxes):
+        """layout, bc tower and the four carried state multifabs (uold, sold, gp, p) on the given box lists"""
+        NL = len(boxes)
+        pd = [((0, 0, 0), ((self.nc << n) - 1,) * 3) for n in range(NL)]
+        mla = bl.MLLayout(pd, boxes, rr=[(2, 2, 2)] * (NL - 1))
+        bct = bl.BCTower(mla, self.phys)
+        mk = lambda nc_, ng, nodal=None: [bl.MultiFab(mla, n, nc_, ng, nodal) for n in range(NL)]   # noqa: E731
+        st = dict(mla=mla, bct=bct, boxes=boxes, uold=mk(self.dm, 3), sold=mk(self.nscal, 3), gp=mk(self.dm, 1), p=mk(1, 1, (1, 1, 1)))
+        for m in st["p"]:
+            m.setval(0.0, all=True)                                               # regrid.f90:298
+        return st
+
+    @staticmethod
+    def _free_state(st):
+        for k in ("uold", "sold", "gp", "p"):
+            for m in st[k]:
+                m.destroy()
+        st["bct"].destroy()
+        st["mla"].destroy()
+
+    def _fill_levels(self, st, nl):
+        """ghost cells of the levels 0 .. nl-1 (what tagging with ghost cells and fillpatch read)"""
+        adv.ml_restrict_and_fill(st["uold"][:nl], 0, 0, self.dm, st["bct"])
+        adv.ml_restrict_and_fill(st["sold"][:nl], 0, self.dm, self.nscal, st["bct"])
+        adv.ml_restrict_and_fill(st["gp"][:nl], 0, self.press_comp, self.dm, st["bct"], same_boundary=True)
+
+    def regrid(self, buf_wid=None):
+        """new grids from the current state, level by level: tag_boxes + make_new_grids on the (already regridded) level below, then
+        build_and_fill_data (regrid.f90:269-339): interpolate from the coarser level, copy the old data of the level over it"""
+        buf = max(self.regrid_int, 1) if buf_wid is None else buf_wid             # amr_buf_width >= regrid_int, probin.template:147-154
+        old = dict(mla=self.mla, bct=self.bct, uold=self.uold, sold=self.sold, gp=self.gp, p=self.p)
+        old_nlev = self.nlev
+        comps = (("uold", self.dm), ("sold", self.nscal), ("gp", self.dm), ("p", 1))
+        cur = self._alloc_state([self.boxes[0]])
+        for k, nc_ in comps:
+            adv.copy_layouts(cur[k][0], 0, old[k][0], 0, nc_)
+        lev = 1
+        while lev < self.max_levs:
+            self._fill_levels(cur, lev)
+            new, _ = adv.make_new_grids(cur["sold"][lev - 1], lev, buf_wid=buf, nest=0 if lev == 1 else 2, min_eff=prm_cluster(self.prm, "min_eff"),
+                                        min_width=prm_cluster(self.prm, "min_width"), blocking=prm_cluster(self.prm, "blocking"), max_grid_size=self.max_grid_size)
+            if not new:
+                break
+            nxt = self._alloc_state(cur["boxes"] + [new])
+            for n in range(lev):
+                for k, nc_ in comps:
+                    adv.copy_layouts(nxt[k][n], 0, cur[k][n], 0, nc_)
+            self._fill_levels(nxt, lev)
+            adv.fillpatch(nxt["uold"][lev], nxt["uold"][lev - 1], 0, self.dm)
+            adv.fillpatch(nxt["sold"][lev], nxt["sold"][lev - 1], 0, self.nscal)
+            adv.fillpatch(nxt["gp"][lev], nxt["gp"][lev - 1], 0, self.dm)
+            adv.ml_nodal_prolongation(nxt["p"][lev], nxt["p"][lev - 1])
+            if old_nlev > lev:
+                for k, nc_ in comps:
+                    adv.copy_layouts(nxt[k][lev], 0, old[k][lev], 0, nc_)
+            self._free_state(cur)
+            cur = nxt
+            lev += 1
+        # the temporaries of the old hierarchy go, the new one takes over
+        for lst in (self.unew, self.snew, self.ext_vel_force, self.ext_scal_force):
+            for m in lst:
+                m.destroy()
+        self._free_state(old)
+        self.mla, self.bct, self.boxes = cur["mla"], cur["bct"], cur["boxes"]
+        self.uold, self.sold, self.gp, self.p = cur["uold"], cur["sold"], cur["gp"], cur["p"]
+        self.nlev = NL = len(self.boxes)
+        self.dx = [[1.0 / (self.nc << n)] * 3 for n in range(NL)]
+        mk = lambda nc_, ng: [bl.MultiFab(self.mla, n, nc_, ng) for n in range(NL)]   # noqa: E731
+        self.unew, self.snew = mk(self.dm, 3), mk(self.nscal, 3)
+        self.ext_vel_force, self.ext_scal_force = mk(self.dm, 1), mk(self.nscal, 1)
+        for n in range(NL):
+            self.ext_vel_force[n].setval(self.grav, self.dm - 1, 1, all=True)
+        self.fill_state_ghosts()                                                  # regrid.f90:252-254
+        for n in range(NL):
+            self.unew[n].copy_c(0, self.uold[n], 0, self.dm, 3)
+            self.snew[n].copy_c(0, self.sold[n], 0, self.nscal, 3)
+            self.p[n].fill_boundary()
+        self.nregrids += 1
 
     def close(self):
         for lst in (self.uold, self.sold, self.unew, self.snew, self.gp, self.p, self.ext_vel_force, self.ext_scal_force):
