@@ -232,6 +232,30 @@ module varden_amd
        type(c_ptr), intent(in) :: mf(*)
        type(c_ptr), value :: bct
      end function
+     integer(c_int) function vdn_fillpatch(fine, crse, icomp, nc) bind(C, name="vdn_fillpatch")
+       import :: c_int, c_ptr
+       type(c_ptr), value :: fine, crse
+       integer(c_int), value :: icomp, nc
+     end function
+     integer(c_int) function vdn_ml_nodal_prolongation(fine, crse) bind(C, name="vdn_ml_nodal_prolongation")
+       import :: c_int, c_ptr
+       type(c_ptr), value :: fine, crse
+     end function
+     integer(c_int) function vdn_multifab_copy_layouts(dst, dcomp, src, scomp, nc) bind(C, name="vdn_multifab_copy_layouts")
+       import :: c_int, c_ptr
+       type(c_ptr), value :: dst, src
+       integer(c_int), value :: dcomp, scomp, nc
+     end function
+     integer(c_int) function vdn_make_new_grids(s, lev1, buf_wid, nest, min_eff, min_width, blocking, max_grid_size, maxboxes, boxes_out, &
+                                                nboxes_out, ntagged) bind(C, name="vdn_make_new_grids")
+       import :: c_int, c_ptr, c_double, c_long, vdn_box
+       type(c_ptr), value :: s
+       integer(c_int), value :: lev1, buf_wid, nest, min_width, blocking, max_grid_size, maxboxes
+       real(c_double), value :: min_eff
+       type(vdn_box), intent(out) :: boxes_out(*)
+       integer(c_int), intent(out) :: nboxes_out
+       integer(c_long), intent(out) :: ntagged
+     end function
      integer(c_size_t) function c_strlen(s) bind(C, name="strlen")
        import :: c_ptr, c_size_t
        type(c_ptr), value :: s
@@ -542,6 +566,38 @@ contains
     call chk(vdn_ml_restrict_and_fill(int(nlevs, c_int), handles(mf), int(icomp - 1, c_int), int(bcomp - 1, c_int), int(nc, c_int), &
                                       merge(1_c_int, 0_c_int, same_boundary), the_bc_tower%h), 'ml_restrict_and_fill')
   end subroutine ml_restrict_and_fill
+
+  ! fillpatch(fine, crse, 0, ...) / ml_nodal_prolongation / multifab_copy_c across box lists: src/regrid.f90:311-337
+  subroutine fillpatch(fine, crse, icomp, nc)
+    type(multifab), intent(inout) :: fine
+    type(multifab), intent(in   ) :: crse
+    integer       , intent(in   ) :: icomp, nc
+    call chk(vdn_fillpatch(fine%h, crse%h, int(icomp - 1, c_int), int(nc, c_int)), 'fillpatch')
+  end subroutine fillpatch
+  subroutine ml_nodal_prolongation(fine, crse)
+    type(multifab), intent(inout) :: fine, crse
+    call chk(vdn_ml_nodal_prolongation(fine%h, crse%h), 'ml_nodal_prolongation')
+  end subroutine ml_nodal_prolongation
+  subroutine multifab_copy_layouts(dst, dcomp, src, scomp, nc)
+    type(multifab), intent(inout) :: dst
+    type(multifab), intent(in   ) :: src
+    integer       , intent(in   ) :: dcomp, scomp, nc
+    call chk(vdn_multifab_copy_layouts(dst%h, int(dcomp - 1, c_int), src%h, int(scomp - 1, c_int), int(nc, c_int)), 'multifab_copy_c')
+  end subroutine multifab_copy_layouts
+  ! tag_boxes + make_new_grids (src/initialize.f90:247-248, src/regrid.f90:148-149): the boxes of level lev+1 from the state of level lev
+  subroutine make_new_grids(new_grid, mf, lev, buf_wid, nest, max_grid_size, boxes, nboxes)
+    logical       , intent(  out) :: new_grid
+    type(multifab), intent(in   ) :: mf
+    integer       , intent(in   ) :: lev, buf_wid, nest, max_grid_size
+    type(vdn_box) , intent(  out) :: boxes(:)
+    integer       , intent(  out) :: nboxes
+    integer(c_int)  :: nb
+    integer(c_long) :: nt
+    call chk(vdn_make_new_grids(mf%h, int(lev, c_int), int(buf_wid, c_int), int(nest, c_int), 0.9_c_double, 4_c_int, 4_c_int, &
+                                int(max_grid_size, c_int), int(size(boxes), c_int), boxes, nb, nt), 'make_new_grids')
+    nboxes = nb
+    new_grid = nb > 0
+  end subroutine make_new_grids
 
   function handles(mfs) result(h)
     type(multifab), intent(in) :: mfs(:)
