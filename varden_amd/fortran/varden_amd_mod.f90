@@ -65,6 +65,7 @@ module varden_amd
             multifab_copy_to_host, multifab_copy_from_host, multifab_fab_size
   public :: advance_timestep, estdt, hgproject, macproject
   public :: ml_cc_restriction, ml_edge_restriction, multifab_fill_ghost_cells, create_umac_grown, ml_restrict_and_fill
+  public :: fillpatch, ml_nodal_prolongation, multifab_copy_layouts, make_new_grids
 
   interface
      subroutine vdn_params_default(p) bind(C, name="vdn_params_default")
