@@ -132,6 +132,7 @@ void vo_visc_solve(vo_fab *unew, const vo_fab *lapu, const vo_fab *rho, const vo
                    const vo_bc *bc, const int pmask[3], const vdn_params *prm, vo_mgstat *st);
 void vo_diff_scalar_solve(vo_fab *snew, const vo_fab *laps, const double dx[3], double mu, const vo_bc *bc, const int pmask[3],
                           const vdn_params *prm, int icomp, int bccomp, vo_mgstat *st);
+void vo_cc_smooth_ab(const vo_fab *rh, vo_fab *phi, const vo_fab *alpha, vo_fab *beta[3], const double dx[3], const int ellbc[3][2], int nsweeps);
 void vo_cc_smooth(const vo_fab *rh, vo_fab *phi, vo_fab *beta[3], const double dx[3], const int ellbc[3][2],
                   int nsweeps);
 /* macproject.f90:20-133, single level */
@@ -174,13 +175,15 @@ void vo_fill_ghost_cells(vo_fab *fine, const vo_fab *crse, int icomp, int nc);
 void vo_create_umac_grown(vo_fab *fine, const vo_fab *crse, int dir);
 void vo_ml_restrict_and_fill(int nlev, vo_fab **mf, int icomp, int bcomp, int nc, int same_boundary, const vo_bc *bc, const int pmask[3],
                              const int *pd, const vdn_params *prm);
-int  vo_ml_cc_solve(int nlev, vo_fab **rh, vo_fab **phi, vo_fab **beta, const double *dx, const int ellbc[][3][2], const int pmask[3], const int *pd,
+int  vo_ml_cc_solve(int nlev, vo_fab **rh, vo_fab **phi, vo_fab **alpha, vo_fab **beta, const double *dx, const int ellbc[][3][2], const int pmask[3], const int *pd,
                     double rel_eps, int max_iter, const vdn_params *prm, vo_mgstat *st);
 void vo_ml_macproject(int nlev, vo_fab **umac, vo_fab **rho, vo_fab **mac_rhs, const double *dx, const vo_bc *bc, const int pmask[3], const int *pd,
                       const vdn_params *prm, vo_mgstat *st);
 
 int  vo_ml_nd_solve(int nlev, vo_fab **rh, vo_fab **phi, vo_fab **coeffs, vo_fab **u, const double *dx, const int ellbc[][3][2], const int pmask[3],
                     double rel_eps, double abs_eps, int max_iter, const vdn_params *prm, vo_mgstat *st);
+void vo_ml_visc_solve(int nlev, vo_fab **unew, vo_fab **lapu, vo_fab **rho, vo_fab **mac_rhs, const double *dx, double mu, const vo_bc *bc,
+                      const int pmask[3], const int *pd, const vdn_params *prm, vo_mgstat *st);
 void vo_ml_hgproject(int nlev, int proj_type, vo_fab **unew, vo_fab **uold, vo_fab **rhohalf, vo_fab **p, vo_fab **gp, const double *dx, double dt,
                      const vo_bc *bc, const int pmask[3], const int *pd, const vdn_params *prm, vo_mgstat *st);
 

@@ -168,7 +168,7 @@ static void cf_interp(vo_fab *pf, const vo_fab *pc, const int ellbc_f[3][2])
 }
 /* res = rh - A phi on the valid cells of one level, phi's ghost layer already filled; returns the max-norm over cells
  * where mask (may be NULL) is 0 */
-static double plain_residual(const vo_fab *rh, const vo_fab *phi, vo_fab *beta[3], const double dx[3], vo_fab *res)
+static double plain_residual(const vo_fab *rh, const vo_fab *phi, const vo_fab *alpha, vo_fab *beta[3], const double dx[3], vo_fab *res)
 {
   const int *lo = rh->lo, *hi = rh->hi;
   const double hi2[3] = { 1.0 / (dx[0] * dx[0]), 1.0 / (dx[1] * dx[1]), 1.0 / (dx[2] * dx[2]) };
@@ -178,7 +178,9 @@ static double plain_residual(const vo_fab *rh, const vo_fab *phi, vo_fab *beta[3
     const double ax = (VF(beta[0], i + 1, j, k, 0) * (p0 - VF(phi, i + 1, j, k, 0)) + VF(beta[0], i, j, k, 0) * (p0 - VF(phi, i - 1, j, k, 0))) * hi2[0];
     const double ay = (VF(beta[1], i, j + 1, k, 0) * (p0 - VF(phi, i, j + 1, k, 0)) + VF(beta[1], i, j, k, 0) * (p0 - VF(phi, i, j - 1, k, 0))) * hi2[1];
     const double az = (VF(beta[2], i, j, k + 1, 0) * (p0 - VF(phi, i, j, k + 1, 0)) + VF(beta[2], i, j, k, 0) * (p0 - VF(phi, i, j, k - 1, 0))) * hi2[2];
-    const double r = VF(rh, i, j, k, 0) - (ax + ay + az);
+    double Ap = ax + ay + az;
+    if (alpha) Ap = Ap + VF(alpha, i, j, k, 0) * p0;
+    const double r = VF(rh, i, j, k, 0) - Ap;
     VF(res, i, j, k, 0) = r;
     nrm = fmax(nrm, fabs(r));
   }
@@ -235,10 +237,10 @@ static void fill_phi_ghosts(int nlev, vo_fab **phi, ellbc_t ellbc, const int pma
 }
 /* composite residual on every level; res[n] on cells covered by level n+1 = restriction of res[n+1]; returns the composite max-norm
  * (cells of each level that are not covered by the next finer one) */
-static double composite_residual(int nlev, vo_fab **rh, vo_fab **phi, vo_fab **beta, const double *dx, ellbc_t ellbc, const int pmask[3], const int *pd, vo_fab **res)
+static double composite_residual(int nlev, vo_fab **rh, vo_fab **phi, vo_fab **alpha, vo_fab **beta, const double *dx, ellbc_t ellbc, const int pmask[3], const int *pd, vo_fab **res)
 {
   fill_phi_ghosts(nlev, phi, ellbc, pmask, pd);
-  for (int n = 0; n < nlev; n++) (void)plain_residual(rh[n], phi[n], beta + 3 * n, dx + 3 * n, res[n]);
+  for (int n = 0; n < nlev; n++) (void)plain_residual(rh[n], phi[n], alpha ? alpha[n] : NULL, beta + 3 * n, dx + 3 * n, res[n]);
   for (int n = 1; n < nlev; n++) reflux_residual(res[n - 1], phi[n - 1], beta + 3 * (n - 1), dx + 3 * (n - 1), phi[n], beta + 3 * n, dx + 3 * n, ellbc[n]);
   for (int n = nlev - 1; n >= 1; n--) vo_ml_cc_restriction(res[n - 1], res[n], 0, 1);
   double nrm = 0.0;
@@ -267,10 +269,27 @@ static void apply_correction(int nlev, int n, vo_fab **phi, vo_fab *e, vo_fab *s
  * One FAC iteration: composite residual / test; for n = finest..1: nu1 red-black sweeps on level n (homogeneous interface), correction
  * applied to level n and prolonged to the finer ones, composite residual; ONE V-cycle of the single-level multigrid on level 0, applied
  * and prolonged, composite residual; for n = 1..finest: nu2 sweeps on level n, applied and prolonged (composite residual before the next). */
-int vo_ml_cc_solve(int nlev, vo_fab **rh, vo_fab **phi, vo_fab **beta, const double *dx, const int ellbc[][3][2], const int pmask[3], const int *pd,
+int vo_ml_cc_solve(int nlev, vo_fab **rh, vo_fab **phi, vo_fab **alpha, vo_fab **beta, const double *dx, const int ellbc[][3][2], const int pmask[3], const int *pd,
                    double rel_eps, int max_iter, const vdn_params *prm, vo_mgstat *st)
 {
   if (nlev < 2 || nlev > VO_MAXLEV) { fprintf(stderr, "vo_ml_cc_solve: 2..%d levels\n", VO_MAXLEV); abort(); }
+  /* inhomogeneous Dirichlet data: the ghost cells of the incoming phi hold the boundary-FACE values (viscsolve.f90:270); the face term
+   * 2b(phi_i - phi_b)/h^2 keeps its phi_i part in the operator (closure ghost = -phi_i) and its phi_b part goes to the right-hand side,
+   * in the order x-lo, x-hi, y-lo, y-hi, z-lo, z-hi (as cc_load of the single-level solver) */
+  for (int n = 0; n < nlev; n++) {
+    const int *lo = rh[n]->lo, *hi = rh[n]->hi;
+    const double hi2[3] = { 1.0 / (dx[3 * n] * dx[3 * n]), 1.0 / (dx[3 * n + 1] * dx[3 * n + 1]), 1.0 / (dx[3 * n + 2] * dx[3 * n + 2]) };
+    for (int k = lo[2]; k <= hi[2]; k++) for (int j = lo[1]; j <= hi[1]; j++) for (int i = lo[0]; i <= hi[0]; i++) {
+      double r = VF(rh[n], i, j, k, 0);
+      if (i == lo[0] && ellbc[n][0][0] == VDN_BC_DIR) r = r + (2.0 * VF(beta[3 * n], i, j, k, 0)) * VF(phi[n], i - 1, j, k, 0) * hi2[0];
+      if (i == hi[0] && ellbc[n][0][1] == VDN_BC_DIR) r = r + (2.0 * VF(beta[3 * n], i + 1, j, k, 0)) * VF(phi[n], i + 1, j, k, 0) * hi2[0];
+      if (j == lo[1] && ellbc[n][1][0] == VDN_BC_DIR) r = r + (2.0 * VF(beta[3 * n + 1], i, j, k, 0)) * VF(phi[n], i, j - 1, k, 0) * hi2[1];
+      if (j == hi[1] && ellbc[n][1][1] == VDN_BC_DIR) r = r + (2.0 * VF(beta[3 * n + 1], i, j + 1, k, 0)) * VF(phi[n], i, j + 1, k, 0) * hi2[1];
+      if (k == lo[2] && ellbc[n][2][0] == VDN_BC_DIR) r = r + (2.0 * VF(beta[3 * n + 2], i, j, k, 0)) * VF(phi[n], i, j, k - 1, 0) * hi2[2];
+      if (k == hi[2] && ellbc[n][2][1] == VDN_BC_DIR) r = r + (2.0 * VF(beta[3 * n + 2], i, j, k + 1, 0)) * VF(phi[n], i, j, k + 1, 0) * hi2[2];
+      VF(rh[n], i, j, k, 0) = r;
+    }
+  }
   vo_fab res[VO_MAXLEV], e[VO_MAXLEV], scr[VO_MAXLEV], *rp[VO_MAXLEV];
   for (int n = 0; n < nlev; n++) { fab_like(&res[n], rh[n], 0, 0.0); fab_like(&e[n], rh[n], 1, 0.0); fab_like(&scr[n], rh[n], 0, 0.0); rp[n] = &res[n]; }
   /* norm of the right-hand side over the composite grid */
@@ -281,25 +300,25 @@ int vo_ml_cc_solve(int nlev, vo_fab **rh, vo_fab **phi, vo_fab **beta, const dou
   int it = 0, conv = 0; double rn = 0.0;
   if (bnorm == 0.0) conv = 1;
   while (!conv) {
-    rn = composite_residual(nlev, rh, phi, beta, dx, ellbc, pmask, pd, rp);
+    rn = composite_residual(nlev, rh, phi, alpha, beta, dx, ellbc, pmask, pd, rp);
     if (rn <= rel_eps * bnorm) { conv = 1; break; }
     if (it >= max_iter) break;
     for (int n = nlev - 1; n >= 1; n--) {               /* pre-relaxation, finest first */
       memset(e[n].p, 0, sizeof(double) * vo_size(&e[n]));
-      vo_cc_smooth(&res[n], &e[n], beta + 3 * n, dx + 3 * n, ellbc[n], prm->mg_nu1);
+      vo_cc_smooth_ab(&res[n], &e[n], alpha ? alpha[n] : NULL, beta + 3 * n, dx + 3 * n, ellbc[n], prm->mg_nu1);
       apply_correction(nlev, n, phi, e, scr);
-      (void)composite_residual(nlev, rh, phi, beta, dx, ellbc, pmask, pd, rp);
+      (void)composite_residual(nlev, rh, phi, alpha, beta, dx, ellbc, pmask, pd, rp);
     }
     /* coarse correction: ONE V-cycle of the single-level multigrid on the whole coarse level */
     memset(e[0].p, 0, sizeof(double) * vo_size(&e[0]));
     vo_mgstat cs;
-    vo_cc_solve_ab(&res[0], &e[0], NULL, beta, dx, ellbc[0], 0.0, -1.0, -1, prm->mg_nu1, prm->mg_nu2, prm->mg_nub, &cs);
+    vo_cc_solve_ab(&res[0], &e[0], alpha ? alpha[0] : NULL, beta, dx, ellbc[0], 0.0, -1.0, -1, prm->mg_nu1, prm->mg_nu2, prm->mg_nub, &cs);
     apply_correction(nlev, 0, phi, e, scr);
     for (int n = 1; n < nlev; n++) {                    /* post-relaxation, coarsest first */
-      if (n < nlev - 1) (void)composite_residual(nlev, rh, phi, beta, dx, ellbc, pmask, pd, rp);
-      else { fill_phi_ghosts(nlev, phi, ellbc, pmask, pd); (void)plain_residual(rh[n], phi[n], beta + 3 * n, dx + 3 * n, &res[n]); }
+      if (n < nlev - 1) (void)composite_residual(nlev, rh, phi, alpha, beta, dx, ellbc, pmask, pd, rp);
+      else { fill_phi_ghosts(nlev, phi, ellbc, pmask, pd); (void)plain_residual(rh[n], phi[n], alpha ? alpha[n] : NULL, beta + 3 * n, dx + 3 * n, &res[n]); }
       memset(e[n].p, 0, sizeof(double) * vo_size(&e[n]));
-      vo_cc_smooth(&res[n], &e[n], beta + 3 * n, dx + 3 * n, ellbc[n], prm->mg_nu2);
+      vo_cc_smooth_ab(&res[n], &e[n], alpha ? alpha[n] : NULL, beta + 3 * n, dx + 3 * n, ellbc[n], prm->mg_nu2);
       apply_correction(nlev, n, phi, e, scr);
     }
     it++;
@@ -335,13 +354,59 @@ void vo_ml_macproject(int nlev, vo_fab **umac, vo_fab **rho, vo_fab **mac_rhs, c
   /* mk_mac_coeffs (macproject.f90:296-334): rho's fine ghosts come from the caller's ml_restrict_and_fill; edge restriction */
   for (int n = 0; n < nlev; n++) vo_mk_mac_coeffs(rho[n], bp + 3 * n);
   for (int n = nlev - 1; n >= 1; n--) for (int d = 0; d < 3; d++) vo_ml_edge_restriction(bp[3 * (n - 1) + d], bp[3 * n + d], d);
-  vo_ml_cc_solve(nlev, rhp, php, bp, dx, (const int (*)[3][2])ellbc, pmask, pd, prm->mac_rel_eps, prm->mg_max_iter, prm, st);
+  vo_ml_cc_solve(nlev, rhp, php, NULL, bp, dx, (const int (*)[3][2])ellbc, pmask, pd, prm->mac_rel_eps, prm->mg_max_iter, prm, st);
   /* mkumac on every level with the solver's ghost cells, then edge restriction and the ghost faces (macproject.f90:103-119) */
   for (int n = 0; n < nlev; n++) vo_mkumac(umac + 3 * n, &phi[n], bp + 3 * n, dx + 3 * n, ellbc[n]);
   for (int n = nlev - 1; n >= 1; n--) for (int d = 0; d < 3; d++) vo_ml_edge_restriction(umac[3 * (n - 1) + d], umac[3 * n + d], d);
   for (int d = 0; d < 3; d++) level_fill_boundary(umac[d], pmask, pd, pd + 3);
   for (int n = 1; n < nlev; n++) for (int d = 0; d < 3; d++) { vo_create_umac_grown(umac[3 * n + d], umac[3 * (n - 1) + d], d); level_fill_boundary(umac[3 * n + d], pmask, pd + 6 * n, pd + 6 * n + 3); }
   for (int n = 0; n < nlev; n++) { free(rh[n].p); free(phi[n].p); for (int d = 0; d < 3; d++) free(beta[3 * n + d].p); }
+}
+
+/* visc_solve (viscsolve.f90:19-306) on nlev levels: per velocity component the composite solve of (rho - div mu grad) u = rhs.
+ * unew: [lev] (ghost cells filled: they carry the wall values), lapu / rho / mac_rhs: [lev] */
+void vo_ml_visc_solve(int nlev, vo_fab **unew, vo_fab **lapu, vo_fab **rho, vo_fab **mac_rhs, const double *dx, double mu, const vo_bc *bc,
+                      const int pmask[3], const int *pd, const vdn_params *prm, vo_mgstat *st)
+{
+  vo_fab rh[VO_MAXLEV], phi[VO_MAXLEV], alpha[VO_MAXLEV], beta[3 * VO_MAXLEV], *rhp[VO_MAXLEV], *php[VO_MAXLEV], *alp[VO_MAXLEV], *bp[3 * VO_MAXLEV];
+  int ellbc[VO_MAXLEV][3][2];
+  for (int n = 0; n < nlev; n++) {
+    fab_like(&rh[n], rho[n], 0, 0.0); fab_like(&phi[n], rho[n], 1, 0.0); fab_like(&alpha[n], rho[n], 0, 0.0);
+    rhp[n] = &rh[n]; php[n] = &phi[n]; alp[n] = &alpha[n];
+    for (int d = 0; d < 3; d++) {
+      int nd[3] = { 0, 0, 0 }; nd[d] = 1;
+      vo_fab_init(&beta[3 * n + d], NULL, rho[n]->lo, rho[n]->hi, 0, nd, 1);
+      long sz = vo_size(&beta[3 * n + d]);
+      beta[3 * n + d].p = (double *)malloc(sizeof(double) * sz);
+      for (long q = 0; q < sz; q++) beta[3 * n + d].p[q] = mu;
+      bp[3 * n + d] = &beta[3 * n + d];
+    }
+    for (int k = rho[n]->lo[2]; k <= rho[n]->hi[2]; k++) for (int j = rho[n]->lo[1]; j <= rho[n]->hi[1]; j++) for (int i = rho[n]->lo[0]; i <= rho[n]->hi[0]; i++)
+      VF(&alpha[n], i, j, k, 0) = VF(rho[n], i, j, k, 0);
+  }
+  const double third = 1.0 / 3.0;
+  const double visc_mu_dt = (prm->diffusion_type == 1) ? 2.0 * mu : mu;
+  for (int d = 0; d < 3; d++) {
+    for (int n = 0; n < nlev; n++) {
+      const int *lo = unew[n]->lo, *hi = unew[n]->hi;
+      for (int k = lo[2] - 1; k <= hi[2] + 1; k++) for (int j = lo[1] - 1; j <= hi[1] + 1; j++) for (int i = lo[0] - 1; i <= hi[0] + 1; i++)
+        VF(&phi[n], i, j, k, 0) = VF(unew[n], i, j, k, d);
+      for (int k = lo[2]; k <= hi[2]; k++) for (int j = lo[1]; j <= hi[1]; j++) for (int i = lo[0]; i <= hi[0]; i++) {
+        double r = VF(unew[n], i, j, k, d) * VF(rho[n], i, j, k, 0);
+        if (prm->diffusion_type == 1) r = r + mu * VF(lapu[n], i, j, k, d);
+        int p[3] = { i, j, k }, m[3] = { i, j, k }; p[d] += 1; m[d] -= 1;
+        r = r + third * visc_mu_dt * (VF(mac_rhs[n], p[0], p[1], p[2], 0) - VF(mac_rhs[n], m[0], m[1], m[2], 0)) / dx[3 * n + d];
+        VF(&rh[n], i, j, k, 0) = r;
+      }
+      for (int a = 0; a < 3; a++) for (int s = 0; s < 2; s++) ellbc[n][a][s] = bc[n].ell[a][s][d];
+    }
+    vo_ml_cc_solve(nlev, rhp, php, alp, bp, dx, (const int (*)[3][2])ellbc, pmask, pd, 1.e-12, prm->mg_max_iter, prm, st);
+    for (int n = 0; n < nlev; n++)
+      for (int k = unew[n]->lo[2]; k <= unew[n]->hi[2]; k++) for (int j = unew[n]->lo[1]; j <= unew[n]->hi[1]; j++) for (int i = unew[n]->lo[0]; i <= unew[n]->hi[0]; i++)
+        VF(unew[n], i, j, k, d) = VF(&phi[n], i, j, k, 0);
+  }
+  vo_ml_restrict_and_fill(nlev, unew, 0, 0, 3, 0, bc, pmask, pd, prm);           /* viscsolve.f90:106 */
+  for (int n = 0; n < nlev; n++) { free(rh[n].p); free(phi[n].p); free(alpha[n].p); for (int d = 0; d < 3; d++) free(beta[3 * n + d].p); }
 }
 
 /* hgproject.f90:17-178 with nlevs > 1 (rel tolerance 1e-11 for two levels, 1e-10 for more: hgproject.f90:115-119) */
@@ -403,8 +468,16 @@ void vo_ml_advance_timestep(int NL, vo_state *S, const double *dx, double dt, co
     for (int d = 0; d < 3; d++) { fab_new_l(&umac[3 * n + d], &S[n].uold, 1, d, 1, 1.e20); ump[3 * n + d] = &umac[3 * n + d]; }
     fab_new_l(&vel_force[n], &S[n].uold, 1, -1, dm, 0.0); vfp[n] = &vel_force[n];
   }
+  /* lapu (advance_timestep.f90:85-93; get_explicit_diffusive_term = cc_applyop per level on the filled ghost cells, then average down) */
+  const int viscous = prm->visc_coef > 0.0;
+  vo_fab lapu[VO_MAXLEV], *lap[VO_MAXLEV];
+  for (int n = 0; n < NL; n++) {
+    fab_new_l(&lapu[n], &S[n].uold, 0, -1, dm, 0.0); lap[n] = &lapu[n];
+    if (viscous) for (int c = 0; c < dm; c++) vo_explicit_diffusive_term(&lapu[n], &S[n].uold, c, c, dx + 3 * n, &bc[n]);
+  }
+  if (viscous) for (int n = NL - 1; n >= 1; n--) vo_ml_cc_restriction(lap[n - 1], lap[n], 0, dm);
   /* advance_premac */
-  for (int n = 0; n < NL; n++) vo_mkvelforce(&vel_force[n], &S[n].ext_vel_force, &S[n].gp, &S[n].sold, NULL, 1.0, prm);
+  for (int n = 0; n < NL; n++) vo_mkvelforce(&vel_force[n], &S[n].ext_vel_force, &S[n].gp, &S[n].sold, viscous ? &lapu[n] : NULL, 1.0, prm);
   vo_ml_restrict_and_fill(NL, vfp, 0, bc[0].extrap_comp, dm, 1, bc, pmask, pd, prm);
   for (int n = 0; n < NL; n++) vo_velpred(&S[n].uold, ump + 3 * n, &vel_force[n], dx + 3 * n, dt, &bc[n], prm);
   for (int d = 0; d < 3; d++) level_fill_boundary(&umac[d], pmask, pd, pd + 3);
@@ -433,23 +506,29 @@ void vo_ml_advance_timestep(int NL, vo_state *S, const double *dx, double dt, co
   }
   for (int n = 0; n < NL; n++) vo_make_at_halftime(&rhohalf[n], 0, &S[n].sold, &S[n].snew, 0);
   vo_ml_restrict_and_fill(NL, rhp, 0, dm + 0, 1, 0, bc, pmask, pd, prm);
+  if (viscous && prm->diffusion_type == 2) for (int n = 0; n < NL; n++) memset(lapu[n].p, 0, sizeof(double) * vo_size(&lapu[n]));    /* advance_timestep.f90:116-120 */
   /* velocity advance */
   {
     int is_cons[3] = { 0, 0, 0 };
     for (int n = 0; n < NL; n++) {
       for (int d = 0; d < 3; d++) { fab_new_l(&uflux[3 * n + d], &S[n].uold, 0, d, dm, 0.0); fab_new_l(&uedge[3 * n + d], &S[n].uold, 0, d, dm, 0.0); ufp[3 * n + d] = &uflux[3 * n + d]; uep[3 * n + d] = &uedge[3 * n + d]; }
-      vo_mkvelforce(&vel_force[n], &S[n].ext_vel_force, &S[n].gp, &S[n].sold, NULL, 1.0, prm);
+      vo_mkvelforce(&vel_force[n], &S[n].ext_vel_force, &S[n].gp, &S[n].sold, viscous ? &lapu[n] : NULL, 1.0, prm);
     }
     vo_ml_restrict_and_fill(NL, vfp, 0, bc[0].extrap_comp, dm, 1, bc, pmask, pd, prm);
     for (int n = 0; n < NL; n++) {
       vo_mkflux(&S[n].uold, uep + 3 * n, ufp + 3 * n, ump + 3 * n, &vel_force[n], &mac_rhs[n], dx + 3 * n, dt, 1, is_cons, 0, &bc[n], prm);
-      vo_mkvelforce(&vel_force[n], &S[n].ext_vel_force, &S[n].gp, &rhohalf[n], NULL, 0.0, prm);
+      vo_mkvelforce(&vel_force[n], &S[n].ext_vel_force, &S[n].gp, &rhohalf[n], viscous ? &lapu[n] : NULL, 0.0, prm);
     }
     vo_ml_restrict_and_fill(NL, vfp, 0, bc[0].extrap_comp, dm, 1, bc, pmask, pd, prm);
     for (int n = 0; n < NL; n++) vo_update(&S[n].uold, ump + 3 * n, uep + 3 * n, ufp + 3 * n, &vel_force[n], &S[n].unew, dx + 3 * n, dt, 1, is_cons);
     vo_ml_restrict_and_fill(NL, unewp, 0, 0, dm, 0, bc, pmask, pd, prm);
+    if (viscous) {                                                                     /* velocity_advance.f90:103-118 */
+      const double visc_mu = (prm->diffusion_type == 1) ? 0.5 * dt * prm->visc_coef : dt * prm->visc_coef;
+      vo_mgstat vst;
+      vo_ml_visc_solve(NL, unewp, lap, rhp, mrp, dx, visc_mu, bc, pmask, pd, prm, &vst);
+    }
     for (int n = 0; n < NL; n++) for (int d = 0; d < 3; d++) { free(uflux[3 * n + d].p); free(uedge[3 * n + d].p); }
   }
   vo_ml_hgproject(NL, proj_type, unewp, uoldp, rhp, pp, gpp, dx, dt, bc, pmask, pd, prm, &st[1]);
-  for (int n = 0; n < NL; n++) { free(mac_rhs[n].p); free(rhohalf[n].p); free(vel_force[n].p); for (int d = 0; d < 3; d++) free(umac[3 * n + d].p); }
+  for (int n = 0; n < NL; n++) { free(mac_rhs[n].p); free(rhohalf[n].p); free(vel_force[n].p); free(lapu[n].p); for (int d = 0; d < 3; d++) free(umac[3 * n + d].p); }
 }

@@ -380,6 +380,14 @@ int vo_cc_solve_ab(const vo_fab *rh, vo_fab *phi, const vo_fab *alpha, vo_fab *b
   return conv ? 0 : 1;
 }
 
+void vo_cc_smooth_ab(const vo_fab *rh, vo_fab *phi, const vo_fab *alpha, vo_fab *beta[3], const double dx[3], const int ellbc[3][2], int nsweeps)
+{
+  ccmg M; ccmg_build(&M, alpha, beta, dx, ellbc);
+  cc_load(&M.lev[0], rh, phi, ellbc);
+  cc_gsrb(&M.lev[0], M.per, nsweeps);
+  cc_store(&M.lev[0], phi, ellbc, M.per);
+  ccmg_free(&M);
+}
 void vo_cc_smooth(const vo_fab *rh, vo_fab *phi, vo_fab *beta[3], const double dx[3], const int ellbc[3][2], int nsweeps)
 {
   ccmg M; ccmg_build(&M, NULL, beta, dx, ellbc);

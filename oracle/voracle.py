@@ -228,7 +228,7 @@ class SimML:
     around advance_timestep for nlevs > 1 (ghost fills by ml_restrict_and_fill, dt = min over levels of estdt).
     boxes: [(lo, hi)] of levels 1.. in each level's own index space."""
 
-    def __init__(self, nc, boxes, phys, prm=None, prob_type=1, grav=-9.8, init_shrink=0.1):
+    def __init__(self, nc, boxes, phys, prm=None, prob_type=1, grav=-9.8, init_shrink=0.1, init_iter=0, do_initial_projection=0):
         L = lib()
         self.prm = prm or default_params()
         self.prm.prob_type = prob_type
@@ -256,10 +256,22 @@ class SimML:
         self.mgstat = (CMgStat * 2)()
         self.time, self.istep = 0.0, 0
         self.fill_state_ghosts()
+        if do_initial_projection:                                 # varden.f90:126-138
+            rhohalf = [Fab(los[n], his[n], 1, 1, val=1.0) for n in range(NL)]
+            st = CMgStat()
+            L.vo_ml_hgproject(NL, INITIAL_PROJECTION, fab_ptr_array(self.uold), fab_ptr_array(self.uold), fab_ptr_array(rhohalf), fab_ptr_array(self.p),
+                              fab_ptr_array(self.gp), self.dx, C.c_double(1.0), self.bcs, self.pmask, self.pd, C.byref(self.prm), C.byref(st))
+            self.initial_projection_stat = (st.cycles, st.res0, st.res)
+            for n in range(NL):
+                self.p[n].a[...] = 0.0
+                self.gp[n].a[...] = 0.0
+            self.fill_state_ghosts()                              # varden.f90:165-178
         for n in range(NL):
             self.unew[n].a[...] = self.uold[n].a
             self.snew[n].a[...] = self.sold[n].a
         self.dt = self.estdt(1.0e20) * init_shrink
+        for _ in range(init_iter):                                # varden.f90:460-490
+            self._advance(PRESSURE_ITERS)
 
     def _rf(self, mfs, icomp, bcomp, nc, same=0):
         lib().vo_ml_restrict_and_fill(self.nlev, fab_ptr_array(mfs), icomp, bcomp, nc, same, self.bcs, self.pmask, self.pd, C.byref(self.prm))
@@ -274,16 +286,19 @@ class SimML:
         return min(L.vo_estdt(self.uold[n].ref, self.sold[n].ref, self.gp[n].ref, self.ext_vel_force[n].ref, dvec(self.dxl[n]),
                               C.c_double(dtold), C.byref(self.prm)) for n in range(self.nlev))
 
+    def _advance(self, proj_type):
+        S = (CState * self.nlev)()
+        for n in range(self.nlev):
+            for k in ("uold", "sold", "unew", "snew", "gp", "p", "ext_vel_force", "ext_scal_force"):
+                setattr(S[n], k, getattr(self, k)[n].c)
+        lib().vo_ml_advance_timestep(self.nlev, S, self.dx, C.c_double(self.dt), self.bcs, self.pmask, self.pd, C.byref(self.prm), proj_type, self.mgstat)
+
     def step(self):
         self.istep += 1
         self.fill_state_ghosts()
         if self.istep > 1:
             self.dt = self.estdt(self.dt)
-        S = (CState * self.nlev)()
-        for n in range(self.nlev):
-            for k in ("uold", "sold", "unew", "snew", "gp", "p", "ext_vel_force", "ext_scal_force"):
-                setattr(S[n], k, getattr(self, k)[n].c)
-        lib().vo_ml_advance_timestep(self.nlev, S, self.dx, C.c_double(self.dt), self.bcs, self.pmask, self.pd, C.byref(self.prm), REGULAR_TIMESTEP, self.mgstat)
+        self._advance(REGULAR_TIMESTEP)
         for n in range(self.nlev):
             self.uold[n].valid()[...] = self.unew[n].valid()
             self.sold[n].valid()[...] = self.snew[n].valid()

@@ -528,3 +528,57 @@ def test_regrid(gpu):
     H.step(); H.step()
     assert np.isfinite(H.snew[0].to_numpy(0)).all()
     H.close()
+
+
+@pytest.mark.parametrize("split,nlev", [(1, 2), (2, 2), (1, 3)])
+def test_multi_level_viscous_advance(gpu, oracle, split, nlev):
+    """exec/test/inputs_bubble_3d in miniature: visc_coef = 0.001 on a refined hierarchy -- the explicit diffusive term per level
+    (averaged down), the composite solves of (rho - div mu grad) u = rhs per velocity component (viscsolve.f90:19-306) with the
+    no-slip wall values in the ghost cells; HIP vs oracle after three steps, 1e-8 relative"""
+    from varden_amd import advance as adv
+    from varden_amd import driver
+    from varden_amd.capi import default_params
+    vo = oracle
+    flo, fhi = (8, 8, 8), (23, 23, 23)
+    finer = FINER if nlev == 3 else []
+    O = vo.SimML(16, [(flo, fhi)] + finer, WALLS, prm=default_params(cflfac=0.9, visc_coef=0.001))
+    fboxes = [(flo, fhi)] if split == 1 else [((8, 8, 8), (15, 23, 23)), ((16, 8, 8), (23, 23, 23))]
+    G = driver.VardenAMR(16, fboxes, WALLS, params=default_params(cflfac=0.9, visc_coef=0.001), finer_levels=[finer] if finer else [])
+    assert G.dt == O.dt
+    for _ in range(3):
+        O.step(); G.step()
+        assert abs(G.dt - O.dt) <= 1e-10 * O.dt
+        assert adv.last_solver_stats("mac")[0] == O.mgstat[0].cycles and adv.last_solver_stats("hg")[0] == O.mgstat[1].cycles
+    for n in range(nlev):
+        for nm, gm, om in (("u", G.unew, O.unew[n]), ("s", G.snew, O.snew[n])):
+            a = np.concatenate([gm[n].to_numpy(i)[3:-3, 3:-3, 3:-3] for i in range(gm[n].nfabs())], axis=0)
+            b = om.valid()
+            scale = max(np.abs(b).max(), 1e-300)
+            assert np.abs(a - b).max() <= 1e-8 * scale, "level %d %s differs by %.3e (scale %.3e)" % (n, nm, np.abs(a - b).max(), scale)
+    G.close()
+
+
+def test_two_level_start_up_sequence(gpu, oracle):
+    """the start-up of src/varden.f90 on two levels: initial projection (hgproject with proj_type = initial_projection, rhohalf = 1,
+    dt = 1; varden.f90:126-138), p = gp = 0, first dt, one pressure iteration (advance_timestep with proj_type = pressure_iters,
+    varden.f90:460-490), then two regular viscous steps -- HIP vs oracle"""
+    from varden_amd import advance as adv
+    from varden_amd import driver
+    from varden_amd.capi import default_params
+    vo = oracle
+    flo, fhi = (8, 8, 8), (23, 23, 23)
+    kw = dict(init_iter=1, do_initial_projection=1)
+    O = vo.SimML(16, [(flo, fhi)], WALLS, prm=default_params(cflfac=0.9, visc_coef=0.001), **kw)
+    G = driver.VardenAMR(16, [(flo, fhi)], WALLS, params=default_params(cflfac=0.9, visc_coef=0.001), **kw)
+    assert G.dt == O.dt
+    for n in range(2):
+        a, b = G.p[n].to_numpy(0)[1:-1, 1:-1, 1:-1], O.p[n].a[1:-1, 1:-1, 1:-1]
+        assert np.abs(a - b).max() <= 1e-7 * max(np.abs(b).max(), 1e-300), "p after the pressure iteration, level %d: %.3e / %.3e" % (n, np.abs(a - b).max(), np.abs(b).max())
+    for _ in range(2):
+        O.step(); G.step()
+        assert abs(G.dt - O.dt) <= 1e-10 * O.dt
+    for n in range(2):
+        for nm, gm, om in (("u", G.unew, O.unew[n]), ("s", G.snew, O.snew[n])):
+            a, b = gm[n].to_numpy(0)[3:-3, 3:-3, 3:-3], om.valid()
+            assert np.abs(a - b).max() <= 1e-8 * max(np.abs(b).max(), 1e-300), "level %d %s differs by %.3e" % (n, nm, np.abs(a - b).max())
+    G.close()

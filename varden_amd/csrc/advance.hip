@@ -38,7 +38,7 @@ extern "C" int vdn_advance_timestep(int istep, vdn_layout *mla, vdn_multifab **s
   const vdn_params &P = ctx().prm;
   const int dm = P.dm, nscal = P.nscal, nlevs = mla->nlev;
   const bool viscous = P.visc_coef > 0.0, diffusive = P.diff_coef > 0.0;
-  REQUIRE(nlevs == 1 || (dm == 3 && !viscous && !diffusive), "advance_timestep: multi-level hierarchies are implemented for dm = 3, inviscid (this round)");
+  REQUIRE(nlevs == 1 || (dm == 3 && !diffusive), "advance_timestep: multi-level hierarchies are implemented for dm = 3 and diff_coef = 0 (this round)");
   REQUIRE(press_comp == dm + nscal + 1, "press_comp must be dm+nscal+1 (got %d)", press_comp);
   for (int n = 0; n < nlevs; n++) {
     REQUIRE(uold[n]->ng >= 3 && sold[n]->ng >= 3 && unew[n]->ng >= 3 && snew[n]->ng >= 3, "state needs ng_cell = 3");
@@ -62,6 +62,7 @@ extern "C" int vdn_advance_timestep(int istep, vdn_layout *mla, vdn_multifab **s
       for (int c = 0; c < dm; c++) k_explicit_diffusive_term(lapu[n], uold[n], c, c, DXL(n), bct);
     }
   }
+  if (viscous) for (int n = nlevs - 1; n >= 1; n--) ml_cc_restriction(lapu[n - 1], lapu[n], 0, dm);     // cc_applyop per level, then average down
 
   // advance_premac.f90:44-51
   {
@@ -121,7 +122,7 @@ extern "C" int vdn_advance_timestep(int istep, vdn_layout *mla, vdn_multifab **s
   // make_at_halftime (advance_timestep.f90:114, make_at_halftime.f90:64-65)
   for (int n = 0; n < nlevs; n++) k_make_at_halftime(rhohalf[n], sold[n], snew[n], 0, 0);
   restrict_and_fill(nlevs, rhohalf, 0, dm + 0, 1, false, bct);
-  if (viscous && P.diffusion_type == 2) mf_setval(lapu[0], 0.0, 0, dm, true);          // advance_timestep.f90:116-120
+  if (viscous && P.diffusion_type == 2) for (int n = 0; n < nlevs; n++) mf_setval(lapu[n], 0.0, 0, dm, true);   // advance_timestep.f90:116-120
 
   // velocity_advance.f90:48-93
   t0 = wall();
@@ -144,7 +145,8 @@ extern "C" int vdn_advance_timestep(int istep, vdn_layout *mla, vdn_multifab **s
     restrict_and_fill(nlevs, unew, 0, 0, dm, false, bct);                               // update.f90:104
     if (viscous) {                                                                      // velocity_advance.f90:103-118
       const double visc_mu = (P.diffusion_type == 1) ? 0.5 * dt * P.visc_coef : dt * P.visc_coef;
-      do_visc_solve(mla, unew[0], lapu[0], rhohalf[0], mac_rhs[0], dx, visc_mu, bct);
+      if (nlevs == 1) do_visc_solve(mla, unew[0], lapu[0], rhohalf[0], mac_rhs[0], dx, visc_mu, bct);
+      else do_ml_visc_solve(mla, unew, lapu, rhohalf, mac_rhs, dx, visc_mu, bct);
     }
     arena_release(mark);
   }

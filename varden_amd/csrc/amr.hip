@@ -339,14 +339,16 @@ static void cf_descs(vdn_multifab *pf, const vdn_multifab *pc, const vdn_bc_towe
   }
 }
 struct ResArgs { double hi2[3]; };
-struct ResidualB { Range3 r; int g[3]; FV rh, phi, bx, by, bz, res; ResArgs A;
+struct ResidualB { Range3 r; int g[3]; FV rh, phi, bx, by, bz, res, alpha; int has_alpha; ResArgs A;
   static __device__ double body(const ResidualB &a, int i, int j, int k, int) {
     const FV &phi = a.phi;
     const double p0 = fv_get(phi, i, j, k);
     const double ax = (fv_get(a.bx, i + 1, j, k) * (p0 - fv_get(phi, i + 1, j, k)) + fv_get(a.bx, i, j, k) * (p0 - fv_get(phi, i - 1, j, k))) * a.A.hi2[0];
     const double ay = (fv_get(a.by, i, j + 1, k) * (p0 - fv_get(phi, i, j + 1, k)) + fv_get(a.by, i, j, k) * (p0 - fv_get(phi, i, j - 1, k))) * a.A.hi2[1];
     const double az = (fv_get(a.bz, i, j, k + 1) * (p0 - fv_get(phi, i, j, k + 1)) + fv_get(a.bz, i, j, k) * (p0 - fv_get(phi, i, j, k - 1))) * a.A.hi2[2];
-    const double rr = fv_get(a.rh, i, j, k) - (ax + ay + az);
+    double Ap = ax + ay + az;
+    if (a.has_alpha) Ap = Ap + fv_get(a.alpha, i, j, k) * p0;
+    const double rr = fv_get(a.rh, i, j, k) - Ap;
     fv_at(a.res, i, j, k) = rr;
     return fabs(rr);
   } };
@@ -383,7 +385,7 @@ struct GsArgs { int lo[3], hi[3]; int e[3][2]; double hi2[3]; };
 // red-black Gauss-Seidel on the fabs of a level: ghost cells of e are 0 at the coarse-fine interface and at Dirichlet faces
 // (b := 2b), Neumann faces carry b := 0 -- the folding of mg_cc.hip applied on the fly; colour by global index.
 // r: lo[0] .. lo[0] + ceil(nx/2) - 1 along x (half the cells of a row), the colour picks which half
-struct GsrbB { Range3 r; int g[3]; FV e, rh, bx, by, bz; GsArgs A;
+struct GsrbB { Range3 r; int g[3]; FV e, rh, bx, by, bz, alpha; int has_alpha; GsArgs A;
   static __device__ double body(const GsrbB &a, int ih, int j, int k, int color) {
     const GsArgs &A = a.A; const FV &e = a.e;
     const int i = A.lo[0] + 2 * (ih - A.lo[0]) + ((A.lo[0] + j + k + color) & 1);
@@ -398,9 +400,25 @@ struct GsrbB { Range3 r; int g[3]; FV e, rh, bx, by, bz; GsArgs A;
     const double ax = (bxp * (p0 - fv_get(e, i + 1, j, k)) + bxm * (p0 - fv_get(e, i - 1, j, k))) * A.hi2[0];
     const double ay = (byp * (p0 - fv_get(e, i, j + 1, k)) + bym * (p0 - fv_get(e, i, j - 1, k))) * A.hi2[1];
     const double az = (bzp * (p0 - fv_get(e, i, j, k + 1)) + bzm * (p0 - fv_get(e, i, j, k - 1))) * A.hi2[2];
-    const double Ap = ax + ay + az;
-    const double diag = (bxp + bxm) * A.hi2[0] + (byp + bym) * A.hi2[1] + (bzp + bzm) * A.hi2[2];
+    double Ap = ax + ay + az;
+    double diag = (bxp + bxm) * A.hi2[0] + (byp + bym) * A.hi2[1] + (bzp + bzm) * A.hi2[2];
+    if (a.has_alpha) { const double a0 = fv_get(a.alpha, i, j, k); Ap = Ap + a0 * p0; diag = diag + a0; }
     if (diag != 0.0) fv_at(e, i, j, k) = p0 + (fv_get(a.rh, i, j, k) - Ap) / diag;
+    return 0.0;
+  } };
+// inhomogeneous Dirichlet data into the right-hand side (kk_cc_load_rh of mg_cc.hip on fabs): rh += 2b * phi_ghost / h^2, faces in the
+// order x-lo, x-hi, y-lo, y-hi, z-lo, z-hi
+struct DirRhsB { Range3 r; int g[3]; FV rh, phi, bx, by, bz; GsArgs A;
+  static __device__ double body(const DirRhsB &a, int i, int j, int k, int) {
+    const GsArgs &A = a.A;
+    double r = fv_get(a.rh, i, j, k);
+    if (i == A.lo[0] && A.e[0][0] == VDN_BC_DIR) r = r + (2.0 * fv_get(a.bx, i, j, k)) * fv_get(a.phi, i - 1, j, k) * A.hi2[0];
+    if (i == A.hi[0] && A.e[0][1] == VDN_BC_DIR) r = r + (2.0 * fv_get(a.bx, i + 1, j, k)) * fv_get(a.phi, i + 1, j, k) * A.hi2[0];
+    if (j == A.lo[1] && A.e[1][0] == VDN_BC_DIR) r = r + (2.0 * fv_get(a.by, i, j, k)) * fv_get(a.phi, i, j - 1, k) * A.hi2[1];
+    if (j == A.hi[1] && A.e[1][1] == VDN_BC_DIR) r = r + (2.0 * fv_get(a.by, i, j + 1, k)) * fv_get(a.phi, i, j + 1, k) * A.hi2[1];
+    if (k == A.lo[2] && A.e[2][0] == VDN_BC_DIR) r = r + (2.0 * fv_get(a.bz, i, j, k)) * fv_get(a.phi, i, j, k - 1) * A.hi2[2];
+    if (k == A.hi[2] && A.e[2][1] == VDN_BC_DIR) r = r + (2.0 * fv_get(a.bz, i, j, k + 1)) * fv_get(a.phi, i, j, k + 1) * A.hi2[2];
+    fv_at(a.rh, i, j, k) = r;
     return 0.0;
   } };
 struct AddB { Range3 r; int g[3]; FV a, b;
@@ -422,7 +440,7 @@ static Range3 valid_range(const vdn_multifab *mf, int b) { Range3 r; for (int d 
 static double read_dev(double *d) { double h; HIPCHK(hipMemcpyAsync(&h, d, sizeof(double), hipMemcpyDeviceToHost, ctx().stream)); HIPCHK(hipStreamSynchronize(ctx().stream)); return h; }
 
 // descriptor sets are built once per solve: the fields of a solve do not move
-struct MLCC { int nlev; vdn_layout *la; vdn_multifab **rh, **phi, **beta; vdn_multifab *res[VDN_MAXLEV], *e[VDN_MAXLEV], *scr[VDN_MAXLEV], *mask[VDN_MAXLEV];
+struct MLCC { int nlev; vdn_layout *la; vdn_multifab **rh, **phi, **beta, **alpha; vdn_multifab *res[VDN_MAXLEV], *e[VDN_MAXLEV], *scr[VDN_MAXLEV], *mask[VDN_MAXLEV];
               const double *dx; const vdn_bc_tower *bct; int bcc; double *d_nrm;
               BatchSet<ClosureB> closure[VDN_MAXLEV]; BatchSet<CfB> cf[VDN_MAXLEV]; BatchSet<ResidualB> resid[VDN_MAXLEV];
               BatchSet<RefluxB> reflux[VDN_MAXLEV][6];          // [fine level][d*2+s]: one launch per side so that a coarse cell is updated once per launch
@@ -452,10 +470,11 @@ static void mlcc_build_sets(MLCC &S) {
       const Range3 r = valid_range(S.rh[n], b);
       ResidualB q; q.r = r; q.rh = S.rh[n]->fabs[b]; q.phi = S.phi[n]->fabs[b]; q.bx = S.beta[3 * n]->fabs[b]; q.by = S.beta[3 * n + 1]->fabs[b]; q.bz = S.beta[3 * n + 2]->fabs[b];
       q.res = S.res[n]->fabs[b]; for (int d = 0; d < 3; d++) q.A.hi2[d] = 1.0 / (S.dx[3 * n + d] * S.dx[3 * n + d]);
+      q.has_alpha = S.alpha ? 1 : 0; q.alpha = S.alpha ? S.alpha[n]->fabs[b] : q.rh;
       vr.push_back(q);
       if (n < L - 1) { AbsmaxB m; m.r = r; m.a = S.res[n]->fabs[b]; m.mask = S.mask[n]->fabs[b]; m.has_mask = 1; va.push_back(m); }
       if (n >= 1) {
-        GsrbB gq; gq.e = S.e[n]->fabs[b]; gq.rh = S.res[n]->fabs[b]; gq.bx = q.bx; gq.by = q.by; gq.bz = q.bz;
+        GsrbB gq; gq.e = S.e[n]->fabs[b]; gq.rh = S.res[n]->fabs[b]; gq.bx = q.bx; gq.by = q.by; gq.bz = q.bz; gq.has_alpha = q.has_alpha; gq.alpha = q.alpha;
         for (int d = 0; d < 3; d++) { gq.A.lo[d] = r.lo[d]; gq.A.hi[d] = r.hi[d]; gq.A.hi2[d] = q.A.hi2[d]; for (int sd = 0; sd < 2; sd++) gq.A.e[d][sd] = S.bct->ell_bc(n, b + 1, d, sd, S.bcc); }
         gq.r = r; gq.r.hi[0] = r.lo[0] + (r.hi[0] - r.lo[0] + 2) / 2 - 1;
         vg.push_back(gq);
@@ -537,13 +556,26 @@ static void apply_correction(MLCC &S, int n) {
   for (int m = n + 1; m < S.nlev; m++) S.prolong[n][m].run(0, (double *)nullptr, ctx().stream);
 }
 // rh, phi: [lev];  beta: [lev*3 + d];  dx: [lev*3 + d]
+// alpha: [lev] cell coefficients of (alpha - div beta grad), or nullptr.  The ghost cells of the incoming phi carry inhomogeneous
+// Dirichlet data (boundary-face values); they are moved into rh, which is modified
 int ml_cc_solve(vdn_layout *la, vdn_multifab **rh, vdn_multifab **phi, vdn_multifab **beta, const double *dx, const vdn_bc_tower *bct, int bc_comp0,
-                double rel_eps, int max_iter, int *iters, double *res0, double *res) {
+                double rel_eps, int max_iter, int *iters, double *res0, double *res, vdn_multifab **alpha) {
   require_amr(la);
   hipStream_t st = ctx().stream;
   const size_t mark = arena_mark();
   const int L = la->nlev;
-  MLCC S; S.nlev = L; S.la = la; S.rh = rh; S.phi = phi; S.beta = beta; S.dx = dx; S.bct = bct; S.bcc = bc_comp0;
+  MLCC S; S.nlev = L; S.la = la; S.rh = rh; S.phi = phi; S.beta = beta; S.alpha = alpha; S.dx = dx; S.bct = bct; S.bcc = bc_comp0;
+  for (int n = 0; n < L; n++) {
+    std::vector<DirRhsB> v;
+    for (int b = 0; b < rh[n]->nfabs(); b++) {
+      DirRhsB q; q.rh = rh[n]->fabs[b]; q.phi = phi[n]->fabs[b]; q.bx = beta[3 * n]->fabs[b]; q.by = beta[3 * n + 1]->fabs[b]; q.bz = beta[3 * n + 2]->fabs[b];
+      bool any = false;
+      for (int d = 0; d < 3; d++) { q.r.lo[d] = q.A.lo[d] = rh[n]->vbox[b].lo[d]; q.r.hi[d] = q.A.hi[d] = rh[n]->vbox[b].hi[d]; q.A.hi2[d] = 1.0 / (dx[3 * n + d] * dx[3 * n + d]);
+        for (int sd = 0; sd < 2; sd++) { q.A.e[d][sd] = bct->ell_bc(n, b + 1, d, sd, bc_comp0); any = any || q.A.e[d][sd] == VDN_BC_DIR; } }
+      if (any) v.push_back(q);
+    }
+    launch_batched(v, 0, (double *)nullptr, 0, ctx().stream);
+  }
   S.d_nrm = (double *)arena_alloc(256);
   for (int n = 0; n < L; n++) {
     S.res[n] = mf_temp(la, n, 1, 0, -1, true, 0.0); S.e[n] = mf_temp(la, n, 1, 1, -1, true, 0.0);
@@ -586,7 +618,7 @@ int ml_cc_solve(vdn_layout *la, vdn_multifab **rh, vdn_multifab **phi, vdn_multi
     // coarse correction: ONE V-cycle of the single-level multigrid on the whole level 0
     mf_setval(S.e[0], 0.0, 0, 1, true);
     int cyc; double r0, rr;
-    cc_solve(S.res[0], S.e[0], beta, dx, ebc0, 0.0, -1.0, -1, &cyc, &r0, &rr);
+    cc_solve(S.res[0], S.e[0], beta, dx, ebc0, 0.0, -1.0, -1, &cyc, &r0, &rr, alpha ? alpha[0] : nullptr);
     apply_correction(S, 0);
     // post-relaxation on the new residual, coarsest level first
     for (int n = 1; n < L; n++) {
@@ -621,7 +653,7 @@ void do_ml_macproject(vdn_layout *mla, vdn_multifab **umac, vdn_multifab **rho, 
   for (int n = L - 1; n >= 1; n--) ml_cc_restriction(rh[n - 1], rh[n], 0, 1);     // 204-206
   for (int n = L - 1; n >= 1; n--) for (int d = 0; d < 3; d++) ml_edge_restriction(beta[3 * (n - 1) + d], beta[3 * n + d], d);       // 330-333
   int it; double r0, rr;
-  int rc = ml_cc_solve(mla, rh, phi, beta, dx, bct, bc_comp0, ctx().prm.mac_rel_eps, ctx().prm.mg_max_iter, &it, &r0, &rr);
+  int rc = ml_cc_solve(mla, rh, phi, beta, dx, bct, bc_comp0, ctx().prm.mac_rel_eps, ctx().prm.mg_max_iter, &it, &r0, &rr, nullptr);
   ctx().solver_cycles[0] = it; ctx().solver_res0[0] = r0; ctx().solver_res[0] = rr;
   if (rc != 0 && ctx().prm.verbose) fprintf(stderr, "varden_amd: composite MAC solve did not converge in %d iterations (res %g / %g)\n", it, rr, r0);
   for (int n = 0; n < L; n++) mac_level_mkumac(umac + 3 * n, phi[n], beta + 3 * n, dx + 3 * n, bct, bc_comp0);   // 103

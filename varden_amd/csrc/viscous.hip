@@ -104,6 +104,39 @@ void do_visc_solve(vdn_layout *mla, vdn_multifab *unew, const vdn_multifab *lapu
   arena_release(mark);
 }
 
+// visc_solve (viscsolve.f90:19-306) on several levels: per velocity component the composite solve of (rho - div mu grad) u = rhs
+// (amr.hip: ml_cc_solve with the alpha term; the wall values sit in the ghost cells of unew and go into the right-hand side)
+void do_ml_visc_solve(vdn_layout *mla, vdn_multifab **unew, vdn_multifab **lapu, vdn_multifab **rho, vdn_multifab **mac_rhs,
+                      const double *dx, double mu, const vdn_bc_tower *bct) {
+  const int L = mla->nlev;
+  hipStream_t st = ctx().stream;
+  size_t mark = arena_mark();
+  vdn_multifab *rh[VDN_MAXLEV], *phi[VDN_MAXLEV], *alpha[VDN_MAXLEV], *beta[3 * VDN_MAXLEV];
+  for (int n = 0; n < L; n++) {
+    rh[n] = mf_temp(mla, n, 1, 0, -1, false, 0.0); phi[n] = mf_temp(mla, n, 1, 1, -1, true, 0.0); alpha[n] = mf_temp(mla, n, 1, 0, -1, false, 0.0);
+    for (int d = 0; d < 3; d++) beta[3 * n + d] = mf_temp(mla, n, 1, 0, d, true, mu);            // setval(beta, mu), viscsolve.f90:58-60
+    mf_copy(alpha[n], 0, rho[n], 0, 1, 0);                                                        // alpha = rho, viscsolve.f90:57
+  }
+  const double visc_mu_dt = (ctx().prm.diffusion_type == 1) ? 2.0 * mu : mu;
+  for (int d = 0; d < 3; d++) {
+    for (int n = 0; n < L; n++)
+      for (int i = 0; i < unew[n]->nfabs(); i++) {
+        const vdn_box &bx = unew[n]->vbox[i];
+        Range3 rg; for (int a = 0; a < 3; a++) { rg.lo[a] = bx.lo[a] - 1; rg.hi[a] = bx.hi[a] + 1; }
+        VrhsArgs A; A.comp = d; A.dtype = ctx().prm.diffusion_type; A.mu = mu; A.third_vmd_over_dx = 0.0;
+        hipLaunchKernelGGL(kk_visc_rhs, grid_for(rg), dim3(64, 4, 1), 0, st, rh[n]->fabs[i], phi[n]->fabs[i], unew[n]->fabs[i], lapu[n]->fabs[i], rho[n]->fabs[i],
+                           mac_rhs[n]->fabs[i], A, rg, bx.lo[0], bx.lo[1], bx.lo[2], bx.hi[0], bx.hi[1], bx.hi[2], dx[3 * n + d], 1.0 / 3.0, visc_mu_dt);
+      }
+    int it; double r0, rr;
+    int rc = ml_cc_solve(mla, rh, phi, beta, dx, bct, d, 1.e-12, ctx().prm.mg_max_iter, &it, &r0, &rr, alpha);      // bc_comp = d, viscsolve.f90:88-99
+    if (rc != 0 && ctx().prm.verbose) fprintf(stderr, "varden_amd: composite viscous solve %d did not converge in %d iterations (res %g / %g)\n", d, it, rr, r0);
+    for (int n = 0; n < L; n++) mf_copy(unew[n], d, phi[n], 0, 1, 0);                            // viscsolve.f90:103
+  }
+  ml_restrict_and_fill(L, unew, 0, 0, 3, false, bct);                                            // viscsolve.f90:106
+  for (int n = L - 1; n >= 0; n--) { for (int d = 2; d >= 0; d--) mf_temp_free(beta[3 * n + d]); mf_temp_free(alpha[n]); mf_temp_free(phi[n]); mf_temp_free(rh[n]); }
+  arena_release(mark);
+}
+
 void do_diff_scalar_solve(vdn_layout *mla, vdn_multifab *snew, const vdn_multifab *laps, const double *dx, double mu,
                           const vdn_bc_tower *bct, int icomp, int bccomp0) {
   if (ctx().prm.dm == 2) { do2_diff_scalar_solve(mla, snew, laps, dx, mu, bct, icomp, bccomp0); return; }

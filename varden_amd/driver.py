@@ -175,7 +175,7 @@ class VardenAMR:
     dt = min over levels of estdt, advance_timestep, new -> old copies."""
 
     def __init__(self, nc, fine_boxes, phys_bc, params=None, prob_type=1, grav=-9.8, init_shrink=0.1, device=0, finer_levels=(),
-                 regrid_int=-1, max_levs=None, max_grid_size=256):
+                 regrid_int=-1, max_levs=None, max_grid_size=256, init_iter=0, do_initial_projection=0):
         self.prm = params or default_params()
         self.grav, self.regrid_int, self.max_grid_size = grav, regrid_int, max_grid_size
         self.prm.prob_type = prob_type
@@ -206,10 +206,24 @@ class VardenAMR:
                 self.sold[n].from_numpy(sb, i)
         self.time, self.istep = 0.0, 0
         self.fill_state_ghosts()
+        if do_initial_projection:                                                      # varden.f90:126-138
+            rhohalf = mk(1, 1)
+            for m in rhohalf:
+                m.setval(1.0, all=True)
+            adv.hgproject(bl.INITIAL_PROJECTION, self.mla, self.uold, self.uold, rhohalf, self.p, self.gp, self.dx, 1.0, self.bct, self.press_comp)
+            self.initial_projection_stat = adv.last_solver_stats("hg")
+            for n in range(self.nlev):
+                rhohalf[n].destroy()
+                self.p[n].setval(0.0, all=True)
+                self.gp[n].setval(0.0, all=True)
+            self.fill_state_ghosts()                                                   # varden.f90:165-172
         for n in range(self.nlev):
             self.unew[n].copy_c(0, self.uold[n], 0, dm, 3)
             self.snew[n].copy_c(0, self.sold[n], 0, ns, 3)
         self.dt = self.estdt(1.0e20) * init_shrink
+        for it in range(init_iter):                                                    # varden.f90:460-490
+            adv.advance_timestep(it + 1, self.mla, self.sold, self.uold, self.snew, self.unew, self.gp, self.p,
+                                 self.ext_vel_force, self.ext_scal_force, self.bct, self.dt, self.time, self.dx, self.press_comp, bl.PRESSURE_ITERS)
 
     @staticmethod
     def tagged_grids(nc, phys_bc, params=None, prob_type=1, max_levs=2, buf_wid=2, max_grid_size=256, device=0):
