@@ -17,11 +17,32 @@
 #include <algorithm>
 
 
+static bool isect(const int alo[3], const int ahi[3], const int blo[3], const int bhi[3], Range3 &r);
+// proper nesting (what initialize.f90:116-118 checks for fixed grids): every box of level n, coarsened and grown by two cells, lies
+// inside the union of the boxes of level n-1 (or outside the domain) -- the coarse-fine interpolations read that far
+static void check_nesting(const vdn_layout *la) {
+  static std::vector<unsigned long> done;
+  if (std::find(done.begin(), done.end(), la->uid) != done.end()) return;
+  for (int n = 1; n < la->nlev; n++)
+    for (size_t f = 0; f < la->boxes[n].size(); f++) {
+      int glo[3], ghi[3]; long want = 1, have = 0;
+      for (int d = 0; d < 3; d++) {
+        glo[d] = std::max(la->boxes[n][f].lo[d] / 2 - 2, la->pd[n - 1].lo[d]); ghi[d] = std::min(la->boxes[n][f].hi[d] / 2 + 2, la->pd[n - 1].hi[d]);
+        want *= (ghi[d] - glo[d] + 1);
+      }
+      for (size_t c = 0; c < la->boxes[n - 1].size(); c++) {
+        Range3 r; if (isect(glo, ghi, la->boxes[n - 1][c].lo, la->boxes[n - 1][c].hi, r)) have += (long)(r.hi[0] - r.lo[0] + 1) * (r.hi[1] - r.lo[1] + 1) * (r.hi[2] - r.lo[2] + 1);
+      }
+      REQUIRE(have == want, "AMR path: box %d of level %d is not properly nested in level %d (two coarse cells of margin are required)", (int)f, n, n - 1);
+    }
+  done.push_back(la->uid);
+}
 static void require_amr(const vdn_layout *la) {
   REQUIRE(la->nlev >= 2 && la->nlev <= VDN_MAXLEV, "AMR path: 2..%d levels are implemented (nlevel = %d)", VDN_MAXLEV, la->nlev);
   REQUIRE(ctx().nranks == 1, "AMR path: single rank only in this round");
   REQUIRE(ctx().prm.dm == 3, "AMR path: dm = 3 only");
   for (size_t d = 0; d < la->rr.size(); d++) REQUIRE(la->rr[d] == 2, "AMR path: refinement ratio 2 only");
+  check_nesting(la);
 }
 DEVI int fdiv2(int a) { return a >= 0 ? a / 2 : -((-a + 1) / 2); }
 static int hfdiv2(int a) { return a >= 0 ? a / 2 : -((-a + 1) / 2); }

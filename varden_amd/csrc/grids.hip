@@ -27,10 +27,17 @@ __global__ void kk_tag(FV s, unsigned char *tags, int n0, int n1, int d0, int d1
 
 namespace {
 struct IBox { int lo[3], hi[3]; };
+struct Lattice;
+bool all_allowed(const Lattice &G, const IBox &b);
 struct Lattice {
-  int n[3]; std::vector<unsigned char> t;
+  int n[3]; std::vector<unsigned char> t, ok;                 // t: tagged blocks; ok: blocks that lie in the nesting region as a whole
   unsigned char at(int i, int j, int k) const { return t[(size_t)i + (size_t)n[0] * ((size_t)j + (size_t)n[1] * (size_t)k)]; }
+  unsigned char allowed(int i, int j, int k) const { return ok[(size_t)i + (size_t)n[0] * ((size_t)j + (size_t)n[1] * (size_t)k)]; }
 };
+bool all_allowed(const Lattice &G, const IBox &b) {
+  for (int k = b.lo[2]; k <= b.hi[2]; k++) for (int j = b.lo[1]; j <= b.hi[1]; j++) for (int i = b.lo[0]; i <= b.hi[0]; i++) if (!G.allowed(i, j, k)) return false;
+  return true;
+}
 long count_tags(const Lattice &G, const IBox &b) {
   long c = 0;
   for (int k = b.lo[2]; k <= b.hi[2]; k++) for (int j = b.lo[1]; j <= b.hi[1]; j++) for (int i = b.lo[0]; i <= b.hi[0]; i++) c += G.at(i, j, k);
@@ -48,7 +55,9 @@ void cluster(const Lattice &G, IBox b, double min_eff, int min_width, std::vecto
   if (!shrink_to_tags(G, b)) return;
   const long vol = (long)(b.hi[0] - b.lo[0] + 1) * (b.hi[1] - b.lo[1] + 1) * (b.hi[2] - b.lo[2] + 1);
   const long ntag = count_tags(G, b);
-  if ((double)ntag >= min_eff * (double)vol) { out.push_back(b); return; }
+  // a box is acceptable only if it stays inside the nesting region (an efficient box may still contain an untagged block outside it)
+  const bool nested = all_allowed(G, b);
+  if (nested && (double)ntag >= min_eff * (double)vol) { out.push_back(b); return; }
   // signatures
   std::vector<long> sig[3];
   for (int d = 0; d < 3; d++) sig[d].assign(b.hi[d] - b.lo[d] + 1, 0);
@@ -84,6 +93,10 @@ void cluster(const Lattice &G, IBox b, double min_eff, int min_width, std::vecto
   if (cut_d < 0) {
     const int d = order[0], len = (int)sig[d].size();
     if (len >= 2 * min_width) { cut_d = d; cut_at = len / 2; }
+  }
+  if (cut_d < 0 && !nested) {                          // too small for the usual rules but not nested: halve the longest side anyway
+    const int d = order[0], len = (int)sig[d].size();
+    if (len >= 2) { cut_d = d; cut_at = len / 2; }
   }
   if (cut_d < 0) { out.push_back(b); return; }       // cannot be cut: accept
   IBox l = b, r = b;
@@ -153,7 +166,7 @@ extern "C" int vdn_make_new_grids(const vdn_multifab *s, int lev1, int buf_wid, 
   for (size_t c = 0; c < ncell; c++) tags[c] &= inside[c];
   // 3. cluster on the lattice of blocks; a block takes part only if it lies in the nesting region as a whole
   Lattice G; for (int d = 0; d < 3; d++) G.n[d] = d < dm ? n[d] / blocking : 1;
-  G.t.assign((size_t)G.n[0] * G.n[1] * G.n[2], 0);
+  G.t.assign((size_t)G.n[0] * G.n[1] * G.n[2], 0); G.ok.assign(G.t.size(), 0);
   const int bz = dm == 3 ? blocking : 1;
   for (int K = 0; K < G.n[2]; K++) for (int J = 0; J < G.n[1]; J++) for (int I = 0; I < G.n[0]; I++) {
     bool any = false, all_in = true;
@@ -162,6 +175,7 @@ extern "C" int vdn_make_new_grids(const vdn_multifab *s, int lev1, int buf_wid, 
       any = any || at(tags, i, j, k); all_in = all_in && at(inside, i, j, k);
     }
     G.t[(size_t)I + (size_t)G.n[0] * ((size_t)J + (size_t)G.n[1] * (size_t)K)] = (any && all_in) ? 1 : 0;
+    G.ok[(size_t)I + (size_t)G.n[0] * ((size_t)J + (size_t)G.n[1] * (size_t)K)] = all_in ? 1 : 0;
   }
   std::vector<IBox> cl;
   IBox whole; for (int d = 0; d < 3; d++) { whole.lo[d] = 0; whole.hi[d] = G.n[d] - 1; }

@@ -1,0 +1,84 @@
+"""Reads the reference's run-time inputs (a Fortran namelist &PROBIN, e.g. exec/test/inputs_bubble_3d) and drives the path the way
+src/varden.f90 does: parameters (src/_parameters), grids (fixed single level, or tag_boxes + make_new_grids), start-up sequence,
+time loop with estdt / regrid / advance_timestep.  Plot and checkpoint files are out of scope."""
+import re
+
+from . import boxlib as bl
+from .capi import default_params
+from .driver import Varden, VardenAMR
+
+# src/_parameters: the defaults that matter to the path
+DEFAULTS = dict(dim_in=2, nscal=2, prob_type=1, grav=0.0, boussinesq=0, max_step=1, stop_time=-1.0, max_levs=1, max_grid_size=256,
+                regrid_int=-1, amr_buf_width=-1, n_cellx=32, n_celly=32, n_cellz=32, prob_hi_x=1.0, prob_hi_y=1.0, prob_hi_z=1.0,
+                init_iter=4, do_initial_projection=1, init_shrink=1.0, cflfac=0.8, max_dt_growth=1.1, visc_coef=0.0, diff_coef=0.0,
+                diffusion_type=1, slope_order=4, use_minion=0, stencil_order=2, verbose=0, mg_verbose=0,
+                bcx_lo=14, bcx_hi=14, bcy_lo=14, bcy_hi=14, bcz_lo=14, bcz_hi=14)
+
+
+def parse_namelist(text):
+    """key = value pairs of the first namelist group; Fortran literals (1.d0, .true., 'str'); indexed keys like u_bc(1,1) kept verbatim"""
+    out = {}
+    body = re.sub(r"!.*", "", text)
+    for m in re.finditer(r"([A-Za-z_][\w]*(?:\(\s*\d+\s*,\s*\d+\s*\))?)\s*=\s*([^\n,/]+)", body):
+        key, val = m.group(1).replace(" ", ""), m.group(2).strip()
+        low = val.lower()
+        if low in (".true.", "t", ".t."):
+            out[key] = 1
+        elif low in (".false.", "f", ".f."):
+            out[key] = 0
+        elif val[:1] in "'\"":
+            out[key] = val.strip("'\"")
+        else:
+            num = re.sub(r"[dD]", "e", val)
+            try:
+                out[key] = int(num)
+            except ValueError:
+                out[key] = float(num)
+    return out
+
+
+def build(text, device=0, max_grid_size_cap=None):
+    """the driver object for an inputs text: Varden (one level) or VardenAMR (max_levs > 1, grids from the tagged initial data)"""
+    nl = dict(DEFAULTS)
+    nl.update(parse_namelist(text))
+    dm = int(nl["dim_in"])
+    prm = default_params(dm=dm, nscal=int(nl["nscal"]), slope_order=int(nl["slope_order"]), use_minion=int(nl["use_minion"]),
+                         boussinesq=int(nl["boussinesq"]), stencil_order=int(nl["stencil_order"]), diffusion_type=int(nl["diffusion_type"]),
+                         verbose=int(nl["verbose"]), prob_type=int(nl["prob_type"]), visc_coef=float(nl["visc_coef"]),
+                         diff_coef=float(nl["diff_coef"]), cflfac=float(nl["cflfac"]), max_dt_growth=float(nl["max_dt_growth"]))
+    for name in ("u_bc", "v_bc", "w_bc", "rho_bc", "trac_bc"):           # inflow data, probin.template:21-23: name(direction, side)
+        for key, v in nl.items():
+            m = re.fullmatch(name + r"\((\d),(\d)\)", key)
+            if m:
+                getattr(prm, name)[int(m.group(1)) - 1][int(m.group(2)) - 1] = float(v)
+    phys = [[int(nl["bc%s_lo" % a]), int(nl["bc%s_hi" % a])] for a in "xyz"[:dm]]
+    n = tuple(int(nl["n_cell" + a]) for a in "xyz"[:dm])
+    prob_hi = tuple(float(nl["prob_hi_" + a]) for a in "xyz"[:dm]) + (1.0,) * (3 - dm)
+    mgs = int(nl["max_grid_size"]) if max_grid_size_cap is None else min(int(nl["max_grid_size"]), max_grid_size_cap)
+    common = dict(prob_type=int(nl["prob_type"]), grav=float(nl["grav"]), init_shrink=float(nl["init_shrink"]),
+                  init_iter=int(nl["init_iter"]), do_initial_projection=int(nl["do_initial_projection"]), device=device)
+    if int(nl["max_levs"]) <= 1:
+        decomp = tuple(max(1, -(-n[d] // mgs)) for d in range(dm)) + (1,) * (3 - dm)
+        return nl, Varden(n, phys, prm, prob_hi=prob_hi, decomp=decomp, **common)
+    if dm != 3 or len(set(n)) != 1 or any(p != 1.0 for p in prob_hi):
+        raise NotImplementedError("adaptive hierarchies: 3-D, cubic unit domain in this round")
+    if any(bl.PERIODIC in side for side in phys):
+        raise NotImplementedError("adaptive hierarchies: periodic domains are not implemented in this round")
+    levels = VardenAMR.tagged_grids(n[0], phys, prm, prob_type=int(nl["prob_type"]), max_levs=int(nl["max_levs"]),
+                                    buf_wid=max(int(nl["amr_buf_width"]), int(nl["regrid_int"]), 1), max_grid_size=mgs, device=device)
+    if not levels:
+        return nl, Varden(n, phys, prm, prob_hi=prob_hi, **common)
+    return nl, VardenAMR(n[0], levels[0], phys, params=prm, finer_levels=levels[1:], regrid_int=int(nl["regrid_int"]),
+                         max_levs=int(nl["max_levs"]), max_grid_size=mgs, **common)
+
+
+def run(text, nsteps=None, report=print, device=0):
+    """the time loop of src/varden.f90:237-371 for max_step steps (or until stop_time)"""
+    nl, G = build(text, device=device)
+    max_step = int(nl["max_step"]) if nsteps is None else nsteps
+    stop_time = float(nl["stop_time"])
+    while G.istep < max_step and (stop_time < 0 or G.time < stop_time):
+        G.step()
+        if report:
+            report(G)
+    return nl, G
