@@ -88,32 +88,6 @@ DEVI void nd_apply(const NLev &L, const double *__restrict__ phi, int i, int j, 
   const int k = blockIdx.z;                                            \
   const bool in_range = (i <= (L).n[0]) && (j <= (L).n[1]) && (k <= (L).n[2]);
 
-__global__ void __launch_bounds__(256) kk_nd_jacobi(NLev L, const double *__restrict__ phi, double *__restrict__ out, double omega) {
-  NODE_IJK(L)
-  if (!in_range) return;
-  const long c = nidx(L, i, j, k);
-  const double p0 = phi[c];
-  double v = p0;
-  if (!nd_is_dir(L, i, j, k)) {
-    double Kp, diag; nd_apply(L, phi, i, j, k, Kp, diag);
-    if (diag != 0.0) v = p0 + omega * ((L.b[c] - Kp) / diag);
-  }
-  out[c] = v;
-}
-__global__ void __launch_bounds__(256) kk_nd_residual(NLev L, double *nrm) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  const int j = blockIdx.y * blockDim.y + threadIdx.y;
-  double rmax = 0.0;
-  if (i <= L.n[0] && j <= L.n[1])
-    for (int k = blockIdx.z; k <= L.n[2]; k += gridDim.z) {
-      const long c = nidx(L, i, j, k);
-      double r = 0.0;
-      if (!nd_is_dir(L, i, j, k)) { double Kp, diag; nd_apply(L, L.phi, i, j, k, Kp, diag); r = L.b[c] - Kp; }
-      L.res[c] = r;
-      rmax = fmax(rmax, fabs(r));
-    }
-  if (nrm) block_atomic_max(nrm, rmax);
-}
 // ---- k-marching forms of the smoother and the residual ----------------------------------------------------------
 // A workgroup owns a 64 x 4 patch of (i,j) and marches through a slab of k planes keeping the three phi planes and
 // the two sigma planes of the 27-point stencil in registers: per node 9 + 4 (+1 rhs) loads instead of 27 + 8 (+1),
@@ -1037,41 +1011,6 @@ __global__ void kk_ndf_residual(FV b, FV phi, FV sig, FV res, NdfArgs A, int exc
   }
   if (nrm) block_atomic_max(nrm, rmax);
 }
-__global__ void kk_ndf_absmax(FV a, NdfArgs A, int excl, Range3 r, double *nrm) {
-  REDUCE_IJ(r)
-  double m = 0.0;
-  if (in_ij) REDUCE_KLOOP(r) {
-    bool skip = false;
-    if (excl == 2) skip = i > A.ilo[0] && i < A.ihi[0] && j > A.ilo[1] && j < A.ihi[1] && k > A.ilo[2] && k < A.ihi[2];
-    if (!skip) m = fmax(m, fabs(fv_get(a, i, j, k)));
-  }
-  block_atomic_max(nrm, m);
-}
-// res_c += full weighting of the fine residual (zero outside the fine box's nodes) on the coarse nodes A.ilo..A.ihi
-__global__ void kk_ndf_restrict_add(FV res_c, FV res_f, NdfArgs Af, NdfArgs Ac, Range3 r) {
-  THREAD_IJK(r)
-  if (!in_range || ndf_pdir(Ac, i, j, k)) return;
-  const double wt[3] = { 0.5, 1.0, 0.5 };
-  double s = 0.0;
-  for (int c = -1; c <= 1; c++) for (int b = -1; b <= 1; b++) for (int a = -1; a <= 1; a++) {
-    const int ii = 2 * i + a, jj = 2 * j + b, kk = 2 * k + c;
-    if (ii < Af.lo[0] || ii > Af.hi[0] || jj < Af.lo[1] || jj > Af.hi[1] || kk < Af.lo[2] || kk > Af.hi[2]) continue;
-    s = s + (wt[a + 1] * wt[b + 1] * wt[c + 1]) * fv_get(res_f, ii, jj, kk);
-  }
-  fv_at(res_c, i, j, k) = fv_get(res_c, i, j, k) + s * 0.125;
-}
-// mode 0: phi_f = P phi_c on the interface nodes;  mode 1: phi_f += P e_c on every node that is not a physical Dirichlet node
-__global__ void kk_ndf_prolong(FV pf, FV pc, NdfArgs Af, int mode, Range3 r) {
-  THREAD_IJK(r)
-  if (!in_range) return;
-  if (ndf_pdir(Af, i, j, k)) return;
-  if (mode == 0 && !ndf_cf(Af, i, j, k)) return;
-  const int I = i >> 1, J = j >> 1, K = k >> 1, oi = i & 1, oj = j & 1, ok = k & 1;
-  double s = 0.0;
-  for (int c = 0; c <= ok; c++) for (int b = 0; b <= oj; b++) for (int a = 0; a <= oi; a++) s = s + fv_get(pc, I + a, J + b, K + c);
-  const double v = s * (1.0 / (double)((1 + oi) * (1 + oj) * (1 + ok)));
-  fv_at(pf, i, j, k) = (mode == 0) ? v : fv_get(pf, i, j, k) + v;
-}
 __global__ void kk_ndf_jacobi(FV ein, FV eout, FV rb, FV sig, NdfArgs A, double omega, Range3 r) {
   THREAD_IJK(r)
   if (!in_range) return;
@@ -1080,21 +1019,6 @@ __global__ void kk_ndf_jacobi(FV ein, FV eout, FV rb, FV sig, NdfArgs A, double 
   if (!ndf_pdir(A, i, j, k) && !ndf_cf(A, i, j, k)) { double Kp, diag; ndf_apply(ein, sig, A.f, i, j, k, Kp, diag); if (diag != 0.0) v = p0 + omega * ((fv_get(rb, i, j, k) - Kp) / diag); }
   fv_at(eout, i, j, k) = v;
 }
-// out = u (3 comps, one ghost layer) with zero outside [klo,khi] (invert = 0) or zero inside it (invert = 1)
-__global__ void kk_ndf_mask_u(FV out, FV u, Range3 r, int k0, int k1, int k2, int h0, int h1, int h2, int invert) {
-  THREAD_IJK(r)
-  if (!in_range) return;
-  const bool in = i >= k0 && i <= h0 && j >= k1 && j <= h1 && k >= k2 && k <= h2;
-  #pragma unroll
-  for (int c = 0; c < 3; c++) fv_at(out, i, j, k, c) = (in != (invert != 0)) ? fv_get(u, i, j, k, c) : 0.0;
-}
-__global__ void kk_ndf_setbox(FV a, Range3 r, double v) { THREAD_IJK(r) if (!in_range) return; fv_at(a, i, j, k) = v; }
-__global__ void kk_ndf_neg(FV out, FV in, NdfArgs A, Range3 r) {       // b = -rh, zero on physical Dirichlet nodes
-  THREAD_IJK(r)
-  if (!in_range) return;
-  fv_at(out, i, j, k) = ndf_pdir(A, i, j, k) ? 0.0 : -fv_get(in, i, j, k);
-}
-__global__ void kk_ndf_add(FV a, FV b, Range3 r) { THREAD_IJK(r) if (!in_range) return; fv_at(a, i, j, k) = fv_get(a, i, j, k) + fv_get(b, i, j, k); }
 
 // k-marching forms of kk_ndf_jacobi / kk_ndf_residual (same structure as kk_nd_march: own-column loads, i-1 / i+1 columns by wave
 // shuffles, three phi planes and two sigma planes in registers).  r: the node range of the box; tiles of 62 nodes along i.
@@ -1218,36 +1142,6 @@ static MarchSet ndf_build_march(std::vector<MarchB> &v) {
 template <int MODE> static void ndf_run_march(const MarchSet &S, double omega, int excl, double *nrm) {
   if (S.nbox == 0) return;
   hipLaunchKernelGGL(kk_ndf_march<MODE>, dim3(S.tot), NBLK, 0, ctx().stream, (const MarchB *)S.d_args, (const int *)S.d_start, S.nbox, omega, excl, nrm);
-}
-__global__ void kk_ndf_absmax_mask(FV a, FV mask, Range3 r, double *nrm) {
-  REDUCE_IJ(r)
-  double m = 0.0;
-  if (in_ij) REDUCE_KLOOP(r) if (fv_get(mask, i, j, k) == 0.0) m = fmax(m, fabs(fv_get(a, i, j, k)));
-  block_atomic_max(nrm, m);
-}
-__global__ void kk_ndf_mul3(FV out, FV u, FV mask, Range3 r) {          // out(1:3) = u(1:3) * mask
-  THREAD_IJK(r)
-  if (!in_range) return;
-  const double m = fv_get(mask, i, j, k);
-  #pragma unroll
-  for (int c = 0; c < 3; c++) fv_at(out, i, j, k, c) = (m != 0.0) ? fv_get(u, i, j, k, c) : 0.0;
-}
-__global__ void kk_ndf_zero3(FV a, Range3 r) { THREAD_IJK(r) if (!in_range) return; fv_at(a, i, j, k, 0) = 0.0; fv_at(a, i, j, k, 1) = 0.0; fv_at(a, i, j, k, 2) = 0.0; }
-// res_c += full weighting of the fine residual of ONE fine box (ghost nodes included: filled from the neighbouring fine boxes,
-// zero outside the fine level).  A coarse node whose centre fine node sits on a face shared by two fine boxes is taken by the
-// box that has it on its LOW face (own_hi[d] = 0 on shared high faces).
-__global__ void kk_ndf_restrict_add2(FV res_c, FV res_f, NdfArgs Af, NdfArgs Ac, int own0, int own1, int own2, Range3 r) {
-  THREAD_IJK(r)
-  if (!in_range || ndf_pdir(Ac, i, j, k)) return;
-  if ((2 * i == Af.hi[0] && !own0) || (2 * j == Af.hi[1] && !own1) || (2 * k == Af.hi[2] && !own2)) return;
-  const double wt[3] = { 0.5, 1.0, 0.5 };
-  double s = 0.0;
-  for (int c = -1; c <= 1; c++) for (int b = -1; b <= 1; b++) for (int a = -1; a <= 1; a++) {
-    const int ii = 2 * i + a, jj = 2 * j + b, kk = 2 * k + c;
-    if (ii < Af.lo[0] - 1 || ii > Af.hi[0] + 1 || jj < Af.lo[1] - 1 || jj > Af.hi[1] + 1 || kk < Af.lo[2] - 1 || kk > Af.hi[2] + 1) continue;
-    s = s + (wt[a + 1] * wt[b + 1] * wt[c + 1]) * fv_get(res_f, ii, jj, kk);
-  }
-  fv_at(res_c, i, j, k) = fv_get(res_c, i, j, k) + s * 0.125;
 }
 
 static double ndf_read(double *d) { double h; HIPCHK(hipMemcpyAsync(&h, d, sizeof(double), hipMemcpyDeviceToHost, ctx().stream)); HIPCHK(hipStreamSynchronize(ctx().stream)); return h; }
