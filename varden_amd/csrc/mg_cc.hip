@@ -291,7 +291,9 @@ __global__ void kk_cc_restrict(CLev F, CLev C) {
   const long f = cidx(F, 2 * i, 2 * j, 2 * k);
   const double *r = F.res;
   double s = r[f] + r[f + 1] + r[f + sy] + r[f + sy + 1] + r[f + sz] + r[f + sz + 1] + r[f + sz + sy] + r[f + sz + sy + 1];
-  C.rh[cidx(C, i, j, k)] = s * 0.125;
+  const long cc = cidx(C, i, j, k);
+  C.rh[cc] = s * 0.125;
+  C.phi[cc] = 0.0;                     // the error equation starts from zero: saves a memset launch per level and cycle (ghost cells stay zero / are refreshed)
 }
 
 __global__ void kk_cc_prolong(CLev F, CLev C) {
@@ -488,7 +490,9 @@ __global__ void kk_cc_unpack_rh(CLev T, double *dst, const double *buf, const GB
   const int tot = g.n[0] * g.n[1] * g.n[2];
   for (int t = blockIdx.x * blockDim.x + threadIdx.x; t < tot; t += gridDim.x * blockDim.x) {
     const int i = t % g.n[0], j = (t / g.n[0]) % g.n[1], k = t / (g.n[0] * g.n[1]);
-    dst[cidx(T, g.c0[0] + i, g.c0[1] + j, g.c0[2] + k)] = buf[g.off + t];
+    const long cc = cidx(T, g.c0[0] + i, g.c0[1] + j, g.c0[2] + k);
+    dst[cc] = buf[g.off + t];
+    T.phi[cc] = 0.0;                    // zero initial guess of the tail's first level (see kk_cc_restrict)
   }
 }
 __global__ void kk_cc_unpack_b(CLev T, const double *buf, const GBox *gb) {
@@ -729,8 +733,7 @@ static void cc_bottom_t(const CCMG &M, const CLev &L) {      // max(nub, N^2) sw
 }
 static void cc_vcycle_t(const CCMG &M, int l) {
   const vdn_params &P = ctx().prm;
-  const CLev &L = M.tail[l];
-  HIPCHK(hipMemsetAsync(L.phi, 0, sizeof(double) * L.sz, ctx().stream));
+  const CLev &L = M.tail[l];                 // phi = 0 on entry: written by the restriction that feeds this level
   if (l == (int)M.tail.size() - 1) { cc_bottom_t(M, L); return; }
   const CLev &C = M.tail[l + 1];
   cc_gsrb_t(M, L, P.mg_nu1);
@@ -776,8 +779,7 @@ static void cc_prolong_up(CCMG &M, int l) {
 static void cc_vcycle_d(CCMG &M, int l) {
   const vdn_params &P = ctx().prm;
   CDLev &DL = M.dlev[l];
-  for (const CBox &B : DL.boxes) HIPCHK(hipMemsetAsync(B.L.phi, 0, sizeof(double) * B.L.sz, ctx().stream));
-  const bool last = (l == (int)M.dlev.size() - 1);
+  const bool last = (l == (int)M.dlev.size() - 1);      // phi = 0 on entry: written by the restriction that feeds this level
   if (last && M.tail.empty()) {         // nothing below: bottom sweeps on the distributed level itself
     const int N = std::max(DL.ng[0], std::max(DL.ng[1], DL.ng[2]));     // largest GLOBAL extent, as in the oracle
     cc_gsrb_d(M, DL, std::max(P.mg_nub, N * N));

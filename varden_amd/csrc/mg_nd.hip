@@ -237,7 +237,9 @@ __global__ void kk_nd_restrict(NLev F, NLev C) {
           s = s + (wa * wb * wc) * F.res[f0 + a + b * sy + c * sz];
         }
   }
-  C.b[nidx(C, i, j, k)] = s * 0.125;
+  const long cn = nidx(C, i, j, k);
+  C.b[cn] = s * 0.125;
+  C.phi[cn] = 0.0;                     // the error equation starts from zero: saves a memset launch per level and cycle (ghost nodes stay zero / are refreshed)
 }
 // trilinear interpolation of the coarse field at fine node offsets (oi,oj,ok) of coarse node (I,J,K): the eight coarse values are
 // loaded in one unconditional batch and added under predicates in the order (c,b,a) ascending of the oracle's loops
@@ -633,9 +635,6 @@ static void nd_residual_d(NDMG &M, NDLev &DL, bool norm) {
   if (DL.halo_res) xplan_run(DL.halo_res);
   if (norm) comm_allreduce_max_dev(M.d_nrm, 1);
 }
-static void nd_zero_phi(NDLev &DL) {
-  for (NBox &B : DL.boxes) HIPCHK(hipMemsetAsync(B.L.phi, 0, sizeof(double) * B.L.sz, ctx().stream));
-}
 
 // ---- replicated tail ------------------------------------------------------------------------------------------------
 static void nd_fill_nodes(const NLev &L, double *a) {
@@ -663,7 +662,8 @@ static void nd_bottom_t(NLev &L) {          // max(nub, 2 N^2) sweeps (same rule
 static void nd_vcycle_t(NDMG &M, int l) {
   const vdn_params &P = ctx().prm;
   NLev &L = M.tail[l];
-  HIPCHK(hipMemsetAsync(L.phi, 0, sizeof(double) * L.sz, ctx().stream));
+  // phi = 0 on entry: deeper tail levels get it from kk_nd_restrict, the first one is filled by the generic gather/unpack
+  if (l == 0) HIPCHK(hipMemsetAsync(L.phi, 0, sizeof(double) * L.sz, ctx().stream));
   if (l == (int)M.tail.size() - 1) { nd_bottom_t(L); return; }
   NLev &C = M.tail[l + 1];
   nd_jacobi_t(L, P.hg_nu1);
@@ -716,8 +716,7 @@ static int nd_bottom_sweeps_global(const NDLev &DL) {
 }
 static void nd_vcycle_d(NDMG &M, int l) {
   const vdn_params &P = ctx().prm;
-  NDLev &DL = M.dlev[l];
-  nd_zero_phi(DL);
+  NDLev &DL = M.dlev[l];                               // phi = 0 on entry: written by kk_nd_restrict
   const bool last = (l == (int)M.dlev.size() - 1);
   if (last && M.tail.empty()) { nd_jacobi_d(DL, nd_bottom_sweeps_global(DL)); return; }
   nd_jacobi_d(DL, P.hg_nu1);
