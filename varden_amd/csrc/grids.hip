@@ -180,6 +180,19 @@ extern "C" int vdn_make_new_grids(const vdn_multifab *s, int lev1, int buf_wid, 
   std::vector<IBox> cl;
   IBox whole; for (int d = 0; d < 3; d++) { whole.lo[d] = 0; whole.hi[d] = G.n[d] - 1; }
   cluster(G, whole, min_eff, std::max(1, (min_width + blocking - 1) / blocking), cl);
+  // 3b. merge neighbours whose union is again a box (the recursion cuts more than the final box set needs, e.g. where a cut for the
+  // nesting region or a hole left two boxes of equal cross-section side by side): fewer, larger boxes for the same cells
+  for (bool merged = true; merged;) {
+    merged = false;
+    for (size_t a = 0; a < cl.size() && !merged; a++)
+      for (size_t b = a + 1; b < cl.size() && !merged; b++)
+        for (int d = 0; d < 3 && !merged; d++) {
+          const int t1 = (d + 1) % 3, t2 = (d + 2) % 3;
+          if (cl[a].lo[t1] != cl[b].lo[t1] || cl[a].hi[t1] != cl[b].hi[t1] || cl[a].lo[t2] != cl[b].lo[t2] || cl[a].hi[t2] != cl[b].hi[t2]) continue;
+          if (cl[a].hi[d] + 1 == cl[b].lo[d]) { cl[a].hi[d] = cl[b].hi[d]; cl.erase(cl.begin() + b); merged = true; }
+          else if (cl[b].hi[d] + 1 == cl[a].lo[d]) { cl[a].lo[d] = cl[b].lo[d]; cl.erase(cl.begin() + b); merged = true; }
+        }
+  }
   // 4. refine (blocks -> cells of this level -> cells of the finer level) and chop to max_grid_size
   std::vector<vdn_box> out;
   for (const IBox &b : cl) {
