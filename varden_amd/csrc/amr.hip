@@ -51,9 +51,37 @@ static bool isect(const int alo[3], const int ahi[3], const int blo[3], const in
   return true;
 }
 
+
+// ---- views of the other level (several ranks: vdn_internal.h SrcView) ------------------------------------------------------------
+// footprint tags keep the cached views of one multifab apart
+enum { VT_REFINE = 1, VT_REFINE_FACE0 = 2, VT_COARSEN_G = 8, VT_COARSEN_1 = 20, VT_REFINE_G1 = 21, VT_COARSEN_0 = 22, VT_NODE_C2F = 23, VT_NODE_F2C = 24 };
+static const std::vector<vdn_box> &level_boxes(const vdn_multifab *mf) { return mf->la->boxes[mf->lev]; }
+static const std::vector<int> &level_owner(const vdn_multifab *mf) { return mf->la->owner[mf->lev]; }
+static int global_index(const vdn_multifab *mf, int li) { return mf->la->local[mf->lev][li]; }
+// the index region of the FINER level over the cells (faces: +1 in dir `face`, -1 = cells; nodes: face = 3) of every box of `crse_side`, grown by g fine points
+static std::vector<vdn_box> refined_footprints(const vdn_multifab *crse_side, int face, int g) {
+  std::vector<vdn_box> fp;
+  for (const vdn_box &b : level_boxes(crse_side)) {
+    vdn_box o;
+    for (int d = 0; d < 3; d++) { const int extra = (face == 3 || face == d) ? 1 : 0; o.lo[d] = 2 * b.lo[d] - g; o.hi[d] = (extra ? 2 * (b.hi[d] + 1) : 2 * b.hi[d] + 1) + g; }
+    fp.push_back(o);
+  }
+  return fp;
+}
+// the index region of the COARSER level under every box of `fine_side` grown by gf fine points, then grown by gc coarse points
+static std::vector<vdn_box> coarsened_footprints(const vdn_multifab *fine_side, int gf, int face, int gc) {
+  std::vector<vdn_box> fp;
+  for (const vdn_box &b : level_boxes(fine_side)) {
+    vdn_box o;
+    for (int d = 0; d < 3; d++) { const int extra = (face == 3 || face == d) ? 1 : 0; o.lo[d] = hfdiv2(b.lo[d] - gf) - gc; o.hi[d] = hfdiv2(b.hi[d] + extra + gf) + extra + gc; }
+    fp.push_back(o);
+  }
+  return fp;
+}
+
 // ---- restriction ----------------------------------------------------------------------------------------------------
 // (all multi-box loops of this file go through launch_batched / BatchSet: one launch per operation and level, vdn_dev.h)
-struct RestrictB { Range3 r; int g[3]; FV crse, fine; int icomp, nc;
+struct RestrictB { Range3 r; int g[3]; FV crse, fine; int icomp, nc, fc0;   // fine holds the components from fc0 on
   static __device__ double body(const RestrictB &a, int i, int j, int k, int) {
     for (int c = a.icomp; c < a.icomp + a.nc; c++) {
       double s = 0.0;
@@ -62,18 +90,21 @@ struct RestrictB { Range3 r; int g[3]; FV crse, fine; int icomp, nc;
         #pragma unroll
         for (int jj = 0; jj < 2; jj++)
           #pragma unroll
-          for (int ii = 0; ii < 2; ii++) s = s + fv_get(a.fine, 2 * i + ii, 2 * j + jj, 2 * k + kk, c);
+          for (int ii = 0; ii < 2; ii++) s = s + fv_get(a.fine, 2 * i + ii, 2 * j + jj, 2 * k + kk, c - a.fc0);
       fv_at(a.crse, i, j, k, c) = s * 0.125;
     }
     return 0.0;
   } };
 void ml_cc_restriction(vdn_multifab *crse, const vdn_multifab *fine, int icomp, int nc) {
+  const SrcView F = make_view(fine, refined_footprints(crse, -1, 0), level_owner(crse), icomp, nc, VT_REFINE);
+  F.refresh();
   std::vector<RestrictB> v;
-  for (int f = 0; f < fine->nfabs(); f++) for (int c = 0; c < crse->nfabs(); c++) {
+  for (int f = 0; f < F.nboxes(); f++) for (int c = 0; c < crse->nfabs(); c++) {
+    if (!F.have[f]) continue;
     int clo[3], chi[3]; RestrictB a;
-    for (int d = 0; d < 3; d++) { clo[d] = fine->vbox[f].lo[d] / 2; chi[d] = fine->vbox[f].hi[d] / 2; }
+    for (int d = 0; d < 3; d++) { clo[d] = F.vbox[f].lo[d] / 2; chi[d] = F.vbox[f].hi[d] / 2; }
     if (!isect(clo, chi, crse->vbox[c].lo, crse->vbox[c].hi, a.r)) continue;
-    a.crse = crse->fabs[c]; a.fine = fine->fabs[f]; a.icomp = icomp; a.nc = nc;
+    a.crse = crse->fabs[c]; a.fine = F.fv[f]; a.icomp = icomp; a.nc = nc; a.fc0 = icomp;
     v.push_back(a);
   }
   launch_batched(v, 0, (double *)nullptr, 0, ctx().stream);
@@ -94,20 +125,23 @@ struct EdgeRestrictB { Range3 r; int g[3]; FV crse, fine; int dir;
     return 0.0;
   } };
 void ml_edge_restriction(vdn_multifab *crse, const vdn_multifab *fine, int dir) {
+  const SrcView F = make_view(fine, refined_footprints(crse, dir, 0), level_owner(crse), 0, 1, VT_REFINE_FACE0 + dir);
+  F.refresh();
   std::vector<EdgeRestrictB> v;
-  for (int f = 0; f < fine->nfabs(); f++) for (int c = 0; c < crse->nfabs(); c++) {
+  for (int f = 0; f < F.nboxes(); f++) for (int c = 0; c < crse->nfabs(); c++) {
+    if (!F.have[f]) continue;
     int clo[3], chi[3], blo[3], bhi[3]; EdgeRestrictB a;
-    for (int d = 0; d < 3; d++) { clo[d] = fine->vbox[f].lo[d] / 2; chi[d] = fine->vbox[f].hi[d] / 2; blo[d] = crse->vbox[c].lo[d]; bhi[d] = crse->vbox[c].hi[d]; }
+    for (int d = 0; d < 3; d++) { clo[d] = F.vbox[f].lo[d] / 2; chi[d] = F.vbox[f].hi[d] / 2; blo[d] = crse->vbox[c].lo[d]; bhi[d] = crse->vbox[c].hi[d]; }
     chi[dir] += 1; bhi[dir] += 1;
     if (!isect(clo, chi, blo, bhi, a.r)) continue;
-    a.crse = crse->fabs[c]; a.fine = fine->fabs[f]; a.dir = dir;
+    a.crse = crse->fabs[c]; a.fine = F.fv[f]; a.dir = dir;
     v.push_back(a);
   }
   launch_batched(v, 0, (double *)nullptr, 0, ctx().stream);
 }
 
 // ---- coarse -> fine ghost interpolation ---------------------------------------------------------------------------------
-struct InterpArgs { int flo[3], fhi[3]; int plo[3], phi[3]; int alo[3], ahi[3]; int icomp, nc; };
+struct InterpArgs { int flo[3], fhi[3]; int plo[3], phi[3]; int alo[3], ahi[3]; int icomp, nc, cc0; };   // crse holds the components from cc0 on
 DEVI double mc_limited(double del, double sm, double s0, double sp) {
   const double dmin = 2.0 * (s0 - sm), dpls = 2.0 * (sp - s0);
   double slim = fmin(fabs(dpls), fabs(dmin));
@@ -124,13 +158,14 @@ struct InterpB { Range3 r; int g[3]; FV fine, crse; InterpArgs A;
   #pragma unroll
   for (int d = 0; d < 3; d++) if (P[d] < A.plo[d] || P[d] > A.phi[d]) return 0.0;
   for (int c = A.icomp; c < A.icomp + A.nc; c++) {
-    const double c0 = fv_get(crse, P[0], P[1], P[2], c);
+    const int cq = c - A.cc0;
+    const double c0 = fv_get(crse, P[0], P[1], P[2], cq);
     double v = c0;
     #pragma unroll
     for (int d = 0; d < 3; d++) {
       double sl = 0.0;
       if (P[d] - 1 >= A.alo[d] && P[d] + 1 <= A.ahi[d]) {
-        const double cm = fv_get(crse, P[0] - (d == 0), P[1] - (d == 1), P[2] - (d == 2), c), cp = fv_get(crse, P[0] + (d == 0), P[1] + (d == 1), P[2] + (d == 2), c);
+        const double cm = fv_get(crse, P[0] - (d == 0), P[1] - (d == 1), P[2] - (d == 2), cq), cp = fv_get(crse, P[0] + (d == 0), P[1] + (d == 1), P[2] + (d == 2), cq);
         sl = mc_limited(0.5 * (cp - cm), cm, c0, cp);
       }
       const double sg = (q[d] - 2 * P[d]) ? 0.25 : -0.25;
@@ -145,41 +180,44 @@ struct InterpB { Range3 r; int g[3]; FV fine, crse; InterpArgs A;
 // cover the domain: parents outside the box (its own ghost cells, filled from the next coarser level) count as "outside"
 void ml_fill_ghost_cells(vdn_multifab *fine, const vdn_multifab *crse, int icomp, int nc) {
   if (fine->ng == 0) return;
+  // the coarse data this rank's fine boxes read: parents of the grown boxes and one more cell for the slopes
+  const SrcView Cv = make_view(crse, coarsened_footprints(fine, fine->ng, -1, 1), level_owner(fine), icomp, nc, VT_COARSEN_G + fine->ng);
+  Cv.refresh();
   std::vector<InterpB> v;
-  const vdn_box &pdc = crse->nfabs() == 1 ? crse->vbox[0] : crse->la->pd[crse->lev];
+  const vdn_box &pdc = Cv.nboxes() == 1 ? Cv.vbox[0] : crse->la->pd[crse->lev];
   for (int f = 0; f < fine->nfabs(); f++) {
     InterpArgs A; Range3 r;
     int glo[3], ghi[3];
     for (int d = 0; d < 3; d++) { A.flo[d] = fine->vbox[f].lo[d]; A.fhi[d] = fine->vbox[f].hi[d]; r.lo[d] = A.flo[d] - fine->ng; r.hi[d] = A.fhi[d] + fine->ng;
       glo[d] = hfdiv2(r.lo[d]); ghi[d] = hfdiv2(r.hi[d]); }
-    A.icomp = icomp; A.nc = nc;
+    A.icomp = icomp; A.nc = nc; A.cc0 = icomp;
     for (int pass = 0; pass < 2; pass++)
-      for (int c = 0; c < crse->nfabs(); c++) {
+      for (int c = 0; c < Cv.nboxes(); c++) {
+        if (!Cv.have[c]) continue;
         int blo[3], bhi[3]; Range3 pr;
-        for (int d = 0; d < 3; d++) { A.alo[d] = crse->vbox[c].lo[d] - crse->ng; A.ahi[d] = crse->vbox[c].hi[d] + crse->ng;
-          blo[d] = pass == 0 ? crse->vbox[c].lo[d] : A.alo[d]; bhi[d] = pass == 0 ? crse->vbox[c].hi[d] : A.ahi[d]; }
+        for (int d = 0; d < 3; d++) { A.alo[d] = Cv.vbox[c].lo[d] - Cv.ng; A.ahi[d] = Cv.vbox[c].hi[d] + Cv.ng;
+          blo[d] = pass == 0 ? Cv.vbox[c].lo[d] : A.alo[d]; bhi[d] = pass == 0 ? Cv.vbox[c].hi[d] : A.ahi[d]; }
         if (!isect(glo, ghi, blo, bhi, pr)) continue;
         if (pass == 1) {
-          // only parents outside the domain; handled per direction slab to stay disjoint from pass 0: use the whole
-          // allocation but skip parents inside the domain in the kernel via plo/phi restricted below
+          // only parents outside the domain; handled per direction slab to stay disjoint from pass 0
           bool any = false;
           for (int d = 0; d < 3; d++) if (pr.lo[d] < pdc.lo[d] || pr.hi[d] > pdc.hi[d]) any = true;
           if (!any) continue;
         }
         for (int d = 0; d < 3; d++) { A.plo[d] = pr.lo[d]; A.phi[d] = pr.hi[d]; }
         if (pass == 1) {
-          // launch one slab per (direction, side) that sticks out of the domain
+          // one slab per (direction, side) that sticks out of the domain
           for (int d = 0; d < 3; d++) for (int s = 0; s < 2; s++) {
             InterpArgs B = A;
             if (s == 0) { if (pr.lo[d] >= pdc.lo[d]) continue; B.phi[d] = std::min(pr.hi[d], pdc.lo[d] - 1); }
             else        { if (pr.hi[d] <= pdc.hi[d]) continue; B.plo[d] = std::max(pr.lo[d], pdc.hi[d] + 1); }
             for (int e = 0; e < d; e++) { B.plo[e] = std::max(B.plo[e], pdc.lo[e]); B.phi[e] = std::min(B.phi[e], pdc.hi[e]); if (B.plo[e] > B.phi[e]) goto next; }
-            { InterpB e; e.r = r; e.fine = fine->fabs[f]; e.crse = crse->fabs[c]; e.A = B; v.push_back(e); }
+            { InterpB e; e.r = r; e.fine = fine->fabs[f]; e.crse = Cv.fv[c]; e.A = B; v.push_back(e); }
             next:;
           }
-          if (crse->nfabs() > 0) break;      // first coarse box whose allocation holds them
+          break;      // the first coarse box (of those present here) whose allocation holds them
         } else
-          { InterpB e; e.r = r; e.fine = fine->fabs[f]; e.crse = crse->fabs[c]; e.A = A; v.push_back(e); }
+          { InterpB e; e.r = r; e.fine = fine->fabs[f]; e.crse = Cv.fv[c]; e.A = A; v.push_back(e); }
       }
   }
   launch_batched(v, 0, (double *)nullptr, 0, ctx().stream);       // every ghost cell has exactly one parent range: order-free
@@ -199,7 +237,7 @@ void ml_fillpatch(vdn_multifab *fine, const vdn_multifab *crse, int icomp, int n
       }
       if (!isect(plo, phi, crse->vbox[c].lo, crse->vbox[c].hi, pr)) continue;
       for (int d = 0; d < 3; d++) { e.A.plo[d] = pr.lo[d]; e.A.phi[d] = pr.hi[d]; }
-      e.A.icomp = icomp; e.A.nc = nc; e.fine = fine->fabs[f]; e.crse = crse->fabs[c];
+      e.A.icomp = icomp; e.A.nc = nc; e.A.cc0 = 0; e.fine = fine->fabs[f]; e.crse = crse->fabs[c];
       v.push_back(e);
     }
   launch_batched(v, 0, (double *)nullptr, 0, ctx().stream);
@@ -272,19 +310,26 @@ struct GrownB { Range3 r; int g[3]; FV fine, crse; GrownArgs A;
 // parents on VALID faces of a coarse box come from that box; the remaining ones (outside the domain, or -- for a one-box coarse
 // level that does not cover the domain -- in that box's own ghost faces) from the first coarse box whose allocation holds them
 void ml_create_umac_grown(vdn_multifab *fine, const vdn_multifab *crse, int dir) {
-  // the first box with its ghost faces (filled by fill_boundary), then every box's valid faces on top (same values where both hold
-  // one): two launches so that the second pass wins
+  // every coarse box present here with its ghost faces (filled by fill_boundary / the level below: equal values where several hold
+  // one), then the valid faces on top: two launches so that the second pass wins
+  const SrcView Cv = make_view(crse, coarsened_footprints(fine, fine->ng, dir, 0), level_owner(fine), 0, 1, VT_COARSEN_0 + 4 * (dir + 1) + fine->ng * 64);
+  Cv.refresh();
   std::vector<GrownB> v0, v1;
   for (int f = 0; f < fine->nfabs(); f++) {
     GrownB e; e.A.dir = dir; e.fine = fine->fabs[f];
     for (int d = 0; d < 3; d++) { e.A.flo[d] = fine->vbox[f].lo[d]; e.A.fhi[d] = fine->vbox[f].hi[d] + (d == dir); e.r.lo[d] = e.A.flo[d] - fine->ng; e.r.hi[d] = e.A.fhi[d] + fine->ng; }
-    for (int d = 0; d < 3; d++) { e.A.plo[d] = crse->vbox[0].lo[d] - crse->ng; e.A.phi[d] = crse->vbox[0].hi[d] + (d == dir) + crse->ng; }
-    e.crse = crse->fabs[0];
-    v0.push_back(e);
-    for (int c = 0; c < crse->nfabs() && crse->nfabs() > 1; c++) {
-      for (int d = 0; d < 3; d++) { e.A.plo[d] = crse->vbox[c].lo[d]; e.A.phi[d] = crse->vbox[c].hi[d] + (d == dir); }
-      e.crse = crse->fabs[c];
-      v1.push_back(e);
+    bool first = true;
+    for (int c = 0; c < Cv.nboxes(); c++) {
+      if (!Cv.have[c]) continue;
+      e.crse = Cv.fv[c];
+      if (first) {        // the first box present here, with its ghost faces
+        for (int d = 0; d < 3; d++) { e.A.plo[d] = Cv.vbox[c].lo[d] - Cv.ng; e.A.phi[d] = Cv.vbox[c].hi[d] + (d == dir) + Cv.ng; }
+        v0.push_back(e); first = false;
+      }
+      if (Cv.nboxes() > 1) {
+        for (int d = 0; d < 3; d++) { e.A.plo[d] = Cv.vbox[c].lo[d]; e.A.phi[d] = Cv.vbox[c].hi[d] + (d == dir); }
+        v1.push_back(e);
+      }
     }
   }
   launch_batched(v0, 0, (double *)nullptr, 0, ctx().stream);
@@ -474,7 +519,7 @@ static void restrict_descs(vdn_multifab *crse, const vdn_multifab *fine, std::ve
     int clo[3], chi[3]; RestrictB a;
     for (int d = 0; d < 3; d++) { clo[d] = fine->vbox[f].lo[d] / 2; chi[d] = fine->vbox[f].hi[d] / 2; }
     if (!isect(clo, chi, crse->vbox[c].lo, crse->vbox[c].hi, a.r)) continue;
-    a.crse = crse->fabs[c]; a.fine = fine->fabs[f]; a.icomp = 0; a.nc = 1;
+    a.crse = crse->fabs[c]; a.fine = fine->fabs[f]; a.icomp = 0; a.nc = 1; a.fc0 = 0;
     v.push_back(a);
   }
 }

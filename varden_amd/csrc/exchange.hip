@@ -266,6 +266,114 @@ void xplan_run(XPlan *P) {
 }
 
 // ====================================================================================================
+// views (see vdn_internal.h): windows of remote boxes for the inter-level operators
+// ====================================================================================================
+struct ViewPlan {
+  std::vector<Peer> peers;            // pack descriptors of what I send; nrecv doubles per peer arrive in d_recv
+  int nc = 1;
+};
+struct ViewKey { unsigned long uid; const void *base; int lev, scomp, nc; unsigned long tag; bool operator<(const ViewKey &o) const {
+  return std::tie(uid, base, lev, scomp, nc, tag) < std::tie(o.uid, o.base, o.lev, o.scomp, o.nc, o.tag); } };
+static std::map<ViewKey, SrcView> g_view_cache;
+static void viewplan_free(ViewPlan *P) {
+  if (!P) return;
+  HIPCHK(hipStreamSynchronize(ctx().stream));
+  for (auto &pr : P->peers) { if (pr.d_pack) HIPCHK(hipFree(pr.d_pack)); if (pr.d_send) HIPCHK(hipFree(pr.d_send)); if (pr.d_recv) HIPCHK(hipFree(pr.d_recv)); }
+  delete P;
+}
+void view_cache_purge(unsigned long uid) {
+  for (auto it = g_view_cache.begin(); it != g_view_cache.end();) {
+    if (it->first.uid == uid) { viewplan_free(it->second.plan); it = g_view_cache.erase(it); } else ++it;
+  }
+}
+void SrcView::refresh() const {
+  if (!plan || plan->peers.empty()) return;
+  hipStream_t st = ctx().stream;
+  need_comm();
+  for (auto &pr : plan->peers)
+    if (!pr.pack.empty()) hipLaunchKernelGGL(k_xpack, dim3(32, 1, (unsigned)pr.pack.size()), dim3(256), 0, st, pr.d_pack, plan->nc, pr.d_send);
+  NCCLCHK(g_rccl.GroupStart());
+  for (auto &pr : plan->peers) {
+    if (pr.nsend) NCCLCHK(g_rccl.Send(pr.d_send, pr.nsend, ncclFloat64, pr.rank, g_rccl.comm, st));
+    if (pr.nrecv) NCCLCHK(g_rccl.Recv(pr.d_recv, pr.nrecv, ncclFloat64, pr.rank, g_rccl.comm, st));
+  }
+  NCCLCHK(g_rccl.GroupEnd());
+}
+SrcView make_view(const vdn_multifab *src, const std::vector<vdn_box> &footprint, const std::vector<int> &dst_owner, int scomp, int nc, unsigned long cache_tag) {
+  const vdn_layout *la = src->la;
+  const int lev = src->lev, me = ctx().rank, nranks = ctx().nranks;
+  const auto &gb = la->boxes[lev];
+  ViewKey key{ la->uid, src->base, lev, scomp, nc, cache_tag };
+  auto hit = g_view_cache.find(key);
+  if (hit != g_view_cache.end()) return hit->second;
+  SrcView V; V.ng = src->ng; V.nc = nc; for (int d = 0; d < 3; d++) V.nodal[d] = src->nodal[d];
+  V.vbox.assign(gb.begin(), gb.end()); V.have.assign(gb.size(), 0); V.fv.resize(gb.size());
+  // local boxes: the fab itself (component offset applied)
+  { int li = 0; for (size_t j = 0; j < gb.size(); j++) if (la->owner[lev][j] == me) { FV f = src->fabs[li++]; f.p += (long)f.sc * scomp; V.fv[j] = f; V.have[j] = 1; } }
+  if (nranks > 1) {
+    // window of box j that rank r needs: bounding box over r's destination boxes of (footprint ∩ allocation of j)
+    ViewPlan *P = new ViewPlan; P->nc = nc;
+    std::map<int, Peer> peers;
+    struct Win { int lo[3], hi[3]; bool any; };
+    for (size_t j = 0; j < gb.size(); j++) {
+      const int oj = la->owner[lev][j];
+      int alo[3], ahi[3];
+      for (int d = 0; d < 3; d++) { alo[d] = gb[j].lo[d] - src->ng; ahi[d] = gb[j].hi[d] + src->nodal[d] + src->ng; }
+      std::vector<Win> win(nranks);
+      for (auto &w : win) { w.any = false; for (int d = 0; d < 3; d++) { w.lo[d] = 1 << 30; w.hi[d] = -(1 << 30); } }
+      for (size_t i = 0; i < footprint.size(); i++) {
+        const int r = dst_owner[i];
+        if (r == oj) continue;
+        int lo[3], hi[3]; bool empty = false;
+        for (int d = 0; d < 3; d++) { lo[d] = std::max(footprint[i].lo[d], alo[d]); hi[d] = std::min(footprint[i].hi[d], ahi[d]); if (lo[d] > hi[d]) empty = true; }
+        if (empty) continue;
+        Win &w = win[r]; w.any = true;
+        for (int d = 0; d < 3; d++) { w.lo[d] = std::min(w.lo[d], lo[d]); w.hi[d] = std::max(w.hi[d], hi[d]); }
+      }
+      for (int r = 0; r < nranks; r++) {
+        if (!win[r].any) continue;
+        const Win &w = win[r];
+        const long tot = (long)(w.hi[0] - w.lo[0] + 1) * (w.hi[1] - w.lo[1] + 1) * (w.hi[2] - w.lo[2] + 1);
+        if (oj == me) {                                      // I send the window of my box j to rank r
+          Peer &pr = peers[r]; pr.rank = r;
+          PackDesc D; memset(&D, 0, sizeof D);
+          D.fv = V.fv[j];
+          for (int d = 0; d < 3; d++) { D.lo[d] = w.lo[d]; D.hi[d] = w.hi[d]; D.sh[d] = 0; D.vlo[d] = 1; D.vhi[d] = 0; }
+          D.off = (long)pr.nsend; pr.nsend += (size_t)tot * nc; pr.pack.push_back(D);
+        } else if (r == me) {                                // I receive it from the owner of j: remember where it will sit
+          Peer &pr = peers[oj]; pr.rank = oj;
+          PackDesc D; memset(&D, 0, sizeof D);
+          for (int d = 0; d < 3; d++) { D.lo[d] = w.lo[d]; D.hi[d] = w.hi[d]; }
+          D.off = (long)pr.nrecv; pr.nrecv += (size_t)tot * nc; D.vlo[0] = (int)j;          // vlo[0] carries the box index until the buffers exist
+          pr.unpack.push_back(D);
+        }
+      }
+    }
+    for (auto &kv : peers) {
+      Peer pr = kv.second;
+      if (!pr.pack.empty()) { HIPCHK(hipMalloc((void **)&pr.d_pack, pr.pack.size() * sizeof(PackDesc)));
+        HIPCHK(hipMemcpyAsync(pr.d_pack, pr.pack.data(), pr.pack.size() * sizeof(PackDesc), hipMemcpyHostToDevice, ctx().stream));
+        HIPCHK(hipMalloc((void **)&pr.d_send, pr.nsend * sizeof(double))); }
+      if (pr.nrecv) {
+        HIPCHK(hipMalloc((void **)&pr.d_recv, pr.nrecv * sizeof(double)));
+        HIPCHK(hipMemsetAsync(pr.d_recv, 0, pr.nrecv * sizeof(double), ctx().stream));
+        for (const PackDesc &D : pr.unpack) {                // the window lives in the receive buffer: same layout as k_xpack writes
+          const int j = D.vlo[0];
+          FV f; f.p = pr.d_recv + D.off; f.a0 = D.lo[0]; f.a1 = D.lo[1]; f.a2 = D.lo[2];
+          f.n0 = D.hi[0] - D.lo[0] + 1; f.n1 = D.hi[1] - D.lo[1] + 1; f.n2 = D.hi[2] - D.lo[2] + 1; f.sc = (long)f.n0 * f.n1 * f.n2;
+          V.fv[j] = f; V.have[j] = 1;
+        }
+      }
+      P->peers.push_back(pr);
+    }
+    HIPCHK(hipStreamSynchronize(ctx().stream));
+    V.plan = P;
+  }
+  g_view_cache.emplace(key, V);
+  return V;
+}
+
+// ====================================================================================================
 // multifab_fill_boundary
 // ====================================================================================================
 std::vector<XBoxInfo> xboxes_of(const vdn_multifab *mf) {
@@ -291,6 +399,7 @@ static std::map<FbKey, XPlan *> g_fb_cache;
 static std::multimap<unsigned long, XPlan *> g_halo_owned;     // multigrid halo plans, by layout uid
 void halo_cache_register(unsigned long uid, XPlan *P) { g_halo_owned.emplace(uid, P); }
 void xplan_cache_purge(unsigned long uid) {
+  view_cache_purge(uid);
   for (auto it = g_fb_cache.begin(); it != g_fb_cache.end();) {
     if (it->first.uid == uid) { xplan_free(it->second); it = g_fb_cache.erase(it); } else ++it;
   }

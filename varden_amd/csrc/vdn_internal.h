@@ -118,6 +118,24 @@ void   xplan_free(XPlan *P);
 void   xplan_cache_purge(unsigned long layout_uid);   // drop every cached plan built for that layout
 void   halo_cache_register(unsigned long layout_uid, XPlan *P);
 std::vector<XBoxInfo> xboxes_of(const vdn_multifab *mf);
+// ---- views of another level's (or another box list's) data, for the inter-level operators on several ranks -----------------------
+// For every GLOBAL box j of `src`'s level: an FV that holds the part of box j (valid + ghost points) this rank's destination boxes
+// read -- the local fab itself when this rank owns j, else a window received from j's owner.  vbox[j] is the TRUE valid box of j
+// (the operators' parent-range filters need it); have[j] tells whether any data of j is present here.  The window buffers persist
+// with the view (descriptor sets built from the FVs stay valid); refresh() re-sends the data.  With one rank a view is just the
+// multifab's own fabs and refresh() does nothing.
+struct ViewPlan;
+struct SrcView {
+  std::vector<char> have; std::vector<FV> fv; std::vector<vdn_box> vbox;
+  int ng = 0, nc = 1, nodal[3] = {0, 0, 0};
+  ViewPlan *plan = nullptr;
+  int nboxes() const { return (int)vbox.size(); }
+  void refresh() const;
+};
+// footprint[i]: for the GLOBAL destination box i (on the level / box list dst_owner describes), the region of src's index space
+// its owner reads (empty: lo > hi).  comps: scomp .. scomp+nc-1 of src travel.
+SrcView make_view(const vdn_multifab *src, const std::vector<vdn_box> &footprint, const std::vector<int> &dst_owner, int scomp, int nc, unsigned long cache_tag);
+void view_cache_purge(unsigned long layout_uid);
 bool   comm_active();
 void   comm_allreduce_max_dev(double *d, int n);
 void   comm_allgather_dev(const double *send, double *recv, size_t count);
