@@ -39,7 +39,6 @@ static void check_nesting(const vdn_layout *la) {
 }
 static void require_amr(const vdn_layout *la) {
   REQUIRE(la->nlev >= 2 && la->nlev <= VDN_MAXLEV, "AMR path: 2..%d levels are implemented (nlevel = %d)", VDN_MAXLEV, la->nlev);
-  REQUIRE(ctx().nranks == 1, "AMR path: single rank only in this round");
   REQUIRE(ctx().prm.dm == 3, "AMR path: dm = 3 only");
   for (size_t d = 0; d < la->rr.size(); d++) REQUIRE(la->rr[d] == 2, "AMR path: refinement ratio 2 only");
   check_nesting(la);
@@ -387,19 +386,19 @@ struct CfB { Range3 r; int g[3]; FV pf, pc; CfArgs A;                // r: the g
   } };
 // ghost cells of the fine phi: coarse-fine interpolation on every face that is not a domain face, then the same-level exchange
 // (which overwrites the cells that another fine box covers); domain faces were closed by the closure
-static void cf_descs(vdn_multifab *pf, const vdn_multifab *pc, const vdn_bc_tower *bct, int bc_comp0, std::vector<CfB> &v) {
+static void cf_descs(vdn_multifab *pf, const SrcView &pc, const vdn_bc_tower *bct, int bc_comp0, std::vector<CfB> &v) {
   for (int f = 0; f < pf->nfabs(); f++) for (int d = 0; d < 3; d++) for (int s = 0; s < 2; s++) {
     if (bct->ell_bc(pf->lev, f + 1, d, s, bc_comp0) != VDN_BC_INT) continue;
     Range3 r; for (int t = 0; t < 3; t++) { r.lo[t] = pf->vbox[f].lo[t]; r.hi[t] = pf->vbox[f].hi[t]; }
     r.lo[d] = r.hi[d] = s ? pf->vbox[f].hi[d] + 1 : pf->vbox[f].lo[d] - 1;
-    for (int c = 0; c < pc->nfabs(); c++) {
+    for (int c = 0; c < pc.nboxes(); c++) {
+      if (!pc.have[c]) continue;
       // only coarse boxes that hold a parent of this slab
-      int plo[3], phi[3], q[3]; Range3 dummy;
-      for (int t = 0; t < 3; t++) { plo[t] = hfdiv2(r.lo[t]); phi[t] = hfdiv2(r.hi[t]); q[t] = 0; }
-      (void)q;
-      if (!isect(plo, phi, pc->vbox[c].lo, pc->vbox[c].hi, dummy)) continue;
-      CfB a; a.r = r; a.pf = pf->fabs[f]; a.pc = pc->fabs[c]; a.A.d = d; a.A.s = s;
-      for (int t = 0; t < 3; t++) { a.A.plo[t] = pc->vbox[c].lo[t]; a.A.phi[t] = pc->vbox[c].hi[t]; }
+      int plo[3], phi[3]; Range3 dummy;
+      for (int t = 0; t < 3; t++) { plo[t] = hfdiv2(r.lo[t]); phi[t] = hfdiv2(r.hi[t]); }
+      if (!isect(plo, phi, pc.vbox[c].lo, pc.vbox[c].hi, dummy)) continue;
+      CfB a; a.r = r; a.pf = pf->fabs[f]; a.pc = pc.fv[c]; a.A.d = d; a.A.s = s;
+      for (int t = 0; t < 3; t++) { a.A.plo[t] = pc.vbox[c].lo[t]; a.A.phi[t] = pc.vbox[c].hi[t]; }
       v.push_back(a);
     }
   }
@@ -513,24 +512,37 @@ struct MLCC { int nlev; vdn_layout *la; vdn_multifab **rh, **phi, **beta, **alph
               BatchSet<AbsmaxB> absmax[VDN_MAXLEV]; BatchSet<GsrbB> gsrb[VDN_MAXLEV]; BatchSet<AddB> add[VDN_MAXLEV];
               BatchSet<AddProlongB> prolong[VDN_MAXLEV][VDN_MAXLEV];   // [source level n][target level m]: src = e[n] (m = n+1) or scr[m-1]
               BatchSet<RestrictB> rphi[VDN_MAXLEV], rres[VDN_MAXLEV];  // [fine level]
+              // the other level's fields as seen from this rank (several ranks: windows of remote boxes, refreshed before each use)
+              SrcView vc_phi[VDN_MAXLEV], vf_phi[VDN_MAXLEV], vf_res[VDN_MAXLEV], vf_beta[VDN_MAXLEV][3], vc_src[VDN_MAXLEV][VDN_MAXLEV];
 };
-static void restrict_descs(vdn_multifab *crse, const vdn_multifab *fine, std::vector<RestrictB> &v) {
-  for (int f = 0; f < fine->nfabs(); f++) for (int c = 0; c < crse->nfabs(); c++) {
+static void restrict_descs(vdn_multifab *crse, const SrcView &fine, std::vector<RestrictB> &v) {
+  for (int f = 0; f < fine.nboxes(); f++) for (int c = 0; c < crse->nfabs(); c++) {
+    if (!fine.have[f]) continue;
     int clo[3], chi[3]; RestrictB a;
-    for (int d = 0; d < 3; d++) { clo[d] = fine->vbox[f].lo[d] / 2; chi[d] = fine->vbox[f].hi[d] / 2; }
+    for (int d = 0; d < 3; d++) { clo[d] = fine.vbox[f].lo[d] / 2; chi[d] = fine.vbox[f].hi[d] / 2; }
     if (!isect(clo, chi, crse->vbox[c].lo, crse->vbox[c].hi, a.r)) continue;
-    a.crse = crse->fabs[c]; a.fine = fine->fabs[f]; a.icomp = 0; a.nc = 1; a.fc0 = 0;
+    a.crse = crse->fabs[c]; a.fine = fine.fv[f]; a.icomp = 0; a.nc = 1; a.fc0 = 0;
     v.push_back(a);
   }
+}
+// a box face that is not on the domain boundary (what ell_bc == BC_INT says for a local box), for ANY box of the level
+static bool face_is_interior(const vdn_layout *la, int lev, const vdn_box &b, int d, int s) {
+  return s ? b.hi[d] != la->pd[lev].hi[d] : b.lo[d] != la->pd[lev].lo[d];
 }
 static void mlcc_build_sets(MLCC &S) {
   hipStream_t st = ctx().stream;
   const int L = S.nlev;
   for (int n = 0; n < L; n++) {
     { std::vector<ClosureB> v; closure_descs(S.phi[n], S.bct, S.bcc, v); S.closure[n].build(v, 0, st); }
-    if (n >= 1) { std::vector<CfB> v; cf_descs(S.phi[n], S.phi[n - 1], S.bct, S.bcc, v); S.cf[n].build(v, 0, st); }
-    if (n >= 1) { std::vector<RestrictB> v; restrict_descs(S.phi[n - 1], S.phi[n], v); S.rphi[n].build(v, 0, st); }
-    if (n >= 1) { std::vector<RestrictB> v; restrict_descs(S.res[n - 1], S.res[n], v); S.rres[n].build(v, 0, st); }
+    if (n >= 1) {
+      S.vc_phi[n] = make_view(S.phi[n - 1], coarsened_footprints(S.phi[n], 1, -1, 1), level_owner(S.phi[n]), 0, 1, VT_COARSEN_1);
+      S.vf_phi[n] = make_view(S.phi[n], refined_footprints(S.phi[n - 1], -1, 2), level_owner(S.phi[n - 1]), 0, 1, VT_REFINE_G1);
+      S.vf_res[n] = make_view(S.res[n], refined_footprints(S.res[n - 1], -1, 0), level_owner(S.res[n - 1]), 0, 1, VT_REFINE);
+      for (int d = 0; d < 3; d++) { S.vf_beta[n][d] = make_view(S.beta[3 * n + d], refined_footprints(S.phi[n - 1], d, 2), level_owner(S.phi[n - 1]), 0, 1, VT_REFINE_G1); S.vf_beta[n][d].refresh(); }
+      { std::vector<CfB> v; cf_descs(S.phi[n], S.vc_phi[n], S.bct, S.bcc, v); S.cf[n].build(v, 0, st); }
+      { std::vector<RestrictB> v; restrict_descs(S.phi[n - 1], S.vf_phi[n], v); S.rphi[n].build(v, 0, st); }
+      { std::vector<RestrictB> v; restrict_descs(S.res[n - 1], S.vf_res[n], v); S.rres[n].build(v, 0, st); }
+    }
     std::vector<ResidualB> vr; std::vector<AbsmaxB> va; std::vector<GsrbB> vg; std::vector<AddB> vadd;
     for (int b = 0; b < S.rh[n]->nfabs(); b++) {
       const Range3 r = valid_range(S.rh[n], b);
@@ -552,9 +564,11 @@ static void mlcc_build_sets(MLCC &S) {
     if (n >= 1)
       for (int d = 0; d < 3; d++) for (int s = 0; s < 2; s++) {
         std::vector<RefluxB> v;
-        for (int f = 0; f < S.phi[n]->nfabs(); f++) {
-          if (S.bct->ell_bc(n, f + 1, d, s, S.bcc) != VDN_BC_INT) continue;
-          const vdn_box &fb = S.phi[n]->vbox[f];
+        const std::vector<vdn_box> &fboxes = level_boxes(S.phi[n]);
+        for (int f = 0; f < (int)fboxes.size(); f++) {
+          if (!face_is_interior(S.la, n, fboxes[f], d, s)) continue;
+          if (!S.vf_phi[n].have[f] || !S.vf_beta[n][d].have[f]) continue;      // no coarse box of this rank reaches that fine box
+          const vdn_box &fb = fboxes[f];
           int clo[3], chi[3];
           for (int t = 0; t < 3; t++) { clo[t] = fb.lo[t] / 2; chi[t] = fb.hi[t] / 2; }
           clo[d] = chi[d] = (s ? fb.hi[d] + 1 : fb.lo[d]) / 2;
@@ -565,7 +579,7 @@ static void mlcc_build_sets(MLCC &S) {
             if (!isect(clo, chi, blo, bhi, q.r)) continue;
             q.A.d = d; q.A.s = s; q.A.dxf = S.dx[3 * n + d]; q.A.dxc = S.dx[3 * (n - 1) + d];
             q.res_c = S.res[n - 1]->fabs[c]; q.phi_c = S.phi[n - 1]->fabs[c]; q.beta_c = S.beta[3 * (n - 1) + d]->fabs[c]; q.mask = S.mask[n - 1]->fabs[c];
-            q.phi_f = S.phi[n]->fabs[f]; q.beta_f = S.beta[3 * n + d]->fabs[f];
+            q.phi_f = S.vf_phi[n].fv[f]; q.beta_f = S.vf_beta[n][d].fv[f];
             v.push_back(q);
           }
         }
@@ -573,12 +587,15 @@ static void mlcc_build_sets(MLCC &S) {
       }
     // prolongation of the correction of level n to the levels above it
     for (int m = n + 1; m < L; m++) {
-      vdn_multifab *src = (m == n + 1) ? S.e[n] : S.scr[m - 1];
+      vdn_multifab *srcmf = (m == n + 1) ? S.e[n] : S.scr[m - 1];
+      S.vc_src[n][m] = make_view(srcmf, coarsened_footprints(S.phi[m], 0, -1, 0), level_owner(S.phi[m]), 0, 1, VT_COARSEN_0);
+      const SrcView &src = S.vc_src[n][m];
       const bool keep = m < L - 1;
       std::vector<AddProlongB> v;
-      for (int f = 0; f < S.phi[m]->nfabs(); f++) for (int c = 0; c < src->nfabs(); c++) {
-        AddProlongB q; q.r = valid_range(S.phi[m], f); q.af = S.phi[m]->fabs[f]; q.sc = keep ? S.scr[m]->fabs[f] : S.phi[m]->fabs[f]; q.keep = keep ? 1 : 0; q.ec = src->fabs[c];
-        for (int d = 0; d < 3; d++) { q.plo[d] = src->vbox[c].lo[d]; q.phi[d] = src->vbox[c].hi[d]; }
+      for (int f = 0; f < S.phi[m]->nfabs(); f++) for (int c = 0; c < src.nboxes(); c++) {
+        if (!src.have[c]) continue;
+        AddProlongB q; q.r = valid_range(S.phi[m], f); q.af = S.phi[m]->fabs[f]; q.sc = keep ? S.scr[m]->fabs[f] : S.phi[m]->fabs[f]; q.keep = keep ? 1 : 0; q.ec = src.fv[c];
+        for (int d = 0; d < 3; d++) { q.plo[d] = src.vbox[c].lo[d]; q.phi[d] = src.vbox[c].hi[d]; }
         int plo[3], phi[3]; Range3 dummy;
         for (int d = 0; d < 3; d++) { plo[d] = q.r.lo[d] / 2; phi[d] = q.r.hi[d] / 2; }
         if (!isect(plo, phi, q.plo, q.phi, dummy)) continue;
@@ -590,9 +607,9 @@ static void mlcc_build_sets(MLCC &S) {
 }
 static void fill_phi_ghosts(MLCC &S) {
   hipStream_t st = ctx().stream;
-  for (int n = S.nlev - 1; n >= 1; n--) S.rphi[n].run(0, (double *)nullptr, st);
+  for (int n = S.nlev - 1; n >= 1; n--) { S.vf_phi[n].refresh(); S.rphi[n].run(0, (double *)nullptr, st); }
   for (int n = 0; n < S.nlev; n++) { S.closure[n].run(0, (double *)nullptr, st); mf_fill_boundary(S.phi[n]); }
-  for (int n = 1; n < S.nlev; n++) { S.cf[n].run(0, (double *)nullptr, st); mf_fill_boundary(S.phi[n]); }
+  for (int n = 1; n < S.nlev; n++) { S.vc_phi[n].refresh(); S.cf[n].run(0, (double *)nullptr, st); mf_fill_boundary(S.phi[n]); }
 }
 static double composite_residual(MLCC &S) {
   hipStream_t st = ctx().stream;
@@ -601,9 +618,10 @@ static double composite_residual(MLCC &S) {
   HIPCHK(hipMemsetAsync(S.d_nrm, 0, sizeof(double), st));
   for (int n = 0; n < L; n++) S.resid[n].run(0, n == L - 1 ? S.d_nrm : (double *)nullptr, st);
   // flux matching: lo faces then hi faces of every direction (one update per coarse cell and launch, hence deterministic)
-  for (int n = 1; n < L; n++) for (int ds = 0; ds < 6; ds++) S.reflux[n][ds].run(0, (double *)nullptr, st);
-  for (int n = L - 1; n >= 1; n--) S.rres[n].run(0, (double *)nullptr, st);
+  for (int n = 1; n < L; n++) { S.vf_phi[n].refresh(); for (int ds = 0; ds < 6; ds++) S.reflux[n][ds].run(0, (double *)nullptr, st); }     // fine phi incl. its ghost cells
+  for (int n = L - 1; n >= 1; n--) { S.vf_res[n].refresh(); S.rres[n].run(0, (double *)nullptr, st); }
   for (int n = 0; n < L - 1; n++) S.absmax[n].run(0, S.d_nrm, st);
+  comm_allreduce_max_dev(S.d_nrm, 1);
   return read_dev(S.d_nrm);
 }
 // nsweeps red-black sweeps of A_n e = res_n from e = 0 (homogeneous coarse-fine interface)
@@ -619,7 +637,7 @@ static void level_relax(MLCC &S, int n, int nsweeps) {
 // phi_n += e_n, and the piecewise-constant prolongation of that correction on every finer level
 static void apply_correction(MLCC &S, int n) {
   S.add[n].run(0, (double *)nullptr, ctx().stream);
-  for (int m = n + 1; m < S.nlev; m++) S.prolong[n][m].run(0, (double *)nullptr, ctx().stream);
+  for (int m = n + 1; m < S.nlev; m++) { S.vc_src[n][m].refresh(); S.prolong[n][m].run(0, (double *)nullptr, ctx().stream); }
 }
 // rh, phi: [lev];  beta: [lev*3 + d];  dx: [lev*3 + d]
 // alpha: [lev] cell coefficients of (alpha - div beta grad), or nullptr.  The ghost cells of the incoming phi carry inhomogeneous
@@ -650,9 +668,10 @@ int ml_cc_solve(vdn_layout *la, vdn_multifab **rh, vdn_multifab **phi, vdn_multi
     if (n < L - 1) {                                         // cells of level n covered by level n+1
       S.mask[n] = mf_temp(la, n, 1, 0, -1, true, 0.0);
       std::vector<SetboxB> v;
-      for (int f = 0; f < phi[n + 1]->nfabs(); f++) for (int c = 0; c < S.mask[n]->nfabs(); c++) {
+      const std::vector<vdn_box> &fb = level_boxes(phi[n + 1]);
+      for (int f = 0; f < (int)fb.size(); f++) for (int c = 0; c < S.mask[n]->nfabs(); c++) {
         int clo[3], chi[3]; SetboxB q;
-        for (int d = 0; d < 3; d++) { clo[d] = phi[n + 1]->vbox[f].lo[d] / 2; chi[d] = phi[n + 1]->vbox[f].hi[d] / 2; }
+        for (int d = 0; d < 3; d++) { clo[d] = fb[f].lo[d] / 2; chi[d] = fb[f].hi[d] / 2; }
         if (!isect(clo, chi, S.mask[n]->vbox[c].lo, S.mask[n]->vbox[c].hi, q.r)) continue;
         q.a = S.mask[n]->fabs[c]; q.v = 1.0; v.push_back(q);
       }
@@ -666,6 +685,7 @@ int ml_cc_solve(vdn_layout *la, vdn_multifab **rh, vdn_multifab **phi, vdn_multi
     for (int b = 0; b < rh[n]->nfabs(); b++) { AbsmaxB q; q.r = valid_range(rh[n], b); q.a = rh[n]->fabs[b]; q.mask = n < L - 1 ? S.mask[n]->fabs[b] : rh[n]->fabs[b]; q.has_mask = n < L - 1 ? 1 : 0; v.push_back(q); }
     launch_batched(v, 0, S.d_nrm, 16, st);
   }
+  comm_allreduce_max_dev(S.d_nrm, 1);
   const double bnorm = read_dev(S.d_nrm);
   const vdn_params &P = ctx().prm;
   int it = 0; bool conv = (bnorm == 0.0); double rn = 0.0;

@@ -272,8 +272,8 @@ struct ViewPlan {
   std::vector<Peer> peers;            // pack descriptors of what I send; nrecv doubles per peer arrive in d_recv
   int nc = 1;
 };
-struct ViewKey { unsigned long uid; const void *base; int lev, scomp, nc; unsigned long tag; bool operator<(const ViewKey &o) const {
-  return std::tie(uid, base, lev, scomp, nc, tag) < std::tie(o.uid, o.base, o.lev, o.scomp, o.nc, o.tag); } };
+struct ViewKey { unsigned long uid; const void *base; int lev, scomp, nc, ng, nd; unsigned long tag; bool operator<(const ViewKey &o) const {
+  return std::tie(uid, base, lev, scomp, nc, ng, nd, tag) < std::tie(o.uid, o.base, o.lev, o.scomp, o.nc, o.ng, o.nd, o.tag); } };
 static std::map<ViewKey, SrcView> g_view_cache;
 static void viewplan_free(ViewPlan *P) {
   if (!P) return;
@@ -303,7 +303,7 @@ SrcView make_view(const vdn_multifab *src, const std::vector<vdn_box> &footprint
   const vdn_layout *la = src->la;
   const int lev = src->lev, me = ctx().rank, nranks = ctx().nranks;
   const auto &gb = la->boxes[lev];
-  ViewKey key{ la->uid, src->base, lev, scomp, nc, cache_tag };
+  ViewKey key{ la->uid, src->base, lev, scomp, nc, src->ng, src->nodal[0] | (src->nodal[1] << 1) | (src->nodal[2] << 2), cache_tag };
   auto hit = g_view_cache.find(key);
   if (hit != g_view_cache.end()) return hit->second;
   SrcView V; V.ng = src->ng; V.nc = nc; for (int d = 0; d < 3; d++) V.nodal[d] = src->nodal[d];
