@@ -1220,6 +1220,19 @@ struct NdmRestrictB { Range3 r; int g[3]; FV res_c, res_f, own_f; NdfArgs Af, Ac
     fv_at(q.res_c, i, j, k) = fv_get(q.res_c, i, j, k) + s * 0.125;
     return 0.0;
   } };
+// node-space footprints for the views of the other level (vdn_internal.h SrcView): the nodes of a box are lo .. hi+1
+static int nd_fdiv2(int a) { return a >= 0 ? a / 2 : -((-a + 1) / 2); }
+static std::vector<vdn_box> nd_coarse_footprints(const vdn_layout *la, int fine_lev) {          // coarse nodes the fine nodes of every fine box interpolate from
+  std::vector<vdn_box> fp;
+  for (const vdn_box &b : la->boxes[fine_lev]) { vdn_box o; for (int d = 0; d < 3; d++) { o.lo[d] = nd_fdiv2(b.lo[d] - 1) - 1; o.hi[d] = nd_fdiv2(b.hi[d] + 2) + 2; } fp.push_back(o); }
+  return fp;
+}
+static std::vector<vdn_box> nd_fine_footprints(const vdn_layout *la, int crse_lev) {            // fine nodes the coarse nodes of every coarse box restrict from
+  std::vector<vdn_box> fp;
+  for (const vdn_box &b : la->boxes[crse_lev]) { vdn_box o; for (int d = 0; d < 3; d++) { o.lo[d] = 2 * b.lo[d] - 2; o.hi[d] = 2 * (b.hi[d] + 1) + 2; } fp.push_back(o); }
+  return fp;
+}
+enum { NVT_C2F = 31, NVT_F2C = 32 };
 static bool nd_isect(const Range3 &a, const Range3 &b, Range3 &r) {
   for (int d = 0; d < 3; d++) { r.lo[d] = std::max(a.lo[d], b.lo[d]); r.hi[d] = std::min(a.hi[d], b.hi[d]); if (r.lo[d] > r.hi[d]) return false; }
   return true;
@@ -1240,19 +1253,24 @@ struct MLND {
   MarchSet m_res[VDN_MAXLEV], m_res0[VDN_MAXLEV];    // residual of phi / of the zero field (norm of the right-hand side)
   MarchSet m_jac[VDN_MAXLEV][2];                     // Jacobi ea -> eb, eb -> ea
   BatchSet<NdmRestrictB> rst[VDN_MAXLEV];            // [fine level]
+  const vdn_layout *la = nullptr;
+  SrcView vf_res[VDN_MAXLEV], vf_own[VDN_MAXLEV], vc_own[VDN_MAXLEV];   // [fine level]: fine residual / fine ownership seen from the coarse boxes, coarse ownership seen from the fine boxes
   BatchSet<NdfAbsmaxB> amax[VDN_MAXLEV];
 };
 // mode 0: slaves of level n <- P phi_{n-1};  mode 1: dst_n += P src_{n-1};  mode 2: dst_n = P src_{n-1} (dst zeroed first by the caller)
 static void ml_nd_prolong(MLND &S, int n, vdn_multifab *dst, vdn_multifab *src, int mode) {
+  const SrcView Cv = make_view(src, nd_coarse_footprints(S.la, n), S.la->owner[n], 0, 1, NVT_C2F);
+  Cv.refresh();
   std::vector<NdmProlongB> v;
   for (size_t f = 0; f < S.A[n].size(); f++)
-    for (size_t c = 0; c < S.A[n - 1].size(); c++) {
-      const Range3 &rc = S.r[n - 1][c];
+    for (int c = 0; c < Cv.nboxes(); c++) {
+      if (!Cv.have[c]) continue;
       NdmProlongB q;
-      for (int d = 0; d < 3; d++) { q.r.lo[d] = std::max(S.r[n][f].lo[d], 2 * rc.lo[d]); q.r.hi[d] = std::min(S.r[n][f].hi[d], 2 * rc.hi[d] + 1); q.clo[d] = rc.lo[d]; q.chi[d] = rc.hi[d]; }
+      for (int d = 0; d < 3; d++) { q.clo[d] = Cv.vbox[c].lo[d]; q.chi[d] = Cv.vbox[c].hi[d] + 1; q.r.lo[d] = std::max(S.r[n][f].lo[d], 2 * q.clo[d]); q.r.hi[d] = std::min(S.r[n][f].hi[d], 2 * q.chi[d] + 1); }
       if (q.r.lo[0] > q.r.hi[0] || q.r.lo[1] > q.r.hi[1] || q.r.lo[2] > q.r.hi[2]) continue;
-      q.pf = dst->fabs[f]; q.pc = src->fabs[c]; q.slave = S.slave[n]->fabs[f];
-      q.own_c = S.own[n - 1] ? S.own[n - 1]->fabs[c] : src->fabs[c]; q.has_own = S.own[n - 1] ? 1 : 0; q.Af = S.A[n][f];
+      q.pf = dst->fabs[f]; q.pc = Cv.fv[c]; q.slave = S.slave[n]->fabs[f];
+      const bool ho = S.own[n - 1] != nullptr && S.vc_own[n].have[c];
+      q.own_c = ho ? S.vc_own[n].fv[c] : Cv.fv[c]; q.has_own = ho ? 1 : 0; q.Af = S.A[n][f];
       v.push_back(q);
     }
   launch_batched(v, mode, (double *)nullptr, 0, ctx().stream);
@@ -1282,10 +1300,12 @@ static double ml_nd_residual(MLND &S, bool finest_only, bool zero_field = false)
     if (finest_only) return 0.0;
     if (S.multi[n]) mf_fill_boundary(S.res[n]);
     if (finest) continue;
+    S.vf_res[n + 1].refresh();
     S.rst[n + 1].run(0, (double *)nullptr, st);
     if (S.multi[n] && n > 0) mf_fill_boundary(S.res[n]);      // the ghost nodes must see the restricted part too before level n-1 restricts them
     S.amax[n].run(0, S.d_nrm, st);
   }
+  comm_allreduce_max_dev(S.d_nrm, 1);
   return ndf_read(S.d_nrm);
 }
 // phi_n += e (nodes of level n) and its trilinear prolongation on every finer level (not on physical Dirichlet nodes)
@@ -1307,17 +1327,17 @@ static void ml_nd_apply_correction(MLND &S, int n, vdn_multifab *e) {
 static int ml_nd_solve(vdn_layout *la, vdn_multifab **rh, vdn_multifab **phi, vdn_multifab **coeffs, vdn_multifab **u, const double *dx,
                        const vdn_bc_tower *bct, int press_comp0, double rel_eps, double abs_eps, int max_iter, int *iters, double *res0, double *res) {
   const int L = la->nlev;
-  REQUIRE(L >= 2 && L <= VDN_MAXLEV && ctx().nranks == 1, "composite nodal solve: 2..%d levels, single rank", VDN_MAXLEV);
+  REQUIRE(L >= 2 && L <= VDN_MAXLEV, "composite nodal solve: 2..%d levels", VDN_MAXLEV);
   REQUIRE(!(la->pmask[0] || la->pmask[1] || la->pmask[2]), "composite nodal solve: periodic domains are not implemented");
   hipStream_t st = ctx().stream;
   const size_t mark = arena_mark();
   const vdn_params &P = ctx().prm;
-  MLND S; S.nlev = L; S.d_nrm = (double *)arena_alloc(256);
+  MLND S; S.nlev = L; S.la = la; S.d_nrm = (double *)arena_alloc(256);
   std::vector<vdn_multifab *> temps;
   auto T = [&](vdn_multifab *m) { temps.push_back(m); return m; };
   for (int n = 0; n < L; n++) {
     const int nb = phi[n]->nfabs();
-    S.multi[n] = nb > 1;
+    S.multi[n] = la->boxes[n].size() > 1;                 // the level has several boxes (anywhere): exchanges between them are needed
     S.A[n].resize(nb); S.r[n].resize(nb);
     for (int f = 0; f < nb; f++) {
       const vdn_box &bx = phi[n]->vbox[f];
@@ -1329,8 +1349,8 @@ static int ml_nd_solve(vdn_layout *la, vdn_multifab **rh, vdn_multifab **phi, vd
         A.dirlo[d] = bct->ell_bc(n, f + 1, d, 0, press_comp0) == VDN_BC_DIR;
         A.dirhi[d] = bct->ell_bc(n, f + 1, d, 1, press_comp0) == VDN_BC_DIR;
         // a one-box level: its interface nodes are those of its non-physical faces (the marching kernels then skip the node mask)
-        A.cflo[d] = (n > 0 && nb == 1 && bct->ell_bc(n, f + 1, d, 0, press_comp0) == VDN_BC_INT) ? 1 : 0;
-        A.cfhi[d] = (n > 0 && nb == 1 && bct->ell_bc(n, f + 1, d, 1, press_comp0) == VDN_BC_INT) ? 1 : 0;
+        A.cflo[d] = (n > 0 && !S.multi[n] && bct->ell_bc(n, f + 1, d, 0, press_comp0) == VDN_BC_INT) ? 1 : 0;
+        A.cfhi[d] = (n > 0 && !S.multi[n] && bct->ell_bc(n, f + 1, d, 1, press_comp0) == VDN_BC_INT) ? 1 : 0;
       }
     }
   }
@@ -1353,7 +1373,11 @@ static int ml_nd_solve(vdn_layout *la, vdn_multifab **rh, vdn_multifab **phi, vd
       std::vector<NdfSetB> v1, v0;
       for (int f = 0; f < nb; f++) {
         NdfSetB q; q.r = S.r[n][f]; q.a = S.own[n]->fabs[f]; q.v = 1.0; v1.push_back(q);
-        for (int g = 0; g < f; g++) { NdfSetB z; if (nd_isect(S.r[n][f], S.r[n][g], z.r)) { z.a = S.own[n]->fabs[f]; z.v = 0.0; v0.push_back(z); } }
+        const int gf = la->local[n][f];
+        for (int g = 0; g < gf; g++) {                       // every box of the level with a lower GLOBAL index takes the shared nodes
+          Range3 rg2; for (int d = 0; d < 3; d++) { rg2.lo[d] = la->boxes[n][g].lo[d]; rg2.hi[d] = la->boxes[n][g].hi[d] + 1; }
+          NdfSetB z; if (nd_isect(S.r[n][f], rg2, z.r)) { z.a = S.own[n]->fabs[f]; z.v = 0.0; v0.push_back(z); }
+        }
       }
       launch_batched(v1, 0, (double *)nullptr, 0, st);
       launch_batched(v0, 0, (double *)nullptr, 0, st);
@@ -1371,8 +1395,8 @@ static int ml_nd_solve(vdn_layout *la, vdn_multifab **rh, vdn_multifab **phi, vd
     if (n < L - 1) {
       cov[n] = T(mf_temp(la, n, 1, 1, -1, true, 0.0));
       std::vector<NdfSetB> vc;
-      for (int f = 0; f < phi[n + 1]->nfabs(); f++) {
-        const vdn_box &fb = phi[n + 1]->vbox[f];
+      for (size_t f = 0; f < la->boxes[n + 1].size(); f++) {
+        const vdn_box &fb = la->boxes[n + 1][f];
         Range3 rcov; for (int d = 0; d < 3; d++) { rcov.lo[d] = fb.lo[d] / 2; rcov.hi[d] = fb.hi[d] / 2; }
         for (int c = 0; c < nb; c++) {
           Range3 rb2; NdfSetB q; for (int d = 0; d < 3; d++) { rb2.lo[d] = phi[n]->vbox[c].lo[d] - 1; rb2.hi[d] = phi[n]->vbox[c].hi[d] + 1; }
@@ -1426,13 +1450,17 @@ static int ml_nd_solve(vdn_layout *la, vdn_multifab **rh, vdn_multifab **phi, vd
     S.m_jac[n][0] = ndf_build_march(vj0); S.m_jac[n][1] = ndf_build_march(vj1);
     S.amax[n].build(va, 16, st);
     if (n >= 1) {
+      S.vf_res[n] = make_view(S.res[n], nd_fine_footprints(la, n - 1), la->owner[n - 1], 0, 1, NVT_F2C);
+      S.vf_own[n] = make_view(S.own[n], nd_fine_footprints(la, n - 1), la->owner[n - 1], 0, 1, NVT_F2C); S.vf_own[n].refresh();
+      if (S.own[n - 1]) { S.vc_own[n] = make_view(S.own[n - 1], nd_coarse_footprints(la, n), la->owner[n], 0, 1, NVT_C2F); S.vc_own[n].refresh(); }
       std::vector<NdmRestrictB> v;
-      for (size_t f = 0; f < S.A[n].size(); f++) {
-        const NdfArgs &Af = S.A[n][f];
+      for (int f = 0; f < S.vf_res[n].nboxes(); f++) {
+        if (!S.vf_res[n].have[f] || !S.vf_own[n].have[f]) continue;
+        NdfArgs Af; for (int d = 0; d < 3; d++) { Af.lo[d] = S.vf_res[n].vbox[f].lo[d]; Af.hi[d] = S.vf_res[n].vbox[f].hi[d] + 1; Af.dirlo[d] = Af.dirhi[d] = Af.cflo[d] = Af.cfhi[d] = Af.ilo[d] = Af.ihi[d] = 0; Af.f[d] = 0.0; }
         Range3 rf; for (int d = 0; d < 3; d++) { rf.lo[d] = (Af.lo[d] + 1) / 2; rf.hi[d] = Af.hi[d] / 2; }       // coarse nodes whose fine twin is a node of box f
         for (size_t c = 0; c < S.A[n - 1].size(); c++) {
           NdmRestrictB q; if (!nd_isect(rf, S.r[n - 1][c], q.r)) continue;
-          q.res_c = S.res[n - 1]->fabs[c]; q.res_f = S.res[n]->fabs[f]; q.own_f = S.own[n]->fabs[f]; q.Af = Af; q.Ac = S.A[n - 1][c];
+          q.res_c = S.res[n - 1]->fabs[c]; q.res_f = S.vf_res[n].fv[f]; q.own_f = S.vf_own[n].fv[f]; q.Af = Af; q.Ac = S.A[n - 1][c];
           v.push_back(q);
         }
       }
