@@ -1,0 +1,53 @@
+"""one rank of a multi-rank AMR run on ONE GPU (tests/test_multirank_gpu.py::test_amr_ranks_reproduce_single_rank): a two- or
+three-level fixed hierarchy whose boxes are dealt to the ranks by cell count.  argv: rank nranks idfile outprefix nlev visc"""
+import os
+import sys
+import time
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+
+def main():
+    rank, nranks = int(sys.argv[1]), int(sys.argv[2])
+    idfile, outprefix = sys.argv[3], sys.argv[4]
+    nlev, visc = int(sys.argv[5]), float(sys.argv[6])
+    from varden_amd import boxlib as bl
+    from varden_amd import driver
+    from varden_amd.capi import default_params
+    prm = default_params(cflfac=0.9, visc_coef=visc)
+    comm_id = None
+    if nranks > 1:
+        bl.initialize(prm, rank, nranks, 0)
+        if rank == 0:
+            with open(idfile + ".tmp", "wb") as f:
+                f.write(bl.comm_get_unique_id())
+            os.rename(idfile + ".tmp", idfile)
+        t0 = time.time()
+        while not os.path.exists(idfile):
+            time.sleep(0.01)
+            assert time.time() - t0 < 120, "rendezvous timed out"
+        comm_id = open(idfile, "rb").read()
+    walls = [[bl.NO_SLIP_WALL] * 2] * 3
+    base = [((0, 0, 0), (7, 7, 15)), ((8, 0, 0), (15, 7, 15)), ((0, 8, 0), (7, 15, 15)), ((8, 8, 0), (15, 15, 15))]    # level 0 in four equal boxes (the single-level multigrid wants equal boxes)
+    fine = [((8, 8, 8), (15, 23, 23)), ((16, 8, 8), (23, 15, 23)), ((16, 16, 8), (23, 23, 23))]          # partial shared faces
+    finer = [[((24, 24, 24), (31, 39, 39)), ((32, 24, 24), (39, 39, 39))]] if nlev == 3 else []
+    G = driver.VardenAMR(16, fine, walls, params=prm, finer_levels=finer, base_boxes=base, init_iter=1, do_initial_projection=1,
+                         rank=rank, nranks=nranks, comm_id=comm_id)
+    dts = []
+    for _ in range(2):
+        G.step()
+        dts.append(G.dt)
+    out = {"dt": np.array(dts)}
+    for n in range(G.nlev):
+        for li, gi in enumerate(G.local[n]):
+            out["u%d_%d" % (n, gi)] = G.unew[n].to_numpy(li)[3:-3, 3:-3, 3:-3]
+            out["s%d_%d" % (n, gi)] = G.snew[n].to_numpy(li)[3:-3, 3:-3, 3:-3]
+            out["p%d_%d" % (n, gi)] = G.p[n].to_numpy(li)[1:-1, 1:-1, 1:-1]
+    np.savez(outprefix + ".%d.npz" % rank, **out)
+    G.close()
+
+
+if __name__ == "__main__":
+    main()

@@ -52,3 +52,44 @@ def test_ranks_reproduce_single_rank_bits(gpu, tmp_path, nranks, decomp, n, peri
     for k in sorted(ref):
         assert np.array_equal(ref[k], got[k]), "%s differs: max %.3e" % (k, np.abs(ref[k] - got[k]).max())
     assert np.isfinite(got["u0"]).all() and np.abs(got["u0"]).max() > 0
+
+
+def run_amr_ranks(tmp_path, tag, nranks, nlev, visc):
+    if nranks > 1 and not os.path.exists(FAKE):
+        subprocess.check_call(["make", "-s", "-C", os.path.dirname(FAKE)])
+    idfile, prefix = str(tmp_path / (tag + ".id")), str(tmp_path / tag)
+    env = dict(os.environ, VDN_RCCL_LIB=FAKE, FAKE_RCCL_DIR=str(tmp_path))
+    procs = [subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "_multirank_amr_worker.py"), str(r), str(nranks), idfile, prefix, str(nlev), str(visc)],
+                              env=env, cwd=ROOT) for r in range(nranks)]
+    try:
+        rcs = [p.wait(timeout=240) for p in procs]
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+    assert rcs == [0] * nranks, rcs
+    out = {}
+    for r in range(nranks):
+        with np.load(prefix + ".%d.npz" % r) as z:
+            for k in z.files:
+                if k == "dt":
+                    out.setdefault("dt", z[k])
+                    assert np.array_equal(out["dt"], z[k]), "ranks disagree on dt"
+                else:
+                    out[k] = z[k]
+    return out
+
+
+@pytest.mark.parametrize("nranks,nlev,visc", [(2, 2, 0.0), (3, 2, 0.001), (2, 3, 0.001)])
+def test_amr_ranks_reproduce_single_rank(gpu, tmp_path, nranks, nlev, visc):
+    """SURVEY.md section 8(e), "multi-level extras", on ONE GPU: the boxes of every level of a fixed hierarchy are dealt to 2 / 3 ranks by cell
+    count (a fine box and the coarse boxes under it usually sit on different ranks); start-up sequence + two steps (composite MAC,
+    viscous and nodal solves, average-down, coarse-fine ghost interpolation, flux matching -- all through windows of remote boxes)
+    reproduce the single-rank run on the same boxes bit for bit.  Transport: the RCCL test double (see the module docstring)."""
+    ref = run_amr_ranks(tmp_path, "aref", 1, nlev, visc)
+    got = run_amr_ranks(tmp_path, "amr", nranks, nlev, visc)
+    assert sorted(ref) == sorted(got)
+    assert np.array_equal(ref["dt"], got["dt"]), (ref["dt"], got["dt"])
+    for k in sorted(ref):
+        assert np.array_equal(ref[k], got[k]), "%s differs: max %.3e" % (k, np.abs(ref[k] - got[k]).max())
+    assert np.isfinite(got["u0_0"]).all() and np.abs(got["u1_0"]).max() > 0

@@ -628,7 +628,7 @@ static double composite_residual(MLCC &S) {
 static void level_relax(MLCC &S, int n, int nsweeps) {
   vdn_multifab *e = S.e[n];
   mf_setval(e, 0.0, 0, 1, true);
-  const bool exchange = e->nfabs() > 1 || S.la->pmask[0] || S.la->pmask[1] || S.la->pmask[2];
+  const bool exchange = level_boxes(e).size() > 1 || S.la->pmask[0] || S.la->pmask[1] || S.la->pmask[2];     // boxes of the level anywhere, not just here: every rank must take part
   for (int s = 0; s < nsweeps; s++) for (int col = 0; col < 2; col++) {
     if (exchange) mf_fill_boundary(e);
     S.gsrb[n].run(col, (double *)nullptr, ctx().stream);

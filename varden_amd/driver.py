@@ -163,6 +163,20 @@ class Varden:
             bl.comm_finalize()
 
 
+def distribute(boxes, nranks):
+    """boxes -> ranks by cell count: largest box first onto the least loaded rank (the knapsack of BASELINE.json configs[4]);
+    deterministic, the same on every rank"""
+    if nranks == 1:
+        return [0] * len(boxes)
+    cells = [int(np.prod([b[1][d] - b[0][d] + 1 for d in range(3)])) for b in boxes]
+    load, owner = [0] * nranks, [0] * len(boxes)
+    for i in sorted(range(len(boxes)), key=lambda i: (-cells[i], i)):
+        r = min(range(nranks), key=lambda r: (load[r], r))
+        owner[i] = r
+        load[r] += cells[i]
+    return owner
+
+
 def prm_cluster(prm, name):
     """cluster_min_eff / cluster_min_width / cluster_blocking_factor (src/_parameters:37-39); not part of vdn_params"""
     return {"min_eff": 0.9, "min_width": 4, "blocking": 4}[name]
@@ -175,11 +189,18 @@ class VardenAMR:
     dt = min over levels of estdt, advance_timestep, new -> old copies."""
 
     def __init__(self, nc, fine_boxes, phys_bc, params=None, prob_type=1, grav=-9.8, init_shrink=0.1, device=0, finer_levels=(),
-                 regrid_int=-1, max_levs=None, max_grid_size=256, init_iter=0, do_initial_projection=0):
+                 regrid_int=-1, max_levs=None, max_grid_size=256, init_iter=0, do_initial_projection=0,
+                 rank=0, nranks=1, comm_id=None, base_boxes=None):
+        """several ranks (one per GPU): the boxes of every level are dealt to the ranks by cell count (`distribute`), `base_boxes` cuts
+        level 0 into several boxes, comm_id is the RCCL unique id broadcast by the caller; regridding is single-rank in this round"""
         self.prm = params or default_params()
         self.grav, self.regrid_int, self.max_grid_size = grav, regrid_int, max_grid_size
         self.prm.prob_type = prob_type
-        bl.initialize(self.prm, 0, 1, device)
+        self.rank, self.nranks = rank, nranks
+        bl.initialize(self.prm, rank, nranks, device)
+        if nranks > 1:
+            bl.comm_init(comm_id)
+            assert regrid_int <= 0, "regridding on several ranks is not implemented"
         self.nc = nc
         self.phys = [[int(phys_bc[d][s]) for s in range(2)] for d in range(3)]
         lev_boxes = [fine_boxes] + list(finer_levels)
@@ -187,8 +208,11 @@ class VardenAMR:
         self.max_levs = max_levs or NL
         self.nregrids = 0
         pd = [((0, 0, 0), ((nc << n) - 1,) * 3) for n in range(NL)]
-        self.boxes = [[pd[0]]] + [[(tuple(b[0]), tuple(b[1])) for b in lb] for lb in lev_boxes]
-        self.mla = bl.MLLayout(pd, self.boxes, rr=[(2, 2, 2)] * (NL - 1))
+        base = [pd[0]] if base_boxes is None else [(tuple(b[0]), tuple(b[1])) for b in base_boxes]
+        self.boxes = [base] + [[(tuple(b[0]), tuple(b[1])) for b in lb] for lb in lev_boxes]
+        self.owner = [distribute(lb, nranks) for lb in self.boxes]
+        self.local = [[i for i, o in enumerate(ow) if o == rank] for ow in self.owner]
+        self.mla = bl.MLLayout(pd, self.boxes, owner=self.owner, rr=[(2, 2, 2)] * (NL - 1))
         self.bct = bl.BCTower(self.mla, self.phys)
         self.dx = [[1.0 / (nc << n)] * 3 for n in range(NL)]
         dm, ns = 3, self.prm.nscal
@@ -199,11 +223,12 @@ class VardenAMR:
         self.ext_vel_force, self.ext_scal_force = mk(dm, 1), mk(ns, 1)
         for n in range(self.nlev):
             self.ext_vel_force[n].setval(grav, dm - 1, 1, all=True)
-            for i, (blo, bhi) in enumerate(self.boxes[n]):
+            for li, gi in enumerate(self.local[n]):         # each rank initialises the boxes it owns
+                blo, bhi = self.boxes[n][gi]
                 nb = tuple(bhi[d] - blo[d] + 1 for d in range(3))
                 ub, sb = initdata_numpy(nb, self.dx[n], prob_type, 3, ns, lo=blo)
-                self.uold[n].from_numpy(ub, i)
-                self.sold[n].from_numpy(sb, i)
+                self.uold[n].from_numpy(ub, li)
+                self.sold[n].from_numpy(sb, li)
         self.time, self.istep = 0.0, 0
         self.fill_state_ghosts()
         if do_initial_projection:                                                      # varden.f90:126-138
@@ -363,3 +388,5 @@ class VardenAMR:
                 m.destroy()
         self.bct.destroy()
         self.mla.destroy()
+        if self.nranks > 1:
+            bl.comm_finalize()
