@@ -179,7 +179,7 @@ int  vdn_hgproject(int proj_type, vdn_layout *mla, vdn_multifab **unew, vdn_mult
 int  vdn_macproject(vdn_layout *mla, vdn_multifab **umac, vdn_multifab **rho, vdn_multifab **mac_rhs,
                     const double *dx, const vdn_bc_tower *bct, int bc_comp);
 
-/* ---- multi-level operators (FBoxLib; up to 4 levels, refinement ratio 2, single rank in this round) ---------------------------------
+/* ---- multi-level operators (FBoxLib; up to 4 levels, refinement ratio 2, boxes on any rank) ---------------------------------
  * ml_cc_restriction(crse, fine, rr)            reference call sites src/macproject.f90:204-206, src/hgproject.f90:355-357
  * ml_edge_restriction(crse, fine, rr, dir)     src/velpred.f90:115-119, src/macproject.f90:330-333, 497-500
  * multifab_fill_ghost_cells(fine, crse, ...)   src/macproject.f90:304-310 (and inside ml_restrict_and_fill)
