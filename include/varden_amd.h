@@ -207,7 +207,7 @@ int vdn_multifab_copy_layouts(vdn_multifab *dst, int dcomp, const vdn_multifab *
  *                                                                src/regrid.f90:148-149; cluster_* parameters src/_parameters:37-39
  * s: the state of level `lev1` (1-based, as in tag_boxes) -- component 0 is tagged; the boxes of level lev1+1 are returned in that
  * level's index space (*nboxes_out = 0: no cell tagged, "new_grid = .false.").  nest: cells of level lev1 kept between the new
- * level and the edge of level lev1 (proper nesting).  Single rank in this round. */
+ * level and the edge of level lev1 (proper nesting).  Collective: every rank passes its part of the level and gets the same boxes. */
 int vdn_make_new_grids(const vdn_multifab *s, int lev1, int buf_wid, int nest, double min_eff, int min_width, int blocking,
                        int max_grid_size, int maxboxes, vdn_box *boxes_out, int *nboxes_out, long *ntagged);
 

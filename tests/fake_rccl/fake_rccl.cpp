@@ -130,6 +130,17 @@ static int post(int kind, void *ptr, size_t count, int dtype, int peer, Comm *c,
 int ncclSend(const void *buf, size_t count, int dtype, int peer, Comm *c, hipStream_t st) { return post(0, (void *)buf, count, dtype, peer, c, st); }
 int ncclRecv(void *buf, size_t count, int dtype, int peer, Comm *c, hipStream_t st) { return post(1, buf, count, dtype, peer, c, st); }
 int ncclAllReduce(const void *send, void *recv, size_t count, int dtype, int op, Comm *c, hipStream_t st) {
+  if (dtype == 1) {                             // ncclUint8, MAX only (tag bitmaps)
+    if (op != 2 || count > red_bytes()) die("allreduce: uint8 MAX up to 16 MB only");
+    unsigned char *mine = (unsigned char *)red_slot(c, c->rank);
+    HC(hipMemcpyAsync(mine, send, count, hipMemcpyDeviceToHost, st)); HC(hipStreamSynchronize(st));
+    barrier(c);
+    std::vector<unsigned char> acc(count);
+    for (size_t i = 0; i < count; i++) { unsigned char v = 0; for (int r = 0; r < c->nranks; r++) { const unsigned char w = ((unsigned char *)red_slot(c, r))[i]; v = v > w ? v : w; } acc[i] = v; }
+    barrier(c);
+    HC(hipMemcpyAsync(recv, acc.data(), count, hipMemcpyHostToDevice, st)); HC(hipStreamSynchronize(st));
+    return 0;
+  }
   if (dtype != 8 || count * 8 > red_bytes()) die("allreduce: f64 up to 16 MB only");
   double *mine = (double *)red_slot(c, c->rank);
   HC(hipMemcpyAsync(mine, send, count * 8, hipMemcpyDeviceToHost, st)); HC(hipStreamSynchronize(st));

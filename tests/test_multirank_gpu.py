@@ -54,12 +54,12 @@ def test_ranks_reproduce_single_rank_bits(gpu, tmp_path, nranks, decomp, n, peri
     assert np.isfinite(got["u0"]).all() and np.abs(got["u0"]).max() > 0
 
 
-def run_amr_ranks(tmp_path, tag, nranks, nlev, visc):
+def run_amr_ranks(tmp_path, tag, nranks, nlev, visc, mode="fixed"):
     if nranks > 1 and not os.path.exists(FAKE):
         subprocess.check_call(["make", "-s", "-C", os.path.dirname(FAKE)])
     idfile, prefix = str(tmp_path / (tag + ".id")), str(tmp_path / tag)
     env = dict(os.environ, VDN_RCCL_LIB=FAKE, FAKE_RCCL_DIR=str(tmp_path))
-    procs = [subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "_multirank_amr_worker.py"), str(r), str(nranks), idfile, prefix, str(nlev), str(visc)],
+    procs = [subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "_multirank_amr_worker.py"), str(r), str(nranks), idfile, prefix, str(nlev), str(visc), mode],
                               env=env, cwd=ROOT) for r in range(nranks)]
     try:
         rcs = [p.wait(timeout=240) for p in procs]
@@ -72,12 +72,24 @@ def run_amr_ranks(tmp_path, tag, nranks, nlev, visc):
     for r in range(nranks):
         with np.load(prefix + ".%d.npz" % r) as z:
             for k in z.files:
-                if k == "dt":
-                    out.setdefault("dt", z[k])
-                    assert np.array_equal(out["dt"], z[k]), "ranks disagree on dt"
+                if k in ("dt", "nboxes", "nregrids"):
+                    out.setdefault(k, z[k])
+                    assert np.array_equal(out[k], z[k]), "ranks disagree on " + k
                 else:
                     out[k] = z[k]
     return out
+
+
+def test_tagged_grids_and_regrid_on_two_ranks(gpu, tmp_path):
+    """inputs_bubble_3d's flow on two ranks: tag_boxes + make_new_grids with the tag bitmap all-reduced, boxes dealt by cell count,
+    regridding every second step (fillpatch, nodal prolongation and the old -> new copies through views) -- same boxes and same bits as
+    one rank"""
+    ref = run_amr_ranks(tmp_path, "tref", 1, 2, 0.001, "tagged")
+    got = run_amr_ranks(tmp_path, "tmr", 2, 2, 0.001, "tagged")
+    assert ref["nregrids"][0] >= 1 and np.array_equal(ref["nboxes"], got["nboxes"]) and np.array_equal(ref["dt"], got["dt"])
+    assert sorted(ref) == sorted(got)
+    for k in sorted(ref):
+        assert np.array_equal(ref[k], got[k]), "%s differs: max %.3e" % (k, np.abs(ref[k] - got[k]).max())
 
 
 @pytest.mark.parametrize("nranks,nlev,visc", [(2, 2, 0.0), (3, 2, 0.001), (2, 3, 0.001)])

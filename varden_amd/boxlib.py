@@ -43,12 +43,23 @@ def comm_get_unique_id():
     return buf.raw
 
 
+_comm_up = False
+
+
 def comm_init(id128):
+    """collective; a second call while the communicator is up is a no-op (drivers built one after another share it)"""
+    global _comm_up
+    if _comm_up:
+        return
     check(capi.load().vdn_comm_init(C.c_char_p(bytes(id128))))
+    _comm_up = True
 
 
 def comm_finalize():
-    check(capi.load().vdn_comm_finalize())
+    global _comm_up
+    if _comm_up:
+        check(capi.load().vdn_comm_finalize())
+    _comm_up = False
 
 
 def finalize():

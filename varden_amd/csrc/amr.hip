@@ -224,19 +224,22 @@ void ml_fill_ghost_cells(vdn_multifab *fine, const vdn_multifab *crse, int icomp
 // fillpatch(fine, crse, ng = 0, ...) of src/regrid.f90:311-325: every VALID cell of the fine level from the coarse one, by the
 // interpolation of multifab_fill_ghost_cells (the coarse ghost cells must be filled; the fine level is properly nested)
 void ml_fillpatch(vdn_multifab *fine, const vdn_multifab *crse, int icomp, int nc) {
+  const SrcView Cv = make_view(crse, coarsened_footprints(fine, 0, -1, 1), level_owner(fine), icomp, nc, VT_COARSEN_1);
+  Cv.refresh();
   std::vector<InterpB> v;
   for (int f = 0; f < fine->nfabs(); f++)
-    for (int c = 0; c < crse->nfabs(); c++) {
+    for (int c = 0; c < Cv.nboxes(); c++) {
+      if (!Cv.have[c]) continue;
       InterpB e; int plo[3], phi[3]; Range3 pr;
       for (int d = 0; d < 3; d++) {
         e.r.lo[d] = fine->vbox[f].lo[d]; e.r.hi[d] = fine->vbox[f].hi[d];
         e.A.flo[d] = 1; e.A.fhi[d] = 0;                                   // no cell is skipped as "valid"
         plo[d] = hfdiv2(e.r.lo[d]); phi[d] = hfdiv2(e.r.hi[d]);
-        e.A.alo[d] = crse->vbox[c].lo[d] - crse->ng; e.A.ahi[d] = crse->vbox[c].hi[d] + crse->ng;
+        e.A.alo[d] = Cv.vbox[c].lo[d] - Cv.ng; e.A.ahi[d] = Cv.vbox[c].hi[d] + Cv.ng;
       }
-      if (!isect(plo, phi, crse->vbox[c].lo, crse->vbox[c].hi, pr)) continue;
+      if (!isect(plo, phi, Cv.vbox[c].lo, Cv.vbox[c].hi, pr)) continue;
       for (int d = 0; d < 3; d++) { e.A.plo[d] = pr.lo[d]; e.A.phi[d] = pr.hi[d]; }
-      e.A.icomp = icomp; e.A.nc = nc; e.A.cc0 = 0; e.fine = fine->fabs[f]; e.crse = crse->fabs[c];
+      e.A.icomp = icomp; e.A.nc = nc; e.A.cc0 = icomp; e.fine = fine->fabs[f]; e.crse = Cv.fv[c];
       v.push_back(e);
     }
   launch_batched(v, 0, (double *)nullptr, 0, ctx().stream);
@@ -254,17 +257,20 @@ struct NodalProlongB { Range3 r; int g[3]; FV pf, pc; int clo[3], chi[3];
 void ml_nodal_prolongation(vdn_multifab *fine, vdn_multifab *crse) {
   REQUIRE(fine->nodal[0] && fine->nodal[1] && fine->nodal[2] && crse->nodal[0] && crse->nodal[1] && crse->nodal[2], "ml_nodal_prolongation: nodal multifabs expected");
   mf_fill_boundary(crse);                                   // a parent node may sit in a coarse box's ghost layer
+  const SrcView Cv = make_view(crse, coarsened_footprints(fine, 0, 3, 1), level_owner(fine), 0, 1, VT_NODE_C2F);
+  Cv.refresh();
   std::vector<NodalProlongB> v;
   for (int f = 0; f < fine->nfabs(); f++)
-    for (int c = 0; c < crse->nfabs(); c++) {
+    for (int c = 0; c < Cv.nboxes(); c++) {
+      if (!Cv.have[c]) continue;
       NodalProlongB q; bool empty = false;
       for (int d = 0; d < 3; d++) {
-        q.clo[d] = crse->vbox[c].lo[d]; q.chi[d] = crse->vbox[c].hi[d] + 1;
+        q.clo[d] = Cv.vbox[c].lo[d]; q.chi[d] = Cv.vbox[c].hi[d] + 1;
         q.r.lo[d] = std::max(fine->vbox[f].lo[d], 2 * q.clo[d]); q.r.hi[d] = std::min(fine->vbox[f].hi[d] + 1, 2 * q.chi[d]);
         if (q.r.lo[d] > q.r.hi[d]) empty = true;
       }
       if (empty) continue;
-      q.pf = fine->fabs[f]; q.pc = crse->fabs[c];
+      q.pf = fine->fabs[f]; q.pc = Cv.fv[c];
       v.push_back(q);
     }
   launch_batched(v, 0, (double *)nullptr, 0, ctx().stream);
@@ -275,17 +281,22 @@ struct CopyLB { Range3 r; int g[3]; FV d, s; int dc, sc, nc;
   static __device__ double body(const CopyLB &q, int i, int j, int k, int) { for (int c = 0; c < q.nc; c++) fv_at(q.d, i, j, k, q.dc + c) = fv_get(q.s, i, j, k, q.sc + c); return 0.0; } };
 void mf_copy_layouts(vdn_multifab *dst, int dcomp, const vdn_multifab *src, int scomp, int nc) {
   for (int d = 0; d < 3; d++) REQUIRE(dst->nodal[d] == src->nodal[d], "copy between layouts: nodal flags differ");
+  std::vector<vdn_box> fp;                                   // what every box of dst's list reads: its own valid points
+  for (const vdn_box &b : level_boxes(dst)) { vdn_box o; for (int d = 0; d < 3; d++) { o.lo[d] = b.lo[d]; o.hi[d] = b.hi[d] + dst->nodal[d]; } fp.push_back(o); }
+  const SrcView Sv = make_view(src, fp, level_owner(dst), scomp, nc, 40 + dst->la->uid * 64);
+  Sv.refresh();
   std::vector<CopyLB> v;
   for (int a = 0; a < dst->nfabs(); a++)
-    for (int b = 0; b < src->nfabs(); b++) {
+    for (int b = 0; b < Sv.nboxes(); b++) {
+      if (!Sv.have[b]) continue;
       CopyLB q; bool empty = false;
       for (int d = 0; d < 3; d++) {
-        q.r.lo[d] = std::max(dst->vbox[a].lo[d], src->vbox[b].lo[d]);
-        q.r.hi[d] = std::min(dst->vbox[a].hi[d], src->vbox[b].hi[d]) + dst->nodal[d];
+        q.r.lo[d] = std::max(dst->vbox[a].lo[d], Sv.vbox[b].lo[d]);
+        q.r.hi[d] = std::min(dst->vbox[a].hi[d], Sv.vbox[b].hi[d]) + dst->nodal[d];
         if (q.r.lo[d] > q.r.hi[d]) empty = true;
       }
       if (empty) continue;
-      q.d = dst->fabs[a]; q.s = src->fabs[b]; q.dc = dcomp; q.sc = scomp; q.nc = nc;
+      q.d = dst->fabs[a]; q.s = Sv.fv[b]; q.dc = dcomp; q.sc = 0; q.nc = nc;
       v.push_back(q);
     }
   launch_batched(v, 0, (double *)nullptr, 0, ctx().stream);

@@ -29,7 +29,7 @@ void mg_halo_cache_purge(unsigned long uid);   // mg_cc.hip / mg_nd.hip keep key
 typedef struct ncclComm *ncclComm_t;
 typedef struct { char internal[128]; } ncclUniqueId;
 enum { ncclSuccess = 0 };
-enum { ncclFloat64 = 8 };       // ncclDataType_t: ncclDouble
+enum { ncclUint8 = 1, ncclFloat64 = 8 };       // ncclDataType_t: ncclUint8, ncclDouble
 enum { ncclSum = 0, ncclMax = 2 };
 struct Rccl {
   void *h = nullptr;
@@ -93,6 +93,14 @@ void comm_allreduce_max_dev(double *d, int n) {
   if (!comm_active()) return;
   need_comm();
   NCCLCHK(g_rccl.AllReduce(d, d, (size_t)n, ncclFloat64, ncclMax, g_rccl.comm, ctx().stream));
+}
+// all-reduce MAX of n device bytes (tag bitmaps of the grid generation), in place, in pieces of 8 MB
+void comm_allreduce_max_u8_dev(unsigned char *d, size_t n) {
+  if (!comm_active()) return;
+  need_comm();
+  const size_t piece = (size_t)8 << 20;
+  for (size_t off = 0; off < n; off += piece)
+    NCCLCHK(g_rccl.AllReduce(d + off, d + off, std::min(piece, n - off), ncclUint8, ncclMax, g_rccl.comm, ctx().stream));
 }
 // all-gather: every rank contributes `count` doubles; recv holds nranks*count
 void comm_allgather_dev(const double *send, double *recv, size_t count) {

@@ -111,7 +111,6 @@ extern "C" int vdn_make_new_grids(const vdn_multifab *s, int lev1, int buf_wid, 
                                   int max_grid_size, int maxboxes, vdn_box *boxes_out, int *nboxes_out, long *ntagged) {
   VDN_TRY
   REQUIRE(s && boxes_out && nboxes_out, "vdn_make_new_grids: null argument");
-  REQUIRE(ctx().nranks == 1, "vdn_make_new_grids: single rank in this round");
   REQUIRE(blocking >= 1 && min_width >= 1 && max_grid_size >= 2 * blocking, "vdn_make_new_grids: bad clustering parameters");
   const vdn_layout *la = s->la;
   const vdn_box &pd = la->pd[s->lev];
@@ -131,10 +130,12 @@ extern "C" int vdn_make_new_grids(const vdn_multifab *s, int lev1, int buf_wid, 
   for (int b = 0; b < s->nfabs(); b++) {
     Range3 r; for (int d = 0; d < 3; d++) { r.lo[d] = s->vbox[b].lo[d]; r.hi[d] = s->vbox[b].hi[d]; }
     hipLaunchKernelGGL(kk_tag, grid_for(r), dim3(64, 4, 1), 0, ctx().stream, s->fabs[b], d_tags, n[0], n[1], pd.lo[0], pd.lo[1], pd.lo[2], rule, tlo, thi, r);
-    for (int k = r.lo[2]; k <= r.hi[2]; k++) for (int j = r.lo[1]; j <= r.hi[1]; j++)
-      std::fill(inside.begin() + ((size_t)(r.lo[0] - pd.lo[0]) + (size_t)n[0] * ((size_t)(j - pd.lo[1]) + (size_t)n[1] * (size_t)(k - pd.lo[2]))),
-                inside.begin() + ((size_t)(r.hi[0] - pd.lo[0]) + 1 + (size_t)n[0] * ((size_t)(j - pd.lo[1]) + (size_t)n[1] * (size_t)(k - pd.lo[2]))), 1);
   }
+  for (const vdn_box &gb : la->boxes[s->lev])              // the cells of the level: every box, on any rank
+    for (int k = gb.lo[2]; k <= gb.hi[2]; k++) for (int j = gb.lo[1]; j <= gb.hi[1]; j++)
+      std::fill(inside.begin() + ((size_t)(gb.lo[0] - pd.lo[0]) + (size_t)n[0] * ((size_t)(j - pd.lo[1]) + (size_t)n[1] * (size_t)(k - pd.lo[2]))),
+                inside.begin() + ((size_t)(gb.hi[0] - pd.lo[0]) + 1 + (size_t)n[0] * ((size_t)(j - pd.lo[1]) + (size_t)n[1] * (size_t)(k - pd.lo[2]))), 1);
+  comm_allreduce_max_u8_dev(d_tags, ncell);                // the tags of the other ranks' boxes: every rank clusters the same bitmap
   HIPCHK(hipMemcpyAsync(tags.data(), d_tags, ncell, hipMemcpyDeviceToHost, ctx().stream));
   HIPCHK(hipStreamSynchronize(ctx().stream));
   HIPCHK(hipFree(d_tags));

@@ -138,6 +138,7 @@ SrcView make_view(const vdn_multifab *src, const std::vector<vdn_box> &footprint
 void view_cache_purge(unsigned long layout_uid);
 bool   comm_active();
 void   comm_allreduce_max_dev(double *d, int n);
+void   comm_allreduce_max_u8_dev(unsigned char *d, size_t n);
 void   comm_allgather_dev(const double *send, double *recv, size_t count);
 
 // helpers shared between translation units

@@ -200,7 +200,6 @@ class VardenAMR:
         bl.initialize(self.prm, rank, nranks, device)
         if nranks > 1:
             bl.comm_init(comm_id)
-            assert regrid_int <= 0, "regridding on several ranks is not implemented"
         self.nc = nc
         self.phys = [[int(phys_bc[d][s]) for s in range(2)] for d in range(3)]
         lev_boxes = [fine_boxes] + list(finer_levels)
@@ -251,25 +250,29 @@ class VardenAMR:
                                  self.ext_vel_force, self.ext_scal_force, self.bct, self.dt, self.time, self.dx, self.press_comp, bl.PRESSURE_ITERS)
 
     @staticmethod
-    def tagged_grids(nc, phys_bc, params=None, prob_type=1, max_levs=2, buf_wid=2, max_grid_size=256, device=0):
+    def tagged_grids(nc, phys_bc, params=None, prob_type=1, max_levs=2, buf_wid=2, max_grid_size=256, device=0, rank=0, nranks=1, comm_id=None, base_boxes=None):
         """the grids the reference's initialize_with_adaptive_grids builds (src/initialize.f90:152-342): level by level, initial data on
         the level -> tag_boxes -> make_new_grids, until nothing is tagged or max_levs is reached.  Returns the box lists of the levels
         1.. (each in its own index space).  Nesting: a new level keeps 2 cells of its parent level around itself."""
         prm = params or default_params()
         prm.prob_type = prob_type
-        bl.initialize(prm, 0, 1, device)
+        bl.initialize(prm, rank, nranks, device)
+        if nranks > 1:
+            bl.comm_init(comm_id)
         ns = prm.nscal
         levels = []
         pd = [((0, 0, 0), (nc - 1,) * 3)]
-        boxes = [[pd[0]]]
+        boxes = [[pd[0]] if base_boxes is None else [(tuple(b[0]), tuple(b[1])) for b in base_boxes]]
         for lev in range(1, max_levs):
-            mla = bl.MLLayout(pd, boxes, rr=[(2, 2, 2)] * (lev - 1))
+            owner = [distribute(lb, nranks) for lb in boxes]
+            mla = bl.MLLayout(pd, boxes, owner=owner, rr=[(2, 2, 2)] * (lev - 1))
             sold = bl.MultiFab(mla, lev - 1, ns, 3)
             dx = [1.0 / (nc << (lev - 1))] * 3
-            for i, (blo, bhi) in enumerate(boxes[lev - 1]):
+            for li, gi in enumerate([i for i, o in enumerate(owner[lev - 1]) if o == rank]):
+                blo, bhi = boxes[lev - 1][gi]
                 nb = tuple(bhi[d] - blo[d] + 1 for d in range(3))
                 _, sb = initdata_numpy(nb, dx, prob_type, 3, ns, lo=blo)
-                sold.from_numpy(sb, i)
+                sold.from_numpy(sb, li)
             new, _ = adv.make_new_grids(sold, lev, buf_wid=buf_wid, nest=0 if lev == 1 else 2, min_eff=prm_cluster(prm, "min_eff"),
                                         min_width=prm_cluster(prm, "min_width"), blocking=prm_cluster(prm, "blocking"), max_grid_size=max_grid_size)
             sold.destroy(); mla.destroy()
@@ -307,10 +310,11 @@ class VardenAMR:
         """layout, bc tower and the four carried state multifabs (uold, sold, gp, p) on the given box lists"""
         NL = len(boxes)
         pd = [((0, 0, 0), ((self.nc << n) - 1,) * 3) for n in range(NL)]
-        mla = bl.MLLayout(pd, boxes, rr=[(2, 2, 2)] * (NL - 1))
+        owner = [distribute(lb, self.nranks) for lb in boxes]
+        mla = bl.MLLayout(pd, boxes, owner=owner, rr=[(2, 2, 2)] * (NL - 1))
         bct = bl.BCTower(mla, self.phys)
         mk = lambda nc_, ng, nodal=None: [bl.MultiFab(mla, n, nc_, ng, nodal) for n in range(NL)]   # noqa: E731
-        st = dict(mla=mla, bct=bct, boxes=boxes, uold=mk(self.dm, 3), sold=mk(self.nscal, 3), gp=mk(self.dm, 1), p=mk(1, 1, (1, 1, 1)))
+        st = dict(mla=mla, bct=bct, boxes=boxes, owner=owner, uold=mk(self.dm, 3), sold=mk(self.nscal, 3), gp=mk(self.dm, 1), p=mk(1, 1, (1, 1, 1)))
         for m in st["p"]:
             m.setval(0.0, all=True)                                               # regrid.f90:298
         return st
@@ -366,7 +370,8 @@ class VardenAMR:
             for m in lst:
                 m.destroy()
         self._free_state(old)
-        self.mla, self.bct, self.boxes = cur["mla"], cur["bct"], cur["boxes"]
+        self.mla, self.bct, self.boxes, self.owner = cur["mla"], cur["bct"], cur["boxes"], cur["owner"]
+        self.local = [[i for i, o in enumerate(ow) if o == self.rank] for ow in self.owner]
         self.uold, self.sold, self.gp, self.p = cur["uold"], cur["sold"], cur["gp"], cur["p"]
         self.nlev = NL = len(self.boxes)
         self.dx = [[1.0 / (self.nc << n)] * 3 for n in range(NL)]
