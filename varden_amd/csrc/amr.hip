@@ -101,7 +101,7 @@ void ml_cc_restriction(vdn_multifab *crse, const vdn_multifab *fine, int icomp, 
   for (int f = 0; f < F.nboxes(); f++) for (int c = 0; c < crse->nfabs(); c++) {
     if (!F.have[f]) continue;
     int clo[3], chi[3]; RestrictB a;
-    for (int d = 0; d < 3; d++) { clo[d] = F.vbox[f].lo[d] / 2; chi[d] = F.vbox[f].hi[d] / 2; }
+    for (int d = 0; d < 3; d++) { clo[d] = hfdiv2(F.vbox[f].lo[d]); chi[d] = hfdiv2(F.vbox[f].hi[d]); }
     if (!isect(clo, chi, crse->vbox[c].lo, crse->vbox[c].hi, a.r)) continue;
     a.crse = crse->fabs[c]; a.fine = F.fv[f]; a.icomp = icomp; a.nc = nc; a.fc0 = icomp;
     v.push_back(a);
@@ -130,7 +130,7 @@ void ml_edge_restriction(vdn_multifab *crse, const vdn_multifab *fine, int dir) 
   for (int f = 0; f < F.nboxes(); f++) for (int c = 0; c < crse->nfabs(); c++) {
     if (!F.have[f]) continue;
     int clo[3], chi[3], blo[3], bhi[3]; EdgeRestrictB a;
-    for (int d = 0; d < 3; d++) { clo[d] = F.vbox[f].lo[d] / 2; chi[d] = F.vbox[f].hi[d] / 2; blo[d] = crse->vbox[c].lo[d]; bhi[d] = crse->vbox[c].hi[d]; }
+    for (int d = 0; d < 3; d++) { clo[d] = hfdiv2(F.vbox[f].lo[d]); chi[d] = hfdiv2(F.vbox[f].hi[d]); blo[d] = crse->vbox[c].lo[d]; bhi[d] = crse->vbox[c].hi[d]; }
     chi[dir] += 1; bhi[dir] += 1;
     if (!isect(clo, chi, blo, bhi, a.r)) continue;
     a.crse = crse->fabs[c]; a.fine = F.fv[f]; a.dir = dir;
@@ -399,7 +399,8 @@ struct CfB { Range3 r; int g[3]; FV pf, pc; CfArgs A;                // r: the g
 // (which overwrites the cells that another fine box covers); domain faces were closed by the closure
 static void cf_descs(vdn_multifab *pf, const SrcView &pc, const vdn_bc_tower *bct, int bc_comp0, std::vector<CfB> &v) {
   for (int f = 0; f < pf->nfabs(); f++) for (int d = 0; d < 3; d++) for (int s = 0; s < 2; s++) {
-    if (bct->ell_bc(pf->lev, f + 1, d, s, bc_comp0) != VDN_BC_INT) continue;
+    const int eb = bct->ell_bc(pf->lev, f + 1, d, s, bc_comp0);
+    if (eb != VDN_BC_INT && eb != VDN_BC_PER) continue;        // periodic faces too: the same-level exchange then overwrites what the level itself covers
     Range3 r; for (int t = 0; t < 3; t++) { r.lo[t] = pf->vbox[f].lo[t]; r.hi[t] = pf->vbox[f].hi[t]; }
     r.lo[d] = r.hi[d] = s ? pf->vbox[f].hi[d] + 1 : pf->vbox[f].lo[d] - 1;
     for (int c = 0; c < pc.nboxes(); c++) {
@@ -530,7 +531,7 @@ static void restrict_descs(vdn_multifab *crse, const SrcView &fine, std::vector<
   for (int f = 0; f < fine.nboxes(); f++) for (int c = 0; c < crse->nfabs(); c++) {
     if (!fine.have[f]) continue;
     int clo[3], chi[3]; RestrictB a;
-    for (int d = 0; d < 3; d++) { clo[d] = fine.vbox[f].lo[d] / 2; chi[d] = fine.vbox[f].hi[d] / 2; }
+    for (int d = 0; d < 3; d++) { clo[d] = hfdiv2(fine.vbox[f].lo[d]); chi[d] = hfdiv2(fine.vbox[f].hi[d]); }
     if (!isect(clo, chi, crse->vbox[c].lo, crse->vbox[c].hi, a.r)) continue;
     a.crse = crse->fabs[c]; a.fine = fine.fv[f]; a.icomp = 0; a.nc = 1; a.fc0 = 0;
     v.push_back(a);
@@ -538,6 +539,7 @@ static void restrict_descs(vdn_multifab *crse, const SrcView &fine, std::vector<
 }
 // a box face that is not on the domain boundary (what ell_bc == BC_INT says for a local box), for ANY box of the level
 static bool face_is_interior(const vdn_layout *la, int lev, const vdn_box &b, int d, int s) {
+  if (la->pmask[d]) return true;                           // a periodic direction has no physical boundary
   return s ? b.hi[d] != la->pd[lev].hi[d] : b.lo[d] != la->pd[lev].lo[d];
 }
 static void mlcc_build_sets(MLCC &S) {
@@ -575,14 +577,14 @@ static void mlcc_build_sets(MLCC &S) {
     if (n >= 1)
       for (int d = 0; d < 3; d++) for (int s = 0; s < 2; s++) {
         std::vector<RefluxB> v;
-        const std::vector<vdn_box> &fboxes = level_boxes(S.phi[n]);
-        for (int f = 0; f < (int)fboxes.size(); f++) {
-          if (!face_is_interior(S.la, n, fboxes[f], d, s)) continue;
-          if (!S.vf_phi[n].have[f] || !S.vf_beta[n][d].have[f]) continue;      // no coarse box of this rank reaches that fine box
-          const vdn_box &fb = fboxes[f];
+        const SrcView &Fv = S.vf_phi[n];                     // entries: fine boxes and their periodic images
+        for (int f = 0; f < Fv.nboxes(); f++) {
+          if (!Fv.have[f] || !S.vf_beta[n][d].have[f]) continue;      // no coarse box of this rank reaches that fine box
+          const vdn_box &fb = Fv.vbox[f];
+          if (!face_is_interior(S.la, n, fb, d, s)) continue;
           int clo[3], chi[3];
-          for (int t = 0; t < 3; t++) { clo[t] = fb.lo[t] / 2; chi[t] = fb.hi[t] / 2; }
-          clo[d] = chi[d] = (s ? fb.hi[d] + 1 : fb.lo[d]) / 2;
+          for (int t = 0; t < 3; t++) { clo[t] = hfdiv2(fb.lo[t]); chi[t] = hfdiv2(fb.hi[t]); }
+          clo[d] = chi[d] = hfdiv2(s ? fb.hi[d] + 1 : fb.lo[d]);
           for (int c = 0; c < S.phi[n - 1]->nfabs(); c++) {
             int blo[3], bhi[3]; RefluxB q;
             for (int t = 0; t < 3; t++) { blo[t] = S.phi[n - 1]->vbox[c].lo[t]; bhi[t] = S.phi[n - 1]->vbox[c].hi[t]; }

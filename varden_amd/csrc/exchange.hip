@@ -20,6 +20,7 @@
 #include <cstdlib>
 #include <algorithm>
 #include <tuple>
+#include <array>
 
 void mg_halo_cache_purge(unsigned long uid);   // mg_cc.hip / mg_nd.hip keep key -> plan maps; they drop the keys
 
@@ -316,49 +317,65 @@ SrcView make_view(const vdn_multifab *src, const std::vector<vdn_box> &footprint
   ViewKey key{ la->uid, src->base, lev, scomp, nc, src->ng, src->nodal[0] | (src->nodal[1] << 1) | (src->nodal[2] << 2), cache_tag };
   auto hit = g_view_cache.find(key);
   if (hit != g_view_cache.end()) return hit->second;
+  // periodic images: an entry of the view is (box, shift); shift 0 first, so that a non-periodic view has one entry per box
+  std::vector<std::array<int, 3>> shifts;
+  {
+    int per[3], ns[3];
+    for (int d = 0; d < 3; d++) { per[d] = la->pd[lev].hi[d] - la->pd[lev].lo[d] + 1; ns[d] = la->pmask[d] ? 1 : 0; }
+    shifts.push_back({ 0, 0, 0 });
+    for (int sz = -ns[2]; sz <= ns[2]; sz++) for (int sy = -ns[1]; sy <= ns[1]; sy++) for (int sx = -ns[0]; sx <= ns[0]; sx++)
+      if (sx || sy || sz) shifts.push_back({ sx * per[0], sy * per[1], sz * per[2] });
+  }
+  const int nsh = (int)shifts.size();
   SrcView V; V.ng = src->ng; V.nc = nc; for (int d = 0; d < 3; d++) V.nodal[d] = src->nodal[d];
-  V.vbox.assign(gb.begin(), gb.end()); V.have.assign(gb.size(), 0); V.fv.resize(gb.size());
-  // local boxes: the fab itself (component offset applied)
-  { int li = 0; for (size_t j = 0; j < gb.size(); j++) if (la->owner[lev][j] == me) { FV f = src->fabs[li++]; f.p += (long)f.sc * scomp; V.fv[j] = f; V.have[j] = 1; } }
-  if (nranks > 1) {
-    // window of box j that rank r needs: bounding box over r's destination boxes of (footprint ∩ allocation of j)
-    ViewPlan *P = new ViewPlan; P->nc = nc;
-    std::map<int, Peer> peers;
-    struct Win { int lo[3], hi[3]; bool any; };
-    for (size_t j = 0; j < gb.size(); j++) {
-      const int oj = la->owner[lev][j];
-      int alo[3], ahi[3];
-      for (int d = 0; d < 3; d++) { alo[d] = gb[j].lo[d] - src->ng; ahi[d] = gb[j].hi[d] + src->nodal[d] + src->ng; }
-      std::vector<Win> win(nranks);
-      for (auto &w : win) { w.any = false; for (int d = 0; d < 3; d++) { w.lo[d] = 1 << 30; w.hi[d] = -(1 << 30); } }
-      for (size_t i = 0; i < footprint.size(); i++) {
-        const int r = dst_owner[i];
-        if (r == oj) continue;
-        int lo[3], hi[3]; bool empty = false;
-        for (int d = 0; d < 3; d++) { lo[d] = std::max(footprint[i].lo[d], alo[d]); hi[d] = std::min(footprint[i].hi[d], ahi[d]); if (lo[d] > hi[d]) empty = true; }
-        if (empty) continue;
-        Win &w = win[r]; w.any = true;
-        for (int d = 0; d < 3; d++) { w.lo[d] = std::min(w.lo[d], lo[d]); w.hi[d] = std::max(w.hi[d], hi[d]); }
-      }
-      for (int r = 0; r < nranks; r++) {
-        if (!win[r].any) continue;
-        const Win &w = win[r];
-        const long tot = (long)(w.hi[0] - w.lo[0] + 1) * (w.hi[1] - w.lo[1] + 1) * (w.hi[2] - w.lo[2] + 1);
-        if (oj == me) {                                      // I send the window of my box j to rank r
-          Peer &pr = peers[r]; pr.rank = r;
-          PackDesc D; memset(&D, 0, sizeof D);
-          D.fv = V.fv[j];
-          for (int d = 0; d < 3; d++) { D.lo[d] = w.lo[d]; D.hi[d] = w.hi[d]; D.sh[d] = 0; D.vlo[d] = 1; D.vhi[d] = 0; }
-          D.off = (long)pr.nsend; pr.nsend += (size_t)tot * nc; pr.pack.push_back(D);
-        } else if (r == me) {                                // I receive it from the owner of j: remember where it will sit
-          Peer &pr = peers[oj]; pr.rank = oj;
-          PackDesc D; memset(&D, 0, sizeof D);
-          for (int d = 0; d < 3; d++) { D.lo[d] = w.lo[d]; D.hi[d] = w.hi[d]; }
-          D.off = (long)pr.nrecv; pr.nrecv += (size_t)tot * nc; D.vlo[0] = (int)j;          // vlo[0] carries the box index until the buffers exist
-          pr.unpack.push_back(D);
-        }
+  V.vbox.resize(gb.size() * nsh); V.have.assign(gb.size() * nsh, 0); V.fv.resize(gb.size() * nsh);
+  std::vector<FV> localfv(gb.size());
+  { int li = 0; for (size_t j = 0; j < gb.size(); j++) if (la->owner[lev][j] == me) { FV f = src->fabs[li++]; f.p += (long)f.sc * scomp; localfv[j] = f; } }
+  ViewPlan *P = nranks > 1 ? new ViewPlan : nullptr;
+  if (P) P->nc = nc;
+  std::map<int, Peer> peers;
+  struct Win { int lo[3], hi[3]; bool any; };
+  for (size_t j = 0; j < gb.size(); j++) for (int si = 0; si < nsh; si++) {
+    const size_t e = j * nsh + si;
+    const int oj = la->owner[lev][j];
+    const std::array<int, 3> &sh = shifts[si];
+    int alo[3], ahi[3];
+    for (int d = 0; d < 3; d++) { V.vbox[e].lo[d] = gb[j].lo[d] + sh[d]; V.vbox[e].hi[d] = gb[j].hi[d] + sh[d]; alo[d] = V.vbox[e].lo[d] - src->ng; ahi[d] = V.vbox[e].hi[d] + src->nodal[d] + src->ng; }
+    // the window of this entry that rank r needs: bounding box over r's destination boxes of (footprint ∩ shifted allocation)
+    std::vector<Win> win(nranks);
+    for (auto &w : win) { w.any = false; for (int d = 0; d < 3; d++) { w.lo[d] = 1 << 30; w.hi[d] = -(1 << 30); } }
+    for (size_t i = 0; i < footprint.size(); i++) {
+      const int r = dst_owner[i];
+      int lo[3], hi[3]; bool empty = false;
+      for (int d = 0; d < 3; d++) { lo[d] = std::max(footprint[i].lo[d], alo[d]); hi[d] = std::min(footprint[i].hi[d], ahi[d]); if (lo[d] > hi[d]) empty = true; }
+      if (empty) continue;
+      Win &w = win[r]; w.any = true;
+      for (int d = 0; d < 3; d++) { w.lo[d] = std::min(w.lo[d], lo[d]); w.hi[d] = std::max(w.hi[d], hi[d]); }
+    }
+    if (oj == me && (si == 0 || win[me].any)) {              // my own box: the fab itself, seen at its shifted position
+      FV f = localfv[j]; f.a0 += sh[0]; f.a1 += sh[1]; f.a2 += sh[2];
+      V.fv[e] = f; V.have[e] = 1;
+    }
+    for (int r = 0; r < nranks && P; r++) {
+      if (!win[r].any || r == oj) continue;
+      const Win &w = win[r];
+      const long tot = (long)(w.hi[0] - w.lo[0] + 1) * (w.hi[1] - w.lo[1] + 1) * (w.hi[2] - w.lo[2] + 1);
+      if (oj == me) {                                        // I send the window of my box j (read at window - shift) to rank r
+        Peer &pr = peers[r]; pr.rank = r;
+        PackDesc D; memset(&D, 0, sizeof D);
+        D.fv = localfv[j];
+        for (int d = 0; d < 3; d++) { D.lo[d] = w.lo[d]; D.hi[d] = w.hi[d]; D.sh[d] = sh[d]; D.vlo[d] = 1; D.vhi[d] = 0; }
+        D.off = (long)pr.nsend; pr.nsend += (size_t)tot * nc; pr.pack.push_back(D);
+      } else if (r == me) {                                  // I receive it from the owner of j: remember where it will sit
+        Peer &pr = peers[oj]; pr.rank = oj;
+        PackDesc D; memset(&D, 0, sizeof D);
+        for (int d = 0; d < 3; d++) { D.lo[d] = w.lo[d]; D.hi[d] = w.hi[d]; }
+        D.off = (long)pr.nrecv; pr.nrecv += (size_t)tot * nc; D.vlo[0] = (int)e;          // vlo[0] carries the entry index until the buffers exist
+        pr.unpack.push_back(D);
       }
     }
+  }
+  if (P) {
     for (auto &kv : peers) {
       Peer pr = kv.second;
       if (!pr.pack.empty()) { HIPCHK(hipMalloc((void **)&pr.d_pack, pr.pack.size() * sizeof(PackDesc)));
@@ -368,10 +385,10 @@ SrcView make_view(const vdn_multifab *src, const std::vector<vdn_box> &footprint
         HIPCHK(hipMalloc((void **)&pr.d_recv, pr.nrecv * sizeof(double)));
         HIPCHK(hipMemsetAsync(pr.d_recv, 0, pr.nrecv * sizeof(double), ctx().stream));
         for (const PackDesc &D : pr.unpack) {                // the window lives in the receive buffer: same layout as k_xpack writes
-          const int j = D.vlo[0];
+          const int e = D.vlo[0];
           FV f; f.p = pr.d_recv + D.off; f.a0 = D.lo[0]; f.a1 = D.lo[1]; f.a2 = D.lo[2];
           f.n0 = D.hi[0] - D.lo[0] + 1; f.n1 = D.hi[1] - D.lo[1] + 1; f.n2 = D.hi[2] - D.lo[2] + 1; f.sc = (long)f.n0 * f.n1 * f.n2;
-          V.fv[j] = f; V.have[j] = 1;
+          V.fv[e] = f; V.have[e] = 1;
         }
       }
       P->peers.push_back(pr);

@@ -1149,7 +1149,7 @@ static double ndf_read(double *d) { double h; HIPCHK(hipMemcpyAsync(&h, d, sizeo
 // cell mask -> node mask.  mode 0 ("slave"): 1 on the nodes that are not physical Dirichlet nodes and touch a cell INSIDE the
 // domain whose mask is 0 (a cell the level does not cover): the nodes of the coarse-fine interface.  mode 1 ("inside"): 1 on the
 // nodes whose eight cells are all inside the domain and masked (strictly inside the region the next finer level covers)
-struct MarkArgs { int dlo[3], dhi[3]; };
+struct MarkArgs { int dlo[3], dhi[3], per[3]; };      // a periodic direction has no outside: the mask's ghost cells hold the periodic images
 struct NdmMarkB { Range3 r; int g[3]; FV out, cmask; NdfArgs A; MarkArgs D; int mode;
   static __device__ double body(const NdmMarkB &q, int i, int j, int k, int) {
     bool any_open = false, all_in = true;
@@ -1160,7 +1160,7 @@ struct NdmMarkB { Range3 r; int g[3]; FV out, cmask; NdfArgs A; MarkArgs D; int 
         #pragma unroll
         for (int a = -1; a <= 0; a++) {
           const int ci = i + a, cj = j + b, ck = k + c;
-          const bool in_dom = ci >= q.D.dlo[0] && ci <= q.D.dhi[0] && cj >= q.D.dlo[1] && cj <= q.D.dhi[1] && ck >= q.D.dlo[2] && ck <= q.D.dhi[2];
+          const bool in_dom = (q.D.per[0] || (ci >= q.D.dlo[0] && ci <= q.D.dhi[0])) && (q.D.per[1] || (cj >= q.D.dlo[1] && cj <= q.D.dhi[1])) && (q.D.per[2] || (ck >= q.D.dlo[2] && ck <= q.D.dhi[2]));
           const bool m = in_dom && fv_get(q.cmask, ci, cj, ck) != 0.0;
           if (in_dom && !m) any_open = true;
           if (!m) all_in = false;
@@ -1328,7 +1328,6 @@ static int ml_nd_solve(vdn_layout *la, vdn_multifab **rh, vdn_multifab **phi, vd
                        const vdn_bc_tower *bct, int press_comp0, double rel_eps, double abs_eps, int max_iter, int *iters, double *res0, double *res) {
   const int L = la->nlev;
   REQUIRE(L >= 2 && L <= VDN_MAXLEV, "composite nodal solve: 2..%d levels", VDN_MAXLEV);
-  REQUIRE(!(la->pmask[0] || la->pmask[1] || la->pmask[2]), "composite nodal solve: periodic domains are not implemented");
   hipStream_t st = ctx().stream;
   const size_t mark = arena_mark();
   const vdn_params &P = ctx().prm;
@@ -1337,7 +1336,7 @@ static int ml_nd_solve(vdn_layout *la, vdn_multifab **rh, vdn_multifab **phi, vd
   auto T = [&](vdn_multifab *m) { temps.push_back(m); return m; };
   for (int n = 0; n < L; n++) {
     const int nb = phi[n]->nfabs();
-    S.multi[n] = la->boxes[n].size() > 1;                 // the level has several boxes (anywhere): exchanges between them are needed
+    S.multi[n] = la->boxes[n].size() > 1 || la->pmask[0] || la->pmask[1] || la->pmask[2];      // several boxes (anywhere) or periodic images: exchanges are needed
     S.A[n].resize(nb); S.r[n].resize(nb);
     for (int f = 0; f < nb; f++) {
       const vdn_box &bx = phi[n]->vbox[f];
@@ -1366,18 +1365,28 @@ static int ml_nd_solve(vdn_layout *la, vdn_multifab **rh, vdn_multifab **phi, vd
   // cell masks: inlev[n] = the cells of level n (its ghost cells included where another box of the level covers them),
   // cov[n] = the cells of level n under level n+1; node masks: own, slave, skip
   for (int n = 0; n < L; n++) {
-    MarkArgs D; for (int d = 0; d < 3; d++) { D.dlo[d] = la->pd[n].lo[d]; D.dhi[d] = la->pd[n].hi[d]; }
+    MarkArgs D; for (int d = 0; d < 3; d++) { D.dlo[d] = la->pd[n].lo[d]; D.dhi[d] = la->pd[n].hi[d]; D.per[d] = la->pmask[d] ? 1 : 0; }
     const int nb = phi[n]->nfabs();
-    if (n >= 1 || S.multi[n]) {
+    if (n >= 1 || S.multi[n]) {                         // (multi: several boxes or periodic images)
       S.own[n] = T(mf_temp(la, n, 1, 1, 3, true, 0.0));
       std::vector<NdfSetB> v1, v0;
       for (int f = 0; f < nb; f++) {
         NdfSetB q; q.r = S.r[n][f]; q.a = S.own[n]->fabs[f]; q.v = 1.0; v1.push_back(q);
         const int gf = la->local[n][f];
-        for (int g = 0; g < gf; g++) {                       // every box of the level with a lower GLOBAL index takes the shared nodes
-          Range3 rg2; for (int d = 0; d < 3; d++) { rg2.lo[d] = la->boxes[n][g].lo[d]; rg2.hi[d] = la->boxes[n][g].hi[d] + 1; }
-          NdfSetB z; if (nd_isect(S.r[n][f], rg2, z.r)) { z.a = S.own[n]->fabs[f]; z.v = 0.0; v0.push_back(z); }
-        }
+        // a node shared by several boxes -- or by a box and a periodic image -- belongs to the copy with the lowest global box index;
+        // among the images of ONE box to the one at the lower coordinates
+        int per[3], ns[3];
+        for (int d = 0; d < 3; d++) { per[d] = la->pd[n].hi[d] - la->pd[n].lo[d] + 1; ns[d] = la->pmask[d] ? 1 : 0; }
+        for (int g = 0; g <= gf; g++)
+          for (int sz = -ns[2]; sz <= ns[2]; sz++) for (int sy = -ns[1]; sy <= ns[1]; sy++) for (int sx = -ns[0]; sx <= ns[0]; sx++) {
+            const int sh[3] = { sx * per[0], sy * per[1], sz * per[2] };
+            if (g == gf) {                                   // my own images: only those at lower coordinates take nodes from me
+              const int first = sx ? sx : (sy ? sy : sz);
+              if (first >= 0) continue;
+            }
+            Range3 rg2; for (int d = 0; d < 3; d++) { rg2.lo[d] = la->boxes[n][g].lo[d] + sh[d]; rg2.hi[d] = la->boxes[n][g].hi[d] + 1 + sh[d]; }
+            NdfSetB z; if (nd_isect(S.r[n][f], rg2, z.r)) { z.a = S.own[n]->fabs[f]; z.v = 0.0; v0.push_back(z); }
+          }
       }
       launch_batched(v1, 0, (double *)nullptr, 0, st);
       launch_batched(v0, 0, (double *)nullptr, 0, st);
@@ -1404,6 +1413,7 @@ static int ml_nd_solve(vdn_layout *la, vdn_multifab **rh, vdn_multifab **phi, vd
         }
       }
       launch_batched(vc, 0, (double *)nullptr, 0, st);
+      if (la->pmask[0] || la->pmask[1] || la->pmask[2]) mf_fill_boundary(cov[n]);       // ghost cells across a periodic boundary
       S.sig[n] = T(mf_temp(la, n, 1, 1, -1, true, 0.0));
       S.skip[n] = T(mf_temp(la, n, 1, 1, 3, true, 0.0));
       if (S.slave[n]) mf_copy(S.skip[n], 0, S.slave[n], 0, 1, 0);
@@ -1457,7 +1467,7 @@ static int ml_nd_solve(vdn_layout *la, vdn_multifab **rh, vdn_multifab **phi, vd
       for (int f = 0; f < S.vf_res[n].nboxes(); f++) {
         if (!S.vf_res[n].have[f] || !S.vf_own[n].have[f]) continue;
         NdfArgs Af; for (int d = 0; d < 3; d++) { Af.lo[d] = S.vf_res[n].vbox[f].lo[d]; Af.hi[d] = S.vf_res[n].vbox[f].hi[d] + 1; Af.dirlo[d] = Af.dirhi[d] = Af.cflo[d] = Af.cfhi[d] = Af.ilo[d] = Af.ihi[d] = 0; Af.f[d] = 0.0; }
-        Range3 rf; for (int d = 0; d < 3; d++) { rf.lo[d] = (Af.lo[d] + 1) / 2; rf.hi[d] = Af.hi[d] / 2; }       // coarse nodes whose fine twin is a node of box f
+        Range3 rf; for (int d = 0; d < 3; d++) { rf.lo[d] = nd_fdiv2(Af.lo[d] + 1); rf.hi[d] = nd_fdiv2(Af.hi[d]); }       // coarse nodes whose fine twin is a node of box f
         for (size_t c = 0; c < S.A[n - 1].size(); c++) {
           NdmRestrictB q; if (!nd_isect(rf, S.r[n - 1][c], q.r)) continue;
           q.res_c = S.res[n - 1]->fabs[c]; q.res_f = S.vf_res[n].fv[f]; q.own_f = S.vf_own[n].fv[f]; q.Af = Af; q.Ac = S.A[n - 1][c];

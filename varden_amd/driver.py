@@ -211,7 +211,8 @@ class VardenAMR:
         self.boxes = [base] + [[(tuple(b[0]), tuple(b[1])) for b in lb] for lb in lev_boxes]
         self.owner = [distribute(lb, nranks) for lb in self.boxes]
         self.local = [[i for i, o in enumerate(ow) if o == rank] for ow in self.owner]
-        self.mla = bl.MLLayout(pd, self.boxes, owner=self.owner, rr=[(2, 2, 2)] * (NL - 1))
+        self.pmask = tuple(1 if self.phys[d][0] == bl.PERIODIC else 0 for d in range(3))
+        self.mla = bl.MLLayout(pd, self.boxes, owner=self.owner, rr=[(2, 2, 2)] * (NL - 1), pmask=self.pmask)
         self.bct = bl.BCTower(self.mla, self.phys)
         self.dx = [[1.0 / (nc << n)] * 3 for n in range(NL)]
         dm, ns = 3, self.prm.nscal
@@ -265,7 +266,7 @@ class VardenAMR:
         boxes = [[pd[0]] if base_boxes is None else [(tuple(b[0]), tuple(b[1])) for b in base_boxes]]
         for lev in range(1, max_levs):
             owner = [distribute(lb, nranks) for lb in boxes]
-            mla = bl.MLLayout(pd, boxes, owner=owner, rr=[(2, 2, 2)] * (lev - 1))
+            mla = bl.MLLayout(pd, boxes, owner=owner, rr=[(2, 2, 2)] * (lev - 1), pmask=tuple(1 if int(phys_bc[d][0]) == bl.PERIODIC else 0 for d in range(3)))
             sold = bl.MultiFab(mla, lev - 1, ns, 3)
             dx = [1.0 / (nc << (lev - 1))] * 3
             for li, gi in enumerate([i for i, o in enumerate(owner[lev - 1]) if o == rank]):
@@ -311,7 +312,7 @@ class VardenAMR:
         NL = len(boxes)
         pd = [((0, 0, 0), ((self.nc << n) - 1,) * 3) for n in range(NL)]
         owner = [distribute(lb, self.nranks) for lb in boxes]
-        mla = bl.MLLayout(pd, boxes, owner=owner, rr=[(2, 2, 2)] * (NL - 1))
+        mla = bl.MLLayout(pd, boxes, owner=owner, rr=[(2, 2, 2)] * (NL - 1), pmask=self.pmask)
         bct = bl.BCTower(mla, self.phys)
         mk = lambda nc_, ng, nodal=None: [bl.MultiFab(mla, n, nc_, ng, nodal) for n in range(NL)]   # noqa: E731
         st = dict(mla=mla, bct=bct, boxes=boxes, owner=owner, uold=mk(self.dm, 3), sold=mk(self.nscal, 3), gp=mk(self.dm, 1), p=mk(1, 1, (1, 1, 1)))
