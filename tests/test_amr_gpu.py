@@ -582,3 +582,51 @@ def test_two_level_start_up_sequence(gpu, oracle):
             a, b = gm[n].to_numpy(0)[3:-3, 3:-3, 3:-3], om.valid()
             assert np.abs(a - b).max() <= 1e-8 * max(np.abs(b).max(), 1e-300), "level %d %s differs by %.3e" % (n, nm, np.abs(a - b).max())
     G.close()
+
+
+def test_periodic_hierarchy_is_translation_invariant(gpu):
+    """a hierarchy on a domain that is periodic in x: shifting the whole problem by half a period -- the bubble then sits ON the periodic
+    boundary and its fine level is two boxes, one at each end of the domain, talking to each other and to the coarse level through
+    periodic images -- must give the shifted solution.  Three steps (MAC, viscous and nodal composite solves each); 1e-8 relative:
+    the two runs cut the fine level differently, so only the solver tolerances separate them."""
+    from varden_amd import advance as adv
+    from varden_amd import driver
+    from varden_amd.capi import default_params
+    nc = 16
+    phys = [[-1, -1], [15, 15], [15, 15]]
+
+    def bubble(xc):
+        def fn(lev, blo, nb, dx):
+            g = 3
+            ax = [(np.arange(blo[d] - g, blo[d] + nb[d] + g) + 0.5) * dx[d] for d in range(3)]
+            X, Y, Z = np.meshgrid(*ax, indexing="ij")
+            dxp = (X - xc + 0.5) % 1.0 - 0.5                   # periodic distance in x
+            r = np.sqrt(dxp ** 2 + (Y - 0.5) ** 2 + (Z - 0.5) ** 2)
+            s = np.zeros(X.shape + (2,), order="F")
+            s[..., 0] = 1.0 + 0.5 * (10.0 - 1.0) * (1.0 - np.tanh(30.0 * (r - 0.1)))
+            s[..., 1] = s[..., 0]
+            return np.zeros(X.shape + (3,), order="F"), s
+        return fn
+
+    prm = lambda: default_params(cflfac=0.9, visc_coef=0.001)   # noqa: E731
+    A = driver.VardenAMR(nc, [((8, 8, 8), (23, 23, 23))], phys, params=prm(), init_fn=bubble(0.5), init_iter=1, do_initial_projection=1)
+    for _ in range(3):
+        A.step()
+    ua0, sa0 = A.unew[0].to_numpy(0)[3:-3, 3:-3, 3:-3], A.snew[0].to_numpy(0)[3:-3, 3:-3, 3:-3]
+    ua1, sa1 = A.unew[1].to_numpy(0)[3:-3, 3:-3, 3:-3], A.snew[1].to_numpy(0)[3:-3, 3:-3, 3:-3]
+    dta, ita = A.dt, (adv.last_solver_stats("mac")[0], adv.last_solver_stats("hg")[0])
+    A.close()
+    B = driver.VardenAMR(nc, [((24, 8, 8), (31, 23, 23)), ((0, 8, 8), (7, 23, 23))], phys, params=prm(), init_fn=bubble(0.0), init_iter=1, do_initial_projection=1)
+    for _ in range(3):
+        B.step()
+    assert abs(B.dt - dta) <= 1e-9 * dta
+    assert abs(adv.last_solver_stats("mac")[0] - ita[0]) <= 1 and abs(adv.last_solver_stats("hg")[0] - ita[1]) <= 1
+    ub0, sb0 = B.unew[0].to_numpy(0)[3:-3, 3:-3, 3:-3], B.snew[0].to_numpy(0)[3:-3, 3:-3, 3:-3]
+    for a, b, nm in ((ua0, ub0, "u"), (sa0, sb0, "s")):
+        assert np.abs(np.roll(a, nc // 2, axis=0) - b).max() <= 1e-8 * np.abs(a).max(), "level 0 %s: %.3e" % (nm, np.abs(np.roll(a, nc // 2, axis=0) - b).max())
+    # level 1: run A's box 8..23 in x is run B's boxes 24..31 (its low half) and 0..7 (its high half)
+    for a, mf, nm in ((ua1, B.unew[1], "u"), (sa1, B.snew[1], "s")):
+        lo_half, hi_half = mf.to_numpy(0)[3:-3, 3:-3, 3:-3], mf.to_numpy(1)[3:-3, 3:-3, 3:-3]
+        assert np.abs(a[:8] - lo_half).max() <= 1e-8 * np.abs(a).max() and np.abs(a[8:] - hi_half).max() <= 1e-8 * np.abs(a).max(), nm
+    assert np.abs(ua1[..., 2]).max() > 0
+    B.close()

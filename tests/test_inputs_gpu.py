@@ -22,7 +22,7 @@ def test_namelist_parser():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("name,nsteps,nlev", [("inputs_bubble_3d", 8, 2), ("inputs_3d-regt", 4, 3), ("inputs_advect_3d", 4, 3)])
+@pytest.mark.parametrize("name,nsteps,nlev", [("inputs_bubble_3d", 8, 2), ("inputs_3d-regt", 4, 3), ("inputs_advect_3d", 4, 3), ("inputs_RayleighTaylor_3d", 5, 2)])
 def test_reference_inputs_run(gpu, name, nsteps, nlev):
     from varden_amd import advance as adv
     from varden_amd import inputs
@@ -42,7 +42,11 @@ def test_reference_inputs_run(gpu, name, nsteps, nlev):
         for i in range(G.unew[n].nfabs()):
             assert np.isfinite(G.unew[n].to_numpy(i)).all() and np.isfinite(G.snew[n].to_numpy(i)).all()
     s0 = G.snew[0].to_numpy(0)[3:-3, 3:-3, 3:-3, 0]
-    if "advect" not in name:                                  # the bubble problems are mirror-symmetric in x and y ...
+    if "Rayleigh" in name:                                    # periodic in x and y, heavy over light: the interface region stays within the two densities
+        assert s0.min() >= 1.0 - 1e-3 and s0.max() <= 2.0 + 1e-3
+        w = G.unew[0].to_numpy(0)[3:-3, 3:-3, 3:-3, 2]
+        assert np.abs(w).max() > 0.0
+    elif "advect" not in name:                                # the bubble problems are mirror-symmetric in x and y ...
         # ... exactly so when the union of boxes is (two levels here); the clustered level 2 of the three-level case is not, and the
         # coarse-fine interfaces then sit at different places left and right: symmetric to truncation error only
         tol = 1e-8 if nlev == 2 else 1e-3

@@ -40,9 +40,13 @@ def initdata_numpy(n, dx, prob_type=1, ng=3, nscal=2, lo=(0, 0, 0), centre=(0.5,
     y = dx[1] * (lo[1] + np.arange(n[1]) + 0.5)
     z = dx[2] * (lo[2] + np.arange(n[2]) + 0.5)
     X, Y, Z = np.meshgrid(x, y, z, indexing="ij")
+    g = ng
+    if prob_type == 3:                                    # Rayleigh-Taylor interface, initdata.f90:195-200, 261-274 (tracer = 0)
+        h = lambda t: 0.02 * np.sin(4.0 * np.pi * t) + 0.01 * np.sin(8.0 * np.pi * t)      # noqa: E731
+        s[g:-g, g:-g, g:-g, 0] = 1.0 + 0.5 + 0.5 * np.tanh((Z - 0.5 - h(X) - h(Y)) / 0.01)
+        return u, s
     dist = np.sqrt((X - centre[0]) ** 2 + (Y - centre[1]) ** 2 + (Z - centre[2]) ** 2)
     r = 1.0 + 0.5 * (10.0 - 1.0) * (1.0 - np.tanh(30.0 * (dist - 0.1)))
-    g = ng
     s[g:-g, g:-g, g:-g, 0] = r
     if nscal > 1:
         s[g:-g, g:-g, g:-g, 1] = r
@@ -190,8 +194,9 @@ class VardenAMR:
 
     def __init__(self, nc, fine_boxes, phys_bc, params=None, prob_type=1, grav=-9.8, init_shrink=0.1, device=0, finer_levels=(),
                  regrid_int=-1, max_levs=None, max_grid_size=256, init_iter=0, do_initial_projection=0,
-                 rank=0, nranks=1, comm_id=None, base_boxes=None):
-        """several ranks (one per GPU): the boxes of every level are dealt to the ranks by cell count (`distribute`), `base_boxes` cuts
+                 rank=0, nranks=1, comm_id=None, base_boxes=None, init_fn=None):
+        """init_fn(level, box_lo, box_shape, dx) -> (u, s) with 3 ghost layers replaces the analytic initial data of prob_type.
+        several ranks (one per GPU): the boxes of every level are dealt to the ranks by cell count (`distribute`), `base_boxes` cuts
         level 0 into several boxes, comm_id is the RCCL unique id broadcast by the caller; regridding is single-rank in this round"""
         self.prm = params or default_params()
         self.grav, self.regrid_int, self.max_grid_size = grav, regrid_int, max_grid_size
@@ -226,7 +231,7 @@ class VardenAMR:
             for li, gi in enumerate(self.local[n]):         # each rank initialises the boxes it owns
                 blo, bhi = self.boxes[n][gi]
                 nb = tuple(bhi[d] - blo[d] + 1 for d in range(3))
-                ub, sb = initdata_numpy(nb, self.dx[n], prob_type, 3, ns, lo=blo)
+                ub, sb = initdata_numpy(nb, self.dx[n], prob_type, 3, ns, lo=blo) if init_fn is None else init_fn(n, blo, nb, self.dx[n])
                 self.uold[n].from_numpy(ub, li)
                 self.sold[n].from_numpy(sb, li)
         self.time, self.istep = 0.0, 0

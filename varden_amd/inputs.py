@@ -62,8 +62,6 @@ def build(text, device=0, max_grid_size_cap=None):
         return nl, Varden(n, phys, prm, prob_hi=prob_hi, decomp=decomp, **common)
     if dm != 3 or len(set(n)) != 1 or any(p != 1.0 for p in prob_hi):
         raise NotImplementedError("adaptive hierarchies: 3-D, cubic unit domain in this round")
-    if any(bl.PERIODIC in side for side in phys):
-        raise NotImplementedError("adaptive hierarchies: periodic domains are not implemented in this round")
     levels = VardenAMR.tagged_grids(n[0], phys, prm, prob_type=int(nl["prob_type"]), max_levs=int(nl["max_levs"]),
                                     buf_wid=max(int(nl["amr_buf_width"]), int(nl["regrid_int"]), 1), max_grid_size=mgs, device=device)
     if not levels:
