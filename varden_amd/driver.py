@@ -41,6 +41,19 @@ def initdata_numpy(n, dx, prob_type=1, ng=3, nscal=2, lo=(0, 0, 0), centre=(0.5,
     z = dx[2] * (lo[2] + np.arange(n[2]) + 0.5)
     X, Y, Z = np.meshgrid(x, y, z, indexing="ij")
     g = ng
+    if prob_type == 4:                                    # vortex tube, initdata.f90:276-306.  The reference measures x, y, z from the
+        # BOX's low corner (float(k - lo(3))): with the one 32^3 box of inputs_vortextube_3d that is the domain's; kept as written
+        xb = dx[0] * (np.arange(n[0]) + 0.5) - 0.5
+        yb = dx[1] * (np.arange(n[1]) + 0.5) - 0.5
+        zb = dx[2] * (np.arange(n[2]) + 0.5) - 0.5
+        Xb, Yb, Zb = np.meshgrid(xb, yb, zb, indexing="ij")
+        r_yz = np.sqrt(Yb * Yb + Zb * Zb)
+        u[g:-g, g:-g, g:-g, 0] = np.tanh((0.15 - r_yz) / 0.0333)
+        u[g:-g, g:-g, g:-g, 2] = 0.05 * np.exp(-15.0 * (Xb * Xb + Yb * Yb))
+        s[g:-g, g:-g, g:-g, 0] = 1.0
+        if nscal > 1:
+            s[g:-g, g:-g, g:-g, 1] = np.exp(-500.0 * (0.15 - r_yz) ** 2)
+        return u, s
     if prob_type == 3:                                    # Rayleigh-Taylor interface, initdata.f90:195-200, 261-274 (tracer = 0)
         h = lambda t: 0.02 * np.sin(4.0 * np.pi * t) + 0.01 * np.sin(8.0 * np.pi * t)      # noqa: E731
         s[g:-g, g:-g, g:-g, 0] = 1.0 + 0.5 + 0.5 * np.tanh((Z - 0.5 - h(X) - h(Y)) / 0.01)
