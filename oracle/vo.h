@@ -184,6 +184,8 @@ int  vo_ml_nd_solve(int nlev, vo_fab **rh, vo_fab **phi, vo_fab **coeffs, vo_fab
                     double rel_eps, double abs_eps, int max_iter, const vdn_params *prm, vo_mgstat *st);
 void vo_ml_visc_solve(int nlev, vo_fab **unew, vo_fab **lapu, vo_fab **rho, vo_fab **mac_rhs, const double *dx, double mu, const vo_bc *bc,
                       const int pmask[3], const int *pd, const vdn_params *prm, vo_mgstat *st);
+void vo_ml_diff_scalar_solve(int nlev, vo_fab **snew, vo_fab **laps, const double *dx, double mu, const vo_bc *bc, const int pmask[3], const int *pd,
+                             const vdn_params *prm, int icomp, int bccomp, vo_mgstat *st);
 void vo_ml_hgproject(int nlev, int proj_type, vo_fab **unew, vo_fab **uold, vo_fab **rhohalf, vo_fab **p, vo_fab **gp, const double *dx, double dt,
                      const vo_bc *bc, const int pmask[3], const int *pd, const vdn_params *prm, vo_mgstat *st);
 

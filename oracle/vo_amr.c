@@ -409,6 +409,42 @@ void vo_ml_visc_solve(int nlev, vo_fab **unew, vo_fab **lapu, vo_fab **rho, vo_f
   for (int n = 0; n < nlev; n++) { free(rh[n].p); free(phi[n].p); free(alpha[n].p); for (int d = 0; d < 3; d++) free(beta[3 * n + d].p); }
 }
 
+/* diff_scalar_solve (viscsolve.f90:308-515) on nlev levels: (1 - div mu grad) s = s [+ mu laps], component icomp, bc component bccomp */
+void vo_ml_diff_scalar_solve(int nlev, vo_fab **snew, vo_fab **laps, const double *dx, double mu, const vo_bc *bc, const int pmask[3], const int *pd,
+                             const vdn_params *prm, int icomp, int bccomp, vo_mgstat *st)
+{
+  vo_fab rh[VO_MAXLEV], phi[VO_MAXLEV], alpha[VO_MAXLEV], beta[3 * VO_MAXLEV], *rhp[VO_MAXLEV], *php[VO_MAXLEV], *alp[VO_MAXLEV], *bp[3 * VO_MAXLEV];
+  int ellbc[VO_MAXLEV][3][2];
+  for (int n = 0; n < nlev; n++) {
+    fab_like(&rh[n], snew[n], 0, 0.0); fab_like(&phi[n], snew[n], 1, 0.0); fab_like(&alpha[n], snew[n], 0, 1.0);
+    rh[n].nc = phi[n].nc = alpha[n].nc = 1;
+    rhp[n] = &rh[n]; php[n] = &phi[n]; alp[n] = &alpha[n];
+    for (int d = 0; d < 3; d++) {
+      int nd[3] = { 0, 0, 0 }; nd[d] = 1;
+      vo_fab_init(&beta[3 * n + d], NULL, snew[n]->lo, snew[n]->hi, 0, nd, 1);
+      long sz = vo_size(&beta[3 * n + d]);
+      beta[3 * n + d].p = (double *)malloc(sizeof(double) * sz);
+      for (long q = 0; q < sz; q++) beta[3 * n + d].p[q] = mu;
+      bp[3 * n + d] = &beta[3 * n + d];
+    }
+    const int *lo = snew[n]->lo, *hi = snew[n]->hi;
+    for (int k = lo[2] - 1; k <= hi[2] + 1; k++) for (int j = lo[1] - 1; j <= hi[1] + 1; j++) for (int i = lo[0] - 1; i <= hi[0] + 1; i++)
+      VF(&phi[n], i, j, k, 0) = VF(snew[n], i, j, k, icomp);
+    for (int k = lo[2]; k <= hi[2]; k++) for (int j = lo[1]; j <= hi[1]; j++) for (int i = lo[0]; i <= hi[0]; i++) {
+      double r = VF(snew[n], i, j, k, icomp);
+      if (prm->diffusion_type == 1) r = r + mu * VF(laps[n], i, j, k, icomp);
+      VF(&rh[n], i, j, k, 0) = r;
+    }
+    for (int a = 0; a < 3; a++) for (int sd = 0; sd < 2; sd++) ellbc[n][a][sd] = bc[n].ell[a][sd][bccomp];
+  }
+  vo_ml_cc_solve(nlev, rhp, php, alp, bp, dx, (const int (*)[3][2])ellbc, pmask, pd, 1.e-12, prm->mg_max_iter, prm, st);
+  for (int n = 0; n < nlev; n++)
+    for (int k = snew[n]->lo[2]; k <= snew[n]->hi[2]; k++) for (int j = snew[n]->lo[1]; j <= snew[n]->hi[1]; j++) for (int i = snew[n]->lo[0]; i <= snew[n]->hi[0]; i++)
+      VF(snew[n], i, j, k, icomp) = VF(&phi[n], i, j, k, 0);
+  vo_ml_restrict_and_fill(nlev, snew, icomp, bccomp, 1, 0, bc, pmask, pd, prm);          /* viscsolve.f90:378-381 */
+  for (int n = 0; n < nlev; n++) { free(rh[n].p); free(phi[n].p); free(alpha[n].p); for (int d = 0; d < 3; d++) free(beta[3 * n + d].p); }
+}
+
 /* hgproject.f90:17-178 with nlevs > 1 (rel tolerance 1e-11 for two levels, 1e-10 for more: hgproject.f90:115-119) */
 void vo_ml_hgproject(int nlev, int proj_type, vo_fab **unew, vo_fab **uold, vo_fab **rhohalf, vo_fab **p, vo_fab **gp, const double *dx, double dt,
                      const vo_bc *bc, const int pmask[3], const int *pd, const vdn_params *prm, vo_mgstat *st)
@@ -488,20 +524,33 @@ void vo_ml_advance_timestep(int NL, vo_state *S, const double *dx, double dt, co
   /* scalar advance */
   {
     int is_cons[VO_MAXCOMP]; is_cons[0] = 1; for (int c = 1; c < nscal; c++) is_cons[c] = 0;
+    const int diffusive = prm->diff_coef > 0.0;
+    vo_fab laps[VO_MAXLEV], *lsp[VO_MAXLEV];
+    for (int n = 0; n < NL; n++) {                                                         /* scalar_advance.f90:80-89, then average down */
+      fab_new_l(&laps[n], &S[n].uold, 0, -1, nscal, 0.0); lsp[n] = &laps[n];
+      if (diffusive) for (int c = 1; c < nscal; c++) vo_explicit_diffusive_term(&laps[n], &S[n].sold, c, dm + c, dx + 3 * n, &bc[n]);
+    }
+    if (diffusive) for (int n = NL - 1; n >= 1; n--) vo_ml_cc_restriction(lsp[n - 1], lsp[n], 1, nscal - 1);
     for (int n = 0; n < NL; n++) {
       fab_new_l(&scal_force[n], &S[n].uold, 1, -1, nscal, 0.0); sfp2[n] = &scal_force[n];
       fab_new_l(&divu[n], &S[n].uold, 1, -1, 1, 0.0);
       for (int d = 0; d < 3; d++) { fab_new_l(&sflux[3 * n + d], &S[n].uold, 0, d, nscal, 0.0); fab_new_l(&sedge[3 * n + d], &S[n].uold, 0, d, nscal, 0.0); sfp[3 * n + d] = &sflux[3 * n + d]; sep[3 * n + d] = &sedge[3 * n + d]; }
-      vo_mkscalforce(&scal_force[n], &S[n].ext_scal_force, NULL, 1.0, prm);
+      vo_mkscalforce(&scal_force[n], &S[n].ext_scal_force, diffusive ? &laps[n] : NULL, 1.0, prm);
     }
     vo_ml_restrict_and_fill(NL, sfp2, 0, bc[0].extrap_comp, nscal, 1, bc, pmask, pd, prm);
     for (int n = 0; n < NL; n++) {
       vo_mkflux(&S[n].sold, sep + 3 * n, sfp + 3 * n, ump + 3 * n, &scal_force[n], &divu[n], dx + 3 * n, dt, 0, is_cons, dm, &bc[n], prm);
-      vo_mkscalforce(&scal_force[n], &S[n].ext_scal_force, NULL, 0.0, prm);
+      vo_mkscalforce(&scal_force[n], &S[n].ext_scal_force, diffusive ? &laps[n] : NULL, 0.0, prm);
     }
     vo_ml_restrict_and_fill(NL, sfp2, 0, bc[0].extrap_comp, nscal, 1, bc, pmask, pd, prm);
     for (int n = 0; n < NL; n++) vo_update(&S[n].sold, ump + 3 * n, sep + 3 * n, sfp + 3 * n, &scal_force[n], &S[n].snew, dx + 3 * n, dt, 0, is_cons);
     vo_ml_restrict_and_fill(NL, snewp, 0, dm, nscal, 0, bc, pmask, pd, prm);
+    if (diffusive) {                                                                   /* scalar_advance.f90:144-162 */
+      const double visc_mu = (prm->diffusion_type == 1) ? 0.5 * dt * prm->diff_coef : dt * prm->diff_coef;
+      vo_mgstat sst;
+      for (int c = 1; c < nscal; c++) vo_ml_diff_scalar_solve(NL, snewp, lsp, dx, visc_mu, bc, pmask, pd, prm, c, dm + c, &sst);
+    }
+    for (int n = 0; n < NL; n++) free(laps[n].p);
     for (int n = 0; n < NL; n++) { free(scal_force[n].p); free(divu[n].p); for (int d = 0; d < 3; d++) { free(sflux[3 * n + d].p); free(sedge[3 * n + d].p); } }
   }
   for (int n = 0; n < NL; n++) vo_make_at_halftime(&rhohalf[n], 0, &S[n].sold, &S[n].snew, 0);

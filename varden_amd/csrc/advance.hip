@@ -38,7 +38,7 @@ extern "C" int vdn_advance_timestep(int istep, vdn_layout *mla, vdn_multifab **s
   const vdn_params &P = ctx().prm;
   const int dm = P.dm, nscal = P.nscal, nlevs = mla->nlev;
   const bool viscous = P.visc_coef > 0.0, diffusive = P.diff_coef > 0.0;
-  REQUIRE(nlevs == 1 || (dm == 3 && !diffusive), "advance_timestep: multi-level hierarchies are implemented for dm = 3 and diff_coef = 0 (this round)");
+  REQUIRE(nlevs == 1 || dm == 3, "advance_timestep: multi-level hierarchies are implemented for dm = 3");
   REQUIRE(press_comp == dm + nscal + 1, "press_comp must be dm+nscal+1 (got %d)", press_comp);
   for (int n = 0; n < nlevs; n++) {
     REQUIRE(uold[n]->ng >= 3 && sold[n]->ng >= 3 && unew[n]->ng >= 3 && snew[n]->ng >= 3, "state needs ng_cell = 3");
@@ -93,14 +93,17 @@ extern "C" int vdn_advance_timestep(int istep, vdn_layout *mla, vdn_multifab **s
     size_t mark = arena_mark();
     int is_cons[VDN_MAXCOMP]; is_cons[0] = 1; for (int c = 1; c < nscal; c++) is_cons[c] = 0;
     vdn_multifab *scal_force[VDN_MAXLEV], *divu[VDN_MAXLEV], *sflux[3 * VDN_MAXLEV], *sedge[3 * VDN_MAXLEV], *laps[VDN_MAXLEV] = { nullptr };
+    if (diffusive) {                                                                    // scalar_advance.f90:80-89 (cc_applyop per level, then average down)
+      for (int n = 0; n < nlevs; n++) {
+        laps[n] = mf_temp(mla, n, nscal, 0, -1, true, 0.0);
+        for (int c = 1; c < nscal; c++) k_explicit_diffusive_term(laps[n], sold[n], c, dm + c, DXL(n), bct);
+      }
+      for (int n = nlevs - 1; n >= 1; n--) ml_cc_restriction(laps[n - 1], laps[n], 1, nscal - 1);
+    }
     for (int n = 0; n < nlevs; n++) {
       scal_force[n] = mf_temp(mla, n, nscal, 1, -1, false, 0.0);
       divu[n] = mf_temp(mla, n, 1, 1, -1, true, 0.0);
       for (int d = 0; d < dm; d++) { sflux[3 * n + d] = mf_temp(mla, n, nscal, 0, d, true, 0.0); sedge[3 * n + d] = mf_temp(mla, n, nscal, 0, d, false, 0.0); }   // mkflux writes every edge state
-      if (diffusive) {                                                                  // scalar_advance.f90:80-89
-        laps[n] = mf_temp(mla, n, nscal, 0, -1, true, 0.0);
-        for (int c = 1; c < nscal; c++) k_explicit_diffusive_term(laps[n], sold[n], c, dm + c, DXL(n), bct);
-      }
       k_mkscalforce(scal_force[n], ext_scal_force[n], laps[n], 1.0);
     }
     restrict_and_fill(nlevs, scal_force, 0, bct->extrap_comp0(), nscal, true, bct);     // mkforce.f90:283-284
@@ -113,7 +116,10 @@ extern "C" int vdn_advance_timestep(int istep, vdn_layout *mla, vdn_multifab **s
     restrict_and_fill(nlevs, snew, 0, dm, nscal, false, bct);                           // update.f90:106
     if (diffusive) {                                                                    // scalar_advance.f90:144-162
       const double visc_mu = (P.diffusion_type == 1) ? 0.5 * dt * P.diff_coef : dt * P.diff_coef;
-      for (int c = 1; c < nscal; c++) do_diff_scalar_solve(mla, snew[0], laps[0], dx, visc_mu, bct, c, dm + c);
+      for (int c = 1; c < nscal; c++) {
+        if (nlevs == 1) do_diff_scalar_solve(mla, snew[0], laps[0], dx, visc_mu, bct, c, dm + c);
+        else do_ml_diff_scalar_solve(mla, snew, laps, dx, visc_mu, bct, c, dm + c);
+      }
     }
     arena_release(mark);
   }

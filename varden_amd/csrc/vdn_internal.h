@@ -218,4 +218,6 @@ int ml_cc_solve(vdn_layout *la, vdn_multifab **rh, vdn_multifab **phi, vdn_multi
                 double rel_eps, int max_iter, int *iters, double *res0, double *res, vdn_multifab **alpha);
 void do_ml_visc_solve(vdn_layout *mla, vdn_multifab **unew, vdn_multifab **lapu, vdn_multifab **rho, vdn_multifab **mac_rhs,
                       const double *dx, double mu, const vdn_bc_tower *bct);
+void do_ml_diff_scalar_solve(vdn_layout *mla, vdn_multifab **snew, vdn_multifab **laps, const double *dx, double mu,
+                             const vdn_bc_tower *bct, int icomp, int bccomp0);
 void do_ml_macproject(vdn_layout *mla, vdn_multifab **umac, vdn_multifab **rho, vdn_multifab **mac_rhs, const double *dx, const vdn_bc_tower *bct, int bc_comp0);

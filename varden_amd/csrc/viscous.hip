@@ -165,3 +165,29 @@ void do_diff_scalar_solve(vdn_layout *mla, vdn_multifab *snew, const vdn_multifa
   mf_temp_free(alpha); mf_temp_free(phi); mf_temp_free(rh);
   arena_release(mark);
 }
+
+// diff_scalar_solve (viscsolve.f90:308-515) on several levels: (1 - div mu grad) s = s [+ mu laps] for component icomp
+void do_ml_diff_scalar_solve(vdn_layout *mla, vdn_multifab **snew, vdn_multifab **laps, const double *dx, double mu,
+                             const vdn_bc_tower *bct, int icomp, int bccomp0) {
+  const int L = mla->nlev;
+  hipStream_t st = ctx().stream;
+  size_t mark = arena_mark();
+  vdn_multifab *rh[VDN_MAXLEV], *phi[VDN_MAXLEV], *alpha[VDN_MAXLEV], *beta[3 * VDN_MAXLEV];
+  for (int n = 0; n < L; n++) {
+    rh[n] = mf_temp(mla, n, 1, 0, -1, false, 0.0); phi[n] = mf_temp(mla, n, 1, 1, -1, true, 0.0); alpha[n] = mf_temp(mla, n, 1, 0, -1, true, 1.0);   // viscsolve.f90:349
+    for (int d = 0; d < 3; d++) beta[3 * n + d] = mf_temp(mla, n, 1, 0, d, true, mu);
+    for (int i = 0; i < snew[n]->nfabs(); i++) {
+      const vdn_box &bx = snew[n]->vbox[i];
+      Range3 rg; for (int a = 0; a < 3; a++) { rg.lo[a] = bx.lo[a] - 1; rg.hi[a] = bx.hi[a] + 1; }
+      hipLaunchKernelGGL(kk_diff_rhs, grid_for(rg), dim3(64, 4, 1), 0, st, rh[n]->fabs[i], phi[n]->fabs[i], snew[n]->fabs[i], laps[n]->fabs[i], icomp,
+                         ctx().prm.diffusion_type, mu, rg, bx.lo[0], bx.lo[1], bx.lo[2], bx.hi[0], bx.hi[1], bx.hi[2]);
+    }
+  }
+  int it; double r0, rr;
+  int rc = ml_cc_solve(mla, rh, phi, beta, dx, bct, bccomp0, 1.e-12, ctx().prm.mg_max_iter, &it, &r0, &rr, alpha);
+  if (rc != 0 && ctx().prm.verbose) fprintf(stderr, "varden_amd: composite diffusive solve did not converge in %d iterations (res %g / %g)\n", it, rr, r0);
+  for (int n = 0; n < L; n++) mf_copy(snew[n], icomp, phi[n], 0, 1, 0);                          // viscsolve.f90:374
+  ml_restrict_and_fill(L, snew, icomp, bccomp0, 1, false, bct);                                  // 378-381
+  for (int n = L - 1; n >= 0; n--) { for (int d = 2; d >= 0; d--) mf_temp_free(beta[3 * n + d]); mf_temp_free(alpha[n]); mf_temp_free(phi[n]); mf_temp_free(rh[n]); }
+  arena_release(mark);
+}
