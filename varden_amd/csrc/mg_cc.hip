@@ -945,76 +945,79 @@ void cc_bench_smoother(vdn_multifab *rh, vdn_multifab *phi, vdn_multifab **beta,
 // ====================================================================================================
 // MAC projection pieces (macproject.f90)
 // ====================================================================================================
-__global__ void kk_divumac(FV um, FV vm, FV wm, FV macrhs, FV rh, double dxi0, double dxi1, double dxi2, Range3 r) {
-  THREAD_IJK(r)
-  if (!in_range) return;
-  // macproject.f90:270-272 then 190-196:  rh = -div + mac_rhs
-  double div = (fv_get(um, i + 1, j, k) - fv_get(um, i, j, k)) * dxi0
-             + (fv_get(vm, i, j + 1, k) - fv_get(vm, i, j, k)) * dxi1
-             + (fv_get(wm, i, j, k + 1) - fv_get(wm, i, j, k)) * dxi2;
-  fv_at(rh, i, j, k) = div * -1.0 + fv_get(macrhs, i, j, k);
-}
-__global__ void kk_mk_mac_coeffs(FV rho, FV bx, FV by, FV bz, Range3 r, int h0, int h1, int h2) {
-  THREAD_IJK(r)
-  if (!in_range) return;
-  const double r0 = fv_get(rho, i, j, k);
-  if (j <= h1 && k <= h2) fv_at(bx, i, j, k) = 2.0 / (r0 + fv_get(rho, i - 1, j, k));     // macproject.f90:376
-  if (i <= h0 && k <= h2) fv_at(by, i, j, k) = 2.0 / (r0 + fv_get(rho, i, j - 1, k));     // 385
-  if (i <= h0 && j <= h1) fv_at(bz, i, j, k) = 2.0 / (r0 + fv_get(rho, i, j, k - 1));     // 394
-}
+struct divumac_K { FV um; FV vm; FV wm; FV macrhs; FV rh; double dxi0; double dxi1; double dxi2;
+  __device__ void cell(int i, int j, int k) const {
+    // macproject.f90:270-272 then 190-196:  rh = -div + mac_rhs
+    double div = (fv_get(um, i + 1, j, k) - fv_get(um, i, j, k)) * dxi0
+               + (fv_get(vm, i, j + 1, k) - fv_get(vm, i, j, k)) * dxi1
+               + (fv_get(wm, i, j, k + 1) - fv_get(wm, i, j, k)) * dxi2;
+    fv_at(rh, i, j, k) = div * -1.0 + fv_get(macrhs, i, j, k);
+  } };
+
+struct mk_mac_coeffs_K { FV rho; FV bx; FV by; FV bz; int h0; int h1; int h2;
+  __device__ void cell(int i, int j, int k) const {
+    const double r0 = fv_get(rho, i, j, k);
+    if (j <= h1 && k <= h2) fv_at(bx, i, j, k) = 2.0 / (r0 + fv_get(rho, i - 1, j, k));     // macproject.f90:376
+    if (i <= h0 && k <= h2) fv_at(by, i, j, k) = 2.0 / (r0 + fv_get(rho, i, j - 1, k));     // 385
+    if (i <= h0 && j <= h1) fv_at(bz, i, j, k) = 2.0 / (r0 + fv_get(rho, i, j, k - 1));     // 394
+  } };
+
 struct UmacArgs { int lo[3], hi[3]; int ebc[3][2]; double dx[3]; };
-__global__ void kk_mkumac(FV um, FV vm, FV wm, FV phi, FV bx, FV by, FV bz, UmacArgs A, Range3 r) {
-  THREAD_IJK(r)
-  if (!in_range) return;
-  const double p0 = fv_get(phi, i, j, k);
-  // macproject.f90:608-612; box faces use the ghost value the solver's closure implies, Neumann faces keep umac
-  if (j <= A.hi[1] && k <= A.hi[2]) {
-    int side = (i == A.lo[0]) ? 0 : (i == A.hi[0] + 1 ? 1 : -1);
-    if (!(side >= 0 && A.ebc[0][side] == VDN_BC_NEU)) {
-      double g = (p0 - fv_get(phi, i - 1, j, k)) / A.dx[0];
-      fv_at(um, i, j, k) = fv_get(um, i, j, k) - fv_get(bx, i, j, k) * g;
+struct mkumac_K { FV um; FV vm; FV wm; FV phi; FV bx; FV by; FV bz; UmacArgs A;
+  __device__ void cell(int i, int j, int k) const {
+    const double p0 = fv_get(phi, i, j, k);
+    // macproject.f90:608-612; box faces use the ghost value the solver's closure implies, Neumann faces keep umac
+    if (j <= A.hi[1] && k <= A.hi[2]) {
+      int side = (i == A.lo[0]) ? 0 : (i == A.hi[0] + 1 ? 1 : -1);
+      if (!(side >= 0 && A.ebc[0][side] == VDN_BC_NEU)) {
+        double g = (p0 - fv_get(phi, i - 1, j, k)) / A.dx[0];
+        fv_at(um, i, j, k) = fv_get(um, i, j, k) - fv_get(bx, i, j, k) * g;
+      }
     }
-  }
-  if (i <= A.hi[0] && k <= A.hi[2]) {
-    int side = (j == A.lo[1]) ? 0 : (j == A.hi[1] + 1 ? 1 : -1);
-    if (!(side >= 0 && A.ebc[1][side] == VDN_BC_NEU)) {
-      double g = (p0 - fv_get(phi, i, j - 1, k)) / A.dx[1];
-      fv_at(vm, i, j, k) = fv_get(vm, i, j, k) - fv_get(by, i, j, k) * g;
+    if (i <= A.hi[0] && k <= A.hi[2]) {
+      int side = (j == A.lo[1]) ? 0 : (j == A.hi[1] + 1 ? 1 : -1);
+      if (!(side >= 0 && A.ebc[1][side] == VDN_BC_NEU)) {
+        double g = (p0 - fv_get(phi, i, j - 1, k)) / A.dx[1];
+        fv_at(vm, i, j, k) = fv_get(vm, i, j, k) - fv_get(by, i, j, k) * g;
+      }
     }
-  }
-  if (i <= A.hi[0] && j <= A.hi[1]) {
-    int side = (k == A.lo[2]) ? 0 : (k == A.hi[2] + 1 ? 1 : -1);
-    if (!(side >= 0 && A.ebc[2][side] == VDN_BC_NEU)) {
-      double g = (p0 - fv_get(phi, i, j, k - 1)) / A.dx[2];
-      fv_at(wm, i, j, k) = fv_get(wm, i, j, k) - fv_get(bz, i, j, k) * g;
+    if (i <= A.hi[0] && j <= A.hi[1]) {
+      int side = (k == A.lo[2]) ? 0 : (k == A.hi[2] + 1 ? 1 : -1);
+      if (!(side >= 0 && A.ebc[2][side] == VDN_BC_NEU)) {
+        double g = (p0 - fv_get(phi, i, j, k - 1)) / A.dx[2];
+        fv_at(wm, i, j, k) = fv_get(wm, i, j, k) - fv_get(bz, i, j, k) * g;
+      }
     }
-  }
-}
+  } };
+
 
 // per-level pieces of macproject, shared by the single-level driver below and the multilevel one in amr.hip
 void mac_level_rhs(vdn_multifab **um, const vdn_multifab *mac_rhs, vdn_multifab *rh, const double *dx) {      // divumac + (190-196)
+  std::vector<std::pair<divumac_K, Range3>> v;
   for (int i = 0; i < rh->nfabs(); i++) {
     Range3 r; for (int d = 0; d < 3; d++) { r.lo[d] = rh->vbox[i].lo[d]; r.hi[d] = rh->vbox[i].hi[d]; }
-    hipLaunchKernelGGL(kk_divumac, grid_for(r), BLK, 0, ctx().stream, um[0]->fabs[i], um[1]->fabs[i], um[2]->fabs[i], mac_rhs->fabs[i], rh->fabs[i],
-                       1.0 / dx[0], 1.0 / dx[1], 1.0 / dx[2], r);
+    v.push_back({ divumac_K{ um[0]->fabs[i], um[1]->fabs[i], um[2]->fabs[i], mac_rhs->fabs[i], rh->fabs[i], 1.0 / dx[0], 1.0 / dx[1], 1.0 / dx[2] }, r });
   }
+  launch_cells(v, ctx().stream);
 }
 void mac_level_coeffs(const vdn_multifab *rho, vdn_multifab **beta) {                                          // mk_mac_coeffs_3d
+  std::vector<std::pair<mk_mac_coeffs_K, Range3>> v;
   for (int i = 0; i < rho->nfabs(); i++) {
     Range3 rf; for (int d = 0; d < 3; d++) { rf.lo[d] = rho->vbox[i].lo[d]; rf.hi[d] = rho->vbox[i].hi[d] + 1; }
-    hipLaunchKernelGGL(kk_mk_mac_coeffs, grid_for(rf), BLK, 0, ctx().stream, rho->fabs[i], beta[0]->fabs[i], beta[1]->fabs[i], beta[2]->fabs[i], rf,
-                       rf.hi[0] - 1, rf.hi[1] - 1, rf.hi[2] - 1);
+    v.push_back({ mk_mac_coeffs_K{ rho->fabs[i], beta[0]->fabs[i], beta[1]->fabs[i], beta[2]->fabs[i], rf.hi[0] - 1, rf.hi[1] - 1, rf.hi[2] - 1 }, rf });
   }
+  launch_cells(v, ctx().stream);
 }
 void mac_level_mkumac(vdn_multifab **um, const vdn_multifab *phi, vdn_multifab **beta, const double *dx, const vdn_bc_tower *bct, int bc_comp0) {
   const int n = phi->lev;
+  std::vector<std::pair<mkumac_K, Range3>> v;
   for (int i = 0; i < phi->nfabs(); i++) {
     UmacArgs A; Range3 rf;
     for (int d = 0; d < 3; d++) { A.lo[d] = rf.lo[d] = phi->vbox[i].lo[d]; A.hi[d] = phi->vbox[i].hi[d]; rf.hi[d] = A.hi[d] + 1; A.dx[d] = dx[d];
       for (int s = 0; s < 2; s++) A.ebc[d][s] = bct->ell_bc(n, i + 1, d, s, bc_comp0); }
-    hipLaunchKernelGGL(kk_mkumac, grid_for(rf), BLK, 0, ctx().stream, um[0]->fabs[i], um[1]->fabs[i], um[2]->fabs[i], phi->fabs[i],
-                       beta[0]->fabs[i], beta[1]->fabs[i], beta[2]->fabs[i], A, rf);
+    v.push_back({ mkumac_K{ um[0]->fabs[i], um[1]->fabs[i], um[2]->fabs[i], phi->fabs[i], beta[0]->fabs[i], beta[1]->fabs[i], beta[2]->fabs[i], A }, rf });
   }
+  launch_cells(v, ctx().stream);
 }
 
 void do_macproject(vdn_layout *mla, vdn_multifab **umac, vdn_multifab **rho, vdn_multifab **mac_rhs, const double *dx,

@@ -376,11 +376,11 @@ DEVI void nd_divu_node(const FV &u, const FV &rh, double fx, double fy, double f
   #undef U
   fv_at(rh, i, j, k) = fv_get(rh, i, j, k) + (dux * fx + duy * fy + duz * fz);
 }
-__global__ void kk_nd_divu(FV u, FV rh, double fx, double fy, double fz, Range3 r) {
-  THREAD_IJK(r)
-  if (!in_range) return;
-  nd_divu_node(u, rh, fx, fy, fz, i, j, k);
-}
+struct nd_divu_K { FV u; FV rh; double fx; double fy; double fz;
+  __device__ void cell(int i, int j, int k) const {
+    nd_divu_node(u, rh, fx, fy, fz, i, j, k);
+  } };
+
 __global__ void kk_nd_load(NLev L, FV rh, FV phi, int lo0, int lo1, int lo2, double *nrm) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   const int j = blockIdx.y * blockDim.y + threadIdx.y;
@@ -772,11 +772,13 @@ int nd_solve(vdn_multifab *rh, vdn_multifab *phi, const vdn_multifab *coeffs, co
   }
   if (u) {                                                  // add_divu = .true., hg_multigrid.f90:96
     REQUIRE(u->ng >= 1 && u->nc >= 3, "nodal multigrid: u needs a ghost cell");
+    std::vector<std::pair<nd_divu_K, Range3>> v;
     for (size_t b = 0; b < D0.boxes.size(); b++) {
       const vdn_box &bx = coeffs->vbox[b];
       Range3 r; for (int d = 0; d < 3; d++) { r.lo[d] = bx.lo[d]; r.hi[d] = bx.hi[d] + 1; }
-      hipLaunchKernelGGL(kk_nd_divu, grid_for(r), NBLK, 0, st, u->fabs[b], rh->fabs[b], 0.25 / dx[0], 0.25 / dx[1], 0.25 / dx[2], r);
+      v.push_back({ nd_divu_K{ u->fabs[b], rh->fabs[b], 0.25 / dx[0], 0.25 / dx[1], 0.25 / dx[2] }, r });
     }
+    launch_cells(v, st);
   }
   HIPCHK(hipMemsetAsync(M.d_nrm, 0, sizeof(double), st));
   for (size_t b = 0; b < D0.boxes.size(); b++) {
@@ -829,80 +831,82 @@ int nd_solve(vdn_multifab *rh, vdn_multifab *phi, const vdn_multifab *coeffs, co
 struct UvecArgs { int lo[3], hi[3], ng; int phys[3][2]; double dt, dtinv; int proj_type; };
 // gp ghost zeroing at INLET, the projected quantity on the grown box, wall ghost planes zeroed
 // (hgproject.f90:453-511), fused in one pass over the ghosted fab
-__global__ void kk_create_uvec(FV unew, FV uold, FV rhohalf, FV gp, UvecArgs A, Range3 r) {
-  THREAD_IJK(r)
-  if (!in_range) return;
-  const int q[3] = { i, j, k };
-  bool g1 = true;                         // inside the box grown by 1
+struct create_uvec_K { FV unew; FV uold; FV rhohalf; FV gp; UvecArgs A;
+  __device__ void cell(int i, int j, int k) const {
+    const int q[3] = { i, j, k };
+    bool g1 = true;                         // inside the box grown by 1
   #pragma unroll
-  for (int d = 0; d < 3; d++) if (q[d] < A.lo[d] - 1 || q[d] > A.hi[d] + 1) g1 = false;
-  bool wall_plane = false, inlet_plane = false;
+    for (int d = 0; d < 3; d++) if (q[d] < A.lo[d] - 1 || q[d] > A.hi[d] + 1) g1 = false;
+    bool wall_plane = false, inlet_plane = false;
   #pragma unroll
-  for (int d = 0; d < 3; d++) {
-    if (q[d] == A.lo[d] - 1) { int p = A.phys[d][0]; if (p == VDN_SLIP_WALL || p == VDN_NO_SLIP_WALL) wall_plane = true; if (p == VDN_INLET) inlet_plane = true; }
-    if (q[d] == A.hi[d] + 1) { int p = A.phys[d][1]; if (p == VDN_SLIP_WALL || p == VDN_NO_SLIP_WALL) wall_plane = true; if (p == VDN_INLET) inlet_plane = true; }
-  }
-  #pragma unroll
-  for (int m = 0; m < 3; m++) {
-    double gpv = 0.0;
-    if (g1) { gpv = fv_get(gp, i, j, k, m); if (inlet_plane) { gpv = 0.0; fv_at(gp, i, j, k, m) = 0.0; } }
-    if (wall_plane) { fv_at(unew, i, j, k, m) = 0.0; continue; }
-    if (!g1) continue;
-    double v = fv_get(unew, i, j, k, m);
-    if (A.proj_type == VDN_PRESSURE_ITERS) v = (v - fv_get(uold, i, j, k, m)) * A.dtinv;
-    else if (A.proj_type == VDN_REGULAR_TIMESTEP) v = v + A.dt * gpv / fv_get(rhohalf, i, j, k, 0);
-    fv_at(unew, i, j, k, m) = v;
-  }
-}
-__global__ void kk_coeffs(FV coeffs, FV rhohalf, Range3 r) {
-  THREAD_IJK(r)
-  if (!in_range) return;
-  fv_at(coeffs, i, j, k) = 1.0 / fv_get(rhohalf, i, j, k, 0);      // hg_multigrid.f90:76-77
-}
-__global__ void kk_mkgphi(FV gp, FV phi, double dxi0, double dxi1, double dxi2, Range3 r) {
-  THREAD_IJK(r)
-  if (!in_range) return;
-  #define P(a, b, c) fv_get(phi, i + (a), j + (b), k + (c))
-  fv_at(gp, i, j, k, 0) = 0.25 * (P(1, 0, 0) + P(1, 1, 0) + P(1, 0, 1) + P(1, 1, 1) - P(0, 0, 0) - P(0, 1, 0) - P(0, 0, 1) - P(0, 1, 1)) * dxi0;
-  fv_at(gp, i, j, k, 1) = 0.25 * (P(0, 1, 0) + P(1, 1, 0) + P(0, 1, 1) + P(1, 1, 1) - P(0, 0, 0) - P(1, 0, 0) - P(0, 0, 1) - P(1, 0, 1)) * dxi1;
-  fv_at(gp, i, j, k, 2) = 0.25 * (P(0, 0, 1) + P(1, 0, 1) + P(0, 1, 1) + P(1, 1, 1) - P(0, 0, 0) - P(1, 0, 0) - P(0, 1, 0) - P(1, 1, 0)) * dxi2;
-  #undef P
-}
-struct HgUpdArgs { int hi[3]; double dt, dtinv; int proj_type; };
-__global__ void kk_hg_update(FV unew, FV uold, FV gp, FV gphi, FV rhohalf, FV p, FV phi, HgUpdArgs A, Range3 r) {
-  THREAD_IJK(r)           // r covers nodes lo..hi+1
-  if (!in_range) return;
-  const bool cell = i <= A.hi[0] && j <= A.hi[1] && k <= A.hi[2];
-  if (cell) {
-    const double rho = fv_get(rhohalf, i, j, k, 0);
-    #pragma unroll
-    for (int m = 0; m < 3; m++) {
-      const double gph = fv_get(gphi, i, j, k, m);
-      double v = fv_get(unew, i, j, k, m) - gph / rho;                    // hgproject.f90:659-667
-      if (A.proj_type == VDN_PRESSURE_ITERS) v = fv_get(uold, i, j, k, m) + A.dt * v;
-      fv_at(unew, i, j, k, m) = v;
-      if (A.proj_type == VDN_PRESSURE_ITERS) fv_at(gp, i, j, k, m) = fv_get(gp, i, j, k, m) + gph;
-      else if (A.proj_type == VDN_REGULAR_TIMESTEP) fv_at(gp, i, j, k, m) = A.dtinv * gph;
+    for (int d = 0; d < 3; d++) {
+      if (q[d] == A.lo[d] - 1) { int p = A.phys[d][0]; if (p == VDN_SLIP_WALL || p == VDN_NO_SLIP_WALL) wall_plane = true; if (p == VDN_INLET) inlet_plane = true; }
+      if (q[d] == A.hi[d] + 1) { int p = A.phys[d][1]; if (p == VDN_SLIP_WALL || p == VDN_NO_SLIP_WALL) wall_plane = true; if (p == VDN_INLET) inlet_plane = true; }
     }
-  }
-  if (A.proj_type == VDN_PRESSURE_ITERS) fv_at(p, i, j, k) = fv_get(p, i, j, k) + fv_get(phi, i, j, k);
-  else if (A.proj_type == VDN_REGULAR_TIMESTEP) fv_at(p, i, j, k) = A.dtinv * fv_get(phi, i, j, k);
-}
+  #pragma unroll
+    for (int m = 0; m < 3; m++) {
+      double gpv = 0.0;
+      if (g1) { gpv = fv_get(gp, i, j, k, m); if (inlet_plane) { gpv = 0.0; fv_at(gp, i, j, k, m) = 0.0; } }
+      if (wall_plane) { fv_at(unew, i, j, k, m) = 0.0; continue; }
+      if (!g1) continue;
+      double v = fv_get(unew, i, j, k, m);
+      if (A.proj_type == VDN_PRESSURE_ITERS) v = (v - fv_get(uold, i, j, k, m)) * A.dtinv;
+      else if (A.proj_type == VDN_REGULAR_TIMESTEP) v = v + A.dt * gpv / fv_get(rhohalf, i, j, k, 0);
+      fv_at(unew, i, j, k, m) = v;
+    }
+  } };
+
+struct coeffs_K { FV coeffs; FV rhohalf;
+  __device__ void cell(int i, int j, int k) const {
+    fv_at(coeffs, i, j, k) = 1.0 / fv_get(rhohalf, i, j, k, 0);      // hg_multigrid.f90:76-77
+  } };
+
+struct mkgphi_K { FV gp; FV phi; double dxi0; double dxi1; double dxi2;
+  __device__ void cell(int i, int j, int k) const {
+  #define P(a, b, c) fv_get(phi, i + (a), j + (b), k + (c))
+    fv_at(gp, i, j, k, 0) = 0.25 * (P(1, 0, 0) + P(1, 1, 0) + P(1, 0, 1) + P(1, 1, 1) - P(0, 0, 0) - P(0, 1, 0) - P(0, 0, 1) - P(0, 1, 1)) * dxi0;
+    fv_at(gp, i, j, k, 1) = 0.25 * (P(0, 1, 0) + P(1, 1, 0) + P(0, 1, 1) + P(1, 1, 1) - P(0, 0, 0) - P(1, 0, 0) - P(0, 0, 1) - P(1, 0, 1)) * dxi1;
+    fv_at(gp, i, j, k, 2) = 0.25 * (P(0, 0, 1) + P(1, 0, 1) + P(0, 1, 1) + P(1, 1, 1) - P(0, 0, 0) - P(1, 0, 0) - P(0, 1, 0) - P(1, 1, 0)) * dxi2;
+  #undef P
+  } };
+
+struct HgUpdArgs { int hi[3]; double dt, dtinv; int proj_type; };
+struct hg_update_K { FV unew; FV uold; FV gp; FV gphi; FV rhohalf; FV p; FV phi; HgUpdArgs A;
+  __device__ void cell(int i, int j, int k) const {
+    const bool cell = i <= A.hi[0] && j <= A.hi[1] && k <= A.hi[2];
+    if (cell) {
+      const double rho = fv_get(rhohalf, i, j, k, 0);
+    #pragma unroll
+      for (int m = 0; m < 3; m++) {
+        const double gph = fv_get(gphi, i, j, k, m);
+        double v = fv_get(unew, i, j, k, m) - gph / rho;                    // hgproject.f90:659-667
+        if (A.proj_type == VDN_PRESSURE_ITERS) v = fv_get(uold, i, j, k, m) + A.dt * v;
+        fv_at(unew, i, j, k, m) = v;
+        if (A.proj_type == VDN_PRESSURE_ITERS) fv_at(gp, i, j, k, m) = fv_get(gp, i, j, k, m) + gph;
+        else if (A.proj_type == VDN_REGULAR_TIMESTEP) fv_at(gp, i, j, k, m) = A.dtinv * gph;
+      }
+    }
+    if (A.proj_type == VDN_PRESSURE_ITERS) fv_at(p, i, j, k) = fv_get(p, i, j, k) + fv_get(phi, i, j, k);
+    else if (A.proj_type == VDN_REGULAR_TIMESTEP) fv_at(p, i, j, k) = A.dtinv * fv_get(phi, i, j, k);
+  } };
+
 
 // per-level pieces of hgproject, shared by the single-level driver and the two-level one
 static void hg_level_pre(int proj_type, vdn_multifab *un, const vdn_multifab *uo, const vdn_multifab *rhh, vdn_multifab *gpp, vdn_multifab *coeffs,
                          double dt, const vdn_bc_tower *bct) {
   hipStream_t st = ctx().stream;
   REQUIRE(un->ng >= 1 && gpp->ng >= 1 && rhh->ng >= 1, "hgproject: ghost widths");
+  std::vector<std::pair<create_uvec_K, Range3>> vu; std::vector<std::pair<coeffs_K, Range3>> vc;
   for (int i = 0; i < un->nfabs(); i++) {
     UvecArgs A; Range3 r; BoxP bp = make_boxp(un, i, bct);
     for (int d = 0; d < 3; d++) { A.lo[d] = bp.lo[d]; A.hi[d] = bp.hi[d]; r.lo[d] = bp.lo[d] - un->ng; r.hi[d] = bp.hi[d] + un->ng;
       for (int s = 0; s < 2; s++) A.phys[d][s] = bp.phys[d][s]; }
     A.ng = un->ng; A.dt = dt; A.dtinv = 1.0 / dt; A.proj_type = proj_type;
-    hipLaunchKernelGGL(kk_create_uvec, grid_for(r), NBLK, 0, st, un->fabs[i], uo->fabs[i], rhh->fabs[i], gpp->fabs[i], A, r);
+    vu.push_back({ create_uvec_K{ un->fabs[i], uo->fabs[i], rhh->fabs[i], gpp->fabs[i], A }, r });
     Range3 rv; for (int d = 0; d < 3; d++) { rv.lo[d] = bp.lo[d]; rv.hi[d] = bp.hi[d]; }
-    hipLaunchKernelGGL(kk_coeffs, grid_for(rv), NBLK, 0, st, coeffs->fabs[i], rhh->fabs[i], rv);
+    vc.push_back({ coeffs_K{ coeffs->fabs[i], rhh->fabs[i] }, rv });
   }
+  launch_cells(vu, st); launch_cells(vc, st);
   mf_fill_boundary(un);                                               // hgproject.f90:232
   mf_fill_boundary(coeffs);                                           // hg_multigrid.f90:79
 }
@@ -910,13 +914,15 @@ static void hg_level_post(int proj_type, vdn_multifab *un, const vdn_multifab *u
                           vdn_multifab *gphi, const vdn_multifab *phi, const double *dx, double dt) {
   hipStream_t st = ctx().stream;
   if (proj_type == VDN_INITIAL_PROJECTION || proj_type == VDN_DIVU_ITERS) { mf_setval(gpp, 0.0, 0, gpp->nc, true); mf_setval(pp, 0.0, 0, 1, true); }   // 673-676
+  std::vector<std::pair<mkgphi_K, Range3>> vg; std::vector<std::pair<hg_update_K, Range3>> vh;
   for (int i = 0; i < un->nfabs(); i++) {
     Range3 rv, rn; HgUpdArgs H;
     for (int d = 0; d < 3; d++) { rv.lo[d] = rn.lo[d] = un->vbox[i].lo[d]; rv.hi[d] = un->vbox[i].hi[d]; rn.hi[d] = rv.hi[d] + 1; H.hi[d] = rv.hi[d]; }
     H.dt = dt; H.dtinv = 1.0 / dt; H.proj_type = proj_type;
-    hipLaunchKernelGGL(kk_mkgphi, grid_for(rv), NBLK, 0, st, gphi->fabs[i], phi->fabs[i], 1.0 / dx[0], 1.0 / dx[1], 1.0 / dx[2], rv);
-    hipLaunchKernelGGL(kk_hg_update, grid_for(rn), NBLK, 0, st, un->fabs[i], uo->fabs[i], gpp->fabs[i], gphi->fabs[i], rhh->fabs[i], pp->fabs[i], phi->fabs[i], H, rn);
+    vg.push_back({ mkgphi_K{ gphi->fabs[i], phi->fabs[i], 1.0 / dx[0], 1.0 / dx[1], 1.0 / dx[2] }, rv });
+    vh.push_back({ hg_update_K{ un->fabs[i], uo->fabs[i], gpp->fabs[i], gphi->fabs[i], rhh->fabs[i], pp->fabs[i], phi->fabs[i], H }, rn });
   }
+  launch_cells(vg, st); launch_cells(vh, st);
 }
 static void do_ml_hgproject(int proj_type, vdn_layout *mla, vdn_multifab **unew, vdn_multifab **uold, vdn_multifab **rhohalf,
                             vdn_multifab **p, vdn_multifab **gp, const double *dx, double dt, const vdn_bc_tower *bct, int press_comp0);

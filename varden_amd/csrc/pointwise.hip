@@ -11,9 +11,7 @@
 
 struct ForceArgs { int lo[3], hi[3]; double visc_coef, fac; int boussinesq, nscal; };
 
-__global__ void kk_mkvelforce(FV vf, FV ext, FV gp, FV s, FV lapu, int has_lapu, ForceArgs A, Range3 r) {
-  THREAD_IJK(r)
-  if (!in_range) return;
+DEVI void mkvelforce_cell(const FV &vf, const FV &ext, const FV &gp, const FV &s, const FV &lapu, int has_lapu, const ForceArgs &A, int i, int j, int k) {
   const int out = (i < A.lo[0]) + (i > A.hi[0]) + (j < A.lo[1]) + (j > A.hi[1]) + (k < A.lo[2]) + (k > A.hi[2]);
   if (out > 1) return;                              // the six face halos only, no edges/corners (mkforce.f90:186-234)
   const int ic = min(max(i, A.lo[0]), A.hi[0]), jc = min(max(j, A.lo[1]), A.hi[1]), kc = min(max(k, A.lo[2]), A.hi[2]);
@@ -27,24 +25,34 @@ __global__ void kk_mkvelforce(FV vf, FV ext, FV gp, FV s, FV lapu, int has_lapu,
     fv_at(vf, i, j, k, m) = e + (lapu_local - fv_get(gp, i, j, k, m)) / rho;
   }
 }
+__global__ void kk_mkvelforce(FV vf, FV ext, FV gp, FV s, FV lapu, int has_lapu, ForceArgs A, Range3 r) {
+  THREAD_IJK(r)
+  if (!in_range) return;
+  mkvelforce_cell(vf, ext, gp, s, lapu, has_lapu, A, i, j, k);
+}
+// several boxes: one launch for the level (vdn_dev.h, kk_batched)
+struct VelForceB { Range3 r; int g[3]; FV vf, ext, gp, s, lapu; int has_lapu; ForceArgs A;
+  static __device__ double body(const VelForceB &q, int i, int j, int k, int) { mkvelforce_cell(q.vf, q.ext, q.gp, q.s, q.lapu, q.has_lapu, q.A, i, j, k); return 0.0; } };
 
 void k_mkvelforce(vdn_multifab *vf, const vdn_multifab *ext, const vdn_multifab *s, const vdn_multifab *gp,
                   const vdn_multifab *lapu, double visc_fac) {
   if (ctx().prm.dm == 2) { k2_mkvelforce(vf, ext, s, gp, lapu, visc_fac); return; }
   REQUIRE(vf->ng >= 1 && ext->ng >= 1 && gp->ng >= 1 && s->ng >= 1, "mkvelforce: operands need a ghost cell");
   mf_setval(vf, 0.0, 0, vf->nc, true);              // mkforce.f90:52
+  std::vector<VelForceB> v;
   for (int i = 0; i < vf->nfabs(); i++) {
     ForceArgs A; Range3 r;
     for (int d = 0; d < 3; d++) { A.lo[d] = vf->vbox[i].lo[d]; A.hi[d] = vf->vbox[i].hi[d]; r.lo[d] = A.lo[d] - 1; r.hi[d] = A.hi[d] + 1; }
     A.visc_coef = ctx().prm.visc_coef; A.fac = visc_fac; A.boussinesq = ctx().prm.boussinesq; A.nscal = ctx().prm.nscal;
-    hipLaunchKernelGGL(kk_mkvelforce, grid_for(r), dim3(64, 4, 1), 0, ctx().stream, vf->fabs[i], ext->fabs[i], gp->fabs[i],
-                       s->fabs[i], lapu ? lapu->fabs[i] : vf->fabs[i], lapu ? 1 : 0, A, r);
+    if (vf->nfabs() == 1)
+      hipLaunchKernelGGL(kk_mkvelforce, grid_for(r), dim3(64, 4, 1), 0, ctx().stream, vf->fabs[i], ext->fabs[i], gp->fabs[i],
+                         s->fabs[i], lapu ? lapu->fabs[i] : vf->fabs[i], lapu ? 1 : 0, A, r);
+    else { VelForceB q; q.r = r; q.vf = vf->fabs[i]; q.ext = ext->fabs[i]; q.gp = gp->fabs[i]; q.s = s->fabs[i]; q.lapu = lapu ? lapu->fabs[i] : vf->fabs[i]; q.has_lapu = lapu ? 1 : 0; q.A = A; v.push_back(q); }
   }
+  launch_batched(v, 0, (double *)nullptr, 0, ctx().stream);
 }
 
-__global__ void kk_mkscalforce(FV sf, FV ext, FV laps, int has_laps, ForceArgs A, Range3 r) {
-  THREAD_IJK(r)
-  if (!in_range) return;
+DEVI void mkscalforce_cell(const FV &sf, const FV &ext, const FV &laps, int has_laps, const ForceArgs &A, int i, int j, int k) {
   const int out = (i < A.lo[0]) + (i > A.hi[0]) + (j < A.lo[1]) + (j > A.hi[1]) + (k < A.lo[2]) + (k > A.hi[2]);
   if (out > 1) return;
   const int ic = min(max(i, A.lo[0]), A.hi[0]), jc = min(max(j, A.lo[1]), A.hi[1]), kc = min(max(k, A.lo[2]), A.hi[2]);
@@ -54,26 +62,35 @@ __global__ void kk_mkscalforce(FV sf, FV ext, FV laps, int has_laps, ForceArgs A
     fv_at(sf, i, j, k, m) = fv_get(ext, i, j, k, m) + laps_local;
   }
 }
+__global__ void kk_mkscalforce(FV sf, FV ext, FV laps, int has_laps, ForceArgs A, Range3 r) {
+  THREAD_IJK(r)
+  if (!in_range) return;
+  mkscalforce_cell(sf, ext, laps, has_laps, A, i, j, k);
+}
+struct ScalForceB { Range3 r; int g[3]; FV sf, ext, laps; int has_laps; ForceArgs A;
+  static __device__ double body(const ScalForceB &q, int i, int j, int k, int) { mkscalforce_cell(q.sf, q.ext, q.laps, q.has_laps, q.A, i, j, k); return 0.0; } };
 
 void k_mkscalforce(vdn_multifab *sf, const vdn_multifab *ext, const vdn_multifab *laps, double diff_fac) {
   if (ctx().prm.dm == 2) { k2_mkscalforce(sf, ext, laps, diff_fac); return; }
   mf_setval(sf, 0.0, 0, sf->nc, true);              // mkforce.f90:267 / 346
+  std::vector<ScalForceB> vb;
   for (int i = 0; i < sf->nfabs(); i++) {
     ForceArgs A; Range3 r;
     for (int d = 0; d < 3; d++) { A.lo[d] = sf->vbox[i].lo[d]; A.hi[d] = sf->vbox[i].hi[d]; r.lo[d] = A.lo[d] - 1; r.hi[d] = A.hi[d] + 1; }
     A.visc_coef = ctx().prm.diff_coef; A.fac = diff_fac; A.boussinesq = 0; A.nscal = ctx().prm.nscal;
-    hipLaunchKernelGGL(kk_mkscalforce, grid_for(r), dim3(64, 4, 1), 0, ctx().stream, sf->fabs[i], ext->fabs[i],
-                       laps ? laps->fabs[i] : sf->fabs[i], laps ? 1 : 0, A, r);
+    if (sf->nfabs() == 1)
+      hipLaunchKernelGGL(kk_mkscalforce, grid_for(r), dim3(64, 4, 1), 0, ctx().stream, sf->fabs[i], ext->fabs[i],
+                         laps ? laps->fabs[i] : sf->fabs[i], laps ? 1 : 0, A, r);
+    else { ScalForceB q; q.r = r; q.sf = sf->fabs[i]; q.ext = ext->fabs[i]; q.laps = laps ? laps->fabs[i] : sf->fabs[i]; q.has_laps = laps ? 1 : 0; q.A = A; vb.push_back(q); }
   }
+  launch_batched(vb, 0, (double *)nullptr, 0, ctx().stream);
 }
 
 // ---- update -------------------------------------------------------------------------------------
 struct UpdArgs { double dx[3], dt; int ncomp; int cons[VDN_MAXCOMP]; };
 
-__global__ void kk_update(FV sold, FV snew, FV um, FV vm, FV wm, FV sx, FV sy, FV sz, FV fx, FV fy, FV fz, FV force,
-                          UpdArgs A, Range3 r) {
-  THREAD_IJK(r)
-  if (!in_range) return;
+DEVI void update_cell(const FV &sold, const FV &snew, const FV &um, const FV &vm, const FV &wm, const FV &sx, const FV &sy, const FV &sz,
+                      const FV &fx, const FV &fy, const FV &fz, const FV &force, const UpdArgs &A, int i, int j, int k) {
   const double ubar = 0.5 * (fv_get(um, i, j, k) + fv_get(um, i + 1, j, k));
   const double vbar = 0.5 * (fv_get(vm, i, j, k) + fv_get(vm, i, j + 1, k));
   const double wbar = 0.5 * (fv_get(wm, i, j, k) + fv_get(wm, i, j, k + 1));
@@ -93,19 +110,32 @@ __global__ void kk_update(FV sold, FV snew, FV um, FV vm, FV wm, FV sx, FV sy, F
     fv_at(snew, i, j, k, c) = v;
   }
 }
+__global__ void kk_update(FV sold, FV snew, FV um, FV vm, FV wm, FV sx, FV sy, FV sz, FV fx, FV fy, FV fz, FV force,
+                          UpdArgs A, Range3 r) {
+  THREAD_IJK(r)
+  if (!in_range) return;
+  update_cell(sold, snew, um, vm, wm, sx, sy, sz, fx, fy, fz, force, A, i, j, k);
+}
+struct UpdateB { Range3 r; int g[3]; FV sold, snew, um, vm, wm, sx, sy, sz, fx, fy, fz, force; UpdArgs A;
+  static __device__ double body(const UpdateB &q, int i, int j, int k, int) { update_cell(q.sold, q.snew, q.um, q.vm, q.wm, q.sx, q.sy, q.sz, q.fx, q.fy, q.fz, q.force, q.A, i, j, k); return 0.0; } };
 
 void k_update(const vdn_multifab *sold, vdn_multifab **umac, vdn_multifab **sedge, vdn_multifab **flux,
               const vdn_multifab *force, vdn_multifab *snew, const double *dx, double dt, bool is_vel, const int *is_cons) {
   if (ctx().prm.dm == 2) { k2_update(sold, umac, sedge, flux, force, snew, dx, dt, is_vel, is_cons); return; }
+  std::vector<UpdateB> vb;
   for (int i = 0; i < sold->nfabs(); i++) {
     UpdArgs A; Range3 r;
     for (int d = 0; d < 3; d++) { A.dx[d] = dx[d]; r.lo[d] = sold->vbox[i].lo[d]; r.hi[d] = sold->vbox[i].hi[d]; }
     A.dt = dt; A.ncomp = sold->nc;
     for (int c = 0; c < sold->nc; c++) A.cons[c] = (!is_vel && is_cons[c]) ? 1 : 0;
-    hipLaunchKernelGGL(kk_update, grid_for(r), dim3(64, 4, 1), 0, ctx().stream, sold->fabs[i], snew->fabs[i],
-                       umac[0]->fabs[i], umac[1]->fabs[i], umac[2]->fabs[i], sedge[0]->fabs[i], sedge[1]->fabs[i],
-                       sedge[2]->fabs[i], flux[0]->fabs[i], flux[1]->fabs[i], flux[2]->fabs[i], force->fabs[i], A, r);
+    if (sold->nfabs() == 1)
+      hipLaunchKernelGGL(kk_update, grid_for(r), dim3(64, 4, 1), 0, ctx().stream, sold->fabs[i], snew->fabs[i],
+                         umac[0]->fabs[i], umac[1]->fabs[i], umac[2]->fabs[i], sedge[0]->fabs[i], sedge[1]->fabs[i],
+                         sedge[2]->fabs[i], flux[0]->fabs[i], flux[1]->fabs[i], flux[2]->fabs[i], force->fabs[i], A, r);
+    else { UpdateB q; q.r = r; q.sold = sold->fabs[i]; q.snew = snew->fabs[i]; q.um = umac[0]->fabs[i]; q.vm = umac[1]->fabs[i]; q.wm = umac[2]->fabs[i];
+      q.sx = sedge[0]->fabs[i]; q.sy = sedge[1]->fabs[i]; q.sz = sedge[2]->fabs[i]; q.fx = flux[0]->fabs[i]; q.fy = flux[1]->fabs[i]; q.fz = flux[2]->fabs[i]; q.force = force->fabs[i]; q.A = A; vb.push_back(q); }
   }
+  launch_batched(vb, 0, (double *)nullptr, 0, ctx().stream);
 }
 
 // ---- rho at half time -----------------------------------------------------------------------------
@@ -114,11 +144,16 @@ __global__ void kk_halftime(FV rh, int oc, FV so, FV sn, int ic, Range3 r) {
   if (!in_range) return;
   fv_at(rh, i, j, k, oc) = 0.5 * (fv_get(so, i, j, k, ic) + fv_get(sn, i, j, k, ic));
 }
+struct HalftimeB { Range3 r; int g[3]; FV rh, so, sn; int oc, ic;
+  static __device__ double body(const HalftimeB &q, int i, int j, int k, int) { fv_at(q.rh, i, j, k, q.oc) = 0.5 * (fv_get(q.so, i, j, k, q.ic) + fv_get(q.sn, i, j, k, q.ic)); return 0.0; } };
 void k_make_at_halftime(vdn_multifab *rhohalf, const vdn_multifab *sold, const vdn_multifab *snew, int in_comp, int out_comp) {
+  std::vector<HalftimeB> vb;
   for (int i = 0; i < rhohalf->nfabs(); i++) {
     Range3 r; for (int d = 0; d < 3; d++) { r.lo[d] = rhohalf->vbox[i].lo[d]; r.hi[d] = rhohalf->vbox[i].hi[d]; }
-    hipLaunchKernelGGL(kk_halftime, grid_for(r), dim3(64, 4, 1), 0, ctx().stream, rhohalf->fabs[i], out_comp, sold->fabs[i], snew->fabs[i], in_comp, r);
+    if (rhohalf->nfabs() == 1) hipLaunchKernelGGL(kk_halftime, grid_for(r), dim3(64, 4, 1), 0, ctx().stream, rhohalf->fabs[i], out_comp, sold->fabs[i], snew->fabs[i], in_comp, r);
+    else { HalftimeB q; q.r = r; q.rh = rhohalf->fabs[i]; q.so = sold->fabs[i]; q.sn = snew->fabs[i]; q.oc = out_comp; q.ic = in_comp; vb.push_back(q); }
   }
+  launch_batched(vb, 0, (double *)nullptr, 0, ctx().stream);
 }
 
 // ---- estdt maxima: wave-level reduction (64 lanes, shuffles) + one atomic per wave ----------------

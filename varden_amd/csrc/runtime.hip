@@ -475,10 +475,7 @@ struct PhysArgs {
   int bc; double ev;   // bc code, EXT_DIR value
   int comp;
 };
-__global__ void k_physbc(FV f, PhysArgs A) {
-  int b1 = A.r1lo + (int)(blockIdx.x * blockDim.x + threadIdx.x);
-  int b2 = A.r2lo + (int)(blockIdx.y * blockDim.y + threadIdx.y);
-  if (b1 > A.r1hi || b2 > A.r2hi) return;
+DEVI void physbc_cell(const FV &f, const PhysArgs &A, int b1, int b2) {
   int q[3]; q[A.t1] = b1; q[A.t2] = b2;
   const int edge = A.s == 0 ? A.lo[A.d] : A.hi[A.d];
   const int in = A.s == 0 ? 1 : -1;
@@ -500,6 +497,15 @@ __global__ void k_physbc(FV f, PhysArgs A) {
     fv_at(f, q[0], q[1], q[2], A.comp) = v;
   }
 }
+__global__ void k_physbc(FV f, PhysArgs A) {
+  int b1 = A.r1lo + (int)(blockIdx.x * blockDim.x + threadIdx.x);
+  int b2 = A.r2lo + (int)(blockIdx.y * blockDim.y + threadIdx.y);
+  if (b1 > A.r1hi || b2 > A.r2hi) return;
+  physbc_cell(f, A, b1, b2);
+}
+// all faces of one direction on every box and component of a level in one launch: the batch runs over (t1, t2, 0)
+struct PhysB { Range3 r; int g[3]; FV f; PhysArgs A;
+  static __device__ double body(const PhysB &q, int i, int j, int, int) { physbc_cell(q.f, q.A, i, j); return 0.0; } };
 
 static bool extdir_value(int icomp1, int d, int s, double *v) {
   const vdn_params &p = g_ctx.prm;
@@ -520,14 +526,20 @@ static bool extdir_value(int icomp1, int d, int s, double *v) {
 void mf_physbc(vdn_multifab *mf, int scomp, int bccomp, int nc, const vdn_bc_tower *bct, bool same_boundary) {
   if (mf->ng == 0) return;
   REQUIRE(!mf->nodal[0] && !mf->nodal[1] && !mf->nodal[2], "physbc on a nodal multifab");
-  for (int i = 0; i < mf->nfabs(); i++) for (int c = 0; c < nc; c++) {
+  // a direction reads the ghost cells the directions before it wrote, boxes and components are independent:
+  // levels of several boxes run one batched launch per direction
+  const bool batch = mf->nfabs() > 1;
+  std::vector<PhysB> pb;
+  for (int d = 0; d < 3; d++) {
+   pb.clear();
+   for (int i = 0; i < mf->nfabs(); i++) for (int c = 0; c < nc; c++) {
     const int bcc = same_boundary ? bccomp : bccomp + c;
     REQUIRE(bcc < bct->ncomp_adv, "physbc: bc component %d out of range", bcc);
     int bc[3][2];
-    for (int d = 0; d < 3; d++) for (int s = 0; s < 2; s++) bc[d][s] = bct->adv_bc(mf->lev, i + 1, d, s, bcc);
+    for (int dd = 0; dd < 3; dd++) for (int s = 0; s < 2; s++) bc[dd][s] = bct->adv_bc(mf->lev, i + 1, dd, s, bcc);
     const int *lo = mf->vbox[i].lo, *hi = mf->vbox[i].hi;
     const int ng = mf->ng;
-    for (int d = 0; d < 3; d++) for (int s = 0; s < 2; s++) {
+    for (int s = 0; s < 2; s++) {
       int b = bc[d][s];
       if (b == VDN_INTERIOR) continue;
       PhysArgs A;
@@ -546,9 +558,12 @@ void mf_physbc(vdn_multifab *mf, int scomp, int bccomp, int nc, const vdn_bc_tow
         rlo[t] = lo[t] - nlo; rhi[t] = hi[t] + nhi;
       }
       A.r1lo = rlo[A.t1]; A.r1hi = rhi[A.t1]; A.r2lo = rlo[A.t2]; A.r2hi = rhi[A.t2];
+      if (batch) { PhysB q; q.r.lo[0] = A.r1lo; q.r.hi[0] = A.r1hi; q.r.lo[1] = A.r2lo; q.r.hi[1] = A.r2hi; q.r.lo[2] = q.r.hi[2] = 0; q.f = mf->fabs[i]; q.A = A; pb.push_back(q); continue; }
       dim3 blk(64, 4, 1), grd((A.r1hi - A.r1lo + 64) / 64, (A.r2hi - A.r2lo + 4) / 4, 1);
       hipLaunchKernelGGL(k_physbc, grd, blk, 0, g_ctx.stream, mf->fabs[i], A);
     }
+   }
+   if (batch) launch_batched(pb, 0, (double *)nullptr, 0, g_ctx.stream);
   }
 }
 extern "C" int vdn_multifab_physbc(vdn_multifab *mf, int scomp, int bccomp, int nc, const vdn_bc_tower *bct) {

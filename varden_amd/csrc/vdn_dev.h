@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <vector>
+#include <utility>
 #include "vdn_internal.h"
 
 #define DEVI __device__ __forceinline__
@@ -113,6 +114,22 @@ static inline void launch_batched(std::vector<A> &v, P extra, double *nrm, int k
   upload_staged(d_args, v.data(), sizeof(A) * v.size());
   upload_staged(d_start, start.data(), sizeof(int) * v.size());
   hipLaunchKernelGGL((kk_batched<A, P>), dim3(tot), dim3(64, 4, 1), 0, st, (const A *)d_args, (const int *)d_start, (int)v.size(), extra, nrm);
+}
+// ---- cell kernels: one body, launched for one box or batched over the boxes of a level --------------------------------------------
+// struct K { <arguments>; __device__ void cell(int i, int j, int k) const { ... } };   then   launch_cells(vector of (K, range))
+template <class K> __global__ void __launch_bounds__(256) kk_cell(K a, Range3 r) {
+  THREAD_IJK(r)
+  if (!in_range) return;
+  a.cell(i, j, k);
+}
+template <class K> struct CellB { Range3 r; int g[3]; K a;
+  static __device__ double body(const CellB &q, int i, int j, int k, int) { q.a.cell(i, j, k); return 0.0; } };
+template <class K> static inline void launch_cells(const std::vector<std::pair<K, Range3>> &v, hipStream_t st) {
+  if (v.empty()) return;
+  if (v.size() == 1) { hipLaunchKernelGGL((kk_cell<K>), grid_for(v[0].second), dim3(64, 4, 1), 0, st, v[0].first, v[0].second); return; }
+  std::vector<CellB<K>> b(v.size());
+  for (size_t i = 0; i < v.size(); i++) { b[i].r = v[i].second; b[i].a = v[i].first; }
+  launch_batched(b, 0, (double *)nullptr, 0, st);
 }
 // a descriptor set that is uploaded once and launched many times (the per-iteration kernels of the composite solves)
 template <class A> struct BatchSet {
