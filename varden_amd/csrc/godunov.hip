@@ -85,9 +85,7 @@ template <int D> DEVI double slope_at(const FV &s, int c, int i, int j, int k, i
   return f0.flag * fmin(fabs(ds), f0.lim);
 }
 
-__global__ void __launch_bounds__(256) kk_slopes(FV s, FV sl0, FV sl1, FV sl2, GArgs A, Range3 r, int dirmask) {
-  THREAD_IJK(r)
-  if (!in_range) return;
+DEVI void slopes_cell(const FV &s, const FV &sl0, const FV &sl1, const FV &sl2, const GArgs &A, int dirmask, int i, int j, int k) {
   for (int c = 0; c < A.ncomp; c++) {
     #define SPEC(d, sd) (A.adv[d][sd][c] == VDN_EXT_DIR || A.adv[d][sd][c] == VDN_HOEXTRAP)
     if (dirmask & 1) fv_at(sl0, i, j, k, c) = slope_at<0>(s, c, i, j, k, A.lo[0], A.hi[0], SPEC(0, 0), SPEC(0, 1), A.slope_order);
@@ -95,6 +93,11 @@ __global__ void __launch_bounds__(256) kk_slopes(FV s, FV sl0, FV sl1, FV sl2, G
     if (dirmask & 4) fv_at(sl2, i, j, k, c) = slope_at<2>(s, c, i, j, k, A.lo[2], A.hi[2], SPEC(2, 0), SPEC(2, 1), A.slope_order);
     #undef SPEC
   }
+}
+__global__ void __launch_bounds__(256) kk_slopes(FV s, FV sl0, FV sl1, FV sl2, GArgs A, Range3 r, int dirmask) {
+  THREAD_IJK(r)
+  if (!in_range) return;
+  slopes_cell(s, sl0, sl1, sl2, A, dirmask, i, j, k);
 }
 
 // ---- boundary rule for a (left,right) pair on a domain face (velpred.f90:2044-2079, 2200-2224;
@@ -282,7 +285,13 @@ __global__ void __launch_bounds__(256) kk_mk_D(FV s, FV sl0, FV sl1, FV sl2, FV 
 // the face owner then applies the complete rule to the pair it has assembled.
 // Code shape: every plane starts with ONE unconditional batch of loads (indices clamped into the arrays; threads outside
 // the computable region produce values nobody uses), the rare boundary work sits in one branch after it.
+// VDN_GODUNOV_BATCH=1 launches the descriptor (box-batched) kernels also for a level of one box. Measured at 256^3: they need
+// fewer VGPRs (mk_D<1> 116 vs 174) yet run slower there (scalar 6.6 vs 5.6 ms, velocity 10.0 vs 8.2 ms), so one box keeps the by-value kernels
+static bool batch_always() { static const bool b = getenv("VDN_GODUNOV_BATCH") && atoi(getenv("VDN_GODUNOV_BATCH")) != 0; return b; }
 static bool plain_godunov() { static const bool p = getenv("VDN_GODUNOV_PLAIN") != nullptr; return p; }
+// parameters of the marching bodies: by value under the by-value kernels, references into the (constant) descriptor under the batched ones
+template <class T, bool R> struct Prm { typedef T type; };
+template <class T> struct Prm<T, true> { typedef const T &type; };
 constexpr int TNY = 8;              // rows per tile: workgroup = 64 x TNY threads
 static int march_chunks() { static const int n = getenv("VDN_KCHUNKS") ? atoi(getenv("VDN_KCHUNKS")) : 12; return n < 1 ? 1 : n; }
 static dim3 march_grid(const Range3 &r, int &klen) {
@@ -293,14 +302,14 @@ static dim3 march_grid(const Range3 &r, int &klen) {
 // i, j: the thread's cell;  ic, jc: the same clamped into the grown box (load indices);  own_ij: this thread emits
 #define MARCH_SETUP(r)                                                                   \
   const int lane = threadIdx.x, row = threadIdx.y;                                       \
-  const int i = (r).lo[0] - 1 + (int)blockIdx.x * 63 + lane;                             \
-  const int j = (r).lo[1] - 1 + (int)blockIdx.y * (TNY - 1) + row;                       \
+  const int i = (r).lo[0] - 1 + BX * 63 + lane;                                                                 \
+  const int j = (r).lo[1] - 1 + BY * (TNY - 1) + row;                                     \
   const bool own_ij = lane >= 1 && row >= 1 && i <= (r).hi[0] && j <= (r).hi[1];         \
   const int ic = min(max(i, A.lo[0] - 1), A.hi[0] + 1), jc = min(max(j, A.lo[1] - 1), A.hi[1] + 1); \
   const int ip = min(ic + 1, A.hi[0] + 1), jp = min(jc + 1, A.hi[1] + 1);                \
   const bool edge_ij = ic == A.lo[0] || ic >= A.hi[0] || jc == A.lo[1] || jc >= A.hi[1]; \
   const bool vx = in_valid(A, 0, i), vy = in_valid(A, 1, j);                             \
-  const int k0 = (r).lo[2] + (int)blockIdx.z * klen, k1 = min(k0 + klen - 1, (r).hi[2]);
+  const int k0 = (r).lo[2] + BZ * klen, k1 = min(k0 + klen - 1, (r).hi[2]);
 #define MARCH_PLANE                                                                      \
     const int kc = min(max(k, A.lo[2] - 1), A.hi[2] + 1), kp = min(kc + 1, A.hi[2] + 1); \
     const bool emit = own_ij && k >= k0;                                                 \
@@ -350,8 +359,7 @@ template <int D> DEVI void mk_face_bc(const GArgs &A, const FV &s, int c, int i,
     }
 
 // ---- stage B ----------------------------------------------------------------------------------------------------
-template <int NC> __global__ void __launch_bounds__(64 * TNY) kk_mk_B_m(FV s, FV sl0, FV sl1, FV sl2, FV um, FV vm, FV wm, FV force, FV macrhs, FV SI,
-                                                                         GArgs A, Range3 r, int klen, const double *umax, int c0, int ns) {
+template <int NC, bool R> __device__ __forceinline__ void mk_B_m_body(typename Prm<FV, R>::type s, typename Prm<FV, R>::type sl0, typename Prm<FV, R>::type sl1, typename Prm<FV, R>::type sl2, typename Prm<FV, R>::type um, typename Prm<FV, R>::type vm, typename Prm<FV, R>::type wm, typename Prm<FV, R>::type force, typename Prm<FV, R>::type macrhs, typename Prm<FV, R>::type SI, typename Prm<GArgs, R>::type A, typename Prm<Range3, R>::type r, int klen, const double *umax, int c0, int ns, const int BX, const int BY, const int BZ) {
   __shared__ double ly[2][NC][TNY][64];
   MARCH_SETUP(r)
   const double eps = eps_from(umax);
@@ -404,11 +412,14 @@ template <int NC> __global__ void __launch_bounds__(64 * TNY) kk_mk_B_m(FV s, FV
     }
   }
 }
+template <int NC> __global__ void __launch_bounds__(64 * TNY) kk_mk_B_m(FV s, FV sl0, FV sl1, FV sl2, FV um, FV vm, FV wm, FV force, FV macrhs, FV SI, GArgs A, Range3 r, int klen, const double *umax, int c0, int ns) {
+  mk_B_m_body<NC, false>(s, sl0, sl1, sl2, um, vm, wm, force, macrhs, SI, A, r, klen, umax, c0, ns, (int)blockIdx.x, (int)blockIdx.y, (int)blockIdx.z);
+}
+
 
 // ---- stage C ----------------------------------------------------------------------------------------------------
 // per cell and component: the three transverse terms t_T (from SI_T, mac_T) and the six chains base_D - t_T
-template <int NC> __global__ void __launch_bounds__(64 * TNY) kk_mk_C_m(FV s, FV sl0, FV sl1, FV sl2, FV um, FV vm, FV wm, FV force, FV macrhs, FV SI, FV SC,
-                                                                         GArgs A, Range3 r, int klen, const double *umax, int c0, int ns) {
+template <int NC, bool R> __device__ __forceinline__ void mk_C_m_body(typename Prm<FV, R>::type s, typename Prm<FV, R>::type sl0, typename Prm<FV, R>::type sl1, typename Prm<FV, R>::type sl2, typename Prm<FV, R>::type um, typename Prm<FV, R>::type vm, typename Prm<FV, R>::type wm, typename Prm<FV, R>::type force, typename Prm<FV, R>::type macrhs, typename Prm<FV, R>::type SI, typename Prm<FV, R>::type SC, typename Prm<GArgs, R>::type A, typename Prm<Range3, R>::type r, int klen, const double *umax, int c0, int ns, const int BX, const int BY, const int BZ) {
   __shared__ double ly[2][NC][2][TNY][64];
   MARCH_SETUP(r)
   const double eps = eps_from(umax);
@@ -499,6 +510,10 @@ template <int NC> __global__ void __launch_bounds__(64 * TNY) kk_mk_C_m(FV s, FV
     }
   }
 }
+template <int NC> __global__ void __launch_bounds__(64 * TNY) kk_mk_C_m(FV s, FV sl0, FV sl1, FV sl2, FV um, FV vm, FV wm, FV force, FV macrhs, FV SI, FV SC, GArgs A, Range3 r, int klen, const double *umax, int c0, int ns) {
+  mk_C_m_body<NC, false>(s, sl0, sl1, sl2, um, vm, wm, force, macrhs, SI, SC, A, r, klen, umax, c0, ns, (int)blockIdx.x, (int)blockIdx.y, (int)blockIdx.z);
+}
+
 
 // ---- stage D ----------------------------------------------------------------------------------------------------
 template <int D> DEVI double mk_edge_bc(const GArgs &A, const FV &s, int c, int i, int j, int k, double s0, double L, double R, double e) {
@@ -514,8 +529,7 @@ template <int D> DEVI double mk_edge_bc(const GArgs &A, const FV &s, int c, int 
   }
   return e;
 }
-template <int NC> __global__ void __launch_bounds__(64 * TNY) kk_mk_D_m(FV s, FV sl0, FV sl1, FV sl2, FV um, FV vm, FV wm, FV force, FV macrhs, FV SC,
-                                                                         FV sex, FV sey, FV sez, FV flx, FV fly, FV flz, GArgs A, Range3 r, int klen, const double *umax, int c0, int ns) {
+template <int NC, bool R> __device__ __forceinline__ void mk_D_m_body(typename Prm<FV, R>::type s, typename Prm<FV, R>::type sl0, typename Prm<FV, R>::type sl1, typename Prm<FV, R>::type sl2, typename Prm<FV, R>::type um, typename Prm<FV, R>::type vm, typename Prm<FV, R>::type wm, typename Prm<FV, R>::type force, typename Prm<FV, R>::type macrhs, typename Prm<FV, R>::type SC, typename Prm<FV, R>::type sex, typename Prm<FV, R>::type sey, typename Prm<FV, R>::type sez, typename Prm<FV, R>::type flx, typename Prm<FV, R>::type fly, typename Prm<FV, R>::type flz, typename Prm<GArgs, R>::type A, typename Prm<Range3, R>::type r, int klen, const double *umax, int c0, int ns, const int BX, const int BY, const int BZ) {
   __shared__ double ly[2][NC][TNY][64];
   MARCH_SETUP(r)
   const double eps = eps_from(umax);
@@ -602,6 +616,10 @@ template <int NC> __global__ void __launch_bounds__(64 * TNY) kk_mk_D_m(FV s, FV
     }
   }
 }
+template <int NC> __global__ void __launch_bounds__(64 * TNY) kk_mk_D_m(FV s, FV sl0, FV sl1, FV sl2, FV um, FV vm, FV wm, FV force, FV macrhs, FV SC, FV sex, FV sey, FV sez, FV flx, FV fly, FV flz, GArgs A, Range3 r, int klen, const double *umax, int c0, int ns) {
+  mk_D_m_body<NC, false>(s, sl0, sl1, sl2, um, vm, wm, force, macrhs, SC, sex, sey, sez, flx, fly, flz, A, r, klen, umax, c0, ns, (int)blockIdx.x, (int)blockIdx.y, (int)blockIdx.z);
+}
+
 
 // max |umac| over the valid faces of the three MAC components (mkflux.f90:1374-1396)
 __global__ void kk_macmax(FV um, FV vm, FV wm, GArgs A, Range3 r, double *out) {
@@ -620,6 +638,85 @@ __global__ void kk_velmax(FV u, Range3 r, double *out) {             // velpred.
   if (in_ij) REDUCE_KLOOP(r) m = fmax(m, fmax(fmax(fabs(fv_get(u, i, j, k, 0)), fabs(fv_get(u, i, j, k, 1))), fabs(fv_get(u, i, j, k, 2))));
   block_atomic_max(out, m);
 }
+
+
+// ====================================================================================================
+// one launch per stage for ALL boxes of a level: a descriptor per box, workgroups bisect a prefix sum for theirs.
+// The descriptors are read through the constant address space (scalar loads, never invalidated by the kernel's stores),
+// exactly like kernel arguments.
+// ====================================================================================================
+struct MkD { FV s, sl0, sl1, sl2, um, vm, wm, force, macrhs, SI, SC, sex, sey, sez, flx, fly, flz; GArgs A; Range3 rm, rg, rf; int klg, klf, gs[3], gm[3], gg[3], gf[3]; double *umax; };
+struct VpD { FV s, sl0, sl1, sl2, force, UI, XC, um, vm, wm;                                     GArgs A; Range3 rm, rg, rf; int klg, klf, gs[3], gm[3], gg[3], gf[3]; double *umax; };
+template <class T> DEVI const T &as_constant(const T *p) {
+  typedef const T __attribute__((address_space(4))) *CP;
+  return *(const T *)(CP)p;
+}
+DEVI int locate_box(const int *start, int nbox, int bid) {
+  int lo = 0, hi = nbox - 1;
+  while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (as_constant(start + mid) <= bid) lo = mid; else hi = mid - 1; }
+  return lo;
+}
+#define BATCH_LOCATE(D, G)                                                              \
+  const int ib_ = locate_box(start, nbox, (int)blockIdx.x);                             \
+  const D &q = as_constant(descs + ib_);                                                \
+  const int l_ = (int)blockIdx.x - as_constant(start + ib_);                            \
+  const int BX = l_ % q.G[0], BY = (l_ / q.G[0]) % q.G[1], BZ = l_ / (q.G[0] * q.G[1]);
+template <class D> __global__ void __launch_bounds__(256) kk_slopes_b(const D *descs, const int *start, int nbox, int dirmask) {
+  BATCH_LOCATE(D, gs)
+  const int i = q.rg.lo[0] + BX * 64 + (int)threadIdx.x, j = q.rg.lo[1] + BY * 4 + (int)threadIdx.y, k = q.rg.lo[2] + BZ;
+  if (i > q.rg.hi[0] || j > q.rg.hi[1] || k > q.rg.hi[2]) return;
+  slopes_cell(q.s, q.sl0, q.sl1, q.sl2, q.A, dirmask, i, j, k);
+}
+// per-box maxima (eps of the upwind tests is per box, as in the reference's per-fab calls)
+__global__ void kk_macmax_b(const MkD *descs, const int *start, int nbox) {
+  BATCH_LOCATE(MkD, gm)
+  const int i = q.rf.lo[0] + BX * 64 + (int)threadIdx.x, j = q.rf.lo[1] + BY * 4 + (int)threadIdx.y;
+  double m = 0.0;
+  if (i <= q.rf.hi[0] && j <= q.rf.hi[1]) for (int k = q.rf.lo[2] + BZ; k <= q.rf.hi[2]; k += q.gm[2]) {
+    if (j <= q.A.hi[1] && k <= q.A.hi[2]) m = fmax(m, fabs(fv_get(q.um, i, j, k)));
+    if (i <= q.A.hi[0] && k <= q.A.hi[2]) m = fmax(m, fabs(fv_get(q.vm, i, j, k)));
+    if (i <= q.A.hi[0] && j <= q.A.hi[1]) m = fmax(m, fabs(fv_get(q.wm, i, j, k)));
+  }
+  block_atomic_max(q.umax, m);
+}
+__global__ void kk_velmax_b(const VpD *descs, const int *start, int nbox) {
+  BATCH_LOCATE(VpD, gm)
+  const int i = q.rm.lo[0] + BX * 64 + (int)threadIdx.x, j = q.rm.lo[1] + BY * 4 + (int)threadIdx.y;
+  double m = 0.0;
+  if (i <= q.rm.hi[0] && j <= q.rm.hi[1]) for (int k = q.rm.lo[2] + BZ; k <= q.rm.hi[2]; k += q.gm[2])
+    m = fmax(m, fmax(fmax(fabs(fv_get(q.s, i, j, k, 0)), fabs(fv_get(q.s, i, j, k, 1))), fabs(fv_get(q.s, i, j, k, 2))));
+  block_atomic_max(q.umax, m);
+}
+template <int NC> __global__ void __launch_bounds__(64 * TNY) kk_mk_B_mb(const MkD *descs, const int *start, int nbox, int c0, int ns) {
+  BATCH_LOCATE(MkD, gg)
+  mk_B_m_body<NC, true>(q.s, q.sl0, q.sl1, q.sl2, q.um, q.vm, q.wm, q.force, q.macrhs, q.SI, q.A, q.rg, q.klg, q.umax, c0, ns, BX, BY, BZ);
+}
+template <int NC> __global__ void __launch_bounds__(64 * TNY) kk_mk_C_mb(const MkD *descs, const int *start, int nbox, int c0, int ns) {
+  BATCH_LOCATE(MkD, gg)
+  mk_C_m_body<NC, true>(q.s, q.sl0, q.sl1, q.sl2, q.um, q.vm, q.wm, q.force, q.macrhs, q.SI, q.SC, q.A, q.rg, q.klg, q.umax, c0, ns, BX, BY, BZ);
+}
+template <int NC> __global__ void __launch_bounds__(64 * TNY) kk_mk_D_mb(const MkD *descs, const int *start, int nbox, int c0, int ns) {
+  BATCH_LOCATE(MkD, gf)
+  mk_D_m_body<NC, true>(q.s, q.sl0, q.sl1, q.sl2, q.um, q.vm, q.wm, q.force, q.macrhs, q.SC, q.sex, q.sey, q.sez, q.flx, q.fly, q.flz, q.A, q.rf, q.klf, q.umax, c0, ns, BX, BY, BZ);
+}
+// host side of a batch: grids of the four launch shapes per box, their prefix sums, and the upload
+template <class D> struct GodBatch {
+  std::vector<D> d; const D *dev = nullptr; const int *st[4] = { nullptr, nullptr, nullptr, nullptr }; int tot[4] = { 0, 0, 0, 0 };
+  void finish() {
+    const int nb = (int)d.size();
+    std::vector<int> start(4 * nb);
+    for (int b = 0; b < nb; b++) {
+      D &q = d[b];
+      const dim3 gs = grid_for(q.rg), gm = reduce_grid(q.rm);
+      const dim3 gg = march_grid(q.rg, q.klg), gf = march_grid(q.rf, q.klf);
+      const dim3 *g[4] = { &gs, &gm, &gg, &gf }; int *o[4] = { q.gs, q.gm, q.gg, q.gf };
+      for (int t = 0; t < 4; t++) { o[t][0] = g[t]->x; o[t][1] = g[t]->y; o[t][2] = g[t]->z; start[t * nb + b] = tot[t]; tot[t] += (int)(g[t]->x * g[t]->y * g[t]->z); }
+    }
+    D *dd = (D *)desc_scratch(sizeof(D) * nb); int *ds = (int *)desc_scratch(sizeof(int) * 4 * nb);
+    upload_staged(dd, d.data(), sizeof(D) * nb); upload_staged(ds, start.data(), sizeof(int) * 4 * nb);
+    dev = dd; for (int t = 0; t < 4; t++) st[t] = ds + t * nb;
+  }
+};
 
 static void fill_gargs(GArgs &A, const vdn_multifab *s, int ibox, const vdn_bc_tower *bct, int bccomp, int ncomp, const double *dx, double dt) {
   memset(&A, 0, sizeof A);
@@ -662,6 +759,47 @@ void k_mkflux(const vdn_multifab *s, vdn_multifab **sedge, vdn_multifab **flux, 
   REQUIRE(s->ng >= 3 && umac[0]->ng >= 1 && force->ng >= 1 && mac_rhs->ng >= 1, "mkflux: ghost widths");
   const int bccomp = is_vel ? 0 : bct->dm;            // mkflux.f90:62-66
   hipStream_t st = ctx().stream;
+  if ((s->nfabs() > 1 || batch_always()) && s->nfabs() > 0 && !plain_godunov()) {            // every stage once for all boxes of the level
+    size_t mark = arena_mark();
+    const int nb = s->nfabs();
+    GodBatch<MkD> B; B.d.resize(nb);
+    double *umax = (double *)arena_alloc(sizeof(double) * nb);
+    HIPCHK(hipMemsetAsync(umax, 0, sizeof(double) * nb, st));
+    for (int ib = 0; ib < nb; ib++) {
+      MkD &q = B.d[ib];
+      fill_gargs(q.A, s, ib, bct, bccomp, ncomp, dx, dt);
+      q.A.is_vel = is_vel ? 1 : 0;
+      for (int c = 0; c < ncomp; c++) q.A.cons[c] = is_cons[c] ? 1 : 0;
+      BoxP bp = make_boxp(s, ib, bct);
+      FV w = work_fv(nullptr, bp, 0);
+      const size_t fld = (size_t)w.sc * sizeof(double);
+      q.sl0 = q.sl1 = q.sl2 = q.SI = q.SC = w;
+      q.sl0.p = (double *)arena_alloc(fld * ncomp); q.sl1.p = (double *)arena_alloc(fld * ncomp); q.sl2.p = (double *)arena_alloc(fld * ncomp);
+      q.SI.p = (double *)arena_alloc(fld * 3 * ncomp); q.SC.p = (double *)arena_alloc(fld * 6 * ncomp);
+      for (int d = 0; d < 3; d++) { q.rg.lo[d] = q.A.lo[d] - 1; q.rg.hi[d] = q.A.hi[d] + 1; q.rf.lo[d] = q.A.lo[d]; q.rf.hi[d] = q.A.hi[d] + 1; }
+      q.rm = q.rf;
+      q.s = s->fabs[ib]; q.um = umac[0]->fabs[ib]; q.vm = umac[1]->fabs[ib]; q.wm = umac[2]->fabs[ib]; q.force = force->fabs[ib]; q.macrhs = mac_rhs->fabs[ib];
+      q.sex = sedge[0]->fabs[ib]; q.sey = sedge[1]->fabs[ib]; q.sez = sedge[2]->fabs[ib]; q.flx = flux[0]->fabs[ib]; q.fly = flux[1]->fabs[ib]; q.flz = flux[2]->fabs[ib];
+      q.umax = umax + ib;
+    }
+    B.finish();
+    const dim3 blk(64, TNY, 1);
+    hipLaunchKernelGGL(kk_macmax_b, dim3(B.tot[1]), dim3(64, 4, 1), 0, st, B.dev, B.st[1], nb);
+    hipLaunchKernelGGL(kk_slopes_b<MkD>, dim3(B.tot[0]), dim3(64, 4, 1), 0, st, B.dev, B.st[0], nb, 7);
+    static const int split_env = getenv("VDN_MK_SPLIT") ? atoi(getenv("VDN_MK_SPLIT")) : -1;
+    const int split = split_env >= 0 ? split_env : (ncomp == 3 ? 4 : 0);
+    #define MKB_STAGE(K, t, bit)                                                                                               \
+      if ((split >> bit) & 1) { for (int c0 = 0; c0 < ncomp; c0++) hipLaunchKernelGGL(K<1>, dim3(B.tot[t]), blk, 0, st, B.dev, B.st[t], nb, c0, ncomp); } \
+      else if (ncomp == 3) hipLaunchKernelGGL(K<3>, dim3(B.tot[t]), blk, 0, st, B.dev, B.st[t], nb, 0, ncomp);                  \
+      else if (ncomp == 2) hipLaunchKernelGGL(K<2>, dim3(B.tot[t]), blk, 0, st, B.dev, B.st[t], nb, 0, ncomp);                  \
+      else hipLaunchKernelGGL(K<1>, dim3(B.tot[t]), blk, 0, st, B.dev, B.st[t], nb, 0, ncomp);
+    MKB_STAGE(kk_mk_B_mb, 2, 0)
+    MKB_STAGE(kk_mk_C_mb, 2, 1)
+    MKB_STAGE(kk_mk_D_mb, 3, 2)
+    #undef MKB_STAGE
+    arena_release(mark);
+    return;
+  }
   for (int ib = 0; ib < s->nfabs(); ib++) {
     size_t mark = arena_mark();
     GArgs A; fill_gargs(A, s, ib, bct, bccomp, ncomp, dx, dt);
@@ -899,7 +1037,7 @@ template <int D> DEVI void vp_B_emit(const FV &UI, int i, int j, int k, const do
       uc[c] = fv_get(u, ic, jc, kc, c); s0[c] = fv_get(sl0, ic, jc, kc, c); s1[c] = fv_get(sl1, ic, jc, kc, c); s2[c] = fv_get(sl2, ic, jc, kc, c); \
     }
 
-__global__ void __launch_bounds__(64 * TNY) kk_vp_B_m(FV u, FV sl0, FV sl1, FV sl2, FV force, FV UI, GArgs A, Range3 r, int klen, const double *umax) {
+template <bool R> __device__ __forceinline__ void vp_B_m_body(typename Prm<FV, R>::type u, typename Prm<FV, R>::type sl0, typename Prm<FV, R>::type sl1, typename Prm<FV, R>::type sl2, typename Prm<FV, R>::type force, typename Prm<FV, R>::type UI, typename Prm<GArgs, R>::type A, typename Prm<Range3, R>::type r, int klen, const double *umax, const int BX, const int BY, const int BZ) {
   __shared__ double ly[2][3][TNY][64];
   MARCH_SETUP(r)
   const double eps = eps_from(umax);
@@ -941,6 +1079,10 @@ __global__ void __launch_bounds__(64 * TNY) kk_vp_B_m(FV u, FV sl0, FV sl1, FV s
     }
   }
 }
+__global__ void __launch_bounds__(64 * TNY) kk_vp_B_m(FV u, FV sl0, FV sl1, FV sl2, FV force, FV UI, GArgs A, Range3 r, int klen, const double *umax) {
+  vp_B_m_body<false>(u, sl0, sl1, sl2, force, UI, A, r, klen, umax, (int)blockIdx.x, (int)blockIdx.y, (int)blockIdx.z);
+}
+
 
 // stage C: XC(C,D) = component C on D-faces corrected by the third direction O
 DEVI double vp_up(double un, double L, double R, double eps) {
@@ -948,7 +1090,7 @@ DEVI double vp_up(double un, double L, double R, double eps) {
   const double av = 0.5 * (L + R);
   return (fabs(un) < eps) ? av : v;
 }
-__global__ void __launch_bounds__(64 * TNY) kk_vp_C_m(FV u, FV sl0, FV sl1, FV sl2, FV force, FV UI, FV XC, GArgs A, Range3 r, int klen, const double *umax) {
+template <bool R> __device__ __forceinline__ void vp_C_m_body(typename Prm<FV, R>::type u, typename Prm<FV, R>::type sl0, typename Prm<FV, R>::type sl1, typename Prm<FV, R>::type sl2, typename Prm<FV, R>::type force, typename Prm<FV, R>::type UI, typename Prm<FV, R>::type XC, typename Prm<GArgs, R>::type A, typename Prm<Range3, R>::type r, int klen, const double *umax, const int BX, const int BY, const int BZ) {
   __shared__ double ly[2][2][TNY][64];
   MARCH_SETUP(r)
   const double eps = eps_from(umax);
@@ -1013,6 +1155,10 @@ __global__ void __launch_bounds__(64 * TNY) kk_vp_C_m(FV u, FV sl0, FV sl1, FV s
     }
   }
 }
+__global__ void __launch_bounds__(64 * TNY) kk_vp_C_m(FV u, FV sl0, FV sl1, FV sl2, FV force, FV UI, FV XC, GArgs A, Range3 r, int klen, const double *umax) {
+  vp_C_m_body<false>(u, sl0, sl1, sl2, force, UI, XC, A, r, klen, umax, (int)blockIdx.x, (int)blockIdx.y, (int)blockIdx.z);
+}
+
 
 // stage D: the MAC velocity on valid D-faces
 template <int D> DEVI double vp_D_face(const GArgs &A, const FV &u, int i, int j, int k, double ucD, double L, double R, double eps, bool edge) {
@@ -1031,7 +1177,7 @@ template <int D> DEVI double vp_D_face(const GArgs &A, const FV &u, int i, int j
   }
   return v;
 }
-__global__ void __launch_bounds__(64 * TNY) kk_vp_D_m(FV u, FV sl0, FV sl1, FV sl2, FV force, FV UI, FV XC, FV um, FV vm, FV wm, GArgs A, Range3 r, int klen, const double *umax) {
+template <bool R> __device__ __forceinline__ void vp_D_m_body(typename Prm<FV, R>::type u, typename Prm<FV, R>::type sl0, typename Prm<FV, R>::type sl1, typename Prm<FV, R>::type sl2, typename Prm<FV, R>::type force, typename Prm<FV, R>::type UI, typename Prm<FV, R>::type XC, typename Prm<FV, R>::type um, typename Prm<FV, R>::type vm, typename Prm<FV, R>::type wm, typename Prm<GArgs, R>::type A, typename Prm<Range3, R>::type r, int klen, const double *umax, const int BX, const int BY, const int BZ) {
   __shared__ double ly[2][TNY][64];
   MARCH_SETUP(r)
   const double eps = eps_from(umax);
@@ -1099,6 +1245,10 @@ __global__ void __launch_bounds__(64 * TNY) kk_vp_D_m(FV u, FV sl0, FV sl1, FV s
     }
   }
 }
+__global__ void __launch_bounds__(64 * TNY) kk_vp_D_m(FV u, FV sl0, FV sl1, FV sl2, FV force, FV UI, FV XC, FV um, FV vm, FV wm, GArgs A, Range3 r, int klen, const double *umax) {
+  vp_D_m_body<false>(u, sl0, sl1, sl2, force, UI, XC, um, vm, wm, A, r, klen, umax, (int)blockIdx.x, (int)blockIdx.y, (int)blockIdx.z);
+}
+
 
 // ====================================================================================================
 // dm = 2 (BASELINE.json configs[0], the reference's CPU-runnable case): velpred_2d (velpred.f90:125-524) and mkflux_2d
@@ -1318,11 +1468,53 @@ static void k2_mkflux(const vdn_multifab *s, vdn_multifab **sedge, vdn_multifab 
   }
 }
 
+__global__ void __launch_bounds__(64 * TNY) kk_vp_B_mb(const VpD *descs, const int *start, int nbox) {
+  BATCH_LOCATE(VpD, gg)
+  vp_B_m_body<true>(q.s, q.sl0, q.sl1, q.sl2, q.force, q.UI, q.A, q.rg, q.klg, q.umax, BX, BY, BZ);
+}
+__global__ void __launch_bounds__(64 * TNY) kk_vp_C_mb(const VpD *descs, const int *start, int nbox) {
+  BATCH_LOCATE(VpD, gg)
+  vp_C_m_body<true>(q.s, q.sl0, q.sl1, q.sl2, q.force, q.UI, q.XC, q.A, q.rg, q.klg, q.umax, BX, BY, BZ);
+}
+__global__ void __launch_bounds__(64 * TNY) kk_vp_D_mb(const VpD *descs, const int *start, int nbox) {
+  BATCH_LOCATE(VpD, gf)
+  vp_D_m_body<true>(q.s, q.sl0, q.sl1, q.sl2, q.force, q.UI, q.XC, q.um, q.vm, q.wm, q.A, q.rf, q.klf, q.umax, BX, BY, BZ);
+}
 void k_velpred(const vdn_multifab *u, vdn_multifab **umac, const vdn_multifab *force, const double *dx, double dt,
                const vdn_bc_tower *bct) {
   if (ctx().prm.dm == 2) { k2_velpred(u, umac, force, dx, dt, bct); return; }
   REQUIRE(u->nc == 3 && u->ng >= 3 && force->ng >= 1 && umac[0]->ng >= 1, "velpred: operand shapes");
   hipStream_t st = ctx().stream;
+  if ((u->nfabs() > 1 || batch_always()) && u->nfabs() > 0 && !plain_godunov()) {
+    size_t mark = arena_mark();
+    const int nb = u->nfabs();
+    GodBatch<VpD> B; B.d.resize(nb);
+    double *umax = (double *)arena_alloc(sizeof(double) * nb);
+    HIPCHK(hipMemsetAsync(umax, 0, sizeof(double) * nb, st));
+    for (int ib = 0; ib < nb; ib++) {
+      VpD &q = B.d[ib];
+      fill_gargs(q.A, u, ib, bct, 0, 3, dx, dt);
+      q.A.is_vel = 1;
+      BoxP bp = make_boxp(u, ib, bct);
+      FV w = work_fv(nullptr, bp, 0);
+      const size_t fld = (size_t)w.sc * sizeof(double);
+      q.sl0 = q.sl1 = q.sl2 = q.UI = q.XC = w;
+      q.sl0.p = (double *)arena_alloc(fld * 3); q.sl1.p = (double *)arena_alloc(fld * 3); q.sl2.p = (double *)arena_alloc(fld * 3);
+      q.UI.p = (double *)arena_alloc(fld * 9); q.XC.p = (double *)arena_alloc(fld * 6);
+      for (int d = 0; d < 3; d++) { q.rm.lo[d] = q.A.lo[d]; q.rm.hi[d] = q.A.hi[d]; q.rg.lo[d] = q.A.lo[d] - 1; q.rg.hi[d] = q.A.hi[d] + 1; q.rf.lo[d] = q.A.lo[d]; q.rf.hi[d] = q.A.hi[d] + 1; }
+      q.s = u->fabs[ib]; q.force = force->fabs[ib]; q.um = umac[0]->fabs[ib]; q.vm = umac[1]->fabs[ib]; q.wm = umac[2]->fabs[ib];
+      q.umax = umax + ib;
+    }
+    B.finish();
+    const dim3 blk(64, TNY, 1);
+    hipLaunchKernelGGL(kk_velmax_b, dim3(B.tot[1]), dim3(64, 4, 1), 0, st, B.dev, B.st[1], nb);
+    hipLaunchKernelGGL(kk_slopes_b<VpD>, dim3(B.tot[0]), dim3(64, 4, 1), 0, st, B.dev, B.st[0], nb, 7);
+    hipLaunchKernelGGL(kk_vp_B_mb, dim3(B.tot[2]), blk, 0, st, B.dev, B.st[2], nb);
+    hipLaunchKernelGGL(kk_vp_C_mb, dim3(B.tot[2]), blk, 0, st, B.dev, B.st[2], nb);
+    hipLaunchKernelGGL(kk_vp_D_mb, dim3(B.tot[3]), blk, 0, st, B.dev, B.st[3], nb);
+    arena_release(mark);
+    return;
+  }
   for (int ib = 0; ib < u->nfabs(); ib++) {
     size_t mark = arena_mark();
     GArgs A; fill_gargs(A, u, ib, bct, 0, 3, dx, dt);
