@@ -116,12 +116,21 @@ void comm_allgather_dev(const double *send, double *recv, size_t count) {
 struct CopyDesc { FV dst, src; int lo[3], hi[3]; int sh[3]; int vlo[3], vhi[3]; };
 struct PackDesc { FV fv; int lo[3], hi[3]; int sh[3]; int vlo[3], vhi[3]; long off; };   // pack: fv = src (read at q - sh); unpack: fv = dst
 
-__global__ void k_xcopy(const CopyDesc *descs, int nc) {
-  const CopyDesc &D = descs[blockIdx.z];
+// box-to-box ghost copies of a level in one launch: a descriptor per (destination, source, shift) overlap, XCOPY_CHUNK points per
+// workgroup, workgroups bisect the prefix sum of chunk counts (a level of a few hundred boxes has thousands of thin slabs)
+constexpr int XCOPY_CHUNK = 1024;
+__global__ void __launch_bounds__(256) k_xcopy(const CopyDesc *descs, const int *start, int ndesc, int nc) {
+  int lo = 0, hi = ndesc - 1;
+  const int bid = (int)blockIdx.x;
+  while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (as_constant(start + mid) <= bid) lo = mid; else hi = mid - 1; }
+  const CopyDesc &D = as_constant(descs + lo);
   const int nx = D.hi[0] - D.lo[0] + 1, ny = D.hi[1] - D.lo[1] + 1, nz = D.hi[2] - D.lo[2] + 1;
-  const long tot = (long)nx * ny * nz;
-  for (long t = (long)blockIdx.x * blockDim.x + threadIdx.x; t < tot; t += (long)gridDim.x * blockDim.x) {
-    const int i = D.lo[0] + (int)(t % nx), j = D.lo[1] + (int)((t / nx) % ny), k = D.lo[2] + (int)(t / ((long)nx * ny));
+  const int tot = nx * ny * nz, t0 = (bid - as_constant(start + lo)) * XCOPY_CHUNK;
+  #pragma unroll
+  for (int u = 0; u < XCOPY_CHUNK / 256; u++) {
+    const int t = t0 + u * 256 + (int)threadIdx.x;
+    if (t >= tot) break;
+    const int i = D.lo[0] + t % nx, j = D.lo[1] + (t / nx) % ny, k = D.lo[2] + t / (nx * ny);
     const bool inside = i >= D.vlo[0] && i <= D.vhi[0] && j >= D.vlo[1] && j <= D.vhi[1] && k >= D.vlo[2] && k <= D.vhi[2];
     if (inside) continue;                 // only ghost points are filled
     for (int c = 0; c < nc; c++) fv_at(D.dst, i, j, k, c) = fv_get(D.src, i - D.sh[0], j - D.sh[1], k - D.sh[2], c);
@@ -156,7 +165,7 @@ struct Peer {
   double *d_send = nullptr, *d_recv = nullptr;
 };
 struct XPlan {
-  std::vector<CopyDesc> local; CopyDesc *d_local = nullptr;
+  std::vector<CopyDesc> local; CopyDesc *d_local = nullptr; int *d_lstart = nullptr; int lchunks = 0;
   std::vector<Peer> peers;
   int nc = 1;
 };
@@ -216,6 +225,15 @@ XPlan *xplan_build(const std::vector<XBoxInfo> &boxes, const vdn_box &pd, const 
   if (!P->local.empty()) {
     HIPCHK(hipMalloc((void **)&P->d_local, P->local.size() * sizeof(CopyDesc)));
     HIPCHK(hipMemcpyAsync(P->d_local, P->local.data(), P->local.size() * sizeof(CopyDesc), hipMemcpyHostToDevice, st));
+    std::vector<int> lstart(P->local.size());
+    for (size_t q = 0; q < P->local.size(); q++) {
+      const CopyDesc &D = P->local[q];
+      const long tot = (long)(D.hi[0] - D.lo[0] + 1) * (D.hi[1] - D.lo[1] + 1) * (D.hi[2] - D.lo[2] + 1);
+      REQUIRE(tot < (1L << 31) && (long)P->lchunks + tot / XCOPY_CHUNK + 1 < (1L << 31), "fill_boundary: overlap too large for 32-bit indexing");
+      lstart[q] = P->lchunks; P->lchunks += (int)((tot + XCOPY_CHUNK - 1) / XCOPY_CHUNK);
+    }
+    HIPCHK(hipMalloc((void **)&P->d_lstart, lstart.size() * sizeof(int)));
+    HIPCHK(hipMemcpy(P->d_lstart, lstart.data(), lstart.size() * sizeof(int), hipMemcpyHostToDevice));
   }
   for (auto &kv : peers) {
     Peer pr = kv.second;
@@ -235,6 +253,7 @@ void xplan_free(XPlan *P) {
   if (!P) return;
   HIPCHK(hipStreamSynchronize(ctx().stream));
   if (P->d_local) HIPCHK(hipFree(P->d_local));
+  if (P->d_lstart) HIPCHK(hipFree(P->d_lstart));
   for (auto &pr : P->peers) {
     if (pr.d_pack) HIPCHK(hipFree(pr.d_pack));
     if (pr.d_unpack) HIPCHK(hipFree(pr.d_unpack));
@@ -270,7 +289,7 @@ void xplan_run(XPlan *P) {
       if (pr.rank == ctx().rank && pr.nsend && !self_rccl) { REQUIRE(pr.nsend == pr.nrecv, "self exchange: send/recv sizes differ"); HIPCHK(hipMemcpyAsync(pr.d_recv, pr.d_send, pr.nsend * sizeof(double), hipMemcpyDeviceToDevice, st)); }
   }
   if (!P->local.empty())
-    hipLaunchKernelGGL(k_xcopy, dim3(64, 1, (unsigned)P->local.size()), dim3(256), 0, st, P->d_local, nc);
+    hipLaunchKernelGGL(k_xcopy, dim3((unsigned)P->lchunks), dim3(256), 0, st, P->d_local, P->d_lstart, (int)P->local.size(), nc);
   for (auto &pr : P->peers)
     if (!pr.unpack.empty()) hipLaunchKernelGGL(k_xunpack, dim3(32, 1, (unsigned)pr.unpack.size()), dim3(256), 0, st, pr.d_unpack, nc, pr.d_recv);
 }

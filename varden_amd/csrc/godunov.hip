@@ -647,10 +647,6 @@ __global__ void kk_velmax(FV u, Range3 r, double *out) {             // velpred.
 // ====================================================================================================
 struct MkD { FV s, sl0, sl1, sl2, um, vm, wm, force, macrhs, SI, SC, sex, sey, sez, flx, fly, flz; GArgs A; Range3 rm, rg, rf; int klg, klf, gs[3], gm[3], gg[3], gf[3]; double *umax; };
 struct VpD { FV s, sl0, sl1, sl2, force, UI, XC, um, vm, wm;                                     GArgs A; Range3 rm, rg, rf; int klg, klf, gs[3], gm[3], gg[3], gf[3]; double *umax; };
-template <class T> DEVI const T &as_constant(const T *p) {
-  typedef const T __attribute__((address_space(4))) *CP;
-  return *(const T *)(CP)p;
-}
 DEVI int locate_box(const int *start, int nbox, int bid) {
   int lo = 0, hi = nbox - 1;
   while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (as_constant(start + mid) <= bid) lo = mid; else hi = mid - 1; }

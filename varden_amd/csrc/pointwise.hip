@@ -171,10 +171,46 @@ __global__ void kk_estdt(FV u, FV s, FV gp, FV ext, Range3 r, double *out6) {
   #pragma unroll
   for (int c = 0; c < 6; c++) block_atomic_max(out6 + c, m[c]);
 }
+// the same for all boxes of a level in one launch
+struct EstB { Range3 r; int g[3]; FV u, s, gp, ext; };
+__global__ void __launch_bounds__(256) kk_estdt_b(const EstB *args, const int *start, int nbox, double *out6) {
+  int lo = 0, hi = nbox - 1;
+  const int bid = (int)blockIdx.x;
+  while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (as_constant(start + mid) <= bid) lo = mid; else hi = mid - 1; }
+  const EstB &a = as_constant(args + lo);
+  const int lb = bid - as_constant(start + lo);
+  const int bx = lb % a.g[0], by = (lb / a.g[0]) % a.g[1], bz = lb / (a.g[0] * a.g[1]);
+  const int i = a.r.lo[0] + bx * 64 + (int)threadIdx.x, j = a.r.lo[1] + by * 4 + (int)threadIdx.y;
+  double m[6] = { 0, 0, 0, 0, 0, 0 };
+  if (i <= a.r.hi[0] && j <= a.r.hi[1]) for (int k = a.r.lo[2] + bz; k <= a.r.hi[2]; k += a.g[2]) {
+    const double rho = fv_get(a.s, i, j, k, 0);
+    #pragma unroll
+    for (int c = 0; c < 3; c++) {
+      m[c] = fmax(m[c], fabs(fv_get(a.u, i, j, k, c)));
+      m[3 + c] = fmax(m[3 + c], fabs(fv_get(a.gp, i, j, k, c) / rho - fv_get(a.ext, i, j, k, c)));
+    }
+  }
+  #pragma unroll
+  for (int c = 0; c < 6; c++) block_atomic_max(out6 + c, m[c]);
+}
 void k_estdt_max(const vdn_multifab *u, const vdn_multifab *s, const vdn_multifab *gp, const vdn_multifab *ext, double out6[6]) {
   if (ctx().prm.dm == 2) { k2_estdt_max(u, s, gp, ext, out6); return; }
   VdnCtx &c = ctx();
   HIPCHK(hipMemsetAsync(c.d_scal, 0, 6 * sizeof(double), c.stream));
+  if (u->nfabs() > 1) {
+    const int nb = u->nfabs();
+    std::vector<EstB> v(nb); std::vector<int> start(nb); int tot = 0;
+    for (int i = 0; i < nb; i++) {
+      EstB &a = v[i];
+      for (int d = 0; d < 3; d++) { a.r.lo[d] = u->vbox[i].lo[d]; a.r.hi[d] = u->vbox[i].hi[d]; }
+      const dim3 g = reduce_grid(a.r);
+      a.g[0] = g.x; a.g[1] = g.y; a.g[2] = g.z; a.u = u->fabs[i]; a.s = s->fabs[i]; a.gp = gp->fabs[i]; a.ext = ext->fabs[i];
+      start[i] = tot; tot += (int)(g.x * g.y * g.z);
+    }
+    EstB *d_args = (EstB *)desc_scratch(sizeof(EstB) * nb); int *d_start = (int *)desc_scratch(sizeof(int) * nb);
+    upload_staged(d_args, v.data(), sizeof(EstB) * nb); upload_staged(d_start, start.data(), sizeof(int) * nb);
+    hipLaunchKernelGGL(kk_estdt_b, dim3(tot), dim3(64, 4, 1), 0, c.stream, (const EstB *)d_args, (const int *)d_start, nb, c.d_scal);
+  } else
   for (int i = 0; i < u->nfabs(); i++) {
     Range3 r; for (int d = 0; d < 3; d++) { r.lo[d] = u->vbox[i].lo[d]; r.hi[d] = u->vbox[i].hi[d]; }
     hipLaunchKernelGGL(kk_estdt, reduce_grid(r), dim3(64, 4, 1), 0, c.stream, u->fabs[i], s->fabs[i], gp->fabs[i], ext->fabs[i], r, c.d_scal);

@@ -50,14 +50,19 @@ DEVI void block_atomic_max_fwd(double *addr, double v);
 //   struct A { Range3 r; int g[3]; ...;  static __device__ double body(const A &a, int i, int j, int k, P extra); };
 // g = workgroups per direction (g[2] may be smaller than the number of planes: the workgroup then strides over k).  `body` returns a
 // non-negative value that is max-reduced into *nrm when nrm is not null.
-struct BatchHdr { int start; };
+// read-only launch data (descriptor arrays) seen through the constant address space: scalar loads that the kernel's own stores never
+// invalidate, so the compiler treats them like kernel arguments (re-loads instead of spilling, no re-read after every store)
+template <class T> DEVI const T &as_constant(const T *p) {
+  typedef const T __attribute__((address_space(4))) *CP;
+  return *(const T *)(CP)p;
+}
 template <class A, class P>
 __global__ void __launch_bounds__(256) kk_batched(const A *args, const int *start, int nbox, P extra, double *nrm) {
   int lo = 0, hi = nbox - 1;
   const int bid = (int)blockIdx.x;
-  while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (start[mid] <= bid) lo = mid; else hi = mid - 1; }
-  const A a = args[lo];                                       // by value: a reference into global memory would be re-read after every store
-  const int lb = bid - start[lo];
+  while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (as_constant(start + mid) <= bid) lo = mid; else hi = mid - 1; }
+  const A &a = as_constant(args + lo);
+  const int lb = bid - as_constant(start + lo);
   const int bx = lb % a.g[0], by = (lb / a.g[0]) % a.g[1], bz = lb / (a.g[0] * a.g[1]);
   const int i = a.r.lo[0] + bx * 64 + (int)threadIdx.x, j = a.r.lo[1] + by * 4 + (int)threadIdx.y;
   double v = 0.0;
