@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <vector>
+#include <type_traits>
 #include <utility>
 #include "vdn_internal.h"
 
@@ -61,7 +62,9 @@ __global__ void __launch_bounds__(256) kk_batched(const A *args, const int *star
   int lo = 0, hi = nbox - 1;
   const int bid = (int)blockIdx.x;
   while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (as_constant(start + mid) <= bid) lo = mid; else hi = mid - 1; }
-  const A &a = as_constant(args + lo);
+  // small descriptors are copied into registers (kernels that loop over k re-read a constant-space one every plane: NdfNegB 106 -> 151 us),
+  // large ones stay in constant space (a by-value copy of UpdateB lands in 632 bytes of scratch: 3.8 ms -> 0.5 ms)
+  typename std::conditional<(sizeof(A) <= 320), const A, const A &>::type a = as_constant(args + lo);
   const int lb = bid - as_constant(start + lo);
   const int bx = lb % a.g[0], by = (lb / a.g[0]) % a.g[1], bz = lb / (a.g[0] * a.g[1]);
   const int i = a.r.lo[0] + bx * 64 + (int)threadIdx.x, j = a.r.lo[1] + by * 4 + (int)threadIdx.y;
