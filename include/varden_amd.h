@@ -211,6 +211,14 @@ int vdn_multifab_copy_layouts(vdn_multifab *dst, int dcomp, const vdn_multifab *
 int vdn_make_new_grids(const vdn_multifab *s, int lev1, int buf_wid, int nest, double min_eff, int min_width, int blocking,
                        int max_grid_size, int maxboxes, vdn_box *boxes_out, int *nboxes_out, long *ntagged);
 
+/* ---- derived plot quantities of write_plotfile (src/varden.f90:532-540) ------------------------------------------------------------
+ * make_vorticity(vort, comp, u, dx, bc)   src/makevort.f90:16-57  (fills the ghost cells of u first, as the reference does;
+ *                                         3-D: |curl u| with one-sided differences next to inflow / no-slip faces, 2-D: v_x - u_y)
+ * make_magvel(magvel, comp, u)            src/makevort.f90:59-91
+ * comp 0-based. */
+int vdn_make_vorticity(vdn_multifab *vort, int comp, vdn_multifab *u, const double *dx /*[dm]*/, const vdn_bc_tower *bct);
+int vdn_make_magvel(vdn_multifab *magvel, int comp, vdn_multifab *u);
+
 /* per-phase wall seconds of the last vdn_advance_timestep (reference prints them,
  * advance_timestep.f90:159-166): [0]=scalar [1]=velocity [2]=MAC [3]=HG [4]=total              */
 int  vdn_last_step_timing(double *sec5);

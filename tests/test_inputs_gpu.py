@@ -23,7 +23,7 @@ def test_namelist_parser():
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("name,nsteps,nlev", [("inputs_bubble_3d", 8, 2), ("inputs_3d-regt", 4, 3), ("inputs_advect_3d", 4, 3), ("inputs_RayleighTaylor_3d", 5, 2)])
-def test_reference_inputs_run(gpu, name, nsteps, nlev):
+def test_reference_inputs_run(gpu, name, nsteps, nlev, tmp_path):
     from varden_amd import advance as adv
     from varden_amd import inputs
     text = open(os.path.join(INP, name)).read().replace("verbose = 1", "verbose = 0")
@@ -35,8 +35,9 @@ def test_reference_inputs_run(gpu, name, nsteps, nlev):
         assert mac[2] <= 1e-10 * mac[1] or mac[1] == 0.0
         seen.append((G.istep, [len(b) for b in G.boxes], G.dt))
 
-    nl, G = inputs.run(text, nsteps, report)
+    nl, G = inputs.run(text, nsteps, report, outdir=str(tmp_path))
     assert G.nlev == nlev and G.istep == nsteps and G.nregrids >= (nsteps - 1) // 2
+    assert os.path.isdir(str(tmp_path / "plt00000")) and G.files_written[0].endswith("plt00000")          # plot_int = 10: step 0 only
     assert all(s[2] > 0 for s in seen)
     for n in range(G.nlev):
         for i in range(G.unew[n].nfabs()):
@@ -74,3 +75,30 @@ def test_vortextube_input_runs(gpu):
     assert 0.9 < np.abs(u[..., 0]).max() < 1.1 and np.abs(s[..., 0] - 1.0).max() <= 1e-4           # the tube's axial velocity ~ 1; the corner-coupled conservative update keeps a constant density only to O(dt^2 grad u grad v) (mkflux.f90:1620-1626 vs 1874-1905), 1.3e-6 here
     assert adv.last_solver_stats("hg")[0] < 40
     G.close()
+
+
+@pytest.mark.gpu
+def test_checkpoint_and_restart_from_inputs(gpu, tmp_path):
+    """inputs_bubble_3d with chk_int = 2: the run restarted from chk00002 (grids and state from the file, the regrid of step 3 included)
+    ends in the same bits as the uninterrupted run; the plot file of step 4 lists the same boxes"""
+    from varden_amd import inputs, plotfile
+    text = open(os.path.join(INP, "inputs_bubble_3d")).read().replace("verbose = 1", "verbose = 0")
+    text = text.replace("chk_int   = 100", "chk_int   = 2").replace("plot_int  = 10", "plot_int  = 4")
+    assert "chk_int   = 2" in text and "plot_int  = 4" in text
+
+    def valid(G):
+        return [G.uold[n].to_numpy(i)[3:-3, 3:-3, 3:-3] for n in range(G.nlev) for i in range(G.uold[n].nfabs())] + \
+               [G.p[n].to_numpy(i)[1:-1, 1:-1, 1:-1] for n in range(G.nlev) for i in range(G.p[n].nfabs())]
+
+    nl, A = inputs.run(text, 4, None, outdir=str(tmp_path))
+    names = [os.path.basename(f) for f in A.files_written]
+    assert names == ["plt00000", "chk00000", "chk00002", "plt00004", "chk00004"], names
+    ref, boxes, tA = valid(A), A.boxes, A.time
+    A.close()
+    nl, B = inputs.run(text.replace("&PROBIN", "&PROBIN\n restart = 2"), 4, None, outdir=str(tmp_path))
+    assert B.istep == 4 and B.time == tA and B.boxes == boxes
+    for x, y in zip(ref, valid(B)):
+        assert np.array_equal(x, y)
+    plt = plotfile.read_ml_multifab(str(tmp_path / "plt00004"))
+    assert plt["nlevs"] == B.nlev and [L["boxes"] for L in plt["levels"]] == [list(b) for b in boxes]
+    B.close()

@@ -1,0 +1,63 @@
+"""plot / checkpoint file layout on the host (no GPU): what write_ml_multifab puts on disk is what read_ml_multifab returns, for
+cell-centred and nodal data on several levels and boxes; header fields follow the BoxLib plotfile layout; the checkpoint header
+is the &chkpoint namelist of src/checkpoint.f90:36-38,74-78."""
+import os
+
+import numpy as np
+
+from varden_amd import plotfile as pf
+
+
+def _levels(rng, nodal=(0, 0, 0), nc=3):
+    boxes = [[((0, 0, 0), (7, 7, 7))], [((4, 4, 4), (11, 9, 11)), ((4, 10, 4), (11, 11, 7))]]
+    out = []
+    for lb in boxes:
+        fabs = [np.asfortranarray(rng.standard_normal(tuple(hi[d] - lo[d] + 1 + nodal[d] for d in range(3)) + (nc,))) for lo, hi in lb]
+        out.append(dict(boxes=lb, nodal=nodal, fabs=fabs))
+    return out
+
+
+def test_ml_multifab_round_trip(tmp_path):
+    rng = np.random.default_rng(3)
+    for nodal in ((0, 0, 0), (1, 1, 1)):
+        lv = _levels(rng, nodal)
+        d = str(tmp_path / ("mf%d" % nodal[0]))
+        pf.write_ml_multifab(d, lv, [2], 3, names=["a", "b", "c"], pd=((0, 0, 0), (7, 7, 7)), prob_lo=[0, 0, 0], prob_hi=[1, 1, 1],
+                             time=0.125, dx=[0.125] * 3)
+        r = pf.read_ml_multifab(d)
+        assert r["names"] == ["a", "b", "c"] and r["dm"] == 3 and r["nlevs"] == 2 and r["time"] == 0.125 and r["rr"] == [2]
+        assert r["pd"] == ((0, 0, 0), (7, 7, 7)) and r["dx"] == [0.125] * 3
+        for L, R in zip(lv, r["levels"]):
+            assert R["boxes"] == L["boxes"] and tuple(R["nodal"]) == nodal
+            for a, b in zip(L["fabs"], R["fabs"]):
+                assert np.array_equal(a, b)
+
+
+def test_header_layout(tmp_path):
+    rng = np.random.default_rng(4)
+    d = str(tmp_path / "plt00007")
+    pf.write_ml_multifab(d, _levels(rng, nc=2), [2], 3, names=["x_vel", "density"], pd=((0, 0, 0), (7, 7, 7)), prob_lo=[0, 0, 0],
+                         prob_hi=[1, 1, 1], time=1.5, dx=[0.125] * 3)
+    h = open(os.path.join(d, "Header")).read().split("\n")
+    assert h[0] == "NavierStokes-V1.1" and h[1] == "2" and h[2:4] == ["x_vel", "density"] and h[4] == "3"
+    assert float(h[5]) == 1.5 and h[6] == "1"                        # time, finest level
+    assert h[9] == "2"                                               # refinement ratios
+    assert h[10] == "((0,0,0) (7,7,7) (0,0,0)) ((0,0,0) (15,15,15) (0,0,0))"
+    assert [float(x) for x in h[12].split()] == [0.125] * 3 and [float(x) for x in h[13].split()] == [0.0625] * 3
+    assert "Level_00/Cell" in h and "Level_01/Cell" in h
+    ch = open(os.path.join(d, "Level_01", "Cell_H")).read().split("\n")
+    assert ch[:4] == ["1", "0", "2", "0"] and ch[4] == "(2 0" and ch[5] == "((4,4,4) (11,9,11) (0,0,0))"
+    assert ch[9].startswith("FabOnDisk: Cell_D_00000 0")
+    raw = open(os.path.join(d, "Level_01", "Cell_D_00000"), "rb").read(200)
+    assert raw.startswith(b"FAB ((8, (64 11 52 0 1 12 0 1023)),(8, (8 7 6 5 4 3 2 1)))((4,4,4) (11,9,11) (0,0,0)) 2\n")
+
+
+def test_two_dimensional_boxes(tmp_path):
+    rng = np.random.default_rng(5)
+    lv = [dict(boxes=[((0, 0, 0), (15, 7, 0))], nodal=(1, 1, 0), fabs=[np.asfortranarray(rng.standard_normal((17, 9, 1, 1)))])]
+    d = str(tmp_path / "p2")
+    pf.write_ml_multifab(d, lv, [], 2)
+    r = pf.read_ml_multifab(d)
+    assert r["dm"] == 2 and r["levels"][0]["boxes"] == lv[0]["boxes"] and tuple(r["levels"][0]["nodal"]) == (1, 1, 0)
+    assert np.array_equal(r["levels"][0]["fabs"][0], lv[0]["fabs"][0])
+    assert "((0,0) (16,8) (1,1))" in open(os.path.join(d, "Level_00", "Cell_H")).read()

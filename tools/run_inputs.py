@@ -1,4 +1,5 @@
 """python tools/run_inputs.py <inputs file> [nsteps]: runs one of the reference's inputs files (exec/test/inputs_*) through the path"""
+import os
 import sys, time
 sys.path.insert(0, ".")
 import numpy as np
@@ -13,7 +14,9 @@ def report(G):
 
 text = open(sys.argv[1]).read()
 t0 = time.time()
-nl, G = inputs.run(text, int(sys.argv[2]) if len(sys.argv) > 2 else None, report)
+outdir = sys.argv[3] if len(sys.argv) > 3 else "gpurun_out/run_inputs"      # plot / checkpoint files land here
+os.makedirs(outdir, exist_ok=True)
+nl, G = inputs.run(text, int(sys.argv[2]) if len(sys.argv) > 2 else None, report, outdir=outdir)
 print("%d steps in %.2f s" % (G.istep, time.time() - t0))
 top = G.snew[-1] if hasattr(G, "nlev") else G.snew[0]
 a = np.concatenate([top.to_numpy(i).reshape(-1, top.nc) for i in range(top.nfabs())])

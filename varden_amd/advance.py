@@ -159,6 +159,17 @@ def fillpatch(fine, crse, icomp, nc):
     check(capi.load().vdn_fillpatch(fine.h, crse.h, icomp, nc))
 
 
+def make_vorticity(vort, comp, u, dx, bct):
+    """make_vorticity(vort, comp, u, dx, bc) of src/makevort.f90:16-57 (comp 0-based; fills the ghost cells of u)"""
+    d = (C.c_double * 3)(*(list(dx) + [1.0] * 3)[:3])
+    check(capi.load().vdn_make_vorticity(vort.h, comp, u.h, d, bct.h))
+
+
+def make_magvel(magvel, comp, u):
+    """make_magvel(magvel, comp, u) of src/makevort.f90:59-91"""
+    check(capi.load().vdn_make_magvel(magvel.h, comp, u.h))
+
+
 def ml_nodal_prolongation(fine, crse):
     check(capi.load().vdn_ml_nodal_prolongation(fine.h, crse.h))
 

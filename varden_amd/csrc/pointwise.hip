@@ -220,3 +220,87 @@ void k_estdt_max(const vdn_multifab *u, const vdn_multifab *s, const vdn_multifa
   HIPCHK(hipStreamSynchronize(c.stream));
   for (int k = 0; k < 6; k++) out6[k] = c.h_scal[k];
 }
+
+// ====================================================================================================
+// derived plot quantities (makevort.f90): vorticity and velocity magnitude of write_plotfile (varden.f90:532-540)
+// ====================================================================================================
+struct VortArgs { int lo[3], hi[3]; int phys[3][2]; double dx[3]; int comp, dm; };
+// d(u_c)/dx_D: centred (uycen & co., makevort.f90:568-572), one-sided next to an inflow / no-slip face (uylo / uyhi, :574-584)
+template <int D> DEVI double vort_der(const FV &u, int c, int side, int i, int j, int k, double dxd) {
+  const double up = fv_get(u, i + (D == 0), j + (D == 1), k + (D == 2), c), u0 = fv_get(u, i, j, k, c), um = fv_get(u, i - (D == 0), j - (D == 1), k - (D == 2), c);
+  if (side < 0) return (up + 3.0 * u0 - 4.0 * um) / (3.0 * dxd);
+  if (side > 0) return -(um + 3.0 * u0 - 4.0 * up) / (3.0 * dxd);
+  return 0.5 * (up - um) / dxd;
+}
+DEVI bool vort_fix3(int p) { return p == VDN_INLET || p == VDN_NO_SLIP_WALL; }                           // makevort.f90:188-195
+DEVI bool vort_fix2(int p) { return p == VDN_INLET || p == VDN_SLIP_WALL || p == VDN_NO_SLIP_WALL; }     // makevort.f90:116-117
+struct vort_K { FV vort, u; VortArgs A;
+  __device__ void cell(int i, int j, int k) const {
+    if (A.dm == 2) {
+      // makevort_2d (makevort.f90:93-156): one-sided forms over dx (not 3 dx), slip walls included; the y-face loops run last and
+      // overwrite, so at a corner the x derivative is the centred one
+      double vx = (fv_get(u, i + 1, j, 0, 1) - fv_get(u, i - 1, j, 0, 1)) / (2.0 * A.dx[0]);
+      double uy = (fv_get(u, i, j + 1, 0, 0) - fv_get(u, i, j - 1, 0, 0)) / (2.0 * A.dx[1]);
+      const bool ylo = j == A.lo[1] && vort_fix2(A.phys[1][0]), yhi = j == A.hi[1] && vort_fix2(A.phys[1][1]);
+      if (!(ylo || yhi)) {
+        if (i == A.lo[0] && vort_fix2(A.phys[0][0])) vx = (fv_get(u, i + 1, j, 0, 1) + 3.0 * fv_get(u, i, j, 0, 1) - 4.0 * fv_get(u, i - 1, j, 0, 1)) / A.dx[0];
+        if (i == A.hi[0] && vort_fix2(A.phys[0][1])) vx = -(fv_get(u, i - 1, j, 0, 1) + 3.0 * fv_get(u, i, j, 0, 1) - 4.0 * fv_get(u, i + 1, j, 0, 1)) / A.dx[0];
+      }
+      if (ylo) uy = (fv_get(u, i, j + 1, 0, 0) + 3.0 * fv_get(u, i, j, 0, 0) - 4.0 * fv_get(u, i, j - 1, 0, 0)) / A.dx[1];
+      if (yhi) uy = -(fv_get(u, i, j - 1, 0, 0) + 3.0 * fv_get(u, i, j, 0, 0) - 4.0 * fv_get(u, i, j + 1, 0, 0)) / A.dx[1];
+      fv_at(vort, i, j, 0, A.comp) = vx - uy;
+      return;
+    }
+    // makevort_3d (makevort.f90:158-682): faces, edges and corners follow one rule per direction
+    const int q[3] = { i, j, k };
+    int side[3];
+    #pragma unroll
+    for (int d = 0; d < 3; d++) {
+      side[d] = 0;
+      if (q[d] == A.lo[d] && vort_fix3(A.phys[d][0])) side[d] = -1;
+      if (q[d] == A.hi[d] && vort_fix3(A.phys[d][1])) side[d] = 1;
+    }
+    const double uy = vort_der<1>(u, 0, side[1], i, j, k, A.dx[1]), uz = vort_der<2>(u, 0, side[2], i, j, k, A.dx[2]);
+    const double vx = vort_der<0>(u, 1, side[0], i, j, k, A.dx[0]), vz = vort_der<2>(u, 1, side[2], i, j, k, A.dx[2]);
+    const double wx = vort_der<0>(u, 2, side[0], i, j, k, A.dx[0]), wy = vort_der<1>(u, 2, side[1], i, j, k, A.dx[1]);
+    fv_at(vort, i, j, k, A.comp) = sqrt((wy - vz) * (wy - vz) + (uz - wx) * (uz - wx) + (vx - uy) * (vx - uy));     // vorfun, :676-680
+  } };
+struct magvel_K { FV mv, u; int comp, dm;
+  __device__ void cell(int i, int j, int k) const {                                                           // makevort.f90:684-724
+    double s = fv_get(u, i, j, k, 0) * fv_get(u, i, j, k, 0) + fv_get(u, i, j, k, 1) * fv_get(u, i, j, k, 1);
+    if (dm == 3) s = s + fv_get(u, i, j, k, 2) * fv_get(u, i, j, k, 2);
+    fv_at(mv, i, j, k, comp) = sqrt(s);
+  } };
+// make_vorticity(vort, comp, u, dx, bc): fills the ghost cells of u (fill_boundary + physbc, makevort.f90:34-38) and writes component comp
+void k_make_vorticity(vdn_multifab *vort, int comp, vdn_multifab *u, const double *dx, const vdn_bc_tower *bct) {
+  const int dm = ctx().prm.dm;
+  REQUIRE(u->ng >= 1 && u->nc >= dm && comp >= 0 && comp < vort->nc && vort->nfabs() == u->nfabs(), "make_vorticity: operand shapes");
+  mf_fill_boundary(u);
+  mf_physbc(u, 0, 0, dm, bct, false);
+  std::vector<std::pair<vort_K, Range3>> v;
+  for (int i = 0; i < u->nfabs(); i++) {
+    VortArgs A; Range3 r; BoxP bp = make_boxp(u, i, bct);
+    for (int d = 0; d < 3; d++) { A.lo[d] = r.lo[d] = bp.lo[d]; A.hi[d] = r.hi[d] = bp.hi[d]; A.dx[d] = d < dm ? dx[d] : 1.0;
+      for (int s = 0; s < 2; s++) A.phys[d][s] = bp.phys[d][s]; }
+    A.comp = comp; A.dm = dm;
+    v.push_back({ vort_K{ vort->fabs[i], u->fabs[i], A }, r });
+  }
+  launch_cells(v, ctx().stream);
+}
+void k_make_magvel(vdn_multifab *mv, int comp, vdn_multifab *u) {
+  const int dm = ctx().prm.dm;
+  REQUIRE(u->nc >= dm && comp >= 0 && comp < mv->nc && mv->nfabs() == u->nfabs(), "make_magvel: operand shapes");
+  mf_fill_boundary(u);                                                                                         // makevort.f90:74
+  std::vector<std::pair<magvel_K, Range3>> v;
+  for (int i = 0; i < u->nfabs(); i++) {
+    Range3 r; for (int d = 0; d < 3; d++) { r.lo[d] = u->vbox[i].lo[d]; r.hi[d] = u->vbox[i].hi[d]; }
+    v.push_back({ magvel_K{ mv->fabs[i], u->fabs[i], comp, dm }, r });
+  }
+  launch_cells(v, ctx().stream);
+}
+extern "C" int vdn_make_vorticity(vdn_multifab *vort, int comp, vdn_multifab *u, const double *dx, const vdn_bc_tower *bct) {
+  VDN_TRY REQUIRE(ctx().inited, "vdn_init has not been called"); k_make_vorticity(vort, comp, u, dx, bct); VDN_CATCH
+}
+extern "C" int vdn_make_magvel(vdn_multifab *magvel, int comp, vdn_multifab *u) {
+  VDN_TRY REQUIRE(ctx().inited, "vdn_init has not been called"); k_make_magvel(magvel, comp, u); VDN_CATCH
+}

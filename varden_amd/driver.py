@@ -69,10 +69,11 @@ def initdata_numpy(n, dx, prob_type=1, ng=3, nscal=2, lo=(0, 0, 0), centre=(0.5,
 class Varden:
     def __init__(self, n, phys_bc, params=None, prob_type=1, grav=-9.8, prob_hi=(1.0, 1.0, 1.0), init_shrink=1.0,
                  init_iter=4, do_initial_projection=1, u0=None, s0=None, device=0, decomp=(1, 1, 1), rank=0, nranks=1,
-                 comm_id=None):
+                 comm_id=None, restart=None, restart_step=0):
         """decomp = (bx, by, bz): the domain is cut into bx*by*bz equal boxes (max_grid_size of the reference,
         src/_parameters:27), dealt round-robin to the ranks (one rank per GPU).  comm_id: the 128-byte RCCL unique
-        id broadcast by the caller when nranks > 1."""
+        id broadcast by the caller when nranks > 1.  restart: a checkpoint read by plotfile.read_checkfile -- the state comes from it
+        and the start-up sequence (initial projection, pressure iterations) is skipped, src/varden.f90:94-97, 119, 180, 227."""
         self.prm = params or default_params()
         dm = int(self.prm.dm)
         self.n = tuple(int(x) for x in (n if hasattr(n, "__len__") else (n,) * dm))
@@ -107,6 +108,14 @@ class Varden:
         self.gp, self.p = mk(dm, 1), mk(1, 1, (1, 1, 1))
         self.ext_vel_force, self.ext_scal_force = mk(dm, 1), mk(ns, 1)
         self.ext_vel_force[0].setval(grav, dm - 1, 1, all=True)                    # varden.f90:428-429
+        if restart is not None:
+            from . import plotfile
+            plotfile.load_restart(self, restart)
+            self.istep = int(restart_step)
+            self.fill_state_ghosts()
+            self.unew[0].copy_c(0, self.uold[0], 0, dm, 3)
+            self.snew[0].copy_c(0, self.sold[0], 0, ns, 3)
+            return
         for li, gi in enumerate(self.local):              # each rank initialises / uploads only the boxes it owns
             blo, bhi = self.boxes[gi]
             if u0 is None:                                # blob centred in the domain (= (0.5,0.5,0.5) on the unit cube)
@@ -207,7 +216,7 @@ class VardenAMR:
 
     def __init__(self, nc, fine_boxes, phys_bc, params=None, prob_type=1, grav=-9.8, init_shrink=0.1, device=0, finer_levels=(),
                  regrid_int=-1, max_levs=None, max_grid_size=256, init_iter=0, do_initial_projection=0,
-                 rank=0, nranks=1, comm_id=None, base_boxes=None, init_fn=None):
+                 rank=0, nranks=1, comm_id=None, base_boxes=None, init_fn=None, restart=None, restart_step=0):
         """init_fn(level, box_lo, box_shape, dx) -> (u, s) with 3 ghost layers replaces the analytic initial data of prob_type.
         several ranks (one per GPU): the boxes of every level are dealt to the ranks by cell count (`distribute`), `base_boxes` cuts
         level 0 into several boxes, comm_id is the RCCL unique id broadcast by the caller; regridding is single-rank in this round"""
@@ -241,6 +250,16 @@ class VardenAMR:
         self.ext_vel_force, self.ext_scal_force = mk(dm, 1), mk(ns, 1)
         for n in range(self.nlev):
             self.ext_vel_force[n].setval(grav, dm - 1, 1, all=True)
+        if restart is not None:                          # initialize_from_restart, src/initialize.f90:22-88
+            from . import plotfile
+            plotfile.load_restart(self, restart)
+            self.istep = int(restart_step)
+            self.fill_state_ghosts()
+            for n in range(self.nlev):
+                self.unew[n].copy_c(0, self.uold[n], 0, dm, 3)
+                self.snew[n].copy_c(0, self.sold[n], 0, ns, 3)
+            return
+        for n in range(self.nlev):
             for li, gi in enumerate(self.local[n]):         # each rank initialises the boxes it owns
                 blo, bhi = self.boxes[n][gi]
                 nb = tuple(bhi[d] - blo[d] + 1 for d in range(3))

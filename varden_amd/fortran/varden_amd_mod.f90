@@ -65,7 +65,7 @@ module varden_amd
             multifab_copy_to_host, multifab_copy_from_host, multifab_fab_size
   public :: advance_timestep, estdt, hgproject, macproject
   public :: ml_cc_restriction, ml_edge_restriction, multifab_fill_ghost_cells, create_umac_grown, ml_restrict_and_fill
-  public :: fillpatch, ml_nodal_prolongation, multifab_copy_layouts, make_new_grids
+  public :: fillpatch, ml_nodal_prolongation, multifab_copy_layouts, make_new_grids, make_vorticity, make_magvel
 
   interface
      subroutine vdn_params_default(p) bind(C, name="vdn_params_default")
@@ -237,6 +237,17 @@ module varden_amd
        import :: c_int, c_ptr
        type(c_ptr), value :: fine, crse
        integer(c_int), value :: icomp, nc
+     end function
+     integer(c_int) function vdn_make_vorticity(vort, comp, u, dx, bct) bind(C, name="vdn_make_vorticity")
+       import :: c_int, c_ptr, c_double
+       type(c_ptr), value :: vort, u, bct
+       integer(c_int), value :: comp
+       real(c_double), intent(in) :: dx(*)
+     end function
+     integer(c_int) function vdn_make_magvel(magvel, comp, u) bind(C, name="vdn_make_magvel")
+       import :: c_int, c_ptr
+       type(c_ptr), value :: magvel, u
+       integer(c_int), value :: comp
      end function
      integer(c_int) function vdn_ml_nodal_prolongation(fine, crse) bind(C, name="vdn_ml_nodal_prolongation")
        import :: c_int, c_ptr
@@ -575,6 +586,21 @@ contains
     integer       , intent(in   ) :: icomp, nc
     call chk(vdn_fillpatch(fine%h, crse%h, int(icomp - 1, c_int), int(nc, c_int)), 'fillpatch')
   end subroutine fillpatch
+  ! vort_module (src/makevort.f90:16-91): the derived quantities of write_plotfile; bc is the tower, the level is u's
+  subroutine make_vorticity(vort, comp, u, dx, the_bc_tower)
+    type(multifab), intent(inout) :: vort, u
+    integer       , intent(in   ) :: comp
+    real(dp_t)    , intent(in   ) :: dx(:)
+    type(bc_tower), intent(in   ) :: the_bc_tower
+    real(c_double) :: d(3)
+    d = 1.0_c_double; d(1:size(dx)) = dx
+    call chk(vdn_make_vorticity(vort%h, int(comp - 1, c_int), u%h, d, the_bc_tower%h), 'make_vorticity')
+  end subroutine make_vorticity
+  subroutine make_magvel(magvel, comp, u)
+    type(multifab), intent(inout) :: magvel, u
+    integer       , intent(in   ) :: comp
+    call chk(vdn_make_magvel(magvel%h, int(comp - 1, c_int), u%h), 'make_magvel')
+  end subroutine make_magvel
   subroutine ml_nodal_prolongation(fine, crse)
     type(multifab), intent(inout) :: fine, crse
     call chk(vdn_ml_nodal_prolongation(fine%h, crse%h), 'ml_nodal_prolongation')

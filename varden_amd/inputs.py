@@ -1,9 +1,12 @@
 """Reads the reference's run-time inputs (a Fortran namelist &PROBIN, e.g. exec/test/inputs_bubble_3d) and drives the path the way
 src/varden.f90 does: parameters (src/_parameters), grids (fixed single level, or tag_boxes + make_new_grids), start-up sequence,
-time loop with estdt / regrid / advance_timestep.  Plot and checkpoint files are out of scope."""
+time loop with estdt / regrid / advance_timestep, plot files every plot_int steps, checkpoints every chk_int steps, restart = n
+continues from chk<n> (src/varden.f90:94-97, 207-229, 349-361)."""
+import os
 import re
 
 from . import boxlib as bl
+from . import plotfile
 from .capi import default_params
 from .driver import Varden, VardenAMR
 
@@ -12,7 +15,8 @@ DEFAULTS = dict(dim_in=2, nscal=2, prob_type=1, grav=0.0, boussinesq=0, max_step
                 regrid_int=-1, amr_buf_width=-1, n_cellx=32, n_celly=32, n_cellz=32, prob_hi_x=1.0, prob_hi_y=1.0, prob_hi_z=1.0,
                 init_iter=4, do_initial_projection=1, init_shrink=1.0, cflfac=0.8, max_dt_growth=1.1, visc_coef=0.0, diff_coef=0.0,
                 diffusion_type=1, slope_order=4, use_minion=0, stencil_order=2, verbose=0, mg_verbose=0,
-                bcx_lo=14, bcx_hi=14, bcy_lo=14, bcy_hi=14, bcz_lo=14, bcz_hi=14)
+                bcx_lo=14, bcx_hi=14, bcy_lo=14, bcy_hi=14, bcz_lo=14, bcz_hi=14,
+                plot_int=0, chk_int=0, restart=-1, plot_base_name="plt", check_base_name="chk")
 
 
 def parse_namelist(text):
@@ -37,8 +41,9 @@ def parse_namelist(text):
     return out
 
 
-def build(text, device=0, max_grid_size_cap=None):
-    """the driver object for an inputs text: Varden (one level) or VardenAMR (max_levs > 1, grids from the tagged initial data)"""
+def build(text, device=0, max_grid_size_cap=None, outdir="."):
+    """the driver object for an inputs text: Varden (one level) or VardenAMR (max_levs > 1, grids from the tagged initial data);
+    restart >= 0: grids and state from the checkpoint <outdir>/<check_base_name><restart:05d> (src/varden.f90:94-97)"""
     nl = dict(DEFAULTS)
     nl.update(parse_namelist(text))
     dm = int(nl["dim_in"])
@@ -57,8 +62,15 @@ def build(text, device=0, max_grid_size_cap=None):
     mgs = int(nl["max_grid_size"]) if max_grid_size_cap is None else min(int(nl["max_grid_size"]), max_grid_size_cap)
     common = dict(prob_type=int(nl["prob_type"]), grav=float(nl["grav"]), init_shrink=float(nl["init_shrink"]),
                   init_iter=int(nl["init_iter"]), do_initial_projection=int(nl["do_initial_projection"]), device=device)
+    decomp = tuple(max(1, -(-n[d] // mgs)) for d in range(dm)) + (1,) * (3 - dm)
+    if int(nl["restart"]) >= 0:
+        chk = plotfile.read_checkfile(os.path.join(outdir, "%s%05d" % (nl["check_base_name"], int(nl["restart"]))))
+        rs = dict(restart=chk, restart_step=int(nl["restart"]))
+        if chk["nlevs"] == 1:
+            return nl, Varden(n, phys, prm, prob_hi=prob_hi, decomp=decomp, **common, **rs)
+        return nl, VardenAMR(n[0], chk["boxes"][1], phys, params=prm, finer_levels=chk["boxes"][2:], base_boxes=chk["boxes"][0],
+                             regrid_int=int(nl["regrid_int"]), max_levs=int(nl["max_levs"]), max_grid_size=mgs, **common, **rs)
     if int(nl["max_levs"]) <= 1:
-        decomp = tuple(max(1, -(-n[d] // mgs)) for d in range(dm)) + (1,) * (3 - dm)
         return nl, Varden(n, phys, prm, prob_hi=prob_hi, decomp=decomp, **common)
     if dm != 3 or len(set(n)) != 1 or any(p != 1.0 for p in prob_hi):
         raise NotImplementedError("adaptive hierarchies: 3-D, cubic unit domain in this round")
@@ -70,13 +82,26 @@ def build(text, device=0, max_grid_size_cap=None):
                          max_levs=int(nl["max_levs"]), max_grid_size=mgs, **common)
 
 
-def run(text, nsteps=None, report=print, device=0):
-    """the time loop of src/varden.f90:237-371 for max_step steps (or until stop_time)"""
-    nl, G = build(text, device=device)
+def run(text, nsteps=None, report=print, device=0, outdir="."):
+    """the time loop of src/varden.f90:237-371 for max_step steps (or until stop_time); plot / checkpoint files at step 0 of a fresh
+    run and after every plot_int-th / chk_int-th step (:207-221, :349-361) under outdir"""
+    nl, G = build(text, device=device, outdir=outdir)
     max_step = int(nl["max_step"]) if nsteps is None else nsteps
     stop_time = float(nl["stop_time"])
+    plot_int, chk_int = int(nl["plot_int"]), int(nl["chk_int"])
+    G.files_written = []
+
+    def dump():
+        if plot_int > 0 and G.istep % plot_int == 0:
+            G.files_written.append(plotfile.write_plotfile(G, base=os.path.join(outdir, str(nl["plot_base_name"]))))
+        if chk_int > 0 and G.istep % chk_int == 0:
+            G.files_written.append(plotfile.write_checkfile(G, base=os.path.join(outdir, str(nl["check_base_name"]))))
+
+    if int(nl["restart"]) < 0:
+        dump()
     while G.istep < max_step and (stop_time < 0 or G.time < stop_time):
         G.step()
         if report:
             report(G)
+        dump()
     return nl, G
