@@ -119,3 +119,19 @@ def test_restart_of_a_hierarchy(gpu, oracle, tmp_path):
     for x, y in zip(ref, _state(B)):
         assert_bits(y, x, "hierarchy state after restart")
     B.close()
+
+
+def test_fixed_dt_and_stop_time(gpu, oracle):
+    """dt control of src/varden.f90:196-199, 318-326: fixed_dt overrides estdt; the last step is cut so that the run ends at stop_time"""
+    from varden_amd import driver
+    A = driver.Varden(32, WALLS, params_for(WALLS, cflfac=0.9), init_shrink=0.1, init_iter=1)
+    dt0 = A.dt
+    A.close()
+    T = 2.5 * dt0
+    B = driver.Varden(32, WALLS, params_for(WALLS, cflfac=0.9), init_shrink=0.1, init_iter=1, fixed_dt=dt0, stop_time=T)
+    dts = []
+    while B.time < T:
+        B.step()
+        dts.append(B.dt)
+    assert len(dts) == 3 and dts[0] == dt0 and dts[1] == dt0 and abs(dts[2] - 0.5 * dt0) < 1e-12 * dt0 and B.time == T
+    B.close()

@@ -66,15 +66,25 @@ def initdata_numpy(n, dx, prob_type=1, ng=3, nscal=2, lo=(0, 0, 0), centre=(0.5,
     return u, s
 
 
+def _limit_dt(sim, dt, first=False):
+    """fixed_dt and stop_time of src/varden.f90:196-199 (first step) and :318-326 (later steps)"""
+    if sim.fixed_dt > 0.0:
+        dt = sim.fixed_dt
+    if sim.stop_time >= 0.0 and sim.time + dt > sim.stop_time:
+        dt = min(dt, sim.stop_time - sim.time) if first else sim.stop_time - sim.time
+    return dt
+
+
 class Varden:
     def __init__(self, n, phys_bc, params=None, prob_type=1, grav=-9.8, prob_hi=(1.0, 1.0, 1.0), init_shrink=1.0,
                  init_iter=4, do_initial_projection=1, u0=None, s0=None, device=0, decomp=(1, 1, 1), rank=0, nranks=1,
-                 comm_id=None, restart=None, restart_step=0):
+                 comm_id=None, restart=None, restart_step=0, fixed_dt=-1.0, stop_time=-1.0):
         """decomp = (bx, by, bz): the domain is cut into bx*by*bz equal boxes (max_grid_size of the reference,
         src/_parameters:27), dealt round-robin to the ranks (one rank per GPU).  comm_id: the 128-byte RCCL unique
         id broadcast by the caller when nranks > 1.  restart: a checkpoint read by plotfile.read_checkfile -- the state comes from it
         and the start-up sequence (initial projection, pressure iterations) is skipped, src/varden.f90:94-97, 119, 180, 227."""
         self.prm = params or default_params()
+        self.fixed_dt, self.stop_time = float(fixed_dt), float(stop_time)
         dm = int(self.prm.dm)
         self.n = tuple(int(x) for x in (n if hasattr(n, "__len__") else (n,) * dm))
         if dm == 2:
@@ -139,7 +149,7 @@ class Varden:
         self.fill_state_ghosts()                                                   # varden.f90:165-172
         self.unew[0].copy_c(0, self.uold[0], 0, dm, 3)                             # varden.f90:175-176
         self.snew[0].copy_c(0, self.sold[0], 0, ns, 3)
-        self.dt = self.estdt(1.0e20) * init_shrink                                 # varden.f90:186-194
+        self.dt = _limit_dt(self, self.estdt(1.0e20) * init_shrink, first=True)    # varden.f90:186-199
         for it in range(init_iter):                                                # varden.f90:460-490
             self.advance(bl.PRESSURE_ITERS, it + 1)
 
@@ -162,7 +172,7 @@ class Varden:
         self.istep += 1
         self.fill_state_ghosts()
         if self.istep > 1:
-            self.dt = self.estdt(self.dt)
+            self.dt = _limit_dt(self, self.estdt(self.dt))
         self.advance(bl.REGULAR_TIMESTEP, self.istep)
         self.uold[0].copy_c(0, self.unew[0], 0, self.dm, 0)
         self.sold[0].copy_c(0, self.snew[0], 0, self.nscal, 0)
@@ -216,12 +226,14 @@ class VardenAMR:
 
     def __init__(self, nc, fine_boxes, phys_bc, params=None, prob_type=1, grav=-9.8, init_shrink=0.1, device=0, finer_levels=(),
                  regrid_int=-1, max_levs=None, max_grid_size=256, init_iter=0, do_initial_projection=0,
-                 rank=0, nranks=1, comm_id=None, base_boxes=None, init_fn=None, restart=None, restart_step=0):
+                 rank=0, nranks=1, comm_id=None, base_boxes=None, init_fn=None, restart=None, restart_step=0,
+                 fixed_dt=-1.0, stop_time=-1.0):
         """init_fn(level, box_lo, box_shape, dx) -> (u, s) with 3 ghost layers replaces the analytic initial data of prob_type.
         several ranks (one per GPU): the boxes of every level are dealt to the ranks by cell count (`distribute`), `base_boxes` cuts
         level 0 into several boxes, comm_id is the RCCL unique id broadcast by the caller; regridding is single-rank in this round"""
         self.prm = params or default_params()
         self.grav, self.regrid_int, self.max_grid_size = grav, regrid_int, max_grid_size
+        self.fixed_dt, self.stop_time = float(fixed_dt), float(stop_time)
         self.prm.prob_type = prob_type
         self.rank, self.nranks = rank, nranks
         bl.initialize(self.prm, rank, nranks, device)
@@ -282,7 +294,7 @@ class VardenAMR:
         for n in range(self.nlev):
             self.unew[n].copy_c(0, self.uold[n], 0, dm, 3)
             self.snew[n].copy_c(0, self.sold[n], 0, ns, 3)
-        self.dt = self.estdt(1.0e20) * init_shrink
+        self.dt = _limit_dt(self, self.estdt(1.0e20) * init_shrink, first=True)
         for it in range(init_iter):                                                    # varden.f90:460-490
             adv.advance_timestep(it + 1, self.mla, self.sold, self.uold, self.snew, self.unew, self.gp, self.p,
                                  self.ext_vel_force, self.ext_scal_force, self.bct, self.dt, self.time, self.dx, self.press_comp, bl.PRESSURE_ITERS)
@@ -335,7 +347,7 @@ class VardenAMR:
             self.regrid()
         self.fill_state_ghosts()
         if self.istep > 1:
-            self.dt = self.estdt(self.dt)
+            self.dt = _limit_dt(self, self.estdt(self.dt))
         adv.advance_timestep(self.istep, self.mla, self.sold, self.uold, self.snew, self.unew, self.gp, self.p,
                              self.ext_vel_force, self.ext_scal_force, self.bct, self.dt, self.time, self.dx, self.press_comp, bl.REGULAR_TIMESTEP)
         for n in range(self.nlev):

@@ -16,7 +16,7 @@ DEFAULTS = dict(dim_in=2, nscal=2, prob_type=1, grav=0.0, boussinesq=0, max_step
                 init_iter=4, do_initial_projection=1, init_shrink=1.0, cflfac=0.8, max_dt_growth=1.1, visc_coef=0.0, diff_coef=0.0,
                 diffusion_type=1, slope_order=4, use_minion=0, stencil_order=2, verbose=0, mg_verbose=0,
                 bcx_lo=14, bcx_hi=14, bcy_lo=14, bcy_hi=14, bcz_lo=14, bcz_hi=14,
-                plot_int=0, chk_int=0, restart=-1, plot_base_name="plt", check_base_name="chk")
+                fixed_dt=-1.0, plot_int=0, chk_int=0, restart=-1, plot_base_name="plt", check_base_name="chk")
 
 
 def parse_namelist(text):
@@ -61,7 +61,8 @@ def build(text, device=0, max_grid_size_cap=None, outdir="."):
     prob_hi = tuple(float(nl["prob_hi_" + a]) for a in "xyz"[:dm]) + (1.0,) * (3 - dm)
     mgs = int(nl["max_grid_size"]) if max_grid_size_cap is None else min(int(nl["max_grid_size"]), max_grid_size_cap)
     common = dict(prob_type=int(nl["prob_type"]), grav=float(nl["grav"]), init_shrink=float(nl["init_shrink"]),
-                  init_iter=int(nl["init_iter"]), do_initial_projection=int(nl["do_initial_projection"]), device=device)
+                  init_iter=int(nl["init_iter"]), do_initial_projection=int(nl["do_initial_projection"]), device=device,
+                  fixed_dt=float(nl["fixed_dt"]), stop_time=float(nl["stop_time"]))
     decomp = tuple(max(1, -(-n[d] // mgs)) for d in range(dm)) + (1,) * (3 - dm)
     if int(nl["restart"]) >= 0:
         chk = plotfile.read_checkfile(os.path.join(outdir, "%s%05d" % (nl["check_base_name"], int(nl["restart"]))))
