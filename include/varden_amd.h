@@ -99,6 +99,9 @@ int  vdn_get_params(vdn_params *out);
 int  vdn_comm_get_unique_id(char *id128);
 int  vdn_comm_init(const char *id128);
 int  vdn_comm_finalize(void);
+/* MAX over the ranks of n host doubles, in place (parallel_reduce(..., MPI_MAX) of a Fortran driver; the file writers use it for the
+ * per-box minima / maxima and as their barrier).  No-op when nranks = 1. */
+int  vdn_comm_allreduce_max(double *host, int n);
 /* host-only introspection of the ghost-exchange plan (used by the CPU multi-process tests): the remote  */
 /* copies rank `as_rank` performs for a multifab (nc, ng, nodal) on the given boxes; rows of 14 longs:  */
 /* [kind 0=send 1=recv, peer, lo[3], hi[3], shift[3], buffer offset (doubles), dst box, src box]          */

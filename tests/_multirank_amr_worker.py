@@ -52,6 +52,10 @@ def main():
             out["u%d_%d" % (n, gi)] = G.unew[n].to_numpy(li)[3:-3, 3:-3, 3:-3]
             out["s%d_%d" % (n, gi)] = G.snew[n].to_numpy(li)[3:-3, 3:-3, 3:-3]
             out["p%d_%d" % (n, gi)] = G.p[n].to_numpy(li)[1:-1, 1:-1, 1:-1]
+    if tagged:                                             # plot and checkpoint files, every rank its own Cell_D file
+        from varden_amd import plotfile
+        plotfile.write_plotfile(G, base=outprefix + "_plt")
+        plotfile.write_checkfile(G, base=outprefix + "_chk")
     np.savez(outprefix + ".%d.npz" % rank, **out)
     G.close()
 

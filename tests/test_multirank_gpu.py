@@ -90,6 +90,18 @@ def test_tagged_grids_and_regrid_on_two_ranks(gpu, tmp_path):
     assert sorted(ref) == sorted(got)
     for k in sorted(ref):
         assert np.array_equal(ref[k], got[k]), "%s differs: max %.3e" % (k, np.abs(ref[k] - got[k]).max())
+    # the plot and checkpoint files of the two ranks (one Cell_D file per rank) read back as the files of the single rank
+    from varden_amd import plotfile
+    for kind, sub in (("_plt00004", ""), ("_chk00004", "State"), ("_chk00004", "Pressure")):
+        a = plotfile.read_ml_multifab(os.path.join(str(tmp_path / ("tref" + kind)), sub))
+        b = plotfile.read_ml_multifab(os.path.join(str(tmp_path / ("tmr" + kind)), sub))
+        assert a["nlevs"] == b["nlevs"] and a["time"] == b["time"] and a["names"] == b["names"]
+        for La, Lb in zip(a["levels"], b["levels"]):
+            assert La["boxes"] == Lb["boxes"]
+            for x, y in zip(La["fabs"], Lb["fabs"]):
+                assert np.array_equal(x, y)
+    assert os.path.exists(str(tmp_path / "tmr_plt00004" / "Level_01" / "Cell_D_00001"))
+    assert open(str(tmp_path / "tref_chk00004" / "Header")).read() == open(str(tmp_path / "tmr_chk00004" / "Header")).read()
 
 
 @pytest.mark.parametrize("nranks,nlev,visc", [(2, 2, 0.0), (3, 2, 0.001), (2, 3, 0.001)])

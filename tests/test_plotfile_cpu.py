@@ -61,3 +61,34 @@ def test_two_dimensional_boxes(tmp_path):
     assert r["dm"] == 2 and r["levels"][0]["boxes"] == lv[0]["boxes"] and tuple(r["levels"][0]["nodal"]) == (1, 1, 0)
     assert np.array_equal(r["levels"][0]["fabs"][0], lv[0]["fabs"][0])
     assert "((0,0) (16,8) (1,1))" in open(os.path.join(d, "Level_00", "Cell_H")).read()
+
+
+def test_two_writers_one_level_set(tmp_path):
+    """the several-ranks layout, two writers one after the other: each rank's fabs in its own Cell_D file, offsets from the box sizes,
+    minima / maxima combined by the MAX reduction, text files by rank 0 -- the reader sees one hierarchy"""
+    rng = np.random.default_rng(6)
+    lv = _levels(rng, nc=2)
+    owner = [[0], [1, 0]]
+    d = str(tmp_path / "two")
+    seen, turn = [], [0]
+
+    def keep(a):                           # rank 1 goes first: remember what it contributes, level by level
+        seen.append(a.copy())
+        return a
+
+    def combine(a):                        # rank 0: the MAX reduction with rank 1's contribution of the same level
+        turn[0] += 1
+        return np.maximum(a, seen[turn[0] - 1])
+
+    for rank, red in ((1, keep), (0, combine)):
+        mine = [dict(boxes=L["boxes"], nodal=L["nodal"], owner=ow, fabs={g: L["fabs"][g] for g in range(len(ow)) if ow[g] == rank}) for L, ow in zip(lv, owner)]
+        pf.write_ml_multifab(d, mine, [2], 3, pd=((0, 0, 0), (7, 7, 7)), nc=2, rank=rank, reduce_max=red)
+    r = pf.read_ml_multifab(d)
+    for L, R in zip(lv, r["levels"]):
+        assert R["boxes"] == L["boxes"]
+        for a, b in zip(L["fabs"], R["fabs"]):
+            assert np.array_equal(a, b)
+    ch = open(os.path.join(d, "Level_01", "Cell_H")).read().split("\n")
+    assert ch[8] == "FabOnDisk: Cell_D_00001 0" and ch[9] == "FabOnDisk: Cell_D_00000 0"
+    mins = [float(x) for x in ch[12].split(",")[:2]]
+    assert mins == [lv[1]["fabs"][0][..., c].min() for c in range(2)]

@@ -55,6 +55,13 @@ def comm_init(id128):
     _comm_up = True
 
 
+def comm_allreduce_max(a):
+    """MAX over the ranks of a float64 numpy array, in place (also the barrier of the file writers)"""
+    a = np.ascontiguousarray(a, dtype=np.float64)
+    check(capi.load().vdn_comm_allreduce_max(a.ctypes.data_as(C.POINTER(C.c_double)), a.size))
+    return a
+
+
 def comm_finalize():
     global _comm_up
     if _comm_up:

@@ -107,6 +107,7 @@ SIGNATURES = {
     "vdn_fillpatch": (C.c_int, [_VP, _VP, C.c_int, C.c_int]),
     "vdn_make_vorticity": (C.c_int, [_VP, C.c_int, _VP, C.POINTER(C.c_double), _VP]),
     "vdn_make_magvel": (C.c_int, [_VP, C.c_int, _VP]),
+    "vdn_comm_allreduce_max": (C.c_int, [C.POINTER(C.c_double), C.c_int]),
     "vdn_ml_nodal_prolongation": (C.c_int, [_VP, _VP]),
     "vdn_multifab_copy_layouts": (C.c_int, [_VP, C.c_int, _VP, C.c_int, C.c_int]),
     "vdn_make_new_grids": (C.c_int, [_VP, C.c_int, C.c_int, C.c_int, C.c_double, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(Box), _PI, C.POINTER(C.c_long)]),

@@ -103,6 +103,20 @@ void comm_allreduce_max_u8_dev(unsigned char *d, size_t n) {
   for (size_t off = 0; off < n; off += piece)
     NCCLCHK(g_rccl.AllReduce(d + off, d + off, std::min(piece, n - off), ncclUint8, ncclMax, g_rccl.comm, ctx().stream));
 }
+// host values (per-box minima / maxima of the plot files, barriers of the file writers): MAX over the ranks, in place
+extern "C" int vdn_comm_allreduce_max(double *host, int n) {
+  VDN_TRY
+  REQUIRE(ctx().inited && n >= 0, "vdn_comm_allreduce_max: not initialised");
+  if (!comm_active() || n == 0) return 0;
+  double *d = nullptr;
+  HIPCHK(hipMalloc((void **)&d, (size_t)n * sizeof(double)));
+  HIPCHK(hipMemcpyAsync(d, host, (size_t)n * sizeof(double), hipMemcpyHostToDevice, ctx().stream));
+  comm_allreduce_max_dev(d, n);
+  HIPCHK(hipMemcpyAsync(host, d, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, ctx().stream));
+  HIPCHK(hipStreamSynchronize(ctx().stream));
+  HIPCHK(hipFree(d));
+  VDN_CATCH
+}
 // all-gather: every rank contributes `count` doubles; recv holds nranks*count
 void comm_allgather_dev(const double *send, double *recv, size_t count) {
   if (!comm_active()) { if (send != recv) HIPCHK(hipMemcpyAsync(recv, send, count * sizeof(double), hipMemcpyDeviceToDevice, ctx().stream)); return; }

@@ -10,7 +10,10 @@ fabio itself is not part of the reference tree (EXT): the layout above is writte
 [EXT-UNVERIFIED] byte for byte (directory names, number formats); what the tests pin is that `read_ml_multifab` returns exactly what
 `write_ml_multifab` was given and that a run restarted from a checkpoint continues bit for bit.
 
-Host-side I/O of one rank: a run on several ranks would write one Cell_D file per rank, not done in this round."""
+Several ranks: every rank writes the fabs it owns into its own Cell_D_<rank:05d> of each level (FabOnDisk names the file, byte offsets
+follow from the box sizes alone, so no rank needs another's data), the per-fab minima / maxima are max-reduced over the ranks
+(vdn_comm_allreduce_max, which is also the barrier), rank 0 writes the text files.  One shared directory, i.e. one node or a
+shared file system."""
 import os
 import re
 
@@ -34,33 +37,50 @@ def _boxstr(lo, hi, nodal, dm):
 
 
 # ---- one level -----------------------------------------------------------------------------------------------------------------------
-def _write_level(dirname, prefix, boxes, nodal, fabs, dm):
-    """fabio_multifab_write_d: boxes = [(lo, hi)] cell boxes, fabs = arrays (nx, ny, nz, nc) of the valid points (incl. the nodal one)"""
+def _write_level(dirname, prefix, boxes, nodal, fabs, dm, nc=None, owner=None, rank=0, reduce_max=None):
+    """fabio_multifab_write_d: boxes = ALL (lo, hi) cell boxes of the level; fabs = arrays (nx, ny, nz, nc) of the valid points (incl. the
+    nodal one) -- a list for every box, or {global box index: array} for the boxes this rank owns (owner = rank of every box)"""
     os.makedirs(dirname, exist_ok=True)
-    nc = fabs[0].shape[3] if fabs else 0
-    dname = prefix + "_D_00000"
-    offs, mins, maxs = [], [], []
-    with open(os.path.join(dirname, dname), "wb") as f:
-        for (lo, hi), a in zip(boxes, fabs):
-            phi = tuple(hi[d] + nodal[d] for d in range(3))
-            assert a.shape[:3] == tuple(phi[d] - lo[d] + 1 for d in range(3)), (a.shape, lo, phi)
-            offs.append(f.tell())
-            f.write(("%s%s %d\n" % (FAB_DESC, _boxstr(lo, phi, nodal, dm), nc)).encode())
-            f.write(np.asfortranarray(a, dtype="<f8").tobytes(order="F"))
-            mins.append([float(a[..., c].min()) for c in range(nc)])
-            maxs.append([float(a[..., c].max()) for c in range(nc)])
+    if not isinstance(fabs, dict):
+        fabs = dict(enumerate(fabs))
+    if nc is None:
+        nc = next(iter(fabs.values())).shape[3]
+    owner = list(owner) if owner is not None else [0] * len(boxes)
+    fname = lambda r: "%s_D_%05d" % (prefix, r)   # noqa: E731
+    hdr = [("%s%s %d\n" % (FAB_DESC, _boxstr(lo, tuple(hi[d] + nodal[d] for d in range(3)), nodal, dm), nc)).encode() for lo, hi in boxes]
+    offs, pos = [], {}
+    for g, (lo, hi) in enumerate(boxes):                 # every rank's file holds its boxes in ascending global order
+        offs.append(pos.get(owner[g], 0))
+        pos[owner[g]] = offs[g] + len(hdr[g]) + 8 * nc * int(np.prod([hi[d] + nodal[d] - lo[d] + 1 for d in range(3)]))
+    mm = np.full((2, len(boxes), max(nc, 1)), -np.inf)   # [0] = -min, [1] = max: one MAX reduction serves both
+    mine = [g for g in range(len(boxes)) if owner[g] == rank]
+    if mine:
+        with open(os.path.join(dirname, fname(rank)), "wb") as f:
+            for g in mine:
+                lo, hi = boxes[g]
+                a = fabs[g]
+                assert a.shape == tuple(hi[d] + nodal[d] - lo[d] + 1 for d in range(3)) + (nc,), (a.shape, lo, hi, nodal, nc)
+                assert f.tell() == offs[g]
+                f.write(hdr[g])
+                f.write(np.asfortranarray(a, dtype="<f8").tobytes(order="F"))
+                mm[0, g, :nc] = [-float(a[..., c].min()) for c in range(nc)]
+                mm[1, g, :nc] = [float(a[..., c].max()) for c in range(nc)]
+    if reduce_max is not None:
+        mm = reduce_max(mm.reshape(-1)).reshape(mm.shape)
+    if rank != 0:
+        return
     with open(os.path.join(dirname, prefix + "_H"), "w") as f:
         f.write("1\n0\n%d\n0\n" % nc)                                   # version, how, ncomp, nghost
         f.write("(%d 0\n" % len(boxes))
         for lo, hi in boxes:
             f.write(_boxstr(lo, tuple(hi[d] + nodal[d] for d in range(3)), nodal, dm) + "\n")
         f.write(")\n%d\n" % len(boxes))
-        for o in offs:
-            f.write("FabOnDisk: %s %d\n" % (dname, o))
-        for rows in (mins, maxs):
+        for g in range(len(boxes)):
+            f.write("FabOnDisk: %s %d\n" % (fname(owner[g]), offs[g]))
+        for rows in (-mm[0], mm[1]):
             f.write("\n%d,%d\n" % (len(boxes), nc))
             for r in rows:
-                f.write("".join(_es(v) + "," for v in r) + "\n")
+                f.write("".join(_es(v) + "," for v in r[:nc]) + "\n")
 
 
 def _read_level(dirname, prefix):
@@ -89,11 +109,15 @@ def _read_level(dirname, prefix):
 
 
 # ---- a hierarchy (fabio_ml_multifab_write_d / _read_d) ---------------------------------------------------------------------------------
-def write_ml_multifab(dirname, levels, rr, dm=3, names=None, pd=None, prob_lo=None, prob_hi=None, time=0.0, dx=None):
-    """levels: per level dict(boxes=[(lo, hi)], nodal=(..), fabs=[arrays]); rr: refinement ratio between consecutive levels;
-    pd: (lo, hi) of the level-0 domain; dx: level-0 mesh spacing.  The optional arguments default as in fabio (names Var-i, unit box)."""
+def write_ml_multifab(dirname, levels, rr, dm=3, names=None, pd=None, prob_lo=None, prob_hi=None, time=0.0, dx=None, nc=None,
+                      rank=0, reduce_max=None):
+    """levels: per level dict(boxes=[(lo, hi)], nodal=(..), fabs=[arrays] or {box index: array}, owner=[rank of each box]);
+    rr: refinement ratio between consecutive levels; pd: (lo, hi) of the level-0 domain; dx: level-0 mesh spacing.  The optional
+    arguments default as in fabio (names Var-i, unit box).  Several ranks: everybody calls with its own fabs, see the module docstring."""
     nl = len(levels)
-    nc = levels[0]["fabs"][0].shape[3]
+    if nc is None:
+        f0 = levels[0]["fabs"]
+        nc = (next(iter(f0.values())) if isinstance(f0, dict) else f0[0]).shape[3]
     names = list(names) if names else ["Var-%d" % (i + 1) for i in range(nc)]
     if pd is None:                                                          # bounding box of level 0
         los, his = zip(*levels[0]["boxes"])
@@ -103,7 +127,10 @@ def write_ml_multifab(dirname, levels, rr, dm=3, names=None, pd=None, prob_lo=No
     dx = list(dx) if dx is not None else [(prob_hi[d] - prob_lo[d]) / (pd[1][d] - pd[0][d] + 1) for d in range(dm)]
     os.makedirs(dirname, exist_ok=True)
     for n, L in enumerate(levels):
-        _write_level(os.path.join(dirname, "Level_%02d" % n), "Cell", L["boxes"], L.get("nodal", (0, 0, 0)), L["fabs"], dm)
+        _write_level(os.path.join(dirname, "Level_%02d" % n), "Cell", L["boxes"], L.get("nodal", (0, 0, 0)), L["fabs"], dm, nc,
+                     L.get("owner"), rank, reduce_max)
+    if rank != 0:
+        return
     with open(os.path.join(dirname, "Header"), "w") as f:
         f.write("NavierStokes-V1.1\n%d\n" % nc)
         for s in names:
@@ -172,14 +199,22 @@ def _valid(mf, li):
     return a[g:a.shape[0] - g, g:a.shape[1] - g, gz:a.shape[2] - gz] if g else a
 
 
+def _owners(sim):
+    return [sim.owner] if sim.owner and isinstance(sim.owner[0], int) else list(sim.owner)
+
+
 def _gather(sim, mfs_per_level, nodal=(0, 0, 0)):
-    if getattr(sim, "nranks", 1) != 1:
-        raise NotImplementedError("plot / checkpoint files: one rank in this round")
     out = []
     for n, (boxes, local) in enumerate(_sim_levels(sim)):
-        fabs = [np.concatenate([_valid(mf[n], li) for mf in mfs_per_level], axis=3) for li in range(len(local))]
-        out.append(dict(boxes=[boxes[g] for g in local], nodal=nodal, fabs=fabs))
+        fabs = {gi: np.concatenate([_valid(mf[n], li) for mf in mfs_per_level], axis=3) for li, gi in enumerate(local)}
+        out.append(dict(boxes=list(boxes), nodal=nodal, fabs=fabs, owner=_owners(sim)[n]))
     return out
+
+
+def _par(sim):
+    """rank and the reduction of the writers"""
+    nr = getattr(sim, "nranks", 1)
+    return dict(rank=getattr(sim, "rank", 0), reduce_max=bl.comm_allreduce_max if nr > 1 else None)
 
 
 def plot_names(dm, nscal):
@@ -216,7 +251,7 @@ def write_plotfile(sim, istep=None, base="plt", prob_lo=None, prob_hi=None):
     name = "%s%05d" % (base, sim.istep if istep is None else istep)
     dx0 = list(sim.dx[0][:dm])
     hi = prob_hi if prob_hi is not None else [dx0[d] * (pd[1][d] + 1) for d in range(dm)]
-    write_ml_multifab(name, levels, [2] * (nl - 1), dm, plot_names(dm, ns), pd, prob_lo or [0.0] * dm, hi, sim.time, dx0)
+    write_ml_multifab(name, levels, [2] * (nl - 1), dm, plot_names(dm, ns), pd, prob_lo or [0.0] * dm, hi, sim.time, dx0, nc=ncomp, **_par(sim))
     return name
 
 
@@ -226,9 +261,12 @@ def write_checkfile(sim, istep=None, base="chk"):
     name = "%s%05d" % (base, sim.istep if istep is None else istep)
     pd, nl = _domain(sim)
     os.makedirs(name, exist_ok=True)
-    write_ml_multifab(os.path.join(name, "State"), _gather(sim, [sim.uold, sim.sold, sim.gp]), [2] * (nl - 1), sim.dm)
+    write_ml_multifab(os.path.join(name, "State"), _gather(sim, [sim.uold, sim.sold, sim.gp]), [2] * (nl - 1), sim.dm, pd=pd,
+                      nc=2 * sim.dm + sim.nscal, **_par(sim))
     nd = (1, 1, 1) if sim.dm == 3 else (1, 1, 0)
-    write_ml_multifab(os.path.join(name, "Pressure"), _gather(sim, [sim.p], nd), [2] * (nl - 1), sim.dm)
+    write_ml_multifab(os.path.join(name, "Pressure"), _gather(sim, [sim.p], nd), [2] * (nl - 1), sim.dm, pd=pd, nc=1, **_par(sim))
+    if getattr(sim, "rank", 0) != 0:
+        return name
     with open(os.path.join(name, "Header"), "w") as f:
         f.write("&CHKPOINT\n TIME=%s,\n DT=%s,\n NLEVS=%d,\n /\n" % (_es(sim.time).strip(), _es(sim.dt).strip(), nl))
         for _ in range(nl - 1):
