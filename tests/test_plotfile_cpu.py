@@ -89,6 +89,6 @@ def test_two_writers_one_level_set(tmp_path):
         for a, b in zip(L["fabs"], R["fabs"]):
             assert np.array_equal(a, b)
     ch = open(os.path.join(d, "Level_01", "Cell_H")).read().split("\n")
-    assert ch[8] == "FabOnDisk: Cell_D_00001 0" and ch[9] == "FabOnDisk: Cell_D_00000 0"
-    mins = [float(x) for x in ch[12].split(",")[:2]]
+    assert ch[9] == "FabOnDisk: Cell_D_00001 0" and ch[10] == "FabOnDisk: Cell_D_00000 0"
+    mins = [float(x) for x in ch[13].split(",")[:2]]
     assert mins == [lv[1]["fabs"][0][..., c].min() for c in range(2)]
