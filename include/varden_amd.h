@@ -274,8 +274,10 @@ int  vdn_nd_solve(vdn_multifab *rh, vdn_multifab *phi, const vdn_multifab *coeff
 
 /* ---- kernel timing (HIP events on the launch stream) for bench.py's roofline object ---------- */
 /* times `nlaunch` back-to-back launches of ONE colour pass of the cc smoother on the finest level
- * and returns the average milliseconds per launch and the number of cells one launch covers      */
-int  vdn_bench_cc_smoother(vdn_multifab *rh, vdn_multifab *phi, vdn_multifab **beta, const double *dx,
+ * and returns the average milliseconds per launch and the number of cells one launch covers.
+ * rho (may be NULL): the density behind beta = 2/(rho_i + rho_i-1); given, the pass is the one macproject runs (face coefficients
+ * recomputed from rho), otherwise the stored-coefficient pass of the viscous solves and the coarser levels       */
+int  vdn_bench_cc_smoother(vdn_multifab *rh, vdn_multifab *phi, vdn_multifab **beta, const vdn_multifab *rho, const double *dx,
                            const int *bc, int nlaunch, double *avg_ms, long *cells);
 
 #ifdef __cplusplus

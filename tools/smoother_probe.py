@@ -13,10 +13,16 @@ rh, phi = bl.MultiFab(mla, 0, 1, 0), bl.MultiFab(mla, 0, 1, 1)
 beta = [bl.MultiFab(mla, 0, 1, 0, tuple(1 if t == d else 0 for t in range(3))) for d in range(3)]
 rng = np.random.default_rng(0)
 r = rng.standard_normal((n, n, n, 1)); rh.from_numpy(r - r.mean())
-for d in range(3):
-    beta[d].from_numpy(rng.uniform(0.1, 1.0, size=beta[d].shape(0)))
-ms, cells = adv.bench_cc_smoother(rh, phi, beta, [1.0 / n] * 3, [[bl.BC_NEU] * 2] * 3, nl)
-print("smoother: %.5f ms/launch, %d cells, %.1f GB/s algorithmic (48 B/cell)" % (ms, cells, 48.0 * cells / ms / 1e6))
+rho = bl.MultiFab(mla, 0, 1, 1)
+ra = rng.uniform(1.0, 10.0, size=rho.shape(0))
+rho.from_numpy(ra)
+for d in range(3):      # beta = 2 / (rho_i + rho_i-1) on the faces, as mk_mac_coeffs builds it
+    hi_sl, lo_sl = [slice(1, -1)] * 3, [slice(1, -1)] * 3
+    hi_sl[d], lo_sl[d] = slice(1, None), slice(0, -1)
+    beta[d].from_numpy(2.0 / (ra[tuple(hi_sl)] + ra[tuple(lo_sl)]))
+stored = len(sys.argv) > 3 and sys.argv[3] == "stored"
+ms, cells = adv.bench_cc_smoother(rh, phi, beta, [1.0 / n] * 3, [[bl.BC_NEU] * 2] * 3, nl, rho=None if stored else rho)
+print("smoother (%s): %.5f ms/launch, %d cells, %.1f GB/s algorithmic (48 B/cell)" % ("stored beta" if stored else "beta from rho", ms, cells, 48.0 * cells / ms / 1e6))
 # calibration: k_copy of one component of an ng=0 multifab = n^3*8 B read + n^3*8 B written, 8 B/lane
 a, b = bl.MultiFab(mla, 0, 1, 0), bl.MultiFab(mla, 0, 1, 0)
 a.setval(1.0)

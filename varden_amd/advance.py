@@ -116,10 +116,12 @@ def nd_solve(rh, phi, coeffs, u, dx, bc, rel_eps, abs_eps=-1.0, max_iter=100):
     return cyc.value, r0.value, r.value
 
 
-def bench_cc_smoother(rh, phi, beta, dx, bc, nlaunch):
+def bench_cc_smoother(rh, phi, beta, dx, bc, nlaunch, rho=None):
+    """rho: the density behind beta -- the pass macproject runs (coefficients recomputed from rho); None: the stored-coefficient pass"""
     ms, cells = C.c_double(), C.c_long()
     flat = _iv([bc[d][s] for d in range(3) for s in range(2)])
-    check(capi.load().vdn_bench_cc_smoother(rh.h, phi.h, handle_array(beta), _dx(dx), flat, nlaunch, C.byref(ms), C.byref(cells)))
+    check(capi.load().vdn_bench_cc_smoother(rh.h, phi.h, handle_array(beta), rho.h if rho is not None else None, _dx(dx), flat, nlaunch,
+                                            C.byref(ms), C.byref(cells)))
     return ms.value, cells.value
 
 

@@ -123,7 +123,7 @@ SIGNATURES = {
     "vdn_cc_solve": (C.c_int, [_VP, _VP, _PVP, _PD, _PI, C.c_double, C.c_double, C.c_int, _PI, _PD, _PD]),
     "vdn_cc_smooth": (C.c_int, [_VP, _VP, _PVP, _PD, _PI, C.c_int]),
     "vdn_nd_solve": (C.c_int, [_VP, _VP, _VP, _VP, _PD, _PI, C.c_double, C.c_double, C.c_int, _PI, _PD, _PD]),
-    "vdn_bench_cc_smoother": (C.c_int, [_VP, _VP, _PVP, _PD, _PI, C.c_int, _PD, C.POINTER(C.c_long)]),
+    "vdn_bench_cc_smoother": (C.c_int, [_VP, _VP, _PVP, _VP, _PD, _PI, C.c_int, _PD, C.POINTER(C.c_long)]),
 }
 
 _lib = None

@@ -287,7 +287,7 @@ extern "C" int vdn_nd_solve(vdn_multifab *rh, vdn_multifab *phi, const vdn_multi
   if (rc != 0) vdn_fail("nodal multigrid did not converge: %d cycles, residual %g (rhs %g)", *cycles, *res, *res0);
   HOOK_END
 }
-extern "C" int vdn_bench_cc_smoother(vdn_multifab *rh, vdn_multifab *phi, vdn_multifab **beta, const double *dx, const int *bc,
+extern "C" int vdn_bench_cc_smoother(vdn_multifab *rh, vdn_multifab *phi, vdn_multifab **beta, const vdn_multifab *rho, const double *dx, const int *bc,
                                      int nlaunch, double *avg_ms, long *cells) {
-  HOOK_BEGIN(rh) int b[3][2]; bc_from_flat(bc, b); cc_bench_smoother(rh, phi, beta, dx, b, nlaunch, avg_ms, cells); HOOK_END
+  HOOK_BEGIN(rh) int b[3][2]; bc_from_flat(bc, b); cc_bench_smoother(rh, phi, beta, rho, dx, b, nlaunch, avg_ms, cells); HOOK_END
 }

@@ -23,17 +23,36 @@ struct CLev {
   double *phi, *rh, *res, *b[3];
   double *alpha;        // cell coefficient of (alpha - div b grad); nullptr when alpha = 0 (MAC projection)
   double *phi2;         // ping-pong partner of phi for the fused red+black sweep (nullptr when not used)
+  const double *rho;    // finest level of the MAC solve: density with one ghost layer, the face coefficients 2/(rho_i + rho_i-1) are
+  int fold[3][2];       //   recomputed from it (8 B/cell instead of 24); fold = bc type of the box faces that are domain faces
 };
 DEVI long cidx(const CLev &L, int i, int j, int k) { return (long)(i + 16) + (long)L.PX * ((long)(j + 1) + (long)L.PY * (long)(k + 1)); }
 
-// A phi and diag in the fixed expression order shared with the oracle (cc_apply in vo_macproject.c)
-DEVI void cc_apply(const CLev &L, long c, double &Ap, double &diag) {
+// the face coefficient of the MAC projection between two cells (macproject.f90:376-394) with the boundary folding of kk_cc_load:
+// the same expression and the same bits as the stored array
+DEVI double beta_of(double ra, double rb, bool at_face, int e) {
+  double v = 2.0 / (ra + rb);
+  if (at_face) { if (e == VDN_BC_NEU) v = 0.0; else if (e == VDN_BC_DIR) v = 2.0 * v; }
+  return v;
+}
+// A phi and diag in the fixed expression order shared with the oracle (cc_apply in vo_macproject.c).  RHO: the six face coefficients
+// come from the density (six divisions per cell instead of 24 B/cell of HBM traffic per pass; the kernels are HBM-bound)
+template <bool RHO = false> DEVI void cc_apply(const CLev &L, long c, double &Ap, double &diag, int i = 0, int j = 0, int k = 0) {
   const long sy = L.PX, sz = (long)L.PX * L.PY;
   const double p0 = L.phi[c];
-  const double bxm = L.b[0][c], bxp = L.b[0][c + 1];
-  const double bym = L.b[1][c], byp = L.b[1][c + sy];
-  const double bzm = L.b[2][c], bzp = L.b[2][c + sz];
-  const double ax = (bxp * (p0 - L.phi[c + 1]) + bxm * (p0 - L.phi[c - 1])) * L.hi2[0];
+  const double pxm = L.phi[c - 1], pxp = L.phi[c + 1];
+  double bxm, bxp, bym, byp, bzm, bzp;
+  if (RHO) {
+    const double r0 = L.rho[c];
+    bxm = beta_of(r0, L.rho[c - 1], i == 0, L.fold[0][0]);  bxp = beta_of(L.rho[c + 1], r0, i == L.n[0] - 1, L.fold[0][1]);
+    bym = beta_of(r0, L.rho[c - sy], j == 0, L.fold[1][0]); byp = beta_of(L.rho[c + sy], r0, j == L.n[1] - 1, L.fold[1][1]);
+    bzm = beta_of(r0, L.rho[c - sz], k == 0, L.fold[2][0]); bzp = beta_of(L.rho[c + sz], r0, k == L.n[2] - 1, L.fold[2][1]);
+  } else {
+    bxm = L.b[0][c]; bxp = L.b[0][c + 1];
+    bym = L.b[1][c]; byp = L.b[1][c + sy];
+    bzm = L.b[2][c]; bzp = L.b[2][c + sz];
+  }
+  const double ax = (bxp * (p0 - pxp) + bxm * (p0 - pxm)) * L.hi2[0];
   const double ay = (byp * (p0 - L.phi[c + sy]) + bym * (p0 - L.phi[c - sy])) * L.hi2[1];
   const double az = (bzp * (p0 - L.phi[c + sz]) + bzm * (p0 - L.phi[c - sz])) * L.hi2[2];
   Ap = ax + ay + az;
@@ -46,14 +65,24 @@ DEVI void cc_apply(const CLev &L, long c, double &Ap, double &diag) {
 }
 
 // one colour pass of red-black Gauss-Seidel: thread t of a row updates cell i = 2t + ((j+k+color)&1)
-__global__ void __launch_bounds__(256) kk_cc_gsrb(CLev L, int color) {
-  const int j = blockIdx.y * blockDim.y + threadIdx.y;
-  const int k = blockIdx.z;
-  const int i = 2 * (int)(blockIdx.x * blockDim.x + threadIdx.x) + ((j + k + color) & 1);
+// (measured at 256^3 and rejected: several k-planes per workgroup 0.161 ms, the x-triplet as one 16-byte load per lane plus lane
+// exchange 0.230 ms, against 0.144 ms for this form -- the pass lives on many short independent waves)
+template <bool RHO> DEVI void cc_gsrb_cell(const CLev &L, int color) {
+  int bx, by, bz; xcd_block(bx, by, bz);
+  const int j = by * blockDim.y + threadIdx.y;
+  const int k = bz;
+  const int i = 2 * (int)(bx * blockDim.x + threadIdx.x) + ((j + k + color) & 1);
   if (i >= L.n[0] || j >= L.n[1]) return;
   const long c = cidx(L, i, j, k);
-  double Ap, diag; cc_apply(L, c, Ap, diag);
+  double Ap, diag; cc_apply<RHO>(L, c, Ap, diag, i, j, k);
   if (diag != 0.0) L.phi[c] = L.phi[c] + (L.rh[c] - Ap) / diag;
+}
+__global__ void __launch_bounds__(256) kk_cc_gsrb(CLev L, int color) { cc_gsrb_cell<false>(L, color); }
+__global__ void __launch_bounds__(256) kk_cc_gsrb_rho(CLev L, int color) { cc_gsrb_cell<true>(L, color); }
+static inline void launch_gsrb(const CLev &L, int color, hipStream_t st) {
+  const dim3 blk(64, 4, 1), g((unsigned)(((L.n[0] + 1) / 2 + 63) / 64), (unsigned)((L.n[1] + 3) / 4), (unsigned)L.n[2]);
+  if (L.rho) hipLaunchKernelGGL(kk_cc_gsrb_rho, g, blk, 0, st, L, color);
+  else hipLaunchKernelGGL(kk_cc_gsrb, g, blk, 0, st, L, color);
 }
 
 // ---- fused red+black sweep ---------------------------------------------------------------------------------------
@@ -267,20 +296,23 @@ static void cc_launch_wave(CLev &L, int nsweeps) {
   }
 }
 
-__global__ void __launch_bounds__(256) kk_cc_residual(CLev L, double *nrm) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  const int j = blockIdx.y * blockDim.y + threadIdx.y;
+template <bool RHO> DEVI void cc_residual_body(const CLev &L, double *nrm) {
+  int bx, by, bz; xcd_block(bx, by, bz);
+  const int i = bx * blockDim.x + threadIdx.x;
+  const int j = by * blockDim.y + threadIdx.y;
   double rmax = 0.0;
   if (i < L.n[0] && j < L.n[1])
-    for (int k = blockIdx.z; k < L.n[2]; k += gridDim.z) {
+    for (int k = bz; k < L.n[2]; k += gridDim.z) {
       const long c = cidx(L, i, j, k);
-      double Ap, diag; cc_apply(L, c, Ap, diag);
+      double Ap, diag; cc_apply<RHO>(L, c, Ap, diag, i, j, k);
       const double r = L.rh[c] - Ap;
       L.res[c] = r;
       rmax = fmax(rmax, fabs(r));
     }
   if (nrm) block_atomic_max(nrm, rmax);
 }
+__global__ void __launch_bounds__(256) kk_cc_residual(CLev L, double *nrm) { cc_residual_body<false>(L, nrm); }
+__global__ void __launch_bounds__(256) kk_cc_residual_rho(CLev L, double *nrm) { cc_residual_body<true>(L, nrm); }
 
 __global__ void kk_cc_restrict(CLev F, CLev C) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -398,6 +430,14 @@ __global__ void kk_cc_load(CLev L, FV rh, FV phi, FV alpha, FV bx, FV by, FV bz,
     if (e == VDN_BC_NEU) v = 0.0; else if (e == VDN_BC_DIR) v = 2.0 * v;
     L.b[2][c] = v;
   }
+}
+// the density with its ghost layer, for the on-the-fly face coefficients of the finest level
+__global__ void kk_cc_load_rho(CLev L, double *dst, FV rho, int lo0, int lo1, int lo2) {
+  const int i = (int)(blockIdx.x * blockDim.x + threadIdx.x) - 1;
+  const int j = (int)(blockIdx.y * blockDim.y + threadIdx.y) - 1;
+  const int k = (int)blockIdx.z - 1;
+  if (i > L.n[0] || j > L.n[1] || k > L.n[2]) return;
+  dst[cidx(L, i, j, k)] = fv_get(rho, lo0 + i, lo1 + j, lo2 + k);
 }
 // right-hand side, with the inhomogeneous Dirichlet data moved into it: the ghost cells of the incoming phi hold the
 // boundary-FACE values (multifab_physbc EXT_DIR; visc_solve hands unew over that way, viscsolve.f90:270); the face term
@@ -545,7 +585,8 @@ static CLev cc_alloc_lev(const int n[3], const double h[3], bool has_alpha) {
   L.phi = base; L.rh = base + L.sz; L.res = base + 2 * L.sz;
   for (int d = 0; d < 3; d++) L.b[d] = base + (3 + d) * L.sz;
   L.alpha = has_alpha ? base + 6 * L.sz : nullptr;
-  L.phi2 = nullptr;
+  L.phi2 = nullptr; L.rho = nullptr;
+  for (int d = 0; d < 3; d++) L.fold[d][0] = L.fold[d][1] = VDN_BC_INT;
   return L;
 }
 static FV cc_phi_view(const CLev &L, const int lo[3]) {
@@ -692,15 +733,18 @@ static void cc_gsrb_d(CCMG &M, CDLev &DL, int nsweeps) {
     cc_halo(M, DL);
     for (const CBox &B : DL.boxes) {
       const int c = (color + B.lo[0] + B.lo[1] + B.lo[2]) & 1;       // colour by GLOBAL cell index
-      hipLaunchKernelGGL(kk_cc_gsrb, g3((B.L.n[0] + 1) / 2, B.L.n[1], B.L.n[2], BLK), BLK, 0, ctx().stream, B.L, c);
+      launch_gsrb(B.L, c, ctx().stream);
     }
   }
 }
 static void cc_residual_d(CCMG &M, CDLev &DL, bool norm) {
   cc_halo(M, DL);
   if (norm) HIPCHK(hipMemsetAsync(M.d_nrm, 0, sizeof(double), ctx().stream));
-  for (const CBox &B : DL.boxes)
-    hipLaunchKernelGGL(kk_cc_residual, g3(B.L.n[0], B.L.n[1], norm ? std::min(B.L.n[2], 16) : B.L.n[2], BLK), BLK, 0, ctx().stream, B.L, norm ? M.d_nrm : nullptr);
+  for (const CBox &B : DL.boxes) {
+    const dim3 g = g3(B.L.n[0], B.L.n[1], norm ? std::min(B.L.n[2], 16) : B.L.n[2], BLK);
+    if (B.L.rho) hipLaunchKernelGGL(kk_cc_residual_rho, g, BLK, 0, ctx().stream, B.L, norm ? M.d_nrm : nullptr);
+    else hipLaunchKernelGGL(kk_cc_residual, g, BLK, 0, ctx().stream, B.L, norm ? M.d_nrm : nullptr);
+  }
   if (norm) comm_allreduce_max_dev(M.d_nrm, 1);
 }
 static double read_scalar(double *d) {
@@ -723,7 +767,7 @@ static void cc_gsrb_t(const CCMG &M, const CLev &L, int nsweeps) {
   }
   for (int s = 0; s < nsweeps; s++) for (int color = 0; color < 2; color++) {
     cc_periodic_t(M, L);
-    hipLaunchKernelGGL(kk_cc_gsrb, g3((L.n[0] + 1) / 2, L.n[1], L.n[2], BLK), BLK, 0, ctx().stream, L, color);
+    launch_gsrb(L, color, ctx().stream);
   }
 }
 static void cc_bottom_t(const CCMG &M, const CLev &L) {      // max(nub, N^2) sweeps, N = largest extent (same rule as the oracle)
@@ -793,13 +837,18 @@ static void cc_vcycle_d(CCMG &M, int l) {
   cc_gsrb_d(M, DL, P.mg_nu2);
 }
 
-static void cc_setup(CCMG &M, vdn_multifab *rh, vdn_multifab *phi, const vdn_multifab *alpha, vdn_multifab **beta, const double *dx, const int bc[3][2]) {
+// VDN_MAC_STORED_BETA=1: the finest level reads the stored face coefficients like the others (the measured alternative of DESIGN.md section 4)
+static bool beta_from_rho() { static const bool b = !(getenv("VDN_MAC_STORED_BETA") && atoi(getenv("VDN_MAC_STORED_BETA")) != 0); return b; }
+static void cc_setup(CCMG &M, vdn_multifab *rh, vdn_multifab *phi, const vdn_multifab *alpha, vdn_multifab **beta, const double *dx, const int bc[3][2],
+                     const vdn_multifab *rho = nullptr) {
   REQUIRE(phi->ng >= 1, "cc multigrid: phi needs one ghost cell");
   cc_build(M, rh, dx, bc, alpha != nullptr);
   const vdn_layout *la = rh->la; const int lev = rh->lev;
   CDLev &D0 = M.dlev[0];
+  // beta = 2 / (rho_i + rho_i-1) (the MAC projection): the finest level recomputes it from rho; not with the fused sweeps (they read b)
+  const bool from_rho = rho && !alpha && beta_from_rho() && rho->ng >= 1 && !(D0.boxes.size() && D0.boxes[0].L.phi2);
   for (size_t b = 0; b < D0.boxes.size(); b++) {
-    const CLev &L0 = D0.boxes[b].L;
+    CLev &L0 = D0.boxes[b].L;
     const vdn_box &bx = rh->vbox[b];
     // boundary folding only on faces that are DOMAIN faces
     int e[3][2];
@@ -812,6 +861,12 @@ static void cc_setup(CCMG &M, vdn_multifab *rh, vdn_multifab *phi, const vdn_mul
                        e[0][0], e[0][1], e[1][0], e[1][1], e[2][0], e[2][1]);
     hipLaunchKernelGGL(kk_cc_load_rh, g3(L0.n[0], L0.n[1], L0.n[2], BLK), BLK, 0, ctx().stream, L0, rh->fabs[b], phi->fabs[b],
                        bx.lo[0], bx.lo[1], bx.lo[2], e[0][0], e[0][1], e[1][0], e[1][1], e[2][0], e[2][1]);
+    if (from_rho) {
+      double *r = (double *)arena_alloc(sizeof(double) * L0.sz);
+      hipLaunchKernelGGL(kk_cc_load_rho, g3(L0.n[0] + 2, L0.n[1] + 2, L0.n[2] + 2, BLK), BLK, 0, ctx().stream, L0, r, rho->fabs[b], bx.lo[0], bx.lo[1], bx.lo[2]);
+      L0.rho = r;
+      for (int d = 0; d < 3; d++) { L0.fold[d][0] = e[d][0]; L0.fold[d][1] = e[d][1]; }
+    }
   }
   for (size_t l = 1; l < M.dlev.size(); l++)
     for (size_t b = 0; b < M.dlev[l].boxes.size(); b++) {
@@ -862,11 +917,11 @@ static void cc_store(CCMG &M, vdn_multifab *phi, const int bc[3][2]) {
 }
 
 int cc_solve(vdn_multifab *rh, vdn_multifab *phi, vdn_multifab **beta, const double *dx, const int bc[3][2],
-             double rel_eps, double abs_eps, int max_iter, int *cycles, double *res0, double *res, const vdn_multifab *alpha) {
+             double rel_eps, double abs_eps, int max_iter, int *cycles, double *res0, double *res, const vdn_multifab *alpha, const vdn_multifab *rho) {
   if (ctx().prm.dm == 2) return cc2_solve(rh, phi, beta, dx, bc, rel_eps, abs_eps, max_iter, cycles, res0, res, alpha);
   const vdn_params &P = ctx().prm;
   size_t mark = arena_mark();
-  CCMG M; cc_setup(M, rh, phi, alpha, beta, dx, bc);
+  CCMG M; cc_setup(M, rh, phi, alpha, beta, dx, bc, rho);
   CDLev &D0 = M.dlev[0];
   const bool single = (M.dlev.size() == 1 && M.tail.empty());
   if (max_iter < 0) {            // exactly -max_iter V-cycles, no norms, no convergence test (the coarse correction of the composite solves)
@@ -915,10 +970,10 @@ void cc_smooth(vdn_multifab *rh, vdn_multifab *phi, vdn_multifab **beta, const d
   arena_release(mark);
 }
 
-void cc_bench_smoother(vdn_multifab *rh, vdn_multifab *phi, vdn_multifab **beta, const double *dx, const int bc[3][2],
+void cc_bench_smoother(vdn_multifab *rh, vdn_multifab *phi, vdn_multifab **beta, const vdn_multifab *rho, const double *dx, const int bc[3][2],
                        int nlaunch, double *avg_ms, long *cells) {
   size_t mark = arena_mark();
-  CCMG M; cc_setup(M, rh, phi, nullptr, beta, dx, bc);
+  CCMG M; cc_setup(M, rh, phi, nullptr, beta, dx, bc, rho);
   REQUIRE(M.dlev[0].boxes.size() == 1, "smoother probe: one local box expected");
   const CLev &L = M.dlev[0].boxes[0].L;
   hipStream_t st = ctx().stream;
@@ -930,9 +985,9 @@ void cc_bench_smoother(vdn_multifab *rh, vdn_multifab *phi, vdn_multifab **beta,
     cc_launch_fused(Lm, nlaunch / 2);
     HIPCHK(hipEventRecord(e1, st));
   } else {
-  for (int w = 0; w < 4; w++) hipLaunchKernelGGL(kk_cc_gsrb, g3((L.n[0] + 1) / 2, L.n[1], L.n[2], BLK), BLK, 0, st, L, w & 1);
+  for (int w = 0; w < 4; w++) launch_gsrb(L, w & 1, st);
   HIPCHK(hipEventRecord(e0, st));
-  for (int w = 0; w < nlaunch; w++) hipLaunchKernelGGL(kk_cc_gsrb, g3((L.n[0] + 1) / 2, L.n[1], L.n[2], BLK), BLK, 0, st, L, w & 1);
+  for (int w = 0; w < nlaunch; w++) launch_gsrb(L, w & 1, st);
   HIPCHK(hipEventRecord(e1, st));
   }
   HIPCHK(hipEventSynchronize(e1));
@@ -1037,7 +1092,7 @@ void do_macproject(vdn_layout *mla, vdn_multifab **umac, vdn_multifab **rho, vdn
   int ebc[3][2];
   for (int d = 0; d < 3; d++) for (int s = 0; s < 2; s++) ebc[d][s] = bct->ell_bc(n, 0, d, s, bc_comp0);   // grid 0 = whole domain
   int cyc; double r0, rr;
-  int rc = cc_solve(rh, phi, beta, dx, ebc, ctx().prm.mac_rel_eps, -1.0, ctx().prm.mg_max_iter, &cyc, &r0, &rr);   // macproject.f90:91-93
+  int rc = cc_solve(rh, phi, beta, dx, ebc, ctx().prm.mac_rel_eps, -1.0, ctx().prm.mg_max_iter, &cyc, &r0, &rr, nullptr, rho[n]);   // macproject.f90:91-93
   ctx().solver_cycles[0] = cyc; ctx().solver_res0[0] = r0; ctx().solver_res[0] = rr;
   if (rc != 0 && ctx().prm.verbose) fprintf(stderr, "varden_amd: MAC multigrid did not converge in %d cycles (res %g / %g)\n", cyc, rr, r0);
   mac_level_mkumac(um, phi, beta, dx, bct, bc_comp0);

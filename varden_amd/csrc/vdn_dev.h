@@ -43,6 +43,22 @@ static inline dim3 grid_for(const Range3 &r, dim3 block = dim3(64, 4, 1)) {
   const bool in_range = (i <= (r).hi[0]) && (j <= (r).hi[1]) && (k <= (r).hi[2]);
 
 DEVI void block_atomic_max_fwd(double *addr, double v);
+// ---- XCD-aware tile order ---------------------------------------------------------------------------------------------------------
+// Workgroups are dealt round-robin over the 8 XCDs, each with its own L2 (blocks b and b + 8 share one).  With the natural order the
+// (x, y) tiles of a k-plane that one XCD works on are scattered over the plane, and every tile's halo rows are fetched into that XCD's
+// L2 on their own (kk_cc_gsrb at 256^3: 64 x 4 tiles, phi and rho cost 1.5x their size per pass).  This remap gives each XCD one
+// contiguous band of tiles per plane, all XCDs marching through the planes together: the halo rows are shared inside the band.
+// Speed only: the mapping is a bijection of the grid (needs gridDim.x * gridDim.y divisible by 8, identity otherwise).
+DEVI void xcd_block(int &bx, int &by, int &bz) {
+  const int gx = gridDim.x, gy = gridDim.y, T = gx * gy;
+  bx = blockIdx.x; by = blockIdx.y; bz = blockIdx.z;
+  if ((T & 7) || T < 16) return;
+  const int id = bx + gx * (by + gy * bz);
+  const int per = T >> 3, slot = id >> 3;
+  const int t = (id & 7) * per + slot % per;
+  bz = slot / per; bx = t % gx; by = t / gx;
+}
+
 // ---- box-batched launches -------------------------------------------------------------------------------------------------------
 // A level of an adaptive hierarchy can hold hundreds of small boxes; one launch per box and operation makes such levels
 // launch-bound (measured: 480 000 launches of ~4 us for two steps on a 271-box level).  A batched kernel takes an array of per-box

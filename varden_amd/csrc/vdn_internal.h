@@ -171,9 +171,9 @@ void do_macproject(vdn_layout *mla, vdn_multifab **umac, vdn_multifab **rho, vdn
                    const vdn_bc_tower *bct, int bc_comp0);
 int  cc_solve(vdn_multifab *rh, vdn_multifab *phi, vdn_multifab **beta, const double *dx, const int bc[3][2],
               double rel_eps, double abs_eps, int max_iter, int *cycles, double *res0, double *res,
-              const vdn_multifab *alpha = nullptr);
+              const vdn_multifab *alpha = nullptr, const vdn_multifab *rho = nullptr);   // rho: beta = 2/(rho_i + rho_i-1), recomputed on the finest level
 void cc_smooth(vdn_multifab *rh, vdn_multifab *phi, vdn_multifab **beta, const double *dx, const int bc[3][2], int nsweeps);
-void cc_bench_smoother(vdn_multifab *rh, vdn_multifab *phi, vdn_multifab **beta, const double *dx, const int bc[3][2],
+void cc_bench_smoother(vdn_multifab *rh, vdn_multifab *phi, vdn_multifab **beta, const vdn_multifab *rho, const double *dx, const int bc[3][2],
                        int nlaunch, double *avg_ms, long *cells);
 // viscous.hip
 void k_explicit_diffusive_term(vdn_multifab *lap, const vdn_multifab *data, int comp, int bccomp0, const double *dx, const vdn_bc_tower *bct);
