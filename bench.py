@@ -138,7 +138,7 @@ def main():
         # HBM traffic per launch from the PMC passes (FETCH_SIZE x2 + WRITE_SIZE, MI355X_MICROARCH.md), collected
         # separately with `rocprofv3 --pmc` on tools/smoother_probe.py and committed under profiles/
         traffic = None
-        pmc = os.path.join(ROOT, "profiles", "r01_smoother_pmc.json")
+        pmc = os.path.join(ROOT, "profiles", "r01_smoother_rho_pmc.json")        # the kernel timed above (kk_cc_gsrb_rho)
         if n == 256 and os.path.exists(pmc):
             traffic = json.load(open(pmc))["hbm_bytes_per_launch"]
         roof = {"bound": "hbm", "kernel": "kk_cc_gsrb_rho (MAC-MG red-black GS colour pass, %d^3; beta recomputed from rho: 32 B/cell of real traffic "
