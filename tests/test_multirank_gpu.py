@@ -104,12 +104,13 @@ def test_tagged_grids_and_regrid_on_two_ranks(gpu, tmp_path):
     assert open(str(tmp_path / "tref_chk00004" / "Header")).read() == open(str(tmp_path / "tmr_chk00004" / "Header")).read()
 
 
-@pytest.mark.parametrize("nranks,nlev,visc", [(2, 2, 0.0), (3, 2, 0.001), (2, 3, 0.001)])
+@pytest.mark.parametrize("nranks,nlev,visc", [(2, 2, 0.0), (3, 2, 0.001), (2, 3, 0.001), (5, 3, 0.001)])
 def test_amr_ranks_reproduce_single_rank(gpu, tmp_path, nranks, nlev, visc):
     """SURVEY.md section 8(e), "multi-level extras", on ONE GPU: the boxes of every level of a fixed hierarchy are dealt to 2 / 3 ranks by cell
     count (a fine box and the coarse boxes under it usually sit on different ranks); start-up sequence + two steps (composite MAC,
     viscous and nodal solves, average-down, coarse-fine ghost interpolation, flux matching -- all through windows of remote boxes)
-    reproduce the single-rank run on the same boxes bit for bit.  Transport: the RCCL test double (see the module docstring)."""
+    reproduce the single-rank run on the same boxes bit for bit.  Five ranks: more ranks than boxes on every level (4, 3, 2 boxes), so
+    some ranks own nothing on a level and still take part in every collective.  Transport: the RCCL test double (see the module docstring)."""
     ref = run_amr_ranks(tmp_path, "aref", 1, nlev, visc)
     got = run_amr_ranks(tmp_path, "amr", nranks, nlev, visc)
     assert sorted(ref) == sorted(got)
