@@ -65,8 +65,9 @@ template <bool RHO = false> DEVI void cc_apply(const CLev &L, long c, double &Ap
 }
 
 // one colour pass of red-black Gauss-Seidel: thread t of a row updates cell i = 2t + ((j+k+color)&1)
-// (measured at 256^3 and rejected: several k-planes per workgroup 0.161 ms, the x-triplet as one 16-byte load per lane plus lane
-// exchange 0.230 ms, against 0.144 ms for this form -- the pass lives on many short independent waves)
+// (measured at 256^3 and rejected: several k-planes per workgroup 0.161 ms; the x-triplet as one 16-byte load per lane plus lane
+// exchange 0.230 ms; all rows staged through LDS as aligned 16-byte pairs, even and odd cells in separate LDS rows so that every global
+// load is a full line and every LDS read unit-stride, 0.157 ms -- against 0.141-0.144 ms for this form)
 template <bool RHO> DEVI void cc_gsrb_cell(const CLev &L, int color) {
   int bx, by, bz; xcd_block(bx, by, bz);
   const int j = by * blockDim.y + threadIdx.y;
