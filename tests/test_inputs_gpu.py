@@ -83,7 +83,7 @@ def test_checkpoint_and_restart_from_inputs(gpu, tmp_path):
     ends in the same bits as the uninterrupted run; the plot file of step 4 lists the same boxes"""
     from varden_amd import inputs, plotfile
     text = open(os.path.join(INP, "inputs_bubble_3d")).read().replace("verbose = 1", "verbose = 0")
-    text = text.replace("chk_int   = 100", "chk_int   = 2").replace("plot_int  = 10", "plot_int  = 4")
+    text = text.replace("chk_int   = 100", "chk_int   = 2").replace("plot_int  = 10", "plot_int  = 4\n grids_file_name = 'grids.out'")
     assert "chk_int   = 2" in text and "plot_int  = 4" in text
 
     def valid(G):
@@ -94,6 +94,10 @@ def test_checkpoint_and_restart_from_inputs(gpu, tmp_path):
     names = [os.path.basename(f) for f in A.files_written]
     assert names == ["plt00000", "chk00000", "chk00002", "plt00004", "chk00004"], names
     ref, boxes, tA = valid(A), A.boxes, A.time
+    grids = open(str(tmp_path / "grids.out")).read()
+    assert grids.count("At step") == 1 + A.nregrids and ("   ((0, 0, 0) (31, 31, 31) (0,0,0))    1\n") in grids
+    info = open(str(tmp_path / "plt00004" / "job_info")).read()
+    assert "Grid Information" in info and "no slip wall" in info and "max_levs" in info
     A.close()
     nl, B = inputs.run(text.replace("&PROBIN", "&PROBIN\n restart = 2"), 4, None, outdir=str(tmp_path))
     assert B.istep == 4 and B.time == tA and B.boxes == boxes

@@ -412,3 +412,50 @@ def test_amr_two_level_bubble(oracle):
     s0 = S.snew[0].valid()[4:12, 4:12, 4:12, 0]
     assert np.abs(s0 - s1.reshape(8, 2, 8, 2, 8, 2).mean(axis=(1, 3, 5))).max() < 1e-13
     assert S.unew[1].valid()[..., 2].min() < 0.0          # the heavy bubble sinks
+
+
+def test_vorticity_of_known_flows(oracle):
+    """makevort.f90: next to an inflow / no-slip face the three-point one-sided difference takes the ghost cell as the value ON the
+    face (the EXT_DIR convention of multifab_physbc), so with such ghosts a linear velocity field is differentiated exactly everywhere:
+    solid-body rotation about z gives |curl u| = 2*omega, a pure strain (potential) flow gives 0; |u| is the norm.
+    2-D: v_x - u_y = 2*omega in the interior; on INLET / wall columns the reference divides the three-point form by dx instead of
+    3 dx (makevort.f90:120, 130), i.e. three times the derivative there -- kept, and pinned here."""
+    L = oracle.lib()
+    n, om = 8, 0.75
+    dx = [1.0 / n] * 3
+    lo, hi = (0, 0, 0), (n - 1,) * 3
+
+    def coords(phys, fixed):
+        xs = []
+        for d in range(3):
+            x = (np.arange(-1, n + 1) + 0.5) / n
+            if phys[d][0] in fixed:
+                x[0] = 0.0                       # the ghost cell holds the face value
+            if phys[d][1] in fixed:
+                x[-1] = 1.0
+            xs.append(x)
+        return np.meshgrid(*xs, indexing="ij")
+
+    for phys in (WALLS, [[11, 12], [14, 14], [-1, -1]], [[15, 11], [11, 15], [15, 15]]):
+        X, Y, Z = coords(phys, (11, 15))                                 # makevort.f90:188-195: INLET and NO_SLIP_WALL only
+        bc = oracle.make_bc(phys)
+        u = oracle.Fab(lo, hi, 1, 3)
+        u.a[..., 0], u.a[..., 1], u.a[..., 2] = -om * Y, om * X, 0.25
+        out = oracle.Fab(lo, hi, 0, 2)
+        L.vo_makevort(out.ref, 1, u.ref, oracle.dvec(dx), C.byref(bc))
+        L.vo_makemagvel(out.ref, 0, u.ref)
+        assert np.allclose(out.a[..., 1], 2 * om, rtol=0, atol=1e-12)
+        assert np.allclose(out.a[..., 0], np.sqrt(u.a[1:-1, 1:-1, 1:-1, 0] ** 2 + u.a[1:-1, 1:-1, 1:-1, 1] ** 2 + 0.0625), rtol=0, atol=1e-15)
+        u.a[..., 0], u.a[..., 1], u.a[..., 2] = X + Z, Y, X - 2.0 * Z     # u = grad(x^2/2 + y^2/2 - z^2 + x z): curl-free
+        L.vo_makevort(out.ref, 1, u.ref, oracle.dvec(dx), C.byref(bc))
+        assert np.abs(out.a[..., 1]).max() < 1e-12
+    # 2-D: walls in x (slip walls count in 2-D, makevort.f90:116-117), periodic in y
+    phys2 = [[14, 15], [-1, -1], [0, 0]]
+    X, Y, _ = coords(phys2, (11, 14, 15))
+    bc2 = oracle.make_bc(phys2, 2)
+    u2 = oracle.Fab((0, 0), (n - 1, n - 1), 1, 2, dm=2)
+    u2.a[:, :, 0, 0], u2.a[:, :, 0, 1] = -om * Y[:, :, 0], om * X[:, :, 0]
+    o2 = oracle.Fab((0, 0), (n - 1, n - 1), 0, 1, dm=2)
+    L.vo_makevort(o2.ref, 0, u2.ref, oracle.dvec(dx), C.byref(bc2))
+    assert np.allclose(o2.a[1:-1, :, 0, 0], 2 * om, atol=1e-12)                     # interior columns
+    assert np.allclose(o2.a[0, :, 0, 0], 3 * om + om, atol=1e-12) and np.allclose(o2.a[-1, :, 0, 0], 3 * om + om, atol=1e-12)   # v_x three times too large

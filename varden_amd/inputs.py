@@ -16,7 +16,7 @@ DEFAULTS = dict(dim_in=2, nscal=2, prob_type=1, grav=0.0, boussinesq=0, max_step
                 init_iter=4, do_initial_projection=1, init_shrink=1.0, cflfac=0.8, max_dt_growth=1.1, visc_coef=0.0, diff_coef=0.0,
                 diffusion_type=1, slope_order=4, use_minion=0, stencil_order=2, verbose=0, mg_verbose=0,
                 bcx_lo=14, bcx_hi=14, bcy_lo=14, bcy_hi=14, bcz_lo=14, bcz_hi=14,
-                fixed_dt=-1.0, plot_int=0, chk_int=0, restart=-1, plot_base_name="plt", check_base_name="chk")
+                fixed_dt=-1.0, plot_int=0, chk_int=0, restart=-1, plot_base_name="plt", check_base_name="chk", grids_file_name="", job_name="")
 
 
 def parse_namelist(text):
@@ -91,6 +91,11 @@ def run(text, nsteps=None, report=print, device=0, outdir="."):
     stop_time = float(nl["stop_time"])
     plot_int, chk_int = int(nl["plot_int"]), int(nl["chk_int"])
     G.files_written = []
+    G.inputs_text, G.job_name = text, str(nl["job_name"])
+    grids_file = os.path.join(outdir, str(nl["grids_file_name"])) if nl["grids_file_name"] else None
+    if grids_file and int(nl["restart"]) < 0 and hasattr(G, "nregrids"):
+        plotfile.write_grids(grids_file, G, 0)                               # initialize.f90:340: the initial adaptive grids
+    regrids_seen = [getattr(G, "nregrids", 0)]
 
     def dump():
         if plot_int > 0 and G.istep % plot_int == 0:
@@ -102,6 +107,9 @@ def run(text, nsteps=None, report=print, device=0, outdir="."):
         dump()
     while G.istep < max_step and (stop_time < 0 or G.time < stop_time):
         G.step()
+        if grids_file and getattr(G, "nregrids", 0) != regrids_seen[0]:      # varden.f90:263-264
+            regrids_seen[0] = G.nregrids
+            plotfile.write_grids(grids_file, G, G.istep)
         if report:
             report(G)
         dump()

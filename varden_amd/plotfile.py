@@ -252,7 +252,54 @@ def write_plotfile(sim, istep=None, base="plt", prob_lo=None, prob_hi=None):
     dx0 = list(sim.dx[0][:dm])
     hi = prob_hi if prob_hi is not None else [dx0[d] * (pd[1][d] + 1) for d in range(dm)]
     write_ml_multifab(name, levels, [2] * (nl - 1), dm, plot_names(dm, ns), pd, prob_lo or [0.0] * dm, hi, sim.time, dx0, nc=ncomp, **_par(sim))
+    if getattr(sim, "rank", 0) == 0:
+        write_job_info(name, sim, getattr(sim, "inputs_text", None), getattr(sim, "job_name", ""), getattr(sim, "inputs_file", ""))   # varden.f90:583
     return name
+
+
+BC_NAMES = {-1: "periodic", 0: "interior", 11: "inlet", 12: "outlet", 13: "symmetry", 14: "slip wall", 15: "no slip wall"}
+
+
+def write_job_info(dirname, sim, inputs_text=None, job_name="", inputs_file=""):
+    """job_info in a plot directory (src/write_job_info.f90): job, output, grid and boundary-condition sections; the build section
+    names this library instead of the Fortran tool chain; the run-time parameters are the namelist the run was started from"""
+    import datetime
+    bar = "=" * 79
+    lv = _sim_levels(sim)
+    pd, _ = _domain(sim)
+    with open(os.path.join(dirname, "job_info"), "w") as f:
+        f.write("%s\n Job Information\n%s\njob name:    %s\ninputs file: %s\n \n" % (bar, bar, job_name, inputs_file))
+        f.write("number of MPI processes %6d\nnumber of threads       %6d\n \n \n" % (getattr(sim, "nranks", 1), 1))
+        now = datetime.datetime.now()
+        f.write("%s\n Plotfile Information\n%s\noutput date:              %s\noutput time:              %s\noutput dir:               %s\n \n \n"
+                % (bar, bar, now.strftime("%Y-%m-%d"), now.strftime("%H:%M:%S"), os.getcwd()))
+        f.write("%s\n Build Information\n%s\nvarden_amd (MI355X, HIP): %s\n \n \n" % (bar, bar, os.path.dirname(os.path.abspath(__file__))))
+        f.write("%s\n Grid Information\n%s\n" % (bar, bar))
+        for n, (boxes, _) in enumerate(lv):
+            ext = [(pd[1][d] + 1) << n for d in range(sim.dm)]
+            f.write(" level: %d\n    number of boxes = %d\n    maximum zones   = %s\n" % (n + 1, len(boxes), " ".join(str(e) for e in ext)))
+        f.write(" \n Boundary Conditions\n")
+        for d in range(sim.dm):
+            f.write("   -%s: %s\n   +%s: %s\n \n" % ("xyz"[d], BC_NAMES.get(sim.phys[d][0], str(sim.phys[d][0])), "xyz"[d], BC_NAMES.get(sim.phys[d][1], str(sim.phys[d][1]))))
+        f.write(" \n%s\n Runtime Parameter Information\n%s\n%s\n" % (bar, bar, (inputs_text or "").strip()))
+
+
+def write_grids(grids_file_name, sim, nstep):
+    """write_grids of src/varden.f90:621-662: the box lists of all levels appended to the grids file (read back by fixed_grids runs)"""
+    lv = _sim_levels(sim)
+    pd, _ = _domain(sim)
+    dm = sim.dm
+    fmt = lambda lo, hi: "((%s) (%s) (%s))" % (", ".join(str(int(x)) for x in lo[:dm]), ", ".join(str(int(x)) for x in hi[:dm]), ",".join("0" for _ in range(dm)))   # noqa: E731
+    if getattr(sim, "rank", 0) != 0:
+        return
+    with open(grids_file_name, "a") as f:
+        f.write("At step %5d:\n%2d\n" % (nstep, len(lv)))
+        for n, (boxes, _) in enumerate(lv):
+            dlo, dhi = [x << n for x in pd[0]], [((x + 1) << n) - 1 for x in pd[1]]
+            f.write("   %s %4d\n" % (fmt(dlo, dhi), len(boxes)))
+            for lo, hi in boxes:
+                f.write("      %s \n" % fmt(lo, hi))
+        f.write(" \n")
 
 
 def write_checkfile(sim, istep=None, base="chk"):
