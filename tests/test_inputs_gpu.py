@@ -106,3 +106,25 @@ def test_checkpoint_and_restart_from_inputs(gpu, tmp_path):
     plt = plotfile.read_ml_multifab(str(tmp_path / "plt00004"))
     assert plt["nlevs"] == B.nlev and [L["boxes"] for L in plt["levels"]] == [list(b) for b in boxes]
     B.close()
+
+
+@pytest.mark.gpu
+def test_fixed_grids_reproduce_the_tagged_run(gpu, tmp_path):
+    """the grids file a run writes (grids_file_name) read back as fixed_grids (src/initialize.f90:93-150): same boxes, same bits, with
+    regridding switched off in both runs"""
+    from varden_amd import inputs
+    text = open(os.path.join(INP, "inputs_bubble_3d")).read().replace("verbose = 1", "verbose = 0")
+    text = text.replace("regrid_int = 2", "regrid_int = -1").replace("plot_int  = 10", "plot_int  = 0").replace("chk_int   = 100", "chk_int   = 0")
+    assert "regrid_int = -1" in text
+
+    def valid(G):
+        return [G.unew[n].to_numpy(i)[3:-3, 3:-3, 3:-3] for n in range(G.nlev) for i in range(G.unew[n].nfabs())]
+
+    nl, A = inputs.run(text.replace("&PROBIN", "&PROBIN\n grids_file_name = 'grids.out'"), 3, None, outdir=str(tmp_path))
+    ref, boxes = valid(A), A.boxes
+    A.close()
+    nl, B = inputs.run(text.replace("&PROBIN", "&PROBIN\n fixed_grids = 'grids.out'"), 3, None, outdir=str(tmp_path))
+    assert B.boxes == boxes and B.nlev == 2
+    for x, y in zip(ref, valid(B)):
+        assert np.array_equal(x, y)
+    B.close()

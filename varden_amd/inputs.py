@@ -16,7 +16,7 @@ DEFAULTS = dict(dim_in=2, nscal=2, prob_type=1, grav=0.0, boussinesq=0, max_step
                 init_iter=4, do_initial_projection=1, init_shrink=1.0, cflfac=0.8, max_dt_growth=1.1, visc_coef=0.0, diff_coef=0.0,
                 diffusion_type=1, slope_order=4, use_minion=0, stencil_order=2, verbose=0, mg_verbose=0,
                 bcx_lo=14, bcx_hi=14, bcy_lo=14, bcy_hi=14, bcz_lo=14, bcz_hi=14,
-                fixed_dt=-1.0, plot_int=0, chk_int=0, restart=-1, plot_base_name="plt", check_base_name="chk", grids_file_name="", job_name="")
+                fixed_dt=-1.0, plot_int=0, chk_int=0, restart=-1, plot_base_name="plt", check_base_name="chk", grids_file_name="", job_name="", fixed_grids="")
 
 
 def parse_namelist(text):
@@ -71,6 +71,15 @@ def build(text, device=0, max_grid_size_cap=None, outdir="."):
             return nl, Varden(n, phys, prm, prob_hi=prob_hi, decomp=decomp, **common, **rs)
         return nl, VardenAMR(n[0], chk["boxes"][1], phys, params=prm, finer_levels=chk["boxes"][2:], base_boxes=chk["boxes"][0],
                              regrid_int=int(nl["regrid_int"]), max_levs=int(nl["max_levs"]), max_grid_size=mgs, **common, **rs)
+    if nl["fixed_grids"]:                                   # initialize_with_fixed_grids, src/initialize.f90:93-150
+        if dm != 3 or len(set(n)) != 1 or any(p != 1.0 for p in prob_hi):
+            raise NotImplementedError("hierarchies: 3-D, cubic unit domain in this round")
+        domains, boxes = plotfile.read_grids(os.path.join(outdir, str(nl["fixed_grids"])))
+        assert domains[0] == ((0, 0, 0), tuple(x - 1 for x in n)), "fixed_grids: level-0 domain differs from n_cell"
+        if len(boxes) == 1:
+            raise NotImplementedError("fixed_grids with one level: use max_grid_size")
+        return nl, VardenAMR(n[0], boxes[1], phys, params=prm, finer_levels=boxes[2:], base_boxes=boxes[0], regrid_int=int(nl["regrid_int"]),
+                             max_levs=max(int(nl["max_levs"]), len(boxes)), max_grid_size=mgs, **common)
     if int(nl["max_levs"]) <= 1:
         return nl, Varden(n, phys, prm, prob_hi=prob_hi, decomp=decomp, **common)
     if dm != 3 or len(set(n)) != 1 or any(p != 1.0 for p in prob_hi):

@@ -302,6 +302,23 @@ def write_grids(grids_file_name, sim, nstep):
         f.write(" \n")
 
 
+def read_grids(grids_file_name):
+    """the box lists of a fixed_grids file (FBoxLib read_a_hgproj_grid, src/initialize.f90:112): number of levels, then per level the
+    domain box with the number of boxes and the boxes -- the block write_grids appends ("At step" lines are skipped, the first block is read)"""
+    rows = [ln.strip() for ln in open(grids_file_name) if ln.strip() and not ln.startswith("At step")]
+    nlev = int(rows[0])
+    pad = lambda v: tuple(v) + (0,) * (3 - len(v))   # noqa: E731
+    box = lambda ln: [pad(tuple(int(x) for x in t.split(","))) for t in re.findall(r"\(([-\d, ]+)\)", ln)]   # noqa: E731
+    k, levels, domains = 1, [], []
+    for _ in range(nlev):
+        g = box(rows[k])
+        nb = int(rows[k].split()[-1])
+        domains.append((g[0], g[1]))
+        levels.append([tuple(box(rows[k + 1 + i])[:2]) for i in range(nb)])
+        k += 1 + nb
+    return domains, levels
+
+
 def write_checkfile(sim, istep=None, base="chk"):
     """write_checkfile of src/varden.f90:587-610 + checkpoint_write (src/checkpoint.f90:15-86): State = (uold, sold, gp) valid cells,
     Pressure = nodal p, Header = namelist &chkpoint (time, dt, nlevs) followed by the refinement ratios"""
