@@ -78,11 +78,76 @@ template <bool RHO> DEVI void cc_gsrb_cell(const CLev &L, int color) {
   double Ap, diag; cc_apply<RHO>(L, c, Ap, diag, i, j, k);
   if (diag != 0.0) L.phi[c] = L.phi[c] + (L.rh[c] - Ap) / diag;
 }
+// cc_apply<true> on values already in registers (the paired colour pass): same expressions, same order
+DEVI void cc_apply_rho_vals(const CLev &L, int i, int j, int k, const double p[7], const double r[7], double &Ap, double &diag) {
+  // p, r: centre, x-, x+, y-, y+, z-, z+
+  const double p0 = p[0], r0 = r[0];
+  const double bxm = beta_of(r0, r[1], i == 0, L.fold[0][0]), bxp = beta_of(r[2], r0, i == L.n[0] - 1, L.fold[0][1]);
+  const double bym = beta_of(r0, r[3], j == 0, L.fold[1][0]), byp = beta_of(r[4], r0, j == L.n[1] - 1, L.fold[1][1]);
+  const double bzm = beta_of(r0, r[5], k == 0, L.fold[2][0]), bzp = beta_of(r[6], r0, k == L.n[2] - 1, L.fold[2][1]);
+  const double ax = (bxp * (p0 - p[2]) + bxm * (p0 - p[1])) * L.hi2[0];
+  const double ay = (byp * (p0 - p[4]) + bym * (p0 - p[3])) * L.hi2[1];
+  const double az = (bzp * (p0 - p[6]) + bzm * (p0 - p[5])) * L.hi2[2];
+  Ap = ax + ay + az;
+  diag = (bxp + bxm) * L.hi2[0] + (byp + bym) * L.hi2[1] + (bzp + bzm) * L.hi2[2];
+}
+// The colour pass is bound by the texture addresser (TA busy 255 k of ~310 k cycles at 256^3, profiles/r01_smoother_rho_pmc.json):
+// 16 memory instructions per updated cell, each an 8-byte access with stride 2 over the lanes.  Paired form: a thread owns the 2 x 2
+// block (columns 2t, 2t+1; rows j, j+1) of a k-plane, which holds exactly two cells of the colour (a diagonal).  All loads are aligned
+// 16-byte pairs, unit-stride over the lanes: the two own rows give both centres, their in-pair x-neighbours and each other's y-neighbour;
+// rows j-1, j+2 and the planes k-1, k+1 give the rest; the x-neighbour outside the pair comes from the adjacent lane (DPP), from memory
+// at the two ends of the wave (one branch-free load per field).  8 + 1 loads per field for two cells instead of 2 x 7.  Same arithmetic.
+struct Pair7 { double a[7], b[7]; };
+DEVI double sel2(const double2 &q, int hi) { return hi ? q.y : q.x; }
+DEVI void pair_gather(const double *v, const CLev &L, long cpA, int par, int lane, Pair7 &o) {
+  const long sy = L.PX, sz = (long)L.PX * L.PY;
+  // the cells just outside the pair along x: previous lane's odd cell / next lane's even cell; the two ends of the wave read memory
+  // (issued first, two active lanes).  par = 0: A (row j, even column) looks left and B (row j+1, odd column) looks right; par = 1 the
+  // other way round.
+  double e = 0.0;
+  if (lane == 0 || lane == 63) e = v[cpA + ((lane == 0) ? (par == 0 ? -1 : sy - 1) : (par == 0 ? sy + 2 : 2))];
+  #define LD2(off) (*reinterpret_cast<const double2 *>(v + cpA + (off)))
+  const double2 PA = LD2(0), PB = LD2(sy), PAm = LD2(-sy), PBp = LD2(2 * sy);
+  const double2 ZAm = LD2(-sz), ZAp = LD2(sz), ZBm = LD2(sy - sz), ZBp = LD2(sy + sz);
+  #undef LD2
+  const double prevv = par == 0 ? lane_prev(PA.y) : lane_prev(PB.y);
+  const double nextv = par == 0 ? lane_next(PB.x) : lane_next(PA.x);
+  const double outl = lane == 0 ? e : prevv, outr = lane == 63 ? e : nextv;
+  o.a[0] = sel2(PA, par);      o.b[0] = sel2(PB, 1 - par);
+  o.a[3] = sel2(PAm, par);     o.a[4] = sel2(PB, par);
+  o.b[3] = sel2(PA, 1 - par);  o.b[4] = sel2(PBp, 1 - par);
+  o.a[5] = sel2(ZAm, par);     o.a[6] = sel2(ZAp, par);
+  o.b[5] = sel2(ZBm, 1 - par); o.b[6] = sel2(ZBp, 1 - par);
+  if (par == 0) { o.a[1] = outl; o.a[2] = PA.y; o.b[1] = PB.x; o.b[2] = outr; }
+  else          { o.a[1] = PA.x; o.a[2] = outr; o.b[1] = outl; o.b[2] = PB.y; }
+}
+__global__ void __launch_bounds__(256) kk_cc_gsrb_rho_pair(CLev L, int color) {
+  int bx, by, bz; xcd_block(bx, by, bz);
+  const int lane = threadIdx.x, k = bz;
+  const int t = bx * 64 + lane, jA = 2 * (by * 4 + (int)threadIdx.y);
+  const bool act = 2 * t + 1 < L.n[0] && jA + 1 < L.n[1];
+  const int par = (jA + k + color) & 1;                              // uniform over the wave
+  const long cpA = cidx(L, 2 * min(t, L.n[0] / 2), min(jA, L.n[1] - 2), k);      // clamped: every lane takes part in the lane exchange
+  Pair7 P, R;
+  pair_gather(L.phi, L, cpA, par, lane, P);
+  pair_gather(L.rho, L, cpA, par, lane, R);
+  const double2 RA = *reinterpret_cast<const double2 *>(L.rh + cpA), RB = *reinterpret_cast<const double2 *>(L.rh + cpA + L.PX);
+  if (!act) return;
+  const int iA = 2 * t + par, iB = 2 * t + 1 - par;
+  double Ap, diag;
+  cc_apply_rho_vals(L, iA, jA, k, P.a, R.a, Ap, diag);
+  if (diag != 0.0) L.phi[cpA + par] = P.a[0] + (sel2(RA, par) - Ap) / diag;
+  cc_apply_rho_vals(L, iB, jA + 1, k, P.b, R.b, Ap, diag);
+  if (diag != 0.0) L.phi[cpA + L.PX + 1 - par] = P.b[0] + (sel2(RB, 1 - par) - Ap) / diag;
+}
 __global__ void __launch_bounds__(256) kk_cc_gsrb(CLev L, int color) { cc_gsrb_cell<false>(L, color); }
 __global__ void __launch_bounds__(256) kk_cc_gsrb_rho(CLev L, int color) { cc_gsrb_cell<true>(L, color); }
 static inline void launch_gsrb(const CLev &L, int color, hipStream_t st) {
   const dim3 blk(64, 4, 1), g((unsigned)(((L.n[0] + 1) / 2 + 63) / 64), (unsigned)((L.n[1] + 3) / 4), (unsigned)L.n[2]);
-  if (L.rho) hipLaunchKernelGGL(kk_cc_gsrb_rho, g, blk, 0, st, L, color);
+  static const bool paired = !(getenv("VDN_GSRB_PAIR") && atoi(getenv("VDN_GSRB_PAIR")) == 0);
+  if (L.rho && paired && L.n[0] % 2 == 0 && L.n[1] % 2 == 0 && L.n[0] >= 128)
+    hipLaunchKernelGGL(kk_cc_gsrb_rho_pair, dim3((unsigned)((L.n[0] / 2 + 63) / 64), (unsigned)((L.n[1] / 2 + 3) / 4), (unsigned)L.n[2]), blk, 0, st, L, color);
+  else if (L.rho) hipLaunchKernelGGL(kk_cc_gsrb_rho, g, blk, 0, st, L, color);
   else hipLaunchKernelGGL(kk_cc_gsrb, g, blk, 0, st, L, color);
 }
 
