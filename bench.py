@@ -138,11 +138,11 @@ def main():
         # HBM traffic per launch from the PMC passes (FETCH_SIZE x2 + WRITE_SIZE, MI355X_MICROARCH.md), collected
         # separately with `rocprofv3 --pmc` on tools/smoother_probe.py and committed under profiles/
         traffic = None
-        pmc = os.path.join(ROOT, "profiles", "r01_smoother_rho_pmc.json")        # the kernel timed above (kk_cc_gsrb_rho)
+        pmc = os.path.join(ROOT, "profiles", "r01_smoother_rho_pmc.json")        # the kernel timed above (kk_cc_gsrb_rho_pair)
         if n == 256 and os.path.exists(pmc):
             traffic = json.load(open(pmc))["hbm_bytes_per_launch"]
-        roof = {"bound": "hbm", "kernel": "kk_cc_gsrb_rho (MAC-MG red-black GS colour pass, %d^3; beta recomputed from rho: 32 B/cell of real traffic "
-                                          "against the 48 B/cell algorithmic figure; stored-beta pass kk_cc_gsrb: %.5f ms)" % (n, ms_stored),
+        roof = {"bound": "hbm", "kernel": "kk_cc_gsrb_rho_pair (MAC-MG red-black GS colour pass, %d^3; beta recomputed from rho, 2x2 cells per thread: ~34 B/cell of "
+                                          "real traffic against the 48 B/cell algorithmic figure; stored-beta pass kk_cc_gsrb: %.5f ms)" % (n, ms_stored),
                 "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                 "avg_launch_ms": round(ms, 5), "alg_bytes_per_launch": alg_bytes}
