@@ -783,7 +783,7 @@ void k_mkflux(const vdn_multifab *s, vdn_multifab **sedge, vdn_multifab **flux, 
     hipLaunchKernelGGL(kk_macmax_b, dim3(B.tot[1]), dim3(64, 4, 1), 0, st, B.dev, B.st[1], nb);
     hipLaunchKernelGGL(kk_slopes_b<MkD>, dim3(B.tot[0]), dim3(64, 4, 1), 0, st, B.dev, B.st[0], nb, 7);
     static const int split_env = getenv("VDN_MK_SPLIT") ? atoi(getenv("VDN_MK_SPLIT")) : -1;
-    const int split = split_env >= 0 ? split_env : (ncomp == 3 ? 4 : 0);
+    const int split = split_env >= 0 ? split_env : (ncomp >= 2 ? 4 : 0);
     #define MKB_STAGE(K, t, bit)                                                                                               \
       if ((split >> bit) & 1) { for (int c0 = 0; c0 < ncomp; c0++) hipLaunchKernelGGL(K<1>, dim3(B.tot[t]), blk, 0, st, B.dev, B.st[t], nb, c0, ncomp); } \
       else if (ncomp == 3) hipLaunchKernelGGL(K<3>, dim3(B.tot[t]), blk, 0, st, B.dev, B.st[t], nb, 0, ncomp);                  \
@@ -828,9 +828,9 @@ void k_mkflux(const vdn_multifab *s, vdn_multifab **sedge, vdn_multifab **flux, 
       #define MK_ARGS_C(c0) s->fabs[ib], sl[0], sl[1], sl[2], um, vm, wm, force->fabs[ib], mac_rhs->fabs[ib], SI, SC, A, rg, klg, umax, c0, ncomp
       #define MK_ARGS_D(c0) s->fabs[ib], sl[0], sl[1], sl[2], um, vm, wm, force->fabs[ib], mac_rhs->fabs[ib], SC, \
                             sedge[0]->fabs[ib], sedge[1]->fabs[ib], sedge[2]->fabs[ib], flux[0]->fabs[ib], flux[1]->fabs[ib], flux[2]->fabs[ib], A, rf, klf, umax, c0, ncomp
-      // measured at 256^3: D fused <3> 3.18 ms (61 spilled VGPRs) vs 3 x <1> 2.3 ms; the 2-component scalars are faster fused
+      // measured at 256^3: D fused <3> 3.18 ms (61 spilled VGPRs) vs 3 x <1> 2.3 ms; D <2> 1.66 ms vs 2 x <1> 1.55 ms; B and C are faster fused
       static const int split_env = getenv("VDN_MK_SPLIT") ? atoi(getenv("VDN_MK_SPLIT")) : -1;   // bit 0: B, 1: C, 2: D per component
-      const int split = split_env >= 0 ? split_env : (ncomp == 3 ? 4 : 0);
+      const int split = split_env >= 0 ? split_env : (ncomp >= 2 ? 4 : 0);
       #define MK_STAGE(K, ARGS, g, bit)                                                                               \
         if ((split >> bit) & 1) { for (int c0 = 0; c0 < ncomp; c0++) hipLaunchKernelGGL(K<1>, g, blk, 0, st, ARGS(c0)); } \
         else if (ncomp == 3) hipLaunchKernelGGL(K<3>, g, blk, 0, st, ARGS(0));                                        \
