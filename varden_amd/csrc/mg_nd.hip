@@ -134,6 +134,9 @@ DEVI void nd_apply_reg(const NLev &L, const double p[3][3][3], const double sg[2
 // Per plane a thread loads only its own column (phi at rows j-1..j+1, sigma at rows j-1..j, rhs) in one unconditional
 // batch and takes the i-1 / i+1 columns from the neighbouring lanes (wave shuffles): 6 loads per node instead of 14.
 // Tiles overlap by two columns: lanes 0 and 63 only feed their neighbours (62 nodes per wave row).
+// (Tried: rotating the three phi planes and two sigma planes by NAME over six unrolled plane steps, to save the 22 register moves of the
+// hand-over among 204 instructions per plane: the scheduler then hoists the loads of later steps, 214 VGPRs, occupancy 2, HG 17.8 -> 24.3 ms;
+// capped at 128 VGPRs it spills 340 B per lane, 38 ms.  The moves stay.)
 template <int MODE>
 __global__ void __launch_bounds__(256) kk_nd_march(NLev L, const double *__restrict__ phi, double *__restrict__ out, double omega, int kchunk, double *nrm) {
   const int lane = threadIdx.x;
