@@ -272,3 +272,28 @@ def test_fused_sweeps_equal_colour_passes(gpu):
         assert out.returncode == 0, out.stderr[-2000:]
         hashes.append([ln for ln in out.stdout.splitlines() if ln.startswith("HASH")][0])
     assert hashes[0] == hashes[1] == hashes[2], hashes
+
+
+def _pair_run(tmp_path, tag, decomp, pair):
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = str(tmp_path / (tag + ".npz"))
+    env = dict(os.environ, VDN_GSRB_PAIR=str(pair))
+    subprocess.check_call([sys.executable, os.path.join(root, "tests", "_pair_worker.py")] + [str(d) for d in decomp] + [out], env=env, cwd=root, timeout=300)
+    return np.load(out)
+
+
+@pytest.mark.gpu
+def test_paired_colour_pass_equals_cell_per_thread_pass(gpu, tmp_path):
+    """the finest level of the MAC multigrid: kk_cc_gsrb_rho_pair (a thread owns a 2 x 2 block, 16-byte loads, lane exchange) against
+    kk_cc_gsrb_rho (one cell per thread) -- same arithmetic, same bits, on one 256 x 128 x 128 box and on two 128^3 boxes (colour by
+    global index, halo cells from the neighbour box); and two boxes against one box to the usual 1e-9"""
+    one_p, one_c = _pair_run(tmp_path, "one_p", (1, 1, 1), 1), _pair_run(tmp_path, "one_c", (1, 1, 1), 0)
+    two_p, two_c = _pair_run(tmp_path, "two_p", (2, 1, 1), 1), _pair_run(tmp_path, "two_c", (2, 1, 1), 0)
+    for a, b, what in ((one_p, one_c, "one box"), (two_p, two_c, "two boxes")):
+        assert int(a["cyc"]) == int(b["cyc"]) and int(a["cyc"]) > 3
+        assert_bits(a["u"], b["u"], "paired vs cell-per-thread colour pass, " + what)
+        assert_bits(a["s"], b["s"], "paired vs cell-per-thread colour pass, " + what)
+    assert np.abs(one_p["u"] - two_p["u"]).max() <= 1e-9 * np.abs(one_p["u"]).max()
