@@ -503,6 +503,16 @@ __global__ void k_physbc(FV f, PhysArgs A) {
   if (b1 > A.r1hi || b2 > A.r2hi) return;
   physbc_cell(f, A, b1, b2);
 }
+// one box: the faces of one direction (two sides x the components) in ONE launch, descriptors as kernel arguments, blockIdx.z = face
+constexpr int PHYS_MULTI = 8;
+struct PhysMulti { PhysArgs A[PHYS_MULTI]; };
+__global__ void k_physbc_multi(FV f, PhysMulti M) {
+  const PhysArgs &A = M.A[blockIdx.z];
+  int b1 = A.r1lo + (int)(blockIdx.x * blockDim.x + threadIdx.x);
+  int b2 = A.r2lo + (int)(blockIdx.y * blockDim.y + threadIdx.y);
+  if (b1 > A.r1hi || b2 > A.r2hi) return;
+  physbc_cell(f, A, b1, b2);
+}
 // all faces of one direction on every box and component of a level in one launch: the batch runs over (t1, t2, 0)
 struct PhysB { Range3 r; int g[3]; FV f; PhysArgs A;
   static __device__ double body(const PhysB &q, int i, int j, int, int) { physbc_cell(q.f, q.A, i, j); return 0.0; } };
@@ -532,6 +542,7 @@ void mf_physbc(vdn_multifab *mf, int scomp, int bccomp, int nc, const vdn_bc_tow
   std::vector<PhysB> pb;
   for (int d = 0; d < 3; d++) {
    pb.clear();
+   PhysMulti pm; int npm = 0, gx = 0, gy = 0;
    for (int i = 0; i < mf->nfabs(); i++) for (int c = 0; c < nc; c++) {
     const int bcc = same_boundary ? bccomp : bccomp + c;
     REQUIRE(bcc < bct->ncomp_adv, "physbc: bc component %d out of range", bcc);
@@ -559,11 +570,12 @@ void mf_physbc(vdn_multifab *mf, int scomp, int bccomp, int nc, const vdn_bc_tow
       }
       A.r1lo = rlo[A.t1]; A.r1hi = rhi[A.t1]; A.r2lo = rlo[A.t2]; A.r2hi = rhi[A.t2];
       if (batch) { PhysB q; q.r.lo[0] = A.r1lo; q.r.hi[0] = A.r1hi; q.r.lo[1] = A.r2lo; q.r.hi[1] = A.r2hi; q.r.lo[2] = q.r.hi[2] = 0; q.f = mf->fabs[i]; q.A = A; pb.push_back(q); continue; }
-      dim3 blk(64, 4, 1), grd((A.r1hi - A.r1lo + 64) / 64, (A.r2hi - A.r2lo + 4) / 4, 1);
-      hipLaunchKernelGGL(k_physbc, grd, blk, 0, g_ctx.stream, mf->fabs[i], A);
+      if (npm == PHYS_MULTI) { hipLaunchKernelGGL(k_physbc_multi, dim3(gx, gy, npm), dim3(64, 4, 1), 0, g_ctx.stream, mf->fabs[0], pm); npm = gx = gy = 0; }
+      pm.A[npm++] = A; gx = std::max(gx, (A.r1hi - A.r1lo + 64) / 64); gy = std::max(gy, (A.r2hi - A.r2lo + 4) / 4);
     }
    }
    if (batch) launch_batched(pb, 0, (double *)nullptr, 0, g_ctx.stream);
+   else if (npm) hipLaunchKernelGGL(k_physbc_multi, dim3(gx, gy, npm), dim3(64, 4, 1), 0, g_ctx.stream, mf->fabs[0], pm);
   }
 }
 extern "C" int vdn_multifab_physbc(vdn_multifab *mf, int scomp, int bccomp, int nc, const vdn_bc_tower *bct) {
