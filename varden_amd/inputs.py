@@ -84,12 +84,18 @@ def build(text, device=0, max_grid_size_cap=None, outdir="."):
         return nl, Varden(n, phys, prm, prob_hi=prob_hi, decomp=decomp, **common)
     if dm != 3 or len(set(n)) != 1 or any(p != 1.0 for p in prob_hi):
         raise NotImplementedError("adaptive hierarchies: 3-D, cubic unit domain in this round")
+    # level 0 is cut by max_grid_size like every other level (boxarray_maxsize, src/initialize.f90:204-206)
+    base = None
+    if any(dc > 1 for dc in decomp):
+        bs = [n[d] // decomp[d] for d in range(3)]
+        base = [((kx * bs[0], ky * bs[1], kz * bs[2]), ((kx + 1) * bs[0] - 1, (ky + 1) * bs[1] - 1, (kz + 1) * bs[2] - 1))
+                for kz in range(decomp[2]) for ky in range(decomp[1]) for kx in range(decomp[0])]
     levels = VardenAMR.tagged_grids(n[0], phys, prm, prob_type=int(nl["prob_type"]), max_levs=int(nl["max_levs"]),
-                                    buf_wid=max(int(nl["amr_buf_width"]), int(nl["regrid_int"]), 1), max_grid_size=mgs, device=device)
+                                    buf_wid=max(int(nl["amr_buf_width"]), int(nl["regrid_int"]), 1), max_grid_size=mgs, device=device, base_boxes=base)
     if not levels:
-        return nl, Varden(n, phys, prm, prob_hi=prob_hi, **common)
+        return nl, Varden(n, phys, prm, prob_hi=prob_hi, decomp=decomp, **common)
     return nl, VardenAMR(n[0], levels[0], phys, params=prm, finer_levels=levels[1:], regrid_int=int(nl["regrid_int"]),
-                         max_levs=int(nl["max_levs"]), max_grid_size=mgs, **common)
+                         max_levs=int(nl["max_levs"]), max_grid_size=mgs, base_boxes=base, **common)
 
 
 def run(text, nsteps=None, report=print, device=0, outdir="."):
