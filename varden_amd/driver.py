@@ -219,9 +219,9 @@ def prm_cluster(prm, name):
 
 
 class VardenAMR:
-    """multi-level hierarchy on fixed grids (the reference's fixed_grids mode, src/initialize.f90:93-150): level 0 = one box covering
-    the domain [0,nc)^3, level 1 = the given fine boxes (fine index space, refinement ratio 2); `finer_levels`: box lists of the
-    levels 2.. (one properly nested box each but the last).  The loop body of src/varden.f90: ml_restrict_and_fill ghost fills,
+    """multi-level hierarchy on fixed grids (the reference's fixed_grids mode, src/initialize.f90:93-150): level 0 = the domain
+    [0,nc)^3 in one box or in `base_boxes` (equal boxes, what max_grid_size makes of it), level 1 = the given fine boxes (fine index
+    space, refinement ratio 2); `finer_levels`: box lists of the levels 2.. (any properly nested unions).  The loop body of src/varden.f90: ml_restrict_and_fill ghost fills,
     dt = min over levels of estdt, advance_timestep, new -> old copies."""
 
     def __init__(self, nc, fine_boxes, phys_bc, params=None, prob_type=1, grav=-9.8, init_shrink=0.1, device=0, finer_levels=(),
