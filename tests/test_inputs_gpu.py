@@ -49,7 +49,8 @@ def test_reference_inputs_run(gpu, name, nsteps, nlev, tmp_path):
 
     nl, G = inputs.run(text, nsteps, report, outdir=str(tmp_path))
     assert G.nlev == nlev and G.istep == nsteps and G.nregrids >= (nsteps - 1) // 2
-    assert os.path.isdir(str(tmp_path / "plt00000")) and G.files_written[0].endswith("plt00000")          # plot_int = 10: step 0 only
+    assert os.path.isdir(str(tmp_path / "plt00000")) and G.files_written[0].endswith("plt00000")          # plot_int = 10: step 0 ...
+    assert os.path.isdir(str(tmp_path / ("plt%05d" % nsteps)))                                            # ... and the last step (varden.f90:376)
     assert all(s[2] > 0 for s in seen)
     for n in range(G.nlev):
         for i in range(G.unew[n].nfabs()):

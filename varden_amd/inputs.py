@@ -112,11 +112,16 @@ def run(text, nsteps=None, report=print, device=0, outdir="."):
         plotfile.write_grids(grids_file, G, 0)                               # initialize.f90:340: the initial adaptive grids
     regrids_seen = [getattr(G, "nregrids", 0)]
 
-    def dump():
-        if plot_int > 0 and G.istep % plot_int == 0:
+    last = dict(plt=-1, chk=-1)
+
+    def dump(final=False):
+        """every plot_int-th / chk_int-th step; final: the last step once more if it has not been written (src/varden.f90:374-377)"""
+        if plot_int > 0 and (G.istep % plot_int == 0 or final) and last["plt"] != G.istep:
             G.files_written.append(plotfile.write_plotfile(G, base=os.path.join(outdir, str(nl["plot_base_name"]))))
-        if chk_int > 0 and G.istep % chk_int == 0:
+            last["plt"] = G.istep
+        if chk_int > 0 and (G.istep % chk_int == 0 or final) and last["chk"] != G.istep:
             G.files_written.append(plotfile.write_checkfile(G, base=os.path.join(outdir, str(nl["check_base_name"]))))
+            last["chk"] = G.istep
 
     if int(nl["restart"]) < 0:
         dump()
@@ -128,4 +133,6 @@ def run(text, nsteps=None, report=print, device=0, outdir="."):
         if report:
             report(G)
         dump()
+    if G.istep > (int(nl["restart"]) if int(nl["restart"]) >= 0 else 0):
+        dump(final=True)
     return nl, G
