@@ -13,7 +13,11 @@ struct ForceArgs { int lo[3], hi[3]; double visc_coef, fac; int boussinesq, nsca
 
 DEVI void mkvelforce_cell(const FV &vf, const FV &ext, const FV &gp, const FV &s, const FV &lapu, int has_lapu, const ForceArgs &A, int i, int j, int k) {
   const int out = (i < A.lo[0]) + (i > A.hi[0]) + (j < A.lo[1]) + (j > A.hi[1]) + (k < A.lo[2]) + (k > A.hi[2]);
-  if (out > 1) return;                              // the six face halos only, no edges/corners (mkforce.f90:186-234)
+  if (out > 1) {                                    // the six face halos only (mkforce.f90:186-234); edges and corners keep the 0 of :52
+    #pragma unroll
+    for (int m = 0; m < 3; m++) fv_at(vf, i, j, k, m) = 0.0;
+    return;
+  }
   const int ic = min(max(i, A.lo[0]), A.hi[0]), jc = min(max(j, A.lo[1]), A.hi[1]), kc = min(max(k, A.lo[2]), A.hi[2]);
   const double rho = fv_get(s, i, j, k, 0);
   #pragma unroll
@@ -38,7 +42,7 @@ void k_mkvelforce(vdn_multifab *vf, const vdn_multifab *ext, const vdn_multifab 
                   const vdn_multifab *lapu, double visc_fac) {
   if (ctx().prm.dm == 2) { k2_mkvelforce(vf, ext, s, gp, lapu, visc_fac); return; }
   REQUIRE(vf->ng >= 1 && ext->ng >= 1 && gp->ng >= 1 && s->ng >= 1, "mkvelforce: operands need a ghost cell");
-  mf_setval(vf, 0.0, 0, vf->nc, true);              // mkforce.f90:52
+  if (vf->ng != 1 || vf->nc != 3) mf_setval(vf, 0.0, 0, vf->nc, true);              // mkforce.f90:52; with one ghost layer the kernel writes every point itself
   std::vector<VelForceB> v;
   for (int i = 0; i < vf->nfabs(); i++) {
     ForceArgs A; Range3 r;
@@ -54,9 +58,10 @@ void k_mkvelforce(vdn_multifab *vf, const vdn_multifab *ext, const vdn_multifab 
 
 DEVI void mkscalforce_cell(const FV &sf, const FV &ext, const FV &laps, int has_laps, const ForceArgs &A, int i, int j, int k) {
   const int out = (i < A.lo[0]) + (i > A.hi[0]) + (j < A.lo[1]) + (j > A.hi[1]) + (k < A.lo[2]) + (k > A.hi[2]);
-  if (out > 1) return;
+  fv_at(sf, i, j, k, 0) = 0.0;                      // density does not diffuse: its force is the 0 of setval(scal_force, 0), mkforce.f90:267
+  if (out > 1) { for (int m = 1; m < A.nscal; m++) fv_at(sf, i, j, k, m) = 0.0; return; }
   const int ic = min(max(i, A.lo[0]), A.hi[0]), jc = min(max(j, A.lo[1]), A.hi[1]), kc = min(max(k, A.lo[2]), A.hi[2]);
-  for (int m = 1; m < A.nscal; m++) {               // density (comp 1) does not diffuse: force stays 0
+  for (int m = 1; m < A.nscal; m++) {
     double l = has_laps ? fv_get(laps, ic, jc, kc, m) : 0.0;
     double laps_local = A.visc_coef * A.fac * l;    // here visc_coef carries diff_coef
     fv_at(sf, i, j, k, m) = fv_get(ext, i, j, k, m) + laps_local;
@@ -72,7 +77,7 @@ struct ScalForceB { Range3 r; int g[3]; FV sf, ext, laps; int has_laps; ForceArg
 
 void k_mkscalforce(vdn_multifab *sf, const vdn_multifab *ext, const vdn_multifab *laps, double diff_fac) {
   if (ctx().prm.dm == 2) { k2_mkscalforce(sf, ext, laps, diff_fac); return; }
-  mf_setval(sf, 0.0, 0, sf->nc, true);              // mkforce.f90:267 / 346
+  if (sf->ng != 1 || sf->nc != ctx().prm.nscal) mf_setval(sf, 0.0, 0, sf->nc, true);              // mkforce.f90:267 / 346; with one ghost layer the kernel writes every point itself
   std::vector<ScalForceB> vb;
   for (int i = 0; i < sf->nfabs(); i++) {
     ForceArgs A; Range3 r;
