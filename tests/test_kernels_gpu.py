@@ -287,8 +287,9 @@ def _pair_run(tmp_path, tag, decomp, pair):
 
 @pytest.mark.gpu
 def test_paired_colour_pass_equals_cell_per_thread_pass(gpu, tmp_path):
-    """the finest level of the MAC multigrid: kk_cc_gsrb_rho_pair (a thread owns a 2 x 2 block, 16-byte loads, lane exchange) against
-    kk_cc_gsrb_rho (one cell per thread) -- same arithmetic, same bits, on one 256 x 128 x 128 box and on two 128^3 boxes (colour by
+    """the finest level of the MAC multigrid: kk_cc_gsrb_rho_pair / kk_cc_residual_rho_pair (a thread owns a 2 x 2 block, 16-byte loads, lane
+    exchange) against kk_cc_gsrb_rho / kk_cc_residual_rho (one cell per thread), and the stored-coefficient pair pass kk_cc_gsrb_pair of the
+    128^3 level and of the three viscous solves (alpha = rho) against kk_cc_gsrb -- same arithmetic, same bits, on one 256 x 128 x 128 box and on two 128^3 boxes (colour by
     global index, halo cells from the neighbour box); and two boxes against one box to the usual 1e-9"""
     one_p, one_c = _pair_run(tmp_path, "one_p", (1, 1, 1), 1), _pair_run(tmp_path, "one_c", (1, 1, 1), 0)
     two_p, two_c = _pair_run(tmp_path, "two_p", (2, 1, 1), 1), _pair_run(tmp_path, "two_c", (2, 1, 1), 0)

@@ -140,6 +140,55 @@ __global__ void __launch_bounds__(256) kk_cc_gsrb_rho_pair(CLev L, int color) {
   cc_apply_rho_vals(L, iB, jA + 1, k, P.b, R.b, Ap, diag);
   if (diag != 0.0) L.phi[cpA + L.PX + 1 - par] = P.b[0] + (sel2(RB, 1 - par) - Ap) / diag;
 }
+// the same pairing for the stored-coefficient pass (viscous / diffusive solves, the 128^3 level of the MAC solve, level 0 of the
+// composite solves): the face coefficients of the two cells come from nine aligned pairs (bx: rows j, j+1; by: rows j, j+1, j+2;
+// bz: planes k, k+1 of both rows), the x+ coefficient of the odd cell from the next lane.  cc_apply's expressions, same order.
+DEVI void cc_apply_vals(const CLev &L, const double p[7], const double b[6], double a0, bool has_alpha, double &Ap, double &diag) {
+  // p: centre, x-, x+, y-, y+, z-, z+;  b: bxm, bxp, bym, byp, bzm, bzp
+  const double p0 = p[0];
+  const double ax = (b[1] * (p0 - p[2]) + b[0] * (p0 - p[1])) * L.hi2[0];
+  const double ay = (b[3] * (p0 - p[4]) + b[2] * (p0 - p[3])) * L.hi2[1];
+  const double az = (b[5] * (p0 - p[6]) + b[4] * (p0 - p[5])) * L.hi2[2];
+  Ap = ax + ay + az;
+  diag = (b[1] + b[0]) * L.hi2[0] + (b[3] + b[2]) * L.hi2[1] + (b[5] + b[4]) * L.hi2[2];
+  if (has_alpha) { Ap = Ap + a0 * p0; diag = diag + a0; }
+}
+__global__ void __launch_bounds__(256) kk_cc_gsrb_pair(CLev L, int color) {
+  int bx, by, bz; xcd_block(bx, by, bz);
+  const int lane = threadIdx.x, k = bz;
+  const int t = bx * 64 + lane, jA = 2 * (by * 4 + (int)threadIdx.y);
+  const bool act = 2 * t + 1 < L.n[0] && jA + 1 < L.n[1];
+  const int par = (jA + k + color) & 1;                              // uniform over the wave
+  const long cpA = cidx(L, 2 * min(t, L.n[0] / 2), min(jA, L.n[1] - 2), k);
+  const long sy = L.PX, sz = (long)L.PX * L.PY;
+  Pair7 P;
+  pair_gather(L.phi, L, cpA, par, lane, P);
+  // x+ face of the odd cell: bx of the next pair's even face (row j+1 when par = 0, row j when par = 1); the last lane reads memory
+  const long rowo = par == 0 ? sy : 0;
+  double e = 0.0;
+  if (lane == 63) e = L.b[0][cpA + rowo + 2];
+  #define LDB(d, off) (*reinterpret_cast<const double2 *>(L.b[d] + cpA + (off)))
+  const double2 XA = LDB(0, 0), XB = LDB(0, sy);
+  const double2 YA = LDB(1, 0), YB = LDB(1, sy), YC = LDB(1, 2 * sy);
+  const double2 ZA0 = LDB(2, 0), ZA1 = LDB(2, sz), ZB0 = LDB(2, sy), ZB1 = LDB(2, sy + sz);
+  #undef LDB
+  const double2 RA = *reinterpret_cast<const double2 *>(L.rh + cpA), RB = *reinterpret_cast<const double2 *>(L.rh + cpA + sy);
+  double2 AA = make_double2(0.0, 0.0), AB = AA;
+  if (L.alpha) { AA = *reinterpret_cast<const double2 *>(L.alpha + cpA); AB = *reinterpret_cast<const double2 *>(L.alpha + cpA + sy); }
+  const double nx = lane_next(par == 0 ? XB.x : XA.x);
+  const double xnext = lane == 63 ? e : nx;
+  if (!act) return;
+  double bA[6], bB[6];
+  if (par == 0) { bA[0] = XA.x; bA[1] = XA.y; bB[0] = XB.y; bB[1] = xnext; }      // A at column 2t, B at 2t+1
+  else          { bA[0] = XA.y; bA[1] = xnext; bB[0] = XB.x; bB[1] = XB.y; }      // A at column 2t+1, B at 2t
+  bA[2] = sel2(YA, par); bA[3] = sel2(YB, par); bB[2] = sel2(YB, 1 - par); bB[3] = sel2(YC, 1 - par);
+  bA[4] = sel2(ZA0, par); bA[5] = sel2(ZA1, par); bB[4] = sel2(ZB0, 1 - par); bB[5] = sel2(ZB1, 1 - par);
+  double Ap, diag;
+  cc_apply_vals(L, P.a, bA, sel2(AA, par), L.alpha != nullptr, Ap, diag);
+  if (diag != 0.0) L.phi[cpA + par] = P.a[0] + (sel2(RA, par) - Ap) / diag;
+  cc_apply_vals(L, P.b, bB, sel2(AB, 1 - par), L.alpha != nullptr, Ap, diag);
+  if (diag != 0.0) L.phi[cpA + sy + 1 - par] = P.b[0] + (sel2(RB, 1 - par) - Ap) / diag;
+}
 __global__ void __launch_bounds__(256) kk_cc_gsrb(CLev L, int color) { cc_gsrb_cell<false>(L, color); }
 __global__ void __launch_bounds__(256) kk_cc_gsrb_rho(CLev L, int color) { cc_gsrb_cell<true>(L, color); }
 static inline void launch_gsrb(const CLev &L, int color, hipStream_t st) {
@@ -148,6 +197,8 @@ static inline void launch_gsrb(const CLev &L, int color, hipStream_t st) {
   if (L.rho && paired && L.n[0] % 2 == 0 && L.n[1] % 2 == 0 && L.n[0] >= 128)
     hipLaunchKernelGGL(kk_cc_gsrb_rho_pair, dim3((unsigned)((L.n[0] / 2 + 63) / 64), (unsigned)((L.n[1] / 2 + 3) / 4), (unsigned)L.n[2]), blk, 0, st, L, color);
   else if (L.rho) hipLaunchKernelGGL(kk_cc_gsrb_rho, g, blk, 0, st, L, color);
+  else if (paired && L.n[0] % 2 == 0 && L.n[1] % 2 == 0 && L.n[0] >= 128)
+    hipLaunchKernelGGL(kk_cc_gsrb_pair, dim3((unsigned)((L.n[0] / 2 + 63) / 64), (unsigned)((L.n[1] / 2 + 3) / 4), (unsigned)L.n[2]), blk, 0, st, L, color);
   else hipLaunchKernelGGL(kk_cc_gsrb, g, blk, 0, st, L, color);
 }
 
