@@ -105,6 +105,8 @@ DEVI void nd_apply_reg(const NLev &L, const double p[3][3][3], const double sg[2
   w[5] = -2.0 * fx + fy - 2.0 * fz;
   w[6] = fx - 2.0 * fy - 2.0 * fz;
   w[7] = -F;
+  // the sums start from their first term instead of 0.0 + first term: ten f64 additions per node less (the kernel is VALU-bound); the
+  // value is the same, only a sum of exact zeros may come out as -0.0 where the oracle's 0.0 + (-0.0) gives +0.0
   double acc = 0.0, ssum = 0.0;
   #pragma unroll
   for (int dk = 0; dk < 2; dk++)
@@ -121,10 +123,12 @@ DEVI void nd_apply_reg(const NLev &L, const double p[3][3][3], const double sg[2
             for (int mx = 0; mx < 2; mx++) {
               const int oa = di + mx - 1, ob = dj + my - 1, oc = dk + mz - 1;
               const int idx = (oa != 0) | ((ob != 0) << 1) | ((oc != 0) << 2);
-              t = t + w[idx] * p[oc + 1][ob + 1][oa + 1];
+              const double term = w[idx] * p[oc + 1][ob + 1][oa + 1];
+              t = (mz | my | mx) == 0 ? term : t + term;
             }
-        acc = acc + sg[dk][dj][di] * t;
-        ssum = ssum + sg[dk][dj][di];
+        const bool first = (dk | dj | di) == 0;
+        acc = first ? sg[dk][dj][di] * t : acc + sg[dk][dj][di] * t;
+        ssum = first ? sg[dk][dj][di] : ssum + sg[dk][dj][di];
       }
   Kp = acc;
   diag = w[0] * ssum;
