@@ -805,7 +805,8 @@ void k_mkflux(const vdn_multifab *s, vdn_multifab **sedge, vdn_multifab **flux, 
     FV w = work_fv(nullptr, bp, 0);
     const size_t fld = (size_t)w.sc * sizeof(double);
     FV sl[3], SI = w, SC = w;
-    for (int d = 0; d < 3; d++) { sl[d] = w; sl[d].p = (double *)arena_alloc(fld * ncomp); }
+    const bool cached = is_vel && ncomp == 3 && s->nfabs() == 1 && ctx().slope_cache[0] && ctx().slope_src == s->fabs[ib].p;
+    for (int d = 0; d < 3; d++) { sl[d] = w; sl[d].p = cached ? ctx().slope_cache[d] : (double *)arena_alloc(fld * ncomp); }
     SI.p = (double *)arena_alloc(fld * 3 * ncomp);
     SC.p = (double *)arena_alloc(fld * 6 * ncomp);
     double *umax = (double *)arena_alloc(256);
@@ -814,7 +815,7 @@ void k_mkflux(const vdn_multifab *s, vdn_multifab **sedge, vdn_multifab **flux, 
     for (int d = 0; d < 3; d++) { rg.lo[d] = A.lo[d] - 1; rg.hi[d] = A.hi[d] + 1; rf.lo[d] = A.lo[d]; rf.hi[d] = A.hi[d] + 1; }
     const FV &um = umac[0]->fabs[ib], &vm = umac[1]->fabs[ib], &wm = umac[2]->fabs[ib];
     hipLaunchKernelGGL(kk_macmax, reduce_grid(rf), dim3(64, 4, 1), 0, st, um, vm, wm, A, rf, umax);
-    hipLaunchKernelGGL(kk_slopes, grid_for(rg), dim3(64, 4, 1), 0, st, s->fabs[ib], sl[0], sl[1], sl[2], A, rg, 7);
+    if (!cached) hipLaunchKernelGGL(kk_slopes, grid_for(rg), dim3(64, 4, 1), 0, st, s->fabs[ib], sl[0], sl[1], sl[2], A, rg, 7);
     if (plain_godunov()) {
       hipLaunchKernelGGL(kk_mk_B, grid_for(rg), dim3(64, 4, 1), 0, st, s->fabs[ib], sl[0], sl[1], sl[2], um, vm, wm, force->fabs[ib], mac_rhs->fabs[ib], SI, A, rg, umax);
       hipLaunchKernelGGL(kk_mk_C, grid_for(rg), dim3(64, 4, 1), 0, st, s->fabs[ib], sl[0], sl[1], sl[2], um, vm, wm, force->fabs[ib], mac_rhs->fabs[ib], SI, SC, A, rg, umax);
@@ -1519,7 +1520,9 @@ void k_velpred(const vdn_multifab *u, vdn_multifab **umac, const vdn_multifab *f
     FV w = work_fv(nullptr, bp, 0);
     const size_t fld = (size_t)w.sc * sizeof(double);
     FV sl[3], UI = w, XC = w;
-    for (int d = 0; d < 3; d++) { sl[d] = w; sl[d].p = (double *)arena_alloc(fld * 3); }
+    const bool keep = ctx().slope_cache[0] != nullptr && u->nfabs() == 1;           // advance_timestep: mkflux(uold) reuses these slopes
+    for (int d = 0; d < 3; d++) { sl[d] = w; sl[d].p = keep ? ctx().slope_cache[d] : (double *)arena_alloc(fld * 3); }
+    if (keep) ctx().slope_src = u->fabs[ib].p;
     UI.p = (double *)arena_alloc(fld * 9);
     XC.p = (double *)arena_alloc(fld * 6);
     double *umax = (double *)arena_alloc(256);

@@ -85,6 +85,8 @@ struct VdnCtx {
   double *d_scal = nullptr; double *h_scal = nullptr;       // 64 doubles each
   double step_sec[5] = {0, 0, 0, 0, 0};
   int solver_cycles[2] = {0, 0}; double solver_res0[2] = {0, 0}, solver_res[2] = {0, 0};
+  // slopes of uold, computed by velpred and used again by the velocity mkflux of the same advance_timestep (one level, one box)
+  double *slope_cache[3] = {nullptr, nullptr, nullptr}; const double *slope_src = nullptr;
 };
 VdnCtx &ctx();
 
