@@ -868,24 +868,25 @@ struct coeffs_K { FV coeffs; FV rhohalf;
     fv_at(coeffs, i, j, k) = 1.0 / fv_get(rhohalf, i, j, k, 0);      // hg_multigrid.f90:76-77
   } };
 
-struct mkgphi_K { FV gp; FV phi; double dxi0; double dxi1; double dxi2;
-  __device__ void cell(int i, int j, int k) const {
+// cell-centred gradient of the nodal phi (mkgphi, hgproject.f90:538-580), component m at cell (i,j,k)
+DEVI double gphi_of(const FV &phi, int i, int j, int k, int m, double dxi) {
   #define P(a, b, c) fv_get(phi, i + (a), j + (b), k + (c))
-    fv_at(gp, i, j, k, 0) = 0.25 * (P(1, 0, 0) + P(1, 1, 0) + P(1, 0, 1) + P(1, 1, 1) - P(0, 0, 0) - P(0, 1, 0) - P(0, 0, 1) - P(0, 1, 1)) * dxi0;
-    fv_at(gp, i, j, k, 1) = 0.25 * (P(0, 1, 0) + P(1, 1, 0) + P(0, 1, 1) + P(1, 1, 1) - P(0, 0, 0) - P(1, 0, 0) - P(0, 0, 1) - P(1, 0, 1)) * dxi1;
-    fv_at(gp, i, j, k, 2) = 0.25 * (P(0, 0, 1) + P(1, 0, 1) + P(0, 1, 1) + P(1, 1, 1) - P(0, 0, 0) - P(1, 0, 0) - P(0, 1, 0) - P(1, 1, 0)) * dxi2;
+  if (m == 0) return 0.25 * (P(1, 0, 0) + P(1, 1, 0) + P(1, 0, 1) + P(1, 1, 1) - P(0, 0, 0) - P(0, 1, 0) - P(0, 0, 1) - P(0, 1, 1)) * dxi;
+  if (m == 1) return 0.25 * (P(0, 1, 0) + P(1, 1, 0) + P(0, 1, 1) + P(1, 1, 1) - P(0, 0, 0) - P(1, 0, 0) - P(0, 0, 1) - P(1, 0, 1)) * dxi;
+  return 0.25 * (P(0, 0, 1) + P(1, 0, 1) + P(0, 1, 1) + P(1, 1, 1) - P(0, 0, 0) - P(1, 0, 0) - P(0, 1, 0) - P(1, 1, 0)) * dxi;
   #undef P
-  } };
+}
 
-struct HgUpdArgs { int hi[3]; double dt, dtinv; int proj_type; };
-struct hg_update_K { FV unew; FV uold; FV gp; FV gphi; FV rhohalf; FV p; FV phi; HgUpdArgs A;
+struct HgUpdArgs { int hi[3]; double dt, dtinv, dxi[3]; int proj_type; };
+// mkgphi and the update of hgproject.f90:659-676 in one pass: grad phi is used where it is computed, no gphi multifab in between
+struct hg_update_K { FV unew; FV uold; FV gp; FV rhohalf; FV p; FV phi; HgUpdArgs A;
   __device__ void cell(int i, int j, int k) const {
     const bool cell = i <= A.hi[0] && j <= A.hi[1] && k <= A.hi[2];
     if (cell) {
       const double rho = fv_get(rhohalf, i, j, k, 0);
     #pragma unroll
       for (int m = 0; m < 3; m++) {
-        const double gph = fv_get(gphi, i, j, k, m);
+        const double gph = gphi_of(phi, i, j, k, m, A.dxi[m]);
         double v = fv_get(unew, i, j, k, m) - gph / rho;                    // hgproject.f90:659-667
         if (A.proj_type == VDN_PRESSURE_ITERS) v = fv_get(uold, i, j, k, m) + A.dt * v;
         fv_at(unew, i, j, k, m) = v;
@@ -921,15 +922,16 @@ static void hg_level_post(int proj_type, vdn_multifab *un, const vdn_multifab *u
                           vdn_multifab *gphi, const vdn_multifab *phi, const double *dx, double dt) {
   hipStream_t st = ctx().stream;
   if (proj_type == VDN_INITIAL_PROJECTION || proj_type == VDN_DIVU_ITERS) { mf_setval(gpp, 0.0, 0, gpp->nc, true); mf_setval(pp, 0.0, 0, 1, true); }   // 673-676
-  std::vector<std::pair<mkgphi_K, Range3>> vg; std::vector<std::pair<hg_update_K, Range3>> vh;
+  std::vector<std::pair<hg_update_K, Range3>> vh;
   for (int i = 0; i < un->nfabs(); i++) {
     Range3 rv, rn; HgUpdArgs H;
     for (int d = 0; d < 3; d++) { rv.lo[d] = rn.lo[d] = un->vbox[i].lo[d]; rv.hi[d] = un->vbox[i].hi[d]; rn.hi[d] = rv.hi[d] + 1; H.hi[d] = rv.hi[d]; }
     H.dt = dt; H.dtinv = 1.0 / dt; H.proj_type = proj_type;
-    vg.push_back({ mkgphi_K{ gphi->fabs[i], phi->fabs[i], 1.0 / dx[0], 1.0 / dx[1], 1.0 / dx[2] }, rv });
-    vh.push_back({ hg_update_K{ un->fabs[i], uo->fabs[i], gpp->fabs[i], gphi->fabs[i], rhh->fabs[i], pp->fabs[i], phi->fabs[i], H }, rn });
+    for (int d = 0; d < 3; d++) H.dxi[d] = 1.0 / dx[d];
+    vh.push_back({ hg_update_K{ un->fabs[i], uo->fabs[i], gpp->fabs[i], rhh->fabs[i], pp->fabs[i], phi->fabs[i], H }, rn });
   }
-  launch_cells(vg, st); launch_cells(vh, st);
+  (void)gphi;
+  launch_cells(vh, st);
 }
 static void do_ml_hgproject(int proj_type, vdn_layout *mla, vdn_multifab **unew, vdn_multifab **uold, vdn_multifab **rhohalf,
                             vdn_multifab **p, vdn_multifab **gp, const double *dx, double dt, const vdn_bc_tower *bct, int press_comp0);
