@@ -13,7 +13,8 @@ def main():
     rank, nranks = int(sys.argv[1]), int(sys.argv[2])
     idfile, outprefix = sys.argv[3], sys.argv[4]
     nlev, visc = int(sys.argv[5]), float(sys.argv[6])
-    tagged = len(sys.argv) > 7 and sys.argv[7] == "tagged"
+    tagged = len(sys.argv) > 7 and sys.argv[7] in ("tagged", "restart")
+    restart = len(sys.argv) > 7 and sys.argv[7] == "restart"          # continue from the checkpoint <argv[8]> written by a "tagged" run
     from varden_amd import boxlib as bl
     from varden_amd import driver
     from varden_amd.capi import default_params
@@ -34,7 +35,12 @@ def main():
     base = [((0, 0, 0), (7, 7, 15)), ((8, 0, 0), (15, 7, 15)), ((0, 8, 0), (7, 15, 15)), ((8, 8, 0), (15, 15, 15))]    # level 0 in four equal boxes (the single-level multigrid wants equal boxes)
     fine = [((8, 8, 8), (15, 23, 23)), ((16, 8, 8), (23, 15, 23)), ((16, 16, 8), (23, 23, 23))]          # partial shared faces
     finer = [[((24, 24, 24), (31, 39, 39)), ((32, 24, 24), (39, 39, 39))]] if nlev == 3 else []
-    if tagged:           # grids from the tagged bubble on a 32^3 base in four boxes, regridding every second step (inputs_bubble_3d)
+    if restart:          # grids and state from the checkpoint, every rank reads the boxes it owns (initialize_from_restart)
+        from varden_amd import plotfile
+        chk = plotfile.read_checkfile(sys.argv[8])
+        G = driver.VardenAMR(32, chk["boxes"][1], walls, params=prm, finer_levels=chk["boxes"][2:], base_boxes=chk["boxes"][0], regrid_int=2, max_levs=nlev,
+                             max_grid_size=16, rank=rank, nranks=nranks, comm_id=comm_id, restart=chk, restart_step=4)
+    elif tagged:         # grids from the tagged bubble on a 32^3 base in four boxes, regridding every second step (inputs_bubble_3d)
         base = [((0, 0, 0), (15, 15, 31)), ((16, 0, 0), (31, 15, 31)), ((0, 16, 0), (15, 31, 31)), ((16, 16, 0), (31, 31, 31))]
         levels = driver.VardenAMR.tagged_grids(32, walls, prm, max_levs=nlev, buf_wid=2, max_grid_size=16, rank=rank, nranks=nranks, comm_id=comm_id, base_boxes=base)
         G = driver.VardenAMR(32, levels[0], walls, params=prm, finer_levels=levels[1:], base_boxes=base, init_iter=1, do_initial_projection=1,
@@ -43,7 +49,7 @@ def main():
         G = driver.VardenAMR(16, fine, walls, params=prm, finer_levels=finer, base_boxes=base, init_iter=1, do_initial_projection=1,
                              rank=rank, nranks=nranks, comm_id=comm_id)
     dts = []
-    for _ in range(4 if tagged else 2):
+    for _ in range(2 if restart else (4 if tagged else 2)):
         G.step()
         dts.append(G.dt)
     out = {"dt": np.array(dts), "nboxes": np.array([len(b) for b in G.boxes]), "nregrids": np.array([G.nregrids])}
@@ -52,7 +58,7 @@ def main():
             out["u%d_%d" % (n, gi)] = G.unew[n].to_numpy(li)[3:-3, 3:-3, 3:-3]
             out["s%d_%d" % (n, gi)] = G.snew[n].to_numpy(li)[3:-3, 3:-3, 3:-3]
             out["p%d_%d" % (n, gi)] = G.p[n].to_numpy(li)[1:-1, 1:-1, 1:-1]
-    if tagged:                                             # plot and checkpoint files, every rank its own Cell_D file
+    if tagged and not restart:                             # plot and checkpoint files, every rank its own Cell_D file
         from varden_amd import plotfile
         plotfile.write_plotfile(G, base=outprefix + "_plt")
         plotfile.write_checkfile(G, base=outprefix + "_chk")

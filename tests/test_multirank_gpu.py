@@ -54,12 +54,12 @@ def test_ranks_reproduce_single_rank_bits(gpu, tmp_path, nranks, decomp, n, peri
     assert np.isfinite(got["u0"]).all() and np.abs(got["u0"]).max() > 0
 
 
-def run_amr_ranks(tmp_path, tag, nranks, nlev, visc, mode="fixed"):
+def run_amr_ranks(tmp_path, tag, nranks, nlev, visc, mode="fixed", extra=()):
     if nranks > 1 and not os.path.exists(FAKE):
         subprocess.check_call(["make", "-s", "-C", os.path.dirname(FAKE)])
     idfile, prefix = str(tmp_path / (tag + ".id")), str(tmp_path / tag)
     env = dict(os.environ, VDN_RCCL_LIB=FAKE, FAKE_RCCL_DIR=str(tmp_path))
-    procs = [subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "_multirank_amr_worker.py"), str(r), str(nranks), idfile, prefix, str(nlev), str(visc), mode],
+    procs = [subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "_multirank_amr_worker.py"), str(r), str(nranks), idfile, prefix, str(nlev), str(visc), mode] + list(extra),
                               env=env, cwd=ROOT) for r in range(nranks)]
     try:
         rcs = [p.wait(timeout=240) for p in procs]
@@ -102,6 +102,12 @@ def test_tagged_grids_and_regrid_on_two_ranks(gpu, tmp_path):
                 assert np.array_equal(x, y)
     assert os.path.exists(str(tmp_path / "tmr_plt00004" / "Level_01" / "Cell_D_00001"))
     assert open(str(tmp_path / "tref_chk00004" / "Header")).read() == open(str(tmp_path / "tmr_chk00004" / "Header")).read()
+    # restart on two ranks from the checkpoint the two ranks wrote == restart on one rank from the one-rank checkpoint (steps 5, 6; regrid at 5)
+    r1 = run_amr_ranks(tmp_path, "rref", 1, 2, 0.001, "restart", [str(tmp_path / "tref_chk00004")])
+    r2 = run_amr_ranks(tmp_path, "rmr", 2, 2, 0.001, "restart", [str(tmp_path / "tmr_chk00004")])
+    assert sorted(r1) == sorted(r2) and np.array_equal(r1["dt"], r2["dt"]) and np.array_equal(r1["nboxes"], r2["nboxes"])
+    for k in sorted(r1):
+        assert np.array_equal(r1[k], r2[k]), "restart: %s differs" % k
 
 
 @pytest.mark.parametrize("nranks,nlev,visc", [(2, 2, 0.0), (3, 2, 0.001), (2, 3, 0.001), (5, 3, 0.001)])
