@@ -86,10 +86,14 @@ __global__ void __launch_bounds__(256) kk_batched(const A *args, const int *star
   typename std::conditional<(sizeof(A) <= 320), const A, const A &>::type a = as_constant(args + lo);
   const int lb = bid - as_constant(start + lo);
   const int bx = lb % a.g[0], by = (lb / a.g[0]) % a.g[1], bz = lb / (a.g[0] * a.g[1]);
-  const int i = a.r.lo[0] + bx * 64 + (int)threadIdx.x, j = a.r.lo[1] + by * 4 + (int)threadIdx.y;
+  // tile of the 256 threads: 64 x 4, 32 x 8 or 16 x 16 by the width of the box (a level of an adaptive hierarchy is full of 16- and
+  // 32-wide boxes: a 64-wide tile would leave half or three quarters of every wave idle); log2(width) rides in the top byte of g[2]
+  const int lw = a.g[2] >> 24, gz = a.g[2] & 0xffffff;
+  const int tid = (int)threadIdx.x + 64 * (int)threadIdx.y;
+  const int i = a.r.lo[0] + (bx << lw) + (tid & ((1 << lw) - 1)), j = a.r.lo[1] + by * (256 >> lw) + (tid >> lw);
   double v = 0.0;
   if (i <= a.r.hi[0] && j <= a.r.hi[1])
-    for (int k = a.r.lo[2] + bz; k <= a.r.hi[2]; k += a.g[2]) v = fmax(v, A::body(a, i, j, k, extra));
+    for (int k = a.r.lo[2] + bz; k <= a.r.hi[2]; k += gz) v = fmax(v, A::body(a, i, j, k, extra));
   if (nrm) block_atomic_max_fwd(nrm, v);
 }
 // wave-level max (64 lanes) then one atomic per wave on a non-negative double stored as u64 bits
@@ -120,6 +124,16 @@ DEVI void block_atomic_max(double *addr, double v) {
   __syncthreads();
 }
 DEVI void block_atomic_max_fwd(double *addr, double v) { block_atomic_max(addr, v); }
+// workgroups of one box: tile width 64, 32 or 16 by the width of its range, kz = at most this many workgroups along k (0 = one per plane);
+// returns their number (an empty range gets one idle workgroup)
+template <class A> static inline int batch_grid(A &a, int kz) {
+  const int nx = a.r.hi[0] - a.r.lo[0] + 1, ny = a.r.hi[1] - a.r.lo[1] + 1, nz = a.r.hi[2] - a.r.lo[2] + 1;
+  const int lw = nx > 32 ? 6 : (nx > 16 ? 5 : 4), w = 1 << lw, h = 256 >> lw;
+  int g0 = nx > 0 ? (nx + w - 1) / w : 0, g1 = ny > 0 ? (ny + h - 1) / h : 0, g2 = nz > 0 ? ((kz > 0 && nz > kz) ? kz : nz) : 0;
+  if (g0 == 0 || g1 == 0 || g2 == 0) { g0 = g1 = g2 = 1; a.r.hi[0] = a.r.lo[0] - 1; }
+  a.g[0] = g0; a.g[1] = g1; a.g[2] = g2 | (lw << 24);
+  return g0 * g1 * g2;
+}
 // host side: fills g / the prefix sums, uploads and launches.  kz: at most this many workgroups along k per box (0 = one per plane)
 void *arena_alloc(size_t bytes);
 void upload_staged(void *dst, const void *src, size_t bytes);     // host -> device on the launch stream through a pinned ring (runtime.hip)
@@ -132,9 +146,8 @@ static inline void launch_batched(std::vector<A> &v, P extra, double *nrm, int k
   for (size_t b = 0; b < v.size(); b++) {
     A &a = v[b];
     const int nx = a.r.hi[0] - a.r.lo[0] + 1, ny = a.r.hi[1] - a.r.lo[1] + 1, nz = a.r.hi[2] - a.r.lo[2] + 1;
-    a.g[0] = nx > 0 ? (nx + 63) / 64 : 0; a.g[1] = ny > 0 ? (ny + 3) / 4 : 0; a.g[2] = nz > 0 ? ((kz > 0 && nz > kz) ? kz : nz) : 0;
-    if (a.g[0] == 0 || a.g[1] == 0 || a.g[2] == 0) { a.g[0] = a.g[1] = a.g[2] = 1; a.r.hi[0] = a.r.lo[0] - 1; }     // empty: one idle workgroup
-    start[b] = tot; tot += a.g[0] * a.g[1] * a.g[2];
+    (void)nx; (void)ny; (void)nz;
+    start[b] = tot; tot += batch_grid(a, kz);
   }
   A *d_args = (A *)desc_scratch(sizeof(A) * v.size());
   int *d_start = (int *)desc_scratch(sizeof(int) * v.size());
@@ -168,9 +181,8 @@ template <class A> struct BatchSet {
     for (size_t b = 0; b < v.size(); b++) {
       A &a = v[b];
       const int nx = a.r.hi[0] - a.r.lo[0] + 1, ny = a.r.hi[1] - a.r.lo[1] + 1, nz = a.r.hi[2] - a.r.lo[2] + 1;
-      a.g[0] = nx > 0 ? (nx + 63) / 64 : 0; a.g[1] = ny > 0 ? (ny + 3) / 4 : 0; a.g[2] = nz > 0 ? ((kz > 0 && nz > kz) ? kz : nz) : 0;
-      if (a.g[0] == 0 || a.g[1] == 0 || a.g[2] == 0) { a.g[0] = a.g[1] = a.g[2] = 1; a.r.hi[0] = a.r.lo[0] - 1; }
-      start[b] = tot; tot += a.g[0] * a.g[1] * a.g[2];
+      (void)nx; (void)ny; (void)nz;
+      start[b] = tot; tot += batch_grid(a, kz);
     }
     d_args = (A *)arena_alloc(sizeof(A) * v.size());
     d_start = (int *)arena_alloc(sizeof(int) * v.size());
