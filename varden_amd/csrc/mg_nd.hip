@@ -1038,7 +1038,7 @@ __global__ void kk_ndf_jacobi(FV ein, FV eout, FV rb, FV sig, NdfArgs A, double 
 // shuffles, three phi planes and two sigma planes in registers).  r: the node range of the box; tiles of 62 nodes along i.
 // MODE 0: eout = ein + omega (rb - K ein)/diag on free nodes;  MODE 1: res = b - K phi (0 on physical Dirichlet nodes), max-norm
 // over the nodes that are not interface nodes (excl = 1) / all nodes (excl = 0)
-struct MarchB { FV phi, out, rb, sig, slave; int has_slave; NdfArgs A; Range3 r; int g[3], kchunk; };
+struct MarchB { FV phi, out, rb, sig, slave; int has_slave; NdfArgs A; Range3 r; int g[3], kchunk, lw; };      // lw: log2 of the lane segment of one node row (6, 5, 4)
 template <int MODE>
 __global__ void __launch_bounds__(256) kk_ndf_march(const MarchB *args, const int *start, int nbox, double omega, int excl, double *nrm) {
   int lo_ = 0, hi_ = nbox - 1;
@@ -1050,11 +1050,15 @@ __global__ void __launch_bounds__(256) kk_ndf_march(const MarchB *args, const in
   const NdfArgs A = B.A; const Range3 r = B.r;
   const int lb = bid - as_constant(start + lo_);
   const int bx = lb % B.g[0], by = (lb / B.g[0]) % B.g[1], bz = lb / (B.g[0] * B.g[1]);
-  const int lane = threadIdx.x;
-  const int i = r.lo[0] + bx * 62 + lane - 1;
-  const int j = r.lo[1] + by * (int)blockDim.y + (int)threadIdx.y;
+  // a wave holds 64 >> lw node rows of 1 << lw lanes each (first and last lane of a row segment only feed their neighbours): boxes
+  // narrower than 31 / 15 nodes put two / four rows into a wave instead of leaving three quarters of it idle; the lane exchange
+  // never crosses a segment for an active lane
+  const int lw = B.lw, sw = 1 << lw, rows = 64 >> lw;
+  const int lane = (int)threadIdx.x & (sw - 1), seg = (int)threadIdx.x >> lw;
+  const int i = r.lo[0] + bx * (sw - 2) + lane - 1;
+  const int j = r.lo[1] + (by * (int)blockDim.y + (int)threadIdx.y) * rows + seg;
   const int k0 = r.lo[2] + bz * kchunk, k1 = min(k0 + kchunk - 1, r.hi[2]);
-  const bool active = lane >= 1 && lane <= 62 && i <= r.hi[0] && j <= r.hi[1];
+  const bool active = lane >= 1 && lane <= sw - 2 && i <= r.hi[0] && j <= r.hi[1];
   const int ic = min(i, r.hi[0] + 1), jc = min(j, r.hi[1]);
   double rmax = 0.0;
   if (k0 <= k1) {
@@ -1140,11 +1144,13 @@ static MarchSet ndf_build_march(std::vector<MarchB> &v) {
   for (size_t b = 0; b < v.size(); b++) {
     MarchB &B = v[b];
     const int nx = B.r.hi[0] - B.r.lo[0] + 1, ny = B.r.hi[1] - B.r.lo[1] + 1, nz = B.r.hi[2] - B.r.lo[2] + 1;
-    const int tiles = ((nx + 61) / 62) * ((ny + 3) / 4);
+    B.lw = nx <= 14 ? 4 : (nx <= 30 ? 5 : 6);
+    const int act = (1 << B.lw) - 2, rows = 4 * (64 >> B.lw);
+    const int tiles = ((nx + act - 1) / act) * ((ny + rows - 1) / rows);
     int kchunk = nz;
     while (kchunk > 8 && tiles * ((nz + kchunk - 1) / kchunk) < 2048) kchunk = (kchunk + 1) / 2;
     if (v.size() > 16 && nz <= 64) kchunk = nz;              // many small boxes fill the chip by themselves: no redundant warm-up planes
-    B.kchunk = kchunk; B.g[0] = (nx + 61) / 62; B.g[1] = (ny + 3) / 4; B.g[2] = (nz + kchunk - 1) / kchunk;
+    B.kchunk = kchunk; B.g[0] = (nx + act - 1) / act; B.g[1] = (ny + rows - 1) / rows; B.g[2] = (nz + kchunk - 1) / kchunk;
     start[b] = S.tot; S.tot += B.g[0] * B.g[1] * B.g[2];
   }
   S.d_args = (MarchB *)arena_alloc(sizeof(MarchB) * v.size());
