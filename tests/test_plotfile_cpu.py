@@ -92,3 +92,25 @@ def test_two_writers_one_level_set(tmp_path):
     assert ch[9] == "FabOnDisk: Cell_D_00001 0" and ch[10] == "FabOnDisk: Cell_D_00000 0"
     mins = [float(x) for x in ch[13].split(",")[:2]]
     assert mins == [lv[1]["fabs"][0][..., c].min() for c in range(2)]
+
+
+class _FakeSim:
+    """the attributes write_grids / write_job_info read from a driver object"""
+    dm, nc, rank, nranks, phys = 3, 16, 0, 1, [[15, 15], [14, 14], [-1, -1]]
+    boxes = [[((0, 0, 0), (15, 15, 15))], [((8, 8, 8), (23, 23, 15)), ((8, 8, 16), (23, 23, 23))]]
+    local = [[0], [0, 1]]
+
+
+def test_grids_file_round_trip_and_job_info(tmp_path):
+    """write_grids (src/varden.f90:621-662) appends a block per call; read_grids (read_a_hgproj_grid) takes the first one"""
+    g = str(tmp_path / "grids.out")
+    pf.write_grids(g, _FakeSim, 0)
+    pf.write_grids(g, _FakeSim, 4)
+    text = open(g).read()
+    assert text.count("At step") == 2 and "   ((0, 0, 0) (15, 15, 15) (0,0,0))    1\n" in text and "   ((0, 0, 0) (31, 31, 31) (0,0,0))    2\n" in text
+    domains, levels = pf.read_grids(g)
+    assert domains == [((0, 0, 0), (15, 15, 15)), ((0, 0, 0), (31, 31, 31))] and levels == _FakeSim.boxes
+    pf.write_job_info(str(tmp_path), _FakeSim, inputs_text="&PROBIN\n max_levs = 2\n/", job_name="bubble")
+    info = open(str(tmp_path / "job_info")).read()
+    assert "job name:    bubble" in info and "level: 2" in info and "number of boxes = 2" in info
+    assert "-x: no slip wall" in info and "+y: slip wall" in info and "-z: periodic" in info and "max_levs = 2" in info
