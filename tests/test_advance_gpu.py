@@ -84,3 +84,23 @@ def test_advance_parity_viscous(gpu, name, phys, prob, dtype):
         err = float(np.abs(a_ - b_).max())
         assert err <= 1e-9 * scale, "%s: %s differs by %.3e (scale %.3e)" % (name, nm, err, scale)
     G.close()
+
+
+def test_long_run_stays_with_the_oracle(gpu):
+    """80 viscous steps of the falling blob at 24^3 -- through the phase in which it reaches the floor and the density leaves its initial
+    bounds: time and time step stay within 1e-12, the fields within 1e-10 (tools/long_vs_oracle.py: 300
+    steps at 32^3, 1e-14 at step 100, 2e-8 at step 300)"""
+    from oracle import voracle as vo
+    from varden_amd import driver
+    mk = lambda: params_for(WALLS, cflfac=0.9, visc_coef=0.001)   # noqa: E731
+    kw = dict(prob_type=1, grav=-9.8, init_shrink=0.1, init_iter=2)
+    O = vo.Sim(24, WALLS, mk(), **kw)
+    G = driver.Varden(24, WALLS, mk(), **kw)
+    for _ in range(80):
+        O.step(); G.step()
+    assert abs(G.time - O.time) <= 1e-12 * O.time and abs(G.dt - O.dt) <= 1e-12 * O.dt
+    s, so = G.snew[0].to_numpy()[3:-3, 3:-3, 3:-3], O.snew.valid()
+    u, uo = G.unew[0].to_numpy()[3:-3, 3:-3, 3:-3], O.unew.valid()
+    assert so[..., 0].max() < 5.0                                   # the blob (rho = 10) has been smeared over the floor
+    assert np.abs(s - so).max() <= 1e-10 * np.abs(so).max() and np.abs(u - uo).max() <= 1e-10 * np.abs(uo).max()
+    G.close()
