@@ -1,24 +1,35 @@
 #!/usr/bin/env python
 """bench.py -- cells*steps/sec of advance_timestep on the MI355X-native hot path.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--box 256] [--skip-cpu]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--config 256|512|amr2|amr3] [--scaling weak|strong]
 
-Workload (BASELINE.json configs[1]): 3-D 256^3 single-level variable-density bubble
-(reference src/initdata.f90:212-238, exec/test/inputs_bubble_3d with visc_coef = 0), one 256^3 box,
-no-slip walls, gravity -9.8, cflfac 0.9, init_shrink 0.1, init_iter 1; MAC + HG projection every
-step.  A "step" = one pass of the reference's time-loop body (src/varden.f90:291-328): ghost fills,
-estdt, advance_timestep, uold<-unew.  All state is resident in HBM before the timed region.
+`--gpus N` with N > 1 STARTS ITS OWN N RANKS: the parent process touches neither torch.cuda nor HIP, spawns N children (one per
+GPU, RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT in their environment), waits for them and exits with their code;
+rank 0 prints the one JSON line.  Under torchrun (WORLD_SIZE already set) the process is one of the ranks and spawns nothing.
 
-One JSON line is printed by rank 0.  `roofline` is the MAC-multigrid red-black Gauss-Seidel colour
-pass on the finest level (48 algorithmic B/cell/pass), timed with HIP events on the launch
-stream inside the library; `cpu_baseline` is the CPU oracle (a port, OpenMP) on a bounded sample.
-For N > 1 the domain is decomposed: one 256^3 box per rank/GPU (weak scaling; N = 8 is the 512^3 / 2x2x2
-case of BASELINE.json configs[2]), ghost cells and multigrid halos exchanged with RCCL point-to-point
-over xGMI, norms / estdt by ncclAllReduce, coarse multigrid levels agglomerated (all-gather).
+Workloads (BASELINE.json `configs`; every run: variable-density bubble of src/initdata.f90:212-238, no-slip walls, gravity -9.8,
+cflfac 0.9, init_shrink 0.1, init_iter 1, MAC + HG projection every step, exec/test/inputs_bubble_3d with visc_coef = 0):
+  256  (default)  configs[1]: 3-D 256^3, one level, one 256^3 box per GPU.  N > 1: weak scaling, the domain grows 2x1x1 / 2x2x1 /
+                  2x2x2 (N = 8 is the 512^3 case of configs[2]).
+  512             configs[2] / the north star's single-GPU case: 512^3, one level, max_grid_size 256 => eight 256^3 boxes dealt
+                  round-robin to the N ranks (N = 1: all eight on one GPU).  `--scaling strong` selects it for any N: the global
+                  problem is fixed, so the per-N values give the strong-scaling curve.
+  amr2            configs[3]: 256^3 base + one refined level over the cells tagged rho > 1.01 (tag_boxes.f90:65-75), grids built
+                  once and fixed (initialize.f90:93-150); boxes dealt to the ranks by cell count.
+  amr3            configs[4]: 256^3 base + two refined levels (rho > 1.01, rho > 1.1); N > 1: the base level is cut into 128^3
+                  boxes so that every level can be dealt to the ranks.
+A "step" = one pass of the reference's time-loop body (src/varden.f90:291-328): ghost fills, estdt, advance_timestep, uold<-unew.
+All state is resident in HBM before the timed region.
+
+`roofline` is the MAC-multigrid red-black Gauss-Seidel colour pass on the finest level (48 algorithmic B/cell/pass),
+timed with HIP events on the launch stream inside the library; `cpu_baseline` is the CPU oracle (a port, OpenMP) on a bounded
+sample of the same workload, with the survey's per-core timing of the reference's own Godunov kernels quoted next to it.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -26,24 +37,73 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0   # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+# the reference's own velpred + mkflux (scalars, velocity) + update, flang -O2, ONE core, 128^3: 2.91 s per
+# step of advection alone => 0.72 Mcells/s/core (no forcing, no ghost fills, no multigrid): an upper bound on the reference's
+# per-core advance_timestep rate
+REF_GODUNOV_MCELLS_PER_CORE = 0.72
 
 
-def main():
+def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--box", dest="n", type=int, default=256)
-    ap.add_argument("--cpu-box", dest="cpu_n", type=int, default=128)
+    ap.add_argument("--config", default=os.environ.get("VDN_BENCH_CONFIG", "256"), choices=["256", "512", "amr2", "amr3"])
+    ap.add_argument("--scaling", default=os.environ.get("VDN_BENCH_SCALING", "weak"), choices=["weak", "strong"])
+    ap.add_argument("--box", dest="n", type=int, default=256, help="box width (256/512) or base-level width (amr2/amr3)")
+    ap.add_argument("--cpu-box", dest="cpu_n", type=int, default=0, help="width of the CPU sample (0: 128, or 64 for amr)")
     ap.add_argument("--skip-cpu", dest="no_cpu", action="store_true")
-    args = ap.parse_args()
+    return ap.parse_args()
+
+
+def spawn_ranks(args):
+    """start one child per GPU; this process never initialises the GPU (no torch import, no HIP call)"""
+    n = args.gpus
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+    rc = 0
+    try:
+        pending = list(procs)
+        while pending:
+            for p in list(pending):
+                r = p.poll()
+                if r is None:
+                    continue
+                pending.remove(p)
+                if r != 0 and rc == 0:
+                    rc = r
+                    for q in pending:          # a rank died: the others would wait in a collective forever
+                        q.terminate()
+            time.sleep(0.05)
+    finally:
+        for p in procs:                        # exact PIDs of the children started above
+            if p.poll() is None:
+                p.kill()
+    return rc
+
+
+def main():
+    args = parse_args()
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        sys.exit(spawn_ranks(args))
+    if args.scaling == "strong" and args.config == "256":
+        args.config = "512"
+    if args.config == "512":
+        args.scaling = "strong"
 
     import torch
     import torch.distributed as dist
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    one_dev = os.environ.get("VDN_BENCH_ONE_DEVICE") == "1"     # debugging aid: every rank on GPU 0, gloo control plane
+    assert args.gpus in (1, world), "--gpus %d but WORLD_SIZE=%d" % (args.gpus, world)
+    one_dev = os.environ.get("VDN_BENCH_ONE_DEVICE") == "1"     # debugging aid: every rank on GPU 0, gloo control plane, RCCL test double
     if one_dev:
         local_rank = 0
     if world > 1:
@@ -55,6 +115,7 @@ def main():
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     assert torch.cuda.is_available(), "bench.py needs a GPU: the product path has no CPU fallback"
 
+    import numpy as np
     from varden_amd import advance as adv
     from varden_amd import boxlib as bl
     from varden_amd import driver
@@ -63,11 +124,6 @@ def main():
     n = args.n
     walls = [[bl.NO_SLIP_WALL] * 2] * 3
     prm = default_params(cflfac=0.9)
-    decomp = {1: (1, 1, 1), 2: (2, 1, 1), 4: (2, 2, 1), 8: (2, 2, 2)}.get(world)
-    assert decomp is not None, "bench.py supports 1, 2, 4 or 8 GPUs"
-    nglob = tuple(n * decomp[d] for d in range(3))
-    h = 1.0 / (n * max(decomp))                            # dx = dy = dz; N = 8 gives the unit cube at 512^3
-    prob_hi = tuple(nglob[d] * h for d in range(3))
     comm_id = None
     if world > 1:                                          # RCCL unique id: rank 0 creates it, everybody receives it
         bl.initialize(prm, rank, world, local_rank)
@@ -76,8 +132,47 @@ def main():
             idt.copy_(torch.tensor(list(bl.comm_get_unique_id()), dtype=torch.uint8))
         dist.broadcast(idt, 0)
         comm_id = bytes(idt.cpu().tolist())
-    G = driver.Varden(nglob, walls, prm, prob_type=1, grav=-9.8, prob_hi=prob_hi, init_shrink=0.1, init_iter=1,
-                      device=local_rank, decomp=decomp, rank=rank, nranks=world, comm_id=comm_id)
+
+    amr = args.config in ("amr2", "amr3")
+    if amr:
+        max_levs = 2 if args.config == "amr2" else 3
+        base_boxes = None
+        if world > 1:                                      # cut the base level so that it can be dealt to the ranks
+            hb = n // 2
+            base_boxes = [((i * hb, j * hb, k * hb), ((i + 1) * hb - 1, (j + 1) * hb - 1, (k + 1) * hb - 1))
+                          for k in range(2) for j in range(2) for i in range(2)]
+        mgs = min(256, n)
+        levels = driver.VardenAMR.tagged_grids(n, walls, prm, max_levs=max_levs, max_grid_size=mgs, device=local_rank, rank=rank, nranks=world,
+                                               comm_id=comm_id, base_boxes=base_boxes)
+        assert len(levels) == max_levs - 1, "tagging produced %d refined levels, %d wanted" % (len(levels), max_levs - 1)
+        G = driver.VardenAMR(n, levels[0], walls, params=prm, finer_levels=levels[1:], init_shrink=0.1, init_iter=1, do_initial_projection=1,
+                             device=local_rank, rank=rank, nranks=world, comm_id=comm_id, base_boxes=base_boxes, max_grid_size=mgs)
+        lev_cells = [n ** 3] + [sum(int(np.prod([b[1][d] - b[0][d] + 1 for d in range(3)])) for b in lb) for lb in levels]
+        cells = sum(lev_cells)
+        workload = ("3D %d-level AMR, base %d^3, refined levels tagged rho > 1.01%s (tag_boxes.f90:65-84), fixed grids: %s boxes, %s cells per level; "
+                    "composite MAC + HG solves each step (BASELINE.json configs[%d])"
+                    % (max_levs, n, " / rho > 1.1" if max_levs == 3 else "", [1 if base_boxes is None else 8] + [len(lb) for lb in levels], lev_cells,
+                       3 if max_levs == 2 else 4))
+        par = "single GPU" if world == 1 else "boxes of every level dealt to %d ranks by cell count (knapsack), RCCL p2p ghost / coarse-fine exchange + allreduce" % world
+    else:
+        if args.config == "512":                           # fixed global problem: 2x2x2 boxes of n^3, dealt round-robin
+            decomp = (2, 2, 2)
+            assert 8 % world == 0, "the 8 boxes of the 512 config need 1, 2, 4 or 8 ranks"
+        else:
+            decomp = {1: (1, 1, 1), 2: (2, 1, 1), 4: (2, 2, 1), 8: (2, 2, 2)}.get(world)
+            assert decomp is not None, "bench.py supports 1, 2, 4 or 8 GPUs"
+        nglob = tuple(n * decomp[d] for d in range(3))
+        h = 1.0 / (n * max(decomp))                        # dx = dy = dz; 2x2x2 gives the unit cube
+        prob_hi = tuple(nglob[d] * h for d in range(3))
+        G = driver.Varden(nglob, walls, prm, prob_type=1, grav=-9.8, prob_hi=prob_hi, init_shrink=0.1, init_iter=1,
+                          device=local_rank, decomp=decomp, rank=rank, nranks=world, comm_id=comm_id)
+        cells = nglob[0] * nglob[1] * nglob[2]
+        nb = decomp[0] * decomp[1] * decomp[2]
+        workload = ("3D %dx%dx%d single-level variable-density bubble, %d box(es) of %d^3, MAC+HG projection each step (BASELINE.json configs[%d])"
+                    % (nglob + (nb, n, 1 if nb == 1 else 2)))
+        par = "single GPU" if world == 1 else ("domain decomposition %dx%dx%d, %d box(es) of %d^3 per GPU, RCCL p2p ghost exchange + allreduce"
+                                               % (decomp + (nb // world, n)))
+    rccl_nranks = bl.comm_nranks()
 
     def barrier():
         if world > 1:
@@ -103,20 +198,23 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         el = float(t.item())
 
-    cells = n ** 3 * world
     value = cells * args.steps / el
-    rho = G.sold[0].to_numpy()[..., 0] if rank == 0 else None      # rank 0's box, for the smoother probe's coefficients
-    G.close()                                                     # also tears the RCCL communicator down
+    rho = None
+    if rank == 0 and not amr:
+        rho = G.sold[0].to_numpy()[..., 0]                  # rank 0's first box, for the smoother probe's coefficients
+    G.close()                                              # also tears the RCCL communicator down
 
-    # ---- roofline of the dominant kernel: one colour pass of the MAC-MG smoother at n^3 ----------
+    # ---- roofline of the dominant kernel: one colour pass of the MAC-MG smoother at 256^3 ----------
     roof = None
     if rank == 0:
         bl.initialize(prm, 0, 1, local_rank)               # the probe is a single-rank, single-box measurement
-        lo0, hi0 = (0, 0, 0), (n - 1,) * 3
+        pn = n if not amr else 256
+        if rho is None:                                     # amr: the same bubble density on one 256^3 box
+            rho = driver.initdata_numpy((pn,) * 3, [1.0 / pn] * 3, 1, 3, 2)[1][..., 0]
+        lo0, hi0 = (0, 0, 0), (pn - 1,) * 3
         mla = bl.MLLayout([(lo0, hi0)], [[(lo0, hi0)]])
         rh, phi = bl.MultiFab(mla, 0, 1, 0), bl.MultiFab(mla, 0, 1, 1)
         beta = [bl.MultiFab(mla, 0, 1, 0, tuple(1 if t == d else 0 for t in range(3))) for d in range(3)]
-        import numpy as np
         for d in range(3):      # beta = 2/(rho_i + rho_{i-1})  (macproject.f90:376-394), built on the host for the probe
             sl_hi = [slice(3, -3)] * 3
             sl_lo = [slice(3, -3)] * 3
@@ -124,27 +222,30 @@ def main():
             sl_lo[d] = slice(2, rho.shape[d] - 3)
             beta[d].from_numpy((2.0 / (rho[tuple(sl_hi)] + rho[tuple(sl_lo)]))[..., None])
         rng = np.random.default_rng(0)
-        r = rng.standard_normal((n, n, n, 1))
+        r = rng.standard_normal((pn, pn, pn, 1))
         rh.from_numpy(r - r.mean())
         bc = [[bl.BC_NEU] * 2] * 3
         rho_mf = bl.MultiFab(mla, 0, 1, 3)
         rho_mf.from_numpy(rho[..., None])
         # the pass macproject runs on its finest level (face coefficients recomputed from rho), and the stored-coefficient pass next to it
-        ms, ncell = adv.bench_cc_smoother(rh, phi, beta, [1.0 / n] * 3, bc, 200, rho=rho_mf)
-        ms_stored, _ = adv.bench_cc_smoother(rh, phi, beta, [1.0 / n] * 3, bc, 200)
+        ms, ncell = adv.bench_cc_smoother(rh, phi, beta, [1.0 / pn] * 3, bc, 200, rho=rho_mf)
+        ms_stored, _ = adv.bench_cc_smoother(rh, phi, beta, [1.0 / pn] * 3, bc, 200)
         rho_mf.destroy()
         alg_bytes = 48.0 * ncell
         achieved = alg_bytes / (ms * 1e-3) / 1e9
-        # HBM traffic per launch from the PMC passes (FETCH_SIZE x2 + WRITE_SIZE, MI355X_MICROARCH.md), collected
-        # separately with `rocprofv3 --pmc` on tools/smoother_probe.py and committed under profiles/
-        traffic = None
-        pmc = os.path.join(ROOT, "profiles", "r01_smoother_rho_pmc.json")        # the kernel timed above (kk_cc_gsrb_rho_pair)
-        if n == 256 and os.path.exists(pmc):
-            traffic = json.load(open(pmc))["hbm_bytes_per_launch"]
+        # HBM bytes per launch: PMC passes (FETCH_SIZE x2 + WRITE_SIZE, MI355X_MICROARCH.md) collected with `rocprofv3 --pmc` on
+        # tools/smoother_probe.py in a separate run and committed; not measured in THIS run, and said so in traffic_source
+        traffic, traffic_source = None, None
+        for name in ("r02_smoother_rho_pmc.json", "r01_smoother_rho_pmc.json"):
+            pmc = os.path.join(ROOT, "profiles", name)
+            if pn == 256 and os.path.exists(pmc):
+                traffic = json.load(open(pmc))["hbm_bytes_per_launch"]
+                traffic_source = "profiles/%s (committed rocprofv3 --pmc passes of the same kernel; not measured in this run)" % name
+                break
         roof = {"bound": "hbm", "kernel": "kk_cc_gsrb_rho_pair (MAC-MG red-black GS colour pass, %d^3; beta recomputed from rho, 2x2 cells per thread: ~34 B/cell of "
-                                          "real traffic against the 48 B/cell algorithmic figure; stored-beta pass kk_cc_gsrb: %.5f ms)" % (n, ms_stored),
+                                          "real traffic against the 48 B/cell algorithmic figure; stored-beta pass kk_cc_gsrb_pair: %.5f ms)" % (pn, ms_stored),
                 "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+                "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_source,
                 "avg_launch_ms": round(ms, 5), "alg_bytes_per_launch": alg_bytes}
         for m in [rh, phi] + beta:
             m.destroy()
@@ -155,32 +256,45 @@ def main():
         nthreads = min(16, os.cpu_count() or 1)
         os.environ["OMP_NUM_THREADS"] = str(nthreads)
         from oracle import voracle as vo
-        cn = args.cpu_n
-        O = vo.Sim(cn, walls, default_params(cflfac=0.9), prob_type=1, grav=-9.8, init_shrink=0.1, init_iter=1)
+        if amr:
+            cn = args.cpu_n or 64
+            # the oracle's hierarchies hold one box per level: the sample refines the bounding box of the tagged region
+            flo, fhi = [cn], [0]
+            for b in driver.VardenAMR.tagged_grids(cn, walls, default_params(cflfac=0.9), max_levs=2, max_grid_size=256, device=local_rank)[0]:
+                flo.append(min(b[0])); fhi.append(max(b[1]))
+            flo, fhi = (min(flo) // 2 * 2,) * 3, ((max(fhi) + 1) // 2 * 2 - 1,) * 3
+            O = vo.Sim2L(cn, flo, fhi, walls, prm=default_params(cflfac=0.9), init_shrink=0.1, init_iter=1, do_initial_projection=1)
+            ccells = cn ** 3 + (fhi[0] - flo[0] + 1) ** 3
+            sample = "%d^3 base + one refined box %s..%s (bounding box of the rho > 1.01 tags), composite solves" % (cn, flo, fhi)
+        else:
+            cn = args.cpu_n or 128
+            O = vo.Sim(cn, walls, default_params(cflfac=0.9), prob_type=1, grav=-9.8, init_shrink=0.1, init_iter=1)
+            ccells = cn ** 3
+            sample = "%d^3 bubble (same problem, smaller box)" % cn
         tc = time.perf_counter()
         O.step()
         tcpu = time.perf_counter() - tc
-        cpu = {"value": round(cn ** 3 / tcpu, 1), "unit": "cells*steps/s", "cores": nthreads, "kind": "port",
-               "sample": "%d^3 bubble (same problem, smaller box), 1 timed step after the initial pressure iteration; "
-                         "gcc -O2 -fopenmp, OMP_NUM_THREADS=%d" % (cn, nthreads)}
+        cpu = {"value": round(ccells / tcpu, 1), "unit": "cells*steps/s", "cores": nthreads, "kind": "port",
+               "sample": "%s, 1 timed step (%.1f s) after the start-up sequence; gcc -O2 -fopenmp, OMP_NUM_THREADS=%d" % (sample, tcpu, nthreads),
+               "reference_godunov_mcells_per_s_per_core": REF_GODUNOV_MCELLS_PER_CORE,
+               "reference_note": "BASELINE.md 1b: the reference's own velpred+mkflux+update (flang -O2, 1 core, 128^3) = 0.72 Mcells/s/core for advection "
+                                 "alone (no multigrid): x%d cores = %.2e cells*steps/s is an upper bound on the reference's advance_timestep on this host"
+                                 % (nthreads, REF_GODUNOV_MCELLS_PER_CORE * 1e6 * nthreads)}
 
     if rank == 0:
         out = {
             "metric": "cells*steps/sec on advance_timestep",
             "value": round(value, 1), "unit": "cells*steps/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "n_gpus": world, "rccl_nranks": rccl_nranks, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(1e3 * el / args.steps, 3),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "higher_is_better": True, "scaling": args.scaling if not amr else "strong", "vs_baseline": None,
             "dtype": "f64", "data": "synthetic",
-            "config": {"workload": "3D %d^3 single-level variable-density bubble, 1 box/GPU, MAC+HG projection each step "
-                                   "(BASELINE.json configs[1])" % n,
-                       "parallelism": "single GPU" if world == 1 else
-                                      "domain decomposition %dx%dx%d, one %d^3 box per GPU (global %dx%dx%d), RCCL p2p ghost exchange + allreduce" % (decomp + (n,) + nglob),
+            "config": {"workload": workload, "parallelism": par, "cells": cells,
                        "phase_ms_per_step": {k: round(1e3 * v / args.steps, 3) for k, v in phases.items()},
                        "vcycles_per_step": {k: round(v / args.steps, 2) for k, v in cyc.items()}},
             "roofline": roof, "cpu_baseline": cpu,
         }
-        print(json.dumps(out))
+        print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()
 

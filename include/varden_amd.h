@@ -99,6 +99,8 @@ int  vdn_get_params(vdn_params *out);
 int  vdn_comm_get_unique_id(char *id128);
 int  vdn_comm_init(const char *id128);
 int  vdn_comm_finalize(void);
+/* ranks of the live RCCL communicator (ncclCommCount); 1 when none is up -- bench.py reports it as rccl_nranks */
+int  vdn_comm_nranks(int *n);
 /* MAX over the ranks of n host doubles, in place (parallel_reduce(..., MPI_MAX) of a Fortran driver; the file writers use it for the
  * per-box minima / maxima and as their barrier).  No-op when nranks = 1. */
 int  vdn_comm_allreduce_max(double *host, int n);

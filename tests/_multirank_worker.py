@@ -19,9 +19,10 @@ def main():
     from varden_amd import driver
     from varden_amd.capi import default_params
     prm = default_params(cflfac=0.9)
+    dev = rank if os.environ.get("VDN_WORKER_DEVICE_PER_RANK") == "1" else 0     # real RCCL: one GPU per rank
     comm_id = None
     if nranks > 1:
-        bl.initialize(prm, rank, nranks, 0)
+        bl.initialize(prm, rank, nranks, dev)
         if rank == 0:
             cid = bl.comm_get_unique_id()
             with open(idfile + ".tmp", "wb") as f:
@@ -37,7 +38,7 @@ def main():
         walls = [[bl.PERIODIC] * 2] + [[bl.NO_SLIP_WALL] * 2] * 2
     h = 1.0 / max(n)
     G = driver.Varden(n, walls, prm, prob_type=1, grav=-9.8, prob_hi=tuple(n[d] * h for d in range(3)), init_shrink=0.1, init_iter=1,
-                      device=0, decomp=decomp, rank=rank, nranks=nranks, comm_id=comm_id)
+                      device=dev, decomp=decomp, rank=rank, nranks=nranks, comm_id=comm_id)
     dts = []
     for _ in range(nsteps):
         G.step()

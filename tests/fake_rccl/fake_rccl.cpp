@@ -107,6 +107,7 @@ int ncclCommInitRank(Comm **out, int nranks, ncclUniqueId id, int rank) {
   *out = c;
   return 0;
 }
+int ncclCommCount(Comm *c, int *count) { *count = c->nranks; return 0; }
 int ncclCommDestroy(Comm *c) {
   barrier(c);
   munmap(c->base, c->map_bytes);

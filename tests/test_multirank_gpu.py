@@ -15,11 +15,15 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 FAKE = os.path.join(ROOT, "tests", "fake_rccl", "libfake_rccl.so")
 
 
-def run_ranks(tmp_path, tag, nranks, decomp, n, nsteps, periodic):
+def run_ranks(tmp_path, tag, nranks, decomp, n, nsteps, periodic, real_rccl=False):
     if nranks > 1 and not os.path.exists(FAKE):
         subprocess.check_call(["make", "-s", "-C", os.path.dirname(FAKE)])
     idfile, prefix = str(tmp_path / (tag + ".id")), str(tmp_path / tag)
-    env = dict(os.environ, VDN_RCCL_LIB=FAKE, FAKE_RCCL_DIR=str(tmp_path))
+    if real_rccl:                                # one GPU per rank, the RCCL torch ships (dlopen of librccl.so.1)
+        env = dict(os.environ, VDN_WORKER_DEVICE_PER_RANK="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+        env.pop("VDN_RCCL_LIB", None)
+    else:
+        env = dict(os.environ, VDN_RCCL_LIB=FAKE, FAKE_RCCL_DIR=str(tmp_path))
     procs = [subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "_multirank_worker.py"), str(r), str(nranks), idfile, prefix]
                               + [str(x) for x in decomp] + [str(x) for x in n] + [str(nsteps), str(int(periodic))], env=env, cwd=ROOT)
              for r in range(nranks)]
@@ -52,6 +56,57 @@ def test_ranks_reproduce_single_rank_bits(gpu, tmp_path, nranks, decomp, n, peri
     for k in sorted(ref):
         assert np.array_equal(ref[k], got[k]), "%s differs: max %.3e" % (k, np.abs(ref[k] - got[k]).max())
     assert np.isfinite(got["u0"]).all() and np.abs(got["u0"]).max() > 0
+
+
+def _ngpus():
+    import torch
+    return torch.cuda.device_count()          # counting devices does not initialise the GPU
+
+
+@pytest.mark.skipif(_ngpus() < 2, reason="needs two GPUs: real RCCL refuses two ranks on one device")
+@pytest.mark.parametrize("periodic", [False, True])
+def test_two_gpus_real_rccl_reproduce_single_rank_bits(gpu, tmp_path, periodic):
+    """2 ranks on 2 REAL GPUs under the real RCCL transport (ncclSend/ncclRecv groups, ncclAllReduce(MAX),
+    ncclAllGather of the agglomerated multigrid tail) reproduce the single-rank run on the same two boxes bit for bit"""
+    ref = run_ranks(tmp_path, "ref", 1, (2, 1, 1), (64, 32, 32), 2, periodic)
+    got = run_ranks(tmp_path, "rccl", 2, (2, 1, 1), (64, 32, 32), 2, periodic, real_rccl=True)
+    assert sorted(ref) == sorted(got) and np.array_equal(ref["dt"], got["dt"])
+    for k in sorted(ref):
+        assert np.array_equal(ref[k], got[k]), "%s differs: max %.3e" % (k, np.abs(ref[k] - got[k]).max())
+
+
+def _bench_line(args, env):
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args, env=env, cwd=ROOT, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, out.stdout
+    import json
+    return json.loads(lines[0])
+
+
+@pytest.mark.parametrize("extra", [[], ["--scaling", "strong"], ["--config", "amr2"]])
+def test_bench_spawns_its_own_ranks(gpu, tmp_path, extra):
+    """`python bench.py --gpus 2` from a bare shell (no torchrun, no WORLD_SIZE) starts two ranks itself and prints ONE line with
+    n_gpus = 2 and rccl_nranks = 2 read back from the communicator.  On a one-GPU box both ranks share the device
+    (VDN_BENCH_ONE_DEVICE) and the transport is the RCCL test double; with two GPUs present the real RCCL runs"""
+    env = dict(os.environ)
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    if _ngpus() < 2:
+        if not os.path.exists(FAKE):
+            subprocess.check_call(["make", "-s", "-C", os.path.dirname(FAKE)])
+        env.update(VDN_BENCH_ONE_DEVICE="1", VDN_RCCL_LIB=FAKE, FAKE_RCCL_DIR=str(tmp_path))
+    line = _bench_line(["--gpus", "2", "--steps", "2", "--warmup", "1", "--box", "32", "--skip-cpu"] + extra, env)
+    assert line["n_gpus"] == 2 and line["rccl_nranks"] == 2 and line["value"] > 0
+    assert line["scaling"] == ("weak" if not extra else "strong")
+    one = _bench_line(["--gpus", "1", "--steps", "2", "--warmup", "1", "--box", "32", "--skip-cpu"] + extra, env)
+    assert one["n_gpus"] == 1 and one["rccl_nranks"] == 1
+    if extra:                                   # strong scaling / fixed hierarchy: the same global problem on 1 and 2 ranks
+        assert one["config"]["cells"] == line["config"]["cells"]
+        if "amr2" not in extra:                 # (the two-rank hierarchy cuts its base level into 8 boxes: per-box eps of the Godunov dead-band)
+            assert one["config"]["vcycles_per_step"] == line["config"]["vcycles_per_step"]
+    else:
+        assert 2 * one["config"]["cells"] == line["config"]["cells"]
 
 
 def run_amr_ranks(tmp_path, tag, nranks, nlev, visc, mode="fixed", extra=()):

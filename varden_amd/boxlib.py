@@ -62,6 +62,13 @@ def comm_allreduce_max(a):
     return a
 
 
+def comm_nranks():
+    """ranks of the live RCCL communicator, read back from RCCL (1 when none is up)"""
+    n = C.c_int(0)
+    check(capi.load().vdn_comm_nranks(C.byref(n)))
+    return int(n.value)
+
+
 def comm_finalize():
     global _comm_up
     if _comm_up:

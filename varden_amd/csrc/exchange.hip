@@ -37,6 +37,7 @@ struct Rccl {
   int (*GetUniqueId)(ncclUniqueId *) = nullptr;
   int (*CommInitRank)(ncclComm_t *, int, ncclUniqueId, int) = nullptr;
   int (*CommDestroy)(ncclComm_t) = nullptr;
+  int (*CommCount)(ncclComm_t, int *) = nullptr;
   int (*Send)(const void *, size_t, int, int, ncclComm_t, hipStream_t) = nullptr;
   int (*Recv)(void *, size_t, int, int, ncclComm_t, hipStream_t) = nullptr;
   int (*AllReduce)(const void *, void *, size_t, int, int, ncclComm_t, hipStream_t) = nullptr;
@@ -57,7 +58,7 @@ static void rccl_load() {
   for (const char *n : names) { if (!n || !*n) continue; g_rccl.h = dlopen(n, RTLD_NOW | RTLD_LOCAL); if (g_rccl.h) break; }
   REQUIRE(g_rccl.h, "cannot dlopen librccl.so.1: %s", dlerror());
   #define SYM(field, name) do { *(void **)(&g_rccl.field) = dlsym(g_rccl.h, name); REQUIRE(g_rccl.field, "RCCL symbol %s missing", name); } while (0)
-  SYM(GetUniqueId, "ncclGetUniqueId"); SYM(CommInitRank, "ncclCommInitRank"); SYM(CommDestroy, "ncclCommDestroy");
+  SYM(GetUniqueId, "ncclGetUniqueId"); SYM(CommInitRank, "ncclCommInitRank"); SYM(CommDestroy, "ncclCommDestroy"); SYM(CommCount, "ncclCommCount");
   SYM(Send, "ncclSend"); SYM(Recv, "ncclRecv"); SYM(AllReduce, "ncclAllReduce"); SYM(AllGather, "ncclAllGather");
   SYM(GroupStart, "ncclGroupStart"); SYM(GroupEnd, "ncclGroupEnd"); SYM(GetErrorString, "ncclGetErrorString");
   #undef SYM
@@ -84,6 +85,13 @@ extern "C" int vdn_comm_init(const char *id128) {
 extern "C" int vdn_comm_finalize(void) {
   VDN_TRY
   if (g_rccl.comm) { HIPCHK(hipStreamSynchronize(ctx().stream)); NCCLCHK(g_rccl.CommDestroy(g_rccl.comm)); g_rccl.comm = nullptr; }
+  VDN_CATCH
+}
+// number of ranks of the live communicator, read back from RCCL (ncclCommCount); 1 when no communicator is up
+extern "C" int vdn_comm_nranks(int *n) {
+  VDN_TRY
+  *n = 1;
+  if (g_rccl.comm) NCCLCHK(g_rccl.CommCount(g_rccl.comm, n));
   VDN_CATCH
 }
 bool comm_active() { return ctx().nranks > 1 || g_rccl.comm != nullptr; }
