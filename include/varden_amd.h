@@ -44,7 +44,7 @@ enum { VDN_INITIAL_PROJECTION = 1, VDN_DIVU_ITERS = 2, VDN_PRESSURE_ITERS = 3, V
 /* ---- runtime parameters read implicitly by the reference kernels through probin_module
  *      (reference src/_parameters, src/probin.template).  One POD passed once. ------------- */
 typedef struct vdn_params {
-  int    dm;              /* dim_in: only 3 is implemented on the device path                 */
+  int    dm;              /* dim_in: 3, or 2 (one level, one box: BASELINE configs[0])         */
   int    nscal;           /* nscal (2)                                                        */
   int    slope_order;     /* 0, 2 or 4 (default 4)                                            */
   int    use_minion;      /* logical use_minion (default 0)                                   */
@@ -69,6 +69,8 @@ typedef struct vdn_params {
   double hg_omega;                /* nodal Jacobi damping                                     */
   double mac_rel_eps;             /* 1e-10: reference src/macproject.f90:91-93                */
   double hg_rel_eps;              /* <=0: use 1e-12/1e-11/1e-10 by nlevs, hgproject.f90:113-119 */
+  int    abort_on_max_iter;       /* 1 (default): a solve that reaches its iteration cap or meets a non-finite norm fails the call,
+                                   * as FBoxLib's solvers abort (bl_error); 0: report through vdn_last_solver_stats and go on */
 } vdn_params;
 
 /* fills *p with the reference defaults (src/_parameters) */

@@ -79,3 +79,12 @@ def test_product_does_not_reference_the_oracle():
                     if re.search(r"(#include|import|from|-l|-L).*(voracle|oracle/|vo\.h|libvoracle)", ln):
                         bad.append((fn, ln.strip()))
     assert not bad, bad
+
+
+def test_namelist_parser_keeps_paths_and_quoted_commas():
+    """a quoted value may hold '/' and ',' (plot_base_name = 'out/plt'); unquoted values still end at ',' '/' or the line"""
+    from varden_amd.inputs import parse_namelist
+    nl = parse_namelist("&PROBIN\n plot_base_name = 'out/plt'  ! comment\n check_base_name = \"a,b/chk\"\n n_cellx = 64, n_celly = 32\n"
+                        " stop_time = 2.5d0\n use_minion = .true.\n u_bc(1,1) = 1.0\n fixed_grids = 'grids/g.txt'\n/\n")
+    assert nl["plot_base_name"] == "out/plt" and nl["check_base_name"] == "a,b/chk" and nl["fixed_grids"] == "grids/g.txt"
+    assert nl["n_cellx"] == 64 and nl["n_celly"] == 32 and nl["stop_time"] == 2.5 and nl["use_minion"] == 1 and nl["u_bc(1,1)"] == 1.0

@@ -109,6 +109,32 @@ def test_macproject(gpu, oracle, bcname):
     case.close()
 
 
+def test_blown_up_field_fails_loudly(gpu, oracle):
+    """the norms are NaN-propagating (a NaN residual used to read as 0 = converged) and a failed solve fails the call,
+    as FBoxLib's solvers abort on max_iter; abort_on_max_iter = 0 restores report-and-continue"""
+    from varden_amd import advance as adv
+    from varden_amd import boxlib as bl
+    case = Case((16, 16, 16), BC_SETS["walls"], seed=3, iso=True)
+    u, s = case.random_state()
+    s.a[..., 0] = np.abs(s.a[..., 0]) + 0.5
+    um = face_fabs(case, 1, 1, 0.0)
+    um[0].a[8, 8, 8, 0] = np.nan
+    mac_rhs = case.ofab(1, 1)
+    gum = [case.gmf(f) for f in um]
+    with pytest.raises(Exception, match="non-finite"):
+        adv.macproject(case.mla, [gum], [case.gmf(s)], [case.gmf(mac_rhs)], [case.dx], case.bct, case.obc.press_comp + 1)
+    u.a[5, 5, 5, 1] = np.inf
+    gp, ext = case.ofab(1, 3), case.ofab(1, 3)
+    with pytest.raises(Exception, match="non-finite"):
+        adv.estdt(1, case.gmf(u), case.gmf(s), case.gmf(gp), case.gmf(ext), case.dx, 1.0)
+    # max_iter reached: one cycle cannot reach 1e-10
+    s2, beta, rh, ell = mac_problem(case)
+    bc = [[ell[d][sd] for sd in range(2)] for d in range(3)]
+    with pytest.raises(Exception, match="did not converge"):
+        adv.cc_solve(case.gmf(rh), case.gmf(case.ofab(1, 1)), [case.gmf(b) for b in beta], case.dx, bc, 1e-10, max_iter=1)
+    case.close()
+
+
 @pytest.mark.parametrize("bcname", ["walls", "periodic", "inout", "mixed"])
 @pytest.mark.parametrize("n", [(16, 16, 16), (8, 16, 32)])
 def test_nd_solve(gpu, oracle, bcname, n):

@@ -45,6 +45,7 @@ extern "C" int vdn_advance_timestep(int istep, vdn_layout *mla, vdn_multifab **s
     REQUIRE(gp[n]->ng >= 1 && p[n]->ng >= 1 && ext_vel_force[n]->ng >= 1 && ext_scal_force[n]->ng >= 1, "gp/p/ext forces need ng = 1");
     REQUIRE(sold[n]->nc == nscal && nscal <= 3, "sold must have nscal (<= 3) components");
   }
+  Prof prof_advance("advance");                                                        // bl_prof names of advance_timestep.f90:60,99,107,123,132
   arena_reset();
   arena_reserve_for(mla);
   const double t_begin = wall();
@@ -75,6 +76,7 @@ extern "C" int vdn_advance_timestep(int istep, vdn_layout *mla, vdn_multifab **s
 
   // advance_premac.f90:44-51
   {
+    Prof pr("advance_premac");
     size_t mark = arena_mark();
     vdn_multifab *vel_force[VDN_MAXLEV];
     for (int n = 0; n < nlevs; n++) {
@@ -93,12 +95,15 @@ extern "C" int vdn_advance_timestep(int istep, vdn_layout *mla, vdn_multifab **s
 
   // MAC projection (advance_timestep.f90:97-104)
   sync(); double t0 = wall();
+  { Prof pr("MAC_Project");
   do_macproject(mla, umac, sold, mac_rhs, dx, bct, press_comp - 1);
+  }
   sync(); ctx().step_sec[2] = wall() - t0;
 
   // scalar_advance.f90:54-118
   t0 = wall();
   {
+    Prof pr("Scalar_update");
     size_t mark = arena_mark();
     int is_cons[VDN_MAXCOMP]; is_cons[0] = 1; for (int c = 1; c < nscal; c++) is_cons[c] = 0;
     vdn_multifab *scal_force[VDN_MAXLEV], *divu[VDN_MAXLEV], *sflux[3 * VDN_MAXLEV], *sedge[3 * VDN_MAXLEV], *laps[VDN_MAXLEV] = { nullptr };
@@ -135,13 +140,14 @@ extern "C" int vdn_advance_timestep(int istep, vdn_layout *mla, vdn_multifab **s
   sync(); ctx().step_sec[0] = wall() - t0;
 
   // make_at_halftime (advance_timestep.f90:114, make_at_halftime.f90:64-65)
-  for (int n = 0; n < nlevs; n++) k_make_at_halftime(rhohalf[n], sold[n], snew[n], 0, 0);
+  { Prof pr("make_at_halftime"); for (int n = 0; n < nlevs; n++) k_make_at_halftime(rhohalf[n], sold[n], snew[n], 0, 0); }
   restrict_and_fill(nlevs, rhohalf, 0, dm + 0, 1, false, bct);
   if (viscous && P.diffusion_type == 2) for (int n = 0; n < nlevs; n++) mf_setval(lapu[n], 0.0, 0, dm, true);   // advance_timestep.f90:116-120
 
   // velocity_advance.f90:48-93
   t0 = wall();
   {
+    Prof pr("Velocity_update");
     size_t mark = arena_mark();
     int is_cons[3] = { 0, 0, 0 };
     vdn_multifab *vel_force[VDN_MAXLEV], *uflux[3 * VDN_MAXLEV], *uedge[3 * VDN_MAXLEV];
@@ -169,7 +175,8 @@ extern "C" int vdn_advance_timestep(int istep, vdn_layout *mla, vdn_multifab **s
 
   // hgproject (advance_timestep.f90:129-137)
   t0 = wall();
-  do_hgproject(proj_type, mla, unew, uold, rhohalf, p, gp, dx, dt, bct, press_comp - 1);
+  { Prof pr("HG_Project");
+  do_hgproject(proj_type, mla, unew, uold, rhohalf, p, gp, dx, dt, bct, press_comp - 1); }
   sync(); ctx().step_sec[3] = wall() - t0;
   #undef DXL
 
@@ -190,6 +197,7 @@ extern "C" int vdn_estdt(int lev, const vdn_multifab *u, const vdn_multifab *s, 
   (void)lev;
   double m[6];
   k_estdt_max(u, s, gp, ext, m);
+  for (int q = 0; q < 6; q++) REQUIRE(m[q] < HUGE_VAL, "estdt: non-finite velocity or pressure-gradient term (the state has blown up)");
   // (multi-rank: all-reduce MAX of the six maxima is equivalent to the reference's MIN of dt_proc)
   const double eps = (double)1.0e-8f;                 // single-precision literal, estdt.f90:146
   double dt = 1.e20;

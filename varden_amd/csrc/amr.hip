@@ -706,8 +706,8 @@ int ml_cc_solve(vdn_layout *la, vdn_multifab **rh, vdn_multifab **phi, vdn_multi
   for (int d = 0; d < 3; d++) for (int s = 0; s < 2; s++) ebc0[d][s] = bct->ell_bc(0, 0, d, s, bc_comp0);
   while (!conv) {
     rn = composite_residual(S);
-    if (rn <= rel_eps * bnorm) { conv = true; break; }
-    if (it >= max_iter) break;
+    if (rn <= rel_eps * bnorm && bnorm < HUGE_VAL) { conv = true; break; }
+    if (it >= max_iter || !(rn < HUGE_VAL) || !(bnorm < HUGE_VAL)) break;
     // pre-relaxation, finest level first (homogeneous interface), then the residual the next coarser level will see
     for (int n = L - 1; n >= 1; n--) {
       level_relax(S, n, P.mg_nu1);
@@ -754,7 +754,7 @@ void do_ml_macproject(vdn_layout *mla, vdn_multifab **umac, vdn_multifab **rho, 
   int it; double r0, rr;
   int rc = ml_cc_solve(mla, rh, phi, beta, dx, bct, bc_comp0, ctx().prm.mac_rel_eps, ctx().prm.mg_max_iter, &it, &r0, &rr, nullptr);
   ctx().solver_cycles[0] = it; ctx().solver_res0[0] = r0; ctx().solver_res[0] = rr;
-  if (rc != 0 && ctx().prm.verbose) fprintf(stderr, "varden_amd: composite MAC solve did not converge in %d iterations (res %g / %g)\n", it, rr, r0);
+  solver_check(rc, "composite MAC solve", it, rr, r0);
   for (int n = 0; n < L; n++) mac_level_mkumac(umac + 3 * n, phi[n], beta + 3 * n, dx + 3 * n, bct, bc_comp0);   // 103
   for (int n = L - 1; n >= 1; n--) for (int d = 0; d < 3; d++) ml_edge_restriction(umac[3 * (n - 1) + d], umac[3 * n + d], d);       // 497-500
   for (int d = 0; d < 3; d++) mf_fill_boundary(umac[d]);

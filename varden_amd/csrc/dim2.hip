@@ -307,8 +307,8 @@ int cc2_solve(vdn_multifab *rh, vdn_multifab *phi, vdn_multifab **beta, const do
     c2_gsrb(M, L0, M.lev.size() == 1 ? c2_bottom(L0) : P.mg_nu1);
     c2_residual(M, L0, true);
     rn = read_scal(M.d_nrm);
-    if (rn <= rel_eps * bnorm || rn <= abs_eps) { conv = true; break; }
-    if (cyc == max_iter) break;
+    if ((rn <= rel_eps * bnorm && bnorm < HUGE_VAL) || rn <= abs_eps) { conv = true; break; }
+    if (cyc == max_iter || !(rn < HUGE_VAL) || !(bnorm < HUGE_VAL)) break;
     if (M.lev.size() > 1) {
       hipLaunchKernelGGL(kk_c2_restrict, g2(M.lev[1].n0, M.lev[1].n1), B2, 0, st, L0, M.lev[1]);
       c2_vcycle(M, 1);
@@ -372,7 +372,7 @@ void do2_macproject(vdn_layout *mla, vdn_multifab **umac, vdn_multifab **rho, vd
   int cyc; double r0, rr;
   int rc = cc2_solve(rh, phi, beta, dx, ebc, ctx().prm.mac_rel_eps, -1.0, ctx().prm.mg_max_iter, &cyc, &r0, &rr, nullptr);
   ctx().solver_cycles[0] = cyc; ctx().solver_res0[0] = r0; ctx().solver_res[0] = rr;
-  if (rc != 0 && ctx().prm.verbose) fprintf(stderr, "varden_amd: MAC multigrid (2-D) did not converge in %d cycles (res %g / %g)\n", cyc, rr, r0);
+  solver_check(rc, "MAC multigrid (2-D)", cyc, rr, r0);
   Um2Args A;
   for (int d = 0; d < 2; d++) { A.lo[d] = bx.lo[d]; A.hi[d] = bx.hi[d]; A.dx[d] = dx[d]; for (int s = 0; s < 2; s++) A.ebc[d][s] = ebc[d][s]; }
   hipLaunchKernelGGL(kk2_mkumac, grid_for(rf), B2, 0, st, umac[0]->fabs[0], umac[1]->fabs[0], phi->fabs[0], beta[0]->fabs[0], beta[1]->fabs[0], A, rf);
@@ -447,7 +447,7 @@ void do2_visc_solve(vdn_layout *mla, vdn_multifab *unew, const vdn_multifab *lap
     int ebc[3][2];
     for (int a = 0; a < 3; a++) for (int s = 0; s < 2; s++) ebc[a][s] = a < 2 ? bct->ell_bc(0, 0, a, s, d) : VDN_BC_INT;
     int cyc; double r0, rr;
-    cc2_solve(rh, phi, beta, dx, ebc, 1.e-12, -1.0, ctx().prm.mg_max_iter, &cyc, &r0, &rr, alpha);
+    solver_check(cc2_solve(rh, phi, beta, dx, ebc, 1.e-12, -1.0, ctx().prm.mg_max_iter, &cyc, &r0, &rr, alpha), "viscous solve (2-D)", cyc, rr, r0, d);
     mf_copy(unew, d, phi, 0, 1, 0);
   }
   mf_restrict_and_fill(unew, 0, 0, 2, false, bct);
@@ -467,7 +467,7 @@ void do2_diff_scalar_solve(vdn_layout *mla, vdn_multifab *snew, const vdn_multif
   int ebc[3][2];
   for (int a = 0; a < 3; a++) for (int s = 0; s < 2; s++) ebc[a][s] = a < 2 ? bct->ell_bc(0, 0, a, s, bccomp0) : VDN_BC_INT;
   int cyc; double r0, rr;
-  cc2_solve(rh, phi, beta, dx, ebc, 1.e-12, -1.0, ctx().prm.mg_max_iter, &cyc, &r0, &rr, alpha);
+  solver_check(cc2_solve(rh, phi, beta, dx, ebc, 1.e-12, -1.0, ctx().prm.mg_max_iter, &cyc, &r0, &rr, alpha), "diffusive solve (2-D)", cyc, rr, r0);
   mf_copy(snew, icomp, phi, 0, 1, 0);
   mf_restrict_and_fill(snew, icomp, bccomp0, 1, false, bct);
   mf_temp_free(beta[0]); mf_temp_free(beta[1]); mf_temp_free(alpha); mf_temp_free(phi); mf_temp_free(rh);
@@ -667,8 +667,8 @@ int nd2_solve(vdn_multifab *rh, vdn_multifab *phi, const vdn_multifab *coeffs, c
     n2_jacobi(M, L0, M.lev.size() == 1 ? n2_bottom(L0) : P.hg_nu1);
     n2_residual(M, L0, true);
     rn = read_scal(M.d_nrm);
-    if (rn <= rel_eps * bnorm || rn <= abs_eps) { conv = true; break; }
-    if (cyc >= max_iter) break;
+    if ((rn <= rel_eps * bnorm && bnorm < HUGE_VAL) || rn <= abs_eps) { conv = true; break; }
+    if (cyc >= max_iter || !(rn < HUGE_VAL) || !(bnorm < HUGE_VAL)) break;     // also: a NaN / inf norm (the reductions turn NaN into +inf)
     if (M.lev.size() > 1) {
       hipLaunchKernelGGL(kk_n2_restrict, g2(M.lev[1].n0 + 1, M.lev[1].n1 + 1), B2, 0, st, L0, M.lev[1]);
       n2_vcycle(M, 1);
@@ -760,7 +760,7 @@ void do2_hgproject(int proj_type, vdn_layout *mla, vdn_multifab **unew, vdn_mult
   int cyc; double r0, rr;
   int rc = nd2_solve(rh, phi, coeffs, un, dx, ebc, rel, abs_eps, ctx().prm.hg_max_iter, &cyc, &r0, &rr);
   ctx().solver_cycles[1] = cyc; ctx().solver_res0[1] = r0; ctx().solver_res[1] = rr;
-  if (rc != 0 && ctx().prm.verbose) fprintf(stderr, "varden_amd: nodal multigrid (2-D) did not converge in %d cycles (res %g / %g)\n", cyc, rr, r0);
+  solver_check(rc, "nodal multigrid (2-D)", cyc, rr, r0);
   if (proj_type == VDN_INITIAL_PROJECTION || proj_type == VDN_DIVU_ITERS) { mf_setval(gpp, 0.0, 0, gpp->nc, true); mf_setval(pp, 0.0, 0, 1, true); }
   Hg2Args H; H.hi[0] = bx.hi[0]; H.hi[1] = bx.hi[1]; H.dt = dt; H.dtinv = 1.0 / dt; H.dxi[0] = 1.0 / dx[0]; H.dxi[1] = 1.0 / dx[1]; H.proj_type = proj_type;
   Range3 rn = rng2(bx.lo[0], bx.hi[0] + 1, bx.lo[1], bx.hi[1] + 1);

@@ -158,20 +158,25 @@ __global__ void __launch_bounds__(256) k_xcopy(const CopyDesc *descs, const int 
     for (int c = 0; c < nc; c++) fv_at(D.dst, i, j, k, c) = fv_get(D.src, i - D.sh[0], j - D.sh[1], k - D.sh[2], c);
   }
 }
+constexpr unsigned XPACK_WG = 32;
 __global__ void k_xpack(const PackDesc *descs, int nc, double *buf) {
-  const PackDesc &D = descs[blockIdx.z];
+  // XPACK_WG workgroups per descriptor, descriptor = blockIdx.x / XPACK_WG (gridDim.x may be 2^31 - 1; gridDim.z is capped at 65535,
+  // which a level of a few thousand boxes with periodic images exceeds)
+  const PackDesc &D = descs[blockIdx.x / XPACK_WG];
   const int nx = D.hi[0] - D.lo[0] + 1, ny = D.hi[1] - D.lo[1] + 1, nz = D.hi[2] - D.lo[2] + 1;
   const long tot = (long)nx * ny * nz;
-  for (long t = (long)blockIdx.x * blockDim.x + threadIdx.x; t < tot; t += (long)gridDim.x * blockDim.x) {
+  for (long t = (long)(blockIdx.x % XPACK_WG) * blockDim.x + threadIdx.x; t < tot; t += (long)XPACK_WG * blockDim.x) {
     const int i = D.lo[0] + (int)(t % nx), j = D.lo[1] + (int)((t / nx) % ny), k = D.lo[2] + (int)(t / ((long)nx * ny));
     for (int c = 0; c < nc; c++) buf[D.off + c * tot + t] = fv_get(D.fv, i - D.sh[0], j - D.sh[1], k - D.sh[2], c);
   }
 }
 __global__ void k_xunpack(const PackDesc *descs, int nc, const double *buf) {
-  const PackDesc &D = descs[blockIdx.z];
+  // XPACK_WG workgroups per descriptor, descriptor = blockIdx.x / XPACK_WG (gridDim.x may be 2^31 - 1; gridDim.z is capped at 65535,
+  // which a level of a few thousand boxes with periodic images exceeds)
+  const PackDesc &D = descs[blockIdx.x / XPACK_WG];
   const int nx = D.hi[0] - D.lo[0] + 1, ny = D.hi[1] - D.lo[1] + 1, nz = D.hi[2] - D.lo[2] + 1;
   const long tot = (long)nx * ny * nz;
-  for (long t = (long)blockIdx.x * blockDim.x + threadIdx.x; t < tot; t += (long)gridDim.x * blockDim.x) {
+  for (long t = (long)(blockIdx.x % XPACK_WG) * blockDim.x + threadIdx.x; t < tot; t += (long)XPACK_WG * blockDim.x) {
     const int i = D.lo[0] + (int)(t % nx), j = D.lo[1] + (int)((t / nx) % ny), k = D.lo[2] + (int)(t / ((long)nx * ny));
     const bool inside = i >= D.vlo[0] && i <= D.vhi[0] && j >= D.vlo[1] && j <= D.vhi[1] && k >= D.vlo[2] && k <= D.vhi[2];
     if (inside) continue;
@@ -295,7 +300,7 @@ void xplan_run(XPlan *P) {
     bool remote = self_rccl;
     for (auto &pr : P->peers) {
       if (pr.rank != ctx().rank) remote = true;
-      if (!pr.pack.empty()) hipLaunchKernelGGL(k_xpack, dim3(32, 1, (unsigned)pr.pack.size()), dim3(256), 0, st, pr.d_pack, nc, pr.d_send);
+      if (!pr.pack.empty()) hipLaunchKernelGGL(k_xpack, dim3(XPACK_WG * (unsigned)pr.pack.size()), dim3(256), 0, st, pr.d_pack, nc, pr.d_send);
     }
     if (remote) {
       need_comm();
@@ -313,7 +318,7 @@ void xplan_run(XPlan *P) {
   if (!P->local.empty())
     hipLaunchKernelGGL(k_xcopy, dim3((unsigned)P->lchunks), dim3(256), 0, st, P->d_local, P->d_lstart, (int)P->local.size(), nc);
   for (auto &pr : P->peers)
-    if (!pr.unpack.empty()) hipLaunchKernelGGL(k_xunpack, dim3(32, 1, (unsigned)pr.unpack.size()), dim3(256), 0, st, pr.d_unpack, nc, pr.d_recv);
+    if (!pr.unpack.empty()) hipLaunchKernelGGL(k_xunpack, dim3(XPACK_WG * (unsigned)pr.unpack.size()), dim3(256), 0, st, pr.d_unpack, nc, pr.d_recv);
 }
 
 // ====================================================================================================
@@ -343,7 +348,7 @@ void SrcView::refresh() const {
   hipStream_t st = ctx().stream;
   need_comm();
   for (auto &pr : plan->peers)
-    if (!pr.pack.empty()) hipLaunchKernelGGL(k_xpack, dim3(32, 1, (unsigned)pr.pack.size()), dim3(256), 0, st, pr.d_pack, plan->nc, pr.d_send);
+    if (!pr.pack.empty()) hipLaunchKernelGGL(k_xpack, dim3(XPACK_WG * (unsigned)pr.pack.size()), dim3(256), 0, st, pr.d_pack, plan->nc, pr.d_send);
   NCCLCHK(g_rccl.GroupStart());
   for (auto &pr : plan->peers) {
     if (pr.nsend) NCCLCHK(g_rccl.Send(pr.d_send, pr.nsend, ncclFloat64, pr.rank, g_rccl.comm, st));

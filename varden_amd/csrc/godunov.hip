@@ -749,6 +749,7 @@ void k_slope(const vdn_multifab *s, vdn_multifab *slope, int dir, int bccomp, co
 void k_mkflux(const vdn_multifab *s, vdn_multifab **sedge, vdn_multifab **flux, vdn_multifab **umac,
               const vdn_multifab *force, const vdn_multifab *mac_rhs, const double *dx, double dt,
               const vdn_bc_tower *bct, bool is_vel, const int *is_cons) {
+  Prof prof_("mkflux");
   if (ctx().prm.dm == 2) { k2_mkflux(s, sedge, flux, umac, force, mac_rhs, dx, dt, bct, is_vel, is_cons); return; }
   const int ncomp = s->nc;
   REQUIRE(ncomp <= 3, "mkflux: at most 3 components per call (got %d)", ncomp);
@@ -1479,6 +1480,7 @@ __global__ void __launch_bounds__(64 * TNY) kk_vp_D_mb(const VpD *descs, const i
 }
 void k_velpred(const vdn_multifab *u, vdn_multifab **umac, const vdn_multifab *force, const double *dx, double dt,
                const vdn_bc_tower *bct) {
+  Prof prof_("velpred");
   if (ctx().prm.dm == 2) { k2_velpred(u, umac, force, dx, dt, bct); return; }
   REQUIRE(u->nc == 3 && u->ng >= 3 && force->ng >= 1 && umac[0]->ng >= 1, "velpred: operand shapes");
   hipStream_t st = ctx().stream;

@@ -424,7 +424,7 @@ template <bool RHO> DEVI void cc_residual_body(const CLev &L, double *nrm) {
       double Ap, diag; cc_apply<RHO>(L, c, Ap, diag, i, j, k);
       const double r = L.rh[c] - Ap;
       L.res[c] = r;
-      rmax = fmax(rmax, fabs(r));
+      rmax = nmax(rmax, fabs(r));
     }
   if (nrm) block_atomic_max(nrm, rmax);
 }
@@ -464,7 +464,7 @@ __global__ void __launch_bounds__(256) kk_cc_residual_rho_pair(CLev L, double *n
       for (int m = 0; m < 4; m++) {
         cc_apply_rho_vals(L, 2 * t + (m & 1), jA + (m >> 1), k, P[m], R[m], Ap, diag);
         r[m] = rhs[m] - Ap;
-        rmax = fmax(rmax, fabs(r[m]));
+        rmax = nmax(rmax, fabs(r[m]));
       }
       *reinterpret_cast<double2 *>(L.res + cpA) = make_double2(r[0], r[1]);
       *reinterpret_cast<double2 *>(L.res + cpA + L.PX) = make_double2(r[2], r[3]);
@@ -1082,6 +1082,7 @@ static void cc_store(CCMG &M, vdn_multifab *phi, const int bc[3][2]) {
 
 int cc_solve(vdn_multifab *rh, vdn_multifab *phi, vdn_multifab **beta, const double *dx, const int bc[3][2],
              double rel_eps, double abs_eps, int max_iter, int *cycles, double *res0, double *res, const vdn_multifab *alpha, const vdn_multifab *rho) {
+  Prof prof_("mac_multigrid");
   if (ctx().prm.dm == 2) return cc2_solve(rh, phi, beta, dx, bc, rel_eps, abs_eps, max_iter, cycles, res0, res, alpha);
   const vdn_params &P = ctx().prm;
   size_t mark = arena_mark();
@@ -1110,8 +1111,8 @@ int cc_solve(vdn_multifab *rh, vdn_multifab *phi, vdn_multifab **beta, const dou
     else cc_gsrb_d(M, D0, P.mg_nu1);
     cc_residual_d(M, D0, true);
     rn = read_scalar(M.d_nrm);
-    if (rn <= rel_eps * bnorm || rn <= abs_eps) { conv = true; break; }
-    if (cyc >= max_iter) break;
+    if ((rn <= rel_eps * bnorm && bnorm < HUGE_VAL) || rn <= abs_eps) { conv = true; break; }
+    if (cyc >= max_iter || !(rn < HUGE_VAL) || !(bnorm < HUGE_VAL)) break;     // also: a NaN / inf norm (the reductions turn NaN into +inf)
     if (!single) {
       cc_restrict_down(M, 0);
       if (M.dlev.size() > 1) cc_vcycle_d(M, 1); else cc_vcycle_t(M, 0);
@@ -1258,7 +1259,7 @@ void do_macproject(vdn_layout *mla, vdn_multifab **umac, vdn_multifab **rho, vdn
   int cyc; double r0, rr;
   int rc = cc_solve(rh, phi, beta, dx, ebc, ctx().prm.mac_rel_eps, -1.0, ctx().prm.mg_max_iter, &cyc, &r0, &rr, nullptr, rho[n]);   // macproject.f90:91-93
   ctx().solver_cycles[0] = cyc; ctx().solver_res0[0] = r0; ctx().solver_res[0] = rr;
-  if (rc != 0 && ctx().prm.verbose) fprintf(stderr, "varden_amd: MAC multigrid did not converge in %d cycles (res %g / %g)\n", cyc, rr, r0);
+  solver_check(rc, "MAC multigrid", cyc, rr, r0);
   mac_level_mkumac(um, phi, beta, dx, bct, bc_comp0);
   for (int d = 0; d < 3; d++) mf_fill_boundary(um[d]);          // macproject.f90:115-119
   for (int d = 0; d < 3; d++) mf_temp_free(beta[d]);

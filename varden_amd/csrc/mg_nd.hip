@@ -185,7 +185,7 @@ __global__ void __launch_bounds__(256) kk_nd_march(NLev L, const double *__restr
         if (active) out[c] = v;
       } else {
         const double r = dir ? 0.0 : rhs - Kp;
-        if (active) { out[c] = r; rmax = fmax(rmax, fabs(r)); }
+        if (active) { out[c] = r; rmax = nmax(rmax, fabs(r)); }
       }
       #pragma unroll
       for (int b = 0; b < 3; b++)
@@ -399,7 +399,7 @@ __global__ void kk_nd_load(NLev L, FV rh, FV phi, int lo0, int lo1, int lo2, dou
       const long c = nidx(L, i, j, k);
       L.b[c] = -r;
       L.phi[c] = dir ? 0.0 : fv_get(phi, lo0 + i, lo1 + j, lo2 + k);
-      rmax = fmax(rmax, fabs(r));
+      rmax = nmax(rmax, fabs(r));
     }
   block_atomic_max(nrm, rmax);
 }
@@ -742,6 +742,7 @@ static double nd_read(double *d) {
 
 int nd_solve(vdn_multifab *rh, vdn_multifab *phi, const vdn_multifab *coeffs, const vdn_multifab *u, const double *dx,
              const int bc[3][2], double rel_eps, double abs_eps, int max_iter, int *cycles, double *res0, double *res) {
+  Prof prof_("hg_multigrid");
   if (ctx().prm.dm == 2) return nd2_solve(rh, phi, coeffs, u, dx, bc, rel_eps, abs_eps, max_iter, cycles, res0, res);
   const vdn_params &P = ctx().prm;
   REQUIRE(rh->ng >= 1 && phi->ng >= 1 && coeffs->ng >= 1, "nodal multigrid: rh, phi, coeffs need one ghost layer");
@@ -812,8 +813,8 @@ int nd_solve(vdn_multifab *rh, vdn_multifab *phi, const vdn_multifab *coeffs, co
     nd_jacobi_d(D0, single ? nd_bottom_sweeps_global(D0) : P.hg_nu1);
     nd_residual_d(M, D0, true);
     rn = nd_read(M.d_nrm);
-    if (rn <= rel_eps * bnorm || rn <= abs_eps) { conv = true; break; }
-    if (cyc >= max_iter) break;
+    if ((rn <= rel_eps * bnorm && bnorm < HUGE_VAL) || rn <= abs_eps) { conv = true; break; }
+    if (cyc >= max_iter || !(rn < HUGE_VAL) || !(bnorm < HUGE_VAL)) break;     // also: a NaN / inf norm (the reductions turn NaN into +inf)
     if (!single) {
       nd_restrict_down(M, 0);
       if (M.dlev.size() > 1) nd_vcycle_d(M, 1); else nd_vcycle_t(M, 0);
@@ -958,7 +959,7 @@ void do_hgproject(int proj_type, vdn_layout *mla, vdn_multifab **unew, vdn_multi
   int cyc; double r0, rr;
   int rc = nd_solve(rh, phi, coeffs, un, dx, ebc, rel, abs_eps, ctx().prm.hg_max_iter, &cyc, &r0, &rr);
   ctx().solver_cycles[1] = cyc; ctx().solver_res0[1] = r0; ctx().solver_res[1] = rr;
-  if (rc != 0 && ctx().prm.verbose) fprintf(stderr, "varden_amd: nodal multigrid did not converge in %d cycles (res %g / %g)\n", cyc, rr, r0);
+  solver_check(rc, "nodal multigrid", cyc, rr, r0);
   hg_level_post(proj_type, un, uo, rhh, gpp, pp, gphi, phi, dx, dt);
   mf_fill_boundary(gpp); mf_fill_boundary(pp);                        // hgproject.f90:359-362
   mf_temp_free(coeffs); mf_temp_free(gphi); mf_temp_free(phi); mf_temp_free(rh);
@@ -1021,7 +1022,7 @@ __global__ void kk_ndf_residual(FV b, FV phi, FV sig, FV res, NdfArgs A, int exc
     bool skip = false;
     if (excl == 1) skip = ndf_cf(A, i, j, k) && !ndf_pdir(A, i, j, k);
     if (excl == 2) skip = i > A.ilo[0] && i < A.ihi[0] && j > A.ilo[1] && j < A.ihi[1] && k > A.ilo[2] && k < A.ihi[2];
-    if (!skip) rmax = fmax(rmax, fabs(rr));
+    if (!skip) rmax = nmax(rmax, fabs(rr));
   }
   if (nrm) block_atomic_max(nrm, rmax);
 }
@@ -1121,7 +1122,7 @@ __global__ void __launch_bounds__(256) kk_ndf_march(const MarchB *args, const in
         if (active) fv_at(out, i, j, k) = v;
       } else {
         const double rr = pdir ? 0.0 : rhs - Kp;
-        if (active) { fv_at(out, i, j, k) = rr; if (!(excl == 1 && cf && !pdir)) rmax = fmax(rmax, fabs(rr)); }
+        if (active) { fv_at(out, i, j, k) = rr; if (!(excl == 1 && cf && !pdir)) rmax = nmax(rmax, fabs(rr)); }
       }
       #pragma unroll
       for (int b = 0; b < 3; b++)
@@ -1506,8 +1507,8 @@ static int ml_nd_solve(vdn_layout *la, vdn_multifab **rh, vdn_multifab **phi, vd
   int it = 0; bool conv = (bnorm == 0.0); double rn = 0.0;
   while (!conv) {
     rn = ml_nd_residual(S, false);
-    if (rn <= rel_eps * bnorm || rn <= abs_eps) { conv = true; break; }
-    if (it >= max_iter) break;
+    if ((rn <= rel_eps * bnorm && bnorm < HUGE_VAL) || rn <= abs_eps) { conv = true; break; }
+    if (it >= max_iter || !(rn < HUGE_VAL) || !(bnorm < HUGE_VAL)) break;
     // coarse correction K_0 e = r_0: one V-cycle of the single-level solver (which takes rh with b = -rh)
     mf_setval(ee, 0.0, 0, 1, true); mf_setval(er, 0.0, 0, 1, true);
     {
@@ -1561,7 +1562,7 @@ static void do_ml_hgproject(int proj_type, vdn_layout *mla, vdn_multifab **unew,
   int it; double r0, rr;
   int rc = ml_nd_solve(mla, rh, phi, coeffs, unew, dx, bct, press_comp0, rel, abs_eps, ctx().prm.hg_max_iter, &it, &r0, &rr);
   ctx().solver_cycles[1] = it; ctx().solver_res0[1] = r0; ctx().solver_res[1] = rr;
-  if (rc != 0 && ctx().prm.verbose) fprintf(stderr, "varden_amd: composite nodal solve did not converge in %d iterations (res %g / %g)\n", it, rr, r0);
+  solver_check(rc, "composite nodal solve", it, rr, r0);
   for (int n = 0; n < L; n++) hg_level_post(proj_type, unew[n], uold[n], rhohalf[n], gp[n], p[n], gphi[n], phi[n], dx + 3 * n, dt);
   for (int n = L - 1; n >= 1; n--) ml_cc_restriction(gp[n - 1], gp[n], 0, 3);      // hgproject.f90:355-357
   for (int n = 0; n < L; n++) { mf_fill_boundary(gp[n]); mf_fill_boundary(p[n]); }

@@ -40,6 +40,7 @@ struct VelForceB { Range3 r; int g[3]; FV vf, ext, gp, s, lapu; int has_lapu; Fo
 
 void k_mkvelforce(vdn_multifab *vf, const vdn_multifab *ext, const vdn_multifab *s, const vdn_multifab *gp,
                   const vdn_multifab *lapu, double visc_fac) {
+  Prof prof_("mkvelforce");
   if (ctx().prm.dm == 2) { k2_mkvelforce(vf, ext, s, gp, lapu, visc_fac); return; }
   REQUIRE(vf->ng >= 1 && ext->ng >= 1 && gp->ng >= 1 && s->ng >= 1, "mkvelforce: operands need a ghost cell");
   if (vf->ng != 1 || vf->nc != 3) mf_setval(vf, 0.0, 0, vf->nc, true);              // mkforce.f90:52; with one ghost layer the kernel writes every point itself
@@ -76,6 +77,7 @@ struct ScalForceB { Range3 r; int g[3]; FV sf, ext, laps; int has_laps; ForceArg
   static __device__ double body(const ScalForceB &q, int i, int j, int k, int) { mkscalforce_cell(q.sf, q.ext, q.laps, q.has_laps, q.A, i, j, k); return 0.0; } };
 
 void k_mkscalforce(vdn_multifab *sf, const vdn_multifab *ext, const vdn_multifab *laps, double diff_fac) {
+  Prof prof_("mkscalforce");
   if (ctx().prm.dm == 2) { k2_mkscalforce(sf, ext, laps, diff_fac); return; }
   if (sf->ng != 1 || sf->nc != ctx().prm.nscal) mf_setval(sf, 0.0, 0, sf->nc, true);              // mkforce.f90:267 / 346; with one ghost layer the kernel writes every point itself
   std::vector<ScalForceB> vb;
@@ -126,6 +128,7 @@ struct UpdateB { Range3 r; int g[3]; FV sold, snew, um, vm, wm, sx, sy, sz, fx, 
 
 void k_update(const vdn_multifab *sold, vdn_multifab **umac, vdn_multifab **sedge, vdn_multifab **flux,
               const vdn_multifab *force, vdn_multifab *snew, const double *dx, double dt, bool is_vel, const int *is_cons) {
+  Prof prof_("update");
   if (ctx().prm.dm == 2) { k2_update(sold, umac, sedge, flux, force, snew, dx, dt, is_vel, is_cons); return; }
   std::vector<UpdateB> vb;
   for (int i = 0; i < sold->nfabs(); i++) {
@@ -169,8 +172,8 @@ __global__ void kk_estdt(FV u, FV s, FV gp, FV ext, Range3 r, double *out6) {
     const double rho = fv_get(s, i, j, k, 0);
     #pragma unroll
     for (int c = 0; c < 3; c++) {
-      m[c] = fmax(m[c], fabs(fv_get(u, i, j, k, c)));
-      m[3 + c] = fmax(m[3 + c], fabs(fv_get(gp, i, j, k, c) / rho - fv_get(ext, i, j, k, c)));
+      m[c] = nmax(m[c], fabs(fv_get(u, i, j, k, c)));
+      m[3 + c] = nmax(m[3 + c], fabs(fv_get(gp, i, j, k, c) / rho - fv_get(ext, i, j, k, c)));
     }
   }
   #pragma unroll
@@ -191,14 +194,15 @@ __global__ void __launch_bounds__(256) kk_estdt_b(const EstB *args, const int *s
     const double rho = fv_get(a.s, i, j, k, 0);
     #pragma unroll
     for (int c = 0; c < 3; c++) {
-      m[c] = fmax(m[c], fabs(fv_get(a.u, i, j, k, c)));
-      m[3 + c] = fmax(m[3 + c], fabs(fv_get(a.gp, i, j, k, c) / rho - fv_get(a.ext, i, j, k, c)));
+      m[c] = nmax(m[c], fabs(fv_get(a.u, i, j, k, c)));
+      m[3 + c] = nmax(m[3 + c], fabs(fv_get(a.gp, i, j, k, c) / rho - fv_get(a.ext, i, j, k, c)));
     }
   }
   #pragma unroll
   for (int c = 0; c < 6; c++) block_atomic_max(out6 + c, m[c]);
 }
 void k_estdt_max(const vdn_multifab *u, const vdn_multifab *s, const vdn_multifab *gp, const vdn_multifab *ext, double out6[6]) {
+  Prof prof_("estdt");
   if (ctx().prm.dm == 2) { k2_estdt_max(u, s, gp, ext, out6); return; }
   VdnCtx &c = ctx();
   HIPCHK(hipMemsetAsync(c.d_scal, 0, 6 * sizeof(double), c.stream));

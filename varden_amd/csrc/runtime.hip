@@ -69,7 +69,37 @@ extern "C" void vdn_params_default(vdn_params *p) {
   p->visc_coef = 0.0; p->diff_coef = 0.0; p->cflfac = 0.8; p->max_dt_growth = 1.1;
   p->mg_nu1 = 2; p->mg_nu2 = 2; p->mg_nub = 8; p->mg_max_iter = 100;
   p->hg_max_iter = 100; p->hg_nu1 = 2; p->hg_nu2 = 1; p->hg_nub = 32; p->hg_omega = 0.9;
-  p->mac_rel_eps = 1.0e-10; p->hg_rel_eps = -1.0;
+  p->mac_rel_eps = 1.0e-10; p->hg_rel_eps = -1.0; p->abort_on_max_iter = 1;
+}
+
+// ---- roctx ranges ------------------------------------------------------------------------------------------------------------
+#include <dlfcn.h>
+static int (*g_roctx_push)(const char *) = nullptr;
+static int (*g_roctx_pop)() = nullptr;
+void prof_load() {
+  static bool tried = false;
+  if (tried) return;
+  tried = true;
+  if (getenv("VDN_NO_ROCTX")) return;
+  for (const char *n : { "librocprofiler-sdk-roctx.so.1", "librocprofiler-sdk-roctx.so", "libroctx64.so.4", "libroctx64.so" }) {
+    void *h = dlopen(n, RTLD_NOW | RTLD_LOCAL);
+    if (!h) continue;
+    *(void **)(&g_roctx_push) = dlsym(h, "roctxRangePushA");
+    *(void **)(&g_roctx_pop) = dlsym(h, "roctxRangePop");
+    if (g_roctx_push && g_roctx_pop) return;
+    g_roctx_push = nullptr; g_roctx_pop = nullptr;
+  }
+}
+Prof::Prof(const char *name) : on(g_roctx_push != nullptr) { if (on) g_roctx_push(name); }
+Prof::~Prof() { if (on) g_roctx_pop(); }
+
+void solver_check(int rc, const char *what, int iters, double res, double res0, int comp) {
+  const bool bad = !(res < HUGE_VAL) || !(res0 < HUGE_VAL);
+  if (rc == 0 && !bad) return;
+  char cs[32] = ""; if (comp >= 0) snprintf(cs, sizeof cs, " (component %d)", comp);
+  if (ctx().prm.abort_on_max_iter)
+    vdn_fail("%s%s %s after %d iterations (residual %g, right-hand side %g)", what, cs, bad ? "met a non-finite norm" : "did not converge", iters, res, res0);
+  if (ctx().prm.verbose) fprintf(stderr, "varden_amd: %s%s did not converge in %d iterations (res %g / %g)\n", what, cs, iters, res, res0);
 }
 
 extern "C" const char *vdn_last_error(void) { return g_err; }
@@ -90,6 +120,7 @@ extern "C" int vdn_init(const vdn_params *prm, int rank, int nranks, int device)
   VdnCtx &c = g_ctx;
   c.prm = *prm; c.rank = rank; c.nranks = nranks; c.device = device;
   if (!c.d_scal) { HIPCHK(hipMalloc((void **)&c.d_scal, 64 * sizeof(double))); HIPCHK(hipHostMalloc((void **)&c.h_scal, 64 * sizeof(double))); }
+  prof_load();
   c.inited = true;
   VDN_CATCH
 }
@@ -423,7 +454,7 @@ extern "C" int vdn_multifab_copy_c(vdn_multifab *dst, int dcomp, const vdn_multi
 __global__ void k_absmax(FV f, Range3 r, int comp, int nc, double *out) {
   REDUCE_IJ(r)
   double v = 0.0;
-  if (in_ij) REDUCE_KLOOP(r) for (int c = comp; c < comp + nc; c++) v = fmax(v, fabs(fv_get(f, i, j, k, c)));
+  if (in_ij) REDUCE_KLOOP(r) for (int c = comp; c < comp + nc; c++) v = nmax(v, fabs(fv_get(f, i, j, k, c)));
   block_atomic_max(out, v);
 }
 __global__ void k_minmax(FV f, Range3 r, int comp, double *out /* [0]=max(-x) shifted, [1]=max(x) shifted */, double shift) {
@@ -534,6 +565,7 @@ static bool extdir_value(int icomp1, int d, int s, double *v) {
 }
 
 void mf_physbc(vdn_multifab *mf, int scomp, int bccomp, int nc, const vdn_bc_tower *bct, bool same_boundary) {
+  Prof prof_("multifab_physbc");
   if (mf->ng == 0) return;
   REQUIRE(!mf->nodal[0] && !mf->nodal[1] && !mf->nodal[2], "physbc on a nodal multifab");
   // a direction reads the ghost cells the directions before it wrote, boxes and components are independent:

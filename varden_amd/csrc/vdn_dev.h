@@ -43,6 +43,9 @@ static inline dim3 grid_for(const Range3 &r, dim3 block = dim3(64, 4, 1)) {
   const bool in_range = (i <= (r).hi[0]) && (j <= (r).hi[1]) && (k <= (r).hi[2]);
 
 DEVI void block_atomic_max_fwd(double *addr, double v);
+// NaN-propagating max for the norms: fmax() drops a NaN operand, so a blown-up field would read as "residual 0 = converged".
+// A NaN becomes +inf, whose bit pattern is the largest among the non-negative doubles, so the u64 atomicMax keeps it.
+DEVI double nmax(double a, double b) { return (b == b) ? fmax(a, b) : __builtin_huge_val(); }
 // ---- XCD-aware tile order ---------------------------------------------------------------------------------------------------------
 // Workgroups are dealt round-robin over the 8 XCDs, each with its own L2 (blocks b and b + 8 share one).  With the natural order the
 // (x, y) tiles of a k-plane that one XCD works on are scattered over the plane, and every tile's halo rows are fetched into that XCD's
@@ -93,7 +96,7 @@ __global__ void __launch_bounds__(256) kk_batched(const A *args, const int *star
   const int i = a.r.lo[0] + (bx << lw) + (tid & ((1 << lw) - 1)), j = a.r.lo[1] + by * (256 >> lw) + (tid >> lw);
   double v = 0.0;
   if (i <= a.r.hi[0] && j <= a.r.hi[1])
-    for (int k = a.r.lo[2] + bz; k <= a.r.hi[2]; k += gz) v = fmax(v, A::body(a, i, j, k, extra));
+    for (int k = a.r.lo[2] + bz; k <= a.r.hi[2]; k += gz) v = nmax(v, A::body(a, i, j, k, extra));
   if (nrm) block_atomic_max_fwd(nrm, v);
 }
 // wave-level max (64 lanes) then one atomic per wave on a non-negative double stored as u64 bits
@@ -112,6 +115,7 @@ DEVI void atomic_max_nonneg(double *addr, double v) {
 // that a launch has only a few thousand workgroups -- see REDUCE_KLOOP / reduce_grid.)
 DEVI void block_atomic_max(double *addr, double v) {
   __shared__ double sm_[16];
+  if (!(v == v)) v = __builtin_huge_val();      // a NaN must not vanish in the fmax chain below
   v = wave_max(v);
   const int tid = threadIdx.x + blockDim.x * (threadIdx.y + blockDim.y * threadIdx.z);
   const int nw = (blockDim.x * blockDim.y * blockDim.z + 63) >> 6;

@@ -15,6 +15,7 @@
 #include <cstdarg>
 #include <cstring>
 #include <stdexcept>
+#include <cmath>
 #include "../../include/varden_amd.h"
 
 // ---- device-visible views ---------------------------------------------------------------------
@@ -96,8 +97,18 @@ struct VdnErr : std::runtime_error { using std::runtime_error::runtime_error; };
 [[noreturn]] void vdn_fail(const char *fmt, ...);
 #define HIPCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) vdn_fail("%s failed: %s (%s:%d)", #x, hipGetErrorString(e_), __FILE__, __LINE__); } while (0)
 #define VDN_TRY try {
-#define VDN_CATCH } catch (const std::exception &e) { vdn_set_error("%s", e.what()); return 1; } return 0;
+// the success path of every C-ABI call also asks HIP for a pending launch error (a kernel launch with a bad grid fails silently otherwise)
+#define VDN_CATCH   if (ctx().inited) { hipError_t le_ = hipGetLastError(); if (le_ != hipSuccess) vdn_fail("a HIP launch failed inside this call: %s", hipGetErrorString(le_)); } \
+  } catch (const std::exception &e) { vdn_set_error("%s", e.what()); return 1; } return 0;
+// outcome of an elliptic solve: FBoxLib's solvers abort on max_iter (bl_error); so do we unless prm.abort_on_max_iter = 0.
+// A non-finite norm (the reductions turn NaN into +inf) is a failure whatever rc says.  comp >= 0: the component being solved
+void solver_check(int rc, const char *what, int iters, double res, double res0, int comp = -1);
 #define REQUIRE(c, ...) do { if (!(c)) vdn_fail(__VA_ARGS__); } while (0)
+
+// bl_prof_timer of the reference (build(bpt, "name") / destroy(bpt), e.g. src/advance_timestep.f90:60,99-101) as roctx ranges: rocprofv3
+// --marker-trace shows the same names.  The roctx library is bound with dlopen at vdn_init; without it the ranges cost one branch.
+struct Prof { explicit Prof(const char *name); ~Prof(); Prof(const Prof &) = delete; bool on; };
+void prof_load();
 
 // arena
 void  arena_reset();

@@ -95,7 +95,7 @@ void do_visc_solve(vdn_layout *mla, vdn_multifab *unew, const vdn_multifab *lapu
     int ebc[3][2]; ell_of(bct, n, d, ebc);                                             // bc_comp = d, viscsolve.f90:99
     int cyc; double r0, rr;
     int rc = cc_solve(rh, phi, beta, dx, ebc, 1.e-12, -1.0, ctx().prm.mg_max_iter, &cyc, &r0, &rr, alpha);   // viscsolve.f90:88-89
-    if (rc != 0 && ctx().prm.verbose) fprintf(stderr, "varden_amd: viscous solve %d did not converge in %d cycles (res %g / %g)\n", d, cyc, rr, r0);
+    solver_check(rc, "viscous solve", cyc, rr, r0, d);
     mf_copy(unew, d, phi, 0, 1, 0);                                                    // viscsolve.f90:103
   }
   mf_restrict_and_fill(unew, 0, 0, 3, false, bct);                                     // viscsolve.f90:106
@@ -129,7 +129,7 @@ void do_ml_visc_solve(vdn_layout *mla, vdn_multifab **unew, vdn_multifab **lapu,
       }
     int it; double r0, rr;
     int rc = ml_cc_solve(mla, rh, phi, beta, dx, bct, d, 1.e-12, ctx().prm.mg_max_iter, &it, &r0, &rr, alpha);      // bc_comp = d, viscsolve.f90:88-99
-    if (rc != 0 && ctx().prm.verbose) fprintf(stderr, "varden_amd: composite viscous solve %d did not converge in %d iterations (res %g / %g)\n", d, it, rr, r0);
+    solver_check(rc, "composite viscous solve", it, rr, r0, d);
     for (int n = 0; n < L; n++) mf_copy(unew[n], d, phi[n], 0, 1, 0);                            // viscsolve.f90:103
   }
   ml_restrict_and_fill(L, unew, 0, 0, 3, false, bct);                                            // viscsolve.f90:106
@@ -157,7 +157,7 @@ void do_diff_scalar_solve(vdn_layout *mla, vdn_multifab *snew, const vdn_multifa
   int ebc[3][2]; ell_of(bct, n, bccomp0, ebc);
   int cyc; double r0, rr;
   int rc = cc_solve(rh, phi, beta, dx, ebc, 1.e-12, -1.0, ctx().prm.mg_max_iter, &cyc, &r0, &rr, alpha);
-  if (rc != 0 && ctx().prm.verbose) fprintf(stderr, "varden_amd: diffusive solve did not converge in %d cycles (res %g / %g)\n", cyc, rr, r0);
+  solver_check(rc, "diffusive solve", cyc, rr, r0);
   mf_copy(snew, icomp, phi, 0, 1, 0);                                                  // viscsolve.f90:374
   mf_fill_boundary(snew);                                                              // 378-381 (all comps: a superset of fill_boundary_c)
   mf_physbc(snew, icomp, bccomp0, 1, bct, false);
@@ -185,7 +185,7 @@ void do_ml_diff_scalar_solve(vdn_layout *mla, vdn_multifab **snew, vdn_multifab 
   }
   int it; double r0, rr;
   int rc = ml_cc_solve(mla, rh, phi, beta, dx, bct, bccomp0, 1.e-12, ctx().prm.mg_max_iter, &it, &r0, &rr, alpha);
-  if (rc != 0 && ctx().prm.verbose) fprintf(stderr, "varden_amd: composite diffusive solve did not converge in %d iterations (res %g / %g)\n", it, rr, r0);
+  solver_check(rc, "composite diffusive solve", it, rr, r0);
   for (int n = 0; n < L; n++) mf_copy(snew[n], icomp, phi[n], 0, 1, 0);                          // viscsolve.f90:374
   ml_restrict_and_fill(L, snew, icomp, bccomp0, 1, false, bct);                                  // 378-381
   for (int n = L - 1; n >= 0; n--) { for (int d = 2; d >= 0; d--) mf_temp_free(beta[3 * n + d]); mf_temp_free(alpha[n]); mf_temp_free(phi[n]); mf_temp_free(rh[n]); }

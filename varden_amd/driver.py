@@ -227,12 +227,13 @@ class VardenAMR:
     def __init__(self, nc, fine_boxes, phys_bc, params=None, prob_type=1, grav=-9.8, init_shrink=0.1, device=0, finer_levels=(),
                  regrid_int=-1, max_levs=None, max_grid_size=256, init_iter=0, do_initial_projection=0,
                  rank=0, nranks=1, comm_id=None, base_boxes=None, init_fn=None, restart=None, restart_step=0,
-                 fixed_dt=-1.0, stop_time=-1.0):
+                 fixed_dt=-1.0, stop_time=-1.0, amr_buf_width=-1):
         """init_fn(level, box_lo, box_shape, dx) -> (u, s) with 3 ghost layers replaces the analytic initial data of prob_type.
         several ranks (one per GPU): the boxes of every level are dealt to the ranks by cell count (`distribute`), `base_boxes` cuts
         level 0 into several boxes, comm_id is the RCCL unique id broadcast by the caller; regridding is single-rank in this round"""
         self.prm = params or default_params()
         self.grav, self.regrid_int, self.max_grid_size = grav, regrid_int, max_grid_size
+        self.amr_buf_width = max(amr_buf_width, regrid_int, 1)    # the tag buffer of initialize.f90:248 AND regrid.f90:149 (probin.template:147-154)
         self.fixed_dt, self.stop_time = float(fixed_dt), float(stop_time)
         self.prm.prob_type = prob_type
         self.rank, self.nranks = rank, nranks
@@ -343,7 +344,7 @@ class VardenAMR:
 
     def step(self):
         self.istep += 1
-        if self.max_levs > 1 and self.regrid_int > 0 and self.istep > 1 and (self.istep - 1) % self.regrid_int == 0:   # varden.f90:256-264
+        if self.max_levs > 1 and self.regrid_int > 0 and (self.istep - 1) % self.regrid_int == 0:   # varden.f90:256-264 (also at istep = 1)
             self.regrid()
         self.fill_state_ghosts()
         if self.istep > 1:
@@ -386,7 +387,7 @@ class VardenAMR:
     def regrid(self, buf_wid=None):
         """new grids from the current state, level by level: tag_boxes + make_new_grids on the (already regridded) level below, then
         build_and_fill_data (regrid.f90:269-339): interpolate from the coarser level, copy the old data of the level over it"""
-        buf = max(self.regrid_int, 1) if buf_wid is None else buf_wid             # amr_buf_width >= regrid_int, probin.template:147-154
+        buf = self.amr_buf_width if buf_wid is None else buf_wid
         old = dict(mla=self.mla, bct=self.bct, uold=self.uold, sold=self.sold, gp=self.gp, p=self.p)
         old_nlev = self.nlev
         comps = (("uold", self.dm), ("sold", self.nscal), ("gp", self.dm), ("p", 1))

@@ -23,7 +23,7 @@ def parse_namelist(text):
     """key = value pairs of the first namelist group; Fortran literals (1.d0, .true., 'str'); indexed keys like u_bc(1,1) kept verbatim"""
     out = {}
     body = re.sub(r"!.*", "", text)
-    for m in re.finditer(r"([A-Za-z_][\w]*(?:\(\s*\d+\s*,\s*\d+\s*\))?)\s*=\s*([^\n,/]+)", body):
+    for m in re.finditer(r"([A-Za-z_][\w]*(?:\(\s*\d+\s*,\s*\d+\s*\))?)\s*=\s*('[^'\n]*'|\"[^\"\n]*\"|[^\n,/]+)", body):
         key, val = m.group(1).replace(" ", ""), m.group(2).strip()
         low = val.lower()
         if low in (".true.", "t", ".t."):
@@ -60,6 +60,7 @@ def build(text, device=0, max_grid_size_cap=None, outdir="."):
     n = tuple(int(nl["n_cell" + a]) for a in "xyz"[:dm])
     prob_hi = tuple(float(nl["prob_hi_" + a]) for a in "xyz"[:dm]) + (1.0,) * (3 - dm)
     mgs = int(nl["max_grid_size"]) if max_grid_size_cap is None else min(int(nl["max_grid_size"]), max_grid_size_cap)
+    abw = max(int(nl["amr_buf_width"]), int(nl["regrid_int"]), 1)      # probin.template:147-154 (amr_buf_width >= regrid_int)
     common = dict(prob_type=int(nl["prob_type"]), grav=float(nl["grav"]), init_shrink=float(nl["init_shrink"]),
                   init_iter=int(nl["init_iter"]), do_initial_projection=int(nl["do_initial_projection"]), device=device,
                   fixed_dt=float(nl["fixed_dt"]), stop_time=float(nl["stop_time"]))
@@ -70,7 +71,7 @@ def build(text, device=0, max_grid_size_cap=None, outdir="."):
         if chk["nlevs"] == 1:
             return nl, Varden(n, phys, prm, prob_hi=prob_hi, decomp=decomp, **common, **rs)
         return nl, VardenAMR(n[0], chk["boxes"][1], phys, params=prm, finer_levels=chk["boxes"][2:], base_boxes=chk["boxes"][0],
-                             regrid_int=int(nl["regrid_int"]), max_levs=int(nl["max_levs"]), max_grid_size=mgs, **common, **rs)
+                             regrid_int=int(nl["regrid_int"]), amr_buf_width=abw, max_levs=int(nl["max_levs"]), max_grid_size=mgs, **common, **rs)
     if nl["fixed_grids"]:                                   # initialize_with_fixed_grids, src/initialize.f90:93-150
         if dm != 3 or len(set(n)) != 1 or any(p != 1.0 for p in prob_hi):
             raise NotImplementedError("hierarchies: 3-D, cubic unit domain in this round")
@@ -78,7 +79,7 @@ def build(text, device=0, max_grid_size_cap=None, outdir="."):
         assert domains[0] == ((0, 0, 0), tuple(x - 1 for x in n)), "fixed_grids: level-0 domain differs from n_cell"
         if len(boxes) == 1:
             raise NotImplementedError("fixed_grids with one level: use max_grid_size")
-        return nl, VardenAMR(n[0], boxes[1], phys, params=prm, finer_levels=boxes[2:], base_boxes=boxes[0], regrid_int=int(nl["regrid_int"]),
+        return nl, VardenAMR(n[0], boxes[1], phys, params=prm, finer_levels=boxes[2:], base_boxes=boxes[0], regrid_int=int(nl["regrid_int"]), amr_buf_width=abw,
                              max_levs=max(int(nl["max_levs"]), len(boxes)), max_grid_size=mgs, **common)
     if int(nl["max_levs"]) <= 1:
         return nl, Varden(n, phys, prm, prob_hi=prob_hi, decomp=decomp, **common)
@@ -91,10 +92,10 @@ def build(text, device=0, max_grid_size_cap=None, outdir="."):
         base = [((kx * bs[0], ky * bs[1], kz * bs[2]), ((kx + 1) * bs[0] - 1, (ky + 1) * bs[1] - 1, (kz + 1) * bs[2] - 1))
                 for kz in range(decomp[2]) for ky in range(decomp[1]) for kx in range(decomp[0])]
     levels = VardenAMR.tagged_grids(n[0], phys, prm, prob_type=int(nl["prob_type"]), max_levs=int(nl["max_levs"]),
-                                    buf_wid=max(int(nl["amr_buf_width"]), int(nl["regrid_int"]), 1), max_grid_size=mgs, device=device, base_boxes=base)
+                                    buf_wid=abw, max_grid_size=mgs, device=device, base_boxes=base)
     if not levels:
         return nl, Varden(n, phys, prm, prob_hi=prob_hi, decomp=decomp, **common)
-    return nl, VardenAMR(n[0], levels[0], phys, params=prm, finer_levels=levels[1:], regrid_int=int(nl["regrid_int"]),
+    return nl, VardenAMR(n[0], levels[0], phys, params=prm, finer_levels=levels[1:], regrid_int=int(nl["regrid_int"]), amr_buf_width=abw,
                          max_levs=int(nl["max_levs"]), max_grid_size=mgs, base_boxes=base, **common)
 
 
