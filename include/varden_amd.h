@@ -24,6 +24,7 @@
  */
 #ifndef VARDEN_AMD_H
 #define VARDEN_AMD_H
+#include <stddef.h>
 
 #ifdef __cplusplus
 extern "C" {
@@ -90,6 +91,8 @@ int  vdn_finalize(void);
 const char *vdn_last_error(void);
 int  vdn_set_stream(void *hip_stream);      /* all kernels are launched on this stream (default 0) */
 int  vdn_device_synchronize(void);
+/* arena of per-step temporaries (the multifabs advance_timestep.f90:65-80 allocates and frees every step): bytes reserved, high-water mark */
+int  vdn_arena_stats(size_t *reserved_bytes, size_t *peak_bytes);
 int  vdn_get_params(vdn_params *out);
 
 /* ------------------------------------------------------------------------------------------- */

@@ -515,9 +515,11 @@ def test_regrid(gpu):
     assert np.isfinite(s0).all() and np.abs(s0 - s0[::-1]).max() <= 1e-8
     G.close()
     # (2) one big fine box -> tagged boxes inside it
-    H = driver.VardenAMR(nc, [((8, 8, 8), (55, 55, 55))], WALLS, params=default_params(cflfac=0.9), regrid_int=2, max_levs=2, max_grid_size=32)
+    # (regrid_int is switched on after the first step: like the reference, src/varden.f90:256, the driver regrids before step 1 too)
+    H = driver.VardenAMR(nc, [((8, 8, 8), (55, 55, 55))], WALLS, params=default_params(cflfac=0.9), regrid_int=-1, max_levs=2, max_grid_size=32)
     H.step()
     big = H.sold[1].to_numpy(0)
+    H.regrid_int, H.amr_buf_width = 2, 2
     H.regrid(buf_wid=2)
     assert len(H.boxes[1]) > 1
     for i, (lo, hi) in enumerate(H.boxes[1]):

@@ -514,7 +514,7 @@ struct SetboxB { Range3 r; int g[3]; FV a; double v;
   static __device__ double body(const SetboxB &q, int i, int j, int k, int) { fv_at(q.a, i, j, k) = q.v; return 0.0; } };
 
 static Range3 valid_range(const vdn_multifab *mf, int b) { Range3 r; for (int d = 0; d < 3; d++) { r.lo[d] = mf->vbox[b].lo[d]; r.hi[d] = mf->vbox[b].hi[d]; } return r; }
-static double read_dev(double *d) { double h; HIPCHK(hipMemcpyAsync(&h, d, sizeof(double), hipMemcpyDeviceToHost, ctx().stream)); HIPCHK(hipStreamSynchronize(ctx().stream)); return h; }
+static double read_dev(double *d) { return read_scalar1(d); }
 
 // descriptor sets are built once per solve: the fields of a solve do not move
 struct MLCC { int nlev; vdn_layout *la; vdn_multifab **rh, **phi, **beta, **alpha; vdn_multifab *res[VDN_MAXLEV], *e[VDN_MAXLEV], *scr[VDN_MAXLEV], *mask[VDN_MAXLEV];

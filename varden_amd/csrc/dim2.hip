@@ -243,7 +243,7 @@ __global__ void kk_c2_store(C2 L, FV phi, C2Bc B) {
 }
 static dim3 g2(int nx, int ny) { return dim3((nx + 63) / 64, (ny + 3) / 4, 1); }
 static double read_scal(double *d) {
-  double h; HIPCHK(hipMemcpyAsync(&h, d, sizeof(double), hipMemcpyDeviceToHost, ctx().stream)); HIPCHK(hipStreamSynchronize(ctx().stream)); return h;
+  return read_scalar1(d);
 }
 struct CC2MG { std::vector<C2> lev; int per[2]; double *d_nrm; };
 static void c2_gsrb(const CC2MG &M, const C2 &L, int ns) {

@@ -912,10 +912,7 @@ static void cc_residual_d(CCMG &M, CDLev &DL, bool norm) {
   if (norm) comm_allreduce_max_dev(M.d_nrm, 1);
 }
 static double read_scalar(double *d) {
-  VdnCtx &c = ctx();
-  HIPCHK(hipMemcpyAsync(c.h_scal, d, sizeof(double), hipMemcpyDeviceToHost, c.stream));
-  HIPCHK(hipStreamSynchronize(c.stream));
-  return c.h_scal[0];
+  return read_scalar1(d);
 }
 
 // ---- the replicated tail: single-box V-cycle --------------------------------------------------------------------
@@ -999,6 +996,40 @@ static void cc_vcycle_d(CCMG &M, int l) {
   if (last) cc_vcycle_t(M, 0); else cc_vcycle_d(M, l + 1);
   cc_prolong_up(M, l);
   cc_gsrb_d(M, DL, P.mg_nu2);
+}
+
+// ---- one cycle as a hipGraph ------------------------------------------------------------------------------------------------------
+// A V-cycle at 256^3 is ~110 launches, most of them 3-15 us kernels on the levels <= 64^3: issued one by one the host cannot keep
+// the GPU busy (r1: 8 ms of a 50 ms step were launch gaps).  The launch sequence of a cycle depends only on the level structures, so
+// it is captured once and replayed; the key hashes every value the launches read from the host side.
+static void cc_key_lev(GraphKey &k, const CLev &L) {
+  k.put(L.n); k.put(L.PX); k.put(L.PY); k.put(L.sz); k.put(L.hi2); k.put(L.phi); k.put(L.rh); k.put(L.res); k.put(L.b); k.put(L.alpha);
+  k.put(L.phi2); k.put(L.rho); k.put(L.fold);
+}
+static unsigned long long cc_graph_key(const CCMG &M, int what) {
+  const vdn_params &P = ctx().prm;
+  GraphKey k; k.put(what); k.put(P.mg_nu1); k.put(P.mg_nu2); k.put(P.mg_nub); k.put(M.per); k.put(M.d_nrm);
+  k.put(M.sendbuf); k.put(M.recvbuf); k.put(M.d_gb_rh); k.put(M.d_gb_b); k.put(M.cnt_rh); k.put(M.cnt_b);
+  for (const CDLev &DL : M.dlev) {
+    k.put(DL.halo); k.put(DL.ng); k.put(DL.single_box);
+    for (const CBox &B : DL.boxes) { cc_key_lev(k, B.L); k.put(B.lo); }
+  }
+  for (const CLev &L : M.tail) cc_key_lev(k, L);
+  for (long o : M.loc_off_rh) k.put(o);
+  return k.h;
+}
+static bool cc_graphable(const CCMG &M) {
+  if (!graphs_enabled()) return false;
+  for (const CDLev &DL : M.dlev) for (const CBox &B : DL.boxes) if (B.L.phi2) return false;     // the fused sweeps swap phi / phi2 on the host
+  return true;
+}
+template <class Body> static void cc_run_cycle(CCMG &M, int what, Body body) {
+  if (!cc_graphable(M)) { body(); return; }
+  const unsigned long long key = cc_graph_key(M, what);
+  if (graph_replay(key)) return;
+  graph_begin();
+  try { body(); } catch (...) { graph_abort(); throw; }
+  graph_end(key);
 }
 
 // VDN_MAC_STORED_BETA=1: the finest level reads the stored face coefficients like the others (the measured alternative of DESIGN.md section 4)
@@ -1092,12 +1123,14 @@ int cc_solve(vdn_multifab *rh, vdn_multifab *phi, vdn_multifab **beta, const dou
   if (max_iter < 0) {            // exactly -max_iter V-cycles, no norms, no convergence test (the coarse correction of the composite solves)
     for (int c = 0; c < -max_iter; c++) {
       if (single) { const int N = std::max(D0.ng[0], std::max(D0.ng[1], D0.ng[2])); cc_gsrb_d(M, D0, std::max(P.mg_nub, N * N)); continue; }
-      cc_gsrb_d(M, D0, P.mg_nu1);
-      cc_residual_d(M, D0, false);
-      cc_restrict_down(M, 0);
-      if (M.dlev.size() > 1) cc_vcycle_d(M, 1); else cc_vcycle_t(M, 0);
-      cc_prolong_up(M, 0);
-      cc_gsrb_d(M, D0, P.mg_nu2);
+      cc_run_cycle(M, 2, [&] {
+        cc_gsrb_d(M, D0, P.mg_nu1);
+        cc_residual_d(M, D0, false);
+        cc_restrict_down(M, 0);
+        if (M.dlev.size() > 1) cc_vcycle_d(M, 1); else cc_vcycle_t(M, 0);
+        cc_prolong_up(M, 0);
+        cc_gsrb_d(M, D0, P.mg_nu2);
+      });
     }
     cc_store(M, phi, bc);
     if (cycles) *cycles = -max_iter; if (res0) *res0 = 0.0; if (res) *res = 0.0;
@@ -1106,20 +1139,24 @@ int cc_solve(vdn_multifab *rh, vdn_multifab *phi, vdn_multifab **beta, const dou
   }
   const double bnorm = mf_norm_inf(rh, 0, 1);
   int cyc = 0; bool conv = (bnorm == 0.0); double rn = 0.0;
+  // pre-smoothing + residual, then per cycle: [coarse correction, post-smoothing, the next cycle's pre-smoothing, residual + norm] as ONE
+  // replayed graph and one 8-byte read-back -- the same launch sequence as testing the residual the cycle computes after pre-smoothing
+  const int nbot = std::max(P.mg_nub, std::max(D0.ng[0], std::max(D0.ng[1], D0.ng[2])) * std::max(D0.ng[0], std::max(D0.ng[1], D0.ng[2])));
+  if (!conv) { cc_gsrb_d(M, D0, single ? nbot : P.mg_nu1); cc_residual_d(M, D0, true); rn = read_scalar(M.d_nrm); }
   while (!conv) {
-    if (single) { const int N = std::max(D0.ng[0], std::max(D0.ng[1], D0.ng[2])); cc_gsrb_d(M, D0, std::max(P.mg_nub, N * N)); }
-    else cc_gsrb_d(M, D0, P.mg_nu1);
-    cc_residual_d(M, D0, true);
-    rn = read_scalar(M.d_nrm);
     if ((rn <= rel_eps * bnorm && bnorm < HUGE_VAL) || rn <= abs_eps) { conv = true; break; }
     if (cyc >= max_iter || !(rn < HUGE_VAL) || !(bnorm < HUGE_VAL)) break;     // also: a NaN / inf norm (the reductions turn NaN into +inf)
-    if (!single) {
+    if (single) { cc_gsrb_d(M, D0, nbot); cc_residual_d(M, D0, true); }
+    else cc_run_cycle(M, 1, [&] {
       cc_restrict_down(M, 0);
       if (M.dlev.size() > 1) cc_vcycle_d(M, 1); else cc_vcycle_t(M, 0);
       cc_prolong_up(M, 0);
       cc_gsrb_d(M, D0, P.mg_nu2);
-    }
+      cc_gsrb_d(M, D0, P.mg_nu1);
+      cc_residual_d(M, D0, true);
+    });
     cyc++;
+    rn = read_scalar(M.d_nrm);
   }
   cc_store(M, phi, bc);
   if (cycles) *cycles = cyc; if (res0) *res0 = bnorm; if (res) *res = rn;

@@ -733,11 +733,40 @@ static void nd_vcycle_d(NDMG &M, int l) {
   nd_prolong_up(M, l);
   nd_jacobi_d(DL, P.hg_nu2);
 }
+// ---- one cycle as a hipGraph (see mg_cc.hip) ----------------------------------------------------------------------------------------
+// The Jacobi sweeps ping-pong phi / tmp on the host side, so a cycle changes the host state: the cache keeps, next to the graph, the
+// state the body left behind (a function of the state it started from, which the key hashes), and a replay installs it.
+static void nd_key_lev(GraphKey &k, const NLev &L) {
+  k.put(L.n); k.put(L.PX); k.put(L.PY); k.put(L.sz); k.put(L.f); k.put(L.phi); k.put(L.tmp); k.put(L.b); k.put(L.res); k.put(L.sig);
+  k.put(L.dirlo); k.put(L.dirhi); k.put(L.per);
+}
+static unsigned long long nd_graph_key(const NDMG &M, int what) {
+  const vdn_params &P = ctx().prm;
+  GraphKey k; k.put(what); k.put(P.hg_nu1); k.put(P.hg_nu2); k.put(P.hg_nub); k.put(P.hg_omega); k.put(M.per); k.put(M.d_nrm);
+  k.put(M.sendbuf); k.put(M.recvbuf); k.put(M.d_gb); k.put(M.cnt_nodes); k.put(M.cnt_cells);
+  for (const NDLev &DL : M.dlev) {
+    k.put(DL.halo_A); k.put(DL.halo_B); k.put(DL.halo_res); k.put(DL.halo_sig); k.put(DL.ng); k.put(DL.flip); k.put(DL.single_box); k.put(DL.per);
+    for (const NBox &B : DL.boxes) { nd_key_lev(k, B.L); k.put(B.lo); k.put(B.A); k.put(B.B); }
+  }
+  for (const NLev &L : M.tail) nd_key_lev(k, L);
+  for (long o : M.loc_off_nodes) k.put(o);
+  return k.h;
+}
+static std::map<unsigned long long, NDMG> g_nd_post;
+template <class Body> static void nd_run_cycle(NDMG &M, int what, Body body) {
+  if (!graphs_enabled()) { body(); return; }
+  const unsigned long long key = nd_graph_key(M, what);
+  auto it = g_nd_post.find(key);
+  if (it != g_nd_post.end() && graph_replay(key)) { M = it->second; return; }
+  graph_begin();
+  try { body(); } catch (...) { graph_abort(); throw; }
+  graph_end(key);
+  if (g_nd_post.size() >= 256) g_nd_post.clear();
+  g_nd_post[key] = M;
+}
+
 static double nd_read(double *d) {
-  VdnCtx &c = ctx();
-  HIPCHK(hipMemcpyAsync(c.h_scal, d, sizeof(double), hipMemcpyDeviceToHost, c.stream));
-  HIPCHK(hipStreamSynchronize(c.stream));
-  return c.h_scal[0];
+  return read_scalar1(d);
 }
 
 int nd_solve(vdn_multifab *rh, vdn_multifab *phi, const vdn_multifab *coeffs, const vdn_multifab *u, const double *dx,
@@ -799,33 +828,42 @@ int nd_solve(vdn_multifab *rh, vdn_multifab *phi, const vdn_multifab *coeffs, co
   const double bnorm = fixed_cycles ? 1.0 : nd_read(M.d_nrm);
   int cyc = 0; bool conv = (bnorm == 0.0); double rn = 0.0;
   for (int c = 0; fixed_cycles && c < -max_iter; c++) {
-    if (single) { nd_jacobi_d(D0, nd_bottom_sweeps_global(D0)); continue; }
-    nd_jacobi_d(D0, P.hg_nu1);
-    nd_residual_d(M, D0, false);
-    nd_restrict_down(M, 0);
-    if (M.dlev.size() > 1) nd_vcycle_d(M, 1); else nd_vcycle_t(M, 0);
-    nd_prolong_up(M, 0);
-    nd_jacobi_d(D0, P.hg_nu2);
-    cyc++;
-  }
-  if (fixed_cycles) conv = true;
-  while (!conv) {
-    nd_jacobi_d(D0, single ? nd_bottom_sweeps_global(D0) : P.hg_nu1);
-    nd_residual_d(M, D0, true);
-    rn = nd_read(M.d_nrm);
-    if ((rn <= rel_eps * bnorm && bnorm < HUGE_VAL) || rn <= abs_eps) { conv = true; break; }
-    if (cyc >= max_iter || !(rn < HUGE_VAL) || !(bnorm < HUGE_VAL)) break;     // also: a NaN / inf norm (the reductions turn NaN into +inf)
-    if (!single) {
+    if (single) { nd_jacobi_d(M.dlev[0], nd_bottom_sweeps_global(M.dlev[0])); continue; }
+    nd_run_cycle(M, 2, [&] {
+      NDLev &D = M.dlev[0];
+      nd_jacobi_d(D, P.hg_nu1);
+      nd_residual_d(M, D, false);
       nd_restrict_down(M, 0);
       if (M.dlev.size() > 1) nd_vcycle_d(M, 1); else nd_vcycle_t(M, 0);
       nd_prolong_up(M, 0);
-      nd_jacobi_d(D0, P.hg_nu2);
-    }
+      nd_jacobi_d(D, P.hg_nu2);
+    });
     cyc++;
   }
-  nd_halo_phi(D0);
-  for (size_t b = 0; b < D0.boxes.size(); b++) {
-    NLev &L0 = D0.boxes[b].L; const vdn_box &bx = coeffs->vbox[b];
+  if (fixed_cycles) conv = true;
+  // pre-smoothing + residual, then per cycle [coarse correction, post-smoothing, next pre-smoothing, residual + norm] as one replayed
+  // graph and one read-back: the same launch sequence as testing the residual the cycle computes after its pre-smoothing
+  if (!conv) { nd_jacobi_d(M.dlev[0], single ? nd_bottom_sweeps_global(M.dlev[0]) : P.hg_nu1); nd_residual_d(M, M.dlev[0], true); rn = nd_read(M.d_nrm); }
+  while (!conv) {
+    if ((rn <= rel_eps * bnorm && bnorm < HUGE_VAL) || rn <= abs_eps) { conv = true; break; }
+    if (cyc >= max_iter || !(rn < HUGE_VAL) || !(bnorm < HUGE_VAL)) break;     // also: a NaN / inf norm (the reductions turn NaN into +inf)
+    if (single) { nd_jacobi_d(M.dlev[0], nd_bottom_sweeps_global(M.dlev[0])); nd_residual_d(M, M.dlev[0], true); }
+    else nd_run_cycle(M, 1, [&] {
+      NDLev &D = M.dlev[0];
+      nd_restrict_down(M, 0);
+      if (M.dlev.size() > 1) nd_vcycle_d(M, 1); else nd_vcycle_t(M, 0);
+      nd_prolong_up(M, 0);
+      nd_jacobi_d(D, P.hg_nu2);
+      nd_jacobi_d(D, P.hg_nu1);
+      nd_residual_d(M, D, true);
+    });
+    cyc++;
+    rn = nd_read(M.d_nrm);
+  }
+  NDLev &DF = M.dlev[0];                    // (a replayed cycle re-assigns M: take the reference afresh)
+  nd_halo_phi(DF);
+  for (size_t b = 0; b < DF.boxes.size(); b++) {
+    NLev &L0 = DF.boxes[b].L; const vdn_box &bx = coeffs->vbox[b];
     hipLaunchKernelGGL(kk_nd_store, ng3(L0.n[0] + 3, L0.n[1] + 3, L0.n[2] + 3), NBLK, 0, st, L0, phi->fabs[b], bx.lo[0], bx.lo[1], bx.lo[2]);
   }
   if (cycles) *cycles = cyc; if (res0) *res0 = bnorm; if (res) *res = rn;
@@ -1165,7 +1203,7 @@ template <int MODE> static void ndf_run_march(const MarchSet &S, double omega, i
   hipLaunchKernelGGL(kk_ndf_march<MODE>, dim3(S.tot), NBLK, 0, ctx().stream, (const MarchB *)S.d_args, (const int *)S.d_start, S.nbox, omega, excl, nrm);
 }
 
-static double ndf_read(double *d) { double h; HIPCHK(hipMemcpyAsync(&h, d, sizeof(double), hipMemcpyDeviceToHost, ctx().stream)); HIPCHK(hipStreamSynchronize(ctx().stream)); return h; }
+static double ndf_read(double *d) { return read_scalar1(d); }
 // ---- composite nodal solve on arbitrary unions of boxes: node masks instead of per-face flags ----------------------------------
 // (batched kernels: one launch per operation and level, vdn_dev.h)
 // cell mask -> node mask.  mode 0 ("slave"): 1 on the nodes that are not physical Dirichlet nodes and touch a cell INSIDE the

@@ -225,9 +225,8 @@ void k_estdt_max(const vdn_multifab *u, const vdn_multifab *s, const vdn_multifa
     hipLaunchKernelGGL(kk_estdt, reduce_grid(r), dim3(64, 4, 1), 0, c.stream, u->fabs[i], s->fabs[i], gp->fabs[i], ext->fabs[i], r, c.d_scal);
   }
   comm_allreduce_max_dev(c.d_scal, 6);        // MAX of the maxima == the reference's MIN over ranks of dt_proc (estdt.f90:69)
-  HIPCHK(hipMemcpyAsync(c.h_scal, c.d_scal, 6 * sizeof(double), hipMemcpyDeviceToHost, c.stream));
-  HIPCHK(hipStreamSynchronize(c.stream));
-  for (int k = 0; k < 6; k++) out6[k] = c.h_scal[k];
+  const double *h = read_scalars(c.d_scal, 6);
+  for (int k = 0; k < 6; k++) out6[k] = h[k];
 }
 
 // ====================================================================================================

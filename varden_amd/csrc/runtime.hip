@@ -59,6 +59,7 @@ void *arena_alloc(size_t bytes) {
     c.arena_bytes = want; off = 0;
   }
   c.arena_off = off + bytes;
+  if (c.arena_off > c.arena_peak) c.arena_peak = c.arena_off;
   return c.arena + off;
 }
 
@@ -93,6 +94,60 @@ void prof_load() {
 Prof::Prof(const char *name) : on(g_roctx_push != nullptr) { if (on) g_roctx_push(name); }
 Prof::~Prof() { if (on) g_roctx_pop(); }
 
+// ---- scalar read-back ------------------------------------------------------------------------------------------------------------
+__global__ void k_publish(double *host_view, const double *dev, int n) { if ((int)threadIdx.x < n) host_view[threadIdx.x] = dev[threadIdx.x]; }
+const double *read_scalars(const double *dev, int n) {
+  VdnCtx &c = g_ctx;
+  REQUIRE(n >= 1 && n <= 64, "read_scalars: 1..64 values");
+  hipLaunchKernelGGL(k_publish, dim3(1), dim3(64), 0, c.stream, c.h_scal_dev, dev, n);
+  HIPCHK(hipStreamSynchronize(c.stream));
+  return c.h_scal;
+}
+
+// ---- hipGraph cache ---------------------------------------------------------------------------------------------------------------
+static std::map<unsigned long long, hipGraphExec_t> g_graphs;
+static bool g_capturing = false;
+bool graphs_enabled() {
+  static const bool off = getenv("VDN_NO_GRAPHS") != nullptr;
+  return !off && !comm_active() && g_ctx.stream != 0 && !g_capturing;
+}
+void graph_cache_clear() {
+  for (auto &kv : g_graphs) (void)hipGraphExecDestroy(kv.second);
+  g_graphs.clear();
+}
+bool graph_replay(unsigned long long key) {
+  auto it = g_graphs.find(key);
+  if (it == g_graphs.end()) return false;
+  HIPCHK(hipGraphLaunch(it->second, g_ctx.stream));
+  return true;
+}
+void graph_begin() {
+  REQUIRE(!g_capturing, "graph_begin: nested capture");
+  HIPCHK(hipStreamBeginCapture(g_ctx.stream, hipStreamCaptureModeThreadLocal));
+  g_capturing = true;
+}
+void graph_abort() {
+  if (!g_capturing) return;
+  hipGraph_t g = nullptr;
+  (void)hipStreamEndCapture(g_ctx.stream, &g);
+  if (g) (void)hipGraphDestroy(g);
+  (void)hipGetLastError();
+  g_capturing = false;
+}
+void graph_end(unsigned long long key) {
+  REQUIRE(g_capturing, "graph_end without graph_begin");
+  hipGraph_t g = nullptr;
+  g_capturing = false;
+  HIPCHK(hipStreamEndCapture(g_ctx.stream, &g));
+  hipGraphExec_t ex = nullptr;
+  hipError_t e = hipGraphInstantiate(&ex, g, nullptr, nullptr, 0);
+  (void)hipGraphDestroy(g);
+  if (e != hipSuccess) vdn_fail("hipGraphInstantiate failed: %s", hipGetErrorString(e));
+  if (g_graphs.size() >= 256) graph_cache_clear();        // stale keys (freed arenas, destroyed layouts) do not pile up
+  g_graphs[key] = ex;
+  HIPCHK(hipGraphLaunch(ex, g_ctx.stream));
+}
+
 void solver_check(int rc, const char *what, int iters, double res, double res0, int comp) {
   const bool bad = !(res < HUGE_VAL) || !(res0 < HUGE_VAL);
   if (rc == 0 && !bad) return;
@@ -119,7 +174,17 @@ extern "C" int vdn_init(const vdn_params *prm, int rank, int nranks, int device)
   HIPCHK(hipSetDevice(device));
   VdnCtx &c = g_ctx;
   c.prm = *prm; c.rank = rank; c.nranks = nranks; c.device = device;
-  if (!c.d_scal) { HIPCHK(hipMalloc((void **)&c.d_scal, 64 * sizeof(double))); HIPCHK(hipHostMalloc((void **)&c.h_scal, 64 * sizeof(double))); }
+  if (!c.d_scal) {
+    HIPCHK(hipMalloc((void **)&c.d_scal, 64 * sizeof(double)));
+    HIPCHK(hipHostMalloc((void **)&c.h_scal, 64 * sizeof(double), hipHostMallocMapped));
+    HIPCHK(hipHostGetDevicePointer((void **)&c.h_scal_dev, c.h_scal, 0));
+  }
+  // our own launch stream: the legacy null stream cannot be captured into a hipGraph, and a second stream next to it could not overlap
+  if (!c.own_stream) {
+    HIPCHK(hipStreamCreateWithFlags(&c.own_stream, hipStreamNonBlocking));
+    HIPCHK(hipStreamCreateWithFlags(&c.halo_stream, hipStreamNonBlocking));
+  }
+  if (c.stream == 0) c.stream = c.own_stream;
   prof_load();
   c.inited = true;
   VDN_CATCH
@@ -128,11 +193,19 @@ extern "C" int vdn_finalize(void) {
   VDN_TRY
   VdnCtx &c = g_ctx;
   if (c.arena) { HIPCHK(hipFree(c.arena)); c.arena = nullptr; c.arena_bytes = 0; c.arena_off = 0; }
-  if (c.d_scal) { HIPCHK(hipFree(c.d_scal)); c.d_scal = nullptr; HIPCHK(hipHostFree(c.h_scal)); c.h_scal = nullptr; }
+  graph_cache_clear();
+  if (c.d_scal) { HIPCHK(hipFree(c.d_scal)); c.d_scal = nullptr; HIPCHK(hipHostFree(c.h_scal)); c.h_scal = nullptr; c.h_scal_dev = nullptr; }
   c.inited = false;
   VDN_CATCH
 }
-extern "C" int vdn_set_stream(void *s) { g_ctx.stream = (hipStream_t)s; return 0; }
+extern "C" int vdn_set_stream(void *s) {            // NULL: back to the library's own stream
+  VDN_TRY
+  if (g_ctx.inited) HIPCHK(hipStreamSynchronize(g_ctx.stream));
+  graph_cache_clear();                                // cached graphs were captured on the old stream
+  g_ctx.stream = s ? (hipStream_t)s : g_ctx.own_stream;
+  VDN_CATCH
+}
+extern "C" int vdn_arena_stats(size_t *reserved_bytes, size_t *peak_bytes) { *reserved_bytes = g_ctx.arena_bytes; *peak_bytes = g_ctx.arena_peak; return 0; }
 extern "C" int vdn_device_synchronize(void) { VDN_TRY HIPCHK(hipStreamSynchronize(g_ctx.stream)); VDN_CATCH }
 extern "C" int vdn_get_params(vdn_params *out) { *out = g_ctx.prm; return 0; }
 extern "C" int vdn_last_step_timing(double *s) { for (int i = 0; i < 5; i++) s[i] = g_ctx.step_sec[i]; return 0; }
@@ -471,9 +544,7 @@ double mf_norm_inf(const vdn_multifab *mf, int comp, int nc) {
     hipLaunchKernelGGL(k_absmax, reduce_grid(r), dim3(64, 4, 1), 0, c.stream, mf->fabs[i], r, comp, nc, c.d_scal);
   }
   comm_allreduce_max_dev(c.d_scal, 1);        // FBoxLib norm_inf is a global (all-rank) norm
-  HIPCHK(hipMemcpyAsync(c.h_scal, c.d_scal, sizeof(double), hipMemcpyDeviceToHost, c.stream));
-  HIPCHK(hipStreamSynchronize(c.stream));
-  return c.h_scal[0];
+  return read_scalar1(c.d_scal);
 }
 extern "C" int vdn_multifab_norm_inf(const vdn_multifab *mf, int comp, int nc, double *out) {
   VDN_TRY *out = mf_norm_inf(mf, comp, nc); VDN_CATCH
@@ -489,9 +560,8 @@ extern "C" int vdn_multifab_min_max(const vdn_multifab *mf, int comp, double *mn
     hipLaunchKernelGGL(k_minmax, reduce_grid(r), dim3(64, 4, 1), 0, c.stream, mf->fabs[i], r, comp, c.d_scal, shift);
   }
   comm_allreduce_max_dev(c.d_scal, 2);
-  HIPCHK(hipMemcpyAsync(c.h_scal, c.d_scal, 2 * sizeof(double), hipMemcpyDeviceToHost, c.stream));
-  HIPCHK(hipStreamSynchronize(c.stream));
-  *mn = shift - c.h_scal[0]; *mx = c.h_scal[1] - shift;
+  const double *h2 = read_scalars(c.d_scal, 2);
+  *mn = shift - h2[0]; *mx = h2[1] - shift;
   VDN_CATCH
 }
 

@@ -79,11 +79,13 @@ struct VdnCtx {
   bool inited = false;
   vdn_params prm;
   int rank = 0, nranks = 1, device = 0;
-  hipStream_t stream = 0;
+  hipStream_t stream = 0;                    // the launch stream: our own non-blocking stream unless vdn_set_stream names another
+  hipStream_t own_stream = 0, halo_stream = 0;    // halo_stream: packed ghost traffic next to interior compute (exchange.hip)
   // persistent arena for per-step temporaries (bump allocator, reset at the start of each public call)
-  char *arena = nullptr; size_t arena_bytes = 0, arena_off = 0;
+  char *arena = nullptr; size_t arena_bytes = 0, arena_off = 0, arena_peak = 0;
   // small device scratch for reductions + pinned host mirror
   double *d_scal = nullptr; double *h_scal = nullptr;       // 64 doubles each
+  double *h_scal_dev = nullptr;                             // device view of the pinned mirror (k_publish writes it)
   double step_sec[5] = {0, 0, 0, 0, 0};
   int solver_cycles[2] = {0, 0}; double solver_res0[2] = {0, 0}, solver_res[2] = {0, 0};
   // slopes of uold, computed by velpred and used again by the velocity mkflux of the same advance_timestep (one level, one box)
@@ -109,6 +111,28 @@ void solver_check(int rc, const char *what, int iters, double res, double res0, 
 // --marker-trace shows the same names.  The roctx library is bound with dlopen at vdn_init; without it the ranges cost one branch.
 struct Prof { explicit Prof(const char *name); ~Prof(); Prof(const Prof &) = delete; bool on; };
 void prof_load();
+
+// n (<= 64) device doubles -> the pinned host mirror, then a stream synchronisation: the one way scalars (norms, estdt maxima)
+// come back.  A 64-thread kernel stores straight into the mapped host buffer: ~3 us instead of the ~20 us blit of an 8-byte
+// hipMemcpyAsync (profiles/r01_bench_kernel_stats.csv: 1120 __amd_rocclr_copyBuffer calls = 4.9 % of a step)
+const double *read_scalars(const double *dev, int n);
+inline double read_scalar1(const double *dev) { return read_scalars(dev, 1)[0]; }
+
+// ---- hipGraph replay of fixed launch sequences (one multigrid cycle = ~100 launches of 3-15 us) ---------------------------------------
+// Usage:  GraphKey k; k.put(...every value the launches depend on...);  if (!graph_replay(k.h)) { graph_begin(); body(); graph_end(k.h); }
+// graph_end instantiates, caches and launches.  Bodies may only enqueue work on ctx().stream (kernels, memsets, device copies).
+// Off when the transport is active (RCCL calls and the test double are not captured) or VDN_NO_GRAPHS is set.
+struct GraphKey {
+  unsigned long long h = 1469598103934665603ull;
+  void add(const void *p, size_t n) { const unsigned char *c = (const unsigned char *)p; for (size_t i = 0; i < n; i++) { h ^= c[i]; h *= 1099511628211ull; } }
+  template <class T> void put(const T &v) { add(&v, sizeof v); }
+};
+bool graphs_enabled();
+bool graph_replay(unsigned long long key);     // true: the cached graph was launched
+void graph_begin();
+void graph_end(unsigned long long key);
+void graph_abort();                            // leave capture mode after an exception inside a body
+void graph_cache_clear();
 
 // arena
 void  arena_reset();
