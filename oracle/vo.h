@@ -220,6 +220,9 @@ void vo2_advance_timestep(vo_state *S, const double dx[2], double dt, const vo_b
 void vo2_initdata(vo_fab *u, vo_fab *s, const double dx[2], int prob_type);
 
 
+/* the nodal 27-point operator on gathered values (see vo_hgproject.c) */
+void vo_nd_stencil(const double f[3], const double p[3][3][3], const double sg[2][2][2], double *Kp, double *diag);
+
 #ifdef __cplusplus
 }
 #endif

@@ -158,6 +158,51 @@ static void nd_fill_cells(const ndlev *L, double *a, const int per[3])
   }
 }
 
+/* the 27-point nodal operator on gathered values: p[oc][ob][oa] = phi at node offset (oa-1, ob-1, oc-1), sg[dk][dj][di] = sigma of
+ * cell (i-1+di, j-1+dj, k-1+dk); f[d] = 1/(36 h_d^2).  See nd_apply for the formula. */
+void vo_nd_stencil(const double f[3], const double p[3][3][3], const double sg[2][2][2], double *Kp, double *diag)
+{
+  const double fx = f[0], fy = f[1], fz = f[2];
+  const double F = fx + fy + fz;
+  const double w0 = 4.0 * F;
+  const double w1 = -4.0 * fx + 2.0 * fy + 2.0 * fz;
+  const double w2 = 2.0 * fx - 4.0 * fy + 2.0 * fz;
+  const double w3 = -2.0 * fx - 2.0 * fy + fz;
+  const double w4 = 2.0 * fx + 2.0 * fy - 4.0 * fz;
+  const double w5 = -2.0 * fx + fy - 2.0 * fz;
+  const double w6 = fx - 2.0 * fy - 2.0 * fz;
+  const double w7 = -F;
+  double cz[2][2], cy[2][2], cx[2][2];
+  for (int b = 0; b < 2; b++) for (int a = 0; a < 2; a++) {
+    cz[b][a] = sg[0][b][a] + sg[1][b][a];          /* the two cells that share an xy-diagonal neighbour */
+    cy[b][a] = sg[b][0][a] + sg[b][1][a];          /* [dk][di]: xz-diagonal */
+    cx[b][a] = sg[b][a][0] + sg[b][a][1];          /* [dk][dj]: yz-diagonal */
+  }
+  const double S8 = (cz[0][0] + cz[0][1]) + (cz[1][0] + cz[1][1]);
+  /* the weights of a row sum to zero (K 1 = 0), so K phi = sum of coefficient * (phi_neighbour - phi_node): differences first, which
+   * keeps the terms at the size of the answer instead of the size of diag * phi (at 256^3 the plain sum stalls at a residual of
+   * ~2e-12 |rhs|, short of the 1e-12 of hgproject.f90:113-114) */
+  const double p0 = p[1][1][1];
+  #define D(c, b, a) (p[c][b][a] - p0)
+  double A7 = sg[0][0][0] * D(0, 0, 0);
+  A7 = fma(sg[0][0][1], D(0, 0, 2), A7); A7 = fma(sg[0][1][0], D(0, 2, 0), A7); A7 = fma(sg[0][1][1], D(0, 2, 2), A7);
+  A7 = fma(sg[1][0][0], D(2, 0, 0), A7); A7 = fma(sg[1][0][1], D(2, 0, 2), A7); A7 = fma(sg[1][1][0], D(2, 2, 0), A7); A7 = fma(sg[1][1][1], D(2, 2, 2), A7);
+  double A3 = cz[0][0] * D(1, 0, 0); A3 = fma(cz[0][1], D(1, 0, 2), A3); A3 = fma(cz[1][0], D(1, 2, 0), A3); A3 = fma(cz[1][1], D(1, 2, 2), A3);
+  double A5 = cy[0][0] * D(0, 1, 0); A5 = fma(cy[0][1], D(0, 1, 2), A5); A5 = fma(cy[1][0], D(2, 1, 0), A5); A5 = fma(cy[1][1], D(2, 1, 2), A5);
+  double A6 = cx[0][0] * D(0, 0, 1); A6 = fma(cx[0][1], D(0, 2, 1), A6); A6 = fma(cx[1][0], D(2, 0, 1), A6); A6 = fma(cx[1][1], D(2, 2, 1), A6);
+  const double dg = w0 * S8;
+  double acc = w3 * A3;
+  acc = fma(w5, A5, acc); acc = fma(w6, A6, acc); acc = fma(w7, A7, acc);
+  if (!(w1 == 0.0 && w2 == 0.0 && w4 == 0.0)) {
+    double A1 = (cz[0][0] + cz[1][0]) * D(1, 1, 0); A1 = fma(cz[0][1] + cz[1][1], D(1, 1, 2), A1);
+    double A2 = (cz[0][0] + cz[0][1]) * D(1, 0, 1); A2 = fma(cz[1][0] + cz[1][1], D(1, 2, 1), A2);
+    double A4 = (cy[0][0] + cy[0][1]) * D(0, 1, 1); A4 = fma(cy[1][0] + cy[1][1], D(2, 1, 1), A4);
+    acc = fma(w1, A1, acc); acc = fma(w2, A2, acc); acc = fma(w4, A4, acc);
+  }
+  #undef D
+  *Kp = acc; *diag = dg;
+}
+
 /* K phi at node (i,j,k) and the diagonal; fixed expression order shared with the HIP kernel:
  * cells in the order (ck,cj,ci) ascending; inside a cell corners (mz,my,mx) ascending. */
 static inline void nd_apply(const ndlev *L, const double *phi, int i, int j, int k, double *Kp, double *diag)
@@ -183,32 +228,16 @@ static inline void nd_apply(const ndlev *L, const double *phi, int i, int j, int
     *Kp = acc; *diag = w[0] * ssum;
     return;
   }
-  const double fx = L->f[0], fy = L->f[1], fz = L->f[2];
-  const double F = fx + fy + fz;
-  /* weight by which coordinates differ: index bit0=x differs, bit1=y, bit2=z */
-  double w[8];
-  w[0] = 4.0 * F;
-  w[1] = -4.0 * fx + 2.0 * fy + 2.0 * fz;
-  w[2] = 2.0 * fx - 4.0 * fy + 2.0 * fz;
-  w[3] = -2.0 * fx - 2.0 * fy + fz;
-  w[4] = 2.0 * fx + 2.0 * fy - 4.0 * fz;
-  w[5] = -2.0 * fx + fy - 2.0 * fz;
-  w[6] = fx - 2.0 * fy - 2.0 * fz;
-  w[7] = -F;
-  double acc = 0.0, ssum = 0.0;
-  for (int ck = k - 1; ck <= k; ck++) for (int cj = j - 1; cj <= j; cj++) for (int ci = i - 1; ci <= i; ci++) {
-    double sg = L->sig[NS(L, ci, cj, ck)];
-    double t = 0.0;
-    for (int mz = 0; mz < 2; mz++) for (int my = 0; my < 2; my++) for (int mx = 0; mx < 2; mx++) {
-      int ni = ci + mx, nj = cj + my, nk = ck + mz;
-      int idx = (ni != i) | ((nj != j) << 1) | ((nk != k) << 2);
-      t = t + w[idx] * phi[NN(L, ni, nj, nk)];
-    }
-    acc = acc + sg * t;
-    ssum = ssum + sg;
-  }
-  *Kp = acc;
-  *diag = w[0] * ssum;
+  /* 3-D, trilinear (Q1) elements, equations scaled by 1/(hx hy hz).  K phi = sum over the 8 cells c around the node of
+   * sigma_c * sum over the cell's 8 corners q of w[type(q)] phi_q, type = which coordinates of q differ from the node's (bit 0 x, 1 y,
+   * 2 z).  Evaluated GROUPED BY NEIGHBOUR TYPE (round 2; the same sum, 41-55 operations instead of 142): a face / edge / corner
+   * neighbour is shared by 4 / 2 / 1 of the cells, so its coefficient is w[type] times the sum of those sigmas.  Fixed order, explicit
+   * fma() -- oracle and HIP (nd_stencil in mg_nd.hip) run the same operation sequence, hence the same bits.  With hx = hy = hz the
+   * face weights w[1], w[2], w[4] are exactly zero (the 21-point stencil, hg_hypre.f90:100-113) and their terms are skipped. */
+  double p[3][3][3], sg[2][2][2];
+  for (int c = 0; c < 3; c++) for (int b = 0; b < 3; b++) for (int a = 0; a < 3; a++) p[c][b][a] = phi[NN(L, i + a - 1, j + b - 1, k + c - 1)];
+  for (int c = 0; c < 2; c++) for (int b = 0; b < 2; b++) for (int a = 0; a < 2; a++) sg[c][b][a] = L->sig[NS(L, i + a - 1, j + b - 1, k + c - 1)];
+  vo_nd_stencil(L->f, p, sg, Kp, diag);
 }
 
 static void nd_jacobi(ndlev *L, const int per[3], int nsweeps, double omega)

@@ -195,13 +195,16 @@ struct XPlan {
   std::vector<CopyDesc> local; CopyDesc *d_local = nullptr; int *d_lstart = nullptr; int lchunks = 0;
   std::vector<Peer> peers;
   int nc = 1;
+  unsigned long serial = 0;          // unique over the life of the process: cache keys (hipGraph replay) must not match a new plan that malloc put at a freed plan's address
 };
+unsigned long xplan_serial(const XPlan *P) { return P ? P->serial : 0; }
 
 // the plan for: every box b (global list) has valid point range [vlo,vhi] (incl. nodal points) and, if
 // local, an FV view; ghosts of width ng are filled from other boxes' valid points, through periodic
 // shifts of the domain `pd` where pmask says so.
 XPlan *xplan_build(const std::vector<XBoxInfo> &boxes, const vdn_box &pd, const int pmask[3], int ng, int nc) {
-  XPlan *P = new XPlan; P->nc = nc;
+  static unsigned long next_serial = 0;
+  XPlan *P = new XPlan; P->nc = nc; P->serial = ++next_serial;
   const int me = ctx().rank;
   // self-test mode: route the rank's OWN box-to-box copies through the pack -> buffer -> unpack path that remote
   // copies take (peer == me, buffer handed over with a device memcpy instead of ncclSend/ncclRecv)

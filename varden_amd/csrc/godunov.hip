@@ -529,7 +529,29 @@ template <int D> DEVI double mk_edge_bc(const GArgs &A, const FV &s, int c, int 
   }
   return e;
 }
-template <int NC, bool R> __device__ __forceinline__ void mk_D_m_body(typename Prm<FV, R>::type s, typename Prm<FV, R>::type sl0, typename Prm<FV, R>::type sl1, typename Prm<FV, R>::type sl2, typename Prm<FV, R>::type um, typename Prm<FV, R>::type vm, typename Prm<FV, R>::type wm, typename Prm<FV, R>::type force, typename Prm<FV, R>::type macrhs, typename Prm<FV, R>::type SC, typename Prm<FV, R>::type sex, typename Prm<FV, R>::type sey, typename Prm<FV, R>::type sez, typename Prm<FV, R>::type flx, typename Prm<FV, R>::type fly, typename Prm<FV, R>::type flz, typename Prm<GArgs, R>::type A, typename Prm<Range3, R>::type r, int klen, const double *umax, int c0, int ns, const int BX, const int BY, const int BZ) {
+// the per-plane inputs of stage D for one cell
+//   q0[c][n] / q1[c][n]: SC component n at the cell's lower / upper face of the direction that component lives on
+//   n: 0 = (0,1) 1 = (0,2) on x-faces, 2 = (1,0) 3 = (1,2) on y-faces, 4 = (2,0) 5 = (2,1) on z-faces
+template <int NC> struct DPlane { double m_lo[3], m_up[3], s0[NC], sl[NC][3], mr, f[NC], q0[NC][6], q1[NC][6]; };
+template <int NC> DEVI void d_load_plane(DPlane<NC> &P, const FV &s, const FV &sl0, const FV &sl1, const FV &sl2, const FV &um, const FV &vm, const FV &wm,
+                                         const FV &force, const FV &macrhs, const FV &SC, const GArgs &A, int ic, int jc, int ip, int jp, int k, int c0, int ns) {
+  const int kc = min(max(k, A.lo[2] - 1), A.hi[2] + 1), kp = min(kc + 1, A.hi[2] + 1);
+  P.m_lo[0] = fv_get(um, ic, jc, kc); P.m_lo[1] = fv_get(vm, ic, jc, kc); P.m_lo[2] = fv_get(wm, ic, jc, kc);
+  P.m_up[0] = fv_get(um, ic + 1, jc, kc); P.m_up[1] = fv_get(vm, ic, jc + 1, kc); P.m_up[2] = fv_get(wm, ic, jc, kc + 1);
+  P.mr = fv_get(macrhs, ic, jc, kc);
+  #pragma unroll
+  for (int c = 0; c < NC; c++) {
+    P.s0[c] = fv_get(s, ic, jc, kc, c0 + c);
+    P.sl[c][0] = fv_get(sl0, ic, jc, kc, c0 + c); P.sl[c][1] = fv_get(sl1, ic, jc, kc, c0 + c); P.sl[c][2] = fv_get(sl2, ic, jc, kc, c0 + c);
+    P.f[c] = fv_get(force, ic, jc, kc, c0 + c);
+    #pragma unroll
+    for (int n = 0; n < 6; n++) P.q0[c][n] = fv_get(SC, ic, jc, kc, n * ns + c0 + c);
+    P.q1[c][0] = fv_get(SC, ip, jc, kc, 0 * ns + c0 + c); P.q1[c][1] = fv_get(SC, ip, jc, kc, 1 * ns + c0 + c);
+    P.q1[c][2] = fv_get(SC, ic, jp, kc, 2 * ns + c0 + c); P.q1[c][3] = fv_get(SC, ic, jp, kc, 3 * ns + c0 + c);
+    P.q1[c][4] = fv_get(SC, ic, jc, kp, 4 * ns + c0 + c); P.q1[c][5] = fv_get(SC, ic, jc, kp, 5 * ns + c0 + c);
+  }
+}
+template <int NC, bool R, bool PF> __device__ __forceinline__ void mk_D_m_body(typename Prm<FV, R>::type s, typename Prm<FV, R>::type sl0, typename Prm<FV, R>::type sl1, typename Prm<FV, R>::type sl2, typename Prm<FV, R>::type um, typename Prm<FV, R>::type vm, typename Prm<FV, R>::type wm, typename Prm<FV, R>::type force, typename Prm<FV, R>::type macrhs, typename Prm<FV, R>::type SC, typename Prm<FV, R>::type sex, typename Prm<FV, R>::type sey, typename Prm<FV, R>::type sez, typename Prm<FV, R>::type flx, typename Prm<FV, R>::type fly, typename Prm<FV, R>::type flz, typename Prm<GArgs, R>::type A, typename Prm<Range3, R>::type r, int klen, const double *umax, int c0, int ns, const int BX, const int BY, const int BZ) {
   __shared__ double ly[2][NC][TNY][64];
   MARCH_SETUP(r)
   const double eps = eps_from(umax);
@@ -537,23 +559,21 @@ template <int NC, bool R> __device__ __forceinline__ void mk_D_m_body(typename P
   double Lz[NC];
   #pragma unroll
   for (int c = 0; c < NC; c++) Lz[c] = 0.0;
+  DPlane<NC> Pn;
+  if (PF) d_load_plane<NC>(Pn, s, sl0, sl1, sl2, um, vm, wm, force, macrhs, SC, A, ic, jc, ip, jp, k0 - 1, c0, ns);
   for (int k = k0 - 1; k <= k1; k++) {
     MARCH_PLANE
-    MK_LOAD_CELL
-    const double mr = fv_get(macrhs, ic, jc, kc);
+    // the plane's loads: with PF they were issued one step ahead (while the previous plane was being computed), so that a workgroup
+    // keeps two planes of loads in flight -- at 2 waves per SIMD the marches are bound by load latency, not by bandwidth
+    DPlane<NC> P;
+    if (PF) { P = Pn; if (k < k1) d_load_plane<NC>(Pn, s, sl0, sl1, sl2, um, vm, wm, force, macrhs, SC, A, ic, jc, ip, jp, k + 1, c0, ns); }
+    else d_load_plane<NC>(P, s, sl0, sl1, sl2, um, vm, wm, force, macrhs, SC, A, ic, jc, ip, jp, k, c0, ns);
+    const double (&m_lo)[3] = P.m_lo, (&m_up)[3] = P.m_up; const double (&s0)[NC] = P.s0; const double (&sl)[NC][3] = P.sl;
+    const double (&q0)[NC][6] = P.q0, (&q1)[NC][6] = P.q1;
+    const double mr = P.mr;
     double ft[NC], mt[NC];
-    // q0[c][n] / q1[c][n]: SC component n at the cell's lower / upper face of the direction that component lives on
-    //   n: 0 = (0,1) 1 = (0,2) on x-faces, 2 = (1,0) 3 = (1,2) on y-faces, 4 = (2,0) 5 = (2,1) on z-faces
-    double q0[NC][6], q1[NC][6];
     #pragma unroll
-    for (int c = 0; c < NC; c++) {
-      ft[c] = dt2 * fv_get(force, ic, jc, kc, c0 + c); mt[c] = dt2 * s0[c] * mr;
-      #pragma unroll
-      for (int n = 0; n < 6; n++) q0[c][n] = fv_get(SC, ic, jc, kc, n * ns + c0 + c);
-      q1[c][0] = fv_get(SC, ip, jc, kc, 0 * ns + c0 + c); q1[c][1] = fv_get(SC, ip, jc, kc, 1 * ns + c0 + c);
-      q1[c][2] = fv_get(SC, ic, jp, kc, 2 * ns + c0 + c); q1[c][3] = fv_get(SC, ic, jp, kc, 3 * ns + c0 + c);
-      q1[c][4] = fv_get(SC, ic, jc, kp, 4 * ns + c0 + c); q1[c][5] = fv_get(SC, ic, jc, kp, 5 * ns + c0 + c);
-    }
+    for (int c = 0; c < NC; c++) { ft[c] = dt2 * P.f[c]; mt[c] = dt2 * s0[c] * mr; }
     double Lb[NC][3], Rb[NC][3];
     #pragma unroll
     for (int c = 0; c < NC; c++) {
@@ -616,8 +636,8 @@ template <int NC, bool R> __device__ __forceinline__ void mk_D_m_body(typename P
     }
   }
 }
-template <int NC> __global__ void __launch_bounds__(64 * TNY) kk_mk_D_m(FV s, FV sl0, FV sl1, FV sl2, FV um, FV vm, FV wm, FV force, FV macrhs, FV SC, FV sex, FV sey, FV sez, FV flx, FV fly, FV flz, GArgs A, Range3 r, int klen, const double *umax, int c0, int ns) {
-  mk_D_m_body<NC, false>(s, sl0, sl1, sl2, um, vm, wm, force, macrhs, SC, sex, sey, sez, flx, fly, flz, A, r, klen, umax, c0, ns, (int)blockIdx.x, (int)blockIdx.y, (int)blockIdx.z);
+template <int NC, bool PF = false> __global__ void __launch_bounds__(64 * TNY) kk_mk_D_m(FV s, FV sl0, FV sl1, FV sl2, FV um, FV vm, FV wm, FV force, FV macrhs, FV SC, FV sex, FV sey, FV sez, FV flx, FV fly, FV flz, GArgs A, Range3 r, int klen, const double *umax, int c0, int ns) {
+  mk_D_m_body<NC, false, PF>(s, sl0, sl1, sl2, um, vm, wm, force, macrhs, SC, sex, sey, sez, flx, fly, flz, A, r, klen, umax, c0, ns, (int)blockIdx.x, (int)blockIdx.y, (int)blockIdx.z);
 }
 
 
@@ -693,7 +713,7 @@ template <int NC> __global__ void __launch_bounds__(64 * TNY) kk_mk_C_mb(const M
 }
 template <int NC> __global__ void __launch_bounds__(64 * TNY) kk_mk_D_mb(const MkD *descs, const int *start, int nbox, int c0, int ns) {
   BATCH_LOCATE(MkD, gf)
-  mk_D_m_body<NC, true>(q.s, q.sl0, q.sl1, q.sl2, q.um, q.vm, q.wm, q.force, q.macrhs, q.SC, q.sex, q.sey, q.sez, q.flx, q.fly, q.flz, q.A, q.rf, q.klf, q.umax, c0, ns, BX, BY, BZ);
+  mk_D_m_body<NC, true, false>(q.s, q.sl0, q.sl1, q.sl2, q.um, q.vm, q.wm, q.force, q.macrhs, q.SC, q.sex, q.sey, q.sez, q.flx, q.fly, q.flz, q.A, q.rf, q.klf, q.umax, c0, ns, BX, BY, BZ);
 }
 // host side of a batch: grids of the four launch shapes per box, their prefix sums, and the upload
 template <class D> struct GodBatch {
@@ -840,7 +860,9 @@ void k_mkflux(const vdn_multifab *s, vdn_multifab **sedge, vdn_multifab **flux, 
         else hipLaunchKernelGGL(K<1>, g, blk, 0, st, ARGS(0));
       MK_STAGE(kk_mk_B_m, MK_ARGS_B, gg, 0)
       MK_STAGE(kk_mk_C_m, MK_ARGS_C, gg, 1)
-      MK_STAGE(kk_mk_D_m, MK_ARGS_D, gf, 2)
+      static const bool pf = getenv("VDN_GOD_PF") && atoi(getenv("VDN_GOD_PF")) != 0;
+      if (pf && ((split >> 2) & 1)) { for (int c0 = 0; c0 < ncomp; c0++) hipLaunchKernelGGL((kk_mk_D_m<1, true>), gf, blk, 0, st, MK_ARGS_D(c0)); }
+      else { MK_STAGE(kk_mk_D_m, MK_ARGS_D, gf, 2) }
       #undef MK_STAGE
       #undef MK_ARGS_B
       #undef MK_ARGS_C

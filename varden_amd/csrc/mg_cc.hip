@@ -1011,7 +1011,7 @@ static unsigned long long cc_graph_key(const CCMG &M, int what) {
   GraphKey k; k.put(what); k.put(P.mg_nu1); k.put(P.mg_nu2); k.put(P.mg_nub); k.put(M.per); k.put(M.d_nrm);
   k.put(M.sendbuf); k.put(M.recvbuf); k.put(M.d_gb_rh); k.put(M.d_gb_b); k.put(M.cnt_rh); k.put(M.cnt_b);
   for (const CDLev &DL : M.dlev) {
-    k.put(DL.halo); k.put(DL.ng); k.put(DL.single_box);
+    k.put(xplan_serial(DL.halo)); k.put(DL.ng); k.put(DL.single_box);
     for (const CBox &B : DL.boxes) { cc_key_lev(k, B.L); k.put(B.lo); }
   }
   for (const CLev &L : M.tail) cc_key_lev(k, L);

@@ -32,54 +32,84 @@ DEVI bool nd_is_dir(const NLev &L, int i, int j, int k) {
          (k == 0 && L.dirlo[2]) || (k == L.n[2] && L.dirhi[2]);
 }
 
-// K phi and the diagonal at node (i,j,k): cells (ck,cj,ci) ascending, corners (mz,my,mx) ascending --
-// the order of nd_apply in oracle/vo_hgproject.c
-DEVI void nd_apply(const NLev &L, const double *__restrict__ phi, int i, int j, int k, double &Kp, double &diag) {
-  const double fx = L.f[0], fy = L.f[1], fz = L.f[2];
+// ---- the 27-point nodal operator -----------------------------------------------------------------------------------------------------
+// K phi = sum over the 8 cells c around the node of sigma_c * sum over the cell's 8 corners q of w[type(q)] phi_q, type = which
+// coordinates of q differ from the node's (bit 0 x, 1 y, 2 z); trilinear (Q1) elements, equations scaled by 1/(hx hy hz).
+// Round 2: evaluated GROUPED BY NEIGHBOUR TYPE -- a face / edge / corner neighbour is shared by 4 / 2 / 1 of the cells, so its
+// coefficient is w[type] times the sum of those sigmas: 41 (hx = hy = hz: the face weights are exactly zero and their terms are
+// skipped, the 21-point stencil of hg_hypre.f90:100-113) to 55 f64 operations with explicit fma, instead of the 142 of the
+// cell-by-cell accumulation of round 1, which kept the sweeps VALU-bound (249 VALU instructions per node, VALU busy 75 %).
+// Same operation sequence as vo_nd_stencil in oracle/vo_hgproject.c, hence the same bits.
+// p[oc][ob][oa] = phi at node offset (oa-1, ob-1, oc-1); sg[dk][dj][di] = sigma of cell (i-1+di, j-1+dj, k-1+dk)
+struct NdW { double w0, w1, w2, w3, w4, w5, w6, w7; int iso; };
+DEVI NdW nd_weights(const double f[3]) {
+  const double fx = f[0], fy = f[1], fz = f[2];
   const double F = fx + fy + fz;
-  double w[8];
-  w[0] = 4.0 * F;
-  w[1] = -4.0 * fx + 2.0 * fy + 2.0 * fz;
-  w[2] = 2.0 * fx - 4.0 * fy + 2.0 * fz;
-  w[3] = -2.0 * fx - 2.0 * fy + fz;
-  w[4] = 2.0 * fx + 2.0 * fy - 4.0 * fz;
-  w[5] = -2.0 * fx + fy - 2.0 * fz;
-  w[6] = fx - 2.0 * fy - 2.0 * fz;
-  w[7] = -F;
+  NdW W;
+  W.w0 = 4.0 * F;
+  W.w1 = -4.0 * fx + 2.0 * fy + 2.0 * fz;
+  W.w2 = 2.0 * fx - 4.0 * fy + 2.0 * fz;
+  W.w3 = -2.0 * fx - 2.0 * fy + fz;
+  W.w4 = 2.0 * fx + 2.0 * fy - 4.0 * fz;
+  W.w5 = -2.0 * fx + fy - 2.0 * fz;
+  W.w6 = fx - 2.0 * fy - 2.0 * fz;
+  W.w7 = -F;
+  W.iso = (W.w1 == 0.0 && W.w2 == 0.0 && W.w4 == 0.0);
+  return W;
+}
+DEVI void nd_stencil(const NdW &W, const double p[3][3][3], const double sg[2][2][2], double &Kp, double &diag) {
+  double cz[2][2], cy[2][2], cx[2][2];
+  #pragma unroll
+  for (int b = 0; b < 2; b++)
+    #pragma unroll
+    for (int a = 0; a < 2; a++) {
+      cz[b][a] = sg[0][b][a] + sg[1][b][a];          // [dj][di]: the two cells that share an xy-diagonal neighbour
+      cy[b][a] = sg[b][0][a] + sg[b][1][a];          // [dk][di]: xz-diagonal
+      cx[b][a] = sg[b][a][0] + sg[b][a][1];          // [dk][dj]: yz-diagonal
+    }
+  const double S8 = (cz[0][0] + cz[0][1]) + (cz[1][0] + cz[1][1]);
+  // the weights of a row sum to zero (K 1 = 0), so K phi = sum of coefficient * (phi_neighbour - phi_node): differences first, which
+  // keeps the terms at the size of the answer instead of the size of diag * phi (at 256^3 the plain sum stalls at a residual of
+  // ~2e-12 |rhs|, short of the 1e-12 of hgproject.f90:113-114)
+  const double p0 = p[1][1][1];
+  #define D(c, b, a) (p[c][b][a] - p0)
+  double A7 = sg[0][0][0] * D(0, 0, 0);
+  A7 = fma(sg[0][0][1], D(0, 0, 2), A7); A7 = fma(sg[0][1][0], D(0, 2, 0), A7); A7 = fma(sg[0][1][1], D(0, 2, 2), A7);
+  A7 = fma(sg[1][0][0], D(2, 0, 0), A7); A7 = fma(sg[1][0][1], D(2, 0, 2), A7); A7 = fma(sg[1][1][0], D(2, 2, 0), A7); A7 = fma(sg[1][1][1], D(2, 2, 2), A7);
+  double A3 = cz[0][0] * D(1, 0, 0); A3 = fma(cz[0][1], D(1, 0, 2), A3); A3 = fma(cz[1][0], D(1, 2, 0), A3); A3 = fma(cz[1][1], D(1, 2, 2), A3);
+  double A5 = cy[0][0] * D(0, 1, 0); A5 = fma(cy[0][1], D(0, 1, 2), A5); A5 = fma(cy[1][0], D(2, 1, 0), A5); A5 = fma(cy[1][1], D(2, 1, 2), A5);
+  double A6 = cx[0][0] * D(0, 0, 1); A6 = fma(cx[0][1], D(0, 2, 1), A6); A6 = fma(cx[1][0], D(2, 0, 1), A6); A6 = fma(cx[1][1], D(2, 2, 1), A6);
+  const double dg = W.w0 * S8;
+  double acc = W.w3 * A3;
+  acc = fma(W.w5, A5, acc); acc = fma(W.w6, A6, acc); acc = fma(W.w7, A7, acc);
+  if (!W.iso) {                                      // uniform over the launch
+    double A1 = (cz[0][0] + cz[1][0]) * D(1, 1, 0); A1 = fma(cz[0][1] + cz[1][1], D(1, 1, 2), A1);
+    double A2 = (cz[0][0] + cz[0][1]) * D(1, 0, 1); A2 = fma(cz[1][0] + cz[1][1], D(1, 2, 1), A2);
+    double A4 = (cy[0][0] + cy[0][1]) * D(0, 1, 1); A4 = fma(cy[1][0] + cy[1][1], D(2, 1, 1), A4);
+    acc = fma(W.w1, A1, acc); acc = fma(W.w2, A2, acc); acc = fma(W.w4, A4, acc);
+  }
+  #undef D
+  Kp = acc; diag = dg;
+}
+// from a level in the multigrid layout
+DEVI void nd_apply(const NLev &L, const double *__restrict__ phi, int i, int j, int k, double &Kp, double &diag) {
+  const NdW W = nd_weights(L.f);
   const long sy = L.PX, sz = (long)L.PX * L.PY;
   const long c0 = nidx(L, i, j, k);
-  double p[3][3][3];
+  double p[3][3][3], sg[2][2][2];
   #pragma unroll
   for (int c = 0; c < 3; c++)
     #pragma unroll
     for (int b = 0; b < 3; b++)
       #pragma unroll
       for (int a = 0; a < 3; a++) p[c][b][a] = phi[c0 + (a - 1) + (b - 1) * sy + (c - 1) * sz];
-  double acc = 0.0, ssum = 0.0;
   #pragma unroll
-  for (int dk = 0; dk < 2; dk++)
+  for (int c = 0; c < 2; c++)
     #pragma unroll
-    for (int dj = 0; dj < 2; dj++)
+    for (int b = 0; b < 2; b++)
       #pragma unroll
-      for (int di = 0; di < 2; di++) {
-        // cell (i-1+di, j-1+dj, k-1+dk); its corner (mx,my,mz) is node offset (di+mx-1, ...) from (i,j,k)
-        const double sg = L.sig[c0 + (di - 1) + (dj - 1) * sy + (dk - 1) * sz];
-        double t = 0.0;
-        #pragma unroll
-        for (int mz = 0; mz < 2; mz++)
-          #pragma unroll
-          for (int my = 0; my < 2; my++)
-            #pragma unroll
-            for (int mx = 0; mx < 2; mx++) {
-              const int oa = di + mx - 1, ob = dj + my - 1, oc = dk + mz - 1;
-              const int idx = (oa != 0) | ((ob != 0) << 1) | ((oc != 0) << 2);
-              t = t + w[idx] * p[oc + 1][ob + 1][oa + 1];
-            }
-        acc = acc + sg * t;
-        ssum = ssum + sg;
-      }
-  Kp = acc;
-  diag = w[0] * ssum;
+      for (int a = 0; a < 2; a++) sg[c][b][a] = L.sig[c0 + (a - 1) + (b - 1) * sy + (c - 1) * sz];
+  nd_stencil(W, p, sg, Kp, diag);
 }
 
 #define NODE_IJK(L)                                                    \
@@ -92,48 +122,7 @@ DEVI void nd_apply(const NLev &L, const double *__restrict__ phi, int i, int j, 
 // A workgroup owns a 64 x 4 patch of (i,j) and marches through a slab of k planes keeping the three phi planes and
 // the two sigma planes of the 27-point stencil in registers: per node 9 + 4 (+1 rhs) loads instead of 27 + 8 (+1),
 // which is what bounds the plain kernels (they run at ~1.6 TB/s algorithmic, limited by L1/TA transactions,
-// not by HBM).  Arithmetic and its order are those of nd_apply.
-DEVI void nd_apply_reg(const NLev &L, const double p[3][3][3], const double sg[2][2][2], double &Kp, double &diag) {
-  const double fx = L.f[0], fy = L.f[1], fz = L.f[2];
-  const double F = fx + fy + fz;
-  double w[8];
-  w[0] = 4.0 * F;
-  w[1] = -4.0 * fx + 2.0 * fy + 2.0 * fz;
-  w[2] = 2.0 * fx - 4.0 * fy + 2.0 * fz;
-  w[3] = -2.0 * fx - 2.0 * fy + fz;
-  w[4] = 2.0 * fx + 2.0 * fy - 4.0 * fz;
-  w[5] = -2.0 * fx + fy - 2.0 * fz;
-  w[6] = fx - 2.0 * fy - 2.0 * fz;
-  w[7] = -F;
-  // the sums start from their first term instead of 0.0 + first term: ten f64 additions per node less (the kernel is VALU-bound); the
-  // value is the same, only a sum of exact zeros may come out as -0.0 where the oracle's 0.0 + (-0.0) gives +0.0
-  double acc = 0.0, ssum = 0.0;
-  #pragma unroll
-  for (int dk = 0; dk < 2; dk++)
-    #pragma unroll
-    for (int dj = 0; dj < 2; dj++)
-      #pragma unroll
-      for (int di = 0; di < 2; di++) {
-        double t = 0.0;
-        #pragma unroll
-        for (int mz = 0; mz < 2; mz++)
-          #pragma unroll
-          for (int my = 0; my < 2; my++)
-            #pragma unroll
-            for (int mx = 0; mx < 2; mx++) {
-              const int oa = di + mx - 1, ob = dj + my - 1, oc = dk + mz - 1;
-              const int idx = (oa != 0) | ((ob != 0) << 1) | ((oc != 0) << 2);
-              const double term = w[idx] * p[oc + 1][ob + 1][oa + 1];
-              t = (mz | my | mx) == 0 ? term : t + term;
-            }
-        const bool first = (dk | dj | di) == 0;
-        acc = first ? sg[dk][dj][di] * t : acc + sg[dk][dj][di] * t;
-        ssum = first ? sg[dk][dj][di] : ssum + sg[dk][dj][di];
-      }
-  Kp = acc;
-  diag = w[0] * ssum;
-}
-
+// not by HBM).  The operator is nd_stencil on the register planes.
 // MODE 0: Jacobi sweep (out = phi + omega (b - K phi)/diag);  MODE 1: residual (res = b - K phi, max-norm)
 // Per plane a thread loads only its own column (phi at rows j-1..j+1, sigma at rows j-1..j, rhs) in one unconditional
 // batch and takes the i-1 / i+1 columns from the neighbouring lanes (wave shuffles): 6 loads per node instead of 14.
@@ -166,6 +155,7 @@ __global__ void __launch_bounds__(256) kk_nd_march(NLev L, const double *__restr
     #pragma unroll
     for (int dj = 0; dj < 2; dj++) sg[0][dj][0] = lane_prev(sg[0][dj][1]);
     const bool dir_ij = (i == 0 && L.dirlo[0]) || (i == L.n[0] && L.dirhi[0]) || (j == 0 && L.dirlo[1]) || (j == L.n[1] && L.dirhi[1]);
+    const NdW W = nd_weights(L.f);
     for (int k = k0; k <= k1; k++, c += sz) {
       #pragma unroll
       for (int b = 0; b < 3; b++) p[2][b][1] = phi[c + sz + (b - 1) * sy];
@@ -178,7 +168,7 @@ __global__ void __launch_bounds__(256) kk_nd_march(NLev L, const double *__restr
       for (int dj = 0; dj < 2; dj++) sg[1][dj][0] = lane_prev(sg[1][dj][1]);
       const bool dir = dir_ij || (k == 0 && L.dirlo[2]) || (k == L.n[2] && L.dirhi[2]);
       const double p0 = p[1][1][1];
-      double Kp, diag; nd_apply_reg(L, p, sg, Kp, diag);
+      double Kp, diag; nd_stencil(W, p, sg, Kp, diag);
       if (MODE == 0) {
         double v = p0;
         if (!dir && diag != 0.0) v = p0 + omega * ((rhs - Kp) / diag);
@@ -196,6 +186,106 @@ __global__ void __launch_bounds__(256) kk_nd_march(NLev L, const double *__restr
         #pragma unroll
         for (int di = 0; di < 2; di++) sg[0][dj][di] = sg[1][dj][di];
     }
+  }
+  if (MODE == 1 && nrm) block_atomic_max(nrm, rmax);
+}
+
+// ---- paired form of the march (levels at least 128 nodes wide) -------------------------------------------------------------------------
+// After the operator was regrouped (nd_stencil) the march at 257^3 stayed at 0.145 ms: what binds it is the texture addresser, as it did
+// the cell-centred colour pass (profiles/r01_smoother_rho_pmc.json) -- seven 8-byte memory instructions per node.  Here a thread owns the
+// two nodes (2t, 2t+1) of a row: every access is an aligned 16-byte pair, the columns 2t-1 / 2t+2 come from the neighbouring lanes
+// (DPP), so a node costs 3.5 memory instructions and half the lane exchanges.  Same arithmetic per node (nd_stencil), same bits.
+DEVI double2 ld2(const double *p) { return *reinterpret_cast<const double2 *>(p); }
+template <int MODE, int ROWS>
+__global__ void __launch_bounds__(64 * ROWS) kk_nd_march_pair(NLev L, const double *__restrict__ phi, double *__restrict__ out, double omega, int kchunk, double *nrm) {
+  const int lane = threadIdx.x;
+  const int ia = 2 * ((int)blockIdx.x * 62 + lane - 1);                 // nodes ia, ia + 1; lanes 0 and 63 only feed their neighbours
+  const int j = blockIdx.y * blockDim.y + threadIdx.y;
+  const int k0 = blockIdx.z * kchunk, k1 = min(k0 + kchunk - 1, L.n[2]);
+  const bool own = lane >= 1 && lane <= 62 && j <= L.n[1];
+  const bool actA = own && ia <= L.n[0], actB = own && ia + 1 <= L.n[0];
+  const int iac = min(ia, L.PX - 18), jc = min(j, L.n[1]);                // load address kept inside the (zero-padded) row
+  double rmax = 0.0;
+  if (k0 <= k1) {          // uniform over the workgroup
+    const long sy = L.PX, sz = (long)L.PX * L.PY;
+    long c = nidx(L, iac, jc, k0);
+    // q[plane][row][col]: col 0..3 = nodes ia-1 .. ia+2;  sg[dk][dj][col]: col 0..2 = cells ia-1 .. ia+1
+    double q[3][3][4], sg[2][2][3];
+    #define LOADP(pl, off) { _Pragma("unroll") for (int b = 0; b < 3; b++) { const double2 v = ld2(phi + (off) + (b - 1) * sy); q[pl][b][1] = v.x; q[pl][b][2] = v.y; } }
+    #define EXCHP(pl) { _Pragma("unroll") for (int b = 0; b < 3; b++) { q[pl][b][0] = lane_prev(q[pl][b][2]); q[pl][b][3] = lane_next(q[pl][b][1]); } }
+    #define LOADS(dk, off) { _Pragma("unroll") for (int dj = 0; dj < 2; dj++) { const double2 v = ld2(L.sig + (off) + (dj - 1) * sy); sg[dk][dj][1] = v.x; sg[dk][dj][2] = v.y; } }
+    #define EXCHS(dk) { _Pragma("unroll") for (int dj = 0; dj < 2; dj++) sg[dk][dj][0] = lane_prev(sg[dk][dj][2]); }
+    LOADP(0, c - sz) LOADP(1, c) LOADS(0, c - sz)
+    // one plane ahead: the loads of plane k + 2 (phi), k + 1 (sigma, rhs) are in flight while plane k is being computed
+    double2 qn[3], sn[2], rhsn;
+    #pragma unroll
+    for (int b = 0; b < 3; b++) qn[b] = ld2(phi + c + sz + (b - 1) * sy);
+    #pragma unroll
+    for (int dj = 0; dj < 2; dj++) sn[dj] = ld2(L.sig + c + (dj - 1) * sy);
+    rhsn = ld2(L.b + c);
+    EXCHP(0) EXCHP(1) EXCHS(0)
+    const bool dirj = (j == 0 && L.dirlo[1]) || (j == L.n[1] && L.dirhi[1]);
+    const bool dirA_ij = dirj || (ia == 0 && L.dirlo[0]) || (ia == L.n[0] && L.dirhi[0]);
+    const bool dirB_ij = dirj || (ia + 1 == L.n[0] && L.dirhi[0]);
+    const NdW W = nd_weights(L.f);
+    for (int k = k0; k <= k1; k++, c += sz) {
+      #pragma unroll
+      for (int b = 0; b < 3; b++) { q[2][b][1] = qn[b].x; q[2][b][2] = qn[b].y; }
+      #pragma unroll
+      for (int dj = 0; dj < 2; dj++) { sg[1][dj][1] = sn[dj].x; sg[1][dj][2] = sn[dj].y; }
+      const double2 rhs = rhsn;
+      if (k < k1) {
+        #pragma unroll
+        for (int b = 0; b < 3; b++) qn[b] = ld2(phi + c + 2 * sz + (b - 1) * sy);
+        #pragma unroll
+        for (int dj = 0; dj < 2; dj++) sn[dj] = ld2(L.sig + c + sz + (dj - 1) * sy);
+        rhsn = ld2(L.b + c + sz);
+      }
+      EXCHP(2) EXCHS(1)
+      const bool dirk = (k == 0 && L.dirlo[2]) || (k == L.n[2] && L.dirhi[2]);
+      double pa[3][3][3], pb[3][3][3], sa[2][2][2], sb[2][2][2];
+      #pragma unroll
+      for (int pl = 0; pl < 3; pl++)
+        #pragma unroll
+        for (int b = 0; b < 3; b++)
+          #pragma unroll
+          for (int a = 0; a < 3; a++) { pa[pl][b][a] = q[pl][b][a]; pb[pl][b][a] = q[pl][b][a + 1]; }
+      #pragma unroll
+      for (int dk = 0; dk < 2; dk++)
+        #pragma unroll
+        for (int dj = 0; dj < 2; dj++)
+          #pragma unroll
+          for (int a = 0; a < 2; a++) { sa[dk][dj][a] = sg[dk][dj][a]; sb[dk][dj][a] = sg[dk][dj][a + 1]; }
+      double KpA, dgA, KpB, dgB;
+      nd_stencil(W, pa, sa, KpA, dgA);
+      nd_stencil(W, pb, sb, KpB, dgB);
+      const double p0A = q[1][1][1], p0B = q[1][1][2];
+      double2 o;
+      if (MODE == 0) {
+        o.x = p0A; o.y = p0B;
+        if (!(dirA_ij || dirk) && dgA != 0.0) o.x = p0A + omega * ((rhs.x - KpA) / dgA);
+        if (!(dirB_ij || dirk) && dgB != 0.0) o.y = p0B + omega * ((rhs.y - KpB) / dgB);
+      } else {
+        o.x = (dirA_ij || dirk) ? 0.0 : rhs.x - KpA;
+        o.y = (dirB_ij || dirk) ? 0.0 : rhs.y - KpB;
+        if (actA) rmax = nmax(rmax, fabs(o.x));
+        if (actB) rmax = nmax(rmax, fabs(o.y));
+      }
+      if (actB) *reinterpret_cast<double2 *>(out + c) = o;
+      else if (actA) out[c] = o.x;
+      #pragma unroll
+      for (int b = 0; b < 3; b++)
+        #pragma unroll
+        for (int a = 0; a < 4; a++) { q[0][b][a] = q[1][b][a]; q[1][b][a] = q[2][b][a]; }
+      #pragma unroll
+      for (int dj = 0; dj < 2; dj++)
+        #pragma unroll
+        for (int a = 0; a < 3; a++) sg[0][dj][a] = sg[1][dj][a];
+    }
+    #undef LOADP
+    #undef EXCHP
+    #undef LOADS
+    #undef EXCHS
   }
   if (MODE == 1 && nrm) block_atomic_max(nrm, rmax);
 }
@@ -480,6 +570,19 @@ template <int MODE> static void nd_launch_march(const NLev &L, const double *phi
   int kchunk = nzp;
   while (kchunk > 8 && tiles * ((nzp + kchunk - 1) / kchunk) < 2048) kchunk = (kchunk + 1) / 2;
   const int nch = (nzp + kchunk - 1) / kchunk;
+  static const bool paired = !(getenv("VDN_ND_PAIR") && atoi(getenv("VDN_ND_PAIR")) == 0);
+  if (paired && L.n[0] >= 127) {                   // 124 nodes per wave row
+    static const int rows = getenv("VDN_ND_ROWS") ? atoi(getenv("VDN_ND_ROWS")) : 4;
+    const int npair = (L.n[0] + 2) / 2, gx = (npair + 61) / 62, gy = (L.n[1] + rows) / rows;
+    static const int minwg = getenv("VDN_ND_MINWG") ? atoi(getenv("VDN_ND_MINWG")) : 2048;
+    int kc = nzp;
+    while (kc > 8 && gx * gy * ((nzp + kc - 1) / kc) < minwg) kc = (kc + 1) / 2;
+    const dim3 g(gx, gy, (nzp + kc - 1) / kc);
+    if (rows == 8) hipLaunchKernelGGL((kk_nd_march_pair<MODE, 8>), g, dim3(64, 8, 1), 0, ctx().stream, L, phi, out, ctx().prm.hg_omega, kc, nrm);
+    else if (rows == 16) hipLaunchKernelGGL((kk_nd_march_pair<MODE, 16>), g, dim3(64, 16, 1), 0, ctx().stream, L, phi, out, ctx().prm.hg_omega, kc, nrm);
+    else hipLaunchKernelGGL((kk_nd_march_pair<MODE, 4>), g, NBLK, 0, ctx().stream, L, phi, out, ctx().prm.hg_omega, kc, nrm);
+    return;
+  }
   hipLaunchKernelGGL(kk_nd_march<MODE>, dim3((L.n[0] + 62) / 62, (L.n[1] + 4) / 4, nch), NBLK, 0, ctx().stream, L, phi, out, ctx().prm.hg_omega, kchunk, nrm);
 }
 
@@ -745,7 +848,7 @@ static unsigned long long nd_graph_key(const NDMG &M, int what) {
   GraphKey k; k.put(what); k.put(P.hg_nu1); k.put(P.hg_nu2); k.put(P.hg_nub); k.put(P.hg_omega); k.put(M.per); k.put(M.d_nrm);
   k.put(M.sendbuf); k.put(M.recvbuf); k.put(M.d_gb); k.put(M.cnt_nodes); k.put(M.cnt_cells);
   for (const NDLev &DL : M.dlev) {
-    k.put(DL.halo_A); k.put(DL.halo_B); k.put(DL.halo_res); k.put(DL.halo_sig); k.put(DL.ng); k.put(DL.flip); k.put(DL.single_box); k.put(DL.per);
+    k.put(xplan_serial(DL.halo_A)); k.put(xplan_serial(DL.halo_B)); k.put(xplan_serial(DL.halo_res)); k.put(xplan_serial(DL.halo_sig)); k.put(DL.ng); k.put(DL.flip); k.put(DL.single_box); k.put(DL.per);
     for (const NBox &B : DL.boxes) { nd_key_lev(k, B.L); k.put(B.lo); k.put(B.A); k.put(B.B); }
   }
   for (const NLev &L : M.tail) nd_key_lev(k, L);
@@ -1010,34 +1113,21 @@ void do_hgproject(int proj_type, vdn_layout *mla, vdn_multifab **unew, vdn_multi
 // Works directly on the multifab fabs (nodal, one ghost layer).  This round: one fine box (the coarse level may be any
 // decomposition the single-level multigrid accepts), single rank.
 DEVI void ndf_apply(const FV &phi, const FV &sig, const double f[3], int i, int j, int k, double &Kp, double &diag) {
-  const double fx = f[0], fy = f[1], fz = f[2], F = fx + fy + fz;
-  double w[8];
-  w[0] = 4.0 * F; w[1] = -4.0 * fx + 2.0 * fy + 2.0 * fz; w[2] = 2.0 * fx - 4.0 * fy + 2.0 * fz; w[3] = -2.0 * fx - 2.0 * fy + fz;
-  w[4] = 2.0 * fx + 2.0 * fy - 4.0 * fz; w[5] = -2.0 * fx + fy - 2.0 * fz; w[6] = fx - 2.0 * fy - 2.0 * fz; w[7] = -F;
-  double acc = 0.0, ssum = 0.0;
+  const NdW W = nd_weights(f);
+  double p[3][3][3], sg[2][2][2];
   #pragma unroll
-  for (int dk = 0; dk < 2; dk++)
+  for (int c = 0; c < 3; c++)
     #pragma unroll
-    for (int dj = 0; dj < 2; dj++)
+    for (int b = 0; b < 3; b++)
       #pragma unroll
-      for (int di = 0; di < 2; di++) {
-        const int ci = i - 1 + di, cj = j - 1 + dj, ck = k - 1 + dk;
-        const double sg = fv_get(sig, ci, cj, ck);
-        double t = 0.0;
-        #pragma unroll
-        for (int mz = 0; mz < 2; mz++)
-          #pragma unroll
-          for (int my = 0; my < 2; my++)
-            #pragma unroll
-            for (int mx = 0; mx < 2; mx++) {
-              const int ni = ci + mx, nj = cj + my, nk = ck + mz;
-              const int idx = (ni != i) | ((nj != j) << 1) | ((nk != k) << 2);
-              t = t + w[idx] * fv_get(phi, ni, nj, nk);
-            }
-        acc = acc + sg * t;
-        ssum = ssum + sg;
-      }
-  Kp = acc; diag = w[0] * ssum;
+      for (int a = 0; a < 3; a++) p[c][b][a] = fv_get(phi, i + a - 1, j + b - 1, k + c - 1);
+  #pragma unroll
+  for (int c = 0; c < 2; c++)
+    #pragma unroll
+    for (int b = 0; b < 2; b++)
+      #pragma unroll
+      for (int a = 0; a < 2; a++) sg[c][b][a] = fv_get(sig, i + a - 1, j + b - 1, k + c - 1);
+  nd_stencil(W, p, sg, Kp, diag);
 }
 struct NdfArgs { double f[3]; int lo[3], hi[3]; int dirlo[3], dirhi[3]; int cflo[3], cfhi[3]; int ilo[3], ihi[3]; };
 DEVI bool ndf_pdir(const NdfArgs &A, int i, int j, int k) {
@@ -1113,10 +1203,7 @@ __global__ void __launch_bounds__(256) kk_ndf_march(const MarchB *args, const in
     }
     #pragma unroll
     for (int dj = 0; dj < 2; dj++) sg[0][dj][0] = lane_prev(sg[0][dj][1]);
-    const double fx = A.f[0], fy = A.f[1], fz = A.f[2], F = fx + fy + fz;
-    double w[8];
-    w[0] = 4.0 * F; w[1] = -4.0 * fx + 2.0 * fy + 2.0 * fz; w[2] = 2.0 * fx - 4.0 * fy + 2.0 * fz; w[3] = -2.0 * fx - 2.0 * fy + fz;
-    w[4] = 2.0 * fx + 2.0 * fy - 4.0 * fz; w[5] = -2.0 * fx + fy - 2.0 * fz; w[6] = fx - 2.0 * fy - 2.0 * fz; w[7] = -F;
+    const NdW W = nd_weights(A.f);
     for (int k = k0; k <= k1; k++) {
       #pragma unroll
       for (int b = 0; b < 3; b++) p[2][b][1] = fv_get(phi, ic, jc + b - 1, k + 1);
@@ -1127,29 +1214,7 @@ __global__ void __launch_bounds__(256) kk_ndf_march(const MarchB *args, const in
       for (int b = 0; b < 3; b++) { p[2][b][0] = lane_prev(p[2][b][1]); p[2][b][2] = lane_next(p[2][b][1]); }
       #pragma unroll
       for (int dj = 0; dj < 2; dj++) sg[1][dj][0] = lane_prev(sg[1][dj][1]);
-      // K phi in the order of ndf_apply: cells (dk,dj,di) ascending, corners (mz,my,mx) ascending
-      double acc = 0.0, ssum = 0.0;
-      #pragma unroll
-      for (int dk = 0; dk < 2; dk++)
-        #pragma unroll
-        for (int dj = 0; dj < 2; dj++)
-          #pragma unroll
-          for (int di = 0; di < 2; di++) {
-            double t = 0.0;
-            #pragma unroll
-            for (int mz = 0; mz < 2; mz++)
-              #pragma unroll
-              for (int my = 0; my < 2; my++)
-                #pragma unroll
-                for (int mx = 0; mx < 2; mx++) {
-                  const int oa = di + mx - 1, ob = dj + my - 1, oc = dk + mz - 1;
-                  const int idx = (oa != 0) | ((ob != 0) << 1) | ((oc != 0) << 2);
-                  t = t + w[idx] * p[oc + 1][ob + 1][oa + 1];
-                }
-            acc = acc + sg[dk][dj][di] * t;
-            ssum = ssum + sg[dk][dj][di];
-          }
-      const double Kp = acc, diag = w[0] * ssum;
+      double Kp, diag; nd_stencil(W, p, sg, Kp, diag);
       const double p0 = p[1][1][1];
       const bool pdir = ndf_pdir(A, i, j, k);
       // slaved to the coarser level: has_slave = 1 node mask (any union of boxes), 2 = the level is ONE box: its non-physical faces (no mask traffic)

@@ -246,7 +246,7 @@ extern "C" int vdn_layout_create(int nlev, const int *rr, const vdn_box *pd, con
   *out = la;
   VDN_CATCH
 }
-extern "C" int vdn_layout_destroy(vdn_layout *la) { VDN_TRY if (la) { xplan_cache_purge(la->uid); delete la; } VDN_CATCH }
+extern "C" int vdn_layout_destroy(vdn_layout *la) { VDN_TRY if (la) { graph_cache_clear(); xplan_cache_purge(la->uid); delete la; } VDN_CATCH }
 extern "C" int vdn_layout_nlevel(const vdn_layout *la) { return la->nlev; }
 extern "C" int vdn_layout_nboxes(const vdn_layout *la, int lev) { return (int)la->boxes[lev].size(); }
 extern "C" int vdn_layout_nlocal(const vdn_layout *la, int lev) { return (int)la->local[lev].size(); }

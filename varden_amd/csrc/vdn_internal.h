@@ -152,6 +152,7 @@ struct XPlan;
 XPlan *xplan_build(const std::vector<XBoxInfo> &boxes, const vdn_box &pd, const int pmask[3], int ng, int nc);
 void   xplan_run(XPlan *P);
 void   xplan_free(XPlan *P);
+unsigned long xplan_serial(const XPlan *P);
 void   xplan_cache_purge(unsigned long layout_uid);   // drop every cached plan built for that layout
 void   halo_cache_register(unsigned long layout_uid, XPlan *P);
 std::vector<XBoxInfo> xboxes_of(const vdn_multifab *mf);
