@@ -16,6 +16,7 @@
 // The per-box dead-band eps needs a max-reduction: wave shuffles + one atomic per wave, consumed from
 // device memory by the next kernel (no host round trip).
 #include "vdn_dev.h"
+#include <algorithm>
 
 // ---------------------------------------------------------------------------------------------------
 struct GArgs {
@@ -152,16 +153,20 @@ template <int D> DEVI void mk_pair(const GArgs &A, const FV &s, const FV &slp, c
 }
 
 // stage B: simh_D on the lower faces of cell (i,j,k);  SI has 3*ncomp comps: [D*ncomp + c]
+struct MkPlain { FV s, sl0, sl1, sl2, um, vm, wm, force, macrhs, SI, SC, sex, sey, sez, flx, fly, flz; GArgs A; const double *umax; };
+DEVI void mk_B_cell(const FV &s, const FV &sl0, const FV &sl1, const FV &sl2, const FV &um, const FV &vm, const FV &wm, const FV &force, const FV &macrhs, const FV &SI,
+                    const GArgs &A, int i, int j, int k, double eps, int dmask = 7) {
+  for (int c = 0; c < A.ncomp; c++) {
+    double L, R;
+    if ((dmask & 1) && i >= A.lo[0]) { mk_pair<0>(A, s, sl0, um, force, macrhs, c, i, j, k, L, R); fv_at(SI, i, j, k, 0 * A.ncomp + c) = upwind_mac(L, R, fv_get(um, i, j, k), eps); }
+    if ((dmask & 2) && j >= A.lo[1]) { mk_pair<1>(A, s, sl1, vm, force, macrhs, c, i, j, k, L, R); fv_at(SI, i, j, k, 1 * A.ncomp + c) = upwind_mac(L, R, fv_get(vm, i, j, k), eps); }
+    if ((dmask & 4) && k >= A.lo[2]) { mk_pair<2>(A, s, sl2, wm, force, macrhs, c, i, j, k, L, R); fv_at(SI, i, j, k, 2 * A.ncomp + c) = upwind_mac(L, R, fv_get(wm, i, j, k), eps); }
+  }
+}
 __global__ void __launch_bounds__(256) kk_mk_B(FV s, FV sl0, FV sl1, FV sl2, FV um, FV vm, FV wm, FV force, FV macrhs, FV SI, GArgs A, Range3 r, const double *umax) {
   THREAD_IJK(r)
   if (!in_range) return;
-  const double eps = eps_from(umax);
-  for (int c = 0; c < A.ncomp; c++) {
-    double L, R;
-    if (i >= A.lo[0]) { mk_pair<0>(A, s, sl0, um, force, macrhs, c, i, j, k, L, R); fv_at(SI, i, j, k, 0 * A.ncomp + c) = upwind_mac(L, R, fv_get(um, i, j, k), eps); }
-    if (j >= A.lo[1]) { mk_pair<1>(A, s, sl1, vm, force, macrhs, c, i, j, k, L, R); fv_at(SI, i, j, k, 1 * A.ncomp + c) = upwind_mac(L, R, fv_get(vm, i, j, k), eps); }
-    if (k >= A.lo[2]) { mk_pair<2>(A, s, sl2, wm, force, macrhs, c, i, j, k, L, R); fv_at(SI, i, j, k, 2 * A.ncomp + c) = upwind_mac(L, R, fv_get(wm, i, j, k), eps); }
-  }
+  mk_B_cell(s, sl0, sl1, sl2, um, vm, wm, force, macrhs, SI, A, i, j, k, eps_from(umax));
 }
 
 // transverse correction of a state extrapolated from cell (ci,cj,ck) by direction T
@@ -195,18 +200,21 @@ template <int D, int T> DEVI void mk_C_one(const GArgs &A, const FV &s, const FV
 }
 DEVI int sc_idx(int D, int T, int ncomp, int c) { return (D * 2 + (T > D ? T - 1 : T)) * ncomp + c; }
 
+DEVI void mk_C_cell(const FV &s, const FV &sl0, const FV &sl1, const FV &sl2, const FV &um, const FV &vm, const FV &wm, const FV &force, const FV &macrhs, const FV &SI, const FV &SC,
+                    const GArgs &A, int i, int j, int k, double eps, int dmask = 7) {
+  for (int c = 0; c < A.ncomp; c++) {
+    if (dmask & 1) mk_C_one<0, 1>(A, s, sl0, um, vm, force, macrhs, SI, SC, c, i, j, k, eps);
+    if (dmask & 1) mk_C_one<0, 2>(A, s, sl0, um, wm, force, macrhs, SI, SC, c, i, j, k, eps);
+    if (dmask & 2) mk_C_one<1, 0>(A, s, sl1, vm, um, force, macrhs, SI, SC, c, i, j, k, eps);
+    if (dmask & 2) mk_C_one<1, 2>(A, s, sl1, vm, wm, force, macrhs, SI, SC, c, i, j, k, eps);
+    if (dmask & 4) mk_C_one<2, 0>(A, s, sl2, wm, um, force, macrhs, SI, SC, c, i, j, k, eps);
+    if (dmask & 4) mk_C_one<2, 1>(A, s, sl2, wm, vm, force, macrhs, SI, SC, c, i, j, k, eps);
+  }
+}
 __global__ void __launch_bounds__(256) kk_mk_C(FV s, FV sl0, FV sl1, FV sl2, FV um, FV vm, FV wm, FV force, FV macrhs, FV SI, FV SC, GArgs A, Range3 r, const double *umax) {
   THREAD_IJK(r)
   if (!in_range) return;
-  const double eps = eps_from(umax);
-  for (int c = 0; c < A.ncomp; c++) {
-    mk_C_one<0, 1>(A, s, sl0, um, vm, force, macrhs, SI, SC, c, i, j, k, eps);
-    mk_C_one<0, 2>(A, s, sl0, um, wm, force, macrhs, SI, SC, c, i, j, k, eps);
-    mk_C_one<1, 0>(A, s, sl1, vm, um, force, macrhs, SI, SC, c, i, j, k, eps);
-    mk_C_one<1, 2>(A, s, sl1, vm, wm, force, macrhs, SI, SC, c, i, j, k, eps);
-    mk_C_one<2, 0>(A, s, sl2, wm, um, force, macrhs, SI, SC, c, i, j, k, eps);
-    mk_C_one<2, 1>(A, s, sl2, wm, vm, force, macrhs, SI, SC, c, i, j, k, eps);
-  }
+  mk_C_cell(s, sl0, sl1, sl2, um, vm, wm, force, macrhs, SI, SC, A, i, j, k, eps_from(umax));
 }
 
 // stage D for direction D (mkflux.f90:2307-2408 x, 2411-2511 y, 1867-1972 z)
@@ -255,17 +263,58 @@ template <int D> DEVI void mk_D_one(const GArgs &A, const FV &s, const FV &slp, 
   if (cons) fv_at(flux, i, j, k, c) = e * um;        // mkflux.f90:1969, 2405, 2508
 }
 
+DEVI void mk_D_cell(const FV &s, const FV &sl0, const FV &sl1, const FV &sl2, const FV &um, const FV &vm, const FV &wm, const FV &force, const FV &macrhs, const FV &SC,
+                    const FV &sex, const FV &sey, const FV &sez, const FV &flx, const FV &fly, const FV &flz, const GArgs &A, int i, int j, int k, double eps, int dmask = 7) {
+  for (int c = 0; c < A.ncomp; c++) {
+    if (dmask & 1) mk_D_one<0>(A, s, sl0, um, vm, wm, force, macrhs, SC, sex, flx, c, i, j, k, eps);
+    if (dmask & 2) mk_D_one<1>(A, s, sl1, vm, um, wm, force, macrhs, SC, sey, fly, c, i, j, k, eps);
+    if (dmask & 4) mk_D_one<2>(A, s, sl2, wm, um, vm, force, macrhs, SC, sez, flz, c, i, j, k, eps);
+  }
+}
 __global__ void __launch_bounds__(256) kk_mk_D(FV s, FV sl0, FV sl1, FV sl2, FV um, FV vm, FV wm, FV force, FV macrhs, FV SC,
                         FV sex, FV sey, FV sez, FV flx, FV fly, FV flz, GArgs A, Range3 r, const double *umax) {
   THREAD_IJK(r)
   if (!in_range) return;
-  const double eps = eps_from(umax);
-  for (int c = 0; c < A.ncomp; c++) {
-    mk_D_one<0>(A, s, sl0, um, vm, wm, force, macrhs, SC, sex, flx, c, i, j, k, eps);
-    mk_D_one<1>(A, s, sl1, vm, um, wm, force, macrhs, SC, sey, fly, c, i, j, k, eps);
-    mk_D_one<2>(A, s, sl2, wm, um, vm, force, macrhs, SC, sez, flz, c, i, j, k, eps);
-  }
+  mk_D_cell(s, sl0, sl1, sl2, um, vm, wm, force, macrhs, SC, sex, sey, sez, flx, fly, flz, A, i, j, k, eps_from(umax));
 }
+
+// ---- boundary slabs --------------------------------------------------------------------------------------------------------------
+// Round 2: the marching kernels below carry NO boundary code.  The physical boundary rules (bc_pair and the edge-state rules) only
+// change states ON the faces of a box that lie on a physical domain boundary: a two-dimensional set.  The marching kernels compute
+// every face with the interior formulas, and each stage is followed by ONE launch of the face-centred code above over the (at most
+// six) one-cell-thick slabs that hold those faces.  The face-centred and the marching forms are bit-identical
+// (tests/test_kernels_gpu.py::test_godunov_marching_equals_face_centred), so the result is what the round-1 kernels produced, while the
+// marches lose their branches, the register copies behind them (47 % of the instructions of kk_vp_B_m were v_mov) and ~100 VGPRs.
+struct Slabs { int n; int dir[6], pos[6]; Range3 r; };
+// slabs of range r (a stage's index range: lo-1..hi+1 for B and C, lo..hi+1 for D) that hold the physical boundary faces of the box
+static Slabs boundary_slabs(const GArgs &A, const Range3 &r) {
+  Slabs S; S.n = 0; S.r = r;
+  for (int d = 0; d < 3; d++) for (int sd = 0; sd < 2; sd++) {
+    const int ph = A.phys[d][sd];
+    if (ph == VDN_INTERIOR || ph == VDN_PERIODIC) continue;
+    S.dir[S.n] = d; S.pos[S.n] = sd == 0 ? A.lo[d] : A.hi[d] + 1; S.n++;
+  }
+  return S;
+}
+template <class F> __global__ void __launch_bounds__(256) kk_slabs(Slabs S, F f) {
+  const int sl = blockIdx.z;
+  const int d = S.dir[sl], da = d == 0 ? 1 : 0, db = d == 2 ? 1 : 2;
+  int q[3];
+  q[d] = S.pos[sl];
+  q[da] = S.r.lo[da] + (int)(blockIdx.x * blockDim.x + threadIdx.x);
+  q[db] = S.r.lo[db] + (int)(blockIdx.y * blockDim.y + threadIdx.y);
+  if (q[da] > S.r.hi[da] || q[db] > S.r.hi[db]) return;
+  f(q[0], q[1], q[2], 1 << d);          // only the states on the faces normal to d change
+}
+template <class F> static void launch_slabs(const Slabs &S, const F &f, hipStream_t st) {
+  if (S.n == 0) return;
+  int m = 1;
+  for (int d = 0; d < 3; d++) m = std::max(m, S.r.hi[d] - S.r.lo[d] + 1);
+  hipLaunchKernelGGL((kk_slabs<F>), dim3((m + 63) / 64, (m + 3) / 4, S.n), dim3(64, 4, 1), 0, st, S, f);
+}
+struct MkBFix { MkPlain P; __device__ void operator()(int i, int j, int k, int dmask) const { mk_B_cell(P.s, P.sl0, P.sl1, P.sl2, P.um, P.vm, P.wm, P.force, P.macrhs, P.SI, P.A, i, j, k, eps_from(P.umax), dmask); } };
+struct MkCFix { MkPlain P; __device__ void operator()(int i, int j, int k, int dmask) const { mk_C_cell(P.s, P.sl0, P.sl1, P.sl2, P.um, P.vm, P.wm, P.force, P.macrhs, P.SI, P.SC, P.A, i, j, k, eps_from(P.umax), dmask); } };
+struct MkDFix { MkPlain P; __device__ void operator()(int i, int j, int k, int dmask) const { mk_D_cell(P.s, P.sl0, P.sl1, P.sl2, P.um, P.vm, P.wm, P.force, P.macrhs, P.SC, P.sex, P.sey, P.sez, P.flx, P.fly, P.flz, P.A, i, j, k, eps_from(P.umax), dmask); } };
 
 // ====================================================================================================
 // Cell-centred, k-marching form of the stage B / C / D kernels (the default path)
@@ -288,10 +337,21 @@ __global__ void __launch_bounds__(256) kk_mk_D(FV s, FV sl0, FV sl1, FV sl2, FV 
 // VDN_GODUNOV_BATCH=1 launches the descriptor (box-batched) kernels also for a level of one box. Measured at 256^3: they need
 // fewer VGPRs (mk_D<1> 116 vs 174) yet run slower there (scalar 6.6 vs 5.6 ms, velocity 10.0 vs 8.2 ms), so one box keeps the by-value kernels
 static bool batch_always() { static const bool b = getenv("VDN_GODUNOV_BATCH") && atoi(getenv("VDN_GODUNOV_BATCH")) != 0; return b; }
+// VDN_GOD_SLAB_BC=0: the round-1 marches with the boundary code inside (kept for comparison); default: interior marches + boundary slabs
+static bool slab_bc() { static const bool b = !(getenv("VDN_GOD_SLAB_BC") && atoi(getenv("VDN_GOD_SLAB_BC")) == 0); return b; }
 static bool plain_godunov() { static const bool p = getenv("VDN_GODUNOV_PLAIN") != nullptr; return p; }
 // parameters of the marching bodies: by value under the by-value kernels, references into the (constant) descriptor under the batched ones
 template <class T, bool R> struct Prm { typedef T type; };
 template <class T> struct Prm<T, true> { typedef const T &type; };
+// tile order of the marching kernels: VDN_GOD_XCD=0 keeps the dispatch order (default: XCD-aware, vdn_dev.h xcd_tile)
+__constant__ int g_god_xcd = 1;
+DEVI void xcd_remap(int &bx, int &by, int &bz) { if (g_god_xcd) xcd_tile(bx, by, bz); else { bx = blockIdx.x; by = blockIdx.y; bz = blockIdx.z; } }
+static void god_xcd_init() {
+  static bool done = false;
+  if (done) return;
+  done = true;
+  if (getenv("VDN_GOD_XCD")) { const int v = atoi(getenv("VDN_GOD_XCD")); HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(g_god_xcd), &v, sizeof(int))); }
+}
 constexpr int TNY = 8;              // rows per tile: workgroup = 64 x TNY threads
 static int march_chunks() { static const int n = getenv("VDN_KCHUNKS") ? atoi(getenv("VDN_KCHUNKS")) : 12; return n < 1 ? 1 : n; }
 static dim3 march_grid(const Range3 &r, int &klen) {
@@ -359,7 +419,7 @@ template <int D> DEVI void mk_face_bc(const GArgs &A, const FV &s, int c, int i,
     }
 
 // ---- stage B ----------------------------------------------------------------------------------------------------
-template <int NC, bool R> __device__ __forceinline__ void mk_B_m_body(typename Prm<FV, R>::type s, typename Prm<FV, R>::type sl0, typename Prm<FV, R>::type sl1, typename Prm<FV, R>::type sl2, typename Prm<FV, R>::type um, typename Prm<FV, R>::type vm, typename Prm<FV, R>::type wm, typename Prm<FV, R>::type force, typename Prm<FV, R>::type macrhs, typename Prm<FV, R>::type SI, typename Prm<GArgs, R>::type A, typename Prm<Range3, R>::type r, int klen, const double *umax, int c0, int ns, const int BX, const int BY, const int BZ) {
+template <int NC, bool R, bool BC> __device__ __forceinline__ void mk_B_m_body(typename Prm<FV, R>::type s, typename Prm<FV, R>::type sl0, typename Prm<FV, R>::type sl1, typename Prm<FV, R>::type sl2, typename Prm<FV, R>::type um, typename Prm<FV, R>::type vm, typename Prm<FV, R>::type wm, typename Prm<FV, R>::type force, typename Prm<FV, R>::type macrhs, typename Prm<FV, R>::type SI, typename Prm<GArgs, R>::type A, typename Prm<Range3, R>::type r, int klen, const double *umax, int c0, int ns, const int BX, const int BY, const int BZ) {
   __shared__ double ly[2][NC][TNY][64];
   MARCH_SETUP(r)
   const double eps = eps_from(umax);
@@ -397,7 +457,7 @@ template <int NC, bool R> __device__ __forceinline__ void mk_B_m_body(typename P
       Lzc[c] = Lz[c]; Lz[c] = Lb[c][2];
     }
     if (emit) {
-      if (edge) {
+      if (BC && edge) {
         #pragma unroll
         for (int c = 0; c < NC; c++) {
           mk_face_bc<0>(A, s, c0 + c, i, j, k, s0[c], Lx[c], Rb[c][0]); mk_face_bc<1>(A, s, c0 + c, i, j, k, s0[c], Ly[c], Rb[c][1]); mk_face_bc<2>(A, s, c0 + c, i, j, k, s0[c], Lzc[c], Rb[c][2]);
@@ -412,14 +472,15 @@ template <int NC, bool R> __device__ __forceinline__ void mk_B_m_body(typename P
     }
   }
 }
-template <int NC> __global__ void __launch_bounds__(64 * TNY) kk_mk_B_m(FV s, FV sl0, FV sl1, FV sl2, FV um, FV vm, FV wm, FV force, FV macrhs, FV SI, GArgs A, Range3 r, int klen, const double *umax, int c0, int ns) {
-  mk_B_m_body<NC, false>(s, sl0, sl1, sl2, um, vm, wm, force, macrhs, SI, A, r, klen, umax, c0, ns, (int)blockIdx.x, (int)blockIdx.y, (int)blockIdx.z);
+template <int NC, bool BC = true> __global__ void __launch_bounds__(64 * TNY) kk_mk_B_m(FV s, FV sl0, FV sl1, FV sl2, FV um, FV vm, FV wm, FV force, FV macrhs, FV SI, GArgs A, Range3 r, int klen, const double *umax, int c0, int ns) {
+  int bx_, by_, bz_; xcd_remap(bx_, by_, bz_);
+  mk_B_m_body<NC, false, BC>(s, sl0, sl1, sl2, um, vm, wm, force, macrhs, SI, A, r, klen, umax, c0, ns, bx_, by_, bz_);
 }
 
 
 // ---- stage C ----------------------------------------------------------------------------------------------------
 // per cell and component: the three transverse terms t_T (from SI_T, mac_T) and the six chains base_D - t_T
-template <int NC, bool R> __device__ __forceinline__ void mk_C_m_body(typename Prm<FV, R>::type s, typename Prm<FV, R>::type sl0, typename Prm<FV, R>::type sl1, typename Prm<FV, R>::type sl2, typename Prm<FV, R>::type um, typename Prm<FV, R>::type vm, typename Prm<FV, R>::type wm, typename Prm<FV, R>::type force, typename Prm<FV, R>::type macrhs, typename Prm<FV, R>::type SI, typename Prm<FV, R>::type SC, typename Prm<GArgs, R>::type A, typename Prm<Range3, R>::type r, int klen, const double *umax, int c0, int ns, const int BX, const int BY, const int BZ) {
+template <int NC, bool R, bool BC> __device__ __forceinline__ void mk_C_m_body(typename Prm<FV, R>::type s, typename Prm<FV, R>::type sl0, typename Prm<FV, R>::type sl1, typename Prm<FV, R>::type sl2, typename Prm<FV, R>::type um, typename Prm<FV, R>::type vm, typename Prm<FV, R>::type wm, typename Prm<FV, R>::type force, typename Prm<FV, R>::type macrhs, typename Prm<FV, R>::type SI, typename Prm<FV, R>::type SC, typename Prm<GArgs, R>::type A, typename Prm<Range3, R>::type r, int klen, const double *umax, int c0, int ns, const int BX, const int BY, const int BZ) {
   __shared__ double ly[2][NC][2][TNY][64];
   MARCH_SETUP(r)
   const double eps = eps_from(umax);
@@ -452,7 +513,7 @@ template <int NC, bool R> __device__ __forceinline__ void mk_C_m_body(typename P
       mk_bases<1>(A, c0 + c, s0[c], sl[c][1], m_lo[1], m_up[1], ft[c], mt[c], Lb[c][1], Rb[c][1]);
       mk_bases<2>(A, c0 + c, s0[c], sl[c][2], m_lo[2], m_up[2], ft[c], mt[c], Lb[c][2], Rb[c][2]);
     }
-    if (edge) {
+    if (BC && edge) {
       #pragma unroll
       for (int c = 0; c < NC; c++) { mk_premod<0>(A, s, c0 + c, ic, jc, kc, Lb[c][0], Rb[c][0]); mk_premod<1>(A, s, c0 + c, ic, jc, kc, Lb[c][1], Rb[c][1]); mk_premod<2>(A, s, c0 + c, ic, jc, kc, Lb[c][2], Rb[c][2]); }
     }
@@ -482,7 +543,7 @@ template <int NC, bool R> __device__ __forceinline__ void mk_C_m_body(typename P
       Lz[c][0] = VL[c][2][0]; Lz[c][1] = VL[c][2][1];
     }
     if (emit) {
-      if (edge) {
+      if (BC && edge) {
         #pragma unroll
         for (int c = 0; c < NC; c++) {
           #pragma unroll
@@ -510,8 +571,9 @@ template <int NC, bool R> __device__ __forceinline__ void mk_C_m_body(typename P
     }
   }
 }
-template <int NC> __global__ void __launch_bounds__(64 * TNY) kk_mk_C_m(FV s, FV sl0, FV sl1, FV sl2, FV um, FV vm, FV wm, FV force, FV macrhs, FV SI, FV SC, GArgs A, Range3 r, int klen, const double *umax, int c0, int ns) {
-  mk_C_m_body<NC, false>(s, sl0, sl1, sl2, um, vm, wm, force, macrhs, SI, SC, A, r, klen, umax, c0, ns, (int)blockIdx.x, (int)blockIdx.y, (int)blockIdx.z);
+template <int NC, bool BC = true> __global__ void __launch_bounds__(64 * TNY) kk_mk_C_m(FV s, FV sl0, FV sl1, FV sl2, FV um, FV vm, FV wm, FV force, FV macrhs, FV SI, FV SC, GArgs A, Range3 r, int klen, const double *umax, int c0, int ns) {
+  int bx_, by_, bz_; xcd_remap(bx_, by_, bz_);
+  mk_C_m_body<NC, false, BC>(s, sl0, sl1, sl2, um, vm, wm, force, macrhs, SI, SC, A, r, klen, umax, c0, ns, bx_, by_, bz_);
 }
 
 
@@ -551,7 +613,7 @@ template <int NC> DEVI void d_load_plane(DPlane<NC> &P, const FV &s, const FV &s
     P.q1[c][4] = fv_get(SC, ic, jc, kp, 4 * ns + c0 + c); P.q1[c][5] = fv_get(SC, ic, jc, kp, 5 * ns + c0 + c);
   }
 }
-template <int NC, bool R, bool PF> __device__ __forceinline__ void mk_D_m_body(typename Prm<FV, R>::type s, typename Prm<FV, R>::type sl0, typename Prm<FV, R>::type sl1, typename Prm<FV, R>::type sl2, typename Prm<FV, R>::type um, typename Prm<FV, R>::type vm, typename Prm<FV, R>::type wm, typename Prm<FV, R>::type force, typename Prm<FV, R>::type macrhs, typename Prm<FV, R>::type SC, typename Prm<FV, R>::type sex, typename Prm<FV, R>::type sey, typename Prm<FV, R>::type sez, typename Prm<FV, R>::type flx, typename Prm<FV, R>::type fly, typename Prm<FV, R>::type flz, typename Prm<GArgs, R>::type A, typename Prm<Range3, R>::type r, int klen, const double *umax, int c0, int ns, const int BX, const int BY, const int BZ) {
+template <int NC, bool R, bool PF, bool BC> __device__ __forceinline__ void mk_D_m_body(typename Prm<FV, R>::type s, typename Prm<FV, R>::type sl0, typename Prm<FV, R>::type sl1, typename Prm<FV, R>::type sl2, typename Prm<FV, R>::type um, typename Prm<FV, R>::type vm, typename Prm<FV, R>::type wm, typename Prm<FV, R>::type force, typename Prm<FV, R>::type macrhs, typename Prm<FV, R>::type SC, typename Prm<FV, R>::type sex, typename Prm<FV, R>::type sey, typename Prm<FV, R>::type sez, typename Prm<FV, R>::type flx, typename Prm<FV, R>::type fly, typename Prm<FV, R>::type flz, typename Prm<GArgs, R>::type A, typename Prm<Range3, R>::type r, int klen, const double *umax, int c0, int ns, const int BX, const int BY, const int BZ) {
   __shared__ double ly[2][NC][TNY][64];
   MARCH_SETUP(r)
   const double eps = eps_from(umax);
@@ -581,7 +643,7 @@ template <int NC, bool R, bool PF> __device__ __forceinline__ void mk_D_m_body(t
       mk_bases<1>(A, c0 + c, s0[c], sl[c][1], m_lo[1], m_up[1], ft[c], mt[c], Lb[c][1], Rb[c][1]);
       mk_bases<2>(A, c0 + c, s0[c], sl[c][2], m_lo[2], m_up[2], ft[c], mt[c], Lb[c][2], Rb[c][2]);
     }
-    if (edge) {
+    if (BC && edge) {
       #pragma unroll
       for (int c = 0; c < NC; c++) { mk_premod<0>(A, s, c0 + c, ic, jc, kc, Lb[c][0], Rb[c][0]); mk_premod<1>(A, s, c0 + c, ic, jc, kc, Lb[c][1], Rb[c][1]); mk_premod<2>(A, s, c0 + c, ic, jc, kc, Lb[c][2], Rb[c][2]); }
     }
@@ -618,7 +680,7 @@ template <int NC, bool R, bool PF> __device__ __forceinline__ void mk_D_m_body(t
       double e[NC][3];
       #pragma unroll
       for (int c = 0; c < NC; c++) { e[c][0] = upwind_mac(L[c][0], VR[c][0], m_lo[0], eps); e[c][1] = upwind_mac(L[c][1], VR[c][1], m_lo[1], eps); e[c][2] = upwind_mac(L[c][2], VR[c][2], m_lo[2], eps); }
-      if (edge) {
+      if (BC && edge) {
         #pragma unroll
         for (int c = 0; c < NC; c++) {
           e[c][0] = mk_edge_bc<0>(A, s, c0 + c, i, j, k, s0[c], L[c][0], VR[c][0], e[c][0]);
@@ -636,8 +698,10 @@ template <int NC, bool R, bool PF> __device__ __forceinline__ void mk_D_m_body(t
     }
   }
 }
-template <int NC, bool PF = false> __global__ void __launch_bounds__(64 * TNY) kk_mk_D_m(FV s, FV sl0, FV sl1, FV sl2, FV um, FV vm, FV wm, FV force, FV macrhs, FV SC, FV sex, FV sey, FV sez, FV flx, FV fly, FV flz, GArgs A, Range3 r, int klen, const double *umax, int c0, int ns) {
-  mk_D_m_body<NC, false, PF>(s, sl0, sl1, sl2, um, vm, wm, force, macrhs, SC, sex, sey, sez, flx, fly, flz, A, r, klen, umax, c0, ns, (int)blockIdx.x, (int)blockIdx.y, (int)blockIdx.z);
+// (measured and rejected: capping the one-component kernel at 128 VGPRs -- 11 spilled -- so that two workgroups share a CU: 0.82 -> 1.04 ms)
+template <int NC, bool PF = false, bool BC = true> __global__ void __launch_bounds__(64 * TNY) kk_mk_D_m(FV s, FV sl0, FV sl1, FV sl2, FV um, FV vm, FV wm, FV force, FV macrhs, FV SC, FV sex, FV sey, FV sez, FV flx, FV fly, FV flz, GArgs A, Range3 r, int klen, const double *umax, int c0, int ns) {
+  int bx_, by_, bz_; xcd_remap(bx_, by_, bz_);
+  mk_D_m_body<NC, false, PF, BC>(s, sl0, sl1, sl2, um, vm, wm, force, macrhs, SC, sex, sey, sez, flx, fly, flz, A, r, klen, umax, c0, ns, bx_, by_, bz_);
 }
 
 
@@ -705,15 +769,15 @@ __global__ void kk_velmax_b(const VpD *descs, const int *start, int nbox) {
 }
 template <int NC> __global__ void __launch_bounds__(64 * TNY) kk_mk_B_mb(const MkD *descs, const int *start, int nbox, int c0, int ns) {
   BATCH_LOCATE(MkD, gg)
-  mk_B_m_body<NC, true>(q.s, q.sl0, q.sl1, q.sl2, q.um, q.vm, q.wm, q.force, q.macrhs, q.SI, q.A, q.rg, q.klg, q.umax, c0, ns, BX, BY, BZ);
+  mk_B_m_body<NC, true, true>(q.s, q.sl0, q.sl1, q.sl2, q.um, q.vm, q.wm, q.force, q.macrhs, q.SI, q.A, q.rg, q.klg, q.umax, c0, ns, BX, BY, BZ);
 }
 template <int NC> __global__ void __launch_bounds__(64 * TNY) kk_mk_C_mb(const MkD *descs, const int *start, int nbox, int c0, int ns) {
   BATCH_LOCATE(MkD, gg)
-  mk_C_m_body<NC, true>(q.s, q.sl0, q.sl1, q.sl2, q.um, q.vm, q.wm, q.force, q.macrhs, q.SI, q.SC, q.A, q.rg, q.klg, q.umax, c0, ns, BX, BY, BZ);
+  mk_C_m_body<NC, true, true>(q.s, q.sl0, q.sl1, q.sl2, q.um, q.vm, q.wm, q.force, q.macrhs, q.SI, q.SC, q.A, q.rg, q.klg, q.umax, c0, ns, BX, BY, BZ);
 }
 template <int NC> __global__ void __launch_bounds__(64 * TNY) kk_mk_D_mb(const MkD *descs, const int *start, int nbox, int c0, int ns) {
   BATCH_LOCATE(MkD, gf)
-  mk_D_m_body<NC, true, false>(q.s, q.sl0, q.sl1, q.sl2, q.um, q.vm, q.wm, q.force, q.macrhs, q.SC, q.sex, q.sey, q.sez, q.flx, q.fly, q.flz, q.A, q.rf, q.klf, q.umax, c0, ns, BX, BY, BZ);
+  mk_D_m_body<NC, true, false, true>(q.s, q.sl0, q.sl1, q.sl2, q.um, q.vm, q.wm, q.force, q.macrhs, q.SC, q.sex, q.sey, q.sez, q.flx, q.fly, q.flz, q.A, q.rf, q.klf, q.umax, c0, ns, BX, BY, BZ);
 }
 // host side of a batch: grids of the four launch shapes per box, their prefix sums, and the upload
 template <class D> struct GodBatch {
@@ -770,6 +834,7 @@ void k_mkflux(const vdn_multifab *s, vdn_multifab **sedge, vdn_multifab **flux, 
               const vdn_multifab *force, const vdn_multifab *mac_rhs, const double *dx, double dt,
               const vdn_bc_tower *bct, bool is_vel, const int *is_cons) {
   Prof prof_("mkflux");
+  god_xcd_init();
   if (ctx().prm.dm == 2) { k2_mkflux(s, sedge, flux, umac, force, mac_rhs, dx, dt, bct, is_vel, is_cons); return; }
   const int ncomp = s->nc;
   REQUIRE(ncomp <= 3, "mkflux: at most 3 components per call (got %d)", ncomp);
@@ -853,16 +918,32 @@ void k_mkflux(const vdn_multifab *s, vdn_multifab **sedge, vdn_multifab **flux, 
       // measured at 256^3: D fused <3> 3.18 ms (61 spilled VGPRs) vs 3 x <1> 2.3 ms; D <2> 1.66 ms vs 2 x <1> 1.55 ms; B and C are faster fused
       static const int split_env = getenv("VDN_MK_SPLIT") ? atoi(getenv("VDN_MK_SPLIT")) : -1;   // bit 0: B, 1: C, 2: D per component
       const int split = split_env >= 0 ? split_env : (ncomp >= 2 ? 4 : 0);
-      #define MK_STAGE(K, ARGS, g, bit)                                                                               \
-        if ((split >> bit) & 1) { for (int c0 = 0; c0 < ncomp; c0++) hipLaunchKernelGGL(K<1>, g, blk, 0, st, ARGS(c0)); } \
-        else if (ncomp == 3) hipLaunchKernelGGL(K<3>, g, blk, 0, st, ARGS(0));                                        \
-        else if (ncomp == 2) hipLaunchKernelGGL(K<2>, g, blk, 0, st, ARGS(0));                                        \
-        else hipLaunchKernelGGL(K<1>, g, blk, 0, st, ARGS(0));
-      MK_STAGE(kk_mk_B_m, MK_ARGS_B, gg, 0)
-      MK_STAGE(kk_mk_C_m, MK_ARGS_C, gg, 1)
-      static const bool pf = getenv("VDN_GOD_PF") && atoi(getenv("VDN_GOD_PF")) != 0;
-      if (pf && ((split >> 2) & 1)) { for (int c0 = 0; c0 < ncomp; c0++) hipLaunchKernelGGL((kk_mk_D_m<1, true>), gf, blk, 0, st, MK_ARGS_D(c0)); }
-      else { MK_STAGE(kk_mk_D_m, MK_ARGS_D, gf, 2) }
+      #define MK_STAGE(K, BCF, ARGS, g, bit)                                                                               \
+        if ((split >> bit) & 1) { for (int c0 = 0; c0 < ncomp; c0++) hipLaunchKernelGGL((K<1, BCF>), g, blk, 0, st, ARGS(c0)); } \
+        else if (ncomp == 3) hipLaunchKernelGGL((K<3, BCF>), g, blk, 0, st, ARGS(0));                                        \
+        else if (ncomp == 2) hipLaunchKernelGGL((K<2, BCF>), g, blk, 0, st, ARGS(0));                                        \
+        else hipLaunchKernelGGL((K<1, BCF>), g, blk, 0, st, ARGS(0));
+      #define MK_STAGE_D(BCF)                                                                                              \
+        if ((split >> 2) & 1) { for (int c0 = 0; c0 < ncomp; c0++) hipLaunchKernelGGL((kk_mk_D_m<1, false, BCF>), gf, blk, 0, st, MK_ARGS_D(c0)); } \
+        else if (ncomp == 3) hipLaunchKernelGGL((kk_mk_D_m<3, false, BCF>), gf, blk, 0, st, MK_ARGS_D(0));                     \
+        else if (ncomp == 2) hipLaunchKernelGGL((kk_mk_D_m<2, false, BCF>), gf, blk, 0, st, MK_ARGS_D(0));                     \
+        else hipLaunchKernelGGL((kk_mk_D_m<1, false, BCF>), gf, blk, 0, st, MK_ARGS_D(0));
+      if (slab_bc()) {             // interior marches, then the face-centred code on the boundary slabs (see kk_slabs)
+        const MkPlain P{ s->fabs[ib], sl[0], sl[1], sl[2], um, vm, wm, force->fabs[ib], mac_rhs->fabs[ib], SI, SC,
+                         sedge[0]->fabs[ib], sedge[1]->fabs[ib], sedge[2]->fabs[ib], flux[0]->fabs[ib], flux[1]->fabs[ib], flux[2]->fabs[ib], A, umax };
+        const Slabs Sg = boundary_slabs(A, rg), Sf = boundary_slabs(A, rf);
+        MK_STAGE(kk_mk_B_m, false, MK_ARGS_B, gg, 0)
+        launch_slabs(Sg, MkBFix{ P }, st);
+        MK_STAGE(kk_mk_C_m, false, MK_ARGS_C, gg, 1)
+        launch_slabs(Sg, MkCFix{ P }, st);
+        MK_STAGE_D(false)
+        launch_slabs(Sf, MkDFix{ P }, st);
+      } else {
+        MK_STAGE(kk_mk_B_m, true, MK_ARGS_B, gg, 0)
+        MK_STAGE(kk_mk_C_m, true, MK_ARGS_C, gg, 1)
+        MK_STAGE_D(true)
+      }
+      #undef MK_STAGE_D
       #undef MK_STAGE
       #undef MK_ARGS_B
       #undef MK_ARGS_C
@@ -921,14 +1002,18 @@ template <int D> DEVI void vp_B_one(const GArgs &A, const FV &u, const FV &slp, 
     fv_at(UI, i, j, k, D * 3 + c) = out;
   }
 }
+struct VpPlain { FV u, sl0, sl1, sl2, force, UI, XC, um, vm, wm; GArgs A; const double *umax; };
+DEVI void vp_B_cell(const FV &u, const FV &sl0, const FV &sl1, const FV &sl2, const FV &force, const FV &UI, const GArgs &A, int i, int j, int k, double eps, int dmask = 7) {
+  if (dmask & 1) vp_B_one<0>(A, u, sl0, force, UI, i, j, k, eps);
+  if (dmask & 2) vp_B_one<1>(A, u, sl1, force, UI, i, j, k, eps);
+  if (dmask & 4) vp_B_one<2>(A, u, sl2, force, UI, i, j, k, eps);
+}
 __global__ void __launch_bounds__(256) kk_vp_B(FV u, FV sl0, FV sl1, FV sl2, FV force, FV UI, GArgs A, Range3 r, const double *umax) {
   THREAD_IJK(r)
   if (!in_range) return;
-  const double eps = eps_from(umax);
-  vp_B_one<0>(A, u, sl0, force, UI, i, j, k, eps);
-  vp_B_one<1>(A, u, sl1, force, UI, i, j, k, eps);
-  vp_B_one<2>(A, u, sl2, force, UI, i, j, k, eps);
+  vp_B_cell(u, sl0, sl1, sl2, force, UI, A, i, j, k, eps_from(umax));
 }
+struct VpBFix { VpPlain P; __device__ void operator()(int i, int j, int k, int dmask) const { vp_B_cell(P.u, P.sl0, P.sl1, P.sl2, P.force, P.UI, P.A, i, j, k, eps_from(P.umax), dmask); } };
 
 // stage C: component C on D-faces corrected by the third direction O = 3-C-D
 // (uimhyz = (C=0,D=1) velpred.f90:2466-2503, wimhxy = (C=2,D=0) 2189-2229, ...)
@@ -954,17 +1039,20 @@ template <int C, int D> DEVI void vp_C_one(const GArgs &A, const FV &u, const FV
   const double av = 0.5 * (L + R);
   fv_at(XC, i, j, k, xc_idx(C, D)) = (fabs(un) < eps) ? av : v;
 }
+DEVI void vp_C_cell(const FV &u, const FV &sl0, const FV &sl1, const FV &sl2, const FV &force, const FV &UI, const FV &XC, const GArgs &A, int i, int j, int k, double eps, int dmask = 7) {
+  if (dmask & 2) vp_C_one<0, 1>(A, u, sl1, force, UI, XC, i, j, k, eps);
+  if (dmask & 4) vp_C_one<0, 2>(A, u, sl2, force, UI, XC, i, j, k, eps);
+  if (dmask & 1) vp_C_one<1, 0>(A, u, sl0, force, UI, XC, i, j, k, eps);
+  if (dmask & 4) vp_C_one<1, 2>(A, u, sl2, force, UI, XC, i, j, k, eps);
+  if (dmask & 1) vp_C_one<2, 0>(A, u, sl0, force, UI, XC, i, j, k, eps);
+  if (dmask & 2) vp_C_one<2, 1>(A, u, sl1, force, UI, XC, i, j, k, eps);
+}
 __global__ void __launch_bounds__(256) kk_vp_C(FV u, FV sl0, FV sl1, FV sl2, FV force, FV UI, FV XC, GArgs A, Range3 r, const double *umax) {
   THREAD_IJK(r)
   if (!in_range) return;
-  const double eps = eps_from(umax);
-  vp_C_one<0, 1>(A, u, sl1, force, UI, XC, i, j, k, eps);
-  vp_C_one<0, 2>(A, u, sl2, force, UI, XC, i, j, k, eps);
-  vp_C_one<1, 0>(A, u, sl0, force, UI, XC, i, j, k, eps);
-  vp_C_one<1, 2>(A, u, sl2, force, UI, XC, i, j, k, eps);
-  vp_C_one<2, 0>(A, u, sl0, force, UI, XC, i, j, k, eps);
-  vp_C_one<2, 1>(A, u, sl1, force, UI, XC, i, j, k, eps);
+  vp_C_cell(u, sl0, sl1, sl2, force, UI, XC, A, i, j, k, eps_from(umax));
 }
+struct VpCFix { VpPlain P; __device__ void operator()(int i, int j, int k, int dmask) const { vp_C_cell(P.u, P.sl0, P.sl1, P.sl2, P.force, P.UI, P.XC, P.A, i, j, k, eps_from(P.umax), dmask); } };
 
 // stage D: the MAC velocity on valid D-faces (velpred.f90:2616-2660, 2666-2710, 2372-2416)
 template <int D> DEVI void vp_D_one(const GArgs &A, const FV &u, const FV &slp, const FV &force, const FV &UI, const FV &XC, const FV &umac,
@@ -1000,14 +1088,18 @@ template <int D> DEVI void vp_D_one(const GArgs &A, const FV &u, const FV &slp, 
   }
   fv_at(umac, i, j, k) = v;
 }
+DEVI void vp_D_cell(const FV &u, const FV &sl0, const FV &sl1, const FV &sl2, const FV &force, const FV &UI, const FV &XC, const FV &um, const FV &vm, const FV &wm,
+                    const GArgs &A, int i, int j, int k, double eps, int dmask = 7) {
+  if (dmask & 1) vp_D_one<0>(A, u, sl0, force, UI, XC, um, i, j, k, eps);
+  if (dmask & 2) vp_D_one<1>(A, u, sl1, force, UI, XC, vm, i, j, k, eps);
+  if (dmask & 4) vp_D_one<2>(A, u, sl2, force, UI, XC, wm, i, j, k, eps);
+}
 __global__ void __launch_bounds__(256) kk_vp_D(FV u, FV sl0, FV sl1, FV sl2, FV force, FV UI, FV XC, FV um, FV vm, FV wm, GArgs A, Range3 r, const double *umax) {
   THREAD_IJK(r)
   if (!in_range) return;
-  const double eps = eps_from(umax);
-  vp_D_one<0>(A, u, sl0, force, UI, XC, um, i, j, k, eps);
-  vp_D_one<1>(A, u, sl1, force, UI, XC, vm, i, j, k, eps);
-  vp_D_one<2>(A, u, sl2, force, UI, XC, wm, i, j, k, eps);
+  vp_D_cell(u, sl0, sl1, sl2, force, UI, XC, um, vm, wm, A, i, j, k, eps_from(umax));
 }
+struct VpDFix { VpPlain P; __device__ void operator()(int i, int j, int k, int dmask) const { vp_D_cell(P.u, P.sl0, P.sl1, P.sl2, P.force, P.UI, P.XC, P.um, P.vm, P.wm, P.A, i, j, k, eps_from(P.umax), dmask); } };
 
 // ---- velpred, cell-centred k-marching form -------------------------------------------------------------------------
 // predictor bases of all three velocity components in a cell along D (vp_pair split by side, no boundary rule)
@@ -1057,7 +1149,7 @@ template <int D> DEVI void vp_B_emit(const FV &UI, int i, int j, int k, const do
       uc[c] = fv_get(u, ic, jc, kc, c); s0[c] = fv_get(sl0, ic, jc, kc, c); s1[c] = fv_get(sl1, ic, jc, kc, c); s2[c] = fv_get(sl2, ic, jc, kc, c); \
     }
 
-template <bool R> __device__ __forceinline__ void vp_B_m_body(typename Prm<FV, R>::type u, typename Prm<FV, R>::type sl0, typename Prm<FV, R>::type sl1, typename Prm<FV, R>::type sl2, typename Prm<FV, R>::type force, typename Prm<FV, R>::type UI, typename Prm<GArgs, R>::type A, typename Prm<Range3, R>::type r, int klen, const double *umax, const int BX, const int BY, const int BZ) {
+template <bool R, bool BC> __device__ __forceinline__ void vp_B_m_body(typename Prm<FV, R>::type u, typename Prm<FV, R>::type sl0, typename Prm<FV, R>::type sl1, typename Prm<FV, R>::type sl2, typename Prm<FV, R>::type force, typename Prm<FV, R>::type UI, typename Prm<GArgs, R>::type A, typename Prm<Range3, R>::type r, int klen, const double *umax, const int BX, const int BY, const int BZ) {
   __shared__ double ly[2][3][TNY][64];
   MARCH_SETUP(r)
   const double eps = eps_from(umax);
@@ -1085,7 +1177,7 @@ template <bool R> __device__ __forceinline__ void vp_B_m_body(typename Prm<FV, R
       Lzc[c] = Lz[c]; Lz[c] = Lb[2][c];
     }
     if (emit) {
-      if (edge) {
+      if (BC && edge) {
         #pragma unroll
         for (int c = 0; c < 3; c++) {
           vp_face_bc<0>(A, u, c, c == 0, true, i, j, k, uc[c], Lx[c], Rb[0][c]);
@@ -1099,8 +1191,9 @@ template <bool R> __device__ __forceinline__ void vp_B_m_body(typename Prm<FV, R
     }
   }
 }
-__global__ void __launch_bounds__(64 * TNY) kk_vp_B_m(FV u, FV sl0, FV sl1, FV sl2, FV force, FV UI, GArgs A, Range3 r, int klen, const double *umax) {
-  vp_B_m_body<false>(u, sl0, sl1, sl2, force, UI, A, r, klen, umax, (int)blockIdx.x, (int)blockIdx.y, (int)blockIdx.z);
+template <bool BC> __global__ void __launch_bounds__(64 * TNY) kk_vp_B_m(FV u, FV sl0, FV sl1, FV sl2, FV force, FV UI, GArgs A, Range3 r, int klen, const double *umax) {
+  int bx_, by_, bz_; xcd_remap(bx_, by_, bz_);
+  vp_B_m_body<false, BC>(u, sl0, sl1, sl2, force, UI, A, r, klen, umax, bx_, by_, bz_);
 }
 
 
@@ -1110,7 +1203,7 @@ DEVI double vp_up(double un, double L, double R, double eps) {
   const double av = 0.5 * (L + R);
   return (fabs(un) < eps) ? av : v;
 }
-template <bool R> __device__ __forceinline__ void vp_C_m_body(typename Prm<FV, R>::type u, typename Prm<FV, R>::type sl0, typename Prm<FV, R>::type sl1, typename Prm<FV, R>::type sl2, typename Prm<FV, R>::type force, typename Prm<FV, R>::type UI, typename Prm<FV, R>::type XC, typename Prm<GArgs, R>::type A, typename Prm<Range3, R>::type r, int klen, const double *umax, const int BX, const int BY, const int BZ) {
+template <bool R, bool BC> __device__ __forceinline__ void vp_C_m_body(typename Prm<FV, R>::type u, typename Prm<FV, R>::type sl0, typename Prm<FV, R>::type sl1, typename Prm<FV, R>::type sl2, typename Prm<FV, R>::type force, typename Prm<FV, R>::type UI, typename Prm<FV, R>::type XC, typename Prm<GArgs, R>::type A, typename Prm<Range3, R>::type r, int klen, const double *umax, const int BX, const int BY, const int BZ) {
   __shared__ double ly[2][2][TNY][64];
   MARCH_SETUP(r)
   const double eps = eps_from(umax);
@@ -1135,7 +1228,7 @@ template <bool R> __device__ __forceinline__ void vp_C_m_body(typename Prm<FV, R
     vp_bases<0>(A, uc, s0, ft, Lb[0], Rb[0]);
     vp_bases<1>(A, uc, s1, ft, Lb[1], Rb[1]);
     vp_bases<2>(A, uc, s2, ft, Lb[2], Rb[2]);
-    if (edge) {
+    if (BC && edge) {
       #pragma unroll
       for (int c = 0; c < 3; c++) { vp_premod<0>(A, u, c, ic, jc, kc, Lb[0][c], Rb[0][c]); vp_premod<1>(A, u, c, ic, jc, kc, Lb[1][c], Rb[1][c]); vp_premod<2>(A, u, c, ic, jc, kc, Lb[2][c], Rb[2][c]); }
     }
@@ -1163,7 +1256,7 @@ template <bool R> __device__ __forceinline__ void vp_C_m_body(typename Prm<FV, R
     L[2][0] = Lz[0]; L[2][1] = Lz[1];
     Lz[0] = VL[2][0]; Lz[1] = VL[2][1];
     if (emit) {
-      if (edge) {
+      if (BC && edge) {
         vp_face_bc<0>(A, u, 1, false, false, i, j, k, uc[1], L[0][0], VR[0][0]); vp_face_bc<0>(A, u, 2, false, false, i, j, k, uc[2], L[0][1], VR[0][1]);
         vp_face_bc<1>(A, u, 0, false, false, i, j, k, uc[0], L[1][0], VR[1][0]); vp_face_bc<1>(A, u, 2, false, false, i, j, k, uc[2], L[1][1], VR[1][1]);
         vp_face_bc<2>(A, u, 0, false, false, i, j, k, uc[0], L[2][0], VR[2][0]); vp_face_bc<2>(A, u, 1, false, false, i, j, k, uc[1], L[2][1], VR[2][1]);
@@ -1175,8 +1268,9 @@ template <bool R> __device__ __forceinline__ void vp_C_m_body(typename Prm<FV, R
     }
   }
 }
-__global__ void __launch_bounds__(64 * TNY) kk_vp_C_m(FV u, FV sl0, FV sl1, FV sl2, FV force, FV UI, FV XC, GArgs A, Range3 r, int klen, const double *umax) {
-  vp_C_m_body<false>(u, sl0, sl1, sl2, force, UI, XC, A, r, klen, umax, (int)blockIdx.x, (int)blockIdx.y, (int)blockIdx.z);
+template <bool BC> __global__ void __launch_bounds__(64 * TNY) kk_vp_C_m(FV u, FV sl0, FV sl1, FV sl2, FV force, FV UI, FV XC, GArgs A, Range3 r, int klen, const double *umax) {
+  int bx_, by_, bz_; xcd_remap(bx_, by_, bz_);
+  vp_C_m_body<false, BC>(u, sl0, sl1, sl2, force, UI, XC, A, r, klen, umax, bx_, by_, bz_);
 }
 
 
@@ -1197,7 +1291,7 @@ template <int D> DEVI double vp_D_face(const GArgs &A, const FV &u, int i, int j
   }
   return v;
 }
-template <bool R> __device__ __forceinline__ void vp_D_m_body(typename Prm<FV, R>::type u, typename Prm<FV, R>::type sl0, typename Prm<FV, R>::type sl1, typename Prm<FV, R>::type sl2, typename Prm<FV, R>::type force, typename Prm<FV, R>::type UI, typename Prm<FV, R>::type XC, typename Prm<FV, R>::type um, typename Prm<FV, R>::type vm, typename Prm<FV, R>::type wm, typename Prm<GArgs, R>::type A, typename Prm<Range3, R>::type r, int klen, const double *umax, const int BX, const int BY, const int BZ) {
+template <bool R, bool BC> __device__ __forceinline__ void vp_D_m_body(typename Prm<FV, R>::type u, typename Prm<FV, R>::type sl0, typename Prm<FV, R>::type sl1, typename Prm<FV, R>::type sl2, typename Prm<FV, R>::type force, typename Prm<FV, R>::type UI, typename Prm<FV, R>::type XC, typename Prm<FV, R>::type um, typename Prm<FV, R>::type vm, typename Prm<FV, R>::type wm, typename Prm<GArgs, R>::type A, typename Prm<Range3, R>::type r, int klen, const double *umax, const int BX, const int BY, const int BZ) {
   __shared__ double ly[2][TNY][64];
   MARCH_SETUP(r)
   const double eps = eps_from(umax);
@@ -1229,7 +1323,7 @@ template <bool R> __device__ __forceinline__ void vp_D_m_body(typename Prm<FV, R
         if (A.use_minion) { Lb[Dd] = Lb[Dd] + ft[Dd]; Rb[Dd] = Rb[Dd] + ft[Dd]; } }
     NBASE(0) NBASE(1) NBASE(2)
     #undef NBASE
-    if (edge) { vp_premod<0>(A, u, 0, ic, jc, kc, Lb[0], Rb[0]); vp_premod<1>(A, u, 1, ic, jc, kc, Lb[1], Rb[1]); vp_premod<2>(A, u, 2, ic, jc, kc, Lb[2], Rb[2]); }
+    if (BC && edge) { vp_premod<0>(A, u, 0, ic, jc, kc, Lb[0], Rb[0]); vp_premod<1>(A, u, 1, ic, jc, kc, Lb[1], Rb[1]); vp_premod<2>(A, u, 2, ic, jc, kc, Lb[2], Rb[2]); }
     double VL[3], VR[3];
     {   // D = 0: T1 = 1 with XC(0,1) = n0,  T2 = 2 with XC(0,2) = n1
       const double a1 = (dt4 / A.dx[1]) * g[1] * (x1[0] - x0[0]);
@@ -1259,14 +1353,15 @@ template <bool R> __device__ __forceinline__ void vp_D_m_body(typename Prm<FV, R
     const double Lzc = Lz;
     Lz = VL[2];
     if (emit) {
-      if (vy && vz) fv_at(um, i, j, k) = vp_D_face<0>(A, u, i, j, k, uc[0], Lx, VR[0], eps, edge);
-      if (vx && vz) fv_at(vm, i, j, k) = vp_D_face<1>(A, u, i, j, k, uc[1], Ly, VR[1], eps, edge);
-      if (vx && vy) fv_at(wm, i, j, k) = vp_D_face<2>(A, u, i, j, k, uc[2], Lzc, VR[2], eps, edge);
+      if (vy && vz) fv_at(um, i, j, k) = vp_D_face<0>(A, u, i, j, k, uc[0], Lx, VR[0], eps, BC && edge);
+      if (vx && vz) fv_at(vm, i, j, k) = vp_D_face<1>(A, u, i, j, k, uc[1], Ly, VR[1], eps, BC && edge);
+      if (vx && vy) fv_at(wm, i, j, k) = vp_D_face<2>(A, u, i, j, k, uc[2], Lzc, VR[2], eps, BC && edge);
     }
   }
 }
-__global__ void __launch_bounds__(64 * TNY) kk_vp_D_m(FV u, FV sl0, FV sl1, FV sl2, FV force, FV UI, FV XC, FV um, FV vm, FV wm, GArgs A, Range3 r, int klen, const double *umax) {
-  vp_D_m_body<false>(u, sl0, sl1, sl2, force, UI, XC, um, vm, wm, A, r, klen, umax, (int)blockIdx.x, (int)blockIdx.y, (int)blockIdx.z);
+template <bool BC> __global__ void __launch_bounds__(64 * TNY) kk_vp_D_m(FV u, FV sl0, FV sl1, FV sl2, FV force, FV UI, FV XC, FV um, FV vm, FV wm, GArgs A, Range3 r, int klen, const double *umax) {
+  int bx_, by_, bz_; xcd_remap(bx_, by_, bz_);
+  vp_D_m_body<false, BC>(u, sl0, sl1, sl2, force, UI, XC, um, vm, wm, A, r, klen, umax, bx_, by_, bz_);
 }
 
 
@@ -1490,19 +1585,20 @@ static void k2_mkflux(const vdn_multifab *s, vdn_multifab **sedge, vdn_multifab 
 
 __global__ void __launch_bounds__(64 * TNY) kk_vp_B_mb(const VpD *descs, const int *start, int nbox) {
   BATCH_LOCATE(VpD, gg)
-  vp_B_m_body<true>(q.s, q.sl0, q.sl1, q.sl2, q.force, q.UI, q.A, q.rg, q.klg, q.umax, BX, BY, BZ);
+  vp_B_m_body<true, true>(q.s, q.sl0, q.sl1, q.sl2, q.force, q.UI, q.A, q.rg, q.klg, q.umax, BX, BY, BZ);
 }
 __global__ void __launch_bounds__(64 * TNY) kk_vp_C_mb(const VpD *descs, const int *start, int nbox) {
   BATCH_LOCATE(VpD, gg)
-  vp_C_m_body<true>(q.s, q.sl0, q.sl1, q.sl2, q.force, q.UI, q.XC, q.A, q.rg, q.klg, q.umax, BX, BY, BZ);
+  vp_C_m_body<true, true>(q.s, q.sl0, q.sl1, q.sl2, q.force, q.UI, q.XC, q.A, q.rg, q.klg, q.umax, BX, BY, BZ);
 }
 __global__ void __launch_bounds__(64 * TNY) kk_vp_D_mb(const VpD *descs, const int *start, int nbox) {
   BATCH_LOCATE(VpD, gf)
-  vp_D_m_body<true>(q.s, q.sl0, q.sl1, q.sl2, q.force, q.UI, q.XC, q.um, q.vm, q.wm, q.A, q.rf, q.klf, q.umax, BX, BY, BZ);
+  vp_D_m_body<true, true>(q.s, q.sl0, q.sl1, q.sl2, q.force, q.UI, q.XC, q.um, q.vm, q.wm, q.A, q.rf, q.klf, q.umax, BX, BY, BZ);
 }
 void k_velpred(const vdn_multifab *u, vdn_multifab **umac, const vdn_multifab *force, const double *dx, double dt,
                const vdn_bc_tower *bct) {
   Prof prof_("velpred");
+  god_xcd_init();
   if (ctx().prm.dm == 2) { k2_velpred(u, umac, force, dx, dt, bct); return; }
   REQUIRE(u->nc == 3 && u->ng >= 3 && force->ng >= 1 && umac[0]->ng >= 1, "velpred: operand shapes");
   hipStream_t st = ctx().stream;
@@ -1563,10 +1659,22 @@ void k_velpred(const vdn_multifab *u, vdn_multifab **umac, const vdn_multifab *f
     } else {
       int klg, klf;
       const dim3 gg = march_grid(rg, klg), gf = march_grid(rf, klf), blk(64, TNY, 1);
-      hipLaunchKernelGGL(kk_vp_B_m, gg, blk, 0, st, u->fabs[ib], sl[0], sl[1], sl[2], force->fabs[ib], UI, A, rg, klg, umax);
-      hipLaunchKernelGGL(kk_vp_C_m, gg, blk, 0, st, u->fabs[ib], sl[0], sl[1], sl[2], force->fabs[ib], UI, XC, A, rg, klg, umax);
-      hipLaunchKernelGGL(kk_vp_D_m, gf, blk, 0, st, u->fabs[ib], sl[0], sl[1], sl[2], force->fabs[ib], UI, XC,
+      if (slab_bc()) {             // interior marches, then the face-centred code on the boundary slabs (see kk_slabs)
+        const VpPlain P{ u->fabs[ib], sl[0], sl[1], sl[2], force->fabs[ib], UI, XC, umac[0]->fabs[ib], umac[1]->fabs[ib], umac[2]->fabs[ib], A, umax };
+        const Slabs Sg = boundary_slabs(A, rg), Sf = boundary_slabs(A, rf);
+        hipLaunchKernelGGL(kk_vp_B_m<false>, gg, blk, 0, st, u->fabs[ib], sl[0], sl[1], sl[2], force->fabs[ib], UI, A, rg, klg, umax);
+        launch_slabs(Sg, VpBFix{ P }, st);
+        hipLaunchKernelGGL(kk_vp_C_m<false>, gg, blk, 0, st, u->fabs[ib], sl[0], sl[1], sl[2], force->fabs[ib], UI, XC, A, rg, klg, umax);
+        launch_slabs(Sg, VpCFix{ P }, st);
+        hipLaunchKernelGGL(kk_vp_D_m<false>, gf, blk, 0, st, u->fabs[ib], sl[0], sl[1], sl[2], force->fabs[ib], UI, XC,
+                           umac[0]->fabs[ib], umac[1]->fabs[ib], umac[2]->fabs[ib], A, rf, klf, umax);
+        launch_slabs(Sf, VpDFix{ P }, st);
+      } else {
+      hipLaunchKernelGGL(kk_vp_B_m<true>, gg, blk, 0, st, u->fabs[ib], sl[0], sl[1], sl[2], force->fabs[ib], UI, A, rg, klg, umax);
+      hipLaunchKernelGGL(kk_vp_C_m<true>, gg, blk, 0, st, u->fabs[ib], sl[0], sl[1], sl[2], force->fabs[ib], UI, XC, A, rg, klg, umax);
+      hipLaunchKernelGGL(kk_vp_D_m<true>, gf, blk, 0, st, u->fabs[ib], sl[0], sl[1], sl[2], force->fabs[ib], UI, XC,
                          umac[0]->fabs[ib], umac[1]->fabs[ib], umac[2]->fabs[ib], A, rf, klf, umax);
+      }
     }
     arena_release(mark);
   }

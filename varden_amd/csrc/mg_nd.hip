@@ -196,12 +196,22 @@ __global__ void __launch_bounds__(256) kk_nd_march(NLev L, const double *__restr
 // two nodes (2t, 2t+1) of a row: every access is an aligned 16-byte pair, the columns 2t-1 / 2t+2 come from the neighbouring lanes
 // (DPP), so a node costs 3.5 memory instructions and half the lane exchanges.  Same arithmetic per node (nd_stencil), same bits.
 DEVI double2 ld2(const double *p) { return *reinterpret_cast<const double2 *>(p); }
+// Stores and loads share one in-order counter (vmcnt) on gfx9: a wave that waits for a load also waits for every OLDER store, and when
+// the number of stores in flight is not known at compile time (a store inside a divergent branch) the compiler waits for ALL of them --
+// `s_waitcnt vmcnt(0)` at the loop latch, i.e. the full store round trip exposed once per plane.  Hence: exactly ONE store instruction
+// per plane, executed by every lane (lanes that own no node write a 16-byte slot of a scratch line instead), issued BEFORE the loads
+// of the next plane, so that the store's latency hides under theirs.
+__device__ double g_nd_sink[128];
+__device__ int g_nd_dbg = 0;      // VDN_ND_DBG (probe only): 1 = no stencil arithmetic, 2 = no loads inside the march
 template <int MODE, int ROWS>
 __global__ void __launch_bounds__(64 * ROWS) kk_nd_march_pair(NLev L, const double *__restrict__ phi, double *__restrict__ out, double omega, int kchunk, double *nrm) {
   const int lane = threadIdx.x;
-  const int ia = 2 * ((int)blockIdx.x * 62 + lane - 1);                 // nodes ia, ia + 1; lanes 0 and 63 only feed their neighbours
-  const int j = blockIdx.y * blockDim.y + threadIdx.y;
-  const int k0 = blockIdx.z * kchunk, k1 = min(k0 + kchunk - 1, L.n[2]);
+  int bx, by, bz; xcd_tile(bx, by, bz);
+  // (measured and rejected: all 64 lanes owning a pair -- whole 128-byte lines per wave row -- with the two outside columns from an extra
+  // two-lane load per row: 0.154 -> 0.202 ms per sweep at 257^3)
+  const int ia = 2 * (bx * 62 + lane - 1);                              // nodes ia, ia + 1; lanes 0 and 63 only feed their neighbours
+  const int j = by * blockDim.y + threadIdx.y;
+  const int k0 = bz * kchunk, k1 = min(k0 + kchunk - 1, L.n[2]);
   const bool own = lane >= 1 && lane <= 62 && j <= L.n[1];
   const bool actA = own && ia <= L.n[0], actB = own && ia + 1 <= L.n[0];
   const int iac = min(ia, L.PX - 18), jc = min(j, L.n[1]);                // load address kept inside the (zero-padded) row
@@ -209,6 +219,10 @@ __global__ void __launch_bounds__(64 * ROWS) kk_nd_march_pair(NLev L, const doub
   if (k0 <= k1) {          // uniform over the workgroup
     const long sy = L.PX, sz = (long)L.PX * L.PY;
     long c = nidx(L, iac, jc, k0);
+    // a lane with node A writes its pair (node B of the last pair of a row may be the ghost node n+1: it gets its old value back, resp. a
+    // zero residual); the other lanes write to the sink.  One pointer, advanced by the plane stride (0 for the sink).
+    double *op = actA ? out + c : g_nd_sink + 2 * lane;       // (rows beyond the level, pairs beyond its width)
+    const long ostep = actA ? sz : 0;
     // q[plane][row][col]: col 0..3 = nodes ia-1 .. ia+2;  sg[dk][dj][col]: col 0..2 = cells ia-1 .. ia+1
     double q[3][3][4], sg[2][2][3];
     #define LOADP(pl, off) { _Pragma("unroll") for (int b = 0; b < 3; b++) { const double2 v = ld2(phi + (off) + (b - 1) * sy); q[pl][b][1] = v.x; q[pl][b][2] = v.y; } }
@@ -216,31 +230,15 @@ __global__ void __launch_bounds__(64 * ROWS) kk_nd_march_pair(NLev L, const doub
     #define LOADS(dk, off) { _Pragma("unroll") for (int dj = 0; dj < 2; dj++) { const double2 v = ld2(L.sig + (off) + (dj - 1) * sy); sg[dk][dj][1] = v.x; sg[dk][dj][2] = v.y; } }
     #define EXCHS(dk) { _Pragma("unroll") for (int dj = 0; dj < 2; dj++) sg[dk][dj][0] = lane_prev(sg[dk][dj][2]); }
     LOADP(0, c - sz) LOADP(1, c) LOADS(0, c - sz)
-    // one plane ahead: the loads of plane k + 2 (phi), k + 1 (sigma, rhs) are in flight while plane k is being computed
-    double2 qn[3], sn[2], rhsn;
-    #pragma unroll
-    for (int b = 0; b < 3; b++) qn[b] = ld2(phi + c + sz + (b - 1) * sy);
-    #pragma unroll
-    for (int dj = 0; dj < 2; dj++) sn[dj] = ld2(L.sig + c + (dj - 1) * sy);
-    rhsn = ld2(L.b + c);
     EXCHP(0) EXCHP(1) EXCHS(0)
     const bool dirj = (j == 0 && L.dirlo[1]) || (j == L.n[1] && L.dirhi[1]);
     const bool dirA_ij = dirj || (ia == 0 && L.dirlo[0]) || (ia == L.n[0] && L.dirhi[0]);
     const bool dirB_ij = dirj || (ia + 1 == L.n[0] && L.dirhi[0]);
     const NdW W = nd_weights(L.f);
-    for (int k = k0; k <= k1; k++, c += sz) {
-      #pragma unroll
-      for (int b = 0; b < 3; b++) { q[2][b][1] = qn[b].x; q[2][b][2] = qn[b].y; }
-      #pragma unroll
-      for (int dj = 0; dj < 2; dj++) { sg[1][dj][1] = sn[dj].x; sg[1][dj][2] = sn[dj].y; }
-      const double2 rhs = rhsn;
-      if (k < k1) {
-        #pragma unroll
-        for (int b = 0; b < 3; b++) qn[b] = ld2(phi + c + 2 * sz + (b - 1) * sy);
-        #pragma unroll
-        for (int dj = 0; dj < 2; dj++) sn[dj] = ld2(L.sig + c + sz + (dj - 1) * sy);
-        rhsn = ld2(L.b + c + sz);
-      }
+    const int dbg = g_nd_dbg;
+    for (int k = k0; k <= k1; k++, c += sz, op += ostep) {
+      double2 rhs = make_double2(1.0, 1.0);
+      if (!(dbg & 2)) { LOADP(2, c + sz) LOADS(1, c) rhs = ld2(L.b + c); }
       EXCHP(2) EXCHS(1)
       const bool dirk = (k == 0 && L.dirlo[2]) || (k == L.n[2] && L.dirhi[2]);
       double pa[3][3][3], pb[3][3][3], sa[2][2][2], sb[2][2][2];
@@ -257,22 +255,24 @@ __global__ void __launch_bounds__(64 * ROWS) kk_nd_march_pair(NLev L, const doub
           #pragma unroll
           for (int a = 0; a < 2; a++) { sa[dk][dj][a] = sg[dk][dj][a]; sb[dk][dj][a] = sg[dk][dj][a + 1]; }
       double KpA, dgA, KpB, dgB;
+      if (dbg & 1) { KpA = pa[2][0][1] + pa[2][1][1] + pa[2][2][1] + sa[1][0][1] + sa[1][1][1]; KpB = pb[2][0][1] + pb[2][1][1] + pb[2][2][1] + sb[1][0][1] + sb[1][1][1]; dgA = dgB = 1.0; }
+      else {
       nd_stencil(W, pa, sa, KpA, dgA);
       nd_stencil(W, pb, sb, KpB, dgB);
+      }
       const double p0A = q[1][1][1], p0B = q[1][1][2];
       double2 o;
       if (MODE == 0) {
         o.x = p0A; o.y = p0B;
         if (!(dirA_ij || dirk) && dgA != 0.0) o.x = p0A + omega * ((rhs.x - KpA) / dgA);
-        if (!(dirB_ij || dirk) && dgB != 0.0) o.y = p0B + omega * ((rhs.y - KpB) / dgB);
+        if (actB && !(dirB_ij || dirk) && dgB != 0.0) o.y = p0B + omega * ((rhs.y - KpB) / dgB);
       } else {
         o.x = (dirA_ij || dirk) ? 0.0 : rhs.x - KpA;
-        o.y = (dirB_ij || dirk) ? 0.0 : rhs.y - KpB;
+        o.y = (!actB || dirB_ij || dirk) ? 0.0 : rhs.y - KpB;
         if (actA) rmax = nmax(rmax, fabs(o.x));
         if (actB) rmax = nmax(rmax, fabs(o.y));
       }
-      if (actB) *reinterpret_cast<double2 *>(out + c) = o;
-      else if (actA) out[c] = o.x;
+      *reinterpret_cast<double2 *>(op) = o;
       #pragma unroll
       for (int b = 0; b < 3; b++)
         #pragma unroll
@@ -926,6 +926,21 @@ int nd_solve(vdn_multifab *rh, vdn_multifab *phi, const vdn_multifab *coeffs, co
     hipLaunchKernelGGL(kk_nd_load, ng3(L0.n[0] + 1, L0.n[1] + 1, std::min(L0.n[2] + 1, 16)), NBLK, 0, st, L0, rh->fabs[b], phi->fabs[b], bx.lo[0], bx.lo[1], bx.lo[2], M.d_nrm);
   }
   comm_allreduce_max_dev(M.d_nrm, 1);
+  {   // VDN_ND_BENCH=n (probe): time n Jacobi sweeps of the finest level here, print the mean, then solve as usual (the sweeps only improve phi)
+    static const int nbench = getenv("VDN_ND_BENCH") ? atoi(getenv("VDN_ND_BENCH")) : 0;
+    if (nbench > 0) {
+      if (getenv("VDN_ND_DBG")) { const int v = atoi(getenv("VDN_ND_DBG")); HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(g_nd_dbg), &v, sizeof(int))); }
+      hipEvent_t e0, e1; HIPCHK(hipEventCreate(&e0)); HIPCHK(hipEventCreate(&e1));
+      nd_jacobi_d(M.dlev[0], 2);
+      HIPCHK(hipEventRecord(e0, st));
+      nd_jacobi_d(M.dlev[0], nbench & ~1);
+      HIPCHK(hipEventRecord(e1, st)); HIPCHK(hipEventSynchronize(e1));
+      float ms = 0; HIPCHK(hipEventElapsedTime(&ms, e0, e1));
+      fprintf(stderr, "VDN_ND_BENCH: %d x %d x %d nodes, %.5f ms per Jacobi sweep\n", M.dlev[0].boxes[0].L.n[0] + 1, M.dlev[0].boxes[0].L.n[1] + 1, M.dlev[0].boxes[0].L.n[2] + 1, ms / (nbench & ~1));
+      const int z = 0; HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(g_nd_dbg), &z, sizeof(int)));
+      HIPCHK(hipEventDestroy(e0)); HIPCHK(hipEventDestroy(e1));
+    }
+  }
   const bool single = (M.dlev.size() == 1 && M.tail.empty());
   const bool fixed_cycles = max_iter < 0;     // exactly -max_iter V-cycles, no norms, no convergence test (composite coarse correction)
   const double bnorm = fixed_cycles ? 1.0 : nd_read(M.d_nrm);
