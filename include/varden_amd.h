@@ -218,6 +218,9 @@ int vdn_multifab_copy_layouts(vdn_multifab *dst, int dcomp, const vdn_multifab *
  * s: the state of level `lev1` (1-based, as in tag_boxes) -- component 0 is tagged; the boxes of level lev1+1 are returned in that
  * level's index space (*nboxes_out = 0: no cell tagged, "new_grid = .false.").  nest: cells of level lev1 kept between the new
  * level and the edge of level lev1 (proper nesting).  Collective: every rank passes its part of the level and gets the same boxes. */
+/* tag_boxes(tagboxes, mf, dx, lev) of src/tag_boxes.f90:17-216 alone: one byte per cell of the level's domain (x fastest), 1 = tagged;
+ * lev1 is the 1-based level the thresholds are chosen by (tag_boxes.f90:65-94, 142-178) */
+int vdn_tag_boxes(const vdn_multifab *s, int lev1, unsigned char *tags_host);
 int vdn_make_new_grids(const vdn_multifab *s, int lev1, int buf_wid, int nest, double min_eff, int min_width, int blocking,
                        int max_grid_size, int maxboxes, vdn_box *boxes_out, int *nboxes_out, long *ntagged);
 

@@ -220,6 +220,11 @@ void vo2_advance_timestep(vo_state *S, const double dx[2], double dt, const vo_b
 void vo2_initdata(vo_fab *u, vo_fab *s, const double dx[2], int prob_type);
 
 
+/* regridding (vo_amr.c): tag_boxes (src/tag_boxes.f90:128-216), fillpatch and ml_nodal_prolongation as src/regrid.f90:311-327 calls them */
+int  vo_tag_boxes(const vo_fab *s, int lev, int prob_type, unsigned char *tags);
+void vo_fillpatch(vo_fab *fine, const vo_fab *crse, int icomp, int nc);
+void vo_nodal_prolongation(vo_fab *fine, const vo_fab *crse);
+
 /* the nodal 27-point operator on gathered values (see vo_hgproject.c) */
 void vo_nd_stencil(const double f[3], const double p[3][3][3], const double sg[2][2][2], double *Kp, double *diag);
 

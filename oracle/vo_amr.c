@@ -90,6 +90,64 @@ void vo_fill_ghost_cells(vo_fab *fine, const vo_fab *crse, int icomp, int nc)
     VF(fine, i, j, k, c) = v;
   }
 }
+/* ---- regridding -------------------------------------------------------------------------------------------
+ * tag_boxes_3d (src/tag_boxes.f90:128-216; tag_boxes_2d :41-127 has the same thresholds): a cell of the level is tagged where the first
+ * component of the state exceeds 1.01 (level 1), 1.1 (level 2), 1.5 (deeper levels) for prob_type 1 and 2, or lies strictly between
+ * 1.2 and 1.8 for prob_type 3 (all levels).  tags: one byte per VALID cell of the fab, x fastest.  Returns -1 for any other prob_type
+ * (bl_error('Unsupported prob_type'), :212). */
+int vo_tag_boxes(const vo_fab *s, int lev, int prob_type, unsigned char *tags)
+{
+  const int nx = s->hi[0] - s->lo[0] + 1, ny = s->hi[1] - s->lo[1] + 1;
+  if (!(prob_type == 1 || prob_type == 2 || prob_type == 3)) return -1;
+  for (int k = s->lo[2]; k <= s->hi[2]; k++) for (int j = s->lo[1]; j <= s->hi[1]; j++) for (int i = s->lo[0]; i <= s->hi[0]; i++) {
+    const double v = VF(s, i, j, k, 0);
+    int t = 0;                                                  /* tagbox = .false. (:140) */
+    if (prob_type == 1 || prob_type == 2) {
+      if (lev == 1) t = v > 1.01;                               /* :147-155 */
+      else if (lev == 2) t = v > 1.1;                           /* :158-166 */
+      else t = v > 1.5;                                         /* :169-177 */
+    } else t = (v > 1.2 && v < 1.8);                            /* :181-210, the same test on every level */
+    tags[(size_t)(i - s->lo[0]) + (size_t)nx * ((size_t)(j - s->lo[1]) + (size_t)ny * (size_t)(k - s->lo[2]))] = (unsigned char)t;
+  }
+  return 0;
+}
+/* fillpatch(fine, crse, ng = 0, ...) as regrid.f90:311-325 uses it (FBoxLib routine, absent from the tree: OUR definition): every valid
+ * cell of the new fine fab from the coarse one by the interpolation of vo_fill_ghost_cells -- parent value + MC-limited central
+ * slopes times -1/4 / +1/4 per direction, zero slope where a coarse neighbour lies outside the coarse fab's allocation */
+void vo_fillpatch(vo_fab *fine, const vo_fab *crse, int icomp, int nc)
+{
+  for (int c = icomp; c < icomp + nc; c++)
+  for (int k = fine->lo[2]; k <= fine->hi[2]; k++) for (int j = fine->lo[1]; j <= fine->hi[1]; j++) for (int i = fine->lo[0]; i <= fine->hi[0]; i++) {
+    const int q[3] = { i, j, k }, P[3] = { fdiv2(i), fdiv2(j), fdiv2(k) };
+    if (P[0] < crse->lo[0] || P[0] > crse->hi[0] || P[1] < crse->lo[1] || P[1] > crse->hi[1] || P[2] < crse->lo[2] || P[2] > crse->hi[2]) continue;
+    const double c0 = VF(crse, P[0], P[1], P[2], c);
+    double v = c0;
+    for (int d = 0; d < 3; d++) {
+      int m[3] = { P[0], P[1], P[2] }, p[3] = { P[0], P[1], P[2] }; m[d] -= 1; p[d] += 1;
+      double sl = 0.0;
+      if (in_alloc(crse, m[0], m[1], m[2]) && in_alloc(crse, p[0], p[1], p[2])) {
+        const double cm = VF(crse, m[0], m[1], m[2], c), cp = VF(crse, p[0], p[1], p[2], c);
+        sl = mc_limited(0.5 * (cp - cm), cm, c0, cp);
+      }
+      const double sg = (q[d] - 2 * P[d]) ? 0.25 : -0.25;
+      v = v + sg * sl;
+    }
+    VF(fine, i, j, k, c) = v;
+  }
+}
+/* ml_nodal_prolongation(fine, crse, rr) of regrid.f90:327 (FBoxLib routine: OUR definition): trilinear interpolation of the nodal pressure --
+ * a fine node that coincides with a coarse node copies it, one on a coarse edge / face / cell centre takes the mean of the 2 / 4 / 8
+ * coarse nodes around it (sum in z, y, x order, times the reciprocal of the count) */
+void vo_nodal_prolongation(vo_fab *fine, const vo_fab *crse)
+{
+  for (int k = fine->lo[2]; k <= fine->hi[2] + 1; k++) for (int j = fine->lo[1]; j <= fine->hi[1] + 1; j++) for (int i = fine->lo[0]; i <= fine->hi[0] + 1; i++) {
+    const int I = fdiv2(i), J = fdiv2(j), K = fdiv2(k), oi = i - 2 * I, oj = j - 2 * J, ok = k - 2 * K;
+    if (I < crse->lo[0] || I > crse->hi[0] + 1 || J < crse->lo[1] || J > crse->hi[1] + 1 || K < crse->lo[2] || K > crse->hi[2] + 1) continue;
+    double s = 0.0;
+    for (int c = 0; c <= ok; c++) for (int b = 0; b <= oj; b++) for (int a = 0; a <= oi; a++) s = s + VF(crse, I + a, J + b, K + c, 0);
+    VF(fine, i, j, k, 0) = s * (1.0 / (double)((1 + oi) * (1 + oj) * (1 + ok)));
+  }
+}
 void vo_create_umac_grown(vo_fab *fine, const vo_fab *crse, int dir)
 {
   const int ng = fine->ng;

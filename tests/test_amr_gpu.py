@@ -482,6 +482,62 @@ def test_fillpatch_and_nodal_prolongation_reproduce_linear_fields(gpu):
     mla.destroy(); mlb.destroy()
 
 
+@pytest.mark.parametrize("split", [1, 2])
+def test_regrid_operators_against_the_oracle(gpu, oracle, split):
+    """SURVEY.md section 8(f-3), VERDICT r1 item 6: the three per-cell operators of regridding against their CPU restatements, bit for bit.
+    tag_boxes_3d (src/tag_boxes.f90:128-216, in the reference tree) for levels 1, 2, 3 and prob_type 1 and 3; fillpatch and
+    ml_nodal_prolongation as src/regrid.f90:311-327 calls them (FBoxLib routines: the definitions are ours, stated in oracle/vo_amr.c,
+    so agreement shows the device code implements THAT definition).  The clustering of make_new_grids (Berger-Rigoutsos on the host,
+    also FBoxLib) has no oracle and stays property-tested: test_tagged_grids_properties_and_run, test_regrid."""
+    from varden_amd import advance as adv
+    from varden_amd import boxlib as bl
+    from varden_amd.capi import default_params
+    vo, L = oracle, oracle.lib()
+    K = Amr2(16, (8, 8, 8), (23, 23, 23), split=split, seed=5)
+    # --- tag_boxes: a density field that crosses every threshold (1.01, 1.1, 1.5; 1.2 .. 1.8), and values exactly ON the thresholds
+    s = K.ofabs(3, 2)
+    for lev in range(2):
+        K.smooth(s[lev], lev, 0.45, 1.35)
+        v = s[lev].a[3:-3, 3:-3, 3:-3, 0]
+        v[0, 0, :6] = [1.01, 1.1, 1.5, 1.2, 1.8, np.nextafter(1.01, 2.0)]          # '>' is strict (tag_boxes.f90:147)
+    g = K.gmfs(s)
+    for prob_type in (1, 3):
+        prm = default_params(); prm.prob_type = prob_type
+        bl.initialize(prm, 0, 1, 0)
+        for lev in (1, 2, 3):
+            for n in range(2):
+                of = s[n]
+                shape = tuple(of.hi[d] - of.lo[d] + 1 for d in range(3))
+                ot = np.zeros(shape, dtype=np.uint8, order="F")
+                assert L.vo_tag_boxes(of.ref, lev, prob_type, ot.ctypes.data_as(C.POINTER(C.c_ubyte))) == 0
+                gt = adv.tag_boxes(g[n], lev)                                       # over the level's domain
+                sl = tuple(slice(of.lo[d], of.hi[d] + 1) for d in range(3))
+                assert np.array_equal(gt[sl], ot), "tags differ: prob_type %d lev %d level-index %d" % (prob_type, lev, n)
+                assert gt.sum() == ot.sum() and 0 < ot.sum() < ot.size              # nothing tagged outside the level's boxes
+    ot = np.zeros(1, dtype=np.uint8)
+    assert L.vo_tag_boxes(s[0].ref, 1, 4, ot.ctypes.data_as(C.POINTER(C.c_ubyte))) == -1    # bl_error('Unsupported prob_type'), :212
+    bl.initialize(default_params(), 0, 1, 0)
+    # --- fillpatch: the new fine level from the coarse one (coarse ghost cells filled)
+    c = K.ofabs(3, 2)
+    K.smooth(c[0], 0, 0.7, 1.0)
+    c[1].a[...] = -99.0
+    gc = K.gmfs(c)
+    L.vo_fillpatch(c[1].ref, c[0].ref, 0, 2)
+    adv.fillpatch(gc[1], gc[0], 0, 2)
+    assert_bits(K.gather(gc[1], c[1])[3:-3, 3:-3, 3:-3], c[1].a[3:-3, 3:-3, 3:-3], "fillpatch")
+    assert c[1].a[3:-3, 3:-3, 3:-3].min() > -50.0                                   # every valid fine cell was written
+    # --- ml_nodal_prolongation of the nodal pressure
+    p = K.ofabs(1, 1, (1, 1, 1))
+    K.smooth(p[0], 0, 1.0, 0.2)
+    p[1].a[...] = -99.0
+    gp = K.gmfs(p)
+    L.vo_nodal_prolongation(p[1].ref, p[0].ref)
+    adv.ml_nodal_prolongation(gp[1], gp[0])
+    assert_bits(K.gather(gp[1], p[1])[1:-1, 1:-1, 1:-1], p[1].a[1:-1, 1:-1, 1:-1], "ml_nodal_prolongation")
+    assert p[1].a[1:-1, 1:-1, 1:-1].min() > -50.0
+    K.close()
+
+
 def test_regrid(gpu):
     """src/regrid.f90: (1) regridding an unchanged state gives the same boxes and, bit for bit, the same data (everything is copied
     from the old level); (2) a hierarchy that starts with ONE large fine box regrids onto the tagged boxes inside it, keeps the old

@@ -459,3 +459,25 @@ def test_vorticity_of_known_flows(oracle):
     L.vo_makevort(o2.ref, 0, u2.ref, oracle.dvec(dx), C.byref(bc2))
     assert np.allclose(o2.a[1:-1, :, 0, 0], 2 * om, atol=1e-12)                     # interior columns
     assert np.allclose(o2.a[0, :, 0, 0], 3 * om + om, atol=1e-12) and np.allclose(o2.a[-1, :, 0, 0], 3 * om + om, atol=1e-12)   # v_x three times too large
+
+
+def test_tag_boxes_thresholds():
+    """oracle/vo_amr.c::vo_tag_boxes against the literal thresholds of src/tag_boxes.f90:142-210: rho > 1.01 / 1.1 / 1.5 on levels 1 / 2 / 3+
+    (prob_type 1, 2), 1.2 < rho < 1.8 on every level (prob_type 3), strict comparisons, anything else is an error"""
+    import ctypes as C
+    from oracle import voracle as vo
+    L = vo.lib()
+    f = vo.Fab((0, 0, 0), (7, 0, 0), 0, 1)
+    vals = np.array([1.0, 1.01, np.nextafter(1.01, 2.0), 1.1, np.nextafter(1.1, 2.0), 1.5, np.nextafter(1.5, 2.0), 1.8])
+    f.a[:, 0, 0, 0] = vals
+    t = np.zeros(8, dtype=np.uint8)
+    tp = t.ctypes.data_as(C.POINTER(C.c_ubyte))
+    for pt in (1, 2):
+        for lev, thr in ((1, 1.01), (2, 1.1), (3, 1.5), (4, 1.5)):
+            assert L.vo_tag_boxes(f.ref, lev, pt, tp) == 0
+            assert np.array_equal(t, (vals > thr).astype(np.uint8)), (pt, lev)
+    f.a[:, 0, 0, 0] = [1.0, 1.2, np.nextafter(1.2, 2.0), 1.5, np.nextafter(1.8, 0.0), 1.8, 2.0, 1.3]
+    for lev in (1, 2, 3):
+        assert L.vo_tag_boxes(f.ref, lev, 3, tp) == 0
+        assert list(t) == [0, 0, 1, 1, 1, 0, 0, 1]
+    assert L.vo_tag_boxes(f.ref, 1, 4, tp) == -1 and L.vo_tag_boxes(f.ref, 1, 0, tp) == -1

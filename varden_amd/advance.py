@@ -156,6 +156,16 @@ def make_new_grids(s, lev, buf_wid=2, nest=2, min_eff=0.9, min_width=4, blocking
     return [(tuple(boxes[i].lo), tuple(boxes[i].hi)) for i in range(nb.value)], nt.value
 
 
+def tag_boxes(s, lev):
+    """tag_boxes of src/tag_boxes.f90 on component 0 of `s` (level `lev`, 1-based): uint8 array over the level's domain (x first)"""
+    import numpy as np
+    lo, hi = s.mla.pd[s.lev]
+    n = tuple(hi[d] - lo[d] + 1 for d in range(3))
+    tags = np.zeros(n, dtype=np.uint8, order="F")
+    check(capi.load().vdn_tag_boxes(s.h, lev, tags.ctypes.data_as(C.POINTER(C.c_ubyte))))
+    return tags
+
+
 def fillpatch(fine, crse, icomp, nc):
     """fillpatch(fine, crse, 0, ...) of src/regrid.f90:311-325: valid cells of a new fine level from the coarser one"""
     check(capi.load().vdn_fillpatch(fine.h, crse.h, icomp, nc))

@@ -113,6 +113,7 @@ SIGNATURES = {
     "vdn_comm_allreduce_max": (C.c_int, [C.POINTER(C.c_double), C.c_int]),
     "vdn_ml_nodal_prolongation": (C.c_int, [_VP, _VP]),
     "vdn_multifab_copy_layouts": (C.c_int, [_VP, C.c_int, _VP, C.c_int, C.c_int]),
+    "vdn_tag_boxes": (C.c_int, [_VP, C.c_int, C.POINTER(C.c_ubyte)]),
     "vdn_make_new_grids": (C.c_int, [_VP, C.c_int, C.c_int, C.c_int, C.c_double, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(Box), _PI, C.POINTER(C.c_long)]),
     "vdn_last_step_timing": (C.c_int, [_PD]),
     "vdn_last_solver_stats": (C.c_int, [C.c_int, _PI, _PD, _PD]),

@@ -293,8 +293,13 @@ void xplan_free(XPlan *P) {
   delete P;
 }
 
-void xplan_run(XPlan *P) {
-  hipStream_t st = ctx().stream;
+bool xplan_has_remote(const XPlan *P) {
+  if (!P) return false;
+  for (const auto &pr : P->peers) if (pr.rank != ctx().rank || packed_mode() == 2) return true;
+  return false;
+}
+void xplan_run(XPlan *P, hipStream_t st) {
+  if (!st) st = ctx().stream;
   if (getenv("VDN_DEBUG_VIEWS")) { fprintf(stderr, "[rank %d] xplan nc %d peers:", ctx().rank, P->nc); for (auto &pr : P->peers) fprintf(stderr, " (%d: send %zu recv %zu)", pr.rank, pr.nsend, pr.nrecv); fprintf(stderr, "\n"); }
   const int nc = P->nc;
   // pack + post the remote traffic first so that it overlaps the local copies

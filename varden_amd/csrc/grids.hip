@@ -106,6 +106,39 @@ void cluster(const Lattice &G, IBox b, double min_eff, int min_width, std::vecto
 }
 }  // namespace
 
+// tag_boxes (src/tag_boxes.f90:17-39 driver, 41-127 2-D, 128-216 3-D) of one level: a byte per cell of the level's DOMAIN (x fastest), 1 where
+// the first component of s exceeds the level's threshold; cells outside the level's boxes stay 0; all ranks end with the same bitmap.
+// Returns a device buffer the caller frees.
+static unsigned char *tag_level(const vdn_multifab *s, int lev1) {
+  const vdn_box &pd = s->la->pd[s->lev];
+  int n[3]; for (int d = 0; d < 3; d++) n[d] = pd.hi[d] - pd.lo[d] + 1;
+  const int pt = ctx().prm.prob_type;
+  REQUIRE(pt == 1 || pt == 2 || pt == 3, "tag_boxes: unsupported prob_type %d (tag_boxes.f90:212)", pt);
+  int rule = 0; double tlo = 0.0, thi = 0.0;
+  if (pt == 3) { rule = 1; tlo = 1.2; thi = 1.8; } else { tlo = lev1 == 1 ? 1.01 : (lev1 == 2 ? 1.1 : 1.5); }
+  const size_t ncell = (size_t)n[0] * n[1] * n[2];
+  unsigned char *d_tags; HIPCHK(hipMalloc((void **)&d_tags, ncell));
+  HIPCHK(hipMemsetAsync(d_tags, 0, ncell, ctx().stream));
+  for (int b = 0; b < s->nfabs(); b++) {
+    Range3 r; for (int d = 0; d < 3; d++) { r.lo[d] = s->vbox[b].lo[d]; r.hi[d] = s->vbox[b].hi[d]; }
+    hipLaunchKernelGGL(kk_tag, grid_for(r), dim3(64, 4, 1), 0, ctx().stream, s->fabs[b], d_tags, n[0], n[1], pd.lo[0], pd.lo[1], pd.lo[2], rule, tlo, thi, r);
+  }
+  comm_allreduce_max_u8_dev(d_tags, ncell);                // the tags of the other ranks' boxes: every rank sees the same bitmap
+  return d_tags;
+}
+// the tag bitmap alone (the parity test against the restated tag_boxes_3d): tags_host holds one byte per cell of the level's domain
+extern "C" int vdn_tag_boxes(const vdn_multifab *s, int lev1, unsigned char *tags_host) {
+  VDN_TRY
+  REQUIRE(s && tags_host, "vdn_tag_boxes: null argument");
+  const vdn_box &pd = s->la->pd[s->lev];
+  size_t ncell = 1; for (int d = 0; d < 3; d++) ncell *= (size_t)(pd.hi[d] - pd.lo[d] + 1);
+  unsigned char *d_tags = tag_level(s, lev1);
+  HIPCHK(hipMemcpyAsync(tags_host, d_tags, ncell, hipMemcpyDeviceToHost, ctx().stream));
+  HIPCHK(hipStreamSynchronize(ctx().stream));
+  HIPCHK(hipFree(d_tags));
+  VDN_CATCH
+}
+
 // s: the state of ONE level (valid cells of its local boxes; single rank).  boxes_out: boxes of the next finer level in ITS index space
 extern "C" int vdn_make_new_grids(const vdn_multifab *s, int lev1, int buf_wid, int nest, double min_eff, int min_width, int blocking,
                                   int max_grid_size, int maxboxes, vdn_box *boxes_out, int *nboxes_out, long *ntagged) {
@@ -118,24 +151,14 @@ extern "C" int vdn_make_new_grids(const vdn_multifab *s, int lev1, int buf_wid, 
   const int dm = ctx().prm.dm;
   for (int d = 0; d < dm; d++) REQUIRE(n[d] % blocking == 0, "vdn_make_new_grids: the domain extent %d is not a multiple of the blocking factor %d", n[d], blocking);
   // 1. tags on the device (tag_boxes.f90:142-210: thresholds by level, prob_type)
-  const int pt = ctx().prm.prob_type;
-  REQUIRE(pt == 1 || pt == 2 || pt == 3, "tag_boxes: unsupported prob_type %d (tag_boxes.f90:212)", pt);
-  int rule = 0; double tlo = 0.0, thi = 0.0;
-  if (pt == 3) { rule = 1; tlo = 1.2; thi = 1.8; } else { tlo = lev1 == 1 ? 1.01 : (lev1 == 2 ? 1.1 : 1.5); }
   const size_t ncell = (size_t)n[0] * n[1] * n[2];
-  unsigned char *d_tags; HIPCHK(hipMalloc((void **)&d_tags, ncell));
-  HIPCHK(hipMemsetAsync(d_tags, 0, ncell, ctx().stream));
+  unsigned char *d_tags = tag_level(s, lev1);
   // inside[]: 1 on the cells of the level (host), for the nesting region
   std::vector<unsigned char> inside(ncell, 0), tags(ncell, 0);
-  for (int b = 0; b < s->nfabs(); b++) {
-    Range3 r; for (int d = 0; d < 3; d++) { r.lo[d] = s->vbox[b].lo[d]; r.hi[d] = s->vbox[b].hi[d]; }
-    hipLaunchKernelGGL(kk_tag, grid_for(r), dim3(64, 4, 1), 0, ctx().stream, s->fabs[b], d_tags, n[0], n[1], pd.lo[0], pd.lo[1], pd.lo[2], rule, tlo, thi, r);
-  }
   for (const vdn_box &gb : la->boxes[s->lev])              // the cells of the level: every box, on any rank
     for (int k = gb.lo[2]; k <= gb.hi[2]; k++) for (int j = gb.lo[1]; j <= gb.hi[1]; j++)
       std::fill(inside.begin() + ((size_t)(gb.lo[0] - pd.lo[0]) + (size_t)n[0] * ((size_t)(j - pd.lo[1]) + (size_t)n[1] * (size_t)(k - pd.lo[2]))),
                 inside.begin() + ((size_t)(gb.hi[0] - pd.lo[0]) + 1 + (size_t)n[0] * ((size_t)(j - pd.lo[1]) + (size_t)n[1] * (size_t)(k - pd.lo[2]))), 1);
-  comm_allreduce_max_u8_dev(d_tags, ncell);                // the tags of the other ranks' boxes: every rank clusters the same bitmap
   HIPCHK(hipMemcpyAsync(tags.data(), d_tags, ncell, hipMemcpyDeviceToHost, ctx().stream));
   HIPCHK(hipStreamSynchronize(ctx().stream));
   HIPCHK(hipFree(d_tags));

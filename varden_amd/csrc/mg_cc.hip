@@ -68,15 +68,39 @@ template <bool RHO = false> DEVI void cc_apply(const CLev &L, long c, double &Ap
 // (measured at 256^3 and rejected: several k-planes per workgroup 0.161 ms; the x-triplet as one 16-byte load per lane plus lane
 // exchange 0.230 ms; all rows staged through LDS as aligned 16-byte pairs, even and odd cells in separate LDS rows so that every global
 // load is a full line and every LDS read unit-stride, 0.157 ms -- against 0.141-0.144 ms for this form)
-template <bool RHO> DEVI void cc_gsrb_cell(const CLev &L, int color) {
+// Overlap of the halo exchange with the pass ("interior kernel, halos on a second stream, boundary kernel"): the cells of a box
+// split into the SHELL (the outermost layer: the only cells that read ghost values) and the INTERIOR.  interior_only = 1: a pass skips
+// the shell cells; they are updated afterwards, once the halo has landed, by kk_cc_gsrb_shell.  Cells of one colour do not read each
+// other, so the order inside a pass is free and the bits are those of the unsplit pass.
+DEVI bool cc_is_shell(const CLev &L, int i, int j, int k) { return i == 0 || i == L.n[0] - 1 || j == 0 || j == L.n[1] - 1 || k == 0 || k == L.n[2] - 1; }
+template <bool RHO> DEVI void cc_update_cell(const CLev &L, int i, int j, int k) {
+  const long c = cidx(L, i, j, k);
+  double Ap, diag; cc_apply<RHO>(L, c, Ap, diag, i, j, k);
+  if (diag != 0.0) L.phi[c] = L.phi[c] + (L.rh[c] - Ap) / diag;
+}
+template <bool RHO> DEVI void cc_gsrb_cell(const CLev &L, int color, int interior_only) {
   int bx, by, bz; xcd_block(bx, by, bz);
   const int j = by * blockDim.y + threadIdx.y;
   const int k = bz;
   const int i = 2 * (int)(bx * blockDim.x + threadIdx.x) + ((j + k + color) & 1);
   if (i >= L.n[0] || j >= L.n[1]) return;
-  const long c = cidx(L, i, j, k);
-  double Ap, diag; cc_apply<RHO>(L, c, Ap, diag, i, j, k);
-  if (diag != 0.0) L.phi[c] = L.phi[c] + (L.rh[c] - Ap) / diag;
+  if (interior_only && cc_is_shell(L, i, j, k)) return;
+  cc_update_cell<RHO>(L, i, j, k);
+}
+// the shell cells of one colour: blockIdx.z = face (x-lo, x-hi, y-lo, y-hi, z-lo, z-hi); the x faces own their edges and corners, the y
+// faces the remaining edges, so that every shell cell is updated exactly once
+template <bool RHO> __global__ void __launch_bounds__(256) kk_cc_gsrb_shell(CLev L, int color) {
+  const int f = blockIdx.z, d = f >> 1, side = f & 1;
+  const int a = blockIdx.x * blockDim.x + threadIdx.x, b = blockIdx.y * blockDim.y + threadIdx.y;
+  int q[3];
+  const int da = d == 0 ? 1 : 0, db = d == 2 ? 1 : 2;
+  q[d] = side ? L.n[d] - 1 : 0; q[da] = a; q[db] = b;
+  if (side && L.n[d] == 1) return;                                   // a one-cell-thick box: its single layer belongs to the lo face
+  if (q[da] >= L.n[da] || q[db] >= L.n[db]) return;
+  if (d >= 1 && (q[0] == 0 || q[0] == L.n[0] - 1)) return;           // owned by an x face
+  if (d == 2 && (q[1] == 0 || q[1] == L.n[1] - 1)) return;           // owned by a y face
+  if ((q[0] + q[1] + q[2] + color) & 1) return;
+  cc_update_cell<RHO>(L, q[0], q[1], q[2]);
 }
 // cc_apply<true> on values already in registers (the paired colour pass): same expressions, same order
 DEVI void cc_apply_rho_vals(const CLev &L, int i, int j, int k, const double p[7], const double r[7], double &Ap, double &diag) {
@@ -121,7 +145,7 @@ DEVI void pair_gather(const double *v, const CLev &L, long cpA, int par, int lan
   if (par == 0) { o.a[1] = outl; o.a[2] = PA.y; o.b[1] = PB.x; o.b[2] = outr; }
   else          { o.a[1] = PA.x; o.a[2] = outr; o.b[1] = outl; o.b[2] = PB.y; }
 }
-__global__ void __launch_bounds__(256) kk_cc_gsrb_rho_pair(CLev L, int color) {
+__global__ void __launch_bounds__(256) kk_cc_gsrb_rho_pair(CLev L, int color, int interior_only) {
   int bx, by, bz; xcd_block(bx, by, bz);
   const int lane = threadIdx.x, k = bz;
   const int t = bx * 64 + lane, jA = 2 * (by * 4 + (int)threadIdx.y);
@@ -136,9 +160,9 @@ __global__ void __launch_bounds__(256) kk_cc_gsrb_rho_pair(CLev L, int color) {
   const int iA = 2 * t + par, iB = 2 * t + 1 - par;
   double Ap, diag;
   cc_apply_rho_vals(L, iA, jA, k, P.a, R.a, Ap, diag);
-  if (diag != 0.0) L.phi[cpA + par] = P.a[0] + (sel2(RA, par) - Ap) / diag;
+  if (diag != 0.0 && !(interior_only && cc_is_shell(L, iA, jA, k))) L.phi[cpA + par] = P.a[0] + (sel2(RA, par) - Ap) / diag;
   cc_apply_rho_vals(L, iB, jA + 1, k, P.b, R.b, Ap, diag);
-  if (diag != 0.0) L.phi[cpA + L.PX + 1 - par] = P.b[0] + (sel2(RB, 1 - par) - Ap) / diag;
+  if (diag != 0.0 && !(interior_only && cc_is_shell(L, iB, jA + 1, k))) L.phi[cpA + L.PX + 1 - par] = P.b[0] + (sel2(RB, 1 - par) - Ap) / diag;
 }
 // the same pairing for the stored-coefficient pass (viscous / diffusive solves, the 128^3 level of the MAC solve, level 0 of the
 // composite solves): the face coefficients of the two cells come from nine aligned pairs (bx: rows j, j+1; by: rows j, j+1, j+2;
@@ -153,7 +177,7 @@ DEVI void cc_apply_vals(const CLev &L, const double p[7], const double b[6], dou
   diag = (b[1] + b[0]) * L.hi2[0] + (b[3] + b[2]) * L.hi2[1] + (b[5] + b[4]) * L.hi2[2];
   if (has_alpha) { Ap = Ap + a0 * p0; diag = diag + a0; }
 }
-__global__ void __launch_bounds__(256) kk_cc_gsrb_pair(CLev L, int color) {
+__global__ void __launch_bounds__(256) kk_cc_gsrb_pair(CLev L, int color, int interior_only) {
   int bx, by, bz; xcd_block(bx, by, bz);
   const int lane = threadIdx.x, k = bz;
   const int t = bx * 64 + lane, jA = 2 * (by * 4 + (int)threadIdx.y);
@@ -184,22 +208,29 @@ __global__ void __launch_bounds__(256) kk_cc_gsrb_pair(CLev L, int color) {
   bA[2] = sel2(YA, par); bA[3] = sel2(YB, par); bB[2] = sel2(YB, 1 - par); bB[3] = sel2(YC, 1 - par);
   bA[4] = sel2(ZA0, par); bA[5] = sel2(ZA1, par); bB[4] = sel2(ZB0, 1 - par); bB[5] = sel2(ZB1, 1 - par);
   double Ap, diag;
+  const int iA = 2 * t + par, iB = 2 * t + 1 - par;
   cc_apply_vals(L, P.a, bA, sel2(AA, par), L.alpha != nullptr, Ap, diag);
-  if (diag != 0.0) L.phi[cpA + par] = P.a[0] + (sel2(RA, par) - Ap) / diag;
+  if (diag != 0.0 && !(interior_only && cc_is_shell(L, iA, jA, k))) L.phi[cpA + par] = P.a[0] + (sel2(RA, par) - Ap) / diag;
   cc_apply_vals(L, P.b, bB, sel2(AB, 1 - par), L.alpha != nullptr, Ap, diag);
-  if (diag != 0.0) L.phi[cpA + sy + 1 - par] = P.b[0] + (sel2(RB, 1 - par) - Ap) / diag;
+  if (diag != 0.0 && !(interior_only && cc_is_shell(L, iB, jA + 1, k))) L.phi[cpA + sy + 1 - par] = P.b[0] + (sel2(RB, 1 - par) - Ap) / diag;
 }
-__global__ void __launch_bounds__(256) kk_cc_gsrb(CLev L, int color) { cc_gsrb_cell<false>(L, color); }
-__global__ void __launch_bounds__(256) kk_cc_gsrb_rho(CLev L, int color) { cc_gsrb_cell<true>(L, color); }
-static inline void launch_gsrb(const CLev &L, int color, hipStream_t st) {
+__global__ void __launch_bounds__(256) kk_cc_gsrb(CLev L, int color, int interior_only) { cc_gsrb_cell<false>(L, color, interior_only); }
+__global__ void __launch_bounds__(256) kk_cc_gsrb_rho(CLev L, int color, int interior_only) { cc_gsrb_cell<true>(L, color, interior_only); }
+static inline void launch_gsrb_shell(const CLev &L, int color, hipStream_t st) {
+  const int m = std::max(L.n[0], std::max(L.n[1], L.n[2]));
+  const dim3 g((unsigned)((m + 63) / 64), (unsigned)((m + 3) / 4), 6);
+  if (L.rho) hipLaunchKernelGGL(kk_cc_gsrb_shell<true>, g, dim3(64, 4, 1), 0, st, L, color);
+  else hipLaunchKernelGGL(kk_cc_gsrb_shell<false>, g, dim3(64, 4, 1), 0, st, L, color);
+}
+static inline void launch_gsrb(const CLev &L, int color, hipStream_t st, int interior_only = 0) {
   const dim3 blk(64, 4, 1), g((unsigned)(((L.n[0] + 1) / 2 + 63) / 64), (unsigned)((L.n[1] + 3) / 4), (unsigned)L.n[2]);
   static const bool paired = !(getenv("VDN_GSRB_PAIR") && atoi(getenv("VDN_GSRB_PAIR")) == 0);
   if (L.rho && paired && L.n[0] % 2 == 0 && L.n[1] % 2 == 0 && L.n[0] >= 128)
-    hipLaunchKernelGGL(kk_cc_gsrb_rho_pair, dim3((unsigned)((L.n[0] / 2 + 63) / 64), (unsigned)((L.n[1] / 2 + 3) / 4), (unsigned)L.n[2]), blk, 0, st, L, color);
-  else if (L.rho) hipLaunchKernelGGL(kk_cc_gsrb_rho, g, blk, 0, st, L, color);
+    hipLaunchKernelGGL(kk_cc_gsrb_rho_pair, dim3((unsigned)((L.n[0] / 2 + 63) / 64), (unsigned)((L.n[1] / 2 + 3) / 4), (unsigned)L.n[2]), blk, 0, st, L, color, interior_only);
+  else if (L.rho) hipLaunchKernelGGL(kk_cc_gsrb_rho, g, blk, 0, st, L, color, interior_only);
   else if (paired && L.n[0] % 2 == 0 && L.n[1] % 2 == 0 && L.n[0] >= 128)
-    hipLaunchKernelGGL(kk_cc_gsrb_pair, dim3((unsigned)((L.n[0] / 2 + 63) / 64), (unsigned)((L.n[1] / 2 + 3) / 4), (unsigned)L.n[2]), blk, 0, st, L, color);
-  else hipLaunchKernelGGL(kk_cc_gsrb, g, blk, 0, st, L, color);
+    hipLaunchKernelGGL(kk_cc_gsrb_pair, dim3((unsigned)((L.n[0] / 2 + 63) / 64), (unsigned)((L.n[1] / 2 + 3) / 4), (unsigned)L.n[2]), blk, 0, st, L, color, interior_only);
+  else hipLaunchKernelGGL(kk_cc_gsrb, g, blk, 0, st, L, color, interior_only);
 }
 
 // ---- fused red+black sweep ---------------------------------------------------------------------------------------
@@ -890,12 +921,25 @@ static void cc_gsrb_d(CCMG &M, CDLev &DL, int nsweeps) {
     return;
   }
   if (DL.single_box && DL.boxes.size() == 1 && DL.boxes[0].L.phi2) { cc_launch_fused(DL.boxes[0].L, nsweeps); return; }
+  // halo exchange next to the pass: when part of the halo comes from another rank (or VDN_OVERLAP=1, the one-GPU rehearsal) the packed
+  // traffic -- pack kernels, the ncclSend / ncclRecv group, box-to-box copies, unpack kernels -- runs on ctx().halo_stream while the
+  // launch stream updates the cells that read no ghost value; the one-cell shell follows when the halo has landed
+  static const int ov_env = getenv("VDN_OVERLAP") ? atoi(getenv("VDN_OVERLAP")) : -1;
+  const bool overlap = DL.halo && (ov_env == 1 || (ov_env != 0 && xplan_has_remote(DL.halo)));
+  VdnCtx &c = ctx();
   for (int s = 0; s < nsweeps; s++) for (int color = 0; color < 2; color++) {
-    cc_halo(M, DL);
-    for (const CBox &B : DL.boxes) {
-      const int c = (color + B.lo[0] + B.lo[1] + B.lo[2]) & 1;       // colour by GLOBAL cell index
-      launch_gsrb(B.L, c, ctx().stream);
+    if (!overlap) {
+      cc_halo(M, DL);
+      for (const CBox &B : DL.boxes) launch_gsrb(B.L, (color + B.lo[0] + B.lo[1] + B.lo[2]) & 1, c.stream);       // colour by GLOBAL cell index
+      continue;
     }
+    HIPCHK(hipEventRecord(c.ev_main, c.stream));                    // phi of the previous pass is complete ...
+    HIPCHK(hipStreamWaitEvent(c.halo_stream, c.ev_main, 0));        // ... before its outermost layer is packed
+    xplan_run(DL.halo, c.halo_stream);
+    HIPCHK(hipEventRecord(c.ev_halo, c.halo_stream));
+    for (const CBox &B : DL.boxes) launch_gsrb(B.L, (color + B.lo[0] + B.lo[1] + B.lo[2]) & 1, c.stream, 1);
+    HIPCHK(hipStreamWaitEvent(c.stream, c.ev_halo, 0));
+    for (const CBox &B : DL.boxes) launch_gsrb_shell(B.L, (color + B.lo[0] + B.lo[1] + B.lo[2]) & 1, c.stream);
   }
 }
 static void cc_residual_d(CCMG &M, CDLev &DL, bool norm) {

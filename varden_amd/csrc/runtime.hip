@@ -183,6 +183,8 @@ extern "C" int vdn_init(const vdn_params *prm, int rank, int nranks, int device)
   if (!c.own_stream) {
     HIPCHK(hipStreamCreateWithFlags(&c.own_stream, hipStreamNonBlocking));
     HIPCHK(hipStreamCreateWithFlags(&c.halo_stream, hipStreamNonBlocking));
+    HIPCHK(hipEventCreateWithFlags(&c.ev_main, hipEventDisableTiming));
+    HIPCHK(hipEventCreateWithFlags(&c.ev_halo, hipEventDisableTiming));
   }
   if (c.stream == 0) c.stream = c.own_stream;
   prof_load();

@@ -81,6 +81,7 @@ struct VdnCtx {
   int rank = 0, nranks = 1, device = 0;
   hipStream_t stream = 0;                    // the launch stream: our own non-blocking stream unless vdn_set_stream names another
   hipStream_t own_stream = 0, halo_stream = 0;    // halo_stream: packed ghost traffic next to interior compute (exchange.hip)
+  hipEvent_t ev_main = nullptr, ev_halo = nullptr; // ordering between the two (no timing)
   // persistent arena for per-step temporaries (bump allocator, reset at the start of each public call)
   char *arena = nullptr; size_t arena_bytes = 0, arena_off = 0, arena_peak = 0;
   // small device scratch for reductions + pinned host mirror
@@ -150,7 +151,8 @@ void mf_temp_free(vdn_multifab *mf);
 struct XBoxInfo { FV fv; int vlo[3], vhi[3]; int owner; };      // valid POINT range (incl. nodal points); fv only if local
 struct XPlan;
 XPlan *xplan_build(const std::vector<XBoxInfo> &boxes, const vdn_box &pd, const int pmask[3], int ng, int nc);
-void   xplan_run(XPlan *P);
+void   xplan_run(XPlan *P, hipStream_t st = nullptr);      // st: the stream the pack / transfer / copy / unpack run on (default: the launch stream)
+bool   xplan_has_remote(const XPlan *P);                  // some of the traffic goes to another rank
 void   xplan_free(XPlan *P);
 unsigned long xplan_serial(const XPlan *P);
 void   xplan_cache_purge(unsigned long layout_uid);   // drop every cached plan built for that layout
