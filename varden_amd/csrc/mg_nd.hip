@@ -290,6 +290,8 @@ __global__ void __launch_bounds__(64 * ROWS) kk_nd_march_pair(NLev L, const doub
   if (MODE == 1 && nrm) block_atomic_max(nrm, rmax);
 }
 
+// (measured and rejected: a plane-per-workgroup form of the paired sweep -- a workgroup owns a 124 x 4 patch of ONE k-plane, the planes
+// shared through the XCD's L2 like the cell-centred colour pass, 14 sixteen-byte loads per pair of nodes: 0.224 ms against 0.150 ms)
 // ghost nodes (and the periodic alias node n): periodic image, else zero
 __global__ void kk_nd_fill_nodes(NLev L, double *a) {
   const int i = (int)(blockIdx.x * blockDim.x + threadIdx.x) - 1;
