@@ -702,6 +702,7 @@ int ml_cc_solve(vdn_layout *la, vdn_multifab **rh, vdn_multifab **phi, vdn_multi
   const double bnorm = read_dev(S.d_nrm);
   const vdn_params &P = ctx().prm;
   int it = 0; bool conv = (bnorm == 0.0); double rn = 0.0;
+  CcKeep *coarse_keep = cc_keep_new();       // the level-0 multigrid hierarchy is built once for all FAC iterations
   int ebc0[3][2];
   for (int d = 0; d < 3; d++) for (int s = 0; s < 2; s++) ebc0[d][s] = bct->ell_bc(0, 0, d, s, bc_comp0);
   while (!conv) {
@@ -717,7 +718,7 @@ int ml_cc_solve(vdn_layout *la, vdn_multifab **rh, vdn_multifab **phi, vdn_multi
     // coarse correction: ONE V-cycle of the single-level multigrid on the whole level 0
     mf_setval(S.e[0], 0.0, 0, 1, true);
     int cyc; double r0, rr;
-    cc_solve(S.res[0], S.e[0], beta, dx, ebc0, 0.0, -1.0, -1, &cyc, &r0, &rr, alpha ? alpha[0] : nullptr);
+    cc_solve(S.res[0], S.e[0], beta, dx, ebc0, 0.0, -1.0, -1, &cyc, &r0, &rr, alpha ? alpha[0] : nullptr, nullptr, coarse_keep);
     apply_correction(S, 0);
     // post-relaxation on the new residual, coarsest level first
     for (int n = 1; n < L; n++) {
@@ -728,6 +729,7 @@ int ml_cc_solve(vdn_layout *la, vdn_multifab **rh, vdn_multifab **phi, vdn_multi
     }
     it++;
   }
+  cc_keep_free(coarse_keep);
   fill_phi_ghosts(S);
   if (iters) *iters = it; if (res0) *res0 = bnorm; if (res) *res = rn;
   for (int n = L - 1; n >= 0; n--) { if (S.mask[n]) mf_temp_free(S.mask[n]); if (S.scr[n]) mf_temp_free(S.scr[n]); mf_temp_free(S.e[n]); mf_temp_free(S.res[n]); }

@@ -623,6 +623,14 @@ __global__ void kk_cc_load(CLev L, FV rh, FV phi, FV alpha, FV bx, FV by, FV bz,
     L.b[2][c] = v;
   }
 }
+// phi alone (a kept hierarchy takes a new right-hand side and initial guess: cc_reload)
+__global__ void kk_cc_load_phi(CLev L, FV phi, int lo0, int lo1, int lo2) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  const int j = blockIdx.y * blockDim.y + threadIdx.y;
+  const int k = blockIdx.z;
+  if (i >= L.n[0] || j >= L.n[1] || k >= L.n[2]) return;
+  L.phi[cidx(L, i, j, k)] = fv_get(phi, lo0 + i, lo1 + j, lo2 + k);
+}
 // the density with its ghost layer, for the on-the-fly face coefficients of the finest level
 __global__ void kk_cc_load_rho(CLev L, double *dst, FV rho, int lo0, int lo1, int lo2) {
   const int i = (int)(blockIdx.x * blockDim.x + threadIdx.x) - 1;
@@ -1042,6 +1050,10 @@ static void cc_vcycle_d(CCMG &M, int l) {
   cc_gsrb_d(M, DL, P.mg_nu2);
 }
 
+struct CcKeep { bool built = false; CCMG M; };
+CcKeep *cc_keep_new() { return new CcKeep; }
+void cc_keep_free(CcKeep *k) { delete k; }
+
 // ---- one cycle as a hipGraph ------------------------------------------------------------------------------------------------------
 // A V-cycle at 256^3 is ~110 launches, most of them 3-15 us kernels on the levels <= 64^3: issued one by one the host cannot keep
 // the GPU busy (r1: 8 ms of a 50 ms step were launch gaps).  The launch sequence of a cycle depends only on the level structures, so
@@ -1138,6 +1150,23 @@ static void cc_setup(CCMG &M, vdn_multifab *rh, vdn_multifab *phi, const vdn_mul
     }
   }
 }
+// a kept hierarchy (coefficients on every level stay): the finest level takes a new right-hand side and initial guess
+static void cc_reload(CCMG &M, vdn_multifab *rh, vdn_multifab *phi, const int bc[3][2]) {
+  const vdn_layout *la = rh->la; const int lev = rh->lev;
+  CDLev &D0 = M.dlev[0];
+  for (size_t b = 0; b < D0.boxes.size(); b++) {
+    CLev &L0 = D0.boxes[b].L;
+    const vdn_box &bx = rh->vbox[b];
+    int e[3][2];
+    for (int d = 0; d < 3; d++) {
+      e[d][0] = (bx.lo[d] == la->pd[lev].lo[d]) ? bc[d][0] : VDN_BC_INT;
+      e[d][1] = (bx.hi[d] == la->pd[lev].hi[d]) ? bc[d][1] : VDN_BC_INT;
+    }
+    hipLaunchKernelGGL(kk_cc_load_phi, g3(L0.n[0], L0.n[1], L0.n[2], BLK), BLK, 0, ctx().stream, L0, phi->fabs[b], bx.lo[0], bx.lo[1], bx.lo[2]);
+    hipLaunchKernelGGL(kk_cc_load_rh, g3(L0.n[0], L0.n[1], L0.n[2], BLK), BLK, 0, ctx().stream, L0, rh->fabs[b], phi->fabs[b],
+                       bx.lo[0], bx.lo[1], bx.lo[2], e[0][0], e[0][1], e[1][0], e[1][1], e[2][0], e[2][1]);
+  }
+}
 static void cc_store(CCMG &M, vdn_multifab *phi, const int bc[3][2]) {
   CDLev &D0 = M.dlev[0];
   cc_halo(M, D0);
@@ -1156,12 +1185,18 @@ static void cc_store(CCMG &M, vdn_multifab *phi, const int bc[3][2]) {
 }
 
 int cc_solve(vdn_multifab *rh, vdn_multifab *phi, vdn_multifab **beta, const double *dx, const int bc[3][2],
-             double rel_eps, double abs_eps, int max_iter, int *cycles, double *res0, double *res, const vdn_multifab *alpha, const vdn_multifab *rho) {
+             double rel_eps, double abs_eps, int max_iter, int *cycles, double *res0, double *res, const vdn_multifab *alpha, const vdn_multifab *rho, CcKeep *keep) {
   Prof prof_("mac_multigrid");
   if (ctx().prm.dm == 2) return cc2_solve(rh, phi, beta, dx, bc, rel_eps, abs_eps, max_iter, cycles, res0, res, alpha);
   const vdn_params &P = ctx().prm;
   size_t mark = arena_mark();
-  CCMG M; cc_setup(M, rh, phi, alpha, beta, dx, bc, rho);
+  // keep: the hierarchy (arrays in the caller's arena scope, coefficients on every level) survives the call; the next call with the
+  // same `keep` loads only its right-hand side and phi (the composite solves: one V-cycle per FAC iteration on the same coefficients)
+  CCMG M_local;
+  CCMG &M = keep ? keep->M : M_local;
+  if (keep && keep->built) cc_reload(M, rh, phi, bc);
+  else cc_setup(M, rh, phi, alpha, beta, dx, bc, rho);
+  if (keep) keep->built = true;
   CDLev &D0 = M.dlev[0];
   const bool single = (M.dlev.size() == 1 && M.tail.empty());
   if (max_iter < 0) {            // exactly -max_iter V-cycles, no norms, no convergence test (the coarse correction of the composite solves)
@@ -1178,7 +1213,7 @@ int cc_solve(vdn_multifab *rh, vdn_multifab *phi, vdn_multifab **beta, const dou
     }
     cc_store(M, phi, bc);
     if (cycles) *cycles = -max_iter; if (res0) *res0 = 0.0; if (res) *res = 0.0;
-    arena_release(mark);
+    if (!keep) arena_release(mark);
     return 0;
   }
   const double bnorm = mf_norm_inf(rh, 0, 1);
@@ -1204,7 +1239,7 @@ int cc_solve(vdn_multifab *rh, vdn_multifab *phi, vdn_multifab **beta, const dou
   }
   cc_store(M, phi, bc);
   if (cycles) *cycles = cyc; if (res0) *res0 = bnorm; if (res) *res = rn;
-  arena_release(mark);
+  if (!keep) arena_release(mark);
   return conv ? 0 : 1;
 }
 

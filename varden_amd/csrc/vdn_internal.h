@@ -211,7 +211,9 @@ void do_macproject(vdn_layout *mla, vdn_multifab **umac, vdn_multifab **rho, vdn
                    const vdn_bc_tower *bct, int bc_comp0);
 int  cc_solve(vdn_multifab *rh, vdn_multifab *phi, vdn_multifab **beta, const double *dx, const int bc[3][2],
               double rel_eps, double abs_eps, int max_iter, int *cycles, double *res0, double *res,
-              const vdn_multifab *alpha = nullptr, const vdn_multifab *rho = nullptr);   // rho: beta = 2/(rho_i + rho_i-1), recomputed on the finest level
+              const vdn_multifab *alpha = nullptr, const vdn_multifab *rho = nullptr,    // rho: beta = 2/(rho_i + rho_i-1), recomputed on the finest level
+              struct CcKeep *keep = nullptr);          // keep: see mg_cc.hip (hierarchy kept between the calls of a composite solve)
+struct CcKeep *cc_keep_new(); void cc_keep_free(struct CcKeep *k);
 void cc_smooth(vdn_multifab *rh, vdn_multifab *phi, vdn_multifab **beta, const double *dx, const int bc[3][2], int nsweeps);
 void cc_bench_smoother(vdn_multifab *rh, vdn_multifab *phi, vdn_multifab **beta, const vdn_multifab *rho, const double *dx, const int bc[3][2],
                        int nlaunch, double *avg_ms, long *cells);
@@ -225,7 +227,7 @@ void do_diff_scalar_solve(vdn_layout *mla, vdn_multifab *snew, const vdn_multifa
 void do_hgproject(int proj_type, vdn_layout *mla, vdn_multifab **unew, vdn_multifab **uold, vdn_multifab **rhohalf,
                   vdn_multifab **p, vdn_multifab **gp, const double *dx, double dt, const vdn_bc_tower *bct, int press_comp0);
 int  nd_solve(vdn_multifab *rh, vdn_multifab *phi, const vdn_multifab *coeffs, const vdn_multifab *u, const double *dx,
-              const int bc[3][2], double rel_eps, double abs_eps, int max_iter, int *cycles, double *res0, double *res);
+              const int bc[3][2], double rel_eps, double abs_eps, int max_iter, int *cycles, double *res0, double *res, struct NdKeep *keep = nullptr);
 
 // dim2.hip: the dm = 2 path (one level, one box)
 void k2_mkvelforce(vdn_multifab *vf, const vdn_multifab *ext, const vdn_multifab *s, const vdn_multifab *gp, const vdn_multifab *lapu, double visc_fac);
