@@ -31,6 +31,8 @@ DEVI bool nd_is_dir(const NLev &L, int i, int j, int k) {
   return (i == 0 && L.dirlo[0]) || (i == L.n[0] && L.dirhi[0]) || (j == 0 && L.dirlo[1]) || (j == L.n[1] && L.dirhi[1]) ||
          (k == 0 && L.dirlo[2]) || (k == L.n[2] && L.dirhi[2]);
 }
+// nodes ON the faces of the box: the only ones whose stencil reaches ghost nodes
+DEVI bool nd_is_shell(const NLev &L, int i, int j, int k) { return i == 0 || i == L.n[0] || j == 0 || j == L.n[1] || k == 0 || k == L.n[2]; }
 
 // ---- the 27-point nodal operator -----------------------------------------------------------------------------------------------------
 // K phi = sum over the 8 cells c around the node of sigma_c * sum over the cell's 8 corners q of w[type(q)] phi_q, type = which
@@ -131,7 +133,7 @@ DEVI void nd_apply(const NLev &L, const double *__restrict__ phi, int i, int j, 
 // hand-over among 204 instructions per plane: the scheduler then hoists the loads of later steps, 214 VGPRs, occupancy 2, HG 17.8 -> 24.3 ms;
 // capped at 128 VGPRs it spills 340 B per lane, 38 ms.  The moves stay.)
 template <int MODE>
-__global__ void __launch_bounds__(256) kk_nd_march(NLev L, const double *__restrict__ phi, double *__restrict__ out, double omega, int kchunk, double *nrm) {
+__global__ void __launch_bounds__(256) kk_nd_march(NLev L, const double *__restrict__ phi, double *__restrict__ out, double omega, int kchunk, double *nrm, int shell_later) {
   const int lane = threadIdx.x;
   const int i = (int)blockIdx.x * 62 + lane - 1;
   const int j = blockIdx.y * blockDim.y + threadIdx.y;
@@ -175,7 +177,7 @@ __global__ void __launch_bounds__(256) kk_nd_march(NLev L, const double *__restr
         if (active) out[c] = v;
       } else {
         const double r = dir ? 0.0 : rhs - Kp;
-        if (active) { out[c] = r; rmax = nmax(rmax, fabs(r)); }
+        if (active) { out[c] = r; if (!(shell_later && nd_is_shell(L, i, j, k))) rmax = nmax(rmax, fabs(r)); }
       }
       #pragma unroll
       for (int b = 0; b < 3; b++)
@@ -204,7 +206,7 @@ DEVI double2 ld2(const double *p) { return *reinterpret_cast<const double2 *>(p)
 __device__ double g_nd_sink[128];
 __device__ int g_nd_dbg = 0;      // VDN_ND_DBG (probe only): 1 = no stencil arithmetic, 2 = no loads inside the march
 template <int MODE, int ROWS>
-__global__ void __launch_bounds__(64 * ROWS) kk_nd_march_pair(NLev L, const double *__restrict__ phi, double *__restrict__ out, double omega, int kchunk, double *nrm) {
+__global__ void __launch_bounds__(64 * ROWS) kk_nd_march_pair(NLev L, const double *__restrict__ phi, double *__restrict__ out, double omega, int kchunk, double *nrm, int shell_later) {
   const int lane = threadIdx.x;
   int bx, by, bz; xcd_tile(bx, by, bz);
   // (measured and rejected: all 64 lanes owning a pair -- whole 128-byte lines per wave row -- with the two outside columns from an extra
@@ -269,8 +271,8 @@ __global__ void __launch_bounds__(64 * ROWS) kk_nd_march_pair(NLev L, const doub
       } else {
         o.x = (dirA_ij || dirk) ? 0.0 : rhs.x - KpA;
         o.y = (!actB || dirB_ij || dirk) ? 0.0 : rhs.y - KpB;
-        if (actA) rmax = nmax(rmax, fabs(o.x));
-        if (actB) rmax = nmax(rmax, fabs(o.y));
+        if (actA && !(shell_later && nd_is_shell(L, ia, j, k))) rmax = nmax(rmax, fabs(o.x));
+        if (actB && !(shell_later && nd_is_shell(L, ia + 1, j, k))) rmax = nmax(rmax, fabs(o.y));
       }
       *reinterpret_cast<double2 *>(op) = o;
       #pragma unroll
@@ -292,6 +294,43 @@ __global__ void __launch_bounds__(64 * ROWS) kk_nd_march_pair(NLev L, const doub
 
 // (measured and rejected: a plane-per-workgroup form of the paired sweep -- a workgroup owns a 124 x 4 patch of ONE k-plane, the planes
 // shared through the XCD's L2 like the cell-centred colour pass, 14 sixteen-byte loads per pair of nodes: 0.224 ms against 0.150 ms)
+// ---- halo exchange next to a sweep ----------------------------------------------------------------------------
+// Only the nodes ON the faces of a box read ghost nodes.  A sweep is out of place (phi -> tmp, phi -> res), so the march may run over the
+// whole box while the halo of phi is still in flight on ctx().halo_stream -- its face nodes come out wrong -- and this kernel then
+// recomputes exactly those nodes once the halo has landed (the x faces own their edges and corners, the y faces the remaining edges).
+// With `shell_later` the march leaves the face nodes out of its residual norm; this kernel contributes theirs.
+template <int MODE>
+__global__ void __launch_bounds__(256) kk_nd_shell(NLev L, const double *__restrict__ phi, double *__restrict__ out, double omega, double *nrm) {
+  const int f = blockIdx.z, d = f >> 1, side = f & 1;
+  const int a = blockIdx.x * blockDim.x + threadIdx.x, b = blockIdx.y * blockDim.y + threadIdx.y;
+  const int da = d == 0 ? 1 : 0, db = d == 2 ? 1 : 2;
+  int q[3];
+  q[d] = side ? L.n[d] : 0; q[da] = a; q[db] = b;
+  bool act = q[da] <= L.n[da] && q[db] <= L.n[db];
+  if (d >= 1 && (q[0] == 0 || q[0] == L.n[0])) act = false;           // owned by an x face
+  if (d == 2 && (q[1] == 0 || q[1] == L.n[1])) act = false;           // owned by a y face
+  double rmax = 0.0;
+  if (act) {
+    const long c = nidx(L, q[0], q[1], q[2]);
+    const double p0 = phi[c];
+    const bool dir = nd_is_dir(L, q[0], q[1], q[2]);
+    double Kp, diag; nd_apply(L, phi, q[0], q[1], q[2], Kp, diag);
+    if (MODE == 0) {
+      double v = p0;
+      if (!dir && diag != 0.0) v = p0 + omega * ((L.b[c] - Kp) / diag);
+      out[c] = v;
+    } else {
+      const double r = dir ? 0.0 : L.b[c] - Kp;
+      out[c] = r; rmax = fabs(r);
+    }
+  }
+  if (MODE == 1 && nrm) block_atomic_max(nrm, rmax);
+}
+template <int MODE> static void nd_launch_shell(const NLev &L, const double *phi, double *out, double *nrm) {
+  const int m = std::max(L.n[0], std::max(L.n[1], L.n[2])) + 1;
+  hipLaunchKernelGGL((kk_nd_shell<MODE>), dim3((m + 63) / 64, (m + 3) / 4, 6), dim3(64, 4, 1), 0, ctx().stream, L, phi, out, ctx().prm.hg_omega, nrm);
+}
+
 // ghost nodes (and the periodic alias node n): periodic image, else zero
 __global__ void kk_nd_fill_nodes(NLev L, double *a) {
   const int i = (int)(blockIdx.x * blockDim.x + threadIdx.x) - 1;
@@ -566,7 +605,7 @@ static dim3 ng3(int nx, int ny, int nz) { return dim3((nx + 63) / 64, (ny + 3) /
 
 // slab thickness: enough workgroups to fill 256 CUs several times over, yet long enough marches to amortise the
 // two warm-up planes (overhead 2/kchunk)
-template <int MODE> static void nd_launch_march(const NLev &L, const double *phi, double *out, double *nrm) {
+template <int MODE> static void nd_launch_march(const NLev &L, const double *phi, double *out, double *nrm, int shell_later = 0) {
   const int nzp = L.n[2] + 1;
   const int tiles = ((L.n[0] + 62) / 62) * ((L.n[1] + 4) / 4);
   int kchunk = nzp;
@@ -574,18 +613,16 @@ template <int MODE> static void nd_launch_march(const NLev &L, const double *phi
   const int nch = (nzp + kchunk - 1) / kchunk;
   static const bool paired = !(getenv("VDN_ND_PAIR") && atoi(getenv("VDN_ND_PAIR")) == 0);
   if (paired && L.n[0] >= 127) {                   // 124 nodes per wave row
-    static const int rows = getenv("VDN_ND_ROWS") ? atoi(getenv("VDN_ND_ROWS")) : 4;
+    const int rows = 4;                          // (measured: 8 rows per workgroup 17.1 -> 18.7 ms of HG per step, 16 rows spill)
     const int npair = (L.n[0] + 2) / 2, gx = (npair + 61) / 62, gy = (L.n[1] + rows) / rows;
     static const int minwg = getenv("VDN_ND_MINWG") ? atoi(getenv("VDN_ND_MINWG")) : 2048;
     int kc = nzp;
     while (kc > 8 && gx * gy * ((nzp + kc - 1) / kc) < minwg) kc = (kc + 1) / 2;
     const dim3 g(gx, gy, (nzp + kc - 1) / kc);
-    if (rows == 8) hipLaunchKernelGGL((kk_nd_march_pair<MODE, 8>), g, dim3(64, 8, 1), 0, ctx().stream, L, phi, out, ctx().prm.hg_omega, kc, nrm);
-    else if (rows == 16) hipLaunchKernelGGL((kk_nd_march_pair<MODE, 16>), g, dim3(64, 16, 1), 0, ctx().stream, L, phi, out, ctx().prm.hg_omega, kc, nrm);
-    else hipLaunchKernelGGL((kk_nd_march_pair<MODE, 4>), g, NBLK, 0, ctx().stream, L, phi, out, ctx().prm.hg_omega, kc, nrm);
+    hipLaunchKernelGGL((kk_nd_march_pair<MODE, 4>), g, NBLK, 0, ctx().stream, L, phi, out, ctx().prm.hg_omega, kc, nrm, shell_later);
     return;
   }
-  hipLaunchKernelGGL(kk_nd_march<MODE>, dim3((L.n[0] + 62) / 62, (L.n[1] + 4) / 4, nch), NBLK, 0, ctx().stream, L, phi, out, ctx().prm.hg_omega, kchunk, nrm);
+  hipLaunchKernelGGL(kk_nd_march<MODE>, dim3((L.n[0] + 62) / 62, (L.n[1] + 4) / 4, nch), NBLK, 0, ctx().stream, L, phi, out, ctx().prm.hg_omega, kchunk, nrm, shell_later);
 }
 
 struct NBox { NLev L; int lo[3]; XPlan *hA = nullptr, *hB = nullptr; double *A = nullptr, *B = nullptr; };
@@ -719,6 +756,22 @@ static void nd_build(NDMG &M, const vdn_multifab *coeffs, const double *dx, cons
 
 // ---- distributed levels ------------------------------------------------------------------------------------------
 static void nd_halo_phi(NDLev &DL) { XPlan *P = DL.flip ? DL.halo_B : DL.halo_A; if (P) xplan_run(P); }
+// the halo of phi next to the sweep that reads it (see kk_nd_shell): when part of it comes from another rank (or VDN_OVERLAP=1, the
+// one-GPU rehearsal) the exchange runs on ctx().halo_stream and nd_halo_begin returns true -- the caller launches its marches, calls
+// nd_halo_end (the launch stream waits for the halo) and recomputes the face nodes; otherwise the exchange is done here, in line
+static bool nd_halo_begin(NDLev &DL) {
+  XPlan *P = DL.flip ? DL.halo_B : DL.halo_A;
+  if (!P) return false;
+  static const int ov_env = getenv("VDN_OVERLAP") ? atoi(getenv("VDN_OVERLAP")) : -1;
+  if (!(ov_env == 1 || (ov_env != 0 && xplan_has_remote(P)))) { xplan_run(P); return false; }
+  VdnCtx &c = ctx();
+  HIPCHK(hipEventRecord(c.ev_main, c.stream));                      // the phi the halo is packed from is complete
+  HIPCHK(hipStreamWaitEvent(c.halo_stream, c.ev_main, 0));
+  xplan_run(P, c.halo_stream);
+  HIPCHK(hipEventRecord(c.ev_halo, c.halo_stream));
+  return true;
+}
+static void nd_halo_end() { VdnCtx &c = ctx(); HIPCHK(hipStreamWaitEvent(c.stream, c.ev_halo, 0)); }
 // levels of at most 9^3 nodes held in ONE box: all sweeps in a single one-workgroup launch (launch-latency bound otherwise)
 static const long SMALL_LEVEL_NODES = 9L * 9 * 9;
 static void nd_jacobi_d(NDLev &DL, int nsweeps) {
@@ -731,19 +784,25 @@ static void nd_jacobi_d(NDLev &DL, int nsweeps) {
     return;
   }
   for (int s = 0; s < nsweeps; s++) {
-    nd_halo_phi(DL);
-    for (NBox &B : DL.boxes) {
-      nd_launch_march<0>(B.L, B.L.phi, B.L.tmp, nullptr);
-      std::swap(B.L.phi, B.L.tmp);
+    const bool ov = nd_halo_begin(DL);
+    for (NBox &B : DL.boxes) nd_launch_march<0>(B.L, B.L.phi, B.L.tmp, nullptr);
+    if (ov) {
+      nd_halo_end();
+      for (NBox &B : DL.boxes) nd_launch_shell<0>(B.L, B.L.phi, B.L.tmp, nullptr);
     }
+    for (NBox &B : DL.boxes) std::swap(B.L.phi, B.L.tmp);
     DL.flip = !DL.flip;
   }
 }
 static void nd_residual_d(NDMG &M, NDLev &DL, bool norm) {
-  nd_halo_phi(DL);
   if (norm) HIPCHK(hipMemsetAsync(M.d_nrm, 0, sizeof(double), ctx().stream));
+  const bool ov = nd_halo_begin(DL);
   for (NBox &B : DL.boxes)
-    nd_launch_march<1>(B.L, B.L.phi, B.L.res, norm ? M.d_nrm : nullptr);
+    nd_launch_march<1>(B.L, B.L.phi, B.L.res, norm ? M.d_nrm : nullptr, ov ? 1 : 0);
+  if (ov) {
+    nd_halo_end();
+    for (NBox &B : DL.boxes) nd_launch_shell<1>(B.L, B.L.phi, B.L.res, norm ? M.d_nrm : nullptr);
+  }
   if (DL.halo_res) xplan_run(DL.halo_res);
   if (norm) comm_allreduce_max_dev(M.d_nrm, 1);
 }
