@@ -339,6 +339,18 @@ struct MkDFix { MkPlain P; __device__ void operator()(int i, int j, int k, int d
 static bool batch_always() { static const bool b = getenv("VDN_GODUNOV_BATCH") && atoi(getenv("VDN_GODUNOV_BATCH")) != 0; return b; }
 // VDN_GOD_SLAB_BC=0: the round-1 marches with the boundary code inside (kept for comparison); default: interior marches + boundary slabs
 static bool slab_bc() { static const bool b = !(getenv("VDN_GOD_SLAB_BC") && atoi(getenv("VDN_GOD_SLAB_BC")) == 0); return b; }
+// one launch per stage for all boxes (descriptors) or one set of launches per box (arguments by value)?  A level of an adaptive
+// hierarchy (hundreds of 16^3 .. 32^3 boxes) is launch-bound box by box; a level of a few large boxes -- 512^3 cut into eight 256^3
+// boxes -- runs faster box by box: the by-value kernels carry no boundary code (boundary slabs) and need fewer registers (measured,
+// eight 256^3 boxes on one GPU: scalar 52 -> 42 ms, velocity 76 -> 54 ms per step).  VDN_GODUNOV_BATCH=1 forces the descriptors.
+static bool use_batched(const vdn_multifab *s) {
+  if (s->nfabs() == 0) return false;
+  if (batch_always()) return true;
+  if (s->nfabs() == 1) return false;
+  long cells = 0;
+  for (int b = 0; b < s->nfabs(); b++) cells += (long)(s->vbox[b].hi[0] - s->vbox[b].lo[0] + 1) * (s->vbox[b].hi[1] - s->vbox[b].lo[1] + 1) * (s->vbox[b].hi[2] - s->vbox[b].lo[2] + 1);
+  return !(s->nfabs() <= 16 && cells / s->nfabs() >= 96L * 96 * 96);
+}
 static bool plain_godunov() { static const bool p = getenv("VDN_GODUNOV_PLAIN") != nullptr; return p; }
 // parameters of the marching bodies: by value under the by-value kernels, references into the (constant) descriptor under the batched ones
 template <class T, bool R> struct Prm { typedef T type; };
@@ -841,7 +853,7 @@ void k_mkflux(const vdn_multifab *s, vdn_multifab **sedge, vdn_multifab **flux, 
   REQUIRE(s->ng >= 3 && umac[0]->ng >= 1 && force->ng >= 1 && mac_rhs->ng >= 1, "mkflux: ghost widths");
   const int bccomp = is_vel ? 0 : bct->dm;            // mkflux.f90:62-66
   hipStream_t st = ctx().stream;
-  if ((s->nfabs() > 1 || batch_always()) && s->nfabs() > 0 && !plain_godunov()) {            // every stage once for all boxes of the level
+  if (use_batched(s) && !plain_godunov()) {            // every stage once for all boxes of the level
     size_t mark = arena_mark();
     const int nb = s->nfabs();
     GodBatch<MkD> B; B.d.resize(nb);
@@ -1602,7 +1614,7 @@ void k_velpred(const vdn_multifab *u, vdn_multifab **umac, const vdn_multifab *f
   if (ctx().prm.dm == 2) { k2_velpred(u, umac, force, dx, dt, bct); return; }
   REQUIRE(u->nc == 3 && u->ng >= 3 && force->ng >= 1 && umac[0]->ng >= 1, "velpred: operand shapes");
   hipStream_t st = ctx().stream;
-  if ((u->nfabs() > 1 || batch_always()) && u->nfabs() > 0 && !plain_godunov()) {
+  if (use_batched(u) && !plain_godunov()) {
     size_t mark = arena_mark();
     const int nb = u->nfabs();
     GodBatch<VpD> B; B.d.resize(nb);
