@@ -23,7 +23,8 @@ def run_ranks(tmp_path, tag, nranks, decomp, n, nsteps, periodic, real_rccl=Fals
         env = dict(os.environ, VDN_WORKER_DEVICE_PER_RANK="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
         env.pop("VDN_RCCL_LIB", None)
     else:
-        env = dict(os.environ, VDN_RCCL_LIB=FAKE, FAKE_RCCL_DIR=str(tmp_path))
+        # VDN_OVERLAP=1: halo exchange on the second stream + shell kernels on every level (by default only boxes of >= 2^20 cells do)
+        env = dict(os.environ, VDN_RCCL_LIB=FAKE, FAKE_RCCL_DIR=str(tmp_path), VDN_OVERLAP=os.environ.get("VDN_OVERLAP", "1"))
     procs = [subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "_multirank_worker.py"), str(r), str(nranks), idfile, prefix]
                               + [str(x) for x in decomp] + [str(x) for x in n] + [str(nsteps), str(int(periodic))], env=env, cwd=ROOT)
              for r in range(nranks)]
@@ -113,7 +114,7 @@ def run_amr_ranks(tmp_path, tag, nranks, nlev, visc, mode="fixed", extra=()):
     if nranks > 1 and not os.path.exists(FAKE):
         subprocess.check_call(["make", "-s", "-C", os.path.dirname(FAKE)])
     idfile, prefix = str(tmp_path / (tag + ".id")), str(tmp_path / tag)
-    env = dict(os.environ, VDN_RCCL_LIB=FAKE, FAKE_RCCL_DIR=str(tmp_path))
+    env = dict(os.environ, VDN_RCCL_LIB=FAKE, FAKE_RCCL_DIR=str(tmp_path), VDN_OVERLAP=os.environ.get("VDN_OVERLAP", "1"))
     procs = [subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "_multirank_amr_worker.py"), str(r), str(nranks), idfile, prefix, str(nlev), str(visc), mode] + list(extra),
                               env=env, cwd=ROOT) for r in range(nranks)]
     try:

@@ -72,7 +72,11 @@ template <bool RHO = false> DEVI void cc_apply(const CLev &L, long c, double &Ap
 // split into the SHELL (the outermost layer: the only cells that read ghost values) and the INTERIOR.  interior_only = 1: a pass skips
 // the shell cells; they are updated afterwards, once the halo has landed, by kk_cc_gsrb_shell.  Cells of one colour do not read each
 // other, so the order inside a pass is free and the bits are those of the unsplit pass.
-DEVI bool cc_is_shell(const CLev &L, int i, int j, int k) { return i == 0 || i == L.n[0] - 1 || j == 0 || j == L.n[1] - 1 || k == 0 || k == L.n[2] - 1; }
+// `hm`: the faces of the box whose ghost cells come from the exchange (bit 2d + side; physical non-periodic faces read none)
+DEVI bool cc_is_shell(const CLev &L, int i, int j, int k, int hm) {
+  return ((hm & 1) && i == 0) || ((hm & 2) && i == L.n[0] - 1) || ((hm & 4) && j == 0) || ((hm & 8) && j == L.n[1] - 1) ||
+         ((hm & 16) && k == 0) || ((hm & 32) && k == L.n[2] - 1);
+}
 template <bool RHO> DEVI void cc_update_cell(const CLev &L, int i, int j, int k) {
   const long c = cidx(L, i, j, k);
   double Ap, diag; cc_apply<RHO>(L, c, Ap, diag, i, j, k);
@@ -84,21 +88,23 @@ template <bool RHO> DEVI void cc_gsrb_cell(const CLev &L, int color, int interio
   const int k = bz;
   const int i = 2 * (int)(bx * blockDim.x + threadIdx.x) + ((j + k + color) & 1);
   if (i >= L.n[0] || j >= L.n[1]) return;
-  if (interior_only && cc_is_shell(L, i, j, k)) return;
+  if (interior_only && cc_is_shell(L, i, j, k, interior_only)) return;
   cc_update_cell<RHO>(L, i, j, k);
 }
 // the shell cells of one colour: blockIdx.z = face (x-lo, x-hi, y-lo, y-hi, z-lo, z-hi); the x faces own their edges and corners, the y
 // faces the remaining edges, so that every shell cell is updated exactly once
-template <bool RHO> __global__ void __launch_bounds__(256) kk_cc_gsrb_shell(CLev L, int color) {
-  const int f = blockIdx.z, d = f >> 1, side = f & 1;
+template <bool RHO> __global__ void __launch_bounds__(256) kk_cc_gsrb_shell(CLev L, int color, int hm) {
+  int f = 0;
+  for (int z = blockIdx.z;; f++) if ((hm >> f) & 1) { if (z == 0) break; z--; }      // blockIdx.z-th face of the mask
+  const int d = f >> 1, side = f & 1;
   const int a = blockIdx.x * blockDim.x + threadIdx.x, b = blockIdx.y * blockDim.y + threadIdx.y;
   int q[3];
   const int da = d == 0 ? 1 : 0, db = d == 2 ? 1 : 2;
   q[d] = side ? L.n[d] - 1 : 0; q[da] = a; q[db] = b;
-  if (side && L.n[d] == 1) return;                                   // a one-cell-thick box: its single layer belongs to the lo face
+  if (side && L.n[d] == 1 && ((hm >> (2 * d)) & 1)) return;          // a one-cell-thick box: its single layer belongs to the lo face
   if (q[da] >= L.n[da] || q[db] >= L.n[db]) return;
-  if (d >= 1 && (q[0] == 0 || q[0] == L.n[0] - 1)) return;           // owned by an x face
-  if (d == 2 && (q[1] == 0 || q[1] == L.n[1] - 1)) return;           // owned by a y face
+  if (d >= 1 && (((hm & 1) && q[0] == 0) || ((hm & 2) && q[0] == L.n[0] - 1))) return;           // owned by an x face
+  if (d == 2 && (((hm & 4) && q[1] == 0) || ((hm & 8) && q[1] == L.n[1] - 1))) return;           // owned by a y face
   if ((q[0] + q[1] + q[2] + color) & 1) return;
   cc_update_cell<RHO>(L, q[0], q[1], q[2]);
 }
@@ -160,9 +166,9 @@ __global__ void __launch_bounds__(256) kk_cc_gsrb_rho_pair(CLev L, int color, in
   const int iA = 2 * t + par, iB = 2 * t + 1 - par;
   double Ap, diag;
   cc_apply_rho_vals(L, iA, jA, k, P.a, R.a, Ap, diag);
-  if (diag != 0.0 && !(interior_only && cc_is_shell(L, iA, jA, k))) L.phi[cpA + par] = P.a[0] + (sel2(RA, par) - Ap) / diag;
+  if (diag != 0.0 && !(interior_only && cc_is_shell(L, iA, jA, k, interior_only))) L.phi[cpA + par] = P.a[0] + (sel2(RA, par) - Ap) / diag;
   cc_apply_rho_vals(L, iB, jA + 1, k, P.b, R.b, Ap, diag);
-  if (diag != 0.0 && !(interior_only && cc_is_shell(L, iB, jA + 1, k))) L.phi[cpA + L.PX + 1 - par] = P.b[0] + (sel2(RB, 1 - par) - Ap) / diag;
+  if (diag != 0.0 && !(interior_only && cc_is_shell(L, iB, jA + 1, k, interior_only))) L.phi[cpA + L.PX + 1 - par] = P.b[0] + (sel2(RB, 1 - par) - Ap) / diag;
 }
 // the same pairing for the stored-coefficient pass (viscous / diffusive solves, the 128^3 level of the MAC solve, level 0 of the
 // composite solves): the face coefficients of the two cells come from nine aligned pairs (bx: rows j, j+1; by: rows j, j+1, j+2;
@@ -210,17 +216,18 @@ __global__ void __launch_bounds__(256) kk_cc_gsrb_pair(CLev L, int color, int in
   double Ap, diag;
   const int iA = 2 * t + par, iB = 2 * t + 1 - par;
   cc_apply_vals(L, P.a, bA, sel2(AA, par), L.alpha != nullptr, Ap, diag);
-  if (diag != 0.0 && !(interior_only && cc_is_shell(L, iA, jA, k))) L.phi[cpA + par] = P.a[0] + (sel2(RA, par) - Ap) / diag;
+  if (diag != 0.0 && !(interior_only && cc_is_shell(L, iA, jA, k, interior_only))) L.phi[cpA + par] = P.a[0] + (sel2(RA, par) - Ap) / diag;
   cc_apply_vals(L, P.b, bB, sel2(AB, 1 - par), L.alpha != nullptr, Ap, diag);
-  if (diag != 0.0 && !(interior_only && cc_is_shell(L, iB, jA + 1, k))) L.phi[cpA + sy + 1 - par] = P.b[0] + (sel2(RB, 1 - par) - Ap) / diag;
+  if (diag != 0.0 && !(interior_only && cc_is_shell(L, iB, jA + 1, k, interior_only))) L.phi[cpA + sy + 1 - par] = P.b[0] + (sel2(RB, 1 - par) - Ap) / diag;
 }
 __global__ void __launch_bounds__(256) kk_cc_gsrb(CLev L, int color, int interior_only) { cc_gsrb_cell<false>(L, color, interior_only); }
 __global__ void __launch_bounds__(256) kk_cc_gsrb_rho(CLev L, int color, int interior_only) { cc_gsrb_cell<true>(L, color, interior_only); }
-static inline void launch_gsrb_shell(const CLev &L, int color, hipStream_t st) {
+static inline void launch_gsrb_shell(const CLev &L, int color, hipStream_t st, int hm) {
+  if (!hm) return;
   const int m = std::max(L.n[0], std::max(L.n[1], L.n[2]));
-  const dim3 g((unsigned)((m + 63) / 64), (unsigned)((m + 3) / 4), 6);
-  if (L.rho) hipLaunchKernelGGL(kk_cc_gsrb_shell<true>, g, dim3(64, 4, 1), 0, st, L, color);
-  else hipLaunchKernelGGL(kk_cc_gsrb_shell<false>, g, dim3(64, 4, 1), 0, st, L, color);
+  const dim3 g((unsigned)((m + 63) / 64), (unsigned)((m + 3) / 4), (unsigned)__builtin_popcount(hm));
+  if (L.rho) hipLaunchKernelGGL(kk_cc_gsrb_shell<true>, g, dim3(64, 4, 1), 0, st, L, color, hm);
+  else hipLaunchKernelGGL(kk_cc_gsrb_shell<false>, g, dim3(64, 4, 1), 0, st, L, color, hm);
 }
 static inline void launch_gsrb(const CLev &L, int color, hipStream_t st, int interior_only = 0) {
   const dim3 blk(64, 4, 1), g((unsigned)(((L.n[0] + 1) / 2 + 63) / 64), (unsigned)((L.n[1] + 3) / 4), (unsigned)L.n[2]);
@@ -758,7 +765,7 @@ __global__ void kk_cc_prolong_tail(CLev F, CLev T, int c00, int c01, int c02) {
 }
 
 // ---- host side ------------------------------------------------------------------------------------------
-struct CBox { CLev L; int lo[3]; int gidx; };                    // one local box on one distributed level; lo = global index of its cell 0
+struct CBox { CLev L; int lo[3]; int gidx; int hmask = 63; /* faces whose ghost cells come from the halo exchange */ };                    // one local box on one distributed level; lo = global index of its cell 0
 struct CDLev { std::vector<CBox> boxes; XPlan *halo = nullptr; int ng[3]; /* global extents of the level */ bool single_box = false; };
 struct CCMG {
   std::vector<CDLev> dlev;          // distributed levels (finest first)
@@ -845,6 +852,13 @@ static void cc_build(CCMG &M, const vdn_multifab *rh, const double *dx, const in
       xb.push_back(x);
     }
     vdn_box lpd; for (int d = 0; d < 3; d++) { lpd.lo[d] = 0; lpd.hi[d] = (la->pd[lev].hi[d] - la->pd[lev].lo[d] + 1) / scale - 1; DL.ng[d] = lpd.hi[d] + 1; }
+    for (CBox &B : DL.boxes) {
+      B.hmask = 0;
+      for (int d = 0; d < 3; d++) {
+        if (B.lo[d] > 0 || M.per[d]) B.hmask |= 1 << (2 * d);
+        if (B.lo[d] + B.L.n[d] < DL.ng[d] || M.per[d]) B.hmask |= 2 << (2 * d);
+      }
+    }
     if (nb > 1 || M.per[0] || M.per[1] || M.per[2]) {
       HaloKey key{ la->uid, DL.boxes.empty() ? nullptr : (const void *)DL.boxes[0].L.phi, lev, (int)M.dlev.size(), M.per[0] | (M.per[1] << 1) | (M.per[2] << 2) };
       auto it = g_halo_cache.find(key);
@@ -861,9 +875,9 @@ static void cc_build(CCMG &M, const vdn_multifab *rh, const double *dx, const in
       if ((N & 1) || N <= 2) can = false;
     }
     if (can) for (int d = 0; d < 3; d++) REQUIRE(!(n[d] & 1), "cc multigrid: box extent %d is odd while the domain can still be coarsened", n[d]);
-    // several boxes: stop exchanging halos once the boxes get small (VDN_MG_AGGLOM, default 32) -- every level that stays distributed costs
-    // ~10 halo exchanges per V-cycle, the replicated tail of a 32^3-per-box level costs microseconds
-    static const int agglom = getenv("VDN_MG_AGGLOM") ? std::max(4, atoi(getenv("VDN_MG_AGGLOM"))) : 32;
+    // several boxes: stop exchanging halos once the boxes get small (VDN_MG_AGGLOM, default 64) -- every level that stays distributed costs
+    // ~10 latency-bound halo exchanges per V-cycle, the replicated tail below a 64^3-per-box level costs microseconds per pass
+    static const int agglom = getenv("VDN_MG_AGGLOM") ? std::max(4, atoi(getenv("VDN_MG_AGGLOM"))) : 64;
     const int min_dist = nb > 1 ? agglom : 4;
     for (int d = 0; d < 3; d++) if (n[d] / 2 < min_dist || ((n[d] / 2) & 1)) next_dist = false;
     if (!can) break;                                   // the domain cannot be coarsened: this level is the bottom
@@ -932,8 +946,15 @@ static void cc_gsrb_d(CCMG &M, CDLev &DL, int nsweeps) {
   // halo exchange next to the pass: when part of the halo comes from another rank (or VDN_OVERLAP=1, the one-GPU rehearsal) the packed
   // traffic -- pack kernels, the ncclSend / ncclRecv group, box-to-box copies, unpack kernels -- runs on ctx().halo_stream while the
   // launch stream updates the cells that read no ghost value; the one-cell shell follows when the halo has landed
+  // Only where the pass is long enough to hide something: boxes of at least VDN_OVERLAP_MIN cells (default 2^20; a 64^3 pass takes 5 us).
   static const int ov_env = getenv("VDN_OVERLAP") ? atoi(getenv("VDN_OVERLAP")) : -1;
-  const bool overlap = DL.halo && (ov_env == 1 || (ov_env != 0 && xplan_has_remote(DL.halo)));
+  static const long ov_min = getenv("VDN_OVERLAP_MIN") ? atol(getenv("VDN_OVERLAP_MIN")) : (1L << 20);
+  bool overlap = DL.halo && (ov_env == 1 || (ov_env != 0 && xplan_has_remote(DL.halo)));
+  if (overlap) {
+    long cells = 0;
+    for (const CBox &B : DL.boxes) cells = std::max(cells, (long)B.L.n[0] * B.L.n[1] * B.L.n[2]);
+    if (cells < ov_min && ov_env != 1) overlap = false;
+  }
   VdnCtx &c = ctx();
   for (int s = 0; s < nsweeps; s++) for (int color = 0; color < 2; color++) {
     if (!overlap) {
@@ -945,9 +966,9 @@ static void cc_gsrb_d(CCMG &M, CDLev &DL, int nsweeps) {
     HIPCHK(hipStreamWaitEvent(c.halo_stream, c.ev_main, 0));        // ... before its outermost layer is packed
     xplan_run(DL.halo, c.halo_stream);
     HIPCHK(hipEventRecord(c.ev_halo, c.halo_stream));
-    for (const CBox &B : DL.boxes) launch_gsrb(B.L, (color + B.lo[0] + B.lo[1] + B.lo[2]) & 1, c.stream, 1);
+    for (const CBox &B : DL.boxes) launch_gsrb(B.L, (color + B.lo[0] + B.lo[1] + B.lo[2]) & 1, c.stream, B.hmask);
     HIPCHK(hipStreamWaitEvent(c.stream, c.ev_halo, 0));
-    for (const CBox &B : DL.boxes) launch_gsrb_shell(B.L, (color + B.lo[0] + B.lo[1] + B.lo[2]) & 1, c.stream);
+    for (const CBox &B : DL.boxes) launch_gsrb_shell(B.L, (color + B.lo[0] + B.lo[1] + B.lo[2]) & 1, c.stream, B.hmask);
   }
 }
 static void cc_residual_d(CCMG &M, CDLev &DL, bool norm) {

@@ -32,7 +32,11 @@ DEVI bool nd_is_dir(const NLev &L, int i, int j, int k) {
          (k == 0 && L.dirlo[2]) || (k == L.n[2] && L.dirhi[2]);
 }
 // nodes ON the faces of the box: the only ones whose stencil reaches ghost nodes
-DEVI bool nd_is_shell(const NLev &L, int i, int j, int k) { return i == 0 || i == L.n[0] || j == 0 || j == L.n[1] || k == 0 || k == L.n[2]; }
+// `hm`: the faces of the box whose ghost nodes come from the exchange (bit 2d + side; the ghost nodes outside a physical face stay zero)
+DEVI bool nd_is_shell(const NLev &L, int i, int j, int k, int hm) {
+  return ((hm & 1) && i == 0) || ((hm & 2) && i == L.n[0]) || ((hm & 4) && j == 0) || ((hm & 8) && j == L.n[1]) ||
+         ((hm & 16) && k == 0) || ((hm & 32) && k == L.n[2]);
+}
 
 // ---- the 27-point nodal operator -----------------------------------------------------------------------------------------------------
 // K phi = sum over the 8 cells c around the node of sigma_c * sum over the cell's 8 corners q of w[type(q)] phi_q, type = which
@@ -177,7 +181,7 @@ __global__ void __launch_bounds__(256) kk_nd_march(NLev L, const double *__restr
         if (active) out[c] = v;
       } else {
         const double r = dir ? 0.0 : rhs - Kp;
-        if (active) { out[c] = r; if (!(shell_later && nd_is_shell(L, i, j, k))) rmax = nmax(rmax, fabs(r)); }
+        if (active) { out[c] = r; if (!(shell_later && nd_is_shell(L, i, j, k, shell_later))) rmax = nmax(rmax, fabs(r)); }
       }
       #pragma unroll
       for (int b = 0; b < 3; b++)
@@ -271,8 +275,8 @@ __global__ void __launch_bounds__(64 * ROWS) kk_nd_march_pair(NLev L, const doub
       } else {
         o.x = (dirA_ij || dirk) ? 0.0 : rhs.x - KpA;
         o.y = (!actB || dirB_ij || dirk) ? 0.0 : rhs.y - KpB;
-        if (actA && !(shell_later && nd_is_shell(L, ia, j, k))) rmax = nmax(rmax, fabs(o.x));
-        if (actB && !(shell_later && nd_is_shell(L, ia + 1, j, k))) rmax = nmax(rmax, fabs(o.y));
+        if (actA && !(shell_later && nd_is_shell(L, ia, j, k, shell_later))) rmax = nmax(rmax, fabs(o.x));
+        if (actB && !(shell_later && nd_is_shell(L, ia + 1, j, k, shell_later))) rmax = nmax(rmax, fabs(o.y));
       }
       *reinterpret_cast<double2 *>(op) = o;
       #pragma unroll
@@ -300,15 +304,17 @@ __global__ void __launch_bounds__(64 * ROWS) kk_nd_march_pair(NLev L, const doub
 // recomputes exactly those nodes once the halo has landed (the x faces own their edges and corners, the y faces the remaining edges).
 // With `shell_later` the march leaves the face nodes out of its residual norm; this kernel contributes theirs.
 template <int MODE>
-__global__ void __launch_bounds__(256) kk_nd_shell(NLev L, const double *__restrict__ phi, double *__restrict__ out, double omega, double *nrm) {
-  const int f = blockIdx.z, d = f >> 1, side = f & 1;
+__global__ void __launch_bounds__(256) kk_nd_shell(NLev L, const double *__restrict__ phi, double *__restrict__ out, double omega, double *nrm, int hm) {
+  int f = 0;
+  for (int z = blockIdx.z;; f++) if ((hm >> f) & 1) { if (z == 0) break; z--; }      // blockIdx.z-th face of the mask
+  const int d = f >> 1, side = f & 1;
   const int a = blockIdx.x * blockDim.x + threadIdx.x, b = blockIdx.y * blockDim.y + threadIdx.y;
   const int da = d == 0 ? 1 : 0, db = d == 2 ? 1 : 2;
   int q[3];
   q[d] = side ? L.n[d] : 0; q[da] = a; q[db] = b;
   bool act = q[da] <= L.n[da] && q[db] <= L.n[db];
-  if (d >= 1 && (q[0] == 0 || q[0] == L.n[0])) act = false;           // owned by an x face
-  if (d == 2 && (q[1] == 0 || q[1] == L.n[1])) act = false;           // owned by a y face
+  if (d >= 1 && (((hm & 1) && q[0] == 0) || ((hm & 2) && q[0] == L.n[0]))) act = false;           // owned by an x face
+  if (d == 2 && (((hm & 4) && q[1] == 0) || ((hm & 8) && q[1] == L.n[1]))) act = false;           // owned by a y face
   double rmax = 0.0;
   if (act) {
     const long c = nidx(L, q[0], q[1], q[2]);
@@ -326,9 +332,10 @@ __global__ void __launch_bounds__(256) kk_nd_shell(NLev L, const double *__restr
   }
   if (MODE == 1 && nrm) block_atomic_max(nrm, rmax);
 }
-template <int MODE> static void nd_launch_shell(const NLev &L, const double *phi, double *out, double *nrm) {
+template <int MODE> static void nd_launch_shell(const NLev &L, const double *phi, double *out, double *nrm, int hm) {
+  if (!hm) return;
   const int m = std::max(L.n[0], std::max(L.n[1], L.n[2])) + 1;
-  hipLaunchKernelGGL((kk_nd_shell<MODE>), dim3((m + 63) / 64, (m + 3) / 4, 6), dim3(64, 4, 1), 0, ctx().stream, L, phi, out, ctx().prm.hg_omega, nrm);
+  hipLaunchKernelGGL((kk_nd_shell<MODE>), dim3((m + 63) / 64, (m + 3) / 4, (unsigned)__builtin_popcount(hm)), dim3(64, 4, 1), 0, ctx().stream, L, phi, out, ctx().prm.hg_omega, nrm, hm);
 }
 
 // ghost nodes (and the periodic alias node n): periodic image, else zero
@@ -625,7 +632,7 @@ template <int MODE> static void nd_launch_march(const NLev &L, const double *phi
   hipLaunchKernelGGL(kk_nd_march<MODE>, dim3((L.n[0] + 62) / 62, (L.n[1] + 4) / 4, nch), NBLK, 0, ctx().stream, L, phi, out, ctx().prm.hg_omega, kchunk, nrm, shell_later);
 }
 
-struct NBox { NLev L; int lo[3]; XPlan *hA = nullptr, *hB = nullptr; double *A = nullptr, *B = nullptr; };
+struct NBox { NLev L; int lo[3]; int hmask = 63; XPlan *hA = nullptr, *hB = nullptr; double *A = nullptr, *B = nullptr; };
 struct NDLev { std::vector<NBox> boxes; XPlan *halo_A = nullptr, *halo_B = nullptr, *halo_res = nullptr, *halo_sig = nullptr; int ng[3]; bool flip = false; bool single_box = false; int per[3] = {0, 0, 0}; };
 struct NDMG {
   std::vector<NDLev> dlev; std::vector<NLev> tail; int per[3]; double *d_nrm;
@@ -687,6 +694,11 @@ static void nd_build(NDMG &M, const vdn_multifab *coeffs, const double *dx, cons
         for (int d = 0; d < 3; d++) {          // Dirichlet (outflow) flags only on DOMAIN faces
           B.L.dirlo[d] = (lo[d] == 0 && bc[d][0] == VDN_BC_DIR); B.L.dirhi[d] = (lo[d] + n[d] == lpd.hi[d] + 1 && bc[d][1] == VDN_BC_DIR);
         }
+        B.hmask = 0;
+        for (int d = 0; d < 3; d++) {
+          if (lo[d] > 0 || M.per[d]) B.hmask |= 1 << (2 * d);
+          if (lo[d] + n[d] < lpd.hi[d] + 1 || M.per[d]) B.hmask |= 2 << (2 * d);
+        }
         B.A = B.L.phi; B.B = B.L.tmp;
         xA.fv = nd_view(B.L, B.A, lo, 3); xB.fv = nd_view(B.L, B.B, lo, 3); xR.fv = nd_view(B.L, B.L.res, lo, 3); xc.fv = nd_view(B.L, B.L.sig, lo, 3);
         DL.boxes.push_back(B);
@@ -709,9 +721,9 @@ static void nd_build(NDMG &M, const vdn_multifab *coeffs, const double *dx, cons
     bool can = true, next_dist = true;
     for (int d = 0; d < 3; d++) { const int N = lpd.hi[d] + 1; if ((N & 1) || N <= 2) can = false; }
     if (can) for (int d = 0; d < 3; d++) REQUIRE(!(n[d] & 1), "nodal multigrid: box extent %d is odd while the domain can still be coarsened", n[d]);
-    // several boxes: stop exchanging halos once the boxes get small (VDN_MG_AGGLOM, default 32) -- every level that stays distributed costs
-    // ~10 halo exchanges per V-cycle, the replicated tail of a 32^3-per-box level costs microseconds
-    static const int agglom = getenv("VDN_MG_AGGLOM") ? std::max(4, atoi(getenv("VDN_MG_AGGLOM"))) : 32;
+    // several boxes: stop exchanging halos once the boxes get small (VDN_MG_AGGLOM, default 64) -- every level that stays distributed costs
+    // ~10 latency-bound halo exchanges per V-cycle, the replicated tail below a 64^3-per-box level costs microseconds per pass
+    static const int agglom = getenv("VDN_MG_AGGLOM") ? std::max(4, atoi(getenv("VDN_MG_AGGLOM"))) : 64;
     const int min_dist = nb > 1 ? agglom : 4;
     for (int d = 0; d < 3; d++) if (n[d] / 2 < min_dist || ((n[d] / 2) & 1)) next_dist = false;
     if (!can) break;
@@ -763,7 +775,10 @@ static bool nd_halo_begin(NDLev &DL) {
   XPlan *P = DL.flip ? DL.halo_B : DL.halo_A;
   if (!P) return false;
   static const int ov_env = getenv("VDN_OVERLAP") ? atoi(getenv("VDN_OVERLAP")) : -1;
-  if (!(ov_env == 1 || (ov_env != 0 && xplan_has_remote(P)))) { xplan_run(P); return false; }
+  static const long ov_min = getenv("VDN_OVERLAP_MIN") ? atol(getenv("VDN_OVERLAP_MIN")) : (1L << 20);     // see cc_gsrb_d
+  long nodes = 0;
+  for (const NBox &B : DL.boxes) nodes = std::max(nodes, (long)B.L.n[0] * B.L.n[1] * B.L.n[2]);
+  if (!(ov_env == 1 || (ov_env != 0 && xplan_has_remote(P) && nodes >= ov_min))) { xplan_run(P); return false; }
   VdnCtx &c = ctx();
   HIPCHK(hipEventRecord(c.ev_main, c.stream));                      // the phi the halo is packed from is complete
   HIPCHK(hipStreamWaitEvent(c.halo_stream, c.ev_main, 0));
@@ -788,7 +803,7 @@ static void nd_jacobi_d(NDLev &DL, int nsweeps) {
     for (NBox &B : DL.boxes) nd_launch_march<0>(B.L, B.L.phi, B.L.tmp, nullptr);
     if (ov) {
       nd_halo_end();
-      for (NBox &B : DL.boxes) nd_launch_shell<0>(B.L, B.L.phi, B.L.tmp, nullptr);
+      for (NBox &B : DL.boxes) nd_launch_shell<0>(B.L, B.L.phi, B.L.tmp, nullptr, B.hmask);
     }
     for (NBox &B : DL.boxes) std::swap(B.L.phi, B.L.tmp);
     DL.flip = !DL.flip;
@@ -798,10 +813,10 @@ static void nd_residual_d(NDMG &M, NDLev &DL, bool norm) {
   if (norm) HIPCHK(hipMemsetAsync(M.d_nrm, 0, sizeof(double), ctx().stream));
   const bool ov = nd_halo_begin(DL);
   for (NBox &B : DL.boxes)
-    nd_launch_march<1>(B.L, B.L.phi, B.L.res, norm ? M.d_nrm : nullptr, ov ? 1 : 0);
+    nd_launch_march<1>(B.L, B.L.phi, B.L.res, norm ? M.d_nrm : nullptr, ov ? B.hmask : 0);
   if (ov) {
     nd_halo_end();
-    for (NBox &B : DL.boxes) nd_launch_shell<1>(B.L, B.L.phi, B.L.res, norm ? M.d_nrm : nullptr);
+    for (NBox &B : DL.boxes) nd_launch_shell<1>(B.L, B.L.phi, B.L.res, norm ? M.d_nrm : nullptr, B.hmask);
   }
   if (DL.halo_res) xplan_run(DL.halo_res);
   if (norm) comm_allreduce_max_dev(M.d_nrm, 1);
