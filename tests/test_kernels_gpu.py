@@ -213,18 +213,21 @@ def test_physbc_fill_boundary_estdt(gpu, oracle, bcname):
 
 
 @pytest.mark.gpu
-def test_godunov_marching_equals_face_centred(gpu):
-    """the cell-centred k-marching stage kernels (default) and the face-centred one-thread-per-cell kernels
-    (VDN_GODUNOV_PLAIN=1, read at the first launch of the process, so run in a child process) agree bit for bit"""
+@pytest.mark.parametrize("shape", [(24, 22, 26), (70, 14, 33)])
+def test_godunov_marching_equals_face_centred(gpu, shape):
+    """three forms of the Godunov stages agree bit for bit: the default (mkflux: stages B + C + D fused into one march per component,
+    velpred: one march per stage), the unfused marches (VDN_GOD_FUSED=0) and the face-centred one-thread-per-cell kernels
+    (VDN_GODUNOV_PLAIN=1); the switches are read at the first launch of a process, hence the child processes.  The second shape spans
+    two x-tiles, three y-tiles and several k-chunks of the fused march; the faces carry all four boundary rules."""
     import os, subprocess, sys, textwrap
     code = textwrap.dedent("""
         import sys, hashlib
         sys.path.insert(0, %r)
         import numpy as np
         from varden_amd import advance as adv, boxlib as bl, capi
-        n = 24
+        n = %d
         bl.initialize(capi.default_params(), 0, 1, 0)
-        lo, hi = (0, 0, 0), (n - 1, n - 3, n + 1)
+        lo, hi = (0, 0, 0), (%d - 1, %d - 1, %d - 1)
         mla = bl.MLLayout([(lo, hi)], [[(lo, hi)]])
         bct = bl.BCTower(mla, [[bl.INLET, bl.OUTLET], [bl.SLIP_WALL, bl.NO_SLIP_WALL], [bl.NO_SLIP_WALL, bl.OUTLET]])
         rng = np.random.default_rng(7)
@@ -245,17 +248,17 @@ def test_godunov_marching_equals_face_centred(gpu):
         for m in umac + ue + se + [sf[d] for d in range(3)]:
             h.update(np.ascontiguousarray(m.to_numpy()).tobytes())
         print("HASH", h.hexdigest())
-    """ % os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    """ % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), max(shape), shape[0], shape[1], shape[2]))
     out = []
-    for plain in (False, True):
+    for extra in ({}, {"VDN_GOD_FUSED": "0"}, {"VDN_GODUNOV_PLAIN": "1"}, {"VDN_FUSED_KCHUNKS": "5"}):
         env = dict(os.environ)
-        env.pop("VDN_GODUNOV_PLAIN", None)
-        if plain:
-            env["VDN_GODUNOV_PLAIN"] = "1"
+        for k in ("VDN_GODUNOV_PLAIN", "VDN_GOD_FUSED", "VDN_FUSED_KCHUNKS"):
+            env.pop(k, None)
+        env.update(extra)
         r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
         assert r.returncode == 0, r.stderr[-2000:]
         out.append([l for l in r.stdout.splitlines() if l.startswith("HASH")][0])
-    assert out[0] == out[1]
+    assert out[0] == out[1] == out[2] == out[3], out
 
 
 def test_fused_sweeps_equal_colour_passes(gpu):

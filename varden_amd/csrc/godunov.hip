@@ -717,6 +717,349 @@ template <int NC, bool PF = false, bool BC = true> __global__ void __launch_boun
 }
 
 
+// ---- stages B + C + D in one march (one component per launch) ------------------------------------------------------------------
+// The three stages above exchange SI (3 fields per component) and SC (6 per component) through HBM: at 256^3 the velocity mkflux moves
+// 18 GB against 2.5 GB of algorithmic traffic (profiles/r02_godunov_pmc.md).  Here a workgroup keeps them in registers: iteration kk of
+// the march loads plane kk and runs stage B on plane kk, stage C on plane kk-1 (its upper z-face SI is B's output of this iteration) and
+// stage D on plane kk-2 (its upper z-face SC is C's output of this iteration).  A cell's upper x-face value is the next lane's lower-face
+// value (DPP), its upper y-face value the next row's (LDS, written one iteration earlier), its own left states come from the previous
+// lane / row / plane exactly as in the separate stages.  A tile therefore owns lanes 1..62 and rows 1..TNY-2: the transverse couplings
+// alternate direction from stage to stage, so the footprint of an output face is one cell either side, not one per stage.
+// Every expression is the one of mk_B_m_body / mk_C_m_body / mk_D_m_body in the same order: bit-identical results
+// (tests/test_kernels_gpu.py::test_mkflux, test_godunov_marching_equals_face_centred).  Reads per component: s, three slopes, three MAC
+// components (+ their upper faces), force, mac_rhs; writes: three edge states (+ fluxes of conservative components).
+// Memory access: the launch carries, per field, the address of plane KB = lo_z - 1 of the component (bytes) and the bytes per plane; a thread
+// keeps ONE 32-bit byte offset per field layout for its (i,j) column and the workgroup advances uniform plane pointers (scalar registers)
+// as the march proceeds -- no per-load index arithmetic (15 fields x fv_idx per plane cost ~150 VALU / ~180 SALU instructions per plane in
+// the first version, and the 40-byte FV descriptors 170 spilled SGPRs).  The quotients of launch constants that the separate stages
+// compute per cell -- dt/3/dx, dt/6/dx, ... -- are evaluated once on the host (the same IEEE operations on the same operands).
+struct FGeo { int a0, a1, n0; };
+struct FArgs {
+  const char *p[9];       // s, sl0, sl1, sl2, um, vm, wm, force, macrhs: plane KB of the component
+  long sp[7];             // bytes per plane: s, slopes, um, vm, wm, force, macrhs
+  FGeo g[7];
+  char *q[6];             // sex, sey, sez, flx, fly, flz
+  long sq[3]; FGeo h[3];  // x-, y-, z-face outputs (edge state and flux of one direction share a layout)
+  long s_row, vm_row;     // bytes per row of s / vm
+  double dt2, dx[3], tC[3], tD[3], aD[3];   // tC[T] = (cons ? dt/3 : dt/6) / dx[T],  tD[T] = (cons ? dt/2 : dt/4) / dx[T],  aD[T] = (dt/2) / dx[T]
+  int lo[3], hi[3], phys[3][2];
+  int cons, use_minion, is_vel, c;
+};
+static bool bc_mode_host(int phys) { return phys == VDN_INLET || phys == VDN_SLIP_WALL || phys == VDN_NO_SLIP_WALL || phys == VDN_OUTLET; }
+static bool same_geom(const FV &a, const FV &b) { return a.a0 == b.a0 && a.a1 == b.a1 && a.a2 == b.a2 && a.n0 == b.n0 && a.n1 == b.n1; }
+DEVI unsigned fg_off(const FGeo &G, int i, int j) { return 8u * (unsigned)((i - G.a0) + G.n0 * (j - G.a1)); }
+DEVI double ldd(const char *q, unsigned o) { return *(const double *)(q + o); }
+DEVI void std_(char *q, unsigned o, double v) { *(double *)(q + o) = v; }
+struct FCell { double m_lo[3], m_up[3], s0, f, mr, Lb[3], Rb[3]; };      // a cell's loads and its bases (before any boundary rule)
+// mk_bases with the launch constants of FArgs: the bases of stage B (force / mac_rhs terms inside only with use_minion); stages C and D of
+// the separate kernels recompute the same ones -- six f64 divisions per cell and stage -- here they ride along with the cell
+DEVI void f_bases(const FArgs &F, FCell &P, const double sl[3]) {
+  double ft = 0.0, mt = 0.0;
+  if (F.use_minion) { ft = F.dt2 * P.f; mt = F.dt2 * P.s0 * P.mr; }
+  #pragma unroll
+  for (int d = 0; d < 3; d++) {
+    double Lb = P.s0 + (0.5 - F.dt2 * P.m_up[d] / F.dx[d]) * sl[d];
+    double Rb = P.s0 - (0.5 + F.dt2 * P.m_lo[d] / F.dx[d]) * sl[d];
+    if (F.use_minion) {
+      Lb = Lb + ft; Rb = Rb + ft;
+      if (F.cons) { Lb = Lb - mt; Rb = Rb - mt; }
+    }
+    P.Lb[d] = Lb; P.Rb[d] = Rb;
+  }
+}
+DEVI double tvq(bool cons, double q, double sp, double s0, double mp, double m0) {     // tv with its quotient (fcons / dxT or fconv / dxT) given
+  if (cons) return q * (sp * mp - s0 * m0);
+  return q * (mp + m0) * (sp - s0);
+}
+constexpr int FNX = 62, FNY = TNY - 2;      // cells a tile owns per row / rows it owns
+static dim3 fused_grid(const Range3 &r, int &klen) {
+  // one 512-thread workgroup per CU at a time: the chunk count is the one that fills the last round of workgroups best
+  const int nx = r.hi[0] - r.lo[0] + 1, ny = r.hi[1] - r.lo[1] + 1, nz = r.hi[2] - r.lo[2] + 1;
+  const int tiles = ((nx + FNX - 1) / FNX) * ((ny + FNY - 1) / FNY);
+  static const int env = getenv("VDN_FUSED_KCHUNKS") ? std::max(1, atoi(getenv("VDN_FUSED_KCHUNKS"))) : 0;
+  int best = 1; double best_cost = 1e300;
+  for (int ch = 1; ch <= 16 && ch <= nz; ch++) {
+    const int kl = (nz + ch - 1) / ch, nch = (nz + kl - 1) / kl;
+    const double cost = std::ceil((double)tiles * nch / 256.0) * (kl + 4);      // rounds x iterations per workgroup
+    if (cost < best_cost) { best_cost = cost; best = ch; }
+  }
+  const int chunks = env ? env : best;
+  klen = (nz + chunks - 1) / chunks; if (klen < 1) klen = 1;
+  return dim3((nx + FNX - 1) / FNX, (ny + FNY - 1) / FNY, (nz + klen - 1) / klen);
+}
+// The boundary rules in compact form.  bc_pair always leaves L = R = v, and upwind_mac(v, v, .) = v, so on a physical boundary face every
+// stage's output IS v -- the inflow value, zero, the inner state, or the inner state clamped (bc_pair / mk_edge_bc: the same four cases):
+//   mode 1: ghost value   2: zero   3: inner state   4: inner state, min(.,0) on a lo face / max(.,0) on a hi face
+// and the "premod" of stages C and D is the same v applied to the base of the cell next to the face.
+DEVI int bc_mode(int phys, bool is_vel, bool normal) {
+  if (phys == VDN_INLET) return 1;
+  if (phys == VDN_SLIP_WALL) return (is_vel && normal) ? 2 : 3;
+  if (phys == VDN_NO_SLIP_WALL) return is_vel ? 2 : 3;
+  if (phys == VDN_OUTLET) return (is_vel && normal) ? 4 : 3;
+  return 0;
+}
+DEVI double bc_v(int m, int side, double in, double ghost) {
+  double v = in;
+  if (m == 4) v = side ? fmax(in, 0.0) : fmin(in, 0.0);
+  if (m == 2) v = 0.0;
+  if (m == 1) v = ghost;
+  return v;
+}
+template <bool BC, bool INL> __device__ __forceinline__ void mk_F_m_body(const FArgs &F, const Range3 &r, int klen, const double *umax, const int BX, const int BY, const int BZ) {
+  __shared__ double lB[2][TNY][64], lSI[2][TNY][64], lC[2][2][TNY][64], lSC[2][2][TNY][64], lD[2][TNY][64];
+  const int lane = threadIdx.x, row = threadIdx.y;
+  const int i = r.lo[0] - 1 + BX * FNX + lane, j = r.lo[1] - 1 + BY * FNY + row;
+  const bool own_ij = lane >= 1 && lane <= FNX && row >= 1 && row <= FNY && i <= r.hi[0] && j <= r.hi[1];
+  const int ic = min(max(i, F.lo[0] - 1), F.hi[0] + 1), jc = min(max(j, F.lo[1] - 1), F.hi[1] + 1);
+  const bool ing_ij = i == ic && j == jc;                            // a cell of the grown box
+  const bool vx = i >= F.lo[0] && i <= F.hi[0], vy = j >= F.lo[1] && j <= F.hi[1];
+  const int rowm = row >= 1 ? row - 1 : 0, rowp = row + 1 < TNY ? row + 1 : TNY - 1;
+  const int k0 = r.lo[2] + BZ * klen, k1 = min(k0 + klen - 1, r.hi[2]);
+  const int KB = F.lo[2] - 1, KT = F.hi[2] + 1;                       // the planes loads are clamped to
+  const double eps = eps_from(umax);
+  const bool cons = F.cons != 0;
+  // the thread's column in every field layout
+  const unsigned o_s = fg_off(F.g[0], ic, jc), o_sl = fg_off(F.g[1], ic, jc), o_um = fg_off(F.g[2], ic, jc), o_vm = fg_off(F.g[3], ic, jc), o_wm = fg_off(F.g[4], ic, jc);
+  const unsigned o_f = fg_off(F.g[5], ic, jc), o_mr = fg_off(F.g[6], ic, jc);
+  const unsigned o_ex = fg_off(F.h[0], i, j), o_ey = fg_off(F.h[1], i, j), o_ez = fg_off(F.h[2], i, j);
+  // boundary modes of this component: the face rule of the cell's lower x / y face (fm*, side fs*), the rule on the bases of the cells next
+  // to a face (pm*0: lowest valid cell, its R base; pm*1: highest valid cell, its L base); z: per plane, below
+  int mode[3][2];
+  #pragma unroll
+  for (int d = 0; d < 3; d++) { mode[d][0] = BC ? bc_mode(F.phys[d][0], F.is_vel != 0, F.c == d) : 0; mode[d][1] = BC ? bc_mode(F.phys[d][1], F.is_vel != 0, F.c == d) : 0; }
+  // The rules that apply to this thread, packed into one word of 4-bit fields holding a code (0 none, 1 ghost value, 2 zero, 3 inner state,
+  // 4 min(inner, 0), 5 max(inner, 0)):  field 0: the cell's lower x-face is a boundary face (+8: the hi one), 1: the cell is the lowest valid cell
+  // along x (rule on its R base), 2: the highest (L base); fields 3..5: the same along y.  The z direction has the same word per plane, uniform.
+  // Inside a flagged (rare, divergent) branch the code is decoded with a few selects; the word is laundered through an empty asm in every
+  // stage so that the decode is not hoisted out of the march (as 64-bit masks: 186 spilled SGPRs in the first version).
+  int cd[3][2];
+  #pragma unroll
+  for (int d = 0; d < 3; d++) { cd[d][0] = mode[d][0] == 4 ? 4 : mode[d][0]; cd[d][1] = mode[d][1] == 4 ? 5 : mode[d][1]; }
+  int bcw = 0;
+  if (BC) {
+    if (ing_ij && i == F.lo[0]) bcw |= cd[0][0];
+    if (ing_ij && i == F.hi[0] + 1 && cd[0][1]) bcw |= cd[0][1] | 8;
+    if (ic == F.lo[0]) bcw |= cd[0][0] << 4;
+    if (ic == F.hi[0]) bcw |= cd[0][1] << 8;
+    if (ing_ij && j == F.lo[1]) bcw |= cd[1][0] << 12;
+    if (ing_ij && j == F.hi[1] + 1 && cd[1][1]) bcw |= (cd[1][1] | 8) << 12;
+    if (jc == F.lo[1]) bcw |= cd[1][0] << 16;
+    if (jc == F.hi[1]) bcw |= cd[1][1] << 20;
+  }
+  // per-thread plane pointers (the thread's column in each field): inputs at the plane the next loads take (kcur), outputs at the plane stage D
+  // emits next.  Fifteen uniform pointers plus their strides do not fit the scalar register file next to everything else (they were
+  // spilled to VGPR lanes and read back every plane); per-thread pointers cost the one 64-bit add per load that forming the address cost anyway.
+  int kcur = min(max(k0 - 2, KB), KT);
+  const char *ps = F.p[0] + (long)(kcur - KB) * F.sp[0] + o_s, *psl0 = F.p[1] + (long)(kcur - KB) * F.sp[1] + o_sl, *psl1 = F.p[2] + (long)(kcur - KB) * F.sp[1] + o_sl, *psl2 = F.p[3] + (long)(kcur - KB) * F.sp[1] + o_sl;
+  const char *pum = F.p[4] + (long)(kcur - KB) * F.sp[2] + o_um, *pvm = F.p[5] + (long)(kcur - KB) * F.sp[3] + o_vm, *pwm = F.p[6] + (long)(kcur - KB) * F.sp[4] + o_wm;
+  const char *pf = F.p[7] + (long)(kcur - KB) * F.sp[5] + o_f, *pmr = F.p[8] + (long)(kcur - KB) * F.sp[6] + o_mr;
+  char *qex = F.q[0] + (long)(k0 - KB) * F.sq[0] + o_ex, *qey = F.q[1] + (long)(k0 - KB) * F.sq[1] + o_ey, *qez = F.q[2] + (long)(k0 - KB) * F.sq[2] + o_ez;
+  char *qfx = F.q[3] + (long)(k0 - KB) * F.sq[0] + o_ex, *qfy = F.q[4] + (long)(k0 - KB) * F.sq[1] + o_ey, *qfz = F.q[5] + (long)(k0 - KB) * F.sq[2] + o_ez;
+  FCell P0, P1, P2;
+  #define FZERO(P) { P.s0 = 0.0; P.f = 0.0; P.mr = 0.0; for (int d = 0; d < 3; d++) { P.m_lo[d] = 0.0; P.m_up[d] = 0.0; P.Lb[d] = 0.0; P.Rb[d] = 0.0; } }
+  FZERO(P0) FZERO(P1)
+  #undef FZERO
+  double LzB = 0.0, LzC[2] = { 0.0, 0.0 }, LzD = 0.0;
+  double si1[3] = { 0.0, 0.0, 0.0 };                                 // SI on the lower faces of the cell in plane kk-1
+  double qp[6] = { 0.0, 0.0, 0.0, 0.0, 0.0, 0.0 };                   // SC on the lower faces of the cell in plane kk-2
+  // ghost values of s for the inflow rule (mode 1), read only where it applies: plane kpl, dbytes along x / y from the thread's (clamped) cell
+  // (INL = false: the launch has no inflow face, the reads and their address arithmetic are compiled out)
+  #define S_AT(kpl, dbytes) (INL ? ldd(ps + (long)((kpl) - kcur) * F.sp[0] + (dbytes), 0u) : 0.0)
+  // v of the rule with code cd_ on the inner state `in`; the ghost value is evaluated only for the inflow rule
+  #define BC_V(v, code, in, ghost_expr) { const int cd_ = (code); const double in_ = (in); double v_ = in_;                      \
+      if (cd_ == 4) v_ = fmin(in_, 0.0); if (cd_ == 5) v_ = fmax(in_, 0.0); if (cd_ == 2) v_ = 0.0; if (cd_ == 1) v_ = (ghost_expr); v = v_; }
+  // the face rule on the upwinded value `out` of a lower face: field sh of word w; left state L, right state Rr, this cell's s, ghost of a lo face
+  #define FACE_BC(out, w, sh, L, Rr, s0_, ghost_expr) { const int f_ = ((w) >> (sh)) & 15;                                        \
+      if (f_) { const bool hi_ = (f_ & 8) != 0; double o_; BC_V(o_, f_ & 7, hi_ ? (L) : (Rr), hi_ ? (s0_) : (ghost_expr)) out = o_; } }
+  // the rule on the bases of the cells next to a face: fields shlo (R base of the lowest cell) and shhi (L base of the highest)
+  #define PREMOD(Lb_, Rb_, w, shlo, shhi, gl_expr, gh_expr) { const int a_ = ((w) >> (shlo)) & 7; if (a_) { double o_; BC_V(o_, a_, Rb_, gl_expr) Rb_ = o_; }  \
+                                                              const int b_ = ((w) >> (shhi)) & 7; if (b_) { double o_; BC_V(o_, b_, Lb_, gh_expr) Lb_ = o_; } }
+  // the word of the z direction for stage plane k (clamped kc): uniform
+  #define Z_WORD(k, kc) (BC ? ((((k) == (kc) && (k) == F.lo[2]) ? cd[2][0] : 0) | (((k) == (kc) && (k) == KT && cd[2][1]) ? (cd[2][1] | 8) : 0) | \
+                                (((kc) == F.lo[2]) ? cd[2][0] << 4 : 0) | (((kc) == F.hi[2]) ? cd[2][1] << 8 : 0)) : 0)
+  // a plane's twelve loads are issued one iteration ahead (N): at two waves per SIMD nothing else hides their latency, and an iteration's
+  // arithmetic (~500 VALU instructions per wave) is longer than the round trip
+  struct FRaw { double m_lo[3], m_up[3], s0, sl[3], f, mr; } N;
+  #define F_LOAD {                                                                                                \
+      N.m_lo[0] = ldd(pum, 0u); N.m_up[0] = ldd(pum, 8u);                                                         \
+      N.m_lo[1] = ldd(pvm, 0u); N.m_up[1] = ldd(pvm + F.vm_row, 0u);                                              \
+      N.m_lo[2] = ldd(pwm, 0u); N.m_up[2] = ldd(pwm + F.sp[4], 0u);                                               \
+      N.s0 = ldd(ps, 0u); N.sl[0] = ldd(psl0, 0u); N.sl[1] = ldd(psl1, 0u); N.sl[2] = ldd(psl2, 0u);               \
+      N.f = ldd(pf, 0u); N.mr = ldd(pmr, 0u); }
+  // move the input pointers to the (clamped) plane of march index kn
+  #define F_ADVANCE(kn) { const int kc_ = min(max((kn), KB), KT);                                                 \
+      if (kc_ != kcur) { ps += F.sp[0]; psl0 += F.sp[1]; psl1 += F.sp[1]; psl2 += F.sp[1]; pum += F.sp[2]; pvm += F.sp[3]; pwm += F.sp[4]; pf += F.sp[5]; pmr += F.sp[6]; kcur = kc_; } }
+  F_LOAD
+  F_ADVANCE(k0 - 1)
+  for (int kk = k0 - 2; kk <= k1 + 2; kk++) {
+    const int buf = kk & 1;
+    P2 = P1; P1 = P0;
+    {
+      #pragma unroll
+      for (int d = 0; d < 3; d++) { P0.m_lo[d] = N.m_lo[d]; P0.m_up[d] = N.m_up[d]; }
+      P0.s0 = N.s0; P0.f = N.f; P0.mr = N.mr;
+      const double sl[3] = { N.sl[0], N.sl[1], N.sl[2] };
+      if (kk < k1 + 2) { F_LOAD  F_ADVANCE(kk + 2) }
+      f_bases(F, P0, sl);
+    }
+    // ---------------- stage B, plane kk ----------------
+    double si0[3];
+    {
+      const int k = kk, kc = min(max(k, KB), KT);
+      const int zw = Z_WORD(k, kc);                                   // uniform
+      const double (&Lb)[3] = P0.Lb, (&Rb)[3] = P0.Rb;
+      lB[buf][row][lane] = Lb[1];
+      __syncthreads();
+      const double Lx = shfl_prev(Lb[0]), Ly = lB[buf][rowm][lane], Lzc = LzB;
+      LzB = Lb[2];
+      si0[0] = upwind_mac(Lx, Rb[0], P0.m_lo[0], eps);
+      si0[1] = upwind_mac(Ly, Rb[1], P0.m_lo[1], eps);
+      si0[2] = upwind_mac(Lzc, Rb[2], P0.m_lo[2], eps);
+      if (BC && k == kc) {
+        int w = bcw; asm volatile("" : "+v"(w));
+        if (w & 0xF00F) { FACE_BC(si0[0], w, 0, Lx, Rb[0], P0.s0, S_AT(kc, -8L)) FACE_BC(si0[1], w, 12, Ly, Rb[1], P0.s0, S_AT(kc, -F.s_row)) }
+        if ((zw & 15) && ing_ij) { FACE_BC(si0[2], zw, 0, Lzc, Rb[2], P0.s0, P1.s0) }
+      }
+      lSI[buf][row][lane] = si0[1];                                   // read by the row below in the next iteration
+    }
+    // ---------------- stage C, plane kk-1 ----------------
+    double qc[6] = { 0.0, 0.0, 0.0, 0.0, 0.0, 0.0 };
+    if (kk - 1 >= k0 - 1) {
+      const int k = kk - 1, kc = min(max(k, KB), KT);
+      const int zw = Z_WORD(k, kc);
+      double Lb[3] = { P1.Lb[0], P1.Lb[1], P1.Lb[2] }, Rb[3] = { P1.Rb[0], P1.Rb[1], P1.Rb[2] };
+      int wc = 0;
+      if (BC) {
+        wc = bcw; asm volatile("" : "+v"(wc));
+        if (wc & 0x770770) { PREMOD(Lb[0], Rb[0], wc, 4, 8, S_AT(kc, -8L), S_AT(kc, 8L)) PREMOD(Lb[1], Rb[1], wc, 16, 20, S_AT(kc, -F.s_row), S_AT(kc, F.s_row)) }
+        if (zw & 0x770) { PREMOD(Lb[2], Rb[2], zw, 4, 8, S_AT(kc - 1, 0L), S_AT(kc + 1, 0L)) }
+      }
+      const double su[3] = { lane_next(si1[0]), lSI[buf ^ 1][rowp][lane], si0[2] };       // SI on the upper faces
+      double t[3];
+      t[0] = tvq(cons, F.tC[0], su[0], si1[0], P1.m_up[0], P1.m_lo[0]);
+      t[1] = tvq(cons, F.tC[1], su[1], si1[1], P1.m_up[1], P1.m_lo[1]);
+      t[2] = tvq(cons, F.tC[2], su[2], si1[2], P1.m_up[2], P1.m_lo[2]);
+      double VL[3][2], VR[3][2];
+      VL[0][0] = Lb[0] - t[1]; VR[0][0] = Rb[0] - t[1]; VL[0][1] = Lb[0] - t[2]; VR[0][1] = Rb[0] - t[2];
+      VL[1][0] = Lb[1] - t[0]; VR[1][0] = Rb[1] - t[0]; VL[1][1] = Lb[1] - t[2]; VR[1][1] = Rb[1] - t[2];
+      VL[2][0] = Lb[2] - t[0]; VR[2][0] = Rb[2] - t[0]; VL[2][1] = Lb[2] - t[1]; VR[2][1] = Rb[2] - t[1];
+      lC[buf][0][row][lane] = VL[1][0]; lC[buf][1][row][lane] = VL[1][1];
+      __syncthreads();
+      double Lx[2], Ly[2], Lzc[2];
+      Lx[0] = shfl_prev(VL[0][0]); Lx[1] = shfl_prev(VL[0][1]);
+      Ly[0] = lC[buf][0][rowm][lane]; Ly[1] = lC[buf][1][rowm][lane];
+      Lzc[0] = LzC[0]; Lzc[1] = LzC[1];
+      LzC[0] = VL[2][0]; LzC[1] = VL[2][1];
+      qc[0] = upwind_mac(Lx[0], VR[0][0], P1.m_lo[0], eps); qc[1] = upwind_mac(Lx[1], VR[0][1], P1.m_lo[0], eps);
+      qc[2] = upwind_mac(Ly[0], VR[1][0], P1.m_lo[1], eps); qc[3] = upwind_mac(Ly[1], VR[1][1], P1.m_lo[1], eps);
+      qc[4] = upwind_mac(Lzc[0], VR[2][0], P1.m_lo[2], eps); qc[5] = upwind_mac(Lzc[1], VR[2][1], P1.m_lo[2], eps);
+      if (BC && k == kc) {
+        if (wc & 0xF00F) {
+          FACE_BC(qc[0], wc, 0, Lx[0], VR[0][0], P1.s0, S_AT(kc, -8L)) FACE_BC(qc[1], wc, 0, Lx[1], VR[0][1], P1.s0, S_AT(kc, -8L))
+          FACE_BC(qc[2], wc, 12, Ly[0], VR[1][0], P1.s0, S_AT(kc, -F.s_row)) FACE_BC(qc[3], wc, 12, Ly[1], VR[1][1], P1.s0, S_AT(kc, -F.s_row))
+        }
+        if ((zw & 15) && ing_ij) { FACE_BC(qc[4], zw, 0, Lzc[0], VR[2][0], P1.s0, P2.s0) FACE_BC(qc[5], zw, 0, Lzc[1], VR[2][1], P1.s0, P2.s0) }
+      }
+      lSC[buf][0][row][lane] = qc[2]; lSC[buf][1][row][lane] = qc[3];            // read by the row below in the next iteration
+    }
+    // ---------------- stage D, plane kk-2 ----------------
+    if (kk - 2 >= k0 - 1) {
+      const int k = kk - 2, kc = min(max(k, KB), KT);
+      const int zw = Z_WORD(k, kc);
+      const bool vz = k >= F.lo[2] && k <= F.hi[2];
+      const double (&m_lo)[3] = P2.m_lo, (&m_up)[3] = P2.m_up;
+      const double s0 = P2.s0;
+      const double ft = F.dt2 * P2.f, mt = F.dt2 * s0 * P2.mr;
+      double Lb[3] = { P2.Lb[0], P2.Lb[1], P2.Lb[2] }, Rb[3] = { P2.Rb[0], P2.Rb[1], P2.Rb[2] };
+      int wd = 0;
+      if (BC) {
+        wd = bcw; asm volatile("" : "+v"(wd));
+        if (wd & 0x770770) { PREMOD(Lb[0], Rb[0], wd, 4, 8, S_AT(kc, -8L), S_AT(kc, 8L)) PREMOD(Lb[1], Rb[1], wd, 16, 20, S_AT(kc, -F.s_row), S_AT(kc, F.s_row)) }
+        if (zw & 0x770) { PREMOD(Lb[2], Rb[2], zw, 4, 8, S_AT(kc - 1, 0L), S_AT(kc + 1, 0L)) }
+      }
+      // SC on the upper faces: x-faces from the next lane, y-faces from the next row (written in the previous iteration), z-faces from stage C above
+      const double q1[6] = { lane_next(qp[0]), lane_next(qp[1]), lSC[buf ^ 1][0][rowp][lane], lSC[buf ^ 1][1][rowp][lane], qc[4], qc[5] };
+      const double (&q0)[6] = qp;
+      double VL[3], VR[3];
+      const double a[3] = { F.aD[0] * s0 * (m_up[0] - m_lo[0]), F.aD[1] * s0 * (m_up[1] - m_lo[1]), F.aD[2] * s0 * (m_up[2] - m_lo[2]) };
+      #define CHAIN(Dd, T1, T2, n1, n2)                                                                    \
+        { const double t1 = tvq(cons, F.tD[T1], q1[n1], q0[n1], m_up[T1], m_lo[T1]);                         \
+          const double t2 = tvq(cons, F.tD[T2], q1[n2], q0[n2], m_up[T2], m_lo[T2]);                         \
+          double vl = Lb[Dd], vr = Rb[Dd];                                                                   \
+          vl = vl - t1; vr = vr - t1; vl = vl - t2; vr = vr - t2;                                            \
+          if (cons) { vl = vl + a[T1]; vr = vr + a[T1]; vl = vl + a[T2]; vr = vr + a[T2]; }                  \
+          if (!F.use_minion) { vl = vl + ft; vr = vr + ft; if (cons) { vl = vl - mt; vr = vr - mt; } }       \
+          VL[Dd] = vl; VR[Dd] = vr; }
+      CHAIN(0, 1, 2, 3, 5)
+      CHAIN(1, 0, 2, 1, 4)
+      CHAIN(2, 0, 1, 0, 2)
+      #undef CHAIN
+      lD[buf][row][lane] = VL[1];
+      __syncthreads();
+      double L[3];
+      L[0] = shfl_prev(VL[0]); L[1] = lD[buf][rowm][lane]; L[2] = LzD; LzD = VL[2];
+      if (k >= k0) {
+        if (own_ij) {
+          double e[3];
+          e[0] = upwind_mac(L[0], VR[0], m_lo[0], eps); e[1] = upwind_mac(L[1], VR[1], m_lo[1], eps); e[2] = upwind_mac(L[2], VR[2], m_lo[2], eps);
+          if (BC) {
+            if (wd & 0xF00F) { FACE_BC(e[0], wd, 0, L[0], VR[0], s0, S_AT(kc, -8L)) FACE_BC(e[1], wd, 12, L[1], VR[1], s0, S_AT(kc, -F.s_row)) }
+            if (zw & 15) { FACE_BC(e[2], zw, 0, L[2], VR[2], s0, S_AT(kc - 1, 0L)) }
+          }
+          if (vy && vz) { std_(qex, 0u, e[0]); if (cons) std_(qfx, 0u, e[0] * m_lo[0]); }
+          if (vx && vz) { std_(qey, 0u, e[1]); if (cons) std_(qfy, 0u, e[1] * m_lo[1]); }
+          if (vx && vy) { std_(qez, 0u, e[2]); if (cons) std_(qfz, 0u, e[2] * m_lo[2]); }
+        }
+        qex += F.sq[0]; qfx += F.sq[0]; qey += F.sq[1]; qfy += F.sq[1]; qez += F.sq[2]; qfz += F.sq[2];
+      }
+    }
+    si1[0] = si0[0]; si1[1] = si0[1]; si1[2] = si0[2];
+    #pragma unroll
+    for (int n = 0; n < 6; n++) qp[n] = qc[n];
+  }
+  #undef F_LOAD
+  #undef F_ADVANCE
+  #undef S_AT
+  #undef BC_V
+  #undef FACE_BC
+  #undef PREMOD
+  #undef Z_WORD
+}
+template <bool BC = true, bool INL = true> __global__ void __launch_bounds__(64 * TNY) kk_mk_F_m(FArgs F, Range3 r, int klen, const double *umax) {
+  int bx_, by_, bz_; xcd_remap(bx_, by_, bz_);
+  mk_F_m_body<BC, INL>(F, r, klen, umax, bx_, by_, bz_);
+}
+// the launch arguments of the fused march for component c; false when the field layouts do not allow the shared offsets
+static bool fused_args(FArgs &F, const GArgs &A, int c, const FV &s, const FV sl[3], const FV &um, const FV &vm, const FV &wm, const FV &force, const FV &macrhs,
+                       const FV &sex, const FV &sey, const FV &sez, const FV &flx, const FV &fly, const FV &flz) {
+  if (!same_geom(sl[0], sl[1]) || !same_geom(sl[0], sl[2]) || !same_geom(sex, flx) || !same_geom(sey, fly) || !same_geom(sez, flz)) return false;
+  const int KB = A.lo[2] - 1;
+  const FV *in[9] = { &s, &sl[0], &sl[1], &sl[2], &um, &vm, &wm, &force, &macrhs };
+  const int comp[9] = { c, c, c, c, 0, 0, 0, c, 0 }, grp[9] = { 0, 1, 1, 1, 2, 3, 4, 5, 6 };
+  for (int f = 0; f < 9; f++) {
+    const FV &v = *in[f];
+    if (KB < v.a2 || A.hi[2] + 1 + (f == 6 ? 1 : 0) >= v.a2 + v.n2) return false;      // the clamped planes must exist (wm: one face more)
+    F.p[f] = (const char *)(v.p + v.sc * comp[f] + (long)v.n0 * v.n1 * (KB - v.a2));
+    F.sp[grp[f]] = 8L * v.n0 * v.n1; F.g[grp[f]] = FGeo{ v.a0, v.a1, v.n0 };
+  }
+  const FV *out[6] = { &sex, &sey, &sez, &flx, &fly, &flz };
+  for (int f = 0; f < 6; f++) {
+    const FV &v = *out[f];
+    F.q[f] = (char *)(v.p + v.sc * c + (long)v.n0 * v.n1 * (KB - v.a2));
+    if (f < 3) { F.sq[f] = 8L * v.n0 * v.n1; F.h[f] = FGeo{ v.a0, v.a1, v.n0 }; }
+  }
+  F.s_row = 8L * s.n0; F.vm_row = 8L * vm.n0;
+  const bool cons = A.cons[c] != 0;
+  const double dt2 = 0.5 * A.dt, dt3 = A.dt / 3.0, dt4 = A.dt / 4.0, dt6 = A.dt / 6.0;
+  F.dt2 = dt2;
+  for (int d = 0; d < 3; d++) {
+    F.dx[d] = A.dx[d]; F.tC[d] = (cons ? dt3 : dt6) / A.dx[d]; F.tD[d] = (cons ? dt2 : dt4) / A.dx[d]; F.aD[d] = dt2 / A.dx[d];
+    F.lo[d] = A.lo[d]; F.hi[d] = A.hi[d]; F.phys[d][0] = A.phys[d][0]; F.phys[d][1] = A.phys[d][1];
+  }
+  F.cons = cons ? 1 : 0; F.use_minion = A.use_minion; F.is_vel = A.is_vel; F.c = c;
+  return true;
+}
+
 // max |umac| over the valid faces of the three MAC components (mkflux.f90:1374-1396)
 __global__ void kk_macmax(FV um, FV vm, FV wm, GArgs A, Range3 r, double *out) {
   REDUCE_IJ(r)
@@ -940,7 +1283,25 @@ void k_mkflux(const vdn_multifab *s, vdn_multifab **sedge, vdn_multifab **flux, 
         else if (ncomp == 3) hipLaunchKernelGGL((kk_mk_D_m<3, false, BCF>), gf, blk, 0, st, MK_ARGS_D(0));                     \
         else if (ncomp == 2) hipLaunchKernelGGL((kk_mk_D_m<2, false, BCF>), gf, blk, 0, st, MK_ARGS_D(0));                     \
         else hipLaunchKernelGGL((kk_mk_D_m<1, false, BCF>), gf, blk, 0, st, MK_ARGS_D(0));
-      if (slab_bc()) {             // interior marches, then the face-centred code on the boundary slabs (see kk_slabs)
+      static const bool fused_env = !(getenv("VDN_GOD_FUSED") && atoi(getenv("VDN_GOD_FUSED")) == 0);
+      FArgs FA[3];
+      bool fused = fused_env;
+      for (int c0 = 0; c0 < ncomp && fused; c0++)
+        fused = fused_args(FA[c0], A, c0, s->fabs[ib], sl, um, vm, wm, force->fabs[ib], mac_rhs->fabs[ib], sedge[0]->fabs[ib], sedge[1]->fabs[ib], sedge[2]->fabs[ib],
+                           flux[0]->fabs[ib], flux[1]->fabs[ib], flux[2]->fabs[ib]);
+      if (fused) {                 // stages B + C + D in one march per component, boundary rules inside (see mk_F_m_body)
+        int klF;
+        const dim3 gF = fused_grid(rf, klF);
+        for (int c0 = 0; c0 < ncomp; c0++) {
+          bool inflow = false;
+          for (int d = 0; d < 3; d++) inflow = inflow || A.phys[d][0] == VDN_INLET || A.phys[d][1] == VDN_INLET;
+          bool any = false;
+          for (int d = 0; d < 3; d++) for (int sd = 0; sd < 2; sd++) any = any || bc_mode_host(A.phys[d][sd]);
+          if (!any) hipLaunchKernelGGL((kk_mk_F_m<false, false>), gF, blk, 0, st, FA[c0], rf, klF, umax);      // no physical face on this box
+          else if (inflow) hipLaunchKernelGGL((kk_mk_F_m<true, true>), gF, blk, 0, st, FA[c0], rf, klF, umax);
+          else hipLaunchKernelGGL((kk_mk_F_m<true, false>), gF, blk, 0, st, FA[c0], rf, klF, umax);
+        }
+      } else if (slab_bc()) {      // interior marches, then the face-centred code on the boundary slabs (see kk_slabs)
         const MkPlain P{ s->fabs[ib], sl[0], sl[1], sl[2], um, vm, wm, force->fabs[ib], mac_rhs->fabs[ib], SI, SC,
                          sedge[0]->fabs[ib], sedge[1]->fabs[ib], sedge[2]->fabs[ib], flux[0]->fabs[ib], flux[1]->fabs[ib], flux[2]->fabs[ib], A, umax };
         const Slabs Sg = boundary_slabs(A, rg), Sf = boundary_slabs(A, rf);
