@@ -602,6 +602,88 @@ __global__ void __launch_bounds__(1024) kk_cc_bottom(CLev L, int nsweeps, int pe
   }
 }
 
+// ---- the small end of a V-cycle in one launch (see kk_nd_tailcycle in mg_nd.hip) -------------------------------------------------------------
+// Levels of at most 8^3 cells: smoothing, residual, restriction, bottom sweeps and prolongation by ONE workgroup, the per-cell code of
+// kk_cc_bottom / cc_residual_body / kk_cc_restrict / kk_cc_prolong in the same order with barriers where the launches ended.
+#define CC_TAIL_MAX 4
+struct CcTailArgs { CLev L[CC_TAIL_MAX]; int nlev, nu1, nu2, nbot, per[3]; };
+DEVI void wg_cc_periodic(const CLev &L, const int per[3]) {
+  if (!(per[0] || per[1] || per[2])) return;
+  const int m = max(L.n[0], max(L.n[1], L.n[2]));
+  for (int t = threadIdx.x; t < 6 * m * m; t += blockDim.x) {
+    const int face = t / (m * m), a = (t / m) % m, b = t % m;
+    const int d = face >> 1, sd = face & 1;
+    const int t1 = (d == 0) ? 1 : 0, t2 = (d == 2) ? 1 : 2;
+    if (per[d] && a < L.n[t1] && b < L.n[t2]) {
+      int g[3], q[3];
+      g[t1] = q[t1] = a; g[t2] = q[t2] = b;
+      g[d] = sd ? L.n[d] : -1; q[d] = sd ? 0 : L.n[d] - 1;
+      L.phi[cidx(L, g[0], g[1], g[2])] = L.phi[cidx(L, q[0], q[1], q[2])];
+    }
+  }
+  __syncthreads();
+}
+DEVI void wg_cc_gsrb(const CLev &L, int nsweeps, const int per[3]) {
+  const int nx = L.n[0], ny = L.n[1], nz = L.n[2];
+  const int half = (nx + 1) / 2, tot = half * ny * nz;
+  for (int s = 0; s < nsweeps; s++) for (int color = 0; color < 2; color++) {
+    wg_cc_periodic(L, per);
+    for (int t = threadIdx.x; t < tot; t += blockDim.x) {
+      const int k = t / (half * ny), j = (t / half) % ny;
+      const int i = 2 * (t % half) + ((j + k + color) & 1);
+      if (i < nx) {
+        const long c = cidx(L, i, j, k);
+        double Ap, diag; cc_apply(L, c, Ap, diag);
+        if (diag != 0.0) L.phi[c] = L.phi[c] + (L.rh[c] - Ap) / diag;
+      }
+    }
+    __syncthreads();
+  }
+}
+DEVI void wg_cc_down(const CLev &F, const CLev &C, const int per[3]) {
+  wg_cc_periodic(F, per);
+  const int tot = F.n[0] * F.n[1] * F.n[2];
+  for (int t = threadIdx.x; t < tot; t += blockDim.x) {
+    const int i = t % F.n[0], j = (t / F.n[0]) % F.n[1], k = t / (F.n[0] * F.n[1]);
+    const long c = cidx(F, i, j, k);
+    double Ap, diag; cc_apply(F, c, Ap, diag, i, j, k);
+    F.res[c] = F.rh[c] - Ap;
+  }
+  __syncthreads();
+  const int ct = C.n[0] * C.n[1] * C.n[2];
+  const long sy = F.PX, sz = (long)F.PX * F.PY;
+  const double *r = F.res;
+  for (int t = threadIdx.x; t < ct; t += blockDim.x) {
+    const int i = t % C.n[0], j = (t / C.n[0]) % C.n[1], k = t / (C.n[0] * C.n[1]);
+    const long f = cidx(F, 2 * i, 2 * j, 2 * k);
+    double s = r[f] + r[f + 1] + r[f + sy] + r[f + sy + 1] + r[f + sz] + r[f + sz + 1] + r[f + sz + sy] + r[f + sz + sy + 1];
+    const long cc = cidx(C, i, j, k);
+    C.rh[cc] = s * 0.125;
+    C.phi[cc] = 0.0;
+  }
+  __syncthreads();
+}
+DEVI void wg_cc_up(const CLev &F, const CLev &C) {
+  const int tot = F.n[0] * F.n[1] * F.n[2];
+  for (int t = threadIdx.x; t < tot; t += blockDim.x) {
+    const int i = t % F.n[0], j = (t / F.n[0]) % F.n[1], k = t / (F.n[0] * F.n[1]);
+    const long f = cidx(F, i, j, k);
+    F.phi[f] = F.phi[f] + C.phi[cidx(C, i >> 1, j >> 1, k >> 1)];
+  }
+  __syncthreads();
+}
+__global__ void __launch_bounds__(1024) kk_cc_tailcycle(CcTailArgs T) {
+  #pragma unroll
+  for (int l = 0; l < CC_TAIL_MAX - 1; l++)
+    if (l < T.nlev - 1) { wg_cc_gsrb(T.L[l], T.nu1, T.per); wg_cc_down(T.L[l], T.L[l + 1], T.per); }
+  #pragma unroll
+  for (int l = 0; l < CC_TAIL_MAX; l++)
+    if (l == T.nlev - 1) wg_cc_gsrb(T.L[l], T.nbot, T.per);
+  #pragma unroll
+  for (int l = CC_TAIL_MAX - 2; l >= 0; l--)
+    if (l < T.nlev - 1) { wg_cc_up(T.L[l], T.L[l + 1]); wg_cc_gsrb(T.L[l], T.nu2, T.per); }
+}
+
 // ---- transfers between BoxLib-layout multifabs and level 0 ---------------------------------------------
 __global__ void kk_cc_load(CLev L, FV rh, FV phi, FV alpha, FV bx, FV by, FV bz, int lo0, int lo1, int lo2, int ebc00, int ebc01, int ebc10, int ebc11, int ebc20, int ebc21) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1009,8 +1091,38 @@ static void cc_bottom_t(const CCMG &M, const CLev &L) {      // max(nub, N^2) sw
   const int ns = std::max(ctx().prm.mg_nub, N * N);
   hipLaunchKernelGGL(kk_cc_bottom, dim3(1), dim3(1024), 0, ctx().stream, L, ns, M.per[0], M.per[1], M.per[2]);
 }
+// The small end of the hierarchy in one launch (kk_cc_tailcycle): distributed levels dl .. end when they are one box of at most 8^3 cells
+// each (dl < 0: none), then the replicated tail levels tl .. end (one rank and one box: the gather between the two is the plain restriction).
+static bool cc_small_end(const CCMG &M, int dl, int tl) {
+  static const bool on = !(getenv("VDN_MG_TAILCYCLE") && atoi(getenv("VDN_MG_TAILCYCLE")) == 0);
+  if (!on) return false;
+  const vdn_params &P = ctx().prm;
+  CcTailArgs T; memset(&T, 0, sizeof T);
+  int nl = 0;
+  if (dl >= 0) {
+    if (!M.tail.empty() && !(ctx().nranks == 1 && M.dlev.back().single_box)) return false;
+    for (int m = dl; m < (int)M.dlev.size(); m++) {
+      const CDLev &D = M.dlev[m];
+      if (!(D.single_box && D.boxes.size() == 1 && !D.boxes[0].L.phi2 && !D.boxes[0].L.rho && (long)D.ng[0] * D.ng[1] * D.ng[2] <= SMALL_LEVEL_CELLS) || nl == CC_TAIL_MAX) return false;
+      T.L[nl++] = D.boxes[0].L;
+    }
+  }
+  for (int m = tl; m < (int)M.tail.size(); m++) {
+    const CLev &L = M.tail[m];
+    if ((long)L.n[0] * L.n[1] * L.n[2] > SMALL_LEVEL_CELLS || nl == CC_TAIL_MAX) return false;
+    T.L[nl++] = L;
+  }
+  if (nl < 2) return false;
+  const CLev &B = T.L[nl - 1];
+  const int N = std::max(B.n[0], std::max(B.n[1], B.n[2]));
+  T.nlev = nl; T.nu1 = P.mg_nu1; T.nu2 = P.mg_nu2; T.nbot = std::max(P.mg_nub, N * N);      // cc_bottom_t / cc_vcycle_d
+  for (int d = 0; d < 3; d++) T.per[d] = M.per[d];
+  hipLaunchKernelGGL(kk_cc_tailcycle, dim3(1), dim3(1024), 0, ctx().stream, T);
+  return true;
+}
 static void cc_vcycle_t(const CCMG &M, int l) {
   const vdn_params &P = ctx().prm;
+  if (cc_small_end(M, -1, l)) return;
   const CLev &L = M.tail[l];                 // phi = 0 on entry: written by the restriction that feeds this level
   if (l == (int)M.tail.size() - 1) { cc_bottom_t(M, L); return; }
   const CLev &C = M.tail[l + 1];
@@ -1058,6 +1170,7 @@ static void cc_vcycle_d(CCMG &M, int l) {
   const vdn_params &P = ctx().prm;
   CDLev &DL = M.dlev[l];
   const bool last = (l == (int)M.dlev.size() - 1);      // phi = 0 on entry: written by the restriction that feeds this level
+  if (cc_small_end(M, l, 0)) return;
   if (last && M.tail.empty()) {         // nothing below: bottom sweeps on the distributed level itself
     const int N = std::max(DL.ng[0], std::max(DL.ng[1], DL.ng[2]));     // largest GLOBAL extent, as in the oracle
     cc_gsrb_d(M, DL, std::max(P.mg_nub, N * N));

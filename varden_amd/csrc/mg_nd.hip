@@ -501,6 +501,109 @@ __global__ void __launch_bounds__(1024) kk_nd_bottom(NLev L, double *a, double *
   }
 }
 
+// ---- the small end of a V-cycle in one launch ---------------------------------------------------------------------------------------------
+// Levels of at most 9^3 nodes (9^3, 5^3, 3^3 under a 257^3 solve) took 13 launches of 5-14 us per cycle -- smoothing, residual, restriction,
+// bottom sweeps, prolongation, each a one-workgroup grid -- 1.5 ms of an HG projection.  One workgroup runs the whole recursion here:
+// the same per-node code (nd_apply, the sums of kk_nd_restrict, nd_interp8) in the same order, barriers instead of launch boundaries.
+// L[0] is entered like any level of nd_vcycle_d (b set, phi = 0) and left with its correction in the array the host's swap parity names.
+#define ND_TAIL_MAX 4
+struct NdTailArgs { NLev L[ND_TAIL_MAX]; int nlev, nu1, nu2, nbot; double omega; };
+DEVI void wg_nd_fill(const NLev &L, double *a) {                     // nd_fill_nodes; ghost nodes outside a physical face stay zero
+  if (!(L.per[0] || L.per[1] || L.per[2])) return;
+  const int ex = L.n[0] + 3, ey = L.n[1] + 3, ez = L.n[2] + 3;
+  for (int t = threadIdx.x; t < ex * ey * ez; t += blockDim.x) {
+    const int i = t % ex - 1, j = (t / ex) % ey - 1, k = t / (ex * ey) - 1;
+    int q[3] = { i, j, k }, sidx[3] = { i, j, k }; bool g = false, zero = false;
+    for (int d = 0; d < 3; d++) {
+      if (L.per[d]) { if (q[d] < 0) { sidx[d] = q[d] + L.n[d]; g = true; } else if (q[d] >= L.n[d]) { sidx[d] = q[d] - L.n[d]; g = true; } }
+      else if (q[d] < 0 || q[d] > L.n[d]) { g = true; zero = true; }
+    }
+    if (g) a[nidx(L, i, j, k)] = zero ? 0.0 : a[nidx(L, sidx[0], sidx[1], sidx[2])];
+  }
+  __syncthreads();
+}
+DEVI void wg_nd_jacobi(const NLev &L, double *&src, double *&dst, int nsweeps, double omega) {
+  const int nx = L.n[0] + 1, ny = L.n[1] + 1, nz = L.n[2] + 1;
+  for (int s = 0; s < nsweeps; s++) {
+    wg_nd_fill(L, src);
+    for (int t = threadIdx.x; t < nx * ny * nz; t += blockDim.x) {
+      const int i = t % nx, j = (t / nx) % ny, k = t / (nx * ny);
+      const long c = nidx(L, i, j, k);
+      const double p0 = src[c];
+      double v = p0;
+      if (!nd_is_dir(L, i, j, k)) {
+        double Kp, diag; nd_apply(L, src, i, j, k, Kp, diag);
+        if (diag != 0.0) v = p0 + omega * ((L.b[c] - Kp) / diag);
+      }
+      dst[c] = v;
+    }
+    __syncthreads();
+    double *tsw = src; src = dst; dst = tsw;
+  }
+}
+DEVI void wg_nd_down(const NLev &F, double *fphi, const NLev &C, double *cphi) {     // residual of F, full weighting into C.b, cphi = 0
+  const int nx = F.n[0] + 1, ny = F.n[1] + 1, nz = F.n[2] + 1;
+  wg_nd_fill(F, fphi);
+  for (int t = threadIdx.x; t < nx * ny * nz; t += blockDim.x) {
+    const int i = t % nx, j = (t / nx) % ny, k = t / (nx * ny);
+    const long c = nidx(F, i, j, k);
+    double r = 0.0;
+    if (!nd_is_dir(F, i, j, k)) { double Kp, diag; nd_apply(F, fphi, i, j, k, Kp, diag); r = F.b[c] - Kp; }
+    F.res[c] = r;
+  }
+  __syncthreads();
+  wg_nd_fill(F, F.res);
+  const int cx = C.n[0] + 1, cy = C.n[1] + 1, cz = C.n[2] + 1;
+  const long sy = F.PX, sz = (long)F.PX * F.PY;
+  for (int t = threadIdx.x; t < cx * cy * cz; t += blockDim.x) {
+    const int i = t % cx, j = (t / cx) % cy, k = t / (cx * cy);
+    double s = 0.0;
+    if (!nd_is_dir(C, i, j, k)) {
+      const long f0 = nidx(F, 2 * i, 2 * j, 2 * k);
+      #pragma unroll
+      for (int c = -1; c <= 1; c++)
+        #pragma unroll
+        for (int b = -1; b <= 1; b++)
+          #pragma unroll
+          for (int a = -1; a <= 1; a++) {
+            const double wa = a ? 0.5 : 1.0, wb = b ? 0.5 : 1.0, wc = c ? 0.5 : 1.0;
+            s = s + (wa * wb * wc) * F.res[f0 + a + b * sy + c * sz];
+          }
+    }
+    const long cn = nidx(C, i, j, k);
+    C.b[cn] = s * 0.125;
+    cphi[cn] = 0.0;
+  }
+  __syncthreads();
+}
+DEVI void wg_nd_up(const NLev &F, double *fphi, const NLev &C, double *cphi) {       // fphi += trilinear interpolation of cphi
+  wg_nd_fill(C, cphi);
+  const int nx = F.n[0] + 1, ny = F.n[1] + 1, nz = F.n[2] + 1;
+  for (int t = threadIdx.x; t < nx * ny * nz; t += blockDim.x) {
+    const int i = t % nx, j = (t / nx) % ny, k = t / (nx * ny);
+    if (nd_is_dir(F, i, j, k)) continue;
+    const long f = nidx(F, i, j, k);
+    fphi[f] = fphi[f] + nd_interp8(C, cphi, i >> 1, j >> 1, k >> 1, i & 1, j & 1, k & 1);
+  }
+  __syncthreads();
+}
+// (The same with the levels copied into LDS for the duration was measured at 66 us per cycle against 57 us on the L2-resident arrays: a phase costs
+// ~2.5 us of dependent instructions of one wave per SIMD, not memory latency.)
+__global__ void __launch_bounds__(1024) kk_nd_tailcycle(NdTailArgs T) {
+  double *ph[ND_TAIL_MAX], *tm[ND_TAIL_MAX];
+  #pragma unroll
+  for (int l = 0; l < ND_TAIL_MAX; l++) { ph[l] = T.L[l].phi; tm[l] = T.L[l].tmp; }
+  #pragma unroll
+  for (int l = 0; l < ND_TAIL_MAX - 1; l++)
+    if (l < T.nlev - 1) { wg_nd_jacobi(T.L[l], ph[l], tm[l], T.nu1, T.omega); wg_nd_down(T.L[l], ph[l], T.L[l + 1], ph[l + 1]); }
+  #pragma unroll
+  for (int l = 0; l < ND_TAIL_MAX; l++)
+    if (l == T.nlev - 1) wg_nd_jacobi(T.L[l], ph[l], tm[l], T.nbot, T.omega);
+  #pragma unroll
+  for (int l = ND_TAIL_MAX - 2; l >= 0; l--)
+    if (l < T.nlev - 1) { wg_nd_up(T.L[l], ph[l], T.L[l + 1], ph[l + 1]); wg_nd_jacobi(T.L[l], ph[l], tm[l], T.nu2, T.omega); }
+}
+
 // ---- load / store / divergence -------------------------------------------------------------------------
 __global__ void kk_nd_load_sigma(NLev L, FV coeffs, int lo0, int lo1, int lo2) {
   const int i = (int)(blockIdx.x * blockDim.x + threadIdx.x) - 1;
@@ -845,11 +948,13 @@ static void nd_bottom_t(NLev &L) {          // max(nub, 2 N^2) sweeps (same rule
   hipLaunchKernelGGL(kk_nd_bottom, dim3(1), dim3(1024), 0, ctx().stream, L, L.phi, L.tmp, ns, ctx().prm.hg_omega);
   if (ns & 1) std::swap(L.phi, L.tmp);
 }
+static bool nd_small_end(NDMG &M, int dl, int tl);
 static void nd_vcycle_t(NDMG &M, int l) {
   const vdn_params &P = ctx().prm;
   NLev &L = M.tail[l];
   // phi = 0 on entry: deeper tail levels get it from kk_nd_restrict, the first one is filled by the generic gather/unpack
   if (l == 0) HIPCHK(hipMemsetAsync(L.phi, 0, sizeof(double) * L.sz, ctx().stream));
+  if (nd_small_end(M, -1, l)) return;
   if (l == (int)M.tail.size() - 1) { nd_bottom_t(L); return; }
   NLev &C = M.tail[l + 1];
   nd_jacobi_t(L, P.hg_nu1);
@@ -900,9 +1005,48 @@ static int nd_bottom_sweeps_global(const NDLev &DL) {
   const int N = std::max(DL.ng[0], std::max(DL.ng[1], DL.ng[2]));
   return std::max(ctx().prm.hg_nub, 2 * N * N);
 }
+// The small end of the hierarchy in one launch (kk_nd_tailcycle): distributed levels dl .. end when they are one box of at most 9^3 nodes
+// each (dl < 0: none), then the replicated tail levels tl .. end (one rank and one box: the gather between the two is the plain restriction).
+static bool nd_small_end(NDMG &M, int dl, int tl) {
+  static const bool on = !(getenv("VDN_MG_TAILCYCLE") && atoi(getenv("VDN_MG_TAILCYCLE")) == 0);
+  if (!on) return false;
+  const vdn_params &P = ctx().prm;
+  NdTailArgs T; memset(&T, 0, sizeof T);
+  int nl = 0;
+  if (dl >= 0) {
+    if (!M.tail.empty() && !(ctx().nranks == 1 && M.dlev.back().single_box)) return false;
+    for (int m = dl; m < (int)M.dlev.size(); m++) {
+      const NDLev &D = M.dlev[m];
+      if (!(D.single_box && D.boxes.size() == 1 && (long)(D.ng[0] + 1) * (D.ng[1] + 1) * (D.ng[2] + 1) <= SMALL_LEVEL_NODES) || nl == ND_TAIL_MAX) return false;
+      T.L[nl] = D.boxes[0].L; for (int d = 0; d < 3; d++) T.L[nl].per[d] = D.per[d];
+      nl++;
+    }
+  }
+  for (int m = tl; m < (int)M.tail.size(); m++) {
+    const NLev &L = M.tail[m];
+    if ((long)(L.n[0] + 1) * (L.n[1] + 1) * (L.n[2] + 1) > SMALL_LEVEL_NODES || nl == ND_TAIL_MAX) return false;
+    T.L[nl++] = L;
+  }
+  if (nl < 2) return false;
+  const NLev &B = T.L[nl - 1];
+  const int N = std::max(B.n[0], std::max(B.n[1], B.n[2]));
+  T.nlev = nl; T.nu1 = P.hg_nu1; T.nu2 = P.hg_nu2; T.nbot = std::max(P.hg_nub, 2 * N * N); T.omega = P.hg_omega;     // nd_bottom_t / nd_bottom_sweeps_global
+  hipLaunchKernelGGL(kk_nd_tailcycle, dim3(1), dim3(1024), 0, ctx().stream, T);
+  int m = 0;                                           // the ping-pong state the sweeps leave behind (nd_jacobi_d / nd_jacobi_t)
+  if (dl >= 0) for (int q = dl; q < (int)M.dlev.size(); q++, m++) {
+    const int sweeps = (m == nl - 1) ? T.nbot : T.nu1 + T.nu2;
+    if (sweeps & 1) { NDLev &D = M.dlev[q]; std::swap(D.boxes[0].L.phi, D.boxes[0].L.tmp); D.flip = !D.flip; }
+  }
+  for (int q = tl; q < (int)M.tail.size(); q++, m++) {
+    const int sweeps = (m == nl - 1) ? T.nbot : T.nu1 + T.nu2;
+    if (sweeps & 1) std::swap(M.tail[q].phi, M.tail[q].tmp);
+  }
+  return true;
+}
 static void nd_vcycle_d(NDMG &M, int l) {
   const vdn_params &P = ctx().prm;
   NDLev &DL = M.dlev[l];                               // phi = 0 on entry: written by kk_nd_restrict
+  if (nd_small_end(M, l, 0)) return;
   const bool last = (l == (int)M.dlev.size() - 1);
   if (last && M.tail.empty()) { nd_jacobi_d(DL, nd_bottom_sweeps_global(DL)); return; }
   nd_jacobi_d(DL, P.hg_nu1);
