@@ -1738,6 +1738,365 @@ template <bool BC> __global__ void __launch_bounds__(64 * TNY) kk_vp_D_m(FV u, F
 }
 
 
+// ---- velpred: stages B + C + D in one march (all three components; the scheme of mk_F_m_body) --------------------------------------------
+// Iteration kk loads plane kk (u, nine slopes, force) and runs stage B on plane kk (UI: the nine upwinded states on the cell's lower faces),
+// stage C on plane kk-1 (XC: six transverse-corrected states) and stage D on plane kk-2 (the MAC velocity on the lower faces).  UI and XC
+// stay in registers; upper-face values come from the next lane (DPP), the next row (LDS, written one iteration earlier) and, along z, from the
+// stage that ran earlier in the same iteration.  A cell carries its eighteen bases from stage B to stage C and the three normal ones on to
+// stage D (the separate stages recompute them: six f64 divisions per cell and stage).  Every expression is the one of vp_B_m_body /
+// vp_C_m_body / vp_D_m_body in the same order (tests/test_kernels_gpu.py::test_velpred, test_godunov_marching_equals_face_centred).
+// Boundary rules as packed per-thread codes (mk_F_m_body): bc_pair leaves L = R = v, v one of {ghost, 0, inner, clamped inner}; the
+// hi-x OUTLET quirk of velpred.f90:2075 (min instead of max on the normal component) is the code 4 in place of 5 in stages B / premod.
+struct VArgs {
+  const char *pu, *psl[3], *pf;       // component 0 of u, the three slope fabs and the force at plane KB
+  long sc_u, sc_sl, sc_f;             // bytes between components
+  long sp_u, sp_sl, sp_f; FGeo g_u, g_sl, g_f;
+  char *q[3]; long sq[3]; FGeo h[3];  // umac, vmac, wmac
+  long u_row;
+  double dt2, dx[3], tC[3], tD[3];    // tC[O] = (dt/6) / dx[O],  tD[T] = (dt/4) / dx[T]
+  int lo[3], hi[3], phys[3][2], use_minion;
+};
+DEVI int vp_code_B(int phys, int D, int side, int c) {
+  if (phys == VDN_INLET) return 1;
+  if (phys == VDN_SLIP_WALL) return c == D ? 2 : 3;
+  if (phys == VDN_NO_SLIP_WALL) return 2;
+  if (phys == VDN_OUTLET) return c == D ? ((side == 0 || D == 0) ? 4 : 5) : 3;
+  return 0;
+}
+DEVI int vp_code_D(int phys, int side) {
+  if (phys == VDN_SLIP_WALL || phys == VDN_NO_SLIP_WALL) return 2;
+  if (phys == VDN_INLET) return 1;
+  if (phys == VDN_OUTLET) return side ? 5 : 4;
+  return 0;
+}
+template <int D> DEVI void vpf_emit(double ui[3], const double L[3], const double R[3], double eps) {      // vp_B_emit into registers
+  const double uavg = 0.5 * (L[D] + R[D]);
+  const bool test = ((L[D] <= 0.0 && R[D] >= 0.0) || (fabs(L[D] + R[D]) < eps));
+  double un = (uavg > 0.0) ? L[D] : R[D];
+  un = test ? 0.0 : un;
+  #pragma unroll
+  for (int c = 0; c < 3; c++) {
+    if (c == D) ui[c] = un;
+    else {
+      const double v = (un > 0.0) ? L[c] : R[c];
+      const double av = 0.5 * (L[c] + R[c]);
+      ui[c] = (fabs(un) < eps) ? av : v;
+    }
+  }
+}
+DEVI double vpf_riemann(double L, double R, double eps) {            // the state of vp_D_face before its boundary rule
+  const double uavg = 0.5 * (L + R);
+  const bool test = ((L <= 0.0 && R >= 0.0) || (fabs(L + R) < eps));
+  const double v = (uavg > 0.0) ? L : R;
+  return test ? 0.0 : v;
+}
+template <bool BC, bool INL> __device__ __forceinline__ void vp_F_m_body(const VArgs &F, const Range3 &r, int klen, const double *umax, const int BX, const int BY, const int BZ) {
+  __shared__ double lB[3][TNY][64], lUI[3][TNY][64], lC[2][TNY][64], lXC[2][TNY][64], lD[TNY][64];
+  const int lane = threadIdx.x, row = threadIdx.y;
+  const int i = r.lo[0] - 1 + BX * FNX + lane, j = r.lo[1] - 1 + BY * FNY + row;
+  const bool own_ij = lane >= 1 && lane <= FNX && row >= 1 && row <= FNY && i <= r.hi[0] && j <= r.hi[1];
+  const int ic = min(max(i, F.lo[0] - 1), F.hi[0] + 1), jc = min(max(j, F.lo[1] - 1), F.hi[1] + 1);
+  const bool ing_ij = i == ic && j == jc;
+  const bool vx = i >= F.lo[0] && i <= F.hi[0], vy = j >= F.lo[1] && j <= F.hi[1];
+  const int rowm = row >= 1 ? row - 1 : 0, rowp = row + 1 < TNY ? row + 1 : TNY - 1;
+  const int k0 = r.lo[2] + BZ * klen, k1 = min(k0 + klen - 1, r.hi[2]);
+  const int KB = F.lo[2] - 1, KT = F.hi[2] + 1;
+  const double eps = eps_from(umax);
+  // packed boundary codes of this thread: wf: x-face (3 comps x 4 bits, +8 = hi side), y-face (bits 12..23), stage-D code of the x-face (24..27) and
+  // of the y-face (28..31);  wpx / wpy: rule on the bases of the lowest valid cell (3 x 4 bits) and of the highest (bits 12..23)
+  unsigned wf = 0, wpx = 0, wpy = 0;
+  if (BC) {
+    #pragma unroll
+    for (int c = 0; c < 3; c++) {
+      if (ing_ij && i == F.lo[0]) wf |= (unsigned)vp_code_B(F.phys[0][0], 0, 0, c) << (4 * c);
+      if (ing_ij && i == F.hi[0] + 1) { const int cd = vp_code_B(F.phys[0][1], 0, 1, c); if (cd) wf |= (unsigned)(cd | 8) << (4 * c); }
+      if (ing_ij && j == F.lo[1]) wf |= (unsigned)vp_code_B(F.phys[1][0], 1, 0, c) << (12 + 4 * c);
+      if (ing_ij && j == F.hi[1] + 1) { const int cd = vp_code_B(F.phys[1][1], 1, 1, c); if (cd) wf |= (unsigned)(cd | 8) << (12 + 4 * c); }
+      if (ic == F.lo[0]) wpx |= (unsigned)vp_code_B(F.phys[0][0], 0, 0, c) << (4 * c);
+      if (ic == F.hi[0]) wpx |= (unsigned)vp_code_B(F.phys[0][1], 0, 1, c) << (12 + 4 * c);
+      if (jc == F.lo[1]) wpy |= (unsigned)vp_code_B(F.phys[1][0], 1, 0, c) << (4 * c);
+      if (jc == F.hi[1]) wpy |= (unsigned)vp_code_B(F.phys[1][1], 1, 1, c) << (12 + 4 * c);
+    }
+    if (ing_ij && i == F.lo[0]) wf |= (unsigned)vp_code_D(F.phys[0][0], 0) << 24;
+    if (ing_ij && i == F.hi[0] + 1) { const int cd = vp_code_D(F.phys[0][1], 1); if (cd) wf |= (unsigned)(cd | 8) << 24; }
+    if (ing_ij && j == F.lo[1]) wf |= (unsigned)vp_code_D(F.phys[1][0], 0) << 28;
+    if (ing_ij && j == F.hi[1] + 1) { const int cd = vp_code_D(F.phys[1][1], 1); if (cd) wf |= (unsigned)(cd | 8) << 28; }
+  }
+  // per-thread plane pointers (the thread's column): inputs at the plane the next loads take (kcur), outputs at the plane stage D emits next
+  int kcur = min(max(k0 - 2, KB), KT);
+  const char *pu = F.pu + (long)(kcur - KB) * F.sp_u + fg_off(F.g_u, ic, jc);
+  const char *ps0 = F.psl[0] + (long)(kcur - KB) * F.sp_sl + fg_off(F.g_sl, ic, jc), *ps1 = F.psl[1] + (long)(kcur - KB) * F.sp_sl + fg_off(F.g_sl, ic, jc), *ps2 = F.psl[2] + (long)(kcur - KB) * F.sp_sl + fg_off(F.g_sl, ic, jc);
+  const char *pf = F.pf + (long)(kcur - KB) * F.sp_f + fg_off(F.g_f, ic, jc);
+  char *qu = F.q[0] + (long)(k0 - KB) * F.sq[0] + fg_off(F.h[0], i, j), *qv = F.q[1] + (long)(k0 - KB) * F.sq[1] + fg_off(F.h[1], i, j), *qw = F.q[2] + (long)(k0 - KB) * F.sq[2] + fg_off(F.h[2], i, j);
+  // state carried from plane to plane
+  double Lb1[3][3], Rb1[3][3], ui1[3][3];          // plane kk-1: bases [D][c], UI [D][c] on the lower faces
+  double LbD[3], RbD[3], sm2[3], xc2[6];           // plane kk-2: normal bases, UI[T][T](+) + UI[T][T], XC on the lower faces
+  #pragma unroll
+  for (int d = 0; d < 3; d++) { LbD[d] = 0.0; RbD[d] = 0.0; sm2[d] = 0.0; for (int c = 0; c < 3; c++) { Lb1[d][c] = 0.0; Rb1[d][c] = 0.0; ui1[d][c] = 0.0; } }
+  #pragma unroll
+  for (int n = 0; n < 6; n++) xc2[n] = 0.0;
+  double LzB[3] = { 0.0, 0.0, 0.0 }, LzC[2] = { 0.0, 0.0 }, LzD = 0.0;
+  #define U_AT(kpl, dbytes, c) (INL ? ldd(pu + (long)((kpl) - kcur) * F.sp_u + (dbytes) + (long)(c) * F.sc_u, 0u) : 0.0)
+  #define BC_V(v, code, in, ghost_expr) { const int cd_ = (code); const double in_ = (in); double v_ = in_;                      \
+      if (cd_ == 4) v_ = fmin(in_, 0.0); if (cd_ == 5) v_ = fmax(in_, 0.0); if (cd_ == 2) v_ = 0.0; if (cd_ == 1) v_ = (ghost_expr); v = v_; }
+  // the face rule on a pair (4-bit field f4: code, +8 = hi face): both states become v
+  #define PAIR_BC(L, Rr, f4, own_expr, ghost_expr) { const int f_ = (int)(f4) & 15;                                              \
+      if (f_) { const bool hi_ = (f_ & 8) != 0; double o_; BC_V(o_, f_ & 7, hi_ ? (L) : (Rr), hi_ ? (own_expr) : (ghost_expr)) L = o_; Rr = o_; } }
+  #define OUT_BC(out, f4, L, Rr, own_expr, ghost_expr) { const int f_ = (int)(f4) & 15;                                          \
+      if (f_) { const bool hi_ = (f_ & 8) != 0; double o_; BC_V(o_, f_ & 7, hi_ ? (L) : (Rr), hi_ ? (own_expr) : (ghost_expr)) out = o_; } }
+  #define PREMOD(Lb_, Rb_, a4, b4, gl_expr, gh_expr) { const int a_ = (int)(a4) & 7; if (a_) { double o_; BC_V(o_, a_, Rb_, gl_expr) Rb_ = o_; }  \
+                                                       const int b_ = (int)(b4) & 7; if (b_) { double o_; BC_V(o_, b_, Lb_, gh_expr) Lb_ = o_; } }
+  // z words of a stage plane (uniform): face codes of the three components (bits 0..11), stage-D code (24..27); premod lo (0..11) / hi (12..23)
+  #define ZF_WORD(k, kc, zf) { zf = 0u; if (BC && (k) == (kc)) {                                                                  \
+      if ((k) == F.lo[2]) { for (int c_ = 0; c_ < 3; c_++) zf |= (unsigned)vp_code_B(F.phys[2][0], 2, 0, c_) << (4 * c_); zf |= (unsigned)vp_code_D(F.phys[2][0], 0) << 24; } \
+      if ((k) == KT) { for (int c_ = 0; c_ < 3; c_++) { const int cd_ = vp_code_B(F.phys[2][1], 2, 1, c_); if (cd_) zf |= (unsigned)(cd_ | 8) << (4 * c_); }             \
+                       const int cd_ = vp_code_D(F.phys[2][1], 1); if (cd_) zf |= (unsigned)(cd_ | 8) << 24; } } }
+  #define ZP_WORD(kc, zp) { zp = 0u; if (BC) {                                                                                     \
+      if ((kc) == F.lo[2]) for (int c_ = 0; c_ < 3; c_++) zp |= (unsigned)vp_code_B(F.phys[2][0], 2, 0, c_) << (4 * c_);           \
+      if ((kc) == F.hi[2]) for (int c_ = 0; c_ < 3; c_++) zp |= (unsigned)vp_code_B(F.phys[2][1], 2, 1, c_) << (12 + 4 * c_); } }
+  struct VRaw { double u[3], sx[3], sy[3], sz[3], f[3]; } N;
+  #define V_LOAD {                                                                                                \
+      _Pragma("unroll") for (int c = 0; c < 3; c++) {                                                              \
+        N.u[c] = ldd(pu + c * F.sc_u, 0u); N.sx[c] = ldd(ps0 + c * F.sc_sl, 0u); N.sy[c] = ldd(ps1 + c * F.sc_sl, 0u); \
+        N.sz[c] = ldd(ps2 + c * F.sc_sl, 0u); N.f[c] = ldd(pf + c * F.sc_f, 0u); } }
+  #define V_ADVANCE(kn) { const int kc_ = min(max((kn), KB), KT);                                                 \
+      if (kc_ != kcur) { pu += F.sp_u; ps0 += F.sp_sl; ps1 += F.sp_sl; ps2 += F.sp_sl; pf += F.sp_f; kcur = kc_; } }
+  double fa[3] = { 0.0, 0.0, 0.0 }, fb[3] = { 0.0, 0.0, 0.0 };       // dt/2 force of planes kk-1, kk-2 (stage D adds it when !use_minion)
+  for (int kk = k0 - 2; kk <= k1 + 2; kk++) {
+    // ---------------- plane kk: loads, bases ----------------
+    double uc[3], Lb[3][3], Rb[3][3], ft[3];
+    {
+      V_LOAD  V_ADVANCE(kk + 1)
+      #pragma unroll
+      for (int c = 0; c < 3; c++) { uc[c] = N.u[c]; ft[c] = F.dt2 * N.f[c]; }
+      const double *sl[3] = { N.sx, N.sy, N.sz };
+      #pragma unroll
+      for (int d = 0; d < 3; d++) {
+        double cfl_l;
+        if (d == 1) cfl_l = F.dt2 * fmax(0.0, uc[d] / F.dx[1]);       // velpred.f90:2108: division inside max()
+        else cfl_l = F.dt2 * fmax(0.0, uc[d]) / F.dx[d];
+        const double cfl_r = F.dt2 * fmin(0.0, uc[d]) / F.dx[d];
+        #pragma unroll
+        for (int c = 0; c < 3; c++) {
+          Lb[d][c] = uc[c] + (0.5 - cfl_l) * sl[d][c];
+          Rb[d][c] = uc[c] - (0.5 + cfl_r) * sl[d][c];
+          if (F.use_minion) { Lb[d][c] = Lb[d][c] + ft[c]; Rb[d][c] = Rb[d][c] + ft[c]; }
+        }
+      }
+    }
+    // values of the next row written in the previous iteration: read before this iteration overwrites them
+    double uiy_up[3], xcy_up[2];
+    #pragma unroll
+    for (int c = 0; c < 3; c++) uiy_up[c] = lUI[c][rowp][lane];
+    xcy_up[0] = lXC[0][rowp][lane]; xcy_up[1] = lXC[1][rowp][lane];
+    // ---------------- stage B, plane kk ----------------
+    double ui0[3][3];
+    {
+      const int k = kk, kc = min(max(k, KB), KT);
+      unsigned zf; ZF_WORD(k, kc, zf)
+      #pragma unroll
+      for (int c = 0; c < 3; c++) lB[c][row][lane] = Lb[1][c];
+      __syncthreads();
+      double Lx[3], Ly[3], Lzc[3], Rx[3], Ry[3], Rz[3];
+      #pragma unroll
+      for (int c = 0; c < 3; c++) {
+        Lx[c] = shfl_prev(Lb[0][c]); Ly[c] = lB[c][rowm][lane]; Lzc[c] = LzB[c]; LzB[c] = Lb[2][c];
+        Rx[c] = Rb[0][c]; Ry[c] = Rb[1][c]; Rz[c] = Rb[2][c];
+      }
+      if (BC && k == kc) {
+        unsigned w = wf; asm volatile("" : "+v"(w));
+        if (w & 0xFFFFFFu) {
+          #pragma unroll
+          for (int c = 0; c < 3; c++) {
+            PAIR_BC(Lx[c], Rx[c], w >> (4 * c), uc[c], U_AT(kc, -8L, c))
+            PAIR_BC(Ly[c], Ry[c], w >> (12 + 4 * c), uc[c], U_AT(kc, -F.u_row, c))
+          }
+        }
+        if ((zf & 0xFFFu) && ing_ij) {
+          #pragma unroll
+          for (int c = 0; c < 3; c++) PAIR_BC(Lzc[c], Rz[c], zf >> (4 * c), uc[c], U_AT(kc - 1, 0L, c))
+        }
+      }
+      vpf_emit<0>(ui0[0], Lx, Rx, eps); vpf_emit<1>(ui0[1], Ly, Ry, eps); vpf_emit<2>(ui0[2], Lzc, Rz, eps);
+      #pragma unroll
+      for (int c = 0; c < 3; c++) lUI[c][row][lane] = ui0[1][c];      // read by the row below at the top of the next iteration
+    }
+    // ---------------- stage C, plane kk-1 ----------------
+    double xc1[6] = { 0.0, 0.0, 0.0, 0.0, 0.0, 0.0 }, sm1[3] = { 0.0, 0.0, 0.0 };
+    if (kk - 1 >= k0 - 1) {
+      const int k = kk - 1, kc = min(max(k, KB), KT);
+      unsigned zf, zp; ZF_WORD(k, kc, zf) ZP_WORD(kc, zp)
+      // w0[O][c] = ui1[O][c]; w1[O][c]: the upper O-face
+      double w1[3][3];
+      #pragma unroll
+      for (int c = 0; c < 3; c++) { w1[0][c] = lane_next(ui1[0][c]); w1[1][c] = uiy_up[c]; w1[2][c] = ui0[2][c]; }
+      double Lc[3][3], Rc[3][3];
+      #pragma unroll
+      for (int d = 0; d < 3; d++) for (int c = 0; c < 3; c++) { Lc[d][c] = Lb1[d][c]; Rc[d][c] = Rb1[d][c]; }
+      unsigned wfc = 0;
+      if (BC) {
+        unsigned px = wpx, py = wpy; asm volatile("" : "+v"(px)); asm volatile("" : "+v"(py));
+        wfc = wf; asm volatile("" : "+v"(wfc));
+        if (px | py) {
+          #pragma unroll
+          for (int c = 0; c < 3; c++) {
+            PREMOD(Lc[0][c], Rc[0][c], px >> (4 * c), px >> (12 + 4 * c), U_AT(kc, -8L, c), U_AT(kc, 8L, c))
+            PREMOD(Lc[1][c], Rc[1][c], py >> (4 * c), py >> (12 + 4 * c), U_AT(kc, -F.u_row, c), U_AT(kc, F.u_row, c))
+          }
+        }
+        if (zp) {
+          #pragma unroll
+          for (int c = 0; c < 3; c++) PREMOD(Lc[2][c], Rc[2][c], zp >> (4 * c), zp >> (12 + 4 * c), U_AT(kc - 1, 0L, c), U_AT(kc + 1, 0L, c))
+        }
+      }
+      double t[3][3];
+      #pragma unroll
+      for (int O = 0; O < 3; O++) {
+        sm1[O] = w1[O][O] + ui1[O][O];
+        #pragma unroll
+        for (int C = 0; C < 3; C++) t[C][O] = F.tC[O] * sm1[O] * (w1[O][C] - ui1[O][C]);
+      }
+      double VL[3][2], VR[3][2];
+      VL[0][0] = Lc[0][1] - t[1][2]; VR[0][0] = Rc[0][1] - t[1][2];   // D=0 C=1 O=2
+      VL[0][1] = Lc[0][2] - t[2][1]; VR[0][1] = Rc[0][2] - t[2][1];   // D=0 C=2 O=1
+      VL[1][0] = Lc[1][0] - t[0][2]; VR[1][0] = Rc[1][0] - t[0][2];   // D=1 C=0 O=2
+      VL[1][1] = Lc[1][2] - t[2][0]; VR[1][1] = Rc[1][2] - t[2][0];   // D=1 C=2 O=0
+      VL[2][0] = Lc[2][0] - t[0][1]; VR[2][0] = Rc[2][0] - t[0][1];   // D=2 C=0 O=1
+      VL[2][1] = Lc[2][1] - t[1][0]; VR[2][1] = Rc[2][1] - t[1][0];   // D=2 C=1 O=0
+      lC[0][row][lane] = VL[1][0]; lC[1][row][lane] = VL[1][1];
+      __syncthreads();
+      double L[3][2];
+      L[0][0] = shfl_prev(VL[0][0]); L[0][1] = shfl_prev(VL[0][1]);
+      L[1][0] = lC[0][rowm][lane]; L[1][1] = lC[1][rowm][lane];
+      L[2][0] = LzC[0]; L[2][1] = LzC[1];
+      LzC[0] = VL[2][0]; LzC[1] = VL[2][1];
+      if (BC && k == kc) {
+        // components: x-faces carry C = 1, 2; y-faces C = 0, 2; z-faces C = 0, 1 (own value for a hi face: the cell's u, re-read)
+        if (wfc & 0xFFFFFFu) {
+          PAIR_BC(L[0][0], VR[0][0], wfc >> 4, U_AT(kc, 0L, 1), U_AT(kc, -8L, 1)) PAIR_BC(L[0][1], VR[0][1], wfc >> 8, U_AT(kc, 0L, 2), U_AT(kc, -8L, 2))
+          PAIR_BC(L[1][0], VR[1][0], wfc >> 12, U_AT(kc, 0L, 0), U_AT(kc, -F.u_row, 0)) PAIR_BC(L[1][1], VR[1][1], wfc >> 20, U_AT(kc, 0L, 2), U_AT(kc, -F.u_row, 2))
+        }
+        if ((zf & 0xFFFu) && ing_ij) {
+          PAIR_BC(L[2][0], VR[2][0], zf, U_AT(kc, 0L, 0), U_AT(kc - 1, 0L, 0)) PAIR_BC(L[2][1], VR[2][1], zf >> 4, U_AT(kc, 0L, 1), U_AT(kc - 1, 0L, 1))
+        }
+      }
+      // XC index n: 0 = (C0,D1) 1 = (C0,D2) 2 = (C1,D0) 3 = (C1,D2) 4 = (C2,D0) 5 = (C2,D1); the advecting velocity is UI[D][D] of the lower face
+      xc1[2] = vp_up(ui1[0][0], L[0][0], VR[0][0], eps); xc1[4] = vp_up(ui1[0][0], L[0][1], VR[0][1], eps);
+      xc1[0] = vp_up(ui1[1][1], L[1][0], VR[1][0], eps); xc1[5] = vp_up(ui1[1][1], L[1][1], VR[1][1], eps);
+      xc1[1] = vp_up(ui1[2][2], L[2][0], VR[2][0], eps); xc1[3] = vp_up(ui1[2][2], L[2][1], VR[2][1], eps);
+      lXC[0][row][lane] = xc1[0]; lXC[1][row][lane] = xc1[5];           // the y-face fields: read by the row below at the top of the next iteration
+    } else {
+      __syncthreads();                                              // keeps lB / lUI single-buffered while stage C is idle (start of a chunk)
+    }
+    // ---------------- stage D, plane kk-2 ----------------
+    if (kk - 2 >= k0 - 1) {
+      const int k = kk - 2, kc = min(max(k, KB), KT);
+      unsigned zf, zp; ZF_WORD(k, kc, zf) ZP_WORD(kc, zp)
+      const bool vz = k >= F.lo[2] && k <= F.hi[2];
+      double Ld[3] = { LbD[0], LbD[1], LbD[2] }, Rd[3] = { RbD[0], RbD[1], RbD[2] };
+      unsigned wfd = 0;
+      if (BC) {
+        unsigned px = wpx, py = wpy; asm volatile("" : "+v"(px)); asm volatile("" : "+v"(py));
+        wfd = wf; asm volatile("" : "+v"(wfd));
+        if (px | py) {
+          PREMOD(Ld[0], Rd[0], px, px >> 12, U_AT(kc, -8L, 0), U_AT(kc, 8L, 0))
+          PREMOD(Ld[1], Rd[1], py >> 4, py >> 16, U_AT(kc, -F.u_row, 1), U_AT(kc, F.u_row, 1))
+        }
+        if (zp) { PREMOD(Ld[2], Rd[2], zp >> 8, zp >> 20, U_AT(kc - 1, 0L, 2), U_AT(kc + 1, 0L, 2)) }
+      }
+      // XC on the upper faces: n0, n5 (y-faces) from the next row, n2, n4 (x-faces) from the next lane, n1, n3 (z-faces) from stage C above
+      const double x1[6] = { xcy_up[0], xc1[1], lane_next(xc2[2]), xc1[3], lane_next(xc2[4]), xcy_up[1] };
+      const double (&x0)[6] = xc2;
+      const double (&g)[3] = sm2;
+      double VL[3], VR[3];
+      {   // D = 0: T1 = 1 with XC(0,1) = n0,  T2 = 2 with XC(0,2) = n1
+        const double a1 = F.tD[1] * g[1] * (x1[0] - x0[0]);
+        const double a2 = F.tD[2] * g[2] * (x1[1] - x0[1]);
+        double vl = Ld[0] - a1 - a2, vr = Rd[0] - a1 - a2;
+        if (!F.use_minion) { vl = vl + fb[0]; vr = vr + fb[0]; }
+        VL[0] = vl; VR[0] = vr;
+      }
+      {   // D = 1: T1 = 0 with XC(1,0) = n2,  T2 = 2 with XC(1,2) = n3
+        const double a1 = F.tD[0] * g[0] * (x1[2] - x0[2]);
+        const double a2 = F.tD[2] * g[2] * (x1[3] - x0[3]);
+        double vl = Ld[1] - a1 - a2, vr = Rd[1] - a1 - a2;
+        if (!F.use_minion) { vl = vl + fb[1]; vr = vr + fb[1]; }
+        VL[1] = vl; VR[1] = vr;
+      }
+      {   // D = 2: T1 = 0 with XC(2,0) = n4,  T2 = 1 with XC(2,1) = n5
+        const double a1 = F.tD[0] * g[0] * (x1[4] - x0[4]);
+        const double a2 = F.tD[1] * g[1] * (x1[5] - x0[5]);
+        double vl = Ld[2] - a1 - a2, vr = Rd[2] - a1 - a2;
+        if (!F.use_minion) { vl = vl + fb[2]; vr = vr + fb[2]; }
+        VL[2] = vl; VR[2] = vr;
+      }
+      lD[row][lane] = VL[1];
+      __syncthreads();
+      const double Lx = shfl_prev(VL[0]), Ly = lD[rowm][lane], Lzc = LzD;
+      LzD = VL[2];
+      if (k >= k0) {
+        if (own_ij) {
+          double e0 = vpf_riemann(Lx, VR[0], eps), e1 = vpf_riemann(Ly, VR[1], eps), e2 = vpf_riemann(Lzc, VR[2], eps);
+          if (BC) {
+            if (wfd >> 24) { OUT_BC(e0, wfd >> 24, Lx, VR[0], U_AT(kc, 0L, 0), U_AT(kc, -8L, 0)) OUT_BC(e1, wfd >> 28, Ly, VR[1], U_AT(kc, 0L, 1), U_AT(kc, -F.u_row, 1)) }
+            if (zf >> 24) { OUT_BC(e2, zf >> 24, Lzc, VR[2], U_AT(kc, 0L, 2), U_AT(kc - 1, 0L, 2)) }
+          }
+          if (vy && vz) std_(qu, 0u, e0);
+          if (vx && vz) std_(qv, 0u, e1);
+          if (vx && vy) std_(qw, 0u, e2);
+        }
+        qu += F.sq[0]; qv += F.sq[1]; qw += F.sq[2];
+      }
+    } else {
+      __syncthreads();
+    }
+    // hand the planes on
+    #pragma unroll
+    for (int d = 0; d < 3; d++) { LbD[d] = Lb1[d][d]; RbD[d] = Rb1[d][d]; sm2[d] = sm1[d]; fb[d] = fa[d]; fa[d] = ft[d]; }
+    #pragma unroll
+    for (int n = 0; n < 6; n++) xc2[n] = xc1[n];
+    #pragma unroll
+    for (int d = 0; d < 3; d++) for (int c = 0; c < 3; c++) { Lb1[d][c] = Lb[d][c]; Rb1[d][c] = Rb[d][c]; ui1[d][c] = ui0[d][c]; }
+  }
+  #undef U_AT
+  #undef BC_V
+  #undef PAIR_BC
+  #undef OUT_BC
+  #undef PREMOD
+  #undef ZF_WORD
+  #undef ZP_WORD
+  #undef V_LOAD
+  #undef V_ADVANCE
+}
+template <bool BC = true, bool INL = true> __global__ void __launch_bounds__(64 * TNY) kk_vp_F_m(VArgs F, Range3 r, int klen, const double *umax) {
+  int bx_, by_, bz_; xcd_remap(bx_, by_, bz_);
+  vp_F_m_body<BC, INL>(F, r, klen, umax, bx_, by_, bz_);
+}
+static bool vfused_args(VArgs &F, const GArgs &A, const FV &u, const FV sl[3], const FV &force, const FV &um, const FV &vm, const FV &wm) {
+  if (!same_geom(sl[0], sl[1]) || !same_geom(sl[0], sl[2]) || sl[0].sc != sl[1].sc || sl[0].sc != sl[2].sc) return false;
+  const int KB = A.lo[2] - 1;
+  const FV *in[5] = { &u, &sl[0], &sl[1], &sl[2], &force };
+  for (int f = 0; f < 5; f++) if (KB < in[f]->a2 || A.hi[2] + 1 >= in[f]->a2 + in[f]->n2) return false;      // the clamped planes must exist
+  F.pu = (const char *)(u.p + (long)u.n0 * u.n1 * (KB - u.a2)); F.sc_u = 8L * u.sc; F.sp_u = 8L * u.n0 * u.n1; F.g_u = FGeo{ u.a0, u.a1, u.n0 };
+  for (int d = 0; d < 3; d++) F.psl[d] = (const char *)(sl[d].p + (long)sl[d].n0 * sl[d].n1 * (KB - sl[d].a2));
+  F.sc_sl = 8L * sl[0].sc; F.sp_sl = 8L * sl[0].n0 * sl[0].n1; F.g_sl = FGeo{ sl[0].a0, sl[0].a1, sl[0].n0 };
+  F.pf = (const char *)(force.p + (long)force.n0 * force.n1 * (KB - force.a2)); F.sc_f = 8L * force.sc; F.sp_f = 8L * force.n0 * force.n1; F.g_f = FGeo{ force.a0, force.a1, force.n0 };
+  const FV *out[3] = { &um, &vm, &wm };
+  for (int f = 0; f < 3; f++) {
+    const FV &v = *out[f];
+    F.q[f] = (char *)(v.p + (long)v.n0 * v.n1 * (KB - v.a2)); F.sq[f] = 8L * v.n0 * v.n1; F.h[f] = FGeo{ v.a0, v.a1, v.n0 };
+  }
+  F.u_row = 8L * u.n0;
+  const double dt2 = 0.5 * A.dt, dt4 = A.dt / 4.0, dt6 = A.dt / 6.0;
+  F.dt2 = dt2;
+  for (int d = 0; d < 3; d++) {
+    F.dx[d] = A.dx[d]; F.tC[d] = dt6 / A.dx[d]; F.tD[d] = dt4 / A.dx[d];
+    F.lo[d] = A.lo[d]; F.hi[d] = A.hi[d]; F.phys[d][0] = A.phys[d][0]; F.phys[d][1] = A.phys[d][1];
+  }
+  F.use_minion = A.use_minion;
+  return true;
+}
+
 // ====================================================================================================
 // dm = 2 (BASELINE.json configs[0], the reference's CPU-runnable case): velpred_2d (velpred.f90:125-524) and mkflux_2d
 // (mkflux.f90:152-691).  Two stages only -- the transverse terms use the stage-B states directly.  One thread per cell
@@ -2032,7 +2391,17 @@ void k_velpred(const vdn_multifab *u, vdn_multifab **umac, const vdn_multifab *f
     } else {
       int klg, klf;
       const dim3 gg = march_grid(rg, klg), gf = march_grid(rf, klf), blk(64, TNY, 1);
-      if (slab_bc()) {             // interior marches, then the face-centred code on the boundary slabs (see kk_slabs)
+      static const bool fused_env = !(getenv("VDN_GOD_FUSED") && atoi(getenv("VDN_GOD_FUSED")) == 0);
+      VArgs VA;
+      if (fused_env && vfused_args(VA, A, u->fabs[ib], sl, force->fabs[ib], umac[0]->fabs[ib], umac[1]->fabs[ib], umac[2]->fabs[ib])) {
+        int klF;                   // stages B + C + D in one march, boundary rules inside (see vp_F_m_body)
+        const dim3 gF = fused_grid(rf, klF);
+        bool any = false, inflow = false;
+        for (int d = 0; d < 3; d++) for (int sd = 0; sd < 2; sd++) { any = any || bc_mode_host(A.phys[d][sd]); inflow = inflow || A.phys[d][sd] == VDN_INLET; }
+        if (!any) hipLaunchKernelGGL((kk_vp_F_m<false, false>), gF, blk, 0, st, VA, rf, klF, umax);
+        else if (inflow) hipLaunchKernelGGL((kk_vp_F_m<true, true>), gF, blk, 0, st, VA, rf, klF, umax);
+        else hipLaunchKernelGGL((kk_vp_F_m<true, false>), gF, blk, 0, st, VA, rf, klF, umax);
+      } else if (slab_bc()) {      // interior marches, then the face-centred code on the boundary slabs (see kk_slabs)
         const VpPlain P{ u->fabs[ib], sl[0], sl[1], sl[2], force->fabs[ib], UI, XC, umac[0]->fabs[ib], umac[1]->fabs[ib], umac[2]->fabs[ib], A, umax };
         const Slabs Sg = boundary_slabs(A, rg), Sf = boundary_slabs(A, rf);
         hipLaunchKernelGGL(kk_vp_B_m<false>, gg, blk, 0, st, u->fabs[ib], sl[0], sl[1], sl[2], force->fabs[ib], UI, A, rg, klg, umax);
