@@ -1096,6 +1096,7 @@ static void cc_bottom_t(const CCMG &M, const CLev &L) {      // max(nub, N^2) sw
 static bool cc_small_end(const CCMG &M, int dl, int tl) {
   static const bool on = !(getenv("VDN_MG_TAILCYCLE") && atoi(getenv("VDN_MG_TAILCYCLE")) == 0);
   if (!on) return false;
+  static const long tail_cells = getenv("VDN_MG_TAIL_CELLS") ? atol(getenv("VDN_MG_TAIL_CELLS")) : SMALL_LEVEL_CELLS;     // largest level the one-workgroup cycle takes (measured: 16^3 no gain, MAC 15.33 -> 15.39 ms)
   const vdn_params &P = ctx().prm;
   CcTailArgs T; memset(&T, 0, sizeof T);
   int nl = 0;
@@ -1103,13 +1104,13 @@ static bool cc_small_end(const CCMG &M, int dl, int tl) {
     if (!M.tail.empty() && !(ctx().nranks == 1 && M.dlev.back().single_box)) return false;
     for (int m = dl; m < (int)M.dlev.size(); m++) {
       const CDLev &D = M.dlev[m];
-      if (!(D.single_box && D.boxes.size() == 1 && !D.boxes[0].L.phi2 && !D.boxes[0].L.rho && (long)D.ng[0] * D.ng[1] * D.ng[2] <= SMALL_LEVEL_CELLS) || nl == CC_TAIL_MAX) return false;
+      if (!(D.single_box && D.boxes.size() == 1 && !D.boxes[0].L.phi2 && !D.boxes[0].L.rho && (long)D.ng[0] * D.ng[1] * D.ng[2] <= tail_cells) || nl == CC_TAIL_MAX) return false;
       T.L[nl++] = D.boxes[0].L;
     }
   }
   for (int m = tl; m < (int)M.tail.size(); m++) {
     const CLev &L = M.tail[m];
-    if ((long)L.n[0] * L.n[1] * L.n[2] > SMALL_LEVEL_CELLS || nl == CC_TAIL_MAX) return false;
+    if ((long)L.n[0] * L.n[1] * L.n[2] > tail_cells || nl == CC_TAIL_MAX) return false;
     T.L[nl++] = L;
   }
   if (nl < 2) return false;

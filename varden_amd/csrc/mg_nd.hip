@@ -1010,6 +1010,7 @@ static int nd_bottom_sweeps_global(const NDLev &DL) {
 static bool nd_small_end(NDMG &M, int dl, int tl) {
   static const bool on = !(getenv("VDN_MG_TAILCYCLE") && atoi(getenv("VDN_MG_TAILCYCLE")) == 0);
   if (!on) return false;
+  static const long tail_nodes = getenv("VDN_MG_TAIL_NODES") ? atol(getenv("VDN_MG_TAIL_NODES")) : SMALL_LEVEL_NODES;    // largest level the one-workgroup cycle takes (measured: 17^3 is slower, HG 16.9 -> 17.6 ms)
   const vdn_params &P = ctx().prm;
   NdTailArgs T; memset(&T, 0, sizeof T);
   int nl = 0;
@@ -1017,14 +1018,14 @@ static bool nd_small_end(NDMG &M, int dl, int tl) {
     if (!M.tail.empty() && !(ctx().nranks == 1 && M.dlev.back().single_box)) return false;
     for (int m = dl; m < (int)M.dlev.size(); m++) {
       const NDLev &D = M.dlev[m];
-      if (!(D.single_box && D.boxes.size() == 1 && (long)(D.ng[0] + 1) * (D.ng[1] + 1) * (D.ng[2] + 1) <= SMALL_LEVEL_NODES) || nl == ND_TAIL_MAX) return false;
+      if (!(D.single_box && D.boxes.size() == 1 && (long)(D.ng[0] + 1) * (D.ng[1] + 1) * (D.ng[2] + 1) <= tail_nodes) || nl == ND_TAIL_MAX) return false;
       T.L[nl] = D.boxes[0].L; for (int d = 0; d < 3; d++) T.L[nl].per[d] = D.per[d];
       nl++;
     }
   }
   for (int m = tl; m < (int)M.tail.size(); m++) {
     const NLev &L = M.tail[m];
-    if ((long)(L.n[0] + 1) * (L.n[1] + 1) * (L.n[2] + 1) > SMALL_LEVEL_NODES || nl == ND_TAIL_MAX) return false;
+    if ((long)(L.n[0] + 1) * (L.n[1] + 1) * (L.n[2] + 1) > tail_nodes || nl == ND_TAIL_MAX) return false;
     T.L[nl++] = L;
   }
   if (nl < 2) return false;
