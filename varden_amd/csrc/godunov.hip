@@ -95,10 +95,17 @@ DEVI void slopes_cell(const FV &s, const FV &sl0, const FV &sl1, const FV &sl2, 
     #undef SPEC
   }
 }
-__global__ void __launch_bounds__(256) kk_slopes(FV s, FV sl0, FV sl1, FV sl2, GArgs A, Range3 r, int dirmask) {
+// vmax (velpred only): max |u| over the valid cells of the three components rides along (kk_velmax, velpred.f90:1965-1975) -- the
+// kernel reads every cell of u anyway
+__global__ void __launch_bounds__(256) kk_slopes(FV s, FV sl0, FV sl1, FV sl2, GArgs A, Range3 r, int dirmask, double *vmax = nullptr) {
   THREAD_IJK(r)
-  if (!in_range) return;
-  slopes_cell(s, sl0, sl1, sl2, A, dirmask, i, j, k);
+  if (in_range) slopes_cell(s, sl0, sl1, sl2, A, dirmask, i, j, k);
+  if (vmax) {                                     // uniform
+    double m = 0.0;
+    if (in_range && i >= A.lo[0] && i <= A.hi[0] && j >= A.lo[1] && j <= A.hi[1] && k >= A.lo[2] && k <= A.hi[2])
+      m = fmax(m, fmax(fmax(fabs(fv_get(s, i, j, k, 0)), fabs(fv_get(s, i, j, k, 1))), fabs(fv_get(s, i, j, k, 2))));
+    block_atomic_max(vmax, m);
+  }
 }
 
 // ---- boundary rule for a (left,right) pair on a domain face (velpred.f90:2044-2079, 2200-2224;
@@ -1264,12 +1271,16 @@ void k_mkflux(const vdn_multifab *s, vdn_multifab **sedge, vdn_multifab **flux, 
     for (int d = 0; d < 3; d++) { sl[d] = w; sl[d].p = cached ? ctx().slope_cache[d] : (double *)arena_alloc(fld * ncomp); }
     SI.p = (double *)arena_alloc(fld * 3 * ncomp);
     SC.p = (double *)arena_alloc(fld * 6 * ncomp);
-    double *umax = (double *)arena_alloc(256);
-    HIPCHK(hipMemsetAsync(umax, 0, sizeof(double), st));
     Range3 rg, rf;
     for (int d = 0; d < 3; d++) { rg.lo[d] = A.lo[d] - 1; rg.hi[d] = A.hi[d] + 1; rf.lo[d] = A.lo[d]; rf.hi[d] = A.hi[d] + 1; }
     const FV &um = umac[0]->fabs[ib], &vm = umac[1]->fabs[ib], &wm = umac[2]->fabs[ib];
-    hipLaunchKernelGGL(kk_macmax, reduce_grid(rf), dim3(64, 4, 1), 0, st, um, vm, wm, A, rf, umax);
+    const bool mm_keep = ctx().macmax_cache != nullptr && s->nfabs() == 1;       // advance_timestep: one reduction serves both mkflux calls of the step
+    double *umax = mm_keep ? ctx().macmax_cache : (double *)arena_alloc(256);
+    if (!(mm_keep && ctx().macmax_src == um.p)) {
+      HIPCHK(hipMemsetAsync(umax, 0, sizeof(double), st));
+      hipLaunchKernelGGL(kk_macmax, reduce_grid(rf), dim3(64, 4, 1), 0, st, um, vm, wm, A, rf, umax);
+      if (mm_keep) ctx().macmax_src = um.p;
+    }
     if (!cached) hipLaunchKernelGGL(kk_slopes, grid_for(rg), dim3(64, 4, 1), 0, st, s->fabs[ib], sl[0], sl[1], sl[2], A, rg, 7);
     if (plain_godunov()) {
       hipLaunchKernelGGL(kk_mk_B, grid_for(rg), dim3(64, 4, 1), 0, st, s->fabs[ib], sl[0], sl[1], sl[2], um, vm, wm, force->fabs[ib], mac_rhs->fabs[ib], SI, A, rg, umax);
@@ -2396,8 +2407,8 @@ void k_velpred(const vdn_multifab *u, vdn_multifab **umac, const vdn_multifab *f
     HIPCHK(hipMemsetAsync(umax, 0, sizeof(double), st));
     Range3 rv, rg, rf;
     for (int d = 0; d < 3; d++) { rv.lo[d] = A.lo[d]; rv.hi[d] = A.hi[d]; rg.lo[d] = A.lo[d] - 1; rg.hi[d] = A.hi[d] + 1; rf.lo[d] = A.lo[d]; rf.hi[d] = A.hi[d] + 1; }
-    hipLaunchKernelGGL(kk_velmax, reduce_grid(rv), dim3(64, 4, 1), 0, st, u->fabs[ib], rv, umax);
-    hipLaunchKernelGGL(kk_slopes, grid_for(rg), dim3(64, 4, 1), 0, st, u->fabs[ib], sl[0], sl[1], sl[2], A, rg, 7);
+    hipLaunchKernelGGL(kk_slopes, grid_for(rg), dim3(64, 4, 1), 0, st, u->fabs[ib], sl[0], sl[1], sl[2], A, rg, 7, umax);      // + max |u| (kk_velmax)
+    (void)rv;
     if (plain_godunov()) {
       hipLaunchKernelGGL(kk_vp_B, grid_for(rg), dim3(64, 4, 1), 0, st, u->fabs[ib], sl[0], sl[1], sl[2], force->fabs[ib], UI, A, rg, umax);
       hipLaunchKernelGGL(kk_vp_C, grid_for(rg), dim3(64, 4, 1), 0, st, u->fabs[ib], sl[0], sl[1], sl[2], force->fabs[ib], UI, XC, A, rg, umax);

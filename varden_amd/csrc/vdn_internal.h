@@ -91,6 +91,7 @@ struct VdnCtx {
   int solver_cycles[2] = {0, 0}; double solver_res0[2] = {0, 0}, solver_res[2] = {0, 0};
   // slopes of uold, computed by velpred and used again by the velocity mkflux of the same advance_timestep (one level, one box)
   double *slope_cache[3] = {nullptr, nullptr, nullptr}; const double *slope_src = nullptr;
+  double *macmax_cache = nullptr; const double *macmax_src = nullptr;   // max |umac| of a one-box level, kept from the scalar mkflux for the velocity mkflux of the step
 };
 VdnCtx &ctx();
 
