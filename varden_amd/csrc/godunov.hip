@@ -53,13 +53,11 @@ DEVI double limited(double del, double sm, double s0, double sp) {   // the one-
   return sgn1(del) * fmin(slim, fabs(del));
 }
 
-// slope of component c along D at cell (i,j,k); needs s at offsets -2..+2 along D
-template <int D> DEVI double slope_at(const FV &s, int c, int i, int j, int k, int is, int ie, bool lo_sp, bool hi_sp, int order) {
+// the limited slope of a cell from its five values along one direction (m2 .. p2 = offsets -2 .. +2); pos: the cell's index along that
+// direction, is / ie: first / last valid index, lo_sp / hi_sp: EXT_DIR or HOEXTRAP on that face (the one-sided formulas of slope.f90)
+DEVI double slope_vals(double m2, double m1, double s0, double p1, double p2, int pos, int is, int ie, bool lo_sp, bool hi_sp, int order) {
   if (order == 0) return 0.0;
-  const int pos = coord<D>(i, j, k);
   const double two3rd = 2.0 / 3.0, sixth = 1.0 / 6.0, third = 1.0 / 3.0, tenth = 0.1;
-  const double m2 = ld<D>(s, i, j, k, -2, c), m1 = ld<D>(s, i, j, k, -1, c), s0 = ld<D>(s, i, j, k, 0, c),
-               p1 = ld<D>(s, i, j, k, 1, c), p2 = ld<D>(s, i, j, k, 2, c);
   if (lo_sp && pos == is - 1) return 0.0;
   if (hi_sp && pos == ie + 1) return 0.0;
   if (order == 2) {
@@ -74,16 +72,20 @@ template <int D> DEVI double slope_at(const FV &s, int c, int i, int j, int k, i
   double fp, fm;
   if (hi_sp && pos == ie - 1)       // revised fromm(ie) = slope(ie)   (slope.f90:277-281)
     fp = limited(-(-16.0 / 15.0 * p2 + 0.5 * p1 + two3rd * s0 - tenth * m1), s0, p1, p2);
-  else {
-    // fromm(i+1) needs s(i+3)?  no: fromm(i+1) uses s(i), s(i+1), s(i+2)
-    fp = fromm_of(s0, p1, p2).fromm;
-  }
+  else fp = fromm_of(s0, p1, p2).fromm;          // fromm(i+1) uses s(i), s(i+1), s(i+2)
   if (lo_sp && pos == is + 1)       // revised fromm(is) = slope(is)   (slope.f90:256-260)
     fm = limited(-16.0 / 15.0 * m2 + 0.5 * m1 + two3rd * s0 - tenth * p1, m2, m1, s0);
   else
     fm = fromm_of(m2, m1, s0).fromm;
   double ds = 2.0 * two3rd * f0.cen - sixth * (fp + fm);
   return f0.flag * fmin(fabs(ds), f0.lim);
+}
+// slope of component c along D at cell (i,j,k); needs s at offsets -2..+2 along D
+template <int D> DEVI double slope_at(const FV &s, int c, int i, int j, int k, int is, int ie, bool lo_sp, bool hi_sp, int order) {
+  if (order == 0) return 0.0;
+  const double m2 = ld<D>(s, i, j, k, -2, c), m1 = ld<D>(s, i, j, k, -1, c), s0 = ld<D>(s, i, j, k, 0, c),
+               p1 = ld<D>(s, i, j, k, 1, c), p2 = ld<D>(s, i, j, k, 2, c);
+  return slope_vals(m2, m1, s0, p1, p2, coord<D>(i, j, k), is, ie, lo_sp, hi_sp, order);
 }
 
 DEVI void slopes_cell(const FV &s, const FV &sl0, const FV &sl1, const FV &sl2, const GArgs &A, int dirmask, int i, int j, int k) {
@@ -106,6 +108,70 @@ __global__ void __launch_bounds__(256) kk_slopes(FV s, FV sl0, FV sl1, FV sl2, G
       m = fmax(m, fmax(fmax(fabs(fv_get(s, i, j, k, 0)), fabs(fv_get(s, i, j, k, 1))), fabs(fv_get(s, i, j, k, 2))));
     block_atomic_max(vmax, m);
   }
+}
+
+// k-marching form of kk_slopes for all three directions at once: kk_slopes reads the five values of every direction through the L1 (13
+// loads per cell and component; texture addresser busy 73 %, 2.1 GB fetched for 0.43 GB of s).  Here a thread keeps the five planes
+// k-2 .. k+2 of its column in registers (one load per plane and component), takes x-neighbours from the lanes next to it and y-neighbours
+// from the rows next to it (LDS); tiles overlap by two cells either side (60 x 12 of 64 x 16 cells owned).  slope_vals on the same values.
+constexpr int SNY = 16;
+// (Measured and not kept: sharing the Fromm slopes between neighbours -- one fromm_of per cell and direction instead of three, exchanged like
+// the values -- needs more than the 128 VGPRs of a 1024-thread workgroup for three components: 3.1 ms spilling, 1.37 ms one component at a
+// time with two barriers each, against 0.69 ms for this form; two components: 0.46 against 0.47 ms.)
+template <int NC> __global__ void __launch_bounds__(64 * SNY) kk_slopes_m(FV s, FV sl0, FV sl1, FV sl2, GArgs A, Range3 r, int klen, double *vmax) {
+  __shared__ double ly[NC][SNY][64];
+  const int lane = threadIdx.x, row = threadIdx.y;
+  const int i = r.lo[0] - 2 + (int)blockIdx.x * 60 + lane, j = r.lo[1] - 2 + (int)blockIdx.y * (SNY - 4) + row;
+  const bool own_ij = lane >= 2 && lane <= 61 && row >= 2 && row <= SNY - 3 && i <= r.hi[0] && j <= r.hi[1];
+  const int ic = min(max(i, A.lo[0] - 3), A.hi[0] + 3), jc = min(max(j, A.lo[1] - 3), A.hi[1] + 3);
+  const int k0 = r.lo[2] + (int)blockIdx.z * klen, k1 = min(k0 + klen - 1, r.hi[2]);
+  const long sp = (long)s.n0 * s.n1;
+  const double *ps[NC];
+  #pragma unroll
+  for (int c = 0; c < NC; c++) ps[c] = s.p + fv_idx(s, ic, jc, s.a2) + s.sc * c;            // plane a2 of the column
+  #define SPL(c, kk) ps[c][(long)(min(max((kk), A.lo[2] - 3), A.hi[2] + 3) - s.a2) * sp]
+  #define SPEC(d, sd, c) (A.adv[d][sd][c] == VDN_EXT_DIR || A.adv[d][sd][c] == VDN_HOEXTRAP)
+  double w[NC][5];                                                    // the column's planes k-2 .. k+2
+  #pragma unroll
+  for (int c = 0; c < NC; c++) { w[c][0] = 0.0; for (int q = 1; q < 5; q++) w[c][q] = SPL(c, k0 - 3 + q); }
+  double m = 0.0;
+  for (int k = k0; k <= k1; k++) {
+    #pragma unroll
+    for (int c = 0; c < NC; c++) { w[c][0] = w[c][1]; w[c][1] = w[c][2]; w[c][2] = w[c][3]; w[c][3] = w[c][4]; w[c][4] = SPL(c, k + 2); }
+    #pragma unroll
+    for (int c = 0; c < NC; c++) ly[c][row][lane] = w[c][2];
+    __syncthreads();
+    #pragma unroll
+    for (int c = 0; c < NC; c++) {
+      const double s0 = w[c][2];
+      const double xm1 = lane_prev(s0), xp1 = lane_next(s0), xm2 = lane_prev(xm1), xp2 = lane_next(xp1);
+      if (own_ij) {
+        const double ym2 = ly[c][row - 2][lane], ym1 = ly[c][row - 1][lane], yp1 = ly[c][row + 1][lane], yp2 = ly[c][row + 2][lane];
+        fv_at(sl0, i, j, k, c) = slope_vals(xm2, xm1, s0, xp1, xp2, i, A.lo[0], A.hi[0], SPEC(0, 0, c), SPEC(0, 1, c), A.slope_order);
+        fv_at(sl1, i, j, k, c) = slope_vals(ym2, ym1, s0, yp1, yp2, j, A.lo[1], A.hi[1], SPEC(1, 0, c), SPEC(1, 1, c), A.slope_order);
+        fv_at(sl2, i, j, k, c) = slope_vals(w[c][0], w[c][1], s0, w[c][3], w[c][4], k, A.lo[2], A.hi[2], SPEC(2, 0, c), SPEC(2, 1, c), A.slope_order);
+        if (vmax && i >= A.lo[0] && i <= A.hi[0] && j >= A.lo[1] && j <= A.hi[1] && k >= A.lo[2] && k <= A.hi[2]) m = fmax(m, fabs(s0));
+      }
+    }
+    __syncthreads();
+  }
+  #undef SPL
+  #undef SPEC
+  if (vmax) block_atomic_max(vmax, m);
+}
+static void launch_slopes(const FV &s, const FV sl[3], const GArgs &A, const Range3 &rg, int ncomp, double *vmax, hipStream_t st) {
+  static const bool marching = !(getenv("VDN_SLOPES_MARCH") && atoi(getenv("VDN_SLOPES_MARCH")) == 0);
+  if (marching && (ncomp == 2 || ncomp == 3) && s.a0 <= A.lo[0] - 3 && s.a1 <= A.lo[1] - 3 && s.a2 <= A.lo[2] - 3) {
+    const int nx = rg.hi[0] - rg.lo[0] + 1, ny = rg.hi[1] - rg.lo[1] + 1, nz = rg.hi[2] - rg.lo[2] + 1;
+    const int tiles = ((nx + 59) / 60) * ((ny + SNY - 5) / (SNY - 4));
+    int chunks = std::max(1, std::min(nz / 8, (4 * 256 + tiles - 1) / tiles));        // ~4 workgroups per CU, chunks of >= 8 planes
+    const int klen = (nz + chunks - 1) / chunks;
+    const dim3 g((nx + 59) / 60, (ny + SNY - 5) / (SNY - 4), (nz + klen - 1) / klen), blk(64, SNY, 1);
+    if (ncomp == 3) hipLaunchKernelGGL(kk_slopes_m<3>, g, blk, 0, st, s, sl[0], sl[1], sl[2], A, rg, klen, vmax);
+    else hipLaunchKernelGGL(kk_slopes_m<2>, g, blk, 0, st, s, sl[0], sl[1], sl[2], A, rg, klen, vmax);
+    return;
+  }
+  hipLaunchKernelGGL(kk_slopes, grid_for(rg), dim3(64, 4, 1), 0, st, s, sl[0], sl[1], sl[2], A, rg, 7, vmax);
 }
 
 // ---- boundary rule for a (left,right) pair on a domain face (velpred.f90:2044-2079, 2200-2224;
@@ -1281,7 +1347,7 @@ void k_mkflux(const vdn_multifab *s, vdn_multifab **sedge, vdn_multifab **flux, 
       hipLaunchKernelGGL(kk_macmax, reduce_grid(rf), dim3(64, 4, 1), 0, st, um, vm, wm, A, rf, umax);
       if (mm_keep) ctx().macmax_src = um.p;
     }
-    if (!cached) hipLaunchKernelGGL(kk_slopes, grid_for(rg), dim3(64, 4, 1), 0, st, s->fabs[ib], sl[0], sl[1], sl[2], A, rg, 7);
+    if (!cached) launch_slopes(s->fabs[ib], sl, A, rg, ncomp, nullptr, st);
     if (plain_godunov()) {
       hipLaunchKernelGGL(kk_mk_B, grid_for(rg), dim3(64, 4, 1), 0, st, s->fabs[ib], sl[0], sl[1], sl[2], um, vm, wm, force->fabs[ib], mac_rhs->fabs[ib], SI, A, rg, umax);
       hipLaunchKernelGGL(kk_mk_C, grid_for(rg), dim3(64, 4, 1), 0, st, s->fabs[ib], sl[0], sl[1], sl[2], um, vm, wm, force->fabs[ib], mac_rhs->fabs[ib], SI, SC, A, rg, umax);
@@ -2407,7 +2473,7 @@ void k_velpred(const vdn_multifab *u, vdn_multifab **umac, const vdn_multifab *f
     HIPCHK(hipMemsetAsync(umax, 0, sizeof(double), st));
     Range3 rv, rg, rf;
     for (int d = 0; d < 3; d++) { rv.lo[d] = A.lo[d]; rv.hi[d] = A.hi[d]; rg.lo[d] = A.lo[d] - 1; rg.hi[d] = A.hi[d] + 1; rf.lo[d] = A.lo[d]; rf.hi[d] = A.hi[d] + 1; }
-    hipLaunchKernelGGL(kk_slopes, grid_for(rg), dim3(64, 4, 1), 0, st, u->fabs[ib], sl[0], sl[1], sl[2], A, rg, 7, umax);      // + max |u| (kk_velmax)
+    launch_slopes(u->fabs[ib], sl, A, rg, 3, umax, st);      // + max |u| (kk_velmax)
     (void)rv;
     if (plain_godunov()) {
       hipLaunchKernelGGL(kk_vp_B, grid_for(rg), dim3(64, 4, 1), 0, st, u->fabs[ib], sl[0], sl[1], sl[2], force->fabs[ib], UI, A, rg, umax);
