@@ -1222,6 +1222,32 @@ template <int NC> __global__ void __launch_bounds__(64 * TNY) kk_mk_D_mb(const M
   mk_D_m_body<NC, true, false, true>(q.s, q.sl0, q.sl1, q.sl2, q.um, q.vm, q.wm, q.force, q.macrhs, q.SC, q.sex, q.sey, q.sez, q.flx, q.fly, q.flz, q.A, q.rf, q.klf, q.umax, c0, ns, BX, BY, BZ);
 }
 // host side of a batch: grids of the four launch shapes per box, their prefix sums, and the upload
+// the fused march for every box of a level in one launch (a descriptor per box and component; see kk_batched for the scheme)
+struct FBatchD { FArgs F; Range3 r; int klen; const double *umax; int g[3]; };
+template <bool INL> __global__ void __launch_bounds__(64 * TNY) kk_mk_F_mb(const FBatchD *descs, const int *start, int nbox) {
+  BATCH_LOCATE(FBatchD, g)
+  bool touch = false;                                // see kk_mk_F_m
+  {
+    const int i0 = q.r.lo[0] - 1 + BX * FNX, i1 = i0 + 63, j0 = q.r.lo[1] - 1 + BY * FNY, j1 = j0 + TNY - 1;
+    const int k0 = q.r.lo[2] + BZ * q.klen - 2, k1 = min(q.r.lo[2] + BZ * q.klen + q.klen - 1, q.r.hi[2]) + 2;
+    const int a0[3] = { i0, j0, k0 }, a1[3] = { i1, j1, k1 };
+    #pragma unroll
+    for (int d = 0; d < 3; d++) {
+      if (bc_mode(q.F.phys[d][0], q.F.is_vel != 0, q.F.c == d) && a0[d] <= q.F.lo[d] + 1) touch = true;
+      if (bc_mode(q.F.phys[d][1], q.F.is_vel != 0, q.F.c == d) && a1[d] >= q.F.hi[d] - 1) touch = true;
+    }
+  }
+  if (touch) mk_F_m_body<true, INL>(q.F, q.r, q.klen, q.umax, BX, BY, BZ);
+  else mk_F_m_body<false, false>(q.F, q.r, q.klen, q.umax, BX, BY, BZ);
+}
+// k-chunks of a box in the batched launch: the boxes of a level fill the device together, so a box is cut only when it is tall
+static void fused_grid_small(const Range3 &r, int &klen, int g[3]) {
+  const int nx = r.hi[0] - r.lo[0] + 1, ny = r.hi[1] - r.lo[1] + 1, nz = r.hi[2] - r.lo[2] + 1;
+  const int chunks = std::max(1, (nz + 47) / 48);
+  klen = (nz + chunks - 1) / chunks;
+  g[0] = (nx + FNX - 1) / FNX; g[1] = (ny + FNY - 1) / FNY; g[2] = (nz + klen - 1) / klen;
+}
+
 template <class D> struct GodBatch {
   std::vector<D> d; const D *dev = nullptr; const int *st[4] = { nullptr, nullptr, nullptr, nullptr }; int tot[4] = { 0, 0, 0, 0 };
   void finish() {
@@ -1310,6 +1336,33 @@ void k_mkflux(const vdn_multifab *s, vdn_multifab **sedge, vdn_multifab **flux, 
     const dim3 blk(64, TNY, 1);
     hipLaunchKernelGGL(kk_macmax_b, dim3(B.tot[1]), dim3(64, 4, 1), 0, st, B.dev, B.st[1], nb);
     hipLaunchKernelGGL(kk_slopes_b<MkD>, dim3(B.tot[0]), dim3(64, 4, 1), 0, st, B.dev, B.st[0], nb, 7);
+    static const bool fused_env = !(getenv("VDN_GOD_FUSED") && atoi(getenv("VDN_GOD_FUSED")) == 0);
+    if (fused_env) {               // stages B + C + D in one march per box and component (mk_F_m_body)
+      std::vector<FBatchD> fd((size_t)nb * ncomp);
+      std::vector<int> fstart((size_t)nb * ncomp);
+      bool ok = true, inflow = false;
+      int tot = 0;
+      for (int ib = 0; ib < nb && ok; ib++) {
+        const MkD &q = B.d[ib];
+        const FV sl[3] = { q.sl0, q.sl1, q.sl2 };
+        for (int d = 0; d < 3; d++) inflow = inflow || q.A.phys[d][0] == VDN_INLET || q.A.phys[d][1] == VDN_INLET;
+        for (int c0 = 0; c0 < ncomp && ok; c0++) {
+          FBatchD &f = fd[(size_t)c0 * nb + ib];
+          ok = fused_args(f.F, q.A, c0, q.s, sl, q.um, q.vm, q.wm, q.force, q.macrhs, q.sex, q.sey, q.sez, q.flx, q.fly, q.flz);
+          f.r = q.rf; f.umax = q.umax;
+          fused_grid_small(f.r, f.klen, f.g);
+        }
+      }
+      if (ok) {
+        for (size_t t = 0; t < fd.size(); t++) { fstart[t] = tot; tot += fd[t].g[0] * fd[t].g[1] * fd[t].g[2]; }
+        FBatchD *dd = (FBatchD *)desc_scratch(sizeof(FBatchD) * fd.size()); int *ds = (int *)desc_scratch(sizeof(int) * fstart.size());
+        upload_staged(dd, fd.data(), sizeof(FBatchD) * fd.size()); upload_staged(ds, fstart.data(), sizeof(int) * fstart.size());
+        if (inflow) hipLaunchKernelGGL(kk_mk_F_mb<true>, dim3(tot), blk, 0, st, dd, ds, (int)fd.size());
+        else hipLaunchKernelGGL(kk_mk_F_mb<false>, dim3(tot), blk, 0, st, dd, ds, (int)fd.size());
+        arena_release(mark);
+        return;
+      }
+    }
     static const int split_env = getenv("VDN_MK_SPLIT") ? atoi(getenv("VDN_MK_SPLIT")) : -1;
     const int split = split_env >= 0 ? split_env : (ncomp >= 2 ? 4 : 0);
     #define MKB_STAGE(K, t, bit)                                                                                               \
@@ -2189,6 +2242,12 @@ static bool vfused_args(VArgs &F, const GArgs &A, const FV &u, const FV sl[3], c
   return true;
 }
 
+struct VBatchD { VArgs F; Range3 r; int klen; const double *umax; int g[3]; };
+template <bool BC, bool INL> __global__ void __launch_bounds__(64 * TNY) kk_vp_F_mb(const VBatchD *descs, const int *start, int nbox) {
+  BATCH_LOCATE(VBatchD, g)
+  vp_F_m_body<BC, INL>(q.F, q.r, q.klen, q.umax, BX, BY, BZ);
+}
+
 // ====================================================================================================
 // dm = 2 (BASELINE.json configs[0], the reference's CPU-runnable case): velpred_2d (velpred.f90:125-524) and mkflux_2d
 // (mkflux.f90:152-691).  Two stages only -- the transverse terms use the stage-B states directly.  One thread per cell
@@ -2450,6 +2509,31 @@ void k_velpred(const vdn_multifab *u, vdn_multifab **umac, const vdn_multifab *f
     const dim3 blk(64, TNY, 1);
     hipLaunchKernelGGL(kk_velmax_b, dim3(B.tot[1]), dim3(64, 4, 1), 0, st, B.dev, B.st[1], nb);
     hipLaunchKernelGGL(kk_slopes_b<VpD>, dim3(B.tot[0]), dim3(64, 4, 1), 0, st, B.dev, B.st[0], nb, 7);
+    static const bool fused_env = !(getenv("VDN_GOD_FUSED") && atoi(getenv("VDN_GOD_FUSED")) == 0);
+    if (fused_env) {               // stages B + C + D in one march per box (vp_F_m_body)
+      std::vector<VBatchD> fd(nb);
+      std::vector<int> fstart(nb);
+      bool ok = true, inflow = false, any = false;
+      int tot = 0;
+      for (int ib = 0; ib < nb && ok; ib++) {
+        const VpD &q = B.d[ib];
+        const FV sl[3] = { q.sl0, q.sl1, q.sl2 };
+        for (int d = 0; d < 3; d++) for (int sd = 0; sd < 2; sd++) { inflow = inflow || q.A.phys[d][sd] == VDN_INLET; any = any || bc_mode_host(q.A.phys[d][sd]); }
+        ok = vfused_args(fd[ib].F, q.A, q.s, sl, q.force, q.um, q.vm, q.wm);
+        fd[ib].r = q.rf; fd[ib].umax = q.umax;
+        fused_grid_small(fd[ib].r, fd[ib].klen, fd[ib].g);
+      }
+      if (ok) {
+        for (int t = 0; t < nb; t++) { fstart[t] = tot; tot += fd[t].g[0] * fd[t].g[1] * fd[t].g[2]; }
+        VBatchD *dd = (VBatchD *)desc_scratch(sizeof(VBatchD) * nb); int *ds = (int *)desc_scratch(sizeof(int) * nb);
+        upload_staged(dd, fd.data(), sizeof(VBatchD) * nb); upload_staged(ds, fstart.data(), sizeof(int) * nb);
+        if (!any) hipLaunchKernelGGL((kk_vp_F_mb<false, false>), dim3(tot), blk, 0, st, dd, ds, nb);
+        else if (inflow) hipLaunchKernelGGL((kk_vp_F_mb<true, true>), dim3(tot), blk, 0, st, dd, ds, nb);
+        else hipLaunchKernelGGL((kk_vp_F_mb<true, false>), dim3(tot), blk, 0, st, dd, ds, nb);
+        arena_release(mark);
+        return;
+      }
+    }
     hipLaunchKernelGGL(kk_vp_B_mb, dim3(B.tot[2]), blk, 0, st, B.dev, B.st[2], nb);
     hipLaunchKernelGGL(kk_vp_C_mb, dim3(B.tot[2]), blk, 0, st, B.dev, B.st[2], nb);
     hipLaunchKernelGGL(kk_vp_D_mb, dim3(B.tot[3]), blk, 0, st, B.dev, B.st[3], nb);
