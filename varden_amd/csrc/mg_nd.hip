@@ -1862,7 +1862,7 @@ static int ml_nd_solve(vdn_layout *la, vdn_multifab **rh, vdn_multifab **phi, vd
     if ((rn <= rel_eps * bnorm && bnorm < HUGE_VAL) || rn <= abs_eps) { conv = true; break; }
     if (it >= max_iter || !(rn < HUGE_VAL) || !(bnorm < HUGE_VAL)) break;
     // coarse correction K_0 e = r_0: one V-cycle of the single-level solver (which takes rh with b = -rh)
-    mf_setval(ee, 0.0, 0, 1, true); mf_setval(er, 0.0, 0, 1, true);
+    mf_setval(ee, 0.0, 0, 1, true);                   // (er: every node is overwritten below, its ghost nodes are never written and stay zero)
     {
       std::vector<NdfNegB> v;
       for (size_t c = 0; c < S.A[0].size(); c++) {
