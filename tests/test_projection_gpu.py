@@ -200,3 +200,35 @@ def test_hgproject(gpu, oracle, bcname, proj_type):
         err = np.abs(g[sl] - o[sl]).max()
         assert err <= 1e-10 * scale, "%s differs after hgproject(%d): %.3e (scale %.3e)" % (name, proj_type, err, scale)
     case.close()
+
+
+def test_multigrid_launch_variants_agree_bit_for_bit(gpu):
+    """the launch-saving forms of the V-cycles change no value: a 128^3 step (the finest MAC level takes the paired density pass only from
+    128 cells up) with (a) the defaults -- prolongation added inside the first post-smoothing sweep (kk_cc_gsrb_rho_pair_t), the levels of
+    at most 9^3 nodes / 8^3 cells in one single-workgroup launch (kk_*_tailcycle), V-cycles replayed as hipGraphs -- against (b) the
+    plain sequence of launches.  The switches are read once per process, hence the child processes."""
+    import hashlib, os, subprocess, sys, textwrap
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = textwrap.dedent("""
+        import sys, hashlib
+        sys.path.insert(0, %r)
+        import numpy as np
+        from varden_amd import driver
+        G = driver.VardenAMR(128, [], [[15, 15]] * 3, init_iter=1, do_initial_projection=1)
+        for _ in range(2):
+            G.step()
+        h = hashlib.sha256()
+        for m in (G.uold[0], G.sold[0], G.p[0], G.gp[0]):
+            h.update(np.ascontiguousarray(m.to_numpy()).tobytes())
+        print("HASH", h.hexdigest(), G.dt)
+    """ % root)
+    out = []
+    for extra in ({}, {"VDN_MG_PROLONG_FUSED": "0", "VDN_MG_TAILCYCLE": "0", "VDN_NO_GRAPHS": "1"}):
+        env = dict(os.environ)
+        for k in ("VDN_MG_PROLONG_FUSED", "VDN_MG_TAILCYCLE", "VDN_NO_GRAPHS"):
+            env.pop(k, None)
+        env.update(extra)
+        r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600, cwd=root)
+        assert r.returncode == 0, r.stderr[-2000:]
+        out.append([ln for ln in r.stdout.splitlines() if ln.startswith("HASH")][0])
+    assert out[0] == out[1], out

@@ -151,6 +151,46 @@ DEVI void pair_gather(const double *v, const CLev &L, long cpA, int par, int lan
   if (par == 0) { o.a[1] = outl; o.a[2] = PA.y; o.b[1] = PB.x; o.b[2] = outr; }
   else          { o.a[1] = PA.x; o.a[2] = outr; o.b[1] = outl; o.b[2] = PB.y; }
 }
+// ADD (the sweep that follows a prolongation, one box without periodic faces): the piecewise-constant correction of the coarse level C is
+// added on the fly instead of by a kk_cc_prolong pass over the level (phi r+w 268 MB, 59 us at 256^3).  ADD = 1, the first colour: every
+// value the pass reads becomes phi + e(parent) -- a 2 x 2 block shares its parent, the six blocks around it give the rest (coarse ghost
+// cells are zero, so box-boundary ghosts stay as they are); the updated cells are stored corrected.  ADD = 2, the second colour: its
+// neighbours are final, only the cell itself still lacks its correction.  The sum phi + e is the one kk_cc_prolong forms.
+template <int ADD> __global__ void __launch_bounds__(256) kk_cc_gsrb_rho_pair_t(CLev L, int color, int interior_only, CLev C) {
+  int bx, by, bz; xcd_block(bx, by, bz);
+  const int lane = threadIdx.x, k = bz;
+  const int t = bx * 64 + lane, jA = 2 * (by * 4 + (int)threadIdx.y);
+  const bool act = 2 * t + 1 < L.n[0] && jA + 1 < L.n[1];
+  const int par = (jA + k + color) & 1;                              // uniform over the wave
+  const long cpA = cidx(L, 2 * min(t, L.n[0] / 2), min(jA, L.n[1] - 2), k);      // clamped: every lane takes part in the lane exchange
+  Pair7 P, R;
+  pair_gather(L.phi, L, cpA, par, lane, P);
+  pair_gather(L.rho, L, cpA, par, lane, R);
+  const double2 RA = *reinterpret_cast<const double2 *>(L.rh + cpA), RB = *reinterpret_cast<const double2 *>(L.rh + cpA + L.PX);
+  if (!act) return;
+  if (ADD) {
+    const int J = jA >> 1, K = k >> 1;
+    const long cc = cidx(C, t, J, K), csy = C.PX, csz = (long)C.PX * C.PY;
+    const double e0 = C.phi[cc];
+    P.a[0] = P.a[0] + e0; P.b[0] = P.b[0] + e0;
+    if (ADD == 1) {
+      const double exm = C.phi[cc - 1], exp_ = C.phi[cc + 1], eym = C.phi[cc - csy], eyp = C.phi[cc + csy], ez = C.phi[(k & 1) ? cc + csz : cc - csz];
+      const double ezm = (k & 1) ? e0 : ez, ezp = (k & 1) ? ez : e0;
+      if (par == 0) { P.a[1] = P.a[1] + exm; P.a[2] = P.a[2] + e0; P.b[1] = P.b[1] + e0; P.b[2] = P.b[2] + exp_; }
+      else          { P.a[1] = P.a[1] + e0; P.a[2] = P.a[2] + exp_; P.b[1] = P.b[1] + exm; P.b[2] = P.b[2] + e0; }
+      P.a[3] = P.a[3] + eym; P.a[4] = P.a[4] + e0; P.b[3] = P.b[3] + e0; P.b[4] = P.b[4] + eyp;
+      P.a[5] = P.a[5] + ezm; P.a[6] = P.a[6] + ezp; P.b[5] = P.b[5] + ezm; P.b[6] = P.b[6] + ezp;
+    }
+  }
+  const int iA = 2 * t + par, iB = 2 * t + 1 - par;
+  double Ap, diag;
+  cc_apply_rho_vals(L, iA, jA, k, P.a, R.a, Ap, diag);
+  if (diag != 0.0 && !(interior_only && cc_is_shell(L, iA, jA, k, interior_only))) L.phi[cpA + par] = P.a[0] + (sel2(RA, par) - Ap) / diag;
+  else if (ADD) L.phi[cpA + par] = P.a[0];
+  cc_apply_rho_vals(L, iB, jA + 1, k, P.b, R.b, Ap, diag);
+  if (diag != 0.0 && !(interior_only && cc_is_shell(L, iB, jA + 1, k, interior_only))) L.phi[cpA + L.PX + 1 - par] = P.b[0] + (sel2(RB, 1 - par) - Ap) / diag;
+  else if (ADD) L.phi[cpA + L.PX + 1 - par] = P.b[0];
+}
 __global__ void __launch_bounds__(256) kk_cc_gsrb_rho_pair(CLev L, int color, int interior_only) {
   int bx, by, bz; xcd_block(bx, by, bz);
   const int lane = threadIdx.x, k = bz;
@@ -1166,6 +1206,22 @@ static void cc_prolong_up(CCMG &M, int l) {
       hipLaunchKernelGGL(kk_cc_prolong_tail, g3(B.L.n[0], B.L.n[1], B.L.n[2], BLK), BLK, 0, ctx().stream, B.L, M.tail[0], B.lo[0] / 2, B.lo[1] / 2, B.lo[2] / 2);
   }
 }
+// prolongation of level l+1 into level l followed by nsweeps of smoothing.  On the finest level of a MAC solve in one box without periodic
+// faces (the paired density pass) the correction is added inside the first sweep (kk_cc_gsrb_rho_pair_t); otherwise kk_cc_prolong first.
+static void cc_prolong_smooth(CCMG &M, int l, int nsweeps) {
+  CDLev &DL = M.dlev[l];
+  static const bool fuse = !(getenv("VDN_MG_PROLONG_FUSED") && atoi(getenv("VDN_MG_PROLONG_FUSED")) == 0);
+  static const bool paired = !(getenv("VDN_GSRB_PAIR") && atoi(getenv("VDN_GSRB_PAIR")) == 0);
+  const bool ok = fuse && paired && nsweeps >= 1 && DL.single_box && DL.boxes.size() == 1 && !DL.halo && l + 1 < (int)M.dlev.size() && M.dlev[l + 1].boxes.size() == 1 &&
+                  !(M.per[0] || M.per[1] || M.per[2]) && DL.boxes[0].L.rho && !DL.boxes[0].L.phi2 &&
+                  DL.boxes[0].L.n[0] % 2 == 0 && DL.boxes[0].L.n[1] % 2 == 0 && DL.boxes[0].L.n[2] % 2 == 0 && DL.boxes[0].L.n[0] >= 128;
+  if (!ok) { cc_prolong_up(M, l); cc_gsrb_d(M, DL, nsweeps); return; }
+  const CLev &L = DL.boxes[0].L, &C = M.dlev[l + 1].boxes[0].L;
+  const dim3 g((unsigned)((L.n[0] / 2 + 63) / 64), (unsigned)((L.n[1] / 2 + 3) / 4), (unsigned)L.n[2]), blk(64, 4, 1);
+  hipLaunchKernelGGL(kk_cc_gsrb_rho_pair_t<1>, g, blk, 0, ctx().stream, L, 0, 0, C);
+  hipLaunchKernelGGL(kk_cc_gsrb_rho_pair_t<2>, g, blk, 0, ctx().stream, L, 1, 0, C);
+  if (nsweeps > 1) cc_gsrb_d(M, DL, nsweeps - 1);
+}
 // error-equation V-cycle on distributed level l (zero initial guess)
 static void cc_vcycle_d(CCMG &M, int l) {
   const vdn_params &P = ctx().prm;
@@ -1181,8 +1237,7 @@ static void cc_vcycle_d(CCMG &M, int l) {
   cc_residual_d(M, DL, false);
   cc_restrict_down(M, l);
   if (last) cc_vcycle_t(M, 0); else cc_vcycle_d(M, l + 1);
-  cc_prolong_up(M, l);
-  cc_gsrb_d(M, DL, P.mg_nu2);
+  cc_prolong_smooth(M, l, P.mg_nu2);
 }
 
 struct CcKeep { bool built = false; CCMG M; };
@@ -1342,8 +1397,7 @@ int cc_solve(vdn_multifab *rh, vdn_multifab *phi, vdn_multifab **beta, const dou
         cc_residual_d(M, D0, false);
         cc_restrict_down(M, 0);
         if (M.dlev.size() > 1) cc_vcycle_d(M, 1); else cc_vcycle_t(M, 0);
-        cc_prolong_up(M, 0);
-        cc_gsrb_d(M, D0, P.mg_nu2);
+        cc_prolong_smooth(M, 0, P.mg_nu2);
       });
     }
     cc_store(M, phi, bc);
@@ -1364,8 +1418,7 @@ int cc_solve(vdn_multifab *rh, vdn_multifab *phi, vdn_multifab **beta, const dou
     else cc_run_cycle(M, 1, [&] {
       cc_restrict_down(M, 0);
       if (M.dlev.size() > 1) cc_vcycle_d(M, 1); else cc_vcycle_t(M, 0);
-      cc_prolong_up(M, 0);
-      cc_gsrb_d(M, D0, P.mg_nu2);
+      cc_prolong_smooth(M, 0, P.mg_nu2);
       cc_gsrb_d(M, D0, P.mg_nu1);
       cc_residual_d(M, D0, true);
     });
