@@ -204,7 +204,8 @@ def test_hgproject(gpu, oracle, bcname, proj_type):
 
 def test_multigrid_launch_variants_agree_bit_for_bit(gpu):
     """the launch-saving forms of the V-cycles change no value: a 128^3 step (the finest MAC level takes the paired density pass only from
-    128 cells up) with (a) the defaults -- prolongation added inside the first post-smoothing sweep (kk_cc_gsrb_rho_pair_t), the levels of
+    128 cells up) with (a) the defaults -- prolongation added inside the first post-smoothing sweep (kk_cc_gsrb_rho_pair_t), restriction inside the
+    residual pass (kk_cc_residual_rho_pair_rst), the levels of
     at most 9^3 nodes / 8^3 cells in one single-workgroup launch (kk_*_tailcycle), V-cycles replayed as hipGraphs -- against (b) the
     plain sequence of launches.  The switches are read once per process, hence the child processes."""
     import hashlib, os, subprocess, sys, textwrap
@@ -223,9 +224,9 @@ def test_multigrid_launch_variants_agree_bit_for_bit(gpu):
         print("HASH", h.hexdigest(), G.dt)
     """ % root)
     out = []
-    for extra in ({}, {"VDN_MG_PROLONG_FUSED": "0", "VDN_MG_TAILCYCLE": "0", "VDN_NO_GRAPHS": "1"}):
+    for extra in ({}, {"VDN_MG_PROLONG_FUSED": "0", "VDN_MG_RESTRICT_FUSED": "0", "VDN_MG_TAILCYCLE": "0", "VDN_NO_GRAPHS": "1"}):
         env = dict(os.environ)
-        for k in ("VDN_MG_PROLONG_FUSED", "VDN_MG_TAILCYCLE", "VDN_NO_GRAPHS"):
+        for k in ("VDN_MG_PROLONG_FUSED", "VDN_MG_RESTRICT_FUSED", "VDN_MG_TAILCYCLE", "VDN_NO_GRAPHS"):
             env.pop(k, None)
         env.update(extra)
         r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600, cwd=root)

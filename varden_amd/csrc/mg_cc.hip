@@ -550,6 +550,45 @@ __global__ void __launch_bounds__(256) kk_cc_residual_rho_pair(CLev L, double *n
   }
   if (nrm) block_atomic_max(nrm, rmax);
 }
+// the same residual with the restriction inside: the thread's 2 x 2 block of planes 2K and 2K+1 is exactly the eight children of coarse cell
+// (t, J, K); their residuals are summed in the order of kk_cc_restrict and stored as the coarse right-hand side (coarse phi = 0), the fine
+// residual itself is not stored -- nothing else reads it (saves its 134 MB write and the 27 us restriction pass at 256^3)
+__global__ void __launch_bounds__(256) kk_cc_residual_rho_pair_rst(CLev L, double *nrm, CLev C) {
+  int bx, by, bz; xcd_block(bx, by, bz);
+  const int lane = threadIdx.x;
+  const int t = bx * 64 + lane, jA = 2 * (by * 4 + (int)threadIdx.y);
+  const bool act = 2 * t + 1 < L.n[0] && jA + 1 < L.n[1];
+  double rmax = 0.0;
+  for (int K = bz; K < L.n[2] / 2; K += gridDim.z) {
+    double s = 0.0;
+    #pragma unroll
+    for (int kk = 0; kk < 2; kk++) {
+      const int k = 2 * K + kk;
+      const long cpA = cidx(L, 2 * min(t, L.n[0] / 2), min(jA, L.n[1] - 2), k);
+      double P[4][7], R[4][7];
+      quad_gather(L.phi, L, cpA, lane, P);
+      quad_gather(L.rho, L, cpA, lane, R);
+      const double2 RA = *reinterpret_cast<const double2 *>(L.rh + cpA), RB = *reinterpret_cast<const double2 *>(L.rh + cpA + L.PX);
+      if (act) {
+        double Ap, diag;
+        const double rhs[4] = { RA.x, RA.y, RB.x, RB.y };
+        #pragma unroll
+        for (int m = 0; m < 4; m++) {
+          cc_apply_rho_vals(L, 2 * t + (m & 1), jA + (m >> 1), k, P[m], R[m], Ap, diag);
+          const double r = rhs[m] - Ap;
+          rmax = nmax(rmax, fabs(r));
+          s = (kk == 0 && m == 0) ? r : s + r;
+        }
+      }
+    }
+    if (act) {
+      const long cc = cidx(C, t, jA >> 1, K);
+      C.rh[cc] = s * 0.125;
+      C.phi[cc] = 0.0;
+    }
+  }
+  if (nrm) block_atomic_max(nrm, rmax);
+}
 __global__ void __launch_bounds__(256) kk_cc_residual(CLev L, double *nrm) { cc_residual_body<false>(L, nrm); }
 __global__ void __launch_bounds__(256) kk_cc_residual_rho(CLev L, double *nrm) { cc_residual_body<true>(L, nrm); }
 
@@ -888,7 +927,8 @@ __global__ void kk_cc_prolong_tail(CLev F, CLev T, int c00, int c01, int c02) {
 
 // ---- host side ------------------------------------------------------------------------------------------
 struct CBox { CLev L; int lo[3]; int gidx; int hmask = 63; /* faces whose ghost cells come from the halo exchange */ };                    // one local box on one distributed level; lo = global index of its cell 0
-struct CDLev { std::vector<CBox> boxes; XPlan *halo = nullptr; int ng[3]; /* global extents of the level */ bool single_box = false; };
+struct CDLev { std::vector<CBox> boxes; XPlan *halo = nullptr; int ng[3]; /* global extents of the level */ bool single_box = false;
+               bool res_restricted = false; /* the last residual pass already restricted into the next level */ };
 struct CCMG {
   std::vector<CDLev> dlev;          // distributed levels (finest first)
   std::vector<CLev> tail;           // agglomerated levels, whole domain, replicated on every rank
@@ -1096,6 +1136,22 @@ static void cc_gsrb_d(CCMG &M, CDLev &DL, int nsweeps) {
 static void cc_residual_d(CCMG &M, CDLev &DL, bool norm) {
   cc_halo(M, DL);
   if (norm) HIPCHK(hipMemsetAsync(M.d_nrm, 0, sizeof(double), ctx().stream));
+  DL.res_restricted = false;
+  {   // the finest level of a MAC solve in one box: residual and restriction in one pass (kk_cc_residual_rho_pair_rst); cc_restrict_down then skips
+    static const bool fuse = !(getenv("VDN_MG_RESTRICT_FUSED") && atoi(getenv("VDN_MG_RESTRICT_FUSED")) == 0);
+    static const bool paired0 = !(getenv("VDN_GSRB_PAIR") && atoi(getenv("VDN_GSRB_PAIR")) == 0);
+    const size_t l = &DL - &M.dlev[0];
+    if (fuse && paired0 && DL.single_box && DL.boxes.size() == 1 && l + 1 < M.dlev.size() && M.dlev[l + 1].boxes.size() == 1) {
+      const CLev &L = DL.boxes[0].L;
+      if (L.rho && L.n[0] % 2 == 0 && L.n[1] % 2 == 0 && L.n[2] % 2 == 0 && L.n[0] >= 128) {
+        const dim3 g((unsigned)((L.n[0] / 2 + 63) / 64), (unsigned)((L.n[1] / 2 + 3) / 4), (unsigned)std::min(L.n[2] / 2, 16));
+        hipLaunchKernelGGL(kk_cc_residual_rho_pair_rst, g, BLK, 0, ctx().stream, L, norm ? M.d_nrm : nullptr, M.dlev[l + 1].boxes[0].L);
+        DL.res_restricted = true;
+        if (norm) comm_allreduce_max_dev(M.d_nrm, 1);
+        return;
+      }
+    }
+  }
   for (const CBox &B : DL.boxes) {
     const dim3 g = g3(B.L.n[0], B.L.n[1], norm ? std::min(B.L.n[2], 16) : B.L.n[2], BLK);
     static const bool paired = !(getenv("VDN_GSRB_PAIR") && atoi(getenv("VDN_GSRB_PAIR")) == 0);
@@ -1179,6 +1235,7 @@ static void cc_vcycle_t(const CCMG &M, int l) {
 // restrict the residual of distributed level l into level l+1 (distributed) or into the tail (gather)
 static void cc_restrict_down(CCMG &M, int l) {
   CDLev &DL = M.dlev[l];
+  if (DL.res_restricted) { DL.res_restricted = false; return; }      // done inside the residual pass
   if (l + 1 < (int)M.dlev.size()) {
     CDLev &DC = M.dlev[l + 1];
     for (size_t b = 0; b < DL.boxes.size(); b++) {
@@ -1257,7 +1314,7 @@ static unsigned long long cc_graph_key(const CCMG &M, int what) {
   GraphKey k; k.put(what); k.put(P.mg_nu1); k.put(P.mg_nu2); k.put(P.mg_nub); k.put(M.per); k.put(M.d_nrm);
   k.put(M.sendbuf); k.put(M.recvbuf); k.put(M.d_gb_rh); k.put(M.d_gb_b); k.put(M.cnt_rh); k.put(M.cnt_b);
   for (const CDLev &DL : M.dlev) {
-    k.put(xplan_serial(DL.halo)); k.put(DL.ng); k.put(DL.single_box);
+    k.put(xplan_serial(DL.halo)); k.put(DL.ng); k.put(DL.single_box); k.put(DL.res_restricted);
     for (const CBox &B : DL.boxes) { cc_key_lev(k, B.L); k.put(B.lo); }
   }
   for (const CLev &L : M.tail) cc_key_lev(k, L);
