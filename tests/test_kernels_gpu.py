@@ -217,7 +217,8 @@ def test_physbc_fill_boundary_estdt(gpu, oracle, bcname):
 def test_godunov_marching_equals_face_centred(gpu, shape):
     """three forms of the Godunov stages agree bit for bit: the default (mkflux: stages B + C + D fused into one march per component,
     velpred: one march per stage), the unfused marches (VDN_GOD_FUSED=0) and the face-centred one-thread-per-cell kernels
-    (VDN_GODUNOV_PLAIN=1); the switches are read at the first launch of a process, hence the child processes.  The second shape spans
+    (VDN_GODUNOV_PLAIN=1, there also with the per-cell slopes kernel instead of the marching one); the switches are read at the first launch of a
+    process, hence the child processes.  The second shape spans
     two x-tiles, three y-tiles and several k-chunks of the fused march; the faces carry all four boundary rules."""
     import os, subprocess, sys, textwrap
     code = textwrap.dedent("""
@@ -250,9 +251,9 @@ def test_godunov_marching_equals_face_centred(gpu, shape):
         print("HASH", h.hexdigest())
     """ % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), max(shape), shape[0], shape[1], shape[2]))
     out = []
-    for extra in ({}, {"VDN_GOD_FUSED": "0"}, {"VDN_GODUNOV_PLAIN": "1"}, {"VDN_FUSED_KCHUNKS": "5"}):
+    for extra in ({}, {"VDN_GOD_FUSED": "0"}, {"VDN_GODUNOV_PLAIN": "1", "VDN_SLOPES_MARCH": "0"}, {"VDN_FUSED_KCHUNKS": "5"}):
         env = dict(os.environ)
-        for k in ("VDN_GODUNOV_PLAIN", "VDN_GOD_FUSED", "VDN_FUSED_KCHUNKS"):
+        for k in ("VDN_GODUNOV_PLAIN", "VDN_GOD_FUSED", "VDN_FUSED_KCHUNKS", "VDN_SLOPES_MARCH"):
             env.pop(k, None)
         env.update(extra)
         r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
