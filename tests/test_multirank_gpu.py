@@ -59,6 +59,18 @@ def test_ranks_reproduce_single_rank_bits(gpu, tmp_path, nranks, decomp, n, peri
     assert np.isfinite(got["u0"]).all() and np.abs(got["u0"]).max() > 0
 
 
+def test_two_ranks_of_128_cubed_with_the_default_overlap_rule(gpu, tmp_path, monkeypatch):
+    """boxes of 2^21 cells: large enough for the default rule (VDN_OVERLAP unset) to put the halo traffic of the finest multigrid level on the
+    second stream and finish its face cells in the shell kernels, for the paired density pass of the MAC solve (n >= 128) and for the fused
+    Godunov marches with interior box faces; the coarser levels take the serial path.  One step, against the single-rank bits."""
+    monkeypatch.setenv("VDN_OVERLAP", "-1")                 # run_ranks passes it on: -1 = the library's own rule
+    ref = run_ranks(tmp_path, "ref", 1, (2, 1, 1), (256, 128, 128), 1, False)
+    got = run_ranks(tmp_path, "mr", 2, (2, 1, 1), (256, 128, 128), 1, False)
+    assert np.array_equal(ref["dt"], got["dt"]), (ref["dt"], got["dt"])
+    for k in sorted(ref):
+        assert np.array_equal(ref[k], got[k]), "%s differs: max %.3e" % (k, np.abs(ref[k] - got[k]).max())
+
+
 def _ngpus():
     import torch
     return torch.cuda.device_count()          # counting devices does not initialise the GPU
