@@ -327,18 +327,26 @@ void ml_create_umac_grown(vdn_multifab *fine, const vdn_multifab *crse, int dir)
   std::vector<GrownB> v0, v1;
   for (int f = 0; f < fine->nfabs(); f++) {
     GrownB e; e.A.dir = dir; e.fine = fine->fabs[f];
-    for (int d = 0; d < 3; d++) { e.A.flo[d] = fine->vbox[f].lo[d]; e.A.fhi[d] = fine->vbox[f].hi[d] + (d == dir); e.r.lo[d] = e.A.flo[d] - fine->ng; e.r.hi[d] = e.A.fhi[d] + fine->ng; }
+    Range3 rfull;
+    for (int d = 0; d < 3; d++) { e.A.flo[d] = fine->vbox[f].lo[d]; e.A.fhi[d] = fine->vbox[f].hi[d] + (d == dir); rfull.lo[d] = e.A.flo[d] - fine->ng; rfull.hi[d] = e.A.fhi[d] + fine->ng; }
+    // a (fine box, coarse box) pair only covers the fine faces whose parents [2 plo, 2 phi + 1] the coarse box can hold: with every pair
+    // launched over the whole grown fine box a level of 997 boxes over 263 took 48 ms per call (262 000 box-sized sub-launches)
+    auto clip = [&](GrownB &q) {
+      for (int d = 0; d < 3; d++) { q.r.lo[d] = std::max(rfull.lo[d], 2 * q.A.plo[d]); q.r.hi[d] = std::min(rfull.hi[d], 2 * q.A.phi[d] + 1); if (q.r.lo[d] > q.r.hi[d]) return false; }
+      return true;
+    };
     bool first = true;
     for (int c = 0; c < Cv.nboxes(); c++) {
       if (!Cv.have[c]) continue;
       e.crse = Cv.fv[c];
       if (first) {        // the first box present here, with its ghost faces
         for (int d = 0; d < 3; d++) { e.A.plo[d] = Cv.vbox[c].lo[d] - Cv.ng; e.A.phi[d] = Cv.vbox[c].hi[d] + (d == dir) + Cv.ng; }
+        e.r = rfull;      // (kept whole: it is the one that also serves parents no box holds as valid faces)
         v0.push_back(e); first = false;
       }
       if (Cv.nboxes() > 1) {
         for (int d = 0; d < 3; d++) { e.A.plo[d] = Cv.vbox[c].lo[d]; e.A.phi[d] = Cv.vbox[c].hi[d] + (d == dir); }
-        v1.push_back(e);
+        if (clip(e)) v1.push_back(e);
       }
     }
   }
