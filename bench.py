@@ -146,7 +146,7 @@ def main():
                                                comm_id=comm_id, base_boxes=base_boxes)
         assert len(levels) == max_levs - 1, "tagging produced %d refined levels, %d wanted" % (len(levels), max_levs - 1)
         G = driver.VardenAMR(n, levels[0], walls, params=prm, finer_levels=levels[1:], init_shrink=0.1, init_iter=1, do_initial_projection=1,
-                             device=local_rank, rank=rank, nranks=world, comm_id=comm_id, base_boxes=base_boxes, max_grid_size=mgs)
+                             device=local_rank, rank=rank, nranks=world, comm_id=comm_id, base_boxes=base_boxes, max_grid_size=mgs, swap_state=True)
         lev_cells = [n ** 3] + [sum(int(np.prod([b[1][d] - b[0][d] + 1 for d in range(3)])) for b in lb) for lb in levels]
         cells = sum(lev_cells)
         workload = ("3D %d-level AMR, base %d^3, refined levels tagged rho > 1.01%s (tag_boxes.f90:65-84), fixed grids: %s boxes, %s cells per level; "
@@ -165,7 +165,8 @@ def main():
         h = 1.0 / (n * max(decomp))                        # dx = dy = dz; 2x2x2 gives the unit cube
         prob_hi = tuple(nglob[d] * h for d in range(3))
         G = driver.Varden(nglob, walls, prm, prob_type=1, grav=-9.8, prob_hi=prob_hi, init_shrink=0.1, init_iter=1,
-                          device=local_rank, decomp=decomp, rank=rank, nranks=world, comm_id=comm_id)
+                          device=local_rank, decomp=decomp, rank=rank, nranks=world, comm_id=comm_id,
+                          swap_state=True)     # uold <- unew as a handle exchange (tests/test_advance_gpu.py::test_handle_swap_equals_copy)
         cells = nglob[0] * nglob[1] * nglob[2]
         nb = decomp[0] * decomp[1] * decomp[2]
         workload = ("3D %dx%dx%d single-level variable-density bubble, %d box(es) of %d^3, MAC+HG projection each step (BASELINE.json configs[%d])"

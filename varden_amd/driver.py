@@ -78,13 +78,14 @@ def _limit_dt(sim, dt, first=False):
 class Varden:
     def __init__(self, n, phys_bc, params=None, prob_type=1, grav=-9.8, prob_hi=(1.0, 1.0, 1.0), init_shrink=1.0,
                  init_iter=4, do_initial_projection=1, u0=None, s0=None, device=0, decomp=(1, 1, 1), rank=0, nranks=1,
-                 comm_id=None, restart=None, restart_step=0, fixed_dt=-1.0, stop_time=-1.0):
+                 comm_id=None, restart=None, restart_step=0, fixed_dt=-1.0, stop_time=-1.0, swap_state=False):
         """decomp = (bx, by, bz): the domain is cut into bx*by*bz equal boxes (max_grid_size of the reference,
         src/_parameters:27), dealt round-robin to the ranks (one rank per GPU).  comm_id: the 128-byte RCCL unique
         id broadcast by the caller when nranks > 1.  restart: a checkpoint read by plotfile.read_checkfile -- the state comes from it
         and the start-up sequence (initial projection, pressure iterations) is skipped, src/varden.f90:94-97, 119, 180, 227."""
         self.prm = params or default_params()
         self.fixed_dt, self.stop_time = float(fixed_dt), float(stop_time)
+        self.swap_state = bool(swap_state)     # uold <- unew by exchanging the handles instead of copying (see step)
         dm = int(self.prm.dm)
         self.n = tuple(int(x) for x in (n if hasattr(n, "__len__") else (n,) * dm))
         if dm == 2:
@@ -174,8 +175,15 @@ class Varden:
         if self.istep > 1:
             self.dt = _limit_dt(self, self.estdt(self.dt))
         self.advance(bl.REGULAR_TIMESTEP, self.istep)
-        self.uold[0].copy_c(0, self.unew[0], 0, self.dm, 0)
-        self.sold[0].copy_c(0, self.snew[0], 0, self.nscal, 0)
+        if self.swap_state:
+            # varden.f90:323-326 copies the valid cells; exchanging the handles gives the same next step because every ghost cell of
+            # uold / sold is refilled before it is read (fill_state_ghosts above) and advance_timestep overwrites unew / snew. After such a
+            # step self.unew / self.snew hold the PREVIOUS state.
+            self.uold[0], self.unew[0] = self.unew[0], self.uold[0]
+            self.sold[0], self.snew[0] = self.snew[0], self.sold[0]
+        else:
+            self.uold[0].copy_c(0, self.unew[0], 0, self.dm, 0)
+            self.sold[0].copy_c(0, self.snew[0], 0, self.nscal, 0)
         self.time += self.dt
 
     def gather_valid(self, mf):
@@ -227,7 +235,7 @@ class VardenAMR:
     def __init__(self, nc, fine_boxes, phys_bc, params=None, prob_type=1, grav=-9.8, init_shrink=0.1, device=0, finer_levels=(),
                  regrid_int=-1, max_levs=None, max_grid_size=256, init_iter=0, do_initial_projection=0,
                  rank=0, nranks=1, comm_id=None, base_boxes=None, init_fn=None, restart=None, restart_step=0,
-                 fixed_dt=-1.0, stop_time=-1.0, amr_buf_width=-1):
+                 fixed_dt=-1.0, stop_time=-1.0, amr_buf_width=-1, swap_state=False):
         """init_fn(level, box_lo, box_shape, dx) -> (u, s) with 3 ghost layers replaces the analytic initial data of prob_type.
         several ranks (one per GPU): the boxes of every level are dealt to the ranks by cell count (`distribute`), `base_boxes` cuts
         level 0 into several boxes, comm_id is the RCCL unique id broadcast by the caller; regridding is single-rank in this round"""
@@ -235,6 +243,7 @@ class VardenAMR:
         self.grav, self.regrid_int, self.max_grid_size = grav, regrid_int, max_grid_size
         self.amr_buf_width = max(amr_buf_width, regrid_int, 1)    # the tag buffer of initialize.f90:248 AND regrid.f90:149 (probin.template:147-154)
         self.fixed_dt, self.stop_time = float(fixed_dt), float(stop_time)
+        self.swap_state = bool(swap_state)     # uold <- unew by exchanging the handles instead of copying (see step)
         self.prm.prob_type = prob_type
         self.rank, self.nranks = rank, nranks
         bl.initialize(self.prm, rank, nranks, device)
@@ -352,8 +361,12 @@ class VardenAMR:
         adv.advance_timestep(self.istep, self.mla, self.sold, self.uold, self.snew, self.unew, self.gp, self.p,
                              self.ext_vel_force, self.ext_scal_force, self.bct, self.dt, self.time, self.dx, self.press_comp, bl.REGULAR_TIMESTEP)
         for n in range(self.nlev):
-            self.uold[n].copy_c(0, self.unew[n], 0, self.dm, 0)
-            self.sold[n].copy_c(0, self.snew[n], 0, self.nscal, 0)
+            if self.swap_state:                      # see Varden.step
+                self.uold[n], self.unew[n] = self.unew[n], self.uold[n]
+                self.sold[n], self.snew[n] = self.snew[n], self.sold[n]
+            else:
+                self.uold[n].copy_c(0, self.unew[n], 0, self.dm, 0)
+                self.sold[n].copy_c(0, self.snew[n], 0, self.nscal, 0)
         self.time += self.dt
 
     # ---- regridding (src/regrid.f90:17-263) ------------------------------------------------------------------------------------
