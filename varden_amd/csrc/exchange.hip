@@ -202,7 +202,9 @@ unsigned long xplan_serial(const XPlan *P) { return P ? P->serial : 0; }
 // the plan for: every box b (global list) has valid point range [vlo,vhi] (incl. nodal points) and, if
 // local, an FV view; ghosts of width ng are filled from other boxes' valid points, through periodic
 // shifts of the domain `pd` where pmask says so.
-XPlan *xplan_build(const std::vector<XBoxInfo> &boxes, const vdn_box &pd, const int pmask[3], int ng, int nc) {
+// faces_only: only the ghost cells that lie outside the valid box in exactly ONE direction are filled (what a 7-point operator reads): with a
+// 2 x 2 x 2 decomposition a rank then exchanges with its three face neighbours instead of seven peers per colour pass
+XPlan *xplan_build(const std::vector<XBoxInfo> &boxes, const vdn_box &pd, const int pmask[3], int ng, int nc, bool faces_only) {
   static unsigned long next_serial = 0;
   XPlan *P = new XPlan; P->nc = nc; P->serial = ++next_serial;
   const int me = ctx().rank;
@@ -230,6 +232,24 @@ XPlan *xplan_build(const std::vector<XBoxInfo> &boxes, const vdn_box &pd, const 
           if (lo[d] < B.vlo[d] || hi[d] > B.vhi[d]) all_inside = false;
         }
         if (empty || all_inside) continue;
+        // the sub-regions to exchange: the whole overlap, or (faces_only) its parts beyond one face of B with the other two directions cut
+        // to B's valid range
+        int nsub = 1, slo[6][3], shi[6][3];
+        for (int d = 0; d < 3; d++) { slo[0][d] = lo[d]; shi[0][d] = hi[d]; }
+        if (faces_only) {
+          nsub = 0;
+          for (int d = 0; d < 3; d++) for (int side = 0; side < 2; side++) {
+            int a[3], b[3]; bool ok = true;
+            for (int t = 0; t < 3; t++) {
+              if (t == d) { a[t] = side ? std::max(lo[t], B.vhi[t] + 1) : lo[t]; b[t] = side ? hi[t] : std::min(hi[t], B.vlo[t] - 1); }
+              else { a[t] = std::max(lo[t], B.vlo[t]); b[t] = std::min(hi[t], B.vhi[t]); }
+              if (a[t] > b[t]) ok = false;
+            }
+            if (ok) { for (int t = 0; t < 3; t++) { slo[nsub][t] = a[t]; shi[nsub][t] = b[t]; } nsub++; }
+          }
+        }
+        for (int q = 0; q < nsub; q++) {
+        for (int d = 0; d < 3; d++) { lo[d] = slo[q][d]; hi[d] = shi[q][d]; }
         const long cnt = (long)(hi[0] - lo[0] + 1) * (hi[1] - lo[1] + 1) * (hi[2] - lo[2] + 1) * nc;
         if (B.owner == me && S.owner == me && !force_packed) {
           CopyDesc D; memset(&D, 0, sizeof D);
@@ -247,6 +267,7 @@ XPlan *xplan_build(const std::vector<XBoxInfo> &boxes, const vdn_box &pd, const 
             Peer &pr = peers[S.owner]; pr.rank = S.owner;
             PackDesc Dr = D; Dr.fv = B.fv; Dr.off = (long)pr.nrecv; pr.nrecv += cnt; pr.unpack.push_back(Dr);
           }
+        }
         }
       }
     }

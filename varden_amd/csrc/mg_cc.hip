@@ -963,6 +963,8 @@ static FV cc_phi_view(const CLev &L, const int lo[3]) {
   return f;
 }
 
+// the 7-point operator reads no edge or corner ghost cell: the halo of phi carries the face cells only (VDN_CC_HALO_FACES=0: the whole shell)
+static bool cc_faces_only() { static const bool f = !(getenv("VDN_CC_HALO_FACES") && atoi(getenv("VDN_CC_HALO_FACES")) == 0); return f; }
 // plans for the per-level phi halos are cached across solves: arena addresses repeat from step to step
 struct HaloKey { unsigned long uid; const void *p0; int lev, l, per; bool operator<(const HaloKey &o) const { return std::tie(uid, p0, lev, l, per) < std::tie(o.uid, o.p0, o.lev, o.l, o.per); } };
 static std::map<HaloKey, XPlan *> g_halo_cache;
@@ -1024,7 +1026,7 @@ static void cc_build(CCMG &M, const vdn_multifab *rh, const double *dx, const in
     if (nb > 1 || M.per[0] || M.per[1] || M.per[2]) {
       HaloKey key{ la->uid, DL.boxes.empty() ? nullptr : (const void *)DL.boxes[0].L.phi, lev, (int)M.dlev.size(), M.per[0] | (M.per[1] << 1) | (M.per[2] << 2) };
       auto it = g_halo_cache.find(key);
-      if (it == g_halo_cache.end()) { XPlan *P = xplan_build(xb, lpd, M.per, 1, 1); halo_cache_register(la->uid, P); it = g_halo_cache.emplace(key, P).first; }
+      if (it == g_halo_cache.end()) { XPlan *P = xplan_build(xb, lpd, M.per, 1, 1, cc_faces_only()); halo_cache_register(la->uid, P); it = g_halo_cache.emplace(key, P).first; }
       DL.halo = it->second;
     }
     DL.single_box = (nb == 1);
