@@ -136,7 +136,7 @@ void comm_allgather_dev(const double *send, double *recv, size_t count) {
 // exchange plans
 // ====================================================================================================
 struct CopyDesc { FV dst, src; int lo[3], hi[3]; int sh[3]; int vlo[3], vhi[3]; };
-struct PackDesc { FV fv; int lo[3], hi[3]; int sh[3]; int vlo[3], vhi[3]; long off; };   // pack: fv = src (read at q - sh); unpack: fv = dst
+struct PackDesc { FV fv; int lo[3], hi[3]; int sh[3]; int vlo[3], vhi[3]; long off; double *buf; };   // pack: fv = src (read at q - sh); unpack: fv = dst; buf: the peer's buffer
 
 // box-to-box ghost copies of a level in one launch: a descriptor per (destination, source, shift) overlap, XCOPY_CHUNK points per
 // workgroup, workgroups bisect the prefix sum of chunk counts (a level of a few hundred boxes has thousands of thin slabs)
@@ -184,6 +184,30 @@ __global__ void k_xunpack(const PackDesc *descs, int nc, const double *buf) {
   }
 }
 
+// all peers in one launch (the descriptor names its peer's buffer): with seven peers per rank a launch per peer and direction put 14 small
+// kernels around every ncclGroup
+__global__ void k_xpack_all(const PackDesc *descs, int nc) {
+  const PackDesc &D = descs[blockIdx.x / XPACK_WG];
+  const int nx = D.hi[0] - D.lo[0] + 1, ny = D.hi[1] - D.lo[1] + 1, nz = D.hi[2] - D.lo[2] + 1;
+  const long tot = (long)nx * ny * nz;
+  double *buf = D.buf;
+  for (long t = (long)(blockIdx.x % XPACK_WG) * blockDim.x + threadIdx.x; t < tot; t += (long)XPACK_WG * blockDim.x) {
+    const int i = D.lo[0] + (int)(t % nx), j = D.lo[1] + (int)((t / nx) % ny), k = D.lo[2] + (int)(t / ((long)nx * ny));
+    for (int c = 0; c < nc; c++) buf[D.off + c * tot + t] = fv_get(D.fv, i - D.sh[0], j - D.sh[1], k - D.sh[2], c);
+  }
+}
+__global__ void k_xunpack_all(const PackDesc *descs, int nc) {
+  const PackDesc &D = descs[blockIdx.x / XPACK_WG];
+  const int nx = D.hi[0] - D.lo[0] + 1, ny = D.hi[1] - D.lo[1] + 1, nz = D.hi[2] - D.lo[2] + 1;
+  const long tot = (long)nx * ny * nz;
+  const double *buf = D.buf;
+  for (long t = (long)(blockIdx.x % XPACK_WG) * blockDim.x + threadIdx.x; t < tot; t += (long)XPACK_WG * blockDim.x) {
+    const int i = D.lo[0] + (int)(t % nx), j = D.lo[1] + (int)((t / nx) % ny), k = D.lo[2] + (int)(t / ((long)nx * ny));
+    const bool inside = i >= D.vlo[0] && i <= D.vhi[0] && j >= D.vlo[1] && j <= D.vhi[1] && k >= D.vlo[2] && k <= D.vhi[2];
+    if (inside) continue;
+    for (int c = 0; c < nc; c++) fv_at(D.fv, i, j, k, c) = buf[D.off + c * tot + t];
+  }
+}
 struct Peer {
   int rank = -1;
   std::vector<PackDesc> pack, unpack;
@@ -194,6 +218,7 @@ struct Peer {
 struct XPlan {
   std::vector<CopyDesc> local; CopyDesc *d_local = nullptr; int *d_lstart = nullptr; int lchunks = 0;
   std::vector<Peer> peers;
+  PackDesc *d_pack_all = nullptr, *d_unpack_all = nullptr; int npack_all = 0, nunpack_all = 0;      // the descriptors of all peers, one launch each way
   int nc = 1;
   unsigned long serial = 0;          // unique over the life of the process: cache keys (hipGraph replay) must not match a new plan that malloc put at a freed plan's address
 };
@@ -296,6 +321,16 @@ XPlan *xplan_build(const std::vector<XBoxInfo> &boxes, const vdn_box &pd, const 
       HIPCHK(hipMalloc((void **)&pr.d_recv, pr.nrecv * sizeof(double))); }
     P->peers.push_back(pr);
   }
+  {
+    std::vector<PackDesc> ap, au;
+    for (auto &pr : P->peers) {
+      for (PackDesc D : pr.pack) { D.buf = pr.d_send; ap.push_back(D); }
+      for (PackDesc D : pr.unpack) { D.buf = pr.d_recv; au.push_back(D); }
+    }
+    P->npack_all = (int)ap.size(); P->nunpack_all = (int)au.size();
+    if (!ap.empty()) { HIPCHK(hipMalloc((void **)&P->d_pack_all, ap.size() * sizeof(PackDesc))); HIPCHK(hipMemcpy(P->d_pack_all, ap.data(), ap.size() * sizeof(PackDesc), hipMemcpyHostToDevice)); }
+    if (!au.empty()) { HIPCHK(hipMalloc((void **)&P->d_unpack_all, au.size() * sizeof(PackDesc))); HIPCHK(hipMemcpy(P->d_unpack_all, au.data(), au.size() * sizeof(PackDesc), hipMemcpyHostToDevice)); }
+  }
   HIPCHK(hipStreamSynchronize(st));
   return P;
 }
@@ -305,6 +340,8 @@ void xplan_free(XPlan *P) {
   HIPCHK(hipStreamSynchronize(ctx().stream));
   if (P->d_local) HIPCHK(hipFree(P->d_local));
   if (P->d_lstart) HIPCHK(hipFree(P->d_lstart));
+  if (P->d_pack_all) HIPCHK(hipFree(P->d_pack_all));
+  if (P->d_unpack_all) HIPCHK(hipFree(P->d_unpack_all));
   for (auto &pr : P->peers) {
     if (pr.d_pack) HIPCHK(hipFree(pr.d_pack));
     if (pr.d_unpack) HIPCHK(hipFree(pr.d_unpack));
@@ -327,10 +364,8 @@ void xplan_run(XPlan *P, hipStream_t st) {
   if (!P->peers.empty()) {
     const bool self_rccl = packed_mode() == 2 && g_rccl.comm != nullptr;    // self peer through ncclSend/ncclRecv
     bool remote = self_rccl;
-    for (auto &pr : P->peers) {
-      if (pr.rank != ctx().rank) remote = true;
-      if (!pr.pack.empty()) hipLaunchKernelGGL(k_xpack, dim3(XPACK_WG * (unsigned)pr.pack.size()), dim3(256), 0, st, pr.d_pack, nc, pr.d_send);
-    }
+    for (auto &pr : P->peers) if (pr.rank != ctx().rank) remote = true;
+    if (P->npack_all) hipLaunchKernelGGL(k_xpack_all, dim3(XPACK_WG * (unsigned)P->npack_all), dim3(256), 0, st, P->d_pack_all, nc);
     if (remote) {
       need_comm();
       NCCLCHK(g_rccl.GroupStart());
@@ -346,8 +381,7 @@ void xplan_run(XPlan *P, hipStream_t st) {
   }
   if (!P->local.empty())
     hipLaunchKernelGGL(k_xcopy, dim3((unsigned)P->lchunks), dim3(256), 0, st, P->d_local, P->d_lstart, (int)P->local.size(), nc);
-  for (auto &pr : P->peers)
-    if (!pr.unpack.empty()) hipLaunchKernelGGL(k_xunpack, dim3(XPACK_WG * (unsigned)pr.unpack.size()), dim3(256), 0, st, pr.d_unpack, nc, pr.d_recv);
+  if (P->nunpack_all) hipLaunchKernelGGL(k_xunpack_all, dim3(XPACK_WG * (unsigned)P->nunpack_all), dim3(256), 0, st, P->d_unpack_all, nc);
 }
 
 // ====================================================================================================
@@ -355,6 +389,7 @@ void xplan_run(XPlan *P, hipStream_t st) {
 // ====================================================================================================
 struct ViewPlan {
   std::vector<Peer> peers;            // pack descriptors of what I send; nrecv doubles per peer arrive in d_recv
+  PackDesc *d_pack_all = nullptr; int npack_all = 0;       // all peers' pack descriptors: one launch (k_xpack_all)
   int nc = 1;
 };
 struct ViewKey { unsigned long uid; const void *base; int lev, scomp, nc, ng, nd; unsigned long tag; bool operator<(const ViewKey &o) const {
@@ -363,6 +398,7 @@ static std::map<ViewKey, SrcView> g_view_cache;
 static void viewplan_free(ViewPlan *P) {
   if (!P) return;
   HIPCHK(hipStreamSynchronize(ctx().stream));
+  if (P->d_pack_all) HIPCHK(hipFree(P->d_pack_all));
   for (auto &pr : P->peers) { if (pr.d_pack) HIPCHK(hipFree(pr.d_pack)); if (pr.d_send) HIPCHK(hipFree(pr.d_send)); if (pr.d_recv) HIPCHK(hipFree(pr.d_recv)); }
   delete P;
 }
@@ -376,8 +412,7 @@ void SrcView::refresh() const {
   if (!plan || plan->peers.empty()) return;
   hipStream_t st = ctx().stream;
   need_comm();
-  for (auto &pr : plan->peers)
-    if (!pr.pack.empty()) hipLaunchKernelGGL(k_xpack, dim3(XPACK_WG * (unsigned)pr.pack.size()), dim3(256), 0, st, pr.d_pack, plan->nc, pr.d_send);
+  if (plan->npack_all) hipLaunchKernelGGL(k_xpack_all, dim3(XPACK_WG * (unsigned)plan->npack_all), dim3(256), 0, st, plan->d_pack_all, plan->nc);
   NCCLCHK(g_rccl.GroupStart());
   for (auto &pr : plan->peers) {
     if (pr.nsend) NCCLCHK(g_rccl.Send(pr.d_send, pr.nsend, ncclFloat64, pr.rank, g_rccl.comm, st));
@@ -467,6 +502,12 @@ SrcView make_view(const vdn_multifab *src, const std::vector<vdn_box> &footprint
         }
       }
       P->peers.push_back(pr);
+    }
+    {
+      std::vector<PackDesc> ap;
+      for (auto &pr : P->peers) for (PackDesc D : pr.pack) { D.buf = pr.d_send; ap.push_back(D); }
+      P->npack_all = (int)ap.size();
+      if (!ap.empty()) { HIPCHK(hipMalloc((void **)&P->d_pack_all, ap.size() * sizeof(PackDesc))); HIPCHK(hipMemcpy(P->d_pack_all, ap.data(), ap.size() * sizeof(PackDesc), hipMemcpyHostToDevice)); }
     }
     HIPCHK(hipStreamSynchronize(ctx().stream));
     V.plan = P;
