@@ -180,9 +180,13 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    import ctypes as C
+    from varden_amd import capi
     for _ in range(args.warmup):
         G.step()
     barrier()
+    cst = (C.c_long * 24)()
+    capi.load().vdn_comm_stats(cst, 1)                     # traffic counters of the timed steps only
     t0 = time.perf_counter()
     phases = dict(scalar=0.0, velocity=0.0, mac=0.0, hg=0.0, total=0.0)
     cyc = dict(mac=0, hg=0)
@@ -200,6 +204,14 @@ def main():
         el = float(t.item())
 
     value = cells * args.steps / el
+    capi.load().vdn_comm_stats(cst, 0)
+    transport = capi.load().vdn_comm_transport().decode()
+    comm = None
+    if cst[0] or cst[3] or cst[4] or cst[6]:               # what this rank asked of the transport per step (include/varden_amd.h: vdn_comm_stats)
+        k = float(args.steps)
+        comm = {"ghost_exchanges": cst[0] / k, "view_refreshes": cst[6] / k, "sends": cst[1] / k, "MB_sent": (cst[2] + cst[7]) * 8e-6 / k,
+                "allreduces": cst[3] / k, "allgathers": cst[4] / k,
+                "exchanges_by_log2_bytes": {str(10 + b): cst[8 + b] / k for b in range(16) if cst[8 + b]}}
     rho = None
     if rank == 0 and not amr:
         rho = G.sold[0].to_numpy()[..., 0]                  # rank 0's first box, for the smoother probe's coefficients
@@ -286,13 +298,14 @@ def main():
         out = {
             "metric": "cells*steps/sec on advance_timestep",
             "value": round(value, 1), "unit": "cells*steps/s",
-            "n_gpus": world, "rccl_nranks": rccl_nranks, "steps": args.steps, "warmup": args.warmup,
+            "n_gpus": world, "rccl_nranks": rccl_nranks, "transport": transport, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(1e3 * el / args.steps, 3),
             "higher_is_better": True, "scaling": args.scaling if not amr else "strong", "vs_baseline": None,
             "dtype": "f64", "data": "synthetic",
             "config": {"workload": workload, "parallelism": par, "cells": cells,
                        "phase_ms_per_step": {k: round(1e3 * v / args.steps, 3) for k, v in phases.items()},
-                       "vcycles_per_step": {k: round(v / args.steps, 2) for k, v in cyc.items()}},
+                       "vcycles_per_step": {k: round(v / args.steps, 2) for k, v in cyc.items()},
+                       "comm_per_step_rank0": comm},
             "roofline": roof, "cpu_baseline": cpu,
         }
         print(json.dumps(out), flush=True)

@@ -109,6 +109,13 @@ int  vdn_comm_nranks(int *n);
 /* MAX over the ranks of n host doubles, in place (parallel_reduce(..., MPI_MAX) of a Fortran driver; the file writers use it for the
  * per-box minima / maxima and as their barrier).  No-op when nranks = 1. */
 int  vdn_comm_allreduce_max(double *host, int n);
+/* traffic counters since the last reset (24 longs): [0] ghost exchanges with remote traffic (pack + one ncclGroup + unpack each),
+ * [1] ncclSend calls, [2] doubles sent, [3] all-reduces, [4] all-gathers, [5] doubles contributed to them, [6] refreshes of
+ * inter-level views, [7] doubles they sent, [8+b] exchanges that sent [2^(10+b), 2^(11+b)) bytes.  The exchange sites of the reference:
+ * src/velpred.f90:102-119, src/macproject.f90:117,492, src/estdt.f90:69; everything inside ml_cc_solve / ml_nd_solve is FBoxLib's. */
+int  vdn_comm_stats(long *out24, int reset);
+/* "rccl", "test-double" (tests/fake_rccl, only with VDN_TESTING=1 -- see exchange.hip) or "none" (no transport loaded: one rank) */
+const char *vdn_comm_transport(void);
 /* host-only introspection of the ghost-exchange plan (used by the CPU multi-process tests): the remote  */
 /* copies rank `as_rank` performs for a multifab (nc, ng, nodal) on the given boxes; rows of 14 longs:  */
 /* [kind 0=send 1=recv, peer, lo[3], hi[3], shift[3], buffer offset (doubles), dst box, src box]          */

@@ -79,6 +79,8 @@ static void run_ops(Comm *c, std::vector<Op> &ops) {
 }
 
 extern "C" {
+// the handshake varden_amd/csrc/exchange.hip asks of a library named by VDN_RCCL_LIB (with VDN_TESTING=1): "vdntest"
+long vdn_test_transport_magic() { return 0x76646e74657374L; }
 const char *ncclGetErrorString(int) { return "fake_rccl error"; }
 int ncclGetUniqueId(ncclUniqueId *id) {
   memset(id, 0, sizeof *id);

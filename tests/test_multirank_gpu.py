@@ -24,7 +24,7 @@ def run_ranks(tmp_path, tag, nranks, decomp, n, nsteps, periodic, real_rccl=Fals
         env.pop("VDN_RCCL_LIB", None)
     else:
         # VDN_OVERLAP=1: halo exchange on the second stream + shell kernels on every level (by default only boxes of >= 2^20 cells do)
-        env = dict(os.environ, VDN_RCCL_LIB=FAKE, FAKE_RCCL_DIR=str(tmp_path), VDN_OVERLAP=os.environ.get("VDN_OVERLAP", "1"))
+        env = dict(os.environ, VDN_RCCL_LIB=FAKE, VDN_TESTING="1", FAKE_RCCL_DIR=str(tmp_path), VDN_OVERLAP=os.environ.get("VDN_OVERLAP", "1"))
     procs = [subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "_multirank_worker.py"), str(r), str(nranks), idfile, prefix]
                               + [str(x) for x in decomp] + [str(x) for x in n] + [str(nsteps), str(int(periodic))], env=env, cwd=ROOT)
              for r in range(nranks)]
@@ -108,7 +108,7 @@ def test_bench_spawns_its_own_ranks(gpu, tmp_path, extra):
     if _ngpus() < 2:
         if not os.path.exists(FAKE):
             subprocess.check_call(["make", "-s", "-C", os.path.dirname(FAKE)])
-        env.update(VDN_BENCH_ONE_DEVICE="1", VDN_RCCL_LIB=FAKE, FAKE_RCCL_DIR=str(tmp_path))
+        env.update(VDN_BENCH_ONE_DEVICE="1", VDN_RCCL_LIB=FAKE, VDN_TESTING="1", FAKE_RCCL_DIR=str(tmp_path))
     line = _bench_line(["--gpus", "2", "--steps", "2", "--warmup", "1", "--box", "32", "--skip-cpu"] + extra, env)
     assert line["n_gpus"] == 2 and line["rccl_nranks"] == 2 and line["value"] > 0
     assert line["scaling"] == ("weak" if not extra else "strong")
@@ -126,7 +126,7 @@ def run_amr_ranks(tmp_path, tag, nranks, nlev, visc, mode="fixed", extra=()):
     if nranks > 1 and not os.path.exists(FAKE):
         subprocess.check_call(["make", "-s", "-C", os.path.dirname(FAKE)])
     idfile, prefix = str(tmp_path / (tag + ".id")), str(tmp_path / tag)
-    env = dict(os.environ, VDN_RCCL_LIB=FAKE, FAKE_RCCL_DIR=str(tmp_path), VDN_OVERLAP=os.environ.get("VDN_OVERLAP", "1"))
+    env = dict(os.environ, VDN_RCCL_LIB=FAKE, VDN_TESTING="1", FAKE_RCCL_DIR=str(tmp_path), VDN_OVERLAP=os.environ.get("VDN_OVERLAP", "1"))
     procs = [subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "_multirank_amr_worker.py"), str(r), str(nranks), idfile, prefix, str(nlev), str(visc), mode] + list(extra),
                               env=env, cwd=ROOT) for r in range(nranks)]
     try:

@@ -46,6 +46,7 @@ struct Rccl {
   int (*GroupEnd)() = nullptr;
   const char *(*GetErrorString)(int) = nullptr;
   ncclComm_t comm = nullptr;
+  bool test_double = false;
 };
 static Rccl g_rccl;
 static int packed_mode() { const char *e = getenv("VDN_FORCE_PACKED"); return e ? atoi(e) : 0; }
@@ -53,9 +54,23 @@ static int packed_mode() { const char *e = getenv("VDN_FORCE_PACKED"); return e 
 
 static void rccl_load() {
   if (g_rccl.h) return;
-  // VDN_RCCL_LIB: an explicit library path (tests/fake_rccl: several ranks on ONE GPU for the multi-rank tests)
-  const char *names[] = { getenv("VDN_RCCL_LIB"), "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1" };
-  for (const char *n : names) { if (!n || !*n) continue; g_rccl.h = dlopen(n, RTLD_NOW | RTLD_LOCAL); if (g_rccl.h) break; }
+  // The transport is RCCL, found by name.  The ONE exception is the test double of the multi-rank tests (tests/fake_rccl: several
+  // ranks on one GPU), and an environment variable alone must not be able to swap the transport of the shipping library: VDN_RCCL_LIB
+  // is honoured only together with VDN_TESTING=1 AND a library that identifies itself through vdn_test_transport_magic(); anything else
+  // named there fails the call.  vdn_comm_transport() says which one is in use (bench.py prints it).
+  const char *forced = getenv("VDN_RCCL_LIB");
+  if (forced && *forced) {
+    const char *t = getenv("VDN_TESTING");
+    REQUIRE(t && atoi(t) == 1, "VDN_RCCL_LIB is set but VDN_TESTING=1 is not: the transport of this library is RCCL; only the test suite may replace it");
+    g_rccl.h = dlopen(forced, RTLD_NOW | RTLD_LOCAL);
+    REQUIRE(g_rccl.h, "cannot dlopen the test transport %s: %s", forced, dlerror());
+    long (*magic)() = nullptr; *(void **)(&magic) = dlsym(g_rccl.h, "vdn_test_transport_magic");
+    REQUIRE(magic && magic() == 0x76646e74657374L, "VDN_RCCL_LIB names %s, which is not the test double of tests/fake_rccl", forced);
+    g_rccl.test_double = true;
+    fprintf(stderr, "varden_amd: TEST TRANSPORT %s in place of RCCL (VDN_TESTING=1)\n", forced);
+  }
+  const char *names[] = { "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1" };
+  for (const char *n : names) { if (g_rccl.h) break; g_rccl.h = dlopen(n, RTLD_NOW | RTLD_LOCAL); }
   REQUIRE(g_rccl.h, "cannot dlopen librccl.so.1: %s", dlerror());
   #define SYM(field, name) do { *(void **)(&g_rccl.field) = dlsym(g_rccl.h, name); REQUIRE(g_rccl.field, "RCCL symbol %s missing", name); } while (0)
   SYM(GetUniqueId, "ncclGetUniqueId"); SYM(CommInitRank, "ncclCommInitRank"); SYM(CommDestroy, "ncclCommDestroy"); SYM(CommCount, "ncclCommCount");
@@ -95,12 +110,29 @@ extern "C" int vdn_comm_nranks(int *n) {
   VDN_CATCH
 }
 bool comm_active() { return ctx().nranks > 1 || g_rccl.comm != nullptr; }
+// traffic counters (vdn_comm_stats): what a step asks of the transport -- the budget of profiles/r03_exchange_budget.md is made of these
+// [0] exchanges with remote traffic (one pack + ncclGroup + unpack each)  [1] ncclSend calls  [2] doubles sent  [3] all-reduces
+// [4] all-gathers  [5] doubles contributed to all-gathers  [6] view refreshes (inter-level operators)  [7] doubles sent by them
+// [8 + b] exchanges whose sends add up to [2^(10+b), 2^(11+b)) bytes, b = 0 .. 15 (b = 0 also takes everything smaller)
+static long g_cstat[24];
+static void cstat_exchange(size_t doubles, int sends, bool view) {
+  g_cstat[view ? 6 : 0]++; g_cstat[1] += sends; g_cstat[view ? 7 : 2] += (long)doubles;
+  if (!view) { int b = 0; size_t bytes = doubles * 8; while (b < 15 && bytes >= ((size_t)2048 << b)) b++; g_cstat[8 + b]++; }
+}
+extern "C" const char *vdn_comm_transport(void) { return !g_rccl.h ? "none" : (g_rccl.test_double ? "test-double" : "rccl"); }
+extern "C" int vdn_comm_stats(long *out24, int reset) {
+  VDN_TRY
+  if (out24) memcpy(out24, g_cstat, sizeof g_cstat);
+  if (reset) memset(g_cstat, 0, sizeof g_cstat);
+  VDN_CATCH
+}
 static void need_comm() { REQUIRE(g_rccl.comm != nullptr, "this operation spans ranks: call vdn_comm_init first (nranks = %d)", ctx().nranks); }
 
 // all-reduce MAX of n device doubles, in place, on the launch stream
 void comm_allreduce_max_dev(double *d, int n) {
   if (!comm_active()) return;
   need_comm();
+  g_cstat[3]++;
   NCCLCHK(g_rccl.AllReduce(d, d, (size_t)n, ncclFloat64, ncclMax, g_rccl.comm, ctx().stream));
 }
 // all-reduce MAX of n device bytes (tag bitmaps of the grid generation), in place, in pieces of 8 MB
@@ -129,6 +161,7 @@ extern "C" int vdn_comm_allreduce_max(double *host, int n) {
 void comm_allgather_dev(const double *send, double *recv, size_t count) {
   if (!comm_active()) { if (send != recv) HIPCHK(hipMemcpyAsync(recv, send, count * sizeof(double), hipMemcpyDeviceToDevice, ctx().stream)); return; }
   need_comm();
+  g_cstat[4]++; g_cstat[5] += (long)count;
   NCCLCHK(g_rccl.AllGather(send, recv, count, ncclFloat64, g_rccl.comm, ctx().stream));
 }
 
@@ -368,6 +401,7 @@ void xplan_run(XPlan *P, hipStream_t st) {
     if (P->npack_all) hipLaunchKernelGGL(k_xpack_all, dim3(XPACK_WG * (unsigned)P->npack_all), dim3(256), 0, st, P->d_pack_all, nc);
     if (remote) {
       need_comm();
+      { size_t tot = 0; int ns = 0; for (auto &pr : P->peers) if (!(pr.rank == ctx().rank && !self_rccl) && pr.nsend) { tot += pr.nsend; ns++; } cstat_exchange(tot, ns, false); }
       NCCLCHK(g_rccl.GroupStart());
       for (auto &pr : P->peers) {
         if (pr.rank == ctx().rank && !self_rccl) continue;
@@ -413,6 +447,7 @@ void SrcView::refresh() const {
   hipStream_t st = ctx().stream;
   need_comm();
   if (plan->npack_all) hipLaunchKernelGGL(k_xpack_all, dim3(XPACK_WG * (unsigned)plan->npack_all), dim3(256), 0, st, plan->d_pack_all, plan->nc);
+  { size_t tot = 0; int ns = 0; for (auto &pr : plan->peers) if (pr.nsend) { tot += pr.nsend; ns++; } cstat_exchange(tot, ns, true); }
   NCCLCHK(g_rccl.GroupStart());
   for (auto &pr : plan->peers) {
     if (pr.nsend) NCCLCHK(g_rccl.Send(pr.d_send, pr.nsend, ncclFloat64, pr.rank, g_rccl.comm, st));

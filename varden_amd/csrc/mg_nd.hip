@@ -209,16 +209,34 @@ DEVI double2 ld2(const double *p) { return *reinterpret_cast<const double2 *>(p)
 // of the next plane, so that the store's latency hides under theirs.
 __device__ double g_nd_sink[128];
 __device__ int g_nd_dbg = 0;      // VDN_ND_DBG (probe only): 1 = no stencil arithmetic, 2 = no loads inside the march
+// Round 3 -- the shape of the launch.  (i) A row of 257 nodes is 129 pairs = two full wave rows (62 owned pairs each) and FIVE pairs more:
+// with one tile shape the third tile of every row ran 57 of its 62 pair lanes idle -- a third of all waves of the sweep issued the loads of
+// 8 % of the nodes, and the sweep is bound by the loads it has in flight.  The remainder columns are now covered by waves that pack several
+// rows: a lane segment of 2^lw lanes (lw = 2..6, the smallest that holds the remainder; its first and last lane feed their neighbours
+// as before -- the DPP shifts cross segment borders only into those two lanes) carries one row, a wave 64 >> lw rows, a workgroup four
+// times that.  Main tiles and remainder tiles are workgroups of ONE launch (1-D grid: main tiles first, in the XCD-aware order).
+// (ii) The k-slabs are balanced (sizes differ by at most one plane): 257 planes in 16 slabs of 17 left a last slab of two planes.
+struct NdPairGrid { int gxm, gy, gz, nmain, lwr, gyr; };       // main tiles gxm x gy x gz (lw = 6), then gyr x gz remainder tiles of segment 2^lwr
 template <int MODE, int ROWS>
-__global__ void __launch_bounds__(64 * ROWS) kk_nd_march_pair(NLev L, const double *__restrict__ phi, double *__restrict__ out, double omega, int kchunk, double *nrm, int shell_later) {
+__global__ void __launch_bounds__(64 * ROWS) kk_nd_march_pair(NLev L, const double *__restrict__ phi, double *__restrict__ out, double omega, NdPairGrid G, double *nrm, int shell_later) {
   const int lane = threadIdx.x;
-  int bx, by, bz; xcd_tile(bx, by, bz);
+  const int id = (int)blockIdx.x;
+  int lw, pair0, j, bz;
+  if (id < G.nmain) {                                                     // xcd_tile's order over the main tiles
+    const int q = G.nmain >> 3, r = G.nmain & 7, x = id & 7, slot = id >> 3;
+    const int t = (x < r) ? x * (q + 1) + slot : r * (q + 1) + (x - r) * q + slot;
+    lw = 6; pair0 = (t % G.gxm) * 62; j = ((t / G.gxm) % G.gy) * ROWS + (int)threadIdx.y; bz = t / (G.gxm * G.gy);
+  } else {
+    const int t = id - G.nmain;
+    lw = G.lwr; pair0 = G.gxm * 62; j = (((t % G.gyr) * ROWS + (int)threadIdx.y) << (6 - lw)) + (lane >> lw); bz = t / G.gyr;
+  }
+  const int seg = 1 << lw, sl = lane & (seg - 1);
   // (measured and rejected: all 64 lanes owning a pair -- whole 128-byte lines per wave row -- with the two outside columns from an extra
   // two-lane load per row: 0.154 -> 0.202 ms per sweep at 257^3)
-  const int ia = 2 * (bx * 62 + lane - 1);                              // nodes ia, ia + 1; lanes 0 and 63 only feed their neighbours
-  const int j = by * blockDim.y + threadIdx.y;
-  const int k0 = bz * kchunk, k1 = min(k0 + kchunk - 1, L.n[2]);
-  const bool own = lane >= 1 && lane <= 62 && j <= L.n[1];
+  const int ia = 2 * (pair0 + sl - 1);                                  // nodes ia, ia + 1; the first and last lane of a segment only feed their neighbours
+  const int nzp = L.n[2] + 1;
+  const int k0 = (int)(((long)bz * nzp) / G.gz), k1 = (int)(((long)(bz + 1) * nzp) / G.gz) - 1;
+  const bool own = sl >= 1 && sl <= seg - 2 && j <= L.n[1];
   const bool actA = own && ia <= L.n[0], actB = own && ia + 1 <= L.n[0];
   const int iac = min(ia, L.PX - 18), jc = min(j, L.n[1]);                // load address kept inside the (zero-padded) row
   double rmax = 0.0;
@@ -724,12 +742,23 @@ template <int MODE> static void nd_launch_march(const NLev &L, const double *phi
   static const bool paired = !(getenv("VDN_ND_PAIR") && atoi(getenv("VDN_ND_PAIR")) == 0);
   if (paired && L.n[0] >= 127) {                   // 124 nodes per wave row
     const int rows = 4;                          // (measured: 8 rows per workgroup 17.1 -> 18.7 ms of HG per step, 16 rows spill)
-    const int npair = (L.n[0] + 2) / 2, gx = (npair + 61) / 62, gy = (L.n[1] + rows) / rows;
+    static const bool use_rem = !(getenv("VDN_ND_REM") && atoi(getenv("VDN_ND_REM")) == 0);
     static const int minwg = getenv("VDN_ND_MINWG") ? atoi(getenv("VDN_ND_MINWG")) : 2048;
+    static const int kc_env = getenv("VDN_ND_KC") ? atoi(getenv("VDN_ND_KC")) : 0;
+    const int npair = (L.n[0] + 2) / 2;
+    NdPairGrid G;
+    G.gxm = npair / 62; G.gy = (L.n[1] + rows) / rows;
+    const int rem = npair - 62 * G.gxm;
+    G.lwr = 6; G.gyr = 0;
+    if (rem > 0 && use_rem) { G.lwr = 2; while ((1 << G.lwr) - 2 < rem) G.lwr++; G.gyr = (L.n[1] + (rows << (6 - G.lwr))) / (rows << (6 - G.lwr)); }
+    else if (rem > 0) G.gxm++;
+    const int tiles = G.gxm * G.gy + G.gyr;
     int kc = nzp;
-    while (kc > 8 && gx * gy * ((nzp + kc - 1) / kc) < minwg) kc = (kc + 1) / 2;
-    const dim3 g(gx, gy, (nzp + kc - 1) / kc);
-    hipLaunchKernelGGL((kk_nd_march_pair<MODE, 4>), g, NBLK, 0, ctx().stream, L, phi, out, ctx().prm.hg_omega, kc, nrm, shell_later);
+    while (kc > 8 && tiles * ((nzp + kc - 1) / kc) < minwg) kc = (kc + 1) / 2;
+    if (kc_env > 0) kc = std::min(kc_env, nzp);
+    G.gz = std::max(1, nzp / kc);                 // balanced slabs of kc or kc + 1 planes
+    G.nmain = G.gxm * G.gy * G.gz;
+    hipLaunchKernelGGL((kk_nd_march_pair<MODE, 4>), dim3(G.nmain + G.gyr * G.gz), NBLK, 0, ctx().stream, L, phi, out, ctx().prm.hg_omega, G, nrm, shell_later);
     return;
   }
   hipLaunchKernelGGL(kk_nd_march<MODE>, dim3((L.n[0] + 62) / 62, (L.n[1] + 4) / 4, nch), NBLK, 0, ctx().stream, L, phi, out, ctx().prm.hg_omega, kchunk, nrm, shell_later);
