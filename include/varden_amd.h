@@ -89,7 +89,12 @@ typedef struct vdn_bc_tower vdn_bc_tower;  /* define_bc_module::bc_tower        
 int  vdn_init(const vdn_params *prm, int rank, int nranks, int device);
 int  vdn_finalize(void);
 const char *vdn_last_error(void);
-int  vdn_set_stream(void *hip_stream);      /* all kernels are launched on this stream (default 0) */
+/* Launch stream.  Default: a PRIVATE non-blocking stream created by vdn_init -- not ordered against the legacy null stream or any
+ * stream of the host application.  Calls that only enqueue work (setval, copy_c, fill_boundary, physbc, the vdn_k_* hooks) return
+ * before it has run; vdn_multifab_dataptr drains the private stream before handing a device pointer out, vdn_device_synchronize
+ * drains it on request.  vdn_set_stream(s) makes every launch go to the caller's stream s instead (the caller then orders its own work
+ * on s; nothing is drained for it); vdn_set_stream(NULL) returns to the private stream. */
+int  vdn_set_stream(void *hip_stream);
 int  vdn_device_synchronize(void);
 /* arena of per-step temporaries (the multifabs advance_timestep.f90:65-80 allocates and frees every step): bytes reserved, high-water mark */
 int  vdn_arena_stats(size_t *reserved_bytes, size_t *peak_bytes);

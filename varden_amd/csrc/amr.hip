@@ -710,7 +710,8 @@ int ml_cc_solve(vdn_layout *la, vdn_multifab **rh, vdn_multifab **phi, vdn_multi
   const double bnorm = read_dev(S.d_nrm);
   const vdn_params &P = ctx().prm;
   int it = 0; bool conv = (bnorm == 0.0); double rn = 0.0;
-  CcKeep *coarse_keep = cc_keep_new();       // the level-0 multigrid hierarchy is built once for all FAC iterations
+  struct KeepGuard { CcKeep *k; ~KeepGuard() { cc_keep_free(k); } } keep_guard{ cc_keep_new() };      // freed on every exit, exceptions included
+  CcKeep *coarse_keep = keep_guard.k;        // the level-0 multigrid hierarchy is built once for all FAC iterations
   int ebc0[3][2];
   for (int d = 0; d < 3; d++) for (int s = 0; s < 2; s++) ebc0[d][s] = bct->ell_bc(0, 0, d, s, bc_comp0);
   while (!conv) {
@@ -737,7 +738,6 @@ int ml_cc_solve(vdn_layout *la, vdn_multifab **rh, vdn_multifab **phi, vdn_multi
     }
     it++;
   }
-  cc_keep_free(coarse_keep);
   fill_phi_ghosts(S);
   if (iters) *iters = it; if (res0) *res0 = bnorm; if (res) *res = rn;
   for (int n = L - 1; n >= 0; n--) { if (S.mask[n]) mf_temp_free(S.mask[n]); if (S.scr[n]) mf_temp_free(S.scr[n]); mf_temp_free(S.e[n]); mf_temp_free(S.res[n]); }

@@ -971,7 +971,9 @@ static FV cc_phi_view(const CLev &L, const int lo[3]) {
 // the 7-point operator reads no edge or corner ghost cell: the halo of phi carries the face cells only (VDN_CC_HALO_FACES=0: the whole shell)
 static bool cc_faces_only() { static const bool f = !(getenv("VDN_CC_HALO_FACES") && atoi(getenv("VDN_CC_HALO_FACES")) == 0); return f; }
 // plans for the per-level phi halos are cached across solves: arena addresses repeat from step to step
-struct HaloKey { unsigned long uid; const void *p0; int lev, l, per; bool operator<(const HaloKey &o) const { return std::tie(uid, p0, lev, l, per) < std::tie(o.uid, o.p0, o.lev, o.l, o.per); } };
+// sig: a hash of EVERY local box's phi address -- the plan bakes those addresses in, and two solves on one level that start at the same
+// arena offset but differ in layout (6 arrays per box without alpha, 7 with) agree on the first box only
+struct HaloKey { unsigned long uid; const void *p0; int lev, l, per; unsigned long long sig; bool operator<(const HaloKey &o) const { return std::tie(uid, p0, lev, l, per, sig) < std::tie(o.uid, o.p0, o.lev, o.l, o.per, o.sig); } };
 static std::map<HaloKey, XPlan *> g_halo_cache;
 void cc_halo_cache_purge(unsigned long uid) {        // the plans themselves are freed by exchange.hip (halo_cache_register)
   for (auto it = g_halo_cache.begin(); it != g_halo_cache.end();) { if (it->first.uid == uid) it = g_halo_cache.erase(it); else ++it; }
@@ -1029,7 +1031,8 @@ static void cc_build(CCMG &M, const vdn_multifab *rh, const double *dx, const in
       }
     }
     if (nb > 1 || M.per[0] || M.per[1] || M.per[2]) {
-      HaloKey key{ la->uid, DL.boxes.empty() ? nullptr : (const void *)DL.boxes[0].L.phi, lev, (int)M.dlev.size(), M.per[0] | (M.per[1] << 1) | (M.per[2] << 2) };
+      GraphKey hk; for (const CBox &B : DL.boxes) { hk.put(B.L.phi); hk.put(B.L.sz); }
+      HaloKey key{ la->uid, DL.boxes.empty() ? nullptr : (const void *)DL.boxes[0].L.phi, lev, (int)M.dlev.size(), M.per[0] | (M.per[1] << 1) | (M.per[2] << 2), hk.h };
       auto it = g_halo_cache.find(key);
       if (it == g_halo_cache.end()) { XPlan *P = xplan_build(xb, lpd, M.per, 1, 1, cc_faces_only()); halo_cache_register(la->uid, P); it = g_halo_cache.emplace(key, P).first; }
       DL.halo = it->second;

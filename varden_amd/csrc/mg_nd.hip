@@ -773,8 +773,8 @@ struct NDMG {
   std::vector<long> loc_off_nodes, loc_off_cells;
 };
 
-struct NdHaloKey { unsigned long uid; const void *p0; int lev, l, which, per; bool operator<(const NdHaloKey &o) const {
-  return std::tie(uid, p0, lev, l, which, per) < std::tie(o.uid, o.p0, o.lev, o.l, o.which, o.per); } };
+struct NdHaloKey { unsigned long uid; const void *p0; int lev, l, which, per; unsigned long long sig; bool operator<(const NdHaloKey &o) const {
+  return std::tie(uid, p0, lev, l, which, per, sig) < std::tie(o.uid, o.p0, o.lev, o.l, o.which, o.per, o.sig); } };      // sig: every local box's address (see mg_cc.hip HaloKey)
 static std::map<NdHaloKey, XPlan *> g_nd_halo_cache;
 void nd_halo_cache_purge(unsigned long uid) {
   for (auto it = g_nd_halo_cache.begin(); it != g_nd_halo_cache.end();) { if (it->first.uid == uid) it = g_nd_halo_cache.erase(it); else ++it; }
@@ -839,8 +839,9 @@ static void nd_build(NDMG &M, const vdn_multifab *coeffs, const double *dx, cons
     }
     if (nb > 1 || perbits) {
       const void *p0 = DL.boxes.empty() ? nullptr : (const void *)DL.boxes[0].A;
+      GraphKey hk; for (const NBox &B : DL.boxes) { hk.put(B.A); hk.put(B.L.sz); }
       auto get = [&](int which, const std::vector<XBoxInfo> &xv, const vdn_box &pdm) {
-        NdHaloKey key{ la->uid, p0, lev, (int)M.dlev.size(), which, perbits };
+        NdHaloKey key{ la->uid, p0, lev, (int)M.dlev.size(), which, perbits, hk.h };
         auto it = g_nd_halo_cache.find(key);
         if (it == g_nd_halo_cache.end()) { XPlan *P = xplan_build(xv, pdm, M.per, 1, 1); halo_cache_register(la->uid, P); it = g_nd_halo_cache.emplace(key, P).first; }
         return it->second;
@@ -1099,21 +1100,24 @@ static unsigned long long nd_graph_key(const NDMG &M, int what) {
   k.put(M.sendbuf); k.put(M.recvbuf); k.put(M.d_gb); k.put(M.cnt_nodes); k.put(M.cnt_cells);
   for (const NDLev &DL : M.dlev) {
     k.put(xplan_serial(DL.halo_A)); k.put(xplan_serial(DL.halo_B)); k.put(xplan_serial(DL.halo_res)); k.put(xplan_serial(DL.halo_sig)); k.put(DL.ng); k.put(DL.flip); k.put(DL.single_box); k.put(DL.per);
-    for (const NBox &B : DL.boxes) { nd_key_lev(k, B.L); k.put(B.lo); k.put(B.A); k.put(B.B); }
+    for (const NBox &B : DL.boxes) { nd_key_lev(k, B.L); k.put(B.lo); k.put(B.A); k.put(B.B); k.put(B.hmask); k.put(xplan_serial(B.hA)); k.put(xplan_serial(B.hB)); }
   }
   for (const NLev &L : M.tail) nd_key_lev(k, L);
   for (long o : M.loc_off_nodes) k.put(o);
   return k.h;
 }
 static std::map<unsigned long long, NDMG> g_nd_post;
+static unsigned long g_nd_post_gen = 0;
 template <class Body> static void nd_run_cycle(NDMG &M, int what, Body body) {
   if (!graphs_enabled()) { body(); return; }
+  if (g_nd_post_gen != graph_generation()) { g_nd_post.clear(); g_nd_post_gen = graph_generation(); }     // the graphs went: so does the state kept next to them
   const unsigned long long key = nd_graph_key(M, what);
   auto it = g_nd_post.find(key);
   if (it != g_nd_post.end() && graph_replay(key)) { M = it->second; return; }
   graph_begin();
   try { body(); } catch (...) { graph_abort(); throw; }
   graph_end(key);
+  if (g_nd_post_gen != graph_generation()) { g_nd_post.clear(); g_nd_post_gen = graph_generation(); }     // graph_end cleared the cache to make room
   if (g_nd_post.size() >= 256) g_nd_post.clear();
   g_nd_post[key] = M;
 }

@@ -24,7 +24,13 @@ void vdn_fail(const char *fmt, ...) {
   throw VdnErr(buf);
 }
 
-void arena_reset() { g_ctx.arena_off = 0; }
+// also drops the pointers advance_timestep keeps INTO the arena (limited slopes of uold, max |umac|): a step that ended in an exception
+// (solver_check throws by default) must not leave them dangling for the next stand-alone vdn_k_mkflux / vdn_k_velpred
+void arena_reset() {
+  g_ctx.arena_off = 0;
+  g_ctx.slope_src = nullptr; g_ctx.macmax_src = nullptr; g_ctx.macmax_cache = nullptr;
+  for (int d = 0; d < 3; d++) g_ctx.slope_cache[d] = nullptr;
+}
 // make sure the arena holds at least `bytes`; only legal while nothing is live in it
 void arena_reserve(size_t bytes) {
   VdnCtx &c = g_ctx;
@@ -111,9 +117,17 @@ bool graphs_enabled() {
   static const bool off = getenv("VDN_NO_GRAPHS") != nullptr;
   return !off && !comm_active() && g_ctx.stream != 0 && !g_capturing;
 }
+// `generation` counts the clears: solvers that keep host state next to a graph (mg_nd.hip: the ping-pong state a cycle leaves behind)
+// drop it when the generation has moved on
+static unsigned long g_graph_generation = 1;
+unsigned long graph_generation() { return g_graph_generation; }
 void graph_cache_clear() {
+  // an exec may still be in flight (fixed-cycle FAC loops replay graphs back to back with no read-back in between), and HIP does not
+  // promise the deferred destruction CUDA gives: drain the launch stream first
+  if (!g_graphs.empty() && g_ctx.stream) (void)hipStreamSynchronize(g_ctx.stream);
   for (auto &kv : g_graphs) (void)hipGraphExecDestroy(kv.second);
   g_graphs.clear();
+  g_graph_generation++;
 }
 bool graph_replay(unsigned long long key) {
   auto it = g_graphs.find(key);
@@ -144,6 +158,8 @@ void graph_end(unsigned long long key) {
   (void)hipGraphDestroy(g);
   if (e != hipSuccess) vdn_fail("hipGraphInstantiate failed: %s", hipGetErrorString(e));
   if (g_graphs.size() >= 256) graph_cache_clear();        // stale keys (freed arenas, destroyed layouts) do not pile up
+  auto old = g_graphs.find(key);                          // a re-capture of a key that still has an exec: destroy, do not leak it
+  if (old != g_graphs.end()) { (void)hipStreamSynchronize(g_ctx.stream); (void)hipGraphExecDestroy(old->second); }
   g_graphs[key] = ex;
   HIPCHK(hipGraphLaunch(ex, g_ctx.stream));
 }
@@ -455,7 +471,15 @@ static void copy_plane0(const vdn_multifab *mf, int i, double *host, bool to_hos
   }
   HIPCHK(hipStreamSynchronize(g_ctx.stream));
 }
-extern "C" int vdn_multifab_dataptr(const vdn_multifab *mf, int i, double **dev) { *dev = mf->fabs[i].p; return 0; }
+// Handing out a raw device pointer is where the host starts touching the data with its OWN stream: when the launch stream is the
+// library's private (non-blocking) one nothing would order the two, so the call drains it first.  With a caller-provided stream
+// (vdn_set_stream) ordering is the caller's, as for any work on their stream.
+extern "C" int vdn_multifab_dataptr(const vdn_multifab *mf, int i, double **dev) {
+  VDN_TRY
+  if (g_ctx.inited && g_ctx.stream == g_ctx.own_stream) HIPCHK(hipStreamSynchronize(g_ctx.stream));
+  *dev = mf->fabs[i].p;
+  VDN_CATCH
+}
 extern "C" int vdn_multifab_copy_to_host(const vdn_multifab *mf, int i, double *host) {
   VDN_TRY
   if (host_2d(mf)) { copy_plane0(mf, i, host, true); return 0; }

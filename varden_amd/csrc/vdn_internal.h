@@ -100,9 +100,11 @@ void vdn_set_error(const char *fmt, ...);
 struct VdnErr : std::runtime_error { using std::runtime_error::runtime_error; };
 [[noreturn]] void vdn_fail(const char *fmt, ...);
 #define HIPCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) vdn_fail("%s failed: %s (%s:%d)", #x, hipGetErrorString(e_), __FILE__, __LINE__); } while (0)
-#define VDN_TRY try {
+// entry: drop whatever error the HOST application left on this thread (torch's event queries leave hipErrorNotReady, an earlier foreign
+// launch may have failed): only an error raised INSIDE the call is ours to report
+#define VDN_TRY try { (void)hipGetLastError();
 // the success path of every C-ABI call also asks HIP for a pending launch error (a kernel launch with a bad grid fails silently otherwise)
-#define VDN_CATCH   if (ctx().inited) { hipError_t le_ = hipGetLastError(); if (le_ != hipSuccess) vdn_fail("a HIP launch failed inside this call: %s", hipGetErrorString(le_)); } \
+#define VDN_CATCH   if (ctx().inited) { hipError_t le_ = hipGetLastError(); if (le_ != hipSuccess && le_ != hipErrorNotReady) vdn_fail("a HIP launch failed inside this call: %s", hipGetErrorString(le_)); } \
   } catch (const std::exception &e) { vdn_set_error("%s", e.what()); return 1; } return 0;
 // outcome of an elliptic solve: FBoxLib's solvers abort on max_iter (bl_error); so do we unless prm.abort_on_max_iter = 0.
 // A non-finite norm (the reductions turn NaN into +inf) is a failure whatever rc says.  comp >= 0: the component being solved
@@ -122,7 +124,7 @@ inline double read_scalar1(const double *dev) { return read_scalars(dev, 1)[0]; 
 
 // ---- hipGraph replay of fixed launch sequences (one multigrid cycle = ~100 launches of 3-15 us) ---------------------------------------
 // Usage:  GraphKey k; k.put(...every value the launches depend on...);  if (!graph_replay(k.h)) { graph_begin(); body(); graph_end(k.h); }
-// graph_end instantiates, caches and launches.  Bodies may only enqueue work on ctx().stream (kernels, memsets, device copies).
+// graph_end instantiates, caches and launches.  graph_generation() changes whenever the cache is cleared.  Bodies may only enqueue work on ctx().stream (kernels, memsets, device copies).
 // Off when the transport is active (RCCL calls and the test double are not captured) or VDN_NO_GRAPHS is set.
 struct GraphKey {
   unsigned long long h = 1469598103934665603ull;
@@ -135,6 +137,7 @@ void graph_begin();
 void graph_end(unsigned long long key);
 void graph_abort();                            // leave capture mode after an exception inside a body
 void graph_cache_clear();
+unsigned long graph_generation();      // bumped by every graph_cache_clear
 
 // arena
 void  arena_reset();
