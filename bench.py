@@ -133,6 +133,11 @@ def main():
         dist.broadcast(idt, 0)
         comm_id = bytes(idt.cpu().tolist())
 
+    if world == 1 and os.environ.get("VDN_FORCE_PACKED") == "2":
+        # one-GPU rehearsal of the N > 1 transport: a 1-rank RCCL communicator, every box-to-box copy packed and sent to the rank itself
+        bl.initialize(prm, 0, 1, local_rank)
+        bl.comm_init(bl.comm_get_unique_id())
+
     amr = args.config in ("amr2", "amr3")
     if amr:
         max_levs = 2 if args.config == "amr2" else 3

@@ -129,14 +129,20 @@ DEVI void cc_apply_rho_vals(const CLev &L, int i, int j, int k, const double p[7
 // at the two ends of the wave (one branch-free load per field).  8 + 1 loads per field for two cells instead of 2 x 7.  Same arithmetic.
 struct Pair7 { double a[7], b[7]; };
 DEVI double sel2(const double2 &q, int hi) { return hi ? q.y : q.x; }
-DEVI void pair_gather(const double *v, const CLev &L, long cpA, int par, int lane, Pair7 &o) {
+typedef double v2d_t __attribute__((ext_vector_type(2)));
+// NT: the loads carry the non-temporal hint (fields that are read once per pass and should not push phi out of the caches)
+template <bool NT> DEVI double2 ld2c(const double *p) {
+  if (NT) { const v2d_t q = __builtin_nontemporal_load(reinterpret_cast<const v2d_t *>(p)); return make_double2(q.x, q.y); }
+  return *reinterpret_cast<const double2 *>(p);
+}
+template <bool NT = false> DEVI void pair_gather(const double *v, const CLev &L, long cpA, int par, int lane, Pair7 &o) {
   const long sy = L.PX, sz = (long)L.PX * L.PY;
   // the cells just outside the pair along x: previous lane's odd cell / next lane's even cell; the two ends of the wave read memory
   // (issued first, two active lanes).  par = 0: A (row j, even column) looks left and B (row j+1, odd column) looks right; par = 1 the
   // other way round.
   double e = 0.0;
   if (lane == 0 || lane == 63) e = v[cpA + ((lane == 0) ? (par == 0 ? -1 : sy - 1) : (par == 0 ? sy + 2 : 2))];
-  #define LD2(off) (*reinterpret_cast<const double2 *>(v + cpA + (off)))
+  #define LD2(off) (ld2c<NT>(v + cpA + (off)))
   const double2 PA = LD2(0), PB = LD2(sy), PAm = LD2(-sy), PBp = LD2(2 * sy);
   const double2 ZAm = LD2(-sz), ZAp = LD2(sz), ZBm = LD2(sy - sz), ZBp = LD2(sy + sz);
   #undef LD2
@@ -191,7 +197,7 @@ template <int ADD> __global__ void __launch_bounds__(256) kk_cc_gsrb_rho_pair_t(
   if (diag != 0.0 && !(interior_only && cc_is_shell(L, iB, jA + 1, k, interior_only))) L.phi[cpA + L.PX + 1 - par] = P.b[0] + (sel2(RB, 1 - par) - Ap) / diag;
   else if (ADD) L.phi[cpA + L.PX + 1 - par] = P.b[0];
 }
-__global__ void __launch_bounds__(256) kk_cc_gsrb_rho_pair(CLev L, int color, int interior_only) {
+template <bool NT> __global__ void __launch_bounds__(256) kk_cc_gsrb_rho_pair(CLev L, int color, int interior_only) {
   int bx, by, bz; xcd_block(bx, by, bz);
   const int lane = threadIdx.x, k = bz;
   const int t = bx * 64 + lane, jA = 2 * (by * 4 + (int)threadIdx.y);
@@ -200,8 +206,8 @@ __global__ void __launch_bounds__(256) kk_cc_gsrb_rho_pair(CLev L, int color, in
   const long cpA = cidx(L, 2 * min(t, L.n[0] / 2), min(jA, L.n[1] - 2), k);      // clamped: every lane takes part in the lane exchange
   Pair7 P, R;
   pair_gather(L.phi, L, cpA, par, lane, P);
-  pair_gather(L.rho, L, cpA, par, lane, R);
-  const double2 RA = *reinterpret_cast<const double2 *>(L.rh + cpA), RB = *reinterpret_cast<const double2 *>(L.rh + cpA + L.PX);
+  pair_gather<NT>(L.rho, L, cpA, par, lane, R);
+  const double2 RA = ld2c<NT>(L.rh + cpA), RB = ld2c<NT>(L.rh + cpA + L.PX);
   if (!act) return;
   const int iA = 2 * t + par, iB = 2 * t + 1 - par;
   double Ap, diag;
@@ -273,7 +279,12 @@ static inline void launch_gsrb(const CLev &L, int color, hipStream_t st, int int
   const dim3 blk(64, 4, 1), g((unsigned)(((L.n[0] + 1) / 2 + 63) / 64), (unsigned)((L.n[1] + 3) / 4), (unsigned)L.n[2]);
   static const bool paired = !(getenv("VDN_GSRB_PAIR") && atoi(getenv("VDN_GSRB_PAIR")) == 0);
   if (L.rho && paired && L.n[0] % 2 == 0 && L.n[1] % 2 == 0 && L.n[0] >= 128)
-    hipLaunchKernelGGL(kk_cc_gsrb_rho_pair, dim3((unsigned)((L.n[0] / 2 + 63) / 64), (unsigned)((L.n[1] / 2 + 3) / 4), (unsigned)L.n[2]), blk, 0, st, L, color, interior_only);
+  {
+    static const bool nt = getenv("VDN_CC_NT") && atoi(getenv("VDN_CC_NT")) != 0;      // probe: rho and rhs with the non-temporal hint
+    const dim3 gp((unsigned)((L.n[0] / 2 + 63) / 64), (unsigned)((L.n[1] / 2 + 3) / 4), (unsigned)L.n[2]);
+    if (nt) hipLaunchKernelGGL(kk_cc_gsrb_rho_pair<true>, gp, blk, 0, st, L, color, interior_only);
+    else hipLaunchKernelGGL(kk_cc_gsrb_rho_pair<false>, gp, blk, 0, st, L, color, interior_only);
+  }
   else if (L.rho) hipLaunchKernelGGL(kk_cc_gsrb_rho, g, blk, 0, st, L, color, interior_only);
   else if (paired && L.n[0] % 2 == 0 && L.n[1] % 2 == 0 && L.n[0] >= 128)
     hipLaunchKernelGGL(kk_cc_gsrb_pair, dim3((unsigned)((L.n[0] / 2 + 63) / 64), (unsigned)((L.n[1] / 2 + 3) / 4), (unsigned)L.n[2]), blk, 0, st, L, color, interior_only);
@@ -512,7 +523,7 @@ DEVI void quad_gather(const double *v, const CLev &L, long cpA, int lane, double
   const long sy = L.PX, sz = (long)L.PX * L.PY;
   double eA = 0.0, eB = 0.0;                                       // the cells outside the wave's span along x, two active lanes
   if (lane == 0 || lane == 63) { const long o = lane == 0 ? -1 : 2; eA = v[cpA + o]; eB = v[cpA + sy + o]; }
-  #define LD2(off) (*reinterpret_cast<const double2 *>(v + cpA + (off)))
+  #define LD2(off) (ld2c<false>(v + cpA + (off)))
   const double2 PA = LD2(0), PB = LD2(sy), PAm = LD2(-sy), PBp = LD2(2 * sy);
   const double2 ZAm = LD2(-sz), ZAp = LD2(sz), ZBm = LD2(sy - sz), ZBp = LD2(sy + sz);
   #undef LD2
