@@ -205,9 +205,11 @@ def test_hgproject(gpu, oracle, bcname, proj_type):
 def test_multigrid_launch_variants_agree_bit_for_bit(gpu):
     """the launch-saving forms of the V-cycles change no value: a 128^3 step (the finest MAC level takes the paired density pass only from
     128 cells up) with (a) the defaults -- prolongation added inside the first post-smoothing sweep (kk_cc_gsrb_rho_pair_t), restriction inside the
-    residual pass (kk_cc_residual_rho_pair_rst), the levels of
+    residual pass (kk_cc_residual_rho_pair_rst), the 16^3 .. 64^3 levels as one LDS-tiled launch down and one up (kk_cc_lds_down / kk_cc_lds_up,
+    kk_nd_lds_down / kk_nd_lds_up), the levels of
     at most 9^3 nodes / 8^3 cells in one single-workgroup launch (kk_*_tailcycle), V-cycles replayed as hipGraphs -- against (b) the
-    plain sequence of launches.  The switches are read once per process, hence the child processes."""
+    plain sequence of launches; and a viscous 64^3 run the same way (the alpha form of the cell-centred kernels: three visc_solves per step).
+    The switches are read once per process, hence the child processes."""
     import hashlib, os, subprocess, sys, textwrap
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     code = textwrap.dedent("""
@@ -215,7 +217,9 @@ def test_multigrid_launch_variants_agree_bit_for_bit(gpu):
         sys.path.insert(0, %r)
         import numpy as np
         from varden_amd import driver
-        G = driver.VardenAMR(128, [], [[15, 15]] * 3, init_iter=1, do_initial_projection=1)
+        from varden_amd.capi import default_params
+        n, visc = int(sys.argv[1]), float(sys.argv[2])
+        G = driver.VardenAMR(n, [], [[15, 15]] * 3, params=default_params(visc_coef=visc, diff_coef=visc), init_iter=1, do_initial_projection=1)
         for _ in range(2):
             G.step()
         h = hashlib.sha256()
@@ -223,13 +227,15 @@ def test_multigrid_launch_variants_agree_bit_for_bit(gpu):
             h.update(np.ascontiguousarray(m.to_numpy()).tobytes())
         print("HASH", h.hexdigest(), G.dt)
     """ % root)
-    out = []
-    for extra in ({}, {"VDN_MG_PROLONG_FUSED": "0", "VDN_MG_RESTRICT_FUSED": "0", "VDN_MG_TAILCYCLE": "0", "VDN_NO_GRAPHS": "1"}):
-        env = dict(os.environ)
-        for k in ("VDN_MG_PROLONG_FUSED", "VDN_MG_RESTRICT_FUSED", "VDN_MG_TAILCYCLE", "VDN_NO_GRAPHS"):
-            env.pop(k, None)
-        env.update(extra)
-        r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600, cwd=root)
-        assert r.returncode == 0, r.stderr[-2000:]
-        out.append([ln for ln in r.stdout.splitlines() if ln.startswith("HASH")][0])
-    assert out[0] == out[1], out
+    switches = ("VDN_MG_PROLONG_FUSED", "VDN_MG_RESTRICT_FUSED", "VDN_MG_TAILCYCLE", "VDN_MG_LDS", "VDN_NO_GRAPHS")
+    for n, visc in ((128, 0.0), (64, 0.01)):
+        out = []
+        for extra in ({}, {"VDN_MG_PROLONG_FUSED": "0", "VDN_MG_RESTRICT_FUSED": "0", "VDN_MG_TAILCYCLE": "0", "VDN_MG_LDS": "0", "VDN_NO_GRAPHS": "1"}):
+            env = dict(os.environ)
+            for k in switches:
+                env.pop(k, None)
+            env.update(extra)
+            r = subprocess.run([sys.executable, "-c", code, str(n), str(visc)], env=env, capture_output=True, text=True, timeout=600, cwd=root)
+            assert r.returncode == 0, r.stderr[-2000:]
+            out.append([ln for ln in r.stdout.splitlines() if ln.startswith("HASH")][0])
+        assert out[0] == out[1], (n, visc, out)

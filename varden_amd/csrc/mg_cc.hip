@@ -129,20 +129,16 @@ DEVI void cc_apply_rho_vals(const CLev &L, int i, int j, int k, const double p[7
 // at the two ends of the wave (one branch-free load per field).  8 + 1 loads per field for two cells instead of 2 x 7.  Same arithmetic.
 struct Pair7 { double a[7], b[7]; };
 DEVI double sel2(const double2 &q, int hi) { return hi ? q.y : q.x; }
-typedef double v2d_t __attribute__((ext_vector_type(2)));
-// NT: the loads carry the non-temporal hint (fields that are read once per pass and should not push phi out of the caches)
-template <bool NT> DEVI double2 ld2c(const double *p) {
-  if (NT) { const v2d_t q = __builtin_nontemporal_load(reinterpret_cast<const v2d_t *>(p)); return make_double2(q.x, q.y); }
-  return *reinterpret_cast<const double2 *>(p);
-}
-template <bool NT = false> DEVI void pair_gather(const double *v, const CLev &L, long cpA, int par, int lane, Pair7 &o) {
+// (round 3, measured and rejected: rho and rhs loaded with the non-temporal hint, so that phi -- 134 MB, read and written by every pass --
+// might stay in the 256 MB Infinity Cache: 0.1178 -> 0.1170 ms at 256^3, 0.0154 -> 0.0182 ms at 128^3, where everything was cached before)
+DEVI void pair_gather(const double *v, const CLev &L, long cpA, int par, int lane, Pair7 &o) {
   const long sy = L.PX, sz = (long)L.PX * L.PY;
   // the cells just outside the pair along x: previous lane's odd cell / next lane's even cell; the two ends of the wave read memory
   // (issued first, two active lanes).  par = 0: A (row j, even column) looks left and B (row j+1, odd column) looks right; par = 1 the
   // other way round.
   double e = 0.0;
   if (lane == 0 || lane == 63) e = v[cpA + ((lane == 0) ? (par == 0 ? -1 : sy - 1) : (par == 0 ? sy + 2 : 2))];
-  #define LD2(off) (ld2c<NT>(v + cpA + (off)))
+  #define LD2(off) (*reinterpret_cast<const double2 *>(v + cpA + (off)))
   const double2 PA = LD2(0), PB = LD2(sy), PAm = LD2(-sy), PBp = LD2(2 * sy);
   const double2 ZAm = LD2(-sz), ZAp = LD2(sz), ZBm = LD2(sy - sz), ZBp = LD2(sy + sz);
   #undef LD2
@@ -197,7 +193,7 @@ template <int ADD> __global__ void __launch_bounds__(256) kk_cc_gsrb_rho_pair_t(
   if (diag != 0.0 && !(interior_only && cc_is_shell(L, iB, jA + 1, k, interior_only))) L.phi[cpA + L.PX + 1 - par] = P.b[0] + (sel2(RB, 1 - par) - Ap) / diag;
   else if (ADD) L.phi[cpA + L.PX + 1 - par] = P.b[0];
 }
-template <bool NT> __global__ void __launch_bounds__(256) kk_cc_gsrb_rho_pair(CLev L, int color, int interior_only) {
+__global__ void __launch_bounds__(256) kk_cc_gsrb_rho_pair(CLev L, int color, int interior_only) {
   int bx, by, bz; xcd_block(bx, by, bz);
   const int lane = threadIdx.x, k = bz;
   const int t = bx * 64 + lane, jA = 2 * (by * 4 + (int)threadIdx.y);
@@ -206,8 +202,8 @@ template <bool NT> __global__ void __launch_bounds__(256) kk_cc_gsrb_rho_pair(CL
   const long cpA = cidx(L, 2 * min(t, L.n[0] / 2), min(jA, L.n[1] - 2), k);      // clamped: every lane takes part in the lane exchange
   Pair7 P, R;
   pair_gather(L.phi, L, cpA, par, lane, P);
-  pair_gather<NT>(L.rho, L, cpA, par, lane, R);
-  const double2 RA = ld2c<NT>(L.rh + cpA), RB = ld2c<NT>(L.rh + cpA + L.PX);
+  pair_gather(L.rho, L, cpA, par, lane, R);
+  const double2 RA = *reinterpret_cast<const double2 *>(L.rh + cpA), RB = *reinterpret_cast<const double2 *>(L.rh + cpA + L.PX);
   if (!act) return;
   const int iA = 2 * t + par, iB = 2 * t + 1 - par;
   double Ap, diag;
@@ -279,12 +275,7 @@ static inline void launch_gsrb(const CLev &L, int color, hipStream_t st, int int
   const dim3 blk(64, 4, 1), g((unsigned)(((L.n[0] + 1) / 2 + 63) / 64), (unsigned)((L.n[1] + 3) / 4), (unsigned)L.n[2]);
   static const bool paired = !(getenv("VDN_GSRB_PAIR") && atoi(getenv("VDN_GSRB_PAIR")) == 0);
   if (L.rho && paired && L.n[0] % 2 == 0 && L.n[1] % 2 == 0 && L.n[0] >= 128)
-  {
-    static const bool nt = getenv("VDN_CC_NT") && atoi(getenv("VDN_CC_NT")) != 0;      // probe: rho and rhs with the non-temporal hint
-    const dim3 gp((unsigned)((L.n[0] / 2 + 63) / 64), (unsigned)((L.n[1] / 2 + 3) / 4), (unsigned)L.n[2]);
-    if (nt) hipLaunchKernelGGL(kk_cc_gsrb_rho_pair<true>, gp, blk, 0, st, L, color, interior_only);
-    else hipLaunchKernelGGL(kk_cc_gsrb_rho_pair<false>, gp, blk, 0, st, L, color, interior_only);
-  }
+    hipLaunchKernelGGL(kk_cc_gsrb_rho_pair, dim3((unsigned)((L.n[0] / 2 + 63) / 64), (unsigned)((L.n[1] / 2 + 3) / 4), (unsigned)L.n[2]), blk, 0, st, L, color, interior_only);
   else if (L.rho) hipLaunchKernelGGL(kk_cc_gsrb_rho, g, blk, 0, st, L, color, interior_only);
   else if (paired && L.n[0] % 2 == 0 && L.n[1] % 2 == 0 && L.n[0] >= 128)
     hipLaunchKernelGGL(kk_cc_gsrb_pair, dim3((unsigned)((L.n[0] / 2 + 63) / 64), (unsigned)((L.n[1] / 2 + 3) / 4), (unsigned)L.n[2]), blk, 0, st, L, color, interior_only);
@@ -523,7 +514,7 @@ DEVI void quad_gather(const double *v, const CLev &L, long cpA, int lane, double
   const long sy = L.PX, sz = (long)L.PX * L.PY;
   double eA = 0.0, eB = 0.0;                                       // the cells outside the wave's span along x, two active lanes
   if (lane == 0 || lane == 63) { const long o = lane == 0 ? -1 : 2; eA = v[cpA + o]; eB = v[cpA + sy + o]; }
-  #define LD2(off) (ld2c<false>(v + cpA + (off)))
+  #define LD2(off) (*reinterpret_cast<const double2 *>(v + cpA + (off)))
   const double2 PA = LD2(0), PB = LD2(sy), PAm = LD2(-sy), PBp = LD2(2 * sy);
   const double2 ZAm = LD2(-sz), ZAp = LD2(sz), ZBm = LD2(sy - sz), ZBp = LD2(sy + sz);
   #undef LD2
@@ -772,6 +763,116 @@ __global__ void __launch_bounds__(1024) kk_cc_tailcycle(CcTailArgs T) {
   #pragma unroll
   for (int l = CC_TAIL_MAX - 2; l >= 0; l--)
     if (l < T.nlev - 1) { wg_cc_up(T.L[l], T.L[l + 1]); wg_cc_gsrb(T.L[l], T.nu2, T.per); }
+}
+
+// ---- levels of 16^3 .. 64^3 cells: one launch down, one launch up (round 3) ------------------------------------------------------------------
+// Below the 128^3 level a V-cycle is a chain of ~5 us launches: eleven per level and cycle (four colour passes, residual, restriction;
+// prolongation, four colour passes), each waiting for the one before -- ~300 launches per MAC solve on the 64^3, 32^3 and 16^3 levels of a 256^3
+// problem, 2.3 ms of a 14 ms projection for 1/500 of its cells.  The bytes are irrelevant there (a 64^3 level is 2 MB per field, L2 resident);
+// what costs is the number of dependent launches.  Both halves of a level's visit therefore run as ONE launch each, tiled through LDS with
+// redundant halo work instead of synchronisation between workgroups ("temporal blocking"):
+//   kk_cc_lds_down  a workgroup owns an 8^3 tile.  phi (zero on entry: the error equation) lives in LDS on the tile grown by 5 cells; colour
+//                   pass p = 0..3 updates the cells of its colour within 4 - p cells of the tile -- what the tile's own cells will need by
+//                   the last pass -- then the residual on the tile, whose 4^3 parents it restricts itself.  The smoothed phi goes to L.res
+//                   (nothing else uses the residual array of such a level), the coarse right-hand side and a zero coarse phi to the next level.
+//   kk_cc_lds_up    loads L.res + the piecewise-constant correction on the tile grown by 4 cells, runs the four post-smoothing passes the same
+//                   way (reach 3, 2, 1, 0) and writes phi of the tile.
+// A workgroup reads only what no workgroup of the same launch writes (down: rhs and coefficients; up: L.res and the coarse phi), so there is
+// nothing to order between workgroups.  Halo cells are recomputed by every tile that needs them, from the same operands with the same
+// expressions (cc_apply_vals, the operator of every other pass), hence the same bits: the results are those of the separate launches
+// (tests/test_kernels_gpu.py::test_multigrid_launch_variants_agree_bit_for_bit runs both).  A thread keeps the six face coefficients, the
+// right-hand side (and alpha) of its four cells in registers for the whole launch.  Conditions: one box, no periodic face (ghost cells of phi
+// are zero, the boundary conditions sit in the coefficients), extents multiples of 8, nu1 = nu2 = 2; anything else takes the separate launches.
+constexpr int LT = 8;                       // tile width
+constexpr int LW = LT + 8;                  // the tile grown by 4: the cells a workgroup holds coefficients for (16^3 = 4 per thread)
+struct LdsCell { double b[6], rh, a0; };
+template <bool ALPHA> DEVI void lds_load_cell(const CLev &L, long c, LdsCell &q) {
+  const long sy = L.PX, sz = (long)L.PX * L.PY;
+  q.b[0] = L.b[0][c]; q.b[1] = L.b[0][c + 1]; q.b[2] = L.b[1][c]; q.b[3] = L.b[1][c + sy]; q.b[4] = L.b[2][c]; q.b[5] = L.b[2][c + sz];
+  q.rh = L.rh[c]; q.a0 = ALPHA ? L.alpha[c] : 0.0;
+}
+// one colour pass on the four cells (x, y, z0 .. z0+3) of this thread -- coordinates in the grown tile, the tile itself at 4 .. 4+LT-1; s = phi in
+// LDS (row stride SX, plane stride SP, `at` = the thread's first cell); par0 = parity of the first cell's global index sum; reach = how far from the
+// tile this pass still has to be right
+template <bool ALPHA, int SX, int SP> DEVI void lds_pass(const CLev &L, double *s, const LdsCell (&q)[4], const bool (&inside)[4], int at, int x, int y, int z0, int par0, int color, int reach) {
+  const bool xy_ok = x >= 4 - reach && x < 4 + LT + reach && y >= 4 - reach && y < 4 + LT + reach;
+  #pragma unroll
+  for (int m = 0; m < 4; m++) {
+    const int z = z0 + m;
+    if (!(xy_ok && inside[m] && z >= 4 - reach && z < 4 + LT + reach && ((par0 + m + color) & 1) == 0)) continue;
+    const int a = at + m * SP;
+    const double p[7] = { s[a], s[a - 1], s[a + 1], s[a - SX], s[a + SX], s[a - SP], s[a + SP] };
+    double Ap, diag; cc_apply_vals(L, p, q[m].b, q[m].a0, ALPHA, Ap, diag);
+    if (diag != 0.0) s[a] = p[0] + (q[m].rh - Ap) / diag;
+  }
+}
+template <bool ALPHA> __global__ void __launch_bounds__(1024) kk_cc_lds_down(CLev L, CLev C) {
+  constexpr int SX = LW + 2, SP = SX * SX;                    // phi on the tile grown by 5: the outermost layer stays at its initial zero
+  __shared__ double s[SX * SX * SX];
+  __shared__ double r[LT * LT * LT];
+  const int t = threadIdx.x, x = t & (LW - 1), y = (t >> 4) & (LW - 1), z0 = 4 * (t >> 8);
+  const int i = (int)blockIdx.x * LT - 4 + x, j = (int)blockIdx.y * LT - 4 + y, k0 = (int)blockIdx.z * LT - 4 + z0;
+  for (int a = t; a < SX * SX * SX; a += 1024) s[a] = 0.0;      // phi = 0 on entry (written by the restriction that fed this level)
+  LdsCell q[4]; bool inside[4];
+  const bool ij_in = i >= 0 && i < L.n[0] && j >= 0 && j < L.n[1];
+  #pragma unroll
+  for (int m = 0; m < 4; m++) {
+    inside[m] = ij_in && k0 + m >= 0 && k0 + m < L.n[2];
+    if (inside[m]) lds_load_cell<ALPHA>(L, cidx(L, i, j, k0 + m), q[m]);
+    else { for (int e = 0; e < 6; e++) q[m].b[e] = 0.0; q[m].rh = 0.0; q[m].a0 = 0.0; }
+  }
+  const int at = (x + 1) + SX * (y + 1) + SP * (z0 + 1), par0 = (i + j + k0) & 1;
+  __syncthreads();
+  #pragma unroll
+  for (int pass = 0; pass < 4; pass++) { lds_pass<ALPHA, SX, SP>(L, s, q, inside, at, x, y, z0, par0, pass & 1, 4 - pass); __syncthreads(); }
+  // residual of the tile's cells (cc_residual_body), smoothed phi to L.res
+  const bool xy_tile = x >= 4 && x < 4 + LT && y >= 4 && y < 4 + LT;
+  #pragma unroll
+  for (int m = 0; m < 4; m++) {
+    const int z = z0 + m;
+    if (!(xy_tile && z >= 4 && z < 4 + LT)) continue;
+    const int a = at + m * SP;
+    const double p[7] = { s[a], s[a - 1], s[a + 1], s[a - SX], s[a + SX], s[a - SP], s[a + SP] };
+    double Ap, diag; cc_apply_vals(L, p, q[m].b, q[m].a0, ALPHA, Ap, diag);
+    r[(x - 4) + LT * ((y - 4) + LT * (z - 4))] = q[m].rh - Ap;
+    L.res[cidx(L, i, j, k0 + m)] = p[0];
+  }
+  __syncthreads();
+  if (t < (LT / 2) * (LT / 2) * (LT / 2)) {                      // kk_cc_restrict on the 4^3 parents of the tile
+    const int ci = t & 3, cj = (t >> 2) & 3, ck = t >> 4;
+    const int f = 2 * ci + LT * (2 * cj + LT * 2 * ck);
+    const double sum = r[f] + r[f + 1] + r[f + LT] + r[f + LT + 1] + r[f + LT * LT] + r[f + LT * LT + 1] + r[f + LT * LT + LT] + r[f + LT * LT + LT + 1];
+    const long cc = cidx(C, (int)blockIdx.x * (LT / 2) + ci, (int)blockIdx.y * (LT / 2) + cj, (int)blockIdx.z * (LT / 2) + ck);
+    C.rh[cc] = sum * 0.125;
+    C.phi[cc] = 0.0;
+  }
+}
+template <bool ALPHA> __global__ void __launch_bounds__(1024) kk_cc_lds_up(CLev L, CLev C) {
+  constexpr int SX = LW, SP = SX * SX;
+  __shared__ double s[SX * SX * SX];
+  const int t = threadIdx.x, x = t & (LW - 1), y = (t >> 4) & (LW - 1), z0 = 4 * (t >> 8);
+  const int i = (int)blockIdx.x * LT - 4 + x, j = (int)blockIdx.y * LT - 4 + y, k0 = (int)blockIdx.z * LT - 4 + z0;
+  LdsCell q[4]; bool inside[4];
+  const bool ij_in = i >= 0 && i < L.n[0] && j >= 0 && j < L.n[1];
+  const int at = x + SX * y + SP * z0, par0 = (i + j + k0) & 1;
+  #pragma unroll
+  for (int m = 0; m < 4; m++) {
+    inside[m] = ij_in && k0 + m >= 0 && k0 + m < L.n[2];
+    double v = 0.0;
+    if (inside[m]) {
+      const long c = cidx(L, i, j, k0 + m);
+      lds_load_cell<ALPHA>(L, c, q[m]);
+      v = L.res[c] + C.phi[cidx(C, i >> 1, j >> 1, (k0 + m) >> 1)];        // kk_cc_prolong on the phi kk_cc_lds_down left in L.res
+    } else { for (int e = 0; e < 6; e++) q[m].b[e] = 0.0; q[m].rh = 0.0; q[m].a0 = 0.0; }
+    s[at + m * SP] = v;
+  }
+  __syncthreads();
+  #pragma unroll
+  for (int pass = 0; pass < 4; pass++) { lds_pass<ALPHA, SX, SP>(L, s, q, inside, at, x, y, z0, par0, pass & 1, 3 - pass); __syncthreads(); }
+  if (x >= 4 && x < 4 + LT && y >= 4 && y < 4 + LT) {
+    #pragma unroll
+    for (int m = 0; m < 4; m++) if (z0 + m >= 4 && z0 + m < 4 + LT) L.phi[cidx(L, i, j, k0 + m)] = s[at + m * SP];
+  }
 }
 
 // ---- transfers between BoxLib-layout multifabs and level 0 ---------------------------------------------
@@ -1300,6 +1401,19 @@ static void cc_prolong_smooth(CCMG &M, int l, int nsweeps) {
   hipLaunchKernelGGL(kk_cc_gsrb_rho_pair_t<2>, g, blk, 0, ctx().stream, L, 1, 0, C);
   if (nsweeps > 1) cc_gsrb_d(M, DL, nsweeps - 1);
 }
+// may level l >= 1 of a V-cycle run as kk_cc_lds_down / kk_cc_lds_up?  (VDN_MG_LDS=0: never; VDN_MG_LDS_MAX: largest extent taken, default 64)
+static bool cc_lds_level(const CCMG &M, int l) {
+  static const bool on = !(getenv("VDN_MG_LDS") && atoi(getenv("VDN_MG_LDS")) == 0);
+  static const int nmax_ = getenv("VDN_MG_LDS_MAX") ? atoi(getenv("VDN_MG_LDS_MAX")) : 64;
+  const vdn_params &P = ctx().prm;
+  if (!on || l < 1 || l + 1 >= (int)M.dlev.size() || P.mg_nu1 != 2 || P.mg_nu2 != 2 || M.per[0] || M.per[1] || M.per[2]) return false;
+  const CDLev &D = M.dlev[l], &DC = M.dlev[l + 1];
+  if (!(D.single_box && D.boxes.size() == 1 && !D.halo && DC.single_box && DC.boxes.size() == 1)) return false;
+  const CLev &L = D.boxes[0].L;
+  if (L.phi2 || L.rho) return false;
+  for (int d = 0; d < 3; d++) if (L.n[d] % LT || L.n[d] < 2 * LT || L.n[d] > nmax_ || D.boxes[0].lo[d] != 0 || DC.boxes[0].L.n[d] * 2 != L.n[d]) return false;
+  return true;
+}
 // error-equation V-cycle on distributed level l (zero initial guess)
 static void cc_vcycle_d(CCMG &M, int l) {
   const vdn_params &P = ctx().prm;
@@ -1309,6 +1423,16 @@ static void cc_vcycle_d(CCMG &M, int l) {
   if (last && M.tail.empty()) {         // nothing below: bottom sweeps on the distributed level itself
     const int N = std::max(DL.ng[0], std::max(DL.ng[1], DL.ng[2]));     // largest GLOBAL extent, as in the oracle
     cc_gsrb_d(M, DL, std::max(P.mg_nub, N * N));
+    return;
+  }
+  if (!last && cc_lds_level(M, l)) {        // 16^3 .. 64^3: smoothing + residual + restriction in one launch, prolongation + smoothing in another
+    const CLev &L = DL.boxes[0].L, &C = M.dlev[l + 1].boxes[0].L;
+    const dim3 g((unsigned)(L.n[0] / LT), (unsigned)(L.n[1] / LT), (unsigned)(L.n[2] / LT));
+    if (L.alpha) hipLaunchKernelGGL(kk_cc_lds_down<true>, g, dim3(1024), 0, ctx().stream, L, C);
+    else hipLaunchKernelGGL(kk_cc_lds_down<false>, g, dim3(1024), 0, ctx().stream, L, C);
+    cc_vcycle_d(M, l + 1);
+    if (L.alpha) hipLaunchKernelGGL(kk_cc_lds_up<true>, g, dim3(1024), 0, ctx().stream, L, C);
+    else hipLaunchKernelGGL(kk_cc_lds_up<false>, g, dim3(1024), 0, ctx().stream, L, C);
     return;
   }
   cc_gsrb_d(M, DL, P.mg_nu1);

@@ -217,14 +217,10 @@ __device__ int g_nd_dbg = 0;      // VDN_ND_DBG (probe only): 1 = no stencil ari
 // times that.  Main tiles and remainder tiles are workgroups of ONE launch (1-D grid: main tiles first, in the XCD-aware order).
 // (ii) The k-slabs are balanced (sizes differ by at most one plane): 257 planes in 16 slabs of 17 left a last slab of two planes.
 struct NdPairGrid { int gxm, gy, gz, nmain, lwr, gyr; };       // main tiles gxm x gy x gz (lw = 6), then gyr x gz remainder tiles of segment 2^lwr
-// VAR (probes, VDN_ND_VAR): bit 0 = sigma and rhs are loaded with the non-temporal hint, bit 1 = at most 128 VGPRs (four waves per SIMD)
-typedef double nd_v2d_t __attribute__((ext_vector_type(2)));
-template <bool NT> DEVI double2 ld2n(const double *p) {
-  if (NT) { const nd_v2d_t q = __builtin_nontemporal_load(reinterpret_cast<const nd_v2d_t *>(p)); return make_double2(q.x, q.y); }
-  return *reinterpret_cast<const double2 *>(p);
-}
-template <int MODE, int ROWS, int VAR>
-__global__ void __launch_bounds__(64 * ROWS, (VAR & 2) ? 4 : 1) kk_nd_march_pair(NLev L, const double *__restrict__ phi, double *__restrict__ out, double omega, NdPairGrid G, double *nrm, int shell_later) {
+// (round 3, measured and rejected at 257^3: sigma and rhs loaded with the non-temporal hint 0.1392 -> 0.1420 ms; the kernel held to 128 VGPRs
+// -- four waves per SIMD, 116 bytes of scratch per lane -- 0.341 ms)
+template <int MODE, int ROWS>
+__global__ void __launch_bounds__(64 * ROWS) kk_nd_march_pair(NLev L, const double *__restrict__ phi, double *__restrict__ out, double omega, NdPairGrid G, double *nrm, int shell_later) {
   const int lane = threadIdx.x;
   const int id = (int)blockIdx.x;
   int lw, pair0, j, bz;
@@ -257,7 +253,7 @@ __global__ void __launch_bounds__(64 * ROWS, (VAR & 2) ? 4 : 1) kk_nd_march_pair
     double q[3][3][4], sg[2][2][3];
     #define LOADP(pl, off) { _Pragma("unroll") for (int b = 0; b < 3; b++) { const double2 v = ld2(phi + (off) + (b - 1) * sy); q[pl][b][1] = v.x; q[pl][b][2] = v.y; } }
     #define EXCHP(pl) { _Pragma("unroll") for (int b = 0; b < 3; b++) { q[pl][b][0] = lane_prev(q[pl][b][2]); q[pl][b][3] = lane_next(q[pl][b][1]); } }
-    #define LOADS(dk, off) { _Pragma("unroll") for (int dj = 0; dj < 2; dj++) { const double2 v = ld2n<(VAR & 1) != 0>(L.sig + (off) + (dj - 1) * sy); sg[dk][dj][1] = v.x; sg[dk][dj][2] = v.y; } }
+    #define LOADS(dk, off) { _Pragma("unroll") for (int dj = 0; dj < 2; dj++) { const double2 v = ld2(L.sig + (off) + (dj - 1) * sy); sg[dk][dj][1] = v.x; sg[dk][dj][2] = v.y; } }
     #define EXCHS(dk) { _Pragma("unroll") for (int dj = 0; dj < 2; dj++) sg[dk][dj][0] = lane_prev(sg[dk][dj][2]); }
     LOADP(0, c - sz) LOADP(1, c) LOADS(0, c - sz)
     EXCHP(0) EXCHP(1) EXCHS(0)
@@ -268,7 +264,7 @@ __global__ void __launch_bounds__(64 * ROWS, (VAR & 2) ? 4 : 1) kk_nd_march_pair
     const int dbg = g_nd_dbg;
     for (int k = k0; k <= k1; k++, c += sz, op += ostep) {
       double2 rhs = make_double2(1.0, 1.0);
-      if (!(dbg & 2)) { LOADP(2, c + sz) LOADS(1, c) rhs = ld2n<(VAR & 1) != 0>(L.b + c); }
+      if (!(dbg & 2)) { LOADP(2, c + sz) LOADS(1, c) rhs = ld2(L.b + c); }
       EXCHP(2) EXCHS(1)
       const bool dirk = (k == 0 && L.dirlo[2]) || (k == L.n[2] && L.dirhi[2]);
       double pa[3][3][3], pb[3][3][3], sa[2][2][2], sb[2][2][2];
@@ -764,11 +760,7 @@ template <int MODE> static void nd_launch_march(const NLev &L, const double *phi
     if (kc_env > 0) kc = std::min(kc_env, nzp);
     G.gz = std::max(1, (nzp + kc - 1) / kc);      // balanced slabs of at most kc planes (257 planes: 16 slabs of 16 or 17 -- measured 0.1396 ms against 0.1443 with 15 slabs)
     G.nmain = G.gxm * G.gy * G.gz;
-    static const int var = getenv("VDN_ND_VAR") ? atoi(getenv("VDN_ND_VAR")) : 0;
-    const dim3 g1(G.nmain + G.gyr * G.gz);
-    #define ND_GO(V) hipLaunchKernelGGL((kk_nd_march_pair<MODE, 4, V>), g1, NBLK, 0, ctx().stream, L, phi, out, ctx().prm.hg_omega, G, nrm, shell_later)
-    if (var == 1) ND_GO(1); else if (var == 2) ND_GO(2); else if (var == 3) ND_GO(3); else ND_GO(0);
-    #undef ND_GO
+    hipLaunchKernelGGL((kk_nd_march_pair<MODE, 4>), dim3(G.nmain + G.gyr * G.gz), NBLK, 0, ctx().stream, L, phi, out, ctx().prm.hg_omega, G, nrm, shell_later);
     return;
   }
   hipLaunchKernelGGL(kk_nd_march<MODE>, dim3((L.n[0] + 62) / 62, (L.n[1] + 4) / 4, nch), NBLK, 0, ctx().stream, L, phi, out, ctx().prm.hg_omega, kchunk, nrm, shell_later);
