@@ -53,6 +53,7 @@ def parse_args():
     ap.add_argument("--box", dest="n", type=int, default=256, help="box width (256/512) or base-level width (amr2/amr3)")
     ap.add_argument("--cpu-box", dest="cpu_n", type=int, default=0, help="width of the CPU sample (0: 128, or 64 for amr)")
     ap.add_argument("--skip-cpu", dest="no_cpu", action="store_true")
+    ap.add_argument("--no-extra", dest="no_extra", action="store_true", help="skip the extra_workloads (512^3 in eight boxes, tagged two-level hierarchy) of the default N = 1 line")
     return ap.parse_args()
 
 
@@ -138,46 +139,51 @@ def main():
         bl.initialize(prm, 0, 1, local_rank)
         bl.comm_init(bl.comm_get_unique_id())
 
-    amr = args.config in ("amr2", "amr3")
-    if amr:
-        max_levs = 2 if args.config == "amr2" else 3
-        base_boxes = None
-        if world > 1:                                      # cut the base level so that it can be dealt to the ranks
-            hb = n // 2
-            base_boxes = [((i * hb, j * hb, k * hb), ((i + 1) * hb - 1, (j + 1) * hb - 1, (k + 1) * hb - 1))
-                          for k in range(2) for j in range(2) for i in range(2)]
-        mgs = min(256, n)
-        levels = driver.VardenAMR.tagged_grids(n, walls, prm, max_levs=max_levs, max_grid_size=mgs, device=local_rank, rank=rank, nranks=world,
-                                               comm_id=comm_id, base_boxes=base_boxes)
-        assert len(levels) == max_levs - 1, "tagging produced %d refined levels, %d wanted" % (len(levels), max_levs - 1)
-        G = driver.VardenAMR(n, levels[0], walls, params=prm, finer_levels=levels[1:], init_shrink=0.1, init_iter=1, do_initial_projection=1,
-                             device=local_rank, rank=rank, nranks=world, comm_id=comm_id, base_boxes=base_boxes, max_grid_size=mgs, swap_state=True)
-        lev_cells = [n ** 3] + [sum(int(np.prod([b[1][d] - b[0][d] + 1 for d in range(3)])) for b in lb) for lb in levels]
-        cells = sum(lev_cells)
-        workload = ("3D %d-level AMR, base %d^3, refined levels tagged rho > 1.01%s (tag_boxes.f90:65-84), fixed grids: %s boxes, %s cells per level; "
-                    "composite MAC + HG solves each step (BASELINE.json configs[%d])"
-                    % (max_levs, n, " / rho > 1.1" if max_levs == 3 else "", [1 if base_boxes is None else 8] + [len(lb) for lb in levels], lev_cells,
-                       3 if max_levs == 2 else 4))
-        par = "single GPU" if world == 1 else "boxes of every level dealt to %d ranks by cell count (knapsack), RCCL p2p ghost / coarse-fine exchange + allreduce" % world
-    else:
-        if args.config == "512":                           # fixed global problem: 2x2x2 boxes of n^3, dealt round-robin
-            decomp = (2, 2, 2)
-            assert 8 % world == 0, "the 8 boxes of the 512 config need 1, 2, 4 or 8 ranks"
+    def build_workload(config, n):
+        """the driver object of one BASELINE.json config: (G, cells, workload, parallelism, is_amr)"""
+        amr = config in ("amr2", "amr3")
+        if amr:
+            max_levs = 2 if config == "amr2" else 3
+            base_boxes = None
+            if world > 1:                                      # cut the base level so that it can be dealt to the ranks
+                hb = n // 2
+                base_boxes = [((i * hb, j * hb, k * hb), ((i + 1) * hb - 1, (j + 1) * hb - 1, (k + 1) * hb - 1))
+                              for k in range(2) for j in range(2) for i in range(2)]
+            mgs = min(256, n)
+            levels = driver.VardenAMR.tagged_grids(n, walls, prm, max_levs=max_levs, max_grid_size=mgs, device=local_rank, rank=rank, nranks=world,
+                                                   comm_id=comm_id, base_boxes=base_boxes)
+            assert len(levels) == max_levs - 1, "tagging produced %d refined levels, %d wanted" % (len(levels), max_levs - 1)
+            G = driver.VardenAMR(n, levels[0], walls, params=prm, finer_levels=levels[1:], init_shrink=0.1, init_iter=1, do_initial_projection=1,
+                                 device=local_rank, rank=rank, nranks=world, comm_id=comm_id, base_boxes=base_boxes, max_grid_size=mgs, swap_state=True)
+            lev_cells = [n ** 3] + [sum(int(np.prod([b[1][d] - b[0][d] + 1 for d in range(3)])) for b in lb) for lb in levels]
+            cells = sum(lev_cells)
+            workload = ("3D %d-level AMR, base %d^3, refined levels tagged rho > 1.01%s (tag_boxes.f90:65-84), fixed grids: %s boxes, %s cells per level; "
+                        "composite MAC + HG solves each step (BASELINE.json configs[%d])"
+                        % (max_levs, n, " / rho > 1.1" if max_levs == 3 else "", [1 if base_boxes is None else 8] + [len(lb) for lb in levels], lev_cells,
+                           3 if max_levs == 2 else 4))
+            par = "single GPU" if world == 1 else "boxes of every level dealt to %d ranks by cell count (knapsack), RCCL p2p ghost / coarse-fine exchange + allreduce" % world
         else:
-            decomp = {1: (1, 1, 1), 2: (2, 1, 1), 4: (2, 2, 1), 8: (2, 2, 2)}.get(world)
-            assert decomp is not None, "bench.py supports 1, 2, 4 or 8 GPUs"
-        nglob = tuple(n * decomp[d] for d in range(3))
-        h = 1.0 / (n * max(decomp))                        # dx = dy = dz; 2x2x2 gives the unit cube
-        prob_hi = tuple(nglob[d] * h for d in range(3))
-        G = driver.Varden(nglob, walls, prm, prob_type=1, grav=-9.8, prob_hi=prob_hi, init_shrink=0.1, init_iter=1,
-                          device=local_rank, decomp=decomp, rank=rank, nranks=world, comm_id=comm_id,
-                          swap_state=True)     # uold <- unew as a handle exchange (tests/test_advance_gpu.py::test_handle_swap_equals_copy)
-        cells = nglob[0] * nglob[1] * nglob[2]
-        nb = decomp[0] * decomp[1] * decomp[2]
-        workload = ("3D %dx%dx%d single-level variable-density bubble, %d box(es) of %d^3, MAC+HG projection each step (BASELINE.json configs[%d])"
-                    % (nglob + (nb, n, 1 if nb == 1 else 2)))
-        par = "single GPU" if world == 1 else ("domain decomposition %dx%dx%d, %d box(es) of %d^3 per GPU, RCCL p2p ghost exchange + allreduce"
-                                               % (decomp + (nb // world, n)))
+            if config == "512":                                # fixed global problem: 2x2x2 boxes of n^3, dealt round-robin
+                decomp = (2, 2, 2)
+                assert 8 % world == 0, "the 8 boxes of the 512 config need 1, 2, 4 or 8 ranks"
+            else:
+                decomp = {1: (1, 1, 1), 2: (2, 1, 1), 4: (2, 2, 1), 8: (2, 2, 2)}.get(world)
+                assert decomp is not None, "bench.py supports 1, 2, 4 or 8 GPUs"
+            nglob = tuple(n * decomp[d] for d in range(3))
+            h = 1.0 / (n * max(decomp))                        # dx = dy = dz; 2x2x2 gives the unit cube
+            prob_hi = tuple(nglob[d] * h for d in range(3))
+            G = driver.Varden(nglob, walls, prm, prob_type=1, grav=-9.8, prob_hi=prob_hi, init_shrink=0.1, init_iter=1,
+                              device=local_rank, decomp=decomp, rank=rank, nranks=world, comm_id=comm_id,
+                              swap_state=True)     # uold <- unew as a handle exchange (tests/test_advance_gpu.py::test_handle_swap_equals_copy)
+            cells = nglob[0] * nglob[1] * nglob[2]
+            nb = decomp[0] * decomp[1] * decomp[2]
+            workload = ("3D %dx%dx%d single-level variable-density bubble, %d box(es) of %d^3, MAC+HG projection each step (BASELINE.json configs[%d])"
+                        % (nglob + (nb, n, 1 if nb == 1 else 2)))
+            par = "single GPU" if world == 1 else ("domain decomposition %dx%dx%d, %d box(es) of %d^3 per GPU, RCCL p2p ghost exchange + allreduce"
+                                                   % (decomp + (nb // world, n)))
+        return G, cells, workload, par, amr
+
+    G, cells, workload, par, amr = build_workload(args.config, n)
     rccl_nranks = bl.comm_nranks()
 
     def barrier():
@@ -221,6 +227,27 @@ def main():
     if rank == 0 and not amr:
         rho = G.sold[0].to_numpy()[..., 0]                  # rank 0's first box, for the smoother probe's coefficients
     G.close()                                              # also tears the RCCL communicator down
+
+    # ---- the other single-GPU workloads of BASELINE.json, a few timed steps each (the headline stays configs[1]) ----------
+    extra = []
+    if world == 1 and args.config == "256" and n == 256 and not args.no_extra:
+        for cfg in ("512", "amr2"):
+            tb = time.perf_counter()
+            G2, cells2, wl2, _, _ = build_workload(cfg, 256)
+            G2.step()                                       # warm-up
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            cyc2 = dict(mac=0, hg=0)
+            for _ in range(3):
+                G2.step()
+                cyc2["mac"] += adv.last_solver_stats("mac")[0]
+                cyc2["hg"] += adv.last_solver_stats("hg")[0]
+            torch.cuda.synchronize()
+            el2 = time.perf_counter() - t1
+            G2.close()
+            extra.append({"workload": wl2, "cells": cells2, "steps": 3, "warmup": 1, "ms_per_step": round(1e3 * el2 / 3, 3),
+                          "value": round(cells2 * 3 / el2, 1), "unit": "cells*steps/s",
+                          "solver_iterations_per_step": {k: round(v / 3.0, 2) for k, v in cyc2.items()}, "wall_s_incl_setup": round(time.perf_counter() - tb, 1)})
 
     # ---- roofline of the dominant kernel: one colour pass of the MAC-MG smoother at 256^3 ----------
     roof = None
@@ -311,7 +338,7 @@ def main():
                        "phase_ms_per_step": {k: round(1e3 * v / args.steps, 3) for k, v in phases.items()},
                        "vcycles_per_step": {k: round(v / args.steps, 2) for k, v in cyc.items()},
                        "comm_per_step_rank0": comm},
-            "roofline": roof, "cpu_baseline": cpu,
+            "roofline": roof, "cpu_baseline": cpu, "extra_workloads": extra,
         }
         print(json.dumps(out), flush=True)
     if world > 1:

@@ -36,7 +36,7 @@ def default_params(**kw):
     p.stencil_order = 2; p.diffusion_type = 1; p.verbose = 0; p.mg_verbose = 0; p.prob_type = 1
     p.visc_coef = 0.0; p.diff_coef = 0.0; p.cflfac = 0.8; p.max_dt_growth = 1.1
     p.mg_nu1 = 2; p.mg_nu2 = 2; p.mg_nub = 8; p.mg_max_iter = 100
-    p.hg_max_iter = 100; p.hg_nu1 = 2; p.hg_nu2 = 1; p.hg_nub = 32; p.hg_omega = 0.9
+    p.hg_max_iter = 100; p.hg_nu1 = 2; p.hg_nu2 = 1; p.hg_nub = 8; p.hg_omega = 0.9
     p.mac_rel_eps = 1.0e-10; p.hg_rel_eps = -1.0; p.abort_on_max_iter = 1
     for k, v in kw.items():
         if not hasattr(p, k):

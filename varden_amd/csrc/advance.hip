@@ -77,12 +77,20 @@ extern "C" int vdn_advance_timestep(int istep, vdn_layout *mla, vdn_multifab **s
   }
 
   // advance_premac.f90:44-51
+  // The velocity forcing of advance_premac -- mkvelforce(ext, gp, sold, lapu, visc_fac = 1) + its ghost fill -- is computed a second time, from
+  // the same operands, at the top of velocity_advance (velocity_advance.f90:63-66; gp changes only in hgproject, sold and ext not at all; lapu is
+  // zeroed in between only for diffusion_type = 2, advance_timestep.f90:116-120).  Unless that is the case the first one is kept for the
+  // velocity mkflux (0.32 ms of a 41 ms step at 256^3): the same values, as with the limited slopes above.
+  static const bool force_reuse = !(getenv("VDN_NO_FORCE_REUSE") && atoi(getenv("VDN_NO_FORCE_REUSE")) != 0);
+  const bool keep_vel_force = force_reuse && !(viscous && P.diffusion_type == 2);
+  vdn_multifab *vel_force0[VDN_MAXLEV] = { nullptr };
+  if (keep_vel_force) for (int n = 0; n < nlevs; n++) vel_force0[n] = mf_temp(mla, n, dm, 1, -1, false, 0.0);
   {
     Prof pr("advance_premac");
     size_t mark = arena_mark();
     vdn_multifab *vel_force[VDN_MAXLEV];
     for (int n = 0; n < nlevs; n++) {
-      vel_force[n] = mf_temp(mla, n, dm, 1, -1, false, 0.0);
+      vel_force[n] = keep_vel_force ? vel_force0[n] : mf_temp(mla, n, dm, 1, -1, false, 0.0);
       k_mkvelforce(vel_force[n], ext_vel_force[n], sold[n], gp[n], lapu[n], 1.0);
     }
     restrict_and_fill(nlevs, vel_force, 0, bct->extrap_comp0(), dm, true, bct);         // mkforce.f90:75-76
@@ -91,7 +99,7 @@ extern "C" int vdn_advance_timestep(int istep, vdn_layout *mla, vdn_multifab **s
     for (int d = 0; d < dm; d++) mf_fill_boundary(umac[d]);
     for (int n = 1; n < nlevs; n++) for (int d = 0; d < dm; d++) { ml_create_umac_grown(umac[3 * n + d], umac[3 * (n - 1) + d], d); mf_fill_boundary(umac[3 * n + d]); }
     for (int n = nlevs - 1; n >= 1; n--) for (int d = 0; d < dm; d++) ml_edge_restriction(umac[3 * (n - 1) + d], umac[3 * n + d], d);
-    for (int n = nlevs - 1; n >= 0; n--) mf_temp_free(vel_force[n]);
+    if (!keep_vel_force) for (int n = nlevs - 1; n >= 0; n--) mf_temp_free(vel_force[n]);
     arena_release(mark);
   }
 
@@ -125,9 +133,9 @@ extern "C" int vdn_advance_timestep(int istep, vdn_layout *mla, vdn_multifab **s
     restrict_and_fill(nlevs, scal_force, 0, bct->extrap_comp0(), nscal, true, bct);     // mkforce.f90:283-284
     for (int n = 0; n < nlevs; n++) {
       k_mkflux(sold[n], sedge + 3 * n, sflux + 3 * n, umac + 3 * n, scal_force[n], divu[n], DXL(n), dt, bct, false, is_cons);
-      k_mkscalforce(scal_force[n], ext_scal_force[n], laps[n], 0.0);
+      if (diffusive || !force_reuse) k_mkscalforce(scal_force[n], ext_scal_force[n], laps[n], 0.0);     // without diffusion: ext_scal_force again, already there
     }
-    restrict_and_fill(nlevs, scal_force, 0, bct->extrap_comp0(), nscal, true, bct);
+    if (diffusive || !force_reuse) restrict_and_fill(nlevs, scal_force, 0, bct->extrap_comp0(), nscal, true, bct);
     for (int n = 0; n < nlevs; n++) k_update(sold[n], umac + 3 * n, sedge + 3 * n, sflux + 3 * n, scal_force[n], snew[n], DXL(n), dt, false, is_cons);
     restrict_and_fill(nlevs, snew, 0, dm, nscal, false, bct);                           // update.f90:106
     if (diffusive) {                                                                    // scalar_advance.f90:144-162
@@ -154,11 +162,11 @@ extern "C" int vdn_advance_timestep(int istep, vdn_layout *mla, vdn_multifab **s
     int is_cons[3] = { 0, 0, 0 };
     vdn_multifab *vel_force[VDN_MAXLEV], *uflux[3 * VDN_MAXLEV], *uedge[3 * VDN_MAXLEV];
     for (int n = 0; n < nlevs; n++) {
-      vel_force[n] = mf_temp(mla, n, dm, 1, -1, false, 0.0);
+      vel_force[n] = keep_vel_force ? vel_force0[n] : mf_temp(mla, n, dm, 1, -1, false, 0.0);
       for (int d = 0; d < dm; d++) { uflux[3 * n + d] = mf_temp(mla, n, dm, 0, d, false, 0.0); uedge[3 * n + d] = mf_temp(mla, n, dm, 0, d, false, 0.0); }   // uedge: written everywhere; uflux: never read (no conservative velocity component)
-      k_mkvelforce(vel_force[n], ext_vel_force[n], sold[n], gp[n], lapu[n], 1.0);
+      if (!keep_vel_force) k_mkvelforce(vel_force[n], ext_vel_force[n], sold[n], gp[n], lapu[n], 1.0);
     }
-    restrict_and_fill(nlevs, vel_force, 0, bct->extrap_comp0(), dm, true, bct);
+    if (!keep_vel_force) restrict_and_fill(nlevs, vel_force, 0, bct->extrap_comp0(), dm, true, bct);
     for (int n = 0; n < nlevs; n++) {
       k_mkflux(uold[n], uedge + 3 * n, uflux + 3 * n, umac + 3 * n, vel_force[n], mac_rhs[n], DXL(n), dt, bct, true, is_cons);
       k_mkvelforce(vel_force[n], ext_vel_force[n], rhohalf[n], gp[n], lapu[n], 0.0);

@@ -26,7 +26,11 @@ void vdn_fail(const char *fmt, ...) {
 
 // also drops the pointers advance_timestep keeps INTO the arena (limited slopes of uold, max |umac|): a step that ended in an exception
 // (solver_check throws by default) must not leave them dangling for the next stand-alone vdn_k_mkflux / vdn_k_velpred
+// the descriptors of arena temporaries (mf_temp) that nobody freed: they die with the arena contents they describe
+static std::vector<vdn_multifab *> g_temp_mfs;
 void arena_reset() {
+  for (vdn_multifab *m : g_temp_mfs) delete m;
+  g_temp_mfs.clear();
   g_ctx.arena_off = 0;
   g_ctx.slope_src = nullptr; g_ctx.macmax_src = nullptr; g_ctx.macmax_cache = nullptr;
   for (int d = 0; d < 3; d++) g_ctx.slope_cache[d] = nullptr;
@@ -75,7 +79,7 @@ extern "C" void vdn_params_default(vdn_params *p) {
   p->stencil_order = 2; p->diffusion_type = 1; p->verbose = 0; p->mg_verbose = 0; p->prob_type = 1;
   p->visc_coef = 0.0; p->diff_coef = 0.0; p->cflfac = 0.8; p->max_dt_growth = 1.1;
   p->mg_nu1 = 2; p->mg_nu2 = 2; p->mg_nub = 8; p->mg_max_iter = 100;
-  p->hg_max_iter = 100; p->hg_nu1 = 2; p->hg_nu2 = 1; p->hg_nub = 32; p->hg_omega = 0.9;
+  p->hg_max_iter = 100; p->hg_nu1 = 2; p->hg_nu2 = 1; p->hg_nub = 8; p->hg_omega = 0.9;     // hg_nub: 32 until round 3 -- the coarsest level (3^3 nodes under a 2^k box) gains nothing from more than max(8, 2 N^2) sweeps (same cycle counts), and each costs ~1.2 us of a one-workgroup launch
   p->mac_rel_eps = 1.0e-10; p->hg_rel_eps = -1.0; p->abort_on_max_iter = 1;
 }
 
@@ -409,9 +413,13 @@ vdn_multifab *mf_temp(const vdn_layout *la, int lev, int nc, int ng, int face_di
   mf->base = (double *)arena_alloc(mf->bytes);
   for (auto &f : mf->fabs) f.p = (double *)((char *)mf->base + (uintptr_t)f.p);
   if (fill) mf_setval(mf, val, 0, nc, true);
+  g_temp_mfs.push_back(mf);
   return mf;
 }
-void mf_temp_free(vdn_multifab *mf) { delete mf; }
+void mf_temp_free(vdn_multifab *mf) {
+  for (size_t i = g_temp_mfs.size(); i-- > 0;) if (g_temp_mfs[i] == mf) { g_temp_mfs.erase(g_temp_mfs.begin() + (long)i); break; }      // (freed in reverse order of creation: found at the end)
+  delete mf;
+}
 
 
 // device scratch for the descriptor arrays of one-off batched launches: a ring; reuse is safe because uploads and launches are
