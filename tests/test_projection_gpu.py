@@ -205,8 +205,8 @@ def test_hgproject(gpu, oracle, bcname, proj_type):
 def test_multigrid_launch_variants_agree_bit_for_bit(gpu):
     """the launch-saving forms of the V-cycles change no value: a 128^3 step (the finest MAC level takes the paired density pass only from
     128 cells up) with (a) the defaults -- prolongation added inside the first post-smoothing sweep (kk_cc_gsrb_rho_pair_t), restriction inside the
-    residual pass (kk_cc_residual_rho_pair_rst), the 16^3 .. 64^3 levels as one LDS-tiled launch down and one up (kk_cc_lds_down / kk_cc_lds_up,
-    kk_nd_lds_down / kk_nd_lds_up), the levels of
+    residual pass (kk_cc_residual_rho_pair_rst), the 16^3 .. 64^3 levels of the cell-centred solver as one LDS-tiled launch down and one up (kk_cc_lds_down /
+    kk_cc_lds_up), the levels of
     at most 9^3 nodes / 8^3 cells in one single-workgroup launch (kk_*_tailcycle), V-cycles replayed as hipGraphs -- against (b) the
     plain sequence of launches; and a viscous 64^3 run the same way (the alpha form of the cell-centred kernels: three visc_solves per step).
     The switches are read once per process, hence the child processes."""

@@ -624,152 +624,10 @@ __global__ void __launch_bounds__(1024) kk_nd_tailcycle(NdTailArgs T) {
     if (l < T.nlev - 1) { wg_nd_up(T.L[l], ph[l], T.L[l + 1], ph[l + 1]); wg_nd_jacobi(T.L[l], ph[l], tm[l], T.nu2, T.omega); }
 }
 
-// ---- levels of 17^3 .. 65^3 nodes: one launch down, one launch up (round 3; the scheme of kk_cc_lds_down / kk_cc_lds_up in mg_cc.hip) -----------
-// A visit of such a level is six dependent launches of 5-10 us (Jacobi, Jacobi, residual, restriction; prolongation, Jacobi) for a few
-// microseconds of work.  Here each half is ONE launch, tiled through LDS, with the halo of a tile recomputed instead of exchanged:
-//   kk_nd_lds_down  tile of 10^3 nodes inside a region of 16^3 (the tile grown by 3): phi = 0 on entry (the error equation), Jacobi sweep 1 on
-//                   the whole region, sweep 2 on the tile grown by 2, the residual on the tile grown by 1, full weighting onto the 5^3 coarse
-//                   nodes of the tile.  The smoothed phi of the tile goes to L.tmp, the coarse right-hand side and a zero coarse phi to C.
-//   kk_nd_lds_up    tile of 14^3 nodes grown by 1: L.tmp + the trilinear correction (nd_interp8), one Jacobi sweep on the tile, result to L.phi.
-// 512 threads, a thread owns a column of 8 nodes; the sigma of the 36 cells around the column and the 8 right-hand sides stay in registers, the
-// three phi planes of a node's stencil slide along the column.  Every node value is formed by nd_stencil from the same operands as in the
-// separate launches (recomputed halo nodes included), hence the same bits (test_multigrid_launch_variants_agree_bit_for_bit).
-// One box, no periodic direction (ghost nodes are zero), nu1 = 2, nu2 = 1; the host's phi / tmp pointers are left as they are (no swaps).
-constexpr int NLR = 16;                       // region width (nodes) of both kernels
-template <int SX> DEVI void ndl_plane(const double *s, int at, double pl[3][3]) {          // the 3 x 3 nodes around `at` in one LDS plane
-  #pragma unroll
-  for (int b = 0; b < 3; b++)
-    #pragma unroll
-    for (int a = 0; a < 3; a++) pl[b][a] = s[at + (a - 1) + (b - 1) * SX];
-}
-// one sweep over the thread's column: MODE 0 Jacobi (src -> dst), MODE 1 residual (src -> dst), MODE 2 Jacobi with the result written to the
-// level array `gout` instead of LDS.  lo .. hi: the region coordinates (all three directions) the sweep covers.  S: sigma of the region's cells
-// (cell cx = node x - 1 + cx of the region, NLR + 1 per direction), read four values per node as the stencil slides along the column
-constexpr int NLC = NLR + 1;
-template <int MODE, int SX> DEVI void ndl_sweep(const NLev &L, const NdW &W, const double *src, double *dst, double *gout, const double *S, const double (&rhs)[8],
-                                                const bool (&valid)[8], const bool (&dir)[8], int at0, int x, int y, int z0, int lo, int hi, double omega, long g0) {
-  constexpr int SP = SX * SX;
-  const bool xy = x >= lo && x < hi && y >= lo && y < hi;
-  double p[3][3][3], sg[2][2][2];
-  ndl_plane<SX>(src, at0 - SP, p[0]); ndl_plane<SX>(src, at0, p[1]);
-  const int sc0 = x + NLC * (y + NLC * z0);
-  #pragma unroll
-  for (int bb = 0; bb < 2; bb++)
-    #pragma unroll
-    for (int aa = 0; aa < 2; aa++) sg[0][bb][aa] = S[sc0 + aa + bb * NLC];
-  #pragma unroll
-  for (int m = 0; m < 8; m++) {
-    ndl_plane<SX>(src, at0 + (m + 1) * SP, p[2]);
-    #pragma unroll
-    for (int bb = 0; bb < 2; bb++)
-      #pragma unroll
-      for (int aa = 0; aa < 2; aa++) sg[1][bb][aa] = S[sc0 + aa + bb * NLC + (m + 1) * NLC * NLC];
-    const int z = z0 + m;
-    if (xy && valid[m] && z >= lo && z < hi) {
-      double Kp, diag; nd_stencil(W, p, sg, Kp, diag);
-      const double p0 = p[1][1][1];
-      if (MODE == 1) dst[at0 + m * SP] = dir[m] ? 0.0 : rhs[m] - Kp;
-      else {
-        double v = p0;
-        if (!dir[m] && diag != 0.0) v = p0 + omega * ((rhs[m] - Kp) / diag);
-        if (MODE == 0) dst[at0 + m * SP] = v; else gout[g0 + (long)m * L.PX * L.PY] = v;
-      }
-    }
-    #pragma unroll
-    for (int bb = 0; bb < 3; bb++)
-      #pragma unroll
-      for (int aa = 0; aa < 3; aa++) { p[0][bb][aa] = p[1][bb][aa]; p[1][bb][aa] = p[2][bb][aa]; }
-    #pragma unroll
-    for (int bb = 0; bb < 2; bb++)
-      #pragma unroll
-      for (int aa = 0; aa < 2; aa++) sg[0][bb][aa] = sg[1][bb][aa];
-  }
-}
-// sigma of the region's cells into LDS (zero outside the level's array: cells beyond the ghost layer), rhs / validity / Dirichlet flag of the column
-DEVI void ndl_setup(const NLev &L, int i0, int j0, int k0r, double *S, int nthreads, int i, int j, int k0, double (&rhs)[8], bool (&valid)[8], bool (&dir)[8]) {
-  for (int a = threadIdx.x; a < NLC * NLC * NLC; a += nthreads) {
-    const int ci = i0 - 1 + a % NLC, cj = j0 - 1 + (a / NLC) % NLC, ck = k0r - 1 + a / (NLC * NLC);
-    const bool in = ci >= -1 && ci <= L.n[0] && cj >= -1 && cj <= L.n[1] && ck >= -1 && ck <= L.n[2];
-    S[a] = in ? L.sig[nidx(L, ci, cj, ck)] : 0.0;
-  }
-  const bool ij = i >= 0 && i <= L.n[0] && j >= 0 && j <= L.n[1];
-  #pragma unroll
-  for (int m = 0; m < 8; m++) {
-    valid[m] = ij && k0 + m >= 0 && k0 + m <= L.n[2];
-    rhs[m] = valid[m] ? L.b[nidx(L, i, j, k0 + m)] : 0.0;
-    dir[m] = valid[m] && nd_is_dir(L, i, j, k0 + m);
-  }
-}
-__global__ void __launch_bounds__(512) kk_nd_lds_down(NLev L, NLev C, double omega) {
-  constexpr int T = 10, H = 3, SX = NLR + 2, SP = SX * SX;
-  __shared__ double A[SX * SX * SX], B[SX * SX * SX], S[NLC * NLC * NLC];
-  const int t = threadIdx.x, x = t & 15, y = (t >> 4) & 15, z0 = 8 * (t >> 8);
-  const int i0 = (int)blockIdx.x * T - H, j0 = (int)blockIdx.y * T - H, k0r = (int)blockIdx.z * T - H;
-  const int i = i0 + x, j = j0 + y, k0 = k0r + z0;
-  for (int a = t; a < SX * SX * SX; a += 512) { A[a] = 0.0; B[a] = 0.0; }        // phi = 0 on entry; nodes outside the level stay zero in both
-  double rhs[8]; bool valid[8], dir[8];
-  ndl_setup(L, i0, j0, k0r, S, 512, i, j, k0, rhs, valid, dir);
-  const NdW W = nd_weights(L.f);
-  const int at0 = (x + 1) + SX * (y + 1) + SP * (z0 + 1);
-  __syncthreads();
-  ndl_sweep<0, SX>(L, W, A, B, nullptr, S, rhs, valid, dir, at0, x, y, z0, 0, NLR, omega, 0);
-  __syncthreads();
-  ndl_sweep<0, SX>(L, W, B, A, nullptr, S, rhs, valid, dir, at0, x, y, z0, 1, NLR - 1, omega, 0);
-  __syncthreads();
-  ndl_sweep<1, SX>(L, W, A, B, nullptr, S, rhs, valid, dir, at0, x, y, z0, 2, NLR - 2, omega, 0);
-  if (x >= H && x < H + T && y >= H && y < H + T) {                                 // the smoothed phi of the tile's nodes
-    #pragma unroll
-    for (int m = 0; m < 8; m++) if (valid[m] && z0 + m >= H && z0 + m < H + T) L.tmp[nidx(L, i, j, k0 + m)] = A[at0 + m * SP];
-  }
-  __syncthreads();
-  if (t < (T / 2) * (T / 2) * (T / 2)) {                                             // kk_nd_restrict on the coarse nodes of the tile
-    const int ci = t % 5, cj = (t / 5) % 5, ck = t / 25;
-    const int I = (int)blockIdx.x * (T / 2) + ci, J = (int)blockIdx.y * (T / 2) + cj, K = (int)blockIdx.z * (T / 2) + ck;
-    if (I <= C.n[0] && J <= C.n[1] && K <= C.n[2]) {
-      double sum = 0.0;
-      if (!nd_is_dir(C, I, J, K)) {
-        const int f0 = (H + 2 * ci + 1) + SX * (H + 2 * cj + 1) + SP * (H + 2 * ck + 1);
-        #pragma unroll
-        for (int c = -1; c <= 1; c++)
-          #pragma unroll
-          for (int b = -1; b <= 1; b++)
-            #pragma unroll
-            for (int a = -1; a <= 1; a++) {
-              const double wa = a ? 0.5 : 1.0, wb = b ? 0.5 : 1.0, wc = c ? 0.5 : 1.0;
-              sum = sum + (wa * wb * wc) * B[f0 + a + b * SX + c * SP];
-            }
-      }
-      const long cn = nidx(C, I, J, K);
-      C.b[cn] = sum * 0.125;
-      C.phi[cn] = 0.0;
-    }
-  }
-}
-__global__ void __launch_bounds__(512) kk_nd_lds_up(NLev L, NLev C, double omega) {
-  constexpr int T = 14, H = 1, SX = NLR + 2, SP = SX * SX;      // (the border layer is never read by a tile node; it keeps the plane loads of the column ends inside A)
-  __shared__ double A[SX * SX * SX], S[NLC * NLC * NLC];
-  const int t = threadIdx.x, x = t & 15, y = (t >> 4) & 15, z0 = 8 * (t >> 8);
-  const int i0 = (int)blockIdx.x * T - H, j0 = (int)blockIdx.y * T - H, k0r = (int)blockIdx.z * T - H;
-  const int i = i0 + x, j = j0 + y, k0 = k0r + z0;
-  for (int a = t; a < SX * SX * SX; a += 512) A[a] = 0.0;
-  double rhs[8]; bool valid[8], dir[8];
-  ndl_setup(L, i0, j0, k0r, S, 512, i, j, k0, rhs, valid, dir);
-  const NdW W = nd_weights(L.f);
-  const int at0 = (x + 1) + SX * (y + 1) + SP * (z0 + 1);
-  __syncthreads();
-  #pragma unroll
-  for (int m = 0; m < 8; m++) {
-    if (valid[m]) {
-      const int k = k0 + m;
-      double v = L.tmp[nidx(L, i, j, k)];
-      if (!dir[m]) v = v + nd_interp8(C, C.phi, i >> 1, j >> 1, k >> 1, i & 1, j & 1, k & 1);      // kk_nd_prolong
-      A[at0 + m * SP] = v;
-    }
-  }
-  __syncthreads();
-  ndl_sweep<2, SX>(L, W, A, nullptr, L.phi, S, rhs, valid, dir, at0, x, y, z0, H, H + T, omega, nidx(L, i, j, k0));
-}
-
+// (round 3, built, measured and removed: the 17^3 .. 65^3 levels as one LDS-tiled launch down -- two Jacobi sweeps on a 16^3 region around a
+// 10^3 tile, residual, full weighting -- and one up, the scheme of kk_cc_lds_down / kk_cc_lds_up in mg_cc.hip.  Bit-identical, and no faster:
+// 17-38 us down and 14-20 us up per level against six launches of 5-10 us; HG 15.75 ms either way.  The 27-point operator costs ~150 f64
+// instructions per node, a tile recomputes 2.9x its own nodes, and a 17^3 level keeps 8 of 256 CUs busy for three dependent sweeps.)
 // ---- load / store / divergence -------------------------------------------------------------------------
 __global__ void kk_nd_load_sigma(NLev L, FV coeffs, int lo0, int lo1, int lo2) {
   const int i = (int)(blockIdx.x * blockDim.x + threadIdx.x) - 1;
@@ -1222,33 +1080,12 @@ static bool nd_small_end(NDMG &M, int dl, int tl) {
   }
   return true;
 }
-// may level l >= 1 of a V-cycle run as kk_nd_lds_down / kk_nd_lds_up?  (VDN_MG_LDS=0: never; VDN_MG_LDS_MAX: largest extent in cells, default 64)
-static bool nd_lds_level(const NDMG &M, int l) {
-  static const bool on = !(getenv("VDN_MG_LDS") && atoi(getenv("VDN_MG_LDS")) == 0);
-  static const int nmax_ = getenv("VDN_MG_LDS_MAX") ? atoi(getenv("VDN_MG_LDS_MAX")) : 64;
-  const vdn_params &P = ctx().prm;
-  if (!on || l < 1 || l + 1 >= (int)M.dlev.size() || P.hg_nu1 != 2 || P.hg_nu2 != 1 || M.per[0] || M.per[1] || M.per[2]) return false;
-  const NDLev &D = M.dlev[l], &DC = M.dlev[l + 1];
-  if (!(D.single_box && D.boxes.size() == 1 && !D.halo_A && DC.single_box && DC.boxes.size() == 1)) return false;
-  const NLev &L = D.boxes[0].L;
-  for (int d = 0; d < 3; d++) if (L.n[d] < 16 || L.n[d] > nmax_ || (L.n[d] & 1) || DC.boxes[0].L.n[d] * 2 != L.n[d] || D.boxes[0].lo[d] != 0) return false;
-  return true;
-}
 static void nd_vcycle_d(NDMG &M, int l) {
   const vdn_params &P = ctx().prm;
   NDLev &DL = M.dlev[l];                               // phi = 0 on entry: written by kk_nd_restrict
   if (nd_small_end(M, l, 0)) return;
   const bool last = (l == (int)M.dlev.size() - 1);
   if (last && M.tail.empty()) { nd_jacobi_d(DL, nd_bottom_sweeps_global(DL)); return; }
-  if (!last && nd_lds_level(M, l)) {
-    const NLev &L = DL.boxes[0].L, &C = M.dlev[l + 1].boxes[0].L;
-    const dim3 gd((unsigned)((L.n[0] + 10) / 10), (unsigned)((L.n[1] + 10) / 10), (unsigned)((L.n[2] + 10) / 10));
-    const dim3 gu((unsigned)((L.n[0] + 14) / 14), (unsigned)((L.n[1] + 14) / 14), (unsigned)((L.n[2] + 14) / 14));
-    hipLaunchKernelGGL(kk_nd_lds_down, gd, dim3(512), 0, ctx().stream, L, C, P.hg_omega);
-    nd_vcycle_d(M, l + 1);
-    hipLaunchKernelGGL(kk_nd_lds_up, gu, dim3(512), 0, ctx().stream, M.dlev[l].boxes[0].L, M.dlev[l + 1].boxes[0].L, P.hg_omega);
-    return;
-  }
   nd_jacobi_d(DL, P.hg_nu1);
   nd_residual_d(M, DL, false);
   nd_restrict_down(M, l);
