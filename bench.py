@@ -43,6 +43,60 @@ HBM_PEAK_GBS = 8000.0   # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s
 REF_GODUNOV_MCELLS_PER_CORE = 0.72
 
 
+def godunov_calibration(vo, n=128):
+    """BASELINE.md 1b on the oracle: velpred (3 comps) + mkflux (scalars, velocity) + update (u + s) on ONE box of n^3, interior
+    (periodic) BCs, smooth velocity + the bubble density, dt = 0.4 dx, ONE thread -- the calls the survey timed in the reference's own
+    Fortran kernels (2.91 s at 128^3 on one core of the survey container).  Returns the seconds per call (second call of each: the first
+    one pays the page faults of the work arrays)."""
+    import ctypes as C
+    import numpy as np
+    from varden_amd.capi import default_params
+    try:
+        C.CDLL("libgomp.so.1").omp_set_num_threads(1)
+    except OSError:
+        pass
+    L = vo.lib()
+    prm = default_params()
+    phys = [[vo.PERIODIC, vo.PERIODIC]] * 3
+    bc, pm = vo.make_bc(phys, 3, 2), vo.ivec([1, 1, 1])
+    lo, hi = (0, 0, 0), (n - 1,) * 3
+    dx = vo.dvec([1.0 / n] * 3)
+    u, s = vo.Fab(lo, hi, 3, 3), vo.Fab(lo, hi, 3, 2)
+    x = (np.arange(-3, n + 3) + 0.5) / n
+    X, Y, Z = np.meshgrid(x, x, x, indexing="ij")
+    u.a[..., 0] = np.sin(2 * np.pi * X) * np.cos(2 * np.pi * Y)
+    u.a[..., 1] = -np.cos(2 * np.pi * X) * np.sin(2 * np.pi * Y) * np.cos(2 * np.pi * Z)
+    u.a[..., 2] = 0.3 * np.sin(2 * np.pi * Z)
+    r = np.sqrt((X - .5) ** 2 + (Y - .5) ** 2 + (Z - .5) ** 2)
+    s.a[..., 0] = 1 + 0.5 * 9 * (1 - np.tanh(30 * (r - 0.1)))
+    s.a[..., 1] = s.a[..., 0]
+
+    def faces(ng, nc, val=0.0):
+        return [vo.Fab(lo, hi, ng, nc, tuple(1 if t == d else 0 for t in range(3)), val) for d in range(3)]
+    fu, fs, mac_rhs = vo.Fab(lo, hi, 1, 3), vo.Fab(lo, hi, 1, 2), vo.Fab(lo, hi, 1, 1)
+    um, se, fl, ue, uf = faces(1, 1, 1e20), faces(0, 2), faces(0, 2), faces(0, 3), faces(0, 3)
+    un, sn = vo.Fab(lo, hi, 3, 3), vo.Fab(lo, hi, 3, 2)
+    dt = C.c_double(0.4 / n)
+    P = vo.fab_ptr_array
+    calls = {
+        "velpred": lambda: L.vo_velpred(u.ref, P(um), fu.ref, dx, dt, C.byref(bc), C.byref(prm)),
+        "mkflux_scalars": lambda: L.vo_mkflux(s.ref, P(se), P(fl), P(um), fs.ref, mac_rhs.ref, dx, dt, 0, vo.ivec([1, 0]), 3, C.byref(bc), C.byref(prm)),
+        "mkflux_velocity": lambda: L.vo_mkflux(u.ref, P(ue), P(uf), P(um), fu.ref, mac_rhs.ref, dx, dt, 1, vo.ivec([0, 0, 0]), 0, C.byref(bc), C.byref(prm)),
+        "update": lambda: (L.vo_update(s.ref, P(um), P(se), P(fl), fs.ref, sn.ref, dx, dt, 0, vo.ivec([1, 0])),
+                           L.vo_update(u.ref, P(um), P(ue), P(uf), fu.ref, un.ref, dx, dt, 1, vo.ivec([0, 0, 0]))),
+    }
+    out = {}
+    for name, f in calls.items():
+        f()
+        if name == "velpred":
+            for m in um:
+                L.vo_fill_boundary(m.ref, pm)
+        t0 = time.perf_counter()
+        f()
+        out[name] = round(time.perf_counter() - t0, 3)
+    return out
+
+
 def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -53,6 +107,7 @@ def parse_args():
     ap.add_argument("--box", dest="n", type=int, default=256, help="box width (256/512) or base-level width (amr2/amr3)")
     ap.add_argument("--cpu-box", dest="cpu_n", type=int, default=0, help="width of the CPU sample (0: 128, or 64 for amr)")
     ap.add_argument("--skip-cpu", dest="no_cpu", action="store_true")
+    ap.add_argument("--no-calib", dest="no_calib", action="store_true", help="skip the one-thread Godunov calibration of the cpu_baseline leg")
     ap.add_argument("--no-extra", dest="no_extra", action="store_true", help="skip the extra_workloads (512^3 in eight boxes, tagged two-level hierarchy) of the default N = 1 line")
     return ap.parse_args()
 
@@ -319,8 +374,19 @@ def main():
         tc = time.perf_counter()
         O.step()
         tcpu = time.perf_counter() - tc
+        phase_s = None
+        if not amr:                                        # the oracle's own split of that step (advance_timestep.f90:159-166)
+            phase_s = {k: round(float(O.phase[i]), 3) for i, k in enumerate(("scalar_advance", "velocity_advance", "mac_project", "hg_project"))}
+            phase_s["other (forces, velpred, ghost fills, estdt)"] = round(tcpu - sum(phase_s.values()), 3)
+        # calibration against the reference's own kernels: the four Godunov calls of a step on one thread, beside the
+        # 2.91 s the survey measured for the reference's Fortran on one core (that was the survey container's CPU, this is
+        # the bench host's: a cross-machine ratio -- DESIGN.md quotes the same-machine one)
+        cal = godunov_calibration(vo, 128) if not args.no_calib else None
         cpu = {"value": round(ccells / tcpu, 1), "unit": "cells*steps/s", "cores": nthreads, "kind": "port",
                "sample": "%s, 1 timed step (%.1f s) after the start-up sequence; gcc -O2 -fopenmp, OMP_NUM_THREADS=%d" % (sample, tcpu, nthreads),
+               "phase_s": phase_s,
+               "godunov_1thread_128_s": cal,
+               "calibration_vs_reference_godunov": (round(sum(cal.values()) / 2.91, 2) if cal else None),
                "reference_godunov_mcells_per_s_per_core": REF_GODUNOV_MCELLS_PER_CORE,
                "reference_note": "BASELINE.md 1b: the reference's own velpred+mkflux+update (flang -O2, 1 core, 128^3) = 0.72 Mcells/s/core for advection "
                                  "alone (no multigrid): x%d cores = %.2e cells*steps/s is an upper bound on the reference's advance_timestep on this host"

@@ -22,7 +22,16 @@
 #ifndef VO_H
 #define VO_H
 #include <stddef.h>
+#include <math.h>
 #include "../include/varden_amd.h"   /* vdn_params and the bc enums: the product's PUBLIC header */
+
+/* fmin / fmax as inline selects.  Without -ffinite-math-only gcc leaves them as calls into libm (16 call sites in the Godunov loops, none
+ * of them vectorisable).  These return exactly what glibc's do on this image, signed zeros and NaNs included (probed: for two zeros and for
+ * a NaN first operand the SECOND operand comes back; a NaN second operand gives the first), so no value changes anywhere. */
+static inline double vo_fmin(double x, double y) { return (x < y || y != y) ? x : y; }
+static inline double vo_fmax(double x, double y) { return (x > y || y != y) ? x : y; }
+#define fmin(x, y) vo_fmin((x), (y))
+#define fmax(x, y) vo_fmax((x), (y))
 
 #ifdef __cplusplus
 extern "C" {

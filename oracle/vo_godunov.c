@@ -263,18 +263,38 @@ void vo_mkflux(const vo_fab *s, vo_fab *sedge[3], vo_fab *flux[3], vo_fab *umac[
   }
   double eps = (umax == 0.0) ? 1.0e-8 : 1.0e-8 * umax;
 
+  /* The stages run tile by tile over (j, k) -- full rows in i -- so that the fifteen work arrays of a tile stay in cache between stage B
+   * (which fills them on the tile grown by 2), stage C (tile grown by 1) and stage D (the faces the tile owns): the full-box form streams
+   * 15 x 18 MB per stage from memory at 128^3 and is bound by that.  Halo entries are recomputed by the neighbouring tiles from the same
+   * operands with the same expressions, so nothing changes in the results (checked bit for bit against the full-box form). */
+  const int TJ = 32, TK = 8;
   wk SL[3], SR[3], SI[3], SC[3][3];
-  for (int d = 0; d < 3; d++) { wk_alloc(&SL[d], lo, hi); wk_alloc(&SR[d], lo, hi); wk_alloc(&SI[d], lo, hi);
-    for (int t = 0; t < 3; t++) if (t != d) wk_alloc(&SC[d][t], lo, hi); }
+  {
+    int wlo[3] = { lo[0], lo[1], lo[2] }, whi[3] = { hi[0], lo[1] + TJ - 1 + 5, lo[2] + TK - 1 + 5 };      /* [lo-1, hi+2] of this = one tile's window, 3 cells either side */
+    wlo[1] -= 2; wlo[2] -= 2;
+    for (int d = 0; d < 3; d++) { wk_alloc(&SL[d], wlo, whi); wk_alloc(&SR[d], wlo, whi); wk_alloc(&SI[d], wlo, whi);
+      for (int t = 0; t < 3; t++) if (t != d) wk_alloc(&SC[d][t], wlo, whi); }
+  }
 
   for (int comp = 0; comp < ncomp; comp++) {
     const int cons = is_cons[comp];
+  for (int tk0 = lo[2]; tk0 <= hi[2]; tk0 += TK) for (int tj0 = lo[1]; tj0 <= hi[1]; tj0 += TJ) {
+    const int tlo[3] = { lo[0], tj0, tk0 };
+    const int thi[3] = { hi[0], tj0 + TJ - 1 < hi[1] ? tj0 + TJ - 1 : hi[1], tk0 + TK - 1 < hi[2] ? tk0 + TK - 1 : hi[2] };
+    for (int d = 0; d < 3; d++) {             /* the work arrays cover [tlo - 3, thi + 4] in j and k */
+      wk *all[5] = { &SL[d], &SR[d], &SI[d], NULL, NULL }; int na = 3;
+      for (int t = 0; t < 3; t++) if (t != d) all[na++] = &SC[d][t];
+      for (int q = 0; q < na; q++) { all[q]->lo[1] = tlo[1] - 3; all[q]->lo[2] = tlo[2] - 3; }
+    }
+    /* clip a stage's range to the tile grown by g (lower side) / g + 1 (upper side: faces and upper neighbours) in j and k */
+    #define CLIP(g) for (int t_ = 1; t_ < 3; t_++) { if (rlo[t_] < tlo[t_] - (g)) rlo[t_] = tlo[t_] - (g); if (rhi[t_] > thi[t_] + (g) + 1) rhi[t_] = thi[t_] + (g) + 1; }
 
     /* stage B: s_L^d, s_R^d (after bc) and simh_d (mkflux.f90:1440-1524 x, 1527-1611 y, 1779-1865 z) */
     for (int d = 0; d < 3; d++) {
       int rlo[3], rhi[3];
       for (int t = 0; t < 3; t++) { rlo[t] = lo[t] - 1; rhi[t] = hi[t] + 1; }
       rlo[d] = lo[d]; rhi[d] = hi[d] + 1;
+      CLIP(2)
       #pragma omp parallel for collapse(2)
       for (int k = rlo[2]; k <= rhi[2]; k++) for (int j = rlo[1]; j <= rhi[1]; j++) for (int i = rlo[0]; i <= rhi[0]; i++) {
         int f[3] = { i, j, k }, cl[3] = { i, j, k };
@@ -304,6 +324,7 @@ void vo_mkflux(const vo_fab *s, vo_fab *sedge[3], vo_fab *flux[3], vo_fab *umac[
       rlo[d] = lo[d]; rhi[d] = hi[d] + 1;
       rlo[t] = lo[t]; rhi[t] = hi[t];
       rlo[o] = lo[o] - 1; rhi[o] = hi[o] + 1;
+      CLIP(1)
       #pragma omp parallel for collapse(2)
       for (int k = rlo[2]; k <= rhi[2]; k++) for (int j = rlo[1]; j <= rhi[1]; j++) for (int i = rlo[0]; i <= rhi[0]; i++) {
         int f[3] = { i, j, k }, cl[3] = { i, j, k }, clp[3], fp[3] = { i, j, k };
@@ -333,6 +354,11 @@ void vo_mkflux(const vo_fab *s, vo_fab *sedge[3], vo_fab *flux[3], vo_fab *umac[
       int rlo[3], rhi[3];
       for (int t = 0; t < 3; t++) { rlo[t] = lo[t]; rhi[t] = hi[t]; }
       rhi[d] = hi[d] + 1;
+      for (int t = 1; t < 3; t++) {           /* the faces / cells this tile owns: its own cells, the upper face of the box with the last tile */
+        if (rlo[t] < tlo[t]) rlo[t] = tlo[t];
+        const int top = (t == d && thi[t] == hi[t]) ? thi[t] + 1 : thi[t];
+        if (rhi[t] > top) rhi[t] = top;
+      }
       #pragma omp parallel for collapse(2)
       for (int k = rlo[2]; k <= rhi[2]; k++) for (int j = rlo[1]; j <= rhi[1]; j++) for (int i = rlo[0]; i <= rhi[0]; i++) {
         int f[3] = { i, j, k }, cl[3] = { i, j, k };
@@ -380,6 +406,8 @@ void vo_mkflux(const vo_fab *s, vo_fab *sedge[3], vo_fab *flux[3], vo_fab *umac[
         if (cons) VF(flux[d], i, j, k, comp) = e * um;    /* mkflux.f90:1969, 2405, 2508 */
       }
     }
+    #undef CLIP
+  }
   }
 
   for (int d = 0; d < 3; d++) {
