@@ -1,0 +1,8 @@
+#!/bin/bash
+# round 3, GPU call 6: hgproject fast path: full suite, A/B bench
+set -o pipefail
+cd "$GRAFT_REPO_ROOT" || exit 1
+export TMPDIR=/tmp
+O=gpurun_out/r3c6; mkdir -p $O
+timeout -k 10 900 python -m pytest tests -m gpu -x -q > $O/pytest.log 2>&1; echo "pytest rc=$?" >> $O/pytest.log; tail -n 5 $O/pytest.log
+for v in "VDN_HG_FAST=0 VDN_ND_LEAN=0" "VDN_HG_FAST=0" "VDN_HG_FAST=1"; do echo "== $v"; env $v timeout -k 10 300 python bench.py --steps 5 --warmup 2 --skip-cpu --no-extra 2>&1 | tail -n 1 | cut -c1-640; done > $O/bench_ab.log 2>&1; cat $O/bench_ab.log

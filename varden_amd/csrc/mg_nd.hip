@@ -676,6 +676,44 @@ __global__ void kk_nd_store(NLev L, FV phi, int lo0, int lo1, int lo2) {
   fv_at(phi, lo0 + i, lo1 + j, lo2 + k) = L.phi[nidx(L, i, j, k)];
 }
 
+// hgproject's fast path (one level): sigma = 1 / rhohalf written straight into the level on the cells of the box, zero on its ghost cells
+// (hg_multigrid.f90:73-79); the ghost cells that have a neighbour or a periodic image then come from the level's sigma halo, exactly as
+// multifab_fill_boundary(coeffs) filled them -- instead of coeffs = 1 / rhohalf, its ghost fill and a copy
+__global__ void kk_nd_load_sigma_rho(NLev L, FV rhohalf, int lo0, int lo1, int lo2) {
+  const int i = (int)(blockIdx.x * blockDim.x + threadIdx.x) - 1;
+  const int j = (int)(blockIdx.y * blockDim.y + threadIdx.y) - 1;
+  const int k = (int)blockIdx.z - 1;
+  if (i > L.n[0] || j > L.n[1] || k > L.n[2]) return;
+  const bool in = i >= 0 && i < L.n[0] && j >= 0 && j < L.n[1] && k >= 0 && k < L.n[2];
+  L.sig[nidx(L, i, j, k)] = in ? 1.0 / fv_get(rhohalf, lo0 + i, lo1 + j, lo2 + k, 0) : 0.0;     // coeffs_K's expression
+}
+// b = -(0 + D u), phi = 0, max |rhs|: nd_divu_node on a zero rh followed by kk_nd_load on a zero phi, without the two multifabs in between
+__global__ void kk_nd_load_divu(NLev L, FV u, double fx, double fy, double fz, int lo0, int lo1, int lo2, double *nrm) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  const int j = blockIdx.y * blockDim.y + threadIdx.y;
+  double rmax = 0.0;
+  if (i <= L.n[0] && j <= L.n[1])
+    for (int k = blockIdx.z; k <= L.n[2]; k += gridDim.z) {
+      const int gi = lo0 + i, gj = lo1 + j, gk = lo2 + k;
+      #define U(a, b, c, m) fv_get(u, gi + (a), gj + (b), gk + (c), m)
+      const double dux = (((U(0, 0, 0, 0) + U(0, -1, 0, 0)) + U(0, 0, -1, 0)) + U(0, -1, -1, 0))
+                       - (((U(-1, 0, 0, 0) + U(-1, -1, 0, 0)) + U(-1, 0, -1, 0)) + U(-1, -1, -1, 0));
+      const double duy = (((U(0, 0, 0, 1) + U(-1, 0, 0, 1)) + U(0, 0, -1, 1)) + U(-1, 0, -1, 1))
+                       - (((U(0, -1, 0, 1) + U(-1, -1, 0, 1)) + U(0, -1, -1, 1)) + U(-1, -1, -1, 1));
+      const double duz = (((U(0, 0, 0, 2) + U(-1, 0, 0, 2)) + U(0, -1, 0, 2)) + U(-1, -1, 0, 2))
+                       - (((U(0, 0, -1, 2) + U(-1, 0, -1, 2)) + U(0, -1, -1, 2)) + U(-1, -1, -1, 2));
+      #undef U
+      const double rhv = 0.0 + (dux * fx + duy * fy + duz * fz);               // rh (zero) + D u
+      const bool dir = nd_is_dir(L, i, j, k);
+      const double r = dir ? 0.0 : rhv;
+      const long c = nidx(L, i, j, k);
+      L.b[c] = -r;
+      L.phi[c] = 0.0;
+      rmax = nmax(rmax, fabs(r));
+    }
+  block_atomic_max(nrm, rmax);
+}
+
 // ---- gather of the first agglomerated level (see mg_cc.hip: same scheme, nodes instead of cells) --------------------
 struct NGBox { int c0[3]; int n[3]; long off; };     // n = coarse CELLS of the box; nodes are n+1
 
@@ -786,13 +824,32 @@ void nd_halo_cache_purge(unsigned long uid) {
   for (auto it = g_nd_halo_cache.begin(); it != g_nd_halo_cache.end();) { if (it->first.uid == uid) it = g_nd_halo_cache.erase(it); else ++it; }
 }
 
+// ghost nodes (index -1 or n+1 in some direction) of up to three node arrays := 0
+__global__ void kk_nd_zero_shell(NLev L, double *a0, double *a1, double *a2) {
+  const int u = (int)(blockIdx.x * blockDim.x + threadIdx.x) - 1, v = (int)(blockIdx.y * blockDim.y + threadIdx.y) - 1;
+  const int face = blockIdx.z, d = face >> 1, side = face & 1;
+  const int da = d == 0 ? 1 : 0, db = d == 2 ? 1 : 2;
+  if (u > L.n[da] + 1 || v > L.n[db] + 1) return;
+  int q[3]; q[d] = side ? L.n[d] + 1 : -1; q[da] = u; q[db] = v;
+  const long c = nidx(L, q[0], q[1], q[2]);
+  a0[c] = 0.0; if (a1) a1[c] = 0.0; if (a2) a2[c] = 0.0;
+}
 static NLev nd_alloc_lev(const int n[3], const double h[3]) {
   NLev L;
   for (int d = 0; d < 3; d++) { L.n[d] = n[d]; L.f[d] = 1.0 / (36.0 * (h[d] * h[d])); L.dirlo[d] = L.dirhi[d] = L.per[d] = 0; }
   L.PX = ((n[0] + 18 + 15) / 16) * 16; L.PY = n[1] + 3; L.sz = (long)L.PX * L.PY * (n[2] + 3);
   double *base = (double *)arena_alloc(sizeof(double) * L.sz * 5);
-  HIPCHK(hipMemsetAsync(base, 0, sizeof(double) * L.sz * 5, ctx().stream));
   L.phi = base; L.tmp = base + L.sz; L.b = base + 2 * L.sz; L.res = base + 3 * L.sz; L.sig = base + 4 * L.sz;
+  // What must be zero is the ghost layer of phi, tmp and res (nodes outside a physical face; the exchange overwrites the others): every node
+  // 0..n of those arrays is written before it is read (phi by the load, tmp by the first sweep, res by the residual), b is read on nodes
+  // 0..n only and sigma is written on every cell -1..n by its load.  On a big level that is a 6-face kernel instead of a fill of five arrays
+  // (780 MB at 257^3, 0.16 ms per solve); the small levels keep the plain fill (their coarse sigma relies on it beyond the domain).
+  // Row padding beyond the ghost nodes only ever reaches lanes whose results are discarded.
+  static const bool lean_on = !(getenv("VDN_ND_LEAN") && atoi(getenv("VDN_ND_LEAN")) == 0);
+  if (lean_on && (long)(n[0] + 1) * (n[1] + 1) * (n[2] + 1) >= (1L << 21)) {
+    const int m = std::max(n[0], std::max(n[1], n[2])) + 3;
+    hipLaunchKernelGGL(kk_nd_zero_shell, dim3((m + 63) / 64, (m + 3) / 4, 6), dim3(64, 4, 1), 0, ctx().stream, L, L.phi, L.tmp, L.res);
+  } else HIPCHK(hipMemsetAsync(base, 0, sizeof(double) * L.sz * 5, ctx().stream));
   return L;
 }
 static FV nd_view(const NLev &L, double *p, const int lo[3], int extra /* 3 for nodes, 2 for cells */) {
@@ -1138,25 +1195,33 @@ static double nd_read(double *d) {
 struct NdKeep { bool built = false; NDMG M; };
 NdKeep *nd_keep_new() { return new NdKeep; }
 void nd_keep_free(NdKeep *k) { delete k; }
+// fast: hgproject's single-level call (NdFast in vdn_internal.h) -- rh and phi are known to be zero and are not touched (may be null), sigma comes
+// from fast->rhohalf (coeffs may be null), and instead of storing phi into a multifab the call returns views of the finest level's phi
+// (ghost nodes exchanged) in fast->phi_view; the level arrays then stay allocated: the CALLER releases the arena (mark taken before the call)
 int nd_solve(vdn_multifab *rh, vdn_multifab *phi, const vdn_multifab *coeffs, const vdn_multifab *u, const double *dx,
-             const int bc[3][2], double rel_eps, double abs_eps, int max_iter, int *cycles, double *res0, double *res, NdKeep *keep) {
+             const int bc[3][2], double rel_eps, double abs_eps, int max_iter, int *cycles, double *res0, double *res, NdKeep *keep, NdFast *fast) {
   Prof prof_("hg_multigrid");
   if (ctx().prm.dm == 2) return nd2_solve(rh, phi, coeffs, u, dx, bc, rel_eps, abs_eps, max_iter, cycles, res0, res);
   const vdn_params &P = ctx().prm;
-  REQUIRE(rh->ng >= 1 && phi->ng >= 1 && coeffs->ng >= 1, "nodal multigrid: rh, phi, coeffs need one ghost layer");
+  if (fast) { REQUIRE(fast->rhohalf && fast->rhohalf->ng >= 1 && u && !keep, "nodal multigrid: the fast path needs rhohalf (one ghost cell) and u"); coeffs = fast->rhohalf; }
+  else REQUIRE(rh->ng >= 1 && phi->ng >= 1 && coeffs->ng >= 1, "nodal multigrid: rh, phi, coeffs need one ghost layer");
   hipStream_t st = ctx().stream;
   size_t mark = arena_mark();
   NDMG M_local;
   NDMG &M = keep ? keep->M : M_local;
   const bool rebuild = !(keep && keep->built);
-  if (rebuild) nd_build(M, coeffs, dx, bc);
+  if (rebuild) nd_build(M, coeffs, dx, bc);          // (of `coeffs` only the layout, the level and the boxes are used)
   NDLev &D0 = M.dlev[0];
   if (rebuild) {
   // sigma: level 0 from the (ghost-filled) coeffs multifab; coarser distributed levels by averaging + halo exchange
   for (size_t b = 0; b < D0.boxes.size(); b++) {
     NLev &L0 = D0.boxes[b].L; const vdn_box &bx = coeffs->vbox[b];
+    if (fast) {
+      hipLaunchKernelGGL(kk_nd_load_sigma_rho, ng3(L0.n[0] + 2, L0.n[1] + 2, L0.n[2] + 2), NBLK, 0, st, L0, fast->rhohalf->fabs[b], bx.lo[0], bx.lo[1], bx.lo[2]);
+    } else
     hipLaunchKernelGGL(kk_nd_load_sigma, ng3(L0.n[0] + 2, L0.n[1] + 2, L0.n[2] + 2), NBLK, 0, st, L0, coeffs->fabs[b], bx.lo[0], bx.lo[1], bx.lo[2]);
   }
+  if (fast && D0.halo_sig) xplan_run(D0.halo_sig);          // neighbours' and periodic images of sigma (what fill_boundary(coeffs) did)
   for (size_t l = 1; l < M.dlev.size(); l++) {
     for (size_t b = 0; b < M.dlev[l].boxes.size(); b++) {
       NLev &C = M.dlev[l].boxes[b].L;
@@ -1182,7 +1247,7 @@ int nd_solve(vdn_multifab *rh, vdn_multifab *phi, const vdn_multifab *coeffs, co
   }
   }
   if (keep) keep->built = true;
-  if (u) {                                                  // add_divu = .true., hg_multigrid.f90:96
+  if (u && !fast) {                                         // add_divu = .true., hg_multigrid.f90:96
     REQUIRE(u->ng >= 1 && u->nc >= 3, "nodal multigrid: u needs a ghost cell");
     std::vector<std::pair<nd_divu_K, Range3>> v;
     for (size_t b = 0; b < D0.boxes.size(); b++) {
@@ -1195,6 +1260,11 @@ int nd_solve(vdn_multifab *rh, vdn_multifab *phi, const vdn_multifab *coeffs, co
   HIPCHK(hipMemsetAsync(M.d_nrm, 0, sizeof(double), st));
   for (size_t b = 0; b < D0.boxes.size(); b++) {
     NLev &L0 = D0.boxes[b].L; const vdn_box &bx = coeffs->vbox[b];
+    if (fast) {
+      REQUIRE(u->ng >= 1 && u->nc >= 3, "nodal multigrid: u needs a ghost cell");
+      hipLaunchKernelGGL(kk_nd_load_divu, ng3(L0.n[0] + 1, L0.n[1] + 1, std::min(L0.n[2] + 1, 16)), NBLK, 0, st, L0, u->fabs[b], 0.25 / dx[0], 0.25 / dx[1], 0.25 / dx[2],
+                         bx.lo[0], bx.lo[1], bx.lo[2], M.d_nrm);
+    } else
     hipLaunchKernelGGL(kk_nd_load, ng3(L0.n[0] + 1, L0.n[1] + 1, std::min(L0.n[2] + 1, 16)), NBLK, 0, st, L0, rh->fabs[b], phi->fabs[b], bx.lo[0], bx.lo[1], bx.lo[2], M.d_nrm);
   }
   comm_allreduce_max_dev(M.d_nrm, 1);
@@ -1252,12 +1322,14 @@ int nd_solve(vdn_multifab *rh, vdn_multifab *phi, const vdn_multifab *coeffs, co
   }
   NDLev &DF = M.dlev[0];                    // (a replayed cycle re-assigns M: take the reference afresh)
   nd_halo_phi(DF);
+  if (fast) fast->phi_view.clear();
   for (size_t b = 0; b < DF.boxes.size(); b++) {
     NLev &L0 = DF.boxes[b].L; const vdn_box &bx = coeffs->vbox[b];
+    if (fast) { fast->phi_view.push_back(nd_view(L0, L0.phi, bx.lo, 3)); continue; }
     hipLaunchKernelGGL(kk_nd_store, ng3(L0.n[0] + 3, L0.n[1] + 3, L0.n[2] + 3), NBLK, 0, st, L0, phi->fabs[b], bx.lo[0], bx.lo[1], bx.lo[2]);
   }
   if (cycles) *cycles = cyc; if (res0) *res0 = bnorm; if (res) *res = rn;
-  if (!keep) arena_release(mark);           // with `keep` the hierarchy stays in the caller's arena scope
+  if (!keep && !fast) arena_release(mark);  // with `keep` / `fast` the hierarchy stays in the caller's arena scope
   return conv ? 0 : 1;
 }
 
@@ -1329,6 +1401,7 @@ struct hg_update_K { FV unew; FV uold; FV gp; FV rhohalf; FV p; FV phi; HgUpdArg
 
 
 // per-level pieces of hgproject, shared by the single-level driver and the two-level one
+// coeffs == nullptr: the caller takes sigma straight from rhohalf (nd_solve's fast path)
 static void hg_level_pre(int proj_type, vdn_multifab *un, const vdn_multifab *uo, const vdn_multifab *rhh, vdn_multifab *gpp, vdn_multifab *coeffs,
                          double dt, const vdn_bc_tower *bct) {
   hipStream_t st = ctx().stream;
@@ -1341,14 +1414,15 @@ static void hg_level_pre(int proj_type, vdn_multifab *un, const vdn_multifab *uo
     A.ng = un->ng; A.dt = dt; A.dtinv = 1.0 / dt; A.proj_type = proj_type;
     vu.push_back({ create_uvec_K{ un->fabs[i], uo->fabs[i], rhh->fabs[i], gpp->fabs[i], A }, r });
     Range3 rv; for (int d = 0; d < 3; d++) { rv.lo[d] = bp.lo[d]; rv.hi[d] = bp.hi[d]; }
-    vc.push_back({ coeffs_K{ coeffs->fabs[i], rhh->fabs[i] }, rv });
+    if (coeffs) vc.push_back({ coeffs_K{ coeffs->fabs[i], rhh->fabs[i] }, rv });
   }
   launch_cells(vu, st); launch_cells(vc, st);
   mf_fill_boundary(un);                                               // hgproject.f90:232
-  mf_fill_boundary(coeffs);                                           // hg_multigrid.f90:79
+  if (coeffs) mf_fill_boundary(coeffs);                               // hg_multigrid.f90:79
 }
+// phi_view: phi of box i as a view of the solver's level array (the fast path) instead of phi->fabs[i]
 static void hg_level_post(int proj_type, vdn_multifab *un, const vdn_multifab *uo, const vdn_multifab *rhh, vdn_multifab *gpp, vdn_multifab *pp,
-                          vdn_multifab *gphi, const vdn_multifab *phi, const double *dx, double dt) {
+                          vdn_multifab *gphi, const vdn_multifab *phi, const double *dx, double dt, const std::vector<FV> *phi_view = nullptr) {
   hipStream_t st = ctx().stream;
   if (proj_type == VDN_INITIAL_PROJECTION || proj_type == VDN_DIVU_ITERS) { mf_setval(gpp, 0.0, 0, gpp->nc, true); mf_setval(pp, 0.0, 0, 1, true); }   // 673-676
   std::vector<std::pair<hg_update_K, Range3>> vh;
@@ -1357,7 +1431,7 @@ static void hg_level_post(int proj_type, vdn_multifab *un, const vdn_multifab *u
     for (int d = 0; d < 3; d++) { rv.lo[d] = rn.lo[d] = un->vbox[i].lo[d]; rv.hi[d] = un->vbox[i].hi[d]; rn.hi[d] = rv.hi[d] + 1; H.hi[d] = rv.hi[d]; }
     H.dt = dt; H.dtinv = 1.0 / dt; H.proj_type = proj_type;
     for (int d = 0; d < 3; d++) H.dxi[d] = 1.0 / dx[d];
-    vh.push_back({ hg_update_K{ un->fabs[i], uo->fabs[i], gpp->fabs[i], rhh->fabs[i], pp->fabs[i], phi->fabs[i], H }, rn });
+    vh.push_back({ hg_update_K{ un->fabs[i], uo->fabs[i], gpp->fabs[i], rhh->fabs[i], pp->fabs[i], phi_view ? (*phi_view)[i] : phi->fabs[i], H }, rn });
   }
   (void)gphi;
   launch_cells(vh, st);
@@ -1372,19 +1446,34 @@ void do_hgproject(int proj_type, vdn_layout *mla, vdn_multifab **unew, vdn_multi
   if (mla->nlev > 1) { do_ml_hgproject(proj_type, mla, unew, uold, rhohalf, p, gp, dx, dt, bct, press_comp0); return; }
   const int n = 0;
   size_t mark = arena_mark();
-  vdn_multifab *rh = mf_temp(mla, n, 1, 1, 3, true, 0.0);
-  vdn_multifab *phi = mf_temp(mla, n, 1, 1, 3, true, 0.0);
-  vdn_multifab *gphi = mf_temp(mla, n, 3, 0, -1, false, 0.0);
-  vdn_multifab *coeffs = mf_temp(mla, n, 1, 1, -1, true, 0.0);        // ghosts 0: hg_multigrid.f90:73
   vdn_multifab *un = unew[n], *uo = uold[n], *rhh = rhohalf[n], *gpp = gp[n], *pp = p[n];
   REQUIRE(pp->ng >= 1, "hgproject: ghost widths");
-  hg_level_pre(proj_type, un, uo, rhh, gpp, coeffs, dt, bct);
   double rel = ctx().prm.hg_rel_eps > 0.0 ? ctx().prm.hg_rel_eps : 1.e-12;   // hgproject.f90:113-119 (nlevs = 1)
   double abs_eps = -1.0;
   if (proj_type == VDN_INITIAL_PROJECTION && ctx().prm.prob_type == 4) abs_eps = 1.e-12;   // 125-127
   int ebc[3][2];
   for (int d = 0; d < 3; d++) for (int s = 0; s < 2; s++) ebc[d][s] = bct->ell_bc(n, 0, d, s, press_comp0);
   int cyc; double r0, rr;
+  // Round 3: rh, phi and coeffs (hgproject.f90:70-76, hg_multigrid.f90:68-80) exist only to carry zeros, D u and 1 / rhohalf into the solver
+  // and phi out of it: the solver takes sigma from rhohalf, forms b = -D u while it loads, and hg_update reads phi from the level array
+  // (0.5 ms of fills, copies and passes per 256^3 projection; VDN_HG_FAST=0: the multifabs as the reference has them -- same values)
+  static const bool fast_on = !(getenv("VDN_HG_FAST") && atoi(getenv("VDN_HG_FAST")) == 0);
+  if (fast_on) {
+    hg_level_pre(proj_type, un, uo, rhh, gpp, nullptr, dt, bct);
+    NdFast F; F.rhohalf = rhh;
+    int rc = nd_solve(nullptr, nullptr, nullptr, un, dx, ebc, rel, abs_eps, ctx().prm.hg_max_iter, &cyc, &r0, &rr, nullptr, &F);
+    ctx().solver_cycles[1] = cyc; ctx().solver_res0[1] = r0; ctx().solver_res[1] = rr;
+    solver_check(rc, "nodal multigrid", cyc, rr, r0);
+    hg_level_post(proj_type, un, uo, rhh, gpp, pp, nullptr, nullptr, dx, dt, &F.phi_view);
+    mf_fill_boundary(gpp); mf_fill_boundary(pp);                      // hgproject.f90:359-362
+    arena_release(mark);
+    return;
+  }
+  vdn_multifab *rh = mf_temp(mla, n, 1, 1, 3, true, 0.0);
+  vdn_multifab *phi = mf_temp(mla, n, 1, 1, 3, true, 0.0);
+  vdn_multifab *gphi = mf_temp(mla, n, 3, 0, -1, false, 0.0);
+  vdn_multifab *coeffs = mf_temp(mla, n, 1, 1, -1, true, 0.0);        // ghosts 0: hg_multigrid.f90:73
+  hg_level_pre(proj_type, un, uo, rhh, gpp, coeffs, dt, bct);
   int rc = nd_solve(rh, phi, coeffs, un, dx, ebc, rel, abs_eps, ctx().prm.hg_max_iter, &cyc, &r0, &rr);
   ctx().solver_cycles[1] = cyc; ctx().solver_res0[1] = r0; ctx().solver_res[1] = rr;
   solver_check(rc, "nodal multigrid", cyc, rr, r0);

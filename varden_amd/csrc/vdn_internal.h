@@ -230,8 +230,11 @@ void do_diff_scalar_solve(vdn_layout *mla, vdn_multifab *snew, const vdn_multifa
 // hgproject.hip / mg_nd.hip
 void do_hgproject(int proj_type, vdn_layout *mla, vdn_multifab **unew, vdn_multifab **uold, vdn_multifab **rhohalf,
                   vdn_multifab **p, vdn_multifab **gp, const double *dx, double dt, const vdn_bc_tower *bct, int press_comp0);
+// nd_solve's fast path for hgproject on one level (mg_nd.hip): sigma = 1 / rhohalf, rh = phi = 0 on entry, phi handed back as views
+struct NdFast { const vdn_multifab *rhohalf = nullptr; std::vector<FV> phi_view; };
 int  nd_solve(vdn_multifab *rh, vdn_multifab *phi, const vdn_multifab *coeffs, const vdn_multifab *u, const double *dx,
-              const int bc[3][2], double rel_eps, double abs_eps, int max_iter, int *cycles, double *res0, double *res, struct NdKeep *keep = nullptr);
+              const int bc[3][2], double rel_eps, double abs_eps, int max_iter, int *cycles, double *res0, double *res, struct NdKeep *keep = nullptr,
+              NdFast *fast = nullptr);
 
 // dim2.hip: the dm = 2 path (one level, one box)
 void k2_mkvelforce(vdn_multifab *vf, const vdn_multifab *ext, const vdn_multifab *s, const vdn_multifab *gp, const vdn_multifab *lapu, double visc_fac);
