@@ -903,6 +903,54 @@ __global__ void kk_cc_load(CLev L, FV rh, FV phi, FV alpha, FV bx, FV by, FV bz,
     L.b[2][c] = v;
   }
 }
+// ---- macproject's fast path on one level (round 3) --------------------------------------------------------------------------------------
+// The multifabs rh, phi and beta of macproject.f90:63-76 only carry -div(umac) + mac_rhs, zeros and 2 / (rho_i + rho_i-1) into the solver and
+// phi out of it.  With the finest level's coefficients recomputed from rho anyway, the level takes its right-hand side straight from the MAC
+// field (kk_cc_load_divumac: divumac_K's expression, the max norm of macproject.f90:77-89 on the way), the 128^3 level its coefficients from
+// rho (kk_cc_coarsen_b_rho: beta_of = the folded value kk_cc_load stores, kk_cc_coarsen_b's mean), and mkumac reads phi from the level array
+// and forms beta from rho (mkumac_rho_K).  1.04 -> 0.4 ms of fills, copies and passes per 256^3 projection; VDN_MAC_FAST=0 restores the multifabs.
+__global__ void kk_cc_load_divumac(CLev L, FV um, FV vm, FV wm, FV macrhs, double dxi0, double dxi1, double dxi2, int lo0, int lo1, int lo2,
+                                   int ebc00, int ebc01, int ebc10, int ebc11, int ebc20, int ebc21, double *nrm) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  const int j = blockIdx.y * blockDim.y + threadIdx.y;
+  double rmax = 0.0;
+  if (i < L.n[0] && j < L.n[1])
+    for (int k = blockIdx.z; k < L.n[2]; k += gridDim.z) {
+      const int gi = lo0 + i, gj = lo1 + j, gk = lo2 + k;
+      const double div = (fv_get(um, gi + 1, gj, gk) - fv_get(um, gi, gj, gk)) * dxi0
+                       + (fv_get(vm, gi, gj + 1, gk) - fv_get(vm, gi, gj, gk)) * dxi1
+                       + (fv_get(wm, gi, gj, gk + 1) - fv_get(wm, gi, gj, gk)) * dxi2;
+      double r = div * -1.0 + fv_get(macrhs, gi, gj, gk);
+      rmax = nmax(rmax, fabs(r));
+      // kk_cc_load_rh with the zero initial guess of macproject: the Dirichlet term is b * 0 * h^-2 = +0 (b is finite): only the sign of a zero can change
+      if (i == 0 && ebc00 == VDN_BC_DIR) r = r + 0.0;
+      if (i == L.n[0] - 1 && ebc01 == VDN_BC_DIR) r = r + 0.0;
+      if (j == 0 && ebc10 == VDN_BC_DIR) r = r + 0.0;
+      if (j == L.n[1] - 1 && ebc11 == VDN_BC_DIR) r = r + 0.0;
+      if (k == 0 && ebc20 == VDN_BC_DIR) r = r + 0.0;
+      if (k == L.n[2] - 1 && ebc21 == VDN_BC_DIR) r = r + 0.0;
+      L.rh[cidx(L, i, j, k)] = r;
+    }
+  block_atomic_max(nrm, rmax);
+}
+// coarse face coefficients from the fine level's DENSITY: the folded fine value (kk_cc_load) of face index I along d is beta_of(rho_I, rho_I-1)
+DEVI double cc_face_rho(const CLev &F, int d, int i, int j, int k) {
+  const long c = cidx(F, i, j, k);
+  const long st = d == 0 ? 1 : (d == 1 ? (long)F.PX : (long)F.PX * F.PY);
+  const int q = d == 0 ? i : (d == 1 ? j : k);
+  return beta_of(F.rho[c], F.rho[c - st], q == 0 || q == F.n[d], q == 0 ? F.fold[d][0] : F.fold[d][1]);
+}
+__global__ void kk_cc_coarsen_b_rho(CLev F, CLev C) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  const int j = blockIdx.y * blockDim.y + threadIdx.y;
+  const int k = blockIdx.z;
+  if (i > C.n[0] || j > C.n[1] || k > C.n[2]) return;
+  const long c = cidx(C, i, j, k);
+  const int I = 2 * i, J = 2 * j, K = 2 * k;
+  if (j < C.n[1] && k < C.n[2]) C.b[0][c] = (cc_face_rho(F, 0, I, J, K) + cc_face_rho(F, 0, I, J + 1, K) + cc_face_rho(F, 0, I, J, K + 1) + cc_face_rho(F, 0, I, J + 1, K + 1)) * 0.25;
+  if (i < C.n[0] && k < C.n[2]) C.b[1][c] = (cc_face_rho(F, 1, I, J, K) + cc_face_rho(F, 1, I + 1, J, K) + cc_face_rho(F, 1, I, J, K + 1) + cc_face_rho(F, 1, I + 1, J, K + 1)) * 0.25;
+  if (i < C.n[0] && j < C.n[1]) C.b[2][c] = (cc_face_rho(F, 2, I, J, K) + cc_face_rho(F, 2, I + 1, J, K) + cc_face_rho(F, 2, I, J + 1, K) + cc_face_rho(F, 2, I + 1, J + 1, K)) * 0.25;
+}
 // phi alone (a kept hierarchy takes a new right-hand side and initial guess: cc_reload)
 __global__ void kk_cc_load_phi(CLev L, FV phi, int lo0, int lo1, int lo2) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1542,6 +1590,54 @@ static void cc_setup(CCMG &M, vdn_multifab *rh, vdn_multifab *phi, const vdn_mul
     }
   }
 }
+// set-up of macproject's fast path: levels from the layout of rho, level 0 = rho + the right-hand side from the MAC field, level 1 from rho,
+// the rest as cc_setup; returns max |rh| (all ranks)
+static double cc_setup_fast(CCMG &M, CcFast *fast, const double *dx, const int bc[3][2]) {
+  const vdn_multifab *rho = fast->rho;
+  cc_build(M, rho, dx, bc, false);
+  REQUIRE(M.dlev.size() >= 2, "cc_setup_fast: needs a second distributed level");
+  const vdn_layout *la = rho->la; const int lev = rho->lev;
+  CDLev &D0 = M.dlev[0];
+  HIPCHK(hipMemsetAsync(M.d_nrm, 0, sizeof(double), ctx().stream));
+  for (size_t b = 0; b < D0.boxes.size(); b++) {
+    CLev &L0 = D0.boxes[b].L;
+    const vdn_box &bx = rho->vbox[b];
+    int e[3][2];
+    for (int d = 0; d < 3; d++) {
+      e[d][0] = (bx.lo[d] == la->pd[lev].lo[d]) ? bc[d][0] : VDN_BC_INT;
+      e[d][1] = (bx.hi[d] == la->pd[lev].hi[d]) ? bc[d][1] : VDN_BC_INT;
+    }
+    double *r = (double *)arena_alloc(sizeof(double) * L0.sz);
+    hipLaunchKernelGGL(kk_cc_load_rho, g3(L0.n[0] + 2, L0.n[1] + 2, L0.n[2] + 2, BLK), BLK, 0, ctx().stream, L0, r, rho->fabs[b], bx.lo[0], bx.lo[1], bx.lo[2]);
+    L0.rho = r;
+    for (int d = 0; d < 3; d++) { L0.fold[d][0] = e[d][0]; L0.fold[d][1] = e[d][1]; }
+    hipLaunchKernelGGL(kk_cc_load_divumac, g3(L0.n[0], L0.n[1], std::min(L0.n[2], 16), BLK), BLK, 0, ctx().stream, L0, fast->um[0]->fabs[b], fast->um[1]->fabs[b], fast->um[2]->fabs[b],
+                       fast->mac_rhs->fabs[b], 1.0 / dx[0], 1.0 / dx[1], 1.0 / dx[2], bx.lo[0], bx.lo[1], bx.lo[2], e[0][0], e[0][1], e[1][0], e[1][1], e[2][0], e[2][1], M.d_nrm);
+  }
+  comm_allreduce_max_dev(M.d_nrm, 1);
+  const double bnorm = read_scalar1(M.d_nrm);
+  for (size_t l = 1; l < M.dlev.size(); l++)
+    for (size_t b = 0; b < M.dlev[l].boxes.size(); b++) {
+      const CLev &C = M.dlev[l].boxes[b].L;
+      if (l == 1) hipLaunchKernelGGL(kk_cc_coarsen_b_rho, g3(C.n[0] + 1, C.n[1] + 1, C.n[2] + 1, BLK), BLK, 0, ctx().stream, M.dlev[0].boxes[b].L, C);
+      else hipLaunchKernelGGL(kk_cc_coarsen_b, g3(C.n[0] + 1, C.n[1] + 1, C.n[2] + 1, BLK), BLK, 0, ctx().stream, M.dlev[l - 1].boxes[b].L, C);
+    }
+  if (!M.tail.empty()) {
+    CDLev &DL = M.dlev.back();
+    for (size_t b = 0; b < DL.boxes.size(); b++) {
+      const CLev &F = DL.boxes[b].L;
+      const int nx = F.n[0] / 2, ny = F.n[1] / 2, nz = F.n[2] / 2;
+      hipLaunchKernelGGL(kk_cc_coarsen_b_pack, g3(nx + 1, ny + 1, nz + 1, BLK), BLK, 0, ctx().stream, F, M.sendbuf, M.loc_off_b[b], nx, ny, nz);
+    }
+    comm_allgather_dev(M.sendbuf, M.recvbuf, M.cnt_b);
+    hipLaunchKernelGGL(kk_cc_unpack_b, dim3(4, 1, (unsigned)M.gb_b.size()), dim3(256), 0, ctx().stream, M.tail[0], M.recvbuf, M.d_gb_b);
+    for (size_t l = 1; l < M.tail.size(); l++) {
+      const CLev &C = M.tail[l];
+      hipLaunchKernelGGL(kk_cc_coarsen_b, g3(C.n[0] + 1, C.n[1] + 1, C.n[2] + 1, BLK), BLK, 0, ctx().stream, M.tail[l - 1], C);
+    }
+  }
+  return bnorm;
+}
 // a kept hierarchy (coefficients on every level stay): the finest level takes a new right-hand side and initial guess
 static void cc_reload(CCMG &M, vdn_multifab *rh, vdn_multifab *phi, const int bc[3][2]) {
   const vdn_layout *la = rh->la; const int lev = rh->lev;
@@ -1576,17 +1672,23 @@ static void cc_store(CCMG &M, vdn_multifab *phi, const int bc[3][2]) {
   }
 }
 
+// fast: macproject's single-level call (CcFast in vdn_internal.h): rh, phi and beta are not used (may be null); phi comes back as views of the
+// finest level's array (ghost cells exchanged) and the level arrays stay allocated -- the CALLER releases the arena
 int cc_solve(vdn_multifab *rh, vdn_multifab *phi, vdn_multifab **beta, const double *dx, const int bc[3][2],
-             double rel_eps, double abs_eps, int max_iter, int *cycles, double *res0, double *res, const vdn_multifab *alpha, const vdn_multifab *rho, CcKeep *keep) {
+             double rel_eps, double abs_eps, int max_iter, int *cycles, double *res0, double *res, const vdn_multifab *alpha, const vdn_multifab *rho, CcKeep *keep,
+             CcFast *fast) {
   Prof prof_("mac_multigrid");
   if (ctx().prm.dm == 2) return cc2_solve(rh, phi, beta, dx, bc, rel_eps, abs_eps, max_iter, cycles, res0, res, alpha);
   const vdn_params &P = ctx().prm;
+  if (fast) REQUIRE(!keep && !alpha && max_iter >= 0 && fast->rho && fast->rho->ng >= 1, "cc_solve: bad use of the fast path");
   size_t mark = arena_mark();
   // keep: the hierarchy (arrays in the caller's arena scope, coefficients on every level) survives the call; the next call with the
   // same `keep` loads only its right-hand side and phi (the composite solves: one V-cycle per FAC iteration on the same coefficients)
   CCMG M_local;
   CCMG &M = keep ? keep->M : M_local;
-  if (keep && keep->built) cc_reload(M, rh, phi, bc);
+  double bnorm_fast = 0.0;
+  if (fast) bnorm_fast = cc_setup_fast(M, fast, dx, bc);
+  else if (keep && keep->built) cc_reload(M, rh, phi, bc);
   else cc_setup(M, rh, phi, alpha, beta, dx, bc, rho);
   if (keep) keep->built = true;
   CDLev &D0 = M.dlev[0];
@@ -1607,7 +1709,7 @@ int cc_solve(vdn_multifab *rh, vdn_multifab *phi, vdn_multifab **beta, const dou
     if (!keep) arena_release(mark);
     return 0;
   }
-  const double bnorm = mf_norm_inf(rh, 0, 1);
+  const double bnorm = fast ? bnorm_fast : mf_norm_inf(rh, 0, 1);
   int cyc = 0; bool conv = (bnorm == 0.0); double rn = 0.0;
   // pre-smoothing + residual, then per cycle: [coarse correction, post-smoothing, the next cycle's pre-smoothing, residual + norm] as ONE
   // replayed graph and one 8-byte read-back -- the same launch sequence as testing the residual the cycle computes after pre-smoothing
@@ -1627,9 +1729,14 @@ int cc_solve(vdn_multifab *rh, vdn_multifab *phi, vdn_multifab **beta, const dou
     cyc++;
     rn = read_scalar(M.d_nrm);
   }
-  cc_store(M, phi, bc);
+  if (fast) {
+    CDLev &DF = M.dlev[0];
+    cc_halo(M, DF);
+    fast->phi_view.clear();
+    for (size_t b = 0; b < DF.boxes.size(); b++) fast->phi_view.push_back(cc_phi_view(DF.boxes[b].L, fast->rho->vbox[b].lo));
+  } else cc_store(M, phi, bc);
   if (cycles) *cycles = cyc; if (res0) *res0 = bnorm; if (res) *res = rn;
-  if (!keep) arena_release(mark);
+  if (!keep && !fast) arena_release(mark);
   return conv ? 0 : 1;
 }
 
@@ -1717,6 +1824,55 @@ struct mkumac_K { FV um; FV vm; FV wm; FV phi; FV bx; FV by; FV bz; UmacArgs A;
   } };
 
 
+// mkumac on the level array: phi's ghost cell beyond a Dirichlet face is what kk_cc_store would have written (-phi of the cell inside), beyond a box
+// face with a neighbour or a periodic image the exchanged value; beta = mk_mac_coeffs_K's expression
+DEVI double phi_closed(const FV &phi, const UmacArgs &A, int i, int j, int k) {
+  if (i < A.lo[0]) { if (A.ebc[0][0] == VDN_BC_DIR) return -fv_get(phi, A.lo[0], j, k); }
+  else if (i > A.hi[0]) { if (A.ebc[0][1] == VDN_BC_DIR) return -fv_get(phi, A.hi[0], j, k); }
+  else if (j < A.lo[1]) { if (A.ebc[1][0] == VDN_BC_DIR) return -fv_get(phi, i, A.lo[1], k); }
+  else if (j > A.hi[1]) { if (A.ebc[1][1] == VDN_BC_DIR) return -fv_get(phi, i, A.hi[1], k); }
+  else if (k < A.lo[2]) { if (A.ebc[2][0] == VDN_BC_DIR) return -fv_get(phi, i, j, A.lo[2]); }
+  else if (k > A.hi[2]) { if (A.ebc[2][1] == VDN_BC_DIR) return -fv_get(phi, i, j, A.hi[2]); }
+  return fv_get(phi, i, j, k);
+}
+struct mkumac_rho_K { FV um; FV vm; FV wm; FV phi; FV rho; UmacArgs A;
+  __device__ void cell(int i, int j, int k) const {
+    const double p0 = phi_closed(phi, A, i, j, k);
+    const double r0 = fv_get(rho, i, j, k);
+    if (j <= A.hi[1] && k <= A.hi[2]) {
+      int side = (i == A.lo[0]) ? 0 : (i == A.hi[0] + 1 ? 1 : -1);
+      if (!(side >= 0 && A.ebc[0][side] == VDN_BC_NEU)) {
+        double g = (p0 - phi_closed(phi, A, i - 1, j, k)) / A.dx[0];
+        fv_at(um, i, j, k) = fv_get(um, i, j, k) - (2.0 / (r0 + fv_get(rho, i - 1, j, k))) * g;
+      }
+    }
+    if (i <= A.hi[0] && k <= A.hi[2]) {
+      int side = (j == A.lo[1]) ? 0 : (j == A.hi[1] + 1 ? 1 : -1);
+      if (!(side >= 0 && A.ebc[1][side] == VDN_BC_NEU)) {
+        double g = (p0 - phi_closed(phi, A, i, j - 1, k)) / A.dx[1];
+        fv_at(vm, i, j, k) = fv_get(vm, i, j, k) - (2.0 / (r0 + fv_get(rho, i, j - 1, k))) * g;
+      }
+    }
+    if (i <= A.hi[0] && j <= A.hi[1]) {
+      int side = (k == A.lo[2]) ? 0 : (k == A.hi[2] + 1 ? 1 : -1);
+      if (!(side >= 0 && A.ebc[2][side] == VDN_BC_NEU)) {
+        double g = (p0 - phi_closed(phi, A, i, j, k - 1)) / A.dx[2];
+        fv_at(wm, i, j, k) = fv_get(wm, i, j, k) - (2.0 / (r0 + fv_get(rho, i, j, k - 1))) * g;
+      }
+    }
+  } };
+static void mac_level_mkumac_rho(vdn_multifab **um, const std::vector<FV> &phi_view, const vdn_multifab *rho, const double *dx, const vdn_bc_tower *bct, int bc_comp0) {
+  const int n = rho->lev;
+  std::vector<std::pair<mkumac_rho_K, Range3>> v;
+  for (int i = 0; i < rho->nfabs(); i++) {
+    UmacArgs A; Range3 rf;
+    for (int d = 0; d < 3; d++) { A.lo[d] = rf.lo[d] = rho->vbox[i].lo[d]; A.hi[d] = rho->vbox[i].hi[d]; rf.hi[d] = A.hi[d] + 1; A.dx[d] = dx[d];
+      for (int s = 0; s < 2; s++) A.ebc[d][s] = bct->ell_bc(n, i + 1, d, s, bc_comp0); }
+    v.push_back({ mkumac_rho_K{ um[0]->fabs[i], um[1]->fabs[i], um[2]->fabs[i], phi_view[i], rho->fabs[i], A }, rf });
+  }
+  launch_cells(v, ctx().stream);
+}
+
 // per-level pieces of macproject, shared by the single-level driver below and the multilevel one in amr.hip
 void mac_level_rhs(vdn_multifab **um, const vdn_multifab *mac_rhs, vdn_multifab *rh, const double *dx) {      // divumac + (190-196)
   std::vector<std::pair<divumac_K, Range3>> v;
@@ -1752,6 +1908,27 @@ void do_macproject(vdn_layout *mla, vdn_multifab **umac, vdn_multifab **rho, vdn
   if (mla->nlev > 1) { do_ml_macproject(mla, umac, rho, mac_rhs, dx, bct, bc_comp0); return; }
   const int n = 0;
   size_t mark = arena_mark();
+  {
+    static const bool fast_on = !(getenv("VDN_MAC_FAST") && atoi(getenv("VDN_MAC_FAST")) == 0);
+    // the second level must exist (its coefficients come from the first level's rho): boxes that halve cleanly to >= 4 cells, as cc_build asks
+    bool ok = fast_on && beta_from_rho() && rho[n]->ng >= 1 && !getenv("VDN_FUSED_GSRB");
+    for (const vdn_box &b : mla->boxes[n]) for (int d = 0; d < 3; d++) { const int w = b.hi[d] - b.lo[d] + 1; if ((w & 1) || w / 2 < 4 || ((w / 2) & 1)) ok = false; }
+    for (int d = 0; d < 3; d++) { const int N = mla->pd[n].hi[d] - mla->pd[n].lo[d] + 1; if ((N & 1) || N <= 2) ok = false; }
+    if (ok) {
+      vdn_multifab *um[3] = { umac[0], umac[1], umac[2] };
+      int ebc[3][2];
+      for (int d = 0; d < 3; d++) for (int s = 0; s < 2; s++) ebc[d][s] = bct->ell_bc(n, 0, d, s, bc_comp0);
+      CcFast F; F.um = um; F.mac_rhs = mac_rhs[n]; F.rho = rho[n];
+      int cyc; double r0, rr;
+      int rc = cc_solve(nullptr, nullptr, nullptr, dx, ebc, ctx().prm.mac_rel_eps, -1.0, ctx().prm.mg_max_iter, &cyc, &r0, &rr, nullptr, rho[n], nullptr, &F);
+      ctx().solver_cycles[0] = cyc; ctx().solver_res0[0] = r0; ctx().solver_res[0] = rr;
+      solver_check(rc, "MAC multigrid", cyc, rr, r0);
+      mac_level_mkumac_rho(um, F.phi_view, rho[n], dx, bct, bc_comp0);
+      for (int d = 0; d < 3; d++) mf_fill_boundary(um[d]);        // macproject.f90:115-119
+      arena_release(mark);
+      return;
+    }
+  }
   vdn_multifab *rh = mf_temp(mla, n, 1, 0, -1, false, 0.0);
   vdn_multifab *phi = mf_temp(mla, n, 1, 1, -1, true, 0.0);
   vdn_multifab *beta[3];

@@ -840,15 +840,18 @@ static NLev nd_alloc_lev(const int n[3], const double h[3]) {
   L.PX = ((n[0] + 18 + 15) / 16) * 16; L.PY = n[1] + 3; L.sz = (long)L.PX * L.PY * (n[2] + 3);
   double *base = (double *)arena_alloc(sizeof(double) * L.sz * 5);
   L.phi = base; L.tmp = base + L.sz; L.b = base + 2 * L.sz; L.res = base + 3 * L.sz; L.sig = base + 4 * L.sz;
-  // What must be zero is the ghost layer of phi, tmp and res (nodes outside a physical face; the exchange overwrites the others): every node
-  // 0..n of those arrays is written before it is read (phi by the load, tmp by the first sweep, res by the residual), b is read on nodes
-  // 0..n only and sigma is written on every cell -1..n by its load.  On a big level that is a 6-face kernel instead of a fill of five arrays
-  // (780 MB at 257^3, 0.16 ms per solve); the small levels keep the plain fill (their coarse sigma relies on it beyond the domain).
+  // What must be zero is the ghost layer of phi, tmp and res (nodes outside a physical face; the exchange overwrites the others) and of sigma
+  // (cells beyond a physical face: a COARSE level's sigma is written on the cells 0..n-1 only): every node 0..n of phi, tmp, res is written
+  // before it is read (phi by the load / the restriction, tmp by the first sweep, res by the residual) and b is read on nodes 0..n only.  On a
+  // big level that is a 6-face kernel and one array fill instead of a fill of five arrays (780 MB at 257^3, 0.16 ms per solve).
   // Row padding beyond the ghost nodes only ever reaches lanes whose results are discarded.
+  // (The first version left sigma to its load as well -- true on the finest level only: the 129^3 level of a 257^3 solve then read
+  // whatever the arena held beyond the walls, which happened to be zeros until hgproject stopped allocating its multifabs in front of it.)
   static const bool lean_on = !(getenv("VDN_ND_LEAN") && atoi(getenv("VDN_ND_LEAN")) == 0);
   if (lean_on && (long)(n[0] + 1) * (n[1] + 1) * (n[2] + 1) >= (1L << 21)) {
     const int m = std::max(n[0], std::max(n[1], n[2])) + 3;
     hipLaunchKernelGGL(kk_nd_zero_shell, dim3((m + 63) / 64, (m + 3) / 4, 6), dim3(64, 4, 1), 0, ctx().stream, L, L.phi, L.tmp, L.res);
+    HIPCHK(hipMemsetAsync(L.sig, 0, sizeof(double) * L.sz, ctx().stream));
   } else HIPCHK(hipMemsetAsync(base, 0, sizeof(double) * L.sz * 5, ctx().stream));
   return L;
 }

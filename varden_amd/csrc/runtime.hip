@@ -26,11 +26,13 @@ void vdn_fail(const char *fmt, ...) {
 
 // also drops the pointers advance_timestep keeps INTO the arena (limited slopes of uold, max |umac|): a step that ended in an exception
 // (solver_check throws by default) must not leave them dangling for the next stand-alone vdn_k_mkflux / vdn_k_velpred
+static bool arena_poison() { static const bool p = getenv("VDN_ARENA_POISON") && atoi(getenv("VDN_ARENA_POISON")) != 0; return p; }
 // the descriptors of arena temporaries (mf_temp) that nobody freed: they die with the arena contents they describe
 static std::vector<vdn_multifab *> g_temp_mfs;
 void arena_reset() {
   for (vdn_multifab *m : g_temp_mfs) delete m;
   g_temp_mfs.clear();
+  if (arena_poison() && g_ctx.arena && g_ctx.arena_peak > 0) HIPCHK(hipMemsetAsync(g_ctx.arena, 0xFF, std::min(g_ctx.arena_peak + (size_t)(64 << 20), g_ctx.arena_bytes), g_ctx.stream));
   g_ctx.arena_off = 0;
   g_ctx.slope_src = nullptr; g_ctx.macmax_src = nullptr; g_ctx.macmax_cache = nullptr;
   for (int d = 0; d < 3; d++) g_ctx.slope_cache[d] = nullptr;
@@ -56,7 +58,13 @@ void arena_reserve_for(const vdn_layout *la) {
   arena_reserve(per_field * 150 + (64u << 20));
 }
 size_t arena_mark() { return g_ctx.arena_off; }
-void arena_release(size_t mark) { g_ctx.arena_off = mark; }
+// VDN_ARENA_POISON=1 (debugging): whatever is handed back to the arena is overwritten with NaNs (all-ones bytes), so that a kernel which reads
+// an entry nobody wrote -- and only worked because the last tenant of that address left zeros there -- meets a NaN; the norms turn it into a
+// failed solve.  The GPU suite is run once per round this way (tools/r3_poison.sh).
+void arena_release(size_t mark) {
+  if (arena_poison() && g_ctx.arena && g_ctx.arena_off > mark) HIPCHK(hipMemsetAsync(g_ctx.arena + mark, 0xFF, g_ctx.arena_off - mark, g_ctx.stream));
+  g_ctx.arena_off = mark;
+}
 void *arena_alloc(size_t bytes) {
   VdnCtx &c = g_ctx;
   size_t off = (c.arena_off + 255) & ~(size_t)255;

@@ -213,10 +213,12 @@ void k_estdt_max(const vdn_multifab *u, const vdn_multifab *s, const vdn_multifa
 // macproject.hip / mg_cc.hip
 void do_macproject(vdn_layout *mla, vdn_multifab **umac, vdn_multifab **rho, vdn_multifab **mac_rhs, const double *dx,
                    const vdn_bc_tower *bct, int bc_comp0);
+// cc_solve's fast path for macproject on one level (mg_cc.hip): right-hand side from the MAC field, coefficients from rho, phi handed back as views
+struct CcFast { vdn_multifab **um = nullptr; const vdn_multifab *mac_rhs = nullptr, *rho = nullptr; std::vector<FV> phi_view; };
 int  cc_solve(vdn_multifab *rh, vdn_multifab *phi, vdn_multifab **beta, const double *dx, const int bc[3][2],
               double rel_eps, double abs_eps, int max_iter, int *cycles, double *res0, double *res,
               const vdn_multifab *alpha = nullptr, const vdn_multifab *rho = nullptr,    // rho: beta = 2/(rho_i + rho_i-1), recomputed on the finest level
-              struct CcKeep *keep = nullptr);          // keep: see mg_cc.hip (hierarchy kept between the calls of a composite solve)
+              struct CcKeep *keep = nullptr, CcFast *fast = nullptr);          // keep: see mg_cc.hip (hierarchy kept between the calls of a composite solve)
 struct CcKeep *cc_keep_new(); void cc_keep_free(struct CcKeep *k);
 void cc_smooth(vdn_multifab *rh, vdn_multifab *phi, vdn_multifab **beta, const double *dx, const int bc[3][2], int nsweeps);
 void cc_bench_smoother(vdn_multifab *rh, vdn_multifab *phi, vdn_multifab **beta, const vdn_multifab *rho, const double *dx, const int bc[3][2],
