@@ -162,3 +162,53 @@ def test_two_level_macproject_at_256(gpu):
     assert np.abs(s0[64:192, 64:192, 64:192] - avg).max() <= 1e-13          # ml_cc_restriction
     assert np.abs(s1 - s1[::-1]).max() <= 1e-9 and np.abs(s1 - s1[:, ::-1]).max() <= 1e-9
     G.close()
+
+
+def _level_dense(mf, comp=0):
+    """the valid cells of every box of a level over the bounding box of the level (origin rounded down to a multiple of 4, extents up), NaN
+    where the level has no box; returns (array, origin)"""
+    boxes = [mf.get_box(i) for i in range(mf.nfabs())]
+    lo = [min(b[0][d] for b in boxes) // 4 * 4 for d in range(3)]
+    hi = [(max(b[1][d] for b in boxes) + 4) // 4 * 4 - 1 for d in range(3)]
+    a = np.full(tuple(hi[d] - lo[d] + 1 for d in range(3)), np.nan)
+    ng = mf.ng
+    for i, (blo, bhi) in enumerate(boxes):
+        f = mf.to_numpy(i)[ng:-ng, ng:-ng, ng:-ng, comp] if ng else mf.to_numpy(i)[..., comp]
+        a[blo[0] - lo[0]:bhi[0] + 1 - lo[0], blo[1] - lo[1]:bhi[1] + 1 - lo[1], blo[2] - lo[2]:bhi[2] + 1 - lo[2]] = f
+    return a, lo
+
+
+@pytest.mark.parametrize("max_levs", [2, 3])
+def test_tagged_hierarchy_step_at_256(gpu, max_levs):
+    """BASELINE configs[3] / configs[4] on their REAL box lists (what `bench.py --config amr2 / amr3` times): 256^3 base, levels tagged at
+    rho > 1.01 (and rho > 1.1) by tag_boxes.f90:65-94 and clustered by make_new_grids -- 263 boxes on level 1, ~1000 on level 2.  One
+    step: both composite solves meet the reference's tolerances (macproject.f90:91-93, hgproject.f90:113-119), every coarse cell under a
+    finer level is the average of its eight children (ml_cc_restriction), the base level keeps the mirror symmetry of the bubble."""
+    from varden_amd import advance as adv
+    from varden_amd import driver
+    from varden_amd.capi import default_params
+    prm = default_params(cflfac=0.9)
+    levels = driver.VardenAMR.tagged_grids(N, WALLS, prm, max_levs=max_levs, max_grid_size=256)
+    assert len(levels) == max_levs - 1 and len(levels[0]) > 100
+    G = driver.VardenAMR(N, levels[0], WALLS, params=prm, finer_levels=levels[1:], init_shrink=0.1, init_iter=1, do_initial_projection=1,
+                         max_grid_size=256, swap_state=True)
+    G.step()
+    mac, hg = adv.last_solver_stats("mac"), adv.last_solver_stats("hg")
+    hg_tol = 1e-11 if max_levs == 2 else 1e-10
+    assert mac[0] < 40 and hg[0] < 40 and mac[2] <= 1e-10 * mac[1] and hg[2] <= hg_tol * hg[1], (mac, hg)
+    for mfs, comp in ((G.sold, 0), (G.uold, 2)):
+        dense = [_level_dense(mfs[l], comp) for l in range(max_levs)]
+        for l in range(max_levs - 1):
+            fine, flo = dense[l + 1]
+            crse, clo = dense[l]
+            nf = fine.shape
+            avg = fine.reshape(nf[0] // 2, 2, nf[1] // 2, 2, nf[2] // 2, 2).mean(axis=(1, 3, 5))        # NaN where any child is missing
+            o = [flo[d] // 2 - clo[d] for d in range(3)]
+            sub = crse[o[0]:o[0] + avg.shape[0], o[1]:o[1] + avg.shape[1], o[2]:o[2] + avg.shape[2]]
+            cov = np.isfinite(avg)
+            assert cov.sum() > 1000 and np.isfinite(sub[cov]).all()
+            assert np.abs(sub[cov] - avg[cov]).max() <= 1e-12 * max(1.0, np.abs(avg[cov]).max())
+        a = dense[0][0]
+        assert a.shape == (N, N, N) and np.isfinite(a).all()
+        assert np.abs(a - a[::-1]).max() <= 1e-7 and np.abs(a - a[:, ::-1]).max() <= 1e-7
+    G.close()

@@ -112,10 +112,13 @@ def test_mkflux(gpu, oracle, bcname, is_vel, minion):
     case.close()
 
 
+@pytest.mark.parametrize("boussinesq", [0, 1])
 @pytest.mark.parametrize("bcname", ["walls", "periodic", "inout"])
-def test_forces_update_halftime(gpu, oracle, bcname):
+def test_forces_update_halftime(gpu, oracle, bcname, boussinesq):
+    """boussinesq = 1: the external force is scaled by the second scalar on the VALID cells only (mkforce.f90:160-177), not on the
+    one-cell face halo that follows (:186-234)"""
     from varden_amd import advance as adv
-    case = Case((8, 12, 16), BC_SETS[bcname], seed=4)
+    case = Case((8, 12, 16), BC_SETS[bcname], seed=4, boussinesq=boussinesq)
     L = oracle.lib()
     u, s = case.random_state()
     ns = case.prm.nscal

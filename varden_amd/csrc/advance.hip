@@ -16,9 +16,6 @@
 static double wall() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 static void sync() { HIPCHK(hipStreamSynchronize(ctx().stream)); }
 
-static void check_single_level(const vdn_layout *mla) {
-  REQUIRE(mla && mla->nlev == 1, "this round implements single-level hierarchies only (nlevel = %d)", mla ? mla->nlev : -1);
-}
 
 // ml_restrict_and_fill: one level = fill_boundary + physbc; two levels = average down + coarse-fine ghost interpolation too
 static void restrict_and_fill(int nlev, vdn_multifab **mf, int icomp, int bcomp, int nc, bool same_boundary, const vdn_bc_tower *bct) {

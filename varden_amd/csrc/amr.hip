@@ -10,7 +10,8 @@
 //                         through an interface face = mean of the four fine fluxes), nu1 red-black sweeps on the levels finest to 1,
 //                         one V-cycle of the single-level multigrid on the whole level 0, piecewise-constant prolongation, nu2 sweeps
 //                         on the levels 1 to finest
-// This round: up to VDN_MAXLEV levels, refinement ratio 2, every box on this rank (nranks = 1); the levels must be properly nested
+// Up to VDN_MAXLEV levels, refinement ratio 2, the boxes of every level on any rank (the other level is seen through SrcView windows,
+// exchange.hip); the levels must be properly nested
 // (a level-n box keeps at least two level-(n-1) cells between itself and the edge of level n-1, or touches the domain boundary).
 #include "vdn_dev.h"
 #include <vector>

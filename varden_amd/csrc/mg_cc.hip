@@ -1912,8 +1912,12 @@ void do_macproject(vdn_layout *mla, vdn_multifab **umac, vdn_multifab **rho, vdn
     static const bool fast_on = !(getenv("VDN_MAC_FAST") && atoi(getenv("VDN_MAC_FAST")) == 0);
     // the second level must exist (its coefficients come from the first level's rho): boxes that halve cleanly to >= 4 cells, as cc_build asks
     bool ok = fast_on && beta_from_rho() && rho[n]->ng >= 1 && !getenv("VDN_FUSED_GSRB");
-    for (const vdn_box &b : mla->boxes[n]) for (int d = 0; d < 3; d++) { const int w = b.hi[d] - b.lo[d] + 1; if ((w & 1) || w / 2 < 4 || ((w / 2) & 1)) ok = false; }
-    for (int d = 0; d < 3; d++) { const int N = mla->pd[n].hi[d] - mla->pd[n].lo[d] + 1; if ((N & 1) || N <= 2) ok = false; }
+    {   // cc_build's rule for a second DISTRIBUTED level: the domain coarsens, the boxes halve cleanly and stay at least min_dist wide
+      const int agglom = getenv("VDN_MG_AGGLOM") ? std::max(4, atoi(getenv("VDN_MG_AGGLOM"))) : 64;
+      const int min_dist = mla->boxes[n].size() > 1 ? agglom : 4;
+      for (const vdn_box &b : mla->boxes[n]) for (int d = 0; d < 3; d++) { const int w = b.hi[d] - b.lo[d] + 1; if ((w & 1) || w / 2 < min_dist || ((w / 2) & 1)) ok = false; }
+      for (int d = 0; d < 3; d++) { const int N = mla->pd[n].hi[d] - mla->pd[n].lo[d] + 1; if ((N & 1) || N <= 2) ok = false; }
+    }
     if (ok) {
       vdn_multifab *um[3] = { umac[0], umac[1], umac[2] };
       int ebc[3][2];
