@@ -164,12 +164,18 @@ extern "C" int vdn_advance_timestep(int istep, vdn_layout *mla, vdn_multifab **s
       if (!keep_vel_force) k_mkvelforce(vel_force[n], ext_vel_force[n], sold[n], gp[n], lapu[n], 1.0);
     }
     if (!keep_vel_force) restrict_and_fill(nlevs, vel_force, 0, bct->extrap_comp0(), dm, true, bct);
+    // one level: the forcing of the update (mkvelforce with rhohalf, visc_fac = 0) is formed inside the update pass; on a hierarchy the
+    // average-down of ml_restrict_and_fill sits between the two, so they stay apart
+    const bool fuse_force = force_reuse && nlevs == 1 && dm == 3;
     for (int n = 0; n < nlevs; n++) {
       k_mkflux(uold[n], uedge + 3 * n, uflux + 3 * n, umac + 3 * n, vel_force[n], mac_rhs[n], DXL(n), dt, bct, true, is_cons);
-      k_mkvelforce(vel_force[n], ext_vel_force[n], rhohalf[n], gp[n], lapu[n], 0.0);
+      if (!fuse_force) k_mkvelforce(vel_force[n], ext_vel_force[n], rhohalf[n], gp[n], lapu[n], 0.0);
     }
-    restrict_and_fill(nlevs, vel_force, 0, bct->extrap_comp0(), dm, true, bct);
-    for (int n = 0; n < nlevs; n++) k_update(uold[n], umac + 3 * n, uedge + 3 * n, uflux + 3 * n, vel_force[n], unew[n], DXL(n), dt, true, is_cons);
+    if (fuse_force) k_update_velforce(uold[0], umac, uedge, ext_vel_force[0], rhohalf[0], gp[0], lapu[0], 0.0, unew[0], DXL(0), dt);
+    else {
+      restrict_and_fill(nlevs, vel_force, 0, bct->extrap_comp0(), dm, true, bct);
+      for (int n = 0; n < nlevs; n++) k_update(uold[n], umac + 3 * n, uedge + 3 * n, uflux + 3 * n, vel_force[n], unew[n], DXL(n), dt, true, is_cons);
+    }
     restrict_and_fill(nlevs, unew, 0, 0, dm, false, bct);                               // update.f90:104
     if (viscous) {                                                                      // velocity_advance.f90:103-118
       const double visc_mu = (P.diffusion_type == 1) ? 0.5 * dt * P.visc_coef : dt * P.visc_coef;

@@ -203,6 +203,8 @@ void k_mkflux(const vdn_multifab *s, vdn_multifab **sedge, vdn_multifab **flux, 
               const vdn_bc_tower *bct, bool is_vel, const int *is_cons);
 void k_slope(const vdn_multifab *s, vdn_multifab *slope, int dir, int bccomp, const vdn_bc_tower *bct);
 // pointwise.hip
+void k_update_velforce(const vdn_multifab *uold, vdn_multifab **umac, vdn_multifab **uedge, const vdn_multifab *ext, const vdn_multifab *s,
+                       const vdn_multifab *gp, const vdn_multifab *lapu, double visc_fac, vdn_multifab *unew, const double *dx, double dt);
 void k_update(const vdn_multifab *sold, vdn_multifab **umac, vdn_multifab **sedge, vdn_multifab **flux,
               const vdn_multifab *force, vdn_multifab *snew, const double *dx, double dt, bool is_vel, const int *is_cons);
 void k_mkvelforce(vdn_multifab *vf, const vdn_multifab *ext, const vdn_multifab *s, const vdn_multifab *gp,
