@@ -113,11 +113,34 @@ Prof::Prof(const char *name) : on(g_roctx_push != nullptr) { if (on) g_roctx_pus
 Prof::~Prof() { if (on) g_roctx_pop(); }
 
 // ---- scalar read-back ------------------------------------------------------------------------------------------------------------
-__global__ void k_publish(double *host_view, const double *dev, int n) { if ((int)threadIdx.x < n) host_view[threadIdx.x] = dev[threadIdx.x]; }
+bool g_capturing_now();
+// The values, then (after a system-scope fence) a sequence number in slot 64 of the pinned buffer: the host spins on that number instead of
+// sleeping in hipStreamSynchronize -- a V-cycle loop reads one norm per cycle, and the wake-up of a blocked host thread was most of the ~20 us
+// the GPU sat idle after every k_publish (profiles/r03_bench_trace_gaps.txt).  The stream is queried now and then: an error or an idle stream
+// without the number (memory that is not host-coherent) falls back to the synchronisation.  VDN_POLL=0: synchronise always.
+__global__ void k_publish(double *host_view, const double *dev, int n, unsigned long long seq) {
+  if ((int)threadIdx.x < n) host_view[threadIdx.x] = dev[threadIdx.x];
+  __syncthreads();
+  if (threadIdx.x == 0) { __threadfence_system(); *reinterpret_cast<volatile unsigned long long *>(host_view + 64) = seq; }
+}
 const double *read_scalars(const double *dev, int n) {
   VdnCtx &c = g_ctx;
   REQUIRE(n >= 1 && n <= 64, "read_scalars: 1..64 values");
-  hipLaunchKernelGGL(k_publish, dim3(1), dim3(64), 0, c.stream, c.h_scal_dev, dev, n);
+  static unsigned long long seq = 0;
+  static const bool poll = !(getenv("VDN_POLL") && atoi(getenv("VDN_POLL")) == 0);
+  ++seq;
+  hipLaunchKernelGGL(k_publish, dim3(1), dim3(64), 0, c.stream, c.h_scal_dev, dev, n, seq);
+  if (poll && !g_capturing_now()) {
+    volatile unsigned long long *flag = reinterpret_cast<volatile unsigned long long *>(c.h_scal + 64);
+    for (unsigned long spins = 1;; spins++) {
+      if (*flag == seq) { __sync_synchronize(); return c.h_scal; }
+      if ((spins & 0x3fff) == 0) {                          // every ~16 k reads: has the stream failed, or finished without the number showing up?
+        const hipError_t q = hipStreamQuery(c.stream);
+        if (q == hipSuccess) break;
+        if (q != hipErrorNotReady) HIPCHK(q);
+      }
+    }
+  }
   HIPCHK(hipStreamSynchronize(c.stream));
   return c.h_scal;
 }
@@ -125,6 +148,7 @@ const double *read_scalars(const double *dev, int n) {
 // ---- hipGraph cache ---------------------------------------------------------------------------------------------------------------
 static std::map<unsigned long long, hipGraphExec_t> g_graphs;
 static bool g_capturing = false;
+bool g_capturing_now() { return g_capturing; }
 bool graphs_enabled() {
   static const bool off = getenv("VDN_NO_GRAPHS") != nullptr;
   return !off && !comm_active() && g_ctx.stream != 0 && !g_capturing;
@@ -204,7 +228,8 @@ extern "C" int vdn_init(const vdn_params *prm, int rank, int nranks, int device)
   c.prm = *prm; c.rank = rank; c.nranks = nranks; c.device = device;
   if (!c.d_scal) {
     HIPCHK(hipMalloc((void **)&c.d_scal, 64 * sizeof(double)));
-    HIPCHK(hipHostMalloc((void **)&c.h_scal, 64 * sizeof(double), hipHostMallocMapped));
+    HIPCHK(hipHostMalloc((void **)&c.h_scal, 72 * sizeof(double), hipHostMallocMapped));      // 64 values + the sequence number of read_scalars
+    memset(c.h_scal, 0, 72 * sizeof(double));
     HIPCHK(hipHostGetDevicePointer((void **)&c.h_scal_dev, c.h_scal, 0));
   }
   // our own launch stream: the legacy null stream cannot be captured into a hipGraph, and a second stream next to it could not overlap
