@@ -406,36 +406,9 @@ __global__ void kk_nd_restrict(NLev F, NLev C) {
   C.b[cn] = s * 0.125;
   C.phi[cn] = 0.0;                     // the error equation starts from zero: saves a memset launch per level and cycle (ghost nodes stay zero / are refreshed)
 }
-// the same restriction for wide levels: lane l of a wave row owns coarse node I and loads the fine pair (2I, 2I+1) of each of the nine
-// (row, plane) lines as one aligned 16-byte load -- a wave reads whole 1-KB runs -- taking fine column 2I-1 from the previous lane's pair
-// (DPP; lane 0 loads it).  9 + 1 memory instructions per coarse node instead of 27 strided 8-byte ones (52.8 -> see DESIGN us at 257^3);
-// kk_nd_restrict's sum in kk_nd_restrict's order.
-__global__ void __launch_bounds__(256) kk_nd_restrict_pair(NLev F, NLev C) {
-  const int lane = threadIdx.x;
-  const int i = blockIdx.x * 64 + lane, j = blockIdx.y * blockDim.y + threadIdx.y, k = blockIdx.z;
-  const int ic = min(i, C.n[0]), jc = min(j, C.n[1]);              // clamped: every lane takes part in the lane exchange
-  const long sy = F.PX, sz = (long)F.PX * F.PY;
-  const long f0 = nidx(F, 2 * ic, 2 * jc, 2 * k);
-  double s = 0.0;
-  #pragma unroll
-  for (int c = -1; c <= 1; c++)
-    #pragma unroll
-    for (int b = -1; b <= 1; b++) {
-      const long o = f0 + b * sy + c * sz;
-      const double2 pr = ld2(F.res + o);                             // fine columns 2I, 2I+1
-      double left = lane_prev(pr.y);                                 // 2I-1 = the previous lane's 2(I-1)+1
-      if (lane == 0) left = F.res[o - 1];
-      const double wb = b ? 0.5 : 1.0, wc = c ? 0.5 : 1.0;
-      s = s + (0.5 * wb * wc) * left;
-      s = s + (1.0 * wb * wc) * pr.x;
-      s = s + (0.5 * wb * wc) * pr.y;
-    }
-  if (i > C.n[0] || j > C.n[1]) return;
-  if (nd_is_dir(C, i, j, k)) s = 0.0;
-  const long cn = nidx(C, i, j, k);
-  C.b[cn] = s * 0.125;
-  C.phi[cn] = 0.0;
-}
+// (round 3, measured and rejected: the restriction of wide levels with aligned 16-byte pairs -- a lane owns coarse node I, loads the fine pair
+// (2I, 2I+1) of each of the nine lines and takes column 2I-1 from the previous lane: 59.8 us against 55.5 us at 257^3 -> 129^3; the 27
+// strided reads of the plain kernel are served by L2 lines the neighbouring threads share anyway)
 // trilinear interpolation of the coarse field at fine node offsets (oi,oj,ok) of coarse node (I,J,K): the eight coarse values are
 // loaded in one unconditional batch and added under predicates in the order (c,b,a) ascending of the oracle's loops
 DEVI double nd_interp8(const NLev &C, const double *__restrict__ cp, int I, int J, int K, int oi, int oj, int ok) {
@@ -1098,11 +1071,9 @@ static void nd_restrict_down(NDMG &M, int l) {
   NDLev &DL = M.dlev[l];
   if (l + 1 < (int)M.dlev.size()) {
     NDLev &DC = M.dlev[l + 1];
-    static const bool pair_on = !(getenv("VDN_ND_RESTRICT_PAIR") && atoi(getenv("VDN_ND_RESTRICT_PAIR")) == 0);
     for (size_t b = 0; b < DL.boxes.size(); b++) {
       NLev &C = DC.boxes[b].L;
-      if (pair_on && C.n[0] >= 63) hipLaunchKernelGGL(kk_nd_restrict_pair, ng3(C.n[0] + 1, C.n[1] + 1, C.n[2] + 1), NBLK, 0, ctx().stream, DL.boxes[b].L, C);
-      else hipLaunchKernelGGL(kk_nd_restrict, ng3(C.n[0] + 1, C.n[1] + 1, C.n[2] + 1), NBLK, 0, ctx().stream, DL.boxes[b].L, C);
+      hipLaunchKernelGGL(kk_nd_restrict, ng3(C.n[0] + 1, C.n[1] + 1, C.n[2] + 1), NBLK, 0, ctx().stream, DL.boxes[b].L, C);
     }
   } else {
     NLev &T = M.tail[0];
