@@ -228,11 +228,11 @@ def test_multigrid_launch_variants_agree_bit_for_bit(gpu):
             h.update(np.ascontiguousarray(m.to_numpy()).tobytes())
         print("HASH", h.hexdigest(), G.dt)
     """ % root)
-    switches = ("VDN_MG_PROLONG_FUSED", "VDN_MG_RESTRICT_FUSED", "VDN_MG_TAILCYCLE", "VDN_MG_LDS", "VDN_NO_GRAPHS", "VDN_HG_FAST", "VDN_MAC_FAST", "VDN_ND_LEAN", "VDN_NO_FORCE_REUSE")
+    switches = ("VDN_MG_PROLONG_FUSED", "VDN_MG_RESTRICT_FUSED", "VDN_MG_TAILCYCLE", "VDN_MG_LDS", "VDN_NO_GRAPHS", "VDN_HG_FAST", "VDN_MAC_FAST", "VDN_ND_LEAN", "VDN_NO_FORCE_REUSE", "VDN_GOD_UPDATE")
     for n, visc in ((128, 0.0), (64, 0.01)):
         out = []
         for extra in ({}, {"VDN_MG_PROLONG_FUSED": "0", "VDN_MG_RESTRICT_FUSED": "0", "VDN_MG_TAILCYCLE": "0", "VDN_MG_LDS": "0", "VDN_NO_GRAPHS": "1",
-                          "VDN_HG_FAST": "0", "VDN_MAC_FAST": "0", "VDN_ND_LEAN": "0", "VDN_NO_FORCE_REUSE": "1"}):
+                          "VDN_HG_FAST": "0", "VDN_MAC_FAST": "0", "VDN_ND_LEAN": "0", "VDN_NO_FORCE_REUSE": "1", "VDN_GOD_UPDATE": "0"}):
             env = dict(os.environ)
             for k in switches:
                 env.pop(k, None)

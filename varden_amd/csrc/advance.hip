@@ -128,12 +128,17 @@ extern "C" int vdn_advance_timestep(int istep, vdn_layout *mla, vdn_multifab **s
       k_mkscalforce(scal_force[n], ext_scal_force[n], laps[n], 1.0);
     }
     restrict_and_fill(nlevs, scal_force, 0, bct->extrap_comp0(), nscal, true, bct);     // mkforce.f90:283-284
+    // one level, no diffusion: the update runs inside the mkflux march where that is the fused one (a level of one box): same forcing term,
+    // the edge states and fluxes never reach memory (godunov.hip, UPD); on a hierarchy the fluxes are restricted in between (mkflux.f90:137-146)
+    bool s_updated = false;
     for (int n = 0; n < nlevs; n++) {
-      k_mkflux(sold[n], sedge + 3 * n, sflux + 3 * n, umac + 3 * n, scal_force[n], divu[n], DXL(n), dt, bct, false, is_cons);
+      MkUpdate U; U.snew = snew[n]; U.fmode = 0;
+      const bool try_upd = force_reuse && nlevs == 1 && dm == 3 && !diffusive;
+      s_updated = k_mkflux(sold[n], sedge + 3 * n, sflux + 3 * n, umac + 3 * n, scal_force[n], divu[n], DXL(n), dt, bct, false, is_cons, try_upd ? &U : nullptr);
       if (diffusive || !force_reuse) k_mkscalforce(scal_force[n], ext_scal_force[n], laps[n], 0.0);     // without diffusion: ext_scal_force again, already there
     }
     if (diffusive || !force_reuse) restrict_and_fill(nlevs, scal_force, 0, bct->extrap_comp0(), nscal, true, bct);
-    for (int n = 0; n < nlevs; n++) k_update(sold[n], umac + 3 * n, sedge + 3 * n, sflux + 3 * n, scal_force[n], snew[n], DXL(n), dt, false, is_cons);
+    if (!s_updated) for (int n = 0; n < nlevs; n++) k_update(sold[n], umac + 3 * n, sedge + 3 * n, sflux + 3 * n, scal_force[n], snew[n], DXL(n), dt, false, is_cons);
     restrict_and_fill(nlevs, snew, 0, dm, nscal, false, bct);                           // update.f90:106
     if (diffusive) {                                                                    // scalar_advance.f90:144-162
       const double visc_mu = (P.diffusion_type == 1) ? 0.5 * dt * P.diff_coef : dt * P.diff_coef;
@@ -167,11 +172,15 @@ extern "C" int vdn_advance_timestep(int istep, vdn_layout *mla, vdn_multifab **s
     // one level: the forcing of the update (mkvelforce with rhohalf, visc_fac = 0) is formed inside the update pass; on a hierarchy the
     // average-down of ml_restrict_and_fill sits between the two, so they stay apart
     const bool fuse_force = force_reuse && nlevs == 1 && dm == 3;
+    bool u_updated = false;
     for (int n = 0; n < nlevs; n++) {
-      k_mkflux(uold[n], uedge + 3 * n, uflux + 3 * n, umac + 3 * n, vel_force[n], mac_rhs[n], DXL(n), dt, bct, true, is_cons);
+      MkUpdate U; U.snew = unew[n]; U.fmode = 1; U.ext = ext_vel_force[n]; U.gp = gp[n]; U.rho = rhohalf[n]; U.lapu0 = P.visc_coef * 0.0 * 0.0;
+      const bool try_upd = fuse_force && !viscous && P.boussinesq == 0;      // (viscous: lapu enters the forcing term; boussinesq: the tracer scales ext)
+      u_updated = k_mkflux(uold[n], uedge + 3 * n, uflux + 3 * n, umac + 3 * n, vel_force[n], mac_rhs[n], DXL(n), dt, bct, true, is_cons, try_upd ? &U : nullptr);
       if (!fuse_force) k_mkvelforce(vel_force[n], ext_vel_force[n], rhohalf[n], gp[n], lapu[n], 0.0);
     }
-    if (fuse_force) k_update_velforce(uold[0], umac, uedge, ext_vel_force[0], rhohalf[0], gp[0], lapu[0], 0.0, unew[0], DXL(0), dt);
+    if (u_updated) { /* unew is written */ }
+    else if (fuse_force) k_update_velforce(uold[0], umac, uedge, ext_vel_force[0], rhohalf[0], gp[0], lapu[0], 0.0, unew[0], DXL(0), dt);
     else {
       restrict_and_fill(nlevs, vel_force, 0, bct->extrap_comp0(), dm, true, bct);
       for (int n = 0; n < nlevs; n++) k_update(uold[n], umac + 3 * n, uedge + 3 * n, uflux + 3 * n, vel_force[n], unew[n], DXL(n), dt, true, is_cons);

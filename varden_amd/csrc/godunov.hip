@@ -817,6 +817,10 @@ struct FArgs {
   double dt2, dx[3], tC[3], tD[3], aD[3];   // tC[T] = (cons ? dt/3 : dt/6) / dx[T],  tD[T] = (cons ? dt/2 : dt/4) / dx[T],  aD[T] = (dt/2) / dx[T]
   int lo[3], hi[3], phys[3][2];
   int cons, use_minion, is_vel, c;
+  // UPD (round 3): update_3d of the component inside the march -- the edge states never reach memory
+  char *qn; long sqn; FGeo hn;      // snew / unew of the component: plane KB, bytes per plane, layout
+  const char *pfu[3]; int fmode;    // the update's forcing term: fmode 0 = the force of this call (p[7]); 1 = ext (pfu[0]) + (lapu0 - gp (pfu[1])) / rho (pfu[2]), force layout
+  double dt, lapu0;
 };
 static bool bc_mode_host(int phys) { return phys == VDN_INLET || phys == VDN_SLIP_WALL || phys == VDN_NO_SLIP_WALL || phys == VDN_OUTLET; }
 static bool same_geom(const FV &a, const FV &b) { return a.a0 == b.a0 && a.a1 == b.a1 && a.a2 == b.a2 && a.n0 == b.n0 && a.n1 == b.n1; }
@@ -878,8 +882,13 @@ DEVI double bc_v(int m, int side, double in, double ghost) {
   if (m == 1) v = ghost;
   return v;
 }
-template <bool BC, bool INL> __device__ __forceinline__ void mk_F_m_body(const FArgs &F, const Range3 &r, int klen, const double *umax, const int BX, const int BY, const int BZ) {
-  __shared__ double lB[2][TNY][64], lSI[2][TNY][64], lC[2][2][TNY][64], lSC[2][2][TNY][64], lD[2][TNY][64];
+// UPD: the conservative / convective update of the component (update.f90:220-269) rides along.  A cell's update needs the edge states on its
+// six faces: the lower three are this thread's stage-D outputs, the upper x one the next lane's (DPP, same iteration), the upper y one the
+// next row's (LDS, read one iteration later, like SI and SC), the upper z one this thread's output for the next plane.  So the x-term of
+// plane k is formed with stage D of plane k, the y- and z-terms one iteration later, and seven doubles travel in between; a k-chunk runs
+// one plane further (the lower z-face of its successor's first plane).  sedge and flux are not stored.  Same expressions as update_cell.
+template <bool BC, bool INL, bool UPD> __device__ __forceinline__ void mk_F_m_body(const FArgs &F, const Range3 &r, int klen, const double *umax, const int BX, const int BY, const int BZ) {
+  __shared__ double lB[2][TNY][64], lSI[2][TNY][64], lC[2][2][TNY][64], lSC[2][2][TNY][64], lD[2][TNY][64], lE[UPD ? 2 : 1][UPD ? TNY : 1][64];
   const int lane = threadIdx.x, row = threadIdx.y;
   const int i = r.lo[0] - 1 + BX * FNX + lane, j = r.lo[1] - 1 + BY * FNY + row;
   const bool own_ij = lane >= 1 && lane <= FNX && row >= 1 && row <= FNY && i <= r.hi[0] && j <= r.hi[1];
@@ -933,6 +942,8 @@ template <bool BC, bool INL> __device__ __forceinline__ void mk_F_m_body(const F
   FZERO(P0) FZERO(P1)
   #undef FZERO
   double LzB = 0.0, LzC[2] = { 0.0, 0.0 }, LzD = 0.0;
+  double c_tx = 0.0, c_e1 = 0.0, c_e2 = 0.0, c_vbar = 0.0, c_wbar = 0.0, c_so = 0.0, c_fu = 0.0;       // UPD: what plane k-1 hands to the next iteration
+  char *qn = UPD ? F.qn + (long)(k0 - KB) * F.sqn + fg_off(F.hn, i, j) : nullptr;
   double si1[3] = { 0.0, 0.0, 0.0 };                                 // SI on the lower faces of the cell in plane kk-1
   double qp[6] = { 0.0, 0.0, 0.0, 0.0, 0.0, 0.0 };                   // SC on the lower faces of the cell in plane kk-2
   // ghost values of s for the inflow rule (mode 1), read only where it applies: plane kpl, dbytes along x / y from the thread's (clamped) cell
@@ -964,7 +975,7 @@ template <bool BC, bool INL> __device__ __forceinline__ void mk_F_m_body(const F
       if (kc_ != kcur) { ps += F.sp[0]; psl0 += F.sp[1]; psl1 += F.sp[1]; psl2 += F.sp[1]; pum += F.sp[2]; pvm += F.sp[3]; pwm += F.sp[4]; pf += F.sp[5]; pmr += F.sp[6]; kcur = kc_; } }
   F_LOAD
   F_ADVANCE(k0 - 1)
-  for (int kk = k0 - 2; kk <= k1 + 2; kk++) {
+  for (int kk = k0 - 2; kk <= k1 + 2 + (UPD ? 1 : 0); kk++) {
     const int buf = kk & 1;
     P2 = P1; P1 = P0;
     {
@@ -1072,18 +1083,44 @@ template <bool BC, bool INL> __device__ __forceinline__ void mk_F_m_body(const F
       double L[3];
       L[0] = shfl_prev(VL[0]); L[1] = lD[buf][rowm][lane]; L[2] = LzD; LzD = VL[2];
       if (k >= k0) {
-        if (own_ij) {
-          double e[3];
+        double e[3] = { 0.0, 0.0, 0.0 };
+        if (UPD || own_ij) {
           e[0] = upwind_mac(L[0], VR[0], m_lo[0], eps); e[1] = upwind_mac(L[1], VR[1], m_lo[1], eps); e[2] = upwind_mac(L[2], VR[2], m_lo[2], eps);
           if (BC) {
             if (wd & 0xF00F) { FACE_BC(e[0], wd, 0, L[0], VR[0], s0, S_AT(kc, -8L)) FACE_BC(e[1], wd, 12, L[1], VR[1], s0, S_AT(kc, -F.s_row)) }
             if (zw & 15) { FACE_BC(e[2], zw, 0, L[2], VR[2], s0, S_AT(kc - 1, 0L)) }
           }
-          if (vy && vz) { std_(qex, 0u, e[0]); if (cons) std_(qfx, 0u, e[0] * m_lo[0]); }
-          if (vx && vz) { std_(qey, 0u, e[1]); if (cons) std_(qfy, 0u, e[1] * m_lo[1]); }
-          if (vx && vy) { std_(qez, 0u, e[2]); if (cons) std_(qfz, 0u, e[2] * m_lo[2]); }
         }
-        qex += F.sq[0]; qfx += F.sq[0]; qey += F.sq[1]; qfy += F.sq[1]; qez += F.sq[2]; qfz += F.sq[2];
+        if (!UPD) {
+          if (own_ij) {
+            if (vy && vz) { std_(qex, 0u, e[0]); if (cons) std_(qfx, 0u, e[0] * m_lo[0]); }
+            if (vx && vz) { std_(qey, 0u, e[1]); if (cons) std_(qfy, 0u, e[1] * m_lo[1]); }
+            if (vx && vy) { std_(qez, 0u, e[2]); if (cons) std_(qfz, 0u, e[2] * m_lo[2]); }
+          }
+          qex += F.sq[0]; qfx += F.sq[0]; qey += F.sq[1]; qfy += F.sq[1]; qez += F.sq[2]; qfz += F.sq[2];
+        } else {
+          // what update_3d differences: fluxes of a conservative component (flux = sedge * umac, mkflux.f90:1969), edge states otherwise
+          const double ex = cons ? e[0] * m_lo[0] : e[0], ey = cons ? e[1] * m_lo[1] : e[1], ez = cons ? e[2] * m_lo[2] : e[2];
+          if (k - 1 >= k0) {                                           // finish plane k-1: its upper y face from the row above, its upper z face = ez
+            const double eyu = lE[buf ^ 1][rowp][lane];
+            const double ty = cons ? (eyu - c_e1) / F.dx[1] : c_vbar * (eyu - c_e1) / F.dx[1];
+            const double tz = cons ? (ez - c_e2) / F.dx[2] : c_wbar * (ez - c_e2) / F.dx[2];
+            const double ug = c_tx + ty + tz;
+            const bool vzp = k - 1 >= F.lo[2] && k - 1 <= F.hi[2];
+            if (own_ij && vx && vy && vzp) std_(qn, 0u, c_so - F.dt * ug + F.dt * c_fu);
+            qn += F.sqn;
+          }
+          const double exu = lane_next(ex);                            // the upper x face: the next lane's lower one
+          c_tx = cons ? (exu - ex) / F.dx[0] : (0.5 * (m_lo[0] + m_up[0])) * (exu - ex) / F.dx[0];
+          c_vbar = 0.5 * (m_lo[1] + m_up[1]); c_wbar = 0.5 * (m_lo[2] + m_up[2]);
+          c_e1 = ey; c_e2 = ez; c_so = s0;
+          if (F.fmode == 0) c_fu = P2.f;
+          else {
+            const long po = (long)(kc - KB) * F.sp[5] + o_f;
+            c_fu = ldd(F.pfu[0] + po, 0u) + (F.lapu0 - ldd(F.pfu[1] + po, 0u)) / ldd(F.pfu[2] + po, 0u);
+          }
+          lE[buf][row][lane] = ey;                                     // read by the row below in the next iteration
+        }
       }
     }
     si1[0] = si0[0]; si1[1] = si0[1]; si1[2] = si0[2];
@@ -1098,14 +1135,14 @@ template <bool BC, bool INL> __device__ __forceinline__ void mk_F_m_body(const F
   #undef PREMOD
   #undef Z_WORD
 }
-template <bool BC = true, bool INL = true> __global__ void __launch_bounds__(64 * TNY) kk_mk_F_m(FArgs F, Range3 r, int klen, const double *umax) {
+template <bool BC = true, bool INL = true, bool UPD = false> __global__ void __launch_bounds__(64 * TNY) kk_mk_F_m(FArgs F, Range3 r, int klen, const double *umax) {
   int bx_, by_, bz_; xcd_remap(bx_, by_, bz_);
   // a workgroup whose tile and k-chunk stay clear of every face that carries a rule runs the body without the boundary code (same values:
   // none of its cells is flagged); compiled into one kernel the lean path keeps its own register allocation (0.69 against 0.96 ms per launch)
   bool touch = false;
   if (BC) {
     const int i0 = r.lo[0] - 1 + bx_ * FNX, i1 = i0 + 63, j0 = r.lo[1] - 1 + by_ * FNY, j1 = j0 + TNY - 1;
-    const int k0 = r.lo[2] + bz_ * klen - 2, k1 = min(r.lo[2] + bz_ * klen + klen - 1, r.hi[2]) + 2;
+    const int k0 = r.lo[2] + bz_ * klen - 2, k1 = min(r.lo[2] + bz_ * klen + klen - 1, r.hi[2]) + 2 + (UPD ? 1 : 0);
     const int a0[3] = { i0, j0, k0 }, a1[3] = { i1, j1, k1 };
     #pragma unroll
     for (int d = 0; d < 3; d++) {
@@ -1113,8 +1150,8 @@ template <bool BC = true, bool INL = true> __global__ void __launch_bounds__(64 
       if (bc_mode(F.phys[d][1], F.is_vel != 0, F.c == d) && a1[d] >= F.hi[d] - 1) touch = true;
     }
   }
-  if (BC && touch) mk_F_m_body<BC, INL>(F, r, klen, umax, bx_, by_, bz_);
-  else mk_F_m_body<false, false>(F, r, klen, umax, bx_, by_, bz_);
+  if (BC && touch) mk_F_m_body<BC, INL, UPD>(F, r, klen, umax, bx_, by_, bz_);
+  else mk_F_m_body<false, false, UPD>(F, r, klen, umax, bx_, by_, bz_);
 }
 // the launch arguments of the fused march for component c; false when the field layouts do not allow the shared offsets
 static bool fused_args(FArgs &F, const GArgs &A, int c, const FV &s, const FV sl[3], const FV &um, const FV &vm, const FV &wm, const FV &force, const FV &macrhs,
@@ -1144,6 +1181,26 @@ static bool fused_args(FArgs &F, const GArgs &A, int c, const FV &s, const FV sl
     F.lo[d] = A.lo[d]; F.hi[d] = A.hi[d]; F.phys[d][0] = A.phys[d][0]; F.phys[d][1] = A.phys[d][1];
   }
   F.cons = cons ? 1 : 0; F.use_minion = A.use_minion; F.is_vel = A.is_vel; F.c = c;
+  F.qn = nullptr; F.sqn = 0; F.hn = FGeo{ 0, 0, 0 }; F.pfu[0] = F.pfu[1] = F.pfu[2] = nullptr; F.fmode = 0; F.dt = A.dt; F.lapu0 = 0.0;
+  return true;
+}
+// the update of component c inside the march (UPD): snew, and the forcing term of the update -- the force of this call (fmode 0) or formed in place
+// from ext, gp and rho, which must share the layout of `force` (fmode 1)
+static bool fused_update_args(FArgs &F, const GArgs &A, int c, const FV &snew, const FV &force, const MkUpdate &U, int ib) {
+  const int KB = A.lo[2] - 1;
+  if (KB < snew.a2 || A.hi[2] + 1 >= snew.a2 + snew.n2) return false;
+  F.qn = (char *)(snew.p + snew.sc * c + (long)snew.n0 * snew.n1 * (KB - snew.a2));
+  F.sqn = 8L * snew.n0 * snew.n1; F.hn = FGeo{ snew.a0, snew.a1, snew.n0 };
+  F.fmode = U.fmode; F.lapu0 = U.lapu0;
+  if (U.fmode == 1) {
+    const FV *in[3] = { &U.ext->fabs[ib], &U.gp->fabs[ib], &U.rho->fabs[ib] };
+    const int comp[3] = { c, c, 0 };
+    for (int f = 0; f < 3; f++) {
+      const FV &v = *in[f];
+      if (!same_geom(v, force) || v.n2 != force.n2) return false;
+      F.pfu[f] = (const char *)(v.p + v.sc * comp[f] + (long)v.n0 * v.n1 * (KB - v.a2));
+    }
+  }
   return true;
 }
 
@@ -1237,8 +1294,8 @@ template <bool INL> __global__ void __launch_bounds__(64 * TNY) kk_mk_F_mb(const
       if (bc_mode(q.F.phys[d][1], q.F.is_vel != 0, q.F.c == d) && a1[d] >= q.F.hi[d] - 1) touch = true;
     }
   }
-  if (touch) mk_F_m_body<true, INL>(q.F, q.r, q.klen, q.umax, BX, BY, BZ);
-  else mk_F_m_body<false, false>(q.F, q.r, q.klen, q.umax, BX, BY, BZ);
+  if (touch) mk_F_m_body<true, INL, false>(q.F, q.r, q.klen, q.umax, BX, BY, BZ);
+  else mk_F_m_body<false, false, false>(q.F, q.r, q.klen, q.umax, BX, BY, BZ);
 }
 // k-chunks of a box in the batched launch: the boxes of a level fill the device together, so a box is cut only when it is tall
 static void fused_grid_small(const Range3 &r, int &klen, int g[3]) {
@@ -1298,12 +1355,15 @@ void k_slope(const vdn_multifab *s, vdn_multifab *slope, int dir, int bccomp, co
   }
 }
 
-void k_mkflux(const vdn_multifab *s, vdn_multifab **sedge, vdn_multifab **flux, vdn_multifab **umac,
+// upd: the caller would run update_3d on the result next (one level): where the fused march is taken -- a level of one box -- the update of
+// every component runs inside it, sedge / flux stay unwritten and the call returns true; otherwise false and the caller updates as usual
+bool k_mkflux(const vdn_multifab *s, vdn_multifab **sedge, vdn_multifab **flux, vdn_multifab **umac,
               const vdn_multifab *force, const vdn_multifab *mac_rhs, const double *dx, double dt,
-              const vdn_bc_tower *bct, bool is_vel, const int *is_cons) {
+              const vdn_bc_tower *bct, bool is_vel, const int *is_cons, const MkUpdate *upd) {
   Prof prof_("mkflux");
   god_xcd_init();
-  if (ctx().prm.dm == 2) { k2_mkflux(s, sedge, flux, umac, force, mac_rhs, dx, dt, bct, is_vel, is_cons); return; }
+  if (ctx().prm.dm == 2) { k2_mkflux(s, sedge, flux, umac, force, mac_rhs, dx, dt, bct, is_vel, is_cons); return false; }
+  bool updated = false;
   const int ncomp = s->nc;
   REQUIRE(ncomp <= 3, "mkflux: at most 3 components per call (got %d)", ncomp);
   REQUIRE(s->ng >= 3 && umac[0]->ng >= 1 && force->ng >= 1 && mac_rhs->ng >= 1, "mkflux: ghost widths");
@@ -1360,7 +1420,7 @@ void k_mkflux(const vdn_multifab *s, vdn_multifab **sedge, vdn_multifab **flux, 
         if (inflow) hipLaunchKernelGGL(kk_mk_F_mb<true>, dim3(tot), blk, 0, st, dd, ds, (int)fd.size());
         else hipLaunchKernelGGL(kk_mk_F_mb<false>, dim3(tot), blk, 0, st, dd, ds, (int)fd.size());
         arena_release(mark);
-        return;
+        return false;
       }
     }
     static const int split_env = getenv("VDN_MK_SPLIT") ? atoi(getenv("VDN_MK_SPLIT")) : -1;
@@ -1375,7 +1435,7 @@ void k_mkflux(const vdn_multifab *s, vdn_multifab **sedge, vdn_multifab **flux, 
     MKB_STAGE(kk_mk_D_mb, 3, 2)
     #undef MKB_STAGE
     arena_release(mark);
-    return;
+    return false;
   }
   for (int ib = 0; ib < s->nfabs(); ib++) {
     size_t mark = arena_mark();
@@ -1433,6 +1493,9 @@ void k_mkflux(const vdn_multifab *s, vdn_multifab **sedge, vdn_multifab **flux, 
       for (int c0 = 0; c0 < ncomp && fused; c0++)
         fused = fused_args(FA[c0], A, c0, s->fabs[ib], sl, um, vm, wm, force->fabs[ib], mac_rhs->fabs[ib], sedge[0]->fabs[ib], sedge[1]->fabs[ib], sedge[2]->fabs[ib],
                            flux[0]->fabs[ib], flux[1]->fabs[ib], flux[2]->fabs[ib]);
+      static const bool upd_env = !(getenv("VDN_GOD_UPDATE") && atoi(getenv("VDN_GOD_UPDATE")) == 0);
+      bool do_upd = fused && upd && upd_env && s->nfabs() == 1;
+      for (int c0 = 0; c0 < ncomp && do_upd; c0++) do_upd = fused_update_args(FA[c0], A, c0, upd->snew->fabs[ib], force->fabs[ib], *upd, ib);
       if (fused) {                 // stages B + C + D in one march per component, boundary rules inside (see mk_F_m_body)
         int klF;
         const dim3 gF = fused_grid(rf, klF);
@@ -1441,10 +1504,17 @@ void k_mkflux(const vdn_multifab *s, vdn_multifab **sedge, vdn_multifab **flux, 
           for (int d = 0; d < 3; d++) inflow = inflow || A.phys[d][0] == VDN_INLET || A.phys[d][1] == VDN_INLET;
           bool any = false;
           for (int d = 0; d < 3; d++) for (int sd = 0; sd < 2; sd++) any = any || bc_mode_host(A.phys[d][sd]);
+          if (do_upd) {
+            if (!any) hipLaunchKernelGGL((kk_mk_F_m<false, false, true>), gF, blk, 0, st, FA[c0], rf, klF, umax);
+            else if (inflow) hipLaunchKernelGGL((kk_mk_F_m<true, true, true>), gF, blk, 0, st, FA[c0], rf, klF, umax);
+            else hipLaunchKernelGGL((kk_mk_F_m<true, false, true>), gF, blk, 0, st, FA[c0], rf, klF, umax);
+            continue;
+          }
           if (!any) hipLaunchKernelGGL((kk_mk_F_m<false, false>), gF, blk, 0, st, FA[c0], rf, klF, umax);      // no physical face on this box
           else if (inflow) hipLaunchKernelGGL((kk_mk_F_m<true, true>), gF, blk, 0, st, FA[c0], rf, klF, umax);
           else hipLaunchKernelGGL((kk_mk_F_m<true, false>), gF, blk, 0, st, FA[c0], rf, klF, umax);
         }
+        updated = do_upd;
       } else if (slab_bc()) {      // interior marches, then the face-centred code on the boundary slabs (see kk_slabs)
         const MkPlain P{ s->fabs[ib], sl[0], sl[1], sl[2], um, vm, wm, force->fabs[ib], mac_rhs->fabs[ib], SI, SC,
                          sedge[0]->fabs[ib], sedge[1]->fabs[ib], sedge[2]->fabs[ib], flux[0]->fabs[ib], flux[1]->fabs[ib], flux[2]->fabs[ib], A, umax };
@@ -1468,6 +1538,7 @@ void k_mkflux(const vdn_multifab *s, vdn_multifab **sedge, vdn_multifab **flux, 
     }
     arena_release(mark);
   }
+  return updated;
 }
 
 // ====================================================================================================

@@ -198,9 +198,12 @@ void mf_restrict_and_fill(vdn_multifab *mf, int icomp, int bcomp, int nc, bool s
 // godunov.hip
 void k_velpred(const vdn_multifab *u, vdn_multifab **umac, const vdn_multifab *force, const double *dx, double dt,
                const vdn_bc_tower *bct);
-void k_mkflux(const vdn_multifab *s, vdn_multifab **sedge, vdn_multifab **flux, vdn_multifab **umac,
+// k_mkflux with the update that follows it inside the same march (godunov.hip, UPD): snew and the update's forcing term -- fmode 0: the
+// force multifab of the call; fmode 1: ext + (lapu0 - gp) / rho formed in place (mkvelforce on a valid cell, no lapu array)
+struct MkUpdate { vdn_multifab *snew = nullptr; int fmode = 0; const vdn_multifab *ext = nullptr, *gp = nullptr, *rho = nullptr; double lapu0 = 0.0; };
+bool k_mkflux(const vdn_multifab *s, vdn_multifab **sedge, vdn_multifab **flux, vdn_multifab **umac,
               const vdn_multifab *force, const vdn_multifab *mac_rhs, const double *dx, double dt,
-              const vdn_bc_tower *bct, bool is_vel, const int *is_cons);
+              const vdn_bc_tower *bct, bool is_vel, const int *is_cons, const MkUpdate *upd = nullptr);
 void k_slope(const vdn_multifab *s, vdn_multifab *slope, int dir, int bccomp, const vdn_bc_tower *bct);
 // pointwise.hip
 void k_update_velforce(const vdn_multifab *uold, vdn_multifab **umac, vdn_multifab **uedge, const vdn_multifab *ext, const vdn_multifab *s,
