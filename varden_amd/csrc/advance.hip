@@ -123,8 +123,10 @@ extern "C" int vdn_advance_timestep(int istep, vdn_layout *mla, vdn_multifab **s
     }
     for (int n = 0; n < nlevs; n++) {
       scal_force[n] = mf_temp(mla, n, nscal, 1, -1, false, 0.0);
-      divu[n] = mf_temp(mla, n, 1, 1, -1, true, 0.0);
-      for (int d = 0; d < dm; d++) { sflux[3 * n + d] = mf_temp(mla, n, nscal, 0, d, true, 0.0); sedge[3 * n + d] = mf_temp(mla, n, nscal, 0, d, false, 0.0); }   // mkflux writes every edge state
+      divu[n] = mac_rhs[n];                            // scalar_advance.f90:63,102 passes a zero divu as mac_rhs: the step's mac_rhs is that zero field (same shape)
+      // mkflux writes every edge state; the fluxes of non-conservative components are never written NOR read on one level (a hierarchy
+      // restricts all components of the flux multifab, so there they are zeroed as the reference's setval does)
+      for (int d = 0; d < dm; d++) { sflux[3 * n + d] = mf_temp(mla, n, nscal, 0, d, nlevs > 1, 0.0); sedge[3 * n + d] = mf_temp(mla, n, nscal, 0, d, false, 0.0); }
       k_mkscalforce(scal_force[n], ext_scal_force[n], laps[n], 1.0);
     }
     restrict_and_fill(nlevs, scal_force, 0, bct->extrap_comp0(), nscal, true, bct);     // mkforce.f90:283-284
