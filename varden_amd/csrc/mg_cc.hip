@@ -1836,6 +1836,7 @@ DEVI double phi_closed(const FV &phi, const UmacArgs &A, int i, int j, int k) {
   return fv_get(phi, i, j, k);
 }
 struct mkumac_rho_K { FV um; FV vm; FV wm; FV phi; FV rho; UmacArgs A;
+  static constexpr bool in_constant = true;       // phi_closed walks A.ebc / A.lo / A.hi: a by-value copy in a batched launch lands in scratch
   __device__ void cell(int i, int j, int k) const {
     const double p0 = phi_closed(phi, A, i, j, k);
     const double r0 = fv_get(rho, i, j, k);

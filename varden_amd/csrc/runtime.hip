@@ -683,6 +683,7 @@ __global__ void k_physbc_multi(FV f, PhysMulti M) {
 }
 // all faces of one direction on every box and component of a level in one launch: the batch runs over (t1, t2, 0)
 struct PhysB { Range3 r; int g[3]; FV f; PhysArgs A;
+  static constexpr bool in_constant = true;       // PhysArgs is indexed by direction / side: by value it went to scratch (168 bytes per lane)
   static __device__ double body(const PhysB &q, int i, int j, int, int) { physbc_cell(q.f, q.A, i, j); return 0.0; } };
 
 static bool extdir_value(int icomp1, int d, int s, double *v) {

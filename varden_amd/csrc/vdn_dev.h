@@ -92,6 +92,11 @@ template <class T> DEVI const T &as_constant(const T *p) {
   typedef const T __attribute__((address_space(4))) *CP;
   return *(const T *)(CP)p;
 }
+// where a batched kernel keeps its descriptor: by value in registers (small ones) or read through the constant address space.  A descriptor may
+// say so itself (`static constexpr bool in_constant`): one that is indexed dynamically (arrays of boundary codes walked in a loop) goes to
+// SCRATCH when it is copied by value -- mkumac_rho_K, 310 bytes: 320 bytes of scratch per lane, 19 ms instead of 2.3 ms per 8-box launch
+template <class T, class = void> struct desc_in_constant : std::integral_constant<bool, (sizeof(T) > 320)> {};
+template <class T> struct desc_in_constant<T, std::void_t<decltype(T::in_constant)>> : std::integral_constant<bool, T::in_constant> {};
 template <class A, class P>
 __global__ void __launch_bounds__(256) kk_batched(const A *args, const int *start, int nbox, P extra, double *nrm) {
   int lo = 0, hi = nbox - 1;
@@ -99,7 +104,7 @@ __global__ void __launch_bounds__(256) kk_batched(const A *args, const int *star
   while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (as_constant(start + mid) <= bid) lo = mid; else hi = mid - 1; }
   // small descriptors are copied into registers (kernels that loop over k re-read a constant-space one every plane: NdfNegB 106 -> 151 us),
   // large ones stay in constant space (a by-value copy of UpdateB lands in 632 bytes of scratch: 3.8 ms -> 0.5 ms)
-  typename std::conditional<(sizeof(A) <= 320), const A, const A &>::type a = as_constant(args + lo);
+  typename std::conditional<!desc_in_constant<A>::value, const A, const A &>::type a = as_constant(args + lo);
   const int lb = bid - as_constant(start + lo);
   const int bx = lb % a.g[0], by = (lb / a.g[0]) % a.g[1], bz = lb / (a.g[0] * a.g[1]);
   // tile of the 256 threads: 64 x 4, 32 x 8 or 16 x 16 by the width of the box (a level of an adaptive hierarchy is full of 16- and
@@ -180,6 +185,7 @@ template <class K> __global__ void __launch_bounds__(256) kk_cell(K a, Range3 r)
   a.cell(i, j, k);
 }
 template <class K> struct CellB { Range3 r; int g[3]; K a;
+  static constexpr bool in_constant = desc_in_constant<K>::value || sizeof(K) + sizeof(Range3) + 3 * sizeof(int) > 320;
   static __device__ double body(const CellB &q, int i, int j, int k, int) { q.a.cell(i, j, k); return 0.0; } };
 template <class K> static inline void launch_cells(const std::vector<std::pair<K, Range3>> &v, hipStream_t st) {
   if (v.empty()) return;
