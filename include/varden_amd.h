@@ -72,6 +72,9 @@ typedef struct vdn_params {
   double hg_rel_eps;              /* <=0: use 1e-12/1e-11/1e-10 by nlevs, hgproject.f90:113-119 */
   int    abort_on_max_iter;       /* 1 (default): a solve that reaches its iteration cap or meets a non-finite norm fails the call,
                                    * as FBoxLib's solvers abort (bl_error); 0: report through vdn_last_solver_stats and go on */
+  int    hg_fmg;                  /* 1 (default): a nodal solve that starts from phi = 0 takes its initial guess from a nested iteration
+                                   * (right-hand side restricted down, one V-cycle per level on the way up): two V-cycles fewer at 1e-12;
+                                   * 0: V-cycles from the zero guess (rounds 1 and 2)                                              */
 } vdn_params;
 
 /* fills *p with the reference defaults (src/_parameters) */

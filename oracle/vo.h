@@ -164,7 +164,7 @@ void vo_hg_update(int proj_type, vo_fab *unew, const vo_fab *uold, vo_fab *gp, c
 void vo_nd_divu(const vo_fab *u, vo_fab *rh, const double dx[3], const int ellbc[3][2]);
 int  vo_nd_solve(vo_fab *rh, vo_fab *phi, const vo_fab *coeffs, const vo_fab *u, const double dx[3],
                  const int ellbc[3][2], const int pmask[3], double rel_eps, double abs_eps, int max_iter,
-                 int nu1, int nu2, int nub, double omega, vo_mgstat *st);
+                 int nu1, int nu2, int nub, double omega, int fmg, vo_mgstat *st);
 /* hgproject.f90:17-178 + hg_multigrid.f90:18-119, single level */
 void vo_hgproject(int proj_type, vo_fab *unew, const vo_fab *uold, vo_fab *rhohalf, vo_fab *p, vo_fab *gp,
                   const double dx[3], double dt, const vo_bc *bc, const int pmask[3], const vdn_params *prm,

@@ -656,20 +656,30 @@ struct nd_divu_K { FV u; FV rh; double fx; double fy; double fz;
     nd_divu_node(u, rh, fx, fy, fz, i, j, k);
   } };
 
+// nrm[0] = max |rhs|, nrm[1] = max |phi| of the initial guess (zero: the solve may start from a nested iteration, nd_fmg)
 __global__ void kk_nd_load(NLev L, FV rh, FV phi, int lo0, int lo1, int lo2, double *nrm) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   const int j = blockIdx.y * blockDim.y + threadIdx.y;
-  double rmax = 0.0;
+  double rmax = 0.0, pmax = 0.0;
   if (i <= L.n[0] && j <= L.n[1])
     for (int k = blockIdx.z; k <= L.n[2]; k += gridDim.z) {
       const bool dir = nd_is_dir(L, i, j, k);
       const double r = dir ? 0.0 : fv_get(rh, lo0 + i, lo1 + j, lo2 + k);
       const long c = nidx(L, i, j, k);
+      const double p0 = dir ? 0.0 : fv_get(phi, lo0 + i, lo1 + j, lo2 + k);
       L.b[c] = -r;
-      L.phi[c] = dir ? 0.0 : fv_get(phi, lo0 + i, lo1 + j, lo2 + k);
-      rmax = nmax(rmax, fabs(r));
+      L.phi[c] = p0;
+      rmax = nmax(rmax, fabs(r)); pmax = nmax(pmax, fabs(p0));
     }
   block_atomic_max(nrm, rmax);
+  block_atomic_max(nrm + 1, pmax);
+}
+// res := b on the nodes of the level (the carrier of the right-hand side's restriction, nd_fmg)
+__global__ void kk_nd_copy_b_res(NLev L) {
+  NODE_IJK(L)
+  if (!in_range) return;
+  const long c = nidx(L, i, j, k);
+  L.res[c] = L.b[c];
 }
 __global__ void kk_nd_store(NLev L, FV phi, int lo0, int lo1, int lo2) {
   const int i = (int)(blockIdx.x * blockDim.x + threadIdx.x) - 1;
@@ -1156,6 +1166,72 @@ static void nd_vcycle_d(NDMG &M, int l) {
   nd_prolong_up(M, l);
   nd_jacobi_d(DL, P.hg_nu2);
 }
+// ---- nested iteration for the initial guess (round 3; vdn_params.hg_fmg; the algorithm is stated with vo_nd_solve in oracle/vo_hgproject.c) ----
+// Only for a solve that starts from phi = 0.  Levels are counted globally: the distributed ones, then the replicated tail.  The right-hand side
+// travels down through the residual arrays (res := b, halo, the cycle's own restriction -- which also zeroes the coarse phi), the coarsest level
+// with more than 9^3 nodes gets two V-cycles from zero, every level above it the interpolated solution of the level below and, except the
+// finest, one V-cycle.  Launched eagerly, once per solve (~0.2 of a fine-level cycle); the V-cycles that follow are the replayed graphs.
+static long nd_level_nodes(const NDMG &M, int g) {
+  const int nd = (int)M.dlev.size();
+  if (g < nd) return (long)(M.dlev[g].ng[0] + 1) * (M.dlev[g].ng[1] + 1) * (M.dlev[g].ng[2] + 1);
+  const NLev &T = M.tail[g - nd];
+  return (long)(T.n[0] + 1) * (T.n[1] + 1) * (T.n[2] + 1);
+}
+// one V-cycle on the phi a level holds (not the error equation: phi is NOT zeroed); level g > 0 with a level below it
+static void nd_cycle_at(NDMG &M, int g) {
+  const vdn_params &P = ctx().prm;
+  const int nd = (int)M.dlev.size();
+  if (g < nd) {
+    nd_jacobi_d(M.dlev[g], P.hg_nu1);
+    nd_residual_d(M, M.dlev[g], false);
+    nd_restrict_down(M, g);
+    if (g + 1 < nd) nd_vcycle_d(M, g + 1); else nd_vcycle_t(M, 0);
+    nd_prolong_up(M, g);
+    nd_jacobi_d(M.dlev[g], P.hg_nu2);
+    return;
+  }
+  const int t = g - nd;
+  nd_jacobi_t(M.tail[t], P.hg_nu1);
+  NLev &L = M.tail[t]; NLev &C = M.tail[t + 1];
+  nd_fill_nodes(L, L.phi);
+  nd_launch_march<1>(L, L.phi, L.res, nullptr);
+  nd_fill_nodes(L, L.res);
+  hipLaunchKernelGGL(kk_nd_restrict, ng3(C.n[0] + 1, C.n[1] + 1, C.n[2] + 1), NBLK, 0, ctx().stream, L, C);
+  nd_vcycle_t(M, t + 1);
+  nd_fill_nodes(M.tail[t + 1], M.tail[t + 1].phi);
+  nd_launch_prolong(M.tail[t], M.tail[t + 1], 0, 0, 0);
+  nd_jacobi_t(M.tail[t], P.hg_nu2);
+}
+static void nd_fmg(NDMG &M) {
+  const int nd = (int)M.dlev.size(), ntot = nd + (int)M.tail.size();
+  int ls = -1;
+  for (int g = 1; g < ntot; g++) if (nd_level_nodes(M, g) > 729) ls = g;
+  if (ls < 1 || ls + 1 >= ntot) return;                 // (a starting level with nothing below it: no nested iteration)
+  hipStream_t st = ctx().stream;
+  for (int g = 0; g < ls; g++) {                         // b_{g+1} = R b_g
+    if (g < nd) {
+      NDLev &DL = M.dlev[g];
+      for (NBox &B : DL.boxes) hipLaunchKernelGGL(kk_nd_copy_b_res, ng3(B.L.n[0] + 1, B.L.n[1] + 1, B.L.n[2] + 1), NBLK, 0, st, B.L);
+      if (DL.halo_res) xplan_run(DL.halo_res);
+      nd_restrict_down(M, g);
+      if (g + 1 == nd) HIPCHK(hipMemsetAsync(M.tail[0].phi, 0, sizeof(double) * M.tail[0].sz, st));      // (the gather fills b only)
+    } else {
+      NLev &L = M.tail[g - nd]; NLev &C = M.tail[g - nd + 1];
+      hipLaunchKernelGGL(kk_nd_copy_b_res, ng3(L.n[0] + 1, L.n[1] + 1, L.n[2] + 1), NBLK, 0, st, L);
+      nd_fill_nodes(L, L.res);
+      hipLaunchKernelGGL(kk_nd_restrict, ng3(C.n[0] + 1, C.n[1] + 1, C.n[2] + 1), NBLK, 0, st, L, C);
+    }
+  }
+  if (ls < nd) nd_vcycle_d(M, ls); else nd_vcycle_t(M, ls - nd);      // from zero
+  for (int g = ls; g >= 0; g--) {
+    if (g < ls) {                                        // the interpolated solution of the level below (phi_g is zero: the restriction left it so)
+      if (g < nd) nd_prolong_up(M, g);
+      else { nd_fill_nodes(M.tail[g - nd + 1], M.tail[g - nd + 1].phi); nd_launch_prolong(M.tail[g - nd], M.tail[g - nd + 1], 0, 0, 0); }
+    }
+    if (g > 0) nd_cycle_at(M, g);
+  }
+}
+
 // ---- one cycle as a hipGraph (see mg_cc.hip) ----------------------------------------------------------------------------------------
 // The Jacobi sweeps ping-pong phi / tmp on the host side, so a cycle changes the host state: the cache keeps, next to the graph, the
 // state the body left behind (a function of the state it started from, which the key hashes), and a replay installs it.
@@ -1263,7 +1339,7 @@ int nd_solve(vdn_multifab *rh, vdn_multifab *phi, const vdn_multifab *coeffs, co
     }
     launch_cells(v, st);
   }
-  HIPCHK(hipMemsetAsync(M.d_nrm, 0, sizeof(double), st));
+  HIPCHK(hipMemsetAsync(M.d_nrm, 0, 2 * sizeof(double), st));
   for (size_t b = 0; b < D0.boxes.size(); b++) {
     NLev &L0 = D0.boxes[b].L; const vdn_box &bx = coeffs->vbox[b];
     if (fast) {
@@ -1273,7 +1349,7 @@ int nd_solve(vdn_multifab *rh, vdn_multifab *phi, const vdn_multifab *coeffs, co
     } else
     hipLaunchKernelGGL(kk_nd_load, ng3(L0.n[0] + 1, L0.n[1] + 1, std::min(L0.n[2] + 1, 16)), NBLK, 0, st, L0, rh->fabs[b], phi->fabs[b], bx.lo[0], bx.lo[1], bx.lo[2], M.d_nrm);
   }
-  comm_allreduce_max_dev(M.d_nrm, 1);
+  comm_allreduce_max_dev(M.d_nrm, 2);
   {   // VDN_ND_BENCH=n (probe): time n Jacobi sweeps of the finest level here, print the mean, then solve as usual (the sweeps only improve phi)
     static const int nbench = getenv("VDN_ND_BENCH") ? atoi(getenv("VDN_ND_BENCH")) : 0;
     if (nbench > 0) {
@@ -1291,8 +1367,10 @@ int nd_solve(vdn_multifab *rh, vdn_multifab *phi, const vdn_multifab *coeffs, co
   }
   const bool single = (M.dlev.size() == 1 && M.tail.empty());
   const bool fixed_cycles = max_iter < 0;     // exactly -max_iter V-cycles, no norms, no convergence test (composite coarse correction)
-  const double bnorm = fixed_cycles ? 1.0 : nd_read(M.d_nrm);
+  double bnorm = 1.0, p0max = 1.0;
+  if (!fixed_cycles) { const double *sc = read_scalars(M.d_nrm, 2); bnorm = sc[0]; p0max = sc[1]; }
   int cyc = 0; bool conv = (bnorm == 0.0); double rn = 0.0;
+  if (P.hg_fmg && !fixed_cycles && !conv && !single && p0max == 0.0 && bnorm < HUGE_VAL) nd_fmg(M);
   for (int c = 0; fixed_cycles && c < -max_iter; c++) {
     if (single) { nd_jacobi_d(M.dlev[0], nd_bottom_sweeps_global(M.dlev[0])); continue; }
     nd_run_cycle(M, 2, [&] {
