@@ -436,8 +436,9 @@ int vo_nd_solve(vo_fab *rh, vo_fab *phi, const vo_fab *coeffs, const vo_fab *u, 
    * hundred unknowns -- gets TWO V-cycles from zero, and every level above it takes the interpolated solution of the level below (the
    * prolongation of the cycle) and, except the finest, one V-cycle of its own.  The V-cycles that follow start from an error at truncation
    * level instead of 100 %: 13 -> 11 cycles to 1e-12 at 64^3 (12 with one cycle on the starting level), for the price of ~0.2 of a
-   * fine-level cycle.  Three dimensions only. */
-  if (fmg && dm == 3 && M.nlev > 1 && max_iter >= 0 && !conv) {
+   * fine-level cycle.  Three dimensions only.  fmg = 1: only with a convergence test (max_iter >= 0); fmg = 2: also before a fixed number of
+   * cycles (the first coarse correction of the composite solve). */
+  if (fmg && dm == 3 && M.nlev > 1 && (max_iter >= 0 || fmg == 2) && !conv) {
     int zero = 1;
     for (int k = 0; k <= n0[2] && zero; k++) for (int j = 0; j <= n0[1] && zero; j++) for (int i = 0; i <= n0[0]; i++)
       if (L0->phi[NN(L0, i, j, k)] != 0.0) { zero = 0; break; }
@@ -734,7 +735,10 @@ int vo_ml_nd_solve(int nlev, vo_fab **rh, vo_fab **phi, vo_fab **coeffs, vo_fab 
     for (int k = 0; k <= Cc->n[2]; k++) for (int j = 0; j <= Cc->n[1]; j++) for (int i = 0; i <= Cc->n[0]; i++)
       VF(&er, er.lo[0] + i, er.lo[1] + j, er.lo[2] + k, 0) = -Cc->res[NN(Cc, i, j, k)];
     vo_mgstat cs;
-    vo_nd_solve(&er, &ee, coeffs[0], NULL, dx, ellbc[0], pmask, 0.0, -1.0, -1, prm->hg_nu1, prm->hg_nu2, prm->hg_nub, prm->hg_omega, 0, &cs);
+    /* (the first correction solve starts from the nested iteration of vo_nd_solve when hg_fmg is set: 13 -> 10 FAC iterations on the
+     * refined bubble, base 64^3) */
+    vo_nd_solve(&er, &ee, coeffs[0], NULL, dx, ellbc[0], pmask, 0.0, -1.0, -1, prm->hg_nu1, prm->hg_nu2, prm->hg_nub, prm->hg_omega,
+                (it == 0 && prm->hg_fmg) ? 2 : 0, &cs);
     for (int k = 0; k <= Cc->n[2]; k++) for (int j = 0; j <= Cc->n[1]; j++) for (int i = 0; i <= Cc->n[0]; i++)
       scratch[0][NN(Cc, i, j, k)] = VF(&ee, ee.lo[0] + i, ee.lo[1] + j, ee.lo[2] + k, 0);
     ml_nd_apply_correction(&M, 0, scratch[0], scratch);

@@ -1281,7 +1281,7 @@ void nd_keep_free(NdKeep *k) { delete k; }
 // from fast->rhohalf (coeffs may be null), and instead of storing phi into a multifab the call returns views of the finest level's phi
 // (ghost nodes exchanged) in fast->phi_view; the level arrays then stay allocated: the CALLER releases the arena (mark taken before the call)
 int nd_solve(vdn_multifab *rh, vdn_multifab *phi, const vdn_multifab *coeffs, const vdn_multifab *u, const double *dx,
-             const int bc[3][2], double rel_eps, double abs_eps, int max_iter, int *cycles, double *res0, double *res, NdKeep *keep, NdFast *fast) {
+             const int bc[3][2], double rel_eps, double abs_eps, int max_iter, int *cycles, double *res0, double *res, NdKeep *keep, NdFast *fast, bool fmg_start) {
   Prof prof_("hg_multigrid");
   if (ctx().prm.dm == 2) return nd2_solve(rh, phi, coeffs, u, dx, bc, rel_eps, abs_eps, max_iter, cycles, res0, res);
   const vdn_params &P = ctx().prm;
@@ -1370,7 +1370,7 @@ int nd_solve(vdn_multifab *rh, vdn_multifab *phi, const vdn_multifab *coeffs, co
   double bnorm = 1.0, p0max = 1.0;
   if (!fixed_cycles) { const double *sc = read_scalars(M.d_nrm, 2); bnorm = sc[0]; p0max = sc[1]; }
   int cyc = 0; bool conv = (bnorm == 0.0); double rn = 0.0;
-  if (P.hg_fmg && !fixed_cycles && !conv && !single && p0max == 0.0 && bnorm < HUGE_VAL) nd_fmg(M);
+  if (P.hg_fmg && !conv && !single && (fixed_cycles ? fmg_start : (p0max == 0.0 && bnorm < HUGE_VAL))) nd_fmg(M);
   for (int c = 0; fixed_cycles && c < -max_iter; c++) {
     if (single) { nd_jacobi_d(M.dlev[0], nd_bottom_sweeps_global(M.dlev[0])); continue; }
     nd_run_cycle(M, 2, [&] {
@@ -2084,7 +2084,7 @@ static int ml_nd_solve(vdn_layout *la, vdn_multifab **rh, vdn_multifab **phi, vd
       launch_batched(v, 0, (double *)nullptr, 0, st);
     }
     int cyc; double r0, rr;
-    nd_solve(er, ee, coeffs[0], nullptr, dx, ebc0, 0.0, -1.0, -1, &cyc, &r0, &rr, &coarse_keep);
+    nd_solve(er, ee, coeffs[0], nullptr, dx, ebc0, 0.0, -1.0, -1, &cyc, &r0, &rr, &coarse_keep, nullptr, it == 0);     // (first correction: from the nested iteration, hg_fmg)
     ml_nd_apply_correction(S, 0, ee);
     // relaxation of K_n e = r_n on the finer levels, coarsest first, with the interface fixed
     for (int n = 1; n < L; n++) {
