@@ -75,6 +75,9 @@ typedef struct vdn_params {
   int    hg_fmg;                  /* 1 (default): a nodal solve that starts from phi = 0 takes its initial guess from a nested iteration
                                    * (right-hand side restricted down, one V-cycle per level on the way up): two V-cycles fewer at 1e-12;
                                    * 0: V-cycles from the zero guess (rounds 1 and 2)                                              */
+  int    mac_fmg;                 /* 1 (default): the same for the cell-centred solve of the MAC projection (whose phi starts from zero):
+                                   * right-hand side averaged down to the coarsest level of at least 16^3 cells, two V-cycles there, then
+                                   * per level a linear interpolation of the solution and one V-cycle; one V-cycle fewer at 1e-10; 0: off */
 } vdn_params;
 
 /* fills *p with the reference defaults (src/_parameters) */

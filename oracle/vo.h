@@ -130,9 +130,9 @@ void vo_mkumac(vo_fab *umac[3], const vo_fab *phi, vo_fab *beta[3], const double
 /* our cell-centred multigrid (replaces FBoxLib ml_cc_solve, mac_multigrid.f90:53) */
 typedef struct vo_mgstat { int cycles; double res0, res; } vo_mgstat;
 int  vo_cc_solve(const vo_fab *rh, vo_fab *phi, vo_fab *beta[3], const double dx[3], const int ellbc[3][2],
-                 double rel_eps, double abs_eps, int max_iter, int nu1, int nu2, int nub, vo_mgstat *st);
+                 double rel_eps, double abs_eps, int max_iter, int nu1, int nu2, int nub, int fmg, vo_mgstat *st);
 int  vo_cc_solve_ab(const vo_fab *rh, vo_fab *phi, const vo_fab *alpha, vo_fab *beta[3], const double dx[3], const int ellbc[3][2],
-                    double rel_eps, double abs_eps, int max_iter, int nu1, int nu2, int nub, vo_mgstat *st);
+                    double rel_eps, double abs_eps, int max_iter, int nu1, int nu2, int nub, int fmg, vo_mgstat *st);
 /* explicit_diffusive_term.f90:16-88 = FBoxLib cc_applyop with alpha = 0, beta = -1: out(comp) = laplacian(data(comp)) with the
  * ell bc of bc component bccomp; Dirichlet faces use the ghost-cell value as the face value */
 void vo_explicit_diffusive_term(vo_fab *lap, const vo_fab *data, int comp, int bccomp, const double dx[3], const vo_bc *bc);

@@ -369,7 +369,7 @@ void vo2_macproject(vo_fab *umac[2], vo_fab *rho, const vo_fab *mac_rhs, const d
   for (int j = lo[1]; j <= hi[1]; j++) for (int i = lo[0]; i <= hi[0] + 1; i++) V2(&beta[0], i, j, 0) = 2.0 / (V2(rho, i, j, 0) + V2(rho, i - 1, j, 0));
   for (int j = lo[1]; j <= hi[1] + 1; j++) for (int i = lo[0]; i <= hi[0]; i++) V2(&beta[1], i, j, 0) = 2.0 / (V2(rho, i, j, 0) + V2(rho, i, j - 1, 0));
   double dx3[3] = { dx[0], dx[1], 1.0 };
-  vo_cc_solve_ab(&rh, &phi, NULL, bp, dx3, ellbc, prm->mac_rel_eps, -1.0, prm->mg_max_iter, prm->mg_nu1, prm->mg_nu2, prm->mg_nub, st);
+  vo_cc_solve_ab(&rh, &phi, NULL, bp, dx3, ellbc, prm->mac_rel_eps, -1.0, prm->mg_max_iter, prm->mg_nu1, prm->mg_nu2, prm->mg_nub, 0, st);
   /* mkumac_2d with the solver's ghost closure (see vo_mkumac) */
   for (int j = lo[1]; j <= hi[1]; j++) for (int i = lo[0]; i <= hi[0] + 1; i++) {
     int side = fside(i, lo[0], hi[0]);
@@ -429,7 +429,7 @@ static void visc_solve2(vo_fab *unew, const vo_fab *lapu, const vo_fab *rho, con
     }
     int ellbc[3][2]; vo_mgstat st;
     for (int a = 0; a < 3; a++) for (int s = 0; s < 2; s++) ellbc[a][s] = a < 2 ? bc->ell[a][s][d] : VDN_BC_INT;
-    vo_cc_solve_ab(&rh, &phi, &alpha, bp, dx3, ellbc, 1.e-12, -1.0, prm->mg_max_iter, prm->mg_nu1, prm->mg_nu2, prm->mg_nub, &st);
+    vo_cc_solve_ab(&rh, &phi, &alpha, bp, dx3, ellbc, 1.e-12, -1.0, prm->mg_max_iter, prm->mg_nu1, prm->mg_nu2, prm->mg_nub, 0, &st);
     for (int j = lo[1]; j <= hi[1]; j++) for (int i = lo[0]; i <= hi[0]; i++) V2(unew, i, j, d) = V2(&phi, i, j, 0);
   }
   vo_fill_boundary(unew, pmask);
@@ -452,7 +452,7 @@ static void diff_scalar_solve2(vo_fab *snew, const vo_fab *laps, const double dx
   int ellbc[3][2]; vo_mgstat st;
   for (int a = 0; a < 3; a++) for (int s = 0; s < 2; s++) ellbc[a][s] = a < 2 ? bc->ell[a][s][bccomp] : VDN_BC_INT;
   double dx3[3] = { dx[0], dx[1], 1.0 };
-  vo_cc_solve_ab(&rh, &phi, &alpha, bp, dx3, ellbc, 1.e-12, -1.0, prm->mg_max_iter, prm->mg_nu1, prm->mg_nu2, prm->mg_nub, &st);
+  vo_cc_solve_ab(&rh, &phi, &alpha, bp, dx3, ellbc, 1.e-12, -1.0, prm->mg_max_iter, prm->mg_nu1, prm->mg_nu2, prm->mg_nub, 0, &st);
   for (int j = lo[1]; j <= hi[1]; j++) for (int i = lo[0]; i <= hi[0]; i++) V2(snew, i, j, icomp) = V2(&phi, i, j, 0);
   vo_fill_boundary(snew, pmask);
   vo_physbc(snew, icomp, bccomp, 1, bc, prm);

@@ -370,7 +370,7 @@ int vo_ml_cc_solve(int nlev, vo_fab **rh, vo_fab **phi, vo_fab **alpha, vo_fab *
     /* coarse correction: ONE V-cycle of the single-level multigrid on the whole coarse level */
     memset(e[0].p, 0, sizeof(double) * vo_size(&e[0]));
     vo_mgstat cs;
-    vo_cc_solve_ab(&res[0], &e[0], alpha ? alpha[0] : NULL, beta, dx, ellbc[0], 0.0, -1.0, -1, prm->mg_nu1, prm->mg_nu2, prm->mg_nub, &cs);
+    vo_cc_solve_ab(&res[0], &e[0], alpha ? alpha[0] : NULL, beta, dx, ellbc[0], 0.0, -1.0, -1, prm->mg_nu1, prm->mg_nu2, prm->mg_nub, 0, &cs);     /* (a nested-iteration start of the FIRST correction saves no FAC iteration here: measured, 10 -> 10) */
     apply_correction(nlev, 0, phi, e, scr);
     for (int n = 1; n < nlev; n++) {                    /* post-relaxation, coarsest first */
       if (n < nlev - 1) (void)composite_residual(nlev, rh, phi, alpha, beta, dx, ellbc, pmask, pd, rp);

@@ -285,6 +285,70 @@ static void cc_vcycle(ccmg *M, int l, int nu1, int nu2, int nub)
   cc_gsrb(L, M->per, nu2);
 }
 
+/* ---- nested iteration for the initial guess (vdn_params.mac_fmg; round 3) --------------------------------------------------------------
+ * The right-hand side is averaged down the hierarchy (the residual's restriction), the coarsest level of at least 16^3 cells gets two V-cycles
+ * (the first from zero), and every level above it takes a LINEAR interpolation of the solution of the level below and, except the finest,
+ * one V-cycle of its own.  The V-cycles that follow start from an error at truncation level: 8 -> 7 cycles to 1e-10 at 64^3 and 128^3.
+ * The interpolation reads face neighbours only -- fine cell = (p0 + px + py + pz)/4 with px, py, pz the coarse neighbours on the fine
+ * cell's side: exact for linear functions like the tri-linear one (which saved the same cycle), and it needs no edge or corner ghost
+ * cells; the piecewise-constant prolongation of the V-cycle saves nothing here.  Three dimensions only. */
+static void cc_restrict_rh(const cclev *F, cclev *C)
+{
+  const int *n = C->n;
+  #pragma omp parallel for
+  for (int k = 0; k < n[2]; k++) for (int j = 0; j < n[1]; j++) for (int i = 0; i < n[0]; i++) {
+    int I = 2 * i, J = 2 * j, K = 2 * k;
+    double s = CC(F, F->rh, I, J, K) + CC(F, F->rh, I + 1, J, K) + CC(F, F->rh, I, J + 1, K) + CC(F, F->rh, I + 1, J + 1, K)
+             + CC(F, F->rh, I, J, K + 1) + CC(F, F->rh, I + 1, J, K + 1) + CC(F, F->rh, I, J + 1, K + 1) + CC(F, F->rh, I + 1, J + 1, K + 1);
+    CC(C, C->rh, i, j, k) = s * 0.125;
+  }
+}
+/* the coarse neighbour of cell q along d (off = -1 / +1) as the solver's boundary closure sees it: the periodic image, the cell itself at a
+ * Neumann face, minus the cell at a (homogeneous) Dirichlet face */
+static inline double cc_nbv(const cclev *C, int d, const int q[3], int off, const int per[3], const int ellbc[3][2])
+{
+  int m[3] = { q[0], q[1], q[2] }; m[d] += off;
+  if (m[d] < 0) { if (per[d]) m[d] += C->n[d]; else return ellbc[d][0] == VDN_BC_DIR ? -PHI(C, q[0], q[1], q[2]) : PHI(C, q[0], q[1], q[2]); }
+  else if (m[d] >= C->n[d]) { if (per[d]) m[d] -= C->n[d]; else return ellbc[d][1] == VDN_BC_DIR ? -PHI(C, q[0], q[1], q[2]) : PHI(C, q[0], q[1], q[2]); }
+  return PHI(C, m[0], m[1], m[2]);
+}
+static void cc_prolong_linear(cclev *F, const cclev *C, const int per[3], const int ellbc[3][2])
+{
+  const int *n = F->n;
+  #pragma omp parallel for
+  for (int k = 0; k < n[2]; k++) for (int j = 0; j < n[1]; j++) for (int i = 0; i < n[0]; i++) {
+    const int q[3] = { i >> 1, j >> 1, k >> 1 };
+    const double p0 = PHI(C, q[0], q[1], q[2]);
+    const double px = cc_nbv(C, 0, q, (i & 1) ? 1 : -1, per, ellbc), py = cc_nbv(C, 1, q, (j & 1) ? 1 : -1, per, ellbc), pz = cc_nbv(C, 2, q, (k & 1) ? 1 : -1, per, ellbc);
+    PHI(F, i, j, k) = 0.25 * (((p0 + px) + py) + pz);
+  }
+}
+static void cc_vcycle(ccmg *M, int l, int nu1, int nu2, int nub);
+/* one V-cycle at level l (with a level below it) on the level's own right-hand side, from the phi it holds */
+static void cc_cycle_at(ccmg *M, int l, int nu1, int nu2, int nub)
+{
+  cclev *L = &M->lev[l];
+  cc_gsrb(L, M->per, nu1);
+  (void)cc_residual(L, M->per);
+  cc_restrict(L, &M->lev[l + 1]);
+  cc_vcycle(M, l + 1, nu1, nu2, nub);
+  cc_prolong_add(L, &M->lev[l + 1]);
+  cc_gsrb(L, M->per, nu2);
+}
+static void cc_fmg(ccmg *M, const int ellbc[3][2], int nu1, int nu2, int nub)
+{
+  int ls = -1;
+  for (int l = 1; l < M->nlev; l++) if ((long)M->lev[l].n[0] * M->lev[l].n[1] * M->lev[l].n[2] >= 4096) ls = l;
+  if (ls < 1 || ls + 1 >= M->nlev) return;            /* (a starting level with nothing below it: no nested iteration) */
+  for (int l = 0; l < ls; l++) cc_restrict_rh(&M->lev[l], &M->lev[l + 1]);
+  cc_vcycle(M, ls, nu1, nu2, nub);                     /* from zero */
+  cc_cycle_at(M, ls, nu1, nu2, nub);
+  for (int l = ls - 1; l >= 0; l--) {
+    cc_prolong_linear(&M->lev[l], &M->lev[l + 1], M->per, ellbc);
+    if (l > 0) cc_cycle_at(M, l, nu1, nu2, nub);
+  }
+}
+
 /* Inhomogeneous Dirichlet data: the ghost cells of the incoming phi hold the boundary-FACE values (that is what
  * multifab_physbc's EXT_DIR fill leaves there, and how visc_solve hands unew to the solver, viscsolve.f90:270).
  * The face term 2 b (phi_i - phi_b)/h^2 is split: the phi_b part moves to the right-hand side here (order:
@@ -328,14 +392,15 @@ static void cc_store(cclev *L, vo_fab *phi, const int ellbc[3][2], const int per
 }
 
 int vo_cc_solve(const vo_fab *rh, vo_fab *phi, vo_fab *beta[3], const double dx[3], const int ellbc[3][2],
-                double rel_eps, double abs_eps, int max_iter, int nu1, int nu2, int nub, vo_mgstat *st)
+                double rel_eps, double abs_eps, int max_iter, int nu1, int nu2, int nub, int fmg, vo_mgstat *st)
 {
-  return vo_cc_solve_ab(rh, phi, NULL, beta, dx, ellbc, rel_eps, abs_eps, max_iter, nu1, nu2, nub, st);
+  return vo_cc_solve_ab(rh, phi, NULL, beta, dx, ellbc, rel_eps, abs_eps, max_iter, nu1, nu2, nub, fmg, st);
 }
 
-/* (alpha - div beta grad) phi = rh; alpha may be NULL (= 0).  Dirichlet data in phi's ghost cells. */
+/* (alpha - div beta grad) phi = rh; alpha may be NULL (= 0).  Dirichlet data in phi's ghost cells.
+ * fmg: nested iteration for the initial guess (cc_fmg) when phi comes in zero, ghost cells included, and max_iter >= 0 */
 int vo_cc_solve_ab(const vo_fab *rh, vo_fab *phi, const vo_fab *alpha, vo_fab *beta[3], const double dx[3], const int ellbc[3][2],
-                   double rel_eps, double abs_eps, int max_iter, int nu1, int nu2, int nub, vo_mgstat *st)
+                   double rel_eps, double abs_eps, int max_iter, int nu1, int nu2, int nub, int fmg, vo_mgstat *st)
 {
   ccmg M; ccmg_build(&M, alpha, beta, dx, ellbc);
   cclev *L0 = &M.lev[0];
@@ -344,6 +409,12 @@ int vo_cc_solve_ab(const vo_fab *rh, vo_fab *phi, const vo_fab *alpha, vo_fab *b
   for (int k = rh->lo[2]; k <= rh->hi[2]; k++) for (int j = rh->lo[1]; j <= rh->hi[1]; j++) for (int i = rh->lo[0]; i <= rh->hi[0]; i++)
     bnorm = fmax(bnorm, fabs(VF(rh, i, j, k, 0)));
   int cyc = 0, conv = 0; double rn = 0.0, r0 = -1.0;
+  if (fmg && L0->dm == 3 && M.nlev > 1 && bnorm != 0.0 && max_iter >= 0) {
+    int zero = 1;
+    for (int k = phi->lo[2] - 1; k <= phi->hi[2] + 1 && zero; k++) for (int j = phi->lo[1] - 1; j <= phi->hi[1] + 1 && zero; j++) for (int i = phi->lo[0] - 1; i <= phi->hi[0] + 1; i++)
+      if (VF(phi, i, j, k, 0) != 0.0) { zero = 0; break; }
+    if (zero) cc_fmg(&M, ellbc, nu1, nu2, nub);
+  }
   if (max_iter < 0) {            /* exactly -max_iter V-cycles, no convergence test (coarse correction of the composite solves) */
     for (int c = 0; c < -max_iter; c++) {
       if (M.nlev == 1) { cc_gsrb(L0, M.per, cc_bottom_sweeps(L0, nub)); continue; }
@@ -420,7 +491,7 @@ void vo_macproject(vo_fab *umac[3], vo_fab *rho, const vo_fab *mac_rhs, const do
     VF(&rh, i, j, k, 0) = VF(&rh, i, j, k, 0) * -1.0 + VF(mac_rhs, i, j, k, 0);
   vo_mk_mac_coeffs(rho, bp);
   /* rel = 1e-10, abs = -1 (macproject.f90:91-93) */
-  vo_cc_solve(&rh, &phi, bp, dx, ellbc, prm->mac_rel_eps, -1.0, prm->mg_max_iter, prm->mg_nu1, prm->mg_nu2, prm->mg_nub, st);
+  vo_cc_solve(&rh, &phi, bp, dx, ellbc, prm->mac_rel_eps, -1.0, prm->mg_max_iter, prm->mg_nu1, prm->mg_nu2, prm->mg_nub, prm->mac_fmg, st);
   vo_mkumac(umac, &phi, bp, dx, ellbc);
   for (int d = 0; d < 3; d++) vo_fill_boundary(umac[d], pmask);     /* macproject.f90:115-119 */
   free(rh.p); free(phi.p); for (int d = 0; d < 3; d++) free(beta[d].p);

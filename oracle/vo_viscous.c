@@ -67,7 +67,7 @@ void vo_visc_solve(vo_fab *unew, const vo_fab *lapu, const vo_fab *rho, const vo
     }
     int ellbc[3][2];
     for (int a = 0; a < 3; a++) for (int s = 0; s < 2; s++) ellbc[a][s] = bc->ell[a][s][d];
-    vo_cc_solve_ab(&rh, &phi, &alpha, bp, dx, ellbc, 1.e-12, -1.0, prm->mg_max_iter, prm->mg_nu1, prm->mg_nu2, prm->mg_nub, st);
+    vo_cc_solve_ab(&rh, &phi, &alpha, bp, dx, ellbc, 1.e-12, -1.0, prm->mg_max_iter, prm->mg_nu1, prm->mg_nu2, prm->mg_nub, 0, st);
     for (int k = lo[2]; k <= hi[2]; k++) for (int j = lo[1]; j <= hi[1]; j++) for (int i = lo[0]; i <= hi[0]; i++)
       VF(unew, i, j, k, d) = VF(&phi, i, j, k, 0);
   }
@@ -94,7 +94,7 @@ void vo_diff_scalar_solve(vo_fab *snew, const vo_fab *laps, const double dx[3], 
   }
   int ellbc[3][2];
   for (int a = 0; a < 3; a++) for (int s = 0; s < 2; s++) ellbc[a][s] = bc->ell[a][s][bccomp];
-  vo_cc_solve_ab(&rh, &phi, &alpha, bp, dx, ellbc, 1.e-12, -1.0, prm->mg_max_iter, prm->mg_nu1, prm->mg_nu2, prm->mg_nub, st);
+  vo_cc_solve_ab(&rh, &phi, &alpha, bp, dx, ellbc, 1.e-12, -1.0, prm->mg_max_iter, prm->mg_nu1, prm->mg_nu2, prm->mg_nub, 0, st);
   for (int k = lo[2]; k <= hi[2]; k++) for (int j = lo[1]; j <= hi[1]; j++) for (int i = lo[0]; i <= hi[0]; i++)
     VF(snew, i, j, k, icomp) = VF(&phi, i, j, k, 0);
   vo_fill_boundary(snew, pmask);                        /* viscsolve.f90:378-381 */

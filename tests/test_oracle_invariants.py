@@ -203,10 +203,43 @@ def test_cc_solver_reproduces_a_manufactured_solution():
         ell[d][0] = ell[d][1] = -1
     st = vo.CMgStat()
     rc = vo.lib().vo_cc_solve(rh.ref, phi.ref, vo.fab_ptr_array(beta), vo.dvec([1.0 / n] * 3), ell, C.c_double(1e-12), C.c_double(-1.0),
-                              100, 2, 2, 8, C.byref(st))
+                              100, 2, 2, 8, 0, C.byref(st))
     assert rc == 0
     got = phi.valid()[..., 0]
     assert np.abs((got - got.mean()) - (star - star.mean())).max() <= 1e-9
+
+
+@pytest.mark.parametrize("bcs", [(-1, -1, -1), (2, 2, 2), (1, 2, -1), (2, 1, 1)])
+def test_cc_nested_iteration_reaches_the_same_solution_in_fewer_cycles(bcs):
+    """vdn_params.mac_fmg: the nested-iteration start changes the iterates, not the equation -- same solution to the solver tolerance,
+    and never more V-cycles than from the zero guess (variable coefficients, periodic / Neumann / Dirichlet faces mixed)"""
+    n = 32
+    lo, hi = (0, 0, 0), (n - 1,) * 3
+    rng = np.random.default_rng(5)
+    x = (np.arange(n) + 0.5) / n
+    X, Y, Z = np.meshgrid(x, x, x, indexing="ij")
+    rh = vo.Fab(lo, hi, 0, 1)
+    rh.a[..., 0] = np.sin(2 * np.pi * X) * np.cos(2 * np.pi * Y) * np.sin(4 * np.pi * Z) + 0.1 * rng.standard_normal((n, n, n))
+    if 1 not in bcs:
+        rh.a[..., 0] -= rh.a[..., 0].mean()                       # singular problem: a compatible right-hand side
+    beta = face_fabs(lo, hi, 0, 1, 1.0)
+    for d, b in enumerate(beta):
+        b.a[...] = 1.0 / (1.0 + 0.5 * np.sin(2 * np.pi * (np.arange(b.a.shape[d]) / n)).reshape([-1 if t == d else 1 for t in range(3)] + [1]) ** 2)
+    ell = ((C.c_int * 2) * 3)()
+    for d in range(3):
+        ell[d][0] = ell[d][1] = bcs[d]
+    out = []
+    for fmg in (0, 1):
+        phi = vo.Fab(lo, hi, 1, 1)
+        st = vo.CMgStat()
+        rc = vo.lib().vo_cc_solve(rh.ref, phi.ref, vo.fab_ptr_array(beta), vo.dvec([1.0 / n] * 3), ell, C.c_double(1e-11), C.c_double(-1.0),
+                                  100, 2, 2, 8, fmg, C.byref(st))
+        assert rc == 0
+        got = phi.valid()[..., 0].copy()
+        out.append((got - (got.mean() if 1 not in bcs else 0.0), st.cycles))
+    (a, ca), (b, cb) = out
+    assert np.abs(a - b).max() <= 1e-9 * max(1.0, np.abs(a).max()), np.abs(a - b).max()
+    assert cb <= ca and cb < ca + 1, (ca, cb)
 
 
 @pytest.mark.parametrize("phys", [WALLS, PER])

@@ -59,7 +59,7 @@ def test_cc_solve(gpu, oracle, bcname, n):
     ophi = case.ofab(1, 1)
     st = oracle.CMgStat()
     rc = oracle.lib().vo_cc_solve(rh.ref, ophi.ref, oracle.fab_ptr_array(beta), case.odx, ell, C.c_double(1e-10), C.c_double(-1.0), 100,
-                                  P.mg_nu1, P.mg_nu2, P.mg_nub, C.byref(st))
+                                  P.mg_nu1, P.mg_nu2, P.mg_nub, P.mac_fmg, C.byref(st))
     assert rc == 0, "oracle MG did not converge"
     gphi = case.gmf(case.ofab(1, 1))
     bc = [[ell[d][sd] for sd in range(2)] for d in range(3)]

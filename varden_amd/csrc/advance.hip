@@ -312,7 +312,10 @@ extern "C" int vdn_cc_solve(vdn_multifab *rh, vdn_multifab *phi, vdn_multifab **
                             double rel_eps, double abs_eps, int max_iter, int *cycles, double *res0, double *res) {
   HOOK_BEGIN(rh)
   int b[3][2]; bc_from_flat(bc, b);
-  int rc = cc_solve(rh, phi, beta, dx, b, rel_eps, abs_eps, max_iter, cycles, res0, res);
+  // nested iteration (vdn_params.mac_fmg) when phi comes in zero, ghost cells included -- the check costs a reduction here; macproject knows
+  int fmg = 0;
+  if (ctx().prm.mac_fmg && max_iter >= 0 && ctx().prm.dm == 3) fmg = mf_norm_inf_grown(phi, 0, 1, 1) == 0.0 ? 1 : 0;
+  int rc = cc_solve(rh, phi, beta, dx, b, rel_eps, abs_eps, max_iter, cycles, res0, res, nullptr, nullptr, nullptr, nullptr, fmg);
   arena_reset();
   if (rc != 0) vdn_fail("cc multigrid did not converge: %d cycles, residual %g (rhs %g)", *cycles, *res, *res0);
   HOOK_END

@@ -728,7 +728,7 @@ int ml_cc_solve(vdn_layout *la, vdn_multifab **rh, vdn_multifab **phi, vdn_multi
     // coarse correction: ONE V-cycle of the single-level multigrid on the whole level 0
     mf_setval(S.e[0], 0.0, 0, 1, true);
     int cyc; double r0, rr;
-    cc_solve(S.res[0], S.e[0], beta, dx, ebc0, 0.0, -1.0, -1, &cyc, &r0, &rr, alpha ? alpha[0] : nullptr, nullptr, coarse_keep);
+    cc_solve(S.res[0], S.e[0], beta, dx, ebc0, 0.0, -1.0, -1, &cyc, &r0, &rr, alpha ? alpha[0] : nullptr, nullptr, coarse_keep);     // (no nested-iteration start here: it saves no FAC iteration, measured)
     apply_correction(S, 0);
     // post-relaxation on the new residual, coarsest level first
     for (int n = 1; n < L; n++) {

@@ -1085,6 +1085,31 @@ __global__ void kk_cc_prolong_tail(CLev F, CLev T, int c00, int c01, int c02) {
   F.phi[f] = F.phi[f] + T.phi[cidx(T, c00 + (i >> 1), c01 + (j >> 1), c02 + (k >> 1))];
 }
 
+// nested iteration (cc_fmg): phi_F = LINEAR interpolation of the coarse solution from face neighbours only -- (p0 + px + py + pz)/4 with px, py, pz
+// the coarse neighbours on the fine cell's side (oracle: cc_prolong_linear).  c0: coarse index of the fine box's cell 0 inside C;  e: what lies
+// behind each face of C -- Neumann: the cell itself, Dirichlet: minus the cell, anything else: the ghost cell (halo / periodic image, filled by the caller)
+struct ProlongLinArgs { int c0[3]; int e[3][2]; };
+__global__ void kk_cc_prolong_lin(CLev F, CLev C, ProlongLinArgs A) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  const int j = blockIdx.y * blockDim.y + threadIdx.y;
+  const int k = blockIdx.z;
+  if (i >= F.n[0] || j >= F.n[1]) return;
+  const int I = A.c0[0] + (i >> 1), J = A.c0[1] + (j >> 1), K = A.c0[2] + (k >> 1);
+  const long sy = C.PX, sz = (long)C.PX * C.PY;
+  const long c = cidx(C, I, J, K);
+  const double p0 = C.phi[c];
+  double px, py, pz;
+  #define NBV(out, q, odd, n, elo, ehi, stride)                                                             \
+    { const int m = (q) + ((odd) ? 1 : -1);                                                                 \
+      const int t = m < 0 ? (elo) : (m >= (n) ? (ehi) : VDN_BC_INT);                                         \
+      out = (t == VDN_BC_NEU) ? p0 : ((t == VDN_BC_DIR) ? -p0 : C.phi[c + ((odd) ? (stride) : -(stride))]); }
+  NBV(px, I, i & 1, C.n[0], A.e[0][0], A.e[0][1], 1L)
+  NBV(py, J, j & 1, C.n[1], A.e[1][0], A.e[1][1], sy)
+  NBV(pz, K, k & 1, C.n[2], A.e[2][0], A.e[2][1], sz)
+  #undef NBV
+  F.phi[cidx(F, i, j, k)] = 0.25 * (((p0 + px) + py) + pz);
+}
+
 // ---- host side ------------------------------------------------------------------------------------------
 struct CBox { CLev L; int lo[3]; int gidx; int hmask = 63; /* faces whose ghost cells come from the halo exchange */ };                    // one local box on one distributed level; lo = global index of its cell 0
 struct CDLev { std::vector<CBox> boxes; XPlan *halo = nullptr; int ng[3]; /* global extents of the level */ bool single_box = false;
@@ -1490,6 +1515,92 @@ static void cc_vcycle_d(CCMG &M, int l) {
   cc_prolong_smooth(M, l, P.mg_nu2);
 }
 
+// ---- nested iteration for the initial guess (vdn_params.mac_fmg; oracle: cc_fmg in vo_macproject.c) ------------------------------------------
+// Levels are numbered globally: g < nd distributed, then the tail.
+static long cc_level_cells(const CCMG &M, int g) {
+  const int nd = (int)M.dlev.size();
+  if (g < nd) return (long)M.dlev[g].ng[0] * M.dlev[g].ng[1] * M.dlev[g].ng[2];
+  const CLev &T = M.tail[g - nd];
+  return (long)T.n[0] * T.n[1] * T.n[2];
+}
+// one V-cycle on the phi a level holds (phi is NOT zeroed); level g has a level below it
+static void cc_cycle_at(CCMG &M, int g) {
+  const vdn_params &P = ctx().prm;
+  const int nd = (int)M.dlev.size();
+  if (g < nd) {
+    CDLev &DL = M.dlev[g];
+    cc_gsrb_d(M, DL, P.mg_nu1);
+    cc_residual_d(M, DL, false);
+    cc_restrict_down(M, g);
+    if (g + 1 < nd) cc_vcycle_d(M, g + 1); else cc_vcycle_t(M, 0);
+    cc_prolong_up(M, g); cc_gsrb_d(M, DL, P.mg_nu2);
+    return;
+  }
+  const CLev &L = M.tail[g - nd], &C = M.tail[g - nd + 1];
+  cc_gsrb_t(M, L, P.mg_nu1);
+  cc_periodic_t(M, L);
+  hipLaunchKernelGGL(kk_cc_residual, g3(L.n[0], L.n[1], L.n[2], BLK), BLK, 0, ctx().stream, L, (double *)nullptr);
+  hipLaunchKernelGGL(kk_cc_restrict, g3(C.n[0], C.n[1], C.n[2], BLK), BLK, 0, ctx().stream, L, C);
+  cc_vcycle_t(M, g - nd + 1);
+  hipLaunchKernelGGL(kk_cc_prolong, g3(L.n[0], L.n[1], L.n[2], BLK), BLK, 0, ctx().stream, L, C);
+  cc_gsrb_t(M, L, P.mg_nu2);
+}
+static void cc_fmg(CCMG &M, const int bc[3][2]) {
+  const int nd = (int)M.dlev.size(), ntot = nd + (int)M.tail.size();
+  int ls = -1;
+  for (int g = 1; g < ntot; g++) if (cc_level_cells(M, g) >= 4096) ls = g;
+  if (ls < 1 || ls + 1 >= ntot) return;                  // (a starting level with nothing below it: no nested iteration)
+  hipStream_t st = ctx().stream;
+  for (int g = 0; g < ls; g++) {                          // rh_{g+1} = mean of the children of rh_g; phi_{g+1} = 0 (written by the same kernels)
+    if (g + 1 < nd) {
+      for (size_t b = 0; b < M.dlev[g].boxes.size(); b++) {
+        CLev F = M.dlev[g].boxes[b].L; F.res = F.rh;      // (kk_cc_restrict reads F.res)
+        const CLev &C = M.dlev[g + 1].boxes[b].L;
+        hipLaunchKernelGGL(kk_cc_restrict, g3(C.n[0], C.n[1], C.n[2], BLK), BLK, 0, st, F, C);
+      }
+    } else if (g + 1 == nd) {
+      const CDLev &DL = M.dlev[g]; const CLev &T = M.tail[0];
+      for (size_t b = 0; b < DL.boxes.size(); b++) {
+        const CLev &F = DL.boxes[b].L;
+        const int nx = F.n[0] / 2, ny = F.n[1] / 2, nz = F.n[2] / 2;
+        hipLaunchKernelGGL(kk_cc_restrict_pack, g3(nx, ny, nz, BLK), BLK, 0, st, F, (const double *)F.rh, M.sendbuf, M.loc_off_rh[b], nx, ny, nz);
+      }
+      comm_allgather_dev(M.sendbuf, M.recvbuf, M.cnt_rh);
+      hipLaunchKernelGGL(kk_cc_unpack_rh, dim3(4, 1, (unsigned)M.gb_rh.size()), dim3(256), 0, st, T, T.rh, M.recvbuf, M.d_gb_rh);
+    } else {
+      CLev F = M.tail[g - nd]; F.res = F.rh;
+      const CLev &C = M.tail[g - nd + 1];
+      hipLaunchKernelGGL(kk_cc_restrict, g3(C.n[0], C.n[1], C.n[2], BLK), BLK, 0, st, F, C);
+    }
+  }
+  if (ls < nd) cc_vcycle_d(M, ls); else cc_vcycle_t(M, ls - nd);      // from zero
+  cc_cycle_at(M, ls);
+  for (int g = ls - 1; g >= 0; g--) {
+    // phi_g = linear interpolation of phi_{g+1}: the coarse level's ghost cells behind box-box and periodic faces first
+    if (g + 1 < nd) {
+      CDLev &DC = M.dlev[g + 1];
+      cc_halo(M, DC);
+      for (size_t b = 0; b < M.dlev[g].boxes.size(); b++) {
+        const CLev &F = M.dlev[g].boxes[b].L; const CBox &CB = DC.boxes[b];
+        ProlongLinArgs A;
+        for (int d = 0; d < 3; d++) { A.c0[d] = 0; A.e[d][0] = (CB.lo[d] == 0) ? bc[d][0] : VDN_BC_INT; A.e[d][1] = (CB.lo[d] + CB.L.n[d] == DC.ng[d]) ? bc[d][1] : VDN_BC_INT; }
+        hipLaunchKernelGGL(kk_cc_prolong_lin, g3(F.n[0], F.n[1], F.n[2], BLK), BLK, 0, st, F, CB.L, A);
+      }
+    } else {
+      const CLev &T = M.tail[g + 1 - nd];
+      cc_periodic_t(M, T);
+      ProlongLinArgs A;
+      for (int d = 0; d < 3; d++) { A.c0[d] = 0; A.e[d][0] = bc[d][0]; A.e[d][1] = bc[d][1]; }
+      if (g >= nd) { const CLev &F = M.tail[g - nd]; hipLaunchKernelGGL(kk_cc_prolong_lin, g3(F.n[0], F.n[1], F.n[2], BLK), BLK, 0, st, F, T, A); }
+      else for (const CBox &B : M.dlev[g].boxes) {
+        for (int d = 0; d < 3; d++) A.c0[d] = B.lo[d] / 2;
+        hipLaunchKernelGGL(kk_cc_prolong_lin, g3(B.L.n[0], B.L.n[1], B.L.n[2], BLK), BLK, 0, st, B.L, T, A);
+      }
+    }
+    if (g > 0) cc_cycle_at(M, g);
+  }
+}
+
 struct CcKeep { bool built = false; CCMG M; };
 CcKeep *cc_keep_new() { return new CcKeep; }
 void cc_keep_free(CcKeep *k) { delete k; }
@@ -1528,6 +1639,12 @@ template <class Body> static void cc_run_cycle(CCMG &M, int what, Body body) {
   graph_end(key);
 }
 
+// graph id of the nested iteration: its interpolation kernels take the boundary types as arguments, so they are part of the key
+static int cc_fmg_what(const int bc[3][2]) {
+  int code = 0;
+  for (int d = 0; d < 3; d++) for (int sd = 0; sd < 2; sd++) code = code * 4 + (bc[d][sd] + 1);
+  return 3 + 4 * code;
+}
 // VDN_MAC_STORED_BETA=1: the finest level reads the stored face coefficients like the others (the measured alternative of DESIGN.md section 4)
 static bool beta_from_rho() { static const bool b = !(getenv("VDN_MAC_STORED_BETA") && atoi(getenv("VDN_MAC_STORED_BETA")) != 0); return b; }
 static void cc_setup(CCMG &M, vdn_multifab *rh, vdn_multifab *phi, const vdn_multifab *alpha, vdn_multifab **beta, const double *dx, const int bc[3][2],
@@ -1676,7 +1793,7 @@ static void cc_store(CCMG &M, vdn_multifab *phi, const int bc[3][2]) {
 // finest level's array (ghost cells exchanged) and the level arrays stay allocated -- the CALLER releases the arena
 int cc_solve(vdn_multifab *rh, vdn_multifab *phi, vdn_multifab **beta, const double *dx, const int bc[3][2],
              double rel_eps, double abs_eps, int max_iter, int *cycles, double *res0, double *res, const vdn_multifab *alpha, const vdn_multifab *rho, CcKeep *keep,
-             CcFast *fast) {
+             CcFast *fast, int fmg) {
   Prof prof_("mac_multigrid");
   if (ctx().prm.dm == 2) return cc2_solve(rh, phi, beta, dx, bc, rel_eps, abs_eps, max_iter, cycles, res0, res, alpha);
   const vdn_params &P = ctx().prm;
@@ -1693,6 +1810,9 @@ int cc_solve(vdn_multifab *rh, vdn_multifab *phi, vdn_multifab **beta, const dou
   if (keep) keep->built = true;
   CDLev &D0 = M.dlev[0];
   const bool single = (M.dlev.size() == 1 && M.tail.empty());
+  // fmg: the caller's phi is zero, ghost cells included, and the solve starts from a nested iteration (not before a fixed number of cycles);
+  // the fast path: vdn_params.mac_fmg
+  if (fast) fmg = P.mac_fmg ? 1 : 0;
   if (max_iter < 0) {            // exactly -max_iter V-cycles, no norms, no convergence test (the coarse correction of the composite solves)
     for (int c = 0; c < -max_iter; c++) {
       if (single) { const int N = std::max(D0.ng[0], std::max(D0.ng[1], D0.ng[2])); cc_gsrb_d(M, D0, std::max(P.mg_nub, N * N)); continue; }
@@ -1714,6 +1834,7 @@ int cc_solve(vdn_multifab *rh, vdn_multifab *phi, vdn_multifab **beta, const dou
   // pre-smoothing + residual, then per cycle: [coarse correction, post-smoothing, the next cycle's pre-smoothing, residual + norm] as ONE
   // replayed graph and one 8-byte read-back -- the same launch sequence as testing the residual the cycle computes after pre-smoothing
   const int nbot = std::max(P.mg_nub, std::max(D0.ng[0], std::max(D0.ng[1], D0.ng[2])) * std::max(D0.ng[0], std::max(D0.ng[1], D0.ng[2])));
+  if (fmg && !conv && !single && bnorm < HUGE_VAL) cc_run_cycle(M, cc_fmg_what(bc), [&] { cc_fmg(M, bc); });
   if (!conv) { cc_gsrb_d(M, D0, single ? nbot : P.mg_nu1); cc_residual_d(M, D0, true); rn = read_scalar(M.d_nrm); }
   while (!conv) {
     if ((rn <= rel_eps * bnorm && bnorm < HUGE_VAL) || rn <= abs_eps) { conv = true; break; }
@@ -1945,7 +2066,8 @@ void do_macproject(vdn_layout *mla, vdn_multifab **umac, vdn_multifab **rho, vdn
   int ebc[3][2];
   for (int d = 0; d < 3; d++) for (int s = 0; s < 2; s++) ebc[d][s] = bct->ell_bc(n, 0, d, s, bc_comp0);   // grid 0 = whole domain
   int cyc; double r0, rr;
-  int rc = cc_solve(rh, phi, beta, dx, ebc, ctx().prm.mac_rel_eps, -1.0, ctx().prm.mg_max_iter, &cyc, &r0, &rr, nullptr, rho[n]);   // macproject.f90:91-93
+  int rc = cc_solve(rh, phi, beta, dx, ebc, ctx().prm.mac_rel_eps, -1.0, ctx().prm.mg_max_iter, &cyc, &r0, &rr, nullptr, rho[n], nullptr, nullptr,
+                    ctx().prm.mac_fmg ? 1 : 0);   // macproject.f90:91-93 (phi was created zero above)
   ctx().solver_cycles[0] = cyc; ctx().solver_res0[0] = r0; ctx().solver_res[0] = rr;
   solver_check(rc, "MAC multigrid", cyc, rr, r0);
   mac_level_mkumac(um, phi, beta, dx, bct, bc_comp0);

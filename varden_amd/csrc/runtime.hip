@@ -88,7 +88,7 @@ extern "C" void vdn_params_default(vdn_params *p) {
   p->visc_coef = 0.0; p->diff_coef = 0.0; p->cflfac = 0.8; p->max_dt_growth = 1.1;
   p->mg_nu1 = 2; p->mg_nu2 = 2; p->mg_nub = 8; p->mg_max_iter = 100;
   p->hg_max_iter = 100; p->hg_nu1 = 2; p->hg_nu2 = 1; p->hg_nub = 8; p->hg_omega = 0.9;     // hg_nub: 32 until round 3 -- the coarsest level (3^3 nodes under a 2^k box) gains nothing from more than max(8, 2 N^2) sweeps (same cycle counts), and each costs ~1.2 us of a one-workgroup launch
-  p->mac_rel_eps = 1.0e-10; p->hg_rel_eps = -1.0; p->abort_on_max_iter = 1; p->hg_fmg = 1;
+  p->mac_rel_eps = 1.0e-10; p->hg_rel_eps = -1.0; p->abort_on_max_iter = 1; p->hg_fmg = 1; p->mac_fmg = 1;
 }
 
 // ---- roctx ranges ------------------------------------------------------------------------------------------------------------
@@ -603,11 +603,13 @@ __global__ void k_minmax(FV f, Range3 r, int comp, double *out /* [0]=max(-x) sh
   if (in_ij) REDUCE_KLOOP(r) { double x = fv_get(f, i, j, k, comp); a = fmax(a, shift - x); b = fmax(b, x + shift); }
   block_atomic_max(out, a); block_atomic_max(out + 1, b);
 }
-double mf_norm_inf(const vdn_multifab *mf, int comp, int nc) {
+double mf_norm_inf(const vdn_multifab *mf, int comp, int nc) { return mf_norm_inf_grown(mf, comp, nc, 0); }
+double mf_norm_inf_grown(const vdn_multifab *mf, int comp, int nc, int grow) {       // over the valid region grown by `grow` ghost cells
   VdnCtx &c = g_ctx;
+  REQUIRE(grow >= 0 && grow <= mf->ng, "norm_inf: more ghost cells asked for than the multifab has");
   HIPCHK(hipMemsetAsync(c.d_scal, 0, sizeof(double), c.stream));
   for (int i = 0; i < mf->nfabs(); i++) {
-    Range3 r = fab_range(mf, i, 0);
+    Range3 r = fab_range(mf, i, grow);
     hipLaunchKernelGGL(k_absmax, reduce_grid(r), dim3(64, 4, 1), 0, c.stream, mf->fabs[i], r, comp, nc, c.d_scal);
   }
   comm_allreduce_max_dev(c.d_scal, 1);        // FBoxLib norm_inf is a global (all-rank) norm

@@ -151,7 +151,10 @@ DEVI void block_atomic_max_fwd(double *addr, double v) { block_atomic_max(addr, 
 template <class A> static inline int batch_grid(A &a, int kz) {
   const int nx = a.r.hi[0] - a.r.lo[0] + 1, ny = a.r.hi[1] - a.r.lo[1] + 1, nz = a.r.hi[2] - a.r.lo[2] + 1;
   const int lw = nx > 32 ? 6 : (nx > 16 ? 5 : 4), w = 1 << lw, h = 256 >> lw;
-  int g0 = nx > 0 ? (nx + w - 1) / w : 0, g1 = ny > 0 ? (ny + h - 1) / h : 0, g2 = nz > 0 ? ((kz > 0 && nz > kz) ? kz : nz) : 0;
+  // planes per workgroup when the caller sets no limit: a 16 x 16 tile of ONE plane is a few KB of traffic behind a bisection over the box
+  // list and a descriptor fetch -- a level of ~30^3 boxes then runs at the rate workgroups can be dispatched, not at the memory's
+  static const int ppw = getenv("VDN_BATCH_PPW") ? std::max(1, atoi(getenv("VDN_BATCH_PPW"))) : 1;
+  int g0 = nx > 0 ? (nx + w - 1) / w : 0, g1 = ny > 0 ? (ny + h - 1) / h : 0, g2 = nz > 0 ? ((kz > 0 && nz > kz) ? kz : (nz + ppw - 1) / ppw) : 0;
   if (g0 == 0 || g1 == 0 || g2 == 0) { g0 = g1 = g2 = 1; a.r.hi[0] = a.r.lo[0] - 1; }
   a.g[0] = g0; a.g[1] = g1; a.g[2] = g2 | (lw << 24);
   return g0 * g1 * g2;

@@ -192,6 +192,7 @@ void mf_fill_boundary(vdn_multifab *mf);
 void mf_physbc(vdn_multifab *mf, int scomp, int bccomp, int nc, const vdn_bc_tower *bct, bool same_boundary = false);
 void mf_copy(vdn_multifab *dst, int dcomp, const vdn_multifab *src, int scomp, int nc, int ng);
 double mf_norm_inf(const vdn_multifab *mf, int comp, int nc);
+double mf_norm_inf_grown(const vdn_multifab *mf, int comp, int nc, int grow);
 // ml_restrict_and_fill on one level = fill_boundary + physbc
 void mf_restrict_and_fill(vdn_multifab *mf, int icomp, int bcomp, int nc, bool same_boundary, const vdn_bc_tower *bct);
 
@@ -223,7 +224,7 @@ struct CcFast { vdn_multifab **um = nullptr; const vdn_multifab *mac_rhs = nullp
 int  cc_solve(vdn_multifab *rh, vdn_multifab *phi, vdn_multifab **beta, const double *dx, const int bc[3][2],
               double rel_eps, double abs_eps, int max_iter, int *cycles, double *res0, double *res,
               const vdn_multifab *alpha = nullptr, const vdn_multifab *rho = nullptr,    // rho: beta = 2/(rho_i + rho_i-1), recomputed on the finest level
-              struct CcKeep *keep = nullptr, CcFast *fast = nullptr);          // keep: see mg_cc.hip (hierarchy kept between the calls of a composite solve)
+              struct CcKeep *keep = nullptr, CcFast *fast = nullptr, int fmg = 0);   // fmg: the caller's phi is zero and max_iter >= 0: start from the nested iteration (cc_fmg)          // keep: see mg_cc.hip (hierarchy kept between the calls of a composite solve)
 struct CcKeep *cc_keep_new(); void cc_keep_free(struct CcKeep *k);
 void cc_smooth(vdn_multifab *rh, vdn_multifab *phi, vdn_multifab **beta, const double *dx, const int bc[3][2], int nsweeps);
 void cc_bench_smoother(vdn_multifab *rh, vdn_multifab *phi, vdn_multifab **beta, const vdn_multifab *rho, const double *dx, const int bc[3][2],

@@ -37,7 +37,7 @@ module varden_amd
      real(c_double) :: u_bc(2,3), v_bc(2,3), w_bc(2,3), rho_bc(2,3), trac_bc(2,3)   ! C [dir][side] == Fortran (side,dir)
      integer(c_int) :: mg_nu1, mg_nu2, mg_nub, mg_max_iter, hg_max_iter, hg_nu1, hg_nu2, hg_nub
      real(c_double) :: hg_omega, mac_rel_eps, hg_rel_eps
-     integer(c_int) :: abort_on_max_iter, hg_fmg
+     integer(c_int) :: abort_on_max_iter, hg_fmg, mac_fmg
   end type vdn_params
 
   type, bind(C), public :: vdn_box
