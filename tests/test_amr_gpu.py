@@ -711,3 +711,43 @@ def test_two_level_scalar_diffusion(gpu, oracle):
     # the tracer (component 1) has diffused away from the density it started equal to
     assert np.abs(O.snew[1].valid()[..., 1] - O.snew[1].valid()[..., 0]).max() > 1e-6
     G.close()
+
+
+def test_composite_launch_variants_agree_bit_for_bit(gpu):
+    """the launch-level forms of the composite solves change no value: a tagged three-level hierarchy (base 32^3, unions of boxes) run (a) with
+    the defaults -- eight planes per workgroup for the light box-batched kernels (vdn_dev.h batch_ppw), the interface interpolation of the
+    nodal solve over box faces only, the composite residual loaded directly as the right-hand side of the coarse correction -- and (b) with one
+    plane per workgroup (VDN_BATCH_PPW=1), the interpolation over whole boxes (VDN_NDM_IFACE_FACES=0) and the negated copy + zero-filled
+    correction of round 2 (VDN_NDM_NEG=1).  The switches are read once per process, hence the child processes."""
+    import os, subprocess, sys, textwrap
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = textwrap.dedent("""
+        import sys, hashlib
+        sys.path.insert(0, %r)
+        import numpy as np
+        from varden_amd import driver
+        from varden_amd.capi import default_params
+        walls = [[15, 15]] * 3
+        prm = default_params(cflfac=0.9)
+        levels = driver.VardenAMR.tagged_grids(32, walls, prm, max_levs=3, max_grid_size=32)
+        G = driver.VardenAMR(32, levels[0], walls, params=prm, finer_levels=levels[1:], init_iter=1, do_initial_projection=1)
+        for _ in range(2):
+            G.step()
+        h = hashlib.sha256()
+        for n in range(3):
+            for m in (G.uold[n], G.sold[n], G.p[n], G.gp[n]):
+                for f in range(m.nfabs()):
+                    h.update(np.ascontiguousarray(m.to_numpy(f)).tobytes())
+        print("HASH", h.hexdigest(), G.dt)
+    """ % root)
+    switches = ("VDN_BATCH_PPW", "VDN_NDM_IFACE_FACES", "VDN_NDM_NEG")
+    out = []
+    for extra in ({}, {"VDN_BATCH_PPW": "1", "VDN_NDM_IFACE_FACES": "0", "VDN_NDM_NEG": "1"}):
+        env = dict(os.environ)
+        for k in switches:
+            env.pop(k, None)
+        env.update(extra)
+        r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600, cwd=root)
+        assert r.returncode == 0, r.stderr[-2000:]
+        out.append([ln for ln in r.stdout.splitlines() if ln.startswith("HASH")][0])
+    assert out[0] == out[1], out

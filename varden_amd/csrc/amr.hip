@@ -54,7 +54,7 @@ static bool isect(const int alo[3], const int ahi[3], const int blo[3], const in
 
 // ---- views of the other level (several ranks: vdn_internal.h SrcView) ------------------------------------------------------------
 // footprint tags keep the cached views of one multifab apart
-enum { VT_REFINE = 1, VT_REFINE_FACE0 = 2, VT_COARSEN_G = 8, VT_COARSEN_1 = 20, VT_REFINE_G1 = 21, VT_COARSEN_0 = 22, VT_NODE_C2F = 23, VT_NODE_F2C = 24 };
+enum { VT_REFINE = 1, VT_REFINE_FACE0 = 2, VT_COARSEN_G = 8, VT_COARSEN_1 = 20, VT_REFINE_G1 = 21, VT_COARSEN_0 = 22, VT_NODE_C2F = 23, VT_NODE_F2C = 24, VT_COARSEN_0G1 = 25 };
 static const std::vector<vdn_box> &level_boxes(const vdn_multifab *mf) { return mf->la->boxes[mf->lev]; }
 static const std::vector<int> &level_owner(const vdn_multifab *mf) { return mf->la->owner[mf->lev]; }
 static int global_index(const vdn_multifab *mf, int li) { return mf->la->local[mf->lev][li]; }
@@ -150,7 +150,7 @@ DEVI double mc_limited(double del, double sm, double s0, double sp) {
 }
 // r: fine cells (the grown fine box); a thread writes its cell if it is a ghost cell whose parent lies in [plo,phi];
 // [alo,ahi]: the allocation of the coarse fab (slopes need both neighbours inside it)
-struct InterpB { Range3 r; int g[3]; FV fine, crse; InterpArgs A;
+struct InterpB { Range3 r; int g[3]; static constexpr int planes_per_wg = 8; FV fine, crse; InterpArgs A;
   static __device__ double body(const InterpB &a_, int i, int j, int k, int) {
   const FV &fine = a_.fine, &crse = a_.crse; const InterpArgs &A = a_.A;
   if (i >= A.flo[0] && i <= A.fhi[0] && j >= A.flo[1] && j <= A.fhi[1] && k >= A.flo[2] && k <= A.fhi[2]) return 0.0;
@@ -385,7 +385,7 @@ static void closure_descs(vdn_multifab *phi, const vdn_bc_tower *bct, int bc_com
     }
 }
 struct CfArgs { int d, s; int plo[3], phi[3]; };
-struct CfB { Range3 r; int g[3]; FV pf, pc; CfArgs A;                // r: the ghost cells just outside face (d,s) of the fine box
+struct CfB { Range3 r; int g[3]; static constexpr int planes_per_wg = 8; FV pf, pc; CfArgs A;                // r: the ghost cells just outside face (d,s) of the fine box
   static __device__ double body(const CfB &a, int i, int j, int k, int) {
     const CfArgs &A = a.A; const FV &pf = a.pf, &pc = a.pc;
     const int gq[3] = { i, j, k };
@@ -425,7 +425,7 @@ static void cf_descs(vdn_multifab *pf, const SrcView &pc, const vdn_bc_tower *bc
   }
 }
 struct ResArgs { double hi2[3]; };
-struct ResidualB { Range3 r; int g[3]; FV rh, phi, bx, by, bz, res, alpha; int has_alpha; ResArgs A;
+struct ResidualB { Range3 r; int g[3]; static constexpr int planes_per_wg = 8; FV rh, phi, bx, by, bz, res, alpha; int has_alpha; ResArgs A;
   static __device__ double body(const ResidualB &a, int i, int j, int k, int) {
     const FV &phi = a.phi;
     const double p0 = fv_get(phi, i, j, k);
@@ -507,19 +507,26 @@ struct DirRhsB { Range3 r; int g[3]; FV rh, phi, bx, by, bz; GsArgs A;
     fv_at(a.rh, i, j, k) = r;
     return 0.0;
   } };
-struct AddB { Range3 r; int g[3]; FV a, b;
+struct AddB { Range3 r; int g[3]; static constexpr int planes_per_wg = 8; FV a, b;
   static __device__ double body(const AddB &q, int i, int j, int k, int) { fv_at(q.a, i, j, k) = fv_get(q.a, i, j, k) + fv_get(q.b, i, j, k); return 0.0; } };
-// af += the parent's increment; keep: also store that increment in sc (the next finer level prolongs it in turn)
-struct AddProlongB { Range3 r; int g[3]; FV af, sc, ec; int keep, plo[3], phi[3];
-  static __device__ double body(const AddProlongB &q, int i, int j, int k, int) {
+// af += the prolonged increment of the parent level; keep: also store it in sc (the next finer level prolongs it in turn).
+// lin = 0: the parent's value (piecewise constant);  lin = 1: (p0 + px + py + pz)/4 with px, py, pz the parent's neighbours on the fine cell's
+// side, read through the source fab's ghost cells (the caller has put the neighbouring boxes' / periodic values there, and the parent's own
+// value where the level ends) -- oracle: apply_correction in vo_amr.c
+struct AddProlongB { Range3 r; int g[3]; static constexpr int planes_per_wg = 8; FV af, sc, ec; int keep, plo[3], phi[3];
+  static __device__ double body(const AddProlongB &q, int i, int j, int k, int lin) {
     const int I = i / 2, J = j / 2, K = k / 2;
     if (I < q.plo[0] || I > q.phi[0] || J < q.plo[1] || J > q.phi[1] || K < q.plo[2] || K > q.phi[2]) return 0.0;
-    const double v = fv_get(q.ec, I, J, K);
+    double v = fv_get(q.ec, I, J, K);
+    if (lin) {
+      const double px = fv_get(q.ec, I + ((i & 1) ? 1 : -1), J, K), py = fv_get(q.ec, I, J + ((j & 1) ? 1 : -1), K), pz = fv_get(q.ec, I, J, K + ((k & 1) ? 1 : -1));
+      v = 0.25 * (((v + px) + py) + pz);
+    }
     if (q.keep) fv_at(q.sc, i, j, k) = v;
     fv_at(q.af, i, j, k) = fv_get(q.af, i, j, k) + v;
     return 0.0;
   } };
-struct SetboxB { Range3 r; int g[3]; FV a; double v;
+struct SetboxB { Range3 r; int g[3]; static constexpr int planes_per_wg = 8; FV a; double v;
   static __device__ double body(const SetboxB &q, int i, int j, int k, int) { fv_at(q.a, i, j, k) = q.v; return 0.0; } };
 
 static Range3 valid_range(const vdn_multifab *mf, int b) { Range3 r; for (int d = 0; d < 3; d++) { r.lo[d] = mf->vbox[b].lo[d]; r.hi[d] = mf->vbox[b].hi[d]; } return r; }
@@ -533,6 +540,7 @@ struct MLCC { int nlev; vdn_layout *la; vdn_multifab **rh, **phi, **beta, **alph
               BatchSet<AbsmaxB> absmax[VDN_MAXLEV]; BatchSet<GsrbB> gsrb[VDN_MAXLEV]; BatchSet<AddB> add[VDN_MAXLEV];
               BatchSet<AddProlongB> prolong[VDN_MAXLEV][VDN_MAXLEV];   // [source level n][target level m]: src = e[n] (m = n+1) or scr[m-1]
               BatchSet<RestrictB> rphi[VDN_MAXLEV], rres[VDN_MAXLEV];  // [fine level]
+              BatchSet<ClosureB> edge_e[VDN_MAXLEV], edge_scr[VDN_MAXLEV];   // ghost cells of e[n] / scr[n] := the adjacent cell, all six faces of every box (before a linear prolongation)
               // the other level's fields as seen from this rank (several ranks: windows of remote boxes, refreshed before each use)
               SrcView vc_phi[VDN_MAXLEV], vf_phi[VDN_MAXLEV], vf_res[VDN_MAXLEV], vf_beta[VDN_MAXLEV][3], vc_src[VDN_MAXLEV][VDN_MAXLEV];
 };
@@ -556,6 +564,18 @@ static void mlcc_build_sets(MLCC &S) {
   const int L = S.nlev;
   for (int n = 0; n < L; n++) {
     { std::vector<ClosureB> v; closure_descs(S.phi[n], S.bct, S.bcc, v); S.closure[n].build(v, 0, st); }
+    if (n >= 1 && n < L - 1)               // levels that are the SOURCE of a linear prolongation (into a level >= 2)
+      for (int which = 0; which < 2; which++) {
+        vdn_multifab *mf = which ? S.scr[n] : S.e[n];
+        std::vector<ClosureB> v;
+        for (int b = 0; b < mf->nfabs(); b++) for (int d = 0; d < 3; d++) for (int sd = 0; sd < 2; sd++) {
+          ClosureB a; a.phi = mf->fabs[b]; a.bc = VDN_BC_NEU; a.d = d; a.s = sd;
+          for (int t = 0; t < 3; t++) { a.r.lo[t] = mf->vbox[b].lo[t]; a.r.hi[t] = mf->vbox[b].hi[t]; }
+          a.r.lo[d] = a.r.hi[d] = sd ? mf->vbox[b].hi[d] : mf->vbox[b].lo[d];
+          v.push_back(a);
+        }
+        (which ? S.edge_scr[n] : S.edge_e[n]).build(v, 0, st);
+      }
     if (n >= 1) {
       S.vc_phi[n] = make_view(S.phi[n - 1], coarsened_footprints(S.phi[n], 1, -1, 1), level_owner(S.phi[n]), 0, 1, VT_COARSEN_1);
       S.vf_phi[n] = make_view(S.phi[n], refined_footprints(S.phi[n - 1], -1, 2), level_owner(S.phi[n - 1]), 0, 1, VT_REFINE_G1);
@@ -610,7 +630,9 @@ static void mlcc_build_sets(MLCC &S) {
     // prolongation of the correction of level n to the levels above it
     for (int m = n + 1; m < L; m++) {
       vdn_multifab *srcmf = (m == n + 1) ? S.e[n] : S.scr[m - 1];
-      S.vc_src[n][m] = make_view(srcmf, coarsened_footprints(S.phi[m], 0, -1, 0), level_owner(S.phi[m]), 0, 1, VT_COARSEN_0);
+      // (into the levels >= 2 the prolongation is linear and reads the parent's face neighbours: one more ring of the source level)
+      if (m >= 2) S.vc_src[n][m] = make_view(srcmf, coarsened_footprints(S.phi[m], 0, -1, 1), level_owner(S.phi[m]), 0, 1, VT_COARSEN_0G1);
+      else S.vc_src[n][m] = make_view(srcmf, coarsened_footprints(S.phi[m], 0, -1, 0), level_owner(S.phi[m]), 0, 1, VT_COARSEN_0);
       const SrcView &src = S.vc_src[n][m];
       const bool keep = m < L - 1;
       std::vector<AddProlongB> v;
@@ -658,8 +680,18 @@ static void level_relax(MLCC &S, int n, int nsweeps) {
 }
 // phi_n += e_n, and the piecewise-constant prolongation of that correction on every finer level
 static void apply_correction(MLCC &S, int n) {
-  S.add[n].run(0, (double *)nullptr, ctx().stream);
-  for (int m = n + 1; m < S.nlev; m++) { S.vc_src[n][m].refresh(); S.prolong[n][m].run(0, (double *)nullptr, ctx().stream); }
+  hipStream_t st = ctx().stream;
+  S.add[n].run(0, (double *)nullptr, st);
+  for (int m = n + 1; m < S.nlev; m++) {
+    const int lin = m >= 2 ? 1 : 0;                      // piecewise constant into level 1, linear into the finer ones (oracle: apply_correction)
+    if (lin) {                                          // the source's ghost cells: the cell itself where the level ends, then the neighbouring boxes' / periodic values
+      vdn_multifab *src = (m == n + 1) ? S.e[n] : S.scr[m - 1];
+      (m == n + 1 ? S.edge_e[m - 1] : S.edge_scr[m - 1]).run(0, (double *)nullptr, st);
+      mf_fill_boundary(src);
+    }
+    S.vc_src[n][m].refresh();
+    S.prolong[n][m].run(lin, (double *)nullptr, st);
+  }
 }
 // rh, phi: [lev];  beta: [lev*3 + d];  dx: [lev*3 + d]
 // alpha: [lev] cell coefficients of (alpha - div beta grad), or nullptr.  The ghost cells of the incoming phi carry inhomogeneous
@@ -685,7 +717,7 @@ int ml_cc_solve(vdn_layout *la, vdn_multifab **rh, vdn_multifab **phi, vdn_multi
   S.d_nrm = (double *)arena_alloc(256);
   for (int n = 0; n < L; n++) {
     S.res[n] = mf_temp(la, n, 1, 0, -1, true, 0.0); S.e[n] = mf_temp(la, n, 1, 1, -1, true, 0.0);
-    S.scr[n] = (n >= 1 && n < L - 1) ? mf_temp(la, n, 1, 0, -1, true, 0.0) : nullptr;
+    S.scr[n] = (n >= 1 && n < L - 1) ? mf_temp(la, n, 1, 1, -1, true, 0.0) : nullptr;      // (one ghost cell: the source of a linear prolongation)
     S.mask[n] = nullptr;
     if (n < L - 1) {                                         // cells of level n covered by level n+1
       S.mask[n] = mf_temp(la, n, 1, 0, -1, true, 0.0);

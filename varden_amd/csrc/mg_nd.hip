@@ -674,6 +674,18 @@ __global__ void kk_nd_load(NLev L, FV rh, FV phi, int lo0, int lo1, int lo2, dou
   block_atomic_max(nrm, rmax);
   block_atomic_max(nrm + 1, pmax);
 }
+// the composite solve's coarse correction: the fab holds b itself (the composite residual), the guess is zero -- what kk_nd_load makes of
+// rh = -b and phi = 0, bit for bit (a Dirichlet node gets b = -0.0 there: -(0.0)), without the negated copy and the zero-filled phi
+__global__ void kk_nd_load_b(NLev L, FV rb, int lo0, int lo1, int lo2) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  const int j = blockIdx.y * blockDim.y + threadIdx.y;
+  if (i <= L.n[0] && j <= L.n[1])
+    for (int k = blockIdx.z; k <= L.n[2]; k += gridDim.z) {
+      const long c = nidx(L, i, j, k);
+      L.b[c] = nd_is_dir(L, i, j, k) ? -0.0 : fv_get(rb, lo0 + i, lo1 + j, lo2 + k);
+      L.phi[c] = 0.0;
+    }
+}
 // res := b on the nodes of the level (the carrier of the right-hand side's restriction, nd_fmg)
 __global__ void kk_nd_copy_b_res(NLev L) {
   NODE_IJK(L)
@@ -1281,7 +1293,7 @@ void nd_keep_free(NdKeep *k) { delete k; }
 // from fast->rhohalf (coeffs may be null), and instead of storing phi into a multifab the call returns views of the finest level's phi
 // (ghost nodes exchanged) in fast->phi_view; the level arrays then stay allocated: the CALLER releases the arena (mark taken before the call)
 int nd_solve(vdn_multifab *rh, vdn_multifab *phi, const vdn_multifab *coeffs, const vdn_multifab *u, const double *dx,
-             const int bc[3][2], double rel_eps, double abs_eps, int max_iter, int *cycles, double *res0, double *res, NdKeep *keep, NdFast *fast, bool fmg_start) {
+             const int bc[3][2], double rel_eps, double abs_eps, int max_iter, int *cycles, double *res0, double *res, NdKeep *keep, NdFast *fast, bool fmg_start, bool rh_is_b) {
   Prof prof_("hg_multigrid");
   if (ctx().prm.dm == 2) return nd2_solve(rh, phi, coeffs, u, dx, bc, rel_eps, abs_eps, max_iter, cycles, res0, res);
   const vdn_params &P = ctx().prm;
@@ -1346,6 +1358,9 @@ int nd_solve(vdn_multifab *rh, vdn_multifab *phi, const vdn_multifab *coeffs, co
       REQUIRE(u->ng >= 1 && u->nc >= 3, "nodal multigrid: u needs a ghost cell");
       hipLaunchKernelGGL(kk_nd_load_divu, ng3(L0.n[0] + 1, L0.n[1] + 1, std::min(L0.n[2] + 1, 16)), NBLK, 0, st, L0, u->fabs[b], 0.25 / dx[0], 0.25 / dx[1], 0.25 / dx[2],
                          bx.lo[0], bx.lo[1], bx.lo[2], M.d_nrm);
+    } else if (rh_is_b) {
+      REQUIRE(max_iter < 0 && !u && ctx().prm.dm == 3, "nodal multigrid: rh_is_b is the fixed-cycle correction solve's");
+      hipLaunchKernelGGL(kk_nd_load_b, ng3(L0.n[0] + 1, L0.n[1] + 1, std::min(L0.n[2] + 1, 16)), NBLK, 0, st, L0, rh->fabs[b], bx.lo[0], bx.lo[1], bx.lo[2]);
     } else
     hipLaunchKernelGGL(kk_nd_load, ng3(L0.n[0] + 1, L0.n[1] + 1, std::min(L0.n[2] + 1, 16)), NBLK, 0, st, L0, rh->fabs[b], phi->fabs[b], bx.lo[0], bx.lo[1], bx.lo[2], M.d_nrm);
   }
@@ -1765,17 +1780,17 @@ struct NdmMaskUB { Range3 r; int g[3]; FV out, u, inlev, cov; int has_inlev, has
   } };
 struct NdDivuB { Range3 r; int g[3]; FV u, rh; double f0, f1, f2;    // rh += D u (kk_nd_divu)
   static __device__ double body(const NdDivuB &q, int i, int j, int k, int) { nd_divu_node(q.u, q.rh, q.f0, q.f1, q.f2, i, j, k); return 0.0; } };
-struct NdfNegB { Range3 r; int g[3]; FV out, in; NdfArgs A;          // b = -rh, zero on physical Dirichlet nodes
+struct NdfNegB { Range3 r; int g[3]; static constexpr int planes_per_wg = 8; FV out, in; NdfArgs A;          // b = -rh, zero on physical Dirichlet nodes
   static __device__ double body(const NdfNegB &q, int i, int j, int k, int) { fv_at(q.out, i, j, k) = ndf_pdir(q.A, i, j, k) ? 0.0 : -fv_get(q.in, i, j, k); return 0.0; } };
-struct NdfAddB { Range3 r; int g[3]; FV a, b;
+struct NdfAddB { Range3 r; int g[3]; static constexpr int planes_per_wg = 8; FV a, b;
   static __device__ double body(const NdfAddB &q, int i, int j, int k, int) { fv_at(q.a, i, j, k) = fv_get(q.a, i, j, k) + fv_get(q.b, i, j, k); return 0.0; } };
-struct NdfSetB { Range3 r; int g[3]; FV a; double v;
+struct NdfSetB { Range3 r; int g[3]; static constexpr int planes_per_wg = 8; FV a; double v;
   static __device__ double body(const NdfSetB &q, int i, int j, int k, int) { fv_at(q.a, i, j, k) = q.v; return 0.0; } };
 struct NdfAbsmaxB { Range3 r; int g[3]; FV a, mask;
   static __device__ double body(const NdfAbsmaxB &q, int i, int j, int k, int) { return fv_get(q.mask, i, j, k) == 0.0 ? fabs(fv_get(q.a, i, j, k)) : 0.0; } };
 // mode 0: phi_f = P phi_c on the slave nodes;  mode 1: phi_f += P e_c on every node that is not a physical Dirichlet node;
 // mode 2: phi_f = P e_c there (0 + P e_c).  Only nodes whose coarse parent (i>>1, j>>1, k>>1) is a valid node of this coarse box
-struct NdmProlongB { Range3 r; int g[3]; FV pf, pc, slave, own_c; int has_own; NdfArgs Af; int clo[3], chi[3];
+struct NdmProlongB { Range3 r; int g[3]; static constexpr int planes_per_wg = 8; FV pf, pc, slave, own_c; int has_own; NdfArgs Af; int clo[3], chi[3];
   static __device__ double body(const NdmProlongB &q, int i, int j, int k, int mode) {
     if (ndf_pdir(q.Af, i, j, k)) return 0.0;
     if (mode == 0 && fv_get(q.slave, i, j, k) == 0.0) return 0.0;
@@ -1844,6 +1859,7 @@ struct MLND {
 };
 // mode 0: slaves of level n <- P phi_{n-1};  mode 1: dst_n += P src_{n-1};  mode 2: dst_n = P src_{n-1} (dst zeroed first by the caller)
 static void ml_nd_prolong(MLND &S, int n, vdn_multifab *dst, vdn_multifab *src, int mode) {
+  static const bool faces_only = !(getenv("VDN_NDM_IFACE_FACES") && atoi(getenv("VDN_NDM_IFACE_FACES")) == 0);
   const SrcView Cv = make_view(src, nd_coarse_footprints(S.la, n), S.la->owner[n], 0, 1, NVT_C2F);
   Cv.refresh();
   std::vector<NdmProlongB> v;
@@ -1856,7 +1872,20 @@ static void ml_nd_prolong(MLND &S, int n, vdn_multifab *dst, vdn_multifab *src, 
       q.pf = dst->fabs[f]; q.pc = Cv.fv[c]; q.slave = S.slave[n]->fabs[f];
       const bool ho = S.own[n - 1] != nullptr && S.vc_own[n].have[c];
       q.own_c = ho ? S.vc_own[n].fv[c] : Cv.fv[c]; q.has_own = ho ? 1 : 0; q.Af = S.A[n][f];
-      v.push_back(q);
+      if (mode != 0 || !faces_only) { v.push_back(q); continue; }
+      // mode 0 writes slave nodes only, and a slave node lies ON a face of its box (a node inside touches eight cells of the box): the six
+      // faces of the box's node range instead of the whole box (the x faces own their edges and corners, the y faces the remaining edges)
+      const Range3 &bx = S.r[n][f];
+      Range3 in = q.r;
+      for (int d = 0; d < 3; d++) {
+        for (int sd = 0; sd < 2; sd++) {
+          const int at = sd ? bx.hi[d] : bx.lo[d];
+          if (at < q.r.lo[d] || at > q.r.hi[d] || (sd == 1 && bx.hi[d] == bx.lo[d])) continue;
+          NdmProlongB t = q; t.r = in; t.r.lo[d] = t.r.hi[d] = at;
+          if (t.r.lo[0] <= t.r.hi[0] && t.r.lo[1] <= t.r.hi[1] && t.r.lo[2] <= t.r.hi[2]) v.push_back(t);
+        }
+        in.lo[d] = std::max(in.lo[d], bx.lo[d] + 1); in.hi[d] = std::min(in.hi[d], bx.hi[d] - 1);      // the next directions leave these faces out
+      }
     }
   launch_batched(v, mode, (double *)nullptr, 0, ctx().stream);
 }
@@ -2069,22 +2098,25 @@ static int ml_nd_solve(vdn_layout *la, vdn_multifab **rh, vdn_multifab **phi, vd
   for (int d = 0; d < 3; d++) for (int s = 0; s < 2; s++) ebc0[d][s] = bct->ell_bc(0, 0, d, s, press_comp0);
   int it = 0; bool conv = (bnorm == 0.0); double rn = 0.0;
   NdKeep coarse_keep;                        // the level-0 multigrid hierarchy is built once for all FAC iterations
+  static const bool neg_copy = getenv("VDN_NDM_NEG") && atoi(getenv("VDN_NDM_NEG")) != 0;
   while (!conv) {
     rn = ml_nd_residual(S, false);
     if ((rn <= rel_eps * bnorm && bnorm < HUGE_VAL) || rn <= abs_eps) { conv = true; break; }
     if (it >= max_iter || !(rn < HUGE_VAL) || !(bnorm < HUGE_VAL)) break;
-    // coarse correction K_0 e = r_0: one V-cycle of the single-level solver (which takes rh with b = -rh)
-    mf_setval(ee, 0.0, 0, 1, true);                   // (er: every node is overwritten below, its ghost nodes are never written and stay zero)
-    {
+    // coarse correction K_0 e = r_0: one V-cycle of the single-level solver from e = 0, the composite residual loaded as its b
+    // (VDN_NDM_NEG=1: through a negated copy and a zero-filled e, as rounds 2 built it -- same bits)
+    int cyc; double r0, rr;
+    if (!neg_copy) nd_solve(S.res[0], ee, coeffs[0], nullptr, dx, ebc0, 0.0, -1.0, -1, &cyc, &r0, &rr, &coarse_keep, nullptr, it == 0, true);
+    else {
+      mf_setval(ee, 0.0, 0, 1, true);                   // (er: every node is overwritten below, its ghost nodes are never written and stay zero)
       std::vector<NdfNegB> v;
       for (size_t c = 0; c < S.A[0].size(); c++) {
         NdfNegB q; q.r = S.r[0][c]; q.out = er->fabs[c]; q.in = S.res[0]->fabs[c]; q.A = S.A[0][c]; for (int d = 0; d < 3; d++) { q.A.dirlo[d] = q.A.dirhi[d] = 0; }
         v.push_back(q);
       }
       launch_batched(v, 0, (double *)nullptr, 0, st);
+      nd_solve(er, ee, coeffs[0], nullptr, dx, ebc0, 0.0, -1.0, -1, &cyc, &r0, &rr, &coarse_keep, nullptr, it == 0);     // (first correction: from the nested iteration, hg_fmg)
     }
-    int cyc; double r0, rr;
-    nd_solve(er, ee, coeffs[0], nullptr, dx, ebc0, 0.0, -1.0, -1, &cyc, &r0, &rr, &coarse_keep, nullptr, it == 0);     // (first correction: from the nested iteration, hg_fmg)
     ml_nd_apply_correction(S, 0, ee);
     // relaxation of K_n e = r_n on the finer levels, coarsest first, with the interface fixed
     for (int n = 1; n < L; n++) {

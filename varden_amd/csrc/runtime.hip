@@ -547,7 +547,7 @@ static Range3 fab_range(const vdn_multifab *mf, int i, int grow) {   // valid (i
   for (int d = 0; d < 3; d++) { r.lo[d] = mf->vbox[i].lo[d] - grow; r.hi[d] = mf->vbox[i].hi[d] + mf->nodal[d] + grow; }
   return r;
 }
-struct SetvalB { Range3 r; int g[3]; FV f; int comp, nc; double val;
+struct SetvalB { Range3 r; int g[3]; static constexpr int planes_per_wg = 8; FV f; int comp, nc; double val;
   static __device__ double body(const SetvalB &q, int i, int j, int k, int) { for (int c = q.comp; c < q.comp + q.nc; c++) fv_at(q.f, i, j, k, c) = q.val; return 0.0; } };
 struct CopyB { Range3 r; int g[3]; FV d, s; int dc, sc, nc;
   static __device__ double body(const CopyB &q, int i, int j, int k, int) { for (int c = 0; c < q.nc; c++) fv_at(q.d, i, j, k, q.dc + c) = fv_get(q.s, i, j, k, q.sc + c); return 0.0; } };

@@ -146,14 +146,22 @@ DEVI void block_atomic_max(double *addr, double v) {
   __syncthreads();
 }
 DEVI void block_atomic_max_fwd(double *addr, double v) { block_atomic_max(addr, v); }
+// Planes a workgroup of a batched launch takes when the caller sets no limit.  A 16 x 16 tile of ONE plane is a few KB of traffic behind the
+// workgroup's prologue (bisection over the box list, descriptor fetch): on the 263-box level of the two-level bench line the light bodies (a
+// few loads per cell) gain from eight planes per workgroup -- CfB 78 -> 43 us, NdfAddB 86 -> 60, NdfNegB 100 -> 56, AddProlongB 68 -> 36,
+// AddB 67 -> 54, InterpB 141 -> 119 -- while heavy bodies and one-cell-thick ranges lose from fewer, longer workgroups (RefluxB 11 -> 21,
+// NdmRestrictB 82 -> 110, GsrbB 97 -> 103).  A descriptor says so itself: `static constexpr int planes_per_wg = 8;` (default 1).  The cell a
+// thread works on and its arithmetic do not depend on it.
+template <class T, class = void> struct batch_ppw : std::integral_constant<int, 1> {};
+template <class T> struct batch_ppw<T, std::void_t<decltype(T::planes_per_wg)>> : std::integral_constant<int, T::planes_per_wg> {};
 // workgroups of one box: tile width 64, 32 or 16 by the width of its range, kz = at most this many workgroups along k (0 = one per plane);
 // returns their number (an empty range gets one idle workgroup)
 template <class A> static inline int batch_grid(A &a, int kz) {
   const int nx = a.r.hi[0] - a.r.lo[0] + 1, ny = a.r.hi[1] - a.r.lo[1] + 1, nz = a.r.hi[2] - a.r.lo[2] + 1;
   const int lw = nx > 32 ? 6 : (nx > 16 ? 5 : 4), w = 1 << lw, h = 256 >> lw;
-  // planes per workgroup when the caller sets no limit: a 16 x 16 tile of ONE plane is a few KB of traffic behind a bisection over the box
-  // list and a descriptor fetch -- a level of ~30^3 boxes then runs at the rate workgroups can be dispatched, not at the memory's
-  static const int ppw = getenv("VDN_BATCH_PPW") ? std::max(1, atoi(getenv("VDN_BATCH_PPW"))) : 1;
+  // planes per workgroup when the caller sets no limit (batch_ppw): VDN_BATCH_PPW overrides every descriptor's own choice
+  static const int ppw_env = getenv("VDN_BATCH_PPW") ? std::max(1, atoi(getenv("VDN_BATCH_PPW"))) : 0;
+  const int ppw = ppw_env > 0 ? ppw_env : batch_ppw<A>::value;
   int g0 = nx > 0 ? (nx + w - 1) / w : 0, g1 = ny > 0 ? (ny + h - 1) / h : 0, g2 = nz > 0 ? ((kz > 0 && nz > kz) ? kz : (nz + ppw - 1) / ppw) : 0;
   if (g0 == 0 || g1 == 0 || g2 == 0) { g0 = g1 = g2 = 1; a.r.hi[0] = a.r.lo[0] - 1; }
   a.g[0] = g0; a.g[1] = g1; a.g[2] = g2 | (lw << 24);

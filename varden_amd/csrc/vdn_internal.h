@@ -242,7 +242,7 @@ void do_hgproject(int proj_type, vdn_layout *mla, vdn_multifab **unew, vdn_multi
 struct NdFast { const vdn_multifab *rhohalf = nullptr; std::vector<FV> phi_view; };
 int  nd_solve(vdn_multifab *rh, vdn_multifab *phi, const vdn_multifab *coeffs, const vdn_multifab *u, const double *dx,
               const int bc[3][2], double rel_eps, double abs_eps, int max_iter, int *cycles, double *res0, double *res, struct NdKeep *keep = nullptr,
-              NdFast *fast = nullptr, bool fmg_start = false);      // fmg_start: nested iteration before a FIXED number of cycles (max_iter < 0; the caller's phi is zero)
+              NdFast *fast = nullptr, bool fmg_start = false, bool rh_is_b = false);      // fmg_start: nested iteration before a FIXED number of cycles (max_iter < 0; the caller's phi is zero); rh_is_b: `rh` holds b = -rh and phi is not read (zero guess; max_iter < 0)
 
 // dim2.hip: the dm = 2 path (one level, one box)
 void k2_mkvelforce(vdn_multifab *vf, const vdn_multifab *ext, const vdn_multifab *s, const vdn_multifab *gp, const vdn_multifab *lapu, double visc_fac);
