@@ -188,7 +188,7 @@ void vo_create_umac_grown(vo_fab *fine, const vo_fab *crse, int dir);
 void vo_ml_restrict_and_fill(int nlev, vo_fab **mf, int icomp, int bcomp, int nc, int same_boundary, const vo_bc *bc, const int pmask[3],
                              const int *pd, const vdn_params *prm);
 int  vo_ml_cc_solve(int nlev, vo_fab **rh, vo_fab **phi, vo_fab **alpha, vo_fab **beta, const double *dx, const int ellbc[][3][2], const int pmask[3], const int *pd,
-                    double rel_eps, int max_iter, const vdn_params *prm, vo_mgstat *st);
+                    double rel_eps, int max_iter, const vdn_params *prm, vo_fab **beta_base, vo_mgstat *st);
 void vo_ml_macproject(int nlev, vo_fab **umac, vo_fab **rho, vo_fab **mac_rhs, const double *dx, const vo_bc *bc, const int pmask[3], const int *pd,
                       const vdn_params *prm, vo_mgstat *st);
 

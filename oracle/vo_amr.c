@@ -346,9 +346,13 @@ static void apply_correction(int nlev, int n, vo_fab **phi, vo_fab *e, vo_fab *s
 /* rh, phi: [lev];  beta: [lev*3 + d];  dx: [lev*3 + d];  ellbc[lev] per box;  pd: [lev][2][3].
  * One FAC iteration: composite residual / test; for n = finest..1: nu1 red-black sweeps on level n (homogeneous interface), correction
  * applied to level n and prolonged to the finer ones, composite residual; ONE V-cycle of the single-level multigrid on level 0, applied
- * and prolonged, composite residual; for n = 1..finest: nu2 sweeps on level n, applied and prolonged (composite residual before the next). */
+ * and prolonged, composite residual; for n = 1..finest: nu2 sweeps on level n, applied and prolonged (composite residual before the next).
+ * beta_base (may be NULL): the face coefficients the level-0 V-cycle takes instead of beta[0..2] -- the MAC projection hands over the
+ * coefficients of level 0's own density, 2/(rho_i + rho_i-1) on every face, where beta carries the edge restriction of the finer level's
+ * under it: the V-cycle is a preconditioner (the composite residual is formed with beta), the FAC counts stay or drop by one (measured),
+ * and the HIP side can run its density-based kernels on that level. */
 int vo_ml_cc_solve(int nlev, vo_fab **rh, vo_fab **phi, vo_fab **alpha, vo_fab **beta, const double *dx, const int ellbc[][3][2], const int pmask[3], const int *pd,
-                   double rel_eps, int max_iter, const vdn_params *prm, vo_mgstat *st)
+                   double rel_eps, int max_iter, const vdn_params *prm, vo_fab **beta_base, vo_mgstat *st)
 {
   if (nlev < 2 || nlev > VO_MAXLEV) { fprintf(stderr, "vo_ml_cc_solve: 2..%d levels\n", VO_MAXLEV); abort(); }
   /* inhomogeneous Dirichlet data: the ghost cells of the incoming phi hold the boundary-FACE values (viscsolve.f90:270); the face term
@@ -390,7 +394,7 @@ int vo_ml_cc_solve(int nlev, vo_fab **rh, vo_fab **phi, vo_fab **alpha, vo_fab *
     /* coarse correction: ONE V-cycle of the single-level multigrid on the whole coarse level */
     memset(e[0].p, 0, sizeof(double) * vo_size(&e[0]));
     vo_mgstat cs;
-    vo_cc_solve_ab(&res[0], &e[0], alpha ? alpha[0] : NULL, beta, dx, ellbc[0], 0.0, -1.0, -1, prm->mg_nu1, prm->mg_nu2, prm->mg_nub, 0, &cs);     /* (a nested-iteration start of the FIRST correction saves no FAC iteration here: measured, 10 -> 10) */
+    vo_cc_solve_ab(&res[0], &e[0], alpha ? alpha[0] : NULL, beta_base ? beta_base : beta, dx, ellbc[0], 0.0, -1.0, -1, prm->mg_nu1, prm->mg_nu2, prm->mg_nub, 0, &cs);     /* (a nested-iteration start of the FIRST correction saves no FAC iteration here: measured, 10 -> 10) */
     apply_correction(nlev, 0, phi, e, scr, pmask, pd);
     for (int n = 1; n < nlev; n++) {                    /* post-relaxation, coarsest first */
       if (n < nlev - 1) (void)composite_residual(nlev, rh, phi, alpha, beta, dx, ellbc, pmask, pd, rp);
@@ -431,8 +435,11 @@ void vo_ml_macproject(int nlev, vo_fab **umac, vo_fab **rho, vo_fab **mac_rhs, c
   for (int n = nlev - 1; n >= 1; n--) vo_ml_cc_restriction(&rh[n - 1], &rh[n], 0, 1);
   /* mk_mac_coeffs (macproject.f90:296-334): rho's fine ghosts come from the caller's ml_restrict_and_fill; edge restriction */
   for (int n = 0; n < nlev; n++) vo_mk_mac_coeffs(rho[n], bp + 3 * n);
+  vo_fab b0[3], *b0p[3];                                /* level 0's own coefficients, before the edge restriction overwrites the covered faces */
+  for (int d = 0; d < 3; d++) { b0[d] = beta[d]; b0[d].p = (double *)malloc(sizeof(double) * vo_size(&beta[d])); memcpy(b0[d].p, beta[d].p, sizeof(double) * vo_size(&beta[d])); b0p[d] = &b0[d]; }
   for (int n = nlev - 1; n >= 1; n--) for (int d = 0; d < 3; d++) vo_ml_edge_restriction(bp[3 * (n - 1) + d], bp[3 * n + d], d);
-  vo_ml_cc_solve(nlev, rhp, php, NULL, bp, dx, (const int (*)[3][2])ellbc, pmask, pd, prm->mac_rel_eps, prm->mg_max_iter, prm, st);
+  vo_ml_cc_solve(nlev, rhp, php, NULL, bp, dx, (const int (*)[3][2])ellbc, pmask, pd, prm->mac_rel_eps, prm->mg_max_iter, prm, b0p, st);
+  for (int d = 0; d < 3; d++) free(b0[d].p);
   /* mkumac on every level with the solver's ghost cells, then edge restriction and the ghost faces (macproject.f90:103-119) */
   for (int n = 0; n < nlev; n++) vo_mkumac(umac + 3 * n, &phi[n], bp + 3 * n, dx + 3 * n, ellbc[n]);
   for (int n = nlev - 1; n >= 1; n--) for (int d = 0; d < 3; d++) vo_ml_edge_restriction(umac[3 * (n - 1) + d], umac[3 * n + d], d);
@@ -478,7 +485,7 @@ void vo_ml_visc_solve(int nlev, vo_fab **unew, vo_fab **lapu, vo_fab **rho, vo_f
       }
       for (int a = 0; a < 3; a++) for (int s = 0; s < 2; s++) ellbc[n][a][s] = bc[n].ell[a][s][d];
     }
-    vo_ml_cc_solve(nlev, rhp, php, alp, bp, dx, (const int (*)[3][2])ellbc, pmask, pd, 1.e-12, prm->mg_max_iter, prm, st);
+    vo_ml_cc_solve(nlev, rhp, php, alp, bp, dx, (const int (*)[3][2])ellbc, pmask, pd, 1.e-12, prm->mg_max_iter, prm, NULL, st);
     for (int n = 0; n < nlev; n++)
       for (int k = unew[n]->lo[2]; k <= unew[n]->hi[2]; k++) for (int j = unew[n]->lo[1]; j <= unew[n]->hi[1]; j++) for (int i = unew[n]->lo[0]; i <= unew[n]->hi[0]; i++)
         VF(unew[n], i, j, k, d) = VF(&phi[n], i, j, k, 0);
@@ -515,7 +522,7 @@ void vo_ml_diff_scalar_solve(int nlev, vo_fab **snew, vo_fab **laps, const doubl
     }
     for (int a = 0; a < 3; a++) for (int sd = 0; sd < 2; sd++) ellbc[n][a][sd] = bc[n].ell[a][sd][bccomp];
   }
-  vo_ml_cc_solve(nlev, rhp, php, alp, bp, dx, (const int (*)[3][2])ellbc, pmask, pd, 1.e-12, prm->mg_max_iter, prm, st);
+  vo_ml_cc_solve(nlev, rhp, php, alp, bp, dx, (const int (*)[3][2])ellbc, pmask, pd, 1.e-12, prm->mg_max_iter, prm, NULL, st);
   for (int n = 0; n < nlev; n++)
     for (int k = snew[n]->lo[2]; k <= snew[n]->hi[2]; k++) for (int j = snew[n]->lo[1]; j <= snew[n]->hi[1]; j++) for (int i = snew[n]->lo[0]; i <= snew[n]->hi[0]; i++)
       VF(snew[n], i, j, k, icomp) = VF(&phi[n], i, j, k, 0);

@@ -697,7 +697,7 @@ static void apply_correction(MLCC &S, int n) {
 // alpha: [lev] cell coefficients of (alpha - div beta grad), or nullptr.  The ghost cells of the incoming phi carry inhomogeneous
 // Dirichlet data (boundary-face values); they are moved into rh, which is modified
 int ml_cc_solve(vdn_layout *la, vdn_multifab **rh, vdn_multifab **phi, vdn_multifab **beta, const double *dx, const vdn_bc_tower *bct, int bc_comp0,
-                double rel_eps, int max_iter, int *iters, double *res0, double *res, vdn_multifab **alpha) {
+                double rel_eps, int max_iter, int *iters, double *res0, double *res, vdn_multifab **alpha, vdn_multifab **base_beta, const vdn_multifab *base_rho) {
   require_amr(la);
   hipStream_t st = ctx().stream;
   const size_t mark = arena_mark();
@@ -760,7 +760,10 @@ int ml_cc_solve(vdn_layout *la, vdn_multifab **rh, vdn_multifab **phi, vdn_multi
     // coarse correction: ONE V-cycle of the single-level multigrid on the whole level 0
     mf_setval(S.e[0], 0.0, 0, 1, true);
     int cyc; double r0, rr;
-    cc_solve(S.res[0], S.e[0], beta, dx, ebc0, 0.0, -1.0, -1, &cyc, &r0, &rr, alpha ? alpha[0] : nullptr, nullptr, coarse_keep);     // (no nested-iteration start here: it saves no FAC iteration, measured)
+    // (base_beta / base_rho, the MAC projection: the V-cycle runs on level 0's OWN coefficients 2/(rho_i + rho_i-1) -- `beta` carries the edge
+    // restriction of the finer level's on the covered faces -- and so on the density-based kernels of the single-level solver; it is a
+    // preconditioner, the composite residual above is formed with `beta`.  Oracle: beta_base of vo_ml_cc_solve)
+    cc_solve(S.res[0], S.e[0], base_beta ? base_beta : beta, dx, ebc0, 0.0, -1.0, -1, &cyc, &r0, &rr, alpha ? alpha[0] : nullptr, base_beta ? base_rho : nullptr, coarse_keep);     // (no nested-iteration start here: it saves no FAC iteration, measured)
     apply_correction(S, 0);
     // post-relaxation on the new residual, coarsest level first
     for (int n = 1; n < L; n++) {
@@ -795,7 +798,11 @@ void do_ml_macproject(vdn_layout *mla, vdn_multifab **umac, vdn_multifab **rho, 
   for (int n = L - 1; n >= 1; n--) ml_cc_restriction(rh[n - 1], rh[n], 0, 1);     // 204-206
   for (int n = L - 1; n >= 1; n--) for (int d = 0; d < 3; d++) ml_edge_restriction(beta[3 * (n - 1) + d], beta[3 * n + d], d);       // 330-333
   int it; double r0, rr;
-  int rc = ml_cc_solve(mla, rh, phi, beta, dx, bct, bc_comp0, ctx().prm.mac_rel_eps, ctx().prm.mg_max_iter, &it, &r0, &rr, nullptr);
+  vdn_multifab *beta0[3];                    // level 0's own coefficients (the covered faces not overwritten): what the coarse correction's V-cycle runs on
+  for (int d = 0; d < 3; d++) beta0[d] = mf_temp(mla, 0, 1, 0, d, false, 0.0);
+  mac_level_coeffs(rho[0], beta0);
+  int rc = ml_cc_solve(mla, rh, phi, beta, dx, bct, bc_comp0, ctx().prm.mac_rel_eps, ctx().prm.mg_max_iter, &it, &r0, &rr, nullptr, beta0, rho[0]);
+  for (int d = 2; d >= 0; d--) mf_temp_free(beta0[d]);
   ctx().solver_cycles[0] = it; ctx().solver_res0[0] = r0; ctx().solver_res[0] = rr;
   solver_check(rc, "composite MAC solve", it, rr, r0);
   for (int n = 0; n < L; n++) mac_level_mkumac(umac + 3 * n, phi[n], beta + 3 * n, dx + 3 * n, bct, bc_comp0);   // 103

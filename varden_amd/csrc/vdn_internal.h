@@ -272,7 +272,7 @@ void ml_fill_ghost_cells(vdn_multifab *fine, const vdn_multifab *crse, int icomp
 void ml_create_umac_grown(vdn_multifab *fine, const vdn_multifab *crse, int dir);
 void ml_restrict_and_fill(int nlev, vdn_multifab **mf, int icomp, int bcomp, int nc, bool same_boundary, const vdn_bc_tower *bct);
 int ml_cc_solve(vdn_layout *la, vdn_multifab **rh, vdn_multifab **phi, vdn_multifab **beta, const double *dx, const vdn_bc_tower *bct, int bc_comp0,
-                double rel_eps, int max_iter, int *iters, double *res0, double *res, vdn_multifab **alpha);
+                double rel_eps, int max_iter, int *iters, double *res0, double *res, vdn_multifab **alpha, vdn_multifab **base_beta = nullptr, const vdn_multifab *base_rho = nullptr);
 void do_ml_visc_solve(vdn_layout *mla, vdn_multifab **unew, vdn_multifab **lapu, vdn_multifab **rho, vdn_multifab **mac_rhs,
                       const double *dx, double mu, const vdn_bc_tower *bct);
 void do_ml_diff_scalar_solve(vdn_layout *mla, vdn_multifab **snew, vdn_multifab **laps, const double *dx, double mu,
