@@ -652,7 +652,8 @@ static void mlcc_build_sets(MLCC &S) {
 static void fill_phi_ghosts(MLCC &S) {
   hipStream_t st = ctx().stream;
   for (int n = S.nlev - 1; n >= 1; n--) { S.vf_phi[n].refresh(); S.rphi[n].run(0, (double *)nullptr, st); }
-  for (int n = 0; n < S.nlev; n++) { S.closure[n].run(0, (double *)nullptr, st); mf_fill_boundary(S.phi[n]); }
+  // (levels >= 1: the exchange follows the coarse-fine interpolation below, which reads no ghost cell of its own level -- one exchange per level)
+  for (int n = 0; n < S.nlev; n++) { S.closure[n].run(0, (double *)nullptr, st); if (n == 0) mf_fill_boundary(S.phi[n]); }
   for (int n = 1; n < S.nlev; n++) { S.vc_phi[n].refresh(); S.cf[n].run(0, (double *)nullptr, st); mf_fill_boundary(S.phi[n]); }
 }
 static double composite_residual(MLCC &S) {
@@ -674,7 +675,7 @@ static void level_relax(MLCC &S, int n, int nsweeps) {
   mf_setval(e, 0.0, 0, 1, true);
   const bool exchange = level_boxes(e).size() > 1 || S.la->pmask[0] || S.la->pmask[1] || S.la->pmask[2];     // boxes of the level anywhere, not just here: every rank must take part
   for (int s = 0; s < nsweeps; s++) for (int col = 0; col < 2; col++) {
-    if (exchange) mf_fill_boundary(e);
+    if (exchange && (s > 0 || col > 0)) mf_fill_boundary(e);      // (the first pass starts from e = 0, ghost cells included)
     S.gsrb[n].run(col, (double *)nullptr, ctx().stream);
   }
 }
