@@ -97,6 +97,7 @@ template <class T> DEVI const T &as_constant(const T *p) {
 // SCRATCH when it is copied by value -- mkumac_rho_K, 310 bytes: 320 bytes of scratch per lane, 19 ms instead of 2.3 ms per 8-box launch
 template <class T, class = void> struct desc_in_constant : std::integral_constant<bool, (sizeof(T) > 320)> {};
 template <class T> struct desc_in_constant<T, std::void_t<decltype(T::in_constant)>> : std::integral_constant<bool, T::in_constant> {};
+enum { BATCH_YZ = 15 };      // tile code in the top byte of g[2] (otherwise log2 of the tile width along x)
 template <class A, class P>
 __global__ void __launch_bounds__(256) kk_batched(const A *args, const int *start, int nbox, P extra, double *nrm) {
   int lo = 0, hi = nbox - 1;
@@ -111,10 +112,16 @@ __global__ void __launch_bounds__(256) kk_batched(const A *args, const int *star
   // 32-wide boxes: a 64-wide tile would leave half or three quarters of every wave idle); log2(width) rides in the top byte of g[2]
   const int lw = a.g[2] >> 24, gz = a.g[2] & 0xffffff;
   const int tid = (int)threadIdx.x + 64 * (int)threadIdx.y;
-  const int i = a.r.lo[0] + (bx << lw) + (tid & ((1 << lw) - 1)), j = a.r.lo[1] + by * (256 >> lw) + (tid >> lw);
   double v = 0.0;
-  if (i <= a.r.hi[0] && j <= a.r.hi[1])
-    for (int k = a.r.lo[2] + bz; k <= a.r.hi[2]; k += gz) v = nmax(v, A::body(a, i, j, k, extra));
+  if (lw == BATCH_YZ) {                   // a range one or two cells thin along x (the x faces of a box): 16 x 16 tiles of (j, k), x inside
+    const int j = a.r.lo[1] + by * 16 + (tid & 15), k = a.r.lo[2] + bz * 16 + (tid >> 4);
+    if (j <= a.r.hi[1] && k <= a.r.hi[2])
+      for (int i = a.r.lo[0]; i <= a.r.hi[0]; i++) v = nmax(v, A::body(a, i, j, k, extra));
+  } else {
+    const int i = a.r.lo[0] + (bx << lw) + (tid & ((1 << lw) - 1)), j = a.r.lo[1] + by * (256 >> lw) + (tid >> lw);
+    if (i <= a.r.hi[0] && j <= a.r.hi[1])
+      for (int k = a.r.lo[2] + bz; k <= a.r.hi[2]; k += gz) v = nmax(v, A::body(a, i, j, k, extra));
+  }
   if (nrm) block_atomic_max_fwd(nrm, v);
 }
 // wave-level max (64 lanes) then one atomic per wave on a non-negative double stored as u64 bits
@@ -164,6 +171,12 @@ template <class T> struct batch_ppw<T, std::void_t<decltype(T::planes_per_wg)>> 
 // returns their number (an empty range gets one idle workgroup)
 template <class A> static inline int batch_grid(A &a, int kz) {
   const int nx = a.r.hi[0] - a.r.lo[0] + 1, ny = a.r.hi[1] - a.r.lo[1] + 1, nz = a.r.hi[2] - a.r.lo[2] + 1;
+  // x faces (ghost slabs, coarse-fine faces, interface nodes): with x along the lanes a 16-wide tile runs one lane in sixteen
+  static const bool yz_on = !(getenv("VDN_BATCH_YZ") && atoi(getenv("VDN_BATCH_YZ")) == 0);
+  if (yz_on && nx >= 1 && nx <= 2 && ny >= 1 && nz >= 1 && (long)ny * nz >= 64) {
+    a.g[0] = 1; a.g[1] = (ny + 15) / 16; a.g[2] = ((nz + 15) / 16) | (BATCH_YZ << 24);
+    return a.g[1] * ((nz + 15) / 16);
+  }
   const int lw = nx > 32 ? 6 : (nx > 16 ? 5 : 4), w = 1 << lw, h = 256 >> lw;
   // planes per workgroup when the caller sets no limit (batch_ppw): VDN_BATCH_PPW overrides every descriptor's own choice
   static const int ppw_env = getenv("VDN_BATCH_PPW") ? std::max(1, atoi(getenv("VDN_BATCH_PPW"))) : 0;
