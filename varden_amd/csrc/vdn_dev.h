@@ -97,7 +97,7 @@ template <class T> DEVI const T &as_constant(const T *p) {
 // SCRATCH when it is copied by value -- mkumac_rho_K, 310 bytes: 320 bytes of scratch per lane, 19 ms instead of 2.3 ms per 8-box launch
 template <class T, class = void> struct desc_in_constant : std::integral_constant<bool, (sizeof(T) > 320)> {};
 template <class T> struct desc_in_constant<T, std::void_t<decltype(T::in_constant)>> : std::integral_constant<bool, T::in_constant> {};
-enum { BATCH_YZ = 15 };      // tile code in the top byte of g[2] (otherwise log2 of the tile width along x)
+enum { BATCH_YZ = 15, BATCH_XZ = 16 };      // tile codes in the top byte of g[2] (otherwise log2 of the tile width along x); XZ + log2 width
 template <class A, class P>
 __global__ void __launch_bounds__(256) kk_batched(const A *args, const int *start, int nbox, P extra, double *nrm) {
   int lo = 0, hi = nbox - 1;
@@ -117,6 +117,11 @@ __global__ void __launch_bounds__(256) kk_batched(const A *args, const int *star
     const int j = a.r.lo[1] + by * 16 + (tid & 15), k = a.r.lo[2] + bz * 16 + (tid >> 4);
     if (j <= a.r.hi[1] && k <= a.r.hi[2])
       for (int i = a.r.lo[0]; i <= a.r.hi[0]; i++) v = nmax(v, A::body(a, i, j, k, extra));
+  } else if (lw >= BATCH_XZ) {            // a range thin along y (the y faces): tiles of (i, k) -- 2^w lanes along x, 256 >> w planes --, y inside
+    const int w = lw - BATCH_XZ;
+    const int i = a.r.lo[0] + (bx << w) + (tid & ((1 << w) - 1)), k = a.r.lo[2] + bz * (256 >> w) + (tid >> w);
+    if (i <= a.r.hi[0] && k <= a.r.hi[2])
+      for (int j = a.r.lo[1]; j <= a.r.hi[1]; j++) v = nmax(v, A::body(a, i, j, k, extra));
   } else {
     const int i = a.r.lo[0] + (bx << lw) + (tid & ((1 << lw) - 1)), j = a.r.lo[1] + by * (256 >> lw) + (tid >> lw);
     if (i <= a.r.hi[0] && j <= a.r.hi[1])
@@ -178,6 +183,10 @@ template <class A> static inline int batch_grid(A &a, int kz) {
     return a.g[1] * ((nz + 15) / 16);
   }
   const int lw = nx > 32 ? 6 : (nx > 16 ? 5 : 4), w = 1 << lw, h = 256 >> lw;
+  if (yz_on && ny >= 1 && ny <= 2 && nx >= 1 && nz >= 4 && (long)nx * nz >= 64) {      // y faces: x along the lanes as always, planes instead of rows
+    a.g[0] = (nx + w - 1) / w; a.g[1] = 1; a.g[2] = ((nz + h - 1) / h) | ((BATCH_XZ + lw) << 24);
+    return a.g[0] * ((nz + h - 1) / h);
+  }
   // planes per workgroup when the caller sets no limit (batch_ppw): VDN_BATCH_PPW overrides every descriptor's own choice
   static const int ppw_env = getenv("VDN_BATCH_PPW") ? std::max(1, atoi(getenv("VDN_BATCH_PPW"))) : 0;
   const int ppw = ppw_env > 0 ? ppw_env : batch_ppw<A>::value;
