@@ -1714,6 +1714,122 @@ __global__ void __launch_bounds__(256) kk_ndf_march(const MarchB *args, const in
   }
   if (MODE == 1 && nrm) block_atomic_max(nrm, rmax);
 }
+// ---- paired form of the box-batched march (round 3) -----------------------------------------------------------------------------------
+// The boxes of a hierarchy are 9 .. 41 nodes wide: with one node per lane and the first and last lane of a row segment feeding their
+// neighbours, a 33-node row fills half of a 64-lane segment and a 17-node row half of a 32-lane one -- the march of a 997-box level ran at
+// 2.5 x the time of its traffic.  Here a lane owns the nodes (ia, ia + 1), ia = lo + 2p, as in kk_nd_march_pair: a row of 33 nodes is 17
+// lanes (+ 2 feeders) of a 32-lane segment, two rows per wave, and every access is a 16-byte pair.  A fab row has no padding: the pair of
+// a lane at the end of a row is read from inside the row and shifted (fv_pair), its unused half is junk; rows are 8-byte aligned only.
+// Same arithmetic per node (nd_stencil), same bits.
+typedef double vdn_d2u __attribute__((ext_vector_type(2), aligned(8)));
+struct PairAt { long idx; int sh; };         // linear index of the (clamped) pair start in a fab, and ia - that start (-1, 0, +1; beyond: junk)
+DEVI PairAt pair_at(const FV &f, int i, int j, int k) {
+  const int ic = min(max(i, f.a0), f.a0 + f.n0 - 2);
+  PairAt q; q.idx = fv_idx(f, ic, j, k); q.sh = i - ic; return q;
+}
+DEVI void ld_pair(const double *p, long idx, int sh, double &a, double &b) {
+  const vdn_d2u v = *reinterpret_cast<const vdn_d2u *>(p + idx);
+  a = sh > 0 ? v.y : v.x; b = sh < 0 ? v.x : v.y;
+}
+template <int MODE>
+__global__ void __launch_bounds__(256) kk_ndf_march2(const MarchB *args, const int *start, int nbox, double omega, int excl, double *nrm) {
+  int lo_ = 0, hi_ = nbox - 1;
+  const int bid = (int)blockIdx.x;
+  while (lo_ < hi_) { const int mid = (lo_ + hi_ + 1) >> 1; if (as_constant(start + mid) <= bid) lo_ = mid; else hi_ = mid - 1; }
+  const MarchB B = as_constant(args + lo_);
+  const FV phi = B.phi, out = B.out, rb = B.rb, sig = B.sig, slave = B.slave;
+  const int has_slave = B.has_slave, kchunk = B.kchunk;
+  const NdfArgs A = B.A; const Range3 r = B.r;
+  const int lb = bid - as_constant(start + lo_);
+  const int bx = lb % B.g[0], by = (lb / B.g[0]) % B.g[1], bz = lb / (B.g[0] * B.g[1]);
+  const int lw = B.lw, sw = 1 << lw, rows = 64 >> lw;
+  const int lane = (int)threadIdx.x & (sw - 1), seg = (int)threadIdx.x >> lw;
+  const int ia = r.lo[0] + 2 * (bx * (sw - 2) + lane - 1);                  // nodes ia, ia + 1
+  const int j = r.lo[1] + (by * (int)blockDim.y + (int)threadIdx.y) * rows + seg;
+  const int k0 = r.lo[2] + bz * kchunk, k1 = min(k0 + kchunk - 1, r.hi[2]);
+  const bool own = lane >= 1 && lane <= sw - 2 && j <= r.hi[1];
+  const bool actA = own && ia <= r.hi[0], actB = own && ia + 1 <= r.hi[0];
+  const int jc = min(j, r.hi[1]);
+  double rmax = 0.0;
+  if (k0 <= k1) {
+    // per fab: where this lane's pair of row jc, plane k0 sits, the row and plane strides
+    const PairAt ap = pair_at(phi, ia, jc, k0), as = pair_at(sig, ia, jc, k0), ab = pair_at(rb, ia, jc, k0);
+    const long syp = phi.n0, szp = (long)phi.n0 * phi.n1, sys = sig.n0, szs = (long)sig.n0 * sig.n1, szb = (long)rb.n0 * rb.n1;
+    PairAt al = ab; long szl = 0;
+    const bool use_mask = has_slave == 1 && (MODE == 0 || excl == 1);
+    if (use_mask) { al = pair_at(slave, ia, jc, k0); szl = (long)slave.n0 * slave.n1; }
+    // the pair store: lanes with both nodes write 16 bytes, the lane whose second node lies beyond the box writes node A alone; every lane
+    // executes both store instructions (the others into a sink): the number of stores in flight is known at compile time (see kk_nd_march_pair)
+    const long io = fv_idx(out, min(ia, r.hi[0]), jc, k0), szo = (long)out.n0 * out.n1;
+    double *op2 = actB ? out.p + io : g_nd_sink + 2 * (int)threadIdx.x;       // (g_nd_sink: 128 doubles, one 16-byte slot per lane of a wave)
+    double *op1 = (actA && !actB) ? out.p + io : g_nd_sink + 2 * (int)threadIdx.x;
+    const long st2 = actB ? szo : 0, st1 = (actA && !actB) ? szo : 0;
+    long cp = ap.idx, cs = as.idx, cb = ab.idx, cl = al.idx;
+    double q[3][3][4], sg[2][2][3];
+    #define LOADP(pl, off) { _Pragma("unroll") for (int b = 0; b < 3; b++) ld_pair(phi.p, (off) + (b - 1) * syp, ap.sh, q[pl][b][1], q[pl][b][2]); }
+    #define EXCHP(pl) { _Pragma("unroll") for (int b = 0; b < 3; b++) { q[pl][b][0] = lane_prev(q[pl][b][2]); q[pl][b][3] = lane_next(q[pl][b][1]); } }
+    #define LOADS(dk, off) { _Pragma("unroll") for (int dj = 0; dj < 2; dj++) ld_pair(sig.p, (off) + (dj - 1) * sys, as.sh, sg[dk][dj][1], sg[dk][dj][2]); }
+    #define EXCHS(dk) { _Pragma("unroll") for (int dj = 0; dj < 2; dj++) sg[dk][dj][0] = lane_prev(sg[dk][dj][2]); }
+    LOADP(0, cp - szp) LOADP(1, cp) LOADS(0, cs - szs)
+    EXCHP(0) EXCHP(1) EXCHS(0)
+    const NdW W = nd_weights(A.f);
+    for (int k = k0; k <= k1; k++, cp += szp, cs += szs, cb += szb, cl += szl, op2 += st2, op1 += st1) {
+      LOADP(2, cp + szp) LOADS(1, cs)
+      double rhsA, rhsB; ld_pair(rb.p, cb, ab.sh, rhsA, rhsB);
+      double mA = 0.0, mB = 0.0;
+      if (use_mask) ld_pair(slave.p, cl, al.sh, mA, mB);
+      EXCHP(2) EXCHS(1)
+      double pa[3][3][3], pb[3][3][3], sa[2][2][2], sb[2][2][2];
+      #pragma unroll
+      for (int pl = 0; pl < 3; pl++)
+        #pragma unroll
+        for (int b = 0; b < 3; b++)
+          #pragma unroll
+          for (int a = 0; a < 3; a++) { pa[pl][b][a] = q[pl][b][a]; pb[pl][b][a] = q[pl][b][a + 1]; }
+      #pragma unroll
+      for (int dk = 0; dk < 2; dk++)
+        #pragma unroll
+        for (int dj = 0; dj < 2; dj++)
+          #pragma unroll
+          for (int a = 0; a < 2; a++) { sa[dk][dj][a] = sg[dk][dj][a]; sb[dk][dj][a] = sg[dk][dj][a + 1]; }
+      double KpA, dgA, KpB, dgB;
+      nd_stencil(W, pa, sa, KpA, dgA);
+      nd_stencil(W, pb, sb, KpB, dgB);
+      const double p0A = q[1][1][1], p0B = q[1][1][2];
+      const bool pdirA = ndf_pdir(A, ia, j, k), pdirB = ndf_pdir(A, ia + 1, j, k);
+      // slaved to the coarser level: has_slave = 1 node mask (any union of boxes), 2 = the level is ONE box: its non-physical faces
+      const bool cfA = (has_slave == 2) ? (ndf_cf(A, ia, j, k) && !pdirA) : (use_mask ? (mA != 0.0) : false);
+      const bool cfB = (has_slave == 2) ? (ndf_cf(A, ia + 1, j, k) && !pdirB) : (use_mask ? (mB != 0.0) : false);
+      double oA, oB;
+      if (MODE == 0) {
+        oA = p0A; oB = p0B;
+        if (!pdirA && !cfA && dgA != 0.0) oA = p0A + omega * ((rhsA - KpA) / dgA);
+        if (!pdirB && !cfB && dgB != 0.0) oB = p0B + omega * ((rhsB - KpB) / dgB);
+      } else {
+        oA = pdirA ? 0.0 : rhsA - KpA;
+        oB = pdirB ? 0.0 : rhsB - KpB;
+        if (actA && !(excl == 1 && cfA && !pdirA)) rmax = nmax(rmax, fabs(oA));
+        if (actB && !(excl == 1 && cfB && !pdirB)) rmax = nmax(rmax, fabs(oB));
+      }
+      vdn_d2u o2; o2.x = oA; o2.y = oB;
+      *reinterpret_cast<vdn_d2u *>(op2) = o2;
+      *op1 = oA;
+      #pragma unroll
+      for (int b = 0; b < 3; b++)
+        #pragma unroll
+        for (int a = 0; a < 4; a++) { q[0][b][a] = q[1][b][a]; q[1][b][a] = q[2][b][a]; }
+      #pragma unroll
+      for (int dj = 0; dj < 2; dj++)
+        #pragma unroll
+        for (int a = 0; a < 3; a++) sg[0][dj][a] = sg[1][dj][a];
+    }
+    #undef LOADP
+    #undef EXCHP
+    #undef LOADS
+    #undef EXCHS
+  }
+  if (MODE == 1 && nrm) block_atomic_max(nrm, rmax);
+}
 // one launch for all boxes of a level
 struct MarchSet { MarchB *d_args = nullptr; int *d_start = nullptr; int nbox = 0, tot = 0; };
 static MarchSet ndf_build_march(std::vector<MarchB> &v) {
@@ -1723,8 +1839,10 @@ static MarchSet ndf_build_march(std::vector<MarchB> &v) {
   for (size_t b = 0; b < v.size(); b++) {
     MarchB &B = v[b];
     const int nx = B.r.hi[0] - B.r.lo[0] + 1, ny = B.r.hi[1] - B.r.lo[1] + 1, nz = B.r.hi[2] - B.r.lo[2] + 1;
-    B.lw = nx <= 14 ? 4 : (nx <= 30 ? 5 : 6);
-    const int act = (1 << B.lw) - 2, rows = 4 * (64 >> B.lw);
+    static const bool paired = !(getenv("VDN_NDF_PAIR") && atoi(getenv("VDN_NDF_PAIR")) == 0);
+    if (paired) B.lw = nx <= 12 ? 3 : (nx <= 28 ? 4 : (nx <= 60 ? 5 : 6));       // kk_ndf_march2: a lane carries two nodes
+    else B.lw = nx <= 14 ? 4 : (nx <= 30 ? 5 : 6);
+    const int act = (paired ? 2 : 1) * ((1 << B.lw) - 2), rows = 4 * (64 >> B.lw);
     const int tiles = ((nx + act - 1) / act) * ((ny + rows - 1) / rows);
     int kchunk = nz;
     while (kchunk > 8 && tiles * ((nz + kchunk - 1) / kchunk) < 2048) kchunk = (kchunk + 1) / 2;
@@ -1740,7 +1858,9 @@ static MarchSet ndf_build_march(std::vector<MarchB> &v) {
 }
 template <int MODE> static void ndf_run_march(const MarchSet &S, double omega, int excl, double *nrm) {
   if (S.nbox == 0) return;
-  hipLaunchKernelGGL(kk_ndf_march<MODE>, dim3(S.tot), NBLK, 0, ctx().stream, (const MarchB *)S.d_args, (const int *)S.d_start, S.nbox, omega, excl, nrm);
+  static const bool paired = !(getenv("VDN_NDF_PAIR") && atoi(getenv("VDN_NDF_PAIR")) == 0);
+  if (paired) hipLaunchKernelGGL(kk_ndf_march2<MODE>, dim3(S.tot), NBLK, 0, ctx().stream, (const MarchB *)S.d_args, (const int *)S.d_start, S.nbox, omega, excl, nrm);
+  else hipLaunchKernelGGL(kk_ndf_march<MODE>, dim3(S.tot), NBLK, 0, ctx().stream, (const MarchB *)S.d_args, (const int *)S.d_start, S.nbox, omega, excl, nrm);
 }
 
 static double ndf_read(double *d) { return read_scalar1(d); }
