@@ -601,7 +601,8 @@ static void mlcc_build_sets(MLCC &S) {
       }
       AddB ad; ad.r = r; ad.a = S.phi[n]->fabs[b]; ad.b = S.e[n]->fabs[b]; vadd.push_back(ad);
     }
-    S.resid[n].build(vr, 16, st); S.absmax[n].build(va, 16, st); S.gsrb[n].build(vg, 0, st); S.add[n].build(vadd, 0, st);
+    S.resid[n].build(vr, 0, st);          // (contiguous chunks of planes per workgroup: the k-1 / k+1 planes of phi stay in cache; its norm's atomics are rare, vdn_dev.h)
+    S.absmax[n].build(va, 16, st); S.gsrb[n].build(vg, 0, st); S.add[n].build(vadd, 0, st);
     // flux matching on the cells of level n-1 next to the boxes of level n
     if (n >= 1)
       for (int d = 0; d < 3; d++) for (int s = 0; s < 2; s++) {

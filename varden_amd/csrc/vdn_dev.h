@@ -106,11 +106,21 @@ __global__ void __launch_bounds__(256) kk_batched(const A *args, const int *star
   // small descriptors are copied into registers (kernels that loop over k re-read a constant-space one every plane: NdfNegB 106 -> 151 us),
   // large ones stay in constant space (a by-value copy of UpdateB lands in 632 bytes of scratch: 3.8 ms -> 0.5 ms)
   typename std::conditional<!desc_in_constant<A>::value, const A, const A &>::type a = as_constant(args + lo);
-  const int lb = bid - as_constant(start + lo);
+  int lb = bid - as_constant(start + lo);
+  const int lw = a.g[2] >> 24, gz = a.g[2] & 0x7fffff;
+  const bool chunks = (a.g[2] >> 23) & 1;       // k: a contiguous chunk of planes per workgroup (the stencil's k-1 / k+1 planes stay in cache) instead of a stride of gz
+  {   // a box with many workgroups (the one-box base level of a hierarchy): workgroups bid, bid + 8, ... share an XCD and its L2 -- give each XCD a
+      // contiguous piece of the box's tile sequence (xcd_tile's bijection, counted from the box's first workgroup) so that tiles which read the
+      // same rows and planes meet in one L2
+    const int N = a.g[0] * a.g[1] * gz;
+    if (N >= 64) {
+      const int s0 = bid - lb, t = (bid - s0) & 7, slot = lb >> 3, q = N >> 3, r = N & 7;
+      lb = t * q + (t < r ? t : r) + slot;
+    }
+  }
   const int bx = lb % a.g[0], by = (lb / a.g[0]) % a.g[1], bz = lb / (a.g[0] * a.g[1]);
   // tile of the 256 threads: 64 x 4, 32 x 8 or 16 x 16 by the width of the box (a level of an adaptive hierarchy is full of 16- and
   // 32-wide boxes: a 64-wide tile would leave half or three quarters of every wave idle); log2(width) rides in the top byte of g[2]
-  const int lw = a.g[2] >> 24, gz = a.g[2] & 0xffffff;
   const int tid = (int)threadIdx.x + 64 * (int)threadIdx.y;
   double v = 0.0;
   if (lw == BATCH_YZ) {                   // a range one or two cells thin along x (the x faces of a box): 16 x 16 tiles of (j, k), x inside
@@ -124,8 +134,13 @@ __global__ void __launch_bounds__(256) kk_batched(const A *args, const int *star
       for (int j = a.r.lo[1]; j <= a.r.hi[1]; j++) v = nmax(v, A::body(a, i, j, k, extra));
   } else {
     const int i = a.r.lo[0] + (bx << lw) + (tid & ((1 << lw) - 1)), j = a.r.lo[1] + by * (256 >> lw) + (tid >> lw);
-    if (i <= a.r.hi[0] && j <= a.r.hi[1])
-      for (int k = a.r.lo[2] + bz; k <= a.r.hi[2]; k += gz) v = nmax(v, A::body(a, i, j, k, extra));
+    if (i <= a.r.hi[0] && j <= a.r.hi[1]) {
+      if (chunks) {
+        const int nz = a.r.hi[2] - a.r.lo[2] + 1, ch = (nz + gz - 1) / gz, ka = a.r.lo[2] + bz * ch, kb = min(ka + ch - 1, a.r.hi[2]);
+        for (int k = ka; k <= kb; k++) v = nmax(v, A::body(a, i, j, k, extra));
+      } else
+        for (int k = a.r.lo[2] + bz; k <= a.r.hi[2]; k += gz) v = nmax(v, A::body(a, i, j, k, extra));
+    }
   }
   if (nrm) block_atomic_max_fwd(nrm, v);
 }
@@ -192,7 +207,10 @@ template <class A> static inline int batch_grid(A &a, int kz) {
   const int ppw = ppw_env > 0 ? ppw_env : batch_ppw<A>::value;
   int g0 = nx > 0 ? (nx + w - 1) / w : 0, g1 = ny > 0 ? (ny + h - 1) / h : 0, g2 = nz > 0 ? ((kz > 0 && nz > kz) ? kz : (nz + ppw - 1) / ppw) : 0;
   if (g0 == 0 || g1 == 0 || g2 == 0) { g0 = g1 = g2 = 1; a.r.hi[0] = a.r.lo[0] - 1; }
-  a.g[0] = g0; a.g[1] = g1; a.g[2] = g2 | (lw << 24);
+  static const bool chunk_on = !(getenv("VDN_BATCH_CHUNK") && atoi(getenv("VDN_BATCH_CHUNK")) == 0);
+  const int chunked = (chunk_on && !(kz > 0 && nz > kz) && ppw > 1 && g2 < nz) ? 1 : 0;      // planes-per-workgroup mode: contiguous planes
+  if (chunked) { const int ch = (nz + g2 - 1) / g2; g2 = (nz + ch - 1) / ch; }                 // (no workgroup without a plane)
+  a.g[0] = g0; a.g[1] = g1; a.g[2] = g2 | (chunked << 23) | (lw << 24);
   return g0 * g1 * g2;
 }
 // host side: fills g / the prefix sums, uploads and launches.  kz: at most this many workgroups along k per box (0 = one per plane)
