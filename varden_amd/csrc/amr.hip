@@ -424,18 +424,37 @@ static void cf_descs(vdn_multifab *pf, const SrcView &pc, const vdn_bc_tower *bc
     }
   }
 }
-struct ResArgs { double hi2[3]; };
-struct ResidualB { Range3 r; int g[3]; static constexpr int planes_per_wg = 8; FV rh, phi, bx, by, bz, res, alpha; int has_alpha; ResArgs A;
+// fuse (the finest level): the pass also writes what the FIRST colour pass of the relaxation that follows makes of e = 0 and this residual --
+// e = 0 + r / diag on the cells with (i + j + k) even (diag from the face coefficients folded at the domain faces as GsrbB folds them), 0 on
+// the others: the same bits as GsrbB's pass from a zero-filled e, without the pass and without the zero fill
+struct ResArgs { double hi2[3]; int lo[3], hi[3], e[3][2]; };
+struct ResidualB { Range3 r; int g[3]; static constexpr int planes_per_wg = 8; FV rh, phi, bx, by, bz, res, alpha, e; int has_alpha, fuse; ResArgs A;
   static __device__ double body(const ResidualB &a, int i, int j, int k, int) {
     const FV &phi = a.phi;
     const double p0 = fv_get(phi, i, j, k);
-    const double ax = (fv_get(a.bx, i + 1, j, k) * (p0 - fv_get(phi, i + 1, j, k)) + fv_get(a.bx, i, j, k) * (p0 - fv_get(phi, i - 1, j, k))) * a.A.hi2[0];
-    const double ay = (fv_get(a.by, i, j + 1, k) * (p0 - fv_get(phi, i, j + 1, k)) + fv_get(a.by, i, j, k) * (p0 - fv_get(phi, i, j - 1, k))) * a.A.hi2[1];
-    const double az = (fv_get(a.bz, i, j, k + 1) * (p0 - fv_get(phi, i, j, k + 1)) + fv_get(a.bz, i, j, k) * (p0 - fv_get(phi, i, j, k - 1))) * a.A.hi2[2];
+    double bxm = fv_get(a.bx, i, j, k), bxp = fv_get(a.bx, i + 1, j, k), bym = fv_get(a.by, i, j, k), byp = fv_get(a.by, i, j + 1, k), bzm = fv_get(a.bz, i, j, k), bzp = fv_get(a.bz, i, j, k + 1);
+    const double ax = (bxp * (p0 - fv_get(phi, i + 1, j, k)) + bxm * (p0 - fv_get(phi, i - 1, j, k))) * a.A.hi2[0];
+    const double ay = (byp * (p0 - fv_get(phi, i, j + 1, k)) + bym * (p0 - fv_get(phi, i, j - 1, k))) * a.A.hi2[1];
+    const double az = (bzp * (p0 - fv_get(phi, i, j, k + 1)) + bzm * (p0 - fv_get(phi, i, j, k - 1))) * a.A.hi2[2];
     double Ap = ax + ay + az;
     if (a.has_alpha) Ap = Ap + fv_get(a.alpha, i, j, k) * p0;
     const double rr = fv_get(a.rh, i, j, k) - Ap;
     fv_at(a.res, i, j, k) = rr;
+    if (a.fuse) {
+      double ev = 0.0;
+      if (((i + j + k) & 1) == 0) {
+        const ResArgs &A = a.A;
+        #define FOLD(b, dd, ss) { const int t = A.e[dd][ss]; if (t == VDN_BC_NEU) b = 0.0; else if (t == VDN_BC_DIR) b = 2.0 * b; }
+        if (i == A.lo[0]) FOLD(bxm, 0, 0) if (i == A.hi[0]) FOLD(bxp, 0, 1)
+        if (j == A.lo[1]) FOLD(bym, 1, 0) if (j == A.hi[1]) FOLD(byp, 1, 1)
+        if (k == A.lo[2]) FOLD(bzm, 2, 0) if (k == A.hi[2]) FOLD(bzp, 2, 1)
+        #undef FOLD
+        double diag = (bxp + bxm) * A.hi2[0] + (byp + bym) * A.hi2[1] + (bzp + bzm) * A.hi2[2];
+        if (a.has_alpha) diag = diag + fv_get(a.alpha, i, j, k);
+        if (diag != 0.0) ev = 0.0 + rr / diag;
+      }
+      fv_at(a.e, i, j, k) = ev;
+    }
     return fabs(rr);
   } };
 struct AbsmaxB { Range3 r; int g[3]; FV a, mask; int has_mask;
@@ -533,7 +552,8 @@ static Range3 valid_range(const vdn_multifab *mf, int b) { Range3 r; for (int d 
 static double read_dev(double *d) { return read_scalar1(d); }
 
 // descriptor sets are built once per solve: the fields of a solve do not move
-struct MLCC { int nlev; vdn_layout *la; vdn_multifab **rh, **phi, **beta, **alpha; vdn_multifab *res[VDN_MAXLEV], *e[VDN_MAXLEV], *scr[VDN_MAXLEV], *mask[VDN_MAXLEV];
+struct MLCC { int nlev; vdn_layout *la; bool fuse_first = false;   /* the finest level's residual pass also writes the first colour pass of its relaxation (ResidualB) */
+              vdn_multifab **rh, **phi, **beta, **alpha; vdn_multifab *res[VDN_MAXLEV], *e[VDN_MAXLEV], *scr[VDN_MAXLEV], *mask[VDN_MAXLEV];
               const double *dx; const vdn_bc_tower *bct; int bcc; double *d_nrm;
               BatchSet<ClosureB> closure[VDN_MAXLEV]; BatchSet<CfB> cf[VDN_MAXLEV]; BatchSet<ResidualB> resid[VDN_MAXLEV];
               BatchSet<RefluxB> reflux[VDN_MAXLEV][6];          // [fine level][d*2+s]: one launch per side so that a coarse cell is updated once per launch
@@ -591,6 +611,8 @@ static void mlcc_build_sets(MLCC &S) {
       ResidualB q; q.r = r; q.rh = S.rh[n]->fabs[b]; q.phi = S.phi[n]->fabs[b]; q.bx = S.beta[3 * n]->fabs[b]; q.by = S.beta[3 * n + 1]->fabs[b]; q.bz = S.beta[3 * n + 2]->fabs[b];
       q.res = S.res[n]->fabs[b]; for (int d = 0; d < 3; d++) q.A.hi2[d] = 1.0 / (S.dx[3 * n + d] * S.dx[3 * n + d]);
       q.has_alpha = S.alpha ? 1 : 0; q.alpha = S.alpha ? S.alpha[n]->fabs[b] : q.rh;
+      q.fuse = (S.fuse_first && n == L - 1) ? 1 : 0; q.e = n >= 1 ? S.e[n]->fabs[b] : q.res;
+      for (int d = 0; d < 3; d++) { q.A.lo[d] = r.lo[d]; q.A.hi[d] = r.hi[d]; for (int sd = 0; sd < 2; sd++) q.A.e[d][sd] = S.bct->ell_bc(n, b + 1, d, sd, S.bcc); }
       vr.push_back(q);
       if (n < L - 1) { AbsmaxB m; m.r = r; m.a = S.res[n]->fabs[b]; m.mask = S.mask[n]->fabs[b]; m.has_mask = 1; va.push_back(m); }
       if (n >= 1) {
@@ -673,9 +695,13 @@ static double composite_residual(MLCC &S) {
 // nsweeps red-black sweeps of A_n e = res_n from e = 0 (homogeneous coarse-fine interface)
 static void level_relax(MLCC &S, int n, int nsweeps) {
   vdn_multifab *e = S.e[n];
-  mf_setval(e, 0.0, 0, 1, true);
+  // the finest level with fuse_first: its residual pass has written the first colour pass (and zeros on the other colour); the ghost cells
+  // beyond the level are zero from e's allocation -- the exchange writes only those that lie in a neighbouring box
+  const bool first_done = S.fuse_first && n == S.nlev - 1 && nsweeps >= 1;
+  if (!first_done) mf_setval(e, 0.0, 0, 1, true);
   const bool exchange = level_boxes(e).size() > 1 || S.la->pmask[0] || S.la->pmask[1] || S.la->pmask[2];     // boxes of the level anywhere, not just here: every rank must take part
   for (int s = 0; s < nsweeps; s++) for (int col = 0; col < 2; col++) {
+    if (first_done && s == 0 && col == 0) continue;
     if (exchange && (s > 0 || col > 0)) mf_fill_boundary(e);      // (the first pass starts from e = 0, ghost cells included)
     S.gsrb[n].run(col, (double *)nullptr, ctx().stream);
   }
@@ -705,6 +731,8 @@ int ml_cc_solve(vdn_layout *la, vdn_multifab **rh, vdn_multifab **phi, vdn_multi
   const size_t mark = arena_mark();
   const int L = la->nlev;
   MLCC S; S.nlev = L; S.la = la; S.rh = rh; S.phi = phi; S.beta = beta; S.alpha = alpha; S.dx = dx; S.bct = bct; S.bcc = bc_comp0;
+  static const bool fuse_first_on = !(getenv("VDN_MLCC_FUSE1") && atoi(getenv("VDN_MLCC_FUSE1")) == 0);
+  S.fuse_first = fuse_first_on && ctx().prm.mg_nu1 >= 1 && ctx().prm.mg_nu2 >= 1;
   for (int n = 0; n < L; n++) {
     std::vector<DirRhsB> v;
     for (int b = 0; b < rh[n]->nfabs(); b++) {
