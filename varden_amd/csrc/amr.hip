@@ -679,15 +679,17 @@ static void fill_phi_ghosts(MLCC &S) {
   for (int n = 0; n < S.nlev; n++) { S.closure[n].run(0, (double *)nullptr, st); if (n == 0) mf_fill_boundary(S.phi[n]); }
   for (int n = 1; n < S.nlev; n++) { S.vc_phi[n].refresh(); S.cf[n].run(0, (double *)nullptr, st); mf_fill_boundary(S.phi[n]); }
 }
-static double composite_residual(MLCC &S) {
+// want_norm = false: the residual fields only (no reduction, no read-back: the host does not wait for the device)
+static double composite_residual(MLCC &S, bool want_norm = true) {
   hipStream_t st = ctx().stream;
   const int L = S.nlev;
   fill_phi_ghosts(S);
-  HIPCHK(hipMemsetAsync(S.d_nrm, 0, sizeof(double), st));
-  for (int n = 0; n < L; n++) S.resid[n].run(0, n == L - 1 ? S.d_nrm : (double *)nullptr, st);
+  if (want_norm) HIPCHK(hipMemsetAsync(S.d_nrm, 0, sizeof(double), st));
+  for (int n = 0; n < L; n++) S.resid[n].run(0, (n == L - 1 && want_norm) ? S.d_nrm : (double *)nullptr, st);
   // flux matching: lo faces then hi faces of every direction (one update per coarse cell and launch, hence deterministic)
   for (int n = 1; n < L; n++) { S.vf_phi[n].refresh(); for (int ds = 0; ds < 6; ds++) S.reflux[n][ds].run(0, (double *)nullptr, st); }     // fine phi incl. its ghost cells
   for (int n = L - 1; n >= 1; n--) { S.vf_res[n].refresh(); S.rres[n].run(0, (double *)nullptr, st); }
+  if (!want_norm) return 0.0;
   for (int n = 0; n < L - 1; n++) S.absmax[n].run(0, S.d_nrm, st);
   comm_allreduce_max_dev(S.d_nrm, 1);
   return read_dev(S.d_nrm);
@@ -785,7 +787,7 @@ int ml_cc_solve(vdn_layout *la, vdn_multifab **rh, vdn_multifab **phi, vdn_multi
     for (int n = L - 1; n >= 1; n--) {
       level_relax(S, n, P.mg_nu1);
       apply_correction(S, n);
-      (void)composite_residual(S);
+      (void)composite_residual(S, false);
     }
     // coarse correction: ONE V-cycle of the single-level multigrid on the whole level 0
     mf_setval(S.e[0], 0.0, 0, 1, true);
@@ -797,7 +799,7 @@ int ml_cc_solve(vdn_layout *la, vdn_multifab **rh, vdn_multifab **phi, vdn_multi
     apply_correction(S, 0);
     // post-relaxation on the new residual, coarsest level first
     for (int n = 1; n < L; n++) {
-      if (n < L - 1) (void)composite_residual(S);
+      if (n < L - 1) (void)composite_residual(S, false);
       else { fill_phi_ghosts(S); S.resid[n].run(0, (double *)nullptr, st); }
       level_relax(S, n, P.mg_nu2);
       apply_correction(S, n);

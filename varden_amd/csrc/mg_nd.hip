@@ -2039,7 +2039,7 @@ static bool ndf_fuse_first() {       // the fused residual + first sweep needs t
   return on;
 }
 // fuse_first (with finest_only): the same march also writes the first damped-Jacobi sweep of K e = r from e = 0 into eb of the finest level
-static double ml_nd_residual(MLND &S, bool finest_only, bool zero_field = false, bool fuse_first = false) {
+static double ml_nd_residual(MLND &S, bool finest_only, bool zero_field = false, bool fuse_first = false, bool want_norm = true) {
   hipStream_t st = ctx().stream;
   const int L = S.nlev;
   if (!zero_field) {
@@ -2050,15 +2050,16 @@ static double ml_nd_residual(MLND &S, bool finest_only, bool zero_field = false,
   for (int n = L - 1; n >= (finest_only ? L - 1 : 0); n--) {
     const bool finest = n == L - 1;
     if (finest_only && fuse_first) { ndf_run_march<2>(S.m_res[n], ctx().prm.hg_omega, S.slave[n] ? 1 : 0, (double *)nullptr); return 0.0; }
-    ndf_run_march<1>(zero_field ? S.m_res0[n] : S.m_res[n], 0.0, (finest && S.slave[n]) ? 1 : 0, (finest && !finest_only) ? S.d_nrm : (double *)nullptr);
+    ndf_run_march<1>(zero_field ? S.m_res0[n] : S.m_res[n], 0.0, (finest && S.slave[n]) ? 1 : 0, (finest && !finest_only && want_norm) ? S.d_nrm : (double *)nullptr);
     if (finest_only) return 0.0;
     if (S.multi[n]) mf_fill_boundary(S.res[n]);
     if (finest) continue;
     S.vf_res[n + 1].refresh();
     S.rst[n + 1].run(0, (double *)nullptr, st);
     if (S.multi[n] && n > 0) mf_fill_boundary(S.res[n]);      // the ghost nodes must see the restricted part too before level n-1 restricts them
-    S.amax[n].run(0, S.d_nrm, st);
+    if (want_norm) S.amax[n].run(0, S.d_nrm, st);
   }
+  if (!want_norm) return 0.0;            // (the residual fields only: no reduction, no read-back)
   comm_allreduce_max_dev(S.d_nrm, 1);
   return ndf_read(S.d_nrm);
 }
@@ -2264,7 +2265,7 @@ static int ml_nd_solve(vdn_layout *la, vdn_multifab **rh, vdn_multifab **phi, vd
       // the finest level (its relaxation runs on the coefficients its residual runs on): the residual march writes the first sweep too -- into
       // eb, where a sweep from ea = 0 puts it; ea's ghost nodes outside the level stay zero from its allocation, no sweep writes them
       const bool fuse = ndf_fuse_first() && n == L - 1 && P.hg_nu1 + P.hg_nu2 >= 1;
-      (void)ml_nd_residual(S, n == L - 1, false, fuse);
+      (void)ml_nd_residual(S, n == L - 1, false, fuse, false);
       if (!fuse) mf_setval(S.ea[n], 0.0, 0, 1, true);
       vdn_multifab *a = S.ea[n], *b2 = S.eb[n];
       for (int s = 0; s < P.hg_nu1 + P.hg_nu2; s++) {
