@@ -709,9 +709,9 @@ static void level_relax(MLCC &S, int n, int nsweeps) {
   }
 }
 // phi_n += e_n, and the piecewise-constant prolongation of that correction on every finer level
-static void apply_correction(MLCC &S, int n) {
+static void apply_correction(MLCC &S, int n, bool added = false) {
   hipStream_t st = ctx().stream;
-  S.add[n].run(0, (double *)nullptr, st);
+  if (!added) S.add[n].run(0, (double *)nullptr, st);
   for (int m = n + 1; m < S.nlev; m++) {
     const int lin = m >= 2 ? 1 : 0;                      // piecewise constant into level 1, linear into the finer ones (oracle: apply_correction)
     if (lin) {                                          // the source's ghost cells: the cell itself where the level ends, then the neighbouring boxes' / periodic values
@@ -790,13 +790,15 @@ int ml_cc_solve(vdn_layout *la, vdn_multifab **rh, vdn_multifab **phi, vdn_multi
       (void)composite_residual(S, false);
     }
     // coarse correction: ONE V-cycle of the single-level multigrid on the whole level 0
-    mf_setval(S.e[0], 0.0, 0, 1, true);
+    static const bool glue = !(getenv("VDN_MLCC_GLUE") && atoi(getenv("VDN_MLCC_GLUE")) == 0);
+    const bool zg = glue && it > 0;           // (the first call builds the kept hierarchy and loads phi as the generic solver does)
+    if (!zg) mf_setval(S.e[0], 0.0, 0, 1, true);
     int cyc; double r0, rr;
     // (base_beta / base_rho, the MAC projection: the V-cycle runs on level 0's OWN coefficients 2/(rho_i + rho_i-1) -- `beta` carries the edge
     // restriction of the finer level's on the covered faces -- and so on the density-based kernels of the single-level solver; it is a
     // preconditioner, the composite residual above is formed with `beta`.  Oracle: beta_base of vo_ml_cc_solve)
-    cc_solve(S.res[0], S.e[0], base_beta ? base_beta : beta, dx, ebc0, 0.0, -1.0, -1, &cyc, &r0, &rr, alpha ? alpha[0] : nullptr, base_beta ? base_rho : nullptr, coarse_keep);     // (no nested-iteration start here: it saves no FAC iteration, measured)
-    apply_correction(S, 0);
+    cc_solve(S.res[0], S.e[0], base_beta ? base_beta : beta, dx, ebc0, 0.0, -1.0, -1, &cyc, &r0, &rr, alpha ? alpha[0] : nullptr, base_beta ? base_rho : nullptr, coarse_keep, nullptr, 0, zg, glue ? S.phi[0] : nullptr);     // (no nested-iteration start here: it saves no FAC iteration, measured)
+    apply_correction(S, 0, glue);            // (glue: phi_0 += e_0 was done where e_0 was stored)
     // post-relaxation on the new residual, coarsest level first
     for (int n = 1; n < L; n++) {
       if (n < L - 1) (void)composite_residual(S, false);

@@ -971,7 +971,8 @@ __global__ void kk_cc_load_rho(CLev L, double *dst, FV rho, int lo0, int lo1, in
 // boundary-FACE values (multifab_physbc EXT_DIR; visc_solve hands unew over that way, viscsolve.f90:270); the face term
 // 2b(phi_i - phi_b)/h^2 keeps its phi_i part in the operator (b := 2b, zero ghost) and its phi_b part goes here, in the
 // order x-lo, x-hi, y-lo, y-hi, z-lo, z-hi (same as the oracle).  Runs after kk_cc_load (needs the folded b).
-__global__ void kk_cc_load_rh(CLev L, FV rh, FV phi, int lo0, int lo1, int lo2, int ebc00, int ebc01, int ebc10, int ebc11, int ebc20, int ebc21) {
+// zg: the initial guess is zero, ghost cells included, and `phi` is not read (the products with 0.0 are kept: r + 0.0 is not always r)
+__global__ void kk_cc_load_rh(CLev L, FV rh, FV phi, int lo0, int lo1, int lo2, int ebc00, int ebc01, int ebc10, int ebc11, int ebc20, int ebc21, int zg = 0) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   const int j = blockIdx.y * blockDim.y + threadIdx.y;
   const int k = blockIdx.z;
@@ -980,12 +981,12 @@ __global__ void kk_cc_load_rh(CLev L, FV rh, FV phi, int lo0, int lo1, int lo2, 
   const long sy = L.PX, sz = (long)L.PX * L.PY;
   const int gi = lo0 + i, gj = lo1 + j, gk = lo2 + k;
   double r = fv_get(rh, gi, gj, gk);
-  if (i == 0 && ebc00 == VDN_BC_DIR)            r = r + L.b[0][c] * fv_get(phi, gi - 1, gj, gk) * L.hi2[0];
-  if (i == L.n[0] - 1 && ebc01 == VDN_BC_DIR)   r = r + L.b[0][c + 1] * fv_get(phi, gi + 1, gj, gk) * L.hi2[0];
-  if (j == 0 && ebc10 == VDN_BC_DIR)            r = r + L.b[1][c] * fv_get(phi, gi, gj - 1, gk) * L.hi2[1];
-  if (j == L.n[1] - 1 && ebc11 == VDN_BC_DIR)   r = r + L.b[1][c + sy] * fv_get(phi, gi, gj + 1, gk) * L.hi2[1];
-  if (k == 0 && ebc20 == VDN_BC_DIR)            r = r + L.b[2][c] * fv_get(phi, gi, gj, gk - 1) * L.hi2[2];
-  if (k == L.n[2] - 1 && ebc21 == VDN_BC_DIR)   r = r + L.b[2][c + sz] * fv_get(phi, gi, gj, gk + 1) * L.hi2[2];
+  if (i == 0 && ebc00 == VDN_BC_DIR)            r = r + L.b[0][c] * (zg ? 0.0 : fv_get(phi, gi - 1, gj, gk)) * L.hi2[0];
+  if (i == L.n[0] - 1 && ebc01 == VDN_BC_DIR)   r = r + L.b[0][c + 1] * (zg ? 0.0 : fv_get(phi, gi + 1, gj, gk)) * L.hi2[0];
+  if (j == 0 && ebc10 == VDN_BC_DIR)            r = r + L.b[1][c] * (zg ? 0.0 : fv_get(phi, gi, gj - 1, gk)) * L.hi2[1];
+  if (j == L.n[1] - 1 && ebc11 == VDN_BC_DIR)   r = r + L.b[1][c + sy] * (zg ? 0.0 : fv_get(phi, gi, gj + 1, gk)) * L.hi2[1];
+  if (k == 0 && ebc20 == VDN_BC_DIR)            r = r + L.b[2][c] * (zg ? 0.0 : fv_get(phi, gi, gj, gk - 1)) * L.hi2[2];
+  if (k == L.n[2] - 1 && ebc21 == VDN_BC_DIR)   r = r + L.b[2][c + sz] * (zg ? 0.0 : fv_get(phi, gi, gj, gk + 1)) * L.hi2[2];
   L.rh[c] = r;
 }
 // mean of the 8 children of a cell field (alpha)
@@ -1001,7 +1002,8 @@ __global__ void kk_cc_coarsen_cell(CLev F, const double *src, CLev C, double *ds
 }
 
 // phi back, incl. the face ghost layer the closure implies (Neumann: phi_i, Dirichlet: -phi_i, periodic: image)
-__global__ void kk_cc_store(CLev L, FV phi, int lo0, int lo1, int lo2, int ebc00, int ebc01, int ebc10, int ebc11, int ebc20, int ebc21) {
+// add: acc += the solution on the cells of the box as well (the composite solve adds its coarse correction to phi of level 0)
+__global__ void kk_cc_store(CLev L, FV phi, int lo0, int lo1, int lo2, int ebc00, int ebc01, int ebc10, int ebc11, int ebc20, int ebc21, int add = 0, FV acc = FV()) {
   const int i = (int)(blockIdx.x * blockDim.x + threadIdx.x) - 1;
   const int j = (int)(blockIdx.y * blockDim.y + threadIdx.y) - 1;
   const int k = (int)blockIdx.z - 1;
@@ -1020,6 +1022,7 @@ __global__ void kk_cc_store(CLev L, FV phi, int lo0, int lo1, int lo2, int ebc00
     else v = L.phi[cidx(L, i, j, k)];          // periodic image already in the ghost slot
   }
   fv_at(phi, lo0 + i, lo1 + j, lo2 + k) = v;
+  if (add && out == 0) fv_at(acc, lo0 + i, lo1 + j, lo2 + k) = fv_get(acc, lo0 + i, lo1 + j, lo2 + k) + v;
 }
 
 // ---- gather of the first agglomerated level ------------------------------------------------------------------
@@ -1756,7 +1759,7 @@ static double cc_setup_fast(CCMG &M, CcFast *fast, const double *dx, const int b
   return bnorm;
 }
 // a kept hierarchy (coefficients on every level stay): the finest level takes a new right-hand side and initial guess
-static void cc_reload(CCMG &M, vdn_multifab *rh, vdn_multifab *phi, const int bc[3][2]) {
+static void cc_reload(CCMG &M, vdn_multifab *rh, vdn_multifab *phi, const int bc[3][2], bool zero_guess = false) {
   const vdn_layout *la = rh->la; const int lev = rh->lev;
   CDLev &D0 = M.dlev[0];
   for (size_t b = 0; b < D0.boxes.size(); b++) {
@@ -1767,12 +1770,13 @@ static void cc_reload(CCMG &M, vdn_multifab *rh, vdn_multifab *phi, const int bc
       e[d][0] = (bx.lo[d] == la->pd[lev].lo[d]) ? bc[d][0] : VDN_BC_INT;
       e[d][1] = (bx.hi[d] == la->pd[lev].hi[d]) ? bc[d][1] : VDN_BC_INT;
     }
-    hipLaunchKernelGGL(kk_cc_load_phi, g3(L0.n[0], L0.n[1], L0.n[2], BLK), BLK, 0, ctx().stream, L0, phi->fabs[b], bx.lo[0], bx.lo[1], bx.lo[2]);
+    if (zero_guess) HIPCHK(hipMemsetAsync(L0.phi, 0, sizeof(double) * L0.sz, ctx().stream));      // (the caller's phi is neither zero-filled nor read)
+    else hipLaunchKernelGGL(kk_cc_load_phi, g3(L0.n[0], L0.n[1], L0.n[2], BLK), BLK, 0, ctx().stream, L0, phi->fabs[b], bx.lo[0], bx.lo[1], bx.lo[2]);
     hipLaunchKernelGGL(kk_cc_load_rh, g3(L0.n[0], L0.n[1], L0.n[2], BLK), BLK, 0, ctx().stream, L0, rh->fabs[b], phi->fabs[b],
-                       bx.lo[0], bx.lo[1], bx.lo[2], e[0][0], e[0][1], e[1][0], e[1][1], e[2][0], e[2][1]);
+                       bx.lo[0], bx.lo[1], bx.lo[2], e[0][0], e[0][1], e[1][0], e[1][1], e[2][0], e[2][1], zero_guess ? 1 : 0);
   }
 }
-static void cc_store(CCMG &M, vdn_multifab *phi, const int bc[3][2]) {
+static void cc_store(CCMG &M, vdn_multifab *phi, const int bc[3][2], vdn_multifab *add_to = nullptr) {
   CDLev &D0 = M.dlev[0];
   cc_halo(M, D0);
   const vdn_layout *la = phi->la; const int lev = phi->lev;
@@ -1785,7 +1789,7 @@ static void cc_store(CCMG &M, vdn_multifab *phi, const int bc[3][2]) {
       e[d][1] = (bx.hi[d] == la->pd[lev].hi[d]) ? bc[d][1] : VDN_BC_INT;
     }
     hipLaunchKernelGGL(kk_cc_store, g3(L0.n[0] + 2, L0.n[1] + 2, L0.n[2] + 2, BLK), BLK, 0, ctx().stream, L0, phi->fabs[b],
-                       bx.lo[0], bx.lo[1], bx.lo[2], e[0][0], e[0][1], e[1][0], e[1][1], e[2][0], e[2][1]);
+                       bx.lo[0], bx.lo[1], bx.lo[2], e[0][0], e[0][1], e[1][0], e[1][1], e[2][0], e[2][1], add_to ? 1 : 0, add_to ? add_to->fabs[b] : phi->fabs[b]);
   }
 }
 
@@ -1793,7 +1797,7 @@ static void cc_store(CCMG &M, vdn_multifab *phi, const int bc[3][2]) {
 // finest level's array (ghost cells exchanged) and the level arrays stay allocated -- the CALLER releases the arena
 int cc_solve(vdn_multifab *rh, vdn_multifab *phi, vdn_multifab **beta, const double *dx, const int bc[3][2],
              double rel_eps, double abs_eps, int max_iter, int *cycles, double *res0, double *res, const vdn_multifab *alpha, const vdn_multifab *rho, CcKeep *keep,
-             CcFast *fast, int fmg) {
+             CcFast *fast, int fmg, bool zero_guess, vdn_multifab *add_to) {
   Prof prof_("mac_multigrid");
   if (ctx().prm.dm == 2) return cc2_solve(rh, phi, beta, dx, bc, rel_eps, abs_eps, max_iter, cycles, res0, res, alpha);
   const vdn_params &P = ctx().prm;
@@ -1805,7 +1809,7 @@ int cc_solve(vdn_multifab *rh, vdn_multifab *phi, vdn_multifab **beta, const dou
   CCMG &M = keep ? keep->M : M_local;
   double bnorm_fast = 0.0;
   if (fast) bnorm_fast = cc_setup_fast(M, fast, dx, bc);
-  else if (keep && keep->built) cc_reload(M, rh, phi, bc);
+  else if (keep && keep->built) cc_reload(M, rh, phi, bc, zero_guess);
   else cc_setup(M, rh, phi, alpha, beta, dx, bc, rho);
   if (keep) keep->built = true;
   CDLev &D0 = M.dlev[0];
@@ -1824,7 +1828,7 @@ int cc_solve(vdn_multifab *rh, vdn_multifab *phi, vdn_multifab **beta, const dou
         cc_prolong_smooth(M, 0, P.mg_nu2);
       });
     }
-    cc_store(M, phi, bc);
+    cc_store(M, phi, bc, add_to);
     if (cycles) *cycles = -max_iter; if (res0) *res0 = 0.0; if (res) *res = 0.0;
     if (!keep) arena_release(mark);
     return 0;

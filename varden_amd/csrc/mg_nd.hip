@@ -700,6 +700,16 @@ __global__ void kk_nd_store(NLev L, FV phi, int lo0, int lo1, int lo2) {
   if (i > L.n[0] + 1 || j > L.n[1] + 1 || k > L.n[2] + 1) return;
   fv_at(phi, lo0 + i, lo1 + j, lo2 + k) = L.phi[nidx(L, i, j, k)];
 }
+// the same, and acc += the solution on the nodes of the box (the composite solve adds its coarse correction to phi of level 0)
+__global__ void kk_nd_store_add(NLev L, FV phi, FV acc, int lo0, int lo1, int lo2) {
+  const int i = (int)(blockIdx.x * blockDim.x + threadIdx.x) - 1;
+  const int j = (int)(blockIdx.y * blockDim.y + threadIdx.y) - 1;
+  const int k = (int)blockIdx.z - 1;
+  if (i > L.n[0] + 1 || j > L.n[1] + 1 || k > L.n[2] + 1) return;
+  const double v = L.phi[nidx(L, i, j, k)];
+  fv_at(phi, lo0 + i, lo1 + j, lo2 + k) = v;
+  if (i >= 0 && i <= L.n[0] && j >= 0 && j <= L.n[1] && k >= 0 && k <= L.n[2]) fv_at(acc, lo0 + i, lo1 + j, lo2 + k) = fv_get(acc, lo0 + i, lo1 + j, lo2 + k) + v;
+}
 
 // hgproject's fast path (one level): sigma = 1 / rhohalf written straight into the level on the cells of the box, zero on its ghost cells
 // (hg_multigrid.f90:73-79); the ghost cells that have a neighbour or a periodic image then come from the level's sigma halo, exactly as
@@ -1293,7 +1303,7 @@ void nd_keep_free(NdKeep *k) { delete k; }
 // from fast->rhohalf (coeffs may be null), and instead of storing phi into a multifab the call returns views of the finest level's phi
 // (ghost nodes exchanged) in fast->phi_view; the level arrays then stay allocated: the CALLER releases the arena (mark taken before the call)
 int nd_solve(vdn_multifab *rh, vdn_multifab *phi, const vdn_multifab *coeffs, const vdn_multifab *u, const double *dx,
-             const int bc[3][2], double rel_eps, double abs_eps, int max_iter, int *cycles, double *res0, double *res, NdKeep *keep, NdFast *fast, bool fmg_start, bool rh_is_b) {
+             const int bc[3][2], double rel_eps, double abs_eps, int max_iter, int *cycles, double *res0, double *res, NdKeep *keep, NdFast *fast, bool fmg_start, bool rh_is_b, vdn_multifab *add_to) {
   Prof prof_("hg_multigrid");
   if (ctx().prm.dm == 2) return nd2_solve(rh, phi, coeffs, u, dx, bc, rel_eps, abs_eps, max_iter, cycles, res0, res);
   const vdn_params &P = ctx().prm;
@@ -1425,6 +1435,8 @@ int nd_solve(vdn_multifab *rh, vdn_multifab *phi, const vdn_multifab *coeffs, co
   for (size_t b = 0; b < DF.boxes.size(); b++) {
     NLev &L0 = DF.boxes[b].L; const vdn_box &bx = coeffs->vbox[b];
     if (fast) { fast->phi_view.push_back(nd_view(L0, L0.phi, bx.lo, 3)); continue; }
+    if (add_to) hipLaunchKernelGGL(kk_nd_store_add, ng3(L0.n[0] + 3, L0.n[1] + 3, L0.n[2] + 3), NBLK, 0, st, L0, phi->fabs[b], add_to->fabs[b], bx.lo[0], bx.lo[1], bx.lo[2]);
+    else
     hipLaunchKernelGGL(kk_nd_store, ng3(L0.n[0] + 3, L0.n[1] + 3, L0.n[2] + 3), NBLK, 0, st, L0, phi->fabs[b], bx.lo[0], bx.lo[1], bx.lo[2]);
   }
   if (cycles) *cycles = cyc; if (res0) *res0 = bnorm; if (res) *res = rn;
@@ -2064,8 +2076,8 @@ static double ml_nd_residual(MLND &S, bool finest_only, bool zero_field = false,
   return ndf_read(S.d_nrm);
 }
 // phi_n += e (nodes of level n) and its trilinear prolongation on every finer level (not on physical Dirichlet nodes)
-static void ml_nd_apply_correction(MLND &S, int n, vdn_multifab *e) {
-  ml_nd_add(S, n, S.phi[n], e);
+static void ml_nd_apply_correction(MLND &S, int n, vdn_multifab *e, bool added = false) {      // added: phi_n += e was done where e was stored
+  if (!added) ml_nd_add(S, n, S.phi[n], e);
   vdn_multifab *src = e;
   for (int m = n + 1; m < S.nlev; m++) {
     if (S.multi[m - 1]) mf_fill_boundary(src);
@@ -2248,7 +2260,7 @@ static int ml_nd_solve(vdn_layout *la, vdn_multifab **rh, vdn_multifab **phi, vd
     // coarse correction K_0 e = r_0: one V-cycle of the single-level solver from e = 0, the composite residual loaded as its b
     // (VDN_NDM_NEG=1: through a negated copy and a zero-filled e, as rounds 2 built it -- same bits)
     int cyc; double r0, rr;
-    if (!neg_copy) nd_solve(S.res[0], ee, coeffs[0], nullptr, dx, ebc0, 0.0, -1.0, -1, &cyc, &r0, &rr, &coarse_keep, nullptr, it == 0, true);
+    if (!neg_copy) nd_solve(S.res[0], ee, coeffs[0], nullptr, dx, ebc0, 0.0, -1.0, -1, &cyc, &r0, &rr, &coarse_keep, nullptr, it == 0, true, S.phi[0]);
     else {
       mf_setval(ee, 0.0, 0, 1, true);                   // (er: every node is overwritten below, its ghost nodes are never written and stay zero)
       std::vector<NdfNegB> v;
@@ -2259,7 +2271,7 @@ static int ml_nd_solve(vdn_layout *la, vdn_multifab **rh, vdn_multifab **phi, vd
       launch_batched(v, 0, (double *)nullptr, 0, st);
       nd_solve(er, ee, coeffs[0], nullptr, dx, ebc0, 0.0, -1.0, -1, &cyc, &r0, &rr, &coarse_keep, nullptr, it == 0);     // (first correction: from the nested iteration, hg_fmg)
     }
-    ml_nd_apply_correction(S, 0, ee);
+    ml_nd_apply_correction(S, 0, ee, !neg_copy);
     // relaxation of K_n e = r_n on the finer levels, coarsest first, with the interface fixed
     for (int n = 1; n < L; n++) {
       // the finest level (its relaxation runs on the coefficients its residual runs on): the residual march writes the first sweep too -- into

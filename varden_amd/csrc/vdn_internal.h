@@ -224,7 +224,7 @@ struct CcFast { vdn_multifab **um = nullptr; const vdn_multifab *mac_rhs = nullp
 int  cc_solve(vdn_multifab *rh, vdn_multifab *phi, vdn_multifab **beta, const double *dx, const int bc[3][2],
               double rel_eps, double abs_eps, int max_iter, int *cycles, double *res0, double *res,
               const vdn_multifab *alpha = nullptr, const vdn_multifab *rho = nullptr,    // rho: beta = 2/(rho_i + rho_i-1), recomputed on the finest level
-              struct CcKeep *keep = nullptr, CcFast *fast = nullptr, int fmg = 0);   // fmg: the caller's phi is zero and max_iter >= 0: start from the nested iteration (cc_fmg)          // keep: see mg_cc.hip (hierarchy kept between the calls of a composite solve)
+              struct CcKeep *keep = nullptr, CcFast *fast = nullptr, int fmg = 0, bool zero_guess = false, vdn_multifab *add_to = nullptr);   // fmg: the caller's phi is zero and max_iter >= 0: start from the nested iteration (cc_fmg); zero_guess (a kept hierarchy's later calls, max_iter < 0): phi is not read, the guess is zero; add_to += the solution on the valid cells          // keep: see mg_cc.hip (hierarchy kept between the calls of a composite solve)
 struct CcKeep *cc_keep_new(); void cc_keep_free(struct CcKeep *k);
 void cc_smooth(vdn_multifab *rh, vdn_multifab *phi, vdn_multifab **beta, const double *dx, const int bc[3][2], int nsweeps);
 void cc_bench_smoother(vdn_multifab *rh, vdn_multifab *phi, vdn_multifab **beta, const vdn_multifab *rho, const double *dx, const int bc[3][2],
@@ -242,7 +242,7 @@ void do_hgproject(int proj_type, vdn_layout *mla, vdn_multifab **unew, vdn_multi
 struct NdFast { const vdn_multifab *rhohalf = nullptr; std::vector<FV> phi_view; };
 int  nd_solve(vdn_multifab *rh, vdn_multifab *phi, const vdn_multifab *coeffs, const vdn_multifab *u, const double *dx,
               const int bc[3][2], double rel_eps, double abs_eps, int max_iter, int *cycles, double *res0, double *res, struct NdKeep *keep = nullptr,
-              NdFast *fast = nullptr, bool fmg_start = false, bool rh_is_b = false);      // fmg_start: nested iteration before a FIXED number of cycles (max_iter < 0; the caller's phi is zero); rh_is_b: `rh` holds b = -rh and phi is not read (zero guess; max_iter < 0)
+              NdFast *fast = nullptr, bool fmg_start = false, bool rh_is_b = false, vdn_multifab *add_to = nullptr);      // fmg_start: nested iteration before a FIXED number of cycles (max_iter < 0; the caller's phi is zero); rh_is_b: `rh` holds b = -rh and phi is not read (zero guess; max_iter < 0); add_to += the solution on the valid nodes
 
 // dim2.hip: the dm = 2 path (one level, one box)
 void k2_mkvelforce(vdn_multifab *vf, const vdn_multifab *ext, const vdn_multifab *s, const vdn_multifab *gp, const vdn_multifab *lapu, double visc_fac);
