@@ -109,6 +109,7 @@ def parse_args():
     ap.add_argument("--skip-cpu", dest="no_cpu", action="store_true")
     ap.add_argument("--hg-fmg", dest="hg_fmg", type=int, default=1, choices=[0, 1], help="nested-iteration start of the nodal solve (vdn_params.hg_fmg; 0: the zero guess of rounds 1-2)")
     ap.add_argument("--mac-fmg", dest="mac_fmg", type=int, default=1, choices=[0, 1], help="nested-iteration start of the MAC solve (vdn_params.mac_fmg; 0: the zero guess)")
+    ap.add_argument("--hg-pre-pair", dest="hg_pre_pair", type=int, default=1, choices=[0, 1], help="two-step damping of the nodal V-cycle's pre-smoothing sweeps (vdn_params.hg_omega_pre1 / 2; 0: hg_omega for both)")
     ap.add_argument("--no-calib", dest="no_calib", action="store_true", help="skip the one-thread Godunov calibration of the cpu_baseline leg")
     ap.add_argument("--no-extra", dest="no_extra", action="store_true", help="skip the extra_workloads (512^3 in eight boxes, tagged two-level hierarchy) of the default N = 1 line")
     return ap.parse_args()
@@ -182,6 +183,8 @@ def main():
     n = args.n
     walls = [[bl.NO_SLIP_WALL] * 2] * 3
     prm = default_params(cflfac=0.9, hg_fmg=args.hg_fmg, mac_fmg=args.mac_fmg)
+    if not args.hg_pre_pair:
+        prm.hg_omega_pre1 = prm.hg_omega_pre2 = 0.0
     comm_id = None
     if world > 1:                                          # RCCL unique id: rank 0 creates it, everybody receives it
         bl.initialize(prm, rank, world, local_rank)

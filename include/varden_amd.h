@@ -78,6 +78,8 @@ typedef struct vdn_params {
   int    mac_fmg;                 /* 1 (default): the same for the cell-centred solve of the MAC projection (whose phi starts from zero):
                                    * right-hand side averaged down to the coarsest level of at least 16^3 cells, two V-cycles there, then
                                    * per level a linear interpolation of the solution and one V-cycle; one V-cycle fewer at 1e-10; 0: off */
+  double hg_omega_pre1, hg_omega_pre2;   /* 1.45, 0.7 (adjacent in memory, in this order): with hg_nu1 = 2 the two pre-smoothing sweeps of the nodal V-cycle
+                                   * are damped by these instead of hg_omega -- a two-step Chebyshev pair, one V-cycle fewer at 256^3; either <= 0: hg_omega */
 } vdn_params;
 
 /* fills *p with the reference defaults (src/_parameters) */

@@ -164,7 +164,9 @@ void vo_hg_update(int proj_type, vo_fab *unew, const vo_fab *uold, vo_fab *gp, c
 void vo_nd_divu(const vo_fab *u, vo_fab *rh, const double dx[3], const int ellbc[3][2]);
 int  vo_nd_solve(vo_fab *rh, vo_fab *phi, const vo_fab *coeffs, const vo_fab *u, const double dx[3],
                  const int ellbc[3][2], const int pmask[3], double rel_eps, double abs_eps, int max_iter,
-                 int nu1, int nu2, int nub, double omega, int fmg, vo_mgstat *st);
+                 int nu1, int nu2, int nub, double omega, int fmg, const double *om_pre, vo_mgstat *st);
+/* the damping pair of the two pre-smoothing sweeps of the nodal V-cycle (NULL: hg_omega for both) */
+static inline const double *vo_om_pre(const vdn_params *prm) { return (prm->hg_omega_pre1 > 0.0 && prm->hg_omega_pre2 > 0.0) ? &prm->hg_omega_pre1 : NULL; }
 /* hgproject.f90:17-178 + hg_multigrid.f90:18-119, single level */
 void vo_hgproject(int proj_type, vo_fab *unew, const vo_fab *uold, vo_fab *rhohalf, vo_fab *p, vo_fab *gp,
                   const double dx[3], double dt, const vo_bc *bc, const int pmask[3], const vdn_params *prm,

@@ -499,7 +499,7 @@ void vo2_hgproject(int proj_type, vo_fab *unew, const vo_fab *uold, vo_fab *rhoh
   for (int j = lo[1]; j <= hi[1]; j++) for (int i = lo[0]; i <= hi[0]; i++) V2(&coeffs, i, j, 0) = 1.0 / V2(rhohalf, i, j, 0);
   vo_fill_boundary(&coeffs, pmask);
   double dx3[3] = { dx[0], dx[1], 1.0 };
-  vo_nd_solve(&rh, &phi, &coeffs, unew, dx3, ellbc, pmask, rel, abs_eps, prm->hg_max_iter, prm->hg_nu1, prm->hg_nu2, prm->hg_nub, prm->hg_omega, 0, st);
+  vo_nd_solve(&rh, &phi, &coeffs, unew, dx3, ellbc, pmask, rel, abs_eps, prm->hg_max_iter, prm->hg_nu1, prm->hg_nu2, prm->hg_nub, prm->hg_omega, 0, NULL, st);
   /* mkgphi_2d (hgproject.f90:517-541) */
   for (int j = lo[1]; j <= hi[1]; j++) for (int i = lo[0]; i <= hi[0]; i++) {
     V2(&gphi, i, j, 0) = 0.5 * (V2(&phi, i + 1, j, 0) + V2(&phi, i + 1, j + 1, 0) - V2(&phi, i, j, 0) - V2(&phi, i, j + 1, 0)) * (1.0 / dx[0]);

@@ -258,6 +258,16 @@ static void nd_jacobi(ndlev *L, const int per[3], int nsweeps, double omega)
   }
 }
 
+/* the nu1 pre-smoothing sweeps of a V-cycle.  With nu1 = 2 and a damping pair given (vdn_params.hg_omega_pre1 / 2; round 3) the first sweep is damped by
+ * pre[0] and the second by pre[1]: two Jacobi sweeps with the damping factors 1.45 and 0.7 reduce the error like the polynomial (1 - 1.45 t)(1 - 0.7 t)
+ * in t = an eigenvalue of D^-1 K -- a two-step Chebyshev smoother for t in about [0.45, 1.7], of modulus < 1 up to t = 2.1 -- where two sweeps at 0.9
+ * give (1 - 0.9 t)^2: 11 -> 10 V-cycles at 64^3, 10 -> 9 at 256^3, the residual after ten cycles 5 x smaller at 128^3.  Three dimensions only. */
+static void nd_presmooth(ndlev *L, const int per[3], int nu1, double omega, const double *pre)
+{
+  if (pre && nu1 == 2 && L->dm == 3) { nd_jacobi(L, per, 1, pre[0]); nd_jacobi(L, per, 1, pre[1]); }
+  else nd_jacobi(L, per, nu1, omega);
+}
+
 static double nd_residual(ndlev *L, const int per[3])
 {
   const int *n = L->n; double nrm = 0.0;
@@ -351,16 +361,16 @@ static int nd_bottom_sweeps(const ndlev *L, int nub)
   return nub > 2 * N * N ? nub : 2 * N * N;
 }
 
-static void nd_vcycle(ndmg *M, int l, int nu1, int nu2, int nub, double omega)
+static void nd_vcycle(ndmg *M, int l, int nu1, int nu2, int nub, double omega, const double *pre)
 {
   ndlev *L = &M->lev[l];
   long nn = (long)(L->n[0] + 3) * (L->n[1] + 3) * (L->n[2] + 3);
   memset(L->phi, 0, sizeof(double) * nn);
   if (l == M->nlev - 1) { nd_jacobi(L, M->per, nd_bottom_sweeps(L, nub), omega); return; }
-  nd_jacobi(L, M->per, nu1, omega);
+  nd_presmooth(L, M->per, nu1, omega, pre);
   (void)nd_residual(L, M->per);
   nd_restrict(L, &M->lev[l + 1]);
-  nd_vcycle(M, l + 1, nu1, nu2, nub, omega);
+  nd_vcycle(M, l + 1, nu1, nu2, nub, omega, pre);
   nd_fill_nodes(&M->lev[l + 1], M->lev[l + 1].phi, M->per);
   nd_prolong_add(L, &M->lev[l + 1]);
   nd_jacobi(L, M->per, nu2, omega);
@@ -397,7 +407,7 @@ void vo_nd_divu(const vo_fab *u, vo_fab *rh, const double dx[3], const int ellbc
 
 int vo_nd_solve(vo_fab *rh, vo_fab *phi, const vo_fab *coeffs, const vo_fab *u, const double dx[3],
                 const int ellbc[3][2], const int pmask[3], double rel_eps, double abs_eps, int max_iter,
-                int nu1, int nu2, int nub, double omega, int fmg, vo_mgstat *st)
+                int nu1, int nu2, int nub, double omega, int fmg, const double *om_pre, vo_mgstat *st)
 {
   ndmg M; M.nlev = 0;
   int n[3]; double h[3];
@@ -452,7 +462,7 @@ int vo_nd_solve(vo_fab *rh, vo_fab *phi, const vo_fab *coeffs, const vo_fab *u, 
         nd_fill_nodes(Lf, Lf->res, M.per);
         nd_restrict(Lf, &M.lev[l + 1]);
       }
-      nd_vcycle(&M, ls, nu1, nu2, nub, omega);        /* from zero */
+      nd_vcycle(&M, ls, nu1, nu2, nub, omega, om_pre);        /* from zero */
       for (int l = ls; l >= 0; l--) {
         ndlev *Lf = &M.lev[l];
         if (l < ls) {                                  /* the interpolated solution of the level below */
@@ -462,10 +472,10 @@ int vo_nd_solve(vo_fab *rh, vo_fab *phi, const vo_fab *coeffs, const vo_fab *u, 
           nd_prolong_add(Lf, &M.lev[l + 1]);
         }
         if (l > 0) {                                   /* one V-cycle on that guess (the starting level: its second) */
-          nd_jacobi(Lf, M.per, nu1, omega);
+          nd_presmooth(Lf, M.per, nu1, omega, om_pre);
           (void)nd_residual(Lf, M.per);
           nd_restrict(Lf, &M.lev[l + 1]);
-          nd_vcycle(&M, l + 1, nu1, nu2, nub, omega);
+          nd_vcycle(&M, l + 1, nu1, nu2, nub, omega, om_pre);
           nd_fill_nodes(&M.lev[l + 1], M.lev[l + 1].phi, M.per);
           nd_prolong_add(Lf, &M.lev[l + 1]);
           nd_jacobi(Lf, M.per, nu2, omega);
@@ -476,10 +486,10 @@ int vo_nd_solve(vo_fab *rh, vo_fab *phi, const vo_fab *coeffs, const vo_fab *u, 
   if (max_iter < 0) {            /* exactly -max_iter V-cycles, no convergence test (coarse correction of the composite solve) */
     for (int c = 0; c < -max_iter; c++) {
       if (M.nlev == 1) { nd_jacobi(L0, M.per, nd_bottom_sweeps(L0, nub), omega); continue; }
-      nd_jacobi(L0, M.per, nu1, omega);
+      nd_presmooth(L0, M.per, nu1, omega, om_pre);
       (void)nd_residual(L0, M.per);
       nd_restrict(L0, &M.lev[1]);
-      nd_vcycle(&M, 1, nu1, nu2, nub, omega);
+      nd_vcycle(&M, 1, nu1, nu2, nub, omega, om_pre);
       nd_fill_nodes(&M.lev[1], M.lev[1].phi, M.per);
       nd_prolong_add(L0, &M.lev[1]);
       nd_jacobi(L0, M.per, nu2, omega);
@@ -488,13 +498,13 @@ int vo_nd_solve(vo_fab *rh, vo_fab *phi, const vo_fab *coeffs, const vo_fab *u, 
     conv = 1;
   }
   while (!conv) {
-    nd_jacobi(L0, M.per, M.nlev == 1 ? nd_bottom_sweeps(L0, nub) : nu1, omega);
+    if (M.nlev == 1) nd_jacobi(L0, M.per, nd_bottom_sweeps(L0, nub), omega); else nd_presmooth(L0, M.per, nu1, omega, om_pre);
     rn = nd_residual(L0, M.per);
     if (rn <= rel_eps * bnorm || rn <= abs_eps) { conv = 1; break; }
     if (cyc >= max_iter) break;
     if (M.nlev > 1) {
       nd_restrict(L0, &M.lev[1]);
-      nd_vcycle(&M, 1, nu1, nu2, nub, omega);
+      nd_vcycle(&M, 1, nu1, nu2, nub, omega, om_pre);
       nd_fill_nodes(&M.lev[1], M.lev[1].phi, M.per);
       nd_prolong_add(L0, &M.lev[1]);
       nd_jacobi(L0, M.per, nu2, omega);
@@ -537,7 +547,7 @@ void vo_hgproject(int proj_type, vo_fab *unew, const vo_fab *uold, vo_fab *rhoha
   vo_fill_boundary(&coeffs, pmask);
 
   vo_nd_solve(&rh, &phi, &coeffs, unew, dx, ellbc, pmask, rel, abs_eps, prm->hg_max_iter,
-              prm->hg_nu1, prm->hg_nu2, prm->hg_nub, prm->hg_omega, prm->hg_fmg, st);
+              prm->hg_nu1, prm->hg_nu2, prm->hg_nub, prm->hg_omega, prm->hg_fmg, vo_om_pre(prm), st);
 
   vo_mkgphi(&gphi, &phi, dx);
   vo_hg_update(proj_type, unew, uold, gp, &gphi, rhohalf, p, &phi, dt);
@@ -738,7 +748,7 @@ int vo_ml_nd_solve(int nlev, vo_fab **rh, vo_fab **phi, vo_fab **coeffs, vo_fab 
     /* (the first correction solve starts from the nested iteration of vo_nd_solve when hg_fmg is set: 13 -> 10 FAC iterations on the
      * refined bubble, base 64^3) */
     vo_nd_solve(&er, &ee, coeffs[0], NULL, dx, ellbc[0], pmask, 0.0, -1.0, -1, prm->hg_nu1, prm->hg_nu2, prm->hg_nub, prm->hg_omega,
-                (it == 0 && prm->hg_fmg) ? 2 : 0, &cs);
+                (it == 0 && prm->hg_fmg) ? 2 : 0, vo_om_pre(prm), &cs);
     for (int k = 0; k <= Cc->n[2]; k++) for (int j = 0; j <= Cc->n[1]; j++) for (int i = 0; i <= Cc->n[0]; i++)
       scratch[0][NN(Cc, i, j, k)] = VF(&ee, ee.lo[0] + i, ee.lo[1] + j, ee.lo[2] + k, 0);
     ml_nd_apply_correction(&M, 0, scratch[0], scratch);

@@ -157,7 +157,7 @@ def test_nd_solve(gpu, oracle, bcname, n):
     orh, ophi = case.ofab(1, 1, nodal), case.ofab(1, 1, nodal)
     st = oracle.CMgStat()
     rc = L.vo_nd_solve(orh.ref, ophi.ref, coeffs.ref, u.ref, case.odx, ell, case.opm, C.c_double(1e-11), C.c_double(-1.0), 100,
-                       P.hg_nu1, P.hg_nu2, P.hg_nub, C.c_double(P.hg_omega), P.hg_fmg, C.byref(st))
+                       P.hg_nu1, P.hg_nu2, P.hg_nub, C.c_double(P.hg_omega), P.hg_fmg, (C.c_double * 2)(P.hg_omega_pre1, P.hg_omega_pre2), C.byref(st))
     assert rc == 0, "oracle nodal MG did not converge (%d cycles, %g / %g)" % (st.cycles, st.res, st.res0)
     grh, gphi = case.gmf(case.ofab(1, 1, nodal)), case.gmf(case.ofab(1, 1, nodal))
     bc = [[ell[d][sd] for sd in range(2)] for d in range(3)]

@@ -352,10 +352,13 @@ __global__ void __launch_bounds__(256) kk_nd_shell(NLev L, const double *__restr
   }
   if (MODE == 1 && nrm) block_atomic_max(nrm, rmax);
 }
+// the damping of the sweep being launched when it is not vdn_params.hg_omega (nd_jacobi_d / nd_jacobi_t set it per sweep: NdOm)
+static double g_nd_omega_now = 0.0;
+static double nd_cur_omega() { return g_nd_omega_now > 0.0 ? g_nd_omega_now : ctx().prm.hg_omega; }
 template <int MODE> static void nd_launch_shell(const NLev &L, const double *phi, double *out, double *nrm, int hm) {
   if (!hm) return;
   const int m = std::max(L.n[0], std::max(L.n[1], L.n[2])) + 1;
-  hipLaunchKernelGGL((kk_nd_shell<MODE>), dim3((m + 63) / 64, (m + 3) / 4, (unsigned)__builtin_popcount(hm)), dim3(64, 4, 1), 0, ctx().stream, L, phi, out, ctx().prm.hg_omega, nrm, hm);
+  hipLaunchKernelGGL((kk_nd_shell<MODE>), dim3((m + 63) / 64, (m + 3) / 4, (unsigned)__builtin_popcount(hm)), dim3(64, 4, 1), 0, ctx().stream, L, phi, out, nd_cur_omega(), nrm, hm);
 }
 
 // ghost nodes (and the periodic alias node n): periodic image, else zero
@@ -493,7 +496,8 @@ __global__ void kk_nd_coarsen_sigma(NLev F, NLev C) {
 // bottom solve: all Jacobi sweeps of the coarsest level in one launch by one workgroup (ping-pong between
 // phi and tmp; ghost nodes refreshed by the same workgroup between sweeps).  Returns with the result in
 // `a` if nsweeps is even, in `b` otherwise (the host swaps accordingly).
-__global__ void __launch_bounds__(1024) kk_nd_bottom(NLev L, double *a, double *b, int nsweeps, double omega) {
+// (om1, om2, nsp: the first nsp sweeps -- the two pre-smoothing sweeps of a V-cycle -- are damped by om1, om2 instead of omega; NdOm below)
+__global__ void __launch_bounds__(1024) kk_nd_bottom(NLev L, double *a, double *b, int nsweeps, double omega, double om1 = 0.0, double om2 = 0.0, int nsp = 0) {
   const int ex = L.n[0] + 3, ey = L.n[1] + 3, ez = L.n[2] + 3;
   const int nx = L.n[0] + 1, ny = L.n[1] + 1, nz = L.n[2] + 1;
   double *src = a, *dst = b;
@@ -515,7 +519,7 @@ __global__ void __launch_bounds__(1024) kk_nd_bottom(NLev L, double *a, double *
       double v = p0;
       if (!nd_is_dir(L, i, j, k)) {
         double Kp, diag; nd_apply(L, src, i, j, k, Kp, diag);
-        if (diag != 0.0) v = p0 + omega * ((L.b[c] - Kp) / diag);
+        if (diag != 0.0) v = p0 + (s < nsp ? (s == 0 ? om1 : om2) : omega) * ((L.b[c] - Kp) / diag);
       }
       dst[c] = v;
     }
@@ -530,7 +534,7 @@ __global__ void __launch_bounds__(1024) kk_nd_bottom(NLev L, double *a, double *
 // the same per-node code (nd_apply, the sums of kk_nd_restrict, nd_interp8) in the same order, barriers instead of launch boundaries.
 // L[0] is entered like any level of nd_vcycle_d (b set, phi = 0) and left with its correction in the array the host's swap parity names.
 #define ND_TAIL_MAX 4
-struct NdTailArgs { NLev L[ND_TAIL_MAX]; int nlev, nu1, nu2, nbot; double omega; };
+struct NdTailArgs { NLev L[ND_TAIL_MAX]; int nlev, nu1, nu2, nbot; double omega, om1, om2; int nsp; };      // om1, om2, nsp: the pre-smoothing sweeps' damping (NdOm)
 DEVI void wg_nd_fill(const NLev &L, double *a) {                     // nd_fill_nodes; ghost nodes outside a physical face stay zero
   if (!(L.per[0] || L.per[1] || L.per[2])) return;
   const int ex = L.n[0] + 3, ey = L.n[1] + 3, ez = L.n[2] + 3;
@@ -545,7 +549,7 @@ DEVI void wg_nd_fill(const NLev &L, double *a) {                     // nd_fill_
   }
   __syncthreads();
 }
-DEVI void wg_nd_jacobi(const NLev &L, double *&src, double *&dst, int nsweeps, double omega) {
+DEVI void wg_nd_jacobi(const NLev &L, double *&src, double *&dst, int nsweeps, double omega, double om1 = 0.0, double om2 = 0.0, int nsp = 0) {
   const int nx = L.n[0] + 1, ny = L.n[1] + 1, nz = L.n[2] + 1;
   for (int s = 0; s < nsweeps; s++) {
     wg_nd_fill(L, src);
@@ -556,7 +560,7 @@ DEVI void wg_nd_jacobi(const NLev &L, double *&src, double *&dst, int nsweeps, d
       double v = p0;
       if (!nd_is_dir(L, i, j, k)) {
         double Kp, diag; nd_apply(L, src, i, j, k, Kp, diag);
-        if (diag != 0.0) v = p0 + omega * ((L.b[c] - Kp) / diag);
+        if (diag != 0.0) v = p0 + (s < nsp ? (s == 0 ? om1 : om2) : omega) * ((L.b[c] - Kp) / diag);
       }
       dst[c] = v;
     }
@@ -618,7 +622,7 @@ __global__ void __launch_bounds__(1024) kk_nd_tailcycle(NdTailArgs T) {
   for (int l = 0; l < ND_TAIL_MAX; l++) { ph[l] = T.L[l].phi; tm[l] = T.L[l].tmp; }
   #pragma unroll
   for (int l = 0; l < ND_TAIL_MAX - 1; l++)
-    if (l < T.nlev - 1) { wg_nd_jacobi(T.L[l], ph[l], tm[l], T.nu1, T.omega); wg_nd_down(T.L[l], ph[l], T.L[l + 1], ph[l + 1]); }
+    if (l < T.nlev - 1) { wg_nd_jacobi(T.L[l], ph[l], tm[l], T.nu1, T.omega, T.om1, T.om2, T.nsp); wg_nd_down(T.L[l], ph[l], T.L[l + 1], ph[l + 1]); }
   #pragma unroll
   for (int l = 0; l < ND_TAIL_MAX; l++)
     if (l == T.nlev - 1) wg_nd_jacobi(T.L[l], ph[l], tm[l], T.nbot, T.omega);
@@ -837,10 +841,10 @@ template <int MODE> static void nd_launch_march(const NLev &L, const double *phi
     if (kc_env > 0) kc = std::min(kc_env, nzp);
     G.gz = std::max(1, (nzp + kc - 1) / kc);      // balanced slabs of at most kc planes (257 planes: 16 slabs of 16 or 17 -- measured 0.1396 ms against 0.1443 with 15 slabs)
     G.nmain = G.gxm * G.gy * G.gz;
-    hipLaunchKernelGGL((kk_nd_march_pair<MODE, 4>), dim3(G.nmain + G.gyr * G.gz), NBLK, 0, ctx().stream, L, phi, out, ctx().prm.hg_omega, G, nrm, shell_later);
+    hipLaunchKernelGGL((kk_nd_march_pair<MODE, 4>), dim3(G.nmain + G.gyr * G.gz), NBLK, 0, ctx().stream, L, phi, out, nd_cur_omega(), G, nrm, shell_later);
     return;
   }
-  hipLaunchKernelGGL(kk_nd_march<MODE>, dim3((L.n[0] + 62) / 62, (L.n[1] + 4) / 4, nch), NBLK, 0, ctx().stream, L, phi, out, ctx().prm.hg_omega, kchunk, nrm, shell_later);
+  hipLaunchKernelGGL(kk_nd_march<MODE>, dim3((L.n[0] + 62) / 62, (L.n[1] + 4) / 4, nch), NBLK, 0, ctx().stream, L, phi, out, nd_cur_omega(), kchunk, nrm, shell_later);
 }
 
 struct NBox { NLev L; int lo[3]; int hmask = 63; XPlan *hA = nullptr, *hB = nullptr; double *A = nullptr, *B = nullptr; };
@@ -1023,16 +1027,27 @@ static bool nd_halo_begin(NDLev &DL) {
 static void nd_halo_end() { VdnCtx &c = ctx(); HIPCHK(hipStreamWaitEvent(c.stream, c.ev_halo, 0)); }
 // levels of at most 9^3 nodes held in ONE box: all sweeps in a single one-workgroup launch (launch-latency bound otherwise)
 static const long SMALL_LEVEL_NODES = 9L * 9 * 9;
-static void nd_jacobi_d(NDLev &DL, int nsweeps) {
+// The damping of a run of sweeps.  `pre` = the nu1 pre-smoothing sweeps of a V-cycle: with nu1 = 2 and vdn_params.hg_omega_pre1 / 2 > 0 the first is
+// damped by pre1 and the second by pre2 (oracle: nd_presmooth); every other sweep by hg_omega.
+struct NdOm { double om, om1, om2; int nsp; double at(int s) const { return s < nsp ? (s == 0 ? om1 : om2) : om; } };
+static NdOm nd_om(bool pre, int nsweeps) {
+  const vdn_params &P = ctx().prm;
+  NdOm o{ P.hg_omega, 0.0, 0.0, 0 };
+  if (pre && nsweeps == 2 && P.hg_nu1 == 2 && P.hg_omega_pre1 > 0.0 && P.hg_omega_pre2 > 0.0) { o.om1 = P.hg_omega_pre1; o.om2 = P.hg_omega_pre2; o.nsp = 2; }
+  return o;
+}
+static void nd_jacobi_d(NDLev &DL, int nsweeps, bool pre = false) {
+  const NdOm om = nd_om(pre, nsweeps);
   if (DL.single_box && DL.boxes.size() == 1 && (long)(DL.ng[0] + 1) * (DL.ng[1] + 1) * (DL.ng[2] + 1) <= SMALL_LEVEL_NODES) {
     NBox &B = DL.boxes[0];
     NLev Lp = B.L;                      // the kernel refreshes periodic images itself: give it the periodicity flags
     for (int d = 0; d < 3; d++) Lp.per[d] = DL.per[d];
-    hipLaunchKernelGGL(kk_nd_bottom, dim3(1), dim3(1024), 0, ctx().stream, Lp, B.L.phi, B.L.tmp, nsweeps, ctx().prm.hg_omega);
+    hipLaunchKernelGGL(kk_nd_bottom, dim3(1), dim3(1024), 0, ctx().stream, Lp, B.L.phi, B.L.tmp, nsweeps, om.om, om.om1, om.om2, om.nsp);
     if (nsweeps & 1) { std::swap(B.L.phi, B.L.tmp); DL.flip = !DL.flip; }
     return;
   }
   for (int s = 0; s < nsweeps; s++) {
+    g_nd_omega_now = om.at(s);
     const bool ov = nd_halo_begin(DL);
     for (NBox &B : DL.boxes) nd_launch_march<0>(B.L, B.L.phi, B.L.tmp, nullptr);
     if (ov) {
@@ -1042,6 +1057,7 @@ static void nd_jacobi_d(NDLev &DL, int nsweeps) {
     for (NBox &B : DL.boxes) std::swap(B.L.phi, B.L.tmp);
     DL.flip = !DL.flip;
   }
+  g_nd_omega_now = 0.0;
 }
 static void nd_residual_d(NDMG &M, NDLev &DL, bool norm) {
   if (norm) HIPCHK(hipMemsetAsync(M.d_nrm, 0, sizeof(double), ctx().stream));
@@ -1061,17 +1077,20 @@ static void nd_fill_nodes(const NLev &L, double *a) {
   if (!(L.per[0] || L.per[1] || L.per[2])) return;     // ghosts stay zero: set once by the setup memset, never written
   hipLaunchKernelGGL(kk_nd_fill_nodes, ng3(L.n[0] + 3, L.n[1] + 3, L.n[2] + 3), NBLK, 0, ctx().stream, L, a);
 }
-static void nd_jacobi_t(NLev &L, int nsweeps) {
+static void nd_jacobi_t(NLev &L, int nsweeps, bool pre = false) {
+  const NdOm om = nd_om(pre, nsweeps);
   if ((long)(L.n[0] + 1) * (L.n[1] + 1) * (L.n[2] + 1) <= SMALL_LEVEL_NODES) {
-    hipLaunchKernelGGL(kk_nd_bottom, dim3(1), dim3(1024), 0, ctx().stream, L, L.phi, L.tmp, nsweeps, ctx().prm.hg_omega);
+    hipLaunchKernelGGL(kk_nd_bottom, dim3(1), dim3(1024), 0, ctx().stream, L, L.phi, L.tmp, nsweeps, om.om, om.om1, om.om2, om.nsp);
     if (nsweeps & 1) std::swap(L.phi, L.tmp);
     return;
   }
   for (int s = 0; s < nsweeps; s++) {
+    g_nd_omega_now = om.at(s);
     nd_fill_nodes(L, L.phi);
     nd_launch_march<0>(L, L.phi, L.tmp, nullptr);
     std::swap(L.phi, L.tmp);
   }
+  g_nd_omega_now = 0.0;
 }
 static void nd_bottom_t(NLev &L) {          // max(nub, 2 N^2) sweeps (same rule as the oracle)
   const int N = std::max(L.n[0], std::max(L.n[1], L.n[2]));
@@ -1088,7 +1107,7 @@ static void nd_vcycle_t(NDMG &M, int l) {
   if (nd_small_end(M, -1, l)) return;
   if (l == (int)M.tail.size() - 1) { nd_bottom_t(L); return; }
   NLev &C = M.tail[l + 1];
-  nd_jacobi_t(L, P.hg_nu1);
+  nd_jacobi_t(L, P.hg_nu1, true);
   nd_fill_nodes(L, L.phi);
   nd_launch_march<1>(L, L.phi, L.res, nullptr);
   nd_fill_nodes(L, L.res);
@@ -1162,7 +1181,7 @@ static bool nd_small_end(NDMG &M, int dl, int tl) {
   if (nl < 2) return false;
   const NLev &B = T.L[nl - 1];
   const int N = std::max(B.n[0], std::max(B.n[1], B.n[2]));
-  T.nlev = nl; T.nu1 = P.hg_nu1; T.nu2 = P.hg_nu2; T.nbot = std::max(P.hg_nub, 2 * N * N); T.omega = P.hg_omega;     // nd_bottom_t / nd_bottom_sweeps_global
+  T.nlev = nl; T.nu1 = P.hg_nu1; T.nu2 = P.hg_nu2; T.nbot = std::max(P.hg_nub, 2 * N * N); T.omega = P.hg_omega; { const NdOm o = nd_om(true, P.hg_nu1); T.om1 = o.om1; T.om2 = o.om2; T.nsp = o.nsp; }     // nd_bottom_t / nd_bottom_sweeps_global
   hipLaunchKernelGGL(kk_nd_tailcycle, dim3(1), dim3(1024), 0, ctx().stream, T);
   int m = 0;                                           // the ping-pong state the sweeps leave behind (nd_jacobi_d / nd_jacobi_t)
   if (dl >= 0) for (int q = dl; q < (int)M.dlev.size(); q++, m++) {
@@ -1181,7 +1200,7 @@ static void nd_vcycle_d(NDMG &M, int l) {
   if (nd_small_end(M, l, 0)) return;
   const bool last = (l == (int)M.dlev.size() - 1);
   if (last && M.tail.empty()) { nd_jacobi_d(DL, nd_bottom_sweeps_global(DL)); return; }
-  nd_jacobi_d(DL, P.hg_nu1);
+  nd_jacobi_d(DL, P.hg_nu1, true);
   nd_residual_d(M, DL, false);
   nd_restrict_down(M, l);
   if (last) nd_vcycle_t(M, 0); else nd_vcycle_d(M, l + 1);
@@ -1204,7 +1223,7 @@ static void nd_cycle_at(NDMG &M, int g) {
   const vdn_params &P = ctx().prm;
   const int nd = (int)M.dlev.size();
   if (g < nd) {
-    nd_jacobi_d(M.dlev[g], P.hg_nu1);
+    nd_jacobi_d(M.dlev[g], P.hg_nu1, true);
     nd_residual_d(M, M.dlev[g], false);
     nd_restrict_down(M, g);
     if (g + 1 < nd) nd_vcycle_d(M, g + 1); else nd_vcycle_t(M, 0);
@@ -1213,7 +1232,7 @@ static void nd_cycle_at(NDMG &M, int g) {
     return;
   }
   const int t = g - nd;
-  nd_jacobi_t(M.tail[t], P.hg_nu1);
+  nd_jacobi_t(M.tail[t], P.hg_nu1, true);
   NLev &L = M.tail[t]; NLev &C = M.tail[t + 1];
   nd_fill_nodes(L, L.phi);
   nd_launch_march<1>(L, L.phi, L.res, nullptr);
@@ -1263,7 +1282,7 @@ static void nd_key_lev(GraphKey &k, const NLev &L) {
 }
 static unsigned long long nd_graph_key(const NDMG &M, int what) {
   const vdn_params &P = ctx().prm;
-  GraphKey k; k.put(what); k.put(P.hg_nu1); k.put(P.hg_nu2); k.put(P.hg_nub); k.put(P.hg_omega); k.put(M.per); k.put(M.d_nrm);
+  GraphKey k; k.put(what); k.put(P.hg_nu1); k.put(P.hg_nu2); k.put(P.hg_nub); k.put(P.hg_omega); k.put(P.hg_omega_pre1); k.put(P.hg_omega_pre2); k.put(M.per); k.put(M.d_nrm);
   k.put(M.sendbuf); k.put(M.recvbuf); k.put(M.d_gb); k.put(M.cnt_nodes); k.put(M.cnt_cells);
   for (const NDLev &DL : M.dlev) {
     k.put(xplan_serial(DL.halo_A)); k.put(xplan_serial(DL.halo_B)); k.put(xplan_serial(DL.halo_res)); k.put(xplan_serial(DL.halo_sig)); k.put(DL.ng); k.put(DL.flip); k.put(DL.single_box); k.put(DL.per);
@@ -1400,7 +1419,7 @@ int nd_solve(vdn_multifab *rh, vdn_multifab *phi, const vdn_multifab *coeffs, co
     if (single) { nd_jacobi_d(M.dlev[0], nd_bottom_sweeps_global(M.dlev[0])); continue; }
     nd_run_cycle(M, 2, [&] {
       NDLev &D = M.dlev[0];
-      nd_jacobi_d(D, P.hg_nu1);
+      nd_jacobi_d(D, P.hg_nu1, true);
       nd_residual_d(M, D, false);
       nd_restrict_down(M, 0);
       if (M.dlev.size() > 1) nd_vcycle_d(M, 1); else nd_vcycle_t(M, 0);
@@ -1412,7 +1431,7 @@ int nd_solve(vdn_multifab *rh, vdn_multifab *phi, const vdn_multifab *coeffs, co
   if (fixed_cycles) conv = true;
   // pre-smoothing + residual, then per cycle [coarse correction, post-smoothing, next pre-smoothing, residual + norm] as one replayed
   // graph and one read-back: the same launch sequence as testing the residual the cycle computes after its pre-smoothing
-  if (!conv) { nd_jacobi_d(M.dlev[0], single ? nd_bottom_sweeps_global(M.dlev[0]) : P.hg_nu1); nd_residual_d(M, M.dlev[0], true); rn = nd_read(M.d_nrm); }
+  if (!conv) { nd_jacobi_d(M.dlev[0], single ? nd_bottom_sweeps_global(M.dlev[0]) : P.hg_nu1, !single); nd_residual_d(M, M.dlev[0], true); rn = nd_read(M.d_nrm); }
   while (!conv) {
     if ((rn <= rel_eps * bnorm && bnorm < HUGE_VAL) || rn <= abs_eps) { conv = true; break; }
     if (cyc >= max_iter || !(rn < HUGE_VAL) || !(bnorm < HUGE_VAL)) break;     // also: a NaN / inf norm (the reductions turn NaN into +inf)
@@ -1423,7 +1442,7 @@ int nd_solve(vdn_multifab *rh, vdn_multifab *phi, const vdn_multifab *coeffs, co
       if (M.dlev.size() > 1) nd_vcycle_d(M, 1); else nd_vcycle_t(M, 0);
       nd_prolong_up(M, 0);
       nd_jacobi_d(D, P.hg_nu2);
-      nd_jacobi_d(D, P.hg_nu1);
+      nd_jacobi_d(D, P.hg_nu1, true);
       nd_residual_d(M, D, true);
     });
     cyc++;
