@@ -355,6 +355,7 @@ __global__ void __launch_bounds__(256) kk_nd_shell(NLev L, const double *__restr
 // the damping of the sweep being launched when it is not vdn_params.hg_omega (nd_jacobi_d / nd_jacobi_t set it per sweep: NdOm)
 static double g_nd_omega_now = 0.0;
 static double nd_cur_omega() { return g_nd_omega_now > 0.0 ? g_nd_omega_now : ctx().prm.hg_omega; }
+struct NdOmegaScope { ~NdOmegaScope() { g_nd_omega_now = 0.0; } };      // the override does not outlive the run of sweeps that set it, exceptions included
 template <int MODE> static void nd_launch_shell(const NLev &L, const double *phi, double *out, double *nrm, int hm) {
   if (!hm) return;
   const int m = std::max(L.n[0], std::max(L.n[1], L.n[2])) + 1;
@@ -1038,6 +1039,7 @@ static NdOm nd_om(bool pre, int nsweeps) {
 }
 static void nd_jacobi_d(NDLev &DL, int nsweeps, bool pre = false) {
   const NdOm om = nd_om(pre, nsweeps);
+  NdOmegaScope scope_;
   if (DL.single_box && DL.boxes.size() == 1 && (long)(DL.ng[0] + 1) * (DL.ng[1] + 1) * (DL.ng[2] + 1) <= SMALL_LEVEL_NODES) {
     NBox &B = DL.boxes[0];
     NLev Lp = B.L;                      // the kernel refreshes periodic images itself: give it the periodicity flags
@@ -1057,7 +1059,6 @@ static void nd_jacobi_d(NDLev &DL, int nsweeps, bool pre = false) {
     for (NBox &B : DL.boxes) std::swap(B.L.phi, B.L.tmp);
     DL.flip = !DL.flip;
   }
-  g_nd_omega_now = 0.0;
 }
 static void nd_residual_d(NDMG &M, NDLev &DL, bool norm) {
   if (norm) HIPCHK(hipMemsetAsync(M.d_nrm, 0, sizeof(double), ctx().stream));
@@ -1079,6 +1080,7 @@ static void nd_fill_nodes(const NLev &L, double *a) {
 }
 static void nd_jacobi_t(NLev &L, int nsweeps, bool pre = false) {
   const NdOm om = nd_om(pre, nsweeps);
+  NdOmegaScope scope_;
   if ((long)(L.n[0] + 1) * (L.n[1] + 1) * (L.n[2] + 1) <= SMALL_LEVEL_NODES) {
     hipLaunchKernelGGL(kk_nd_bottom, dim3(1), dim3(1024), 0, ctx().stream, L, L.phi, L.tmp, nsweeps, om.om, om.om1, om.om2, om.nsp);
     if (nsweeps & 1) std::swap(L.phi, L.tmp);
@@ -1090,7 +1092,6 @@ static void nd_jacobi_t(NLev &L, int nsweeps, bool pre = false) {
     nd_launch_march<0>(L, L.phi, L.tmp, nullptr);
     std::swap(L.phi, L.tmp);
   }
-  g_nd_omega_now = 0.0;
 }
 static void nd_bottom_t(NLev &L) {          // max(nub, 2 N^2) sweeps (same rule as the oracle)
   const int N = std::max(L.n[0], std::max(L.n[1], L.n[2]));
