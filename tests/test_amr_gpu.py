@@ -751,3 +751,51 @@ def test_composite_launch_variants_agree_bit_for_bit(gpu):
         assert r.returncode == 0, r.stderr[-2000:]
         out.append([ln for ln in r.stdout.splitlines() if ln.startswith("HASH")][0])
     assert out[0] == out[1], out
+
+
+def test_periodic_three_level_hierarchy_is_translation_invariant(gpu):
+    """three levels on a domain periodic in x, shifted by half a period so that the boxes of BOTH refined levels sit across the periodic
+    boundary: the corrections prolonged linearly into level 2 then read their coarse neighbours through periodic images of another box
+    (amr.hip apply_correction: edge fill + same-level exchange of the source).  Two steps; 1e-8 relative, iteration counts within one."""
+    from varden_amd import advance as adv
+    from varden_amd import driver
+    from varden_amd.capi import default_params
+    nc = 16
+    phys = [[-1, -1], [15, 15], [15, 15]]
+
+    def bubble(xc):
+        def fn(lev, blo, nb, dx):
+            g = 3
+            ax = [(np.arange(blo[d] - g, blo[d] + nb[d] + g) + 0.5) * dx[d] for d in range(3)]
+            X, Y, Z = np.meshgrid(*ax, indexing="ij")
+            dxp = (X - xc + 0.5) % 1.0 - 0.5
+            r = np.sqrt(dxp ** 2 + (Y - 0.5) ** 2 + (Z - 0.5) ** 2)
+            s = np.zeros(X.shape + (2,), order="F")
+            s[..., 0] = 1.0 + 0.5 * (10.0 - 1.0) * (1.0 - np.tanh(30.0 * (r - 0.1)))
+            s[..., 1] = s[..., 0]
+            return np.zeros(X.shape + (3,), order="F"), s
+        return fn
+
+    prm = lambda: default_params(cflfac=0.9)   # noqa: E731
+    A = driver.VardenAMR(nc, [((8, 8, 8), (23, 23, 23))], phys, params=prm(), finer_levels=[[((24, 24, 24), (39, 39, 39))]], init_fn=bubble(0.5), init_iter=1,
+                         do_initial_projection=1)
+    for _ in range(2):
+        A.step()
+    ua0 = A.unew[0].to_numpy(0)[3:-3, 3:-3, 3:-3]
+    sa2 = A.snew[2].to_numpy(0)[3:-3, 3:-3, 3:-3]
+    ua2 = A.unew[2].to_numpy(0)[3:-3, 3:-3, 3:-3]
+    dta, ita = A.dt, (adv.last_solver_stats("mac")[0], adv.last_solver_stats("hg")[0])
+    A.close()
+    B = driver.VardenAMR(nc, [((24, 8, 8), (31, 23, 23)), ((0, 8, 8), (7, 23, 23))], phys, params=prm(),
+                         finer_levels=[[((56, 24, 24), (63, 39, 39)), ((0, 24, 24), (7, 39, 39))]], init_fn=bubble(0.0), init_iter=1, do_initial_projection=1)
+    for _ in range(2):
+        B.step()
+    assert abs(B.dt - dta) <= 1e-9 * dta
+    assert abs(adv.last_solver_stats("mac")[0] - ita[0]) <= 1 and abs(adv.last_solver_stats("hg")[0] - ita[1]) <= 1, (ita, adv.last_solver_stats("mac")[0], adv.last_solver_stats("hg")[0])
+    ub0 = B.unew[0].to_numpy(0)[3:-3, 3:-3, 3:-3]
+    assert np.abs(np.roll(ua0, nc // 2, axis=0) - ub0).max() <= 1e-8 * np.abs(ua0).max()
+    for a, mf, nm in ((ua2, B.unew[2], "u"), (sa2, B.snew[2], "s")):
+        lo_half, hi_half = mf.to_numpy(0)[3:-3, 3:-3, 3:-3], mf.to_numpy(1)[3:-3, 3:-3, 3:-3]
+        assert np.abs(a[:8] - lo_half).max() <= 1e-8 * np.abs(a).max() and np.abs(a[8:] - hi_half).max() <= 1e-8 * np.abs(a).max(), nm
+    assert np.abs(ua2[..., 2]).max() > 0
+    B.close()
