@@ -111,7 +111,7 @@ def parse_args():
     ap.add_argument("--mac-fmg", dest="mac_fmg", type=int, default=1, choices=[0, 1], help="nested-iteration start of the MAC solve (vdn_params.mac_fmg; 0: the zero guess)")
     ap.add_argument("--hg-pre-pair", dest="hg_pre_pair", type=int, default=1, choices=[0, 1], help="two-step damping of the nodal V-cycle's pre-smoothing sweeps (vdn_params.hg_omega_pre1 / 2; 0: hg_omega for both)")
     ap.add_argument("--no-calib", dest="no_calib", action="store_true", help="skip the one-thread Godunov calibration of the cpu_baseline leg")
-    ap.add_argument("--no-extra", dest="no_extra", action="store_true", help="skip the extra_workloads (512^3 in eight boxes, tagged two-level hierarchy) of the default N = 1 line")
+    ap.add_argument("--no-extra", dest="no_extra", action="store_true", help="skip the extra_workloads (512^3 in eight boxes and in one box, tagged two-level hierarchy) of the default N = 1 line")
     return ap.parse_args()
 
 
@@ -237,8 +237,8 @@ def main():
                               swap_state=True)     # uold <- unew as a handle exchange (tests/test_advance_gpu.py::test_handle_swap_equals_copy)
             cells = nglob[0] * nglob[1] * nglob[2]
             nb = decomp[0] * decomp[1] * decomp[2]
-            workload = ("3D %dx%dx%d single-level variable-density bubble, %d box(es) of %d^3, MAC+HG projection each step (BASELINE.json configs[%d])"
-                        % (nglob + (nb, n, 1 if nb == 1 else 2)))
+            workload = ("3D %dx%dx%d single-level variable-density bubble, %d box(es) of %d^3, MAC+HG projection each step (BASELINE.json configs[%d]%s)"
+                        % (nglob + (nb, n, 1 if nb == 1 else 2, "" if (nb > 1 or n == 256) else " at north_star's single-GPU box size" if n == 512 else " at another box size")))
             par = "single GPU" if world == 1 else ("domain decomposition %dx%dx%d, %d box(es) of %d^3 per GPU, RCCL p2p ghost exchange + allreduce"
                                                    % (decomp + (nb // world, n)))
         return G, cells, workload, par, amr
@@ -291,9 +291,9 @@ def main():
     # ---- the other single-GPU workloads of BASELINE.json, a few timed steps each (the headline stays configs[1]) ----------
     extra = []
     if world == 1 and args.config == "256" and n == 256 and not args.no_extra:
-        for cfg in ("512", "amr2"):
+        for cfg, n2 in (("512", 256), ("256", 512), ("amr2", 256)):      # 512^3 as eight boxes (configs[2] on one GPU), 512^3 as ONE box (north_star's single-GPU size), the tagged hierarchy
             tb = time.perf_counter()
-            G2, cells2, wl2, _, _ = build_workload(cfg, 256)
+            G2, cells2, wl2, _, _ = build_workload(cfg, n2)
             G2.step()                                       # warm-up
             torch.cuda.synchronize()
             t1 = time.perf_counter()
