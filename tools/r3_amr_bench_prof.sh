@@ -1,9 +1,9 @@
 #!/bin/bash
-# round 3, GPU call 23: composite MAC solve, coarse correction on level 0's own coefficients (density-based kernels): AMR tests, amr2 / amr3, kernel stats of both
+# round 3, composite MAC solve, coarse correction on level 0's own coefficients (density-based kernels): AMR tests, amr2 / amr3, kernel stats of both
 set -o pipefail
 cd "$GRAFT_REPO_ROOT" || exit 1
 export TMPDIR=/tmp
-O=$GRAFT_REPO_ROOT/gpurun_out/r3c23; mkdir -p $O
+O=$GRAFT_REPO_ROOT/gpurun_out/r3_amr; mkdir -p $O
 timeout -k 10 900 python -m pytest tests/test_amr_gpu.py tests/test_fullsize_gpu.py -m gpu -x -q > $O/pytest.log 2>&1; rc=$?; echo "pytest rc=$rc" >> $O/pytest.log; tail -n 12 $O/pytest.log | cut -c1-220
 [ $rc -eq 0 ] || exit $rc
 for c in amr2 amr3; do echo "== $c"; timeout -k 10 400 python bench.py --config $c --steps 5 --warmup 2 --skip-cpu --no-extra 2>&1 | tail -n 1 | cut -c1-1000 || exit 1; done > $O/bench.log 2>&1 && cat $O/bench.log &&

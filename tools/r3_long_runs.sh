@@ -1,10 +1,10 @@
 #!/bin/bash
-# round 3, GPU call 41: long runs with the round's solver iterates (nested iteration, damping pair, linear AMR prolongation): HIP against the oracle over
+# round 3, long runs with the round's solver iterates (nested iteration, damping pair, linear AMR prolongation): HIP against the oracle over
 # 150 steps on one level and 80 on two, and the reference's 3-D inputs files for a few dozen steps each
 set -o pipefail
 cd "$GRAFT_REPO_ROOT" || exit 1
 export TMPDIR=/tmp
-O=$GRAFT_REPO_ROOT/gpurun_out/r3c41; mkdir -p $O
+O=$GRAFT_REPO_ROOT/gpurun_out/r3_long; mkdir -p $O
 timeout -k 10 400 python tools/long_vs_oracle.py 150 > $O/long1.log 2>&1 || { tail -n 5 $O/long1.log; exit 1; }; tail -n 6 $O/long1.log
 timeout -k 10 400 python tools/long_vs_oracle_amr.py 80 > $O/long2.log 2>&1 || { tail -n 5 $O/long2.log; exit 1; }; tail -n 4 $O/long2.log
 for f in inputs_bubble_3d:60 inputs_3d-regt:40 inputs_RayleighTaylor_3d:30 inputs_advect_3d:30 inputs_vortextube_3d:20; do
