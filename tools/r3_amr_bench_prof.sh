@@ -1,5 +1,5 @@
 #!/bin/bash
-# round 3, composite MAC solve, coarse correction on level 0's own coefficients (density-based kernels): AMR tests, amr2 / amr3, kernel stats of both
+# round 3: the AMR tests and the full-size property tests, the two- and three-level bench lines, kernel statistics of both -> gpurun_out/r3_amr/
 set -o pipefail
 cd "$GRAFT_REPO_ROOT" || exit 1
 export TMPDIR=/tmp
