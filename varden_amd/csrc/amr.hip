@@ -680,15 +680,20 @@ static void fill_phi_ghosts(MLCC &S) {
   for (int n = 1; n < S.nlev; n++) { S.vc_phi[n].refresh(); S.cf[n].run(0, (double *)nullptr, st); mf_fill_boundary(S.phi[n]); }
 }
 // want_norm = false: the residual fields only (no reduction, no read-back: the host does not wait for the device)
-static double composite_residual(MLCC &S, bool want_norm = true) {
+// lowest > 0 (without the norm): the residual fields of the levels >= lowest only -- what the relaxation of level `lowest` reads; the levels below
+// are recomputed by the next call before anything reads them (three levels: the residual, flux matching and restriction of the 256^3 base level
+// twice per iteration)
+static double composite_residual(MLCC &S, bool want_norm = true, int lowest = 0) {
   hipStream_t st = ctx().stream;
   const int L = S.nlev;
+  static const bool partial = !(getenv("VDN_MLCC_PARTIAL") && atoi(getenv("VDN_MLCC_PARTIAL")) == 0);
+  if (want_norm || !partial) lowest = 0;
   fill_phi_ghosts(S);
   if (want_norm) HIPCHK(hipMemsetAsync(S.d_nrm, 0, sizeof(double), st));
-  for (int n = 0; n < L; n++) S.resid[n].run(0, (n == L - 1 && want_norm) ? S.d_nrm : (double *)nullptr, st);
+  for (int n = lowest; n < L; n++) S.resid[n].run(0, (n == L - 1 && want_norm) ? S.d_nrm : (double *)nullptr, st);
   // flux matching: lo faces then hi faces of every direction (one update per coarse cell and launch, hence deterministic)
-  for (int n = 1; n < L; n++) { S.vf_phi[n].refresh(); for (int ds = 0; ds < 6; ds++) S.reflux[n][ds].run(0, (double *)nullptr, st); }     // fine phi incl. its ghost cells
-  for (int n = L - 1; n >= 1; n--) { S.vf_res[n].refresh(); S.rres[n].run(0, (double *)nullptr, st); }
+  for (int n = lowest + 1; n < L; n++) { S.vf_phi[n].refresh(); for (int ds = 0; ds < 6; ds++) S.reflux[n][ds].run(0, (double *)nullptr, st); }     // fine phi incl. its ghost cells
+  for (int n = L - 1; n >= lowest + 1; n--) { S.vf_res[n].refresh(); S.rres[n].run(0, (double *)nullptr, st); }
   if (!want_norm) return 0.0;
   for (int n = 0; n < L - 1; n++) S.absmax[n].run(0, S.d_nrm, st);
   comm_allreduce_max_dev(S.d_nrm, 1);
@@ -787,7 +792,7 @@ int ml_cc_solve(vdn_layout *la, vdn_multifab **rh, vdn_multifab **phi, vdn_multi
     for (int n = L - 1; n >= 1; n--) {
       level_relax(S, n, P.mg_nu1);
       apply_correction(S, n);
-      (void)composite_residual(S, false);
+      (void)composite_residual(S, false, n - 1);
     }
     // coarse correction: ONE V-cycle of the single-level multigrid on the whole level 0
     static const bool glue = !(getenv("VDN_MLCC_GLUE") && atoi(getenv("VDN_MLCC_GLUE")) == 0);
@@ -801,7 +806,7 @@ int ml_cc_solve(vdn_layout *la, vdn_multifab **rh, vdn_multifab **phi, vdn_multi
     apply_correction(S, 0, glue);            // (glue: phi_0 += e_0 was done where e_0 was stored)
     // post-relaxation on the new residual, coarsest level first
     for (int n = 1; n < L; n++) {
-      if (n < L - 1) (void)composite_residual(S, false);
+      if (n < L - 1) (void)composite_residual(S, false, n);
       else { fill_phi_ghosts(S); S.resid[n].run(0, (double *)nullptr, st); }
       level_relax(S, n, P.mg_nu2);
       apply_correction(S, n);
