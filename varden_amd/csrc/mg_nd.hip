@@ -2071,7 +2071,8 @@ static bool ndf_fuse_first() {       // the fused residual + first sweep needs t
   return on;
 }
 // fuse_first (with finest_only): the same march also writes the first damped-Jacobi sweep of K e = r from e = 0 into eb of the finest level
-static double ml_nd_residual(MLND &S, bool finest_only, bool zero_field = false, bool fuse_first = false, bool want_norm = true) {
+// lowest > 0 (without the norm): the residual fields of the levels >= lowest only (what the relaxation of level `lowest` reads)
+static double ml_nd_residual(MLND &S, bool finest_only, bool zero_field = false, bool fuse_first = false, bool want_norm = true, int lowest = 0) {
   hipStream_t st = ctx().stream;
   const int L = S.nlev;
   if (!zero_field) {
@@ -2079,7 +2080,9 @@ static double ml_nd_residual(MLND &S, bool finest_only, bool zero_field = false,
     else { if (S.multi[0]) mf_fill_boundary(S.phi[0]); for (int n = 1; n < L; n++) ml_nd_interface(S, n); }
   }
   if (!finest_only) HIPCHK(hipMemsetAsync(S.d_nrm, 0, sizeof(double), st));
-  for (int n = L - 1; n >= (finest_only ? L - 1 : 0); n--) {
+  static const bool partial = !(getenv("VDN_MLND_PARTIAL") && atoi(getenv("VDN_MLND_PARTIAL")) == 0);
+  if (want_norm || !partial || zero_field) lowest = 0;
+  for (int n = L - 1; n >= (finest_only ? L - 1 : lowest); n--) {
     const bool finest = n == L - 1;
     if (finest_only && fuse_first) { ndf_run_march<2>(S.m_res[n], ctx().prm.hg_omega, S.slave[n] ? 1 : 0, (double *)nullptr); return 0.0; }
     ndf_run_march<1>(zero_field ? S.m_res0[n] : S.m_res[n], 0.0, (finest && S.slave[n]) ? 1 : 0, (finest && !finest_only && want_norm) ? S.d_nrm : (double *)nullptr);
@@ -2297,7 +2300,7 @@ static int ml_nd_solve(vdn_layout *la, vdn_multifab **rh, vdn_multifab **phi, vd
       // the finest level (its relaxation runs on the coefficients its residual runs on): the residual march writes the first sweep too -- into
       // eb, where a sweep from ea = 0 puts it; ea's ghost nodes outside the level stay zero from its allocation, no sweep writes them
       const bool fuse = ndf_fuse_first() && n == L - 1 && P.hg_nu1 + P.hg_nu2 >= 1;
-      (void)ml_nd_residual(S, n == L - 1, false, fuse, false);
+      (void)ml_nd_residual(S, n == L - 1, false, fuse, false, n);
       if (!fuse) mf_setval(S.ea[n], 0.0, 0, 1, true);
       vdn_multifab *a = S.ea[n], *b2 = S.eb[n];
       for (int s = 0; s < P.hg_nu1 + P.hg_nu2; s++) {
