@@ -1965,7 +1965,7 @@ struct NdmProlongB { Range3 r; int g[3]; static constexpr int planes_per_wg = 8;
     if (q.has_own && fv_get(q.own_c, I, J, K) == 0.0) return 0.0;          // a coarse node shared by several boxes: its owner does the work, once
     double s = 0.0;
     for (int c = 0; c <= ok; c++) for (int b = 0; b <= oj; b++) for (int a = 0; a <= oi; a++) s = s + fv_get(q.pc, I + a, J + b, K + c);
-    const double v = s * (1.0 / (double)((1 + oi) * (1 + oj) * (1 + ok)));
+    const double v = s * ((oi ? 0.5 : 1.0) * (oj ? 0.5 : 1.0) * (ok ? 0.5 : 1.0));      // = s * (1.0 / (double)((1 + oi) * (1 + oj) * (1 + ok))): the same power of two, without the division
     fv_at(q.pf, i, j, k) = (mode == 1) ? fv_get(q.pf, i, j, k) + v : v;
     return 0.0;
   } };
