@@ -97,7 +97,7 @@ template <class T> DEVI const T &as_constant(const T *p) {
 // SCRATCH when it is copied by value -- mkumac_rho_K, 310 bytes: 320 bytes of scratch per lane, 19 ms instead of 2.3 ms per 8-box launch
 template <class T, class = void> struct desc_in_constant : std::integral_constant<bool, (sizeof(T) > 320)> {};
 template <class T> struct desc_in_constant<T, std::void_t<decltype(T::in_constant)>> : std::integral_constant<bool, T::in_constant> {};
-enum { BATCH_YZ = 15, BATCH_XZ = 16 };      // tile codes in the top byte of g[2] (otherwise log2 of the tile width along x); XZ + log2 width
+enum { BATCH_FLAT = 14, BATCH_YZ = 15, BATCH_XZ = 16 };      // tile codes in the top byte of g[2] (otherwise log2 of the tile width along x); XZ + log2 width
 template <class A, class P>
 __global__ void __launch_bounds__(256) kk_batched(const A *args, const int *start, int nbox, P extra, double *nrm) {
   int lo = 0, hi = nbox - 1;
@@ -127,6 +127,16 @@ __global__ void __launch_bounds__(256) kk_batched(const A *args, const int *star
     const int j = a.r.lo[1] + by * 16 + (tid & 15), k = a.r.lo[2] + bz * 16 + (tid >> 4);
     if (j <= a.r.hi[1] && k <= a.r.hi[2])
       for (int i = a.r.lo[0]; i <= a.r.hi[0]; i++) v = nmax(v, A::body(a, i, j, k, extra));
+  } else if (lw == BATCH_FLAT) {          // the (i, j) plane of the range flattened over the workgroups' threads: a 33 x 33 plane of nodes is 5 workgroups, not 9 tiles of 64 x 4
+    const int nx = a.r.hi[0] - a.r.lo[0] + 1, t = bx * 256 + tid;
+    const int jj = t / nx, i = a.r.lo[0] + (t - jj * nx), j = a.r.lo[1] + jj;
+    if (j <= a.r.hi[1]) {
+      if (chunks) {
+        const int nz = a.r.hi[2] - a.r.lo[2] + 1, ch = (nz + gz - 1) / gz, ka = a.r.lo[2] + bz * ch, kb = min(ka + ch - 1, a.r.hi[2]);
+        for (int k = ka; k <= kb; k++) v = nmax(v, A::body(a, i, j, k, extra));
+      } else
+        for (int k = a.r.lo[2] + bz; k <= a.r.hi[2]; k += gz) v = nmax(v, A::body(a, i, j, k, extra));
+    }
   } else if (lw >= BATCH_XZ) {            // a range thin along y (the y faces): tiles of (i, k) -- 2^w lanes along x, 256 >> w planes --, y inside
     const int w = lw - BATCH_XZ;
     const int i = a.r.lo[0] + (bx << w) + (tid & ((1 << w) - 1)), k = a.r.lo[2] + bz * (256 >> w) + (tid >> w);
@@ -207,10 +217,14 @@ template <class A> static inline int batch_grid(A &a, int kz) {
   const int ppw = ppw_env > 0 ? ppw_env : batch_ppw<A>::value;
   int g0 = nx > 0 ? (nx + w - 1) / w : 0, g1 = ny > 0 ? (ny + h - 1) / h : 0, g2 = nz > 0 ? ((kz > 0 && nz > kz) ? kz : (nz + ppw - 1) / ppw) : 0;
   if (g0 == 0 || g1 == 0 || g2 == 0) { g0 = g1 = g2 = 1; a.r.hi[0] = a.r.lo[0] - 1; }
+  // widths that fill the 16 / 32 / 64-wide tiles badly (node ranges: 17, 25, 33, 41): the plane flattened over the threads when that takes fewer workgroups
+  static const bool flat_on = !(getenv("VDN_BATCH_FLAT") && atoi(getenv("VDN_BATCH_FLAT")) == 0);
+  int code = lw;
+  if (flat_on && nx > 0 && ny > 0 && (long)nx * ny < (1L << 24)) { const int gf = (nx * ny + 255) / 256; if (gf < g0 * g1) { g0 = gf; g1 = 1; code = BATCH_FLAT; } }
   static const bool chunk_on = !(getenv("VDN_BATCH_CHUNK") && atoi(getenv("VDN_BATCH_CHUNK")) == 0);
   const int chunked = (chunk_on && !(kz > 0 && nz > kz) && ppw > 1 && g2 < nz) ? 1 : 0;      // planes-per-workgroup mode: contiguous planes
   if (chunked) { const int ch = (nz + g2 - 1) / g2; g2 = (nz + ch - 1) / ch; }                 // (no workgroup without a plane)
-  a.g[0] = g0; a.g[1] = g1; a.g[2] = g2 | (chunked << 23) | (lw << 24);
+  a.g[0] = g0; a.g[1] = g1; a.g[2] = g2 | (chunked << 23) | (code << 24);
   return g0 * g1 * g2;
 }
 // host side: fills g / the prefix sums, uploads and launches.  kz: at most this many workgroups along k per box (0 = one per plane)
