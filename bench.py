@@ -185,6 +185,7 @@ def main():
     prm = default_params(cflfac=0.9, hg_fmg=args.hg_fmg, mac_fmg=args.mac_fmg)
     if not args.hg_pre_pair:
         prm.hg_omega_pre1 = prm.hg_omega_pre2 = 0.0
+        prm.hg_omega_fac1 = prm.hg_omega_fac2 = prm.hg_omega_fac3 = 0.0
     comm_id = None
     if world > 1:                                          # RCCL unique id: rank 0 creates it, everybody receives it
         bl.initialize(prm, rank, world, local_rank)

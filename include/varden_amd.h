@@ -80,6 +80,8 @@ typedef struct vdn_params {
                                    * per level a linear interpolation of the solution and one V-cycle; one V-cycle fewer at 1e-10; 0: off */
   double hg_omega_pre1, hg_omega_pre2;   /* 1.45, 0.7 (adjacent in memory, in this order): with hg_nu1 = 2 the two pre-smoothing sweeps of the nodal V-cycle
                                    * are damped by these instead of hg_omega -- a two-step Chebyshev pair, one V-cycle fewer at 256^3; either <= 0: hg_omega */
+  double hg_omega_fac1, hg_omega_fac2, hg_omega_fac3;   /* 1.6, 0.9, 0.65: with hg_nu1 + hg_nu2 = 3 the three relaxation sweeps on a refined level of the
+                                   * composite nodal solve (nlevs > 1) are damped by these -- a three-step Chebyshev set; any <= 0: hg_omega */
 } vdn_params;
 
 /* fills *p with the reference defaults (src/_parameters) */

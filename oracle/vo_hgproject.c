@@ -761,6 +761,9 @@ int vo_ml_nd_solve(int nlev, vo_fab **rh, vo_fab **phi, vo_fab **coeffs, vo_fab 
       double *e = (double *)calloc(nnf, sizeof(double)), *rb = (double *)malloc(sizeof(double) * nnf);
       memcpy(rb, F->res, sizeof(double) * nnf);
       F->phi = e; F->b = rb; F->sig = M.sigfull[n];
+      if (nu_f == 3 && prm->hg_omega_fac1 > 0.0 && prm->hg_omega_fac2 > 0.0 && prm->hg_omega_fac3 > 0.0) {      /* three-step damping set (round 3): 15 -> 14 and 14 -> 13 FAC iterations on the tagged hierarchies */
+        nd_jacobi(F, M.per, 1, prm->hg_omega_fac1); nd_jacobi(F, M.per, 1, prm->hg_omega_fac2); nd_jacobi(F, M.per, 1, prm->hg_omega_fac3);
+      } else
       nd_jacobi(F, M.per, nu_f, prm->hg_omega);           /* ping-pongs between F->phi and F->tmp */
       e = F->phi;
       F->b = sb; F->sig = ssig;

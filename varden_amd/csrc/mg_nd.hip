@@ -2066,6 +2066,13 @@ static void ml_nd_interface(MLND &S, int n) {
   if (S.multi[n]) mf_fill_boundary(S.phi[n]);
 }
 // finest_only: just the finest level's residual (what its relaxation needs), no norm.  zero_field: the residual of phi = 0
+// the damping of sweep s of the relaxation of a refined level in the composite solve: with hg_nu1 + hg_nu2 = 3 and vdn_params.hg_omega_fac1..3 > 0 the
+// three sweeps take those (a three-step Chebyshev set, 1.6 / 0.9 / 0.65: one FAC iteration fewer on the tagged hierarchies), otherwise hg_omega
+static double ndf_relax_omega(int s) {
+  const vdn_params &P = ctx().prm;
+  const double o[3] = { P.hg_omega_fac1, P.hg_omega_fac2, P.hg_omega_fac3 };
+  return (P.hg_nu1 + P.hg_nu2 == 3 && s < 3 && o[0] > 0.0 && o[1] > 0.0 && o[2] > 0.0) ? o[s] : P.hg_omega;
+}
 static bool ndf_fuse_first() {       // the fused residual + first sweep needs the paired march
   static const bool on = !(getenv("VDN_NDF_FUSE1") && atoi(getenv("VDN_NDF_FUSE1")) == 0) && !(getenv("VDN_NDF_PAIR") && atoi(getenv("VDN_NDF_PAIR")) == 0);
   return on;
@@ -2084,7 +2091,7 @@ static double ml_nd_residual(MLND &S, bool finest_only, bool zero_field = false,
   if (want_norm || !partial || zero_field) lowest = 0;
   for (int n = L - 1; n >= (finest_only ? L - 1 : lowest); n--) {
     const bool finest = n == L - 1;
-    if (finest_only && fuse_first) { ndf_run_march<2>(S.m_res[n], ctx().prm.hg_omega, S.slave[n] ? 1 : 0, (double *)nullptr); return 0.0; }
+    if (finest_only && fuse_first) { ndf_run_march<2>(S.m_res[n], ndf_relax_omega(0), S.slave[n] ? 1 : 0, (double *)nullptr); return 0.0; }
     ndf_run_march<1>(zero_field ? S.m_res0[n] : S.m_res[n], 0.0, (finest && S.slave[n]) ? 1 : 0, (finest && !finest_only && want_norm) ? S.d_nrm : (double *)nullptr);
     if (finest_only) return 0.0;
     if (S.multi[n]) mf_fill_boundary(S.res[n]);
@@ -2306,7 +2313,7 @@ static int ml_nd_solve(vdn_layout *la, vdn_multifab **rh, vdn_multifab **phi, vd
       for (int s = 0; s < P.hg_nu1 + P.hg_nu2; s++) {
         if (fuse && s == 0) { std::swap(a, b2); continue; }
         if (S.multi[n] && s > 0) mf_fill_boundary(a);
-        ndf_run_march<0>(S.m_jac[n][s & 1], P.hg_omega, 0, (double *)nullptr);
+        ndf_run_march<0>(S.m_jac[n][s & 1], ndf_relax_omega(s), 0, (double *)nullptr);
         std::swap(a, b2);
       }
       ml_nd_apply_correction(S, n, a);

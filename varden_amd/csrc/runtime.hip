@@ -88,7 +88,7 @@ extern "C" void vdn_params_default(vdn_params *p) {
   p->visc_coef = 0.0; p->diff_coef = 0.0; p->cflfac = 0.8; p->max_dt_growth = 1.1;
   p->mg_nu1 = 2; p->mg_nu2 = 2; p->mg_nub = 8; p->mg_max_iter = 100;
   p->hg_max_iter = 100; p->hg_nu1 = 2; p->hg_nu2 = 1; p->hg_nub = 8; p->hg_omega = 0.9;     // hg_nub: 32 until round 3 -- the coarsest level (3^3 nodes under a 2^k box) gains nothing from more than max(8, 2 N^2) sweeps (same cycle counts), and each costs ~1.2 us of a one-workgroup launch
-  p->mac_rel_eps = 1.0e-10; p->hg_rel_eps = -1.0; p->abort_on_max_iter = 1; p->hg_fmg = 1; p->mac_fmg = 1; p->hg_omega_pre1 = 1.45; p->hg_omega_pre2 = 0.7;
+  p->mac_rel_eps = 1.0e-10; p->hg_rel_eps = -1.0; p->abort_on_max_iter = 1; p->hg_fmg = 1; p->mac_fmg = 1; p->hg_omega_pre1 = 1.45; p->hg_omega_pre2 = 0.7; p->hg_omega_fac1 = 1.6; p->hg_omega_fac2 = 0.9; p->hg_omega_fac3 = 0.65;
 }
 
 // ---- roctx ranges ------------------------------------------------------------------------------------------------------------

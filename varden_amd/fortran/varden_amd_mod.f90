@@ -38,7 +38,7 @@ module varden_amd
      integer(c_int) :: mg_nu1, mg_nu2, mg_nub, mg_max_iter, hg_max_iter, hg_nu1, hg_nu2, hg_nub
      real(c_double) :: hg_omega, mac_rel_eps, hg_rel_eps
      integer(c_int) :: abort_on_max_iter, hg_fmg, mac_fmg
-     real(c_double) :: hg_omega_pre1, hg_omega_pre2
+     real(c_double) :: hg_omega_pre1, hg_omega_pre2, hg_omega_fac1, hg_omega_fac2, hg_omega_fac3
   end type vdn_params
 
   type, bind(C), public :: vdn_box
