@@ -1969,6 +1969,45 @@ struct NdmProlongB { Range3 r; int g[3]; static constexpr int planes_per_wg = 8;
     fv_at(q.pf, i, j, k) = (mode == 1) ? fv_get(q.pf, i, j, k) + v : v;
     return 0.0;
   } };
+// modes 1 and 2 of NdmProlongB with a thread per COARSE node: it reads the eight corners of its cell once and writes its (up to) eight children
+// 2I + a, 2J + b, 2K + c -- 8 gathers for 8 nodes where a thread per fine node issues 27; the sums run in NdmProlongB's order, same bits.
+// r: coarse nodes whose children may lie in rf (the fine range of NdmProlongB)
+struct NdmProlong8B { Range3 r; int g[3]; static constexpr int planes_per_wg = 4; FV pf, pc, own_c; int has_own; NdfArgs Af; Range3 rf;
+  static __device__ double body(const NdmProlong8B &q, int I, int J, int K, int mode) {
+    if (q.has_own && fv_get(q.own_c, I, J, K) == 0.0) return 0.0;          // a coarse node shared by several boxes: its owner does the work, once
+    double p[2][2][2];                                                      // [c][b][a]
+    #pragma unroll
+    for (int c = 0; c < 2; c++)
+      #pragma unroll
+      for (int b = 0; b < 2; b++)
+        #pragma unroll
+        for (int a = 0; a < 2; a++) p[c][b][a] = fv_get(q.pc, I + a, J + b, K + c);
+    #pragma unroll
+    for (int ok = 0; ok < 2; ok++) {
+      const int k = 2 * K + ok;
+      if (k < q.rf.lo[2] || k > q.rf.hi[2]) continue;
+      #pragma unroll
+      for (int oj = 0; oj < 2; oj++) {
+        const int j = 2 * J + oj;
+        if (j < q.rf.lo[1] || j > q.rf.hi[1]) continue;
+        #pragma unroll
+        for (int oi = 0; oi < 2; oi++) {
+          const int i = 2 * I + oi;
+          if (i < q.rf.lo[0] || i > q.rf.hi[0] || ndf_pdir(q.Af, i, j, k)) continue;
+          double s = 0.0;
+          #pragma unroll
+          for (int c = 0; c <= ok; c++)
+            #pragma unroll
+            for (int b = 0; b <= oj; b++)
+              #pragma unroll
+              for (int a = 0; a <= oi; a++) s = s + p[c][b][a];
+          const double v = s * ((oi ? 0.5 : 1.0) * (oj ? 0.5 : 1.0) * (ok ? 0.5 : 1.0));
+          fv_at(q.pf, i, j, k) = (mode == 1) ? fv_get(q.pf, i, j, k) + v : v;
+        }
+      }
+    }
+    return 0.0;
+  } };
 // res_c += full weighting of the fine residual around the fine node (2i,2j,2k), taken from the fine box that OWNS that node (its
 // ghost nodes hold the neighbouring boxes' values, zero outside the level)
 struct NdmRestrictB { Range3 r; int g[3]; FV res_c, res_f, own_f; NdfArgs Af, Ac;
@@ -2028,7 +2067,8 @@ static void ml_nd_prolong(MLND &S, int n, vdn_multifab *dst, vdn_multifab *src, 
   static const bool faces_only = !(getenv("VDN_NDM_IFACE_FACES") && atoi(getenv("VDN_NDM_IFACE_FACES")) == 0);
   const SrcView Cv = make_view(src, nd_coarse_footprints(S.la, n), S.la->owner[n], 0, 1, NVT_C2F);
   Cv.refresh();
-  std::vector<NdmProlongB> v;
+  static const bool by_parent = !(getenv("VDN_NDM_PROLONG8") && atoi(getenv("VDN_NDM_PROLONG8")) == 0);
+  std::vector<NdmProlongB> v; std::vector<NdmProlong8B> v8;
   for (size_t f = 0; f < S.A[n].size(); f++)
     for (int c = 0; c < Cv.nboxes(); c++) {
       if (!Cv.have[c]) continue;
@@ -2038,6 +2078,11 @@ static void ml_nd_prolong(MLND &S, int n, vdn_multifab *dst, vdn_multifab *src, 
       q.pf = dst->fabs[f]; q.pc = Cv.fv[c]; q.slave = S.slave[n]->fabs[f];
       const bool ho = S.own[n - 1] != nullptr && S.vc_own[n].have[c];
       q.own_c = ho ? S.vc_own[n].fv[c] : Cv.fv[c]; q.has_own = ho ? 1 : 0; q.Af = S.A[n][f];
+      if (mode != 0 && by_parent) {
+        NdmProlong8B t; t.pf = q.pf; t.pc = q.pc; t.own_c = q.own_c; t.has_own = q.has_own; t.Af = q.Af; t.rf = q.r;
+        for (int d = 0; d < 3; d++) { t.r.lo[d] = nd_fdiv2(q.r.lo[d]); t.r.hi[d] = nd_fdiv2(q.r.hi[d]); }
+        v8.push_back(t); continue;
+      }
       if (mode != 0 || !faces_only) { v.push_back(q); continue; }
       // mode 0 writes slave nodes only, and a slave node lies ON a face of its box (a node inside touches eight cells of the box): the six
       // faces of the box's node range instead of the whole box (the x faces own their edges and corners, the y faces the remaining edges)
@@ -2054,6 +2099,7 @@ static void ml_nd_prolong(MLND &S, int n, vdn_multifab *dst, vdn_multifab *src, 
       }
     }
   launch_batched(v, mode, (double *)nullptr, 0, ctx().stream);
+  launch_batched(v8, mode, (double *)nullptr, 0, ctx().stream);
 }
 static void ml_nd_add(MLND &S, int n, vdn_multifab *dst, vdn_multifab *src) {
   std::vector<NdfAddB> v;
