@@ -128,6 +128,9 @@ void vo_mk_mac_coeffs(const vo_fab *rho, vo_fab *beta[3]);
 /* macproject.f90:578-645 restated with ghost-phi gradients at box faces (see vo_macproject.c) */
 void vo_mkumac(vo_fab *umac[3], const vo_fab *phi, vo_fab *beta[3], const double dx[3], const int ellbc[3][2]);
 /* our cell-centred multigrid (replaces FBoxLib ml_cc_solve, mac_multigrid.f90:53) */
+/* max-norm accumulation of the solvers' stopping tests: a NaN turns the norm into +inf (fmax alone would drop it and a solve that blew up
+ * would pass for converged with a zero residual) -- the HIP reductions do the same, and solver_check fails the call on a non-finite norm */
+static inline double vo_nrm_acc(double nrm, double x) { x = x < 0.0 ? -x : x; return (x != x) ? HUGE_VAL : (x > nrm ? x : nrm); }
 typedef struct vo_mgstat { int cycles; double res0, res; } vo_mgstat;
 int  vo_cc_solve(const vo_fab *rh, vo_fab *phi, vo_fab *beta[3], const double dx[3], const int ellbc[3][2],
                  double rel_eps, double abs_eps, int max_iter, int nu1, int nu2, int nub, int fmg, vo_mgstat *st);
@@ -165,6 +168,13 @@ void vo_nd_divu(const vo_fab *u, vo_fab *rh, const double dx[3], const int ellbc
 int  vo_nd_solve(vo_fab *rh, vo_fab *phi, const vo_fab *coeffs, const vo_fab *u, const double dx[3],
                  const int ellbc[3][2], const int pmask[3], double rel_eps, double abs_eps, int max_iter,
                  int nu1, int nu2, int nub, double omega, int fmg, const double *om_pre, vo_mgstat *st);
+/* the multi-step damping sets of the nodal solver (hg_omega_pre1/2, hg_omega_fac1..3) were tuned on dx = dy = dz and lose to (or diverge against)
+ * the plain hg_omega when the spacings differ by more than a quarter: they are used only on grids with max(dx) <= 1.25 min(dx) (round 4) */
+static inline int vo_nd_isotropic(const double *dx, int dm) {
+  double lo = dx[0], hi = dx[0];
+  for (int d = 1; d < dm; d++) { if (dx[d] < lo) lo = dx[d]; if (dx[d] > hi) hi = dx[d]; }
+  return hi <= 1.25 * lo;
+}
 /* the damping pair of the two pre-smoothing sweeps of the nodal V-cycle (NULL: hg_omega for both) */
 static inline const double *vo_om_pre(const vdn_params *prm) { return (prm->hg_omega_pre1 > 0.0 && prm->hg_omega_pre2 > 0.0) ? &prm->hg_omega_pre1 : NULL; }
 /* hgproject.f90:17-178 + hg_multigrid.f90:18-119, single level */

@@ -240,7 +240,7 @@ static double plain_residual(const vo_fab *rh, const vo_fab *phi, const vo_fab *
     if (alpha) Ap = Ap + VF(alpha, i, j, k, 0) * p0;
     const double r = VF(rh, i, j, k, 0) - Ap;
     VF(res, i, j, k, 0) = r;
-    nrm = fmax(nrm, fabs(r));
+    nrm = vo_nrm_acc(nrm, r);
   }
   return nrm;
 }
@@ -304,7 +304,7 @@ static double composite_residual(int nlev, vo_fab **rh, vo_fab **phi, vo_fab **a
   double nrm = 0.0;
   for (int n = 0; n < nlev; n++)
     for (int k = res[n]->lo[2]; k <= res[n]->hi[2]; k++) for (int j = res[n]->lo[1]; j <= res[n]->hi[1]; j++) for (int i = res[n]->lo[0]; i <= res[n]->hi[0]; i++)
-      if (n == nlev - 1 || !covered(phi[n + 1], i, j, k)) nrm = fmax(nrm, fabs(VF(res[n], i, j, k, 0)));
+      if (n == nlev - 1 || !covered(phi[n + 1], i, j, k)) nrm = vo_nrm_acc(nrm, VF(res[n], i, j, k, 0));
   return nrm;
 }
 /* phi[n] += e (valid cells of level n), and the prolongation of that correction on every finer level m: piecewise constant into level 1,
@@ -378,7 +378,7 @@ int vo_ml_cc_solve(int nlev, vo_fab **rh, vo_fab **phi, vo_fab **alpha, vo_fab *
   double bnorm = 0.0;
   for (int n = 0; n < nlev; n++)
     for (int k = rh[n]->lo[2]; k <= rh[n]->hi[2]; k++) for (int j = rh[n]->lo[1]; j <= rh[n]->hi[1]; j++) for (int i = rh[n]->lo[0]; i <= rh[n]->hi[0]; i++)
-      if (n == nlev - 1 || !covered(rh[n + 1], i, j, k)) bnorm = fmax(bnorm, fabs(VF(rh[n], i, j, k, 0)));
+      if (n == nlev - 1 || !covered(rh[n + 1], i, j, k)) bnorm = vo_nrm_acc(bnorm, VF(rh[n], i, j, k, 0));
   int it = 0, conv = 0; double rn = 0.0;
   if (bnorm == 0.0) conv = 1;
   while (!conv) {

@@ -280,7 +280,7 @@ static double nd_residual(ndlev *L, const int per[3])
       r = L->b[NN(L, i, j, k)] - Kp;
     }
     L->res[NN(L, i, j, k)] = r;
-    nrm = fmax(nrm, fabs(r));
+    nrm = vo_nrm_acc(nrm, r);
   }
   nd_fill_nodes(L, L->res, per);
   return nrm;
@@ -409,6 +409,7 @@ int vo_nd_solve(vo_fab *rh, vo_fab *phi, const vo_fab *coeffs, const vo_fab *u, 
                 const int ellbc[3][2], const int pmask[3], double rel_eps, double abs_eps, int max_iter,
                 int nu1, int nu2, int nub, double omega, int fmg, const double *om_pre, vo_mgstat *st)
 {
+  if (!vo_nd_isotropic(dx, coeffs->dm)) om_pre = NULL;     /* the damping pair was tuned for dx = dy = dz: plain hg_omega on stretched grids (round 4) */
   ndmg M; M.nlev = 0;
   int n[3]; double h[3];
   const int dm = coeffs->dm;
@@ -437,7 +438,7 @@ int vo_nd_solve(vo_fab *rh, vo_fab *phi, const vo_fab *coeffs, const vo_fab *u, 
     if (L0->dir[NM(L0, i, j, k)]) r = 0.0;
     L0->b[NN(L0, i, j, k)] = -r;
     L0->phi[NN(L0, i, j, k)] = L0->dir[NM(L0, i, j, k)] ? 0.0 : VF(phi, phi->lo[0] + i, phi->lo[1] + j, phi->lo[2] + k, 0);
-    bnorm = fmax(bnorm, fabs(r));
+    bnorm = vo_nrm_acc(bnorm, r);
   }
   int cyc = 0, conv = 0; double rn = 0.0;
   if (bnorm == 0.0) conv = 1;
@@ -647,7 +648,7 @@ static double ml_nd_residual(mlnd *M)
       L->res[NN(L, i, j, k)] = r;
       int skip = M->cf[n] && M->cf[n][NM(L, i, j, k)];
       if (has_fine && i > M->ilo[n][0] && i < M->ihi[n][0] && j > M->ilo[n][1] && j < M->ihi[n][1] && k > M->ilo[n][2] && k < M->ihi[n][2]) skip = 1;
-      if (!skip) nrm = fmax(nrm, fabs(r));
+      if (!skip) nrm = vo_nrm_acc(nrm, r);
     }
   }
   return nrm;
@@ -761,7 +762,7 @@ int vo_ml_nd_solve(int nlev, vo_fab **rh, vo_fab **phi, vo_fab **coeffs, vo_fab 
       double *e = (double *)calloc(nnf, sizeof(double)), *rb = (double *)malloc(sizeof(double) * nnf);
       memcpy(rb, F->res, sizeof(double) * nnf);
       F->phi = e; F->b = rb; F->sig = M.sigfull[n];
-      if (nu_f == 3 && prm->hg_omega_fac1 > 0.0 && prm->hg_omega_fac2 > 0.0 && prm->hg_omega_fac3 > 0.0) {      /* three-step damping set (round 3): 15 -> 14 and 14 -> 13 FAC iterations on the tagged hierarchies */
+      if (nu_f == 3 && prm->hg_omega_fac1 > 0.0 && prm->hg_omega_fac2 > 0.0 && prm->hg_omega_fac3 > 0.0 && vo_nd_isotropic(dx + 3 * n, 3)) {      /* three-step damping set (round 3): 15 -> 14 and 14 -> 13 FAC iterations on the tagged hierarchies */
         nd_jacobi(F, M.per, 1, prm->hg_omega_fac1); nd_jacobi(F, M.per, 1, prm->hg_omega_fac2); nd_jacobi(F, M.per, 1, prm->hg_omega_fac3);
       } else
       nd_jacobi(F, M.per, nu_f, prm->hg_omega);           /* ping-pongs between F->phi and F->tmp */

@@ -160,7 +160,7 @@ static double cc_residual(cclev *L, const int per[3])
     double Ap, diag; cc_apply(L, i, j, k, &Ap, &diag);
     double r = CC(L, L->rh, i, j, k) - Ap;
     CC(L, L->res, i, j, k) = r;
-    nrm = fmax(nrm, fabs(r));
+    nrm = vo_nrm_acc(nrm, r);
   }
   return nrm;
 }
@@ -407,7 +407,7 @@ int vo_cc_solve_ab(const vo_fab *rh, vo_fab *phi, const vo_fab *alpha, vo_fab *b
   cc_load(L0, rh, phi, ellbc);
   double bnorm = 0.0;      /* norm of the right-hand side as given (before the Dirichlet data moved into it) */
   for (int k = rh->lo[2]; k <= rh->hi[2]; k++) for (int j = rh->lo[1]; j <= rh->hi[1]; j++) for (int i = rh->lo[0]; i <= rh->hi[0]; i++)
-    bnorm = fmax(bnorm, fabs(VF(rh, i, j, k, 0)));
+    bnorm = vo_nrm_acc(bnorm, VF(rh, i, j, k, 0));
   int cyc = 0, conv = 0; double rn = 0.0, r0 = -1.0;
   if (fmg && L0->dm == 3 && M.nlev > 1 && bnorm != 0.0 && max_iter >= 0) {
     int zero = 1;

@@ -551,3 +551,35 @@ def test_tag_boxes_thresholds():
         assert L.vo_tag_boxes(f.ref, lev, 3, tp) == 0
         assert list(t) == [0, 0, 1, 1, 1, 0, 0, 1]
     assert L.vo_tag_boxes(f.ref, 1, 4, tp) == -1 and L.vo_tag_boxes(f.ref, 1, 0, tp) == -1
+
+
+def test_nodal_damping_sets_are_used_on_isotropic_grids_only():
+    """the two-step pair (hg_omega_pre1 / 2) was tuned for dx = dy = dz and loses to hg_omega on stretched grids (50 against 38 cycles at
+    dz = 2 dx, divergence at 1 : 3), so a solve with max(dx) > 1.25 min(dx) runs the plain sequence: with dz = 2 dx the defaults give exactly the
+    iterates of hg_omega_pre1 = hg_omega_pre2 = 0; at 1 : 1.25 the pair is still in use and costs no cycle"""
+    n = (16, 16, 8)
+    bc = vo.make_bc(WALLS)
+    pm = vo.ivec([0, 0, 0])
+    lo, hi = (0, 0, 0), tuple(x - 1 for x in n)
+    x = [(np.arange(-3, n[d] + 3) + 0.5) / n[d] for d in range(3)]
+    X, Y, Z = np.meshgrid(*x, indexing="ij")
+    u0 = np.zeros(X.shape + (3,))
+    u0[..., 0] = np.sin(np.pi * X) * np.cos(2 * np.pi * Y); u0[..., 1] = np.sin(np.pi * Y) * np.cos(np.pi * Z); u0[..., 2] = np.sin(2 * np.pi * Z) * np.cos(np.pi * X)
+    rho = 1.0 + 0.8 * np.exp(-40.0 * ((X - 0.5) ** 2 + (Y - 0.45) ** 2 + (Z - 0.55) ** 2))
+    for h, same in (([1.0 / 16, 1.0 / 16, 1.0 / 8], True), ([1.0 / 16, 1.0 / 16, 1.25 / 16], False)):
+        out = []
+        for kw in (dict(), dict(hg_omega_pre1=0.0, hg_omega_pre2=0.0)):
+            prm = default_params(**kw)
+            unew = vo.Fab(lo, hi, 3, 3); unew.a[...] = u0
+            uold = unew.copy()
+            rhohalf = vo.Fab(lo, hi, 1, 1); rhohalf.a[..., 0] = rho[2:-2, 2:-2, 2:-2]
+            p, gp = vo.Fab(lo, hi, 1, 1, (1, 1, 1)), vo.Fab(lo, hi, 1, 3)
+            st = vo.CMgStat()
+            vo.lib().vo_hgproject(vo.REGULAR_TIMESTEP, unew.ref, uold.ref, rhohalf.ref, p.ref, gp.ref, vo.dvec(h), C.c_double(0.05), C.byref(bc), pm, C.byref(prm), C.byref(st))
+            assert st.res <= 1e-12 * st.res0
+            out.append((unew.valid().copy(), st.cycles))
+        (ua, ca), (ub, cb) = out
+        if same:
+            assert ca == cb and np.array_equal(ua, ub)
+        else:
+            assert ca <= cb and not np.array_equal(ua, ub)

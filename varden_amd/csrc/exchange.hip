@@ -59,23 +59,29 @@ static void rccl_load() {
   // is honoured only together with VDN_TESTING=1 AND a library that identifies itself through vdn_test_transport_magic(); anything else
   // named there fails the call.  vdn_comm_transport() says which one is in use (bench.py prints it).
   const char *forced = getenv("VDN_RCCL_LIB");
+  // the handle and the entry points go into a local copy: g_rccl is assigned only when the handshake and every lookup succeeded, so a
+  // failed load leaves no half-bound state behind (a later call would otherwise return early here and jump through null pointers)
+  Rccl R;
+  struct Closer { void *&h; bool armed = true; ~Closer() { if (armed && h) { dlclose(h); h = nullptr; } } } closer{ R.h };
   if (forced && *forced) {
     const char *t = getenv("VDN_TESTING");
     REQUIRE(t && atoi(t) == 1, "VDN_RCCL_LIB is set but VDN_TESTING=1 is not: the transport of this library is RCCL; only the test suite may replace it");
-    g_rccl.h = dlopen(forced, RTLD_NOW | RTLD_LOCAL);
-    REQUIRE(g_rccl.h, "cannot dlopen the test transport %s: %s", forced, dlerror());
-    long (*magic)() = nullptr; *(void **)(&magic) = dlsym(g_rccl.h, "vdn_test_transport_magic");
+    R.h = dlopen(forced, RTLD_NOW | RTLD_LOCAL);
+    REQUIRE(R.h, "cannot dlopen the test transport %s: %s", forced, dlerror());
+    long (*magic)() = nullptr; *(void **)(&magic) = dlsym(R.h, "vdn_test_transport_magic");
     REQUIRE(magic && magic() == 0x76646e74657374L, "VDN_RCCL_LIB names %s, which is not the test double of tests/fake_rccl", forced);
-    g_rccl.test_double = true;
+    R.test_double = true;
     fprintf(stderr, "varden_amd: TEST TRANSPORT %s in place of RCCL (VDN_TESTING=1)\n", forced);
   }
   const char *names[] = { "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1" };
-  for (const char *n : names) { if (g_rccl.h) break; g_rccl.h = dlopen(n, RTLD_NOW | RTLD_LOCAL); }
-  REQUIRE(g_rccl.h, "cannot dlopen librccl.so.1: %s", dlerror());
-  #define SYM(field, name) do { *(void **)(&g_rccl.field) = dlsym(g_rccl.h, name); REQUIRE(g_rccl.field, "RCCL symbol %s missing", name); } while (0)
+  for (const char *n : names) { if (R.h) break; R.h = dlopen(n, RTLD_NOW | RTLD_LOCAL); }
+  REQUIRE(R.h, "cannot dlopen librccl.so.1: %s", dlerror());
+  #define SYM(field, name) do { *(void **)(&R.field) = dlsym(R.h, name); REQUIRE(R.field, "RCCL symbol %s missing", name); } while (0)
   SYM(GetUniqueId, "ncclGetUniqueId"); SYM(CommInitRank, "ncclCommInitRank"); SYM(CommDestroy, "ncclCommDestroy"); SYM(CommCount, "ncclCommCount");
   SYM(Send, "ncclSend"); SYM(Recv, "ncclRecv"); SYM(AllReduce, "ncclAllReduce"); SYM(AllGather, "ncclAllGather");
   SYM(GroupStart, "ncclGroupStart"); SYM(GroupEnd, "ncclGroupEnd"); SYM(GetErrorString, "ncclGetErrorString");
+  closer.armed = false;
+  g_rccl = R;
   #undef SYM
 }
 

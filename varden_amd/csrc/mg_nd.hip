@@ -1031,10 +1031,17 @@ static const long SMALL_LEVEL_NODES = 9L * 9 * 9;
 // The damping of a run of sweeps.  `pre` = the nu1 pre-smoothing sweeps of a V-cycle: with nu1 = 2 and vdn_params.hg_omega_pre1 / 2 > 0 the first is
 // damped by pre1 and the second by pre2 (oracle: nd_presmooth); every other sweep by hg_omega.
 struct NdOm { double om, om1, om2; int nsp; double at(int s) const { return s < nsp ? (s == 0 ? om1 : om2) : om; } };
+// The multi-step sets were tuned for dx = dy = dz; with spacings more than a quarter apart they lose to the plain hg_omega or diverge (oracle, round 4:
+// 50 against 38 cycles at dz = 2 dx), so a solve on such a grid keeps hg_omega (oracle: vo_nd_isotropic).  Set on entry of nd_solve / ml_nd_solve.
+static bool g_nd_iso = true;
+static bool nd_isotropic(const double *dx) {
+  const double lo = std::min(dx[0], std::min(dx[1], dx[2])), hi = std::max(dx[0], std::max(dx[1], dx[2]));
+  return hi <= 1.25 * lo;
+}
 static NdOm nd_om(bool pre, int nsweeps) {
   const vdn_params &P = ctx().prm;
   NdOm o{ P.hg_omega, 0.0, 0.0, 0 };
-  if (pre && nsweeps == 2 && P.hg_nu1 == 2 && P.hg_omega_pre1 > 0.0 && P.hg_omega_pre2 > 0.0) { o.om1 = P.hg_omega_pre1; o.om2 = P.hg_omega_pre2; o.nsp = 2; }
+  if (g_nd_iso && pre && nsweeps == 2 && P.hg_nu1 == 2 && P.hg_omega_pre1 > 0.0 && P.hg_omega_pre2 > 0.0) { o.om1 = P.hg_omega_pre1; o.om2 = P.hg_omega_pre2; o.nsp = 2; }
   return o;
 }
 static void nd_jacobi_d(NDLev &DL, int nsweeps, bool pre = false) {
@@ -1327,7 +1334,8 @@ int nd_solve(vdn_multifab *rh, vdn_multifab *phi, const vdn_multifab *coeffs, co
   Prof prof_("hg_multigrid");
   if (ctx().prm.dm == 2) return nd2_solve(rh, phi, coeffs, u, dx, bc, rel_eps, abs_eps, max_iter, cycles, res0, res);
   const vdn_params &P = ctx().prm;
-  if (fast) { REQUIRE(fast->rhohalf && fast->rhohalf->ng >= 1 && u && !keep, "nodal multigrid: the fast path needs rhohalf (one ghost cell) and u"); coeffs = fast->rhohalf; }
+  g_nd_iso = nd_isotropic(dx);
+  if (fast) { REQUIRE(fast->rhohalf && u && !keep, "nodal multigrid: the fast path needs rhohalf and u"); /* rhohalf is read on valid cells only: no ghost layer needed */ coeffs = fast->rhohalf; }
   else REQUIRE(rh->ng >= 1 && phi->ng >= 1 && coeffs->ng >= 1, "nodal multigrid: rh, phi, coeffs need one ghost layer");
   hipStream_t st = ctx().stream;
   size_t mark = arena_mark();
@@ -2117,7 +2125,7 @@ static void ml_nd_interface(MLND &S, int n) {
 static double ndf_relax_omega(int s) {
   const vdn_params &P = ctx().prm;
   const double o[3] = { P.hg_omega_fac1, P.hg_omega_fac2, P.hg_omega_fac3 };
-  return (P.hg_nu1 + P.hg_nu2 == 3 && s < 3 && o[0] > 0.0 && o[1] > 0.0 && o[2] > 0.0) ? o[s] : P.hg_omega;
+  return (g_nd_iso && P.hg_nu1 + P.hg_nu2 == 3 && s < 3 && o[0] > 0.0 && o[1] > 0.0 && o[2] > 0.0) ? o[s] : P.hg_omega;
 }
 static bool ndf_fuse_first() {       // the fused residual + first sweep needs the paired march
   static const bool on = !(getenv("VDN_NDF_FUSE1") && atoi(getenv("VDN_NDF_FUSE1")) == 0) && !(getenv("VDN_NDF_PAIR") && atoi(getenv("VDN_NDF_PAIR")) == 0);
@@ -2171,6 +2179,7 @@ static int ml_nd_solve(vdn_layout *la, vdn_multifab **rh, vdn_multifab **phi, vd
                        const vdn_bc_tower *bct, int press_comp0, double rel_eps, double abs_eps, int max_iter, int *iters, double *res0, double *res) {
   const int L = la->nlev;
   REQUIRE(L >= 2 && L <= VDN_MAXLEV, "composite nodal solve: 2..%d levels", VDN_MAXLEV);
+  g_nd_iso = nd_isotropic(dx);                         // (the ratio of the spacings is the same on every level)
   hipStream_t st = ctx().stream;
   const size_t mark = arena_mark();
   const vdn_params &P = ctx().prm;

@@ -93,6 +93,7 @@ extern "C" void vdn_params_default(vdn_params *p) {
 
 // ---- roctx ranges ------------------------------------------------------------------------------------------------------------
 #include <dlfcn.h>
+#include <thread>
 static int (*g_roctx_push)(const char *) = nullptr;
 static int (*g_roctx_pop)() = nullptr;
 void prof_load() {
@@ -127,17 +128,22 @@ const double *read_scalars(const double *dev, int n) {
   VdnCtx &c = g_ctx;
   REQUIRE(n >= 1 && n <= 64, "read_scalars: 1..64 values");
   static unsigned long long seq = 0;
-  static const bool poll = !(getenv("VDN_POLL") && atoi(getenv("VDN_POLL")) == 0);
+  // VDN_POLL: 1 = spin, 0 = synchronise always; unset: spin on a one-rank run, synchronise when several ranks run (each rank's spinning thread would
+  // take a core from RCCL's proxy threads and from the other ranks of an oversubscribed host)
+  static const int poll_env = getenv("VDN_POLL") ? atoi(getenv("VDN_POLL")) : -1;
+  const bool poll = poll_env >= 0 ? poll_env != 0 : c.nranks == 1;
   ++seq;
   hipLaunchKernelGGL(k_publish, dim3(1), dim3(64), 0, c.stream, c.h_scal_dev, dev, n, seq);
   if (poll && !g_capturing_now()) {
     volatile unsigned long long *flag = reinterpret_cast<volatile unsigned long long *>(c.h_scal + 64);
     for (unsigned long spins = 1;; spins++) {
       if (*flag == seq) { __sync_synchronize(); return c.h_scal; }
-      if ((spins & 0x3fff) == 0) {                          // every ~16 k reads: has the stream failed, or finished without the number showing up?
+      __builtin_ia32_pause();                               // a spin-wait hint: the sibling hyperthread keeps its issue slots
+      if ((spins & 0xfff) == 0) {                           // every ~4 k reads: has the stream failed, or finished without the number showing up?
         const hipError_t q = hipStreamQuery(c.stream);
         if (q == hipSuccess) break;
         if (q != hipErrorNotReady) HIPCHK(q);
+        if (spins > 0x40000) std::this_thread::yield();     // a long wait (a whole solve queued ahead): let other threads of the host run
       }
     }
   }

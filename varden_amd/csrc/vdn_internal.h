@@ -100,11 +100,13 @@ void vdn_set_error(const char *fmt, ...);
 struct VdnErr : std::runtime_error { using std::runtime_error::runtime_error; };
 [[noreturn]] void vdn_fail(const char *fmt, ...);
 #define HIPCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) vdn_fail("%s failed: %s (%s:%d)", #x, hipGetErrorString(e_), __FILE__, __LINE__); } while (0)
-// entry: drop whatever error the HOST application left on this thread (torch's event queries leave hipErrorNotReady, an earlier foreign
-// launch may have failed): only an error raised INSIDE the call is ours to report
-#define VDN_TRY try { (void)hipGetLastError();
+// entry: the error the HOST application may have left on this thread (a failed launch of its own, torch's event queries leave hipErrorNotReady) is
+// LOOKED AT, not cleared -- the host still finds it at its next check.  On the way out a pending error is ours only if it differs from the one seen
+// on entry; the benign hipErrorNotReady residue of our own hipStreamQuery / hipEventQuery polls is the one thing that is cleared.
+#define VDN_TRY try { const hipError_t entry_err_ = hipPeekAtLastError(); if (entry_err_ == hipErrorNotReady) (void)hipGetLastError();
 // the success path of every C-ABI call also asks HIP for a pending launch error (a kernel launch with a bad grid fails silently otherwise)
-#define VDN_CATCH   if (ctx().inited) { hipError_t le_ = hipGetLastError(); if (le_ != hipSuccess && le_ != hipErrorNotReady) vdn_fail("a HIP launch failed inside this call: %s", hipGetErrorString(le_)); } \
+#define VDN_CATCH   if (ctx().inited) { hipError_t le_ = hipPeekAtLastError(); if (le_ == hipErrorNotReady) { (void)hipGetLastError(); le_ = hipSuccess; } \
+    if (le_ != hipSuccess && le_ != entry_err_) { (void)hipGetLastError(); vdn_fail("a HIP launch failed inside this call: %s", hipGetErrorString(le_)); } } \
   } catch (const std::exception &e) { vdn_set_error("%s", e.what()); return 1; } return 0;
 // outcome of an elliptic solve: FBoxLib's solvers abort on max_iter (bl_error); so do we unless prm.abort_on_max_iter = 0.
 // A non-finite norm (the reductions turn NaN into +inf) is a failure whatever rc says.  comp >= 0: the component being solved
