@@ -438,7 +438,14 @@ void vo_ml_macproject(int nlev, vo_fab **umac, vo_fab **rho, vo_fab **mac_rhs, c
   vo_fab b0[3], *b0p[3];                                /* level 0's own coefficients, before the edge restriction overwrites the covered faces */
   for (int d = 0; d < 3; d++) { b0[d] = beta[d]; b0[d].p = (double *)malloc(sizeof(double) * vo_size(&beta[d])); memcpy(b0[d].p, beta[d].p, sizeof(double) * vo_size(&beta[d])); b0p[d] = &b0[d]; }
   for (int n = nlev - 1; n >= 1; n--) for (int d = 0; d < 3; d++) vo_ml_edge_restriction(bp[3 * (n - 1) + d], bp[3 * n + d], d);
-  vo_ml_cc_solve(nlev, rhp, php, NULL, bp, dx, (const int (*)[3][2])ellbc, pmask, pd, prm->mac_rel_eps, prm->mg_max_iter, prm, b0p, st);
+  /* The level-0 V-cycle may run on level 0's own coefficients (round 3: the density-based kernels of the single-level solver) only where they are
+   * close to the edge-restricted ones.  On averaged-down data 2/(rho_i + rho_i-1) is 1 / (mean rho), the restricted beta a mean of 1 / rho: with a sharp
+   * density jump the own coefficients are softer by up to the density ratio, the correction overshoots and the FAC iteration slows down (10 : 1
+   * one-cell jump: 45 iterations against 12) or diverges (100 : 1).  Round 4: own coefficients only if they agree with the restricted ones to 25 % on
+   * every face (the smooth profiles of the reference's inputs at production resolution), else the restricted ones (the round-2 iteration). */
+  double worst = 1.0;
+  for (int d = 0; d < 3; d++) { const long sz = vo_size(&beta[d]); for (long q = 0; q < sz; q++) { const double a = beta[d].p[q], b = b0[d].p[q]; const double r1 = a / b, r2 = b / a; worst = vo_nrm_acc(worst, r1 > r2 ? r1 : r2); } }
+  vo_ml_cc_solve(nlev, rhp, php, NULL, bp, dx, (const int (*)[3][2])ellbc, pmask, pd, prm->mac_rel_eps, prm->mg_max_iter, prm, worst <= 1.25 ? b0p : NULL, st);
   for (int d = 0; d < 3; d++) free(b0[d].p);
   /* mkumac on every level with the solver's ghost cells, then edge restriction and the ghost faces (macproject.f90:103-119) */
   for (int n = 0; n < nlev; n++) vo_mkumac(umac + 3 * n, &phi[n], bp + 3 * n, dx + 3 * n, ellbc[n]);
@@ -551,6 +558,12 @@ void vo_ml_hgproject(int nlev, int proj_type, vo_fab **unew, vo_fab **uold, vo_f
       VF(&coeffs[n], i, j, k, 0) = 1.0 / VF(rhohalf[n], i, j, k, 0);
     level_fill_boundary(&coeffs[n], pmask, pd + 6 * n, pd + 6 * n + 3);
   }
+  /* Under a finer level the coefficient of a level is the MEAN OF THE FINE sigma (what the multigrid's own coarsening takes, round 4), not
+   * 1 / (mean of the fine rho) as coeffs = 1 / rhohalf gives on averaged-down data: the level's V-cycle and relaxation precondition the fine
+   * equations, and with a sharp density jump the two differ by the density ratio (one heavy child among eight: 1/mean(rho) = 8/rho_heavy against
+   * mean(1/rho) = 7/8) -- the softer operator overshoots and the FAC iteration diverged for one-cell jumps of 300 : 1 and more.  Smooth fields: the
+   * same to O(h^2).  The composite equations themselves read sigma only on uncovered cells and are unchanged. */
+  for (int n = nlev - 1; n >= 1; n--) { vo_ml_cc_restriction(&coeffs[n - 1], &coeffs[n], 0, 1); level_fill_boundary(&coeffs[n - 1], pmask, pd + 6 * (n - 1), pd + 6 * (n - 1) + 3); }
   double rel = prm->hg_rel_eps > 0.0 ? prm->hg_rel_eps : (nlev == 2 ? 1.e-11 : 1.e-10);
   double abs_eps = -1.0;
   if (proj_type == VDN_INITIAL_PROJECTION && prm->prob_type == 4) abs_eps = 1.e-12;

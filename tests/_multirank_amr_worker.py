@@ -1,5 +1,5 @@
-"""one rank of a multi-rank AMR run on ONE GPU (tests/test_multirank_gpu.py::test_amr_ranks_reproduce_single_rank): a two- or
-three-level fixed hierarchy whose boxes are dealt to the ranks by cell count.  argv: rank nranks idfile outprefix nlev visc"""
+"""one or several ranks (threads, tests/_rank_threads.py) of a multi-rank AMR run on ONE GPU (tests/test_multirank_gpu.py::test_amr_ranks_reproduce_single_rank): a two- or
+three-level fixed hierarchy whose boxes are dealt to the ranks by cell count.  argv: rank[,rank...] nranks idfile outprefix nlev visc [tagged | restart <checkpoint>]"""
 import os
 import sys
 import time
@@ -10,15 +10,18 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 
 def main():
-    rank, nranks = int(sys.argv[1]), int(sys.argv[2])
+    ranks, nranks = [int(r) for r in sys.argv[1].split(",")], int(sys.argv[2])
+    from tests._rank_threads import run_ranks
+    run_ranks(ranks, lambda rank, pkg: one_rank(rank, nranks, pkg), os.path.dirname(sys.argv[4]))
+
+
+def one_rank(rank, nranks, pkg):
     idfile, outprefix = sys.argv[3], sys.argv[4]
     nlev, visc = int(sys.argv[5]), float(sys.argv[6])
     tagged = len(sys.argv) > 7 and sys.argv[7] in ("tagged", "restart")
     restart = len(sys.argv) > 7 and sys.argv[7] == "restart"          # continue from the checkpoint <argv[8]> written by a "tagged" run
-    from varden_amd import boxlib as bl
-    from varden_amd import driver
-    from varden_amd.capi import default_params
-    prm = default_params(cflfac=0.9, visc_coef=visc)
+    bl, driver, plotfile = pkg.boxlib, pkg.driver, pkg.plotfile
+    prm = pkg.capi.default_params(cflfac=0.9, visc_coef=visc)
     comm_id = None
     if nranks > 1:
         bl.initialize(prm, rank, nranks, 0)
@@ -36,7 +39,6 @@ def main():
     fine = [((8, 8, 8), (15, 23, 23)), ((16, 8, 8), (23, 15, 23)), ((16, 16, 8), (23, 23, 23))]          # partial shared faces
     finer = [[((24, 24, 24), (31, 39, 39)), ((32, 24, 24), (39, 39, 39))]] if nlev == 3 else []
     if restart:          # grids and state from the checkpoint, every rank reads the boxes it owns (initialize_from_restart)
-        from varden_amd import plotfile
         chk = plotfile.read_checkfile(sys.argv[8])
         G = driver.VardenAMR(32, chk["boxes"][1], walls, params=prm, finer_levels=chk["boxes"][2:], base_boxes=chk["boxes"][0], regrid_int=2, max_levs=nlev,
                              max_grid_size=16, rank=rank, nranks=nranks, comm_id=comm_id, restart=chk, restart_step=4)
@@ -59,7 +61,6 @@ def main():
             out["s%d_%d" % (n, gi)] = G.snew[n].to_numpy(li)[3:-3, 3:-3, 3:-3]
             out["p%d_%d" % (n, gi)] = G.p[n].to_numpy(li)[1:-1, 1:-1, 1:-1]
     if tagged and not restart:                             # plot and checkpoint files, every rank its own Cell_D file
-        from varden_amd import plotfile
         plotfile.write_plotfile(G, base=outprefix + "_plt")
         plotfile.write_checkfile(G, base=outprefix + "_chk")
     np.savez(outprefix + ".%d.npz" % rank, **out)

@@ -1,5 +1,7 @@
-"""one rank of a multi-rank run on ONE GPU (tests/test_multirank_gpu.py): ranks are processes, the transport is the RCCL test
-double tests/fake_rccl (VDN_RCCL_LIB), the rendezvous a file.  argv: rank nranks idfile outprefix bx by bz nx ny nz nsteps periodic"""
+"""one or several ranks of a multi-rank run on ONE GPU (tests/test_multirank_gpu.py): ranks are processes -- or threads of a process, each on
+its private copy of the library (tests/_rank_threads.py: an eight-rank run fits the six-process limit of a GPU box as 4 x 2) --, the
+transport is the RCCL test double tests/fake_rccl (VDN_RCCL_LIB), the rendezvous a file.
+argv: rank[,rank...] nranks idfile outprefix bx by bz nx ny nz nsteps periodic"""
 import os
 import sys
 import time
@@ -10,15 +12,18 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 
 def main():
-    rank, nranks = int(sys.argv[1]), int(sys.argv[2])
+    ranks, nranks = [int(r) for r in sys.argv[1].split(",")], int(sys.argv[2])
+    from tests._rank_threads import run_ranks
+    run_ranks(ranks, lambda rank, pkg: one_rank(rank, nranks, pkg), os.path.dirname(sys.argv[4]))
+
+
+def one_rank(rank, nranks, pkg):
     idfile, outprefix = sys.argv[3], sys.argv[4]
     decomp = tuple(int(x) for x in sys.argv[5:8])
     n = tuple(int(x) for x in sys.argv[8:11])
     nsteps, periodic = int(sys.argv[11]), int(sys.argv[12])
-    from varden_amd import boxlib as bl
-    from varden_amd import driver
-    from varden_amd.capi import default_params
-    prm = default_params(cflfac=0.9)
+    bl, driver = pkg.boxlib, pkg.driver
+    prm = pkg.capi.default_params(cflfac=0.9)
     dev = rank if os.environ.get("VDN_WORKER_DEVICE_PER_RANK") == "1" else 0     # real RCCL: one GPU per rank
     comm_id = None
     if nranks > 1:

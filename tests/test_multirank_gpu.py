@@ -15,7 +15,13 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 FAKE = os.path.join(ROOT, "tests", "fake_rccl", "libfake_rccl.so")
 
 
-def run_ranks(tmp_path, tag, nranks, decomp, n, nsteps, periodic, real_rccl=False):
+def rank_groups(nranks, per_proc):
+    """the ranks each worker process hosts: a GPU box admits six processes on its card, so eight ranks run as four processes of two rank
+    threads (tests/_rank_threads.py: one private copy of the library per rank)"""
+    return [",".join(str(r) for r in range(a, min(a + per_proc, nranks))) for a in range(0, nranks, per_proc)]
+
+
+def run_ranks(tmp_path, tag, nranks, decomp, n, nsteps, periodic, real_rccl=False, per_proc=1):
     if nranks > 1 and not os.path.exists(FAKE):
         subprocess.check_call(["make", "-s", "-C", os.path.dirname(FAKE)])
     idfile, prefix = str(tmp_path / (tag + ".id")), str(tmp_path / tag)
@@ -25,16 +31,18 @@ def run_ranks(tmp_path, tag, nranks, decomp, n, nsteps, periodic, real_rccl=Fals
     else:
         # VDN_OVERLAP=1: halo exchange on the second stream + shell kernels on every level (by default only boxes of >= 2^20 cells do)
         env = dict(os.environ, VDN_RCCL_LIB=FAKE, VDN_TESTING="1", FAKE_RCCL_DIR=str(tmp_path), VDN_OVERLAP=os.environ.get("VDN_OVERLAP", "1"))
-    procs = [subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "_multirank_worker.py"), str(r), str(nranks), idfile, prefix]
+        if nranks >= 8:
+            env["FAKE_RCCL_MAXMSG_MB"] = "8"     # 64 mailboxes: keep the memory-mapped file small (the messages of 32^3 boxes are a few hundred KB)
+    procs = [subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "_multirank_worker.py"), g, str(nranks), idfile, prefix]
                               + [str(x) for x in decomp] + [str(x) for x in n] + [str(nsteps), str(int(periodic))], env=env, cwd=ROOT)
-             for r in range(nranks)]
+             for g in rank_groups(nranks, per_proc)]
     try:
-        rcs = [p.wait(timeout=240) for p in procs]
+        rcs = [p.wait(timeout=400) for p in procs]
     finally:
         for p in procs:                      # exact PIDs of the children this test started
             if p.poll() is None:
                 p.kill()
-    assert rcs == [0] * nranks, rcs
+    assert rcs == [0] * len(procs), rcs
     out = {}
     for r in range(nranks):
         with np.load(prefix + ".%d.npz" % r) as z:
@@ -57,6 +65,31 @@ def test_ranks_reproduce_single_rank_bits(gpu, tmp_path, nranks, decomp, n, peri
     for k in sorted(ref):
         assert np.array_equal(ref[k], got[k]), "%s differs: max %.3e" % (k, np.abs(ref[k] - got[k]).max())
     assert np.isfinite(got["u0"]).all() and np.abs(got["u0"]).max() > 0
+
+
+@pytest.mark.parametrize("periodic", [False, True])
+def test_eight_ranks_2x2x2_reproduce_single_rank_bits(gpu, tmp_path, periodic):
+    """BASELINE.json configs[2]'s rank topology (2 x 2 x 2, one 32^3 box per rank; velpred.f90:102-119, macproject.f90:117,492, estdt.f90:69 are the
+    exchange sites): every rank has SEVEN peers -- three across faces, three across edges and one across the corner, the last four only in
+    the nodal halos and the state's ghost shells --, the agglomerated multigrid tails are gathered from eight ranks, three multigrid levels per
+    solver stay distributed.  Start-up sequence + two steps, bit for bit against one rank on the same eight boxes; periodic: the x direction
+    wraps, so the two ranks of a row are each other's neighbour on both sides.  Eight ranks = four processes of two rank threads."""
+    ref = run_ranks(tmp_path, "ref", 1, (2, 2, 2), (64, 64, 64), 2, periodic)
+    got = run_ranks(tmp_path, "mr8", 8, (2, 2, 2), (64, 64, 64), 2, periodic, per_proc=2)
+    assert sorted(ref) == sorted(got) and len([k for k in got if k.startswith("u")]) == 8
+    assert np.array_equal(ref["dt"], got["dt"]), (ref["dt"], got["dt"])
+    for k in sorted(ref):
+        assert np.array_equal(ref[k], got[k]), "%s differs: max %.3e" % (k, np.abs(ref[k] - got[k]).max())
+    assert np.isfinite(got["u0"]).all() and np.abs(got["u7"]).max() > 0
+
+
+def test_two_rank_threads_in_one_process_equal_two_processes(gpu, tmp_path):
+    """the harness itself: two ranks as threads of ONE process (private library copies) give the bits of two ranks in two processes"""
+    a = run_ranks(tmp_path, "pp", 2, (2, 1, 1), (64, 32, 32), 2, False)
+    b = run_ranks(tmp_path, "tt", 2, (2, 1, 1), (64, 32, 32), 2, False, per_proc=2)
+    assert sorted(a) == sorted(b)
+    for k in sorted(a):
+        assert np.array_equal(a[k], b[k]), k
 
 
 def test_two_ranks_of_128_cubed_with_the_default_overlap_rule(gpu, tmp_path, monkeypatch):
@@ -122,20 +155,22 @@ def test_bench_spawns_its_own_ranks(gpu, tmp_path, extra):
         assert 2 * one["config"]["cells"] == line["config"]["cells"]
 
 
-def run_amr_ranks(tmp_path, tag, nranks, nlev, visc, mode="fixed", extra=()):
+def run_amr_ranks(tmp_path, tag, nranks, nlev, visc, mode="fixed", extra=(), per_proc=1):
     if nranks > 1 and not os.path.exists(FAKE):
         subprocess.check_call(["make", "-s", "-C", os.path.dirname(FAKE)])
     idfile, prefix = str(tmp_path / (tag + ".id")), str(tmp_path / tag)
     env = dict(os.environ, VDN_RCCL_LIB=FAKE, VDN_TESTING="1", FAKE_RCCL_DIR=str(tmp_path), VDN_OVERLAP=os.environ.get("VDN_OVERLAP", "1"))
-    procs = [subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "_multirank_amr_worker.py"), str(r), str(nranks), idfile, prefix, str(nlev), str(visc), mode] + list(extra),
-                              env=env, cwd=ROOT) for r in range(nranks)]
+    if nranks >= 8:
+        env["FAKE_RCCL_MAXMSG_MB"] = "8"
+    procs = [subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "_multirank_amr_worker.py"), g, str(nranks), idfile, prefix, str(nlev), str(visc), mode] + list(extra),
+                              env=env, cwd=ROOT) for g in rank_groups(nranks, per_proc)]
     try:
-        rcs = [p.wait(timeout=240) for p in procs]
+        rcs = [p.wait(timeout=400) for p in procs]
     finally:
         for p in procs:
             if p.poll() is None:
                 p.kill()
-    assert rcs == [0] * nranks, rcs
+    assert rcs == [0] * len(procs), rcs
     out = {}
     for r in range(nranks):
         with np.load(prefix + ".%d.npz" % r) as z:
@@ -176,6 +211,18 @@ def test_tagged_grids_and_regrid_on_two_ranks(gpu, tmp_path):
     assert sorted(r1) == sorted(r2) and np.array_equal(r1["dt"], r2["dt"]) and np.array_equal(r1["nboxes"], r2["nboxes"])
     for k in sorted(r1):
         assert np.array_equal(r1[k], r2[k]), "restart: %s differs" % k
+
+
+def test_tagged_three_level_hierarchy_on_eight_ranks(gpu, tmp_path):
+    """BASELINE.json configs[4]'s shape on eight ranks (four processes of two rank threads): a tagged three-level hierarchy (tag_boxes.f90:65-94,
+    32^3 base in four boxes, max_grid_size 16), its boxes dealt to the ranks by cell count -- so some ranks own nothing on level 0 --, viscous,
+    start-up sequence, four steps with a regrid every second one: same boxes, same dt, same bits as one rank"""
+    ref = run_amr_ranks(tmp_path, "t3ref", 1, 3, 0.001, "tagged")
+    got = run_amr_ranks(tmp_path, "t3mr", 8, 3, 0.001, "tagged", per_proc=2)
+    assert len(ref["nboxes"]) == 3 and ref["nregrids"][0] >= 1
+    assert np.array_equal(ref["nboxes"], got["nboxes"]) and np.array_equal(ref["dt"], got["dt"]) and sorted(ref) == sorted(got)
+    for k in sorted(ref):
+        assert np.array_equal(ref[k], got[k]), "%s differs: max %.3e" % (k, np.abs(ref[k] - got[k]).max())
 
 
 @pytest.mark.parametrize("nranks,nlev,visc", [(2, 2, 0.0), (3, 2, 0.001), (2, 3, 0.001), (5, 3, 0.001)])

@@ -21,7 +21,7 @@ def blob_density(X, Y, Z, ratio, sharp):
     return 1.0 + 0.5 * (ratio - 1.0) * (1.0 - np.tanh(30.0 * (r - 0.2)))          # initdata.f90:230 with densfact = ratio
 
 
-def test_field(X, Y, Z, periodic):
+def velocity_field(X, Y, Z, periodic):
     u = np.zeros(X.shape + (3,))
     if periodic:
         u[..., 0] = np.sin(2 * np.pi * X) * np.cos(2 * np.pi * Y); u[..., 1] = np.cos(4 * np.pi * Y) * np.sin(2 * np.pi * Z); u[..., 2] = np.sin(2 * np.pi * Z + 1.0) * np.cos(2 * np.pi * X)
@@ -40,7 +40,7 @@ def hg_problem(case, ratio, sharp):
     vo = __import__("oracle.voracle", fromlist=["x"])
     periodic = case.phys is PER
     unew = case.ofab(3, 3)
-    unew.a[...] = test_field(*cell_coords(case.n, 3, case.dx), periodic)
+    unew.a[...] = velocity_field(*cell_coords(case.n, 3, case.dx), periodic)
     vo.lib().vo_fill_boundary(unew.ref, case.opm)
     rhoh = case.ofab(1, 1)
     rhoh.a[..., 0] = blob_density(*cell_coords(case.n, 1, case.dx), ratio, sharp)
@@ -96,7 +96,7 @@ def test_macproject_large_density_ratios(gpu, oracle, bcname, ratio, sharp):
         f = case.ofab(1, 1, tuple(1 if t == d else 0 for t in range(3)))
         idx = [np.arange(-1, case.n[t] + 1 + (1 if t == d else 0)) for t in range(3)]
         X, Y, Z = np.meshgrid(*[(idx[t] + (0.0 if t == d else 0.5)) * case.dx[t] for t in range(3)], indexing="ij")
-        f.a[..., 0] = test_field(X, Y, Z, periodic)[..., d]          # (the wall-normal component vanishes on the walls)
+        f.a[..., 0] = velocity_field(X, Y, Z, periodic)[..., d]          # (the wall-normal component vanishes on the walls)
         L.vo_fill_boundary(f.ref, case.opm)
         oum.append(f)
     mac_rhs = case.ofab(1, 1)
@@ -170,7 +170,7 @@ def test_two_level_projections_large_density_ratios(gpu, oracle, ratio, sharp):
     # ---- nodal
     unew, uold, rhoh, gp, p = K.ofabs(3, 3), K.ofabs(3, 3), K.ofabs(1, 1), K.ofabs(1, 3), K.ofabs(1, 1, (1, 1, 1))
     for lev in range(2):
-        unew[lev].a[...] = test_field(*coords(unew[lev], lev), False)
+        unew[lev].a[...] = velocity_field(*coords(unew[lev], lev), False)
         rhoh[lev].a[..., 0] = blob_density(*coords(rhoh[lev], lev), ratio, sharp)
     L.vo_ml_restrict_and_fill(2, vo.fab_ptr_array(unew), 0, 0, 3, 0, K.obcs, K.opm, K.opd, C.byref(K.prm))
     L.vo_ml_restrict_and_fill(2, vo.fab_ptr_array(rhoh), 0, 3, 1, 0, K.obcs, K.opm, K.opd, C.byref(K.prm))
@@ -196,7 +196,7 @@ def test_two_level_projections_large_density_ratios(gpu, oracle, ratio, sharp):
     for lev in range(2):
         for d in range(3):
             f = K.ofabs(1, 1, tuple(1 if t == d else 0 for t in range(3)))[lev]
-            f.a[..., 0] = test_field(*coords(f, lev), False)[..., d]
+            f.a[..., 0] = velocity_field(*coords(f, lev), False)[..., d]
             um.append(f)
     for d in range(3):
         L.vo_ml_edge_restriction(um[d].ref, um[3 + d].ref, d)

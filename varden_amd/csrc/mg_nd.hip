@@ -2395,6 +2395,10 @@ static void do_ml_hgproject(int proj_type, vdn_layout *mla, vdn_multifab **unew,
     gphi[n] = mf_temp(mla, n, 3, 0, -1, false, 0.0); coeffs[n] = mf_temp(mla, n, 1, 1, -1, true, 0.0);
     hg_level_pre(proj_type, unew[n], uold[n], rhohalf[n], gp[n], coeffs[n], dt, bct);
   }
+  // under a finer level a level's coefficient is the mean of the fine sigma, not 1 / (averaged-down rho): see oracle/vo_amr.c (vo_ml_hgproject) --
+  // the FAC iteration diverged on one-cell density jumps of 300 : 1 and more with the softer operator.  The composite equations read sigma on
+  // uncovered cells only; this changes the preconditioner (level V-cycle, relaxation of intermediate levels), not the system.
+  for (int n = L - 1; n >= 1; n--) { ml_cc_restriction(coeffs[n - 1], coeffs[n], 0, 1); mf_fill_boundary(coeffs[n - 1]); }
   double rel = ctx().prm.hg_rel_eps > 0.0 ? ctx().prm.hg_rel_eps : (L == 2 ? 1.e-11 : 1.e-10);
   double abs_eps = -1.0;
   if (proj_type == VDN_INITIAL_PROJECTION && ctx().prm.prob_type == 4) abs_eps = 1.e-12;

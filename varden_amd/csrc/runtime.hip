@@ -621,6 +621,27 @@ double mf_norm_inf_grown(const vdn_multifab *mf, int comp, int nc, int grow) {  
   comm_allreduce_max_dev(c.d_scal, 1);        // FBoxLib norm_inf is a global (all-rank) norm
   return read_scalar1(c.d_scal);
 }
+// max over the valid points of three pairs of multifabs (component 0) of max(a / b, b / a): how far two sets of face coefficients are apart
+// (amr.hip: the composite MAC solve's choice of the level-0 V-cycle's coefficients); NaN -> +inf; all ranks
+__global__ void k_maxratio(FV a, FV b, Range3 r, double *out) {
+  REDUCE_IJ(r)
+  double v = 0.0;
+  if (in_ij) REDUCE_KLOOP(r) { const double x = fv_get(a, i, j, k, 0), y = fv_get(b, i, j, k, 0); const double r1 = x / y, r2 = y / x; v = nmax(v, r1 > r2 ? r1 : r2); }
+  block_atomic_max(out, v);
+}
+double mf_max_ratio3(vdn_multifab *const *a, vdn_multifab *const *b) {
+  VdnCtx &c = g_ctx;
+  HIPCHK(hipMemsetAsync(c.d_scal, 0, sizeof(double), c.stream));
+  for (int d = 0; d < 3; d++) {
+    REQUIRE(a[d]->nfabs() == b[d]->nfabs(), "max_ratio: layouts differ");
+    for (int i = 0; i < a[d]->nfabs(); i++) {
+      Range3 r = fab_range(a[d], i, 0);
+      hipLaunchKernelGGL(k_maxratio, reduce_grid(r), dim3(64, 4, 1), 0, c.stream, a[d]->fabs[i], b[d]->fabs[i], r, c.d_scal);
+    }
+  }
+  comm_allreduce_max_dev(c.d_scal, 1);
+  return read_scalar1(c.d_scal);
+}
 extern "C" int vdn_multifab_norm_inf(const vdn_multifab *mf, int comp, int nc, double *out) {
   VDN_TRY *out = mf_norm_inf(mf, comp, nc); VDN_CATCH
 }

@@ -195,6 +195,7 @@ void mf_physbc(vdn_multifab *mf, int scomp, int bccomp, int nc, const vdn_bc_tow
 void mf_copy(vdn_multifab *dst, int dcomp, const vdn_multifab *src, int scomp, int nc, int ng);
 double mf_norm_inf(const vdn_multifab *mf, int comp, int nc);
 double mf_norm_inf_grown(const vdn_multifab *mf, int comp, int nc, int grow);
+double mf_max_ratio3(vdn_multifab *const *a, vdn_multifab *const *b);      // max of max(a/b, b/a) over the valid points of three pairs (component 0), all ranks
 // ml_restrict_and_fill on one level = fill_boundary + physbc
 void mf_restrict_and_fill(vdn_multifab *mf, int icomp, int bcomp, int nc, bool same_boundary, const vdn_bc_tower *bct);
 
