@@ -111,7 +111,7 @@ def parse_args():
     ap.add_argument("--mac-fmg", dest="mac_fmg", type=int, default=1, choices=[0, 1], help="nested-iteration start of the MAC solve (vdn_params.mac_fmg; 0: the zero guess)")
     ap.add_argument("--hg-pre-pair", dest="hg_pre_pair", type=int, default=1, choices=[0, 1], help="two-step damping of the nodal V-cycle's pre-smoothing sweeps (vdn_params.hg_omega_pre1 / 2; 0: hg_omega for both)")
     ap.add_argument("--no-calib", dest="no_calib", action="store_true", help="skip the one-thread Godunov calibration of the cpu_baseline leg")
-    ap.add_argument("--no-extra", dest="no_extra", action="store_true", help="skip the extra_workloads (512^3 in eight boxes and in one box, tagged two-level hierarchy) of the default N = 1 line")
+    ap.add_argument("--no-extra", dest="no_extra", action="store_true", help="skip the extra_workloads (512^3 in eight boxes and in one box, tagged two- and three-level hierarchies) of the default N = 1 line")
     return ap.parse_args()
 
 
@@ -292,23 +292,25 @@ def main():
     # ---- the other single-GPU workloads of BASELINE.json, a few timed steps each (the headline stays configs[1]) ----------
     extra = []
     if world == 1 and args.config == "256" and n == 256 and not args.no_extra:
-        for cfg, n2 in (("512", 256), ("256", 512), ("amr2", 256)):      # 512^3 as eight boxes (configs[2] on one GPU), 512^3 as ONE box (north_star's single-GPU size), the tagged hierarchy
+        XS = 5                                             # timed steps of every extra workload (one warm-up step before)
+        # 512^3 as eight boxes (configs[2] on one GPU), 512^3 as ONE box (north_star's single-GPU size), the tagged hierarchies of configs[3] and configs[4]
+        for cfg, n2 in (("512", 256), ("256", 512), ("amr2", 256), ("amr3", 256)):
             tb = time.perf_counter()
             G2, cells2, wl2, _, _ = build_workload(cfg, n2)
             G2.step()                                       # warm-up
             torch.cuda.synchronize()
             t1 = time.perf_counter()
             cyc2 = dict(mac=0, hg=0)
-            for _ in range(3):
+            for _ in range(XS):
                 G2.step()
                 cyc2["mac"] += adv.last_solver_stats("mac")[0]
                 cyc2["hg"] += adv.last_solver_stats("hg")[0]
             torch.cuda.synchronize()
             el2 = time.perf_counter() - t1
             G2.close()
-            extra.append({"workload": wl2, "cells": cells2, "steps": 3, "warmup": 1, "ms_per_step": round(1e3 * el2 / 3, 3),
-                          "value": round(cells2 * 3 / el2, 1), "unit": "cells*steps/s",
-                          "solver_iterations_per_step": {k: round(v / 3.0, 2) for k, v in cyc2.items()}, "wall_s_incl_setup": round(time.perf_counter() - tb, 1)})
+            extra.append({"workload": wl2, "cells": cells2, "steps": XS, "warmup": 1, "ms_per_step": round(1e3 * el2 / XS, 3),
+                          "value": round(cells2 * XS / el2, 1), "unit": "cells*steps/s",
+                          "solver_iterations_per_step": {k: round(v / float(XS), 2) for k, v in cyc2.items()}, "wall_s_incl_setup": round(time.perf_counter() - tb, 1)})
 
     # ---- roofline of the dominant kernel: one colour pass of the MAC-MG smoother at 256^3 ----------
     roof = None
@@ -388,9 +390,25 @@ def main():
         # 2.91 s the survey measured for the reference's Fortran on one core (that was the survey container's CPU, this is
         # the bench host's: a cross-machine ratio -- DESIGN.md quotes the same-machine one)
         cal = godunov_calibration(vo, 128) if not args.no_calib else None
+        # the GPU on the SAME sample (like for like with `value` of this object): single-level samples only
+        gpu_same_ms = None
+        if not amr:
+            bl.initialize(prm, 0, 1, local_rank)
+            Gs = driver.Varden((cn,) * 3, walls, default_params(cflfac=0.9), prob_type=1, grav=-9.8, init_shrink=0.1, init_iter=1, device=local_rank, swap_state=True)
+            for _ in range(2):
+                Gs.step()
+            torch.cuda.synchronize()
+            tg = time.perf_counter()
+            for _ in range(5):
+                Gs.step()
+            torch.cuda.synchronize()
+            gpu_same_ms = round(1e3 * (time.perf_counter() - tg) / 5, 3)
+            Gs.close()
         cpu = {"value": round(ccells / tcpu, 1), "unit": "cells*steps/s", "cores": nthreads, "kind": "port",
                "sample": "%s, 1 timed step (%.1f s) after the start-up sequence; gcc -O2 -fopenmp, OMP_NUM_THREADS=%d" % (sample, tcpu, nthreads),
                "phase_s": phase_s,
+               "gpu_same_sample_ms": gpu_same_ms,
+               "gpu_over_cpu_same_sample": (round(1e3 * tcpu / gpu_same_ms, 1) if gpu_same_ms else None),
                "godunov_1thread_128_s": cal,
                "calibration_vs_reference_godunov": (round(sum(cal.values()) / 2.91, 2) if cal else None),
                "reference_godunov_mcells_per_s_per_core": REF_GODUNOV_MCELLS_PER_CORE,

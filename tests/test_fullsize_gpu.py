@@ -145,6 +145,45 @@ def test_eight_boxes_equal_one_box_at_256(gpu):
     assert hashes[0] == hashes[1], hashes
 
 
+def test_512_in_eight_boxes_against_one_box(gpu):
+    """BASELINE.json configs[2]'s problem on one GPU: 512^3 in eight 256^3 boxes (velpred.f90:102-119's ghost exchange between them, three
+    distributed multigrid levels per solver, the agglomerated tail) next to the same 512^3 in ONE box.  Start-up sequence + one step each: both
+    solvers meet the reference's tolerances, the two layouts take the same numbers of V-cycles, the density agrees bit for bit box by box
+    (the per-box dead-band eps of velpred.f90:1965-1980 touches no cell here, as at 256^3), the flux-form update conserves mass between walls
+    to round-off, and the step keeps the mirror symmetries x -> 1 - x, y -> 1 - y of the bubble"""
+    from varden_amd import advance as adv
+    from varden_amd import driver
+    from varden_amd.capi import default_params
+    n, g = 512, 3
+    out = {}
+    for decomp in ((2, 2, 2), (1, 1, 1)):
+        G = driver.Varden(n, WALLS, default_params(cflfac=0.9), init_shrink=0.1, init_iter=1, decomp=decomp)
+        m0 = sum(G.sold[0].to_numpy(li)[g:-g, g:-g, g:-g, 0].sum(dtype=np.float64) for li in range(len(G.local)))
+        G.step()
+        mac, hg = adv.last_solver_stats("mac"), adv.last_solver_stats("hg")
+        assert mac[2] <= 1e-10 * mac[1] and hg[2] <= 1e-12 * hg[1], (mac, hg)          # macproject.f90:92, hgproject.f90:113-114
+        rho = {}
+        for li, gi in enumerate(G.local):
+            blo, _ = G.boxes[gi]
+            rho[tuple(blo)] = G.snew[0].to_numpy(li)[g:-g, g:-g, g:-g, 0].copy()
+        m1 = sum(a.sum(dtype=np.float64) for a in rho.values())
+        assert abs(m1 - m0) <= 1e-12 * abs(m0), (decomp, m0, m1)
+        out[decomp] = (mac[0], hg[0], rho, G.dt)
+        G.close()
+    (mc8, hc8, r8, dt8), (mc1, hc1, r1, dt1) = out[(2, 2, 2)], out[(1, 1, 1)]
+    assert (mc8, hc8) == (mc1, hc1) and dt8 == dt1, ((mc8, hc8, dt8), (mc1, hc1, dt1))
+    one = r1[(0, 0, 0)]
+    assert np.isfinite(one).all()
+    for blo, a in r8.items():
+        b = one[blo[0]:blo[0] + 256, blo[1]:blo[1] + 256, blo[2]:blo[2] + 256]
+        assert np.array_equal(a, b), "box at %r differs from the one-box run: max %.3e" % (blo, np.abs(a - b).max())
+    # mirror symmetry of the decomposed run: box (0, j, k) against the reflected box (256, j, k), and the same in y
+    for k in (0, 256):
+        for t in (0, 256):
+            assert np.abs(r8[(0, t, k)] - r8[(256, t, k)][::-1]).max() <= 1e-9
+            assert np.abs(r8[(t, 0, k)] - r8[(t, 256, k)][:, ::-1]).max() <= 1e-9
+
+
 def test_two_level_macproject_at_256(gpu):
     """configs[3] at full size (256^3 base + a 256^3 refined box over the bubble): the composite MAC projection leaves both levels
     divergence-free and the levels consistent (coarse faces under the fine box = mean of the four fine faces)"""
