@@ -367,8 +367,6 @@ static void nd_vcycle(ndmg *M, int l, int nu1, int nu2, int nub, double omega, c
   long nn = (long)(L->n[0] + 3) * (L->n[1] + 3) * (L->n[2] + 3);
   memset(L->phi, 0, sizeof(double) * nn);
   if (l == M->nlev - 1) { nd_jacobi(L, M->per, nd_bottom_sweeps(L, nub), omega); return; }
-  const int gamma = getenv("VO_GAMMA") ? atoi(getenv("VO_GAMMA")) : 1, gl = getenv("VO_GAMMA_L") ? atoi(getenv("VO_GAMMA_L")) : 1;
-  for (int g = 0; g < (((getenv("VO_GAMMA_ONLY") ? l == gl : l >= gl)) ? gamma : 1); g++) {
   nd_presmooth(L, M->per, nu1, omega, pre);
   (void)nd_residual(L, M->per);
   nd_restrict(L, &M->lev[l + 1]);
@@ -376,7 +374,6 @@ static void nd_vcycle(ndmg *M, int l, int nu1, int nu2, int nub, double omega, c
   nd_fill_nodes(&M->lev[l + 1], M->lev[l + 1].phi, M->per);
   nd_prolong_add(L, &M->lev[l + 1]);
   nd_jacobi(L, M->per, nu2, omega);
-  }
 }
 
 /* nodal divergence, our definition (see header comment); u must have >= 1 ghost cell */
