@@ -82,6 +82,11 @@ typedef struct vdn_params {
                                    * are damped by these instead of hg_omega -- a two-step Chebyshev pair, one V-cycle fewer at 256^3; either <= 0: hg_omega */
   double hg_omega_fac1, hg_omega_fac2, hg_omega_fac3;   /* 1.6, 0.9, 0.65: with hg_nu1 + hg_nu2 = 3 the three relaxation sweeps on a refined level of the
                                    * composite nodal solve (nlevs > 1) are damped by these -- a three-step Chebyshev set; any <= 0: hg_omega */
+  int    mg_predict;              /* 1 (default): a projection's multigrid (one level, zero initial guess) does not read its residual norm back before the
+                                   * cycle at which the previous solve of the same size stopped, minus one: the norms of the cycles in between are kept on the
+                                   * device and read in one go (one read-back -- at N > 1 one all-reduce -- instead of one per V-cycle).  The stopping cycle is
+                                   * decided by the same norms: if the history shows an earlier cycle had already converged, the solve is REPEATED with a
+                                   * read-back per cycle, so results never depend on the prediction; 0: read every cycle (rounds 1-3) */
 } vdn_params;
 
 /* fills *p with the reference defaults (src/_parameters) */

@@ -215,3 +215,55 @@ def test_two_level_projections_large_density_ratios(gpu, oracle, ratio, sharp):
             a, b = K.gather(gum[d][lev], um[3 * lev + d])[1:-1, 1:-1, 1:-1], um[3 * lev + d].a[1:-1, 1:-1, 1:-1]
             assert np.abs(a - b).max() <= 1e-9 * scale
     K.close()
+
+
+def test_predicted_cycle_counts_never_change_results(gpu, oracle):
+    """vdn_params.mg_predict: a projection's multigrid skips the residual read-backs before the cycle the previous solve of that size stopped at, minus
+    one.  (i) A hard solve (one-cell 1000 : 1 jump, 42 V-cycles) followed by an easy one (tanh 10 : 1, 12): the prediction overshoots by thirty
+    cycles, the history shows it, and the solve is repeated -- same cycle count and same bits as with mg_predict = 0.  (ii) The easy solve again
+    (prediction exact: one read-back after cycle 11): same bits again.  (iii) The same for the MAC projection."""
+    from varden_amd import advance as adv
+    from varden_amd import boxlib as bl
+    from varden_amd.capi import default_params
+
+    def hg(case, prob):
+        g = [case.gmf(f) for f in prob]
+        adv.hgproject(oracle.REGULAR_TIMESTEP, case.mla, [g[0]], [g[1]], [g[2]], [g[3]], [g[4]], [case.dx], 0.05, case.bct, case.obc.press_comp + 1)
+        return adv.last_solver_stats("hg")[0], g[0].to_numpy().copy(), g[3].to_numpy().copy()
+
+    def mac_fields(case, ratio, sharp):
+        s = case.ofab(3, 2)
+        s.a[..., 0] = blob_density(*cell_coords(case.n, 3, case.dx), ratio, sharp)
+        oum = []
+        for d in range(3):
+            f = case.ofab(1, 1, tuple(1 if t == d else 0 for t in range(3)))
+            idx = [np.arange(-1, case.n[t] + 1 + (1 if t == d else 0)) for t in range(3)]
+            X, Y, Z = np.meshgrid(*[(idx[t] + (0.0 if t == d else 0.5)) * case.dx[t] for t in range(3)], indexing="ij")
+            f.a[..., 0] = velocity_field(X, Y, Z, False)[..., d]
+            oum.append(f)
+        return s, oum, case.ofab(1, 1)
+
+    def mac(case, fields):
+        s, oum, rhs = fields
+        gum = [case.gmf(f) for f in oum]
+        adv.macproject(case.mla, [gum], [case.gmf(s)], [case.gmf(rhs)], [case.dx], case.bct, case.obc.press_comp + 1)
+        return adv.last_solver_stats("mac")[0], [m.to_numpy().copy() for m in gum]
+
+    case = Case((64, 64, 64), WALLS, iso=True)
+    hard, easy = hg_problem(case, 1000, 1), hg_problem(case, 10, 0)
+    mhard, measy = mac_fields(case, 1000, 1), mac_fields(case, 10, 0)
+    bl.initialize(default_params(mg_predict=0), 0, 1, 0)
+    ref_c, ref_u, ref_p = hg(case, easy)
+    mref_c, mref_um = mac(case, measy)
+    bl.initialize(default_params(mg_predict=1), 0, 1, 0)
+    c_hard = hg(case, hard)[0]
+    assert c_hard >= ref_c + 10, (c_hard, ref_c)
+    for what in ("overshoot", "exact", "exact again"):
+        c, u, p = hg(case, easy)
+        assert c == ref_c and np.array_equal(u, ref_u) and np.array_equal(p, ref_p), (what, c, ref_c)
+    cm_hard = mac(case, mhard)[0]
+    assert cm_hard >= mref_c + 2, (cm_hard, mref_c)
+    for what in ("overshoot", "exact"):
+        c, um = mac(case, measy)
+        assert c == mref_c and all(np.array_equal(a, b) for a, b in zip(um, mref_um)), (what, c, mref_c)
+    case.close()

@@ -25,7 +25,7 @@ class Params(C.Structure):
         ("hg_max_iter", C.c_int), ("hg_nu1", C.c_int), ("hg_nu2", C.c_int), ("hg_nub", C.c_int),
         ("hg_omega", C.c_double), ("mac_rel_eps", C.c_double), ("hg_rel_eps", C.c_double),
         ("abort_on_max_iter", C.c_int), ("hg_fmg", C.c_int), ("mac_fmg", C.c_int), ("hg_omega_pre1", C.c_double), ("hg_omega_pre2", C.c_double),
-        ("hg_omega_fac1", C.c_double), ("hg_omega_fac2", C.c_double), ("hg_omega_fac3", C.c_double),
+        ("hg_omega_fac1", C.c_double), ("hg_omega_fac2", C.c_double), ("hg_omega_fac3", C.c_double), ("mg_predict", C.c_int),
     ]
 
 
@@ -38,7 +38,7 @@ def default_params(**kw):
     p.visc_coef = 0.0; p.diff_coef = 0.0; p.cflfac = 0.8; p.max_dt_growth = 1.1
     p.mg_nu1 = 2; p.mg_nu2 = 2; p.mg_nub = 8; p.mg_max_iter = 100
     p.hg_max_iter = 100; p.hg_nu1 = 2; p.hg_nu2 = 1; p.hg_nub = 8; p.hg_omega = 0.9
-    p.mac_rel_eps = 1.0e-10; p.hg_rel_eps = -1.0; p.abort_on_max_iter = 1; p.hg_fmg = 1; p.mac_fmg = 1; p.hg_omega_pre1 = 1.45; p.hg_omega_pre2 = 0.7; p.hg_omega_fac1 = 1.6; p.hg_omega_fac2 = 0.9; p.hg_omega_fac3 = 0.65
+    p.mac_rel_eps = 1.0e-10; p.hg_rel_eps = -1.0; p.abort_on_max_iter = 1; p.hg_fmg = 1; p.mac_fmg = 1; p.hg_omega_pre1 = 1.45; p.hg_omega_pre2 = 0.7; p.hg_omega_fac1 = 1.6; p.hg_omega_fac2 = 0.9; p.hg_omega_fac3 = 0.65; p.mg_predict = 1
     for k, v in kw.items():
         if not hasattr(p, k):
             raise AttributeError("vdn_params has no field %r" % k)

@@ -1331,7 +1331,7 @@ static void cc_gsrb_d(CCMG &M, CDLev &DL, int nsweeps) {
     for (const CBox &B : DL.boxes) launch_gsrb_shell(B.L, (color + B.lo[0] + B.lo[1] + B.lo[2]) & 1, c.stream, B.hmask);
   }
 }
-static void cc_residual_d(CCMG &M, CDLev &DL, bool norm) {
+static void cc_residual_d(CCMG &M, CDLev &DL, bool norm, bool reduce = true) {       // reduce = false: the norm stays rank-local (norm history, mg_predict)
   cc_halo(M, DL);
   if (norm) HIPCHK(hipMemsetAsync(M.d_nrm, 0, sizeof(double), ctx().stream));
   DL.res_restricted = false;
@@ -1345,7 +1345,7 @@ static void cc_residual_d(CCMG &M, CDLev &DL, bool norm) {
         const dim3 g((unsigned)((L.n[0] / 2 + 63) / 64), (unsigned)((L.n[1] / 2 + 3) / 4), (unsigned)std::min(L.n[2] / 2, 16));
         hipLaunchKernelGGL(kk_cc_residual_rho_pair_rst, g, BLK, 0, ctx().stream, L, norm ? M.d_nrm : nullptr, M.dlev[l + 1].boxes[0].L);
         DL.res_restricted = true;
-        if (norm) comm_allreduce_max_dev(M.d_nrm, 1);
+        if (norm && reduce) comm_allreduce_max_dev(M.d_nrm, 1);
         return;
       }
     }
@@ -1358,7 +1358,7 @@ static void cc_residual_d(CCMG &M, CDLev &DL, bool norm) {
     else if (B.L.rho) hipLaunchKernelGGL(kk_cc_residual_rho, g, BLK, 0, ctx().stream, B.L, norm ? M.d_nrm : nullptr);
     else hipLaunchKernelGGL(kk_cc_residual, g, BLK, 0, ctx().stream, B.L, norm ? M.d_nrm : nullptr);
   }
-  if (norm) comm_allreduce_max_dev(M.d_nrm, 1);
+  if (norm && reduce) comm_allreduce_max_dev(M.d_nrm, 1);
 }
 static double read_scalar(double *d) {
   return read_scalar1(d);
@@ -1839,7 +1839,38 @@ int cc_solve(vdn_multifab *rh, vdn_multifab *phi, vdn_multifab **beta, const dou
   // replayed graph and one 8-byte read-back -- the same launch sequence as testing the residual the cycle computes after pre-smoothing
   const int nbot = std::max(P.mg_nub, std::max(D0.ng[0], std::max(D0.ng[1], D0.ng[2])) * std::max(D0.ng[0], std::max(D0.ng[1], D0.ng[2])));
   if (fmg && !conv && !single && bnorm < HUGE_VAL) cc_run_cycle(M, cc_fmg_what(bc), [&] { cc_fmg(M, bc); });
-  if (!conv) { cc_gsrb_d(M, D0, single ? nbot : P.mg_nu1); cc_residual_d(M, D0, true); rn = read_scalar(M.d_nrm); }
+  // vdn_params.mg_predict (macproject's call: zero guess): see nd_solve in mg_nd.hip -- the norms of the cycles before the one the previous solve of this
+  // size stopped at, minus one, go into the device-side history and are read in one go; a history that shows an earlier stop repeats the solve
+  const int gn[3] = { D0.ng[0], D0.ng[1], D0.ng[2] };
+  const int pred = (fast && !single && !conv && bnorm < HUGE_VAL) ? std::min(mg_predict_get(0, gn), std::min(max_iter, 63)) : 0;
+  if (!conv) {
+    cc_gsrb_d(M, D0, single ? nbot : P.mg_nu1);
+    if (pred >= 2) {
+      cc_residual_d(M, D0, true, false);
+      norm_hist_reset(); norm_hist_push(M.d_nrm);
+      for (int c = 1; c <= pred - 1; c++)
+        cc_run_cycle(M, 4, [&] {      // (graph id 4: 1 and 2 are the plain cycles, 3 + 4 code the nested iterations)
+          cc_restrict_down(M, 0);
+          if (M.dlev.size() > 1) cc_vcycle_d(M, 1); else cc_vcycle_t(M, 0);
+          cc_prolong_smooth(M, 0, P.mg_nu2);
+          cc_gsrb_d(M, D0, P.mg_nu1);
+          cc_residual_d(M, D0, true, false);
+          norm_hist_push(M.d_nrm);
+        });
+      const double *h = norm_hist_read(pred);
+      int first = -1;
+      for (int c = 0; c < pred && first < 0; c++)
+        if (((h[c] <= rel_eps * bnorm && bnorm < HUGE_VAL) || h[c] <= abs_eps) || !(h[c] < HUGE_VAL)) first = c;
+      if (first >= 0 && first < pred - 1) {                      // overshot: repeat without the prediction
+        arena_release(mark);
+        struct Off { Off() { g_mg_predict_off++; } ~Off() { g_mg_predict_off--; } } off_;
+        return cc_solve(rh, phi, beta, dx, bc, rel_eps, abs_eps, max_iter, cycles, res0, res, alpha, rho, keep, fast, fmg, zero_guess, add_to);
+      }
+      cyc = pred - 1; rn = h[pred - 1];
+    } else {
+      cc_residual_d(M, D0, true); rn = read_scalar(M.d_nrm);
+    }
+  }
   while (!conv) {
     if ((rn <= rel_eps * bnorm && bnorm < HUGE_VAL) || rn <= abs_eps) { conv = true; break; }
     if (cyc >= max_iter || !(rn < HUGE_VAL) || !(bnorm < HUGE_VAL)) break;     // also: a NaN / inf norm (the reductions turn NaN into +inf)
@@ -1861,6 +1892,7 @@ int cc_solve(vdn_multifab *rh, vdn_multifab *phi, vdn_multifab **beta, const dou
     for (size_t b = 0; b < DF.boxes.size(); b++) fast->phi_view.push_back(cc_phi_view(DF.boxes[b].L, fast->rho->vbox[b].lo));
   } else cc_store(M, phi, bc);
   if (cycles) *cycles = cyc; if (res0) *res0 = bnorm; if (res) *res = rn;
+  if (conv && fast && !single && cyc >= 1) mg_predict_set(0, gn, cyc);
   if (!keep && !fast) arena_release(mark);
   return conv ? 0 : 1;
 }

@@ -1067,7 +1067,7 @@ static void nd_jacobi_d(NDLev &DL, int nsweeps, bool pre = false) {
     DL.flip = !DL.flip;
   }
 }
-static void nd_residual_d(NDMG &M, NDLev &DL, bool norm) {
+static void nd_residual_d(NDMG &M, NDLev &DL, bool norm, bool reduce = true) {     // reduce = false: the norm stays rank-local (it goes into the norm history, made global when that is read)
   if (norm) HIPCHK(hipMemsetAsync(M.d_nrm, 0, sizeof(double), ctx().stream));
   const bool ov = nd_halo_begin(DL);
   for (NBox &B : DL.boxes)
@@ -1077,7 +1077,7 @@ static void nd_residual_d(NDMG &M, NDLev &DL, bool norm) {
     for (NBox &B : DL.boxes) nd_launch_shell<1>(B.L, B.L.phi, B.L.res, norm ? M.d_nrm : nullptr, B.hmask);
   }
   if (DL.halo_res) xplan_run(DL.halo_res);
-  if (norm) comm_allreduce_max_dev(M.d_nrm, 1);
+  if (norm && reduce) comm_allreduce_max_dev(M.d_nrm, 1);
 }
 
 // ---- replicated tail ------------------------------------------------------------------------------------------------
@@ -1440,7 +1440,42 @@ int nd_solve(vdn_multifab *rh, vdn_multifab *phi, const vdn_multifab *coeffs, co
   if (fixed_cycles) conv = true;
   // pre-smoothing + residual, then per cycle [coarse correction, post-smoothing, next pre-smoothing, residual + norm] as one replayed
   // graph and one read-back: the same launch sequence as testing the residual the cycle computes after its pre-smoothing
-  if (!conv) { nd_jacobi_d(M.dlev[0], single ? nd_bottom_sweeps_global(M.dlev[0]) : P.hg_nu1, !single); nd_residual_d(M, M.dlev[0], true); rn = nd_read(M.d_nrm); }
+  // vdn_params.mg_predict (hgproject's call, zero guess): the previous solve of this size stopped after `pred` cycles, so the norms of the cycles
+  // before pred - 1 are not waited for -- they go into the device-side history and are read in one go after cycle pred - 1.  Should the history show
+  // that an earlier cycle had already met the tolerance, this solve is thrown away and repeated with a read-back per cycle (rare: the count
+  // dropped by two or more from one solve to the next), so the result is the one the plain loop gives, whatever the prediction was.
+  int gn[3] = { M.dlev[0].ng[0], M.dlev[0].ng[1], M.dlev[0].ng[2] };
+  int pred = (fast && !fixed_cycles && !single && !conv && p0max == 0.0) ? std::min(mg_predict_get(1, gn), std::min(max_iter, 63)) : 0;
+  if (!conv) {
+    nd_jacobi_d(M.dlev[0], single ? nd_bottom_sweeps_global(M.dlev[0]) : P.hg_nu1, !single);
+    if (pred >= 2) {
+      nd_residual_d(M, M.dlev[0], true, false);
+      norm_hist_reset(); norm_hist_push(M.d_nrm);
+      for (int c = 1; c <= pred - 1; c++)
+        nd_run_cycle(M, 4, [&] {
+          NDLev &D = M.dlev[0];
+          nd_restrict_down(M, 0);
+          if (M.dlev.size() > 1) nd_vcycle_d(M, 1); else nd_vcycle_t(M, 0);
+          nd_prolong_up(M, 0);
+          nd_jacobi_d(D, P.hg_nu2);
+          nd_jacobi_d(D, P.hg_nu1, true);
+          nd_residual_d(M, D, true, false);
+          norm_hist_push(M.d_nrm);
+        });
+      const double *h = norm_hist_read(pred);
+      int first = -1;                                            // the first cycle count at which the plain loop would have stopped
+      for (int c = 0; c < pred && first < 0; c++)
+        if (((h[c] <= rel_eps * bnorm && bnorm < HUGE_VAL) || h[c] <= abs_eps) || !(h[c] < HUGE_VAL)) first = c;
+      if (first >= 0 && first < pred - 1) {                      // overshot: repeat without the prediction
+        arena_release(mark);
+        struct Off { Off() { g_mg_predict_off++; } ~Off() { g_mg_predict_off--; } } off_;
+        return nd_solve(rh, phi, nullptr, u, dx, bc, rel_eps, abs_eps, max_iter, cycles, res0, res, keep, fast, fmg_start, rh_is_b, add_to);
+      }
+      cyc = pred - 1; rn = h[pred - 1];
+    } else {
+      nd_residual_d(M, M.dlev[0], true); rn = nd_read(M.d_nrm);
+    }
+  }
   while (!conv) {
     if ((rn <= rel_eps * bnorm && bnorm < HUGE_VAL) || rn <= abs_eps) { conv = true; break; }
     if (cyc >= max_iter || !(rn < HUGE_VAL) || !(bnorm < HUGE_VAL)) break;     // also: a NaN / inf norm (the reductions turn NaN into +inf)
@@ -1468,6 +1503,7 @@ int nd_solve(vdn_multifab *rh, vdn_multifab *phi, const vdn_multifab *coeffs, co
     hipLaunchKernelGGL(kk_nd_store, ng3(L0.n[0] + 3, L0.n[1] + 3, L0.n[2] + 3), NBLK, 0, st, L0, phi->fabs[b], bx.lo[0], bx.lo[1], bx.lo[2]);
   }
   if (cycles) *cycles = cyc; if (res0) *res0 = bnorm; if (res) *res = rn;
+  if (conv && fast && !fixed_cycles && !single && cyc >= 1) mg_predict_set(1, gn, cyc);
   if (!keep && !fast) arena_release(mark);  // with `keep` / `fast` the hierarchy stays in the caller's arena scope
   return conv ? 0 : 1;
 }

@@ -88,7 +88,7 @@ extern "C" void vdn_params_default(vdn_params *p) {
   p->visc_coef = 0.0; p->diff_coef = 0.0; p->cflfac = 0.8; p->max_dt_growth = 1.1;
   p->mg_nu1 = 2; p->mg_nu2 = 2; p->mg_nub = 8; p->mg_max_iter = 100;
   p->hg_max_iter = 100; p->hg_nu1 = 2; p->hg_nu2 = 1; p->hg_nub = 8; p->hg_omega = 0.9;     // hg_nub: 32 until round 3 -- the coarsest level (3^3 nodes under a 2^k box) gains nothing from more than max(8, 2 N^2) sweeps (same cycle counts), and each costs ~1.2 us of a one-workgroup launch
-  p->mac_rel_eps = 1.0e-10; p->hg_rel_eps = -1.0; p->abort_on_max_iter = 1; p->hg_fmg = 1; p->mac_fmg = 1; p->hg_omega_pre1 = 1.45; p->hg_omega_pre2 = 0.7; p->hg_omega_fac1 = 1.6; p->hg_omega_fac2 = 0.9; p->hg_omega_fac3 = 0.65;
+  p->mac_rel_eps = 1.0e-10; p->hg_rel_eps = -1.0; p->abort_on_max_iter = 1; p->hg_fmg = 1; p->mac_fmg = 1; p->hg_omega_pre1 = 1.45; p->hg_omega_pre2 = 0.7; p->hg_omega_fac1 = 1.6; p->hg_omega_fac2 = 0.9; p->hg_omega_fac3 = 0.65; p->mg_predict = 1;
 }
 
 // ---- roctx ranges ------------------------------------------------------------------------------------------------------------
@@ -150,6 +150,30 @@ const double *read_scalars(const double *dev, int n) {
   HIPCHK(hipStreamSynchronize(c.stream));
   return c.h_scal;
 }
+
+// ---- residual-norm history (vdn_params.mg_predict) --------------------------------------------------------------------------------
+__global__ void k_hist_push(double *hist, const double *nrm) {
+  int *cnt = reinterpret_cast<int *>(hist + 64);
+  const int c = *cnt;
+  if (c < 64) hist[c] = *nrm;
+  *cnt = c + 1;
+}
+void norm_hist_reset() { HIPCHK(hipMemsetAsync(g_ctx.d_hist + 64, 0, sizeof(double), g_ctx.stream)); }
+void norm_hist_push(const double *d_nrm) { hipLaunchKernelGGL(k_hist_push, dim3(1), dim3(1), 0, g_ctx.stream, g_ctx.d_hist, d_nrm); }
+const double *norm_hist_read(int n) {
+  REQUIRE(n >= 1 && n <= 64, "norm_hist_read: 1..64 entries");
+  comm_allreduce_max_dev(g_ctx.d_hist, n);
+  return read_scalars(g_ctx.d_hist, n);
+}
+int g_mg_predict_off = 0;
+static std::map<unsigned long long, int> g_mg_pred;
+static unsigned long long mg_pred_key(int solver, const int n[3]) { GraphKey k; k.put(solver); k.put(n[0]); k.put(n[1]); k.put(n[2]); return k.h; }
+int mg_predict_get(int solver, const int n[3]) {
+  if (!g_ctx.prm.mg_predict || g_mg_predict_off > 0) return 0;
+  auto it = g_mg_pred.find(mg_pred_key(solver, n));
+  return it == g_mg_pred.end() ? 0 : it->second;
+}
+void mg_predict_set(int solver, const int n[3], int cycles) { if (g_mg_pred.size() > 4096) g_mg_pred.clear(); g_mg_pred[mg_pred_key(solver, n)] = cycles; }
 
 // ---- hipGraph cache ---------------------------------------------------------------------------------------------------------------
 static std::map<unsigned long long, hipGraphExec_t> g_graphs;
@@ -234,6 +258,7 @@ extern "C" int vdn_init(const vdn_params *prm, int rank, int nranks, int device)
   c.prm = *prm; c.rank = rank; c.nranks = nranks; c.device = device;
   if (!c.d_scal) {
     HIPCHK(hipMalloc((void **)&c.d_scal, 64 * sizeof(double)));
+    HIPCHK(hipMalloc((void **)&c.d_hist, 65 * sizeof(double)));
     HIPCHK(hipHostMalloc((void **)&c.h_scal, 72 * sizeof(double), hipHostMallocMapped));      // 64 values + the sequence number of read_scalars
     memset(c.h_scal, 0, 72 * sizeof(double));
     HIPCHK(hipHostGetDevicePointer((void **)&c.h_scal_dev, c.h_scal, 0));
@@ -255,6 +280,7 @@ extern "C" int vdn_finalize(void) {
   VdnCtx &c = g_ctx;
   if (c.arena) { HIPCHK(hipFree(c.arena)); c.arena = nullptr; c.arena_bytes = 0; c.arena_off = 0; }
   graph_cache_clear();
+  if (c.d_hist) { HIPCHK(hipFree(c.d_hist)); c.d_hist = nullptr; }
   if (c.d_scal) { HIPCHK(hipFree(c.d_scal)); c.d_scal = nullptr; HIPCHK(hipHostFree(c.h_scal)); c.h_scal = nullptr; c.h_scal_dev = nullptr; }
   c.inited = false;
   VDN_CATCH

@@ -87,6 +87,7 @@ struct VdnCtx {
   // small device scratch for reductions + pinned host mirror
   double *d_scal = nullptr; double *h_scal = nullptr;       // 64 doubles each
   double *h_scal_dev = nullptr;                             // device view of the pinned mirror (k_publish writes it)
+  double *d_hist = nullptr;                                 // 64 norms of consecutive V-cycles + (slot 64, as an integer) their count: norm_hist_*
   double step_sec[5] = {0, 0, 0, 0, 0};
   int solver_cycles[2] = {0, 0}; double solver_res0[2] = {0, 0}, solver_res[2] = {0, 0};
   // slopes of uold, computed by velpred and used again by the velocity mkflux of the same advance_timestep (one level, one box)
@@ -123,6 +124,15 @@ void prof_load();
 // hipMemcpyAsync (profiles/r01_bench_kernel_stats.csv: 1120 __amd_rocclr_copyBuffer calls = 4.9 % of a step)
 const double *read_scalars(const double *dev, int n);
 inline double read_scalar1(const double *dev) { return read_scalars(dev, 1)[0]; }
+// Residual norms of consecutive V-cycles kept on the device (vdn_params.mg_predict): norm_hist_push appends *d_nrm (a one-thread kernel on the launch
+// stream, capturable in a cycle's graph), norm_hist_read makes the first n entries global (ONE all-reduce when several ranks run) and reads them back.
+void norm_hist_reset();
+void norm_hist_push(const double *d_nrm);
+const double *norm_hist_read(int n);
+// The V-cycle count of the previous solve of one kind and size (0: none yet) -- a performance hint only, results never depend on it
+int  mg_predict_get(int solver, const int n[3]);
+void mg_predict_set(int solver, const int n[3], int cycles);
+extern int g_mg_predict_off;          // > 0: inside the repeat of a solve whose prediction overshot
 
 // ---- hipGraph replay of fixed launch sequences (one multigrid cycle = ~100 launches of 3-15 us) ---------------------------------------
 // Usage:  GraphKey k; k.put(...every value the launches depend on...);  if (!graph_replay(k.h)) { graph_begin(); body(); graph_end(k.h); }

@@ -39,6 +39,7 @@ module varden_amd
      real(c_double) :: hg_omega, mac_rel_eps, hg_rel_eps
      integer(c_int) :: abort_on_max_iter, hg_fmg, mac_fmg
      real(c_double) :: hg_omega_pre1, hg_omega_pre2, hg_omega_fac1, hg_omega_fac2, hg_omega_fac3
+     integer(c_int) :: mg_predict
   end type vdn_params
 
   type, bind(C), public :: vdn_box
