@@ -209,7 +209,8 @@ def test_multigrid_launch_variants_agree_bit_for_bit(gpu):
     kk_cc_lds_up), the levels of
     at most 9^3 nodes / 8^3 cells in one single-workgroup launch (kk_*_tailcycle), V-cycles replayed as hipGraphs -- against (b) the
     plain sequence of launches, with the rh / phi / coeffs / beta multifabs of hgproject and macproject as the reference has them (VDN_HG_FAST=0, VDN_MAC_FAST=0), whole-array zero fills
-    (VDN_ND_LEAN=0) and every forcing term computed where the reference computes it (VDN_NO_FORCE_REUSE=1); and a viscous 64^3 run the same way (the alpha form of the cell-centred kernels: three visc_solves per step).
+    (VDN_ND_LEAN=0), every forcing term computed where the reference computes it (VDN_NO_FORCE_REUSE=1) and the Godunov marches dividing by dx where the
+    default scales by 1 / dx on these power-of-two grids (VDN_GOD_P2=0); and a viscous 64^3 run the same way (the alpha form of the cell-centred kernels: three visc_solves per step).
     The switches are read once per process, hence the child processes."""
     import hashlib, os, subprocess, sys, textwrap
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -228,11 +229,11 @@ def test_multigrid_launch_variants_agree_bit_for_bit(gpu):
             h.update(np.ascontiguousarray(m.to_numpy()).tobytes())
         print("HASH", h.hexdigest(), G.dt)
     """ % root)
-    switches = ("VDN_MG_PROLONG_FUSED", "VDN_MG_RESTRICT_FUSED", "VDN_MG_TAILCYCLE", "VDN_MG_LDS", "VDN_NO_GRAPHS", "VDN_HG_FAST", "VDN_MAC_FAST", "VDN_ND_LEAN", "VDN_NO_FORCE_REUSE", "VDN_GOD_UPDATE")
+    switches = ("VDN_MG_PROLONG_FUSED", "VDN_MG_RESTRICT_FUSED", "VDN_MG_TAILCYCLE", "VDN_MG_LDS", "VDN_NO_GRAPHS", "VDN_HG_FAST", "VDN_MAC_FAST", "VDN_ND_LEAN", "VDN_NO_FORCE_REUSE", "VDN_GOD_UPDATE", "VDN_GOD_P2")
     for n, visc in ((128, 0.0), (64, 0.01)):
         out = []
         for extra in ({}, {"VDN_MG_PROLONG_FUSED": "0", "VDN_MG_RESTRICT_FUSED": "0", "VDN_MG_TAILCYCLE": "0", "VDN_MG_LDS": "0", "VDN_NO_GRAPHS": "1",
-                          "VDN_HG_FAST": "0", "VDN_MAC_FAST": "0", "VDN_ND_LEAN": "0", "VDN_NO_FORCE_REUSE": "1", "VDN_GOD_UPDATE": "0"}):
+                          "VDN_HG_FAST": "0", "VDN_MAC_FAST": "0", "VDN_ND_LEAN": "0", "VDN_NO_FORCE_REUSE": "1", "VDN_GOD_UPDATE": "0", "VDN_GOD_P2": "0"}):
             env = dict(os.environ)
             for k in switches:
                 env.pop(k, None)

@@ -815,6 +815,7 @@ struct FArgs {
   long sq[3]; FGeo h[3];  // x-, y-, z-face outputs (edge state and flux of one direction share a layout)
   long s_row, vm_row;     // bytes per row of s / vm
   double dt2, dx[3], tC[3], tD[3], aD[3];   // tC[T] = (cons ? dt/3 : dt/6) / dx[T],  tD[T] = (cons ? dt/2 : dt/4) / dx[T],  aD[T] = (dt/2) / dx[T]
+  double idx[3]; int p2;                    // 1 / dx and "every dx is a power of two": x / dx is then the exact scaling x * (1 / dx), bit for bit (P2 kernels)
   int lo[3], hi[3], phys[3][2];
   int cons, use_minion, is_vel, c;
   // UPD (round 3): update_3d of the component inside the march -- the edge states never reach memory
@@ -830,13 +831,20 @@ DEVI void std_(char *q, unsigned o, double v) { *(double *)(q + o) = v; }
 struct FCell { double m_lo[3], m_up[3], s0, f, mr, Lb[3], Rb[3]; };      // a cell's loads and its bases (before any boundary rule)
 // mk_bases with the launch constants of FArgs: the bases of stage B (force / mac_rhs terms inside only with use_minion); stages C and D of
 // the separate kernels recompute the same ones -- six f64 divisions per cell and stage -- here they ride along with the cell
-DEVI void f_bases(const FArgs &F, FCell &P, const double sl[3]) {
+// A division by a power of two is an exact scaling: x / dx and x * (1 / dx) are the same double for every x (zeros, infinities and subnormal
+// results included: both are the correctly rounded value of the same real number), so where every dx is a power of two -- the unit cube on
+// 2^n cells, every level of a hierarchy over it -- the P2 kernels multiply.  The ten f64 divisions per cell and plane of the fused march were a
+// third of its f64 instructions (v_div_scale x 2, v_rcp, eight fma, v_div_fmas, v_div_fixup each).  Other spacings keep the division.
+static bool no_p2() { static const bool off = getenv("VDN_GOD_P2") && atoi(getenv("VDN_GOD_P2")) == 0; return off; }      // (the variants test: division path on power-of-two grids)
+static bool is_pow2(double x) { int e; return x > 0.0 && std::frexp(x, &e) == 0.5; }
+#define DIVDX(x, d) (PW2 ? (x) * F.idx[d] : (x) / F.dx[d])
+template <bool PW2> DEVI void f_bases(const FArgs &F, FCell &P, const double sl[3]) {
   double ft = 0.0, mt = 0.0;
   if (F.use_minion) { ft = F.dt2 * P.f; mt = F.dt2 * P.s0 * P.mr; }
   #pragma unroll
   for (int d = 0; d < 3; d++) {
-    double Lb = P.s0 + (0.5 - F.dt2 * P.m_up[d] / F.dx[d]) * sl[d];
-    double Rb = P.s0 - (0.5 + F.dt2 * P.m_lo[d] / F.dx[d]) * sl[d];
+    double Lb = P.s0 + (0.5 - DIVDX(F.dt2 * P.m_up[d], d)) * sl[d];
+    double Rb = P.s0 - (0.5 + DIVDX(F.dt2 * P.m_lo[d], d)) * sl[d];
     if (F.use_minion) {
       Lb = Lb + ft; Rb = Rb + ft;
       if (F.cons) { Lb = Lb - mt; Rb = Rb - mt; }
@@ -887,7 +895,7 @@ DEVI double bc_v(int m, int side, double in, double ghost) {
 // next row's (LDS, read one iteration later, like SI and SC), the upper z one this thread's output for the next plane.  So the x-term of
 // plane k is formed with stage D of plane k, the y- and z-terms one iteration later, and seven doubles travel in between; a k-chunk runs
 // one plane further (the lower z-face of its successor's first plane).  sedge and flux are not stored.  Same expressions as update_cell.
-template <bool BC, bool INL, bool UPD> __device__ __forceinline__ void mk_F_m_body(const FArgs &F, const Range3 &r, int klen, const double *umax, const int BX, const int BY, const int BZ) {
+template <bool BC, bool INL, bool UPD, bool PW2> __device__ __forceinline__ void mk_F_m_body(const FArgs &F, const Range3 &r, int klen, const double *umax, const int BX, const int BY, const int BZ) {
   __shared__ double lB[2][TNY][64], lSI[2][TNY][64], lC[2][2][TNY][64], lSC[2][2][TNY][64], lD[2][TNY][64], lE[UPD ? 2 : 1][UPD ? TNY : 1][64];
   const int lane = threadIdx.x, row = threadIdx.y;
   const int i = r.lo[0] - 1 + BX * FNX + lane, j = r.lo[1] - 1 + BY * FNY + row;
@@ -984,7 +992,7 @@ template <bool BC, bool INL, bool UPD> __device__ __forceinline__ void mk_F_m_bo
       P0.s0 = N.s0; P0.f = N.f; P0.mr = N.mr;
       const double sl[3] = { N.sl[0], N.sl[1], N.sl[2] };
       if (kk < k1 + 2) { F_LOAD  F_ADVANCE(kk + 2) }
-      f_bases(F, P0, sl);
+      f_bases<PW2>(F, P0, sl);
     }
     // ---------------- stage B, plane kk ----------------
     double si0[3];
@@ -1103,15 +1111,15 @@ template <bool BC, bool INL, bool UPD> __device__ __forceinline__ void mk_F_m_bo
           const double ex = cons ? e[0] * m_lo[0] : e[0], ey = cons ? e[1] * m_lo[1] : e[1], ez = cons ? e[2] * m_lo[2] : e[2];
           if (k - 1 >= k0) {                                           // finish plane k-1: its upper y face from the row above, its upper z face = ez
             const double eyu = lE[buf ^ 1][rowp][lane];
-            const double ty = cons ? (eyu - c_e1) / F.dx[1] : c_vbar * (eyu - c_e1) / F.dx[1];
-            const double tz = cons ? (ez - c_e2) / F.dx[2] : c_wbar * (ez - c_e2) / F.dx[2];
+            const double ty = cons ? DIVDX(eyu - c_e1, 1) : DIVDX(c_vbar * (eyu - c_e1), 1);
+            const double tz = cons ? DIVDX(ez - c_e2, 2) : DIVDX(c_wbar * (ez - c_e2), 2);
             const double ug = c_tx + ty + tz;
             const bool vzp = k - 1 >= F.lo[2] && k - 1 <= F.hi[2];
             if (own_ij && vx && vy && vzp) std_(qn, 0u, c_so - F.dt * ug + F.dt * c_fu);
             qn += F.sqn;
           }
           const double exu = lane_next(ex);                            // the upper x face: the next lane's lower one
-          c_tx = cons ? (exu - ex) / F.dx[0] : (0.5 * (m_lo[0] + m_up[0])) * (exu - ex) / F.dx[0];
+          c_tx = cons ? DIVDX(exu - ex, 0) : DIVDX((0.5 * (m_lo[0] + m_up[0])) * (exu - ex), 0);
           c_vbar = 0.5 * (m_lo[1] + m_up[1]); c_wbar = 0.5 * (m_lo[2] + m_up[2]);
           c_e1 = ey; c_e2 = ez; c_so = s0;
           if (F.fmode == 0) c_fu = P2.f;
@@ -1135,7 +1143,7 @@ template <bool BC, bool INL, bool UPD> __device__ __forceinline__ void mk_F_m_bo
   #undef PREMOD
   #undef Z_WORD
 }
-template <bool BC = true, bool INL = true, bool UPD = false> __global__ void __launch_bounds__(64 * TNY) kk_mk_F_m(FArgs F, Range3 r, int klen, const double *umax) {
+template <bool BC = true, bool INL = true, bool UPD = false, bool PW2 = false> __global__ void __launch_bounds__(64 * TNY) kk_mk_F_m(FArgs F, Range3 r, int klen, const double *umax) {
   int bx_, by_, bz_; xcd_remap(bx_, by_, bz_);
   // a workgroup whose tile and k-chunk stay clear of every face that carries a rule runs the body without the boundary code (same values:
   // none of its cells is flagged); compiled into one kernel the lean path keeps its own register allocation (0.69 against 0.96 ms per launch)
@@ -1150,8 +1158,8 @@ template <bool BC = true, bool INL = true, bool UPD = false> __global__ void __l
       if (bc_mode(F.phys[d][1], F.is_vel != 0, F.c == d) && a1[d] >= F.hi[d] - 1) touch = true;
     }
   }
-  if (BC && touch) mk_F_m_body<BC, INL, UPD>(F, r, klen, umax, bx_, by_, bz_);
-  else mk_F_m_body<false, false, UPD>(F, r, klen, umax, bx_, by_, bz_);
+  if (BC && touch) mk_F_m_body<BC, INL, UPD, PW2>(F, r, klen, umax, bx_, by_, bz_);
+  else mk_F_m_body<false, false, UPD, PW2>(F, r, klen, umax, bx_, by_, bz_);
 }
 // the launch arguments of the fused march for component c; false when the field layouts do not allow the shared offsets
 static bool fused_args(FArgs &F, const GArgs &A, int c, const FV &s, const FV sl[3], const FV &um, const FV &vm, const FV &wm, const FV &force, const FV &macrhs,
@@ -1177,10 +1185,11 @@ static bool fused_args(FArgs &F, const GArgs &A, int c, const FV &s, const FV sl
   const double dt2 = 0.5 * A.dt, dt3 = A.dt / 3.0, dt4 = A.dt / 4.0, dt6 = A.dt / 6.0;
   F.dt2 = dt2;
   for (int d = 0; d < 3; d++) {
-    F.dx[d] = A.dx[d]; F.tC[d] = (cons ? dt3 : dt6) / A.dx[d]; F.tD[d] = (cons ? dt2 : dt4) / A.dx[d]; F.aD[d] = dt2 / A.dx[d];
+    F.dx[d] = A.dx[d]; F.idx[d] = 1.0 / A.dx[d]; F.tC[d] = (cons ? dt3 : dt6) / A.dx[d]; F.tD[d] = (cons ? dt2 : dt4) / A.dx[d]; F.aD[d] = dt2 / A.dx[d];
     F.lo[d] = A.lo[d]; F.hi[d] = A.hi[d]; F.phys[d][0] = A.phys[d][0]; F.phys[d][1] = A.phys[d][1];
   }
   F.cons = cons ? 1 : 0; F.use_minion = A.use_minion; F.is_vel = A.is_vel; F.c = c;
+  F.p2 = (is_pow2(A.dx[0]) && is_pow2(A.dx[1]) && is_pow2(A.dx[2]) && !no_p2()) ? 1 : 0;
   F.qn = nullptr; F.sqn = 0; F.hn = FGeo{ 0, 0, 0 }; F.pfu[0] = F.pfu[1] = F.pfu[2] = nullptr; F.fmode = 0; F.dt = A.dt; F.lapu0 = 0.0;
   return true;
 }
@@ -1281,7 +1290,7 @@ template <int NC> __global__ void __launch_bounds__(64 * TNY) kk_mk_D_mb(const M
 // host side of a batch: grids of the four launch shapes per box, their prefix sums, and the upload
 // the fused march for every box of a level in one launch (a descriptor per box and component; see kk_batched for the scheme)
 struct FBatchD { FArgs F; Range3 r; int klen; const double *umax; int g[3]; };
-template <bool INL> __global__ void __launch_bounds__(64 * TNY) kk_mk_F_mb(const FBatchD *descs, const int *start, int nbox) {
+template <bool INL, bool PW2 = false> __global__ void __launch_bounds__(64 * TNY) kk_mk_F_mb(const FBatchD *descs, const int *start, int nbox) {
   BATCH_LOCATE(FBatchD, g)
   bool touch = false;                                // see kk_mk_F_m
   {
@@ -1294,8 +1303,8 @@ template <bool INL> __global__ void __launch_bounds__(64 * TNY) kk_mk_F_mb(const
       if (bc_mode(q.F.phys[d][1], q.F.is_vel != 0, q.F.c == d) && a1[d] >= q.F.hi[d] - 1) touch = true;
     }
   }
-  if (touch) mk_F_m_body<true, INL, false>(q.F, q.r, q.klen, q.umax, BX, BY, BZ);
-  else mk_F_m_body<false, false, false>(q.F, q.r, q.klen, q.umax, BX, BY, BZ);
+  if (touch) mk_F_m_body<true, INL, false, PW2>(q.F, q.r, q.klen, q.umax, BX, BY, BZ);
+  else mk_F_m_body<false, false, false, PW2>(q.F, q.r, q.klen, q.umax, BX, BY, BZ);
 }
 // k-chunks of a box in the batched launch: the boxes of a level fill the device together, so a box is cut only when it is tall
 static void fused_grid_small(const Range3 &r, int &klen, int g[3]) {
@@ -1418,6 +1427,7 @@ bool k_mkflux(const vdn_multifab *s, vdn_multifab **sedge, vdn_multifab **flux, 
         FBatchD *dd = (FBatchD *)desc_scratch(sizeof(FBatchD) * fd.size()); int *ds = (int *)desc_scratch(sizeof(int) * fstart.size());
         upload_staged(dd, fd.data(), sizeof(FBatchD) * fd.size()); upload_staged(ds, fstart.data(), sizeof(int) * fstart.size());
         if (inflow) hipLaunchKernelGGL(kk_mk_F_mb<true>, dim3(tot), blk, 0, st, dd, ds, (int)fd.size());
+        else if (fd[0].F.p2) hipLaunchKernelGGL((kk_mk_F_mb<false, true>), dim3(tot), blk, 0, st, dd, ds, (int)fd.size());
         else hipLaunchKernelGGL(kk_mk_F_mb<false>, dim3(tot), blk, 0, st, dd, ds, (int)fd.size());
         arena_release(mark);
         return false;
@@ -1505,13 +1515,17 @@ bool k_mkflux(const vdn_multifab *s, vdn_multifab **sedge, vdn_multifab **flux, 
           bool any = false;
           for (int d = 0; d < 3; d++) for (int sd = 0; sd < 2; sd++) any = any || bc_mode_host(A.phys[d][sd]);
           if (do_upd) {
-            if (!any) hipLaunchKernelGGL((kk_mk_F_m<false, false, true>), gF, blk, 0, st, FA[c0], rf, klF, umax);
+            const bool p2 = FA[c0].p2 != 0;                              // (the inflow variants keep the division: fewer instantiations)
+            if (!any) { if (p2) hipLaunchKernelGGL((kk_mk_F_m<false, false, true, true>), gF, blk, 0, st, FA[c0], rf, klF, umax); else hipLaunchKernelGGL((kk_mk_F_m<false, false, true>), gF, blk, 0, st, FA[c0], rf, klF, umax); }
             else if (inflow) hipLaunchKernelGGL((kk_mk_F_m<true, true, true>), gF, blk, 0, st, FA[c0], rf, klF, umax);
+            else if (p2) hipLaunchKernelGGL((kk_mk_F_m<true, false, true, true>), gF, blk, 0, st, FA[c0], rf, klF, umax);
             else hipLaunchKernelGGL((kk_mk_F_m<true, false, true>), gF, blk, 0, st, FA[c0], rf, klF, umax);
             continue;
           }
-          if (!any) hipLaunchKernelGGL((kk_mk_F_m<false, false>), gF, blk, 0, st, FA[c0], rf, klF, umax);      // no physical face on this box
+          const bool p2 = FA[c0].p2 != 0;
+          if (!any) { if (p2) hipLaunchKernelGGL((kk_mk_F_m<false, false, false, true>), gF, blk, 0, st, FA[c0], rf, klF, umax); else hipLaunchKernelGGL((kk_mk_F_m<false, false>), gF, blk, 0, st, FA[c0], rf, klF, umax); }      // no physical face on this box
           else if (inflow) hipLaunchKernelGGL((kk_mk_F_m<true, true>), gF, blk, 0, st, FA[c0], rf, klF, umax);
+          else if (p2) hipLaunchKernelGGL((kk_mk_F_m<true, false, false, true>), gF, blk, 0, st, FA[c0], rf, klF, umax);
           else hipLaunchKernelGGL((kk_mk_F_m<true, false>), gF, blk, 0, st, FA[c0], rf, klF, umax);
         }
         updated = do_upd;
@@ -1969,6 +1983,7 @@ struct VArgs {
   char *q[3]; long sq[3]; FGeo h[3];  // umac, vmac, wmac
   long u_row;
   double dt2, dx[3], tC[3], tD[3];    // tC[O] = (dt/6) / dx[O],  tD[T] = (dt/4) / dx[T]
+  double idx[3]; int p2;              // as in FArgs: 1 / dx, every dx a power of two (P2 kernels multiply)
   int lo[3], hi[3], phys[3][2], use_minion;
 };
 DEVI int vp_code_B(int phys, int D, int side, int c) {
@@ -2005,7 +2020,7 @@ DEVI double vpf_riemann(double L, double R, double eps) {            // the stat
   const double v = (uavg > 0.0) ? L : R;
   return test ? 0.0 : v;
 }
-template <bool BC, bool INL> __device__ __forceinline__ void vp_F_m_body(const VArgs &F, const Range3 &r, int klen, const double *umax, const int BX, const int BY, const int BZ) {
+template <bool BC, bool INL, bool PW2> __device__ __forceinline__ void vp_F_m_body(const VArgs &F, const Range3 &r, int klen, const double *umax, const int BX, const int BY, const int BZ) {
   __shared__ double lB[3][TNY][64], lUI[3][TNY][64], lC[2][TNY][64], lXC[2][TNY][64], lD[TNY][64];
   const int lane = threadIdx.x, row = threadIdx.y;
   const int i = r.lo[0] - 1 + BX * FNX + lane, j = r.lo[1] - 1 + BY * FNY + row;
@@ -2088,9 +2103,9 @@ template <bool BC, bool INL> __device__ __forceinline__ void vp_F_m_body(const V
       #pragma unroll
       for (int d = 0; d < 3; d++) {
         double cfl_l;
-        if (d == 1) cfl_l = F.dt2 * fmax(0.0, uc[d] / F.dx[1]);       // velpred.f90:2108: division inside max()
-        else cfl_l = F.dt2 * fmax(0.0, uc[d]) / F.dx[d];
-        const double cfl_r = F.dt2 * fmin(0.0, uc[d]) / F.dx[d];
+        if (d == 1) cfl_l = F.dt2 * fmax(0.0, DIVDX(uc[d], 1));       // velpred.f90:2108: division inside max()
+        else cfl_l = DIVDX(F.dt2 * fmax(0.0, uc[d]), d);
+        const double cfl_r = DIVDX(F.dt2 * fmin(0.0, uc[d]), d);
         #pragma unroll
         for (int c = 0; c < 3; c++) {
           Lb[d][c] = uc[c] + (0.5 - cfl_l) * sl[d][c];
@@ -2284,9 +2299,9 @@ template <bool BC, bool INL> __device__ __forceinline__ void vp_F_m_body(const V
   #undef V_ADVANCE
 }
 // (the interior / boundary workgroup dispatch of kk_mk_F_m was measured here too: 1.198 -> 1.227 ms, not kept)
-template <bool BC = true, bool INL = true> __global__ void __launch_bounds__(64 * TNY) kk_vp_F_m(VArgs F, Range3 r, int klen, const double *umax) {
+template <bool BC = true, bool INL = true, bool PW2 = false> __global__ void __launch_bounds__(64 * TNY) kk_vp_F_m(VArgs F, Range3 r, int klen, const double *umax) {
   int bx_, by_, bz_; xcd_remap(bx_, by_, bz_);
-  vp_F_m_body<BC, INL>(F, r, klen, umax, bx_, by_, bz_);
+  vp_F_m_body<BC, INL, PW2>(F, r, klen, umax, bx_, by_, bz_);
 }
 static bool vfused_args(VArgs &F, const GArgs &A, const FV &u, const FV sl[3], const FV &force, const FV &um, const FV &vm, const FV &wm) {
   if (!same_geom(sl[0], sl[1]) || !same_geom(sl[0], sl[2]) || sl[0].sc != sl[1].sc || sl[0].sc != sl[2].sc) return false;
@@ -2306,17 +2321,18 @@ static bool vfused_args(VArgs &F, const GArgs &A, const FV &u, const FV sl[3], c
   const double dt2 = 0.5 * A.dt, dt4 = A.dt / 4.0, dt6 = A.dt / 6.0;
   F.dt2 = dt2;
   for (int d = 0; d < 3; d++) {
-    F.dx[d] = A.dx[d]; F.tC[d] = dt6 / A.dx[d]; F.tD[d] = dt4 / A.dx[d];
+    F.dx[d] = A.dx[d]; F.idx[d] = 1.0 / A.dx[d]; F.tC[d] = dt6 / A.dx[d]; F.tD[d] = dt4 / A.dx[d];
     F.lo[d] = A.lo[d]; F.hi[d] = A.hi[d]; F.phys[d][0] = A.phys[d][0]; F.phys[d][1] = A.phys[d][1];
   }
   F.use_minion = A.use_minion;
+  F.p2 = (is_pow2(A.dx[0]) && is_pow2(A.dx[1]) && is_pow2(A.dx[2]) && !no_p2()) ? 1 : 0;
   return true;
 }
 
 struct VBatchD { VArgs F; Range3 r; int klen; const double *umax; int g[3]; };
-template <bool BC, bool INL> __global__ void __launch_bounds__(64 * TNY) kk_vp_F_mb(const VBatchD *descs, const int *start, int nbox) {
+template <bool BC, bool INL, bool PW2 = false> __global__ void __launch_bounds__(64 * TNY) kk_vp_F_mb(const VBatchD *descs, const int *start, int nbox) {
   BATCH_LOCATE(VBatchD, g)
-  vp_F_m_body<BC, INL>(q.F, q.r, q.klen, q.umax, BX, BY, BZ);
+  vp_F_m_body<BC, INL, PW2>(q.F, q.r, q.klen, q.umax, BX, BY, BZ);
 }
 
 // ====================================================================================================
@@ -2598,8 +2614,10 @@ void k_velpred(const vdn_multifab *u, vdn_multifab **umac, const vdn_multifab *f
         for (int t = 0; t < nb; t++) { fstart[t] = tot; tot += fd[t].g[0] * fd[t].g[1] * fd[t].g[2]; }
         VBatchD *dd = (VBatchD *)desc_scratch(sizeof(VBatchD) * nb); int *ds = (int *)desc_scratch(sizeof(int) * nb);
         upload_staged(dd, fd.data(), sizeof(VBatchD) * nb); upload_staged(ds, fstart.data(), sizeof(int) * nb);
-        if (!any) hipLaunchKernelGGL((kk_vp_F_mb<false, false>), dim3(tot), blk, 0, st, dd, ds, nb);
+        const bool p2 = fd[0].F.p2 != 0;
+        if (!any) { if (p2) hipLaunchKernelGGL((kk_vp_F_mb<false, false, true>), dim3(tot), blk, 0, st, dd, ds, nb); else hipLaunchKernelGGL((kk_vp_F_mb<false, false>), dim3(tot), blk, 0, st, dd, ds, nb); }
         else if (inflow) hipLaunchKernelGGL((kk_vp_F_mb<true, true>), dim3(tot), blk, 0, st, dd, ds, nb);
+        else if (p2) hipLaunchKernelGGL((kk_vp_F_mb<true, false, true>), dim3(tot), blk, 0, st, dd, ds, nb);
         else hipLaunchKernelGGL((kk_vp_F_mb<true, false>), dim3(tot), blk, 0, st, dd, ds, nb);
         arena_release(mark);
         return;
@@ -2645,8 +2663,10 @@ void k_velpred(const vdn_multifab *u, vdn_multifab **umac, const vdn_multifab *f
         const dim3 gF = fused_grid(rf, klF);
         bool any = false, inflow = false;
         for (int d = 0; d < 3; d++) for (int sd = 0; sd < 2; sd++) { any = any || bc_mode_host(A.phys[d][sd]); inflow = inflow || A.phys[d][sd] == VDN_INLET; }
-        if (!any) hipLaunchKernelGGL((kk_vp_F_m<false, false>), gF, blk, 0, st, VA, rf, klF, umax);
+        const bool p2 = VA.p2 != 0;
+        if (!any) { if (p2) hipLaunchKernelGGL((kk_vp_F_m<false, false, true>), gF, blk, 0, st, VA, rf, klF, umax); else hipLaunchKernelGGL((kk_vp_F_m<false, false>), gF, blk, 0, st, VA, rf, klF, umax); }
         else if (inflow) hipLaunchKernelGGL((kk_vp_F_m<true, true>), gF, blk, 0, st, VA, rf, klF, umax);
+        else if (p2) hipLaunchKernelGGL((kk_vp_F_m<true, false, true>), gF, blk, 0, st, VA, rf, klF, umax);
         else hipLaunchKernelGGL((kk_vp_F_m<true, false>), gF, blk, 0, st, VA, rf, klF, umax);
       } else if (slab_bc()) {      // interior marches, then the face-centred code on the boundary slabs (see kk_slabs)
         const VpPlain P{ u->fabs[ib], sl[0], sl[1], sl[2], force->fabs[ib], UI, XC, umac[0]->fabs[ib], umac[1]->fabs[ib], umac[2]->fabs[ib], A, umax };
