@@ -131,36 +131,55 @@ static void nd_alloc(ndlev *L, const int n[3], const double h[3], int dm)
 static void nd_free(ndlev *L) { free(L->phi); free(L->tmp); free(L->b); free(L->res); free(L->sig); free(L->dir); }
 
 /* ghost nodes: periodic image, else zero.  Also makes node n[d] the alias of node 0. */
+/* (round 4: rows whose j and k are interior are visited at i = -1, n, n+1 only -- the entries the rule can touch --, planes in parallel: a source node
+ * is never itself a ghost or alias node, so the order of the assignments does not matter) */
+static inline void nd_fill_node1(const ndlev *L, double *a, const int per[3], int i, int j, int k)
+{
+  const int *n = L->n;
+  int q[3] = { i, j, k }, s[3] = { i, j, k }, g = 0, zero = 0;
+  for (int d = 0; d < L->dm; d++) {
+    if (per[d]) { if (q[d] < 0) { s[d] = q[d] + n[d]; g = 1; } else if (q[d] >= n[d]) { s[d] = q[d] - n[d]; g = 1; } }
+    else if (q[d] < 0 || q[d] > n[d]) { g = 1; zero = 1; }
+  }
+  if (g) a[NN(L, i, j, k)] = zero ? 0.0 : a[NN(L, s[0], s[1], s[2])];
+}
 static void nd_fill_nodes(const ndlev *L, double *a, const int per[3])
 {
   const int *n = L->n;
   const int k0 = L->dm == 2 ? 0 : -1, k1 = L->dm == 2 ? 0 : n[2] + 1;
-  for (int k = k0; k <= k1; k++) for (int j = -1; j <= n[1] + 1; j++) for (int i = -1; i <= n[0] + 1; i++) {
-    int q[3] = { i, j, k }, s[3] = { i, j, k }, g = 0, zero = 0;
-    for (int d = 0; d < L->dm; d++) {
-      if (per[d]) { if (q[d] < 0) { s[d] = q[d] + n[d]; g = 1; } else if (q[d] >= n[d]) { s[d] = q[d] - n[d]; g = 1; } }
-      else if (q[d] < 0 || q[d] > n[d]) { g = 1; zero = 1; }
-    }
-    if (g) a[NN(L, i, j, k)] = zero ? 0.0 : a[NN(L, s[0], s[1], s[2])];
+  #pragma omp parallel for
+  for (int k = k0; k <= k1; k++) for (int j = -1; j <= n[1] + 1; j++) {
+    const int edge = (j < 0 || j >= n[1]) || (L->dm == 3 && (k < 0 || k >= n[2]));
+    if (edge) for (int i = -1; i <= n[0] + 1; i++) nd_fill_node1(L, a, per, i, j, k);
+    else { nd_fill_node1(L, a, per, -1, j, k); nd_fill_node1(L, a, per, n[0], j, k); nd_fill_node1(L, a, per, n[0] + 1, j, k); }
   }
+}
+static inline void nd_fill_cell1(const ndlev *L, double *a, const int per[3], int i, int j, int k)
+{
+  const int *n = L->n;
+  int q[3] = { i, j, k }, s[3] = { i, j, k }, g = 0, zero = 0;
+  for (int d = 0; d < L->dm; d++) {
+    if (q[d] < 0) { g = 1; if (per[d]) s[d] = q[d] + n[d]; else zero = 1; }
+    else if (q[d] >= n[d]) { g = 1; if (per[d]) s[d] = q[d] - n[d]; else zero = 1; }
+  }
+  if (g) a[NS(L, i, j, k)] = zero ? 0.0 : a[NS(L, s[0], s[1], s[2])];
 }
 static void nd_fill_cells(const ndlev *L, double *a, const int per[3])
 {
   const int *n = L->n;
   const int k0 = L->dm == 2 ? 0 : -1, k1 = L->dm == 2 ? 0 : n[2];
-  for (int k = k0; k <= k1; k++) for (int j = -1; j <= n[1]; j++) for (int i = -1; i <= n[0]; i++) {
-    int q[3] = { i, j, k }, s[3] = { i, j, k }, g = 0, zero = 0;
-    for (int d = 0; d < L->dm; d++) {
-      if (q[d] < 0) { g = 1; if (per[d]) s[d] = q[d] + n[d]; else zero = 1; }
-      else if (q[d] >= n[d]) { g = 1; if (per[d]) s[d] = q[d] - n[d]; else zero = 1; }
-    }
-    if (g) a[NS(L, i, j, k)] = zero ? 0.0 : a[NS(L, s[0], s[1], s[2])];
+  #pragma omp parallel for
+  for (int k = k0; k <= k1; k++) for (int j = -1; j <= n[1]; j++) {
+    const int edge = (j < 0 || j >= n[1]) || (L->dm == 3 && (k < 0 || k >= n[2]));
+    if (edge) for (int i = -1; i <= n[0]; i++) nd_fill_cell1(L, a, per, i, j, k);
+    else { nd_fill_cell1(L, a, per, -1, j, k); nd_fill_cell1(L, a, per, n[0], j, k); }
   }
 }
 
 /* the 27-point nodal operator on gathered values: p[oc][ob][oa] = phi at node offset (oa-1, ob-1, oc-1), sg[dk][dj][di] = sigma of
  * cell (i-1+di, j-1+dj, k-1+dk); f[d] = 1/(36 h_d^2).  See nd_apply for the formula. */
-void vo_nd_stencil(const double f[3], const double p[3][3][3], const double sg[2][2][2], double *Kp, double *diag)
+/* iso: 1 = the face weights w1, w2, w4 are known to be zero (hx = hy = hz), 0 = known not all zero, -1 = test them here */
+static inline __attribute__((always_inline)) void nd_stencil_inl(const double f[3], const double p[3][3][3], const double sg[2][2][2], double *Kp, double *diag, const int iso)
 {
   const double fx = f[0], fy = f[1], fz = f[2];
   const double F = fx + fy + fz;
@@ -172,12 +191,11 @@ void vo_nd_stencil(const double f[3], const double p[3][3][3], const double sg[2
   const double w5 = -2.0 * fx + fy - 2.0 * fz;
   const double w6 = fx - 2.0 * fy - 2.0 * fz;
   const double w7 = -F;
-  double cz[2][2], cy[2][2], cx[2][2];
-  for (int b = 0; b < 2; b++) for (int a = 0; a < 2; a++) {
-    cz[b][a] = sg[0][b][a] + sg[1][b][a];          /* the two cells that share an xy-diagonal neighbour */
-    cy[b][a] = sg[b][0][a] + sg[b][1][a];          /* [dk][di]: xz-diagonal */
-    cx[b][a] = sg[b][a][0] + sg[b][a][1];          /* [dk][dj]: yz-diagonal */
-  }
+  /* cz[b][a] = sg[0][b][a] + sg[1][b][a]: the two cells that share an xy-diagonal neighbour; cy[dk][di] = sg[dk][0][di] + sg[dk][1][di] (xz-diagonal);
+   * cx[dk][dj] = sg[dk][dj][0] + sg[dk][dj][1] (yz-diagonal) -- written out so that the row loop of nd_row has no inner loop */
+  const double cz[2][2] = { { sg[0][0][0] + sg[1][0][0], sg[0][0][1] + sg[1][0][1] }, { sg[0][1][0] + sg[1][1][0], sg[0][1][1] + sg[1][1][1] } };
+  const double cy[2][2] = { { sg[0][0][0] + sg[0][1][0], sg[0][0][1] + sg[0][1][1] }, { sg[1][0][0] + sg[1][1][0], sg[1][0][1] + sg[1][1][1] } };
+  const double cx[2][2] = { { sg[0][0][0] + sg[0][0][1], sg[0][1][0] + sg[0][1][1] }, { sg[1][0][0] + sg[1][0][1], sg[1][1][0] + sg[1][1][1] } };
   const double S8 = (cz[0][0] + cz[0][1]) + (cz[1][0] + cz[1][1]);
   /* the weights of a row sum to zero (K 1 = 0), so K phi = sum of coefficient * (phi_neighbour - phi_node): differences first, which
    * keeps the terms at the size of the answer instead of the size of diag * phi (at 256^3 the plain sum stalls at a residual of
@@ -193,7 +211,7 @@ void vo_nd_stencil(const double f[3], const double p[3][3][3], const double sg[2
   const double dg = w0 * S8;
   double acc = w3 * A3;
   acc = fma(w5, A5, acc); acc = fma(w6, A6, acc); acc = fma(w7, A7, acc);
-  if (!(w1 == 0.0 && w2 == 0.0 && w4 == 0.0)) {
+  if (iso < 0 ? !(w1 == 0.0 && w2 == 0.0 && w4 == 0.0) : !iso) {
     double A1 = (cz[0][0] + cz[1][0]) * D(1, 1, 0); A1 = fma(cz[0][1] + cz[1][1], D(1, 1, 2), A1);
     double A2 = (cz[0][0] + cz[0][1]) * D(1, 0, 1); A2 = fma(cz[1][0] + cz[1][1], D(1, 2, 1), A2);
     double A4 = (cy[0][0] + cy[0][1]) * D(0, 1, 1); A4 = fma(cy[1][0] + cy[1][1], D(2, 1, 1), A4);
@@ -201,6 +219,12 @@ void vo_nd_stencil(const double f[3], const double p[3][3][3], const double sg[2
   }
   #undef D
   *Kp = acc; *diag = dg;
+}
+void vo_nd_stencil(const double f[3], const double p[3][3][3], const double sg[2][2][2], double *Kp, double *diag) { nd_stencil_inl(f, p, sg, Kp, diag, -1); }
+static int nd_iso_weights(const double f[3]) {      /* the test of nd_stencil_inl on the same expressions */
+  const double fx = f[0], fy = f[1], fz = f[2];
+  const double w1 = -4.0 * fx + 2.0 * fy + 2.0 * fz, w2 = 2.0 * fx - 4.0 * fy + 2.0 * fz, w4 = 2.0 * fx + 2.0 * fy - 4.0 * fz;
+  return w1 == 0.0 && w2 == 0.0 && w4 == 0.0;
 }
 
 /* K phi at node (i,j,k) and the diagonal; fixed expression order shared with the HIP kernel:
@@ -234,18 +258,58 @@ static inline void nd_apply(const ndlev *L, const double *phi, int i, int j, int
    * neighbour is shared by 4 / 2 / 1 of the cells, so its coefficient is w[type] times the sum of those sigmas.  Fixed order, explicit
    * fma() -- oracle and HIP (nd_stencil in mg_nd.hip) run the same operation sequence, hence the same bits.  With hx = hy = hz the
    * face weights w[1], w[2], w[4] are exactly zero (the 21-point stencil, hg_hypre.f90:100-113) and their terms are skipped. */
+  /* (round 4: the 27 + 8 values through one base index each and constant strides) */
+  const long sy = L->n[0] + 3, sz = sy * (L->n[1] + 3), ty = L->n[0] + 2, tz = ty * (L->n[1] + 2);
+  const double *pp = phi + NN(L, i - 1, j - 1, k - 1), *ps = L->sig + NS(L, i - 1, j - 1, k - 1);
   double p[3][3][3], sg[2][2][2];
-  for (int c = 0; c < 3; c++) for (int b = 0; b < 3; b++) for (int a = 0; a < 3; a++) p[c][b][a] = phi[NN(L, i + a - 1, j + b - 1, k + c - 1)];
-  for (int c = 0; c < 2; c++) for (int b = 0; b < 2; b++) for (int a = 0; a < 2; a++) sg[c][b][a] = L->sig[NS(L, i + a - 1, j + b - 1, k + c - 1)];
-  vo_nd_stencil(L->f, p, sg, Kp, diag);
+  for (int c = 0; c < 3; c++) for (int b = 0; b < 3; b++) for (int a = 0; a < 3; a++) p[c][b][a] = pp[a + b * sy + c * sz];
+  for (int c = 0; c < 2; c++) for (int b = 0; b < 2; b++) for (int a = 0; a < 2; a++) sg[c][b][a] = ps[a + b * ty + c * tz];
+  nd_stencil_inl(L->f, p, sg, Kp, diag, -1);
 }
 
+/* K phi and the diagonal on the whole row (0..n0, j, k) of a 3-D level: the same nd_stencil_inl on the same 27 + 8 values per node, the loop over i written
+ * so that the compiler vectorises it (unit-stride loads; round 4 -- the oracle's nodal solve was 3.5 of the 6.9 s of the bench's CPU step) */
+static inline __attribute__((always_inline)) void nd_row_(const ndlev *L, const double *phi, int j, int k, double *restrict Kp, double *restrict dg, const int iso)
+{
+  const long sy = L->n[0] + 3, sz = sy * (L->n[1] + 3), ty = L->n[0] + 2, tz = ty * (L->n[1] + 2);
+  const double *pp = phi + NN(L, -1, j - 1, k - 1), *ps = L->sig + NS(L, -1, j - 1, k - 1);
+  const double f[3] = { L->f[0], L->f[1], L->f[2] };
+  const int n0 = L->n[0];
+  #pragma omp simd
+  for (int i = 0; i <= n0; i++) {
+    /* (written out: the vectoriser does not take a loop nest with inner loops) */
+    const double p[3][3][3] = { { { pp[i + 0 + 0 * sy + 0 * sz], pp[i + 1 + 0 * sy + 0 * sz], pp[i + 2 + 0 * sy + 0 * sz] }, { pp[i + 0 + 1 * sy + 0 * sz], pp[i + 1 + 1 * sy + 0 * sz], pp[i + 2 + 1 * sy + 0 * sz] }, { pp[i + 0 + 2 * sy + 0 * sz], pp[i + 1 + 2 * sy + 0 * sz], pp[i + 2 + 2 * sy + 0 * sz] } }, { { pp[i + 0 + 0 * sy + 1 * sz], pp[i + 1 + 0 * sy + 1 * sz], pp[i + 2 + 0 * sy + 1 * sz] }, { pp[i + 0 + 1 * sy + 1 * sz], pp[i + 1 + 1 * sy + 1 * sz], pp[i + 2 + 1 * sy + 1 * sz] }, { pp[i + 0 + 2 * sy + 1 * sz], pp[i + 1 + 2 * sy + 1 * sz], pp[i + 2 + 2 * sy + 1 * sz] } }, { { pp[i + 0 + 0 * sy + 2 * sz], pp[i + 1 + 0 * sy + 2 * sz], pp[i + 2 + 0 * sy + 2 * sz] }, { pp[i + 0 + 1 * sy + 2 * sz], pp[i + 1 + 1 * sy + 2 * sz], pp[i + 2 + 1 * sy + 2 * sz] }, { pp[i + 0 + 2 * sy + 2 * sz], pp[i + 1 + 2 * sy + 2 * sz], pp[i + 2 + 2 * sy + 2 * sz] } } };
+    const double sg[2][2][2] = { { { ps[i + 0 + 0 * ty + 0 * tz], ps[i + 1 + 0 * ty + 0 * tz] }, { ps[i + 0 + 1 * ty + 0 * tz], ps[i + 1 + 1 * ty + 0 * tz] } }, { { ps[i + 0 + 0 * ty + 1 * tz], ps[i + 1 + 0 * ty + 1 * tz] }, { ps[i + 0 + 1 * ty + 1 * tz], ps[i + 1 + 1 * ty + 1 * tz] } } };
+    double kp, d;
+    nd_stencil_inl(f, p, sg, &kp, &d, iso);
+    Kp[i] = kp; dg[i] = d;
+  }
+}
+static void nd_row(const ndlev *L, const double *phi, int j, int k, double *restrict Kp, double *restrict dg)
+{
+  if (nd_iso_weights(L->f)) nd_row_(L, phi, j, k, Kp, dg, 1); else nd_row_(L, phi, j, k, Kp, dg, 0);
+}
+#define ND_ROW_MAX 2048        /* longest row the row form takes (stack buffers); longer rows and dm = 2 go node by node */
 static void nd_jacobi(ndlev *L, const int per[3], int nsweeps, double omega)
 {
   const int *n = L->n;
   for (int s = 0; s < nsweeps; s++) {
     nd_fill_nodes(L, L->phi, per);
-    #pragma omp parallel for
+    if (L->dm == 3 && n[0] + 1 <= ND_ROW_MAX) {
+      #pragma omp parallel for collapse(2) schedule(static)
+      for (int k = 0; k <= n[2]; k++) for (int j = 0; j <= n[1]; j++) {
+        double Kp[ND_ROW_MAX], dg[ND_ROW_MAX];
+        nd_row(L, L->phi, j, k, Kp, dg);
+        const double *ph = L->phi + NN(L, 0, j, k), *bb = L->b + NN(L, 0, j, k); double *out = L->tmp + NN(L, 0, j, k);
+        const unsigned char *dr = L->dir + NM(L, 0, j, k);
+        for (int i = 0; i <= n[0]; i++) {
+          double p0 = ph[i], v = p0;
+          if (!dr[i] && dg[i] != 0.0) v = p0 + omega * ((bb[i] - Kp[i]) / dg[i]);
+          out[i] = v;
+        }
+      }
+    } else {
+    #pragma omp parallel for collapse(2) schedule(static)
     for (int k = 0; k <= n[2]; k++) for (int j = 0; j <= n[1]; j++) for (int i = 0; i <= n[0]; i++) {
       double p0 = L->phi[NN(L, i, j, k)], v = p0;
       if (!L->dir[NM(L, i, j, k)]) {
@@ -253,6 +317,7 @@ static void nd_jacobi(ndlev *L, const int per[3], int nsweeps, double omega)
         if (diag != 0.0) v = p0 + omega * ((L->b[NN(L, i, j, k)] - Kp) / diag);
       }
       L->tmp[NN(L, i, j, k)] = v;
+    }
     }
     double *t = L->phi; L->phi = L->tmp; L->tmp = t;
   }
@@ -272,7 +337,21 @@ static double nd_residual(ndlev *L, const int per[3])
 {
   const int *n = L->n; double nrm = 0.0;
   nd_fill_nodes(L, L->phi, per);
-  #pragma omp parallel for reduction(max : nrm)
+  if (L->dm == 3 && n[0] + 1 <= ND_ROW_MAX) {
+    #pragma omp parallel for collapse(2) schedule(static) reduction(max : nrm)
+    for (int k = 0; k <= n[2]; k++) for (int j = 0; j <= n[1]; j++) {
+      double Kp[ND_ROW_MAX], dg[ND_ROW_MAX];
+      nd_row(L, L->phi, j, k, Kp, dg);
+      const double *bb = L->b + NN(L, 0, j, k); double *out = L->res + NN(L, 0, j, k);
+      const unsigned char *dr = L->dir + NM(L, 0, j, k);
+      for (int i = 0; i <= n[0]; i++) {
+        const double r = dr[i] ? 0.0 : bb[i] - Kp[i];
+        out[i] = r;
+        nrm = vo_nrm_acc(nrm, r);
+      }
+    }
+  } else
+  #pragma omp parallel for collapse(2) schedule(static) reduction(max : nrm)
   for (int k = 0; k <= n[2]; k++) for (int j = 0; j <= n[1]; j++) for (int i = 0; i <= n[0]; i++) {
     double r = 0.0;
     if (!L->dir[NM(L, i, j, k)]) {
@@ -325,6 +404,7 @@ static void nd_prolong_add(ndlev *Fv, const ndlev *C)
 static void nd_coarsen_sigma(const ndlev *Fv, ndlev *C, const int per[3])
 {
   const int *n = C->n;
+  #pragma omp parallel for
   for (int k = 0; k < (C->dm == 2 ? 1 : n[2]); k++) for (int j = 0; j < n[1]; j++) for (int i = 0; i < n[0]; i++) {
     double s = 0.0;
     if (C->dm == 2) {
@@ -342,6 +422,7 @@ static void nd_coarsen_sigma(const ndlev *Fv, ndlev *C, const int per[3])
 static void nd_set_mask(ndlev *L, const int ellbc[3][2])
 {
   const int *n = L->n;
+  #pragma omp parallel for
   for (int k = 0; k <= n[2]; k++) for (int j = 0; j <= n[1]; j++) for (int i = 0; i <= n[0]; i++) {
     int q[3] = { i, j, k }, dflag = 0;
     for (int d = 0; d < L->dm; d++) {

@@ -142,7 +142,7 @@ static void cc_gsrb(cclev *L, const int per[3], int nsweeps)
   const int *n = L->n;
   for (int s = 0; s < nsweeps; s++) for (int color = 0; color < 2; color++) {
     cc_fill_periodic(L, per);
-    #pragma omp parallel for
+    #pragma omp parallel for collapse(2) schedule(static)
     for (int k = 0; k < n[2]; k++) for (int j = 0; j < n[1]; j++)
       for (int i = (j + k + color) & 1; i < n[0]; i += 2) {
         double Ap, diag; cc_apply(L, i, j, k, &Ap, &diag);
@@ -155,7 +155,7 @@ static double cc_residual(cclev *L, const int per[3])
 {
   const int *n = L->n; double nrm = 0.0;
   cc_fill_periodic(L, per);
-  #pragma omp parallel for reduction(max : nrm)
+  #pragma omp parallel for collapse(2) schedule(static) reduction(max : nrm)
   for (int k = 0; k < n[2]; k++) for (int j = 0; j < n[1]; j++) for (int i = 0; i < n[0]; i++) {
     double Ap, diag; cc_apply(L, i, j, k, &Ap, &diag);
     double r = CC(L, L->rh, i, j, k) - Ap;
