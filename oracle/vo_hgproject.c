@@ -379,9 +379,20 @@ static void nd_restrict(const ndlev *Fv, ndlev *C)
       C->b[NN(C, i, j, k)] = s * 0.25;
       continue;
     }
-    if (!C->dir[NM(C, i, j, k)])
-      for (int c = -1; c <= 1; c++) for (int b = -1; b <= 1; b++) for (int a = -1; a <= 1; a++)
-        s = s + (wt[a + 1] * wt[b + 1] * wt[c + 1]) * Fv->res[NN(Fv, 2 * i + a, 2 * j + b, 2 * k + c)];
+    /* full weighting, separably and in this order (round 4; HIP: nd_fw27): along x on each of the nine lines, X = (0.5 r[-1] + r[0]) + 0.5 r[+1]; along z on
+     * each of the three rows of X; along y last -- the order in which the HIP residual march can form the sums from the lanes and planes it holds */
+    if (!C->dir[NM(C, i, j, k)]) {
+      double xz[3];
+      for (int b = -1; b <= 1; b++) {
+        double x[3];
+        for (int c = -1; c <= 1; c++) {
+          const double *q = Fv->res + NN(Fv, 2 * i, 2 * j + b, 2 * k + c);
+          x[c + 1] = (0.5 * q[-1] + q[0]) + 0.5 * q[1];
+        }
+        xz[b + 1] = (0.5 * x[0] + x[1]) + 0.5 * x[2];
+      }
+      s = (0.5 * xz[0] + xz[1]) + 0.5 * xz[2];
+    }
     C->b[NN(C, i, j, k)] = s * 0.125;
   }
 }

@@ -205,7 +205,7 @@ def test_hgproject(gpu, oracle, bcname, proj_type):
 def test_multigrid_launch_variants_agree_bit_for_bit(gpu):
     """the launch-saving forms of the V-cycles change no value: a 128^3 step (the finest MAC level takes the paired density pass only from
     128 cells up) with (a) the defaults -- prolongation added inside the first post-smoothing sweep (kk_cc_gsrb_rho_pair_t), restriction inside the
-    residual pass (kk_cc_residual_rho_pair_rst), the 16^3 .. 64^3 levels of the cell-centred solver as one LDS-tiled launch down and one up (kk_cc_lds_down /
+    residual pass (kk_cc_residual_rho_pair_rst; nodal: the x- and z-sums of the full weighting inside the residual march, kk_nd_march_pair_rst + kk_nd_rst_y), the 16^3 .. 64^3 levels of the cell-centred solver as one LDS-tiled launch down and one up (kk_cc_lds_down /
     kk_cc_lds_up), the levels of
     at most 9^3 nodes / 8^3 cells in one single-workgroup launch (kk_*_tailcycle), V-cycles replayed as hipGraphs -- against (b) the
     plain sequence of launches, with the rh / phi / coeffs / beta multifabs of hgproject and macproject as the reference has them (VDN_HG_FAST=0, VDN_MAC_FAST=0), whole-array zero fills
@@ -229,11 +229,11 @@ def test_multigrid_launch_variants_agree_bit_for_bit(gpu):
             h.update(np.ascontiguousarray(m.to_numpy()).tobytes())
         print("HASH", h.hexdigest(), G.dt)
     """ % root)
-    switches = ("VDN_MG_PROLONG_FUSED", "VDN_MG_RESTRICT_FUSED", "VDN_MG_TAILCYCLE", "VDN_MG_LDS", "VDN_NO_GRAPHS", "VDN_HG_FAST", "VDN_MAC_FAST", "VDN_ND_LEAN", "VDN_NO_FORCE_REUSE", "VDN_GOD_UPDATE", "VDN_GOD_P2")
+    switches = ("VDN_MG_PROLONG_FUSED", "VDN_MG_RESTRICT_FUSED", "VDN_MG_TAILCYCLE", "VDN_MG_LDS", "VDN_NO_GRAPHS", "VDN_HG_FAST", "VDN_MAC_FAST", "VDN_ND_LEAN", "VDN_NO_FORCE_REUSE", "VDN_GOD_UPDATE", "VDN_GOD_P2", "VDN_ND_RESTRICT_FUSED")
     for n, visc in ((128, 0.0), (64, 0.01)):
         out = []
         for extra in ({}, {"VDN_MG_PROLONG_FUSED": "0", "VDN_MG_RESTRICT_FUSED": "0", "VDN_MG_TAILCYCLE": "0", "VDN_MG_LDS": "0", "VDN_NO_GRAPHS": "1",
-                          "VDN_HG_FAST": "0", "VDN_MAC_FAST": "0", "VDN_ND_LEAN": "0", "VDN_NO_FORCE_REUSE": "1", "VDN_GOD_UPDATE": "0", "VDN_GOD_P2": "0"}):
+                          "VDN_HG_FAST": "0", "VDN_MAC_FAST": "0", "VDN_ND_LEAN": "0", "VDN_NO_FORCE_REUSE": "1", "VDN_GOD_UPDATE": "0", "VDN_GOD_P2": "0", "VDN_ND_RESTRICT_FUSED": "0"}):
             env = dict(os.environ)
             for k in switches:
                 env.pop(k, None)

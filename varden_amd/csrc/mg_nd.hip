@@ -316,6 +316,134 @@ __global__ void __launch_bounds__(64 * ROWS) kk_nd_march_pair(NLev L, const doub
   if (MODE == 1 && nrm) block_atomic_max(nrm, rmax);
 }
 
+// Full weighting (P^T / 8 up to the factor 0.125 applied by the caller) of the 27 residuals around r[0], SEPARABLY and in this order (round 4; oracle:
+// nd_restrict): along x on each of the nine lines, X = (0.5 r[-1] + r[0]) + 0.5 r[+1]; along z on each of the three rows, (0.5 X[k-1] + X[k]) + 0.5 X[k+1];
+// along y last.  The residual march of a wide one-box level forms the x- and z-sums from the lanes and planes it holds anyway and never stores the
+// residual (kk_nd_march_pair_rst); this function is the same arithmetic from the stored residual (narrow, multi-box, periodic levels; the nested iteration).
+DEVI double nd_fw3(double m, double c, double p) { return (0.5 * m + c) + 0.5 * p; }
+DEVI double nd_fw27(const double *__restrict__ r, long sy, long sz) {
+  double xz[3];
+  #pragma unroll
+  for (int b = -1; b <= 1; b++) {
+    double x[3];
+    #pragma unroll
+    for (int c = -1; c <= 1; c++) { const double *q = r + b * sy + c * sz; x[c + 1] = nd_fw3(q[-1], q[0], q[1]); }
+    xz[b + 1] = nd_fw3(x[0], x[1], x[2]);
+  }
+  return nd_fw3(xz[0], xz[1], xz[2]);
+}
+// ---- residual + full weighting in one march (round 4) -------------------------------------------------------------------------------------
+// The V-cycle's residual is read once more by the restriction and by nothing else.  Here the residual march of a wide ONE-BOX, non-periodic level keeps
+// it in registers: per plane a thread forms X = (0.5 r[ia-1] + r[ia]) + 0.5 r[ia+1] for its coarse column I = ia / 2 (r[ia-1] is the previous lane's
+// node B -- also the feed lane's, whose node-B stencil is complete), every second plane Z = (0.5 X[2K-1] + X[2K]) + 0.5 X[2K+1], and stores Z for
+// every FINE row j into T(I, j, K) -- a quarter of the level, kept in the level's residual array, which is otherwise unused now; kk_nd_rst_y
+// finishes along y.  The order of nd_fw27 / the oracle's nd_restrict, hence the same bits as the unfused pair (tests: the variants test).
+// Slabs hold whole coarse planes Ka .. Kb, i.e. fine planes 2Ka-1 .. 2Kb+1: neighbouring slabs both evaluate the odd plane between them.
+// Saves the 8 B/node store and the restriction's 8 B/node load + launch: 0.143 + 0.052 -> ms per cycle at 257^3 see DESIGN section 11.
+template <int ROWS>
+__global__ void __launch_bounds__(64 * ROWS) kk_nd_march_pair_rst(NLev L, const double *__restrict__ phi, double *__restrict__ T, NdPairGrid G, double *nrm) {
+  const int lane = threadIdx.x;
+  const int id = (int)blockIdx.x;
+  int lw, pair0, j, bz;
+  if (id < G.nmain) {
+    const int q = G.nmain >> 3, r = G.nmain & 7, x = id & 7, slot = id >> 3;
+    const int t = (x < r) ? x * (q + 1) + slot : r * (q + 1) + (x - r) * q + slot;
+    lw = 6; pair0 = (t % G.gxm) * 62; j = ((t / G.gxm) % G.gy) * ROWS + (int)threadIdx.y; bz = t / (G.gxm * G.gy);
+  } else {
+    const int t = id - G.nmain;
+    lw = G.lwr; pair0 = G.gxm * 62; j = (((t % G.gyr) * ROWS + (int)threadIdx.y) << (6 - lw)) + (lane >> lw); bz = t / G.gyr;
+  }
+  const int seg = 1 << lw, sl = lane & (seg - 1);
+  const int ia = 2 * (pair0 + sl - 1);
+  const int ncp = L.n[2] / 2 + 1;                                        // coarse planes
+  const int Ka = (int)(((long)bz * ncp) / G.gz), Kb = (int)(((long)(bz + 1) * ncp) / G.gz) - 1;
+  const bool own = sl >= 1 && sl <= seg - 2 && j <= L.n[1];
+  const bool actA = own && ia <= L.n[0], actB = own && ia + 1 <= L.n[0];
+  const bool feedB = sl <= seg - 2 && j <= L.n[1] && ia + 1 >= 0 && ia + 1 <= L.n[0];      // node B's residual is complete on this lane (the feed lane 0 included)
+  const int iac = min(max(ia, -16), L.PX - 18), jc = min(j, L.n[1]);
+  double rmax = 0.0;
+  if (Ka <= Kb) {
+    const int kf = max(2 * Ka - 1, 0), kl = min(2 * Kb + 1, L.n[2]);
+    const long sy = L.PX, sz = (long)L.PX * L.PY;
+    long c = nidx(L, iac, jc, kf);
+    const int NI = L.n[0] / 2 + 1;
+    double *tp = T + ((long)Ka * (L.n[1] + 1) + jc) * NI + min(max(ia, 0), L.n[0]) / 2;
+    const long tstep = (long)(L.n[1] + 1) * NI;
+    double q[3][3][4], sg[2][2][3];
+    #define LOADP(pl, off) { _Pragma("unroll") for (int b = 0; b < 3; b++) { const double2 v = ld2(phi + (off) + (b - 1) * sy); q[pl][b][1] = v.x; q[pl][b][2] = v.y; } }
+    #define EXCHP(pl) { _Pragma("unroll") for (int b = 0; b < 3; b++) { q[pl][b][0] = lane_prev(q[pl][b][2]); q[pl][b][3] = lane_next(q[pl][b][1]); } }
+    #define LOADS(dk, off) { _Pragma("unroll") for (int dj = 0; dj < 2; dj++) { const double2 v = ld2(L.sig + (off) + (dj - 1) * sy); sg[dk][dj][1] = v.x; sg[dk][dj][2] = v.y; } }
+    #define EXCHS(dk) { _Pragma("unroll") for (int dj = 0; dj < 2; dj++) sg[dk][dj][0] = lane_prev(sg[dk][dj][2]); }
+    LOADP(0, c - sz) LOADP(1, c) LOADS(0, c - sz)
+    EXCHP(0) EXCHP(1) EXCHS(0)
+    const bool dirj = (j == 0 && L.dirlo[1]) || (j == L.n[1] && L.dirhi[1]);
+    const bool dirA_ij = dirj || (ia == 0 && L.dirlo[0]) || (ia == L.n[0] && L.dirhi[0]);
+    const bool dirB_ij = dirj || (ia + 1 == L.n[0] && L.dirhi[0]);
+    const NdW W = nd_weights(L.f);
+    double Xm = 0.0, X0 = 0.0;                                           // X on the planes 2K-1 and 2K of the coarse plane being assembled
+    for (int k = kf; k <= kl; k++, c += sz) {
+      LOADP(2, c + sz) LOADS(1, c)
+      const double2 rhs = ld2(L.b + c);
+      EXCHP(2) EXCHS(1)
+      const bool dirk = (k == 0 && L.dirlo[2]) || (k == L.n[2] && L.dirhi[2]);
+      double pa[3][3][3], pb[3][3][3], sa[2][2][2], sb[2][2][2];
+      #pragma unroll
+      for (int pl = 0; pl < 3; pl++)
+        #pragma unroll
+        for (int b = 0; b < 3; b++)
+          #pragma unroll
+          for (int a = 0; a < 3; a++) { pa[pl][b][a] = q[pl][b][a]; pb[pl][b][a] = q[pl][b][a + 1]; }
+      #pragma unroll
+      for (int dk = 0; dk < 2; dk++)
+        #pragma unroll
+        for (int dj = 0; dj < 2; dj++)
+          #pragma unroll
+          for (int a = 0; a < 2; a++) { sa[dk][dj][a] = sg[dk][dj][a]; sb[dk][dj][a] = sg[dk][dj][a + 1]; }
+      double KpA, dgA, KpB, dgB;
+      nd_stencil(W, pa, sa, KpA, dgA);
+      nd_stencil(W, pb, sb, KpB, dgB);
+      const double rA = (!actA || dirA_ij || dirk) ? 0.0 : rhs.x - KpA;
+      const double rB = (!feedB || dirB_ij || dirk) ? 0.0 : rhs.y - KpB;
+      if (actA) rmax = nmax(rmax, fabs(rA));
+      if (actB) rmax = nmax(rmax, fabs(rB));
+      const double X = nd_fw3(lane_prev(rB), rA, rB);
+      if (k & 1) {                                                       // uniform: plane 2K+1 completes coarse plane K = (k - 1) / 2 and opens K + 1
+        if (((k - 1) >> 1) >= Ka) { if (actA) *tp = nd_fw3(Xm, X0, X); tp += tstep; }
+        Xm = X;
+      } else X0 = X;
+      #pragma unroll
+      for (int b = 0; b < 3; b++)
+        #pragma unroll
+        for (int a = 0; a < 4; a++) { q[0][b][a] = q[1][b][a]; q[1][b][a] = q[2][b][a]; }
+      #pragma unroll
+      for (int dj = 0; dj < 2; dj++)
+        #pragma unroll
+        for (int a = 0; a < 3; a++) sg[0][dj][a] = sg[1][dj][a];
+    }
+    if (!(kl & 1) && actA) *tp = nd_fw3(Xm, X0, 0.0);                     // the level's last plane n2 = 2 Kb is even: plane n2 + 1 holds no residual
+    #undef LOADP
+    #undef EXCHP
+    #undef LOADS
+    #undef EXCHS
+  }
+  if (nrm) block_atomic_max(nrm, rmax);
+}
+// the y-sums of the fused residual + restriction: T(I, j, K) -> b of the coarse level, phi of the coarse level := 0 (as kk_nd_restrict)
+__global__ void kk_nd_rst_y(NLev F, const double *__restrict__ T, NLev C) {
+  NODE_IJK(C)
+  if (!in_range) return;
+  double s = 0.0;
+  if (!nd_is_dir(C, i, j, k)) {
+    const int NI = F.n[0] / 2 + 1;
+    const double *t = T + ((long)k * (F.n[1] + 1) + 2 * j) * NI + i;
+    const double tm = (2 * j - 1 >= 0) ? t[-NI] : 0.0, tp = (2 * j + 1 <= F.n[1]) ? t[NI] : 0.0;
+    s = nd_fw3(tm, t[0], tp);
+  }
+  const long cn = nidx(C, i, j, k);
+  C.b[cn] = s * 0.125;
+  C.phi[cn] = 0.0;
+}
+
 // (measured and rejected: a plane-per-workgroup form of the paired sweep -- a workgroup owns a 124 x 4 patch of ONE k-plane, the planes
 // shared through the XCD's L2 like the cell-centred colour pass, 14 sixteen-byte loads per pair of nodes: 0.224 ms against 0.150 ms)
 // ---- halo exchange next to a sweep ----------------------------------------------------------------------------
@@ -396,15 +524,7 @@ __global__ void kk_nd_restrict(NLev F, NLev C) {
   if (!nd_is_dir(C, i, j, k)) {
     const long sy = F.PX, sz = (long)F.PX * F.PY;
     const long f0 = nidx(F, 2 * i, 2 * j, 2 * k);
-    #pragma unroll
-    for (int c = -1; c <= 1; c++)
-      #pragma unroll
-      for (int b = -1; b <= 1; b++)
-        #pragma unroll
-        for (int a = -1; a <= 1; a++) {
-          const double wa = a ? 0.5 : 1.0, wb = b ? 0.5 : 1.0, wc = c ? 0.5 : 1.0;
-          s = s + (wa * wb * wc) * F.res[f0 + a + b * sy + c * sz];
-        }
+    s = nd_fw27(F.res + f0, sy, sz);
   }
   const long cn = nidx(C, i, j, k);
   C.b[cn] = s * 0.125;
@@ -588,15 +708,7 @@ DEVI void wg_nd_down(const NLev &F, double *fphi, const NLev &C, double *cphi) {
     double s = 0.0;
     if (!nd_is_dir(C, i, j, k)) {
       const long f0 = nidx(F, 2 * i, 2 * j, 2 * k);
-      #pragma unroll
-      for (int c = -1; c <= 1; c++)
-        #pragma unroll
-        for (int b = -1; b <= 1; b++)
-          #pragma unroll
-          for (int a = -1; a <= 1; a++) {
-            const double wa = a ? 0.5 : 1.0, wb = b ? 0.5 : 1.0, wc = c ? 0.5 : 1.0;
-            s = s + (wa * wb * wc) * F.res[f0 + a + b * sy + c * sz];
-          }
+      s = nd_fw27(F.res + f0, sy, sz);
     }
     const long cn = nidx(C, i, j, k);
     C.b[cn] = s * 0.125;
@@ -764,15 +876,7 @@ __global__ void kk_nd_restrict_pack(NLev F, NLev Cf /* flags + extents of the co
   if (!nd_is_dir(Cf, i, j, k)) {
     const long sy = F.PX, sz = (long)F.PX * F.PY;
     const long f0 = nidx(F, 2 * i, 2 * j, 2 * k);
-    #pragma unroll
-    for (int c = -1; c <= 1; c++)
-      #pragma unroll
-      for (int b = -1; b <= 1; b++)
-        #pragma unroll
-        for (int a = -1; a <= 1; a++) {
-          const double wa = a ? 0.5 : 1.0, wb = b ? 0.5 : 1.0, wc = c ? 0.5 : 1.0;
-          s = s + (wa * wb * wc) * F.res[f0 + a + b * sy + c * sz];
-        }
+    s = nd_fw27(F.res + f0, sy, sz);
   }
   buf[off + i + (long)(Cf.n[0] + 1) * (j + (long)(Cf.n[1] + 1) * k)] = s * 0.125;
 }
@@ -815,6 +919,23 @@ __global__ void kk_nd_prolong_tail(NLev F, NLev T, int c00, int c01, int c02, in
 static const dim3 NBLK(64, 4, 1);
 static dim3 ng3(int nx, int ny, int nz) { return dim3((nx + 63) / 64, (ny + 3) / 4, nz); }
 
+// tiles and k-slabs of the paired march over `nzu` k-units (planes of the level for a sweep, coarse planes for the fused residual + restriction)
+static NdPairGrid nd_pair_grid(const NLev &L, int rows, int nzu, bool use_rem, int minwg, int kc_env) {
+  const int npair = (L.n[0] + 2) / 2;
+  NdPairGrid G;
+  G.gxm = npair / 62; G.gy = (L.n[1] + rows) / rows;
+  const int rem = npair - 62 * G.gxm;
+  G.lwr = 6; G.gyr = 0;
+  if (rem > 0 && use_rem) { G.lwr = 2; while ((1 << G.lwr) - 2 < rem) G.lwr++; G.gyr = (L.n[1] + (rows << (6 - G.lwr))) / (rows << (6 - G.lwr)); }
+  else if (rem > 0) G.gxm++;
+  const int tiles = G.gxm * G.gy + G.gyr;
+  int kc = nzu;
+  while (kc > 8 && tiles * ((nzu + kc - 1) / kc) < minwg) kc = (kc + 1) / 2;
+  if (kc_env > 0) kc = std::min(kc_env, nzu);
+  G.gz = std::max(1, (nzu + kc - 1) / kc);      // balanced slabs of at most kc planes (257 planes: 16 slabs of 16 or 17 -- measured 0.1396 ms against 0.1443 with 15 slabs)
+  G.nmain = G.gxm * G.gy * G.gz;
+  return G;
+}
 // slab thickness: enough workgroups to fill 256 CUs several times over, yet long enough marches to amortise the
 // two warm-up planes (overhead 2/kchunk)
 template <int MODE> static void nd_launch_march(const NLev &L, const double *phi, double *out, double *nrm, int shell_later = 0) {
@@ -829,19 +950,7 @@ template <int MODE> static void nd_launch_march(const NLev &L, const double *phi
     static const bool use_rem = !(getenv("VDN_ND_REM") && atoi(getenv("VDN_ND_REM")) == 0);
     static const int minwg = getenv("VDN_ND_MINWG") ? atoi(getenv("VDN_ND_MINWG")) : 2048;
     static const int kc_env = getenv("VDN_ND_KC") ? atoi(getenv("VDN_ND_KC")) : 0;
-    const int npair = (L.n[0] + 2) / 2;
-    NdPairGrid G;
-    G.gxm = npair / 62; G.gy = (L.n[1] + rows) / rows;
-    const int rem = npair - 62 * G.gxm;
-    G.lwr = 6; G.gyr = 0;
-    if (rem > 0 && use_rem) { G.lwr = 2; while ((1 << G.lwr) - 2 < rem) G.lwr++; G.gyr = (L.n[1] + (rows << (6 - G.lwr))) / (rows << (6 - G.lwr)); }
-    else if (rem > 0) G.gxm++;
-    const int tiles = G.gxm * G.gy + G.gyr;
-    int kc = nzp;
-    while (kc > 8 && tiles * ((nzp + kc - 1) / kc) < minwg) kc = (kc + 1) / 2;
-    if (kc_env > 0) kc = std::min(kc_env, nzp);
-    G.gz = std::max(1, (nzp + kc - 1) / kc);      // balanced slabs of at most kc planes (257 planes: 16 slabs of 16 or 17 -- measured 0.1396 ms against 0.1443 with 15 slabs)
-    G.nmain = G.gxm * G.gy * G.gz;
+    const NdPairGrid G = nd_pair_grid(L, rows, nzp, use_rem, minwg, kc_env);
     hipLaunchKernelGGL((kk_nd_march_pair<MODE, 4>), dim3(G.nmain + G.gyr * G.gz), NBLK, 0, ctx().stream, L, phi, out, nd_cur_omega(), G, nrm, shell_later);
     return;
   }
@@ -849,7 +958,8 @@ template <int MODE> static void nd_launch_march(const NLev &L, const double *phi
 }
 
 struct NBox { NLev L; int lo[3]; int hmask = 63; XPlan *hA = nullptr, *hB = nullptr; double *A = nullptr, *B = nullptr; };
-struct NDLev { std::vector<NBox> boxes; XPlan *halo_A = nullptr, *halo_B = nullptr, *halo_res = nullptr, *halo_sig = nullptr; int ng[3]; bool flip = false; bool single_box = false; int per[3] = {0, 0, 0}; };
+struct NDLev { std::vector<NBox> boxes; XPlan *halo_A = nullptr, *halo_B = nullptr, *halo_res = nullptr, *halo_sig = nullptr; int ng[3]; bool flip = false; bool single_box = false; int per[3] = {0, 0, 0};
+               bool res_restricted = false; /* the last residual pass left the x- and z-sums of the full weighting in res (kk_nd_march_pair_rst): nd_restrict_down finishes along y */ };
 struct NDMG {
   std::vector<NDLev> dlev; std::vector<NLev> tail; int per[3]; double *d_nrm;
   std::vector<NGBox> gb; NGBox *d_gb = nullptr;
@@ -1069,6 +1179,23 @@ static void nd_jacobi_d(NDLev &DL, int nsweeps, bool pre = false) {
 }
 static void nd_residual_d(NDMG &M, NDLev &DL, bool norm, bool reduce = true) {     // reduce = false: the norm stays rank-local (it goes into the norm history, made global when that is read)
   if (norm) HIPCHK(hipMemsetAsync(M.d_nrm, 0, sizeof(double), ctx().stream));
+  DL.res_restricted = false;
+  {   // a wide one-box level without periodic images whose next level is one box too: residual and the x / z part of the restriction in one march
+    static const bool fuse = !(getenv("VDN_ND_RESTRICT_FUSED") && atoi(getenv("VDN_ND_RESTRICT_FUSED")) == 0);
+    static const bool paired = !(getenv("VDN_ND_PAIR") && atoi(getenv("VDN_ND_PAIR")) == 0);
+    const size_t l = &DL - &M.dlev[0];
+    if (fuse && paired && DL.single_box && DL.boxes.size() == 1 && !DL.halo_res && !(DL.per[0] || DL.per[1] || DL.per[2]) && l + 1 < M.dlev.size() && M.dlev[l + 1].boxes.size() == 1) {
+      const NLev &L = DL.boxes[0].L;
+      if (L.n[0] >= 127 && L.n[0] % 2 == 0 && L.n[1] % 2 == 0 && L.n[2] % 2 == 0) {
+        nd_halo_phi(DL);                                                  // (no neighbour, no image: nothing to exchange; kept for symmetry with the plain path)
+        const NdPairGrid G = nd_pair_grid(L, 4, L.n[2] / 2 + 1, true, 2048, 0);
+        hipLaunchKernelGGL((kk_nd_march_pair_rst<4>), dim3(G.nmain + G.gyr * G.gz), NBLK, 0, ctx().stream, L, (const double *)L.phi, L.res, G, norm ? M.d_nrm : nullptr);
+        DL.res_restricted = true;
+        if (norm && reduce) comm_allreduce_max_dev(M.d_nrm, 1);
+        return;
+      }
+    }
+  }
   const bool ov = nd_halo_begin(DL);
   for (NBox &B : DL.boxes)
     nd_launch_march<1>(B.L, B.L.phi, B.L.res, norm ? M.d_nrm : nullptr, ov ? B.hmask : 0);
@@ -1132,8 +1259,10 @@ static void nd_restrict_down(NDMG &M, int l) {
     NDLev &DC = M.dlev[l + 1];
     for (size_t b = 0; b < DL.boxes.size(); b++) {
       NLev &C = DC.boxes[b].L;
-      hipLaunchKernelGGL(kk_nd_restrict, ng3(C.n[0] + 1, C.n[1] + 1, C.n[2] + 1), NBLK, 0, ctx().stream, DL.boxes[b].L, C);
+      if (DL.res_restricted) hipLaunchKernelGGL(kk_nd_rst_y, ng3(C.n[0] + 1, C.n[1] + 1, C.n[2] + 1), NBLK, 0, ctx().stream, DL.boxes[b].L, (const double *)DL.boxes[b].L.res, C);
+      else hipLaunchKernelGGL(kk_nd_restrict, ng3(C.n[0] + 1, C.n[1] + 1, C.n[2] + 1), NBLK, 0, ctx().stream, DL.boxes[b].L, C);
     }
+    DL.res_restricted = false;
   } else {
     NLev &T = M.tail[0];
     const int nb = (int)M.gb.size() / 2;
@@ -1261,6 +1390,7 @@ static void nd_fmg(NDMG &M) {
     if (g < nd) {
       NDLev &DL = M.dlev[g];
       for (NBox &B : DL.boxes) hipLaunchKernelGGL(kk_nd_copy_b_res, ng3(B.L.n[0] + 1, B.L.n[1] + 1, B.L.n[2] + 1), NBLK, 0, st, B.L);
+      DL.res_restricted = false;                                          // (res holds b itself: the plain restriction)
       if (DL.halo_res) xplan_run(DL.halo_res);
       nd_restrict_down(M, g);
       if (g + 1 == nd) HIPCHK(hipMemsetAsync(M.tail[0].phi, 0, sizeof(double) * M.tail[0].sz, st));      // (the gather fills b only)
@@ -1293,7 +1423,7 @@ static unsigned long long nd_graph_key(const NDMG &M, int what) {
   GraphKey k; k.put(what); k.put(P.hg_nu1); k.put(P.hg_nu2); k.put(P.hg_nub); k.put(P.hg_omega); k.put(P.hg_omega_pre1); k.put(P.hg_omega_pre2); k.put(M.per); k.put(M.d_nrm);
   k.put(M.sendbuf); k.put(M.recvbuf); k.put(M.d_gb); k.put(M.cnt_nodes); k.put(M.cnt_cells);
   for (const NDLev &DL : M.dlev) {
-    k.put(xplan_serial(DL.halo_A)); k.put(xplan_serial(DL.halo_B)); k.put(xplan_serial(DL.halo_res)); k.put(xplan_serial(DL.halo_sig)); k.put(DL.ng); k.put(DL.flip); k.put(DL.single_box); k.put(DL.per);
+    k.put(xplan_serial(DL.halo_A)); k.put(xplan_serial(DL.halo_B)); k.put(xplan_serial(DL.halo_res)); k.put(xplan_serial(DL.halo_sig)); k.put(DL.ng); k.put(DL.flip); k.put(DL.single_box); k.put(DL.per); k.put(DL.res_restricted);
     for (const NBox &B : DL.boxes) { nd_key_lev(k, B.L); k.put(B.lo); k.put(B.A); k.put(B.B); k.put(B.hmask); k.put(xplan_serial(B.hA)); k.put(xplan_serial(B.hB)); }
   }
   for (const NLev &L : M.tail) nd_key_lev(k, L);
