@@ -840,29 +840,49 @@ __global__ void kk_nd_load_sigma_rho(NLev L, FV rhohalf, int lo0, int lo1, int l
   L.sig[nidx(L, i, j, k)] = in ? 1.0 / fv_get(rhohalf, lo0 + i, lo1 + j, lo2 + k, 0) : 0.0;     // coeffs_K's expression
 }
 // b = -(0 + D u), phi = 0, max |rhs|: nd_divu_node on a zero rh followed by kk_nd_load on a zero phi, without the two multifabs in between
-__global__ void kk_nd_load_divu(NLev L, FV u, double fx, double fy, double fz, int lo0, int lo1, int lo2, double *nrm) {
+// Round 4: a k-march.  A thread keeps the values of its column (cells (i, j) and (i, j-1)) of plane k-1 in registers, loads the two of plane k and takes
+// the cells (i-1, .) from the lane before it (lane 0 of a row loads them): 6 loads per node instead of 24 (0.38 -> ms at 257^3, the gather form was bound
+// by the texture addresser like every other stencil kernel that reads its neighbours through the L1).  The sums are formed in the order of nd_divu_K.
+__global__ void __launch_bounds__(256) kk_nd_load_divu(NLev L, FV u, double fx, double fy, double fz, int lo0, int lo1, int lo2, double *nrm) {
+  const int lane = threadIdx.x;
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   const int j = blockIdx.y * blockDim.y + threadIdx.y;
+  const int nzp = L.n[2] + 1;
+  const int k0 = (int)(((long)blockIdx.z * nzp) / gridDim.z), k1 = (int)(((long)(blockIdx.z + 1) * nzp) / gridDim.z) - 1;
   double rmax = 0.0;
-  if (i <= L.n[0] && j <= L.n[1])
-    for (int k = blockIdx.z; k <= L.n[2]; k += gridDim.z) {
-      const int gi = lo0 + i, gj = lo1 + j, gk = lo2 + k;
-      #define U(a, b, c, m) fv_get(u, gi + (a), gj + (b), gk + (c), m)
-      const double dux = (((U(0, 0, 0, 0) + U(0, -1, 0, 0)) + U(0, 0, -1, 0)) + U(0, -1, -1, 0))
-                       - (((U(-1, 0, 0, 0) + U(-1, -1, 0, 0)) + U(-1, 0, -1, 0)) + U(-1, -1, -1, 0));
-      const double duy = (((U(0, 0, 0, 1) + U(-1, 0, 0, 1)) + U(0, 0, -1, 1)) + U(-1, 0, -1, 1))
-                       - (((U(0, -1, 0, 1) + U(-1, -1, 0, 1)) + U(0, -1, -1, 1)) + U(-1, -1, -1, 1));
-      const double duz = (((U(0, 0, 0, 2) + U(-1, 0, 0, 2)) + U(0, -1, 0, 2)) + U(-1, -1, 0, 2))
-                       - (((U(0, 0, -1, 2) + U(-1, 0, -1, 2)) + U(0, -1, -1, 2)) + U(-1, -1, -1, 2));
-      #undef U
+  if (k0 <= k1) {                                                       // uniform
+    const int ic = min(i, L.n[0]), jc = min(j, L.n[1]);                 // (lanes beyond the level load a valid column and store nothing)
+    const bool act = i <= L.n[0] && j <= L.n[1];
+    const long sp = (long)u.n0 * u.n1;
+    const double *pc = u.p + fv_idx(u, lo0 + ic, lo1 + jc, lo2 + k0 - 1);   // cell (i, j, k0 - 1) of component 0
+    const long dj = -(long)u.n0;
+    // [m][0] = u(i, j), [m][1] = u(i, j-1), [m][2] = u(i-1, j), [m][3] = u(i-1, j-1) of the plane below
+    double lo[3][4], hi[3][4];
+    #define LOADPL(dst, q) { _Pragma("unroll") for (int m = 0; m < 3; m++) { dst[m][0] = (q)[m * u.sc]; dst[m][1] = (q)[m * u.sc + dj]; }                                   \
+                             _Pragma("unroll") for (int m = 0; m < 3; m++) { dst[m][2] = lane_prev(dst[m][0]); dst[m][3] = lane_prev(dst[m][1]); }                            \
+                             if (lane == 0) { _Pragma("unroll") for (int m = 0; m < 3; m++) { dst[m][2] = (q)[m * u.sc - 1]; dst[m][3] = (q)[m * u.sc + dj - 1]; } } }
+    LOADPL(lo, pc)
+    const bool dir_ij = (i == 0 && L.dirlo[0]) || (i == L.n[0] && L.dirhi[0]) || (j == 0 && L.dirlo[1]) || (j == L.n[1] && L.dirhi[1]);
+    long c = nidx(L, ic, jc, k0);
+    const long cz = (long)L.PX * L.PY;
+    for (int k = k0; k <= k1; k++, c += cz) {
+      pc += sp;
+      LOADPL(hi, pc)
+      // U(a, b, c, m): a = 0 / -1 -> index 0,1 / 2,3;  b = 0 / -1 -> even / odd index;  c = 0 -> hi, -1 -> lo
+      const double dux = (((hi[0][0] + hi[0][1]) + lo[0][0]) + lo[0][1]) - (((hi[0][2] + hi[0][3]) + lo[0][2]) + lo[0][3]);
+      const double duy = (((hi[1][0] + hi[1][2]) + lo[1][0]) + lo[1][2]) - (((hi[1][1] + hi[1][3]) + lo[1][1]) + lo[1][3]);
+      const double duz = (((hi[2][0] + hi[2][2]) + hi[2][1]) + hi[2][3]) - (((lo[2][0] + lo[2][2]) + lo[2][1]) + lo[2][3]);
       const double rhv = 0.0 + (dux * fx + duy * fy + duz * fz);               // rh (zero) + D u
-      const bool dir = nd_is_dir(L, i, j, k);
+      const bool dir = dir_ij || (k == 0 && L.dirlo[2]) || (k == L.n[2] && L.dirhi[2]);
       const double r = dir ? 0.0 : rhv;
-      const long c = nidx(L, i, j, k);
-      L.b[c] = -r;
-      L.phi[c] = 0.0;
-      rmax = nmax(rmax, fabs(r));
+      if (act) { L.b[c] = -r; L.phi[c] = 0.0; rmax = nmax(rmax, fabs(r)); }
+      #pragma unroll
+      for (int m = 0; m < 3; m++)
+        #pragma unroll
+        for (int t = 0; t < 4; t++) lo[m][t] = hi[m][t];
     }
+    #undef LOADPL
+  }
   block_atomic_max(nrm, rmax);
 }
 
