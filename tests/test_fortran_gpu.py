@@ -56,3 +56,40 @@ def test_fortran_driver_matches_the_python_mirror(gpu, nlevs, n):
         assert abs(umax - fumax) <= 1e-12 * fumax, (istep, umax, fumax)
     assert frows[-1][3] > 0.0 and np.isfinite(frows[-1][3])
     G.close()
+
+
+MAIN = os.path.join(FDIR, "varden_main")
+
+
+def test_fortran_main_runs_the_regression_inputs_like_the_python_mirror(gpu, tmp_path):
+    """varden_main.f90 -- the flow of src/varden.f90 in Fortran: &PROBIN namelist, level 0 cut by max_grid_size, refined levels
+    from tag_boxes + make_new_grids, start-up sequence, time loop with regrid every regrid_int steps through fillpatch / ml_nodal_prolongation /
+    copies between box lists (src/regrid.f90:17-263), viscous solves -- on exec/test/inputs_3d-regt (64^3, three levels, regrid_int = 2), six
+    steps (three regrids), against varden_amd/inputs.py: run on the same file: the same boxes on every level, and time, dt, max|u| to the last digits"""
+    from varden_amd import inputs
+    if not os.path.exists(MAIN):
+        if shutil.which("amdflang") is None and not os.path.exists("/opt/rocm/lib/llvm/bin/flang"):
+            pytest.skip("no flang on this box and no prebuilt varden_main")
+        subprocess.check_call(["make", "-s", "-C", FDIR])
+    path = os.path.join(ROOT, "tests", "golden", "inputs", "inputs_3d-regt")
+    nsteps = 6
+    out = subprocess.run([MAIN, path, str(nsteps)], cwd=str(tmp_path), capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+    frows = []
+    for ln in out.stdout.splitlines():
+        m = re.match(r"\s*step\s+(\d+)\s+time\s+(\S+)\s+dt\s+(\S+)\s+\|u\|max\s+(\S+)\s+levels\s+(\d+)\s+boxes\s+(.*)", ln)
+        if m:
+            frows.append((int(m.group(1)), float(m.group(2)), float(m.group(3)), float(m.group(4)), int(m.group(5)), [int(x) for x in m.group(6).split()]))
+    assert len(frows) == nsteps, out.stdout[-3000:]
+    regrids = int(re.search(r"regrids:\s+(\d+)", out.stdout).group(1))
+    prows = []
+
+    def report(G):
+        prows.append((G.istep, G.time, G.dt, max(m.norm_inf() for m in G.unew), G.nlev, [len(b) for b in G.boxes]))
+    nl, G = inputs.run(open(path).read(), nsteps=nsteps, report=report, outdir=str(tmp_path))
+    assert regrids == G.nregrids == 3
+    for f, p in zip(frows, prows):
+        assert f[0] == p[0] and f[4] == p[4] and f[5][:p[4]] == p[5], (f, p)
+        assert abs(f[1] - p[1]) <= 1e-12 * p[1] and abs(f[2] - p[2]) <= 1e-12 * p[2] and abs(f[3] - p[3]) <= 1e-10 * p[3], (f, p)
+    assert frows[-1][4] == 3
+    G.close()
