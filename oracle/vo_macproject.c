@@ -137,11 +137,57 @@ static inline void cc_apply(const cclev *L, int i, int j, int k, double *Ap, dou
   }
 }
 
+/* A phi and the diagonal on the whole row (0 .. n0-1, j, k): cc_apply's expressions cell by cell, the loop over i with unit stride so that the compiler
+ * vectorises it (round 4).  A colour pass evaluates the row for BOTH colours and stores the cells of its colour: their neighbours are of the other
+ * colour and do not change during the pass, so the values are the ones the cell-by-cell loop computes. */
+#define CC_ROW_MAX 2048
+static inline void cc_row(const cclev *L, int j, int k, double *restrict Ap, double *restrict dg)
+{
+  const int n0 = L->n[0];
+  const long sy = n0 + 2, sz = sy * (L->n[1] + 2);
+  const double *p = &PHI(L, 0, j, k);
+  const double *bx = &BX(L, 0, j, k), *by0 = &BY(L, 0, j, k), *by1 = &BY(L, 0, j + 1, k), *bz0 = &BZ(L, 0, j, k), *bz1 = &BZ(L, 0, j, k + 1);
+  const double h0 = L->hi2[0], h1 = L->hi2[1], h2 = L->hi2[2];
+  const double *al = L->alpha ? &CC(L, L->alpha, 0, j, k) : NULL;
+  if (al) {
+    #pragma omp simd
+    for (int i = 0; i < n0; i++) {
+      const double p0 = p[i], bxm = bx[i], bxp = bx[i + 1], bym = by0[i], byp = by1[i], bzm = bz0[i], bzp = bz1[i];
+      const double ax = (bxp * (p0 - p[i + 1]) + bxm * (p0 - p[i - 1])) * h0;
+      const double ay = (byp * (p0 - p[i + sy]) + bym * (p0 - p[i - sy])) * h1;
+      const double az = (bzp * (p0 - p[i + sz]) + bzm * (p0 - p[i - sz])) * h2;
+      const double a0 = al[i];
+      Ap[i] = (ax + ay + az) + a0 * p0;
+      dg[i] = ((bxp + bxm) * h0 + (byp + bym) * h1 + (bzp + bzm) * h2) + a0;
+    }
+  } else {
+    #pragma omp simd
+    for (int i = 0; i < n0; i++) {
+      const double p0 = p[i], bxm = bx[i], bxp = bx[i + 1], bym = by0[i], byp = by1[i], bzm = bz0[i], bzp = bz1[i];
+      const double ax = (bxp * (p0 - p[i + 1]) + bxm * (p0 - p[i - 1])) * h0;
+      const double ay = (byp * (p0 - p[i + sy]) + bym * (p0 - p[i - sy])) * h1;
+      const double az = (bzp * (p0 - p[i + sz]) + bzm * (p0 - p[i - sz])) * h2;
+      Ap[i] = ax + ay + az;
+      dg[i] = (bxp + bxm) * h0 + (byp + bym) * h1 + (bzp + bzm) * h2;
+    }
+  }
+}
 static void cc_gsrb(cclev *L, const int per[3], int nsweeps)
 {
   const int *n = L->n;
   for (int s = 0; s < nsweeps; s++) for (int color = 0; color < 2; color++) {
     cc_fill_periodic(L, per);
+    if (L->dm == 3 && n[0] <= CC_ROW_MAX) {
+      #pragma omp parallel for collapse(2) schedule(static)
+      for (int k = 0; k < n[2]; k++) for (int j = 0; j < n[1]; j++) {
+        double Ap[CC_ROW_MAX], dg[CC_ROW_MAX];
+        cc_row(L, j, k, Ap, dg);
+        double *p = &PHI(L, 0, j, k); const double *rh = &CC(L, L->rh, 0, j, k);
+        for (int i = (j + k + color) & 1; i < n[0]; i += 2)
+          if (dg[i] != 0.0) p[i] = p[i] + (rh[i] - Ap[i]) / dg[i];
+      }
+      continue;
+    }
     #pragma omp parallel for collapse(2) schedule(static)
     for (int k = 0; k < n[2]; k++) for (int j = 0; j < n[1]; j++)
       for (int i = (j + k + color) & 1; i < n[0]; i += 2) {
@@ -155,6 +201,16 @@ static double cc_residual(cclev *L, const int per[3])
 {
   const int *n = L->n; double nrm = 0.0;
   cc_fill_periodic(L, per);
+  if (L->dm == 3 && n[0] <= CC_ROW_MAX) {
+    #pragma omp parallel for collapse(2) schedule(static) reduction(max : nrm)
+    for (int k = 0; k < n[2]; k++) for (int j = 0; j < n[1]; j++) {
+      double Ap[CC_ROW_MAX], dg[CC_ROW_MAX];
+      cc_row(L, j, k, Ap, dg);
+      const double *rh = &CC(L, L->rh, 0, j, k); double *out = &CC(L, L->res, 0, j, k);
+      for (int i = 0; i < n[0]; i++) { const double r = rh[i] - Ap[i]; out[i] = r; nrm = vo_nrm_acc(nrm, r); }
+    }
+    return nrm;
+  }
   #pragma omp parallel for collapse(2) schedule(static) reduction(max : nrm)
   for (int k = 0; k < n[2]; k++) for (int j = 0; j < n[1]; j++) for (int i = 0; i < n[0]; i++) {
     double Ap, diag; cc_apply(L, i, j, k, &Ap, &diag);
