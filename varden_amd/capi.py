@@ -70,6 +70,7 @@ SIGNATURES = {
     "vdn_comm_nranks": (C.c_int, [C.POINTER(C.c_int)]),
     "vdn_comm_stats": (C.c_int, [C.POINTER(C.c_long), C.c_int]),
     "vdn_comm_transport": (C.c_char_p, []),
+    "vdn_debug_switches": (C.c_char_p, []),
     "vdn_plan_describe": (C.c_int, [C.POINTER(Box), _PI, C.c_int, C.POINTER(Box), _PI, C.c_int, C.c_int, _PI, C.c_int,
                                     C.POINTER(C.c_long), C.c_int, _PI, _PI]),
     "vdn_layout_create": (C.c_int, [C.c_int, _PI, C.POINTER(Box), _PI, C.POINTER(Box), _PI, _PI, _PVP]),

@@ -65,7 +65,7 @@ extern "C" int vdn_advance_timestep(int istep, vdn_layout *mla, vdn_multifab **s
   // reference computes them twice (velpred.f90:1985-1990, mkflux.f90:1207-1212); one level of one box keeps velpred's for mkflux
   ctx().slope_src = nullptr; ctx().macmax_src = nullptr; ctx().macmax_cache = nullptr;
   for (int d = 0; d < 3; d++) ctx().slope_cache[d] = nullptr;
-  if (nlevs == 1 && dm == 3 && uold[0]->nfabs() == 1 && !getenv("VDN_NO_SLOPE_CACHE")) {
+  if (nlevs == 1 && dm == 3 && uold[0]->nfabs() == 1 && !vdn_env("VDN_NO_SLOPE_CACHE")) {
     const vdn_box &b = uold[0]->vbox[0];
     const size_t fld = (size_t)(b.hi[0] - b.lo[0] + 3) * (b.hi[1] - b.lo[1] + 3) * (b.hi[2] - b.lo[2] + 3) * sizeof(double);
     for (int d = 0; d < 3; d++) ctx().slope_cache[d] = (double *)arena_alloc(fld * 3);
@@ -78,7 +78,7 @@ extern "C" int vdn_advance_timestep(int istep, vdn_layout *mla, vdn_multifab **s
   // the same operands, at the top of velocity_advance (velocity_advance.f90:63-66; gp changes only in hgproject, sold and ext not at all; lapu is
   // zeroed in between only for diffusion_type = 2, advance_timestep.f90:116-120).  Unless that is the case the first one is kept for the
   // velocity mkflux (0.32 ms of a 41 ms step at 256^3): the same values, as with the limited slopes above.
-  static const bool force_reuse = !(getenv("VDN_NO_FORCE_REUSE") && atoi(getenv("VDN_NO_FORCE_REUSE")) != 0);
+  static const bool force_reuse = !(vdn_env("VDN_NO_FORCE_REUSE") && atoi(vdn_env("VDN_NO_FORCE_REUSE")) != 0);
   const bool keep_vel_force = force_reuse && !(viscous && P.diffusion_type == 2);
   vdn_multifab *vel_force0[VDN_MAXLEV] = { nullptr };
   if (keep_vel_force) for (int n = 0; n < nlevs; n++) vel_force0[n] = mf_temp(mla, n, dm, 1, -1, false, 0.0);

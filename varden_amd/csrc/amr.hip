@@ -686,7 +686,7 @@ static void fill_phi_ghosts(MLCC &S) {
 static double composite_residual(MLCC &S, bool want_norm = true, int lowest = 0) {
   hipStream_t st = ctx().stream;
   const int L = S.nlev;
-  static const bool partial = !(getenv("VDN_MLCC_PARTIAL") && atoi(getenv("VDN_MLCC_PARTIAL")) == 0);
+  static const bool partial = !(vdn_env("VDN_MLCC_PARTIAL") && atoi(vdn_env("VDN_MLCC_PARTIAL")) == 0);
   if (want_norm || !partial) lowest = 0;
   fill_phi_ghosts(S);
   if (want_norm) HIPCHK(hipMemsetAsync(S.d_nrm, 0, sizeof(double), st));
@@ -738,7 +738,7 @@ int ml_cc_solve(vdn_layout *la, vdn_multifab **rh, vdn_multifab **phi, vdn_multi
   const size_t mark = arena_mark();
   const int L = la->nlev;
   MLCC S; S.nlev = L; S.la = la; S.rh = rh; S.phi = phi; S.beta = beta; S.alpha = alpha; S.dx = dx; S.bct = bct; S.bcc = bc_comp0;
-  static const bool fuse_first_on = !(getenv("VDN_MLCC_FUSE1") && atoi(getenv("VDN_MLCC_FUSE1")) == 0);
+  static const bool fuse_first_on = !(vdn_env("VDN_MLCC_FUSE1") && atoi(vdn_env("VDN_MLCC_FUSE1")) == 0);
   S.fuse_first = fuse_first_on && ctx().prm.mg_nu1 >= 1 && ctx().prm.mg_nu2 >= 1;
   for (int n = 0; n < L; n++) {
     std::vector<DirRhsB> v;
@@ -795,7 +795,7 @@ int ml_cc_solve(vdn_layout *la, vdn_multifab **rh, vdn_multifab **phi, vdn_multi
       (void)composite_residual(S, false, n - 1);
     }
     // coarse correction: ONE V-cycle of the single-level multigrid on the whole level 0
-    static const bool glue = !(getenv("VDN_MLCC_GLUE") && atoi(getenv("VDN_MLCC_GLUE")) == 0);
+    static const bool glue = !(vdn_env("VDN_MLCC_GLUE") && atoi(vdn_env("VDN_MLCC_GLUE")) == 0);
     const bool zg = glue && it > 0;           // (the first call builds the kept hierarchy and loads phi as the generic solver does)
     if (!zg) mf_setval(S.e[0], 0.0, 0, 1, true);
     int cyc; double r0, rr;

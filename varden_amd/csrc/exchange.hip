@@ -49,7 +49,7 @@ struct Rccl {
   bool test_double = false;
 };
 static Rccl g_rccl;
-static int packed_mode() { const char *e = getenv("VDN_FORCE_PACKED"); return e ? atoi(e) : 0; }
+static int packed_mode() { const char *e = vdn_env("VDN_FORCE_PACKED"); return e ? atoi(e) : 0; }
 #define NCCLCHK(x) do { int r_ = (x); if (r_ != ncclSuccess) vdn_fail("%s failed: %s", #x, g_rccl.GetErrorString ? g_rccl.GetErrorString(r_) : "?"); } while (0)
 
 static void rccl_load() {
@@ -58,13 +58,13 @@ static void rccl_load() {
   // ranks on one GPU), and an environment variable alone must not be able to swap the transport of the shipping library: VDN_RCCL_LIB
   // is honoured only together with VDN_TESTING=1 AND a library that identifies itself through vdn_test_transport_magic(); anything else
   // named there fails the call.  vdn_comm_transport() says which one is in use (bench.py prints it).
-  const char *forced = getenv("VDN_RCCL_LIB");
+  const char *forced = vdn_env("VDN_RCCL_LIB");
   // the handle and the entry points go into a local copy: g_rccl is assigned only when the handshake and every lookup succeeded, so a
   // failed load leaves no half-bound state behind (a later call would otherwise return early here and jump through null pointers)
   Rccl R;
   struct Closer { void *&h; bool armed = true; ~Closer() { if (armed && h) { dlclose(h); h = nullptr; } } } closer{ R.h };
   if (forced && *forced) {
-    const char *t = getenv("VDN_TESTING");
+    const char *t = vdn_env("VDN_TESTING");
     REQUIRE(t && atoi(t) == 1, "VDN_RCCL_LIB is set but VDN_TESTING=1 is not: the transport of this library is RCCL; only the test suite may replace it");
     R.h = dlopen(forced, RTLD_NOW | RTLD_LOCAL);
     REQUIRE(R.h, "cannot dlopen the test transport %s: %s", forced, dlerror());
@@ -397,7 +397,7 @@ bool xplan_has_remote(const XPlan *P) {
 }
 void xplan_run(XPlan *P, hipStream_t st) {
   if (!st) st = ctx().stream;
-  if (getenv("VDN_DEBUG_VIEWS")) { fprintf(stderr, "[rank %d] xplan nc %d peers:", ctx().rank, P->nc); for (auto &pr : P->peers) fprintf(stderr, " (%d: send %zu recv %zu)", pr.rank, pr.nsend, pr.nrecv); fprintf(stderr, "\n"); }
+  if (vdn_env("VDN_DEBUG_VIEWS")) { fprintf(stderr, "[rank %d] xplan nc %d peers:", ctx().rank, P->nc); for (auto &pr : P->peers) fprintf(stderr, " (%d: send %zu recv %zu)", pr.rank, pr.nsend, pr.nrecv); fprintf(stderr, "\n"); }
   const int nc = P->nc;
   // pack + post the remote traffic first so that it overlaps the local copies
   if (!P->peers.empty()) {
@@ -448,7 +448,7 @@ void view_cache_purge(unsigned long uid) {
   }
 }
 void SrcView::refresh() const {
-  if (getenv("VDN_DEBUG_VIEWS")) { fprintf(stderr, "[rank %d] view refresh ng %d nc %d nboxes %d peers:", ctx().rank, ng, nc, nboxes()); if (plan) for (auto &pr : plan->peers) fprintf(stderr, " (%d: send %zu recv %zu)", pr.rank, pr.nsend, pr.nrecv); fprintf(stderr, "\n"); }
+  if (vdn_env("VDN_DEBUG_VIEWS")) { fprintf(stderr, "[rank %d] view refresh ng %d nc %d nboxes %d peers:", ctx().rank, ng, nc, nboxes()); if (plan) for (auto &pr : plan->peers) fprintf(stderr, " (%d: send %zu recv %zu)", pr.rank, pr.nsend, pr.nrecv); fprintf(stderr, "\n"); }
   if (!plan || plan->peers.empty()) return;
   hipStream_t st = ctx().stream;
   need_comm();

@@ -160,7 +160,7 @@ template <int NC> __global__ void __launch_bounds__(64 * SNY) kk_slopes_m(FV s, 
   if (vmax) block_atomic_max(vmax, m);
 }
 static void launch_slopes(const FV &s, const FV sl[3], const GArgs &A, const Range3 &rg, int ncomp, double *vmax, hipStream_t st) {
-  static const bool marching = !(getenv("VDN_SLOPES_MARCH") && atoi(getenv("VDN_SLOPES_MARCH")) == 0);
+  static const bool marching = !(vdn_env("VDN_SLOPES_MARCH") && atoi(vdn_env("VDN_SLOPES_MARCH")) == 0);
   if (marching && (ncomp == 2 || ncomp == 3) && s.a0 <= A.lo[0] - 3 && s.a1 <= A.lo[1] - 3 && s.a2 <= A.lo[2] - 3) {
     const int nx = rg.hi[0] - rg.lo[0] + 1, ny = rg.hi[1] - rg.lo[1] + 1, nz = rg.hi[2] - rg.lo[2] + 1;
     const int tiles = ((nx + 59) / 60) * ((ny + SNY - 5) / (SNY - 4));
@@ -409,9 +409,9 @@ struct MkDFix { MkPlain P; __device__ void operator()(int i, int j, int k, int d
 // the computable region produce values nobody uses), the rare boundary work sits in one branch after it.
 // VDN_GODUNOV_BATCH=1 launches the descriptor (box-batched) kernels also for a level of one box. Measured at 256^3: they need
 // fewer VGPRs (mk_D<1> 116 vs 174) yet run slower there (scalar 6.6 vs 5.6 ms, velocity 10.0 vs 8.2 ms), so one box keeps the by-value kernels
-static bool batch_always() { static const bool b = getenv("VDN_GODUNOV_BATCH") && atoi(getenv("VDN_GODUNOV_BATCH")) != 0; return b; }
+static bool batch_always() { static const bool b = vdn_env("VDN_GODUNOV_BATCH") && atoi(vdn_env("VDN_GODUNOV_BATCH")) != 0; return b; }
 // VDN_GOD_SLAB_BC=0: the round-1 marches with the boundary code inside (kept for comparison); default: interior marches + boundary slabs
-static bool slab_bc() { static const bool b = !(getenv("VDN_GOD_SLAB_BC") && atoi(getenv("VDN_GOD_SLAB_BC")) == 0); return b; }
+static bool slab_bc() { static const bool b = !(vdn_env("VDN_GOD_SLAB_BC") && atoi(vdn_env("VDN_GOD_SLAB_BC")) == 0); return b; }
 // one launch per stage for all boxes (descriptors) or one set of launches per box (arguments by value)?  A level of an adaptive
 // hierarchy (hundreds of 16^3 .. 32^3 boxes) is launch-bound box by box; a level of a few large boxes -- 512^3 cut into eight 256^3
 // boxes -- runs faster box by box: the by-value kernels carry no boundary code (boundary slabs) and need fewer registers (measured,
@@ -424,7 +424,7 @@ static bool use_batched(const vdn_multifab *s) {
   for (int b = 0; b < s->nfabs(); b++) cells += (long)(s->vbox[b].hi[0] - s->vbox[b].lo[0] + 1) * (s->vbox[b].hi[1] - s->vbox[b].lo[1] + 1) * (s->vbox[b].hi[2] - s->vbox[b].lo[2] + 1);
   return !(s->nfabs() <= 16 && cells / s->nfabs() >= 96L * 96 * 96);
 }
-static bool plain_godunov() { static const bool p = getenv("VDN_GODUNOV_PLAIN") != nullptr; return p; }
+static bool plain_godunov() { static const bool p = vdn_env("VDN_GODUNOV_PLAIN") != nullptr; return p; }
 // parameters of the marching bodies: by value under the by-value kernels, references into the (constant) descriptor under the batched ones
 template <class T, bool R> struct Prm { typedef T type; };
 template <class T> struct Prm<T, true> { typedef const T &type; };
@@ -435,10 +435,10 @@ static void god_xcd_init() {
   static bool done = false;
   if (done) return;
   done = true;
-  if (getenv("VDN_GOD_XCD")) { const int v = atoi(getenv("VDN_GOD_XCD")); HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(g_god_xcd), &v, sizeof(int))); }
+  if (vdn_env("VDN_GOD_XCD")) { const int v = atoi(vdn_env("VDN_GOD_XCD")); HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(g_god_xcd), &v, sizeof(int))); }
 }
 constexpr int TNY = 8;              // rows per tile: workgroup = 64 x TNY threads
-static int march_chunks() { static const int n = getenv("VDN_KCHUNKS") ? atoi(getenv("VDN_KCHUNKS")) : 12; return n < 1 ? 1 : n; }
+static int march_chunks() { static const int n = vdn_env("VDN_KCHUNKS") ? atoi(vdn_env("VDN_KCHUNKS")) : 12; return n < 1 ? 1 : n; }
 static dim3 march_grid(const Range3 &r, int &klen) {
   const int nx = r.hi[0] - r.lo[0] + 1, ny = r.hi[1] - r.lo[1] + 1, nz = r.hi[2] - r.lo[2] + 1;
   klen = (nz + march_chunks() - 1) / march_chunks(); if (klen < 1) klen = 1;
@@ -835,7 +835,7 @@ struct FCell { double m_lo[3], m_up[3], s0, f, mr, Lb[3], Rb[3]; };      // a ce
 // results included: both are the correctly rounded value of the same real number), so where every dx is a power of two -- the unit cube on
 // 2^n cells, every level of a hierarchy over it -- the P2 kernels multiply.  The ten f64 divisions per cell and plane of the fused march were a
 // third of its f64 instructions (v_div_scale x 2, v_rcp, eight fma, v_div_fmas, v_div_fixup each).  Other spacings keep the division.
-static bool no_p2() { static const bool off = getenv("VDN_GOD_P2") && atoi(getenv("VDN_GOD_P2")) == 0; return off; }      // (the variants test: division path on power-of-two grids)
+static bool no_p2() { static const bool off = vdn_env("VDN_GOD_P2") && atoi(vdn_env("VDN_GOD_P2")) == 0; return off; }      // (the variants test: division path on power-of-two grids)
 static bool is_pow2(double x) { int e; return x > 0.0 && std::frexp(x, &e) == 0.5; }
 #define DIVDX(x, d) (PW2 ? (x) * F.idx[d] : (x) / F.dx[d])
 template <bool PW2> DEVI void f_bases(const FArgs &F, FCell &P, const double sl[3]) {
@@ -861,7 +861,7 @@ static dim3 fused_grid(const Range3 &r, int &klen) {
   // one 512-thread workgroup per CU at a time: the chunk count is the one that fills the last round of workgroups best
   const int nx = r.hi[0] - r.lo[0] + 1, ny = r.hi[1] - r.lo[1] + 1, nz = r.hi[2] - r.lo[2] + 1;
   const int tiles = ((nx + FNX - 1) / FNX) * ((ny + FNY - 1) / FNY);
-  static const int env = getenv("VDN_FUSED_KCHUNKS") ? std::max(1, atoi(getenv("VDN_FUSED_KCHUNKS"))) : 0;
+  static const int env = vdn_env("VDN_FUSED_KCHUNKS") ? std::max(1, atoi(vdn_env("VDN_FUSED_KCHUNKS"))) : 0;
   int best = 1; double best_cost = 1e300;
   for (int ch = 1; ch <= 16 && ch <= nz; ch++) {
     const int kl = (nz + ch - 1) / ch, nch = (nz + kl - 1) / kl;
@@ -1405,7 +1405,7 @@ bool k_mkflux(const vdn_multifab *s, vdn_multifab **sedge, vdn_multifab **flux, 
     const dim3 blk(64, TNY, 1);
     hipLaunchKernelGGL(kk_macmax_b, dim3(B.tot[1]), dim3(64, 4, 1), 0, st, B.dev, B.st[1], nb);
     hipLaunchKernelGGL(kk_slopes_b<MkD>, dim3(B.tot[0]), dim3(64, 4, 1), 0, st, B.dev, B.st[0], nb, 7);
-    static const bool fused_env = !(getenv("VDN_GOD_FUSED") && atoi(getenv("VDN_GOD_FUSED")) == 0);
+    static const bool fused_env = !(vdn_env("VDN_GOD_FUSED") && atoi(vdn_env("VDN_GOD_FUSED")) == 0);
     if (fused_env) {               // stages B + C + D in one march per box and component (mk_F_m_body)
       std::vector<FBatchD> fd((size_t)nb * ncomp);
       std::vector<int> fstart((size_t)nb * ncomp);
@@ -1433,7 +1433,7 @@ bool k_mkflux(const vdn_multifab *s, vdn_multifab **sedge, vdn_multifab **flux, 
         return false;
       }
     }
-    static const int split_env = getenv("VDN_MK_SPLIT") ? atoi(getenv("VDN_MK_SPLIT")) : -1;
+    static const int split_env = vdn_env("VDN_MK_SPLIT") ? atoi(vdn_env("VDN_MK_SPLIT")) : -1;
     const int split = split_env >= 0 ? split_env : (ncomp >= 2 ? 4 : 0);
     #define MKB_STAGE(K, t, bit)                                                                                               \
       if ((split >> bit) & 1) { for (int c0 = 0; c0 < ncomp; c0++) hipLaunchKernelGGL(K<1>, dim3(B.tot[t]), blk, 0, st, B.dev, B.st[t], nb, c0, ncomp); } \
@@ -1485,7 +1485,7 @@ bool k_mkflux(const vdn_multifab *s, vdn_multifab **sedge, vdn_multifab **flux, 
       #define MK_ARGS_D(c0) s->fabs[ib], sl[0], sl[1], sl[2], um, vm, wm, force->fabs[ib], mac_rhs->fabs[ib], SC, \
                             sedge[0]->fabs[ib], sedge[1]->fabs[ib], sedge[2]->fabs[ib], flux[0]->fabs[ib], flux[1]->fabs[ib], flux[2]->fabs[ib], A, rf, klf, umax, c0, ncomp
       // measured at 256^3: D fused <3> 3.18 ms (61 spilled VGPRs) vs 3 x <1> 2.3 ms; D <2> 1.66 ms vs 2 x <1> 1.55 ms; B and C are faster fused
-      static const int split_env = getenv("VDN_MK_SPLIT") ? atoi(getenv("VDN_MK_SPLIT")) : -1;   // bit 0: B, 1: C, 2: D per component
+      static const int split_env = vdn_env("VDN_MK_SPLIT") ? atoi(vdn_env("VDN_MK_SPLIT")) : -1;   // bit 0: B, 1: C, 2: D per component
       const int split = split_env >= 0 ? split_env : (ncomp >= 2 ? 4 : 0);
       #define MK_STAGE(K, BCF, ARGS, g, bit)                                                                               \
         if ((split >> bit) & 1) { for (int c0 = 0; c0 < ncomp; c0++) hipLaunchKernelGGL((K<1, BCF>), g, blk, 0, st, ARGS(c0)); } \
@@ -1497,13 +1497,13 @@ bool k_mkflux(const vdn_multifab *s, vdn_multifab **sedge, vdn_multifab **flux, 
         else if (ncomp == 3) hipLaunchKernelGGL((kk_mk_D_m<3, false, BCF>), gf, blk, 0, st, MK_ARGS_D(0));                     \
         else if (ncomp == 2) hipLaunchKernelGGL((kk_mk_D_m<2, false, BCF>), gf, blk, 0, st, MK_ARGS_D(0));                     \
         else hipLaunchKernelGGL((kk_mk_D_m<1, false, BCF>), gf, blk, 0, st, MK_ARGS_D(0));
-      static const bool fused_env = !(getenv("VDN_GOD_FUSED") && atoi(getenv("VDN_GOD_FUSED")) == 0);
+      static const bool fused_env = !(vdn_env("VDN_GOD_FUSED") && atoi(vdn_env("VDN_GOD_FUSED")) == 0);
       FArgs FA[3];
       bool fused = fused_env;
       for (int c0 = 0; c0 < ncomp && fused; c0++)
         fused = fused_args(FA[c0], A, c0, s->fabs[ib], sl, um, vm, wm, force->fabs[ib], mac_rhs->fabs[ib], sedge[0]->fabs[ib], sedge[1]->fabs[ib], sedge[2]->fabs[ib],
                            flux[0]->fabs[ib], flux[1]->fabs[ib], flux[2]->fabs[ib]);
-      static const bool upd_env = !(getenv("VDN_GOD_UPDATE") && atoi(getenv("VDN_GOD_UPDATE")) == 0);
+      static const bool upd_env = !(vdn_env("VDN_GOD_UPDATE") && atoi(vdn_env("VDN_GOD_UPDATE")) == 0);
       bool do_upd = fused && upd && upd_env && s->nfabs() == 1;
       for (int c0 = 0; c0 < ncomp && do_upd; c0++) do_upd = fused_update_args(FA[c0], A, c0, upd->snew->fabs[ib], force->fabs[ib], *upd, ib);
       if (fused) {                 // stages B + C + D in one march per component, boundary rules inside (see mk_F_m_body)
@@ -2596,7 +2596,7 @@ void k_velpred(const vdn_multifab *u, vdn_multifab **umac, const vdn_multifab *f
     const dim3 blk(64, TNY, 1);
     hipLaunchKernelGGL(kk_velmax_b, dim3(B.tot[1]), dim3(64, 4, 1), 0, st, B.dev, B.st[1], nb);
     hipLaunchKernelGGL(kk_slopes_b<VpD>, dim3(B.tot[0]), dim3(64, 4, 1), 0, st, B.dev, B.st[0], nb, 7);
-    static const bool fused_env = !(getenv("VDN_GOD_FUSED") && atoi(getenv("VDN_GOD_FUSED")) == 0);
+    static const bool fused_env = !(vdn_env("VDN_GOD_FUSED") && atoi(vdn_env("VDN_GOD_FUSED")) == 0);
     if (fused_env) {               // stages B + C + D in one march per box (vp_F_m_body)
       std::vector<VBatchD> fd(nb);
       std::vector<int> fstart(nb);
@@ -2656,7 +2656,7 @@ void k_velpred(const vdn_multifab *u, vdn_multifab **umac, const vdn_multifab *f
     } else {
       int klg, klf;
       const dim3 gg = march_grid(rg, klg), gf = march_grid(rf, klf), blk(64, TNY, 1);
-      static const bool fused_env = !(getenv("VDN_GOD_FUSED") && atoi(getenv("VDN_GOD_FUSED")) == 0);
+      static const bool fused_env = !(vdn_env("VDN_GOD_FUSED") && atoi(vdn_env("VDN_GOD_FUSED")) == 0);
       VArgs VA;
       if (fused_env && vfused_args(VA, A, u->fabs[ib], sl, force->fabs[ib], umac[0]->fabs[ib], umac[1]->fabs[ib], umac[2]->fabs[ib])) {
         int klF;                   // stages B + C + D in one march, boundary rules inside (see vp_F_m_body)

@@ -273,7 +273,7 @@ static inline void launch_gsrb_shell(const CLev &L, int color, hipStream_t st, i
 }
 static inline void launch_gsrb(const CLev &L, int color, hipStream_t st, int interior_only = 0) {
   const dim3 blk(64, 4, 1), g((unsigned)(((L.n[0] + 1) / 2 + 63) / 64), (unsigned)((L.n[1] + 3) / 4), (unsigned)L.n[2]);
-  static const bool paired = !(getenv("VDN_GSRB_PAIR") && atoi(getenv("VDN_GSRB_PAIR")) == 0);
+  static const bool paired = !(vdn_env("VDN_GSRB_PAIR") && atoi(vdn_env("VDN_GSRB_PAIR")) == 0);
   if (L.rho && paired && L.n[0] % 2 == 0 && L.n[1] % 2 == 0 && L.n[0] >= 128)
     hipLaunchKernelGGL(kk_cc_gsrb_rho_pair, dim3((unsigned)((L.n[0] / 2 + 63) / 64), (unsigned)((L.n[1] / 2 + 3) / 4), (unsigned)L.n[2]), blk, 0, st, L, color, interior_only);
   else if (L.rho) hipLaunchKernelGGL(kk_cc_gsrb_rho, g, blk, 0, st, L, color, interior_only);
@@ -1157,7 +1157,7 @@ static FV cc_phi_view(const CLev &L, const int lo[3]) {
 }
 
 // the 7-point operator reads no edge or corner ghost cell: the halo of phi carries the face cells only (VDN_CC_HALO_FACES=0: the whole shell)
-static bool cc_faces_only() { static const bool f = !(getenv("VDN_CC_HALO_FACES") && atoi(getenv("VDN_CC_HALO_FACES")) == 0); return f; }
+static bool cc_faces_only() { static const bool f = !(vdn_env("VDN_CC_HALO_FACES") && atoi(vdn_env("VDN_CC_HALO_FACES")) == 0); return f; }
 // plans for the per-level phi halos are cached across solves: arena addresses repeat from step to step
 // sig: a hash of EVERY local box's phi address -- the plan bakes those addresses in, and two solves on one level that start at the same
 // arena offset but differ in layout (6 arrays per box without alpha, 7 with) agree on the first box only
@@ -1200,7 +1200,7 @@ static void cc_build(CCMG &M, const vdn_multifab *rh, const double *dx, const in
         // colour-pass launches, and are slower still on the 64^3 / 128^3 levels.  Halving the HBM traffic does not pay here: the
         // plane pipeline costs a barrier per plane, the halo rings recompute 40 % of the red cells, and the f64 divisions of two
         // updates per thread and step keep the SIMDs busy for ~2 us per plane -- see DESIGN.md
-        static const bool use_fused = getenv("VDN_FUSED_GSRB") && atoi(getenv("VDN_FUSED_GSRB")) >= 1;
+        static const bool use_fused = vdn_env("VDN_FUSED_GSRB") && atoi(vdn_env("VDN_FUSED_GSRB")) >= 1;
         if (use_fused && nb == 1 && !(M.per[0] || M.per[1] || M.per[2]) && (long)n[0] * n[1] * n[2] > 32L * 32 * 32) {
           B.L.phi2 = (double *)arena_alloc(sizeof(double) * B.L.sz);
           HIPCHK(hipMemsetAsync(B.L.phi2, 0, sizeof(double) * B.L.sz, ctx().stream));
@@ -1237,7 +1237,7 @@ static void cc_build(CCMG &M, const vdn_multifab *rh, const double *dx, const in
     if (can) for (int d = 0; d < 3; d++) REQUIRE(!(n[d] & 1), "cc multigrid: box extent %d is odd while the domain can still be coarsened", n[d]);
     // several boxes: stop exchanging halos once the boxes get small (VDN_MG_AGGLOM, default 64) -- every level that stays distributed costs
     // ~10 latency-bound halo exchanges per V-cycle, the replicated tail below a 64^3-per-box level costs microseconds per pass
-    static const int agglom = getenv("VDN_MG_AGGLOM") ? std::max(4, atoi(getenv("VDN_MG_AGGLOM"))) : 64;
+    static const int agglom = vdn_env("VDN_MG_AGGLOM") ? std::max(4, atoi(vdn_env("VDN_MG_AGGLOM"))) : 64;
     const int min_dist = nb > 1 ? agglom : 4;
     for (int d = 0; d < 3; d++) if (n[d] / 2 < min_dist || ((n[d] / 2) & 1)) next_dist = false;
     if (!can) break;                                   // the domain cannot be coarsened: this level is the bottom
@@ -1286,7 +1286,7 @@ static void cc_halo(CCMG &M, CDLev &DL) { if (DL.halo) xplan_run(DL.halo); }
 static const long SMALL_LEVEL_CELLS = 8L * 8 * 8;
 static void cc_launch_wave(CLev &L, int nsweeps);
 static void cc_launch_fused(CLev &L, int nsweeps) {
-  static const int mode = getenv("VDN_FUSED_GSRB") ? atoi(getenv("VDN_FUSED_GSRB")) : 0;
+  static const int mode = vdn_env("VDN_FUSED_GSRB") ? atoi(vdn_env("VDN_FUSED_GSRB")) : 0;
   if (mode == 2) { cc_launch_wave(L, nsweeps); return; }
   const int tiles = ((L.n[0] + FT_X - 1) / FT_X) * ((L.n[1] + FT_Y - 1) / FT_Y);
   int kchunk = L.n[2];
@@ -1307,8 +1307,8 @@ static void cc_gsrb_d(CCMG &M, CDLev &DL, int nsweeps) {
   // traffic -- pack kernels, the ncclSend / ncclRecv group, box-to-box copies, unpack kernels -- runs on ctx().halo_stream while the
   // launch stream updates the cells that read no ghost value; the one-cell shell follows when the halo has landed
   // Only where the pass is long enough to hide something: boxes of at least VDN_OVERLAP_MIN cells (default 2^20; a 64^3 pass takes 5 us).
-  static const int ov_env = getenv("VDN_OVERLAP") ? atoi(getenv("VDN_OVERLAP")) : -1;
-  static const long ov_min = getenv("VDN_OVERLAP_MIN") ? atol(getenv("VDN_OVERLAP_MIN")) : (1L << 20);
+  static const int ov_env = vdn_env("VDN_OVERLAP") ? atoi(vdn_env("VDN_OVERLAP")) : -1;
+  static const long ov_min = vdn_env("VDN_OVERLAP_MIN") ? atol(vdn_env("VDN_OVERLAP_MIN")) : (1L << 20);
   bool overlap = DL.halo && (ov_env == 1 || (ov_env != 0 && xplan_has_remote(DL.halo)));
   if (overlap) {
     long cells = 0;
@@ -1336,8 +1336,8 @@ static void cc_residual_d(CCMG &M, CDLev &DL, bool norm, bool reduce = true) {  
   if (norm) HIPCHK(hipMemsetAsync(M.d_nrm, 0, sizeof(double), ctx().stream));
   DL.res_restricted = false;
   {   // the finest level of a MAC solve in one box: residual and restriction in one pass (kk_cc_residual_rho_pair_rst); cc_restrict_down then skips
-    static const bool fuse = !(getenv("VDN_MG_RESTRICT_FUSED") && atoi(getenv("VDN_MG_RESTRICT_FUSED")) == 0);
-    static const bool paired0 = !(getenv("VDN_GSRB_PAIR") && atoi(getenv("VDN_GSRB_PAIR")) == 0);
+    static const bool fuse = !(vdn_env("VDN_MG_RESTRICT_FUSED") && atoi(vdn_env("VDN_MG_RESTRICT_FUSED")) == 0);
+    static const bool paired0 = !(vdn_env("VDN_GSRB_PAIR") && atoi(vdn_env("VDN_GSRB_PAIR")) == 0);
     const size_t l = &DL - &M.dlev[0];
     if (fuse && paired0 && DL.single_box && DL.boxes.size() == 1 && l + 1 < M.dlev.size() && M.dlev[l + 1].boxes.size() == 1) {
       const CLev &L = DL.boxes[0].L;
@@ -1352,7 +1352,7 @@ static void cc_residual_d(CCMG &M, CDLev &DL, bool norm, bool reduce = true) {  
   }
   for (const CBox &B : DL.boxes) {
     const dim3 g = g3(B.L.n[0], B.L.n[1], norm ? std::min(B.L.n[2], 16) : B.L.n[2], BLK);
-    static const bool paired = !(getenv("VDN_GSRB_PAIR") && atoi(getenv("VDN_GSRB_PAIR")) == 0);
+    static const bool paired = !(vdn_env("VDN_GSRB_PAIR") && atoi(vdn_env("VDN_GSRB_PAIR")) == 0);
     if (B.L.rho && paired && B.L.n[0] % 2 == 0 && B.L.n[1] % 2 == 0 && B.L.n[0] >= 128)
       hipLaunchKernelGGL(kk_cc_residual_rho_pair, dim3((unsigned)((B.L.n[0] / 2 + 63) / 64), (unsigned)((B.L.n[1] / 2 + 3) / 4), g.z), BLK, 0, ctx().stream, B.L, norm ? M.d_nrm : nullptr);
     else if (B.L.rho) hipLaunchKernelGGL(kk_cc_residual_rho, g, BLK, 0, ctx().stream, B.L, norm ? M.d_nrm : nullptr);
@@ -1388,9 +1388,9 @@ static void cc_bottom_t(const CCMG &M, const CLev &L) {      // max(nub, N^2) sw
 // The small end of the hierarchy in one launch (kk_cc_tailcycle): distributed levels dl .. end when they are one box of at most 8^3 cells
 // each (dl < 0: none), then the replicated tail levels tl .. end (one rank and one box: the gather between the two is the plain restriction).
 static bool cc_small_end(const CCMG &M, int dl, int tl) {
-  static const bool on = !(getenv("VDN_MG_TAILCYCLE") && atoi(getenv("VDN_MG_TAILCYCLE")) == 0);
+  static const bool on = !(vdn_env("VDN_MG_TAILCYCLE") && atoi(vdn_env("VDN_MG_TAILCYCLE")) == 0);
   if (!on) return false;
-  static const long tail_cells = getenv("VDN_MG_TAIL_CELLS") ? atol(getenv("VDN_MG_TAIL_CELLS")) : SMALL_LEVEL_CELLS;     // largest level the one-workgroup cycle takes (measured: 16^3 no gain, MAC 15.33 -> 15.39 ms)
+  static const long tail_cells = vdn_env("VDN_MG_TAIL_CELLS") ? atol(vdn_env("VDN_MG_TAIL_CELLS")) : SMALL_LEVEL_CELLS;     // largest level the one-workgroup cycle takes (measured: 16^3 no gain, MAC 15.33 -> 15.39 ms)
   const vdn_params &P = ctx().prm;
   CcTailArgs T; memset(&T, 0, sizeof T);
   int nl = 0;
@@ -1465,8 +1465,8 @@ static void cc_prolong_up(CCMG &M, int l) {
 // faces (the paired density pass) the correction is added inside the first sweep (kk_cc_gsrb_rho_pair_t); otherwise kk_cc_prolong first.
 static void cc_prolong_smooth(CCMG &M, int l, int nsweeps) {
   CDLev &DL = M.dlev[l];
-  static const bool fuse = !(getenv("VDN_MG_PROLONG_FUSED") && atoi(getenv("VDN_MG_PROLONG_FUSED")) == 0);
-  static const bool paired = !(getenv("VDN_GSRB_PAIR") && atoi(getenv("VDN_GSRB_PAIR")) == 0);
+  static const bool fuse = !(vdn_env("VDN_MG_PROLONG_FUSED") && atoi(vdn_env("VDN_MG_PROLONG_FUSED")) == 0);
+  static const bool paired = !(vdn_env("VDN_GSRB_PAIR") && atoi(vdn_env("VDN_GSRB_PAIR")) == 0);
   const bool ok = fuse && paired && nsweeps >= 1 && DL.single_box && DL.boxes.size() == 1 && !DL.halo && l + 1 < (int)M.dlev.size() && M.dlev[l + 1].boxes.size() == 1 &&
                   !(M.per[0] || M.per[1] || M.per[2]) && DL.boxes[0].L.rho && !DL.boxes[0].L.phi2 &&
                   DL.boxes[0].L.n[0] % 2 == 0 && DL.boxes[0].L.n[1] % 2 == 0 && DL.boxes[0].L.n[2] % 2 == 0 && DL.boxes[0].L.n[0] >= 128;
@@ -1479,8 +1479,8 @@ static void cc_prolong_smooth(CCMG &M, int l, int nsweeps) {
 }
 // may level l >= 1 of a V-cycle run as kk_cc_lds_down / kk_cc_lds_up?  (VDN_MG_LDS=0: never; VDN_MG_LDS_MAX: largest extent taken, default 64)
 static bool cc_lds_level(const CCMG &M, int l) {
-  static const bool on = !(getenv("VDN_MG_LDS") && atoi(getenv("VDN_MG_LDS")) == 0);
-  static const int nmax_ = getenv("VDN_MG_LDS_MAX") ? atoi(getenv("VDN_MG_LDS_MAX")) : 64;
+  static const bool on = !(vdn_env("VDN_MG_LDS") && atoi(vdn_env("VDN_MG_LDS")) == 0);
+  static const int nmax_ = vdn_env("VDN_MG_LDS_MAX") ? atoi(vdn_env("VDN_MG_LDS_MAX")) : 64;
   const vdn_params &P = ctx().prm;
   if (!on || l < 1 || l + 1 >= (int)M.dlev.size() || P.mg_nu1 != 2 || P.mg_nu2 != 2 || M.per[0] || M.per[1] || M.per[2]) return false;
   const CDLev &D = M.dlev[l], &DC = M.dlev[l + 1];
@@ -1649,7 +1649,7 @@ static int cc_fmg_what(const int bc[3][2]) {
   return 3 + 4 * code;
 }
 // VDN_MAC_STORED_BETA=1: the finest level reads the stored face coefficients like the others (the measured alternative of DESIGN.md section 4)
-static bool beta_from_rho() { static const bool b = !(getenv("VDN_MAC_STORED_BETA") && atoi(getenv("VDN_MAC_STORED_BETA")) != 0); return b; }
+static bool beta_from_rho() { static const bool b = !(vdn_env("VDN_MAC_STORED_BETA") && atoi(vdn_env("VDN_MAC_STORED_BETA")) != 0); return b; }
 static void cc_setup(CCMG &M, vdn_multifab *rh, vdn_multifab *phi, const vdn_multifab *alpha, vdn_multifab **beta, const double *dx, const int bc[3][2],
                      const vdn_multifab *rho = nullptr) {
   REQUIRE(phi->ng >= 1, "cc multigrid: phi needs one ghost cell");
@@ -2067,11 +2067,11 @@ void do_macproject(vdn_layout *mla, vdn_multifab **umac, vdn_multifab **rho, vdn
   const int n = 0;
   size_t mark = arena_mark();
   {
-    static const bool fast_on = !(getenv("VDN_MAC_FAST") && atoi(getenv("VDN_MAC_FAST")) == 0);
+    static const bool fast_on = !(vdn_env("VDN_MAC_FAST") && atoi(vdn_env("VDN_MAC_FAST")) == 0);
     // the second level must exist (its coefficients come from the first level's rho): boxes that halve cleanly to >= 4 cells, as cc_build asks
-    bool ok = fast_on && beta_from_rho() && rho[n]->ng >= 1 && !getenv("VDN_FUSED_GSRB");
+    bool ok = fast_on && beta_from_rho() && rho[n]->ng >= 1 && !vdn_env("VDN_FUSED_GSRB");
     {   // cc_build's rule for a second DISTRIBUTED level: the domain coarsens, the boxes halve cleanly and stay at least min_dist wide
-      const int agglom = getenv("VDN_MG_AGGLOM") ? std::max(4, atoi(getenv("VDN_MG_AGGLOM"))) : 64;
+      const int agglom = vdn_env("VDN_MG_AGGLOM") ? std::max(4, atoi(vdn_env("VDN_MG_AGGLOM"))) : 64;
       const int min_dist = mla->boxes[n].size() > 1 ? agglom : 4;
       for (const vdn_box &b : mla->boxes[n]) for (int d = 0; d < 3; d++) { const int w = b.hi[d] - b.lo[d] + 1; if ((w & 1) || w / 2 < min_dist || ((w / 2) & 1)) ok = false; }
       for (int d = 0; d < 3; d++) { const int N = mla->pd[n].hi[d] - mla->pd[n].lo[d] + 1; if ((N & 1) || N <= 2) ok = false; }

@@ -964,12 +964,12 @@ template <int MODE> static void nd_launch_march(const NLev &L, const double *phi
   int kchunk = nzp;
   while (kchunk > 8 && tiles * ((nzp + kchunk - 1) / kchunk) < 2048) kchunk = (kchunk + 1) / 2;
   const int nch = (nzp + kchunk - 1) / kchunk;
-  static const bool paired = !(getenv("VDN_ND_PAIR") && atoi(getenv("VDN_ND_PAIR")) == 0);
+  static const bool paired = !(vdn_env("VDN_ND_PAIR") && atoi(vdn_env("VDN_ND_PAIR")) == 0);
   if (paired && L.n[0] >= 127) {                   // 124 nodes per wave row
     const int rows = 4;                          // (measured: 8 rows per workgroup 17.1 -> 18.7 ms of HG per step, 16 rows spill)
-    static const bool use_rem = !(getenv("VDN_ND_REM") && atoi(getenv("VDN_ND_REM")) == 0);
-    static const int minwg = getenv("VDN_ND_MINWG") ? atoi(getenv("VDN_ND_MINWG")) : 2048;
-    static const int kc_env = getenv("VDN_ND_KC") ? atoi(getenv("VDN_ND_KC")) : 0;
+    static const bool use_rem = !(vdn_env("VDN_ND_REM") && atoi(vdn_env("VDN_ND_REM")) == 0);
+    static const int minwg = vdn_env("VDN_ND_MINWG") ? atoi(vdn_env("VDN_ND_MINWG")) : 2048;
+    static const int kc_env = vdn_env("VDN_ND_KC") ? atoi(vdn_env("VDN_ND_KC")) : 0;
     const NdPairGrid G = nd_pair_grid(L, rows, nzp, use_rem, minwg, kc_env);
     hipLaunchKernelGGL((kk_nd_march_pair<MODE, 4>), dim3(G.nmain + G.gyr * G.gz), NBLK, 0, ctx().stream, L, phi, out, nd_cur_omega(), G, nrm, shell_later);
     return;
@@ -1017,7 +1017,7 @@ static NLev nd_alloc_lev(const int n[3], const double h[3]) {
   // Row padding beyond the ghost nodes only ever reaches lanes whose results are discarded.
   // (The first version left sigma to its load as well -- true on the finest level only: the 129^3 level of a 257^3 solve then read
   // whatever the arena held beyond the walls, which happened to be zeros until hgproject stopped allocating its multifabs in front of it.)
-  static const bool lean_on = !(getenv("VDN_ND_LEAN") && atoi(getenv("VDN_ND_LEAN")) == 0);
+  static const bool lean_on = !(vdn_env("VDN_ND_LEAN") && atoi(vdn_env("VDN_ND_LEAN")) == 0);
   if (lean_on && (long)(n[0] + 1) * (n[1] + 1) * (n[2] + 1) >= (1L << 21)) {
     const int m = std::max(n[0], std::max(n[1], n[2])) + 3;
     hipLaunchKernelGGL(kk_nd_zero_shell, dim3((m + 63) / 64, (m + 3) / 4, 6), dim3(64, 4, 1), 0, ctx().stream, L, L.phi, L.tmp, L.res);
@@ -1092,7 +1092,7 @@ static void nd_build(NDMG &M, const vdn_multifab *coeffs, const double *dx, cons
     if (can) for (int d = 0; d < 3; d++) REQUIRE(!(n[d] & 1), "nodal multigrid: box extent %d is odd while the domain can still be coarsened", n[d]);
     // several boxes: stop exchanging halos once the boxes get small (VDN_MG_AGGLOM, default 64) -- every level that stays distributed costs
     // ~10 latency-bound halo exchanges per V-cycle, the replicated tail below a 64^3-per-box level costs microseconds per pass
-    static const int agglom = getenv("VDN_MG_AGGLOM") ? std::max(4, atoi(getenv("VDN_MG_AGGLOM"))) : 64;
+    static const int agglom = vdn_env("VDN_MG_AGGLOM") ? std::max(4, atoi(vdn_env("VDN_MG_AGGLOM"))) : 64;
     const int min_dist = nb > 1 ? agglom : 4;
     for (int d = 0; d < 3; d++) if (n[d] / 2 < min_dist || ((n[d] / 2) & 1)) next_dist = false;
     if (!can) break;
@@ -1143,8 +1143,8 @@ static void nd_halo_phi(NDLev &DL) { XPlan *P = DL.flip ? DL.halo_B : DL.halo_A;
 static bool nd_halo_begin(NDLev &DL) {
   XPlan *P = DL.flip ? DL.halo_B : DL.halo_A;
   if (!P) return false;
-  static const int ov_env = getenv("VDN_OVERLAP") ? atoi(getenv("VDN_OVERLAP")) : -1;
-  static const long ov_min = getenv("VDN_OVERLAP_MIN") ? atol(getenv("VDN_OVERLAP_MIN")) : (1L << 20);     // see cc_gsrb_d
+  static const int ov_env = vdn_env("VDN_OVERLAP") ? atoi(vdn_env("VDN_OVERLAP")) : -1;
+  static const long ov_min = vdn_env("VDN_OVERLAP_MIN") ? atol(vdn_env("VDN_OVERLAP_MIN")) : (1L << 20);     // see cc_gsrb_d
   long nodes = 0;
   for (const NBox &B : DL.boxes) nodes = std::max(nodes, (long)B.L.n[0] * B.L.n[1] * B.L.n[2]);
   if (!(ov_env == 1 || (ov_env != 0 && xplan_has_remote(P) && nodes >= ov_min))) { xplan_run(P); return false; }
@@ -1201,8 +1201,8 @@ static void nd_residual_d(NDMG &M, NDLev &DL, bool norm, bool reduce = true) {  
   if (norm) HIPCHK(hipMemsetAsync(M.d_nrm, 0, sizeof(double), ctx().stream));
   DL.res_restricted = false;
   {   // a wide one-box level without periodic images whose next level is one box too: residual and the x / z part of the restriction in one march
-    static const bool fuse = !(getenv("VDN_ND_RESTRICT_FUSED") && atoi(getenv("VDN_ND_RESTRICT_FUSED")) == 0);
-    static const bool paired = !(getenv("VDN_ND_PAIR") && atoi(getenv("VDN_ND_PAIR")) == 0);
+    static const bool fuse = !(vdn_env("VDN_ND_RESTRICT_FUSED") && atoi(vdn_env("VDN_ND_RESTRICT_FUSED")) == 0);
+    static const bool paired = !(vdn_env("VDN_ND_PAIR") && atoi(vdn_env("VDN_ND_PAIR")) == 0);
     const size_t l = &DL - &M.dlev[0];
     if (fuse && paired && DL.single_box && DL.boxes.size() == 1 && !DL.halo_res && !(DL.per[0] || DL.per[1] || DL.per[2]) && l + 1 < M.dlev.size() && M.dlev[l + 1].boxes.size() == 1) {
       const NLev &L = DL.boxes[0].L;
@@ -1315,9 +1315,9 @@ static int nd_bottom_sweeps_global(const NDLev &DL) {
 // The small end of the hierarchy in one launch (kk_nd_tailcycle): distributed levels dl .. end when they are one box of at most 9^3 nodes
 // each (dl < 0: none), then the replicated tail levels tl .. end (one rank and one box: the gather between the two is the plain restriction).
 static bool nd_small_end(NDMG &M, int dl, int tl) {
-  static const bool on = !(getenv("VDN_MG_TAILCYCLE") && atoi(getenv("VDN_MG_TAILCYCLE")) == 0);
+  static const bool on = !(vdn_env("VDN_MG_TAILCYCLE") && atoi(vdn_env("VDN_MG_TAILCYCLE")) == 0);
   if (!on) return false;
-  static const long tail_nodes = getenv("VDN_MG_TAIL_NODES") ? atol(getenv("VDN_MG_TAIL_NODES")) : SMALL_LEVEL_NODES;    // largest level the one-workgroup cycle takes (measured: 17^3 is slower, HG 16.9 -> 17.6 ms)
+  static const long tail_nodes = vdn_env("VDN_MG_TAIL_NODES") ? atol(vdn_env("VDN_MG_TAIL_NODES")) : SMALL_LEVEL_NODES;    // largest level the one-workgroup cycle takes (measured: 17^3 is slower, HG 16.9 -> 17.6 ms)
   const vdn_params &P = ctx().prm;
   NdTailArgs T; memset(&T, 0, sizeof T);
   int nl = 0;
@@ -1554,9 +1554,9 @@ int nd_solve(vdn_multifab *rh, vdn_multifab *phi, const vdn_multifab *coeffs, co
   }
   comm_allreduce_max_dev(M.d_nrm, 2);
   {   // VDN_ND_BENCH=n (probe): time n Jacobi sweeps of the finest level here, print the mean, then solve as usual (the sweeps only improve phi)
-    static const int nbench = getenv("VDN_ND_BENCH") ? atoi(getenv("VDN_ND_BENCH")) : 0;
+    static const int nbench = vdn_env("VDN_ND_BENCH") ? atoi(vdn_env("VDN_ND_BENCH")) : 0;
     if (nbench > 0) {
-      if (getenv("VDN_ND_DBG")) { const int v = atoi(getenv("VDN_ND_DBG")); HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(g_nd_dbg), &v, sizeof(int))); }
+      if (vdn_env("VDN_ND_DBG")) { const int v = atoi(vdn_env("VDN_ND_DBG")); HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(g_nd_dbg), &v, sizeof(int))); }
       hipEvent_t e0, e1; HIPCHK(hipEventCreate(&e0)); HIPCHK(hipEventCreate(&e1));
       nd_jacobi_d(M.dlev[0], 2);
       HIPCHK(hipEventRecord(e0, st));
@@ -1782,7 +1782,7 @@ void do_hgproject(int proj_type, vdn_layout *mla, vdn_multifab **unew, vdn_multi
   // Round 3: rh, phi and coeffs (hgproject.f90:70-76, hg_multigrid.f90:68-80) exist only to carry zeros, D u and 1 / rhohalf into the solver
   // and phi out of it: the solver takes sigma from rhohalf, forms b = -D u while it loads, and hg_update reads phi from the level array
   // (0.5 ms of fills, copies and passes per 256^3 projection; VDN_HG_FAST=0: the multifabs as the reference has them -- same values)
-  static const bool fast_on = !(getenv("VDN_HG_FAST") && atoi(getenv("VDN_HG_FAST")) == 0);
+  static const bool fast_on = !(vdn_env("VDN_HG_FAST") && atoi(vdn_env("VDN_HG_FAST")) == 0);
   if (fast_on) {
     hg_level_pre(proj_type, un, uo, rhh, gpp, nullptr, dt, bct);
     NdFast F; F.rhohalf = rhh;
@@ -2079,7 +2079,7 @@ static MarchSet ndf_build_march(std::vector<MarchB> &v) {
   for (size_t b = 0; b < v.size(); b++) {
     MarchB &B = v[b];
     const int nx = B.r.hi[0] - B.r.lo[0] + 1, ny = B.r.hi[1] - B.r.lo[1] + 1, nz = B.r.hi[2] - B.r.lo[2] + 1;
-    static const bool paired = !(getenv("VDN_NDF_PAIR") && atoi(getenv("VDN_NDF_PAIR")) == 0);
+    static const bool paired = !(vdn_env("VDN_NDF_PAIR") && atoi(vdn_env("VDN_NDF_PAIR")) == 0);
     if (paired) B.lw = nx <= 12 ? 3 : (nx <= 28 ? 4 : (nx <= 60 ? 5 : 6));       // kk_ndf_march2: a lane carries two nodes
     else B.lw = nx <= 14 ? 4 : (nx <= 30 ? 5 : 6);
     const int act = (paired ? 2 : 1) * ((1 << B.lw) - 2), rows = 4 * (64 >> B.lw);
@@ -2098,7 +2098,7 @@ static MarchSet ndf_build_march(std::vector<MarchB> &v) {
 }
 template <int MODE> static void ndf_run_march(const MarchSet &S, double omega, int excl, double *nrm) {
   if (S.nbox == 0) return;
-  static const bool paired = !(getenv("VDN_NDF_PAIR") && atoi(getenv("VDN_NDF_PAIR")) == 0);
+  static const bool paired = !(vdn_env("VDN_NDF_PAIR") && atoi(vdn_env("VDN_NDF_PAIR")) == 0);
   if (paired) hipLaunchKernelGGL(kk_ndf_march2<MODE>, dim3(S.tot), NBLK, 0, ctx().stream, (const MarchB *)S.d_args, (const int *)S.d_start, S.nbox, omega, excl, nrm);
   else { REQUIRE(MODE != 2, "the fused residual + sweep is the paired march's"); hipLaunchKernelGGL(kk_ndf_march<(MODE == 2 ? 1 : MODE)>, dim3(S.tot), NBLK, 0, ctx().stream, (const MarchB *)S.d_args, (const int *)S.d_start, S.nbox, omega, excl, nrm); }
 }
@@ -2258,10 +2258,10 @@ struct MLND {
 };
 // mode 0: slaves of level n <- P phi_{n-1};  mode 1: dst_n += P src_{n-1};  mode 2: dst_n = P src_{n-1} (dst zeroed first by the caller)
 static void ml_nd_prolong(MLND &S, int n, vdn_multifab *dst, vdn_multifab *src, int mode) {
-  static const bool faces_only = !(getenv("VDN_NDM_IFACE_FACES") && atoi(getenv("VDN_NDM_IFACE_FACES")) == 0);
+  static const bool faces_only = !(vdn_env("VDN_NDM_IFACE_FACES") && atoi(vdn_env("VDN_NDM_IFACE_FACES")) == 0);
   const SrcView Cv = make_view(src, nd_coarse_footprints(S.la, n), S.la->owner[n], 0, 1, NVT_C2F);
   Cv.refresh();
-  static const bool by_parent = !(getenv("VDN_NDM_PROLONG8") && atoi(getenv("VDN_NDM_PROLONG8")) == 0);
+  static const bool by_parent = !(vdn_env("VDN_NDM_PROLONG8") && atoi(vdn_env("VDN_NDM_PROLONG8")) == 0);
   std::vector<NdmProlongB> v; std::vector<NdmProlong8B> v8;
   for (size_t f = 0; f < S.A[n].size(); f++)
     for (int c = 0; c < Cv.nboxes(); c++) {
@@ -2314,7 +2314,7 @@ static double ndf_relax_omega(int s) {
   return (g_nd_iso && P.hg_nu1 + P.hg_nu2 == 3 && s < 3 && o[0] > 0.0 && o[1] > 0.0 && o[2] > 0.0) ? o[s] : P.hg_omega;
 }
 static bool ndf_fuse_first() {       // the fused residual + first sweep needs the paired march
-  static const bool on = !(getenv("VDN_NDF_FUSE1") && atoi(getenv("VDN_NDF_FUSE1")) == 0) && !(getenv("VDN_NDF_PAIR") && atoi(getenv("VDN_NDF_PAIR")) == 0);
+  static const bool on = !(vdn_env("VDN_NDF_FUSE1") && atoi(vdn_env("VDN_NDF_FUSE1")) == 0) && !(vdn_env("VDN_NDF_PAIR") && atoi(vdn_env("VDN_NDF_PAIR")) == 0);
   return on;
 }
 // fuse_first (with finest_only): the same march also writes the first damped-Jacobi sweep of K e = r from e = 0 into eb of the finest level
@@ -2327,7 +2327,7 @@ static double ml_nd_residual(MLND &S, bool finest_only, bool zero_field = false,
     else { if (S.multi[0]) mf_fill_boundary(S.phi[0]); for (int n = 1; n < L; n++) ml_nd_interface(S, n); }
   }
   if (!finest_only) HIPCHK(hipMemsetAsync(S.d_nrm, 0, sizeof(double), st));
-  static const bool partial = !(getenv("VDN_MLND_PARTIAL") && atoi(getenv("VDN_MLND_PARTIAL")) == 0);
+  static const bool partial = !(vdn_env("VDN_MLND_PARTIAL") && atoi(vdn_env("VDN_MLND_PARTIAL")) == 0);
   if (want_norm || !partial || zero_field) lowest = 0;
   for (int n = L - 1; n >= (finest_only ? L - 1 : lowest); n--) {
     const bool finest = n == L - 1;
@@ -2523,7 +2523,7 @@ static int ml_nd_solve(vdn_layout *la, vdn_multifab **rh, vdn_multifab **phi, vd
   for (int d = 0; d < 3; d++) for (int s = 0; s < 2; s++) ebc0[d][s] = bct->ell_bc(0, 0, d, s, press_comp0);
   int it = 0; bool conv = (bnorm == 0.0); double rn = 0.0;
   NdKeep coarse_keep;                        // the level-0 multigrid hierarchy is built once for all FAC iterations
-  static const bool neg_copy = getenv("VDN_NDM_NEG") && atoi(getenv("VDN_NDM_NEG")) != 0;
+  static const bool neg_copy = vdn_env("VDN_NDM_NEG") && atoi(vdn_env("VDN_NDM_NEG")) != 0;
   while (!conv) {
     rn = ml_nd_residual(S, false);
     if ((rn <= rel_eps * bnorm && bnorm < HUGE_VAL) || rn <= abs_eps) { conv = true; break; }

@@ -26,7 +26,7 @@ void vdn_fail(const char *fmt, ...) {
 
 // also drops the pointers advance_timestep keeps INTO the arena (limited slopes of uold, max |umac|): a step that ended in an exception
 // (solver_check throws by default) must not leave them dangling for the next stand-alone vdn_k_mkflux / vdn_k_velpred
-static bool arena_poison() { static const bool p = getenv("VDN_ARENA_POISON") && atoi(getenv("VDN_ARENA_POISON")) != 0; return p; }
+static bool arena_poison() { static const bool p = vdn_env("VDN_ARENA_POISON") && atoi(vdn_env("VDN_ARENA_POISON")) != 0; return p; }
 // the descriptors of arena temporaries (mf_temp) that nobody freed: they die with the arena contents they describe
 static std::vector<vdn_multifab *> g_temp_mfs;
 void arena_reset() {
@@ -100,7 +100,7 @@ void prof_load() {
   static bool tried = false;
   if (tried) return;
   tried = true;
-  if (getenv("VDN_NO_ROCTX")) return;
+  if (vdn_env("VDN_NO_ROCTX")) return;
   for (const char *n : { "librocprofiler-sdk-roctx.so.1", "librocprofiler-sdk-roctx.so", "libroctx64.so.4", "libroctx64.so" }) {
     void *h = dlopen(n, RTLD_NOW | RTLD_LOCAL);
     if (!h) continue;
@@ -112,6 +112,96 @@ void prof_load() {
 }
 Prof::Prof(const char *name) : on(g_roctx_push != nullptr) { if (on) g_roctx_push(name); }
 Prof::~Prof() { if (on) g_roctx_pop(); }
+
+// ---- debug / measurement switches ------------------------------------------------------------------------------------------------
+// Every environment variable the library reads, with what it does.  None changes a result: they select between launch forms that the tests hold bit-for-bit
+// equal (tests/test_projection_gpu.py::test_multigrid_launch_variants_agree_bit_for_bit, test_kernels_gpu.py, test_amr_gpu.py) or are probes.  vdn_env() is the
+// only way the library reads the environment: a name missing from this table fails the call, and vdn_init warns about VDN_* variables it does not know
+// (a misspelt switch would otherwise be silently ignored).  vdn_debug_switches() hands the table out (include/varden_amd.h).
+struct EnvSwitch { const char *name, *doc; };
+static const EnvSwitch g_switches[] = {
+  { "VDN_TESTING", "1: allows VDN_RCCL_LIB (the test transport of tests/fake_rccl); nothing else" },
+  { "VDN_RCCL_LIB", "path of a library that stands in for librccl -- honoured only with VDN_TESTING=1 and the test double's handshake" },
+  { "VDN_FORCE_PACKED", "1: box-to-box copies of one rank go through the packed per-peer buffers (device memcpy for send/recv); 2: through a 1-rank RCCL communicator (one-GPU rehearsal of the N > 1 transport)" },
+  { "VDN_DEBUG_VIEWS", "print the peers and message sizes of every exchange plan built" },
+  { "VDN_ARENA_POISON", "1: every byte handed back to the arena is overwritten with NaNs (a read of an entry nobody wrote fails the next solve)" },
+  { "VDN_NO_ROCTX", "do not bind the roctx library (no bl_prof ranges)" },
+  { "VDN_POLL", "scalar read-back: 1 spin on the pinned sequence number, 0 hipStreamSynchronize; default: spin on one rank, synchronise on several" },
+  { "VDN_NO_GRAPHS", "launch every multigrid cycle eagerly instead of replaying its hipGraph" },
+  { "VDN_NO_SLOPE_CACHE", "velocity mkflux recomputes the slopes of uold that velpred computed in the same step" },
+  { "VDN_NO_FORCE_REUSE", "1: every forcing term is computed where the reference computes it (advance_premac AND velocity_advance, ...)" },
+  { "VDN_SLOPES_MARCH", "0: the per-cell slopes kernel instead of the k-marching one" },
+  { "VDN_GODUNOV_BATCH", "1: the descriptor (box-batched) Godunov kernels also on a level of one box" },
+  { "VDN_GOD_SLAB_BC", "0: (unfused marches) boundary rules inside the marches instead of the face-centred code on boundary slabs" },
+  { "VDN_GODUNOV_PLAIN", "the face-centred one-thread-per-cell Godunov kernels of round 1 (the marching kernels' bit-for-bit reference)" },
+  { "VDN_GOD_XCD", "0: plain blockIdx order instead of the XCD-aware tile order of the Godunov marches" },
+  { "VDN_KCHUNKS", "k-chunks of the unfused Godunov marches (default 12)" },
+  { "VDN_GOD_P2", "0: the fused marches divide by dx also where every dx is a power of two (default there: scale by 1/dx, the same doubles)" },
+  { "VDN_FUSED_KCHUNKS", "k-chunks of the fused marches (default: the count that fills the last round of workgroups best)" },
+  { "VDN_GOD_FUSED", "0: one march per Godunov stage (B, C, D) instead of the fused B+C+D march" },
+  { "VDN_MK_SPLIT", "components per launch of the unfused mkflux marches (-1: by register budget)" },
+  { "VDN_GOD_UPDATE", "0: update_3d as its own pass instead of inside the fused mkflux march" },
+  { "VDN_GSRB_PAIR", "0: one cell per thread in the colour passes / residuals of wide levels instead of the 2 x 2 pair form" },
+  { "VDN_CC_HALO_FACES", "0: the cell-centred multigrid exchanges the whole ghost shell instead of the faces only" },
+  { "VDN_FUSED_GSRB", "1 / 2: the fused red+black sweep experiments (LDS plane ring / register column pairs) -- slower, kept for their bit-equality test" },
+  { "VDN_MG_AGGLOM", "several boxes: smallest box extent (cells) of a multigrid level that stays distributed; below it the level is gathered and relaxed on every rank (default 64)" },
+  { "VDN_OVERLAP", "halo exchange of multigrid passes next to interior work: 1 always, 0 never, default: when a plan has a remote peer and the box is large" },
+  { "VDN_OVERLAP_MIN", "smallest box (cells / nodes) whose halo exchange is overlapped (default 2^20)" },
+  { "VDN_MG_RESTRICT_FUSED", "0: cell-centred residual and restriction as two passes" },
+  { "VDN_MG_TAILCYCLE", "0: the smallest levels launch by launch instead of one single-workgroup cycle" },
+  { "VDN_MG_TAIL_CELLS", "largest level (cells) the single-workgroup cell-centred tail cycle takes (default 8^3)" },
+  { "VDN_MG_TAIL_NODES", "largest level (nodes) the single-workgroup nodal tail cycle takes (default 9^3)" },
+  { "VDN_MG_PROLONG_FUSED", "0: cell-centred prolongation as its own pass instead of inside the first post-smoothing colour pass" },
+  { "VDN_MG_LDS", "0: the 16^3..64^3 cell-centred levels launch by launch instead of the LDS-tiled down / up kernels" },
+  { "VDN_MG_LDS_MAX", "largest level the LDS-tiled kernels take (default 64)" },
+  { "VDN_MAC_STORED_BETA", "1: the finest MAC level reads stored face coefficients instead of recomputing them from rho" },
+  { "VDN_MAC_FAST", "0: macproject with its rh / phi / beta multifabs as the reference has them" },
+  { "VDN_HG_FAST", "0: hgproject with its rh / phi / coeffs multifabs as the reference has them" },
+  { "VDN_ND_PAIR", "0: one node per lane in the nodal march instead of the pair form" },
+  { "VDN_ND_REM", "0: remainder columns of the paired nodal march in full-width tiles" },
+  { "VDN_ND_MINWG", "workgroups the paired nodal march aims for when it cuts k-slabs (default 2048)" },
+  { "VDN_ND_KC", "planes per k-slab of the paired nodal march (default: from VDN_ND_MINWG)" },
+  { "VDN_ND_LEAN", "0: whole-array zero fills of the big nodal levels instead of shell-only" },
+  { "VDN_ND_RESTRICT_FUSED", "0: nodal residual and full weighting as two passes" },
+  { "VDN_ND_BENCH", "n: time n Jacobi sweeps of the finest nodal level inside the next solve and print the mean (probe)" },
+  { "VDN_ND_DBG", "probe only, with VDN_ND_BENCH: 1 no stencil arithmetic, 2 no loads in the march" },
+  { "VDN_NDF_PAIR", "0: one node per lane in the box-batched nodal march of the composite solve" },
+  { "VDN_NDF_FUSE1", "0: the composite nodal solve's finest-level residual and first relaxation sweep as two launches" },
+  { "VDN_NDM_IFACE_FACES", "0: interface interpolation of the composite nodal solve over whole boxes instead of box faces" },
+  { "VDN_NDM_PROLONG8", "0: correction interpolation with a thread per fine node instead of per coarse node" },
+  { "VDN_NDM_NEG", "1: the composite nodal solve copies -res into the correction's right-hand side instead of loading it directly" },
+  { "VDN_MLND_PARTIAL", "0: every composite nodal residual computes all levels" },
+  { "VDN_MLCC_PARTIAL", "0: every composite cell-centred residual computes all levels" },
+  { "VDN_MLCC_GLUE", "0: the level-0 correction of the composite MAC solve stored and added in separate passes" },
+  { "VDN_MLCC_FUSE1", "0: the composite MAC solve's finest-level residual and first colour pass as two launches" },
+  { "VDN_BATCH_YZ", "0: no (j,k) / (i,k) tiles for thin ranges in the box-batched kernels" },
+  { "VDN_BATCH_PPW", "planes per workgroup of the light box-batched kernels (default 8)" },
+  { "VDN_BATCH_FLAT", "0: no flattened (i,j) plane mapping for badly filling tiles" },
+  { "VDN_BATCH_CHUNK", "0: box-batched workgroups take strided instead of contiguous plane chunks" }
+};
+const char *vdn_env(const char *name) {
+  for (const EnvSwitch &e : g_switches) if (!strcmp(e.name, name)) return getenv(name);
+  vdn_fail("internal: the switch %s is not declared in the table of runtime.hip", name);
+}
+extern char **environ;
+static void env_warn_unknown() {
+  static bool done = false;
+  if (done) return;
+  done = true;
+  for (char **e = environ; e && *e; e++) {
+    if (strncmp(*e, "VDN_", 4) != 0 || !strncmp(*e, "VDN_BENCH_", 10) || !strncmp(*e, "VDN_WORKER_", 11)) continue;     // (bench.py's and the test workers' own variables)
+    const char *eq = strchr(*e, '=');
+    const size_t len = eq ? (size_t)(eq - *e) : strlen(*e);
+    bool known = false;
+    for (const EnvSwitch &s : g_switches) if (strlen(s.name) == len && !strncmp(s.name, *e, len)) known = true;
+    if (!known) fprintf(stderr, "varden_amd: warning: environment variable %.*s is not a switch of this library (vdn_debug_switches lists them)\n", (int)len, *e);
+  }
+}
+extern "C" const char *vdn_debug_switches(void) {
+  static std::string out;
+  if (out.empty()) for (const EnvSwitch &s : g_switches) { const char *v = getenv(s.name); out += s.name; out += v ? std::string(" = ") + v : std::string(" (unset)"); out += ": "; out += s.doc; out += "\n"; }
+  return out.c_str();
+}
 
 // ---- scalar read-back ------------------------------------------------------------------------------------------------------------
 bool g_capturing_now();
@@ -130,7 +220,7 @@ const double *read_scalars(const double *dev, int n) {
   static unsigned long long seq = 0;
   // VDN_POLL: 1 = spin, 0 = synchronise always; unset: spin on a one-rank run, synchronise when several ranks run (each rank's spinning thread would
   // take a core from RCCL's proxy threads and from the other ranks of an oversubscribed host)
-  static const int poll_env = getenv("VDN_POLL") ? atoi(getenv("VDN_POLL")) : -1;
+  static const int poll_env = vdn_env("VDN_POLL") ? atoi(vdn_env("VDN_POLL")) : -1;
   const bool poll = poll_env >= 0 ? poll_env != 0 : c.nranks == 1;
   ++seq;
   hipLaunchKernelGGL(k_publish, dim3(1), dim3(64), 0, c.stream, c.h_scal_dev, dev, n, seq);
@@ -180,7 +270,7 @@ static std::map<unsigned long long, hipGraphExec_t> g_graphs;
 static bool g_capturing = false;
 bool g_capturing_now() { return g_capturing; }
 bool graphs_enabled() {
-  static const bool off = getenv("VDN_NO_GRAPHS") != nullptr;
+  static const bool off = vdn_env("VDN_NO_GRAPHS") != nullptr;
   return !off && !comm_active() && g_ctx.stream != 0 && !g_capturing;
 }
 // `generation` counts the clears: solvers that keep host state next to a graph (mg_nd.hip: the ping-pong state a cycle leaves behind)
@@ -243,6 +333,7 @@ extern "C" const char *vdn_last_error(void) { return g_err; }
 
 extern "C" int vdn_init(const vdn_params *prm, int rank, int nranks, int device) {
   VDN_TRY
+  env_warn_unknown();
   REQUIRE(prm != nullptr, "vdn_init: null params");
   REQUIRE(prm->dm == 3 || prm->dm == 2, "vdn_init: dm must be 2 or 3 (got %d)", prm->dm);
   REQUIRE(prm->nscal >= 1 && prm->nscal + 5 <= VDN_MAXCOMP, "vdn_init: bad nscal %d", prm->nscal);

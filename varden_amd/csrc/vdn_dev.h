@@ -202,7 +202,7 @@ template <class T> struct batch_ppw<T, std::void_t<decltype(T::planes_per_wg)>> 
 template <class A> static inline int batch_grid(A &a, int kz) {
   const int nx = a.r.hi[0] - a.r.lo[0] + 1, ny = a.r.hi[1] - a.r.lo[1] + 1, nz = a.r.hi[2] - a.r.lo[2] + 1;
   // x faces (ghost slabs, coarse-fine faces, interface nodes): with x along the lanes a 16-wide tile runs one lane in sixteen
-  static const bool yz_on = !(getenv("VDN_BATCH_YZ") && atoi(getenv("VDN_BATCH_YZ")) == 0);
+  static const bool yz_on = !(vdn_env("VDN_BATCH_YZ") && atoi(vdn_env("VDN_BATCH_YZ")) == 0);
   if (yz_on && nx >= 1 && nx <= 2 && ny >= 1 && nz >= 1 && (long)ny * nz >= 64) {
     a.g[0] = 1; a.g[1] = (ny + 15) / 16; a.g[2] = ((nz + 15) / 16) | (BATCH_YZ << 24);
     return a.g[1] * ((nz + 15) / 16);
@@ -213,15 +213,15 @@ template <class A> static inline int batch_grid(A &a, int kz) {
     return a.g[0] * ((nz + h - 1) / h);
   }
   // planes per workgroup when the caller sets no limit (batch_ppw): VDN_BATCH_PPW overrides every descriptor's own choice
-  static const int ppw_env = getenv("VDN_BATCH_PPW") ? std::max(1, atoi(getenv("VDN_BATCH_PPW"))) : 0;
+  static const int ppw_env = vdn_env("VDN_BATCH_PPW") ? std::max(1, atoi(vdn_env("VDN_BATCH_PPW"))) : 0;
   const int ppw = ppw_env > 0 ? ppw_env : batch_ppw<A>::value;
   int g0 = nx > 0 ? (nx + w - 1) / w : 0, g1 = ny > 0 ? (ny + h - 1) / h : 0, g2 = nz > 0 ? ((kz > 0 && nz > kz) ? kz : (nz + ppw - 1) / ppw) : 0;
   if (g0 == 0 || g1 == 0 || g2 == 0) { g0 = g1 = g2 = 1; a.r.hi[0] = a.r.lo[0] - 1; }
   // widths that fill the 16 / 32 / 64-wide tiles badly (node ranges: 17, 25, 33, 41): the plane flattened over the threads when that takes fewer workgroups
-  static const bool flat_on = !(getenv("VDN_BATCH_FLAT") && atoi(getenv("VDN_BATCH_FLAT")) == 0);
+  static const bool flat_on = !(vdn_env("VDN_BATCH_FLAT") && atoi(vdn_env("VDN_BATCH_FLAT")) == 0);
   int code = lw;
   if (flat_on && nx > 0 && ny > 0 && (long)nx * ny < (1L << 24)) { const int gf = (nx * ny + 255) / 256; if (gf < g0 * g1) { g0 = gf; g1 = 1; code = BATCH_FLAT; } }
-  static const bool chunk_on = !(getenv("VDN_BATCH_CHUNK") && atoi(getenv("VDN_BATCH_CHUNK")) == 0);
+  static const bool chunk_on = !(vdn_env("VDN_BATCH_CHUNK") && atoi(vdn_env("VDN_BATCH_CHUNK")) == 0);
   const int chunked = (chunk_on && !(kz > 0 && nz > kz) && ppw > 1 && g2 < nz) ? 1 : 0;      // planes-per-workgroup mode: contiguous planes
   if (chunked) { const int ch = (nz + g2 - 1) / g2; g2 = (nz + ch - 1) / ch; }                 // (no workgroup without a plane)
   a.g[0] = g0; a.g[1] = g1; a.g[2] = g2 | (chunked << 23) | (code << 24);

@@ -96,6 +96,8 @@ struct VdnCtx {
 };
 VdnCtx &ctx();
 
+// the one way the library reads its environment: getenv for a name declared in the switch table of runtime.hip (fails for any other name)
+const char *vdn_env(const char *name);
 // error handling: C-ABI functions wrap their body in VDN_TRY/VDN_CATCH
 void vdn_set_error(const char *fmt, ...);
 struct VdnErr : std::runtime_error { using std::runtime_error::runtime_error; };
