@@ -1848,15 +1848,16 @@ int cc_solve(vdn_multifab *rh, vdn_multifab *phi, vdn_multifab **beta, const dou
     if (pred >= 2) {
       cc_residual_d(M, D0, true, false);
       norm_hist_reset(); norm_hist_push(M.d_nrm);
-      for (int c = 1; c <= pred - 1; c++)
-        cc_run_cycle(M, 4, [&] {      // (graph id 4: 1 and 2 are the plain cycles, 3 + 4 code the nested iterations)
+      cc_run_cycle(M, 4 + 4 * pred, [&] {      // all blind cycles as ONE graph (ids: 1 and 2 the plain cycles, 3 + 4 code the nested iterations, multiples of 4 these)
+        for (int c = 1; c <= pred - 1; c++) {
           cc_restrict_down(M, 0);
           if (M.dlev.size() > 1) cc_vcycle_d(M, 1); else cc_vcycle_t(M, 0);
           cc_prolong_smooth(M, 0, P.mg_nu2);
           cc_gsrb_d(M, D0, P.mg_nu1);
           cc_residual_d(M, D0, true, false);
           norm_hist_push(M.d_nrm);
-        });
+        }
+      });
       const double *h = norm_hist_read(pred);
       int first = -1;
       for (int c = 0; c < pred && first < 0; c++)

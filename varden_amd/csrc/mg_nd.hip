@@ -1601,8 +1601,8 @@ int nd_solve(vdn_multifab *rh, vdn_multifab *phi, const vdn_multifab *coeffs, co
     if (pred >= 2) {
       nd_residual_d(M, M.dlev[0], true, false);
       norm_hist_reset(); norm_hist_push(M.d_nrm);
-      for (int c = 1; c <= pred - 1; c++)
-        nd_run_cycle(M, 4, [&] {
+      nd_run_cycle(M, 4 + 4 * pred, [&] {                  // all blind cycles as ONE graph (ids 1, 2: the plain cycles; nothing else is a multiple of 4)
+        for (int c = 1; c <= pred - 1; c++) {
           NDLev &D = M.dlev[0];
           nd_restrict_down(M, 0);
           if (M.dlev.size() > 1) nd_vcycle_d(M, 1); else nd_vcycle_t(M, 0);
@@ -1611,7 +1611,8 @@ int nd_solve(vdn_multifab *rh, vdn_multifab *phi, const vdn_multifab *coeffs, co
           nd_jacobi_d(D, P.hg_nu1, true);
           nd_residual_d(M, D, true, false);
           norm_hist_push(M.d_nrm);
-        });
+        }
+      });
       const double *h = norm_hist_read(pred);
       int first = -1;                                            // the first cycle count at which the plain loop would have stopped
       for (int c = 0; c < pred && first < 0; c++)
