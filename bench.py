@@ -344,7 +344,7 @@ def main():
         # HBM bytes per launch: PMC passes (FETCH_SIZE x2 + WRITE_SIZE, MI355X_MICROARCH.md) collected with `rocprofv3 --pmc` on
         # tools/smoother_probe.py in a separate run and committed; not measured in THIS run, and said so in traffic_source
         traffic, traffic_source = None, None
-        for name in ("r03_smoother_rho_pmc.json", "r02_smoother_rho_pmc.json", "r01_smoother_rho_pmc.json"):
+        for name in ("r04_smoother_rho_pmc.json", "r03_smoother_rho_pmc.json", "r02_smoother_rho_pmc.json", "r01_smoother_rho_pmc.json"):
             pmc = os.path.join(ROOT, "profiles", name)
             if pn == 256 and os.path.exists(pmc):
                 traffic = json.load(open(pmc))["hbm_bytes_per_launch"]
