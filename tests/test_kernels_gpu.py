@@ -269,22 +269,6 @@ def test_godunov_marching_equals_face_centred(gpu, shape):
     assert out[0] == out[1] == out[2] == out[3], out
 
 
-def test_fused_sweeps_equal_colour_passes(gpu):
-    """the two fused red+black sweep kernels (VDN_FUSED_GSRB=1: LDS plane ring, =2: register/shuffle column pairs) produce the bits of
-    two kk_cc_gsrb colour-pass launches; the variant is fixed per process, hence the subprocesses"""
-    import os
-    import subprocess
-    import sys
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    hashes = []
-    for mode in ("0", "1", "2"):
-        out = subprocess.run([sys.executable, os.path.join(root, "tests", "_fused_worker.py")], env=dict(os.environ, VDN_FUSED_GSRB=mode),
-                             capture_output=True, text=True, timeout=300, cwd=root)
-        assert out.returncode == 0, out.stderr[-2000:]
-        hashes.append([ln for ln in out.stdout.splitlines() if ln.startswith("HASH")][0])
-    assert hashes[0] == hashes[1] == hashes[2], hashes
-
-
 def _pair_run(tmp_path, tag, decomp, pair):
     import os
     import subprocess

@@ -34,7 +34,7 @@ def mac_problem(case):
 
 
 @pytest.mark.parametrize("bcname", ["walls", "periodic", "inout", "mixed"])
-@pytest.mark.parametrize("n", [(16, 8, 12), (72, 36, 44)])      # the larger box takes the fused red+black LDS kernel (non-periodic cases)
+@pytest.mark.parametrize("n", [(16, 8, 12), (72, 36, 44)])
 def test_cc_smoother_bits(gpu, oracle, bcname, n):
     from varden_amd import advance as adv
     case = Case(n, BC_SETS[bcname], seed=11, iso=True)

@@ -22,7 +22,6 @@ struct CLev {
   double hi2[3];
   double *phi, *rh, *res, *b[3];
   double *alpha;        // cell coefficient of (alpha - div b grad); nullptr when alpha = 0 (MAC projection)
-  double *phi2;         // ping-pong partner of phi for the fused red+black sweep (nullptr when not used)
   const double *rho;    // finest level of the MAC solve: density with one ghost layer, the face coefficients 2/(rho_i + rho_i-1) are
   int fold[3][2];       //   recomputed from it (8 B/cell instead of 24); fold = bc type of the box faces that are domain faces
 };
@@ -282,217 +281,8 @@ static inline void launch_gsrb(const CLev &L, int color, hipStream_t st, int int
   else hipLaunchKernelGGL(kk_cc_gsrb, g, blk, 0, st, L, color, interior_only);
 }
 
-// ---- fused red+black sweep ---------------------------------------------------------------------------------------
-// One launch = one full red-black Gauss-Seidel sweep (both colour passes) with ONE read of phi, rhs, b and one write of
-// phi: half the HBM traffic of two colour-pass launches.  A workgroup owns a 64 x 8 tile of (i,j) and marches through
-// a slab of k planes with a rolling window of four phi planes in LDS (tile grown by 2): at step k it (1) loads plane
-// k+2, (2) updates the RED cells of plane k+1 on the tile grown by 1 (their black neighbours are still old), (3) updates
-// the BLACK cells of plane k on the tile (their red neighbours in planes k-1, k, k+1 are new) and writes plane k out.
-// Red cells in the one-cell ring around the tile are recomputed by the neighbouring workgroups too (identical
-// arithmetic, so identical bits); results are bit-identical to two kk_cc_gsrb launches.  The sweep reads `pin` and
-// writes `pout` (ping-pong: a neighbour workgroup must still see the OLD black values in its halo).
-// Valid when the level is one box without periodic faces: then the ghost layer of phi is identically zero.
-#define FT_X 64
-#define FT_Y 8
-DEVI double cc_point_update(const CLev &L, long c, double p0, double pxm, double pxp, double pym, double pyp, double pzm, double pzp) {
-  const long sy = L.PX, sz = (long)L.PX * L.PY;
-  const double bxm = L.b[0][c], bxp = L.b[0][c + 1];
-  const double bym = L.b[1][c], byp = L.b[1][c + sy];
-  const double bzm = L.b[2][c], bzp = L.b[2][c + sz];
-  const double ax = (bxp * (p0 - pxp) + bxm * (p0 - pxm)) * L.hi2[0];
-  const double ay = (byp * (p0 - pyp) + bym * (p0 - pym)) * L.hi2[1];
-  const double az = (bzp * (p0 - pzp) + bzm * (p0 - pzm)) * L.hi2[2];
-  double Ap = ax + ay + az;
-  double diag = (bxp + bxm) * L.hi2[0] + (byp + bym) * L.hi2[1] + (bzp + bzm) * L.hi2[2];
-  if (L.alpha) { const double a0 = L.alpha[c]; Ap = Ap + a0 * p0; diag = diag + a0; }
-  return (diag != 0.0) ? p0 + (L.rh[c] - Ap) / diag : p0;
-}
-__global__ void __launch_bounds__(256) kk_cc_gsrb_fused(CLev L, const double *__restrict__ pin, double *__restrict__ pout, int kchunk) {
-  __shared__ double sp[4][FT_Y + 4][FT_X + 4];
-  const int tid = threadIdx.x;
-  const int i0 = blockIdx.x * FT_X, j0 = blockIdx.y * FT_Y;
-  const int nx = L.n[0], ny = L.n[1], nz = L.n[2];
-  const int k0 = blockIdx.z * kchunk, k1 = min(k0 + kchunk, nz) - 1;
-  if (k0 > k1) return;
-  // old values of plane k into slot k&3; zero outside the allocated [-1..n] range
-  auto load_plane = [&](int k) {
-    for (int t = tid; t < (FT_Y + 4) * (FT_X + 4); t += 256) {
-      const int jl = t / (FT_X + 4), il = t - jl * (FT_X + 4);
-      const int gi = i0 + il - 2, gj = j0 + jl - 2;
-      double v = 0.0;
-      if (k >= -1 && k <= nz && gj >= -1 && gj <= ny && gi >= -1 && gi <= nx) v = pin[cidx(L, gi, gj, k)];
-      sp[k & 3][jl][il] = v;
-    }
-  };
-  auto point = [&](int gi, int gj, int k) -> double {
-    const int il = gi - i0 + 2, jl = gj - j0 + 2;
-    const int s0 = k & 3, sm = (k - 1) & 3, sq = (k + 1) & 3;
-    return cc_point_update(L, cidx(L, gi, gj, k), sp[s0][jl][il], sp[s0][jl][il - 1], sp[s0][jl][il + 1], sp[s0][jl - 1][il], sp[s0][jl + 1][il],
-                           sp[sm][jl][il], sp[sq][jl][il]);
-  };
-  // red cells ((i+j+k) even) of plane k on the tile grown by one
-  auto red = [&](int k) {
-    if (k < 0 || k >= nz) return;
-    constexpr int HW = (FT_X + 2) / 2;                     // 33 red cells per row of 66
-    for (int t = tid; t < (FT_Y + 2) * HW; t += 256) {
-      const int jr = t / HW, ii = t - jr * HW;
-      const int gj = j0 - 1 + jr;
-      const int gi = i0 - 1 + 2 * ii + ((i0 - 1 + gj + k) & 1);
-      if (gi >= 0 && gi < nx && gj >= 0 && gj < ny && gi <= i0 + FT_X) {
-        const double v = point(gi, gj, k);
-        sp[k & 3][gj - j0 + 2][gi - i0 + 2] = v;           // red updates of one plane do not read each other
-      }
-    }
-  };
-  load_plane(k0 - 2); load_plane(k0 - 1); load_plane(k0); load_plane(k0 + 1);
-  __syncthreads();
-  red(k0 - 1);
-  __syncthreads();
-  red(k0);
-  __syncthreads();
-  for (int k = k0; k <= k1; k++) {
-    load_plane(k + 2);                                     // overwrites plane k-2, no longer needed
-    __syncthreads();
-    red(k + 1);
-    __syncthreads();
-    {                                                      // black cells of plane k on the tile: one per thread (64*8/2 = 256)
-      const int jr = tid / (FT_X / 2), ii = tid - jr * (FT_X / 2);
-      const int gj = j0 + jr;
-      const int gi = i0 + 2 * ii + ((i0 + gj + k + 1) & 1);
-      double v = 0.0; bool ok = (gi < nx && gj < ny);
-      if (ok) v = point(gi, gj, k);
-      __syncthreads();                                     // every black update has read its neighbours
-      if (ok) sp[k & 3][gj - j0 + 2][gi - i0 + 2] = v;
-    }
-    __syncthreads();
-    for (int t = tid; t < FT_Y * FT_X; t += 256) {         // write plane k of the tile (both colours final), x-contiguous
-      const int jr = t / FT_X, il = t - jr * FT_X;
-      const int gi = i0 + il, gj = j0 + jr;
-      if (gi < nx && gj < ny) pout[cidx(L, gi, gj, k)] = sp[k & 3][jr + 2][il + 2];
-    }
-    __syncthreads();
-  }
-}
-
-// ---- fused red+black sweep, register/shuffle form -----------------------------------------------------------------------
-// Same pipeline as kk_cc_gsrb_fused (per k step: load plane k+2, RED cells of plane k+1, BLACK cells of plane k, write plane k)
-// with the planes in registers.  A thread owns a PAIR of adjacent columns (2t, 2t+1) of one row j: in step k exactly one column
-// of the pair (the same one for the whole wave: the "worker") has its cell of plane k+1 red and its cell of plane k black, so
-// every lane does one red and one black update per step -- no idle lanes -- and fetches, unconditionally, the coefficients of
-// the OTHER column's two updates of step k+1 (software prefetch by one step, one register set per column).  Neighbours:
-// i-1 / i+1 = the thread's other column and the adjacent lane's (one wave shuffle), j-1 / j+1 = a three-plane LDS ring,
-// k-1 / k+1 = own registers.  One barrier per plane.  A workgroup is 16 rows x 128 columns; the outer ring of two columns/rows
-// only feeds values (tile of 124 x 12 outputs), the ring of one recomputes the red cells its neighbours own (identical
-// arithmetic, identical bits).  Reads `pin`, writes `pout`.  Valid when the level is one box without periodic faces (the ghost
-// layer of phi is then identically zero).
-#define GW_L 64            // lanes per row
-#define GW_Y 16
-#define GW_OX (2 * GW_L - 4)
-#define GW_OY (GW_Y - 4)
-struct CCoef { double bxm, bxp, bym, byp, bzm, bzp, rh, a0; };
-DEVI void cc_load_coef(const CLev &L, long c, CCoef &q) {
-  const long sy = L.PX, sz = (long)L.PX * L.PY;
-  q.bxm = L.b[0][c]; q.bxp = L.b[0][c + 1];
-  q.bym = L.b[1][c]; q.byp = L.b[1][c + sy];
-  q.bzm = L.b[2][c]; q.bzp = L.b[2][c + sz];
-  q.rh = L.rh[c];
-  q.a0 = L.alpha ? L.alpha[c] : 0.0;
-}
-DEVI double cc_update_coef(const CLev &L, const CCoef &q, double p0, double pxm, double pxp, double pym, double pyp, double pzm, double pzp) {
-  const double ax = (q.bxp * (p0 - pxp) + q.bxm * (p0 - pxm)) * L.hi2[0];
-  const double ay = (q.byp * (p0 - pyp) + q.bym * (p0 - pym)) * L.hi2[1];
-  const double az = (q.bzp * (p0 - pzp) + q.bzm * (p0 - pzm)) * L.hi2[2];
-  double Ap = ax + ay + az;
-  double diag = (q.bxp + q.bxm) * L.hi2[0] + (q.byp + q.bym) * L.hi2[1] + (q.bzp + q.bzm) * L.hi2[2];
-  if (L.alpha) { Ap = Ap + q.a0 * p0; diag = diag + q.a0; }
-  return (diag != 0.0) ? p0 + (q.rh - Ap) / diag : p0;
-}
-__global__ void __launch_bounds__(GW_L * GW_Y) kk_cc_gsrb_wave(CLev L, const double *__restrict__ pin, double *__restrict__ pout, int kchunk) {
-  __shared__ double sp[3][GW_Y][2][GW_L];                     // [plane ring][row][even / odd column of the pair][lane]
-  const int lane = threadIdx.x, row = threadIdx.y;
-  const int nx = L.n[0], ny = L.n[1], nz = L.n[2];
-  const int j = (int)blockIdx.y * GW_OY - 2 + row;
-  const int k0 = (int)blockIdx.z * kchunk, k1 = min(k0 + kchunk, nz) - 1;
-  if (k0 > k1) return;
-  // X = the column that works in the steps with k - k0 even: (iX + j + k0) odd.  The pair starts at an even i.
-  // colours: X is red in the planes k0-1, k0+1, ..., Y in the planes k0, k0+2, ...
-  const bool xleft = ((j + k0) & 1) != 0;                    // wave-uniform: X is the left (even) column of the pair
-  const int cX = xleft ? 0 : 1, cY = 1 - cX;
-  const int ia = (int)blockIdx.x * GW_OX - 2 + 2 * lane;
-  const int iX = ia + cX, iY = ia + cY, pX = 2 * lane + cX, pY = 2 * lane + cY;       // global index / position in the 128-column row
-  const bool row_red = row >= 1 && row <= GW_Y - 2 && j >= 0 && j < ny, row_out = row >= 2 && row <= GW_Y - 3 && j >= 0 && j < ny;
-  const bool redX = row_red && iX >= 0 && iX < nx && pX >= 1 && pX <= 2 * GW_L - 2, outX = row_out && iX >= 0 && iX < nx && pX >= 2 && pX <= 2 * GW_L - 3;
-  const bool redY = row_red && iY >= 0 && iY < nx && pY >= 1 && pY <= 2 * GW_L - 2, outY = row_out && iY >= 0 && iY < nx && pY >= 2 && pY <= 2 * GW_L - 3;
-  const int jc = min(max(j, -1), ny), jcc = min(max(j, 0), ny - 1);
-  const long sz = (long)L.PX * L.PY;
-  const long colX = cidx(L, min(max(iX, -1), nx), jc, 0), colY = cidx(L, min(max(iY, -1), nx), jc, 0);          // phi columns (ghost ring allowed)
-  const long cofX = cidx(L, min(max(iX, 0), nx - 1), jcc, 0), cofY = cidx(L, min(max(iY, 0), nx - 1), jcc, 0);  // coefficient columns (cells)
-  const int rm = max(row - 1, 0), rp = min(row + 1, GW_Y - 1);
-  auto ldp = [&](long col, int k) -> double { return pin[col + (long)min(max(k, -1), nz) * sz]; };
-  auto cof = [&](long c, int k) -> long { return c + (long)min(max(k, 0), nz - 1) * sz; };
-  // x-neighbours (lo = i-1, hi = i+1) of an X cell are Y cells -- the thread's own and the adjacent lane's -- and vice versa
-  auto nbr_of_X = [&](double vY, double &lo, double &hi) { const double sh = xleft ? __shfl_up(vY, 1, 64) : __shfl_down(vY, 1, 64); lo = xleft ? sh : vY; hi = xleft ? vY : sh; };
-  auto nbr_of_Y = [&](double vX, double &lo, double &hi) { const double sh = xleft ? __shfl_down(vX, 1, 64) : __shfl_up(vX, 1, 64); lo = xleft ? vX : sh; hi = xleft ? sh : vX; };
-  double pmX = ldp(colX, k0 - 1), p0X = ldp(colX, k0), p1X = ldp(colX, k0 + 1), p2X = ldp(colX, k0 + 2);
-  double pmY = ldp(colY, k0 - 1), p0Y = ldp(colY, k0), p1Y = ldp(colY, k0 + 1), p2Y = ldp(colY, k0 + 2);
-  const double pmmX = ldp(colX, k0 - 2);
-  double q1X = ldp(colX, k0 + 3), q1Y = ldp(colY, k0 + 3), q2X = ldp(colX, k0 + 4), q2Y = ldp(colY, k0 + 4);     // planes fetched ahead
-  CCoef crX, cbX, crY, cbY;
-  cc_load_coef(L, cof(cofX, k0 + 1), crX); cc_load_coef(L, cof(cofX, k0), cbX);       // step k0: X red in plane k0+1, black in plane k0
-  // warm-up: the red cells of planes k0-1 (column X) and k0 (column Y).  Slot of plane p: (p + 3) % 3
-  sp[(k0 + 2) % 3][row][cX][lane] = pmX; sp[(k0 + 2) % 3][row][cY][lane] = pmY;
-  sp[k0 % 3][row][cX][lane] = p0X;       sp[k0 % 3][row][cY][lane] = p0Y;
-  sp[(k0 + 1) % 3][row][cX][lane] = p1X; sp[(k0 + 1) % 3][row][cY][lane] = p1Y;
-  __syncthreads();
-  {
-    double lo, hi; nbr_of_X(pmY, lo, hi);
-    CCoef q; cc_load_coef(L, cof(cofX, k0 - 1), q);
-    if (redX && k0 - 1 >= 0) pmX = cc_update_coef(L, q, pmX, lo, hi, sp[(k0 + 2) % 3][rm][cX][lane], sp[(k0 + 2) % 3][rp][cX][lane], pmmX, p0X);
-  }
-  {
-    double lo, hi; nbr_of_Y(p0X, lo, hi);
-    CCoef q; cc_load_coef(L, cof(cofY, k0), q);
-    if (redY) { p0Y = cc_update_coef(L, q, p0Y, lo, hi, sp[k0 % 3][rm][cY][lane], sp[k0 % 3][rp][cY][lane], pmY, p1Y); sp[k0 % 3][row][cY][lane] = p0Y; }
-  }
-  // one step: U = the working column, V = the other one
-  #define GW_STEP(k, U, V)                                                                                                         \
-  {                                                                                                                                \
-    cc_load_coef(L, cof(cof##V, (k) + 2), cr##V); cc_load_coef(L, cof(cof##V, (k) + 1), cb##V);   /* for step k+1 */               \
-    __syncthreads();                                            /* plane k+1 (old) and the red cells of plane k are visible */    \
-    sp[((k) + 2) % 3][row][cX][lane] = p2X; sp[((k) + 2) % 3][row][cY][lane] = p2Y;      /* old plane k+2, read in the next step */ \
-    double lo1, hi1, lo0, hi0;                                                                                                     \
-    nbr_of_##U(p1##V, lo1, hi1);                                                                                                   \
-    nbr_of_##U(p0##V, lo0, hi0);                                                                                                   \
-    if (red##U && (k) + 1 < nz) {                                                                                                  \
-      p1##U = cc_update_coef(L, cr##U, p1##U, lo1, hi1, sp[((k) + 1) % 3][rm][c##U][lane], sp[((k) + 1) % 3][rp][c##U][lane], p0##U, p2##U); \
-      sp[((k) + 1) % 3][row][c##U][lane] = p1##U;                                                                                  \
-    }                                                                                                                              \
-    if (out##U) p0##U = cc_update_coef(L, cb##U, p0##U, lo0, hi0, sp[(k) % 3][rm][c##U][lane], sp[(k) % 3][rp][c##U][lane], pm##U, p1##U); \
-    if (outX) pout[colX + (long)(k) * sz] = p0X;                                                                                   \
-    if (outY) pout[colY + (long)(k) * sz] = p0Y;                                                                                   \
-    pmX = p0X; p0X = p1X; p1X = p2X; p2X = q1X; q1X = q2X; q2X = ldp(colX, (k) + 5);                                               \
-    pmY = p0Y; p0Y = p1Y; p1Y = p2Y; p2Y = q1Y; q1Y = q2Y; q2Y = ldp(colY, (k) + 5);                                               \
-  }
-  int k = k0;
-  for (; k + 1 <= k1; k += 2) {
-    GW_STEP(k, X, Y)
-    GW_STEP(k + 1, Y, X)
-  }
-  if (k <= k1) GW_STEP(k, X, Y)
-  #undef GW_STEP
-}
-static void cc_launch_wave(CLev &L, int nsweeps) {
-  const int tx = (L.n[0] + GW_OX - 1) / GW_OX, ty = (L.n[1] + GW_OY - 1) / GW_OY;
-  int kchunk = L.n[2];
-  while (kchunk > 32 && tx * ty * ((L.n[2] + kchunk - 1) / kchunk) < 512) kchunk = (kchunk + 1) / 2;
-  kchunk += kchunk & 1;                                       // even: the column roles of a chunk follow from (j + k0)
-  const int nch = (L.n[2] + kchunk - 1) / kchunk;
-  for (int s = 0; s < nsweeps; s++) {
-    hipLaunchKernelGGL(kk_cc_gsrb_wave, dim3(tx, ty, nch), dim3(GW_L, GW_Y, 1), 0, ctx().stream, L, (const double *)L.phi, L.phi2, kchunk);
-    std::swap(L.phi, L.phi2);
-  }
-}
-
+// (Rounds 1-2 measured two fused red+black sweeps -- an LDS plane ring and register / DPP column pairs: 0.30 and 0.33 ms per sweep at 256^3 against
+// 2 x 0.116 ms for two colour passes; both were bit-identical and slower, and were removed in round 4.  DESIGN.md section 9.)
 template <bool RHO> DEVI void cc_residual_body(const CLev &L, double *nrm) {
   int bx, by, bz; xcd_block(bx, by, bz);
   const int i = bx * blockDim.x + threadIdx.x;
@@ -1147,7 +937,7 @@ static CLev cc_alloc_lev(const int n[3], const double h[3], bool has_alpha) {
   L.phi = base; L.rh = base + L.sz; L.res = base + 2 * L.sz;
   for (int d = 0; d < 3; d++) L.b[d] = base + (3 + d) * L.sz;
   L.alpha = has_alpha ? base + 6 * L.sz : nullptr;
-  L.phi2 = nullptr; L.rho = nullptr;
+  L.rho = nullptr;
   for (int d = 0; d < 3; d++) L.fold[d][0] = L.fold[d][1] = VDN_BC_INT;
   return L;
 }
@@ -1195,16 +985,7 @@ static void cc_build(CCMG &M, const vdn_multifab *rh, const double *dx, const in
       x.owner = la->owner[lev][g];
       if (x.owner == ctx().rank) {
         CBox B; B.L = cc_alloc_lev(n, h, has_alpha); B.gidx = g;
-        // the fused red+black sweeps are opt-in experiments (VDN_FUSED_GSRB=1: LDS plane ring, =2: register/shuffle column
-        // pairs): measured on MI355X at 256^3 they take 0.30 ms (=1) and 0.33 ms (=2) per sweep against 2 x 0.15 ms for two
-        // colour-pass launches, and are slower still on the 64^3 / 128^3 levels.  Halving the HBM traffic does not pay here: the
-        // plane pipeline costs a barrier per plane, the halo rings recompute 40 % of the red cells, and the f64 divisions of two
-        // updates per thread and step keep the SIMDs busy for ~2 us per plane -- see DESIGN.md
-        static const bool use_fused = vdn_env("VDN_FUSED_GSRB") && atoi(vdn_env("VDN_FUSED_GSRB")) >= 1;
-        if (use_fused && nb == 1 && !(M.per[0] || M.per[1] || M.per[2]) && (long)n[0] * n[1] * n[2] > 32L * 32 * 32) {
-          B.L.phi2 = (double *)arena_alloc(sizeof(double) * B.L.sz);
-          HIPCHK(hipMemsetAsync(B.L.phi2, 0, sizeof(double) * B.L.sz, ctx().stream));
-        } for (int d = 0; d < 3; d++) B.lo[d] = lo[d];
+        for (int d = 0; d < 3; d++) B.lo[d] = lo[d];
         x.fv = cc_phi_view(B.L, lo);
         DL.boxes.push_back(B);
       }
@@ -1284,25 +1065,11 @@ static void cc_halo(CCMG &M, CDLev &DL) { if (DL.halo) xplan_run(DL.halo); }
 // levels of at most 8^3 cells held in ONE box are smoothed by a single workgroup in one launch (all sweeps, both
 // colours, periodic images included): such levels are launch-latency bound, not bandwidth bound
 static const long SMALL_LEVEL_CELLS = 8L * 8 * 8;
-static void cc_launch_wave(CLev &L, int nsweeps);
-static void cc_launch_fused(CLev &L, int nsweeps) {
-  static const int mode = vdn_env("VDN_FUSED_GSRB") ? atoi(vdn_env("VDN_FUSED_GSRB")) : 0;
-  if (mode == 2) { cc_launch_wave(L, nsweeps); return; }
-  const int tiles = ((L.n[0] + FT_X - 1) / FT_X) * ((L.n[1] + FT_Y - 1) / FT_Y);
-  int kchunk = L.n[2];
-  while (kchunk > 16 && tiles * ((L.n[2] + kchunk - 1) / kchunk) < 1024) kchunk = (kchunk + 1) / 2;
-  const int nch = (L.n[2] + kchunk - 1) / kchunk;
-  for (int s = 0; s < nsweeps; s++) {
-    hipLaunchKernelGGL(kk_cc_gsrb_fused, dim3((L.n[0] + FT_X - 1) / FT_X, (L.n[1] + FT_Y - 1) / FT_Y, nch), dim3(256), 0, ctx().stream, L, (const double *)L.phi, L.phi2, kchunk);
-    std::swap(L.phi, L.phi2);
-  }
-}
 static void cc_gsrb_d(CCMG &M, CDLev &DL, int nsweeps) {
   if (DL.single_box && DL.boxes.size() == 1 && (long)DL.ng[0] * DL.ng[1] * DL.ng[2] <= SMALL_LEVEL_CELLS) {
     hipLaunchKernelGGL(kk_cc_bottom, dim3(1), dim3(1024), 0, ctx().stream, DL.boxes[0].L, nsweeps, M.per[0], M.per[1], M.per[2]);
     return;
   }
-  if (DL.single_box && DL.boxes.size() == 1 && DL.boxes[0].L.phi2) { cc_launch_fused(DL.boxes[0].L, nsweeps); return; }
   // halo exchange next to the pass: when part of the halo comes from another rank (or VDN_OVERLAP=1, the one-GPU rehearsal) the packed
   // traffic -- pack kernels, the ncclSend / ncclRecv group, box-to-box copies, unpack kernels -- runs on ctx().halo_stream while the
   // launch stream updates the cells that read no ghost value; the one-cell shell follows when the halo has landed
@@ -1398,7 +1165,7 @@ static bool cc_small_end(const CCMG &M, int dl, int tl) {
     if (!M.tail.empty() && !(ctx().nranks == 1 && M.dlev.back().single_box)) return false;
     for (int m = dl; m < (int)M.dlev.size(); m++) {
       const CDLev &D = M.dlev[m];
-      if (!(D.single_box && D.boxes.size() == 1 && !D.boxes[0].L.phi2 && !D.boxes[0].L.rho && (long)D.ng[0] * D.ng[1] * D.ng[2] <= tail_cells) || nl == CC_TAIL_MAX) return false;
+      if (!(D.single_box && D.boxes.size() == 1 && !D.boxes[0].L.rho && (long)D.ng[0] * D.ng[1] * D.ng[2] <= tail_cells) || nl == CC_TAIL_MAX) return false;
       T.L[nl++] = D.boxes[0].L;
     }
   }
@@ -1468,7 +1235,7 @@ static void cc_prolong_smooth(CCMG &M, int l, int nsweeps) {
   static const bool fuse = !(vdn_env("VDN_MG_PROLONG_FUSED") && atoi(vdn_env("VDN_MG_PROLONG_FUSED")) == 0);
   static const bool paired = !(vdn_env("VDN_GSRB_PAIR") && atoi(vdn_env("VDN_GSRB_PAIR")) == 0);
   const bool ok = fuse && paired && nsweeps >= 1 && DL.single_box && DL.boxes.size() == 1 && !DL.halo && l + 1 < (int)M.dlev.size() && M.dlev[l + 1].boxes.size() == 1 &&
-                  !(M.per[0] || M.per[1] || M.per[2]) && DL.boxes[0].L.rho && !DL.boxes[0].L.phi2 &&
+                  !(M.per[0] || M.per[1] || M.per[2]) && DL.boxes[0].L.rho &&
                   DL.boxes[0].L.n[0] % 2 == 0 && DL.boxes[0].L.n[1] % 2 == 0 && DL.boxes[0].L.n[2] % 2 == 0 && DL.boxes[0].L.n[0] >= 128;
   if (!ok) { cc_prolong_up(M, l); cc_gsrb_d(M, DL, nsweeps); return; }
   const CLev &L = DL.boxes[0].L, &C = M.dlev[l + 1].boxes[0].L;
@@ -1486,7 +1253,7 @@ static bool cc_lds_level(const CCMG &M, int l) {
   const CDLev &D = M.dlev[l], &DC = M.dlev[l + 1];
   if (!(D.single_box && D.boxes.size() == 1 && !D.halo && DC.single_box && DC.boxes.size() == 1)) return false;
   const CLev &L = D.boxes[0].L;
-  if (L.phi2 || L.rho) return false;
+  if (L.rho) return false;
   for (int d = 0; d < 3; d++) if (L.n[d] % LT || L.n[d] < 2 * LT || L.n[d] > nmax_ || D.boxes[0].lo[d] != 0 || DC.boxes[0].L.n[d] * 2 != L.n[d]) return false;
   return true;
 }
@@ -1614,7 +1381,7 @@ void cc_keep_free(CcKeep *k) { delete k; }
 // it is captured once and replayed; the key hashes every value the launches read from the host side.
 static void cc_key_lev(GraphKey &k, const CLev &L) {
   k.put(L.n); k.put(L.PX); k.put(L.PY); k.put(L.sz); k.put(L.hi2); k.put(L.phi); k.put(L.rh); k.put(L.res); k.put(L.b); k.put(L.alpha);
-  k.put(L.phi2); k.put(L.rho); k.put(L.fold);
+  k.put(L.rho); k.put(L.fold);
 }
 static unsigned long long cc_graph_key(const CCMG &M, int what) {
   const vdn_params &P = ctx().prm;
@@ -1629,9 +1396,8 @@ static unsigned long long cc_graph_key(const CCMG &M, int what) {
   return k.h;
 }
 static bool cc_graphable(const CCMG &M) {
-  if (!graphs_enabled()) return false;
-  for (const CDLev &DL : M.dlev) for (const CBox &B : DL.boxes) if (B.L.phi2) return false;     // the fused sweeps swap phi / phi2 on the host
-  return true;
+  (void)M;
+  return graphs_enabled();
 }
 template <class Body> static void cc_run_cycle(CCMG &M, int what, Body body) {
   if (!cc_graphable(M)) { body(); return; }
@@ -1657,7 +1423,7 @@ static void cc_setup(CCMG &M, vdn_multifab *rh, vdn_multifab *phi, const vdn_mul
   const vdn_layout *la = rh->la; const int lev = rh->lev;
   CDLev &D0 = M.dlev[0];
   // beta = 2 / (rho_i + rho_i-1) (the MAC projection): the finest level recomputes it from rho; not with the fused sweeps (they read b)
-  const bool from_rho = rho && !alpha && beta_from_rho() && rho->ng >= 1 && !(D0.boxes.size() && D0.boxes[0].L.phi2);
+  const bool from_rho = rho && !alpha && beta_from_rho() && rho->ng >= 1;
   for (size_t b = 0; b < D0.boxes.size(); b++) {
     CLev &L0 = D0.boxes[b].L;
     const vdn_box &bx = rh->vbox[b];
@@ -1915,17 +1681,11 @@ void cc_bench_smoother(vdn_multifab *rh, vdn_multifab *phi, vdn_multifab **beta,
   hipStream_t st = ctx().stream;
   hipEvent_t e0, e1; HIPCHK(hipEventCreate(&e0)); HIPCHK(hipEventCreate(&e1));
   CLev &Lm = M.dlev[0].boxes[0].L;
-  if (Lm.phi2) {           // the fused sweep is what the solver runs: time full sweeps, reported per colour pass (nlaunch counts passes)
-    cc_launch_fused(Lm, 2);
-    HIPCHK(hipEventRecord(e0, st));
-    cc_launch_fused(Lm, nlaunch / 2);
-    HIPCHK(hipEventRecord(e1, st));
-  } else {
+  (void)Lm;
   for (int w = 0; w < 4; w++) launch_gsrb(L, w & 1, st);
   HIPCHK(hipEventRecord(e0, st));
   for (int w = 0; w < nlaunch; w++) launch_gsrb(L, w & 1, st);
   HIPCHK(hipEventRecord(e1, st));
-  }
   HIPCHK(hipEventSynchronize(e1));
   float ms = 0; HIPCHK(hipEventElapsedTime(&ms, e0, e1));
   *avg_ms = (double)ms / nlaunch; *cells = (long)L.n[0] * L.n[1] * L.n[2];
@@ -2070,7 +1830,7 @@ void do_macproject(vdn_layout *mla, vdn_multifab **umac, vdn_multifab **rho, vdn
   {
     static const bool fast_on = !(vdn_env("VDN_MAC_FAST") && atoi(vdn_env("VDN_MAC_FAST")) == 0);
     // the second level must exist (its coefficients come from the first level's rho): boxes that halve cleanly to >= 4 cells, as cc_build asks
-    bool ok = fast_on && beta_from_rho() && rho[n]->ng >= 1 && !vdn_env("VDN_FUSED_GSRB");
+    bool ok = fast_on && beta_from_rho() && rho[n]->ng >= 1;
     {   // cc_build's rule for a second DISTRIBUTED level: the domain coarsens, the boxes halve cleanly and stay at least min_dist wide
       const int agglom = vdn_env("VDN_MG_AGGLOM") ? std::max(4, atoi(vdn_env("VDN_MG_AGGLOM"))) : 64;
       const int min_dist = mla->boxes[n].size() > 1 ? agglom : 4;

@@ -143,7 +143,6 @@ static const EnvSwitch g_switches[] = {
   { "VDN_GOD_UPDATE", "0: update_3d as its own pass instead of inside the fused mkflux march" },
   { "VDN_GSRB_PAIR", "0: one cell per thread in the colour passes / residuals of wide levels instead of the 2 x 2 pair form" },
   { "VDN_CC_HALO_FACES", "0: the cell-centred multigrid exchanges the whole ghost shell instead of the faces only" },
-  { "VDN_FUSED_GSRB", "1 / 2: the fused red+black sweep experiments (LDS plane ring / register column pairs) -- slower, kept for their bit-equality test" },
   { "VDN_MG_AGGLOM", "several boxes: smallest box extent (cells) of a multigrid level that stays distributed; below it the level is gathered and relaxed on every rank (default 64)" },
   { "VDN_OVERLAP", "halo exchange of multigrid passes next to interior work: 1 always, 0 never, default: when a plan has a remote peer and the box is large" },
   { "VDN_OVERLAP_MIN", "smallest box (cells / nodes) whose halo exchange is overlapped (default 2^20)" },
