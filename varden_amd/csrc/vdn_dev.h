@@ -261,6 +261,16 @@ template <class K> struct CellB { Range3 r; int g[3]; K a;
 template <class K> static inline void launch_cells(const std::vector<std::pair<K, Range3>> &v, hipStream_t st) {
   if (v.empty()) return;
   if (v.size() == 1) { hipLaunchKernelGGL((kk_cell<K>), grid_for(v[0].second), dim3(64, 4, 1), 0, st, v[0].first, v[0].second); return; }
+  // a few LARGE boxes (512^3 cut into eight 256^3 boxes): box by box with the by-value kernel -- the descriptor form pays for its indirection there
+  // (mkumac: 5.7 ms for eight boxes against 8 x 0.25, profiles/r04_bench512_kernel_stats.csv); the same cell() per cell, the same bits
+  if (v.size() <= 16) {
+    long cells = 0;
+    for (const auto &e : v) cells += (long)(e.second.hi[0] - e.second.lo[0] + 1) * (e.second.hi[1] - e.second.lo[1] + 1) * (e.second.hi[2] - e.second.lo[2] + 1);
+    if (cells / (long)v.size() >= 96L * 96 * 96) {
+      for (const auto &e : v) hipLaunchKernelGGL((kk_cell<K>), grid_for(e.second), dim3(64, 4, 1), 0, st, e.first, e.second);
+      return;
+    }
+  }
   std::vector<CellB<K>> b(v.size());
   for (size_t i = 0; i < v.size(); i++) { b[i].r = v[i].second; b[i].a = v[i].first; }
   launch_batched(b, 0, (double *)nullptr, 0, st);
