@@ -63,14 +63,18 @@ extern "C" int vdn_advance_timestep(int istep, vdn_layout *mla, vdn_multifab **s
   if (viscous) for (int n = nlevs - 1; n >= 1; n--) ml_cc_restriction(lapu[n - 1], lapu[n], 0, dm);     // cc_applyop per level, then average down
   // velpred (advance_premac) and the velocity mkflux (velocity_advance) both start from the limited slopes of the same uold: the
   // reference computes them twice (velpred.f90:1985-1990, mkflux.f90:1207-1212); one level of one box keeps velpred's for mkflux
-  ctx().slope_src = nullptr; ctx().macmax_src = nullptr; ctx().macmax_cache = nullptr;
-  for (int d = 0; d < 3; d++) ctx().slope_cache[d] = nullptr;
-  if (nlevs == 1 && dm == 3 && uold[0]->nfabs() == 1 && !vdn_env("VDN_NO_SLOPE_CACHE")) {
-    const vdn_box &b = uold[0]->vbox[0];
-    const size_t fld = (size_t)(b.hi[0] - b.lo[0] + 3) * (b.hi[1] - b.lo[1] + 3) * (b.hi[2] - b.lo[2] + 3) * sizeof(double);
-    for (int d = 0; d < 3; d++) ctx().slope_cache[d] = (double *)arena_alloc(fld * 3);
-    // likewise max |umac| (the dead band of the upwinding, mkflux.f90:1374-1401): scalar_advance and velocity_advance see the same MAC field
-    ctx().macmax_cache = (double *)arena_alloc(256); ctx().macmax_src = nullptr;
+  ctx().drop_step_caches();
+  if (nlevs == 1 && dm == 3 && god_per_box(uold[0]) && !vdn_env("VDN_NO_SLOPE_CACHE")) {
+    const int nb = uold[0]->nfabs();
+    for (int d = 0; d < 3; d++) ctx().slope_cache[d].assign(nb, nullptr);
+    ctx().slope_src.assign(nb, nullptr); ctx().macmax_cache.assign(nb, nullptr); ctx().macmax_src.assign(nb, nullptr);
+    for (int ib = 0; ib < nb; ib++) {
+      const vdn_box &b = uold[0]->vbox[ib];
+      const size_t fld = (size_t)(b.hi[0] - b.lo[0] + 3) * (b.hi[1] - b.lo[1] + 3) * (b.hi[2] - b.lo[2] + 3) * sizeof(double);
+      for (int d = 0; d < 3; d++) ctx().slope_cache[d][ib] = (double *)arena_alloc(fld * 3);
+      // likewise max |umac| (the dead band of the upwinding, mkflux.f90:1374-1401): scalar_advance and velocity_advance see the same MAC field
+      ctx().macmax_cache[ib] = (double *)arena_alloc(256);
+    }
   }
 
   // advance_premac.f90:44-51
@@ -205,8 +209,7 @@ extern "C" int vdn_advance_timestep(int istep, vdn_layout *mla, vdn_multifab **s
   #undef DXL
 
   arena_reset();
-  ctx().slope_src = nullptr; ctx().macmax_src = nullptr; ctx().macmax_cache = nullptr;
-  for (int d = 0; d < 3; d++) ctx().slope_cache[d] = nullptr;
+  ctx().drop_step_caches();
   ctx().step_sec[4] = wall() - t_begin;
   if (P.verbose >= 1 && ctx().rank == 0) {                                              // advance_timestep.f90:159-166
     printf(" Timing summary:\n Scalar   update: %g seconds\n Velocity update: %g seconds\n  MAC Projection: %g seconds\n   HG Projection: %g seconds\n\n",

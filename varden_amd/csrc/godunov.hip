@@ -424,6 +424,7 @@ static bool use_batched(const vdn_multifab *s) {
   for (int b = 0; b < s->nfabs(); b++) cells += (long)(s->vbox[b].hi[0] - s->vbox[b].lo[0] + 1) * (s->vbox[b].hi[1] - s->vbox[b].lo[1] + 1) * (s->vbox[b].hi[2] - s->vbox[b].lo[2] + 1);
   return !(s->nfabs() <= 16 && cells / s->nfabs() >= 96L * 96 * 96);
 }
+bool god_per_box(const vdn_multifab *s) { return s->nfabs() >= 1 && !use_batched(s); }
 static bool plain_godunov() { static const bool p = vdn_env("VDN_GODUNOV_PLAIN") != nullptr; return p; }
 // parameters of the marching bodies: by value under the by-value kernels, references into the (constant) descriptor under the batched ones
 template <class T, bool R> struct Prm { typedef T type; };
@@ -1456,19 +1457,19 @@ bool k_mkflux(const vdn_multifab *s, vdn_multifab **sedge, vdn_multifab **flux, 
     FV w = work_fv(nullptr, bp, 0);
     const size_t fld = (size_t)w.sc * sizeof(double);
     FV sl[3], SI = w, SC = w;
-    const bool cached = is_vel && ncomp == 3 && s->nfabs() == 1 && ctx().slope_cache[0] && ctx().slope_src == s->fabs[ib].p;
-    for (int d = 0; d < 3; d++) { sl[d] = w; sl[d].p = cached ? ctx().slope_cache[d] : (double *)arena_alloc(fld * ncomp); }
+    const bool cached = is_vel && ncomp == 3 && (int)ctx().slope_src.size() == s->nfabs() && ctx().slope_src[ib] == s->fabs[ib].p;
+    for (int d = 0; d < 3; d++) { sl[d] = w; sl[d].p = cached ? ctx().slope_cache[d][ib] : (double *)arena_alloc(fld * ncomp); }
     SI.p = (double *)arena_alloc(fld * 3 * ncomp);
     SC.p = (double *)arena_alloc(fld * 6 * ncomp);
     Range3 rg, rf;
     for (int d = 0; d < 3; d++) { rg.lo[d] = A.lo[d] - 1; rg.hi[d] = A.hi[d] + 1; rf.lo[d] = A.lo[d]; rf.hi[d] = A.hi[d] + 1; }
     const FV &um = umac[0]->fabs[ib], &vm = umac[1]->fabs[ib], &wm = umac[2]->fabs[ib];
-    const bool mm_keep = ctx().macmax_cache != nullptr && s->nfabs() == 1;       // advance_timestep: one reduction serves both mkflux calls of the step
-    double *umax = mm_keep ? ctx().macmax_cache : (double *)arena_alloc(256);
-    if (!(mm_keep && ctx().macmax_src == um.p)) {
+    const bool mm_keep = (int)ctx().macmax_cache.size() == s->nfabs();       // advance_timestep: one reduction serves both mkflux calls of the step
+    double *umax = mm_keep ? ctx().macmax_cache[ib] : (double *)arena_alloc(256);
+    if (!(mm_keep && ctx().macmax_src[ib] == um.p)) {
       HIPCHK(hipMemsetAsync(umax, 0, sizeof(double), st));
       hipLaunchKernelGGL(kk_macmax, reduce_grid(rf), dim3(64, 4, 1), 0, st, um, vm, wm, A, rf, umax);
-      if (mm_keep) ctx().macmax_src = um.p;
+      if (mm_keep) ctx().macmax_src[ib] = um.p;
     }
     if (!cached) launch_slopes(s->fabs[ib], sl, A, rg, ncomp, nullptr, st);
     if (plain_godunov()) {
@@ -1504,7 +1505,7 @@ bool k_mkflux(const vdn_multifab *s, vdn_multifab **sedge, vdn_multifab **flux, 
         fused = fused_args(FA[c0], A, c0, s->fabs[ib], sl, um, vm, wm, force->fabs[ib], mac_rhs->fabs[ib], sedge[0]->fabs[ib], sedge[1]->fabs[ib], sedge[2]->fabs[ib],
                            flux[0]->fabs[ib], flux[1]->fabs[ib], flux[2]->fabs[ib]);
       static const bool upd_env = !(vdn_env("VDN_GOD_UPDATE") && atoi(vdn_env("VDN_GOD_UPDATE")) == 0);
-      bool do_upd = fused && upd && upd_env && s->nfabs() == 1;
+      bool do_upd = fused && upd && upd_env;        // (every box of a box-by-box level: the conditions are geometric and the same for all of them -- checked below)
       for (int c0 = 0; c0 < ncomp && do_upd; c0++) do_upd = fused_update_args(FA[c0], A, c0, upd->snew->fabs[ib], force->fabs[ib], *upd, ib);
       if (fused) {                 // stages B + C + D in one march per component, boundary rules inside (see mk_F_m_body)
         int klF;
@@ -1528,6 +1529,7 @@ bool k_mkflux(const vdn_multifab *s, vdn_multifab **sedge, vdn_multifab **flux, 
           else if (p2) hipLaunchKernelGGL((kk_mk_F_m<true, false, false, true>), gF, blk, 0, st, FA[c0], rf, klF, umax);
           else hipLaunchKernelGGL((kk_mk_F_m<true, false>), gF, blk, 0, st, FA[c0], rf, klF, umax);
         }
+        REQUIRE(ib == 0 || updated == do_upd, "mkflux: the update would ride along on some boxes of the level only");
         updated = do_upd;
       } else if (slab_bc()) {      // interior marches, then the face-centred code on the boundary slabs (see kk_slabs)
         const MkPlain P{ s->fabs[ib], sl[0], sl[1], sl[2], um, vm, wm, force->fabs[ib], mac_rhs->fabs[ib], SI, SC,
@@ -2637,9 +2639,9 @@ void k_velpred(const vdn_multifab *u, vdn_multifab **umac, const vdn_multifab *f
     FV w = work_fv(nullptr, bp, 0);
     const size_t fld = (size_t)w.sc * sizeof(double);
     FV sl[3], UI = w, XC = w;
-    const bool keep = ctx().slope_cache[0] != nullptr && u->nfabs() == 1;           // advance_timestep: mkflux(uold) reuses these slopes
-    for (int d = 0; d < 3; d++) { sl[d] = w; sl[d].p = keep ? ctx().slope_cache[d] : (double *)arena_alloc(fld * 3); }
-    if (keep) ctx().slope_src = u->fabs[ib].p;
+    const bool keep = (int)ctx().slope_src.size() == u->nfabs();           // advance_timestep: mkflux(uold) reuses these slopes
+    for (int d = 0; d < 3; d++) { sl[d] = w; sl[d].p = keep ? ctx().slope_cache[d][ib] : (double *)arena_alloc(fld * 3); }
+    if (keep) ctx().slope_src[ib] = u->fabs[ib].p;
     UI.p = (double *)arena_alloc(fld * 9);
     XC.p = (double *)arena_alloc(fld * 6);
     double *umax = (double *)arena_alloc(256);

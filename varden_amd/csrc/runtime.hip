@@ -34,8 +34,7 @@ void arena_reset() {
   g_temp_mfs.clear();
   if (arena_poison() && g_ctx.arena && g_ctx.arena_peak > 0) HIPCHK(hipMemsetAsync(g_ctx.arena, 0xFF, std::min(g_ctx.arena_peak + (size_t)(64 << 20), g_ctx.arena_bytes), g_ctx.stream));
   g_ctx.arena_off = 0;
-  g_ctx.slope_src = nullptr; g_ctx.macmax_src = nullptr; g_ctx.macmax_cache = nullptr;
-  for (int d = 0; d < 3; d++) g_ctx.slope_cache[d] = nullptr;
+  g_ctx.drop_step_caches();
 }
 // make sure the arena holds at least `bytes`; only legal while nothing is live in it
 void arena_reserve(size_t bytes) {

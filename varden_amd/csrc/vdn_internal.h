@@ -90,9 +90,11 @@ struct VdnCtx {
   double *d_hist = nullptr;                                 // 64 norms of consecutive V-cycles + (slot 64, as an integer) their count: norm_hist_*
   double step_sec[5] = {0, 0, 0, 0, 0};
   int solver_cycles[2] = {0, 0}; double solver_res0[2] = {0, 0}, solver_res[2] = {0, 0};
-  // slopes of uold, computed by velpred and used again by the velocity mkflux of the same advance_timestep (one level, one box)
-  double *slope_cache[3] = {nullptr, nullptr, nullptr}; const double *slope_src = nullptr;
-  double *macmax_cache = nullptr; const double *macmax_src = nullptr;   // max |umac| of a one-box level, kept from the scalar mkflux for the velocity mkflux of the step
+  // per local box of a level handled box by box (one box, or a few large ones): the slopes of uold computed by velpred are used again by the velocity
+  // mkflux of the same advance_timestep, max |umac| of the scalar mkflux by the velocity mkflux (empty vectors: off)
+  std::vector<double *> slope_cache[3]; std::vector<const double *> slope_src;
+  std::vector<double *> macmax_cache; std::vector<const double *> macmax_src;
+  void drop_step_caches() { for (int d = 0; d < 3; d++) slope_cache[d].clear(); slope_src.clear(); macmax_cache.clear(); macmax_src.clear(); }
 };
 VdnCtx &ctx();
 
@@ -212,6 +214,7 @@ double mf_max_ratio3(vdn_multifab *const *a, vdn_multifab *const *b);      // ma
 void mf_restrict_and_fill(vdn_multifab *mf, int icomp, int bcomp, int nc, bool same_boundary, const vdn_bc_tower *bct);
 
 // godunov.hip
+bool god_per_box(const vdn_multifab *s);       // the level takes the box-by-box Godunov path (one box, or a few large boxes), not the box-batched one
 void k_velpred(const vdn_multifab *u, vdn_multifab **umac, const vdn_multifab *force, const double *dx, double dt,
                const vdn_bc_tower *bct);
 // k_mkflux with the update that follows it inside the same march (godunov.hip, UPD): snew and the update's forcing term -- fmode 0: the
