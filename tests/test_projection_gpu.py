@@ -50,7 +50,7 @@ def test_cc_smoother_bits(gpu, oracle, bcname, n):
 
 
 @pytest.mark.parametrize("bcname", ["walls", "periodic", "inout", "mixed"])
-@pytest.mark.parametrize("n", [(16, 16, 16), (32, 16, 8), (12, 20, 24)])
+@pytest.mark.parametrize("n", [(16, 16, 16), (32, 16, 8), (12, 20, 24), (128, 16, 32)])      # 128 wide: the 2 x 2 pair passes on a flat box
 def test_cc_solve(gpu, oracle, bcname, n):
     from varden_amd import advance as adv
     case = Case(n, BC_SETS[bcname], seed=12, iso=True)
@@ -136,7 +136,7 @@ def test_blown_up_field_fails_loudly(gpu, oracle):
 
 
 @pytest.mark.parametrize("bcname", ["walls", "periodic", "inout", "mixed"])
-@pytest.mark.parametrize("n", [(16, 16, 16), (8, 16, 32)])
+@pytest.mark.parametrize("n", [(16, 16, 16), (8, 16, 32), (128, 16, 32)])      # 128 wide: the paired march and the fused residual + restriction (kk_nd_march_pair_rst) on a flat box
 def test_nd_solve(gpu, oracle, bcname, n):
     from varden_amd import advance as adv
     case = Case(n, BC_SETS[bcname], seed=14, iso=True)
