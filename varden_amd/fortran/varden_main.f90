@@ -5,7 +5,7 @@
 ! runs the start-up sequence (initial projection varden.f90:126-138, ghost fills :165-178, first dt :186-199, pressure iterations :460-490) and
 ! the time loop (varden.f90:237-345: regrid every regrid_int steps :256-264 through src/regrid.f90:17-263 -- fillpatch, ml_nodal_prolongation,
 ! copies of the old data --, ghost fills, estdt over the levels, advance_timestep, new -> old) until max_step or stop_time.
-! Scope: dim_in = 3, a cubic unit domain, prob_type 1 (the bubble of src/initdata.f90:212-238), one rank; plot and checkpoint files stay with the
+! Scope: dim_in = 3, a cubic unit domain (every 3-D input of exec/test), prob_type 1 .. 4 (src/initdata.f90:190-306), one rank; plot and checkpoint files stay with the
 ! Python mirror (varden_amd/plotfile.py).  The Python mirror of the same flow (varden_amd/inputs.py: run) sits on the same C-ABI: every step prints
 ! time, dt, max|u| and the boxes per level with 17 significant digits and tests/test_fortran_gpu.py compares the two step for step.
 program varden_main
@@ -62,7 +62,7 @@ program varden_main
   if (dim_in /= 3) stop 'varden_main: dim_in = 3 only (the 2-D path is one level, one box: varden_amd/driver.py)'
   if (n_cellx /= n_celly .or. n_cellx /= n_cellz .or. prob_hi_x /= 1.d0 .or. prob_hi_y /= 1.d0 .or. prob_hi_z /= 1.d0) &
        stop 'varden_main: cubic unit domain only'
-  if (prob_type /= 1) stop 'varden_main: prob_type 1 only (the initial data of the other problems live in varden_amd/driver.py)'
+  if (prob_type < 1 .or. prob_type > 4) stop 'varden_main: prob_type 1 .. 4 (src/initdata.f90)'
   if (max_levs > MAXL) stop 'varden_main: at most 4 levels'
 
   call probin_defaults(prm)
@@ -288,33 +288,54 @@ contains
     call fill_levels(H, H%nlev)
   end subroutine fill_state_ghosts
 
-  ! initdata_3d, prob_type 1 (src/initdata.f90:212-238), on every box of level l: u = 0, rho = tracer = the tanh blob; ghost cells at the background
+  ! initdata_3d (src/initdata.f90:190-306) on every box of level l; ghost cells at the background state.  prob_type 1: the bubble (u = 0, rho = tracer = the
+  ! tanh blob, :212-238); 2: the same blob advected by u = (1, 0, 0) (:240-259); 3: the Rayleigh-Taylor interface (:195-200, 261-274; tracer 0);
+  ! 4: the vortex tube (:276-306; coordinates measured from the BOX's low corner, as the reference writes it)
   subroutine init_level(G, l)
     type(hier), intent(inout) :: G
     integer, intent(in) :: l
     real(dp_t), allocatable :: s0(:,:,:,:), u0(:,:,:,:)
     integer :: b, i, j, k, lo(3), hi(3)
-    real(dp_t) :: x, y, z, dist, r
+    real(dp_t) :: x, y, z, dist, r, xb, yb, zb, ryz
+    real(dp_t), parameter :: pi = 3.141592653589793238462643383279502884d0
     do b = 1, G%nb(l)
        lo = G%bx(b, l)%lo; hi = G%bx(b, l)%hi
        allocate(u0(lo(1)-3:hi(1)+3, lo(2)-3:hi(2)+3, lo(3)-3:hi(3)+3, dm), s0(lo(1)-3:hi(1)+3, lo(2)-3:hi(2)+3, lo(3)-3:hi(3)+3, nscal))
        u0 = 0.d0; s0(:,:,:,1) = 1.d0; s0(:,:,:,2:) = 0.d0
+       if (prob_type == 2) u0(:,:,:,1) = 1.d0
        do k = lo(3), hi(3)
           z = dx(l,3) * (k + 0.5d0)
           do j = lo(2), hi(2)
              y = dx(l,2) * (j + 0.5d0)
              do i = lo(1), hi(1)
                 x = dx(l,1) * (i + 0.5d0)
-                dist = sqrt((x - 0.5d0)**2 + (y - 0.5d0)**2 + (z - 0.5d0)**2)
-                r = 1.d0 + 0.5d0 * (10.d0 - 1.d0) * (1.d0 - tanh(30.d0 * (dist - 0.1d0)))
-                s0(i,j,k,1) = r
-                if (nscal > 1) s0(i,j,k,2) = r
+                select case (prob_type)
+                case (1, 2)
+                   dist = sqrt((x - 0.5d0)**2 + (y - 0.5d0)**2 + (z - 0.5d0)**2)
+                   r = 1.d0 + 0.5d0 * (10.d0 - 1.d0) * (1.d0 - tanh(30.d0 * (dist - 0.1d0)))
+                   s0(i,j,k,1) = r
+                   if (nscal > 1) s0(i,j,k,2) = r
+                case (3)
+                   s0(i,j,k,1) = 1.d0 + 0.5d0 + 0.5d0 * tanh((z - 0.5d0 - pert(x) - pert(y)) / 0.01d0)
+                case (4)
+                   xb = dx(l,1) * (i - lo(1) + 0.5d0) - 0.5d0; yb = dx(l,2) * (j - lo(2) + 0.5d0) - 0.5d0; zb = dx(l,3) * (k - lo(3) + 0.5d0) - 0.5d0
+                   ryz = sqrt(yb * yb + zb * zb)
+                   u0(i,j,k,1) = tanh((0.15d0 - ryz) / 0.0333d0)
+                   u0(i,j,k,3) = 0.05d0 * exp(-15.d0 * (xb * xb + yb * yb))
+                   s0(i,j,k,1) = 1.d0
+                   if (nscal > 1) s0(i,j,k,2) = exp(-500.d0 * (0.15d0 - ryz)**2)
+                end select
              end do
           end do
        end do
        call multifab_copy_from_host(G%uold(l), b, u0); call multifab_copy_from_host(G%sold(l), b, s0)
        deallocate(u0, s0)
     end do
+  contains
+    real(dp_t) function pert(t)
+      real(dp_t), intent(in) :: t
+      pert = 0.02d0 * sin(4.d0 * pi * t) + 0.01d0 * sin(8.d0 * pi * t)
+    end function pert
   end subroutine init_level
 
   subroutine make_temporaries()
