@@ -146,6 +146,9 @@ static inline void nd_fill_node1(const ndlev *L, double *a, const int per[3], in
 static void nd_fill_nodes(const ndlev *L, double *a, const int per[3])
 {
   const int *n = L->n;
+  /* without a periodic direction the rule only writes zeros into ghost nodes, and those are zero already: every node array of a level is calloc'ed and the
+   * sweeps, residuals, restrictions and prolongations write nodes 0 .. n only (the HIP levels rely on the same: ghosts zeroed at set-up, mg_nd.hip) */
+  if (!per[0] && !per[1] && !(L->dm == 3 && per[2])) return;
   const int k0 = L->dm == 2 ? 0 : -1, k1 = L->dm == 2 ? 0 : n[2] + 1;
   #pragma omp parallel for
   for (int k = k0; k <= k1; k++) for (int j = -1; j <= n[1] + 1; j++) {
