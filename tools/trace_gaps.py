@@ -3,7 +3,7 @@ durations, the idle time between kernels, and the largest gaps with the kernels 
 import sqlite3, sys, collections
 db = sqlite3.connect(sys.argv[1])
 rows = db.execute("select name, start, end, grid_x, grid_y, grid_z from kernels order by start").fetchall()
-est = [i for i, r in enumerate(rows) if r[0].startswith("kk_estdt")]
+est = [i for i, r in enumerate(rows) if r[0].startswith("kk_estdt(")]
 which = int(sys.argv[2]) if len(sys.argv) > 2 else len(est) - 2
 a, b = est[which], est[which + 1]
 seg = rows[a:b]
@@ -21,6 +21,12 @@ print("gap histogram (us: count, total ms):", [(k, v, round(sum(g for g, _ in ga
 print("largest gaps:")
 for g, i in sorted(gaps, reverse=True)[:25]:
     print("  %8.1f us after %-50s before %-50s" % (g / 1e3, seg[i - 1][0][:50], seg[i][0][:50]))
+grp = collections.defaultdict(lambda: [0, 0.0])
+for g, i in gaps:
+    if g >= 50e3: k = (seg[i - 1][0].split("(")[0][:44], seg[i][0].split("(")[0][:44]); grp[k][0] += 1; grp[k][1] += g / 1e6
+print("gaps of 50 us and more by the kernels around them (count, total ms):")
+for k, v in sorted(grp.items(), key=lambda kv: -kv[1][1])[:30]:
+    print("  %-46s -> %-46s %4d  %8.3f" % (k[0], k[1], v[0], v[1]))
 agg = collections.defaultdict(lambda: [0, 0.0])
 for r in seg:
     key = r[0].split("(")[0][:60] + (" g=%dx%dx%d" % (r[3], r[4], r[5]) if len(sys.argv) > 3 else "")

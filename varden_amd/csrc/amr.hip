@@ -99,13 +99,17 @@ void ml_cc_restriction(vdn_multifab *crse, const vdn_multifab *fine, int icomp, 
   const SrcView F = make_view(fine, refined_footprints(crse, -1, 0), level_owner(crse), icomp, nc, VT_REFINE);
   F.refresh();
   std::vector<RestrictB> v;
-  for (int f = 0; f < F.nboxes(); f++) for (int c = 0; c < crse->nfabs(); c++) {
+  const BoxBins cb(crse->vbox);
+  for (int f = 0; f < F.nboxes(); f++) {
     if (!F.have[f]) continue;
-    int clo[3], chi[3]; RestrictB a;
+    int clo[3], chi[3];
     for (int d = 0; d < 3; d++) { clo[d] = hfdiv2(F.vbox[f].lo[d]); chi[d] = hfdiv2(F.vbox[f].hi[d]); }
+    for (int c : cb.near(clo, chi, 1)) {
+    RestrictB a;
     if (!isect(clo, chi, crse->vbox[c].lo, crse->vbox[c].hi, a.r)) continue;
     a.crse = crse->fabs[c]; a.fine = F.fv[f]; a.icomp = icomp; a.nc = nc; a.fc0 = icomp;
     v.push_back(a);
+    }
   }
   launch_batched(v, 0, (double *)nullptr, 0, ctx().stream);
 }
@@ -128,14 +132,19 @@ void ml_edge_restriction(vdn_multifab *crse, const vdn_multifab *fine, int dir) 
   const SrcView F = make_view(fine, refined_footprints(crse, dir, 0), level_owner(crse), 0, 1, VT_REFINE_FACE0 + dir);
   F.refresh();
   std::vector<EdgeRestrictB> v;
-  for (int f = 0; f < F.nboxes(); f++) for (int c = 0; c < crse->nfabs(); c++) {
+  const BoxBins cb(crse->vbox);
+  for (int f = 0; f < F.nboxes(); f++) {
     if (!F.have[f]) continue;
+    int qlo[3], qhi[3];
+    for (int d = 0; d < 3; d++) { qlo[d] = hfdiv2(F.vbox[f].lo[d]); qhi[d] = hfdiv2(F.vbox[f].hi[d]); }
+    for (int c : cb.near(qlo, qhi, 2)) {
     int clo[3], chi[3], blo[3], bhi[3]; EdgeRestrictB a;
-    for (int d = 0; d < 3; d++) { clo[d] = hfdiv2(F.vbox[f].lo[d]); chi[d] = hfdiv2(F.vbox[f].hi[d]); blo[d] = crse->vbox[c].lo[d]; bhi[d] = crse->vbox[c].hi[d]; }
+    for (int d = 0; d < 3; d++) { clo[d] = qlo[d]; chi[d] = qhi[d]; blo[d] = crse->vbox[c].lo[d]; bhi[d] = crse->vbox[c].hi[d]; }
     chi[dir] += 1; bhi[dir] += 1;
     if (!isect(clo, chi, blo, bhi, a.r)) continue;
     a.crse = crse->fabs[c]; a.fine = F.fv[f]; a.dir = dir;
     v.push_back(a);
+    }
   }
   launch_batched(v, 0, (double *)nullptr, 0, ctx().stream);
 }
@@ -185,6 +194,7 @@ void ml_fill_ghost_cells(vdn_multifab *fine, const vdn_multifab *crse, int icomp
   Cv.refresh();
   std::vector<InterpB> v;
   const vdn_box &pdc = Cv.nboxes() == 1 ? Cv.vbox[0] : crse->la->pd[crse->lev];
+  const BoxBins cb(Cv.vbox, &Cv.have);
   for (int f = 0; f < fine->nfabs(); f++) {
     InterpArgs A; Range3 r;
     int glo[3], ghi[3];
@@ -192,8 +202,7 @@ void ml_fill_ghost_cells(vdn_multifab *fine, const vdn_multifab *crse, int icomp
       glo[d] = hfdiv2(r.lo[d]); ghi[d] = hfdiv2(r.hi[d]); }
     A.icomp = icomp; A.nc = nc; A.cc0 = icomp;
     for (int pass = 0; pass < 2; pass++)
-      for (int c = 0; c < Cv.nboxes(); c++) {
-        if (!Cv.have[c]) continue;
+      for (int c : cb.near(glo, ghi, Cv.ng + 1)) {
         int blo[3], bhi[3]; Range3 pr;
         for (int d = 0; d < 3; d++) { A.alo[d] = Cv.vbox[c].lo[d] - Cv.ng; A.ahi[d] = Cv.vbox[c].hi[d] + Cv.ng;
           blo[d] = pass == 0 ? Cv.vbox[c].lo[d] : A.alo[d]; bhi[d] = pass == 0 ? Cv.vbox[c].hi[d] : A.ahi[d]; }
@@ -228,9 +237,11 @@ void ml_fillpatch(vdn_multifab *fine, const vdn_multifab *crse, int icomp, int n
   const SrcView Cv = make_view(crse, coarsened_footprints(fine, 0, -1, 1), level_owner(fine), icomp, nc, VT_COARSEN_1);
   Cv.refresh();
   std::vector<InterpB> v;
-  for (int f = 0; f < fine->nfabs(); f++)
-    for (int c = 0; c < Cv.nboxes(); c++) {
-      if (!Cv.have[c]) continue;
+  const BoxBins cb(Cv.vbox, &Cv.have);
+  for (int f = 0; f < fine->nfabs(); f++) {
+    int qlo[3], qhi[3];
+    for (int d = 0; d < 3; d++) { qlo[d] = hfdiv2(fine->vbox[f].lo[d]); qhi[d] = hfdiv2(fine->vbox[f].hi[d]); }
+    for (int c : cb.near(qlo, qhi, 1)) {
       InterpB e; int plo[3], phi[3]; Range3 pr;
       for (int d = 0; d < 3; d++) {
         e.r.lo[d] = fine->vbox[f].lo[d]; e.r.hi[d] = fine->vbox[f].hi[d];
@@ -243,6 +254,7 @@ void ml_fillpatch(vdn_multifab *fine, const vdn_multifab *crse, int icomp, int n
       e.A.icomp = icomp; e.A.nc = nc; e.A.cc0 = icomp; e.fine = fine->fabs[f]; e.crse = Cv.fv[c];
       v.push_back(e);
     }
+  }
   launch_batched(v, 0, (double *)nullptr, 0, ctx().stream);
 }
 // ml_nodal_prolongation(fine, crse, rr) of src/regrid.f90:327: trilinear interpolation of a nodal field on every node of the fine level
@@ -261,9 +273,11 @@ void ml_nodal_prolongation(vdn_multifab *fine, vdn_multifab *crse) {
   const SrcView Cv = make_view(crse, coarsened_footprints(fine, 0, 3, 1), level_owner(fine), 0, 1, VT_NODE_C2F);
   Cv.refresh();
   std::vector<NodalProlongB> v;
-  for (int f = 0; f < fine->nfabs(); f++)
-    for (int c = 0; c < Cv.nboxes(); c++) {
-      if (!Cv.have[c]) continue;
+  const BoxBins cb(Cv.vbox, &Cv.have);
+  for (int f = 0; f < fine->nfabs(); f++) {
+    int qlo[3], qhi[3];
+    for (int d = 0; d < 3; d++) { qlo[d] = hfdiv2(fine->vbox[f].lo[d]); qhi[d] = hfdiv2(fine->vbox[f].hi[d] + 1); }
+    for (int c : cb.near(qlo, qhi, 2)) {
       NodalProlongB q; bool empty = false;
       for (int d = 0; d < 3; d++) {
         q.clo[d] = Cv.vbox[c].lo[d]; q.chi[d] = Cv.vbox[c].hi[d] + 1;
@@ -274,6 +288,7 @@ void ml_nodal_prolongation(vdn_multifab *fine, vdn_multifab *crse) {
       q.pf = fine->fabs[f]; q.pc = Cv.fv[c];
       v.push_back(q);
     }
+  }
   launch_batched(v, 0, (double *)nullptr, 0, ctx().stream);
 }
 // multifab_copy_c between two multifabs of the SAME index space whose box lists differ (src/regrid.f90:333-337): valid points of
@@ -287,9 +302,9 @@ void mf_copy_layouts(vdn_multifab *dst, int dcomp, const vdn_multifab *src, int 
   const SrcView Sv = make_view(src, fp, level_owner(dst), scomp, nc, 40 + dst->la->uid * 64);
   Sv.refresh();
   std::vector<CopyLB> v;
+  const BoxBins sb(Sv.vbox, &Sv.have);
   for (int a = 0; a < dst->nfabs(); a++)
-    for (int b = 0; b < Sv.nboxes(); b++) {
-      if (!Sv.have[b]) continue;
+    for (int b : sb.near(dst->vbox[a].lo, dst->vbox[a].hi, 2)) {
       CopyLB q; bool empty = false;
       for (int d = 0; d < 3; d++) {
         q.r.lo[d] = std::max(dst->vbox[a].lo[d], Sv.vbox[b].lo[d]);
@@ -326,6 +341,9 @@ void ml_create_umac_grown(vdn_multifab *fine, const vdn_multifab *crse, int dir)
   const SrcView Cv = make_view(crse, coarsened_footprints(fine, fine->ng, dir, 0), level_owner(fine), 0, 1, VT_COARSEN_0 + 4 * (dir + 1) + fine->ng * 64);
   Cv.refresh();
   std::vector<GrownB> v0, v1;
+  const BoxBins cb(Cv.vbox, &Cv.have);
+  int first_here = -1;
+  for (int c = 0; c < Cv.nboxes() && first_here < 0; c++) if (Cv.have[c]) first_here = c;
   for (int f = 0; f < fine->nfabs(); f++) {
     GrownB e; e.A.dir = dir; e.fine = fine->fabs[f];
     Range3 rfull;
@@ -336,15 +354,17 @@ void ml_create_umac_grown(vdn_multifab *fine, const vdn_multifab *crse, int dir)
       for (int d = 0; d < 3; d++) { q.r.lo[d] = std::max(rfull.lo[d], 2 * q.A.plo[d]); q.r.hi[d] = std::min(rfull.hi[d], 2 * q.A.phi[d] + 1); if (q.r.lo[d] > q.r.hi[d]) return false; }
       return true;
     };
-    bool first = true;
-    for (int c = 0; c < Cv.nboxes(); c++) {
-      if (!Cv.have[c]) continue;
+    if (first_here >= 0) {        // the first box present here, with its ghost faces
+      const int c = first_here;
       e.crse = Cv.fv[c];
-      if (first) {        // the first box present here, with its ghost faces
-        for (int d = 0; d < 3; d++) { e.A.plo[d] = Cv.vbox[c].lo[d] - Cv.ng; e.A.phi[d] = Cv.vbox[c].hi[d] + (d == dir) + Cv.ng; }
-        e.r = rfull;      // (kept whole: it is the one that also serves parents no box holds as valid faces)
-        v0.push_back(e); first = false;
-      }
+      for (int d = 0; d < 3; d++) { e.A.plo[d] = Cv.vbox[c].lo[d] - Cv.ng; e.A.phi[d] = Cv.vbox[c].hi[d] + (d == dir) + Cv.ng; }
+      e.r = rfull;      // (kept whole: it is the one that also serves parents no box holds as valid faces)
+      v0.push_back(e);
+    }
+    int qlo[3], qhi[3];
+    for (int d = 0; d < 3; d++) { qlo[d] = hfdiv2(rfull.lo[d]); qhi[d] = hfdiv2(rfull.hi[d]); }
+    for (int c : cb.near(qlo, qhi, 2)) {
+      e.crse = Cv.fv[c];
       if (Cv.nboxes() > 1) {
         for (int d = 0; d < 3; d++) { e.A.plo[d] = Cv.vbox[c].lo[d]; e.A.phi[d] = Cv.vbox[c].hi[d] + (d == dir); }
         if (clip(e)) v1.push_back(e);
@@ -407,16 +427,16 @@ struct CfB { Range3 r; int g[3]; static constexpr int planes_per_wg = 8; FV pf, 
 // ghost cells of the fine phi: coarse-fine interpolation on every face that is not a domain face, then the same-level exchange
 // (which overwrites the cells that another fine box covers); domain faces were closed by the closure
 static void cf_descs(vdn_multifab *pf, const SrcView &pc, const vdn_bc_tower *bct, int bc_comp0, std::vector<CfB> &v) {
+  const BoxBins cb(pc.vbox, &pc.have);
   for (int f = 0; f < pf->nfabs(); f++) for (int d = 0; d < 3; d++) for (int s = 0; s < 2; s++) {
     const int eb = bct->ell_bc(pf->lev, f + 1, d, s, bc_comp0);
     if (eb != VDN_BC_INT && eb != VDN_BC_PER) continue;        // periodic faces too: the same-level exchange then overwrites what the level itself covers
     Range3 r; for (int t = 0; t < 3; t++) { r.lo[t] = pf->vbox[f].lo[t]; r.hi[t] = pf->vbox[f].hi[t]; }
     r.lo[d] = r.hi[d] = s ? pf->vbox[f].hi[d] + 1 : pf->vbox[f].lo[d] - 1;
-    for (int c = 0; c < pc.nboxes(); c++) {
-      if (!pc.have[c]) continue;
+    int plo[3], phi[3]; Range3 dummy;
+    for (int t = 0; t < 3; t++) { plo[t] = hfdiv2(r.lo[t]); phi[t] = hfdiv2(r.hi[t]); }
+    for (int c : cb.near(plo, phi, 1)) {
       // only coarse boxes that hold a parent of this slab
-      int plo[3], phi[3]; Range3 dummy;
-      for (int t = 0; t < 3; t++) { plo[t] = hfdiv2(r.lo[t]); phi[t] = hfdiv2(r.hi[t]); }
       if (!isect(plo, phi, pc.vbox[c].lo, pc.vbox[c].hi, dummy)) continue;
       CfB a; a.r = r; a.pf = pf->fabs[f]; a.pc = pc.fv[c]; a.A.d = d; a.A.s = s;
       for (int t = 0; t < 3; t++) { a.A.plo[t] = pc.vbox[c].lo[t]; a.A.phi[t] = pc.vbox[c].hi[t]; }
@@ -565,13 +585,17 @@ struct MLCC { int nlev; vdn_layout *la; bool fuse_first = false;   /* the finest
               SrcView vc_phi[VDN_MAXLEV], vf_phi[VDN_MAXLEV], vf_res[VDN_MAXLEV], vf_beta[VDN_MAXLEV][3], vc_src[VDN_MAXLEV][VDN_MAXLEV];
 };
 static void restrict_descs(vdn_multifab *crse, const SrcView &fine, std::vector<RestrictB> &v) {
-  for (int f = 0; f < fine.nboxes(); f++) for (int c = 0; c < crse->nfabs(); c++) {
+  const BoxBins cb(crse->vbox);
+  for (int f = 0; f < fine.nboxes(); f++) {
     if (!fine.have[f]) continue;
-    int clo[3], chi[3]; RestrictB a;
+    int clo[3], chi[3];
     for (int d = 0; d < 3; d++) { clo[d] = hfdiv2(fine.vbox[f].lo[d]); chi[d] = hfdiv2(fine.vbox[f].hi[d]); }
-    if (!isect(clo, chi, crse->vbox[c].lo, crse->vbox[c].hi, a.r)) continue;
-    a.crse = crse->fabs[c]; a.fine = fine.fv[f]; a.icomp = 0; a.nc = 1; a.fc0 = 0;
-    v.push_back(a);
+    for (int c : cb.near(clo, chi, 1)) {
+      RestrictB a;
+      if (!isect(clo, chi, crse->vbox[c].lo, crse->vbox[c].hi, a.r)) continue;
+      a.crse = crse->fabs[c]; a.fine = fine.fv[f]; a.icomp = 0; a.nc = 1; a.fc0 = 0;
+      v.push_back(a);
+    }
   }
 }
 // a box face that is not on the domain boundary (what ell_bc == BC_INT says for a local box), for ANY box of the level
@@ -626,6 +650,7 @@ static void mlcc_build_sets(MLCC &S) {
     S.resid[n].build(vr, 0, st);          // (contiguous chunks of planes per workgroup: the k-1 / k+1 planes of phi stay in cache; its norm's atomics are rare, vdn_dev.h)
     S.absmax[n].build(va, 16, st); S.gsrb[n].build(vg, 0, st); S.add[n].build(vadd, 0, st);
     // flux matching on the cells of level n-1 next to the boxes of level n
+    const BoxBins cbins(n >= 1 ? S.phi[n - 1]->vbox : std::vector<vdn_box>());
     if (n >= 1)
       for (int d = 0; d < 3; d++) for (int s = 0; s < 2; s++) {
         std::vector<RefluxB> v;
@@ -637,7 +662,7 @@ static void mlcc_build_sets(MLCC &S) {
           int clo[3], chi[3];
           for (int t = 0; t < 3; t++) { clo[t] = hfdiv2(fb.lo[t]); chi[t] = hfdiv2(fb.hi[t]); }
           clo[d] = chi[d] = hfdiv2(s ? fb.hi[d] + 1 : fb.lo[d]);
-          for (int c = 0; c < S.phi[n - 1]->nfabs(); c++) {
+          for (int c : cbins.near(clo, chi, 2)) {
             int blo[3], bhi[3]; RefluxB q;
             for (int t = 0; t < 3; t++) { blo[t] = S.phi[n - 1]->vbox[c].lo[t]; bhi[t] = S.phi[n - 1]->vbox[c].hi[t]; }
             if (s == 0) { blo[d] += 1; bhi[d] += 1; }          // the coarse cell that gets the correction must be a valid cell of box c
@@ -659,14 +684,18 @@ static void mlcc_build_sets(MLCC &S) {
       const SrcView &src = S.vc_src[n][m];
       const bool keep = m < L - 1;
       std::vector<AddProlongB> v;
-      for (int f = 0; f < S.phi[m]->nfabs(); f++) for (int c = 0; c < src.nboxes(); c++) {
-        if (!src.have[c]) continue;
+      const BoxBins sb(src.vbox, &src.have);
+      for (int f = 0; f < S.phi[m]->nfabs(); f++) {
+        int qlo[3], qhi[3];
+        for (int d = 0; d < 3; d++) { qlo[d] = S.phi[m]->vbox[f].lo[d] / 2; qhi[d] = S.phi[m]->vbox[f].hi[d] / 2; }
+        for (int c : sb.near(qlo, qhi, 2)) {
         AddProlongB q; q.r = valid_range(S.phi[m], f); q.af = S.phi[m]->fabs[f]; q.sc = keep ? S.scr[m]->fabs[f] : S.phi[m]->fabs[f]; q.keep = keep ? 1 : 0; q.ec = src.fv[c];
         for (int d = 0; d < 3; d++) { q.plo[d] = src.vbox[c].lo[d]; q.phi[d] = src.vbox[c].hi[d]; }
         int plo[3], phi[3]; Range3 dummy;
         for (int d = 0; d < 3; d++) { plo[d] = q.r.lo[d] / 2; phi[d] = q.r.hi[d] / 2; }
         if (!isect(plo, phi, q.plo, q.phi, dummy)) continue;
         v.push_back(q);
+        }
       }
       S.prolong[n][m].build(v, 0, st);
     }
@@ -760,11 +789,15 @@ int ml_cc_solve(vdn_layout *la, vdn_multifab **rh, vdn_multifab **phi, vdn_multi
       S.mask[n] = mf_temp(la, n, 1, 0, -1, true, 0.0);
       std::vector<SetboxB> v;
       const std::vector<vdn_box> &fb = level_boxes(phi[n + 1]);
-      for (int f = 0; f < (int)fb.size(); f++) for (int c = 0; c < S.mask[n]->nfabs(); c++) {
-        int clo[3], chi[3]; SetboxB q;
+      const BoxBins mb(S.mask[n]->vbox);
+      for (int f = 0; f < (int)fb.size(); f++) {
+        int clo[3], chi[3];
         for (int d = 0; d < 3; d++) { clo[d] = fb[f].lo[d] / 2; chi[d] = fb[f].hi[d] / 2; }
+        for (int c : mb.near(clo, chi, 1)) {
+        SetboxB q;
         if (!isect(clo, chi, S.mask[n]->vbox[c].lo, S.mask[n]->vbox[c].hi, q.r)) continue;
         q.a = S.mask[n]->fabs[c]; q.v = 1.0; v.push_back(q);
+        }
       }
       launch_batched(v, 0, (double *)nullptr, 0, st);
     }

@@ -2256,17 +2256,29 @@ struct MLND {
   const vdn_layout *la = nullptr;
   SrcView vf_res[VDN_MAXLEV], vf_own[VDN_MAXLEV], vc_own[VDN_MAXLEV];   // [fine level]: fine residual / fine ownership seen from the coarse boxes, coarse ownership seen from the fine boxes
   BatchSet<NdfAbsmaxB> amax[VDN_MAXLEV];
+  // prolongations and additions of the iteration: the descriptor set of a (level, destination, source, kind) is built at its first use in the solve
+  // (the pair loop over fine x coarse boxes and the upload cost the host 0.7-1 ms per call on a level of a thousand boxes, the GPU idle meanwhile)
+  struct ProlongSet { SrcView Cv; BatchSet<NdmProlongB> s; BatchSet<NdmProlong8B> s8; };
+  std::map<std::tuple<int, const void *, const void *, int>, ProlongSet> pro;
+  std::map<std::tuple<int, const void *, const void *>, BatchSet<NdfAddB>> adds;
 };
 // mode 0: slaves of level n <- P phi_{n-1};  mode 1: dst_n += P src_{n-1};  mode 2: dst_n = P src_{n-1} (dst zeroed first by the caller)
 static void ml_nd_prolong(MLND &S, int n, vdn_multifab *dst, vdn_multifab *src, int mode) {
   static const bool faces_only = !(vdn_env("VDN_NDM_IFACE_FACES") && atoi(vdn_env("VDN_NDM_IFACE_FACES")) == 0);
-  const SrcView Cv = make_view(src, nd_coarse_footprints(S.la, n), S.la->owner[n], 0, 1, NVT_C2F);
+  const auto key = std::make_tuple(n, (const void *)dst, (const void *)src, mode == 0 ? 0 : 1);
+  auto hit = S.pro.find(key);
+  if (hit != S.pro.end()) { hit->second.Cv.refresh(); hit->second.s.run(mode, (double *)nullptr, ctx().stream); hit->second.s8.run(mode, (double *)nullptr, ctx().stream); return; }
+  MLND::ProlongSet &PS = S.pro[key];
+  PS.Cv = make_view(src, nd_coarse_footprints(S.la, n), S.la->owner[n], 0, 1, NVT_C2F);
+  const SrcView &Cv = PS.Cv;
   Cv.refresh();
   static const bool by_parent = !(vdn_env("VDN_NDM_PROLONG8") && atoi(vdn_env("VDN_NDM_PROLONG8")) == 0);
   std::vector<NdmProlongB> v; std::vector<NdmProlong8B> v8;
-  for (size_t f = 0; f < S.A[n].size(); f++)
-    for (int c = 0; c < Cv.nboxes(); c++) {
-      if (!Cv.have[c]) continue;
+  const BoxBins cb(Cv.vbox, &Cv.have);
+  for (size_t f = 0; f < S.A[n].size(); f++) {
+    int qlo[3], qhi[3];
+    for (int d = 0; d < 3; d++) { qlo[d] = nd_fdiv2(S.r[n][f].lo[d]); qhi[d] = nd_fdiv2(S.r[n][f].hi[d]); }
+    for (int c : cb.near(qlo, qhi, 2)) {
       NdmProlongB q;
       for (int d = 0; d < 3; d++) { q.clo[d] = Cv.vbox[c].lo[d]; q.chi[d] = Cv.vbox[c].hi[d] + 1; q.r.lo[d] = std::max(S.r[n][f].lo[d], 2 * q.clo[d]); q.r.hi[d] = std::min(S.r[n][f].hi[d], 2 * q.chi[d] + 1); }
       if (q.r.lo[0] > q.r.hi[0] || q.r.lo[1] > q.r.hi[1] || q.r.lo[2] > q.r.hi[2]) continue;
@@ -2293,13 +2305,20 @@ static void ml_nd_prolong(MLND &S, int n, vdn_multifab *dst, vdn_multifab *src, 
         in.lo[d] = std::max(in.lo[d], bx.lo[d] + 1); in.hi[d] = std::min(in.hi[d], bx.hi[d] - 1);      // the next directions leave these faces out
       }
     }
-  launch_batched(v, mode, (double *)nullptr, 0, ctx().stream);
-  launch_batched(v8, mode, (double *)nullptr, 0, ctx().stream);
+  }
+  PS.s.build(v, 0, ctx().stream); PS.s8.build(v8, 0, ctx().stream);
+  PS.s.run(mode, (double *)nullptr, ctx().stream); PS.s8.run(mode, (double *)nullptr, ctx().stream);
 }
 static void ml_nd_add(MLND &S, int n, vdn_multifab *dst, vdn_multifab *src) {
-  std::vector<NdfAddB> v;
-  for (size_t f = 0; f < S.A[n].size(); f++) { NdfAddB q; q.r = S.r[n][f]; q.a = dst->fabs[f]; q.b = src->fabs[f]; v.push_back(q); }
-  launch_batched(v, 0, (double *)nullptr, 0, ctx().stream);
+  const auto key = std::make_tuple(n, (const void *)dst, (const void *)src);
+  auto hit = S.adds.find(key);
+  if (hit == S.adds.end()) {
+    std::vector<NdfAddB> v;
+    for (size_t f = 0; f < S.A[n].size(); f++) { NdfAddB q; q.r = S.r[n][f]; q.a = dst->fabs[f]; q.b = src->fabs[f]; v.push_back(q); }
+    hit = S.adds.emplace(key, BatchSet<NdfAddB>()).first;
+    hit->second.build(v, 0, ctx().stream);
+  }
+  hit->second.run(0, (double *)nullptr, ctx().stream);
 }
 static void ml_nd_interface(MLND &S, int n) {
   if (S.multi[n - 1]) mf_fill_boundary(S.phi[n - 1]);        // the parents of a fine node may sit in a coarse box's ghost nodes
@@ -2409,6 +2428,7 @@ static int ml_nd_solve(vdn_layout *la, vdn_multifab **rh, vdn_multifab **phi, vd
     if (n >= 1 || S.multi[n]) {                         // (multi: several boxes or periodic images)
       S.own[n] = T(mf_temp(la, n, 1, 1, 3, true, 0.0));
       std::vector<NdfSetB> v1, v0;
+      const BoxBins lb(la->boxes[n]);
       for (int f = 0; f < nb; f++) {
         NdfSetB q; q.r = S.r[n][f]; q.a = S.own[n]->fabs[f]; q.v = 1.0; v1.push_back(q);
         const int gf = la->local[n][f];
@@ -2416,9 +2436,12 @@ static int ml_nd_solve(vdn_layout *la, vdn_multifab **rh, vdn_multifab **phi, vd
         // among the images of ONE box to the one at the lower coordinates
         int per[3], ns[3];
         for (int d = 0; d < 3; d++) { per[d] = la->pd[n].hi[d] - la->pd[n].lo[d] + 1; ns[d] = la->pmask[d] ? 1 : 0; }
-        for (int g = 0; g <= gf; g++)
-          for (int sz = -ns[2]; sz <= ns[2]; sz++) for (int sy = -ns[1]; sy <= ns[1]; sy++) for (int sx = -ns[0]; sx <= ns[0]; sx++) {
-            const int sh[3] = { sx * per[0], sy * per[1], sz * per[2] };
+        for (int sz = -ns[2]; sz <= ns[2]; sz++) for (int sy = -ns[1]; sy <= ns[1]; sy++) for (int sx = -ns[0]; sx <= ns[0]; sx++) {
+          const int sh[3] = { sx * per[0], sy * per[1], sz * per[2] };
+          int qlo[3], qhi[3];
+          for (int d = 0; d < 3; d++) { qlo[d] = S.r[n][f].lo[d] - sh[d]; qhi[d] = S.r[n][f].hi[d] - sh[d]; }
+          for (int g : lb.near(qlo, qhi, 2)) {                 // (a set of zero fills: their order is free)
+            if (g > gf) break;
             if (g == gf) {                                   // my own images: only those at lower coordinates take nodes from me
               const int first = sx ? sx : (sy ? sy : sz);
               if (first >= 0) continue;
@@ -2426,6 +2449,7 @@ static int ml_nd_solve(vdn_layout *la, vdn_multifab **rh, vdn_multifab **phi, vd
             Range3 rg2; for (int d = 0; d < 3; d++) { rg2.lo[d] = la->boxes[n][g].lo[d] + sh[d]; rg2.hi[d] = la->boxes[n][g].hi[d] + 1 + sh[d]; }
             NdfSetB z; if (nd_isect(S.r[n][f], rg2, z.r)) { z.a = S.own[n]->fabs[f]; z.v = 0.0; v0.push_back(z); }
           }
+        }
       }
       launch_batched(v1, 0, (double *)nullptr, 0, st);
       launch_batched(v0, 0, (double *)nullptr, 0, st);
@@ -2443,10 +2467,11 @@ static int ml_nd_solve(vdn_layout *la, vdn_multifab **rh, vdn_multifab **phi, vd
     if (n < L - 1) {
       cov[n] = T(mf_temp(la, n, 1, 1, -1, true, 0.0));
       std::vector<NdfSetB> vc;
+      const BoxBins pb(phi[n]->vbox);
       for (size_t f = 0; f < la->boxes[n + 1].size(); f++) {
         const vdn_box &fb = la->boxes[n + 1][f];
         Range3 rcov; for (int d = 0; d < 3; d++) { rcov.lo[d] = fb.lo[d] / 2; rcov.hi[d] = fb.hi[d] / 2; }
-        for (int c = 0; c < nb; c++) {
+        for (int c : pb.near(rcov.lo, rcov.hi, 2)) {
           Range3 rb2; NdfSetB q; for (int d = 0; d < 3; d++) { rb2.lo[d] = phi[n]->vbox[c].lo[d] - 1; rb2.hi[d] = phi[n]->vbox[c].hi[d] + 1; }
           if (nd_isect(rcov, rb2, q.r)) { q.a = cov[n]->fabs[c]; q.v = 1.0; vc.push_back(q); }
         }
@@ -2504,11 +2529,12 @@ static int ml_nd_solve(vdn_layout *la, vdn_multifab **rh, vdn_multifab **phi, vd
       S.vf_own[n] = make_view(S.own[n], nd_fine_footprints(la, n - 1), la->owner[n - 1], 0, 1, NVT_F2C); S.vf_own[n].refresh();
       if (S.own[n - 1]) { S.vc_own[n] = make_view(S.own[n - 1], nd_coarse_footprints(la, n), la->owner[n], 0, 1, NVT_C2F); S.vc_own[n].refresh(); }
       std::vector<NdmRestrictB> v;
+      const BoxBins cbn(phi[n - 1]->vbox);
       for (int f = 0; f < S.vf_res[n].nboxes(); f++) {
         if (!S.vf_res[n].have[f] || !S.vf_own[n].have[f]) continue;
         NdfArgs Af; for (int d = 0; d < 3; d++) { Af.lo[d] = S.vf_res[n].vbox[f].lo[d]; Af.hi[d] = S.vf_res[n].vbox[f].hi[d] + 1; Af.dirlo[d] = Af.dirhi[d] = Af.cflo[d] = Af.cfhi[d] = Af.ilo[d] = Af.ihi[d] = 0; Af.f[d] = 0.0; }
         Range3 rf; for (int d = 0; d < 3; d++) { rf.lo[d] = nd_fdiv2(Af.lo[d] + 1); rf.hi[d] = nd_fdiv2(Af.hi[d]); }       // coarse nodes whose fine twin is a node of box f
-        for (size_t c = 0; c < S.A[n - 1].size(); c++) {
+        for (int c : cbn.near(rf.lo, rf.hi, 2)) {
           NdmRestrictB q; if (!nd_isect(rf, S.r[n - 1][c], q.r)) continue;
           q.res_c = S.res[n - 1]->fabs[c]; q.res_f = S.vf_res[n].fv[f]; q.own_f = S.vf_own[n].fv[f]; q.Af = Af; q.Ac = S.A[n - 1][c];
           v.push_back(q);
