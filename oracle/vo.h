@@ -145,6 +145,7 @@ void vo_visc_solve(vo_fab *unew, const vo_fab *lapu, const vo_fab *rho, const vo
 void vo_diff_scalar_solve(vo_fab *snew, const vo_fab *laps, const double dx[3], double mu, const vo_bc *bc, const int pmask[3],
                           const vdn_params *prm, int icomp, int bccomp, vo_mgstat *st);
 void vo_cc_smooth_ab(const vo_fab *rh, vo_fab *phi, const vo_fab *alpha, vo_fab *beta[3], const double dx[3], const int ellbc[3][2], int nsweeps);
+void vo_cc_smooth_ab_iface(const vo_fab *rh, vo_fab *phi, const vo_fab *alpha, vo_fab *beta[3], const double dx[3], const int ellbc[3][2], int nsweeps);
 /* vo_plot.c: derived plot quantities (makevort.f90) */
 void vo_makevort(vo_fab *vort, int comp, const vo_fab *u, const double dx[3], const vo_bc *bc);
 void vo_makemagvel(vo_fab *magvel, int comp, const vo_fab *u);

@@ -307,46 +307,68 @@ static double composite_residual(int nlev, vo_fab **rh, vo_fab **phi, vo_fab **a
       if (n == nlev - 1 || !covered(phi[n + 1], i, j, k)) nrm = vo_nrm_acc(nrm, VF(res[n], i, j, k, 0));
   return nrm;
 }
-/* phi[n] += e (valid cells of level n), and the prolongation of that correction on every finer level m: piecewise constant into level 1,
+/* fine += the prolongation of the correction `src` of the next coarser level (valid cells): piecewise constant into level 1,
  * LINEAR into the levels m >= 2 -- fine cell = (p0 + px + py + pz)/4 with p0 its parent and px, py, pz the parent's neighbours on the fine
  * cell's side; a neighbour that is not a cell of the source level (beyond the coarse-fine interface or a wall) counts as the parent itself,
  * one across a periodic boundary of a level that spans the domain is the periodic image.  (Round 3.  With the constant prolongation on every
  * hop three nested levels need 20 FAC iterations where two need 10; with the linear one into the levels >= 2, 11-12.  Into level 1 the
  * constant one is kept: the linear one costs two levels one or two iterations -- measured, base 32^3 and 64^3.) */
-static void apply_correction(int nlev, int n, vo_fab **phi, vo_fab *e, vo_fab *scratch, const int pmask[3], const int *pd)
+static void prolong_add(vo_fab *fine, const vo_fab *src, int m, const int pmask[3], const int *pd)
 {
-  for (int k = phi[n]->lo[2]; k <= phi[n]->hi[2]; k++) for (int j = phi[n]->lo[1]; j <= phi[n]->hi[1]; j++) for (int i = phi[n]->lo[0]; i <= phi[n]->hi[0]; i++)
-    VF(phi[n], i, j, k, 0) = VF(phi[n], i, j, k, 0) + VF(&e[n], i, j, k, 0);
-  const vo_fab *src = &e[n];
-  for (int m = n + 1; m < nlev; m++) {
-    const int *plo = pd + 6 * (m - 1), *phi_ = pd + 6 * (m - 1) + 3;         /* the source level's domain */
-    int wrap[3];
-    for (int d = 0; d < 3; d++) wrap[d] = pmask[d] && src->lo[d] == plo[d] && src->hi[d] == phi_[d];
-    for (int k = phi[m]->lo[2]; k <= phi[m]->hi[2]; k++) for (int j = phi[m]->lo[1]; j <= phi[m]->hi[1]; j++) for (int i = phi[m]->lo[0]; i <= phi[m]->hi[0]; i++) {
-      const int q[3] = { i / 2, j / 2, k / 2 };
-      double v = VF(src, q[0], q[1], q[2], 0);
-      if (m >= 2) {
-        const int o[3] = { (i & 1) ? 1 : -1, (j & 1) ? 1 : -1, (k & 1) ? 1 : -1 };
-        double pn[3];
-        for (int d = 0; d < 3; d++) {
-          int t[3] = { q[0], q[1], q[2] }; t[d] += o[d];
-          if (t[d] < src->lo[d]) { if (wrap[d]) t[d] = src->hi[d]; else { pn[d] = v; continue; } }
-          else if (t[d] > src->hi[d]) { if (wrap[d]) t[d] = src->lo[d]; else { pn[d] = v; continue; } }
-          pn[d] = VF(src, t[0], t[1], t[2], 0);
-        }
-        v = 0.25 * (((v + pn[0]) + pn[1]) + pn[2]);
+  const int *plo = pd + 6 * (m - 1), *phi_ = pd + 6 * (m - 1) + 3;         /* the source level's domain */
+  int wrap[3];
+  for (int d = 0; d < 3; d++) wrap[d] = pmask[d] && src->lo[d] == plo[d] && src->hi[d] == phi_[d];
+  for (int k = fine->lo[2]; k <= fine->hi[2]; k++) for (int j = fine->lo[1]; j <= fine->hi[1]; j++) for (int i = fine->lo[0]; i <= fine->hi[0]; i++) {
+    const int q[3] = { i / 2, j / 2, k / 2 };
+    double v = VF(src, q[0], q[1], q[2], 0);
+    if (m >= 2) {
+      const int o[3] = { (i & 1) ? 1 : -1, (j & 1) ? 1 : -1, (k & 1) ? 1 : -1 };
+      double pn[3];
+      for (int d = 0; d < 3; d++) {
+        int t[3] = { q[0], q[1], q[2] }; t[d] += o[d];
+        if (t[d] < src->lo[d]) { if (wrap[d]) t[d] = src->hi[d]; else { pn[d] = v; continue; } }
+        else if (t[d] > src->hi[d]) { if (wrap[d]) t[d] = src->lo[d]; else { pn[d] = v; continue; } }
+        pn[d] = VF(src, t[0], t[1], t[2], 0);
       }
-      VF(&scratch[m], i, j, k, 0) = v;
-      VF(phi[m], i, j, k, 0) = VF(phi[m], i, j, k, 0) + v;
+      v = 0.25 * (((v + pn[0]) + pn[1]) + pn[2]);
     }
-    src = &scratch[m];
+    VF(fine, i, j, k, 0) = VF(fine, i, j, k, 0) + v;
+  }
+}
+/* ghost layer of the correction e of level n as the operator of the composite residual sees it: closure at the domain faces, periodic
+ * images, and beyond the coarse-fine interface the interpolation cf_interp from the correction ec of the next coarser level */
+static void fill_e_ghosts(vo_fab *e, const vo_fab *ec, const int ellbc[3][2], const int pmask[3], const int *pdlo, const int *pdhi)
+{
+  phi_closure(e, ellbc, pmask, pdlo, pdhi);
+  if (ec) cf_interp(e, ec, ellbc);
+}
+/* ... and as the relaxation wants it: zero beyond the domain faces (their closure is folded into the coefficients) */
+static void zero_domain_ghosts(vo_fab *e, const int ellbc[3][2])
+{
+  const int *lo = e->lo, *hi = e->hi;
+  for (int d = 0; d < 3; d++) for (int s = 0; s < 2; s++) {
+    if (ellbc[d][s] != VDN_BC_NEU && ellbc[d][s] != VDN_BC_DIR) continue;
+    const int t1 = (d + 1) % 3, t2 = (d + 2) % 3;
+    for (int b2 = lo[t2]; b2 <= hi[t2]; b2++) for (int b1 = lo[t1]; b1 <= hi[t1]; b1++) {
+      int g[3]; g[t1] = b1; g[t2] = b2; g[d] = s ? hi[d] + 1 : lo[d] - 1;
+      VF(e, g[0], g[1], g[2], 0) = 0.0;
+    }
   }
 }
 
 /* rh, phi: [lev];  beta: [lev*3 + d];  dx: [lev*3 + d];  ellbc[lev] per box;  pd: [lev][2][3].
- * One FAC iteration: composite residual / test; for n = finest..1: nu1 red-black sweeps on level n (homogeneous interface), correction
- * applied to level n and prolonged to the finer ones, composite residual; ONE V-cycle of the single-level multigrid on level 0, applied
- * and prolonged, composite residual; for n = 1..finest: nu2 sweeps on level n, applied and prolonged (composite residual before the next).
+ * One FAC iteration is a V-cycle over the levels in correction form (round 4; rounds 2-3 applied every level's correction to phi at once
+ * and formed the composite residual again after each -- five residual passes over the finest of three levels per iteration where this
+ * form makes two; on two levels the iterates are the same in exact arithmetic, on three the levels below see r_n - A_n e_n under a finer
+ * level instead of the restriction of the finer level's new residual):
+ *   composite residual r_n on every level / test;
+ *   down, n = finest..1:  e_n = 0, nu1 red-black sweeps of A_n e_n = r_n (zero beyond the interface);  t = r_n - A_n e_n with the ghost cells of
+ *        e_n as the composite operator fills them (closure, interpolation from e_{n-1} = 0);  r_{n-1} := restriction of t under level n, and
+ *        its flux matching next to level n with the fluxes of e_n (the operator is linear: the change of the composite residual);
+ *   level 0: ONE V-cycle of the single-level multigrid, A_0 e_0 = r_0;
+ *   up, n = 1..finest:  e_n += P e_{n-1};  ghost cells of e_n beyond the interface interpolated from e_{n-1} and held;  nu2 sweeps of
+ *        A_n e_n = r_n;
+ *   phi_n += e_n on every level.
  * beta_base (may be NULL): the face coefficients the level-0 V-cycle takes instead of beta[0..2] -- the MAC projection hands over the
  * coefficients of level 0's own density, 2/(rho_i + rho_i-1) on every face, where beta carries the edge restriction of the finer level's
  * under it: the V-cycle is a preconditioner (the composite residual is formed with beta), the FAC counts stay or drop by one (measured),
@@ -385,24 +407,28 @@ int vo_ml_cc_solve(int nlev, vo_fab **rh, vo_fab **phi, vo_fab **alpha, vo_fab *
     rn = composite_residual(nlev, rh, phi, alpha, beta, dx, ellbc, pmask, pd, rp);
     if (rn <= rel_eps * bnorm) { conv = 1; break; }
     if (it >= max_iter) break;
-    for (int n = nlev - 1; n >= 1; n--) {               /* pre-relaxation, finest first */
-      memset(e[n].p, 0, sizeof(double) * vo_size(&e[n]));
+    for (int n = 0; n < nlev; n++) memset(e[n].p, 0, sizeof(double) * vo_size(&e[n]));
+    for (int n = nlev - 1; n >= 1; n--) {               /* down: pre-relaxation, then the residual the next coarser level sees */
       vo_cc_smooth_ab(&res[n], &e[n], alpha ? alpha[n] : NULL, beta + 3 * n, dx + 3 * n, ellbc[n], prm->mg_nu1);
-      apply_correction(nlev, n, phi, e, scr, pmask, pd);
-      (void)composite_residual(nlev, rh, phi, alpha, beta, dx, ellbc, pmask, pd, rp);
+      fill_e_ghosts(&e[n], &e[n - 1], ellbc[n], pmask, pd + 6 * n, pd + 6 * n + 3);                   /* (e[n-1] = 0 here) */
+      (void)plain_residual(&res[n], &e[n], alpha ? alpha[n] : NULL, beta + 3 * n, dx + 3 * n, &scr[n]);
+      reflux_residual(&res[n - 1], &e[n - 1], beta + 3 * (n - 1), dx + 3 * (n - 1), &e[n], beta + 3 * n, dx + 3 * n, ellbc[n]);
+      vo_ml_cc_restriction(&res[n - 1], &scr[n], 0, 1);
     }
     /* coarse correction: ONE V-cycle of the single-level multigrid on the whole coarse level */
-    memset(e[0].p, 0, sizeof(double) * vo_size(&e[0]));
     vo_mgstat cs;
     vo_cc_solve_ab(&res[0], &e[0], alpha ? alpha[0] : NULL, beta_base ? beta_base : beta, dx, ellbc[0], 0.0, -1.0, -1, prm->mg_nu1, prm->mg_nu2, prm->mg_nub, 0, &cs);     /* (a nested-iteration start of the FIRST correction saves no FAC iteration here: measured, 10 -> 10) */
-    apply_correction(nlev, 0, phi, e, scr, pmask, pd);
-    for (int n = 1; n < nlev; n++) {                    /* post-relaxation, coarsest first */
-      if (n < nlev - 1) (void)composite_residual(nlev, rh, phi, alpha, beta, dx, ellbc, pmask, pd, rp);
-      else { fill_phi_ghosts(nlev, phi, ellbc, pmask, pd); (void)plain_residual(rh[n], phi[n], alpha ? alpha[n] : NULL, beta + 3 * n, dx + 3 * n, &res[n]); }
-      memset(e[n].p, 0, sizeof(double) * vo_size(&e[n]));
-      vo_cc_smooth_ab(&res[n], &e[n], alpha ? alpha[n] : NULL, beta + 3 * n, dx + 3 * n, ellbc[n], prm->mg_nu2);
-      apply_correction(nlev, n, phi, e, scr, pmask, pd);
+    fill_e_ghosts(&e[0], NULL, ellbc[0], pmask, pd, pd + 3);
+    for (int n = 1; n < nlev; n++) {                    /* up: the coarser correction prolonged, post-relaxation with it beyond the interface */
+      prolong_add(&e[n], &e[n - 1], n, pmask, pd);
+      fill_e_ghosts(&e[n], &e[n - 1], ellbc[n], pmask, pd + 6 * n, pd + 6 * n + 3);
+      zero_domain_ghosts(&e[n], ellbc[n]);
+      vo_cc_smooth_ab_iface(&res[n], &e[n], alpha ? alpha[n] : NULL, beta + 3 * n, dx + 3 * n, ellbc[n], prm->mg_nu2);
+      if (n < nlev - 1) fill_e_ghosts(&e[n], &e[n - 1], ellbc[n], pmask, pd + 6 * n, pd + 6 * n + 3);      /* what the next finer level's interface reads */
     }
+    for (int n = 0; n < nlev; n++)
+      for (int k = phi[n]->lo[2]; k <= phi[n]->hi[2]; k++) for (int j = phi[n]->lo[1]; j <= phi[n]->hi[1]; j++) for (int i = phi[n]->lo[0]; i <= phi[n]->hi[0]; i++)
+        VF(phi[n], i, j, k, 0) = VF(phi[n], i, j, k, 0) + VF(&e[n], i, j, k, 0);
     it++;
   }
   fill_phi_ghosts(nlev, phi, ellbc, pmask, pd);       /* leave phi with consistent ghosts for mkumac */

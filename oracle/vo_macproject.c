@@ -515,6 +515,28 @@ void vo_cc_smooth_ab(const vo_fab *rh, vo_fab *phi, const vo_fab *alpha, vo_fab 
   cc_store(&M.lev[0], phi, ellbc, M.per);
   ccmg_free(&M);
 }
+/* the same sweeps with the ghost cells of phi beyond the faces that are neither domain nor periodic faces (VDN_BC_INT: the coarse-fine
+ * interface of a refined level) taken as data and held fixed; phi's ghost layer is left as it came.  (The composite solve relaxes the
+ * correction of a refined level with the interpolated coarse correction beyond the interface.) */
+void vo_cc_smooth_ab_iface(const vo_fab *rh, vo_fab *phi, const vo_fab *alpha, vo_fab *beta[3], const double dx[3], const int ellbc[3][2], int nsweeps)
+{
+  ccmg M; ccmg_build(&M, alpha, beta, dx, ellbc);
+  cclev *L = &M.lev[0];
+  cc_load(L, rh, phi, ellbc);
+  const int *n = L->n;
+  for (int d = 0; d < L->dm; d++) for (int s = 0; s < 2; s++) {
+    if (ellbc[d][s] != VDN_BC_INT) continue;
+    const int t1 = (d + 1) % 3, t2 = (d + 2) % 3;
+    for (int b2 = 0; b2 < n[t2]; b2++) for (int b1 = 0; b1 < n[t1]; b1++) {
+      int g[3]; g[t1] = b1; g[t2] = b2; g[d] = s ? n[d] : -1;
+      PHI(L, g[0], g[1], g[2]) = VF(phi, phi->lo[0] + g[0], phi->lo[1] + g[1], phi->lo[2] + g[2], 0);
+    }
+  }
+  cc_gsrb(L, M.per, nsweeps);
+  for (int k = 0; k < n[2]; k++) for (int j = 0; j < n[1]; j++) for (int i = 0; i < n[0]; i++)
+    VF(phi, phi->lo[0] + i, phi->lo[1] + j, phi->lo[2] + k, 0) = PHI(L, i, j, k);
+  ccmg_free(&M);
+}
 void vo_cc_smooth(const vo_fab *rh, vo_fab *phi, vo_fab *beta[3], const double dx[3], const int ellbc[3][2], int nsweeps)
 {
   ccmg M; ccmg_build(&M, NULL, beta, dx, ellbc);

@@ -385,20 +385,22 @@ void ml_restrict_and_fill(int nlev, vdn_multifab **mf, int icomp, int bcomp, int
 
 // ---- composite cell-centred solve -------------------------------------------------------------------------------------------
 struct FaceBc { int lo[3], hi[3]; int e[3][2]; };
+enum { CLOSURE_ZERO = -99 };
 struct ClosureB { Range3 r; int g[3]; FV phi; int bc, d, s;          // r: the boundary cells of face (d,s)
   static __device__ double body(const ClosureB &a, int i, int j, int k, int) {
     const double v = fv_get(a.phi, i, j, k);
     const int d = a.d, s = a.s;
     const int gi = i + (d == 0 ? (s ? 1 : -1) : 0), gj = j + (d == 1 ? (s ? 1 : -1) : 0), gk = k + (d == 2 ? (s ? 1 : -1) : 0);
-    fv_at(a.phi, gi, gj, gk) = (a.bc == VDN_BC_NEU) ? v : -v;
+    fv_at(a.phi, gi, gj, gk) = (a.bc == VDN_BC_NEU) ? v : (a.bc == CLOSURE_ZERO ? 0.0 : -v);
     return 0.0;
   } };
-static void closure_descs(vdn_multifab *phi, const vdn_bc_tower *bct, int bc_comp0, std::vector<ClosureB> &v) {
+// zero: the ghost cells beyond the domain faces := 0 (what the relaxation, with the closure folded into its coefficients, wants there)
+static void closure_descs(vdn_multifab *phi, const vdn_bc_tower *bct, int bc_comp0, std::vector<ClosureB> &v, bool zero = false) {
   for (int b = 0; b < phi->nfabs(); b++)
     for (int d = 0; d < 3; d++) for (int s = 0; s < 2; s++) {
       const int e = bct->ell_bc(phi->lev, b + 1, d, s, bc_comp0);
       if (e != VDN_BC_NEU && e != VDN_BC_DIR) continue;
-      ClosureB a; a.phi = phi->fabs[b]; a.bc = e; a.d = d; a.s = s;
+      ClosureB a; a.phi = phi->fabs[b]; a.bc = zero ? CLOSURE_ZERO : e; a.d = d; a.s = s;
       for (int t = 0; t < 3; t++) { a.r.lo[t] = phi->vbox[b].lo[t]; a.r.hi[t] = phi->vbox[b].hi[t]; }
       a.r.lo[d] = a.r.hi[d] = s ? phi->vbox[b].hi[d] : phi->vbox[b].lo[d];
       v.push_back(a);
@@ -484,7 +486,8 @@ struct AbsmaxB { Range3 r; int g[3]; FV a, mask; int has_mask;
   } };
 struct RefluxArgs { int d, s; double dxf, dxc; };
 // r: coarse faces (index along d fixed = the interface); the uncovered cell is on the outside of the fine box
-struct RefluxB { Range3 r; int g[3]; FV res_c, phi_c, beta_c, mask, phi_f, beta_f; RefluxArgs A;
+// nocrs: the coarse field is zero (the correction of the coarser level before its relaxation): no coarse flux
+struct RefluxB { Range3 r; int g[3]; FV res_c, phi_c, beta_c, mask, phi_f, beta_f; RefluxArgs A; int nocrs;
   static __device__ double body(const RefluxB &a, int i, int j, int k, int) {
     const RefluxArgs &A = a.A;
     const int Q[3] = { i, j, k };
@@ -501,7 +504,7 @@ struct RefluxB { Range3 r; int g[3]; FV res_c, phi_c, beta_c, mask, phi_f, beta_
         sum = sum + fv_get(a.beta_f, q[0], q[1], q[2]) * (fv_get(a.phi_f, q[0], q[1], q[2]) - fv_get(a.phi_f, m[0], m[1], m[2])) / A.dxf;
       }
     const double Ff = sum * 0.25;
-    const double Fc = fv_get(a.beta_c, Q[0], Q[1], Q[2]) * (fv_get(a.phi_c, Q[0], Q[1], Q[2]) - fv_get(a.phi_c, M[0], M[1], M[2])) / A.dxc;
+    const double Fc = a.nocrs ? 0.0 : fv_get(a.beta_c, Q[0], Q[1], Q[2]) * (fv_get(a.phi_c, Q[0], Q[1], Q[2]) - fv_get(a.phi_c, M[0], M[1], M[2])) / A.dxc;
     if (A.s == 0) fv_at(a.res_c, M[0], M[1], M[2]) = fv_get(a.res_c, M[0], M[1], M[2]) + (Ff - Fc) / A.dxc;
     else          fv_at(a.res_c, Q[0], Q[1], Q[2]) = fv_get(a.res_c, Q[0], Q[1], Q[2]) - (Ff - Fc) / A.dxc;
     return 0.0;
@@ -573,16 +576,21 @@ static double read_dev(double *d) { return read_scalar1(d); }
 
 // descriptor sets are built once per solve: the fields of a solve do not move
 struct MLCC { int nlev; vdn_layout *la; bool fuse_first = false;   /* the finest level's residual pass also writes the first colour pass of its relaxation (ResidualB) */
-              vdn_multifab **rh, **phi, **beta, **alpha; vdn_multifab *res[VDN_MAXLEV], *e[VDN_MAXLEV], *scr[VDN_MAXLEV], *mask[VDN_MAXLEV];
+              vdn_multifab **rh, **phi, **beta, **alpha; vdn_multifab *res[VDN_MAXLEV], *e[VDN_MAXLEV], *t[VDN_MAXLEV], *mask[VDN_MAXLEV];   // t[n] = res[n] - A_n e[n] (levels >= 1)
               const double *dx; const vdn_bc_tower *bct; int bcc; double *d_nrm;
               BatchSet<ClosureB> closure[VDN_MAXLEV]; BatchSet<CfB> cf[VDN_MAXLEV]; BatchSet<ResidualB> resid[VDN_MAXLEV];
               BatchSet<RefluxB> reflux[VDN_MAXLEV][6];          // [fine level][d*2+s]: one launch per side so that a coarse cell is updated once per launch
               BatchSet<AbsmaxB> absmax[VDN_MAXLEV]; BatchSet<GsrbB> gsrb[VDN_MAXLEV]; BatchSet<AddB> add[VDN_MAXLEV];
-              BatchSet<AddProlongB> prolong[VDN_MAXLEV][VDN_MAXLEV];   // [source level n][target level m]: src = e[n] (m = n+1) or scr[m-1]
-              BatchSet<RestrictB> rphi[VDN_MAXLEV], rres[VDN_MAXLEV];  // [fine level]
-              BatchSet<ClosureB> edge_e[VDN_MAXLEV], edge_scr[VDN_MAXLEV];   // ghost cells of e[n] / scr[n] := the adjacent cell, all six faces of every box (before a linear prolongation)
+              BatchSet<AddProlongB> prolong[VDN_MAXLEV];               // [target level m]: e[m] += P e[m-1]
+              BatchSet<RestrictB> rphi[VDN_MAXLEV], rres[VDN_MAXLEV], rres_t[VDN_MAXLEV];  // [fine level]: phi, res, t onto the level below
+              BatchSet<ClosureB> edge_e[VDN_MAXLEV];                   // ghost cells of e[n] := the adjacent cell, all six faces of every box (before a linear prolongation)
+              // the correction form of the iteration: ghost cells of e[n] (closure at the domain faces / zero there / interpolation beyond the interface /
+              // zero everywhere), t[n] = res[n] - A_n e[n], the flux matching of res[n-1] with the fluxes of e[n]
+              BatchSet<ClosureB> closure_e[VDN_MAXLEV], zero_e[VDN_MAXLEV]; BatchSet<CfB> cf_e[VDN_MAXLEV]; BatchSet<SetboxB> zero_ghost_e[VDN_MAXLEV];
+              BatchSet<ResidualB> resid_e[VDN_MAXLEV]; BatchSet<RefluxB> reflux_e[VDN_MAXLEV][6];
               // the other level's fields as seen from this rank (several ranks: windows of remote boxes, refreshed before each use)
-              SrcView vc_phi[VDN_MAXLEV], vf_phi[VDN_MAXLEV], vf_res[VDN_MAXLEV], vf_beta[VDN_MAXLEV][3], vc_src[VDN_MAXLEV][VDN_MAXLEV];
+              SrcView vc_phi[VDN_MAXLEV], vf_phi[VDN_MAXLEV], vf_res[VDN_MAXLEV], vf_beta[VDN_MAXLEV][3], vc_src[VDN_MAXLEV];
+              SrcView vc_e[VDN_MAXLEV], vf_e[VDN_MAXLEV], vf_t[VDN_MAXLEV];   // [fine level n]: e[n-1] under the grown boxes of level n; e[n] (with ghost cells) and t[n] over the boxes of level n-1
 };
 static void restrict_descs(vdn_multifab *crse, const SrcView &fine, std::vector<RestrictB> &v) {
   const BoxBins cb(crse->vbox);
@@ -608,9 +616,11 @@ static void mlcc_build_sets(MLCC &S) {
   const int L = S.nlev;
   for (int n = 0; n < L; n++) {
     { std::vector<ClosureB> v; closure_descs(S.phi[n], S.bct, S.bcc, v); S.closure[n].build(v, 0, st); }
+    { std::vector<ClosureB> v; closure_descs(S.e[n], S.bct, S.bcc, v); S.closure_e[n].build(v, 0, st); }
+    if (n >= 1) { std::vector<ClosureB> v; closure_descs(S.e[n], S.bct, S.bcc, v, true); S.zero_e[n].build(v, 0, st); }
     if (n >= 1 && n < L - 1)               // levels that are the SOURCE of a linear prolongation (into a level >= 2)
-      for (int which = 0; which < 2; which++) {
-        vdn_multifab *mf = which ? S.scr[n] : S.e[n];
+      {
+        vdn_multifab *mf = S.e[n];
         std::vector<ClosureB> v;
         for (int b = 0; b < mf->nfabs(); b++) for (int d = 0; d < 3; d++) for (int sd = 0; sd < 2; sd++) {
           ClosureB a; a.phi = mf->fabs[b]; a.bc = VDN_BC_NEU; a.d = d; a.s = sd;
@@ -618,7 +628,7 @@ static void mlcc_build_sets(MLCC &S) {
           a.r.lo[d] = a.r.hi[d] = sd ? mf->vbox[b].hi[d] : mf->vbox[b].lo[d];
           v.push_back(a);
         }
-        (which ? S.edge_scr[n] : S.edge_e[n]).build(v, 0, st);
+        S.edge_e[n].build(v, 0, st);
       }
     if (n >= 1) {
       S.vc_phi[n] = make_view(S.phi[n - 1], coarsened_footprints(S.phi[n], 1, -1, 1), level_owner(S.phi[n]), 0, 1, VT_COARSEN_1);
@@ -628,8 +638,21 @@ static void mlcc_build_sets(MLCC &S) {
       { std::vector<CfB> v; cf_descs(S.phi[n], S.vc_phi[n], S.bct, S.bcc, v); S.cf[n].build(v, 0, st); }
       { std::vector<RestrictB> v; restrict_descs(S.phi[n - 1], S.vf_phi[n], v); S.rphi[n].build(v, 0, st); }
       { std::vector<RestrictB> v; restrict_descs(S.res[n - 1], S.vf_res[n], v); S.rres[n].build(v, 0, st); }
+      S.vc_e[n] = make_view(S.e[n - 1], coarsened_footprints(S.e[n], 1, -1, 1), level_owner(S.e[n]), 0, 1, VT_COARSEN_1);
+      S.vf_e[n] = make_view(S.e[n], refined_footprints(S.e[n - 1], -1, 2), level_owner(S.e[n - 1]), 0, 1, VT_REFINE_G1);
+      S.vf_t[n] = make_view(S.t[n], refined_footprints(S.res[n - 1], -1, 0), level_owner(S.res[n - 1]), 0, 1, VT_REFINE);
+      { std::vector<CfB> v; cf_descs(S.e[n], S.vc_e[n], S.bct, S.bcc, v); S.cf_e[n].build(v, 0, st); }
+      { std::vector<RestrictB> v; restrict_descs(S.res[n - 1], S.vf_t[n], v); S.rres_t[n].build(v, 0, st); }
+      { std::vector<SetboxB> v;                            // every ghost cell of e[n] := 0 (six slabs per box)
+        for (int b = 0; b < S.e[n]->nfabs(); b++) for (int d = 0; d < 3; d++) for (int sd = 0; sd < 2; sd++) {
+          SetboxB q; q.a = S.e[n]->fabs[b]; q.v = 0.0;
+          for (int t = 0; t < 3; t++) { q.r.lo[t] = S.e[n]->vbox[b].lo[t] - 1; q.r.hi[t] = S.e[n]->vbox[b].hi[t] + 1; }
+          q.r.lo[d] = q.r.hi[d] = sd ? S.e[n]->vbox[b].hi[d] + 1 : S.e[n]->vbox[b].lo[d] - 1;
+          v.push_back(q);
+        }
+        S.zero_ghost_e[n].build(v, 0, st); }
     }
-    std::vector<ResidualB> vr; std::vector<AbsmaxB> va; std::vector<GsrbB> vg; std::vector<AddB> vadd;
+    std::vector<ResidualB> vr, vre; std::vector<AbsmaxB> va; std::vector<GsrbB> vg; std::vector<AddB> vadd;
     for (int b = 0; b < S.rh[n]->nfabs(); b++) {
       const Range3 r = valid_range(S.rh[n], b);
       ResidualB q; q.r = r; q.rh = S.rh[n]->fabs[b]; q.phi = S.phi[n]->fabs[b]; q.bx = S.beta[3 * n]->fabs[b]; q.by = S.beta[3 * n + 1]->fabs[b]; q.bz = S.beta[3 * n + 2]->fabs[b];
@@ -638,6 +661,7 @@ static void mlcc_build_sets(MLCC &S) {
       q.fuse = (S.fuse_first && n == L - 1) ? 1 : 0; q.e = n >= 1 ? S.e[n]->fabs[b] : q.res;
       for (int d = 0; d < 3; d++) { q.A.lo[d] = r.lo[d]; q.A.hi[d] = r.hi[d]; for (int sd = 0; sd < 2; sd++) q.A.e[d][sd] = S.bct->ell_bc(n, b + 1, d, sd, S.bcc); }
       vr.push_back(q);
+      if (n >= 1) { ResidualB qe = q; qe.rh = S.res[n]->fabs[b]; qe.phi = S.e[n]->fabs[b]; qe.res = S.t[n]->fabs[b]; qe.fuse = 0; vre.push_back(qe); }
       if (n < L - 1) { AbsmaxB m; m.r = r; m.a = S.res[n]->fabs[b]; m.mask = S.mask[n]->fabs[b]; m.has_mask = 1; va.push_back(m); }
       if (n >= 1) {
         GsrbB gq; gq.e = S.e[n]->fabs[b]; gq.rh = S.res[n]->fabs[b]; gq.bx = q.bx; gq.by = q.by; gq.bz = q.bz; gq.has_alpha = q.has_alpha; gq.alpha = q.alpha;
@@ -647,13 +671,14 @@ static void mlcc_build_sets(MLCC &S) {
       }
       AddB ad; ad.r = r; ad.a = S.phi[n]->fabs[b]; ad.b = S.e[n]->fabs[b]; vadd.push_back(ad);
     }
+    S.resid_e[n].build(vre, 0, st);
     S.resid[n].build(vr, 0, st);          // (contiguous chunks of planes per workgroup: the k-1 / k+1 planes of phi stay in cache; its norm's atomics are rare, vdn_dev.h)
     S.absmax[n].build(va, 16, st); S.gsrb[n].build(vg, 0, st); S.add[n].build(vadd, 0, st);
     // flux matching on the cells of level n-1 next to the boxes of level n
     const BoxBins cbins(n >= 1 ? S.phi[n - 1]->vbox : std::vector<vdn_box>());
     if (n >= 1)
       for (int d = 0; d < 3; d++) for (int s = 0; s < 2; s++) {
-        std::vector<RefluxB> v;
+        std::vector<RefluxB> v, ve;
         const SrcView &Fv = S.vf_phi[n];                     // entries: fine boxes and their periodic images
         for (int f = 0; f < Fv.nboxes(); f++) {
           if (!Fv.have[f] || !S.vf_beta[n][d].have[f]) continue;      // no coarse box of this rank reaches that fine box
@@ -669,27 +694,28 @@ static void mlcc_build_sets(MLCC &S) {
             if (!isect(clo, chi, blo, bhi, q.r)) continue;
             q.A.d = d; q.A.s = s; q.A.dxf = S.dx[3 * n + d]; q.A.dxc = S.dx[3 * (n - 1) + d];
             q.res_c = S.res[n - 1]->fabs[c]; q.phi_c = S.phi[n - 1]->fabs[c]; q.beta_c = S.beta[3 * (n - 1) + d]->fabs[c]; q.mask = S.mask[n - 1]->fabs[c];
-            q.phi_f = S.vf_phi[n].fv[f]; q.beta_f = S.vf_beta[n][d].fv[f];
+            q.phi_f = S.vf_phi[n].fv[f]; q.beta_f = S.vf_beta[n][d].fv[f]; q.nocrs = 0;
             v.push_back(q);
+            if (S.vf_e[n].have[f]) { q.phi_f = S.vf_e[n].fv[f]; q.phi_c = S.e[n - 1]->fabs[c]; q.nocrs = 1; ve.push_back(q); }
           }
         }
-        S.reflux[n][2 * d + s].build(v, 0, st);
+        S.reflux[n][2 * d + s].build(v, 0, st); S.reflux_e[n][2 * d + s].build(ve, 0, st);
       }
-    // prolongation of the correction of level n to the levels above it
-    for (int m = n + 1; m < L; m++) {
-      vdn_multifab *srcmf = (m == n + 1) ? S.e[n] : S.scr[m - 1];
+    // prolongation of the correction of level n-1 into e[n]
+    if (n >= 1) {
+      const int m = n;
+      vdn_multifab *srcmf = S.e[m - 1];
       // (into the levels >= 2 the prolongation is linear and reads the parent's face neighbours: one more ring of the source level)
-      if (m >= 2) S.vc_src[n][m] = make_view(srcmf, coarsened_footprints(S.phi[m], 0, -1, 1), level_owner(S.phi[m]), 0, 1, VT_COARSEN_0G1);
-      else S.vc_src[n][m] = make_view(srcmf, coarsened_footprints(S.phi[m], 0, -1, 0), level_owner(S.phi[m]), 0, 1, VT_COARSEN_0);
-      const SrcView &src = S.vc_src[n][m];
-      const bool keep = m < L - 1;
+      if (m >= 2) S.vc_src[m] = make_view(srcmf, coarsened_footprints(S.phi[m], 0, -1, 1), level_owner(S.phi[m]), 0, 1, VT_COARSEN_0G1);
+      else S.vc_src[m] = make_view(srcmf, coarsened_footprints(S.phi[m], 0, -1, 0), level_owner(S.phi[m]), 0, 1, VT_COARSEN_0);
+      const SrcView &src = S.vc_src[m];
       std::vector<AddProlongB> v;
       const BoxBins sb(src.vbox, &src.have);
-      for (int f = 0; f < S.phi[m]->nfabs(); f++) {
+      for (int f = 0; f < S.e[m]->nfabs(); f++) {
         int qlo[3], qhi[3];
-        for (int d = 0; d < 3; d++) { qlo[d] = S.phi[m]->vbox[f].lo[d] / 2; qhi[d] = S.phi[m]->vbox[f].hi[d] / 2; }
+        for (int d = 0; d < 3; d++) { qlo[d] = S.e[m]->vbox[f].lo[d] / 2; qhi[d] = S.e[m]->vbox[f].hi[d] / 2; }
         for (int c : sb.near(qlo, qhi, 2)) {
-        AddProlongB q; q.r = valid_range(S.phi[m], f); q.af = S.phi[m]->fabs[f]; q.sc = keep ? S.scr[m]->fabs[f] : S.phi[m]->fabs[f]; q.keep = keep ? 1 : 0; q.ec = src.fv[c];
+        AddProlongB q; q.r = valid_range(S.e[m], f); q.af = S.e[m]->fabs[f]; q.sc = q.af; q.keep = 0; q.ec = src.fv[c];
         for (int d = 0; d < 3; d++) { q.plo[d] = src.vbox[c].lo[d]; q.phi[d] = src.vbox[c].hi[d]; }
         int plo[3], phi[3]; Range3 dummy;
         for (int d = 0; d < 3; d++) { plo[d] = q.r.lo[d] / 2; phi[d] = q.r.hi[d] / 2; }
@@ -697,7 +723,7 @@ static void mlcc_build_sets(MLCC &S) {
         v.push_back(q);
         }
       }
-      S.prolong[n][m].build(v, 0, st);
+      S.prolong[m].build(v, 0, st);
     }
   }
 }
@@ -708,54 +734,39 @@ static void fill_phi_ghosts(MLCC &S) {
   for (int n = 0; n < S.nlev; n++) { S.closure[n].run(0, (double *)nullptr, st); if (n == 0) mf_fill_boundary(S.phi[n]); }
   for (int n = 1; n < S.nlev; n++) { S.vc_phi[n].refresh(); S.cf[n].run(0, (double *)nullptr, st); mf_fill_boundary(S.phi[n]); }
 }
-// want_norm = false: the residual fields only (no reduction, no read-back: the host does not wait for the device)
-// lowest > 0 (without the norm): the residual fields of the levels >= lowest only -- what the relaxation of level `lowest` reads; the levels below
-// are recomputed by the next call before anything reads them (three levels: the residual, flux matching and restriction of the 256^3 base level
-// twice per iteration)
-static double composite_residual(MLCC &S, bool want_norm = true, int lowest = 0) {
+// the composite residual on every level and its norm over the composite grid
+static double composite_residual(MLCC &S) {
   hipStream_t st = ctx().stream;
   const int L = S.nlev;
-  static const bool partial = !(vdn_env("VDN_MLCC_PARTIAL") && atoi(vdn_env("VDN_MLCC_PARTIAL")) == 0);
-  if (want_norm || !partial) lowest = 0;
   fill_phi_ghosts(S);
-  if (want_norm) HIPCHK(hipMemsetAsync(S.d_nrm, 0, sizeof(double), st));
-  for (int n = lowest; n < L; n++) S.resid[n].run(0, (n == L - 1 && want_norm) ? S.d_nrm : (double *)nullptr, st);
+  HIPCHK(hipMemsetAsync(S.d_nrm, 0, sizeof(double), st));
+  for (int n = 0; n < L; n++) S.resid[n].run(0, n == L - 1 ? S.d_nrm : (double *)nullptr, st);
   // flux matching: lo faces then hi faces of every direction (one update per coarse cell and launch, hence deterministic)
-  for (int n = lowest + 1; n < L; n++) { S.vf_phi[n].refresh(); for (int ds = 0; ds < 6; ds++) S.reflux[n][ds].run(0, (double *)nullptr, st); }     // fine phi incl. its ghost cells
-  for (int n = L - 1; n >= lowest + 1; n--) { S.vf_res[n].refresh(); S.rres[n].run(0, (double *)nullptr, st); }
-  if (!want_norm) return 0.0;
+  for (int n = 1; n < L; n++) { S.vf_phi[n].refresh(); for (int ds = 0; ds < 6; ds++) S.reflux[n][ds].run(0, (double *)nullptr, st); }     // fine phi incl. its ghost cells
+  for (int n = L - 1; n >= 1; n--) { S.vf_res[n].refresh(); S.rres[n].run(0, (double *)nullptr, st); }
   for (int n = 0; n < L - 1; n++) S.absmax[n].run(0, S.d_nrm, st);
   comm_allreduce_max_dev(S.d_nrm, 1);
   return read_dev(S.d_nrm);
 }
-// nsweeps red-black sweeps of A_n e = res_n from e = 0 (homogeneous coarse-fine interface)
-static void level_relax(MLCC &S, int n, int nsweeps) {
+// nsweeps red-black sweeps of A_n e = res_n on the e at hand; its ghost cells beyond the interface are data (zero on the way down, interpolated from
+// the coarser correction on the way up), those beyond the domain faces zero (the closure is folded into the coefficients), the neighbouring boxes'
+// are exchanged before every pass but the first (ghosts_current: the caller has just filled them; otherwise e = 0 with ghost cells)
+static void level_relax(MLCC &S, int n, int nsweeps, bool first_done) {
   vdn_multifab *e = S.e[n];
-  // the finest level with fuse_first: its residual pass has written the first colour pass (and zeros on the other colour); the ghost cells
-  // beyond the level are zero from e's allocation -- the exchange writes only those that lie in a neighbouring box
-  const bool first_done = S.fuse_first && n == S.nlev - 1 && nsweeps >= 1;
-  if (!first_done) mf_setval(e, 0.0, 0, 1, true);
   const bool exchange = level_boxes(e).size() > 1 || S.la->pmask[0] || S.la->pmask[1] || S.la->pmask[2];     // boxes of the level anywhere, not just here: every rank must take part
   for (int s = 0; s < nsweeps; s++) for (int col = 0; col < 2; col++) {
-    if (first_done && s == 0 && col == 0) continue;
-    if (exchange && (s > 0 || col > 0)) mf_fill_boundary(e);      // (the first pass starts from e = 0, ghost cells included)
+    if (first_done && s == 0 && col == 0) continue;     // (the finest level's residual pass has written the first colour pass from e = 0)
+    if (exchange && (s > 0 || col > 0)) mf_fill_boundary(e);
     S.gsrb[n].run(col, (double *)nullptr, ctx().stream);
   }
 }
-// phi_n += e_n, and the piecewise-constant prolongation of that correction on every finer level
-static void apply_correction(MLCC &S, int n, bool added = false) {
+// ghost cells of e[n] as the operator of the composite residual reads them: closure at the domain faces, interpolation from e[n-1] beyond the
+// interface, the neighbouring boxes' values (fill_phi_ghosts for one level of the correction)
+static void fill_e_ghosts(MLCC &S, int n) {
   hipStream_t st = ctx().stream;
-  if (!added) S.add[n].run(0, (double *)nullptr, st);
-  for (int m = n + 1; m < S.nlev; m++) {
-    const int lin = m >= 2 ? 1 : 0;                      // piecewise constant into level 1, linear into the finer ones (oracle: apply_correction)
-    if (lin) {                                          // the source's ghost cells: the cell itself where the level ends, then the neighbouring boxes' / periodic values
-      vdn_multifab *src = (m == n + 1) ? S.e[n] : S.scr[m - 1];
-      (m == n + 1 ? S.edge_e[m - 1] : S.edge_scr[m - 1]).run(0, (double *)nullptr, st);
-      mf_fill_boundary(src);
-    }
-    S.vc_src[n][m].refresh();
-    S.prolong[n][m].run(lin, (double *)nullptr, st);
-  }
+  S.closure_e[n].run(0, (double *)nullptr, st);
+  if (n >= 1) { S.vc_e[n].refresh(); S.cf_e[n].run(0, (double *)nullptr, st); }
+  mf_fill_boundary(S.e[n]);
 }
 // rh, phi: [lev];  beta: [lev*3 + d];  dx: [lev*3 + d]
 // alpha: [lev] cell coefficients of (alpha - div beta grad), or nullptr.  The ghost cells of the incoming phi carry inhomogeneous
@@ -783,7 +794,7 @@ int ml_cc_solve(vdn_layout *la, vdn_multifab **rh, vdn_multifab **phi, vdn_multi
   S.d_nrm = (double *)arena_alloc(256);
   for (int n = 0; n < L; n++) {
     S.res[n] = mf_temp(la, n, 1, 0, -1, true, 0.0); S.e[n] = mf_temp(la, n, 1, 1, -1, true, 0.0);
-    S.scr[n] = (n >= 1 && n < L - 1) ? mf_temp(la, n, 1, 1, -1, true, 0.0) : nullptr;      // (one ghost cell: the source of a linear prolongation)
+    S.t[n] = n >= 1 ? mf_temp(la, n, 1, 0, -1, true, 0.0) : nullptr;
     S.mask[n] = nullptr;
     if (n < L - 1) {                                         // cells of level n covered by level n+1
       S.mask[n] = mf_temp(la, n, 1, 0, -1, true, 0.0);
@@ -821,34 +832,48 @@ int ml_cc_solve(vdn_layout *la, vdn_multifab **rh, vdn_multifab **phi, vdn_multi
     rn = composite_residual(S);
     if (rn <= rel_eps * bnorm && bnorm < HUGE_VAL) { conv = true; break; }
     if (it >= max_iter || !(rn < HUGE_VAL) || !(bnorm < HUGE_VAL)) break;
-    // pre-relaxation, finest level first (homogeneous interface), then the residual the next coarser level will see
+    // one V-cycle over the levels in correction form (oracle: vo_ml_cc_solve).  Down, finest level first: e_n = 0, nu1 sweeps, t = res_n - A_n e_n,
+    // res_{n-1} := restriction of t under level n and the flux matching with e_n's fluxes next to it
+    for (int n = 1; n < L; n++) {
+      if (S.fuse_first && n == L - 1) S.zero_ghost_e[n].run(0, (double *)nullptr, st);      // (its cells hold the first colour pass already)
+      else mf_setval(S.e[n], 0.0, 0, 1, true);
+    }
+    mf_setval(S.e[0], 0.0, 0, 1, true);
     for (int n = L - 1; n >= 1; n--) {
-      level_relax(S, n, P.mg_nu1);
-      apply_correction(S, n);
-      (void)composite_residual(S, false, n - 1);
+      level_relax(S, n, P.mg_nu1, S.fuse_first && n == L - 1);
+      fill_e_ghosts(S, n);                                 // (e[n-1] = 0 here)
+      S.resid_e[n].run(0, (double *)nullptr, st);
+      S.vf_e[n].refresh(); for (int ds = 0; ds < 6; ds++) S.reflux_e[n][ds].run(0, (double *)nullptr, st);
+      S.vf_t[n].refresh(); S.rres_t[n].run(0, (double *)nullptr, st);
     }
     // coarse correction: ONE V-cycle of the single-level multigrid on the whole level 0
     static const bool glue = !(vdn_env("VDN_MLCC_GLUE") && atoi(vdn_env("VDN_MLCC_GLUE")) == 0);
     const bool zg = glue && it > 0;           // (the first call builds the kept hierarchy and loads phi as the generic solver does)
-    if (!zg) mf_setval(S.e[0], 0.0, 0, 1, true);
     int cyc; double r0, rr;
     // (base_beta / base_rho, the MAC projection: the V-cycle runs on level 0's OWN coefficients 2/(rho_i + rho_i-1) -- `beta` carries the edge
     // restriction of the finer level's on the covered faces -- and so on the density-based kernels of the single-level solver; it is a
     // preconditioner, the composite residual above is formed with `beta`.  Oracle: beta_base of vo_ml_cc_solve)
     cc_solve(S.res[0], S.e[0], base_beta ? base_beta : beta, dx, ebc0, 0.0, -1.0, -1, &cyc, &r0, &rr, alpha ? alpha[0] : nullptr, base_beta ? base_rho : nullptr, coarse_keep, nullptr, 0, zg, glue ? S.phi[0] : nullptr);     // (no nested-iteration start here: it saves no FAC iteration, measured)
-    apply_correction(S, 0, glue);            // (glue: phi_0 += e_0 was done where e_0 was stored)
-    // post-relaxation on the new residual, coarsest level first
+    if (!glue) S.add[0].run(0, (double *)nullptr, st);     // (glue: phi_0 += e_0 was done where e_0 was stored)
+    fill_e_ghosts(S, 0);
+    // up, coarsest level first: e_n += P e_{n-1}, the interface ghost cells from e_{n-1}, nu2 sweeps, phi_n += e_n
     for (int n = 1; n < L; n++) {
-      if (n < L - 1) (void)composite_residual(S, false, n);
-      else { fill_phi_ghosts(S); S.resid[n].run(0, (double *)nullptr, st); }
-      level_relax(S, n, P.mg_nu2);
-      apply_correction(S, n);
+      const int lin = n >= 2 ? 1 : 0;                     // piecewise constant into level 1, linear into the finer ones (oracle: prolong_add)
+      if (lin) { S.edge_e[n - 1].run(0, (double *)nullptr, st); mf_fill_boundary(S.e[n - 1]); }     // the source's ghost cells: the cell itself where the level ends, then the neighbouring boxes' / periodic values
+      S.vc_src[n].refresh();
+      S.prolong[n].run(lin, (double *)nullptr, st);
+      if (lin) fill_e_ghosts(S, n - 1);                   // (back to what the interface interpolation reads)
+      S.zero_e[n].run(0, (double *)nullptr, st);
+      S.vc_e[n].refresh(); S.cf_e[n].run(0, (double *)nullptr, st);
+      mf_fill_boundary(S.e[n]);
+      level_relax(S, n, P.mg_nu2, false);
+      S.add[n].run(0, (double *)nullptr, st);
     }
     it++;
   }
   fill_phi_ghosts(S);
   if (iters) *iters = it; if (res0) *res0 = bnorm; if (res) *res = rn;
-  for (int n = L - 1; n >= 0; n--) { if (S.mask[n]) mf_temp_free(S.mask[n]); if (S.scr[n]) mf_temp_free(S.scr[n]); mf_temp_free(S.e[n]); mf_temp_free(S.res[n]); }
+  for (int n = L - 1; n >= 0; n--) { if (S.mask[n]) mf_temp_free(S.mask[n]); if (S.t[n]) mf_temp_free(S.t[n]); mf_temp_free(S.e[n]); mf_temp_free(S.res[n]); }
   HIPCHK(hipStreamSynchronize(st));
   arena_release(mark);
   return conv ? 0 : 1;

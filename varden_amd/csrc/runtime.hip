@@ -169,7 +169,6 @@ static const EnvSwitch g_switches[] = {
   { "VDN_NDM_PROLONG8", "0: correction interpolation with a thread per fine node instead of per coarse node" },
   { "VDN_NDM_NEG", "1: the composite nodal solve copies -res into the correction's right-hand side instead of loading it directly" },
   { "VDN_MLND_PARTIAL", "0: every composite nodal residual computes all levels" },
-  { "VDN_MLCC_PARTIAL", "0: every composite cell-centred residual computes all levels" },
   { "VDN_MLCC_GLUE", "0: the level-0 correction of the composite MAC solve stored and added in separate passes" },
   { "VDN_MLCC_FUSE1", "0: the composite MAC solve's finest-level residual and first colour pass as two launches" },
   { "VDN_BATCH_YZ", "0: no (j,k) / (i,k) tiles for thin ranges in the box-batched kernels" },
