@@ -748,26 +748,6 @@ static double ml_nd_residual(mlnd *M)
   }
   return nrm;
 }
-/* phi_n += e (local node array of level n), and its trilinear prolongation on every finer level (not on physical Dirichlet nodes) */
-static void ml_nd_apply_correction(mlnd *M, int n, double *e, double **scratch)
-{
-  ndlev *L = &M->L[n];
-  for (int k = 0; k <= L->n[2]; k++) for (int j = 0; j <= L->n[1]; j++) for (int i = 0; i <= L->n[0]; i++)
-    L->phi[NN(L, i, j, k)] = L->phi[NN(L, i, j, k)] + e[NN(L, i, j, k)];
-  const double *src = e;
-  for (int m = n + 1; m < M->nlev; m++) {
-    ndlev *F = &M->L[m];
-    memset(scratch[m], 0, sizeof(double) * (size_t)(F->n[0] + 3) * (F->n[1] + 3) * (F->n[2] + 3));
-    for (int k = 0; k <= F->n[2]; k++) for (int j = 0; j <= F->n[1]; j++) for (int i = 0; i <= F->n[0]; i++) {
-      if (M->pdir[m][NM(F, i, j, k)]) continue;
-      const double v = ml_nd_interp(M, m, &M->L[m - 1], src, i, j, k);
-      scratch[m][NN(F, i, j, k)] = v;
-      F->phi[NN(F, i, j, k)] = F->phi[NN(F, i, j, k)] + v;
-    }
-    src = scratch[m];
-  }
-}
-
 /* rh[lev] nodal (ng 1; in: extra source, normally 0), phi[lev] nodal (ng 1, in/out), coeffs[lev] cells (ng 1, ghost 0 outside the
  * level), u[lev] cells with >= 1 ghost (wall ghosts zeroed by create_uvec); dx: [lev*3+d]; ellbc per level/box */
 int vo_ml_nd_solve(int nlev, vo_fab **rh, vo_fab **phi, vo_fab **coeffs, vo_fab **u, const double *dx, const int ellbc[][3][2], const int pmask[3],
@@ -847,15 +827,22 @@ int vo_ml_nd_solve(int nlev, vo_fab **rh, vo_fab **phi, vo_fab **coeffs, vo_fab 
                 (it == 0 && prm->hg_fmg) ? 2 : 0, vo_om_pre(prm), &cs);
     for (int k = 0; k <= Cc->n[2]; k++) for (int j = 0; j <= Cc->n[1]; j++) for (int i = 0; i <= Cc->n[0]; i++)
       scratch[0][NN(Cc, i, j, k)] = VF(&ee, ee.lo[0] + i, ee.lo[1] + j, ee.lo[2] + k, 0);
-    ml_nd_apply_correction(&M, 0, scratch[0], scratch);
-    /* relaxation of the correction equation K_n e = r_n on the finer levels, coarsest first; interface nodes fixed (e = 0) */
+    for (int k = 0; k <= Cc->n[2]; k++) for (int j = 0; j <= Cc->n[1]; j++) for (int i = 0; i <= Cc->n[0]; i++)
+      Cc->phi[NN(Cc, i, j, k)] = Cc->phi[NN(Cc, i, j, k)] + scratch[0][NN(Cc, i, j, k)];
+    /* the finer levels, coarsest first, in correction form (round 4; rounds 2-3 applied every correction to phi on all finer levels at once
+     * and formed the composite residual again before each relaxation): e_n = P e_{n-1} (trilinear, not on physical Dirichlet nodes), then
+     * the damped-Jacobi sweeps of K_n e_n = r_n -- r_n the residual from the top of the iteration -- with the interface nodes held at
+     * P e_{n-1}, then phi_n += e_n.  On the finest level K_n is the operator of the residual, so that two levels make the same iterates
+     * as before in exact arithmetic; an intermediate level relaxes with its full sigma against r_n, whose part under the next finer level
+     * is the restricted fine residual, where the earlier form recomputed that part with the prolonged correction applied. */
     for (int n = 1; n < nlev; n++) {
       ndlev *F = &M.L[n];
-      (void)ml_nd_residual(&M);
       double *sphi = F->phi, *sb = F->b, *ssig = F->sig;
       long nnf = (long)(F->n[0] + 3) * (F->n[1] + 3) * (F->n[2] + 3);
       double *e = (double *)calloc(nnf, sizeof(double)), *rb = (double *)malloc(sizeof(double) * nnf);
       memcpy(rb, F->res, sizeof(double) * nnf);
+      for (int k = 0; k <= F->n[2]; k++) for (int j = 0; j <= F->n[1]; j++) for (int i = 0; i <= F->n[0]; i++)
+        if (!M.pdir[n][NM(F, i, j, k)]) e[NN(F, i, j, k)] = ml_nd_interp(&M, n, &M.L[n - 1], scratch[n - 1], i, j, k);
       F->phi = e; F->b = rb; F->sig = M.sigfull[n];
       if (nu_f == 3 && prm->hg_omega_fac1 > 0.0 && prm->hg_omega_fac2 > 0.0 && prm->hg_omega_fac3 > 0.0 && vo_nd_isotropic(dx + 3 * n, 3)) {      /* three-step damping set (round 3): 15 -> 14 and 14 -> 13 FAC iterations on the tagged hierarchies */
         nd_jacobi(F, M.per, 1, prm->hg_omega_fac1); nd_jacobi(F, M.per, 1, prm->hg_omega_fac2); nd_jacobi(F, M.per, 1, prm->hg_omega_fac3);
@@ -866,7 +853,9 @@ int vo_ml_nd_solve(int nlev, vo_fab **rh, vo_fab **phi, vo_fab **coeffs, vo_fab 
       double *other = F->tmp;
       F->phi = sphi;
       /* after the sweeps one of the two scratch buffers holds e and the other is F->tmp: keep them apart from sphi */
-      ml_nd_apply_correction(&M, n, e, scratch);
+      for (int k = 0; k <= F->n[2]; k++) for (int j = 0; j <= F->n[1]; j++) for (int i = 0; i <= F->n[0]; i++)
+        F->phi[NN(F, i, j, k)] = F->phi[NN(F, i, j, k)] + e[NN(F, i, j, k)];
+      memcpy(scratch[n], e, sizeof(double) * nnf);
       if (other == sphi) { F->tmp = e; } else { free(e); }
       free(rb);
     }

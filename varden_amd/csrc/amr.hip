@@ -450,11 +450,24 @@ static void cf_descs(vdn_multifab *pf, const SrcView &pc, const vdn_bc_tower *bc
 // e = 0 + r / diag on the cells with (i + j + k) even (diag from the face coefficients folded at the domain faces as GsrbB folds them), 0 on
 // the others: the same bits as GsrbB's pass from a zero-filled e, without the pass and without the zero fill
 struct ResArgs { double hi2[3]; int lo[3], hi[3], e[3][2]; };
-struct ResidualB { Range3 r; int g[3]; static constexpr int planes_per_wg = 8; FV rh, phi, bx, by, bz, res, alpha, e; int has_alpha, fuse; ResArgs A;
+// use_rho (the finest level of the MAC projection): the face coefficients 2 / (rho_i + rho_i-1) of mk_mac_coeffs formed on the fly -- the bits of the
+// stored ones, one cell array read instead of three face arrays
+#define MLCC_FACE_COEFFS(a, i, j, k)                                                                                                                 \
+  double bxm, bxp, bym, byp, bzm, bzp;                                                                                                               \
+  if (a.use_rho) {                                                                                                                                   \
+    const double r0_ = fv_get(a.rho, i, j, k);                                                                                                       \
+    bxm = 2.0 / (r0_ + fv_get(a.rho, i - 1, j, k)); bxp = 2.0 / (fv_get(a.rho, i + 1, j, k) + r0_);                                                  \
+    bym = 2.0 / (r0_ + fv_get(a.rho, i, j - 1, k)); byp = 2.0 / (fv_get(a.rho, i, j + 1, k) + r0_);                                                  \
+    bzm = 2.0 / (r0_ + fv_get(a.rho, i, j, k - 1)); bzp = 2.0 / (fv_get(a.rho, i, j, k + 1) + r0_);                                                  \
+  } else {                                                                                                                                           \
+    bxm = fv_get(a.bx, i, j, k); bxp = fv_get(a.bx, i + 1, j, k); bym = fv_get(a.by, i, j, k); byp = fv_get(a.by, i, j + 1, k);                     \
+    bzm = fv_get(a.bz, i, j, k); bzp = fv_get(a.bz, i, j, k + 1);                                                                                    \
+  }
+struct ResidualB { Range3 r; int g[3]; static constexpr int planes_per_wg = 8; FV rh, phi, bx, by, bz, res, alpha, e, rho; int has_alpha, fuse, use_rho; ResArgs A;
   static __device__ double body(const ResidualB &a, int i, int j, int k, int) {
     const FV &phi = a.phi;
     const double p0 = fv_get(phi, i, j, k);
-    double bxm = fv_get(a.bx, i, j, k), bxp = fv_get(a.bx, i + 1, j, k), bym = fv_get(a.by, i, j, k), byp = fv_get(a.by, i, j + 1, k), bzm = fv_get(a.bz, i, j, k), bzp = fv_get(a.bz, i, j, k + 1);
+    MLCC_FACE_COEFFS(a, i, j, k)
     const double ax = (bxp * (p0 - fv_get(phi, i + 1, j, k)) + bxm * (p0 - fv_get(phi, i - 1, j, k))) * a.A.hi2[0];
     const double ay = (byp * (p0 - fv_get(phi, i, j + 1, k)) + bym * (p0 - fv_get(phi, i, j - 1, k))) * a.A.hi2[1];
     const double az = (bzp * (p0 - fv_get(phi, i, j, k + 1)) + bzm * (p0 - fv_get(phi, i, j, k - 1))) * a.A.hi2[2];
@@ -513,12 +526,12 @@ struct GsArgs { int lo[3], hi[3]; int e[3][2]; double hi2[3]; };
 // red-black Gauss-Seidel on the fabs of a level: ghost cells of e are 0 at the coarse-fine interface and at Dirichlet faces
 // (b := 2b), Neumann faces carry b := 0 -- the folding of mg_cc.hip applied on the fly; colour by global index.
 // r: lo[0] .. lo[0] + ceil(nx/2) - 1 along x (half the cells of a row), the colour picks which half
-struct GsrbB { Range3 r; int g[3]; FV e, rh, bx, by, bz, alpha; int has_alpha; GsArgs A;
+struct GsrbB { Range3 r; int g[3]; FV e, rh, bx, by, bz, alpha, rho; int has_alpha, use_rho; GsArgs A;
   static __device__ double body(const GsrbB &a, int ih, int j, int k, int color) {
     const GsArgs &A = a.A; const FV &e = a.e;
     const int i = A.lo[0] + 2 * (ih - A.lo[0]) + ((A.lo[0] + j + k + color) & 1);
     if (i > A.hi[0]) return 0.0;
-    double bxm = fv_get(a.bx, i, j, k), bxp = fv_get(a.bx, i + 1, j, k), bym = fv_get(a.by, i, j, k), byp = fv_get(a.by, i, j + 1, k), bzm = fv_get(a.bz, i, j, k), bzp = fv_get(a.bz, i, j, k + 1);
+    MLCC_FACE_COEFFS(a, i, j, k)
     #define FOLD(b, dd, ss) { const int t = A.e[dd][ss]; if (t == VDN_BC_NEU) b = 0.0; else if (t == VDN_BC_DIR) b = 2.0 * b; }
     if (i == A.lo[0]) FOLD(bxm, 0, 0) if (i == A.hi[0]) FOLD(bxp, 0, 1)
     if (j == A.lo[1]) FOLD(bym, 1, 0) if (j == A.hi[1]) FOLD(byp, 1, 1)
@@ -577,7 +590,7 @@ static double read_dev(double *d) { return read_scalar1(d); }
 // descriptor sets are built once per solve: the fields of a solve do not move
 struct MLCC { int nlev; vdn_layout *la; bool fuse_first = false;   /* the finest level's residual pass also writes the first colour pass of its relaxation (ResidualB) */
               vdn_multifab **rh, **phi, **beta, **alpha; vdn_multifab *res[VDN_MAXLEV], *e[VDN_MAXLEV], *t[VDN_MAXLEV], *mask[VDN_MAXLEV];   // t[n] = res[n] - A_n e[n] (levels >= 1)
-              const double *dx; const vdn_bc_tower *bct; int bcc; double *d_nrm;
+              const double *dx; const vdn_bc_tower *bct; int bcc; double *d_nrm; const vdn_multifab *fine_rho = nullptr;   // the finest level's density when its face coefficients are mk_mac_coeffs of it
               BatchSet<ClosureB> closure[VDN_MAXLEV]; BatchSet<CfB> cf[VDN_MAXLEV]; BatchSet<ResidualB> resid[VDN_MAXLEV];
               BatchSet<RefluxB> reflux[VDN_MAXLEV][6];          // [fine level][d*2+s]: one launch per side so that a coarse cell is updated once per launch
               BatchSet<AbsmaxB> absmax[VDN_MAXLEV]; BatchSet<GsrbB> gsrb[VDN_MAXLEV]; BatchSet<AddB> add[VDN_MAXLEV];
@@ -658,13 +671,14 @@ static void mlcc_build_sets(MLCC &S) {
       ResidualB q; q.r = r; q.rh = S.rh[n]->fabs[b]; q.phi = S.phi[n]->fabs[b]; q.bx = S.beta[3 * n]->fabs[b]; q.by = S.beta[3 * n + 1]->fabs[b]; q.bz = S.beta[3 * n + 2]->fabs[b];
       q.res = S.res[n]->fabs[b]; for (int d = 0; d < 3; d++) q.A.hi2[d] = 1.0 / (S.dx[3 * n + d] * S.dx[3 * n + d]);
       q.has_alpha = S.alpha ? 1 : 0; q.alpha = S.alpha ? S.alpha[n]->fabs[b] : q.rh;
+      q.use_rho = (S.fine_rho && n == L - 1) ? 1 : 0; q.rho = q.use_rho ? S.fine_rho->fabs[b] : q.rh;
       q.fuse = (S.fuse_first && n == L - 1) ? 1 : 0; q.e = n >= 1 ? S.e[n]->fabs[b] : q.res;
       for (int d = 0; d < 3; d++) { q.A.lo[d] = r.lo[d]; q.A.hi[d] = r.hi[d]; for (int sd = 0; sd < 2; sd++) q.A.e[d][sd] = S.bct->ell_bc(n, b + 1, d, sd, S.bcc); }
       vr.push_back(q);
       if (n >= 1) { ResidualB qe = q; qe.rh = S.res[n]->fabs[b]; qe.phi = S.e[n]->fabs[b]; qe.res = S.t[n]->fabs[b]; qe.fuse = 0; vre.push_back(qe); }
       if (n < L - 1) { AbsmaxB m; m.r = r; m.a = S.res[n]->fabs[b]; m.mask = S.mask[n]->fabs[b]; m.has_mask = 1; va.push_back(m); }
       if (n >= 1) {
-        GsrbB gq; gq.e = S.e[n]->fabs[b]; gq.rh = S.res[n]->fabs[b]; gq.bx = q.bx; gq.by = q.by; gq.bz = q.bz; gq.has_alpha = q.has_alpha; gq.alpha = q.alpha;
+        GsrbB gq; gq.e = S.e[n]->fabs[b]; gq.rh = S.res[n]->fabs[b]; gq.bx = q.bx; gq.by = q.by; gq.bz = q.bz; gq.has_alpha = q.has_alpha; gq.alpha = q.alpha; gq.use_rho = q.use_rho; gq.rho = q.rho;
         for (int d = 0; d < 3; d++) { gq.A.lo[d] = r.lo[d]; gq.A.hi[d] = r.hi[d]; gq.A.hi2[d] = q.A.hi2[d]; for (int sd = 0; sd < 2; sd++) gq.A.e[d][sd] = S.bct->ell_bc(n, b + 1, d, sd, S.bcc); }
         gq.r = r; gq.r.hi[0] = r.lo[0] + (r.hi[0] - r.lo[0] + 2) / 2 - 1;
         vg.push_back(gq);
@@ -731,8 +745,8 @@ static void fill_phi_ghosts(MLCC &S) {
   hipStream_t st = ctx().stream;
   for (int n = S.nlev - 1; n >= 1; n--) { S.vf_phi[n].refresh(); S.rphi[n].run(0, (double *)nullptr, st); }
   // (levels >= 1: the exchange follows the coarse-fine interpolation below, which reads no ghost cell of its own level -- one exchange per level)
-  for (int n = 0; n < S.nlev; n++) { S.closure[n].run(0, (double *)nullptr, st); if (n == 0) mf_fill_boundary(S.phi[n]); }
-  for (int n = 1; n < S.nlev; n++) { S.vc_phi[n].refresh(); S.cf[n].run(0, (double *)nullptr, st); mf_fill_boundary(S.phi[n]); }
+  for (int n = 0; n < S.nlev; n++) { S.closure[n].run(0, (double *)nullptr, st); if (n == 0) mf_fill_boundary(S.phi[n], true); }
+  for (int n = 1; n < S.nlev; n++) { S.vc_phi[n].refresh(); S.cf[n].run(0, (double *)nullptr, st); mf_fill_boundary(S.phi[n], true); }
 }
 // the composite residual on every level and its norm over the composite grid
 static double composite_residual(MLCC &S) {
@@ -756,7 +770,7 @@ static void level_relax(MLCC &S, int n, int nsweeps, bool first_done) {
   const bool exchange = level_boxes(e).size() > 1 || S.la->pmask[0] || S.la->pmask[1] || S.la->pmask[2];     // boxes of the level anywhere, not just here: every rank must take part
   for (int s = 0; s < nsweeps; s++) for (int col = 0; col < 2; col++) {
     if (first_done && s == 0 && col == 0) continue;     // (the finest level's residual pass has written the first colour pass from e = 0)
-    if (exchange && (s > 0 || col > 0)) mf_fill_boundary(e);
+    if (exchange && (s > 0 || col > 0)) mf_fill_boundary(e, true);
     S.gsrb[n].run(col, (double *)nullptr, ctx().stream);
   }
 }
@@ -766,13 +780,13 @@ static void fill_e_ghosts(MLCC &S, int n) {
   hipStream_t st = ctx().stream;
   S.closure_e[n].run(0, (double *)nullptr, st);
   if (n >= 1) { S.vc_e[n].refresh(); S.cf_e[n].run(0, (double *)nullptr, st); }
-  mf_fill_boundary(S.e[n]);
+  mf_fill_boundary(S.e[n], true);
 }
 // rh, phi: [lev];  beta: [lev*3 + d];  dx: [lev*3 + d]
 // alpha: [lev] cell coefficients of (alpha - div beta grad), or nullptr.  The ghost cells of the incoming phi carry inhomogeneous
 // Dirichlet data (boundary-face values); they are moved into rh, which is modified
 int ml_cc_solve(vdn_layout *la, vdn_multifab **rh, vdn_multifab **phi, vdn_multifab **beta, const double *dx, const vdn_bc_tower *bct, int bc_comp0,
-                double rel_eps, int max_iter, int *iters, double *res0, double *res, vdn_multifab **alpha, vdn_multifab **base_beta, const vdn_multifab *base_rho) {
+                double rel_eps, int max_iter, int *iters, double *res0, double *res, vdn_multifab **alpha, vdn_multifab **base_beta, const vdn_multifab *base_rho, const vdn_multifab *fine_rho) {
   require_amr(la);
   hipStream_t st = ctx().stream;
   const size_t mark = arena_mark();
@@ -780,6 +794,9 @@ int ml_cc_solve(vdn_layout *la, vdn_multifab **rh, vdn_multifab **phi, vdn_multi
   MLCC S; S.nlev = L; S.la = la; S.rh = rh; S.phi = phi; S.beta = beta; S.alpha = alpha; S.dx = dx; S.bct = bct; S.bcc = bc_comp0;
   static const bool fuse_first_on = !(vdn_env("VDN_MLCC_FUSE1") && atoi(vdn_env("VDN_MLCC_FUSE1")) == 0);
   S.fuse_first = fuse_first_on && ctx().prm.mg_nu1 >= 1 && ctx().prm.mg_nu2 >= 1;
+  static const bool rho_form = !(vdn_env("VDN_MLCC_RHO") && atoi(vdn_env("VDN_MLCC_RHO")) == 0);
+  S.fine_rho = (rho_form && !alpha) ? fine_rho : nullptr;
+  if (S.fine_rho) REQUIRE(S.fine_rho->ng >= 1 && S.fine_rho->lev == L - 1, "composite solve: the finest level's density with a filled ghost cell expected");
   for (int n = 0; n < L; n++) {
     std::vector<DirRhsB> v;
     for (int b = 0; b < rh[n]->nfabs(); b++) {
@@ -859,13 +876,13 @@ int ml_cc_solve(vdn_layout *la, vdn_multifab **rh, vdn_multifab **phi, vdn_multi
     // up, coarsest level first: e_n += P e_{n-1}, the interface ghost cells from e_{n-1}, nu2 sweeps, phi_n += e_n
     for (int n = 1; n < L; n++) {
       const int lin = n >= 2 ? 1 : 0;                     // piecewise constant into level 1, linear into the finer ones (oracle: prolong_add)
-      if (lin) { S.edge_e[n - 1].run(0, (double *)nullptr, st); mf_fill_boundary(S.e[n - 1]); }     // the source's ghost cells: the cell itself where the level ends, then the neighbouring boxes' / periodic values
+      if (lin) { S.edge_e[n - 1].run(0, (double *)nullptr, st); mf_fill_boundary(S.e[n - 1], true); }     // the source's ghost cells: the cell itself where the level ends, then the neighbouring boxes' / periodic values
       S.vc_src[n].refresh();
       S.prolong[n].run(lin, (double *)nullptr, st);
       if (lin) fill_e_ghosts(S, n - 1);                   // (back to what the interface interpolation reads)
       S.zero_e[n].run(0, (double *)nullptr, st);
       S.vc_e[n].refresh(); S.cf_e[n].run(0, (double *)nullptr, st);
-      mf_fill_boundary(S.e[n]);
+      mf_fill_boundary(S.e[n], true);
       level_relax(S, n, P.mg_nu2, false);
       S.add[n].run(0, (double *)nullptr, st);
     }
@@ -902,7 +919,7 @@ void do_ml_macproject(vdn_layout *mla, vdn_multifab **umac, vdn_multifab **rho, 
   // coefficients are 1 / (mean rho), the restricted ones a mean of 1 / rho; across a sharp density jump the softer operator makes the correction
   // overshoot -- 45 FAC iterations instead of 12 at a one-cell jump of 10 : 1, divergence at 100 : 1).  One reduction and read-back per solve.
   const bool own = mf_max_ratio3(beta, beta0) <= 1.25;
-  int rc = ml_cc_solve(mla, rh, phi, beta, dx, bct, bc_comp0, ctx().prm.mac_rel_eps, ctx().prm.mg_max_iter, &it, &r0, &rr, nullptr, own ? beta0 : nullptr, own ? rho[0] : nullptr);
+  int rc = ml_cc_solve(mla, rh, phi, beta, dx, bct, bc_comp0, ctx().prm.mac_rel_eps, ctx().prm.mg_max_iter, &it, &r0, &rr, nullptr, own ? beta0 : nullptr, own ? rho[0] : nullptr, rho[L - 1]);
   for (int d = 2; d >= 0; d--) mf_temp_free(beta0[d]);
   ctx().solver_cycles[0] = it; ctx().solver_res0[0] = r0; ctx().solver_res[0] = rr;
   solver_check(rc, "composite MAC solve", it, rr, r0);

@@ -593,12 +593,17 @@ void xplan_cache_purge(unsigned long uid) {
   mg_halo_cache_purge(uid);
 }
 
-void mf_fill_boundary(vdn_multifab *mf) {
+// faces_only: the ghost cells beyond ONE face of a box only (what 7-point operators, the coarse-fine interpolation and the flux matching of the
+// composite cell-centred solve read): a level of a thousand 32^3 boxes has 26 neighbour regions per box, 20 of them edges and corners of 32 cells
+// or one -- three quarters of the copy kernel's workgroups
+void mf_fill_boundary(vdn_multifab *mf, bool faces_only) {
   if (mf->ng == 0) return;
-  FbKey key{ mf->la->uid, mf->base, mf->lev, mf->nc, mf->ng, mf->nodal[0] | (mf->nodal[1] << 1) | (mf->nodal[2] << 2) };
+  static const bool faces_ok = !(vdn_env("VDN_FB_FACES") && atoi(vdn_env("VDN_FB_FACES")) == 0);
+  faces_only = faces_only && faces_ok;
+  FbKey key{ mf->la->uid, mf->base, mf->lev, mf->nc, mf->ng, (mf->nodal[0] | (mf->nodal[1] << 1) | (mf->nodal[2] << 2)) + (faces_only ? 8 : 0) };
   auto it = g_fb_cache.find(key);
   if (it == g_fb_cache.end()) {
-    XPlan *P = xplan_build(xboxes_of(mf), mf->la->pd[mf->lev], mf->la->pmask, mf->ng, mf->nc);
+    XPlan *P = xplan_build(xboxes_of(mf), mf->la->pd[mf->lev], mf->la->pmask, mf->ng, mf->nc, faces_only);
     it = g_fb_cache.emplace(key, P).first;
     if (g_fb_cache.size() > 4096) vdn_fail("fill_boundary plan cache grew beyond 4096 entries (leaking multifabs?)");
   }
@@ -606,7 +611,7 @@ void mf_fill_boundary(vdn_multifab *mf) {
   if (P->local.empty() && P->peers.empty()) return;
   xplan_run(P);
 }
-extern "C" int vdn_multifab_fill_boundary(vdn_multifab *mf) { VDN_TRY mf_fill_boundary(mf); VDN_CATCH }
+extern "C" int vdn_multifab_fill_boundary(vdn_multifab *mf) { VDN_TRY mf_fill_boundary(mf, false); VDN_CATCH }
 
 // plan introspection for the CPU tests of the host logic (pure host code, no GPU, no layout object): the remote
 // descriptors rank `as_rank` would build for a multifab of the given shape on the given boxes, one row of 14

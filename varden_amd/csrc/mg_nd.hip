@@ -2247,7 +2247,7 @@ struct MLND {
   vdn_multifab *slave[VDN_MAXLEV];                   // nodes slaved to the next coarser level (levels >= 1)
   vdn_multifab *own[VDN_MAXLEV];                     // 1 in the fab that owns a node shared by several boxes (lowest box index)
   vdn_multifab *skip[VDN_MAXLEV];                    // nodes left out of the norm: slaves and nodes strictly inside the finer level
-  vdn_multifab *ea[VDN_MAXLEV], *eb[VDN_MAXLEV], *scr[VDN_MAXLEV];   // Jacobi ping-pong of the correction; prolonged increment
+  vdn_multifab *ea[VDN_MAXLEV], *eb[VDN_MAXLEV];   // Jacobi ping-pong of the correction
   std::vector<NdfArgs> A[VDN_MAXLEV]; std::vector<Range3> r[VDN_MAXLEV];      // per box: operator weights, node range, physical Dirichlet faces
   bool multi[VDN_MAXLEV]; double *d_nrm;
   MarchSet m_res[VDN_MAXLEV], m_res0[VDN_MAXLEV];    // residual of phi / of the zero field (norm of the right-hand side)
@@ -2325,7 +2325,6 @@ static void ml_nd_interface(MLND &S, int n) {
   ml_nd_prolong(S, n, S.phi[n], S.phi[n - 1], 0);
   if (S.multi[n]) mf_fill_boundary(S.phi[n]);
 }
-// finest_only: just the finest level's residual (what its relaxation needs), no norm.  zero_field: the residual of phi = 0
 // the damping of sweep s of the relaxation of a refined level in the composite solve: with hg_nu1 + hg_nu2 = 3 and vdn_params.hg_omega_fac1..3 > 0 the
 // three sweeps take those (a three-step Chebyshev set, 1.6 / 0.9 / 0.65: one FAC iteration fewer on the tagged hierarchies), otherwise hg_omega
 static double ndf_relax_omega(int s) {
@@ -2333,52 +2332,24 @@ static double ndf_relax_omega(int s) {
   const double o[3] = { P.hg_omega_fac1, P.hg_omega_fac2, P.hg_omega_fac3 };
   return (g_nd_iso && P.hg_nu1 + P.hg_nu2 == 3 && s < 3 && o[0] > 0.0 && o[1] > 0.0 && o[2] > 0.0) ? o[s] : P.hg_omega;
 }
-static bool ndf_fuse_first() {       // the fused residual + first sweep needs the paired march
-  static const bool on = !(vdn_env("VDN_NDF_FUSE1") && atoi(vdn_env("VDN_NDF_FUSE1")) == 0) && !(vdn_env("VDN_NDF_PAIR") && atoi(vdn_env("VDN_NDF_PAIR")) == 0);
-  return on;
-}
-// fuse_first (with finest_only): the same march also writes the first damped-Jacobi sweep of K e = r from e = 0 into eb of the finest level
-// lowest > 0 (without the norm): the residual fields of the levels >= lowest only (what the relaxation of level `lowest` reads)
-static double ml_nd_residual(MLND &S, bool finest_only, bool zero_field = false, bool fuse_first = false, bool want_norm = true, int lowest = 0) {
+// the composite residual on every level and its norm.  zero_field: the residual of phi = 0 (the norm of the right-hand side)
+static double ml_nd_residual(MLND &S, bool zero_field = false) {
   hipStream_t st = ctx().stream;
   const int L = S.nlev;
-  if (!zero_field) {
-    if (finest_only) ml_nd_interface(S, L - 1);
-    else { if (S.multi[0]) mf_fill_boundary(S.phi[0]); for (int n = 1; n < L; n++) ml_nd_interface(S, n); }
-  }
-  if (!finest_only) HIPCHK(hipMemsetAsync(S.d_nrm, 0, sizeof(double), st));
-  static const bool partial = !(vdn_env("VDN_MLND_PARTIAL") && atoi(vdn_env("VDN_MLND_PARTIAL")) == 0);
-  if (want_norm || !partial || zero_field) lowest = 0;
-  for (int n = L - 1; n >= (finest_only ? L - 1 : lowest); n--) {
+  if (!zero_field) { if (S.multi[0]) mf_fill_boundary(S.phi[0]); for (int n = 1; n < L; n++) ml_nd_interface(S, n); }
+  HIPCHK(hipMemsetAsync(S.d_nrm, 0, sizeof(double), st));
+  for (int n = L - 1; n >= 0; n--) {
     const bool finest = n == L - 1;
-    if (finest_only && fuse_first) { ndf_run_march<2>(S.m_res[n], ndf_relax_omega(0), S.slave[n] ? 1 : 0, (double *)nullptr); return 0.0; }
-    ndf_run_march<1>(zero_field ? S.m_res0[n] : S.m_res[n], 0.0, (finest && S.slave[n]) ? 1 : 0, (finest && !finest_only && want_norm) ? S.d_nrm : (double *)nullptr);
-    if (finest_only) return 0.0;
+    ndf_run_march<1>(zero_field ? S.m_res0[n] : S.m_res[n], 0.0, (finest && S.slave[n]) ? 1 : 0, finest ? S.d_nrm : (double *)nullptr);
     if (S.multi[n]) mf_fill_boundary(S.res[n]);
     if (finest) continue;
     S.vf_res[n + 1].refresh();
     S.rst[n + 1].run(0, (double *)nullptr, st);
     if (S.multi[n] && n > 0) mf_fill_boundary(S.res[n]);      // the ghost nodes must see the restricted part too before level n-1 restricts them
-    if (want_norm) S.amax[n].run(0, S.d_nrm, st);
+    S.amax[n].run(0, S.d_nrm, st);
   }
-  if (!want_norm) return 0.0;            // (the residual fields only: no reduction, no read-back)
   comm_allreduce_max_dev(S.d_nrm, 1);
   return ndf_read(S.d_nrm);
-}
-// phi_n += e (nodes of level n) and its trilinear prolongation on every finer level (not on physical Dirichlet nodes)
-static void ml_nd_apply_correction(MLND &S, int n, vdn_multifab *e, bool added = false) {      // added: phi_n += e was done where e was stored
-  if (!added) ml_nd_add(S, n, S.phi[n], e);
-  vdn_multifab *src = e;
-  for (int m = n + 1; m < S.nlev; m++) {
-    if (S.multi[m - 1]) mf_fill_boundary(src);
-    if (m == S.nlev - 1) ml_nd_prolong(S, m, S.phi[m], src, 1);
-    else {                                               // keep the increment for the next finer level
-      mf_setval(S.scr[m], 0.0, 0, 1, true);
-      ml_nd_prolong(S, m, S.scr[m], src, 2);
-      ml_nd_add(S, m, S.phi[m], S.scr[m]);
-      src = S.scr[m];
-    }
-  }
 }
 // rh, phi: nodal ng 1 per level; coeffs: cells ng 1 (ghost 0 outside the level); u: cells (>= 1 ghost); dx: [lev*3+d]
 static int ml_nd_solve(vdn_layout *la, vdn_multifab **rh, vdn_multifab **phi, vdn_multifab **coeffs, vdn_multifab **u, const double *dx,
@@ -2415,9 +2386,8 @@ static int ml_nd_solve(vdn_layout *la, vdn_multifab **rh, vdn_multifab **phi, vd
   for (int n = 0; n < L; n++) {
     S.phi[n] = phi[n]; S.b[n] = T(mf_temp(la, n, 1, 1, 3, true, 0.0)); S.res[n] = T(mf_temp(la, n, 1, 1, 3, true, 0.0));
     zero[n] = T(mf_temp(la, n, 1, 1, 3, true, 0.0));
-    S.sigfull[n] = coeffs[n]; S.sig[n] = coeffs[n]; S.skip[n] = S.slave[n] = S.own[n] = S.scr[n] = nullptr;
+    S.sigfull[n] = coeffs[n]; S.sig[n] = coeffs[n]; S.skip[n] = S.slave[n] = S.own[n] = nullptr;
     S.ea[n] = n >= 1 ? T(mf_temp(la, n, 1, 1, 3, true, 0.0)) : nullptr; S.eb[n] = n >= 1 ? T(mf_temp(la, n, 1, 1, 3, true, 0.0)) : nullptr;
-    if (n >= 1 && n < L - 1) S.scr[n] = T(mf_temp(la, n, 1, 1, 3, true, 0.0));
     inlev[n] = cov[n] = nullptr;
   }
   // cell masks: inlev[n] = the cells of level n (its ghost cells included where another box of the level covers them),
@@ -2512,7 +2482,7 @@ static int ml_nd_solve(vdn_layout *la, vdn_multifab **rh, vdn_multifab **phi, vd
     for (size_t f = 0; f < S.A[n].size(); f++) {
       MarchB q; q.phi = phi[n]->fabs[f]; q.out = S.res[n]->fabs[f]; q.rb = S.b[n]->fabs[f]; q.sig = S.sig[n]->fabs[f];
       q.slave = S.slave[n] ? S.slave[n]->fabs[f] : phi[n]->fabs[f]; q.has_slave = S.slave[n] ? (S.multi[n] ? 1 : 2) : 0; q.A = S.A[n][f]; q.r = S.r[n][f];
-      q.out2 = n >= 1 ? S.eb[n]->fabs[f] : q.out;          // (kk_ndf_march2<2>: the finest level's residual and first relaxation sweep in one march)
+      q.out2 = q.out;
       vr.push_back(q);
       q.phi = zero[n]->fabs[f]; vr0.push_back(q);
       if (n >= 1) {
@@ -2544,7 +2514,7 @@ static int ml_nd_solve(vdn_layout *la, vdn_multifab **rh, vdn_multifab **phi, vd
     }
   }
   // norm of the composite right-hand side = composite residual of phi = 0
-  const double bnorm = ml_nd_residual(S, false, true);
+  const double bnorm = ml_nd_residual(S, true);
   vdn_multifab *er = zero[0], *ee = T(mf_temp(la, 0, 1, 1, 3, true, 0.0));      // scratch of the coarse correction solve
   int ebc0[3][2];
   for (int d = 0; d < 3; d++) for (int s = 0; s < 2; s++) ebc0[d][s] = bct->ell_bc(0, 0, d, s, press_comp0);
@@ -2552,7 +2522,7 @@ static int ml_nd_solve(vdn_layout *la, vdn_multifab **rh, vdn_multifab **phi, vd
   NdKeep coarse_keep;                        // the level-0 multigrid hierarchy is built once for all FAC iterations
   static const bool neg_copy = vdn_env("VDN_NDM_NEG") && atoi(vdn_env("VDN_NDM_NEG")) != 0;
   while (!conv) {
-    rn = ml_nd_residual(S, false);
+    rn = ml_nd_residual(S);
     if ((rn <= rel_eps * bnorm && bnorm < HUGE_VAL) || rn <= abs_eps) { conv = true; break; }
     if (it >= max_iter || !(rn < HUGE_VAL) || !(bnorm < HUGE_VAL)) break;
     // coarse correction K_0 e = r_0: one V-cycle of the single-level solver from e = 0, the composite residual loaded as its b
@@ -2569,22 +2539,24 @@ static int ml_nd_solve(vdn_layout *la, vdn_multifab **rh, vdn_multifab **phi, vd
       launch_batched(v, 0, (double *)nullptr, 0, st);
       nd_solve(er, ee, coeffs[0], nullptr, dx, ebc0, 0.0, -1.0, -1, &cyc, &r0, &rr, &coarse_keep, nullptr, it == 0);     // (first correction: from the nested iteration, hg_fmg)
     }
-    ml_nd_apply_correction(S, 0, ee, !neg_copy);
-    // relaxation of K_n e = r_n on the finer levels, coarsest first, with the interface fixed
+    if (neg_copy) ml_nd_add(S, 0, S.phi[0], ee);           // (otherwise phi_0 += e_0 was done where e_0 was stored)
+    // the finer levels, coarsest first, in correction form (oracle: vo_ml_nd_solve): e_n = P e_{n-1} (trilinear, not on physical Dirichlet nodes),
+    // the sweeps of K_n e_n = r_n -- r_n from the top of the iteration -- with the interface nodes held at P e_{n-1}, phi_n += e_n.  (Rounds 2-3 applied
+    // every correction to phi on all finer levels at once and recomputed the composite residual before each relaxation: three residual passes over
+    // the finest of three levels per iteration where this form makes one.)
+    vdn_multifab *src = ee;
     for (int n = 1; n < L; n++) {
-      // the finest level (its relaxation runs on the coefficients its residual runs on): the residual march writes the first sweep too -- into
-      // eb, where a sweep from ea = 0 puts it; ea's ghost nodes outside the level stay zero from its allocation, no sweep writes them
-      const bool fuse = ndf_fuse_first() && n == L - 1 && P.hg_nu1 + P.hg_nu2 >= 1;
-      (void)ml_nd_residual(S, n == L - 1, false, fuse, false, n);
-      if (!fuse) mf_setval(S.ea[n], 0.0, 0, 1, true);
+      if (S.multi[n - 1]) mf_fill_boundary(src);         // a parent node may sit in a coarse box's ghost layer
+      mf_setval(S.ea[n], 0.0, 0, 1, true);
+      ml_nd_prolong(S, n, S.ea[n], src, 2);
       vdn_multifab *a = S.ea[n], *b2 = S.eb[n];
       for (int s = 0; s < P.hg_nu1 + P.hg_nu2; s++) {
-        if (fuse && s == 0) { std::swap(a, b2); continue; }
-        if (S.multi[n] && s > 0) mf_fill_boundary(a);
+        if (S.multi[n]) mf_fill_boundary(a);
         ndf_run_march<0>(S.m_jac[n][s & 1], ndf_relax_omega(s), 0, (double *)nullptr);
         std::swap(a, b2);
       }
-      ml_nd_apply_correction(S, n, a);
+      ml_nd_add(S, n, S.phi[n], a);
+      src = a;
     }
     it++;
   }

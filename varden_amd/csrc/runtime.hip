@@ -164,11 +164,11 @@ static const EnvSwitch g_switches[] = {
   { "VDN_ND_BENCH", "n: time n Jacobi sweeps of the finest nodal level inside the next solve and print the mean (probe)" },
   { "VDN_ND_DBG", "probe only, with VDN_ND_BENCH: 1 no stencil arithmetic, 2 no loads in the march" },
   { "VDN_NDF_PAIR", "0: one node per lane in the box-batched nodal march of the composite solve" },
-  { "VDN_NDF_FUSE1", "0: the composite nodal solve's finest-level residual and first relaxation sweep as two launches" },
   { "VDN_NDM_IFACE_FACES", "0: interface interpolation of the composite nodal solve over whole boxes instead of box faces" },
   { "VDN_NDM_PROLONG8", "0: correction interpolation with a thread per fine node instead of per coarse node" },
   { "VDN_NDM_NEG", "1: the composite nodal solve copies -res into the correction's right-hand side instead of loading it directly" },
-  { "VDN_MLND_PARTIAL", "0: every composite nodal residual computes all levels" },
+  { "VDN_FB_FACES", "0: the ghost exchanges of the composite cell-centred solve fill edges and corners too" },
+  { "VDN_MLCC_RHO", "0: the composite MAC solve reads stored face coefficients on its finest level too" },
   { "VDN_MLCC_GLUE", "0: the level-0 correction of the composite MAC solve stored and added in separate passes" },
   { "VDN_MLCC_FUSE1", "0: the composite MAC solve's finest-level residual and first colour pass as two launches" },
   { "VDN_BATCH_YZ", "0: no (j,k) / (i,k) tiles for thin ranges in the box-batched kernels" },

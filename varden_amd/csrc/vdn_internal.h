@@ -250,7 +250,7 @@ struct BoxBins {
 // helpers shared between translation units
 BoxP make_boxp(const vdn_multifab *mf, int i, const vdn_bc_tower *bct);
 void mf_setval(vdn_multifab *mf, double val, int comp, int nc, bool all);
-void mf_fill_boundary(vdn_multifab *mf);
+void mf_fill_boundary(vdn_multifab *mf, bool faces_only = false);
 void mf_physbc(vdn_multifab *mf, int scomp, int bccomp, int nc, const vdn_bc_tower *bct, bool same_boundary = false);
 void mf_copy(vdn_multifab *dst, int dcomp, const vdn_multifab *src, int scomp, int nc, int ng);
 double mf_norm_inf(const vdn_multifab *mf, int comp, int nc);
@@ -336,7 +336,7 @@ void ml_fill_ghost_cells(vdn_multifab *fine, const vdn_multifab *crse, int icomp
 void ml_create_umac_grown(vdn_multifab *fine, const vdn_multifab *crse, int dir);
 void ml_restrict_and_fill(int nlev, vdn_multifab **mf, int icomp, int bcomp, int nc, bool same_boundary, const vdn_bc_tower *bct);
 int ml_cc_solve(vdn_layout *la, vdn_multifab **rh, vdn_multifab **phi, vdn_multifab **beta, const double *dx, const vdn_bc_tower *bct, int bc_comp0,
-                double rel_eps, int max_iter, int *iters, double *res0, double *res, vdn_multifab **alpha, vdn_multifab **base_beta = nullptr, const vdn_multifab *base_rho = nullptr);
+                double rel_eps, int max_iter, int *iters, double *res0, double *res, vdn_multifab **alpha, vdn_multifab **base_beta = nullptr, const vdn_multifab *base_rho = nullptr, const vdn_multifab *fine_rho = nullptr);
 void do_ml_visc_solve(vdn_layout *mla, vdn_multifab **unew, vdn_multifab **lapu, vdn_multifab **rho, vdn_multifab **mac_rhs,
                       const double *dx, double mu, const vdn_bc_tower *bct);
 void do_ml_diff_scalar_solve(vdn_layout *mla, vdn_multifab **snew, vdn_multifab **laps, const double *dx, double mu,
