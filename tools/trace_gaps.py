@@ -4,6 +4,7 @@ import sqlite3, sys, collections
 db = sqlite3.connect(sys.argv[1])
 rows = db.execute("select name, start, end, grid_x, grid_y, grid_z from kernels order by start").fetchall()
 est = [i for i, r in enumerate(rows) if r[0].startswith("kk_estdt(")]
+if len(est) < 2: est = [i for i, r in enumerate(rows) if r[0].startswith("kk_estdt_b")]      # (every level in boxes: the batched form only)
 which = int(sys.argv[2]) if len(sys.argv) > 2 else len(est) - 2
 a, b = est[which], est[which + 1]
 seg = rows[a:b]

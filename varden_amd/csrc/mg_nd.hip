@@ -1869,7 +1869,7 @@ __global__ void kk_ndf_jacobi(FV ein, FV eout, FV rb, FV sig, NdfArgs A, double 
 // shuffles, three phi planes and two sigma planes in registers).  r: the node range of the box; tiles of 62 nodes along i.
 // MODE 0: eout = ein + omega (rb - K ein)/diag on free nodes;  MODE 1: res = b - K phi (0 on physical Dirichlet nodes), max-norm
 // over the nodes that are not interface nodes (excl = 1) / all nodes (excl = 0)
-struct MarchB { FV phi, out, rb, sig, slave, out2; int has_slave; NdfArgs A; Range3 r; int g[3], kchunk, lw; };      // out2: MODE 2 of kk_ndf_march2      // lw: log2 of the lane segment of one node row (6, 5, 4)
+struct MarchB { FV phi, out, rb, sig, slave; int has_slave; NdfArgs A; Range3 r; int g[3], kchunk, lw; };      // lw: log2 of the lane segment of one node row (6, 5, 4)
 template <int MODE>
 __global__ void __launch_bounds__(256) kk_ndf_march(const MarchB *args, const int *start, int nbox, double omega, int excl, double *nrm) {
   int lo_ = 0, hi_ = nbox - 1;
@@ -1983,7 +1983,7 @@ __global__ void __launch_bounds__(256) kk_ndf_march2(const MarchB *args, const i
     const PairAt ap = pair_at(phi, ia, jc, k0), as = pair_at(sig, ia, jc, k0), ab = pair_at(rb, ia, jc, k0);
     const long syp = phi.n0, szp = (long)phi.n0 * phi.n1, sys = sig.n0, szs = (long)sig.n0 * sig.n1, szb = (long)rb.n0 * rb.n1;
     PairAt al = ab; long szl = 0;
-    const bool use_mask = has_slave == 1 && (MODE == 0 || MODE == 2 || excl == 1);
+    const bool use_mask = has_slave == 1 && (MODE == 0 || excl == 1);
     if (use_mask) { al = pair_at(slave, ia, jc, k0); szl = (long)slave.n0 * slave.n1; }
     // the pair store: lanes with both nodes write 16 bytes, the lane whose second node lies beyond the box writes node A alone; every lane
     // executes both store instructions (the others into a sink): the number of stores in flight is known at compile time (see kk_nd_march_pair)
@@ -1991,13 +1991,6 @@ __global__ void __launch_bounds__(256) kk_ndf_march2(const MarchB *args, const i
     double *op2 = actB ? out.p + io : g_nd_sink + 2 * (int)threadIdx.x;       // (g_nd_sink: 128 doubles, one 16-byte slot per lane of a wave)
     double *op1 = (actA && !actB) ? out.p + io : g_nd_sink + 2 * (int)threadIdx.x;
     const long st2 = actB ? szo : 0, st1 = (actA && !actB) ? szo : 0;
-    // MODE 2: the residual AND the first damped-Jacobi sweep of the correction equation K e = r from e = 0, e1 = omega r / diag, into out2
-    double *oq2 = g_nd_sink + 2 * (int)threadIdx.x, *oq1 = oq2; long sq2 = 0, sq1 = 0;
-    if (MODE == 2) {
-      const long io2 = fv_idx(B.out2, min(ia, r.hi[0]), jc, k0), szo2 = (long)B.out2.n0 * B.out2.n1;
-      if (actB) { oq2 = B.out2.p + io2; sq2 = szo2; }
-      if (actA && !actB) { oq1 = B.out2.p + io2; sq1 = szo2; }
-    }
     long cp = ap.idx, cs = as.idx, cb = ab.idx, cl = al.idx;
     double q[3][3][4], sg[2][2][3];
     #define LOADP(pl, off) { _Pragma("unroll") for (int b = 0; b < 3; b++) ld_pair(phi.p, (off) + (b - 1) * syp, ap.sh, q[pl][b][1], q[pl][b][2]); }
@@ -2007,7 +2000,7 @@ __global__ void __launch_bounds__(256) kk_ndf_march2(const MarchB *args, const i
     LOADP(0, cp - szp) LOADP(1, cp) LOADS(0, cs - szs)
     EXCHP(0) EXCHP(1) EXCHS(0)
     const NdW W = nd_weights(A.f);
-    for (int k = k0; k <= k1; k++, cp += szp, cs += szs, cb += szb, cl += szl, op2 += st2, op1 += st1, oq2 += sq2, oq1 += sq1) {
+    for (int k = k0; k <= k1; k++, cp += szp, cs += szs, cb += szb, cl += szl, op2 += st2, op1 += st1) {
       LOADP(2, cp + szp) LOADS(1, cs)
       double rhsA, rhsB; ld_pair(rb.p, cb, ab.sh, rhsA, rhsB);
       double mA = 0.0, mB = 0.0;
@@ -2048,13 +2041,6 @@ __global__ void __launch_bounds__(256) kk_ndf_march2(const MarchB *args, const i
       vdn_d2u o2; o2.x = oA; o2.y = oB;
       *reinterpret_cast<vdn_d2u *>(op2) = o2;
       *op1 = oA;
-      if (MODE == 2) {       // what kk_ndf_march2<0> makes of phi = 0, rb = this residual: K 0 = 0, v = 0 + omega ((r - 0) / diag) -- same bits (0 + x loses the sign of a zero either way)
-        vdn_d2u e2; e2.x = 0.0; e2.y = 0.0;
-        if (!pdirA && !cfA && dgA != 0.0) e2.x = 0.0 + omega * (oA / dgA);
-        if (!pdirB && !cfB && dgB != 0.0) e2.y = 0.0 + omega * (oB / dgB);
-        *reinterpret_cast<vdn_d2u *>(oq2) = e2;
-        *oq1 = e2.x;
-      }
       #pragma unroll
       for (int b = 0; b < 3; b++)
         #pragma unroll
@@ -2101,7 +2087,7 @@ template <int MODE> static void ndf_run_march(const MarchSet &S, double omega, i
   if (S.nbox == 0) return;
   static const bool paired = !(vdn_env("VDN_NDF_PAIR") && atoi(vdn_env("VDN_NDF_PAIR")) == 0);
   if (paired) hipLaunchKernelGGL(kk_ndf_march2<MODE>, dim3(S.tot), NBLK, 0, ctx().stream, (const MarchB *)S.d_args, (const int *)S.d_start, S.nbox, omega, excl, nrm);
-  else { REQUIRE(MODE != 2, "the fused residual + sweep is the paired march's"); hipLaunchKernelGGL(kk_ndf_march<(MODE == 2 ? 1 : MODE)>, dim3(S.tot), NBLK, 0, ctx().stream, (const MarchB *)S.d_args, (const int *)S.d_start, S.nbox, omega, excl, nrm); }
+  else hipLaunchKernelGGL(kk_ndf_march<MODE>, dim3(S.tot), NBLK, 0, ctx().stream, (const MarchB *)S.d_args, (const int *)S.d_start, S.nbox, omega, excl, nrm);
 }
 
 static double ndf_read(double *d) { return read_scalar1(d); }
@@ -2482,7 +2468,6 @@ static int ml_nd_solve(vdn_layout *la, vdn_multifab **rh, vdn_multifab **phi, vd
     for (size_t f = 0; f < S.A[n].size(); f++) {
       MarchB q; q.phi = phi[n]->fabs[f]; q.out = S.res[n]->fabs[f]; q.rb = S.b[n]->fabs[f]; q.sig = S.sig[n]->fabs[f];
       q.slave = S.slave[n] ? S.slave[n]->fabs[f] : phi[n]->fabs[f]; q.has_slave = S.slave[n] ? (S.multi[n] ? 1 : 2) : 0; q.A = S.A[n][f]; q.r = S.r[n][f];
-      q.out2 = q.out;
       vr.push_back(q);
       q.phi = zero[n]->fabs[f]; vr0.push_back(q);
       if (n >= 1) {
