@@ -1869,7 +1869,7 @@ __global__ void kk_ndf_jacobi(FV ein, FV eout, FV rb, FV sig, NdfArgs A, double 
 // shuffles, three phi planes and two sigma planes in registers).  r: the node range of the box; tiles of 62 nodes along i.
 // MODE 0: eout = ein + omega (rb - K ein)/diag on free nodes;  MODE 1: res = b - K phi (0 on physical Dirichlet nodes), max-norm
 // over the nodes that are not interface nodes (excl = 1) / all nodes (excl = 0)
-struct MarchB { FV phi, out, rb, sig, slave; int has_slave; NdfArgs A; Range3 r; int g[3], kchunk, lw; };      // lw: log2 of the lane segment of one node row (6, 5, 4)
+struct MarchB { FV phi, out, rb, sig, slave; int has_slave; NdfArgs A; Range3 r; int g[3], kchunk, sw; };      // sw: lanes of the segment that carries one node row (4 .. 64)
 template <int MODE>
 __global__ void __launch_bounds__(256) kk_ndf_march(const MarchB *args, const int *start, int nbox, double omega, int excl, double *nrm) {
   int lo_ = 0, hi_ = nbox - 1;
@@ -1881,15 +1881,15 @@ __global__ void __launch_bounds__(256) kk_ndf_march(const MarchB *args, const in
   const NdfArgs A = B.A; const Range3 r = B.r;
   const int lb = bid - as_constant(start + lo_);
   const int bx = lb % B.g[0], by = (lb / B.g[0]) % B.g[1], bz = lb / (B.g[0] * B.g[1]);
-  // a wave holds 64 >> lw node rows of 1 << lw lanes each (first and last lane of a row segment only feed their neighbours): boxes
-  // narrower than 31 / 15 nodes put two / four rows into a wave instead of leaving three quarters of it idle; the lane exchange
-  // never crosses a segment for an active lane
-  const int lw = B.lw, sw = 1 << lw, rows = 64 >> lw;
-  const int lane = (int)threadIdx.x & (sw - 1), seg = (int)threadIdx.x >> lw;
+  // a wave holds 64 / sw node rows of sw lanes each (first and last lane of a row segment only feed their neighbours; sw need not be a power of
+  // two -- the lanes left over after the last segment own nothing): narrow boxes put several rows into a wave instead of leaving most of it idle;
+  // the lane exchange never crosses a segment for an active lane
+  const int sw = B.sw, rows = 64 / sw;
+  const int lane = (int)threadIdx.x % sw, seg = (int)threadIdx.x / sw;
   const int i = r.lo[0] + bx * (sw - 2) + lane - 1;
   const int j = r.lo[1] + (by * (int)blockDim.y + (int)threadIdx.y) * rows + seg;
   const int k0 = r.lo[2] + bz * kchunk, k1 = min(k0 + kchunk - 1, r.hi[2]);
-  const bool active = lane >= 1 && lane <= sw - 2 && i <= r.hi[0] && j <= r.hi[1];
+  const bool active = seg < rows && lane >= 1 && lane <= sw - 2 && i <= r.hi[0] && j <= r.hi[1];
   const int ic = min(i, r.hi[0] + 1), jc = min(j, r.hi[1]);
   double rmax = 0.0;
   if (k0 <= k1) {
@@ -1969,12 +1969,12 @@ __global__ void __launch_bounds__(256) kk_ndf_march2(const MarchB *args, const i
   const NdfArgs A = B.A; const Range3 r = B.r;
   const int lb = bid - as_constant(start + lo_);
   const int bx = lb % B.g[0], by = (lb / B.g[0]) % B.g[1], bz = lb / (B.g[0] * B.g[1]);
-  const int lw = B.lw, sw = 1 << lw, rows = 64 >> lw;
-  const int lane = (int)threadIdx.x & (sw - 1), seg = (int)threadIdx.x >> lw;
+  const int sw = B.sw, rows = 64 / sw;
+  const int lane = (int)threadIdx.x % sw, seg = (int)threadIdx.x / sw;
   const int ia = r.lo[0] + 2 * (bx * (sw - 2) + lane - 1);                  // nodes ia, ia + 1
   const int j = r.lo[1] + (by * (int)blockDim.y + (int)threadIdx.y) * rows + seg;
   const int k0 = r.lo[2] + bz * kchunk, k1 = min(k0 + kchunk - 1, r.hi[2]);
-  const bool own = lane >= 1 && lane <= sw - 2 && j <= r.hi[1];
+  const bool own = seg < rows && lane >= 1 && lane <= sw - 2 && j <= r.hi[1];
   const bool actA = own && ia <= r.hi[0], actB = own && ia + 1 <= r.hi[0];
   const int jc = min(j, r.hi[1]);
   double rmax = 0.0;
@@ -2067,9 +2067,18 @@ static MarchSet ndf_build_march(std::vector<MarchB> &v) {
     MarchB &B = v[b];
     const int nx = B.r.hi[0] - B.r.lo[0] + 1, ny = B.r.hi[1] - B.r.lo[1] + 1, nz = B.r.hi[2] - B.r.lo[2] + 1;
     static const bool paired = !(vdn_env("VDN_NDF_PAIR") && atoi(vdn_env("VDN_NDF_PAIR")) == 0);
-    if (paired) B.lw = nx <= 12 ? 3 : (nx <= 28 ? 4 : (nx <= 60 ? 5 : 6));       // kk_ndf_march2: a lane carries two nodes
-    else B.lw = nx <= 14 ? 4 : (nx <= 30 ? 5 : 6);
-    const int act = (paired ? 2 : 1) * ((1 << B.lw) - 2), rows = 4 * (64 >> B.lw);
+    // the segment width that needs the fewest waves per node row (kk_ndf_march2: a lane carries two nodes): tiles along x / rows per wave; a box of
+    // 33 nodes takes 19 lanes (17 pairs + the two feeding lanes), three rows per wave, where the power-of-two segments of round 3 gave it 32 and two
+    static const bool any_width = !(vdn_env("VDN_NDF_SEGW") && atoi(vdn_env("VDN_NDF_SEGW")) == 0);
+    const int per_lane = paired ? 2 : 1;
+    int best = 64; double best_cost = 1e30;
+    for (int sw = 4; sw <= 64; sw++) {
+      if (!any_width && (sw & (sw - 1))) continue;
+      const double cost = (double)((nx + per_lane * (sw - 2) - 1) / (per_lane * (sw - 2))) / (double)(64 / sw);
+      if (cost < best_cost - 1e-12) { best_cost = cost; best = sw; }
+    }
+    B.sw = best;
+    const int act = per_lane * (B.sw - 2), rows = 4 * (64 / B.sw);
     const int tiles = ((nx + act - 1) / act) * ((ny + rows - 1) / rows);
     int kchunk = nz;
     while (kchunk > 8 && tiles * ((nz + kchunk - 1) / kchunk) < 2048) kchunk = (kchunk + 1) / 2;

@@ -163,6 +163,7 @@ static const EnvSwitch g_switches[] = {
   { "VDN_ND_RESTRICT_FUSED", "0: nodal residual and full weighting as two passes" },
   { "VDN_ND_BENCH", "n: time n Jacobi sweeps of the finest nodal level inside the next solve and print the mean (probe)" },
   { "VDN_ND_DBG", "probe only, with VDN_ND_BENCH: 1 no stencil arithmetic, 2 no loads in the march" },
+  { "VDN_NDF_SEGW", "0: the marches of the composite nodal solve use power-of-two lane segments per node row only" },
   { "VDN_NDF_PAIR", "0: one node per lane in the box-batched nodal march of the composite solve" },
   { "VDN_NDM_IFACE_FACES", "0: interface interpolation of the composite nodal solve over whole boxes instead of box faces" },
   { "VDN_NDM_PROLONG8", "0: correction interpolation with a thread per fine node instead of per coarse node" },
