@@ -150,6 +150,9 @@ const char *vdn_comm_transport(void);
 int  vdn_plan_describe(const vdn_box *pd, const int *pmask, int nboxes, const vdn_box *boxes, const int *owner,
                        int nc, int ng, const int *nodal, int as_rank, long *rows, int maxrows,
                        int *nrows, int *nlocal_descs);
+/* host-only introspection of the box index behind the box-pair loops of the inter-level operators (CPU tests): the boxes of the list that the  */
+/* index names as candidates for touching [qlo - margin, qhi + margin], ascending; *ncand their number (out holds the first maxout)            */
+int  vdn_box_candidates(int nboxes, const vdn_box *boxes, const int *qlo, const int *qhi, int margin, int *out, int maxout, int *ncand);
 
 /* ------------------------------------------------------------------------------------------- */
 /* ml_layout: nlev levels; rr[nlev-1][3] refinement ratios; pd[nlev] problem domains;          */

@@ -173,3 +173,30 @@ def test_exchange_plan_two_gloo_ranks():
         p.join(60)
     for r, msg in res:
         assert msg == "ok", "rank %d: %s" % (r, msg)
+
+
+def test_box_index_names_every_touching_box():
+    """the bin index behind the box-pair loops of the inter-level operators (vdn_internal.h BoxBins, host code): for random box lists -- sizes 1 to 40, some
+    far outside the cloud, negative indices -- and random query regions its candidates are ascending, unique, and contain every box that touches the grown query"""
+    from varden_amd import capi
+    lib = capi.load()
+    rng = np.random.default_rng(5)
+    for trial in range(40):
+        nb = int(rng.integers(1, 400))
+        los = rng.integers(-64, 512, size=(nb, 3)); ext = rng.integers(0, 40, size=(nb, 3))
+        if trial % 5 == 0:
+            los[0] = (-5000, 3000, 7); ext[0] = (0, 0, 0)
+        boxes = (capi.Box * nb)()
+        for i in range(nb):
+            for d in range(3):
+                boxes[i].lo[d] = int(los[i, d]); boxes[i].hi[d] = int(los[i, d] + ext[i, d])
+        for q in range(30):
+            qlo = rng.integers(-100, 560, size=3); qhi = qlo + rng.integers(0, 70, size=3)
+            margin = int(rng.integers(0, 4))
+            out = (C.c_int * nb)(); nc = C.c_int(0)
+            rc = lib.vdn_box_candidates(nb, boxes, (C.c_int * 3)(*[int(x) for x in qlo]), (C.c_int * 3)(*[int(x) for x in qhi]), margin, out, nb, C.byref(nc))
+            assert rc == 0
+            cand = list(out[:nc.value])
+            assert cand == sorted(set(cand)) and all(0 <= c < nb for c in cand)
+            touch = np.all((los + ext >= qlo - margin) & (los <= qhi + margin), axis=1)
+            assert set(np.nonzero(touch)[0]) <= set(cand), (trial, q)

@@ -22,6 +22,9 @@ print("gap histogram (us: count, total ms):", [(k, v, round(sum(g for g, _ in ga
 print("largest gaps:")
 for g, i in sorted(gaps, reverse=True)[:25]:
     print("  %8.1f us after %-50s before %-50s" % (g / 1e3, seg[i - 1][0][:50], seg[i][0][:50]))
+print("around the four largest gaps (five kernels before, five after):")
+for g, i in sorted(gaps, reverse=True)[:4]:
+    print("  gap %.1f us: ... %s  ||  %s ..." % (g / 1e3, " > ".join(r[0].split("(")[0][-40:] for r in seg[max(0, i - 5):i]), " > ".join(r[0].split("(")[0][-40:] for r in seg[i:i + 5])))
 grp = collections.defaultdict(lambda: [0, 0.0])
 for g, i in gaps:
     if g >= 50e3: k = (seg[i - 1][0].split("(")[0][:44], seg[i][0].split("(")[0][:44]); grp[k][0] += 1; grp[k][1] += g / 1e6

@@ -73,6 +73,7 @@ SIGNATURES = {
     "vdn_debug_switches": (C.c_char_p, []),
     "vdn_plan_describe": (C.c_int, [C.POINTER(Box), _PI, C.c_int, C.POINTER(Box), _PI, C.c_int, C.c_int, _PI, C.c_int,
                                     C.POINTER(C.c_long), C.c_int, _PI, _PI]),
+    "vdn_box_candidates": (C.c_int, [C.c_int, C.POINTER(Box), _PI, _PI, C.c_int, _PI, C.c_int, _PI]),
     "vdn_layout_create": (C.c_int, [C.c_int, _PI, C.POINTER(Box), _PI, C.POINTER(Box), _PI, _PI, _PVP]),
     "vdn_layout_destroy": (C.c_int, [_VP]),
     "vdn_layout_nlevel": (C.c_int, [_VP]),

@@ -428,21 +428,29 @@ struct CfB { Range3 r; int g[3]; static constexpr int planes_per_wg = 8; FV pf, 
   } };
 // ghost cells of the fine phi: coarse-fine interpolation on every face that is not a domain face, then the same-level exchange
 // (which overwrites the cells that another fine box covers); domain faces were closed by the closure
-static void cf_descs(vdn_multifab *pf, const SrcView &pc, const vdn_bc_tower *bct, int bc_comp0, std::vector<CfB> &v) {
+// idx (optional): the (fine box, coarse view entry) of every descriptor -- a second field on the same boxes takes the list with its own pointers
+static void cf_descs(vdn_multifab *pf, const SrcView &pc, const vdn_bc_tower *bct, int bc_comp0, std::vector<CfB> &v, std::vector<std::pair<int, int>> *idx = nullptr) {
   const BoxBins cb(pc.vbox, &pc.have);
-  for (int f = 0; f < pf->nfabs(); f++) for (int d = 0; d < 3; d++) for (int s = 0; s < 2; s++) {
-    const int eb = bct->ell_bc(pf->lev, f + 1, d, s, bc_comp0);
-    if (eb != VDN_BC_INT && eb != VDN_BC_PER) continue;        // periodic faces too: the same-level exchange then overwrites what the level itself covers
-    Range3 r; for (int t = 0; t < 3; t++) { r.lo[t] = pf->vbox[f].lo[t]; r.hi[t] = pf->vbox[f].hi[t]; }
-    r.lo[d] = r.hi[d] = s ? pf->vbox[f].hi[d] + 1 : pf->vbox[f].lo[d] - 1;
-    int plo[3], phi[3]; Range3 dummy;
-    for (int t = 0; t < 3; t++) { plo[t] = hfdiv2(r.lo[t]); phi[t] = hfdiv2(r.hi[t]); }
-    for (int c : cb.near(plo, phi, 1)) {
-      // only coarse boxes that hold a parent of this slab
-      if (!isect(plo, phi, pc.vbox[c].lo, pc.vbox[c].hi, dummy)) continue;
-      CfB a; a.r = r; a.pf = pf->fabs[f]; a.pc = pc.fv[c]; a.A.d = d; a.A.s = s;
-      for (int t = 0; t < 3; t++) { a.A.plo[t] = pc.vbox[c].lo[t]; a.A.phi[t] = pc.vbox[c].hi[t]; }
-      v.push_back(a);
+  v.reserve((size_t)pf->nfabs() * 8);
+  for (int f = 0; f < pf->nfabs(); f++) {
+    int glo[3], ghi[3];
+    for (int t = 0; t < 3; t++) { glo[t] = hfdiv2(pf->vbox[f].lo[t] - 1); ghi[t] = hfdiv2(pf->vbox[f].hi[t] + 1); }
+    const std::vector<int> &cand = cb.near(glo, ghi, 1);     // one query per box: the parents of all its six ghost slabs
+    for (int d = 0; d < 3; d++) for (int s = 0; s < 2; s++) {
+      const int eb = bct->ell_bc(pf->lev, f + 1, d, s, bc_comp0);
+      if (eb != VDN_BC_INT && eb != VDN_BC_PER) continue;        // periodic faces too: the same-level exchange then overwrites what the level itself covers
+      Range3 r; for (int t = 0; t < 3; t++) { r.lo[t] = pf->vbox[f].lo[t]; r.hi[t] = pf->vbox[f].hi[t]; }
+      r.lo[d] = r.hi[d] = s ? pf->vbox[f].hi[d] + 1 : pf->vbox[f].lo[d] - 1;
+      int plo[3], phi[3]; Range3 dummy;
+      for (int t = 0; t < 3; t++) { plo[t] = hfdiv2(r.lo[t]); phi[t] = hfdiv2(r.hi[t]); }
+      for (int c : cand) {
+        // only coarse boxes that hold a parent of this slab
+        if (!isect(plo, phi, pc.vbox[c].lo, pc.vbox[c].hi, dummy)) continue;
+        CfB a; a.r = r; a.pf = pf->fabs[f]; a.pc = pc.fv[c]; a.A.d = d; a.A.s = s;
+        for (int t = 0; t < 3; t++) { a.A.plo[t] = pc.vbox[c].lo[t]; a.A.phi[t] = pc.vbox[c].hi[t]; }
+        v.push_back(a);
+        if (idx) idx->push_back({ f, c });
+      }
     }
   }
 }
@@ -605,8 +613,9 @@ struct MLCC { int nlev; vdn_layout *la; bool fuse_first = false;   /* the finest
               SrcView vc_phi[VDN_MAXLEV], vf_phi[VDN_MAXLEV], vf_res[VDN_MAXLEV], vf_beta[VDN_MAXLEV][3], vc_src[VDN_MAXLEV];
               SrcView vc_e[VDN_MAXLEV], vf_e[VDN_MAXLEV], vf_t[VDN_MAXLEV];   // [fine level n]: e[n-1] under the grown boxes of level n; e[n] (with ghost cells) and t[n] over the boxes of level n-1
 };
-static void restrict_descs(vdn_multifab *crse, const SrcView &fine, std::vector<RestrictB> &v) {
+static void restrict_descs(vdn_multifab *crse, const SrcView &fine, std::vector<RestrictB> &v, std::vector<std::pair<int, int>> *idx = nullptr) {
   const BoxBins cb(crse->vbox);
+  v.reserve((size_t)fine.nboxes() * 2);
   for (int f = 0; f < fine.nboxes(); f++) {
     if (!fine.have[f]) continue;
     int clo[3], chi[3];
@@ -616,6 +625,7 @@ static void restrict_descs(vdn_multifab *crse, const SrcView &fine, std::vector<
       if (!isect(clo, chi, crse->vbox[c].lo, crse->vbox[c].hi, a.r)) continue;
       a.crse = crse->fabs[c]; a.fine = fine.fv[f]; a.icomp = 0; a.nc = 1; a.fc0 = 0;
       v.push_back(a);
+      if (idx) idx->push_back({ f, c });
     }
   }
 }
@@ -648,14 +658,20 @@ static void mlcc_build_sets(MLCC &S) {
       S.vf_phi[n] = make_view(S.phi[n], refined_footprints(S.phi[n - 1], -1, 2), level_owner(S.phi[n - 1]), 0, 1, VT_REFINE_G1);
       S.vf_res[n] = make_view(S.res[n], refined_footprints(S.res[n - 1], -1, 0), level_owner(S.res[n - 1]), 0, 1, VT_REFINE);
       for (int d = 0; d < 3; d++) { S.vf_beta[n][d] = make_view(S.beta[3 * n + d], refined_footprints(S.phi[n - 1], d, 2), level_owner(S.phi[n - 1]), 0, 1, VT_REFINE_G1); S.vf_beta[n][d].refresh(); }
-      { std::vector<CfB> v; cf_descs(S.phi[n], S.vc_phi[n], S.bct, S.bcc, v); S.cf[n].build(v, 0, st); }
-      { std::vector<RestrictB> v; restrict_descs(S.phi[n - 1], S.vf_phi[n], v); S.rphi[n].build(v, 0, st); }
-      { std::vector<RestrictB> v; restrict_descs(S.res[n - 1], S.vf_res[n], v); S.rres[n].build(v, 0, st); }
+      std::vector<CfB> vcf; std::vector<std::pair<int, int>> icf;
+      cf_descs(S.phi[n], S.vc_phi[n], S.bct, S.bcc, vcf, &icf);
+      std::vector<RestrictB> vrr; std::vector<std::pair<int, int>> irr;
+      restrict_descs(S.res[n - 1], S.vf_res[n], vrr, &irr);
       S.vc_e[n] = make_view(S.e[n - 1], coarsened_footprints(S.e[n], 1, -1, 1), level_owner(S.e[n]), 0, 1, VT_COARSEN_1);
       S.vf_e[n] = make_view(S.e[n], refined_footprints(S.e[n - 1], -1, 2), level_owner(S.e[n - 1]), 0, 1, VT_REFINE_G1);
       S.vf_t[n] = make_view(S.t[n], refined_footprints(S.res[n - 1], -1, 0), level_owner(S.res[n - 1]), 0, 1, VT_REFINE);
-      { std::vector<CfB> v; cf_descs(S.e[n], S.vc_e[n], S.bct, S.bcc, v); S.cf_e[n].build(v, 0, st); }
-      { std::vector<RestrictB> v; restrict_descs(S.res[n - 1], S.vf_t[n], v); S.rres_t[n].build(v, 0, st); }
+      // the same boxes carry phi / e and res / t / phi: the lists above with the other fields' pointers (the views of one pair of levels have the same entries;
+      // an entry a wider footprint adds touches no valid cell of a coarse box)
+      { std::vector<CfB> v = vcf; for (size_t q = 0; q < v.size(); q++) { REQUIRE(S.vc_e[n].have[icf[q].second], "composite solve: views of one level pair differ"); v[q].pf = S.e[n]->fabs[icf[q].first]; v[q].pc = S.vc_e[n].fv[icf[q].second]; } S.cf_e[n].build(v, 0, st); }
+      S.cf[n].build(vcf, 0, st);
+      { std::vector<RestrictB> v = vrr; for (size_t q = 0; q < v.size(); q++) { REQUIRE(S.vf_t[n].have[irr[q].first], "composite solve: views of one level pair differ"); v[q].fine = S.vf_t[n].fv[irr[q].first]; } S.rres_t[n].build(v, 0, st); }
+      { std::vector<RestrictB> v = vrr; for (size_t q = 0; q < v.size(); q++) { REQUIRE(S.vf_phi[n].have[irr[q].first], "composite solve: views of one level pair differ"); v[q].crse = S.phi[n - 1]->fabs[irr[q].second]; v[q].fine = S.vf_phi[n].fv[irr[q].first]; } S.rphi[n].build(v, 0, st); }
+      S.rres[n].build(vrr, 0, st);
       { std::vector<SetboxB> v;                            // every ghost cell of e[n] := 0 (six slabs per box)
         for (int b = 0; b < S.e[n]->nfabs(); b++) for (int d = 0; d < 3; d++) for (int sd = 0; sd < 2; sd++) {
           SetboxB q; q.a = S.e[n]->fabs[b]; q.v = 0.0;
@@ -689,7 +705,18 @@ static void mlcc_build_sets(MLCC &S) {
     S.resid[n].build(vr, 0, st);          // (contiguous chunks of planes per workgroup: the k-1 / k+1 planes of phi stay in cache; its norm's atomics are rare, vdn_dev.h)
     S.absmax[n].build(va, 16, st); S.gsrb[n].build(vg, 0, st); S.add[n].build(vadd, 0, st);
     // flux matching on the cells of level n-1 next to the boxes of level n
-    const BoxBins cbins(n >= 1 ? S.phi[n - 1]->vbox : std::vector<vdn_box>());
+    std::vector<std::vector<int>> cand;                     // per fine view entry: the coarse boxes around it (one query for its six faces)
+    if (n >= 1) {
+      const BoxBins cbins(S.phi[n - 1]->vbox);
+      const SrcView &Fv = S.vf_phi[n];
+      cand.resize(Fv.nboxes());
+      for (int f = 0; f < Fv.nboxes(); f++) {
+        if (!Fv.have[f]) continue;
+        int glo[3], ghi[3];
+        for (int t = 0; t < 3; t++) { glo[t] = hfdiv2(Fv.vbox[f].lo[t]); ghi[t] = hfdiv2(Fv.vbox[f].hi[t] + 1); }
+        cand[f] = cbins.near(glo, ghi, 2);
+      }
+    }
     if (n >= 1)
       for (int d = 0; d < 3; d++) for (int s = 0; s < 2; s++) {
         std::vector<RefluxB> v, ve;
@@ -701,7 +728,7 @@ static void mlcc_build_sets(MLCC &S) {
           int clo[3], chi[3];
           for (int t = 0; t < 3; t++) { clo[t] = hfdiv2(fb.lo[t]); chi[t] = hfdiv2(fb.hi[t]); }
           clo[d] = chi[d] = hfdiv2(s ? fb.hi[d] + 1 : fb.lo[d]);
-          for (int c : cbins.near(clo, chi, 2)) {
+          for (int c : cand[f]) {
             int blo[3], bhi[3]; RefluxB q;
             for (int t = 0; t < 3; t++) { blo[t] = S.phi[n - 1]->vbox[c].lo[t]; bhi[t] = S.phi[n - 1]->vbox[c].hi[t]; }
             if (s == 0) { blo[d] += 1; bhi[d] += 1; }          // the coarse cell that gets the correction must be a valid cell of box c

@@ -654,3 +654,12 @@ extern "C" int vdn_plan_describe(const vdn_box *pd, const int *pmask, int nboxes
   if (nlocal_descs) *nlocal_descs = nloc;
   VDN_CATCH
 }
+extern "C" int vdn_box_candidates(int nboxes, const vdn_box *boxes, const int *qlo, const int *qhi, int margin, int *out, int maxout, int *ncand) {
+  VDN_TRY
+  const std::vector<vdn_box> b(boxes, boxes + nboxes);
+  const BoxBins bins(b);
+  const std::vector<int> &c = bins.near(qlo, qhi, margin);
+  for (size_t i = 0; i < c.size() && (int)i < maxout; i++) out[i] = c[i];
+  *ncand = (int)c.size();
+  VDN_CATCH
+}

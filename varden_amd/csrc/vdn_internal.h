@@ -207,7 +207,7 @@ void   comm_allgather_dev(const double *send, double *recv, size_t count);
 #include <algorithm>
 struct BoxBins {
   int lo[3] = {0, 0, 0}, w[3] = {1, 1, 1}, n[3] = {0, 0, 0};
-  std::vector<std::vector<int>> bins; mutable std::vector<int> out;
+  std::vector<int> first, items; mutable std::vector<int> out;        // bin b holds items[first[b] .. first[b + 1])
   explicit BoxBins(const std::vector<vdn_box> &b, const std::vector<char> *have = nullptr) {
     int hi[3] = {0, 0, 0}; bool any = false;
     for (size_t i = 0; i < b.size(); i++) {
@@ -221,18 +221,26 @@ struct BoxBins {
     }
     if (!any) return;
     for (int d = 0; d < 3; d++) n[d] = (hi[d] - lo[d]) / w[d] + 1;
-    bins.resize((size_t)n[0] * n[1] * n[2]);
-    for (size_t i = 0; i < b.size(); i++) {
-      if (have && !(*have)[i]) continue;
-      int a[3], z[3];
-      for (int d = 0; d < 3; d++) { a[d] = (b[i].lo[d] - lo[d]) / w[d]; z[d] = (b[i].hi[d] - lo[d]) / w[d]; }
-      for (int k = a[2]; k <= z[2]; k++) for (int j = a[1]; j <= z[1]; j++) for (int q = a[0]; q <= z[0]; q++) bins[((size_t)k * n[1] + j) * n[0] + q].push_back((int)i);
+    const size_t nb = (size_t)n[0] * n[1] * n[2];
+    first.assign(nb + 1, 0);
+    for (int pass = 0; pass < 2; pass++) {                 // count, prefix sums, fill
+      for (size_t i = 0; i < b.size(); i++) {
+        if (have && !(*have)[i]) continue;
+        int a[3], z[3];
+        for (int d = 0; d < 3; d++) { a[d] = (b[i].lo[d] - lo[d]) / w[d]; z[d] = (b[i].hi[d] - lo[d]) / w[d]; }
+        for (int k = a[2]; k <= z[2]; k++) for (int j = a[1]; j <= z[1]; j++) for (int q = a[0]; q <= z[0]; q++) {
+          const size_t bin = ((size_t)k * n[1] + j) * n[0] + q;
+          if (pass == 0) first[bin + 1]++; else items[first[bin]++] = (int)i;
+        }
+      }
+      if (pass == 0) { for (size_t q = 0; q < nb; q++) first[q + 1] += first[q]; items.resize(first[nb]); }
+      else { for (size_t q = nb; q > 0; q--) first[q] = first[q - 1]; first[0] = 0; }      // (the fill advanced every start to its end)
     }
   }
   // boxes that may intersect [qlo - margin, qhi + margin] (a superset of those that do), ascending
   const std::vector<int> &near(const int qlo[3], const int qhi[3], int margin) const {
     out.clear();
-    if (bins.empty()) return out;
+    if (first.empty()) return out;
     int a[3], z[3];
     for (int d = 0; d < 3; d++) {
       const int l = qlo[d] - margin - lo[d], h = qhi[d] + margin - lo[d];
@@ -240,8 +248,8 @@ struct BoxBins {
       a[d] = l < 0 ? 0 : l / w[d]; z[d] = std::min(h / w[d], n[d] - 1);
     }
     for (int k = a[2]; k <= z[2]; k++) for (int j = a[1]; j <= z[1]; j++) for (int q = a[0]; q <= z[0]; q++) {
-      const std::vector<int> &bn = bins[((size_t)k * n[1] + j) * n[0] + q];
-      out.insert(out.end(), bn.begin(), bn.end());
+      const size_t bin = ((size_t)k * n[1] + j) * n[0] + q;
+      out.insert(out.end(), items.begin() + first[bin], items.begin() + first[bin + 1]);
     }
     std::sort(out.begin(), out.end()); out.erase(std::unique(out.begin(), out.end()), out.end());
     return out;
