@@ -891,20 +891,49 @@ DEVI double bc_v(int m, int side, double in, double ghost) {
   if (m == 1) v = ghost;
   return v;
 }
+// NAR (box-batched launches, boxes narrower than a tile): a wave carries 64 / W node... cell rows of W lanes each (lanes 1 .. W-2 of a segment own cells, the
+// two outer ones feed their neighbours, exactly as lanes 0 and 63 of the full-width tile), a workgroup TNY * (64 / W) rows of which all but the first and
+// last own cells; W is the descriptor's.  The shared arrays keep their size and are addressed flat (row * W + lane); lanes left over after a wave's last
+// segment own nothing, load clamped addresses and park their stores in the slots the rows do not use.  A level of 997 boxes of which 670 are 8 cells wide
+// marches 0.52 x the wave-planes of the full-width tiling (tools/box_histogram.py).
+struct SegGeo { int W, ROWS, lane, row, rowm, rowp, o0, om, op; bool live; };
+template <bool NAR> DEVI SegGeo seg_geo(int W_) {
+  SegGeo G;
+  if (!NAR) {
+    G.W = 64; G.ROWS = TNY; G.lane = threadIdx.x; G.row = threadIdx.y; G.live = true;
+    G.rowm = G.row >= 1 ? G.row - 1 : 0; G.rowp = G.row + 1 < TNY ? G.row + 1 : TNY - 1;
+    G.o0 = G.om = G.op = 0;
+    return G;
+  }
+  const int tid = threadIdx.x, rpw = 64 / W_, seg = tid / W_;
+  G.W = W_; G.ROWS = TNY * rpw; G.live = seg < rpw; G.lane = tid - seg * W_;
+  G.row = G.live ? (int)threadIdx.y * rpw + seg : G.ROWS - 1;
+  G.rowm = G.row >= 1 ? G.row - 1 : 0; G.rowp = G.row + 1 < G.ROWS ? G.row + 1 : G.ROWS - 1;
+  G.o0 = G.live ? G.row * W_ + G.lane : G.ROWS * W_ + (int)threadIdx.y * (64 - rpw * W_) + (tid - rpw * W_);
+  G.om = G.rowm * W_ + G.lane; G.op = G.rowp * W_ + G.lane;
+  return G;
+}
+// this thread's slot / the slot of the row below / above in a [TNY][64] shared array
+#define LS(A) (*(NAR ? &(&A[0][0])[G.o0] : &A[row][lane]))
+#define LM(A) (NAR ? (&A[0][0])[G.om] : A[rowm][lane])
+#define LP(A) (NAR ? (&A[0][0])[G.op] : A[rowp][lane])
 // UPD: the conservative / convective update of the component (update.f90:220-269) rides along.  A cell's update needs the edge states on its
 // six faces: the lower three are this thread's stage-D outputs, the upper x one the next lane's (DPP, same iteration), the upper y one the
 // next row's (LDS, read one iteration later, like SI and SC), the upper z one this thread's output for the next plane.  So the x-term of
 // plane k is formed with stage D of plane k, the y- and z-terms one iteration later, and seven doubles travel in between; a k-chunk runs
 // one plane further (the lower z-face of its successor's first plane).  sedge and flux are not stored.  Same expressions as update_cell.
-template <bool BC, bool INL, bool UPD, bool PW2> __device__ __forceinline__ void mk_F_m_body(const FArgs &F, const Range3 &r, int klen, const double *umax, const int BX, const int BY, const int BZ) {
+template <bool BC, bool INL, bool UPD, bool PW2, bool NAR = false> __device__ __forceinline__ void mk_F_m_body(const FArgs &F, const Range3 &r, int klen, const double *umax, const int BX, const int BY, const int BZ, const int segw = 64) {
+  static_assert(!(NAR && UPD), "the update rides along in full-width tiles only");
   __shared__ double lB[2][TNY][64], lSI[2][TNY][64], lC[2][2][TNY][64], lSC[2][2][TNY][64], lD[2][TNY][64], lE[UPD ? 2 : 1][UPD ? TNY : 1][64];
-  const int lane = threadIdx.x, row = threadIdx.y;
-  const int i = r.lo[0] - 1 + BX * FNX + lane, j = r.lo[1] - 1 + BY * FNY + row;
-  const bool own_ij = lane >= 1 && lane <= FNX && row >= 1 && row <= FNY && i <= r.hi[0] && j <= r.hi[1];
+  const SegGeo G = seg_geo<NAR>(segw);
+  const int lane = G.lane, row = G.row;
+  const int ownx = NAR ? G.W - 2 : FNX, owny = NAR ? G.ROWS - 2 : FNY;
+  const int i = r.lo[0] - 1 + BX * ownx + lane, j = r.lo[1] - 1 + BY * owny + row;
+  const bool own_ij = G.live && lane >= 1 && lane <= ownx && row >= 1 && row <= owny && i <= r.hi[0] && j <= r.hi[1];
   const int ic = min(max(i, F.lo[0] - 1), F.hi[0] + 1), jc = min(max(j, F.lo[1] - 1), F.hi[1] + 1);
   const bool ing_ij = i == ic && j == jc;                            // a cell of the grown box
   const bool vx = i >= F.lo[0] && i <= F.hi[0], vy = j >= F.lo[1] && j <= F.hi[1];
-  const int rowm = row >= 1 ? row - 1 : 0, rowp = row + 1 < TNY ? row + 1 : TNY - 1;
+  const int rowm = G.rowm, rowp = G.rowp;
   const int k0 = r.lo[2] + BZ * klen, k1 = min(k0 + klen - 1, r.hi[2]);
   const int KB = F.lo[2] - 1, KT = F.hi[2] + 1;                       // the planes loads are clamped to
   const double eps = eps_from(umax);
@@ -1001,9 +1030,9 @@ template <bool BC, bool INL, bool UPD, bool PW2> __device__ __forceinline__ void
       const int k = kk, kc = min(max(k, KB), KT);
       const int zw = Z_WORD(k, kc);                                   // uniform
       const double (&Lb)[3] = P0.Lb, (&Rb)[3] = P0.Rb;
-      lB[buf][row][lane] = Lb[1];
+      LS(lB[buf]) = Lb[1];
       __syncthreads();
-      const double Lx = shfl_prev(Lb[0]), Ly = lB[buf][rowm][lane], Lzc = LzB;
+      const double Lx = shfl_prev(Lb[0]), Ly = LM(lB[buf]), Lzc = LzB;
       LzB = Lb[2];
       si0[0] = upwind_mac(Lx, Rb[0], P0.m_lo[0], eps);
       si0[1] = upwind_mac(Ly, Rb[1], P0.m_lo[1], eps);
@@ -1013,7 +1042,7 @@ template <bool BC, bool INL, bool UPD, bool PW2> __device__ __forceinline__ void
         if (w & 0xF00F) { FACE_BC(si0[0], w, 0, Lx, Rb[0], P0.s0, S_AT(kc, -8L)) FACE_BC(si0[1], w, 12, Ly, Rb[1], P0.s0, S_AT(kc, -F.s_row)) }
         if ((zw & 15) && ing_ij) { FACE_BC(si0[2], zw, 0, Lzc, Rb[2], P0.s0, P1.s0) }
       }
-      lSI[buf][row][lane] = si0[1];                                   // read by the row below in the next iteration
+      LS(lSI[buf]) = si0[1];                                   // read by the row below in the next iteration
     }
     // ---------------- stage C, plane kk-1 ----------------
     double qc[6] = { 0.0, 0.0, 0.0, 0.0, 0.0, 0.0 };
@@ -1027,7 +1056,7 @@ template <bool BC, bool INL, bool UPD, bool PW2> __device__ __forceinline__ void
         if (wc & 0x770770) { PREMOD(Lb[0], Rb[0], wc, 4, 8, S_AT(kc, -8L), S_AT(kc, 8L)) PREMOD(Lb[1], Rb[1], wc, 16, 20, S_AT(kc, -F.s_row), S_AT(kc, F.s_row)) }
         if (zw & 0x770) { PREMOD(Lb[2], Rb[2], zw, 4, 8, S_AT(kc - 1, 0L), S_AT(kc + 1, 0L)) }
       }
-      const double su[3] = { lane_next(si1[0]), lSI[buf ^ 1][rowp][lane], si0[2] };       // SI on the upper faces
+      const double su[3] = { lane_next(si1[0]), LP(lSI[buf ^ 1]), si0[2] };       // SI on the upper faces
       double t[3];
       t[0] = tvq(cons, F.tC[0], su[0], si1[0], P1.m_up[0], P1.m_lo[0]);
       t[1] = tvq(cons, F.tC[1], su[1], si1[1], P1.m_up[1], P1.m_lo[1]);
@@ -1036,11 +1065,11 @@ template <bool BC, bool INL, bool UPD, bool PW2> __device__ __forceinline__ void
       VL[0][0] = Lb[0] - t[1]; VR[0][0] = Rb[0] - t[1]; VL[0][1] = Lb[0] - t[2]; VR[0][1] = Rb[0] - t[2];
       VL[1][0] = Lb[1] - t[0]; VR[1][0] = Rb[1] - t[0]; VL[1][1] = Lb[1] - t[2]; VR[1][1] = Rb[1] - t[2];
       VL[2][0] = Lb[2] - t[0]; VR[2][0] = Rb[2] - t[0]; VL[2][1] = Lb[2] - t[1]; VR[2][1] = Rb[2] - t[1];
-      lC[buf][0][row][lane] = VL[1][0]; lC[buf][1][row][lane] = VL[1][1];
+      LS(lC[buf][0]) = VL[1][0]; LS(lC[buf][1]) = VL[1][1];
       __syncthreads();
       double Lx[2], Ly[2], Lzc[2];
       Lx[0] = shfl_prev(VL[0][0]); Lx[1] = shfl_prev(VL[0][1]);
-      Ly[0] = lC[buf][0][rowm][lane]; Ly[1] = lC[buf][1][rowm][lane];
+      Ly[0] = LM(lC[buf][0]); Ly[1] = LM(lC[buf][1]);
       Lzc[0] = LzC[0]; Lzc[1] = LzC[1];
       LzC[0] = VL[2][0]; LzC[1] = VL[2][1];
       qc[0] = upwind_mac(Lx[0], VR[0][0], P1.m_lo[0], eps); qc[1] = upwind_mac(Lx[1], VR[0][1], P1.m_lo[0], eps);
@@ -1053,7 +1082,7 @@ template <bool BC, bool INL, bool UPD, bool PW2> __device__ __forceinline__ void
         }
         if ((zw & 15) && ing_ij) { FACE_BC(qc[4], zw, 0, Lzc[0], VR[2][0], P1.s0, P2.s0) FACE_BC(qc[5], zw, 0, Lzc[1], VR[2][1], P1.s0, P2.s0) }
       }
-      lSC[buf][0][row][lane] = qc[2]; lSC[buf][1][row][lane] = qc[3];            // read by the row below in the next iteration
+      LS(lSC[buf][0]) = qc[2]; LS(lSC[buf][1]) = qc[3];            // read by the row below in the next iteration
     }
     // ---------------- stage D, plane kk-2 ----------------
     if (kk - 2 >= k0 - 1) {
@@ -1071,7 +1100,7 @@ template <bool BC, bool INL, bool UPD, bool PW2> __device__ __forceinline__ void
         if (zw & 0x770) { PREMOD(Lb[2], Rb[2], zw, 4, 8, S_AT(kc - 1, 0L), S_AT(kc + 1, 0L)) }
       }
       // SC on the upper faces: x-faces from the next lane, y-faces from the next row (written in the previous iteration), z-faces from stage C above
-      const double q1[6] = { lane_next(qp[0]), lane_next(qp[1]), lSC[buf ^ 1][0][rowp][lane], lSC[buf ^ 1][1][rowp][lane], qc[4], qc[5] };
+      const double q1[6] = { lane_next(qp[0]), lane_next(qp[1]), LP(lSC[buf ^ 1][0]), LP(lSC[buf ^ 1][1]), qc[4], qc[5] };
       const double (&q0)[6] = qp;
       double VL[3], VR[3];
       const double a[3] = { F.aD[0] * s0 * (m_up[0] - m_lo[0]), F.aD[1] * s0 * (m_up[1] - m_lo[1]), F.aD[2] * s0 * (m_up[2] - m_lo[2]) };
@@ -1087,10 +1116,10 @@ template <bool BC, bool INL, bool UPD, bool PW2> __device__ __forceinline__ void
       CHAIN(1, 0, 2, 1, 4)
       CHAIN(2, 0, 1, 0, 2)
       #undef CHAIN
-      lD[buf][row][lane] = VL[1];
+      LS(lD[buf]) = VL[1];
       __syncthreads();
       double L[3];
-      L[0] = shfl_prev(VL[0]); L[1] = lD[buf][rowm][lane]; L[2] = LzD; LzD = VL[2];
+      L[0] = shfl_prev(VL[0]); L[1] = LM(lD[buf]); L[2] = LzD; LzD = VL[2];
       if (k >= k0) {
         double e[3] = { 0.0, 0.0, 0.0 };
         if (UPD || own_ij) {
@@ -1111,7 +1140,7 @@ template <bool BC, bool INL, bool UPD, bool PW2> __device__ __forceinline__ void
           // what update_3d differences: fluxes of a conservative component (flux = sedge * umac, mkflux.f90:1969), edge states otherwise
           const double ex = cons ? e[0] * m_lo[0] : e[0], ey = cons ? e[1] * m_lo[1] : e[1], ez = cons ? e[2] * m_lo[2] : e[2];
           if (k - 1 >= k0) {                                           // finish plane k-1: its upper y face from the row above, its upper z face = ez
-            const double eyu = lE[buf ^ 1][rowp][lane];
+            const double eyu = LP(lE[buf ^ 1]);
             const double ty = cons ? DIVDX(eyu - c_e1, 1) : DIVDX(c_vbar * (eyu - c_e1), 1);
             const double tz = cons ? DIVDX(ez - c_e2, 2) : DIVDX(c_wbar * (ez - c_e2), 2);
             const double ug = c_tx + ty + tz;
@@ -1128,7 +1157,7 @@ template <bool BC, bool INL, bool UPD, bool PW2> __device__ __forceinline__ void
             const long po = (long)(kc - KB) * F.sp[5] + o_f;
             c_fu = ldd(F.pfu[0] + po, 0u) + (F.lapu0 - ldd(F.pfu[1] + po, 0u)) / ldd(F.pfu[2] + po, 0u);
           }
-          lE[buf][row][lane] = ey;                                     // read by the row below in the next iteration
+          LS(lE[buf]) = ey;                                     // read by the row below in the next iteration
         }
       }
     }
@@ -1249,10 +1278,18 @@ DEVI int locate_box(const int *start, int nbox, int bid) {
   const int ib_ = locate_box(start, nbox, (int)blockIdx.x);                             \
   const D &q = as_constant(descs + ib_);                                                \
   const int l_ = (int)blockIdx.x - as_constant(start + ib_);                            \
-  const int BX = l_ % q.G[0], BY = (l_ / q.G[0]) % q.G[1], BZ = l_ / (q.G[0] * q.G[1]);
+  const int gy_ = q.G[1] > 0 ? q.G[1] : 1;                                               \
+  const int BX = l_ % q.G[0], BY = (l_ / q.G[0]) % gy_, BZ = l_ / (q.G[0] * gy_);
 template <class D> __global__ void __launch_bounds__(256) kk_slopes_b(const D *descs, const int *start, int nbox, int dirmask) {
   BATCH_LOCATE(D, gs)
-  const int i = q.rg.lo[0] + BX * 64 + (int)threadIdx.x, j = q.rg.lo[1] + BY * 4 + (int)threadIdx.y, k = q.rg.lo[2] + BZ;
+  // gs[1] == 0: the plane flattened over the workgroup's 256 threads (gs[0] workgroups per plane) -- a 14 x 14 plane of a grown 8^3 box is one
+  // workgroup at 77 % instead of four 64 x 4 tiles at 19 %
+  int i, j, k;
+  if (q.gs[1] == 0) {
+    const int nx = q.rg.hi[0] - q.rg.lo[0] + 1, l_2 = (int)blockIdx.x - as_constant(start + ib_);
+    const int t = (l_2 % q.gs[0]) * 256 + (int)threadIdx.y * 64 + (int)threadIdx.x;
+    i = q.rg.lo[0] + t % nx; j = q.rg.lo[1] + t / nx; k = q.rg.lo[2] + l_2 / q.gs[0];
+  } else { i = q.rg.lo[0] + BX * 64 + (int)threadIdx.x; j = q.rg.lo[1] + BY * 4 + (int)threadIdx.y; k = q.rg.lo[2] + BZ; }
   if (i > q.rg.hi[0] || j > q.rg.hi[1] || k > q.rg.hi[2]) return;
   slopes_cell(q.s, q.sl0, q.sl1, q.sl2, q.A, dirmask, i, j, k);
 }
@@ -1290,12 +1327,13 @@ template <int NC> __global__ void __launch_bounds__(64 * TNY) kk_mk_D_mb(const M
 }
 // host side of a batch: grids of the four launch shapes per box, their prefix sums, and the upload
 // the fused march for every box of a level in one launch (a descriptor per box and component; see kk_batched for the scheme)
-struct FBatchD { FArgs F; Range3 r; int klen; const double *umax; int g[3]; };
-template <bool INL, bool PW2 = false> __global__ void __launch_bounds__(64 * TNY) kk_mk_F_mb(const FBatchD *descs, const int *start, int nbox) {
+struct FBatchD { FArgs F; Range3 r; int klen; const double *umax; int g[3], sw; };      // sw: lanes of a row segment (NAR launches; seg_geo)
+template <bool INL, bool PW2 = false, bool NAR = false> __global__ void __launch_bounds__(64 * TNY) kk_mk_F_mb(const FBatchD *descs, const int *start, int nbox) {
   BATCH_LOCATE(FBatchD, g)
   bool touch = false;                                // see kk_mk_F_m
   {
-    const int i0 = q.r.lo[0] - 1 + BX * FNX, i1 = i0 + 63, j0 = q.r.lo[1] - 1 + BY * FNY, j1 = j0 + TNY - 1;
+    const int tw = NAR ? q.sw : 64, th = NAR ? TNY * (64 / q.sw) : TNY;
+    const int i0 = q.r.lo[0] - 1 + BX * (tw - 2), i1 = i0 + tw - 1, j0 = q.r.lo[1] - 1 + BY * (th - 2), j1 = j0 + th - 1;
     const int k0 = q.r.lo[2] + BZ * q.klen - 2, k1 = min(q.r.lo[2] + BZ * q.klen + q.klen - 1, q.r.hi[2]) + 2;
     const int a0[3] = { i0, j0, k0 }, a1[3] = { i1, j1, k1 };
     #pragma unroll
@@ -1304,15 +1342,25 @@ template <bool INL, bool PW2 = false> __global__ void __launch_bounds__(64 * TNY
       if (bc_mode(q.F.phys[d][1], q.F.is_vel != 0, q.F.c == d) && a1[d] >= q.F.hi[d] - 1) touch = true;
     }
   }
-  if (touch) mk_F_m_body<true, INL, false, PW2>(q.F, q.r, q.klen, q.umax, BX, BY, BZ);
-  else mk_F_m_body<false, false, false, PW2>(q.F, q.r, q.klen, q.umax, BX, BY, BZ);
+  if (touch) mk_F_m_body<true, INL, false, PW2, NAR>(q.F, q.r, q.klen, q.umax, BX, BY, BZ, q.sw);
+  else mk_F_m_body<false, false, false, PW2, NAR>(q.F, q.r, q.klen, q.umax, BX, BY, BZ, q.sw);
 }
 // k-chunks of a box in the batched launch: the boxes of a level fill the device together, so a box is cut only when it is tall
-static void fused_grid_small(const Range3 &r, int &klen, int g[3]) {
+// sw: 0 = full-width tiles (64 x TNY threads own 62 x 6 cells), else the width of the row segments that take the fewest workgroups (seg_geo: a
+// workgroup owns (sw - 2) x (TNY * (64 / sw) - 2) cells)
+static void fused_grid_small(const Range3 &r, int &klen, int g[3], int &sw) {
   const int nx = r.hi[0] - r.lo[0] + 1, ny = r.hi[1] - r.lo[1] + 1, nz = r.hi[2] - r.lo[2] + 1;
   const int chunks = std::max(1, (nz + 47) / 48);
   klen = (nz + chunks - 1) / chunks;
   g[0] = (nx + FNX - 1) / FNX; g[1] = (ny + FNY - 1) / FNY; g[2] = (nz + klen - 1) / klen;
+  sw = 0;
+  static const bool narrow_on = !(vdn_env("VDN_GOD_SEGW") && atoi(vdn_env("VDN_GOD_SEGW")) == 0);
+  if (!narrow_on) return;
+  int best = g[0] * g[1];
+  for (int w = 6; w <= 32; w++) {
+    const int ox = w - 2, oy = TNY * (64 / w) - 2, c = ((nx + ox - 1) / ox) * ((ny + oy - 1) / oy);
+    if (c < best) { best = c; sw = w; g[0] = (nx + ox - 1) / ox; g[1] = (ny + oy - 1) / oy; }
+  }
 }
 
 template <class D> struct GodBatch {
@@ -1326,6 +1374,14 @@ template <class D> struct GodBatch {
       const dim3 gg = march_grid(q.rg, q.klg), gf = march_grid(q.rf, q.klf);
       const dim3 *g[4] = { &gs, &gm, &gg, &gf }; int *o[4] = { q.gs, q.gm, q.gg, q.gf };
       for (int t = 0; t < 4; t++) { o[t][0] = g[t]->x; o[t][1] = g[t]->y; o[t][2] = g[t]->z; start[t * nb + b] = tot[t]; tot[t] += (int)(g[t]->x * g[t]->y * g[t]->z); }
+      // the slope launch: the plane flattened over the workgroup when that takes fewer workgroups (kk_slopes_b: gs[1] = 0)
+      static const bool flat_on = !(vdn_env("VDN_BATCH_FLAT") && atoi(vdn_env("VDN_BATCH_FLAT")) == 0);
+      const int pnx = q.rg.hi[0] - q.rg.lo[0] + 1, pny = q.rg.hi[1] - q.rg.lo[1] + 1;
+      if (flat_on && pnx > 0 && pny > 0 && (pnx * pny + 255) / 256 < (int)(gs.x * gs.y)) {
+        const int gfl = (pnx * pny + 255) / 256;
+        tot[0] += (gfl - (int)(gs.x * gs.y)) * (int)gs.z;
+        q.gs[0] = gfl; q.gs[1] = 0;
+      }
     }
     D *dd = (D *)desc_scratch(sizeof(D) * nb); int *ds = (int *)desc_scratch(sizeof(int) * 4 * nb);
     upload_staged(dd, d.data(), sizeof(D) * nb); upload_staged(ds, start.data(), sizeof(int) * 4 * nb);
@@ -1420,16 +1476,29 @@ bool k_mkflux(const vdn_multifab *s, vdn_multifab **sedge, vdn_multifab **flux, 
           FBatchD &f = fd[(size_t)c0 * nb + ib];
           ok = fused_args(f.F, q.A, c0, q.s, sl, q.um, q.vm, q.wm, q.force, q.macrhs, q.sex, q.sey, q.sez, q.flx, q.fly, q.flz);
           f.r = q.rf; f.umax = q.umax;
-          fused_grid_small(f.r, f.klen, f.g);
+          fused_grid_small(f.r, f.klen, f.g, f.sw);
         }
       }
       if (ok) {
-        for (size_t t = 0; t < fd.size(); t++) { fstart[t] = tot; tot += fd[t].g[0] * fd[t].g[1] * fd[t].g[2]; }
+        // two launches: the boxes in full-width tiles, the narrow ones in row segments (seg_geo)
+        std::stable_partition(fd.begin(), fd.end(), [](const FBatchD &f) { return f.sw == 0; });
+        const size_t nwide = std::count_if(fd.begin(), fd.end(), [](const FBatchD &f) { return f.sw == 0; });
+        int totn = 0;
+        for (size_t t = 0; t < fd.size(); t++) { int &T = t < nwide ? tot : totn; fstart[t] = T; T += fd[t].g[0] * fd[t].g[1] * fd[t].g[2]; }
         FBatchD *dd = (FBatchD *)desc_scratch(sizeof(FBatchD) * fd.size()); int *ds = (int *)desc_scratch(sizeof(int) * fstart.size());
         upload_staged(dd, fd.data(), sizeof(FBatchD) * fd.size()); upload_staged(ds, fstart.data(), sizeof(int) * fstart.size());
-        if (inflow) hipLaunchKernelGGL(kk_mk_F_mb<true>, dim3(tot), blk, 0, st, dd, ds, (int)fd.size());
-        else if (fd[0].F.p2) hipLaunchKernelGGL((kk_mk_F_mb<false, true>), dim3(tot), blk, 0, st, dd, ds, (int)fd.size());
-        else hipLaunchKernelGGL(kk_mk_F_mb<false>, dim3(tot), blk, 0, st, dd, ds, (int)fd.size());
+        const bool p2 = fd[0].F.p2 != 0;
+        if (nwide) {
+          if (inflow) hipLaunchKernelGGL(kk_mk_F_mb<true>, dim3(tot), blk, 0, st, dd, ds, (int)nwide);
+          else if (p2) hipLaunchKernelGGL((kk_mk_F_mb<false, true>), dim3(tot), blk, 0, st, dd, ds, (int)nwide);
+          else hipLaunchKernelGGL(kk_mk_F_mb<false>, dim3(tot), blk, 0, st, dd, ds, (int)nwide);
+        }
+        if (nwide < fd.size()) {
+          const int nn = (int)(fd.size() - nwide);
+          if (inflow) hipLaunchKernelGGL((kk_mk_F_mb<true, false, true>), dim3(totn), blk, 0, st, dd + nwide, ds + nwide, nn);
+          else if (p2) hipLaunchKernelGGL((kk_mk_F_mb<false, true, true>), dim3(totn), blk, 0, st, dd + nwide, ds + nwide, nn);
+          else hipLaunchKernelGGL((kk_mk_F_mb<false, false, true>), dim3(totn), blk, 0, st, dd + nwide, ds + nwide, nn);
+        }
         arena_release(mark);
         return false;
       }
@@ -2022,15 +2091,17 @@ DEVI double vpf_riemann(double L, double R, double eps) {            // the stat
   const double v = (uavg > 0.0) ? L : R;
   return test ? 0.0 : v;
 }
-template <bool BC, bool INL, bool PW2> __device__ __forceinline__ void vp_F_m_body(const VArgs &F, const Range3 &r, int klen, const double *umax, const int BX, const int BY, const int BZ) {
+template <bool BC, bool INL, bool PW2, bool NAR = false> __device__ __forceinline__ void vp_F_m_body(const VArgs &F, const Range3 &r, int klen, const double *umax, const int BX, const int BY, const int BZ, const int segw = 64) {
   __shared__ double lB[3][TNY][64], lUI[3][TNY][64], lC[2][TNY][64], lXC[2][TNY][64], lD[TNY][64];
-  const int lane = threadIdx.x, row = threadIdx.y;
-  const int i = r.lo[0] - 1 + BX * FNX + lane, j = r.lo[1] - 1 + BY * FNY + row;
-  const bool own_ij = lane >= 1 && lane <= FNX && row >= 1 && row <= FNY && i <= r.hi[0] && j <= r.hi[1];
+  const SegGeo G = seg_geo<NAR>(segw);
+  const int lane = G.lane, row = G.row;
+  const int ownx = NAR ? G.W - 2 : FNX, owny = NAR ? G.ROWS - 2 : FNY;
+  const int i = r.lo[0] - 1 + BX * ownx + lane, j = r.lo[1] - 1 + BY * owny + row;
+  const bool own_ij = G.live && lane >= 1 && lane <= ownx && row >= 1 && row <= owny && i <= r.hi[0] && j <= r.hi[1];
   const int ic = min(max(i, F.lo[0] - 1), F.hi[0] + 1), jc = min(max(j, F.lo[1] - 1), F.hi[1] + 1);
   const bool ing_ij = i == ic && j == jc;
   const bool vx = i >= F.lo[0] && i <= F.hi[0], vy = j >= F.lo[1] && j <= F.hi[1];
-  const int rowm = row >= 1 ? row - 1 : 0, rowp = row + 1 < TNY ? row + 1 : TNY - 1;
+  const int rowm = G.rowm, rowp = G.rowp;
   const int k0 = r.lo[2] + BZ * klen, k1 = min(k0 + klen - 1, r.hi[2]);
   const int KB = F.lo[2] - 1, KT = F.hi[2] + 1;
   const double eps = eps_from(umax);
@@ -2119,20 +2190,20 @@ template <bool BC, bool INL, bool PW2> __device__ __forceinline__ void vp_F_m_bo
     // values of the next row written in the previous iteration: read before this iteration overwrites them
     double uiy_up[3], xcy_up[2];
     #pragma unroll
-    for (int c = 0; c < 3; c++) uiy_up[c] = lUI[c][rowp][lane];
-    xcy_up[0] = lXC[0][rowp][lane]; xcy_up[1] = lXC[1][rowp][lane];
+    for (int c = 0; c < 3; c++) uiy_up[c] = LP(lUI[c]);
+    xcy_up[0] = LP(lXC[0]); xcy_up[1] = LP(lXC[1]);
     // ---------------- stage B, plane kk ----------------
     double ui0[3][3];
     {
       const int k = kk, kc = min(max(k, KB), KT);
       unsigned zf; ZF_WORD(k, kc, zf)
       #pragma unroll
-      for (int c = 0; c < 3; c++) lB[c][row][lane] = Lb[1][c];
+      for (int c = 0; c < 3; c++) LS(lB[c]) = Lb[1][c];
       __syncthreads();
       double Lx[3], Ly[3], Lzc[3], Rx[3], Ry[3], Rz[3];
       #pragma unroll
       for (int c = 0; c < 3; c++) {
-        Lx[c] = shfl_prev(Lb[0][c]); Ly[c] = lB[c][rowm][lane]; Lzc[c] = LzB[c]; LzB[c] = Lb[2][c];
+        Lx[c] = shfl_prev(Lb[0][c]); Ly[c] = LM(lB[c]); Lzc[c] = LzB[c]; LzB[c] = Lb[2][c];
         Rx[c] = Rb[0][c]; Ry[c] = Rb[1][c]; Rz[c] = Rb[2][c];
       }
       if (BC && k == kc) {
@@ -2151,7 +2222,7 @@ template <bool BC, bool INL, bool PW2> __device__ __forceinline__ void vp_F_m_bo
       }
       vpf_emit<0>(ui0[0], Lx, Rx, eps); vpf_emit<1>(ui0[1], Ly, Ry, eps); vpf_emit<2>(ui0[2], Lzc, Rz, eps);
       #pragma unroll
-      for (int c = 0; c < 3; c++) lUI[c][row][lane] = ui0[1][c];      // read by the row below at the top of the next iteration
+      for (int c = 0; c < 3; c++) LS(lUI[c]) = ui0[1][c];      // read by the row below at the top of the next iteration
     }
     // ---------------- stage C, plane kk-1 ----------------
     double xc1[6] = { 0.0, 0.0, 0.0, 0.0, 0.0, 0.0 }, sm1[3] = { 0.0, 0.0, 0.0 };
@@ -2195,11 +2266,11 @@ template <bool BC, bool INL, bool PW2> __device__ __forceinline__ void vp_F_m_bo
       VL[1][1] = Lc[1][2] - t[2][0]; VR[1][1] = Rc[1][2] - t[2][0];   // D=1 C=2 O=0
       VL[2][0] = Lc[2][0] - t[0][1]; VR[2][0] = Rc[2][0] - t[0][1];   // D=2 C=0 O=1
       VL[2][1] = Lc[2][1] - t[1][0]; VR[2][1] = Rc[2][1] - t[1][0];   // D=2 C=1 O=0
-      lC[0][row][lane] = VL[1][0]; lC[1][row][lane] = VL[1][1];
+      LS(lC[0]) = VL[1][0]; LS(lC[1]) = VL[1][1];
       __syncthreads();
       double L[3][2];
       L[0][0] = shfl_prev(VL[0][0]); L[0][1] = shfl_prev(VL[0][1]);
-      L[1][0] = lC[0][rowm][lane]; L[1][1] = lC[1][rowm][lane];
+      L[1][0] = LM(lC[0]); L[1][1] = LM(lC[1]);
       L[2][0] = LzC[0]; L[2][1] = LzC[1];
       LzC[0] = VL[2][0]; LzC[1] = VL[2][1];
       if (BC && k == kc) {
@@ -2216,7 +2287,7 @@ template <bool BC, bool INL, bool PW2> __device__ __forceinline__ void vp_F_m_bo
       xc1[2] = vp_up(ui1[0][0], L[0][0], VR[0][0], eps); xc1[4] = vp_up(ui1[0][0], L[0][1], VR[0][1], eps);
       xc1[0] = vp_up(ui1[1][1], L[1][0], VR[1][0], eps); xc1[5] = vp_up(ui1[1][1], L[1][1], VR[1][1], eps);
       xc1[1] = vp_up(ui1[2][2], L[2][0], VR[2][0], eps); xc1[3] = vp_up(ui1[2][2], L[2][1], VR[2][1], eps);
-      lXC[0][row][lane] = xc1[0]; lXC[1][row][lane] = xc1[5];           // the y-face fields: read by the row below at the top of the next iteration
+      LS(lXC[0]) = xc1[0]; LS(lXC[1]) = xc1[5];           // the y-face fields: read by the row below at the top of the next iteration
     } else {
       __syncthreads();                                              // keeps lB / lUI single-buffered while stage C is idle (start of a chunk)
     }
@@ -2262,9 +2333,9 @@ template <bool BC, bool INL, bool PW2> __device__ __forceinline__ void vp_F_m_bo
         if (!F.use_minion) { vl = vl + fb[2]; vr = vr + fb[2]; }
         VL[2] = vl; VR[2] = vr;
       }
-      lD[row][lane] = VL[1];
+      LS(lD) = VL[1];
       __syncthreads();
-      const double Lx = shfl_prev(VL[0]), Ly = lD[rowm][lane], Lzc = LzD;
+      const double Lx = shfl_prev(VL[0]), Ly = LM(lD), Lzc = LzD;
       LzD = VL[2];
       if (k >= k0) {
         if (own_ij) {
@@ -2331,10 +2402,10 @@ static bool vfused_args(VArgs &F, const GArgs &A, const FV &u, const FV sl[3], c
   return true;
 }
 
-struct VBatchD { VArgs F; Range3 r; int klen; const double *umax; int g[3]; };
-template <bool BC, bool INL, bool PW2 = false> __global__ void __launch_bounds__(64 * TNY) kk_vp_F_mb(const VBatchD *descs, const int *start, int nbox) {
+struct VBatchD { VArgs F; Range3 r; int klen; const double *umax; int g[3], sw; };      // sw: lanes of a row segment (NAR launches; seg_geo)
+template <bool BC, bool INL, bool PW2 = false, bool NAR = false> __global__ void __launch_bounds__(64 * TNY) kk_vp_F_mb(const VBatchD *descs, const int *start, int nbox) {
   BATCH_LOCATE(VBatchD, g)
-  vp_F_m_body<BC, INL, PW2>(q.F, q.r, q.klen, q.umax, BX, BY, BZ);
+  vp_F_m_body<BC, INL, PW2, NAR>(q.F, q.r, q.klen, q.umax, BX, BY, BZ, q.sw);
 }
 
 // ====================================================================================================
@@ -2610,17 +2681,25 @@ void k_velpred(const vdn_multifab *u, vdn_multifab **umac, const vdn_multifab *f
         for (int d = 0; d < 3; d++) for (int sd = 0; sd < 2; sd++) { inflow = inflow || q.A.phys[d][sd] == VDN_INLET; any = any || bc_mode_host(q.A.phys[d][sd]); }
         ok = vfused_args(fd[ib].F, q.A, q.s, sl, q.force, q.um, q.vm, q.wm);
         fd[ib].r = q.rf; fd[ib].umax = q.umax;
-        fused_grid_small(fd[ib].r, fd[ib].klen, fd[ib].g);
+        fused_grid_small(fd[ib].r, fd[ib].klen, fd[ib].g, fd[ib].sw);
       }
       if (ok) {
-        for (int t = 0; t < nb; t++) { fstart[t] = tot; tot += fd[t].g[0] * fd[t].g[1] * fd[t].g[2]; }
+        // two launches: the boxes in full-width tiles, the narrow ones in row segments (seg_geo)
+        std::stable_partition(fd.begin(), fd.end(), [](const VBatchD &f) { return f.sw == 0; });
+        const int nwide = (int)std::count_if(fd.begin(), fd.end(), [](const VBatchD &f) { return f.sw == 0; });
+        int totn = 0;
+        for (int t = 0; t < nb; t++) { int &T = t < nwide ? tot : totn; fstart[t] = T; T += fd[t].g[0] * fd[t].g[1] * fd[t].g[2]; }
         VBatchD *dd = (VBatchD *)desc_scratch(sizeof(VBatchD) * nb); int *ds = (int *)desc_scratch(sizeof(int) * nb);
         upload_staged(dd, fd.data(), sizeof(VBatchD) * nb); upload_staged(ds, fstart.data(), sizeof(int) * nb);
         const bool p2 = fd[0].F.p2 != 0;
-        if (!any) { if (p2) hipLaunchKernelGGL((kk_vp_F_mb<false, false, true>), dim3(tot), blk, 0, st, dd, ds, nb); else hipLaunchKernelGGL((kk_vp_F_mb<false, false>), dim3(tot), blk, 0, st, dd, ds, nb); }
-        else if (inflow) hipLaunchKernelGGL((kk_vp_F_mb<true, true>), dim3(tot), blk, 0, st, dd, ds, nb);
-        else if (p2) hipLaunchKernelGGL((kk_vp_F_mb<true, false, true>), dim3(tot), blk, 0, st, dd, ds, nb);
-        else hipLaunchKernelGGL((kk_vp_F_mb<true, false>), dim3(tot), blk, 0, st, dd, ds, nb);
+        #define VP_LAUNCH(NARROW, T, D0, S0, N)                                                                                                          \
+          if (!any) { if (p2) hipLaunchKernelGGL((kk_vp_F_mb<false, false, true, NARROW>), dim3(T), blk, 0, st, D0, S0, N); else hipLaunchKernelGGL((kk_vp_F_mb<false, false, false, NARROW>), dim3(T), blk, 0, st, D0, S0, N); } \
+          else if (inflow) hipLaunchKernelGGL((kk_vp_F_mb<true, true, false, NARROW>), dim3(T), blk, 0, st, D0, S0, N);                                      \
+          else if (p2) hipLaunchKernelGGL((kk_vp_F_mb<true, false, true, NARROW>), dim3(T), blk, 0, st, D0, S0, N);                                          \
+          else hipLaunchKernelGGL((kk_vp_F_mb<true, false, false, NARROW>), dim3(T), blk, 0, st, D0, S0, N);
+        if (nwide) { VP_LAUNCH(false, tot, dd, ds, nwide) }
+        if (nwide < nb) { VP_LAUNCH(true, totn, dd + nwide, ds + nwide, nb - nwide) }
+        #undef VP_LAUNCH
         arena_release(mark);
         return;
       }

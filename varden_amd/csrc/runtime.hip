@@ -133,6 +133,7 @@ static const EnvSwitch g_switches[] = {
   { "VDN_GODUNOV_BATCH", "1: the descriptor (box-batched) Godunov kernels also on a level of one box" },
   { "VDN_GOD_SLAB_BC", "0: (unfused marches) boundary rules inside the marches instead of the face-centred code on boundary slabs" },
   { "VDN_GODUNOV_PLAIN", "the face-centred one-thread-per-cell Godunov kernels of round 1 (the marching kernels' bit-for-bit reference)" },
+  { "VDN_GOD_SEGW", "0: the box-batched fused Godunov marches use full-width (64 x 8) tiles for every box" },
   { "VDN_GOD_XCD", "0: plain blockIdx order instead of the XCD-aware tile order of the Godunov marches" },
   { "VDN_KCHUNKS", "k-chunks of the unfused Godunov marches (default 12)" },
   { "VDN_GOD_P2", "0: the fused marches divide by dx also where every dx is a power of two (default there: scale by 1/dx, the same doubles)" },
