@@ -50,3 +50,38 @@ for n, lb in enumerate(levels):
         new += best; new8 += best8
     ideal = sum((hi[0] - lo[0] + 1) * (hi[1] - lo[1] + 1) * (hi[2] - lo[2] + 1) for lo, hi in lb) / 64.0
     print("level", n + 1, "wave-planes now %d; any segment width, 8 waves: %d (%.2f); and 2 / 4 / 8 waves: %d (%.2f); cells/64 = %d" % (cur, new8, new8 / cur, new, new / cur, ideal))
+# the box-batched cell kernels (vdn_dev.h batch_grid: 16 x 16 / 32 x 8 / 64 x 4 tiles by the width of the range, or the plane flattened over 256 threads when
+# that takes fewer workgroups; ppw planes per workgroup).  GsrbB: the range is half a row wide (one colour), one plane per workgroup
+def batch_wgs(nx, ny, nz, ppw=1):
+    lw = 6 if nx > 32 else (5 if nx > 16 else 4); w = 1 << lw; h = 256 >> lw
+    g = math.ceil(nx / w) * math.ceil(ny / h)
+    g = min(g, math.ceil(nx * ny / 256))
+    return g * math.ceil(nz / ppw)
+for n, lb in enumerate(levels):
+    gs = 0; rs = 0; ideal = 0; gs_by = collections.Counter()
+    for lo, hi in lb:
+        w = [hi[d] - lo[d] + 1 for d in range(3)]
+        c = batch_wgs((w[0] + 1) // 2, w[1], w[2]); gs += c; gs_by[w[0]] += c
+        rs += batch_wgs(w[0], w[1], w[2], 8) * 8
+        ideal += w[0] * w[1] * w[2]
+    print("level", n + 1, "colour pass: %d workgroups for %d needed (%.2f); residual: %d workgroup-planes for %d (%.2f)" % (gs, ideal / 512, gs / (ideal / 512), rs, ideal / 256, rs / (ideal / 256)))
+    print("  colour pass workgroups by x width:", [(k, round(gs_by[k] / gs, 3)) for k in sorted(gs_by)])
+# the nodal marches of the composite solve (mg_nd.hip ndf_build_march: a lane carries two nodes, row segments of sw lanes, 64 / sw rows per wave, four waves per
+# workgroup, the whole box height per workgroup on levels of many boxes): thread-planes marched against node pairs
+for n, lb in enumerate(levels):
+    tp = 0; ideal = 0; by = collections.Counter()
+    for lo, hi in lb:
+        nn = [hi[d] - lo[d] + 2 for d in range(3)]
+        best = None
+        for sw in range(4, 65):
+            cost = math.ceil(nn[0] / (2 * (sw - 2))) / (64 // sw)
+            if best is None or cost < best[0] - 1e-12: best = (cost, sw)
+        sw = best[1]; rows = 4 * (64 // sw)
+        wgs = math.ceil(nn[0] / (2 * (sw - 2))) * math.ceil(nn[1] / rows)
+        kchunk = nn[2]
+        if not (len(lb) > 16 and nn[2] <= 64):
+            while kchunk > 8 and wgs * math.ceil(nn[2] / kchunk) < 2048: kchunk = (kchunk + 1) // 2
+        c = wgs * math.ceil(nn[2] / kchunk) * (kchunk + 2) * 256
+        tp += c; by[hi[0] - lo[0] + 1] += c
+        ideal += nn[0] * nn[1] * nn[2] / 2
+    print("level", n + 1, "nodal march: %.2f thread-planes per node pair" % (tp / ideal), " share by x width:", [(k, round(by[k] / tp, 3)) for k in sorted(by)])
