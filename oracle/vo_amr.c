@@ -394,8 +394,8 @@ int vo_ml_cc_solve(int nlev, vo_fab **rh, vo_fab **phi, vo_fab **alpha, vo_fab *
       VF(rh[n], i, j, k, 0) = r;
     }
   }
-  vo_fab res[VO_MAXLEV], e[VO_MAXLEV], scr[VO_MAXLEV], *rp[VO_MAXLEV];
-  for (int n = 0; n < nlev; n++) { fab_like(&res[n], rh[n], 0, 0.0); fab_like(&e[n], rh[n], 1, 0.0); fab_like(&scr[n], rh[n], 0, 0.0); rp[n] = &res[n]; }
+  vo_fab res[VO_MAXLEV], e[VO_MAXLEV], t[VO_MAXLEV], *rp[VO_MAXLEV];
+  for (int n = 0; n < nlev; n++) { fab_like(&res[n], rh[n], 0, 0.0); fab_like(&e[n], rh[n], 1, 0.0); fab_like(&t[n], rh[n], 0, 0.0); rp[n] = &res[n]; }
   /* norm of the right-hand side over the composite grid */
   double bnorm = 0.0;
   for (int n = 0; n < nlev; n++)
@@ -411,9 +411,9 @@ int vo_ml_cc_solve(int nlev, vo_fab **rh, vo_fab **phi, vo_fab **alpha, vo_fab *
     for (int n = nlev - 1; n >= 1; n--) {               /* down: pre-relaxation, then the residual the next coarser level sees */
       vo_cc_smooth_ab(&res[n], &e[n], alpha ? alpha[n] : NULL, beta + 3 * n, dx + 3 * n, ellbc[n], prm->mg_nu1);
       fill_e_ghosts(&e[n], &e[n - 1], ellbc[n], pmask, pd + 6 * n, pd + 6 * n + 3);                   /* (e[n-1] = 0 here) */
-      (void)plain_residual(&res[n], &e[n], alpha ? alpha[n] : NULL, beta + 3 * n, dx + 3 * n, &scr[n]);
+      (void)plain_residual(&res[n], &e[n], alpha ? alpha[n] : NULL, beta + 3 * n, dx + 3 * n, &t[n]);
       reflux_residual(&res[n - 1], &e[n - 1], beta + 3 * (n - 1), dx + 3 * (n - 1), &e[n], beta + 3 * n, dx + 3 * n, ellbc[n]);
-      vo_ml_cc_restriction(&res[n - 1], &scr[n], 0, 1);
+      vo_ml_cc_restriction(&res[n - 1], &t[n], 0, 1);
     }
     /* coarse correction: ONE V-cycle of the single-level multigrid on the whole coarse level */
     vo_mgstat cs;
@@ -433,7 +433,7 @@ int vo_ml_cc_solve(int nlev, vo_fab **rh, vo_fab **phi, vo_fab **alpha, vo_fab *
   }
   fill_phi_ghosts(nlev, phi, ellbc, pmask, pd);       /* leave phi with consistent ghosts for mkumac */
   if (st) { st->cycles = it; st->res0 = bnorm; st->res = rn; }
-  for (int n = 0; n < nlev; n++) { free(res[n].p); free(e[n].p); free(scr[n].p); }
+  for (int n = 0; n < nlev; n++) { free(res[n].p); free(e[n].p); free(t[n].p); }
   return conv ? 0 : 1;
 }
 

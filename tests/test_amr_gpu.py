@@ -756,7 +756,7 @@ def test_composite_launch_variants_agree_bit_for_bit(gpu):
 def test_periodic_three_level_hierarchy_is_translation_invariant(gpu):
     """three levels on a domain periodic in x, shifted by half a period so that the boxes of BOTH refined levels sit across the periodic
     boundary: the corrections prolonged linearly into level 2 then read their coarse neighbours through periodic images of another box
-    (amr.hip apply_correction: edge fill + same-level exchange of the source).  Two steps; 1e-8 relative, iteration counts within one."""
+    (amr.hip ml_cc_solve, the way up: edge fill + same-level exchange of the source).  Two steps; 1e-8 relative, iteration counts within one."""
     from varden_amd import advance as adv
     from varden_amd import driver
     from varden_amd.capi import default_params

@@ -572,11 +572,11 @@ struct DirRhsB { Range3 r; int g[3]; FV rh, phi, bx, by, bz; GsArgs A;
   } };
 struct AddB { Range3 r; int g[3]; static constexpr int planes_per_wg = 8; FV a, b;
   static __device__ double body(const AddB &q, int i, int j, int k, int) { fv_at(q.a, i, j, k) = fv_get(q.a, i, j, k) + fv_get(q.b, i, j, k); return 0.0; } };
-// af += the prolonged increment of the parent level; keep: also store it in sc (the next finer level prolongs it in turn).
+// af += the prolonged correction of the parent level.
 // lin = 0: the parent's value (piecewise constant);  lin = 1: (p0 + px + py + pz)/4 with px, py, pz the parent's neighbours on the fine cell's
 // side, read through the source fab's ghost cells (the caller has put the neighbouring boxes' / periodic values there, and the parent's own
-// value where the level ends) -- oracle: apply_correction in vo_amr.c
-struct AddProlongB { Range3 r; int g[3]; static constexpr int planes_per_wg = 8; FV af, sc, ec; int keep, plo[3], phi[3];
+// value where the level ends) -- oracle: prolong_add in vo_amr.c
+struct AddProlongB { Range3 r; int g[3]; static constexpr int planes_per_wg = 8; FV af, ec; int plo[3], phi[3];
   static __device__ double body(const AddProlongB &q, int i, int j, int k, int lin) {
     const int I = i / 2, J = j / 2, K = k / 2;
     if (I < q.plo[0] || I > q.phi[0] || J < q.plo[1] || J > q.phi[1] || K < q.plo[2] || K > q.phi[2]) return 0.0;
@@ -585,7 +585,6 @@ struct AddProlongB { Range3 r; int g[3]; static constexpr int planes_per_wg = 8;
       const double px = fv_get(q.ec, I + ((i & 1) ? 1 : -1), J, K), py = fv_get(q.ec, I, J + ((j & 1) ? 1 : -1), K), pz = fv_get(q.ec, I, J, K + ((k & 1) ? 1 : -1));
       v = 0.25 * (((v + px) + py) + pz);
     }
-    if (q.keep) fv_at(q.sc, i, j, k) = v;
     fv_at(q.af, i, j, k) = fv_get(q.af, i, j, k) + v;
     return 0.0;
   } };
@@ -756,7 +755,7 @@ static void mlcc_build_sets(MLCC &S) {
         int qlo[3], qhi[3];
         for (int d = 0; d < 3; d++) { qlo[d] = S.e[m]->vbox[f].lo[d] / 2; qhi[d] = S.e[m]->vbox[f].hi[d] / 2; }
         for (int c : sb.near(qlo, qhi, 2)) {
-        AddProlongB q; q.r = valid_range(S.e[m], f); q.af = S.e[m]->fabs[f]; q.sc = q.af; q.keep = 0; q.ec = src.fv[c];
+        AddProlongB q; q.r = valid_range(S.e[m], f); q.af = S.e[m]->fabs[f]; q.ec = src.fv[c];
         for (int d = 0; d < 3; d++) { q.plo[d] = src.vbox[c].lo[d]; q.phi[d] = src.vbox[c].hi[d]; }
         int plo[3], phi[3]; Range3 dummy;
         for (int d = 0; d < 3; d++) { plo[d] = q.r.lo[d] / 2; phi[d] = q.r.hi[d] / 2; }
