@@ -740,9 +740,9 @@ def test_composite_launch_variants_agree_bit_for_bit(gpu):
                     h.update(np.ascontiguousarray(m.to_numpy(f)).tobytes())
         print("HASH", h.hexdigest(), G.dt)
     """ % root)
-    switches = ("VDN_BATCH_PPW", "VDN_NDM_IFACE_FACES", "VDN_NDM_NEG", "VDN_BATCH_YZ", "VDN_NDF_PAIR", "VDN_BATCH_CHUNK", "VDN_MLCC_FUSE1", "VDN_MLCC_GLUE", "VDN_MLCC_RHO", "VDN_FB_FACES", "VDN_NDF_SEGW", "VDN_GOD_SEGW", "VDN_BATCH_FLAT", "VDN_NDM_PROLONG8")
+    switches = ("VDN_BATCH_PPW", "VDN_NDM_IFACE_FACES", "VDN_NDM_NEG", "VDN_BATCH_YZ", "VDN_NDF_PAIR", "VDN_BATCH_CHUNK", "VDN_MLCC_FUSE1", "VDN_MLCC_GLUE", "VDN_MLCC_RHO", "VDN_FB_FACES", "VDN_NDF_SEGW", "VDN_GOD_SEGW", "VDN_KEEP_SETS", "VDN_BATCH_FLAT", "VDN_NDM_PROLONG8")
     out = []
-    for extra in ({}, {"VDN_BATCH_PPW": "1", "VDN_NDM_IFACE_FACES": "0", "VDN_NDM_NEG": "1", "VDN_BATCH_YZ": "0", "VDN_NDF_PAIR": "0", "VDN_BATCH_CHUNK": "0", "VDN_MLCC_FUSE1": "0", "VDN_MLCC_GLUE": "0", "VDN_MLCC_RHO": "0", "VDN_FB_FACES": "0", "VDN_NDF_SEGW": "0", "VDN_GOD_SEGW": "0", "VDN_BATCH_FLAT": "0", "VDN_NDM_PROLONG8": "0"}):
+    for extra in ({}, {"VDN_BATCH_PPW": "1", "VDN_NDM_IFACE_FACES": "0", "VDN_NDM_NEG": "1", "VDN_BATCH_YZ": "0", "VDN_NDF_PAIR": "0", "VDN_BATCH_CHUNK": "0", "VDN_MLCC_FUSE1": "0", "VDN_MLCC_GLUE": "0", "VDN_MLCC_RHO": "0", "VDN_FB_FACES": "0", "VDN_NDF_SEGW": "0", "VDN_GOD_SEGW": "0", "VDN_KEEP_SETS": "0", "VDN_BATCH_FLAT": "0", "VDN_NDM_PROLONG8": "0"}):
         env = dict(os.environ)
         for k in switches:
             env.pop(k, None)

@@ -58,6 +58,10 @@ enum { VT_REFINE = 1, VT_REFINE_FACE0 = 2, VT_COARSEN_G = 8, VT_COARSEN_1 = 20, 
 static const std::vector<vdn_box> &level_boxes(const vdn_multifab *mf) { return mf->la->boxes[mf->lev]; }
 static const std::vector<int> &level_owner(const vdn_multifab *mf) { return mf->la->owner[mf->lev]; }
 static int global_index(const vdn_multifab *mf, int li) { return mf->la->local[mf->lev][li]; }
+// what the fab pointers of a multifab follow from (keys of kept descriptor sets, vdn_internal.h)
+static void key_mf(GraphKey &k, const vdn_multifab *mf) {
+  k.put(mf->la->uid); k.put(mf->lev); k.put(mf->nc); k.put(mf->ng); k.put(mf->nodal[0] | (mf->nodal[1] << 1) | (mf->nodal[2] << 2)); k.put((const void *)mf->base);
+}
 // the index region of the FINER level over the cells (faces: +1 in dir `face`, -1 = cells; nodes: face = 3) of every box of `crse_side`, grown by g fine points
 static std::vector<vdn_box> refined_footprints(const vdn_multifab *crse_side, int face, int g) {
   std::vector<vdn_box> fp;
@@ -98,20 +102,21 @@ struct RestrictB { Range3 r; int g[3]; FV crse, fine; int icomp, nc, fc0;   // f
 void ml_cc_restriction(vdn_multifab *crse, const vdn_multifab *fine, int icomp, int nc) {
   const SrcView F = make_view(fine, refined_footprints(crse, -1, 0), level_owner(crse), icomp, nc, VT_REFINE);
   F.refresh();
-  std::vector<RestrictB> v;
-  const BoxBins cb(crse->vbox);
-  for (int f = 0; f < F.nboxes(); f++) {
-    if (!F.have[f]) continue;
-    int clo[3], chi[3];
-    for (int d = 0; d < 3; d++) { clo[d] = hfdiv2(F.vbox[f].lo[d]); chi[d] = hfdiv2(F.vbox[f].hi[d]); }
-    for (int c : cb.near(clo, chi, 1)) {
-    RestrictB a;
-    if (!isect(clo, chi, crse->vbox[c].lo, crse->vbox[c].hi, a.r)) continue;
-    a.crse = crse->fabs[c]; a.fine = F.fv[f]; a.icomp = icomp; a.nc = nc; a.fc0 = icomp;
-    v.push_back(a);
+  GraphKey key; key.put(0x7201); key_mf(key, crse); key_mf(key, fine); key.put(icomp); key.put(nc);
+  launch_batched_kept<RestrictB>(key.h, crse->la->uid, [&](std::vector<RestrictB> &v) {
+    const BoxBins cb(crse->vbox);
+    for (int f = 0; f < F.nboxes(); f++) {
+      if (!F.have[f]) continue;
+      int clo[3], chi[3];
+      for (int d = 0; d < 3; d++) { clo[d] = hfdiv2(F.vbox[f].lo[d]); chi[d] = hfdiv2(F.vbox[f].hi[d]); }
+      for (int c : cb.near(clo, chi, 1)) {
+        RestrictB a;
+        if (!isect(clo, chi, crse->vbox[c].lo, crse->vbox[c].hi, a.r)) continue;
+        a.crse = crse->fabs[c]; a.fine = F.fv[f]; a.icomp = icomp; a.nc = nc; a.fc0 = icomp;
+        v.push_back(a);
+      }
     }
-  }
-  launch_batched(v, 0, (double *)nullptr, 0, ctx().stream);
+  }, 0, (double *)nullptr, 0, ctx().stream);
 }
 struct EdgeRestrictB { Range3 r; int g[3]; FV crse, fine; int dir;
   static __device__ double body(const EdgeRestrictB &a, int i, int j, int k, int) {
@@ -131,7 +136,8 @@ struct EdgeRestrictB { Range3 r; int g[3]; FV crse, fine; int dir;
 void ml_edge_restriction(vdn_multifab *crse, const vdn_multifab *fine, int dir) {
   const SrcView F = make_view(fine, refined_footprints(crse, dir, 0), level_owner(crse), 0, 1, VT_REFINE_FACE0 + dir);
   F.refresh();
-  std::vector<EdgeRestrictB> v;
+  GraphKey key; key.put(0x7202); key_mf(key, crse); key_mf(key, fine); key.put(dir);
+  launch_batched_kept<EdgeRestrictB>(key.h, crse->la->uid, [&](std::vector<EdgeRestrictB> &v) {
   const BoxBins cb(crse->vbox);
   for (int f = 0; f < F.nboxes(); f++) {
     if (!F.have[f]) continue;
@@ -146,7 +152,7 @@ void ml_edge_restriction(vdn_multifab *crse, const vdn_multifab *fine, int dir) 
     v.push_back(a);
     }
   }
-  launch_batched(v, 0, (double *)nullptr, 0, ctx().stream);
+  }, 0, (double *)nullptr, 0, ctx().stream);
 }
 
 // ---- coarse -> fine ghost interpolation ---------------------------------------------------------------------------------
@@ -192,7 +198,8 @@ void ml_fill_ghost_cells(vdn_multifab *fine, const vdn_multifab *crse, int icomp
   // the coarse data this rank's fine boxes read: parents of the grown boxes and one more cell for the slopes
   const SrcView Cv = make_view(crse, coarsened_footprints(fine, fine->ng, -1, 1), level_owner(fine), icomp, nc, VT_COARSEN_G + fine->ng);
   Cv.refresh();
-  std::vector<InterpB> v;
+  GraphKey key; key.put(0x7203); key_mf(key, fine); key_mf(key, crse); key.put(icomp); key.put(nc);
+  launch_batched_kept<InterpB>(key.h, fine->la->uid, [&](std::vector<InterpB> &v) {
   const vdn_box &pdc = Cv.nboxes() == 1 ? Cv.vbox[0] : crse->la->pd[crse->lev];
   const BoxBins cb(Cv.vbox, &Cv.have);
   for (int f = 0; f < fine->nfabs(); f++) {
@@ -229,7 +236,7 @@ void ml_fill_ghost_cells(vdn_multifab *fine, const vdn_multifab *crse, int icomp
           { InterpB e; e.r = r; e.fine = fine->fabs[f]; e.crse = Cv.fv[c]; e.A = A; v.push_back(e); }
       }
   }
-  launch_batched(v, 0, (double *)nullptr, 0, ctx().stream);       // every ghost cell has exactly one parent range: order-free
+  }, 0, (double *)nullptr, 0, ctx().stream);       // every ghost cell has exactly one parent range: order-free
 }
 // fillpatch(fine, crse, ng = 0, ...) of src/regrid.f90:311-325: every VALID cell of the fine level from the coarse one, by the
 // interpolation of multifab_fill_ghost_cells (the coarse ghost cells must be filled; the fine level is properly nested)
@@ -340,6 +347,15 @@ void ml_create_umac_grown(vdn_multifab *fine, const vdn_multifab *crse, int dir)
   // one), then the valid faces on top: two launches so that the second pass wins
   const SrcView Cv = make_view(crse, coarsened_footprints(fine, fine->ng, dir, 0), level_owner(fine), 0, 1, VT_COARSEN_0 + 4 * (dir + 1) + fine->ng * 64);
   Cv.refresh();
+  GraphKey key; key.put(0x7204); key_mf(key, fine); key_mf(key, crse); key.put(dir);
+  if (kept_sets_enabled()) {
+    KeptSet *k0 = kept_find(key.h), *k1 = kept_find(key.h + 1);
+    if (k0 && k1) {
+      if (k0->nbox) hipLaunchKernelGGL((kk_batched<GrownB, int>), dim3(k0->tot), dim3(64, 4, 1), 0, ctx().stream, (const GrownB *)k0->d_args, (const int *)k0->d_start, k0->nbox, 0, (double *)nullptr);
+      if (k1->nbox) hipLaunchKernelGGL((kk_batched<GrownB, int>), dim3(k1->tot), dim3(64, 4, 1), 0, ctx().stream, (const GrownB *)k1->d_args, (const int *)k1->d_start, k1->nbox, 0, (double *)nullptr);
+      return;
+    }
+  }
   std::vector<GrownB> v0, v1;
   const BoxBins cb(Cv.vbox, &Cv.have);
   int first_here = -1;
@@ -371,8 +387,8 @@ void ml_create_umac_grown(vdn_multifab *fine, const vdn_multifab *crse, int dir)
       }
     }
   }
-  launch_batched(v0, 0, (double *)nullptr, 0, ctx().stream);
-  launch_batched(v1, 0, (double *)nullptr, 0, ctx().stream);
+  launch_batched_kept<GrownB>(key.h, fine->la->uid, [&](std::vector<GrownB> &v) { v = v0; }, 0, (double *)nullptr, 0, ctx().stream);
+  launch_batched_kept<GrownB>(key.h + 1, fine->la->uid, [&](std::vector<GrownB> &v) { v = v1; }, 0, (double *)nullptr, 0, ctx().stream);
 }
 void ml_restrict_and_fill(int nlev, vdn_multifab **mf, int icomp, int bcomp, int nc, bool same_boundary, const vdn_bc_tower *bct) {
   for (int n = nlev - 1; n >= 1; n--) ml_cc_restriction(mf[n - 1], mf[n], icomp, nc);
@@ -808,6 +824,14 @@ static void fill_e_ghosts(MLCC &S, int n) {
   if (n >= 1) { S.vc_e[n].refresh(); S.cf_e[n].run(0, (double *)nullptr, st); }
   mf_fill_boundary(S.e[n], true);
 }
+// the sets of a solve kept across solves (vdn_internal.h: kept descriptor sets): the MLCC of the solve that built them, reused with the per-call fields replaced
+struct MLCCKept { KeeperMem mem; unsigned long uid = 0; MLCC S; };
+static std::map<unsigned long long, MLCCKept *> g_mlcc_kept;
+void mlcc_kept_purge(unsigned long uid) {
+  for (auto it = g_mlcc_kept.begin(); it != g_mlcc_kept.end();) {
+    if (uid == 0 || it->second->uid == uid) { keeper_free(&it->second->mem); delete it->second; it = g_mlcc_kept.erase(it); } else ++it;
+  }
+}
 // rh, phi: [lev];  beta: [lev*3 + d];  dx: [lev*3 + d]
 // alpha: [lev] cell coefficients of (alpha - div beta grad), or nullptr.  The ghost cells of the incoming phi carry inhomogeneous
 // Dirichlet data (boundary-face values); they are moved into rh, which is modified
@@ -817,51 +841,79 @@ int ml_cc_solve(vdn_layout *la, vdn_multifab **rh, vdn_multifab **phi, vdn_multi
   hipStream_t st = ctx().stream;
   const size_t mark = arena_mark();
   const int L = la->nlev;
-  MLCC S; S.nlev = L; S.la = la; S.rh = rh; S.phi = phi; S.beta = beta; S.alpha = alpha; S.dx = dx; S.bct = bct; S.bcc = bc_comp0;
   static const bool fuse_first_on = !(vdn_env("VDN_MLCC_FUSE1") && atoi(vdn_env("VDN_MLCC_FUSE1")) == 0);
-  S.fuse_first = fuse_first_on && ctx().prm.mg_nu1 >= 1 && ctx().prm.mg_nu2 >= 1;
   static const bool rho_form = !(vdn_env("VDN_MLCC_RHO") && atoi(vdn_env("VDN_MLCC_RHO")) == 0);
-  S.fine_rho = (rho_form && !alpha) ? fine_rho : nullptr;
-  if (S.fine_rho) REQUIRE(S.fine_rho->ng >= 1 && S.fine_rho->lev == L - 1, "composite solve: the finest level's density with a filled ghost cell expected");
+  const bool fuse_first = fuse_first_on && ctx().prm.mg_nu1 >= 1 && ctx().prm.mg_nu2 >= 1;
+  const vdn_multifab *frho = (rho_form && !alpha) ? fine_rho : nullptr;
+  if (frho) REQUIRE(frho->ng >= 1 && frho->lev == L - 1, "composite solve: the finest level's density with a filled ghost cell expected");
+  // everything the descriptor sets of this solve follow from: the key of the kept ones (vdn_internal.h)
+  GraphKey key; key.put(0x7301); key.put(la->uid); key.put(L); key.put(bct->serial); key.put(bc_comp0); key.put(fuse_first); key.put((const void *)(frho ? frho->base : nullptr));
   for (int n = 0; n < L; n++) {
-    std::vector<DirRhsB> v;
-    for (int b = 0; b < rh[n]->nfabs(); b++) {
-      DirRhsB q; q.rh = rh[n]->fabs[b]; q.phi = phi[n]->fabs[b]; q.bx = beta[3 * n]->fabs[b]; q.by = beta[3 * n + 1]->fabs[b]; q.bz = beta[3 * n + 2]->fabs[b];
-      bool any = false;
-      for (int d = 0; d < 3; d++) { q.r.lo[d] = q.A.lo[d] = rh[n]->vbox[b].lo[d]; q.r.hi[d] = q.A.hi[d] = rh[n]->vbox[b].hi[d]; q.A.hi2[d] = 1.0 / (dx[3 * n + d] * dx[3 * n + d]);
-        for (int sd = 0; sd < 2; sd++) { q.A.e[d][sd] = bct->ell_bc(n, b + 1, d, sd, bc_comp0); any = any || q.A.e[d][sd] == VDN_BC_DIR; } }
-      if (any) v.push_back(q);
-    }
-    launch_batched(v, 0, (double *)nullptr, 0, ctx().stream);
+    key_mf(key, rh[n]); key_mf(key, phi[n]); for (int d = 0; d < 3; d++) { key_mf(key, beta[3 * n + d]); key.put(dx[3 * n + d]); }
+    key.put(alpha != nullptr); if (alpha) key_mf(key, alpha[n]);
   }
-  S.d_nrm = (double *)arena_alloc(256);
   for (int n = 0; n < L; n++) {
-    S.res[n] = mf_temp(la, n, 1, 0, -1, true, 0.0); S.e[n] = mf_temp(la, n, 1, 1, -1, true, 0.0);
-    S.t[n] = n >= 1 ? mf_temp(la, n, 1, 0, -1, true, 0.0) : nullptr;
-    S.mask[n] = nullptr;
-    if (n < L - 1) {                                         // cells of level n covered by level n+1
-      S.mask[n] = mf_temp(la, n, 1, 0, -1, true, 0.0);
-      std::vector<SetboxB> v;
-      const std::vector<vdn_box> &fb = level_boxes(phi[n + 1]);
-      const BoxBins mb(S.mask[n]->vbox);
-      for (int f = 0; f < (int)fb.size(); f++) {
-        int clo[3], chi[3];
-        for (int d = 0; d < 3; d++) { clo[d] = fb[f].lo[d] / 2; chi[d] = fb[f].hi[d] / 2; }
-        for (int c : mb.near(clo, chi, 1)) {
-        SetboxB q;
-        if (!isect(clo, chi, S.mask[n]->vbox[c].lo, S.mask[n]->vbox[c].hi, q.r)) continue;
-        q.a = S.mask[n]->fabs[c]; q.v = 1.0; v.push_back(q);
-        }
+    GraphKey k2 = key; k2.put(0x11); k2.put(n);
+    launch_batched_kept<DirRhsB>(k2.h, la->uid, [&](std::vector<DirRhsB> &v) {
+      for (int b = 0; b < rh[n]->nfabs(); b++) {
+        DirRhsB q; q.rh = rh[n]->fabs[b]; q.phi = phi[n]->fabs[b]; q.bx = beta[3 * n]->fabs[b]; q.by = beta[3 * n + 1]->fabs[b]; q.bz = beta[3 * n + 2]->fabs[b];
+        bool any = false;
+        for (int d = 0; d < 3; d++) { q.r.lo[d] = q.A.lo[d] = rh[n]->vbox[b].lo[d]; q.r.hi[d] = q.A.hi[d] = rh[n]->vbox[b].hi[d]; q.A.hi2[d] = 1.0 / (dx[3 * n + d] * dx[3 * n + d]);
+          for (int sd = 0; sd < 2; sd++) { q.A.e[d][sd] = bct->ell_bc(n, b + 1, d, sd, bc_comp0); any = any || q.A.e[d][sd] == VDN_BC_DIR; } }
+        if (any) v.push_back(q);
       }
-      launch_batched(v, 0, (double *)nullptr, 0, st);
+    }, 0, (double *)nullptr, 0, ctx().stream);
+  }
+  double *d_nrm = (double *)arena_alloc(256);
+  vdn_multifab *t_res[VDN_MAXLEV], *t_e[VDN_MAXLEV], *t_t[VDN_MAXLEV], *t_mask[VDN_MAXLEV];
+  for (int n = 0; n < L; n++) {
+    t_res[n] = mf_temp(la, n, 1, 0, -1, true, 0.0); t_e[n] = mf_temp(la, n, 1, 1, -1, true, 0.0);
+    t_t[n] = n >= 1 ? mf_temp(la, n, 1, 0, -1, true, 0.0) : nullptr;
+    t_mask[n] = nullptr;
+    key.put((const void *)t_res[n]->base); key.put((const void *)t_e[n]->base); key.put((const void *)(t_t[n] ? t_t[n]->base : nullptr));
+    if (n < L - 1) {                                         // cells of level n covered by level n+1
+      t_mask[n] = mf_temp(la, n, 1, 0, -1, true, 0.0);
+      key.put((const void *)t_mask[n]->base);
+      GraphKey k2 = key; k2.put(0x12);
+      launch_batched_kept<SetboxB>(k2.h, la->uid, [&](std::vector<SetboxB> &v) {
+        const std::vector<vdn_box> &fb = level_boxes(phi[n + 1]);
+        const BoxBins mb(t_mask[n]->vbox);
+        for (int f = 0; f < (int)fb.size(); f++) {
+          int clo[3], chi[3];
+          for (int d = 0; d < 3; d++) { clo[d] = fb[f].lo[d] / 2; chi[d] = fb[f].hi[d] / 2; }
+          for (int c : mb.near(clo, chi, 1)) {
+            SetboxB q;
+            if (!isect(clo, chi, t_mask[n]->vbox[c].lo, t_mask[n]->vbox[c].hi, q.r)) continue;
+            q.a = t_mask[n]->fabs[c]; q.v = 1.0; v.push_back(q);
+          }
+        }
+      }, 0, (double *)nullptr, 0, st);
     }
   }
-  mlcc_build_sets(S);
+  // the sets of the iteration: kept across solves under the key (a hit skips every pair loop and upload), else built into the arena
+  MLCC S_local; MLCC *Sp = &S_local; bool hit = false; MLCCKept *kept = nullptr;
+  if (kept_sets_enabled()) {
+    auto itk = g_mlcc_kept.find(key.h);
+    if (itk != g_mlcc_kept.end()) { kept = itk->second; hit = true; }
+    else { if (g_mlcc_kept.size() >= 64) mlcc_kept_purge(0); kept = new MLCCKept; kept->uid = la->uid; g_mlcc_kept[key.h] = kept; }
+    Sp = &kept->S;
+  }
+  MLCC &S = *Sp;
+  S.nlev = L; S.la = la; S.rh = rh; S.phi = phi; S.beta = beta; S.alpha = alpha; S.dx = dx; S.bct = bct; S.bcc = bc_comp0; S.fuse_first = fuse_first; S.fine_rho = frho; S.d_nrm = d_nrm;
+  for (int n = 0; n < L; n++) { S.res[n] = t_res[n]; S.e[n] = t_e[n]; S.t[n] = t_t[n]; S.mask[n] = t_mask[n]; }
+  if (!hit) {
+    if (kept) keeper_begin(&kept->mem);
+    try { mlcc_build_sets(S); }
+    catch (...) { if (kept) { keeper_end(); HIPCHK(hipStreamSynchronize(st)); keeper_free(&kept->mem); g_mlcc_kept.erase(key.h); delete kept; } throw; }
+    if (kept) keeper_end();
+  } else
+    for (int n = 1; n < L; n++) for (int d = 0; d < 3; d++) S.vf_beta[n][d].refresh();      // (the coefficients change from solve to solve: the windows of remote boxes)
   HIPCHK(hipMemsetAsync(S.d_nrm, 0, sizeof(double), st));
   for (int n = 0; n < L; n++) {
-    std::vector<AbsmaxB> v;
-    for (int b = 0; b < rh[n]->nfabs(); b++) { AbsmaxB q; q.r = valid_range(rh[n], b); q.a = rh[n]->fabs[b]; q.mask = n < L - 1 ? S.mask[n]->fabs[b] : rh[n]->fabs[b]; q.has_mask = n < L - 1 ? 1 : 0; v.push_back(q); }
-    launch_batched(v, 0, S.d_nrm, 16, st);
+    GraphKey k2 = key; k2.put(0x13); k2.put(n);
+    launch_batched_kept<AbsmaxB>(k2.h, la->uid, [&](std::vector<AbsmaxB> &v) {
+      for (int b = 0; b < rh[n]->nfabs(); b++) { AbsmaxB q; q.r = valid_range(rh[n], b); q.a = rh[n]->fabs[b]; q.mask = n < L - 1 ? S.mask[n]->fabs[b] : rh[n]->fabs[b]; q.has_mask = n < L - 1 ? 1 : 0; v.push_back(q); }
+    }, 0, S.d_nrm, 16, st);
   }
   comm_allreduce_max_dev(S.d_nrm, 1);
   const double bnorm = read_dev(S.d_nrm);

@@ -583,6 +583,7 @@ static std::map<FbKey, XPlan *> g_fb_cache;
 static std::multimap<unsigned long, XPlan *> g_halo_owned;     // multigrid halo plans, by layout uid
 void halo_cache_register(unsigned long uid, XPlan *P) { g_halo_owned.emplace(uid, P); }
 void xplan_cache_purge(unsigned long uid) {
+  kept_purge(uid);                              // descriptor sets hold pointers into the views' windows
   view_cache_purge(uid);
   for (auto it = g_fb_cache.begin(); it != g_fb_cache.end();) {
     if (it->first.uid == uid) { xplan_free(it->second); it = g_fb_cache.erase(it); } else ++it;

@@ -41,7 +41,7 @@ void arena_reserve(size_t bytes) {
   VdnCtx &c = g_ctx;
   if (bytes <= c.arena_bytes) return;
   REQUIRE(c.arena_off == 0, "arena_reserve while temporaries are live");
-  if (c.arena) { HIPCHK(hipStreamSynchronize(c.stream)); HIPCHK(hipFree(c.arena)); c.arena = nullptr; c.arena_bytes = 0; }
+  if (c.arena) { HIPCHK(hipStreamSynchronize(c.stream)); kept_purge(0); HIPCHK(hipFree(c.arena)); c.arena = nullptr; c.arena_bytes = 0; }      // (kept descriptor sets point at temporaries)
   HIPCHK(hipMalloc((void **)&c.arena, bytes));
   c.arena_bytes = bytes;
 }
@@ -71,7 +71,7 @@ void *arena_alloc(size_t bytes) {
     // grow: only legal when nothing is live (arena_off == 0) -- otherwise fail loudly
     if (c.arena_off != 0) vdn_fail("arena exhausted: need %zu more bytes (have %zu); call vdn_reserve first", bytes, c.arena_bytes);
     size_t want = std::max(bytes * 2, c.arena_bytes * 2);
-    if (c.arena) HIPCHK(hipFree(c.arena));
+    if (c.arena) { kept_purge(0); HIPCHK(hipFree(c.arena)); }
     HIPCHK(hipMalloc((void **)&c.arena, want));
     c.arena_bytes = want; off = 0;
   }
@@ -171,6 +171,7 @@ static const EnvSwitch g_switches[] = {
   { "VDN_NDM_NEG", "1: the composite nodal solve copies -res into the correction's right-hand side instead of loading it directly" },
   { "VDN_FB_FACES", "0: the ghost exchanges of the composite cell-centred solve fill edges and corners too" },
   { "VDN_MLCC_RHO", "0: the composite MAC solve reads stored face coefficients on its finest level too" },
+  { "VDN_KEEP_SETS", "0: the descriptor arrays of the inter-level operators and composite solves are rebuilt and uploaded at every call" },
   { "VDN_MLCC_GLUE", "0: the level-0 correction of the composite MAC solve stored and added in separate passes" },
   { "VDN_MLCC_FUSE1", "0: the composite MAC solve's finest-level residual and first colour pass as two launches" },
   { "VDN_BATCH_YZ", "0: no (j,k) / (i,k) tiles for thin ranges in the box-batched kernels" },
@@ -368,6 +369,7 @@ extern "C" int vdn_init(const vdn_params *prm, int rank, int nranks, int device)
 extern "C" int vdn_finalize(void) {
   VDN_TRY
   VdnCtx &c = g_ctx;
+  kept_purge(0);
   if (c.arena) { HIPCHK(hipFree(c.arena)); c.arena = nullptr; c.arena_bytes = 0; c.arena_off = 0; }
   graph_cache_clear();
   if (c.d_hist) { HIPCHK(hipFree(c.d_hist)); c.d_hist = nullptr; }
@@ -482,6 +484,7 @@ static void build_adv_ell(int p, int d, int dm, int nscal, int *a, int *e) {
 extern "C" int vdn_bc_tower_create(const vdn_layout *la, const int *phys_bc, vdn_bc_tower **out) {
   VDN_TRY
   vdn_bc_tower *b = new vdn_bc_tower;
+  { static unsigned long next_serial = 0; b->serial = ++next_serial; }
   b->la = la; b->dm = g_ctx.prm.dm; b->nscal = g_ctx.prm.nscal;
   b->ncomp_adv = b->dm + b->nscal + 2; b->ncomp_ell = b->dm + b->nscal + 1;
   for (int d = 0; d < 3; d++) for (int s = 0; s < 2; s++) b->domain_bc[d][s] = (d < b->dm) ? phys_bc[d * 2 + s] : VDN_INTERIOR;   // dm = 2: no z faces
@@ -577,6 +580,42 @@ void mf_temp_free(vdn_multifab *mf) {
 }
 
 
+// descriptor sets kept across calls (vdn_internal.h)
+static std::map<unsigned long long, KeptSet> g_kept;
+bool kept_sets_enabled() { static const bool on = !(vdn_env("VDN_KEEP_SETS") && atoi(vdn_env("VDN_KEEP_SETS")) == 0); return on; }
+KeptSet *kept_find(unsigned long long key) { auto it = g_kept.find(key); return it == g_kept.end() ? nullptr : &it->second; }
+static void kept_free(KeptSet &k) { if (k.d_args) HIPCHK(hipFree(k.d_args)); if (k.d_start) HIPCHK(hipFree(k.d_start)); k.d_args = nullptr; k.d_start = nullptr; }
+static KeeperMem *g_keeper = nullptr;
+void keeper_begin(KeeperMem *m) { REQUIRE(!g_keeper, "kept descriptor sets: nested keeper"); g_keeper = m; }
+void keeper_end() { g_keeper = nullptr; }
+void keeper_free(KeeperMem *m) { for (void *p : m->chunks) HIPCHK(hipFree(p)); m->chunks.clear(); m->cur = nullptr; m->left = 0; }
+void *set_alloc(size_t bytes) {
+  if (!g_keeper) return arena_alloc(bytes);
+  KeeperMem &m = *g_keeper;
+  const size_t need = (bytes + 255) & ~(size_t)255;
+  if (need > m.left) {
+    const size_t chunk = std::max<size_t>(need, (size_t)4 << 20);
+    void *p = nullptr; HIPCHK(hipMalloc(&p, chunk));
+    m.chunks.push_back(p); m.cur = (char *)p; m.left = chunk;
+  }
+  void *r = m.cur; m.cur += need; m.left -= need;
+  return r;
+}
+void kept_purge(unsigned long uid) {
+  if (ctx().inited) HIPCHK(hipStreamSynchronize(ctx().stream));
+  mlcc_kept_purge(uid); mlnd_kept_purge(uid);
+  if (g_kept.empty()) return;
+  for (auto it = g_kept.begin(); it != g_kept.end();) { if (uid == 0 || it->second.uid == uid) { kept_free(it->second); it = g_kept.erase(it); } else ++it; }
+}
+KeptSet *kept_store(unsigned long long key, unsigned long uid, const void *args, size_t arg_bytes, const int *start, int nbox, int tot) {
+  if (g_kept.size() >= 4096) kept_purge(0);          // (temporaries that wander through the arena: bounded, and rebuilt on demand)
+  KeptSet k; k.nbox = nbox; k.tot = tot; k.uid = uid;
+  if (nbox > 0) {
+    HIPCHK(hipMalloc(&k.d_args, arg_bytes)); HIPCHK(hipMalloc((void **)&k.d_start, sizeof(int) * nbox));
+    upload_staged(k.d_args, args, arg_bytes); upload_staged(k.d_start, start, sizeof(int) * nbox);
+  }
+  return &(g_kept[key] = k);
+}
 // device scratch for the descriptor arrays of one-off batched launches: a ring; reuse is safe because uploads and launches are
 // ordered on the one launch stream
 void *desc_scratch(size_t bytes) {

@@ -229,6 +229,7 @@ template <class A> static inline int batch_grid(A &a, int kz) {
 }
 // host side: fills g / the prefix sums, uploads and launches.  kz: at most this many workgroups along k per box (0 = one per plane)
 void *arena_alloc(size_t bytes);
+void *set_alloc(size_t bytes);
 void upload_staged(void *dst, const void *src, size_t bytes);     // host -> device on the launch stream through a pinned ring (runtime.hip)
 void *desc_scratch(size_t bytes);                                   // device ring for one-off descriptor arrays (runtime.hip)
 template <class A, class P>
@@ -247,6 +248,21 @@ static inline void launch_batched(std::vector<A> &v, P extra, double *nrm, int k
   upload_staged(d_args, v.data(), sizeof(A) * v.size());
   upload_staged(d_start, start.data(), sizeof(int) * v.size());
   hipLaunchKernelGGL((kk_batched<A, P>), dim3(tot), dim3(64, 4, 1), 0, st, (const A *)d_args, (const int *)d_start, (int)v.size(), extra, nrm);
+}
+// the same launch from a descriptor set kept on the device under `key` (vdn_internal.h): build(v) fills the descriptors only when the key is new
+template <class A, class P, class F>
+static inline void launch_batched_kept(unsigned long long key, unsigned long uid, F &&build, P extra, double *nrm, int kz, hipStream_t st) {
+  if (!kept_sets_enabled()) { std::vector<A> v; build(v); launch_batched(v, extra, nrm, kz, st); return; }
+  KeptSet *k = kept_find(key);
+  if (!k) {
+    std::vector<A> v; build(v);
+    std::vector<int> start(v.size());
+    int tot = 0;
+    for (size_t b = 0; b < v.size(); b++) { start[b] = tot; tot += batch_grid(v[b], kz); }
+    k = kept_store(key, uid, v.data(), sizeof(A) * v.size(), start.data(), (int)v.size(), tot);
+  }
+  if (k->nbox == 0) return;
+  hipLaunchKernelGGL((kk_batched<A, P>), dim3(k->tot), dim3(64, 4, 1), 0, st, (const A *)k->d_args, (const int *)k->d_start, k->nbox, extra, nrm);
 }
 // ---- cell kernels: one body, launched for one box or batched over the boxes of a level --------------------------------------------
 // struct K { <arguments>; __device__ void cell(int i, int j, int k) const { ... } };   then   launch_cells(vector of (K, range))
@@ -288,8 +304,8 @@ template <class A> struct BatchSet {
       (void)nx; (void)ny; (void)nz;
       start[b] = tot; tot += batch_grid(a, kz);
     }
-    d_args = (A *)arena_alloc(sizeof(A) * v.size());
-    d_start = (int *)arena_alloc(sizeof(int) * v.size());
+    d_args = (A *)set_alloc(sizeof(A) * v.size());          // (the arena, or the memory of a kept group of sets: vdn_internal.h)
+    d_start = (int *)set_alloc(sizeof(int) * v.size());
     upload_staged(d_args, v.data(), sizeof(A) * v.size());
     upload_staged(d_start, start.data(), sizeof(int) * v.size());
     (void)st;

@@ -61,6 +61,7 @@ struct vdn_multifab {
 
 struct vdn_bc_tower {
   const vdn_layout *la = nullptr;
+  unsigned long serial = 0;                                  // unique per tower ever created (keys of kept descriptor sets)
   int dm = 3, nscal = 2;
   int ncomp_adv = 0, ncomp_ell = 0;
   // [lev][grid (0 = domain, 1.. = local boxes)]
@@ -147,6 +148,26 @@ struct GraphKey {
   void add(const void *p, size_t n) { const unsigned char *c = (const unsigned char *)p; for (size_t i = 0; i < n; i++) { h ^= c[i]; h *= 1099511628211ull; } }
   template <class T> void put(const T &v) { add(&v, sizeof v); }
 };
+// ---- descriptor sets kept across calls -------------------------------------------------------------------------------------------------
+// The inter-level operators and the composite solves describe their box-batched launches by descriptor arrays built on the host (pair loops over
+// the boxes of two levels) and uploaded: 0.3-1 ms per call on a level of a thousand boxes, with the GPU idle meanwhile, a few dozen times per step.
+// State fields live at fixed addresses and temporaries come back at the same arena offsets every step, so the arrays of one call site are the same
+// bytes step after step: they are kept on the device under a key made of everything they depend on (GraphKey over the layout uid, levels, base
+// pointers, components, ...) and dropped with the layout (xplan_cache_purge) or when the table outgrows its bound.  VDN_KEEP_SETS=0: rebuilt every call.
+struct GraphKey;
+struct KeptSet { void *d_args = nullptr; int *d_start = nullptr; int nbox = 0, tot = 0; unsigned long uid = 0; };
+bool     kept_sets_enabled();
+KeptSet *kept_find(unsigned long long key);
+KeptSet *kept_store(unsigned long long key, unsigned long uid, const void *args, size_t arg_bytes, const int *start, int nbox, int tot);
+void     kept_purge(unsigned long uid);            // uid 0: every entry
+// ... and whole groups of BatchSets (the composite solves): while a KeeperMem is open, BatchSet::build takes its device memory from it instead of the arena
+struct KeeperMem { std::vector<void *> chunks; char *cur = nullptr; size_t left = 0; };
+void  keeper_begin(KeeperMem *m);
+void  keeper_end();
+void  keeper_free(KeeperMem *m);
+void *set_alloc(size_t bytes);                     // the open KeeperMem, or the arena
+void  mlcc_kept_purge(unsigned long uid);          // amr.hip
+void  mlnd_kept_purge(unsigned long uid);          // mg_nd.hip
 bool graphs_enabled();
 bool graph_replay(unsigned long long key);     // true: the cached graph was launched
 void graph_begin();
