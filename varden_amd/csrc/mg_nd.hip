@@ -18,7 +18,6 @@
 void cc_halo_cache_purge(unsigned long uid);
 void nd_halo_cache_purge(unsigned long uid);
 void mg_halo_cache_purge(unsigned long uid) { cc_halo_cache_purge(uid); nd_halo_cache_purge(uid); }
-void mlnd_kept_purge(unsigned long) {}
 
 struct NLev {
   int n[3]; int PX, PY; long sz;
