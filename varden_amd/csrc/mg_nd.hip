@@ -2082,7 +2082,7 @@ static MarchSet ndf_build_march(std::vector<MarchB> &v) {
     const int tiles = ((nx + act - 1) / act) * ((ny + rows - 1) / rows);
     int kchunk = nz;
     while (kchunk > 8 && tiles * ((nz + kchunk - 1) / kchunk) < 2048) kchunk = (kchunk + 1) / 2;
-    if (v.size() > 16 && nz <= 64) kchunk = nz;              // many small boxes fill the chip by themselves: no redundant warm-up planes
+    if (v.size() > 16) { const int nch = (nz + 63) / 64; kchunk = (nz + nch - 1) / nch; }      // many boxes fill the chip together: whole boxes, tall ones in chunks of <= 64 planes (two warm-up planes each)
     B.kchunk = kchunk; B.g[0] = (nx + act - 1) / act; B.g[1] = (ny + rows - 1) / rows; B.g[2] = (nz + kchunk - 1) / kchunk;
     start[b] = S.tot; S.tot += B.g[0] * B.g[1] * B.g[2];
   }
