@@ -2255,8 +2255,16 @@ struct MLND {
   // (the pair loop over fine x coarse boxes and the upload cost the host 0.7-1 ms per call on a level of a thousand boxes, the GPU idle meanwhile)
   struct ProlongSet { SrcView Cv; BatchSet<NdmProlongB> s; BatchSet<NdmProlong8B> s8; };
   std::map<std::tuple<int, const void *, const void *, int>, ProlongSet> pro;
-  std::map<std::tuple<int, const void *, const void *>, BatchSet<NdfAddB>> adds;
+  unsigned long long base_key = 0;                   // what every descriptor of the solve follows from besides its fields: layout, boundary conditions, spacings (kept descriptor sets, vdn_internal.h)
 };
+// the prolongation sets of a (level, destination, source, kind) kept across solves
+struct NdProKept { KeeperMem mem; unsigned long uid = 0; BatchSet<NdmProlongB> s; BatchSet<NdmProlong8B> s8; };
+static std::map<unsigned long long, NdProKept *> g_ndpro_kept;
+void mlnd_kept_purge(unsigned long uid) {
+  for (auto it = g_ndpro_kept.begin(); it != g_ndpro_kept.end();) {
+    if (uid == 0 || it->second->uid == uid) { keeper_free(&it->second->mem); delete it->second; it = g_ndpro_kept.erase(it); } else ++it;
+  }
+}
 // mode 0: slaves of level n <- P phi_{n-1};  mode 1: dst_n += P src_{n-1};  mode 2: dst_n = P src_{n-1} (dst zeroed first by the caller)
 static void ml_nd_prolong(MLND &S, int n, vdn_multifab *dst, vdn_multifab *src, int mode) {
   static const bool faces_only = !(vdn_env("VDN_NDM_IFACE_FACES") && atoi(vdn_env("VDN_NDM_IFACE_FACES")) == 0);
@@ -2267,6 +2275,15 @@ static void ml_nd_prolong(MLND &S, int n, vdn_multifab *dst, vdn_multifab *src, 
   PS.Cv = make_view(src, nd_coarse_footprints(S.la, n), S.la->owner[n], 0, 1, NVT_C2F);
   const SrcView &Cv = PS.Cv;
   Cv.refresh();
+  GraphKey gk; gk.put(0x7401); gk.put(S.base_key); gk.put(n); gk.put((const void *)dst->base); gk.put((const void *)src->base); gk.put(mode == 0 ? 0 : 1);
+  gk.put((const void *)(S.slave[n] ? S.slave[n]->base : nullptr)); gk.put((const void *)(S.own[n - 1] ? S.own[n - 1]->base : nullptr));
+  NdProKept *kept = nullptr;
+  if (kept_sets_enabled()) {
+    auto itk = g_ndpro_kept.find(gk.h);
+    if (itk != g_ndpro_kept.end()) { PS.s = itk->second->s; PS.s8 = itk->second->s8; PS.s.run(mode, (double *)nullptr, ctx().stream); PS.s8.run(mode, (double *)nullptr, ctx().stream); return; }
+    if (g_ndpro_kept.size() >= 512) mlnd_kept_purge(0);
+    kept = new NdProKept; kept->uid = S.la->uid;
+  }
   static const bool by_parent = !(vdn_env("VDN_NDM_PROLONG8") && atoi(vdn_env("VDN_NDM_PROLONG8")) == 0);
   std::vector<NdmProlongB> v; std::vector<NdmProlong8B> v8;
   const BoxBins cb(Cv.vbox, &Cv.have);
@@ -2301,19 +2318,17 @@ static void ml_nd_prolong(MLND &S, int n, vdn_multifab *dst, vdn_multifab *src, 
       }
     }
   }
-  PS.s.build(v, 0, ctx().stream); PS.s8.build(v8, 0, ctx().stream);
+  if (kept) keeper_begin(&kept->mem);
+  try { PS.s.build(v, 0, ctx().stream); PS.s8.build(v8, 0, ctx().stream); }
+  catch (...) { if (kept) { keeper_end(); keeper_free(&kept->mem); delete kept; } throw; }
+  if (kept) { keeper_end(); kept->s = PS.s; kept->s8 = PS.s8; g_ndpro_kept[gk.h] = kept; }
   PS.s.run(mode, (double *)nullptr, ctx().stream); PS.s8.run(mode, (double *)nullptr, ctx().stream);
 }
 static void ml_nd_add(MLND &S, int n, vdn_multifab *dst, vdn_multifab *src) {
-  const auto key = std::make_tuple(n, (const void *)dst, (const void *)src);
-  auto hit = S.adds.find(key);
-  if (hit == S.adds.end()) {
-    std::vector<NdfAddB> v;
+  GraphKey gk; gk.put(0x7402); gk.put(S.la->uid); gk.put(n); gk.put((const void *)dst->base); gk.put((const void *)src->base);
+  launch_batched_kept<NdfAddB>(gk.h, S.la->uid, [&](std::vector<NdfAddB> &v) {
     for (size_t f = 0; f < S.A[n].size(); f++) { NdfAddB q; q.r = S.r[n][f]; q.a = dst->fabs[f]; q.b = src->fabs[f]; v.push_back(q); }
-    hit = S.adds.emplace(key, BatchSet<NdfAddB>()).first;
-    hit->second.build(v, 0, ctx().stream);
-  }
-  hit->second.run(0, (double *)nullptr, ctx().stream);
+  }, 0, (double *)nullptr, 0, ctx().stream);
 }
 static void ml_nd_interface(MLND &S, int n) {
   if (S.multi[n - 1]) mf_fill_boundary(S.phi[n - 1]);        // the parents of a fine node may sit in a coarse box's ghost nodes
@@ -2377,6 +2392,7 @@ static int ml_nd_solve(vdn_layout *la, vdn_multifab **rh, vdn_multifab **phi, vd
       }
     }
   }
+  { GraphKey gk; gk.put(la->uid); gk.put(bct->serial); gk.put(press_comp0); gk.put(L); for (int q = 0; q < 3 * L; q++) gk.put(dx[q]); S.base_key = gk.h; }
   vdn_multifab *zero[VDN_MAXLEV], *inlev[VDN_MAXLEV], *cov[VDN_MAXLEV];
   for (int n = 0; n < L; n++) {
     S.phi[n] = phi[n]; S.b[n] = T(mf_temp(la, n, 1, 1, 3, true, 0.0)); S.res[n] = T(mf_temp(la, n, 1, 1, 3, true, 0.0));

@@ -603,7 +603,7 @@ void *set_alloc(size_t bytes) {
 }
 void kept_purge(unsigned long uid) {
   if (ctx().inited) HIPCHK(hipStreamSynchronize(ctx().stream));
-  mlcc_kept_purge(uid);
+  mlcc_kept_purge(uid); mlnd_kept_purge(uid);
   if (g_kept.empty()) return;
   for (auto it = g_kept.begin(); it != g_kept.end();) { if (uid == 0 || it->second.uid == uid) { kept_free(it->second); it = g_kept.erase(it); } else ++it; }
 }

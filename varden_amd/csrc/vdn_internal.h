@@ -167,6 +167,7 @@ void  keeper_end();
 void  keeper_free(KeeperMem *m);
 void *set_alloc(size_t bytes);                     // the open KeeperMem, or the arena
 void  mlcc_kept_purge(unsigned long uid);          // amr.hip
+void  mlnd_kept_purge(unsigned long uid);          // mg_nd.hip
 bool graphs_enabled();
 bool graph_replay(unsigned long long key);     // true: the cached graph was launched
 void graph_begin();
