@@ -14,7 +14,9 @@
  * Conventions
  *   - every function returns 0 on success, non-zero on error; the message is
  *     available from vdn_last_error() (reference: bl_error aborts; the Fortran
- *     shim turns non-zero into `error stop`).
+ *     shim turns non-zero into `error stop`).  A HIP error the CALLER left pending on the
+ *     calling thread is cleared at entry (noted once on stderr) and not restored: every
+ *     entry point then reports any launch failure of its own, whatever its code.
  *   - plain pointers and sizes only.  "device" pointers are hipMalloc'ed HBM.
  *   - all floating point data is IEEE f64; arrays use the BoxLib fab layout:
  *         p(lo1-ng:hi1+ng[+nodal1], lo2-ng:..., lo3-ng:..., 1:nc)   column-major,

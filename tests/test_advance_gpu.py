@@ -39,6 +39,40 @@ def test_advance_parity_small(gpu, name, phys, prob):
     G.close()
 
 
+PERX = [[-1, -1], [15, 15], [15, 15]]            # periodic along x, no-slip walls elsewhere
+
+
+@pytest.mark.parametrize("n,name,phys", [(64, "walls", WALLS), (64, "periodic-x", PERX), (128, "walls", WALLS), (128, "periodic-x", PERX)])
+def test_advance_parity_large(gpu, n, name, phys):
+    """the full step against the oracle at the sizes where the production launch forms run INSIDE an oracle-checked step: at
+    64^3 and 128^3 the multigrids have 5-7 levels -- the XCD-ordered 2 x 2 pair colour pass, the LDS-tiled 16^3-64^3 levels, the single-workgroup tail
+    cycles, the fused residual + restriction marches, the nested-iteration starts and mg_predict -- and the Godunov marches run several tiles and
+    chunks per plane with the power-of-two spacing form.  Start-up sequence (initial projection, one pressure iteration) + 2 steps; u, rho, tracer
+    to 1e-9, the pressure to 1e-6, dt bit for bit, equal V-cycle counts of both projections in every step."""
+    from oracle import voracle as vo
+    from varden_amd import advance as adv
+    from varden_amd import driver
+    O = vo.Sim(n, phys, params_for(phys, cflfac=0.9), prob_type=1, init_shrink=0.1, init_iter=1)
+    G = driver.Varden(n, phys, params_for(phys, cflfac=0.9), prob_type=1, init_shrink=0.1, init_iter=1)
+    assert G.initial_projection_stat[0] == O.initial_projection_stat[0], "initial projection: V-cycle counts differ"
+    assert G.dt == O.dt
+    g = 3
+    for step in range(2):
+        O.step(); G.step()
+        assert G.dt == O.dt, "dt diverged at step %d: %r vs %r" % (step, G.dt, O.dt)
+        cg = (adv.last_solver_stats("mac")[0], adv.last_solver_stats("hg")[0])
+        co = (O.mgstat[0].cycles, O.mgstat[1].cycles)
+        assert cg == co, "%d^3 %s step %d: V-cycle counts (MAC, HG) %r on the GPU, %r in the oracle" % (n, name, step, cg, co)
+        for nm, gm, om in (("u", G.unew[0], O.unew), ("s", G.snew[0], O.snew)):
+            a, b = gm.to_numpy()[g:-g, g:-g, g:-g], om.valid()
+            scale = max(float(np.abs(b).max()), 1e-300)
+            err = float(np.abs(a - b).max())
+            assert err <= 1e-9 * scale, "%d^3 %s step %d: %s differs by %.3e (scale %.3e)" % (n, name, step, nm, err, scale)
+        a, b = G.p[0].to_numpy()[1:-1, 1:-1, 1:-1], O.p.valid()
+        assert np.abs((a - a.mean()) - (b - b.mean())).max() <= 1e-6 * max(np.abs(b - b.mean()).max(), 1e-300)
+    G.close()
+
+
 def test_advance_properties_64(gpu):
     """size-independent checks at 64^3 (no oracle run): symmetry of the bubble about x=y=1/2, conservation of
     mass to round-off with the conservative density update (update.f90:250-253) under wall bcs (zero boundary

@@ -718,7 +718,8 @@ def test_composite_launch_variants_agree_bit_for_bit(gpu):
     the defaults -- eight planes per workgroup for the light box-batched kernels (vdn_dev.h batch_ppw), the interface interpolation of the
     nodal solve over box faces only, the composite residual loaded directly as the right-hand side of the coarse correction -- and (b) with one
     plane per workgroup (VDN_BATCH_PPW=1), the interpolation over whole boxes (VDN_NDM_IFACE_FACES=0) and the negated copy + zero-filled
-    correction of round 2 (VDN_NDM_NEG=1).  The switches are read once per process, hence the child processes."""
+    correction of round 2 (VDN_NDM_NEG=1), and (c) with the defaults and the kept descriptor tables bounded to two entries (VDN_KEPT_BOUND=2).  The switches are
+    read once per process, hence the child processes."""
     import os, subprocess, sys, textwrap
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     code = textwrap.dedent("""
@@ -740,9 +741,11 @@ def test_composite_launch_variants_agree_bit_for_bit(gpu):
                     h.update(np.ascontiguousarray(m.to_numpy(f)).tobytes())
         print("HASH", h.hexdigest(), G.dt)
     """ % root)
-    switches = ("VDN_BATCH_PPW", "VDN_NDM_IFACE_FACES", "VDN_NDM_NEG", "VDN_BATCH_YZ", "VDN_NDF_PAIR", "VDN_BATCH_CHUNK", "VDN_MLCC_FUSE1", "VDN_MLCC_GLUE", "VDN_MLCC_RHO", "VDN_FB_FACES", "VDN_NDF_SEGW", "VDN_GOD_SEGW", "VDN_KEEP_SETS", "VDN_BATCH_FLAT", "VDN_NDM_PROLONG8")
+    switches = ("VDN_BATCH_PPW", "VDN_NDM_IFACE_FACES", "VDN_NDM_NEG", "VDN_BATCH_YZ", "VDN_NDF_PAIR", "VDN_BATCH_CHUNK", "VDN_MLCC_FUSE1", "VDN_MLCC_GLUE", "VDN_MLCC_RHO", "VDN_FB_FACES", "VDN_NDF_SEGW", "VDN_GOD_SEGW", "VDN_KEEP_SETS", "VDN_BATCH_FLAT", "VDN_NDM_PROLONG8", "VDN_KEPT_BOUND")
     out = []
-    for extra in ({}, {"VDN_BATCH_PPW": "1", "VDN_NDM_IFACE_FACES": "0", "VDN_NDM_NEG": "1", "VDN_BATCH_YZ": "0", "VDN_NDF_PAIR": "0", "VDN_BATCH_CHUNK": "0", "VDN_MLCC_FUSE1": "0", "VDN_MLCC_GLUE": "0", "VDN_MLCC_RHO": "0", "VDN_FB_FACES": "0", "VDN_NDF_SEGW": "0", "VDN_GOD_SEGW": "0", "VDN_KEEP_SETS": "0", "VDN_BATCH_FLAT": "0", "VDN_NDM_PROLONG8": "0"}):
+    # third run: the kept descriptor tables bounded to two entries each, so that every bound is hit in the MIDDLE of the composite solves of a three-level
+    # step (ADVICE r4: an eviction there must not free the sets the running solve is bound to)
+    for extra in ({}, {"VDN_KEPT_BOUND": "2"}, {"VDN_BATCH_PPW": "1", "VDN_NDM_IFACE_FACES": "0", "VDN_NDM_NEG": "1", "VDN_BATCH_YZ": "0", "VDN_NDF_PAIR": "0", "VDN_BATCH_CHUNK": "0", "VDN_MLCC_FUSE1": "0", "VDN_MLCC_GLUE": "0", "VDN_MLCC_RHO": "0", "VDN_FB_FACES": "0", "VDN_NDF_SEGW": "0", "VDN_GOD_SEGW": "0", "VDN_KEEP_SETS": "0", "VDN_BATCH_FLAT": "0", "VDN_NDM_PROLONG8": "0"}):
         env = dict(os.environ)
         for k in switches:
             env.pop(k, None)
@@ -750,7 +753,7 @@ def test_composite_launch_variants_agree_bit_for_bit(gpu):
         r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600, cwd=root)
         assert r.returncode == 0, r.stderr[-2000:]
         out.append([ln for ln in r.stdout.splitlines() if ln.startswith("HASH")][0])
-    assert out[0] == out[1], out
+    assert out[0] == out[1] == out[2], out
 
 
 def test_periodic_three_level_hierarchy_is_translation_invariant(gpu):

@@ -895,7 +895,7 @@ int ml_cc_solve(vdn_layout *la, vdn_multifab **rh, vdn_multifab **phi, vdn_multi
   if (kept_sets_enabled()) {
     auto itk = g_mlcc_kept.find(key.h);
     if (itk != g_mlcc_kept.end()) { kept = itk->second; hit = true; }
-    else { if (g_mlcc_kept.size() >= 64) mlcc_kept_purge(0); kept = new MLCCKept; kept->uid = la->uid; g_mlcc_kept[key.h] = kept; }
+    else { if ((int)g_mlcc_kept.size() >= kept_bound(64)) { HIPCHK(hipStreamSynchronize(st)); mlcc_kept_purge(0); } kept = new MLCCKept; kept->uid = la->uid; g_mlcc_kept[key.h] = kept; }
     Sp = &kept->S;
   }
   MLCC &S = *Sp;

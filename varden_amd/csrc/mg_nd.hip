@@ -2281,8 +2281,7 @@ static void ml_nd_prolong(MLND &S, int n, vdn_multifab *dst, vdn_multifab *src, 
   if (kept_sets_enabled()) {
     auto itk = g_ndpro_kept.find(gk.h);
     if (itk != g_ndpro_kept.end()) { PS.s = itk->second->s; PS.s8 = itk->second->s8; PS.s.run(mode, (double *)nullptr, ctx().stream); PS.s8.run(mode, (double *)nullptr, ctx().stream); return; }
-    if (g_ndpro_kept.size() >= 512) mlnd_kept_purge(0);
-    kept = new NdProKept; kept->uid = S.la->uid;
+    kept = new NdProKept; kept->uid = S.la->uid;     // (the table is bounded at the entry of ml_nd_solve: sets already bound to this solve must not be freed here)
   }
   static const bool by_parent = !(vdn_env("VDN_NDM_PROLONG8") && atoi(vdn_env("VDN_NDM_PROLONG8")) == 0);
   std::vector<NdmProlongB> v; std::vector<NdmProlong8B> v8;
@@ -2368,6 +2367,7 @@ static int ml_nd_solve(vdn_layout *la, vdn_multifab **rh, vdn_multifab **phi, vd
   REQUIRE(L >= 2 && L <= VDN_MAXLEV, "composite nodal solve: 2..%d levels", VDN_MAXLEV);
   g_nd_iso = nd_isotropic(dx);                         // (the ratio of the spacings is the same on every level)
   hipStream_t st = ctx().stream;
+  if ((int)g_ndpro_kept.size() >= kept_bound(512)) { HIPCHK(hipStreamSynchronize(st)); mlnd_kept_purge(0); }     // before any kept set is bound to this solve
   const size_t mark = arena_mark();
   const vdn_params &P = ctx().prm;
   MLND S; S.nlev = L; S.la = la; S.d_nrm = (double *)arena_alloc(256);

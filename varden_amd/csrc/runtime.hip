@@ -172,6 +172,7 @@ static const EnvSwitch g_switches[] = {
   { "VDN_FB_FACES", "0: the ghost exchanges of the composite cell-centred solve fill edges and corners too" },
   { "VDN_MLCC_RHO", "0: the composite MAC solve reads stored face coefficients on its finest level too" },
   { "VDN_KEEP_SETS", "0: the descriptor arrays of the inter-level operators and composite solves are rebuilt and uploaded at every call" },
+  { "VDN_KEPT_BOUND", "n > 0: the kept descriptor tables hold at most n entries each (default 4096 / 64 / 512): the eviction paths in a test" },
   { "VDN_MLCC_GLUE", "0: the level-0 correction of the composite MAC solve stored and added in separate passes" },
   { "VDN_MLCC_FUSE1", "0: the composite MAC solve's finest-level residual and first colour pass as two launches" },
   { "VDN_BATCH_YZ", "0: no (j,k) / (i,k) tiles for thin ranges in the box-batched kernels" },
@@ -607,8 +608,18 @@ void kept_purge(unsigned long uid) {
   if (g_kept.empty()) return;
   for (auto it = g_kept.begin(); it != g_kept.end();) { if (uid == 0 || it->second.uid == uid) { kept_free(it->second); it = g_kept.erase(it); } else ++it; }
 }
+// the size bounds of the three tables (plain sets here, the groups of the composite solves in amr.hip / mg_nd.hip); VDN_KEPT_BOUND shrinks them for
+// the eviction test (tests/test_amr_gpu.py)
+int kept_bound(int dflt) { static const int env = vdn_env("VDN_KEPT_BOUND") ? atoi(vdn_env("VDN_KEPT_BOUND")) : 0; return env > 0 ? env : dflt; }
 KeptSet *kept_store(unsigned long long key, unsigned long uid, const void *args, size_t arg_bytes, const int *start, int nbox, int tot) {
-  if (g_kept.size() >= 4096) kept_purge(0);          // (temporaries that wander through the arena: bounded, and rebuilt on demand)
+  // Bounded (temporaries that wander through the arena), rebuilt on demand.  This runs INSIDE the composite solves (launch_batched_kept), whose own
+  // groups (MLCCKept, NdProKept) are bound to the running solve: the bound drops the plain entries only -- nobody holds a KeptSet across a store --
+  // and the groups are bounded at the entry of their solves, before any of them is bound
+  if ((int)g_kept.size() >= kept_bound(4096)) {
+    HIPCHK(hipStreamSynchronize(ctx().stream));
+    for (auto &kv : g_kept) kept_free(kv.second);
+    g_kept.clear();
+  }
   KeptSet k; k.nbox = nbox; k.tot = tot; k.uid = uid;
   if (nbox > 0) {
     HIPCHK(hipMalloc(&k.d_args, arg_bytes)); HIPCHK(hipMalloc((void **)&k.d_start, sizeof(int) * nbox));

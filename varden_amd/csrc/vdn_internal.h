@@ -106,13 +106,16 @@ void vdn_set_error(const char *fmt, ...);
 struct VdnErr : std::runtime_error { using std::runtime_error::runtime_error; };
 [[noreturn]] void vdn_fail(const char *fmt, ...);
 #define HIPCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) vdn_fail("%s failed: %s (%s:%d)", #x, hipGetErrorString(e_), __FILE__, __LINE__); } while (0)
-// entry: the error the HOST application may have left on this thread (a failed launch of its own, torch's event queries leave hipErrorNotReady) is
-// LOOKED AT, not cleared -- the host still finds it at its next check.  On the way out a pending error is ours only if it differs from the one seen
-// on entry; the benign hipErrorNotReady residue of our own hipStreamQuery / hipEventQuery polls is the one thing that is cleared.
-#define VDN_TRY try { const hipError_t entry_err_ = hipPeekAtLastError(); if (entry_err_ == hipErrorNotReady) (void)hipGetLastError();
-// the success path of every C-ABI call also asks HIP for a pending launch error (a kernel launch with a bad grid fails silently otherwise)
-#define VDN_CATCH   if (ctx().inited) { hipError_t le_ = hipPeekAtLastError(); if (le_ == hipErrorNotReady) { (void)hipGetLastError(); le_ = hipSuccess; } \
-    if (le_ != hipSuccess && le_ != entry_err_) { (void)hipGetLastError(); vdn_fail("a HIP launch failed inside this call: %s", hipGetErrorString(le_)); } } \
+// entry: an error the HOST application left pending on this thread (a failed launch of its own; torch's event queries leave hipErrorNotReady) is
+// taken off the thread (HIP has no way to look past it) so that EVERY launch failure inside the call is seen on the way out, whatever its code
+// (comparing codes hid a failure of ours that happened to carry the stale code).  A stale error other than hipErrorNotReady is reported
+// once on stderr -- it is the host's, the call goes on -- and is NOT restored: include/varden_amd.h says so under "Error convention".
+#define VDN_TRY try { { const hipError_t entry_err_ = hipGetLastError(); \
+    if (entry_err_ != hipSuccess && entry_err_ != hipErrorNotReady) fprintf(stderr, "varden_amd: note: the caller left a pending HIP error on this thread (%s); cleared at entry\n", hipGetErrorString(entry_err_)); }
+// the success path of every C-ABI call also asks HIP for a pending launch error (a kernel launch with a bad grid fails silently otherwise);
+// hipErrorNotReady is the benign residue of our own hipStreamQuery / hipEventQuery polls
+#define VDN_CATCH   if (ctx().inited) { const hipError_t le_ = hipGetLastError(); \
+    if (le_ != hipSuccess && le_ != hipErrorNotReady) vdn_fail("a HIP launch failed inside this call: %s", hipGetErrorString(le_)); } \
   } catch (const std::exception &e) { vdn_set_error("%s", e.what()); return 1; } return 0;
 // outcome of an elliptic solve: FBoxLib's solvers abort on max_iter (bl_error); so do we unless prm.abort_on_max_iter = 0.
 // A non-finite norm (the reductions turn NaN into +inf) is a failure whatever rc says.  comp >= 0: the component being solved
@@ -159,7 +162,8 @@ struct KeptSet { void *d_args = nullptr; int *d_start = nullptr; int nbox = 0, t
 bool     kept_sets_enabled();
 KeptSet *kept_find(unsigned long long key);
 KeptSet *kept_store(unsigned long long key, unsigned long uid, const void *args, size_t arg_bytes, const int *start, int nbox, int tot);
-void     kept_purge(unsigned long uid);            // uid 0: every entry
+void     kept_purge(unsigned long uid);            // uid 0: every entry (plain sets AND the groups of the composite solves: never from inside a solve)
+int      kept_bound(int dflt);                     // size bound of a kept table (VDN_KEPT_BOUND overrides)
 // ... and whole groups of BatchSets (the composite solves): while a KeeperMem is open, BatchSet::build takes its device memory from it instead of the arena
 struct KeeperMem { std::vector<void *> chunks; char *cur = nullptr; size_t left = 0; };
 void  keeper_begin(KeeperMem *m);
