@@ -151,6 +151,9 @@ void vo_makevort(vo_fab *vort, int comp, const vo_fab *u, const double dx[3], co
 void vo_makemagvel(vo_fab *magvel, int comp, const vo_fab *u);
 void vo_cc_smooth(const vo_fab *rh, vo_fab *phi, vo_fab *beta[3], const double dx[3], const int ellbc[3][2],
                   int nsweeps);
+/* test hooks: the operators the two solvers iterate on, applied once (compared with independently assembled scipy matrices) */
+void vo_cc_apply(const vo_fab *phi, const vo_fab *alpha, vo_fab *beta[3], const double dx[3], const int ellbc[3][2], vo_fab *out);
+void vo_nd_apply(const vo_fab *phi, const vo_fab *coeffs, const double dx[3], const int ellbc[3][2], const int pmask[3], vo_fab *out);
 /* macproject.f90:20-133, single level */
 void vo_macproject(vo_fab *umac[3], vo_fab *rho, const vo_fab *mac_rhs, const double dx[3], const vo_bc *bc,
                    const int pmask[3], const vdn_params *prm, vo_mgstat *st);

@@ -615,6 +615,26 @@ int vo_nd_solve(vo_fab *rh, vo_fab *phi, const vo_fab *coeffs, const vo_fab *u, 
   return conv ? 0 : 1;
 }
 
+/* test hook: out = K phi on the nodes of one level (0 on Dirichlet nodes), K the operator of nd_apply -- what every sweep and residual of the nodal
+ * solver applies -- once.  tests/test_operators_assembled_cpu.py compares it with the Q1 stiffness matrix assembled element by element. */
+void vo_nd_apply(const vo_fab *phi, const vo_fab *coeffs, const double dx[3], const int ellbc[3][2], const int pmask[3], vo_fab *out)
+{
+  ndlev Lv, *L = &Lv; int n[3], per[3];
+  for (int d = 0; d < 3; d++) { n[d] = coeffs->hi[d] - coeffs->lo[d] + 1; per[d] = pmask[d]; }
+  nd_alloc(L, n, dx, 3); nd_set_mask(L, ellbc);
+  for (int k = -1; k <= n[2]; k++) for (int j = -1; j <= n[1]; j++) for (int i = -1; i <= n[0]; i++)
+    L->sig[NS(L, i, j, k)] = VF(coeffs, coeffs->lo[0] + i, coeffs->lo[1] + j, coeffs->lo[2] + k, 0);
+  for (int k = 0; k <= n[2]; k++) for (int j = 0; j <= n[1]; j++) for (int i = 0; i <= n[0]; i++)
+    L->phi[NN(L, i, j, k)] = L->dir[NM(L, i, j, k)] ? 0.0 : VF(phi, phi->lo[0] + i, phi->lo[1] + j, phi->lo[2] + k, 0);
+  nd_fill_nodes(L, L->phi, per);
+  for (int k = 0; k <= n[2]; k++) for (int j = 0; j <= n[1]; j++) for (int i = 0; i <= n[0]; i++) {
+    double Kp = 0.0, diag;
+    if (!L->dir[NM(L, i, j, k)]) nd_apply(L, L->phi, i, j, k, &Kp, &diag);
+    VF(out, out->lo[0] + i, out->lo[1] + j, out->lo[2] + k, 0) = Kp;
+  }
+  nd_free(L);
+}
+
 /* hgproject.f90:17-178 with hg_multigrid.f90:18-119, one level / one box */
 void vo_hgproject(int proj_type, vo_fab *unew, const vo_fab *uold, vo_fab *rhohalf, vo_fab *p, vo_fab *gp,
                   const double dx[3], double dt, const vo_bc *bc, const int pmask[3], const vdn_params *prm,

@@ -537,6 +537,23 @@ void vo_cc_smooth_ab_iface(const vo_fab *rh, vo_fab *phi, const vo_fab *alpha, v
     VF(phi, phi->lo[0] + i, phi->lo[1] + j, phi->lo[2] + k, 0) = PHI(L, i, j, k);
   ccmg_free(&M);
 }
+/* test hook: out = A phi on the valid cells, A = (alpha - div beta grad) with the boundary closure of ccmg_build -- the operator every sweep and
+ * residual of this file applies (cc_apply), once.  phi's ghost cells are not read (homogeneous closure).  tests/test_operators_assembled_cpu.py
+ * compares it with a scipy matrix assembled from SURVEY.md Appendix C.1. */
+void vo_cc_apply(const vo_fab *phi, const vo_fab *alpha, vo_fab *beta[3], const double dx[3], const int ellbc[3][2], vo_fab *out)
+{
+  ccmg M; ccmg_build(&M, alpha, beta, dx, ellbc);
+  cclev *L = &M.lev[0];
+  const int *n = L->n;
+  for (int k = 0; k < n[2]; k++) for (int j = 0; j < n[1]; j++) for (int i = 0; i < n[0]; i++)
+    PHI(L, i, j, k) = VF(phi, phi->lo[0] + i, phi->lo[1] + j, phi->lo[2] + k, 0);
+  cc_fill_periodic(L, M.per);
+  for (int k = 0; k < n[2]; k++) for (int j = 0; j < n[1]; j++) for (int i = 0; i < n[0]; i++) {
+    double Ap, diag; cc_apply(L, i, j, k, &Ap, &diag);
+    VF(out, out->lo[0] + i, out->lo[1] + j, out->lo[2] + k, 0) = Ap;
+  }
+  ccmg_free(&M);
+}
 void vo_cc_smooth(const vo_fab *rh, vo_fab *phi, vo_fab *beta[3], const double dx[3], const int ellbc[3][2], int nsweeps)
 {
   ccmg M; ccmg_build(&M, NULL, beta, dx, ellbc);
