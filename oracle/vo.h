@@ -196,29 +196,83 @@ void vo_advance_timestep(vo_state *S, const double dx[3], double dt, const vo_bc
 /* ---- initdata.f90:201-311 (prob_type 1 and 2) ----------------------------------------------- */
 void vo_initdata(vo_fab *u, vo_fab *s, const double dx[3], int prob_type);
 
-/* ---- two-level AMR (oracle/vo_amr.c): FBoxLib's multi-level operators (our definitions) and the multilevel macproject ---- */
+/* ---- multi-level AMR (oracle/vo_amr.c, vo_hgproject.c): FBoxLib's multi-level operators (our definitions) and the multilevel projections / advance ----
+ * A level of a hierarchy is a LIST OF BOXES (round 5).  Its cell- and node-centred fields are LEVEL ARRAYS: one vo_fab over the bounding box of the
+ * boxes (lo / hi = the bounding box) with `valid` marking the cells of the union -- every such field is single-valued on the level, and a cell outside
+ * the union but inside the allocation holds what a ghost cell there holds in BoxLib (the coarse interpolation, a physical boundary value), whichever box
+ * it is a ghost cell of.  Face-centred MAC velocities, edge states and fluxes are held PER BOX (vo_bmf): the upwinding's dead band is per box
+ * (velpred.f90:1965-1980), so two boxes may disagree on the face they share, as in BoxLib.  A NULL vo_level (or nbox = 1) is the one-box level of
+ * rounds 2-4: the fab's own lo..hi.  Level 0 is one box, the domain.  Periodic sides are not supported on hierarchies here (pmask must be 0). */
+typedef struct vo_level {
+  int nbox;
+  const int *boxes;            /* [nbox][2][3]: lo, hi of every box, cell indices of the level */
+  int blo[3], bhi[3];          /* bounding box */
+  int mg;                      /* `valid` covers blo - mg .. bhi + mg */
+  unsigned char *valid;        /* 1 on the cells of the union; x fastest */
+} vo_level;
+void vo_level_build(vo_level *L, int nbox, const int *boxes);
+void vo_level_free(vo_level *L);
+static inline int vo_valid(const vo_level *L, int i, int j, int k) {
+  const int g = L->mg, nx = L->bhi[0] - L->blo[0] + 1 + 2 * g, ny = L->bhi[1] - L->blo[1] + 1 + 2 * g, nz = L->bhi[2] - L->blo[2] + 1 + 2 * g;
+  const int a = i - L->blo[0] + g, b = j - L->blo[1] + g, c = k - L->blo[2] + g;
+  if (a < 0 || a >= nx || b < 0 || b >= ny || c < 0 || c >= nz) return 0;
+  return L->valid[(size_t)a + (size_t)nx * ((size_t)b + (size_t)ny * (size_t)c)];
+}
+static inline int vo_lv_multi(const vo_level *L) { return L && L->nbox > 1; }
+/* cell (i,j,k) is a cell of the level whose cell-centred level array is f */
+static inline int vo_lv_valid(const vo_level *L, const vo_fab *f, int i, int j, int k) {
+  if (vo_lv_multi(L)) return vo_valid(L, i, j, k);
+  return i >= f->lo[0] && i <= f->hi[0] && j >= f->lo[1] && j <= f->hi[1] && k >= f->lo[2] && k <= f->hi[2];
+}
+/* a face- (or cell-) centred field held box by box */
+typedef struct vo_bmf { int nbox; vo_fab *f; } vo_bmf;
+
+/* the `_g` forms take the box lists (lev: [nlev], an entry may be NULL = one box); the plain forms are the one-box hierarchies of rounds 2-4 */
 void vo_ml_cc_restriction(vo_fab *crse, const vo_fab *fine, int icomp, int nc);
+void vo_ml_cc_restriction_g(vo_fab *crse, const vo_fab *fine, const vo_level *Lf, int icomp, int nc);
 void vo_ml_edge_restriction(vo_fab *crse, const vo_fab *fine, int dir);
+void vo_ml_edge_restriction_g(vo_fab *crse, const vo_fab *fine, const vo_level *Lf, int dir);
 void vo_fill_ghost_cells(vo_fab *fine, const vo_fab *crse, int icomp, int nc);
+void vo_fill_ghost_cells_g(vo_fab *fine, const vo_fab *crse, const vo_level *Lf, int icomp, int nc);
 void vo_create_umac_grown(vo_fab *fine, const vo_fab *crse, int dir);
 void vo_ml_restrict_and_fill(int nlev, vo_fab **mf, int icomp, int bcomp, int nc, int same_boundary, const vo_bc *bc, const int pmask[3],
                              const int *pd, const vdn_params *prm);
+void vo_ml_restrict_and_fill_g(int nlev, const vo_level *const *lev, vo_fab **mf, int icomp, int bcomp, int nc, int same_boundary, const vo_bc *bc, const int pmask[3],
+                               const int *pd, const vdn_params *prm);
 int  vo_ml_cc_solve(int nlev, vo_fab **rh, vo_fab **phi, vo_fab **alpha, vo_fab **beta, const double *dx, const int ellbc[][3][2], const int pmask[3], const int *pd,
                     double rel_eps, int max_iter, const vdn_params *prm, vo_fab **beta_base, vo_mgstat *st);
+/* ghost: [lev*6 + 2 d + side] (may be NULL): on return the value of phi beyond the coarse-fine interface next to each valid cell (arrays indexed like rh) */
+int  vo_ml_cc_solve_g(int nlev, const vo_level *const *lev, vo_fab **rh, vo_fab **phi, vo_fab **alpha, vo_fab **beta, const double *dx, const int ellbc[][3][2], const int pmask[3],
+                      const int *pd, double rel_eps, int max_iter, const vdn_params *prm, vo_fab **beta_base, vo_mgstat *st, double **ghost);
+/* umac: [lev*3 + d], one fab per box of the level */
 void vo_ml_macproject(int nlev, vo_fab **umac, vo_fab **rho, vo_fab **mac_rhs, const double *dx, const vo_bc *bc, const int pmask[3], const int *pd,
                       const vdn_params *prm, vo_mgstat *st);
+void vo_ml_macproject_g(int nlev, const vo_level *const *lev, vo_bmf *umac, vo_fab **rho, vo_fab **mac_rhs, const double *dx, const vo_bc *bc, const int pmask[3], const int *pd,
+                        const vdn_params *prm, vo_mgstat *st);
 
 int  vo_ml_nd_solve(int nlev, vo_fab **rh, vo_fab **phi, vo_fab **coeffs, vo_fab **u, const double *dx, const int ellbc[][3][2], const int pmask[3],
                     double rel_eps, double abs_eps, int max_iter, const vdn_params *prm, vo_mgstat *st);
+int  vo_ml_nd_solve_g(int nlev, const vo_level *const *lev, vo_fab **rh, vo_fab **phi, vo_fab **coeffs, vo_fab **u, const double *dx, const int ellbc[][3][2], const int pmask[3],
+                      const int *pd, double rel_eps, double abs_eps, int max_iter, const vdn_params *prm, vo_mgstat *st);
 void vo_ml_visc_solve(int nlev, vo_fab **unew, vo_fab **lapu, vo_fab **rho, vo_fab **mac_rhs, const double *dx, double mu, const vo_bc *bc,
                       const int pmask[3], const int *pd, const vdn_params *prm, vo_mgstat *st);
+void vo_ml_visc_solve_g(int nlev, const vo_level *const *lev, vo_fab **unew, vo_fab **lapu, vo_fab **rho, vo_fab **mac_rhs, const double *dx, double mu, const vo_bc *bc,
+                        const int pmask[3], const int *pd, const vdn_params *prm, vo_mgstat *st);
 void vo_ml_diff_scalar_solve(int nlev, vo_fab **snew, vo_fab **laps, const double *dx, double mu, const vo_bc *bc, const int pmask[3], const int *pd,
                              const vdn_params *prm, int icomp, int bccomp, vo_mgstat *st);
+void vo_ml_diff_scalar_solve_g(int nlev, const vo_level *const *lev, vo_fab **snew, vo_fab **laps, const double *dx, double mu, const vo_bc *bc, const int pmask[3], const int *pd,
+                               const vdn_params *prm, int icomp, int bccomp, vo_mgstat *st);
 void vo_ml_hgproject(int nlev, int proj_type, vo_fab **unew, vo_fab **uold, vo_fab **rhohalf, vo_fab **p, vo_fab **gp, const double *dx, double dt,
                      const vo_bc *bc, const int pmask[3], const int *pd, const vdn_params *prm, vo_mgstat *st);
+void vo_ml_hgproject_g(int nlev, const vo_level *const *lev, int proj_type, vo_fab **unew, vo_fab **uold, vo_fab **rhohalf, vo_fab **p, vo_fab **gp, const double *dx, double dt,
+                       const vo_bc *bc, const int pmask[3], const int *pd, const vdn_params *prm, vo_mgstat *st);
 
 void vo_ml_advance_timestep(int nlev, vo_state *S, const double *dx, double dt, const vo_bc *bc, const int pmask[3], const int *pd, const vdn_params *prm,
                             int proj_type, vo_mgstat st[2]);
+void vo_ml_advance_timestep_g(int nlev, const vo_level *const *lev, vo_state *S, const double *dx, double dt, const vo_bc *bc, const int pmask[3], const int *pd,
+                              const vdn_params *prm, int proj_type, vo_mgstat st[2]);
+/* estdt (estdt.f90:15-78) of one level of a hierarchy: the minimum over its boxes */
+double vo_estdt_g(const vo_level *L, const vo_fab *u, const vo_fab *s, const vo_fab *gp, const vo_fab *ext, const double dx[3], double dtold, const vdn_params *prm);
 
 /* ---- the 2-D path (oracle/vo_2d.c): velpred_2d, mkflux_2d, update_2d, mkforce 2-D, estdt_2d, macproject / hgproject
  *      2-D kernels, our 5-point cell-centred and 9-point nodal multigrids, advance_timestep with dm = 2 ------------ */

@@ -17,8 +17,9 @@
  *                         mean of the four fine fluxes.  Algorithm: FAC iteration -- composite residual, one V-cycle of
  *                         nu1 red-black sweeps on the fine level (homogeneous interface), one V-cycle of the single-level
  *                         multigrid on the whole coarse level, piecewise-constant prolongation, nu2 fine sweeps.
- * This round: ONE box per level, two levels, refinement ratio 2, the fine box properly nested (>= 1 coarse cell away from
- * any domain face it does not touch).
+ * Refinement ratio 2, up to four levels, every refined level a LIST OF BOXES (round 5: level arrays with a cell mask, face fields box by box -- vo.h);
+ * the levels properly nested (every box, coarsened and grown by two cells, inside the next coarser level or outside the domain).  Level 0 is one box;
+ * no periodic sides on a hierarchy.
  */
 #include <math.h>
 #include <stdlib.h>
@@ -41,16 +42,45 @@ static inline int in_alloc(const vo_fab *f, int i, int j, int k)
          k >= f->lo[2] - f->gz && k <= f->hi[2] + f->nd[2] + f->gz;
 }
 
-void vo_ml_cc_restriction(vo_fab *crse, const vo_fab *fine, int icomp, int nc)
+/* ---- levels as box lists (vo.h) ---------------------------------------------------------------------------------------------------------- */
+void vo_level_build(vo_level *L, int nbox, const int *boxes)
+{
+  L->nbox = nbox; L->boxes = boxes; L->mg = 4;
+  for (int d = 0; d < 3; d++) { L->blo[d] = boxes[d]; L->bhi[d] = boxes[3 + d]; }
+  for (int b = 1; b < nbox; b++) for (int d = 0; d < 3; d++) {
+    if (boxes[6 * b + d] < L->blo[d]) L->blo[d] = boxes[6 * b + d];
+    if (boxes[6 * b + 3 + d] > L->bhi[d]) L->bhi[d] = boxes[6 * b + 3 + d];
+  }
+  const int g = L->mg;
+  const size_t nx = (size_t)(L->bhi[0] - L->blo[0] + 1 + 2 * g), ny = (size_t)(L->bhi[1] - L->blo[1] + 1 + 2 * g), nz = (size_t)(L->bhi[2] - L->blo[2] + 1 + 2 * g);
+  L->valid = (unsigned char *)calloc(nx * ny * nz, 1);
+  for (int b = 0; b < nbox; b++) {
+    const int *lo = boxes + 6 * b, *hi = lo + 3;
+    for (int k = lo[2]; k <= hi[2]; k++) for (int j = lo[1]; j <= hi[1]; j++) for (int i = lo[0]; i <= hi[0]; i++) {
+      unsigned char *v = &L->valid[(size_t)(i - L->blo[0] + g) + nx * ((size_t)(j - L->blo[1] + g) + ny * (size_t)(k - L->blo[2] + g))];
+      if (*v) { fprintf(stderr, "vo_level_build: boxes %d overlaps another box\n", b); abort(); }
+      *v = 1;
+    }
+  }
+}
+void vo_level_free(vo_level *L) { free(L->valid); L->valid = NULL; }
+#define lv_valid vo_lv_valid
+#define lv_multi vo_lv_multi
+
+void vo_ml_cc_restriction(vo_fab *crse, const vo_fab *fine, int icomp, int nc) { vo_ml_cc_restriction_g(crse, fine, NULL, icomp, nc); }
+void vo_ml_cc_restriction_g(vo_fab *crse, const vo_fab *fine, const vo_level *Lf, int icomp, int nc)
 {
   for (int c = icomp; c < icomp + nc; c++)
   for (int K = fine->lo[2] / 2; K <= fine->hi[2] / 2; K++) for (int J = fine->lo[1] / 2; J <= fine->hi[1] / 2; J++) for (int I = fine->lo[0] / 2; I <= fine->hi[0] / 2; I++) {
+    if (lv_multi(Lf) && !vo_valid(Lf, 2 * I, 2 * J, 2 * K)) continue;          /* boxes are coarse-aligned: all eight children or none */
     double s = 0.0;
     for (int kk = 0; kk < 2; kk++) for (int jj = 0; jj < 2; jj++) for (int ii = 0; ii < 2; ii++) s = s + VF(fine, 2 * I + ii, 2 * J + jj, 2 * K + kk, c);
     VF(crse, I, J, K, c) = s * 0.125;
   }
 }
-void vo_ml_edge_restriction(vo_fab *crse, const vo_fab *fine, int dir)
+void vo_ml_edge_restriction(vo_fab *crse, const vo_fab *fine, int dir) { vo_ml_edge_restriction_g(crse, fine, NULL, dir); }
+/* level arrays of a single-valued face field (the solvers' face coefficients): a coarse face is covered where a fine cell on either side of it is */
+void vo_ml_edge_restriction_g(vo_fab *crse, const vo_fab *fine, const vo_level *Lf, int dir)
 {
   int lo[3], hi[3];
   for (int d = 0; d < 3; d++) { lo[d] = fine->lo[d] / 2; hi[d] = fine->hi[d] / 2; }
@@ -58,6 +88,10 @@ void vo_ml_edge_restriction(vo_fab *crse, const vo_fab *fine, int dir)
   const int t1 = (dir + 1) % 3, t2 = (dir + 2) % 3;
   for (int K = lo[2]; K <= hi[2]; K++) for (int J = lo[1]; J <= hi[1]; J++) for (int I = lo[0]; I <= hi[0]; I++) {
     int Q[3] = { I, J, K };
+    if (lv_multi(Lf)) {
+      int qa[3] = { 2 * I, 2 * J, 2 * K }, qb[3] = { 2 * I, 2 * J, 2 * K }; qb[dir] -= 1;
+      if (!vo_valid(Lf, qa[0], qa[1], qa[2]) && !vo_valid(Lf, qb[0], qb[1], qb[2])) continue;
+    }
     double s = 0.0;
     for (int b = 0; b < 2; b++) for (int a = 0; a < 2; a++) {
       int q[3]; q[dir] = 2 * Q[dir]; q[t1] = 2 * Q[t1] + a; q[t2] = 2 * Q[t2] + b;
@@ -66,13 +100,15 @@ void vo_ml_edge_restriction(vo_fab *crse, const vo_fab *fine, int dir)
     VF(crse, I, J, K, 0) = s * 0.25;
   }
 }
-/* every ghost cell of the fine fab whose parent lies inside the coarse fab's allocation */
-void vo_fill_ghost_cells(vo_fab *fine, const vo_fab *crse, int icomp, int nc)
+/* every cell of the fine level array that is not a cell of the level and whose parent lies inside the coarse array's allocation (a level of several
+ * boxes: also the cells between the boxes -- each is a ghost cell of the boxes within ng cells of it, with the value BoxLib puts there) */
+void vo_fill_ghost_cells(vo_fab *fine, const vo_fab *crse, int icomp, int nc) { vo_fill_ghost_cells_g(fine, crse, NULL, icomp, nc); }
+void vo_fill_ghost_cells_g(vo_fab *fine, const vo_fab *crse, const vo_level *Lf, int icomp, int nc)
 {
   const int ng = fine->ng;
   for (int c = icomp; c < icomp + nc; c++)
   for (int k = fine->lo[2] - ng; k <= fine->hi[2] + ng; k++) for (int j = fine->lo[1] - ng; j <= fine->hi[1] + ng; j++) for (int i = fine->lo[0] - ng; i <= fine->hi[0] + ng; i++) {
-    if (i >= fine->lo[0] && i <= fine->hi[0] && j >= fine->lo[1] && j <= fine->hi[1] && k >= fine->lo[2] && k <= fine->hi[2]) continue;
+    if (lv_valid(Lf, fine, i, j, k)) continue;
     const int q[3] = { i, j, k }, P[3] = { fdiv2(i), fdiv2(j), fdiv2(k) };
     if (!in_alloc(crse, P[0], P[1], P[2])) continue;
     const double c0 = VF(crse, P[0], P[1], P[2], c);
@@ -169,113 +205,187 @@ static void level_fill_boundary(vo_fab *f, const int pmask[3], const int pdlo[3]
   for (int d = 0; d < 3; d++) pm[d] = pmask[d] && f->lo[d] == pdlo[d] && f->hi[d] == pdhi[d];
   vo_fill_boundary(f, pm);
 }
-/* ml_restrict_and_fill for two levels: average down, coarse ghosts, fine ghosts (coarse interpolation, then same-level
- * periodic images, then the physical boundary) */
+static void require_no_periodic(int nlev, const vo_level *const *lev, const int pmask[3], const char *who)
+{
+  int multi = 0;
+  for (int n = 0; lev && n < nlev; n++) if (lv_multi(lev[n])) multi = 1;
+  if (multi && (pmask[0] || pmask[1] || pmask[2])) { fprintf(stderr, "%s: levels of several boxes on a periodic domain are not supported by the oracle\n", who); abort(); }
+}
+#define LEV(lev, n) ((lev) ? (lev)[n] : NULL)
+/* ml_restrict_and_fill: average down, then per level the coarse-fine ghost interpolation, the same-level periodic images, the physical boundary.
+ * (On a level array the same-level exchange between boxes is the identity: a ghost cell inside another box IS that box's cell.) */
 void vo_ml_restrict_and_fill(int nlev, vo_fab **mf, int icomp, int bcomp, int nc, int same_boundary, const vo_bc *bc, const int pmask[3],
                              const int *pd /* [lev][2][3] */, const vdn_params *prm)
 {
-  for (int n = nlev - 1; n >= 1; n--) vo_ml_cc_restriction(mf[n - 1], mf[n], icomp, nc);
+  vo_ml_restrict_and_fill_g(nlev, NULL, mf, icomp, bcomp, nc, same_boundary, bc, pmask, pd, prm);
+}
+void vo_ml_restrict_and_fill_g(int nlev, const vo_level *const *lev, vo_fab **mf, int icomp, int bcomp, int nc, int same_boundary, const vo_bc *bc, const int pmask[3],
+                               const int *pd, const vdn_params *prm)
+{
+  require_no_periodic(nlev, lev, pmask, "vo_ml_restrict_and_fill");
+  for (int n = nlev - 1; n >= 1; n--) vo_ml_cc_restriction_g(mf[n - 1], mf[n], LEV(lev, n), icomp, nc);
   for (int n = 0; n < nlev; n++) {
-    if (n > 0) vo_fill_ghost_cells(mf[n], mf[n - 1], icomp, nc);
+    if (n > 0) vo_fill_ghost_cells_g(mf[n], mf[n - 1], LEV(lev, n), icomp, nc);
     level_fill_boundary(mf[n], pmask, pd + 6 * n, pd + 6 * n + 3);
     for (int c = 0; c < nc; c++) vo_physbc(mf[n], icomp + c, same_boundary ? bcomp : bcomp + c, 1, &bc[n], prm);
   }
 }
 
 /* ---------------------------------------------------------------------------------------------------------------------
- * composite cell-centred solve, two levels
+ * composite cell-centred solve
+ *
+ * Levels are level arrays with a cell mask (vo.h).  The value of a field beyond a cell's face is: the neighbouring cell where that is a cell of the
+ * level; the solver's closure where the face is a domain face (Neumann: the cell's own value, Dirichlet: minus it -- or, in the relaxation, zero with
+ * the closure folded into the face coefficient: b := 0 / 2 b); else the coarse-fine interface value, held PER CELL AND DIRECTION (gh[2 d + side]): at a
+ * re-entrant corner of a union of boxes the same ghost position is reached from two directions with two different interpolated values, exactly as
+ * the ghost cells of two different boxes hold them in BoxLib.
  * ------------------------------------------------------------------------------------------------------------------- */
-/* ghost layer of phi on one level: domain faces by the solver's closure (Neumann: phi_i, Dirichlet: -phi_i), periodic images */
-static void phi_closure(vo_fab *phi, const int ellbc[3][2], const int pmask[3], const int pdlo[3], const int pdhi[3])
+#define VO_MAXLEV 4
+typedef const int (*ellbc_t)[3][2];
+typedef struct clev {
+  const vo_level *L;
+  vo_fab *rh, *phi, *alpha, **beta;
+  const double *dx; const int (*ell)[2]; const int *pdlo, *pdhi;
+  vo_fab res, e, t;
+  double *gphi[6], *ge[6];          /* interface values of phi / of the correction e next to each valid cell (indexed like res) */
+  long ncell;
+} clev;
+static inline long cidx(const clev *M, int i, int j, int k) { return vo_idx(&M->res, i, j, k, 0); }
+static inline int cvalid(const clev *M, int i, int j, int k) { return lv_valid(M->L, &M->res, i, j, k); }
+static inline int in_domain1(const clev *M, int d, int q) { return q >= M->pdlo[d] && q <= M->pdhi[d]; }
+/* value of F beyond face (d, s) of the valid cell (i,j,k) whose own value is p0, as the OPERATOR OF THE RESIDUAL reads it */
+static inline double nb_res(const clev *M, const vo_fab *F, double *const G[6], int i, int j, int k, int d, int s, double p0)
 {
-  const int *lo = phi->lo, *hi = phi->hi;
-  for (int d = 0; d < 3; d++) for (int s = 0; s < 2; s++) {
-    if (ellbc[d][s] != VDN_BC_NEU && ellbc[d][s] != VDN_BC_DIR) continue;
-    const int t1 = (d + 1) % 3, t2 = (d + 2) % 3;
-    for (int b2 = lo[t2]; b2 <= hi[t2]; b2++) for (int b1 = lo[t1]; b1 <= hi[t1]; b1++) {
-      int q[3], g[3]; q[t1] = g[t1] = b1; q[t2] = g[t2] = b2; q[d] = s ? hi[d] : lo[d]; g[d] = s ? hi[d] + 1 : lo[d] - 1;
-      const double v = VF(phi, q[0], q[1], q[2], 0);
-      VF(phi, g[0], g[1], g[2], 0) = (ellbc[d][s] == VDN_BC_NEU) ? v : -v;
-    }
-  }
-  level_fill_boundary(phi, pmask, pdlo, pdhi);
+  int q[3] = { i, j, k }; q[d] += s ? 1 : -1;
+  if (!in_domain1(M, d, q[d])) return M->ell[d][s] == VDN_BC_NEU ? p0 : -p0;
+  if (cvalid(M, q[0], q[1], q[2])) return VF(F, q[0], q[1], q[2], 0);
+  return G[2 * d + s][cidx(M, i, j, k)];
 }
-/* coarse-fine ghost cells of the fine phi on the faces of the fine box that are not domain faces */
-static void cf_interp(vo_fab *pf, const vo_fab *pc, const int ellbc_f[3][2])
+/* ... and as the RELAXATION reads it (zero beyond a domain face) */
+static inline double nb_rlx(const clev *M, const vo_fab *F, double *const G[6], int i, int j, int k, int d, int s)
 {
-  const int *lo = pf->lo, *hi = pf->hi;
+  int q[3] = { i, j, k }; q[d] += s ? 1 : -1;
+  if (!in_domain1(M, d, q[d])) return 0.0;
+  if (cvalid(M, q[0], q[1], q[2])) return VF(F, q[0], q[1], q[2], 0);
+  return G[2 * d + s][cidx(M, i, j, k)];
+}
+/* the coarse field pc at coarse cell Q as the interpolation reads it: a cell of the coarse level, or its closure beyond a domain face */
+static inline double crse_val(const clev *C, const vo_fab *pc, const int Q[3])
+{
+  int q[3] = { Q[0], Q[1], Q[2] }; double w = 1.0;
+  for (int d = 0; d < 3; d++) {
+    if (q[d] < C->pdlo[d]) { q[d] = C->pdlo[d]; if (C->ell[d][0] != VDN_BC_NEU) w = -w; }
+    else if (q[d] > C->pdhi[d]) { q[d] = C->pdhi[d]; if (C->ell[d][1] != VDN_BC_NEU) w = -w; }
+  }
+  return w * VF(pc, q[0], q[1], q[2], 0);
+}
+/* interface values of the fine field pf (level F) from the coarse field pc (level C): quadratic interpolation normal to the interface (8/15, 2/3, -1/5)
+ * of the coarse parent -- moved to the ghost cell's transverse position by central differences of the coarse field, +-1/8 each -- and the two fine
+ * cells inside */
+static void cf_interp(const clev *F, const clev *C, const vo_fab *pf, const vo_fab *pc, double *G[6])
+{
+  const vo_fab *r = &F->res;
   for (int d = 0; d < 3; d++) for (int s = 0; s < 2; s++) {
-    if (ellbc_f[d][s] != VDN_BC_INT) continue;
     const int t1 = (d + 1) % 3, t2 = (d + 2) % 3;
     const int ta = t1 < t2 ? t1 : t2, tb = t1 < t2 ? t2 : t1;
-    for (int b2 = lo[tb]; b2 <= hi[tb]; b2++) for (int b1 = lo[ta]; b1 <= hi[ta]; b1++) {
-      int g[3], f1[3], f2[3]; g[ta] = f1[ta] = f2[ta] = b1; g[tb] = f1[tb] = f2[tb] = b2;
-      g[d] = s ? hi[d] + 1 : lo[d] - 1; f1[d] = s ? hi[d] : lo[d]; f2[d] = s ? hi[d] - 1 : lo[d] + 1;
+    for (int k = r->lo[2]; k <= r->hi[2]; k++) for (int j = r->lo[1]; j <= r->hi[1]; j++) for (int i = r->lo[0]; i <= r->hi[0]; i++) {
+      if (!cvalid(F, i, j, k)) continue;
+      int g[3] = { i, j, k }, f2[3] = { i, j, k }; g[d] += s ? 1 : -1; f2[d] += s ? -1 : 1;
+      if (!in_domain1(F, d, g[d]) || cvalid(F, g[0], g[1], g[2])) continue;
       const int P[3] = { fdiv2(g[0]), fdiv2(g[1]), fdiv2(g[2]) };
-      double pcs = VF(pc, P[0], P[1], P[2], 0);
+      double pcs = crse_val(C, pc, P);
       const int tt[2] = { ta, tb };
       for (int n = 0; n < 2; n++) {
         const int t = tt[n];
         int m[3] = { P[0], P[1], P[2] }, p[3] = { P[0], P[1], P[2] }; m[t] -= 1; p[t] += 1;
         const double sg = (g[t] - 2 * P[t]) ? 0.125 : -0.125;
-        pcs = pcs + sg * (VF(pc, p[0], p[1], p[2], 0) - VF(pc, m[0], m[1], m[2], 0));
+        pcs = pcs + sg * (crse_val(C, pc, p) - crse_val(C, pc, m));
       }
-      VF(pf, g[0], g[1], g[2], 0) = (8.0 / 15.0) * pcs + (2.0 / 3.0) * VF(pf, f1[0], f1[1], f1[2], 0) - 0.2 * VF(pf, f2[0], f2[1], f2[2], 0);
+      G[2 * d + s][cidx(F, i, j, k)] = (8.0 / 15.0) * pcs + (2.0 / 3.0) * VF(pf, i, j, k, 0) - 0.2 * VF(pf, f2[0], f2[1], f2[2], 0);
     }
   }
 }
-/* res = rh - A phi on the valid cells of one level, phi's ghost layer already filled; returns the max-norm over cells
- * where mask (may be NULL) is 0 */
-static double plain_residual(const vo_fab *rh, const vo_fab *phi, const vo_fab *alpha, vo_fab *beta[3], const double dx[3], vo_fab *res)
+/* out = rhs - A F on the valid cells (A's expression order: cc_apply of vo_macproject.c); returns the max-norm */
+static double plain_residual(const clev *M, const vo_fab *rhs, const vo_fab *F, double *const G[6], vo_fab *out)
 {
-  const int *lo = rh->lo, *hi = rh->hi;
+  const vo_fab *r = &M->res; const double *dx = M->dx;
   const double hi2[3] = { 1.0 / (dx[0] * dx[0]), 1.0 / (dx[1] * dx[1]), 1.0 / (dx[2] * dx[2]) };
   double nrm = 0.0;
-  for (int k = lo[2]; k <= hi[2]; k++) for (int j = lo[1]; j <= hi[1]; j++) for (int i = lo[0]; i <= hi[0]; i++) {
-    const double p0 = VF(phi, i, j, k, 0);
-    const double ax = (VF(beta[0], i + 1, j, k, 0) * (p0 - VF(phi, i + 1, j, k, 0)) + VF(beta[0], i, j, k, 0) * (p0 - VF(phi, i - 1, j, k, 0))) * hi2[0];
-    const double ay = (VF(beta[1], i, j + 1, k, 0) * (p0 - VF(phi, i, j + 1, k, 0)) + VF(beta[1], i, j, k, 0) * (p0 - VF(phi, i, j - 1, k, 0))) * hi2[1];
-    const double az = (VF(beta[2], i, j, k + 1, 0) * (p0 - VF(phi, i, j, k + 1, 0)) + VF(beta[2], i, j, k, 0) * (p0 - VF(phi, i, j, k - 1, 0))) * hi2[2];
+  for (int k = r->lo[2]; k <= r->hi[2]; k++) for (int j = r->lo[1]; j <= r->hi[1]; j++) for (int i = r->lo[0]; i <= r->hi[0]; i++) {
+    if (!cvalid(M, i, j, k)) continue;
+    const double p0 = VF(F, i, j, k, 0);
+    const double ax = (VF(M->beta[0], i + 1, j, k, 0) * (p0 - nb_res(M, F, G, i, j, k, 0, 1, p0)) + VF(M->beta[0], i, j, k, 0) * (p0 - nb_res(M, F, G, i, j, k, 0, 0, p0))) * hi2[0];
+    const double ay = (VF(M->beta[1], i, j + 1, k, 0) * (p0 - nb_res(M, F, G, i, j, k, 1, 1, p0)) + VF(M->beta[1], i, j, k, 0) * (p0 - nb_res(M, F, G, i, j, k, 1, 0, p0))) * hi2[1];
+    const double az = (VF(M->beta[2], i, j, k + 1, 0) * (p0 - nb_res(M, F, G, i, j, k, 2, 1, p0)) + VF(M->beta[2], i, j, k, 0) * (p0 - nb_res(M, F, G, i, j, k, 2, 0, p0))) * hi2[2];
     double Ap = ax + ay + az;
-    if (alpha) Ap = Ap + VF(alpha, i, j, k, 0) * p0;
-    const double r = VF(rh, i, j, k, 0) - Ap;
-    VF(res, i, j, k, 0) = r;
-    nrm = vo_nrm_acc(nrm, r);
+    if (M->alpha) Ap = Ap + VF(M->alpha, i, j, k, 0) * p0;
+    const double rr = VF(rhs, i, j, k, 0) - Ap;
+    VF(out, i, j, k, 0) = rr;
+    nrm = vo_nrm_acc(nrm, rr);
   }
   return nrm;
 }
-/* Neumann domain faces carry no flux: the plain residual above would use beta*(phi_i - ghost) with ghost = phi_i = 0 flux, and
- * Dirichlet faces beta*(phi_i - (-phi_i)) = the 2b closure -- so the closure ghosts make the plain stencil exact. */
-
-/* flux matching: replace, in the residual of the uncovered coarse cells next to the fine box, the coarse flux through each
- * interface face by the mean of the four fine fluxes */
-static void reflux_residual(vo_fab *res_c, const vo_fab *phi_c, vo_fab *beta_c[3], const double dxc[3],
-                            const vo_fab *phi_f, vo_fab *beta_f[3], const double dxf[3], const int ellbc_f[3][2])
+/* nsweeps red-black Gauss-Seidel sweeps of A F = rhs on the valid cells; interface values G held (NULL: zero); colour by the level array's index
+ * (the boxes of a refined level start at even indices: the colour of the global index) */
+static void relax(const clev *M, const vo_fab *rhs, vo_fab *F, double *const G[6], int nsweeps)
 {
-  const int *flo = phi_f->lo, *fhi = phi_f->hi;
+  const vo_fab *r = &M->res; const double *dx = M->dx;
+  const double hi2[3] = { 1.0 / (dx[0] * dx[0]), 1.0 / (dx[1] * dx[1]), 1.0 / (dx[2] * dx[2]) };
+  double *zero[6]; double *Z = NULL;
+  if (!G) { Z = (double *)calloc((size_t)M->ncell, sizeof(double)); for (int q = 0; q < 6; q++) zero[q] = Z; G = zero; }
+  for (int s = 0; s < nsweeps; s++) for (int color = 0; color < 2; color++) {
+    #pragma omp parallel for collapse(2) schedule(static)
+    for (int k = r->lo[2]; k <= r->hi[2]; k++) for (int j = r->lo[1]; j <= r->hi[1]; j++)
+      for (int i = r->lo[0] + (((j - r->lo[1]) + (k - r->lo[2]) + color) & 1); i <= r->hi[0]; i += 2) {
+        if (!cvalid(M, i, j, k)) continue;
+        double b[3][2];
+        for (int d = 0; d < 3; d++) for (int sd = 0; sd < 2; sd++) {
+          int f[3] = { i, j, k }, q[3] = { i, j, k }; f[d] += sd; q[d] += sd ? 1 : -1;
+          double v = VF(M->beta[d], f[0], f[1], f[2], 0);
+          if (!in_domain1(M, d, q[d])) { if (M->ell[d][sd] == VDN_BC_NEU) v = 0.0; else if (M->ell[d][sd] == VDN_BC_DIR) v = 2.0 * v; }
+          b[d][sd] = v;
+        }
+        const double p0 = VF(F, i, j, k, 0);
+        const double ax = (b[0][1] * (p0 - nb_rlx(M, F, G, i, j, k, 0, 1)) + b[0][0] * (p0 - nb_rlx(M, F, G, i, j, k, 0, 0))) * hi2[0];
+        const double ay = (b[1][1] * (p0 - nb_rlx(M, F, G, i, j, k, 1, 1)) + b[1][0] * (p0 - nb_rlx(M, F, G, i, j, k, 1, 0))) * hi2[1];
+        const double az = (b[2][1] * (p0 - nb_rlx(M, F, G, i, j, k, 2, 1)) + b[2][0] * (p0 - nb_rlx(M, F, G, i, j, k, 2, 0))) * hi2[2];
+        double Ap = ax + ay + az;
+        double diag = (b[0][1] + b[0][0]) * hi2[0] + (b[1][1] + b[1][0]) * hi2[1] + (b[2][1] + b[2][0]) * hi2[2];
+        if (M->alpha) { const double a0 = VF(M->alpha, i, j, k, 0); Ap = Ap + a0 * p0; diag = diag + a0; }
+        if (diag != 0.0) VF(F, i, j, k, 0) = p0 + (VF(rhs, i, j, k, 0) - Ap) / diag;
+      }
+  }
+  free(Z);
+}
+static inline int covered_by(const clev *F, int I, int J, int K) { return cvalid(F, 2 * I, 2 * J, 2 * K); }
+/* flux matching: in the residual of the uncovered coarse cells next to the fine level, replace the coarse flux through each interface face by the mean
+ * of the four fine fluxes.  Faces in the order x-lo, x-hi, y-lo, y-hi, z-lo, z-hi of the FINE level (lo: the fine level lies on the high side). */
+static void reflux_residual(const clev *C, const clev *F, vo_fab *res_c, const vo_fab *phi_c, const vo_fab *phi_f, double *const Gf[6])
+{
+  const vo_fab *r = &C->res;
   for (int d = 0; d < 3; d++) for (int s = 0; s < 2; s++) {
-    if (ellbc_f[d][s] != VDN_BC_INT) continue;
     const int t1 = (d + 1) % 3, t2 = (d + 2) % 3;
-    const int ff = s ? fhi[d] + 1 : flo[d];              /* fine face index of the interface */
-    const int Fc = ff / 2;                                /* coarse face index */
-    for (int B2 = flo[t2] / 2; B2 <= fhi[t2] / 2; B2++) for (int B1 = flo[t1] / 2; B1 <= fhi[t1] / 2; B1++) {
+    for (int k = r->lo[2]; k <= r->hi[2]; k++) for (int j = r->lo[1]; j <= r->hi[1]; j++) for (int i = r->lo[0]; i <= r->hi[0]; i++) {
+      /* (i,j,k): the UNCOVERED coarse cell; the covered one lies beyond its hi face (s = 0) or its lo face (s = 1) */
+      if (!cvalid(C, i, j, k) || covered_by(F, i, j, k)) continue;
+      int cv[3] = { i, j, k }; cv[d] += s ? -1 : 1;
+      if (!in_domain1(C, d, cv[d]) || !cvalid(C, cv[0], cv[1], cv[2]) || !covered_by(F, cv[0], cv[1], cv[2])) continue;
+      int Q[3] = { i, j, k }; if (s == 0) Q[d] += 1;            /* the coarse face, index of its high cell */
+      int M_[3] = { Q[0], Q[1], Q[2] }; M_[d] -= 1;
       double sum = 0.0;
       for (int b = 0; b < 2; b++) for (int a = 0; a < 2; a++) {
-        int q[3], m[3]; q[d] = ff; q[t1] = 2 * B1 + a; q[t2] = 2 * B2 + b; m[0] = q[0]; m[1] = q[1]; m[2] = q[2]; m[d] -= 1;
-        sum = sum + VF(beta_f[d], q[0], q[1], q[2], 0) * (VF(phi_f, q[0], q[1], q[2], 0) - VF(phi_f, m[0], m[1], m[2], 0)) / dxf[d];
+        int q[3], m[3]; q[d] = 2 * Q[d]; q[t1] = 2 * Q[t1] + a; q[t2] = 2 * Q[t2] + b; m[0] = q[0]; m[1] = q[1]; m[2] = q[2]; m[d] -= 1;
+        /* s = 0: q is a fine cell, m lies beyond its lo face; s = 1: m is a fine cell, q beyond its hi face */
+        const double vq = s == 0 ? VF(phi_f, q[0], q[1], q[2], 0) : Gf[2 * d + 1][cidx(F, m[0], m[1], m[2])];
+        const double vm = s == 0 ? Gf[2 * d + 0][cidx(F, q[0], q[1], q[2])] : VF(phi_f, m[0], m[1], m[2], 0);
+        sum = sum + VF(F->beta[d], q[0], q[1], q[2], 0) * (vq - vm) / F->dx[d];
       }
       const double Ff = sum * 0.25;
-      int Q[3], M[3]; Q[d] = Fc; Q[t1] = B1; Q[t2] = B2; M[0] = Q[0]; M[1] = Q[1]; M[2] = Q[2]; M[d] -= 1;
-      const double Fcrs = VF(beta_c[d], Q[0], Q[1], Q[2], 0) * (VF(phi_c, Q[0], Q[1], Q[2], 0) - VF(phi_c, M[0], M[1], M[2], 0)) / dxc[d];
-      /* r = rh + (F_hi - F_lo)/h:  lo side of the fine box: the interface is the HI face of the uncovered cell M */
-      if (s == 0) VF(res_c, M[0], M[1], M[2], 0) = VF(res_c, M[0], M[1], M[2], 0) + (Ff - Fcrs) / dxc[d];
-      else        VF(res_c, Q[0], Q[1], Q[2], 0) = VF(res_c, Q[0], Q[1], Q[2], 0) - (Ff - Fcrs) / dxc[d];
+      const double Fcrs = VF(C->beta[d], Q[0], Q[1], Q[2], 0) * (VF(phi_c, Q[0], Q[1], Q[2], 0) - VF(phi_c, M_[0], M_[1], M_[2], 0)) / C->dx[d];
+      if (s == 0) VF(res_c, M_[0], M_[1], M_[2], 0) = VF(res_c, M_[0], M_[1], M_[2], 0) + (Ff - Fcrs) / C->dx[d];
+      else        VF(res_c, Q[0], Q[1], Q[2], 0) = VF(res_c, Q[0], Q[1], Q[2], 0) - (Ff - Fcrs) / C->dx[d];
     }
   }
-}
-static int covered(const vo_fab *fine, int I, int J, int K)
-{
-  return I >= fine->lo[0] / 2 && I <= fine->hi[0] / 2 && J >= fine->lo[1] / 2 && J <= fine->hi[1] / 2 && K >= fine->lo[2] / 2 && K <= fine->hi[2] / 2;
 }
 static void fab_like(vo_fab *f, const vo_fab *like, int ng, double val)
 {
@@ -284,41 +394,37 @@ static void fab_like(vo_fab *f, const vo_fab *like, int ng, double val)
   f->p = (double *)malloc(sizeof(double) * n);
   for (long i = 0; i < n; i++) f->p[i] = val;
 }
-
-#define VO_MAXLEV 4
-typedef const int (*ellbc_t)[3][2];
-static void fill_phi_ghosts(int nlev, vo_fab **phi, ellbc_t ellbc, const int pmask[3], const int *pd)
+static void fill_phi_ghosts(int nlev, clev *M)
 {
-  for (int n = nlev - 1; n >= 1; n--) vo_ml_cc_restriction(phi[n - 1], phi[n], 0, 1);     /* keep coarser levels consistent under finer ones */
-  for (int n = 0; n < nlev; n++) phi_closure(phi[n], ellbc[n], pmask, pd + 6 * n, pd + 6 * n + 3);
-  for (int n = 1; n < nlev; n++) cf_interp(phi[n], phi[n - 1], ellbc[n]);
+  for (int n = nlev - 1; n >= 1; n--) vo_ml_cc_restriction_g(M[n - 1].phi, M[n].phi, M[n].L, 0, 1);     /* keep coarser levels consistent under finer ones */
+  for (int n = 1; n < nlev; n++) cf_interp(&M[n], &M[n - 1], M[n].phi, M[n - 1].phi, M[n].gphi);
 }
 /* composite residual on every level; res[n] on cells covered by level n+1 = restriction of res[n+1]; returns the composite max-norm
  * (cells of each level that are not covered by the next finer one) */
-static double composite_residual(int nlev, vo_fab **rh, vo_fab **phi, vo_fab **alpha, vo_fab **beta, const double *dx, ellbc_t ellbc, const int pmask[3], const int *pd, vo_fab **res)
+static double composite_residual(int nlev, clev *M)
 {
-  fill_phi_ghosts(nlev, phi, ellbc, pmask, pd);
-  for (int n = 0; n < nlev; n++) (void)plain_residual(rh[n], phi[n], alpha ? alpha[n] : NULL, beta + 3 * n, dx + 3 * n, res[n]);
-  for (int n = 1; n < nlev; n++) reflux_residual(res[n - 1], phi[n - 1], beta + 3 * (n - 1), dx + 3 * (n - 1), phi[n], beta + 3 * n, dx + 3 * n, ellbc[n]);
-  for (int n = nlev - 1; n >= 1; n--) vo_ml_cc_restriction(res[n - 1], res[n], 0, 1);
+  fill_phi_ghosts(nlev, M);
+  for (int n = 0; n < nlev; n++) (void)plain_residual(&M[n], M[n].rh, M[n].phi, M[n].gphi, &M[n].res);
+  for (int n = 1; n < nlev; n++) reflux_residual(&M[n - 1], &M[n], &M[n - 1].res, M[n - 1].phi, M[n].phi, M[n].gphi);
+  for (int n = nlev - 1; n >= 1; n--) vo_ml_cc_restriction_g(&M[n - 1].res, &M[n].res, M[n].L, 0, 1);
   double nrm = 0.0;
-  for (int n = 0; n < nlev; n++)
-    for (int k = res[n]->lo[2]; k <= res[n]->hi[2]; k++) for (int j = res[n]->lo[1]; j <= res[n]->hi[1]; j++) for (int i = res[n]->lo[0]; i <= res[n]->hi[0]; i++)
-      if (n == nlev - 1 || !covered(phi[n + 1], i, j, k)) nrm = vo_nrm_acc(nrm, VF(res[n], i, j, k, 0));
+  for (int n = 0; n < nlev; n++) {
+    const vo_fab *r = &M[n].res;
+    for (int k = r->lo[2]; k <= r->hi[2]; k++) for (int j = r->lo[1]; j <= r->hi[1]; j++) for (int i = r->lo[0]; i <= r->hi[0]; i++)
+      if (cvalid(&M[n], i, j, k) && (n == nlev - 1 || !covered_by(&M[n + 1], i, j, k))) nrm = vo_nrm_acc(nrm, VF(r, i, j, k, 0));
+  }
   return nrm;
 }
 /* fine += the prolongation of the correction `src` of the next coarser level (valid cells): piecewise constant into level 1,
  * LINEAR into the levels m >= 2 -- fine cell = (p0 + px + py + pz)/4 with p0 its parent and px, py, pz the parent's neighbours on the fine
- * cell's side; a neighbour that is not a cell of the source level (beyond the coarse-fine interface or a wall) counts as the parent itself,
- * one across a periodic boundary of a level that spans the domain is the periodic image.  (Round 3.  With the constant prolongation on every
- * hop three nested levels need 20 FAC iterations where two need 10; with the linear one into the levels >= 2, 11-12.  Into level 1 the
- * constant one is kept: the linear one costs two levels one or two iterations -- measured, base 32^3 and 64^3.) */
-static void prolong_add(vo_fab *fine, const vo_fab *src, int m, const int pmask[3], const int *pd)
+ * cell's side; a neighbour that is not a cell of the source level (beyond the coarse-fine interface or a wall) counts as the parent itself.
+ * (Round 3.  With the constant prolongation on every hop three nested levels need 20 FAC iterations where two need 10; with the linear one into the
+ * levels >= 2, 11-12.  Into level 1 the constant one is kept: the linear one costs two levels one or two iterations -- measured, base 32^3 and 64^3.) */
+static void prolong_add(const clev *F, const clev *C, vo_fab *fine, const vo_fab *src, int m)
 {
-  const int *plo = pd + 6 * (m - 1), *phi_ = pd + 6 * (m - 1) + 3;         /* the source level's domain */
-  int wrap[3];
-  for (int d = 0; d < 3; d++) wrap[d] = pmask[d] && src->lo[d] == plo[d] && src->hi[d] == phi_[d];
-  for (int k = fine->lo[2]; k <= fine->hi[2]; k++) for (int j = fine->lo[1]; j <= fine->hi[1]; j++) for (int i = fine->lo[0]; i <= fine->hi[0]; i++) {
+  const vo_fab *r = &F->res;
+  for (int k = r->lo[2]; k <= r->hi[2]; k++) for (int j = r->lo[1]; j <= r->hi[1]; j++) for (int i = r->lo[0]; i <= r->hi[0]; i++) {
+    if (!cvalid(F, i, j, k)) continue;
     const int q[3] = { i / 2, j / 2, k / 2 };
     double v = VF(src, q[0], q[1], q[2], 0);
     if (m >= 2) {
@@ -326,48 +432,25 @@ static void prolong_add(vo_fab *fine, const vo_fab *src, int m, const int pmask[
       double pn[3];
       for (int d = 0; d < 3; d++) {
         int t[3] = { q[0], q[1], q[2] }; t[d] += o[d];
-        if (t[d] < src->lo[d]) { if (wrap[d]) t[d] = src->hi[d]; else { pn[d] = v; continue; } }
-        else if (t[d] > src->hi[d]) { if (wrap[d]) t[d] = src->lo[d]; else { pn[d] = v; continue; } }
-        pn[d] = VF(src, t[0], t[1], t[2], 0);
+        pn[d] = (in_domain1(C, d, t[d]) && cvalid(C, t[0], t[1], t[2])) ? VF(src, t[0], t[1], t[2], 0) : v;
       }
       v = 0.25 * (((v + pn[0]) + pn[1]) + pn[2]);
     }
     VF(fine, i, j, k, 0) = VF(fine, i, j, k, 0) + v;
   }
 }
-/* ghost layer of the correction e of level n as the operator of the composite residual sees it: closure at the domain faces, periodic
- * images, and beyond the coarse-fine interface the interpolation cf_interp from the correction ec of the next coarser level */
-static void fill_e_ghosts(vo_fab *e, const vo_fab *ec, const int ellbc[3][2], const int pmask[3], const int *pdlo, const int *pdhi)
-{
-  phi_closure(e, ellbc, pmask, pdlo, pdhi);
-  if (ec) cf_interp(e, ec, ellbc);
-}
-/* ... and as the relaxation wants it: zero beyond the domain faces (their closure is folded into the coefficients) */
-static void zero_domain_ghosts(vo_fab *e, const int ellbc[3][2])
-{
-  const int *lo = e->lo, *hi = e->hi;
-  for (int d = 0; d < 3; d++) for (int s = 0; s < 2; s++) {
-    if (ellbc[d][s] != VDN_BC_NEU && ellbc[d][s] != VDN_BC_DIR) continue;
-    const int t1 = (d + 1) % 3, t2 = (d + 2) % 3;
-    for (int b2 = lo[t2]; b2 <= hi[t2]; b2++) for (int b1 = lo[t1]; b1 <= hi[t1]; b1++) {
-      int g[3]; g[t1] = b1; g[t2] = b2; g[d] = s ? hi[d] + 1 : lo[d] - 1;
-      VF(e, g[0], g[1], g[2], 0) = 0.0;
-    }
-  }
-}
 
-/* rh, phi: [lev];  beta: [lev*3 + d];  dx: [lev*3 + d];  ellbc[lev] per box;  pd: [lev][2][3].
+/* rh, phi: [lev];  beta: [lev*3 + d];  dx: [lev*3 + d];  ellbc[lev]: of the level's bounding box;  pd: [lev][2][3].
  * One FAC iteration is a V-cycle over the levels in correction form (round 4; rounds 2-3 applied every level's correction to phi at once
  * and formed the composite residual again after each -- five residual passes over the finest of three levels per iteration where this
  * form makes two; on two levels the iterates are the same in exact arithmetic, on three the levels below see r_n - A_n e_n under a finer
  * level instead of the restriction of the finer level's new residual):
  *   composite residual r_n on every level / test;
- *   down, n = finest..1:  e_n = 0, nu1 red-black sweeps of A_n e_n = r_n (zero beyond the interface);  t = r_n - A_n e_n with the ghost cells of
- *        e_n as the composite operator fills them (closure, interpolation from e_{n-1} = 0);  r_{n-1} := restriction of t under level n, and
+ *   down, n = finest..1:  e_n = 0, nu1 red-black sweeps of A_n e_n = r_n (zero beyond the interface);  t = r_n - A_n e_n with the values of
+ *        e_n beyond the interface as the composite operator takes them (interpolation from e_{n-1} = 0);  r_{n-1} := restriction of t under level n, and
  *        its flux matching next to level n with the fluxes of e_n (the operator is linear: the change of the composite residual);
  *   level 0: ONE V-cycle of the single-level multigrid, A_0 e_0 = r_0;
- *   up, n = 1..finest:  e_n += P e_{n-1};  ghost cells of e_n beyond the interface interpolated from e_{n-1} and held;  nu2 sweeps of
- *        A_n e_n = r_n;
+ *   up, n = 1..finest:  e_n += P e_{n-1};  the values of e_n beyond the interface interpolated from e_{n-1} and held;  nu2 sweeps of A_n e_n = r_n;
  *   phi_n += e_n on every level.
  * beta_base (may be NULL): the face coefficients the level-0 V-cycle takes instead of beta[0..2] -- the MAC projection hands over the
  * coefficients of level 0's own density, 2/(rho_i + rho_i-1) on every face, where beta carries the edge restriction of the finer level's
@@ -376,75 +459,213 @@ static void zero_domain_ghosts(vo_fab *e, const int ellbc[3][2])
 int vo_ml_cc_solve(int nlev, vo_fab **rh, vo_fab **phi, vo_fab **alpha, vo_fab **beta, const double *dx, const int ellbc[][3][2], const int pmask[3], const int *pd,
                    double rel_eps, int max_iter, const vdn_params *prm, vo_fab **beta_base, vo_mgstat *st)
 {
+  return vo_ml_cc_solve_g(nlev, NULL, rh, phi, alpha, beta, dx, ellbc, pmask, pd, rel_eps, max_iter, prm, beta_base, st, NULL);
+}
+int vo_ml_cc_solve_g(int nlev, const vo_level *const *lev, vo_fab **rh, vo_fab **phi, vo_fab **alpha, vo_fab **beta, const double *dx, const int ellbc[][3][2], const int pmask[3],
+                     const int *pd, double rel_eps, int max_iter, const vdn_params *prm, vo_fab **beta_base, vo_mgstat *st, double **ghost)
+{
   if (nlev < 2 || nlev > VO_MAXLEV) { fprintf(stderr, "vo_ml_cc_solve: 2..%d levels\n", VO_MAXLEV); abort(); }
+  if (pmask[0] || pmask[1] || pmask[2]) { fprintf(stderr, "vo_ml_cc_solve: periodic hierarchies are not supported by the oracle\n"); abort(); }
+  clev M[VO_MAXLEV];
+  for (int n = 0; n < nlev; n++) {
+    clev *m = &M[n];
+    m->L = LEV(lev, n); m->rh = rh[n]; m->phi = phi[n]; m->alpha = alpha ? alpha[n] : NULL; m->beta = beta + 3 * n; m->dx = dx + 3 * n;
+    m->ell = ellbc[n]; m->pdlo = pd + 6 * n; m->pdhi = pd + 6 * n + 3;
+    fab_like(&m->res, rh[n], 0, 0.0); fab_like(&m->e, rh[n], 1, 0.0); fab_like(&m->t, rh[n], 0, 0.0);
+    m->ncell = vo_size(&m->res);
+    for (int q = 0; q < 6; q++) { m->gphi[q] = (double *)calloc((size_t)m->ncell, sizeof(double)); m->ge[q] = (double *)calloc((size_t)m->ncell, sizeof(double)); }
+  }
   /* inhomogeneous Dirichlet data: the ghost cells of the incoming phi hold the boundary-FACE values (viscsolve.f90:270); the face term
-   * 2b(phi_i - phi_b)/h^2 keeps its phi_i part in the operator (closure ghost = -phi_i) and its phi_b part goes to the right-hand side,
+   * 2b(phi_i - phi_b)/h^2 keeps its phi_i part in the operator (closure: -phi_i beyond the face) and its phi_b part goes to the right-hand side,
    * in the order x-lo, x-hi, y-lo, y-hi, z-lo, z-hi (as cc_load of the single-level solver) */
   for (int n = 0; n < nlev; n++) {
-    const int *lo = rh[n]->lo, *hi = rh[n]->hi;
+    const clev *m = &M[n]; const vo_fab *r = &m->res;
     const double hi2[3] = { 1.0 / (dx[3 * n] * dx[3 * n]), 1.0 / (dx[3 * n + 1] * dx[3 * n + 1]), 1.0 / (dx[3 * n + 2] * dx[3 * n + 2]) };
-    for (int k = lo[2]; k <= hi[2]; k++) for (int j = lo[1]; j <= hi[1]; j++) for (int i = lo[0]; i <= hi[0]; i++) {
-      double r = VF(rh[n], i, j, k, 0);
-      if (i == lo[0] && ellbc[n][0][0] == VDN_BC_DIR) r = r + (2.0 * VF(beta[3 * n], i, j, k, 0)) * VF(phi[n], i - 1, j, k, 0) * hi2[0];
-      if (i == hi[0] && ellbc[n][0][1] == VDN_BC_DIR) r = r + (2.0 * VF(beta[3 * n], i + 1, j, k, 0)) * VF(phi[n], i + 1, j, k, 0) * hi2[0];
-      if (j == lo[1] && ellbc[n][1][0] == VDN_BC_DIR) r = r + (2.0 * VF(beta[3 * n + 1], i, j, k, 0)) * VF(phi[n], i, j - 1, k, 0) * hi2[1];
-      if (j == hi[1] && ellbc[n][1][1] == VDN_BC_DIR) r = r + (2.0 * VF(beta[3 * n + 1], i, j + 1, k, 0)) * VF(phi[n], i, j + 1, k, 0) * hi2[1];
-      if (k == lo[2] && ellbc[n][2][0] == VDN_BC_DIR) r = r + (2.0 * VF(beta[3 * n + 2], i, j, k, 0)) * VF(phi[n], i, j, k - 1, 0) * hi2[2];
-      if (k == hi[2] && ellbc[n][2][1] == VDN_BC_DIR) r = r + (2.0 * VF(beta[3 * n + 2], i, j, k + 1, 0)) * VF(phi[n], i, j, k + 1, 0) * hi2[2];
-      VF(rh[n], i, j, k, 0) = r;
+    for (int k = r->lo[2]; k <= r->hi[2]; k++) for (int j = r->lo[1]; j <= r->hi[1]; j++) for (int i = r->lo[0]; i <= r->hi[0]; i++) {
+      if (!cvalid(m, i, j, k)) continue;
+      double v = VF(rh[n], i, j, k, 0);
+      if (i == m->pdlo[0] && m->ell[0][0] == VDN_BC_DIR) v = v + (2.0 * VF(beta[3 * n], i, j, k, 0)) * VF(phi[n], i - 1, j, k, 0) * hi2[0];
+      if (i == m->pdhi[0] && m->ell[0][1] == VDN_BC_DIR) v = v + (2.0 * VF(beta[3 * n], i + 1, j, k, 0)) * VF(phi[n], i + 1, j, k, 0) * hi2[0];
+      if (j == m->pdlo[1] && m->ell[1][0] == VDN_BC_DIR) v = v + (2.0 * VF(beta[3 * n + 1], i, j, k, 0)) * VF(phi[n], i, j - 1, k, 0) * hi2[1];
+      if (j == m->pdhi[1] && m->ell[1][1] == VDN_BC_DIR) v = v + (2.0 * VF(beta[3 * n + 1], i, j + 1, k, 0)) * VF(phi[n], i, j + 1, k, 0) * hi2[1];
+      if (k == m->pdlo[2] && m->ell[2][0] == VDN_BC_DIR) v = v + (2.0 * VF(beta[3 * n + 2], i, j, k, 0)) * VF(phi[n], i, j, k - 1, 0) * hi2[2];
+      if (k == m->pdhi[2] && m->ell[2][1] == VDN_BC_DIR) v = v + (2.0 * VF(beta[3 * n + 2], i, j, k + 1, 0)) * VF(phi[n], i, j, k + 1, 0) * hi2[2];
+      VF(rh[n], i, j, k, 0) = v;
     }
   }
-  vo_fab res[VO_MAXLEV], e[VO_MAXLEV], t[VO_MAXLEV], *rp[VO_MAXLEV];
-  for (int n = 0; n < nlev; n++) { fab_like(&res[n], rh[n], 0, 0.0); fab_like(&e[n], rh[n], 1, 0.0); fab_like(&t[n], rh[n], 0, 0.0); rp[n] = &res[n]; }
   /* norm of the right-hand side over the composite grid */
   double bnorm = 0.0;
-  for (int n = 0; n < nlev; n++)
-    for (int k = rh[n]->lo[2]; k <= rh[n]->hi[2]; k++) for (int j = rh[n]->lo[1]; j <= rh[n]->hi[1]; j++) for (int i = rh[n]->lo[0]; i <= rh[n]->hi[0]; i++)
-      if (n == nlev - 1 || !covered(rh[n + 1], i, j, k)) bnorm = vo_nrm_acc(bnorm, VF(rh[n], i, j, k, 0));
+  for (int n = 0; n < nlev; n++) {
+    const vo_fab *r = &M[n].res;
+    for (int k = r->lo[2]; k <= r->hi[2]; k++) for (int j = r->lo[1]; j <= r->hi[1]; j++) for (int i = r->lo[0]; i <= r->hi[0]; i++)
+      if (cvalid(&M[n], i, j, k) && (n == nlev - 1 || !covered_by(&M[n + 1], i, j, k))) bnorm = vo_nrm_acc(bnorm, VF(rh[n], i, j, k, 0));
+  }
   int it = 0, conv = 0; double rn = 0.0;
   if (bnorm == 0.0) conv = 1;
   while (!conv) {
-    rn = composite_residual(nlev, rh, phi, alpha, beta, dx, ellbc, pmask, pd, rp);
+    rn = composite_residual(nlev, M);
     if (rn <= rel_eps * bnorm) { conv = 1; break; }
     if (it >= max_iter) break;
-    for (int n = 0; n < nlev; n++) memset(e[n].p, 0, sizeof(double) * vo_size(&e[n]));
+    for (int n = 0; n < nlev; n++) memset(M[n].e.p, 0, sizeof(double) * vo_size(&M[n].e));
     for (int n = nlev - 1; n >= 1; n--) {               /* down: pre-relaxation, then the residual the next coarser level sees */
-      vo_cc_smooth_ab(&res[n], &e[n], alpha ? alpha[n] : NULL, beta + 3 * n, dx + 3 * n, ellbc[n], prm->mg_nu1);
-      fill_e_ghosts(&e[n], &e[n - 1], ellbc[n], pmask, pd + 6 * n, pd + 6 * n + 3);                   /* (e[n-1] = 0 here) */
-      (void)plain_residual(&res[n], &e[n], alpha ? alpha[n] : NULL, beta + 3 * n, dx + 3 * n, &t[n]);
-      reflux_residual(&res[n - 1], &e[n - 1], beta + 3 * (n - 1), dx + 3 * (n - 1), &e[n], beta + 3 * n, dx + 3 * n, ellbc[n]);
-      vo_ml_cc_restriction(&res[n - 1], &t[n], 0, 1);
+      relax(&M[n], &M[n].res, &M[n].e, NULL, prm->mg_nu1);
+      cf_interp(&M[n], &M[n - 1], &M[n].e, &M[n - 1].e, M[n].ge);                                       /* (e[n-1] = 0 here) */
+      (void)plain_residual(&M[n], &M[n].res, &M[n].e, M[n].ge, &M[n].t);
+      reflux_residual(&M[n - 1], &M[n], &M[n - 1].res, &M[n - 1].e, &M[n].e, M[n].ge);
+      vo_ml_cc_restriction_g(&M[n - 1].res, &M[n].t, M[n].L, 0, 1);
     }
     /* coarse correction: ONE V-cycle of the single-level multigrid on the whole coarse level */
     vo_mgstat cs;
-    vo_cc_solve_ab(&res[0], &e[0], alpha ? alpha[0] : NULL, beta_base ? beta_base : beta, dx, ellbc[0], 0.0, -1.0, -1, prm->mg_nu1, prm->mg_nu2, prm->mg_nub, 0, &cs);     /* (a nested-iteration start of the FIRST correction saves no FAC iteration here: measured, 10 -> 10) */
-    fill_e_ghosts(&e[0], NULL, ellbc[0], pmask, pd, pd + 3);
+    vo_cc_solve_ab(&M[0].res, &M[0].e, M[0].alpha, beta_base ? beta_base : beta, dx, ellbc[0], 0.0, -1.0, -1, prm->mg_nu1, prm->mg_nu2, prm->mg_nub, 0, &cs);     /* (a nested-iteration start of the FIRST correction saves no FAC iteration here: measured, 10 -> 10) */
     for (int n = 1; n < nlev; n++) {                    /* up: the coarser correction prolonged, post-relaxation with it beyond the interface */
-      prolong_add(&e[n], &e[n - 1], n, pmask, pd);
-      fill_e_ghosts(&e[n], &e[n - 1], ellbc[n], pmask, pd + 6 * n, pd + 6 * n + 3);
-      zero_domain_ghosts(&e[n], ellbc[n]);
-      vo_cc_smooth_ab_iface(&res[n], &e[n], alpha ? alpha[n] : NULL, beta + 3 * n, dx + 3 * n, ellbc[n], prm->mg_nu2);
-      if (n < nlev - 1) fill_e_ghosts(&e[n], &e[n - 1], ellbc[n], pmask, pd + 6 * n, pd + 6 * n + 3);      /* what the next finer level's interface reads */
+      prolong_add(&M[n], &M[n - 1], &M[n].e, &M[n - 1].e, n);
+      cf_interp(&M[n], &M[n - 1], &M[n].e, &M[n - 1].e, M[n].ge);
+      relax(&M[n], &M[n].res, &M[n].e, M[n].ge, prm->mg_nu2);
     }
-    for (int n = 0; n < nlev; n++)
-      for (int k = phi[n]->lo[2]; k <= phi[n]->hi[2]; k++) for (int j = phi[n]->lo[1]; j <= phi[n]->hi[1]; j++) for (int i = phi[n]->lo[0]; i <= phi[n]->hi[0]; i++)
-        VF(phi[n], i, j, k, 0) = VF(phi[n], i, j, k, 0) + VF(&e[n], i, j, k, 0);
+    for (int n = 0; n < nlev; n++) {
+      const vo_fab *r = &M[n].res;
+      for (int k = r->lo[2]; k <= r->hi[2]; k++) for (int j = r->lo[1]; j <= r->hi[1]; j++) for (int i = r->lo[0]; i <= r->hi[0]; i++)
+        if (cvalid(&M[n], i, j, k)) VF(phi[n], i, j, k, 0) = VF(phi[n], i, j, k, 0) + VF(&M[n].e, i, j, k, 0);
+    }
     it++;
   }
-  fill_phi_ghosts(nlev, phi, ellbc, pmask, pd);       /* leave phi with consistent ghosts for mkumac */
+  fill_phi_ghosts(nlev, M);                            /* phi consistent under the finer levels, interface values for mkumac */
+  if (ghost) for (int n = 0; n < nlev; n++) for (int q = 0; q < 6; q++) { ghost[6 * n + q] = M[n].gphi[q]; M[n].gphi[q] = NULL; }
   if (st) { st->cycles = it; st->res0 = bnorm; st->res = rn; }
-  for (int n = 0; n < nlev; n++) { free(res[n].p); free(e[n].p); free(t[n].p); }
+  for (int n = 0; n < nlev; n++) { free(M[n].res.p); free(M[n].e.p); free(M[n].t.p); for (int q = 0; q < 6; q++) { free(M[n].gphi[q]); free(M[n].ge[q]); } }
   return conv ? 0 : 1;
 }
 
-/* macproject.f90:20-133 on nlev levels.  umac: [lev*3 + d] (ng = 1), rho: [lev] (ghosts filled), mac_rhs: [lev] */
+/* ---- fields held box by box (vo_bmf) ---------------------------------------------------------------------------------------------------- */
+static int level_nbox(const vo_level *L) { return lv_multi(L) ? L->nbox : 1; }
+static void level_box(const vo_level *L, const vo_fab *like, int b, int lo[3], int hi[3])
+{
+  for (int d = 0; d < 3; d++) { lo[d] = lv_multi(L) ? L->boxes[6 * b + d] : like->lo[d]; hi[d] = lv_multi(L) ? L->boxes[6 * b + 3 + d] : like->hi[d]; }
+}
+static void fab_new(vo_fab *f, const int *lo, const int *hi, int ng, int face_dir, int nc, double val)
+{
+  int nd[3] = { 0, 0, 0 }; if (face_dir >= 0) nd[face_dir] = 1;
+  vo_fab_init(f, NULL, lo, hi, ng, nd, nc);
+  long n = vo_size(f);
+  f->p = (double *)malloc(sizeof(double) * n);
+  for (long i = 0; i < n; i++) f->p[i] = val;
+}
+static void bmf_new(vo_bmf *m, const vo_level *L, const vo_fab *like, int ng, int face_dir, int nc, double val)
+{
+  m->nbox = level_nbox(L); m->f = (vo_fab *)malloc(sizeof(vo_fab) * (size_t)m->nbox);
+  for (int b = 0; b < m->nbox; b++) { int lo[3], hi[3]; level_box(L, like, b, lo, hi); fab_new(&m->f[b], lo, hi, ng, face_dir, nc, val); }
+}
+static void bmf_free(vo_bmf *m) { for (int b = 0; b < m->nbox; b++) free(m->f[b].p); free(m->f); m->f = NULL; m->nbox = 0; }
+static inline int in_valid(const vo_fab *f, int i, int j, int k)
+{
+  return i >= f->lo[0] && i <= f->hi[0] + f->nd[0] && j >= f->lo[1] && j <= f->hi[1] + f->nd[1] && k >= f->lo[2] && k <= f->hi[2] + f->nd[2];
+}
+/* the field at point (i,j,k): from the first box that holds it as a VALID point, else from the first whose allocation holds it (*ok = 0: nobody) */
+static double bmf_lookup(const vo_bmf *m, int i, int j, int k, int c, int *ok)
+{
+  *ok = 1;
+  for (int b = 0; b < m->nbox; b++) if (in_valid(&m->f[b], i, j, k)) return VF(&m->f[b], i, j, k, c);
+  for (int b = 0; b < m->nbox; b++) if (in_alloc(&m->f[b], i, j, k)) return VF(&m->f[b], i, j, k, c);
+  *ok = 0; return 0.0;
+}
+/* multifab_fill_boundary: the ghost points of every box from the valid points of the others (a point two boxes hold -- the face they share -- comes
+ * from the first of them: BoxLib does not say which, and the two agree except inside the upwinding's dead band) */
+static void bmf_fill_boundary(vo_bmf *m, const int pmask[3], const int pdlo[3], const int pdhi[3])
+{
+  if (m->nbox == 1) { level_fill_boundary(&m->f[0], pmask, pdlo, pdhi); return; }
+  for (int b = 0; b < m->nbox; b++) {
+    vo_fab *f = &m->f[b]; const int ng = f->ng;
+    for (int c = 0; c < f->nc; c++)
+    for (int k = f->lo[2] - ng; k <= f->hi[2] + f->nd[2] + ng; k++) for (int j = f->lo[1] - ng; j <= f->hi[1] + f->nd[1] + ng; j++) for (int i = f->lo[0] - ng; i <= f->hi[0] + f->nd[0] + ng; i++) {
+      if (in_valid(f, i, j, k)) continue;
+      for (int s = 0; s < m->nbox; s++) if (s != b && in_valid(&m->f[s], i, j, k)) { VF(f, i, j, k, c) = VF(&m->f[s], i, j, k, c); break; }
+    }
+  }
+}
+/* create_umac_grown on box lists: the ghost faces of every fine box from the coarse level's boxes */
+static void bmf_umac_grown(vo_bmf *fine, const vo_bmf *crse, int dir)
+{
+  if (fine->nbox == 1 && crse->nbox == 1) { vo_create_umac_grown(&fine->f[0], &crse->f[0], dir); return; }
+  for (int fb = 0; fb < fine->nbox; fb++) {
+    vo_fab *f = &fine->f[fb]; const int ng = f->ng;
+    for (int k = f->lo[2] - ng; k <= f->hi[2] + f->nd[2] + ng; k++) for (int j = f->lo[1] - ng; j <= f->hi[1] + f->nd[1] + ng; j++) for (int i = f->lo[0] - ng; i <= f->hi[0] + f->nd[0] + ng; i++) {
+      if (in_valid(f, i, j, k)) continue;
+      const int q[3] = { i, j, k };
+      int P[3] = { fdiv2(i), fdiv2(j), fdiv2(k) }, P2[3];
+      const int odd = q[dir] - 2 * P[dir];
+      P2[0] = P[0]; P2[1] = P[1]; P2[2] = P[2]; P2[dir] += 1;
+      int ok1, ok2 = 1;
+      const double v1 = bmf_lookup(crse, P[0], P[1], P[2], 0, &ok1), v2 = odd ? bmf_lookup(crse, P2[0], P2[1], P2[2], 0, &ok2) : 0.0;
+      if (!ok1 || !ok2) continue;
+      VF(f, i, j, k, 0) = odd ? 0.5 * (v1 + v2) : v1;
+    }
+  }
+}
+/* ml_edge_restriction on box lists, component c: every coarse face under the fine level = mean of the four fine faces that cover it */
+static void bmf_edge_restriction(vo_bmf *crse, const vo_bmf *fine, int dir, int c)
+{
+  const int t1 = (dir + 1) % 3, t2 = (dir + 2) % 3;
+  for (int cb = 0; cb < crse->nbox; cb++) for (int fb = 0; fb < fine->nbox; fb++) {
+    vo_fab *C = &crse->f[cb]; const vo_fab *Fv = &fine->f[fb];
+    int lo[3], hi[3], empty = 0;
+    for (int d = 0; d < 3; d++) {
+      int flo = Fv->lo[d] / 2, fhi = Fv->hi[d] / 2 + (d == dir ? 1 : 0);
+      lo[d] = flo > C->lo[d] ? flo : C->lo[d]; hi[d] = fhi < C->hi[d] + C->nd[d] ? fhi : C->hi[d] + C->nd[d];
+      if (lo[d] > hi[d]) empty = 1;
+    }
+    if (empty) continue;
+    for (int K = lo[2]; K <= hi[2]; K++) for (int J = lo[1]; J <= hi[1]; J++) for (int I = lo[0]; I <= hi[0]; I++) {
+      int Q[3] = { I, J, K };
+      double s = 0.0;
+      for (int b = 0; b < 2; b++) for (int a = 0; a < 2; a++) {
+        int q[3]; q[dir] = 2 * Q[dir]; q[t1] = 2 * Q[t1] + a; q[t2] = 2 * Q[t2] + b;
+        s = s + VF(Fv, q[0], q[1], q[2], c);
+      }
+      VF(C, I, J, K, c) = s * 0.25;
+    }
+  }
+}
+/* a copy of the cells lo-ng .. hi+ng of a cell-centred level array (all components) / the box's valid cells written back */
+static void box_gather(vo_fab *box, const int *lo, const int *hi, int ng, const vo_fab *levarr)
+{
+  fab_new(box, lo, hi, ng, -1, levarr->nc, 0.0);
+  for (int c = 0; c < levarr->nc; c++)
+  for (int k = lo[2] - ng; k <= hi[2] + ng; k++) for (int j = lo[1] - ng; j <= hi[1] + ng; j++) for (int i = lo[0] - ng; i <= hi[0] + ng; i++)
+    if (in_alloc(levarr, i, j, k)) VF(box, i, j, k, c) = VF(levarr, i, j, k, c);
+}
+static void box_scatter(vo_fab *levarr, const vo_fab *box, int c0, int nc)
+{
+  for (int c = c0; c < c0 + nc; c++)
+  for (int k = box->lo[2]; k <= box->hi[2]; k++) for (int j = box->lo[1]; j <= box->hi[1]; j++) for (int i = box->lo[0]; i <= box->hi[0]; i++)
+    VF(levarr, i, j, k, c) = VF(box, i, j, k, c);
+}
+/* the bc tables of one box of a level: the level's physical boundary where the box touches it, INTERIOR elsewhere (define_bc_tower.f90:199-335 per box) */
+static void box_bc(vo_bc *out, const vo_bc *levbc, const int *lo, const int *hi, const int *pdlo, const int *pdhi, const vdn_params *prm)
+{
+  int phys[3][2];
+  for (int d = 0; d < 3; d++) { phys[d][0] = lo[d] == pdlo[d] ? levbc->phys[d][0] : VDN_INTERIOR; phys[d][1] = hi[d] == pdhi[d] ? levbc->phys[d][1] : VDN_INTERIOR; }
+  vo_bc_build(out, phys, 3, prm->nscal);
+}
+/* run `body` for every box of level n with the level's cell-centred arrays seen as that box's fabs.  One box: the level arrays themselves. */
+#define FOR_BOXES(L, like, b, lo, hi) for (int b = 0, nb_ = level_nbox(L); b < nb_; b++) for (int lo[3], hi[3], once_ = (level_box(L, like, b, lo, hi), 1); once_; once_ = 0)
+
+/* macproject.f90:20-133 on nlev levels.  umac: [lev*3 + d], per box (ng = 1); rho: [lev] (ghost cells filled); mac_rhs: [lev] */
 void vo_ml_macproject(int nlev, vo_fab **umac, vo_fab **rho, vo_fab **mac_rhs, const double *dx, const vo_bc *bc, const int pmask[3], const int *pd,
                       const vdn_params *prm, vo_mgstat *st)
 {
+  vo_bmf um[3 * VO_MAXLEV];
+  for (int q = 0; q < 3 * nlev; q++) { um[q].nbox = 1; um[q].f = umac[q]; }
+  vo_ml_macproject_g(nlev, NULL, um, rho, mac_rhs, dx, bc, pmask, pd, prm, st);
+}
+void vo_ml_macproject_g(int nlev, const vo_level *const *lev, vo_bmf *umac, vo_fab **rho, vo_fab **mac_rhs, const double *dx, const vo_bc *bc, const int pmask[3], const int *pd,
+                        const vdn_params *prm, vo_mgstat *st)
+{
+  require_no_periodic(nlev, lev, pmask, "vo_ml_macproject");
   vo_fab rh[VO_MAXLEV], phi[VO_MAXLEV], beta[3 * VO_MAXLEV], *rhp[VO_MAXLEV], *php[VO_MAXLEV], *bp[3 * VO_MAXLEV];
   int ellbc[VO_MAXLEV][3][2];
   for (int n = 0; n < nlev; n++) {
     fab_like(&rh[n], rho[n], 0, 0.0); fab_like(&phi[n], rho[n], 1, 0.0); rhp[n] = &rh[n]; php[n] = &phi[n];
+    rh[n].nc = phi[n].nc = 1;
     for (int d = 0; d < 3; d++) {
       int nd[3] = { 0, 0, 0 }; nd[d] = 1;
       vo_fab_init(&beta[3 * n + d], NULL, rho[n]->lo, rho[n]->hi, 0, nd, 1);
@@ -452,18 +673,23 @@ void vo_ml_macproject(int nlev, vo_fab **umac, vo_fab **rho, vo_fab **mac_rhs, c
       for (int s = 0; s < 2; s++) ellbc[n][d][s] = bc[n].ell[d][s][bc[n].press_comp];
     }
   }
-  /* divumac (macproject.f90:161-206): rh = mac_rhs - div(umac) on every level, then ml_cc_restriction */
+  /* divumac (macproject.f90:161-206): rh = mac_rhs - div(umac) box by box, then ml_cc_restriction */
   for (int n = 0; n < nlev; n++) {
-    vo_divumac(umac + 3 * n, &rh[n], dx + 3 * n);
-    for (int k = rh[n].lo[2]; k <= rh[n].hi[2]; k++) for (int j = rh[n].lo[1]; j <= rh[n].hi[1]; j++) for (int i = rh[n].lo[0]; i <= rh[n].hi[0]; i++)
-      VF(&rh[n], i, j, k, 0) = VF(&rh[n], i, j, k, 0) * -1.0 + VF(mac_rhs[n], i, j, k, 0);
+    FOR_BOXES(LEV(lev, n), rho[n], b, lo, hi) {
+      vo_fab r; fab_new(&r, lo, hi, 0, -1, 1, 0.0);
+      vo_fab *u3[3] = { &umac[3 * n].f[b], &umac[3 * n + 1].f[b], &umac[3 * n + 2].f[b] };
+      vo_divumac(u3, &r, dx + 3 * n);
+      for (int k = lo[2]; k <= hi[2]; k++) for (int j = lo[1]; j <= hi[1]; j++) for (int i = lo[0]; i <= hi[0]; i++)
+        VF(&rh[n], i, j, k, 0) = VF(&r, i, j, k, 0) * -1.0 + VF(mac_rhs[n], i, j, k, 0);
+      free(r.p);
+    }
   }
-  for (int n = nlev - 1; n >= 1; n--) vo_ml_cc_restriction(&rh[n - 1], &rh[n], 0, 1);
+  for (int n = nlev - 1; n >= 1; n--) vo_ml_cc_restriction_g(&rh[n - 1], &rh[n], LEV(lev, n), 0, 1);
   /* mk_mac_coeffs (macproject.f90:296-334): rho's fine ghosts come from the caller's ml_restrict_and_fill; edge restriction */
   for (int n = 0; n < nlev; n++) vo_mk_mac_coeffs(rho[n], bp + 3 * n);
   vo_fab b0[3], *b0p[3];                                /* level 0's own coefficients, before the edge restriction overwrites the covered faces */
   for (int d = 0; d < 3; d++) { b0[d] = beta[d]; b0[d].p = (double *)malloc(sizeof(double) * vo_size(&beta[d])); memcpy(b0[d].p, beta[d].p, sizeof(double) * vo_size(&beta[d])); b0p[d] = &b0[d]; }
-  for (int n = nlev - 1; n >= 1; n--) for (int d = 0; d < 3; d++) vo_ml_edge_restriction(bp[3 * (n - 1) + d], bp[3 * n + d], d);
+  for (int n = nlev - 1; n >= 1; n--) for (int d = 0; d < 3; d++) vo_ml_edge_restriction_g(bp[3 * (n - 1) + d], bp[3 * n + d], LEV(lev, n), d);
   /* The level-0 V-cycle may run on level 0's own coefficients (round 3: the density-based kernels of the single-level solver) only where they are
    * close to the edge-restricted ones.  On averaged-down data 2/(rho_i + rho_i-1) is 1 / (mean rho), the restricted beta a mean of 1 / rho: with a sharp
    * density jump the own coefficients are softer by up to the density ratio, the correction overshoots and the FAC iteration slows down (10 : 1
@@ -471,13 +697,39 @@ void vo_ml_macproject(int nlev, vo_fab **umac, vo_fab **rho, vo_fab **mac_rhs, c
    * every face (the smooth profiles of the reference's inputs at production resolution), else the restricted ones (the round-2 iteration). */
   double worst = 1.0;
   for (int d = 0; d < 3; d++) { const long sz = vo_size(&beta[d]); for (long q = 0; q < sz; q++) { const double a = beta[d].p[q], b = b0[d].p[q]; const double r1 = a / b, r2 = b / a; worst = vo_nrm_acc(worst, r1 > r2 ? r1 : r2); } }
-  vo_ml_cc_solve(nlev, rhp, php, NULL, bp, dx, (const int (*)[3][2])ellbc, pmask, pd, prm->mac_rel_eps, prm->mg_max_iter, prm, worst <= 1.25 ? b0p : NULL, st);
+  double *gh[6 * VO_MAXLEV];
+  vo_ml_cc_solve_g(nlev, lev, rhp, php, NULL, bp, dx, (const int (*)[3][2])ellbc, pmask, pd, prm->mac_rel_eps, prm->mg_max_iter, prm, worst <= 1.25 ? b0p : NULL, st, gh);
   for (int d = 0; d < 3; d++) free(b0[d].p);
-  /* mkumac on every level with the solver's ghost cells, then edge restriction and the ghost faces (macproject.f90:103-119) */
-  for (int n = 0; n < nlev; n++) vo_mkumac(umac + 3 * n, &phi[n], bp + 3 * n, dx + 3 * n, ellbc[n]);
-  for (int n = nlev - 1; n >= 1; n--) for (int d = 0; d < 3; d++) vo_ml_edge_restriction(umac[3 * (n - 1) + d], umac[3 * n + d], d);
-  for (int d = 0; d < 3; d++) level_fill_boundary(umac[d], pmask, pd, pd + 3);
-  for (int n = 1; n < nlev; n++) for (int d = 0; d < 3; d++) { vo_create_umac_grown(umac[3 * n + d], umac[3 * (n - 1) + d], d); level_fill_boundary(umac[3 * n + d], pmask, pd + 6 * n, pd + 6 * n + 3); }
+  /* mkumac box by box (macproject.f90:578-645): u -= beta (phi_hi - phi_lo)/dx with phi beyond a box face = the neighbouring box's cell, the solver's
+   * closure at a domain face (Neumann: the face keeps its velocity), or the interface value of the solve */
+  for (int n = 0; n < nlev; n++) {
+    const int *pdlo = pd + 6 * n, *pdhi = pd + 6 * n + 3;
+    const vo_level *L = LEV(lev, n);
+    FOR_BOXES(L, rho[n], b, lo, hi) {
+      for (int d = 0; d < 3; d++) {
+        vo_fab *u = &umac[3 * n + d].f[b];
+        int rhi[3] = { hi[0], hi[1], hi[2] }; rhi[d] += 1;
+        for (int k = lo[2]; k <= rhi[2]; k++) for (int j = lo[1]; j <= rhi[1]; j++) for (int i = lo[0]; i <= rhi[0]; i++) {
+          int q[3] = { i, j, k }, m[3] = { i, j, k }; m[d] -= 1;
+          double vq, vm;
+          if (q[d] > pdhi[d]) { if (ellbc[n][d][1] == VDN_BC_NEU) continue; vm = VF(&phi[n], m[0], m[1], m[2], 0); vq = -vm; }
+          else if (m[d] < pdlo[d]) { if (ellbc[n][d][0] == VDN_BC_NEU) continue; vq = VF(&phi[n], q[0], q[1], q[2], 0); vm = -vq; }
+          else {
+            const int qv = lv_valid(L, &rh[n], q[0], q[1], q[2]), mv = lv_valid(L, &rh[n], m[0], m[1], m[2]);
+            vq = qv ? VF(&phi[n], q[0], q[1], q[2], 0) : gh[6 * n + 2 * d + 1][vo_idx(&rh[n], m[0], m[1], m[2], 0)];
+            vm = mv ? VF(&phi[n], m[0], m[1], m[2], 0) : gh[6 * n + 2 * d + 0][vo_idx(&rh[n], q[0], q[1], q[2], 0)];
+          }
+          const double gphi = (vq - vm) / dx[3 * n + d];
+          VF(u, i, j, k, 0) = VF(u, i, j, k, 0) - VF(&beta[3 * n + d], i, j, k, 0) * gphi;
+        }
+      }
+    }
+  }
+  for (int n = 0; n < nlev; n++) for (int q = 0; q < 6; q++) free(gh[6 * n + q]);
+  /* edge restriction and the ghost faces (macproject.f90:103-119) */
+  for (int n = nlev - 1; n >= 1; n--) for (int d = 0; d < 3; d++) bmf_edge_restriction(&umac[3 * (n - 1) + d], &umac[3 * n + d], d, 0);
+  for (int d = 0; d < 3; d++) bmf_fill_boundary(&umac[d], pmask, pd, pd + 3);
+  for (int n = 1; n < nlev; n++) for (int d = 0; d < 3; d++) { bmf_umac_grown(&umac[3 * n + d], &umac[3 * (n - 1) + d], d); bmf_fill_boundary(&umac[3 * n + d], pmask, pd + 6 * n, pd + 6 * n + 3); }
   for (int n = 0; n < nlev; n++) { free(rh[n].p); free(phi[n].p); for (int d = 0; d < 3; d++) free(beta[3 * n + d].p); }
 }
 
@@ -485,6 +737,11 @@ void vo_ml_macproject(int nlev, vo_fab **umac, vo_fab **rho, vo_fab **mac_rhs, c
  * unew: [lev] (ghost cells filled: they carry the wall values), lapu / rho / mac_rhs: [lev] */
 void vo_ml_visc_solve(int nlev, vo_fab **unew, vo_fab **lapu, vo_fab **rho, vo_fab **mac_rhs, const double *dx, double mu, const vo_bc *bc,
                       const int pmask[3], const int *pd, const vdn_params *prm, vo_mgstat *st)
+{
+  vo_ml_visc_solve_g(nlev, NULL, unew, lapu, rho, mac_rhs, dx, mu, bc, pmask, pd, prm, st);
+}
+void vo_ml_visc_solve_g(int nlev, const vo_level *const *lev, vo_fab **unew, vo_fab **lapu, vo_fab **rho, vo_fab **mac_rhs, const double *dx, double mu, const vo_bc *bc,
+                        const int pmask[3], const int *pd, const vdn_params *prm, vo_mgstat *st)
 {
   vo_fab rh[VO_MAXLEV], phi[VO_MAXLEV], alpha[VO_MAXLEV], beta[3 * VO_MAXLEV], *rhp[VO_MAXLEV], *php[VO_MAXLEV], *alp[VO_MAXLEV], *bp[3 * VO_MAXLEV];
   int ellbc[VO_MAXLEV][3][2];
@@ -518,18 +775,23 @@ void vo_ml_visc_solve(int nlev, vo_fab **unew, vo_fab **lapu, vo_fab **rho, vo_f
       }
       for (int a = 0; a < 3; a++) for (int s = 0; s < 2; s++) ellbc[n][a][s] = bc[n].ell[a][s][d];
     }
-    vo_ml_cc_solve(nlev, rhp, php, alp, bp, dx, (const int (*)[3][2])ellbc, pmask, pd, 1.e-12, prm->mg_max_iter, prm, NULL, st);
+    vo_ml_cc_solve_g(nlev, lev, rhp, php, alp, bp, dx, (const int (*)[3][2])ellbc, pmask, pd, 1.e-12, prm->mg_max_iter, prm, NULL, st, NULL);
     for (int n = 0; n < nlev; n++)
       for (int k = unew[n]->lo[2]; k <= unew[n]->hi[2]; k++) for (int j = unew[n]->lo[1]; j <= unew[n]->hi[1]; j++) for (int i = unew[n]->lo[0]; i <= unew[n]->hi[0]; i++)
-        VF(unew[n], i, j, k, d) = VF(&phi[n], i, j, k, 0);
+        if (lv_valid(LEV(lev, n), unew[n], i, j, k)) VF(unew[n], i, j, k, d) = VF(&phi[n], i, j, k, 0);
   }
-  vo_ml_restrict_and_fill(nlev, unew, 0, 0, 3, 0, bc, pmask, pd, prm);           /* viscsolve.f90:106 */
+  vo_ml_restrict_and_fill_g(nlev, lev, unew, 0, 0, 3, 0, bc, pmask, pd, prm);           /* viscsolve.f90:106 */
   for (int n = 0; n < nlev; n++) { free(rh[n].p); free(phi[n].p); free(alpha[n].p); for (int d = 0; d < 3; d++) free(beta[3 * n + d].p); }
 }
 
 /* diff_scalar_solve (viscsolve.f90:308-515) on nlev levels: (1 - div mu grad) s = s [+ mu laps], component icomp, bc component bccomp */
 void vo_ml_diff_scalar_solve(int nlev, vo_fab **snew, vo_fab **laps, const double *dx, double mu, const vo_bc *bc, const int pmask[3], const int *pd,
                              const vdn_params *prm, int icomp, int bccomp, vo_mgstat *st)
+{
+  vo_ml_diff_scalar_solve_g(nlev, NULL, snew, laps, dx, mu, bc, pmask, pd, prm, icomp, bccomp, st);
+}
+void vo_ml_diff_scalar_solve_g(int nlev, const vo_level *const *lev, vo_fab **snew, vo_fab **laps, const double *dx, double mu, const vo_bc *bc, const int pmask[3], const int *pd,
+                               const vdn_params *prm, int icomp, int bccomp, vo_mgstat *st)
 {
   vo_fab rh[VO_MAXLEV], phi[VO_MAXLEV], alpha[VO_MAXLEV], beta[3 * VO_MAXLEV], *rhp[VO_MAXLEV], *php[VO_MAXLEV], *alp[VO_MAXLEV], *bp[3 * VO_MAXLEV];
   int ellbc[VO_MAXLEV][3][2];
@@ -555,11 +817,11 @@ void vo_ml_diff_scalar_solve(int nlev, vo_fab **snew, vo_fab **laps, const doubl
     }
     for (int a = 0; a < 3; a++) for (int sd = 0; sd < 2; sd++) ellbc[n][a][sd] = bc[n].ell[a][sd][bccomp];
   }
-  vo_ml_cc_solve(nlev, rhp, php, alp, bp, dx, (const int (*)[3][2])ellbc, pmask, pd, 1.e-12, prm->mg_max_iter, prm, NULL, st);
+  vo_ml_cc_solve_g(nlev, lev, rhp, php, alp, bp, dx, (const int (*)[3][2])ellbc, pmask, pd, 1.e-12, prm->mg_max_iter, prm, NULL, st, NULL);
   for (int n = 0; n < nlev; n++)
     for (int k = snew[n]->lo[2]; k <= snew[n]->hi[2]; k++) for (int j = snew[n]->lo[1]; j <= snew[n]->hi[1]; j++) for (int i = snew[n]->lo[0]; i <= snew[n]->hi[0]; i++)
-      VF(snew[n], i, j, k, icomp) = VF(&phi[n], i, j, k, 0);
-  vo_ml_restrict_and_fill(nlev, snew, icomp, bccomp, 1, 0, bc, pmask, pd, prm);          /* viscsolve.f90:378-381 */
+      if (lv_valid(LEV(lev, n), snew[n], i, j, k)) VF(snew[n], i, j, k, icomp) = VF(&phi[n], i, j, k, 0);
+  vo_ml_restrict_and_fill_g(nlev, lev, snew, icomp, bccomp, 1, 0, bc, pmask, pd, prm);          /* viscsolve.f90:378-381 */
   for (int n = 0; n < nlev; n++) { free(rh[n].p); free(phi[n].p); free(alpha[n].p); for (int d = 0; d < 3; d++) free(beta[3 * n + d].p); }
 }
 
@@ -567,21 +829,41 @@ void vo_ml_diff_scalar_solve(int nlev, vo_fab **snew, vo_fab **laps, const doubl
 void vo_ml_hgproject(int nlev, int proj_type, vo_fab **unew, vo_fab **uold, vo_fab **rhohalf, vo_fab **p, vo_fab **gp, const double *dx, double dt,
                      const vo_bc *bc, const int pmask[3], const int *pd, const vdn_params *prm, vo_mgstat *st)
 {
+  vo_ml_hgproject_g(nlev, NULL, proj_type, unew, uold, rhohalf, p, gp, dx, dt, bc, pmask, pd, prm, st);
+}
+void vo_ml_hgproject_g(int nlev, const vo_level *const *lev, int proj_type, vo_fab **unew, vo_fab **uold, vo_fab **rhohalf, vo_fab **p, vo_fab **gp, const double *dx, double dt,
+                       const vo_bc *bc, const int pmask[3], const int *pd, const vdn_params *prm, vo_mgstat *st)
+{
+  require_no_periodic(nlev, lev, pmask, "vo_ml_hgproject");
   vo_fab rh[VO_MAXLEV], phi[VO_MAXLEV], gphi[VO_MAXLEV], coeffs[VO_MAXLEV], *rhp[VO_MAXLEV], *php[VO_MAXLEV], *cfp[VO_MAXLEV];
   int ellbc[VO_MAXLEV][3][2];
   int nd1[3] = { 1, 1, 1 };
   for (int n = 0; n < nlev; n++) {
     const int *lo = unew[n]->lo, *hi = unew[n]->hi;
+    const vo_level *L = LEV(lev, n);
     vo_fab_init(&rh[n], NULL, lo, hi, 1, nd1, 1);    rh[n].p = (double *)calloc(vo_size(&rh[n]), sizeof(double));
     vo_fab_init(&phi[n], NULL, lo, hi, 1, nd1, 1);   phi[n].p = (double *)calloc(vo_size(&phi[n]), sizeof(double));
     vo_fab_init(&gphi[n], NULL, lo, hi, 0, NULL, 3); gphi[n].p = (double *)calloc(vo_size(&gphi[n]), sizeof(double));
     vo_fab_init(&coeffs[n], NULL, lo, hi, 1, NULL, 1); coeffs[n].p = (double *)calloc(vo_size(&coeffs[n]), sizeof(double));
     rhp[n] = &rh[n]; php[n] = &phi[n]; cfp[n] = &coeffs[n];
     for (int d = 0; d < 3; d++) for (int s = 0; s < 2; s++) ellbc[n][d][s] = bc[n].ell[d][s][bc[n].press_comp];
-    vo_create_uvec(unew[n], uold[n], rhohalf[n], gp[n], dt, &bc[n], proj_type);
-    level_fill_boundary(unew[n], pmask, pd + 6 * n, pd + 6 * n + 3);
+    if (!lv_multi(L)) {
+      vo_create_uvec(unew[n], uold[n], rhohalf[n], gp[n], dt, &bc[n], proj_type);
+      level_fill_boundary(unew[n], pmask, pd + 6 * n, pd + 6 * n + 3);
+    } else {
+      /* create_uvec box by box (it rewrites unew on the box and one ghost ring): the cells of the box go back; of the ring the composite right-hand side reads
+       * nothing on a refined level (the velocity is masked to the level's own cells there) */
+      FOR_BOXES(L, unew[n], b, blo, bhi) {
+        vo_fab bu, bo, br, bg; vo_bc bb;
+        box_gather(&bu, blo, bhi, unew[n]->ng, unew[n]); box_gather(&bo, blo, bhi, uold[n]->ng, uold[n]); box_gather(&br, blo, bhi, rhohalf[n]->ng, rhohalf[n]); box_gather(&bg, blo, bhi, gp[n]->ng, gp[n]);
+        box_bc(&bb, &bc[n], blo, bhi, pd + 6 * n, pd + 6 * n + 3, prm);
+        vo_create_uvec(&bu, &bo, &br, &bg, dt, &bb, proj_type);
+        box_scatter(unew[n], &bu, 0, 3);
+        free(bu.p); free(bo.p); free(br.p); free(bg.p);
+      }
+    }
     for (int k = lo[2]; k <= hi[2]; k++) for (int j = lo[1]; j <= hi[1]; j++) for (int i = lo[0]; i <= hi[0]; i++)
-      VF(&coeffs[n], i, j, k, 0) = 1.0 / VF(rhohalf[n], i, j, k, 0);
+      if (lv_valid(L, unew[n], i, j, k)) VF(&coeffs[n], i, j, k, 0) = 1.0 / VF(rhohalf[n], i, j, k, 0);
     level_fill_boundary(&coeffs[n], pmask, pd + 6 * n, pd + 6 * n + 3);
   }
   /* Under a finer level the coefficient of a level is the MEAN OF THE FINE sigma (what the multigrid's own coarsening takes, round 4), not
@@ -589,43 +871,103 @@ void vo_ml_hgproject(int nlev, int proj_type, vo_fab **unew, vo_fab **uold, vo_f
    * equations, and with a sharp density jump the two differ by the density ratio (one heavy child among eight: 1/mean(rho) = 8/rho_heavy against
    * mean(1/rho) = 7/8) -- the softer operator overshoots and the FAC iteration diverged for one-cell jumps of 300 : 1 and more.  Smooth fields: the
    * same to O(h^2).  The composite equations themselves read sigma only on uncovered cells and are unchanged. */
-  for (int n = nlev - 1; n >= 1; n--) { vo_ml_cc_restriction(&coeffs[n - 1], &coeffs[n], 0, 1); level_fill_boundary(&coeffs[n - 1], pmask, pd + 6 * (n - 1), pd + 6 * (n - 1) + 3); }
+  for (int n = nlev - 1; n >= 1; n--) { vo_ml_cc_restriction_g(&coeffs[n - 1], &coeffs[n], LEV(lev, n), 0, 1); level_fill_boundary(&coeffs[n - 1], pmask, pd + 6 * (n - 1), pd + 6 * (n - 1) + 3); }
   double rel = prm->hg_rel_eps > 0.0 ? prm->hg_rel_eps : (nlev == 2 ? 1.e-11 : 1.e-10);
   double abs_eps = -1.0;
   if (proj_type == VDN_INITIAL_PROJECTION && prm->prob_type == 4) abs_eps = 1.e-12;
-  vo_ml_nd_solve(nlev, rhp, php, cfp, unew, dx, (const int (*)[3][2])ellbc, pmask, rel, abs_eps, prm->hg_max_iter, prm, st);
+  vo_ml_nd_solve_g(nlev, lev, rhp, php, cfp, unew, dx, (const int (*)[3][2])ellbc, pmask, pd, rel, abs_eps, prm->hg_max_iter, prm, st);
   for (int n = 0; n < nlev; n++) {
-    vo_mkgphi(&gphi[n], &phi[n], dx + 3 * n);
-    vo_hg_update(proj_type, unew[n], uold[n], gp[n], &gphi[n], rhohalf[n], p[n], &phi[n], dt);
+    const vo_level *L = LEV(lev, n);
+    if (!lv_multi(L)) {
+      vo_mkgphi(&gphi[n], &phi[n], dx + 3 * n);
+      vo_hg_update(proj_type, unew[n], uold[n], gp[n], &gphi[n], rhohalf[n], p[n], &phi[n], dt);
+    } else {
+      /* initial projection / divu iterations zero gp and p everywhere (hg_update's memset): here on the whole level array once */
+      if (proj_type == VDN_INITIAL_PROJECTION || proj_type == VDN_DIVU_ITERS) { memset(gp[n]->p, 0, sizeof(double) * vo_size(gp[n])); memset(p[n]->p, 0, sizeof(double) * vo_size(p[n])); }
+      vo_fab pin = *p[n];                               /* the incoming pressure: boxes share nodes, and the pressure iterations ADD to it */
+      pin.p = (double *)malloc(sizeof(double) * vo_size(p[n])); memcpy(pin.p, p[n]->p, sizeof(double) * vo_size(p[n]));
+      FOR_BOXES(L, unew[n], b, blo, bhi) {
+        vo_fab bu, bo, br, bg, bgp, bp_, bph;
+        box_gather(&bu, blo, bhi, 0, unew[n]); box_gather(&bo, blo, bhi, 0, uold[n]); box_gather(&br, blo, bhi, 0, rhohalf[n]); box_gather(&bg, blo, bhi, 0, gp[n]);
+        fab_new(&bgp, blo, bhi, 0, -1, 3, 0.0);
+        vo_fab_init(&bp_, NULL, blo, bhi, 0, nd1, 1); bp_.p = (double *)calloc(vo_size(&bp_), sizeof(double));
+        vo_fab_init(&bph, NULL, blo, bhi, 0, nd1, 1); bph.p = (double *)calloc(vo_size(&bph), sizeof(double));
+        for (int k = blo[2]; k <= bhi[2] + 1; k++) for (int j = blo[1]; j <= bhi[1] + 1; j++) for (int i = blo[0]; i <= bhi[0] + 1; i++) { VF(&bph, i, j, k, 0) = VF(&phi[n], i, j, k, 0); VF(&bp_, i, j, k, 0) = VF(&pin, i, j, k, 0); }
+        vo_mkgphi(&bgp, &bph, dx + 3 * n);
+        vo_hg_update(proj_type, &bu, &bo, &bg, &bgp, &br, &bp_, &bph, dt);
+        box_scatter(unew[n], &bu, 0, 3); box_scatter(gp[n], &bg, 0, 3);
+        for (int k = blo[2]; k <= bhi[2] + 1; k++) for (int j = blo[1]; j <= bhi[1] + 1; j++) for (int i = blo[0]; i <= bhi[0] + 1; i++) VF(p[n], i, j, k, 0) = VF(&bp_, i, j, k, 0);
+        free(bu.p); free(bo.p); free(br.p); free(bg.p); free(bgp.p); free(bp_.p); free(bph.p);
+      }
+      free(pin.p);
+    }
   }
-  for (int n = nlev - 1; n >= 1; n--) vo_ml_cc_restriction(gp[n - 1], gp[n], 0, 3);              /* hgproject.f90:355-357 */
+  for (int n = nlev - 1; n >= 1; n--) vo_ml_cc_restriction_g(gp[n - 1], gp[n], LEV(lev, n), 0, 3);              /* hgproject.f90:355-357 */
   for (int n = 0; n < nlev; n++) { level_fill_boundary(gp[n], pmask, pd + 6 * n, pd + 6 * n + 3); level_fill_boundary(p[n], pmask, pd + 6 * n, pd + 6 * n + 3); }
-  vo_ml_restrict_and_fill(nlev, unew, 0, 0, 3, 0, bc, pmask, pd, prm);        /* hgproject.f90:364-366 */
+  vo_ml_restrict_and_fill_g(nlev, lev, unew, 0, 0, 3, 0, bc, pmask, pd, prm);        /* hgproject.f90:364-366 */
   for (int n = 0; n < nlev; n++) { free(rh[n].p); free(phi[n].p); free(gphi[n].p); free(coeffs[n].p); }
 }
 
-/* advance_timestep.f90:26-170 on nlev levels (inviscid): the orchestration of oracle/vo_advance.c with level loops, ml_restrict_and_fill
- * in place of fill_boundary + physbc, the velpred tail of velpred.f90:102-122 and the multilevel projections.  S: [lev] */
-static void fab_new_l(vo_fab *f, const vo_fab *like, int ng, int face_dir, int nc, double val)
+/* estdt of one level: the minimum over its boxes (estdt.f90:47-78) */
+double vo_estdt_g(const vo_level *L, const vo_fab *u, const vo_fab *s, const vo_fab *gp, const vo_fab *ext, const double dx[3], double dtold, const vdn_params *prm)
 {
-  int nd[3] = { 0, 0, 0 }; if (face_dir >= 0) nd[face_dir] = 1;
-  vo_fab_init(f, NULL, like->lo, like->hi, ng, nd, nc);
-  long n = vo_size(f);
-  f->p = (double *)malloc(sizeof(double) * n);
-  for (long i = 0; i < n; i++) f->p[i] = val;
+  if (!lv_multi(L)) return vo_estdt(u, s, gp, ext, dx, dtold, prm);
+  double dt = 1.e300;
+  FOR_BOXES(L, u, b, lo, hi) {
+    vo_fab bu, bs, bg, be;
+    box_gather(&bu, lo, hi, 0, u); box_gather(&bs, lo, hi, 0, s); box_gather(&bg, lo, hi, 0, gp); box_gather(&be, lo, hi, 0, ext);
+    const double d1 = vo_estdt(&bu, &bs, &bg, &be, dx, dtold, prm);
+    if (d1 < dt) dt = d1;
+    free(bu.p); free(bs.p); free(bg.p); free(be.p);
+  }
+  return dt;
 }
+
+/* advance_timestep.f90:26-170 on nlev levels: the orchestration of oracle/vo_advance.c with level loops, ml_restrict_and_fill
+ * in place of fill_boundary + physbc, the velpred tail of velpred.f90:102-122, the restriction of the conservative fluxes (mkflux.f90:137-146)
+ * and the multilevel projections.  S: [lev], level arrays.  The per-box kernels run on copies of each box with its ghost cells. */
+static void fab_new_l(vo_fab *f, const vo_fab *like, int ng, int face_dir, int nc, double val) { fab_new(f, like->lo, like->hi, ng, face_dir, nc, val); }
 void vo_ml_advance_timestep(int NL, vo_state *S, const double *dx, double dt, const vo_bc *bc, const int pmask[3], const int *pd, const vdn_params *prm,
                             int proj_type, vo_mgstat st[2])
 {
+  vo_ml_advance_timestep_g(NL, NULL, S, dx, dt, bc, pmask, pd, prm, proj_type, st);
+}
+/* one cell-centred kernel on every box of a level: in[] are gathered with their own ghost widths, out (components c0..c0+nc-1 of outarr) scattered back */
+typedef void (*boxfn)(vo_fab *out, vo_fab **in, const vo_bc *bcb, const int *lo, const int *hi, void *ctx);
+static void on_boxes(const vo_level *L, vo_fab *outarr, int c0, int nc, vo_fab **inarr, int nin, const vo_bc *levbc, const int *pdlo, const int *pdhi, const vdn_params *prm, boxfn fn, void *ctx)
+{
+  if (!lv_multi(L)) { fn(outarr, inarr, levbc, outarr->lo, outarr->hi, ctx); return; }
+  FOR_BOXES(L, outarr, b, lo, hi) {
+    vo_fab bo, bi[8], *bip[8]; vo_bc bb;
+    box_gather(&bo, lo, hi, outarr->ng, outarr);
+    for (int q = 0; q < nin; q++) { if (inarr[q]) { box_gather(&bi[q], lo, hi, inarr[q]->ng, inarr[q]); bip[q] = &bi[q]; } else bip[q] = NULL; }
+    box_bc(&bb, levbc, lo, hi, pdlo, pdhi, prm);
+    fn(&bo, bip, &bb, lo, hi, ctx);
+    box_scatter(outarr, &bo, c0, nc);
+    free(bo.p); for (int q = 0; q < nin; q++) if (inarr[q]) free(bi[q].p);
+  }
+}
+typedef struct { const vdn_params *prm; double fac; const double *dx; int comp, bccomp; } kctx;
+static void k_velforce(vo_fab *out, vo_fab **in, const vo_bc *bcb, const int *lo, const int *hi, void *c) { (void)bcb; (void)lo; (void)hi; kctx *k = (kctx *)c; vo_mkvelforce(out, in[0], in[1], in[2], in[3], k->fac, k->prm); }
+static void k_scalforce(vo_fab *out, vo_fab **in, const vo_bc *bcb, const int *lo, const int *hi, void *c) { (void)bcb; (void)lo; (void)hi; kctx *k = (kctx *)c; vo_mkscalforce(out, in[0], in[1], k->fac, k->prm); }
+static void k_lap(vo_fab *out, vo_fab **in, const vo_bc *bcb, const int *lo, const int *hi, void *c) { (void)lo; (void)hi; kctx *k = (kctx *)c; vo_explicit_diffusive_term(out, in[0], k->comp, k->bccomp, k->dx, bcb); }
+static void k_halftime(vo_fab *out, vo_fab **in, const vo_bc *bcb, const int *lo, const int *hi, void *c) { (void)bcb; (void)lo; (void)hi; (void)c; vo_make_at_halftime(out, 0, in[0], in[1], 0); }
+
+void vo_ml_advance_timestep_g(int NL, const vo_level *const *lev, vo_state *S, const double *dx, double dt, const vo_bc *bc, const int pmask[3], const int *pd,
+                              const vdn_params *prm, int proj_type, vo_mgstat st[2])
+{
+  require_no_periodic(NL, lev, pmask, "vo_ml_advance_timestep");
   const int dm = 3, nscal = prm->nscal;
-  vo_fab mac_rhs[VO_MAXLEV], rhohalf[VO_MAXLEV], umac[3 * VO_MAXLEV], vel_force[VO_MAXLEV], scal_force[VO_MAXLEV], divu[VO_MAXLEV], sedge[3 * VO_MAXLEV], sflux[3 * VO_MAXLEV], uedge[3 * VO_MAXLEV], uflux[3 * VO_MAXLEV];
-  vo_fab *mrp[VO_MAXLEV], *rhp[VO_MAXLEV], *ump[3 * VO_MAXLEV], *vfp[VO_MAXLEV], *sfp2[VO_MAXLEV], *sep[3 * VO_MAXLEV], *sfp[3 * VO_MAXLEV], *uep[3 * VO_MAXLEV], *ufp[3 * VO_MAXLEV];
+  vo_fab mac_rhs[VO_MAXLEV], rhohalf[VO_MAXLEV], vel_force[VO_MAXLEV], scal_force[VO_MAXLEV], divu[VO_MAXLEV];
+  vo_bmf umac[3 * VO_MAXLEV], sedge[3 * VO_MAXLEV], sflux[3 * VO_MAXLEV], uedge[3 * VO_MAXLEV], uflux[3 * VO_MAXLEV];
+  vo_fab *mrp[VO_MAXLEV], *rhp[VO_MAXLEV], *vfp[VO_MAXLEV], *sfp2[VO_MAXLEV];
   vo_fab *uoldp[VO_MAXLEV], *soldp[VO_MAXLEV], *unewp[VO_MAXLEV], *snewp[VO_MAXLEV], *gpp[VO_MAXLEV], *pp[VO_MAXLEV];
+  #define PDL(n) (pd + 6 * (n)), (pd + 6 * (n) + 3)
   for (int n = 0; n < NL; n++) {
     uoldp[n] = &S[n].uold; soldp[n] = &S[n].sold; unewp[n] = &S[n].unew; snewp[n] = &S[n].snew; gpp[n] = &S[n].gp; pp[n] = &S[n].p;
     fab_new_l(&mac_rhs[n], &S[n].uold, 1, -1, 1, 0.0); mrp[n] = &mac_rhs[n];
     fab_new_l(&rhohalf[n], &S[n].uold, 1, -1, dm, 0.0); rhp[n] = &rhohalf[n];
-    for (int d = 0; d < 3; d++) { fab_new_l(&umac[3 * n + d], &S[n].uold, 1, d, 1, 1.e20); ump[3 * n + d] = &umac[3 * n + d]; }
+    for (int d = 0; d < 3; d++) bmf_new(&umac[3 * n + d], LEV(lev, n), &S[n].uold, 1, d, 1, 1.e20);
     fab_new_l(&vel_force[n], &S[n].uold, 1, -1, dm, 0.0); vfp[n] = &vel_force[n];
   }
   /* lapu (advance_timestep.f90:85-93; get_explicit_diffusive_term = cc_applyop per level on the filled ghost cells, then average down) */
@@ -633,18 +975,28 @@ void vo_ml_advance_timestep(int NL, vo_state *S, const double *dx, double dt, co
   vo_fab lapu[VO_MAXLEV], *lap[VO_MAXLEV];
   for (int n = 0; n < NL; n++) {
     fab_new_l(&lapu[n], &S[n].uold, 0, -1, dm, 0.0); lap[n] = &lapu[n];
-    if (viscous) for (int c = 0; c < dm; c++) vo_explicit_diffusive_term(&lapu[n], &S[n].uold, c, c, dx + 3 * n, &bc[n]);
+    if (viscous) for (int c = 0; c < dm; c++) { kctx k = { prm, 0.0, dx + 3 * n, c, c }; vo_fab *in[1] = { &S[n].uold }; on_boxes(LEV(lev, n), &lapu[n], c, 1, in, 1, &bc[n], PDL(n), prm, k_lap, &k); }
   }
-  if (viscous) for (int n = NL - 1; n >= 1; n--) vo_ml_cc_restriction(lap[n - 1], lap[n], 0, dm);
+  if (viscous) for (int n = NL - 1; n >= 1; n--) vo_ml_cc_restriction_g(lap[n - 1], lap[n], LEV(lev, n), 0, dm);
   /* advance_premac */
-  for (int n = 0; n < NL; n++) vo_mkvelforce(&vel_force[n], &S[n].ext_vel_force, &S[n].gp, &S[n].sold, viscous ? &lapu[n] : NULL, 1.0, prm);
-  vo_ml_restrict_and_fill(NL, vfp, 0, bc[0].extrap_comp, dm, 1, bc, pmask, pd, prm);
-  for (int n = 0; n < NL; n++) vo_velpred(&S[n].uold, ump + 3 * n, &vel_force[n], dx + 3 * n, dt, &bc[n], prm);
-  for (int d = 0; d < 3; d++) level_fill_boundary(&umac[d], pmask, pd, pd + 3);
-  for (int n = 1; n < NL; n++) for (int d = 0; d < 3; d++) { vo_create_umac_grown(&umac[3 * n + d], &umac[3 * (n - 1) + d], d); level_fill_boundary(&umac[3 * n + d], pmask, pd + 6 * n, pd + 6 * n + 3); }
-  for (int n = NL - 1; n >= 1; n--) for (int d = 0; d < 3; d++) vo_ml_edge_restriction(&umac[3 * (n - 1) + d], &umac[3 * n + d], d);
+  for (int n = 0; n < NL; n++) { kctx k = { prm, 1.0, NULL, 0, 0 }; vo_fab *in[4] = { &S[n].ext_vel_force, &S[n].gp, &S[n].sold, viscous ? &lapu[n] : NULL }; on_boxes(LEV(lev, n), &vel_force[n], 0, dm, in, 4, &bc[n], PDL(n), prm, k_velforce, &k); }
+  vo_ml_restrict_and_fill_g(NL, lev, vfp, 0, bc[0].extrap_comp, dm, 1, bc, pmask, pd, prm);
+  for (int n = 0; n < NL; n++) {
+    const vo_level *L = LEV(lev, n);
+    FOR_BOXES(L, &S[n].uold, b, lo, hi) {
+      vo_fab *u3[3] = { &umac[3 * n].f[b], &umac[3 * n + 1].f[b], &umac[3 * n + 2].f[b] };
+      if (!lv_multi(L)) { vo_velpred(&S[n].uold, u3, &vel_force[n], dx + 3 * n, dt, &bc[n], prm); continue; }
+      vo_fab bu, bf; vo_bc bb;
+      box_gather(&bu, lo, hi, S[n].uold.ng, &S[n].uold); box_gather(&bf, lo, hi, 1, &vel_force[n]); box_bc(&bb, &bc[n], lo, hi, PDL(n), prm);
+      vo_velpred(&bu, u3, &bf, dx + 3 * n, dt, &bb, prm);
+      free(bu.p); free(bf.p);
+    }
+  }
+  for (int d = 0; d < 3; d++) bmf_fill_boundary(&umac[d], pmask, pd, pd + 3);
+  for (int n = 1; n < NL; n++) for (int d = 0; d < 3; d++) { bmf_umac_grown(&umac[3 * n + d], &umac[3 * (n - 1) + d], d); bmf_fill_boundary(&umac[3 * n + d], pmask, PDL(n)); }
+  for (int n = NL - 1; n >= 1; n--) for (int d = 0; d < 3; d++) bmf_edge_restriction(&umac[3 * (n - 1) + d], &umac[3 * n + d], d, 0);
   /* MAC projection */
-  vo_ml_macproject(NL, ump, soldp, mrp, dx, bc, pmask, pd, prm, &st[0]);
+  vo_ml_macproject_g(NL, lev, umac, soldp, mrp, dx, bc, pmask, pd, prm, &st[0]);
   /* scalar advance */
   {
     int is_cons[VO_MAXCOMP]; is_cons[0] = 1; for (int c = 1; c < nscal; c++) is_cons[c] = 0;
@@ -652,56 +1004,102 @@ void vo_ml_advance_timestep(int NL, vo_state *S, const double *dx, double dt, co
     vo_fab laps[VO_MAXLEV], *lsp[VO_MAXLEV];
     for (int n = 0; n < NL; n++) {                                                         /* scalar_advance.f90:80-89, then average down */
       fab_new_l(&laps[n], &S[n].uold, 0, -1, nscal, 0.0); lsp[n] = &laps[n];
-      if (diffusive) for (int c = 1; c < nscal; c++) vo_explicit_diffusive_term(&laps[n], &S[n].sold, c, dm + c, dx + 3 * n, &bc[n]);
+      if (diffusive) for (int c = 1; c < nscal; c++) { kctx k = { prm, 0.0, dx + 3 * n, c, dm + c }; vo_fab *in[1] = { &S[n].sold }; on_boxes(LEV(lev, n), &laps[n], c, 1, in, 1, &bc[n], PDL(n), prm, k_lap, &k); }
     }
-    if (diffusive) for (int n = NL - 1; n >= 1; n--) vo_ml_cc_restriction(lsp[n - 1], lsp[n], 1, nscal - 1);
+    if (diffusive) for (int n = NL - 1; n >= 1; n--) vo_ml_cc_restriction_g(lsp[n - 1], lsp[n], LEV(lev, n), 1, nscal - 1);
     for (int n = 0; n < NL; n++) {
       fab_new_l(&scal_force[n], &S[n].uold, 1, -1, nscal, 0.0); sfp2[n] = &scal_force[n];
       fab_new_l(&divu[n], &S[n].uold, 1, -1, 1, 0.0);
-      for (int d = 0; d < 3; d++) { fab_new_l(&sflux[3 * n + d], &S[n].uold, 0, d, nscal, 0.0); fab_new_l(&sedge[3 * n + d], &S[n].uold, 0, d, nscal, 0.0); sfp[3 * n + d] = &sflux[3 * n + d]; sep[3 * n + d] = &sedge[3 * n + d]; }
-      vo_mkscalforce(&scal_force[n], &S[n].ext_scal_force, diffusive ? &laps[n] : NULL, 1.0, prm);
+      for (int d = 0; d < 3; d++) { bmf_new(&sflux[3 * n + d], LEV(lev, n), &S[n].uold, 0, d, nscal, 0.0); bmf_new(&sedge[3 * n + d], LEV(lev, n), &S[n].uold, 0, d, nscal, 0.0); }
+      kctx k = { prm, 1.0, NULL, 0, 0 }; vo_fab *in[2] = { &S[n].ext_scal_force, diffusive ? &laps[n] : NULL };
+      on_boxes(LEV(lev, n), &scal_force[n], 0, nscal, in, 2, &bc[n], PDL(n), prm, k_scalforce, &k);
     }
-    vo_ml_restrict_and_fill(NL, sfp2, 0, bc[0].extrap_comp, nscal, 1, bc, pmask, pd, prm);
+    vo_ml_restrict_and_fill_g(NL, lev, sfp2, 0, bc[0].extrap_comp, nscal, 1, bc, pmask, pd, prm);
     for (int n = 0; n < NL; n++) {
-      vo_mkflux(&S[n].sold, sep + 3 * n, sfp + 3 * n, ump + 3 * n, &scal_force[n], &divu[n], dx + 3 * n, dt, 0, is_cons, dm, &bc[n], prm);
-      vo_mkscalforce(&scal_force[n], &S[n].ext_scal_force, diffusive ? &laps[n] : NULL, 0.0, prm);
+      const vo_level *L = LEV(lev, n);
+      FOR_BOXES(L, &S[n].uold, b, lo, hi) {
+        vo_fab *u3[3] = { &umac[3 * n].f[b], &umac[3 * n + 1].f[b], &umac[3 * n + 2].f[b] }, *e3[3] = { &sedge[3 * n].f[b], &sedge[3 * n + 1].f[b], &sedge[3 * n + 2].f[b] }, *f3[3] = { &sflux[3 * n].f[b], &sflux[3 * n + 1].f[b], &sflux[3 * n + 2].f[b] };
+        if (!lv_multi(L)) { vo_mkflux(&S[n].sold, e3, f3, u3, &scal_force[n], &divu[n], dx + 3 * n, dt, 0, is_cons, dm, &bc[n], prm); continue; }
+        vo_fab bs, bf, bd; vo_bc bb;
+        box_gather(&bs, lo, hi, S[n].sold.ng, &S[n].sold); box_gather(&bf, lo, hi, 1, &scal_force[n]); box_gather(&bd, lo, hi, 1, &divu[n]); box_bc(&bb, &bc[n], lo, hi, PDL(n), prm);
+        vo_mkflux(&bs, e3, f3, u3, &bf, &bd, dx + 3 * n, dt, 0, is_cons, dm, &bb, prm);
+        free(bs.p); free(bf.p); free(bd.p);
+      }
+      kctx k = { prm, 0.0, NULL, 0, 0 }; vo_fab *in[2] = { &S[n].ext_scal_force, diffusive ? &laps[n] : NULL };
+      on_boxes(L, &scal_force[n], 0, nscal, in, 2, &bc[n], PDL(n), prm, k_scalforce, &k);
     }
-    vo_ml_restrict_and_fill(NL, sfp2, 0, bc[0].extrap_comp, nscal, 1, bc, pmask, pd, prm);
-    for (int n = 0; n < NL; n++) vo_update(&S[n].sold, ump + 3 * n, sep + 3 * n, sfp + 3 * n, &scal_force[n], &S[n].snew, dx + 3 * n, dt, 0, is_cons);
-    vo_ml_restrict_and_fill(NL, snewp, 0, dm, nscal, 0, bc, pmask, pd, prm);
+    /* mkflux.f90:137-146: the fluxes of the conservative components on a coarse face under a finer level = the mean of the fine fluxes -- the coarse
+     * cells next to the finer level are updated with the fine level's fluxes through the interface (round 5: missing in rounds 2-4) */
+    for (int n = NL - 1; n >= 1; n--) for (int c = 0; c < nscal; c++) if (is_cons[c]) for (int d = 0; d < 3; d++) bmf_edge_restriction(&sflux[3 * (n - 1) + d], &sflux[3 * n + d], d, c);
+    vo_ml_restrict_and_fill_g(NL, lev, sfp2, 0, bc[0].extrap_comp, nscal, 1, bc, pmask, pd, prm);
+    for (int n = 0; n < NL; n++) {
+      const vo_level *L = LEV(lev, n);
+      FOR_BOXES(L, &S[n].uold, b, lo, hi) {
+        vo_fab *u3[3] = { &umac[3 * n].f[b], &umac[3 * n + 1].f[b], &umac[3 * n + 2].f[b] }, *e3[3] = { &sedge[3 * n].f[b], &sedge[3 * n + 1].f[b], &sedge[3 * n + 2].f[b] }, *f3[3] = { &sflux[3 * n].f[b], &sflux[3 * n + 1].f[b], &sflux[3 * n + 2].f[b] };
+        if (!lv_multi(L)) { vo_update(&S[n].sold, u3, e3, f3, &scal_force[n], &S[n].snew, dx + 3 * n, dt, 0, is_cons); continue; }
+        vo_fab bs, bf, bn;
+        box_gather(&bs, lo, hi, 0, &S[n].sold); box_gather(&bf, lo, hi, 0, &scal_force[n]); box_gather(&bn, lo, hi, 0, &S[n].snew);
+        vo_update(&bs, u3, e3, f3, &bf, &bn, dx + 3 * n, dt, 0, is_cons);
+        box_scatter(&S[n].snew, &bn, 0, nscal);
+        free(bs.p); free(bf.p); free(bn.p);
+      }
+    }
+    vo_ml_restrict_and_fill_g(NL, lev, snewp, 0, dm, nscal, 0, bc, pmask, pd, prm);
     if (diffusive) {                                                                   /* scalar_advance.f90:144-162 */
       const double visc_mu = (prm->diffusion_type == 1) ? 0.5 * dt * prm->diff_coef : dt * prm->diff_coef;
       vo_mgstat sst;
-      for (int c = 1; c < nscal; c++) vo_ml_diff_scalar_solve(NL, snewp, lsp, dx, visc_mu, bc, pmask, pd, prm, c, dm + c, &sst);
+      for (int c = 1; c < nscal; c++) vo_ml_diff_scalar_solve_g(NL, lev, snewp, lsp, dx, visc_mu, bc, pmask, pd, prm, c, dm + c, &sst);
     }
     for (int n = 0; n < NL; n++) free(laps[n].p);
-    for (int n = 0; n < NL; n++) { free(scal_force[n].p); free(divu[n].p); for (int d = 0; d < 3; d++) { free(sflux[3 * n + d].p); free(sedge[3 * n + d].p); } }
+    for (int n = 0; n < NL; n++) { free(scal_force[n].p); free(divu[n].p); for (int d = 0; d < 3; d++) { bmf_free(&sflux[3 * n + d]); bmf_free(&sedge[3 * n + d]); } }
   }
-  for (int n = 0; n < NL; n++) vo_make_at_halftime(&rhohalf[n], 0, &S[n].sold, &S[n].snew, 0);
-  vo_ml_restrict_and_fill(NL, rhp, 0, dm + 0, 1, 0, bc, pmask, pd, prm);
+  for (int n = 0; n < NL; n++) { vo_fab *in[2] = { &S[n].sold, &S[n].snew }; on_boxes(LEV(lev, n), &rhohalf[n], 0, 1, in, 2, &bc[n], PDL(n), prm, k_halftime, NULL); }
+  vo_ml_restrict_and_fill_g(NL, lev, rhp, 0, dm + 0, 1, 0, bc, pmask, pd, prm);
   if (viscous && prm->diffusion_type == 2) for (int n = 0; n < NL; n++) memset(lapu[n].p, 0, sizeof(double) * vo_size(&lapu[n]));    /* advance_timestep.f90:116-120 */
   /* velocity advance */
   {
     int is_cons[3] = { 0, 0, 0 };
     for (int n = 0; n < NL; n++) {
-      for (int d = 0; d < 3; d++) { fab_new_l(&uflux[3 * n + d], &S[n].uold, 0, d, dm, 0.0); fab_new_l(&uedge[3 * n + d], &S[n].uold, 0, d, dm, 0.0); ufp[3 * n + d] = &uflux[3 * n + d]; uep[3 * n + d] = &uedge[3 * n + d]; }
-      vo_mkvelforce(&vel_force[n], &S[n].ext_vel_force, &S[n].gp, &S[n].sold, viscous ? &lapu[n] : NULL, 1.0, prm);
+      for (int d = 0; d < 3; d++) { bmf_new(&uflux[3 * n + d], LEV(lev, n), &S[n].uold, 0, d, dm, 0.0); bmf_new(&uedge[3 * n + d], LEV(lev, n), &S[n].uold, 0, d, dm, 0.0); }
+      kctx k = { prm, 1.0, NULL, 0, 0 }; vo_fab *in[4] = { &S[n].ext_vel_force, &S[n].gp, &S[n].sold, viscous ? &lapu[n] : NULL };
+      on_boxes(LEV(lev, n), &vel_force[n], 0, dm, in, 4, &bc[n], PDL(n), prm, k_velforce, &k);
     }
-    vo_ml_restrict_and_fill(NL, vfp, 0, bc[0].extrap_comp, dm, 1, bc, pmask, pd, prm);
+    vo_ml_restrict_and_fill_g(NL, lev, vfp, 0, bc[0].extrap_comp, dm, 1, bc, pmask, pd, prm);
     for (int n = 0; n < NL; n++) {
-      vo_mkflux(&S[n].uold, uep + 3 * n, ufp + 3 * n, ump + 3 * n, &vel_force[n], &mac_rhs[n], dx + 3 * n, dt, 1, is_cons, 0, &bc[n], prm);
-      vo_mkvelforce(&vel_force[n], &S[n].ext_vel_force, &S[n].gp, &rhohalf[n], viscous ? &lapu[n] : NULL, 0.0, prm);
+      const vo_level *L = LEV(lev, n);
+      FOR_BOXES(L, &S[n].uold, b, lo, hi) {
+        vo_fab *u3[3] = { &umac[3 * n].f[b], &umac[3 * n + 1].f[b], &umac[3 * n + 2].f[b] }, *e3[3] = { &uedge[3 * n].f[b], &uedge[3 * n + 1].f[b], &uedge[3 * n + 2].f[b] }, *f3[3] = { &uflux[3 * n].f[b], &uflux[3 * n + 1].f[b], &uflux[3 * n + 2].f[b] };
+        if (!lv_multi(L)) { vo_mkflux(&S[n].uold, e3, f3, u3, &vel_force[n], &mac_rhs[n], dx + 3 * n, dt, 1, is_cons, 0, &bc[n], prm); continue; }
+        vo_fab bu, bf, bm; vo_bc bb;
+        box_gather(&bu, lo, hi, S[n].uold.ng, &S[n].uold); box_gather(&bf, lo, hi, 1, &vel_force[n]); box_gather(&bm, lo, hi, 1, &mac_rhs[n]); box_bc(&bb, &bc[n], lo, hi, PDL(n), prm);
+        vo_mkflux(&bu, e3, f3, u3, &bf, &bm, dx + 3 * n, dt, 1, is_cons, 0, &bb, prm);
+        free(bu.p); free(bf.p); free(bm.p);
+      }
+      kctx k = { prm, 0.0, NULL, 0, 0 }; vo_fab *in[4] = { &S[n].ext_vel_force, &S[n].gp, &rhohalf[n], viscous ? &lapu[n] : NULL };
+      on_boxes(L, &vel_force[n], 0, dm, in, 4, &bc[n], PDL(n), prm, k_velforce, &k);
     }
-    vo_ml_restrict_and_fill(NL, vfp, 0, bc[0].extrap_comp, dm, 1, bc, pmask, pd, prm);
-    for (int n = 0; n < NL; n++) vo_update(&S[n].uold, ump + 3 * n, uep + 3 * n, ufp + 3 * n, &vel_force[n], &S[n].unew, dx + 3 * n, dt, 1, is_cons);
-    vo_ml_restrict_and_fill(NL, unewp, 0, 0, dm, 0, bc, pmask, pd, prm);
+    vo_ml_restrict_and_fill_g(NL, lev, vfp, 0, bc[0].extrap_comp, dm, 1, bc, pmask, pd, prm);
+    for (int n = 0; n < NL; n++) {
+      const vo_level *L = LEV(lev, n);
+      FOR_BOXES(L, &S[n].uold, b, lo, hi) {
+        vo_fab *u3[3] = { &umac[3 * n].f[b], &umac[3 * n + 1].f[b], &umac[3 * n + 2].f[b] }, *e3[3] = { &uedge[3 * n].f[b], &uedge[3 * n + 1].f[b], &uedge[3 * n + 2].f[b] }, *f3[3] = { &uflux[3 * n].f[b], &uflux[3 * n + 1].f[b], &uflux[3 * n + 2].f[b] };
+        if (!lv_multi(L)) { vo_update(&S[n].uold, u3, e3, f3, &vel_force[n], &S[n].unew, dx + 3 * n, dt, 1, is_cons); continue; }
+        vo_fab bu, bf, bn;
+        box_gather(&bu, lo, hi, 0, &S[n].uold); box_gather(&bf, lo, hi, 0, &vel_force[n]); box_gather(&bn, lo, hi, 0, &S[n].unew);
+        vo_update(&bu, u3, e3, f3, &bf, &bn, dx + 3 * n, dt, 1, is_cons);
+        box_scatter(&S[n].unew, &bn, 0, dm);
+        free(bu.p); free(bf.p); free(bn.p);
+      }
+    }
+    vo_ml_restrict_and_fill_g(NL, lev, unewp, 0, 0, dm, 0, bc, pmask, pd, prm);
     if (viscous) {                                                                     /* velocity_advance.f90:103-118 */
       const double visc_mu = (prm->diffusion_type == 1) ? 0.5 * dt * prm->visc_coef : dt * prm->visc_coef;
       vo_mgstat vst;
-      vo_ml_visc_solve(NL, unewp, lap, rhp, mrp, dx, visc_mu, bc, pmask, pd, prm, &vst);
+      vo_ml_visc_solve_g(NL, lev, unewp, lap, rhp, mrp, dx, visc_mu, bc, pmask, pd, prm, &vst);
     }
-    for (int n = 0; n < NL; n++) for (int d = 0; d < 3; d++) { free(uflux[3 * n + d].p); free(uedge[3 * n + d].p); }
+    for (int n = 0; n < NL; n++) for (int d = 0; d < 3; d++) { bmf_free(&uflux[3 * n + d]); bmf_free(&uedge[3 * n + d]); }
   }
-  vo_ml_hgproject(NL, proj_type, unewp, uoldp, rhp, pp, gpp, dx, dt, bc, pmask, pd, prm, &st[1]);
-  for (int n = 0; n < NL; n++) { free(mac_rhs[n].p); free(rhohalf[n].p); free(vel_force[n].p); free(lapu[n].p); for (int d = 0; d < 3; d++) free(umac[3 * n + d].p); }
+  vo_ml_hgproject_g(NL, lev, proj_type, unewp, uoldp, rhp, pp, gpp, dx, dt, bc, pmask, pd, prm, &st[1]);
+  for (int n = 0; n < NL; n++) { free(mac_rhs[n].p); free(rhohalf[n].p); free(vel_force[n].p); free(lapu[n].p); for (int d = 0; d < 3; d++) bmf_free(&umac[3 * n + d]); }
+  #undef PDL
 }

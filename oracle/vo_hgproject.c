@@ -692,16 +692,16 @@ static void nd_level_from_fab(ndlev *L, const vo_fab *coeffs, const double dx[3]
   for (int k = -1; k <= n[2]; k++) for (int j = -1; j <= n[1]; j++) for (int i = -1; i <= n[0]; i++)
     L->sig[NS(L, i, j, k)] = VF(coeffs, coeffs->lo[0] + i, coeffs->lo[1] + j, coeffs->lo[2] + k, 0);
 }
-/* copy of u with one ghost layer, zero outside the level's own box (cells blo..bhi; NULL: keep everything) and zero in the cells
- * covered by the next finer level (clo..chi; NULL: none) */
-static void masked_u(vo_fab *out, const vo_fab *u, const int *blo, const int *bhi, const int *clo, const int *chi)
+/* copy of u with one ghost layer, zero outside the level's own cells (levels >= 1: `own`; level 0 keeps everything, its ghost cells carry the inflow
+ * data) and zero in the cells covered by the next finer level */
+static void masked_u(vo_fab *out, const vo_fab *u, const vo_level *Lown, int own, const vo_level *Lfine, const vo_fab *fine)
 {
   vo_fab_init(out, NULL, u->lo, u->hi, 1, NULL, 3);
   out->p = (double *)calloc(vo_size(out), sizeof(double));
   for (int c = 0; c < 3; c++) for (int k = u->lo[2] - 1; k <= u->hi[2] + 1; k++) for (int j = u->lo[1] - 1; j <= u->hi[1] + 1; j++) for (int i = u->lo[0] - 1; i <= u->hi[0] + 1; i++) {
     int keep = 1;
-    if (blo && !(i >= blo[0] && i <= bhi[0] && j >= blo[1] && j <= bhi[1] && k >= blo[2] && k <= bhi[2])) keep = 0;
-    if (clo && (i >= clo[0] && i <= chi[0] && j >= clo[1] && j <= chi[1] && k >= clo[2] && k <= chi[2])) keep = 0;
+    if (own && !vo_lv_valid(Lown, u, i, j, k)) keep = 0;
+    if (fine && vo_lv_valid(Lfine, fine, 2 * i, 2 * j, 2 * k)) keep = 0;
     VF(out, i, j, k, c) = keep ? VF(u, i, j, k, c) : 0.0;
   }
 }
@@ -712,9 +712,10 @@ typedef struct mlnd {
   double *sigfull[ND_MAXLEV];         /* full sigma (relaxation of the levels >= 1; level 0's correction solve takes the fab) */
   int per[3];
   int org[ND_MAXLEV][3];              /* global index of local node 0 */
-  int ilo[ND_MAXLEV][3], ihi[ND_MAXLEV][3];   /* node range, local to level n, of the box of level n+1 */
+  unsigned char *under[ND_MAXLEV];    /* per node of level n, of the 8 cells around it: 1 = some are covered by level n+1 (its equation takes the restricted fine-side
+                                       * parts), 2 = all are (no equation of its own: left out of the norm), 0 = none */
   unsigned char *cf[ND_MAXLEV];       /* nodes slaved to level n-1 (coarse-fine interface) */
-  unsigned char *pdir[ND_MAXLEV];     /* physical Dirichlet nodes */
+  unsigned char *pdir[ND_MAXLEV];     /* physical Dirichlet nodes, and the nodes of the level array that touch no cell of the level (a level of several boxes) */
 } mlnd;
 
 /* trilinear interpolation of the coarse array `cp` (level n-1, local indexing of Lc) at local node (i,j,k) of level n */
@@ -748,7 +749,7 @@ static double ml_nd_residual(mlnd *M)
       if (!M->pdir[n][NM(L, i, j, k)]) {
         double Kp, diag; nd_apply(L, L->phi, i, j, k, &Kp, &diag);
         r = L->b[NN(L, i, j, k)] - Kp;
-        if (has_fine && i >= M->ilo[n][0] && i <= M->ihi[n][0] && j >= M->ilo[n][1] && j <= M->ihi[n][1] && k >= M->ilo[n][2] && k <= M->ihi[n][2]) {
+        if (has_fine && M->under[n][NM(L, i, j, k)]) {
           const ndlev *F = &M->L[n + 1];
           int fi = 2 * (i + M->org[n][0]) - M->org[n + 1][0], fj = 2 * (j + M->org[n][1]) - M->org[n + 1][1], fk = 2 * (k + M->org[n][2]) - M->org[n + 1][2];
           double s = 0.0;
@@ -762,52 +763,77 @@ static double ml_nd_residual(mlnd *M)
       }
       L->res[NN(L, i, j, k)] = r;
       int skip = M->cf[n] && M->cf[n][NM(L, i, j, k)];
-      if (has_fine && i > M->ilo[n][0] && i < M->ihi[n][0] && j > M->ilo[n][1] && j < M->ihi[n][1] && k > M->ilo[n][2] && k < M->ihi[n][2]) skip = 1;
+      if (has_fine && M->under[n][NM(L, i, j, k)] == 2) skip = 1;
       if (!skip) nrm = vo_nrm_acc(nrm, r);
     }
   }
   return nrm;
 }
 /* rh[lev] nodal (ng 1; in: extra source, normally 0), phi[lev] nodal (ng 1, in/out), coeffs[lev] cells (ng 1, ghost 0 outside the
- * level), u[lev] cells with >= 1 ghost (wall ghosts zeroed by create_uvec); dx: [lev*3+d]; ellbc per level/box */
+ * level), u[lev] cells with >= 1 ghost (wall ghosts zeroed by create_uvec); dx: [lev*3+d]; ellbc per level (of its bounding box).
+ * lev (may be NULL): the box lists -- the fields are level arrays (vo.h) and every test "inside the box" becomes one on the cells around a node:
+ * a node with cells of the level AND cells of the domain that are not the level's around it is a slave of the next coarser level; a node of level n
+ * with cells covered by level n+1 around it takes the restricted fine-side parts, with all eight covered it has no equation. */
 int vo_ml_nd_solve(int nlev, vo_fab **rh, vo_fab **phi, vo_fab **coeffs, vo_fab **u, const double *dx, const int ellbc[][3][2], const int pmask[3],
                    double rel_eps, double abs_eps, int max_iter, const vdn_params *prm, vo_mgstat *st)
+{
+  /* the domain of each level as far as the one-box form needs it: a face of the box is a domain face unless its bc says "interior" */
+  int pd[6 * ND_MAXLEV];
+  for (int n = 0; n < nlev && n < ND_MAXLEV; n++) for (int d = 0; d < 3; d++) {
+    pd[6 * n + d] = ellbc[n][d][0] == VDN_BC_INT ? coeffs[n]->lo[d] - (1 << 20) : coeffs[n]->lo[d];
+    pd[6 * n + 3 + d] = ellbc[n][d][1] == VDN_BC_INT ? coeffs[n]->hi[d] + (1 << 20) : coeffs[n]->hi[d];
+  }
+  return vo_ml_nd_solve_g(nlev, NULL, rh, phi, coeffs, u, dx, ellbc, pmask, pd, rel_eps, abs_eps, max_iter, prm, st);
+}
+int vo_ml_nd_solve_g(int nlev, const vo_level *const *lev, vo_fab **rh, vo_fab **phi, vo_fab **coeffs, vo_fab **u, const double *dx, const int ellbc[][3][2], const int pmask[3],
+                     const int *pd, double rel_eps, double abs_eps, int max_iter, const vdn_params *prm, vo_mgstat *st)
 {
   if (nlev < 2 || nlev > ND_MAXLEV) { fprintf(stderr, "vo_ml_nd_solve: 2..%d levels\n", ND_MAXLEV); abort(); }
   mlnd M; memset(&M, 0, sizeof M);
   M.nlev = nlev; (void)pmask;
   double *scratch[ND_MAXLEV] = { 0 };
+  #define LV(n) (lev ? lev[n] : NULL)
   for (int n = 0; n < nlev; n++) {
     for (int d = 0; d < 3; d++) M.org[n][d] = coeffs[n]->lo[d];
     const int has_fine = n < nlev - 1;
-    int klo[3] = { 0, 0, 0 }, khi[3] = { -1, -1, -1 };
-    if (has_fine) for (int d = 0; d < 3; d++) { klo[d] = coeffs[n + 1]->lo[d] / 2; khi[d] = coeffs[n + 1]->hi[d] / 2; M.ilo[n][d] = klo[d] - M.org[n][d]; M.ihi[n][d] = khi[d] + 1 - M.org[n][d]; }
-    /* masked sigma level; the full sigma kept aside */
+    const int *pdlo = pd + 6 * n, *pdhi = pd + 6 * n + 3;
+    /* masked sigma level (zero outside the level's cells and under the next finer level); the full sigma kept aside */
     vo_fab cm; vo_fab_init(&cm, NULL, coeffs[n]->lo, coeffs[n]->hi, 1, NULL, 1); cm.p = (double *)malloc(sizeof(double) * vo_size(&cm));
     memcpy(cm.p, coeffs[n]->p, sizeof(double) * vo_size(&cm));
-    for (int k = klo[2]; k <= khi[2]; k++) for (int j = klo[1]; j <= khi[1]; j++) for (int i = klo[0]; i <= khi[0]; i++) VF(&cm, i, j, k, 0) = 0.0;
+    const int *clo = coeffs[n]->lo, *chi = coeffs[n]->hi;
+    for (int k = clo[2] - 1; k <= chi[2] + 1; k++) for (int j = clo[1] - 1; j <= chi[1] + 1; j++) for (int i = clo[0] - 1; i <= chi[0] + 1; i++) {
+      if (vo_lv_multi(LV(n)) && !vo_lv_valid(LV(n), coeffs[n], i, j, k)) VF(&cm, i, j, k, 0) = 0.0;
+      if (has_fine && vo_lv_valid(LV(n + 1), coeffs[n + 1], 2 * i, 2 * j, 2 * k)) VF(&cm, i, j, k, 0) = 0.0;
+    }
     ndlev *L = &M.L[n];
     nd_level_from_fab(L, &cm, dx + 3 * n); nd_set_mask(L, ellbc[n]);
     free(cm.p);
     long ns = (long)(L->n[0] + 2) * (L->n[1] + 2) * (L->n[2] + 2), nn = (long)(L->n[0] + 3) * (L->n[1] + 3) * (L->n[2] + 3);
     M.sigfull[n] = (double *)malloc(sizeof(double) * ns);
     for (int k = -1; k <= L->n[2]; k++) for (int j = -1; j <= L->n[1]; j++) for (int i = -1; i <= L->n[0]; i++)
-      M.sigfull[n][NS(L, i, j, k)] = VF(coeffs[n], coeffs[n]->lo[0] + i, coeffs[n]->lo[1] + j, coeffs[n]->lo[2] + k, 0);
+      M.sigfull[n][NS(L, i, j, k)] = (vo_lv_multi(LV(n)) && !vo_lv_valid(LV(n), coeffs[n], clo[0] + i, clo[1] + j, clo[2] + k)) ? 0.0 : VF(coeffs[n], clo[0] + i, clo[1] + j, clo[2] + k, 0);
     scratch[n] = (double *)calloc(nn, sizeof(double));
     long nnm = (long)(L->n[0] + 1) * (L->n[1] + 1) * (L->n[2] + 1);
     M.pdir[n] = (unsigned char *)malloc(nnm); memcpy(M.pdir[n], L->dir, nnm);
-    M.cf[n] = NULL;
-    if (n >= 1) {
-      M.cf[n] = (unsigned char *)calloc(nnm, 1);
-      for (int k = 0; k <= L->n[2]; k++) for (int j = 0; j <= L->n[1]; j++) for (int i = 0; i <= L->n[0]; i++) {
-        int q[3] = { i, j, k }, onface = 0;
-        for (int d = 0; d < 3; d++) { if (q[d] == 0 && ellbc[n][d][0] == VDN_BC_INT) onface = 1; if (q[d] == L->n[d] && ellbc[n][d][1] == VDN_BC_INT) onface = 1; }
-        if (onface && !M.pdir[n][NM(L, i, j, k)]) { M.cf[n][NM(L, i, j, k)] = 1; L->dir[NM(L, i, j, k)] = 1; }      /* fixed during the relaxation */
+    M.cf[n] = n >= 1 ? (unsigned char *)calloc(nnm, 1) : NULL;
+    M.under[n] = has_fine ? (unsigned char *)calloc(nnm, 1) : NULL;
+    for (int k = 0; k <= L->n[2]; k++) for (int j = 0; j <= L->n[1]; j++) for (int i = 0; i <= L->n[0]; i++) {
+      int own = 0, other = 0, cov = 0;          /* of the 8 cells around the node: cells of the level / cells of the domain that are not / cells under level n+1 */
+      for (int c = -1; c <= 0; c++) for (int b = -1; b <= 0; b++) for (int a = -1; a <= 0; a++) {
+        const int q[3] = { clo[0] + i + a, clo[1] + j + b, clo[2] + k + c };
+        const int indom = q[0] >= pdlo[0] && q[0] <= pdhi[0] && q[1] >= pdlo[1] && q[1] <= pdhi[1] && q[2] >= pdlo[2] && q[2] <= pdhi[2];
+        const int v = indom && vo_lv_valid(LV(n), coeffs[n], q[0], q[1], q[2]);
+        own += v; other += indom && !v;
+        if (has_fine && v && vo_lv_valid(LV(n + 1), coeffs[n + 1], 2 * q[0], 2 * q[1], 2 * q[2])) cov++;
       }
+      const long nm = NM(L, i, j, k);
+      if (!own) { M.pdir[n][nm] = 1; L->dir[nm] = 1; }                                         /* touches no cell of the level: inert */
+      if (n >= 1 && own && other && !M.pdir[n][nm]) { M.cf[n][nm] = 1; L->dir[nm] = 1; }         /* slave: fixed during the relaxation */
+      if (has_fine) M.under[n][nm] = cov == 8 ? 2 : (cov ? 1 : 0);
     }
     /* right-hand side: rh += D u with the masked velocity (vo_nd_divu), b = -rh */
     vo_fab um;
-    masked_u(&um, u[n], n >= 1 ? coeffs[n]->lo : NULL, n >= 1 ? coeffs[n]->hi : NULL, has_fine ? klo : NULL, has_fine ? khi : NULL);
+    masked_u(&um, u[n], LV(n), n >= 1, has_fine ? LV(n + 1) : NULL, has_fine ? coeffs[n + 1] : NULL);
     vo_nd_divu(&um, rh[n], dx + 3 * n, ellbc[n]);
     free(um.p);
     for (int k = 0; k <= L->n[2]; k++) for (int j = 0; j <= L->n[1]; j++) for (int i = 0; i <= L->n[0]; i++) {
@@ -817,6 +843,7 @@ int vo_ml_nd_solve(int nlev, vo_fab **rh, vo_fab **phi, vo_fab **coeffs, vo_fab 
       L->phi[NN(L, i, j, k)] = M.pdir[n][NM(L, i, j, k)] ? 0.0 : VF(phi[n], phi[n]->lo[0] + i, phi[n]->lo[1] + j, phi[n]->lo[2] + k, 0);
     }
   }
+  #undef LV
   /* norm of the composite right-hand side = composite residual of phi = 0 */
   double bnorm;
   {
@@ -890,6 +917,6 @@ int vo_ml_nd_solve(int nlev, vo_fab **rh, vo_fab **phi, vo_fab **coeffs, vo_fab 
   }
   if (st) { st->cycles = it; st->res0 = bnorm; st->res = rn; }
   free(er.p); free(ee.p);
-  for (int n = 0; n < nlev; n++) { free(M.cf[n]); free(M.pdir[n]); free(M.sigfull[n]); free(scratch[n]); nd_free(&M.L[n]); }
+  for (int n = 0; n < nlev; n++) { free(M.cf[n]); free(M.pdir[n]); free(M.under[n]); free(M.sigfull[n]); free(scratch[n]); nd_free(&M.L[n]); }
   return conv ? 0 : 1;
 }

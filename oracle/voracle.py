@@ -42,6 +42,45 @@ class CState(C.Structure):
     _fields_ = [(k, CFab) for k in ("uold", "sold", "unew", "snew", "gp", "p", "ext_vel_force", "ext_scal_force")]
 
 
+class CLevel(C.Structure):
+    """vo_level (oracle/vo.h): one level of a hierarchy as a box list; built by vo_level_build"""
+    _fields_ = [("nbox", C.c_int), ("boxes", C.POINTER(C.c_int)), ("blo", C.c_int * 3), ("bhi", C.c_int * 3), ("mg", C.c_int), ("valid", C.c_void_p)]
+
+
+class Level:
+    """a level = a list of boxes [(lo, hi), ...] in the level's own index space"""
+
+    def __init__(self, boxes):
+        self.boxes = [(tuple(int(x) for x in b[0]), tuple(int(x) for x in b[1])) for b in boxes]
+        flat = []
+        for lo, hi in self.boxes:
+            flat += list(lo) + list(hi)
+        self._flat = (C.c_int * len(flat))(*flat)
+        self.c = CLevel()
+        lib().vo_level_build(C.byref(self.c), len(self.boxes), self._flat)
+        self.lo, self.hi = tuple(self.c.blo), tuple(self.c.bhi)
+
+    def mask(self):
+        """boolean array over the bounding box: True on the cells of the union"""
+        m = np.zeros(tuple(self.hi[d] - self.lo[d] + 1 for d in range(3)), dtype=bool)
+        for lo, hi in self.boxes:
+            m[tuple(slice(lo[d] - self.lo[d], hi[d] - self.lo[d] + 1) for d in range(3))] = True
+        return m
+
+    def __del__(self):
+        try:
+            lib().vo_level_free(C.byref(self.c))
+        except Exception:
+            pass
+
+
+def level_ptr_array(levels):
+    arr = (C.POINTER(CLevel) * len(levels))()
+    for i, l in enumerate(levels):
+        arr[i] = C.pointer(l.c)
+    return arr
+
+
 def build():
     subprocess.check_call(["make", "-s", "-C", _HERE])
 
@@ -63,6 +102,7 @@ def lib():
         _lib.vo2_estdt.restype = C.c_double
         _lib.vo_cc_solve.restype = C.c_int
         _lib.vo_nd_solve.restype = C.c_int
+        _lib.vo_estdt_g.restype = C.c_double
     return _lib
 
 
@@ -224,9 +264,10 @@ class Sim:
 
 
 class SimML:
-    """multi-level (fixed properly nested grids, one box per level) bubble run on the CPU oracle: what src/varden.f90's time loop does
-    around advance_timestep for nlevs > 1 (ghost fills by ml_restrict_and_fill, dt = min over levels of estdt).
-    boxes: [(lo, hi)] of levels 1.. in each level's own index space."""
+    """multi-level (fixed properly nested grids) bubble run on the CPU oracle: what src/varden.f90's time loop does around advance_timestep for
+    nlevs > 1 (ghost fills by ml_restrict_and_fill, dt = min over levels and boxes of estdt).
+    boxes: per refined level either ONE box (lo, hi) or a LIST of boxes [(lo, hi), ...], in the level's own index space.  The fields of a level are
+    level arrays over the bounding box of its boxes (oracle/vo.h); `levels[n].mask()` marks the cells that belong to the level."""
 
     def __init__(self, nc, boxes, phys, prm=None, prob_type=1, grav=-9.8, init_shrink=0.1, init_iter=0, do_initial_projection=0):
         L = lib()
@@ -235,7 +276,12 @@ class SimML:
         self.nc = nc
         self.nlev = NL = 1 + len(boxes)
         ns = self.prm.nscal
-        los, his = [(0, 0, 0)] + [tuple(b[0]) for b in boxes], [(nc - 1,) * 3] + [tuple(b[1]) for b in boxes]
+        blists = [[((0, 0, 0), (nc - 1,) * 3)]]
+        for b in boxes:
+            blists.append([b] if (len(b) == 2 and not hasattr(b[0][0], "__len__")) else list(b))
+        self.levels = [Level(bl_) for bl_ in blists]
+        self.lev = level_ptr_array(self.levels)
+        los, his = [lv.lo for lv in self.levels], [lv.hi for lv in self.levels]
         bcl, pd, self.dxl = [make_bc(phys, 3, ns)], [0, 0, 0, nc - 1, nc - 1, nc - 1], [[1.0 / nc] * 3]
         for n in range(1, NL):
             nd = nc << n
@@ -259,8 +305,8 @@ class SimML:
         if do_initial_projection:                                 # varden.f90:126-138
             rhohalf = [Fab(los[n], his[n], 1, 1, val=1.0) for n in range(NL)]
             st = CMgStat()
-            L.vo_ml_hgproject(NL, INITIAL_PROJECTION, fab_ptr_array(self.uold), fab_ptr_array(self.uold), fab_ptr_array(rhohalf), fab_ptr_array(self.p),
-                              fab_ptr_array(self.gp), self.dx, C.c_double(1.0), self.bcs, self.pmask, self.pd, C.byref(self.prm), C.byref(st))
+            L.vo_ml_hgproject_g(NL, self.lev, INITIAL_PROJECTION, fab_ptr_array(self.uold), fab_ptr_array(self.uold), fab_ptr_array(rhohalf), fab_ptr_array(self.p),
+                                fab_ptr_array(self.gp), self.dx, C.c_double(1.0), self.bcs, self.pmask, self.pd, C.byref(self.prm), C.byref(st))
             self.initial_projection_stat = (st.cycles, st.res0, st.res)
             for n in range(NL):
                 self.p[n].a[...] = 0.0
@@ -274,7 +320,7 @@ class SimML:
             self._advance(PRESSURE_ITERS)
 
     def _rf(self, mfs, icomp, bcomp, nc, same=0):
-        lib().vo_ml_restrict_and_fill(self.nlev, fab_ptr_array(mfs), icomp, bcomp, nc, same, self.bcs, self.pmask, self.pd, C.byref(self.prm))
+        lib().vo_ml_restrict_and_fill_g(self.nlev, self.lev, fab_ptr_array(mfs), icomp, bcomp, nc, same, self.bcs, self.pmask, self.pd, C.byref(self.prm))
 
     def fill_state_ghosts(self):
         self._rf(self.uold, 0, 0, 3)
@@ -283,15 +329,15 @@ class SimML:
 
     def estdt(self, dtold):
         L = lib()
-        return min(L.vo_estdt(self.uold[n].ref, self.sold[n].ref, self.gp[n].ref, self.ext_vel_force[n].ref, dvec(self.dxl[n]),
-                              C.c_double(dtold), C.byref(self.prm)) for n in range(self.nlev))
+        return min(L.vo_estdt_g(self.lev[n], self.uold[n].ref, self.sold[n].ref, self.gp[n].ref, self.ext_vel_force[n].ref, dvec(self.dxl[n]),
+                                C.c_double(dtold), C.byref(self.prm)) for n in range(self.nlev))
 
     def _advance(self, proj_type):
         S = (CState * self.nlev)()
         for n in range(self.nlev):
             for k in ("uold", "sold", "unew", "snew", "gp", "p", "ext_vel_force", "ext_scal_force"):
                 setattr(S[n], k, getattr(self, k)[n].c)
-        lib().vo_ml_advance_timestep(self.nlev, S, self.dx, C.c_double(self.dt), self.bcs, self.pmask, self.pd, C.byref(self.prm), proj_type, self.mgstat)
+        lib().vo_ml_advance_timestep_g(self.nlev, self.lev, S, self.dx, C.c_double(self.dt), self.bcs, self.pmask, self.pd, C.byref(self.prm), proj_type, self.mgstat)
 
     def step(self):
         self.istep += 1
@@ -299,7 +345,7 @@ class SimML:
         if self.istep > 1:
             self.dt = self.estdt(self.dt)
         self._advance(REGULAR_TIMESTEP)
-        for n in range(self.nlev):
+        for n in range(self.nlev):                              # (cells outside the level are overwritten by the next ghost fill)
             self.uold[n].valid()[...] = self.unew[n].valid()
             self.sold[n].valid()[...] = self.snew[n].valid()
         self.time += self.dt

@@ -442,6 +442,62 @@ def test_tagged_grids_properties_and_run(gpu, max_levs):
     G.close()
 
 
+@pytest.mark.parametrize("nc,max_levs", [(32, 2), (32, 3), (64, 2), (64, 3)])
+def test_tagged_hierarchy_against_the_box_list_oracle(gpu, oracle, nc, max_levs):
+    """BASELINE.json configs[3] / [4] in small: the refined levels are the boxes make_new_grids returns for the tagged bubble (tag_boxes.f90:65-94: rho > 1.01 /
+    rho > 1.1) -- unions that are not rectangles, re-entrant interface edges, boxes of a few cells -- and the ORACLE RUNS THE SAME BOX LISTS (oracle/vo.h:
+    level arrays with a cell mask, MAC velocities and the Godunov kernels box by box; VERDICT r4 missing 3).  Start-up (initial projection + one pressure
+    iteration) and two steps: dt bit for bit, the FAC iteration counts of both composite solves equal in every call, u / rho / tracer to 1e-9 on every box
+    of every level, the pressure to 1e-6; and the composite mass is conserved to round-off (the conservative fluxes are restricted, mkflux.f90:137-146)."""
+    from varden_amd import advance as adv
+    from varden_amd import driver
+    from varden_amd.capi import default_params
+    vo = oracle
+    levels = driver.VardenAMR.tagged_grids(nc, WALLS, default_params(cflfac=0.9), max_levs=max_levs, max_grid_size=32)
+    assert len(levels) == max_levs - 1 and len(levels[0]) > 1, "the tagged bubble should give unions of several boxes: %r" % ([len(lb) for lb in levels],)
+    G = driver.VardenAMR(nc, levels[0], WALLS, params=default_params(cflfac=0.9), finer_levels=levels[1:], init_shrink=0.1, init_iter=1, do_initial_projection=1)
+    O = vo.SimML(nc, levels, WALLS, prm=default_params(cflfac=0.9), init_shrink=0.1, init_iter=1, do_initial_projection=1)
+    assert G.initial_projection_stat[0] == O.initial_projection_stat[0], "initial projection: FAC iterations %r (GPU) vs %r (oracle)" % (G.initial_projection_stat[0], O.initial_projection_stat[0])
+    assert G.dt == O.dt
+
+    def mass():
+        m = 0.0
+        for n in range(O.nlev):
+            msk = O.levels[n].mask()
+            if n + 1 < O.nlev:
+                f = O.levels[n + 1]
+                fm = f.mask()[::2, ::2, ::2]
+                o = [f.lo[d] // 2 - O.levels[n].lo[d] for d in range(3)]
+                cov = np.zeros_like(msk)
+                cov[o[0]:o[0] + fm.shape[0], o[1]:o[1] + fm.shape[1], o[2]:o[2] + fm.shape[2]] = fm
+                msk = msk & ~cov
+            for i in range(G.sold[n].nfabs()):
+                lo, hi = G.sold[n].get_box(i)
+                sl = tuple(slice(lo[d] - O.levels[n].lo[d], hi[d] - O.levels[n].lo[d] + 1) for d in range(3))
+                m += (G.sold[n].to_numpy(i)[3:-3, 3:-3, 3:-3, 0] * msk[sl]).sum() / 8.0 ** n
+        return m
+    m0 = mass()
+    for step in range(2):
+        O.step(); G.step()
+        assert G.dt == O.dt, "dt diverged at step %d: %r vs %r" % (step, G.dt, O.dt)
+        cg = (adv.last_solver_stats("mac")[0], adv.last_solver_stats("hg")[0])
+        co = (O.mgstat[0].cycles, O.mgstat[1].cycles)
+        assert cg == co, "base %d^3, %d levels, step %d: FAC iterations (MAC, HG) %r on the GPU, %r in the oracle" % (nc, max_levs, step, cg, co)
+        for n in range(O.nlev):
+            olo = O.levels[n].lo
+            for nm, gm, om, g, tol in (("u", G.uold[n], O.uold[n], 3, 1e-9), ("s", G.sold[n], O.sold[n], 3, 1e-9), ("gp", G.gp[n], O.gp[n], 1, 1e-6)):
+                scale = max(float(np.abs(om.valid()).max()), 1e-300)
+                for i in range(gm.nfabs()):
+                    lo, hi = gm.get_box(i)
+                    a = gm.to_numpy(i)[g:-g, g:-g, g:-g]
+                    b = om.valid()[tuple(slice(lo[d] - olo[d], hi[d] - olo[d] + 1) for d in range(3))]
+                    err = float(np.abs(a - b).max())
+                    assert err <= tol * scale, "level %d box %d step %d: %s differs by %.3e (scale %.3e)" % (n, i, step, nm, err, scale)
+    m1 = mass()
+    assert abs(m1 - m0) <= 1e-12 * m0, "composite mass drifted by %.3e" % ((m1 - m0) / m0)
+    G.close()
+
+
 def test_fillpatch_and_nodal_prolongation_reproduce_linear_fields(gpu):
     """regrid.f90:311-327: fillpatch (limited linear interpolation) is exact for a linear cell field, ml_nodal_prolongation (trilinear)
     for a trilinear nodal field; copy between layouts moves exactly the points valid in both"""

@@ -143,6 +143,10 @@ extern "C" int vdn_advance_timestep(int istep, vdn_layout *mla, vdn_multifab **s
       s_updated = k_mkflux(sold[n], sedge + 3 * n, sflux + 3 * n, umac + 3 * n, scal_force[n], divu[n], DXL(n), dt, bct, false, is_cons, try_upd ? &U : nullptr);
       if (diffusive || !force_reuse) k_mkscalforce(scal_force[n], ext_scal_force[n], laps[n], 0.0);     // without diffusion: ext_scal_force again, already there
     }
+    // mkflux.f90:137-146: on a hierarchy the flux of every conservative component through a coarse face under a finer level is the mean of the four fine
+    // fluxes -- the coarse cells NEXT TO the finer level are updated with the fine level's fluxes through the interface, which is what conserves the mass
+    // of the composite grid (round 5: rounds 2-4 left the coarse level its own fluxes)
+    for (int n = nlevs - 1; n >= 1; n--) for (int c = 0; c < nscal; c++) if (is_cons[c]) for (int d = 0; d < dm; d++) ml_edge_restriction(sflux[3 * (n - 1) + d], sflux[3 * n + d], d, c);
     if (diffusive || !force_reuse) restrict_and_fill(nlevs, scal_force, 0, bct->extrap_comp0(), nscal, true, bct);
     if (!s_updated) for (int n = 0; n < nlevs; n++) k_update(sold[n], umac + 3 * n, sedge + 3 * n, sflux + 3 * n, scal_force[n], snew[n], DXL(n), dt, false, is_cons);
     restrict_and_fill(nlevs, snew, 0, dm, nscal, false, bct);                           // update.f90:106

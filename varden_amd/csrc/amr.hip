@@ -133,10 +133,12 @@ struct EdgeRestrictB { Range3 r; int g[3]; FV crse, fine; int dir;
     fv_at(a.crse, i, j, k) = s * 0.25;
     return 0.0;
   } };
-void ml_edge_restriction(vdn_multifab *crse, const vdn_multifab *fine, int dir) {
-  const SrcView F = make_view(fine, refined_footprints(crse, dir, 0), level_owner(crse), 0, 1, VT_REFINE_FACE0 + dir);
+// comp: the component restricted (ml_edge_restriction_c of mkflux.f90:137-146: the conservative fluxes; 0 for the one-component MAC fields)
+void ml_edge_restriction(vdn_multifab *crse, const vdn_multifab *fine, int dir, int comp) {
+  REQUIRE(comp >= 0 && comp < crse->nc && comp < fine->nc, "ml_edge_restriction: component %d of a %d / %d-component pair", comp, crse->nc, fine->nc);
+  const SrcView F = make_view(fine, refined_footprints(crse, dir, 0), level_owner(crse), comp, 1, VT_REFINE_FACE0 + dir);
   F.refresh();
-  GraphKey key; key.put(0x7202); key_mf(key, crse); key_mf(key, fine); key.put(dir);
+  GraphKey key; key.put(0x7202); key_mf(key, crse); key_mf(key, fine); key.put(dir); key.put(comp);
   launch_batched_kept<EdgeRestrictB>(key.h, crse->la->uid, [&](std::vector<EdgeRestrictB> &v) {
   const BoxBins cb(crse->vbox);
   for (int f = 0; f < F.nboxes(); f++) {
@@ -148,7 +150,7 @@ void ml_edge_restriction(vdn_multifab *crse, const vdn_multifab *fine, int dir) 
     for (int d = 0; d < 3; d++) { clo[d] = qlo[d]; chi[d] = qhi[d]; blo[d] = crse->vbox[c].lo[d]; bhi[d] = crse->vbox[c].hi[d]; }
     chi[dir] += 1; bhi[dir] += 1;
     if (!isect(clo, chi, blo, bhi, a.r)) continue;
-    a.crse = crse->fabs[c]; a.fine = F.fv[f]; a.dir = dir;
+    a.crse = crse->fabs[c]; a.crse.p += (long)a.crse.sc * comp; a.fine = F.fv[f]; a.dir = dir;
     v.push_back(a);
     }
   }
@@ -1011,7 +1013,7 @@ void do_ml_macproject(vdn_layout *mla, vdn_multifab **umac, vdn_multifab **rho, 
 
 // ---- C-ABI ------------------------------------------------------------------------------------------------------------------
 extern "C" int vdn_ml_cc_restriction(vdn_multifab *crse, const vdn_multifab *fine, int icomp, int nc) { VDN_TRY ml_cc_restriction(crse, fine, icomp, nc); VDN_CATCH }
-extern "C" int vdn_ml_edge_restriction(vdn_multifab *crse, const vdn_multifab *fine, int dir) { VDN_TRY ml_edge_restriction(crse, fine, dir); VDN_CATCH }
+extern "C" int vdn_ml_edge_restriction(vdn_multifab *crse, const vdn_multifab *fine, int dir) { VDN_TRY ml_edge_restriction(crse, fine, dir, 0); VDN_CATCH }
 extern "C" int vdn_multifab_fill_ghost_cells(vdn_multifab *fine, const vdn_multifab *crse, int icomp, int nc) { VDN_TRY ml_fill_ghost_cells(fine, crse, icomp, nc); VDN_CATCH }
 extern "C" int vdn_create_umac_grown(vdn_multifab *fine, const vdn_multifab *crse, int dir) { VDN_TRY ml_create_umac_grown(fine, crse, dir); VDN_CATCH }
 extern "C" int vdn_fillpatch(vdn_multifab *fine, const vdn_multifab *crse, int icomp, int nc) { VDN_TRY ml_fillpatch(fine, crse, icomp, nc); VDN_CATCH }

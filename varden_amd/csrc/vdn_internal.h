@@ -364,7 +364,7 @@ void mac_level_rhs(vdn_multifab **um, const vdn_multifab *mac_rhs, vdn_multifab 
 void mac_level_coeffs(const vdn_multifab *rho, vdn_multifab **beta);
 void mac_level_mkumac(vdn_multifab **um, const vdn_multifab *phi, vdn_multifab **beta, const double *dx, const vdn_bc_tower *bct, int bc_comp0);
 void ml_cc_restriction(vdn_multifab *crse, const vdn_multifab *fine, int icomp, int nc);
-void ml_edge_restriction(vdn_multifab *crse, const vdn_multifab *fine, int dir);
+void ml_edge_restriction(vdn_multifab *crse, const vdn_multifab *fine, int dir, int comp = 0);
 void ml_fill_ghost_cells(vdn_multifab *fine, const vdn_multifab *crse, int icomp, int nc);
 void ml_create_umac_grown(vdn_multifab *fine, const vdn_multifab *crse, int dir);
 void ml_restrict_and_fill(int nlev, vdn_multifab **mf, int icomp, int bcomp, int nc, bool same_boundary, const vdn_bc_tower *bct);
