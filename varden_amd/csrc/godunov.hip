@@ -857,6 +857,7 @@ DEVI double tvq(bool cons, double q, double sp, double s0, double mp, double m0)
   if (cons) return q * (sp * mp - s0 * m0);
   return q * (mp + m0) * (sp - s0);
 }
+static bool god_oneb() { static const bool on = !(vdn_env("VDN_GOD_1B") && atoi(vdn_env("VDN_GOD_1B")) == 0); return on; }
 constexpr int FNX = 62, FNY = TNY - 2;      // cells a tile owns per row / rows it owns
 static dim3 fused_grid(const Range3 &r, int &klen) {
   // one 512-thread workgroup per CU at a time: the chunk count is the one that fills the last round of workgroups best
@@ -922,9 +923,17 @@ template <bool NAR> DEVI SegGeo seg_geo(int W_) {
 // next row's (LDS, read one iteration later, like SI and SC), the upper z one this thread's output for the next plane.  So the x-term of
 // plane k is formed with stage D of plane k, the y- and z-terms one iteration later, and seven doubles travel in between; a k-chunk runs
 // one plane further (the lower z-face of its successor's first plane).  sedge and flux are not stored.  Same expressions as update_cell.
-template <bool BC, bool INL, bool UPD, bool PW2, bool NAR = false> __device__ __forceinline__ void mk_F_m_body(const FArgs &F, const Range3 &r, int klen, const double *umax, const int BX, const int BY, const int BZ, const int segw = 64) {
-  static_assert(!(NAR && UPD), "the update rides along in full-width tiles only");
-  __shared__ double lB[2][TNY][64], lSI[2][TNY][64], lC[2][2][TNY][64], lSC[2][2][TNY][64], lD[2][TNY][64], lE[UPD ? 2 : 1][UPD ? TNY : 1][64];
+// ONEB (round 5): ONE workgroup barrier per plane instead of three.  The three stages exchange their y-direction left states through LDS (lB, lC, lD) and
+// each had its own write -> barrier -> read.  What a stage WRITES depends on no LDS value of the same iteration -- stage C's lC needs t[0] (x: DPP) and
+// t[2] (z: registers), stage D's lD the chain of direction y, whose transverse terms are x (DPP) and z (stage C's z-faces, registers) -- so all three
+// writes move in front of one barrier, with every x- and z-direction upwind that needs no LDS value, and everything that reads LDS (this iteration's
+// lB / lC / lD, last iteration's lSI / lSC / lE) behind it.  Same expressions, same operands, same bits; the buffers stay double: a wave that has
+// passed barrier kk reads buffer kk & 1 and last iteration's lSI / lSC / lE while the fastest wave writes buffer (kk + 1) & 1 and this iteration's.
+// the y-exchange arrays of the march, ONE allocation per kernel shared by the bodies inlined into it (boundary / lean, full-width / narrow)
+template <bool UPD> struct FShared { double lB[2][TNY][64], lSI[2][TNY][64], lC[2][2][TNY][64], lSC[2][2][TNY][64], lD[2][TNY][64], lE[UPD ? 2 : 1][UPD ? TNY : 1][64]; };
+template <bool BC, bool INL, bool UPD, bool PW2, bool NAR = false, bool ONEB = true> __device__ __forceinline__ void mk_F_m_body(FShared<UPD> &S, const FArgs &F, const Range3 &r, int klen, const double *umax, const int BX, const int BY, const int BZ, const int segw = 64) {
+  double (&lB)[2][TNY][64] = S.lB, (&lSI)[2][TNY][64] = S.lSI, (&lC)[2][2][TNY][64] = S.lC, (&lSC)[2][2][TNY][64] = S.lSC, (&lD)[2][TNY][64] = S.lD;
+  double (&lE)[UPD ? 2 : 1][UPD ? TNY : 1][64] = S.lE;
   const SegGeo G = seg_geo<NAR>(segw);
   const int lane = G.lane, row = G.row;
   const int ownx = NAR ? G.W - 2 : FNX, owny = NAR ? G.ROWS - 2 : FNY;
@@ -1013,6 +1022,177 @@ template <bool BC, bool INL, bool UPD, bool PW2, bool NAR = false> __device__ __
       if (kc_ != kcur) { ps += F.sp[0]; psl0 += F.sp[1]; psl1 += F.sp[1]; psl2 += F.sp[1]; pum += F.sp[2]; pvm += F.sp[3]; pwm += F.sp[4]; pf += F.sp[5]; pmr += F.sp[6]; kcur = kc_; } }
   F_LOAD
   F_ADVANCE(k0 - 1)
+  if (ONEB) {
+  for (int kk = k0 - 2; kk <= k1 + 2 + (UPD ? 1 : 0); kk++) {
+    const int buf = kk & 1;
+    P2 = P1; P1 = P0;
+    {
+      #pragma unroll
+      for (int d = 0; d < 3; d++) { P0.m_lo[d] = N.m_lo[d]; P0.m_up[d] = N.m_up[d]; }
+      P0.s0 = N.s0; P0.f = N.f; P0.mr = N.mr;
+      const double sl[3] = { N.sl[0], N.sl[1], N.sl[2] };
+      if (kk < k1 + 2) { F_LOAD  F_ADVANCE(kk + 2) }
+      f_bases<PW2>(F, P0, sl);
+    }
+    const bool doC = kk - 1 >= k0 - 1, doD = kk - 2 >= k0 - 1;
+    // ================= in front of the barrier: the three LDS writes and every upwind that reads no LDS value =================
+    // ---- stage B, plane kk: x and z faces
+    double si0[3];
+    const int kB = kk, kcB = min(max(kB, KB), KT), zwB = Z_WORD(kB, kcB);
+    double LxB;
+    {
+      LS(lB[buf]) = P0.Lb[1];
+      LxB = shfl_prev(P0.Lb[0]);
+      const double Lzc = LzB;
+      LzB = P0.Lb[2];
+      si0[0] = upwind_mac(LxB, P0.Rb[0], P0.m_lo[0], eps);
+      si0[2] = upwind_mac(Lzc, P0.Rb[2], P0.m_lo[2], eps);
+      if (BC && kB == kcB) {
+        int w = bcw; asm volatile("" : "+v"(w));
+        if (w & 0xF) { FACE_BC(si0[0], w, 0, LxB, P0.Rb[0], P0.s0, S_AT(kcB, -8L)) }
+        if ((zwB & 15) && ing_ij) { FACE_BC(si0[2], zwB, 0, Lzc, P0.Rb[2], P0.s0, P1.s0) }
+      }
+    }
+    // ---- stage C, plane kk-1: t[0], t[2], the y left states, and the faces whose transverse term is not the y one (x-face / z term, z-face / x term)
+    double qc[6] = { 0.0, 0.0, 0.0, 0.0, 0.0, 0.0 };
+    double cLb[3] = { 0.0, 0.0, 0.0 }, cRb[3] = { 0.0, 0.0, 0.0 }, ct0 = 0.0, ct2 = 0.0, cLz1 = 0.0;
+    const int kC = kk - 1, kcC = min(max(kC, KB), KT), zwC = Z_WORD(kC, kcC);
+    int wc = 0;
+    if (doC) {
+      #pragma unroll
+      for (int d = 0; d < 3; d++) { cLb[d] = P1.Lb[d]; cRb[d] = P1.Rb[d]; }
+      if (BC) {
+        wc = bcw; asm volatile("" : "+v"(wc));
+        if (wc & 0x770770) { PREMOD(cLb[0], cRb[0], wc, 4, 8, S_AT(kcC, -8L), S_AT(kcC, 8L)) PREMOD(cLb[1], cRb[1], wc, 16, 20, S_AT(kcC, -F.s_row), S_AT(kcC, F.s_row)) }
+        if (zwC & 0x770) { PREMOD(cLb[2], cRb[2], zwC, 4, 8, S_AT(kcC - 1, 0L), S_AT(kcC + 1, 0L)) }
+      }
+      ct0 = tvq(cons, F.tC[0], lane_next(si1[0]), si1[0], P1.m_up[0], P1.m_lo[0]);
+      ct2 = tvq(cons, F.tC[2], si0[2], si1[2], P1.m_up[2], P1.m_lo[2]);
+      LS(lC[buf][0]) = cLb[1] - ct0; LS(lC[buf][1]) = cLb[1] - ct2;
+      const double VL01 = cLb[0] - ct2, VR01 = cRb[0] - ct2, VL20 = cLb[2] - ct0, VR20 = cRb[2] - ct0;
+      const double Lx1 = shfl_prev(VL01), Lz0 = LzC[0];
+      cLz1 = LzC[1];
+      LzC[0] = VL20;
+      qc[1] = upwind_mac(Lx1, VR01, P1.m_lo[0], eps);
+      qc[4] = upwind_mac(Lz0, VR20, P1.m_lo[2], eps);
+      if (BC && kC == kcC) {
+        if (wc & 0xF) { FACE_BC(qc[1], wc, 0, Lx1, VR01, P1.s0, S_AT(kcC, -8L)) }
+        if ((zwC & 15) && ing_ij) { FACE_BC(qc[4], zwC, 0, Lz0, VR20, P1.s0, P2.s0) }
+      }
+    }
+    // ---- stage D, plane kk-2: the chain of direction y (transverse terms x and z) and its left state
+    double dLb[3] = { 0.0, 0.0, 0.0 }, dRb[3] = { 0.0, 0.0, 0.0 }, dVR1 = 0.0, da[3] = { 0.0, 0.0, 0.0 }, dft = 0.0, dmt = 0.0;
+    const int kD = kk - 2, kcD = min(max(kD, KB), KT), zwD = Z_WORD(kD, kcD);
+    int wd = 0;
+    #define CHAIN1(vl_, vr_, Dd, T1, T2, q1a, q0a, q1b, q0b)                                                   \
+        { const double t1 = tvq(cons, F.tD[T1], q1a, q0a, P2.m_up[T1], P2.m_lo[T1]);                             \
+          const double t2 = tvq(cons, F.tD[T2], q1b, q0b, P2.m_up[T2], P2.m_lo[T2]);                             \
+          double vl = dLb[Dd], vr = dRb[Dd];                                                                     \
+          vl = vl - t1; vr = vr - t1; vl = vl - t2; vr = vr - t2;                                                \
+          if (cons) { vl = vl + da[T1]; vr = vr + da[T1]; vl = vl + da[T2]; vr = vr + da[T2]; }                  \
+          if (!F.use_minion) { vl = vl + dft; vr = vr + dft; if (cons) { vl = vl - dmt; vr = vr - dmt; } }       \
+          vl_ = vl; vr_ = vr; }
+    if (doD) {
+      dft = F.dt2 * P2.f; dmt = F.dt2 * P2.s0 * P2.mr;
+      #pragma unroll
+      for (int d = 0; d < 3; d++) { dLb[d] = P2.Lb[d]; dRb[d] = P2.Rb[d]; da[d] = F.aD[d] * P2.s0 * (P2.m_up[d] - P2.m_lo[d]); }
+      if (BC) {
+        wd = bcw; asm volatile("" : "+v"(wd));
+        if (wd & 0x770770) { PREMOD(dLb[0], dRb[0], wd, 4, 8, S_AT(kcD, -8L), S_AT(kcD, 8L)) PREMOD(dLb[1], dRb[1], wd, 16, 20, S_AT(kcD, -F.s_row), S_AT(kcD, F.s_row)) }
+        if (zwD & 0x770) { PREMOD(dLb[2], dRb[2], zwD, 4, 8, S_AT(kcD - 1, 0L), S_AT(kcD + 1, 0L)) }
+      }
+      double vl1;
+      CHAIN1(vl1, dVR1, 1, 0, 2, lane_next(qp[1]), qp[1], qc[4], qp[4])
+      LS(lD[buf]) = vl1;
+    }
+    __syncthreads();
+    // ================= behind the barrier: everything that reads LDS =================
+    // ---- stage B: the y face
+    {
+      const double Ly = LM(lB[buf]);
+      si0[1] = upwind_mac(Ly, P0.Rb[1], P0.m_lo[1], eps);
+      if (BC && kB == kcB) {
+        int w = bcw; asm volatile("" : "+v"(w));
+        if (w & 0xF000) { FACE_BC(si0[1], w, 12, Ly, P0.Rb[1], P0.s0, S_AT(kcB, -F.s_row)) }
+      }
+      LS(lSI[buf]) = si0[1];                                   // read by the row below in the next iteration
+    }
+    // ---- stage C: t[1] (SI on the upper y face: the row above, last iteration) and the faces that need it or the y left states
+    if (doC) {
+      const double ct1 = tvq(cons, F.tC[1], LP(lSI[buf ^ 1]), si1[1], P1.m_up[1], P1.m_lo[1]);
+      const double VL00 = cLb[0] - ct1, VR00 = cRb[0] - ct1, VR10 = cRb[1] - ct0, VR11 = cRb[1] - ct2, VL21 = cLb[2] - ct1, VR21 = cRb[2] - ct1;
+      const double Lx0 = shfl_prev(VL00), Ly0 = LM(lC[buf][0]), Ly1 = LM(lC[buf][1]);
+      LzC[1] = VL21;
+      qc[0] = upwind_mac(Lx0, VR00, P1.m_lo[0], eps);
+      qc[2] = upwind_mac(Ly0, VR10, P1.m_lo[1], eps); qc[3] = upwind_mac(Ly1, VR11, P1.m_lo[1], eps);
+      qc[5] = upwind_mac(cLz1, VR21, P1.m_lo[2], eps);
+      if (BC && kC == kcC) {
+        if (wc & 0xF00F) {
+          FACE_BC(qc[0], wc, 0, Lx0, VR00, P1.s0, S_AT(kcC, -8L))
+          FACE_BC(qc[2], wc, 12, Ly0, VR10, P1.s0, S_AT(kcC, -F.s_row)) FACE_BC(qc[3], wc, 12, Ly1, VR11, P1.s0, S_AT(kcC, -F.s_row))
+        }
+        if ((zwC & 15) && ing_ij) { FACE_BC(qc[5], zwC, 0, cLz1, VR21, P1.s0, P2.s0) }
+      }
+      LS(lSC[buf][0]) = qc[2]; LS(lSC[buf][1]) = qc[3];            // read by the row below in the next iteration
+    }
+    // ---- stage D: the chains of directions x and z, the three edge states, the update
+    if (doD) {
+      const int k = kD, kc = kcD, zw = zwD;
+      const bool vz = k >= F.lo[2] && k <= F.hi[2];
+      const double (&m_lo)[3] = P2.m_lo, (&m_up)[3] = P2.m_up;
+      const double s0 = P2.s0;
+      double VL[3], VR[3];
+      VR[1] = dVR1;
+      CHAIN1(VL[0], VR[0], 0, 1, 2, LP(lSC[buf ^ 1][1]), qp[3], qc[5], qp[5])
+      CHAIN1(VL[2], VR[2], 2, 0, 1, lane_next(qp[0]), qp[0], LP(lSC[buf ^ 1][0]), qp[2])
+      double L[3];
+      L[0] = shfl_prev(VL[0]); L[1] = LM(lD[buf]); L[2] = LzD; LzD = VL[2];
+      if (k >= k0) {
+        double e[3] = { 0.0, 0.0, 0.0 };
+        if (UPD || own_ij) {
+          e[0] = upwind_mac(L[0], VR[0], m_lo[0], eps); e[1] = upwind_mac(L[1], VR[1], m_lo[1], eps); e[2] = upwind_mac(L[2], VR[2], m_lo[2], eps);
+          if (BC) {
+            if (wd & 0xF00F) { FACE_BC(e[0], wd, 0, L[0], VR[0], s0, S_AT(kc, -8L)) FACE_BC(e[1], wd, 12, L[1], VR[1], s0, S_AT(kc, -F.s_row)) }
+            if (zw & 15) { FACE_BC(e[2], zw, 0, L[2], VR[2], s0, S_AT(kc - 1, 0L)) }
+          }
+        }
+        if (!UPD) {
+          if (own_ij) {
+            if (vy && vz) { std_(qex, 0u, e[0]); if (cons) std_(qfx, 0u, e[0] * m_lo[0]); }
+            if (vx && vz) { std_(qey, 0u, e[1]); if (cons) std_(qfy, 0u, e[1] * m_lo[1]); }
+            if (vx && vy) { std_(qez, 0u, e[2]); if (cons) std_(qfz, 0u, e[2] * m_lo[2]); }
+          }
+          qex += F.sq[0]; qfx += F.sq[0]; qey += F.sq[1]; qfy += F.sq[1]; qez += F.sq[2]; qfz += F.sq[2];
+        } else {
+          const double ex = cons ? e[0] * m_lo[0] : e[0], ey = cons ? e[1] * m_lo[1] : e[1], ez = cons ? e[2] * m_lo[2] : e[2];
+          if (k - 1 >= k0) {                                           // finish plane k-1: its upper y face from the row above, its upper z face = ez
+            const double eyu = LP(lE[buf ^ 1]);
+            const double ty = cons ? DIVDX(eyu - c_e1, 1) : DIVDX(c_vbar * (eyu - c_e1), 1);
+            const double tz = cons ? DIVDX(ez - c_e2, 2) : DIVDX(c_wbar * (ez - c_e2), 2);
+            const double ug = c_tx + ty + tz;
+            const bool vzp = k - 1 >= F.lo[2] && k - 1 <= F.hi[2];
+            if (own_ij && vx && vy && vzp) std_(qn, 0u, c_so - F.dt * ug + F.dt * c_fu);
+            qn += F.sqn;
+          }
+          const double exu = lane_next(ex);                            // the upper x face: the next lane's lower one
+          c_tx = cons ? DIVDX(exu - ex, 0) : DIVDX((0.5 * (m_lo[0] + m_up[0])) * (exu - ex), 0);
+          c_vbar = 0.5 * (m_lo[1] + m_up[1]); c_wbar = 0.5 * (m_lo[2] + m_up[2]);
+          c_e1 = ey; c_e2 = ez; c_so = s0;
+          if (F.fmode == 0) c_fu = P2.f;
+          else {
+            const long po = (long)(kc - KB) * F.sp[5] + o_f;
+            c_fu = ldd(F.pfu[0] + po, 0u) + (F.lapu0 - ldd(F.pfu[1] + po, 0u)) / ldd(F.pfu[2] + po, 0u);
+          }
+          LS(lE[buf]) = ey;                                     // read by the row below in the next iteration
+        }
+      }
+    }
+    #undef CHAIN1
+    si1[0] = si0[0]; si1[1] = si0[1]; si1[2] = si0[2];
+    #pragma unroll
+    for (int n = 0; n < 6; n++) qp[n] = qc[n];
+  }
+  } else
   for (int kk = k0 - 2; kk <= k1 + 2 + (UPD ? 1 : 0); kk++) {
     const int buf = kk & 1;
     P2 = P1; P1 = P0;
@@ -1173,7 +1353,7 @@ template <bool BC, bool INL, bool UPD, bool PW2, bool NAR = false> __device__ __
   #undef PREMOD
   #undef Z_WORD
 }
-template <bool BC = true, bool INL = true, bool UPD = false, bool PW2 = false> __global__ void __launch_bounds__(64 * TNY) kk_mk_F_m(FArgs F, Range3 r, int klen, const double *umax) {
+template <bool BC = true, bool INL = true, bool UPD = false, bool PW2 = false, bool ONEB = true> __global__ void __launch_bounds__(64 * TNY) kk_mk_F_m(FArgs F, Range3 r, int klen, const double *umax) {
   int bx_, by_, bz_; xcd_remap(bx_, by_, bz_);
   // a workgroup whose tile and k-chunk stay clear of every face that carries a rule runs the body without the boundary code (same values:
   // none of its cells is flagged); compiled into one kernel the lean path keeps its own register allocation (0.69 against 0.96 ms per launch)
@@ -1188,8 +1368,45 @@ template <bool BC = true, bool INL = true, bool UPD = false, bool PW2 = false> _
       if (bc_mode(F.phys[d][1], F.is_vel != 0, F.c == d) && a1[d] >= F.hi[d] - 1) touch = true;
     }
   }
-  if (BC && touch) mk_F_m_body<BC, INL, UPD, PW2>(F, r, klen, umax, bx_, by_, bz_);
-  else mk_F_m_body<false, false, UPD, PW2>(F, r, klen, umax, bx_, by_, bz_);
+  __shared__ FShared<UPD> S;
+  if (BC && touch) mk_F_m_body<BC, INL, UPD, PW2, false, ONEB>(S, F, r, klen, umax, bx_, by_, bz_);
+  else mk_F_m_body<false, false, UPD, PW2, false, ONEB>(S, F, r, klen, umax, bx_, by_, bz_);
+}
+// The remainder column of a one-box level in narrow segments (round 5).  A row of 256 cells is four 62-cell tiles and 8 cells: the fifth tile column
+// marched 64 lanes for 8 cells (a fifth of all workgroups at 256^3).  With NCOL that column runs in segments of (cells + 2) lanes, 64 / W rows per wave
+// (NAR, see seg_geo): 10 lanes x 6 rows, a workgroup 48 rows of which 46 own cells -- 6 workgroups per k-chunk instead of 43; the other workgroups of the
+// column's grid slots leave at once.  ONE launch (as a second launch the 42 workgroups were a round of their own: measured, slower than the full tiles).
+// Same body, same values; the update rides along as in the full-width tiles (the shared arrays are addressed flat).
+template <bool BC, bool INL, bool UPD, bool PW2> __global__ void __launch_bounds__(64 * TNY) kk_mk_F_mc(FArgs F, Range3 r, int klen, const double *umax, int full, int segw) {
+  int bx_, by_, bz_; xcd_remap(bx_, by_, bz_);
+  const bool narrow = bx_ == full;
+  Range3 rr = r;
+  int tw = 64, th = TNY, ownx = FNX;
+  if (narrow) {
+    tw = segw; th = TNY * (64 / segw); ownx = segw - 2;
+    rr.lo[0] = r.lo[0] + full * FNX;
+    if (by_ * (th - 2) > r.hi[1] - r.lo[1]) return;                 // the narrow column needs fewer workgroups along y than the grid has
+    bx_ = 0;
+  } else rr.hi[0] = r.lo[0] + full * FNX - 1;
+  bool touch = false;
+  if (BC) {
+    const int i0 = rr.lo[0] - 1 + bx_ * ownx, i1 = i0 + tw - 1, j0 = rr.lo[1] - 1 + by_ * (th - 2), j1 = j0 + th - 1;
+    const int k0 = rr.lo[2] + bz_ * klen - 2, k1 = min(rr.lo[2] + bz_ * klen + klen - 1, rr.hi[2]) + 2 + (UPD ? 1 : 0);
+    const int a0[3] = { i0, j0, k0 }, a1[3] = { i1, j1, k1 };
+    #pragma unroll
+    for (int d = 0; d < 3; d++) {
+      if (bc_mode(F.phys[d][0], F.is_vel != 0, F.c == d) && a0[d] <= F.lo[d] + 1) touch = true;
+      if (bc_mode(F.phys[d][1], F.is_vel != 0, F.c == d) && a1[d] >= F.hi[d] - 1) touch = true;
+    }
+  }
+  __shared__ FShared<UPD> S;
+  if (narrow) {
+    if (BC && touch) mk_F_m_body<BC, INL, UPD, PW2, true>(S, F, rr, klen, umax, bx_, by_, bz_, segw);
+    else mk_F_m_body<false, false, UPD, PW2, true>(S, F, rr, klen, umax, bx_, by_, bz_, segw);
+  } else {
+    if (BC && touch) mk_F_m_body<BC, INL, UPD, PW2>(S, F, rr, klen, umax, bx_, by_, bz_);
+    else mk_F_m_body<false, false, UPD, PW2>(S, F, rr, klen, umax, bx_, by_, bz_);
+  }
 }
 // the launch arguments of the fused march for component c; false when the field layouts do not allow the shared offsets
 static bool fused_args(FArgs &F, const GArgs &A, int c, const FV &s, const FV sl[3], const FV &um, const FV &vm, const FV &wm, const FV &force, const FV &macrhs,
@@ -1342,8 +1559,9 @@ template <bool INL, bool PW2 = false, bool NAR = false> __global__ void __launch
       if (bc_mode(q.F.phys[d][1], q.F.is_vel != 0, q.F.c == d) && a1[d] >= q.F.hi[d] - 1) touch = true;
     }
   }
-  if (touch) mk_F_m_body<true, INL, false, PW2, NAR>(q.F, q.r, q.klen, q.umax, BX, BY, BZ, q.sw);
-  else mk_F_m_body<false, false, false, PW2, NAR>(q.F, q.r, q.klen, q.umax, BX, BY, BZ, q.sw);
+  __shared__ FShared<false> S;
+  if (touch) mk_F_m_body<true, INL, false, PW2, NAR>(S, q.F, q.r, q.klen, q.umax, BX, BY, BZ, q.sw);
+  else mk_F_m_body<false, false, false, PW2, NAR>(S, q.F, q.r, q.klen, q.umax, BX, BY, BZ, q.sw);
 }
 // k-chunks of a box in the batched launch: the boxes of a level fill the device together, so a box is cut only when it is tall
 // sw: 0 = full-width tiles (64 x TNY threads own 62 x 6 cells), else the width of the row segments that take the fewest workgroups (seg_geo: a
@@ -1588,7 +1806,26 @@ bool k_mkflux(const vdn_multifab *s, vdn_multifab **sedge, vdn_multifab **flux, 
             const bool p2 = FA[c0].p2 != 0;                              // (the inflow variants keep the division: fewer instantiations)
             if (!any) { if (p2) hipLaunchKernelGGL((kk_mk_F_m<false, false, true, true>), gF, blk, 0, st, FA[c0], rf, klF, umax); else hipLaunchKernelGGL((kk_mk_F_m<false, false, true>), gF, blk, 0, st, FA[c0], rf, klF, umax); }
             else if (inflow) hipLaunchKernelGGL((kk_mk_F_m<true, true, true>), gF, blk, 0, st, FA[c0], rf, klF, umax);
-            else if (p2) hipLaunchKernelGGL((kk_mk_F_m<true, false, true, true>), gF, blk, 0, st, FA[c0], rf, klF, umax);
+            else if (p2 && !god_oneb()) hipLaunchKernelGGL((kk_mk_F_m<true, false, true, true, false>), gF, blk, 0, st, FA[c0], rf, klF, umax);     // the three-barrier loop, kept for the variants test
+            else if (p2) {
+              // full 62-cell tiles, then the remainder column in narrow segments (kk_mk_F_mn) where that saves workgroups
+              static const bool narrow_env = !(vdn_env("VDN_GOD_NARROW") && atoi(vdn_env("VDN_GOD_NARROW")) == 0);
+              const int nxf = rf.hi[0] - rf.lo[0] + 1, nyf = rf.hi[1] - rf.lo[1] + 1, full = nxf / FNX, rem = nxf - full * FNX;
+              if (narrow_env && full >= 1 && rem > 0 && rem + 2 <= 32) {
+                // the chunk count for the workgroups that do work: full tiles + the narrow column's
+                const int segw = rem + 2, rows = TNY * (64 / segw) - 2, nzf = rf.hi[2] - rf.lo[2] + 1;
+                const int tiles = full * ((nyf + FNY - 1) / FNY) + (nyf + rows - 1) / rows;
+                int best = 1; double best_cost = 1e300;
+                for (int ch = 1; ch <= 16 && ch <= nzf; ch++) {
+                  const int kl = (nzf + ch - 1) / ch, nch = (nzf + kl - 1) / kl;
+                  const double cost = std::ceil((double)tiles * nch / 256.0) * (kl + 4);
+                  if (cost < best_cost) { best_cost = cost; best = ch; }
+                }
+                const int klM = (nzf + best - 1) / best;
+                const dim3 gM(full + 1, (nyf + FNY - 1) / FNY, (nzf + klM - 1) / klM);
+                hipLaunchKernelGGL((kk_mk_F_mc<true, false, true, true>), gM, blk, 0, st, FA[c0], rf, klM, umax, full, segw);
+              } else hipLaunchKernelGGL((kk_mk_F_m<true, false, true, true>), gF, blk, 0, st, FA[c0], rf, klF, umax);
+            }
             else hipLaunchKernelGGL((kk_mk_F_m<true, false, true>), gF, blk, 0, st, FA[c0], rf, klF, umax);
             continue;
           }

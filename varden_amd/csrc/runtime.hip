@@ -171,6 +171,8 @@ static const EnvSwitch g_switches[] = {
   { "VDN_NDM_NEG", "1: the composite nodal solve copies -res into the correction's right-hand side instead of loading it directly" },
   { "VDN_FB_FACES", "0: the ghost exchanges of the composite cell-centred solve fill edges and corners too" },
   { "VDN_MLCC_RHO", "0: the composite MAC solve reads stored face coefficients on its finest level too" },
+  { "VDN_GOD_NARROW", "0: the remainder tile column of the fused mkflux + update march in full 64-lane tiles instead of narrow segments (kk_mk_F_mn)" },
+  { "VDN_GOD_1B", "0: the fused mkflux + update march of a one-box level with three workgroup barriers per plane (round 4) instead of one (godunov.hip, ONEB)" },
   { "VDN_KEEP_SETS", "0: the descriptor arrays of the inter-level operators and composite solves are rebuilt and uploaded at every call" },
   { "VDN_KEPT_BOUND", "n > 0: the kept descriptor tables hold at most n entries each (default 4096 / 64 / 512): the eviction paths in a test" },
   { "VDN_MLCC_GLUE", "0: the level-0 correction of the composite MAC solve stored and added in separate passes" },
