@@ -1,4 +1,4 @@
-"""profiles/r04_smoother_rho_pmc.json from the summary tools/pmc_summary.py wrote for `tools/smoother_probe.py 256 20` (tools/final_profiles_r04.sh):
+"""profiles/r05_smoother_rho_pmc.json from the summary tools/pmc_summary.py wrote for `tools/smoother_probe.py 256 20` (tools/final_profiles_r05.sh):
 HBM bytes per launch of the roofline kernel = 2 x FETCH_SIZE (gfx950 reports half of a coalesced streaming read, MI355X_MICROARCH.md, checked on
 the k_copy line of the same run) + WRITE_SIZE.  usage: make_pmc_json.py <smoother_pmc_summary.txt> <out.json>"""
 import json, sys
@@ -15,7 +15,7 @@ k, c = row("kk_cc_gsrb_rho_pair"), row("k_copy")
 n = 256
 out = {
     "_comment": "rocprofv3 --pmc passes (FETCH_SIZE / WRITE_SIZE / TA_BUSY_avr TA_BUSY_max / TCC_HIT_sum TCC_MISS_sum / VALUBusy MemUnitBusy, separate runs, "
-                "--kernel-trace, csv; tools/final_profiles_r04.sh) of `python3 tools/smoother_probe.py 256 20` on MI355X, round 4; per-launch means over %d dispatches of "
+                "--kernel-trace, csv; tools/final_profiles_r05.sh) of `python3 tools/smoother_probe.py 256 20` on MI355X, round 5; per-launch means over %d dispatches of "
                 "kk_cc_gsrb_rho_pair at 256^3, the colour pass macproject runs on its finest level.  Sizes in KB.  FETCH_SIZE is doubled per MI355X_MICROARCH.md; "
                 "the k_copy calibration of the same run (134217728 B read and written per launch) is alongside." % k["calls"],
     "kernel": "kk_cc_gsrb_rho_pair(CLev, int, int)", "n": n,

@@ -874,6 +874,27 @@ static dim3 fused_grid(const Range3 &r, int &klen) {
   klen = (nz + chunks - 1) / chunks; if (klen < 1) klen = 1;
   return dim3((nx + FNX - 1) / FNX, (ny + FNY - 1) / FNY, (nz + klen - 1) / klen);
 }
+// the grid of a fused march whose remainder tile column runs in narrow segments (kk_mk_F_mc, kk_vp_F_mc): `full` 62-cell tile columns + one column of
+// segments of segw lanes; false when the box has no remainder column worth it.  The chunk count is chosen for the workgroups that do work.
+static bool fused_grid_cols(const Range3 &rf, dim3 &g, int &klen, int &full, int &segw) {
+  static const bool narrow_env = !(vdn_env("VDN_GOD_NARROW") && atoi(vdn_env("VDN_GOD_NARROW")) == 0);
+  const int nx = rf.hi[0] - rf.lo[0] + 1, ny = rf.hi[1] - rf.lo[1] + 1, nz = rf.hi[2] - rf.lo[2] + 1;
+  full = nx / FNX;
+  const int rem = nx - full * FNX;
+  if (!narrow_env || full < 1 || rem <= 0 || rem + 2 > 32) return false;
+  segw = rem + 2;
+  const int rows = TNY * (64 / segw) - 2;
+  const int tiles = full * ((ny + FNY - 1) / FNY) + (ny + rows - 1) / rows;
+  int best = 1; double best_cost = 1e300;
+  for (int ch = 1; ch <= 16 && ch <= nz; ch++) {
+    const int kl = (nz + ch - 1) / ch, nch = (nz + kl - 1) / kl;
+    const double cost = std::ceil((double)tiles * nch / 256.0) * (kl + 4);
+    if (cost < best_cost) { best_cost = cost; best = ch; }
+  }
+  klen = (nz + best - 1) / best;
+  g = dim3(full + 1, (ny + FNY - 1) / FNY, (nz + klen - 1) / klen);
+  return true;
+}
 // The boundary rules in compact form.  bc_pair always leaves L = R = v, and upwind_mac(v, v, .) = v, so on a physical boundary face every
 // stage's output IS v -- the inflow value, zero, the inner state, or the inner state clamped (bc_pair / mk_edge_bc: the same four cases):
 //   mode 1: ghost value   2: zero   3: inner state   4: inner state, min(.,0) on a lo face / max(.,0) on a hi face
@@ -1809,20 +1830,8 @@ bool k_mkflux(const vdn_multifab *s, vdn_multifab **sedge, vdn_multifab **flux, 
             else if (p2 && !god_oneb()) hipLaunchKernelGGL((kk_mk_F_m<true, false, true, true, false>), gF, blk, 0, st, FA[c0], rf, klF, umax);     // the three-barrier loop, kept for the variants test
             else if (p2) {
               // full 62-cell tiles, then the remainder column in narrow segments (kk_mk_F_mn) where that saves workgroups
-              static const bool narrow_env = !(vdn_env("VDN_GOD_NARROW") && atoi(vdn_env("VDN_GOD_NARROW")) == 0);
-              const int nxf = rf.hi[0] - rf.lo[0] + 1, nyf = rf.hi[1] - rf.lo[1] + 1, full = nxf / FNX, rem = nxf - full * FNX;
-              if (narrow_env && full >= 1 && rem > 0 && rem + 2 <= 32) {
-                // the chunk count for the workgroups that do work: full tiles + the narrow column's
-                const int segw = rem + 2, rows = TNY * (64 / segw) - 2, nzf = rf.hi[2] - rf.lo[2] + 1;
-                const int tiles = full * ((nyf + FNY - 1) / FNY) + (nyf + rows - 1) / rows;
-                int best = 1; double best_cost = 1e300;
-                for (int ch = 1; ch <= 16 && ch <= nzf; ch++) {
-                  const int kl = (nzf + ch - 1) / ch, nch = (nzf + kl - 1) / kl;
-                  const double cost = std::ceil((double)tiles * nch / 256.0) * (kl + 4);
-                  if (cost < best_cost) { best_cost = cost; best = ch; }
-                }
-                const int klM = (nzf + best - 1) / best;
-                const dim3 gM(full + 1, (nyf + FNY - 1) / FNY, (nzf + klM - 1) / klM);
+              dim3 gM; int klM, full, segw;
+              if (fused_grid_cols(rf, gM, klM, full, segw)) {
                 hipLaunchKernelGGL((kk_mk_F_mc<true, false, true, true>), gM, blk, 0, st, FA[c0], rf, klM, umax, full, segw);
               } else hipLaunchKernelGGL((kk_mk_F_m<true, false, true, true>), gF, blk, 0, st, FA[c0], rf, klF, umax);
             }
@@ -2613,6 +2622,19 @@ template <bool BC = true, bool INL = true, bool PW2 = false> __global__ void __l
   int bx_, by_, bz_; xcd_remap(bx_, by_, bz_);
   vp_F_m_body<BC, INL, PW2>(F, r, klen, umax, bx_, by_, bz_);
 }
+// the remainder tile column in narrow segments inside the same launch (see kk_mk_F_mc)
+template <bool BC, bool INL, bool PW2> __global__ void __launch_bounds__(64 * TNY) kk_vp_F_mc(VArgs F, Range3 r, int klen, const double *umax, int full, int segw) {
+  int bx_, by_, bz_; xcd_remap(bx_, by_, bz_);
+  Range3 rr = r;
+  if (bx_ == full) {
+    rr.lo[0] = r.lo[0] + full * FNX;
+    if (by_ * (TNY * (64 / segw) - 2) > r.hi[1] - r.lo[1]) return;
+    vp_F_m_body<BC, INL, PW2, true>(F, rr, klen, umax, 0, by_, bz_, segw);
+  } else {
+    rr.hi[0] = r.lo[0] + full * FNX - 1;
+    vp_F_m_body<BC, INL, PW2>(F, rr, klen, umax, bx_, by_, bz_);
+  }
+}
 static bool vfused_args(VArgs &F, const GArgs &A, const FV &u, const FV sl[3], const FV &force, const FV &um, const FV &vm, const FV &wm) {
   if (!same_geom(sl[0], sl[1]) || !same_geom(sl[0], sl[2]) || sl[0].sc != sl[1].sc || sl[0].sc != sl[2].sc) return false;
   const int KB = A.lo[2] - 1;
@@ -2984,7 +3006,11 @@ void k_velpred(const vdn_multifab *u, vdn_multifab **umac, const vdn_multifab *f
         const bool p2 = VA.p2 != 0;
         if (!any) { if (p2) hipLaunchKernelGGL((kk_vp_F_m<false, false, true>), gF, blk, 0, st, VA, rf, klF, umax); else hipLaunchKernelGGL((kk_vp_F_m<false, false>), gF, blk, 0, st, VA, rf, klF, umax); }
         else if (inflow) hipLaunchKernelGGL((kk_vp_F_m<true, true>), gF, blk, 0, st, VA, rf, klF, umax);
-        else if (p2) hipLaunchKernelGGL((kk_vp_F_m<true, false, true>), gF, blk, 0, st, VA, rf, klF, umax);
+        else if (p2) {
+          dim3 gM; int klM, full, segw;
+          if (fused_grid_cols(rf, gM, klM, full, segw)) hipLaunchKernelGGL((kk_vp_F_mc<true, false, true>), gM, blk, 0, st, VA, rf, klM, umax, full, segw);
+          else hipLaunchKernelGGL((kk_vp_F_m<true, false, true>), gF, blk, 0, st, VA, rf, klF, umax);
+        }
         else hipLaunchKernelGGL((kk_vp_F_m<true, false>), gF, blk, 0, st, VA, rf, klF, umax);
       } else if (slab_bc()) {      // interior marches, then the face-centred code on the boundary slabs (see kk_slabs)
         const VpPlain P{ u->fabs[ib], sl[0], sl[1], sl[2], force->fabs[ib], UI, XC, umac[0]->fabs[ib], umac[1]->fabs[ib], umac[2]->fabs[ib], A, umax };
