@@ -164,18 +164,25 @@ class NodalLevel:
 # cell-centred, two levels (composite): unknowns = all coarse cells (the covered ones tied to the mean of their children) + fine cells
 # ------------------------------------------------------------------------------------------------------------------------------------
 class CompositeCC:
-    """coarse level: one box [0, nc)^3 = the domain; fine level: the box flo..fhi (fine indices, even-aligned, properly nested).
-    beta_c[d], beta_f[d]: face arrays of the two boxes (fine: shape nf + e_d);  ellbc: the domain's [d][side] (no periodic sides here)"""
+    """coarse level: one box [0, nc)^3 = the domain; fine level: the box flo..fhi, or -- `boxes` -- a UNION of boxes inside it (fine indices, even-aligned,
+    properly nested; flo..fhi is then the bounding box and every fine array a level array over it).
+    beta_c[d], beta_f[d]: face arrays of the two levels (fine: shape nf + e_d);  ellbc: the domain's [d][side] (no periodic sides here)"""
 
-    def __init__(self, nc, dxc, flo, fhi, beta_c, beta_f, ellbc):
+    def __init__(self, nc, dxc, flo, fhi, beta_c, beta_f, ellbc, boxes=None):
         self.nc = (nc,) * 3 if np.isscalar(nc) else tuple(nc)
         self.dxc = tuple(float(x) for x in dxc)
         self.dxf = tuple(0.5 * x for x in self.dxc)
         self.flo, self.fhi = tuple(flo), tuple(fhi)
         self.nf = tuple(fhi[d] - flo[d] + 1 for d in range(3))
         self.bc, self.bf, self.ellbc = beta_c, beta_f, ellbc
-        self.Nc = int(np.prod(self.nc)); self.Nf = int(np.prod(self.nf))
-        self.clo = tuple(flo[d] // 2 for d in range(3)); self.chi = tuple(fhi[d] // 2 for d in range(3))
+        self.mask = np.zeros(self.nf, dtype=bool)
+        for lo, hi in (boxes if boxes is not None else [(self.flo, self.fhi)]):
+            self.mask[tuple(slice(lo[d] - self.flo[d], hi[d] - self.flo[d] + 1) for d in range(3))] = True
+        self.fnum = np.full(self.nf, -1, dtype=np.int64)       # unknown number of a fine cell (x fastest), -1 outside the union
+        self.fnum[self.mask] = 0
+        order = np.flatnonzero(self.mask.ravel(order="F"))
+        flat = self.fnum.ravel(order="F").copy(); flat[order] = np.arange(order.size); self.fnum = flat.reshape(self.nf, order="F")
+        self.Nc = int(np.prod(self.nc)); self.Nf = int(order.size)
         self.A = None
 
     # -- index helpers
@@ -183,13 +190,15 @@ class CompositeCC:
         return Q[0] + self.nc[0] * (Q[1] + self.nc[1] * Q[2])
 
     def fidx(self, q):
-        return self.Nc + (q[0] - self.flo[0]) + self.nf[0] * ((q[1] - self.flo[1]) + self.nf[1] * (q[2] - self.flo[2]))
+        n = self.fnum[q[0] - self.flo[0], q[1] - self.flo[1], q[2] - self.flo[2]]
+        assert n >= 0, "a fine cell outside the union was asked for"
+        return self.Nc + int(n)
 
     def covered(self, Q):
-        return all(self.clo[d] <= Q[d] <= self.chi[d] for d in range(3))
+        return self.in_fine((2 * Q[0], 2 * Q[1], 2 * Q[2]))
 
     def in_fine(self, q):
-        return all(self.flo[d] <= q[d] <= self.fhi[d] for d in range(3))
+        return all(self.flo[d] <= q[d] <= self.fhi[d] for d in range(3)) and bool(self.mask[q[0] - self.flo[0], q[1] - self.flo[1], q[2] - self.flo[2]])
 
     def coarse_val(self, Q):
         """phi of coarse cell Q as a linear form; outside the domain the closure ghost: Neumann = the cell inside, Dirichlet = minus it"""
@@ -266,10 +275,12 @@ class CompositeCC:
                                 bcv = self.bc[d][tuple(face)]
                                 self.axpy(row, bcv * hc2, me); self.axpy(row, -bcv * hc2, self.coarse_val(Nb))
                     rows.append(row)
-        # fine cells
+        # fine cells (x fastest, the cells of the union only: the order of fnum)
         for k in range(self.flo[2], self.fhi[2] + 1):
             for j in range(self.flo[1], self.fhi[1] + 1):
                 for i in range(self.flo[0], self.fhi[0] + 1):
+                    if not self.in_fine((i, j, k)):
+                        continue
                     q = (i, j, k); row = {}; me = {self.fidx(q): 1.0}
                     for d in range(3):
                         hf2 = 1.0 / (self.dxf[d] ** 2)
@@ -287,16 +298,26 @@ class CompositeCC:
         self.A = _csr(acc, (N, N))
         return self.A
 
+    def fine_vector(self, a):
+        """the cells of the union out of a fine level array, in unknown order"""
+        return np.asarray(a).ravel(order="F")[np.flatnonzero(self.mask.ravel(order="F"))]
+
     def rhs(self, rh_c, rh_f):
-        b = np.concatenate([np.asarray(rh_c).ravel(order="F"), np.asarray(rh_f).ravel(order="F")])
-        for K in range(self.clo[2], self.chi[2] + 1):
-            for J in range(self.clo[1], self.chi[1] + 1):
-                for I in range(self.clo[0], self.chi[0] + 1):
-                    b[self.cidx((I, J, K))] = 0.0           # the tie rows
+        b = np.concatenate([np.asarray(rh_c).ravel(order="F"), self.fine_vector(rh_f)])
+        for K in range(self.nc[2]):
+            for J in range(self.nc[1]):
+                for I in range(self.nc[0]):
+                    if self.covered((I, J, K)):
+                        b[self.cidx((I, J, K))] = 0.0       # the tie rows
         return b
 
+    def vector(self, phi_c, phi_f):
+        return np.concatenate([np.asarray(phi_c).ravel(order="F"), self.fine_vector(phi_f)])
+
     def split(self, x):
-        return x[:self.Nc].reshape(self.nc, order="F"), x[self.Nc:].reshape(self.nf, order="F")
+        f = np.full(int(np.prod(self.nf)), np.nan)
+        f[np.flatnonzero(self.mask.ravel(order="F"))] = x[self.Nc:]
+        return x[:self.Nc].reshape(self.nc, order="F"), f.reshape(self.nf, order="F")
 
 
 # ------------------------------------------------------------------------------------------------------------------------------------
@@ -304,42 +325,58 @@ class CompositeCC:
 # ------------------------------------------------------------------------------------------------------------------------------------
 class CompositeND:
     """unknowns: every coarse node that is not strictly inside the fine region + every fine node strictly inside it; fine nodes ON the
-    interface (not on the domain boundary) are trilinear slaves of the coarse nodes.  K = P^T diag(K_c[sigma = 0 under the fine box], K_f) P"""
+    interface (not on the domain boundary) are trilinear slaves of the coarse nodes.  K = P^T diag(K_c[sigma = 0 under the fine level], K_f) P.
+    The fine region is the box flo..fhi or -- `boxes` -- a union of boxes inside it (fine arrays are level arrays over the bounding box; a node
+    belongs to the fine level when a cell of the union touches it, and is a slave when a cell of the domain that is NOT of the union touches it too)."""
 
-    def __init__(self, nc, dxc, flo, fhi):
+    def __init__(self, nc, dxc, flo, fhi, boxes=None):
         self.nc = (nc,) * 3 if np.isscalar(nc) else tuple(nc)
         self.C = NodalLevel(self.nc, dxc)
         self.flo, self.fhi = tuple(flo), tuple(fhi)
         self.nf = tuple(fhi[d] - flo[d] + 1 for d in range(3))
         self.F = NodalLevel(self.nf, [0.5 * x for x in dxc])
-        clo, chi = [flo[d] // 2 for d in range(3)], [fhi[d] // 2 + 1 for d in range(3)]       # coarse NODE range of the fine region
         nfd = [2 * self.nc[d] for d in range(3)]
-        # classify
-        Cn = np.zeros(self.C.nn, dtype=int) - 1            # unknown number of a coarse node, -1: strictly inside the fine region
+        self.fmask = np.zeros(self.nf, dtype=bool)
+        for lo, hi in (boxes if boxes is not None else [(self.flo, self.fhi)]):
+            self.fmask[tuple(slice(lo[d] - flo[d], hi[d] - flo[d] + 1) for d in range(3))] = True
+        # per fine node (of the bounding box): cells of the union / cells of the domain outside the union around it
+        own = np.zeros(self.F.nn, dtype=int); other = np.zeros(self.F.nn, dtype=int)
+        for c, b, a in itertools.product(range(-1, 1), repeat=3):
+            for k in range(self.F.nn[2]):
+                kk = k + c
+                for j in range(self.F.nn[1]):
+                    jj = j + b
+                    for i in range(self.F.nn[0]):
+                        ii = i + a
+                        g = (flo[0] + ii, flo[1] + jj, flo[2] + kk)
+                        if not all(0 <= g[d] < nfd[d] for d in range(3)):
+                            continue                          # outside the domain: a natural boundary, neither
+                        inb = 0 <= ii < self.nf[0] and 0 <= jj < self.nf[1] and 0 <= kk < self.nf[2]
+                        if inb and self.fmask[ii, jj, kk]:
+                            own[i, j, k] += 1
+                        else:
+                            other[i, j, k] += 1
+        self.slave = (own > 0) & (other > 0)
+        funk = (own > 0) & (other == 0)
+        # unknowns: coarse nodes whose fine twin is not a fine unknown, then the fine unknowns
+        Cn = np.zeros(self.C.nn, dtype=int) - 1
         cnt = 0
         for K in range(self.C.nn[2]):
             for J in range(self.C.nn[1]):
                 for I in range(self.C.nn[0]):
-                    Q = (I, J, K)
-                    in_closed = all(clo[d] <= Q[d] <= chi[d] for d in range(3))
-                    on_iface = any((Q[d] == clo[d] and flo[d] != 0) or (Q[d] == chi[d] and fhi[d] + 1 != nfd[d]) for d in range(3))
-                    strictly = in_closed and not on_iface   # (a face of the fine box ON the domain boundary is no interface: natural boundary of the fine level)
-                    if not strictly:
-                        Cn[Q] = cnt; cnt += 1
+                    t = (2 * I - flo[0], 2 * J - flo[1], 2 * K - flo[2])
+                    twin = all(0 <= t[d] < self.F.nn[d] for d in range(3)) and funk[t]
+                    if not twin:
+                        Cn[I, J, K] = cnt; cnt += 1
         self.Cn, self.ncu = Cn, cnt
         Fn = np.zeros(self.F.nn, dtype=int) - 1
-        slave = np.zeros(self.F.nn, dtype=bool)
         for k in range(self.F.nn[2]):
             for j in range(self.F.nn[1]):
                 for i in range(self.F.nn[0]):
-                    q = (i, j, k)
-                    on_iface = any((q[d] == 0 and flo[d] != 0) or (q[d] == self.nf[d] and fhi[d] + 1 != nfd[d]) for d in range(3))
-                    if on_iface:
-                        slave[q] = True
-                    else:
-                        Fn[q] = cnt; cnt += 1
-        self.Fn, self.slave, self.N = Fn, slave, cnt
-        # prolongation P: (all coarse nodes, all fine nodes) <- unknowns
+                    if funk[i, j, k]:
+                        Fn[i, j, k] = cnt; cnt += 1
+        self.Fn, self.N = Fn, cnt
+        # prolongation P: (all coarse nodes, all fine nodes of the bounding box) <- unknowns
         acc = _coo()
         Ncn = self.C.N
         for K in range(self.C.nn[2]):
@@ -351,9 +388,11 @@ class CompositeND:
             for j in range(self.F.nn[1]):
                 for i in range(self.F.nn[0]):
                     r = Ncn + self.F.node_index(i, j, k)
-                    if not slave[i, j, k]:
+                    if funk[i, j, k]:
                         acc[0].append([r]); acc[1].append([Fn[i, j, k]]); acc[2].append([1.0])
                         continue
+                    if not self.slave[i, j, k]:
+                        continue                              # no cell of the union touches it: not a node of the level
                     g = (flo[0] + i, flo[1] + j, flo[2] + k)                   # global fine node index
                     base = [x // 2 for x in g]; odd = [x & 1 for x in g]
                     for c, b, a in itertools.product(range(2), repeat=3):
@@ -364,18 +403,23 @@ class CompositeND:
                         assert Cn[Q] >= 0, "a slave node's parent is not an unknown"
                         acc[0].append([r]); acc[1].append([Cn[Q]]); acc[2].append([w])
         self.P = _csr(acc, (Ncn + self.F.N, self.N))
+        self.fnode = own > 0
         self.cmask = np.ones(self.nc)                      # 0 in covered coarse cells
-        self.cmask[tuple(slice(flo[d] // 2, fhi[d] // 2 + 1) for d in range(3))] = 0.0
+        cm = self.fmask[::2, ::2, ::2]
+        self.cmask[tuple(slice(flo[d] // 2, flo[d] // 2 + cm.shape[d]) for d in range(3))] = np.where(cm, 0.0, 1.0)
 
     def system(self, sigma_c, sigma_f, u_c, u_f):
-        Kc = self.C.stiffness(sigma_c * self.cmask); Kf = self.F.stiffness(sigma_f)
+        fm = self.fmask.astype(float)
+        Kc = self.C.stiffness(sigma_c * self.cmask); Kf = self.F.stiffness(sigma_f * fm)
         Kall = sp.block_diag([Kc, Kf], format="csr")
-        w = np.concatenate([self.C.load(u_c * self.cmask[..., None]), self.F.load(u_f)])
+        w = np.concatenate([self.C.load(u_c * self.cmask[..., None]), self.F.load(u_f * fm[..., None])])
         return (self.P.T @ Kall @ self.P).tocsr(), self.P.T @ w
 
     def scatter(self, y):
-        """solution on all nodes of both levels (slaves interpolated, coarse nodes inside the fine region NaN)"""
+        """solution on all nodes of both levels (slaves interpolated; coarse nodes inside the fine region and nodes of the fine array outside the
+        level NaN)"""
         full = self.P @ y
         c = self.C.to_grid(full[:self.C.N]); f = self.F.to_grid(full[self.C.N:])
         c = np.where(self.Cn >= 0, c, np.nan)
+        f = np.where(self.fnode, f, np.nan)
         return c, f

@@ -153,7 +153,7 @@ template <int NC> __global__ void __launch_bounds__(64 * SNY) kk_slopes_m(FV s, 
         if (vmax && i >= A.lo[0] && i <= A.hi[0] && j >= A.lo[1] && j <= A.hi[1] && k >= A.lo[2] && k <= A.hi[2]) m = fmax(m, fabs(s0));
       }
     }
-    __syncthreads();
+    __syncthreads();      // (round 5, measured: double-buffering ly to drop this barrier made the march slower, 0.681 -> 0.736 ms: 48 KB of LDS per workgroup)
   }
   #undef SPL
   #undef SPEC
