@@ -1847,6 +1847,7 @@ bool k_mkflux(const vdn_multifab *s, vdn_multifab **sedge, vdn_multifab **flux, 
         REQUIRE(ib == 0 || updated == do_upd, "mkflux: the update would ride along on some boxes of the level only");
         updated = do_upd;
       } else if (slab_bc()) {      // interior marches, then the face-centred code on the boundary slabs (see kk_slabs)
+        REQUIRE(!updated, "mkflux: the update rode along on an earlier box of the level but cannot on box %d", ib);      // (every box or none)
         const MkPlain P{ s->fabs[ib], sl[0], sl[1], sl[2], um, vm, wm, force->fabs[ib], mac_rhs->fabs[ib], SI, SC,
                          sedge[0]->fabs[ib], sedge[1]->fabs[ib], sedge[2]->fabs[ib], flux[0]->fabs[ib], flux[1]->fabs[ib], flux[2]->fabs[ib], A, umax };
         const Slabs Sg = boundary_slabs(A, rg), Sf = boundary_slabs(A, rf);
@@ -1857,6 +1858,7 @@ bool k_mkflux(const vdn_multifab *s, vdn_multifab **sedge, vdn_multifab **flux, 
         MK_STAGE_D(false)
         launch_slabs(Sf, MkDFix{ P }, st);
       } else {
+        REQUIRE(!updated, "mkflux: the update rode along on an earlier box of the level but cannot on box %d", ib);
         MK_STAGE(kk_mk_B_m, true, MK_ARGS_B, gg, 0)
         MK_STAGE(kk_mk_C_m, true, MK_ARGS_C, gg, 1)
         MK_STAGE_D(true)

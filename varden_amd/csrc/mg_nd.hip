@@ -2257,6 +2257,10 @@ struct MLND {
   std::map<std::tuple<int, const void *, const void *, int>, ProlongSet> pro;
   unsigned long long base_key = 0;                   // what every descriptor of the solve follows from besides its fields: layout, boundary conditions, spacings (kept descriptor sets, vdn_internal.h)
 };
+// what the fab pointers and strides of a multifab follow from (keys of kept descriptor sets; amr.hip: key_mf)
+static void nd_key_mf(GraphKey &k, const vdn_multifab *mf) {
+  k.put(mf->la->uid); k.put(mf->lev); k.put(mf->nc); k.put(mf->ng); k.put(mf->nodal[0] | (mf->nodal[1] << 1) | (mf->nodal[2] << 2)); k.put((const void *)mf->base);
+}
 // the prolongation sets of a (level, destination, source, kind) kept across solves
 struct NdProKept { KeeperMem mem; unsigned long uid = 0; BatchSet<NdmProlongB> s; BatchSet<NdmProlong8B> s8; };
 static std::map<unsigned long long, NdProKept *> g_ndpro_kept;
@@ -2275,7 +2279,7 @@ static void ml_nd_prolong(MLND &S, int n, vdn_multifab *dst, vdn_multifab *src, 
   PS.Cv = make_view(src, nd_coarse_footprints(S.la, n), S.la->owner[n], 0, 1, NVT_C2F);
   const SrcView &Cv = PS.Cv;
   Cv.refresh();
-  GraphKey gk; gk.put(0x7401); gk.put(S.base_key); gk.put(n); gk.put((const void *)dst->base); gk.put((const void *)src->base); gk.put(mode == 0 ? 0 : 1);
+  GraphKey gk; gk.put(0x7401); gk.put(S.base_key); gk.put(n); nd_key_mf(gk, dst); nd_key_mf(gk, src); gk.put(mode == 0 ? 0 : 1);
   gk.put((const void *)(S.slave[n] ? S.slave[n]->base : nullptr)); gk.put((const void *)(S.own[n - 1] ? S.own[n - 1]->base : nullptr));
   NdProKept *kept = nullptr;
   if (kept_sets_enabled()) {
@@ -2324,7 +2328,8 @@ static void ml_nd_prolong(MLND &S, int n, vdn_multifab *dst, vdn_multifab *src, 
   PS.s.run(mode, (double *)nullptr, ctx().stream); PS.s8.run(mode, (double *)nullptr, ctx().stream);
 }
 static void ml_nd_add(MLND &S, int n, vdn_multifab *dst, vdn_multifab *src) {
-  GraphKey gk; gk.put(0x7402); gk.put(S.la->uid); gk.put(n); gk.put((const void *)dst->base); gk.put((const void *)src->base);
+  // (the key carries the shapes as well as the addresses: a multifab re-created at the same address with another ghost width must not replay stale strides -- ADVICE r4)
+  GraphKey gk; gk.put(0x7402); gk.put(S.base_key); gk.put(S.la->uid); gk.put(n); nd_key_mf(gk, dst); nd_key_mf(gk, src);
   launch_batched_kept<NdfAddB>(gk.h, S.la->uid, [&](std::vector<NdfAddB> &v) {
     for (size_t f = 0; f < S.A[n].size(); f++) { NdfAddB q; q.r = S.r[n][f]; q.a = dst->fabs[f]; q.b = src->fabs[f]; v.push_back(q); }
   }, 0, (double *)nullptr, 0, ctx().stream);
