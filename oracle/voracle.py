@@ -273,31 +273,13 @@ class SimML:
         L = lib()
         self.prm = prm or default_params()
         self.prm.prob_type = prob_type
-        self.nc = nc
-        self.nlev = NL = 1 + len(boxes)
-        ns = self.prm.nscal
-        blists = [[((0, 0, 0), (nc - 1,) * 3)]]
-        for b in boxes:
-            blists.append([b] if (len(b) == 2 and not hasattr(b[0][0], "__len__")) else list(b))
-        self.levels = [Level(bl_) for bl_ in blists]
-        self.lev = level_ptr_array(self.levels)
+        self.nc, self.phys, self.grav = nc, phys, grav
+        self._set_grids(boxes)
+        NL, ns = self.nlev, self.prm.nscal
         los, his = [lv.lo for lv in self.levels], [lv.hi for lv in self.levels]
-        bcl, pd, self.dxl = [make_bc(phys, 3, ns)], [0, 0, 0, nc - 1, nc - 1, nc - 1], [[1.0 / nc] * 3]
-        for n in range(1, NL):
-            nd = nc << n
-            bcl.append(make_bc([[phys[d][0] if los[n][d] == 0 else INTERIOR, phys[d][1] if his[n][d] == nd - 1 else INTERIOR] for d in range(3)], 3, ns))
-            pd += [0, 0, 0, nd - 1, nd - 1, nd - 1]
-            self.dxl.append([1.0 / nd] * 3)
-        self.bcs = (CBc * NL)(*bcl)
-        self.pmask = ivec([0, 0, 0])
-        self.pd = ivec(pd)
-        self.dx = (C.c_double * (3 * NL))(*sum(self.dxl, []))
-        mk = lambda ng, ncomp, nodal=(0, 0, 0): [Fab(los[n], his[n], ng, ncomp, nodal) for n in range(NL)]   # noqa: E731
-        self.uold, self.sold, self.unew, self.snew = mk(3, 3), mk(3, ns), mk(3, 3), mk(3, ns)
-        self.gp, self.p = mk(1, 3), mk(1, 1, (1, 1, 1))
-        self.ext_vel_force, self.ext_scal_force = mk(1, 3), mk(1, ns)
+        self.uold, self.sold, self.gp, self.p = self._mk(3, 3), self._mk(3, ns), self._mk(1, 3), self._mk(1, 1, (1, 1, 1))
+        self._alloc_temps()
         for n in range(NL):
-            self.ext_vel_force[n].a[..., 2] = grav
             L.vo_initdata(self.uold[n].ref, self.sold[n].ref, dvec(self.dxl[n]), prob_type)
         self.mgstat = (CMgStat * 2)()
         self.time, self.istep = 0.0, 0
@@ -318,6 +300,87 @@ class SimML:
         self.dt = self.estdt(1.0e20) * init_shrink
         for _ in range(init_iter):                                # varden.f90:460-490
             self._advance(PRESSURE_ITERS)
+
+    def _set_grids(self, boxes):
+        """the box lists of the refined levels -> levels, bc tables, domains, spacings"""
+        nc, phys, ns = self.nc, self.phys, self.prm.nscal
+        self.nlev = NL = 1 + len(boxes)
+        blists = [[((0, 0, 0), (nc - 1,) * 3)]]
+        for b in boxes:
+            blists.append([b] if (len(b) == 2 and not hasattr(b[0][0], "__len__")) else list(b))
+        self.levels = [Level(bl_) for bl_ in blists]
+        self.lev = level_ptr_array(self.levels)
+        los, his = [lv.lo for lv in self.levels], [lv.hi for lv in self.levels]
+        bcl, pd, self.dxl = [make_bc(phys, 3, ns)], [0, 0, 0, nc - 1, nc - 1, nc - 1], [[1.0 / nc] * 3]
+        for n in range(1, NL):
+            nd = nc << n
+            bcl.append(make_bc([[phys[d][0] if los[n][d] == 0 else INTERIOR, phys[d][1] if his[n][d] == nd - 1 else INTERIOR] for d in range(3)], 3, ns))
+            pd += [0, 0, 0, nd - 1, nd - 1, nd - 1]
+            self.dxl.append([1.0 / nd] * 3)
+        self.bcs = (CBc * NL)(*bcl)
+        self.pmask = ivec([0, 0, 0])
+        self.pd = ivec(pd)
+        self.dx = (C.c_double * (3 * NL))(*sum(self.dxl, []))
+
+    def _mk(self, ng, ncomp, nodal=(0, 0, 0)):
+        return [Fab(self.levels[n].lo, self.levels[n].hi, ng, ncomp, nodal) for n in range(self.nlev)]
+
+    def _alloc_temps(self):
+        ns = self.prm.nscal
+        self.unew, self.snew = self._mk(3, 3), self._mk(3, ns)
+        self.ext_vel_force, self.ext_scal_force = self._mk(1, 3), self._mk(1, ns)
+        for n in range(self.nlev):
+            self.ext_vel_force[n].a[..., 2] = self.grav
+
+    def node_mask(self, n):
+        """nodes of level n's array that a cell of the level touches"""
+        m = self.levels[n].mask()
+        out = np.zeros(tuple(x + 1 for x in m.shape), dtype=bool)
+        for c in (0, 1):
+            for b in (0, 1):
+                for a in (0, 1):
+                    out[a:a + m.shape[0], b:b + m.shape[1], c:c + m.shape[2]] |= m
+        return out
+
+    def regrid(self, boxes):
+        """the state moved onto NEW box lists of the refined levels -- build_and_fill_data of src/regrid.f90:269-339, coarsest level first: the ghost cells
+        of the levels below filled, every cell of the new level interpolated from the level below (fillpatch), the pressure prolonged node by node
+        (ml_nodal_prolongation), then the old level's data copied wherever the old level had cells (multifab_copy_c between the box lists).  The grids
+        themselves (tag_boxes + make_new_grids) come from the caller."""
+        L = lib()
+        old_levels, old_nlev = self.levels, self.nlev
+        old = dict(uold=self.uold, sold=self.sold, gp=self.gp, p=self.p)
+        old_nmask = [self.node_mask(n) for n in range(old_nlev)]
+        self._set_grids(boxes)
+        ns = self.prm.nscal
+        new = dict(uold=self._mk(3, 3), sold=self._mk(3, ns), gp=self._mk(1, 3), p=self._mk(1, 1, (1, 1, 1)))
+        for k in new:
+            new[k][0].a[...] = old[k][0].a
+        for n in range(1, self.nlev):
+            for k, ic, bc_, nc_, same in (("uold", 0, 0, 3, 0), ("sold", 0, 3, ns, 0), ("gp", 0, 3 + ns + 1, 3, 1)):
+                L.vo_ml_restrict_and_fill_g(n, self.lev, fab_ptr_array(new[k][:n]), ic, bc_, nc_, same, self.bcs, self.pmask, self.pd, C.byref(self.prm))
+                L.vo_fillpatch(new[k][n].ref, new[k][n - 1].ref, 0, nc_)
+            L.vo_nodal_prolongation(new["p"][n].ref, new["p"][n - 1].ref)
+            if n < old_nlev:                                     # the old level's data where it had cells (nodes: where a cell of it touches)
+                ol, nl = old_levels[n], self.levels[n]
+                lo = [max(ol.lo[d], nl.lo[d]) for d in range(3)]; hi = [min(ol.hi[d], nl.hi[d]) for d in range(3)]
+                if all(lo[d] <= hi[d] for d in range(3)):
+                    so = tuple(slice(lo[d] - ol.lo[d], hi[d] - ol.lo[d] + 1) for d in range(3))
+                    sn = tuple(slice(lo[d] - nl.lo[d], hi[d] - nl.lo[d] + 1) for d in range(3))
+                    both = ol.mask()[so] & nl.mask()[sn]
+                    for k in ("uold", "sold", "gp"):
+                        dst, src = new[k][n].valid(), old[k][n].valid()
+                        dst[sn][both] = src[so][both]
+                    so_n = tuple(slice(lo[d] - ol.lo[d], hi[d] - ol.lo[d] + 2) for d in range(3))
+                    sn_n = tuple(slice(lo[d] - nl.lo[d], hi[d] - nl.lo[d] + 2) for d in range(3))
+                    bothn = old_nmask[n][so_n] & self.node_mask(n)[sn_n]
+                    new["p"][n].valid()[sn_n][bothn] = old["p"][n].valid()[so_n][bothn]
+        self.uold, self.sold, self.gp, self.p = new["uold"], new["sold"], new["gp"], new["p"]
+        self._alloc_temps()
+        self.fill_state_ghosts()                                  # regrid.f90:252-254
+        for n in range(self.nlev):
+            self.unew[n].a[...] = self.uold[n].a
+            self.snew[n].a[...] = self.sold[n].a
 
     def _rf(self, mfs, icomp, bcomp, nc, same=0):
         lib().vo_ml_restrict_and_fill_g(self.nlev, self.lev, fab_ptr_array(mfs), icomp, bcomp, nc, same, self.bcs, self.pmask, self.pd, C.byref(self.prm))

@@ -86,3 +86,29 @@ def test_flux_restriction_is_what_conserves_the_composite_mass():
     assert abs(m1 - m0) <= 1e-13 * m0, (m1 - m0) / m0
     # the bubble (radius 0.1 around the centre, cell 16 of 32 on the fine level) is cut by the fine level's high-x face at fine cell 19
     assert S.sold[1].valid()[-1, :, :, 0].max() > 1.5
+
+
+def test_regridding_onto_the_same_and_onto_other_box_lists():
+    """SimML.regrid (build_and_fill_data of src/regrid.f90:269-339 on level arrays): onto the SAME box lists the state comes back bit for bit (every cell and
+    node is copied from the old level); onto a smaller level the remaining cells keep their data and the run goes on; onto a larger one the new cells are
+    the fillpatch interpolation of the level below -- a linear density stays linear there"""
+    S, _, _, _ = run([TWO], steps=1)
+    before = [f.valid().copy() for f in S.uold + S.sold + S.gp + S.p]
+    S.regrid([TWO])
+    after = [f.valid() for f in S.uold + S.sold + S.gp + S.p]
+    msk = [S.levels[n].mask() for n in range(2)] * 3 + [S.node_mask(n) for n in range(2)]
+    for a, b, m in zip(before, after, msk):
+        assert np.array_equal(a[m], b[m])
+    S.regrid([[TWO[0]]])                                  # the level shrinks to its first box
+    assert S.levels[1].hi == TWO[0][1]
+    S.step()
+    assert np.isfinite(S.uold[1].valid()).all() and S.mgstat[0].cycles < 30 and S.mgstat[1].cycles < 40
+    # growth: a field that is linear in x on both levels is reproduced on the cells the level gains
+    for n in range(2):
+        h = 1.0 / (16 << n)
+        x = (np.arange(S.levels[n].lo[0] - 3, S.levels[n].hi[0] + 4) + 0.5) * h
+        S.sold[n].a[..., 0] = 1.0 + x[:, None, None]
+    S.regrid([EIGHT])
+    h = 1.0 / 32
+    x = (np.arange(S.levels[1].lo[0], S.levels[1].hi[0] + 1) + 0.5) * h
+    assert np.abs(S.sold[1].valid()[..., 0] - (1.0 + x[:, None, None])).max() <= 1e-14
