@@ -221,7 +221,8 @@ def _level_dense(mf, comp=0):
 def test_tagged_hierarchy_step_at_256(gpu, max_levs):
     """BASELINE configs[3] / configs[4] on their REAL box lists (what `bench.py --config amr2 / amr3` times): 256^3 base, levels tagged at
     rho > 1.01 (and rho > 1.1) by tag_boxes.f90:65-94 and clustered by make_new_grids -- 263 boxes on level 1, ~1000 on level 2.  One
-    step: both composite solves meet the reference's tolerances (macproject.f90:91-93, hgproject.f90:113-119), every coarse cell under a
+    step: both composite solves meet the reference's tolerances (macproject.f90:91-93, hgproject.f90:113-119), the mass of the composite grid is conserved to
+    round-off (the coarse cells next to a finer level take the fine fluxes, mkflux.f90:137-146), every coarse cell under a
     finer level is the average of its eight children (ml_cc_restriction), the base level keeps the mirror symmetry of the bubble to truncation level."""
     from varden_amd import advance as adv
     from varden_amd import driver
@@ -231,7 +232,26 @@ def test_tagged_hierarchy_step_at_256(gpu, max_levs):
     assert len(levels) == max_levs - 1 and len(levels[0]) > 100
     G = driver.VardenAMR(N, levels[0], WALLS, params=prm, finer_levels=levels[1:], init_shrink=0.1, init_iter=1, do_initial_projection=1,
                          max_grid_size=256, swap_state=True)
+
+    def composite_mass():
+        """sum of rho * cell volume over the cells of every level that no finer level covers"""
+        dense = [_level_dense(G.sold[l], 0) for l in range(max_levs)]
+        m = 0.0
+        for l in range(max_levs):
+            a, lo = dense[l]
+            unc = np.isfinite(a)
+            if l + 1 < max_levs:
+                fine, flo = dense[l + 1]
+                cov = np.isfinite(fine[::2, ::2, ::2])
+                o = [flo[d] // 2 - lo[d] for d in range(3)]
+                unc[o[0]:o[0] + cov.shape[0], o[1]:o[1] + cov.shape[1], o[2]:o[2] + cov.shape[2]] &= ~cov
+            m += float(a[unc].sum()) / 8.0 ** l
+        return m
+    m0 = composite_mass()
     G.step()
+    # round 5: the conservative fluxes are restricted onto the coarser level (mkflux.f90:137-146) -- the mass of the composite grid does not drift
+    m1 = composite_mass()
+    assert abs(m1 - m0) <= 1e-12 * m0, "composite mass drifted by %.3e in one step" % ((m1 - m0) / m0)
     mac, hg = adv.last_solver_stats("mac"), adv.last_solver_stats("hg")
     hg_tol = 1e-11 if max_levs == 2 else 1e-10
     assert mac[0] < 40 and hg[0] < 40 and mac[2] <= 1e-10 * mac[1] and hg[2] <= hg_tol * hg[1], (mac, hg)
