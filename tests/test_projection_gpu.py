@@ -229,10 +229,12 @@ def test_multigrid_launch_variants_agree_bit_for_bit(gpu):
             h.update(np.ascontiguousarray(m.to_numpy()).tobytes())
         print("HASH", h.hexdigest(), G.dt)
     """ % root)
-    switches = ("VDN_MG_PROLONG_FUSED", "VDN_MG_RESTRICT_FUSED", "VDN_MG_TAILCYCLE", "VDN_MG_LDS", "VDN_NO_GRAPHS", "VDN_HG_FAST", "VDN_MAC_FAST", "VDN_ND_LEAN", "VDN_NO_FORCE_REUSE", "VDN_GOD_UPDATE", "VDN_GOD_P2", "VDN_ND_RESTRICT_FUSED")
+    switches = ("VDN_MG_PROLONG_FUSED", "VDN_MG_RESTRICT_FUSED", "VDN_MG_TAILCYCLE", "VDN_MG_LDS", "VDN_NO_GRAPHS", "VDN_HG_FAST", "VDN_MAC_FAST", "VDN_ND_LEAN", "VDN_NO_FORCE_REUSE", "VDN_GOD_UPDATE", "VDN_GOD_P2", "VDN_ND_RESTRICT_FUSED", "VDN_GOD_1B", "VDN_GOD_NARROW")
     for n, visc in ((128, 0.0), (64, 0.01)):
         out = []
-        for extra in ({}, {"VDN_MG_PROLONG_FUSED": "0", "VDN_MG_RESTRICT_FUSED": "0", "VDN_MG_TAILCYCLE": "0", "VDN_MG_LDS": "0", "VDN_NO_GRAPHS": "1",
+        # third run (round 5): the defaults with the fused mkflux + update march in its round-4 form -- three workgroup barriers per plane, the
+        # remainder tile column in full 64-lane tiles -- against one barrier and narrow segments
+        for extra in ({}, {"VDN_GOD_1B": "0", "VDN_GOD_NARROW": "0"}, {"VDN_MG_PROLONG_FUSED": "0", "VDN_MG_RESTRICT_FUSED": "0", "VDN_MG_TAILCYCLE": "0", "VDN_MG_LDS": "0", "VDN_NO_GRAPHS": "1",
                           "VDN_HG_FAST": "0", "VDN_MAC_FAST": "0", "VDN_ND_LEAN": "0", "VDN_NO_FORCE_REUSE": "1", "VDN_GOD_UPDATE": "0", "VDN_GOD_P2": "0", "VDN_ND_RESTRICT_FUSED": "0"}):
             env = dict(os.environ)
             for k in switches:
@@ -241,4 +243,4 @@ def test_multigrid_launch_variants_agree_bit_for_bit(gpu):
             r = subprocess.run([sys.executable, "-c", code, str(n), str(visc)], env=env, capture_output=True, text=True, timeout=600, cwd=root)
             assert r.returncode == 0, r.stderr[-2000:]
             out.append([ln for ln in r.stdout.splitlines() if ln.startswith("HASH")][0])
-        assert out[0] == out[1], (n, visc, out)
+        assert out[0] == out[1] == out[2], (n, visc, out)
