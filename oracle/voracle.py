@@ -269,11 +269,13 @@ class SimML:
     boxes: per refined level either ONE box (lo, hi) or a LIST of boxes [(lo, hi), ...], in the level's own index space.  The fields of a level are
     level arrays over the bounding box of its boxes (oracle/vo.h); `levels[n].mask()` marks the cells that belong to the level."""
 
-    def __init__(self, nc, boxes, phys, prm=None, prob_type=1, grav=-9.8, init_shrink=0.1, init_iter=0, do_initial_projection=0):
+    def __init__(self, nc, boxes, phys, prm=None, prob_type=1, grav=-9.8, init_shrink=0.1, init_iter=0, do_initial_projection=0, base_boxes=None):
+        """base_boxes: level 0 cut into boxes (what max_grid_size makes of it); default: one box"""
         L = lib()
         self.prm = prm or default_params()
         self.prm.prob_type = prob_type
         self.nc, self.phys, self.grav = nc, phys, grav
+        self.base_boxes = [((0, 0, 0), (nc - 1,) * 3)] if base_boxes is None else [(tuple(b[0]), tuple(b[1])) for b in base_boxes]
         self._set_grids(boxes)
         NL, ns = self.nlev, self.prm.nscal
         los, his = [lv.lo for lv in self.levels], [lv.hi for lv in self.levels]
@@ -305,7 +307,7 @@ class SimML:
         """the box lists of the refined levels -> levels, bc tables, domains, spacings"""
         nc, phys, ns = self.nc, self.phys, self.prm.nscal
         self.nlev = NL = 1 + len(boxes)
-        blists = [[((0, 0, 0), (nc - 1,) * 3)]]
+        blists = [list(self.base_boxes)]
         for b in boxes:
             blists.append([b] if (len(b) == 2 and not hasattr(b[0][0], "__len__")) else list(b))
         self.levels = [Level(bl_) for bl_ in blists]

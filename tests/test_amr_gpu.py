@@ -445,7 +445,8 @@ def test_tagged_grids_properties_and_run(gpu, max_levs):
 INOUT_BC = [[11, 12], [15, 15], [15, 15]]          # inputs_advect_3d: inflow x-lo, outflow x-hi, no-slip elsewhere
 
 
-@pytest.mark.parametrize("nc,max_levs,case", [(32, 2, "bubble"), (32, 3, "bubble"), (64, 2, "bubble"), (64, 3, "bubble"), (32, 3, "bubble-viscous"), (32, 3, "advect-viscous")])
+@pytest.mark.parametrize("nc,max_levs,case", [(32, 2, "bubble"), (32, 3, "bubble"), (64, 2, "bubble"), (64, 3, "bubble"), (32, 3, "bubble-viscous"), (32, 3, "advect-viscous"),
+                                              (32, 3, "bubble-base-in-eight")])
 def test_tagged_hierarchy_against_the_box_list_oracle(gpu, oracle, nc, max_levs, case):
     """BASELINE.json configs[3] / [4] in small: the refined levels are the boxes make_new_grids returns for the tagged bubble (tag_boxes.f90:65-94: rho > 1.01 /
     rho > 1.1) -- unions that are not rectangles, re-entrant interface edges, boxes of a few cells -- and the ORACLE RUNS THE SAME BOX LISTS (oracle/vo.h:
@@ -465,10 +466,15 @@ def test_tagged_hierarchy_against_the_box_list_oracle(gpu, oracle, nc, max_levs,
     elif case == "advect-viscous":
         phys, prob, grav = INOUT_BC, 2, 0.0
         kw.update(visc_coef=0.001)
-    levels = driver.VardenAMR.tagged_grids(nc, phys, params_for(phys, **kw), prob_type=prob, max_levs=max_levs, max_grid_size=32 if prob == 1 else 16)
+    base = None
+    if case == "bubble-base-in-eight":                      # level 0 cut into 2 x 2 x 2 boxes, as `bench.py --config amr3` cuts it for several ranks (configs[4])
+        hb = nc // 2
+        base = [((i * hb, j * hb, k * hb), ((i + 1) * hb - 1, (j + 1) * hb - 1, (k + 1) * hb - 1)) for k in range(2) for j in range(2) for i in range(2)]
+    levels = driver.VardenAMR.tagged_grids(nc, phys, params_for(phys, **kw), prob_type=prob, max_levs=max_levs, max_grid_size=32 if prob == 1 else 16, base_boxes=base)
     assert len(levels) == max_levs - 1 and len(levels[0]) > 1, "the tagged blob should give unions of several boxes: %r" % ([len(lb) for lb in levels],)
-    G = driver.VardenAMR(nc, levels[0], phys, params=params_for(phys, **kw), prob_type=prob, grav=grav, finer_levels=levels[1:], init_shrink=0.1, init_iter=1, do_initial_projection=1)
-    O = vo.SimML(nc, levels, phys, prm=params_for(phys, **kw), prob_type=prob, grav=grav, init_shrink=0.1, init_iter=1, do_initial_projection=1)
+    G = driver.VardenAMR(nc, levels[0], phys, params=params_for(phys, **kw), prob_type=prob, grav=grav, finer_levels=levels[1:], init_shrink=0.1, init_iter=1, do_initial_projection=1,
+                         base_boxes=base)
+    O = vo.SimML(nc, levels, phys, prm=params_for(phys, **kw), prob_type=prob, grav=grav, init_shrink=0.1, init_iter=1, do_initial_projection=1, base_boxes=base)
     assert G.initial_projection_stat[0] == O.initial_projection_stat[0], "initial projection: FAC iterations %r (GPU) vs %r (oracle)" % (G.initial_projection_stat[0], O.initial_projection_stat[0])
     assert G.dt == O.dt
 
