@@ -157,9 +157,9 @@ DEVI void pair_gather(const double *v, const CLev &L, long cpA, int par, int lan
 // value the pass reads becomes phi + e(parent) -- a 2 x 2 block shares its parent, the six blocks around it give the rest (coarse ghost
 // cells are zero, so box-boundary ghosts stay as they are); the updated cells are stored corrected.  ADD = 2, the second colour: its
 // neighbours are final, only the cell itself still lacks its correction.  The sum phi + e is the one kk_cc_prolong forms.
-template <int ADD> __global__ void __launch_bounds__(256) kk_cc_gsrb_rho_pair_t(CLev L, int color, int interior_only, CLev C) {
+template <int ADD> __global__ void __launch_bounds__(256) kk_cc_gsrb_rho_pair_t(CLev L, int color, int interior_only, CLev C, int kdown) {
   int bx, by, bz; xcd_block(bx, by, bz);
-  const int lane = threadIdx.x, k = bz;
+  const int lane = threadIdx.x, k = kdown ? L.n[2] - 1 - bz : bz;
   const int t = bx * 64 + lane, jA = 2 * (by * 4 + (int)threadIdx.y);
   const bool act = 2 * t + 1 < L.n[0] && jA + 1 < L.n[1];
   const int par = (jA + k + color) & 1;                              // uniform over the wave
@@ -192,9 +192,10 @@ template <int ADD> __global__ void __launch_bounds__(256) kk_cc_gsrb_rho_pair_t(
   if (diag != 0.0 && !(interior_only && cc_is_shell(L, iB, jA + 1, k, interior_only))) L.phi[cpA + L.PX + 1 - par] = P.b[0] + (sel2(RB, 1 - par) - Ap) / diag;
   else if (ADD) L.phi[cpA + L.PX + 1 - par] = P.b[0];
 }
-__global__ void __launch_bounds__(256) kk_cc_gsrb_rho_pair(CLev L, int color, int interior_only) {
+// kdown: the planes from the top (launch_gsrb: the second colour of a sweep -- it starts on what the first colour's pass touched last, still in the Infinity Cache)
+__global__ void __launch_bounds__(256) kk_cc_gsrb_rho_pair(CLev L, int color, int interior_only, int kdown) {
   int bx, by, bz; xcd_block(bx, by, bz);
-  const int lane = threadIdx.x, k = bz;
+  const int lane = threadIdx.x, k = kdown ? L.n[2] - 1 - bz : bz;
   const int t = bx * 64 + lane, jA = 2 * (by * 4 + (int)threadIdx.y);
   const bool act = 2 * t + 1 < L.n[0] && jA + 1 < L.n[1];
   const int par = (jA + k + color) & 1;                              // uniform over the wave
@@ -211,6 +212,153 @@ __global__ void __launch_bounds__(256) kk_cc_gsrb_rho_pair(CLev L, int color, in
   cc_apply_rho_vals(L, iB, jA + 1, k, P.b, R.b, Ap, diag);
   if (diag != 0.0 && !(interior_only && cc_is_shell(L, iB, jA + 1, k, interior_only))) L.phi[cpA + L.PX + 1 - par] = P.b[0] + (sel2(RB, 1 - par) - Ap) / diag;
 }
+// ---- round 5: the finest level of macproject's solve STORED BY COLOUR ---------------------------------------------------------------------------
+// The paired pass above still moves whole lines of phi and rhs although half of every line belongs to the other colour: 572 MB per pass at 256^3
+// (profiles/r05_smoother_rho_pmc.json) where the cells it touches hold 402 MB.  Split storage: cells with (i + j + k) & 1 == c live in arrays [c],
+// entry ih of row (j, k) is cell i = 2 ih + ((j + k + c) & 1); rows, planes and the ghost layer as in the level array, 8 entries of padding in front
+// of a row.  A colour pass then reads its own phi / rhs / rho and the OTHER colour's phi / rho -- nothing it does not use -- as aligned 16-byte
+// pairs: the y and z neighbours of entry ih are entry ih of the other colour's rows j -+ 1 / planes k -+ 1, the x neighbours its entries ih - 1, ih
+// (row parity 0) or ih, ih + 1 (parity 1).  Same expressions, same order, same bits as the interleaved pass (cc_apply_rho_vals);
+// tools/probes/split_colour_probe.hip measured the form first (0.0865 against 0.1135 ms per pass at 256^3).  VDN_MAC_SPLIT=0 keeps the level interleaved.
+struct CSplit { int PXH; long sy, sz, tot; double *phi[2], *rh[2], *rho[2]; };
+DEVI long sidx(const CSplit &S, int ih, int j, int k) { return (long)(ih + 8) + S.sy * (long)(j + 1) + S.sz * (long)(k + 1); }
+// interleaved -> split, every entry of the padded rows (what lies outside cells -2 .. n+1 becomes zero): one aligned pair (cells 2 ih, 2 ih + 1) feeds both colours
+__global__ void __launch_bounds__(256) kk_cc_to_split(CLev L, CSplit S, int what) {       // what: 1 phi, 2 rhs, 4 rho
+  const int e = blockIdx.x * 64 + threadIdx.x, j = (int)(blockIdx.y * 4 + threadIdx.y) - 1, k = (int)blockIdx.z - 1;
+  if (e >= S.PXH || j > L.n[1]) return;
+  const int ih = e - 8;
+  const bool in = ih >= -1 && ih <= L.n[0] / 2;
+  const long src = cidx(L, in ? 2 * ih : 0, j, k), dst = sidx(S, ih, j, k);
+  const int c0 = (j + k) & 1;                    // the colour of the even cells of this row
+  const double2 z = make_double2(0.0, 0.0);
+  if (what & 1) { const double2 v = in ? *reinterpret_cast<const double2 *>(L.phi + src) : z; S.phi[c0][dst] = v.x; S.phi[1 - c0][dst] = v.y; }
+  if (what & 2) { const double2 v = in ? *reinterpret_cast<const double2 *>(L.rh + src) : z;  S.rh[c0][dst] = v.x;  S.rh[1 - c0][dst] = v.y; }
+  if (what & 4) { const double2 v = in ? *reinterpret_cast<const double2 *>(L.rho + src) : z; S.rho[c0][dst] = v.x; S.rho[1 - c0][dst] = v.y; }
+}
+// split -> interleaved: phi on the valid cells
+__global__ void __launch_bounds__(256) kk_cc_from_split(CLev L, CSplit S) {
+  const int ih = blockIdx.x * 64 + threadIdx.x, j = blockIdx.y * 4 + threadIdx.y, k = blockIdx.z;
+  if (ih >= L.n[0] / 2 || j >= L.n[1]) return;
+  const int c0 = (j + k) & 1;
+  const long s = sidx(S, ih, j, k);
+  *reinterpret_cast<double2 *>(L.phi + cidx(L, 2 * ih, j, k)) = make_double2(S.phi[c0][s], S.phi[1 - c0][s]);
+}
+// a thread owns entries ih, ih + 1 of a row (A, B); a wave a row segment of 128 entries = 256 cells; 8 rows per workgroup.  ADD as in kk_cc_gsrb_rho_pair_t:
+// the parent of entry ih is coarse cell ih.
+template <int ADD> __global__ void __launch_bounds__(512) kk_cc_gsrb_rho_split(CLev L, CSplit S, int color, CLev C, int kdown) {
+  const int lane = threadIdx.x, k = kdown ? L.n[2] - 1 - (int)blockIdx.z : (int)blockIdx.z;
+  const int t = blockIdx.x * 64 + lane, nh = L.n[0] / 2;
+  const int jr = blockIdx.y * 8 + threadIdx.y, j = min(jr, L.n[1] - 1);
+  const bool act = 2 * t + 1 < nh && jr < L.n[1];
+  const int p = (j + k + color) & 1;                                 // parity of i on this row (uniform over the wave): i = 2 ih + p
+  const int ih = 2 * min(t, nh / 2);                                 // clamped: every lane takes part in the lane exchange, the pair (nh, nh + 1) lies inside the row
+  const long c = sidx(S, ih, j, k);
+  const double *po = S.phi[color], *px = S.phi[1 - color], *ro = S.rho[color], *rx = S.rho[1 - color];
+  double ep = 0.0, er = 0.0;                                         // the other colour's entry outside the wave's span: ih - 1 (p = 0, first lane) or ih + 2 (p = 1, last lane)
+  if ((p == 0 && lane == 0) || (p == 1 && lane == 63)) { const long o = c + (p ? 2 : -1); ep = px[o]; er = rx[o]; }
+  #define LDS2(v, off) (*reinterpret_cast<const double2 *>((v) + c + (off)))
+  const double2 PO = LDS2(po, 0), RH = LDS2(S.rh[color], 0), RO = LDS2(ro, 0);
+  const double2 PX = LDS2(px, 0), PYm = LDS2(px, -S.sy), PYp = LDS2(px, S.sy), PZm = LDS2(px, -S.sz), PZp = LDS2(px, S.sz);
+  const double2 RX = LDS2(rx, 0), RYm = LDS2(rx, -S.sy), RYp = LDS2(rx, S.sy), RZm = LDS2(rx, -S.sz), RZp = LDS2(rx, S.sz);
+  #undef LDS2
+  const double pl = lane_prev(PX.y), pr = lane_next(PX.x), rl = lane_prev(RX.y), rr = lane_next(RX.x);
+  if (!act) return;
+  // centre, x-, x+, y-, y+, z-, z+
+  double pa[7] = { PO.x, p ? PX.x : (lane == 0 ? ep : pl), p ? PX.y : PX.x, PYm.x, PYp.x, PZm.x, PZp.x };
+  double pb[7] = { PO.y, p ? PX.y : PX.x, p ? (lane == 63 ? ep : pr) : PX.y, PYm.y, PYp.y, PZm.y, PZp.y };
+  const double ra[7] = { RO.x, p ? RX.x : (lane == 0 ? er : rl), p ? RX.y : RX.x, RYm.x, RYp.x, RZm.x, RZp.x };
+  const double rb[7] = { RO.y, p ? RX.y : RX.x, p ? (lane == 63 ? er : rr) : RX.y, RYm.y, RYp.y, RZm.y, RZp.y };
+  if (ADD) {
+    const int J = j >> 1, K = k >> 1;
+    const long cc = cidx(C, ih, J, K), csy = C.PX, csz = (long)C.PX * C.PY;
+    const double eA = C.phi[cc], eB = C.phi[cc + 1];
+    pa[0] = pa[0] + eA; pb[0] = pb[0] + eB;
+    if (ADD == 1) {
+      const double xo = C.phi[cc + (p ? 2 : -1)];
+      const long oy = (j & 1) ? csy : -csy, oz = (k & 1) ? csz : -csz;
+      const double yA = C.phi[cc + oy], yB = C.phi[cc + 1 + oy], zA = C.phi[cc + oz], zB = C.phi[cc + 1 + oz];
+      if (p == 0) { pa[1] = pa[1] + xo; pa[2] = pa[2] + eA; pb[1] = pb[1] + eA; pb[2] = pb[2] + eB; }
+      else        { pa[1] = pa[1] + eA; pa[2] = pa[2] + eB; pb[1] = pb[1] + eB; pb[2] = pb[2] + xo; }
+      pa[3] = pa[3] + ((j & 1) ? eA : yA); pa[4] = pa[4] + ((j & 1) ? yA : eA); pb[3] = pb[3] + ((j & 1) ? eB : yB); pb[4] = pb[4] + ((j & 1) ? yB : eB);
+      pa[5] = pa[5] + ((k & 1) ? eA : zA); pa[6] = pa[6] + ((k & 1) ? zA : eA); pb[5] = pb[5] + ((k & 1) ? eB : zB); pb[6] = pb[6] + ((k & 1) ? zB : eB);
+    }
+  }
+  double Ap, diag;
+  double2 out = make_double2(pa[0], pb[0]);
+  cc_apply_rho_vals(L, 2 * ih + p, j, k, pa, ra, Ap, diag);
+  if (diag != 0.0) out.x = pa[0] + (RH.x - Ap) / diag;
+  cc_apply_rho_vals(L, 2 * ih + 2 + p, j, k, pb, rb, Ap, diag);
+  if (diag != 0.0) out.y = pb[0] + (RH.y - Ap) / diag;
+  *reinterpret_cast<double2 *>(S.phi[color] + c) = out;
+}
+// residual + restriction on the split level (kk_cc_residual_rho_pair_rst's job): a thread owns entries ih, ih + 1 of BOTH colours in rows 2J, 2J + 1 of planes
+// 2K, 2K + 1 = cells 2 ih .. 2 ih + 3 of each row = the children of coarse cells (ih, J, K) and (ih + 1, J, K).  Per plane: E = the row's even cells (2 ih, 2 ih + 2),
+// O = its odd cells (2 ih + 1, 2 ih + 3), each one aligned pair of the colour that holds them ((parity + j + k) & 1); q[jj][m]: cell 2 ih + m of row 2J + jj.
+DEVI void split_gather(double *const v[2], const CSplit &S, long c, int e, int lane, double q[2][4][7]) {
+  // e: the colour of the even cells of row 2J in this plane
+  const long sy = S.sy, sz = S.sz;
+  double a0 = 0.0, a1 = 0.0;                                       // outside the wave's span along x, two active lanes
+  if (lane == 0)  { a0 = v[1 - e][c - 1]; a1 = v[e][c + sy - 1]; }
+  if (lane == 63) { a0 = v[e][c + 2];     a1 = v[1 - e][c + sy + 2]; }
+  #define LD(col, off) (*reinterpret_cast<const double2 *>(v[col] + c + (off)))
+  const double2 E0 = LD(e, 0), O0 = LD(1 - e, 0), E1 = LD(1 - e, sy), O1 = LD(e, sy);
+  const double2 Em = LD(1 - e, -sy), Om = LD(e, -sy), Ep = LD(e, 2 * sy), Op = LD(1 - e, 2 * sy);
+  const double2 E0m = LD(1 - e, -sz), O0m = LD(e, -sz), E0p = LD(1 - e, sz), O0p = LD(e, sz);
+  const double2 E1m = LD(e, sy - sz), O1m = LD(1 - e, sy - sz), E1p = LD(e, sy + sz), O1p = LD(1 - e, sy + sz);
+  #undef LD
+  const double l0 = lane_prev(O0.y), r0 = lane_next(E0.x), l1 = lane_prev(O1.y), r1 = lane_next(E1.x);
+  // centre, x-, x+, y-, y+, z-, z+
+  q[0][0][0] = E0.x; q[0][0][1] = lane == 0 ? a0 : l0; q[0][0][2] = O0.x; q[0][0][3] = Em.x; q[0][0][4] = E1.x; q[0][0][5] = E0m.x; q[0][0][6] = E0p.x;
+  q[0][1][0] = O0.x; q[0][1][1] = E0.x; q[0][1][2] = E0.y; q[0][1][3] = Om.x; q[0][1][4] = O1.x; q[0][1][5] = O0m.x; q[0][1][6] = O0p.x;
+  q[0][2][0] = E0.y; q[0][2][1] = O0.x; q[0][2][2] = O0.y; q[0][2][3] = Em.y; q[0][2][4] = E1.y; q[0][2][5] = E0m.y; q[0][2][6] = E0p.y;
+  q[0][3][0] = O0.y; q[0][3][1] = E0.y; q[0][3][2] = lane == 63 ? a0 : r0; q[0][3][3] = Om.y; q[0][3][4] = O1.y; q[0][3][5] = O0m.y; q[0][3][6] = O0p.y;
+  q[1][0][0] = E1.x; q[1][0][1] = lane == 0 ? a1 : l1; q[1][0][2] = O1.x; q[1][0][3] = E0.x; q[1][0][4] = Ep.x; q[1][0][5] = E1m.x; q[1][0][6] = E1p.x;
+  q[1][1][0] = O1.x; q[1][1][1] = E1.x; q[1][1][2] = E1.y; q[1][1][3] = O0.x; q[1][1][4] = Op.x; q[1][1][5] = O1m.x; q[1][1][6] = O1p.x;
+  q[1][2][0] = E1.y; q[1][2][1] = O1.x; q[1][2][2] = O1.y; q[1][2][3] = E0.y; q[1][2][4] = Ep.y; q[1][2][5] = E1m.y; q[1][2][6] = E1p.y;
+  q[1][3][0] = O1.y; q[1][3][1] = E1.y; q[1][3][2] = lane == 63 ? a1 : r1; q[1][3][3] = O0.y; q[1][3][4] = Op.y; q[1][3][5] = O1m.y; q[1][3][6] = O1p.y;
+}
+__global__ void __launch_bounds__(256) kk_cc_residual_rho_split_rst(CLev L, CSplit S, double *nrm, CLev C) {
+  const int lane = threadIdx.x, nh = L.n[0] / 2;
+  const int u = blockIdx.x * 64 + lane, Jr = blockIdx.y * 4 + threadIdx.y, J = min(Jr, L.n[1] / 2 - 1);
+  const bool act = 2 * u + 1 < nh && Jr < L.n[1] / 2;
+  const int ih = 2 * min(u, nh / 2);
+  double rmax = 0.0;
+  for (int K = blockIdx.z; K < L.n[2] / 2; K += gridDim.z) {
+    double s0 = 0.0, s1 = 0.0;
+    #pragma unroll
+    for (int kk = 0; kk < 2; kk++) {
+      const int k = 2 * K + kk, e = kk;                            // (0 + 2J + k) & 1
+      const long c = sidx(S, ih, 2 * J, k);
+      double P[2][4][7], R[2][4][7];
+      split_gather(S.phi, S, c, e, lane, P);
+      split_gather(S.rho, S, c, e, lane, R);
+      const double2 H0e = *reinterpret_cast<const double2 *>(S.rh[e] + c), H0o = *reinterpret_cast<const double2 *>(S.rh[1 - e] + c);
+      const double2 H1e = *reinterpret_cast<const double2 *>(S.rh[1 - e] + c + S.sy), H1o = *reinterpret_cast<const double2 *>(S.rh[e] + c + S.sy);
+      if (act) {
+        const double rhs[2][4] = { { H0e.x, H0o.x, H0e.y, H0o.y }, { H1e.x, H1o.x, H1e.y, H1o.y } };
+        #pragma unroll
+        for (int jj = 0; jj < 2; jj++) {
+          #pragma unroll
+          for (int m = 0; m < 4; m++) {
+            double Ap, diag;
+            cc_apply_rho_vals(L, 2 * ih + m, 2 * J + jj, k, P[jj][m], R[jj][m], Ap, diag);
+            const double r = rhs[jj][m] - Ap;
+            rmax = nmax(rmax, fabs(r));
+            if (m < 2) s0 = (kk == 0 && jj == 0 && m == 0) ? r : s0 + r;
+            else       s1 = (kk == 0 && jj == 0 && m == 2) ? r : s1 + r;
+          }
+        }
+      }
+    }
+    if (act) {
+      const long cc = cidx(C, ih, J, K);
+      *reinterpret_cast<double2 *>(C.rh + cc) = make_double2(s0 * 0.125, s1 * 0.125);
+      *reinterpret_cast<double2 *>(C.phi + cc) = make_double2(0.0, 0.0);
+    }
+  }
+  if (nrm) block_atomic_max(nrm, rmax);
+}
+// (measured and rejected: one coarse cell per thread -- unit-stride 8-byte loads, half the registers, twice the waves: MAC solve 10.02 -> 10.18 ms per step)
 // the same pairing for the stored-coefficient pass (viscous / diffusive solves, the 128^3 level of the MAC solve, level 0 of the
 // composite solves): the face coefficients of the two cells come from nine aligned pairs (bx: rows j, j+1; by: rows j, j+1, j+2;
 // bz: planes k, k+1 of both rows), the x+ coefficient of the odd cell from the next lane.  cc_apply's expressions, same order.
@@ -224,9 +372,9 @@ DEVI void cc_apply_vals(const CLev &L, const double p[7], const double b[6], dou
   diag = (b[1] + b[0]) * L.hi2[0] + (b[3] + b[2]) * L.hi2[1] + (b[5] + b[4]) * L.hi2[2];
   if (has_alpha) { Ap = Ap + a0 * p0; diag = diag + a0; }
 }
-__global__ void __launch_bounds__(256) kk_cc_gsrb_pair(CLev L, int color, int interior_only) {
+__global__ void __launch_bounds__(256) kk_cc_gsrb_pair(CLev L, int color, int interior_only, int kdown) {
   int bx, by, bz; xcd_block(bx, by, bz);
-  const int lane = threadIdx.x, k = bz;
+  const int lane = threadIdx.x, k = kdown ? L.n[2] - 1 - bz : bz;
   const int t = bx * 64 + lane, jA = 2 * (by * 4 + (int)threadIdx.y);
   const bool act = 2 * t + 1 < L.n[0] && jA + 1 < L.n[1];
   const int par = (jA + k + color) & 1;                              // uniform over the wave
@@ -270,14 +418,16 @@ static inline void launch_gsrb_shell(const CLev &L, int color, hipStream_t st, i
   if (L.rho) hipLaunchKernelGGL(kk_cc_gsrb_shell<true>, g, dim3(64, 4, 1), 0, st, L, color, hm);
   else hipLaunchKernelGGL(kk_cc_gsrb_shell<false>, g, dim3(64, 4, 1), 0, st, L, color, hm);
 }
+static bool mac_kflip() { static const bool b = !(vdn_env("VDN_MAC_KFLIP") && atoi(vdn_env("VDN_MAC_KFLIP")) == 0); return b; }
 static inline void launch_gsrb(const CLev &L, int color, hipStream_t st, int interior_only = 0) {
   const dim3 blk(64, 4, 1), g((unsigned)(((L.n[0] + 1) / 2 + 63) / 64), (unsigned)((L.n[1] + 3) / 4), (unsigned)L.n[2]);
   static const bool paired = !(vdn_env("VDN_GSRB_PAIR") && atoi(vdn_env("VDN_GSRB_PAIR")) == 0);
+  const int kdown = (mac_kflip() && (color & 1)) ? 1 : 0;
   if (L.rho && paired && L.n[0] % 2 == 0 && L.n[1] % 2 == 0 && L.n[0] >= 128)
-    hipLaunchKernelGGL(kk_cc_gsrb_rho_pair, dim3((unsigned)((L.n[0] / 2 + 63) / 64), (unsigned)((L.n[1] / 2 + 3) / 4), (unsigned)L.n[2]), blk, 0, st, L, color, interior_only);
+    hipLaunchKernelGGL(kk_cc_gsrb_rho_pair, dim3((unsigned)((L.n[0] / 2 + 63) / 64), (unsigned)((L.n[1] / 2 + 3) / 4), (unsigned)L.n[2]), blk, 0, st, L, color, interior_only, kdown);
   else if (L.rho) hipLaunchKernelGGL(kk_cc_gsrb_rho, g, blk, 0, st, L, color, interior_only);
   else if (paired && L.n[0] % 2 == 0 && L.n[1] % 2 == 0 && L.n[0] >= 128)
-    hipLaunchKernelGGL(kk_cc_gsrb_pair, dim3((unsigned)((L.n[0] / 2 + 63) / 64), (unsigned)((L.n[1] / 2 + 3) / 4), (unsigned)L.n[2]), blk, 0, st, L, color, interior_only);
+    hipLaunchKernelGGL(kk_cc_gsrb_pair, dim3((unsigned)((L.n[0] / 2 + 63) / 64), (unsigned)((L.n[1] / 2 + 3) / 4), (unsigned)L.n[2]), blk, 0, st, L, color, interior_only, kdown);
   else hipLaunchKernelGGL(kk_cc_gsrb, g, blk, 0, st, L, color, interior_only);
 }
 
@@ -906,7 +1056,8 @@ __global__ void kk_cc_prolong_lin(CLev F, CLev C, ProlongLinArgs A) {
 // ---- host side ------------------------------------------------------------------------------------------
 struct CBox { CLev L; int lo[3]; int gidx; int hmask = 63; /* faces whose ghost cells come from the halo exchange */ };                    // one local box on one distributed level; lo = global index of its cell 0
 struct CDLev { std::vector<CBox> boxes; XPlan *halo = nullptr; int ng[3]; /* global extents of the level */ bool single_box = false;
-               bool res_restricted = false; /* the last residual pass already restricted into the next level */ };
+               bool res_restricted = false; /* the last residual pass already restricted into the next level */
+               bool split = false; CSplit sp; /* macproject's finest level in one box: phi, rhs, rho by colour (cc_split_setup); phi of the level array is stale between cc_to_split / cc_from_split */ };
 struct CCMG {
   std::vector<CDLev> dlev;          // distributed levels (finest first)
   std::vector<CLev> tail;           // agglomerated levels, whole domain, replicated on every rank
@@ -920,6 +1071,50 @@ struct CCMG {
 
 static dim3 g3(int nx, int ny, int nz, dim3 b) { return dim3((nx + b.x - 1) / b.x, (ny + b.y - 1) / b.y, nz); }
 static const dim3 BLK(64, 4, 1);
+
+// ---- macproject's finest level by colour (kk_cc_gsrb_rho_split): host side --------------------------------------------------------------------
+// The level array keeps rhs and rho (level 1's coefficients, the nested iteration and the residual read them there); phi lives in the split arrays
+// from cc_to_split (after the nested iteration) to cc_from_split (before the residual pass, which reads the level array, and at the end of the solve).
+static bool mac_split_on() { static const bool b = !(vdn_env("VDN_MAC_SPLIT") && atoi(vdn_env("VDN_MAC_SPLIT")) == 0); return b; }
+template <int ADD> static inline void launch_gsrb_split(const CDLev &DL, int color, hipStream_t st, const CLev &C) {
+  const CLev &L = DL.boxes[0].L;
+  const dim3 g((unsigned)((L.n[0] / 4 + 63) / 64), (unsigned)((L.n[1] + 7) / 8), (unsigned)L.n[2]);
+  // the second colour walks the planes downwards: what the first colour's pass touched last is what it reads first (Infinity Cache; VDN_MAC_KFLIP=0: both upwards)
+  static const bool kflip = !(vdn_env("VDN_MAC_KFLIP") && atoi(vdn_env("VDN_MAC_KFLIP")) == 0);
+  hipLaunchKernelGGL(kk_cc_gsrb_rho_split<ADD>, g, dim3(64, 8, 1), 0, st, L, DL.sp, color, C, (kflip && color) ? 1 : 0);
+}
+static void cc_to_split(const CDLev &DL, int what) {
+  const CLev &L = DL.boxes[0].L;
+  const dim3 g((unsigned)((DL.sp.PXH + 63) / 64), (unsigned)((L.n[1] + 2 + 3) / 4), (unsigned)(L.n[2] + 2));
+  hipLaunchKernelGGL(kk_cc_to_split, g, BLK, 0, ctx().stream, L, DL.sp, what);
+}
+static void cc_from_split(const CDLev &DL) {
+  const CLev &L = DL.boxes[0].L;
+  hipLaunchKernelGGL(kk_cc_from_split, g3(L.n[0] / 2, L.n[1], L.n[2], BLK), BLK, 0, ctx().stream, L, DL.sp);
+}
+// one box that is the whole domain, no periodic face, the density form, the extents the paired kernels take, the default launch forms
+static bool cc_split_ok(const CCMG &M) {
+  static const bool dflt = !(vdn_env("VDN_GSRB_PAIR") && atoi(vdn_env("VDN_GSRB_PAIR")) == 0) && !(vdn_env("VDN_MG_RESTRICT_FUSED") && atoi(vdn_env("VDN_MG_RESTRICT_FUSED")) == 0) &&
+                           !(vdn_env("VDN_MG_PROLONG_FUSED") && atoi(vdn_env("VDN_MG_PROLONG_FUSED")) == 0);
+  if (!mac_split_on() || !dflt || M.dlev.size() < 2 || ctx().prm.mg_nu2 < 1 || M.per[0] || M.per[1] || M.per[2]) return false;
+  const CDLev &D0 = M.dlev[0];
+  if (!(D0.single_box && D0.boxes.size() == 1 && !D0.halo && M.dlev[1].boxes.size() == 1)) return false;
+  const CLev &L = D0.boxes[0].L;
+  for (int d = 0; d < 3; d++) if (D0.boxes[0].lo[d] != 0) return false;
+  // (128^3 stays interleaved: its arrays live in the caches, the conversions cost more than the passes gain -- 6.98 against 7.21 ms per step)
+  static const long nmin = vdn_env("VDN_MAC_SPLIT_MIN") ? atol(vdn_env("VDN_MAC_SPLIT_MIN")) : (1L << 23);
+  return L.rho && L.n[0] % 4 == 0 && L.n[1] % 2 == 0 && L.n[2] % 2 == 0 && L.n[0] >= 128 && (long)L.n[0] * L.n[1] * L.n[2] >= nmin;
+}
+static void cc_split_setup(CCMG &M) {
+  CDLev &D0 = M.dlev[0];
+  const CLev &L = D0.boxes[0].L;
+  CSplit &S = D0.sp;
+  S.PXH = ((L.n[0] / 2 + 10 + 7) / 8) * 8; S.sy = S.PXH; S.sz = (long)S.PXH * (L.n[1] + 2); S.tot = S.sz * (L.n[2] + 2);
+  double *base = (double *)arena_alloc(sizeof(double) * S.tot * 6);
+  for (int c = 0; c < 2; c++) { S.phi[c] = base + c * S.tot; S.rh[c] = base + (2 + c) * S.tot; S.rho[c] = base + (4 + c) * S.tot; }
+  D0.split = true;
+  cc_to_split(D0, 2 | 4);
+}
 
 static CLev cc_alloc_lev(const int n[3], const double h[3], bool has_alpha) {
   CLev L;
@@ -1083,6 +1278,10 @@ static void cc_gsrb_d(CCMG &M, CDLev &DL, int nsweeps) {
     if (cells < ov_min && ov_env != 1) overlap = false;
   }
   VdnCtx &c = ctx();
+  if (DL.split) {
+    for (int s = 0; s < nsweeps; s++) for (int color = 0; color < 2; color++) launch_gsrb_split<0>(DL, color, c.stream, DL.boxes[0].L);
+    return;
+  }
   for (int s = 0; s < nsweeps; s++) for (int color = 0; color < 2; color++) {
     if (!overlap) {
       cc_halo(M, DL);
@@ -1102,6 +1301,18 @@ static void cc_residual_d(CCMG &M, CDLev &DL, bool norm, bool reduce = true) {  
   cc_halo(M, DL);
   if (norm) HIPCHK(hipMemsetAsync(M.d_nrm, 0, sizeof(double), ctx().stream));
   DL.res_restricted = false;
+  if (DL.split) {
+    static const bool split_res = !(vdn_env("VDN_MAC_SPLIT") && atoi(vdn_env("VDN_MAC_SPLIT")) == 2);      // 2: only the colour passes run on the split arrays
+    if (split_res) {
+      const CLev &L = DL.boxes[0].L;
+      const dim3 g((unsigned)((L.n[0] / 4 + 63) / 64), (unsigned)((L.n[1] / 2 + 3) / 4), (unsigned)std::min(L.n[2] / 2, 16));
+      hipLaunchKernelGGL(kk_cc_residual_rho_split_rst, g, BLK, 0, ctx().stream, L, DL.sp, norm ? M.d_nrm : nullptr, M.dlev[1].boxes[0].L);
+      DL.res_restricted = true;
+      if (norm && reduce) comm_allreduce_max_dev(M.d_nrm, 1);
+      return;
+    }
+    cc_from_split(DL);
+  }
   {   // the finest level of a MAC solve in one box: residual and restriction in one pass (kk_cc_residual_rho_pair_rst); cc_restrict_down then skips
     static const bool fuse = !(vdn_env("VDN_MG_RESTRICT_FUSED") && atoi(vdn_env("VDN_MG_RESTRICT_FUSED")) == 0);
     static const bool paired0 = !(vdn_env("VDN_GSRB_PAIR") && atoi(vdn_env("VDN_GSRB_PAIR")) == 0);
@@ -1232,6 +1443,13 @@ static void cc_prolong_up(CCMG &M, int l) {
 // faces (the paired density pass) the correction is added inside the first sweep (kk_cc_gsrb_rho_pair_t); otherwise kk_cc_prolong first.
 static void cc_prolong_smooth(CCMG &M, int l, int nsweeps) {
   CDLev &DL = M.dlev[l];
+  if (DL.split) {
+    const CLev &C = M.dlev[l + 1].boxes[0].L;
+    launch_gsrb_split<1>(DL, 0, ctx().stream, C);
+    launch_gsrb_split<2>(DL, 1, ctx().stream, C);
+    if (nsweeps > 1) cc_gsrb_d(M, DL, nsweeps - 1);
+    return;
+  }
   static const bool fuse = !(vdn_env("VDN_MG_PROLONG_FUSED") && atoi(vdn_env("VDN_MG_PROLONG_FUSED")) == 0);
   static const bool paired = !(vdn_env("VDN_GSRB_PAIR") && atoi(vdn_env("VDN_GSRB_PAIR")) == 0);
   const bool ok = fuse && paired && nsweeps >= 1 && DL.single_box && DL.boxes.size() == 1 && !DL.halo && l + 1 < (int)M.dlev.size() && M.dlev[l + 1].boxes.size() == 1 &&
@@ -1240,8 +1458,8 @@ static void cc_prolong_smooth(CCMG &M, int l, int nsweeps) {
   if (!ok) { cc_prolong_up(M, l); cc_gsrb_d(M, DL, nsweeps); return; }
   const CLev &L = DL.boxes[0].L, &C = M.dlev[l + 1].boxes[0].L;
   const dim3 g((unsigned)((L.n[0] / 2 + 63) / 64), (unsigned)((L.n[1] / 2 + 3) / 4), (unsigned)L.n[2]), blk(64, 4, 1);
-  hipLaunchKernelGGL(kk_cc_gsrb_rho_pair_t<1>, g, blk, 0, ctx().stream, L, 0, 0, C);
-  hipLaunchKernelGGL(kk_cc_gsrb_rho_pair_t<2>, g, blk, 0, ctx().stream, L, 1, 0, C);
+  hipLaunchKernelGGL(kk_cc_gsrb_rho_pair_t<1>, g, blk, 0, ctx().stream, L, 0, 0, C, 0);
+  hipLaunchKernelGGL(kk_cc_gsrb_rho_pair_t<2>, g, blk, 0, ctx().stream, L, 1, 0, C, mac_kflip() ? 1 : 0);
   if (nsweeps > 1) cc_gsrb_d(M, DL, nsweeps - 1);
 }
 // may level l >= 1 of a V-cycle run as kk_cc_lds_down / kk_cc_lds_up?  (VDN_MG_LDS=0: never; VDN_MG_LDS_MAX: largest extent taken, default 64)
@@ -1389,6 +1607,7 @@ static unsigned long long cc_graph_key(const CCMG &M, int what) {
   k.put(M.sendbuf); k.put(M.recvbuf); k.put(M.d_gb_rh); k.put(M.d_gb_b); k.put(M.cnt_rh); k.put(M.cnt_b);
   for (const CDLev &DL : M.dlev) {
     k.put(xplan_serial(DL.halo)); k.put(DL.ng); k.put(DL.single_box); k.put(DL.res_restricted);
+    k.put(DL.split); if (DL.split) { k.put(DL.sp.PXH); k.put(DL.sp.phi); k.put(DL.sp.rh); k.put(DL.sp.rho); }
     for (const CBox &B : DL.boxes) { cc_key_lev(k, B.L); k.put(B.lo); }
   }
   for (const CLev &L : M.tail) cc_key_lev(k, L);
@@ -1574,7 +1793,7 @@ int cc_solve(vdn_multifab *rh, vdn_multifab *phi, vdn_multifab **beta, const dou
   CCMG M_local;
   CCMG &M = keep ? keep->M : M_local;
   double bnorm_fast = 0.0;
-  if (fast) bnorm_fast = cc_setup_fast(M, fast, dx, bc);
+  if (fast) { bnorm_fast = cc_setup_fast(M, fast, dx, bc); if (cc_split_ok(M)) cc_split_setup(M); }
   else if (keep && keep->built) cc_reload(M, rh, phi, bc, zero_guess);
   else cc_setup(M, rh, phi, alpha, beta, dx, bc, rho);
   if (keep) keep->built = true;
@@ -1605,6 +1824,7 @@ int cc_solve(vdn_multifab *rh, vdn_multifab *phi, vdn_multifab **beta, const dou
   // replayed graph and one 8-byte read-back -- the same launch sequence as testing the residual the cycle computes after pre-smoothing
   const int nbot = std::max(P.mg_nub, std::max(D0.ng[0], std::max(D0.ng[1], D0.ng[2])) * std::max(D0.ng[0], std::max(D0.ng[1], D0.ng[2])));
   if (fmg && !conv && !single && bnorm < HUGE_VAL) cc_run_cycle(M, cc_fmg_what(bc), [&] { cc_fmg(M, bc); });
+  if (D0.split) cc_to_split(D0, 1);
   // vdn_params.mg_predict (macproject's call: zero guess): see nd_solve in mg_nd.hip -- the norms of the cycles before the one the previous solve of this
   // size stopped at, minus one, go into the device-side history and are read in one go; a history that shows an earlier stop repeats the solve
   const int gn[3] = { D0.ng[0], D0.ng[1], D0.ng[2] };
@@ -1654,6 +1874,7 @@ int cc_solve(vdn_multifab *rh, vdn_multifab *phi, vdn_multifab **beta, const dou
   }
   if (fast) {
     CDLev &DF = M.dlev[0];
+    if (DF.split) cc_from_split(DF);
     cc_halo(M, DF);
     fast->phi_view.clear();
     for (size_t b = 0; b < DF.boxes.size(); b++) fast->phi_view.push_back(cc_phi_view(DF.boxes[b].L, fast->rho->vbox[b].lo));
@@ -1680,11 +1901,12 @@ void cc_bench_smoother(vdn_multifab *rh, vdn_multifab *phi, vdn_multifab **beta,
   const CLev &L = M.dlev[0].boxes[0].L;
   hipStream_t st = ctx().stream;
   hipEvent_t e0, e1; HIPCHK(hipEventCreate(&e0)); HIPCHK(hipEventCreate(&e1));
-  CLev &Lm = M.dlev[0].boxes[0].L;
-  (void)Lm;
-  for (int w = 0; w < 4; w++) launch_gsrb(L, w & 1, st);
+  CDLev &D0 = M.dlev[0];
+  if (cc_split_ok(M)) { cc_split_setup(M); cc_to_split(D0, 1); }            // the form macproject's solve runs (VDN_MAC_SPLIT=0: the interleaved pass)
+  auto pass = [&](int w) { if (D0.split) launch_gsrb_split<0>(D0, w & 1, st, L); else launch_gsrb(L, w & 1, st); };
+  for (int w = 0; w < 4; w++) pass(w);
   HIPCHK(hipEventRecord(e0, st));
-  for (int w = 0; w < nlaunch; w++) launch_gsrb(L, w & 1, st);
+  for (int w = 0; w < nlaunch; w++) pass(w);
   HIPCHK(hipEventRecord(e1, st));
   HIPCHK(hipEventSynchronize(e1));
   float ms = 0; HIPCHK(hipEventElapsedTime(&ms, e0, e1));

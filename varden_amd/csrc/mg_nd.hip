@@ -216,7 +216,7 @@ __device__ int g_nd_dbg = 0;      // VDN_ND_DBG (probe only): 1 = no stencil ari
 // as before -- the DPP shifts cross segment borders only into those two lanes) carries one row, a wave 64 >> lw rows, a workgroup four
 // times that.  Main tiles and remainder tiles are workgroups of ONE launch (1-D grid: main tiles first, in the XCD-aware order).
 // (ii) The k-slabs are balanced (sizes differ by at most one plane): 257 planes in 16 slabs of 17 left a last slab of two planes.
-struct NdPairGrid { int gxm, gy, gz, nmain, lwr, gyr; };       // main tiles gxm x gy x gz (lw = 6), then gyr x gz remainder tiles of segment 2^lwr
+struct NdPairGrid { int gxm, gy, gz, nmain, lwr, gyr, rev; };       // main tiles gxm x gy x gz (lw = 6), then gyr x gz remainder tiles of segment 2^lwr
 // (round 3, measured and rejected at 257^3: sigma and rhs loaded with the non-temporal hint 0.1392 -> 0.1420 ms; the kernel held to 128 VGPRs
 // -- four waves per SIMD, 116 bytes of scratch per lane -- 0.341 ms)
 template <int MODE, int ROWS>
@@ -226,10 +226,11 @@ __global__ void __launch_bounds__(64 * ROWS) kk_nd_march_pair(NLev L, const doub
   int lw, pair0, j, bz;
   if (id < G.nmain) {                                                     // xcd_tile's order over the main tiles
     const int q = G.nmain >> 3, r = G.nmain & 7, x = id & 7, slot = id >> 3;
-    const int t = (x < r) ? x * (q + 1) + slot : r * (q + 1) + (x - r) * q + slot;
+    int t = (x < r) ? x * (q + 1) + slot : r * (q + 1) + (x - r) * q + slot;
+    if (G.rev) t = G.nmain - 1 - t;                                       // every other march of a level walks the tiles backwards (nd_pair_grid)
     lw = 6; pair0 = (t % G.gxm) * 62; j = ((t / G.gxm) % G.gy) * ROWS + (int)threadIdx.y; bz = t / (G.gxm * G.gy);
   } else {
-    const int t = id - G.nmain;
+    const int t = G.rev ? G.gyr * G.gz - 1 - (id - G.nmain) : id - G.nmain;
     lw = G.lwr; pair0 = G.gxm * 62; j = (((t % G.gyr) * ROWS + (int)threadIdx.y) << (6 - lw)) + (lane >> lw); bz = t / G.gyr;
   }
   const int seg = 1 << lw, sl = lane & (seg - 1);
@@ -347,10 +348,11 @@ __global__ void __launch_bounds__(64 * ROWS) kk_nd_march_pair_rst(NLev L, const 
   int lw, pair0, j, bz;
   if (id < G.nmain) {
     const int q = G.nmain >> 3, r = G.nmain & 7, x = id & 7, slot = id >> 3;
-    const int t = (x < r) ? x * (q + 1) + slot : r * (q + 1) + (x - r) * q + slot;
+    int t = (x < r) ? x * (q + 1) + slot : r * (q + 1) + (x - r) * q + slot;
+    if (G.rev) t = G.nmain - 1 - t;                                       // every other march of a level walks the tiles backwards (nd_pair_grid)
     lw = 6; pair0 = (t % G.gxm) * 62; j = ((t / G.gxm) % G.gy) * ROWS + (int)threadIdx.y; bz = t / (G.gxm * G.gy);
   } else {
-    const int t = id - G.nmain;
+    const int t = G.rev ? G.gyr * G.gz - 1 - (id - G.nmain) : id - G.nmain;
     lw = G.lwr; pair0 = G.gxm * 62; j = (((t % G.gyr) * ROWS + (int)threadIdx.y) << (6 - lw)) + (lane >> lw); bz = t / G.gyr;
   }
   const int seg = 1 << lw, sl = lane & (seg - 1);
@@ -954,11 +956,14 @@ static NdPairGrid nd_pair_grid(const NLev &L, int rows, int nzu, bool use_rem, i
   if (kc_env > 0) kc = std::min(kc_env, nzu);
   G.gz = std::max(1, (nzu + kc - 1) / kc);      // balanced slabs of at most kc planes (257 planes: 16 slabs of 16 or 17 -- measured 0.1396 ms against 0.1443 with 15 slabs)
   G.nmain = G.gxm * G.gy * G.gz;
+  G.rev = 0;
   return G;
 }
 // slab thickness: enough workgroups to fill 256 CUs several times over, yet long enough marches to amortise the
 // two warm-up planes (overhead 2/kchunk)
-template <int MODE> static void nd_launch_march(const NLev &L, const double *phi, double *out, double *nrm, int shell_later = 0) {
+// rev: the tiles in reverse order.  Consecutive marches of a level alternate (NDLev::rev): a sweep reads what the previous one wrote and the same sigma and
+// right-hand side, and the planes that one touched last are the ones still in the 256 MB Infinity Cache (same bits: a Jacobi sweep has no order)
+template <int MODE> static void nd_launch_march(const NLev &L, const double *phi, double *out, double *nrm, int shell_later = 0, int rev = 0) {
   const int nzp = L.n[2] + 1;
   const int tiles = ((L.n[0] + 62) / 62) * ((L.n[1] + 4) / 4);
   int kchunk = nzp;
@@ -970,7 +975,9 @@ template <int MODE> static void nd_launch_march(const NLev &L, const double *phi
     static const bool use_rem = !(vdn_env("VDN_ND_REM") && atoi(vdn_env("VDN_ND_REM")) == 0);
     static const int minwg = vdn_env("VDN_ND_MINWG") ? atoi(vdn_env("VDN_ND_MINWG")) : 2048;
     static const int kc_env = vdn_env("VDN_ND_KC") ? atoi(vdn_env("VDN_ND_KC")) : 0;
-    const NdPairGrid G = nd_pair_grid(L, rows, nzp, use_rem, minwg, kc_env);
+    NdPairGrid G = nd_pair_grid(L, rows, nzp, use_rem, minwg, kc_env);
+    static const bool flip = !(vdn_env("VDN_ND_REV") && atoi(vdn_env("VDN_ND_REV")) == 0);
+    G.rev = flip ? rev : 0;
     hipLaunchKernelGGL((kk_nd_march_pair<MODE, 4>), dim3(G.nmain + G.gyr * G.gz), NBLK, 0, ctx().stream, L, phi, out, nd_cur_omega(), G, nrm, shell_later);
     return;
   }
@@ -979,6 +986,7 @@ template <int MODE> static void nd_launch_march(const NLev &L, const double *phi
 
 struct NBox { NLev L; int lo[3]; int hmask = 63; XPlan *hA = nullptr, *hB = nullptr; double *A = nullptr, *B = nullptr; };
 struct NDLev { std::vector<NBox> boxes; XPlan *halo_A = nullptr, *halo_B = nullptr, *halo_res = nullptr, *halo_sig = nullptr; int ng[3]; bool flip = false; bool single_box = false; int per[3] = {0, 0, 0};
+               int rev = 0; /* tile order of the next march (nd_launch_march) */
                bool res_restricted = false; /* the last residual pass left the x- and z-sums of the full weighting in res (kk_nd_march_pair_rst): nd_restrict_down finishes along y */ };
 struct NDMG {
   std::vector<NDLev> dlev; std::vector<NLev> tail; int per[3]; double *d_nrm;
@@ -1188,7 +1196,8 @@ static void nd_jacobi_d(NDLev &DL, int nsweeps, bool pre = false) {
   for (int s = 0; s < nsweeps; s++) {
     g_nd_omega_now = om.at(s);
     const bool ov = nd_halo_begin(DL);
-    for (NBox &B : DL.boxes) nd_launch_march<0>(B.L, B.L.phi, B.L.tmp, nullptr);
+    for (NBox &B : DL.boxes) nd_launch_march<0>(B.L, B.L.phi, B.L.tmp, nullptr, 0, DL.rev);
+    DL.rev ^= 1;
     if (ov) {
       nd_halo_end();
       for (NBox &B : DL.boxes) nd_launch_shell<0>(B.L, B.L.phi, B.L.tmp, nullptr, B.hmask);
@@ -1208,7 +1217,9 @@ static void nd_residual_d(NDMG &M, NDLev &DL, bool norm, bool reduce = true) {  
       const NLev &L = DL.boxes[0].L;
       if (L.n[0] >= 127 && L.n[0] % 2 == 0 && L.n[1] % 2 == 0 && L.n[2] % 2 == 0) {
         nd_halo_phi(DL);                                                  // (no neighbour, no image: nothing to exchange; kept for symmetry with the plain path)
-        const NdPairGrid G = nd_pair_grid(L, 4, L.n[2] / 2 + 1, true, 2048, 0);
+        NdPairGrid G = nd_pair_grid(L, 4, L.n[2] / 2 + 1, true, 2048, 0);
+        static const bool flip = !(vdn_env("VDN_ND_REV") && atoi(vdn_env("VDN_ND_REV")) == 0);
+        G.rev = flip ? DL.rev : 0; DL.rev ^= 1;
         hipLaunchKernelGGL((kk_nd_march_pair_rst<4>), dim3(G.nmain + G.gyr * G.gz), NBLK, 0, ctx().stream, L, (const double *)L.phi, L.res, G, norm ? M.d_nrm : nullptr);
         DL.res_restricted = true;
         if (norm && reduce) comm_allreduce_max_dev(M.d_nrm, 1);
@@ -1218,7 +1229,8 @@ static void nd_residual_d(NDMG &M, NDLev &DL, bool norm, bool reduce = true) {  
   }
   const bool ov = nd_halo_begin(DL);
   for (NBox &B : DL.boxes)
-    nd_launch_march<1>(B.L, B.L.phi, B.L.res, norm ? M.d_nrm : nullptr, ov ? B.hmask : 0);
+    nd_launch_march<1>(B.L, B.L.phi, B.L.res, norm ? M.d_nrm : nullptr, ov ? B.hmask : 0, DL.rev);
+  DL.rev ^= 1;
   if (ov) {
     nd_halo_end();
     for (NBox &B : DL.boxes) nd_launch_shell<1>(B.L, B.L.phi, B.L.res, norm ? M.d_nrm : nullptr, B.hmask);

@@ -142,6 +142,10 @@ static const EnvSwitch g_switches[] = {
   { "VDN_MK_SPLIT", "components per launch of the unfused mkflux marches (-1: by register budget)" },
   { "VDN_GOD_UPDATE", "0: update_3d as its own pass instead of inside the fused mkflux march" },
   { "VDN_GSRB_PAIR", "0: one cell per thread in the colour passes / residuals of wide levels instead of the 2 x 2 pair form" },
+  { "VDN_MAC_SPLIT", "0: the finest level of macproject's one-box solve stays interleaved (kk_cc_gsrb_rho_pair) instead of stored by colour (kk_cc_gsrb_rho_split); 2: only the colour passes on the split arrays, the residual on the level array" },
+  { "VDN_MAC_SPLIT_MIN", "fewest cells of a level stored by colour (default 2^23)" },
+  { "VDN_ND_REV", "0: every march of a nodal level walks its tiles in the same order (default: consecutive marches alternate)" },
+  { "VDN_MAC_KFLIP", "0: both colour passes of a sweep walk the planes upwards (default: the second colour downwards; paired and split passes of the cell-centred multigrid)" },
   { "VDN_CC_HALO_FACES", "0: the cell-centred multigrid exchanges the whole ghost shell instead of the faces only" },
   { "VDN_MG_AGGLOM", "several boxes: smallest box extent (cells) of a multigrid level that stays distributed; below it the level is gathered and relaxed on every rank (default 64)" },
   { "VDN_OVERLAP", "halo exchange of multigrid passes next to interior work: 1 always, 0 never, default: when a plan has a remote peer and the box is large" },
