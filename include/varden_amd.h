@@ -277,6 +277,9 @@ int vdn_make_magvel(vdn_multifab *magvel, int comp, vdn_multifab *u);
 int  vdn_last_step_timing(double *sec5);
 /* diagnostics of the last MAC / HG solves: cycles, initial and final residual norms             */
 int  vdn_last_solver_stats(int which /*0=MAC,1=HG*/, int *cycles, double *res0, double *res);
+/* how the last macproject solve on one box kept its finest level: 0 interleaved (the level array), 1 by colour (passes and residual on the
+ * split arrays), 2 by colour for the passes only (VDN_MAC_SPLIT=2).  No reference counterpart: the tests use it to know which kernels they exercised. */
+int  vdn_last_mac_level_form(void);
 
 /* ------------------------------------------------------------------------------------------- */
 /* unit-test hooks: one per reference kernel, single-level, all local boxes.                    */

@@ -122,6 +122,7 @@ SIGNATURES = {
     "vdn_make_new_grids": (C.c_int, [_VP, C.c_int, C.c_int, C.c_int, C.c_double, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(Box), _PI, C.POINTER(C.c_long)]),
     "vdn_last_step_timing": (C.c_int, [_PD]),
     "vdn_last_solver_stats": (C.c_int, [C.c_int, _PI, _PD, _PD]),
+    "vdn_last_mac_level_form": (C.c_int, []),
     "vdn_k_slope": (C.c_int, [_VP, _VP, C.c_int, C.c_int, _VP]),
     "vdn_k_velpred": (C.c_int, [_VP, _PVP, _VP, _PD, C.c_double, _VP]),
     "vdn_k_mkflux": (C.c_int, [_VP, _PVP, _PVP, _PVP, _VP, _VP, _PD, C.c_double, _VP, C.c_int, _PI]),

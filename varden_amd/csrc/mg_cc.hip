@@ -1105,6 +1105,8 @@ static bool cc_split_ok(const CCMG &M) {
   static const long nmin = vdn_env("VDN_MAC_SPLIT_MIN") ? atol(vdn_env("VDN_MAC_SPLIT_MIN")) : (1L << 23);
   return L.rho && L.n[0] % 4 == 0 && L.n[1] % 2 == 0 && L.n[2] % 2 == 0 && L.n[0] >= 128 && (long)L.n[0] * L.n[1] * L.n[2] >= nmin;
 }
+static int g_mac_level_form = 0;
+extern "C" int vdn_last_mac_level_form(void) { return g_mac_level_form; }
 static void cc_split_setup(CCMG &M) {
   CDLev &D0 = M.dlev[0];
   const CLev &L = D0.boxes[0].L;
@@ -1793,7 +1795,11 @@ int cc_solve(vdn_multifab *rh, vdn_multifab *phi, vdn_multifab **beta, const dou
   CCMG M_local;
   CCMG &M = keep ? keep->M : M_local;
   double bnorm_fast = 0.0;
-  if (fast) { bnorm_fast = cc_setup_fast(M, fast, dx, bc); if (cc_split_ok(M)) cc_split_setup(M); }
+  if (fast) {
+    bnorm_fast = cc_setup_fast(M, fast, dx, bc);
+    if (cc_split_ok(M)) cc_split_setup(M);
+    g_mac_level_form = !M.dlev[0].split ? 0 : (vdn_env("VDN_MAC_SPLIT") && atoi(vdn_env("VDN_MAC_SPLIT")) == 2) ? 2 : 1;
+  }
   else if (keep && keep->built) cc_reload(M, rh, phi, bc, zero_guess);
   else cc_setup(M, rh, phi, alpha, beta, dx, bc, rho);
   if (keep) keep->built = true;
