@@ -113,14 +113,15 @@ def test_macproject(gpu, oracle, bcname):
 def test_split_colour_level_matches_the_oracle_and_the_interleaved_level(gpu, oracle, bcname):
     """round 5: macproject's one-box solve keeps its finest level BY COLOUR from 2^23 cells up (kk_cc_gsrb_rho_split, kk_cc_residual_rho_split_rst; the
     256^3 tests run it).  Here on 132 x 36 x 40 cells (VDN_MAC_SPLIT_MIN=0; 33 lane pairs: the clamped tail of a wave, one-sided y / z extents): the
-    projected velocities against the oracle's in the worker, and the same bits (a) split with the second colour walking the planes downwards,
+    projected velocities against the oracle's in the worker, and the same bits (a) split, the passes and the residual time-skewed over slabs of 7 planes
+    (cc_split_run; 40 planes: six slabs, the last a sliver), the second colour walking its planes downwards,
     (b) split passes only, residual on the level array, both colours upwards, (c) interleaved.  tests/_split_worker.py."""
     import os, subprocess, sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     out, form = [], []
-    for extra in ({"VDN_MAC_SPLIT_MIN": "0"}, {"VDN_MAC_SPLIT_MIN": "0", "VDN_MAC_SPLIT": "2", "VDN_MAC_KFLIP": "0"}, {"VDN_MAC_SPLIT": "0"}):
+    for extra in ({"VDN_MAC_SPLIT_MIN": "0", "VDN_MAC_SLAB": "7"}, {"VDN_MAC_SPLIT_MIN": "0", "VDN_MAC_SPLIT": "2", "VDN_MAC_KFLIP": "0"}, {"VDN_MAC_SPLIT": "0"}):
         env = dict(os.environ)
-        for k in ("VDN_MAC_SPLIT", "VDN_MAC_SPLIT_MIN", "VDN_MAC_KFLIP"):
+        for k in ("VDN_MAC_SPLIT", "VDN_MAC_SPLIT_MIN", "VDN_MAC_KFLIP", "VDN_MAC_SLAB"):
             env.pop(k, None)
         env.update(extra)
         r = subprocess.run([sys.executable, os.path.join(root, "tests", "_split_worker.py"), bcname], env=env, capture_output=True, text=True, timeout=600, cwd=root)
@@ -251,14 +252,14 @@ def test_multigrid_launch_variants_agree_bit_for_bit(gpu):
             h.update(np.ascontiguousarray(m.to_numpy()).tobytes())
         print("HASH", h.hexdigest(), G.dt)
     """ % root)
-    switches = ("VDN_MG_PROLONG_FUSED", "VDN_MG_RESTRICT_FUSED", "VDN_MG_TAILCYCLE", "VDN_MG_LDS", "VDN_NO_GRAPHS", "VDN_HG_FAST", "VDN_MAC_FAST", "VDN_ND_LEAN", "VDN_NO_FORCE_REUSE", "VDN_GOD_UPDATE", "VDN_GOD_P2", "VDN_ND_RESTRICT_FUSED", "VDN_GOD_1B", "VDN_GOD_NARROW", "VDN_MAC_SPLIT", "VDN_MAC_SPLIT_MIN", "VDN_MAC_KFLIP", "VDN_ND_REV")
+    switches = ("VDN_MG_PROLONG_FUSED", "VDN_MG_RESTRICT_FUSED", "VDN_MG_TAILCYCLE", "VDN_MG_LDS", "VDN_NO_GRAPHS", "VDN_HG_FAST", "VDN_MAC_FAST", "VDN_ND_LEAN", "VDN_NO_FORCE_REUSE", "VDN_GOD_UPDATE", "VDN_GOD_P2", "VDN_ND_RESTRICT_FUSED", "VDN_GOD_1B", "VDN_GOD_NARROW", "VDN_MAC_SPLIT", "VDN_MAC_SPLIT_MIN", "VDN_MAC_KFLIP", "VDN_ND_REV", "VDN_MAC_SLAB")
     for n, visc in ((128, 0.0), (64, 0.01)):
         out = []
         # third run (round 5): the defaults with the fused mkflux + update march in its round-4 form -- three workgroup barriers per plane, the
         # remainder tile column in full 64-lane tiles -- against one barrier and narrow segments
         # round 5 also: the first two runs keep the finest MAC level by colour (VDN_MAC_SPLIT_MIN=0: from any size), the third interleaved; the second and third
-        # walk every colour pass / nodal march in the same order (VDN_MAC_KFLIP=0, VDN_ND_REV=0)
-        for extra in ({"VDN_MAC_SPLIT_MIN": "0"}, {"VDN_GOD_1B": "0", "VDN_GOD_NARROW": "0", "VDN_MAC_SPLIT_MIN": "0", "VDN_MAC_KFLIP": "0", "VDN_ND_REV": "0"},
+        # walk every colour pass / nodal march in the same order (VDN_MAC_KFLIP=0, VDN_ND_REV=0); the first in two plane slabs (cc_split_run), the second in whole-level launches
+        for extra in ({"VDN_MAC_SPLIT_MIN": "0"}, {"VDN_GOD_1B": "0", "VDN_GOD_NARROW": "0", "VDN_MAC_SPLIT_MIN": "0", "VDN_MAC_KFLIP": "0", "VDN_ND_REV": "0", "VDN_MAC_SLAB": "0"},
                       {"VDN_MAC_KFLIP": "0", "VDN_ND_REV": "0", "VDN_MAC_SPLIT": "0", "VDN_MG_PROLONG_FUSED": "0", "VDN_MG_RESTRICT_FUSED": "0", "VDN_MG_TAILCYCLE": "0", "VDN_MG_LDS": "0", "VDN_NO_GRAPHS": "1",
                           "VDN_HG_FAST": "0", "VDN_MAC_FAST": "0", "VDN_ND_LEAN": "0", "VDN_NO_FORCE_REUSE": "1", "VDN_GOD_UPDATE": "0", "VDN_GOD_P2": "0", "VDN_ND_RESTRICT_FUSED": "0"}):
             env = dict(os.environ)

@@ -245,8 +245,9 @@ __global__ void __launch_bounds__(256) kk_cc_from_split(CLev L, CSplit S) {
 }
 // a thread owns entries ih, ih + 1 of a row (A, B); a wave a row segment of 128 entries = 256 cells; 8 rows per workgroup.  ADD as in kk_cc_gsrb_rho_pair_t:
 // the parent of entry ih is coarse cell ih.
-template <int ADD> __global__ void __launch_bounds__(512) kk_cc_gsrb_rho_split(CLev L, CSplit S, int color, CLev C, int kdown) {
-  const int lane = threadIdx.x, k = kdown ? L.n[2] - 1 - (int)blockIdx.z : (int)blockIdx.z;
+// planes k0 .. k0 + gridDim.z - 1 (kdown: from the top of that range)
+template <int ADD> __global__ void __launch_bounds__(512) kk_cc_gsrb_rho_split(CLev L, CSplit S, int color, CLev C, int kdown, int k0) {
+  const int lane = threadIdx.x, k = k0 + (kdown ? (int)gridDim.z - 1 - (int)blockIdx.z : (int)blockIdx.z);
   const int t = blockIdx.x * 64 + lane, nh = L.n[0] / 2;
   const int jr = blockIdx.y * 8 + threadIdx.y, j = min(jr, L.n[1] - 1);
   const bool act = 2 * t + 1 < nh && jr < L.n[1];
@@ -317,13 +318,13 @@ DEVI void split_gather(double *const v[2], const CSplit &S, long c, int e, int l
   q[1][2][0] = E1.y; q[1][2][1] = O1.x; q[1][2][2] = O1.y; q[1][2][3] = E0.y; q[1][2][4] = Ep.y; q[1][2][5] = E1m.y; q[1][2][6] = E1p.y;
   q[1][3][0] = O1.y; q[1][3][1] = E1.y; q[1][3][2] = lane == 63 ? a1 : r1; q[1][3][3] = O0.y; q[1][3][4] = Op.y; q[1][3][5] = O1m.y; q[1][3][6] = O1p.y;
 }
-__global__ void __launch_bounds__(256) kk_cc_residual_rho_split_rst(CLev L, CSplit S, double *nrm, CLev C) {
+__global__ void __launch_bounds__(256) kk_cc_residual_rho_split_rst(CLev L, CSplit S, double *nrm, CLev C, int Ka, int Kb) {       // coarse planes Ka .. Kb - 1
   const int lane = threadIdx.x, nh = L.n[0] / 2;
   const int u = blockIdx.x * 64 + lane, Jr = blockIdx.y * 4 + threadIdx.y, J = min(Jr, L.n[1] / 2 - 1);
   const bool act = 2 * u + 1 < nh && Jr < L.n[1] / 2;
   const int ih = 2 * min(u, nh / 2);
   double rmax = 0.0;
-  for (int K = blockIdx.z; K < L.n[2] / 2; K += gridDim.z) {
+  for (int K = Ka + blockIdx.z; K < Kb; K += gridDim.z) {
     double s0 = 0.0, s1 = 0.0;
     #pragma unroll
     for (int kk = 0; kk < 2; kk++) {
@@ -1076,12 +1077,13 @@ static const dim3 BLK(64, 4, 1);
 // The level array keeps rhs and rho (level 1's coefficients, the nested iteration and the residual read them there); phi lives in the split arrays
 // from cc_to_split (after the nested iteration) to cc_from_split (before the residual pass, which reads the level array, and at the end of the solve).
 static bool mac_split_on() { static const bool b = !(vdn_env("VDN_MAC_SPLIT") && atoi(vdn_env("VDN_MAC_SPLIT")) == 0); return b; }
-template <int ADD> static inline void launch_gsrb_split(const CDLev &DL, int color, hipStream_t st, const CLev &C) {
+template <int ADD> static inline void launch_gsrb_split(const CDLev &DL, int color, hipStream_t st, const CLev &C, int k0 = 0, int k1 = -1) {
   const CLev &L = DL.boxes[0].L;
-  const dim3 g((unsigned)((L.n[0] / 4 + 63) / 64), (unsigned)((L.n[1] + 7) / 8), (unsigned)L.n[2]);
+  if (k1 < 0) k1 = L.n[2];
+  const dim3 g((unsigned)((L.n[0] / 4 + 63) / 64), (unsigned)((L.n[1] + 7) / 8), (unsigned)(k1 - k0));
   // the second colour walks the planes downwards: what the first colour's pass touched last is what it reads first (Infinity Cache; VDN_MAC_KFLIP=0: both upwards)
   static const bool kflip = !(vdn_env("VDN_MAC_KFLIP") && atoi(vdn_env("VDN_MAC_KFLIP")) == 0);
-  hipLaunchKernelGGL(kk_cc_gsrb_rho_split<ADD>, g, dim3(64, 8, 1), 0, st, L, DL.sp, color, C, (kflip && color) ? 1 : 0);
+  hipLaunchKernelGGL(kk_cc_gsrb_rho_split<ADD>, g, dim3(64, 8, 1), 0, st, L, DL.sp, color, C, (kflip && color) ? 1 : 0, k0);
 }
 static void cc_to_split(const CDLev &DL, int what) {
   const CLev &L = DL.boxes[0].L;
@@ -1308,7 +1310,7 @@ static void cc_residual_d(CCMG &M, CDLev &DL, bool norm, bool reduce = true) {  
     if (split_res) {
       const CLev &L = DL.boxes[0].L;
       const dim3 g((unsigned)((L.n[0] / 4 + 63) / 64), (unsigned)((L.n[1] / 2 + 3) / 4), (unsigned)std::min(L.n[2] / 2, 16));
-      hipLaunchKernelGGL(kk_cc_residual_rho_split_rst, g, BLK, 0, ctx().stream, L, DL.sp, norm ? M.d_nrm : nullptr, M.dlev[1].boxes[0].L);
+      hipLaunchKernelGGL(kk_cc_residual_rho_split_rst, g, BLK, 0, ctx().stream, L, DL.sp, norm ? M.d_nrm : nullptr, M.dlev[1].boxes[0].L, 0, L.n[2] / 2);
       DL.res_restricted = true;
       if (norm && reduce) comm_allreduce_max_dev(M.d_nrm, 1);
       return;
@@ -1463,6 +1465,53 @@ static void cc_prolong_smooth(CCMG &M, int l, int nsweeps) {
   hipLaunchKernelGGL(kk_cc_gsrb_rho_pair_t<1>, g, blk, 0, ctx().stream, L, 0, 0, C, 0);
   hipLaunchKernelGGL(kk_cc_gsrb_rho_pair_t<2>, g, blk, 0, ctx().stream, L, 1, 0, C, mac_kflip() ? 1 : 0);
   if (nsweeps > 1) cc_gsrb_d(M, DL, nsweeps - 1);
+}
+// The finest level's part of a cycle -- [prolongation inside the first sweep,] nsweeps red-black sweeps, residual + restriction -- on the SPLIT level in plane
+// slabs (time skewing): pass p runs on the planes pass p - 1 has left behind by at least two (plane k needs pass p - 1 done on k + 1, and must not touch
+// plane k' - 1 before pass p - 1 has read it for k'), so a slab of VDN_MAC_SLAB planes goes through ALL passes while it sits in the 256 MB Infinity
+// Cache: nine launches over the whole level read each of its six arrays nine times from HBM, the slabs read them about once.  Cells of a colour do not
+// read each other and the residual only reads: the order changes no bit.  VDN_MAC_SLAB=0: whole-level launches.
+// Measured at 256^3 (MAC solve per step): whole-level launches 10.03 ms; slabs of 32 / 48 / 64 / 96 / 128 planes 10.66 / 10.28 / 9.86 / 9.65 / 9.44 ms -- a pass
+// served from the cache takes 0.069 ms per 256 planes against 0.090 from HBM, and every launch costs its ramp and tail; the default is half the level.
+static int mac_slab(int n2) { static const int k = vdn_env("VDN_MAC_SLAB") ? atoi(vdn_env("VDN_MAC_SLAB")) : -1; return k < 0 ? (n2 + 1) / 2 : k; }
+static void cc_split_run(CCMG &M, CDLev &DL, bool prolong, int nsweeps, bool residual, bool norm, bool reduce) {
+  const CLev &L = DL.boxes[0].L, &C = M.dlev[1].boxes[0].L;
+  hipStream_t st = ctx().stream;
+  const int R = 2 * nsweeps, n2 = L.n[2], nK = n2 / 2, slab = mac_slab(n2);
+  if (residual && norm) HIPCHK(hipMemsetAsync(M.d_nrm, 0, sizeof(double), st));
+  DL.res_restricted = false;
+  std::vector<int> done(R + 1, 0);                  // planes [0, done[p]) have seen pass p; done[R]: coarse planes of the residual
+  for (int top = slab + R; ; top += slab) {         // (the first slab longer by the skew: the last one is then not a sliver)
+    for (int p = 0; p < R; p++) {
+      const int hi = p == 0 ? std::min(top, n2) : (done[p - 1] == n2 ? n2 : done[p - 1] - 1);
+      if (hi <= done[p]) continue;
+      const int add = prolong ? (p == 0 ? 1 : p == 1 ? 2 : 0) : 0;
+      if (add == 1) launch_gsrb_split<1>(DL, p & 1, st, C, done[p], hi);
+      else if (add == 2) launch_gsrb_split<2>(DL, p & 1, st, C, done[p], hi);
+      else launch_gsrb_split<0>(DL, p & 1, st, L, done[p], hi);
+      done[p] = hi;
+    }
+    if (residual) {                                  // coarse plane K reads the fine planes 2K - 1 .. 2K + 2
+      const int hiK = done[R - 1] == n2 ? nK : std::max(0, (done[R - 1] - 1) / 2);
+      if (hiK > done[R]) {
+        const dim3 g((unsigned)((L.n[0] / 4 + 63) / 64), (unsigned)((L.n[1] / 2 + 3) / 4), (unsigned)std::min(hiK - done[R], 16));
+        hipLaunchKernelGGL(kk_cc_residual_rho_split_rst, g, BLK, 0, st, L, DL.sp, norm ? M.d_nrm : nullptr, C, done[R], hiK);
+        done[R] = hiK;
+      }
+    }
+    if (done[R - 1] == n2 && (!residual || done[R] == nK)) break;
+  }
+  if (residual) { DL.res_restricted = true; if (norm && reduce) comm_allreduce_max_dev(M.d_nrm, 1); }
+}
+// the finest level between two coarse corrections: post-smoothing (after_coarse: with the prolongation), the next cycle's pre-smoothing, residual
+static void cc_fine_seq(CCMG &M, bool after_coarse, bool residual, bool norm, bool reduce = true) {
+  const vdn_params &P = ctx().prm;
+  CDLev &D0 = M.dlev[0];
+  static const bool split_res = !(vdn_env("VDN_MAC_SPLIT") && atoi(vdn_env("VDN_MAC_SPLIT")) == 2);
+  if (D0.split && mac_slab(D0.boxes[0].L.n[2]) > 0 && split_res && residual) { cc_split_run(M, D0, after_coarse, (after_coarse ? P.mg_nu2 : 0) + P.mg_nu1, true, norm, reduce); return; }
+  if (after_coarse) cc_prolong_smooth(M, 0, P.mg_nu2);
+  cc_gsrb_d(M, D0, P.mg_nu1);
+  if (residual) cc_residual_d(M, D0, norm, reduce);
 }
 // may level l >= 1 of a V-cycle run as kk_cc_lds_down / kk_cc_lds_up?  (VDN_MG_LDS=0: never; VDN_MG_LDS_MAX: largest extent taken, default 64)
 static bool cc_lds_level(const CCMG &M, int l) {
@@ -1836,17 +1885,14 @@ int cc_solve(vdn_multifab *rh, vdn_multifab *phi, vdn_multifab **beta, const dou
   const int gn[3] = { D0.ng[0], D0.ng[1], D0.ng[2] };
   const int pred = (fast && !single && !conv && bnorm < HUGE_VAL) ? std::min(mg_predict_get(0, gn), std::min(max_iter, 63)) : 0;
   if (!conv) {
-    cc_gsrb_d(M, D0, single ? nbot : P.mg_nu1);
+    if (single) cc_gsrb_d(M, D0, nbot); else cc_fine_seq(M, false, pred >= 2, true, false);
     if (pred >= 2) {
-      cc_residual_d(M, D0, true, false);
       norm_hist_reset(); norm_hist_push(M.d_nrm);
       cc_run_cycle(M, 4 + 4 * pred, [&] {      // all blind cycles as ONE graph (ids: 1 and 2 the plain cycles, 3 + 4 code the nested iterations, multiples of 4 these)
         for (int c = 1; c <= pred - 1; c++) {
           cc_restrict_down(M, 0);
           if (M.dlev.size() > 1) cc_vcycle_d(M, 1); else cc_vcycle_t(M, 0);
-          cc_prolong_smooth(M, 0, P.mg_nu2);
-          cc_gsrb_d(M, D0, P.mg_nu1);
-          cc_residual_d(M, D0, true, false);
+          cc_fine_seq(M, true, true, true, false);
           norm_hist_push(M.d_nrm);
         }
       });
@@ -1871,9 +1917,7 @@ int cc_solve(vdn_multifab *rh, vdn_multifab *phi, vdn_multifab **beta, const dou
     else cc_run_cycle(M, 1, [&] {
       cc_restrict_down(M, 0);
       if (M.dlev.size() > 1) cc_vcycle_d(M, 1); else cc_vcycle_t(M, 0);
-      cc_prolong_smooth(M, 0, P.mg_nu2);
-      cc_gsrb_d(M, D0, P.mg_nu1);
-      cc_residual_d(M, D0, true);
+      cc_fine_seq(M, true, true, true);
     });
     cyc++;
     rn = read_scalar(M.d_nrm);
