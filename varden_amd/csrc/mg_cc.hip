@@ -215,18 +215,18 @@ __global__ void __launch_bounds__(256) kk_cc_gsrb_rho_pair(CLev L, int color, in
 // ---- round 5: the finest level of macproject's solve STORED BY COLOUR ---------------------------------------------------------------------------
 // The paired pass above still moves whole lines of phi and rhs although half of every line belongs to the other colour: 572 MB per pass at 256^3
 // (profiles/r05_smoother_rho_pmc.json) where the cells it touches hold 402 MB.  Split storage: cells with (i + j + k) & 1 == c live in arrays [c],
-// entry ih of row (j, k) is cell i = 2 ih + ((j + k + c) & 1); rows, planes and the ghost layer as in the level array, 8 entries of padding in front
+// entry ih of row (j, k) is cell i = 2 ih + ((j + k + c) & 1); rows, planes and the ghost layer as in the level array, 16 entries (one line) of padding in front
 // of a row.  A colour pass then reads its own phi / rhs / rho and the OTHER colour's phi / rho -- nothing it does not use -- as aligned 16-byte
 // pairs: the y and z neighbours of entry ih are entry ih of the other colour's rows j -+ 1 / planes k -+ 1, the x neighbours its entries ih - 1, ih
 // (row parity 0) or ih, ih + 1 (parity 1).  Same expressions, same order, same bits as the interleaved pass (cc_apply_rho_vals);
 // tools/probes/split_colour_probe.hip measured the form first (0.0865 against 0.1135 ms per pass at 256^3).  VDN_MAC_SPLIT=0 keeps the level interleaved.
-struct CSplit { int PXH; long sy, sz, tot; double *phi[2], *rh[2], *rho[2]; };
-DEVI long sidx(const CSplit &S, int ih, int j, int k) { return (long)(ih + 8) + S.sy * (long)(j + 1) + S.sz * (long)(k + 1); }
+struct CSplit { int PXH, off; long sy, sz, tot; double *phi[2], *rh[2], *rho[2]; };
+DEVI long sidx(const CSplit &S, int ih, int j, int k) { return (long)(ih + S.off) + S.sy * (long)(j + 1) + S.sz * (long)(k + 1); }
 // interleaved -> split, every entry of the padded rows (what lies outside cells -2 .. n+1 becomes zero): one aligned pair (cells 2 ih, 2 ih + 1) feeds both colours
 __global__ void __launch_bounds__(256) kk_cc_to_split(CLev L, CSplit S, int what) {       // what: 1 phi, 2 rhs, 4 rho
   const int e = blockIdx.x * 64 + threadIdx.x, j = (int)(blockIdx.y * 4 + threadIdx.y) - 1, k = (int)blockIdx.z - 1;
   if (e >= S.PXH || j > L.n[1]) return;
-  const int ih = e - 8;
+  const int ih = e - S.off;
   const bool in = ih >= -1 && ih <= L.n[0] / 2;
   const long src = cidx(L, in ? 2 * ih : 0, j, k), dst = sidx(S, ih, j, k);
   const int c0 = (j + k) & 1;                    // the colour of the even cells of this row
@@ -255,8 +255,10 @@ template <int ADD> __global__ void __launch_bounds__(512) kk_cc_gsrb_rho_split(C
   const int ih = 2 * min(t, nh / 2);                                 // clamped: every lane takes part in the lane exchange, the pair (nh, nh + 1) lies inside the row
   const long c = sidx(S, ih, j, k);
   const double *po = S.phi[color], *px = S.phi[1 - color], *ro = S.rho[color], *rx = S.rho[1 - color];
-  double ep = 0.0, er = 0.0;                                         // the other colour's entry outside the wave's span: ih - 1 (p = 0, first lane) or ih + 2 (p = 1, last lane)
-  if ((p == 0 && lane == 0) || (p == 1 && lane == 63)) { const long o = c + (p ? 2 : -1); ep = px[o]; er = rx[o]; }
+  // the other colour's entry outside the wave's span: ih - 1 (p = 0, first lane) or ih + 2 (p = 1, last lane).  At the two ends of a row that is a ghost cell of the
+  // box -- a physical face here (cc_split_ok): phi is zero there, and rho only enters the coefficient of a Dirichlet face (beta_of) -- so its line is fetched for those only
+  double ep = 0.0, er = 0.0;
+  if ((p == 0 && lane == 0 && (t > 0 || L.fold[0][0] == VDN_BC_DIR)) || (p == 1 && lane == 63 && (ih + 2 < nh || L.fold[0][1] == VDN_BC_DIR))) { const long o = c + (p ? 2 : -1); ep = px[o]; er = rx[o]; }
   #define LDS2(v, off) (*reinterpret_cast<const double2 *>((v) + c + (off)))
   const double2 PO = LDS2(po, 0), RH = LDS2(S.rh[color], 0), RO = LDS2(ro, 0);
   const double2 PX = LDS2(px, 0), PYm = LDS2(px, -S.sy), PYp = LDS2(px, S.sy), PZm = LDS2(px, -S.sz), PZp = LDS2(px, S.sz);
@@ -295,12 +297,12 @@ template <int ADD> __global__ void __launch_bounds__(512) kk_cc_gsrb_rho_split(C
 // residual + restriction on the split level (kk_cc_residual_rho_pair_rst's job): a thread owns entries ih, ih + 1 of BOTH colours in rows 2J, 2J + 1 of planes
 // 2K, 2K + 1 = cells 2 ih .. 2 ih + 3 of each row = the children of coarse cells (ih, J, K) and (ih + 1, J, K).  Per plane: E = the row's even cells (2 ih, 2 ih + 2),
 // O = its odd cells (2 ih + 1, 2 ih + 3), each one aligned pair of the colour that holds them ((parity + j + k) & 1); q[jj][m]: cell 2 ih + m of row 2J + jj.
-DEVI void split_gather(double *const v[2], const CSplit &S, long c, int e, int lane, double q[2][4][7]) {
-  // e: the colour of the even cells of row 2J in this plane
+DEVI void split_gather(double *const v[2], const CSplit &S, long c, int e, int lane, double q[2][4][7], bool ldl, bool ldr) {
+  // e: the colour of the even cells of row 2J in this plane;  ldl / ldr: the entry left of the first / right of the last lane is read (a cell, or the ghost cell of a Dirichlet face)
   const long sy = S.sy, sz = S.sz;
   double a0 = 0.0, a1 = 0.0;                                       // outside the wave's span along x, two active lanes
-  if (lane == 0)  { a0 = v[1 - e][c - 1]; a1 = v[e][c + sy - 1]; }
-  if (lane == 63) { a0 = v[e][c + 2];     a1 = v[1 - e][c + sy + 2]; }
+  if (lane == 0 && ldl)  { a0 = v[1 - e][c - 1]; a1 = v[e][c + sy - 1]; }
+  if (lane == 63 && ldr) { a0 = v[e][c + 2];     a1 = v[1 - e][c + sy + 2]; }
   #define LD(col, off) (*reinterpret_cast<const double2 *>(v[col] + c + (off)))
   const double2 E0 = LD(e, 0), O0 = LD(1 - e, 0), E1 = LD(1 - e, sy), O1 = LD(e, sy);
   const double2 Em = LD(1 - e, -sy), Om = LD(e, -sy), Ep = LD(e, 2 * sy), Op = LD(1 - e, 2 * sy);
@@ -331,8 +333,9 @@ __global__ void __launch_bounds__(256) kk_cc_residual_rho_split_rst(CLev L, CSpl
       const int k = 2 * K + kk, e = kk;                            // (0 + 2J + k) & 1
       const long c = sidx(S, ih, 2 * J, k);
       double P[2][4][7], R[2][4][7];
-      split_gather(S.phi, S, c, e, lane, P);
-      split_gather(S.rho, S, c, e, lane, R);
+      const bool ldl = u > 0 || L.fold[0][0] == VDN_BC_DIR, ldr = ih + 2 < nh || L.fold[0][1] == VDN_BC_DIR;
+      split_gather(S.phi, S, c, e, lane, P, ldl, ldr);
+      split_gather(S.rho, S, c, e, lane, R, ldl, ldr);
       const double2 H0e = *reinterpret_cast<const double2 *>(S.rh[e] + c), H0o = *reinterpret_cast<const double2 *>(S.rh[1 - e] + c);
       const double2 H1e = *reinterpret_cast<const double2 *>(S.rh[1 - e] + c + S.sy), H1o = *reinterpret_cast<const double2 *>(S.rh[e] + c + S.sy);
       if (act) {
@@ -1113,7 +1116,11 @@ static void cc_split_setup(CCMG &M) {
   CDLev &D0 = M.dlev[0];
   const CLev &L = D0.boxes[0].L;
   CSplit &S = D0.sp;
-  S.PXH = ((L.n[0] / 2 + 10 + 7) / 8) * 8; S.sy = S.PXH; S.sz = (long)S.PXH * (L.n[1] + 2); S.tot = S.sz * (L.n[2] + 2);
+  // rows start on a 128-byte line and are whole lines long (measured at 256^3: 8 entries in front, rows of 144: FETCH_SIZE 204.8 MB raw, 0.0895 ms per pass; 16 / 160: 189.3 MB, 0.0848 ms)
+  static const int off = vdn_env("VDN_MAC_SPLIT_OFF") ? atoi(vdn_env("VDN_MAC_SPLIT_OFF")) : 16;
+  static const int rnd = vdn_env("VDN_MAC_SPLIT_RND") ? atoi(vdn_env("VDN_MAC_SPLIT_RND")) : 16;
+  S.off = off;
+  S.PXH = ((L.n[0] / 2 + off + 2 + rnd - 1) / rnd) * rnd; S.sy = S.PXH; S.sz = (long)S.PXH * (L.n[1] + 2); S.tot = S.sz * (L.n[2] + 2);
   double *base = (double *)arena_alloc(sizeof(double) * S.tot * 6);
   for (int c = 0; c < 2; c++) { S.phi[c] = base + c * S.tot; S.rh[c] = base + (2 + c) * S.tot; S.rho[c] = base + (4 + c) * S.tot; }
   D0.split = true;
@@ -1658,7 +1665,7 @@ static unsigned long long cc_graph_key(const CCMG &M, int what) {
   k.put(M.sendbuf); k.put(M.recvbuf); k.put(M.d_gb_rh); k.put(M.d_gb_b); k.put(M.cnt_rh); k.put(M.cnt_b);
   for (const CDLev &DL : M.dlev) {
     k.put(xplan_serial(DL.halo)); k.put(DL.ng); k.put(DL.single_box); k.put(DL.res_restricted);
-    k.put(DL.split); if (DL.split) { k.put(DL.sp.PXH); k.put(DL.sp.phi); k.put(DL.sp.rh); k.put(DL.sp.rho); }
+    k.put(DL.split); if (DL.split) { k.put(DL.sp.PXH); k.put(DL.sp.off); k.put(DL.sp.phi); k.put(DL.sp.rh); k.put(DL.sp.rho); }
     for (const CBox &B : DL.boxes) { cc_key_lev(k, B.L); k.put(B.lo); }
   }
   for (const CLev &L : M.tail) cc_key_lev(k, L);
