@@ -21,7 +21,7 @@ cflfac 0.9, init_shrink 0.1, init_iter 1, MAC + HG projection every step, exec/t
 A "step" = one pass of the reference's time-loop body (src/varden.f90:291-328): ghost fills, estdt, advance_timestep, uold<-unew.
 All state is resident in HBM before the timed region.
 
-`roofline` is the MAC-multigrid red-black Gauss-Seidel colour pass on the finest level (48 algorithmic B/cell/pass),
+`roofline` is the MAC-multigrid red-black Gauss-Seidel colour pass on the finest level (48 algorithmic B/cell/pass; round 5: the level by colour),
 timed with HIP events on the launch stream inside the library; `cpu_baseline` is the CPU oracle (a port, OpenMP) on a bounded
 sample of the same workload, with the survey's per-core timing of the reference's own Godunov kernels quoted next to it.
 """
@@ -345,19 +345,32 @@ def main():
         # HBM bytes per launch: PMC passes (FETCH_SIZE x2 + WRITE_SIZE, MI355X_MICROARCH.md) collected with `rocprofv3 --pmc` on
         # tools/smoother_probe.py in a separate run and committed; not measured in THIS run, and said so in traffic_source
         traffic, traffic_source = None, None
-        for name in ("r05_smoother_rho_pmc.json", "r04_smoother_rho_pmc.json", "r03_smoother_rho_pmc.json", "r02_smoother_rho_pmc.json", "r01_smoother_rho_pmc.json"):
+        # which form ran: the level by colour (kk_cc_gsrb_rho_split, from 2^23 cells on one box; the default) or interleaved (kk_cc_gsrb_rho_pair)
+        split = os.environ.get("VDN_MAC_SPLIT", "1") != "0" and ncell >= int(os.environ.get("VDN_MAC_SPLIT_MIN", str(1 << 23)))
+        names = (["r05_smoother_split_pmc.json"] if split else
+                 ["r05_smoother_rho_pmc.json", "r04_smoother_rho_pmc.json", "r03_smoother_rho_pmc.json", "r02_smoother_rho_pmc.json", "r01_smoother_rho_pmc.json"])
+        for name in names:
             pmc = os.path.join(ROOT, "profiles", name)
             if pn == 256 and os.path.exists(pmc):
                 traffic = json.load(open(pmc))["hbm_bytes_per_launch"]
                 traffic_source = "profiles/%s (committed rocprofv3 --pmc passes of the same kernel; not measured in this run)" % name
                 break
-        roof = {"bound": "hbm", "kernel": "kk_cc_gsrb_rho_pair (MAC-MG red-black GS colour pass, %d^3; beta recomputed from rho, 2x2 cells per thread: ~34 B/cell of "
-                                          "real traffic against the 48 B/cell algorithmic figure; stored-beta pass kk_cc_gsrb_pair: %.5f ms)" % (pn, ms_stored),
+        # the bytes of the entries a pass touches in this layout: phi own r + w, rhs own, rho both colours, phi other colour = 48 B per UPDATED cell
+        # = 24 B per cell of the level (split); the interleaved pass cannot avoid whole lines of phi and rhs: 34 B per cell of the level
+        touched = (24.0 if split else 34.0) * ncell
+        kname = ("kk_cc_gsrb_rho_split<0> (MAC-MG red-black GS colour pass, %d^3, the level stored BY COLOUR; beta recomputed from rho, two cells per thread. "
+                 "`achieved` / `frac` price the pass at SURVEY section 8(d)'s 48 B per cell of the level -- stored face coefficients, whole lines of phi and rhs; "
+                 "this layout touches 24 B per cell (48 B per updated cell), so `frac` can exceed 1: `frac_physical` (counter bytes / time / peak) and "
+                 "`frac_touched` (24 B/cell / time / peak) are the physical fractions. Interleaved stored-beta pass kk_cc_gsrb_pair: %.5f ms)" % (pn, ms_stored)) if split else \
+                ("kk_cc_gsrb_rho_pair (MAC-MG red-black GS colour pass, %d^3; beta recomputed from rho, 2x2 cells per thread: ~34 B/cell of "
+                 "real traffic against the 48 B/cell algorithmic figure; stored-beta pass kk_cc_gsrb_pair: %.5f ms)" % (pn, ms_stored))
+        roof = {"bound": "hbm", "kernel": kname,
                 "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_source,
-                # the physical rate: counter bytes / launch time (the rho form moves fewer bytes than the 48-B model prices)
+                # the physical rate: counter bytes / launch time
                 "achieved_physical": (round(traffic / (ms * 1e-3) / 1e9, 1) if traffic else None),
                 "frac_physical": (round(traffic / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if traffic else None),
+                "touched_bytes_per_launch": touched, "frac_touched": round(touched / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
                 "avg_launch_ms": round(ms, 5), "alg_bytes_per_launch": alg_bytes}
         for m in [rh, phi] + beta:
             m.destroy()
@@ -430,6 +443,8 @@ def main():
         # the GPU's time on the SAME sample (like for like with `value` of this object): single-level samples only
         gpu_same_ms = None
         if not amr:
+            for _ in range(5):                                # the card idled through the CPU legs: untimed steps first
+                Gs.step()
             torch.cuda.synchronize()
             tg = time.perf_counter()
             for _ in range(5):

@@ -21,4 +21,15 @@ for ctr in FETCH_SIZE WRITE_SIZE "TA_BUSY_avr TA_BUSY_max" "TCC_HIT_sum TCC_MISS
   rocprofv3 --pmc $ctr --kernel-trace --output-format csv -d $O/smo/p$i -o p -- python3 tools/smoother_probe.py 256 20 > $O/smo$i.log 2>&1
 done
 python tools/pmc_summary.py $O/smo > $O/smoother_pmc_summary.txt 2>&1
+python tools/make_pmc_json.py $O/smoother_pmc_summary.txt $O/smoother_split_pmc.json > /dev/null 2>&1
+# 4b. the interleaved pass (VDN_MAC_SPLIT=0; what every multi-box / multi-rank level runs): fetch and write sizes
+export VDN_MAC_SPLIT=0
+i=0
+for ctr in FETCH_SIZE WRITE_SIZE "TA_BUSY_avr TA_BUSY_max" "TCC_HIT_sum TCC_MISS_sum" "VALUBusy MemUnitBusy"; do
+  i=$((i+1))
+  rocprofv3 --pmc $ctr --kernel-trace --output-format csv -d $O/smo_pair/p$i -o p -- python3 tools/smoother_probe.py 256 20 > $O/smo_pair$i.log 2>&1
+done
+unset VDN_MAC_SPLIT
+python tools/pmc_summary.py $O/smo_pair > $O/smoother_pair_pmc_summary.txt 2>&1
+python tools/make_pmc_json.py $O/smoother_pair_pmc_summary.txt $O/smoother_rho_pmc.json pair > /dev/null 2>&1
 ls $O; head -n 12 $O/smoother_pmc_summary.txt; tail -n 1 $O/bench.log | cut -c1-300

@@ -1117,8 +1117,7 @@ static void cc_split_setup(CCMG &M) {
   const CLev &L = D0.boxes[0].L;
   CSplit &S = D0.sp;
   // rows start on a 128-byte line and are whole lines long (measured at 256^3: 8 entries in front, rows of 144: FETCH_SIZE 204.8 MB raw, 0.0895 ms per pass; 16 / 160: 189.3 MB, 0.0848 ms)
-  static const int off = vdn_env("VDN_MAC_SPLIT_OFF") ? atoi(vdn_env("VDN_MAC_SPLIT_OFF")) : 16;
-  static const int rnd = vdn_env("VDN_MAC_SPLIT_RND") ? atoi(vdn_env("VDN_MAC_SPLIT_RND")) : 16;
+  const int off = 16, rnd = 16;
   S.off = off;
   S.PXH = ((L.n[0] / 2 + off + 2 + rnd - 1) / rnd) * rnd; S.sy = S.PXH; S.sz = (long)S.PXH * (L.n[1] + 2); S.tot = S.sz * (L.n[2] + 2);
   double *base = (double *)arena_alloc(sizeof(double) * S.tot * 6);
