@@ -52,7 +52,8 @@ extern "C" int vdn_advance_timestep(int istep, vdn_layout *mla, vdn_multifab **s
   vdn_multifab *mac_rhs[VDN_MAXLEV], *rhohalf[VDN_MAXLEV], *umac[3 * VDN_MAXLEV] = { nullptr }, *lapu[VDN_MAXLEV] = { nullptr };
   for (int n = 0; n < nlevs; n++) {
     mac_rhs[n] = mf_temp(mla, n, 1, 1, -1, true, 0.0);
-    rhohalf[n] = mf_temp(mla, n, dm, 1, -1, true, 0.0);
+    rhohalf[n] = mf_temp(mla, n, dm, 1, -1, false, 0.0);          // (dm components as the reference builds it, advance_timestep.f90:70; only the first is ever written or read:
+    mf_setval(rhohalf[n], 0.0, 0, 1, true);                        //  its setval, :73, is applied to that one)
     for (int d = 0; d < dm; d++) umac[3 * n + d] = mf_temp(mla, n, 1, 1, d, true, 1.e20);
     // lapu (advance_timestep.f90:85-93); NULL stands for the all-zero field when visc_coef == 0
     if (viscous) {
