@@ -495,7 +495,7 @@ def test_tagged_hierarchy_against_the_box_list_oracle(gpu, oracle, nc, max_levs,
                 m += (G.sold[n].to_numpy(i)[3:-3, 3:-3, 3:-3, 0] * msk[sl]).sum() / 8.0 ** n
         return m
     m0 = mass()
-    for step in range(2):
+    for step in range(1 if (nc, max_levs) == (64, 3) else 2):          # (the largest case: one step -- the oracle takes 25 s for each; the GPU suite has 900 s)
         O.step(); G.step()
         assert G.dt == O.dt, "dt diverged at step %d: %r vs %r" % (step, G.dt, O.dt)
         cg = (adv.last_solver_stats("mac")[0], adv.last_solver_stats("hg")[0])
