@@ -1478,12 +1478,19 @@ static void cc_prolong_smooth(CCMG &M, int l, int nsweeps) {
 // Cache: nine launches over the whole level read each of its six arrays nine times from HBM, the slabs read them about once.  Cells of a colour do not
 // read each other and the residual only reads: the order changes no bit.  VDN_MAC_SLAB=0: whole-level launches.
 // Measured at 256^3 (MAC solve per step): whole-level launches 10.03 ms; slabs of 32 / 48 / 64 / 96 / 128 planes 10.66 / 10.28 / 9.86 / 9.65 / 9.44 ms -- a pass
-// served from the cache takes 0.069 ms per 256 planes against 0.090 from HBM, and every launch costs its ramp and tail; the default is half the level.
-static int mac_slab(int n2) { static const int k = vdn_env("VDN_MAC_SLAB") ? atoi(vdn_env("VDN_MAC_SLAB")) : -1; return k < 0 ? (n2 + 1) / 2 : k; }
+// served from the cache takes 0.069 ms per 256 planes against 0.090 from HBM, and every launch costs its ramp and tail.  The default:
+// the planes whose pass traffic (24 B per cell of the level) adds up to ~200 MB -- what stays in the cache between two passes over it; at most half the level.
+// 512^3 (plane = 6.3 MB; MAC solve per step): whole-level launches 69.8 ms; slabs of 16 / 24 / 28 / 32 / 40 / 64 / 256 planes 67.9 / 65.2 / 64.5 / 64.7 / 65.2 / 67.5 / 69.1 ms.
+static int mac_slab(const CLev &L) {
+  static const int k = vdn_env("VDN_MAC_SLAB") ? atoi(vdn_env("VDN_MAC_SLAB")) : -1;
+  if (k >= 0) return k;
+  const long fit = (long)(200.0e6 / (24.0 * L.n[0] * L.n[1]));
+  return (int)std::max(8L, std::min((long)(L.n[2] + 1) / 2, fit));
+}
 static void cc_split_run(CCMG &M, CDLev &DL, bool prolong, int nsweeps, bool residual, bool norm, bool reduce) {
   const CLev &L = DL.boxes[0].L, &C = M.dlev[1].boxes[0].L;
   hipStream_t st = ctx().stream;
-  const int R = 2 * nsweeps, n2 = L.n[2], nK = n2 / 2, slab = mac_slab(n2);
+  const int R = 2 * nsweeps, n2 = L.n[2], nK = n2 / 2, slab = mac_slab(L);
   if (residual && norm) HIPCHK(hipMemsetAsync(M.d_nrm, 0, sizeof(double), st));
   DL.res_restricted = false;
   std::vector<int> done(R + 1, 0);                  // planes [0, done[p]) have seen pass p; done[R]: coarse planes of the residual
@@ -1514,7 +1521,7 @@ static void cc_fine_seq(CCMG &M, bool after_coarse, bool residual, bool norm, bo
   const vdn_params &P = ctx().prm;
   CDLev &D0 = M.dlev[0];
   static const bool split_res = !(vdn_env("VDN_MAC_SPLIT") && atoi(vdn_env("VDN_MAC_SPLIT")) == 2);
-  if (D0.split && mac_slab(D0.boxes[0].L.n[2]) > 0 && split_res && residual) { cc_split_run(M, D0, after_coarse, (after_coarse ? P.mg_nu2 : 0) + P.mg_nu1, true, norm, reduce); return; }
+  if (D0.split && mac_slab(D0.boxes[0].L) > 0 && split_res && residual) { cc_split_run(M, D0, after_coarse, (after_coarse ? P.mg_nu2 : 0) + P.mg_nu1, true, norm, reduce); return; }
   if (after_coarse) cc_prolong_smooth(M, 0, P.mg_nu2);
   cc_gsrb_d(M, D0, P.mg_nu1);
   if (residual) cc_residual_d(M, D0, norm, reduce);

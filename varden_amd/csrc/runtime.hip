@@ -145,7 +145,7 @@ static const EnvSwitch g_switches[] = {
   { "VDN_MAC_SPLIT", "0: the finest level of macproject's one-box solve stays interleaved (kk_cc_gsrb_rho_pair) instead of stored by colour (kk_cc_gsrb_rho_split); 2: only the colour passes on the split arrays, the residual on the level array" },
   { "VDN_MAC_SPLIT_MIN", "fewest cells of a level stored by colour (default 2^23)" },
   { "VDN_ND_REV", "0: every march of a nodal level walks its tiles in the same order (default: consecutive marches alternate)" },
-  { "VDN_MAC_SLAB", "planes per slab of the time-skewed schedule of the split level's passes (cc_split_run; default: half the level); 0: whole-level launches" },
+  { "VDN_MAC_SLAB", "planes per slab of the time-skewed schedule of the split level's passes (cc_split_run; default: ~200 MB of pass traffic, at most half the level); 0: whole-level launches" },
   { "VDN_MAC_KFLIP", "0: both colour passes of a sweep walk the planes upwards (default: the second colour downwards; paired and split passes of the cell-centred multigrid)" },
   { "VDN_CC_HALO_FACES", "0: the cell-centred multigrid exchanges the whole ghost shell instead of the faces only" },
   { "VDN_MG_AGGLOM", "several boxes: smallest box extent (cells) of a multigrid level that stays distributed; below it the level is gathered and relaxed on every rank (default 64)" },
