@@ -1,4 +1,4 @@
-"""macproject on one 132 x 36 x 40 box (tests/test_projection_gpu.py::test_split_colour_level_*): argv = bc-set name.  Compares with the oracle and prints a
+"""macproject on one 132 x 36 x 40 box (tests/test_projection_gpu.py::test_split_colour_level_*): argv = bc-set name [nx ny nz].  Compares with the oracle and prints a
 hash of the projected MAC velocities; how the finest level of the solve is stored comes from VDN_MAC_SPLIT / VDN_MAC_SPLIT_MIN / VDN_MAC_KFLIP (read once per
 process).  132 cells: 33 lane pairs of the split pass, a clamped tail of the wave."""
 import ctypes as C
@@ -17,7 +17,8 @@ def main():
     from tests.test_projection_gpu import face_fabs
     from varden_amd import advance as adv
     sets = dict(BC_SETS, zout=[[15, 12], [14, 15], [11, 12]])           # outlets at x-hi and z-hi, inlet at z-lo
-    case = Case((132, 36, 40), sets[sys.argv[1]], seed=13, iso=True)
+    n = tuple(int(v) for v in sys.argv[2:5]) if len(sys.argv) >= 5 else (132, 36, 40)
+    case = Case(n, sets[sys.argv[1]], seed=13, iso=True)
     L = oracle.lib()
     _, s = case.random_state()
     s.a[..., 0] = np.abs(s.a[..., 0]) + 0.5

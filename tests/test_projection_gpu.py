@@ -109,13 +109,14 @@ def test_macproject(gpu, oracle, bcname):
     case.close()
 
 
-@pytest.mark.parametrize("bcname", ["walls", "inout", "zout"])
-def test_split_colour_level_matches_the_oracle_and_the_interleaved_level(gpu, oracle, bcname):
+@pytest.mark.parametrize("bcname,n", [("walls", (132, 36, 40)), ("inout", (132, 36, 40)), ("zout", (132, 36, 40)), ("inout", (260, 20, 24))])
+def test_split_colour_level_matches_the_oracle_and_the_interleaved_level(gpu, oracle, bcname, n):
     """round 5: macproject's one-box solve keeps its finest level BY COLOUR from 2^23 cells up (kk_cc_gsrb_rho_split, kk_cc_residual_rho_split_rst; the
     256^3 tests run it).  Here on 132 x 36 x 40 cells (VDN_MAC_SPLIT_MIN=0; 33 lane pairs: the clamped tail of a wave, one-sided y / z extents): the
     projected velocities against the oracle's in the worker, and the same bits (a) split, the passes and the residual time-skewed over slabs of 7 planes
     (cc_split_run; 40 planes: six slabs, the last a sliver), the second colour walking its planes downwards,
-    (b) split passes only, residual on the level array, both colours upwards, (c) interleaved.  tests/_split_worker.py."""
+    (b) split passes only, residual on the level array, both colours upwards, (c) interleaved.  260 cells: two waves per row, the second with one active lane pair
+    (the lane that ends a wave inside the row reads its neighbour from memory).  tests/_split_worker.py."""
     import os, subprocess, sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     out, form = [], []
@@ -124,7 +125,7 @@ def test_split_colour_level_matches_the_oracle_and_the_interleaved_level(gpu, or
         for k in ("VDN_MAC_SPLIT", "VDN_MAC_SPLIT_MIN", "VDN_MAC_KFLIP", "VDN_MAC_SLAB"):
             env.pop(k, None)
         env.update(extra)
-        r = subprocess.run([sys.executable, os.path.join(root, "tests", "_split_worker.py"), bcname], env=env, capture_output=True, text=True, timeout=600, cwd=root)
+        r = subprocess.run([sys.executable, os.path.join(root, "tests", "_split_worker.py"), bcname] + [str(v) for v in n], env=env, capture_output=True, text=True, timeout=600, cwd=root)
         assert r.returncode == 0, r.stderr[-2000:]
         out.append([ln for ln in r.stdout.splitlines() if ln.startswith("HASH")][0])
         form.append([ln for ln in r.stdout.splitlines() if ln.startswith("FORM")][0])
