@@ -22,7 +22,7 @@ A "step" = one pass of the reference's time-loop body (src/varden.f90:291-328): 
 All state is resident in HBM before the timed region.
 
 `roofline` is the MAC-multigrid red-black Gauss-Seidel colour pass on the finest level (48 algorithmic B/cell/pass; round 5: the level by colour),
-timed with HIP events on the launch stream inside the library; `cpu_baseline` is the CPU oracle (a port, OpenMP) on a bounded
+timed with HIP events on the launch stream inside the library, its HBM bytes per launch measured in the same run by two rocprofv3 --pmc child passes; `cpu_baseline` is the CPU oracle (a port, OpenMP) on a bounded
 sample of the same workload, with the survey's per-core timing of the reference's own Godunov kernels quoted next to it.
 """
 import argparse
@@ -35,6 +35,38 @@ import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+
+def measure_pass_traffic(kernel_substr, timeout_s=240):
+    """HBM bytes per launch of the roofline kernel, MEASURED NOW: rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE as two child runs of tools/smoother_probe.py
+    (the same kernel on the same 256^3 data as the timed probe; counters in passes of their own, as MI355X_MICROARCH.md prescribes), per-launch means over its
+    24 dispatches, bytes = (2 x FETCH_SIZE + WRITE_SIZE) KB (the guide's gfx950 correction for streaming reads).  None when rocprofv3 is missing or a pass fails."""
+    import csv, glob, shutil, tempfile
+    exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(exe):
+        return None
+    out = tempfile.mkdtemp(prefix="vdn_pmc_", dir="/tmp")
+    means = {}
+    try:
+        for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
+            d = os.path.join(out, ctr)
+            subprocess.run([exe, "--pmc", ctr, "--kernel-trace", "--output-format", "csv", "-d", d, "-o", "p", "--",
+                            sys.executable, os.path.join(ROOT, "tools", "smoother_probe.py"), "256", "20"],
+                           capture_output=True, text=True, timeout=timeout_s, cwd=ROOT, env=dict(os.environ, TMPDIR="/tmp"), check=True)
+            tot = cnt = 0
+            for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
+                for r in csv.DictReader(open(f)):
+                    if kernel_substr in r["Kernel_Name"] and r["Counter_Name"] == ctr:
+                        tot += float(r["Counter_Value"]); cnt += 1
+            if cnt == 0:
+                return None
+            means[ctr] = tot / cnt
+        return int(round((2.0 * means["FETCH_SIZE"] + means["WRITE_SIZE"]) * 1024)), means
+    except Exception as e:                                   # (a missing profiler or a failed pass must not fail the bench line)
+        print("bench: traffic not measured in this run (%s)" % (str(e)[:200],), file=sys.stderr)
+        return None
+    finally:
+        shutil.rmtree(out, ignore_errors=True)
+
 
 HBM_PEAK_GBS = 8000.0   # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 # BASELINE.md section 1b: the reference's own velpred + mkflux (scalars, velocity) + update, flang -O2, ONE core, 128^3: 2.91 s per
@@ -112,6 +144,8 @@ def parse_args():
     ap.add_argument("--mac-fmg", dest="mac_fmg", type=int, default=1, choices=[0, 1], help="nested-iteration start of the MAC solve (vdn_params.mac_fmg; 0: the zero guess)")
     ap.add_argument("--hg-pre-pair", dest="hg_pre_pair", type=int, default=1, choices=[0, 1], help="two-step damping of the nodal V-cycle's pre-smoothing sweeps (vdn_params.hg_omega_pre1 / 2; 0: hg_omega for both)")
     ap.add_argument("--no-calib", dest="no_calib", action="store_true", help="skip the one-thread Godunov calibration of the cpu_baseline leg")
+    ap.add_argument("--no-pmc", dest="no_pmc", action="store_true", help="do not measure roofline.traffic in this run (two rocprofv3 --pmc child passes on tools/smoother_probe.py); "
+                    "the committed counter summary is quoted instead.  Needed when bench.py itself runs under rocprofv3")
     ap.add_argument("--no-extra", dest="no_extra", action="store_true", help="skip the extra_workloads (512^3 in eight boxes and in one box, tagged two- and three-level hierarchies) of the default N = 1 line")
     return ap.parse_args()
 
@@ -349,7 +383,13 @@ def main():
         split = os.environ.get("VDN_MAC_SPLIT", "1") != "0" and ncell >= int(os.environ.get("VDN_MAC_SPLIT_MIN", str(1 << 23)))
         names = (["r05_smoother_split_pmc.json"] if split else
                  ["r05_smoother_rho_pmc.json", "r04_smoother_rho_pmc.json", "r03_smoother_rho_pmc.json", "r02_smoother_rho_pmc.json", "r01_smoother_rho_pmc.json"])
-        for name in names:
+        if pn == 256 and world == 1 and not args.no_pmc:
+            got = measure_pass_traffic("kk_cc_gsrb_rho_split<0>" if split else "kk_cc_gsrb_rho_pair(")
+            if got:
+                traffic = got[0]
+                traffic_source = ("measured in this run: rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE, one child run of tools/smoother_probe.py 256 20 each (the timed probe's "
+                                  "kernel and data), per-launch means %.1f / %.1f KB, bytes = 2 x FETCH_SIZE + WRITE_SIZE (MI355X_MICROARCH.md)" % (got[1]["FETCH_SIZE"], got[1]["WRITE_SIZE"]))
+        for name in ([] if traffic else names):
             pmc = os.path.join(ROOT, "profiles", name)
             if pn == 256 and os.path.exists(pmc):
                 traffic = json.load(open(pmc))["hbm_bytes_per_launch"]

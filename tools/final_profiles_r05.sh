@@ -3,15 +3,15 @@
 export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
 O=$GRAFT_REPO_ROOT/gpurun_out/r05; mkdir -p $O
 # 1. kernel trace + stats of the default bench line
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/bench -o b -- python3 bench.py --steps 5 --warmup 2 --skip-cpu --no-extra > $O/bench.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/bench -o b -- python3 bench.py --steps 5 --warmup 2 --skip-cpu --no-extra --no-pmc > $O/bench.log 2>&1
 # 2. the same command, sqlite, for the gap analysis
-rocprofv3 --kernel-trace -d $O/bench_db -o t -- python3 bench.py --steps 5 --warmup 2 --skip-cpu --no-extra > $O/bench_db.log 2>&1
+rocprofv3 --kernel-trace -d $O/bench_db -o t -- python3 bench.py --steps 5 --warmup 2 --skip-cpu --no-extra --no-pmc > $O/bench_db.log 2>&1
 python tools/trace_gaps.py $O/bench_db/t_results.db 5 grid > $O/trace_gaps.txt 2>&1
 # 3. HBM counters of the whole bench (separate passes)
 i=0
 for ctr in FETCH_SIZE WRITE_SIZE "TA_BUSY_avr TA_BUSY_max" "TCC_HIT_sum TCC_MISS_sum" "VALUBusy MemUnitBusy"; do
   i=$((i+1))
-  rocprofv3 --pmc $ctr --kernel-trace --output-format csv -d $O/pmc/p$i -o p -- python3 bench.py --steps 2 --warmup 1 --skip-cpu --no-extra > $O/pmc$i.log 2>&1
+  rocprofv3 --pmc $ctr --kernel-trace --output-format csv -d $O/pmc/p$i -o p -- python3 bench.py --steps 2 --warmup 1 --skip-cpu --no-extra --no-pmc > $O/pmc$i.log 2>&1
 done
 python tools/pmc_summary.py $O/pmc > $O/pmc_summary.txt 2>&1
 # 4. the smoother probe (the roofline kernel alone): counters per launch + copy calibration
