@@ -107,9 +107,9 @@ int  vdn_init(const vdn_params *prm, int rank, int nranks, int device);
 /* Debug / measurement switches.  The library reads environment variables VDN_* only through one table (varden_amd/csrc/runtime.hip, g_switches): each
  * selects between launch forms that the test suite holds bit-for-bit equal, or is a probe; none changes a result, none is needed in production.  This call
  * returns the table as text -- one line per switch: name, current value, what it does.  vdn_init warns on stderr about VDN_* variables that are not in it.
- * Groups: transport rehearsal (VDN_FORCE_PACKED, VDN_RCCL_LIB + VDN_TESTING, VDN_DEBUG_VIEWS); runtime (VDN_ARENA_POISON, VDN_POLL, VDN_NO_GRAPHS,
- * VDN_NO_ROCTX, VDN_KEEP_SETS, VDN_KEPT_BOUND); advance (VDN_NO_SLOPE_CACHE, VDN_NO_FORCE_REUSE); Godunov launch forms (VDN_GOD_*, VDN_GODUNOV_*, VDN_SLOPES_MARCH, VDN_KCHUNKS,
- * VDN_FUSED_KCHUNKS, VDN_MK_SPLIT); cell-centred multigrid (VDN_GSRB_PAIR, VDN_CC_HALO_FACES, VDN_MG_*, VDN_MAC_*, VDN_OVERLAP*); nodal
+ * Groups: transport rehearsal (VDN_FORCE_PACKED, VDN_RCCL_LIB + VDN_TESTING); runtime (VDN_ARENA_POISON, VDN_POLL, VDN_NO_GRAPHS,
+ * VDN_NO_ROCTX, VDN_KEEP_SETS, VDN_KEPT_BOUND); advance (VDN_NO_SLOPE_CACHE, VDN_NO_FORCE_REUSE); Godunov launch forms (VDN_GOD_*, VDN_GODUNOV_*, VDN_SLOPES_MARCH,
+ * VDN_FUSED_KCHUNKS); cell-centred multigrid (VDN_GSRB_PAIR, VDN_CC_HALO_FACES, VDN_MG_*, VDN_MAC_*, VDN_OVERLAP*); nodal
  * multigrid (VDN_ND_*, VDN_HG_FAST); composite solves (VDN_NDF_*, VDN_NDM_*, VDN_MLCC_*, VDN_FB_FACES); box-batched kernels (VDN_BATCH_*). */
 const char *vdn_debug_switches(void);
 int  vdn_finalize(void);

@@ -397,7 +397,6 @@ bool xplan_has_remote(const XPlan *P) {
 }
 void xplan_run(XPlan *P, hipStream_t st) {
   if (!st) st = ctx().stream;
-  if (vdn_env("VDN_DEBUG_VIEWS")) { fprintf(stderr, "[rank %d] xplan nc %d peers:", ctx().rank, P->nc); for (auto &pr : P->peers) fprintf(stderr, " (%d: send %zu recv %zu)", pr.rank, pr.nsend, pr.nrecv); fprintf(stderr, "\n"); }
   const int nc = P->nc;
   // pack + post the remote traffic first so that it overlaps the local copies
   if (!P->peers.empty()) {
@@ -448,7 +447,6 @@ void view_cache_purge(unsigned long uid) {
   }
 }
 void SrcView::refresh() const {
-  if (vdn_env("VDN_DEBUG_VIEWS")) { fprintf(stderr, "[rank %d] view refresh ng %d nc %d nboxes %d peers:", ctx().rank, ng, nc, nboxes()); if (plan) for (auto &pr : plan->peers) fprintf(stderr, " (%d: send %zu recv %zu)", pr.rank, pr.nsend, pr.nrecv); fprintf(stderr, "\n"); }
   if (!plan || plan->peers.empty()) return;
   hipStream_t st = ctx().stream;
   need_comm();

@@ -429,17 +429,16 @@ static bool plain_godunov() { static const bool p = vdn_env("VDN_GODUNOV_PLAIN")
 // parameters of the marching bodies: by value under the by-value kernels, references into the (constant) descriptor under the batched ones
 template <class T, bool R> struct Prm { typedef T type; };
 template <class T> struct Prm<T, true> { typedef const T &type; };
-// tile order of the marching kernels: VDN_GOD_XCD=0 keeps the dispatch order (default: XCD-aware, vdn_dev.h xcd_tile)
+// tile order of the marching kernels: XCD-aware (vdn_dev.h xcd_tile)
 __constant__ int g_god_xcd = 1;
 DEVI void xcd_remap(int &bx, int &by, int &bz) { if (g_god_xcd) xcd_tile(bx, by, bz); else { bx = blockIdx.x; by = blockIdx.y; bz = blockIdx.z; } }
 static void god_xcd_init() {
   static bool done = false;
   if (done) return;
   done = true;
-  if (vdn_env("VDN_GOD_XCD")) { const int v = atoi(vdn_env("VDN_GOD_XCD")); HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(g_god_xcd), &v, sizeof(int))); }
 }
 constexpr int TNY = 8;              // rows per tile: workgroup = 64 x TNY threads
-static int march_chunks() { static const int n = vdn_env("VDN_KCHUNKS") ? atoi(vdn_env("VDN_KCHUNKS")) : 12; return n < 1 ? 1 : n; }
+static int march_chunks() { return 12; }
 static dim3 march_grid(const Range3 &r, int &klen) {
   const int nx = r.hi[0] - r.lo[0] + 1, ny = r.hi[1] - r.lo[1] + 1, nz = r.hi[2] - r.lo[2] + 1;
   klen = (nz + march_chunks() - 1) / march_chunks(); if (klen < 1) klen = 1;
@@ -1742,8 +1741,7 @@ bool k_mkflux(const vdn_multifab *s, vdn_multifab **sedge, vdn_multifab **flux, 
         return false;
       }
     }
-    static const int split_env = vdn_env("VDN_MK_SPLIT") ? atoi(vdn_env("VDN_MK_SPLIT")) : -1;
-    const int split = split_env >= 0 ? split_env : (ncomp >= 2 ? 4 : 0);
+    const int split = ncomp >= 2 ? 4 : 0;
     #define MKB_STAGE(K, t, bit)                                                                                               \
       if ((split >> bit) & 1) { for (int c0 = 0; c0 < ncomp; c0++) hipLaunchKernelGGL(K<1>, dim3(B.tot[t]), blk, 0, st, B.dev, B.st[t], nb, c0, ncomp); } \
       else if (ncomp == 3) hipLaunchKernelGGL(K<3>, dim3(B.tot[t]), blk, 0, st, B.dev, B.st[t], nb, 0, ncomp);                  \
@@ -1794,8 +1792,7 @@ bool k_mkflux(const vdn_multifab *s, vdn_multifab **sedge, vdn_multifab **flux, 
       #define MK_ARGS_D(c0) s->fabs[ib], sl[0], sl[1], sl[2], um, vm, wm, force->fabs[ib], mac_rhs->fabs[ib], SC, \
                             sedge[0]->fabs[ib], sedge[1]->fabs[ib], sedge[2]->fabs[ib], flux[0]->fabs[ib], flux[1]->fabs[ib], flux[2]->fabs[ib], A, rf, klf, umax, c0, ncomp
       // measured at 256^3: D fused <3> 3.18 ms (61 spilled VGPRs) vs 3 x <1> 2.3 ms; D <2> 1.66 ms vs 2 x <1> 1.55 ms; B and C are faster fused
-      static const int split_env = vdn_env("VDN_MK_SPLIT") ? atoi(vdn_env("VDN_MK_SPLIT")) : -1;   // bit 0: B, 1: C, 2: D per component
-      const int split = split_env >= 0 ? split_env : (ncomp >= 2 ? 4 : 0);
+      const int split = ncomp >= 2 ? 4 : 0;          // bit 0: B, 1: C, 2: D per component
       #define MK_STAGE(K, BCF, ARGS, g, bit)                                                                               \
         if ((split >> bit) & 1) { for (int c0 = 0; c0 < ncomp; c0++) hipLaunchKernelGGL((K<1, BCF>), g, blk, 0, st, ARGS(c0)); } \
         else if (ncomp == 3) hipLaunchKernelGGL((K<3, BCF>), g, blk, 0, st, ARGS(0));                                        \

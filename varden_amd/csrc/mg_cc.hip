@@ -1221,9 +1221,9 @@ static void cc_build(CCMG &M, const vdn_multifab *rh, const double *dx, const in
       if ((N & 1) || N <= 2) can = false;
     }
     if (can) for (int d = 0; d < 3; d++) REQUIRE(!(n[d] & 1), "cc multigrid: box extent %d is odd while the domain can still be coarsened", n[d]);
-    // several boxes: stop exchanging halos once the boxes get small (VDN_MG_AGGLOM, default 64) -- every level that stays distributed costs
+    // several boxes: stop exchanging halos once the boxes get small (below 64 cells) -- every level that stays distributed costs
     // ~10 latency-bound halo exchanges per V-cycle, the replicated tail below a 64^3-per-box level costs microseconds per pass
-    static const int agglom = vdn_env("VDN_MG_AGGLOM") ? std::max(4, atoi(vdn_env("VDN_MG_AGGLOM"))) : 64;
+    static const int agglom = 64;
     const int min_dist = nb > 1 ? agglom : 4;
     for (int d = 0; d < 3; d++) if (n[d] / 2 < min_dist || ((n[d] / 2) & 1)) next_dist = false;
     if (!can) break;                                   // the domain cannot be coarsened: this level is the bottom
@@ -1278,9 +1278,9 @@ static void cc_gsrb_d(CCMG &M, CDLev &DL, int nsweeps) {
   // halo exchange next to the pass: when part of the halo comes from another rank (or VDN_OVERLAP=1, the one-GPU rehearsal) the packed
   // traffic -- pack kernels, the ncclSend / ncclRecv group, box-to-box copies, unpack kernels -- runs on ctx().halo_stream while the
   // launch stream updates the cells that read no ghost value; the one-cell shell follows when the halo has landed
-  // Only where the pass is long enough to hide something: boxes of at least VDN_OVERLAP_MIN cells (default 2^20; a 64^3 pass takes 5 us).
+  // Only where the pass is long enough to hide something: boxes of at least 2^20 cells (a 64^3 pass takes 5 us).
   static const int ov_env = vdn_env("VDN_OVERLAP") ? atoi(vdn_env("VDN_OVERLAP")) : -1;
-  static const long ov_min = vdn_env("VDN_OVERLAP_MIN") ? atol(vdn_env("VDN_OVERLAP_MIN")) : (1L << 20);
+  static const long ov_min = 1L << 20;
   bool overlap = DL.halo && (ov_env == 1 || (ov_env != 0 && xplan_has_remote(DL.halo)));
   if (overlap) {
     long cells = 0;
@@ -1378,7 +1378,7 @@ static void cc_bottom_t(const CCMG &M, const CLev &L) {      // max(nub, N^2) sw
 static bool cc_small_end(const CCMG &M, int dl, int tl) {
   static const bool on = !(vdn_env("VDN_MG_TAILCYCLE") && atoi(vdn_env("VDN_MG_TAILCYCLE")) == 0);
   if (!on) return false;
-  static const long tail_cells = vdn_env("VDN_MG_TAIL_CELLS") ? atol(vdn_env("VDN_MG_TAIL_CELLS")) : SMALL_LEVEL_CELLS;     // largest level the one-workgroup cycle takes (measured: 16^3 no gain, MAC 15.33 -> 15.39 ms)
+  static const long tail_cells = SMALL_LEVEL_CELLS;     // largest level the one-workgroup cycle takes (measured: 16^3 no gain, MAC 15.33 -> 15.39 ms)
   const vdn_params &P = ctx().prm;
   CcTailArgs T; memset(&T, 0, sizeof T);
   int nl = 0;
@@ -1526,10 +1526,10 @@ static void cc_fine_seq(CCMG &M, bool after_coarse, bool residual, bool norm, bo
   cc_gsrb_d(M, D0, P.mg_nu1);
   if (residual) cc_residual_d(M, D0, norm, reduce);
 }
-// may level l >= 1 of a V-cycle run as kk_cc_lds_down / kk_cc_lds_up?  (VDN_MG_LDS=0: never; VDN_MG_LDS_MAX: largest extent taken, default 64)
+// may level l >= 1 of a V-cycle run as kk_cc_lds_down / kk_cc_lds_up?  (VDN_MG_LDS=0: never; extents up to 64)
 static bool cc_lds_level(const CCMG &M, int l) {
   static const bool on = !(vdn_env("VDN_MG_LDS") && atoi(vdn_env("VDN_MG_LDS")) == 0);
-  static const int nmax_ = vdn_env("VDN_MG_LDS_MAX") ? atoi(vdn_env("VDN_MG_LDS_MAX")) : 64;
+  static const int nmax_ = 64;                 // (measured in round 5: the 128^3 level of a 256^3 solve as LDS tiles too, MAC 8.98 -> 10.33 ms per step)
   const vdn_params &P = ctx().prm;
   if (!on || l < 1 || l + 1 >= (int)M.dlev.size() || P.mg_nu1 != 2 || P.mg_nu2 != 2 || M.per[0] || M.per[1] || M.per[2]) return false;
   const CDLev &D = M.dlev[l], &DC = M.dlev[l + 1];
@@ -2117,7 +2117,7 @@ void do_macproject(vdn_layout *mla, vdn_multifab **umac, vdn_multifab **rho, vdn
     // the second level must exist (its coefficients come from the first level's rho): boxes that halve cleanly to >= 4 cells, as cc_build asks
     bool ok = fast_on && beta_from_rho() && rho[n]->ng >= 1;
     {   // cc_build's rule for a second DISTRIBUTED level: the domain coarsens, the boxes halve cleanly and stay at least min_dist wide
-      const int agglom = vdn_env("VDN_MG_AGGLOM") ? std::max(4, atoi(vdn_env("VDN_MG_AGGLOM"))) : 64;
+      const int agglom = 64;
       const int min_dist = mla->boxes[n].size() > 1 ? agglom : 4;
       for (const vdn_box &b : mla->boxes[n]) for (int d = 0; d < 3; d++) { const int w = b.hi[d] - b.lo[d] + 1; if ((w & 1) || w / 2 < min_dist || ((w / 2) & 1)) ok = false; }
       for (int d = 0; d < 3; d++) { const int N = mla->pd[n].hi[d] - mla->pd[n].lo[d] + 1; if ((N & 1) || N <= 2) ok = false; }

@@ -208,7 +208,7 @@ DEVI double2 ld2(const double *p) { return *reinterpret_cast<const double2 *>(p)
 // per plane, executed by every lane (lanes that own no node write a 16-byte slot of a scratch line instead), issued BEFORE the loads
 // of the next plane, so that the store's latency hides under theirs.
 __device__ double g_nd_sink[128];
-__device__ int g_nd_dbg = 0;      // VDN_ND_DBG (probe only): 1 = no stencil arithmetic, 2 = no loads inside the march
+__device__ int g_nd_dbg = 0;      // (probe of round 3, always 0 now: 1 = no stencil arithmetic, 2 = no loads inside the march)
 // Round 3 -- the shape of the launch.  (i) A row of 257 nodes is 129 pairs = two full wave rows (62 owned pairs each) and FIVE pairs more:
 // with one tile shape the third tile of every row ran 57 of its 62 pair lanes idle -- a third of all waves of the sweep issued the loads of
 // 8 % of the nodes, and the sweep is bound by the loads it has in flight.  The remainder columns are now covered by waves that pack several
@@ -972,9 +972,7 @@ template <int MODE> static void nd_launch_march(const NLev &L, const double *phi
   static const bool paired = !(vdn_env("VDN_ND_PAIR") && atoi(vdn_env("VDN_ND_PAIR")) == 0);
   if (paired && L.n[0] >= 127) {                   // 124 nodes per wave row
     const int rows = 4;                          // (measured: 8 rows per workgroup 17.1 -> 18.7 ms of HG per step, 16 rows spill)
-    static const bool use_rem = !(vdn_env("VDN_ND_REM") && atoi(vdn_env("VDN_ND_REM")) == 0);
-    static const int minwg = vdn_env("VDN_ND_MINWG") ? atoi(vdn_env("VDN_ND_MINWG")) : 2048;
-    static const int kc_env = vdn_env("VDN_ND_KC") ? atoi(vdn_env("VDN_ND_KC")) : 0;
+    const bool use_rem = true; const int minwg = 2048, kc_env = 0;
     NdPairGrid G = nd_pair_grid(L, rows, nzp, use_rem, minwg, kc_env);
     static const bool flip = !(vdn_env("VDN_ND_REV") && atoi(vdn_env("VDN_ND_REV")) == 0);
     G.rev = flip ? rev : 0;
@@ -1098,9 +1096,9 @@ static void nd_build(NDMG &M, const vdn_multifab *coeffs, const double *dx, cons
     bool can = true, next_dist = true;
     for (int d = 0; d < 3; d++) { const int N = lpd.hi[d] + 1; if ((N & 1) || N <= 2) can = false; }
     if (can) for (int d = 0; d < 3; d++) REQUIRE(!(n[d] & 1), "nodal multigrid: box extent %d is odd while the domain can still be coarsened", n[d]);
-    // several boxes: stop exchanging halos once the boxes get small (VDN_MG_AGGLOM, default 64) -- every level that stays distributed costs
+    // several boxes: stop exchanging halos once the boxes get small (below 64 cells) -- every level that stays distributed costs
     // ~10 latency-bound halo exchanges per V-cycle, the replicated tail below a 64^3-per-box level costs microseconds per pass
-    static const int agglom = vdn_env("VDN_MG_AGGLOM") ? std::max(4, atoi(vdn_env("VDN_MG_AGGLOM"))) : 64;
+    static const int agglom = 64;
     const int min_dist = nb > 1 ? agglom : 4;
     for (int d = 0; d < 3; d++) if (n[d] / 2 < min_dist || ((n[d] / 2) & 1)) next_dist = false;
     if (!can) break;
@@ -1152,7 +1150,7 @@ static bool nd_halo_begin(NDLev &DL) {
   XPlan *P = DL.flip ? DL.halo_B : DL.halo_A;
   if (!P) return false;
   static const int ov_env = vdn_env("VDN_OVERLAP") ? atoi(vdn_env("VDN_OVERLAP")) : -1;
-  static const long ov_min = vdn_env("VDN_OVERLAP_MIN") ? atol(vdn_env("VDN_OVERLAP_MIN")) : (1L << 20);     // see cc_gsrb_d
+  static const long ov_min = 1L << 20;     // see cc_gsrb_d
   long nodes = 0;
   for (const NBox &B : DL.boxes) nodes = std::max(nodes, (long)B.L.n[0] * B.L.n[1] * B.L.n[2]);
   if (!(ov_env == 1 || (ov_env != 0 && xplan_has_remote(P) && nodes >= ov_min))) { xplan_run(P); return false; }
@@ -1329,7 +1327,7 @@ static int nd_bottom_sweeps_global(const NDLev &DL) {
 static bool nd_small_end(NDMG &M, int dl, int tl) {
   static const bool on = !(vdn_env("VDN_MG_TAILCYCLE") && atoi(vdn_env("VDN_MG_TAILCYCLE")) == 0);
   if (!on) return false;
-  static const long tail_nodes = vdn_env("VDN_MG_TAIL_NODES") ? atol(vdn_env("VDN_MG_TAIL_NODES")) : SMALL_LEVEL_NODES;    // largest level the one-workgroup cycle takes (measured: 17^3 is slower, HG 16.9 -> 17.6 ms)
+  static const long tail_nodes = SMALL_LEVEL_NODES;    // largest level the one-workgroup cycle takes (measured: 17^3 is slower, HG 16.9 -> 17.6 ms)
   const vdn_params &P = ctx().prm;
   NdTailArgs T; memset(&T, 0, sizeof T);
   int nl = 0;
@@ -1565,21 +1563,6 @@ int nd_solve(vdn_multifab *rh, vdn_multifab *phi, const vdn_multifab *coeffs, co
     hipLaunchKernelGGL(kk_nd_load, ng3(L0.n[0] + 1, L0.n[1] + 1, std::min(L0.n[2] + 1, 16)), NBLK, 0, st, L0, rh->fabs[b], phi->fabs[b], bx.lo[0], bx.lo[1], bx.lo[2], M.d_nrm);
   }
   comm_allreduce_max_dev(M.d_nrm, 2);
-  {   // VDN_ND_BENCH=n (probe): time n Jacobi sweeps of the finest level here, print the mean, then solve as usual (the sweeps only improve phi)
-    static const int nbench = vdn_env("VDN_ND_BENCH") ? atoi(vdn_env("VDN_ND_BENCH")) : 0;
-    if (nbench > 0) {
-      if (vdn_env("VDN_ND_DBG")) { const int v = atoi(vdn_env("VDN_ND_DBG")); HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(g_nd_dbg), &v, sizeof(int))); }
-      hipEvent_t e0, e1; HIPCHK(hipEventCreate(&e0)); HIPCHK(hipEventCreate(&e1));
-      nd_jacobi_d(M.dlev[0], 2);
-      HIPCHK(hipEventRecord(e0, st));
-      nd_jacobi_d(M.dlev[0], nbench & ~1);
-      HIPCHK(hipEventRecord(e1, st)); HIPCHK(hipEventSynchronize(e1));
-      float ms = 0; HIPCHK(hipEventElapsedTime(&ms, e0, e1));
-      fprintf(stderr, "VDN_ND_BENCH: %d x %d x %d nodes, %.5f ms per Jacobi sweep\n", M.dlev[0].boxes[0].L.n[0] + 1, M.dlev[0].boxes[0].L.n[1] + 1, M.dlev[0].boxes[0].L.n[2] + 1, ms / (nbench & ~1));
-      const int z = 0; HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(g_nd_dbg), &z, sizeof(int)));
-      HIPCHK(hipEventDestroy(e0)); HIPCHK(hipEventDestroy(e1));
-    }
-  }
   const bool single = (M.dlev.size() == 1 && M.tail.empty());
   const bool fixed_cycles = max_iter < 0;     // exactly -max_iter V-cycles, no norms, no convergence test (composite coarse correction)
   double bnorm = 1.0, p0max = 1.0;

@@ -122,7 +122,6 @@ static const EnvSwitch g_switches[] = {
   { "VDN_TESTING", "1: allows VDN_RCCL_LIB (the test transport of tests/fake_rccl); nothing else" },
   { "VDN_RCCL_LIB", "path of a library that stands in for librccl -- honoured only with VDN_TESTING=1 and the test double's handshake" },
   { "VDN_FORCE_PACKED", "1: box-to-box copies of one rank go through the packed per-peer buffers (device memcpy for send/recv); 2: through a 1-rank RCCL communicator (one-GPU rehearsal of the N > 1 transport)" },
-  { "VDN_DEBUG_VIEWS", "print the peers and message sizes of every exchange plan built" },
   { "VDN_ARENA_POISON", "1: every byte handed back to the arena is overwritten with NaNs (a read of an entry nobody wrote fails the next solve)" },
   { "VDN_NO_ROCTX", "do not bind the roctx library (no bl_prof ranges)" },
   { "VDN_POLL", "scalar read-back: 1 spin on the pinned sequence number, 0 hipStreamSynchronize; default: spin on one rank, synchronise on several" },
@@ -134,12 +133,9 @@ static const EnvSwitch g_switches[] = {
   { "VDN_GOD_SLAB_BC", "0: (unfused marches) boundary rules inside the marches instead of the face-centred code on boundary slabs" },
   { "VDN_GODUNOV_PLAIN", "the face-centred one-thread-per-cell Godunov kernels of round 1 (the marching kernels' bit-for-bit reference)" },
   { "VDN_GOD_SEGW", "0: the box-batched fused Godunov marches use full-width (64 x 8) tiles for every box" },
-  { "VDN_GOD_XCD", "0: plain blockIdx order instead of the XCD-aware tile order of the Godunov marches" },
-  { "VDN_KCHUNKS", "k-chunks of the unfused Godunov marches (default 12)" },
   { "VDN_GOD_P2", "0: the fused marches divide by dx also where every dx is a power of two (default there: scale by 1/dx, the same doubles)" },
   { "VDN_FUSED_KCHUNKS", "k-chunks of the fused marches (default: the count that fills the last round of workgroups best)" },
   { "VDN_GOD_FUSED", "0: one march per Godunov stage (B, C, D) instead of the fused B+C+D march" },
-  { "VDN_MK_SPLIT", "components per launch of the unfused mkflux marches (-1: by register budget)" },
   { "VDN_GOD_UPDATE", "0: update_3d as its own pass instead of inside the fused mkflux march" },
   { "VDN_GSRB_PAIR", "0: one cell per thread in the colour passes / residuals of wide levels instead of the 2 x 2 pair form" },
   { "VDN_MAC_SPLIT", "0: the finest level of macproject's one-box solve stays interleaved (kk_cc_gsrb_rho_pair) instead of stored by colour (kk_cc_gsrb_rho_split); 2: only the colour passes on the split arrays, the residual on the level array" },
@@ -148,27 +144,17 @@ static const EnvSwitch g_switches[] = {
   { "VDN_MAC_SLAB", "planes per slab of the time-skewed schedule of the split level's passes (cc_split_run; default: ~200 MB of pass traffic, at most half the level); 0: whole-level launches" },
   { "VDN_MAC_KFLIP", "0: both colour passes of a sweep walk the planes upwards (default: the second colour downwards; paired and split passes of the cell-centred multigrid)" },
   { "VDN_CC_HALO_FACES", "0: the cell-centred multigrid exchanges the whole ghost shell instead of the faces only" },
-  { "VDN_MG_AGGLOM", "several boxes: smallest box extent (cells) of a multigrid level that stays distributed; below it the level is gathered and relaxed on every rank (default 64)" },
   { "VDN_OVERLAP", "halo exchange of multigrid passes next to interior work: 1 always, 0 never, default: when a plan has a remote peer and the box is large" },
-  { "VDN_OVERLAP_MIN", "smallest box (cells / nodes) whose halo exchange is overlapped (default 2^20)" },
   { "VDN_MG_RESTRICT_FUSED", "0: cell-centred residual and restriction as two passes" },
   { "VDN_MG_TAILCYCLE", "0: the smallest levels launch by launch instead of one single-workgroup cycle" },
-  { "VDN_MG_TAIL_CELLS", "largest level (cells) the single-workgroup cell-centred tail cycle takes (default 8^3)" },
-  { "VDN_MG_TAIL_NODES", "largest level (nodes) the single-workgroup nodal tail cycle takes (default 9^3)" },
   { "VDN_MG_PROLONG_FUSED", "0: cell-centred prolongation as its own pass instead of inside the first post-smoothing colour pass" },
   { "VDN_MG_LDS", "0: the 16^3..64^3 cell-centred levels launch by launch instead of the LDS-tiled down / up kernels" },
-  { "VDN_MG_LDS_MAX", "largest level the LDS-tiled kernels take (default 64)" },
   { "VDN_MAC_STORED_BETA", "1: the finest MAC level reads stored face coefficients instead of recomputing them from rho" },
   { "VDN_MAC_FAST", "0: macproject with its rh / phi / beta multifabs as the reference has them" },
   { "VDN_HG_FAST", "0: hgproject with its rh / phi / coeffs multifabs as the reference has them" },
   { "VDN_ND_PAIR", "0: one node per lane in the nodal march instead of the pair form" },
-  { "VDN_ND_REM", "0: remainder columns of the paired nodal march in full-width tiles" },
-  { "VDN_ND_MINWG", "workgroups the paired nodal march aims for when it cuts k-slabs (default 2048)" },
-  { "VDN_ND_KC", "planes per k-slab of the paired nodal march (default: from VDN_ND_MINWG)" },
   { "VDN_ND_LEAN", "0: whole-array zero fills of the big nodal levels instead of shell-only" },
   { "VDN_ND_RESTRICT_FUSED", "0: nodal residual and full weighting as two passes" },
-  { "VDN_ND_BENCH", "n: time n Jacobi sweeps of the finest nodal level inside the next solve and print the mean (probe)" },
-  { "VDN_ND_DBG", "probe only, with VDN_ND_BENCH: 1 no stencil arithmetic, 2 no loads in the march" },
   { "VDN_NDF_SEGW", "0: the marches of the composite nodal solve use power-of-two lane segments per node row only" },
   { "VDN_NDF_PAIR", "0: one node per lane in the box-batched nodal march of the composite solve" },
   { "VDN_NDM_IFACE_FACES", "0: interface interpolation of the composite nodal solve over whole boxes instead of box faces" },
