@@ -159,8 +159,69 @@ template <int NC> __global__ void __launch_bounds__(64 * SNY) kk_slopes_m(FV s, 
   #undef SPEC
   if (vmax) block_atomic_max(vmax, m);
 }
+// The same march without the row exchange (round 5): the y-neighbours of plane k come straight from memory (they are the values the rows next door loaded
+// two planes ago: L2 hits), so there is no LDS, no barrier and no row overlap -- 64 x 4 threads own 60 x 4 cells, several workgroups share a CU.
+// (Measured on this form and not kept: one fromm_of per cell along x and z -- the neighbours' from the lanes next door / carried from plane to plane -- instead of
+// three: 0.659 -> 0.737 ms for three components, 0.390 -> 0.412 for two; the kernel is not bound by its arithmetic.)
+template <int NC> __global__ void __launch_bounds__(256) kk_slopes_my(FV s, FV sl0, FV sl1, FV sl2, GArgs A, Range3 r, int klen, double *vmax) {
+  const int lane = threadIdx.x, row = threadIdx.y;
+  const int i = r.lo[0] - 2 + (int)blockIdx.x * 60 + lane, j = r.lo[1] + (int)blockIdx.y * 4 + row;
+  const bool own_ij = lane >= 2 && lane <= 61 && i <= r.hi[0] && j <= r.hi[1];
+  const int ic = min(max(i, A.lo[0] - 3), A.hi[0] + 3), jc = min(max(j, A.lo[1] - 3), A.hi[1] + 3);
+  const int k0 = r.lo[2] + (int)blockIdx.z * klen, k1 = min(k0 + klen - 1, r.hi[2]);
+  const long sp = (long)s.n0 * s.n1;
+  long oy[4];                                                         // rows j-2, j-1, j+1, j+2 relative to the column (kept inside the allocation like the planes)
+  { const int dj[4] = { -2, -1, 1, 2 };
+    #pragma unroll
+    for (int q = 0; q < 4; q++) oy[q] = (long)(min(max(j + dj[q], A.lo[1] - 3), A.hi[1] + 3) - jc) * s.n0; }
+  const double *ps[NC];
+  #pragma unroll
+  for (int c = 0; c < NC; c++) ps[c] = s.p + fv_idx(s, ic, jc, s.a2) + s.sc * c;
+  #define SPL(c, kk) ps[c][(long)(min(max((kk), A.lo[2] - 3), A.hi[2] + 3) - s.a2) * sp]
+  #define SPY(c, kk, q) ps[c][(long)(min(max((kk), A.lo[2] - 3), A.hi[2] + 3) - s.a2) * sp + oy[q]]
+  #define SPEC(d, sd, c) (A.adv[d][sd][c] == VDN_EXT_DIR || A.adv[d][sd][c] == VDN_HOEXTRAP)
+  double w[NC][5];
+  #pragma unroll
+  for (int c = 0; c < NC; c++) { w[c][0] = 0.0; for (int q = 1; q < 5; q++) w[c][q] = SPL(c, k0 - 3 + q); }
+  double m = 0.0;
+  for (int k = k0; k <= k1; k++) {
+    double y[NC][4];
+    #pragma unroll
+    for (int c = 0; c < NC; c++) {
+      w[c][0] = w[c][1]; w[c][1] = w[c][2]; w[c][2] = w[c][3]; w[c][3] = w[c][4]; w[c][4] = SPL(c, k + 2);
+      #pragma unroll
+      for (int q = 0; q < 4; q++) y[c][q] = SPY(c, k, q);
+    }
+    #pragma unroll
+    for (int c = 0; c < NC; c++) {
+      const double s0 = w[c][2];
+      const double xm1 = lane_prev(s0), xp1 = lane_next(s0), xm2 = lane_prev(xm1), xp2 = lane_next(xp1);
+      if (own_ij) {
+        fv_at(sl0, i, j, k, c) = slope_vals(xm2, xm1, s0, xp1, xp2, i, A.lo[0], A.hi[0], SPEC(0, 0, c), SPEC(0, 1, c), A.slope_order);
+        fv_at(sl2, i, j, k, c) = slope_vals(w[c][0], w[c][1], s0, w[c][3], w[c][4], k, A.lo[2], A.hi[2], SPEC(2, 0, c), SPEC(2, 1, c), A.slope_order);
+        fv_at(sl1, i, j, k, c) = slope_vals(y[c][0], y[c][1], s0, y[c][2], y[c][3], j, A.lo[1], A.hi[1], SPEC(1, 0, c), SPEC(1, 1, c), A.slope_order);
+      }
+      if (own_ij && vmax && i >= A.lo[0] && i <= A.hi[0] && j >= A.lo[1] && j <= A.hi[1] && k >= A.lo[2] && k <= A.hi[2]) m = fmax(m, fabs(s0));
+    }
+  }
+  #undef SPL
+  #undef SPY
+  #undef SPEC
+  if (vmax) block_atomic_max(vmax, m);
+}
 static void launch_slopes(const FV &s, const FV sl[3], const GArgs &A, const Range3 &rg, int ncomp, double *vmax, hipStream_t st) {
   static const bool marching = !(vdn_env("VDN_SLOPES_MARCH") && atoi(vdn_env("VDN_SLOPES_MARCH")) == 0);
+  static const bool yglobal = !(vdn_env("VDN_SLOPES_Y") && atoi(vdn_env("VDN_SLOPES_Y")) == 0);        // 0: the row exchange through LDS (kk_slopes_m: 0.691 / 0.470 ms)
+  if (marching && yglobal && (ncomp == 2 || ncomp == 3) && s.a0 <= A.lo[0] - 3 && s.a1 <= A.lo[1] - 3 && s.a2 <= A.lo[2] - 3) {
+    const int nx = rg.hi[0] - rg.lo[0] + 1, ny = rg.hi[1] - rg.lo[1] + 1, nz = rg.hi[2] - rg.lo[2] + 1;
+    const int tiles = ((nx + 59) / 60) * ((ny + 3) / 4);
+    int chunks = std::max(1, std::min(nz / 8, (32 * 256 + tiles - 1) / tiles));      // (measured at 256^3, three / two components: 4 x 256 workgroups 0.741 / 0.477 ms, 8 x 0.667 / 0.418, 16 x 0.661 / 0.406, 32 x 0.645 / 0.384)
+    const int klen = (nz + chunks - 1) / chunks;
+    const dim3 g((nx + 59) / 60, (ny + 3) / 4, (nz + klen - 1) / klen), blk(64, 4, 1);
+    if (ncomp == 3) hipLaunchKernelGGL(kk_slopes_my<3>, g, blk, 0, st, s, sl[0], sl[1], sl[2], A, rg, klen, vmax);
+    else hipLaunchKernelGGL(kk_slopes_my<2>, g, blk, 0, st, s, sl[0], sl[1], sl[2], A, rg, klen, vmax);
+    return;
+  }
   if (marching && (ncomp == 2 || ncomp == 3) && s.a0 <= A.lo[0] - 3 && s.a1 <= A.lo[1] - 3 && s.a2 <= A.lo[2] - 3) {
     const int nx = rg.hi[0] - rg.lo[0] + 1, ny = rg.hi[1] - rg.lo[1] + 1, nz = rg.hi[2] - rg.lo[2] + 1;
     const int tiles = ((nx + 59) / 60) * ((ny + SNY - 5) / (SNY - 4));

@@ -128,6 +128,7 @@ static const EnvSwitch g_switches[] = {
   { "VDN_NO_GRAPHS", "launch every multigrid cycle eagerly instead of replaying its hipGraph" },
   { "VDN_NO_SLOPE_CACHE", "velocity mkflux recomputes the slopes of uold that velpred computed in the same step" },
   { "VDN_NO_FORCE_REUSE", "1: every forcing term is computed where the reference computes it (advance_premac AND velocity_advance, ...)" },
+  { "VDN_SLOPES_Y", "0: the slopes march exchanges rows through LDS (kk_slopes_m) instead of reading the y-neighbours from memory (kk_slopes_my)" },
   { "VDN_SLOPES_MARCH", "0: the per-cell slopes kernel instead of the k-marching one" },
   { "VDN_GODUNOV_BATCH", "1: the descriptor (box-batched) Godunov kernels also on a level of one box" },
   { "VDN_GOD_SLAB_BC", "0: (unfused marches) boundary rules inside the marches instead of the face-centred code on boundary slabs" },
