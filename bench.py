@@ -421,6 +421,7 @@ def main():
         nthreads = min(16, os.cpu_count() or 1)
         os.environ["OMP_NUM_THREADS"] = str(nthreads)
         from oracle import voracle as vo
+        vo.lib(); vo.set_threads(nthreads)          # (torch's libgomp is in the process already and has read its environment: set the count directly)
         if amr:
             cn = args.cpu_n or 64
             # the oracle's hierarchies hold one box per level: the sample refines the bounding box of the tagged region

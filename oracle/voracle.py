@@ -88,16 +88,28 @@ def build():
 _lib = None
 
 
+def set_threads(n):
+    """OpenMP threads of the oracle from here on (omp_set_num_threads of the libgomp the process holds)"""
+    try:
+        C.CDLL("libgomp.so.1").omp_set_num_threads(int(n))
+    except (OSError, AttributeError):
+        pass
+
+
 def lib():
     global _lib
     if _lib is None:
         if not os.path.exists(LIB):
             build()
         # libgomp sizes its pool from the visible CPUs, which on the GPU boxes is far more than the
-        # cgroup share; oversubscribed spinning threads make the many tiny parallel regions crawl
+        # cgroup share; oversubscribed spinning threads make the many tiny parallel regions crawl.  (With the count right the threads may spin:
+        # OMP_WAIT_POLICY=passive costs the many small parallel regions a factor of four here.)
         os.environ.setdefault("OMP_NUM_THREADS", str(min(8, os.cpu_count() or 1)))
-        os.environ.setdefault("OMP_WAIT_POLICY", "passive")
         _lib = C.CDLL(LIB)
+        # a libgomp that was already in the process (torch brings one and initialises it on import, before the lines above could matter) has read its
+        # environment long ago: tell it directly (round 5: the GPU suite collected a module that imports torch first, and the oracle ran on ~200 threads
+        # of a 16-core share -- five to ten times slower)
+        set_threads(int(os.environ["OMP_NUM_THREADS"]))
         _lib.vo_estdt.restype = C.c_double
         _lib.vo2_estdt.restype = C.c_double
         _lib.vo_cc_solve.restype = C.c_int

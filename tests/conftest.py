@@ -8,6 +8,8 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 
+# before anything imports torch (its libgomp reads this once, and the oracle shares that runtime): the oracle's threads
+os.environ.setdefault("OMP_NUM_THREADS", str(min(8, os.cpu_count() or 1)))
 os.environ.setdefault("VO_POISON", "1")      # the oracle's work arrays are handed out full of NaN: a read of an unset entry shows up (oracle/vo_godunov.c)
 
 
