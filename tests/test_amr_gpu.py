@@ -451,7 +451,7 @@ def test_tagged_hierarchy_against_the_box_list_oracle(gpu, oracle, nc, max_levs,
     """BASELINE.json configs[3] / [4] in small: the refined levels are the boxes make_new_grids returns for the tagged bubble (tag_boxes.f90:65-94: rho > 1.01 /
     rho > 1.1) -- unions that are not rectangles, re-entrant interface edges, boxes of a few cells -- and the ORACLE RUNS THE SAME BOX LISTS (oracle/vo.h:
     level arrays with a cell mask, MAC velocities and the Godunov kernels box by box; VERDICT r4 missing 3).  Start-up (initial projection + one pressure
-    iteration) and one or two steps: dt bit for bit, the FAC iteration counts of both composite solves equal in every call, u / rho / tracer to 1e-9 on every box
+    iteration) and two steps: dt bit for bit, the FAC iteration counts of both composite solves equal in every call, u / rho / tracer to 1e-9 on every box
     of every level, the pressure to 1e-6; and the composite mass is conserved to round-off (the conservative fluxes are restricted, mkflux.f90:137-146).
     Cases: the inviscid bubble between walls (the bench's configuration); the same with visc_coef = 0.001 as exec/test/inputs_bubble_3d and inputs_3d-regt
     have it (explicit diffusive term + composite Crank-Nicolson solves per velocity component); the advected blob of inputs_advect_3d (prob_type 2, inflow /
@@ -495,7 +495,7 @@ def test_tagged_hierarchy_against_the_box_list_oracle(gpu, oracle, nc, max_levs,
                 m += (G.sold[n].to_numpy(i)[3:-3, 3:-3, 3:-3, 0] * msk[sl]).sum() / 8.0 ** n
         return m
     m0 = mass()
-    for step in range(2 if (nc, case) == (32, "bubble") else 1):          # (two steps for the 32^3 bubble, one for the others: the oracle takes 10-25 s per step of those, the GPU suite has 900 s)
+    for step in range(2):
         O.step(); G.step()
         assert G.dt == O.dt, "dt diverged at step %d: %r vs %r" % (step, G.dt, O.dt)
         cg = (adv.last_solver_stats("mac")[0], adv.last_solver_stats("hg")[0])
@@ -519,7 +519,7 @@ def test_tagged_hierarchy_against_the_box_list_oracle(gpu, oracle, nc, max_levs,
 
 def test_regridding_run_against_the_box_list_oracle(gpu, oracle):
     """the time loop WITH regridding (src/varden.f90:256-264, src/regrid.f90: tag_boxes + make_new_grids every regrid_int steps, fillpatch,
-    ml_nodal_prolongation, copies between the old and the new box lists) on both sides: three levels on a 32^3 base, regrid_int = 2, four steps (two
+    ml_nodal_prolongation, copies between the old and the new box lists) on both sides: three levels on a 32^3 base, regrid_int = 2, six steps (three
     regrids on the moving bubble).  The oracle takes the box lists the GPU's make_new_grids returns and moves ITS OWN state onto them
     (voracle.SimML.regrid); from then on the two runs must go on agreeing: dt bit for bit, equal FAC counts, u / rho to 1e-9 on every box."""
     from varden_amd import advance as adv
@@ -532,7 +532,7 @@ def test_regridding_run_against_the_box_list_oracle(gpu, oracle):
                          regrid_int=2, max_levs=3, max_grid_size=32)
     O = vo.SimML(nc, levels, WALLS, prm=default_params(cflfac=0.9), init_shrink=0.1, init_iter=1, do_initial_projection=1)
     nreg = 0
-    for step in range(4):
+    for step in range(6):
         G.step()
         if G.nregrids != nreg:                              # the GPU regridded at the top of this step: the oracle follows with the same grids
             nreg = G.nregrids
@@ -553,7 +553,7 @@ def test_regridding_run_against_the_box_list_oracle(gpu, oracle):
                     b = om.valid()[tuple(slice(lo[d] - olo[d], hi[d] - olo[d] + 1) for d in range(3))]
                     err = float(np.abs(a - b).max())
                     assert err <= 1e-9 * scale, "level %d box %d step %d: %s differs by %.3e (scale %.3e)" % (n, i, step, nm, err, scale)
-    assert nreg == 2, nreg
+    assert nreg == 3, nreg
     G.close()
 
 
