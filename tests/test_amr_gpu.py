@@ -446,13 +446,14 @@ INOUT_BC = [[11, 12], [15, 15], [15, 15]]          # inputs_advect_3d: inflow x-
 
 
 @pytest.mark.parametrize("nc,max_levs,case", [(32, 2, "bubble"), (32, 3, "bubble"), (64, 2, "bubble"), (64, 3, "bubble"), (32, 3, "bubble-viscous"), (32, 3, "advect-viscous"),
-                                              (32, 3, "bubble-base-in-eight")])
+                                              (32, 3, "bubble-base-in-eight"), (128, 2, "bubble"), (128, 3, "bubble")])
 def test_tagged_hierarchy_against_the_box_list_oracle(gpu, oracle, nc, max_levs, case):
     """BASELINE.json configs[3] / [4] in small: the refined levels are the boxes make_new_grids returns for the tagged bubble (tag_boxes.f90:65-94: rho > 1.01 /
     rho > 1.1) -- unions that are not rectangles, re-entrant interface edges, boxes of a few cells -- and the ORACLE RUNS THE SAME BOX LISTS (oracle/vo.h:
     level arrays with a cell mask, MAC velocities and the Godunov kernels box by box; VERDICT r4 missing 3).  Start-up (initial projection + one pressure
     iteration) and two steps: dt bit for bit, the FAC iteration counts of both composite solves equal in every call, u / rho / tracer to 1e-9 on every box
     of every level, the pressure to 1e-6; and the composite mass is conserved to round-off (the conservative fluxes are restricted, mkflux.f90:137-146).
+    Bases of 32^3, 64^3 and 128^3 cells (the last: half the linear size of configs[3] / [4], one step; three levels there resolve the bubble like a 512^3 grid).
     Cases: the inviscid bubble between walls (the bench's configuration); the same with visc_coef = 0.001 as exec/test/inputs_bubble_3d and inputs_3d-regt
     have it (explicit diffusive term + composite Crank-Nicolson solves per velocity component); the advected blob of inputs_advect_3d (prob_type 2, inflow /
     outflow: Dirichlet sides in both composite solves, inhomogeneous boundary data in the viscous ones)."""
@@ -495,7 +496,7 @@ def test_tagged_hierarchy_against_the_box_list_oracle(gpu, oracle, nc, max_levs,
                 m += (G.sold[n].to_numpy(i)[3:-3, 3:-3, 3:-3, 0] * msk[sl]).sum() / 8.0 ** n
         return m
     m0 = mass()
-    for step in range(2):
+    for step in range(1 if nc == 128 else 2):                 # (128^3 base: half the linear size of configs[3], one step)
         O.step(); G.step()
         assert G.dt == O.dt, "dt diverged at step %d: %r vs %r" % (step, G.dt, O.dt)
         cg = (adv.last_solver_stats("mac")[0], adv.last_solver_stats("hg")[0])
