@@ -261,7 +261,7 @@ def test_multigrid_launch_variants_agree_bit_for_bit(gpu):
         # remainder tile column in full 64-lane tiles -- against one barrier and narrow segments
         # round 5 also: the first two runs keep the finest MAC level by colour (VDN_MAC_SPLIT_MIN=0: from any size), the third interleaved; the second and third
         # walk every colour pass / nodal march in the same order (VDN_MAC_KFLIP=0, VDN_ND_REV=0); the first in two plane slabs (cc_split_run), the second in whole-level launches
-        for extra in ({"VDN_MAC_SPLIT_MIN": "0"}, {"VDN_GOD_1B": "0", "VDN_GOD_NARROW": "0", "VDN_SLOPES_Y": "0", "VDN_MAC_SPLIT_MIN": "0", "VDN_MAC_KFLIP": "0", "VDN_ND_REV": "0", "VDN_MAC_SLAB": "0"},
+        for extra in ({"VDN_MAC_SPLIT_MIN": "0"}, {"VDN_GOD_1B": "0", "VDN_GOD_NARROW": "0", "VDN_SLOPES_Y": "0", "VDN_MAC_SPLIT_MIN": "0", "VDN_MAC_KFLIP": "0", "VDN_ND_REV": "0", "VDN_MAC_SLAB": "0", "VDN_NO_GRAPHS": "1"},
                       {"VDN_MAC_KFLIP": "0", "VDN_ND_REV": "0", "VDN_MAC_SPLIT": "0", "VDN_ND_PAIR": "0", "VDN_MAC_STORED_BETA": "1", "VDN_NO_SLOPE_CACHE": "1", "VDN_CC_HALO_FACES": "0",
                        "VDN_GOD_SLAB_BC": "0", "VDN_GODUNOV_BATCH": "1", "VDN_MG_PROLONG_FUSED": "0", "VDN_MG_RESTRICT_FUSED": "0", "VDN_MG_TAILCYCLE": "0", "VDN_MG_LDS": "0", "VDN_NO_GRAPHS": "1",
                           "VDN_HG_FAST": "0", "VDN_MAC_FAST": "0", "VDN_ND_LEAN": "0", "VDN_NO_FORCE_REUSE": "1", "VDN_GOD_UPDATE": "0", "VDN_GOD_P2": "0", "VDN_ND_RESTRICT_FUSED": "0"}):
