@@ -254,7 +254,7 @@ def test_multigrid_launch_variants_agree_bit_for_bit(gpu):
         print("HASH", h.hexdigest(), G.dt)
     """ % root)
     switches = ("VDN_MG_PROLONG_FUSED", "VDN_MG_RESTRICT_FUSED", "VDN_MG_TAILCYCLE", "VDN_MG_LDS", "VDN_NO_GRAPHS", "VDN_HG_FAST", "VDN_MAC_FAST", "VDN_ND_LEAN", "VDN_NO_FORCE_REUSE", "VDN_GOD_UPDATE", "VDN_GOD_P2", "VDN_ND_RESTRICT_FUSED", "VDN_GOD_1B", "VDN_GOD_NARROW", "VDN_MAC_SPLIT", "VDN_MAC_SPLIT_MIN", "VDN_MAC_KFLIP", "VDN_ND_REV", "VDN_MAC_SLAB",
-                "VDN_SLOPES_Y", "VDN_ND_PAIR", "VDN_MAC_STORED_BETA", "VDN_NO_SLOPE_CACHE", "VDN_CC_HALO_FACES", "VDN_GOD_SLAB_BC", "VDN_GODUNOV_BATCH")
+                "VDN_SLOPES_Y", "VDN_MAC_UMAX", "VDN_ND_PAIR", "VDN_MAC_STORED_BETA", "VDN_NO_SLOPE_CACHE", "VDN_CC_HALO_FACES", "VDN_GOD_SLAB_BC", "VDN_GODUNOV_BATCH")
     for n, visc in ((128, 0.0), (64, 0.01)):
         out = []
         # third run (round 5): the defaults with the fused mkflux + update march in its round-4 form -- three workgroup barriers per plane, the
@@ -262,7 +262,7 @@ def test_multigrid_launch_variants_agree_bit_for_bit(gpu):
         # round 5 also: the first two runs keep the finest MAC level by colour (VDN_MAC_SPLIT_MIN=0: from any size), the third interleaved; the second and third
         # walk every colour pass / nodal march in the same order (VDN_MAC_KFLIP=0, VDN_ND_REV=0); the first in two plane slabs (cc_split_run), the second in whole-level launches
         for extra in ({"VDN_MAC_SPLIT_MIN": "0"}, {"VDN_GOD_1B": "0", "VDN_GOD_NARROW": "0", "VDN_SLOPES_Y": "0", "VDN_MAC_SPLIT_MIN": "0", "VDN_MAC_KFLIP": "0", "VDN_ND_REV": "0", "VDN_MAC_SLAB": "0", "VDN_NO_GRAPHS": "1"},
-                      {"VDN_MAC_KFLIP": "0", "VDN_ND_REV": "0", "VDN_MAC_SPLIT": "0", "VDN_ND_PAIR": "0", "VDN_MAC_STORED_BETA": "1", "VDN_NO_SLOPE_CACHE": "1", "VDN_CC_HALO_FACES": "0",
+                      {"VDN_MAC_KFLIP": "0", "VDN_ND_REV": "0", "VDN_MAC_SPLIT": "0", "VDN_MAC_UMAX": "0", "VDN_ND_PAIR": "0", "VDN_MAC_STORED_BETA": "1", "VDN_NO_SLOPE_CACHE": "1", "VDN_CC_HALO_FACES": "0",
                        "VDN_GOD_SLAB_BC": "0", "VDN_GODUNOV_BATCH": "1", "VDN_MG_PROLONG_FUSED": "0", "VDN_MG_RESTRICT_FUSED": "0", "VDN_MG_TAILCYCLE": "0", "VDN_MG_LDS": "0", "VDN_NO_GRAPHS": "1",
                           "VDN_HG_FAST": "0", "VDN_MAC_FAST": "0", "VDN_ND_LEAN": "0", "VDN_NO_FORCE_REUSE": "1", "VDN_GOD_UPDATE": "0", "VDN_GOD_P2": "0", "VDN_ND_RESTRICT_FUSED": "0"}):
             env = dict(os.environ)

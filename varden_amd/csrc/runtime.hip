@@ -143,6 +143,7 @@ static const EnvSwitch g_switches[] = {
   { "VDN_MAC_SPLIT_MIN", "fewest cells of a level stored by colour (default 2^23)" },
   { "VDN_ND_REV", "0: every march of a nodal level walks its tiles in the same order (default: consecutive marches alternate)" },
   { "VDN_MAC_SLAB", "planes per slab of the time-skewed schedule of the split level's passes (cc_split_run; default: ~200 MB of pass traffic, at most half the level); 0: whole-level launches" },
+  { "VDN_MAC_UMAX", "0: max |umac| by its own pass (kk_macmax) instead of inside macproject's velocity update (kk_mkumac_rho_max)" },
   { "VDN_MAC_KFLIP", "0: both colour passes of a sweep walk the planes upwards (default: the second colour downwards; paired and split passes of the cell-centred multigrid)" },
   { "VDN_CC_HALO_FACES", "0: the cell-centred multigrid exchanges the whole ghost shell instead of the faces only" },
   { "VDN_OVERLAP", "halo exchange of multigrid passes next to interior work: 1 always, 0 never, default: when a plan has a remote peer and the box is large" },
