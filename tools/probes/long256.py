@@ -6,7 +6,10 @@ from varden_amd import driver, advance as adv
 from varden_amd.capi import default_params
 ns = int(sys.argv[1]) if len(sys.argv) > 1 else 300
 n = int(sys.argv[2]) if len(sys.argv) > 2 else 256
-G = driver.Varden(n, [[15, 15]] * 3, default_params(cflfac=0.9), init_shrink=0.1, init_iter=1, swap_state=True)
+extra = {}
+for a in sys.argv[3:]:                         # further vdn_params fields as name=value (e.g. hg_omega_pre1=0 hg_omega_pre2=0: plain damping in the pre-smoothing sweeps)
+    k, v = a.split("="); extra[k] = float(v)
+G = driver.Varden(n, [[15, 15]] * 3, default_params(cflfac=0.9, **extra), init_shrink=0.1, init_iter=1, swap_state=True)
 for it in range(ns):
     try:
         G.step()
