@@ -161,6 +161,8 @@ template <int NC> __global__ void __launch_bounds__(64 * SNY) kk_slopes_m(FV s, 
 }
 // The same march without the row exchange (round 5): the y-neighbours of plane k come straight from memory (they are the values the rows next door loaded
 // two planes ago: L2 hits), so there is no LDS, no barrier and no row overlap -- 64 x 4 threads own 60 x 4 cells, several workgroups share a CU.
+// (Counters: 1.77 GB fetched per three-component launch for 0.43 GB of s -- the row and plane halos of neighbouring tiles rarely meet in one L2.  Measured and not
+// kept: the XCD-aware tile order of the other marches (xcd_tile) 0.645 -> 0.674 ms, with 64 x 8 workgroups 0.87 ms; fewer k-chunks no better.)
 // (Measured on this form and not kept: one fromm_of per cell along x and z -- the neighbours' from the lanes next door / carried from plane to plane -- instead of
 // three: 0.659 -> 0.737 ms for three components, 0.390 -> 0.412 for two; the kernel is not bound by its arithmetic.)
 template <int NC> __global__ void __launch_bounds__(256) kk_slopes_my(FV s, FV sl0, FV sl1, FV sl2, GArgs A, Range3 r, int klen, double *vmax) {
