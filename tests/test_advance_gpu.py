@@ -144,6 +144,33 @@ def test_long_run_stays_with_the_oracle(gpu):
     G.close()
 
 
+def test_inviscid_run_through_the_impact_stays_with_the_oracle(gpu):
+    """the bench's configuration (inviscid blob between walls, cflfac 0.9) at 64^3 for 100 steps: the blob reaches the floor near step 45, |u| jumps from 3 to 7
+    and the density starts to leave its bounds (at 128^3 for 170 steps: tools/long_vs_oracle_inviscid.py, 1e-14).  Every step: dt to 1e-12, the
+    V-cycle counts of both projections equal; every 20 steps u and rho within 1e-11 of the oracle's."""
+    from oracle import voracle as vo
+    from varden_amd import advance as adv
+    from varden_amd import driver
+    kw = dict(prob_type=1, grav=-9.8, init_shrink=0.1, init_iter=1)
+    O = vo.Sim(64, WALLS, params_for(WALLS, cflfac=0.9), **kw)
+    G = driver.Varden(64, WALLS, params_for(WALLS, cflfac=0.9), **kw)
+    umax = 0.0
+    for step in range(100):
+        O.step(); G.step()
+        assert abs(G.dt - O.dt) <= 1e-12 * O.dt, "dt diverged at step %d: %r vs %r" % (step, G.dt, O.dt)      # (the fields agree to ~1e-14, not to the bit: neither does their max norm)
+        cg = (adv.last_solver_stats("mac")[0], adv.last_solver_stats("hg")[0])
+        co = (O.mgstat[0].cycles, O.mgstat[1].cycles)
+        assert cg == co, "step %d: V-cycle counts (MAC, HG) %r on the GPU, %r in the oracle" % (step, cg, co)
+        if step % 20 == 19:
+            for nm, gm, om in (("u", G.unew[0], O.unew), ("s", G.snew[0], O.snew)):
+                a, b = gm.to_numpy()[3:-3, 3:-3, 3:-3], om.valid()
+                scale = float(np.abs(b).max())
+                assert float(np.abs(a - b).max()) <= 1e-11 * scale, "step %d: %s differs by %.3e (scale %.3e)" % (step, nm, np.abs(a - b).max(), scale)
+            umax = max(umax, float(np.abs(O.unew.valid()).max()))
+    assert umax > 5.0, "the blob should have hit the floor (max |u| %.2f)" % umax
+    G.close()
+
+
 @pytest.mark.parametrize("phys", [WALLS, PER, INOUT], ids=["walls", "periodic", "inout"])
 def test_handle_swap_equals_copy(gpu, phys):
     """`swap_state=True` (what bench.py runs: uold <- unew by exchanging the multifab handles instead of varden.f90:323-326's copy of the
