@@ -1101,7 +1101,7 @@ static void cc_from_split(const CDLev &DL) {
 static bool cc_split_ok(const CCMG &M) {
   static const bool dflt = !(vdn_env("VDN_GSRB_PAIR") && atoi(vdn_env("VDN_GSRB_PAIR")) == 0) && !(vdn_env("VDN_MG_RESTRICT_FUSED") && atoi(vdn_env("VDN_MG_RESTRICT_FUSED")) == 0) &&
                            !(vdn_env("VDN_MG_PROLONG_FUSED") && atoi(vdn_env("VDN_MG_PROLONG_FUSED")) == 0);
-  if (!mac_split_on() || !dflt || M.dlev.size() < 2 || ctx().prm.mg_nu2 < 1 || M.per[0] || M.per[1] || M.per[2]) return false;
+  if (!mac_split_on() || !dflt || M.dlev.size() < 2 || ctx().prm.mg_nu1 < 1 || ctx().prm.mg_nu2 < 1 || M.per[0] || M.per[1] || M.per[2]) return false;
   const CDLev &D0 = M.dlev[0];
   if (!(D0.single_box && D0.boxes.size() == 1 && !D0.halo && M.dlev[1].boxes.size() == 1)) return false;
   const CLev &L = D0.boxes[0].L;
@@ -1477,6 +1477,9 @@ static void cc_prolong_smooth(CCMG &M, int l, int nsweeps) {
 // plane k' - 1 before pass p - 1 has read it for k'), so a slab of VDN_MAC_SLAB planes goes through ALL passes while it sits in the 256 MB Infinity
 // Cache: nine launches over the whole level read each of its six arrays nine times from HBM, the slabs read them about once.  Cells of a colour do not
 // read each other and the residual only reads: the order changes no bit.  VDN_MAC_SLAB=0: whole-level launches.
+// (The residual also WRITES the next level -- its right-hand side and a zero phi -- while the first two passes of a later slab still READ that phi, the correction
+// they add: coarse plane K is zeroed once the fine planes up to 2K + 2 have seen the LAST pass, R - 1 >= 3 planes behind the first; the first pass on plane k
+// reads coarse planes (k >> 1) - 1 .. (k >> 1) + 1 with k at least R - 1 planes ahead of that, i.e. coarse planes the residual has not reached.)
 // Measured at 256^3 (MAC solve per step): whole-level launches 10.03 ms; slabs of 32 / 48 / 64 / 96 / 128 planes 10.66 / 10.28 / 9.86 / 9.65 / 9.44 ms -- a pass
 // served from the cache takes 0.069 ms per 256 planes against 0.090 from HBM, and every launch costs its ramp and tail.  The default:
 // the planes whose pass traffic (24 B per cell of the level) adds up to ~200 MB -- what stays in the cache between two passes over it; at most half the level.
