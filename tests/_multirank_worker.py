@@ -54,6 +54,8 @@ def one_rank(rank, nranks, pkg):
         out["s%d" % gi] = G.snew[0].to_numpy(li)[3:-3, 3:-3, 3:-3]
         out["p%d" % gi] = G.p[0].to_numpy(li)[1:-1, 1:-1, 1:-1]
     np.savez(outprefix + ".%d.npz" % rank, **out)
+    with open(outprefix + ".%d.form" % rank, "w") as f:        # how the last MAC solve kept its finest level (vdn_last_mac_level_form)
+        f.write("%d\n" % pkg.capi.load().vdn_last_mac_level_form())
     G.close()
 
 

@@ -104,6 +104,24 @@ def test_two_ranks_of_128_cubed_with_the_default_overlap_rule(gpu, tmp_path, mon
         assert np.array_equal(ref[k], got[k]), "%s differs: max %.3e" % (k, np.abs(ref[k] - got[k]).max())
 
 
+def test_two_ranks_with_the_finest_mac_level_by_colour(gpu, tmp_path, monkeypatch):
+    """round 6: macproject's finest level stored by colour on two ranks (VDN_MAC_SPLIT_MIN=0: from any size; by default from 2^23 cells per rank, i.e. configs[2]'s
+    256^3 box per GPU): the ghost entries of one colour travel through the packed buffers of the split arrays' own plan, on the halo stream next to the interior
+    cells, the shell kernel behind them (the library's own overlap rule), the coarse correction inside the first sweep, residual + restriction per box.
+    One step of two 128^3 boxes against ONE rank with the level interleaved (round 5's form): the same bits."""
+    monkeypatch.setenv("VDN_OVERLAP", "-1")
+    monkeypatch.setenv("VDN_MAC_SPLIT", "0")
+    ref = run_ranks(tmp_path, "ref", 1, (2, 1, 1), (256, 128, 128), 1, False)
+    monkeypatch.delenv("VDN_MAC_SPLIT")
+    monkeypatch.setenv("VDN_MAC_SPLIT_MIN", "0")
+    got = run_ranks(tmp_path, "mr", 2, (2, 1, 1), (256, 128, 128), 1, False)
+    assert np.array_equal(ref["dt"], got["dt"]), (ref["dt"], got["dt"])
+    for k in sorted(ref):
+        assert np.array_equal(ref[k], got[k]), "%s differs: max %.3e" % (k, np.abs(ref[k] - got[k]).max())
+    forms = sorted(open(str(tmp_path / ("mr.%d.form" % r))).read().strip() for r in range(2))
+    assert forms == ["1", "1"], forms          # (vdn_last_mac_level_form on both ranks: the split level ran)
+
+
 def _ngpus():
     import torch
     return torch.cuda.device_count()          # counting devices does not initialise the GPU

@@ -133,6 +133,33 @@ def test_split_colour_level_matches_the_oracle_and_the_interleaved_level(gpu, or
     assert out[0] == out[1] == out[2], (bcname, out)
 
 
+@pytest.mark.parametrize("bcname,n,nb", [("periodic", (132, 36, 40), (1, 1, 1)), ("periodicyz", (132, 36, 40), (1, 1, 1)), ("walls", (264, 128, 128), (2, 1, 1)),
+                                         ("periodicx", (264, 128, 128), (2, 1, 1)), ("inout", (132, 256, 256), (1, 2, 2))])
+def test_split_colour_level_with_a_halo(gpu, oracle, bcname, n, nb):
+    """round 6: the level by colour also where a ghost exchange runs between the passes -- periodic faces of one box (the box is its own neighbour), several boxes
+    (two along x: the ghost ENTRY -1 / nh of a row; 1 x 2 x 2: ghost rows and planes; x periodic with two boxes: each the other's neighbour on both sides).  The exchange
+    runs on the split arrays (cc_split_plan: phi of one colour in the index space halved along x), the correction of the coarse level rides in the first sweep with the
+    coarse level's ghost cells exchanged, residual + restriction per box.  Against the oracle in the first run; the same bits (a) split, (b) split with the exchange on
+    the halo stream next to the interior cells and the shell kernel behind it (VDN_OVERLAP=1), (c) split through the packed per-peer buffers (VDN_FORCE_PACKED=1: the
+    path to another rank), (d) interleaved (round 5's form of these levels).  Boxes of 132 x 128 x 128 cells: the smallest that keep a second distributed level."""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out, form = [], []
+    variants = ({"VDN_MAC_SPLIT_MIN": "0"}, {"VDN_MAC_SPLIT_MIN": "0", "VDN_OVERLAP": "1", "VDN_WORKER_ORACLE": "0"},
+                {"VDN_MAC_SPLIT_MIN": "0", "VDN_FORCE_PACKED": "1", "VDN_WORKER_ORACLE": "0"}, {"VDN_MAC_SPLIT": "0", "VDN_WORKER_ORACLE": "0"})
+    for extra in variants:
+        env = dict(os.environ)
+        for k in ("VDN_MAC_SPLIT", "VDN_MAC_SPLIT_MIN", "VDN_MAC_KFLIP", "VDN_MAC_SLAB", "VDN_OVERLAP", "VDN_FORCE_PACKED", "VDN_MAC_SPLIT_HALO"):
+            env.pop(k, None)
+        env.update(extra)
+        r = subprocess.run([sys.executable, os.path.join(root, "tests", "_split_worker.py"), bcname] + [str(v) for v in n + nb], env=env, capture_output=True, text=True, timeout=900, cwd=root)
+        assert r.returncode == 0, r.stderr[-2000:]
+        out.append([ln for ln in r.stdout.splitlines() if ln.startswith("HASH")][0])
+        form.append([ln for ln in r.stdout.splitlines() if ln.startswith("FORM")][0])
+    assert form == ["FORM 1", "FORM 1", "FORM 1", "FORM 0"], form
+    assert out[0] == out[1] == out[2] == out[3], (bcname, out)
+
+
 def test_blown_up_field_fails_loudly(gpu, oracle):
     """the norms are NaN-propagating (a NaN residual used to read as 0 = converged) and a failed solve fails the call,
     as FBoxLib's solvers abort on max_iter; abort_on_max_iter = 0 restores report-and-continue"""

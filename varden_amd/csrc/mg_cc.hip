@@ -246,7 +246,9 @@ __global__ void __launch_bounds__(256) kk_cc_from_split(CLev L, CSplit S) {
 // a thread owns entries ih, ih + 1 of a row (A, B); a wave a row segment of 128 entries = 256 cells; 8 rows per workgroup.  ADD as in kk_cc_gsrb_rho_pair_t:
 // the parent of entry ih is coarse cell ih.
 // planes k0 .. k0 + gridDim.z - 1 (kdown: from the top of that range)
-template <int ADD> __global__ void __launch_bounds__(512) kk_cc_gsrb_rho_split(CLev L, CSplit S, int color, CLev C, int kdown, int k0) {
+// hm != 0 (levels with a halo, the exchange in flight on the halo stream): the cells of the one-cell shell behind the faces of `hm` keep their value; kk_cc_gsrb_split_shell
+// updates them once the halo has landed (ADD passes run whole, after their exchange)
+template <int ADD> __global__ void __launch_bounds__(512) kk_cc_gsrb_rho_split(CLev L, CSplit S, int color, CLev C, int kdown, int k0, int hm) {
   const int lane = threadIdx.x, k = k0 + (kdown ? (int)gridDim.z - 1 - (int)blockIdx.z : (int)blockIdx.z);
   const int t = blockIdx.x * 64 + lane, nh = L.n[0] / 2;
   const int jr = blockIdx.y * 8 + threadIdx.y, j = min(jr, L.n[1] - 1);
@@ -256,9 +258,10 @@ template <int ADD> __global__ void __launch_bounds__(512) kk_cc_gsrb_rho_split(C
   const long c = sidx(S, ih, j, k);
   const double *po = S.phi[color], *px = S.phi[1 - color], *ro = S.rho[color], *rx = S.rho[1 - color];
   // the other colour's entry outside the wave's span: ih - 1 (p = 0, first lane) or ih + 2 (p = 1, last lane).  At the two ends of a row that is a ghost cell of the
-  // box -- a physical face here (cc_split_ok): phi is zero there, and rho only enters the coefficient of a Dirichlet face (beta_of) -- so its line is fetched for those only
+  // box: behind a Neumann face phi is zero there and the coefficient is zero whatever rho holds (beta_of), so its line is not fetched; behind a Dirichlet face (rho enters
+  // the coefficient), a neighbouring box or a periodic image (round 6: levels with a halo) it is
   double ep = 0.0, er = 0.0;
-  if ((p == 0 && lane == 0 && (t > 0 || L.fold[0][0] == VDN_BC_DIR)) || (p == 1 && lane == 63 && (ih + 2 < nh || L.fold[0][1] == VDN_BC_DIR))) { const long o = c + (p ? 2 : -1); ep = px[o]; er = rx[o]; }
+  if ((p == 0 && lane == 0 && (t > 0 || L.fold[0][0] != VDN_BC_NEU)) || (p == 1 && lane == 63 && (ih + 2 < nh || L.fold[0][1] != VDN_BC_NEU))) { const long o = c + (p ? 2 : -1); ep = px[o]; er = rx[o]; }
   #define LDS2(v, off) (*reinterpret_cast<const double2 *>((v) + c + (off)))
   const double2 PO = LDS2(po, 0), RH = LDS2(S.rh[color], 0), RO = LDS2(ro, 0);
   const double2 PX = LDS2(px, 0), PYm = LDS2(px, -S.sy), PYp = LDS2(px, S.sy), PZm = LDS2(px, -S.sz), PZp = LDS2(px, S.sz);
@@ -289,10 +292,38 @@ template <int ADD> __global__ void __launch_bounds__(512) kk_cc_gsrb_rho_split(C
   double Ap, diag;
   double2 out = make_double2(pa[0], pb[0]);
   cc_apply_rho_vals(L, 2 * ih + p, j, k, pa, ra, Ap, diag);
-  if (diag != 0.0) out.x = pa[0] + (RH.x - Ap) / diag;
+  if (diag != 0.0 && !(hm && cc_is_shell(L, 2 * ih + p, j, k, hm))) out.x = pa[0] + (RH.x - Ap) / diag;
   cc_apply_rho_vals(L, 2 * ih + 2 + p, j, k, pb, rb, Ap, diag);
-  if (diag != 0.0) out.y = pb[0] + (RH.y - Ap) / diag;
+  if (diag != 0.0 && !(hm && cc_is_shell(L, 2 * ih + 2 + p, j, k, hm))) out.y = pb[0] + (RH.y - Ap) / diag;
   *reinterpret_cast<double2 *>(S.phi[color] + c) = out;
+}
+// one value of a field stored by colour: cell (i, j, k), ghost layer included (i = -1: entry -1 of an odd row)
+DEVI double split_get(double *const v[2], const CSplit &S, int i, int j, int k) {
+  const int p = i & 1, c = (i + j + k) & 1;
+  return v[c][sidx(S, (i - p) >> 1, j, k)];
+}
+// the shell cells of one colour on the split level (kk_cc_gsrb_shell's job and face ownership): cell by cell through split_get, cc_apply_rho_vals' expressions
+__global__ void __launch_bounds__(256) kk_cc_gsrb_split_shell(CLev L, CSplit S, int color, int hm) {
+  int f = 0;
+  for (int z = blockIdx.z;; f++) if ((hm >> f) & 1) { if (z == 0) break; z--; }      // blockIdx.z-th face of the mask
+  const int d = f >> 1, side = f & 1;
+  const int a = blockIdx.x * blockDim.x + threadIdx.x, b = blockIdx.y * blockDim.y + threadIdx.y;
+  int q[3];
+  const int da = d == 0 ? 1 : 0, db = d == 2 ? 1 : 2;
+  q[d] = side ? L.n[d] - 1 : 0; q[da] = a; q[db] = b;
+  if (side && L.n[d] == 1 && ((hm >> (2 * d)) & 1)) return;
+  if (q[da] >= L.n[da] || q[db] >= L.n[db]) return;
+  if (d >= 1 && (((hm & 1) && q[0] == 0) || ((hm & 2) && q[0] == L.n[0] - 1))) return;           // owned by an x face
+  if (d == 2 && (((hm & 4) && q[1] == 0) || ((hm & 8) && q[1] == L.n[1] - 1))) return;           // owned by a y face
+  if ((q[0] + q[1] + q[2] + color) & 1) return;
+  const int i = q[0], j = q[1], k = q[2];
+  const double p[7] = { split_get(S.phi, S, i, j, k), split_get(S.phi, S, i - 1, j, k), split_get(S.phi, S, i + 1, j, k), split_get(S.phi, S, i, j - 1, k),
+                        split_get(S.phi, S, i, j + 1, k), split_get(S.phi, S, i, j, k - 1), split_get(S.phi, S, i, j, k + 1) };
+  const double r[7] = { split_get(S.rho, S, i, j, k), split_get(S.rho, S, i - 1, j, k), split_get(S.rho, S, i + 1, j, k), split_get(S.rho, S, i, j - 1, k),
+                        split_get(S.rho, S, i, j + 1, k), split_get(S.rho, S, i, j, k - 1), split_get(S.rho, S, i, j, k + 1) };
+  double Ap, diag;
+  cc_apply_rho_vals(L, i, j, k, p, r, Ap, diag);
+  if (diag != 0.0) S.phi[color][sidx(S, (i - (i & 1)) >> 1, j, k)] = p[0] + (split_get(S.rh, S, i, j, k) - Ap) / diag;
 }
 // residual + restriction on the split level (kk_cc_residual_rho_pair_rst's job): a thread owns entries ih, ih + 1 of BOTH colours in rows 2J, 2J + 1 of planes
 // 2K, 2K + 1 = cells 2 ih .. 2 ih + 3 of each row = the children of coarse cells (ih, J, K) and (ih + 1, J, K).  Per plane: E = the row's even cells (2 ih, 2 ih + 2),
@@ -333,7 +364,7 @@ __global__ void __launch_bounds__(256) kk_cc_residual_rho_split_rst(CLev L, CSpl
       const int k = 2 * K + kk, e = kk;                            // (0 + 2J + k) & 1
       const long c = sidx(S, ih, 2 * J, k);
       double P[2][4][7], R[2][4][7];
-      const bool ldl = u > 0 || L.fold[0][0] == VDN_BC_DIR, ldr = ih + 2 < nh || L.fold[0][1] == VDN_BC_DIR;
+      const bool ldl = u > 0 || L.fold[0][0] != VDN_BC_NEU, ldr = ih + 2 < nh || L.fold[0][1] != VDN_BC_NEU;
       split_gather(S.phi, S, c, e, lane, P, ldl, ldr);
       split_gather(S.rho, S, c, e, lane, R, ldl, ldr);
       const double2 H0e = *reinterpret_cast<const double2 *>(S.rh[e] + c), H0o = *reinterpret_cast<const double2 *>(S.rh[1 - e] + c);
@@ -1058,10 +1089,13 @@ __global__ void kk_cc_prolong_lin(CLev F, CLev C, ProlongLinArgs A) {
 }
 
 // ---- host side ------------------------------------------------------------------------------------------
-struct CBox { CLev L; int lo[3]; int gidx; int hmask = 63; /* faces whose ghost cells come from the halo exchange */ };                    // one local box on one distributed level; lo = global index of its cell 0
+struct CBox { CLev L; int lo[3]; int gidx; int hmask = 63; /* faces whose ghost cells come from the halo exchange */
+              CSplit sp; /* the box by colour (CDLev::split) */ };                    // one local box on one distributed level; lo = global index of its cell 0
 struct CDLev { std::vector<CBox> boxes; XPlan *halo = nullptr; int ng[3]; /* global extents of the level */ bool single_box = false;
                bool res_restricted = false; /* the last residual pass already restricted into the next level */
-               bool split = false; CSplit sp; /* macproject's finest level in one box: phi, rhs, rho by colour (cc_split_setup); phi of the level array is stale between cc_to_split / cc_from_split */ };
+               bool split = false;      /* macproject's finest level: phi, rhs, rho of every box by colour (cc_split_setup); phi of the level arrays is stale between cc_to_split / cc_from_split */
+               XPlan *shalo[2] = { nullptr, nullptr };      /* round 6: the ghost exchange of phi[colour] on the split arrays (levels with a halo) */
+               std::vector<XBoxInfo> xb; vdn_box lpd; unsigned long la_uid = 0; int la_lev = 0;      /* the level's global box list, kept for cc_split_setup's plans */ };
 struct CCMG {
   std::vector<CDLev> dlev;          // distributed levels (finest first)
   std::vector<CLev> tail;           // agglomerated levels, whole domain, replicated on every rank
@@ -1080,49 +1114,73 @@ static const dim3 BLK(64, 4, 1);
 // The level array keeps rhs and rho (level 1's coefficients, the nested iteration and the residual read them there); phi lives in the split arrays
 // from cc_to_split (after the nested iteration) to cc_from_split (before the residual pass, which reads the level array, and at the end of the solve).
 static bool mac_split_on() { static const bool b = !(vdn_env("VDN_MAC_SPLIT") && atoi(vdn_env("VDN_MAC_SPLIT")) == 0); return b; }
-template <int ADD> static inline void launch_gsrb_split(const CDLev &DL, int color, hipStream_t st, const CLev &C, int k0 = 0, int k1 = -1) {
-  const CLev &L = DL.boxes[0].L;
+// hm: the shell behind these faces is left to kk_cc_gsrb_split_shell (cc_gsrb_d's overlap of the exchange with the pass)
+template <int ADD> static inline void launch_gsrb_split(const CBox &B, int color, hipStream_t st, const CLev &C, int k0 = 0, int k1 = -1, int hm = 0) {
+  const CLev &L = B.L;
   if (k1 < 0) k1 = L.n[2];
   const dim3 g((unsigned)((L.n[0] / 4 + 63) / 64), (unsigned)((L.n[1] + 7) / 8), (unsigned)(k1 - k0));
   // the second colour walks the planes downwards: what the first colour's pass touched last is what it reads first (Infinity Cache; VDN_MAC_KFLIP=0: both upwards)
-  static const bool kflip = !(vdn_env("VDN_MAC_KFLIP") && atoi(vdn_env("VDN_MAC_KFLIP")) == 0);
-  hipLaunchKernelGGL(kk_cc_gsrb_rho_split<ADD>, g, dim3(64, 8, 1), 0, st, L, DL.sp, color, C, (kflip && color) ? 1 : 0, k0);
+  hipLaunchKernelGGL(kk_cc_gsrb_rho_split<ADD>, g, dim3(64, 8, 1), 0, st, L, B.sp, color, C, (mac_kflip() && color) ? 1 : 0, k0, hm);
+}
+static inline void launch_gsrb_split_shell(const CBox &B, int color, hipStream_t st, int hm) {
+  if (!hm) return;
+  const CLev &L = B.L;
+  const int m = std::max(L.n[0], std::max(L.n[1], L.n[2]));
+  hipLaunchKernelGGL(kk_cc_gsrb_split_shell, dim3((unsigned)((m + 63) / 64), (unsigned)((m + 3) / 4), (unsigned)__builtin_popcount(hm)), dim3(64, 4, 1), 0, st, L, B.sp, color, hm);
 }
 static void cc_to_split(const CDLev &DL, int what) {
-  const CLev &L = DL.boxes[0].L;
-  const dim3 g((unsigned)((DL.sp.PXH + 63) / 64), (unsigned)((L.n[1] + 2 + 3) / 4), (unsigned)(L.n[2] + 2));
-  hipLaunchKernelGGL(kk_cc_to_split, g, BLK, 0, ctx().stream, L, DL.sp, what);
+  for (const CBox &B : DL.boxes) {
+    const CLev &L = B.L;
+    const dim3 g((unsigned)((B.sp.PXH + 63) / 64), (unsigned)((L.n[1] + 2 + 3) / 4), (unsigned)(L.n[2] + 2));
+    hipLaunchKernelGGL(kk_cc_to_split, g, BLK, 0, ctx().stream, L, B.sp, what);
+  }
 }
 static void cc_from_split(const CDLev &DL) {
-  const CLev &L = DL.boxes[0].L;
-  hipLaunchKernelGGL(kk_cc_from_split, g3(L.n[0] / 2, L.n[1], L.n[2], BLK), BLK, 0, ctx().stream, L, DL.sp);
+  for (const CBox &B : DL.boxes) hipLaunchKernelGGL(kk_cc_from_split, g3(B.L.n[0] / 2, B.L.n[1], B.L.n[2], BLK), BLK, 0, ctx().stream, B.L, B.sp);
 }
-// one box that is the whole domain, no periodic face, the density form, the extents the paired kernels take, the default launch forms
+// the ghost entries of phi[colour] from the neighbouring boxes / periodic images (no plan: one box without periodic faces)
+static void split_halo(const CDLev &DL, int colour, hipStream_t st = nullptr) { if (DL.shalo[colour]) xplan_run(DL.shalo[colour], st); }
+// The finest level of macproject's solve goes by colour when: the density form, the default launch forms, a second distributed level with the same boxes; every local box
+// with the extents the paired kernels take and even corner indices (its colours are then the global ones and a row's parity is the same on both sides of a box face),
+// and enough cells on this rank that the level does not live in the caches anyway.  Round 5 took one box without periodic faces only; round 6: any box list, periodic faces,
+// several ranks -- the ghost exchange runs on the split arrays themselves (cc_split_setup).
 static bool cc_split_ok(const CCMG &M) {
   static const bool dflt = !(vdn_env("VDN_GSRB_PAIR") && atoi(vdn_env("VDN_GSRB_PAIR")) == 0) && !(vdn_env("VDN_MG_RESTRICT_FUSED") && atoi(vdn_env("VDN_MG_RESTRICT_FUSED")) == 0) &&
                            !(vdn_env("VDN_MG_PROLONG_FUSED") && atoi(vdn_env("VDN_MG_PROLONG_FUSED")) == 0);
-  if (!mac_split_on() || !dflt || M.dlev.size() < 2 || ctx().prm.mg_nu1 < 1 || ctx().prm.mg_nu2 < 1 || M.per[0] || M.per[1] || M.per[2]) return false;
+  if (!mac_split_on() || !dflt || M.dlev.size() < 2 || ctx().prm.mg_nu1 < 1 || ctx().prm.mg_nu2 < 1) return false;
   const CDLev &D0 = M.dlev[0];
-  if (!(D0.single_box && D0.boxes.size() == 1 && !D0.halo && M.dlev[1].boxes.size() == 1)) return false;
-  const CLev &L = D0.boxes[0].L;
-  for (int d = 0; d < 3; d++) if (D0.boxes[0].lo[d] != 0) return false;
+  if (D0.boxes.empty() || D0.boxes.size() != M.dlev[1].boxes.size()) return false;
+  static const bool halo_ok = !(vdn_env("VDN_MAC_SPLIT_HALO") && atoi(vdn_env("VDN_MAC_SPLIT_HALO")) == 0);      // 0: round 5's rule (one box, no exchange)
+  if (D0.halo && !halo_ok) return false;
+  long cells = 0;
+  for (const CBox &B : D0.boxes) {
+    const CLev &L = B.L;
+    if (!(L.rho && L.n[0] % 4 == 0 && L.n[1] % 2 == 0 && L.n[2] % 2 == 0 && L.n[0] >= 128)) return false;
+    for (int d = 0; d < 3; d++) if (B.lo[d] & 1) return false;
+    cells += (long)L.n[0] * L.n[1] * L.n[2];
+  }
+  for (int d = 0; d < 3; d++) if (D0.ng[d] & 1) return false;
   // (128^3 stays interleaved: its arrays live in the caches, the conversions cost more than the passes gain -- 6.98 against 7.21 ms per step)
   static const long nmin = vdn_env("VDN_MAC_SPLIT_MIN") ? atol(vdn_env("VDN_MAC_SPLIT_MIN")) : (1L << 23);
-  return L.rho && L.n[0] % 4 == 0 && L.n[1] % 2 == 0 && L.n[2] % 2 == 0 && L.n[0] >= 128 && (long)L.n[0] * L.n[1] * L.n[2] >= nmin;
+  return cells >= nmin;
 }
 static int g_mac_level_form = 0;
 extern "C" int vdn_last_mac_level_form(void) { return g_mac_level_form; }
+static XPlan *cc_split_plan(const CDLev &D0, int colour, const int per[3]);
 static void cc_split_setup(CCMG &M) {
   CDLev &D0 = M.dlev[0];
-  const CLev &L = D0.boxes[0].L;
-  CSplit &S = D0.sp;
-  // rows start on a 128-byte line and are whole lines long (measured at 256^3: 8 entries in front, rows of 144: FETCH_SIZE 204.8 MB raw, 0.0895 ms per pass; 16 / 160: 189.3 MB, 0.0848 ms)
-  const int off = 16, rnd = 16;
-  S.off = off;
-  S.PXH = ((L.n[0] / 2 + off + 2 + rnd - 1) / rnd) * rnd; S.sy = S.PXH; S.sz = (long)S.PXH * (L.n[1] + 2); S.tot = S.sz * (L.n[2] + 2);
-  double *base = (double *)arena_alloc(sizeof(double) * S.tot * 6);
-  for (int c = 0; c < 2; c++) { S.phi[c] = base + c * S.tot; S.rh[c] = base + (2 + c) * S.tot; S.rho[c] = base + (4 + c) * S.tot; }
+  for (CBox &B : D0.boxes) {
+    const CLev &L = B.L;
+    CSplit &S = B.sp;
+    // rows start on a 128-byte line and are whole lines long (measured at 256^3: 8 entries in front, rows of 144: FETCH_SIZE 204.8 MB raw, 0.0895 ms per pass; 16 / 160: 189.3 MB, 0.0848 ms)
+    const int off = 16, rnd = 16;
+    S.off = off;
+    S.PXH = ((L.n[0] / 2 + off + 2 + rnd - 1) / rnd) * rnd; S.sy = S.PXH; S.sz = (long)S.PXH * (L.n[1] + 2); S.tot = S.sz * (L.n[2] + 2);
+    double *base = (double *)arena_alloc(sizeof(double) * S.tot * 6);
+    for (int c = 0; c < 2; c++) { S.phi[c] = base + c * S.tot; S.rh[c] = base + (2 + c) * S.tot; S.rho[c] = base + (4 + c) * S.tot; }
+  }
   D0.split = true;
+  if (D0.halo) for (int c = 0; c < 2; c++) D0.shalo[c] = cc_split_plan(D0, c, M.per);
   cc_to_split(D0, 2 | 4);
 }
 
@@ -1160,6 +1218,31 @@ struct HaloKey { unsigned long uid; const void *p0; int lev, l, per; unsigned lo
 static std::map<HaloKey, XPlan *> g_halo_cache;
 void cc_halo_cache_purge(unsigned long uid) {        // the plans themselves are freed by exchange.hip (halo_cache_register)
   for (auto it = g_halo_cache.begin(); it != g_halo_cache.end();) { if (it->first.uid == uid) it = g_halo_cache.erase(it); else ++it; }
+}
+
+// the exchange of phi[colour] in the index space (ih, j, k) of the split arrays: boxes and domain halved along x.  Extents and corner indices are even (cc_split_ok), so a
+// row has the same parity on both sides of a box face or a periodic image: entry ih of a ghost row / plane is entry ih of the neighbour's row / plane, the ghost entry -1 (nh)
+// of a row its entry nh - 1 (0) -- cell i = -1 (i = nx) on the rows of odd (even) parity, an entry nobody reads on the others: a plain one-entry-wide face exchange, built,
+// cached and run like the level arrays' (local copies, packed buffers to other ranks)
+static XPlan *cc_split_plan(const CDLev &D0, int colour, const int per[3]) {
+  std::vector<XBoxInfo> xb = D0.xb;
+  size_t li = 0;
+  GraphKey hk;
+  for (XBoxInfo &x : xb) {
+    const int nh = (x.vhi[0] - x.vlo[0] + 1) / 2;
+    x.vlo[0] /= 2; x.vhi[0] = x.vlo[0] + nh - 1;
+    if (x.owner == ctx().rank) {
+      const CBox &B = D0.boxes[li++];
+      const CSplit &S = B.sp;
+      FV f; f.p = S.phi[colour]; f.a0 = x.vlo[0] - S.off; f.a1 = x.vlo[1] - 1; f.a2 = x.vlo[2] - 1; f.n0 = S.PXH; f.n1 = B.L.n[1] + 2; f.n2 = B.L.n[2] + 2; f.sc = S.tot;
+      x.fv = f; hk.put(f.p); hk.put(S.tot);
+    }
+  }
+  vdn_box lpd = D0.lpd; lpd.hi[0] = (lpd.hi[0] + 1) / 2 - 1;
+  HaloKey key{ D0.la_uid, (const void *)D0.boxes[0].sp.phi[colour], D0.la_lev, 1000 + colour, per[0] | (per[1] << 1) | (per[2] << 2), hk.h };
+  auto it = g_halo_cache.find(key);
+  if (it == g_halo_cache.end()) { XPlan *P = xplan_build(xb, lpd, per, 1, 1, cc_faces_only()); halo_cache_register(D0.la_uid, P); it = g_halo_cache.emplace(key, P).first; }
+  return it->second;
 }
 
 static void cc_build(CCMG &M, const vdn_multifab *rh, const double *dx, const int bc[3][2], bool has_alpha) {
@@ -1212,6 +1295,7 @@ static void cc_build(CCMG &M, const vdn_multifab *rh, const double *dx, const in
       DL.halo = it->second;
     }
     DL.single_box = (nb == 1);
+    DL.xb = xb; DL.lpd = lpd; DL.la_uid = la->uid; DL.la_lev = lev;
     M.dlev.push_back(DL);
     // the hierarchy of GLOBAL levels is the single-box one (oracle rule: coarsen while every global extent is
     // even and > 2); a level stays distributed while the boxes halve cleanly to extents >= 4
@@ -1288,8 +1372,21 @@ static void cc_gsrb_d(CCMG &M, CDLev &DL, int nsweeps) {
     if (cells < ov_min && ov_env != 1) overlap = false;
   }
   VdnCtx &c = ctx();
-  if (DL.split) {
-    for (int s = 0; s < nsweeps; s++) for (int color = 0; color < 2; color++) launch_gsrb_split<0>(DL, color, c.stream, DL.boxes[0].L);
+  if (DL.split) {          // by colour: before a pass the OTHER colour's ghost entries are exchanged (half the volume of the level array's exchange)
+    for (int s = 0; s < nsweeps; s++) for (int color = 0; color < 2; color++) {
+      if (!overlap) {
+        split_halo(DL, 1 - color);
+        for (const CBox &B : DL.boxes) launch_gsrb_split<0>(B, color, c.stream, B.L);
+        continue;
+      }
+      HIPCHK(hipEventRecord(c.ev_main, c.stream));
+      HIPCHK(hipStreamWaitEvent(c.halo_stream, c.ev_main, 0));
+      split_halo(DL, 1 - color, c.halo_stream);
+      HIPCHK(hipEventRecord(c.ev_halo, c.halo_stream));
+      for (const CBox &B : DL.boxes) launch_gsrb_split<0>(B, color, c.stream, B.L, 0, -1, B.hmask);
+      HIPCHK(hipStreamWaitEvent(c.stream, c.ev_halo, 0));
+      for (const CBox &B : DL.boxes) launch_gsrb_split_shell(B, color, c.stream, B.hmask);
+    }
     return;
   }
   for (int s = 0; s < nsweeps; s++) for (int color = 0; color < 2; color++) {
@@ -1308,21 +1405,25 @@ static void cc_gsrb_d(CCMG &M, CDLev &DL, int nsweeps) {
   }
 }
 static void cc_residual_d(CCMG &M, CDLev &DL, bool norm, bool reduce = true) {       // reduce = false: the norm stays rank-local (norm history, mg_predict)
-  cc_halo(M, DL);
   if (norm) HIPCHK(hipMemsetAsync(M.d_nrm, 0, sizeof(double), ctx().stream));
   DL.res_restricted = false;
   if (DL.split) {
     static const bool split_res = !(vdn_env("VDN_MAC_SPLIT") && atoi(vdn_env("VDN_MAC_SPLIT")) == 2);      // 2: only the colour passes run on the split arrays
     if (split_res) {
-      const CLev &L = DL.boxes[0].L;
-      const dim3 g((unsigned)((L.n[0] / 4 + 63) / 64), (unsigned)((L.n[1] / 2 + 3) / 4), (unsigned)std::min(L.n[2] / 2, 16));
-      hipLaunchKernelGGL(kk_cc_residual_rho_split_rst, g, BLK, 0, ctx().stream, L, DL.sp, norm ? M.d_nrm : nullptr, M.dlev[1].boxes[0].L, 0, L.n[2] / 2);
+      // the residual reads both colours' ghost entries: colour 0's were exchanged before the last pass (of colour 1) and have not changed since
+      split_halo(DL, 1);
+      for (size_t b = 0; b < DL.boxes.size(); b++) {
+        const CBox &B = DL.boxes[b]; const CLev &L = B.L;
+        const dim3 g((unsigned)((L.n[0] / 4 + 63) / 64), (unsigned)((L.n[1] / 2 + 3) / 4), (unsigned)std::min(L.n[2] / 2, 16));
+        hipLaunchKernelGGL(kk_cc_residual_rho_split_rst, g, BLK, 0, ctx().stream, L, B.sp, norm ? M.d_nrm : nullptr, M.dlev[1].boxes[b].L, 0, L.n[2] / 2);
+      }
       DL.res_restricted = true;
       if (norm && reduce) comm_allreduce_max_dev(M.d_nrm, 1);
       return;
     }
     cc_from_split(DL);
   }
+  cc_halo(M, DL);
   {   // the finest level of a MAC solve in one box: residual and restriction in one pass (kk_cc_residual_rho_pair_rst); cc_restrict_down then skips
     static const bool fuse = !(vdn_env("VDN_MG_RESTRICT_FUSED") && atoi(vdn_env("VDN_MG_RESTRICT_FUSED")) == 0);
     static const bool paired0 = !(vdn_env("VDN_GSRB_PAIR") && atoi(vdn_env("VDN_GSRB_PAIR")) == 0);
@@ -1454,9 +1555,12 @@ static void cc_prolong_up(CCMG &M, int l) {
 static void cc_prolong_smooth(CCMG &M, int l, int nsweeps) {
   CDLev &DL = M.dlev[l];
   if (DL.split) {
-    const CLev &C = M.dlev[l + 1].boxes[0].L;
-    launch_gsrb_split<1>(DL, 0, ctx().stream, C);
-    launch_gsrb_split<2>(DL, 1, ctx().stream, C);
+    // the correction rides in the first sweep.  With a halo: the ghost cells of the first colour's neighbours must become phi + e(parent) like the cells they mirror --
+    // phi's ghost entries are current (exchanged before the residual), e's come from one exchange of the coarse level; the sum is the neighbour's own phi + e
+    if (DL.halo) cc_halo(M, M.dlev[l + 1]);
+    for (size_t b = 0; b < DL.boxes.size(); b++) launch_gsrb_split<1>(DL.boxes[b], 0, ctx().stream, M.dlev[l + 1].boxes[b].L);
+    split_halo(DL, 0);
+    for (size_t b = 0; b < DL.boxes.size(); b++) launch_gsrb_split<2>(DL.boxes[b], 1, ctx().stream, M.dlev[l + 1].boxes[b].L);
     if (nsweeps > 1) cc_gsrb_d(M, DL, nsweeps - 1);
     return;
   }
@@ -1491,7 +1595,8 @@ static int mac_slab(const CLev &L) {
   return (int)std::max(8L, std::min((long)(L.n[2] + 1) / 2, fit));
 }
 static void cc_split_run(CCMG &M, CDLev &DL, bool prolong, int nsweeps, bool residual, bool norm, bool reduce) {
-  const CLev &L = DL.boxes[0].L, &C = M.dlev[1].boxes[0].L;
+  const CBox &B0 = DL.boxes[0];
+  const CLev &L = B0.L, &C = M.dlev[1].boxes[0].L;
   hipStream_t st = ctx().stream;
   const int R = 2 * nsweeps, n2 = L.n[2], nK = n2 / 2, slab = mac_slab(L);
   if (residual && norm) HIPCHK(hipMemsetAsync(M.d_nrm, 0, sizeof(double), st));
@@ -1502,16 +1607,16 @@ static void cc_split_run(CCMG &M, CDLev &DL, bool prolong, int nsweeps, bool res
       const int hi = p == 0 ? std::min(top, n2) : (done[p - 1] == n2 ? n2 : done[p - 1] - 1);
       if (hi <= done[p]) continue;
       const int add = prolong ? (p == 0 ? 1 : p == 1 ? 2 : 0) : 0;
-      if (add == 1) launch_gsrb_split<1>(DL, p & 1, st, C, done[p], hi);
-      else if (add == 2) launch_gsrb_split<2>(DL, p & 1, st, C, done[p], hi);
-      else launch_gsrb_split<0>(DL, p & 1, st, L, done[p], hi);
+      if (add == 1) launch_gsrb_split<1>(B0, p & 1, st, C, done[p], hi);
+      else if (add == 2) launch_gsrb_split<2>(B0, p & 1, st, C, done[p], hi);
+      else launch_gsrb_split<0>(B0, p & 1, st, L, done[p], hi);
       done[p] = hi;
     }
     if (residual) {                                  // coarse plane K reads the fine planes 2K - 1 .. 2K + 2
       const int hiK = done[R - 1] == n2 ? nK : std::max(0, (done[R - 1] - 1) / 2);
       if (hiK > done[R]) {
         const dim3 g((unsigned)((L.n[0] / 4 + 63) / 64), (unsigned)((L.n[1] / 2 + 3) / 4), (unsigned)std::min(hiK - done[R], 16));
-        hipLaunchKernelGGL(kk_cc_residual_rho_split_rst, g, BLK, 0, st, L, DL.sp, norm ? M.d_nrm : nullptr, C, done[R], hiK);
+        hipLaunchKernelGGL(kk_cc_residual_rho_split_rst, g, BLK, 0, st, L, B0.sp, norm ? M.d_nrm : nullptr, C, done[R], hiK);
         done[R] = hiK;
       }
     }
@@ -1524,7 +1629,8 @@ static void cc_fine_seq(CCMG &M, bool after_coarse, bool residual, bool norm, bo
   const vdn_params &P = ctx().prm;
   CDLev &D0 = M.dlev[0];
   static const bool split_res = !(vdn_env("VDN_MAC_SPLIT") && atoi(vdn_env("VDN_MAC_SPLIT")) == 2);
-  if (D0.split && mac_slab(D0.boxes[0].L) > 0 && split_res && residual) { cc_split_run(M, D0, after_coarse, (after_coarse ? P.mg_nu2 : 0) + P.mg_nu1, true, norm, reduce); return; }
+  // (the slab schedule: one box without an exchange between the passes)
+  if (D0.split && !D0.halo && D0.boxes.size() == 1 && mac_slab(D0.boxes[0].L) > 0 && split_res && residual) { cc_split_run(M, D0, after_coarse, (after_coarse ? P.mg_nu2 : 0) + P.mg_nu1, true, norm, reduce); return; }
   if (after_coarse) cc_prolong_smooth(M, 0, P.mg_nu2);
   cc_gsrb_d(M, D0, P.mg_nu1);
   if (residual) cc_residual_d(M, D0, norm, reduce);
@@ -1674,8 +1780,8 @@ static unsigned long long cc_graph_key(const CCMG &M, int what) {
   k.put(M.sendbuf); k.put(M.recvbuf); k.put(M.d_gb_rh); k.put(M.d_gb_b); k.put(M.cnt_rh); k.put(M.cnt_b);
   for (const CDLev &DL : M.dlev) {
     k.put(xplan_serial(DL.halo)); k.put(DL.ng); k.put(DL.single_box); k.put(DL.res_restricted);
-    k.put(DL.split); if (DL.split) { k.put(DL.sp.PXH); k.put(DL.sp.off); k.put(DL.sp.phi); k.put(DL.sp.rh); k.put(DL.sp.rho); }
-    for (const CBox &B : DL.boxes) { cc_key_lev(k, B.L); k.put(B.lo); }
+    k.put(DL.split); k.put(xplan_serial(DL.shalo[0])); k.put(xplan_serial(DL.shalo[1]));
+    for (const CBox &B : DL.boxes) { cc_key_lev(k, B.L); k.put(B.lo); if (DL.split) { k.put(B.sp.PXH); k.put(B.sp.off); k.put(B.sp.phi); k.put(B.sp.rh); k.put(B.sp.rho); } }
   }
   for (const CLev &L : M.tail) cc_key_lev(k, L);
   for (long o : M.loc_off_rh) k.put(o);
@@ -1865,8 +1971,8 @@ int cc_solve(vdn_multifab *rh, vdn_multifab *phi, vdn_multifab **beta, const dou
     if (cc_split_ok(M)) cc_split_setup(M);
     g_mac_level_form = !M.dlev[0].split ? 0 : (vdn_env("VDN_MAC_SPLIT") && atoi(vdn_env("VDN_MAC_SPLIT")) == 2) ? 2 : 1;
   }
-  else if (keep && keep->built) cc_reload(M, rh, phi, bc, zero_guess);
-  else cc_setup(M, rh, phi, alpha, beta, dx, bc, rho);
+  else if (keep && keep->built) { cc_reload(M, rh, phi, bc, zero_guess); g_mac_level_form = 0; }
+  else { cc_setup(M, rh, phi, alpha, beta, dx, bc, rho); g_mac_level_form = 0; }
   if (keep) keep->built = true;
   CDLev &D0 = M.dlev[0];
   const bool single = (M.dlev.size() == 1 && M.tail.empty());
@@ -1969,7 +2075,8 @@ void cc_bench_smoother(vdn_multifab *rh, vdn_multifab *phi, vdn_multifab **beta,
   hipEvent_t e0, e1; HIPCHK(hipEventCreate(&e0)); HIPCHK(hipEventCreate(&e1));
   CDLev &D0 = M.dlev[0];
   if (cc_split_ok(M)) { cc_split_setup(M); cc_to_split(D0, 1); }            // the form macproject's solve runs (VDN_MAC_SPLIT=0: the interleaved pass)
-  auto pass = [&](int w) { if (D0.split) launch_gsrb_split<0>(D0, w & 1, st, L); else launch_gsrb(L, w & 1, st); };
+  g_mac_level_form = D0.split ? 1 : 0;                                      // (bench.py reads it back: which kernel the probe timed)
+  auto pass = [&](int w) { if (D0.split) launch_gsrb_split<0>(D0.boxes[0], w & 1, st, L); else launch_gsrb(L, w & 1, st); };
   for (int w = 0; w < 4; w++) pass(w);
   HIPCHK(hipEventRecord(e0, st));
   for (int w = 0; w < nlaunch; w++) pass(w);

@@ -139,8 +139,9 @@ static const EnvSwitch g_switches[] = {
   { "VDN_GOD_FUSED", "0: one march per Godunov stage (B, C, D) instead of the fused B+C+D march" },
   { "VDN_GOD_UPDATE", "0: update_3d as its own pass instead of inside the fused mkflux march" },
   { "VDN_GSRB_PAIR", "0: one cell per thread in the colour passes / residuals of wide levels instead of the 2 x 2 pair form" },
-  { "VDN_MAC_SPLIT", "0: the finest level of macproject's one-box solve stays interleaved (kk_cc_gsrb_rho_pair) instead of stored by colour (kk_cc_gsrb_rho_split); 2: only the colour passes on the split arrays, the residual on the level array" },
-  { "VDN_MAC_SPLIT_MIN", "fewest cells of a level stored by colour (default 2^23)" },
+  { "VDN_MAC_SPLIT", "0: the finest level of macproject's one-level solve stays interleaved (kk_cc_gsrb_rho_pair) instead of stored by colour (kk_cc_gsrb_rho_split); 2: only the colour passes on the split arrays, the residual on the level array" },
+  { "VDN_MAC_SPLIT_MIN", "fewest cells (of this rank's boxes together) of a level stored by colour (default 2^23)" },
+  { "VDN_MAC_SPLIT_HALO", "0: only a one-box level without periodic faces is stored by colour (round 5); default: any box list, periodic faces and several ranks too, the ghost exchange on the split arrays" },
   { "VDN_ND_REV", "0: every march of a nodal level walks its tiles in the same order (default: consecutive marches alternate)" },
   { "VDN_MAC_SLAB", "planes per slab of the time-skewed schedule of the split level's passes (cc_split_run; default: ~200 MB of pass traffic, at most half the level); 0: whole-level launches" },
   { "VDN_MAC_UMAX", "0: max |umac| by its own pass (kk_macmax) instead of inside macproject's velocity update (kk_mkumac_rho_max)" },
