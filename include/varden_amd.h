@@ -15,8 +15,10 @@
  *   - every function returns 0 on success, non-zero on error; the message is
  *     available from vdn_last_error() (reference: bl_error aborts; the Fortran
  *     shim turns non-zero into `error stop`).  A HIP error the CALLER left pending on the
- *     calling thread is cleared at entry (noted once on stderr) and not restored: every
- *     entry point then reports any launch failure of its own, whatever its code.
+ *     calling thread is cleared at entry (noted once per process on stderr) and not restored
+ *     -- HIP offers no way to put it back --: every entry point then reports any launch
+ *     failure of its own, whatever its code.  A host that polls hipGetLastError() after
+ *     calling in asks vdn_last_stale_hip_error() for what was taken off its thread.
  *   - plain pointers and sizes only.  "device" pointers are hipMalloc'ed HBM.
  *   - all floating point data is IEEE f64; arrays use the BoxLib fab layout:
  *         p(lo1-ng:hi1+ng[+nodal1], lo2-ng:..., lo3-ng:..., 1:nc)   column-major,
@@ -114,6 +116,8 @@ int  vdn_init(const vdn_params *prm, int rank, int nranks, int device);
 const char *vdn_debug_switches(void);
 int  vdn_finalize(void);
 const char *vdn_last_error(void);
+/* the hipError_t (as int; 0 = none) most recently found pending at the entry of a call and cleared there (see Conventions); clear != 0 resets it */
+int  vdn_last_stale_hip_error(int clear);
 /* Launch stream.  Default: a PRIVATE non-blocking stream created by vdn_init -- not ordered against the legacy null stream or any
  * stream of the host application.  Calls that only enqueue work (setval, copy_c, fill_boundary, physbc, the vdn_k_* hooks) return
  * before it has run; vdn_multifab_dataptr drains the private stream before handing a device pointer out, vdn_device_synchronize
@@ -332,6 +336,11 @@ int  vdn_nd_solve(vdn_multifab *rh, vdn_multifab *phi, const vdn_multifab *coeff
  * recomputed from rho), otherwise the stored-coefficient pass of the viscous solves and the coarser levels       */
 int  vdn_bench_cc_smoother(vdn_multifab *rh, vdn_multifab *phi, vdn_multifab **beta, const vdn_multifab *rho, const double *dx,
                            const int *bc, int nlaunch, double *avg_ms, long *cells);
+/* the same passes launched as they are INSIDE a solve: `nsweeps` red-black sweeps time-skewed over plane slabs (the level stored by colour, one box; a slab is served
+ * from the Infinity Cache from its second pass on), about `nlaunch` passes in all; avg_ms = time per pass over the whole level, cells = 0 when the level has no slab
+ * schedule (smaller than 2^23 cells, several boxes, periodic faces).  bench.py: roofline.in_solve_ms_per_level_pass                                              */
+int  vdn_bench_cc_smoother_in_solve(vdn_multifab *rh, vdn_multifab *phi, vdn_multifab **beta, const vdn_multifab *rho, const double *dx,
+                                    const int *bc, int nsweeps, int nlaunch, double *avg_ms, long *cells);
 
 #ifdef __cplusplus
 }

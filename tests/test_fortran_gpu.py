@@ -1,4 +1,4 @@
-"""north_star: "Host code stays Fortran (ISO_C_BINDING)".  varden_amd/fortran/varden_drv -- a flang-built driver that calls the hot path
+"""north_star: "Host code stays Fortran (ISO_C_BINDING)".  tests/fortran/varden_drv -- a flang-built driver that calls the hot path
 through varden_amd_mod.f90, the module that keeps the reference's names and argument lists (advance_timestep.f90:26-44, estdt.f90:15,
 hgproject.f90:17, varden.f90:291-328) -- runs as a fresh child process and must reproduce, step for step, what the Python mirror of the same
 flow computes through ctypes: both are thin hosts over ONE C-ABI, so time, dt and max|u| agree to the last printed digit (17 significant
@@ -14,8 +14,9 @@ import pytest
 
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-FDIR = os.path.join(ROOT, "varden_amd", "fortran")
-DRV = os.path.join(FDIR, "varden_drv")
+FDIR = os.path.join(ROOT, "varden_amd", "fortran")           # the product's modules and varden_main
+XDIR = os.path.join(ROOT, "tests", "fortran")                # the boundary fixtures varden_drv / varden_loop (test infrastructure)
+DRV = os.path.join(XDIR, "varden_drv")
 WALLS = [[15, 15]] * 3
 
 
@@ -23,7 +24,7 @@ def _run_fortran(n, nsteps, nlevs):
     if not os.path.exists(DRV):                                   # built by __graft_entry__.build(); build here when flang is at hand
         if shutil.which("amdflang") is None and not os.path.exists("/opt/rocm/lib/llvm/bin/flang"):
             pytest.skip("no flang on this box and no prebuilt varden_drv")
-        subprocess.check_call(["make", "-s", "-C", FDIR])
+        subprocess.check_call(["make", "-s", "-C", XDIR])
     out = subprocess.run([DRV, str(n), str(nsteps), str(nlevs)], cwd=ROOT, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
     rows = []
@@ -58,7 +59,7 @@ def test_fortran_driver_matches_the_python_mirror(gpu, nlevs, n):
     G.close()
 
 
-LOOP = os.path.join(FDIR, "varden_loop")
+LOOP = os.path.join(XDIR, "varden_loop")
 
 
 @pytest.mark.parametrize("nlevs,n", [(1, 32), (2, 16)])
@@ -73,7 +74,7 @@ def test_the_reference_call_syntax_drops_onto_the_library(gpu, nlevs, n):
         if not os.path.exists(exe):
             if shutil.which("amdflang") is None and not os.path.exists("/opt/rocm/lib/llvm/bin/flang"):
                 pytest.skip("no flang on this box and no prebuilt Fortran executables")
-            subprocess.check_call(["make", "-s", "-C", FDIR])
+            subprocess.check_call(["make", "-s", "-C", XDIR])
     lines = []
     for exe in (DRV, LOOP):
         out = subprocess.run([exe, str(n), "4", str(nlevs)], cwd=ROOT, capture_output=True, text=True, timeout=600)

@@ -8,7 +8,7 @@ for ctr in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY" "SQ_ACTI
            "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD" "SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_VMEM_WR" \
            "MemUnitStalled MeanOccupancyPerCU SQ_WAVES GRBM_GUI_ACTIVE" "SQ_INST_CYCLES_VMEM_RD SQ_INST_CYCLES_VMEM_WR TCP_PENDING_STALL_CYCLES_sum SQ_THREAD_CYCLES_VALU"; do
   i=$((i+1))
-  rocprofv3 --pmc $ctr --kernel-trace --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/$tag/p$i -o p -- python3 $GRAFT_REPO_ROOT/bench.py --steps 2 --warmup 1 --skip-cpu --no-extra > $GRAFT_REPO_ROOT/gpurun_out/$tag.p$i.log 2>&1
+  rocprofv3 --pmc $ctr --kernel-trace --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/$tag/p$i -o p -- python3 $GRAFT_REPO_ROOT/bench.py --steps 2 --warmup 1 --skip-cpu --no-extra --no-pmc > $GRAFT_REPO_ROOT/gpurun_out/$tag.p$i.log 2>&1
   echo "pass $i ($ctr) rc=$?"
 done
 cd $GRAFT_REPO_ROOT && python tools/pmc_summary.py gpurun_out/$tag > gpurun_out/$tag.txt 2>&1; head -c 3000 gpurun_out/$tag.txt

@@ -125,6 +125,14 @@ def bench_cc_smoother(rh, phi, beta, dx, bc, nlaunch, rho=None):
     return ms.value, cells.value
 
 
+def bench_cc_smoother_in_solve(rh, phi, beta, dx, bc, nsweeps, nlaunch, rho):
+    """the colour passes as a solve launches them (sweeps time-skewed over plane slabs): (ms per pass over the whole level, cells); cells = 0: no slab schedule here"""
+    ms, cells = C.c_double(), C.c_long()
+    flat = _iv([bc[d][s] for d in range(3) for s in range(2)])
+    check(capi.load().vdn_bench_cc_smoother_in_solve(rh.h, phi.h, handle_array(beta), rho.h, _dx(dx), flat, nsweeps, nlaunch, C.byref(ms), C.byref(cells)))
+    return ms.value, cells.value
+
+
 # ---- multi-level operators (two levels) -----------------------------------------------------------------------------------
 def ml_cc_restriction(crse, fine, icomp=0, nc=None):
     check(capi.load().vdn_ml_cc_restriction(crse.h, fine.h, icomp, crse.nc if nc is None else nc))

@@ -60,6 +60,7 @@ SIGNATURES = {
     "vdn_init": (C.c_int, [C.POINTER(Params), C.c_int, C.c_int, C.c_int]),
     "vdn_finalize": (C.c_int, []),
     "vdn_last_error": (C.c_char_p, []),
+    "vdn_last_stale_hip_error": (C.c_int, [C.c_int]),
     "vdn_set_stream": (C.c_int, [_VP]),
     "vdn_device_synchronize": (C.c_int, []),
     "vdn_get_params": (C.c_int, [C.POINTER(Params)]),
@@ -134,6 +135,7 @@ SIGNATURES = {
     "vdn_cc_smooth": (C.c_int, [_VP, _VP, _PVP, _PD, _PI, C.c_int]),
     "vdn_nd_solve": (C.c_int, [_VP, _VP, _VP, _VP, _PD, _PI, C.c_double, C.c_double, C.c_int, _PI, _PD, _PD]),
     "vdn_bench_cc_smoother": (C.c_int, [_VP, _VP, _PVP, _VP, _PD, _PI, C.c_int, _PD, C.POINTER(C.c_long)]),
+    "vdn_bench_cc_smoother_in_solve": (C.c_int, [_VP, _VP, _PVP, _VP, _PD, _PI, C.c_int, C.c_int, _PD, C.POINTER(C.c_long)]),
 }
 
 _lib = None

@@ -345,3 +345,7 @@ extern "C" int vdn_bench_cc_smoother(vdn_multifab *rh, vdn_multifab *phi, vdn_mu
                                      int nlaunch, double *avg_ms, long *cells) {
   HOOK_BEGIN(rh) int b[3][2]; bc_from_flat(bc, b); cc_bench_smoother(rh, phi, beta, rho, dx, b, nlaunch, avg_ms, cells); HOOK_END
 }
+extern "C" int vdn_bench_cc_smoother_in_solve(vdn_multifab *rh, vdn_multifab *phi, vdn_multifab **beta, const vdn_multifab *rho, const double *dx, const int *bc,
+                                              int nsweeps, int nlaunch, double *avg_ms, long *cells) {
+  HOOK_BEGIN(rh) int b[3][2]; bc_from_flat(bc, b); REQUIRE(nsweeps >= 1 && rho, "vdn_bench_cc_smoother_in_solve: nsweeps >= 1 and rho"); cc_bench_smoother(rh, phi, beta, rho, dx, b, nlaunch, avg_ms, cells, nsweeps); HOOK_END
+}

@@ -327,6 +327,14 @@ void solver_check(int rc, const char *what, int iters, double res, double res0, 
 }
 
 extern "C" const char *vdn_last_error(void) { return g_err; }
+// a HIP error the host application left pending when it called in (VDN_TRY took it off the thread): kept for the host to ask for, noted once per process
+static int g_stale_hip_error = 0;
+void vdn_note_stale_error(hipError_t e) {
+  static bool noted = false;
+  g_stale_hip_error = (int)e;
+  if (!noted) { noted = true; fprintf(stderr, "varden_amd: note: the caller left a pending HIP error on this thread (%s); cleared at entry (vdn_last_stale_hip_error returns it; further ones are not printed)\n", hipGetErrorString(e)); }
+}
+extern "C" int vdn_last_stale_hip_error(int clear) { const int e = g_stale_hip_error; if (clear) g_stale_hip_error = 0; return e; }
 
 extern "C" int vdn_init(const vdn_params *prm, int rank, int nranks, int device) {
   VDN_TRY

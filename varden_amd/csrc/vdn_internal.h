@@ -109,9 +109,11 @@ struct VdnErr : std::runtime_error { using std::runtime_error::runtime_error; };
 // entry: an error the HOST application left pending on this thread (a failed launch of its own; torch's event queries leave hipErrorNotReady) is
 // taken off the thread (HIP has no way to look past it) so that EVERY launch failure inside the call is seen on the way out, whatever its code
 // (comparing codes hid a failure of ours that happened to carry the stale code).  A stale error other than hipErrorNotReady is reported
-// once on stderr -- it is the host's, the call goes on -- and is NOT restored: include/varden_amd.h says so under "Error convention".
+// once per process on stderr -- it is the host's, the call goes on -- and is NOT restored (HIP cannot put it back): the host reads the last one taken this
+// way through vdn_last_stale_hip_error(); include/varden_amd.h says so under "Error convention", INTEGRATION.md section 4.
+void vdn_note_stale_error(hipError_t e);       // runtime.hip: remembers it (vdn_last_stale_hip_error) and prints the note ONCE per process
 #define VDN_TRY try { { const hipError_t entry_err_ = hipGetLastError(); \
-    if (entry_err_ != hipSuccess && entry_err_ != hipErrorNotReady) fprintf(stderr, "varden_amd: note: the caller left a pending HIP error on this thread (%s); cleared at entry\n", hipGetErrorString(entry_err_)); }
+    if (entry_err_ != hipSuccess && entry_err_ != hipErrorNotReady) vdn_note_stale_error(entry_err_); }
 // the success path of every C-ABI call also asks HIP for a pending launch error (a kernel launch with a bad grid fails silently otherwise);
 // hipErrorNotReady is the benign residue of our own hipStreamQuery / hipEventQuery polls
 #define VDN_CATCH   if (ctx().inited) { const hipError_t le_ = hipGetLastError(); \
@@ -325,7 +327,7 @@ int  cc_solve(vdn_multifab *rh, vdn_multifab *phi, vdn_multifab **beta, const do
 struct CcKeep *cc_keep_new(); void cc_keep_free(struct CcKeep *k);
 void cc_smooth(vdn_multifab *rh, vdn_multifab *phi, vdn_multifab **beta, const double *dx, const int bc[3][2], int nsweeps);
 void cc_bench_smoother(vdn_multifab *rh, vdn_multifab *phi, vdn_multifab **beta, const vdn_multifab *rho, const double *dx, const int bc[3][2],
-                       int nlaunch, double *avg_ms, long *cells);
+                       int nlaunch, double *avg_ms, long *cells, int slab_sweeps = 0);
 // viscous.hip
 void k_explicit_diffusive_term(vdn_multifab *lap, const vdn_multifab *data, int comp, int bccomp0, const double *dx, const vdn_bc_tower *bct);
 void do_visc_solve(vdn_layout *mla, vdn_multifab *unew, const vdn_multifab *lapu, const vdn_multifab *rho, const vdn_multifab *mac_rhs,

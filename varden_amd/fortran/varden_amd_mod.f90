@@ -64,7 +64,7 @@ module varden_amd
   public :: ml_layout_build, ml_layout_destroy
   public :: bc_tower_build, bc_tower_destroy
   public :: multifab_build, multifab_build_edge, multifab_build_nodal, multifab_destroy, nfabs, get_box, dataptr, &
-            setval, multifab_copy_c, norm_inf, multifab_fill_boundary, multifab_physbc, &
+            setval, multifab_copy_c, norm_inf, norm_inf_c, multifab_fill_boundary, multifab_physbc, &
             multifab_copy_to_host, multifab_copy_from_host, multifab_fab_size
   public :: advance_timestep, estdt, hgproject, macproject
   public :: ml_cc_restriction, ml_edge_restriction, multifab_fill_ghost_cells, create_umac_grown, ml_restrict_and_fill
@@ -461,6 +461,12 @@ contains
     type(multifab), intent(in) :: mf
     call chk(vdn_multifab_norm_inf(mf%h, 0_c_int, int(mf%nc, c_int), norm_inf), 'norm_inf')
   end function norm_inf
+  ! norm_inf(mf, comp, nc)   (FBoxLib; src/advance_timestep.f90:187: the max norm of nc components from comp, 1-based)
+  real(dp_t) function norm_inf_c(mf, comp, nc)
+    type(multifab), intent(in) :: mf
+    integer, intent(in) :: comp, nc
+    call chk(vdn_multifab_norm_inf(mf%h, int(comp - 1, c_int), int(nc, c_int), norm_inf_c), 'norm_inf')
+  end function norm_inf_c
 
   subroutine multifab_fill_boundary(mf)
     type(multifab), intent(inout) :: mf

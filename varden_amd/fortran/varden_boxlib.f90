@@ -44,12 +44,166 @@ module proj_parameters
   integer, parameter :: initial_projection = 1, divu_iters = 2, pressure_iters = 3, regular_timestep = 4
 end module proj_parameters
 
+! ---- FBoxLib's process-level utilities that its container modules re-export (parallel_IOProcessor, bl_prof_timer, bl_error reach the reference's files through
+! multifab_module and friends without a `use` line of their own)
+module parallel
+  use iso_c_binding
+  use bl_types
+  implicit none
+  integer, parameter :: MPI_MAX = 1, MPI_MIN = 2, MPI_SUM = 3
+  integer, save :: par_rank = 0, par_nranks = 1
+  interface
+     integer(c_int) function vdn_comm_allreduce_max_c(host, n) bind(C, name="vdn_comm_allreduce_max")
+       import :: c_int, c_double
+       real(c_double), intent(inout) :: host(*)
+       integer(c_int), value :: n
+     end function vdn_comm_allreduce_max_c
+  end interface
+  interface parallel_reduce
+     module procedure parallel_reduce_d, parallel_reduce_dv, parallel_reduce_i
+  end interface
+contains
+  subroutine parallel_set_ranks(rank, nranks)
+    integer, intent(in) :: rank, nranks
+    par_rank = rank; par_nranks = nranks
+  end subroutine parallel_set_ranks
+  integer function parallel_myproc()
+    parallel_myproc = par_rank
+  end function parallel_myproc
+  integer function parallel_nprocs()
+    parallel_nprocs = par_nranks
+  end function parallel_nprocs
+  logical function parallel_IOProcessor()
+    parallel_IOProcessor = par_rank == 0
+  end function parallel_IOProcessor
+  integer function parallel_IOProcessorNode()
+    parallel_IOProcessorNode = 0
+  end function parallel_IOProcessorNode
+  real(dp_t) function parallel_wtime()
+    integer(8) :: c, r
+    call system_clock(c, r)
+    parallel_wtime = real(c, dp_t) / real(r, dp_t)
+  end function parallel_wtime
+  subroutine parallel_barrier()
+    real(dp_t) :: z(1)
+    z = 0.0_dp_t
+    if (par_nranks > 1) then
+       if (vdn_comm_allreduce_max_c(z, 1_c_int) /= 0) error stop 'parallel_barrier: the all-reduce failed'
+    end if
+  end subroutine parallel_barrier
+  ! parallel_reduce(r, a, op, proc): MAX and MIN over the ranks through ncclAllReduce(MAX) (every rank receives the result, as FBoxLib's allreduce form does)
+  subroutine parallel_reduce_dv(r, a, op, proc)
+    real(dp_t), intent(out) :: r(:)
+    real(dp_t), intent(in) :: a(:)
+    integer, intent(in) :: op
+    integer, intent(in), optional :: proc
+    r = a
+    if (par_nranks == 1) return
+    select case (op)
+    case (MPI_MAX)
+       if (vdn_comm_allreduce_max_c(r, int(size(r), c_int)) /= 0) error stop 'parallel_reduce: the all-reduce failed'
+    case (MPI_MIN)
+       r = -r
+       if (vdn_comm_allreduce_max_c(r, int(size(r), c_int)) /= 0) error stop 'parallel_reduce: the all-reduce failed'
+       r = -r
+    case default
+       error stop 'parallel_reduce: MPI_SUM across ranks is not an operation of the hot path (its global scalars are maxima)'
+    end select
+  end subroutine parallel_reduce_dv
+  subroutine parallel_reduce_d(r, a, op, proc)
+    real(dp_t), intent(out) :: r
+    real(dp_t), intent(in) :: a
+    integer, intent(in) :: op
+    integer, intent(in), optional :: proc
+    real(dp_t) :: rv(1)
+    call parallel_reduce_dv(rv, (/ a /), op)
+    r = rv(1)
+  end subroutine parallel_reduce_d
+  subroutine parallel_reduce_i(r, a, op, proc)
+    integer, intent(out) :: r
+    integer, intent(in) :: a, op
+    integer, intent(in), optional :: proc
+    real(dp_t) :: rv(1)
+    call parallel_reduce_dv(rv, (/ real(a, dp_t) /), op)
+    r = nint(rv(1))
+  end subroutine parallel_reduce_i
+end module parallel
+
+module bl_error_module
+  implicit none
+contains
+  subroutine bl_error(str)
+    character(len=*), intent(in) :: str
+    write(*, '(a,a)') 'BOXLIB ERROR: ', str
+    error stop 1
+  end subroutine bl_error
+  subroutine bl_warn(str)
+    character(len=*), intent(in) :: str
+    write(*, '(a,a)') 'BOXLIB WARN: ', str
+  end subroutine bl_warn
+  subroutine bl_assert(cond, str)
+    logical, intent(in) :: cond
+    character(len=*), intent(in) :: str
+    if (.not. cond) call bl_error(str)
+  end subroutine bl_assert
+end module bl_error_module
+
+module bl_IO_module
+  implicit none
+contains
+  integer function unit_new()
+    logical :: used
+    do unit_new = 20, 999
+       inquire(unit=unit_new, opened=used)
+       if (.not. used) return
+    end do
+    error stop 'unit_new: no free unit'
+  end function unit_new
+end module bl_IO_module
+
+module bl_prof_module
+  implicit none
+  type bl_prof_timer
+     character(len=64) :: name = ''
+  end type bl_prof_timer
+  interface build
+     module procedure bl_prof_timer_build
+  end interface
+  interface destroy
+     module procedure bl_prof_timer_destroy
+  end interface
+contains
+  subroutine bl_prof_initialize(on)                         ! src/main.f90:17,27,29: profiling is rocprofv3's job here (roctx ranges under the reference's timer names)
+    logical, intent(in), optional :: on
+  end subroutine bl_prof_initialize
+  subroutine bl_prof_glean(fname)
+    character(len=*), intent(in) :: fname
+  end subroutine bl_prof_glean
+  subroutine bl_prof_finalize()
+  end subroutine bl_prof_finalize
+  subroutine bl_prof_timer_build(bpt, name)
+    type(bl_prof_timer), intent(inout) :: bpt
+    character(len=*), intent(in) :: name
+    bpt%name = name
+  end subroutine bl_prof_timer_build
+  subroutine bl_prof_timer_destroy(bpt)
+    type(bl_prof_timer), intent(inout) :: bpt
+    bpt%name = ''
+  end subroutine bl_prof_timer_destroy
+end module bl_prof_module
+
 module box_module
   implicit none
   type box
      integer :: dim = 3
      integer :: lo(3) = 0, hi(3) = -1
   end type box
+  interface refine
+     module procedure refine_i, refine_v
+  end interface
+  interface coarsen
+     module procedure coarsen_i, coarsen_v
+  end interface
 contains
   function make_box(lo, hi) result(bx)
     integer, intent(in) :: lo(:), hi(:)
@@ -67,6 +221,46 @@ contains
     integer :: hi(bx%dim)
     hi = bx%hi(1:bx%dim)
   end function upb
+  ! refine(bx, rr) / coarsen(bx, rr), rr a scalar or one ratio per direction   (FBoxLib; src/initialize.f90:205, src/regrid.f90:114, src/varden.f90:554): cell-centred boxes
+  function refine_v(bx, rr) result(r)
+    type(box), intent(in) :: bx
+    integer, intent(in) :: rr(:)
+    type(box) :: r
+    r = bx
+    r%lo(1:bx%dim) = bx%lo(1:bx%dim) * rr(1:bx%dim)
+    r%hi(1:bx%dim) = (bx%hi(1:bx%dim) + 1) * rr(1:bx%dim) - 1
+  end function refine_v
+  function refine_i(bx, rr) result(r)
+    type(box), intent(in) :: bx
+    integer, intent(in) :: rr
+    type(box) :: r
+    integer :: v(3)
+    v = rr
+    r = refine_v(bx, v)
+  end function refine_i
+  function coarsen_v(bx, rr) result(r)
+    type(box), intent(in) :: bx
+    integer, intent(in) :: rr(:)
+    type(box) :: r
+    integer :: d
+    r = bx
+    do d = 1, bx%dim
+       r%lo(d) = floor(real(bx%lo(d)) / real(rr(d)))
+       r%hi(d) = floor(real(bx%hi(d)) / real(rr(d)))
+    end do
+  end function coarsen_v
+  function coarsen_i(bx, rr) result(r)
+    type(box), intent(in) :: bx
+    integer, intent(in) :: rr
+    type(box) :: r
+    integer :: v(3)
+    v = rr
+    r = coarsen_v(bx, v)
+  end function coarsen_i
+  pure logical function box_equal(a, b)
+    type(box), intent(in) :: a, b
+    box_equal = a%dim == b%dim .and. all(a%lo(1:a%dim) == b%lo(1:a%dim)) .and. all(a%hi(1:a%dim) == b%hi(1:a%dim))
+  end function box_equal
 end module box_module
 
 module boxarray_module
@@ -78,6 +272,12 @@ module boxarray_module
   end type boxarray
   interface destroy
      module procedure boxarray_destroy
+  end interface
+  interface nboxes
+     module procedure boxarray_nboxes
+  end interface
+  interface get_box
+     module procedure boxarray_get_box
   end interface
 contains
   subroutine boxarray_build_bx(ba, bx)
@@ -95,6 +295,25 @@ contains
     if (associated(ba%bxs)) deallocate(ba%bxs)
     ba%bxs => null(); ba%nboxes = 0
   end subroutine boxarray_destroy
+  integer function boxarray_nboxes(ba)                      ! nboxes(mla%mba%bas(n))   (src/varden.f90:640)
+    type(boxarray), intent(in) :: ba
+    boxarray_nboxes = ba%nboxes
+  end function boxarray_nboxes
+  function boxarray_get_box(ba, i) result(bx)               ! get_box(mla%mba%bas(n), i)   (src/varden.f90:649)
+    type(boxarray), intent(in) :: ba
+    integer, intent(in) :: i
+    type(box) :: bx
+    bx = ba%bxs(i)
+  end function boxarray_get_box
+  logical function boxarray_same_q(a, b)                    ! src/regrid.f90:302
+    type(boxarray), intent(in) :: a, b
+    integer :: i
+    boxarray_same_q = a%nboxes == b%nboxes
+    if (.not. boxarray_same_q) return
+    do i = 1, a%nboxes
+       if (.not. box_equal(a%bxs(i), b%bxs(i))) boxarray_same_q = .false.
+    end do
+  end function boxarray_same_q
 end module boxarray_module
 
 module ml_boxarray_module
@@ -133,13 +352,38 @@ contains
 end module ml_boxarray_module
 
 module layout_module
-  use iso_c_binding, only: c_ptr, c_null_ptr
+  use iso_c_binding, only: c_ptr, c_null_ptr, c_associated
   implicit none
   ! the layout of ONE level: the hierarchy's handle and the level number (the C-ABI keeps the box lists of all levels in one vdn_layout)
   type layout
      type(c_ptr) :: h = c_null_ptr
      integer :: lev = 0, dim = 3, nlevel = 0
   end type layout
+  interface destroy
+     module procedure layout_destroy
+  end interface
+  interface operator(.eq.)
+     module procedure layout_eq
+  end interface
+  interface operator(.ne.)
+     module procedure layout_ne
+  end interface
+contains
+  ! a level's layout is a view of the hierarchy's handle: the hierarchy is released by destroy(mla) (src/regrid.f90:214,242 destroy single layouts)
+  subroutine layout_destroy(la)
+    type(layout), intent(inout) :: la
+    la%h = c_null_ptr; la%lev = 0
+  end subroutine layout_destroy
+  pure logical function layout_eq(a, b)
+    type(layout), intent(in) :: a, b
+    layout_eq = c_associated(a%h, b%h) .and. a%lev == b%lev
+  end function layout_eq
+  pure logical function layout_ne(a, b)                     ! src/regrid.f90:223
+    type(layout), intent(in) :: a, b
+    layout_ne = .not. layout_eq(a, b)
+  end function layout_ne
+  subroutine layout_flush_copyassoc_cache()                 ! src/main.f90:23: the library keeps its exchange plans per layout and drops them with it
+  end subroutine layout_flush_copyassoc_cache
 end module layout_module
 
 module ml_layout_module
@@ -196,8 +440,15 @@ contains
        mla%la(n)%h = mla%v%h; mla%la(n)%lev = n; mla%la(n)%dim = mba%dim; mla%la(n)%nlevel = mba%nlevel
     end do
   end subroutine ml_layout_build
-  subroutine ml_layout_destroy(mla)
+  function ml_layout_get_pd(mla, n) result(bx)               ! src/varden.f90:641
+    type(ml_layout), intent(in) :: mla
+    integer, intent(in) :: n
+    type(box) :: bx
+    bx = mla%mba%pd(n)
+  end function ml_layout_get_pd
+  subroutine ml_layout_destroy(mla, keep_coarse_layout)
     type(ml_layout), intent(inout) :: mla
+    logical, intent(in), optional :: keep_coarse_layout        ! (src/regrid.f90:214; one handle holds every level here: it goes as a whole)
     call vamd_layout_destroy(mla%v)
     call ml_boxarray_destroy(mla%mba)
     if (associated(mla%la)) deallocate(mla%la)
@@ -209,11 +460,15 @@ end module ml_layout_module
 module multifab_module
   use iso_c_binding
   use bl_types
+  use parallel
+  use bl_error_module
+  use bl_prof_module
   use box_module
+  use boxarray_module
   use layout_module
   use varden_amd, only: vamd_multifab => multifab, vamd_ml_layout => ml_layout, vamd_build => multifab_build, vamd_build_edge => multifab_build_edge, &
                         vamd_build_nodal => multifab_build_nodal, vamd_destroy => multifab_destroy, vamd_nfabs => nfabs, vamd_get_box => get_box, &
-                        vamd_dataptr => dataptr, vamd_setval => setval, vamd_copy_c => multifab_copy_c, vamd_norm_inf => norm_inf, &
+                        vamd_dataptr => dataptr, vamd_setval => setval, vamd_copy_c => multifab_copy_c, vamd_norm_inf => norm_inf, vamd_norm_inf_c => norm_inf_c, &
                         vamd_fill_boundary => multifab_fill_boundary, multifab_copy_to_host_v => multifab_copy_to_host, &
                         multifab_copy_from_host_v => multifab_copy_from_host, vamd_fab_size => multifab_fab_size, vdn_box
   implicit none
@@ -221,6 +476,7 @@ module multifab_module
      type(vamd_multifab) :: v
      integer :: dim = 3, nc = 1, ng = 0
      logical :: nodal(3) = .false.
+     type(layout) :: la                                      ! the level it was built on (get_layout)
   end type multifab
   interface build
      module procedure multifab_build
@@ -230,6 +486,12 @@ module multifab_module
   end interface
   interface setval
      module procedure multifab_setval, multifab_setval_c
+  end interface
+  interface norm_inf
+     module procedure multifab_norm_inf, multifab_norm_inf_c
+  end interface
+  interface get_box
+     module procedure multifab_get_box
   end interface
 contains
   function as_vamd_layout(la) result(v)
@@ -256,7 +518,7 @@ contains
     else
        error stop 'multifab_build: nodal in two directions is not a layout of the hot path'
     end if
-    mf%nc = c; mf%ng = g; mf%dim = la%dim
+    mf%nc = c; mf%ng = g; mf%dim = la%dim; mf%la = la
   end subroutine multifab_build
   ! multifab_build_edge(mf, la, nc, ng, dir)   (src/advance_timestep.f90:78)
   subroutine multifab_build_edge(mf, la, nc, ng, dir)
@@ -265,7 +527,7 @@ contains
     integer, intent(in) :: nc, ng, dir
     call vamd_build_edge(mf%v, as_vamd_layout(la), la%lev, nc, ng, dir)
     mf%nodal = .false.; mf%nodal(dir) = .true.
-    mf%nc = nc; mf%ng = ng; mf%dim = la%dim
+    mf%nc = nc; mf%ng = ng; mf%dim = la%dim; mf%la = la
   end subroutine multifab_build_edge
   subroutine multifab_destroy(mf)
     type(multifab), intent(inout) :: mf
@@ -283,18 +545,23 @@ contains
     type(multifab), intent(in) :: mf
     nghost = mf%ng
   end function nghost
-  integer function get_dim(mf)
+  pure integer function get_dim(mf)
     type(multifab), intent(in) :: mf
     get_dim = mf%dim
   end function get_dim
-  function get_box(mf, i) result(bx)
+  function get_layout(mf) result(la)                        ! src/initialize.f90:71
+    type(multifab), intent(in) :: mf
+    type(layout) :: la
+    la = mf%la
+  end function get_layout
+  function multifab_get_box(mf, i) result(bx)
     type(multifab), intent(in) :: mf
     integer, intent(in) :: i
     type(box) :: bx
     type(vdn_box) :: b
     b = vamd_get_box(mf%v, i)
     bx%dim = mf%dim; bx%lo = b%lo; bx%hi = b%hi
-  end function get_box
+  end function multifab_get_box
   ! the DEVICE address of fab i (the reference's dataptr returns a host pointer: host access goes through multifab_copy_to_host / _from_host)
   function dataptr(mf, i) result(dev)
     type(multifab), intent(in) :: mf
@@ -355,16 +622,27 @@ contains
     type(multifab), intent(inout) :: mf
     call vamd_fill_boundary(mf%v)
   end subroutine multifab_fill_boundary
-  real(dp_t) function norm_inf(mf)
+  real(dp_t) function multifab_norm_inf(mf)
     type(multifab), intent(in) :: mf
-    norm_inf = vamd_norm_inf(mf%v)
-  end function norm_inf
+    multifab_norm_inf = vamd_norm_inf(mf%v)
+  end function multifab_norm_inf
+  ! norm_inf(mf, comp, nc)   (src/advance_timestep.f90:187-189)
+  real(dp_t) function multifab_norm_inf_c(mf, comp, nc, all)
+    type(multifab), intent(in) :: mf
+    integer, intent(in) :: comp
+    integer, intent(in), optional :: nc
+    logical, intent(in), optional :: all
+    integer :: n
+    n = 1; if (present(nc)) n = nc
+    multifab_norm_inf_c = vamd_norm_inf_c(mf%v, comp, n)
+  end function multifab_norm_inf_c
 end module multifab_module
 
 module define_bc_module
   use iso_c_binding
   use bc_module
   use layout_module
+  use ml_layout_module
   use varden_amd, only: vamd_bc_tower => bc_tower, vamd_ml_layout => ml_layout, vamd_bc_build => bc_tower_build, vamd_bc_destroy => bc_tower_destroy
   implicit none
   ! the bc tables of one level live in the C-side tower; a bc_level names the tower and the level
@@ -557,25 +835,87 @@ contains
   end subroutine advance_timestep
 end module advance_module
 
-! the subset of the reference's generated probin_module (src/probin.template, src/_parameters) that the callers of the hot path read; the values go to the
-! library with varden_amd_initialize (probin_to_library)
+! the reference's generated probin_module (src/probin.template + src/_parameters through FBoxLib's write_probin.py): EVERY entry of src/_parameters with its default,
+! the &PROBIN namelist, probin_init (the inputs file: $PROBIN, else the first command-line argument, else ./inputs_varden -- probin.template:62-98; the command-line
+! overrides `--name value` of the generated file are not parsed) and probin_close.  The values reach the library with probin_to_library (vdn_params).
 module probin_module
   use bl_types
   use varden_amd, only: vdn_params, probin_defaults, varden_amd_initialize, varden_amd_finalize
   implicit none
-  integer, save :: dim_in = 3, nscal = 2, max_levs = 1, nlevs = 1, ng_cell = 3, ng_grow = 1, init_iter = 4, max_step = 1, verbose = 0
-  integer, save :: do_initial_projection = 1, prob_type = 1, slope_order = 4
-  integer, save :: bcx_lo = 14, bcx_hi = 14, bcy_lo = 14, bcy_hi = 14, bcz_lo = 14, bcz_hi = 14
-  real(dp_t), save :: grav = 0.0_dp_t, cflfac = 0.8_dp_t, init_shrink = 1.0_dp_t, fixed_dt = -1.0_dp_t, stop_time = -1.0_dp_t
-  real(dp_t), save :: visc_coef = 0.0_dp_t, diff_coef = 0.0_dp_t, max_dt_growth = 1.1_dp_t
+  integer, save :: dim_in = 2, nscal = 2, prob_type = 1, boussinesq = 0, max_step = 1, ref_ratio = 2, ng_cell = 3, ng_grow = 1, max_levs = 1, nlevs = -1
+  integer, save :: max_grid_size = 256, stencil_order = 2, init_iter = 4, plot_int = 0, chk_int = 0, regrid_int = -1, amr_buf_width = -1
+  integer, save :: cluster_min_width = 4, cluster_blocking_factor = 4, use_hypre = 0, verbose = 0, mg_verbose = 0, cg_verbose = 0
+  integer, save :: mg_bottom_solver = -1, hg_bottom_solver = -1, max_mg_bottom_nlevels = 1000, do_initial_projection = 1, restart = -1
+  integer, save :: bcx_lo = 14, bcy_lo = 14, bcz_lo = 14, bcx_hi = 14, bcy_hi = 14, bcz_hi = 14, diffusion_type = 1, slope_order = 4
+  integer, save :: n_cellx = 32, n_celly = 32, n_cellz = 32
+  real(dp_t), save :: grav = 0.0_dp_t, stop_time = -1.0_dp_t, cluster_min_eff = 0.9_dp_t
+  real(dp_t), save :: prob_lo_x = 0.0_dp_t, prob_lo_y = 0.0_dp_t, prob_lo_z = 0.0_dp_t, prob_hi_x = 1.0_dp_t, prob_hi_y = 1.0_dp_t, prob_hi_z = 1.0_dp_t
+  real(dp_t), save :: init_shrink = 1.0_dp_t, fixed_dt = -1.0_dp_t, max_dt_growth = 1.1_dp_t, visc_coef = 0.0_dp_t, diff_coef = 0.0_dp_t, cflfac = 0.8_dp_t
+  logical, save :: need_inputs = .true., use_godunov_debug = .false., use_minion = .false.
+  character(len=128), save :: fixed_grids = '', grids_file_name = '', plot_base_name = 'plt', check_base_name = 'chk', job_name = ''
+  character(len=128), save :: inputs_file_used = ''
+  real(dp_t), save :: rho_bc(3,2) = 0.0_dp_t, trac_bc(3,2) = 0.0_dp_t, u_bc(3,2) = 0.0_dp_t, v_bc(3,2) = 0.0_dp_t, w_bc(3,2) = 0.0_dp_t
+  ! (the generated file allocates nodal, pmask, prob_lo, prob_hi with dim_in entries in probin_init; fixed extent 3 here, read through (1:dm) or whole)
   logical, save :: pmask(3) = .false., nodal(3) = .true.
+  real(dp_t), save :: prob_lo(3) = 0.0_dp_t, prob_hi(3) = 1.0_dp_t
+  integer, parameter :: MAX_ALLOWED_LEVS = 10
+  integer, save :: extrap_comp = 0
+  namelist /probin/ dim_in, nscal, prob_type, grav, boussinesq, max_step, stop_time, ref_ratio, ng_cell, ng_grow, max_levs, nlevs, max_grid_size, stencil_order, &
+       init_iter, plot_int, chk_int, regrid_int, amr_buf_width, cluster_min_eff, cluster_min_width, cluster_blocking_factor, prob_lo_x, prob_lo_y, prob_lo_z, &
+       prob_hi_x, prob_hi_y, prob_hi_z, use_hypre, verbose, mg_verbose, cg_verbose, mg_bottom_solver, hg_bottom_solver, max_mg_bottom_nlevels, init_shrink, &
+       fixed_dt, do_initial_projection, need_inputs, fixed_grids, grids_file_name, restart, bcx_lo, bcy_lo, bcz_lo, bcx_hi, bcy_hi, bcz_hi, diffusion_type, &
+       max_dt_growth, slope_order, use_godunov_debug, use_minion, plot_base_name, check_base_name, visc_coef, diff_coef, cflfac, n_cellx, n_celly, n_cellz, job_name, &
+       rho_bc, trac_bc, u_bc, v_bc, w_bc
 contains
+  ! probin.template:44-196 (what the hot path's callers rely on: the namelist read, amr_buf_width >= regrid_int, prob_lo / prob_hi, pmask from the bc flags, extrap_comp)
+  subroutine probin_init()
+    character(len=128) :: fname
+    logical :: lexist, need
+    integer :: un, ierr
+    need = .true.
+    call get_environment_variable('PROBIN', fname, status=ierr)
+    if (ierr == 0) then
+       call read_nml(fname); need = .false.
+    end if
+    if (need .and. command_argument_count() >= 1) then
+       call get_command_argument(1, value=fname)
+       inquire(file=fname, exist=lexist)
+       if (lexist) then
+          call read_nml(fname); need = .false.
+       end if
+    end if
+    inquire(file='inputs_varden', exist=lexist)
+    if (need .and. lexist) then
+       call read_nml('inputs_varden'); need = .false.
+    end if
+    if (max_levs > 1 .and. fixed_grids == '' .and. regrid_int < 1) error stop 'regrid_int must be specified if max_levs > 1'
+    if (regrid_int > 0 .and. amr_buf_width < regrid_int) amr_buf_width = regrid_int
+    prob_lo = (/ prob_lo_x, prob_lo_y, prob_lo_z /); prob_hi = (/ prob_hi_x, prob_hi_y, prob_hi_z /)
+    nodal = .true.
+    pmask = .false.
+    if (bcx_lo == -1 .and. bcx_hi == -1) pmask(1) = .true.
+    if (dim_in > 1 .and. bcy_lo == -1 .and. bcy_hi == -1) pmask(2) = .true.
+    if (dim_in > 2 .and. bcz_lo == -1 .and. bcz_hi == -1) pmask(3) = .true.
+    extrap_comp = dim_in + nscal + 2
+  contains
+    subroutine read_nml(f)
+      character(len=*), intent(in) :: f
+      open(newunit=un, file=f, status='old', action='read')
+      read(unit=un, nml=probin)
+      close(unit=un)
+      inputs_file_used = f
+    end subroutine read_nml
+  end subroutine probin_init
+  subroutine probin_close()
+  end subroutine probin_close
   subroutine probin_to_library(rank, nranks, device)
     integer, intent(in) :: rank, nranks, device
     type(vdn_params) :: prm
     call probin_defaults(prm)
-    prm%nscal = nscal; prm%prob_type = prob_type; prm%slope_order = slope_order; prm%verbose = verbose
+    prm%dm = dim_in; prm%nscal = nscal; prm%prob_type = prob_type; prm%slope_order = slope_order; prm%verbose = verbose
+    prm%use_minion = merge(1, 0, use_minion); prm%boussinesq = boussinesq; prm%stencil_order = stencil_order; prm%diffusion_type = diffusion_type
     prm%cflfac = cflfac; prm%max_dt_growth = max_dt_growth; prm%visc_coef = visc_coef; prm%diff_coef = diff_coef
+    prm%u_bc = transpose(u_bc); prm%v_bc = transpose(v_bc); prm%w_bc = transpose(w_bc); prm%rho_bc = transpose(rho_bc); prm%trac_bc = transpose(trac_bc)
     call varden_amd_initialize(prm, rank, nranks, device)
   end subroutine probin_to_library
 end module probin_module
