@@ -200,6 +200,10 @@ def spawn_ranks(args):
 
 def main():
     args = parse_args()
+    # the one-GPU rehearsals of the N > 1 transport (packed buffers through a 1-rank RCCL communicator; every rank on GPU 0 over the RCCL test double) are switches
+    # of the TESTING build of the library; a plain run loads the product, which reads no environment variable
+    if os.environ.get("VDN_FORCE_PACKED") or os.environ.get("VDN_BENCH_ONE_DEVICE") == "1" or os.environ.get("VDN_RCCL_LIB"):
+        os.environ.setdefault("VDN_LIB_FLAVOUR", "testing")
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
         sys.exit(spawn_ranks(args))
     if args.scaling == "strong" and args.config == "256":
@@ -570,7 +574,7 @@ def main():
         out = {
             "metric": "cells*steps/sec on advance_timestep",
             "value": round(value, 1), "unit": "cells*steps/s",
-            "n_gpus": world, "rccl_nranks": rccl_nranks, "transport": transport, "steps": args.steps, "warmup": args.warmup,
+            "n_gpus": world, "rccl_nranks": rccl_nranks, "transport": transport, "library": capi.load().vdn_build_flavour().decode(), "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(1e3 * el / args.steps, 3),
             "higher_is_better": True, "scaling": args.scaling if not amr else "strong", "vs_baseline": None,
             "dtype": "f64", "data": "synthetic",

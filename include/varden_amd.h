@@ -114,6 +114,9 @@ int  vdn_init(const vdn_params *prm, int rank, int nranks, int device);
  * VDN_FUSED_KCHUNKS); cell-centred multigrid (VDN_GSRB_PAIR, VDN_CC_HALO_FACES, VDN_MG_*, VDN_MAC_*, VDN_OVERLAP*); nodal
  * multigrid (VDN_ND_*, VDN_HG_FAST); composite solves (VDN_NDF_*, VDN_NDM_*, VDN_MLCC_*, VDN_FB_FACES); box-batched kernels (VDN_BATCH_*). */
 const char *vdn_debug_switches(void);
+/* "release": libvarden_amd.so -- reads NO environment variable (the switches are compiled out, RCCL is the only transport); "testing": libvarden_amd_testing.so,
+ * the same objects with the switch table and the test-transport seam compiled in (the test suite, the A/B tools, the one-GPU transport rehearsal) */
+const char *vdn_build_flavour(void);
 int  vdn_finalize(void);
 const char *vdn_last_error(void);
 /* the hipError_t (as int; 0 = none) most recently found pending at the entry of a call and cleared there (see Conventions); clear != 0 resets it */

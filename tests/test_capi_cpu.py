@@ -24,6 +24,23 @@ def test_library_exports_every_declared_symbol():
     for s in syms:
         assert hasattr(lib, s), "libvarden_amd.so does not export %s" % s
     assert set(syms) == set(capi.SIGNATURES), set(syms) ^ set(capi.SIGNATURES)
+    # both builds of the library (csrc/Makefile): the product and the suite's, the same objects but for the switch table and the transport seam
+    flav = {}
+    for name in ("libvarden_amd.so", "libvarden_amd_testing.so"):
+        L = C.CDLL(os.path.join(ROOT, "varden_amd", "csrc", name), mode=os.RTLD_LOCAL)
+        for s in syms:
+            assert hasattr(L, s), "%s does not export %s" % (name, s)
+        L.vdn_build_flavour.restype = C.c_char_p
+        flav[name] = L.vdn_build_flavour()
+    assert flav == {"libvarden_amd.so": b"release", "libvarden_amd_testing.so": b"testing"}, flav
+    assert lib.vdn_build_flavour() == capi.FLAVOUR.encode()
+
+
+def test_release_build_reads_no_switch():
+    """the shipped library's vdn_env never calls getenv: its switch table reports the release note, whatever the environment holds"""
+    L = C.CDLL(os.path.join(ROOT, "varden_amd", "csrc", "libvarden_amd.so"), mode=os.RTLD_LOCAL)
+    L.vdn_debug_switches.restype = C.c_char_p
+    assert L.vdn_debug_switches().startswith(b"release build")
 
 
 def test_param_defaults_in_sync_with_reference_parameters():

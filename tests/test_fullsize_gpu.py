@@ -230,8 +230,18 @@ def test_tagged_hierarchy_step_at_256(gpu, max_levs):
     prm = default_params(cflfac=0.9)
     levels = driver.VardenAMR.tagged_grids(N, WALLS, prm, max_levs=max_levs, max_grid_size=256)
     assert len(levels) == max_levs - 1 and len(levels[0]) > 100
+    # round 6: the full-size step AGAINST THE ORACLE inside the driver's suite -- tests/golden/amr<n>_fullsize_samples.npz holds what the CPU oracle computed on
+    # exactly these box lists (tools/amr_fullsize_fixture.py, run in the build container: the oracle needs minutes here): dt, the FAC iteration counts, per-box
+    # sums and sampled cells of u, rho, tracer, grad p on every level.  The lists themselves are a fixture too (tests/golden/amr_grids_256_l<n>.json)
+    import json, os
+    gold = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    want = json.load(open(os.path.join(gold, "amr_grids_256_l%d.json" % max_levs)))
+    assert [[[list(b[0]), list(b[1])] for b in lb] for lb in levels] == want, "tag_boxes + make_new_grids no longer produce the committed box lists"
+    fx = np.load(os.path.join(gold, "amr%d_fullsize_samples.npz" % max_levs))
     G = driver.VardenAMR(N, levels[0], WALLS, params=prm, finer_levels=levels[1:], init_shrink=0.1, init_iter=1, do_initial_projection=1,
                          max_grid_size=256, swap_state=True)
+    assert G.dt == float(fx["dt_startup"]), (G.dt, float(fx["dt_startup"]))
+    assert G.initial_projection_stat[0] == int(fx["fac_initial_projection"])
 
     def composite_mass():
         """sum of rho * cell volume over the cells of every level that no finer level covers"""
@@ -253,6 +263,27 @@ def test_tagged_hierarchy_step_at_256(gpu, max_levs):
     m1 = composite_mass()
     assert abs(m1 - m0) <= 1e-12 * m0, "composite mass drifted by %.3e in one step" % ((m1 - m0) / m0)
     mac, hg = adv.last_solver_stats("mac"), adv.last_solver_stats("hg")
+    # ---- against the oracle's fixture: equal FAC counts, dt bit for bit, fields to 1e-9 of the level's max (grad p: 1e-6, the projection's tolerance) ----
+    assert (mac[0], hg[0]) == (int(fx["fac_mac"]), int(fx["fac_hg"])), ((mac[0], hg[0]), (int(fx["fac_mac"]), int(fx["fac_hg"])))
+    assert G.dt == float(fx["dt_step"]), (G.dt, float(fx["dt_step"]))
+    for l in range(max_levs):
+        idx, val, bsum, amax = fx["idx_%d" % l], fx["val_%d" % l], fx["boxsum_%d" % l], fx["absmax_%d" % l]
+        tol = np.array([1e-9] * 5 + [1e-6] * 3) * np.maximum(amax, 1e-300)
+        nb = G.uold[l].nfabs()
+        assert nb == bsum.shape[0]
+        seen = 0
+        for i in range(nb):
+            lo, hi = G.uold[l].get_box(i)
+            f = np.concatenate([G.uold[l].to_numpy(i)[3:-3, 3:-3, 3:-3], G.sold[l].to_numpy(i)[3:-3, 3:-3, 3:-3], G.gp[l].to_numpy(i)[1:-1, 1:-1, 1:-1]], axis=3)
+            ncell = float(np.prod(f.shape[:3]))
+            assert (np.abs(f.sum(axis=(0, 1, 2)) - bsum[i]) <= tol * ncell).all(), (l, i, f.sum(axis=(0, 1, 2)) - bsum[i])
+            m = np.all((idx >= np.array(lo)) & (idx <= np.array(hi)), axis=1)
+            if m.any():
+                q = idx[m] - np.array(lo)
+                d = np.abs(f[q[:, 0], q[:, 1], q[:, 2]] - val[m])
+                assert (d <= tol).all(), (l, i, d.max(axis=0), tol)
+                seen += int(m.sum())
+        assert seen == len(idx), (l, seen, len(idx))
     hg_tol = 1e-11 if max_levs == 2 else 1e-10
     assert mac[0] < 40 and hg[0] < 40 and mac[2] <= 1e-10 * mac[1] and hg[2] <= hg_tol * hg[1], (mac, hg)
     for mfs, comp in ((G.sold, 0), (G.uold, 2)):

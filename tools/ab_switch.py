@@ -32,6 +32,6 @@ code = textwrap.dedent("""
     print("RESULT ms/step %%.3f  phases %%s  hash %%s" %% (1e3 * el / %d, {k: round(1e3 * v / %d, 3) for k, v in ph.items()}, h.hexdigest()[:16]))
 """ % (ROOT, n, steps, steps, steps))
 for v in vals:
-    env = dict(os.environ); env[name] = v
+    env = dict(os.environ, VDN_LIB_FLAVOUR="testing"); env[name] = v      # (the switches live in the testing build)
     r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, cwd=ROOT)
     print(name, "=", v, ":", [ln for ln in r.stdout.splitlines() if ln.startswith("RESULT")] or r.stderr[-1500:], flush=True)

@@ -66,7 +66,7 @@ def main():
         return child(sys.argv[1])
     rows = []
     for mode, env in (("local", {}), ("packed1", {"VDN_FORCE_PACKED": "1"}), ("packed2", {"VDN_FORCE_PACKED": "2"})):
-        p = subprocess.run([sys.executable, os.path.abspath(__file__), mode], env=dict(os.environ, **env), capture_output=True, text=True, timeout=600)
+        p = subprocess.run([sys.executable, os.path.abspath(__file__), mode], env=dict(os.environ, VDN_LIB_FLAVOUR="testing", **env), capture_output=True, text=True, timeout=600)
         if p.returncode != 0:
             print("mode %s failed:\n%s\n%s" % (mode, p.stdout[-2000:], p.stderr[-2000:]))
             continue

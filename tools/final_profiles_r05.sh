@@ -1,6 +1,7 @@
 #!/bin/bash
 # the round's judged profile artefacts, written under gpurun_out/r05/ (copied into profiles/ afterwards)
 export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
+export VDN_LIB_FLAVOUR=testing      # (round 6: the VDN_* switches below exist in the testing build of the library only)
 O=$GRAFT_REPO_ROOT/gpurun_out/r05; mkdir -p $O
 # 1. kernel trace + stats of the default bench line
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/bench -o b -- python3 bench.py --steps 5 --warmup 2 --skip-cpu --no-extra --no-pmc > $O/bench.log 2>&1

@@ -8,7 +8,10 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libvarden_amd.so")
+# VDN_LIB_FLAVOUR=testing: the suite's build of the same objects with the launch-form switches (VDN_*) and the test-transport seam compiled in
+# (csrc/Makefile); anything else: the product, which reads no environment variable
+FLAVOUR = "testing" if os.environ.get("VDN_LIB_FLAVOUR") == "testing" else "release"
+LIB_PATH = os.path.join(_HERE, "csrc", "libvarden_amd_testing.so" if FLAVOUR == "testing" else "libvarden_amd.so")
 
 
 class Params(C.Structure):
@@ -60,6 +63,7 @@ SIGNATURES = {
     "vdn_init": (C.c_int, [C.POINTER(Params), C.c_int, C.c_int, C.c_int]),
     "vdn_finalize": (C.c_int, []),
     "vdn_last_error": (C.c_char_p, []),
+    "vdn_build_flavour": (C.c_char_p, []),
     "vdn_last_stale_hip_error": (C.c_int, [C.c_int]),
     "vdn_set_stream": (C.c_int, [_VP]),
     "vdn_device_synchronize": (C.c_int, []),

@@ -58,7 +58,11 @@ static void rccl_load() {
   // ranks on one GPU), and an environment variable alone must not be able to swap the transport of the shipping library: VDN_RCCL_LIB
   // is honoured only together with VDN_TESTING=1 AND a library that identifies itself through vdn_test_transport_magic(); anything else
   // named there fails the call.  vdn_comm_transport() says which one is in use (bench.py prints it).
+#ifdef VDN_TESTING_BUILD
   const char *forced = vdn_env("VDN_RCCL_LIB");
+#else
+  const char *forced = nullptr;            // the release build has no seam for another transport: RCCL by name, nothing else
+#endif
   // the handle and the entry points go into a local copy: g_rccl is assigned only when the handshake and every lookup succeeded, so a
   // failed load leaves no half-bound state behind (a later call would otherwise return early here and jump through null pointers)
   Rccl R;

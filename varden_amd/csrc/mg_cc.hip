@@ -1928,10 +1928,14 @@ static void cc_reload(CCMG &M, vdn_multifab *rh, vdn_multifab *phi, const int bc
       e[d][0] = (bx.lo[d] == la->pd[lev].lo[d]) ? bc[d][0] : VDN_BC_INT;
       e[d][1] = (bx.hi[d] == la->pd[lev].hi[d]) ? bc[d][1] : VDN_BC_INT;
     }
-    if (zero_guess) HIPCHK(hipMemsetAsync(L0.phi, 0, sizeof(double) * L0.sz, ctx().stream));      // (the caller's phi is neither zero-filled nor read)
+    if (zero_guess) { if (!D0.split) HIPCHK(hipMemsetAsync(L0.phi, 0, sizeof(double) * L0.sz, ctx().stream)); }      // (the caller's phi is neither zero-filled nor read; by colour: the split arrays hold phi)
     else hipLaunchKernelGGL(kk_cc_load_phi, g3(L0.n[0], L0.n[1], L0.n[2], BLK), BLK, 0, ctx().stream, L0, phi->fabs[b], bx.lo[0], bx.lo[1], bx.lo[2]);
     hipLaunchKernelGGL(kk_cc_load_rh, g3(L0.n[0], L0.n[1], L0.n[2], BLK), BLK, 0, ctx().stream, L0, rh->fabs[b], phi->fabs[b],
                        bx.lo[0], bx.lo[1], bx.lo[2], e[0][0], e[0][1], e[1][0], e[1][1], e[2][0], e[2][1], zero_guess ? 1 : 0);
+  }
+  if (D0.split) {              // a kept hierarchy whose finest level lives by colour (the level-0 V-cycles of the composite MAC solve): the new right-hand side and guess
+    cc_to_split(D0, zero_guess ? 2 : 3);
+    if (zero_guess) for (const CBox &B : D0.boxes) HIPCHK(hipMemsetAsync(B.sp.phi[0], 0, sizeof(double) * 2 * B.sp.tot, ctx().stream));      // (phi[0], phi[1] are adjacent: cc_split_setup)
   }
 }
 static void cc_store(CCMG &M, vdn_multifab *phi, const int bc[3][2], vdn_multifab *add_to = nullptr) {
@@ -1972,7 +1976,13 @@ int cc_solve(vdn_multifab *rh, vdn_multifab *phi, vdn_multifab **beta, const dou
     g_mac_level_form = !M.dlev[0].split ? 0 : (vdn_env("VDN_MAC_SPLIT") && atoi(vdn_env("VDN_MAC_SPLIT")) == 2) ? 2 : 1;
   }
   else if (keep && keep->built) { cc_reload(M, rh, phi, bc, zero_guess); g_mac_level_form = 0; }
-  else { cc_setup(M, rh, phi, alpha, beta, dx, bc, rho); g_mac_level_form = 0; }
+  else {
+    cc_setup(M, rh, phi, alpha, beta, dx, bc, rho);
+    g_mac_level_form = 0;
+    // round 6: the V-cycles a composite MAC solve runs on its level 0 (a kept hierarchy, one cycle per FAC iteration, the density form) take the level by colour
+    // too -- for the tagged 256^3 hierarchies that is a whole 256^3 level, 23 cycles per step
+    if (keep && max_iter < 0 && !alpha && cc_split_ok(M)) { cc_split_setup(M); cc_to_split(M.dlev[0], 1); g_mac_level_form = 1; }
+  }
   if (keep) keep->built = true;
   CDLev &D0 = M.dlev[0];
   const bool single = (M.dlev.size() == 1 && M.tail.empty());
@@ -1983,13 +1993,16 @@ int cc_solve(vdn_multifab *rh, vdn_multifab *phi, vdn_multifab **beta, const dou
     for (int c = 0; c < -max_iter; c++) {
       if (single) { const int N = std::max(D0.ng[0], std::max(D0.ng[1], D0.ng[2])); cc_gsrb_d(M, D0, std::max(P.mg_nub, N * N)); continue; }
       cc_run_cycle(M, 2, [&] {
-        cc_gsrb_d(M, D0, P.mg_nu1);
-        cc_residual_d(M, D0, false);
+        const bool slabs = D0.split && !D0.halo && D0.boxes.size() == 1 && mac_slab(D0.boxes[0].L) > 0;
+        if (slabs) cc_split_run(M, D0, false, P.mg_nu1, true, false, false);
+        else { cc_gsrb_d(M, D0, P.mg_nu1); cc_residual_d(M, D0, false); }
         cc_restrict_down(M, 0);
         if (M.dlev.size() > 1) cc_vcycle_d(M, 1); else cc_vcycle_t(M, 0);
-        cc_prolong_smooth(M, 0, P.mg_nu2);
+        if (slabs) cc_split_run(M, D0, true, P.mg_nu2, false, false, false);
+        else cc_prolong_smooth(M, 0, P.mg_nu2);
       });
     }
+    if (D0.split) cc_from_split(D0);
     cc_store(M, phi, bc, add_to);
     if (cycles) *cycles = -max_iter; if (res0) *res0 = 0.0; if (res) *res = 0.0;
     if (!keep) arena_release(mark);

@@ -176,8 +176,24 @@ static const EnvSwitch g_switches[] = {
   { "VDN_BATCH_FLAT", "0: no flattened (i,j) plane mapping for badly filling tiles" },
   { "VDN_BATCH_CHUNK", "0: box-batched workgroups take strided instead of contiguous plane chunks" }
 };
+// Round 6: the switches exist in the TESTING build only (libvarden_amd_testing.so: -DVDN_TESTING_BUILD on this file and exchange.hip; the suite, the A/B tools and
+// the one-GPU transport rehearsal load it -- VDN_LIB_FLAVOUR=testing in the Python mirror).  The shipped libvarden_amd.so reads NO environment variable: every launch
+// form is the default one, every choice that matters is a field of vdn_params; vdn_init says so once if VDN_* switches are set.
+extern "C" const char *vdn_build_flavour(void) {
+#ifdef VDN_TESTING_BUILD
+  return "testing";
+#else
+  return "release";
+#endif
+}
 const char *vdn_env(const char *name) {
-  for (const EnvSwitch &e : g_switches) if (!strcmp(e.name, name)) return getenv(name);
+  for (const EnvSwitch &e : g_switches) if (!strcmp(e.name, name)) {
+#ifdef VDN_TESTING_BUILD
+    return getenv(name);
+#else
+    return nullptr;
+#endif
+  }
   vdn_fail("internal: the switch %s is not declared in the table of runtime.hip", name);
 }
 extern char **environ;
@@ -191,12 +207,19 @@ static void env_warn_unknown() {
     const size_t len = eq ? (size_t)(eq - *e) : strlen(*e);
     bool known = false;
     for (const EnvSwitch &s : g_switches) if (strlen(s.name) == len && !strncmp(s.name, *e, len)) known = true;
+    if (!strncmp(*e, "VDN_LIB_FLAVOUR", 15)) continue;                  // (read by the Python mirror: which of the two libraries to load)
     if (!known) fprintf(stderr, "varden_amd: warning: environment variable %.*s is not a switch of this library (vdn_debug_switches lists them)\n", (int)len, *e);
+#ifndef VDN_TESTING_BUILD
+    else fprintf(stderr, "varden_amd: note: %.*s is set but this is the release build: launch-form switches are compiled out (libvarden_amd_testing.so reads them)\n", (int)len, *e);
+#endif
   }
 }
 extern "C" const char *vdn_debug_switches(void) {
   static std::string out;
-  if (out.empty()) for (const EnvSwitch &s : g_switches) { const char *v = getenv(s.name); out += s.name; out += v ? std::string(" = ") + v : std::string(" (unset)"); out += ": "; out += s.doc; out += "\n"; }
+#ifndef VDN_TESTING_BUILD
+  if (out.empty()) out = "release build: the switches below are compiled out, every launch form is the default one (libvarden_amd_testing.so reads them)\n";
+#endif
+  if (out.find("VDN_TESTING ") == std::string::npos) for (const EnvSwitch &s : g_switches) { const char *v = getenv(s.name); out += s.name; out += v ? std::string(" = ") + v : std::string(" (unset)"); out += ": "; out += s.doc; out += "\n"; }
   return out.c_str();
 }
 
