@@ -18,8 +18,10 @@
  *                         nu1 red-black sweeps on the fine level (homogeneous interface), one V-cycle of the single-level
  *                         multigrid on the whole coarse level, piecewise-constant prolongation, nu2 fine sweeps.
  * Refinement ratio 2, up to four levels, every refined level a LIST OF BOXES (round 5: level arrays with a cell mask, face fields box by box -- vo.h);
- * the levels properly nested (every box, coarsened and grown by two cells, inside the next coarser level or outside the domain).  Level 0 is one box;
- * no periodic sides on a hierarchy.
+ * the levels properly nested (every box, coarsened and grown by two cells, inside the next coarser level or outside the domain).  Level 0 is one box.
+ * Periodic sides (round 6): level 0 -- one box that spans the domain -- wraps; a refined level must stay clear of the periodic faces (its boxes, grown by the
+ * ghost width, inside the domain in that direction: require_periodic_ok), so that every value it reads beyond its own cells is a coarse-fine interface value or a
+ * cell of the level, never a periodic image.  (A refined level that reaches a periodic face is held on the HIP side by translation-invariance properties only.)
  */
 #include <math.h>
 #include <stdlib.h>
@@ -205,11 +207,20 @@ static void level_fill_boundary(vo_fab *f, const int pmask[3], const int pdlo[3]
   for (int d = 0; d < 3; d++) pm[d] = pmask[d] && f->lo[d] == pdlo[d] && f->hi[d] == pdhi[d];
   vo_fill_boundary(f, pm);
 }
-static void require_no_periodic(int nlev, const vo_level *const *lev, const int pmask[3], const char *who)
+/* periodic directions: level 0 spans the domain and wraps; every refined level keeps `margin` cells (its ghost width; 4 covers every caller) between its bounding
+ * box and the periodic faces.  mf[n]: any cell-centred field of level n (its lo / hi are the level's bounding box) */
+static void require_periodic_ok(int nlev, vo_fab *const *mf, const int pmask[3], const int *pd, const char *who)
 {
-  int multi = 0;
-  for (int n = 0; lev && n < nlev; n++) if (lv_multi(lev[n])) multi = 1;
-  if (multi && (pmask[0] || pmask[1] || pmask[2])) { fprintf(stderr, "%s: levels of several boxes on a periodic domain are not supported by the oracle\n", who); abort(); }
+  if (!(pmask[0] || pmask[1] || pmask[2])) return;
+  for (int d = 0; d < 3; d++) {
+    if (!pmask[d]) continue;
+    if (mf[0]->lo[d] != pd[d] || mf[0]->hi[d] != pd[3 + d]) { fprintf(stderr, "%s: level 0 must span the domain in the periodic direction %d\n", who, d); abort(); }
+    for (int n = 1; n < nlev; n++)
+      if (mf[n]->lo[d] - 4 < pd[6 * n + d] || mf[n]->hi[d] + 4 > pd[6 * n + 3 + d]) {
+        fprintf(stderr, "%s: level %d reaches the periodic faces of direction %d (cells %d..%d of %d..%d): not supported by the oracle\n", who, n, d, mf[n]->lo[d], mf[n]->hi[d], pd[6 * n + d], pd[6 * n + 3 + d]);
+        abort();
+      }
+  }
 }
 #define LEV(lev, n) ((lev) ? (lev)[n] : NULL)
 /* ml_restrict_and_fill: average down, then per level the coarse-fine ghost interpolation, the same-level periodic images, the physical boundary.
@@ -222,7 +233,7 @@ void vo_ml_restrict_and_fill(int nlev, vo_fab **mf, int icomp, int bcomp, int nc
 void vo_ml_restrict_and_fill_g(int nlev, const vo_level *const *lev, vo_fab **mf, int icomp, int bcomp, int nc, int same_boundary, const vo_bc *bc, const int pmask[3],
                                const int *pd, const vdn_params *prm)
 {
-  require_no_periodic(nlev, lev, pmask, "vo_ml_restrict_and_fill");
+  require_periodic_ok(nlev, mf, pmask, pd, "vo_ml_restrict_and_fill");
   for (int n = nlev - 1; n >= 1; n--) vo_ml_cc_restriction_g(mf[n - 1], mf[n], LEV(lev, n), icomp, nc);
   for (int n = 0; n < nlev; n++) {
     if (n > 0) vo_fill_ghost_cells_g(mf[n], mf[n - 1], LEV(lev, n), icomp, nc);
@@ -252,12 +263,15 @@ typedef struct clev {
 } clev;
 static inline long cidx(const clev *M, int i, int j, int k) { return vo_idx(&M->res, i, j, k, 0); }
 static inline int cvalid(const clev *M, int i, int j, int k) { return lv_valid(M->L, &M->res, i, j, k); }
+/* (a periodic direction has no outside: the index wraps -- only level 0 ever asks, require_periodic_ok) */
+static inline int is_per(const clev *M, int d) { return M->ell[d][0] == VDN_BC_PER; }
+static inline int wrap1(const clev *M, int d, int q) { const int N = M->pdhi[d] - M->pdlo[d] + 1; return q < M->pdlo[d] ? q + N : (q > M->pdhi[d] ? q - N : q); }
 static inline int in_domain1(const clev *M, int d, int q) { return q >= M->pdlo[d] && q <= M->pdhi[d]; }
 /* value of F beyond face (d, s) of the valid cell (i,j,k) whose own value is p0, as the OPERATOR OF THE RESIDUAL reads it */
 static inline double nb_res(const clev *M, const vo_fab *F, double *const G[6], int i, int j, int k, int d, int s, double p0)
 {
   int q[3] = { i, j, k }; q[d] += s ? 1 : -1;
-  if (!in_domain1(M, d, q[d])) return M->ell[d][s] == VDN_BC_NEU ? p0 : -p0;
+  if (!in_domain1(M, d, q[d])) { if (is_per(M, d)) q[d] = wrap1(M, d, q[d]); else return M->ell[d][s] == VDN_BC_NEU ? p0 : -p0; }
   if (cvalid(M, q[0], q[1], q[2])) return VF(F, q[0], q[1], q[2], 0);
   return G[2 * d + s][cidx(M, i, j, k)];
 }
@@ -265,7 +279,7 @@ static inline double nb_res(const clev *M, const vo_fab *F, double *const G[6], 
 static inline double nb_rlx(const clev *M, const vo_fab *F, double *const G[6], int i, int j, int k, int d, int s)
 {
   int q[3] = { i, j, k }; q[d] += s ? 1 : -1;
-  if (!in_domain1(M, d, q[d])) return 0.0;
+  if (!in_domain1(M, d, q[d])) { if (is_per(M, d)) q[d] = wrap1(M, d, q[d]); else return 0.0; }
   if (cvalid(M, q[0], q[1], q[2])) return VF(F, q[0], q[1], q[2], 0);
   return G[2 * d + s][cidx(M, i, j, k)];
 }
@@ -274,6 +288,7 @@ static inline double crse_val(const clev *C, const vo_fab *pc, const int Q[3])
 {
   int q[3] = { Q[0], Q[1], Q[2] }; double w = 1.0;
   for (int d = 0; d < 3; d++) {
+    if (is_per(C, d)) { q[d] = wrap1(C, d, q[d]); continue; }
     if (q[d] < C->pdlo[d]) { q[d] = C->pdlo[d]; if (C->ell[d][0] != VDN_BC_NEU) w = -w; }
     else if (q[d] > C->pdhi[d]) { q[d] = C->pdhi[d]; if (C->ell[d][1] != VDN_BC_NEU) w = -w; }
   }
@@ -465,7 +480,7 @@ int vo_ml_cc_solve_g(int nlev, const vo_level *const *lev, vo_fab **rh, vo_fab *
                      const int *pd, double rel_eps, int max_iter, const vdn_params *prm, vo_fab **beta_base, vo_mgstat *st, double **ghost)
 {
   if (nlev < 2 || nlev > VO_MAXLEV) { fprintf(stderr, "vo_ml_cc_solve: 2..%d levels\n", VO_MAXLEV); abort(); }
-  if (pmask[0] || pmask[1] || pmask[2]) { fprintf(stderr, "vo_ml_cc_solve: periodic hierarchies are not supported by the oracle\n"); abort(); }
+  require_periodic_ok(nlev, rh, pmask, pd, "vo_ml_cc_solve");
   clev M[VO_MAXLEV];
   for (int n = 0; n < nlev; n++) {
     clev *m = &M[n];
@@ -660,7 +675,7 @@ void vo_ml_macproject(int nlev, vo_fab **umac, vo_fab **rho, vo_fab **mac_rhs, c
 void vo_ml_macproject_g(int nlev, const vo_level *const *lev, vo_bmf *umac, vo_fab **rho, vo_fab **mac_rhs, const double *dx, const vo_bc *bc, const int pmask[3], const int *pd,
                         const vdn_params *prm, vo_mgstat *st)
 {
-  require_no_periodic(nlev, lev, pmask, "vo_ml_macproject");
+  require_periodic_ok(nlev, rho, pmask, pd, "vo_ml_macproject");
   vo_fab rh[VO_MAXLEV], phi[VO_MAXLEV], beta[3 * VO_MAXLEV], *rhp[VO_MAXLEV], *php[VO_MAXLEV], *bp[3 * VO_MAXLEV];
   int ellbc[VO_MAXLEV][3][2];
   for (int n = 0; n < nlev; n++) {
@@ -712,7 +727,9 @@ void vo_ml_macproject_g(int nlev, const vo_level *const *lev, vo_bmf *umac, vo_f
         for (int k = lo[2]; k <= rhi[2]; k++) for (int j = lo[1]; j <= rhi[1]; j++) for (int i = lo[0]; i <= rhi[0]; i++) {
           int q[3] = { i, j, k }, m[3] = { i, j, k }; m[d] -= 1;
           double vq, vm;
-          if (q[d] > pdhi[d]) { if (ellbc[n][d][1] == VDN_BC_NEU) continue; vm = VF(&phi[n], m[0], m[1], m[2], 0); vq = -vm; }
+          if (q[d] > pdhi[d] && ellbc[n][d][1] == VDN_BC_PER) { int w[3] = { q[0], q[1], q[2] }; w[d] = pdlo[d]; vm = VF(&phi[n], m[0], m[1], m[2], 0); vq = VF(&phi[n], w[0], w[1], w[2], 0); }
+          else if (m[d] < pdlo[d] && ellbc[n][d][0] == VDN_BC_PER) { int w[3] = { m[0], m[1], m[2] }; w[d] = pdhi[d]; vq = VF(&phi[n], q[0], q[1], q[2], 0); vm = VF(&phi[n], w[0], w[1], w[2], 0); }
+          else if (q[d] > pdhi[d]) { if (ellbc[n][d][1] == VDN_BC_NEU) continue; vm = VF(&phi[n], m[0], m[1], m[2], 0); vq = -vm; }
           else if (m[d] < pdlo[d]) { if (ellbc[n][d][0] == VDN_BC_NEU) continue; vq = VF(&phi[n], q[0], q[1], q[2], 0); vm = -vq; }
           else {
             const int qv = lv_valid(L, &rh[n], q[0], q[1], q[2]), mv = lv_valid(L, &rh[n], m[0], m[1], m[2]);
@@ -834,7 +851,7 @@ void vo_ml_hgproject(int nlev, int proj_type, vo_fab **unew, vo_fab **uold, vo_f
 void vo_ml_hgproject_g(int nlev, const vo_level *const *lev, int proj_type, vo_fab **unew, vo_fab **uold, vo_fab **rhohalf, vo_fab **p, vo_fab **gp, const double *dx, double dt,
                        const vo_bc *bc, const int pmask[3], const int *pd, const vdn_params *prm, vo_mgstat *st)
 {
-  require_no_periodic(nlev, lev, pmask, "vo_ml_hgproject");
+  require_periodic_ok(nlev, unew, pmask, pd, "vo_ml_hgproject");
   vo_fab rh[VO_MAXLEV], phi[VO_MAXLEV], gphi[VO_MAXLEV], coeffs[VO_MAXLEV], *rhp[VO_MAXLEV], *php[VO_MAXLEV], *cfp[VO_MAXLEV];
   int ellbc[VO_MAXLEV][3][2];
   int nd1[3] = { 1, 1, 1 };
@@ -956,7 +973,8 @@ static void k_halftime(vo_fab *out, vo_fab **in, const vo_bc *bcb, const int *lo
 void vo_ml_advance_timestep_g(int NL, const vo_level *const *lev, vo_state *S, const double *dx, double dt, const vo_bc *bc, const int pmask[3], const int *pd,
                               const vdn_params *prm, int proj_type, vo_mgstat st[2])
 {
-  require_no_periodic(NL, lev, pmask, "vo_ml_advance_timestep");
+  if ((pmask[0] || pmask[1] || pmask[2]) && lev && lv_multi(lev[0])) { fprintf(stderr, "vo_ml_advance_timestep: a periodic level 0 must be ONE box in the oracle\n"); abort(); }
+  { vo_fab *chk[VO_MAXLEV] = { 0 }; for (int n = 0; n < NL; n++) chk[n] = &S[n].uold; require_periodic_ok(NL, chk, pmask, pd, "vo_ml_advance_timestep"); }
   const int dm = 3, nscal = prm->nscal;
   vo_fab mac_rhs[VO_MAXLEV], rhohalf[VO_MAXLEV], vel_force[VO_MAXLEV], scal_force[VO_MAXLEV], divu[VO_MAXLEV];
   vo_bmf umac[3 * VO_MAXLEV], sedge[3 * VO_MAXLEV], sflux[3 * VO_MAXLEV], uedge[3 * VO_MAXLEV], uflux[3 * VO_MAXLEV];

@@ -710,7 +710,8 @@ typedef struct mlnd {
   int nlev;
   ndlev L[ND_MAXLEV];                 /* sig = MASKED sigma (zero in the cells covered by the next finer level) */
   double *sigfull[ND_MAXLEV];         /* full sigma (relaxation of the levels >= 1; level 0's correction solve takes the fab) */
-  int per[3];
+  int per[3];                         /* all zero: a refined level stays clear of the periodic faces (vo_amr.c: require_periodic_ok) ... */
+  int per0[3];                        /* ... and level 0, which spans the domain, wraps (round 6) */
   int org[ND_MAXLEV][3];              /* global index of local node 0 */
   unsigned char *under[ND_MAXLEV];    /* per node of level n, of the 8 cells around it: 1 = some are covered by level n+1 (its equation takes the restricted fine-side
                                        * parts), 2 = all are (no equation of its own: left out of the norm), 0 = none */
@@ -739,7 +740,7 @@ static double ml_nd_residual(mlnd *M)
   double nrm = 0.0;
   const double wt[3] = { 0.5, 1.0, 0.5 };
   for (int n = 1; n < M->nlev; n++) ml_nd_interface(M, n);
-  for (int n = 0; n < M->nlev; n++) nd_fill_nodes(&M->L[n], M->L[n].phi, M->per);
+  for (int n = 0; n < M->nlev; n++) nd_fill_nodes(&M->L[n], M->L[n].phi, n == 0 ? M->per0 : M->per);
   for (int n = M->nlev - 1; n >= 0; n--) {
     ndlev *L = &M->L[n];
     const int has_fine = n < M->nlev - 1;
@@ -790,7 +791,12 @@ int vo_ml_nd_solve_g(int nlev, const vo_level *const *lev, vo_fab **rh, vo_fab *
 {
   if (nlev < 2 || nlev > ND_MAXLEV) { fprintf(stderr, "vo_ml_nd_solve: 2..%d levels\n", ND_MAXLEV); abort(); }
   mlnd M; memset(&M, 0, sizeof M);
-  M.nlev = nlev; (void)pmask;
+  M.nlev = nlev;
+  for (int d = 0; d < 3; d++) {
+    M.per0[d] = pmask[d];
+    if (pmask[d]) for (int n = 1; n < nlev; n++)
+      if (coeffs[n]->lo[d] - 2 < pd[6 * n + d] || coeffs[n]->hi[d] + 2 > pd[6 * n + 3 + d]) { fprintf(stderr, "vo_ml_nd_solve: level %d reaches the periodic faces of direction %d: not supported by the oracle\n", n, d); abort(); }
+  }
   double *scratch[ND_MAXLEV] = { 0 };
   #define LV(n) (lev ? lev[n] : NULL)
   for (int n = 0; n < nlev; n++) {
@@ -911,7 +917,7 @@ int vo_ml_nd_solve_g(int nlev, const vo_level *const *lev, vo_fab **rh, vo_fab *
   for (int n = 1; n < nlev; n++) ml_nd_interface(&M, n);
   for (int n = 0; n < nlev; n++) {
     ndlev *L = &M.L[n];
-    nd_fill_nodes(L, L->phi, M.per);
+    nd_fill_nodes(L, L->phi, n == 0 ? M.per0 : M.per);
     for (int k = -1; k <= L->n[2] + 1; k++) for (int j = -1; j <= L->n[1] + 1; j++) for (int i = -1; i <= L->n[0] + 1; i++)
       VF(phi[n], phi[n]->lo[0] + i, phi[n]->lo[1] + j, phi[n]->lo[2] + k, 0) = L->phi[NN(L, i, j, k)];
   }

@@ -332,7 +332,7 @@ class SimML:
             pd += [0, 0, 0, nd - 1, nd - 1, nd - 1]
             self.dxl.append([1.0 / nd] * 3)
         self.bcs = (CBc * NL)(*bcl)
-        self.pmask = ivec([0, 0, 0])
+        self.pmask = ivec([1 if phys[d][0] == PERIODIC else 0 for d in range(3)])      # (round 6: level 0 wraps; refined levels must stay clear of the periodic faces)
         self.pd = ivec(pd)
         self.dx = (C.c_double * (3 * NL))(*sum(self.dxl, []))
 

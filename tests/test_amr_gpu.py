@@ -446,7 +446,7 @@ INOUT_BC = [[11, 12], [15, 15], [15, 15]]          # inputs_advect_3d: inflow x-
 
 
 @pytest.mark.parametrize("nc,max_levs,case", [(32, 2, "bubble"), (32, 3, "bubble"), (64, 2, "bubble"), (64, 3, "bubble"), (32, 3, "bubble-viscous"), (32, 3, "advect-viscous"),
-                                              (32, 3, "bubble-base-in-eight"), (128, 2, "bubble"), (128, 3, "bubble")])
+                                              (32, 3, "bubble-base-in-eight"), (128, 2, "bubble"), (128, 3, "bubble"), (32, 2, "advect-periodic-x"), (64, 3, "advect-periodic-x")])
 def test_tagged_hierarchy_against_the_box_list_oracle(gpu, oracle, nc, max_levs, case):
     """BASELINE.json configs[3] / [4] in small: the refined levels are the boxes make_new_grids returns for the tagged bubble (tag_boxes.f90:65-94: rho > 1.01 /
     rho > 1.1) -- unions that are not rectangles, re-entrant interface edges, boxes of a few cells -- and the ORACLE RUNS THE SAME BOX LISTS (oracle/vo.h:
@@ -456,7 +456,10 @@ def test_tagged_hierarchy_against_the_box_list_oracle(gpu, oracle, nc, max_levs,
     Bases of 32^3, 64^3 and 128^3 cells (the last: half the linear size of configs[3] / [4], one step; three levels there resolve the bubble like a 512^3 grid).
     Cases: the inviscid bubble between walls (the bench's configuration); the same with visc_coef = 0.001 as exec/test/inputs_bubble_3d and inputs_3d-regt
     have it (explicit diffusive term + composite Crank-Nicolson solves per velocity component); the advected blob of inputs_advect_3d (prob_type 2, inflow /
-    outflow: Dirichlet sides in both composite solves, inhomogeneous boundary data in the viscous ones)."""
+    outflow: Dirichlet sides in both composite solves, inhomogeneous boundary data in the viscous ones); round 6, a PERIODIC hierarchy against the oracle: the same
+    blob carried at u = 1 THROUGH periodic x faces while gravity pulls it down (slip walls in y, no-slip in z) -- level 0 wraps in every operator of both composite
+    solves, the Godunov ghost cells and mkumac; the refined levels follow the blob in the interior (the oracle takes periodic faces on level 0 only,
+    oracle/vo_amr.c: require_periodic_ok; a face treated as a wall would stop a unit through-flow)."""
     from tests.util import params_for
     from varden_amd import advance as adv
     from varden_amd import driver
@@ -467,6 +470,8 @@ def test_tagged_hierarchy_against_the_box_list_oracle(gpu, oracle, nc, max_levs,
     elif case == "advect-viscous":
         phys, prob, grav = INOUT_BC, 2, 0.0
         kw.update(visc_coef=0.001)
+    elif case == "advect-periodic-x":
+        phys, prob, grav = [[-1, -1], [14, 14], [15, 15]], 2, -9.8
     base = None
     if case == "bubble-base-in-eight":                      # level 0 cut into 2 x 2 x 2 boxes, as `bench.py --config amr3` cuts it for several ranks (configs[4])
         hb = nc // 2
@@ -513,7 +518,7 @@ def test_tagged_hierarchy_against_the_box_list_oracle(gpu, oracle, nc, max_levs,
                     err = float(np.abs(a - b).max())
                     assert err <= tol * scale, "level %d box %d step %d: %s differs by %.3e (scale %.3e)" % (n, i, step, nm, err, scale)
     m1 = mass()
-    if phys is WALLS:                                       # (inflow / outflow: mass enters and leaves)
+    if phys is WALLS or case == "advect-periodic-x":        # (inflow / outflow: mass enters and leaves)
         assert abs(m1 - m0) <= 1e-12 * m0, "composite mass drifted by %.3e" % ((m1 - m0) / m0)
     G.close()
 
