@@ -421,7 +421,7 @@ def main():
         traffic, traffic_source = None, None
         # which form ran: the level by colour (kk_cc_gsrb_rho_split, from 2^23 cells on one box; the default) or interleaved (kk_cc_gsrb_rho_pair)
         split = level_form == 1
-        names = (["r05_smoother_split_pmc.json"] if split else
+        names = (["r06_smoother_split_pmc.json", "r05_smoother_split_pmc.json"] if split else
                  ["r05_smoother_rho_pmc.json", "r04_smoother_rho_pmc.json", "r03_smoother_rho_pmc.json", "r02_smoother_rho_pmc.json", "r01_smoother_rho_pmc.json"])
         if pn == 256 and world == 1 and not args.no_pmc:
             got = measure_pass_traffic("kk_cc_gsrb_rho_split<0>" if split else "kk_cc_gsrb_rho_pair(")
