@@ -149,9 +149,10 @@ def test_split_colour_level_with_a_halo(gpu, oracle, bcname, n, nb):
                 {"VDN_MAC_SPLIT_MIN": "0", "VDN_FORCE_PACKED": "1", "VDN_WORKER_ORACLE": "0"}, {"VDN_MAC_SPLIT": "0", "VDN_WORKER_ORACLE": "0"})
     for extra in variants:
         env = dict(os.environ)
-        for k in ("VDN_MAC_SPLIT", "VDN_MAC_SPLIT_MIN", "VDN_MAC_KFLIP", "VDN_MAC_SLAB", "VDN_OVERLAP", "VDN_FORCE_PACKED", "VDN_MAC_SPLIT_HALO"):
+        for k in ("VDN_MAC_SPLIT", "VDN_MAC_SPLIT_MIN", "VDN_MAC_KFLIP", "VDN_MAC_SLAB", "VDN_OVERLAP", "VDN_FORCE_PACKED", "VDN_MAC_SPLIT_HALO", "VDN_MG_AGGLOM"):
             env.pop(k, None)
         env.update(extra)
+        env["VDN_MG_AGGLOM"] = "64"          # (boxes of 128 cells on ONE rank are gathered right below the finest level by default, mg_agglom: keep the second distributed level the split form asks for)
         r = subprocess.run([sys.executable, os.path.join(root, "tests", "_split_worker.py"), bcname] + [str(v) for v in n + nb], env=env, capture_output=True, text=True, timeout=900, cwd=root)
         assert r.returncode == 0, r.stderr[-2000:]
         out.append([ln for ln in r.stdout.splitlines() if ln.startswith("HASH")][0])

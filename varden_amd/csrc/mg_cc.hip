@@ -1245,6 +1245,20 @@ static XPlan *cc_split_plan(const CDLev &D0, int colour, const int per[3]) {
   return it->second;
 }
 
+// Several boxes: a level stays distributed box by box while its boxes, halved, are at least this wide; below that the level of the WHOLE domain is gathered and every rank
+// runs the rest of the hierarchy on one box.  64 where the boxes live on several ranks: every level that stays distributed costs ~10 latency-bound halo exchanges per V-cycle,
+// the replicated levels below 64^3 per box cost microseconds per pass.  Round 6: 128 where every box of the level is this rank's and no transport is up (configs[2] on one GPU):
+// eight 64^3 boxes are eight 5-us launches and a ghost-copy kernel per pass -- three times the ONE pass over the gathered 128^3 level -- and the gather is a device copy.
+// The arithmetic is that of the single-box hierarchy wherever the cut is made (global colours, global bottom-sweep counts): tests/test_multirank_gpu.py compares ranks that
+// cut at 64 with one rank that cuts at 128, bit for bit.  VDN_MG_AGGLOM (testing build): a fixed value.
+int mg_agglom(const vdn_layout *la, int lev) {
+  static const int env = vdn_env("VDN_MG_AGGLOM") ? atoi(vdn_env("VDN_MG_AGGLOM")) : 0;
+  if (env > 0) return env;
+  bool all_local = true;
+  for (int o : la->owner[lev]) if (o != ctx().rank) all_local = false;
+  return (all_local && !comm_active()) ? 128 : 64;
+}
+
 static void cc_build(CCMG &M, const vdn_multifab *rh, const double *dx, const int bc[3][2], bool has_alpha) {
   const vdn_layout *la = rh->la; const int lev = rh->lev;
   const auto &gboxes = la->boxes[lev];
@@ -1307,7 +1321,7 @@ static void cc_build(CCMG &M, const vdn_multifab *rh, const double *dx, const in
     if (can) for (int d = 0; d < 3; d++) REQUIRE(!(n[d] & 1), "cc multigrid: box extent %d is odd while the domain can still be coarsened", n[d]);
     // several boxes: stop exchanging halos once the boxes get small (below 64 cells) -- every level that stays distributed costs
     // ~10 latency-bound halo exchanges per V-cycle, the replicated tail below a 64^3-per-box level costs microseconds per pass
-    static const int agglom = 64;
+    const int agglom = mg_agglom(la, lev);
     const int min_dist = nb > 1 ? agglom : 4;
     for (int d = 0; d < 3; d++) if (n[d] / 2 < min_dist || ((n[d] / 2) & 1)) next_dist = false;
     if (!can) break;                                   // the domain cannot be coarsened: this level is the bottom
@@ -1504,12 +1518,32 @@ static bool cc_small_end(const CCMG &M, int dl, int tl) {
   hipLaunchKernelGGL(kk_cc_tailcycle, dim3(1), dim3(1024), 0, ctx().stream, T);
   return true;
 }
+// may tail level l run as kk_cc_lds_down / kk_cc_lds_up?  (round 6: the replicated levels of 16^3 .. 64^3 cells take the two-launch form of the one-box hierarchy too --
+// they were eleven launches per level and cycle; cc_lds_level's conditions)
+static bool cc_lds_tail_level(const CCMG &M, int l) {
+  static const bool on = !(vdn_env("VDN_MG_LDS") && atoi(vdn_env("VDN_MG_LDS")) == 0);
+  const vdn_params &P = ctx().prm;
+  if (!on || l + 1 >= (int)M.tail.size() || P.mg_nu1 != 2 || P.mg_nu2 != 2 || M.per[0] || M.per[1] || M.per[2]) return false;
+  const CLev &L = M.tail[l], &C = M.tail[l + 1];
+  if (L.rho) return false;
+  for (int d = 0; d < 3; d++) if (L.n[d] % LT || L.n[d] < 2 * LT || L.n[d] > 64 || C.n[d] * 2 != L.n[d]) return false;
+  return true;
+}
 static void cc_vcycle_t(const CCMG &M, int l) {
   const vdn_params &P = ctx().prm;
   if (cc_small_end(M, -1, l)) return;
   const CLev &L = M.tail[l];                 // phi = 0 on entry: written by the restriction that feeds this level
   if (l == (int)M.tail.size() - 1) { cc_bottom_t(M, L); return; }
   const CLev &C = M.tail[l + 1];
+  if (cc_lds_tail_level(M, l)) {
+    const dim3 g((unsigned)(L.n[0] / LT), (unsigned)(L.n[1] / LT), (unsigned)(L.n[2] / LT));
+    if (L.alpha) hipLaunchKernelGGL(kk_cc_lds_down<true>, g, dim3(1024), 0, ctx().stream, L, C);
+    else hipLaunchKernelGGL(kk_cc_lds_down<false>, g, dim3(1024), 0, ctx().stream, L, C);
+    cc_vcycle_t(M, l + 1);
+    if (L.alpha) hipLaunchKernelGGL(kk_cc_lds_up<true>, g, dim3(1024), 0, ctx().stream, L, C);
+    else hipLaunchKernelGGL(kk_cc_lds_up<false>, g, dim3(1024), 0, ctx().stream, L, C);
+    return;
+  }
   cc_gsrb_t(M, L, P.mg_nu1);
   cc_periodic_t(M, L);
   hipLaunchKernelGGL(kk_cc_residual, g3(L.n[0], L.n[1], L.n[2], BLK), BLK, 0, ctx().stream, L, (double *)nullptr);
@@ -2277,7 +2311,7 @@ void do_macproject(vdn_layout *mla, vdn_multifab **umac, vdn_multifab **rho, vdn
     // the second level must exist (its coefficients come from the first level's rho): boxes that halve cleanly to >= 4 cells, as cc_build asks
     bool ok = fast_on && beta_from_rho() && rho[n]->ng >= 1;
     {   // cc_build's rule for a second DISTRIBUTED level: the domain coarsens, the boxes halve cleanly and stay at least min_dist wide
-      const int agglom = 64;
+      const int agglom = mg_agglom(mla, n);
       const int min_dist = mla->boxes[n].size() > 1 ? agglom : 4;
       for (const vdn_box &b : mla->boxes[n]) for (int d = 0; d < 3; d++) { const int w = b.hi[d] - b.lo[d] + 1; if ((w & 1) || w / 2 < min_dist || ((w / 2) & 1)) ok = false; }
       for (int d = 0; d < 3; d++) { const int N = mla->pd[n].hi[d] - mla->pd[n].lo[d] + 1; if ((N & 1) || N <= 2) ok = false; }

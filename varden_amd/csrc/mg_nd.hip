@@ -1098,7 +1098,7 @@ static void nd_build(NDMG &M, const vdn_multifab *coeffs, const double *dx, cons
     if (can) for (int d = 0; d < 3; d++) REQUIRE(!(n[d] & 1), "nodal multigrid: box extent %d is odd while the domain can still be coarsened", n[d]);
     // several boxes: stop exchanging halos once the boxes get small (below 64 cells) -- every level that stays distributed costs
     // ~10 latency-bound halo exchanges per V-cycle, the replicated tail below a 64^3-per-box level costs microseconds per pass
-    static const int agglom = 64;
+    const int agglom = mg_agglom(la, lev);            // (mg_cc.hip: 64 across ranks, 128 where every box is this rank's)
     const int min_dist = nb > 1 ? agglom : 4;
     for (int d = 0; d < 3; d++) if (n[d] / 2 < min_dist || ((n[d] / 2) & 1)) next_dist = false;
     if (!can) break;

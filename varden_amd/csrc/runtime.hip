@@ -148,6 +148,7 @@ static const EnvSwitch g_switches[] = {
   { "VDN_MAC_KFLIP", "0: both colour passes of a sweep walk the planes upwards (default: the second colour downwards; paired and split passes of the cell-centred multigrid)" },
   { "VDN_CC_HALO_FACES", "0: the cell-centred multigrid exchanges the whole ghost shell instead of the faces only" },
   { "VDN_OVERLAP", "halo exchange of multigrid passes next to interior work: 1 always, 0 never, default: when a plan has a remote peer and the box is large" },
+  { "VDN_MG_AGGLOM", "box width below which a multi-box multigrid level is gathered into one box (default: 64 across ranks, 128 where every box is this rank's)" },
   { "VDN_MG_RESTRICT_FUSED", "0: cell-centred residual and restriction as two passes" },
   { "VDN_MG_TAILCYCLE", "0: the smallest levels launch by launch instead of one single-workgroup cycle" },
   { "VDN_MG_PROLONG_FUSED", "0: cell-centred prolongation as its own pass instead of inside the first post-smoothing colour pass" },

@@ -325,6 +325,7 @@ int  cc_solve(vdn_multifab *rh, vdn_multifab *phi, vdn_multifab **beta, const do
               const vdn_multifab *alpha = nullptr, const vdn_multifab *rho = nullptr,    // rho: beta = 2/(rho_i + rho_i-1), recomputed on the finest level
               struct CcKeep *keep = nullptr, CcFast *fast = nullptr, int fmg = 0, bool zero_guess = false, vdn_multifab *add_to = nullptr);   // fmg: the caller's phi is zero and max_iter >= 0: start from the nested iteration (cc_fmg); zero_guess (a kept hierarchy's later calls, max_iter < 0): phi is not read, the guess is zero; add_to += the solution on the valid cells          // keep: see mg_cc.hip (hierarchy kept between the calls of a composite solve)
 struct CcKeep *cc_keep_new(); void cc_keep_free(struct CcKeep *k);
+int  mg_agglom(const vdn_layout *la, int lev);     // box width below which a multi-box multigrid level is gathered into one box (mg_cc.hip)
 void cc_smooth(vdn_multifab *rh, vdn_multifab *phi, vdn_multifab **beta, const double *dx, const int bc[3][2], int nsweeps);
 void cc_bench_smoother(vdn_multifab *rh, vdn_multifab *phi, vdn_multifab **beta, const vdn_multifab *rho, const double *dx, const int bc[3][2],
                        int nlaunch, double *avg_ms, long *cells, int slab_sweeps = 0);
