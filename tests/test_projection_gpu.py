@@ -134,10 +134,10 @@ def test_split_colour_level_matches_the_oracle_and_the_interleaved_level(gpu, or
 
 
 @pytest.mark.parametrize("bcname,n,nb", [("periodic", (132, 36, 40), (1, 1, 1)), ("periodicyz", (132, 36, 40), (1, 1, 1)), ("walls", (264, 128, 128), (2, 1, 1)),
-                                         ("periodicx", (264, 128, 128), (2, 1, 1)), ("inout", (132, 256, 256), (1, 2, 2))])
+                                         ("periodicx", (264, 128, 128), (2, 1, 1)), ("inout", (132, 256, 128), (1, 2, 1)), ("zout", (132, 128, 256), (1, 1, 2))])
 def test_split_colour_level_with_a_halo(gpu, oracle, bcname, n, nb):
     """round 6: the level by colour also where a ghost exchange runs between the passes -- periodic faces of one box (the box is its own neighbour), several boxes
-    (two along x: the ghost ENTRY -1 / nh of a row; 1 x 2 x 2: ghost rows and planes; x periodic with two boxes: each the other's neighbour on both sides).  The exchange
+    (two along x: the ghost ENTRY -1 / nh of a row; two along y / along z: ghost rows / planes; x periodic with two boxes: each the other's neighbour on both sides).  The exchange
     runs on the split arrays (cc_split_plan: phi of one colour in the index space halved along x), the correction of the coarse level rides in the first sweep with the
     coarse level's ghost cells exchanged, residual + restriction per box.  Against the oracle in the first run; the same bits (a) split, (b) split with the exchange on
     the halo stream next to the interior cells and the shell kernel behind it (VDN_OVERLAP=1), (c) split through the packed per-peer buffers (VDN_FORCE_PACKED=1: the
@@ -147,6 +147,8 @@ def test_split_colour_level_with_a_halo(gpu, oracle, bcname, n, nb):
     out, form = [], []
     variants = ({"VDN_MAC_SPLIT_MIN": "0"}, {"VDN_MAC_SPLIT_MIN": "0", "VDN_OVERLAP": "1", "VDN_WORKER_ORACLE": "0"},
                 {"VDN_MAC_SPLIT_MIN": "0", "VDN_FORCE_PACKED": "1", "VDN_WORKER_ORACLE": "0"}, {"VDN_MAC_SPLIT": "0", "VDN_WORKER_ORACLE": "0"})
+    if nb[0] == 1 and nb != (1, 1, 1):          # (the y / z decompositions: split with the overlap path against interleaved -- the packed path's descriptors do not depend on the direction)
+        variants = (variants[0], variants[1], variants[3])
     for extra in variants:
         env = dict(os.environ)
         for k in ("VDN_MAC_SPLIT", "VDN_MAC_SPLIT_MIN", "VDN_MAC_KFLIP", "VDN_MAC_SLAB", "VDN_OVERLAP", "VDN_FORCE_PACKED", "VDN_MAC_SPLIT_HALO", "VDN_MG_AGGLOM"):
@@ -157,8 +159,8 @@ def test_split_colour_level_with_a_halo(gpu, oracle, bcname, n, nb):
         assert r.returncode == 0, r.stderr[-2000:]
         out.append([ln for ln in r.stdout.splitlines() if ln.startswith("HASH")][0])
         form.append([ln for ln in r.stdout.splitlines() if ln.startswith("FORM")][0])
-    assert form == ["FORM 1", "FORM 1", "FORM 1", "FORM 0"], form
-    assert out[0] == out[1] == out[2] == out[3], (bcname, out)
+    assert form == ["FORM 1"] * (len(variants) - 1) + ["FORM 0"], form
+    assert len(set(out)) == 1, (bcname, out)
 
 
 def test_blown_up_field_fails_loudly(gpu, oracle):
