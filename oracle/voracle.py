@@ -281,8 +281,9 @@ class SimML:
     boxes: per refined level either ONE box (lo, hi) or a LIST of boxes [(lo, hi), ...], in the level's own index space.  The fields of a level are
     level arrays over the bounding box of its boxes (oracle/vo.h); `levels[n].mask()` marks the cells that belong to the level."""
 
-    def __init__(self, nc, boxes, phys, prm=None, prob_type=1, grav=-9.8, init_shrink=0.1, init_iter=0, do_initial_projection=0, base_boxes=None):
-        """base_boxes: level 0 cut into boxes (what max_grid_size makes of it); default: one box"""
+    def __init__(self, nc, boxes, phys, prm=None, prob_type=1, grav=-9.8, init_shrink=0.1, init_iter=0, do_initial_projection=0, base_boxes=None, init_fn=None):
+        """base_boxes: level 0 cut into boxes (what max_grid_size makes of it); default: one box.
+        init_fn(level, lo, shape, dx) -> (u, s) with 3 ghost layers over the level array replaces the analytic initial data (as varden_amd/driver.py: VardenAMR)"""
         L = lib()
         self.prm = prm or default_params()
         self.prm.prob_type = prob_type
@@ -295,6 +296,10 @@ class SimML:
         self._alloc_temps()
         for n in range(NL):
             L.vo_initdata(self.uold[n].ref, self.sold[n].ref, dvec(self.dxl[n]), prob_type)
+            if init_fn is not None:
+                ub, sb = init_fn(n, los[n], tuple(his[n][d] - los[n][d] + 1 for d in range(3)), self.dxl[n])
+                self.uold[n].a[...] = ub
+                self.sold[n].a[...] = sb
         self.mgstat = (CMgStat * 2)()
         self.time, self.istep = 0.0, 0
         self.fill_state_ghosts()

@@ -812,6 +812,56 @@ def test_periodic_hierarchy_is_translation_invariant(gpu):
     B.close()
 
 
+@pytest.mark.parametrize("nlev", [2, 3])
+def test_refined_boxes_across_a_periodic_face_against_the_oracle(gpu, oracle, nlev):
+    """round 6: the box-list oracle wraps level 0 but keeps no periodic IMAGES of refined boxes (oracle/vo_amr.c: require_periodic_ok).  What it cannot run directly it checks
+    through the translation: the oracle runs the bubble in the MIDDLE of a domain periodic in x (its fine box in the interior); the library runs the same problem shifted by
+    half a period -- the bubble ON the periodic face, its fine level two boxes, one at each end of the domain, talking to each other and to level 0 through periodic images in
+    every operator of both composite solves, the viscous ones, the ghost fills and the Godunov stencils -- and must give the oracle's fields, shifted.  Three steps, 1e-8 of the
+    field's max (the two runs cut the fine level differently: the solver tolerances separate them), dt to 1e-9, FAC counts within one.  nlev = 3: a second refined level, also
+    cut in two by the periodic face (the corrections prolonged linearly into level 2 read their coarse neighbours through periodic images of another box)."""
+    from varden_amd import advance as adv
+    from varden_amd import driver
+    from varden_amd.capi import default_params
+    vo = oracle
+    nc = 16
+    phys = [[-1, -1], [15, 15], [15, 15]]
+
+    def bubble(xc):
+        def fn(lev, blo, nb, dx):
+            g = 3
+            ax = [(np.arange(blo[d] - g, blo[d] + nb[d] + g) + 0.5) * dx[d] for d in range(3)]
+            X, Y, Z = np.meshgrid(*ax, indexing="ij")
+            dxp = (X - xc + 0.5) % 1.0 - 0.5                   # periodic distance in x
+            r = np.sqrt(dxp ** 2 + (Y - 0.5) ** 2 + (Z - 0.5) ** 2)
+            s = np.zeros(X.shape + (2,), order="F")
+            s[..., 0] = 1.0 + 0.5 * (10.0 - 1.0) * (1.0 - np.tanh(30.0 * (r - 0.1)))
+            s[..., 1] = s[..., 0]
+            return np.zeros(X.shape + (3,), order="F"), s
+        return fn
+
+    prm = lambda: default_params(cflfac=0.9, visc_coef=0.001)   # noqa: E731
+    obox = [((8, 8, 8), (23, 23, 23))] + ([((24, 24, 24), (39, 39, 39))] if nlev == 3 else [])
+    O = vo.SimML(nc, obox, phys, prm=prm(), init_fn=bubble(0.5), init_iter=1, do_initial_projection=1)
+    B = driver.VardenAMR(nc, [((24, 8, 8), (31, 23, 23)), ((0, 8, 8), (7, 23, 23))], phys, params=prm(), init_fn=bubble(0.0), init_iter=1, do_initial_projection=1,
+                         finer_levels=[[((56, 24, 24), (63, 39, 39)), ((0, 24, 24), (7, 39, 39))]] if nlev == 3 else ())
+    assert abs(B.dt - O.dt) <= 1e-9 * O.dt
+    for _ in range(3):
+        O.step(); B.step()
+        assert abs(B.dt - O.dt) <= 1e-9 * O.dt, (B.dt, O.dt)
+        assert abs(adv.last_solver_stats("mac")[0] - O.mgstat[0].cycles) <= 1 and abs(adv.last_solver_stats("hg")[0] - O.mgstat[1].cycles) <= 1
+    for nm, gm, om in (("u", B.unew, O.unew), ("s", B.snew, O.snew)):
+        a0, b0 = om[0].valid(), gm[0].to_numpy(0)[3:-3, 3:-3, 3:-3]
+        assert np.abs(np.roll(a0, nc // 2, axis=0) - b0).max() <= 1e-8 * np.abs(a0).max(), "level 0 %s: %.3e" % (nm, np.abs(np.roll(a0, nc // 2, axis=0) - b0).max())
+        for n in range(1, nlev):                                # the oracle's box (8..23 / 24..39 in x) is the library's two boxes: its low half at the high end of the domain, its high half at the low end
+            a1 = om[n].valid()
+            h = a1.shape[0] // 2
+            lo_half, hi_half = gm[n].to_numpy(0)[3:-3, 3:-3, 3:-3], gm[n].to_numpy(1)[3:-3, 3:-3, 3:-3]
+            assert np.abs(a1[:h] - lo_half).max() <= 1e-8 * np.abs(a1).max() and np.abs(a1[h:] - hi_half).max() <= 1e-8 * np.abs(a1).max(), (nm, n)
+    assert np.abs(O.unew[1].valid()[..., 2]).max() > 0
+    B.close()
+
+
 def test_two_level_scalar_diffusion(gpu, oracle):
     """diff_coef > 0 on a refined hierarchy: the explicit diffusive term of the tracer per level (averaged down) and the composite solve
     of (1 - div mu grad) s = rhs (viscsolve.f90:308-515); with visc_coef > 0 as well.  HIP vs oracle after three steps, 1e-8 relative"""
