@@ -14,7 +14,7 @@
 !     call macproject(mla, umac, sold, mac_rhs, dx, the_bc_tower, press_comp)   src/advance_timestep.f90:104, src/macproject.f90:20
 !     call advance_timestep(istep, mla, sold, uold, snew, unew, gp, p, ext_vel_force, ext_scal_force, the_bc_tower, dt, time, dx, press_comp, regular_timestep)
 ! so that a file of the reference that drives the hot path compiles against these modules with its `use` lines and calls UNCHANGED
-! (varden_loop.f90 is such a file: the time-loop body of src/varden.f90 as the reference spells it).  Every routine forwards to module varden_amd
+! (tests/fortran/varden_loop.f90 is such a file: the time-loop body of src/varden.f90 as the reference spells it).  Every routine forwards to module varden_amd
 ! (varden_amd_mod.f90), i.e. to the C-ABI of include/varden_amd.h; all multifab data lives in HBM.
 !
 ! What is NOT here: FBoxLib's host-side data access (dataptr returns a device address, see varden_amd_mod.f90), parallel I/O, fabio, the box calculus
