@@ -205,3 +205,28 @@ def test_handle_swap_equals_copy_two_levels(gpu):
     assert runs[0][0] == runs[1][0]
     for a, b in zip(*[r[1] for r in runs]):
         assert np.array_equal(a, b)
+
+
+@pytest.mark.parametrize("bcname,n,diff", [("walls", (132, 36, 40), 0.0), ("slipz", (132, 36, 40), 0.002), ("periodicx", (132, 36, 40), 0.0), ("inout", (260, 20, 24), 0.0)])
+def test_viscous_solves_by_colour(gpu, oracle, bcname, n, diff):
+    """round 6: the three Crank-Nicolson velocity solves of a viscous step (and the tracer's with diff_coef > 0) keep their finest level BY COLOUR -- the face coefficients of
+    (rho - div mu grad) are the constant mu (viscsolve.f90:57-60), so a colour pass reads phi, rhs and alpha = rho only (kk_cc_gsrb_rho_split<., VISC>), 20 B per cell of the level
+    where the stored-coefficient pass moves 56; residual + restriction fused, the correction inside the first sweep, the slab schedule.  By default from 2^23 cells (at 256^3 the
+    three solves were 24 of 51 ms per step); here VDN_MAC_SPLIT_MIN=0 on 132 x 36 x 40 cells: two steps against the oracle (u, rho, tracer to 1e-9, equal V-cycle counts of both
+    projections, dt bit for bit) and the same state hash (a) by colour with slabs of 7 planes, (b) by colour, whole-level launches, (c) interleaved.  Dirichlet walls (no-slip: every
+    component), mixed (slip walls: the normal component Dirichlet, the tangential ones Neumann -- the folding differs per component), periodic x (ghost entries exchanged), inflow /
+    outflow (inhomogeneous Dirichlet data in the right-hand side), 260 cells (two waves per row)."""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out, form = [], []
+    for extra in ({"VDN_MAC_SPLIT_MIN": "0", "VDN_MAC_SLAB": "7"}, {"VDN_MAC_SPLIT_MIN": "0", "VDN_MAC_SLAB": "0", "VDN_WORKER_ORACLE": "0"}, {"VDN_MAC_SPLIT": "0", "VDN_WORKER_ORACLE": "0"}):
+        env = dict(os.environ)
+        for k in ("VDN_MAC_SPLIT", "VDN_MAC_SPLIT_MIN", "VDN_MAC_KFLIP", "VDN_MAC_SLAB"):
+            env.pop(k, None)
+        env.update(extra)
+        r = subprocess.run([sys.executable, os.path.join(root, "tests", "_visc_split_worker.py"), bcname] + [str(v) for v in n] + [str(diff)], env=env, capture_output=True, text=True, timeout=600, cwd=root)
+        assert r.returncode == 0, r.stderr[-2000:]
+        out.append([ln for ln in r.stdout.splitlines() if ln.startswith("HASH")][0])
+        form.append([ln for ln in r.stdout.splitlines() if ln.startswith("FORM")][0])
+    assert form[0].split()[1] == "1" and form[1].split()[1] == "1" and form[2].split()[1] == "0", form       # (the start-up's last cell-centred solve: a viscous one)
+    assert out[0] == out[1] == out[2], (bcname, out)

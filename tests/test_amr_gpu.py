@@ -974,3 +974,38 @@ def test_periodic_three_level_hierarchy_is_translation_invariant(gpu):
         assert np.abs(a[:8] - lo_half).max() <= 1e-8 * np.abs(a).max() and np.abs(a[8:] - hi_half).max() <= 1e-8 * np.abs(a).max(), nm
     assert np.abs(ua2[..., 2]).max() > 0
     B.close()
+
+
+def test_level0_cycles_of_composite_solves_by_colour_agree_bit_for_bit(gpu):
+    """round 6: the V-cycle a composite solve runs on level 0 in every FAC iteration takes the level by colour -- the MAC projection's (the density form) and, with viscosity, the three
+    velocity solves' (constant face coefficients) -- from 2^23 cells (the 256^3 base of configs[3] / [4]).  Here a 128^3 base with one refined box, visc_coef = 0.001, start-up + one
+    step, VDN_MAC_SPLIT_MIN=0 (slabs of 16 planes) against VDN_MAC_SPLIT=0: the same state, bit for bit, and the by-colour form did run."""
+    import os, subprocess, sys, textwrap
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = textwrap.dedent("""
+        import sys, hashlib
+        sys.path.insert(0, %r)
+        import numpy as np
+        from varden_amd import driver, capi
+        from varden_amd.capi import default_params
+        G = driver.VardenAMR(128, [((48, 48, 40), (111, 111, 103))], [[15, 15]] * 3, params=default_params(cflfac=0.9, visc_coef=0.001), init_shrink=0.1, init_iter=1, do_initial_projection=1)
+        G.step()
+        h = hashlib.sha256()
+        for n in range(2):
+            for m in (G.uold[n], G.sold[n], G.p[n], G.gp[n]):
+                for f in range(m.nfabs()):
+                    h.update(np.ascontiguousarray(m.to_numpy(f)).tobytes())
+        print("HASH", h.hexdigest(), G.dt, "FORM", capi.load().vdn_last_mac_level_form())
+        G.close()
+    """ % root)
+    out = []
+    for extra in ({"VDN_MAC_SPLIT_MIN": "0", "VDN_MAC_SLAB": "16"}, {"VDN_MAC_SPLIT": "0"}):
+        env = dict(os.environ)
+        for k in ("VDN_MAC_SPLIT", "VDN_MAC_SPLIT_MIN", "VDN_MAC_SLAB"):
+            env.pop(k, None)
+        env.update(extra)
+        r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600, cwd=root)
+        assert r.returncode == 0, r.stderr[-2000:]
+        out.append([ln for ln in r.stdout.splitlines() if ln.startswith("HASH")][0].split())
+    assert out[0][1] == out[1][1] and out[0][2] == out[1][2], out
+    assert out[0][4] == "1" and out[1][4] == "0", out          # (the last cell-centred solve of the step: a viscous composite one; its level-0 cycles by colour / interleaved)

@@ -838,7 +838,8 @@ void mlcc_kept_purge(unsigned long uid) {
 // alpha: [lev] cell coefficients of (alpha - div beta grad), or nullptr.  The ghost cells of the incoming phi carry inhomogeneous
 // Dirichlet data (boundary-face values); they are moved into rh, which is modified
 int ml_cc_solve(vdn_layout *la, vdn_multifab **rh, vdn_multifab **phi, vdn_multifab **beta, const double *dx, const vdn_bc_tower *bct, int bc_comp0,
-                double rel_eps, int max_iter, int *iters, double *res0, double *res, vdn_multifab **alpha, vdn_multifab **base_beta, const vdn_multifab *base_rho, const vdn_multifab *fine_rho) {
+                double rel_eps, int max_iter, int *iters, double *res0, double *res, vdn_multifab **alpha, vdn_multifab **base_beta, const vdn_multifab *base_rho, const vdn_multifab *fine_rho,
+                double const_beta) {
   require_amr(la);
   hipStream_t st = ctx().stream;
   const size_t mark = arena_mark();
@@ -950,7 +951,7 @@ int ml_cc_solve(vdn_layout *la, vdn_multifab **rh, vdn_multifab **phi, vdn_multi
     // (base_beta / base_rho, the MAC projection: the V-cycle runs on level 0's OWN coefficients 2/(rho_i + rho_i-1) -- `beta` carries the edge
     // restriction of the finer level's on the covered faces -- and so on the density-based kernels of the single-level solver; it is a
     // preconditioner, the composite residual above is formed with `beta`.  Oracle: beta_base of vo_ml_cc_solve)
-    cc_solve(S.res[0], S.e[0], base_beta ? base_beta : beta, dx, ebc0, 0.0, -1.0, -1, &cyc, &r0, &rr, alpha ? alpha[0] : nullptr, base_beta ? base_rho : nullptr, coarse_keep, nullptr, 0, zg, glue ? S.phi[0] : nullptr);     // (no nested-iteration start here: it saves no FAC iteration, measured)
+    cc_solve(S.res[0], S.e[0], base_beta ? base_beta : beta, dx, ebc0, 0.0, -1.0, -1, &cyc, &r0, &rr, alpha ? alpha[0] : nullptr, base_beta ? base_rho : nullptr, coarse_keep, nullptr, 0, zg, glue ? S.phi[0] : nullptr, const_beta);     // (no nested-iteration start here: it saves no FAC iteration, measured)
     if (!glue) S.add[0].run(0, (double *)nullptr, st);     // (glue: phi_0 += e_0 was done where e_0 was stored)
     fill_e_ghosts(S, 0);
     // up, coarsest level first: e_n += P e_{n-1}, the interface ghost cells from e_{n-1}, nu2 sweeps, phi_n += e_n

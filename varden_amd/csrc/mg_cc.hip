@@ -24,6 +24,8 @@ struct CLev {
   double *alpha;        // cell coefficient of (alpha - div b grad); nullptr when alpha = 0 (MAC projection)
   const double *rho;    // finest level of the MAC solve: density with one ghost layer, the face coefficients 2/(rho_i + rho_i-1) are
   int fold[3][2];       //   recomputed from it (8 B/cell instead of 24); fold = bc type of the box faces that are domain faces
+  double cmu;           // > 0 (round 6, the viscous / diffusive solves, viscsolve.f90:57-60: beta = mu on every face, alpha = rho or 1): the finest level's face
+                        //   coefficients are this constant, folded at the domain faces like the stored ones -- the level by colour reads phi, rhs and alpha only
 };
 DEVI long cidx(const CLev &L, int i, int j, int k) { return (long)(i + 16) + (long)L.PX * ((long)(j + 1) + (long)L.PY * (long)(k + 1)); }
 
@@ -119,6 +121,26 @@ DEVI void cc_apply_rho_vals(const CLev &L, int i, int j, int k, const double p[7
   const double az = (bzp * (p0 - p[6]) + bzm * (p0 - p[5])) * L.hi2[2];
   Ap = ax + ay + az;
   diag = (bxp + bxm) * L.hi2[0] + (byp + bym) * L.hi2[1] + (bzp + bzm) * L.hi2[2];
+}
+// ... and the operator of the viscous / diffusive solves on values in registers: the face coefficients are the constant L.cmu, folded at the domain faces exactly as
+// kk_cc_load folds the stored ones (Neumann 0, Dirichlet 2 mu), the alpha term as cc_apply / cc_apply_vals add it -- the same expressions in the same order, the same bits
+DEVI double beta_const(double mu, bool at_face, int e) {
+  double v = mu;
+  if (at_face) { if (e == VDN_BC_NEU) v = 0.0; else if (e == VDN_BC_DIR) v = 2.0 * v; }
+  return v;
+}
+DEVI void cc_apply_cmu_vals(const CLev &L, int i, int j, int k, const double p[7], double a0, double &Ap, double &diag) {
+  const double p0 = p[0];
+  const double bxm = beta_const(L.cmu, i == 0, L.fold[0][0]), bxp = beta_const(L.cmu, i == L.n[0] - 1, L.fold[0][1]);
+  const double bym = beta_const(L.cmu, j == 0, L.fold[1][0]), byp = beta_const(L.cmu, j == L.n[1] - 1, L.fold[1][1]);
+  const double bzm = beta_const(L.cmu, k == 0, L.fold[2][0]), bzp = beta_const(L.cmu, k == L.n[2] - 1, L.fold[2][1]);
+  const double ax = (bxp * (p0 - p[2]) + bxm * (p0 - p[1])) * L.hi2[0];
+  const double ay = (byp * (p0 - p[4]) + bym * (p0 - p[3])) * L.hi2[1];
+  const double az = (bzp * (p0 - p[6]) + bzm * (p0 - p[5])) * L.hi2[2];
+  Ap = ax + ay + az;
+  diag = (bxp + bxm) * L.hi2[0] + (byp + bym) * L.hi2[1] + (bzp + bzm) * L.hi2[2];
+  Ap = Ap + a0 * p0;
+  diag = diag + a0;
 }
 // The colour pass is bound by the texture addresser (TA busy 255 k of ~310 k cycles at 256^3, profiles/r01_smoother_rho_pmc.json):
 // 16 memory instructions per updated cell, each an 8-byte access with stride 2 over the lanes.  Paired form: a thread owns the 2 x 2
@@ -233,7 +255,7 @@ __global__ void __launch_bounds__(256) kk_cc_to_split(CLev L, CSplit S, int what
   const double2 z = make_double2(0.0, 0.0);
   if (what & 1) { const double2 v = in ? *reinterpret_cast<const double2 *>(L.phi + src) : z; S.phi[c0][dst] = v.x; S.phi[1 - c0][dst] = v.y; }
   if (what & 2) { const double2 v = in ? *reinterpret_cast<const double2 *>(L.rh + src) : z;  S.rh[c0][dst] = v.x;  S.rh[1 - c0][dst] = v.y; }
-  if (what & 4) { const double2 v = in ? *reinterpret_cast<const double2 *>(L.rho + src) : z; S.rho[c0][dst] = v.x; S.rho[1 - c0][dst] = v.y; }
+  if (what & 4) { const double *rsrc = L.cmu > 0.0 ? L.alpha : L.rho; const double2 v = in ? *reinterpret_cast<const double2 *>(rsrc + src) : z; S.rho[c0][dst] = v.x; S.rho[1 - c0][dst] = v.y; }
 }
 // split -> interleaved: phi on the valid cells
 __global__ void __launch_bounds__(256) kk_cc_from_split(CLev L, CSplit S) {
@@ -248,7 +270,9 @@ __global__ void __launch_bounds__(256) kk_cc_from_split(CLev L, CSplit S) {
 // planes k0 .. k0 + gridDim.z - 1 (kdown: from the top of that range)
 // hm != 0 (levels with a halo, the exchange in flight on the halo stream): the cells of the one-cell shell behind the faces of `hm` keep their value; kk_cc_gsrb_split_shell
 // updates them once the halo has landed (ADD passes run whole, after their exchange)
-template <int ADD> __global__ void __launch_bounds__(512) kk_cc_gsrb_rho_split(CLev L, CSplit S, int color, CLev C, int kdown, int k0, int hm) {
+// VISC (round 6): the level of a viscous / diffusive solve -- constant face coefficients (L.cmu), alpha in the arrays that hold rho for the MAC solve (S.rho: the cell's own
+// entry is all the pass reads of them): phi own r + w, rhs own, alpha own, phi other = 20 B per cell of the level where the stored-coefficient pass moves 56
+template <int ADD, bool VISC = false> __global__ void __launch_bounds__(512) kk_cc_gsrb_rho_split(CLev L, CSplit S, int color, CLev C, int kdown, int k0, int hm) {
   const int lane = threadIdx.x, k = k0 + (kdown ? (int)gridDim.z - 1 - (int)blockIdx.z : (int)blockIdx.z);
   const int t = blockIdx.x * 64 + lane, nh = L.n[0] / 2;
   const int jr = blockIdx.y * 8 + threadIdx.y, j = min(jr, L.n[1] - 1);
@@ -261,13 +285,14 @@ template <int ADD> __global__ void __launch_bounds__(512) kk_cc_gsrb_rho_split(C
   // box: behind a Neumann face phi is zero there and the coefficient is zero whatever rho holds (beta_of), so its line is not fetched; behind a Dirichlet face (rho enters
   // the coefficient), a neighbouring box or a periodic image (round 6: levels with a halo) it is
   double ep = 0.0, er = 0.0;
-  if ((p == 0 && lane == 0 && (t > 0 || L.fold[0][0] != VDN_BC_NEU)) || (p == 1 && lane == 63 && (ih + 2 < nh || L.fold[0][1] != VDN_BC_NEU))) { const long o = c + (p ? 2 : -1); ep = px[o]; er = rx[o]; }
+  if ((p == 0 && lane == 0 && (t > 0 || L.fold[0][0] != VDN_BC_NEU)) || (p == 1 && lane == 63 && (ih + 2 < nh || L.fold[0][1] != VDN_BC_NEU))) { const long o = c + (p ? 2 : -1); ep = px[o]; if (!VISC) er = rx[o]; }
   #define LDS2(v, off) (*reinterpret_cast<const double2 *>((v) + c + (off)))
   const double2 PO = LDS2(po, 0), RH = LDS2(S.rh[color], 0), RO = LDS2(ro, 0);
   const double2 PX = LDS2(px, 0), PYm = LDS2(px, -S.sy), PYp = LDS2(px, S.sy), PZm = LDS2(px, -S.sz), PZp = LDS2(px, S.sz);
-  const double2 RX = LDS2(rx, 0), RYm = LDS2(rx, -S.sy), RYp = LDS2(rx, S.sy), RZm = LDS2(rx, -S.sz), RZp = LDS2(rx, S.sz);
+  const double2 zz = make_double2(0.0, 0.0);
+  const double2 RX = VISC ? zz : LDS2(rx, 0), RYm = VISC ? zz : LDS2(rx, -S.sy), RYp = VISC ? zz : LDS2(rx, S.sy), RZm = VISC ? zz : LDS2(rx, -S.sz), RZp = VISC ? zz : LDS2(rx, S.sz);
   #undef LDS2
-  const double pl = lane_prev(PX.y), pr = lane_next(PX.x), rl = lane_prev(RX.y), rr = lane_next(RX.x);
+  const double pl = lane_prev(PX.y), pr = lane_next(PX.x), rl = VISC ? 0.0 : lane_prev(RX.y), rr = VISC ? 0.0 : lane_next(RX.x);
   if (!act) return;
   // centre, x-, x+, y-, y+, z-, z+
   double pa[7] = { PO.x, p ? PX.x : (lane == 0 ? ep : pl), p ? PX.y : PX.x, PYm.x, PYp.x, PZm.x, PZp.x };
@@ -291,9 +316,9 @@ template <int ADD> __global__ void __launch_bounds__(512) kk_cc_gsrb_rho_split(C
   }
   double Ap, diag;
   double2 out = make_double2(pa[0], pb[0]);
-  cc_apply_rho_vals(L, 2 * ih + p, j, k, pa, ra, Ap, diag);
+  if (VISC) cc_apply_cmu_vals(L, 2 * ih + p, j, k, pa, ra[0], Ap, diag); else cc_apply_rho_vals(L, 2 * ih + p, j, k, pa, ra, Ap, diag);
   if (diag != 0.0 && !(hm && cc_is_shell(L, 2 * ih + p, j, k, hm))) out.x = pa[0] + (RH.x - Ap) / diag;
-  cc_apply_rho_vals(L, 2 * ih + 2 + p, j, k, pb, rb, Ap, diag);
+  if (VISC) cc_apply_cmu_vals(L, 2 * ih + 2 + p, j, k, pb, rb[0], Ap, diag); else cc_apply_rho_vals(L, 2 * ih + 2 + p, j, k, pb, rb, Ap, diag);
   if (diag != 0.0 && !(hm && cc_is_shell(L, 2 * ih + 2 + p, j, k, hm))) out.y = pb[0] + (RH.y - Ap) / diag;
   *reinterpret_cast<double2 *>(S.phi[color] + c) = out;
 }
@@ -322,7 +347,7 @@ __global__ void __launch_bounds__(256) kk_cc_gsrb_split_shell(CLev L, CSplit S, 
   const double r[7] = { split_get(S.rho, S, i, j, k), split_get(S.rho, S, i - 1, j, k), split_get(S.rho, S, i + 1, j, k), split_get(S.rho, S, i, j - 1, k),
                         split_get(S.rho, S, i, j + 1, k), split_get(S.rho, S, i, j, k - 1), split_get(S.rho, S, i, j, k + 1) };
   double Ap, diag;
-  cc_apply_rho_vals(L, i, j, k, p, r, Ap, diag);
+  if (L.cmu > 0.0) cc_apply_cmu_vals(L, i, j, k, p, r[0], Ap, diag); else cc_apply_rho_vals(L, i, j, k, p, r, Ap, diag);
   if (diag != 0.0) S.phi[color][sidx(S, (i - (i & 1)) >> 1, j, k)] = p[0] + (split_get(S.rh, S, i, j, k) - Ap) / diag;
 }
 // residual + restriction on the split level (kk_cc_residual_rho_pair_rst's job): a thread owns entries ih, ih + 1 of BOTH colours in rows 2J, 2J + 1 of planes
@@ -351,7 +376,7 @@ DEVI void split_gather(double *const v[2], const CSplit &S, long c, int e, int l
   q[1][2][0] = E1.y; q[1][2][1] = O1.x; q[1][2][2] = O1.y; q[1][2][3] = E0.y; q[1][2][4] = Ep.y; q[1][2][5] = E1m.y; q[1][2][6] = E1p.y;
   q[1][3][0] = O1.y; q[1][3][1] = E1.y; q[1][3][2] = lane == 63 ? a1 : r1; q[1][3][3] = O0.y; q[1][3][4] = Op.y; q[1][3][5] = O1m.y; q[1][3][6] = O1p.y;
 }
-__global__ void __launch_bounds__(256) kk_cc_residual_rho_split_rst(CLev L, CSplit S, double *nrm, CLev C, int Ka, int Kb) {       // coarse planes Ka .. Kb - 1
+template <bool VISC = false> __global__ void __launch_bounds__(256) kk_cc_residual_rho_split_rst(CLev L, CSplit S, double *nrm, CLev C, int Ka, int Kb) {       // coarse planes Ka .. Kb - 1
   const int lane = threadIdx.x, nh = L.n[0] / 2;
   const int u = blockIdx.x * 64 + lane, Jr = blockIdx.y * 4 + threadIdx.y, J = min(Jr, L.n[1] / 2 - 1);
   const bool act = 2 * u + 1 < nh && Jr < L.n[1] / 2;
@@ -366,6 +391,12 @@ __global__ void __launch_bounds__(256) kk_cc_residual_rho_split_rst(CLev L, CSpl
       double P[2][4][7], R[2][4][7];
       const bool ldl = u > 0 || L.fold[0][0] != VDN_BC_NEU, ldr = ih + 2 < nh || L.fold[0][1] != VDN_BC_NEU;
       split_gather(S.phi, S, c, e, lane, P, ldl, ldr);
+      if (VISC) {                                                  // alpha of the eight cells themselves: four aligned pairs
+        const double2 A0e = *reinterpret_cast<const double2 *>(S.rho[e] + c), A0o = *reinterpret_cast<const double2 *>(S.rho[1 - e] + c);
+        const double2 A1e = *reinterpret_cast<const double2 *>(S.rho[1 - e] + c + S.sy), A1o = *reinterpret_cast<const double2 *>(S.rho[e] + c + S.sy);
+        R[0][0][0] = A0e.x; R[0][1][0] = A0o.x; R[0][2][0] = A0e.y; R[0][3][0] = A0o.y;
+        R[1][0][0] = A1e.x; R[1][1][0] = A1o.x; R[1][2][0] = A1e.y; R[1][3][0] = A1o.y;
+      } else
       split_gather(S.rho, S, c, e, lane, R, ldl, ldr);
       const double2 H0e = *reinterpret_cast<const double2 *>(S.rh[e] + c), H0o = *reinterpret_cast<const double2 *>(S.rh[1 - e] + c);
       const double2 H1e = *reinterpret_cast<const double2 *>(S.rh[1 - e] + c + S.sy), H1o = *reinterpret_cast<const double2 *>(S.rh[e] + c + S.sy);
@@ -376,7 +407,7 @@ __global__ void __launch_bounds__(256) kk_cc_residual_rho_split_rst(CLev L, CSpl
           #pragma unroll
           for (int m = 0; m < 4; m++) {
             double Ap, diag;
-            cc_apply_rho_vals(L, 2 * ih + m, 2 * J + jj, k, P[jj][m], R[jj][m], Ap, diag);
+            if (VISC) cc_apply_cmu_vals(L, 2 * ih + m, 2 * J + jj, k, P[jj][m], R[jj][m][0], Ap, diag); else cc_apply_rho_vals(L, 2 * ih + m, 2 * J + jj, k, P[jj][m], R[jj][m], Ap, diag);
             const double r = rhs[jj][m] - Ap;
             rmax = nmax(rmax, fabs(r));
             if (m < 2) s0 = (kk == 0 && jj == 0 && m == 0) ? r : s0 + r;
@@ -1120,7 +1151,13 @@ template <int ADD> static inline void launch_gsrb_split(const CBox &B, int color
   if (k1 < 0) k1 = L.n[2];
   const dim3 g((unsigned)((L.n[0] / 4 + 63) / 64), (unsigned)((L.n[1] + 7) / 8), (unsigned)(k1 - k0));
   // the second colour walks the planes downwards: what the first colour's pass touched last is what it reads first (Infinity Cache; VDN_MAC_KFLIP=0: both upwards)
-  hipLaunchKernelGGL(kk_cc_gsrb_rho_split<ADD>, g, dim3(64, 8, 1), 0, st, L, B.sp, color, C, (mac_kflip() && color) ? 1 : 0, k0, hm);
+  if (L.cmu > 0.0) hipLaunchKernelGGL((kk_cc_gsrb_rho_split<ADD, true>), g, dim3(64, 8, 1), 0, st, L, B.sp, color, C, (mac_kflip() && color) ? 1 : 0, k0, hm);
+  else hipLaunchKernelGGL((kk_cc_gsrb_rho_split<ADD, false>), g, dim3(64, 8, 1), 0, st, L, B.sp, color, C, (mac_kflip() && color) ? 1 : 0, k0, hm);
+}
+static inline void launch_residual_split_rst(const CLev &L, const CSplit &S, double *nrm, const CLev &C, int Ka, int Kb, hipStream_t st) {
+  const dim3 g((unsigned)((L.n[0] / 4 + 63) / 64), (unsigned)((L.n[1] / 2 + 3) / 4), (unsigned)std::min(Kb - Ka, 16));
+  if (L.cmu > 0.0) hipLaunchKernelGGL(kk_cc_residual_rho_split_rst<true>, g, BLK, 0, st, L, S, nrm, C, Ka, Kb);
+  else hipLaunchKernelGGL(kk_cc_residual_rho_split_rst<false>, g, BLK, 0, st, L, S, nrm, C, Ka, Kb);
 }
 static inline void launch_gsrb_split_shell(const CBox &B, int color, hipStream_t st, int hm) {
   if (!hm) return;
@@ -1155,7 +1192,7 @@ static bool cc_split_ok(const CCMG &M) {
   long cells = 0;
   for (const CBox &B : D0.boxes) {
     const CLev &L = B.L;
-    if (!(L.rho && L.n[0] % 4 == 0 && L.n[1] % 2 == 0 && L.n[2] % 2 == 0 && L.n[0] >= 128)) return false;
+    if (!((L.rho || (L.cmu > 0.0 && L.alpha)) && L.n[0] % 4 == 0 && L.n[1] % 2 == 0 && L.n[2] % 2 == 0 && L.n[0] >= 128)) return false;
     for (int d = 0; d < 3; d++) if (B.lo[d] & 1) return false;
     cells += (long)L.n[0] * L.n[1] * L.n[2];
   }
@@ -1200,7 +1237,7 @@ static CLev cc_alloc_lev(const int n[3], const double h[3], bool has_alpha) {
   L.phi = base; L.rh = base + L.sz; L.res = base + 2 * L.sz;
   for (int d = 0; d < 3; d++) L.b[d] = base + (3 + d) * L.sz;
   L.alpha = has_alpha ? base + 6 * L.sz : nullptr;
-  L.rho = nullptr;
+  L.rho = nullptr; L.cmu = 0.0;
   for (int d = 0; d < 3; d++) L.fold[d][0] = L.fold[d][1] = VDN_BC_INT;
   return L;
 }
@@ -1428,8 +1465,7 @@ static void cc_residual_d(CCMG &M, CDLev &DL, bool norm, bool reduce = true) {  
       split_halo(DL, 1);
       for (size_t b = 0; b < DL.boxes.size(); b++) {
         const CBox &B = DL.boxes[b]; const CLev &L = B.L;
-        const dim3 g((unsigned)((L.n[0] / 4 + 63) / 64), (unsigned)((L.n[1] / 2 + 3) / 4), (unsigned)std::min(L.n[2] / 2, 16));
-        hipLaunchKernelGGL(kk_cc_residual_rho_split_rst, g, BLK, 0, ctx().stream, L, B.sp, norm ? M.d_nrm : nullptr, M.dlev[1].boxes[b].L, 0, L.n[2] / 2);
+        launch_residual_split_rst(L, B.sp, norm ? M.d_nrm : nullptr, M.dlev[1].boxes[b].L, 0, L.n[2] / 2, ctx().stream);
       }
       DL.res_restricted = true;
       if (norm && reduce) comm_allreduce_max_dev(M.d_nrm, 1);
@@ -1649,8 +1685,7 @@ static void cc_split_run(CCMG &M, CDLev &DL, bool prolong, int nsweeps, bool res
     if (residual) {                                  // coarse plane K reads the fine planes 2K - 1 .. 2K + 2
       const int hiK = done[R - 1] == n2 ? nK : std::max(0, (done[R - 1] - 1) / 2);
       if (hiK > done[R]) {
-        const dim3 g((unsigned)((L.n[0] / 4 + 63) / 64), (unsigned)((L.n[1] / 2 + 3) / 4), (unsigned)std::min(hiK - done[R], 16));
-        hipLaunchKernelGGL(kk_cc_residual_rho_split_rst, g, BLK, 0, st, L, B0.sp, norm ? M.d_nrm : nullptr, C, done[R], hiK);
+        launch_residual_split_rst(L, B0.sp, norm ? M.d_nrm : nullptr, C, done[R], hiK, st);
         done[R] = hiK;
       }
     }
@@ -1806,7 +1841,7 @@ void cc_keep_free(CcKeep *k) { delete k; }
 // it is captured once and replayed; the key hashes every value the launches read from the host side.
 static void cc_key_lev(GraphKey &k, const CLev &L) {
   k.put(L.n); k.put(L.PX); k.put(L.PY); k.put(L.sz); k.put(L.hi2); k.put(L.phi); k.put(L.rh); k.put(L.res); k.put(L.b); k.put(L.alpha);
-  k.put(L.rho); k.put(L.fold);
+  k.put(L.rho); k.put(L.fold); k.put(L.cmu);
 }
 static unsigned long long cc_graph_key(const CCMG &M, int what) {
   const vdn_params &P = ctx().prm;
@@ -1843,7 +1878,7 @@ static int cc_fmg_what(const int bc[3][2]) {
 // VDN_MAC_STORED_BETA=1: the finest level reads the stored face coefficients like the others (the measured alternative of DESIGN.md section 4)
 static bool beta_from_rho() { static const bool b = !(vdn_env("VDN_MAC_STORED_BETA") && atoi(vdn_env("VDN_MAC_STORED_BETA")) != 0); return b; }
 static void cc_setup(CCMG &M, vdn_multifab *rh, vdn_multifab *phi, const vdn_multifab *alpha, vdn_multifab **beta, const double *dx, const int bc[3][2],
-                     const vdn_multifab *rho = nullptr) {
+                     const vdn_multifab *rho = nullptr, double const_beta = 0.0) {
   REQUIRE(phi->ng >= 1, "cc multigrid: phi needs one ghost cell");
   cc_build(M, rh, dx, bc, alpha != nullptr);
   const vdn_layout *la = rh->la; const int lev = rh->lev;
@@ -1868,6 +1903,10 @@ static void cc_setup(CCMG &M, vdn_multifab *rh, vdn_multifab *phi, const vdn_mul
       double *r = (double *)arena_alloc(sizeof(double) * L0.sz);
       hipLaunchKernelGGL(kk_cc_load_rho, g3(L0.n[0] + 2, L0.n[1] + 2, L0.n[2] + 2, BLK), BLK, 0, ctx().stream, L0, r, rho->fabs[b], bx.lo[0], bx.lo[1], bx.lo[2]);
       L0.rho = r;
+      for (int d = 0; d < 3; d++) { L0.fold[d][0] = e[d][0]; L0.fold[d][1] = e[d][1]; }
+    }
+    if (const_beta > 0.0 && alpha) {        // the caller vouches that every face coefficient is this constant (visc_solve / diff_scalar_solve: setval(beta, mu))
+      L0.cmu = const_beta;
       for (int d = 0; d < 3; d++) { L0.fold[d][0] = e[d][0]; L0.fold[d][1] = e[d][1]; }
     }
   }
@@ -1993,7 +2032,7 @@ static void cc_store(CCMG &M, vdn_multifab *phi, const int bc[3][2], vdn_multifa
 // finest level's array (ghost cells exchanged) and the level arrays stay allocated -- the CALLER releases the arena
 int cc_solve(vdn_multifab *rh, vdn_multifab *phi, vdn_multifab **beta, const double *dx, const int bc[3][2],
              double rel_eps, double abs_eps, int max_iter, int *cycles, double *res0, double *res, const vdn_multifab *alpha, const vdn_multifab *rho, CcKeep *keep,
-             CcFast *fast, int fmg, bool zero_guess, vdn_multifab *add_to) {
+             CcFast *fast, int fmg, bool zero_guess, vdn_multifab *add_to, double const_beta) {
   Prof prof_("mac_multigrid");
   if (ctx().prm.dm == 2) return cc2_solve(rh, phi, beta, dx, bc, rel_eps, abs_eps, max_iter, cycles, res0, res, alpha);
   const vdn_params &P = ctx().prm;
@@ -2009,13 +2048,16 @@ int cc_solve(vdn_multifab *rh, vdn_multifab *phi, vdn_multifab **beta, const dou
     if (cc_split_ok(M)) cc_split_setup(M);
     g_mac_level_form = !M.dlev[0].split ? 0 : (vdn_env("VDN_MAC_SPLIT") && atoi(vdn_env("VDN_MAC_SPLIT")) == 2) ? 2 : 1;
   }
-  else if (keep && keep->built) { cc_reload(M, rh, phi, bc, zero_guess); g_mac_level_form = 0; }
+  else if (keep && keep->built) { cc_reload(M, rh, phi, bc, zero_guess); g_mac_level_form = M.dlev[0].split ? 1 : 0; }
   else {
-    cc_setup(M, rh, phi, alpha, beta, dx, bc, rho);
+    cc_setup(M, rh, phi, alpha, beta, dx, bc, rho, const_beta);
     g_mac_level_form = 0;
     // round 6: the V-cycles a composite MAC solve runs on its level 0 (a kept hierarchy, one cycle per FAC iteration, the density form) take the level by colour
     // too -- for the tagged 256^3 hierarchies that is a whole 256^3 level, 23 cycles per step
-    if (keep && max_iter < 0 && !alpha && cc_split_ok(M)) { cc_split_setup(M); cc_to_split(M.dlev[0], 1); g_mac_level_form = 1; }
+    if (keep && max_iter < 0 && (!alpha || const_beta > 0.0) && cc_split_ok(M)) { cc_split_setup(M); cc_to_split(M.dlev[0], 1); g_mac_level_form = 1; }      // (also the composite viscous solves: constant coefficients)
+    // ... and the viscous / diffusive solves (constant face coefficients: the caller's const_beta): every 3-D input of exec/test runs three of them per step, at 256^3 they were
+    // 24 ms of a 51 ms step on the stored-coefficient passes (56 B per cell and pass; by colour, without coefficient arrays: 20)
+    else if (!keep && max_iter >= 0 && alpha && const_beta > 0.0 && cc_split_ok(M)) { cc_split_setup(M); g_mac_level_form = 1; }      // (phi goes over after the nested iteration, below)
   }
   if (keep) keep->built = true;
   CDLev &D0 = M.dlev[0];
@@ -2072,7 +2114,7 @@ int cc_solve(vdn_multifab *rh, vdn_multifab *phi, vdn_multifab **beta, const dou
       if (first >= 0 && first < pred - 1) {                      // overshot: repeat without the prediction
         arena_release(mark);
         struct Off { Off() { g_mg_predict_off++; } ~Off() { g_mg_predict_off--; } } off_;
-        return cc_solve(rh, phi, beta, dx, bc, rel_eps, abs_eps, max_iter, cycles, res0, res, alpha, rho, keep, fast, fmg, zero_guess, add_to);
+        return cc_solve(rh, phi, beta, dx, bc, rel_eps, abs_eps, max_iter, cycles, res0, res, alpha, rho, keep, fast, fmg, zero_guess, add_to, const_beta);
       }
       cyc = pred - 1; rn = h[pred - 1];
     } else {
@@ -2097,7 +2139,7 @@ int cc_solve(vdn_multifab *rh, vdn_multifab *phi, vdn_multifab **beta, const dou
     cc_halo(M, DF);
     fast->phi_view.clear();
     for (size_t b = 0; b < DF.boxes.size(); b++) fast->phi_view.push_back(cc_phi_view(DF.boxes[b].L, fast->rho->vbox[b].lo));
-  } else cc_store(M, phi, bc);
+  } else { if (M.dlev[0].split) cc_from_split(M.dlev[0]); cc_store(M, phi, bc); }
   if (cycles) *cycles = cyc; if (res0) *res0 = bnorm; if (res) *res = rn;
   if (conv && fast && !single && cyc >= 1) mg_predict_set(0, gn, cyc);
   if (!keep && !fast) arena_release(mark);

@@ -323,7 +323,8 @@ struct CcFast { vdn_multifab **um = nullptr; const vdn_multifab *mac_rhs = nullp
 int  cc_solve(vdn_multifab *rh, vdn_multifab *phi, vdn_multifab **beta, const double *dx, const int bc[3][2],
               double rel_eps, double abs_eps, int max_iter, int *cycles, double *res0, double *res,
               const vdn_multifab *alpha = nullptr, const vdn_multifab *rho = nullptr,    // rho: beta = 2/(rho_i + rho_i-1), recomputed on the finest level
-              struct CcKeep *keep = nullptr, CcFast *fast = nullptr, int fmg = 0, bool zero_guess = false, vdn_multifab *add_to = nullptr);   // fmg: the caller's phi is zero and max_iter >= 0: start from the nested iteration (cc_fmg); zero_guess (a kept hierarchy's later calls, max_iter < 0): phi is not read, the guess is zero; add_to += the solution on the valid cells          // keep: see mg_cc.hip (hierarchy kept between the calls of a composite solve)
+              struct CcKeep *keep = nullptr, CcFast *fast = nullptr, int fmg = 0, bool zero_guess = false, vdn_multifab *add_to = nullptr,
+              double const_beta = 0.0);      // const_beta > 0 (with alpha): every face coefficient of `beta` is this constant (visc_solve, diff_scalar_solve) -- the finest level may then live by colour without coefficient arrays   // fmg: the caller's phi is zero and max_iter >= 0: start from the nested iteration (cc_fmg); zero_guess (a kept hierarchy's later calls, max_iter < 0): phi is not read, the guess is zero; add_to += the solution on the valid cells          // keep: see mg_cc.hip (hierarchy kept between the calls of a composite solve)
 struct CcKeep *cc_keep_new(); void cc_keep_free(struct CcKeep *k);
 int  mg_agglom(const vdn_layout *la, int lev);     // box width below which a multi-box multigrid level is gathered into one box (mg_cc.hip)
 void cc_smooth(vdn_multifab *rh, vdn_multifab *phi, vdn_multifab **beta, const double *dx, const int bc[3][2], int nsweeps);
@@ -372,7 +373,8 @@ void ml_fill_ghost_cells(vdn_multifab *fine, const vdn_multifab *crse, int icomp
 void ml_create_umac_grown(vdn_multifab *fine, const vdn_multifab *crse, int dir);
 void ml_restrict_and_fill(int nlev, vdn_multifab **mf, int icomp, int bcomp, int nc, bool same_boundary, const vdn_bc_tower *bct);
 int ml_cc_solve(vdn_layout *la, vdn_multifab **rh, vdn_multifab **phi, vdn_multifab **beta, const double *dx, const vdn_bc_tower *bct, int bc_comp0,
-                double rel_eps, int max_iter, int *iters, double *res0, double *res, vdn_multifab **alpha, vdn_multifab **base_beta = nullptr, const vdn_multifab *base_rho = nullptr, const vdn_multifab *fine_rho = nullptr);
+                double rel_eps, int max_iter, int *iters, double *res0, double *res, vdn_multifab **alpha, vdn_multifab **base_beta = nullptr, const vdn_multifab *base_rho = nullptr, const vdn_multifab *fine_rho = nullptr,
+                double const_beta = 0.0);      // const_beta > 0: every face coefficient on every level is this constant (the viscous / diffusive solves): handed to level 0's V-cycles
 void do_ml_visc_solve(vdn_layout *mla, vdn_multifab **unew, vdn_multifab **lapu, vdn_multifab **rho, vdn_multifab **mac_rhs,
                       const double *dx, double mu, const vdn_bc_tower *bct);
 void do_ml_diff_scalar_solve(vdn_layout *mla, vdn_multifab **snew, vdn_multifab **laps, const double *dx, double mu,

@@ -94,7 +94,7 @@ void do_visc_solve(vdn_layout *mla, vdn_multifab *unew, const vdn_multifab *lapu
     }
     int ebc[3][2]; ell_of(bct, n, d, ebc);                                             // bc_comp = d, viscsolve.f90:99
     int cyc; double r0, rr;
-    int rc = cc_solve(rh, phi, beta, dx, ebc, 1.e-12, -1.0, ctx().prm.mg_max_iter, &cyc, &r0, &rr, alpha);   // viscsolve.f90:88-89
+    int rc = cc_solve(rh, phi, beta, dx, ebc, 1.e-12, -1.0, ctx().prm.mg_max_iter, &cyc, &r0, &rr, alpha, nullptr, nullptr, nullptr, 0, false, nullptr, mu);   // viscsolve.f90:88-89 (beta = mu on every face)
     solver_check(rc, "viscous solve", cyc, rr, r0, d);
     mf_copy(unew, d, phi, 0, 1, 0);                                                    // viscsolve.f90:103
   }
@@ -128,7 +128,7 @@ void do_ml_visc_solve(vdn_layout *mla, vdn_multifab **unew, vdn_multifab **lapu,
                            mac_rhs[n]->fabs[i], A, rg, bx.lo[0], bx.lo[1], bx.lo[2], bx.hi[0], bx.hi[1], bx.hi[2], dx[3 * n + d], 1.0 / 3.0, visc_mu_dt);
       }
     int it; double r0, rr;
-    int rc = ml_cc_solve(mla, rh, phi, beta, dx, bct, d, 1.e-12, ctx().prm.mg_max_iter, &it, &r0, &rr, alpha);      // bc_comp = d, viscsolve.f90:88-99
+    int rc = ml_cc_solve(mla, rh, phi, beta, dx, bct, d, 1.e-12, ctx().prm.mg_max_iter, &it, &r0, &rr, alpha, nullptr, nullptr, nullptr, mu);      // bc_comp = d, viscsolve.f90:88-99
     solver_check(rc, "composite viscous solve", it, rr, r0, d);
     for (int n = 0; n < L; n++) mf_copy(unew[n], d, phi[n], 0, 1, 0);                            // viscsolve.f90:103
   }
@@ -156,7 +156,7 @@ void do_diff_scalar_solve(vdn_layout *mla, vdn_multifab *snew, const vdn_multifa
   }
   int ebc[3][2]; ell_of(bct, n, bccomp0, ebc);
   int cyc; double r0, rr;
-  int rc = cc_solve(rh, phi, beta, dx, ebc, 1.e-12, -1.0, ctx().prm.mg_max_iter, &cyc, &r0, &rr, alpha);
+  int rc = cc_solve(rh, phi, beta, dx, ebc, 1.e-12, -1.0, ctx().prm.mg_max_iter, &cyc, &r0, &rr, alpha, nullptr, nullptr, nullptr, 0, false, nullptr, mu);
   solver_check(rc, "diffusive solve", cyc, rr, r0);
   mf_copy(snew, icomp, phi, 0, 1, 0);                                                  // viscsolve.f90:374
   mf_fill_boundary(snew);                                                              // 378-381 (all comps: a superset of fill_boundary_c)
@@ -184,7 +184,7 @@ void do_ml_diff_scalar_solve(vdn_layout *mla, vdn_multifab **snew, vdn_multifab 
     }
   }
   int it; double r0, rr;
-  int rc = ml_cc_solve(mla, rh, phi, beta, dx, bct, bccomp0, 1.e-12, ctx().prm.mg_max_iter, &it, &r0, &rr, alpha);
+  int rc = ml_cc_solve(mla, rh, phi, beta, dx, bct, bccomp0, 1.e-12, ctx().prm.mg_max_iter, &it, &r0, &rr, alpha, nullptr, nullptr, nullptr, mu);
   solver_check(rc, "composite diffusive solve", it, rr, r0);
   for (int n = 0; n < L; n++) mf_copy(snew[n], icomp, phi[n], 0, 1, 0);                          // viscsolve.f90:374
   ml_restrict_and_fill(L, snew, icomp, bccomp0, 1, false, bct);                                  // 378-381
