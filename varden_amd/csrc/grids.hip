@@ -1,5 +1,6 @@
 // grids.hip -- the grid generation that sits in front of the AMR hot path: tag_boxes (src/tag_boxes.f90:17-216) on the device and
-// FBoxLib's make_new_grids (src/initialize.f90:247-248, src/regrid.f90:148-149) on the host.
+// FBoxLib's make_new_grids (src/initialize.f90:247-248, src/regrid.f90:148-149): the per-cell maps on the device, the clustering of the block lattice
+// (1/blocking^3 of the cells) on the host.
 //
 // make_new_grids is not in the reference tree (FBoxLib); the call sites and the probin parameters fix what goes in and out, the
 // procedure below is ours:
@@ -23,6 +24,46 @@ __global__ void kk_tag(FV s, unsigned char *tags, int n0, int n1, int d0, int d1
   const double v = fv_get(s, i, j, k);
   const bool t = rule == 0 ? (v > tlo) : (v > tlo && v < thi);
   tags[(size_t)(i - d0) + (size_t)n0 * ((size_t)(j - d1) + (size_t)n1 * (size_t)(k - d2))] = t ? 1 : 0;
+}
+
+// the byte maps of make_new_grids on the device: one byte per cell of the level's domain, x fastest
+__global__ void kk_count_bytes(const unsigned char *a, size_t n, unsigned long long *out) {
+  unsigned long long c = 0;
+  for (size_t q = (size_t)blockIdx.x * blockDim.x + threadIdx.x; q < n; q += (size_t)gridDim.x * blockDim.x) c += a[q];
+  for (int o = 32; o > 0; o >>= 1) c += __shfl_down(c, o);
+  if ((threadIdx.x & 63) == 0 && c) atomicAdd(out, c);
+}
+__global__ void kk_fill_bytes(unsigned char *a, int n0, int n1, Range3 r) {
+  THREAD_IJK(r)
+  if (in_range) a[(size_t)i + (size_t)n0 * ((size_t)j + (size_t)n1 * (size_t)k)] = 1;
+}
+// box dilation (OR) or erosion (AND) by `width` cells in direction d; cells outside the domain do not take part
+__global__ void kk_sweep_bytes(const unsigned char *in, unsigned char *out, int n0, int n1, int n2, int d, int width, int dilate) {
+  const int i = (int)(blockIdx.x * blockDim.x + threadIdx.x), j = (int)(blockIdx.y * blockDim.y + threadIdx.y), k = (int)(blockIdx.z * blockDim.z + threadIdx.z);
+  if (i >= n0 || j >= n1 || k >= n2) return;
+  const size_t c = (size_t)i + (size_t)n0 * ((size_t)j + (size_t)n1 * (size_t)k);
+  const size_t stride = d == 0 ? 1 : (d == 1 ? (size_t)n0 : (size_t)n0 * n1);
+  const int q = d == 0 ? i : (d == 1 ? j : k), nq = d == 0 ? n0 : (d == 1 ? n1 : n2);
+  unsigned char v = dilate ? 0 : 1;
+  for (int w = -width; w <= width; w++) {
+    if (q + w < 0 || q + w >= nq) continue;
+    const unsigned char x = in[(long)c + (long)w * (long)stride];
+    if (dilate) v |= x; else v &= x;
+  }
+  out[c] = v;
+}
+// per block of blocking^dm cells: ok = every cell inside the nesting region, t = ok and any cell tagged
+__global__ void kk_block_lattice(const unsigned char *tags, const unsigned char *inside, unsigned char *t, unsigned char *ok, int n0, int n1, int g0, int g1,
+                                 int blocking, int bz, Range3 r) {
+  THREAD_IJK(r)
+  if (!in_range) return;
+  bool any = false, all_in = true;
+  for (int c = 0; c < bz; c++) for (int b = 0; b < blocking; b++) for (int a = 0; a < blocking; a++) {
+    const size_t q = (size_t)(i * blocking + a) + (size_t)n0 * ((size_t)(j * blocking + b) + (size_t)n1 * (size_t)(k * bz + c));
+    any = any || tags[q]; all_in = all_in && inside[q];
+  }
+  t[(size_t)i + (size_t)g0 * ((size_t)j + (size_t)g1 * (size_t)k)] = (any && all_in) ? 1 : 0;
+  ok[(size_t)i + (size_t)g0 * ((size_t)j + (size_t)g1 * (size_t)k)] = all_in ? 1 : 0;
 }
 
 namespace {
@@ -153,69 +194,84 @@ extern "C" int vdn_make_new_grids(const vdn_multifab *s, int lev1, int buf_wid, 
   // 1. tags on the device (tag_boxes.f90:142-210: thresholds by level, prob_type)
   const size_t ncell = (size_t)n[0] * n[1] * n[2];
   unsigned char *d_tags = tag_level(s, lev1);
-  // inside[]: 1 on the cells of the level (host), for the nesting region
-  std::vector<unsigned char> inside(ncell, 0), tags(ncell, 0);
-  for (const vdn_box &gb : la->boxes[s->lev])              // the cells of the level: every box, on any rank
-    for (int k = gb.lo[2]; k <= gb.hi[2]; k++) for (int j = gb.lo[1]; j <= gb.hi[1]; j++)
-      std::fill(inside.begin() + ((size_t)(gb.lo[0] - pd.lo[0]) + (size_t)n[0] * ((size_t)(j - pd.lo[1]) + (size_t)n[1] * (size_t)(k - pd.lo[2]))),
-                inside.begin() + ((size_t)(gb.hi[0] - pd.lo[0]) + 1 + (size_t)n[0] * ((size_t)(j - pd.lo[1]) + (size_t)n[1] * (size_t)(k - pd.lo[2]))), 1);
-  HIPCHK(hipMemcpyAsync(tags.data(), d_tags, ncell, hipMemcpyDeviceToHost, ctx().stream));
-  HIPCHK(hipStreamSynchronize(ctx().stream));
-  HIPCHK(hipFree(d_tags));
-  long nt = 0; for (size_t c = 0; c < ncell; c++) nt += tags[c];
-  if (ntagged) *ntagged = nt;
+  // 2. on the device (a 512^3 level is 134 M cells: the host loops of rounds 2-5 took 5 s of a 0.5 s step, tools/probes/regrid_profile_probe.py): count the tags,
+  // grow them by buf_wid (box dilation, one direction after the other), inside[] = 1 on the cells of the level -- every box, on any rank --, shrunk by `nest`
+  // the same way (cells outside the domain count as inside: a level may touch the domain boundary)
+  hipStream_t st = ctx().stream;
+  unsigned char *d_in = nullptr, *d_tmp = nullptr; unsigned long long *d_cnt = nullptr;
+  HIPCHK(hipMalloc((void **)&d_in, ncell)); HIPCHK(hipMalloc((void **)&d_tmp, ncell)); HIPCHK(hipMalloc((void **)&d_cnt, sizeof(unsigned long long)));
+  HIPCHK(hipMemsetAsync(d_cnt, 0, sizeof(unsigned long long), st));
+  hipLaunchKernelGGL(kk_count_bytes, dim3((unsigned)std::min<size_t>((ncell + 255) / 256, 4096)), dim3(256), 0, st, d_tags, ncell, d_cnt);
+  unsigned long long nt = 0;
+  HIPCHK(hipMemcpyAsync(&nt, d_cnt, sizeof(nt), hipMemcpyDeviceToHost, st));
+  HIPCHK(hipStreamSynchronize(st));
+  if (ntagged) *ntagged = (long)nt;
   *nboxes_out = 0;
-  if (nt == 0) return 0;
-  auto at = [&](std::vector<unsigned char> &a, int i, int j, int k) -> unsigned char & { return a[(size_t)i + (size_t)n[0] * ((size_t)j + (size_t)n[1] * (size_t)k)]; };
-  // 2. grow the tags by buf_wid (box dilation, one direction after the other); shrink `inside` by `nest` the same way (cells
-  // outside the domain count as inside: a level may touch the domain boundary)
-  auto sweep = [&](std::vector<unsigned char> &a, int width, bool dilate) {
+  if (nt == 0) { HIPCHK(hipFree(d_tags)); HIPCHK(hipFree(d_in)); HIPCHK(hipFree(d_tmp)); HIPCHK(hipFree(d_cnt)); return 0; }
+  Range3 whole_cells; for (int d = 0; d < 3; d++) { whole_cells.lo[d] = 0; whole_cells.hi[d] = n[d] - 1; }
+  auto sweep = [&](unsigned char *&a, unsigned char *&tmp, int width, int dilate) {
     if (width <= 0) return;
     for (int d = 0; d < dm; d++) {
-      std::vector<unsigned char> o(a);
-      const int e[3] = { d == 0, d == 1, d == 2 };
-      for (int k = 0; k < n[2]; k++) for (int j = 0; j < n[1]; j++) for (int i = 0; i < n[0]; i++) {
-        unsigned char v = dilate ? 0 : 1;
-        for (int w = -width; w <= width; w++) {
-          const int ii = i + w * e[0], jj = j + w * e[1], kk = k + w * e[2];
-          if (ii < 0 || ii >= n[0] || jj < 0 || jj >= n[1] || kk < 0 || kk >= n[2]) continue;
-          if (dilate) v |= at(o, ii, jj, kk); else v &= at(o, ii, jj, kk);
-        }
-        at(a, i, j, k) = v;
-      }
+      hipLaunchKernelGGL(kk_sweep_bytes, grid_for(whole_cells), dim3(64, 4, 1), 0, st, (const unsigned char *)a, tmp, n[0], n[1], n[2], d, width, dilate);
+      std::swap(a, tmp);
     }
   };
-  sweep(tags, buf_wid, true);
-  sweep(inside, nest, false);
-  for (size_t c = 0; c < ncell; c++) tags[c] &= inside[c];
-  // 3. cluster on the lattice of blocks; a block takes part only if it lies in the nesting region as a whole
-  Lattice G; for (int d = 0; d < 3; d++) G.n[d] = d < dm ? n[d] / blocking : 1;
-  G.t.assign((size_t)G.n[0] * G.n[1] * G.n[2], 0); G.ok.assign(G.t.size(), 0);
-  const int bz = dm == 3 ? blocking : 1;
-  for (int K = 0; K < G.n[2]; K++) for (int J = 0; J < G.n[1]; J++) for (int I = 0; I < G.n[0]; I++) {
-    bool any = false, all_in = true;
-    for (int c = 0; c < bz; c++) for (int b = 0; b < blocking; b++) for (int a = 0; a < blocking; a++) {
-      const int i = I * blocking + a, j = J * blocking + b, k = K * bz + c;
-      any = any || at(tags, i, j, k); all_in = all_in && at(inside, i, j, k);
-    }
-    G.t[(size_t)I + (size_t)G.n[0] * ((size_t)J + (size_t)G.n[1] * (size_t)K)] = (any && all_in) ? 1 : 0;
-    G.ok[(size_t)I + (size_t)G.n[0] * ((size_t)J + (size_t)G.n[1] * (size_t)K)] = all_in ? 1 : 0;
+  HIPCHK(hipMemsetAsync(d_in, 0, ncell, st));
+  for (const vdn_box &gb : la->boxes[s->lev]) {
+    Range3 r; for (int d = 0; d < 3; d++) { r.lo[d] = gb.lo[d] - pd.lo[d]; r.hi[d] = gb.hi[d] - pd.lo[d]; }
+    hipLaunchKernelGGL(kk_fill_bytes, grid_for(r), dim3(64, 4, 1), 0, st, d_in, n[0], n[1], r);
   }
+  sweep(d_tags, d_tmp, buf_wid, 1);
+  sweep(d_in, d_tmp, nest, 0);
+  // 3. cluster on the lattice of blocks; a block takes part only if it lies in the nesting region as a whole (a tagged cell outside the nesting region
+  // cannot tag a block: the block is then not inside as a whole either)
+  Lattice G; for (int d = 0; d < 3; d++) G.n[d] = d < dm ? n[d] / blocking : 1;
+  const size_t nblk = (size_t)G.n[0] * G.n[1] * G.n[2];
+  G.t.assign(nblk, 0); G.ok.assign(nblk, 0);
+  const int bz = dm == 3 ? blocking : 1;
+  {
+    unsigned char *d_lat = nullptr; HIPCHK(hipMalloc((void **)&d_lat, 2 * nblk));
+    Range3 rb; for (int d = 0; d < 3; d++) { rb.lo[d] = 0; rb.hi[d] = G.n[d] - 1; }
+    hipLaunchKernelGGL(kk_block_lattice, grid_for(rb), dim3(64, 4, 1), 0, st, (const unsigned char *)d_tags, (const unsigned char *)d_in, d_lat, d_lat + nblk,
+                       n[0], n[1], G.n[0], G.n[1], blocking, bz, rb);
+    HIPCHK(hipMemcpyAsync(G.t.data(), d_lat, nblk, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipMemcpyAsync(G.ok.data(), d_lat + nblk, nblk, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    HIPCHK(hipFree(d_lat));
+  }
+  HIPCHK(hipFree(d_tags)); HIPCHK(hipFree(d_in)); HIPCHK(hipFree(d_tmp)); HIPCHK(hipFree(d_cnt));
   std::vector<IBox> cl;
   IBox whole; for (int d = 0; d < 3; d++) { whole.lo[d] = 0; whole.hi[d] = G.n[d] - 1; }
   cluster(G, whole, min_eff, std::max(1, (min_width + blocking - 1) / blocking), cl);
   // 3b. merge neighbours whose union is again a box (the recursion cuts more than the final box set needs, e.g. where a cut for the
   // nesting region or a hole left two boxes of equal cross-section side by side): fewer, larger boxes for the same cells
-  for (bool merged = true; merged;) {
-    merged = false;
-    for (size_t a = 0; a < cl.size() && !merged; a++)
-      for (size_t b = a + 1; b < cl.size() && !merged; b++)
-        for (int d = 0; d < 3 && !merged; d++) {
-          const int t1 = (d + 1) % 3, t2 = (d + 2) % 3;
-          if (cl[a].lo[t1] != cl[b].lo[t1] || cl[a].hi[t1] != cl[b].hi[t1] || cl[a].lo[t2] != cl[b].lo[t2] || cl[a].hi[t2] != cl[b].hi[t2]) continue;
-          if (cl[a].hi[d] + 1 == cl[b].lo[d]) { cl[a].hi[d] = cl[b].hi[d]; cl.erase(cl.begin() + b); merged = true; }
-          else if (cl[b].hi[d] + 1 == cl[a].lo[d]) { cl[a].lo[d] = cl[b].lo[d]; cl.erase(cl.begin() + b); merged = true; }
-        }
+  // The rule: take the first pair (a, b), a < b, in lexicographic order whose union is a box, replace a by the union, drop b, start again.  Starting again
+  // from (0, 1) each time is cubic in the number of boxes (a thousand on a 512^3 level); the same sequence of merges comes out of keeping the row: after a
+  // merge into row a only pairs WITH the changed box can have become mergeable -- (x, a) for x < a, in increasing x, then row a from a + 1 on.
+  auto mergeable = [&](const IBox &p, const IBox &q) {
+    for (int d = 0; d < 3; d++) {
+      const int t1 = (d + 1) % 3, t2 = (d + 2) % 3;
+      if (p.lo[t1] != q.lo[t1] || p.hi[t1] != q.hi[t1] || p.lo[t2] != q.lo[t2] || p.hi[t2] != q.hi[t2]) continue;
+      if (p.hi[d] + 1 == q.lo[d] || q.hi[d] + 1 == p.lo[d]) return d;
+    }
+    return -1;
+  };
+  auto absorb = [&](size_t a, size_t b) {                  // cl[a] = cl[a] u cl[b]; b goes
+    const int d = mergeable(cl[a], cl[b]);
+    cl[a].lo[d] = std::min(cl[a].lo[d], cl[b].lo[d]); cl[a].hi[d] = std::max(cl[a].hi[d], cl[b].hi[d]);
+    cl.erase(cl.begin() + b);
+  };
+  for (size_t row = 0; row < cl.size();) {
+    size_t b = row + 1;
+    while (b < cl.size() && mergeable(cl[row], cl[b]) < 0) b++;
+    if (b == cl.size()) { row++; continue; }
+    absorb(row, b);
+    size_t dirty = row;
+    for (bool again = true; again;) {
+      again = false;
+      for (size_t x = 0; x < dirty; x++) if (mergeable(cl[x], cl[dirty]) >= 0) { absorb(x, dirty); dirty = x; again = true; break; }
+    }
+    row = dirty;
   }
   // 4. refine (blocks -> cells of this level -> cells of the finer level) and chop to max_grid_size
   std::vector<vdn_box> out;
