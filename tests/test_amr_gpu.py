@@ -999,13 +999,15 @@ def test_level0_cycles_of_composite_solves_by_colour_agree_bit_for_bit(gpu):
         G.close()
     """ % root)
     out = []
-    for extra in ({"VDN_MAC_SPLIT_MIN": "0", "VDN_MAC_SLAB": "16"}, {"VDN_MAC_SPLIT": "0"}):
+    # third run: the refined levels' sweeps and residuals READ the face coefficients (VDN_MLCC_RHO=0) instead of forming them from the density (MAC) or taking
+    # the constant mu (viscous solves: use_rho == 2 of amr.hip) -- the same bits again
+    for extra in ({"VDN_MAC_SPLIT_MIN": "0", "VDN_MAC_SLAB": "16"}, {"VDN_MAC_SPLIT": "0"}, {"VDN_MAC_SPLIT": "0", "VDN_MLCC_RHO": "0"}):
         env = dict(os.environ)
-        for k in ("VDN_MAC_SPLIT", "VDN_MAC_SPLIT_MIN", "VDN_MAC_SLAB"):
+        for k in ("VDN_MAC_SPLIT", "VDN_MAC_SPLIT_MIN", "VDN_MAC_SLAB", "VDN_MLCC_RHO"):
             env.pop(k, None)
         env.update(extra)
         r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600, cwd=root)
         assert r.returncode == 0, r.stderr[-2000:]
         out.append([ln for ln in r.stdout.splitlines() if ln.startswith("HASH")][0].split())
-    assert out[0][1] == out[1][1] and out[0][2] == out[1][2], out
+    assert out[0][1] == out[1][1] == out[2][1] and out[0][2] == out[1][2] == out[2][2], out
     assert out[0][4] == "1" and out[1][4] == "0", out          # (the last cell-centred solve of the step: a viscous composite one; its level-0 cycles by colour / interleaved)

@@ -8,9 +8,9 @@
 #include "vdn_dev.h"
 
 struct LapArgs { int lo[3], hi[3]; int ebc[3][2]; double hi2[3]; int comp; };
-__global__ void kk_lap(FV lap, FV data, LapArgs A, Range3 r) {
-  THREAD_IJK(r)
-  if (!in_range) return;
+// one descriptor per box, all boxes of a level in one launch (launch_cells: a level of a thousand boxes was a thousand launches, 36 ms of a viscous three-level step)
+struct lap_K { FV lap; FV data; LapArgs A;
+  __device__ void cell(int i, int j, int k) const {
   const int q[3] = { i, j, k };
   const double p0 = fv_get(data, i, j, k, A.comp);
   double sum = 0.0;
@@ -24,12 +24,13 @@ __global__ void kk_lap(FV lap, FV data, LapArgs A, Range3 r) {
     sum = sum + (fp - fm) * A.hi2[d];
   }
   fv_at(lap, i, j, k, A.comp) = sum;
-}
+} };
 
 // lap(comp) = laplacian(data(comp)); bccomp0 = 0-based ell bc component.  data must have its ghost cells filled.
 void k_explicit_diffusive_term(vdn_multifab *lap, const vdn_multifab *data, int comp, int bccomp0, const double *dx, const vdn_bc_tower *bct) {
   if (ctx().prm.dm == 2) { k2_explicit_diffusive_term(lap, data, comp, bccomp0, dx, bct); return; }
   REQUIRE(data->ng >= 1, "explicit diffusive term: data needs a filled ghost cell");
+  std::vector<std::pair<lap_K, Range3>> v;
   for (int i = 0; i < data->nfabs(); i++) {
     LapArgs A; Range3 r;
     for (int d = 0; d < 3; d++) {
@@ -37,15 +38,15 @@ void k_explicit_diffusive_term(vdn_multifab *lap, const vdn_multifab *data, int 
       for (int s = 0; s < 2; s++) A.ebc[d][s] = bct->ell_bc(data->lev, i + 1, d, s, bccomp0);     // BC_INT on interior box faces
     }
     A.comp = comp;
-    hipLaunchKernelGGL(kk_lap, grid_for(r), dim3(64, 4, 1), 0, ctx().stream, lap->fabs[i], data->fabs[i], A, r);
+    v.push_back({ lap_K{ lap->fabs[i], data->fabs[i], A }, r });
   }
+  launch_cells(v, ctx().stream);
 }
 
 struct VrhsArgs { int comp, dtype; double mu, third_vmd_over_dx; };
 // mkrhs_3d (viscsolve.f90:264-302): phi = unew(comp) on the grown box, rh = rho*unew + mu*lapu [+ (1/3) visc_mu_dt d(mac_rhs)/dx_comp]
-__global__ void kk_visc_rhs(FV rh, FV phi, FV unew, FV lapu, FV rho, FV macrhs, VrhsArgs A, Range3 rg, int lo0, int lo1, int lo2, int hi0, int hi1, int hi2, double dxc, double third, double visc_mu_dt) {
-  THREAD_IJK(rg)
-  if (!in_range) return;
+struct visc_rhs_K { FV rh; FV phi; FV unew; FV lapu; FV rho; FV macrhs; VrhsArgs A; int lo0, lo1, lo2, hi0, hi1, hi2; double dxc, third, visc_mu_dt;
+  __device__ void cell(int i, int j, int k) const {
   const double u = fv_get(unew, i, j, k, A.comp);
   fv_at(phi, i, j, k) = u;
   if (i < lo0 || i > hi0 || j < lo1 || j > hi1 || k < lo2 || k > hi2) return;
@@ -55,16 +56,37 @@ __global__ void kk_visc_rhs(FV rh, FV phi, FV unew, FV lapu, FV rho, FV macrhs, 
   const double mp = fv_get(macrhs, i + (c == 0), j + (c == 1), k + (c == 2)), mm = fv_get(macrhs, i - (c == 0), j - (c == 1), k - (c == 2));
   r = r + third * visc_mu_dt * (mp - mm) / dxc;
   fv_at(rh, i, j, k) = r;
-}
-__global__ void kk_diff_rhs(FV rh, FV phi, FV snew, FV laps, int comp, int dtype, double mu, Range3 rg, int lo0, int lo1, int lo2, int hi0, int hi1, int hi2) {
-  THREAD_IJK(rg)
-  if (!in_range) return;
+} };
+struct diff_rhs_K { FV rh; FV phi; FV snew; FV laps; int comp, dtype; double mu; int lo0, lo1, lo2, hi0, hi1, hi2;
+  __device__ void cell(int i, int j, int k) const {
   const double s = fv_get(snew, i, j, k, comp);
   fv_at(phi, i, j, k) = s;
   if (i < lo0 || i > hi0 || j < lo1 || j > hi1 || k < lo2 || k > hi2) return;
   double r = s;
   if (dtype == 1) r = r + mu * fv_get(laps, i, j, k, comp);
   fv_at(rh, i, j, k) = r;
+} };
+// the right-hand sides of one level, all its boxes in one launch
+static void visc_rhs_level(vdn_multifab *rh, vdn_multifab *phi, const vdn_multifab *unew, const vdn_multifab *lapu, const vdn_multifab *rho, const vdn_multifab *mac_rhs,
+                           int comp, double mu, double dxc, double visc_mu_dt) {
+  std::vector<std::pair<visc_rhs_K, Range3>> v;
+  for (int i = 0; i < unew->nfabs(); i++) {
+    const vdn_box &bx = unew->vbox[i];
+    Range3 rg; for (int a = 0; a < 3; a++) { rg.lo[a] = bx.lo[a] - 1; rg.hi[a] = bx.hi[a] + 1; }
+    VrhsArgs A; A.comp = comp; A.dtype = ctx().prm.diffusion_type; A.mu = mu; A.third_vmd_over_dx = 0.0;
+    v.push_back({ visc_rhs_K{ rh->fabs[i], phi->fabs[i], unew->fabs[i], lapu->fabs[i], rho->fabs[i], mac_rhs->fabs[i], A, bx.lo[0], bx.lo[1], bx.lo[2], bx.hi[0], bx.hi[1], bx.hi[2],
+                              dxc, 1.0 / 3.0, visc_mu_dt }, rg });
+  }
+  launch_cells(v, ctx().stream);
+}
+static void diff_rhs_level(vdn_multifab *rh, vdn_multifab *phi, const vdn_multifab *snew, const vdn_multifab *laps, int icomp, double mu) {
+  std::vector<std::pair<diff_rhs_K, Range3>> v;
+  for (int i = 0; i < snew->nfabs(); i++) {
+    const vdn_box &bx = snew->vbox[i];
+    Range3 rg; for (int a = 0; a < 3; a++) { rg.lo[a] = bx.lo[a] - 1; rg.hi[a] = bx.hi[a] + 1; }
+    v.push_back({ diff_rhs_K{ rh->fabs[i], phi->fabs[i], snew->fabs[i], laps->fabs[i], icomp, ctx().prm.diffusion_type, mu, bx.lo[0], bx.lo[1], bx.lo[2], bx.hi[0], bx.hi[1], bx.hi[2] }, rg });
+  }
+  launch_cells(v, ctx().stream);
 }
 
 static void ell_of(const vdn_bc_tower *bct, int lev, int comp0, int ebc[3][2]) {
@@ -75,7 +97,6 @@ void do_visc_solve(vdn_layout *mla, vdn_multifab *unew, const vdn_multifab *lapu
                    const double *dx, double mu, const vdn_bc_tower *bct) {
   if (ctx().prm.dm == 2) { do2_visc_solve(mla, unew, lapu, rho, mac_rhs, dx, mu, bct); return; }
   const int n = 0;
-  hipStream_t st = ctx().stream;
   size_t mark = arena_mark();
   vdn_multifab *rh = mf_temp(mla, n, 1, 0, -1, false, 0.0);
   vdn_multifab *phi = mf_temp(mla, n, 1, 1, -1, true, 0.0);
@@ -85,13 +106,7 @@ void do_visc_solve(vdn_layout *mla, vdn_multifab *unew, const vdn_multifab *lapu
   mf_copy(alpha, 0, rho, 0, 1, 0);                                                     // alpha = rho, viscsolve.f90:57
   const double visc_mu_dt = (ctx().prm.diffusion_type == 1) ? 2.0 * mu : mu;
   for (int d = 0; d < 3; d++) {
-    for (int i = 0; i < unew->nfabs(); i++) {
-      const vdn_box &bx = unew->vbox[i];
-      Range3 rg; for (int a = 0; a < 3; a++) { rg.lo[a] = bx.lo[a] - 1; rg.hi[a] = bx.hi[a] + 1; }
-      VrhsArgs A; A.comp = d; A.dtype = ctx().prm.diffusion_type; A.mu = mu; A.third_vmd_over_dx = 0.0;
-      hipLaunchKernelGGL(kk_visc_rhs, grid_for(rg), dim3(64, 4, 1), 0, st, rh->fabs[i], phi->fabs[i], unew->fabs[i], lapu->fabs[i], rho->fabs[i],
-                         mac_rhs->fabs[i], A, rg, bx.lo[0], bx.lo[1], bx.lo[2], bx.hi[0], bx.hi[1], bx.hi[2], dx[d], 1.0 / 3.0, visc_mu_dt);
-    }
+    visc_rhs_level(rh, phi, unew, lapu, rho, mac_rhs, d, mu, dx[d], visc_mu_dt);
     int ebc[3][2]; ell_of(bct, n, d, ebc);                                             // bc_comp = d, viscsolve.f90:99
     int cyc; double r0, rr;
     int rc = cc_solve(rh, phi, beta, dx, ebc, 1.e-12, -1.0, ctx().prm.mg_max_iter, &cyc, &r0, &rr, alpha, nullptr, nullptr, nullptr, 0, false, nullptr, mu);   // viscsolve.f90:88-89 (beta = mu on every face)
@@ -109,7 +124,6 @@ void do_visc_solve(vdn_layout *mla, vdn_multifab *unew, const vdn_multifab *lapu
 void do_ml_visc_solve(vdn_layout *mla, vdn_multifab **unew, vdn_multifab **lapu, vdn_multifab **rho, vdn_multifab **mac_rhs,
                       const double *dx, double mu, const vdn_bc_tower *bct) {
   const int L = mla->nlev;
-  hipStream_t st = ctx().stream;
   size_t mark = arena_mark();
   vdn_multifab *rh[VDN_MAXLEV], *phi[VDN_MAXLEV], *alpha[VDN_MAXLEV], *beta[3 * VDN_MAXLEV];
   for (int n = 0; n < L; n++) {
@@ -119,14 +133,7 @@ void do_ml_visc_solve(vdn_layout *mla, vdn_multifab **unew, vdn_multifab **lapu,
   }
   const double visc_mu_dt = (ctx().prm.diffusion_type == 1) ? 2.0 * mu : mu;
   for (int d = 0; d < 3; d++) {
-    for (int n = 0; n < L; n++)
-      for (int i = 0; i < unew[n]->nfabs(); i++) {
-        const vdn_box &bx = unew[n]->vbox[i];
-        Range3 rg; for (int a = 0; a < 3; a++) { rg.lo[a] = bx.lo[a] - 1; rg.hi[a] = bx.hi[a] + 1; }
-        VrhsArgs A; A.comp = d; A.dtype = ctx().prm.diffusion_type; A.mu = mu; A.third_vmd_over_dx = 0.0;
-        hipLaunchKernelGGL(kk_visc_rhs, grid_for(rg), dim3(64, 4, 1), 0, st, rh[n]->fabs[i], phi[n]->fabs[i], unew[n]->fabs[i], lapu[n]->fabs[i], rho[n]->fabs[i],
-                           mac_rhs[n]->fabs[i], A, rg, bx.lo[0], bx.lo[1], bx.lo[2], bx.hi[0], bx.hi[1], bx.hi[2], dx[3 * n + d], 1.0 / 3.0, visc_mu_dt);
-      }
+    for (int n = 0; n < L; n++) visc_rhs_level(rh[n], phi[n], unew[n], lapu[n], rho[n], mac_rhs[n], d, mu, dx[3 * n + d], visc_mu_dt);
     int it; double r0, rr;
     int rc = ml_cc_solve(mla, rh, phi, beta, dx, bct, d, 1.e-12, ctx().prm.mg_max_iter, &it, &r0, &rr, alpha, nullptr, nullptr, nullptr, mu);      // bc_comp = d, viscsolve.f90:88-99
     solver_check(rc, "composite viscous solve", it, rr, r0, d);
@@ -141,19 +148,13 @@ void do_diff_scalar_solve(vdn_layout *mla, vdn_multifab *snew, const vdn_multifa
                           const vdn_bc_tower *bct, int icomp, int bccomp0) {
   if (ctx().prm.dm == 2) { do2_diff_scalar_solve(mla, snew, laps, dx, mu, bct, icomp, bccomp0); return; }
   const int n = 0;
-  hipStream_t st = ctx().stream;
   size_t mark = arena_mark();
   vdn_multifab *rh = mf_temp(mla, n, 1, 0, -1, false, 0.0);
   vdn_multifab *phi = mf_temp(mla, n, 1, 1, -1, true, 0.0);
   vdn_multifab *alpha = mf_temp(mla, n, 1, 0, -1, true, 1.0);                          // viscsolve.f90:349
   vdn_multifab *beta[3];
   for (int d = 0; d < 3; d++) beta[d] = mf_temp(mla, n, 1, 0, d, true, mu);
-  for (int i = 0; i < snew->nfabs(); i++) {
-    const vdn_box &bx = snew->vbox[i];
-    Range3 rg; for (int a = 0; a < 3; a++) { rg.lo[a] = bx.lo[a] - 1; rg.hi[a] = bx.hi[a] + 1; }
-    hipLaunchKernelGGL(kk_diff_rhs, grid_for(rg), dim3(64, 4, 1), 0, st, rh->fabs[i], phi->fabs[i], snew->fabs[i], laps->fabs[i], icomp,
-                       ctx().prm.diffusion_type, mu, rg, bx.lo[0], bx.lo[1], bx.lo[2], bx.hi[0], bx.hi[1], bx.hi[2]);
-  }
+  diff_rhs_level(rh, phi, snew, laps, icomp, mu);
   int ebc[3][2]; ell_of(bct, n, bccomp0, ebc);
   int cyc; double r0, rr;
   int rc = cc_solve(rh, phi, beta, dx, ebc, 1.e-12, -1.0, ctx().prm.mg_max_iter, &cyc, &r0, &rr, alpha, nullptr, nullptr, nullptr, 0, false, nullptr, mu);
@@ -170,18 +171,12 @@ void do_diff_scalar_solve(vdn_layout *mla, vdn_multifab *snew, const vdn_multifa
 void do_ml_diff_scalar_solve(vdn_layout *mla, vdn_multifab **snew, vdn_multifab **laps, const double *dx, double mu,
                              const vdn_bc_tower *bct, int icomp, int bccomp0) {
   const int L = mla->nlev;
-  hipStream_t st = ctx().stream;
   size_t mark = arena_mark();
   vdn_multifab *rh[VDN_MAXLEV], *phi[VDN_MAXLEV], *alpha[VDN_MAXLEV], *beta[3 * VDN_MAXLEV];
   for (int n = 0; n < L; n++) {
     rh[n] = mf_temp(mla, n, 1, 0, -1, false, 0.0); phi[n] = mf_temp(mla, n, 1, 1, -1, true, 0.0); alpha[n] = mf_temp(mla, n, 1, 0, -1, true, 1.0);   // viscsolve.f90:349
     for (int d = 0; d < 3; d++) beta[3 * n + d] = mf_temp(mla, n, 1, 0, d, true, mu);
-    for (int i = 0; i < snew[n]->nfabs(); i++) {
-      const vdn_box &bx = snew[n]->vbox[i];
-      Range3 rg; for (int a = 0; a < 3; a++) { rg.lo[a] = bx.lo[a] - 1; rg.hi[a] = bx.hi[a] + 1; }
-      hipLaunchKernelGGL(kk_diff_rhs, grid_for(rg), dim3(64, 4, 1), 0, st, rh[n]->fabs[i], phi[n]->fabs[i], snew[n]->fabs[i], laps[n]->fabs[i], icomp,
-                         ctx().prm.diffusion_type, mu, rg, bx.lo[0], bx.lo[1], bx.lo[2], bx.hi[0], bx.hi[1], bx.hi[2]);
-    }
+    diff_rhs_level(rh[n], phi[n], snew[n], laps[n], icomp, mu);
   }
   int it; double r0, rr;
   int rc = ml_cc_solve(mla, rh, phi, beta, dx, bct, bccomp0, 1.e-12, ctx().prm.mg_max_iter, &it, &r0, &rr, alpha, nullptr, nullptr, nullptr, mu);
