@@ -36,26 +36,99 @@ void arena_reset() {
   g_ctx.arena_off = 0;
   g_ctx.drop_step_caches();
 }
-// make sure the arena holds at least `bytes`; only legal while nothing is live in it
-void arena_reserve(size_t bytes) {
+// The arena is a range of device ADDRESSES reserved once (hipMemAddressReserve: the card's whole memory, rounded up) into which physical memory is mapped in
+// 1 GB chunks as the high-water mark moves (hipMemCreate + hipMemMap + hipMemSetAccess: tens of microseconds per chunk, tools/probes/vmm_probe2.hip).  Rounds 1-5
+// sized it up front -- 150 ghosted fields of the layout, 120 GB for the three-level 256^3 hierarchy -- with one hipMalloc, and a regrid that needed more freed it
+// and allocated again: 3-7 SECONDS per hipMalloc beyond some 30 GB on this card (profiles/r06_regrid_cost.txt), every kept descriptor set and graph dropped because
+// the base moved.  Now the base never moves, nothing is guessed, and only what a step touches is backed by memory.
+static const size_t ARENA_CHUNK = (size_t)1 << 30;
+static std::vector<hipMemGenericAllocationHandle_t> g_arena_chunks;
+static size_t g_arena_va = 0;
+static void arena_map_to(size_t bytes) {                   // c.arena_bytes (= mapped bytes) >= bytes afterwards
   VdnCtx &c = g_ctx;
   if (bytes <= c.arena_bytes) return;
-  REQUIRE(c.arena_off == 0, "arena_reserve while temporaries are live");
-  if (c.arena) { HIPCHK(hipStreamSynchronize(c.stream)); kept_purge(0); HIPCHK(hipFree(c.arena)); c.arena = nullptr; c.arena_bytes = 0; }      // (kept descriptor sets point at temporaries)
-  HIPCHK(hipMalloc((void **)&c.arena, bytes));
-  c.arena_bytes = bytes;
-}
-// temporaries needed by one advance_timestep / projection on this layout: a generous count of
-// ng=3 cell fields per local box (Appendix B of SURVEY.md lists ~45 live fields; the Godunov
-// intermediates add ~40 more)
-void arena_reserve_for(const vdn_layout *la) {
-  size_t per_field = 0;
-  for (int l = 0; l < la->nlev; l++) for (int g : la->local[l]) {
-    const vdn_box &b = la->boxes[l][g];
-    per_field += (size_t)(b.hi[0] - b.lo[0] + 8) * (b.hi[1] - b.lo[1] + 8) * (b.hi[2] - b.lo[2] + 8) * sizeof(double);
+  if (!c.arena) {
+    int vmm = 0; HIPCHK(hipDeviceGetAttribute(&vmm, hipDeviceAttributeVirtualMemoryManagementSupported, c.device));
+    REQUIRE(vmm, "the device does not support hipMemAddressReserve / hipMemMap (the scratch arena needs them)");
+    size_t free_b = 0, total_b = 0; HIPCHK(hipMemGetInfo(&free_b, &total_b));
+    g_arena_va = ((total_b + ARENA_CHUNK - 1) / ARENA_CHUNK) * ARENA_CHUNK;
+    void *base = nullptr; HIPCHK(hipMemAddressReserve(&base, g_arena_va, (size_t)2 << 20, nullptr, 0));
+    c.arena = (char *)base;
   }
-  arena_reserve(per_field * 150 + (64u << 20));
+  hipMemAllocationProp prop = {}; prop.type = hipMemAllocationTypePinned; prop.location.type = hipMemLocationTypeDevice; prop.location.id = c.device;
+  hipMemAccessDesc acc = {}; acc.location.type = hipMemLocationTypeDevice; acc.location.id = c.device; acc.flags = hipMemAccessFlagsProtReadWrite;
+  // (a temporary first asked for inside a graph capture: the mapping calls are no stream work, the relaxed mode says so for this thread while they run)
+  struct Relax { hipStreamCaptureMode m = hipStreamCaptureModeRelaxed; Relax() { (void)hipThreadExchangeStreamCaptureMode(&m); } ~Relax() { (void)hipThreadExchangeStreamCaptureMode(&m); } } relax_;
+  while (c.arena_bytes < bytes) {
+    if (c.arena_bytes + ARENA_CHUNK > g_arena_va) vdn_fail("arena exhausted: %zu bytes wanted, the card holds %zu", bytes, g_arena_va);
+    hipMemGenericAllocationHandle_t h;
+    hipError_t e = hipMemCreate(&h, ARENA_CHUNK, &prop, 0);
+    if (e != hipSuccess) { (void)hipGetLastError(); vdn_fail("arena: no device memory for another chunk (%zu bytes mapped, %zu wanted): %s", c.arena_bytes, bytes, hipGetErrorString(e)); }
+    e = hipMemMap(c.arena + c.arena_bytes, ARENA_CHUNK, 0, h, 0);
+    if (e == hipSuccess) e = hipMemSetAccess(c.arena + c.arena_bytes, ARENA_CHUNK, &acc, 1);
+    if (e != hipSuccess) { (void)hipGetLastError(); (void)hipMemRelease(h); vdn_fail("arena: mapping a chunk at offset %zu failed: %s", c.arena_bytes, hipGetErrorString(e)); }
+    g_arena_chunks.push_back(h);
+    c.arena_bytes += ARENA_CHUNK;
+  }
 }
+static void arena_destroy() {
+  VdnCtx &c = g_ctx;
+  if (!c.arena) return;
+  if (c.arena_bytes) HIPCHK(hipMemUnmap(c.arena, c.arena_bytes));
+  for (hipMemGenericAllocationHandle_t h : g_arena_chunks) HIPCHK(hipMemRelease(h));
+  g_arena_chunks.clear();
+  HIPCHK(hipMemAddressFree(c.arena, g_arena_va));
+  c.arena = nullptr; c.arena_bytes = 0; c.arena_off = 0; g_arena_va = 0;
+}
+// The fields of the state (vdn_multifab_create) come the same way: an address range per field, backed by 64 MB chunks of physical memory that go back to a POOL
+// when the field is destroyed, not to the driver.  A regrid frees and creates some 36 GB-sized fields of slightly different sizes; memory that comes back from the
+// driver costs about 10 ms per GB on this card (hipMalloc and hipMemCreate alike -- 360 ms of a regrid, tools/probes/regrid_profile_probe.py), chunks from
+// the pool cost the mapping calls, some 10 us each.  Fields below 32 MB are plain hipMalloc blocks (a chunk each would waste the card on the small cases).
+static const size_t FIELD_CHUNK = (size_t)64 << 20, FIELD_SMALL = (size_t)32 << 20;
+struct FieldAlloc { size_t va_bytes; std::vector<hipMemGenericAllocationHandle_t> chunks; };
+static std::map<void *, FieldAlloc> g_field_allocs;
+static std::vector<hipMemGenericAllocationHandle_t> g_chunk_pool;
+static void *field_alloc(size_t bytes) {
+  VdnCtx &c = g_ctx;
+  if (bytes < FIELD_SMALL) { void *q = nullptr; HIPCHK(hipMalloc(&q, bytes)); return q; }
+  const size_t n = (bytes + FIELD_CHUNK - 1) / FIELD_CHUNK, sz = n * FIELD_CHUNK;
+  hipMemAllocationProp prop = {}; prop.type = hipMemAllocationTypePinned; prop.location.type = hipMemLocationTypeDevice; prop.location.id = c.device;
+  hipMemAccessDesc acc = {}; acc.location.type = hipMemLocationTypeDevice; acc.location.id = c.device; acc.flags = hipMemAccessFlagsProtReadWrite;
+  void *p = nullptr;
+  HIPCHK(hipMemAddressReserve(&p, sz, (size_t)2 << 20, nullptr, 0));
+  FieldAlloc A; A.va_bytes = sz;
+  hipError_t e = hipSuccess;
+  for (size_t i = 0; i < n && e == hipSuccess; i++) {
+    hipMemGenericAllocationHandle_t h;
+    if (!g_chunk_pool.empty()) { h = g_chunk_pool.back(); g_chunk_pool.pop_back(); }
+    else if ((e = hipMemCreate(&h, FIELD_CHUNK, &prop, 0)) != hipSuccess) break;
+    e = hipMemMap((char *)p + i * FIELD_CHUNK, FIELD_CHUNK, 0, h, 0);
+    if (e == hipSuccess) A.chunks.push_back(h); else g_chunk_pool.push_back(h);
+  }
+  if (e == hipSuccess) e = hipMemSetAccess(p, sz, &acc, 1);
+  if (e != hipSuccess) {
+    (void)hipGetLastError();
+    if (!A.chunks.empty()) (void)hipMemUnmap(p, A.chunks.size() * FIELD_CHUNK);
+    for (auto h : A.chunks) g_chunk_pool.push_back(h);
+    (void)hipMemAddressFree(p, sz);
+    vdn_fail("no device memory for a field of %zu bytes (%zu chunks in the pool): %s", bytes, g_chunk_pool.size(), hipGetErrorString(e));
+  }
+  g_field_allocs[p] = std::move(A);
+  return p;
+}
+static void field_free(void *p) {
+  auto it = g_field_allocs.find(p);
+  if (it == g_field_allocs.end()) { HIPCHK(hipFree(p)); return; }      // (a small field)
+  HIPCHK(hipMemUnmap(p, it->second.va_bytes));
+  for (auto h : it->second.chunks) g_chunk_pool.push_back(h);
+  HIPCHK(hipMemAddressFree(p, it->second.va_bytes));
+  g_field_allocs.erase(it);
+}
+static void field_pool_release() { for (auto h : g_chunk_pool) (void)hipMemRelease(h); g_chunk_pool.clear(); }
+// back at least `bytes` of the arena with memory now
+void arena_reserve(size_t bytes) { arena_map_to(bytes); }
+// nothing to size: the arena follows the steps' high-water mark (kept for its callers: the start of every public entry point)
+void arena_reserve_for(const vdn_layout *) {}
 size_t arena_mark() { return g_ctx.arena_off; }
 // VDN_ARENA_POISON=1 (debugging): whatever is handed back to the arena is overwritten with NaNs (all-ones bytes), so that a kernel which reads
 // an entry nobody wrote -- and only worked because the last tenant of that address left zeros there -- meets a NaN; the norms turn it into a
@@ -67,14 +140,7 @@ void arena_release(size_t mark) {
 void *arena_alloc(size_t bytes) {
   VdnCtx &c = g_ctx;
   size_t off = (c.arena_off + 255) & ~(size_t)255;
-  if (off + bytes > c.arena_bytes) {
-    // grow: only legal when nothing is live (arena_off == 0) -- otherwise fail loudly
-    if (c.arena_off != 0) vdn_fail("arena exhausted: need %zu more bytes (have %zu); call vdn_reserve first", bytes, c.arena_bytes);
-    size_t want = std::max(bytes * 2, c.arena_bytes * 2);
-    if (c.arena) { kept_purge(0); HIPCHK(hipFree(c.arena)); }
-    HIPCHK(hipMalloc((void **)&c.arena, want));
-    c.arena_bytes = want; off = 0;
-  }
+  if (off + bytes > c.arena_bytes) arena_map_to(off + bytes);      // (legal with temporaries live and work in flight: the mapped part does not move)
   c.arena_off = off + bytes;
   if (c.arena_off > c.arena_peak) c.arena_peak = c.arena_off;
   return c.arena + off;
@@ -399,7 +465,7 @@ extern "C" int vdn_finalize(void) {
   VDN_TRY
   VdnCtx &c = g_ctx;
   kept_purge(0);
-  if (c.arena) { HIPCHK(hipFree(c.arena)); c.arena = nullptr; c.arena_bytes = 0; c.arena_off = 0; }
+  arena_destroy(); field_pool_release();
   graph_cache_clear();
   if (c.d_hist) { HIPCHK(hipFree(c.d_hist)); c.d_hist = nullptr; }
   if (c.d_scal) { HIPCHK(hipFree(c.d_scal)); c.d_scal = nullptr; HIPCHK(hipHostFree(c.h_scal)); c.h_scal = nullptr; c.h_scal_dev = nullptr; }
@@ -584,7 +650,7 @@ extern "C" int vdn_multifab_create(const vdn_layout *la, int lev, int nc, int ng
   for (int d = 0; d < 3; d++) mf->nodal[d] = nodal ? (nodal[d] != 0) : 0;
   size_t tot; mf_layout_fabs(mf, &tot);
   mf->bytes = std::max<size_t>(tot, 1) * sizeof(double);
-  HIPCHK(hipMalloc((void **)&mf->base, mf->bytes));
+  mf->base = (double *)field_alloc(mf->bytes);
   for (auto &f : mf->fabs) f.p = (double *)((char *)mf->base + (uintptr_t)f.p);
   HIPCHK(hipMemsetAsync(mf->base, 0, mf->bytes, g_ctx.stream));
   *out = mf;
@@ -689,7 +755,7 @@ void upload_staged(void *dst, const void *src, size_t bytes) {
 
 extern "C" int vdn_multifab_destroy(vdn_multifab *mf) {
   VDN_TRY
-  if (mf) { if (mf->owns && mf->base) { HIPCHK(hipStreamSynchronize(g_ctx.stream)); HIPCHK(hipFree(mf->base)); } delete mf; }
+  if (mf) { if (mf->owns && mf->base) { HIPCHK(hipStreamSynchronize(g_ctx.stream)); field_free(mf->base); } delete mf; }
   VDN_CATCH
 }
 extern "C" int vdn_multifab_nfabs(const vdn_multifab *mf) { return mf->nfabs(); }
