@@ -41,7 +41,9 @@ void arena_reset() {
 // sized it up front -- 150 ghosted fields of the layout, 120 GB for the three-level 256^3 hierarchy -- with one hipMalloc, and a regrid that needed more freed it
 // and allocated again: 3-7 SECONDS per hipMalloc beyond some 30 GB on this card (profiles/r06_regrid_cost.txt), every kept descriptor set and graph dropped because
 // the base moved.  Now the base never moves, nothing is guessed, and only what a step touches is backed by memory.
-static const size_t ARENA_CHUNK = (size_t)1 << 30;
+static size_t env_mb(const char *name, size_t dflt_mb) { const char *e = vdn_env(name); const long v = e ? atol(e) : 0; return (size_t)(v > 0 ? v : (long)dflt_mb) << 20; }
+static size_t arena_chunk() { static const size_t v = env_mb("VDN_ARENA_CHUNK_MB", 1024); return v; }
+#define ARENA_CHUNK arena_chunk()
 static std::vector<hipMemGenericAllocationHandle_t> g_arena_chunks;
 static size_t g_arena_va = 0;
 static void arena_map_to(size_t bytes) {                   // c.arena_bytes (= mapped bytes) >= bytes afterwards
@@ -84,7 +86,10 @@ static void arena_destroy() {
 // when the field is destroyed, not to the driver.  A regrid frees and creates some 36 GB-sized fields of slightly different sizes; memory that comes back from the
 // driver costs about 10 ms per GB on this card (hipMalloc and hipMemCreate alike -- 360 ms of a regrid, tools/probes/regrid_profile_probe.py), chunks from
 // the pool cost the mapping calls, some 10 us each.  Fields below 32 MB are plain hipMalloc blocks (a chunk each would waste the card on the small cases).
-static const size_t FIELD_CHUNK = (size_t)64 << 20, FIELD_SMALL = (size_t)32 << 20;
+static size_t field_chunk() { static const size_t v = env_mb("VDN_FIELD_CHUNK_MB", 64); return v; }
+static size_t field_small() { static const size_t v = vdn_env("VDN_FIELD_VMM") && atoi(vdn_env("VDN_FIELD_VMM")) == 0 ? ~(size_t)0 : (size_t)32 << 20; return v; }
+#define FIELD_CHUNK field_chunk()
+#define FIELD_SMALL field_small()
 struct FieldAlloc { size_t va_bytes; std::vector<hipMemGenericAllocationHandle_t> chunks; };
 static std::map<void *, FieldAlloc> g_field_allocs;
 static std::vector<hipMemGenericAllocationHandle_t> g_chunk_pool;
@@ -189,6 +194,9 @@ static const EnvSwitch g_switches[] = {
   { "VDN_RCCL_LIB", "path of a library that stands in for librccl -- honoured only with VDN_TESTING=1 and the test double's handshake" },
   { "VDN_FORCE_PACKED", "1: box-to-box copies of one rank go through the packed per-peer buffers (device memcpy for send/recv); 2: through a 1-rank RCCL communicator (one-GPU rehearsal of the N > 1 transport)" },
   { "VDN_ARENA_POISON", "1: every byte handed back to the arena is overwritten with NaNs (a read of an entry nobody wrote fails the next solve)" },
+  { "VDN_ARENA_CHUNK_MB", "size of the physical chunks mapped into the arena's address range (default 1024)" },
+  { "VDN_FIELD_CHUNK_MB", "size of the pooled physical chunks behind the state fields (default 64)" },
+  { "VDN_FIELD_VMM", "0: every state field is one hipMalloc block (rounds 1-5) instead of pooled chunks mapped into its own address range" },
   { "VDN_NO_ROCTX", "do not bind the roctx library (no bl_prof ranges)" },
   { "VDN_POLL", "scalar read-back: 1 spin on the pinned sequence number, 0 hipStreamSynchronize; default: spin on one rank, synchronise on several" },
   { "VDN_NO_GRAPHS", "launch every multigrid cycle eagerly instead of replaying its hipGraph" },
