@@ -162,7 +162,7 @@ def parse_args():
     ap.add_argument("--no-cpu256", dest="no_cpu256", action="store_true", help="skip cpu_baseline.sample_256 (one oracle step at the headline size, about 20 s with its start-up)")
     ap.add_argument("--no-pmc", dest="no_pmc", action="store_true", help="do not measure roofline.traffic in this run (two rocprofv3 --pmc child passes on tools/smoother_probe.py); "
                     "the committed counter summary is quoted instead.  Needed when bench.py itself runs under rocprofv3")
-    ap.add_argument("--no-extra", dest="no_extra", action="store_true", help="skip the extra_workloads (512^3 in eight boxes and in one box, tagged two- and three-level hierarchies) of the default N = 1 line")
+    ap.add_argument("--no-extra", dest="no_extra", action="store_true", help="skip the extra_workloads (512^3 in eight boxes and in one box, tagged two- and three-level hierarchies, the viscous 256^3 step, the viscous three-level run with regridding) of the default N = 1 line")
     return ap.parse_args()
 
 
@@ -383,6 +383,40 @@ def main():
             extra.append({"workload": wl2, "cells": cells2, "steps": XS, "warmup": 1, "ms_per_step": round(1e3 * el2 / XS, 3),
                           "value": round(cells2 * XS / el2, 1), "unit": "cells*steps/s",
                           "solver_iterations_per_step": {k: round(v / float(XS), 2) for k, v in cyc2.items()}, "wall_s_incl_setup": round(time.perf_counter() - tb, 1)})
+        # the shape of the reference's own 3-D inputs, which the inviscid headline leaves out: visc_coef = 0.001 (exec/test/inputs_bubble_3d: three Crank-Nicolson
+        # velocity solves per step) on one 256^3 box, and on the three-level hierarchy with the grids rebuilt every second step (exec/test/inputs_3d-regt: regrid_int = 2)
+        vprm = default_params(cflfac=0.9, hg_fmg=args.hg_fmg, mac_fmg=args.mac_fmg, visc_coef=0.001)
+        tb = time.perf_counter()
+        Gv = driver.Varden((256,) * 3, walls, vprm, prob_type=1, grav=-9.8, init_shrink=0.1, init_iter=1, device=local_rank, swap_state=True)
+        Gv.step(); torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(XS):
+            Gv.step()
+        torch.cuda.synchronize()
+        elv = time.perf_counter() - t1
+        Gv.close()
+        extra.append({"workload": "3D 256x256x256 single-level bubble with visc_coef = 0.001 (exec/test/inputs_bubble_3d's value; the headline is the same run with visc_coef = 0)", "cells": 256 ** 3,
+                      "steps": XS, "warmup": 1, "ms_per_step": round(1e3 * elv / XS, 3), "value": round(256 ** 3 * XS / elv, 1), "unit": "cells*steps/s", "wall_s_incl_setup": round(time.perf_counter() - tb, 1)})
+        tb = time.perf_counter()
+        lv = driver.VardenAMR.tagged_grids(256, walls, vprm, max_levs=3, max_grid_size=256, device=local_rank)
+        Gr = driver.VardenAMR(256, lv[0], walls, params=vprm, finer_levels=lv[1:], init_shrink=0.1, init_iter=1, do_initial_projection=1, device=local_rank, max_grid_size=256, swap_state=True,
+                              regrid_int=2, max_levs=3)
+        Gr.step(); torch.cuda.synchronize()
+        tsr, cells_r = [], 0
+        for _ in range(XS):
+            t1 = time.perf_counter(); nreg = Gr.nregrids
+            Gr.step(); torch.cuda.synchronize()
+            tsr.append((time.perf_counter() - t1, Gr.nregrids > nreg))
+            cells_r += sum(int(np.prod([b[1][d] - b[0][d] + 1 for d in range(3)])) for lb in Gr.boxes for b in lb)
+        boxes_r = [len(lb) for lb in Gr.boxes]
+        Gr.close()
+        elr = sum(t for t, _ in tsr)
+        t_reg, t_plain = [t for t, r in tsr if r], [t for t, r in tsr if not r]
+        extra.append({"workload": "3D 3-level AMR, base 256^3, visc_coef = 0.001, the grids rebuilt every second step (regrid_int = 2 as exec/test/inputs_3d-regt: tag_boxes + make_new_grids + "
+                                  "fillpatch of the new levels inside the timed steps); %s boxes per level at the end" % boxes_r,
+                      "cells": int(cells_r / XS), "steps": XS, "warmup": 1, "ms_per_step": round(1e3 * elr / XS, 3), "value": round(cells_r / elr, 1), "unit": "cells*steps/s",
+                      "ms_per_step_with_a_regrid": round(1e3 * sum(t_reg) / max(1, len(t_reg)), 1), "ms_per_step_without": round(1e3 * sum(t_plain) / max(1, len(t_plain)), 1),
+                      "regrids": len(t_reg), "wall_s_incl_setup": round(time.perf_counter() - tb, 1)})
 
     # ---- roofline of the dominant kernel: one colour pass of the MAC-MG smoother at 256^3 ----------
     roof = None

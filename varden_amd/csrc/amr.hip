@@ -481,7 +481,7 @@ struct ResArgs { double hi2[3]; int lo[3], hi[3], e[3][2]; };
 // viscsolve.f90:58-60): the constant itself, no coefficient read at all -- the same bits again (the arrays hold exactly mu)
 #define MLCC_FACE_COEFFS(a, i, j, k)                                                                                                                 \
   double bxm, bxp, bym, byp, bzm, bzp;                                                                                                               \
-  if (a.use_rho == 2) { bxm = bxp = bym = byp = bzm = bzp = a.cmu; }                                                                                 \
+  if (a.use_rho == 2) { bxm = bxp = bym = byp = bzm = bzp = *a.cmu_p; }                                                                               \
   else if (a.use_rho) {                                                                                                                               \
     const double r0_ = fv_get(a.rho, i, j, k);                                                                                                       \
     bxm = 2.0 / (r0_ + fv_get(a.rho, i - 1, j, k)); bxp = 2.0 / (fv_get(a.rho, i + 1, j, k) + r0_);                                                  \
@@ -491,7 +491,7 @@ struct ResArgs { double hi2[3]; int lo[3], hi[3], e[3][2]; };
     bxm = fv_get(a.bx, i, j, k); bxp = fv_get(a.bx, i + 1, j, k); bym = fv_get(a.by, i, j, k); byp = fv_get(a.by, i, j + 1, k);                     \
     bzm = fv_get(a.bz, i, j, k); bzp = fv_get(a.bz, i, j, k + 1);                                                                                    \
   }
-struct ResidualB { Range3 r; int g[3]; static constexpr int planes_per_wg = 8; FV rh, phi, bx, by, bz, res, alpha, e, rho; int has_alpha, fuse, use_rho; double cmu; ResArgs A;
+struct ResidualB { Range3 r; int g[3]; static constexpr int planes_per_wg = 8; FV rh, phi, bx, by, bz, res, alpha, e, rho; int has_alpha, fuse, use_rho; const double *cmu_p; ResArgs A;
   static __device__ double body(const ResidualB &a, int i, int j, int k, int) {
     const FV &phi = a.phi;
     const double p0 = fv_get(phi, i, j, k);
@@ -551,10 +551,11 @@ struct RefluxB { Range3 r; int g[3]; FV res_c, phi_c, beta_c, mask, phi_f, beta_
     return 0.0;
   } };
 struct GsArgs { int lo[3], hi[3]; int e[3][2]; double hi2[3]; };
+__global__ void k_set1(double *p, double v) { *p = v; }
 // red-black Gauss-Seidel on the fabs of a level: ghost cells of e are 0 at the coarse-fine interface and at Dirichlet faces
 // (b := 2b), Neumann faces carry b := 0 -- the folding of mg_cc.hip applied on the fly; colour by global index.
 // r: lo[0] .. lo[0] + ceil(nx/2) - 1 along x (half the cells of a row), the colour picks which half
-struct GsrbB { Range3 r; int g[3]; FV e, rh, bx, by, bz, alpha, rho; int has_alpha, use_rho; double cmu; GsArgs A;
+struct GsrbB { Range3 r; int g[3]; FV e, rh, bx, by, bz, alpha, rho; int has_alpha, use_rho; const double *cmu_p; GsArgs A;
   static __device__ double body(const GsrbB &a, int ih, int j, int k, int color) {
     const GsArgs &A = a.A; const FV &e = a.e;
     const int i = A.lo[0] + 2 * (ih - A.lo[0]) + ((A.lo[0] + j + k + color) & 1);
@@ -617,7 +618,7 @@ static double read_dev(double *d) { return read_scalar1(d); }
 // descriptor sets are built once per solve: the fields of a solve do not move
 struct MLCC { int nlev; vdn_layout *la; bool fuse_first = false;   /* the finest level's residual pass also writes the first colour pass of its relaxation (ResidualB) */
               vdn_multifab **rh, **phi, **beta, **alpha; vdn_multifab *res[VDN_MAXLEV], *e[VDN_MAXLEV], *t[VDN_MAXLEV], *mask[VDN_MAXLEV];   // t[n] = res[n] - A_n e[n] (levels >= 1)
-              const double *dx; const vdn_bc_tower *bct; int bcc; double *d_nrm; double cmu = 0.0; /* > 0: every face coefficient of every level is this constant */ const vdn_multifab *fine_rho = nullptr;   // the finest level's density when its face coefficients are mk_mac_coeffs of it
+              const double *dx; const vdn_bc_tower *bct; int bcc; double *d_nrm; double cmu = 0.0; double *d_cmu = nullptr; /* cmu > 0: every face coefficient of every level is this constant, read from *d_cmu (it changes with dt: the kept sets do not) */ const vdn_multifab *fine_rho = nullptr;   // the finest level's density when its face coefficients are mk_mac_coeffs of it
               BatchSet<ClosureB> closure[VDN_MAXLEV]; BatchSet<CfB> cf[VDN_MAXLEV]; BatchSet<ResidualB> resid[VDN_MAXLEV];
               BatchSet<RefluxB> reflux[VDN_MAXLEV][6];          // [fine level][d*2+s]: one launch per side so that a coarse cell is updated once per launch
               BatchSet<AbsmaxB> absmax[VDN_MAXLEV]; BatchSet<GsrbB> gsrb[VDN_MAXLEV]; BatchSet<AddB> add[VDN_MAXLEV];
@@ -654,6 +655,8 @@ static bool face_is_interior(const vdn_layout *la, int lev, const vdn_box &b, in
   return s ? b.hi[d] != la->pd[lev].hi[d] : b.lo[d] != la->pd[lev].lo[d];
 }
 static void mlcc_build_sets(MLCC &S) {
+  Prof prof_("mlcc_build_sets");
+  S.d_cmu = (double *)set_alloc(256);
   hipStream_t st = ctx().stream;
   const int L = S.nlev;
   for (int n = 0; n < L; n++) {
@@ -707,14 +710,14 @@ static void mlcc_build_sets(MLCC &S) {
       q.res = S.res[n]->fabs[b]; for (int d = 0; d < 3; d++) q.A.hi2[d] = 1.0 / (S.dx[3 * n + d] * S.dx[3 * n + d]);
       q.has_alpha = S.alpha ? 1 : 0; q.alpha = S.alpha ? S.alpha[n]->fabs[b] : q.rh;
       q.use_rho = (S.fine_rho && n == L - 1) ? 1 : 0; q.rho = q.use_rho ? S.fine_rho->fabs[b] : q.rh;
-      q.cmu = S.cmu; if (S.cmu > 0.0) q.use_rho = 2;
+      q.cmu_p = S.d_cmu; if (S.cmu > 0.0) q.use_rho = 2;
       q.fuse = (S.fuse_first && n == L - 1) ? 1 : 0; q.e = n >= 1 ? S.e[n]->fabs[b] : q.res;
       for (int d = 0; d < 3; d++) { q.A.lo[d] = r.lo[d]; q.A.hi[d] = r.hi[d]; for (int sd = 0; sd < 2; sd++) q.A.e[d][sd] = S.bct->ell_bc(n, b + 1, d, sd, S.bcc); }
       vr.push_back(q);
       if (n >= 1) { ResidualB qe = q; qe.rh = S.res[n]->fabs[b]; qe.phi = S.e[n]->fabs[b]; qe.res = S.t[n]->fabs[b]; qe.fuse = 0; vre.push_back(qe); }
       if (n < L - 1) { AbsmaxB m; m.r = r; m.a = S.res[n]->fabs[b]; m.mask = S.mask[n]->fabs[b]; m.has_mask = 1; va.push_back(m); }
       if (n >= 1) {
-        GsrbB gq; gq.e = S.e[n]->fabs[b]; gq.rh = S.res[n]->fabs[b]; gq.bx = q.bx; gq.by = q.by; gq.bz = q.bz; gq.has_alpha = q.has_alpha; gq.alpha = q.alpha; gq.use_rho = q.use_rho; gq.rho = q.rho; gq.cmu = q.cmu;
+        GsrbB gq; gq.e = S.e[n]->fabs[b]; gq.rh = S.res[n]->fabs[b]; gq.bx = q.bx; gq.by = q.by; gq.bz = q.bz; gq.has_alpha = q.has_alpha; gq.alpha = q.alpha; gq.use_rho = q.use_rho; gq.rho = q.rho; gq.cmu_p = q.cmu_p;
         for (int d = 0; d < 3; d++) { gq.A.lo[d] = r.lo[d]; gq.A.hi[d] = r.hi[d]; gq.A.hi2[d] = q.A.hi2[d]; for (int sd = 0; sd < 2; sd++) gq.A.e[d][sd] = S.bct->ell_bc(n, b + 1, d, sd, S.bcc); }
         gq.r = r; gq.r.hi[0] = r.lo[0] + (r.hi[0] - r.lo[0] + 2) / 2 - 1;
         vg.push_back(gq);
@@ -853,7 +856,7 @@ int ml_cc_solve(vdn_layout *la, vdn_multifab **rh, vdn_multifab **phi, vdn_multi
   const vdn_multifab *frho = (rho_form && !alpha) ? fine_rho : nullptr;
   if (frho) REQUIRE(frho->ng >= 1 && frho->lev == L - 1, "composite solve: the finest level's density with a filled ghost cell expected");
   // everything the descriptor sets of this solve follow from: the key of the kept ones (vdn_internal.h)
-  GraphKey key; key.put(0x7301); key.put(la->uid); key.put(L); key.put(bct->serial); key.put(bc_comp0); key.put(fuse_first); key.put((const void *)(frho ? frho->base : nullptr)); key.put(const_beta);
+  GraphKey key; key.put(0x7301); key.put(la->uid); key.put(L); key.put(bct->serial); key.put(bc_comp0); key.put(fuse_first); key.put((const void *)(frho ? frho->base : nullptr)); key.put(rho_form && const_beta > 0.0);
   for (int n = 0; n < L; n++) {
     key_mf(key, rh[n]); key_mf(key, phi[n]); for (int d = 0; d < 3; d++) { key_mf(key, beta[3 * n + d]); key.put(dx[3 * n + d]); }
     key.put(alpha != nullptr); if (alpha) key_mf(key, alpha[n]);
@@ -914,6 +917,7 @@ int ml_cc_solve(vdn_layout *la, vdn_multifab **rh, vdn_multifab **phi, vdn_multi
     if (kept) keeper_end();
   } else
     for (int n = 1; n < L; n++) for (int d = 0; d < 3; d++) S.vf_beta[n][d].refresh();      // (the coefficients change from solve to solve: the windows of remote boxes)
+  if (S.cmu > 0.0) hipLaunchKernelGGL(k_set1, dim3(1), dim3(1), 0, st, S.d_cmu, S.cmu);
   HIPCHK(hipMemsetAsync(S.d_nrm, 0, sizeof(double), st));
   for (int n = 0; n < L; n++) {
     GraphKey k2 = key; k2.put(0x13); k2.put(n);

@@ -273,6 +273,7 @@ unsigned long xplan_serial(const XPlan *P) { return P ? P->serial : 0; }
 // faces_only: only the ghost cells that lie outside the valid box in exactly ONE direction are filled (what a 7-point operator reads): with a
 // 2 x 2 x 2 decomposition a rank then exchanges with its three face neighbours instead of seven peers per colour pass
 XPlan *xplan_build(const std::vector<XBoxInfo> &boxes, const vdn_box &pd, const int pmask[3], int ng, int nc, bool faces_only) {
+  Prof prof_("xplan_build");
   static unsigned long next_serial = 0;
   XPlan *P = new XPlan; P->nc = nc; P->serial = ++next_serial;
   const int me = ctx().rank;
@@ -283,11 +284,25 @@ XPlan *xplan_build(const std::vector<XBoxInfo> &boxes, const vdn_box &pd, const 
   for (int d = 0; d < 3; d++) { per[d] = pd.hi[d] - pd.lo[d] + 1; nshift[d] = pmask[d] ? 1 : 0; }
   std::map<int, Peer> peers;
   const int nb = (int)boxes.size();
+  std::vector<vdn_box> vb(nb);
+  for (int i = 0; i < nb; i++) for (int d = 0; d < 3; d++) { vb[i].lo[d] = boxes[i].vlo[d]; vb[i].hi[d] = boxes[i].vhi[d]; }
+  const BoxBins bins(vb);
+  std::vector<int> cand;
   for (int i = 0; i < nb; i++) {
     const XBoxInfo &B = boxes[i];
     int glo[3], ghi[3];
     for (int d = 0; d < 3; d++) { glo[d] = B.vlo[d] - ng; ghi[d] = B.vhi[d] + ng; }
-    for (int j = 0; j < nb; j++) {
+    // the boxes whose valid range, shifted by a period or not, can reach B's grown box: from the bins, in ascending order -- the pairs and their order are those of
+    // the loop over all j (a level of a thousand boxes: 51 plans after a regrid took 140 ms of pair tests, profiles/r06_regrid_cost.txt)
+    cand.clear();
+    for (int sz = -nshift[2]; sz <= nshift[2]; sz++) for (int sy = -nshift[1]; sy <= nshift[1]; sy++) for (int sx = -nshift[0]; sx <= nshift[0]; sx++) {
+      const int sh[3] = { sx * per[0], sy * per[1], sz * per[2] };
+      int qlo[3], qhi[3]; for (int d = 0; d < 3; d++) { qlo[d] = glo[d] - sh[d]; qhi[d] = ghi[d] - sh[d]; }
+      const std::vector<int> &c = bins.near(qlo, qhi, 0);
+      cand.insert(cand.end(), c.begin(), c.end());
+    }
+    if (nshift[0] || nshift[1] || nshift[2]) { std::sort(cand.begin(), cand.end()); cand.erase(std::unique(cand.begin(), cand.end()), cand.end()); }
+    for (int j : cand) {
       const XBoxInfo &S = boxes[j];
       if (B.owner != me && S.owner != me) continue;
       for (int sz = -nshift[2]; sz <= nshift[2]; sz++) for (int sy = -nshift[1]; sy <= nshift[1]; sy++) for (int sx = -nshift[0]; sx <= nshift[0]; sx++) {
@@ -340,10 +355,9 @@ XPlan *xplan_build(const std::vector<XBoxInfo> &boxes, const vdn_box &pd, const 
       }
     }
   }
-  hipStream_t st = ctx().stream;
   if (!P->local.empty()) {
     HIPCHK(hipMalloc((void **)&P->d_local, P->local.size() * sizeof(CopyDesc)));
-    HIPCHK(hipMemcpyAsync(P->d_local, P->local.data(), P->local.size() * sizeof(CopyDesc), hipMemcpyHostToDevice, st));
+    upload_staged(P->d_local, P->local.data(), P->local.size() * sizeof(CopyDesc));
     std::vector<int> lstart(P->local.size());
     for (size_t q = 0; q < P->local.size(); q++) {
       const CopyDesc &D = P->local[q];
@@ -352,15 +366,15 @@ XPlan *xplan_build(const std::vector<XBoxInfo> &boxes, const vdn_box &pd, const 
       lstart[q] = P->lchunks; P->lchunks += (int)((tot + XCOPY_CHUNK - 1) / XCOPY_CHUNK);
     }
     HIPCHK(hipMalloc((void **)&P->d_lstart, lstart.size() * sizeof(int)));
-    HIPCHK(hipMemcpy(P->d_lstart, lstart.data(), lstart.size() * sizeof(int), hipMemcpyHostToDevice));
+    upload_staged(P->d_lstart, lstart.data(), lstart.size() * sizeof(int));
   }
   for (auto &kv : peers) {
     Peer pr = kv.second;
     if (!pr.pack.empty()) { HIPCHK(hipMalloc((void **)&pr.d_pack, pr.pack.size() * sizeof(PackDesc)));
-      HIPCHK(hipMemcpyAsync(pr.d_pack, pr.pack.data(), pr.pack.size() * sizeof(PackDesc), hipMemcpyHostToDevice, st));
+      upload_staged(pr.d_pack, pr.pack.data(), pr.pack.size() * sizeof(PackDesc));
       HIPCHK(hipMalloc((void **)&pr.d_send, pr.nsend * sizeof(double))); }
     if (!pr.unpack.empty()) { HIPCHK(hipMalloc((void **)&pr.d_unpack, pr.unpack.size() * sizeof(PackDesc)));
-      HIPCHK(hipMemcpyAsync(pr.d_unpack, pr.unpack.data(), pr.unpack.size() * sizeof(PackDesc), hipMemcpyHostToDevice, st));
+      upload_staged(pr.d_unpack, pr.unpack.data(), pr.unpack.size() * sizeof(PackDesc));
       HIPCHK(hipMalloc((void **)&pr.d_recv, pr.nrecv * sizeof(double))); }
     P->peers.push_back(pr);
   }
@@ -371,10 +385,11 @@ XPlan *xplan_build(const std::vector<XBoxInfo> &boxes, const vdn_box &pd, const 
       for (PackDesc D : pr.unpack) { D.buf = pr.d_recv; au.push_back(D); }
     }
     P->npack_all = (int)ap.size(); P->nunpack_all = (int)au.size();
-    if (!ap.empty()) { HIPCHK(hipMalloc((void **)&P->d_pack_all, ap.size() * sizeof(PackDesc))); HIPCHK(hipMemcpy(P->d_pack_all, ap.data(), ap.size() * sizeof(PackDesc), hipMemcpyHostToDevice)); }
-    if (!au.empty()) { HIPCHK(hipMalloc((void **)&P->d_unpack_all, au.size() * sizeof(PackDesc))); HIPCHK(hipMemcpy(P->d_unpack_all, au.data(), au.size() * sizeof(PackDesc), hipMemcpyHostToDevice)); }
+    if (!ap.empty()) { HIPCHK(hipMalloc((void **)&P->d_pack_all, ap.size() * sizeof(PackDesc))); upload_staged(P->d_pack_all, ap.data(), ap.size() * sizeof(PackDesc)); }
+    if (!au.empty()) { HIPCHK(hipMalloc((void **)&P->d_unpack_all, au.size() * sizeof(PackDesc))); upload_staged(P->d_unpack_all, au.data(), au.size() * sizeof(PackDesc)); }
   }
-  HIPCHK(hipStreamSynchronize(st));
+  // (no synchronisation: the uploads went through the pinned ring, asynchronous on the launch stream that every user of the plan is ordered after --
+  // a regrid builds some fifty plans, and each used to drain the stream)
   return P;
 }
 

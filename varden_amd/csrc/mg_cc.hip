@@ -1297,6 +1297,7 @@ int mg_agglom(const vdn_layout *la, int lev) {
 }
 
 static void cc_build(CCMG &M, const vdn_multifab *rh, const double *dx, const int bc[3][2], bool has_alpha) {
+  Prof prof_("cc_build");
   const vdn_layout *la = rh->la; const int lev = rh->lev;
   const auto &gboxes = la->boxes[lev];
   const int nb = (int)gboxes.size();

@@ -1037,6 +1037,7 @@ static FV nd_view(const NLev &L, double *p, const int lo[3], int extra /* 3 for 
 }
 
 static void nd_build(NDMG &M, const vdn_multifab *coeffs, const double *dx, const int bc[3][2]) {
+  Prof prof_("nd_build");
   const vdn_layout *la = coeffs->la; const int lev = coeffs->lev;
   const auto &gboxes = la->boxes[lev];
   const int nb = (int)gboxes.size();
