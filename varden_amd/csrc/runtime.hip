@@ -85,23 +85,25 @@ static void arena_destroy() {
 // The fields of the state (vdn_multifab_create) come the same way: an address range per field, backed by 64 MB chunks of physical memory that go back to a POOL
 // when the field is destroyed, not to the driver.  A regrid frees and creates some 36 GB-sized fields of slightly different sizes; memory that comes back from the
 // driver costs about 10 ms per GB on this card (hipMalloc and hipMemCreate alike -- 360 ms of a regrid, tools/probes/regrid_profile_probe.py), chunks from
-// the pool cost the mapping calls, some 10 us each.  Fields below 32 MB are plain hipMalloc blocks (a chunk each would waste the card on the small cases).
+// the pool cost the mapping calls, some 10 us each.  Fields below 32 MB are plain hipMalloc blocks (a chunk each would waste the card on the small cases), and so are
+// the fields of a ONE-level layout, which are created once: the one-box 512^3 step runs 3 % slower on chunk-backed fields than on hipMalloc blocks (7 % on 1 GB chunks;
+// a per-field offset into the chunk did not change that: profiles/r06_allocator_ab.txt) -- the boxes of a hierarchy are small and show no difference.
 static size_t field_chunk() { static const size_t v = env_mb("VDN_FIELD_CHUNK_MB", 64); return v; }
 static size_t field_small() { static const size_t v = vdn_env("VDN_FIELD_VMM") && atoi(vdn_env("VDN_FIELD_VMM")) == 0 ? ~(size_t)0 : (size_t)32 << 20; return v; }
 #define FIELD_CHUNK field_chunk()
 #define FIELD_SMALL field_small()
-struct FieldAlloc { size_t va_bytes; std::vector<hipMemGenericAllocationHandle_t> chunks; };
+struct FieldAlloc { void *va; size_t va_bytes; std::vector<hipMemGenericAllocationHandle_t> chunks; };
 static std::map<void *, FieldAlloc> g_field_allocs;
 static std::vector<hipMemGenericAllocationHandle_t> g_chunk_pool;
-static void *field_alloc(size_t bytes) {
+static void *field_alloc(size_t bytes, bool pooled) {
   VdnCtx &c = g_ctx;
-  if (bytes < FIELD_SMALL) { void *q = nullptr; HIPCHK(hipMalloc(&q, bytes)); return q; }
+  if (!pooled || bytes < FIELD_SMALL) { void *q = nullptr; HIPCHK(hipMalloc(&q, bytes)); return q; }
   const size_t n = (bytes + FIELD_CHUNK - 1) / FIELD_CHUNK, sz = n * FIELD_CHUNK;
   hipMemAllocationProp prop = {}; prop.type = hipMemAllocationTypePinned; prop.location.type = hipMemLocationTypeDevice; prop.location.id = c.device;
   hipMemAccessDesc acc = {}; acc.location.type = hipMemLocationTypeDevice; acc.location.id = c.device; acc.flags = hipMemAccessFlagsProtReadWrite;
   void *p = nullptr;
   HIPCHK(hipMemAddressReserve(&p, sz, (size_t)2 << 20, nullptr, 0));
-  FieldAlloc A; A.va_bytes = sz;
+  FieldAlloc A; A.va = p; A.va_bytes = sz;
   hipError_t e = hipSuccess;
   for (size_t i = 0; i < n && e == hipSuccess; i++) {
     hipMemGenericAllocationHandle_t h;
@@ -124,9 +126,9 @@ static void *field_alloc(size_t bytes) {
 static void field_free(void *p) {
   auto it = g_field_allocs.find(p);
   if (it == g_field_allocs.end()) { HIPCHK(hipFree(p)); return; }      // (a small field)
-  HIPCHK(hipMemUnmap(p, it->second.va_bytes));
+  HIPCHK(hipMemUnmap(it->second.va, it->second.va_bytes));
   for (auto h : it->second.chunks) g_chunk_pool.push_back(h);
-  HIPCHK(hipMemAddressFree(p, it->second.va_bytes));
+  HIPCHK(hipMemAddressFree(it->second.va, it->second.va_bytes));
   g_field_allocs.erase(it);
 }
 static void field_pool_release() { for (auto h : g_chunk_pool) (void)hipMemRelease(h); g_chunk_pool.clear(); }
@@ -658,7 +660,7 @@ extern "C" int vdn_multifab_create(const vdn_layout *la, int lev, int nc, int ng
   for (int d = 0; d < 3; d++) mf->nodal[d] = nodal ? (nodal[d] != 0) : 0;
   size_t tot; mf_layout_fabs(mf, &tot);
   mf->bytes = std::max<size_t>(tot, 1) * sizeof(double);
-  mf->base = (double *)field_alloc(mf->bytes);
+  mf->base = (double *)field_alloc(mf->bytes, la->nlev > 1);
   for (auto &f : mf->fabs) f.p = (double *)((char *)mf->base + (uintptr_t)f.p);
   HIPCHK(hipMemsetAsync(mf->base, 0, mf->bytes, g_ctx.stream));
   *out = mf;
