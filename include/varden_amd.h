@@ -128,7 +128,8 @@ int  vdn_last_stale_hip_error(int clear);
  * on s; nothing is drained for it); vdn_set_stream(NULL) returns to the private stream. */
 int  vdn_set_stream(void *hip_stream);
 int  vdn_device_synchronize(void);
-/* arena of per-step temporaries (the multifabs advance_timestep.f90:65-80 allocates and frees every step): bytes reserved, high-water mark */
+/* arena of per-step temporaries (the multifabs advance_timestep.f90:65-80 allocates and frees every step): bytes backed by device memory (1 GB chunks mapped
+ * into a reserved address range as the high-water mark moves), high-water mark */
 int  vdn_arena_stats(size_t *reserved_bytes, size_t *peak_bytes);
 int  vdn_get_params(vdn_params *out);
 
