@@ -524,6 +524,37 @@ def test_tagged_hierarchy_against_the_box_list_oracle(gpu, oracle, nc, max_levs,
     G.close()
 
 
+def test_regridding_keeps_its_memory_and_its_addresses(gpu):
+    """round 6: the arena of per-step temporaries is an address range reserved once with physical chunks mapped on demand, the fields of a hierarchy sit on pooled chunks
+    (runtime.hip: arena_map_to, field_alloc) -- until then a regrid whose layout wanted a larger arena freed and allocated 120 GB (3-7 s) and every regrid returned the
+    fields' memory to the driver.  A 128^3 base with three levels, viscous, regrid_int = 2, twelve steps (six regrids, the field sizes change every time): the memory
+    backing the arena stops growing after the first steps, the device memory in use settles (no chunk leaks from the pool, no plan or descriptor set outlives its layout)
+    and the run stays finite and converged."""
+    import ctypes as C
+    import torch
+    from varden_amd import advance as adv, capi, driver
+    from varden_amd.capi import default_params
+    prm = default_params(cflfac=0.9, visc_coef=0.001)
+    nc = 128
+    levels = driver.VardenAMR.tagged_grids(nc, WALLS, prm, max_levs=3, max_grid_size=64)
+    G = driver.VardenAMR(nc, levels[0], WALLS, params=prm, finer_levels=levels[1:], init_shrink=0.1, init_iter=1, do_initial_projection=1, regrid_int=2, max_levs=3, max_grid_size=64)
+    hist = []
+    for s in range(12):
+        G.step()
+        torch.cuda.synchronize()
+        free, total = torch.cuda.mem_get_info()
+        rb, pk = C.c_size_t(), C.c_size_t()
+        capi.load().vdn_arena_stats(C.byref(rb), C.byref(pk))
+        hist.append((total - free, rb.value, pk.value))
+        assert adv.last_solver_stats("mac")[2] <= 1e-10 * adv.last_solver_stats("mac")[1]
+    assert G.nregrids == 6
+    assert hist[-1][1] == hist[3][1], "the arena kept growing: %r" % [h[1] >> 20 for h in hist]
+    assert hist[-1][1] - hist[-1][2] <= (1 << 30), "more than one chunk mapped beyond the high-water mark"
+    assert hist[-1][0] <= hist[5][0] + (256 << 20), "device memory in use grew over the last six steps (three regrids): %r MB" % [h[0] >> 20 for h in hist]
+    assert all(np.isfinite(G.uold[n].to_numpy(0)).all() for n in range(G.nlev))
+    G.close()
+
+
 def test_regridding_run_against_the_box_list_oracle(gpu, oracle):
     """the time loop WITH regridding (src/varden.f90:256-264, src/regrid.f90: tag_boxes + make_new_grids every regrid_int steps, fillpatch,
     ml_nodal_prolongation, copies between the old and the new box lists) on both sides: three levels on a 32^3 base, regrid_int = 2, six steps (three
