@@ -131,6 +131,11 @@ int  vdn_device_synchronize(void);
 /* arena of per-step temporaries (the multifabs advance_timestep.f90:65-80 allocates and frees every step): bytes backed by device memory (1 GB chunks mapped
  * into a reserved address range as the high-water mark moves), high-water mark */
 int  vdn_arena_stats(size_t *reserved_bytes, size_t *peak_bytes);
+/* A 2-D problem run as its z-uniform, z-periodic 3-D copy (the hierarchies of the reference's 2-D inputs: varden_amd/driver.py, VardenAMR(extrude2d = nz)): with
+ * w = 0 and nothing varying along z the 3-D scheme IS the 2-D one -- velpred_3d / mkflux_3d reduce to velpred_2d / mkflux_2d, the 7-point and 27-point operators to
+ * the 5-point and 9-point ones -- except where the reference's two restatements differ: velpred_3d clamps the normal velocity of a hi-x OUTLET face with min()
+ * (src/velpred.f90:2075), velpred_2d with max() (:305).  on != 0 selects velpred_2d's rule in the 3-D kernels.  Default 0; reset by vdn_init. */
+int  vdn_set_extruded_2d(int on);
 int  vdn_get_params(vdn_params *out);
 
 /* ------------------------------------------------------------------------------------------- */

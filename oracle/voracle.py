@@ -281,14 +281,16 @@ class SimML:
     boxes: per refined level either ONE box (lo, hi) or a LIST of boxes [(lo, hi), ...], in the level's own index space.  The fields of a level are
     level arrays over the bounding box of its boxes (oracle/vo.h); `levels[n].mask()` marks the cells that belong to the level."""
 
-    def __init__(self, nc, boxes, phys, prm=None, prob_type=1, grav=-9.8, init_shrink=0.1, init_iter=0, do_initial_projection=0, base_boxes=None, init_fn=None):
-        """base_boxes: level 0 cut into boxes (what max_grid_size makes of it); default: one box.
+    def __init__(self, nc, boxes, phys, prm=None, prob_type=1, grav=-9.8, init_shrink=0.1, init_iter=0, do_initial_projection=0, base_boxes=None, init_fn=None, grav_dir=2):
+        """nc: cells of level 0 per direction, an int (a cube) or three ints (dx = dy = dz = 1 / nc[0]: the z-uniform copies of 2-D problems, varden_amd/driver.py: extrude2d;
+        grav_dir = 1 puts gravity along y there).  base_boxes: level 0 cut into boxes (what max_grid_size makes of it); default: one box.
         init_fn(level, lo, shape, dx) -> (u, s) with 3 ghost layers over the level array replaces the analytic initial data (as varden_amd/driver.py: VardenAMR)"""
         L = lib()
         self.prm = prm or default_params()
         self.prm.prob_type = prob_type
-        self.nc, self.phys, self.grav = nc, phys, grav
-        self.base_boxes = [((0, 0, 0), (nc - 1,) * 3)] if base_boxes is None else [(tuple(b[0]), tuple(b[1])) for b in base_boxes]
+        self.nc, self.phys, self.grav, self.grav_dir = nc, phys, grav, int(grav_dir)
+        self.ncs = tuple(int(x) for x in nc) if hasattr(nc, "__len__") else (int(nc),) * 3
+        self.base_boxes = [((0, 0, 0), tuple(c - 1 for c in self.ncs))] if base_boxes is None else [(tuple(b[0]), tuple(b[1])) for b in base_boxes]
         self._set_grids(boxes)
         NL, ns = self.nlev, self.prm.nscal
         los, his = [lv.lo for lv in self.levels], [lv.hi for lv in self.levels]
@@ -322,7 +324,7 @@ class SimML:
 
     def _set_grids(self, boxes):
         """the box lists of the refined levels -> levels, bc tables, domains, spacings"""
-        nc, phys, ns = self.nc, self.phys, self.prm.nscal
+        ncs, phys, ns = self.ncs, self.phys, self.prm.nscal
         self.nlev = NL = 1 + len(boxes)
         blists = [list(self.base_boxes)]
         for b in boxes:
@@ -330,12 +332,12 @@ class SimML:
         self.levels = [Level(bl_) for bl_ in blists]
         self.lev = level_ptr_array(self.levels)
         los, his = [lv.lo for lv in self.levels], [lv.hi for lv in self.levels]
-        bcl, pd, self.dxl = [make_bc(phys, 3, ns)], [0, 0, 0, nc - 1, nc - 1, nc - 1], [[1.0 / nc] * 3]
+        bcl, pd, self.dxl = [make_bc(phys, 3, ns)], [0, 0, 0, ncs[0] - 1, ncs[1] - 1, ncs[2] - 1], [[1.0 / ncs[0]] * 3]
         for n in range(1, NL):
-            nd = nc << n
-            bcl.append(make_bc([[phys[d][0] if los[n][d] == 0 else INTERIOR, phys[d][1] if his[n][d] == nd - 1 else INTERIOR] for d in range(3)], 3, ns))
-            pd += [0, 0, 0, nd - 1, nd - 1, nd - 1]
-            self.dxl.append([1.0 / nd] * 3)
+            nd = [c << n for c in ncs]
+            bcl.append(make_bc([[phys[d][0] if los[n][d] == 0 else INTERIOR, phys[d][1] if his[n][d] == nd[d] - 1 else INTERIOR] for d in range(3)], 3, ns))
+            pd += [0, 0, 0, nd[0] - 1, nd[1] - 1, nd[2] - 1]
+            self.dxl.append([1.0 / nd[0]] * 3)
         self.bcs = (CBc * NL)(*bcl)
         self.pmask = ivec([1 if phys[d][0] == PERIODIC else 0 for d in range(3)])      # (round 6: level 0 wraps; refined levels must stay clear of the periodic faces)
         self.pd = ivec(pd)
@@ -349,7 +351,7 @@ class SimML:
         self.unew, self.snew = self._mk(3, 3), self._mk(3, ns)
         self.ext_vel_force, self.ext_scal_force = self._mk(1, 3), self._mk(1, ns)
         for n in range(self.nlev):
-            self.ext_vel_force[n].a[..., 2] = self.grav
+            self.ext_vel_force[n].a[..., self.grav_dir] = self.grav
 
     def node_mask(self, n):
         """nodes of level n's array that a cell of the level touches"""

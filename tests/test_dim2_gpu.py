@@ -181,3 +181,144 @@ def test_config0_bubble_128(gpu):
     assert np.abs(u[..., 0] + u[::-1, :, 0]).max() <= 1e-9 * np.abs(u).max()
     assert adv.last_solver_stats("mac")[0] < 30 and adv.last_solver_stats("hg")[0] < 40
     G.close()
+
+
+# ---- 2-D hierarchies: the 2-D problem run as its z-uniform copy on the 3-D machinery (round 6; driver.VardenAMR: extrude2d, include/varden_amd.h: vdn_set_extruded_2d) -----------
+def _prm_pair(bc, **kw):
+    from varden_amd.capi import default_params
+    out = []
+    for dm in (2, 3):
+        p = default_params(dm=dm, cflfac=0.9, **kw) if dm == 2 else default_params(cflfac=0.9, **kw)
+        for d in range(2):
+            for s in range(2):
+                if bc[d][s] == 11:
+                    [p.u_bc, p.v_bc][d][d][s] = 1.0 if s == 0 else -1.0
+                    p.rho_bc[d][s] = 1.0
+                    p.trac_bc[d][s] = 0.5
+        out.append(p)
+    return out
+
+
+@pytest.mark.parametrize("name,bc,prob,visc", [("bubble-walls", [[15, 15], [15, 15]], 1, 0.0), ("bubble-periodic-x-viscous", [[-1, -1], [15, 15]], 1, 0.001),
+                                                ("blob-inflow-outflow-walls", [[11, 12], [15, 15]], 2, 0.001), ("blob-inflow-outflow-slip", [[11, 12], [14, 14]], 2, 0.0),
+                                                ("outflow-both-x", [[12, 12], [15, 15]], 2, 0.0), ("outflow-y", [[15, 15], [12, 12]], 2, 0.0),
+                                                ("rayleigh-taylor-periodic-x", [[-1, -1], [15, 15]], 3, 0.01)])
+def test_extruded_copy_reproduces_the_2d_path(gpu, name, bc, prob, visc):
+    """The basis of the 2-D hierarchies: a 2-D run (dim2.hip: velpred_2d / mkflux_2d, 5- and 9-point solvers, checked against oracle/vo_2d.c above) against the SAME data
+    extruded along a periodic z -- n x n x nz cells, w = 0, gravity along y -- through the 3-D kernels: with nothing varying along z every 3-D operator is its 2-D
+    counterpart (the red-black order and the solvers' tolerances leave 1e-13).  The one place where the reference's two restatements differ -- velpred_3d clamps the normal
+    velocity of a hi-x OUTLET with min(), velpred.f90:2075, velpred_2d with max(), :305 -- takes the 2-D rule (vdn_set_extruded_2d); without it the outflow corners differ by
+    5e-4 after four steps (tools/probes/extruded2d_inout_probe.py).  Every boundary pair of the four 2-D inputs of exec/test, four steps after the start-up sequence: dt bit for
+    bit or to 1e-12, u, rho, tracer and grad p of plane k = 0 to 1e-10 of their scale, |w| and the spread over z below 1e-10."""
+    from varden_amd import driver
+    n, nz, nsteps = 32, 8, 4
+    p2, p3 = _prm_pair(bc, visc_coef=visc)
+    kw = dict(prob_type=prob, init_shrink=0.1, init_iter=1)
+    G2 = driver.Varden(n, [bc[0], bc[1], [0, 0]], p2, **kw)
+    for _ in range(nsteps):
+        G2.step()
+    u2, s2, g2, dt2 = G2.gather_valid(G2.uold[0])[:, :, 0, :], G2.gather_valid(G2.sold[0])[:, :, 0, :], G2.gather_valid(G2.gp[0])[:, :, 0, :], G2.dt
+    G2.close()
+    u0_2, s0_2 = driver.initdata_numpy((n, n), [1.0 / n] * 2, prob, 3, 2, dm=2)
+    u0 = np.zeros((n + 6, n + 6, nz + 6, 3), order="F")
+    s0 = np.zeros((n + 6, n + 6, nz + 6, 2), order="F")
+    u0[..., :2] = u0_2[:, :, 0, None, :]
+    s0[...] = s0_2[:, :, 0, None, :]
+    G3 = driver.Varden((n, n, nz), [bc[0], bc[1], [-1, -1]], p3, prob_hi=(1.0, 1.0, nz / float(n)), u0=u0, s0=s0, grav_dir=1, extruded2d=True, **kw)
+    for _ in range(nsteps):
+        G3.step()
+    u3, s3, g3 = G3.gather_valid(G3.uold[0]), G3.gather_valid(G3.sold[0]), G3.gather_valid(G3.gp[0])
+    assert abs(G3.dt - dt2) <= 1e-12 * dt2
+    G3.close()
+    su, sg = max(np.abs(u2).max(), 1e-3), max(np.abs(g2).max(), 1e-3)
+    assert np.abs(u3[:, :, 0, :2] - u2).max() <= 1e-10 * su, name
+    assert np.abs(s3[:, :, 0, :] - s2).max() <= 1e-10 * np.abs(s2).max(), name
+    assert np.abs(g3[:, :, 0, :2] - g2).max() <= 1e-8 * sg, name
+    assert np.abs(u3[..., 2]).max() <= 1e-10 * su and np.abs(u3 - u3[:, :, :1, :]).max() <= 1e-10 * su and np.abs(s3 - s3[:, :, :1, :]).max() <= 1e-10
+
+
+@pytest.mark.parametrize("name,bc,prob,max_levs", [("bubble-walls", [[15, 15], [15, 15]], 1, 3), ("bubble-periodic-x", [[-1, -1], [15, 15]], 1, 2)])
+def test_extruded_hierarchy_against_the_box_list_oracle(gpu, oracle, name, bc, prob, max_levs):
+    """A tagged 2-D hierarchy as its z-uniform copy, held against the CPU oracle's box-list hierarchies (oracle/vo_amr.c) on the same boxes: 32 x 32 x 8 cells of level 0, the
+    levels tagged from initdata_2d (tag_boxes.f90:65-84, the same thresholds in tag_boxes_2d), viscous, start-up + two steps.  The oracle keeps no periodic images of refined boxes, so its copy
+    stands between SLIP WALLS along z -- the same z-uniform solution (w = 0 on the wall, nothing to reflect) -- and the library runs both forms: against the oracle with the walls
+    (dt bit for bit, equal FAC counts, u / rho to 1e-9), and with the periodic z of the product path against its own wall run (plane k = 0 to 1e-10: the refined boxes talk
+    to their own periodic images along z there)."""
+    from varden_amd import advance as adv, driver
+    from varden_amd.capi import default_params
+    vo = oracle
+    n, nz = 32, 8
+    prm = lambda: default_params(cflfac=0.9, visc_coef=0.001)   # noqa: E731
+    levels = driver.VardenAMR.tagged_grids((n, n), bc, prm(), prob_type=prob, max_levs=max_levs, max_grid_size=32, extrude2d=nz)
+    assert len(levels) == max_levs - 1
+    for lb in levels:                                       # the boxes are columns: z-uniform tags cluster into z-uniform footprints
+        foot = {}
+        for lo, hi in lb:
+            foot.setdefault((lo[0], lo[1], hi[0], hi[1]), []).append((lo[2], hi[2]))
+        top = max(hi[2] for _, hi in lb)
+        for f, zs in foot.items():
+            zs.sort()
+            assert zs[0][0] == 0 and zs[-1][1] == top and all(zs[i][1] + 1 == zs[i + 1][0] for i in range(len(zs) - 1)), (f, zs)
+    kw = dict(prob_type=prob, init_shrink=0.1, init_iter=1, do_initial_projection=1)
+    init = driver.extruded_initdata(prob, 2)
+    phys3w = [bc[0], bc[1], [14, 14]]
+    O = vo.SimML((n, n, nz), levels, phys3w, prm=prm(), init_fn=init, grav_dir=1, **kw)
+    Gw = driver.VardenAMR((n, n), levels[0], bc, params=prm(), finer_levels=levels[1:], extrude2d=nz, extrude_zbc=[14, 14], **kw)
+    assert Gw.dt == O.dt
+    for _ in range(2):
+        O.step(); Gw.step()
+        assert Gw.dt == O.dt
+        assert adv.last_solver_stats("mac")[0] == O.mgstat[0].cycles and adv.last_solver_stats("hg")[0] == O.mgstat[1].cycles
+    planes_w = [Gw.slice2d(Gw.uold), Gw.slice2d(Gw.sold)]
+    for lev in range(Gw.nlev):
+        olo = O.levels[lev].lo
+        for li, gi in enumerate(Gw.local[lev]):
+            lo, hi = Gw.boxes[lev][gi]
+            sl = tuple(slice(lo[d] - olo[d], hi[d] - olo[d] + 1) for d in range(3))
+            a = Gw.uold[lev].to_numpy(li)[3:-3, 3:-3, 3:-3]
+            b = O.uold[lev].valid()[sl]
+            assert np.abs(a - b).max() <= 1e-9 * max(np.abs(b).max(), 1e-3), (name, lev, gi)
+            a = Gw.sold[lev].to_numpy(li)[3:-3, 3:-3, 3:-3]
+            b = O.sold[lev].valid()[sl]
+            assert np.abs(a - b).max() <= 1e-9 * np.abs(b).max(), (name, lev, gi)
+    Gw.close()
+    Gp = driver.VardenAMR((n, n), levels[0], bc, params=prm(), finer_levels=levels[1:], extrude2d=nz, **kw)
+    for _ in range(2):
+        Gp.step()
+    for wl, pl in zip(planes_w, [Gp.slice2d(Gp.uold), Gp.slice2d(Gp.sold)]):
+        for lev in range(Gp.nlev):
+            m = np.isfinite(wl[lev])
+            assert (m == np.isfinite(pl[lev])).all()
+            assert np.abs(wl[lev][m] - pl[lev][m]).max() <= 1e-10 * max(np.abs(wl[lev][m]).max(), 1e-3), (name, lev)
+    Gp.close()
+
+
+@pytest.mark.parametrize("inputs_name,steps", [("inputs_bubble_2d", 6), ("inputs_2d-regt", 6), ("inputs_advect_2d", 6), ("inputs_RayleighTaylor_2d", 5)])
+def test_2d_inputs_of_the_reference_run_as_extruded_hierarchies(gpu, tmp_path, inputs_name, steps):
+    """The four 2-D inputs of exec/test (all adaptive: max_levs 3-4, regrid_int 1-2, viscous) through varden_amd.inputs: tagging and clustering of the initial data, start-up,
+    time loop with regridding, plot files of the 3-D copy.  Every step: both composite solves converge, |w| and the spread over z stay at round-off, the bubble stays
+    mirror-symmetric in x up to the truncation error of its (unsymmetric) box layout; the grids were rebuilt; the finest level sits where the density varies."""
+    import os
+    from varden_amd import advance as adv, inputs
+    text = open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "inputs", inputs_name)).read()
+    seen = []
+
+    def rep(G):
+        assert adv.last_solver_stats("mac")[2] <= 1e-10 * adv.last_solver_stats("mac")[1] and adv.last_solver_stats("hg")[0] < 60
+        seen.append((G.istep, G.nregrids, [len(b) for b in G.boxes]))
+    nl, G = inputs.run(text, nsteps=steps, report=rep, outdir=str(tmp_path))
+    assert G.extrude2d and G.nlev == int(nl["max_levs"]) and G.nregrids >= steps // max(int(nl["regrid_int"]), 1) - 1
+    umax = max(np.abs(G.uold[n].to_numpy(i)[3:-3, 3:-3, 3:-3, :2]).max() for n in range(G.nlev) for i in range(G.uold[n].nfabs()))
+    assert np.isfinite(umax) and umax > 0
+    for n in range(G.nlev):
+        for i in range(G.uold[n].nfabs()):
+            u, s = G.uold[n].to_numpy(i)[3:-3, 3:-3, 3:-3], G.sold[n].to_numpy(i)[3:-3, 3:-3, 3:-3]
+            assert np.abs(u[..., 2]).max() <= 1e-10 * umax and np.abs(u - u[:, :, :1]).max() <= 1e-10 * umax and np.abs(s - s[:, :, :1]).max() <= 1e-10
+    rho = G.slice2d(G.sold)
+    if inputs_name in ("inputs_bubble_2d", "inputs_2d-regt"):
+        r0 = rho[0][..., 0]
+        assert np.abs(r0 - r0[::-1, :]).max() <= 5e-3              # (the clustered boxes are not mirror images of each other: symmetric up to the coarse-fine truncation error)
+    fin = np.isfinite(rho[-1][..., 0])
+    assert fin.any() and (np.abs(rho[0][..., 0] - (1.0 if inputs_name != "inputs_RayleighTaylor_2d" else rho[0][0, 0, 0])) > 0.05).any()
+    assert any(f.startswith(str(tmp_path)) for f in G.files_written)
+    G.close()

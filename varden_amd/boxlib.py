@@ -36,6 +36,11 @@ def initialize(params=None, rank=0, nranks=1, device=0):
     return prm
 
 
+def set_extruded_2d(on=True):
+    """the 3-D kernels run a z-uniform copy of a 2-D problem (include/varden_amd.h: vdn_set_extruded_2d); reset by initialize"""
+    check(capi.load().vdn_set_extruded_2d(1 if on else 0))
+
+
 def comm_get_unique_id():
     """rank 0: the 128-byte RCCL unique id to broadcast to the other ranks"""
     buf = C.create_string_buffer(128)

@@ -69,6 +69,7 @@ SIGNATURES = {
     "vdn_device_synchronize": (C.c_int, []),
     "vdn_get_params": (C.c_int, [C.POINTER(Params)]),
     "vdn_arena_stats": (C.c_int, [C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]),
+    "vdn_set_extruded_2d": (C.c_int, [C.c_int]),
     "vdn_comm_get_unique_id": (C.c_int, [C.c_char_p]),
     "vdn_comm_init": (C.c_int, [C.c_char_p]),
     "vdn_comm_finalize": (C.c_int, []),

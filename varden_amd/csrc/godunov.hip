@@ -26,6 +26,7 @@ struct GArgs {
   double dx[3], dt;
   int ncomp, is_vel, use_minion, slope_order;
   int cons[3];
+  int outlet2d;              // 1: velpred's hi-x OUTLET takes velpred_2d's rule (max, velpred.f90:305) instead of velpred_3d's (min, :2075): vdn_set_extruded_2d
 };
 
 template <int D> DEVI double ld(const FV &f, int i, int j, int k, int off, int c = 0) {
@@ -1700,7 +1701,7 @@ static void fill_gargs(GArgs &A, const vdn_multifab *s, int ibox, const vdn_bc_t
       for (int c = 0; c < ncomp && c < 3; c++) A.adv[d][sd][c] = bct->adv_bc(s->lev, ibox + 1, d, sd, bccomp + c);
     }
   }
-  A.dt = dt; A.ncomp = ncomp; A.use_minion = ctx().prm.use_minion; A.slope_order = ctx().prm.slope_order;
+  A.dt = dt; A.ncomp = ncomp; A.use_minion = ctx().prm.use_minion; A.slope_order = ctx().prm.slope_order; A.outlet2d = ctx().extruded2d ? 1 : 0;
 }
 static void k2_velpred(const vdn_multifab *u, vdn_multifab **umac, const vdn_multifab *force, const double *dx, double dt, const vdn_bc_tower *bct);
 static void k2_mkflux(const vdn_multifab *s, vdn_multifab **sedge, vdn_multifab **flux, vdn_multifab **umac, const vdn_multifab *force,
@@ -1957,7 +1958,7 @@ template <int D> DEVI void vp_pair(const GArgs &A, const FV &u, const FV &slp, c
     #pragma unroll
     for (int c = 0; c < 3; c++) {
       const double ghost = (side == 0) ? ld<D>(u, i, j, k, -1, c) : fv_get(u, i, j, k, c);
-      bc_pair(L[c], R[c], A.phys[D][side], side, true, c == D, ghost, D == 0 && side == 1);   // :2075 quirk
+      bc_pair(L[c], R[c], A.phys[D][side], side, true, c == D, ghost, D == 0 && side == 1 && !A.outlet2d);   // :2075 quirk
     }
   }
 }
@@ -2101,11 +2102,11 @@ template <int D> DEVI void vp_bases(const GArgs &A, const double uc[3], const do
 template <int D> DEVI void vp_premod(const GArgs &A, const FV &u, int c, int i, int j, int k, double &Lb, double &Rb) {
   const int q = coord<D>(i, j, k);
   if (q == A.lo[D]) { double o = Rb; bc_pair(o, Rb, A.phys[D][0], 0, true, c == D, ld<D>(u, i, j, k, -1, c), false); }
-  if (q == A.hi[D]) { double o = Lb; bc_pair(Lb, o, A.phys[D][1], 1, true, c == D, ld<D>(u, i, j, k, 1, c), D == 0); }   // :2075 quirk
+  if (q == A.hi[D]) { double o = Lb; bc_pair(Lb, o, A.phys[D][1], 1, true, c == D, ld<D>(u, i, j, k, 1, c), D == 0 && !A.outlet2d); }   // :2075 quirk
 }
 template <int D> DEVI void vp_face_bc(const GArgs &A, const FV &u, int c, bool normal, bool quirk_ok, int i, int j, int k, double uc, double &L, double &R) {
   const int side = face_side<D>(A, i, j, k);
-  if (side >= 0) bc_pair(L, R, A.phys[D][side], side, true, normal, side == 0 ? ld<D>(u, i, j, k, -1, c) : uc, quirk_ok && D == 0 && side == 1);
+  if (side >= 0) bc_pair(L, R, A.phys[D][side], side, true, normal, side == 0 ? ld<D>(u, i, j, k, -1, c) : uc, quirk_ok && D == 0 && side == 1 && !A.outlet2d);
 }
 template <int D> DEVI void vp_B_emit(const FV &UI, int i, int j, int k, const double L[3], const double R[3], double eps) {
   const double uavg = 0.5 * (L[D] + R[D]);
@@ -2363,13 +2364,13 @@ struct VArgs {
   long u_row;
   double dt2, dx[3], tC[3], tD[3];    // tC[O] = (dt/6) / dx[O],  tD[T] = (dt/4) / dx[T]
   double idx[3]; int p2;              // as in FArgs: 1 / dx, every dx a power of two (P2 kernels multiply)
-  int lo[3], hi[3], phys[3][2], use_minion;
+  int lo[3], hi[3], phys[3][2], use_minion, outlet2d;
 };
-DEVI int vp_code_B(int phys, int D, int side, int c) {
+DEVI int vp_code_B(int phys, int D, int side, int c, int outlet2d) {
   if (phys == VDN_INLET) return 1;
   if (phys == VDN_SLIP_WALL) return c == D ? 2 : 3;
   if (phys == VDN_NO_SLIP_WALL) return 2;
-  if (phys == VDN_OUTLET) return c == D ? ((side == 0 || D == 0) ? 4 : 5) : 3;
+  if (phys == VDN_OUTLET) return c == D ? ((side == 0 || (D == 0 && !outlet2d)) ? 4 : 5) : 3;
   return 0;
 }
 DEVI int vp_code_D(int phys, int side) {
@@ -2419,14 +2420,14 @@ template <bool BC, bool INL, bool PW2, bool NAR = false> __device__ __forceinlin
   if (BC) {
     #pragma unroll
     for (int c = 0; c < 3; c++) {
-      if (ing_ij && i == F.lo[0]) wf |= (unsigned)vp_code_B(F.phys[0][0], 0, 0, c) << (4 * c);
-      if (ing_ij && i == F.hi[0] + 1) { const int cd = vp_code_B(F.phys[0][1], 0, 1, c); if (cd) wf |= (unsigned)(cd | 8) << (4 * c); }
-      if (ing_ij && j == F.lo[1]) wf |= (unsigned)vp_code_B(F.phys[1][0], 1, 0, c) << (12 + 4 * c);
-      if (ing_ij && j == F.hi[1] + 1) { const int cd = vp_code_B(F.phys[1][1], 1, 1, c); if (cd) wf |= (unsigned)(cd | 8) << (12 + 4 * c); }
-      if (ic == F.lo[0]) wpx |= (unsigned)vp_code_B(F.phys[0][0], 0, 0, c) << (4 * c);
-      if (ic == F.hi[0]) wpx |= (unsigned)vp_code_B(F.phys[0][1], 0, 1, c) << (12 + 4 * c);
-      if (jc == F.lo[1]) wpy |= (unsigned)vp_code_B(F.phys[1][0], 1, 0, c) << (4 * c);
-      if (jc == F.hi[1]) wpy |= (unsigned)vp_code_B(F.phys[1][1], 1, 1, c) << (12 + 4 * c);
+      if (ing_ij && i == F.lo[0]) wf |= (unsigned)vp_code_B(F.phys[0][0], 0, 0, c, F.outlet2d) << (4 * c);
+      if (ing_ij && i == F.hi[0] + 1) { const int cd = vp_code_B(F.phys[0][1], 0, 1, c, F.outlet2d); if (cd) wf |= (unsigned)(cd | 8) << (4 * c); }
+      if (ing_ij && j == F.lo[1]) wf |= (unsigned)vp_code_B(F.phys[1][0], 1, 0, c, F.outlet2d) << (12 + 4 * c);
+      if (ing_ij && j == F.hi[1] + 1) { const int cd = vp_code_B(F.phys[1][1], 1, 1, c, F.outlet2d); if (cd) wf |= (unsigned)(cd | 8) << (12 + 4 * c); }
+      if (ic == F.lo[0]) wpx |= (unsigned)vp_code_B(F.phys[0][0], 0, 0, c, F.outlet2d) << (4 * c);
+      if (ic == F.hi[0]) wpx |= (unsigned)vp_code_B(F.phys[0][1], 0, 1, c, F.outlet2d) << (12 + 4 * c);
+      if (jc == F.lo[1]) wpy |= (unsigned)vp_code_B(F.phys[1][0], 1, 0, c, F.outlet2d) << (4 * c);
+      if (jc == F.hi[1]) wpy |= (unsigned)vp_code_B(F.phys[1][1], 1, 1, c, F.outlet2d) << (12 + 4 * c);
     }
     if (ing_ij && i == F.lo[0]) wf |= (unsigned)vp_code_D(F.phys[0][0], 0) << 24;
     if (ing_ij && i == F.hi[0] + 1) { const int cd = vp_code_D(F.phys[0][1], 1); if (cd) wf |= (unsigned)(cd | 8) << 24; }
@@ -2459,12 +2460,12 @@ template <bool BC, bool INL, bool PW2, bool NAR = false> __device__ __forceinlin
                                                        const int b_ = (int)(b4) & 7; if (b_) { double o_; BC_V(o_, b_, Lb_, gh_expr) Lb_ = o_; } }
   // z words of a stage plane (uniform): face codes of the three components (bits 0..11), stage-D code (24..27); premod lo (0..11) / hi (12..23)
   #define ZF_WORD(k, kc, zf) { zf = 0u; if (BC && (k) == (kc)) {                                                                  \
-      if ((k) == F.lo[2]) { for (int c_ = 0; c_ < 3; c_++) zf |= (unsigned)vp_code_B(F.phys[2][0], 2, 0, c_) << (4 * c_); zf |= (unsigned)vp_code_D(F.phys[2][0], 0) << 24; } \
-      if ((k) == KT) { for (int c_ = 0; c_ < 3; c_++) { const int cd_ = vp_code_B(F.phys[2][1], 2, 1, c_); if (cd_) zf |= (unsigned)(cd_ | 8) << (4 * c_); }             \
+      if ((k) == F.lo[2]) { for (int c_ = 0; c_ < 3; c_++) zf |= (unsigned)vp_code_B(F.phys[2][0], 2, 0, c_, F.outlet2d) << (4 * c_); zf |= (unsigned)vp_code_D(F.phys[2][0], 0) << 24; } \
+      if ((k) == KT) { for (int c_ = 0; c_ < 3; c_++) { const int cd_ = vp_code_B(F.phys[2][1], 2, 1, c_, F.outlet2d); if (cd_) zf |= (unsigned)(cd_ | 8) << (4 * c_); }             \
                        const int cd_ = vp_code_D(F.phys[2][1], 1); if (cd_) zf |= (unsigned)(cd_ | 8) << 24; } } }
   #define ZP_WORD(kc, zp) { zp = 0u; if (BC) {                                                                                     \
-      if ((kc) == F.lo[2]) for (int c_ = 0; c_ < 3; c_++) zp |= (unsigned)vp_code_B(F.phys[2][0], 2, 0, c_) << (4 * c_);           \
-      if ((kc) == F.hi[2]) for (int c_ = 0; c_ < 3; c_++) zp |= (unsigned)vp_code_B(F.phys[2][1], 2, 1, c_) << (12 + 4 * c_); } }
+      if ((kc) == F.lo[2]) for (int c_ = 0; c_ < 3; c_++) zp |= (unsigned)vp_code_B(F.phys[2][0], 2, 0, c_, F.outlet2d) << (4 * c_);           \
+      if ((kc) == F.hi[2]) for (int c_ = 0; c_ < 3; c_++) zp |= (unsigned)vp_code_B(F.phys[2][1], 2, 1, c_, F.outlet2d) << (12 + 4 * c_); } }
   struct VRaw { double u[3], sx[3], sy[3], sz[3], f[3]; } N;
   #define V_LOAD {                                                                                                \
       _Pragma("unroll") for (int c = 0; c < 3; c++) {                                                              \
@@ -2718,7 +2719,7 @@ static bool vfused_args(VArgs &F, const GArgs &A, const FV &u, const FV sl[3], c
     F.dx[d] = A.dx[d]; F.idx[d] = 1.0 / A.dx[d]; F.tC[d] = dt6 / A.dx[d]; F.tD[d] = dt4 / A.dx[d];
     F.lo[d] = A.lo[d]; F.hi[d] = A.hi[d]; F.phys[d][0] = A.phys[d][0]; F.phys[d][1] = A.phys[d][1];
   }
-  F.use_minion = A.use_minion;
+  F.use_minion = A.use_minion; F.outlet2d = A.outlet2d;
   F.p2 = (is_pow2(A.dx[0]) && is_pow2(A.dx[1]) && is_pow2(A.dx[2]) && !no_p2()) ? 1 : 0;
   return true;
 }

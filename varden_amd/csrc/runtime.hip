@@ -440,6 +440,7 @@ extern "C" int vdn_init(const vdn_params *prm, int rank, int nranks, int device)
   VDN_TRY
   env_warn_unknown();
   REQUIRE(prm != nullptr, "vdn_init: null params");
+  g_ctx.extruded2d = false;
   REQUIRE(prm->dm == 3 || prm->dm == 2, "vdn_init: dm must be 2 or 3 (got %d)", prm->dm);
   REQUIRE(prm->nscal >= 1 && prm->nscal + 5 <= VDN_MAXCOMP, "vdn_init: bad nscal %d", prm->nscal);
   REQUIRE(prm->visc_coef >= 0.0 && prm->diff_coef >= 0.0, "vdn_init: negative visc_coef / diff_coef");
@@ -492,6 +493,7 @@ extern "C" int vdn_set_stream(void *s) {            // NULL: back to the library
 extern "C" int vdn_arena_stats(size_t *reserved_bytes, size_t *peak_bytes) { *reserved_bytes = g_ctx.arena_bytes; *peak_bytes = g_ctx.arena_peak; return 0; }
 extern "C" int vdn_device_synchronize(void) { VDN_TRY HIPCHK(hipStreamSynchronize(g_ctx.stream)); VDN_CATCH }
 extern "C" int vdn_get_params(vdn_params *out) { *out = g_ctx.prm; return 0; }
+extern "C" int vdn_set_extruded_2d(int on) { g_ctx.extruded2d = on != 0; return 0; }
 extern "C" int vdn_last_step_timing(double *s) { for (int i = 0; i < 5; i++) s[i] = g_ctx.step_sec[i]; return 0; }
 extern "C" int vdn_last_solver_stats(int w, int *cyc, double *r0, double *r) {
   if (w < 0 || w > 1) return 1;

@@ -80,6 +80,7 @@ struct VdnCtx {
   bool inited = false;
   vdn_params prm;
   int rank = 0, nranks = 1, device = 0;
+  bool extruded2d = false;    // vdn_set_extruded_2d: the 3-D kernels run a z-uniform, z-periodic copy of a 2-D problem (godunov.hip: velpred's hi-x OUTLET rule)
   hipStream_t stream = 0;                    // the launch stream: our own non-blocking stream unless vdn_set_stream names another
   hipStream_t own_stream = 0, halo_stream = 0;    // halo_stream: packed ghost traffic next to interior compute (exchange.hip)
   hipEvent_t ev_main = nullptr, ev_halo = nullptr; // ordering between the two (no timing)

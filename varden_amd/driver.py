@@ -26,6 +26,13 @@ def initdata_numpy(n, dx, prob_type=1, ng=3, nscal=2, lo=(0, 0, 0), centre=(0.5,
         y = dx[1] * (lo[1] + np.arange(n[1]) + 0.5)
         X, Y = np.meshgrid(x, y, indexing="ij")
         dist = np.sqrt((X - centre[0]) ** 2 + (Y - centre[1]) ** 2)
+        if prob_type == 3:                                # Rayleigh-Taylor interface, initdata.f90:175-185, 195-200 (tracer = 0); prob_lo = 0, prob_hi(1) = 2 * centre(1)
+            Lx = 2.0 * centre[0]
+            h = 0.02 * np.sin(4.0 * np.pi * X * Lx) + 0.01 * np.sin(8.0 * np.pi * X * Lx)
+            s[ng:-ng, ng:-ng, 0, 0] = 1.0 + 0.5 + 0.5 * np.tanh((Y - 0.5 - h) / 0.01)
+            if nscal > 1:
+                s[..., 1] = 0.0
+            return u, s
         r = 1.0 + 0.5 * (2.0 - 1.0) * (1.0 - np.tanh(30.0 * (dist - 0.1)))
         s[ng:-ng, ng:-ng, 0, 0] = r
         if nscal > 1:
@@ -78,7 +85,7 @@ def _limit_dt(sim, dt, first=False):
 class Varden:
     def __init__(self, n, phys_bc, params=None, prob_type=1, grav=-9.8, prob_hi=(1.0, 1.0, 1.0), init_shrink=1.0,
                  init_iter=4, do_initial_projection=1, u0=None, s0=None, device=0, decomp=(1, 1, 1), rank=0, nranks=1,
-                 comm_id=None, restart=None, restart_step=0, fixed_dt=-1.0, stop_time=-1.0, swap_state=False):
+                 comm_id=None, restart=None, restart_step=0, fixed_dt=-1.0, stop_time=-1.0, swap_state=False, grav_dir=None, extruded2d=False):
         """decomp = (bx, by, bz): the domain is cut into bx*by*bz equal boxes (max_grid_size of the reference,
         src/_parameters:27), dealt round-robin to the ranks (one rank per GPU).  comm_id: the 128-byte RCCL unique
         id broadcast by the caller when nranks > 1.  restart: a checkpoint read by plotfile.read_checkfile -- the state comes from it
@@ -94,6 +101,8 @@ class Varden:
         self.prm.prob_type = prob_type
         self.rank, self.nranks = rank, nranks
         bl.initialize(self.prm, rank, nranks, device)
+        if extruded2d:                                    # a z-uniform, z-periodic copy of a 2-D problem: velpred_2d's hi-x OUTLET rule (include/varden_amd.h)
+            bl.set_extruded_2d(True)
         if nranks > 1:
             bl.comm_init(comm_id)
         self.phys = [[int(phys_bc[d][s]) for s in range(2)] if d < dm else [bl.INTERIOR, bl.INTERIOR] for d in range(3)]
@@ -118,7 +127,7 @@ class Varden:
         self.uold, self.sold, self.unew, self.snew = mk(dm, 3), mk(ns, 3), mk(dm, 3), mk(ns, 3)
         self.gp, self.p = mk(dm, 1), mk(1, 1, (1, 1, 1))
         self.ext_vel_force, self.ext_scal_force = mk(dm, 1), mk(ns, 1)
-        self.ext_vel_force[0].setval(grav, dm - 1, 1, all=True)                    # varden.f90:428-429
+        self.ext_vel_force[0].setval(grav, dm - 1 if grav_dir is None else int(grav_dir), 1, all=True)   # varden.f90:428-429 (grav_dir: the extruded 2-D problems, gravity along y)
         if restart is not None:
             from . import plotfile
             plotfile.load_restart(self, restart)
@@ -226,6 +235,28 @@ def prm_cluster(prm, name):
     return {"min_eff": 0.9, "min_width": 4, "blocking": 4}[name]
 
 
+def _ncs(nc):
+    """cells of level 0 per direction: an int (a cube) or three ints"""
+    return tuple(int(x) for x in nc) if hasattr(nc, "__len__") else (int(nc),) * 3
+
+
+def _level_domain(ncs, n):
+    return ((0, 0, 0), tuple((c << n) - 1 for c in ncs))
+
+
+def extruded_initdata(prob_type, nscal, prob_hi2=(1.0, 1.0)):
+    """init_fn of a 2-D problem run as its z-uniform 3-D copy (VardenAMR(extrude2d = nz)): initdata_2d (src/initdata.f90:127-171) on the box's (x, y) cells, the same
+    values on every plane; w = 0"""
+    def fn(level, blo, nb, dx):
+        u2, s2 = initdata_numpy((nb[0], nb[1]), dx, prob_type, 3, nscal, lo=blo, centre=(0.5 * prob_hi2[0], 0.5 * prob_hi2[1], 0.0), dm=2)
+        u = np.zeros((nb[0] + 6, nb[1] + 6, nb[2] + 6, 3), order="F")
+        s = np.zeros((nb[0] + 6, nb[1] + 6, nb[2] + 6, nscal), order="F")
+        u[..., :2] = u2[:, :, 0, None, :]
+        s[...] = s2[:, :, 0, None, :]
+        return u, s
+    return fn
+
+
 class VardenAMR:
     """multi-level hierarchy on fixed grids (the reference's fixed_grids mode, src/initialize.f90:93-150): level 0 = the domain
     [0,nc)^3 in one box or in `base_boxes` (equal boxes, what max_grid_size makes of it), level 1 = the given fine boxes (fine index
@@ -235,8 +266,13 @@ class VardenAMR:
     def __init__(self, nc, fine_boxes, phys_bc, params=None, prob_type=1, grav=-9.8, init_shrink=0.1, device=0, finer_levels=(),
                  regrid_int=-1, max_levs=None, max_grid_size=256, init_iter=0, do_initial_projection=0,
                  rank=0, nranks=1, comm_id=None, base_boxes=None, init_fn=None, restart=None, restart_step=0,
-                 fixed_dt=-1.0, stop_time=-1.0, amr_buf_width=-1, swap_state=False):
-        """init_fn(level, box_lo, box_shape, dx) -> (u, s) with 3 ghost layers replaces the analytic initial data of prob_type.
+                 fixed_dt=-1.0, stop_time=-1.0, amr_buf_width=-1, swap_state=False, extrude2d=None, extrude_zbc=None):
+        """nc: cells of level 0 per direction (an int: a cube; dx = dy = dz = 1 / nc[0]).
+        extrude2d = nz: a 2-D problem of nc[0] x nc[1] cells (phys_bc: its two directions) run as its z-uniform copy -- nz cells of level 0 along a periodic z, gravity along y,
+        initdata_2d on every plane, velpred_2d's outlet rule (include/varden_amd.h: vdn_set_extruded_2d).  With w = 0 and nothing varying along z the 3-D scheme is the 2-D one
+        (tests/test_dim2_gpu.py::test_extruded_copy_reproduces_the_2d_path: 1e-12 on every boundary pair of the 2-D inputs), so the hierarchies of the reference's four 2-D inputs
+        -- tagging, regridding, composite solves -- run on the 3-D machinery; plane k = 0 is the 2-D answer (slice2d).
+        init_fn(level, box_lo, box_shape, dx) -> (u, s) with 3 ghost layers replaces the analytic initial data of prob_type.
         several ranks (one per GPU): the boxes of every level are dealt to the ranks by cell count (`distribute`), `base_boxes` cuts
         level 0 into several boxes, comm_id is the RCCL unique id broadcast by the caller; regridding is single-rank in this round"""
         self.prm = params or default_params()
@@ -247,15 +283,27 @@ class VardenAMR:
         self.prm.prob_type = prob_type
         self.rank, self.nranks = rank, nranks
         bl.initialize(self.prm, rank, nranks, device)
+        self.extrude2d = extrude2d
+        self.grav_dir = 2
+        if extrude2d:
+            bl.set_extruded_2d(True)
+            nc2 = _ncs(nc)
+            nc = (nc2[0], nc2[1], int(extrude2d))
+            phys_bc = [list(phys_bc[0]), list(phys_bc[1]), list(extrude_zbc) if extrude_zbc else [bl.PERIODIC, bl.PERIODIC]]      # (slip walls along z carry the same z-uniform solution: the oracle's form, tests/test_dim2_gpu.py)
+            self.grav_dir = 1
+            if init_fn is None:
+                init_fn = extruded_initdata(prob_type, self.prm.nscal, (1.0, nc2[1] / float(nc2[0])))
         if nranks > 1:
             bl.comm_init(comm_id)
         self.nc = nc
+        self.ncs = _ncs(nc)
+        self.init_fn = init_fn
         self.phys = [[int(phys_bc[d][s]) for s in range(2)] for d in range(3)]
         lev_boxes = [fine_boxes] + list(finer_levels)
         self.nlev = NL = 1 + len(lev_boxes)
         self.max_levs = max_levs or NL
         self.nregrids = 0
-        pd = [((0, 0, 0), ((nc << n) - 1,) * 3) for n in range(NL)]
+        pd = [_level_domain(self.ncs, n) for n in range(NL)]
         base = [pd[0]] if base_boxes is None else [(tuple(b[0]), tuple(b[1])) for b in base_boxes]
         self.boxes = [base] + [[(tuple(b[0]), tuple(b[1])) for b in lb] for lb in lev_boxes]
         self.owner = [distribute(lb, nranks) for lb in self.boxes]
@@ -263,7 +311,7 @@ class VardenAMR:
         self.pmask = tuple(1 if self.phys[d][0] == bl.PERIODIC else 0 for d in range(3))
         self.mla = bl.MLLayout(pd, self.boxes, owner=self.owner, rr=[(2, 2, 2)] * (NL - 1), pmask=self.pmask)
         self.bct = bl.BCTower(self.mla, self.phys)
-        self.dx = [[1.0 / (nc << n)] * 3 for n in range(NL)]
+        self.dx = [[1.0 / (self.ncs[0] << n)] * 3 for n in range(NL)]
         dm, ns = 3, self.prm.nscal
         self.dm, self.nscal, self.press_comp = dm, ns, dm + ns + 1
         mk = lambda nc_, ng, nodal=None: [bl.MultiFab(self.mla, n, nc_, ng, nodal) for n in range(NL)]   # noqa: E731
@@ -271,7 +319,7 @@ class VardenAMR:
         self.gp, self.p = mk(dm, 1), mk(1, 1, (1, 1, 1))
         self.ext_vel_force, self.ext_scal_force = mk(dm, 1), mk(ns, 1)
         for n in range(self.nlev):
-            self.ext_vel_force[n].setval(grav, dm - 1, 1, all=True)
+            self.ext_vel_force[n].setval(grav, self.grav_dir, 1, all=True)
         if restart is not None:                          # initialize_from_restart, src/initialize.f90:22-88
             from . import plotfile
             plotfile.load_restart(self, restart)
@@ -310,7 +358,7 @@ class VardenAMR:
                                  self.ext_vel_force, self.ext_scal_force, self.bct, self.dt, self.time, self.dx, self.press_comp, bl.PRESSURE_ITERS)
 
     @staticmethod
-    def tagged_grids(nc, phys_bc, params=None, prob_type=1, max_levs=2, buf_wid=2, max_grid_size=256, device=0, rank=0, nranks=1, comm_id=None, base_boxes=None):
+    def tagged_grids(nc, phys_bc, params=None, prob_type=1, max_levs=2, buf_wid=2, max_grid_size=256, device=0, rank=0, nranks=1, comm_id=None, base_boxes=None, extrude2d=None):
         """the grids the reference's initialize_with_adaptive_grids builds (src/initialize.f90:152-342): level by level, initial data on
         the level -> tag_boxes -> make_new_grids, until nothing is tagged or max_levs is reached.  Returns the box lists of the levels
         1.. (each in its own index space).  Nesting: a new level keeps 2 cells of its parent level around itself."""
@@ -321,17 +369,24 @@ class VardenAMR:
             bl.comm_init(comm_id)
         ns = prm.nscal
         levels = []
-        pd = [((0, 0, 0), (nc - 1,) * 3)]
+        init_fn = None
+        if extrude2d:                                      # (the 2-D problem as its z-uniform copy: see __init__)
+            nc2 = _ncs(nc)
+            nc = (nc2[0], nc2[1], int(extrude2d))
+            phys_bc = [list(phys_bc[0]), list(phys_bc[1]), [bl.PERIODIC, bl.PERIODIC]]
+            init_fn = extruded_initdata(prob_type, ns, (1.0, nc2[1] / float(nc2[0])))
+        ncs = _ncs(nc)
+        pd = [_level_domain(ncs, 0)]
         boxes = [[pd[0]] if base_boxes is None else [(tuple(b[0]), tuple(b[1])) for b in base_boxes]]
         for lev in range(1, max_levs):
             owner = [distribute(lb, nranks) for lb in boxes]
             mla = bl.MLLayout(pd, boxes, owner=owner, rr=[(2, 2, 2)] * (lev - 1), pmask=tuple(1 if int(phys_bc[d][0]) == bl.PERIODIC else 0 for d in range(3)))
             sold = bl.MultiFab(mla, lev - 1, ns, 3)
-            dx = [1.0 / (nc << (lev - 1))] * 3
+            dx = [1.0 / (ncs[0] << (lev - 1))] * 3
             for li, gi in enumerate([i for i, o in enumerate(owner[lev - 1]) if o == rank]):
                 blo, bhi = boxes[lev - 1][gi]
                 nb = tuple(bhi[d] - blo[d] + 1 for d in range(3))
-                _, sb = initdata_numpy(nb, dx, prob_type, 3, ns, lo=blo)
+                _, sb = initdata_numpy(nb, dx, prob_type, 3, ns, lo=blo) if init_fn is None else init_fn(lev - 1, blo, nb, dx)
                 sold.from_numpy(sb, li)
             new, _ = adv.make_new_grids(sold, lev, buf_wid=buf_wid, nest=0 if lev == 1 else 2, min_eff=prm_cluster(prm, "min_eff"),
                                         min_width=prm_cluster(prm, "min_width"), blocking=prm_cluster(prm, "blocking"), max_grid_size=max_grid_size)
@@ -339,7 +394,7 @@ class VardenAMR:
             if not new:
                 break
             levels.append(new)
-            pd.append(((0, 0, 0), ((nc << lev) - 1,) * 3))
+            pd.append(_level_domain(ncs, lev))
             boxes.append(new)
         return levels
 
@@ -373,7 +428,7 @@ class VardenAMR:
     def _alloc_state(self, boxes):
         """layout, bc tower and the four carried state multifabs (uold, sold, gp, p) on the given box lists"""
         NL = len(boxes)
-        pd = [((0, 0, 0), ((self.nc << n) - 1,) * 3) for n in range(NL)]
+        pd = [_level_domain(self.ncs, n) for n in range(NL)]
         owner = [distribute(lb, self.nranks) for lb in boxes]
         mla = bl.MLLayout(pd, boxes, owner=owner, rr=[(2, 2, 2)] * (NL - 1), pmask=self.pmask)
         bct = bl.BCTower(mla, self.phys)
@@ -438,18 +493,33 @@ class VardenAMR:
         self.local = [[i for i, o in enumerate(ow) if o == self.rank] for ow in self.owner]
         self.uold, self.sold, self.gp, self.p = cur["uold"], cur["sold"], cur["gp"], cur["p"]
         self.nlev = NL = len(self.boxes)
-        self.dx = [[1.0 / (self.nc << n)] * 3 for n in range(NL)]
+        self.dx = [[1.0 / (self.ncs[0] << n)] * 3 for n in range(NL)]
         mk = lambda nc_, ng: [bl.MultiFab(self.mla, n, nc_, ng) for n in range(NL)]   # noqa: E731
         self.unew, self.snew = mk(self.dm, 3), mk(self.nscal, 3)
         self.ext_vel_force, self.ext_scal_force = mk(self.dm, 1), mk(self.nscal, 1)
         for n in range(NL):
-            self.ext_vel_force[n].setval(self.grav, self.dm - 1, 1, all=True)
+            self.ext_vel_force[n].setval(self.grav, self.grav_dir, 1, all=True)
         self.fill_state_ghosts()                                                  # regrid.f90:252-254
         for n in range(NL):
             self.unew[n].copy_c(0, self.uold[n], 0, self.dm, 3)
             self.snew[n].copy_c(0, self.sold[n], 0, self.nscal, 3)
             self.p[n].fill_boundary()
         self.nregrids += 1
+
+    def slice2d(self, mfs):
+        """plane k = 0 of a per-level list of cell multifabs as level-domain arrays (nx << n, ny << n, nc), NaN outside the level's boxes: the 2-D answer of an extruded run"""
+        out = []
+        for n, mf in enumerate(mfs):
+            a = np.full(((self.ncs[0] << n), (self.ncs[1] << n), mf.nc), np.nan)
+            g = mf.ng
+            for li, gi in enumerate(self.local[n]):
+                lo, hi = self.boxes[n][gi]
+                if lo[2] != 0:
+                    continue
+                f = mf.to_numpy(li)
+                a[lo[0]:hi[0] + 1, lo[1]:hi[1] + 1, :] = f[g:f.shape[0] - g, g:f.shape[1] - g, g, :]
+            out.append(a)
+        return out
 
     def close(self):
         for lst in (self.uold, self.sold, self.unew, self.snew, self.gp, self.p, self.ext_vel_force, self.ext_scal_force):

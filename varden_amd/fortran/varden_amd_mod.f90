@@ -83,6 +83,10 @@ module varden_amd
      integer(c_int) function vdn_finalize() bind(C, name="vdn_finalize")
        import :: c_int
      end function
+     integer(c_int) function vdn_set_extruded_2d(on) bind(C, name="vdn_set_extruded_2d")   ! a 2-D problem as its z-uniform 3-D copy: velpred_2d's hi-x OUTLET rule
+       import :: c_int
+       integer(c_int), value :: on
+     end function
      type(c_ptr) function vdn_last_error() bind(C, name="vdn_last_error")
        import :: c_ptr
      end function

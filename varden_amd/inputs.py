@@ -41,7 +41,7 @@ def parse_namelist(text):
     return out
 
 
-def build(text, device=0, max_grid_size_cap=None, outdir="."):
+def build(text, device=0, max_grid_size_cap=None, outdir=".", extrude_nz=16):
     """the driver object for an inputs text: Varden (one level) or VardenAMR (max_levs > 1, grids from the tagged initial data);
     restart >= 0: grids and state from the checkpoint <outdir>/<check_base_name><restart:05d> (src/varden.f90:94-97)"""
     nl = dict(DEFAULTS)
@@ -83,8 +83,33 @@ def build(text, device=0, max_grid_size_cap=None, outdir="."):
                              max_levs=max(int(nl["max_levs"]), len(boxes)), max_grid_size=mgs, **common)
     if int(nl["max_levs"]) <= 1:
         return nl, Varden(n, phys, prm, prob_hi=prob_hi, decomp=decomp, **common)
-    if dm != 3 or len(set(n)) != 1 or any(p != 1.0 for p in prob_hi):
-        raise NotImplementedError("adaptive hierarchies: 3-D, cubic unit domain in this round")
+    if dm == 2:
+        # the 2-D inputs of exec/test (all four adaptive): the hierarchy runs as the z-uniform, z-periodic 3-D copy of the problem (driver.VardenAMR: extrude2d) --
+        # plane k = 0 of every field is the 2-D answer, plot files are those of the 3-D copy
+        if prob_hi[0] != 1.0 or abs(prob_hi[1] / n[1] - prob_hi[0] / n[0]) > 1e-15:
+            raise NotImplementedError("2-D hierarchies: prob_hi_x = 1 and square cells")
+        nz = int(extrude_nz)                                  # cells of level 0 along the periodic z of the copy (a multiple of the blocking factor)
+        prm3 = default_params(dm=3, nscal=int(nl["nscal"]), slope_order=int(nl["slope_order"]), use_minion=int(nl["use_minion"]),
+                              boussinesq=int(nl["boussinesq"]), stencil_order=int(nl["stencil_order"]), diffusion_type=int(nl["diffusion_type"]),
+                              verbose=int(nl["verbose"]), prob_type=int(nl["prob_type"]), visc_coef=float(nl["visc_coef"]),
+                              diff_coef=float(nl["diff_coef"]), cflfac=float(nl["cflfac"]), max_dt_growth=float(nl["max_dt_growth"]))
+        for name in ("u_bc", "v_bc", "rho_bc", "trac_bc"):
+            for d in range(2):
+                for sd in range(2):
+                    getattr(prm3, name)[d][sd] = getattr(prm, name)[d][sd]
+        base = None
+        if any(dc > 1 for dc in decomp[:2]) or nz > mgs:
+            bs = [n[0] // decomp[0], n[1] // decomp[1], min(nz, mgs)]
+            base = [((kx * bs[0], ky * bs[1], kz * bs[2]), ((kx + 1) * bs[0] - 1, (ky + 1) * bs[1] - 1, (kz + 1) * bs[2] - 1))
+                    for kz in range(nz // bs[2]) for ky in range(decomp[1]) for kx in range(decomp[0])]
+        levels = VardenAMR.tagged_grids(n, phys, prm3, prob_type=int(nl["prob_type"]), max_levs=int(nl["max_levs"]), buf_wid=abw, max_grid_size=mgs, device=device,
+                                        base_boxes=base, extrude2d=nz)
+        if not levels:
+            return nl, Varden(n, phys, prm, prob_hi=prob_hi, decomp=decomp, **common)
+        return nl, VardenAMR(n, levels[0], phys, params=prm3, finer_levels=levels[1:], regrid_int=int(nl["regrid_int"]), amr_buf_width=abw,
+                             max_levs=int(nl["max_levs"]), max_grid_size=mgs, base_boxes=base, extrude2d=nz, **common)
+    if len(set(n)) != 1 or any(p != 1.0 for p in prob_hi):
+        raise NotImplementedError("adaptive hierarchies: cubic unit domain in this round")
     # level 0 is cut by max_grid_size like every other level (boxarray_maxsize, src/initialize.f90:204-206)
     base = None
     if any(dc > 1 for dc in decomp):
@@ -99,10 +124,10 @@ def build(text, device=0, max_grid_size_cap=None, outdir="."):
                          max_levs=int(nl["max_levs"]), max_grid_size=mgs, base_boxes=base, **common)
 
 
-def run(text, nsteps=None, report=print, device=0, outdir="."):
+def run(text, nsteps=None, report=print, device=0, outdir=".", extrude_nz=16):
     """the time loop of src/varden.f90:237-371 for max_step steps (or until stop_time); plot / checkpoint files at step 0 of a fresh
     run and after every plot_int-th / chk_int-th step (:207-221, :349-361) under outdir"""
-    nl, G = build(text, device=device, outdir=outdir)
+    nl, G = build(text, device=device, outdir=outdir, extrude_nz=extrude_nz)
     max_step = int(nl["max_step"]) if nsteps is None else nsteps
     stop_time = float(nl["stop_time"])
     plot_int, chk_int = int(nl["plot_int"]), int(nl["chk_int"])

@@ -226,7 +226,7 @@ def plot_names(dm, nscal):
 
 def _domain(sim):
     lv = _sim_levels(sim)
-    n = sim.n if hasattr(sim, "n") else (sim.nc,) * 3
+    n = sim.n if hasattr(sim, "n") else getattr(sim, "ncs", None) or (sim.nc,) * 3
     return ((0, 0, 0), tuple(int(x) - 1 for x in n)), len(lv)
 
 
