@@ -515,6 +515,31 @@ int vo_ml_cc_solve_g(int nlev, const vo_level *const *lev, vo_fab **rh, vo_fab *
     for (int k = r->lo[2]; k <= r->hi[2]; k++) for (int j = r->lo[1]; j <= r->hi[1]; j++) for (int i = r->lo[0]; i <= r->hi[0]; i++)
       if (cvalid(&M[n], i, j, k) && (n == nlev - 1 || !covered_by(&M[n + 1], i, j, k))) bnorm = vo_nrm_acc(bnorm, VF(rh[n], i, j, k, 0));
   }
+  /* solvability of a singular system (no Dirichlet face, no alpha): velpred's per-box dead band (velpred.f90:215-226) can leave the two copies of a face shared by two
+   * boxes O(1e-9) apart, and div(umac) then does not sum to zero; a mean defect above 1e-11 of the norm is subtracted (varden_amd/csrc/amr.hip: composite_mean -- the
+   * same rule; the summation order differs, the test tolerances cover it) */
+  {
+    int singular = alpha == NULL;
+    for (int d = 0; d < 3; d++) for (int sd = 0; sd < 2; sd++) if (ellbc[0][d][sd] == VDN_BC_DIR) singular = 0;
+    if (singular && bnorm > 0.0) {
+      double total = 0.0;
+      for (int n = 0; n < nlev; n++) {
+        const vo_fab *r = &M[n].res; double lev = 0.0;
+        for (int k = r->lo[2]; k <= r->hi[2]; k++) for (int j = r->lo[1]; j <= r->hi[1]; j++) for (int i = r->lo[0]; i <= r->hi[0]; i++)
+          if (cvalid(&M[n], i, j, k) && (n == nlev - 1 || !covered_by(&M[n + 1], i, j, k))) lev = lev + VF(rh[n], i, j, k, 0);
+        total = total + lev * (dx[3 * n] * dx[3 * n + 1] * dx[3 * n + 2]);
+      }
+      double vol = dx[0] * dx[1] * dx[2];
+      for (int d = 0; d < 3; d++) vol = vol * (double)(pd[3 + d] - pd[d] + 1);
+      const double mean = total / vol;
+      if (fabs(mean) > 1.e-11 * bnorm)
+        for (int n = 0; n < nlev; n++) {
+          const vo_fab *r = &M[n].res;
+          for (int k = r->lo[2]; k <= r->hi[2]; k++) for (int j = r->lo[1]; j <= r->hi[1]; j++) for (int i = r->lo[0]; i <= r->hi[0]; i++)
+            if (cvalid(&M[n], i, j, k)) VF(rh[n], i, j, k, 0) = VF(rh[n], i, j, k, 0) - mean;
+        }
+    }
+  }
   int it = 0, conv = 0; double rn = 0.0;
   if (bnorm == 0.0) conv = 1;
   while (!conv) {

@@ -840,6 +840,77 @@ void mlcc_kept_purge(unsigned long uid) {
     if (uid == 0 || it->second->uid == uid) { keeper_free(&it->second->mem); delete it->second; it = g_mlcc_kept.erase(it); } else ++it;
   }
 }
+// ---- a singular composite system (no Dirichlet face, no alpha term) needs a right-hand side whose volume-weighted sum over the composite grid is zero.  The MAC
+// projection's is div(umac), a telescoping sum -- but the reference's velpred upwinds with a dead band eps = 1e-8 * (the BOX's own max |u|) (velpred.f90:215-226,
+// 1965-1980: decomposition-dependent by design), so two boxes can give their shared face values that differ by O(1e-9) where the normal velocity passes through zero -- a
+// periodic face on a symmetry plane of inputs_RayleighTaylor_2d -- and the residual then cannot fall below that defect (it sat at 1.3e-9 for 100 iterations, bit for
+// bit).  FBoxLib's solvers deal with singular systems themselves; here: when the mean defect exceeds 1e-11 of the right-hand side's norm it is subtracted (below that the
+// solve converges anyway and nothing is touched: every run that converged before keeps its bits).  The sums are deterministic: one workgroup per box with a fixed tree,
+// the boxes added on the host in order, ranks in rank order.
+struct SumD { FV a, mask; Range3 r; int has_mask; };
+__global__ void __launch_bounds__(256) kk_box_sums(const SumD *descs, double *partial) {
+  const SumD &D = descs[blockIdx.x];
+  const int nx = D.r.hi[0] - D.r.lo[0] + 1, ny = D.r.hi[1] - D.r.lo[1] + 1, nz = D.r.hi[2] - D.r.lo[2] + 1;
+  const long tot = (long)nx * ny * nz;
+  double acc = 0.0;
+  for (long t = threadIdx.x; t < tot; t += 256) {
+    const int i = D.r.lo[0] + (int)(t % nx), j = D.r.lo[1] + (int)((t / nx) % ny), k = D.r.lo[2] + (int)(t / ((long)nx * ny));
+    if (D.has_mask && fv_get(D.mask, i, j, k) != 0.0) continue;
+    acc = acc + fv_get(D.a, i, j, k);
+  }
+  __shared__ double sh[256];
+  sh[threadIdx.x] = acc;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) { if ((int)threadIdx.x < o) sh[threadIdx.x] = sh[threadIdx.x] + sh[threadIdx.x + o]; __syncthreads(); }
+  if (threadIdx.x == 0) partial[blockIdx.x] = sh[0];
+}
+struct add_const_K { FV a; double v; __device__ void cell(int i, int j, int k) const { fv_at(a, i, j, k) = fv_get(a, i, j, k) + v; } };
+// volume-weighted mean of rh over the cells of the composite grid (mask[n] != 0: covered by level n + 1), all ranks
+static double composite_mean(int L, vdn_multifab **rh, vdn_multifab **mask, const double *dx, const vdn_layout *la) {
+  hipStream_t st = ctx().stream;
+  double local = 0.0;
+  for (int n = 0; n < L; n++) {
+    const int nb = rh[n]->nfabs();
+    if (nb == 0) continue;
+    std::vector<SumD> v(nb);
+    for (int b = 0; b < nb; b++) { v[b].a = rh[n]->fabs[b]; v[b].has_mask = (n < L - 1 && mask[n]) ? 1 : 0; v[b].mask = v[b].has_mask ? mask[n]->fabs[b] : rh[n]->fabs[b]; v[b].r = valid_range(rh[n], b); }
+    const size_t mark = arena_mark();
+    SumD *d_desc = (SumD *)arena_alloc(sizeof(SumD) * nb);
+    double *d_part = (double *)arena_alloc(sizeof(double) * nb);
+    upload_staged(d_desc, v.data(), sizeof(SumD) * nb);
+    hipLaunchKernelGGL(kk_box_sums, dim3(nb), dim3(256), 0, st, (const SumD *)d_desc, d_part);
+    std::vector<double> h(nb);
+    HIPCHK(hipMemcpyAsync(h.data(), d_part, sizeof(double) * nb, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    arena_release(mark);
+    double lev = 0.0;
+    for (int b = 0; b < nb; b++) lev = lev + h[b];
+    local = local + lev * (dx[3 * n] * dx[3 * n + 1] * dx[3 * n + 2]);
+  }
+  double total = local;
+  if (comm_active()) {
+    const size_t mark = arena_mark();
+    const int nr = ctx().nranks;
+    double *d_all = (double *)arena_alloc(sizeof(double) * (nr + 1));
+    HIPCHK(hipMemcpyAsync(d_all + nr, &local, sizeof(double), hipMemcpyHostToDevice, st));
+    comm_allgather_dev(d_all + nr, d_all, 1);
+    std::vector<double> h(nr);
+    HIPCHK(hipMemcpyAsync(h.data(), d_all, sizeof(double) * nr, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    arena_release(mark);
+    total = 0.0;
+    for (int r = 0; r < nr; r++) total = total + h[r];
+  }
+  double vol = dx[0] * dx[1] * dx[2];
+  for (int d = 0; d < 3; d++) vol = vol * (double)(la->pd[0].hi[d] - la->pd[0].lo[d] + 1);
+  return total / vol;
+}
+static void add_constant(vdn_multifab *mf, double v) {
+  std::vector<std::pair<add_const_K, Range3>> w;
+  for (int b = 0; b < mf->nfabs(); b++) w.push_back({ add_const_K{ mf->fabs[b], v }, valid_range(mf, b) });
+  launch_cells(w, ctx().stream);
+}
+
 // rh, phi: [lev];  beta: [lev*3 + d];  dx: [lev*3 + d]
 // alpha: [lev] cell coefficients of (alpha - div beta grad), or nullptr.  The ghost cells of the incoming phi carry inhomogeneous
 // Dirichlet data (boundary-face values); they are moved into rh, which is modified
@@ -928,6 +999,14 @@ int ml_cc_solve(vdn_layout *la, vdn_multifab **rh, vdn_multifab **phi, vdn_multi
   comm_allreduce_max_dev(S.d_nrm, 1);
   const double bnorm = read_dev(S.d_nrm);
   const vdn_params &P = ctx().prm;
+  {   // solvability of a singular system (see composite_mean)
+    bool singular = !alpha;
+    for (int d = 0; d < 3 && singular; d++) for (int sd = 0; sd < 2; sd++) if (bct->ell_bc(0, 0, d, sd, bc_comp0) == VDN_BC_DIR) singular = false;
+    if (singular && bnorm > 0.0 && bnorm < HUGE_VAL) {
+      const double mean = composite_mean(L, rh, S.mask, dx, la);
+      if (fabs(mean) > 1.e-11 * bnorm) for (int n = 0; n < L; n++) add_constant(rh[n], -mean);
+    }
+  }
   int it = 0; bool conv = (bnorm == 0.0); double rn = 0.0;
   struct KeepGuard { CcKeep *k; ~KeepGuard() { cc_keep_free(k); } } keep_guard{ cc_keep_new() };      // freed on every exit, exceptions included
   CcKeep *coarse_keep = keep_guard.k;        // the level-0 multigrid hierarchy is built once for all FAC iterations
@@ -935,6 +1014,8 @@ int ml_cc_solve(vdn_layout *la, vdn_multifab **rh, vdn_multifab **phi, vdn_multi
   for (int d = 0; d < 3; d++) for (int s = 0; s < 2; s++) ebc0[d][s] = bct->ell_bc(0, 0, d, s, bc_comp0);
   while (!conv) {
     rn = composite_residual(S);
+    { static const bool trace = vdn_env("VDN_MLCC_TRACE") && atoi(vdn_env("VDN_MLCC_TRACE")) != 0;
+      if (trace) fprintf(stderr, "  ml_cc_solve: iteration %d, composite residual %.6e (right-hand side %.6e, target %.3e)\n", it, rn, bnorm, rel_eps * bnorm); }
     if (rn <= rel_eps * bnorm && bnorm < HUGE_VAL) { conv = true; break; }
     if (it >= max_iter || !(rn < HUGE_VAL) || !(bnorm < HUGE_VAL)) break;
     // one V-cycle over the levels in correction form (oracle: vo_ml_cc_solve).  Down, finest level first: e_n = 0, nu1 sweeps, t = res_n - A_n e_n,

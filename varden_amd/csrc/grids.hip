@@ -6,7 +6,7 @@
 // procedure below is ours:
 //   1. tags = tag_boxes(first component of `s`, level) on the valid cells of the level (the reference's thresholds);
 //   2. the tags are grown by amr_buf_width cells (probin.template:147-154) and clipped to the nesting region: the cells of the
-//      level that keep `nest` cells of the level between themselves and any cell outside it (domain boundaries do not count) --
+//      level that keep `nest` cells of the level between themselves and any cell outside it (domain boundaries do not count; a periodic face is no boundary: the maps wrap) --
 //      the coarse-fine interpolation of the finer level then always finds its parents on this level;
 //   3. Berger-Rigoutsos clustering on the lattice of cluster_blocking_factor^3 blocks: take the bounding box of the tagged
 //      blocks; accept it when tagged/total >= cluster_min_eff or it cannot be cut; otherwise cut it at a hole of the tag
@@ -38,8 +38,10 @@ __global__ void kk_fill_bytes(unsigned char *a, int n0, int n1, Range3 r) {
   THREAD_IJK(r)
   if (in_range) a[(size_t)i + (size_t)n0 * ((size_t)j + (size_t)n1 * (size_t)k)] = 1;
 }
-// box dilation (OR) or erosion (AND) by `width` cells in direction d; cells outside the domain do not take part
-__global__ void kk_sweep_bytes(const unsigned char *in, unsigned char *out, int n0, int n1, int n2, int d, int width, int dilate) {
+// box dilation (OR) or erosion (AND) by `width` cells in direction d; cells outside the domain do not take part, except across a periodic face, where the
+// map wraps (a refined box at a periodic face needs its parents' periodic images underneath it: without the wrap the nesting region ignored them and
+// inputs_RayleighTaylor_2d met an improperly nested level at its 31st regrid)
+__global__ void kk_sweep_bytes(const unsigned char *in, unsigned char *out, int n0, int n1, int n2, int d, int width, int dilate, int periodic) {
   const int i = (int)(blockIdx.x * blockDim.x + threadIdx.x), j = (int)(blockIdx.y * blockDim.y + threadIdx.y), k = (int)(blockIdx.z * blockDim.z + threadIdx.z);
   if (i >= n0 || j >= n1 || k >= n2) return;
   const size_t c = (size_t)i + (size_t)n0 * ((size_t)j + (size_t)n1 * (size_t)k);
@@ -47,8 +49,9 @@ __global__ void kk_sweep_bytes(const unsigned char *in, unsigned char *out, int 
   const int q = d == 0 ? i : (d == 1 ? j : k), nq = d == 0 ? n0 : (d == 1 ? n1 : n2);
   unsigned char v = dilate ? 0 : 1;
   for (int w = -width; w <= width; w++) {
-    if (q + w < 0 || q + w >= nq) continue;
-    const unsigned char x = in[(long)c + (long)w * (long)stride];
+    int ww = w;
+    if (q + w < 0 || q + w >= nq) { if (!periodic) continue; ww = ((q + w) % nq + nq) % nq - q; }
+    const unsigned char x = in[(long)c + (long)ww * (long)stride];
     if (dilate) v |= x; else v &= x;
   }
   out[c] = v;
@@ -134,7 +137,7 @@ extern "C" int vdn_make_new_grids(const vdn_multifab *s, int lev1, int buf_wid, 
   auto sweep = [&](unsigned char *&a, unsigned char *&tmp, int width, int dilate) {
     if (width <= 0) return;
     for (int d = 0; d < dm; d++) {
-      hipLaunchKernelGGL(kk_sweep_bytes, grid_for(whole_cells), dim3(64, 4, 1), 0, st, (const unsigned char *)a, tmp, n[0], n[1], n[2], d, width, dilate);
+      hipLaunchKernelGGL(kk_sweep_bytes, grid_for(whole_cells), dim3(64, 4, 1), 0, st, (const unsigned char *)a, tmp, n[0], n[1], n[2], d, width, dilate, la->pmask[d] ? 1 : 0);
       std::swap(a, tmp);
     }
   };

@@ -199,6 +199,7 @@ static const EnvSwitch g_switches[] = {
   { "VDN_ARENA_CHUNK_MB", "size of the physical chunks mapped into the arena's address range (default 1024)" },
   { "VDN_FIELD_CHUNK_MB", "size of the pooled physical chunks behind the state fields (default 64)" },
   { "VDN_FIELD_VMM", "0: every state field is one hipMalloc block (rounds 1-5) instead of pooled chunks mapped into its own address range" },
+  { "VDN_MLCC_TRACE", "1: the composite cell-centred solve prints its residual at every FAC iteration (stderr)" },
   { "VDN_NO_ROCTX", "do not bind the roctx library (no bl_prof ranges)" },
   { "VDN_POLL", "scalar read-back: 1 spin on the pinned sequence number, 0 hipStreamSynchronize; default: spin on one rank, synchronise on several" },
   { "VDN_NO_GRAPHS", "launch every multigrid cycle eagerly instead of replaying its hipGraph" },

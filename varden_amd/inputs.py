@@ -41,7 +41,7 @@ def parse_namelist(text):
     return out
 
 
-def build(text, device=0, max_grid_size_cap=None, outdir=".", extrude_nz=16):
+def build(text, device=0, max_grid_size_cap=None, outdir=".", extrude_nz=16, extrude_zbc=None):
     """the driver object for an inputs text: Varden (one level) or VardenAMR (max_levs > 1, grids from the tagged initial data);
     restart >= 0: grids and state from the checkpoint <outdir>/<check_base_name><restart:05d> (src/varden.f90:94-97)"""
     nl = dict(DEFAULTS)
@@ -107,7 +107,7 @@ def build(text, device=0, max_grid_size_cap=None, outdir=".", extrude_nz=16):
         if not levels:
             return nl, Varden(n, phys, prm, prob_hi=prob_hi, decomp=decomp, **common)
         return nl, VardenAMR(n, levels[0], phys, params=prm3, finer_levels=levels[1:], regrid_int=int(nl["regrid_int"]), amr_buf_width=abw,
-                             max_levs=int(nl["max_levs"]), max_grid_size=mgs, base_boxes=base, extrude2d=nz, **common)
+                             max_levs=int(nl["max_levs"]), max_grid_size=mgs, base_boxes=base, extrude2d=nz, extrude_zbc=extrude_zbc, **common)
     if len(set(n)) != 1 or any(p != 1.0 for p in prob_hi):
         raise NotImplementedError("adaptive hierarchies: cubic unit domain in this round")
     # level 0 is cut by max_grid_size like every other level (boxarray_maxsize, src/initialize.f90:204-206)
