@@ -87,7 +87,9 @@ MAIN = os.path.join(FDIR, "varden_main")
 
 
 @pytest.mark.parametrize("name,nsteps,nregrids", [("inputs_3d-regt", 6, 3), ("inputs_bubble_3d", 5, 3), ("inputs_advect_3d", 4, 2), ("inputs_RayleighTaylor_3d", 4, 4),
-                                                  ("inputs_vortextube_3d", 3, 0)])
+                                                  ("inputs_vortextube_3d", 3, 0),
+                                                  # round 6: the four 2-D inputs (all adaptive) as z-uniform copies on the 3-D machinery (varden_main.f90: extruded)
+                                                  ("inputs_2d-regt", 6, 3), ("inputs_bubble_2d", 5, 3), ("inputs_advect_2d", 4, 2), ("inputs_RayleighTaylor_2d", 4, 4)])
 def test_fortran_main_runs_the_regression_inputs_like_the_python_mirror(gpu, tmp_path, name, nsteps, nregrids):
     """varden_main.f90 -- the flow of src/varden.f90 in Fortran: &PROBIN namelist, level 0 cut by max_grid_size, refined levels
     from tag_boxes + make_new_grids, start-up sequence, time loop with regrid every regrid_int steps through fillpatch / ml_nodal_prolongation /

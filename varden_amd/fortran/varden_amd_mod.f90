@@ -60,7 +60,7 @@ module varden_amd
      type(c_ptr) :: h = c_null_ptr
   end type bc_tower
 
-  public :: varden_amd_initialize, varden_amd_finalize, probin_defaults
+  public :: varden_amd_initialize, varden_amd_finalize, probin_defaults, varden_amd_set_extruded_2d
   public :: ml_layout_build, ml_layout_destroy
   public :: bc_tower_build, bc_tower_destroy
   public :: multifab_build, multifab_build_edge, multifab_build_nodal, multifab_destroy, nfabs, get_box, dataptr, &
@@ -313,6 +313,12 @@ contains
     integer, intent(in) :: rank, nranks, device
     call chk(vdn_init(p, int(rank, c_int), int(nranks, c_int), int(device, c_int)), 'vdn_init')
   end subroutine varden_amd_initialize
+
+  ! the 3-D kernels run a z-uniform copy of a 2-D problem: velpred_2d's hi-x OUTLET rule (include/varden_amd.h: vdn_set_extruded_2d); after varden_amd_initialize
+  subroutine varden_amd_set_extruded_2d(on)
+    logical, intent(in) :: on
+    call chk(vdn_set_extruded_2d(merge(1_c_int, 0_c_int, on)), 'vdn_set_extruded_2d')
+  end subroutine varden_amd_set_extruded_2d
 
   subroutine varden_amd_finalize()
     call chk(vdn_finalize(), 'vdn_finalize')

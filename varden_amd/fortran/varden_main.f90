@@ -5,7 +5,9 @@
 ! runs the start-up sequence (initial projection varden.f90:126-138, ghost fills :165-178, first dt :186-199, pressure iterations :460-490) and
 ! the time loop (varden.f90:237-345: regrid every regrid_int steps :256-264 through src/regrid.f90:17-263 -- fillpatch, ml_nodal_prolongation,
 ! copies of the old data --, ghost fills, estdt over the levels, advance_timestep, new -> old) until max_step or stop_time.
-! Scope: dim_in = 3, a cubic unit domain (every 3-D input of exec/test), prob_type 1 .. 4 (src/initdata.f90:190-306), one rank; plot and checkpoint files stay with the
+! Scope: dim_in = 3, a cubic unit domain (every 3-D input of exec/test), prob_type 1 .. 4 (src/initdata.f90:190-306), one rank; dim_in = 2 (the four 2-D inputs of
+! exec/test, all adaptive): the problem runs as its z-uniform copy -- n_cellx x n_celly x 16 cells of level 0, periodic along z, gravity along y, initdata_2d on every
+! plane, velpred_2d's outlet rule (vdn_set_extruded_2d; DESIGN.md section 13): plane k = 0 is the 2-D answer.  Plot and checkpoint files stay with the
 ! Python mirror (varden_amd/plotfile.py).  The Python mirror of the same flow (varden_amd/inputs.py: run) sits on the same C-ABI: every step prints
 ! time, dt, max|u| and the boxes per level with 17 significant digits and tests/test_fortran_gpu.py compares the two step for step.
 program varden_main
@@ -41,6 +43,9 @@ program varden_main
   type(vdn_params) :: prm
   character(len=256) :: fname, arg
   integer :: un, ios, n, dm, press_comp, istep, lev, abw, mgs, nsteps_arg, nregrids
+  integer :: nn(3), gdir                                          ! cells of level 0 per direction; the component gravity acts on
+  logical :: extruded = .false.
+  integer, parameter :: NZ_EXT = 16                               ! cells of level 0 along z of the extruded copy of a 2-D problem
   integer :: phys_bc(3, 2)
   real(dp_t) :: dx(MAXL, 3), dt, dtold, dtlev, time, umax
   type(vdn_box), allocatable :: newb(:)
@@ -59,9 +64,17 @@ program varden_main
      call get_command_argument(2, arg); read(arg, *) nsteps_arg
   end if
   if (nsteps_arg >= 0) max_step = nsteps_arg
-  if (dim_in /= 3) stop 'varden_main: dim_in = 3 only (the 2-D path is one level, one box: varden_amd/driver.py)'
-  if (n_cellx /= n_celly .or. n_cellx /= n_cellz .or. prob_hi_x /= 1.d0 .or. prob_hi_y /= 1.d0 .or. prob_hi_z /= 1.d0) &
-       stop 'varden_main: cubic unit domain only'
+  if (dim_in == 2) then                                         ! the z-uniform copy of the 2-D problem (see the header)
+     if (prob_hi_x /= 1.d0 .or. abs(prob_hi_y / n_celly - prob_hi_x / n_cellx) > 1.d-15) stop 'varden_main: dim_in = 2: prob_hi_x = 1 and square cells'
+     if (prob_type < 1 .or. prob_type > 3) stop 'varden_main: dim_in = 2: prob_type 1 .. 3 (src/initdata.f90:127-185)'
+     extruded = .true.
+     n_cellz = NZ_EXT; bcz_lo = PERIODIC; bcz_hi = PERIODIC
+     dim_in = 3
+  else
+     if (dim_in /= 3) stop 'varden_main: dim_in = 2 or 3'
+     if (n_cellx /= n_celly .or. n_cellx /= n_cellz .or. prob_hi_x /= 1.d0 .or. prob_hi_y /= 1.d0 .or. prob_hi_z /= 1.d0) &
+          stop 'varden_main: cubic unit domain only'
+  end if
   if (prob_type < 1 .or. prob_type > 4) stop 'varden_main: prob_type 1 .. 4 (src/initdata.f90)'
   if (max_levs > MAXL) stop 'varden_main: at most 4 levels'
 
@@ -71,7 +84,10 @@ program varden_main
   prm%visc_coef = visc_coef; prm%diff_coef = diff_coef; prm%cflfac = cflfac; prm%max_dt_growth = max_dt_growth
   prm%u_bc = transpose(u_bc); prm%v_bc = transpose(v_bc); prm%w_bc = transpose(w_bc); prm%rho_bc = transpose(rho_bc); prm%trac_bc = transpose(trac_bc)
   call varden_amd_initialize(prm, 0, 1, 0)
+  if (extruded) call varden_amd_set_extruded_2d(.true.)
   n = n_cellx; dm = 3; press_comp = dm + nscal + 1
+  nn = (/ n_cellx, n_celly, n_cellz /)
+  gdir = merge(2, 3, extruded)
   mgs = max_grid_size
   abw = max(amr_buf_width, regrid_int, 1)                       ! probin.template:147-154
   phys_bc(1,:) = (/ bcx_lo, bcx_hi /); phys_bc(2,:) = (/ bcy_lo, bcy_hi /); phys_bc(3,:) = (/ bcz_lo, bcz_hi /)
@@ -181,16 +197,16 @@ contains
   ! level 0 cut by max_grid_size (boxarray_maxsize, initialize.f90:204-206): equal boxes, x fastest
   subroutine base_boxes(G)
     type(hier), intent(inout) :: G
-    integer :: nd, bs, kx, ky, kz, q
+    integer :: nd(3), bs(3), kx, ky, kz, q
     if (.not. allocated(G%bx)) allocate(G%bx(MAXB, MAXL))
-    nd = max(1, (n + mgs - 1) / mgs); bs = n / nd
+    nd = max(1, (nn + mgs - 1) / mgs); bs = nn / nd
     q = 0
-    do kz = 0, nd - 1
-       do ky = 0, nd - 1
-          do kx = 0, nd - 1
+    do kz = 0, nd(3) - 1
+       do ky = 0, nd(2) - 1
+          do kx = 0, nd(1) - 1
              q = q + 1
-             G%bx(q, 1)%lo = (/ kx * bs, ky * bs, kz * bs /)
-             G%bx(q, 1)%hi = (/ (kx + 1) * bs - 1, (ky + 1) * bs - 1, (kz + 1) * bs - 1 /)
+             G%bx(q, 1)%lo = (/ kx * bs(1), ky * bs(2), kz * bs(3) /)
+             G%bx(q, 1)%hi = (/ (kx + 1) * bs(1) - 1, (ky + 1) * bs(2) - 1, (kz + 1) * bs(3) - 1 /)
           end do
        end do
     end do
@@ -208,7 +224,7 @@ contains
     allocate(flat(tot), owner(tot))
     q = 0
     do l = 1, G%nlev
-       pd(l)%lo = 0; pd(l)%hi = n * 2**(l - 1) - 1
+       pd(l)%lo = 0; pd(l)%hi = nn * 2**(l - 1) - 1
        flat(q + 1:q + G%nb(l)) = G%bx(1:G%nb(l), l)
        q = q + G%nb(l)
     end do
@@ -309,6 +325,18 @@ contains
              y = dx(l,2) * (j + 0.5d0)
              do i = lo(1), hi(1)
                 x = dx(l,1) * (i + 0.5d0)
+                if (extruded) then                          ! initdata_2d (src/initdata.f90:127-185; densfact = 2) on every plane
+                   select case (prob_type)
+                   case (1, 2)
+                      dist = sqrt((x - 0.5d0)**2 + (y - 0.5d0 * nn(2) / dble(nn(1)))**2)
+                      r = 1.d0 + 0.5d0 * (2.d0 - 1.d0) * (1.d0 - tanh(30.d0 * (dist - 0.1d0)))
+                      s0(i,j,k,1) = r
+                      if (nscal > 1) s0(i,j,k,2) = r
+                   case (3)
+                      s0(i,j,k,1) = 1.d0 + 0.5d0 + 0.5d0 * tanh((y - 0.5d0 - pert(x)) / 0.01d0)
+                   end select
+                   cycle
+                end if
                 select case (prob_type)
                 case (1, 2)
                    dist = sqrt((x - 0.5d0)**2 + (y - 0.5d0)**2 + (z - 0.5d0)**2)
@@ -343,7 +371,7 @@ contains
     do l = 1, H%nlev
        call multifab_build(unew(l), H%mla, l, dm, 3); call multifab_build(snew(l), H%mla, l, nscal, 3)
        call multifab_build(ext_vel_force(l), H%mla, l, dm, 1); call multifab_build(ext_scal_force(l), H%mla, l, nscal, 1)
-       call setval(ext_vel_force(l), grav, dm, 1, all=.true.)          ! varden.f90:428-429
+       call setval(ext_vel_force(l), grav, gdir, 1, all=.true.)        ! varden.f90:428-429 (the extruded copy of a 2-D problem: along y)
     end do
   end subroutine make_temporaries
 
