@@ -343,3 +343,34 @@ def test_2d_inputs_of_the_reference_run_as_extruded_hierarchies(gpu, tmp_path, i
     assert fin.any() and (np.abs(rho[0][..., 0] - (1.0 if inputs_name != "inputs_RayleighTaylor_2d" else rho[0][0, 0, 0])) > 0.05).any()
     assert any(f.startswith(str(tmp_path)) for f in G.files_written)
     G.close()
+
+
+def test_extruded_hierarchy_follows_the_fine_2d_run(gpu):
+    """No 2-D oracle for hierarchies exists; the physical check beside the parity chain above: the bubble on a 32^2 base with its tagged region refined (two levels, viscous, walls), run as
+    the extruded copy, against the ONE-level 2-D runs (dim2.hip) at 32^2 and at 64^2 with the same fixed dt, twenty steps.  Where the hierarchy is refined it must follow the fine
+    run: u to 1e-3 (0.3 % of max|u|; the coarse run is 2.5e-2 away on the same cells), rho to 1e-4 (coarse run: 0.16) -- measured 3.3e-4 and 1.1e-5 (tools/probes/extruded2d_vs_fine_probe.py)."""
+    from varden_amd import driver
+    from varden_amd.capi import default_params
+    bc = [[15, 15], [15, 15]]
+    dt, nsteps = 2.0e-3, 20
+    runs = {}
+    for n in (32, 64):
+        G = driver.Varden(n, [bc[0], bc[1], [0, 0]], default_params(dm=2, cflfac=0.9, visc_coef=0.001), prob_type=1, init_shrink=1.0, init_iter=1, fixed_dt=dt)
+        for _ in range(nsteps):
+            G.step()
+        runs[n] = (G.gather_valid(G.uold[0])[:, :, 0, :], G.gather_valid(G.sold[0])[:, :, 0, :])
+        G.close()
+    levels = driver.VardenAMR.tagged_grids((32, 32), bc, default_params(cflfac=0.9, visc_coef=0.001), prob_type=1, max_levs=2, max_grid_size=32, extrude2d=8)
+    G = driver.VardenAMR((32, 32), levels[0], bc, params=default_params(cflfac=0.9, visc_coef=0.001), prob_type=1, init_shrink=1.0, init_iter=1, do_initial_projection=1,
+                         extrude2d=8, fixed_dt=dt)
+    for _ in range(nsteps):
+        G.step()
+    u, s = G.slice2d(G.uold), G.slice2d(G.sold)
+    G.close()
+    m = np.isfinite(u[1][..., 0])
+    assert 0.1 * m.size < m.sum() < 0.6 * m.size
+    (uf, sf), (uc, sc) = runs[64], runs[32]
+    up = lambda a: np.repeat(np.repeat(a, 2, axis=0), 2, axis=1)      # noqa: E731
+    du, dr = np.abs(u[1][..., :2][m] - uf[m]).max(), np.abs(s[1][..., 0][m] - sf[..., 0][m]).max()
+    cu, cr = np.abs(up(uc)[m] - uf[m]).max(), np.abs(up(sc)[..., 0][m] - sf[..., 0][m]).max()
+    assert du <= 1e-3 and dr <= 1e-4 and du <= 0.05 * cu and dr <= 0.01 * cr, (du, dr, cu, cr)
