@@ -458,7 +458,7 @@ def main():
         names = (["r06_smoother_split_pmc.json", "r05_smoother_split_pmc.json"] if split else
                  ["r05_smoother_rho_pmc.json", "r04_smoother_rho_pmc.json", "r03_smoother_rho_pmc.json", "r02_smoother_rho_pmc.json", "r01_smoother_rho_pmc.json"])
         if pn == 256 and world == 1 and not args.no_pmc:
-            got = measure_pass_traffic("kk_cc_gsrb_rho_split<0>" if split else "kk_cc_gsrb_rho_pair(")
+            got = measure_pass_traffic("kk_cc_gsrb_rho_split<0, false>" if split else "kk_cc_gsrb_rho_pair(")
             if got:
                 traffic = got[0]
                 traffic_source = ("measured in this run: rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE, one child run of tools/smoother_probe.py 256 20 each (the timed probe's "
@@ -472,7 +472,7 @@ def main():
         # the bytes of the entries a pass touches in this layout: phi own r + w, rhs own, rho both colours, phi other colour = 48 B per UPDATED cell
         # = 24 B per cell of the level (split); the interleaved pass cannot avoid whole lines of phi and rhs: 34 B per cell of the level
         touched = (24.0 if split else 34.0) * ncell
-        kname = ("kk_cc_gsrb_rho_split<0> (MAC-MG red-black GS colour pass, %d^3, the level stored BY COLOUR; beta recomputed from rho, two cells per thread. "
+        kname = ("kk_cc_gsrb_rho_split<0, false> (MAC-MG red-black GS colour pass, %d^3, the level stored BY COLOUR; beta recomputed from rho, two cells per thread. "
                  "`achieved` / `frac` are BANDWIDTH: the HBM bytes the counters saw per launch / launch time (/ peak); without counters the bytes of the entries the pass "
                  "touches, 24 B per cell of the level.  SURVEY section 8(d)'s 48 B per cell of the level (stored face coefficients, whole lines of phi and rhs) is what "
                  "an interleaved stored-coefficient pass would move for the same work: `model_48B_rate` / `frac_model` price the pass that way -- a work rate, NOT bandwidth, "

@@ -12,7 +12,7 @@ def row(prefix):
             return {"grid": f[0], "calls": int(f[1]), **{n: float(v) for n, v in zip(names, f[2:])}}
     raise SystemExit("no line for " + prefix)
 pair = len(sys.argv) > 3 and sys.argv[3] == "pair"
-kname = "kk_cc_gsrb_rho_pair" if pair else "void kk_cc_gsrb_rho_split<0>"
+kname = "kk_cc_gsrb_rho_pair" if pair else "void kk_cc_gsrb_rho_split<0, false>"
 k, c = row(kname), row("k_copy")
 n = 256
 out = {

@@ -872,19 +872,25 @@ static double composite_mean(int L, vdn_multifab **rh, vdn_multifab **mask, cons
   for (int n = 0; n < L; n++) {
     const int nb = rh[n]->nfabs();
     if (nb == 0) continue;
-    std::vector<SumD> v(nb);
-    for (int b = 0; b < nb; b++) { v[b].a = rh[n]->fabs[b]; v[b].has_mask = (n < L - 1 && mask[n]) ? 1 : 0; v[b].mask = v[b].has_mask ? mask[n]->fabs[b] : rh[n]->fabs[b]; v[b].r = valid_range(rh[n], b); }
+    std::vector<SumD> v;                                   // a descriptor (= a workgroup) per slab of at most ~64 K cells of a box: the one 256^3 box of a base level is 256 of them
+    for (int b = 0; b < nb; b++) {
+      SumD q; q.a = rh[n]->fabs[b]; q.has_mask = (n < L - 1 && mask[n]) ? 1 : 0; q.mask = q.has_mask ? mask[n]->fabs[b] : rh[n]->fabs[b]; q.r = valid_range(rh[n], b);
+      const long plane = (long)(q.r.hi[0] - q.r.lo[0] + 1) * (q.r.hi[1] - q.r.lo[1] + 1);
+      const int kper = (int)std::max<long>(1, 65536 / plane), k0 = q.r.lo[2], k1 = q.r.hi[2];
+      for (int k = k0; k <= k1; k += kper) { SumD c = q; c.r.lo[2] = k; c.r.hi[2] = std::min(k + kper - 1, k1); v.push_back(c); }
+    }
+    const int nd = (int)v.size();
     const size_t mark = arena_mark();
-    SumD *d_desc = (SumD *)arena_alloc(sizeof(SumD) * nb);
-    double *d_part = (double *)arena_alloc(sizeof(double) * nb);
-    upload_staged(d_desc, v.data(), sizeof(SumD) * nb);
-    hipLaunchKernelGGL(kk_box_sums, dim3(nb), dim3(256), 0, st, (const SumD *)d_desc, d_part);
-    std::vector<double> h(nb);
-    HIPCHK(hipMemcpyAsync(h.data(), d_part, sizeof(double) * nb, hipMemcpyDeviceToHost, st));
+    SumD *d_desc = (SumD *)arena_alloc(sizeof(SumD) * nd);
+    double *d_part = (double *)arena_alloc(sizeof(double) * nd);
+    upload_staged(d_desc, v.data(), sizeof(SumD) * nd);
+    hipLaunchKernelGGL(kk_box_sums, dim3(nd), dim3(256), 0, st, (const SumD *)d_desc, d_part);
+    std::vector<double> h(nd);
+    HIPCHK(hipMemcpyAsync(h.data(), d_part, sizeof(double) * nd, hipMemcpyDeviceToHost, st));
     HIPCHK(hipStreamSynchronize(st));
     arena_release(mark);
     double lev = 0.0;
-    for (int b = 0; b < nb; b++) lev = lev + h[b];
+    for (int b = 0; b < nd; b++) lev = lev + h[b];
     local = local + lev * (dx[3 * n] * dx[3 * n + 1] * dx[3 * n + 2]);
   }
   double total = local;
