@@ -70,9 +70,13 @@ def build(text, device=0, max_grid_size_cap=None, outdir=".", extrude_nz=16, ext
         rs = dict(restart=chk, restart_step=int(nl["restart"]))
         if chk["nlevs"] == 1:
             return nl, Varden(n, phys, prm, prob_hi=prob_hi, decomp=decomp, **common, **rs)
+        if dm == 2:
+            raise NotImplementedError("restart of a 2-D hierarchy (an extruded copy, DESIGN section 13): not in this round -- its checkpoint is the 3-D copy's")
         return nl, VardenAMR(n[0], chk["boxes"][1], phys, params=prm, finer_levels=chk["boxes"][2:], base_boxes=chk["boxes"][0],
                              regrid_int=int(nl["regrid_int"]), amr_buf_width=abw, max_levs=int(nl["max_levs"]), max_grid_size=mgs, **common, **rs)
     if nl["fixed_grids"]:                                   # initialize_with_fixed_grids, src/initialize.f90:93-150
+        if dm == 2:
+            raise NotImplementedError("fixed_grids with dim_in = 2: not in this round (adaptive 2-D hierarchies run as extruded copies)")
         if dm != 3 or len(set(n)) != 1 or any(p != 1.0 for p in prob_hi):
             raise NotImplementedError("hierarchies: 3-D, cubic unit domain in this round")
         domains, boxes = plotfile.read_grids(os.path.join(outdir, str(nl["fixed_grids"])))
