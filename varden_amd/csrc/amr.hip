@@ -350,7 +350,7 @@ void ml_create_umac_grown(vdn_multifab *fine, const vdn_multifab *crse, int dir)
   const SrcView Cv = make_view(crse, coarsened_footprints(fine, fine->ng, dir, 0), level_owner(fine), 0, 1, VT_COARSEN_0 + 4 * (dir + 1) + fine->ng * 64);
   Cv.refresh();
   GraphKey key; key.put(0x7204); key_mf(key, fine); key_mf(key, crse); key.put(dir);
-  if (kept_sets_enabled()) {
+  if (kept_family_enabled(2)) {
     KeptSet *k0 = kept_find(key.h), *k1 = kept_find(key.h + 1);
     if (k0 && k1) {
       if (k0->nbox) hipLaunchKernelGGL((kk_batched<GrownB, int>), dim3(k0->tot), dim3(64, 4, 1), 0, ctx().stream, (const GrownB *)k0->d_args, (const int *)k0->d_start, k0->nbox, 0, (double *)nullptr);
@@ -978,7 +978,7 @@ int ml_cc_solve(vdn_layout *la, vdn_multifab **rh, vdn_multifab **phi, vdn_multi
   }
   // the sets of the iteration: kept across solves under the key (a hit skips every pair loop and upload), else built into the arena
   MLCC S_local; MLCC *Sp = &S_local; bool hit = false; MLCCKept *kept = nullptr;
-  if (kept_sets_enabled()) {
+  if (kept_family_enabled(4)) {
     auto itk = g_mlcc_kept.find(key.h);
     if (itk != g_mlcc_kept.end()) { kept = itk->second; hit = true; }
     else { if ((int)g_mlcc_kept.size() >= kept_bound(64)) { HIPCHK(hipStreamSynchronize(st)); mlcc_kept_purge(0); } kept = new MLCCKept; kept->uid = la->uid; g_mlcc_kept[key.h] = kept; }

@@ -2278,7 +2278,7 @@ static void ml_nd_prolong(MLND &S, int n, vdn_multifab *dst, vdn_multifab *src, 
   GraphKey gk; gk.put(0x7401); gk.put(S.base_key); gk.put(n); nd_key_mf(gk, dst); nd_key_mf(gk, src); gk.put(mode == 0 ? 0 : 1);
   gk.put((const void *)(S.slave[n] ? S.slave[n]->base : nullptr)); gk.put((const void *)(S.own[n - 1] ? S.own[n - 1]->base : nullptr));
   NdProKept *kept = nullptr;
-  if (kept_sets_enabled()) {
+  if (kept_family_enabled(8)) {
     auto itk = g_ndpro_kept.find(gk.h);
     if (itk != g_ndpro_kept.end()) { PS.s = itk->second->s; PS.s8 = itk->second->s8; PS.s.run(mode, (double *)nullptr, ctx().stream); PS.s8.run(mode, (double *)nullptr, ctx().stream); return; }
     kept = new NdProKept; kept->uid = S.la->uid;     // (the table is bounded at the entry of ml_nd_solve: sets already bound to this solve must not be freed here)

@@ -200,6 +200,7 @@ static const EnvSwitch g_switches[] = {
   { "VDN_FIELD_CHUNK_MB", "size of the pooled physical chunks behind the state fields (default 64)" },
   { "VDN_FIELD_VMM", "0: every state field is one hipMalloc block (rounds 1-5) instead of pooled chunks mapped into its own address range" },
   { "VDN_MLCC_TRACE", "1: the composite cell-centred solve prints its residual at every FAC iteration (stderr)" },
+  { "VDN_KEEP_OFF", "mask of kept-descriptor families rebuilt at every call: 1 generic sets, 2 create_umac_grown, 4 composite cell-centred solve, 8 nodal prolongation" },
   { "VDN_NO_ROCTX", "do not bind the roctx library (no bl_prof ranges)" },
   { "VDN_POLL", "scalar read-back: 1 spin on the pinned sequence number, 0 hipStreamSynchronize; default: spin on one rank, synchronise on several" },
   { "VDN_NO_GRAPHS", "launch every multigrid cycle eagerly instead of replaying its hipGraph" },
@@ -691,6 +692,8 @@ void mf_temp_free(vdn_multifab *mf) {
 // descriptor sets kept across calls (vdn_internal.h)
 static std::map<unsigned long long, KeptSet> g_kept;
 bool kept_sets_enabled() { static const bool on = !(vdn_env("VDN_KEEP_SETS") && atoi(vdn_env("VDN_KEEP_SETS")) == 0); return on; }
+// VDN_KEEP_OFF: a mask of families switched off one by one (1 the generic launch_batched_kept sets, 2 create_umac_grown, 4 the composite cell-centred solve, 8 the nodal prolongation)
+bool kept_family_enabled(int fam) { static const int off = vdn_env("VDN_KEEP_OFF") ? atoi(vdn_env("VDN_KEEP_OFF")) : 0; return kept_sets_enabled() && !(off & fam); }
 KeptSet *kept_find(unsigned long long key) { auto it = g_kept.find(key); return it == g_kept.end() ? nullptr : &it->second; }
 static void kept_free(KeptSet &k) { if (k.d_args) HIPCHK(hipFree(k.d_args)); if (k.d_start) HIPCHK(hipFree(k.d_start)); k.d_args = nullptr; k.d_start = nullptr; }
 static KeeperMem *g_keeper = nullptr;

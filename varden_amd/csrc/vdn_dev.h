@@ -252,7 +252,7 @@ static inline void launch_batched(std::vector<A> &v, P extra, double *nrm, int k
 // the same launch from a descriptor set kept on the device under `key` (vdn_internal.h): build(v) fills the descriptors only when the key is new
 template <class A, class P, class F>
 static inline void launch_batched_kept(unsigned long long key, unsigned long uid, F &&build, P extra, double *nrm, int kz, hipStream_t st) {
-  if (!kept_sets_enabled()) { std::vector<A> v; build(v); launch_batched(v, extra, nrm, kz, st); return; }
+  if (!kept_family_enabled(1)) { std::vector<A> v; build(v); launch_batched(v, extra, nrm, kz, st); return; }
   KeptSet *k = kept_find(key);
   if (!k) {
     std::vector<A> v; build(v);
