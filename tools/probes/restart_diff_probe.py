@@ -36,3 +36,18 @@ for tag, H in (("uninterrupted", A_hist), ("restarted", B_hist)):
             g = 3 if k[0] in ("u", "s") else 1
             h.update(np.ascontiguousarray(H[st][0][k][g:-g, g:-g, g:-g]).tobytes())
         print("hash of the valid cells, %s step %d: %s" % (tag, st, h.hexdigest()[:16]))
+
+# bitwise: where do the two runs first differ in BITS (signs of zeros included)?
+for st in sorted(B_hist):
+    a, b = A_hist[st], B_hist[st]
+    rep_ = []
+    for k in sorted(a[0]):
+        g = 3 if k[0] in ("u", "s") else 1
+        x, y = a[0][k][g:-g, g:-g, g:-g], b[0][k][g:-g, g:-g, g:-g]
+        xb, yb = np.ascontiguousarray(x).view(np.uint64), np.ascontiguousarray(y).view(np.uint64)
+        nd = int((xb != yb).sum())
+        if nd:
+            idx = np.argwhere(xb != yb)[0]
+            rep_.append("%s lev %d box %d: %d entries differ in bits (first at %s: %r vs %r)" % (k[0], k[1], k[2], nd, tuple(idx), x[tuple(idx)], y[tuple(idx)]))
+    print("step %d: %d arrays differ in bits" % (st, len(rep_)))
+    for r in rep_[:6]: print("    " + r)

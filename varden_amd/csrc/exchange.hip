@@ -440,6 +440,7 @@ void xplan_run(XPlan *P, hipStream_t st) {
   if (!P->local.empty())
     hipLaunchKernelGGL(k_xcopy, dim3((unsigned)P->lchunks), dim3(256), 0, st, P->d_local, P->d_lstart, (int)P->local.size(), nc);
   if (P->nunpack_all) hipLaunchKernelGGL(k_xunpack_all, dim3(XPACK_WG * (unsigned)P->nunpack_all), dim3(256), 0, st, P->d_unpack_all, nc);
+  dbg_sync(4);
 }
 
 // ====================================================================================================

@@ -30,6 +30,7 @@ static bool arena_poison() { static const bool p = vdn_env("VDN_ARENA_POISON") &
 // the descriptors of arena temporaries (mf_temp) that nobody freed: they die with the arena contents they describe
 static std::vector<vdn_multifab *> g_temp_mfs;
 void arena_reset() {
+  dbg_sync(16);
   for (vdn_multifab *m : g_temp_mfs) delete m;
   g_temp_mfs.clear();
   if (arena_poison() && g_ctx.arena && g_ctx.arena_peak > 0) HIPCHK(hipMemsetAsync(g_ctx.arena, 0xFF, std::min(g_ctx.arena_peak + (size_t)(64 << 20), g_ctx.arena_bytes), g_ctx.stream));
@@ -70,6 +71,9 @@ static void arena_map_to(size_t bytes) {                   // c.arena_bytes (= m
     if (e == hipSuccess) e = hipMemSetAccess(c.arena + c.arena_bytes, ARENA_CHUNK, &acc, 1);
     if (e != hipSuccess) { (void)hipGetLastError(); (void)hipMemRelease(h); vdn_fail("arena: mapping a chunk at offset %zu failed: %s", c.arena_bytes, hipGetErrorString(e)); }
     g_arena_chunks.push_back(h);
+    // fresh device memory holds whatever its last owner left: a temporary that is read where nobody wrote (a ghost entry multiplied by a zero coefficient ...) would make
+    // a run differ from process to process.  Zeros -- or, under VDN_ARENA_POISON, the NaNs that released arena bytes get, so that such a read fails loudly
+    HIPCHK(hipMemsetAsync(c.arena + c.arena_bytes, arena_poison() ? 0xFF : 0x00, ARENA_CHUNK, c.stream));
     c.arena_bytes += ARENA_CHUNK;
   }
 }
@@ -201,6 +205,7 @@ static const EnvSwitch g_switches[] = {
   { "VDN_FIELD_VMM", "0: every state field is one hipMalloc block (rounds 1-5) instead of pooled chunks mapped into its own address range" },
   { "VDN_MLCC_TRACE", "1: the composite cell-centred solve prints its residual at every FAC iteration (stderr)" },
   { "VDN_KEEP_OFF", "mask of kept-descriptor families rebuilt at every call: 1 generic sets, 2 create_umac_grown, 4 composite cell-centred solve, 8 nodal prolongation" },
+  { "VDN_SYNC_POINTS", "mask of points that synchronise the device (race hunting): 1 after every batched launch, 2 after every staged upload, 4 after every exchange, 8 before a scalar read-back, 16 at arena_reset, 32 after launch_cells" },
   { "VDN_NO_ROCTX", "do not bind the roctx library (no bl_prof ranges)" },
   { "VDN_POLL", "scalar read-back: 1 spin on the pinned sequence number, 0 hipStreamSynchronize; default: spin on one rank, synchronise on several" },
   { "VDN_NO_GRAPHS", "launch every multigrid cycle eagerly instead of replaying its hipGraph" },
@@ -322,6 +327,7 @@ const double *read_scalars(const double *dev, int n) {
   static const int poll_env = vdn_env("VDN_POLL") ? atoi(vdn_env("VDN_POLL")) : -1;
   const bool poll = poll_env >= 0 ? poll_env != 0 : c.nranks == 1;
   ++seq;
+  dbg_sync(8);
   hipLaunchKernelGGL(k_publish, dim3(1), dim3(64), 0, c.stream, c.h_scal_dev, dev, n, seq);
   if (poll && !g_capturing_now()) {
     volatile unsigned long long *flag = reinterpret_cast<volatile unsigned long long *>(c.h_scal + 64);
@@ -693,6 +699,7 @@ void mf_temp_free(vdn_multifab *mf) {
 static std::map<unsigned long long, KeptSet> g_kept;
 bool kept_sets_enabled() { static const bool on = !(vdn_env("VDN_KEEP_SETS") && atoi(vdn_env("VDN_KEEP_SETS")) == 0); return on; }
 // VDN_KEEP_OFF: a mask of families switched off one by one (1 the generic launch_batched_kept sets, 2 create_umac_grown, 4 the composite cell-centred solve, 8 the nodal prolongation)
+void dbg_sync(int bit) { static const int m = vdn_env("VDN_SYNC_POINTS") ? atoi(vdn_env("VDN_SYNC_POINTS")) : 0; if (m & bit) HIPCHK(hipDeviceSynchronize()); }
 bool kept_family_enabled(int fam) { static const int off = vdn_env("VDN_KEEP_OFF") ? atoi(vdn_env("VDN_KEEP_OFF")) : 0; return kept_sets_enabled() && !(off & fam); }
 KeptSet *kept_find(unsigned long long key) { auto it = g_kept.find(key); return it == g_kept.end() ? nullptr : &it->second; }
 static void kept_free(KeptSet &k) { if (k.d_args) HIPCHK(hipFree(k.d_args)); if (k.d_start) HIPCHK(hipFree(k.d_start)); k.d_args = nullptr; k.d_start = nullptr; }
@@ -767,6 +774,7 @@ void upload_staged(void *dst, const void *src, size_t bytes) {
   memcpy(ring + head, src, bytes);
   HIPCHK(hipMemcpyAsync(dst, ring + head, bytes, hipMemcpyHostToDevice, c.stream));
   head += need;
+  dbg_sync(2);
 }
 
 extern "C" int vdn_multifab_destroy(vdn_multifab *mf) {

@@ -248,6 +248,7 @@ static inline void launch_batched(std::vector<A> &v, P extra, double *nrm, int k
   upload_staged(d_args, v.data(), sizeof(A) * v.size());
   upload_staged(d_start, start.data(), sizeof(int) * v.size());
   hipLaunchKernelGGL((kk_batched<A, P>), dim3(tot), dim3(64, 4, 1), 0, st, (const A *)d_args, (const int *)d_start, (int)v.size(), extra, nrm);
+  dbg_sync(1);
 }
 // the same launch from a descriptor set kept on the device under `key` (vdn_internal.h): build(v) fills the descriptors only when the key is new
 template <class A, class P, class F>
@@ -263,6 +264,7 @@ static inline void launch_batched_kept(unsigned long long key, unsigned long uid
   }
   if (k->nbox == 0) return;
   hipLaunchKernelGGL((kk_batched<A, P>), dim3(k->tot), dim3(64, 4, 1), 0, st, (const A *)k->d_args, (const int *)k->d_start, k->nbox, extra, nrm);
+  dbg_sync(1);
 }
 // ---- cell kernels: one body, launched for one box or batched over the boxes of a level --------------------------------------------
 // struct K { <arguments>; __device__ void cell(int i, int j, int k) const { ... } };   then   launch_cells(vector of (K, range))
@@ -290,6 +292,7 @@ template <class K> static inline void launch_cells(const std::vector<std::pair<K
   std::vector<CellB<K>> b(v.size());
   for (size_t i = 0; i < v.size(); i++) { b[i].r = v[i].second; b[i].a = v[i].first; }
   launch_batched(b, 0, (double *)nullptr, 0, st);
+  dbg_sync(32);
 }
 // a descriptor set that is uploaded once and launched many times (the per-iteration kernels of the composite solves)
 template <class A> struct BatchSet {
@@ -313,6 +316,7 @@ template <class A> struct BatchSet {
   template <class P> void run(P extra, double *nrm, hipStream_t st) const {
     if (nbox == 0) return;
     hipLaunchKernelGGL((kk_batched<A, P>), dim3(tot), dim3(64, 4, 1), 0, st, (const A *)d_args, (const int *)d_start, nbox, extra, nrm);
+    dbg_sync(1);
   }
 };
 // grid for a reduction over range r: x,y tiled by the block, at most 8 workgroups along z, each looping

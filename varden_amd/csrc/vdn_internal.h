@@ -164,6 +164,7 @@ struct GraphKey;
 struct KeptSet { void *d_args = nullptr; int *d_start = nullptr; int nbox = 0, tot = 0; unsigned long uid = 0; };
 bool     kept_sets_enabled();
 bool     kept_family_enabled(int fam);
+void     dbg_sync(int bit);          // VDN_SYNC_POINTS (testing build): hipDeviceSynchronize at the points whose bit is set -- the search for a host / device race
 KeptSet *kept_find(unsigned long long key);
 KeptSet *kept_store(unsigned long long key, unsigned long uid, const void *args, size_t arg_bytes, const int *start, int nbox, int tot);
 void     kept_purge(unsigned long uid);            // uid 0: every entry (plain sets AND the groups of the composite solves: never from inside a solve)
