@@ -23,6 +23,52 @@ static void restrict_and_fill(int nlev, vdn_multifab **mf, int icomp, int bcomp,
   else ml_restrict_and_fill(nlev, mf, icomp, bcomp, nc, same_boundary, bct);
 }
 
+// VDN_PHASE_HASH=1 (testing build; the hunt for the run-to-run differences of profiles/r06_determinism.txt): a checksum of whole multifabs (ghost cells included) at the
+// phase boundaries of a step, on stderr
+static void dbg_phase_hash(const char *tag, int nlevs, vdn_multifab **mfs, int per_level = 1, bool whole = false) {
+  static const bool on = vdn_env("VDN_PHASE_HASH") && atoi(vdn_env("VDN_PHASE_HASH")) != 0;
+  if (!on) return;
+  HIPCHK(hipStreamSynchronize(ctx().stream));
+  unsigned long long h = 1469598103934665603ull;
+  for (int n = 0; n < nlevs; n++) for (int q = 0; q < per_level; q++) {
+    const vdn_multifab *m = mfs[per_level == 1 ? n : 3 * n + q];
+    if (!m) continue;
+    std::vector<unsigned long long> buf(m->bytes / 8);
+    HIPCHK(hipMemcpy(buf.data(), m->base, m->bytes, hipMemcpyDeviceToHost));
+    for (int b = 0; b < m->nfabs(); b++) {                 // the valid cells / faces / nodes only: ghost entries of a temporary may never have been written
+      const FV &f = m->fabs[b]; vdn_box vb = m->vbox[b];
+      if (whole) for (int d = 0; d < 3; d++) { vb.lo[d] -= m->ng; vb.hi[d] += m->ng; }
+      const size_t off = (size_t)(f.p - m->base);
+      unsigned long long hb = 1469598103934665603ull;
+      for (int c = 0; c < m->nc; c++)
+        for (int k = vb.lo[2]; k <= vb.hi[2] + m->nodal[2]; k++) for (int j = vb.lo[1]; j <= vb.hi[1] + m->nodal[1]; j++) for (int i = vb.lo[0]; i <= vb.hi[0] + m->nodal[0]; i++) {
+          { const unsigned long long v_ = buf[off + (size_t)(i - f.a0) + (size_t)f.n0 * ((size_t)(j - f.a1) + (size_t)f.n1 * (size_t)(k - f.a2)) + (size_t)c * (size_t)f.sc]; hb ^= v_; hb *= 1099511628211ull; }
+          const unsigned long long v = buf[off + (size_t)(i - f.a0) + (size_t)f.n0 * ((size_t)(j - f.a1) + (size_t)f.n1 * (size_t)(k - f.a2)) + (size_t)c * (size_t)f.sc];
+          h ^= v; h *= 1099511628211ull;
+        }
+      if (whole) fprintf(stderr, "PHASEBOX %-20s lev %d box %3d (%d,%d,%d)-(%d,%d,%d) %016llx\n", tag, n, b, m->vbox[b].lo[0], m->vbox[b].lo[1], m->vbox[b].lo[2], m->vbox[b].hi[0], m->vbox[b].hi[1], m->vbox[b].hi[2], hb);
+    }
+  }
+  fprintf(stderr, "PHASE %-22s %016llx\n", tag, h);
+  if (per_level == 3) {                                     // face fields: a checksum per level, direction and box as well
+    for (int n = 0; n < nlevs; n++) for (int q = 0; q < 3; q++) {
+      const vdn_multifab *m = mfs[3 * n + q];
+      std::vector<unsigned long long> buf(m->bytes / 8);
+      HIPCHK(hipMemcpy(buf.data(), m->base, m->bytes, hipMemcpyDeviceToHost));
+      for (int b = 0; b < m->nfabs(); b++) {
+        const FV &f = m->fabs[b]; const vdn_box &vb = m->vbox[b];
+        const size_t off = (size_t)(f.p - m->base);
+        unsigned long long hb = 1469598103934665603ull; long nan = 0;
+        for (int k = vb.lo[2]; k <= vb.hi[2] + m->nodal[2]; k++) for (int j = vb.lo[1]; j <= vb.hi[1] + m->nodal[1]; j++) for (int i = vb.lo[0]; i <= vb.hi[0] + m->nodal[0]; i++) {
+          const unsigned long long v = buf[off + (size_t)(i - f.a0) + (size_t)f.n0 * ((size_t)(j - f.a1) + (size_t)f.n1 * (size_t)(k - f.a2))];
+          hb ^= v; hb *= 1099511628211ull;
+          double dv; memcpy(&dv, &v, 8); if (dv != dv) nan++;
+        }
+        fprintf(stderr, "PHASEBOX %-20s lev %d dir %d box %3d (%d,%d,%d)-(%d,%d,%d) %016llx nan %ld\n", tag, n, q, b, vb.lo[0], vb.lo[1], vb.lo[2], vb.hi[0], vb.hi[1], vb.hi[2], hb, nan);
+      }
+    }
+  }
+}
 extern "C" int vdn_advance_timestep(int istep, vdn_layout *mla, vdn_multifab **sold, vdn_multifab **uold,
                                     vdn_multifab **snew, vdn_multifab **unew, vdn_multifab **gp, vdn_multifab **p,
                                     vdn_multifab **ext_vel_force, vdn_multifab **ext_scal_force,
@@ -42,6 +88,8 @@ extern "C" int vdn_advance_timestep(int istep, vdn_layout *mla, vdn_multifab **s
     REQUIRE(gp[n]->ng >= 1 && p[n]->ng >= 1 && ext_vel_force[n]->ng >= 1 && ext_scal_force[n]->ng >= 1, "gp/p/ext forces need ng = 1");
     REQUIRE(sold[n]->nc == nscal && nscal <= 3, "sold must have nscal (<= 3) components");
   }
+  dbg_phase_hash("uold at entry", nlevs, uold); dbg_phase_hash("sold at entry", nlevs, sold); dbg_phase_hash("gp at entry", nlevs, gp);
+  dbg_phase_hash("uold+ghosts at entry", nlevs, uold, 1, true); dbg_phase_hash("sold+ghosts at entry", nlevs, sold, 1, true); dbg_phase_hash("gp+ghosts at entry", nlevs, gp, 1, true);
   Prof prof_advance("advance");                                                        // bl_prof names of advance_timestep.f90:60,99,107,123,132
   arena_reset();
   arena_reserve_for(mla);
@@ -101,6 +149,7 @@ extern "C" int vdn_advance_timestep(int istep, vdn_layout *mla, vdn_multifab **s
     for (int d = 0; d < dm; d++) mf_fill_boundary(umac[d]);
     for (int n = 1; n < nlevs; n++) for (int d = 0; d < dm; d++) { ml_create_umac_grown(umac[3 * n + d], umac[3 * (n - 1) + d], d); mf_fill_boundary(umac[3 * n + d]); }
     for (int n = nlevs - 1; n >= 1; n--) for (int d = 0; d < dm; d++) ml_edge_restriction(umac[3 * (n - 1) + d], umac[3 * n + d], d);
+    dbg_phase_hash("vel_force", nlevs, vel_force); dbg_phase_hash("umac after velpred", nlevs, umac, 3);
     if (!keep_vel_force) for (int n = nlevs - 1; n >= 0; n--) mf_temp_free(vel_force[n]);
     arena_release(mark);
   }
@@ -111,6 +160,7 @@ extern "C" int vdn_advance_timestep(int istep, vdn_layout *mla, vdn_multifab **s
   do_macproject(mla, umac, sold, mac_rhs, dx, bct, press_comp - 1);
   }
   sync(); ctx().step_sec[2] = wall() - t0;
+  dbg_phase_hash("umac after MAC", nlevs, umac, 3);
 
   // scalar_advance.f90:54-118
   t0 = wall();
@@ -149,7 +199,9 @@ extern "C" int vdn_advance_timestep(int istep, vdn_layout *mla, vdn_multifab **s
     // of the composite grid (round 5: rounds 2-4 left the coarse level its own fluxes)
     for (int n = nlevs - 1; n >= 1; n--) for (int c = 0; c < nscal; c++) if (is_cons[c]) for (int d = 0; d < dm; d++) ml_edge_restriction(sflux[3 * (n - 1) + d], sflux[3 * n + d], d, c);
     if (diffusive || !force_reuse) restrict_and_fill(nlevs, scal_force, 0, bct->extrap_comp0(), nscal, true, bct);
+    dbg_phase_hash("sedge after mkflux", nlevs, sedge, 3); dbg_phase_hash("sflux restricted", nlevs, sflux, 3); dbg_phase_hash("scal_force", nlevs, scal_force);
     if (!s_updated) for (int n = 0; n < nlevs; n++) k_update(sold[n], umac + 3 * n, sedge + 3 * n, sflux + 3 * n, scal_force[n], snew[n], DXL(n), dt, false, is_cons);
+    dbg_phase_hash("snew before r_and_f", nlevs, snew);
     restrict_and_fill(nlevs, snew, 0, dm, nscal, false, bct);                           // update.f90:106
     if (diffusive) {                                                                    // scalar_advance.f90:144-162
       const double visc_mu = (P.diffusion_type == 1) ? 0.5 * dt * P.diff_coef : dt * P.diff_coef;
@@ -161,6 +213,7 @@ extern "C" int vdn_advance_timestep(int istep, vdn_layout *mla, vdn_multifab **s
     arena_release(mark);
   }
   sync(); ctx().step_sec[0] = wall() - t0;
+  dbg_phase_hash("snew after scalars", nlevs, snew);
 
   // make_at_halftime (advance_timestep.f90:114, make_at_halftime.f90:64-65)
   { Prof pr("make_at_halftime"); for (int n = 0; n < nlevs; n++) k_make_at_halftime(rhohalf[n], sold[n], snew[n], 0, 0); }
@@ -190,13 +243,16 @@ extern "C" int vdn_advance_timestep(int istep, vdn_layout *mla, vdn_multifab **s
       u_updated = k_mkflux(uold[n], uedge + 3 * n, uflux + 3 * n, umac + 3 * n, vel_force[n], mac_rhs[n], DXL(n), dt, bct, true, is_cons, try_upd ? &U : nullptr);
       if (!fuse_force) k_mkvelforce(vel_force[n], ext_vel_force[n], rhohalf[n], gp[n], lapu[n], 0.0);
     }
+    dbg_phase_hash("uedge after mkflux", nlevs, uedge, 3); dbg_phase_hash("vel_force (update)", nlevs, vel_force);
     if (u_updated) { /* unew is written */ }
     else if (fuse_force) k_update_velforce(uold[0], umac, uedge, ext_vel_force[0], rhohalf[0], gp[0], lapu[0], 0.0, unew[0], DXL(0), dt);
     else {
       restrict_and_fill(nlevs, vel_force, 0, bct->extrap_comp0(), dm, true, bct);
       for (int n = 0; n < nlevs; n++) k_update(uold[n], umac + 3 * n, uedge + 3 * n, uflux + 3 * n, vel_force[n], unew[n], DXL(n), dt, true, is_cons);
     }
+    dbg_phase_hash("unew before r_and_f", nlevs, unew);
     restrict_and_fill(nlevs, unew, 0, 0, dm, false, bct);                               // update.f90:104
+    dbg_phase_hash("unew after update", nlevs, unew);
     if (viscous) {                                                                      // velocity_advance.f90:103-118
       const double visc_mu = (P.diffusion_type == 1) ? 0.5 * dt * P.visc_coef : dt * P.visc_coef;
       if (nlevs == 1) do_visc_solve(mla, unew[0], lapu[0], rhohalf[0], mac_rhs[0], dx, visc_mu, bct);
@@ -205,12 +261,14 @@ extern "C" int vdn_advance_timestep(int istep, vdn_layout *mla, vdn_multifab **s
     arena_release(mark);
   }
   sync(); ctx().step_sec[1] = wall() - t0;
+  dbg_phase_hash("unew after viscous", nlevs, unew);
 
   // hgproject (advance_timestep.f90:129-137)
   t0 = wall();
   { Prof pr("HG_Project");
   do_hgproject(proj_type, mla, unew, uold, rhohalf, p, gp, dx, dt, bct, press_comp - 1); }
   sync(); ctx().step_sec[3] = wall() - t0;
+  dbg_phase_hash("unew after HG", nlevs, unew); dbg_phase_hash("p after HG", nlevs, p); dbg_phase_hash("gp after HG", nlevs, gp);
   #undef DXL
 
   arena_reset();

@@ -139,22 +139,30 @@ void ml_edge_restriction(vdn_multifab *crse, const vdn_multifab *fine, int dir, 
   const SrcView F = make_view(fine, refined_footprints(crse, dir, 0), level_owner(crse), comp, 1, VT_REFINE_FACE0 + dir);
   F.refresh();
   GraphKey key; key.put(0x7202); key_mf(key, crse); key_mf(key, fine); key.put(dir); key.put(comp);
-  launch_batched_kept<EdgeRestrictB>(key.h, crse->la->uid, [&](std::vector<EdgeRestrictB> &v) {
-  const BoxBins cb(crse->vbox);
-  for (int f = 0; f < F.nboxes(); f++) {
-    if (!F.have[f]) continue;
-    int qlo[3], qhi[3];
-    for (int d = 0; d < 3; d++) { qlo[d] = hfdiv2(F.vbox[f].lo[d]); qhi[d] = hfdiv2(F.vbox[f].hi[d]); }
-    for (int c : cb.near(qlo, qhi, 2)) {
-    int clo[3], chi[3], blo[3], bhi[3]; EdgeRestrictB a;
-    for (int d = 0; d < 3; d++) { clo[d] = qlo[d]; chi[d] = qhi[d]; blo[d] = crse->vbox[c].lo[d]; bhi[d] = crse->vbox[c].hi[d]; }
-    chi[dir] += 1; bhi[dir] += 1;
-    if (!isect(clo, chi, blo, bhi, a.r)) continue;
-    a.crse = crse->fabs[c]; a.crse.p += (long)a.crse.sc * comp; a.fine = F.fv[f]; a.dir = dir;
-    v.push_back(a);
+  // Two launches: the plane of faces on the HIGH side of every fine box first, everything else second.  Two fine boxes that share a plane both hold its faces, and
+  // their copies need not be equal -- velpred's dead band is per box (velpred.f90:215-226), the copies can be 1e-9 apart -- so one launch over both boxes let the
+  // scheduler decide which copy a coarse face under the shared plane received: runs of a three-level hierarchy with many boxes differed from process to process
+  // at 1e-11 (profiles/r06_determinism.txt; found with VDN_PHASE_HASH).  Now the box on the plane's high side (whose LOW plane it is) always wins.
+  for (int pass = 0; pass < 2; pass++) {
+    GraphKey k2 = key; k2.put(0x51 + pass);
+    launch_batched_kept<EdgeRestrictB>(k2.h, crse->la->uid, [&](std::vector<EdgeRestrictB> &v) {
+    const BoxBins cb(crse->vbox);
+    for (int f = 0; f < F.nboxes(); f++) {
+      if (!F.have[f]) continue;
+      int qlo[3], qhi[3];
+      for (int d = 0; d < 3; d++) { qlo[d] = hfdiv2(F.vbox[f].lo[d]); qhi[d] = hfdiv2(F.vbox[f].hi[d]); }
+      for (int c : cb.near(qlo, qhi, 2)) {
+      int clo[3], chi[3], blo[3], bhi[3]; EdgeRestrictB a;
+      for (int d = 0; d < 3; d++) { clo[d] = qlo[d]; chi[d] = qhi[d]; blo[d] = crse->vbox[c].lo[d]; bhi[d] = crse->vbox[c].hi[d]; }
+      if (pass == 0) clo[dir] = chi[dir] = qhi[dir] + 1;       // the high plane alone
+      bhi[dir] += 1;
+      if (!isect(clo, chi, blo, bhi, a.r)) continue;
+      a.crse = crse->fabs[c]; a.crse.p += (long)a.crse.sc * comp; a.fine = F.fv[f]; a.dir = dir;
+      v.push_back(a);
+      }
     }
+    }, 0, (double *)nullptr, 0, ctx().stream);
   }
-  }, 0, (double *)nullptr, 0, ctx().stream);
 }
 
 // ---- coarse -> fine ghost interpolation ---------------------------------------------------------------------------------

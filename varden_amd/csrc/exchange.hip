@@ -272,7 +272,7 @@ unsigned long xplan_serial(const XPlan *P) { return P ? P->serial : 0; }
 // shifts of the domain `pd` where pmask says so.
 // faces_only: only the ghost cells that lie outside the valid box in exactly ONE direction are filled (what a 7-point operator reads): with a
 // 2 x 2 x 2 decomposition a rank then exchanges with its three face neighbours instead of seven peers per colour pass
-XPlan *xplan_build(const std::vector<XBoxInfo> &boxes, const vdn_box &pd, const int pmask[3], int ng, int nc, bool faces_only) {
+XPlan *xplan_build(const std::vector<XBoxInfo> &boxes, const vdn_box &pd, const int pmask[3], int ng, int nc, bool faces_only, const int *src_trim) {
   Prof prof_("xplan_build");
   static unsigned long next_serial = 0;
   XPlan *P = new XPlan; P->nc = nc; P->serial = ++next_serial;
@@ -310,7 +310,7 @@ XPlan *xplan_build(const std::vector<XBoxInfo> &boxes, const vdn_box &pd, const 
         const int sh[3] = { sx * per[0], sy * per[1], sz * per[2] };
         int lo[3], hi[3]; bool empty = false, all_inside = true;
         for (int d = 0; d < 3; d++) {
-          lo[d] = std::max(glo[d], S.vlo[d] + sh[d]); hi[d] = std::min(ghi[d], S.vhi[d] + sh[d]);
+          lo[d] = std::max(glo[d], S.vlo[d] + sh[d]); hi[d] = std::min(ghi[d], S.vhi[d] - (src_trim ? src_trim[d] : 0) + sh[d]);
           if (lo[d] > hi[d]) empty = true;
           if (lo[d] < B.vlo[d] || hi[d] > B.vhi[d]) all_inside = false;
         }
@@ -629,6 +629,20 @@ void mf_fill_boundary(vdn_multifab *mf, bool faces_only) {
   XPlan *P = it->second;
   if (P->local.empty() && P->peers.empty()) return;
   xplan_run(P);
+  // Face-centred and nodal data: the boxes on both sides of a shared plane hold its points, and their copies need not be equal bit for bit (velpred's dead band is
+  // per box, velpred.f90:215-226: two copies of a MAC velocity can be 1e-9 apart).  A ghost point that both copies cover then received whichever the scheduler
+  // wrote last -- runs of a three-level hierarchy differed from process to process (profiles/r06_determinism.txt).  A second exchange from the sources WITHOUT
+  // their high planes follows: wherever a box holds the point on its low side or inside, that copy is the one that stays.
+  if (mf->nodal[0] | mf->nodal[1] | mf->nodal[2]) {
+    FbKey k2 = key; k2.nd += 16;
+    auto it2 = g_fb_cache.find(k2);
+    if (it2 == g_fb_cache.end()) {
+      const int trim[3] = { mf->nodal[0], mf->nodal[1], mf->nodal[2] };
+      it2 = g_fb_cache.emplace(k2, xplan_build(xboxes_of(mf), mf->la->pd[mf->lev], mf->la->pmask, mf->ng, mf->nc, faces_only, trim)).first;
+    }
+    XPlan *P2 = it2->second;
+    if (!(P2->local.empty() && P2->peers.empty())) xplan_run(P2);
+  }
 }
 extern "C" int vdn_multifab_fill_boundary(vdn_multifab *mf) { VDN_TRY mf_fill_boundary(mf, false); VDN_CATCH }
 

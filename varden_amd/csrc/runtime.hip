@@ -206,6 +206,7 @@ static const EnvSwitch g_switches[] = {
   { "VDN_MLCC_TRACE", "1: the composite cell-centred solve prints its residual at every FAC iteration (stderr)" },
   { "VDN_KEEP_OFF", "mask of kept-descriptor families rebuilt at every call: 1 generic sets, 2 create_umac_grown, 4 composite cell-centred solve, 8 nodal prolongation" },
   { "VDN_SYNC_POINTS", "mask of points that synchronise the device (race hunting): 1 after every batched launch, 2 after every staged upload, 4 after every exchange, 8 before a scalar read-back, 16 at arena_reset, 32 after launch_cells" },
+  { "VDN_PHASE_HASH", "1: advance_timestep prints a checksum of its fields at every phase boundary (stderr)" },
   { "VDN_NO_ROCTX", "do not bind the roctx library (no bl_prof ranges)" },
   { "VDN_POLL", "scalar read-back: 1 spin on the pinned sequence number, 0 hipStreamSynchronize; default: spin on one rank, synchronise on several" },
   { "VDN_NO_GRAPHS", "launch every multigrid cycle eagerly instead of replaying its hipGraph" },
@@ -685,6 +686,10 @@ vdn_multifab *mf_temp(const vdn_layout *la, int lev, int nc, int ng, int face_di
   mf->bytes = std::max<size_t>(tot, 1) * sizeof(double);
   mf->base = (double *)arena_alloc(mf->bytes);
   for (auto &f : mf->fabs) f.p = (double *)((char *)mf->base + (uintptr_t)f.p);
+  {   // (VDN_PHASE_HASH: every temporary starts from zeros, so that entries nobody writes -- and nobody reads -- do not differ from process to process in the checksums)
+    static const bool clr = vdn_env("VDN_PHASE_HASH") && atoi(vdn_env("VDN_PHASE_HASH")) != 0;
+    if (clr) HIPCHK(hipMemsetAsync(mf->base, 0, mf->bytes, g_ctx.stream));
+  }
   if (fill) mf_setval(mf, val, 0, nc, true);
   g_temp_mfs.push_back(mf);
   return mf;

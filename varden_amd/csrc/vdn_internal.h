@@ -200,7 +200,7 @@ void mf_temp_free(vdn_multifab *mf);
 // exchange.hip: ghost exchange plans and the RCCL transport
 struct XBoxInfo { FV fv; int vlo[3], vhi[3]; int owner; };      // valid POINT range (incl. nodal points); fv only if local
 struct XPlan;
-XPlan *xplan_build(const std::vector<XBoxInfo> &boxes, const vdn_box &pd, const int pmask[3], int ng, int nc, bool faces_only = false);
+XPlan *xplan_build(const std::vector<XBoxInfo> &boxes, const vdn_box &pd, const int pmask[3], int ng, int nc, bool faces_only = false, const int *src_trim = nullptr);   // src_trim[d] = 1: the sources give their points without their high plane along d
 void   xplan_run(XPlan *P, hipStream_t st = nullptr);      // st: the stream the pack / transfer / copy / unpack run on (default: the launch stream)
 bool   xplan_has_remote(const XPlan *P);                  // some of the traffic goes to another rank
 void   xplan_free(XPlan *P);
