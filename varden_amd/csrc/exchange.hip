@@ -310,7 +310,8 @@ XPlan *xplan_build(const std::vector<XBoxInfo> &boxes, const vdn_box &pd, const 
         const int sh[3] = { sx * per[0], sy * per[1], sz * per[2] };
         int lo[3], hi[3]; bool empty = false, all_inside = true;
         for (int d = 0; d < 3; d++) {
-          lo[d] = std::max(glo[d], S.vlo[d] + sh[d]); hi[d] = std::min(ghi[d], S.vhi[d] - (src_trim ? src_trim[d] : 0) + sh[d]);
+          const int st_ = src_trim ? src_trim[d] : 0;             // 1: the source without its high plane along d; 2: its high plane alone
+          lo[d] = std::max(glo[d], (st_ == 2 ? S.vhi[d] : S.vlo[d]) + sh[d]); hi[d] = std::min(ghi[d], S.vhi[d] - (st_ == 1 ? 1 : 0) + sh[d]);
           if (lo[d] > hi[d]) empty = true;
           if (lo[d] < B.vlo[d] || hi[d] > B.vhi[d]) all_inside = false;
         }
@@ -619,30 +620,28 @@ void mf_fill_boundary(vdn_multifab *mf, bool faces_only) {
   if (mf->ng == 0) return;
   static const bool faces_ok = !(vdn_env("VDN_FB_FACES") && atoi(vdn_env("VDN_FB_FACES")) == 0);
   faces_only = faces_only && faces_ok;
-  FbKey key{ mf->la->uid, mf->base, mf->lev, mf->nc, mf->ng, (mf->nodal[0] | (mf->nodal[1] << 1) | (mf->nodal[2] << 2)) + (faces_only ? 8 : 0) };
-  auto it = g_fb_cache.find(key);
-  if (it == g_fb_cache.end()) {
-    XPlan *P = xplan_build(xboxes_of(mf), mf->la->pd[mf->lev], mf->la->pmask, mf->ng, mf->nc, faces_only);
-    it = g_fb_cache.emplace(key, P).first;
-    if (g_fb_cache.size() > 4096) vdn_fail("fill_boundary plan cache grew beyond 4096 entries (leaking multifabs?)");
-  }
-  XPlan *P = it->second;
-  if (P->local.empty() && P->peers.empty()) return;
-  xplan_run(P);
-  // Face-centred and nodal data: the boxes on both sides of a shared plane hold its points, and their copies need not be equal bit for bit (velpred's dead band is
-  // per box, velpred.f90:215-226: two copies of a MAC velocity can be 1e-9 apart).  A ghost point that both copies cover then received whichever the scheduler
-  // wrote last -- runs of a three-level hierarchy differed from process to process (profiles/r06_determinism.txt).  A second exchange from the sources WITHOUT
-  // their high planes follows: wherever a box holds the point on its low side or inside, that copy is the one that stays.
-  if (mf->nodal[0] | mf->nodal[1] | mf->nodal[2]) {
-    FbKey k2 = key; k2.nd += 16;
-    auto it2 = g_fb_cache.find(k2);
-    if (it2 == g_fb_cache.end()) {
-      const int trim[3] = { mf->nodal[0], mf->nodal[1], mf->nodal[2] };
-      it2 = g_fb_cache.emplace(k2, xplan_build(xboxes_of(mf), mf->la->pd[mf->lev], mf->la->pmask, mf->ng, mf->nc, faces_only, trim)).first;
+  const int ndflags = mf->nodal[0] | (mf->nodal[1] << 1) | (mf->nodal[2] << 2);
+  auto plan = [&](int variant, const int *trim) -> XPlan * {
+    FbKey key{ mf->la->uid, mf->base, mf->lev, mf->nc, mf->ng, ndflags + (faces_only ? 8 : 0) + 16 * variant };
+    auto it = g_fb_cache.find(key);
+    if (it == g_fb_cache.end()) {
+      it = g_fb_cache.emplace(key, xplan_build(xboxes_of(mf), mf->la->pd[mf->lev], mf->la->pmask, mf->ng, mf->nc, faces_only, trim)).first;
+      if (g_fb_cache.size() > 4096) vdn_fail("fill_boundary plan cache grew beyond 4096 entries (leaking multifabs?)");
     }
-    XPlan *P2 = it2->second;
-    if (!(P2->local.empty() && P2->peers.empty())) xplan_run(P2);
-  }
+    return it->second;
+  };
+  auto run = [&](XPlan *P) { if (!(P->local.empty() && P->peers.empty())) xplan_run(P); };
+  // (fully nodal fields -- the pressure, the nodal solvers' iterates -- keep the one exchange: their shared nodes are computed alike on every box that holds them,
+  // and the solvers exchange them several times per sweep)
+  if (ndflags != 1 && ndflags != 2 && ndflags != 4) { run(plan(0, nullptr)); return; }
+  // Face-centred data: the boxes on both sides of a shared plane hold its points, and their copies need not be equal bit for bit (velpred's dead band is
+  // per box, velpred.f90:215-226: two copies of a MAC velocity can be 1e-9 apart).  A ghost point that both copies cover received whichever the scheduler wrote
+  // last when one exchange carried both -- runs of a three-level hierarchy differed from process to process (profiles/r06_determinism.txt).  So: first the HIGH
+  // plane of every source along each nodal direction (thin launches), then everything else of every source; wherever a box holds a point on its low side or
+  // inside, that copy is the one that stays, and the volume moved is that of the one exchange.
+  for (int d = 0; d < 3; d++) if (mf->nodal[d]) { int trim[3] = { 0, 0, 0 }; trim[d] = 2; run(plan(1 + d, trim)); }
+  const int trim[3] = { mf->nodal[0], mf->nodal[1], mf->nodal[2] };
+  run(plan(4, trim));
 }
 extern "C" int vdn_multifab_fill_boundary(vdn_multifab *mf) { VDN_TRY mf_fill_boundary(mf, false); VDN_CATCH }
 
