@@ -164,3 +164,18 @@ def test_the_restart_regression_case_of_the_reference(gpu, tmp_path):
     for x, y in zip(ref, valid(B)):
         assert np.array_equal(x, y)
     B.close()
+
+
+@pytest.mark.gpu
+def test_three_level_regridding_run_is_reproducible_from_process_to_process(gpu):
+    """inputs-restart-regt (three levels, max_grid_size 32, regrid_int = 2, viscous), eight steps, in three separate processes: the same bits after every step.  Until round 6
+    such runs forked from step 6 on (differences of 1e-11; three to six variants in twelve runs): the two copies of a plane of MAC faces shared by two boxes differ by velpred's
+    per-box dead band, and the edge restriction and the ghost-face exchange let the scheduler pick one (profiles/r06_determinism.txt)."""
+    import subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    outs = []
+    for _ in range(3):
+        r = subprocess.run([sys.executable, os.path.join(root, "tools", "probes", "determinism_probe.py")], capture_output=True, text=True, timeout=300, cwd=root)
+        assert r.returncode == 0, r.stderr[-1500:]
+        outs.append([ln for ln in r.stdout.splitlines() if ln.startswith("inputs-restart-regt")][0])
+    assert outs[0] == outs[1] == outs[2], outs
