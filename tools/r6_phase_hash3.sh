@@ -1,7 +1,7 @@
 #!/bin/bash
 cd $GRAFT_REPO_ROOT; export VDN_LIB_FLAVOUR=testing VDN_PHASE_HASH=1
 N=${1:-6}; mkdir -p /tmp/ph
-for i in $(seq $N); do timeout -k 10 100 python tools/probes/determinism_probe.py 2>&1 | grep "^PHASE" > /tmp/ph/$i.txt; done
+for i in $(seq $N); do timeout -k 10 200 python tools/probes/determinism_probe.py ${PROBE_ARGS:-} 2>&1 | grep "^PHASE" > /tmp/ph/$i.txt; done
 python3 - $N <<'PY'
 import sys, collections
 N = int(sys.argv[1])

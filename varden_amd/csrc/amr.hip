@@ -211,6 +211,7 @@ void ml_fill_ghost_cells(vdn_multifab *fine, const vdn_multifab *crse, int icomp
   GraphKey key; key.put(0x7203); key_mf(key, fine); key_mf(key, crse); key.put(icomp); key.put(nc);
   launch_batched_kept<InterpB>(key.h, fine->la->uid, [&](std::vector<InterpB> &v) {
   const vdn_box &pdc = Cv.nboxes() == 1 ? Cv.vbox[0] : crse->la->pd[crse->lev];
+  const int pmk[3] = { Cv.nboxes() == 1 ? 0 : crse->la->pmask[0], Cv.nboxes() == 1 ? 0 : crse->la->pmask[1], Cv.nboxes() == 1 ? 0 : crse->la->pmask[2] };
   const BoxBins cb(Cv.vbox, &Cv.have);
   for (int f = 0; f < fine->nfabs(); f++) {
     InterpArgs A; Range3 r;
@@ -225,19 +226,22 @@ void ml_fill_ghost_cells(vdn_multifab *fine, const vdn_multifab *crse, int icomp
           blo[d] = pass == 0 ? Cv.vbox[c].lo[d] : A.alo[d]; bhi[d] = pass == 0 ? Cv.vbox[c].hi[d] : A.ahi[d]; }
         if (!isect(glo, ghi, blo, bhi, pr)) continue;
         if (pass == 1) {
-          // only parents outside the domain; handled per direction slab to stay disjoint from pass 0
+          // only parents outside the domain; handled per direction slab to stay disjoint from pass 0.  Beyond a PERIODIC face the parents are valid cells of the
+          // view's periodic images and pass 0 has them: taking them from a box's ghost cells here as well gave such fine ghost cells two writers whose limited
+          // slopes differ where a stencil meets the edge of an allocation -- the scheduler chose (inputs_RayleighTaylor_2d differed from run to run)
           bool any = false;
-          for (int d = 0; d < 3; d++) if (pr.lo[d] < pdc.lo[d] || pr.hi[d] > pdc.hi[d]) any = true;
+          for (int d = 0; d < 3; d++) if (!pmk[d] && (pr.lo[d] < pdc.lo[d] || pr.hi[d] > pdc.hi[d])) any = true;
           if (!any) continue;
         }
         for (int d = 0; d < 3; d++) { A.plo[d] = pr.lo[d]; A.phi[d] = pr.hi[d]; }
         if (pass == 1) {
           // one slab per (direction, side) that sticks out of the domain
           for (int d = 0; d < 3; d++) for (int s = 0; s < 2; s++) {
+            if (pmk[d]) continue;
             InterpArgs B = A;
             if (s == 0) { if (pr.lo[d] >= pdc.lo[d]) continue; B.phi[d] = std::min(pr.hi[d], pdc.lo[d] - 1); }
             else        { if (pr.hi[d] <= pdc.hi[d]) continue; B.plo[d] = std::max(pr.lo[d], pdc.hi[d] + 1); }
-            for (int e = 0; e < d; e++) { B.plo[e] = std::max(B.plo[e], pdc.lo[e]); B.phi[e] = std::min(B.phi[e], pdc.hi[e]); if (B.plo[e] > B.phi[e]) goto next; }
+            for (int e = 0; e < d; e++) { if (pmk[e]) continue; B.plo[e] = std::max(B.plo[e], pdc.lo[e]); B.phi[e] = std::min(B.phi[e], pdc.hi[e]); if (B.plo[e] > B.phi[e]) goto next; }
             { InterpB e; e.r = r; e.fine = fine->fabs[f]; e.crse = Cv.fv[c]; e.A = B; v.push_back(e); }
             next:;
           }
