@@ -363,14 +363,16 @@ void ml_create_umac_grown(vdn_multifab *fine, const vdn_multifab *crse, int dir)
   Cv.refresh();
   GraphKey key; key.put(0x7204); key_mf(key, fine); key_mf(key, crse); key.put(dir);
   if (kept_family_enabled(2)) {
-    KeptSet *k0 = kept_find(key.h), *k1 = kept_find(key.h + 1);
-    if (k0 && k1) {
-      if (k0->nbox) hipLaunchKernelGGL((kk_batched<GrownB, int>), dim3(k0->tot), dim3(64, 4, 1), 0, ctx().stream, (const GrownB *)k0->d_args, (const int *)k0->d_start, k0->nbox, 0, (double *)nullptr);
-      if (k1->nbox) hipLaunchKernelGGL((kk_batched<GrownB, int>), dim3(k1->tot), dim3(64, 4, 1), 0, ctx().stream, (const GrownB *)k1->d_args, (const int *)k1->d_start, k1->nbox, 0, (double *)nullptr);
+    KeptSet *k0 = kept_find(key.h), *k1 = kept_find(key.h + 1), *k2 = kept_find(key.h + 2);
+    if (k0 && k1 && k2) {
+      for (KeptSet *k : { k0, k1, k2 })
+        if (k->nbox) hipLaunchKernelGGL((kk_batched<GrownB, int>), dim3(k->tot), dim3(64, 4, 1), 0, ctx().stream, (const GrownB *)k->d_args, (const int *)k->d_start, k->nbox, 0, (double *)nullptr);
       return;
     }
   }
-  std::vector<GrownB> v0, v1;
+  // v0: parents among a box's ghost faces; v1a / v1b: parents among the VALID faces of the coarse boxes -- the high plane of every box first, the rest second: two boxes that
+  // share a plane hold copies of its faces that can be 1e-9 apart (velpred's per-box dead band), and one launch over both let the scheduler choose (profiles/r06_determinism.txt)
+  std::vector<GrownB> v0, v1, v1a;
   const BoxBins cb(Cv.vbox, &Cv.have);
   int first_here = -1;
   for (int c = 0; c < Cv.nboxes() && first_here < 0; c++) if (Cv.have[c]) first_here = c;
@@ -397,12 +399,18 @@ void ml_create_umac_grown(vdn_multifab *fine, const vdn_multifab *crse, int dir)
       e.crse = Cv.fv[c];
       if (Cv.nboxes() > 1) {
         for (int d = 0; d < 3; d++) { e.A.plo[d] = Cv.vbox[c].lo[d]; e.A.phi[d] = Cv.vbox[c].hi[d] + (d == dir); }
-        if (clip(e)) v1.push_back(e);
+        if (clip(e)) {                                                                    // without the fine faces ON the high plane (an odd face below it still reads the plane)
+          e.r.hi[dir] = std::min(e.r.hi[dir], 2 * (Cv.vbox[c].hi[dir] + 1) - 1);
+          if (e.r.lo[dir] <= e.r.hi[dir]) v1.push_back(e);
+        }
+        e.A.plo[dir] = e.A.phi[dir] = Cv.vbox[c].hi[dir] + 1;
+        if (clip(e)) v1a.push_back(e);                                                    // the fine faces on the high plane alone
       }
     }
   }
   launch_batched_kept<GrownB>(key.h, fine->la->uid, [&](std::vector<GrownB> &v) { v = v0; }, 0, (double *)nullptr, 0, ctx().stream);
-  launch_batched_kept<GrownB>(key.h + 1, fine->la->uid, [&](std::vector<GrownB> &v) { v = v1; }, 0, (double *)nullptr, 0, ctx().stream);
+  launch_batched_kept<GrownB>(key.h + 1, fine->la->uid, [&](std::vector<GrownB> &v) { v = v1a; }, 0, (double *)nullptr, 0, ctx().stream);
+  launch_batched_kept<GrownB>(key.h + 2, fine->la->uid, [&](std::vector<GrownB> &v) { v = v1; }, 0, (double *)nullptr, 0, ctx().stream);
 }
 void ml_restrict_and_fill(int nlev, vdn_multifab **mf, int icomp, int bcomp, int nc, bool same_boundary, const vdn_bc_tower *bct) {
   for (int n = nlev - 1; n >= 1; n--) ml_cc_restriction(mf[n - 1], mf[n], icomp, nc);
