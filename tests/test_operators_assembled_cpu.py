@@ -155,7 +155,10 @@ STAIRS = [((4, 4, 4), (19, 11, 27)), ((4, 12, 4), (11, 19, 27)), ((12, 12, 4), (
 
 @pytest.mark.parametrize("name,ellbc,flo,fhi,boxes", [("walls-interior-box", NEU3, (8, 8, 8), (23, 23, 23), None), ("outflow-box-at-the-walls", MIX3, (0, 8, 12), (15, 23, 31), None),
                                                       ("walls-box-in-a-corner", NEU3, (0, 0, 0), (15, 19, 11), None), ("walls-L-shaped-union", NEU3, (8, 8, 8), (23, 23, 23), LSHAPE),
-                                                      ("outflow-stairs", MIX3, (4, 4, 4), (19, 19, 27), STAIRS)])
+                                                      ("outflow-stairs", MIX3, (4, 4, 4), (19, 19, 27), STAIRS),
+                                                      # round 6: a right-hand side that misses solvability by 1e-7 of its norm (what velpred's per-box dead band does to div(umac) on a
+                                                      # periodic symmetry plane, vo_amr.c: vo_ml_cc_solve_g) must still be solved -- to the solution of its compatible part
+                                                      ("walls-interior-box-INCOMPATIBLE", NEU3, (8, 8, 8), (23, 23, 23), None), ("walls-L-shaped-union-INCOMPATIBLE", NEU3, (8, 8, 8), (23, 23, 23), LSHAPE)])
 def test_composite_cell_centred_solution(name, ellbc, flo, fhi, boxes):
     """vo_ml_cc_solve (FAC) against the direct solution of the composite finite-volume system assembled from its definition -- one fine box, and unions of
     boxes that are no rectangle (the oracle's level arrays with a cell mask and per-direction interface values against the matrix's plain cell list)"""
@@ -208,6 +211,10 @@ def test_composite_cell_centred_solution(name, ellbc, flo, fhi, boxes):
         rh[0].a[..., 0] = smooth(rh[0].a.shape[:3], dxc, 8) + 0.1 * rng.standard_normal(rh[0].a.shape[:3])
         rh[1].a[..., 0] = smooth(rh[1].a.shape[:3], dxf, 9, lo=flo) + 0.1 * rng.standard_normal(rh[1].a.shape[:3])
     b = CS.rhs(rh[0].a[..., 0], rh[1].a[..., 0])
+    if name.endswith("INCOMPATIBLE"):                      # the same constant on every cell of both levels: the volume-weighted composite mean is that constant
+        off = 1e-7 * max(np.abs(rh[0].a).max(), np.abs(rh[1].a).max())
+        rh[0].a[...] += off
+        rh[1].a[...] += off
     phi = [vo.Fab(clo, chi, 1, 1), vo.Fab(flo, fhi, 1, 1)]
     nd2 = 2 * nc
     ells = (((C.c_int * 2) * 3) * 2)()
@@ -222,7 +229,7 @@ def test_composite_cell_centred_solution(name, ellbc, flo, fhi, boxes):
     L.vo_ml_cc_solve_g.restype = C.c_int
     rc = L.vo_ml_cc_solve_g(2, lev, vo.fab_ptr_array(rh), vo.fab_ptr_array(phi), None, vo.fab_ptr_array(beta), dx, ells, vo.ivec([0, 0, 0]), pd, C.c_double(1e-11), 100,
                             C.byref(prm), None, C.byref(st), None)
-    assert rc == 0, "%s: FAC did not converge (%d iterations)" % (name, st.cycles)
+    assert rc == 0 and st.cycles <= 30, "%s: FAC did not converge (%d iterations)" % (name, st.cycles)
     xm = CS.vector(phi[0].valid()[..., 0], phi[1].valid()[..., 0])
     r = b - A @ xm
     assert np.abs(r).max() <= 5e-11 * np.abs(b).max(), "%s: the FAC solution leaves a residual of %.3e |b| in the assembled composite system" % (name, np.abs(r).max() / np.abs(b).max())
