@@ -192,6 +192,46 @@ contains
   end subroutine bl_prof_timer_destroy
 end module bl_prof_module
 
+! bl_mem_stat_module (FBoxLib): the allocation counters the reference's main program prints at its end (src/main.f90:35-47).  Here: how many objects of a kind the host built and
+! destroyed through this surface (device memory is the library's: vdn_arena_stats); the associations of FBoxLib's layouts (boxassoc, fgassoc, ...) have no counterpart -- the
+! exchange plans live inside the library, per layout -- and report zero.
+module bl_mem_stat_module
+  implicit none
+  type mem_stats
+     integer(kind=8) :: num_alloc = 0, num_dealloc = 0
+     integer(kind=8) :: cnt_alloc = 0, cnt_dealloc = 0
+  end type mem_stats
+  interface print
+     module procedure mem_stats_print
+  end interface
+contains
+  subroutine mem_stats_print(ms, str, unit, advance, total)
+    type(mem_stats), intent(in) :: ms
+    character(len=*), intent(in), optional :: str, advance
+    integer, intent(in), optional :: unit
+    logical, intent(in), optional :: total
+    integer :: un
+    un = 6; if (present(unit)) un = unit
+    if (present(str)) then
+       write(un, '(a,": built ",i0,", destroyed ",i0)') str, ms%num_alloc, ms%num_dealloc
+    else
+       write(un, '("built ",i0,", destroyed ",i0)') ms%num_alloc, ms%num_dealloc
+    end if
+  end subroutine mem_stats_print
+  subroutine mem_stats_alloc(ms, n)
+    type(mem_stats), intent(inout) :: ms
+    integer, intent(in), optional :: n
+    ms%num_alloc = ms%num_alloc + 1
+    if (present(n)) ms%cnt_alloc = ms%cnt_alloc + n
+  end subroutine mem_stats_alloc
+  subroutine mem_stats_dealloc(ms, n)
+    type(mem_stats), intent(inout) :: ms
+    integer, intent(in), optional :: n
+    ms%num_dealloc = ms%num_dealloc + 1
+    if (present(n)) ms%cnt_dealloc = ms%cnt_dealloc + n
+  end subroutine mem_stats_dealloc
+end module bl_mem_stat_module
+
 module box_module
   implicit none
   type box
@@ -265,7 +305,9 @@ end module box_module
 
 module boxarray_module
   use box_module
+  use bl_mem_stat_module
   implicit none
+  type(mem_stats), save :: boxarray_ms
   type boxarray
      integer :: dim = 3, nboxes = 0
      type(box), pointer :: bxs(:) => null()
@@ -314,6 +356,10 @@ contains
        if (.not. box_equal(a%bxs(i), b%bxs(i))) boxarray_same_q = .false.
     end do
   end function boxarray_same_q
+  function boxarray_mem_stats() result(r)                     ! src/main.f90:41
+    type(mem_stats) :: r
+    r = boxarray_ms
+  end function boxarray_mem_stats
 end module boxarray_module
 
 module ml_boxarray_module
@@ -353,7 +399,9 @@ end module ml_boxarray_module
 
 module layout_module
   use iso_c_binding, only: c_ptr, c_null_ptr, c_associated
+  use bl_mem_stat_module
   implicit none
+  type(mem_stats), save :: layout_ms
   ! the layout of ONE level: the hierarchy's handle and the level number (the C-ABI keeps the box lists of all levels in one vdn_layout)
   type layout
      type(c_ptr) :: h = c_null_ptr
@@ -384,6 +432,26 @@ contains
   end function layout_ne
   subroutine layout_flush_copyassoc_cache()                 ! src/main.f90:23: the library keeps its exchange plans per layout and drops them with it
   end subroutine layout_flush_copyassoc_cache
+  ! src/main.f90:42-47: layouts built through ml_layout_build count here; FBoxLib's association caches do not exist on this side (the library's plans are per layout, inside it)
+  function layout_mem_stats() result(r)
+    type(mem_stats) :: r
+    r = layout_ms
+  end function layout_mem_stats
+  function boxassoc_mem_stats() result(r)
+    type(mem_stats) :: r
+  end function boxassoc_mem_stats
+  function fgassoc_mem_stats() result(r)
+    type(mem_stats) :: r
+  end function fgassoc_mem_stats
+  function syncassoc_mem_stats() result(r)
+    type(mem_stats) :: r
+  end function syncassoc_mem_stats
+  function copyassoc_mem_stats() result(r)
+    type(mem_stats) :: r
+  end function copyassoc_mem_stats
+  function fluxassoc_mem_stats() result(r)
+    type(mem_stats) :: r
+  end function fluxassoc_mem_stats
 end module layout_module
 
 module ml_layout_module
@@ -438,6 +506,7 @@ contains
     allocate(mla%la(mba%nlevel))
     do n = 1, mba%nlevel
        mla%la(n)%h = mla%v%h; mla%la(n)%lev = n; mla%la(n)%dim = mba%dim; mla%la(n)%nlevel = mba%nlevel
+       call mem_stats_alloc(layout_ms)
     end do
   end subroutine ml_layout_build
   function ml_layout_get_pd(mla, n) result(bx)               ! src/varden.f90:641
@@ -472,6 +541,7 @@ module multifab_module
                         vamd_fill_boundary => multifab_fill_boundary, multifab_copy_to_host_v => multifab_copy_to_host, &
                         multifab_copy_from_host_v => multifab_copy_from_host, vamd_fab_size => multifab_fab_size, vdn_box
   implicit none
+  type(mem_stats), save :: multifab_ms, fab_ms
   type multifab
      type(vamd_multifab) :: v
      integer :: dim = 3, nc = 1, ng = 0
@@ -519,6 +589,7 @@ contains
        error stop 'multifab_build: nodal in two directions is not a layout of the hot path'
     end if
     mf%nc = c; mf%ng = g; mf%dim = la%dim; mf%la = la
+    call mem_stats_alloc(multifab_ms); call mem_stats_alloc(fab_ms, vamd_nfabs(mf%v))
   end subroutine multifab_build
   ! multifab_build_edge(mf, la, nc, ng, dir)   (src/advance_timestep.f90:78)
   subroutine multifab_build_edge(mf, la, nc, ng, dir)
@@ -528,11 +599,21 @@ contains
     call vamd_build_edge(mf%v, as_vamd_layout(la), la%lev, nc, ng, dir)
     mf%nodal = .false.; mf%nodal(dir) = .true.
     mf%nc = nc; mf%ng = ng; mf%dim = la%dim; mf%la = la
+    call mem_stats_alloc(multifab_ms); call mem_stats_alloc(fab_ms, vamd_nfabs(mf%v))
   end subroutine multifab_build_edge
   subroutine multifab_destroy(mf)
     type(multifab), intent(inout) :: mf
+    call mem_stats_dealloc(multifab_ms); call mem_stats_dealloc(fab_ms, vamd_nfabs(mf%v))
     call vamd_destroy(mf%v)
   end subroutine multifab_destroy
+  function multifab_mem_stats() result(r)                     ! src/main.f90:39-40
+    type(mem_stats) :: r
+    r = multifab_ms
+  end function multifab_mem_stats
+  function fab_mem_stats() result(r)
+    type(mem_stats) :: r
+    r = fab_ms
+  end function fab_mem_stats
   integer function nfabs(mf)
     type(multifab), intent(in) :: mf
     nfabs = vamd_nfabs(mf%v)
